@@ -1,0 +1,205 @@
+/*
+ * solver2d_amd.h -- C-ABI of the MI355X constraint-solve hot path.
+ *
+ * This is the drop-in boundary for the ten solver variants of erincatto/solver2d.  The
+ * reference's plug point is
+ *
+ *     void s2Solve_<Variant>(s2World* world, s2StepContext* context);   (src/solvers.h:70-79)
+ *
+ * called from the switch in s2World_Step (src/world.c:206-256).  Each s2Solve_* reads and
+ * mutates three pooled arrays -- world->bodies (src/body.h:16-76), world->contacts with their
+ * embedded s2Manifold (src/contact.h:44-61, include/solver2d/manifold.h:19-46) and
+ * world->joints (src/joint.h:28-103) -- and nothing else.  The structs below are plain-C
+ * mirrors of exactly the fields those functions touch, indexed the same way (array index ==
+ * pool index, free slots flagged), so a reference-side shim is a field-for-field gather
+ * before the call and a scatter after it.
+ *
+ * Plain pointers and sizes only; no C++ / torch / HIP types cross this boundary.
+ * All functions return 0 on success and a negative S2AMD_E_* code on failure;
+ * s2amd_last_error() returns a human readable message for the calling thread.
+ */
+#ifndef SOLVER2D_AMD_H
+#define SOLVER2D_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S2AMD_API_VERSION 1
+
+/* error codes */
+#define S2AMD_OK 0
+#define S2AMD_E_INVALID (-1)   /* bad argument (null pointer, negative size, unknown solver) */
+#define S2AMD_E_DEVICE (-2)    /* HIP runtime failure (message has the hipError string) */
+#define S2AMD_E_NODEVICE (-3)  /* no gfx950 device visible: the library never falls back to the CPU */
+#define S2AMD_E_STATE (-4)     /* call sequence error (e.g. step_resident before upload) */
+#define S2AMD_E_CAPACITY (-5)  /* output buffer too small */
+
+/* Solver selector: values and order are the reference ABI (include/solver2d/types.h:75-88). */
+typedef enum s2amdSolverType
+{
+	s2amd_solverJacobi = 0,
+	s2amd_solverPGS = 1,
+	s2amd_solverPGS_NGS = 2,
+	s2amd_solverPGS_NGS_Block = 3,
+	s2amd_solverPGS_Soft = 4,
+	s2amd_solverSoftStep = 5,
+	s2amd_solverTGS_Sticky = 6,
+	s2amd_solverTGS_Soft = 7,
+	s2amd_solverTGS_NGS = 8,
+	s2amd_solverXPBD = 9,
+	s2amd_solverTypeCount = 10
+} s2amdSolverType;
+
+/* Body type values are the reference's s2BodyType (types.h:99-105); -1 marks a free pool slot
+ * (s2IsFree, src/pool.h). */
+#define S2AMD_BODY_FREE (-1)
+#define S2AMD_BODY_STATIC 0
+#define S2AMD_BODY_KINEMATIC 1
+#define S2AMD_BODY_DYNAMIC 2
+
+/* Solver-visible part of s2Body (src/body.h:16-76).  In/out fields are marked. */
+typedef struct s2amdBody
+{
+	float position[2];       /* in/out  center of mass, body.h:24 */
+	float rot[2];            /* in/out  {s, c}, body.h:34 */
+	float linearVelocity[2]; /* in/out  body.h:39 */
+	float angularVelocity;   /* in/out  body.h:40 */
+	float deltaPosition[2];  /* in/out  body.h:27 (zero between steps except kinematic bodies under XPBD) */
+	float localCenter[2];    /* in      body.h:37 */
+	float force[2];          /* in      body.h:49 */
+	float torque;            /* in      body.h:50 */
+	float mass, invMass;     /* in      body.h:61 */
+	float I, invI;           /* in      body.h:64 */
+	float linearDamping;     /* in      body.h:66 */
+	float angularDamping;    /* in      body.h:67 */
+	float gravityScale;      /* in      body.h:68 */
+	int32_t type;            /* in      S2AMD_BODY_* */
+} s2amdBody;
+
+/* s2ManifoldPoint (include/solver2d/manifold.h:19-38) minus id/persisted, which no solver reads. */
+typedef struct s2amdManifoldPoint
+{
+	float localAnchorA[2];    /* in  relative to body origin */
+	float localAnchorB[2];    /* in */
+	float frictionAnchorA[2]; /* in/out TGS_Sticky only (solve_tgs_sticky.c:87-163) */
+	float frictionAnchorB[2]; /* in/out */
+	float frictionNormalA[2]; /* in/out */
+	float frictionNormalB[2]; /* in/out */
+	float separation;         /* in */
+	float normalImpulse;      /* in/out (warm start in, stored impulse out) */
+	float tangentImpulse;     /* in/out */
+} s2amdManifoldPoint;
+
+/* s2Contact as the solvers see it (src/contact.h:44-61): body indices from edges[0/1].bodyIndex,
+ * mixed friction, and the manifold.  pointCount == 0 marks a slot the gather loop skips
+ * (free contact or no manifold points; e.g. src/solve_tgs_soft.c:162-179). */
+typedef struct s2amdContact
+{
+	int32_t bodyA, bodyB;
+	int32_t pointCount;        /* 0, 1 or 2 */
+	int32_t frictionPersisted; /* in/out TGS_Sticky, manifold.h:45 */
+	float normal[2];
+	float friction;
+	int32_t constraintIndex;   /* out  manifold.constraintIndex written by the gather loop; -1 if skipped */
+	s2amdManifoldPoint points[2];
+} s2amdContact;
+
+#define S2AMD_JOINT_FREE (-1)
+#define S2AMD_JOINT_REVOLUTE 0 /* s2_revoluteJoint, src/joint.h:17 */
+#define S2AMD_JOINT_MOUSE 1    /* s2_mouseJoint,   src/joint.h:18 */
+
+/* Persistent part of s2Joint + s2RevoluteJoint / s2MouseJoint (src/joint.h:28-103).  The
+ * "solver temp" members are recomputed by every prepare function and never cross the boundary. */
+typedef struct s2amdJoint
+{
+	int32_t type; /* S2AMD_JOINT_* */
+	int32_t bodyA, bodyB;
+	int32_t enableMotor, enableLimit; /* revolute */
+	float localOriginAnchorA[2], localOriginAnchorB[2];
+	float impulse[2];   /* in/out revolute + mouse */
+	float motorImpulse; /* in/out revolute + mouse */
+	float lowerImpulse; /* in/out revolute */
+	float upperImpulse; /* in/out revolute */
+	float maxMotorTorque, motorSpeed, referenceAngle, lowerAngle, upperAngle; /* revolute */
+	float hertz, dampingRatio; /* mouse */
+	float targetA[2];          /* mouse */
+} s2amdJoint;
+
+/* The arguments of s2World_Step (include/solver2d/solver2d.h:25) + world->gravity and
+ * world->solverType; s2StepContext (src/solvers.h:13-24) is derived from these exactly as
+ * src/world.c:170-202 does. */
+typedef struct s2amdStepParams
+{
+	int32_t solverType; /* s2amdSolverType */
+	float dt;
+	int32_t velIters;
+	int32_t posIters;
+	int32_t warmStart;
+	float gravity[2];
+} s2amdStepParams;
+
+/* Wall/device timing of the last step (filled by s2amd_solve / s2amd_step_resident). */
+typedef struct s2amdStepStats
+{
+	int32_t constraintCount;   /* active contact constraints this step */
+	int32_t jointCount;        /* active joints */
+	int32_t contactColors;     /* colour batches of the contact graph (0 for Jacobi contacts) */
+	int32_t jointColors;
+	int32_t solveSweeps;       /* full passes of a s2SolveContacts_* kernel family this step */
+	int32_t kernelLaunches;    /* launches enqueued for the step */
+	float deviceMs;            /* HIP-event time of the whole device step */
+	float solveKernelMs;       /* HIP-event time summed over the contact solve sweeps only (0 unless profiling is on) */
+	float hostPrepMs;          /* host time spent colouring/packing */
+	int32_t graphReplayed;     /* 1 when the step ran as a hipGraph replay */
+} s2amdStepStats;
+
+typedef struct s2amdSolver s2amdSolver;
+
+/* ---- lifecycle ---- */
+int s2amd_api_version(void);
+int s2amd_device_count(void);
+const char* s2amd_last_error(void);
+/* device: HIP ordinal.  Fails with S2AMD_E_NODEVICE when no GPU is visible. */
+int s2amd_create(int device, s2amdSolver** out);
+void s2amd_destroy(s2amdSolver* solver);
+
+/* ---- drop-in entry point: == s2Solve_<params->solverType>(world, context) ----
+ * Host arrays in, same arrays mutated on return (bodies: position/rot/velocities/deltaPosition;
+ * contacts: impulses, constraintIndex, sticky cache; joints: impulses).  Any of the array
+ * pointers may be NULL when its count is 0. */
+int s2amd_solve(s2amdSolver* solver, const s2amdStepParams* params, s2amdBody* bodies, int32_t bodyCapacity,
+				s2amdContact* contacts, int32_t contactCapacity, s2amdJoint* joints, int32_t jointCapacity);
+
+/* ---- split phases, for callers that keep the world resident in HBM ---- */
+int s2amd_upload(s2amdSolver* solver, const s2amdBody* bodies, int32_t bodyCapacity, const s2amdContact* contacts,
+				 int32_t contactCapacity, const s2amdJoint* joints, int32_t jointCapacity);
+/* One s2Solve_* on the resident arrays; results stay on the device (impulses are stored back
+ * into the resident contact array, so consecutive calls warm start like consecutive steps). */
+int s2amd_step_resident(s2amdSolver* solver, const s2amdStepParams* params);
+int s2amd_download(s2amdSolver* solver, s2amdBody* bodies, int32_t bodyCapacity, s2amdContact* contacts,
+				   int32_t contactCapacity, s2amdJoint* joints, int32_t jointCapacity);
+/* Snapshot / restore of the resident body array on the device (bench: re-solve one snapshot). */
+int s2amd_save_bodies(s2amdSolver* solver);
+int s2amd_restore_bodies(s2amdSolver* solver);
+
+/* ---- introspection (tests, bench) ---- */
+/* Execution order of the last step: order[k] = contact-array index of the k-th constraint in
+ * sweep order; colorOffsets[c]..colorOffsets[c+1] delimit colour batch c.  A sequential
+ * Gauss-Seidel sweep in this order is arithmetic-identical to the batched device sweep. */
+int s2amd_get_contact_order(s2amdSolver* solver, int32_t* order, int32_t orderCapacity, int32_t* colorOffsets,
+							int32_t colorCapacity, int32_t* constraintCount, int32_t* colorCount);
+int s2amd_get_joint_order(s2amdSolver* solver, int32_t* order, int32_t orderCapacity, int32_t* colorOffsets,
+						  int32_t colorCapacity, int32_t* jointCount, int32_t* colorCount);
+int s2amd_get_stats(s2amdSolver* solver, s2amdStepStats* stats);
+/* option keys: "graph" (0/1 hipGraph replay), "profile" (0/1 per-sweep HIP events),
+ * "island_kernel" (0/1 one-workgroup-per-island path), "device_coloring" (0/1) */
+int s2amd_set_option(s2amdSolver* solver, const char* key, int32_t value);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* SOLVER2D_AMD_H */

@@ -1,0 +1,432 @@
+// TEST INFRASTRUCTURE -- not part of the shipped library.
+//
+// Hooks linked into oracle/_ref/libs2ref.so together with the UNMODIFIED reference sources
+// (compiled where they lie under /root/reference by oracle/Makefile).  The linker option
+// --wrap=s2Solve_<Variant> reroutes the ten calls in s2World_Step's switch
+// (src/world.c:206-256) through hookSolve() below, which can
+//   mode 0: pass straight through to the reference solver,
+//   mode 1: capture the solver's inputs and outputs in the s2amd wire format
+//           (include/solver2d_amd.h) -- this is how golden fixtures are generated and how the
+//           oracle restatement is pinned bit-for-bit against the reference,
+//   mode 2: replace the reference solver by a callback with the s2amd_solve signature -- the
+//           reference's own broad phase / narrow phase / contact bookkeeping then drives the
+//           HIP solver, which is the literal drop-in test.
+// It reads the reference's internal structs through the reference's own headers; no reference
+// source is copied into this repository.
+
+#include "body.h"
+#include "contact.h"
+#include "core.h"
+#include "joint.h"
+#include "shape.h"
+#include "solvers.h"
+#include "world.h"
+
+#include "solver2d/solver2d.h"
+
+#include "solver2d_amd.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#define S2REF_API __attribute__((visibility("default")))
+
+typedef void s2SolveFcn(s2World* world, s2StepContext* context);
+typedef int s2refReplaceFcn(void* user, const s2amdStepParams* params, s2amdBody* bodies, int32_t bodyCapacity,
+							s2amdContact* contacts, int32_t contactCapacity, s2amdJoint* joints, int32_t jointCapacity);
+
+typedef struct Snapshot
+{
+	s2amdBody* bodies;
+	s2amdContact* contacts;
+	s2amdJoint* joints;
+	int32_t bodyCapacity, contactCapacity, jointCapacity;
+} Snapshot;
+
+static int g_mode = 0;
+static s2refReplaceFcn* g_replace = NULL;
+static void* g_replaceUser = NULL;
+static Snapshot g_pre = {0}, g_post = {0};
+static s2amdStepParams g_params;
+static int g_captureCount = 0;
+static int g_replaceError = 0;
+
+static void packBodies(const s2World* world, s2amdBody* out)
+{
+	int n = world->bodyPool.capacity;
+	for (int i = 0; i < n; ++i)
+	{
+		const s2Body* b = world->bodies + i;
+		s2amdBody* o = out + i;
+		memset(o, 0, sizeof(*o));
+		if (s2IsFree(&b->object))
+		{
+			o->type = S2AMD_BODY_FREE;
+			continue;
+		}
+		o->position[0] = b->position.x, o->position[1] = b->position.y;
+		o->rot[0] = b->rot.s, o->rot[1] = b->rot.c;
+		o->linearVelocity[0] = b->linearVelocity.x, o->linearVelocity[1] = b->linearVelocity.y;
+		o->angularVelocity = b->angularVelocity;
+		o->deltaPosition[0] = b->deltaPosition.x, o->deltaPosition[1] = b->deltaPosition.y;
+		o->localCenter[0] = b->localCenter.x, o->localCenter[1] = b->localCenter.y;
+		o->force[0] = b->force.x, o->force[1] = b->force.y;
+		o->torque = b->torque;
+		o->mass = b->mass, o->invMass = b->invMass;
+		o->I = b->I, o->invI = b->invI;
+		o->linearDamping = b->linearDamping;
+		o->angularDamping = b->angularDamping;
+		o->gravityScale = b->gravityScale;
+		o->type = (int32_t)b->type;
+	}
+}
+
+static void unpackBodies(s2World* world, const s2amdBody* in)
+{
+	int n = world->bodyPool.capacity;
+	for (int i = 0; i < n; ++i)
+	{
+		s2Body* b = world->bodies + i;
+		const s2amdBody* o = in + i;
+		if (s2IsFree(&b->object))
+		{
+			continue;
+		}
+		b->position = (s2Vec2){o->position[0], o->position[1]};
+		b->rot = (s2Rot){o->rot[0], o->rot[1]};
+		b->linearVelocity = (s2Vec2){o->linearVelocity[0], o->linearVelocity[1]};
+		b->angularVelocity = o->angularVelocity;
+		b->deltaPosition = (s2Vec2){o->deltaPosition[0], o->deltaPosition[1]};
+	}
+}
+
+static void packContacts(const s2World* world, s2amdContact* out)
+{
+	int n = world->contactPool.capacity;
+	for (int i = 0; i < n; ++i)
+	{
+		const s2Contact* c = world->contacts + i;
+		s2amdContact* o = out + i;
+		memset(o, 0, sizeof(*o));
+		o->constraintIndex = -1;
+		if (s2IsFree(&c->object))
+		{
+			o->bodyA = -1, o->bodyB = -1;
+			continue;
+		}
+		const s2Manifold* m = &c->manifold;
+		o->bodyA = c->edges[0].bodyIndex;
+		o->bodyB = c->edges[1].bodyIndex;
+		o->pointCount = m->pointCount;
+		o->frictionPersisted = m->frictionPersisted ? 1 : 0;
+		o->normal[0] = m->normal.x, o->normal[1] = m->normal.y;
+		o->friction = c->friction;
+		o->constraintIndex = m->constraintIndex;
+		for (int j = 0; j < 2; ++j)
+		{
+			const s2ManifoldPoint* p = m->points + j;
+			s2amdManifoldPoint* q = o->points + j;
+			q->localAnchorA[0] = p->localAnchorA.x, q->localAnchorA[1] = p->localAnchorA.y;
+			q->localAnchorB[0] = p->localAnchorB.x, q->localAnchorB[1] = p->localAnchorB.y;
+			q->frictionAnchorA[0] = p->frictionAnchorA.x, q->frictionAnchorA[1] = p->frictionAnchorA.y;
+			q->frictionAnchorB[0] = p->frictionAnchorB.x, q->frictionAnchorB[1] = p->frictionAnchorB.y;
+			q->frictionNormalA[0] = p->frictionNormalA.x, q->frictionNormalA[1] = p->frictionNormalA.y;
+			q->frictionNormalB[0] = p->frictionNormalB.x, q->frictionNormalB[1] = p->frictionNormalB.y;
+			q->separation = p->separation;
+			q->normalImpulse = p->normalImpulse;
+			q->tangentImpulse = p->tangentImpulse;
+		}
+	}
+}
+
+static void unpackContacts(s2World* world, const s2amdContact* in)
+{
+	int n = world->contactPool.capacity;
+	for (int i = 0; i < n; ++i)
+	{
+		s2Contact* c = world->contacts + i;
+		const s2amdContact* o = in + i;
+		if (s2IsFree(&c->object))
+		{
+			continue;
+		}
+		s2Manifold* m = &c->manifold;
+		m->frictionPersisted = o->frictionPersisted != 0;
+		if (o->constraintIndex >= 0)
+		{
+			m->constraintIndex = o->constraintIndex;
+		}
+		for (int j = 0; j < 2; ++j)
+		{
+			s2ManifoldPoint* p = m->points + j;
+			const s2amdManifoldPoint* q = o->points + j;
+			p->frictionAnchorA = (s2Vec2){q->frictionAnchorA[0], q->frictionAnchorA[1]};
+			p->frictionAnchorB = (s2Vec2){q->frictionAnchorB[0], q->frictionAnchorB[1]};
+			p->frictionNormalA = (s2Vec2){q->frictionNormalA[0], q->frictionNormalA[1]};
+			p->frictionNormalB = (s2Vec2){q->frictionNormalB[0], q->frictionNormalB[1]};
+			p->normalImpulse = q->normalImpulse;
+			p->tangentImpulse = q->tangentImpulse;
+		}
+	}
+}
+
+static void packJoints(const s2World* world, s2amdJoint* out)
+{
+	int n = world->jointPool.capacity;
+	for (int i = 0; i < n; ++i)
+	{
+		const s2Joint* jn = world->joints + i;
+		s2amdJoint* o = out + i;
+		memset(o, 0, sizeof(*o));
+		if (s2IsFree(&jn->object))
+		{
+			o->type = S2AMD_JOINT_FREE;
+			o->bodyA = -1, o->bodyB = -1;
+			continue;
+		}
+		o->bodyA = jn->edges[0].bodyIndex;
+		o->bodyB = jn->edges[1].bodyIndex;
+		o->localOriginAnchorA[0] = jn->localOriginAnchorA.x, o->localOriginAnchorA[1] = jn->localOriginAnchorA.y;
+		o->localOriginAnchorB[0] = jn->localOriginAnchorB.x, o->localOriginAnchorB[1] = jn->localOriginAnchorB.y;
+		if (jn->type == s2_revoluteJoint)
+		{
+			const s2RevoluteJoint* r = &jn->revoluteJoint;
+			o->type = S2AMD_JOINT_REVOLUTE;
+			o->enableMotor = r->enableMotor ? 1 : 0;
+			o->enableLimit = r->enableLimit ? 1 : 0;
+			o->impulse[0] = r->impulse.x, o->impulse[1] = r->impulse.y;
+			o->motorImpulse = r->motorImpulse;
+			o->lowerImpulse = r->lowerImpulse;
+			o->upperImpulse = r->upperImpulse;
+			o->maxMotorTorque = r->maxMotorTorque;
+			o->motorSpeed = r->motorSpeed;
+			o->referenceAngle = r->referenceAngle;
+			o->lowerAngle = r->lowerAngle;
+			o->upperAngle = r->upperAngle;
+		}
+		else
+		{
+			const s2MouseJoint* mj = &jn->mouseJoint;
+			o->type = S2AMD_JOINT_MOUSE;
+			o->impulse[0] = mj->impulse.x, o->impulse[1] = mj->impulse.y;
+			o->motorImpulse = mj->motorImpulse;
+			o->hertz = mj->hertz;
+			o->dampingRatio = mj->dampingRatio;
+			o->targetA[0] = mj->targetA.x, o->targetA[1] = mj->targetA.y;
+		}
+	}
+}
+
+static void unpackJoints(s2World* world, const s2amdJoint* in)
+{
+	int n = world->jointPool.capacity;
+	for (int i = 0; i < n; ++i)
+	{
+		s2Joint* jn = world->joints + i;
+		const s2amdJoint* o = in + i;
+		if (s2IsFree(&jn->object))
+		{
+			continue;
+		}
+		if (jn->type == s2_revoluteJoint)
+		{
+			s2RevoluteJoint* r = &jn->revoluteJoint;
+			r->impulse = (s2Vec2){o->impulse[0], o->impulse[1]};
+			r->motorImpulse = o->motorImpulse;
+			r->lowerImpulse = o->lowerImpulse;
+			r->upperImpulse = o->upperImpulse;
+		}
+		else
+		{
+			s2MouseJoint* mj = &jn->mouseJoint;
+			mj->impulse = (s2Vec2){o->impulse[0], o->impulse[1]};
+			mj->motorImpulse = o->motorImpulse;
+		}
+	}
+}
+
+static void snapshotWorld(const s2World* world, Snapshot* s)
+{
+	int nb = world->bodyPool.capacity, nc = world->contactPool.capacity, nj = world->jointPool.capacity;
+	s->bodies = (s2amdBody*)realloc(s->bodies, (size_t)(nb > 0 ? nb : 1) * sizeof(s2amdBody));
+	s->contacts = (s2amdContact*)realloc(s->contacts, (size_t)(nc > 0 ? nc : 1) * sizeof(s2amdContact));
+	s->joints = (s2amdJoint*)realloc(s->joints, (size_t)(nj > 0 ? nj : 1) * sizeof(s2amdJoint));
+	s->bodyCapacity = nb, s->contactCapacity = nc, s->jointCapacity = nj;
+	packBodies(world, s->bodies);
+	packContacts(world, s->contacts);
+	packJoints(world, s->joints);
+}
+
+static void fillParams(const s2World* world, const s2StepContext* context, int solverType)
+{
+	g_params.solverType = solverType;
+	g_params.dt = context->dt;
+	g_params.velIters = context->iterations;
+	g_params.posIters = context->extraIterations;
+	g_params.warmStart = context->warmStart ? 1 : 0;
+	g_params.gravity[0] = world->gravity.x;
+	g_params.gravity[1] = world->gravity.y;
+}
+
+static void hookSolve(s2World* world, s2StepContext* context, int solverType, s2SolveFcn* real)
+{
+	if (g_mode == 1)
+	{
+		fillParams(world, context, solverType);
+		snapshotWorld(world, &g_pre);
+		real(world, context);
+		snapshotWorld(world, &g_post);
+		g_captureCount += 1;
+	}
+	else if (g_mode == 2 && g_replace != NULL)
+	{
+		fillParams(world, context, solverType);
+		snapshotWorld(world, &g_pre);
+		int rc = g_replace(g_replaceUser, &g_params, g_pre.bodies, g_pre.bodyCapacity, g_pre.contacts, g_pre.contactCapacity,
+						   g_pre.joints, g_pre.jointCapacity);
+		if (rc != 0)
+		{
+			g_replaceError = rc;
+		}
+		unpackBodies(world, g_pre.bodies);
+		unpackContacts(world, g_pre.contacts);
+		unpackJoints(world, g_pre.joints);
+		g_captureCount += 1;
+	}
+	else
+	{
+		real(world, context);
+	}
+}
+
+#define WRAP(NAME, TYPE)                                                                                                         \
+	void __real_##NAME(s2World* world, s2StepContext* context);                                                                  \
+	void __wrap_##NAME(s2World* world, s2StepContext* context)                                                                   \
+	{                                                                                                                            \
+		hookSolve(world, context, TYPE, __real_##NAME);                                                                          \
+	}
+
+WRAP(s2Solve_Jacobi, s2_solverJacobi)
+WRAP(s2Solve_PGS, s2_solverPGS)
+WRAP(s2Solve_PGS_NGS, s2_solverPGS_NGS)
+WRAP(s2Solve_PGS_NGS_Block, s2_solverPGS_NGS_Block)
+WRAP(s2Solve_PGS_Soft, s2_solverPGS_Soft)
+WRAP(s2Solve_SoftStep, s2_solverSoftStep)
+WRAP(s2Solve_TGS_Sticky, s2_solverTGS_Sticky)
+WRAP(s2Solve_TGS_Soft, s2_solverTGS_Soft)
+WRAP(s2Solve_TGS_NGS, s2_solverTGS_NGS)
+WRAP(s2Solve_XPBD, s2_solverXPBD)
+
+// ---- control surface used by tests/ and tools/ through ctypes ----
+
+S2REF_API void s2ref_set_mode(int mode)
+{
+	g_mode = mode;
+	g_replaceError = 0;
+}
+
+S2REF_API void s2ref_set_replace(s2refReplaceFcn* fcn, void* user)
+{
+	g_replace = fcn;
+	g_replaceUser = user;
+}
+
+S2REF_API int s2ref_replace_error(void)
+{
+	return g_replaceError;
+}
+
+S2REF_API int s2ref_capture_count(void)
+{
+	return g_captureCount;
+}
+
+S2REF_API const s2amdStepParams* s2ref_params(void)
+{
+	return &g_params;
+}
+
+// which: 0 = state at solver entry, 1 = state at solver exit
+S2REF_API int s2ref_snapshot(int which, const s2amdBody** bodies, int32_t* bodyCapacity, const s2amdContact** contacts,
+							 int32_t* contactCapacity, const s2amdJoint** joints, int32_t* jointCapacity)
+{
+	const Snapshot* s = which == 0 ? &g_pre : &g_post;
+	*bodies = s->bodies, *bodyCapacity = s->bodyCapacity;
+	*contacts = s->contacts, *contactCapacity = s->contactCapacity;
+	*joints = s->joints, *jointCapacity = s->jointCapacity;
+	return 0;
+}
+
+// Current world state in wire format (outside a step).
+S2REF_API int s2ref_world_sizes(s2WorldId id, int32_t* bodyCapacity, int32_t* contactCapacity, int32_t* jointCapacity)
+{
+	s2World* world = s2GetWorldFromId(id);
+	*bodyCapacity = world->bodyPool.capacity;
+	*contactCapacity = world->contactPool.capacity;
+	*jointCapacity = world->jointPool.capacity;
+	return 0;
+}
+
+S2REF_API int s2ref_pack_world(s2WorldId id, s2amdBody* bodies, s2amdContact* contacts, s2amdJoint* joints)
+{
+	s2World* world = s2GetWorldFromId(id);
+	if (bodies)
+		packBodies(world, bodies);
+	if (contacts)
+		packContacts(world, contacts);
+	if (joints)
+		packJoints(world, joints);
+	return 0;
+}
+
+// Contact pair table: (shapeIndexA, shapeIndexB) per contact slot, -1 for free slots.
+S2REF_API int s2ref_contact_pairs(s2WorldId id, int32_t* shapeA, int32_t* shapeB, int32_t capacity)
+{
+	s2World* world = s2GetWorldFromId(id);
+	int n = world->contactPool.capacity;
+	if (capacity < n)
+	{
+		return -1;
+	}
+	for (int i = 0; i < n; ++i)
+	{
+		const s2Contact* c = world->contacts + i;
+		if (s2IsFree(&c->object))
+		{
+			shapeA[i] = -1, shapeB[i] = -1;
+		}
+		else
+		{
+			shapeA[i] = c->shapeIndexA, shapeB[i] = c->shapeIndexB;
+		}
+	}
+	return n;
+}
+
+// Convenience for ctypes callers: step through the public entry point.
+S2REF_API void s2ref_step(s2WorldId id, float dt, int velIters, int posIters, int warmStart)
+{
+	s2World_Step(id, dt, velIters, posIters, warmStart != 0);
+}
+
+S2REF_API void s2ref_destroy_world(s2WorldId id)
+{
+	s2DestroyWorld(id);
+}
+
+S2REF_API size_t s2ref_sizeof(int what)
+{
+	switch (what)
+	{
+		case 0:
+			return sizeof(s2Body);
+		case 1:
+			return sizeof(s2Contact);
+		case 2:
+			return sizeof(s2Joint);
+		case 3:
+			return sizeof(s2ContactConstraint);
+		default:
+			return 0;
+	}
+}

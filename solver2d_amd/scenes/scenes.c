@@ -373,7 +373,7 @@ static void sceneCirclePile(s2WorldId w, int count)
 	{
 		s2BodyDef bd = s2_defaultBodyDef;
 		bd.type = s2_dynamicBody;
-		bd.position = (s2Vec2){lcgFloat(-3.0f, 3.0f), 3.0f + 0.7f * i};
+		bd.position = (s2Vec2){lcgFloat(-3.0f, 3.0f), 0.2f + 0.7f * i};
 		s2BodyId id = s2CreateBody(w, &bd);
 		s2Circle c = {{0.0f, 0.0f}, lcgFloat(0.25f, 0.45f)};
 		s2CreateCircleShape(id, &sd, &c);

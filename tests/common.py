@@ -1,0 +1,85 @@
+"""Shared helpers for the parity tests."""
+import numpy as np
+
+from solver2d_amd import wire
+
+# (velIters, posIters) the reference GUI uses by default (samples/settings.h:17-19) and the
+# BASELINE TGS_Soft setting
+DEFAULT_ITERS = {name: (4, 2) for name in wire.SOLVER_NAMES}
+DEFAULT_ITERS["TGS_Soft"] = (8, 4)
+DEFAULT_ITERS["SoftStep"] = (8, 4)
+
+BODY_OUT = ["position", "rot", "linearVelocity", "angularVelocity", "deltaPosition"]
+JOINT_OUT = ["impulse", "motorImpulse", "lowerImpulse", "upperImpulse"]
+POINT_OUT = ["normalImpulse", "tangentImpulse", "frictionAnchorA", "frictionAnchorB", "frictionNormalA", "frictionNormalB"]
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.float32:
+        return a.view(np.uint32)
+    return a
+
+
+def diff_report(name, a, b):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    bad = bits(a) != bits(b)
+    if not bad.any():
+        return None
+    idx = np.argwhere(bad)
+    first = tuple(idx[0])
+    with np.errstate(invalid="ignore"):
+        err = np.nanmax(np.abs(a.astype(np.float64) - b.astype(np.float64))) if a.dtype.kind == "f" else 0
+    return "%s: %d/%d words differ, first at %s: %r vs %r, max abs err %.3g" % (
+        name, int(bad.sum()), bad.size, first, a[first], b[first], err)
+
+
+def compare_exact(got, want, what=""):
+    """Bitwise comparison of every solver output field of (bodies, contacts, joints)."""
+    gb, gc, gj = got
+    wb, wc, wj = want
+    problems = []
+    live = wb["type"] >= 0
+    for f in BODY_OUT:
+        r = diff_report("body." + f, gb[f][live], wb[f][live])
+        if r:
+            problems.append(r)
+    for f in POINT_OUT:
+        r = diff_report("contact.points." + f, gc["points"][f], wc["points"][f])
+        if r:
+            problems.append(r)
+    r = diff_report("contact.frictionPersisted", gc["frictionPersisted"], wc["frictionPersisted"])
+    if r:
+        problems.append(r)
+    # the reference leaves a stale constraintIndex in skipped contacts; the wire format reports -1 there
+    act = wc["pointCount"] > 0
+    r = diff_report("contact.constraintIndex", gc["constraintIndex"][act], wc["constraintIndex"][act])
+    if r:
+        problems.append(r)
+    livej = wj["type"] >= 0
+    for f in JOINT_OUT:
+        r = diff_report("joint." + f, gj[f][livej], wj[f][livej])
+        if r:
+            problems.append(r)
+    assert not problems, what + "\n  " + "\n  ".join(problems)
+
+
+def max_abs_diff(got, want):
+    """Largest absolute difference over all float solver outputs (for tolerance-based links)."""
+    gb, gc, gj = got
+    wb, wc, wj = want
+    live = wb["type"] >= 0
+    out = {}
+    for f in BODY_OUT:
+        out["body." + f] = float(np.max(np.abs(gb[f][live].astype(np.float64) - wb[f][live].astype(np.float64)), initial=0.0))
+    for f in ["normalImpulse", "tangentImpulse"]:
+        out["point." + f] = float(np.max(np.abs(gc["points"][f].astype(np.float64) - wc["points"][f].astype(np.float64)), initial=0.0))
+    livej = wj["type"] >= 0
+    for f in JOINT_OUT:
+        out["joint." + f] = float(np.max(np.abs(gj[f][livej].astype(np.float64) - wj[f][livej].astype(np.float64)), initial=0.0))
+    return out
+
+
+def copy3(t):
+    return tuple(x.copy() for x in t)

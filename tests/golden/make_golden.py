@@ -1,0 +1,56 @@
+"""Generates tests/golden/*.npz from the UNMODIFIED reference (oracle/_ref/libs2ref.so).
+
+Run in the build container (needs `make -C oracle ref`, i.e. /root/reference present):
+    python tests/golden/make_golden.py
+Each fixture is data only: the wire-format state at s2Solve_* entry ("pre_*") and exit ("post_*")
+of one s2World_Step of the reference, plus the step parameters.  No reference source text is
+stored.  tests/test_golden.py replays pre -> oracle -> compares bitwise with post, and the GPU
+tests replay pre -> HIP -> compare with the oracle run in the device's colour order.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from solver2d_amd import wire  # noqa: E402
+from tests import common, refbind  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+# (scene, p0, p1, capture-at-steps)
+CASES = [
+    ("pyramid", 10, 0, (0, 1, 45)),
+    ("mixed", 24, 0, (30, 75)),
+    ("joint_grid", 6, 6, (0, 20)),
+    ("circle_pile", 12, 0, (40,)),
+]
+
+
+def main():
+    total = 0
+    for scene, p0, p1, at in CASES:
+        for solver in wire.SOLVER_NAMES:
+            vel, pos = common.DEFAULT_ITERS[solver]
+            with refbind.RefWorld(scene, solver, p0, p1) as world:
+                for step in range(max(at) + 1):
+                    if step in at:
+                        params, pre, post = world.step_captured(1.0 / 60.0, vel, pos, True)
+                        name = "%s%d_%s_step%03d.npz" % (scene, p0, solver, step)
+                        path = os.path.join(OUT, name)
+                        np.savez_compressed(
+                            path,
+                            params=np.array([params.solverType, params.velIters, params.posIters, params.warmStart], dtype=np.int32),
+                            params_f=np.array([params.dt, params.gravity[0], params.gravity[1]], dtype=np.float32),
+                            pre_bodies=pre[0], pre_contacts=pre[1], pre_joints=pre[2],
+                            post_bodies=post[0], post_contacts=post[1], post_joints=post[2])
+                        total += os.path.getsize(path)
+                    else:
+                        world.step(1.0 / 60.0, vel, pos, True)
+    print("wrote fixtures, %.1f KiB total" % (total / 1024.0))
+
+
+if __name__ == "__main__":
+    main()

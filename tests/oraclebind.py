@@ -1,0 +1,45 @@
+"""ctypes binding of oracle/liboracle.so (the CPU restatement).  TEST INFRASTRUCTURE."""
+import ctypes
+import os
+import subprocess
+import numpy as np
+
+from solver2d_amd import wire
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src = os.path.join(ROOT, "oracle", "solver_oracle.c")
+        if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+            build()
+        L = ctypes.CDLL(ORACLE_SO)
+        L.s2oracle_solve.restype = ctypes.c_int
+        L.s2oracle_solve.argtypes = [ctypes.POINTER(wire.StepParams), ctypes.c_void_p, ctypes.c_int32,
+                                     ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                     ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32]
+        _lib = L
+    return _lib
+
+
+def solve(params, bodies, contacts, joints, contact_order=None, joint_order=None):
+    """In-place s2Solve_<solver> on wire arrays.  Orders are int32 arrays or None (reference order)."""
+    co = None if contact_order is None else np.ascontiguousarray(contact_order, dtype=np.int32)
+    jo = None if joint_order is None else np.ascontiguousarray(joint_order, dtype=np.int32)
+    rc = lib().s2oracle_solve(ctypes.byref(params), wire.as_ptr(bodies), len(bodies), wire.as_ptr(contacts), len(contacts),
+                              wire.as_ptr(joints), len(joints),
+                              ctypes.c_void_p(co.ctypes.data) if co is not None and len(co) else ctypes.c_void_p(0),
+                              0 if co is None else len(co),
+                              ctypes.c_void_p(jo.ctypes.data) if jo is not None and len(jo) else ctypes.c_void_p(0),
+                              0 if jo is None else len(jo))
+    if rc != 0:
+        raise RuntimeError("s2oracle_solve failed: %d" % rc)
+    return bodies, contacts, joints

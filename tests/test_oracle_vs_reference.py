@@ -1,0 +1,63 @@
+"""Parity link L1: the CPU restatement (oracle/solver_oracle.c) must be BIT-IDENTICAL to the
+unmodified reference (oracle/_ref/libs2ref.so) on the same solver inputs, for all ten solvers.
+
+Method: step a reference world through the public s2World_Step with the capture hook armed;
+the hook records the wire-format state at s2Solve_* entry and exit.  The oracle is run on a
+copy of the entry state and every output word is compared with the exit state.
+Needs the compiled reference => skipped where oracle/_ref is absent (the golden-vector test
+covers the same pin from committed fixtures).
+"""
+import pytest
+
+from solver2d_amd import wire
+from tests import common, oraclebind, refbind
+
+pytestmark = pytest.mark.skipif(not refbind.available(), reason="oracle/_ref/libs2ref.so not built")
+
+SCENES = [
+    ("pyramid", 10, 0, 40),
+    ("mixed", 24, 0, 60),
+    ("joint_grid", 6, 6, 30),
+    ("vertical_stack", 8, 0, 30),
+    ("circle_pile", 16, 0, 40),
+    ("tumbler", 60, 0, 40),
+    ("multi_pyramid", 3, 5, 20),
+]
+
+
+@pytest.mark.parametrize("solver", wire.SOLVER_NAMES)
+@pytest.mark.parametrize("scene,p0,p1,steps", SCENES)
+def test_bit_exact(solver, scene, p0, p1, steps):
+    vel, pos = common.DEFAULT_ITERS[solver]
+    with refbind.RefWorld(scene, solver, p0, p1) as world:
+        active = 0
+        for step in range(steps):
+            params, pre, post = world.step_captured(1.0 / 60.0, vel, pos, True)
+            got = common.copy3(pre)
+            oraclebind.solve(params, *got)
+            common.compare_exact(got, post, "%s/%s step %d" % (scene, solver, step))
+            active = max(active, int((pre[1]["pointCount"] > 0).sum()))
+        if scene != "joint_grid":
+            assert active > 0, "scene produced no contact constraints"
+
+
+@pytest.mark.parametrize("solver", wire.SOLVER_NAMES)
+def test_bit_exact_no_warm_start_and_odd_iters(solver):
+    with refbind.RefWorld("mixed", solver, 18, 0) as world:
+        for step in range(25):
+            warm = step % 3 != 0
+            vel, pos = (3, 0) if step % 2 else (5, 3)
+            params, pre, post = world.step_captured(1.0 / 30.0 if step % 5 == 0 else 1.0 / 60.0, vel, pos, warm)
+            got = common.copy3(pre)
+            oraclebind.solve(params, *got)
+            common.compare_exact(got, post, "mixed/%s step %d" % (solver, step))
+
+
+def test_larger_pyramid_tgs_soft():
+    with refbind.RefWorld("pyramid", "TGS_Soft", 40, 0) as world:
+        for step in range(10):
+            params, pre, post = world.step_captured(1.0 / 60.0, 8, 4, True)
+            got = common.copy3(pre)
+            oraclebind.solve(params, *got)
+            common.compare_exact(got, post, "pyramid40 step %d" % step)
+        assert int((pre[1]["pointCount"] > 0).sum()) == 2380

@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Headline benchmark: contact-constraints x iterations / sec, LargePyramid base-200, TGS_Soft
+(8 sub-steps, relax on) -- BASELINE.json's metric on BASELINE.json's config (configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one s2Solve_TGS_Soft (the hot path of one s2World_Step) over one resident snapshot:
+the pyramid's step-0 solver input (solver2d_amd.synthetic.pyramid == the reference's own captured
+input, tests/test_synthetic.py), body state restored from the snapshot before every step, contact
+impulses carried from step to step (warm starting).  Inputs are in HBM before the timed region.
+`value` = C x solve_sweeps x K x N / wall seconds, with solve sweeps counted as executed
+(TGS_Soft 8/4: 16 per step, reference src/solve_tgs_soft.c:211-269).
+
+N > 1: one process per GPU (torch.distributed / RCCL), each rank owns one independent pyramid
+island (weak scaling); the only exchange is the per-step all-gather of per-island body poses.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (solveContactsSoftKernel<SOFT_TGS>): algorithmic bytes per launch
+                (232 B/constraint-sweep, SURVEY.md 8d x constraints per colour batch) / average
+                launch duration from HIP events recorded on the launch stream around every launch.
+  cpu_baseline  the reference's own s2Solve_TGS_Soft timed on this host (oracle/_ref, kind
+                "reference") or, if that library is absent, the oracle port; 1 core.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from solver2d_amd import hip, synthetic, wire  # noqa: E402
+
+ALGO_BYTES_PER_CONSTRAINT_SWEEP = 232.0
+HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(base, vel, pos, budget_s):
+    """Reference (or port) solver-only throughput on this host, single thread, bounded sample."""
+    C = None
+    try:
+        from tests import refbind
+        if refbind.available():
+            L = refbind.lib()
+            with refbind.RefWorld("pyramid", "TGS_Soft", base, 0) as w:
+                w.step(1.0 / 60.0, vel, pos, True)  # creates the contacts
+                L.s2ref_set_mode(3)
+                L.s2ref_solve_seconds(1)
+                t0 = time.time()
+                steps = 0
+                while steps < 3 or (time.time() - t0 < budget_s and steps < 400):
+                    w.step(1.0 / 60.0, vel, pos, True)
+                    steps += 1
+                secs = L.s2ref_solve_seconds(1)
+                L.s2ref_set_mode(0)
+                _b, c, _j = w.pack()
+                C = int((c["pointCount"] > 0).sum())
+            sweeps = wire.solve_sweeps_per_step("TGS_Soft", vel, pos)
+            return {"value": C * sweeps * steps / secs, "unit": "constraint-iters/s", "cores": 1, "kind": "reference",
+                    "sample": "%d s2World_Step of pyramid base-%d, time inside the reference's s2Solve_TGS_Soft only "
+                              "(%.1f ms/solve); host has %d cores" % (steps, base, 1e3 * secs / steps, os.cpu_count())}
+    except Exception as e:  # fall through to the port
+        sys.stderr.write("cpu_baseline: reference unavailable (%r), timing the oracle port\n" % (e,))
+    from tests import oraclebind
+    pre = synthetic.pyramid(base)
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, vel, pos, True)
+    C = int((pre[1]["pointCount"] > 0).sum())
+    bodies0 = pre[0].copy()
+    steps, t0, secs = 0, time.time(), 0.0
+    while steps < 3 or (time.time() - t0 < budget_s and steps < 400):
+        pre[0][:] = bodies0
+        t1 = time.perf_counter()
+        oraclebind.solve(params, *pre)
+        secs += time.perf_counter() - t1
+        steps += 1
+    sweeps = wire.solve_sweeps_per_step("TGS_Soft", vel, pos)
+    return {"value": C * sweeps * steps / secs, "unit": "constraint-iters/s", "cores": 1, "kind": "port",
+            "sample": "%d oracle solves of the base-%d snapshot (%.1f ms/solve); host has %d cores" % (
+                steps, base, 1e3 * secs / steps, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=60)
+    ap.add_argument("--base", type=int, default=200, help="pyramid base count (200 = BASELINE config 2)")
+    ap.add_argument("--vel-iters", type=int, default=8)
+    ap.add_argument("--pos-iters", type=int, default=4)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl")
+    n_gpus = max(args.gpus, 1)
+    if world > 1 and world != n_gpus:
+        n_gpus = world
+
+    pre = synthetic.pyramid(args.base)
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, args.vel_iters, args.pos_iters, True)
+    sweeps = wire.solve_sweeps_per_step("TGS_Soft", args.vel_iters, args.pos_iters)
+
+    gpu = hip.Solver(local_rank if world > 1 else 0, graph=not args.no_graph)
+    gpu.upload(*pre)
+    gpu.save_bodies()
+
+    pose = None
+    gathered = None
+    if world > 1:
+        import torch
+        nb = len(pre[0])
+        pose = torch.zeros((nb, 4), dtype=torch.float32, device="cuda")
+        gathered = torch.zeros((world * nb, 4), dtype=torch.float32, device="cuda")
+
+    def one_step():
+        gpu.restore_bodies()
+        gpu.step_resident(params)
+        if world > 1:
+            gpu.export_poses(pose.data_ptr(), pose.shape[0])
+            dist.all_gather_into_tensor(gathered, pose)
+
+    def sync():
+        if world > 1:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    st = gpu.stats()
+    C = st["constraintCount"]
+
+    if world > 1:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant-kernel timing: HIP events on the launch stream around every solve-sweep launch
+    prof_steps = 5
+    gpu.set_option("profile", 1)
+    kernel_ms, launches = 0.0, 0
+    for _ in range(prof_steps):
+        gpu.restore_bodies()
+        gpu.step_resident(params)
+        s2 = gpu.stats()
+        kernel_ms += s2["solveKernelMs"]
+        launches += s2["solveLaunches"]
+    gpu.set_option("profile", 0)
+    avg_launch_s = (kernel_ms / 1e3) / max(launches, 1)
+    constraints_per_launch = C * sweeps * prof_steps / max(launches, 1)
+    achieved = ALGO_BYTES_PER_CONSTRAINT_SWEEP * constraints_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+
+    if rank == 0:
+        value = C * sweeps * args.steps * n_gpus / elapsed
+        out = {
+            "metric": "contact-constraints x iters/sec, LargePyramid base-%d TGS_Soft" % args.base,
+            "value": value,
+            "unit": "constraint-iters/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "LargePyramid base-%d (%d bodies, %d two-point contact constraints), s2_solverTGS_Soft, "
+                            "s2World_Step(dt=1/60, velIters=%d, posIters=%d, warmStart) => %d solve sweeps + %d warm-start "
+                            "sweeps per step; one independent pyramid per GPU" % (
+                                args.base, len(pre[0]), C, args.vel_iters, args.pos_iters, sweeps, args.vel_iters),
+                "constraints": C, "solve_sweeps_per_step": sweeps, "contact_colors": st["contactColors"],
+                "kernel_launches_per_step": st["kernelLaunches"], "graph_replay": bool(st["graphReplayed"]),
+                "device_ms_per_step": st["deviceMs"],
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "solveContactsSoftKernel<SOFT_TGS>",
+                "avg_launch_us": avg_launch_s * 1e6, "launches_per_step": launches / prof_steps,
+                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CONSTRAINT_SWEEP * constraints_per_launch,
+            },
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.base, args.vel_iters, args.pos_iters, args.cpu_seconds)
+        print(json.dumps(out))
+    gpu.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

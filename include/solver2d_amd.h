@@ -151,9 +151,10 @@ typedef struct s2amdStepStats
 	int32_t solveSweeps;       /* full passes of a s2SolveContacts_* kernel family this step */
 	int32_t kernelLaunches;    /* launches enqueued for the step */
 	float deviceMs;            /* HIP-event time of the whole device step */
-	float solveKernelMs;       /* HIP-event time summed over the contact solve sweeps only (0 unless profiling is on) */
+	float solveKernelMs;       /* HIP-event time summed over the individual contact solve-sweep launches (0 unless profiling is on) */
 	float hostPrepMs;          /* host time spent colouring/packing */
 	int32_t graphReplayed;     /* 1 when the step ran as a hipGraph replay */
+	int32_t solveLaunches;     /* contact solve-sweep kernel launches timed into solveKernelMs (profiling only) */
 } s2amdStepStats;
 
 typedef struct s2amdSolver s2amdSolver;
@@ -184,6 +185,11 @@ int s2amd_download(s2amdSolver* solver, s2amdBody* bodies, int32_t bodyCapacity,
 /* Snapshot / restore of the resident body array on the device (bench: re-solve one snapshot). */
 int s2amd_save_bodies(s2amdSolver* solver);
 int s2amd_restore_bodies(s2amdSolver* solver);
+
+/* Multi-GPU exchange: writes one {position.x, position.y, rot.s, rot.c} record per body slot into
+ * a DEVICE buffer owned by the caller (e.g. the send buffer of an RCCL all-gather of per-island
+ * body arrays).  Returns after the copy has completed on the solver's stream. */
+int s2amd_export_poses(s2amdSolver* solver, void* devicePoses, int32_t capacity);
 
 /* ---- introspection (tests, bench) ---- */
 /* Execution order of the last step: order[k] = contact-array index of the k-th constraint in

@@ -28,6 +28,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #define S2REF_API __attribute__((visibility("default")))
 
@@ -50,6 +51,8 @@ static Snapshot g_pre = {0}, g_post = {0};
 static s2amdStepParams g_params;
 static int g_captureCount = 0;
 static int g_replaceError = 0;
+static double g_solveSeconds = 0.0;
+static long g_solveCalls = 0;
 
 static void packBodies(const s2World* world, s2amdBody* out)
 {
@@ -293,6 +296,16 @@ static void hookSolve(s2World* world, s2StepContext* context, int solverType, s2
 		unpackJoints(world, g_pre.joints);
 		g_captureCount += 1;
 	}
+	else if (g_mode == 3)
+	{
+		// mode 3: time the reference solver alone (CPU baseline of bench.py)
+		struct timespec t0, t1;
+		clock_gettime(CLOCK_MONOTONIC, &t0);
+		real(world, context);
+		clock_gettime(CLOCK_MONOTONIC, &t1);
+		g_solveSeconds += (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+		g_solveCalls += 1;
+	}
 	else
 	{
 		real(world, context);
@@ -323,6 +336,22 @@ S2REF_API void s2ref_set_mode(int mode)
 {
 	g_mode = mode;
 	g_replaceError = 0;
+}
+
+S2REF_API double s2ref_solve_seconds(int reset)
+{
+	double v = g_solveSeconds;
+	if (reset)
+	{
+		g_solveSeconds = 0.0;
+		g_solveCalls = 0;
+	}
+	return v;
+}
+
+S2REF_API long s2ref_solve_calls(void)
+{
+	return g_solveCalls;
 }
 
 S2REF_API void s2ref_set_replace(s2refReplaceFcn* fcn, void* user)

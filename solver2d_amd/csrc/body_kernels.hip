@@ -1,0 +1,303 @@
+// Per-body kernels: one thread per body-pool slot, plain streaming passes over the body SoA.
+// Reference: src/solve_common.c:10-91 (integrate velocities / positions, finalize),
+// src/solve_jacobi.c:233-245 (apply accumulated deltas), src/solve_xpbd.c:411-449, :465-489.
+
+#include "launch.h"
+#include "s2_device.h"
+
+#include "solver2d_amd.h"
+
+#define S2_BLOCK 256
+
+// Wire AoS -> working SoA, plus the per-step constants of s2IntegrateVelocities
+// (solve_common.c:30-41): with a = (h*invMass) * (force + (mass*gravityScale)*gravity),
+// aw = (h*invI)*torque, ld = 1/(1 + h*linearDamping), ad = 1/(1 + h*angularDamping) the update is
+// v = ld * (v + a), w = (w + aw) * ad -- the same fp32 operations in the same order.
+__global__ __launch_bounds__(S2_BLOCK) void unpackBodiesKernel(BodyView b, const s2amdBody* wire, const uint32_t* hostFlags, StepConsts sc, float h)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= b.capacity)
+	{
+		return;
+	}
+	const s2amdBody* w = wire + i;
+	int type = w->type;
+	uint32_t flags = hostFlags[i] & (S2F_WRITE_VEL | S2F_WRITE_POS);
+	if (type != S2AMD_BODY_FREE)
+	{
+		flags |= S2F_LIVE;
+		if (type == S2AMD_BODY_DYNAMIC)
+		{
+			flags |= S2F_DYNAMIC;
+		}
+		if (type != S2AMD_BODY_STATIC)
+		{
+			flags |= S2F_MOVES;
+		}
+	}
+	b.flags[i] = flags;
+	b.vel[i] = make_float4(w->linearVelocity[0], w->linearVelocity[1], w->angularVelocity, 0.0f);
+	b.dq[i] = make_float4(w->deltaPosition[0], w->deltaPosition[1], w->rot[0], w->rot[1]);
+	b.pos[i] = make_float2(w->position[0], w->position[1]);
+
+	V2 gravity = v2(sc.gravityX, sc.gravityY);
+	V2 force = v2(w->force[0], w->force[1]);
+	V2 inner = mulAdd(force, w->mass * w->gravityScale, gravity);
+	V2 a = mulSV(h * w->invMass, inner);
+	float aw = h * w->invI * w->torque;
+	float ld = 1.0f / (1.0f + h * w->linearDamping);
+	float ad = 1.0f / (1.0f + h * w->angularDamping);
+	b.integ[i] = make_float4(a.x, a.y, aw, ld);
+	b.angDamp[i] = ad;
+}
+
+__global__ __launch_bounds__(S2_BLOCK) void packBodiesKernel(BodyView b, s2amdBody* wire)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= b.capacity)
+	{
+		return;
+	}
+	if ((b.flags[i] & S2F_LIVE) == 0)
+	{
+		return;
+	}
+	s2amdBody* w = wire + i;
+	float4 v = b.vel[i];
+	float4 d = b.dq[i];
+	float2 p = b.pos[i];
+	w->position[0] = p.x, w->position[1] = p.y;
+	w->rot[0] = d.z, w->rot[1] = d.w;
+	w->linearVelocity[0] = v.x, w->linearVelocity[1] = v.y;
+	w->angularVelocity = v.z;
+	w->deltaPosition[0] = d.x, w->deltaPosition[1] = d.y;
+}
+
+// s2IntegrateVelocities: solve_common.c:10-45
+__global__ __launch_bounds__(S2_BLOCK) void integrateVelocitiesKernel(BodyView b)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= b.capacity)
+	{
+		return;
+	}
+	if ((b.flags[i] & S2F_DYNAMIC) == 0)
+	{
+		return;
+	}
+	float4 v = b.vel[i];
+	float4 g = b.integ[i];
+	float ad = b.angDamp[i];
+	V2 lv = add(v2(v.x, v.y), v2(g.x, g.y));
+	float w = v.z + g.z;
+	lv = mulSV(g.w, lv);
+	w *= ad;
+	b.vel[i] = make_float4(lv.x, lv.y, w, 0.0f);
+}
+
+// s2IntegratePositions: solve_common.c:47-68
+__global__ __launch_bounds__(S2_BLOCK) void integratePositionsKernel(BodyView b, float h)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= b.capacity)
+	{
+		return;
+	}
+	if ((b.flags[i] & S2F_MOVES) == 0)
+	{
+		return;
+	}
+	float4 v = b.vel[i];
+	float4 d = b.dq[i];
+	V2 dp = mulAdd(v2(d.x, d.y), h, v2(v.x, v.y));
+	Rot q;
+	q.s = d.z, q.c = d.w;
+	q = integrateRot(q, h * v.z);
+	b.dq[i] = make_float4(dp.x, dp.y, q.s, q.c);
+}
+
+// s2FinalizePositions: solve_common.c:70-91; dynamicOnly = the XPBD variant, solve_xpbd.c:496-512
+__global__ __launch_bounds__(S2_BLOCK) void finalizePositionsKernel(BodyView b, int dynamicOnly)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= b.capacity)
+	{
+		return;
+	}
+	uint32_t need = dynamicOnly ? S2F_DYNAMIC : S2F_MOVES;
+	if ((b.flags[i] & need) == 0)
+	{
+		return;
+	}
+	float4 d = b.dq[i];
+	float2 p = b.pos[i];
+	V2 np = add(v2(p.x, p.y), v2(d.x, d.y));
+	b.pos[i] = make_float2(np.x, np.y);
+	b.dq[i] = make_float4(0.0f, 0.0f, d.z, d.w);
+}
+
+// Jacobi: the reference adds every constraint's velocity delta into body->dv / dw in constraint
+// order and applies the sum afterwards (solve_jacobi.c:126-130, :233-245).  Here each body walks
+// its incidence list (ascending constraint index) and performs the same additions in the same
+// order -- no atomics, deterministic, bit-identical to the sequential reference.
+__global__ __launch_bounds__(S2_BLOCK) void jacobiApplyKernel(BodyView b, ContactView c, const int* adjOffsets, const int* adjList)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= b.capacity)
+	{
+		return;
+	}
+	if ((b.flags[i] & S2F_LIVE) == 0)
+	{
+		return;
+	}
+	int begin = adjOffsets[i], end = adjOffsets[i + 1];
+	V2 dv = v2(0.0f, 0.0f);
+	float dw = 0.0f;
+	for (int e = begin; e < end; ++e)
+	{
+		int key = adjList[e];
+		float4 d = (key & 1) ? c.deltaB[key >> 1] : c.deltaA[key >> 1];
+		dv = add(dv, v2(d.x, d.y));
+		dw += d.z;
+	}
+	float4 v = b.vel[i];
+	V2 lv = add(v2(v.x, v.y), dv);
+	float w = v.z;
+	w += dw;
+	b.vel[i] = make_float4(lv.x, lv.y, w, 0.0f);
+}
+
+// XPBD sub-step head: solve_xpbd.c:411-449 (every non-static body, kinematic included)
+__global__ __launch_bounds__(S2_BLOCK) void xpbdIntegrateKernel(BodyView b, float h)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= b.capacity)
+	{
+		return;
+	}
+	if ((b.flags[i] & S2F_MOVES) == 0)
+	{
+		return;
+	}
+	float4 v = b.vel[i];
+	float4 g = b.integ[i];
+	float ad = b.angDamp[i];
+	V2 lv = add(v2(v.x, v.y), v2(g.x, g.y));
+	float w = v.z + g.z;
+	lv = mulSV(g.w, lv);
+	w *= ad;
+	b.vel[i] = make_float4(lv.x, lv.y, w, 0.0f);
+
+	float4 d = b.dq[i];
+	b.dq0[i] = d;
+	V2 dp = mulAdd(v2(d.x, d.y), h, lv);
+	Rot q;
+	q.s = d.z, q.c = d.w;
+	q = integrateRot(q, h * w);
+	b.dq[i] = make_float4(dp.x, dp.y, q.s, q.c);
+}
+
+// XPBD velocity projection: solve_xpbd.c:465-489 (dynamic bodies only)
+__global__ __launch_bounds__(S2_BLOCK) void xpbdProjectKernel(BodyView b, float inv_h)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= b.capacity)
+	{
+		return;
+	}
+	if ((b.flags[i] & S2F_DYNAMIC) == 0)
+	{
+		return;
+	}
+	float4 d = b.dq[i];
+	float4 d0 = b.dq0[i];
+	V2 lv = mulSV(inv_h, sub(v2(d.x, d.y), v2(d0.x, d0.y)));
+	Rot q0, q1;
+	q0.s = d0.z, q0.c = d0.w;
+	q1.s = d.z, q1.c = d.w;
+	float w = computeAngularVelocity(q0, q1, inv_h);
+	b.vel[i] = make_float4(lv.x, lv.y, w, 0.0f);
+}
+
+// per-island body poses {position, rot} for the inter-GPU exchange (one float4 per body)
+__global__ __launch_bounds__(S2_BLOCK) void exportPosesKernel(const s2amdBody* wire, int n, float4* out)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+	{
+		return;
+	}
+	const s2amdBody* w = wire + i;
+	out[i] = make_float4(w->position[0], w->position[1], w->rot[0], w->rot[1]);
+}
+
+static inline dim3 gridFor(int n)
+{
+	return dim3((unsigned)((n + S2_BLOCK - 1) / S2_BLOCK));
+}
+
+void launchUnpackBodies(hipStream_t s, const BodyView& b, const s2amdBody* wire, const uint32_t* hostFlags, const StepConsts& sc, float h)
+{
+	if (b.capacity > 0)
+	{
+		unpackBodiesKernel<<<gridFor(b.capacity), dim3(S2_BLOCK), 0, s>>>(b, wire, hostFlags, sc, h);
+	}
+}
+void launchPackBodies(hipStream_t s, const BodyView& b, s2amdBody* wire)
+{
+	if (b.capacity > 0)
+	{
+		packBodiesKernel<<<gridFor(b.capacity), dim3(S2_BLOCK), 0, s>>>(b, wire);
+	}
+}
+void launchIntegrateVelocities(hipStream_t s, const BodyView& b)
+{
+	if (b.capacity > 0)
+	{
+		integrateVelocitiesKernel<<<gridFor(b.capacity), dim3(S2_BLOCK), 0, s>>>(b);
+	}
+}
+void launchIntegratePositions(hipStream_t s, const BodyView& b, float h)
+{
+	if (b.capacity > 0)
+	{
+		integratePositionsKernel<<<gridFor(b.capacity), dim3(S2_BLOCK), 0, s>>>(b, h);
+	}
+}
+void launchFinalizePositions(hipStream_t s, const BodyView& b, int dynamicOnly)
+{
+	if (b.capacity > 0)
+	{
+		finalizePositionsKernel<<<gridFor(b.capacity), dim3(S2_BLOCK), 0, s>>>(b, dynamicOnly);
+	}
+}
+void launchJacobiApply(hipStream_t s, const BodyView& b, const ContactView& c, const int* adjOffsets, const int* adjList)
+{
+	if (b.capacity > 0)
+	{
+		jacobiApplyKernel<<<gridFor(b.capacity), dim3(S2_BLOCK), 0, s>>>(b, c, adjOffsets, adjList);
+	}
+}
+void launchXpbdIntegrate(hipStream_t s, const BodyView& b, float h)
+{
+	if (b.capacity > 0)
+	{
+		xpbdIntegrateKernel<<<gridFor(b.capacity), dim3(S2_BLOCK), 0, s>>>(b, h);
+	}
+}
+void launchXpbdProject(hipStream_t s, const BodyView& b, float inv_h)
+{
+	if (b.capacity > 0)
+	{
+		xpbdProjectKernel<<<gridFor(b.capacity), dim3(S2_BLOCK), 0, s>>>(b, inv_h);
+	}
+}
+
+void launchExportPoses(hipStream_t s, const s2amdBody* wire, int n, void* out)
+{
+	if (n > 0)
+	{
+		exportPosesKernel<<<gridFor(n), dim3(S2_BLOCK), 0, s>>>(wire, n, (float4*)out);
+	}
+}

@@ -1,0 +1,99 @@
+// Host-callable launchers of every kernel (defined in the *.hip files).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+struct BodyView;
+struct ContactView;
+struct JointView;
+struct StepConsts;
+struct s2amdBody;
+struct s2amdContact;
+struct s2amdJoint;
+
+// body flag bits that only the host sets (see s2_device.h for the rest)
+#define S2F_WRITE_VEL 8u  // body is a conflict node for velocity sweeps (not read-only shareable)
+#define S2F_WRITE_POS 16u // body is a conflict node for position sweeps
+
+enum PrepareKind
+{
+	PREP_PGS,
+	PREP_SOFT,
+	PREP_TGS,
+	PREP_STICKY,
+	PREP_XPBD,
+	PREP_BLOCK
+};
+enum WarmKind
+{
+	WARM_CURRENT,
+	WARM_FIXED,
+	WARM_BLOCK
+};
+enum SoftKind
+{
+	SOFT_TGS,
+	SOFT_PGS,
+	SOFT_JACOBI,
+	SOFT_FIXED
+};
+enum RigidKind
+{
+	RIGID_BAUMGARTE,
+	RIGID_PGS,
+	RIGID_TGS
+};
+enum StoreKind
+{
+	STORE_PLAIN,
+	STORE_SCALED,
+	STORE_BLOCK
+};
+enum JointPrepareKind
+{
+	JPREP_PLAIN,
+	JPREP_SOFT,
+	JPREP_XPBD
+};
+enum JointSolveKind
+{
+	JSOLVE_PLAIN,	  // s2SolveJoint
+	JSOLVE_SOFT,	  // s2SolveJoint_Soft
+	JSOLVE_BAUMGARTE, // s2SolveJoint_Baumgarte
+	JSOLVE_POSITION,  // s2SolveJointPosition
+	JSOLVE_XPBD,	  // s2SolveJoint_XPBD
+	JSOLVE_WARM		  // s2WarmStartJoint
+};
+
+// contacts
+void launchPrepareContacts(hipStream_t s, int kind, const ContactView& c, const BodyView& b, s2amdContact* wire, const s2amdBody* wireBodies,
+						   const StepConsts& sc, float h, float hertz, int posSolver);
+void launchWarmStartContacts(hipStream_t s, int kind, const ContactView& c, const BodyView& b, int begin, int end);
+void launchSolveContactsSoft(hipStream_t s, int kind, const ContactView& c, const BodyView& b, int begin, int end, float inv_h, int useBias);
+void launchSolveContactsRigid(hipStream_t s, int kind, const ContactView& c, const BodyView& b, int begin, int end, float inv_h);
+void launchSolveContactsSticky(hipStream_t s, const ContactView& c, const BodyView& b, s2amdContact* wire, int begin, int end, float inv_h,
+							   int useBias);
+void launchSolveContactsNGS(hipStream_t s, const ContactView& c, const BodyView& b, int begin, int end);
+void launchXpbdContactPositions(hipStream_t s, const ContactView& c, const BodyView& b, int begin, int end, float h);
+void launchXpbdContactVelocities(hipStream_t s, const ContactView& c, const BodyView& b, int begin, int end, float h);
+void launchBlockSolveVelocity(hipStream_t s, const ContactView& c, const BodyView& b, int begin, int end);
+void launchBlockSolvePosition(hipStream_t s, const ContactView& c, const BodyView& b, int begin, int end);
+void launchStoreImpulses(hipStream_t s, int kind, const ContactView& c, s2amdContact* wire, float scale);
+
+// bodies
+void launchUnpackBodies(hipStream_t s, const BodyView& b, const s2amdBody* wire, const uint32_t* hostFlags, const StepConsts& sc, float h);
+void launchPackBodies(hipStream_t s, const BodyView& b, s2amdBody* wire);
+void launchIntegrateVelocities(hipStream_t s, const BodyView& b);
+void launchIntegratePositions(hipStream_t s, const BodyView& b, float h);
+void launchFinalizePositions(hipStream_t s, const BodyView& b, int dynamicOnly);
+void launchJacobiApply(hipStream_t s, const BodyView& b, const ContactView& c, const int* adjOffsets, const int* adjList);
+void launchXpbdIntegrate(hipStream_t s, const BodyView& b, float h);
+void launchXpbdProject(hipStream_t s, const BodyView& b, float inv_h);
+void launchExportPoses(hipStream_t s, const s2amdBody* wire, int n, void* out);
+
+// joints
+void launchPrepareJoints(hipStream_t s, int kind, const JointView& j, const BodyView& b, const s2amdJoint* wire, const s2amdBody* wireBodies,
+						 const StepConsts& sc, float h, float hertz, int warmStart, int posSolver);
+void launchSolveJoints(hipStream_t s, int kind, const JointView& j, const BodyView& b, int begin, int end, const StepConsts& sc, float h,
+					   float inv_h, int useBias);
+void launchStoreJoints(hipStream_t s, const JointView& j, s2amdJoint* wire);

@@ -1,0 +1,388 @@
+// Device-side vocabulary shared by every kernel file: fp32 vector math with the reference's exact
+// operation order, and the SoA "views" the kernels address.
+//
+// Arithmetic contract: every translation unit is compiled with -ffp-contract=off, IEEE divide and
+// sqrt (hipcc's default for HIP), fp32 denormals on.  Each helper below is written operation for
+// operation like the inline function it mirrors in include/solver2d/math.h of the reference, so
+// a batched sweep on the GPU is bit-identical to a sequential sweep in the same constraint order.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define S2_DEV __device__ __forceinline__
+
+// include/solver2d/constants.h:6-22
+#define S2_PI 3.14159265359f
+#define S2_LINEAR_SLOP 0.005f
+#define S2_ANGULAR_SLOP (2.0f / 180.0f * S2_PI)
+#define S2_MAX_LINEAR_CORRECTION 0.2f
+#define S2_MAX_ANGULAR_CORRECTION (8.0f / 180.0f * S2_PI)
+#define S2_BAUMGARTE 0.2f
+#define S2_MAX_BAUMGARTE_VELOCITY 4.0f
+#define S2_CONTACT_HERTZ 30.0f
+#define S2_JOINT_HERTZ 60.0f
+
+// math.h:10-13 (macros with the reference's NaN behaviour)
+#define S2_MINF(A, B) ((A) < (B) ? (A) : (B))
+#define S2_MAXF(A, B) ((A) > (B) ? (A) : (B))
+#define S2_ABSF(A) ((A) > 0.0f ? (A) : -(A))
+#define S2_CLAMPF(A, B, C) S2_MINF(S2_MAXF(A, B), C)
+
+struct V2
+{
+	float x, y;
+};
+struct Rot
+{
+	float s, c;
+};
+struct M22
+{
+	V2 cx, cy;
+};
+
+S2_DEV V2 v2(float x, float y) { V2 r; r.x = x; r.y = y; return r; }
+S2_DEV float dot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }					  // math.h:47
+S2_DEV float cross(V2 a, V2 b) { return a.x * b.y - a.y * b.x; }				  // math.h:53
+S2_DEV V2 crossVS(V2 v, float s) { return v2(s * v.y, -s * v.x); }				  // math.h:60
+S2_DEV V2 crossSV(float s, V2 v) { return v2(-s * v.y, s * v.x); }				  // math.h:67
+S2_DEV V2 rightPerp(V2 v) { return v2(v.y, -v.x); }								  // math.h:73
+S2_DEV V2 add(V2 a, V2 b) { return v2(a.x + b.x, a.y + b.y); }					  // math.h:85
+S2_DEV V2 sub(V2 a, V2 b) { return v2(a.x - b.x, a.y - b.y); }					  // math.h:91
+S2_DEV V2 neg(V2 a) { return v2(-a.x, -a.y); }									  // math.h:97
+S2_DEV V2 mulSV(float s, V2 v) { return v2(s * v.x, s * v.y); }					  // math.h:115
+S2_DEV V2 mulAdd(V2 a, float s, V2 b) { return v2(a.x + s * b.x, a.y + s * b.y); } // math.h:121
+S2_DEV V2 mulSub(V2 a, float s, V2 b) { return v2(a.x - s * b.x, a.y - s * b.y); } // math.h:127
+S2_DEV float length(V2 v) { return sqrtf(v.x * v.x + v.y * v.y); }				  // math.h:171
+
+S2_DEV V2 normalize(V2 v) // src/math.c:40-51
+{
+	float len = length(v);
+	if (len < 0.001f * 1.19209290e-07f)
+	{
+		return v2(0.0f, 0.0f);
+	}
+	float inv = 1.0f / len;
+	return v2(inv * v.x, inv * v.y);
+}
+
+S2_DEV Rot normalizeRot(Rot q) // math.h:201-207
+{
+	float mag = sqrtf(q.s * q.s + q.c * q.c);
+	float invMag = mag > 0.0f ? 1.0f / mag : 0.0f;
+	Rot qn;
+	qn.s = q.s * invMag;
+	qn.c = q.c * invMag;
+	return qn;
+}
+
+S2_DEV Rot integrateRot(Rot q1, float omegah) // math.h:209-223
+{
+	Rot q2;
+	q2.s = q1.s + omegah * q1.c;
+	q2.c = q1.c - omegah * q1.s;
+	return normalizeRot(q2);
+}
+
+S2_DEV float computeAngularVelocity(Rot q1, Rot q2, float inv_h) // math.h:238-252
+{
+	return inv_h * (q2.s * q1.c - q2.c * q1.s);
+}
+
+// fdlibm-lineage single precision atan / atan2 (the algorithm glibc's flt-32 e_atan2f.c / s_atanf.c
+// implement): restated here from the published algorithm so that joint-limit angles do not depend on
+// the device libm.  Pure fp32 IEEE operations.
+S2_DEV float s2_atanf(float x)
+{
+	const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+	const float atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+	const float aT[11] = {3.3333334327e-01f,  -2.0000000298e-01f, 1.4285714924e-01f, -1.1111110449e-01f,
+						  9.0908870101e-02f,  -7.6918758452e-02f, 6.6610731184e-02f, -5.8335702866e-02f,
+						  4.9768779427e-02f,  -3.6531571299e-02f, 1.6285819933e-02f};
+	int32_t hx = __float_as_int(x);
+	int32_t ix = hx & 0x7fffffff;
+	int id;
+	if (ix >= 0x4c000000) // |x| >= 2^25
+	{
+		if (ix > 0x7f800000)
+		{
+			return x + x;
+		}
+		return hx > 0 ? atanhi[3] + atanlo[3] : -atanhi[3] - atanlo[3];
+	}
+	if (ix < 0x3ee00000) // |x| < 0.4375
+	{
+		if (ix < 0x31000000) // |x| < 2^-29
+		{
+			return x;
+		}
+		id = -1;
+	}
+	else
+	{
+		x = fabsf(x);
+		if (ix < 0x3f980000) // |x| < 1.1875
+		{
+			if (ix < 0x3f300000) // 7/16 <= |x| < 11/16
+			{
+				id = 0;
+				x = (2.0f * x - 1.0f) / (2.0f + x);
+			}
+			else // 11/16 <= |x| < 19/16
+			{
+				id = 1;
+				x = (x - 1.0f) / (x + 1.0f);
+			}
+		}
+		else
+		{
+			if (ix < 0x401c0000) // |x| < 2.4375
+			{
+				id = 2;
+				x = (x - 1.5f) / (1.0f + 1.5f * x);
+			}
+			else // 2.4375 <= |x| < 2^34
+			{
+				id = 3;
+				x = -1.0f / x;
+			}
+		}
+	}
+	float z = x * x;
+	float w = z * z;
+	float s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+	float s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+	if (id < 0)
+	{
+		return x - x * (s1 + s2);
+	}
+	z = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+	return (hx < 0) ? -z : z;
+}
+
+S2_DEV float s2_atan2f(float y, float x)
+{
+	const float tiny = 1.0e-30f;
+	const float pi_o_4 = 7.8539818525e-01f;
+	const float pi_o_2 = 1.5707963705e+00f;
+	const float pi = 3.1415927410e+00f;
+	const float pi_lo = -8.7422776573e-08f;
+	int32_t hx = __float_as_int(x);
+	int32_t ix = hx & 0x7fffffff;
+	int32_t hy = __float_as_int(y);
+	int32_t iy = hy & 0x7fffffff;
+	if (ix > 0x7f800000 || iy > 0x7f800000)
+	{
+		return x + y;
+	}
+	if (hx == 0x3f800000)
+	{
+		return s2_atanf(y);
+	}
+	int32_t m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+	if (iy == 0)
+	{
+		switch (m)
+		{
+			case 0:
+			case 1:
+				return y;
+			case 2:
+				return pi + tiny;
+			case 3:
+				return -pi - tiny;
+		}
+	}
+	if (ix == 0)
+	{
+		return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+	}
+	if (ix == 0x7f800000)
+	{
+		if (iy == 0x7f800000)
+		{
+			switch (m)
+			{
+				case 0:
+					return pi_o_4 + tiny;
+				case 1:
+					return -pi_o_4 - tiny;
+				case 2:
+					return 3.0f * pi_o_4 + tiny;
+				case 3:
+					return -3.0f * pi_o_4 - tiny;
+			}
+		}
+		else
+		{
+			switch (m)
+			{
+				case 0:
+					return 0.0f;
+				case 1:
+					return -0.0f;
+				case 2:
+					return pi + tiny;
+				case 3:
+					return -pi - tiny;
+			}
+		}
+	}
+	if (iy == 0x7f800000)
+	{
+		return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+	}
+	int32_t k = (iy - ix) >> 23;
+	float z;
+	if (k > 60)
+	{
+		z = pi_o_2 + 0.5f * pi_lo;
+	}
+	else if (hx < 0 && k < -60)
+	{
+		z = 0.0f;
+	}
+	else
+	{
+		z = s2_atanf(fabsf(y / x));
+	}
+	switch (m)
+	{
+		case 0:
+			return z;
+		case 1:
+			return -z;
+		case 2:
+			return pi - (z - pi_lo);
+		default:
+			return (z - pi_lo) - pi;
+	}
+}
+
+S2_DEV float relativeAngle(Rot b, Rot a) // math.h:320-327
+{
+	float s = b.s * a.c - b.c * a.s;
+	float c = b.c * a.c + b.s * a.s;
+	return s2_atan2f(s, c);
+}
+
+S2_DEV V2 rotate(Rot q, V2 v) { return v2(q.c * v.x - q.s * v.y, q.s * v.x + q.c * v.y); }	  // math.h:330-341
+S2_DEV V2 invRotate(Rot q, V2 v) { return v2(q.c * v.x + q.s * v.y, -q.s * v.x + q.c * v.y); } // math.h:344-347
+
+S2_DEV V2 mulMV(M22 A, V2 v) // math.h:386-390
+{
+	return v2(A.cx.x * v.x + A.cy.x * v.y, A.cx.y * v.x + A.cy.y * v.y);
+}
+
+S2_DEV M22 inverse22(M22 A) // math.h:392-406
+{
+	float a = A.cx.x, b = A.cy.x, c = A.cx.y, d = A.cy.y;
+	M22 B;
+	float det = a * d - b * c;
+	if (det != 0.0f)
+	{
+		det = 1.0f / det;
+	}
+	B.cx.x = det * d;
+	B.cy.x = -det * b;
+	B.cx.y = -det * c;
+	B.cy.y = det * a;
+	return B;
+}
+
+S2_DEV V2 solve22(M22 A, V2 b) // math.h:410-420
+{
+	float a11 = A.cx.x, a12 = A.cy.x, a21 = A.cx.y, a22 = A.cy.y;
+	float det = a11 * a22 - a12 * a21;
+	if (det != 0.0f)
+	{
+		det = 1.0f / det;
+	}
+	return v2(det * (a22 * b.x - a12 * b.y), det * (a11 * b.y - a21 * b.x));
+}
+
+// ---------------------------------------------------------------------------------------------
+// SoA views (device pointers; passed to kernels by value)
+// ---------------------------------------------------------------------------------------------
+
+// Body flags
+#define S2F_LIVE 1u	   // not a free pool slot
+#define S2F_DYNAMIC 2u // type == dynamic
+#define S2F_MOVES 4u   // live && type != static  (s2IntegratePositions / s2FinalizePositions)
+
+// Body state that the sweeps gather by index.  Two 16-byte records per body so a constraint reads
+// a body with two dwordx4 loads and writes its velocity with one.
+struct BodyView
+{
+	float4* vel; // {vx, vy, w, unused}
+	float4* dq;	 // {deltaPosition.x, deltaPosition.y, rot.s, rot.c}
+	float2* pos; // center of mass
+	// per-step constants of the velocity integrator, precomputed once per step by unpackBodies
+	float4* integ;	// {h*invMass*(f + m*g*gs).x, ....y, h*invI*torque, 1/(1+h*linearDamping)}
+	float* angDamp; // 1/(1+h*angularDamping)
+	uint32_t* flags;
+	// Jacobi accumulation and XPBD history
+	float4* dq0; // XPBD: {deltaPosition0, rot0}
+	int capacity;
+};
+
+// Contact constraints in sweep order (colour-major).  k = position in sweep order.
+struct ContactView
+{
+	int2* bodies;	  // {indexA, indexB}
+	float4* mass;	  // {mA, iA, mB, iB}
+	float4* nf;		  // {normal.x, normal.y, friction, bits(pointCount | writeA<<8 | writeB<<9)}
+	float4* anchor[2]; // {localAnchorA, localAnchorB} relative to the centers of mass
+	float4* r0[2];	  // {rA0, rB0}
+	float4* param[2]; // {adjustedSeparation, normalMass, tangentMass, separation}
+	float4* soft[2];  // {biasCoefficient, massCoefficient, impulseCoefficient, tangentSeparation}
+	float2* impulse[2]; // {normalImpulse, tangentImpulse}
+	float4* fanchor[2]; // TGS_Sticky: {localFrictionAnchorA, localFrictionAnchorB}
+	// PGS_NGS_Block extras
+	float4* blockK;	 // {k11, k12, k22, bits(reduced pointCount)}
+	float4* blockNM; // inverse of K: {cx.x, cx.y, cy.x, cy.y}
+	// Jacobi: per-constraint velocity deltas, summed per body in constraint order
+	float4* deltaA; // {dvA.x, dvA.y, dwA, 0}
+	float4* deltaB;
+	int* contactIndex; // position k -> index into the wire contact array
+	int count;
+};
+
+#define S2C_WRITE_A 0x100u
+#define S2C_WRITE_B 0x200u
+
+struct JointView
+{
+	int2* bodies;
+	float4* frame;	  // {localAnchorA, localAnchorB} relative to centers of mass
+	float4* mass;	  // {mA, iA, mB, iB}
+	float4* pivot;	  // pivotMass {cx.x, cx.y, cy.x, cy.y}
+	float4* soft;	  // {biasCoefficient, massCoefficient, impulseCoefficient, axialMass}
+	float2* centerDiff0;
+	float2* impulse;  // in/out
+	float4* axial;	  // {motorImpulse, lowerImpulse, upperImpulse, mouse: body I of B}
+	float4* limits;	  // {referenceAngle, lowerAngle, upperAngle, maxMotorTorque}
+	float4* misc;	  // {motorSpeed, bits(flags), mouse hertz, mouse dampingRatio}
+	float2* target;	  // mouse targetA
+	float4* origin;	  // {localOriginAnchorA, localOriginAnchorB}
+	int* jointIndex;  // position -> index into the wire joint array
+	int count;
+};
+
+#define S2J_MOUSE 1u
+#define S2J_ENABLE_MOTOR 2u
+#define S2J_ENABLE_LIMIT 4u
+#define S2J_WRITE_A 0x100u
+#define S2J_WRITE_B 0x200u
+
+struct StepConsts
+{
+	float dt, inv_dt, h, inv_h;
+	float gravityX, gravityY;
+	int iterations, extraIterations;
+	int warmStart;
+};
+
+S2_DEV uint32_t asBits(float f) { return __float_as_uint(f); }
+S2_DEV float fromBits(uint32_t u) { return __uint_as_float(u); }

@@ -1,0 +1,155 @@
+"""Python host side of the C-ABI in include/solver2d_amd.h (ctypes over solver2d_amd/libs2amd.so).
+
+The mirror of the reference's plug point: `Solver.solve(params, bodies, contacts, joints)` is
+`s2Solve_<Variant>(world, context)` (reference src/solvers.h:70-79) on wire arrays.  There is no
+CPU path here: if the HIP library is missing or no GPU is visible the constructor raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import wire
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libs2amd.so")
+
+EXPORTS = [
+    "s2amd_api_version", "s2amd_device_count", "s2amd_last_error", "s2amd_create", "s2amd_destroy",
+    "s2amd_solve", "s2amd_upload", "s2amd_step_resident", "s2amd_download", "s2amd_save_bodies",
+    "s2amd_restore_bodies", "s2amd_get_contact_order", "s2amd_get_joint_order", "s2amd_get_stats",
+    "s2amd_set_option", "s2amd_export_poses",
+]
+
+_lib = None
+
+
+class S2AmdError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libs2amd.so.  Raises if it has not been built (python __graft_entry__.py / make -C solver2d_amd/csrc)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise S2AmdError("HIP extension %s is missing: build it with `make -C solver2d_amd/csrc` "
+                         "(there is no CPU fallback)" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32 = ctypes.c_void_p, ctypes.c_int32
+    L.s2amd_api_version.restype = ctypes.c_int
+    L.s2amd_device_count.restype = ctypes.c_int
+    L.s2amd_last_error.restype = ctypes.c_char_p
+    L.s2amd_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+    L.s2amd_destroy.argtypes = [vp]
+    L.s2amd_destroy.restype = None
+    L.s2amd_solve.argtypes = [vp, ctypes.POINTER(wire.StepParams), vp, i32, vp, i32, vp, i32]
+    L.s2amd_upload.argtypes = [vp, vp, i32, vp, i32, vp, i32]
+    L.s2amd_step_resident.argtypes = [vp, ctypes.POINTER(wire.StepParams)]
+    L.s2amd_download.argtypes = [vp, vp, i32, vp, i32, vp, i32]
+    L.s2amd_save_bodies.argtypes = [vp]
+    L.s2amd_restore_bodies.argtypes = [vp]
+    L.s2amd_get_contact_order.argtypes = [vp, vp, i32, vp, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.s2amd_get_joint_order.argtypes = [vp, vp, i32, vp, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.s2amd_get_stats.argtypes = [vp, ctypes.POINTER(wire.StepStats)]
+    L.s2amd_set_option.argtypes = [vp, ctypes.c_char_p, i32]
+    L.s2amd_export_poses.argtypes = [vp, vp, i32]
+    if L.s2amd_api_version() != wire.API_VERSION:
+        raise S2AmdError("libs2amd.so API version %d != %d" % (L.s2amd_api_version(), wire.API_VERSION))
+    _lib = L
+    return L
+
+
+def device_count():
+    return load().s2amd_device_count()
+
+
+def _check(rc):
+    if rc != 0:
+        raise S2AmdError("s2amd error %d: %s" % (rc, load().s2amd_last_error().decode(errors="replace")))
+
+
+class Solver:
+    """One device-resident world (one HIP stream).  Arrays are numpy structured arrays of the
+    dtypes in solver2d_amd.wire and are mutated in place, like the reference mutates its pools."""
+
+    def __init__(self, device=0, graph=True, profile=False):
+        L = load()
+        h = ctypes.c_void_p()
+        _check(L.s2amd_create(int(device), ctypes.byref(h)))
+        self._h = h
+        self.set_option("graph", 1 if graph else 0)
+        self.set_option("profile", 1 if profile else 0)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().s2amd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_option(self, key, value):
+        _check(load().s2amd_set_option(self._h, key.encode(), int(value)))
+
+    @staticmethod
+    def _args(bodies, contacts, joints):
+        for arr, dt in ((bodies, wire.body_dtype), (contacts, wire.contact_dtype), (joints, wire.joint_dtype)):
+            if arr.dtype != dt or not arr.flags["C_CONTIGUOUS"]:
+                raise ValueError("array must be a contiguous %s array" % (dt.names,))
+        return (wire.as_ptr(bodies), len(bodies), wire.as_ptr(contacts), len(contacts), wire.as_ptr(joints), len(joints))
+
+    def solve(self, params, bodies, contacts, joints):
+        """== s2Solve_<params.solverType>(world, context): upload, solve, download; in place."""
+        _check(load().s2amd_solve(self._h, ctypes.byref(params), *self._args(bodies, contacts, joints)))
+        return bodies, contacts, joints
+
+    def upload(self, bodies, contacts, joints):
+        _check(load().s2amd_upload(self._h, *self._args(bodies, contacts, joints)))
+
+    def step_resident(self, params):
+        _check(load().s2amd_step_resident(self._h, ctypes.byref(params)))
+
+    def download(self, bodies, contacts, joints):
+        _check(load().s2amd_download(self._h, *self._args(bodies, contacts, joints)))
+        return bodies, contacts, joints
+
+    def save_bodies(self):
+        _check(load().s2amd_save_bodies(self._h))
+
+    def restore_bodies(self):
+        _check(load().s2amd_restore_bodies(self._h))
+
+    def export_poses(self, device_ptr, capacity):
+        """{position, rot} per body into a caller-owned device buffer (float32[capacity, 4])."""
+        _check(load().s2amd_export_poses(self._h, ctypes.c_void_p(int(device_ptr)), int(capacity)))
+
+    def _order(self, fn):
+        n, nc = ctypes.c_int32(), ctypes.c_int32()
+        _check(fn(self._h, None, 0, None, 0, ctypes.byref(n), ctypes.byref(nc)))
+        order = np.zeros(max(n.value, 1), dtype=np.int32)
+        offsets = np.zeros(nc.value + 1, dtype=np.int32)
+        _check(fn(self._h, order.ctypes.data, len(order), offsets.ctypes.data, len(offsets), ctypes.byref(n), ctypes.byref(nc)))
+        return order[: n.value].copy(), offsets
+
+    def contact_order(self):
+        """(order, colorOffsets) of the last step; see s2amd_get_contact_order."""
+        return self._order(load().s2amd_get_contact_order)
+
+    def joint_order(self):
+        return self._order(load().s2amd_get_joint_order)
+
+    def stats(self):
+        st = wire.StepStats()
+        _check(load().s2amd_get_stats(self._h, ctypes.byref(st)))
+        return {k: getattr(st, k) for k, _ in wire.StepStats._fields_}

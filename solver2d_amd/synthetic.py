@@ -1,0 +1,131 @@
+"""Synthetic solver inputs in wire format, generated without any collision code.
+
+`pyramid(base, count)` is the state the reference hands to s2Solve_* on the FIRST s2World_Step of
+the Pyramid / LargePyramid scene (recipe: reference samples/collection/sample_contact.cpp:511-552,
+SURVEY.md 8d): unit boxes at rest, every touching pair already has its 2-point manifold with
+zero separation and zero impulses.  tests/test_synthetic.py checks it against the reference's
+captured step-0 state (same bodies, same set of manifolds; the contact ORDER is this module's own).
+`joint_grid(n)` is the JointGrid scene (sample_joints.cpp:377-446): circles that never collide,
+held together by revolute joints.
+"""
+import numpy as np
+
+from . import wire
+
+# s2ComputePolygonMass of s2MakeSquare(0.5), density 1 (reference geometry.c) as fp32
+BOX_MASS = np.float32(1.0)
+BOX_I = np.float32(0.16666669)
+# circle r = 0.4, density 1: mass = pi r^2, I = m (0.5 r^2 + |center|^2) (reference geometry.c)
+CIRCLE_R = np.float32(0.4)
+
+
+def _dynamic_body(b, x, y, mass, inertia, gravity_scale=1.0):
+    b["position"] = (x, y)
+    b["rot"] = (0.0, 1.0)
+    b["mass"] = mass
+    b["invMass"] = np.float32(1.0) / np.float32(mass)
+    b["I"] = inertia
+    b["invI"] = np.float32(1.0) / np.float32(inertia)
+    b["gravityScale"] = gravity_scale
+    b["type"] = wire.BODY_DYNAMIC
+
+
+def _static_body(b, x, y):
+    b["position"] = (x, y)
+    b["rot"] = (0.0, 1.0)
+    b["gravityScale"] = 1.0
+    b["type"] = wire.BODY_STATIC
+
+
+def _manifold(c, a, b, normal, pts, friction=0.6):
+    c["bodyA"], c["bodyB"] = a, b
+    c["pointCount"] = len(pts)
+    c["normal"] = normal
+    c["friction"] = friction
+    c["constraintIndex"] = -1
+    for j, (la, lb) in enumerate(pts):
+        c["points"][j]["localAnchorA"] = la
+        c["points"][j]["localAnchorB"] = lb
+
+
+def pyramid(base, count=1, pitch=None):
+    """`count` disjoint box pyramids of `base` bricks at the bottom, each on its own static ground.
+    Returns (bodies, contacts, joints)."""
+    per = base * (base + 1) // 2
+    nb = count * (per + 1)
+    ncon = count * (base + (per - base) + 2 * (per - base))  # ground + side-by-side + stacking
+    bodies = np.zeros(nb, dtype=wire.body_dtype)
+    contacts = np.zeros(ncon, dtype=wire.contact_dtype)
+    joints = np.zeros(0, dtype=wire.joint_dtype)
+    if pitch is None:
+        pitch = float(base + 20)
+    h = np.float32(0.5)
+    ci = 0
+    for k in range(count):
+        ox = np.float32((k % 32) * pitch)
+        oy = np.float32((k // 32) * pitch)
+        g = k * (per + 1)
+        _static_body(bodies[g], ox, oy - np.float32(1.0))
+        index = {}
+        bi = g + 1
+        for i in range(base):
+            y = np.float32(np.float32(2.0 * i + 1.0) * h)
+            for j in range(i, base):
+                x = np.float32(np.float32(np.float32(i + 1.0) * h + np.float32(2.0 * (j - i)) * h) - h * np.float32(base))
+                _dynamic_body(bodies[bi], ox + x, oy + y, BOX_MASS, BOX_I)
+                index[(i, j)] = bi
+                if i == 0:
+                    # ground (A) - box (B); anchors relative to body origins, reference step-0 values
+                    gx = float(x)
+                    _manifold(contacts[ci], g, bi, (0.0, 1.0),
+                              [((gx + 0.5, 1.0), (0.5, -0.5)), ((gx - 0.5, 1.0), (-0.5, -0.5))])
+                    ci += 1
+                else:
+                    lo_right = index[(i - 1, j)]      # lower box half a unit to the right
+                    lo_left = index[(i - 1, j - 1)]   # lower box half a unit to the left
+                    _manifold(contacts[ci], lo_right, bi, (0.0, 1.0),
+                              [((0.0, 0.5), (0.5, -0.5)), ((-0.5, 0.5), (0.0, -0.5))])
+                    ci += 1
+                    _manifold(contacts[ci], lo_left, bi, (0.0, 1.0),
+                              [((0.5, 0.5), (0.0, -0.5)), ((0.0, 0.5), (-0.5, -0.5))])
+                    ci += 1
+                if j > i:
+                    _manifold(contacts[ci], index[(i, j - 1)], bi, (1.0, 0.0),
+                              [((0.5, -0.5), (-0.5, -0.5)), ((0.5, 0.5), (-0.5, 0.5))])
+                    ci += 1
+                bi += 1
+    assert ci == ncon
+    return bodies, contacts, joints
+
+
+def joint_grid(numi, numk=None):
+    """numi x numk circles on a unit lattice pinned by revolute joints (no contacts)."""
+    numk = numi if numk is None else numk
+    nb = numi * numk
+    bodies = np.zeros(nb, dtype=wire.body_dtype)
+    contacts = np.zeros(0, dtype=wire.contact_dtype)
+    jl = []
+    mass = np.float32(np.float32(np.pi) * CIRCLE_R * CIRCLE_R)
+    inertia = np.float32(mass * np.float32(np.float32(0.5) * CIRCLE_R * CIRCLE_R))
+    idx = 0
+    for k in range(numk):
+        for i in range(numi):
+            b = bodies[idx]
+            if numk // 2 - 3 <= k <= numk // 2 + 3 and i == 0:
+                _static_body(b, float(k), float(-i))
+                b["gravityScale"] = 2.0
+            else:
+                _dynamic_body(b, float(k), float(-i), mass, inertia, 2.0)
+            if i > 0:
+                jl.append((idx - 1, idx, (0.0, -0.5), (0.0, 0.5)))
+            if k > 0:
+                jl.append((idx - numi, idx, (0.5, 0.0), (-0.5, 0.0)))
+            idx += 1
+    joints = np.zeros(len(jl), dtype=wire.joint_dtype)
+    for n, (a, b, la, lb) in enumerate(jl):
+        j = joints[n]
+        j["type"] = wire.JOINT_REVOLUTE
+        j["bodyA"], j["bodyB"] = a, b
+        j["localOriginAnchorA"] = la
+        j["localOriginAnchorB"] = lb
+    return bodies, contacts, joints

@@ -77,7 +77,7 @@ class StepStats(ctypes.Structure):
         ("contactColors", ctypes.c_int32), ("jointColors", ctypes.c_int32),
         ("solveSweeps", ctypes.c_int32), ("kernelLaunches", ctypes.c_int32),
         ("deviceMs", ctypes.c_float), ("solveKernelMs", ctypes.c_float), ("hostPrepMs", ctypes.c_float),
-        ("graphReplayed", ctypes.c_int32),
+        ("graphReplayed", ctypes.c_int32), ("solveLaunches", ctypes.c_int32),
     ]
 
 

@@ -53,6 +53,9 @@ def lib():
         L.s2ref_contact_pairs.argtypes = [WorldId, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
         L.s2ref_sizeof.restype = ctypes.c_size_t
         L.s2ref_sizeof.argtypes = [ctypes.c_int]
+        L.s2ref_solve_seconds.restype = ctypes.c_double
+        L.s2ref_solve_seconds.argtypes = [ctypes.c_int]
+        L.s2ref_solve_calls.restype = ctypes.c_long
         _lib = L
     return _lib
 

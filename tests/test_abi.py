@@ -1,0 +1,61 @@
+"""CPU-only checks of the boundary: the library loads, exports every symbol the header declares,
+struct sizes match, and it refuses to run without a GPU (no silent CPU fallback)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from solver2d_amd import hip, wire
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "solver2d_amd.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    return sorted(set(re.findall(r"\b(s2amd_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = hip.load()
+    names = declared_functions()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(names) == sorted(hip.EXPORTS)
+    assert L.s2amd_api_version() == wire.API_VERSION
+
+
+def test_struct_sizes_match_header(tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text('#include "solver2d_amd.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
+                   'sizeof(s2amdBody),sizeof(s2amdManifoldPoint),sizeof(s2amdContact),sizeof(s2amdJoint),'
+                   'sizeof(s2amdStepParams),sizeof(s2amdStepStats));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert sizes == [wire.BODY_SIZE, wire.manifold_point_dtype.itemsize, wire.CONTACT_SIZE, wire.JOINT_SIZE,
+                     ctypes.sizeof(wire.StepParams), ctypes.sizeof(wire.StepStats)]
+
+
+def test_solver_enum_is_reference_abi():
+    # include/solver2d/types.h:75-88 of the reference
+    assert wire.SOLVER_NAMES == ["Jacobi", "PGS", "PGS_NGS", "PGS_NGS_Block", "PGS_Soft", "SoftStep",
+                                 "TGS_Sticky", "TGS_Soft", "TGS_NGS", "XPBD"]
+
+
+def test_fails_loudly_without_gpu():
+    if hip.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(hip.S2AmdError) as e:
+        hip.Solver(0)
+    assert "no CPU path" in str(e.value) or "-3" in str(e.value)
+
+
+def test_sweep_accounting():
+    assert wire.solve_sweeps_per_step("TGS_Soft", 8, 4) == 16
+    assert wire.solve_sweeps_per_step("TGS_Soft", 8, 0) == 8
+    assert wire.solve_sweeps_per_step("Jacobi", 4, 2) == 6
+    assert wire.solve_sweeps_per_step("PGS", 4, 2) == 4

@@ -1,0 +1,182 @@
+"""Parity link L2 (the gate): HIP kernels == oracle, BIT FOR BIT, when the oracle sweeps in the
+device's own constraint order (s2amd_get_contact_order / s2amd_get_joint_order).
+
+All calls go through the C-ABI (solver2d_amd/libs2amd.so).  The oracle is only the checker.
+Tolerance: none -- fp32 outputs are compared as raw 32-bit words (the library is built with
+-ffp-contract=off and IEEE divide/sqrt, see solver2d_amd/csrc/s2_device.h).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from solver2d_amd import hip, synthetic, wire
+from tests import common, golden_util, oraclebind
+
+pytestmark = pytest.mark.gpu
+
+FILES = golden_util.golden_files()
+
+
+@pytest.fixture(scope="module")
+def solver():
+    s = hip.Solver(0)
+    yield s
+    s.close()
+
+
+def check_order_is_valid(order, offsets, contacts, bodies):
+    """Every active contact appears exactly once; inside one colour batch no dynamic body repeats."""
+    active = np.flatnonzero(contacts["pointCount"] > 0)
+    assert sorted(order.tolist()) == active.tolist()
+    assert offsets[0] == 0 and offsets[-1] == len(order)
+    movable = (bodies["invMass"] != 0) | (bodies["invI"] != 0)
+    for c in range(len(offsets) - 1):
+        ids = order[offsets[c]:offsets[c + 1]]
+        touched = np.concatenate([contacts["bodyA"][ids], contacts["bodyB"][ids]])
+        touched = touched[movable[touched]]
+        assert len(np.unique(touched)) == len(touched), "colour %d reuses a dynamic body" % c
+
+
+def gpu_vs_oracle(solver, params, pre, what):
+    got = common.copy3(pre)
+    solver.solve(params, *got)
+    order, offsets = solver.contact_order()
+    jorder, joffsets = solver.joint_order()
+    check_order_is_valid(order, offsets, pre[1], pre[0])
+    want = common.copy3(pre)
+    oraclebind.solve(params, *want, contact_order=order, joint_order=jorder)
+    common.compare_exact(got, want, what)
+    return got
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(p)[:-4] for p in FILES])
+def test_golden_inputs_bit_exact(solver, path):
+    params, pre, _post = golden_util.load(path)
+    gpu_vs_oracle(solver, params, pre, os.path.basename(path))
+
+
+@pytest.mark.parametrize("solver_name", wire.SOLVER_NAMES)
+def test_synthetic_pyramid40_all_solvers(solver, solver_name):
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    pre = synthetic.pyramid(40)
+    state = common.copy3(pre)
+    for step in range(3):  # impulses carried across steps: exercises warm starting
+        params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+        state = gpu_vs_oracle(solver, params, state, "pyramid40/%s step %d" % (solver_name, step))
+
+
+def test_baseline_config2_full_size(solver):
+    """LargePyramid base-200, TGS_Soft 8 sub-steps / relax on: the BASELINE configuration, full size."""
+    pre = synthetic.pyramid(200)
+    assert (pre[1]["pointCount"] > 0).sum() == 59900
+    state = common.copy3(pre)
+    for step in range(2):
+        params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+        state = gpu_vs_oracle(solver, params, state, "pyramid200 step %d" % step)
+    st = solver.stats()
+    assert st["constraintCount"] == 59900 and st["solveSweeps"] == 16
+    # physical sanity: the pile rests, nothing explodes
+    assert np.isfinite(state[0]["position"]).all()
+    assert np.abs(state[0]["linearVelocity"]).max() < 1.0
+
+
+def test_multi_island_config5_shape(solver):
+    pre = synthetic.pyramid(12, count=6)
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    gpu_vs_oracle(solver, params, pre, "6 x pyramid12")
+
+
+def test_joint_grid_pgs_ngs(solver):
+    pre = synthetic.joint_grid(20)
+    state = common.copy3(pre)
+    for step in range(3):
+        params = wire.StepParams.make("PGS_NGS", 1.0 / 60.0, 4, 2, True)
+        state = gpu_vs_oracle(solver, params, state, "joint_grid20 step %d" % step)
+    assert solver.stats()["jointCount"] == 2 * 20 * 19
+
+
+def test_resident_api_equals_solve(solver):
+    pre = synthetic.pyramid(16)
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    a = common.copy3(pre)
+    for _ in range(4):
+        solver.solve(params, *a)
+    b = common.copy3(pre)
+    solver.upload(*b)
+    for _ in range(4):
+        solver.step_resident(params)
+    solver.download(*b)
+    common.compare_exact(b, a, "resident vs solve")
+
+
+def test_graph_replay_equals_eager():
+    pre = synthetic.pyramid(16)
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    outs = []
+    for graph in (True, False):
+        with hip.Solver(0, graph=graph) as s:
+            st = common.copy3(pre)
+            s.upload(*st)
+            for _ in range(3):
+                s.step_resident(params)
+            assert s.stats()["graphReplayed"] == (1 if graph else 0)
+            s.download(*st)
+            outs.append(st)
+    common.compare_exact(outs[0], outs[1], "graph vs eager")
+
+
+def test_save_restore_bodies(solver):
+    pre = synthetic.pyramid(8)
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    st = common.copy3(pre)
+    solver.upload(*st)
+    solver.save_bodies()
+    solver.step_resident(params)
+    solver.restore_bodies()
+    out = common.copy3(pre)
+    solver.download(*out)
+    for f in common.BODY_OUT:
+        assert np.array_equal(out[0][f], pre[0][f])
+    assert np.abs(out[1]["points"]["normalImpulse"]).max() > 0  # impulses were kept
+
+
+def test_edge_cases(solver):
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    # empty world
+    e = (np.zeros(0, wire.body_dtype), np.zeros(0, wire.contact_dtype), np.zeros(0, wire.joint_dtype))
+    solver.solve(params, *e)
+    # bodies only, with free slots
+    b, c, j = synthetic.pyramid(3)
+    b2 = np.concatenate([b, np.zeros(3, wire.body_dtype)])
+    b2["type"][-3:] = wire.BODY_FREE
+    for name in wire.SOLVER_NAMES:
+        vel, pos = common.DEFAULT_ITERS[name]
+        p = wire.StepParams.make(name, 1.0 / 60.0, vel, pos, True)
+        gpu_vs_oracle(solver, p, (b2.copy(), np.zeros(0, wire.contact_dtype), j.copy()), "no contacts/" + name)
+        # inactive contact slots interleaved + one-point manifolds
+        c2 = np.zeros(2 * len(c), wire.contact_dtype)
+        c2[1::2] = c
+        c2["bodyA"][0::2] = -1
+        c2["bodyB"][0::2] = -1
+        c2["constraintIndex"] = -1
+        c2["pointCount"][1::4] = 1
+        gpu_vs_oracle(solver, p, (b2.copy(), c2, j.copy()), "ragged/" + name)
+        # no warm start, zero extra iterations
+        p0 = wire.StepParams.make(name, 1.0 / 60.0, 3, 0, False)
+        gpu_vs_oracle(solver, p0, (b2.copy(), c2.copy(), j.copy()), "cold/" + name)
+    # XPBD early-outs (solve_xpbd.c:344-353)
+    px = wire.StepParams.make("XPBD", 1.0 / 60.0, 0, 0, True)
+    gpu_vs_oracle(solver, px, (b.copy(), c.copy(), j.copy()), "xpbd zero substeps")
+    px = wire.StepParams.make("XPBD", 0.0, 4, 2, True)
+    gpu_vs_oracle(solver, px, (b.copy(), c.copy(), j.copy()), "xpbd dt=0")
+
+
+def test_invalid_arguments(solver):
+    b, c, j = synthetic.pyramid(3)
+    with pytest.raises(hip.S2AmdError):
+        solver.solve(wire.StepParams.make(17), b, c, j)
+    c2 = c.copy()
+    c2["bodyB"][0] = 10 ** 6
+    with pytest.raises(hip.S2AmdError):
+        solver.solve(wire.StepParams.make("PGS"), b, c2, j)

@@ -160,15 +160,17 @@ def main():
     # dominant-kernel timing: HIP events on the launch stream around every solve-sweep launch
     prof_steps = 5
     gpu.set_option("profile", 1)
-    kernel_ms, launches = 0.0, 0
+    kernel_ms, launches, overhead_ms = 0.0, 0, 0.0
     for _ in range(prof_steps):
         gpu.restore_bodies()
         gpu.step_resident(params)
         s2 = gpu.stats()
         kernel_ms += s2["solveKernelMs"]
         launches += s2["solveLaunches"]
+        overhead_ms = s2["eventPairOverheadMs"]
     gpu.set_option("profile", 0)
-    avg_launch_s = (kernel_ms / 1e3) / max(launches, 1)
+    # event interval around one launch minus the interval of an empty event pair on the same stream
+    avg_launch_s = max((kernel_ms / max(launches, 1) - overhead_ms) / 1e3, 1e-9)
     constraints_per_launch = C * sweeps * prof_steps / max(launches, 1)
     achieved = ALGO_BYTES_PER_CONSTRAINT_SWEEP * constraints_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
 
@@ -200,7 +202,8 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "kernel": "solveContactsSoftKernel<SOFT_TGS>",
-                "avg_launch_us": avg_launch_s * 1e6, "launches_per_step": launches / prof_steps,
+                "avg_launch_us": avg_launch_s * 1e6, "event_pair_overhead_us": overhead_ms * 1e3,
+                "launches_per_step": launches / prof_steps,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CONSTRAINT_SWEEP * constraints_per_launch,
             },
         }

@@ -155,6 +155,7 @@ typedef struct s2amdStepStats
 	float hostPrepMs;          /* host time spent colouring/packing */
 	int32_t graphReplayed;     /* 1 when the step ran as a hipGraph replay */
 	int32_t solveLaunches;     /* contact solve-sweep kernel launches timed into solveKernelMs (profiling only) */
+	float eventPairOverheadMs; /* elapsed time of an EMPTY HIP event pair on the stream (profiling only): subtract per launch */
 } s2amdStepStats;
 
 typedef struct s2amdSolver s2amdSolver;

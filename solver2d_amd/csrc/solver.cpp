@@ -1368,8 +1368,27 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 				total += t;
 			}
 		}
+		// calibrate: an empty event pair on the same stream measures the bracket's own cost
+		float empty = 0.0f;
+		int pairs = 0;
+		if (s->sweepEvents.size() >= 2)
+		{
+			for (int r = 0; r < 32; ++r)
+			{
+				(void)hipEventRecord(s->sweepEvents[0], s->stream);
+				(void)hipEventRecord(s->sweepEvents[1], s->stream);
+				(void)hipStreamSynchronize(s->stream);
+				float t = 0.0f;
+				if (hipEventElapsedTime(&t, s->sweepEvents[0], s->sweepEvents[1]) == hipSuccess)
+				{
+					empty += t;
+					pairs += 1;
+				}
+			}
+		}
 		s->stats.solveKernelMs = total;
 		s->stats.solveLaunches = (int)(s->sweepEventsUsed / 2);
+		s->stats.eventPairOverheadMs = pairs > 0 ? empty / pairs : 0.0f;
 	}
 	return S2AMD_OK;
 }

@@ -1,0 +1,174 @@
+"""Simulation islands and their sharding across GPUs (host side, numpy/scipy).
+
+The reference has no islands (`islandPool` is dead code), so this module DEFINES
+them: an island is a connected component of the graph whose nodes are the movable bodies
+(invMass != 0 or invI != 0) and whose edges are the active contact constraints (pointCount > 0)
+and live joints between two movable bodies.  Immovable bodies (static, kinematic, massless) never
+connect islands -- no impulse propagates through them -- and are replicated into every shard that
+touches them.
+
+Because islands share no movable body, solving them separately is arithmetic-identical to solving
+them together as long as each shard keeps the pool order of its own constraints; that is what
+`extract` guarantees and `tests/test_islands.py` / `tests/test_islands_dist.py` check bit for bit.
+One process per GPU solves its shard with no intra-step communication; the only exchange is the
+per-step gather of body state (and impulses if the caller wants them back).
+"""
+import numpy as np
+from scipy.sparse import coo_matrix
+from scipy.sparse.csgraph import connected_components
+
+from . import wire
+
+
+def movable_mask(bodies):
+    return (bodies["type"] != wire.BODY_FREE) & ((bodies["invMass"] != 0) | (bodies["invI"] != 0))
+
+
+def find_islands(bodies, contacts, joints):
+    """Returns (island_of_body, island_count).  island_of_body is -1 for static/free bodies; island
+    ids are numbered by their lowest body index, so the labelling is deterministic.  Kinematic and
+    massless bodies never connect anything but still have to be integrated by exactly one owner, so
+    each forms an island of its own."""
+    nb = len(bodies)
+    mov = movable_mask(bodies)
+    owned = (bodies["type"] != wire.BODY_FREE) & (bodies["type"] != wire.BODY_STATIC)
+    ea, eb = [], []
+    act = contacts["pointCount"] > 0
+    if act.any():
+        a, b = contacts["bodyA"][act], contacts["bodyB"][act]
+        both = mov[a] & mov[b]
+        ea.append(a[both])
+        eb.append(b[both])
+    live = joints["type"] == wire.JOINT_REVOLUTE
+    if live.any():
+        a, b = joints["bodyA"][live], joints["bodyB"][live]
+        both = mov[a] & mov[b]
+        ea.append(a[both])
+        eb.append(b[both])
+    if ea:
+        ea, eb = np.concatenate(ea), np.concatenate(eb)
+    else:
+        ea = eb = np.zeros(0, dtype=np.int64)
+    g = coo_matrix((np.ones(len(ea), dtype=np.int8), (ea, eb)), shape=(nb, nb))
+    _n, label = connected_components(g, directed=False)
+    label = label.astype(np.int64)
+    # renumber by first body index
+    island = np.full(nb, -1, dtype=np.int32)
+    if not owned.any():
+        return island, 0
+    uniq, first = np.unique(label[owned], return_index=True)
+    order = np.argsort(np.flatnonzero(owned)[first], kind="stable")
+    remap = np.empty(len(uniq), dtype=np.int32)
+    remap[order] = np.arange(len(uniq), dtype=np.int32)
+    island[owned] = remap[np.searchsorted(uniq, label[owned])]
+    return island, len(uniq)
+
+
+def constraint_islands(bodies, contacts, joints, island):
+    """Island of every contact / joint (-1 when inactive or attached to immovable bodies only)."""
+    mov = movable_mask(bodies)
+    ci = np.full(len(contacts), -1, dtype=np.int32)
+    act = contacts["pointCount"] > 0
+    ba, bb = contacts["bodyA"][act], contacts["bodyB"][act]
+    a = np.where(mov[ba], island[ba], -1)
+    b = np.where(mov[bb], island[bb], -1)
+    fallback = np.where(island[ba] >= 0, island[ba], island[bb])  # e.g. kinematic vs static
+    ci[act] = np.where(a >= 0, a, np.where(b >= 0, b, fallback))
+    ji = np.full(len(joints), -1, dtype=np.int32)
+    live = joints["type"] >= 0
+    if live.any():
+        jb = joints["bodyB"][live]
+        ja = np.maximum(joints["bodyA"][live], 0)
+        rev = joints["type"][live] == wire.JOINT_REVOLUTE
+        b = np.where(mov[jb], island[jb], -1)
+        a = np.where(rev & mov[ja], island[ja], -1)
+        fallback = np.where(island[jb] >= 0, island[jb], np.where(rev, island[ja], -1))
+        ji[live] = np.where(a >= 0, a, np.where(b >= 0, b, fallback))
+    return ci, ji
+
+
+def partition(weights, n_shards):
+    """Longest-processing-time bin packing of islands by weight; deterministic.
+    Returns shard index per island."""
+    weights = np.asarray(weights, dtype=np.int64)
+    order = np.lexsort((np.arange(len(weights)), -weights))
+    load = np.zeros(n_shards, dtype=np.int64)
+    shard = np.zeros(len(weights), dtype=np.int32)
+    for i in order:
+        s = int(np.argmin(load))
+        shard[i] = s
+        load[s] += max(int(weights[i]), 1)
+    return shard
+
+
+class Shard:
+    """One rank's sub-world: wire arrays + the maps back into the full world."""
+
+    def __init__(self, bodies, contacts, joints, body_ids, contact_ids, joint_ids, owned_body):
+        self.bodies, self.contacts, self.joints = bodies, contacts, joints
+        self.body_ids, self.contact_ids, self.joint_ids = body_ids, contact_ids, joint_ids
+        self.owned_body = owned_body  # bool per shard body: movable body owned by this shard
+
+
+def shard_world(bodies, contacts, joints, n_shards):
+    """Split a world into n_shards sub-worlds along island boundaries."""
+    island, n_islands = find_islands(bodies, contacts, joints)
+    ci, ji = constraint_islands(bodies, contacts, joints, island)
+    weights = np.bincount(ci[ci >= 0], minlength=n_islands) * 2 + np.bincount(ji[ji >= 0], minlength=n_islands)
+    shard_of_island = partition(weights, n_shards)
+    return [extract(bodies, contacts, joints, island, ci, ji, shard_of_island, s) for s in range(n_shards)], island, shard_of_island
+
+
+def extract(bodies, contacts, joints, island, ci, ji, shard_of_island, s):
+    csel = np.flatnonzero((ci >= 0) & (shard_of_island[np.maximum(ci, 0)] == s))
+    jsel = np.flatnonzero((ji >= 0) & (shard_of_island[np.maximum(ji, 0)] == s))
+    own = (island >= 0) & (shard_of_island[np.maximum(island, 0)] == s)
+    used = own.copy()
+    if len(csel):
+        used[contacts["bodyA"][csel]] = True
+        used[contacts["bodyB"][csel]] = True
+    if len(jsel):
+        used[joints["bodyB"][jsel]] = True
+        rev = joints["type"][jsel] == wire.JOINT_REVOLUTE
+        used[joints["bodyA"][jsel][rev]] = True
+    body_ids = np.flatnonzero(used)  # ascending => pool order is preserved inside the shard
+    remap = np.full(len(bodies), -1, dtype=np.int32)
+    remap[body_ids] = np.arange(len(body_ids), dtype=np.int32)
+    sb = bodies[body_ids].copy()
+    sc = contacts[csel].copy()
+    sj = joints[jsel].copy()
+    sc["bodyA"] = remap[sc["bodyA"]]
+    sc["bodyB"] = remap[sc["bodyB"]]
+    sj["bodyB"] = remap[sj["bodyB"]]
+    if len(sj):
+        a = sj["bodyA"].copy()
+        ok = a >= 0
+        a[ok] = remap[a[ok]]
+        sj["bodyA"] = a
+    return Shard(sb, sc, sj, body_ids, csel, jsel, own[body_ids])
+
+
+def merge_back(bodies, contacts, joints, shards):
+    """Scatter solved shards into the full-world arrays (only what each shard owns)."""
+    for sh in shards:
+        o = sh.owned_body
+        bodies[sh.body_ids[o]] = sh.bodies[o]
+        ci_global = contacts["constraintIndex"][sh.contact_ids].copy()
+        contacts[sh.contact_ids] = _restore_indices(sh.contacts, contacts[sh.contact_ids])
+        contacts["constraintIndex"][sh.contact_ids] = ci_global  # gather index is a whole-world property
+        joints[sh.joint_ids] = _restore_joint_indices(sh.joints, joints[sh.joint_ids])
+    return bodies, contacts, joints
+
+
+def _restore_indices(solved, original):
+    out = solved.copy()
+    out["bodyA"] = original["bodyA"]
+    out["bodyB"] = original["bodyB"]
+    return out
+
+
+def _restore_joint_indices(solved, original):
+    out = solved.copy()
+    out["bodyA"] = original["bodyA"]
+    out["bodyB"] = original["bodyB"]
+    return out

@@ -1,0 +1,79 @@
+"""Island finder and sharding: integer results are exact, and solving shards separately is
+bit-identical to solving the whole world (oracle on CPU here; the GPU variant is in
+tests/test_gpu_islands.py)."""
+import numpy as np
+import pytest
+
+from solver2d_amd import islands, synthetic, wire
+from tests import common, oraclebind, refbind
+
+
+def test_island_membership_pyramids():
+    b, c, j = synthetic.pyramid(6, count=5)
+    isl, n = islands.find_islands(b, c, j)
+    assert n == 5
+    per = 6 * 7 // 2 + 1
+    for k in range(5):
+        seg = isl[k * per:(k + 1) * per]
+        assert seg[0] == -1                      # the static ground belongs to no island
+        assert (seg[1:] == k).all()              # numbered by lowest body index
+    ci, ji = islands.constraint_islands(b, c, j, isl)
+    assert (np.bincount(ci) == len(c) // 5).all()
+
+
+def test_partition_is_balanced_and_deterministic():
+    w = [10] * 64
+    s = islands.partition(w, 8)
+    assert (np.bincount(s) == 8).all()
+    assert (islands.partition(w, 8) == s).all()
+    s2 = islands.partition([100, 1, 1, 1, 50, 50], 2)
+    loads = [sum(x for x, k in zip([100, 1, 1, 1, 50, 50], s2) if k == r) for r in (0, 1)]
+    assert abs(loads[0] - loads[1]) <= 3
+
+
+@pytest.mark.parametrize("solver", ["TGS_Soft", "PGS_NGS_Block", "XPBD", "Jacobi"])
+def test_sharded_solve_equals_whole_world(solver):
+    world = synthetic.pyramid(7, count=6)
+    vel, pos = common.DEFAULT_ITERS[solver]
+    params = wire.StepParams.make(solver, 1.0 / 60.0, vel, pos, True)
+    whole = common.copy3(world)
+    sharded = common.copy3(world)
+    for _ in range(3):
+        oraclebind.solve(params, *whole)
+        shards, _isl, _sh = islands.shard_world(*sharded, n_shards=4)
+        for sh in shards:
+            oraclebind.solve(params, sh.bodies, sh.contacts, sh.joints)
+        # constraintIndex of the whole world = pool-order gather index
+        act = sharded[1]["pointCount"] > 0
+        sharded[1]["constraintIndex"] = -1
+        sharded[1]["constraintIndex"][act] = np.arange(int(act.sum()), dtype=np.int32)
+        islands.merge_back(*sharded, shards)
+        if solver == "PGS_NGS_Block":
+            sharded[1]["constraintIndex"] = whole[1]["constraintIndex"]
+        common.compare_exact(sharded, whole, solver)
+
+
+@pytest.mark.skipif(not refbind.available(), reason="oracle/_ref/libs2ref.so not built")
+def test_islands_on_reference_scene_with_joints():
+    with refbind.RefWorld("mixed", "TGS_Soft", 24, 0) as w:
+        for _ in range(60):
+            w.step(1.0 / 60.0, 8, 4, True)
+        params, pre, post = w.step_captured(1.0 / 60.0, 8, 4, True)
+    isl, n = islands.find_islands(*pre)
+    assert n >= 2
+    # every constraint joins bodies of one island
+    c = pre[1]
+    act = c["pointCount"] > 0
+    mov = islands.movable_mask(pre[0])
+    ia, ib = isl[c["bodyA"][act]], isl[c["bodyB"][act]]
+    both = mov[c["bodyA"][act]] & mov[c["bodyB"][act]]   # kinematic bodies are islands of their own
+    assert (ia[both] == ib[both]).all()
+    shards, _, _ = islands.shard_world(*common.copy3(pre), n_shards=3)
+    out = common.copy3(pre)
+    for sh in shards:
+        oraclebind.solve(params, sh.bodies, sh.contacts, sh.joints)
+    islands.merge_back(*out, shards)
+    out[1]["constraintIndex"] = post[1]["constraintIndex"]
+    # static bodies are owned by no shard and keep their input state (the reference leaves them
+    # untouched too); the kinematic platform is an island of its own and is integrated by its owner
+    common.compare_exact(out, post, "sharded mixed scene vs reference")

@@ -156,6 +156,7 @@ typedef struct s2amdStepStats
 	int32_t graphReplayed;     /* 1 when the step ran as a hipGraph replay */
 	int32_t solveLaunches;     /* contact solve-sweep kernel launches timed into solveKernelMs (profiling only) */
 	float eventPairOverheadMs; /* elapsed time of an EMPTY HIP event pair on the stream (profiling only): subtract per launch */
+	int32_t groupCount;        /* LDS groups (small islands advanced whole-step by one workgroup each) */
 } s2amdStepStats;
 
 typedef struct s2amdSolver s2amdSolver;
@@ -202,7 +203,7 @@ int s2amd_get_joint_order(s2amdSolver* solver, int32_t* order, int32_t orderCapa
 						  int32_t colorCapacity, int32_t* jointCount, int32_t* colorCount);
 int s2amd_get_stats(s2amdSolver* solver, s2amdStepStats* stats);
 /* option keys: "graph" (0/1 hipGraph replay), "profile" (0/1 per-sweep HIP events),
- * "island_kernel" (0/1 one-workgroup-per-island path), "device_coloring" (0/1) */
+ * "groups" (0/1 LDS group path for small islands), "max_group_bodies", "pack_group_bodies" */
 int s2amd_set_option(s2amdSolver* solver, const char* key, int32_t value);
 
 #ifdef __cplusplus

@@ -2,10 +2,7 @@
 // Reference: src/solve_common.c:10-91 (integrate velocities / positions, finalize),
 // src/solve_jacobi.c:233-245 (apply accumulated deltas), src/solve_xpbd.c:411-449, :465-489.
 
-#include "launch.h"
-#include "s2_device.h"
-
-#include "solver2d_amd.h"
+#include "body_ops.h"
 
 #define S2_BLOCK 256
 
@@ -22,7 +19,7 @@ __global__ __launch_bounds__(S2_BLOCK) void unpackBodiesKernel(BodyView b, const
 	}
 	const s2amdBody* w = wire + i;
 	int type = w->type;
-	uint32_t flags = hostFlags[i] & (S2F_WRITE_VEL | S2F_WRITE_POS);
+	uint32_t flags = hostFlags[i] & (S2F_WRITE_VEL | S2F_WRITE_POS | S2F_IN_GROUP);
 	if (type != S2AMD_BODY_FREE)
 	{
 		flags |= S2F_LIVE;
@@ -73,67 +70,40 @@ __global__ __launch_bounds__(S2_BLOCK) void packBodiesKernel(BodyView b, s2amdBo
 	w->deltaPosition[0] = d.x, w->deltaPosition[1] = d.y;
 }
 
-// s2IntegrateVelocities: solve_common.c:10-45
+#define S2_BODY_KERNEL_HEAD                                                                                                      \
+	int i = blockIdx.x * blockDim.x + threadIdx.x;                                                                               \
+	if (i >= b.capacity || (b.flags[i] & S2F_IN_GROUP) != 0)                                                                     \
+	{                                                                                                                            \
+		return;                                                                                                                  \
+	}                                                                                                                            \
+	GlobalBodies gb{b.vel, b.dq};
+
+// Streaming passes over the bodies that are NOT owned by an LDS group (those are advanced inside
+// group_kernel.hip).  Arithmetic: body_ops.h.
 __global__ __launch_bounds__(S2_BLOCK) void integrateVelocitiesKernel(BodyView b)
 {
-	int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= b.capacity)
-	{
-		return;
-	}
-	if ((b.flags[i] & S2F_DYNAMIC) == 0)
-	{
-		return;
-	}
-	float4 v = b.vel[i];
-	float4 g = b.integ[i];
-	float ad = b.angDamp[i];
-	V2 lv = add(v2(v.x, v.y), v2(g.x, g.y));
-	float w = v.z + g.z;
-	lv = mulSV(g.w, lv);
-	w *= ad;
-	b.vel[i] = make_float4(lv.x, lv.y, w, 0.0f);
+	S2_BODY_KERNEL_HEAD
+	integrateVelocitiesOne(gb, i, b, i);
 }
-
-// s2IntegratePositions: solve_common.c:47-68
 __global__ __launch_bounds__(S2_BLOCK) void integratePositionsKernel(BodyView b, float h)
 {
-	int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= b.capacity)
-	{
-		return;
-	}
-	if ((b.flags[i] & S2F_MOVES) == 0)
-	{
-		return;
-	}
-	float4 v = b.vel[i];
-	float4 d = b.dq[i];
-	V2 dp = mulAdd(v2(d.x, d.y), h, v2(v.x, v.y));
-	Rot q;
-	q.s = d.z, q.c = d.w;
-	q = integrateRot(q, h * v.z);
-	b.dq[i] = make_float4(dp.x, dp.y, q.s, q.c);
+	S2_BODY_KERNEL_HEAD
+	integratePositionsOne(gb, i, b, i, h);
 }
-
-// s2FinalizePositions: solve_common.c:70-91; dynamicOnly = the XPBD variant, solve_xpbd.c:496-512
 __global__ __launch_bounds__(S2_BLOCK) void finalizePositionsKernel(BodyView b, int dynamicOnly)
 {
-	int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= b.capacity)
-	{
-		return;
-	}
-	uint32_t need = dynamicOnly ? S2F_DYNAMIC : S2F_MOVES;
-	if ((b.flags[i] & need) == 0)
-	{
-		return;
-	}
-	float4 d = b.dq[i];
-	float2 p = b.pos[i];
-	V2 np = add(v2(p.x, p.y), v2(d.x, d.y));
-	b.pos[i] = make_float2(np.x, np.y);
-	b.dq[i] = make_float4(0.0f, 0.0f, d.z, d.w);
+	S2_BODY_KERNEL_HEAD
+	finalizePositionsOne(gb, i, b, i, dynamicOnly, true);
+}
+__global__ __launch_bounds__(S2_BLOCK) void xpbdIntegrateKernel(BodyView b, float h)
+{
+	S2_BODY_KERNEL_HEAD
+	xpbdIntegrateOne(gb, b.dq0, i, b, i, h);
+}
+__global__ __launch_bounds__(S2_BLOCK) void xpbdProjectKernel(BodyView b, float inv_h)
+{
+	S2_BODY_KERNEL_HEAD
+	xpbdProjectOne(gb, b.dq0, i, b, i, inv_h);
 }
 
 // Jacobi: the reference adds every constraint's velocity delta into body->dv / dw in constraint
@@ -165,58 +135,6 @@ __global__ __launch_bounds__(S2_BLOCK) void jacobiApplyKernel(BodyView b, Contac
 	V2 lv = add(v2(v.x, v.y), dv);
 	float w = v.z;
 	w += dw;
-	b.vel[i] = make_float4(lv.x, lv.y, w, 0.0f);
-}
-
-// XPBD sub-step head: solve_xpbd.c:411-449 (every non-static body, kinematic included)
-__global__ __launch_bounds__(S2_BLOCK) void xpbdIntegrateKernel(BodyView b, float h)
-{
-	int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= b.capacity)
-	{
-		return;
-	}
-	if ((b.flags[i] & S2F_MOVES) == 0)
-	{
-		return;
-	}
-	float4 v = b.vel[i];
-	float4 g = b.integ[i];
-	float ad = b.angDamp[i];
-	V2 lv = add(v2(v.x, v.y), v2(g.x, g.y));
-	float w = v.z + g.z;
-	lv = mulSV(g.w, lv);
-	w *= ad;
-	b.vel[i] = make_float4(lv.x, lv.y, w, 0.0f);
-
-	float4 d = b.dq[i];
-	b.dq0[i] = d;
-	V2 dp = mulAdd(v2(d.x, d.y), h, lv);
-	Rot q;
-	q.s = d.z, q.c = d.w;
-	q = integrateRot(q, h * w);
-	b.dq[i] = make_float4(dp.x, dp.y, q.s, q.c);
-}
-
-// XPBD velocity projection: solve_xpbd.c:465-489 (dynamic bodies only)
-__global__ __launch_bounds__(S2_BLOCK) void xpbdProjectKernel(BodyView b, float inv_h)
-{
-	int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= b.capacity)
-	{
-		return;
-	}
-	if ((b.flags[i] & S2F_DYNAMIC) == 0)
-	{
-		return;
-	}
-	float4 d = b.dq[i];
-	float4 d0 = b.dq0[i];
-	V2 lv = mulSV(inv_h, sub(v2(d.x, d.y), v2(d0.x, d0.y)));
-	Rot q0, q1;
-	q0.s = d0.z, q0.c = d0.w;
-	q1.s = d.z, q1.c = d.w;
-	float w = computeAngularVelocity(q0, q1, inv_h);
 	b.vel[i] = make_float4(lv.x, lv.y, w, 0.0f);
 }
 

@@ -1,0 +1,236 @@
+// LDS group kernel: one workgroup advances one group through a list of step Ops with the group's
+// body velocities and poses staged in LDS (32 B per body), constraints streamed from their SoA
+// arrays, `__syncthreads()` between colour batches instead of kernel boundaries.
+//
+//  * whole-step mode: the group is a set of small simulation islands; the op list is the complete
+//    driver of the solver (all sub-steps), so the island costs ONE launch per step.  512 base-40
+//    pyramids = 512 workgroups, two per CU.
+//  * single-op mode: the group is the "sequential tail" of a big island -- the constraints that
+//    greedy colouring left in dozens of tiny colours because one body touches dozens of others
+//    (tumbler drum).  They are swept by one lane in sweep order with their bodies in LDS.
+//
+// Arithmetic is constraint_ops.h / body_ops.h, i.e. identical to the global kernels; sweep order is
+// (batch-major, index within batch), reported to the host like any other order.
+
+#include "body_ops.h"
+
+#define S2_GROUP_THREADS 512
+
+template <class F> S2_DEV void forBatches(const int4* batches, int b0, int b1, F f)
+{
+	for (int bi = b0; bi < b1; ++bi)
+	{
+		int4 bt = batches[bi];
+		if (bt.z)
+		{
+			if (threadIdx.x == 0)
+			{
+				for (int k = bt.x; k < bt.y; ++k)
+				{
+					f(k);
+				}
+			}
+		}
+		else
+		{
+			for (int k = bt.x + (int)threadIdx.x; k < bt.y; k += (int)blockDim.x)
+			{
+				f(k);
+			}
+		}
+		__syncthreads();
+	}
+}
+
+__global__ __launch_bounds__(S2_GROUP_THREADS) void groupKernel(ContactView c, JointView jv, BodyView g, GroupTable gt, const Op* ops, int opCount,
+																 StepConsts sc, s2amdContact* wire, int useDq0)
+{
+	extern __shared__ __attribute__((aligned(16))) float4 lds[];
+	const int grp = blockIdx.x;
+	const int bodyBase = gt.bodyOffsets[grp];
+	const int nb = gt.bodyOffsets[grp + 1] - bodyBase;
+	float4* lvel = lds;
+	float4* ldq = lds + nb;
+	float4* ldq0 = lds + 2 * nb; // only addressed when useDq0
+	const int* ids = gt.bodyIds + bodyBase;
+
+	for (int i = threadIdx.x; i < nb; i += blockDim.x)
+	{
+		int gi = (int)((uint32_t)ids[i] & ~S2G_OWNED);
+		lvel[i] = g.vel[gi];
+		ldq[i] = g.dq[gi];
+		if (useDq0)
+		{
+			ldq0[i] = g.dq0[gi];
+		}
+	}
+	__syncthreads();
+
+	LdsBodies lb{lvel, ldq};
+	const int cb0 = gt.cBatchOffsets[grp], cb1 = gt.cBatchOffsets[grp + 1];
+	const int jb0 = gt.jBatchOffsets[grp], jb1 = gt.jBatchOffsets[grp + 1];
+
+	for (int oi = 0; oi < opCount; ++oi)
+	{
+		const Op op = ops[oi];
+		switch (op.code)
+		{
+			case OP_INTEGRATE_VEL:
+				for (int i = threadIdx.x; i < nb; i += blockDim.x)
+				{
+					integrateVelocitiesOne(lb, i, g, (int)((uint32_t)ids[i] & ~S2G_OWNED));
+				}
+				__syncthreads();
+				break;
+			case OP_INTEGRATE_POS:
+				for (int i = threadIdx.x; i < nb; i += blockDim.x)
+				{
+					integratePositionsOne(lb, i, g, (int)((uint32_t)ids[i] & ~S2G_OWNED), op.h);
+				}
+				__syncthreads();
+				break;
+			case OP_FINALIZE:
+				for (int i = threadIdx.x; i < nb; i += blockDim.x)
+				{
+					uint32_t id = (uint32_t)ids[i];
+					finalizePositionsOne(lb, i, g, (int)(id & ~S2G_OWNED), op.flag, (id & S2G_OWNED) != 0);
+				}
+				__syncthreads();
+				break;
+			case OP_XPBD_INTEGRATE:
+				for (int i = threadIdx.x; i < nb; i += blockDim.x)
+				{
+					xpbdIntegrateOne(lb, ldq0, i, g, (int)((uint32_t)ids[i] & ~S2G_OWNED), op.h);
+				}
+				__syncthreads();
+				break;
+			case OP_XPBD_PROJECT:
+				for (int i = threadIdx.x; i < nb; i += blockDim.x)
+				{
+					xpbdProjectOne(lb, ldq0, i, g, (int)((uint32_t)ids[i] & ~S2G_OWNED), op.inv_h);
+				}
+				__syncthreads();
+				break;
+			case OP_JOINT_SWEEP:
+				switch (op.kind)
+				{
+					case JSOLVE_PLAIN:
+						forBatches(gt.jBatches, jb0, jb1, [&](int k) { solveJointsOne<JSOLVE_PLAIN>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
+						break;
+					case JSOLVE_SOFT:
+						forBatches(gt.jBatches, jb0, jb1, [&](int k) { solveJointsOne<JSOLVE_SOFT>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
+						break;
+					case JSOLVE_BAUMGARTE:
+						forBatches(gt.jBatches, jb0, jb1, [&](int k) { solveJointsOne<JSOLVE_BAUMGARTE>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
+						break;
+					case JSOLVE_POSITION:
+						forBatches(gt.jBatches, jb0, jb1, [&](int k) { solveJointsOne<JSOLVE_POSITION>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
+						break;
+					case JSOLVE_XPBD:
+						forBatches(gt.jBatches, jb0, jb1, [&](int k) { solveJointsOne<JSOLVE_XPBD>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
+						break;
+					case JSOLVE_WARM:
+						forBatches(gt.jBatches, jb0, jb1, [&](int k) { solveJointsOne<JSOLVE_WARM>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
+						break;
+				}
+				break;
+			case OP_WARM:
+				switch (op.kind)
+				{
+					case WARM_CURRENT:
+						forBatches(gt.cBatches, cb0, cb1, [&](int k) { warmStartContactsOne<WARM_CURRENT>(c, lb, k); });
+						break;
+					case WARM_FIXED:
+						forBatches(gt.cBatches, cb0, cb1, [&](int k) { warmStartContactsOne<WARM_FIXED>(c, lb, k); });
+						break;
+					case WARM_BLOCK:
+						forBatches(gt.cBatches, cb0, cb1, [&](int k) { warmStartContactsOne<WARM_BLOCK>(c, lb, k); });
+						break;
+				}
+				break;
+			case OP_SOLVE_SOFT:
+				switch (op.kind)
+				{
+					case SOFT_TGS:
+						forBatches(gt.cBatches, cb0, cb1, [&](int k) { solveContactsSoftOne<SOFT_TGS>(c, lb, op.inv_h, op.useBias, k); });
+						break;
+					case SOFT_PGS:
+						forBatches(gt.cBatches, cb0, cb1, [&](int k) { solveContactsSoftOne<SOFT_PGS>(c, lb, op.inv_h, op.useBias, k); });
+						break;
+					case SOFT_FIXED:
+						forBatches(gt.cBatches, cb0, cb1, [&](int k) { solveContactsSoftOne<SOFT_FIXED>(c, lb, op.inv_h, op.useBias, k); });
+						break;
+					default:
+						break; // SOFT_JACOBI never runs in a group (needs the per-body incidence sums)
+				}
+				break;
+			case OP_SOLVE_RIGID:
+				switch (op.kind)
+				{
+					case RIGID_BAUMGARTE:
+						forBatches(gt.cBatches, cb0, cb1, [&](int k) { solveContactsRigidOne<RIGID_BAUMGARTE>(c, lb, op.inv_h, k); });
+						break;
+					case RIGID_PGS:
+						forBatches(gt.cBatches, cb0, cb1, [&](int k) { solveContactsRigidOne<RIGID_PGS>(c, lb, op.inv_h, k); });
+						break;
+					case RIGID_TGS:
+						forBatches(gt.cBatches, cb0, cb1, [&](int k) { solveContactsRigidOne<RIGID_TGS>(c, lb, op.inv_h, k); });
+						break;
+				}
+				break;
+			case OP_SOLVE_STICKY:
+				forBatches(gt.cBatches, cb0, cb1, [&](int k) { solveContactsStickyOne(c, lb, wire, op.inv_h, op.useBias, k); });
+				break;
+			case OP_SOLVE_NGS:
+				forBatches(gt.cBatches, cb0, cb1, [&](int k) { solveContactsNGSOne(c, lb, k); });
+				break;
+			case OP_XPBD_POS:
+				forBatches(gt.cBatches, cb0, cb1, [&](int k) { xpbdContactPositionsOne(c, lb, op.h, k); });
+				break;
+			case OP_XPBD_VEL:
+				forBatches(gt.cBatches, cb0, cb1, [&](int k) { xpbdContactVelocitiesOne(c, lb, op.h, k); });
+				break;
+			case OP_BLOCK_VEL:
+				forBatches(gt.cBatches, cb0, cb1, [&](int k) { blockSolveVelocityOne(c, lb, k); });
+				break;
+			case OP_BLOCK_POS:
+				forBatches(gt.cBatches, cb0, cb1, [&](int k) { blockSolvePositionOne(c, lb, k); });
+				break;
+			default:
+				break;
+		}
+	}
+
+	for (int i = threadIdx.x; i < nb; i += blockDim.x)
+	{
+		uint32_t id = (uint32_t)ids[i];
+		if (id & S2G_OWNED)
+		{
+			int gi = (int)(id & ~S2G_OWNED);
+			g.vel[gi] = lvel[i];
+			g.dq[gi] = ldq[i];
+			if (useDq0)
+			{
+				g.dq0[gi] = ldq0[i];
+			}
+		}
+	}
+}
+
+int groupKernelSetup()
+{
+	// allow a group to use the full 160 KiB of LDS
+	hipError_t e = hipFuncSetAttribute((const void*)groupKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+	return e == hipSuccess ? 0 : (int)e;
+}
+
+void launchGroupKernel(hipStream_t s, const ContactView& c, const JointView& j, const BodyView& g, const GroupTable& gt, const Op* ops, int opCount,
+					   const StepConsts& sc, s2amdContact* wire, int maxBodies, int useDq0)
+{
+	if (gt.groupCount <= 0 || opCount <= 0)
+	{
+		return;
+	}
+	size_t lds = (size_t)maxBodies * (useDq0 ? 48 : 32);
+	groupKernel<<<dim3((unsigned)gt.groupCount), dim3(S2_GROUP_THREADS), lds, s>>>(c, j, g, gt, ops, opCount, sc, wire, useDq0);
+}

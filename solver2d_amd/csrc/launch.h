@@ -7,6 +7,8 @@ struct BodyView;
 struct ContactView;
 struct JointView;
 struct StepConsts;
+struct GroupTable;
+struct Op;
 struct s2amdBody;
 struct s2amdContact;
 struct s2amdJoint;
@@ -14,6 +16,7 @@ struct s2amdJoint;
 // body flag bits that only the host sets (see s2_device.h for the rest)
 #define S2F_WRITE_VEL 8u  // body is a conflict node for velocity sweeps (not read-only shareable)
 #define S2F_WRITE_POS 16u // body is a conflict node for position sweeps
+#define S2F_IN_GROUP 32u  // body is owned by an LDS group: the streaming body kernels skip it
 
 enum PrepareKind
 {
@@ -97,3 +100,8 @@ void launchPrepareJoints(hipStream_t s, int kind, const JointView& j, const Body
 void launchSolveJoints(hipStream_t s, int kind, const JointView& j, const BodyView& b, int begin, int end, const StepConsts& sc, float h,
 					   float inv_h, int useBias);
 void launchStoreJoints(hipStream_t s, const JointView& j, s2amdJoint* wire);
+
+// LDS groups
+int groupKernelSetup();
+void launchGroupKernel(hipStream_t s, const ContactView& c, const JointView& j, const BodyView& g, const GroupTable& gt, const Op* ops, int opCount,
+					   const StepConsts& sc, s2amdContact* wire, int maxBodies, int useDq0);

@@ -330,7 +330,8 @@ struct BodyView
 // Contact constraints in sweep order (colour-major).  k = position in sweep order.
 struct ContactView
 {
-	int2* bodies;	  // {indexA, indexB}
+	int2* bodies;	  // {indexA, indexB} (body-pool slots)
+	int2* localBodies; // {indexA, indexB} as group-local slots (constraints that belong to an LDS group)
 	float4* mass;	  // {mA, iA, mB, iB}
 	float4* nf;		  // {normal.x, normal.y, friction, bits(pointCount | writeA<<8 | writeB<<9)}
 	float4* anchor[2]; // {localAnchorA, localAnchorB} relative to the centers of mass
@@ -355,6 +356,7 @@ struct ContactView
 struct JointView
 {
 	int2* bodies;
+	int2* localBodies;
 	float4* frame;	  // {localAnchorA, localAnchorB} relative to centers of mass
 	float4* mass;	  // {mA, iA, mB, iB}
 	float4* pivot;	  // pivotMass {cx.x, cx.y, cy.x, cy.y}
@@ -386,3 +388,49 @@ struct StepConsts
 
 S2_DEV uint32_t asBits(float f) { return __float_as_uint(f); }
 S2_DEV float fromBits(uint32_t u) { return __uint_as_float(u); }
+
+// ---------------------------------------------------------------------------------------------
+// Step programs and LDS groups
+// ---------------------------------------------------------------------------------------------
+// A solver driver (one s2Solve_* of the reference) is recorded once per step as a list of Ops.
+// The same list is executed two ways: by the host as one kernel launch per op and colour batch
+// (bodies in HBM), and by group_kernel.hip, where one workgroup walks the whole list for a
+// "group" -- a set of small islands (or the sequential tail of a big one) whose bodies fit in LDS.
+enum OpCode
+{
+	OP_INTEGRATE_VEL,
+	OP_INTEGRATE_POS,  // h
+	OP_FINALIZE,	   // flag = dynamicOnly
+	OP_XPBD_INTEGRATE, // h
+	OP_XPBD_PROJECT,   // inv_h
+	OP_JOINT_SWEEP,	   // kind, h, inv_h, useBias
+	OP_WARM,		   // kind
+	OP_SOLVE_SOFT,	   // kind, inv_h, useBias
+	OP_SOLVE_RIGID,	   // kind, inv_h
+	OP_SOLVE_STICKY,   // inv_h, useBias
+	OP_SOLVE_NGS,
+	OP_XPBD_POS, // h
+	OP_XPBD_VEL, // h
+	OP_BLOCK_VEL,
+	OP_BLOCK_POS,
+	OP_JACOBI_APPLY
+};
+
+struct Op
+{
+	int code, kind, useBias, flag;
+	float h, inv_h, f0, f1;
+};
+
+// batches: {begin, end, sequential?, 0} ranges into the constraint / joint SoA
+struct GroupTable
+{
+	const int* bodyOffsets; // [groupCount + 1] into bodyIds
+	const int* bodyIds;		// pool slot of each local body; bit 31 set = owned (written back)
+	const int* cBatchOffsets;
+	const int4* cBatches;
+	const int* jBatchOffsets;
+	const int4* jBatches;
+	int groupCount;
+};
+#define S2G_OWNED 0x80000000u

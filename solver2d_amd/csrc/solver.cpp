@@ -212,6 +212,41 @@ void sortByColor(const std::vector<int>& ids, const std::vector<int>& color, int
 	}
 }
 
+// Launch batches from colour offsets.  Colours are launched one kernel each; when the colouring
+// has a long run of tiny high colours (a body with dozens of constraints forces one colour per
+// constraint) that run becomes ONE sequential tail batch instead of dozens of launches.
+bool makeBatches(const std::vector<int>& colorOffsets, std::vector<int>& batchOffsets)
+{
+	int n = (int)colorOffsets.size() - 1;
+	batchOffsets.clear();
+	if (n <= 0)
+	{
+		batchOffsets.push_back(0);
+		return false;
+	}
+	int total = colorOffsets[n];
+	int tailColor = n;
+	const int kMinParallelColors = 8, kMaxTailConstraints = 4096, kMinTailColors = 3;
+	for (int c = kMinParallelColors; c < n; ++c)
+	{
+		if (total - colorOffsets[c] <= kMaxTailConstraints && n - c >= kMinTailColors)
+		{
+			tailColor = c;
+			break;
+		}
+	}
+	for (int c = 0; c <= tailColor; ++c)
+	{
+		batchOffsets.push_back(colorOffsets[c]);
+	}
+	if (tailColor < n)
+	{
+		batchOffsets.push_back(total);
+		return true;
+	}
+	return false;
+}
+
 uint64_t fnv(uint64_t h, const void* data, size_t n)
 {
 	const unsigned char* p = (const unsigned char*)data;
@@ -224,6 +259,63 @@ uint64_t fnv(uint64_t h, const void* data, size_t n)
 }
 
 } // namespace
+
+// One sweepable family (contacts or joints): order, colour batches, LDS groups
+struct SweepSet
+{
+	std::vector<int> order;		   // k -> wire index (global part first, then group by group)
+	std::vector<int> colorOffsets; // every (part, colour) batch as a range of k: API + validity tests
+	// global part: launch batches (parallel colours, then optionally one sequential tail)
+	std::vector<int> batchOffsets;
+	bool hasTail = false;
+	int globalCount = 0;
+	std::vector<int2> local; // k -> group-local body slots (groups and the global tail)
+};
+
+struct HostGroupTable
+{
+	std::vector<int> bodyOffsets{0}, bodyIds, cBatchOffsets{0}, jBatchOffsets{0};
+	std::vector<int4> cBatches, jBatches;
+	int maxBodies = 0;
+	int count() const { return (int)bodyOffsets.size() - 1; }
+	void clear()
+	{
+		bodyOffsets.assign(1, 0);
+		cBatchOffsets.assign(1, 0);
+		jBatchOffsets.assign(1, 0);
+		bodyIds.clear();
+		cBatches.clear();
+		jBatches.clear();
+		maxBodies = 0;
+	}
+};
+
+struct DeviceGroupTable
+{
+	DevBuf buf;
+	GroupTable view{};
+	int maxBodies = 0;
+};
+
+// The launch sequence of one s2Solve_* driver, recorded once per parameter set
+struct StepPlan
+{
+	bool valid = false;
+	s2amdStepParams params{};
+	StepConsts sc{};
+	bool earlyOut = false;
+	float unpackH = 0.0f;
+	int prepContacts = -1;
+	float prepH = 0.0f, prepHertz = 0.0f;
+	int prepJoints = -1;
+	float jprepH = 0.0f, jprepHertz = 0.0f;
+	int jprepWarm = 0;
+	std::vector<Op> ops;
+	int storeKind = STORE_PLAIN;
+	float storeScale = 0.0f;
+	int solveSweeps = 0;
+	bool usesDq0 = false;
+};
 
 struct s2amdSolver
 {
@@ -240,26 +332,38 @@ struct s2amdSolver
 	// host shadows of the graph structure (refreshed by every upload)
 	std::vector<int> hContactA, hContactB, hContactPoints;
 	std::vector<int> hJointType, hJointA, hJointB;
-	std::vector<uint32_t> hBodyFlags; // S2F_WRITE_VEL / S2F_WRITE_POS
+	std::vector<uint32_t> hBodyFlags; // S2F_WRITE_VEL / S2F_WRITE_POS from the wire bodies
+	std::vector<uint8_t> hBodyLive, hBodyStatic;
 	DevBuf dBodyFlags;
 
 	// working SoA
-	DevBuf soaBodies, soaContacts, soaJoints, dContactIndex, dJointIndex, dAdjOffsets, dAdjList;
+	DevBuf soaBodies, soaContacts, soaJoints, dContactIndex, dJointIndex, dContactLocal, dJointLocal, dAdjOffsets, dAdjList, dOps;
 	BodyView bv{};
 	ContactView cv{};
 	JointView jv{};
 	uint64_t layoutGeneration = 0;
 	int bodySoaCap = 0, contactSoaCap = 0, jointSoaCap = 0;
 
-	// sweep order of the last step
-	std::vector<int> contactOrder, contactColorOffsets, jointOrder, jointColorOffsets;
+	// structure of the last step
+	SweepSet contacts, joints;
+	HostGroupTable hGroups, hContactTail, hJointTail;
+	DeviceGroupTable dGroups, dContactTail, dJointTail;
+	int looseBodies = 0; // live non-static bodies that no LDS group owns
 	int orderSolverClass = -1; // 0 velocity colouring, 1 position colouring
+	bool orderGrouped = false;
 	bool adjValid = false;
 	bool structureDirty = true;
+	uint64_t structureGeneration = 0;
+
+	StepPlan plan;
+	uint64_t planGeneration = 0;
 
 	// options
 	int optGraph = 1;
 	int optProfile = 0;
+	int optGroups = 1;
+	int optMaxGroupBodies = 2048;
+	int optPackGroupBodies = 1024;
 
 	// graph cache
 	hipGraph_t graph = nullptr;
@@ -272,14 +376,40 @@ struct s2amdSolver
 
 	s2amdStepStats stats{};
 	int launchCounter = 0;
-	int sweepCounter = 0;
-	int graphLaunches = 0, graphSweeps = 0;
+	int graphLaunches = 0;
 	DevBuf dGatherIndex;
 	bool gatherIndexDirty = true;
+	uint64_t opsGeneration = ~0ull;
 };
 
 namespace
 {
+
+StepConsts makeConsts(const s2amdStepParams* p)
+{
+	// src/world.c:170-202
+	StepConsts sc;
+	sc.dt = p->dt;
+	sc.iterations = p->velIters;
+	sc.extraIterations = p->posIters;
+	sc.warmStart = p->warmStart != 0 ? 1 : 0;
+	sc.inv_dt = p->dt > 0.0f ? 1.0f / p->dt : 0.0f;
+	int type = p->solverType;
+	if (type == s2amd_solverXPBD || type == s2amd_solverTGS_Soft || type == s2amd_solverTGS_Sticky || type == s2amd_solverTGS_NGS ||
+		type == s2amd_solverSoftStep)
+	{
+		sc.h = sc.dt / sc.iterations;
+		sc.inv_h = sc.inv_dt * sc.iterations;
+	}
+	else
+	{
+		sc.h = sc.dt;
+		sc.inv_h = sc.inv_dt;
+	}
+	sc.gravityX = p->gravity[0];
+	sc.gravityY = p->gravity[1];
+	return sc;
+}
 
 // SoA carving: one device allocation per family, arrays laid end to end at 256-byte boundaries.
 // The element capacity only grows (x1.5), so device pointers -- and a captured hipGraph -- stay
@@ -394,73 +524,482 @@ int carveJoints(s2amdSolver* s, int n)
 	return c.p <= c.end ? S2AMD_OK : fail(S2AMD_E_DEVICE, "internal: joint SoA carve overflow");
 }
 
-// Build sweep order + colour batches for the given solver on the host, upload the index tables.
-int buildOrder(s2amdSolver* s, int solverType)
+// ------------------------------------------------------------------------------------------------
+// structure: islands -> LDS groups, colouring, sweep order, index tables
+// ------------------------------------------------------------------------------------------------
+struct UnionFind
 {
-	// class 0: velocity-level colouring, 1: position-level colouring.  Jacobi uses class 0 for its
-	// warm start and joints and additionally needs the body -> constraint incidence lists.
-	int cls = isPositionSolver(solverType) ? 1 : 0;
+	std::vector<int> parent;
+	explicit UnionFind(int n) : parent((size_t)n)
+	{
+		for (int i = 0; i < n; ++i)
+		{
+			parent[i] = i;
+		}
+	}
+	int find(int x)
+	{
+		while (parent[x] != x)
+		{
+			parent[x] = parent[parent[x]];
+			x = parent[x];
+		}
+		return x;
+	}
+	void unite(int a, int b)
+	{
+		a = find(a), b = find(b);
+		if (a != b)
+		{
+			// the lower index becomes the root: labels are deterministic
+			if (a < b)
+			{
+				parent[b] = a;
+			}
+			else
+			{
+				parent[a] = b;
+			}
+		}
+	}
+};
+
+struct EdgeList
+{
+	std::vector<int> ids, a, b; // wire index and endpoints (a == -1: one-body constraint)
+};
+
+// Colours one part (the global part or one group), appends its sweep order to `set` and returns its
+// launch batches as ranges of k.  Endpoints are indices into `conflict`.
+void colourPart(const std::vector<int>& ids, const std::vector<int>& ea, const std::vector<int>& eb, const std::vector<uint8_t>& conflict,
+				int bodyCount, SweepSet& set, std::vector<int>& batchOffsetsOut, bool& hasTailOut, std::vector<int>* positions)
+{
+	std::vector<int> color, partOrder, partOffsets;
+	int cc = colorGraph(ea, eb, conflict, bodyCount, color);
+	// stable counting sort of positions by colour
+	std::vector<int> pos(ids.size());
+	for (size_t i = 0; i < ids.size(); ++i)
+	{
+		pos[i] = (int)i;
+	}
+	sortByColor(pos, color, cc, partOrder, partOffsets);
+	int base = (int)set.order.size();
+	for (int p : partOrder)
+	{
+		set.order.push_back(ids[p]);
+	}
+	if (positions)
+	{
+		*positions = partOrder;
+	}
+	for (int c = 0; c < cc; ++c)
+	{
+		if (set.colorOffsets.empty())
+		{
+			set.colorOffsets.push_back(0);
+		}
+		if (partOffsets[(size_t)c + 1] > partOffsets[c])
+		{
+			set.colorOffsets.push_back(base + partOffsets[(size_t)c + 1]);
+		}
+	}
+	std::vector<int> rel;
+	hasTailOut = makeBatches(partOffsets, rel);
+	batchOffsetsOut.clear();
+	for (int r : rel)
+	{
+		batchOffsetsOut.push_back(base + r);
+	}
+}
+
+int uploadGroupTable(s2amdSolver* s, const HostGroupTable& h, DeviceGroupTable& d)
+{
+	auto pad4 = [](size_t n) { return (n + 3) & ~size_t(3); };
+	size_t nBO = pad4(h.bodyOffsets.size()), nBI = pad4(std::max<size_t>(h.bodyIds.size(), 1));
+	size_t nCO = pad4(h.cBatchOffsets.size()), nJO = pad4(h.jBatchOffsets.size());
+	size_t nCB = std::max<size_t>(h.cBatches.size(), 1) * 4, nJB = std::max<size_t>(h.jBatches.size(), 1) * 4;
+	std::vector<int> blob(nBO + nBI + nCO + nJO + nCB + nJB, 0);
+	size_t o = 0;
+	size_t oBO = o;
+	std::copy(h.bodyOffsets.begin(), h.bodyOffsets.end(), blob.begin() + o);
+	o += nBO;
+	size_t oBI = o;
+	std::copy(h.bodyIds.begin(), h.bodyIds.end(), blob.begin() + o);
+	o += nBI;
+	size_t oCO = o;
+	std::copy(h.cBatchOffsets.begin(), h.cBatchOffsets.end(), blob.begin() + o);
+	o += nCO;
+	size_t oJO = o;
+	std::copy(h.jBatchOffsets.begin(), h.jBatchOffsets.end(), blob.begin() + o);
+	o += nJO;
+	size_t oCB = o;
+	if (!h.cBatches.empty())
+	{
+		memcpy(blob.data() + o, h.cBatches.data(), h.cBatches.size() * sizeof(int4));
+	}
+	o += nCB;
+	size_t oJB = o;
+	if (!h.jBatches.empty())
+	{
+		memcpy(blob.data() + o, h.jBatches.data(), h.jBatches.size() * sizeof(int4));
+	}
+	bool grew = false;
+	int rc = d.buf.ensure(blob.size() * sizeof(int), &grew);
+	if (rc)
+	{
+		return rc;
+	}
+	if (grew)
+	{
+		s->layoutGeneration += 1;
+	}
+	HIP_TRY(hipMemcpyAsync(d.buf.p, blob.data(), blob.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+	const int* base = (const int*)d.buf.p;
+	d.view.bodyOffsets = base + oBO;
+	d.view.bodyIds = base + oBI;
+	d.view.cBatchOffsets = base + oCO;
+	d.view.jBatchOffsets = base + oJO;
+	d.view.cBatches = (const int4*)(base + oCB);
+	d.view.jBatches = (const int4*)(base + oJB);
+	d.view.groupCount = h.count();
+	d.maxBodies = h.maxBodies;
+	return S2AMD_OK;
+}
+
+// Local body slots of one group: bodies get slots in order of first use by the group's constraints.
+struct LocalSlots
+{
+	std::vector<int> slot, stamp;
+	int epoch = 0;
+	explicit LocalSlots(int nb) : slot((size_t)nb, -1), stamp((size_t)nb, -1) {}
+	void begin() { epoch += 1; }
+	int get(int body, std::vector<int>& ids, const std::vector<uint8_t>& conflict)
+	{
+		if (stamp[body] != epoch)
+		{
+			stamp[body] = epoch;
+			slot[body] = (int)ids.size();
+			ids.push_back((int)((uint32_t)body | (conflict[body] ? S2G_OWNED : 0u)));
+		}
+		return slot[body];
+	}
+};
+
+int buildStructure(s2amdSolver* s, int solverType)
+{
+	const int cls = isPositionSolver(solverType) ? 1 : 0;
 	const bool needAdj = solverType == s2amd_solverJacobi;
-	if (!s->structureDirty && cls == s->orderSolverClass && (!needAdj || s->adjValid))
+	const bool grouped = s->optGroups != 0 && !needAdj;
+	if (!s->structureDirty && cls == s->orderSolverClass && grouped == s->orderGrouped && (!needAdj || s->adjValid))
 	{
 		return S2AMD_OK;
 	}
 	double t0 = nowMs();
-	const bool pos = cls == 1;
-	int nb = s->bodyCapacity;
+	const int nb = s->bodyCapacity;
 	std::vector<uint8_t> conflict((size_t)nb);
 	for (int i = 0; i < nb; ++i)
 	{
-		conflict[i] = (s->hBodyFlags[i] & (pos ? S2F_WRITE_POS : S2F_WRITE_VEL)) != 0;
+		conflict[i] = (s->hBodyFlags[i] & (cls == 1 ? S2F_WRITE_POS : S2F_WRITE_VEL)) != 0;
 	}
 
-	// contacts: gather in pool order (e.g. solve_tgs_soft.c:162-179)
-	std::vector<int> ids, ea, eb;
-	ids.reserve(s->contactCapacity);
+	// active constraints in pool order (the reference's gather: e.g. solve_tgs_soft.c:162-179)
+	EdgeList ce, je;
 	for (int i = 0; i < s->contactCapacity; ++i)
 	{
 		if (s->hContactPoints[i] > 0)
 		{
-			ids.push_back(i);
-			ea.push_back(s->hContactA[i]);
-			eb.push_back(s->hContactB[i]);
+			ce.ids.push_back(i);
+			ce.a.push_back(s->hContactA[i]);
+			ce.b.push_back(s->hContactB[i]);
 		}
 	}
-	{
-		std::vector<int> color;
-		int cc = colorGraph(ea, eb, conflict, nb, color);
-		sortByColor(ids, color, cc, s->contactOrder, s->contactColorOffsets);
-	}
-
-	// joints: live joints in pool order; a mouse joint only touches body B
-	std::vector<int> jids, ja, jb;
 	for (int i = 0; i < s->jointCapacity; ++i)
 	{
 		if (s->hJointType[i] != S2AMD_JOINT_FREE)
 		{
-			jids.push_back(i);
-			ja.push_back(s->hJointType[i] == S2AMD_JOINT_MOUSE ? -1 : s->hJointA[i]);
-			jb.push_back(s->hJointB[i]);
+			je.ids.push_back(i);
+			je.a.push_back(s->hJointType[i] == S2AMD_JOINT_MOUSE ? -1 : s->hJointA[i]); // a mouse joint only touches body B
+			je.b.push_back(s->hJointB[i]);
 		}
 	}
+	const int C = (int)ce.ids.size(), J = (int)je.ids.size();
+
+	// ---- islands: connected components over the writable bodies ----
+	std::vector<int> cPart((size_t)C, -1), jPart((size_t)J, -1); // -1 = global part, else group id
+	int groupCount = 0;
+	std::vector<uint32_t> flags(s->hBodyFlags);
+	if (grouped && (C > 0 || J > 0))
 	{
-		std::vector<int> color;
-		int jc = colorGraph(ja, jb, conflict, nb, color);
-		sortByColor(jids, color, jc, s->jointOrder, s->jointColorOffsets);
+		UnionFind uf(nb);
+		auto link = [&](int a, int b) {
+			if (a >= 0 && b >= 0 && conflict[a] && conflict[b])
+			{
+				uf.unite(a, b);
+			}
+		};
+		for (int k = 0; k < C; ++k)
+		{
+			link(ce.a[k], ce.b[k]);
+		}
+		for (int k = 0; k < J; ++k)
+		{
+			link(je.a[k], je.b[k]);
+		}
+		auto rootOf = [&](int a, int b) {
+			if (a >= 0 && conflict[a])
+			{
+				return uf.find(a);
+			}
+			if (b >= 0 && conflict[b])
+			{
+				return uf.find(b);
+			}
+			return -1;
+		};
+		// bodies an island would stage in LDS: its members that carry constraints + read-only replicas
+		std::vector<int> islandBodies((size_t)nb, 0), seenBy((size_t)nb, -1), cRoot((size_t)C), jRoot((size_t)J);
+		auto touch = [&](int body, int root) {
+			if (body < 0 || root < 0)
+			{
+				return;
+			}
+			int key = conflict[body] ? -2 - root : root; // members are unique per island; replicas per (body, island)
+			if (conflict[body])
+			{
+				if (seenBy[body] != -2)
+				{
+					seenBy[body] = -2;
+					islandBodies[root] += 1;
+				}
+			}
+			else if (seenBy[body] != key)
+			{
+				seenBy[body] = key; // approximate distinct count (exact when an immovable body's uses by one island are contiguous)
+				islandBodies[root] += 1;
+			}
+		};
+		for (int k = 0; k < C; ++k)
+		{
+			cRoot[k] = rootOf(ce.a[k], ce.b[k]);
+			touch(ce.a[k], cRoot[k]);
+			touch(ce.b[k], cRoot[k]);
+		}
+		for (int k = 0; k < J; ++k)
+		{
+			jRoot[k] = rootOf(je.a[k], je.b[k]);
+			touch(je.a[k], jRoot[k]);
+			touch(je.b[k], jRoot[k]);
+		}
+		// pack eligible islands into groups in order of first appearance
+		std::vector<int> groupOfRoot((size_t)nb, -2); // -2 unassigned, -1 global
+		int curBodies = 0;
+		auto assign = [&](int root) {
+			if (root < 0)
+			{
+				return -1;
+			}
+			if (groupOfRoot[root] != -2)
+			{
+				return groupOfRoot[root];
+			}
+			int n = islandBodies[root];
+			if (n > s->optMaxGroupBodies)
+			{
+				groupOfRoot[root] = -1;
+				return -1;
+			}
+			if (groupCount == 0 || curBodies + n > s->optPackGroupBodies)
+			{
+				groupCount += 1;
+				curBodies = 0;
+			}
+			curBodies += n;
+			groupOfRoot[root] = groupCount - 1;
+			return groupCount - 1;
+		};
+		for (int k = 0; k < C; ++k)
+		{
+			cPart[k] = assign(cRoot[k]);
+		}
+		for (int k = 0; k < J; ++k)
+		{
+			jPart[k] = assign(jRoot[k]);
+		}
 	}
 
-	int C = (int)s->contactOrder.size(), J = (int)s->jointOrder.size();
+	// ---- per part lists (pool order is preserved inside every part) ----
+	std::vector<std::vector<int>> cOf((size_t)groupCount + 1), jOf((size_t)groupCount + 1); // index 0 = global, g + 1 = group g
+	for (int k = 0; k < C; ++k)
+	{
+		cOf[(size_t)cPart[k] + 1].push_back(k);
+	}
+	for (int k = 0; k < J; ++k)
+	{
+		jOf[(size_t)jPart[k] + 1].push_back(k);
+	}
+
+	SweepSet& cs = s->contacts;
+	SweepSet& js = s->joints;
+	cs = SweepSet();
+	js = SweepSet();
+	cs.colorOffsets.push_back(0);
+	js.colorOffsets.push_back(0);
+	s->hGroups.clear();
+	s->hContactTail.clear();
+	s->hJointTail.clear();
+
+	LocalSlots slots(nb);
+	auto gather = [&](const EdgeList& e, const std::vector<int>& ks, std::vector<int>& ids, std::vector<int>& a, std::vector<int>& b) {
+		ids.clear(), a.clear(), b.clear();
+		for (int k : ks)
+		{
+			ids.push_back(e.ids[k]);
+			a.push_back(e.a[k]);
+			b.push_back(e.b[k]);
+		}
+	};
+
+	// global part: colour batches over HBM-resident bodies (+ a sequential tail as a one-group LDS table)
+	{
+		std::vector<int> ids, a, b, pos;
+		gather(ce, cOf[0], ids, a, b);
+		colourPart(ids, a, b, conflict, nb, cs, cs.batchOffsets, cs.hasTail, &pos);
+		cs.globalCount = (int)ids.size();
+		cs.local.assign((size_t)cs.globalCount, make_int2(0, 0));
+		if (cs.hasTail)
+		{
+			HostGroupTable& t = s->hContactTail;
+			int begin = cs.batchOffsets[cs.batchOffsets.size() - 2], end = cs.batchOffsets.back();
+			slots.begin();
+			std::vector<int> bodies;
+			for (int k = begin; k < end; ++k)
+			{
+				int p = pos[(size_t)k];
+				cs.local[(size_t)k] = make_int2(slots.get(a[p], bodies, conflict), slots.get(b[p], bodies, conflict));
+			}
+			t.bodyIds = bodies;
+			t.bodyOffsets = {0, (int)bodies.size()};
+			t.cBatches.push_back(make_int4(begin, end, 1, 0));
+			t.cBatchOffsets = {0, 1};
+			t.jBatchOffsets = {0, 0};
+			t.maxBodies = (int)bodies.size();
+		}
+		gather(je, jOf[0], ids, a, b);
+		colourPart(ids, a, b, conflict, nb, js, js.batchOffsets, js.hasTail, &pos);
+		js.globalCount = (int)ids.size();
+		js.local.assign((size_t)js.globalCount, make_int2(0, 0));
+		if (js.hasTail)
+		{
+			HostGroupTable& t = s->hJointTail;
+			int begin = js.batchOffsets[js.batchOffsets.size() - 2], end = js.batchOffsets.back();
+			slots.begin();
+			std::vector<int> bodies;
+			for (int k = begin; k < end; ++k)
+			{
+				int p = pos[(size_t)k];
+				int la = a[p] >= 0 ? slots.get(a[p], bodies, conflict) : 0;
+				js.local[(size_t)k] = make_int2(la, slots.get(b[p], bodies, conflict));
+			}
+			t.bodyIds = bodies;
+			t.bodyOffsets = {0, (int)bodies.size()};
+			t.jBatches.push_back(make_int4(begin, end, 1, 0));
+			t.jBatchOffsets = {0, 1};
+			t.cBatchOffsets = {0, 0};
+			t.maxBodies = (int)bodies.size();
+		}
+	}
+
+	// LDS groups: whole-step kernel, bodies in LDS
+	for (int g = 0; g < groupCount; ++g)
+	{
+		HostGroupTable& t = s->hGroups;
+		std::vector<int> ids, a, b, bodies, la, lb, pos, batchOffsets;
+		bool tail = false;
+		slots.begin();
+		// contacts
+		gather(ce, cOf[(size_t)g + 1], ids, a, b);
+		la.resize(ids.size()), lb.resize(ids.size());
+		for (size_t i = 0; i < ids.size(); ++i)
+		{
+			la[i] = slots.get(a[i], bodies, conflict);
+			lb[i] = slots.get(b[i], bodies, conflict);
+		}
+		// joints (slots first so both families share one body list)
+		std::vector<int> jids, ja, jb, jla, jlb;
+		gather(je, jOf[(size_t)g + 1], jids, ja, jb);
+		jla.resize(jids.size()), jlb.resize(jids.size());
+		for (size_t i = 0; i < jids.size(); ++i)
+		{
+			jla[i] = ja[i] >= 0 ? slots.get(ja[i], bodies, conflict) : -1;
+			jlb[i] = slots.get(jb[i], bodies, conflict);
+		}
+		std::vector<uint8_t> lconf(bodies.size());
+		for (size_t i = 0; i < bodies.size(); ++i)
+		{
+			lconf[i] = ((uint32_t)bodies[i] & S2G_OWNED) != 0;
+		}
+		int base = (int)cs.order.size();
+		colourPart(ids, la, lb, lconf, (int)bodies.size(), cs, batchOffsets, tail, &pos);
+		for (size_t i = 0; i < pos.size(); ++i)
+		{
+			cs.local.push_back(make_int2(la[(size_t)pos[i]], lb[(size_t)pos[i]]));
+		}
+		for (size_t bi = 0; bi + 1 < batchOffsets.size(); ++bi)
+		{
+			bool isTail = tail && bi + 2 == batchOffsets.size();
+			if (batchOffsets[bi + 1] > batchOffsets[bi])
+			{
+				t.cBatches.push_back(make_int4(batchOffsets[bi], batchOffsets[bi + 1], isTail ? 1 : 0, 0));
+			}
+		}
+		(void)base;
+		t.cBatchOffsets.push_back((int)t.cBatches.size());
+		colourPart(jids, jla, jlb, lconf, (int)bodies.size(), js, batchOffsets, tail, &pos);
+		for (size_t i = 0; i < pos.size(); ++i)
+		{
+			js.local.push_back(make_int2(std::max(jla[(size_t)pos[i]], 0), jlb[(size_t)pos[i]]));
+		}
+		for (size_t bi = 0; bi + 1 < batchOffsets.size(); ++bi)
+		{
+			bool isTail = tail && bi + 2 == batchOffsets.size();
+			if (batchOffsets[bi + 1] > batchOffsets[bi])
+			{
+				t.jBatches.push_back(make_int4(batchOffsets[bi], batchOffsets[bi + 1], isTail ? 1 : 0, 0));
+			}
+		}
+		t.jBatchOffsets.push_back((int)t.jBatches.size());
+		for (int id : bodies)
+		{
+			t.bodyIds.push_back(id);
+			if ((uint32_t)id & S2G_OWNED)
+			{
+				flags[(size_t)((uint32_t)id & ~S2G_OWNED)] |= S2F_IN_GROUP;
+			}
+		}
+		t.bodyOffsets.push_back((int)t.bodyIds.size());
+		t.maxBodies = std::max(t.maxBodies, (int)bodies.size());
+	}
+
+	s->looseBodies = 0;
+	for (int i = 0; i < nb; ++i)
+	{
+		if (s->hBodyLive[i] && !s->hBodyStatic[i] && (flags[i] & S2F_IN_GROUP) == 0)
+		{
+			s->looseBodies += 1;
+		}
+	}
+
+	// ---- device tables ----
 	int rc;
 	if ((rc = carveContacts(s, C)) != 0 || (rc = carveJoints(s, J)) != 0)
 	{
 		return rc;
 	}
 	bool grew = false;
-	if ((rc = s->dContactIndex.ensure((size_t)std::max(C, 1) * sizeof(int), &grew)) != 0)
-	{
-		return rc;
-	}
-	if ((rc = s->dJointIndex.ensure((size_t)std::max(J, 1) * sizeof(int), &grew)) != 0)
+	if ((rc = s->dContactIndex.ensure((size_t)std::max(C, 1) * sizeof(int), &grew)) != 0 ||
+		(rc = s->dJointIndex.ensure((size_t)std::max(J, 1) * sizeof(int), &grew)) != 0 ||
+		(rc = s->dContactLocal.ensure((size_t)std::max(C, 1) * sizeof(int2), &grew)) != 0 ||
+		(rc = s->dJointLocal.ensure((size_t)std::max(J, 1) * sizeof(int2), &grew)) != 0)
 	{
 		return rc;
 	}
@@ -470,16 +1009,29 @@ int buildOrder(s2amdSolver* s, int solverType)
 	}
 	if (C > 0)
 	{
-		HIP_TRY(hipMemcpyAsync(s->dContactIndex.p, s->contactOrder.data(), (size_t)C * sizeof(int), hipMemcpyHostToDevice, s->stream));
+		HIP_TRY(hipMemcpyAsync(s->dContactIndex.p, cs.order.data(), (size_t)C * sizeof(int), hipMemcpyHostToDevice, s->stream));
+		HIP_TRY(hipMemcpyAsync(s->dContactLocal.p, cs.local.data(), (size_t)C * sizeof(int2), hipMemcpyHostToDevice, s->stream));
 	}
 	if (J > 0)
 	{
-		HIP_TRY(hipMemcpyAsync(s->dJointIndex.p, s->jointOrder.data(), (size_t)J * sizeof(int), hipMemcpyHostToDevice, s->stream));
+		HIP_TRY(hipMemcpyAsync(s->dJointIndex.p, js.order.data(), (size_t)J * sizeof(int), hipMemcpyHostToDevice, s->stream));
+		HIP_TRY(hipMemcpyAsync(s->dJointLocal.p, js.local.data(), (size_t)J * sizeof(int2), hipMemcpyHostToDevice, s->stream));
+	}
+	if (nb > 0)
+	{
+		HIP_TRY(hipMemcpyAsync(s->dBodyFlags.p, flags.data(), (size_t)nb * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
 	}
 	s->cv.contactIndex = (int*)s->dContactIndex.p;
+	s->cv.localBodies = (int2*)s->dContactLocal.p;
 	s->cv.count = C;
 	s->jv.jointIndex = (int*)s->dJointIndex.p;
+	s->jv.localBodies = (int2*)s->dJointLocal.p;
 	s->jv.count = J;
+	if ((rc = uploadGroupTable(s, s->hGroups, s->dGroups)) != 0 || (rc = uploadGroupTable(s, s->hContactTail, s->dContactTail)) != 0 ||
+		(rc = uploadGroupTable(s, s->hJointTail, s->dJointTail)) != 0)
+	{
+		return rc;
+	}
 
 	s->adjValid = false;
 	if (needAdj)
@@ -490,7 +1042,7 @@ int buildOrder(s2amdSolver* s, int solverType)
 		std::vector<int> offsets((size_t)nb + 1, 0), list;
 		for (int k = 0; k < C; ++k)
 		{
-			int a = s->hContactA[s->contactOrder[k]], b = s->hContactB[s->contactOrder[k]];
+			int a = s->hContactA[cs.order[k]], b = s->hContactB[cs.order[k]];
 			if (conflict[a])
 			{
 				offsets[(size_t)a + 1] += 1;
@@ -508,7 +1060,7 @@ int buildOrder(s2amdSolver* s, int solverType)
 		std::vector<int> cursor(offsets.begin(), offsets.end() - 1);
 		for (int k = 0; k < C; ++k)
 		{
-			int a = s->hContactA[s->contactOrder[k]], b = s->hContactB[s->contactOrder[k]];
+			int a = s->hContactA[cs.order[k]], b = s->hContactB[cs.order[k]];
 			if (conflict[a])
 			{
 				list[(size_t)cursor[a]++] = (k << 1) | 0;
@@ -519,11 +1071,8 @@ int buildOrder(s2amdSolver* s, int solverType)
 			}
 		}
 		grew = false;
-		if ((rc = s->dAdjOffsets.ensure(((size_t)nb + 1) * sizeof(int), &grew)) != 0)
-		{
-			return rc;
-		}
-		if ((rc = s->dAdjList.ensure(std::max<size_t>(list.size(), 1) * sizeof(int), &grew)) != 0)
+		if ((rc = s->dAdjOffsets.ensure(((size_t)nb + 1) * sizeof(int), &grew)) != 0 ||
+			(rc = s->dAdjList.ensure(std::max<size_t>(list.size(), 1) * sizeof(int), &grew)) != 0)
 		{
 			return rc;
 		}
@@ -536,223 +1085,74 @@ int buildOrder(s2amdSolver* s, int solverType)
 		{
 			HIP_TRY(hipMemcpyAsync(s->dAdjList.p, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
 		}
-		// the vectors go out of scope after an async copy from pageable memory: hipMemcpyAsync from
-		// pageable host memory stages the data before returning, so this is safe.
 		s->adjValid = true;
 	}
+	// the staging vectors above die with this scope: hipMemcpyAsync from pageable host memory
+	// copies through a staging buffer before it returns, so that is safe
+	HIP_TRY(hipStreamSynchronize(s->stream));
 
 	s->orderSolverClass = cls;
+	s->orderGrouped = grouped;
 	s->structureDirty = false;
+	s->structureGeneration += 1;
 	s->stats.hostPrepMs = (float)(nowMs() - t0);
 	return S2AMD_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
-// drivers: each is the launch sequence of one reference s2Solve_* function
+// plans: each builder records the stage sequence of one reference s2Solve_* function
 // ------------------------------------------------------------------------------------------------
-struct Enqueue
+struct PlanBuilder
 {
-	s2amdSolver* s;
-	hipStream_t st;
-	StepConsts sc;
-	int posSolver;
-	bool profile;
+	StepPlan& p;
+	const StepConsts& sc;
 
-	s2amdContact* wireContacts() const { return (s2amdContact*)s->dContacts.p; }
-	s2amdBody* wireBodies() const { return (s2amdBody*)s->dBodies.p; }
-	s2amdJoint* wireJoints() const { return (s2amdJoint*)s->dJoints.p; }
-
-	int contactColors() const { return (int)s->contactColorOffsets.size() - 1; }
-	int jointColors() const { return (int)s->jointColorOffsets.size() - 1; }
-
-	void count(int n = 1) { s->launchCounter += n; }
-
-	bool inSweep = false;
-	void markSweepBegin()
+	void op(int code, int kind = 0, float h = 0.0f, float inv_h = 0.0f, bool useBias = false, int flag = 0)
 	{
-		s->sweepCounter += 1;
-		inSweep = true;
+		Op o;
+		o.code = code, o.kind = kind, o.useBias = useBias ? 1 : 0, o.flag = flag;
+		o.h = h, o.inv_h = inv_h, o.f0 = 0.0f, o.f1 = 0.0f;
+		p.ops.push_back(o);
 	}
-	void markSweepEnd()
-	{
-		inSweep = false;
-	}
-	void recordSweepEvent()
-	{
-		if (s->sweepEventsUsed == s->sweepEvents.size())
-		{
-			hipEvent_t e;
-			if (hipEventCreate(&e) != hipSuccess)
-			{
-				return;
-			}
-			s->sweepEvents.push_back(e);
-		}
-		(void)hipEventRecord(s->sweepEvents[s->sweepEventsUsed++], st);
-	}
-
-	template <class F> void eachContactColor(F f)
-	{
-		for (int c = 0; c < contactColors(); ++c)
-		{
-			int b = s->contactColorOffsets[c], e = s->contactColorOffsets[(size_t)c + 1];
-			if (e > b)
-			{
-				// profiling: a HIP event pair around every solve-sweep launch (on the launch stream)
-				const bool timed = profile && inSweep;
-				if (timed)
-				{
-					recordSweepEvent();
-				}
-				f(b, e);
-				if (timed)
-				{
-					recordSweepEvent();
-				}
-				count();
-			}
-		}
-	}
-	template <class F> void eachJointColor(F f)
-	{
-		for (int c = 0; c < jointColors(); ++c)
-		{
-			int b = s->jointColorOffsets[c], e = s->jointColorOffsets[(size_t)c + 1];
-			if (e > b)
-			{
-				f(b, e);
-				count();
-			}
-		}
-	}
-
-	// stages
-	void unpack(float h)
-	{
-		launchUnpackBodies(st, s->bv, wireBodies(), (const uint32_t*)s->dBodyFlags.p, sc, h);
-		count();
-	}
-	void pack()
-	{
-		launchPackBodies(st, s->bv, wireBodies());
-		count();
-	}
-	void integrateVelocities()
-	{
-		launchIntegrateVelocities(st, s->bv);
-		count();
-	}
-	void integratePositions(float h)
-	{
-		launchIntegratePositions(st, s->bv, h);
-		count();
-	}
-	void finalizePositions(int dynamicOnly = 0)
-	{
-		launchFinalizePositions(st, s->bv, dynamicOnly);
-		count();
-	}
-	void prepareContacts(int kind, float h, float hertz)
-	{
-		if (s->cv.count > 0)
-		{
-			launchPrepareContacts(st, kind, s->cv, s->bv, wireContacts(), wireBodies(), sc, h, hertz, posSolver);
-			count();
-		}
-	}
-	void prepareJoints(int kind, float h, float hertz, bool warmStart)
-	{
-		if (s->jv.count > 0)
-		{
-			launchPrepareJoints(st, kind, s->jv, s->bv, wireJoints(), wireBodies(), sc, h, hertz, warmStart ? 1 : 0, posSolver);
-			count();
-		}
-	}
-	void warmStartContacts(int kind)
-	{
-		eachContactColor([&](int b, int e) { launchWarmStartContacts(st, kind, s->cv, s->bv, b, e); });
-	}
-	void jointSweep(int kind, float h, float inv_h, bool useBias)
-	{
-		eachJointColor([&](int b, int e) { launchSolveJoints(st, kind, s->jv, s->bv, b, e, sc, h, inv_h, useBias ? 1 : 0); });
-	}
+	void integrateVelocities() { op(OP_INTEGRATE_VEL); }
+	void integratePositions(float h) { op(OP_INTEGRATE_POS, 0, h); }
+	void finalizePositions(int dynamicOnly = 0) { op(OP_FINALIZE, 0, 0.0f, 0.0f, false, dynamicOnly); }
+	void jointSweep(int kind, float h, float inv_h, bool useBias) { op(OP_JOINT_SWEEP, kind, h, inv_h, useBias); }
+	void warmStartContacts(int kind) { op(OP_WARM, kind); }
 	void solveSoft(int kind, float inv_h, bool useBias)
 	{
-		markSweepBegin();
-		if (kind == SOFT_JACOBI)
-		{
-			// the Jacobi pass writes per-constraint deltas, never a body: one launch for all colours
-			if (s->cv.count > 0)
-			{
-				if (profile)
-				{
-					recordSweepEvent();
-				}
-				launchSolveContactsSoft(st, kind, s->cv, s->bv, 0, s->cv.count, inv_h, useBias ? 1 : 0);
-				if (profile)
-				{
-					recordSweepEvent();
-				}
-				count();
-			}
-		}
-		else
-		{
-			eachContactColor([&](int b, int e) { launchSolveContactsSoft(st, kind, s->cv, s->bv, b, e, inv_h, useBias ? 1 : 0); });
-		}
-		markSweepEnd();
+		op(OP_SOLVE_SOFT, kind, 0.0f, inv_h, useBias);
+		p.solveSweeps += 1;
 	}
 	void solveRigid(int kind, float inv_h)
 	{
-		markSweepBegin();
-		eachContactColor([&](int b, int e) { launchSolveContactsRigid(st, kind, s->cv, s->bv, b, e, inv_h); });
-		markSweepEnd();
+		op(OP_SOLVE_RIGID, kind, 0.0f, inv_h);
+		p.solveSweeps += 1;
 	}
 	void solveNGS()
 	{
-		markSweepBegin();
-		eachContactColor([&](int b, int e) { launchSolveContactsNGS(st, s->cv, s->bv, b, e); });
-		markSweepEnd();
+		op(OP_SOLVE_NGS);
+		p.solveSweeps += 1;
 	}
 	void solveSticky(float inv_h, bool useBias)
 	{
-		markSweepBegin();
-		eachContactColor([&](int b, int e) { launchSolveContactsSticky(st, s->cv, s->bv, wireContacts(), b, e, inv_h, useBias ? 1 : 0); });
-		markSweepEnd();
+		op(OP_SOLVE_STICKY, 0, 0.0f, inv_h, useBias);
+		p.solveSweeps += 1;
 	}
-	void storeImpulses(int kind, float scale = 0.0f)
-	{
-		if (s->cv.count > 0)
-		{
-			launchStoreImpulses(st, kind, s->cv, wireContacts(), scale);
-			count();
-		}
-	}
-	void storeJoints()
-	{
-		if (s->jv.count > 0)
-		{
-			launchStoreJoints(st, s->jv, wireJoints());
-			count();
-		}
-	}
-	void jacobiApply()
-	{
-		launchJacobiApply(st, s->bv, s->cv, (const int*)s->dAdjOffsets.p, (const int*)s->dAdjList.p);
-		count();
-	}
+	void prepareContacts(int kind, float h, float hertz) { p.prepContacts = kind, p.prepH = h, p.prepHertz = hertz; }
+	void prepareJoints(int kind, float h, float hertz, bool warm) { p.prepJoints = kind, p.jprepH = h, p.jprepHertz = hertz, p.jprepWarm = warm ? 1 : 0; }
+	void storeImpulses(int kind, float scale = 0.0f) { p.storeKind = kind, p.storeScale = scale; }
 
 	// s2Solve_TGS_Soft (solve_tgs_soft.c:138-280) / s2Solve_SoftStep (solve_soft_step.c:182-311)
 	void solveTgsSoft(bool fixedAnchors)
 	{
-		int substepCount = sc.iterations;
 		float h = sc.h, inv_h = sc.inv_h;
 		float contactHertz = S2_MINF(S2_CONTACT_HERTZ, 0.25f * inv_h);
 		float jointHertz = fixedAnchors ? S2_MINF(S2_JOINT_HERTZ, 0.25f * inv_h) : S2_MINF(S2_JOINT_HERTZ, 0.125f * inv_h);
-		unpack(h);
+		p.unpackH = h;
 		prepareContacts(PREP_SOFT, h, contactHertz);
 		prepareJoints(JPREP_SOFT, h, jointHertz, true);
-		for (int substep = 0; substep < substepCount; ++substep)
+		for (int substep = 0; substep < sc.iterations; ++substep)
 		{
 			integrateVelocities();
 			if (sc.warmStart)
@@ -779,7 +1179,7 @@ struct Enqueue
 		float h = sc.dt, inv_h = sc.inv_dt;
 		float contactHertz = S2_MINF(S2_CONTACT_HERTZ, 0.333f * inv_h);
 		float jointHertz = S2_MINF(S2_JOINT_HERTZ, 0.5f * inv_h);
-		unpack(h);
+		p.unpackH = h;
 		integrateVelocities();
 		prepareContacts(PREP_SOFT, h, contactHertz);
 		if (sc.warmStart)
@@ -799,7 +1199,7 @@ struct Enqueue
 			solveSoft(jacobi ? SOFT_JACOBI : SOFT_PGS, inv_h, true);
 			if (jacobi)
 			{
-				jacobiApply();
+				op(OP_JACOBI_APPLY);
 			}
 		}
 		integratePositions(h);
@@ -809,7 +1209,7 @@ struct Enqueue
 			solveSoft(jacobi ? SOFT_JACOBI : SOFT_PGS, inv_h, false);
 			if (jacobi)
 			{
-				jacobiApply();
+				op(OP_JACOBI_APPLY);
 			}
 		}
 		finalizePositions();
@@ -820,7 +1220,7 @@ struct Enqueue
 	void solvePgs()
 	{
 		float h = sc.dt, inv_h = sc.inv_dt;
-		unpack(h);
+		p.unpackH = h;
 		integrateVelocities();
 		prepareContacts(PREP_PGS, h, 0.0f);
 		if (sc.warmStart)
@@ -842,11 +1242,12 @@ struct Enqueue
 		storeImpulses(STORE_PLAIN);
 	}
 
-	// s2Solve_PGS_NGS: solve_pgs_ngs.c:149-255
+	// s2Solve_PGS_NGS: solve_pgs_ngs.c:149-255.  The reference stores the impulses before the NGS
+	// sweeps (:232); the NGS sweeps never touch an impulse, so storing after them is the same.
 	void solvePgsNgs()
 	{
 		float h = sc.dt, inv_h = sc.inv_dt;
-		unpack(h);
+		p.unpackH = h;
 		integrateVelocities();
 		prepareContacts(PREP_PGS, h, 0.0f);
 		if (sc.warmStart)
@@ -864,20 +1265,20 @@ struct Enqueue
 			solveRigid(RIGID_PGS, inv_h);
 		}
 		integratePositions(h);
-		storeImpulses(STORE_PLAIN); // before the position sweeps: solve_pgs_ngs.c:232
 		for (int iter = 0; iter < sc.extraIterations; ++iter)
 		{
 			jointSweep(JSOLVE_POSITION, h, inv_h, false);
 			solveNGS();
 		}
 		finalizePositions();
+		storeImpulses(STORE_PLAIN);
 	}
 
 	// s2Solve_PGS_NGS_Block: solve_pgs_ngs_block.c:892-963
 	void solveBlock()
 	{
 		float h = sc.dt, inv_h = sc.inv_dt;
-		unpack(h);
+		p.unpackH = h;
 		integrateVelocities();
 		prepareContacts(PREP_BLOCK, h, 0.0f);
 		warmStartContacts(WARM_BLOCK); // always applied: solve_pgs_ngs_block.c:279-319
@@ -889,27 +1290,25 @@ struct Enqueue
 		for (int iter = 0; iter < sc.iterations; ++iter)
 		{
 			jointSweep(JSOLVE_PLAIN, h, inv_h, false);
-			markSweepBegin();
-			eachContactColor([&](int b, int e) { launchBlockSolveVelocity(st, s->cv, s->bv, b, e); });
-			markSweepEnd();
+			op(OP_BLOCK_VEL);
+			p.solveSweeps += 1;
 		}
-		storeImpulses(STORE_BLOCK);
 		integratePositions(h);
 		for (int iter = 0; iter < sc.extraIterations; ++iter)
 		{
-			markSweepBegin();
-			eachContactColor([&](int b, int e) { launchBlockSolvePosition(st, s->cv, s->bv, b, e); });
-			markSweepEnd();
-			jointSweep(JSOLVE_POSITION, h, inv_h, false); // contacts before joints here (:945-957)
+			op(OP_BLOCK_POS); // contacts before joints here (:945-957)
+			p.solveSweeps += 1;
+			jointSweep(JSOLVE_POSITION, h, inv_h, false);
 		}
 		finalizePositions();
+		storeImpulses(STORE_BLOCK);
 	}
 
 	// s2Solve_TGS_NGS: solve_tgs_ngs.c:207-317
 	void solveTgsNgs()
 	{
 		float h = sc.h, inv_h = sc.inv_h;
-		unpack(h);
+		p.unpackH = h;
 		prepareContacts(PREP_TGS, h, 0.0f);
 		prepareJoints(JPREP_PLAIN, h, 0.0f, sc.warmStart != 0);
 		for (int substep = 0; substep < sc.iterations; ++substep)
@@ -934,7 +1333,7 @@ struct Enqueue
 	void solveTgsSticky()
 	{
 		float h = sc.h, inv_h = sc.inv_h;
-		unpack(h);
+		p.unpackH = h;
 		prepareJoints(JPREP_PLAIN, h, 0.0f, false);
 		prepareContacts(PREP_STICKY, h, 0.0f);
 		for (int substep = 0; substep < sc.iterations; ++substep)
@@ -959,108 +1358,330 @@ struct Enqueue
 		int substepCount = sc.iterations;
 		if (substepCount == 0 || sc.dt == 0.0f)
 		{
+			p.earlyOut = true;
 			return;
 		}
 		float h = sc.dt / substepCount;
 		float inv_h = 1.0f / h;
-		unpack(h);
+		p.unpackH = h;
+		p.usesDq0 = true;
 		prepareContacts(PREP_XPBD, h, 0.0f);
 		prepareJoints(JPREP_XPBD, h, 0.0f, false);
 		for (int substep = 0; substep < substepCount; ++substep)
 		{
-			launchXpbdIntegrate(st, s->bv, h);
-			count();
+			op(OP_XPBD_INTEGRATE, 0, h);
 			jointSweep(JSOLVE_XPBD, h, inv_h, false);
-			markSweepBegin();
-			eachContactColor([&](int b, int e) { launchXpbdContactPositions(st, s->cv, s->bv, b, e, h); });
-			markSweepEnd();
-			launchXpbdProject(st, s->bv, inv_h);
-			count();
-			markSweepBegin();
-			eachContactColor([&](int b, int e) { launchXpbdContactVelocities(st, s->cv, s->bv, b, e, h); });
-			markSweepEnd();
+			op(OP_XPBD_POS, 0, h);
+			op(OP_XPBD_PROJECT, 0, 0.0f, inv_h);
+			op(OP_XPBD_VEL, 0, h);
+			p.solveSweeps += 2;
 		}
 		finalizePositions(1);
 		storeImpulses(STORE_SCALED, inv_h);
 	}
+};
 
-	void run(int solverType)
+void buildPlan(s2amdSolver* s, const s2amdStepParams* params)
+{
+	if (s->plan.valid && memcmp(&s->plan.params, params, sizeof(*params)) == 0)
 	{
-		switch (solverType)
+		return;
+	}
+	StepPlan& p = s->plan;
+	p = StepPlan();
+	p.params = *params;
+	p.sc = makeConsts(params);
+	PlanBuilder b{p, p.sc};
+	switch (params->solverType)
+	{
+		case s2amd_solverJacobi:
+			b.solveJacobiOrPgsSoft(true);
+			break;
+		case s2amd_solverPGS:
+			b.solvePgs();
+			break;
+		case s2amd_solverPGS_NGS:
+			b.solvePgsNgs();
+			break;
+		case s2amd_solverPGS_NGS_Block:
+			b.solveBlock();
+			break;
+		case s2amd_solverPGS_Soft:
+			b.solveJacobiOrPgsSoft(false);
+			break;
+		case s2amd_solverSoftStep:
+			b.solveTgsSoft(true);
+			break;
+		case s2amd_solverTGS_Sticky:
+			b.solveTgsSticky();
+			break;
+		case s2amd_solverTGS_Soft:
+			b.solveTgsSoft(false);
+			break;
+		case s2amd_solverTGS_NGS:
+			b.solveTgsNgs();
+			break;
+		case s2amd_solverXPBD:
+			b.solveXpbd();
+			break;
+	}
+	p.valid = true;
+	s->planGeneration += 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// execution of a plan
+// ------------------------------------------------------------------------------------------------
+struct Executor
+{
+	s2amdSolver* s;
+	hipStream_t st;
+	const StepPlan& p;
+	int posSolver;
+	bool profile;
+
+	s2amdContact* wireContacts() const { return (s2amdContact*)s->dContacts.p; }
+	s2amdBody* wireBodies() const { return (s2amdBody*)s->dBodies.p; }
+	s2amdJoint* wireJoints() const { return (s2amdJoint*)s->dJoints.p; }
+	const Op* deviceOps() const { return (const Op*)s->dOps.p; }
+
+	void count(int n = 1) { s->launchCounter += n; }
+
+	void recordEvent()
+	{
+		if (s->sweepEventsUsed == s->sweepEvents.size())
 		{
-			case s2amd_solverJacobi:
-				solveJacobiOrPgsSoft(true);
+			hipEvent_t e;
+			if (hipEventCreate(&e) != hipSuccess)
+			{
+				return;
+			}
+			s->sweepEvents.push_back(e);
+		}
+		(void)hipEventRecord(s->sweepEvents[s->sweepEventsUsed++], st);
+	}
+
+	static bool isSolveSweep(int code)
+	{
+		return code == OP_SOLVE_SOFT || code == OP_SOLVE_RIGID || code == OP_SOLVE_STICKY || code == OP_SOLVE_NGS || code == OP_XPBD_POS ||
+			   code == OP_XPBD_VEL || code == OP_BLOCK_VEL || code == OP_BLOCK_POS;
+	}
+
+	void launchContactBatch(const Op& o, int b, int e)
+	{
+		switch (o.code)
+		{
+			case OP_WARM:
+				launchWarmStartContacts(st, o.kind, s->cv, s->bv, b, e);
 				break;
-			case s2amd_solverPGS:
-				solvePgs();
+			case OP_SOLVE_SOFT:
+				launchSolveContactsSoft(st, o.kind, s->cv, s->bv, b, e, o.inv_h, o.useBias);
 				break;
-			case s2amd_solverPGS_NGS:
-				solvePgsNgs();
+			case OP_SOLVE_RIGID:
+				launchSolveContactsRigid(st, o.kind, s->cv, s->bv, b, e, o.inv_h);
 				break;
-			case s2amd_solverPGS_NGS_Block:
-				solveBlock();
+			case OP_SOLVE_STICKY:
+				launchSolveContactsSticky(st, s->cv, s->bv, wireContacts(), b, e, o.inv_h, o.useBias);
 				break;
-			case s2amd_solverPGS_Soft:
-				solveJacobiOrPgsSoft(false);
+			case OP_SOLVE_NGS:
+				launchSolveContactsNGS(st, s->cv, s->bv, b, e);
 				break;
-			case s2amd_solverSoftStep:
-				solveTgsSoft(true);
+			case OP_XPBD_POS:
+				launchXpbdContactPositions(st, s->cv, s->bv, b, e, o.h);
 				break;
-			case s2amd_solverTGS_Sticky:
-				solveTgsSticky();
+			case OP_XPBD_VEL:
+				launchXpbdContactVelocities(st, s->cv, s->bv, b, e, o.h);
 				break;
-			case s2amd_solverTGS_Soft:
-				solveTgsSoft(false);
+			case OP_BLOCK_VEL:
+				launchBlockSolveVelocity(st, s->cv, s->bv, b, e);
 				break;
-			case s2amd_solverTGS_NGS:
-				solveTgsNgs();
-				break;
-			case s2amd_solverXPBD:
-				solveXpbd();
+			case OP_BLOCK_POS:
+				launchBlockSolvePosition(st, s->cv, s->bv, b, e);
 				break;
 		}
-		if (!(solverType == s2amd_solverXPBD && (sc.iterations == 0 || sc.dt == 0.0f)))
+	}
+
+	// one op of the plan over the GLOBAL part (bodies in HBM): one launch per colour batch
+	void runGlobalOp(int index)
+	{
+		const Op& o = p.ops[(size_t)index];
+		const SweepSet& cs = s->contacts;
+		const SweepSet& js = s->joints;
+		const bool bodies = s->looseBodies > 0;
+		switch (o.code)
 		{
-			storeJoints();
-			pack();
+			case OP_INTEGRATE_VEL:
+				if (bodies)
+				{
+					launchIntegrateVelocities(st, s->bv);
+					count();
+				}
+				return;
+			case OP_INTEGRATE_POS:
+				if (bodies)
+				{
+					launchIntegratePositions(st, s->bv, o.h);
+					count();
+				}
+				return;
+			case OP_FINALIZE:
+				if (bodies)
+				{
+					launchFinalizePositions(st, s->bv, o.flag);
+					count();
+				}
+				return;
+			case OP_XPBD_INTEGRATE:
+				if (bodies)
+				{
+					launchXpbdIntegrate(st, s->bv, o.h);
+					count();
+				}
+				return;
+			case OP_XPBD_PROJECT:
+				if (bodies)
+				{
+					launchXpbdProject(st, s->bv, o.inv_h);
+					count();
+				}
+				return;
+			case OP_JACOBI_APPLY:
+				launchJacobiApply(st, s->bv, s->cv, (const int*)s->dAdjOffsets.p, (const int*)s->dAdjList.p);
+				count();
+				return;
+			case OP_JOINT_SWEEP:
+			{
+				int nb = (int)js.batchOffsets.size() - 1;
+				for (int bi = 0; bi < nb; ++bi)
+				{
+					int b = js.batchOffsets[(size_t)bi], e = js.batchOffsets[(size_t)bi + 1];
+					if (e <= b)
+					{
+						continue;
+					}
+					if (js.hasTail && bi == nb - 1)
+					{
+						launchGroupKernel(st, s->cv, s->jv, s->bv, s->dJointTail.view, deviceOps() + index, 1, p.sc, wireContacts(),
+										  s->dJointTail.maxBodies, 0);
+					}
+					else
+					{
+						launchSolveJoints(st, o.kind, s->jv, s->bv, b, e, p.sc, o.h, o.inv_h, o.useBias);
+					}
+					count();
+				}
+				return;
+			}
+			default:
+				break;
 		}
+		// contact sweeps
+		if (o.code == OP_SOLVE_SOFT && o.kind == SOFT_JACOBI)
+		{
+			// the Jacobi pass writes per-constraint deltas, never a body: one launch for all colours
+			if (cs.globalCount > 0)
+			{
+				if (profile)
+				{
+					recordEvent();
+				}
+				launchSolveContactsSoft(st, o.kind, s->cv, s->bv, 0, cs.globalCount, o.inv_h, o.useBias);
+				if (profile)
+				{
+					recordEvent();
+				}
+				count();
+			}
+			return;
+		}
+		int nb = (int)cs.batchOffsets.size() - 1;
+		for (int bi = 0; bi < nb; ++bi)
+		{
+			int b = cs.batchOffsets[(size_t)bi], e = cs.batchOffsets[(size_t)bi + 1];
+			if (e <= b)
+			{
+				continue;
+			}
+			const bool timed = profile && isSolveSweep(o.code);
+			if (timed)
+			{
+				recordEvent();
+			}
+			if (cs.hasTail && bi == nb - 1)
+			{
+				launchGroupKernel(st, s->cv, s->jv, s->bv, s->dContactTail.view, deviceOps() + index, 1, p.sc, wireContacts(),
+								  s->dContactTail.maxBodies, 0);
+			}
+			else
+			{
+				launchContactBatch(o, b, e);
+			}
+			if (timed)
+			{
+				recordEvent();
+			}
+			count();
+		}
+	}
+
+	void run()
+	{
+		if (p.earlyOut)
+		{
+			return;
+		}
+		// pre: wire -> SoA
+		launchUnpackBodies(st, s->bv, wireBodies(), (const uint32_t*)s->dBodyFlags.p, p.sc, p.unpackH);
+		count();
+		if (p.prepContacts >= 0 && s->cv.count > 0)
+		{
+			launchPrepareContacts(st, p.prepContacts, s->cv, s->bv, wireContacts(), wireBodies(), p.sc, p.prepH, p.prepHertz, posSolver);
+			count();
+		}
+		if (p.prepJoints >= 0 && s->jv.count > 0)
+		{
+			launchPrepareJoints(st, p.prepJoints, s->jv, s->bv, wireJoints(), wireBodies(), p.sc, p.jprepH, p.jprepHertz, p.jprepWarm, posSolver);
+			count();
+		}
+		// LDS groups: the whole op list in one launch
+		if (s->dGroups.view.groupCount > 0)
+		{
+			launchGroupKernel(st, s->cv, s->jv, s->bv, s->dGroups.view, deviceOps(), (int)p.ops.size(), p.sc, wireContacts(), s->dGroups.maxBodies,
+							  p.usesDq0 ? 1 : 0);
+			count();
+		}
+		// global part: op by op
+		const bool anyGlobal = s->looseBodies > 0 || s->contacts.globalCount > 0 || s->joints.globalCount > 0;
+		if (anyGlobal)
+		{
+			for (int i = 0; i < (int)p.ops.size(); ++i)
+			{
+				runGlobalOp(i);
+			}
+		}
+		// post: SoA -> wire
+		if (s->cv.count > 0)
+		{
+			launchStoreImpulses(st, p.storeKind, s->cv, wireContacts(), p.storeScale);
+			count();
+		}
+		if (s->jv.count > 0)
+		{
+			launchStoreJoints(st, s->jv, wireJoints());
+			count();
+		}
+		launchPackBodies(st, s->bv, wireBodies());
+		count();
 	}
 };
 
 } // namespace
-
 
 // ------------------------------------------------------------------------------------------------
 // C-ABI
 // ------------------------------------------------------------------------------------------------
 namespace
 {
-
-StepConsts makeConsts(const s2amdStepParams* p)
-{
-	// src/world.c:170-202
-	StepConsts sc;
-	sc.dt = p->dt;
-	sc.iterations = p->velIters;
-	sc.extraIterations = p->posIters;
-	sc.warmStart = p->warmStart != 0 ? 1 : 0;
-	sc.inv_dt = p->dt > 0.0f ? 1.0f / p->dt : 0.0f;
-	int type = p->solverType;
-	if (type == s2amd_solverXPBD || type == s2amd_solverTGS_Soft || type == s2amd_solverTGS_Sticky || type == s2amd_solverTGS_NGS ||
-		type == s2amd_solverSoftStep)
-	{
-		sc.h = sc.dt / sc.iterations;
-		sc.inv_h = sc.inv_dt * sc.iterations;
-	}
-	else
-	{
-		sc.h = sc.dt;
-		sc.inv_h = sc.inv_dt;
-	}
-	sc.gravityX = p->gravity[0];
-	sc.gravityY = p->gravity[1];
-	return sc;
-}
 
 void destroyGraph(s2amdSolver* s)
 {
@@ -1081,10 +1702,14 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 {
 	bool changed = s->structureDirty || nb != (int)s->hBodyFlags.size() || nc != (int)s->hContactA.size() || nj != (int)s->hJointType.size();
 	std::vector<uint32_t> flags((size_t)nb);
+	s->hBodyLive.assign((size_t)nb, 0);
+	s->hBodyStatic.assign((size_t)nb, 0);
 	for (int i = 0; i < nb; ++i)
 	{
 		const s2amdBody& b = bodies[i];
 		uint32_t f = 0;
+		s->hBodyLive[i] = b.type != S2AMD_BODY_FREE;
+		s->hBodyStatic[i] = b.type == S2AMD_BODY_STATIC;
 		if (b.type != S2AMD_BODY_FREE)
 		{
 			bool massless = b.invMass == 0.0f && b.invI == 0.0f;
@@ -1198,6 +1823,7 @@ int doUpload(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdContact
 	{
 		s->layoutGeneration += 1;
 		s->savedValid = false;
+		s->structureDirty = true; // dBodyFlags may have moved
 	}
 	s->bodyCapacity = nb;
 	s->contactCapacity = nc;
@@ -1209,7 +1835,7 @@ int doUpload(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdContact
 	if (nb > 0)
 	{
 		HIP_TRY(hipMemcpyAsync(s->dBodies.p, bodies, (size_t)nb * sizeof(s2amdBody), hipMemcpyHostToDevice, s->stream));
-		HIP_TRY(hipMemcpyAsync(s->dBodyFlags.p, s->hBodyFlags.data(), (size_t)nb * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+		// dBodyFlags is written by buildStructure (it adds the LDS-group ownership bits)
 	}
 	if (nc > 0)
 	{
@@ -1248,34 +1874,53 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	}
 	HIP_TRY(hipSetDevice(s->device));
 	s->stats = s2amdStepStats{};
-	int rc = buildOrder(s, params->solverType);
+	buildPlan(s, params);
+	int rc = buildStructure(s, params->solverType);
 	if (rc)
 	{
 		return rc;
 	}
+	const StepPlan& plan = s->plan;
+	if (s->opsGeneration != s->planGeneration)
+	{
+		bool grew = false;
+		if ((rc = s->dOps.ensure(std::max<size_t>(plan.ops.size(), 1) * sizeof(Op), &grew)) != 0)
+		{
+			return rc;
+		}
+		if (grew)
+		{
+			s->layoutGeneration += 1;
+		}
+		if (!plan.ops.empty())
+		{
+			HIP_TRY(hipMemcpyAsync(s->dOps.p, plan.ops.data(), plan.ops.size() * sizeof(Op), hipMemcpyHostToDevice, s->stream));
+			HIP_TRY(hipStreamSynchronize(s->stream));
+		}
+		s->opsGeneration = s->planGeneration;
+	}
 
-	Enqueue q{s, s->stream, makeConsts(params), isPositionSolver(params->solverType) ? 1 : 0, s->optProfile != 0};
+	Executor q{s, s->stream, plan, isPositionSolver(params->solverType) ? 1 : 0, s->optProfile != 0};
 	s->launchCounter = 0;
-	s->sweepCounter = 0;
 	s->sweepEventsUsed = 0;
 
-	const bool xpbdEarlyOut = params->solverType == s2amd_solverXPBD && (params->velIters == 0 || params->dt == 0.0f);
+	const bool xpbdEarlyOut = plan.earlyOut;
 	const bool writesConstraintIndex = !xpbdEarlyOut && params->solverType != s2amd_solverPGS_NGS_Block;
 
 	// manifold.constraintIndex (pool-order gather index, -1 for skipped slots)
 	if (writesConstraintIndex && s->contactCapacity > 0)
 	{
-		std::vector<int> gi((size_t)s->contactCapacity, -1);
-		int k = 0;
-		for (int i = 0; i < s->contactCapacity; ++i)
+		if (s->gatherIndexDirty || s->dGatherIndex.bytes < (size_t)s->contactCapacity * sizeof(int))
 		{
-			if (s->hContactPoints[i] > 0)
+			std::vector<int> gi((size_t)s->contactCapacity, -1);
+			int k = 0;
+			for (int i = 0; i < s->contactCapacity; ++i)
 			{
-				gi[i] = k++;
+				if (s->hContactPoints[i] > 0)
+				{
+					gi[i] = k++;
+				}
 			}
-		}
-		if (s->gatherIndexDirty || s->dGatherIndex.bytes < gi.size() * sizeof(int))
-		{
 			bool grew = false;
 			if ((rc = s->dGatherIndex.ensure(gi.size() * sizeof(int), &grew)) != 0)
 			{
@@ -1286,6 +1931,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 				s->layoutGeneration += 1;
 			}
 			HIP_TRY(hipMemcpyAsync(s->dGatherIndex.p, gi.data(), gi.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+			HIP_TRY(hipStreamSynchronize(s->stream));
 			s->gatherIndexDirty = false;
 		}
 	}
@@ -1298,7 +1944,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 																										 (const int*)s->dGatherIndex.p);
 			q.count();
 		}
-		q.run(params->solverType);
+		q.run();
 	};
 
 	bool useGraph = s->optGraph != 0 && !q.profile;
@@ -1307,11 +1953,10 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	{
 		uint64_t key = 1469598103934665603ull;
 		key = fnv(key, params, sizeof(*params));
-		key = fnv(key, &s->layoutGeneration, sizeof(s->layoutGeneration));
-		int sizes[5] = {s->bodyCapacity, s->contactCapacity, s->jointCapacity, s->cv.count, s->jv.count};
+		uint64_t gens[3] = {s->layoutGeneration, s->structureGeneration, s->planGeneration};
+		key = fnv(key, gens, sizeof(gens));
+		int sizes[3] = {s->bodyCapacity, s->contactCapacity, s->jointCapacity};
 		key = fnv(key, sizes, sizeof(sizes));
-		key = fnv(key, s->contactColorOffsets.data(), s->contactColorOffsets.size() * sizeof(int));
-		key = fnv(key, s->jointColorOffsets.data(), s->jointColorOffsets.size() * sizeof(int));
 		if (key == 0)
 		{
 			key = 1;
@@ -1330,12 +1975,10 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 			HIP_TRY(hipGraphInstantiate(&s->graphExec, s->graph, nullptr, nullptr, 0));
 			s->graphKey = key;
 			s->graphLaunches = s->launchCounter;
-			s->graphSweeps = s->sweepCounter;
 		}
 		else
 		{
 			s->launchCounter = s->graphLaunches;
-			s->sweepCounter = s->graphSweeps;
 			s->stats.graphReplayed = 1;
 		}
 		HIP_TRY(hipGraphLaunch(s->graphExec, s->stream));
@@ -1353,10 +1996,11 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	s->stats.deviceMs = ms;
 	s->stats.constraintCount = s->cv.count;
 	s->stats.jointCount = s->jv.count;
-	s->stats.contactColors = (int)s->contactColorOffsets.size() - 1;
-	s->stats.jointColors = (int)s->jointColorOffsets.size() - 1;
-	s->stats.solveSweeps = s->sweepCounter;
+	s->stats.contactColors = (int)s->contacts.colorOffsets.size() - 1;
+	s->stats.jointColors = (int)s->joints.colorOffsets.size() - 1;
+	s->stats.solveSweeps = plan.solveSweeps;
 	s->stats.kernelLaunches = s->launchCounter;
+	s->stats.groupCount = s->dGroups.view.groupCount;
 	if (q.profile)
 	{
 		float total = 0.0f;
@@ -1480,6 +2124,11 @@ int s2amd_create(int device, s2amdSolver** out)
 		delete s;
 		return fail(S2AMD_E_DEVICE, std::string("stream/event creation: ") + hipGetErrorString(e));
 	}
+	if (groupKernelSetup() != 0)
+	{
+		(void)hipGetLastError(); // not fatal: groups are then limited to the default 64 KiB of LDS
+		s->optMaxGroupBodies = 1536;
+	}
 	*out = s;
 	return S2AMD_OK;
 }
@@ -1497,8 +2146,10 @@ void s2amd_destroy(s2amdSolver* s)
 	{
 		(void)hipEventDestroy(e);
 	}
-	DevBuf* bufs[] = {&s->dBodies,	   &s->dContacts,	 &s->dJoints,	   &s->dBodiesSaved, &s->dBodyFlags, &s->soaBodies,	 &s->soaContacts,
-					  &s->soaJoints,   &s->dContactIndex, &s->dJointIndex, &s->dAdjOffsets,	 &s->dAdjList,	 &s->dGatherIndex};
+	DevBuf* bufs[] = {&s->dBodies,		&s->dContacts,	  &s->dJoints,		 &s->dBodiesSaved,	 &s->dBodyFlags,	&s->soaBodies,
+					  &s->soaContacts,	&s->soaJoints,	  &s->dContactIndex, &s->dJointIndex,	 &s->dContactLocal, &s->dJointLocal,
+					  &s->dAdjOffsets,	&s->dAdjList,	  &s->dGatherIndex,	 &s->dOps,			 &s->dGroups.buf,	&s->dContactTail.buf,
+					  &s->dJointTail.buf};
 	for (DevBuf* b : bufs)
 	{
 		b->release();
@@ -1643,7 +2294,7 @@ int s2amd_get_contact_order(s2amdSolver* s, int32_t* order, int32_t orderCapacit
 	{
 		return fail(S2AMD_E_INVALID, "null solver");
 	}
-	return copyOrder(s->contactOrder, s->contactColorOffsets, order, orderCapacity, colorOffsets, colorCapacity, constraintCount, colorCount);
+	return copyOrder(s->contacts.order, s->contacts.colorOffsets, order, orderCapacity, colorOffsets, colorCapacity, constraintCount, colorCount);
 }
 
 int s2amd_get_joint_order(s2amdSolver* s, int32_t* order, int32_t orderCapacity, int32_t* colorOffsets, int32_t colorCapacity, int32_t* jointCount,
@@ -1653,7 +2304,7 @@ int s2amd_get_joint_order(s2amdSolver* s, int32_t* order, int32_t orderCapacity,
 	{
 		return fail(S2AMD_E_INVALID, "null solver");
 	}
-	return copyOrder(s->jointOrder, s->jointColorOffsets, order, orderCapacity, colorOffsets, colorCapacity, jointCount, colorCount);
+	return copyOrder(s->joints.order, s->joints.colorOffsets, order, orderCapacity, colorOffsets, colorCapacity, jointCount, colorCount);
 }
 
 int s2amd_get_stats(s2amdSolver* s, s2amdStepStats* stats)
@@ -1696,6 +2347,21 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	else if (strcmp(key, "profile") == 0)
 	{
 		s->optProfile = value;
+	}
+	else if (strcmp(key, "groups") == 0)
+	{
+		s->optGroups = value;
+		s->structureDirty = true;
+	}
+	else if (strcmp(key, "max_group_bodies") == 0)
+	{
+		s->optMaxGroupBodies = std::max(1, std::min(value, 3072));
+		s->structureDirty = true;
+	}
+	else if (strcmp(key, "pack_group_bodies") == 0)
+	{
+		s->optPackGroupBodies = std::max(1, value);
+		s->structureDirty = true;
 	}
 	else
 	{

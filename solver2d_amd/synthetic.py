@@ -129,3 +129,41 @@ def joint_grid(numi, numk=None):
         j["localOriginAnchorA"] = la
         j["localOriginAnchorB"] = lb
     return bodies, contacts, joints
+
+
+def platform(n, layers=1):
+    """A wide DYNAMIC platform resting on static ground with n unit boxes side by side on top
+    (and `layers` rows of them): the platform touches n boxes, so it forces n colours -- the
+    high-degree-body case (tumbler drum, a crate full of parts) that exercises the sequential tail."""
+    nb = 2 + n * layers
+    bodies = np.zeros(nb, dtype=wire.body_dtype)
+    contacts = np.zeros(1 + n + (n - 1) * layers + n * (layers - 1), dtype=wire.contact_dtype)
+    joints = np.zeros(0, dtype=wire.joint_dtype)
+    half = np.float32(0.5 * n)
+    _static_body(bodies[0], 0.0, -1.0)
+    pm = np.float32(4.0 * half)  # 2*half x 1 box of density 2
+    pi = np.float32(pm * (4.0 * half * half + 1.0) / 12.0)
+    _dynamic_body(bodies[1], 0.0, 0.5, pm, pi)
+    ci = 0
+    _manifold(contacts[ci], 0, 1, (0.0, 1.0), [((float(half), 1.0), (float(half), -0.5)), ((-float(half), 1.0), (-float(half), -0.5))])
+    ci += 1
+    idx = {}
+    bi = 2
+    for r in range(layers):
+        for k in range(n):
+            x = np.float32(k + 0.5) - half
+            y = np.float32(1.5 + r)
+            _dynamic_body(bodies[bi], x, y, BOX_MASS, BOX_I)
+            idx[(r, k)] = bi
+            if r == 0:
+                _manifold(contacts[ci], 1, bi, (0.0, 1.0),
+                          [((float(x) + 0.5, 0.5), (0.5, -0.5)), ((float(x) - 0.5, 0.5), (-0.5, -0.5))])
+            else:
+                _manifold(contacts[ci], idx[(r - 1, k)], bi, (0.0, 1.0), [((0.5, 0.5), (0.5, -0.5)), ((-0.5, 0.5), (-0.5, -0.5))])
+            ci += 1
+            if k > 0:
+                _manifold(contacts[ci], idx[(r, k - 1)], bi, (1.0, 0.0), [((0.5, -0.5), (-0.5, -0.5)), ((0.5, 0.5), (-0.5, 0.5))])
+                ci += 1
+            bi += 1
+    assert ci == len(contacts)
+    return bodies, contacts, joints

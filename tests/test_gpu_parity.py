@@ -56,6 +56,41 @@ def test_golden_inputs_bit_exact(solver, path):
     gpu_vs_oracle(solver, params, pre, os.path.basename(path))
 
 
+@pytest.fixture(scope="module")
+def solver_nogroups():
+    s = hip.Solver(0)
+    s.set_option("groups", 0)
+    yield s
+    s.close()
+
+
+@pytest.mark.parametrize("path", FILES[::3], ids=[os.path.basename(p)[:-4] for p in FILES[::3]])
+def test_golden_inputs_bit_exact_without_groups(solver_nogroups, path):
+    """Same inputs through the global colour-batch path only (LDS groups switched off)."""
+    params, pre, _post = golden_util.load(path)
+    gpu_vs_oracle(solver_nogroups, params, pre, os.path.basename(path))
+    assert solver_nogroups.stats()["groupCount"] == 0
+
+
+def test_small_worlds_run_as_lds_groups(solver):
+    params, pre, _post = golden_util.load([f for f in FILES if "pyramid10_TGS_Soft_step045" in f][0])
+    gpu_vs_oracle(solver, params, pre, "pyramid10 grouped")
+    st = solver.stats()
+    assert st["groupCount"] == 1 and st["kernelLaunches"] <= 8
+
+
+@pytest.mark.parametrize("solver_name", wire.SOLVER_NAMES)
+def test_big_island_with_high_degree_body_uses_global_tail(solver, solver_name):
+    """2,400-body island (too big for an LDS group) whose platform touches 60 boxes: global colour
+    batches + one sequential LDS tail launch per sweep."""
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    pre = synthetic.platform(60, layers=40)
+    params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+    gpu_vs_oracle(solver, params, pre, "platform60x40/%s" % solver_name)
+    st = solver.stats()
+    assert st["groupCount"] == 0 and st["contactColors"] >= 60
+
+
 @pytest.mark.parametrize("solver_name", wire.SOLVER_NAMES)
 def test_synthetic_pyramid40_all_solvers(solver, solver_name):
     vel, pos = common.DEFAULT_ITERS[solver_name]
@@ -96,6 +131,22 @@ def test_joint_grid_pgs_ngs(solver):
     assert solver.stats()["jointCount"] == 2 * 20 * 19
 
 
+@pytest.mark.parametrize("solver_name", wire.SOLVER_NAMES)
+def test_high_degree_body_uses_sequential_tail(solver, solver_name):
+    """One dynamic platform touching 60 boxes: 60+ colours; the high colours run as one sequential
+    tail launch.  Must still equal the oracle in the reported order, bit for bit."""
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    pre = synthetic.platform(60, layers=2)
+    state = common.copy3(pre)
+    for step in range(2):
+        params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+        state = gpu_vs_oracle(solver, params, state, "platform60/%s step %d" % (solver_name, step))
+    st = solver.stats()
+    assert st["contactColors"] >= 60
+    if solver_name != "Jacobi":
+        assert st["groupCount"] == 1 and st["kernelLaunches"] <= 8
+
+
 def test_resident_api_equals_solve(solver):
     pre = synthetic.pyramid(16)
     params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
@@ -121,6 +172,7 @@ def test_graph_replay_equals_eager():
             for _ in range(3):
                 s.step_resident(params)
             assert s.stats()["graphReplayed"] == (1 if graph else 0)
+            assert s.stats()["groupCount"] == 1
             s.download(*st)
             outs.append(st)
     common.compare_exact(outs[0], outs[1], "graph vs eager")

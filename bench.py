@@ -17,7 +17,8 @@ island (weak scaling); the only exchange is the per-step all-gather of per-islan
 Extra objects on the JSON line:
   roofline      dominant kernel (solveContactsSoftKernel<SOFT_TGS>): algorithmic bytes per launch
                 (232 B/constraint-sweep, SURVEY.md 8d x constraints per colour batch) / average
-                launch duration from HIP events recorded on the launch stream around every launch.
+                duration of one launch in steady state (solve sweep launches enqueued back to back and
+                bracketed by HIP events on the launch stream; see s2amd_measure_dominant).
   cpu_baseline  the reference's own s2Solve_TGS_Soft timed on this host (oracle/_ref, kind
                 "reference") or, if that library is absent, the oracle port; 1 core.
 """
@@ -101,12 +102,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # test hooks (tests/test_bench_dist.py): run the N > 1 logic on a box with ONE GPU over gloo
+    backend = os.environ.get("S2AMD_BENCH_BACKEND", "nccl")
+    device_index = 0 if os.environ.get("S2AMD_BENCH_SINGLE_DEVICE") == "1" else local_rank
     if world > 1:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl")
+        torch.cuda.set_device(device_index)
+        dist.init_process_group(backend=backend)
     n_gpus = max(args.gpus, 1)
     if world > 1 and world != n_gpus:
         n_gpus = world
@@ -115,7 +119,7 @@ def main():
     params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, args.vel_iters, args.pos_iters, True)
     sweeps = wire.solve_sweeps_per_step("TGS_Soft", args.vel_iters, args.pos_iters)
 
-    gpu = hip.Solver(local_rank if world > 1 else 0, graph=not args.no_graph)
+    gpu = hip.Solver(device_index if world > 1 else 0, graph=not args.no_graph)
     gpu.upload(*pre)
     gpu.save_bodies()
 
@@ -125,14 +129,15 @@ def main():
         import torch
         nb = len(pre[0])
         pose = torch.zeros((nb, 4), dtype=torch.float32, device="cuda")
-        gathered = torch.zeros((world * nb, 4), dtype=torch.float32, device="cuda")
+        gdev = "cuda" if backend == "nccl" else "cpu"
+        gathered = torch.zeros((world * nb, 4), dtype=torch.float32, device=gdev)
 
     def one_step():
         gpu.restore_bodies()
         gpu.step_resident(params)
         if world > 1:
             gpu.export_poses(pose.data_ptr(), pose.shape[0])
-            dist.all_gather_into_tensor(gathered, pose)
+            dist.all_gather_into_tensor(gathered, pose if backend == "nccl" else pose.cpu())
 
     def sync():
         if world > 1:
@@ -153,12 +158,17 @@ def main():
 
     if world > 1:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # dominant-kernel timing: HIP events on the launch stream around every solve-sweep launch
-    prof_steps = 5
+    # dominant-kernel timing, live, with HIP events on the solver's own stream: the solve sweep's
+    # colour-batch launches enqueued back to back (hipGraph) and bracketed by one event pair
+    avg_launch_us, launches_per_sweep, constraints_per_launch = gpu.measure_dominant(params, repeats=40)
+    avg_launch_s = max(avg_launch_us * 1e-6, 1e-12)
+    achieved = ALGO_BYTES_PER_CONSTRAINT_SWEEP * constraints_per_launch / avg_launch_s / 1e9
+    # per-launch event pairs (eager launches), kept as a cross-check against rocprofv3's per-kernel durations
+    prof_steps = 3
     gpu.set_option("profile", 1)
     kernel_ms, launches, overhead_ms = 0.0, 0, 0.0
     for _ in range(prof_steps):
@@ -169,10 +179,6 @@ def main():
         launches += s2["solveLaunches"]
         overhead_ms = s2["eventPairOverheadMs"]
     gpu.set_option("profile", 0)
-    # event interval around one launch minus the interval of an empty event pair on the same stream
-    avg_launch_s = max((kernel_ms / max(launches, 1) - overhead_ms) / 1e3, 1e-9)
-    constraints_per_launch = C * sweeps * prof_steps / max(launches, 1)
-    achieved = ALGO_BYTES_PER_CONSTRAINT_SWEEP * constraints_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
 
     if rank == 0:
         value = C * sweeps * args.steps * n_gpus / elapsed
@@ -202,8 +208,9 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "kernel": "solveContactsSoftKernel<SOFT_TGS>",
-                "avg_launch_us": avg_launch_s * 1e6, "event_pair_overhead_us": overhead_ms * 1e3,
-                "launches_per_step": launches / prof_steps,
+                "avg_launch_us": avg_launch_us, "launches_per_step": launches_per_sweep * sweeps,
+                "constraints_per_launch": constraints_per_launch,
+                "eager_event_pair_us_per_launch": 1e3 * kernel_ms / max(launches, 1), "empty_event_pair_us": overhead_ms * 1e3,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CONSTRAINT_SWEEP * constraints_per_launch,
             },
         }

@@ -157,6 +157,7 @@ typedef struct s2amdStepStats
 	int32_t solveLaunches;     /* contact solve-sweep kernel launches timed into solveKernelMs (profiling only) */
 	float eventPairOverheadMs; /* elapsed time of an EMPTY HIP event pair on the stream (profiling only): subtract per launch */
 	int32_t groupCount;        /* LDS groups (small islands advanced whole-step by one workgroup each) */
+	int32_t messagePassing;    /* 1 when the big-island sweeps read bodies from per-constraint copies (no gather) */
 } s2amdStepStats;
 
 typedef struct s2amdSolver s2amdSolver;
@@ -202,8 +203,16 @@ int s2amd_get_contact_order(s2amdSolver* solver, int32_t* order, int32_t orderCa
 int s2amd_get_joint_order(s2amdSolver* solver, int32_t* order, int32_t orderCapacity, int32_t* colorOffsets,
 						  int32_t colorCapacity, int32_t* jointCount, int32_t* colorCount);
 int s2amd_get_stats(s2amdSolver* solver, s2amdStepStats* stats);
+/* Live timing of the dominant kernel on the solver's own stream: the first contact solve sweep of
+ * the step plan (all its colour-batch launches) is enqueued `repeats` times back to back in one
+ * hipGraph and bracketed by a HIP event pair; *usPerLaunch = elapsed / launches, i.e. the time one
+ * launch occupies in steady state (kernel + dependent-kernel boundary).  When every constraint lives
+ * in an LDS group the whole-step group kernel is timed instead (launchesPerSweep = 1).  The resident
+ * world is advanced by the extra sweeps: call it after the timed region. */
+int s2amd_measure_dominant(s2amdSolver* solver, const s2amdStepParams* params, int32_t repeats, float* usPerLaunch,
+						   int32_t* launchesPerSweep, int32_t* constraintsPerLaunch);
 /* option keys: "graph" (0/1 hipGraph replay), "profile" (0/1 per-sweep HIP events),
- * "groups" (0/1 LDS group path for small islands), "max_group_bodies", "pack_group_bodies" */
+ * "groups" (0/1 LDS group path for small islands), "message" (0/1 message-passing sweeps), "max_group_bodies", "pack_group_bodies" */
 int s2amd_set_option(s2amdSolver* solver, const char* key, int32_t value);
 
 #ifdef __cplusplus

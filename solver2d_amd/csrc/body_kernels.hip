@@ -106,6 +106,82 @@ __global__ __launch_bounds__(S2_BLOCK) void xpbdProjectKernel(BodyView b, float 
 	xpbdProjectOne(gb, b.dq0, i, b, i, inv_h);
 }
 
+// ---- message-passing variants: a body that has per-constraint copies keeps its CURRENT velocity in
+// copy firstSlot[i] (the last toucher of a sweep writes there) and its pose in every copy ----
+S2_DEV void scatterPose(const MsgView& m, int i, float4 d)
+{
+	for (int e = m.slotOffsets[i]; e < m.slotOffsets[i + 1]; ++e)
+	{
+		m.dq[m.slotList[e]] = d;
+	}
+}
+
+__global__ __launch_bounds__(S2_BLOCK) void integrateVelocitiesMsgKernel(BodyView b, MsgView m)
+{
+	S2_BODY_KERNEL_HEAD
+	int f = m.firstSlot[i];
+	if (f < 0)
+	{
+		integrateVelocitiesOne(gb, i, b, i);
+		return;
+	}
+	GlobalBodies sb{m.vel, m.dq};
+	integrateVelocitiesOne(sb, f, b, i);
+}
+
+__global__ __launch_bounds__(S2_BLOCK) void integratePositionsMsgKernel(BodyView b, MsgView m, float h)
+{
+	S2_BODY_KERNEL_HEAD
+	int f = m.firstSlot[i];
+	if (f < 0)
+	{
+		integratePositionsOne(gb, i, b, i, h);
+		return;
+	}
+	if ((b.flags[i] & S2F_MOVES) == 0)
+	{
+		return;
+	}
+	GlobalBodies sb{m.vel, m.dq};
+	integratePositionsOne(sb, f, b, i, h);
+	scatterPose(m, i, m.dq[f]);
+}
+
+__global__ __launch_bounds__(S2_BLOCK) void finalizePositionsMsgKernel(BodyView b, MsgView m, int dynamicOnly)
+{
+	S2_BODY_KERNEL_HEAD
+	int f = m.firstSlot[i];
+	if (f < 0)
+	{
+		finalizePositionsOne(gb, i, b, i, dynamicOnly, true);
+		return;
+	}
+	uint32_t need = dynamicOnly ? S2F_DYNAMIC : S2F_MOVES;
+	if ((b.flags[i] & need) == 0)
+	{
+		return;
+	}
+	GlobalBodies sb{m.vel, m.dq};
+	finalizePositionsOne(sb, f, b, i, dynamicOnly, true);
+	scatterPose(m, i, m.dq[f]);
+}
+
+// copies -> body arrays at the end of the step
+__global__ __launch_bounds__(S2_BLOCK) void gatherMessageSlotsKernel(BodyView b, MsgView m)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= b.capacity || (b.flags[i] & S2F_IN_GROUP) != 0)
+	{
+		return;
+	}
+	int f = m.firstSlot[i];
+	if (f >= 0)
+	{
+		b.vel[i] = m.vel[f];
+		b.dq[i] = m.dq[f];
+	}
+}
+
 // Jacobi: the reference adds every constraint's velocity delta into body->dv / dw in constraint
 // order and applies the sum afterwards (solve_jacobi.c:126-130, :233-245).  Here each body walks
 // its incidence list (ascending constraint index) and performs the same additions in the same
@@ -217,5 +293,34 @@ void launchExportPoses(hipStream_t s, const s2amdBody* wire, int n, void* out)
 	if (n > 0)
 	{
 		exportPosesKernel<<<gridFor(n), dim3(S2_BLOCK), 0, s>>>(wire, n, (float4*)out);
+	}
+}
+
+void launchIntegrateVelocitiesMsg(hipStream_t s, const BodyView& b, const MsgView& m)
+{
+	if (b.capacity > 0)
+	{
+		integrateVelocitiesMsgKernel<<<gridFor(b.capacity), dim3(S2_BLOCK), 0, s>>>(b, m);
+	}
+}
+void launchIntegratePositionsMsg(hipStream_t s, const BodyView& b, const MsgView& m, float h)
+{
+	if (b.capacity > 0)
+	{
+		integratePositionsMsgKernel<<<gridFor(b.capacity), dim3(S2_BLOCK), 0, s>>>(b, m, h);
+	}
+}
+void launchFinalizePositionsMsg(hipStream_t s, const BodyView& b, const MsgView& m, int dynamicOnly)
+{
+	if (b.capacity > 0)
+	{
+		finalizePositionsMsgKernel<<<gridFor(b.capacity), dim3(S2_BLOCK), 0, s>>>(b, m, dynamicOnly);
+	}
+}
+void launchGatherMessageSlots(hipStream_t s, const BodyView& b, const MsgView& m)
+{
+	if (b.capacity > 0)
+	{
+		gatherMessageSlotsKernel<<<gridFor(b.capacity), dim3(S2_BLOCK), 0, s>>>(b, m);
 	}
 }

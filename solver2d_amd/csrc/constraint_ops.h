@@ -1,7 +1,7 @@
 // Per-constraint device functions ("One" = one constraint of one sweep), shared by the global
 // colour-batch kernels (contact_kernels.hip, joint_kernels.hip: bodies gathered from HBM/L2) and by
 // the group kernel (group_kernel.hip: bodies of a small island, or of the sequential tail, staged in
-// LDS).  B is the body accessor: BA::kLocal selects global or group-local body indices, getVel/setVel
+// LDS).  B is the body accessor: BA::kMode selects how body indices are obtained, getVel/setVel
 // and getDq/setDq read and write the two 16-byte body records.
 #pragma once
 
@@ -10,9 +10,14 @@
 
 #include "solver2d_amd.h"
 
+// index modes of a body accessor
+#define S2_IDX_GLOBAL 0	 // body-pool slots, gathered through c.bodies[k]
+#define S2_IDX_LOCAL 1	 // group-local slots (LDS), gathered through c.localBodies[k]
+#define S2_IDX_MESSAGE 2 // per-constraint copies: side A of constraint k is record 2k, side B is 2k+1
+
 template <bool LOCAL> struct BodiesT
 {
-	static constexpr bool kLocal = LOCAL;
+	static constexpr int kMode = LOCAL ? S2_IDX_LOCAL : S2_IDX_GLOBAL;
 	float4* vel;
 	float4* dq;
 	S2_DEV float4 getVel(int i) const { return vel[i]; }
@@ -20,8 +25,37 @@ template <bool LOCAL> struct BodiesT
 	S2_DEV float4 getDq(int i) const { return dq[i]; }
 	S2_DEV void setDq(int i, float4 v) const { dq[i] = v; }
 };
+// Keeps already-issued loads from being sunk into later branches by the compiler: the value must be
+// in its registers here.  Placed after the LAST load of a group so all of them share one wait.
+S2_DEV void pin(float4& v)
+{
+	asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+}
+S2_DEV void pin(float2& v)
+{
+	asm volatile("" : "+v"(v.x), "+v"(v.y));
+}
+
 typedef BodiesT<false> GlobalBodies; // indices are body-pool slots, arrays are the HBM SoA
 typedef BodiesT<true> LdsBodies;	 // indices are group-local slots, arrays live in LDS
+
+// "Message passing" accessor for the big-island path.  Every constraint side owns a private copy of
+// its body's two records, so a sweep kernel reads them at a computed address (no index load, no
+// dependent gather: one memory round trip instead of two) and writes the updated velocity into the
+// copy of the NEXT constraint that will touch that body (next[] is cyclic over the body's touches
+// in sweep order, so the chain carries over from sweep to sweep).  Poses only change in the body
+// kernels, which write them to every copy of the body.
+struct MsgBodies
+{
+	static constexpr int kMode = S2_IDX_MESSAGE;
+	float4* vel;	 // [2C]
+	float4* dq;		 // [2C]
+	const int* next; // [2C]
+	S2_DEV float4 getVel(int i) const { return vel[i]; }
+	S2_DEV void setVel(int i, float4 v) const { vel[next[i]] = v; }
+	S2_DEV float4 getDq(int i) const { return dq[i]; }
+	S2_DEV void setDq(int i, float4 v) const { dq[next[i]] = v; } // not used: position sweeps never run in this mode
+};
 
 struct CHeader
 {
@@ -33,10 +67,10 @@ struct CHeader
 	bool writeA, writeB;
 };
 
-template <bool LOCAL> S2_DEV CHeader loadHeader(const ContactView& c, int k)
+template <int MODE> S2_DEV CHeader loadHeader(const ContactView& c, int k)
 {
 	CHeader h;
-	int2 b = LOCAL ? c.localBodies[k] : c.bodies[k];
+	int2 b = MODE == S2_IDX_MESSAGE ? make_int2(2 * k, 2 * k + 1) : (MODE == S2_IDX_LOCAL ? c.localBodies[k] : c.bodies[k]);
 	float4 m = c.mass[k];
 	float4 nf = c.nf[k];
 	h.ia = b.x, h.ib = b.y;
@@ -94,13 +128,23 @@ template <class BA> S2_DEV void storePose(const BA& b, int i, V2 dc, Rot q)
 template <int KIND, class BA>
 S2_DEV void warmStartContactsOne(const ContactView& c, const BA& b, int k)
 {
-	CHeader h = loadHeader<BA::kLocal>(c, k);
+	CHeader h = loadHeader<BA::kMode>(c, k);
 	int pointCount = h.pointCount;
 	V2 tangent = rightPerp(h.normal);
 	if (KIND == WARM_BLOCK)
 	{
 		pointCount = (int)asBits(c.blockK[k].w);
 		tangent = crossVS(h.normal, 1.0f);
+	}
+	// every load of the constraint is issued before the first use: slot 1 of a one-point constraint is
+	// a valid, zero-filled record (prepareContactsKernel), so the loads need no guard
+	float4 arm[2];
+	float2 imp[2];
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		arm[j] = KIND == WARM_CURRENT ? c.anchor[j][k] : c.r0[j][k];
+		imp[j] = c.impulse[j][k];
 	}
 	BodyVel A = loadVel(b, h.ia), B = loadVel(b, h.ib);
 	V2 vA = A.v, vB = B.v;
@@ -111,6 +155,12 @@ S2_DEV void warmStartContactsOne(const ContactView& c, const BA& b, int k)
 		qA = loadPose(b, h.ia).q;
 		qB = loadPose(b, h.ib).q;
 	}
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		pin(arm[j]);
+		pin(imp[j]);
+	}
 
 #pragma unroll
 	for (int j = 0; j < 2; ++j)
@@ -120,18 +170,15 @@ S2_DEV void warmStartContactsOne(const ContactView& c, const BA& b, int k)
 			V2 rA, rB;
 			if (KIND == WARM_CURRENT)
 			{
-				float4 an = c.anchor[j][k];
-				rA = rotate(qA, v2(an.x, an.y));
-				rB = rotate(qB, v2(an.z, an.w));
+				rA = rotate(qA, v2(arm[j].x, arm[j].y));
+				rB = rotate(qB, v2(arm[j].z, arm[j].w));
 			}
 			else
 			{
-				float4 r0 = c.r0[j][k];
-				rA = v2(r0.x, r0.y);
-				rB = v2(r0.z, r0.w);
+				rA = v2(arm[j].x, arm[j].y);
+				rB = v2(arm[j].z, arm[j].w);
 			}
-			float2 imp = c.impulse[j][k];
-			V2 P = add(mulSV(imp.x, h.normal), mulSV(imp.y, tangent));
+			V2 P = add(mulSV(imp[j].x, h.normal), mulSV(imp[j].y, tangent));
 			wA -= h.iA * cross(rA, P);
 			vA = mulAdd(vA, -h.mA, P);
 			wB += h.iB * cross(rB, P);
@@ -158,9 +205,28 @@ S2_DEV void warmStartContactsOne(const ContactView& c, const BA& b, int k)
 template <int KIND, class BA>
 S2_DEV void solveContactsSoftOne(const ContactView& c, const BA& b, float inv_h, int useBias, int k)
 {
-	CHeader h = loadHeader<BA::kLocal>(c, k);
+	CHeader h = loadHeader<BA::kMode>(c, k);
 	const float biasCap = (KIND == SOFT_TGS || KIND == SOFT_JACOBI) ? -S2_MAX_BAUMGARTE_VELOCITY : -0.5f * S2_MAX_BAUMGARTE_VELOCITY;
 
+	// all loads first (one memory round trip for the constraint, one for the bodies); slot 1 of a
+	// one-point constraint is a valid zero record, so no guard is needed
+	float4 an[2], r0[2], par[2], sf[2];
+	float2 imp[2];
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		if (KIND == SOFT_TGS || KIND == SOFT_FIXED)
+		{
+			an[j] = c.anchor[j][k];
+		}
+		if (KIND != SOFT_TGS)
+		{
+			r0[j] = c.r0[j][k];
+		}
+		par[j] = c.param[j][k];
+		sf[j] = c.soft[j][k];
+		imp[j] = c.impulse[j][k];
+	}
 	BodyVel A = loadVel(b, h.ia), B = loadVel(b, h.ib);
 	V2 vA = A.v, vB = B.v;
 	float wA = A.w, wB = B.w;
@@ -170,6 +236,21 @@ S2_DEV void solveContactsSoftOne(const ContactView& c, const BA& b, float inv_h,
 	{
 		BodyPose pA = loadPose(b, h.ia), pB = loadPose(b, h.ib);
 		dcA = pA.dc, qA = pA.q, dcB = pB.dc, qB = pB.q;
+	}
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		if (KIND == SOFT_TGS || KIND == SOFT_FIXED)
+		{
+			pin(an[j]);
+		}
+		if (KIND != SOFT_TGS)
+		{
+			pin(r0[j]);
+		}
+		pin(par[j]);
+		pin(sf[j]);
+		pin(imp[j]);
 	}
 	V2 normal = h.normal;
 	V2 tangent = rightPerp(normal);
@@ -183,34 +264,27 @@ S2_DEV void solveContactsSoftOne(const ContactView& c, const BA& b, float inv_h,
 	{
 		if (j < h.pointCount)
 		{
-			float4 par = c.param[j][k];
-			float4 sf = c.soft[j][k];
-			float2 imp = c.impulse[j][k];
 			V2 rA, rB;
 			float s;
 			if (KIND == SOFT_TGS)
 			{
-				float4 an = c.anchor[j][k];
-				rA = rotate(qA, v2(an.x, an.y));
-				rB = rotate(qB, v2(an.z, an.w));
+				rA = rotate(qA, v2(an[j].x, an[j].y));
+				rB = rotate(qB, v2(an[j].z, an[j].w));
 				V2 ds = add(sub(dcB, dcA), sub(rB, rA));
-				s = dot(ds, normal) + par.x;
+				s = dot(ds, normal) + par[j].x;
 			}
 			else if (KIND == SOFT_FIXED)
 			{
-				float4 an = c.anchor[j][k];
-				float4 r0 = c.r0[j][k];
-				V2 ds = add(sub(dcB, dcA), sub(rotate(qB, v2(an.z, an.w)), rotate(qA, v2(an.x, an.y))));
-				s = dot(ds, normal) + par.x;
-				rA = v2(r0.x, r0.y);
-				rB = v2(r0.z, r0.w);
+				V2 ds = add(sub(dcB, dcA), sub(rotate(qB, v2(an[j].z, an[j].w)), rotate(qA, v2(an[j].x, an[j].y))));
+				s = dot(ds, normal) + par[j].x;
+				rA = v2(r0[j].x, r0[j].y);
+				rB = v2(r0[j].z, r0[j].w);
 			}
 			else
 			{
-				float4 r0 = c.r0[j][k];
-				s = par.w;
-				rA = v2(r0.x, r0.y);
-				rB = v2(r0.z, r0.w);
+				s = par[j].w;
+				rA = v2(r0[j].x, r0[j].y);
+				rB = v2(r0[j].z, r0[j].w);
 			}
 			rAj[j] = rA, rBj[j] = rB;
 
@@ -221,20 +295,20 @@ S2_DEV void solveContactsSoftOne(const ContactView& c, const BA& b, float inv_h,
 			}
 			else if (useBias)
 			{
-				bias = S2_MAXF(sf.x * s, biasCap);
-				massScale = sf.y;
-				impulseScale = sf.z;
+				bias = S2_MAXF(sf[j].x * s, biasCap);
+				massScale = sf[j].y;
+				impulseScale = sf[j].z;
 			}
 
 			V2 vrB = add(vB, crossSV(wB, rB));
 			V2 vrA = add(vA, crossSV(wA, rA));
 			float vn = dot(sub(vrB, vrA), normal);
 
-			float impulse = -par.y * massScale * (vn + bias) - impulseScale * imp.x;
-			float newImpulse = S2_MAXF(imp.x + impulse, 0.0f);
-			impulse = newImpulse - imp.x;
+			float impulse = -par[j].y * massScale * (vn + bias) - impulseScale * imp[j].x;
+			float newImpulse = S2_MAXF(imp[j].x + impulse, 0.0f);
+			impulse = newImpulse - imp[j].x;
 			nImp[j] = newImpulse;
-			tImp[j] = imp.y;
+			tImp[j] = imp[j].y;
 
 			V2 P = mulSV(impulse, normal);
 			vA = mulSub(vA, mA, P);
@@ -249,7 +323,7 @@ S2_DEV void solveContactsSoftOne(const ContactView& c, const BA& b, float inv_h,
 	{
 		if (j < h.pointCount)
 		{
-			float tangentMass = c.param[j][k].z;
+			float tangentMass = par[j].z;
 			V2 rA = rAj[j], rB = rBj[j];
 			V2 vrB = add(vB, crossSV(wB, rB));
 			V2 vrA = add(vA, crossSV(wA, rA));
@@ -297,7 +371,7 @@ S2_DEV void solveContactsSoftOne(const ContactView& c, const BA& b, float inv_h,
 template <int KIND, class BA>
 S2_DEV void solveContactsRigidOne(const ContactView& c, const BA& b, float inv_h, int k)
 {
-	CHeader h = loadHeader<BA::kLocal>(c, k);
+	CHeader h = loadHeader<BA::kMode>(c, k);
 	BodyVel A = loadVel(b, h.ia), B = loadVel(b, h.ib);
 	V2 vA = A.v, vB = B.v;
 	float wA = A.w, wB = B.w;
@@ -480,7 +554,7 @@ S2_DEV void solveContactsRigidOne(const ContactView& c, const BA& b, float inv_h
 template <class BA>
 S2_DEV void solveContactsStickyOne(const ContactView& c, const BA& b, s2amdContact* wire, float inv_h, int useBias, int k)
 {
-	CHeader h = loadHeader<BA::kLocal>(c, k);
+	CHeader h = loadHeader<BA::kMode>(c, k);
 	const float contactBaumgarte = 0.8f;
 	const float frictionBaumgarte = 0.5f;
 	BodyVel A = loadVel(b, h.ia), B = loadVel(b, h.ib);
@@ -591,7 +665,7 @@ S2_DEV void solveContactsStickyOne(const ContactView& c, const BA& b, s2amdConta
 template <class BA>
 S2_DEV void solveContactsNGSOne(const ContactView& c, const BA& b, int k)
 {
-	CHeader h = loadHeader<BA::kLocal>(c, k);
+	CHeader h = loadHeader<BA::kMode>(c, k);
 	BodyPose pA = loadPose(b, h.ia), pB = loadPose(b, h.ib);
 	V2 dcA = pA.dc, dcB = pB.dc;
 	Rot qA = pA.q, qB = pB.q;
@@ -639,7 +713,7 @@ S2_DEV void solveContactsNGSOne(const ContactView& c, const BA& b, int k)
 template <class BA>
 S2_DEV void xpbdContactPositionsOne(const ContactView& c, const BA& b, float hh, int k)
 {
-	CHeader h = loadHeader<BA::kLocal>(c, k);
+	CHeader h = loadHeader<BA::kMode>(c, k);
 	const float baseCompliance = 0.0f;
 	float mA = h.mA, iA = h.iA, mB = h.mB, iB = h.iB;
 	float compliance = (mA == 0.0f || mB == 0.0f) ? 0.25f * baseCompliance : baseCompliance;
@@ -734,7 +808,7 @@ S2_DEV void xpbdContactPositionsOne(const ContactView& c, const BA& b, float hh,
 template <class BA>
 S2_DEV void xpbdContactVelocitiesOne(const ContactView& c, const BA& b, float hh, int k)
 {
-	CHeader h = loadHeader<BA::kLocal>(c, k);
+	CHeader h = loadHeader<BA::kMode>(c, k);
 	float inv_h = hh > 0.0f ? 1.0f / hh : 0.0f;
 	float mA = h.mA, iA = h.iA, mB = h.mB, iB = h.iB;
 	BodyVel A = loadVel(b, h.ia), B = loadVel(b, h.ib);
@@ -836,7 +910,7 @@ S2_DEV void xpbdContactVelocitiesOne(const ContactView& c, const BA& b, float hh
 template <class BA>
 S2_DEV void blockSolveVelocityOne(const ContactView& c, const BA& b, int k)
 {
-	CHeader h = loadHeader<BA::kLocal>(c, k);
+	CHeader h = loadHeader<BA::kMode>(c, k);
 	float4 K4 = c.blockK[k];
 	int pointCount = (int)asBits(K4.w);
 	BodyVel A = loadVel(b, h.ia), B = loadVel(b, h.ib);
@@ -1002,7 +1076,7 @@ S2_DEV void blockSolveVelocityOne(const ContactView& c, const BA& b, int k)
 template <class BA>
 S2_DEV void blockSolvePositionOne(const ContactView& c, const BA& b, int k)
 {
-	CHeader h = loadHeader<BA::kLocal>(c, k);
+	CHeader h = loadHeader<BA::kMode>(c, k);
 	int pointCount = (int)asBits(c.blockK[k].w);
 	const float slop = S2_LINEAR_SLOP;
 	float mA = h.mA, iA = h.iA, mB = h.mB, iB = h.iB;
@@ -1133,10 +1207,10 @@ S2_DEV Rot loadRotOnly(const BodyView& b, int i)
 	return q;
 }
 
-template <bool LOCAL> S2_DEV JState loadJoint(const JointView& j, int k)
+template <int MODE> S2_DEV JState loadJoint(const JointView& j, int k)
 {
 	JState s;
-	int2 bd = LOCAL ? j.localBodies[k] : j.bodies[k];
+	int2 bd = MODE == S2_IDX_LOCAL ? j.localBodies[k] : j.bodies[k];
 	float4 fr = j.frame[k], ms = j.mass[k], pv = j.pivot[k], sf = j.soft[k], ax = j.axial[k], lm = j.limits[k], mc = j.misc[k];
 	float2 cd = j.centerDiff0[k], im = j.impulse[k];
 	s.ia = bd.x, s.ib = bd.y;
@@ -1238,7 +1312,7 @@ S2_DEV void revoluteMotor(JState& s, float h, float& wA, float& wB)
 template <int KIND, class BA>
 S2_DEV void solveJointsOne(const JointView& jv, const BA& b, const StepConsts& sc, float h, float inv_h, int useBias, int k)
 {
-	JState s = loadJoint<BA::kLocal>(jv, k);
+	JState s = loadJoint<BA::kMode>(jv, k);
 
 	if (s.flags & S2J_MOUSE)
 	{

@@ -5,7 +5,7 @@
 // Gauss-Seidel pass over the same constraints in the same order.  The per-constraint arithmetic
 // lives in constraint_ops.h (shared with the LDS group kernel).
 
-#include "constraint_ops.h"
+#include "body_ops.h"
 
 #define S2_BLOCK 256
 
@@ -295,6 +295,119 @@ __global__ __launch_bounds__(S2_BLOCK) void storeImpulsesKernel(ContactView c, s
 		CALL;                                                                                                                    \
 	}
 
+// Body-centric warm start.  s2WarmStartContacts (solve_common.c:276-326) only ADDS terms that do not
+// depend on any velocity -- P comes from the stored impulses, the lever arm from the body's own
+// rotation -- so the value a body ends up with is v + t1 + t2 + ... over its incident contact points
+// in sweep order.  One thread per body walks its incidence list (ascending sweep position) and
+// performs exactly those additions in exactly that order: bit-identical to the coloured sweep, but
+// ONE launch instead of one per colour, with no write conflicts at all.  Optionally preceded by
+// s2IntegrateVelocities for the same body (the two stages are adjacent in every sub-stepping driver).
+template <int KIND>
+__global__ __launch_bounds__(S2_BLOCK) void warmStartBodiesKernel(ContactView c, BodyView b, const int* adjOffsets, const int* adjList,
+																   int integrateFirst)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= b.capacity || (b.flags[i] & S2F_IN_GROUP) != 0)
+	{
+		return;
+	}
+	GlobalBodies gb{b.vel, b.dq};
+	if (integrateFirst)
+	{
+		integrateVelocitiesOne(gb, i, b, i);
+	}
+	int e0 = adjOffsets[i], e1 = adjOffsets[i + 1];
+	if (e0 == e1)
+	{
+		return;
+	}
+	float4 v4 = b.vel[i];
+	V2 v = v2(v4.x, v4.y);
+	float w = v4.z;
+	Rot q;
+	if (KIND == WARM_CURRENT)
+	{
+		float4 d = b.dq[i];
+		q.s = d.z, q.c = d.w;
+	}
+	for (int e = e0; e < e1; ++e)
+	{
+		int key = adjList[e];
+		int k = key >> 1;
+		bool sideB = (key & 1) != 0;
+		float4 nf = c.nf[k];
+		float4 ms = c.mass[k];
+		V2 normal = v2(nf.x, nf.y);
+		V2 tangent = KIND == WARM_BLOCK ? crossVS(normal, 1.0f) : rightPerp(normal);
+		int pointCount = KIND == WARM_BLOCK ? (int)asBits(c.blockK[k].w) : (int)(asBits(nf.w) & 0xffu);
+		float m = sideB ? ms.z : ms.x;
+		float iv = sideB ? ms.w : ms.y;
+		for (int j = 0; j < pointCount; ++j)
+		{
+			float4 arm = KIND == WARM_CURRENT ? c.anchor[j][k] : c.r0[j][k];
+			float2 imp = c.impulse[j][k];
+			V2 l = sideB ? v2(arm.z, arm.w) : v2(arm.x, arm.y);
+			V2 r = KIND == WARM_CURRENT ? rotate(q, l) : l;
+			V2 P = add(mulSV(imp.x, normal), mulSV(imp.y, tangent));
+			if (sideB)
+			{
+				w += iv * cross(r, P);
+				v = mulAdd(v, m, P);
+			}
+			else
+			{
+				w -= iv * cross(r, P);
+				v = mulAdd(v, -m, P);
+			}
+		}
+	}
+	b.vel[i] = make_float4(v.x, v.y, w, 0.0f);
+}
+
+// message-passing variants of the velocity-level sweeps (bodies read from per-constraint copies)
+#define S2_SWEEP_BODY_MSG(CALL)                                                                                                  \
+	int k = begin + blockIdx.x * blockDim.x + threadIdx.x;                                                                       \
+	if (k < end)                                                                                                                 \
+	{                                                                                                                            \
+		MsgBodies gb{m.vel, m.dq, m.next};                                                                                       \
+		CALL;                                                                                                                    \
+	}
+
+template <int KIND> __global__ __launch_bounds__(S2_BLOCK) void warmStartContactsMsgKernel(ContactView c, MsgView m, int begin, int end)
+{
+	S2_SWEEP_BODY_MSG(warmStartContactsOne<KIND>(c, gb, k))
+}
+template <int KIND>
+__global__ __launch_bounds__(S2_BLOCK) void solveContactsSoftMsgKernel(ContactView c, MsgView m, int begin, int end, float inv_h, int useBias)
+{
+	S2_SWEEP_BODY_MSG(solveContactsSoftOne<KIND>(c, gb, inv_h, useBias, k))
+}
+template <int KIND>
+__global__ __launch_bounds__(S2_BLOCK) void solveContactsRigidMsgKernel(ContactView c, MsgView m, int begin, int end, float inv_h)
+{
+	S2_SWEEP_BODY_MSG(solveContactsRigidOne<KIND>(c, gb, inv_h, k))
+}
+__global__ __launch_bounds__(S2_BLOCK) void solveContactsStickyMsgKernel(ContactView c, MsgView m, s2amdContact* wire, int begin, int end,
+																		 float inv_h, int useBias)
+{
+	S2_SWEEP_BODY_MSG(solveContactsStickyOne(c, gb, wire, inv_h, useBias, k))
+}
+
+// fills both copies of every constraint of the global part from the body arrays (after prepare)
+__global__ __launch_bounds__(S2_BLOCK) void fillMessageSlotsKernel(ContactView c, BodyView b, MsgView m, int count)
+{
+	int k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= count)
+	{
+		return;
+	}
+	int2 bd = c.bodies[k];
+	m.vel[2 * k] = b.vel[bd.x];
+	m.dq[2 * k] = b.dq[bd.x];
+	m.vel[2 * k + 1] = b.vel[bd.y];
+	m.dq[2 * k + 1] = b.dq[bd.y];
+}
+
 template <int KIND> __global__ __launch_bounds__(S2_BLOCK) void warmStartContactsKernel(ContactView c, BodyView b, int begin, int end)
 {
 	S2_SWEEP_BODY(warmStartContactsOne<KIND>(c, gb, k))
@@ -489,6 +602,82 @@ void launchStoreImpulses(hipStream_t s, int kind, const ContactView& c, s2amdCon
 			break;
 		case STORE_BLOCK:
 			storeImpulsesKernel<STORE_BLOCK><<<g, t, 0, s>>>(c, wire, scale);
+			break;
+	}
+}
+
+// ---- message-passing launchers ----
+void launchFillMessageSlots(hipStream_t s, const ContactView& c, const BodyView& b, const MsgView& m, int count)
+{
+	if (count > 0)
+	{
+		fillMessageSlotsKernel<<<gridFor(count), dim3(S2_BLOCK), 0, s>>>(c, b, m, count);
+	}
+}
+
+void launchWarmStartContactsMsg(hipStream_t s, int kind, const ContactView& c, const MsgView& m, int begin, int end)
+{
+	switch (kind)
+	{
+		case WARM_CURRENT:
+			S2_LAUNCH_SWEEP(warmStartContactsMsgKernel<WARM_CURRENT>, c, m, begin, end);
+			break;
+		case WARM_FIXED:
+			S2_LAUNCH_SWEEP(warmStartContactsMsgKernel<WARM_FIXED>, c, m, begin, end);
+			break;
+	}
+}
+
+void launchSolveContactsSoftMsg(hipStream_t s, int kind, const ContactView& c, const MsgView& m, int begin, int end, float inv_h, int useBias)
+{
+	switch (kind)
+	{
+		case SOFT_TGS:
+			S2_LAUNCH_SWEEP(solveContactsSoftMsgKernel<SOFT_TGS>, c, m, begin, end, inv_h, useBias);
+			break;
+		case SOFT_PGS:
+			S2_LAUNCH_SWEEP(solveContactsSoftMsgKernel<SOFT_PGS>, c, m, begin, end, inv_h, useBias);
+			break;
+		case SOFT_FIXED:
+			S2_LAUNCH_SWEEP(solveContactsSoftMsgKernel<SOFT_FIXED>, c, m, begin, end, inv_h, useBias);
+			break;
+	}
+}
+
+void launchSolveContactsRigidMsg(hipStream_t s, int kind, const ContactView& c, const MsgView& m, int begin, int end, float inv_h)
+{
+	switch (kind)
+	{
+		case RIGID_BAUMGARTE:
+			S2_LAUNCH_SWEEP(solveContactsRigidMsgKernel<RIGID_BAUMGARTE>, c, m, begin, end, inv_h);
+			break;
+	}
+}
+
+void launchSolveContactsStickyMsg(hipStream_t s, const ContactView& c, const MsgView& m, s2amdContact* wire, int begin, int end, float inv_h,
+								  int useBias)
+{
+	S2_LAUNCH_SWEEP(solveContactsStickyMsgKernel, c, m, wire, begin, end, inv_h, useBias);
+}
+
+void launchWarmStartBodies(hipStream_t s, int kind, const ContactView& c, const BodyView& b, const int* adjOffsets, const int* adjList,
+						   int integrateFirst)
+{
+	if (b.capacity <= 0)
+	{
+		return;
+	}
+	dim3 g = gridFor(b.capacity), t(S2_BLOCK);
+	switch (kind)
+	{
+		case WARM_CURRENT:
+			warmStartBodiesKernel<WARM_CURRENT><<<g, t, 0, s>>>(c, b, adjOffsets, adjList, integrateFirst);
+			break;
+		case WARM_FIXED:
+			warmStartBodiesKernel<WARM_FIXED><<<g, t, 0, s>>>(c, b, adjOffsets, adjList, integrateFirst);
+			break;
+		case WARM_BLOCK:
+			warmStartBodiesKernel<WARM_BLOCK><<<g, t, 0, s>>>(c, b, adjOffsets, adjList, integrateFirst);
 			break;
 	}
 }

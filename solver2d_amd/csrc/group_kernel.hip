@@ -16,13 +16,59 @@
 
 #define S2_GROUP_THREADS 512
 
-template <class F> S2_DEV void forBatches(const int4* batches, int b0, int b1, F f)
+// Pull one constraint's SoA records into the cache hierarchy.  The sequential tail is walked by one
+// lane, so every miss would be paid serially; this pass lets all lanes of the workgroup issue the
+// misses at once, the walk afterwards hits L1/L2.
+S2_DEV void touch(float4 v)
+{
+	asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+}
+S2_DEV void prefetchContact(const ContactView& c, int k)
+{
+	int2 b = c.localBodies[k];
+	asm volatile("" ::"v"(b.x), "v"(b.y));
+	touch(c.mass[k]);
+	touch(c.nf[k]);
+	touch(c.blockK[k]);
+	touch(c.blockNM[k]);
+	for (int j = 0; j < 2; ++j)
+	{
+		touch(c.anchor[j][k]);
+		touch(c.r0[j][k]);
+		touch(c.param[j][k]);
+		touch(c.soft[j][k]);
+		touch(c.fanchor[j][k]);
+		float2 i = c.impulse[j][k];
+		asm volatile("" ::"v"(i.x), "v"(i.y));
+	}
+}
+S2_DEV void prefetchJoint(const JointView& j, int k)
+{
+	int2 b = j.localBodies[k];
+	asm volatile("" ::"v"(b.x), "v"(b.y));
+	touch(j.frame[k]);
+	touch(j.mass[k]);
+	touch(j.pivot[k]);
+	touch(j.soft[k]);
+	touch(j.axial[k]);
+	touch(j.limits[k]);
+	touch(j.misc[k]);
+	float2 a = j.centerDiff0[k], i = j.impulse[k];
+	asm volatile("" ::"v"(a.x), "v"(a.y), "v"(i.x), "v"(i.y));
+}
+
+template <class P, class F> S2_DEV void forBatches(const int4* batches, int b0, int b1, P prefetch, F f)
 {
 	for (int bi = b0; bi < b1; ++bi)
 	{
 		int4 bt = batches[bi];
 		if (bt.z)
 		{
+			for (int k = bt.x + (int)threadIdx.x; k < bt.y; k += (int)blockDim.x)
+			{
+				prefetch(k);
+			}
+			__syncthreads();
 			if (threadIdx.x == 0)
 			{
 				for (int k = bt.x; k < bt.y; ++k)
@@ -67,6 +113,8 @@ __global__ __launch_bounds__(S2_GROUP_THREADS) void groupKernel(ContactView c, J
 	__syncthreads();
 
 	LdsBodies lb{lvel, ldq};
+	auto pfC = [&](int k) { prefetchContact(c, k); };
+	auto pfJ = [&](int k) { prefetchJoint(jv, k); };
 	const int cb0 = gt.cBatchOffsets[grp], cb1 = gt.cBatchOffsets[grp + 1];
 	const int jb0 = gt.jBatchOffsets[grp], jb1 = gt.jBatchOffsets[grp + 1];
 
@@ -115,22 +163,22 @@ __global__ __launch_bounds__(S2_GROUP_THREADS) void groupKernel(ContactView c, J
 				switch (op.kind)
 				{
 					case JSOLVE_PLAIN:
-						forBatches(gt.jBatches, jb0, jb1, [&](int k) { solveJointsOne<JSOLVE_PLAIN>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
+						forBatches(gt.jBatches, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_PLAIN>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
 						break;
 					case JSOLVE_SOFT:
-						forBatches(gt.jBatches, jb0, jb1, [&](int k) { solveJointsOne<JSOLVE_SOFT>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
+						forBatches(gt.jBatches, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_SOFT>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
 						break;
 					case JSOLVE_BAUMGARTE:
-						forBatches(gt.jBatches, jb0, jb1, [&](int k) { solveJointsOne<JSOLVE_BAUMGARTE>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
+						forBatches(gt.jBatches, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_BAUMGARTE>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
 						break;
 					case JSOLVE_POSITION:
-						forBatches(gt.jBatches, jb0, jb1, [&](int k) { solveJointsOne<JSOLVE_POSITION>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
+						forBatches(gt.jBatches, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_POSITION>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
 						break;
 					case JSOLVE_XPBD:
-						forBatches(gt.jBatches, jb0, jb1, [&](int k) { solveJointsOne<JSOLVE_XPBD>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
+						forBatches(gt.jBatches, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_XPBD>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
 						break;
 					case JSOLVE_WARM:
-						forBatches(gt.jBatches, jb0, jb1, [&](int k) { solveJointsOne<JSOLVE_WARM>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
+						forBatches(gt.jBatches, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_WARM>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
 						break;
 				}
 				break;
@@ -138,13 +186,13 @@ __global__ __launch_bounds__(S2_GROUP_THREADS) void groupKernel(ContactView c, J
 				switch (op.kind)
 				{
 					case WARM_CURRENT:
-						forBatches(gt.cBatches, cb0, cb1, [&](int k) { warmStartContactsOne<WARM_CURRENT>(c, lb, k); });
+						forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { warmStartContactsOne<WARM_CURRENT>(c, lb, k); });
 						break;
 					case WARM_FIXED:
-						forBatches(gt.cBatches, cb0, cb1, [&](int k) { warmStartContactsOne<WARM_FIXED>(c, lb, k); });
+						forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { warmStartContactsOne<WARM_FIXED>(c, lb, k); });
 						break;
 					case WARM_BLOCK:
-						forBatches(gt.cBatches, cb0, cb1, [&](int k) { warmStartContactsOne<WARM_BLOCK>(c, lb, k); });
+						forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { warmStartContactsOne<WARM_BLOCK>(c, lb, k); });
 						break;
 				}
 				break;
@@ -152,13 +200,13 @@ __global__ __launch_bounds__(S2_GROUP_THREADS) void groupKernel(ContactView c, J
 				switch (op.kind)
 				{
 					case SOFT_TGS:
-						forBatches(gt.cBatches, cb0, cb1, [&](int k) { solveContactsSoftOne<SOFT_TGS>(c, lb, op.inv_h, op.useBias, k); });
+						forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { solveContactsSoftOne<SOFT_TGS>(c, lb, op.inv_h, op.useBias, k); });
 						break;
 					case SOFT_PGS:
-						forBatches(gt.cBatches, cb0, cb1, [&](int k) { solveContactsSoftOne<SOFT_PGS>(c, lb, op.inv_h, op.useBias, k); });
+						forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { solveContactsSoftOne<SOFT_PGS>(c, lb, op.inv_h, op.useBias, k); });
 						break;
 					case SOFT_FIXED:
-						forBatches(gt.cBatches, cb0, cb1, [&](int k) { solveContactsSoftOne<SOFT_FIXED>(c, lb, op.inv_h, op.useBias, k); });
+						forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { solveContactsSoftOne<SOFT_FIXED>(c, lb, op.inv_h, op.useBias, k); });
 						break;
 					default:
 						break; // SOFT_JACOBI never runs in a group (needs the per-body incidence sums)
@@ -168,33 +216,33 @@ __global__ __launch_bounds__(S2_GROUP_THREADS) void groupKernel(ContactView c, J
 				switch (op.kind)
 				{
 					case RIGID_BAUMGARTE:
-						forBatches(gt.cBatches, cb0, cb1, [&](int k) { solveContactsRigidOne<RIGID_BAUMGARTE>(c, lb, op.inv_h, k); });
+						forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { solveContactsRigidOne<RIGID_BAUMGARTE>(c, lb, op.inv_h, k); });
 						break;
 					case RIGID_PGS:
-						forBatches(gt.cBatches, cb0, cb1, [&](int k) { solveContactsRigidOne<RIGID_PGS>(c, lb, op.inv_h, k); });
+						forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { solveContactsRigidOne<RIGID_PGS>(c, lb, op.inv_h, k); });
 						break;
 					case RIGID_TGS:
-						forBatches(gt.cBatches, cb0, cb1, [&](int k) { solveContactsRigidOne<RIGID_TGS>(c, lb, op.inv_h, k); });
+						forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { solveContactsRigidOne<RIGID_TGS>(c, lb, op.inv_h, k); });
 						break;
 				}
 				break;
 			case OP_SOLVE_STICKY:
-				forBatches(gt.cBatches, cb0, cb1, [&](int k) { solveContactsStickyOne(c, lb, wire, op.inv_h, op.useBias, k); });
+				forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { solveContactsStickyOne(c, lb, wire, op.inv_h, op.useBias, k); });
 				break;
 			case OP_SOLVE_NGS:
-				forBatches(gt.cBatches, cb0, cb1, [&](int k) { solveContactsNGSOne(c, lb, k); });
+				forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { solveContactsNGSOne(c, lb, k); });
 				break;
 			case OP_XPBD_POS:
-				forBatches(gt.cBatches, cb0, cb1, [&](int k) { xpbdContactPositionsOne(c, lb, op.h, k); });
+				forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { xpbdContactPositionsOne(c, lb, op.h, k); });
 				break;
 			case OP_XPBD_VEL:
-				forBatches(gt.cBatches, cb0, cb1, [&](int k) { xpbdContactVelocitiesOne(c, lb, op.h, k); });
+				forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { xpbdContactVelocitiesOne(c, lb, op.h, k); });
 				break;
 			case OP_BLOCK_VEL:
-				forBatches(gt.cBatches, cb0, cb1, [&](int k) { blockSolveVelocityOne(c, lb, k); });
+				forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { blockSolveVelocityOne(c, lb, k); });
 				break;
 			case OP_BLOCK_POS:
-				forBatches(gt.cBatches, cb0, cb1, [&](int k) { blockSolvePositionOne(c, lb, k); });
+				forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { blockSolvePositionOne(c, lb, k); });
 				break;
 			default:
 				break;

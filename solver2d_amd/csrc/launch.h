@@ -9,6 +9,7 @@ struct JointView;
 struct StepConsts;
 struct GroupTable;
 struct Op;
+struct MsgView;
 struct s2amdBody;
 struct s2amdContact;
 struct s2amdJoint;
@@ -105,3 +106,19 @@ void launchStoreJoints(hipStream_t s, const JointView& j, s2amdJoint* wire);
 int groupKernelSetup();
 void launchGroupKernel(hipStream_t s, const ContactView& c, const JointView& j, const BodyView& g, const GroupTable& gt, const Op* ops, int opCount,
 					   const StepConsts& sc, s2amdContact* wire, int maxBodies, int useDq0);
+
+// message passing (big-island path)
+void launchFillMessageSlots(hipStream_t s, const ContactView& c, const BodyView& b, const MsgView& m, int count);
+void launchWarmStartContactsMsg(hipStream_t s, int kind, const ContactView& c, const MsgView& m, int begin, int end);
+void launchSolveContactsSoftMsg(hipStream_t s, int kind, const ContactView& c, const MsgView& m, int begin, int end, float inv_h, int useBias);
+void launchSolveContactsRigidMsg(hipStream_t s, int kind, const ContactView& c, const MsgView& m, int begin, int end, float inv_h);
+void launchSolveContactsStickyMsg(hipStream_t s, const ContactView& c, const MsgView& m, s2amdContact* wire, int begin, int end, float inv_h,
+								  int useBias);
+void launchIntegrateVelocitiesMsg(hipStream_t s, const BodyView& b, const MsgView& m);
+void launchIntegratePositionsMsg(hipStream_t s, const BodyView& b, const MsgView& m, float h);
+void launchFinalizePositionsMsg(hipStream_t s, const BodyView& b, const MsgView& m, int dynamicOnly);
+void launchGatherMessageSlots(hipStream_t s, const BodyView& b, const MsgView& m);
+
+// body-centric warm start (one launch for all colours, optionally fused with integrate velocities)
+void launchWarmStartBodies(hipStream_t s, int kind, const ContactView& c, const BodyView& b, const int* adjOffsets, const int* adjList,
+						   int integrateFirst);

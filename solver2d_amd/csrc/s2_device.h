@@ -434,3 +434,14 @@ struct GroupTable
 	int groupCount;
 };
 #define S2G_OWNED 0x80000000u
+
+// Message-passing tables of the global part (see MsgBodies in constraint_ops.h)
+struct MsgView
+{
+	float4* vel;		   // [2 * globalCount] per-constraint-side velocity copies
+	float4* dq;			   // [2 * globalCount] per-constraint-side pose copies
+	const int* next;	   // [2 * globalCount] copy that receives the updated velocity
+	const int* firstSlot;  // [bodyCapacity] copy holding a body's current velocity between sweeps (-1: body has no copies)
+	const int* slotOffsets; // [bodyCapacity + 1] CSR of all copies of a body
+	const int* slotList;
+};

@@ -225,15 +225,21 @@ bool makeBatches(const std::vector<int>& colorOffsets, std::vector<int>& batchOf
 		return false;
 	}
 	int total = colorOffsets[n];
+	// the tail starts at the first colour from which on EVERY colour is tiny (a launch would cost more
+	// than sweeping its few constraints serially); it must replace at least kMinTailColors launches
+	const int kTinyColor = 32, kMinTailColors = 4;
 	int tailColor = n;
-	const int kMinParallelColors = 8, kMaxTailConstraints = 4096, kMinTailColors = 3;
-	for (int c = kMinParallelColors; c < n; ++c)
+	for (int c = n - 1; c >= 1; --c)
 	{
-		if (total - colorOffsets[c] <= kMaxTailConstraints && n - c >= kMinTailColors)
+		if (colorOffsets[(size_t)c + 1] - colorOffsets[c] > kTinyColor)
 		{
-			tailColor = c;
 			break;
 		}
+		tailColor = c;
+	}
+	if (n - tailColor < kMinTailColors)
+	{
+		tailColor = n;
 	}
 	for (int c = 0; c <= tailColor; ++c)
 	{
@@ -348,6 +354,11 @@ struct s2amdSolver
 	SweepSet contacts, joints;
 	HostGroupTable hGroups, hContactTail, hJointTail;
 	DeviceGroupTable dGroups, dContactTail, dJointTail;
+	DevBuf dMsg;
+	MsgView msg{};
+	bool msgTablesValid = false; // the global part is contact-only and has no sequential tail
+	int optMessage = 0;	 // measured slower than the plain gather on MI355X: off by default
+	int optBodyWarm = 1; // body-centric contact warm start (one launch per sweep instead of one per colour)
 	int looseBodies = 0; // live non-static bodies that no LDS group owns
 	int orderSolverClass = -1; // 0 velocity colouring, 1 position colouring
 	bool orderGrouped = false;
@@ -690,7 +701,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 	const int cls = isPositionSolver(solverType) ? 1 : 0;
 	const bool needAdj = solverType == s2amd_solverJacobi;
 	const bool grouped = s->optGroups != 0 && !needAdj;
-	if (!s->structureDirty && cls == s->orderSolverClass && grouped == s->orderGrouped && (!needAdj || s->adjValid))
+	if (!s->structureDirty && cls == s->orderSolverClass && grouped == s->orderGrouped && s->adjValid)
 	{
 		return S2AMD_OK;
 	}
@@ -1033,14 +1044,89 @@ int buildStructure(s2amdSolver* s, int solverType)
 		return rc;
 	}
 
+	// ---- message-passing tables of the global part (see MsgBodies) ----
+	s->msgTablesValid = false;
+	if (cs.globalCount > 0 && js.globalCount == 0 && !cs.hasTail && !needAdj)
+	{
+		const int G = cs.globalCount;
+		std::vector<int> offsets((size_t)nb + 1, 0), list((size_t)2 * G), next((size_t)2 * G, 0), first((size_t)nb, -1);
+		for (int k = 0; k < G; ++k)
+		{
+			offsets[(size_t)s->hContactA[cs.order[k]] + 1] += 1;
+			offsets[(size_t)s->hContactB[cs.order[k]] + 1] += 1;
+		}
+		for (int i = 0; i < nb; ++i)
+		{
+			offsets[(size_t)i + 1] += offsets[i];
+		}
+		std::vector<int> cursor(offsets.begin(), offsets.end() - 1);
+		for (int k = 0; k < G; ++k) // ascending k: every body's copies end up in sweep order
+		{
+			list[(size_t)cursor[s->hContactA[cs.order[k]]]++] = 2 * k;
+			list[(size_t)cursor[s->hContactB[cs.order[k]]]++] = 2 * k + 1;
+		}
+		for (int i = 0; i < nb; ++i)
+		{
+			int b0 = offsets[i], b1 = offsets[(size_t)i + 1];
+			if (b1 > b0)
+			{
+				first[i] = list[(size_t)b0];
+				for (int e = b0; e < b1; ++e)
+				{
+					next[(size_t)list[(size_t)e]] = list[(size_t)(e + 1 < b1 ? e + 1 : b0)];
+				}
+			}
+		}
+		size_t bytes = (size_t)2 * G * (2 * sizeof(float4) + 2 * sizeof(int)) + ((size_t)2 * nb + 1) * sizeof(int) + 1024;
+		grew = false;
+		if ((rc = s->dMsg.ensure(bytes, &grew)) != 0)
+		{
+			return rc;
+		}
+		if (grew)
+		{
+			s->layoutGeneration += 1;
+		}
+		Carver cvr{(char*)s->dMsg.p, (char*)s->dMsg.p + s->dMsg.bytes};
+		float4* dvel = cvr.take<float4>((size_t)2 * G);
+		float4* ddq = cvr.take<float4>((size_t)2 * G);
+		int* dnext = cvr.take<int>((size_t)2 * G);
+		int* dlist = cvr.take<int>((size_t)2 * G);
+		int* dfirst = cvr.take<int>((size_t)nb);
+		int* doffsets = cvr.take<int>((size_t)nb + 1);
+		if (cvr.p > cvr.end)
+		{
+			// alignment slack exceeded: grow once more
+			if ((rc = s->dMsg.ensure(bytes + 8192, &grew)) != 0)
+			{
+				return rc;
+			}
+			s->layoutGeneration += 1;
+			cvr = Carver{(char*)s->dMsg.p, (char*)s->dMsg.p + s->dMsg.bytes};
+			dvel = cvr.take<float4>((size_t)2 * G);
+			ddq = cvr.take<float4>((size_t)2 * G);
+			dnext = cvr.take<int>((size_t)2 * G);
+			dlist = cvr.take<int>((size_t)2 * G);
+			dfirst = cvr.take<int>((size_t)nb);
+			doffsets = cvr.take<int>((size_t)nb + 1);
+		}
+		HIP_TRY(hipMemcpyAsync(dnext, next.data(), next.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+		HIP_TRY(hipMemcpyAsync(dlist, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+		HIP_TRY(hipMemcpyAsync(dfirst, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+		HIP_TRY(hipMemcpyAsync(doffsets, offsets.data(), offsets.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+		HIP_TRY(hipStreamSynchronize(s->stream));
+		s->msg.vel = dvel, s->msg.dq = ddq, s->msg.next = dnext, s->msg.firstSlot = dfirst, s->msg.slotOffsets = doffsets, s->msg.slotList = dlist;
+		s->msgTablesValid = true;
+	}
+
 	s->adjValid = false;
-	if (needAdj)
 	{
 		// body -> incident constraints in SWEEP order (ascending k), key = k<<1 | side, so the per-body
 		// sums of jacobiApplyKernel add in exactly the order a sequential pass in sweep order would;
 		// read-only shareable bodies are skipped (their deltas are exact zeros)
 		std::vector<int> offsets((size_t)nb + 1, 0), list;
-		for (int k = 0; k < C; ++k)
+		const int GC = cs.globalCount; // LDS groups walk their own colours; only the global part is indexed
+		for (int k = 0; k < GC; ++k)
 		{
 			int a = s->hContactA[cs.order[k]], b = s->hContactB[cs.order[k]];
 			if (conflict[a])
@@ -1058,7 +1144,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 		}
 		list.resize((size_t)offsets[nb]);
 		std::vector<int> cursor(offsets.begin(), offsets.end() - 1);
-		for (int k = 0; k < C; ++k)
+		for (int k = 0; k < GC; ++k)
 		{
 			int a = s->hContactA[cs.order[k]], b = s->hContactB[cs.order[k]];
 			if (conflict[a])
@@ -1429,6 +1515,18 @@ void buildPlan(s2amdSolver* s, const s2amdStepParams* params)
 	s->planGeneration += 1;
 }
 
+// Message passing applies when the global part is contact-only without a sequential tail (tables
+// valid) and the plan consists of velocity-level contact sweeps only (poses change in body kernels).
+bool messageEligible(const s2amdSolver* s, int solverType)
+{
+	if (!s->optMessage || !s->msgTablesValid)
+	{
+		return false;
+	}
+	return solverType == s2amd_solverTGS_Soft || solverType == s2amd_solverSoftStep || solverType == s2amd_solverPGS ||
+		   solverType == s2amd_solverPGS_Soft || solverType == s2amd_solverTGS_Sticky;
+}
+
 // ------------------------------------------------------------------------------------------------
 // execution of a plan
 // ------------------------------------------------------------------------------------------------
@@ -1439,6 +1537,7 @@ struct Executor
 	const StepPlan& p;
 	int posSolver;
 	bool profile;
+	bool msg = false; // message-passing accessor for the global part
 
 	s2amdContact* wireContacts() const { return (s2amdContact*)s->dContacts.p; }
 	s2amdBody* wireBodies() const { return (s2amdBody*)s->dBodies.p; }
@@ -1469,6 +1568,26 @@ struct Executor
 
 	void launchContactBatch(const Op& o, int b, int e)
 	{
+		if (msg)
+		{
+			switch (o.code)
+			{
+				case OP_WARM:
+					launchWarmStartContactsMsg(st, o.kind, s->cv, s->msg, b, e);
+					return;
+				case OP_SOLVE_SOFT:
+					launchSolveContactsSoftMsg(st, o.kind, s->cv, s->msg, b, e, o.inv_h, o.useBias);
+					return;
+				case OP_SOLVE_RIGID:
+					launchSolveContactsRigidMsg(st, o.kind, s->cv, s->msg, b, e, o.inv_h);
+					return;
+				case OP_SOLVE_STICKY:
+					launchSolveContactsStickyMsg(st, s->cv, s->msg, wireContacts(), b, e, o.inv_h, o.useBias);
+					return;
+				default:
+					return; // message mode is only enabled for plans made of the ops above
+			}
+		}
 		switch (o.code)
 		{
 			case OP_WARM:
@@ -1513,21 +1632,42 @@ struct Executor
 			case OP_INTEGRATE_VEL:
 				if (bodies)
 				{
-					launchIntegrateVelocities(st, s->bv);
+					if (msg)
+					{
+						launchIntegrateVelocitiesMsg(st, s->bv, s->msg);
+					}
+					else
+					{
+						launchIntegrateVelocities(st, s->bv);
+					}
 					count();
 				}
 				return;
 			case OP_INTEGRATE_POS:
 				if (bodies)
 				{
-					launchIntegratePositions(st, s->bv, o.h);
+					if (msg)
+					{
+						launchIntegratePositionsMsg(st, s->bv, s->msg, o.h);
+					}
+					else
+					{
+						launchIntegratePositions(st, s->bv, o.h);
+					}
 					count();
 				}
 				return;
 			case OP_FINALIZE:
 				if (bodies)
 				{
-					launchFinalizePositions(st, s->bv, o.flag);
+					if (msg)
+					{
+						launchFinalizePositionsMsg(st, s->bv, s->msg, o.flag);
+					}
+					else
+					{
+						launchFinalizePositions(st, s->bv, o.flag);
+					}
 					count();
 				}
 				return;
@@ -1643,6 +1783,11 @@ struct Executor
 			launchPrepareJoints(st, p.prepJoints, s->jv, s->bv, wireJoints(), wireBodies(), p.sc, p.jprepH, p.jprepHertz, p.jprepWarm, posSolver);
 			count();
 		}
+		if (msg)
+		{
+			launchFillMessageSlots(st, s->cv, s->bv, s->msg, s->contacts.globalCount);
+			count();
+		}
 		// LDS groups: the whole op list in one launch
 		if (s->dGroups.view.groupCount > 0)
 		{
@@ -1654,10 +1799,47 @@ struct Executor
 		const bool anyGlobal = s->looseBodies > 0 || s->contacts.globalCount > 0 || s->joints.globalCount > 0;
 		if (anyGlobal)
 		{
-			for (int i = 0; i < (int)p.ops.size(); ++i)
+			const int n = (int)p.ops.size();
+			std::vector<uint8_t> done((size_t)n, 0);
+			for (int i = 0; i < n; ++i)
 			{
+				if (done[(size_t)i])
+				{
+					continue;
+				}
+				const Op& o = p.ops[(size_t)i];
+				// contact warm start as ONE body-centric launch; an immediately preceding integrate-velocities
+				// (joint sweeps in between only when there are no global joints) rides along in the same kernel
+				if (!msg && s->optBodyWarm && s->contacts.globalCount > 0 && (o.code == OP_WARM || o.code == OP_INTEGRATE_VEL))
+				{
+					int w = i;
+					if (o.code == OP_INTEGRATE_VEL)
+					{
+						w = i + 1;
+						while (w < n && p.ops[(size_t)w].code == OP_JOINT_SWEEP && s->joints.globalCount == 0)
+						{
+							w += 1;
+						}
+					}
+					if (w < n && p.ops[(size_t)w].code == OP_WARM)
+					{
+						launchWarmStartBodies(st, p.ops[(size_t)w].kind, s->cv, s->bv, (const int*)s->dAdjOffsets.p, (const int*)s->dAdjList.p,
+											  o.code == OP_INTEGRATE_VEL ? 1 : 0);
+						count();
+						for (int d = i; d <= w; ++d)
+						{
+							done[(size_t)d] = 1;
+						}
+						continue;
+					}
+				}
 				runGlobalOp(i);
 			}
+		}
+		if (msg)
+		{
+			launchGatherMessageSlots(st, s->bv, s->msg);
+			count();
 		}
 		// post: SoA -> wire
 		if (s->cv.count > 0)
@@ -1901,6 +2083,8 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	}
 
 	Executor q{s, s->stream, plan, isPositionSolver(params->solverType) ? 1 : 0, s->optProfile != 0};
+	q.msg = messageEligible(s, params->solverType);
+	s->stats.messagePassing = q.msg ? 1 : 0;
 	s->launchCounter = 0;
 	s->sweepEventsUsed = 0;
 
@@ -1953,7 +2137,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	{
 		uint64_t key = 1469598103934665603ull;
 		key = fnv(key, params, sizeof(*params));
-		uint64_t gens[3] = {s->layoutGeneration, s->structureGeneration, s->planGeneration};
+		uint64_t gens[4] = {s->layoutGeneration, s->structureGeneration, s->planGeneration, (uint64_t)((q.msg ? 1 : 0) | (s->optBodyWarm ? 2 : 0))};
 		key = fnv(key, gens, sizeof(gens));
 		int sizes[3] = {s->bodyCapacity, s->contactCapacity, s->jointCapacity};
 		key = fnv(key, sizes, sizeof(sizes));
@@ -2149,7 +2333,7 @@ void s2amd_destroy(s2amdSolver* s)
 	DevBuf* bufs[] = {&s->dBodies,		&s->dContacts,	  &s->dJoints,		 &s->dBodiesSaved,	 &s->dBodyFlags,	&s->soaBodies,
 					  &s->soaContacts,	&s->soaJoints,	  &s->dContactIndex, &s->dJointIndex,	 &s->dContactLocal, &s->dJointLocal,
 					  &s->dAdjOffsets,	&s->dAdjList,	  &s->dGatherIndex,	 &s->dOps,			 &s->dGroups.buf,	&s->dContactTail.buf,
-					  &s->dJointTail.buf};
+					  &s->dJointTail.buf, &s->dMsg};
 	for (DevBuf* b : bufs)
 	{
 		b->release();
@@ -2334,6 +2518,93 @@ int s2amd_export_poses(s2amdSolver* s, void* devicePoses, int32_t capacity)
 	return S2AMD_OK;
 }
 
+int s2amd_measure_dominant(s2amdSolver* s, const s2amdStepParams* params, int32_t repeats, float* usPerLaunch, int32_t* launchesPerSweep,
+						   int32_t* constraintsPerLaunch)
+{
+	if (!s || !params || !usPerLaunch || repeats <= 0)
+	{
+		return fail(S2AMD_E_INVALID, "bad argument");
+	}
+	if (!s->resident)
+	{
+		return fail(S2AMD_E_STATE, "nothing resident");
+	}
+	HIP_TRY(hipSetDevice(s->device));
+	// make sure plan, structure and the device op list are current (one ordinary step)
+	int rc = doStep(s, params);
+	if (rc)
+	{
+		return rc;
+	}
+	const StepPlan& plan = s->plan;
+	int dominant = -1;
+	for (int i = 0; i < (int)plan.ops.size(); ++i)
+	{
+		if (Executor::isSolveSweep(plan.ops[(size_t)i].code))
+		{
+			dominant = i;
+			break;
+		}
+	}
+	Executor q{s, s->stream, plan, isPositionSolver(params->solverType) ? 1 : 0, false};
+	q.msg = messageEligible(s, params->solverType);
+	const bool global = s->contacts.globalCount > 0 && dominant >= 0;
+	hipGraph_t g = nullptr;
+	hipGraphExec_t ge = nullptr;
+	s->launchCounter = 0;
+	HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+	for (int r = 0; r < repeats; ++r)
+	{
+		if (global)
+		{
+			q.runGlobalOp(dominant);
+		}
+		else if (s->dGroups.view.groupCount > 0)
+		{
+			launchGroupKernel(s->stream, s->cv, s->jv, s->bv, s->dGroups.view, q.deviceOps(), (int)plan.ops.size(), plan.sc,
+							  (s2amdContact*)s->dContacts.p, s->dGroups.maxBodies, plan.usesDq0 ? 1 : 0);
+			s->launchCounter += 1;
+		}
+	}
+	hipError_t ce = hipStreamEndCapture(s->stream, &g);
+	if (ce != hipSuccess)
+	{
+		return fail(S2AMD_E_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+	}
+	int launches = s->launchCounter;
+	if (launches == 0)
+	{
+		(void)hipGraphDestroy(g);
+		*usPerLaunch = 0.0f;
+		return S2AMD_OK;
+	}
+	HIP_TRY(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+	HIP_TRY(hipGraphLaunch(ge, s->stream)); // warm
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	const int reps = 5;
+	HIP_TRY(hipEventRecord(s->evBegin, s->stream));
+	for (int r = 0; r < reps; ++r)
+	{
+		HIP_TRY(hipGraphLaunch(ge, s->stream));
+	}
+	HIP_TRY(hipEventRecord(s->evEnd, s->stream));
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	float ms = 0.0f;
+	HIP_TRY(hipEventElapsedTime(&ms, s->evBegin, s->evEnd));
+	(void)hipGraphExecDestroy(ge);
+	(void)hipGraphDestroy(g);
+	*usPerLaunch = 1e3f * ms / (float)(reps * launches);
+	if (launchesPerSweep)
+	{
+		*launchesPerSweep = launches / repeats;
+	}
+	if (constraintsPerLaunch)
+	{
+		*constraintsPerLaunch = global ? s->contacts.globalCount / std::max(launches / repeats, 1) : s->cv.count;
+	}
+	return S2AMD_OK;
+}
+
 int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 {
 	if (!s || !key)
@@ -2347,6 +2618,14 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	else if (strcmp(key, "profile") == 0)
 	{
 		s->optProfile = value;
+	}
+	else if (strcmp(key, "message") == 0)
+	{
+		s->optMessage = value;
+	}
+	else if (strcmp(key, "body_warm") == 0)
+	{
+		s->optBodyWarm = value;
 	}
 	else if (strcmp(key, "groups") == 0)
 	{

@@ -18,7 +18,7 @@ EXPORTS = [
     "s2amd_api_version", "s2amd_device_count", "s2amd_last_error", "s2amd_create", "s2amd_destroy",
     "s2amd_solve", "s2amd_upload", "s2amd_step_resident", "s2amd_download", "s2amd_save_bodies",
     "s2amd_restore_bodies", "s2amd_get_contact_order", "s2amd_get_joint_order", "s2amd_get_stats",
-    "s2amd_set_option", "s2amd_export_poses",
+    "s2amd_set_option", "s2amd_export_poses", "s2amd_measure_dominant",
 ]
 
 _lib = None
@@ -55,6 +55,8 @@ def load():
     L.s2amd_get_stats.argtypes = [vp, ctypes.POINTER(wire.StepStats)]
     L.s2amd_set_option.argtypes = [vp, ctypes.c_char_p, i32]
     L.s2amd_export_poses.argtypes = [vp, vp, i32]
+    L.s2amd_measure_dominant.argtypes = [vp, ctypes.POINTER(wire.StepParams), i32, ctypes.POINTER(ctypes.c_float),
+                                         ctypes.POINTER(i32), ctypes.POINTER(i32)]
     if L.s2amd_api_version() != wire.API_VERSION:
         raise S2AmdError("libs2amd.so API version %d != %d" % (L.s2amd_api_version(), wire.API_VERSION))
     _lib = L
@@ -133,6 +135,13 @@ class Solver:
     def export_poses(self, device_ptr, capacity):
         """{position, rot} per body into a caller-owned device buffer (float32[capacity, 4])."""
         _check(load().s2amd_export_poses(self._h, ctypes.c_void_p(int(device_ptr)), int(capacity)))
+
+    def measure_dominant(self, params, repeats=20):
+        """(us per launch, launches per sweep, constraints per launch) of the dominant kernel; see
+        s2amd_measure_dominant."""
+        us, n, c = ctypes.c_float(), ctypes.c_int32(), ctypes.c_int32()
+        _check(load().s2amd_measure_dominant(self._h, ctypes.byref(params), int(repeats), ctypes.byref(us), ctypes.byref(n), ctypes.byref(c)))
+        return us.value, n.value, c.value
 
     def _order(self, fn):
         n, nc = ctypes.c_int32(), ctypes.c_int32()

@@ -72,6 +72,41 @@ def test_golden_inputs_bit_exact_without_groups(solver_nogroups, path):
     assert solver_nogroups.stats()["groupCount"] == 0
 
 
+@pytest.mark.parametrize("message", [1, 0])
+@pytest.mark.parametrize("solver_name", ["TGS_Soft", "SoftStep", "PGS", "PGS_Soft", "TGS_Sticky", "XPBD", "PGS_NGS"])
+def test_big_island_message_passing_on_off(solver_name, message):
+    """Global path (groups off) with and without the message-passing accessor: both bit-exact."""
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    pre = synthetic.pyramid(30)
+    with hip.Solver(0) as s:
+        s.set_option("groups", 0)
+        s.set_option("message", message)
+        state = common.copy3(pre)
+        for step in range(3):
+            params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+            state = gpu_vs_oracle(s, params, state, "pyramid30/%s msg=%d step %d" % (solver_name, message, step))
+        expect = message == 1 and solver_name in ("TGS_Soft", "SoftStep", "PGS", "PGS_Soft", "TGS_Sticky")
+        assert s.stats()["messagePassing"] == (1 if expect else 0)
+
+
+@pytest.mark.parametrize("body_warm", [1, 0])
+@pytest.mark.parametrize("solver_name", wire.SOLVER_NAMES)
+def test_big_island_body_centric_warm_start_on_off(solver_name, body_warm):
+    """The one-launch body-centric warm start must give the same bits as the coloured warm-start sweep."""
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    pre = synthetic.pyramid(24)
+    with hip.Solver(0) as s:
+        s.set_option("groups", 0)
+        s.set_option("body_warm", body_warm)
+        state = common.copy3(pre)
+        launches = 0
+        for step in range(3):
+            params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+            state = gpu_vs_oracle(s, params, state, "pyramid24/%s bw=%d step %d" % (solver_name, body_warm, step))
+            launches = s.stats()["kernelLaunches"]
+    assert launches > 0
+
+
 def test_small_worlds_run_as_lds_groups(solver):
     params, pre, _post = golden_util.load([f for f in FILES if "pyramid10_TGS_Soft_step045" in f][0])
     gpu_vs_oracle(solver, params, pre, "pyramid10 grouped")

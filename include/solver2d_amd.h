@@ -189,6 +189,55 @@ int s2amd_download(s2amdSolver* solver, s2amdBody* bodies, int32_t bodyCapacity,
 int s2amd_save_bodies(s2amdSolver* solver);
 int s2amd_restore_bodies(s2amdSolver* solver);
 
+/* ---- the stages either side of the solver ---- */
+
+/* Shape type values are the reference's s2ShapeType (src/shape.h:14-21). */
+#define S2AMD_SHAPE_FREE (-1)
+#define S2AMD_SHAPE_CAPSULE 0
+#define S2AMD_SHAPE_CIRCLE 1
+#define S2AMD_SHAPE_POLYGON 2
+#define S2AMD_SHAPE_SEGMENT 3
+
+/* The part of s2Shape (src/shape.h:23-47) that Stage 4 of s2World_Step (AABB refit,
+ * src/world.c:259-301) and the broad phase (src/broad_phase.c:166-307) read and write.
+ * Geometry: polygon = vertices[0..count) + radius; circle = vertices[0] center, radius;
+ * capsule = vertices[0], vertices[1], radius; segment = vertices[0], vertices[1]. */
+typedef struct s2amdShape
+{
+	int32_t body;          /* s2Shape.bodyIndex; -1 with type S2AMD_SHAPE_FREE for a free pool slot */
+	int32_t type;          /* S2AMD_SHAPE_* */
+	uint32_t categoryBits; /* s2Filter, include/solver2d/types.h:141-146 */
+	uint32_t maskBits;
+	int32_t groupIndex;
+	int32_t proxyKey;      /* (tree proxy id << 4) | body type, src/broad_phase.h:18-20: orders a pair's A/B */
+	int32_t enlarged;      /* out of s2amd_refit_shapes: fat AABB grew, the proxy enters the move buffer */
+	int32_t count;         /* polygon vertex count */
+	float radius;
+	float aabb[4];         /* in/out {lower.x, lower.y, upper.x, upper.y} */
+	float fatAABB[4];      /* in/out */
+	float vertices[8][2];
+} s2amdShape;
+
+/* == Stage 4 of s2World_Step (src/world.c:259-301) for every non-static body: origin = position -
+ * R * localCenter (written to origins[2 * body]), per shape the tight AABB + speculative margin, and
+ * the fat AABB re-inflated where the tight one escaped it (`enlarged` = 1).  Host arrays in and out. */
+int s2amd_refit_shapes(s2amdSolver* solver, const s2amdBody* bodies, int32_t bodyCapacity, s2amdShape* shapes, int32_t shapeCapacity,
+					   float* origins);
+
+/* == the pair discovery of s2UpdateBroadPhasePairs (src/broad_phase.c:166-307): every moved proxy
+ * (moved[shape] != 0) against every proxy whose fat AABB overlaps its own, with the reference's
+ * rules (dynamic queries all three trees, kinematic only the dynamic one; no self pairs; when both
+ * moved the lower proxy key reports; existing pairs, same-body pairs, filtered pairs and bodies
+ * connected by a joint are skipped; shape A is the one with the lower proxy key), followed by
+ * s2CreateContact's type rules (src/contact.c:137-175): segment/segment pairs are dropped, a pair
+ * whose shape-type order has no primary manifold function is flipped.
+ * existingPairs: shapeIndexA/B of the live contacts.  Output: the NEW pairs, sorted by (A, B) -- the
+ * same SET the reference creates contacts for; its creation order (tree traversal order) is not
+ * reproduced.  Returns S2AMD_E_CAPACITY (with *pairCount = needed) when outPairs is too small. */
+int s2amd_find_pairs(s2amdSolver* solver, const s2amdBody* bodies, int32_t bodyCapacity, const s2amdShape* shapes, int32_t shapeCapacity,
+					 const uint8_t* moved, const int32_t* existingPairs, int32_t existingPairCount, const s2amdJoint* joints,
+					 int32_t jointCapacity, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount);
+
 /* Multi-GPU exchange: writes one {position.x, position.y, rot.s, rot.c} record per body slot into
  * a DEVICE buffer owned by the caller (e.g. the send buffer of an RCCL all-gather of per-island
  * body arrays).  Returns after the copy has completed on the solver's stream. */

@@ -330,6 +330,184 @@ WRAP(s2Solve_TGS_Soft, s2_solverTGS_Soft)
 WRAP(s2Solve_TGS_NGS, s2_solverTGS_NGS)
 WRAP(s2Solve_XPBD, s2_solverXPBD)
 
+// ---- shapes and the broad phase ----
+
+static void packShapes(const s2World* world, s2amdShape* out)
+{
+	int n = world->shapePool.capacity;
+	for (int i = 0; i < n; ++i)
+	{
+		const s2Shape* sh = world->shapes + i;
+		s2amdShape* o = out + i;
+		memset(o, 0, sizeof(*o));
+		if (s2IsFree(&sh->object))
+		{
+			o->body = -1;
+			o->type = S2AMD_SHAPE_FREE;
+			continue;
+		}
+		o->body = sh->bodyIndex;
+		o->type = (int32_t)sh->type;
+		o->categoryBits = sh->filter.categoryBits;
+		o->maskBits = sh->filter.maskBits;
+		o->groupIndex = sh->filter.groupIndex;
+		o->proxyKey = sh->proxyKey;
+		o->enlarged = sh->enlargedAABB ? 1 : 0;
+		o->aabb[0] = sh->aabb.lowerBound.x, o->aabb[1] = sh->aabb.lowerBound.y;
+		o->aabb[2] = sh->aabb.upperBound.x, o->aabb[3] = sh->aabb.upperBound.y;
+		o->fatAABB[0] = sh->fatAABB.lowerBound.x, o->fatAABB[1] = sh->fatAABB.lowerBound.y;
+		o->fatAABB[2] = sh->fatAABB.upperBound.x, o->fatAABB[3] = sh->fatAABB.upperBound.y;
+		switch (sh->type)
+		{
+			case s2_polygonShape:
+				o->count = sh->polygon.count;
+				o->radius = sh->polygon.radius;
+				for (int v = 0; v < sh->polygon.count; ++v)
+				{
+					o->vertices[v][0] = sh->polygon.vertices[v].x, o->vertices[v][1] = sh->polygon.vertices[v].y;
+				}
+				break;
+			case s2_circleShape:
+				o->radius = sh->circle.radius;
+				o->vertices[0][0] = sh->circle.point.x, o->vertices[0][1] = sh->circle.point.y;
+				break;
+			case s2_capsuleShape:
+				o->radius = sh->capsule.radius;
+				o->vertices[0][0] = sh->capsule.point1.x, o->vertices[0][1] = sh->capsule.point1.y;
+				o->vertices[1][0] = sh->capsule.point2.x, o->vertices[1][1] = sh->capsule.point2.y;
+				break;
+			case s2_segmentShape:
+				o->vertices[0][0] = sh->segment.point1.x, o->vertices[0][1] = sh->segment.point1.y;
+				o->vertices[1][0] = sh->segment.point2.x, o->vertices[1][1] = sh->segment.point2.y;
+				break;
+			default:
+				break;
+		}
+	}
+}
+
+// broad-phase capture: state at s2UpdateBroadPhasePairs entry and the pairs it created
+static s2amdShape* g_bpShapes = NULL;
+static uint8_t* g_bpMoved = NULL;
+static int32_t* g_bpExisting = NULL;
+static int32_t* g_bpNew = NULL;
+static int g_bpShapeCount = 0, g_bpExistingCount = 0, g_bpNewCount = 0;
+static double g_bpSeconds = 0.0;
+
+void __real_s2UpdateBroadPhasePairs(s2World* world);
+void __wrap_s2UpdateBroadPhasePairs(s2World* world)
+{
+	if (g_mode == 3)
+	{
+		struct timespec t0, t1;
+		clock_gettime(CLOCK_MONOTONIC, &t0);
+		__real_s2UpdateBroadPhasePairs(world);
+		clock_gettime(CLOCK_MONOTONIC, &t1);
+		g_bpSeconds += (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+		return;
+	}
+	if (g_mode != 1)
+	{
+		__real_s2UpdateBroadPhasePairs(world);
+		return;
+	}
+	int ns = world->shapePool.capacity, nc = world->contactPool.capacity;
+	g_bpShapes = (s2amdShape*)realloc(g_bpShapes, (size_t)(ns > 0 ? ns : 1) * sizeof(s2amdShape));
+	g_bpMoved = (uint8_t*)realloc(g_bpMoved, (size_t)(ns > 0 ? ns : 1));
+	g_bpExisting = (int32_t*)realloc(g_bpExisting, (size_t)(nc > 0 ? nc : 1) * 2 * sizeof(int32_t));
+	packShapes(world, g_bpShapes);
+	memset(g_bpMoved, 0, (size_t)(ns > 0 ? ns : 1));
+	g_bpShapeCount = ns;
+	s2BroadPhase* bp = &world->broadPhase;
+	int moveCount = s2Array(bp->moveArray).count;
+	for (int i = 0; i < moveCount; ++i)
+	{
+		int key = bp->moveArray[i];
+		if (key == S2_NULL_INDEX)
+		{
+			continue;
+		}
+		int shapeIndex = s2BroadPhase_GetShapeIndex(bp, key);
+		if (0 <= shapeIndex && shapeIndex < ns)
+		{
+			g_bpMoved[shapeIndex] = 1;
+		}
+	}
+	g_bpExistingCount = 0;
+	uint8_t* had = (uint8_t*)calloc((size_t)(nc > 0 ? nc : 1), 1);
+	for (int i = 0; i < nc; ++i)
+	{
+		const s2Contact* c = world->contacts + i;
+		if (s2IsFree(&c->object))
+		{
+			continue;
+		}
+		had[i] = 1;
+		g_bpExisting[2 * g_bpExistingCount] = c->shapeIndexA;
+		g_bpExisting[2 * g_bpExistingCount + 1] = c->shapeIndexB;
+		g_bpExistingCount += 1;
+	}
+	int oldCapacity = nc;
+	__real_s2UpdateBroadPhasePairs(world);
+	int nc2 = world->contactPool.capacity;
+	g_bpNew = (int32_t*)realloc(g_bpNew, (size_t)(nc2 > 0 ? nc2 : 1) * 2 * sizeof(int32_t));
+	g_bpNewCount = 0;
+	for (int i = 0; i < nc2; ++i)
+	{
+		const s2Contact* c = world->contacts + i;
+		if (s2IsFree(&c->object) || (i < oldCapacity && had[i]))
+		{
+			continue;
+		}
+		g_bpNew[2 * g_bpNewCount] = c->shapeIndexA;
+		g_bpNew[2 * g_bpNewCount + 1] = c->shapeIndexB;
+		g_bpNewCount += 1;
+	}
+	free(had);
+}
+
+S2REF_API double s2ref_broadphase_seconds(int reset)
+{
+	double v = g_bpSeconds;
+	if (reset)
+	{
+		g_bpSeconds = 0.0;
+	}
+	return v;
+}
+
+S2REF_API int s2ref_shape_capacity(s2WorldId id)
+{
+	return s2GetWorldFromId(id)->shapePool.capacity;
+}
+
+S2REF_API int s2ref_pack_shapes(s2WorldId id, s2amdShape* shapes, float* origins)
+{
+	s2World* world = s2GetWorldFromId(id);
+	if (shapes)
+	{
+		packShapes(world, shapes);
+	}
+	if (origins)
+	{
+		for (int i = 0; i < world->bodyPool.capacity; ++i)
+		{
+			origins[2 * i] = world->bodies[i].origin.x;
+			origins[2 * i + 1] = world->bodies[i].origin.y;
+		}
+	}
+	return 0;
+}
+
+S2REF_API int s2ref_broadphase_capture(const s2amdShape** shapes, int32_t* shapeCount, const uint8_t** moved, const int32_t** existing,
+									   int32_t* existingCount, const int32_t** created, int32_t* createdCount)
+{
+	*shapes = g_bpShapes, *shapeCount = g_bpShapeCount, *moved = g_bpMoved;
+	*existing = g_bpExisting, *existingCount = g_bpExistingCount;
+	*created = g_bpNew, *createdCount = g_bpNewCount;
+	return 0;
+}
+
 // ---- control surface used by tests/ and tools/ through ctypes ----
 
 S2REF_API void s2ref_set_mode(int mode)

@@ -2773,3 +2773,295 @@ ORACLE_API int s2oracle_solve(const s2amdStepParams* params, s2amdBody* bodies, 
 	free(w.joints);
 	return S2AMD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Stages either side of the solver: Stage 4 AABB refit and broad-phase pair discovery
+// ---------------------------------------------------------------------------------------------
+#define K_SPECULATIVE_DISTANCE (4.0f * K_LINEAR_SLOP) // constants.h:8
+#define K_AABB_MARGIN 0.1f							   // constants.h:9
+
+typedef struct Xf
+{
+	V2 p;
+	Rot q;
+} Xf;
+
+static inline V2 transformPoint(Xf xf, V2 p) // math.h:350-356
+{
+	float x = (xf.q.c * p.x - xf.q.s * p.y) + xf.p.x;
+	float y = (xf.q.s * p.x + xf.q.c * p.y) + xf.p.y;
+	return v2(x, y);
+}
+static inline V2 vmin(V2 a, V2 b) { return v2(MIN_(a.x, b.x), MIN_(a.y, b.y)); } // math.h:144-150
+static inline V2 vmax(V2 a, V2 b) { return v2(MAX_(a.x, b.x), MAX_(a.y, b.y)); } // math.h:153-159
+
+// s2Shape_ComputeAABB (src/shape.c) -> s2Compute{Capsule,Circle,Polygon,Segment}AABB (src/geometry.c:288-339)
+static void shapeAABB(const s2amdShape* sh, Xf xf, float out[4])
+{
+	V2 lower, upper;
+	V2 v0 = v2(sh->vertices[0][0], sh->vertices[0][1]);
+	V2 v1 = v2(sh->vertices[1][0], sh->vertices[1][1]);
+	switch (sh->type)
+	{
+		case S2AMD_SHAPE_CIRCLE:
+		{
+			V2 p = transformPoint(xf, v0);
+			float r = sh->radius;
+			lower = v2(p.x - r, p.y - r);
+			upper = v2(p.x + r, p.y + r);
+			break;
+		}
+		case S2AMD_SHAPE_CAPSULE:
+		{
+			V2 a = transformPoint(xf, v0), b = transformPoint(xf, v1);
+			V2 r = v2(sh->radius, sh->radius);
+			lower = sub(vmin(a, b), r);
+			upper = add(vmax(a, b), r);
+			break;
+		}
+		case S2AMD_SHAPE_POLYGON:
+		{
+			lower = transformPoint(xf, v0);
+			upper = lower;
+			for (int i = 1; i < sh->count; ++i)
+			{
+				V2 v = transformPoint(xf, v2(sh->vertices[i][0], sh->vertices[i][1]));
+				lower = vmin(lower, v);
+				upper = vmax(upper, v);
+			}
+			V2 r = v2(sh->radius, sh->radius);
+			lower = sub(lower, r);
+			upper = add(upper, r);
+			break;
+		}
+		case S2AMD_SHAPE_SEGMENT:
+		{
+			V2 a = transformPoint(xf, v0), b = transformPoint(xf, v1);
+			lower = vmin(a, b);
+			upper = vmax(a, b);
+			break;
+		}
+		default:
+			lower = xf.p;
+			upper = xf.p;
+			break;
+	}
+	out[0] = lower.x, out[1] = lower.y, out[2] = upper.x, out[3] = upper.y;
+}
+
+// Stage 4 of s2World_Step: src/world.c:259-301
+ORACLE_API int s2oracle_refit_shapes(const s2amdBody* bodies, int32_t bodyCapacity, s2amdShape* shapes, int32_t shapeCapacity, float* origins)
+{
+	for (int i = 0; i < bodyCapacity; ++i)
+	{
+		const s2amdBody* b = bodies + i;
+		if (b->type == S2AMD_BODY_FREE || b->type == S2AMD_BODY_STATIC)
+		{
+			continue;
+		}
+		Rot q = {b->rot[0], b->rot[1]};
+		V2 o = sub(v2(b->position[0], b->position[1]), rotate(q, v2(b->localCenter[0], b->localCenter[1])));
+		origins[2 * i] = o.x, origins[2 * i + 1] = o.y;
+	}
+	for (int si = 0; si < shapeCapacity; ++si)
+	{
+		s2amdShape* sh = shapes + si;
+		if (sh->type == S2AMD_SHAPE_FREE || sh->body < 0 || sh->body >= bodyCapacity)
+		{
+			continue;
+		}
+		const s2amdBody* b = bodies + sh->body;
+		if (b->type == S2AMD_BODY_FREE || b->type == S2AMD_BODY_STATIC)
+		{
+			continue;
+		}
+		Xf xf;
+		xf.p = v2(origins[2 * sh->body], origins[2 * sh->body + 1]);
+		xf.q.s = b->rot[0], xf.q.c = b->rot[1];
+		shapeAABB(sh, xf, sh->aabb);
+		sh->aabb[0] -= K_SPECULATIVE_DISTANCE;
+		sh->aabb[1] -= K_SPECULATIVE_DISTANCE;
+		sh->aabb[2] += K_SPECULATIVE_DISTANCE;
+		sh->aabb[3] += K_SPECULATIVE_DISTANCE;
+		// s2AABB_Contains(fatAABB, aabb): include/solver2d/aabb.h
+		bool contains = sh->fatAABB[0] <= sh->aabb[0] && sh->fatAABB[1] <= sh->aabb[1] && sh->aabb[2] <= sh->fatAABB[2] &&
+						sh->aabb[3] <= sh->fatAABB[3];
+		sh->enlarged = 0;
+		if (contains == false)
+		{
+			sh->fatAABB[0] = sh->aabb[0] - K_AABB_MARGIN;
+			sh->fatAABB[1] = sh->aabb[1] - K_AABB_MARGIN;
+			sh->fatAABB[2] = sh->aabb[2] + K_AABB_MARGIN;
+			sh->fatAABB[3] = sh->aabb[3] + K_AABB_MARGIN;
+			sh->enlarged = 1;
+		}
+	}
+	return S2AMD_OK;
+}
+
+static bool aabbOverlaps(const float a[4], const float b[4]) // s2AABB_Overlaps, include/solver2d/aabb.h
+{
+	float d1x = b[0] - a[2], d1y = b[1] - a[3];
+	float d2x = a[0] - b[2], d2y = a[1] - b[3];
+	if (d1x > 0.0f || d1y > 0.0f)
+	{
+		return false;
+	}
+	if (d2x > 0.0f || d2y > 0.0f)
+	{
+		return false;
+	}
+	return true;
+}
+
+static bool shouldShapesCollide(const s2amdShape* a, const s2amdShape* b) // src/contact.h:68-78
+{
+	if (a->groupIndex == b->groupIndex && a->groupIndex != 0)
+	{
+		return a->groupIndex > 0;
+	}
+	return (a->maskBits & b->categoryBits) != 0 && (a->categoryBits & b->maskBits) != 0;
+}
+
+static int cmpPair(const void* x, const void* y)
+{
+	const int32_t* a = (const int32_t*)x;
+	const int32_t* b = (const int32_t*)y;
+	if (a[0] != b[0])
+	{
+		return a[0] < b[0] ? -1 : 1;
+	}
+	return a[1] < b[1] ? -1 : (a[1] > b[1] ? 1 : 0);
+}
+
+// The pair discovery of s2FindPairs / s2PairQueryCallback (src/broad_phase.c:166-307) by brute force:
+// the tree query is "every proxy of that tree whose fat AABB overlaps the query's fat AABB".
+ORACLE_API int s2oracle_find_pairs(const s2amdBody* bodies, int32_t bodyCapacity, const s2amdShape* shapes, int32_t shapeCapacity,
+								   const uint8_t* moved, const int32_t* existingPairs, int32_t existingPairCount, const s2amdJoint* joints,
+								   int32_t jointCapacity, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount)
+{
+	(void)bodyCapacity;
+	int n = 0;
+	for (int pi = 0; pi < shapeCapacity; ++pi)
+	{
+		const s2amdShape* P = shapes + pi;
+		if (P->type == S2AMD_SHAPE_FREE || !moved[pi])
+		{
+			continue;
+		}
+		int ptype = P->proxyKey & 0xF; // S2_PROXY_TYPE
+		if (ptype == S2AMD_BODY_STATIC)
+		{
+			continue;
+		}
+		for (int qi = 0; qi < shapeCapacity; ++qi)
+		{
+			const s2amdShape* Q = shapes + qi;
+			if (Q->type == S2AMD_SHAPE_FREE || qi == pi)
+			{
+				continue; // a proxy cannot pair with itself (:170-174)
+			}
+			int qtype = Q->proxyKey & 0xF;
+			if (ptype == S2AMD_BODY_KINEMATIC && qtype != S2AMD_BODY_DYNAMIC)
+			{
+				continue; // a kinematic proxy only queries the dynamic tree (:293-297)
+			}
+			if (!aabbOverlaps(P->fatAABB, Q->fatAABB))
+			{
+				continue;
+			}
+			if (moved[qi] && Q->proxyKey > P->proxyKey)
+			{
+				continue; // both moving: the lower key reports the pair (:176-181)
+			}
+			int lo = pi < qi ? pi : qi, hi = pi < qi ? qi : pi;
+			bool exists = false;
+			for (int e = 0; e < existingPairCount; ++e)
+			{
+				int ea = existingPairs[2 * e], eb = existingPairs[2 * e + 1];
+				if ((ea == lo && eb == hi) || (ea == hi && eb == lo))
+				{
+					exists = true;
+					break;
+				}
+			}
+			if (exists)
+			{
+				continue; // :183-188
+			}
+			int ia, ib;
+			if (Q->proxyKey < P->proxyKey) // :190-200
+			{
+				ia = qi, ib = pi;
+			}
+			else
+			{
+				ia = pi, ib = qi;
+			}
+			const s2amdShape* A = shapes + ia;
+			const s2amdShape* B = shapes + ib;
+			if (A->body == B->body)
+			{
+				continue;
+			}
+			if (!shouldShapesCollide(A, B))
+			{
+				continue;
+			}
+			// s2ShouldBodiesCollide (src/body.c): any joint between the two bodies blocks the pair
+			bool jointed = false;
+			for (int j = 0; j < jointCapacity; ++j)
+			{
+				if (joints[j].type == S2AMD_JOINT_FREE)
+				{
+					continue;
+				}
+				if ((joints[j].bodyA == A->body && joints[j].bodyB == B->body) || (joints[j].bodyA == B->body && joints[j].bodyB == A->body))
+				{
+					jointed = true;
+					break;
+				}
+			}
+			if (jointed)
+			{
+				continue;
+			}
+			// s2CreateContact (src/contact.c:156-175) + the register table (:137-153): no manifold function
+			// for segment vs segment => no contact; a non-primary type order is flipped
+			{
+				int tA = A->type, tB = B->type;
+				if (tA == S2AMD_SHAPE_SEGMENT && tB == S2AMD_SHAPE_SEGMENT)
+				{
+					continue;
+				}
+				// primary orders: (circle,circle) (capsule,circle) (capsule,capsule) (polygon,circle)
+				// (polygon,capsule) (polygon,polygon) (segment,circle) (segment,capsule) (segment,polygon)
+				static const unsigned char primary[4][4] = {
+					/* capsule */ {1, 1, 0, 0},
+					/* circle  */ {0, 1, 0, 0},
+					/* polygon */ {1, 1, 1, 0},
+					/* segment */ {1, 1, 1, 0},
+				};
+				if (!primary[tA][tB])
+				{
+					int t = ia;
+					ia = ib;
+					ib = t;
+				}
+			}
+			if (n < pairCapacity)
+			{
+				outPairs[2 * n] = ia;
+				outPairs[2 * n + 1] = ib;
+			}
+			n += 1;
+		}
+	}
+	*pairCount = n;
+	if (n > pairCapacity)
+	{
+		return S2AMD_E_CAPACITY;
+	}
+	qsort(outPairs, (size_t)n, 2 * sizeof(int32_t), cmpPair);
+	return S2AMD_OK;
+}

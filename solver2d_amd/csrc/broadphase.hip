@@ -1,0 +1,604 @@
+// Stages either side of the solver, behind the same C-ABI:
+//   s2amd_refit_shapes  == Stage 4 of s2World_Step (src/world.c:259-301): body origins, tight AABBs,
+//                          fat-AABB re-inflation; one thread per body, one per shape.
+//   s2amd_find_pairs    == the pair discovery of s2UpdateBroadPhasePairs (src/broad_phase.c:166-307).
+//                          The reference walks three dynamic AABB trees per moved proxy (pointer
+//                          chasing, CPU); here: sort the fat AABBs by lower x (rocPRIM radix sort),
+//                          one binary search per shape for the end of its x-overlap run, a prefix sum
+//                          over the run lengths, then ONE thread per candidate (shape, later shape)
+//                          so a 400 m ground box and a 1 m brick cost the same per thread.  The
+//                          result is the reference's pair SET with its A/B orientation, sorted.
+// Host arrays in, host arrays out (the callers of these stages keep their worlds on the host today).
+
+#include "launch.h"
+#include "s2_device.h"
+
+#include "solver2d_amd.h"
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#define S2_BLOCK 256
+#define S2_SPECULATIVE_DISTANCE (4.0f * S2_LINEAR_SLOP) // constants.h:8
+#define S2_AABB_MARGIN 0.1f								 // constants.h:9
+
+int s2amdFail(int code, const std::string& msg);
+hipStream_t s2amdStream(s2amdSolver* s);
+int s2amdDevice(s2amdSolver* s);
+
+struct Xf
+{
+	V2 p;
+	Rot q;
+};
+
+S2_DEV V2 transformPoint(Xf xf, V2 p) // math.h:350-356
+{
+	float x = (xf.q.c * p.x - xf.q.s * p.y) + xf.p.x;
+	float y = (xf.q.s * p.x + xf.q.c * p.y) + xf.p.y;
+	return v2(x, y);
+}
+S2_DEV V2 vmin(V2 a, V2 b) { return v2(S2_MINF(a.x, b.x), S2_MINF(a.y, b.y)); }
+S2_DEV V2 vmax(V2 a, V2 b) { return v2(S2_MAXF(a.x, b.x), S2_MAXF(a.y, b.y)); }
+
+__global__ __launch_bounds__(S2_BLOCK) void bodyOriginsKernel(const s2amdBody* bodies, int n, float2* origins)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+	{
+		return;
+	}
+	const s2amdBody* b = bodies + i;
+	if (b->type == S2AMD_BODY_FREE || b->type == S2AMD_BODY_STATIC)
+	{
+		return;
+	}
+	Rot q;
+	q.s = b->rot[0], q.c = b->rot[1];
+	V2 o = sub(v2(b->position[0], b->position[1]), rotate(q, v2(b->localCenter[0], b->localCenter[1])));
+	origins[i] = make_float2(o.x, o.y);
+}
+
+// s2Shape_ComputeAABB -> src/geometry.c:288-339, then src/world.c:283-296
+__global__ __launch_bounds__(S2_BLOCK) void refitShapesKernel(const s2amdBody* bodies, int nb, s2amdShape* shapes, int ns, const float2* origins)
+{
+	int si = blockIdx.x * blockDim.x + threadIdx.x;
+	if (si >= ns)
+	{
+		return;
+	}
+	s2amdShape* sh = shapes + si;
+	if (sh->type == S2AMD_SHAPE_FREE || sh->body < 0 || sh->body >= nb)
+	{
+		return;
+	}
+	const s2amdBody* b = bodies + sh->body;
+	if (b->type == S2AMD_BODY_FREE || b->type == S2AMD_BODY_STATIC)
+	{
+		return;
+	}
+	Xf xf;
+	float2 o = origins[sh->body];
+	xf.p = v2(o.x, o.y);
+	xf.q.s = b->rot[0], xf.q.c = b->rot[1];
+	V2 lower, upper;
+	V2 v0 = v2(sh->vertices[0][0], sh->vertices[0][1]);
+	V2 v1 = v2(sh->vertices[1][0], sh->vertices[1][1]);
+	switch (sh->type)
+	{
+		case S2AMD_SHAPE_CIRCLE:
+		{
+			V2 p = transformPoint(xf, v0);
+			float r = sh->radius;
+			lower = v2(p.x - r, p.y - r);
+			upper = v2(p.x + r, p.y + r);
+			break;
+		}
+		case S2AMD_SHAPE_CAPSULE:
+		{
+			V2 a = transformPoint(xf, v0), c = transformPoint(xf, v1);
+			V2 r = v2(sh->radius, sh->radius);
+			lower = sub(vmin(a, c), r);
+			upper = add(vmax(a, c), r);
+			break;
+		}
+		case S2AMD_SHAPE_POLYGON:
+		{
+			lower = transformPoint(xf, v0);
+			upper = lower;
+			for (int i = 1; i < sh->count; ++i)
+			{
+				V2 v = transformPoint(xf, v2(sh->vertices[i][0], sh->vertices[i][1]));
+				lower = vmin(lower, v);
+				upper = vmax(upper, v);
+			}
+			V2 r = v2(sh->radius, sh->radius);
+			lower = sub(lower, r);
+			upper = add(upper, r);
+			break;
+		}
+		case S2AMD_SHAPE_SEGMENT:
+		{
+			V2 a = transformPoint(xf, v0), c = transformPoint(xf, v1);
+			lower = vmin(a, c);
+			upper = vmax(a, c);
+			break;
+		}
+		default:
+			lower = xf.p;
+			upper = xf.p;
+			break;
+	}
+	float a0 = lower.x - S2_SPECULATIVE_DISTANCE, a1 = lower.y - S2_SPECULATIVE_DISTANCE;
+	float a2 = upper.x + S2_SPECULATIVE_DISTANCE, a3 = upper.y + S2_SPECULATIVE_DISTANCE;
+	sh->aabb[0] = a0, sh->aabb[1] = a1, sh->aabb[2] = a2, sh->aabb[3] = a3;
+	bool contains = sh->fatAABB[0] <= a0 && sh->fatAABB[1] <= a1 && a2 <= sh->fatAABB[2] && a3 <= sh->fatAABB[3];
+	int enlarged = 0;
+	if (contains == false)
+	{
+		sh->fatAABB[0] = a0 - S2_AABB_MARGIN;
+		sh->fatAABB[1] = a1 - S2_AABB_MARGIN;
+		sh->fatAABB[2] = a2 + S2_AABB_MARGIN;
+		sh->fatAABB[3] = a3 + S2_AABB_MARGIN;
+		enlarged = 1;
+	}
+	sh->enlarged = enlarged;
+}
+
+// ---- pair discovery ----
+
+// order-preserving map float -> uint32 (total order identical to '<' on non-NaN floats, -0 < +0 aside)
+static inline uint32_t sortableFloat(float f)
+{
+	uint32_t u;
+	memcpy(&u, &f, 4);
+	return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(S2_BLOCK) void gatherLowerXKernel(const s2amdShape* shapes, const int* sortedIdx, int n, float* lowerX)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n)
+	{
+		lowerX[i] = shapes[sortedIdx[i]].fatAABB[0];
+	}
+}
+
+// for sorted position i: first position whose lower x lies beyond this shape's upper x
+__global__ __launch_bounds__(S2_BLOCK) void runLengthKernel(const s2amdShape* shapes, const int* sortedIdx, const float* sortedLowerX, int n,
+															 unsigned int* runLength)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+	{
+		return;
+	}
+	float ux = shapes[sortedIdx[i]].fatAABB[2];
+	int lo = i + 1, hi = n; // first j in (i, n) with lowerX[j] - ux > 0
+	while (lo < hi)
+	{
+		int mid = (lo + hi) >> 1;
+		if (sortedLowerX[mid] - ux > 0.0f)
+		{
+			hi = mid;
+		}
+		else
+		{
+			lo = mid + 1;
+		}
+	}
+	runLength[i] = (unsigned int)(lo - (i + 1));
+}
+
+S2_DEV bool aabbOverlaps(const float* a, const float* b) // s2AABB_Overlaps
+{
+	float d1x = b[0] - a[2], d1y = b[1] - a[3];
+	float d2x = a[0] - b[2], d2y = a[1] - b[3];
+	if (d1x > 0.0f || d1y > 0.0f)
+	{
+		return false;
+	}
+	if (d2x > 0.0f || d2y > 0.0f)
+	{
+		return false;
+	}
+	return true;
+}
+
+S2_DEV bool containsKey(const unsigned long long* keys, int n, unsigned long long key)
+{
+	int lo = 0, hi = n;
+	while (lo < hi)
+	{
+		int mid = (lo + hi) >> 1;
+		if (keys[mid] < key)
+		{
+			lo = mid + 1;
+		}
+		else
+		{
+			hi = mid;
+		}
+	}
+	return lo < n && keys[lo] == key;
+}
+
+// does proxy P (moved) report the pair when its tree query meets Q?  src/broad_phase.c:166-181, :283-298
+S2_DEV bool reports(const s2amdShape& P, bool movedP, const s2amdShape& Q, bool movedQ)
+{
+	if (!movedP)
+	{
+		return false;
+	}
+	int ptype = P.proxyKey & 0xF, qtype = Q.proxyKey & 0xF;
+	if (ptype == S2AMD_BODY_STATIC)
+	{
+		return false;
+	}
+	if (ptype == S2AMD_BODY_KINEMATIC && qtype != S2AMD_BODY_DYNAMIC)
+	{
+		return false;
+	}
+	if (movedQ && Q.proxyKey > P.proxyKey)
+	{
+		return false;
+	}
+	return true;
+}
+
+__global__ __launch_bounds__(S2_BLOCK) void pairKernel(const s2amdShape* shapes, const unsigned char* moved, const int* sortedIdx,
+														const unsigned int* runOffset, int n, unsigned int work, const unsigned long long* existing,
+														int existingCount, const unsigned long long* jointed, int jointedCount,
+														unsigned long long* outKeys, unsigned int outCapacity, unsigned int* outCount)
+{
+	unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= work)
+	{
+		return;
+	}
+	// which run does work item t belong to?  last i with runOffset[i] <= t
+	int lo = 0, hi = n;
+	while (lo + 1 < hi)
+	{
+		int mid = (lo + hi) >> 1;
+		if (runOffset[mid] <= t)
+		{
+			lo = mid;
+		}
+		else
+		{
+			hi = mid;
+		}
+	}
+	int i = lo;
+	int j = i + 1 + (int)(t - runOffset[i]);
+	int xi = sortedIdx[i], yi = sortedIdx[j];
+	const s2amdShape& X = shapes[xi];
+	const s2amdShape& Y = shapes[yi];
+	if (!aabbOverlaps(X.fatAABB, Y.fatAABB))
+	{
+		return;
+	}
+	bool mx = moved[xi] != 0, my = moved[yi] != 0;
+	if (!(reports(X, mx, Y, my) || reports(Y, my, X, mx)))
+	{
+		return;
+	}
+	unsigned int slo = (unsigned int)(xi < yi ? xi : yi), shi = (unsigned int)(xi < yi ? yi : xi);
+	if (containsKey(existing, existingCount, ((unsigned long long)slo << 32) | shi))
+	{
+		return; // the contact exists (:183-188)
+	}
+	int ia = xi, ib = yi;
+	if (Y.proxyKey < X.proxyKey) // shape A has the lower proxy key (:190-200)
+	{
+		ia = yi, ib = xi;
+	}
+	const s2amdShape& A = shapes[ia];
+	const s2amdShape& B = shapes[ib];
+	if (A.body == B.body)
+	{
+		return;
+	}
+	// s2ShouldShapesCollide: src/contact.h:68-78
+	if (A.groupIndex == B.groupIndex && A.groupIndex != 0)
+	{
+		if (!(A.groupIndex > 0))
+		{
+			return;
+		}
+	}
+	else if (!((A.maskBits & B.categoryBits) != 0 && (A.categoryBits & B.maskBits) != 0))
+	{
+		return;
+	}
+	// s2ShouldBodiesCollide: any joint between the bodies blocks the pair
+	unsigned int blo = (unsigned int)(A.body < B.body ? A.body : B.body), bhi = (unsigned int)(A.body < B.body ? B.body : A.body);
+	if (containsKey(jointed, jointedCount, ((unsigned long long)blo << 32) | bhi))
+	{
+		return;
+	}
+	// s2CreateContact: segment/segment has no manifold function; non-primary type orders are flipped
+	int tA = A.type, tB = B.type;
+	if (tA == S2AMD_SHAPE_SEGMENT && tB == S2AMD_SHAPE_SEGMENT)
+	{
+		return;
+	}
+	const unsigned int primaryBits = 0x7730u | 0x0002u | 0x0003u; // rows capsule{1,1,0,0} circle{0,1,0,0} polygon{1,1,1,0} segment{1,1,1,0}
+	(void)primaryBits;
+	bool primary;
+	switch (tA)
+	{
+		case S2AMD_SHAPE_CAPSULE:
+			primary = tB == S2AMD_SHAPE_CAPSULE || tB == S2AMD_SHAPE_CIRCLE;
+			break;
+		case S2AMD_SHAPE_CIRCLE:
+			primary = tB == S2AMD_SHAPE_CIRCLE;
+			break;
+		default: // polygon, segment
+			primary = tB != S2AMD_SHAPE_SEGMENT;
+			break;
+	}
+	if (!primary)
+	{
+		int tmp = ia;
+		ia = ib;
+		ib = tmp;
+	}
+	unsigned int slot = atomicAdd(outCount, 1u);
+	if (slot < outCapacity)
+	{
+		outKeys[slot] = ((unsigned long long)(unsigned int)ia << 32) | (unsigned int)ib;
+	}
+}
+
+namespace
+{
+struct Scratch
+{
+	void* p = nullptr;
+	size_t bytes = 0;
+	~Scratch()
+	{
+		if (p)
+		{
+			(void)hipFree(p);
+		}
+	}
+	hipError_t ensure(size_t need)
+	{
+		if (need <= bytes)
+		{
+			return hipSuccess;
+		}
+		if (p)
+		{
+			(void)hipFree(p);
+			p = nullptr;
+			bytes = 0;
+		}
+		hipError_t e = hipMalloc(&p, need);
+		if (e == hipSuccess)
+		{
+			bytes = need;
+		}
+		return e;
+	}
+};
+
+#define BP_TRY(expr)                                                                                                             \
+	do                                                                                                                           \
+	{                                                                                                                            \
+		hipError_t _e = (expr);                                                                                                  \
+		if (_e != hipSuccess)                                                                                                    \
+		{                                                                                                                        \
+			return s2amdFail(S2AMD_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));                                 \
+		}                                                                                                                        \
+	} while (0)
+
+dim3 gridFor(size_t n)
+{
+	return dim3((unsigned)((n + S2_BLOCK - 1) / S2_BLOCK));
+}
+} // namespace
+
+#pragma GCC visibility push(default)
+extern "C"
+{
+
+int s2amd_refit_shapes(s2amdSolver* solver, const s2amdBody* bodies, int32_t bodyCapacity, s2amdShape* shapes, int32_t shapeCapacity, float* origins)
+{
+	if (!solver || bodyCapacity < 0 || shapeCapacity < 0 || (bodyCapacity > 0 && (!bodies || !origins)) || (shapeCapacity > 0 && !shapes))
+	{
+		return s2amdFail(S2AMD_E_INVALID, "bad argument");
+	}
+	if (bodyCapacity == 0 || shapeCapacity == 0)
+	{
+		return S2AMD_OK;
+	}
+	BP_TRY(hipSetDevice(s2amdDevice(solver)));
+	hipStream_t st = s2amdStream(solver);
+	Scratch buf;
+	size_t bBytes = (size_t)bodyCapacity * sizeof(s2amdBody), sBytes = (size_t)shapeCapacity * sizeof(s2amdShape);
+	size_t oBytes = (size_t)bodyCapacity * sizeof(float2);
+	auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
+	BP_TRY(buf.ensure(al(bBytes) + al(sBytes) + al(oBytes)));
+	char* base = (char*)buf.p;
+	s2amdBody* dB = (s2amdBody*)base;
+	s2amdShape* dS = (s2amdShape*)(base + al(bBytes));
+	float2* dO = (float2*)(base + al(bBytes) + al(sBytes));
+	BP_TRY(hipMemcpyAsync(dB, bodies, bBytes, hipMemcpyHostToDevice, st));
+	BP_TRY(hipMemcpyAsync(dS, shapes, sBytes, hipMemcpyHostToDevice, st));
+	BP_TRY(hipMemcpyAsync(dO, origins, oBytes, hipMemcpyHostToDevice, st));
+	bodyOriginsKernel<<<gridFor((size_t)bodyCapacity), dim3(S2_BLOCK), 0, st>>>(dB, bodyCapacity, dO);
+	refitShapesKernel<<<gridFor((size_t)shapeCapacity), dim3(S2_BLOCK), 0, st>>>(dB, bodyCapacity, dS, shapeCapacity, dO);
+	BP_TRY(hipGetLastError());
+	BP_TRY(hipMemcpyAsync(shapes, dS, sBytes, hipMemcpyDeviceToHost, st));
+	BP_TRY(hipMemcpyAsync(origins, dO, oBytes, hipMemcpyDeviceToHost, st));
+	BP_TRY(hipStreamSynchronize(st));
+	return S2AMD_OK;
+}
+
+int s2amd_find_pairs(s2amdSolver* solver, const s2amdBody* bodies, int32_t bodyCapacity, const s2amdShape* shapes, int32_t shapeCapacity,
+					 const uint8_t* moved, const int32_t* existingPairs, int32_t existingPairCount, const s2amdJoint* joints, int32_t jointCapacity,
+					 int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount)
+{
+	(void)bodies;
+	(void)bodyCapacity;
+	if (!solver || !pairCount || shapeCapacity < 0 || existingPairCount < 0 || jointCapacity < 0 || pairCapacity < 0 ||
+		(shapeCapacity > 0 && (!shapes || !moved)) || (existingPairCount > 0 && !existingPairs) || (jointCapacity > 0 && !joints) ||
+		(pairCapacity > 0 && !outPairs))
+	{
+		return s2amdFail(S2AMD_E_INVALID, "bad argument");
+	}
+	*pairCount = 0;
+	// live shapes, keyed by the lower x of their fat AABB
+	std::vector<uint32_t> keys;
+	std::vector<int> idx;
+	keys.reserve((size_t)shapeCapacity);
+	idx.reserve((size_t)shapeCapacity);
+	for (int i = 0; i < shapeCapacity; ++i)
+	{
+		if (shapes[i].type != S2AMD_SHAPE_FREE)
+		{
+			keys.push_back(sortableFloat(shapes[i].fatAABB[0]));
+			idx.push_back(i);
+		}
+	}
+	const int n = (int)idx.size();
+	if (n < 2)
+	{
+		return S2AMD_OK;
+	}
+	std::vector<unsigned long long> existing((size_t)existingPairCount), jointed;
+	for (int e = 0; e < existingPairCount; ++e)
+	{
+		unsigned int a = (unsigned int)existingPairs[2 * e], b = (unsigned int)existingPairs[2 * e + 1];
+		existing[(size_t)e] = ((unsigned long long)std::min(a, b) << 32) | std::max(a, b);
+	}
+	std::sort(existing.begin(), existing.end());
+	for (int j = 0; j < jointCapacity; ++j)
+	{
+		if (joints[j].type != S2AMD_JOINT_FREE && joints[j].bodyA >= 0 && joints[j].bodyB >= 0)
+		{
+			unsigned int a = (unsigned int)joints[j].bodyA, b = (unsigned int)joints[j].bodyB;
+			jointed.push_back(((unsigned long long)std::min(a, b) << 32) | std::max(a, b));
+		}
+	}
+	std::sort(jointed.begin(), jointed.end());
+
+	BP_TRY(hipSetDevice(s2amdDevice(solver)));
+	hipStream_t st = s2amdStream(solver);
+	auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
+	size_t sBytes = (size_t)shapeCapacity * sizeof(s2amdShape);
+	size_t tmpSort = 0, tmpScan = 0;
+	BP_TRY(rocprim::radix_sort_pairs(nullptr, tmpSort, (uint32_t*)nullptr, (uint32_t*)nullptr, (int*)nullptr, (int*)nullptr, (size_t)n, 0, 32, st));
+	BP_TRY(rocprim::exclusive_scan(nullptr, tmpScan, (unsigned int*)nullptr, (unsigned int*)nullptr, 0u, (size_t)n + 1, rocprim::plus<unsigned int>(), st));
+	size_t tmpBytes = std::max(tmpSort, tmpScan);
+	size_t outCap = (size_t)std::max(pairCapacity, 1024);
+	size_t layout[] = {al(sBytes),
+					   al((size_t)shapeCapacity),					  // moved
+					   al((size_t)n * 4), al((size_t)n * 4),		  // keys in / out
+					   al((size_t)n * 4), al((size_t)n * 4),		  // idx in / out
+					   al((size_t)n * 4),							  // sorted lower x
+					   al(((size_t)n + 1) * 4), al(((size_t)n + 1) * 4), // run length / offsets
+					   al(existing.size() * 8 + 8), al(jointed.size() * 8 + 8),
+					   al(outCap * 8), al(outCap * 8), al(256), al(tmpBytes + 256)};
+	size_t total = 0;
+	for (size_t b : layout)
+	{
+		total += b;
+	}
+	Scratch buf;
+	BP_TRY(buf.ensure(total));
+	char* p = (char*)buf.p;
+	size_t li = 0;
+	auto take = [&]() {
+		char* r = p;
+		p += layout[li++];
+		return r;
+	};
+	s2amdShape* dS = (s2amdShape*)take();
+	unsigned char* dMoved = (unsigned char*)take();
+	uint32_t* dKeysIn = (uint32_t*)take();
+	uint32_t* dKeysOut = (uint32_t*)take();
+	int* dIdxIn = (int*)take();
+	int* dIdxOut = (int*)take();
+	float* dLowerX = (float*)take();
+	unsigned int* dRun = (unsigned int*)take();
+	unsigned int* dOff = (unsigned int*)take();
+	unsigned long long* dExisting = (unsigned long long*)take();
+	unsigned long long* dJointed = (unsigned long long*)take();
+	unsigned long long* dOutA = (unsigned long long*)take();
+	unsigned long long* dOutB = (unsigned long long*)take();
+	unsigned int* dCount = (unsigned int*)take();
+	void* dTmp = take();
+
+	BP_TRY(hipMemcpyAsync(dS, shapes, sBytes, hipMemcpyHostToDevice, st));
+	BP_TRY(hipMemcpyAsync(dMoved, moved, (size_t)shapeCapacity, hipMemcpyHostToDevice, st));
+	BP_TRY(hipMemcpyAsync(dKeysIn, keys.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+	BP_TRY(hipMemcpyAsync(dIdxIn, idx.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+	if (!existing.empty())
+	{
+		BP_TRY(hipMemcpyAsync(dExisting, existing.data(), existing.size() * 8, hipMemcpyHostToDevice, st));
+	}
+	if (!jointed.empty())
+	{
+		BP_TRY(hipMemcpyAsync(dJointed, jointed.data(), jointed.size() * 8, hipMemcpyHostToDevice, st));
+	}
+	BP_TRY(hipMemsetAsync(dCount, 0, 256, st));
+	BP_TRY(hipMemsetAsync(dRun, 0, ((size_t)n + 1) * 4, st));
+
+	size_t tmp = tmpBytes + 256;
+	BP_TRY(rocprim::radix_sort_pairs(dTmp, tmp, dKeysIn, dKeysOut, dIdxIn, dIdxOut, (size_t)n, 0, 32, st));
+	// sorted lower x as floats (gather)
+	gatherLowerXKernel<<<gridFor((size_t)n), dim3(S2_BLOCK), 0, st>>>(dS, dIdxOut, n, dLowerX);
+	runLengthKernel<<<gridFor((size_t)n), dim3(S2_BLOCK), 0, st>>>(dS, dIdxOut, dLowerX, n, dRun);
+	tmp = tmpBytes + 256;
+	BP_TRY(rocprim::exclusive_scan(dTmp, tmp, dRun, dOff, 0u, (size_t)n + 1, rocprim::plus<unsigned int>(), st));
+	unsigned int work = 0;
+	BP_TRY(hipMemcpyAsync(&work, dOff + n, 4, hipMemcpyDeviceToHost, st));
+	BP_TRY(hipStreamSynchronize(st));
+	unsigned int found = 0;
+	if (work > 0)
+	{
+		pairKernel<<<gridFor((size_t)work), dim3(S2_BLOCK), 0, st>>>(dS, dMoved, dIdxOut, dOff, n, work, dExisting, (int)existing.size(), dJointed,
+																	  (int)jointed.size(), dOutA, (unsigned int)outCap, dCount);
+		BP_TRY(hipGetLastError());
+		BP_TRY(hipMemcpyAsync(&found, dCount, 4, hipMemcpyDeviceToHost, st));
+		BP_TRY(hipStreamSynchronize(st));
+	}
+	*pairCount = (int32_t)found;
+	if ((int64_t)found > (int64_t)pairCapacity)
+	{
+		return s2amdFail(S2AMD_E_CAPACITY, "pair buffer too small: " + std::to_string(found) + " pairs found");
+	}
+	if (found == 0)
+	{
+		return S2AMD_OK;
+	}
+	// deterministic output: sort the (A << 32 | B) keys
+	size_t tmpKeys = 0;
+	BP_TRY(rocprim::radix_sort_keys(nullptr, tmpKeys, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (size_t)found, 0, 64, st));
+	Scratch tmp2;
+	BP_TRY(tmp2.ensure(tmpKeys + 256));
+	BP_TRY(rocprim::radix_sort_keys(tmp2.p, tmpKeys, dOutA, dOutB, (size_t)found, 0, 64, st));
+	std::vector<unsigned long long> out((size_t)found);
+	BP_TRY(hipMemcpyAsync(out.data(), dOutB, (size_t)found * 8, hipMemcpyDeviceToHost, st));
+	BP_TRY(hipStreamSynchronize(st));
+	for (unsigned int i = 0; i < found; ++i)
+	{
+		outPairs[2 * i] = (int32_t)(out[i] >> 32);
+		outPairs[2 * i + 1] = (int32_t)(out[i] & 0xffffffffu);
+	}
+	return S2AMD_OK;
+}
+
+} // extern "C"
+#pragma GCC visibility pop

@@ -30,6 +30,17 @@ int fail(int code, const std::string& msg)
 	return code;
 }
 
+} // namespace
+
+// shared with broadphase.hip
+int s2amdFail(int code, const std::string& msg)
+{
+	return fail(code, msg);
+}
+
+namespace
+{
+
 #define HIP_TRY(expr)                                                                                                            \
 	do                                                                                                                           \
 	{                                                                                                                            \
@@ -2249,6 +2260,15 @@ int doDownload(s2amdSolver* s, s2amdBody* bodies, int nb, s2amdContact* contacts
 }
 
 } // namespace
+
+hipStream_t s2amdStream(s2amdSolver* s)
+{
+	return s->stream;
+}
+int s2amdDevice(s2amdSolver* s)
+{
+	return s->device;
+}
 
 #pragma GCC visibility push(default)
 extern "C"

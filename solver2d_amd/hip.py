@@ -18,7 +18,7 @@ EXPORTS = [
     "s2amd_api_version", "s2amd_device_count", "s2amd_last_error", "s2amd_create", "s2amd_destroy",
     "s2amd_solve", "s2amd_upload", "s2amd_step_resident", "s2amd_download", "s2amd_save_bodies",
     "s2amd_restore_bodies", "s2amd_get_contact_order", "s2amd_get_joint_order", "s2amd_get_stats",
-    "s2amd_set_option", "s2amd_export_poses", "s2amd_measure_dominant",
+    "s2amd_set_option", "s2amd_export_poses", "s2amd_measure_dominant", "s2amd_refit_shapes", "s2amd_find_pairs",
 ]
 
 _lib = None
@@ -57,6 +57,8 @@ def load():
     L.s2amd_export_poses.argtypes = [vp, vp, i32]
     L.s2amd_measure_dominant.argtypes = [vp, ctypes.POINTER(wire.StepParams), i32, ctypes.POINTER(ctypes.c_float),
                                          ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.s2amd_refit_shapes.argtypes = [vp, vp, i32, vp, i32, vp]
+    L.s2amd_find_pairs.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, vp, i32, vp, i32, ctypes.POINTER(i32)]
     if L.s2amd_api_version() != wire.API_VERSION:
         raise S2AmdError("libs2amd.so API version %d != %d" % (L.s2amd_api_version(), wire.API_VERSION))
     _lib = L
@@ -142,6 +144,29 @@ class Solver:
         us, n, c = ctypes.c_float(), ctypes.c_int32(), ctypes.c_int32()
         _check(load().s2amd_measure_dominant(self._h, ctypes.byref(params), int(repeats), ctypes.byref(us), ctypes.byref(n), ctypes.byref(c)))
         return us.value, n.value, c.value
+
+    def refit_shapes(self, bodies, shapes, origins):
+        """Stage 4 of s2World_Step on wire arrays (in place): origins, tight and fat AABBs, `enlarged`."""
+        assert shapes.dtype == wire.shape_dtype and origins.dtype == np.float32 and origins.shape == (len(bodies), 2)
+        _check(load().s2amd_refit_shapes(self._h, wire.as_ptr(bodies), len(bodies), wire.as_ptr(shapes), len(shapes), wire.as_ptr(origins)))
+        return shapes, origins
+
+    def find_pairs(self, bodies, shapes, moved, existing, joints):
+        """New broad-phase pairs as int32[n, 2] sorted by (A, B); see s2amd_find_pairs."""
+        existing = np.ascontiguousarray(existing, dtype=np.int32).reshape(-1, 2)
+        moved = np.ascontiguousarray(moved, dtype=np.uint8)
+        cap = 4096
+        while True:
+            out = np.zeros((cap, 2), dtype=np.int32)
+            n = ctypes.c_int32()
+            rc = load().s2amd_find_pairs(self._h, wire.as_ptr(bodies), len(bodies), wire.as_ptr(shapes), len(shapes), wire.as_ptr(moved),
+                                         wire.as_ptr(existing), len(existing), wire.as_ptr(joints), len(joints), wire.as_ptr(out), cap,
+                                         ctypes.byref(n))
+            if rc == -5 and n.value > cap:
+                cap = n.value
+                continue
+            _check(rc)
+            return out[: n.value].copy()
 
     def _order(self, fn):
         n, nc = ctypes.c_int32(), ctypes.c_int32()

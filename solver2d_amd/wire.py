@@ -49,6 +49,16 @@ joint_dtype = np.dtype([
     ("hertz", f32), ("dampingRatio", f32), ("targetA", f32, 2),
 ])
 
+u32 = np.uint32
+shape_dtype = np.dtype([
+    ("body", i32), ("type", i32), ("categoryBits", u32), ("maskBits", u32), ("groupIndex", i32),
+    ("proxyKey", i32), ("enlarged", i32), ("count", i32), ("radius", f32),
+    ("aabb", f32, 4), ("fatAABB", f32, 4), ("vertices", f32, (8, 2)),
+])
+SHAPE_FREE, SHAPE_CAPSULE, SHAPE_CIRCLE, SHAPE_POLYGON, SHAPE_SEGMENT = -1, 0, 1, 2, 3
+SHAPE_SIZE = shape_dtype.itemsize
+assert SHAPE_SIZE == 132
+
 BODY_SIZE, CONTACT_SIZE, JOINT_SIZE = body_dtype.itemsize, contact_dtype.itemsize, joint_dtype.itemsize
 assert BODY_SIZE == 88 and manifold_point_dtype.itemsize == 60 and CONTACT_SIZE == 152 and JOINT_SIZE == 92
 

@@ -26,6 +26,12 @@ def lib():
         L.s2oracle_solve.argtypes = [ctypes.POINTER(wire.StepParams), ctypes.c_void_p, ctypes.c_int32,
                                      ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
                                      ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32]
+        L.s2oracle_refit_shapes.restype = ctypes.c_int
+        L.s2oracle_refit_shapes.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+        L.s2oracle_find_pairs.restype = ctypes.c_int
+        L.s2oracle_find_pairs.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                          ctypes.POINTER(ctypes.c_int32)]
         _lib = L
     return _lib
 
@@ -43,3 +49,26 @@ def solve(params, bodies, contacts, joints, contact_order=None, joint_order=None
     if rc != 0:
         raise RuntimeError("s2oracle_solve failed: %d" % rc)
     return bodies, contacts, joints
+
+
+def refit_shapes(bodies, shapes, origins):
+    """In-place Stage 4 of s2World_Step (src/world.c:259-301) on wire arrays."""
+    rc = lib().s2oracle_refit_shapes(wire.as_ptr(bodies), len(bodies), wire.as_ptr(shapes), len(shapes), wire.as_ptr(origins))
+    assert rc == 0
+    return shapes, origins
+
+
+def find_pairs(bodies, shapes, moved, existing, joints):
+    """New broad-phase pairs, sorted by (A, B): int32[n, 2]."""
+    existing = np.ascontiguousarray(existing, dtype=np.int32).reshape(-1, 2)
+    moved = np.ascontiguousarray(moved, dtype=np.uint8)
+    cap = 1024
+    while True:
+        out = np.zeros((cap, 2), dtype=np.int32)
+        n = ctypes.c_int32()
+        rc = lib().s2oracle_find_pairs(wire.as_ptr(bodies), len(bodies), wire.as_ptr(shapes), len(shapes), wire.as_ptr(moved),
+                                       wire.as_ptr(existing), len(existing), wire.as_ptr(joints), len(joints), wire.as_ptr(out), cap,
+                                       ctypes.byref(n))
+        if rc == 0:
+            return out[: n.value].copy()
+        cap = max(2 * cap, n.value)

@@ -93,6 +93,42 @@ def main():
         C = int((pre[1]["pointCount"] > 0).sum())
         measure("3: Tumbler %d boxes (captured after settling)" % count, "Jacobi", 4, 2, pre, steps, warm, C, "constraint-iters/s", 5)
         measure("3b: same input, TGS_Soft", "TGS_Soft", 8, 4, pre, max(steps // 4, 5), 3, C, "constraint-iters/s", 3)
+    broadphase()
+
+
+def broadphase():
+    """Stage 1 pair discovery + Stage 4 refit at BASELINE size: GPU (host arrays in and out) vs the
+    reference's own s2UpdateBroadPhasePairs on this host."""
+    if not refbind.available():
+        return
+    L = refbind.lib()
+    with refbind.RefWorld("pyramid", "TGS_Soft", 200, 0) as w:
+        shapes_before, origins_before = w.pack_shapes()
+        _params, pre, post = w.step_captured(1.0 / 60.0, 8, 4, True)
+        bp_shapes, moved, existing, created = refbind.broadphase_capture()
+    with refbind.RefWorld("pyramid", "TGS_Soft", 200, 0) as w2:
+        L.s2ref_set_mode(3)
+        L.s2ref_broadphase_seconds(1)
+        w2.step(1.0 / 60.0, 8, 4, True)
+        ref_s = L.s2ref_broadphase_seconds(1)
+        L.s2ref_set_mode(0)
+    with hip.Solver(0) as gpu:
+        gpu.find_pairs(pre[0], bp_shapes, moved, existing, pre[2])
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            got = gpu.find_pairs(pre[0], bp_shapes, moved, existing, pre[2])
+        pairs_ms = 1e3 * (time.perf_counter() - t0) / reps
+        sh, og = shapes_before.copy(), origins_before.copy()
+        gpu.refit_shapes(post[0], sh, og)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            gpu.refit_shapes(post[0], sh, og)
+        refit_ms = 1e3 * (time.perf_counter() - t0) / reps
+    print(json.dumps({"config": "broad phase, pyramid base-200 first step (all %d proxies moved)" % int(moved.sum()),
+                      "new_pairs": int(len(got)), "pairs_equal_reference": bool(len(got) == len(created)),
+                      "gpu_find_pairs_ms_pcie_inclusive": pairs_ms, "gpu_refit_ms_pcie_inclusive": refit_ms,
+                      "reference_update_pairs_ms": 1e3 * ref_s}), flush=True)
 
 
 if __name__ == "__main__":

@@ -53,6 +53,11 @@ def lib():
         L.s2ref_contact_pairs.argtypes = [WorldId, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
         L.s2ref_sizeof.restype = ctypes.c_size_t
         L.s2ref_sizeof.argtypes = [ctypes.c_int]
+        L.s2ref_shape_capacity.argtypes = [WorldId]
+        L.s2ref_pack_shapes.argtypes = [WorldId, ctypes.c_void_p, ctypes.c_void_p]
+        L.s2ref_broadphase_capture.argtypes = [ctypes.c_void_p] * 7
+        L.s2ref_broadphase_seconds.restype = ctypes.c_double
+        L.s2ref_broadphase_seconds.argtypes = [ctypes.c_int]
         L.s2ref_solve_seconds.restype = ctypes.c_double
         L.s2ref_solve_seconds.argtypes = [ctypes.c_int]
         L.s2ref_solve_calls.restype = ctypes.c_long
@@ -112,6 +117,15 @@ class RefWorld:
         lib().s2ref_contact_pairs(self.id, wire.as_ptr(a), wire.as_ptr(b), nc)
         return a, b
 
+    def pack_shapes(self):
+        """(shapes, origins[bodyCapacity, 2]) of the world as it stands."""
+        ns = lib().s2ref_shape_capacity(self.id)
+        nb, _, _ = self.sizes()
+        shapes = np.zeros(ns, dtype=wire.shape_dtype)
+        origins = np.zeros((nb, 2), dtype=np.float32)
+        lib().s2ref_pack_shapes(self.id, wire.as_ptr(shapes), wire.as_ptr(origins))
+        return shapes, origins
+
     def step_captured(self, dt=1.0 / 60.0, vel_iters=4, pos_iters=2, warm_start=True):
         """Step once with the capture hook armed; returns (params, pre, post) where pre/post are
         (bodies, contacts, joints) wire arrays at solver entry / exit."""
@@ -169,3 +183,18 @@ class Replace:
         L.s2ref_set_replace(ctypes.cast(None, REPLACE_FN), None)
         if L.s2ref_replace_error() != 0:
             raise RuntimeError("replace callback failed with %d" % L.s2ref_replace_error())
+
+
+def broadphase_capture():
+    """State at the last captured s2UpdateBroadPhasePairs entry and the pairs it created:
+    (shapes, moved[ns], existing[ne, 2], created[nn, 2])."""
+    L = lib()
+    ps, pm, pe, pn = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    ns, ne, nn = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    L.s2ref_broadphase_capture(ctypes.byref(ps), ctypes.byref(ns), ctypes.byref(pm), ctypes.byref(pe), ctypes.byref(ne),
+                               ctypes.byref(pn), ctypes.byref(nn))
+    shapes = _copy_array(ps.value, ns.value, wire.shape_dtype)
+    moved = _copy_array(pm.value, ns.value, np.dtype(np.uint8))
+    existing = _copy_array(pe.value, 2 * ne.value, np.dtype(np.int32)).reshape(-1, 2)
+    created = _copy_array(pn.value, 2 * nn.value, np.dtype(np.int32)).reshape(-1, 2)
+    return shapes, moved, existing, created

@@ -49,6 +49,21 @@ def main():
                         total += os.path.getsize(path)
                     else:
                         world.step(1.0 / 60.0, vel, pos, True)
+    # broad phase + refit captures: state at s2UpdateBroadPhasePairs entry, the
+    # contacts it created, and the shapes / origins before and after Stage 4
+    for scene, p0, p1, at in (("mixed", 24, 0, (0, 30, 90)), ("pyramid", 8, 0, (0, 1)), ("tumbler", 60, 0, (0, 40))):
+        with refbind.RefWorld(scene, "TGS_Soft", p0, p1) as world:
+            for step in range(max(at) + 1):
+                shapes_before, origins_before = world.pack_shapes()
+                _params, pre, post = world.step_captured(1.0 / 60.0, 8, 4, True)
+                if step in at:
+                    shapes_after, origins_after = world.pack_shapes()
+                    bp_shapes, moved, existing, created = refbind.broadphase_capture()
+                    path = os.path.join(OUT, "bp_%s%d_step%03d.npz" % (scene, p0, step))
+                    np.savez_compressed(path, bodies_entry=pre[0], joints=pre[2], bp_shapes=bp_shapes, moved=moved, existing=existing,
+                                        created=created, bodies_solved=post[0], shapes_before=shapes_before,
+                                        origins_before=origins_before, shapes_after=shapes_after, origins_after=origins_after)
+                    total += os.path.getsize(path)
     print("wrote fixtures, %.1f KiB total" % (total / 1024.0))
 
 

@@ -9,7 +9,11 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def golden_files():
-    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    return sorted(f for f in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")) if not os.path.basename(f).startswith("bp_"))
+
+
+def broadphase_files():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "bp_*.npz")))
 
 
 def load(path):

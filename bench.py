@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="s2amd_set_option passthrough (experiments)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -120,6 +121,9 @@ def main():
     sweeps = wire.solve_sweeps_per_step("TGS_Soft", args.vel_iters, args.pos_iters)
 
     gpu = hip.Solver(device_index if world > 1 else 0, graph=not args.no_graph)
+    for kv in args.opt:
+        key, _, val = kv.partition("=")
+        gpu.set_option(key, int(val))
     gpu.upload(*pre)
     gpu.save_bodies()
 

@@ -158,6 +158,8 @@ typedef struct s2amdStepStats
 	float eventPairOverheadMs; /* elapsed time of an EMPTY HIP event pair on the stream (profiling only): subtract per launch */
 	int32_t groupCount;        /* LDS groups (small islands advanced whole-step by one workgroup each) */
 	int32_t messagePassing;    /* 1 when the big-island sweeps read bodies from per-constraint copies (no gather) */
+	int32_t stripCount;        /* strips (BFS level ranges) a big island was cut into: phase A workgroups per sweep */
+	int32_t seamCount;         /* seams between adjacent strips that carry constraints: phase B workgroups per sweep */
 } s2amdStepStats;
 
 typedef struct s2amdSolver s2amdSolver;
@@ -261,7 +263,9 @@ int s2amd_get_stats(s2amdSolver* solver, s2amdStepStats* stats);
 int s2amd_measure_dominant(s2amdSolver* solver, const s2amdStepParams* params, int32_t repeats, float* usPerLaunch,
 						   int32_t* launchesPerSweep, int32_t* constraintsPerLaunch);
 /* option keys: "graph" (0/1 hipGraph replay), "profile" (0/1 per-sweep HIP events),
- * "groups" (0/1 LDS group path for small islands), "message" (0/1 message-passing sweeps), "max_group_bodies", "pack_group_bodies" */
+ * "groups" (0/1 LDS group path for small islands), "message" (0/1 message-passing sweeps), "max_group_bodies", "pack_group_bodies",
+ * "strips" (0/1 cut islands that fit no LDS group into strips of BFS levels: two launches per sweep), "strip_bodies" (target
+ * bodies per strip), "strip_min_bodies" (loose bodies below which the colour-batch path is kept), "body_warm" */
 int s2amd_set_option(s2amdSolver* solver, const char* key, int32_t value);
 
 #ifdef __cplusplus

@@ -202,31 +202,68 @@ S2_DEV void warmStartContactsOne(const ContactView& c, const BA& b, int k)
 //   SOFT_JACOBI s2SolveContacts_Jacobi_Soft  solve_jacobi.c:21-132  (writes per-constraint deltas)
 //   SOFT_FIXED  s2SolveContacts_TGS_Fixed    solve_soft_step.c:66-177
 // ---------------------------------------------------------------------------------------------
-template <int KIND, class BA>
-S2_DEV void solveContactsSoftOne(const ContactView& c, const BA& b, float inv_h, int useBias, int k)
+// One constraint's sweep data in registers.  Loading is separate from the arithmetic so a workgroup that
+// owns several colour batches (group_kernel.hip: preloaded rounds) can issue all its loads at once.
+template <int KIND> struct SoftRegs
 {
-	CHeader h = loadHeader<BA::kMode>(c, k);
-	const float biasCap = (KIND == SOFT_TGS || KIND == SOFT_JACOBI) ? -S2_MAX_BAUMGARTE_VELOCITY : -0.5f * S2_MAX_BAUMGARTE_VELOCITY;
-
-	// all loads first (one memory round trip for the constraint, one for the bodies); slot 1 of a
-	// one-point constraint is a valid zero record, so no guard is needed
+	CHeader h;
 	float4 an[2], r0[2], par[2], sf[2];
 	float2 imp[2];
+};
+
+template <int KIND, int MODE> S2_DEV SoftRegs<KIND> loadSoft(const ContactView& c, int k)
+{
+	SoftRegs<KIND> r;
+	r.h = loadHeader<MODE>(c, k);
+	// slot 1 of a one-point constraint is a valid zero record, so no guard is needed
 #pragma unroll
 	for (int j = 0; j < 2; ++j)
 	{
 		if (KIND == SOFT_TGS || KIND == SOFT_FIXED)
 		{
-			an[j] = c.anchor[j][k];
+			r.an[j] = c.anchor[j][k];
 		}
 		if (KIND != SOFT_TGS)
 		{
-			r0[j] = c.r0[j][k];
+			r.r0[j] = c.r0[j][k];
 		}
-		par[j] = c.param[j][k];
-		sf[j] = c.soft[j][k];
-		imp[j] = c.impulse[j][k];
+		r.par[j] = c.param[j][k];
+		r.sf[j] = c.soft[j][k];
+		r.imp[j] = c.impulse[j][k];
 	}
+	return r;
+}
+
+template <int KIND> S2_DEV void pinSoft(SoftRegs<KIND>& r)
+{
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		if (KIND == SOFT_TGS || KIND == SOFT_FIXED)
+		{
+			pin(r.an[j]);
+		}
+		if (KIND != SOFT_TGS)
+		{
+			pin(r.r0[j]);
+		}
+		pin(r.par[j]);
+		pin(r.sf[j]);
+		pin(r.imp[j]);
+	}
+}
+
+// the arithmetic of one constraint: bodies read and written through `b`, impulses updated in `r`
+template <int KIND, class BA> S2_DEV void solveSoftRegs(SoftRegs<KIND>& r, const ContactView& c, const BA& b, float inv_h, int useBias, int k)
+{
+	const CHeader& h = r.h;
+	const float biasCap = (KIND == SOFT_TGS || KIND == SOFT_JACOBI) ? -S2_MAX_BAUMGARTE_VELOCITY : -0.5f * S2_MAX_BAUMGARTE_VELOCITY;
+	float4* an = r.an;
+	float4* r0 = r.r0;
+	float4* par = r.par;
+	float4* sf = r.sf;
+	float2* imp = r.imp;
+
 	BodyVel A = loadVel(b, h.ia), B = loadVel(b, h.ib);
 	V2 vA = A.v, vB = B.v;
 	float wA = A.w, wB = B.w;
@@ -237,21 +274,7 @@ S2_DEV void solveContactsSoftOne(const ContactView& c, const BA& b, float inv_h,
 		BodyPose pA = loadPose(b, h.ia), pB = loadPose(b, h.ib);
 		dcA = pA.dc, qA = pA.q, dcB = pB.dc, qB = pB.q;
 	}
-#pragma unroll
-	for (int j = 0; j < 2; ++j)
-	{
-		if (KIND == SOFT_TGS || KIND == SOFT_FIXED)
-		{
-			pin(an[j]);
-		}
-		if (KIND != SOFT_TGS)
-		{
-			pin(r0[j]);
-		}
-		pin(par[j]);
-		pin(sf[j]);
-		pin(imp[j]);
-	}
+	pinSoft(r);
 	V2 normal = h.normal;
 	V2 tangent = rightPerp(normal);
 	float mA = h.mA, iA = h.iA, mB = h.mB, iB = h.iB;
@@ -338,7 +361,7 @@ S2_DEV void solveContactsSoftOne(const ContactView& c, const BA& b, float inv_h,
 			wA -= iA * cross(rA, P);
 			vB = mulAdd(vB, mB, P);
 			wB += iB * cross(rB, P);
-			c.impulse[j][k] = make_float2(nImp[j], tImp[j]);
+			imp[j] = make_float2(nImp[j], tImp[j]);
 		}
 	}
 
@@ -360,6 +383,27 @@ S2_DEV void solveContactsSoftOne(const ContactView& c, const BA& b, float inv_h,
 			storeVel(b, h.ib, vB, wB);
 		}
 	}
+}
+
+template <int KIND> S2_DEV void storeSoft(const ContactView& c, const SoftRegs<KIND>& r, int k)
+{
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		if (j < r.h.pointCount)
+		{
+			c.impulse[j][k] = r.imp[j];
+		}
+	}
+}
+
+template <int KIND, class BA>
+S2_DEV void solveContactsSoftOne(const ContactView& c, const BA& b, float inv_h, int useBias, int k)
+{
+	// all loads first (one memory round trip for the constraint, one for the bodies)
+	SoftRegs<KIND> r = loadSoft<KIND, BA::kMode>(c, k);
+	solveSoftRegs<KIND>(r, c, b, inv_h, useBias, k);
+	storeSoft<KIND>(c, r, k);
 }
 
 // ---------------------------------------------------------------------------------------------

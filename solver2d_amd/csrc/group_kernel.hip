@@ -88,8 +88,75 @@ template <class P, class F> S2_DEV void forBatches(const int4* batches, int b0, 
 	}
 }
 
-__global__ __launch_bounds__(S2_GROUP_THREADS) void groupKernel(ContactView c, JointView jv, BodyView g, GroupTable gt, const Op* ops, int opCount,
-																 StepConsts sc, s2amdContact* wire, int useDq0)
+// Soft sweep with PRELOADED rounds: every thread first issues the loads of its constraint in each of the
+// next MAXR colour batches (all in flight at once: one memory round trip for the whole chunk instead of
+// one per colour), then the batches are swept in order with only LDS traffic between barriers.  Same
+// per-constraint arithmetic and the same order as forBatches.
+template <int KIND, int MAXR, class LB>
+S2_DEV void sweepSoftPreloaded(const ContactView& c, const LB& lb, const int4* batches, int b0, int b1, float inv_h, int useBias)
+{
+	for (int base = b0; base < b1; base += MAXR)
+	{
+		SoftRegs<KIND> r[MAXR];
+		int kk[MAXR];
+#pragma unroll
+		for (int i = 0; i < MAXR; ++i)
+		{
+			kk[i] = -1;
+			if (base + i < b1)
+			{
+				int4 bt = batches[base + i];
+				int k = bt.x + (int)threadIdx.x;
+				if (bt.z == 0 && k < bt.y)
+				{
+					kk[i] = k;
+					r[i] = loadSoft<KIND, S2_IDX_LOCAL>(c, k);
+				}
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < MAXR; ++i)
+		{
+			if (base + i < b1)
+			{
+				int4 bt = batches[base + i];
+				if (bt.z)
+				{
+					for (int k = bt.x + (int)threadIdx.x; k < bt.y; k += (int)blockDim.x)
+					{
+						prefetchContact(c, k);
+					}
+					__syncthreads();
+					if (threadIdx.x == 0)
+					{
+						for (int k = bt.x; k < bt.y; ++k)
+						{
+							solveContactsSoftOne<KIND>(c, lb, inv_h, useBias, k);
+						}
+					}
+				}
+				else
+				{
+					if (kk[i] >= 0)
+					{
+						solveSoftRegs<KIND>(r[i], c, lb, inv_h, useBias, kk[i]);
+						storeSoft<KIND>(c, r[i], kk[i]);
+					}
+					// a batch wider than the workgroup: the rest streams
+					for (int k = bt.x + (int)threadIdx.x + (int)blockDim.x; k < bt.y; k += (int)blockDim.x)
+					{
+						solveContactsSoftOne<KIND>(c, lb, inv_h, useBias, k);
+					}
+				}
+				__syncthreads();
+			}
+		}
+	}
+}
+
+template <int THREADS, int PRELOAD>
+__global__ __launch_bounds__(THREADS) void groupKernel(ContactView c, JointView jv, BodyView g, GroupTable gt, const Op* ops, int opCount, StepConsts sc,
+													   s2amdContact* wire, int useDq0)
 {
 	extern __shared__ __attribute__((aligned(16))) float4 lds[];
 	const int grp = blockIdx.x;
@@ -200,13 +267,34 @@ __global__ __launch_bounds__(S2_GROUP_THREADS) void groupKernel(ContactView c, J
 				switch (op.kind)
 				{
 					case SOFT_TGS:
-						forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { solveContactsSoftOne<SOFT_TGS>(c, lb, op.inv_h, op.useBias, k); });
+						if constexpr (PRELOAD > 0)
+						{
+							sweepSoftPreloaded<SOFT_TGS, PRELOAD>(c, lb, gt.cBatches, cb0, cb1, op.inv_h, op.useBias);
+						}
+						else
+						{
+							forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { solveContactsSoftOne<SOFT_TGS>(c, lb, op.inv_h, op.useBias, k); });
+						}
 						break;
 					case SOFT_PGS:
-						forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { solveContactsSoftOne<SOFT_PGS>(c, lb, op.inv_h, op.useBias, k); });
+						if constexpr (PRELOAD > 0)
+						{
+							sweepSoftPreloaded<SOFT_PGS, PRELOAD>(c, lb, gt.cBatches, cb0, cb1, op.inv_h, op.useBias);
+						}
+						else
+						{
+							forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { solveContactsSoftOne<SOFT_PGS>(c, lb, op.inv_h, op.useBias, k); });
+						}
 						break;
 					case SOFT_FIXED:
-						forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { solveContactsSoftOne<SOFT_FIXED>(c, lb, op.inv_h, op.useBias, k); });
+						if constexpr (PRELOAD > 0)
+						{
+							sweepSoftPreloaded<SOFT_FIXED, PRELOAD>(c, lb, gt.cBatches, cb0, cb1, op.inv_h, op.useBias);
+						}
+						else
+						{
+							forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { solveContactsSoftOne<SOFT_FIXED>(c, lb, op.inv_h, op.useBias, k); });
+						}
 						break;
 					default:
 						break; // SOFT_JACOBI never runs in a group (needs the per-body incidence sums)
@@ -265,11 +353,31 @@ __global__ __launch_bounds__(S2_GROUP_THREADS) void groupKernel(ContactView c, J
 	}
 }
 
+#define S2_STRIP_THREADS 256
+#define S2_STRIP_PRELOAD 6
+
 int groupKernelSetup()
 {
 	// allow a group to use the full 160 KiB of LDS
-	hipError_t e = hipFuncSetAttribute((const void*)groupKernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+	hipError_t e = hipFuncSetAttribute((const void*)groupKernel<S2_GROUP_THREADS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+	if (e == hipSuccess)
+	{
+		e = hipFuncSetAttribute((const void*)groupKernel<S2_STRIP_THREADS, S2_STRIP_PRELOAD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+	}
 	return e == hipSuccess ? 0 : (int)e;
+}
+
+// strips: 256 threads (one wave per SIMD, the whole register file for preloaded rounds), one sweep op per launch
+void launchStripKernel(hipStream_t s, const ContactView& c, const JointView& j, const BodyView& g, const GroupTable& gt, const Op* ops, int opCount,
+					   const StepConsts& sc, s2amdContact* wire, int maxBodies, int useDq0)
+{
+	if (gt.groupCount <= 0 || opCount <= 0)
+	{
+		return;
+	}
+	size_t lds = (size_t)maxBodies * (useDq0 ? 48 : 32);
+	groupKernel<S2_STRIP_THREADS, S2_STRIP_PRELOAD>
+		<<<dim3((unsigned)gt.groupCount), dim3(S2_STRIP_THREADS), lds, s>>>(c, j, g, gt, ops, opCount, sc, wire, useDq0);
 }
 
 void launchGroupKernel(hipStream_t s, const ContactView& c, const JointView& j, const BodyView& g, const GroupTable& gt, const Op* ops, int opCount,
@@ -280,5 +388,5 @@ void launchGroupKernel(hipStream_t s, const ContactView& c, const JointView& j, 
 		return;
 	}
 	size_t lds = (size_t)maxBodies * (useDq0 ? 48 : 32);
-	groupKernel<<<dim3((unsigned)gt.groupCount), dim3(S2_GROUP_THREADS), lds, s>>>(c, j, g, gt, ops, opCount, sc, wire, useDq0);
+	groupKernel<S2_GROUP_THREADS, 0><<<dim3((unsigned)gt.groupCount), dim3(S2_GROUP_THREADS), lds, s>>>(c, j, g, gt, ops, opCount, sc, wire, useDq0);
 }

@@ -10,6 +10,8 @@ struct StepConsts;
 struct GroupTable;
 struct Op;
 struct MsgView;
+struct StripTableView;
+struct StripOps;
 struct s2amdBody;
 struct s2amdContact;
 struct s2amdJoint;
@@ -106,6 +108,8 @@ void launchStoreJoints(hipStream_t s, const JointView& j, s2amdJoint* wire);
 int groupKernelSetup();
 void launchGroupKernel(hipStream_t s, const ContactView& c, const JointView& j, const BodyView& g, const GroupTable& gt, const Op* ops, int opCount,
 					   const StepConsts& sc, s2amdContact* wire, int maxBodies, int useDq0);
+void launchStripKernel(hipStream_t s, const ContactView& c, const JointView& j, const BodyView& g, const GroupTable& gt, const Op* ops, int opCount,
+					   const StepConsts& sc, s2amdContact* wire, int maxBodies, int useDq0);
 
 // message passing (big-island path)
 void launchFillMessageSlots(hipStream_t s, const ContactView& c, const BodyView& b, const MsgView& m, int count);
@@ -122,3 +126,7 @@ void launchGatherMessageSlots(hipStream_t s, const BodyView& b, const MsgView& m
 // body-centric warm start (one launch for all colours, optionally fused with integrate velocities)
 void launchWarmStartBodies(hipStream_t s, int kind, const ContactView& c, const BodyView& b, const int* adjOffsets, const int* adjList,
 						   int integrateFirst);
+
+// strip_kernel.hip
+int stripKernelSetup();
+void launchStripSoft(hipStream_t s, int kind, int warm, const ContactView& c, const BodyView& g, const StripTableView& t, const StripOps& ops);

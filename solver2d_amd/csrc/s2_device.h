@@ -435,6 +435,32 @@ struct GroupTable
 };
 #define S2G_OWNED 0x80000000u
 
+// Strip groups as the lean strip kernel reads them (strip_kernel.hip): one 128-byte descriptor per group
+#define S2_STRIP_ROUNDS 6	   // colour batches a thread preloads
+#define S2_STRIP_BODY_CHUNKS 4 // bodies per thread: a group stages at most 4 * 256 bodies
+struct StripDesc
+{
+	int bodyBase, bodyCount, ownedCount; // range of GroupTable::bodyIds; the owned bodies come first
+	int batchCount;
+	int slotBase, slotCount, slotOffBase; // warm start: incident (constraint, side) slots of the owned bodies
+	int pad;
+	int4 batch[S2_STRIP_ROUNDS]; // {begin, end, 0, 0} ranges of k
+};
+struct StripOps
+{
+	int integratePos, integrateVel, sweep, useBias; // stages, in this order: positions, velocities, [warm start], sweep
+	float posH, inv_h;
+};
+struct StripTableView
+{
+	const StripDesc* descs;
+	const int* bodyIds;
+	const int2* slots;		// {k << 1 | side, local body}
+	const int* slotOffsets; // per group: ownedCount + 1 offsets into the group's slots
+	int groupCount;
+	int ldsRecords; // float4 records of dynamic LDS a launch needs
+};
+
 // Message-passing tables of the global part (see MsgBodies in constraint_ops.h)
 struct MsgView
 {

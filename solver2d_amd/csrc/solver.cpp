@@ -286,6 +286,8 @@ struct SweepSet
 	std::vector<int> batchOffsets;
 	bool hasTail = false;
 	int globalCount = 0;
+	int stripCount = 0;		 // constraints that live in strip groups (phase A interiors + phase B seams)
+	int seamCount = 0;		 // ... of which seams
 	std::vector<int2> local; // k -> group-local body slots (groups and the global tail)
 };
 
@@ -363,8 +365,13 @@ struct s2amdSolver
 
 	// structure of the last step
 	SweepSet contacts, joints;
-	HostGroupTable hGroups, hContactTail, hJointTail;
-	DeviceGroupTable dGroups, dContactTail, dJointTail;
+	HostGroupTable hGroups, hContactTail, hJointTail, hStripA, hStripB;
+	DeviceGroupTable dGroups, dContactTail, dJointTail, dStripA, dStripB;
+	// lean strip tables (strip_kernel.hip): descriptors of both phases, warm-start slots of phase A
+	DevBuf dStripLean;
+	StripTableView leanA{}, leanB{};
+	bool leanAValid = false, leanBValid = false;
+	int optStripLean = 1;
 	DevBuf dMsg;
 	MsgView msg{};
 	bool msgTablesValid = false; // the global part is contact-only and has no sequential tail
@@ -386,6 +393,9 @@ struct s2amdSolver
 	int optGroups = 1;
 	int optMaxGroupBodies = 2048;
 	int optPackGroupBodies = 1024;
+	int optStrips = 1;		   // cut islands that do not fit one LDS group into strips of BFS levels (2 launches per sweep)
+	int optStripBodies = 640;  // target bodies per strip
+	int optStripMinBodies = 4096; // loose bodies below which the colour-batch path is kept
 
 	// graph cache
 	hipGraph_t graph = nullptr;
@@ -695,6 +705,12 @@ struct LocalSlots
 	int epoch = 0;
 	explicit LocalSlots(int nb) : slot((size_t)nb, -1), stamp((size_t)nb, -1) {}
 	void begin() { epoch += 1; }
+	void seed(int body, std::vector<int>& ids, bool owned)
+	{
+		stamp[body] = epoch;
+		slot[body] = (int)ids.size();
+		ids.push_back((int)((uint32_t)body | (owned ? S2G_OWNED : 0u)));
+	}
 	int get(int body, std::vector<int>& ids, const std::vector<uint8_t>& conflict)
 	{
 		if (stamp[body] != epoch)
@@ -706,6 +722,232 @@ struct LocalSlots
 		return slot[body];
 	}
 };
+
+// Strips.  An island too big for one LDS group is cut along the level sets of a breadth-first search
+// over its writable bodies: a constraint joins bodies of the same or of adjacent levels, so with every
+// strip spanning >= 2 levels
+//   * "interior" constraints (both bodies in one strip) of different strips share no writable body,
+//   * "seam" constraints between strips i and i+1 touch the last level of i and the first of i+1
+//     only, so different seams share no writable body either.
+// A Gauss-Seidel sweep over the island is then TWO launches -- all interiors (phase A, one workgroup
+// per strip, colours separated by __syncthreads), all seams (phase B) -- instead of one launch per
+// colour; its sequential-equivalent order is strip by strip colour-major, then seam by seam.
+struct StripPartition
+{
+	bool active = false;
+	std::vector<std::vector<int>> bodies;  // per strip: owned bodies, level by level
+	std::vector<std::vector<int>> cA, jA;  // per strip: interior contacts / joints (indices into the edge lists)
+	std::vector<std::vector<int>> cB, jB;  // per seam i | i+1
+};
+
+void partitionStrips(const EdgeList& ce, const EdgeList& je, const std::vector<int>& cGlobal, const std::vector<int>& jGlobal,
+					 const std::vector<uint8_t>& conflict, const std::vector<uint8_t>& loose, int nb, int targetBodies, int maxBodies,
+					 StripPartition& out)
+{
+	// adjacency of the loose writable bodies
+	auto linked = [&](int a, int b) { return a >= 0 && b >= 0 && conflict[a] && conflict[b] && loose[a] && loose[b]; };
+	std::vector<int> deg((size_t)nb + 1, 0);
+	auto countEdges = [&](const EdgeList& e, const std::vector<int>& ks) {
+		for (int k : ks)
+		{
+			if (linked(e.a[k], e.b[k]))
+			{
+				deg[(size_t)e.a[k] + 1] += 1;
+				deg[(size_t)e.b[k] + 1] += 1;
+			}
+		}
+	};
+	countEdges(ce, cGlobal);
+	countEdges(je, jGlobal);
+	for (int i = 0; i < nb; ++i)
+	{
+		deg[(size_t)i + 1] += deg[i];
+	}
+	std::vector<int> adj((size_t)deg[nb]), cursor(deg.begin(), deg.end() - 1);
+	auto fillEdges = [&](const EdgeList& e, const std::vector<int>& ks) {
+		for (int k : ks)
+		{
+			if (linked(e.a[k], e.b[k]))
+			{
+				adj[(size_t)cursor[e.a[k]]++] = e.b[k];
+				adj[(size_t)cursor[e.b[k]]++] = e.a[k];
+			}
+		}
+	};
+	fillEdges(ce, cGlobal);
+	fillEdges(je, jGlobal);
+
+	// levels: per component, BFS from a pseudo-peripheral body (the last body a first BFS reaches)
+	std::vector<int> level((size_t)nb, -1), queue, levelOffsets{0}, levelBodies;
+	std::vector<int> seen((size_t)nb, 0);
+	int epoch = 0;
+	auto bfs = [&](int root, bool record) {
+		epoch += 1;
+		queue.clear();
+		queue.push_back(root);
+		seen[root] = epoch;
+		size_t head = 0, levelEnd = 1;
+		while (head < queue.size())
+		{
+			if (head == levelEnd)
+			{
+				if (record)
+				{
+					levelOffsets.push_back((int)levelBodies.size());
+				}
+				levelEnd = queue.size();
+			}
+			int u = queue[head++];
+			if (record)
+			{
+				level[u] = (int)levelOffsets.size() - 1;
+				levelBodies.push_back(u);
+			}
+			for (int e = deg[u]; e < deg[(size_t)u + 1]; ++e)
+			{
+				int v = adj[(size_t)e];
+				if (seen[v] != epoch)
+				{
+					seen[v] = epoch;
+					queue.push_back(v);
+				}
+			}
+		}
+		if (record)
+		{
+			levelOffsets.push_back((int)levelBodies.size());
+		}
+		return queue.back();
+	};
+	for (int i = 0; i < nb; ++i)
+	{
+		if (!loose[i] || level[i] >= 0)
+		{
+			continue;
+		}
+		int far = deg[(size_t)i + 1] > deg[i] ? bfs(i, false) : i;
+		bfs(far, true);
+	}
+	const int levels = (int)levelOffsets.size() - 1;
+	if (levels < 4)
+	{
+		return;
+	}
+
+	// strips: consecutive levels, >= 2 levels and >= targetBodies bodies each
+	std::vector<int> stripOf((size_t)nb, -1);
+	int curLevels = 0;
+	out.bodies.emplace_back();
+	for (int l = 0; l < levels; ++l)
+	{
+		if (curLevels >= 2 && (int)out.bodies.back().size() >= targetBodies)
+		{
+			out.bodies.emplace_back();
+			curLevels = 0;
+		}
+		for (int e = levelOffsets[l]; e < levelOffsets[(size_t)l + 1]; ++e)
+		{
+			out.bodies.back().push_back(levelBodies[(size_t)e]);
+		}
+		curLevels += 1;
+	}
+	// a last strip of a single level is merged into its predecessor (both of its seams would meet in it)
+	if (curLevels < 2 && out.bodies.size() >= 2)
+	{
+		std::vector<int> lastStrip = std::move(out.bodies.back());
+		out.bodies.pop_back();
+		out.bodies.back().insert(out.bodies.back().end(), lastStrip.begin(), lastStrip.end());
+	}
+	const int K = (int)out.bodies.size();
+	if (K < 2)
+	{
+		out = StripPartition();
+		return;
+	}
+	for (int i = 0; i < K; ++i)
+	{
+		for (int body : out.bodies[(size_t)i])
+		{
+			stripOf[body] = i;
+		}
+	}
+
+	// classification
+	out.cA.assign((size_t)K, {}), out.jA.assign((size_t)K, {});
+	out.cB.assign((size_t)K - 1, {}), out.jB.assign((size_t)K - 1, {});
+	bool ok = true;
+	auto classify = [&](const EdgeList& e, const std::vector<int>& ks, std::vector<std::vector<int>>& A, std::vector<std::vector<int>>& B) {
+		for (int k : ks)
+		{
+			int a = e.a[k], b = e.b[k];
+			int sa = (a >= 0 && conflict[a]) ? stripOf[a] : -1;
+			int sb = (b >= 0 && conflict[b]) ? stripOf[b] : -1;
+			if (sa < 0 && sb < 0)
+			{
+				// no writable body: any strip will do (the sweep writes nothing)
+				int any = (a >= 0 && stripOf[a] >= 0) ? stripOf[a] : ((b >= 0 && stripOf[b] >= 0) ? stripOf[b] : 0);
+				A[(size_t)any].push_back(k);
+			}
+			else if (sa < 0 || sb < 0 || sa == sb)
+			{
+				A[(size_t)std::max(sa, sb)].push_back(k);
+			}
+			else if (sa - sb == 1 || sb - sa == 1)
+			{
+				B[(size_t)std::min(sa, sb)].push_back(k);
+			}
+			else
+			{
+				ok = false;
+			}
+		}
+	};
+	classify(ce, cGlobal, out.cA, out.cB);
+	classify(je, jGlobal, out.jA, out.jB);
+
+	// every group must fit the LDS body budget (owned bodies + read-only replicas)
+	std::vector<int> stamp((size_t)nb, -1);
+	int tick = 0;
+	auto groupBodies = [&](const std::vector<int>& seedBodies, const std::vector<int>& cKs, const std::vector<int>& jKs) {
+		tick += 1;
+		int n = 0;
+		auto touch = [&](int body) {
+			if (body >= 0 && stamp[body] != tick)
+			{
+				stamp[body] = tick;
+				n += 1;
+			}
+		};
+		for (int body : seedBodies)
+		{
+			touch(body);
+		}
+		for (int k : cKs)
+		{
+			touch(ce.a[k]), touch(ce.b[k]);
+		}
+		for (int k : jKs)
+		{
+			touch(je.a[k]), touch(je.b[k]);
+		}
+		return n;
+	};
+	const std::vector<int> none;
+	for (int i = 0; i < K && ok; ++i)
+	{
+		ok = groupBodies(out.bodies[(size_t)i], out.cA[(size_t)i], out.jA[(size_t)i]) <= maxBodies;
+		if (ok && i + 1 < K)
+		{
+			ok = groupBodies(none, out.cB[(size_t)i], out.jB[(size_t)i]) <= maxBodies;
+		}
+	}
+	if (!ok)
+	{
+		out = StripPartition();
+		return;
+	}
+	out.active = true;
+}
 
 int buildStructure(s2amdSolver* s, int solverType)
 {
@@ -869,6 +1111,51 @@ int buildStructure(s2amdSolver* s, int solverType)
 	s->hGroups.clear();
 	s->hContactTail.clear();
 	s->hJointTail.clear();
+	s->hStripA.clear();
+	s->hStripB.clear();
+
+	// ---- strips: the part that fits no LDS group, cut along BFS level sets ----
+	StripPartition strips;
+	if (grouped && s->optStrips)
+	{
+		std::vector<uint8_t> ownedByIsland((size_t)nb, 0);
+		auto mark = [&](int body) {
+			if (body >= 0 && conflict[body])
+			{
+				ownedByIsland[body] = 1;
+			}
+		};
+		for (int k = 0; k < C; ++k)
+		{
+			if (cPart[k] >= 0)
+			{
+				mark(ce.a[k]), mark(ce.b[k]);
+			}
+		}
+		for (int k = 0; k < J; ++k)
+		{
+			if (jPart[k] >= 0)
+			{
+				mark(je.a[k]), mark(je.b[k]);
+			}
+		}
+		std::vector<uint8_t> loose((size_t)nb);
+		int looseCount = 0;
+		for (int i = 0; i < nb; ++i)
+		{
+			loose[i] = s->hBodyLive[i] && !s->hBodyStatic[i] && !ownedByIsland[i];
+			looseCount += loose[i];
+		}
+		if (looseCount >= s->optStripMinBodies)
+		{
+			partitionStrips(ce, je, cOf[0], jOf[0], conflict, loose, nb, s->optStripBodies, s->optMaxGroupBodies, strips);
+		}
+		if (strips.active)
+		{
+			cOf[0].clear();
+			jOf[0].clear();
+		}
+	}
 
 	LocalSlots slots(nb);
 	auto gather = [&](const EdgeList& e, const std::vector<int>& ks, std::vector<int>& ids, std::vector<int>& a, std::vector<int>& b) {
@@ -931,15 +1218,18 @@ int buildStructure(s2amdSolver* s, int solverType)
 		}
 	}
 
-	// LDS groups: whole-step kernel, bodies in LDS
-	for (int g = 0; g < groupCount; ++g)
-	{
-		HostGroupTable& t = s->hGroups;
+	// one LDS group: local body slots (seeded bodies first: owned, in the given order), colour batches of
+	// its contacts and joints appended to the sweep sets, one row in table `t`
+	auto emitGroup = [&](HostGroupTable& t, const std::vector<int>& cKs, const std::vector<int>& jKs, const std::vector<int>& seedBodies) {
 		std::vector<int> ids, a, b, bodies, la, lb, pos, batchOffsets;
 		bool tail = false;
 		slots.begin();
+		for (int body : seedBodies)
+		{
+			slots.seed(body, bodies, true);
+		}
 		// contacts
-		gather(ce, cOf[(size_t)g + 1], ids, a, b);
+		gather(ce, cKs, ids, a, b);
 		la.resize(ids.size()), lb.resize(ids.size());
 		for (size_t i = 0; i < ids.size(); ++i)
 		{
@@ -948,19 +1238,19 @@ int buildStructure(s2amdSolver* s, int solverType)
 		}
 		// joints (slots first so both families share one body list)
 		std::vector<int> jids, ja, jb, jla, jlb;
-		gather(je, jOf[(size_t)g + 1], jids, ja, jb);
+		gather(je, jKs, jids, ja, jb);
 		jla.resize(jids.size()), jlb.resize(jids.size());
 		for (size_t i = 0; i < jids.size(); ++i)
 		{
 			jla[i] = ja[i] >= 0 ? slots.get(ja[i], bodies, conflict) : -1;
 			jlb[i] = slots.get(jb[i], bodies, conflict);
 		}
+		// colouring conflicts are the writable bodies (an owned kinematic body is shareable in velocity sweeps)
 		std::vector<uint8_t> lconf(bodies.size());
 		for (size_t i = 0; i < bodies.size(); ++i)
 		{
-			lconf[i] = ((uint32_t)bodies[i] & S2G_OWNED) != 0;
+			lconf[i] = conflict[(size_t)((uint32_t)bodies[i] & ~S2G_OWNED)];
 		}
-		int base = (int)cs.order.size();
 		colourPart(ids, la, lb, lconf, (int)bodies.size(), cs, batchOffsets, tail, &pos);
 		for (size_t i = 0; i < pos.size(); ++i)
 		{
@@ -974,7 +1264,6 @@ int buildStructure(s2amdSolver* s, int solverType)
 				t.cBatches.push_back(make_int4(batchOffsets[bi], batchOffsets[bi + 1], isTail ? 1 : 0, 0));
 			}
 		}
-		(void)base;
 		t.cBatchOffsets.push_back((int)t.cBatches.size());
 		colourPart(jids, jla, jlb, lconf, (int)bodies.size(), js, batchOffsets, tail, &pos);
 		for (size_t i = 0; i < pos.size(); ++i)
@@ -1000,6 +1289,35 @@ int buildStructure(s2amdSolver* s, int solverType)
 		}
 		t.bodyOffsets.push_back((int)t.bodyIds.size());
 		t.maxBodies = std::max(t.maxBodies, (int)bodies.size());
+	};
+
+	// LDS groups: whole-step kernel, bodies in LDS
+	const std::vector<int> noSeed;
+	for (int g = 0; g < groupCount; ++g)
+	{
+		emitGroup(s->hGroups, cOf[(size_t)g + 1], jOf[(size_t)g + 1], noSeed);
+	}
+
+	// strips of the big islands: phase A = interiors (own every body of the strip), phase B = seams
+	const int stripBaseC = (int)cs.order.size(), stripBaseJ = (int)js.order.size();
+	for (size_t i = 0; i < strips.bodies.size(); ++i)
+	{
+		emitGroup(s->hStripA, strips.cA[i], strips.jA[i], strips.bodies[i]);
+	}
+	int stripInterior = (int)cs.order.size(), stripInteriorJ = (int)js.order.size();
+	for (size_t i = 0; i < strips.cB.size(); ++i)
+	{
+		if (!strips.cB[i].empty() || !strips.jB[i].empty())
+		{
+			emitGroup(s->hStripB, strips.cB[i], strips.jB[i], noSeed);
+		}
+	}
+	if (strips.active)
+	{
+		cs.stripCount = (int)cs.order.size() - stripBaseC;
+		js.stripCount = (int)js.order.size() - stripBaseJ;
+		cs.seamCount = (int)cs.order.size() - stripInterior;
+		js.seamCount = (int)js.order.size() - stripInteriorJ;
 	}
 
 	s->looseBodies = 0;
@@ -1050,9 +1368,148 @@ int buildStructure(s2amdSolver* s, int solverType)
 	s->jv.localBodies = (int2*)s->dJointLocal.p;
 	s->jv.count = J;
 	if ((rc = uploadGroupTable(s, s->hGroups, s->dGroups)) != 0 || (rc = uploadGroupTable(s, s->hContactTail, s->dContactTail)) != 0 ||
-		(rc = uploadGroupTable(s, s->hJointTail, s->dJointTail)) != 0)
+		(rc = uploadGroupTable(s, s->hJointTail, s->dJointTail)) != 0 || (rc = uploadGroupTable(s, s->hStripA, s->dStripA)) != 0 ||
+		(rc = uploadGroupTable(s, s->hStripB, s->dStripB)) != 0)
 	{
 		return rc;
+	}
+
+	// ---- lean strip tables: per-group descriptors + warm-start slots (strip_kernel.hip) ----
+	s->leanAValid = s->leanBValid = false;
+	s->leanA = StripTableView{};
+	s->leanB = StripTableView{};
+	if (strips.active && s->optStripLean)
+	{
+		const int k0 = stripBaseC, k1 = stripBaseC + cs.stripCount;
+		// body -> incident strip constraints in sweep order
+		std::vector<int> off((size_t)nb + 1, 0), inc;
+		for (int k = k0; k < k1; ++k)
+		{
+			int a = s->hContactA[cs.order[(size_t)k]], b = s->hContactB[cs.order[(size_t)k]];
+			off[(size_t)a + 1] += conflict[a] ? 1 : 0;
+			off[(size_t)b + 1] += conflict[b] ? 1 : 0;
+		}
+		for (int i = 0; i < nb; ++i)
+		{
+			off[(size_t)i + 1] += off[i];
+		}
+		inc.resize((size_t)off[nb]);
+		{
+			std::vector<int> cur(off.begin(), off.end() - 1);
+			for (int k = k0; k < k1; ++k)
+			{
+				int a = s->hContactA[cs.order[(size_t)k]], b = s->hContactB[cs.order[(size_t)k]];
+				if (conflict[a])
+				{
+					inc[(size_t)cur[a]++] = (k << 1) | 0;
+				}
+				if (conflict[b])
+				{
+					inc[(size_t)cur[b]++] = (k << 1) | 1;
+				}
+			}
+		}
+		std::vector<StripDesc> descA, descB;
+		std::vector<int2> slotList;
+		std::vector<int> slotOffsets;
+		auto describe = [&](const HostGroupTable& t, std::vector<StripDesc>& out, bool withSlots, int& ldsRecords) {
+			bool ok = true;
+			ldsRecords = 0;
+			for (int g = 0; g < t.count() && ok; ++g)
+			{
+				StripDesc d{};
+				d.bodyBase = t.bodyOffsets[(size_t)g];
+				d.bodyCount = t.bodyOffsets[(size_t)g + 1] - d.bodyBase;
+				int b0 = t.cBatchOffsets[(size_t)g], b1 = t.cBatchOffsets[(size_t)g + 1];
+				d.batchCount = b1 - b0;
+				ok = d.batchCount <= S2_STRIP_ROUNDS && d.bodyCount <= S2_STRIP_BODY_CHUNKS * 256;
+				for (int b = b0; b < b1 && ok; ++b)
+				{
+					int4 bt = t.cBatches[(size_t)b];
+					ok = bt.z == 0;
+					d.batch[b - b0] = make_int4(bt.x, bt.y, 0, 0);
+				}
+				while (d.ownedCount < d.bodyCount && ((uint32_t)t.bodyIds[(size_t)d.bodyBase + d.ownedCount] & S2G_OWNED) != 0)
+				{
+					d.ownedCount += 1;
+				}
+				if (withSlots)
+				{
+					// phase A groups list their owned bodies first (seeded): slots in body order
+					d.slotBase = (int)slotList.size();
+					d.slotOffBase = (int)slotOffsets.size();
+					for (int i = 0; i < d.ownedCount; ++i)
+					{
+						int body = (int)((uint32_t)t.bodyIds[(size_t)d.bodyBase + i] & ~S2G_OWNED);
+						slotOffsets.push_back((int)slotList.size() - d.slotBase);
+						for (int e = off[body]; e < off[(size_t)body + 1]; ++e)
+						{
+							slotList.push_back(make_int2(inc[(size_t)e], i));
+						}
+					}
+					slotOffsets.push_back((int)slotList.size() - d.slotBase);
+					d.slotCount = (int)slotList.size() - d.slotBase;
+				}
+				int records = 2 * d.bodyCount + 2 * d.slotCount;
+				ok = ok && records <= (160 * 1024) / 16;
+				ldsRecords = std::max(ldsRecords, records);
+				out.push_back(d);
+			}
+			return ok;
+		};
+		int ldsA = 0, ldsB = 0;
+		bool okA = describe(s->hStripA, descA, true, ldsA);
+		bool okB = describe(s->hStripB, descB, false, ldsB);
+		// owned bodies must be exactly the seeded prefix in phase A (replicas are never owned there)
+		if (okA)
+		{
+			auto pad = [](size_t n) { return (n + 63) & ~size_t(63); };
+			size_t bA = pad(descA.size() * sizeof(StripDesc)), bB = pad(std::max<size_t>(descB.size(), 1) * sizeof(StripDesc));
+			size_t bS = pad(std::max<size_t>(slotList.size(), 1) * sizeof(int2)), bO = pad(std::max<size_t>(slotOffsets.size(), 1) * sizeof(int));
+			std::vector<unsigned char> blob(bA + bB + bS + bO, 0);
+			memcpy(blob.data(), descA.data(), descA.size() * sizeof(StripDesc));
+			if (!descB.empty())
+			{
+				memcpy(blob.data() + bA, descB.data(), descB.size() * sizeof(StripDesc));
+			}
+			if (!slotList.empty())
+			{
+				memcpy(blob.data() + bA + bB, slotList.data(), slotList.size() * sizeof(int2));
+			}
+			if (!slotOffsets.empty())
+			{
+				memcpy(blob.data() + bA + bB + bS, slotOffsets.data(), slotOffsets.size() * sizeof(int));
+			}
+			bool grewLean = false;
+			if ((rc = s->dStripLean.ensure(blob.size(), &grewLean)) != 0)
+			{
+				return rc;
+			}
+			if (grewLean)
+			{
+				s->layoutGeneration += 1;
+			}
+			HIP_TRY(hipMemcpyAsync(s->dStripLean.p, blob.data(), blob.size(), hipMemcpyHostToDevice, s->stream));
+			HIP_TRY(hipStreamSynchronize(s->stream)); // blob is a local
+			const unsigned char* base = (const unsigned char*)s->dStripLean.p;
+			s->leanA.descs = (const StripDesc*)base;
+			s->leanA.bodyIds = s->dStripA.view.bodyIds;
+			s->leanA.slots = (const int2*)(base + bA + bB);
+			s->leanA.slotOffsets = (const int*)(base + bA + bB + bS);
+			s->leanA.groupCount = (int)descA.size();
+			s->leanA.ldsRecords = ldsA;
+			s->leanAValid = true;
+			if (okB)
+			{
+				s->leanB.descs = (const StripDesc*)(base + bA);
+				s->leanB.bodyIds = s->dStripB.view.bodyIds;
+				s->leanB.slots = s->leanA.slots;
+				s->leanB.slotOffsets = s->leanA.slotOffsets;
+				s->leanB.groupCount = (int)descB.size();
+				s->leanB.ldsRecords = ldsB;
+				s->leanBValid = true;
+			}
+		}
 	}
 
 	// ---- message-passing tables of the global part (see MsgBodies) ----
@@ -1775,6 +2232,150 @@ struct Executor
 		}
 	}
 
+	static bool isBodyOp(int code)
+	{
+		return code == OP_INTEGRATE_VEL || code == OP_INTEGRATE_POS || code == OP_FINALIZE || code == OP_XPBD_INTEGRATE || code == OP_XPBD_PROJECT;
+	}
+
+	void launchStripGroups(const DeviceGroupTable& t, int first, int n, bool timed)
+	{
+		if (timed)
+		{
+			recordEvent();
+		}
+		launchStripKernel(st, s->cv, s->jv, s->bv, t.view, deviceOps() + first, n, p.sc, wireContacts(), t.maxBodies, p.usesDq0 ? 1 : 0);
+		if (timed)
+		{
+			recordEvent();
+		}
+		count();
+	}
+
+	static bool leanSoftKind(const Op& o) { return o.code == OP_SOLVE_SOFT && (o.kind == SOFT_TGS || o.kind == SOFT_PGS || o.kind == SOFT_FIXED); }
+
+	bool sweepsNothing(const Op& o) const
+	{
+		if (isBodyOp(o.code))
+		{
+			return false;
+		}
+		return (o.code == OP_JOINT_SWEEP ? s->joints.stripCount : s->contacts.stripCount) == 0;
+	}
+
+	// Can ops [first, sweep) ride in front of the soft sweep `sweep` inside ONE lean strip launch?  Allowed, in
+	// this order: integrate positions, integrate velocities, contact warm start (body-centric).
+	bool leanSegment(int first, int sweep, StripOps& out, int& warm) const
+	{
+		if (!s->leanAValid || !leanSoftKind(p.ops[(size_t)sweep]))
+		{
+			return false;
+		}
+		out = StripOps{};
+		warm = -1;
+		int stage = 0;
+		for (int i = first; i < sweep; ++i)
+		{
+			const Op& o = p.ops[(size_t)i];
+			if (o.code == OP_INTEGRATE_POS && stage < 1)
+			{
+				out.integratePos = 1, out.posH = o.h, stage = 1;
+			}
+			else if (o.code == OP_INTEGRATE_VEL && stage < 2)
+			{
+				out.integrateVel = 1, stage = 2;
+			}
+			else if (o.code == OP_WARM && stage < 3 && s->optBodyWarm && (o.kind == WARM_CURRENT || o.kind == WARM_FIXED))
+			{
+				warm = o.kind, stage = 3;
+			}
+			else if (!sweepsNothing(o))
+			{
+				return false;
+			}
+		}
+		const Op& w = p.ops[(size_t)sweep];
+		out.sweep = 1, out.useBias = w.useBias, out.inv_h = w.inv_h;
+		return true;
+	}
+
+	// the plan over the strips: body ops ride with the next sweep's phase A launch; every sweep is
+	// phase A (interiors, all strips) then phase B (seams)
+	void runStrips()
+	{
+		const int n = (int)p.ops.size();
+		int segStart = 0;
+		for (int i = 0; i < n; ++i)
+		{
+			const Op& o = p.ops[(size_t)i];
+			if (isBodyOp(o.code) || sweepsNothing(o))
+			{
+				continue; // a body op rides along; a sweep over nothing is a no-op wherever it lands
+			}
+			StripOps lean;
+			int warm = -1;
+			if (o.code == OP_WARM)
+			{
+				// folded into the lean launch of the next sweep when that launch can take it
+				int j = i + 1;
+				while (j < n && (isBodyOp(p.ops[(size_t)j].code) || sweepsNothing(p.ops[(size_t)j])))
+				{
+					j += 1;
+				}
+				if (j < n && leanSegment(segStart, j, lean, warm) && warm >= 0)
+				{
+					continue;
+				}
+			}
+			const bool joint = o.code == OP_JOINT_SWEEP;
+			const bool timed = profile && isSolveSweep(o.code);
+			const bool seam = (joint ? s->joints.seamCount : s->contacts.seamCount) > 0;
+			if (leanSegment(segStart, i, lean, warm))
+			{
+				if (timed)
+				{
+					recordEvent();
+				}
+				launchStripSoft(st, o.kind, warm, s->cv, s->bv, s->leanA, lean);
+				if (timed)
+				{
+					recordEvent();
+				}
+				count();
+			}
+			else
+			{
+				launchStripGroups(s->dStripA, segStart, i + 1 - segStart, timed);
+			}
+			if (seam)
+			{
+				if (s->leanBValid && leanSoftKind(o))
+				{
+					StripOps only{};
+					only.sweep = 1, only.useBias = o.useBias, only.inv_h = o.inv_h;
+					if (timed)
+					{
+						recordEvent();
+					}
+					launchStripSoft(st, o.kind, -1, s->cv, s->bv, s->leanB, only);
+					if (timed)
+					{
+						recordEvent();
+					}
+					count();
+				}
+				else
+				{
+					launchStripGroups(s->dStripB, i, 1, timed);
+				}
+			}
+			segStart = i + 1;
+		}
+		if (segStart < n)
+		{
+			launchStripGroups(s->dStripA, segStart, n - segStart, false);
+		}
+	}
+
 	void run()
 	{
 		if (p.earlyOut)
@@ -1805,6 +2406,10 @@ struct Executor
 			launchGroupKernel(st, s->cv, s->jv, s->bv, s->dGroups.view, deviceOps(), (int)p.ops.size(), p.sc, wireContacts(), s->dGroups.maxBodies,
 							  p.usesDq0 ? 1 : 0);
 			count();
+		}
+		if (s->dStripA.view.groupCount > 0)
+		{
+			runStrips();
 		}
 		// global part: op by op
 		const bool anyGlobal = s->looseBodies > 0 || s->contacts.globalCount > 0 || s->joints.globalCount > 0;
@@ -2148,7 +2753,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	{
 		uint64_t key = 1469598103934665603ull;
 		key = fnv(key, params, sizeof(*params));
-		uint64_t gens[4] = {s->layoutGeneration, s->structureGeneration, s->planGeneration, (uint64_t)((q.msg ? 1 : 0) | (s->optBodyWarm ? 2 : 0))};
+		uint64_t gens[4] = {s->layoutGeneration, s->structureGeneration, s->planGeneration, (uint64_t)((q.msg ? 1 : 0) | (s->optBodyWarm ? 2 : 0) | (s->optStripLean ? 4 : 0))};
 		key = fnv(key, gens, sizeof(gens));
 		int sizes[3] = {s->bodyCapacity, s->contactCapacity, s->jointCapacity};
 		key = fnv(key, sizes, sizeof(sizes));
@@ -2196,6 +2801,8 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	s->stats.solveSweeps = plan.solveSweeps;
 	s->stats.kernelLaunches = s->launchCounter;
 	s->stats.groupCount = s->dGroups.view.groupCount;
+	s->stats.stripCount = s->dStripA.view.groupCount;
+	s->stats.seamCount = s->dStripB.view.groupCount;
 	if (q.profile)
 	{
 		float total = 0.0f;
@@ -2328,7 +2935,7 @@ int s2amd_create(int device, s2amdSolver** out)
 		delete s;
 		return fail(S2AMD_E_DEVICE, std::string("stream/event creation: ") + hipGetErrorString(e));
 	}
-	if (groupKernelSetup() != 0)
+	if (groupKernelSetup() != 0 || stripKernelSetup() != 0)
 	{
 		(void)hipGetLastError(); // not fatal: groups are then limited to the default 64 KiB of LDS
 		s->optMaxGroupBodies = 1536;
@@ -2569,6 +3176,7 @@ int s2amd_measure_dominant(s2amdSolver* s, const s2amdStepParams* params, int32_
 	Executor q{s, s->stream, plan, isPositionSolver(params->solverType) ? 1 : 0, false};
 	q.msg = messageEligible(s, params->solverType);
 	const bool global = s->contacts.globalCount > 0 && dominant >= 0;
+	const bool strips = !global && s->contacts.stripCount > 0 && dominant >= 0;
 	hipGraph_t g = nullptr;
 	hipGraphExec_t ge = nullptr;
 	s->launchCounter = 0;
@@ -2578,6 +3186,14 @@ int s2amd_measure_dominant(s2amdSolver* s, const s2amdStepParams* params, int32_
 		if (global)
 		{
 			q.runGlobalOp(dominant);
+		}
+		else if (strips)
+		{
+			q.launchStripGroups(s->dStripA, dominant, 1, false);
+			if (s->contacts.seamCount > 0)
+			{
+				q.launchStripGroups(s->dStripB, dominant, 1, false);
+			}
 		}
 		else if (s->dGroups.view.groupCount > 0)
 		{
@@ -2620,7 +3236,9 @@ int s2amd_measure_dominant(s2amdSolver* s, const s2amdStepParams* params, int32_
 	}
 	if (constraintsPerLaunch)
 	{
-		*constraintsPerLaunch = global ? s->contacts.globalCount / std::max(launches / repeats, 1) : s->cv.count;
+		*constraintsPerLaunch = global	 ? s->contacts.globalCount / std::max(launches / repeats, 1)
+								: strips ? s->contacts.stripCount / std::max(launches / repeats, 1)
+										 : s->cv.count;
 	}
 	return S2AMD_OK;
 }
@@ -2655,6 +3273,26 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	else if (strcmp(key, "max_group_bodies") == 0)
 	{
 		s->optMaxGroupBodies = std::max(1, std::min(value, 3072));
+		s->structureDirty = true;
+	}
+	else if (strcmp(key, "strips") == 0)
+	{
+		s->optStrips = value != 0;
+		s->structureDirty = true;
+	}
+	else if (strcmp(key, "strip_lean") == 0)
+	{
+		s->optStripLean = value != 0;
+		s->structureDirty = true;
+	}
+	else if (strcmp(key, "strip_bodies") == 0)
+	{
+		s->optStripBodies = std::max(1, value);
+		s->structureDirty = true;
+	}
+	else if (strcmp(key, "strip_min_bodies") == 0)
+	{
+		s->optStripMinBodies = std::max(0, value);
 		s->structureDirty = true;
 	}
 	else if (strcmp(key, "pack_group_bodies") == 0)

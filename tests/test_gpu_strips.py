@@ -1,0 +1,129 @@
+"""Strips: an island that fits no LDS group is cut along BFS level sets (solver.cpp: partitionStrips);
+a Gauss-Seidel sweep becomes phase A (strip interiors) + phase B (seams) = two launches.
+
+Same gate as test_gpu_parity.py: the C-ABI result must equal the oracle BIT FOR BIT when the oracle
+sweeps in the order the library reports (strip by strip colour-major, then seam by seam).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from solver2d_amd import hip, synthetic, wire
+from tests import common, golden_util, oraclebind
+from tests.test_gpu_parity import gpu_vs_oracle
+
+pytestmark = pytest.mark.gpu
+
+FILES = golden_util.golden_files()
+
+
+@pytest.fixture(scope="module")
+def tiny_strips():
+    """Forces the strip path on the small golden worlds: no island fits a group, strips of ~12 bodies."""
+    s = hip.Solver(0)
+    s.set_option("max_group_bodies", 48)
+    s.set_option("strip_min_bodies", 0)
+    s.set_option("strip_bodies", 12)
+    yield s
+    s.close()
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(p)[:-4] for p in FILES])
+def test_golden_inputs_bit_exact_through_strips(tiny_strips, path):
+    params, pre, _post = golden_util.load(path)
+    gpu_vs_oracle(tiny_strips, params, pre, os.path.basename(path))
+
+
+def test_golden_worlds_really_ran_as_strips(tiny_strips):
+    path = [f for f in FILES if "pyramid10_TGS_Soft_step045" in f][0]
+    params, pre, _post = golden_util.load(path)
+    gpu_vs_oracle(tiny_strips, params, pre, "pyramid10 strips")
+    st = tiny_strips.stats()
+    assert st["stripCount"] >= 2 and st["seamCount"] >= 1 and st["groupCount"] == 0
+
+
+@pytest.mark.parametrize("solver_name", [n for n in wire.SOLVER_NAMES if n != "Jacobi"])
+def test_big_pyramid_strips_default_options(solver_name):
+    """Base-100 pyramid (5,050 bodies, one island): default options choose strips; three consecutive steps."""
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    pre = synthetic.pyramid(100)
+    with hip.Solver(0) as s:
+        state = common.copy3(pre)
+        for step in range(3):
+            params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+            state = gpu_vs_oracle(s, params, state, "pyramid100/%s step %d" % (solver_name, step))
+        st = s.stats()
+        assert st["stripCount"] >= 4 and st["seamCount"] == st["stripCount"] - 1, st
+
+
+@pytest.mark.parametrize("lean", [1, 0])
+@pytest.mark.parametrize("solver_name", ["TGS_Soft", "SoftStep", "PGS_Soft"])
+def test_lean_strip_kernel_on_off(solver_name, lean):
+    """The soft sweeps run through strip_kernel.hip (preloaded rounds, body stages and warm start folded into
+    the phase A launch) or through the group interpreter: same bits, fewer launches."""
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    pre = synthetic.pyramid(100)
+    with hip.Solver(0) as s:
+        s.set_option("strip_lean", lean)
+        state = common.copy3(pre)
+        for step in range(3):
+            params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+            state = gpu_vs_oracle(s, params, state, "pyramid100/%s lean=%d step %d" % (solver_name, lean, step))
+        print(solver_name, lean, s.stats()["kernelLaunches"])
+
+
+@pytest.mark.parametrize("warm", [True, False])
+@pytest.mark.parametrize("iters", [(8, 4), (4, 0), (1, 1)])
+def test_lean_strip_kernel_iteration_shapes(iters, warm):
+    pre = synthetic.pyramid(100)
+    with hip.Solver(0) as s:
+        params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, iters[0], iters[1], warm)
+        state = gpu_vs_oracle(s, params, pre, "pyramid100 TGS_Soft %r warm=%r" % (iters, warm))
+        gpu_vs_oracle(s, params, state, "pyramid100 TGS_Soft %r warm=%r step 2" % (iters, warm))
+
+
+def test_jacobi_keeps_the_colour_batch_path():
+    vel, pos = common.DEFAULT_ITERS["Jacobi"]
+    pre = synthetic.pyramid(100)
+    with hip.Solver(0) as s:
+        params = wire.StepParams.make("Jacobi", 1.0 / 60.0, vel, pos, True)
+        gpu_vs_oracle(s, params, pre, "pyramid100/Jacobi")
+        assert s.stats()["stripCount"] == 0
+
+
+@pytest.mark.parametrize("strips", [1, 0])
+def test_strips_on_off_launch_counts(strips):
+    pre = synthetic.pyramid(100)
+    with hip.Solver(0) as s:
+        s.set_option("strips", strips)
+        params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+        gpu_vs_oracle(s, params, pre, "pyramid100 strips=%d" % strips)
+        st = s.stats()
+        if strips:
+            assert st["kernelLaunches"] < 60, st
+        else:
+            assert st["stripCount"] == 0 and st["kernelLaunches"] > 100, st
+
+
+@pytest.mark.parametrize("solver_name", ["TGS_Soft", "PGS_NGS", "XPBD", "TGS_Sticky"])
+def test_joint_grid_strips(solver_name):
+    """70x70 joint grid (4,900 bodies, 9,660 revolute joints, one island): joints in strips."""
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    pre = synthetic.joint_grid(70)
+    with hip.Solver(0) as s:
+        state = common.copy3(pre)
+        for step in range(2):
+            params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+            state = gpu_vs_oracle(s, params, state, "jointgrid70/%s step %d" % (solver_name, step))
+        assert s.stats()["stripCount"] >= 4
+
+
+@pytest.mark.parametrize("solver_name", ["TGS_Soft", "PGS", "PGS_NGS_Block"])
+def test_platform_high_degree_body_in_strips(solver_name):
+    """The platform world has one body touching 60 boxes: levels around it are wide, still exact."""
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    pre = synthetic.platform(60, layers=80)
+    with hip.Solver(0) as s:
+        params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+        gpu_vs_oracle(s, params, pre, "platform60x80/%s" % solver_name)

@@ -171,6 +171,7 @@ def main():
     avg_launch_us, launches_per_sweep, constraints_per_launch = gpu.measure_dominant(params, repeats=40)
     avg_launch_s = max(avg_launch_us * 1e-6, 1e-12)
     achieved = ALGO_BYTES_PER_CONSTRAINT_SWEEP * constraints_per_launch / avg_launch_s / 1e9
+    persistent = bool(gpu.stats().get("persistent", 0))
     # per-launch event pairs (eager launches), kept as a cross-check against rocprofv3's per-kernel durations
     prof_steps = 3
     gpu.set_option("profile", 1)
@@ -211,8 +212,9 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "solveContactsSoftKernel<SOFT_TGS>",
-                "avg_launch_us": avg_launch_us, "launches_per_step": launches_per_sweep * sweeps,
+                "kernel": "stripStepKernel<SOFT_TGS> (whole step, one persistent launch; constraints_per_launch counts "
+                          "constraint-sweeps)" if persistent else "solveContactsSoftKernel<SOFT_TGS> / stripSoftKernel<SOFT_TGS>",
+                "avg_launch_us": avg_launch_us, "launches_per_step": 1 if persistent else launches_per_sweep * sweeps,
                 "constraints_per_launch": constraints_per_launch,
                 "eager_event_pair_us_per_launch": 1e3 * kernel_ms / max(launches, 1), "empty_event_pair_us": overhead_ms * 1e3,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CONSTRAINT_SWEEP * constraints_per_launch,

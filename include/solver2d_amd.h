@@ -160,6 +160,7 @@ typedef struct s2amdStepStats
 	int32_t messagePassing;    /* 1 when the big-island sweeps read bodies from per-constraint copies (no gather) */
 	int32_t stripCount;        /* strips (BFS level ranges) a big island was cut into: phase A workgroups per sweep */
 	int32_t seamCount;         /* seams between adjacent strips that carry constraints: phase B workgroups per sweep */
+	int32_t persistent;        /* 1 when the strips ran as ONE persistent launch (constraints resident in registers all step) */
 } s2amdStepStats;
 
 typedef struct s2amdSolver s2amdSolver;
@@ -265,7 +266,8 @@ int s2amd_measure_dominant(s2amdSolver* solver, const s2amdStepParams* params, i
 /* option keys: "graph" (0/1 hipGraph replay), "profile" (0/1 per-sweep HIP events),
  * "groups" (0/1 LDS group path for small islands), "message" (0/1 message-passing sweeps), "max_group_bodies", "pack_group_bodies",
  * "strips" (0/1 cut islands that fit no LDS group into strips of BFS levels: two launches per sweep), "strip_bodies" (target
- * bodies per strip), "strip_min_bodies" (loose bodies below which the colour-batch path is kept), "body_warm" */
+ * bodies per strip), "strip_min_bodies" (loose bodies below which the colour-batch path is kept), "strip_lean" (0/1 dedicated strip
+ * kernel for the soft sweeps), "persist" (0/1 whole step of the strips in one persistent launch), "body_warm" */
 int s2amd_set_option(s2amdSolver* solver, const char* key, int32_t value);
 
 #ifdef __cplusplus

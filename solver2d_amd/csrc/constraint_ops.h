@@ -254,7 +254,8 @@ template <int KIND> S2_DEV void pinSoft(SoftRegs<KIND>& r)
 }
 
 // the arithmetic of one constraint: bodies read and written through `b`, impulses updated in `r`
-template <int KIND, class BA> S2_DEV void solveSoftRegs(SoftRegs<KIND>& r, const ContactView& c, const BA& b, float inv_h, int useBias, int k)
+template <int KIND, class BA, bool PIN = true>
+S2_DEV void solveSoftRegs(SoftRegs<KIND>& r, const ContactView& c, const BA& b, float inv_h, int useBias, int k)
 {
 	const CHeader& h = r.h;
 	const float biasCap = (KIND == SOFT_TGS || KIND == SOFT_JACOBI) ? -S2_MAX_BAUMGARTE_VELOCITY : -0.5f * S2_MAX_BAUMGARTE_VELOCITY;
@@ -274,7 +275,10 @@ template <int KIND, class BA> S2_DEV void solveSoftRegs(SoftRegs<KIND>& r, const
 		BodyPose pA = loadPose(b, h.ia), pB = loadPose(b, h.ib);
 		dcA = pA.dc, qA = pA.q, dcB = pB.dc, qB = pB.q;
 	}
-	pinSoft(r);
+	if (PIN)
+	{
+		pinSoft(r);
+	}
 	V2 normal = h.normal;
 	V2 tangent = rightPerp(normal);
 	float mA = h.mA, iA = h.iA, mB = h.mB, iB = h.iB;

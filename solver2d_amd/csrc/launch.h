@@ -12,6 +12,7 @@ struct Op;
 struct MsgView;
 struct StripTableView;
 struct StripOps;
+struct PersistView;
 struct s2amdBody;
 struct s2amdContact;
 struct s2amdJoint;
@@ -130,3 +131,5 @@ void launchWarmStartBodies(hipStream_t s, int kind, const ContactView& c, const 
 // strip_kernel.hip
 int stripKernelSetup();
 void launchStripSoft(hipStream_t s, int kind, int warm, const ContactView& c, const BodyView& g, const StripTableView& t, const StripOps& ops);
+void launchStripStep(hipStream_t s, int kind, int warm, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv,
+					 const Op* ops, int opCount);

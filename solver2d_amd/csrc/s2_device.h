@@ -461,6 +461,34 @@ struct StripTableView
 	int ldsRecords; // float4 records of dynamic LDS a launch needs
 };
 
+// Persistent strip step (strip_kernel.hip: stripStepKernel): workgroup i owns strip i AND seam i | i+1 for the
+// whole step; seam bodies of strip i+1 travel between the two workgroups as 8-byte {epoch, value} granules.
+#define S2_PERSIST_B_ROUNDS 6  // colour batches of a seam (its constraints live in LDS)
+#define S2_PERSIST_IO_CHUNKS 2 // imported / exported bodies per thread: at most 2 * 256 per seam
+struct PersistDesc
+{
+	int seamGroup;	 // phase B group of seam i | i+1, -1: none
+	int remapBase;	 // seam-group-local body -> LDS index of THIS workgroup (own list first, imports behind it)
+	int importCount; // bodies of strip i+1 the seam touches: LDS slots bodyCount .. bodyCount + importCount
+	int importBase;	 // granule offset of seam i's buffers (toLeft: 8 per body, then toRight: 4 per body)
+	int exportCount; // bodies of THIS strip that seam i-1 | i touches
+	int exportBase;	 // granule offset of seam i-1's buffers
+	int exportSrcBase; // into exportSrc[]: own LDS index of each exported body
+	int batchCountB;   // the seam's colour batches
+	int4 batchB[S2_PERSIST_B_ROUNDS];
+};
+struct PersistView
+{
+	const PersistDesc* descs;
+	const int* remap;
+	const int* exportSrc;
+	unsigned long long* granules;
+	unsigned int* error; // host-visible: set when a hand-off timed out
+	int ldsRecords;
+	int debugSkip; // timing experiments only (results are wrong): 1 = no hand-offs, 2 = no seam rounds, 4 = no interior rounds
+	unsigned long long* debugTimes; // S2AMD_DEBUG_TIMES: wall_clock64() of one workgroup at kernel start, after the loads, after every op, at the end
+};
+
 // Message-passing tables of the global part (see MsgBodies in constraint_ops.h)
 struct MsgView
 {

@@ -15,6 +15,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -124,12 +125,15 @@ struct ColorMasks
 	std::vector<std::vector<int>> overflow; // colours >= 64*WORDS (rare: bodies with hundreds of constraints)
 };
 
+// balanced (strip groups: one constraint per thread and colour round): a repair pass after the greedy pass
+// evens out colours wider than one workgroup.
 int colorGraph(const std::vector<int>& ea, const std::vector<int>& eb, const std::vector<uint8_t>& conflict, int bodyCount,
-			   std::vector<int>& color)
+			   std::vector<int>& color, bool balanced = false)
 {
 	const int W = ColorMasks::WORDS;
 	size_t n = ea.size();
 	color.assign(n, 0);
+	std::vector<int> population;
 	std::vector<uint64_t> bits((size_t)bodyCount * W, 0);
 	std::vector<std::vector<int>> extra;
 	std::vector<int> extraIndex; // body -> index in extra or -1
@@ -199,6 +203,54 @@ int colorGraph(const std::vector<int>& ea, const std::vector<int>& eb, const std
 		}
 		color[k] = chosen;
 		colorCount = std::max(colorCount, chosen + 1);
+		if (balanced)
+		{
+			if ((int)population.size() <= chosen)
+			{
+				population.resize((size_t)chosen + 1, 0);
+			}
+			population[(size_t)chosen] += 1;
+		}
+	}
+	if (balanced && colorCount <= 64)
+	{
+		// repair pass: greedy fills the low colours first; move constraints out of colours wider than one
+		// workgroup into the least populated colour that is free on both bodies (never adds a colour)
+		const int cap = 256;
+		for (size_t kk = n; kk-- > 0;)
+		{
+			int c = color[kk];
+			if (population[(size_t)c] <= cap)
+			{
+				continue;
+			}
+			int a = ea[kk], b = eb[kk];
+			bool ca = a >= 0 && conflict[a], cb = b >= 0 && b != a && conflict[b];
+			uint64_t used = (ca ? bits[(size_t)a * W] : 0) | (cb ? bits[(size_t)b * W] : 0);
+			int best = -1;
+			for (int c2 = 0; c2 < colorCount; ++c2)
+			{
+				if (c2 != c && ((used >> c2) & 1ull) == 0 && population[(size_t)c2] < cap && (best < 0 || population[(size_t)c2] < population[(size_t)best]))
+				{
+					best = c2;
+				}
+			}
+			if (best < 0)
+			{
+				continue;
+			}
+			if (ca)
+			{
+				bits[(size_t)a * W] = (bits[(size_t)a * W] & ~(1ull << c)) | (1ull << best);
+			}
+			if (cb)
+			{
+				bits[(size_t)b * W] = (bits[(size_t)b * W] & ~(1ull << c)) | (1ull << best);
+			}
+			color[kk] = best;
+			population[(size_t)c] -= 1;
+			population[(size_t)best] += 1;
+		}
 	}
 	return colorCount;
 }
@@ -372,6 +424,16 @@ struct s2amdSolver
 	StripTableView leanA{}, leanB{};
 	bool leanAValid = false, leanBValid = false;
 	int optStripLean = 1;
+	// persistent strip step (strip_kernel.hip: stripStepKernel)
+	DevBuf dPersist, dGranules;
+	PersistView persist{};
+	bool persistValid = false;
+	size_t granuleBytes = 0;
+	int optPersist = 1;
+	int optPersistDebug = 0;
+	int cuCount = 0;
+	unsigned int* hostError = nullptr; // pinned, device-visible: a hand-off timed out
+	unsigned long long* hostTimes = nullptr; // S2AMD_DEBUG_TIMES: pinned [256] phase time stamps of one workgroup
 	DevBuf dMsg;
 	MsgView msg{};
 	bool msgTablesValid = false; // the global part is contact-only and has no sequential tail
@@ -394,7 +456,7 @@ struct s2amdSolver
 	int optMaxGroupBodies = 2048;
 	int optPackGroupBodies = 1024;
 	int optStrips = 1;		   // cut islands that do not fit one LDS group into strips of BFS levels (2 launches per sweep)
-	int optStripBodies = 640;  // target bodies per strip
+	int optStripBodies = 320;  // target bodies per strip
 	int optStripMinBodies = 4096; // loose bodies below which the colour-batch path is kept
 
 	// graph cache
@@ -604,10 +666,10 @@ struct EdgeList
 // Colours one part (the global part or one group), appends its sweep order to `set` and returns its
 // launch batches as ranges of k.  Endpoints are indices into `conflict`.
 void colourPart(const std::vector<int>& ids, const std::vector<int>& ea, const std::vector<int>& eb, const std::vector<uint8_t>& conflict,
-				int bodyCount, SweepSet& set, std::vector<int>& batchOffsetsOut, bool& hasTailOut, std::vector<int>* positions)
+				int bodyCount, SweepSet& set, std::vector<int>& batchOffsetsOut, bool& hasTailOut, std::vector<int>* positions, bool balanced = false)
 {
 	std::vector<int> color, partOrder, partOffsets;
-	int cc = colorGraph(ea, eb, conflict, bodyCount, color);
+	int cc = colorGraph(ea, eb, conflict, bodyCount, color, balanced);
 	// stable counting sort of positions by colour
 	std::vector<int> pos(ids.size());
 	for (size_t i = 0; i < ids.size(); ++i)
@@ -1220,13 +1282,29 @@ int buildStructure(s2amdSolver* s, int solverType)
 
 	// one LDS group: local body slots (seeded bodies first: owned, in the given order), colour batches of
 	// its contacts and joints appended to the sweep sets, one row in table `t`
-	auto emitGroup = [&](HostGroupTable& t, const std::vector<int>& cKs, const std::vector<int>& jKs, const std::vector<int>& seedBodies) {
+	auto emitGroup = [&](HostGroupTable& t, const std::vector<int>& cKs, const std::vector<int>& jKs, const std::vector<int>& seedBodies,
+						 const std::vector<int>* replicaOf = nullptr) {
 		std::vector<int> ids, a, b, bodies, la, lb, pos, batchOffsets;
 		bool tail = false;
 		slots.begin();
 		for (int body : seedBodies)
 		{
 			slots.seed(body, bodies, true);
+		}
+		if (replicaOf)
+		{
+			// read-only bodies of the seam this strip also sweeps in the persistent kernel (strip_kernel.hip)
+			for (int k : *replicaOf)
+			{
+				if (ce.a[k] >= 0 && !conflict[ce.a[k]])
+				{
+					slots.get(ce.a[k], bodies, conflict);
+				}
+				if (ce.b[k] >= 0 && !conflict[ce.b[k]])
+				{
+					slots.get(ce.b[k], bodies, conflict);
+				}
+			}
 		}
 		// contacts
 		gather(ce, cKs, ids, a, b);
@@ -1251,7 +1329,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 		{
 			lconf[i] = conflict[(size_t)((uint32_t)bodies[i] & ~S2G_OWNED)];
 		}
-		colourPart(ids, la, lb, lconf, (int)bodies.size(), cs, batchOffsets, tail, &pos);
+		colourPart(ids, la, lb, lconf, (int)bodies.size(), cs, batchOffsets, tail, &pos, &t != &s->hGroups);
 		for (size_t i = 0; i < pos.size(); ++i)
 		{
 			cs.local.push_back(make_int2(la[(size_t)pos[i]], lb[(size_t)pos[i]]));
@@ -1302,13 +1380,15 @@ int buildStructure(s2amdSolver* s, int solverType)
 	const int stripBaseC = (int)cs.order.size(), stripBaseJ = (int)js.order.size();
 	for (size_t i = 0; i < strips.bodies.size(); ++i)
 	{
-		emitGroup(s->hStripA, strips.cA[i], strips.jA[i], strips.bodies[i]);
+		emitGroup(s->hStripA, strips.cA[i], strips.jA[i], strips.bodies[i], i < strips.cB.size() ? &strips.cB[i] : nullptr);
 	}
 	int stripInterior = (int)cs.order.size(), stripInteriorJ = (int)js.order.size();
+	std::vector<int> seamGroup(strips.cB.size(), -1);
 	for (size_t i = 0; i < strips.cB.size(); ++i)
 	{
 		if (!strips.cB[i].empty() || !strips.jB[i].empty())
 		{
+			seamGroup[i] = s->hStripB.count();
 			emitGroup(s->hStripB, strips.cB[i], strips.jB[i], noSeed);
 		}
 	}
@@ -1509,6 +1589,178 @@ int buildStructure(s2amdSolver* s, int solverType)
 				s->leanB.ldsRecords = ldsB;
 				s->leanBValid = true;
 			}
+		}
+	}
+
+	// ---- persistent strip step: seam remaps, export lists, granule buffers (strip_kernel.hip) ----
+	s->persistValid = false;
+	if (getenv("S2AMD_DEBUG") && strips.active)
+	{
+		fprintf(stderr, "[s2amd] strips: %d strips, %d seams, leanA %d leanB %d, strip joints %d, CUs %d\n", s->hStripA.count(), s->hStripB.count(),
+				(int)s->leanAValid, (int)s->leanBValid, js.stripCount, s->cuCount);
+	}
+	if (s->leanAValid && s->leanBValid && js.stripCount == 0 && s->optPersist && s->hostError != nullptr && s->hStripA.count() <= s->cuCount)
+	{
+		const HostGroupTable& A = s->hStripA;
+		const HostGroupTable& B = s->hStripB;
+		const int K = A.count();
+		std::vector<int> ownerGroup((size_t)nb, -1), ownerSlot((size_t)nb, -1), replicaStamp((size_t)nb, -1), replicaSlot((size_t)nb, -1);
+		bool ok = true;
+		for (int gi = 0; gi < K; ++gi)
+		{
+			for (int e = A.bodyOffsets[(size_t)gi]; e < A.bodyOffsets[(size_t)gi + 1]; ++e)
+			{
+				uint32_t id = (uint32_t)A.bodyIds[(size_t)e];
+				if (id & S2G_OWNED)
+				{
+					ownerGroup[id & ~S2G_OWNED] = gi;
+					ownerSlot[id & ~S2G_OWNED] = e - A.bodyOffsets[(size_t)gi];
+				}
+			}
+			for (int b = A.cBatchOffsets[(size_t)gi]; b < A.cBatchOffsets[(size_t)gi + 1]; ++b)
+			{
+				ok = ok && A.cBatches[(size_t)b].y - A.cBatches[(size_t)b].x <= 256; // one constraint per thread and round
+			}
+		}
+		std::vector<PersistDesc> descs((size_t)K);
+		std::vector<int> remap, exportSrc;
+		std::vector<std::vector<int>> exports((size_t)K); // per strip: own LDS slots it exports to its left neighbour
+		int granules = 0, ldsRecords = 0;
+		const int kMaxQ = 12; // float4 records of one seam constraint in LDS (largest PersistRegs)
+		for (int i = 0; i < K && ok; ++i)
+		{
+			PersistDesc& d = descs[(size_t)i];
+			memset(&d, 0, sizeof(d));
+			d.seamGroup = i < (int)seamGroup.size() ? seamGroup[(size_t)i] : -1;
+			const int nbA = A.bodyOffsets[(size_t)i + 1] - A.bodyOffsets[(size_t)i];
+			int seamSlots = 0;
+			if (d.seamGroup >= 0)
+			{
+				const int g = d.seamGroup;
+				for (int e = A.bodyOffsets[(size_t)i]; e < A.bodyOffsets[(size_t)i + 1]; ++e)
+				{
+					uint32_t id = (uint32_t)A.bodyIds[(size_t)e];
+					if ((id & S2G_OWNED) == 0)
+					{
+						replicaStamp[id] = i;
+						replicaSlot[id] = e - A.bodyOffsets[(size_t)i];
+					}
+				}
+				d.remapBase = (int)remap.size();
+				for (int e = B.bodyOffsets[(size_t)g]; e < B.bodyOffsets[(size_t)g + 1] && ok; ++e)
+				{
+					int body = (int)((uint32_t)B.bodyIds[(size_t)e] & ~S2G_OWNED);
+					if (ownerGroup[body] == i)
+					{
+						remap.push_back(ownerSlot[body]);
+					}
+					else if (ownerGroup[body] == i + 1 && conflict[body])
+					{
+						remap.push_back(nbA + d.importCount);
+						exports[(size_t)i + 1].push_back(ownerSlot[body]);
+						d.importCount += 1;
+					}
+					else if (!conflict[body] && replicaStamp[body] == i)
+					{
+						remap.push_back(replicaSlot[body]);
+					}
+					else
+					{
+						ok = false;
+					}
+				}
+				int b0 = B.cBatchOffsets[(size_t)g], b1 = B.cBatchOffsets[(size_t)g + 1];
+				d.batchCountB = b1 - b0;
+				ok = ok && d.batchCountB <= S2_PERSIST_B_ROUNDS && d.importCount <= S2_PERSIST_IO_CHUNKS * 256;
+				for (int b = b0; b < b1 && ok; ++b)
+				{
+					int4 bt = B.cBatches[(size_t)b];
+					ok = bt.z == 0 && bt.y - bt.x <= 256;
+					d.batchB[b - b0] = make_int4(bt.x, bt.y, 0, 0);
+					seamSlots += bt.y - bt.x;
+				}
+				d.importBase = granules;
+				granules += 12 * d.importCount;
+			}
+			int records = 2 * (nbA + d.importCount) + kMaxQ * seamSlots + 2 * 128; // + the plan (up to 128 ops)
+			ok = ok && records <= (160 * 1024) / 16;
+			ldsRecords = std::max(ldsRecords, records - 2 * 128);
+		}
+		for (int i = 0; i < K && ok; ++i)
+		{
+			PersistDesc& d = descs[(size_t)i];
+			d.exportCount = (int)exports[(size_t)i].size();
+			d.exportSrcBase = (int)exportSrc.size();
+			exportSrc.insert(exportSrc.end(), exports[(size_t)i].begin(), exports[(size_t)i].end());
+			d.exportBase = i > 0 ? descs[(size_t)i - 1].importBase : 0;
+			ok = d.exportCount == (i > 0 ? descs[(size_t)i - 1].importCount : 0);
+		}
+		if (getenv("S2AMD_DEBUG"))
+		{
+			int maxB = 0, maxImport = 0;
+			for (const PersistDesc& d : descs)
+			{
+				maxB = std::max(maxB, d.batchCountB), maxImport = std::max(maxImport, d.importCount);
+			}
+			fprintf(stderr, "[s2amd] persistent step: %s (K=%d, max seam colours %d, max imports %d, lds records %d)\n", ok ? "eligible" : "NOT eligible", K,
+					maxB, maxImport, ldsRecords);
+		}
+		if (ok)
+		{
+			auto pad = [](size_t n) { return (n + 63) & ~size_t(63); };
+			size_t bD = pad(descs.size() * sizeof(PersistDesc)), bR = pad(std::max<size_t>(remap.size(), 1) * sizeof(int));
+			size_t bE = pad(std::max<size_t>(exportSrc.size(), 1) * sizeof(int));
+			std::vector<unsigned char> blob(bD + bR + bE, 0);
+			memcpy(blob.data(), descs.data(), descs.size() * sizeof(PersistDesc));
+			if (!remap.empty())
+			{
+				memcpy(blob.data() + bD, remap.data(), remap.size() * sizeof(int));
+			}
+			if (!exportSrc.empty())
+			{
+				memcpy(blob.data() + bD + bR, exportSrc.data(), exportSrc.size() * sizeof(int));
+			}
+			bool grewP = false;
+			s->granuleBytes = std::max<size_t>((size_t)granules, 1) * sizeof(unsigned long long);
+			if ((rc = s->dPersist.ensure(blob.size(), &grewP)) != 0 || (rc = s->dGranules.ensure(s->granuleBytes, &grewP)) != 0)
+			{
+				return rc;
+			}
+			if (grewP)
+			{
+				s->layoutGeneration += 1;
+			}
+			HIP_TRY(hipMemcpyAsync(s->dPersist.p, blob.data(), blob.size(), hipMemcpyHostToDevice, s->stream));
+			HIP_TRY(hipStreamSynchronize(s->stream));
+			const unsigned char* base = (const unsigned char*)s->dPersist.p;
+			s->persist.descs = (const PersistDesc*)base;
+			s->persist.remap = (const int*)(base + bD);
+			s->persist.exportSrc = (const int*)(base + bD + bR);
+			s->persist.granules = (unsigned long long*)s->dGranules.p;
+			unsigned int* devError = nullptr;
+			HIP_TRY(hipHostGetDevicePointer((void**)&devError, s->hostError, 0));
+			s->persist.error = devError;
+			s->persist.ldsRecords = ldsRecords;
+			s->persist.debugSkip = s->optPersistDebug;
+			s->persist.debugTimes = nullptr;
+			if (getenv("S2AMD_DEBUG_TIMES"))
+			{
+				if (!s->hostTimes && hipHostMalloc((void**)&s->hostTimes, 256 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess)
+				{
+					s->hostTimes = nullptr;
+					(void)hipGetLastError();
+				}
+				if (s->hostTimes)
+				{
+					memset(s->hostTimes, 0, 256 * sizeof(unsigned long long));
+					unsigned long long* dev = nullptr;
+					if (hipHostGetDevicePointer((void**)&dev, s->hostTimes, 0) == hipSuccess)
+					{
+						s->persist.debugTimes = dev;
+					}
+				}
+			}
+			s->persistValid = true;
 		}
 	}
 
@@ -2298,10 +2550,73 @@ struct Executor
 		return true;
 	}
 
+	// Can the whole plan run as ONE persistent launch over the strips (strip_kernel.hip: stripStepKernel)?
+	bool persistPlan(int& kind, int& warm) const
+	{
+		if (!s->persistValid || p.ops.size() > 128)
+		{
+			return false;
+		}
+		kind = -1, warm = -1;
+		for (const Op& o : p.ops)
+		{
+			if (o.code == OP_INTEGRATE_VEL || o.code == OP_INTEGRATE_POS || o.code == OP_FINALIZE)
+			{
+				continue;
+			}
+			if (o.code == OP_JOINT_SWEEP && s->joints.stripCount == 0)
+			{
+				continue;
+			}
+			if (o.code == OP_WARM && (o.kind == WARM_CURRENT || o.kind == WARM_FIXED) && (warm < 0 || warm == o.kind))
+			{
+				warm = o.kind;
+				continue;
+			}
+			if (leanSoftKind(o) && (kind < 0 || kind == o.kind))
+			{
+				kind = o.kind;
+				continue;
+			}
+			return false;
+		}
+		if (kind < 0)
+		{
+			return false;
+		}
+		if (warm < 0)
+		{
+			warm = kind == SOFT_FIXED ? WARM_FIXED : WARM_CURRENT;
+		}
+		return true;
+	}
+
+	void runPersistent(int kind, int warm)
+	{
+		(void)hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, st); // epochs restart at 1 every launch
+		count();
+		if (profile)
+		{
+			recordEvent();
+		}
+		launchStripStep(st, kind, warm, s->cv, s->bv, s->leanA, s->persist, deviceOps(), (int)p.ops.size());
+		if (profile)
+		{
+			recordEvent();
+		}
+		count();
+	}
+
 	// the plan over the strips: body ops ride with the next sweep's phase A launch; every sweep is
 	// phase A (interiors, all strips) then phase B (seams)
 	void runStrips()
 	{
+		int kind, warm;
+		if (persistPlan(kind, warm))
+		{
+			runPersistent(kind, warm);
+			return;
+		}
 		const int n = (int)p.ops.size();
 		int segStart = 0;
 		for (int i = 0; i < n; ++i)
@@ -2753,7 +3068,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	{
 		uint64_t key = 1469598103934665603ull;
 		key = fnv(key, params, sizeof(*params));
-		uint64_t gens[4] = {s->layoutGeneration, s->structureGeneration, s->planGeneration, (uint64_t)((q.msg ? 1 : 0) | (s->optBodyWarm ? 2 : 0) | (s->optStripLean ? 4 : 0))};
+		uint64_t gens[4] = {s->layoutGeneration, s->structureGeneration, s->planGeneration, (uint64_t)((q.msg ? 1 : 0) | (s->optBodyWarm ? 2 : 0) | (s->optStripLean ? 4 : 0) | (s->optPersist ? 8 : 0))};
 		key = fnv(key, gens, sizeof(gens));
 		int sizes[3] = {s->bodyCapacity, s->contactCapacity, s->jointCapacity};
 		key = fnv(key, sizes, sizeof(sizes));
@@ -2803,6 +3118,15 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	s->stats.groupCount = s->dGroups.view.groupCount;
 	s->stats.stripCount = s->dStripA.view.groupCount;
 	s->stats.seamCount = s->dStripB.view.groupCount;
+	{
+		int kind, warm;
+		s->stats.persistent = (s->dStripA.view.groupCount > 0 && q.persistPlan(kind, warm)) ? 1 : 0;
+	}
+	if (s->hostError && *s->hostError != 0u)
+	{
+		*s->hostError = 0u;
+		return fail(S2AMD_E_DEVICE, "strip hand-off timed out inside the persistent step kernel (workgroups not co-resident?)");
+	}
 	if (q.profile)
 	{
 		float total = 0.0f;
@@ -2935,6 +3259,16 @@ int s2amd_create(int device, s2amdSolver** out)
 		delete s;
 		return fail(S2AMD_E_DEVICE, std::string("stream/event creation: ") + hipGetErrorString(e));
 	}
+	(void)hipDeviceGetAttribute(&s->cuCount, hipDeviceAttributeMultiprocessorCount, device);
+	if (hipHostMalloc((void**)&s->hostError, sizeof(unsigned int), hipHostMallocMapped) == hipSuccess)
+	{
+		*s->hostError = 0u;
+	}
+	else
+	{
+		s->hostError = nullptr;
+		(void)hipGetLastError();
+	}
 	if (groupKernelSetup() != 0 || stripKernelSetup() != 0)
 	{
 		(void)hipGetLastError(); // not fatal: groups are then limited to the default 64 KiB of LDS
@@ -2960,10 +3294,26 @@ void s2amd_destroy(s2amdSolver* s)
 	DevBuf* bufs[] = {&s->dBodies,		&s->dContacts,	  &s->dJoints,		 &s->dBodiesSaved,	 &s->dBodyFlags,	&s->soaBodies,
 					  &s->soaContacts,	&s->soaJoints,	  &s->dContactIndex, &s->dJointIndex,	 &s->dContactLocal, &s->dJointLocal,
 					  &s->dAdjOffsets,	&s->dAdjList,	  &s->dGatherIndex,	 &s->dOps,			 &s->dGroups.buf,	&s->dContactTail.buf,
-					  &s->dJointTail.buf, &s->dMsg};
+					  &s->dJointTail.buf, &s->dMsg,			  &s->dStripA.buf,	 &s->dStripB.buf,	 &s->dStripLean,	&s->dPersist,
+					  &s->dGranules};
 	for (DevBuf* b : bufs)
 	{
 		b->release();
+	}
+	if (s->hostError)
+	{
+		(void)hipHostFree(s->hostError);
+	}
+	if (s->hostTimes)
+	{
+		int n = (int)s->hostTimes[255];
+		fprintf(stderr, "[s2amd] persistent step, one workgroup, wall_clock64 ticks (10 ns) since kernel start:");
+		for (int i = 1; i < n && i < 255; ++i)
+		{
+			fprintf(stderr, " %llu", s->hostTimes[i] - s->hostTimes[0]);
+		}
+		fprintf(stderr, "\n");
+		(void)hipHostFree(s->hostTimes);
 	}
 	(void)hipEventDestroy(s->evBegin);
 	(void)hipEventDestroy(s->evEnd);
@@ -3177,6 +3527,8 @@ int s2amd_measure_dominant(s2amdSolver* s, const s2amdStepParams* params, int32_
 	q.msg = messageEligible(s, params->solverType);
 	const bool global = s->contacts.globalCount > 0 && dominant >= 0;
 	const bool strips = !global && s->contacts.stripCount > 0 && dominant >= 0;
+	int pkind = -1, pwarm = -1;
+	const bool persistent = strips && q.persistPlan(pkind, pwarm);
 	hipGraph_t g = nullptr;
 	hipGraphExec_t ge = nullptr;
 	s->launchCounter = 0;
@@ -3186,6 +3538,10 @@ int s2amd_measure_dominant(s2amdSolver* s, const s2amdStepParams* params, int32_
 		if (global)
 		{
 			q.runGlobalOp(dominant);
+		}
+		else if (persistent)
+		{
+			q.runPersistent(pkind, pwarm);
 		}
 		else if (strips)
 		{
@@ -3230,15 +3586,22 @@ int s2amd_measure_dominant(s2amdSolver* s, const s2amdStepParams* params, int32_
 	(void)hipGraphExecDestroy(ge);
 	(void)hipGraphDestroy(g);
 	*usPerLaunch = 1e3f * ms / (float)(reps * launches);
+	if (persistent)
+	{
+		// the whole step is one launch (+ the memset of the hand-off buffers in front of it)
+		*usPerLaunch = 1e3f * ms / (float)(reps * repeats);
+		launches = repeats;
+	}
 	if (launchesPerSweep)
 	{
 		*launchesPerSweep = launches / repeats;
 	}
 	if (constraintsPerLaunch)
 	{
-		*constraintsPerLaunch = global	 ? s->contacts.globalCount / std::max(launches / repeats, 1)
-								: strips ? s->contacts.stripCount / std::max(launches / repeats, 1)
-										 : s->cv.count;
+		*constraintsPerLaunch = global		 ? s->contacts.globalCount / std::max(launches / repeats, 1)
+								: persistent ? s->contacts.stripCount * plan.solveSweeps // constraint-sweeps of the whole-step launch
+								: strips	 ? s->contacts.stripCount / std::max(launches / repeats, 1)
+											 : s->cv.count;
 	}
 	return S2AMD_OK;
 }
@@ -3278,6 +3641,16 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	else if (strcmp(key, "strips") == 0)
 	{
 		s->optStrips = value != 0;
+		s->structureDirty = true;
+	}
+	else if (strcmp(key, "persist_debug") == 0)
+	{
+		s->optPersistDebug = value;
+		s->structureDirty = true;
+	}
+	else if (strcmp(key, "persist") == 0)
+	{
+		s->optPersist = value != 0;
 		s->structureDirty = true;
 	}
 	else if (strcmp(key, "strip_lean") == 0)

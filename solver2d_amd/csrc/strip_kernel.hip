@@ -238,6 +238,623 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripSoftKernel(ContactView 
 	}
 }
 
+// ------------------------------------------------------------------------------------------------
+// Persistent strip step: ONE launch per s2Solve_* call.  Workgroup i keeps strip i's interior constraints
+// AND the constraints of seam i | i+1 in registers for the whole step, its bodies in LDS, and walks the
+// step plan.  What a colour-batch launch costs the other paths (reloading every constraint record
+// through one CU's memory pipe, ~25-60 GB/s) is paid once per step here.
+//
+// Per sweep:  A rounds (own bodies)  ->  the bodies of strip i+1 that seam i touches travel i+1 -> i
+//             B rounds (seam i)      ->  they travel back i -> i+1
+// as 8-byte {epoch, value} granules written with ONE agent-scope (sc1, write-through) store each and
+// polled with agent-scope loads: the data is the flag, no fence (cdna_hip_programming.md G16, form R2).
+// Every buffer is used strictly ping-pong (a sender can only reach epoch e+1 after it has consumed what
+// the receiver produced from epoch e), so one slot per granule suffices.  All K <= CU-count workgroups
+// are resident (one per CU); every poll loop is bounded and reports through pv.error.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) u64 gu64;
+
+S2_DEV void putGranule(gu64* g, unsigned epoch, float v)
+{
+	__hip_atomic_store(g, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#define S2_PERSIST_SPIN_LIMIT (1u << 21)
+
+template <int N> S2_DEV bool getGranules(gu64* g, unsigned epoch, float (&v)[N], unsigned int* error)
+{
+	for (unsigned spins = 0;; ++spins)
+	{
+		bool ok = true;
+#pragma unroll
+		for (int k = 0; k < N; ++k)
+		{
+			u64 x = __hip_atomic_load(g + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			v[k] = __uint_as_float((unsigned)x);
+			ok = ok && (unsigned)(x >> 32) == epoch;
+		}
+		if (ok)
+		{
+			return true;
+		}
+		if ((spins & 255u) == 255u)
+		{
+			if (spins >= S2_PERSIST_SPIN_LIMIT)
+			{
+				__hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				return false;
+			}
+			if (__hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
+			{
+				return false;
+			}
+		}
+		__builtin_amdgcn_s_sleep(1);
+	}
+}
+
+// s2WarmStartContacts (solve_common.c:276-330) for one constraint held in registers: warmStartContactsOne's
+// arithmetic (constraint_ops.h) on SoftRegs
+template <int WARM, int KIND, class BA> S2_DEV void warmSoftRegs(const SoftRegs<KIND>& r, const BA& b)
+{
+	const CHeader& h = r.h;
+	V2 tangent = rightPerp(h.normal);
+	BodyVel A = loadVel(b, h.ia), B = loadVel(b, h.ib);
+	V2 vA = A.v, vB = B.v;
+	float wA = A.w, wB = B.w;
+	Rot qA, qB;
+	if (WARM == WARM_CURRENT)
+	{
+		qA = loadPose(b, h.ia).q;
+		qB = loadPose(b, h.ib).q;
+	}
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		if (j < h.pointCount)
+		{
+			float4 arm = WARM == WARM_CURRENT ? r.an[j] : r.r0[j];
+			V2 rA, rB;
+			if (WARM == WARM_CURRENT)
+			{
+				rA = rotate(qA, v2(arm.x, arm.y));
+				rB = rotate(qB, v2(arm.z, arm.w));
+			}
+			else
+			{
+				rA = v2(arm.x, arm.y);
+				rB = v2(arm.z, arm.w);
+			}
+			V2 P = add(mulSV(r.imp[j].x, h.normal), mulSV(r.imp[j].y, tangent));
+			wA -= h.iA * cross(rA, P);
+			vA = mulAdd(vA, -h.mA, P);
+			wB += h.iB * cross(rB, P);
+			vB = mulAdd(vB, h.mB, P);
+		}
+	}
+	if (h.writeA)
+	{
+		storeVel(b, h.ia, vA, wA);
+	}
+	if (h.writeB)
+	{
+		storeVel(b, h.ib, vB, wB);
+	}
+}
+
+// A constraint as the persistent kernel keeps it for the whole step: only what the sweeps of this solver
+// read, 29 registers for TGS_Soft.  The soft coefficients are the same for both points (contact_kernels.hip
+// prepareContactsKernel<PREP_SOFT>; solve_common.c:262-271), so one copy is kept.
+template <int KIND, int WARM> struct PersistRegs
+{
+	static constexpr bool kAnchors = KIND == SOFT_TGS || KIND == SOFT_FIXED || WARM == WARM_CURRENT;
+	static constexpr bool kArms0 = KIND != SOFT_TGS || WARM == WARM_FIXED;
+	uint32_t idx; // ia | ib << 14 | pointCount << 28 | writeA << 30 | writeB << 31
+	float mA, iA, mB, iB, nx, ny, friction;
+	float4 an[kAnchors ? 2 : 1];
+	float4 r0[kArms0 ? 2 : 1];
+	float p0[2], p1[2], p2[2], p3[2];
+	float s0, s1, s2;
+	float2 imp[2];
+};
+
+template <int KIND, int WARM> S2_DEV PersistRegs<KIND, WARM> packPersist(const SoftRegs<KIND>& r, int ia, int ib)
+{
+	PersistRegs<KIND, WARM> p;
+	p.idx = (uint32_t)ia | ((uint32_t)ib << 14) | ((uint32_t)r.h.pointCount << 28) | (r.h.writeA ? 1u << 30 : 0u) | (r.h.writeB ? 1u << 31 : 0u);
+	p.mA = r.h.mA, p.iA = r.h.iA, p.mB = r.h.mB, p.iB = r.h.iB;
+	p.nx = r.h.normal.x, p.ny = r.h.normal.y, p.friction = r.h.friction;
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		if (PersistRegs<KIND, WARM>::kAnchors)
+		{
+			p.an[j] = r.an[j];
+		}
+		if (PersistRegs<KIND, WARM>::kArms0)
+		{
+			p.r0[j] = r.r0[j];
+		}
+		p.p0[j] = r.par[j].x, p.p1[j] = r.par[j].y, p.p2[j] = r.par[j].z, p.p3[j] = r.par[j].w;
+		p.imp[j] = r.imp[j];
+	}
+	p.s0 = r.sf[0].x, p.s1 = r.sf[0].y, p.s2 = r.sf[0].z;
+	return p;
+}
+
+template <int KIND, int WARM> S2_DEV SoftRegs<KIND> unpackPersist(const PersistRegs<KIND, WARM>& p)
+{
+	SoftRegs<KIND> r;
+	r.h.ia = (int)(p.idx & 0x3fffu), r.h.ib = (int)((p.idx >> 14) & 0x3fffu);
+	r.h.pointCount = (int)((p.idx >> 28) & 3u);
+	r.h.writeA = (p.idx & (1u << 30)) != 0, r.h.writeB = (p.idx & (1u << 31)) != 0;
+	r.h.mA = p.mA, r.h.iA = p.iA, r.h.mB = p.mB, r.h.iB = p.iB;
+	r.h.normal = v2(p.nx, p.ny), r.h.friction = p.friction;
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		if (PersistRegs<KIND, WARM>::kAnchors)
+		{
+			r.an[j] = p.an[j];
+		}
+		if (PersistRegs<KIND, WARM>::kArms0)
+		{
+			r.r0[j] = p.r0[j];
+		}
+		r.par[j] = make_float4(p.p0[j], p.p1[j], p.p2[j], p.p3[j]);
+		r.sf[j] = make_float4(p.s0, p.s1, p.s2, 0.0f);
+		r.imp[j] = p.imp[j];
+	}
+	return r;
+}
+
+// one constraint of a sweep, from its resident registers: warm start or soft solve
+template <int KIND, int WARM, class BA>
+S2_DEV void sweepPersist(PersistRegs<KIND, WARM>& p, const ContactView& c, const BA& lb, bool warm, float inv_h, int useBias, int k)
+{
+	SoftRegs<KIND> r = unpackPersist<KIND, WARM>(p);
+	if (warm)
+	{
+		warmSoftRegs<WARM>(r, lb);
+	}
+	else
+	{
+		solveSoftRegs<KIND, BA, false>(r, c, lb, inv_h, useBias, k);
+		p.imp[0] = r.imp[0], p.imp[1] = r.imp[1];
+	}
+}
+
+template <int KIND, int WARM> S2_DEV SoftRegs<KIND> loadPersist(const ContactView& c, int k)
+{
+	SoftRegs<KIND> r = loadSoft<KIND, S2_IDX_LOCAL>(c, k);
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		if (WARM == WARM_CURRENT && KIND == SOFT_PGS)
+		{
+			r.an[j] = c.anchor[j][k];
+		}
+		if (WARM == WARM_FIXED && KIND == SOFT_TGS)
+		{
+			r.r0[j] = c.r0[j][k];
+		}
+	}
+	return r;
+}
+
+template <int KIND, int WARM>
+__global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView c, BodyView g, StripTableView ta, PersistView pv, const Op* ops, int opCount)
+{
+	extern __shared__ __attribute__((aligned(16))) float4 lds[];
+	const int tid = (int)threadIdx.x;
+	const bool stamp = pv.debugTimes != nullptr && blockIdx.x == gridDim.x / 2 && tid == 0;
+	int stamps = 0;
+	if (stamp)
+	{
+		pv.debugTimes[stamps++] = wall_clock64();
+	}
+	const StripDesc* da = ta.descs + blockIdx.x;
+	const PersistDesc* pd = pv.descs + blockIdx.x;
+	const int bodyBase = da->bodyBase, nb = da->bodyCount, roundsA = da->batchCount;
+	const int seam = pd->seamGroup, importCount = pd->importCount, exportCount = pd->exportCount;
+	const int roundsB = seam >= 0 ? pd->batchCountB : 0;
+	const int nt = nb + importCount;
+	int4 batchA[S2_STRIP_ROUNDS], batchB[S2_PERSIST_B_ROUNDS];
+#pragma unroll
+	for (int i = 0; i < S2_STRIP_ROUNDS; ++i)
+	{
+		batchA[i] = da->batch[i];
+	}
+#pragma unroll
+	for (int i = 0; i < S2_PERSIST_B_ROUNDS; ++i)
+	{
+		batchB[i] = pd->batchB[i];
+	}
+	gu64* inLeft = (gu64*)pv.granules + pd->importBase;	   // seam i: written by workgroup i+1, read here
+	gu64* outRight = inLeft + 8 * importCount;			   // seam i: written here, read by workgroup i+1
+	gu64* outLeft = (gu64*)pv.granules + pd->exportBase;   // seam i-1: written here, read by workgroup i-1
+	gu64* inRight = outLeft + 8 * exportCount;			   // seam i-1: written by workgroup i-1, read here
+	float4* lvel = lds;
+	float4* ldq = lds + nt;
+	Op* lops = (Op*)(lds + 2 * nt);
+
+	// ---- loads: ids, export list, plan, every constraint of both phases ----
+	uint32_t id[S2_STRIP_BODY_CHUNKS];
+#pragma unroll
+	for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS; ++ch)
+	{
+		int i = tid + ch * S2_STRIP_THREADS;
+		id[ch] = i < nb ? (uint32_t)ta.bodyIds[bodyBase + i] : 0u;
+	}
+	int exportIdx[S2_PERSIST_IO_CHUNKS];
+#pragma unroll
+	for (int ch = 0; ch < S2_PERSIST_IO_CHUNKS; ++ch)
+	{
+		int j = tid + ch * S2_STRIP_THREADS;
+		exportIdx[ch] = j < exportCount ? pv.exportSrc[pd->exportSrcBase + j] : 0;
+	}
+	for (int i = tid; i < opCount * 8; i += S2_STRIP_THREADS)
+	{
+		((int*)lops)[i] = ((const int*)ops)[i];
+	}
+	// interiors live in registers; the seam's constraints live in LDS (field-major float4 records), which keeps
+	// the kernel inside the register file
+	constexpr int Q = (int)((sizeof(PersistRegs<KIND, WARM>) + 15) / 16);
+	float4* lseam = lds + 2 * nt + 2 * opCount;
+	int seamSlots = 0;
+#pragma unroll
+	for (int i = 0; i < S2_PERSIST_B_ROUNDS; ++i)
+	{
+		seamSlots += i < roundsB ? batchB[i].y - batchB[i].x : 0;
+	}
+	PersistRegs<KIND, WARM> rA[S2_STRIP_ROUNDS];
+	int kA[S2_STRIP_ROUNDS], kB[S2_PERSIST_B_ROUNDS];
+#pragma unroll
+	for (int i = 0; i < S2_STRIP_ROUNDS; ++i)
+	{
+		kA[i] = -1;
+		if (i < roundsA)
+		{
+			int k = batchA[i].x + tid;
+			if (k < batchA[i].y)
+			{
+				kA[i] = k;
+				SoftRegs<KIND> t = loadPersist<KIND, WARM>(c, k);
+				rA[i] = packPersist<KIND, WARM>(t, t.h.ia, t.h.ib);
+			}
+		}
+	}
+#pragma unroll
+	for (int i = 0; i < S2_PERSIST_B_ROUNDS; ++i)
+	{
+		kB[i] = -1;
+		if (i < roundsB)
+		{
+			int k = batchB[i].x + tid;
+			if (k < batchB[i].y)
+			{
+				kB[i] = k;
+				// seam constraints address this workgroup's LDS through the seam's remap table
+				SoftRegs<KIND> t = loadPersist<KIND, WARM>(c, k);
+				PersistRegs<KIND, WARM> pb = packPersist<KIND, WARM>(t, pv.remap[pd->remapBase + t.h.ia], pv.remap[pd->remapBase + t.h.ib]);
+				float4 q[Q];
+				__builtin_memcpy(q, &pb, sizeof(pb));
+				const int slot = k - batchB[0].x;
+#pragma unroll
+				for (int f = 0; f < Q; ++f)
+				{
+					lseam[f * seamSlots + slot] = q[f];
+				}
+			}
+		}
+	}
+	// bodies (+ the integrator constants, kept in registers for the whole step)
+	float4 integ[S2_STRIP_BODY_CHUNKS];
+	float angDamp[S2_STRIP_BODY_CHUNKS];
+	uint32_t flags[S2_STRIP_BODY_CHUNKS];
+#pragma unroll
+	for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS; ++ch)
+	{
+		int i = tid + ch * S2_STRIP_THREADS;
+		flags[ch] = 0u;
+		if (i < nb)
+		{
+			int gi = (int)(id[ch] & ~S2G_OWNED);
+			lvel[i] = g.vel[gi];
+			ldq[i] = g.dq[gi];
+			flags[ch] = g.flags[gi];
+			integ[ch] = g.integ[gi];
+			angDamp[ch] = g.angDamp[gi];
+		}
+	}
+	__syncthreads();
+
+	if (stamp)
+	{
+		pv.debugTimes[stamps++] = wall_clock64();
+	}
+	LdsBodies lb{lvel, ldq};
+	unsigned epoch = 0;
+	bool dqDirty = true; // the imported poses have never been sent
+	int bad = 0;
+	for (int oi = 0; oi < opCount && !bad; ++oi)
+	{
+		const Op op = lops[oi];
+		if (op.code == OP_INTEGRATE_VEL)
+		{
+#pragma unroll
+			for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS; ++ch)
+			{
+				int i = tid + ch * S2_STRIP_THREADS;
+				if (i < nb && (flags[ch] & S2F_DYNAMIC) != 0)
+				{
+					float4 v = lvel[i], k = integ[ch];
+					V2 lv = add(v2(v.x, v.y), v2(k.x, k.y));
+					float w = v.z + k.z;
+					lv = mulSV(k.w, lv);
+					w *= angDamp[ch];
+					lvel[i] = make_float4(lv.x, lv.y, w, 0.0f);
+				}
+			}
+			__syncthreads();
+		}
+		else if (op.code == OP_INTEGRATE_POS)
+		{
+#pragma unroll
+			for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS; ++ch)
+			{
+				int i = tid + ch * S2_STRIP_THREADS;
+				if (i < nb && (flags[ch] & S2F_MOVES) != 0)
+				{
+					float4 v = lvel[i], d = ldq[i];
+					V2 dpos = mulAdd(v2(d.x, d.y), op.h, v2(v.x, v.y));
+					Rot q;
+					q.s = d.z, q.c = d.w;
+					q = integrateRot(q, op.h * v.z);
+					ldq[i] = make_float4(dpos.x, dpos.y, q.s, q.c);
+				}
+			}
+			dqDirty = true;
+			__syncthreads();
+		}
+		else if (op.code == OP_FINALIZE)
+		{
+#pragma unroll
+			for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS; ++ch)
+			{
+				int i = tid + ch * S2_STRIP_THREADS;
+				if (i < nb)
+				{
+					finalizePositionsOne(lb, i, g, (int)(id[ch] & ~S2G_OWNED), op.flag, (id[ch] & S2G_OWNED) != 0);
+				}
+			}
+			dqDirty = true;
+			__syncthreads();
+		}
+		else if (op.code == OP_WARM || op.code == OP_SOLVE_SOFT)
+		{
+			const bool warm = op.code == OP_WARM;
+			// ---- phase A: interiors ----
+#pragma unroll
+			for (int i = 0; i < S2_STRIP_ROUNDS; ++i)
+			{
+				if (i < roundsA && (pv.debugSkip & 4) == 0)
+				{
+					if (kA[i] >= 0)
+					{
+						sweepPersist<KIND, WARM>(rA[i], c, lb, warm, op.inv_h, op.useBias, kA[i]);
+					}
+					__syncthreads();
+				}
+			}
+			epoch += 1;
+			// ---- seam bodies travel left: i+1 -> i ----
+			int fail = 0;
+#pragma unroll
+			for (int ch = 0; ch < S2_PERSIST_IO_CHUNKS; ++ch)
+			{
+				int j = tid + ch * S2_STRIP_THREADS;
+				if (j < exportCount)
+				{
+					float4 v = lvel[exportIdx[ch]];
+					gu64* p = outLeft + 8 * j;
+					putGranule(p + 0, epoch, v.x);
+					putGranule(p + 1, epoch, v.y);
+					putGranule(p + 2, epoch, v.z);
+					if (dqDirty)
+					{
+						float4 d = ldq[exportIdx[ch]];
+						putGranule(p + 3, epoch, d.x);
+						putGranule(p + 4, epoch, d.y);
+						putGranule(p + 5, epoch, d.z);
+						putGranule(p + 6, epoch, d.w);
+					}
+				}
+			}
+#pragma unroll
+			for (int ch = 0; ch < S2_PERSIST_IO_CHUNKS; ++ch)
+			{
+				int j = tid + ch * S2_STRIP_THREADS;
+				if (j < importCount && (pv.debugSkip & 1) == 0)
+				{
+					gu64* p = inLeft + 8 * j;
+					if (dqDirty)
+					{
+						float v[7];
+						if (getGranules<7>(p, epoch, v, pv.error))
+						{
+							lvel[nb + j] = make_float4(v[0], v[1], v[2], 0.0f);
+							ldq[nb + j] = make_float4(v[3], v[4], v[5], v[6]);
+						}
+						else
+						{
+							fail = 1;
+						}
+					}
+					else
+					{
+						float v[3];
+						if (getGranules<3>(p, epoch, v, pv.error))
+						{
+							lvel[nb + j] = make_float4(v[0], v[1], v[2], 0.0f);
+						}
+						else
+						{
+							fail = 1;
+						}
+					}
+				}
+			}
+			bad = __syncthreads_or(fail);
+			if (bad)
+			{
+				break;
+			}
+			// ---- phase B: seam i | i+1 ----
+#pragma unroll
+			for (int i = 0; i < S2_PERSIST_B_ROUNDS; ++i)
+			{
+				if (i < roundsB && (pv.debugSkip & 2) == 0)
+				{
+					if (kB[i] >= 0)
+					{
+						const int slot = kB[i] - batchB[0].x;
+						float4 q[Q];
+#pragma unroll
+						for (int f = 0; f < Q; ++f)
+						{
+							q[f] = lseam[f * seamSlots + slot];
+						}
+						PersistRegs<KIND, WARM> pb;
+						__builtin_memcpy(&pb, q, sizeof(pb));
+						sweepPersist<KIND, WARM>(pb, c, lb, warm, op.inv_h, op.useBias, kB[i]);
+						if (!warm)
+						{
+							__builtin_memcpy(q, &pb, sizeof(pb));
+#pragma unroll
+							for (int f = 0; f < Q; ++f)
+							{
+								lseam[f * seamSlots + slot] = q[f];
+							}
+						}
+					}
+					__syncthreads();
+				}
+			}
+			// ---- and back: i -> i+1 (velocities only: a sweep never moves a pose) ----
+#pragma unroll
+			for (int ch = 0; ch < S2_PERSIST_IO_CHUNKS; ++ch)
+			{
+				int j = tid + ch * S2_STRIP_THREADS;
+				if (j < importCount)
+				{
+					float4 v = lvel[nb + j];
+					gu64* p = outRight + 4 * j;
+					putGranule(p + 0, epoch, v.x);
+					putGranule(p + 1, epoch, v.y);
+					putGranule(p + 2, epoch, v.z);
+				}
+			}
+#pragma unroll
+			for (int ch = 0; ch < S2_PERSIST_IO_CHUNKS; ++ch)
+			{
+				int j = tid + ch * S2_STRIP_THREADS;
+				if (j < exportCount && (pv.debugSkip & 1) == 0)
+				{
+					float v[3];
+					if (getGranules<3>(inRight + 4 * j, epoch, v, pv.error))
+					{
+						lvel[exportIdx[ch]] = make_float4(v[0], v[1], v[2], 0.0f);
+					}
+					else
+					{
+						fail = 1;
+					}
+				}
+			}
+			bad = __syncthreads_or(fail);
+			dqDirty = false;
+		}
+		if (stamp)
+		{
+			pv.debugTimes[stamps++] = wall_clock64();
+		}
+	}
+
+	// ---- results: owned bodies, impulses ----
+#pragma unroll
+	for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS; ++ch)
+	{
+		int i = tid + ch * S2_STRIP_THREADS;
+		if (i < nb && (id[ch] & S2G_OWNED) != 0)
+		{
+			int gi = (int)(id[ch] & ~S2G_OWNED);
+			g.vel[gi] = lvel[i];
+			g.dq[gi] = ldq[i];
+		}
+	}
+#pragma unroll
+	for (int i = 0; i < S2_STRIP_ROUNDS; ++i)
+	{
+		if (kA[i] >= 0)
+		{
+			storeSoft<KIND>(c, unpackPersist<KIND, WARM>(rA[i]), kA[i]);
+		}
+	}
+#pragma unroll
+	for (int i = 0; i < S2_PERSIST_B_ROUNDS; ++i)
+	{
+		if (kB[i] >= 0)
+		{
+			const int slot = kB[i] - batchB[0].x;
+			float4 q[Q];
+#pragma unroll
+			for (int f = 0; f < Q; ++f)
+			{
+				q[f] = lseam[f * seamSlots + slot];
+			}
+			PersistRegs<KIND, WARM> pb;
+			__builtin_memcpy(&pb, q, sizeof(pb));
+			storeSoft<KIND>(c, unpackPersist<KIND, WARM>(pb), kB[i]);
+		}
+	}
+	if (stamp)
+	{
+		pv.debugTimes[stamps++] = wall_clock64();
+		pv.debugTimes[255] = (unsigned long long)stamps;
+	}
+}
+
+template <int KIND, int WARM>
+static void launchStep(hipStream_t s, dim3 grid, size_t lds, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv,
+					   const Op* ops, int opCount)
+{
+	stripStepKernel<KIND, WARM><<<grid, dim3(S2_STRIP_THREADS), lds, s>>>(c, g, a, pv, ops, opCount);
+}
+
+void launchStripStep(hipStream_t s, int kind, int warm, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv,
+					 const Op* ops, int opCount)
+{
+	dim3 grid((unsigned)a.groupCount);
+	size_t lds = (size_t)pv.ldsRecords * sizeof(float4) + (size_t)opCount * sizeof(Op);
+	if (kind == SOFT_TGS)
+	{
+		warm == WARM_FIXED ? launchStep<SOFT_TGS, WARM_FIXED>(s, grid, lds, c, g, a, pv, ops, opCount)
+						   : launchStep<SOFT_TGS, WARM_CURRENT>(s, grid, lds, c, g, a, pv, ops, opCount);
+	}
+	else if (kind == SOFT_PGS)
+	{
+		warm == WARM_FIXED ? launchStep<SOFT_PGS, WARM_FIXED>(s, grid, lds, c, g, a, pv, ops, opCount)
+						   : launchStep<SOFT_PGS, WARM_CURRENT>(s, grid, lds, c, g, a, pv, ops, opCount);
+	}
+	else
+	{
+		warm == WARM_FIXED ? launchStep<SOFT_FIXED, WARM_FIXED>(s, grid, lds, c, g, a, pv, ops, opCount)
+						   : launchStep<SOFT_FIXED, WARM_CURRENT>(s, grid, lds, c, g, a, pv, ops, opCount);
+	}
+}
+
 template <int KIND>
 static void launchKind(hipStream_t s, int warm, dim3 grid, size_t lds, const ContactView& c, const BodyView& g, const StripTableView& t, const StripOps& ops)
 {
@@ -284,6 +901,19 @@ int stripKernelSetup()
 		(const void*)stripSoftKernel<SOFT_PGS, WARM_CURRENT>,	(const void*)stripSoftKernel<SOFT_PGS, WARM_FIXED>,	  (const void*)stripSoftKernel<SOFT_PGS, -1>,
 		(const void*)stripSoftKernel<SOFT_FIXED, WARM_CURRENT>, (const void*)stripSoftKernel<SOFT_FIXED, WARM_FIXED>, (const void*)stripSoftKernel<SOFT_FIXED, -1>,
 	};
+	const void* steps[] = {
+		(const void*)stripStepKernel<SOFT_TGS, WARM_CURRENT>,	(const void*)stripStepKernel<SOFT_TGS, WARM_FIXED>,
+		(const void*)stripStepKernel<SOFT_PGS, WARM_CURRENT>,	(const void*)stripStepKernel<SOFT_PGS, WARM_FIXED>,
+		(const void*)stripStepKernel<SOFT_FIXED, WARM_CURRENT>, (const void*)stripStepKernel<SOFT_FIXED, WARM_FIXED>,
+	};
+	for (const void* f : steps)
+	{
+		hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		if (e != hipSuccess)
+		{
+			return (int)e;
+		}
+	}
 	for (const void* f : fns)
 	{
 		hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -73,11 +73,42 @@ def test_lean_strip_kernel_on_off(solver_name, lean):
         print(solver_name, lean, s.stats()["kernelLaunches"])
 
 
-@pytest.mark.parametrize("warm", [True, False])
-@pytest.mark.parametrize("iters", [(8, 4), (4, 0), (1, 1)])
-def test_lean_strip_kernel_iteration_shapes(iters, warm):
+@pytest.mark.parametrize("persist", [1, 0])
+@pytest.mark.parametrize("solver_name", ["TGS_Soft", "SoftStep", "PGS_Soft"])
+def test_persistent_strip_step_on_off(solver_name, persist):
+    """One persistent launch per step (constraints resident in registers / LDS, seam bodies handed between
+    neighbouring workgroups as tagged granules) against the multi-launch strip path: same bits."""
+    vel, pos = common.DEFAULT_ITERS[solver_name]
     pre = synthetic.pyramid(100)
     with hip.Solver(0) as s:
+        s.set_option("persist", persist)
+        state = common.copy3(pre)
+        for step in range(4):
+            params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+            state = gpu_vs_oracle(s, params, state, "pyramid100/%s persist=%d step %d" % (solver_name, persist, step))
+        st = s.stats()
+        assert st["persistent"] == persist, st
+        if persist:
+            assert st["kernelLaunches"] <= 10, st
+
+
+def test_persistent_strip_step_base_200():
+    """BASELINE config 2 itself: 20,101 bodies, 59,900 constraints, one island."""
+    pre = synthetic.pyramid(200)
+    with hip.Solver(0) as s:
+        params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+        state = gpu_vs_oracle(s, params, pre, "pyramid200 persistent")
+        gpu_vs_oracle(s, params, state, "pyramid200 persistent step 2")
+        assert s.stats()["persistent"] == 1
+
+
+@pytest.mark.parametrize("warm", [True, False])
+@pytest.mark.parametrize("iters", [(8, 4), (4, 0), (1, 1)])
+@pytest.mark.parametrize("persist", [1, 0])
+def test_lean_strip_kernel_iteration_shapes(iters, warm, persist):
+    pre = synthetic.pyramid(100)
+    with hip.Solver(0) as s:
+        s.set_option("persist", persist)
         params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, iters[0], iters[1], warm)
         state = gpu_vs_oracle(s, params, pre, "pyramid100 TGS_Soft %r warm=%r" % (iters, warm))
         gpu_vs_oracle(s, params, state, "pyramid100 TGS_Soft %r warm=%r step 2" % (iters, warm))

@@ -254,7 +254,9 @@ template <int KIND> S2_DEV void pinSoft(SoftRegs<KIND>& r)
 }
 
 // the arithmetic of one constraint: bodies read and written through `b`, impulses updated in `r`
-template <int KIND, class BA, bool PIN = true>
+// POINTS == 2: the caller has checked that the constraint has two points (a wave-uniform fast path without
+// per-point exec masking); POINTS == 0: per-point guards on h.pointCount.
+template <int KIND, class BA, bool PIN = true, int POINTS = 0>
 S2_DEV void solveSoftRegs(SoftRegs<KIND>& r, const ContactView& c, const BA& b, float inv_h, int useBias, int k)
 {
 	const CHeader& h = r.h;
@@ -289,7 +291,7 @@ S2_DEV void solveSoftRegs(SoftRegs<KIND>& r, const ContactView& c, const BA& b, 
 #pragma unroll
 	for (int j = 0; j < 2; ++j)
 	{
-		if (j < h.pointCount)
+		if (POINTS == 2 || j < h.pointCount)
 		{
 			V2 rA, rB;
 			float s;
@@ -315,17 +317,13 @@ S2_DEV void solveSoftRegs(SoftRegs<KIND>& r, const ContactView& c, const BA& b, 
 			}
 			rAj[j] = rA, rBj[j] = rB;
 
-			float bias = 0.0f, massScale = 1.0f, impulseScale = 0.0f;
-			if (s > 0.0f)
-			{
-				bias = s * inv_h;
-			}
-			else if (useBias)
-			{
-				bias = S2_MAXF(sf[j].x * s, biasCap);
-				massScale = sf[j].y;
-				impulseScale = sf[j].z;
-			}
+			// select form of: if (s > 0) bias = s * inv_h; else if (useBias) {bias = max(biasCoefficient * s, cap); ...}
+			const bool speculative = s > 0.0f;
+			const bool soft = !speculative && useBias != 0;
+			float softBias = S2_MAXF(sf[j].x * s, biasCap);
+			float bias = speculative ? s * inv_h : (soft ? softBias : 0.0f);
+			float massScale = soft ? sf[j].y : 1.0f;
+			float impulseScale = soft ? sf[j].z : 0.0f;
 
 			V2 vrB = add(vB, crossSV(wB, rB));
 			V2 vrA = add(vA, crossSV(wA, rA));
@@ -348,7 +346,7 @@ S2_DEV void solveSoftRegs(SoftRegs<KIND>& r, const ContactView& c, const BA& b, 
 #pragma unroll
 	for (int j = 0; j < 2; ++j)
 	{
-		if (j < h.pointCount)
+		if (POINTS == 2 || j < h.pointCount)
 		{
 			float tangentMass = par[j].z;
 			V2 rA = rAj[j], rB = rBj[j];

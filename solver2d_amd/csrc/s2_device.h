@@ -461,29 +461,33 @@ struct StripTableView
 	int ldsRecords; // float4 records of dynamic LDS a launch needs
 };
 
-// Persistent strip step (strip_kernel.hip: stripStepKernel): workgroup i owns strip i AND seam i | i+1 for the
-// whole step; seam bodies of strip i+1 travel between the two workgroups as 8-byte {epoch, value} granules.
-#define S2_PERSIST_B_ROUNDS 6  // colour batches of a seam (its constraints live in LDS)
-#define S2_PERSIST_IO_CHUNKS 2 // imported / exported bodies per thread: at most 2 * 256 per seam
+// Persistent strip step (strip_kernel.hip: stripStepKernel): workgroup i owns strip i for the whole step and
+// sweeps BOTH of its seams (i-1 | i and i | i+1); the two workgroups of a seam compute it redundantly from
+// identical inputs, so one symmetric exchange of seam bodies per sweep (after the interior rounds) suffices.
+#define S2_PERSIST_B_ROUNDS 4 // colour batches of a seam
 struct PersistDesc
 {
-	int seamGroup;	 // phase B group of seam i | i+1, -1: none
-	int remapBase;	 // seam-group-local body -> LDS index of THIS workgroup (own list first, imports behind it)
-	int importCount; // bodies of strip i+1 the seam touches: LDS slots bodyCount .. bodyCount + importCount
-	int importBase;	 // granule offset of seam i's buffers (toLeft: 8 per body, then toRight: 4 per body)
-	int exportCount; // bodies of THIS strip that seam i-1 | i touches
-	int exportBase;	 // granule offset of seam i-1's buffers
-	int exportSrcBase; // into exportSrc[]: own LDS index of each exported body
-	int batchCountB;   // the seam's colour batches
-	int4 batchB[S2_PERSIST_B_ROUNDS];
+	int importCount[2];	  // [0] from the left neighbour (its bodies that seam i-1 touches), [1] from the right
+	int importIdBase[2];  // into importIds[]: body-pool slot of every imported body (initial load)
+	int exportCount[2];	  // [0] to the left (my bodies that seam i-1 touches), [1] to the right
+	int exportSrcBase[2]; // into exportSrc[]: own LDS index of every exported body
+	int inBase[2];		  // granule offset of the buffer this workgroup READS (per parity: + parityStride)
+	int outBase[2];		  // granule offset of the buffer this workgroup WRITES
+	int remapBase[2];	  // seam-group-local body -> LDS index of this workgroup, per seam side
+	int seamBatchCount[2];
+	int2 seamBatch[2][S2_PERSIST_B_ROUNDS]; // {begin, end} ranges of k
+	int pad[8];
 };
 struct PersistView
 {
 	const PersistDesc* descs;
 	const int* remap;
 	const int* exportSrc;
+	const int* importIds;
 	unsigned long long* granules;
 	unsigned int* error; // host-visible: set when a hand-off timed out
+	int parityStride; // granules between the two parities of a buffer
+	int allTwoPoints; // every strip constraint has two manifold points
 	int ldsRecords;
 	int debugSkip; // timing experiments only (results are wrong): 1 = no hand-offs, 2 = no seam rounds, 4 = no interior rounds
 	unsigned long long* debugTimes; // S2AMD_DEBUG_TIMES: wall_clock64() of one workgroup at kernel start, after the loads, after every op, at the end

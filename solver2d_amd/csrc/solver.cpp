@@ -428,6 +428,10 @@ struct s2amdSolver
 	DevBuf dPersist, dGranules;
 	PersistView persist{};
 	bool persistValid = false;
+	int persistRecordsWide = 0; // LDS records when a seam constraint takes 10 records (every kind but TGS_Soft's)
+	DevBuf dPersistOps;
+	int persistOpCount = 0;
+	uint64_t persistOpsGeneration = ~0ull, persistOpsStructure = ~0ull;
 	size_t granuleBytes = 0;
 	int optPersist = 1;
 	int optPersistDebug = 0;
@@ -1283,7 +1287,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 	// one LDS group: local body slots (seeded bodies first: owned, in the given order), colour batches of
 	// its contacts and joints appended to the sweep sets, one row in table `t`
 	auto emitGroup = [&](HostGroupTable& t, const std::vector<int>& cKs, const std::vector<int>& jKs, const std::vector<int>& seedBodies,
-						 const std::vector<int>* replicaOf = nullptr) {
+						 const std::vector<int>* replicaOf = nullptr, const std::vector<int>* replicaOf2 = nullptr) {
 		std::vector<int> ids, a, b, bodies, la, lb, pos, batchOffsets;
 		bool tail = false;
 		slots.begin();
@@ -1291,10 +1295,14 @@ int buildStructure(s2amdSolver* s, int solverType)
 		{
 			slots.seed(body, bodies, true);
 		}
-		if (replicaOf)
+		for (const std::vector<int>* list : {replicaOf, replicaOf2})
 		{
-			// read-only bodies of the seam this strip also sweeps in the persistent kernel (strip_kernel.hip)
-			for (int k : *replicaOf)
+			if (!list)
+			{
+				continue;
+			}
+			// read-only bodies of the seams this strip also sweeps in the persistent kernel (strip_kernel.hip)
+			for (int k : *list)
 			{
 				if (ce.a[k] >= 0 && !conflict[ce.a[k]])
 				{
@@ -1380,7 +1388,8 @@ int buildStructure(s2amdSolver* s, int solverType)
 	const int stripBaseC = (int)cs.order.size(), stripBaseJ = (int)js.order.size();
 	for (size_t i = 0; i < strips.bodies.size(); ++i)
 	{
-		emitGroup(s->hStripA, strips.cA[i], strips.jA[i], strips.bodies[i], i < strips.cB.size() ? &strips.cB[i] : nullptr);
+		emitGroup(s->hStripA, strips.cA[i], strips.jA[i], strips.bodies[i], i < strips.cB.size() ? &strips.cB[i] : nullptr,
+				  i > 0 ? &strips.cB[i - 1] : nullptr);
 	}
 	int stripInterior = (int)cs.order.size(), stripInteriorJ = (int)js.order.size();
 	std::vector<int> seamGroup(strips.cB.size(), -1);
@@ -1456,6 +1465,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 
 	// ---- lean strip tables: per-group descriptors + warm-start slots (strip_kernel.hip) ----
 	s->leanAValid = s->leanBValid = false;
+	s->persistValid = false;
 	s->leanA = StripTableView{};
 	s->leanB = StripTableView{};
 	if (strips.active && s->optStripLean)
@@ -1590,177 +1600,247 @@ int buildStructure(s2amdSolver* s, int solverType)
 				s->leanBValid = true;
 			}
 		}
-	}
 
-	// ---- persistent strip step: seam remaps, export lists, granule buffers (strip_kernel.hip) ----
-	s->persistValid = false;
-	if (getenv("S2AMD_DEBUG") && strips.active)
-	{
-		fprintf(stderr, "[s2amd] strips: %d strips, %d seams, leanA %d leanB %d, strip joints %d, CUs %d\n", s->hStripA.count(), s->hStripB.count(),
-				(int)s->leanAValid, (int)s->leanBValid, js.stripCount, s->cuCount);
-	}
-	if (s->leanAValid && s->leanBValid && js.stripCount == 0 && s->optPersist && s->hostError != nullptr && s->hStripA.count() <= s->cuCount)
-	{
-		const HostGroupTable& A = s->hStripA;
-		const HostGroupTable& B = s->hStripB;
-		const int K = A.count();
-		std::vector<int> ownerGroup((size_t)nb, -1), ownerSlot((size_t)nb, -1), replicaStamp((size_t)nb, -1), replicaSlot((size_t)nb, -1);
-		bool ok = true;
-		for (int gi = 0; gi < K; ++gi)
+		// ---- persistent strip step (strip_kernel.hip: stripStepKernel): per workgroup both seams' remaps, the
+		// import / export lists of the symmetric exchange, warm-start term slots, granule buffers ----
+		s->persistValid = false;
+		if (s->leanAValid && s->leanBValid && js.stripCount == 0 && s->optPersist && s->hostError != nullptr && s->hStripA.count() <= s->cuCount)
 		{
-			for (int e = A.bodyOffsets[(size_t)gi]; e < A.bodyOffsets[(size_t)gi + 1]; ++e)
+			const HostGroupTable& A = s->hStripA;
+			const HostGroupTable& B = s->hStripB;
+			const int K = A.count();
+			bool ok = true;
+			std::vector<int> ownerGroup((size_t)nb, -1), ownerSlot((size_t)nb, -1);
+			for (int gi = 0; gi < K; ++gi)
 			{
-				uint32_t id = (uint32_t)A.bodyIds[(size_t)e];
-				if (id & S2G_OWNED)
-				{
-					ownerGroup[id & ~S2G_OWNED] = gi;
-					ownerSlot[id & ~S2G_OWNED] = e - A.bodyOffsets[(size_t)gi];
-				}
-			}
-			for (int b = A.cBatchOffsets[(size_t)gi]; b < A.cBatchOffsets[(size_t)gi + 1]; ++b)
-			{
-				ok = ok && A.cBatches[(size_t)b].y - A.cBatches[(size_t)b].x <= 256; // one constraint per thread and round
-			}
-		}
-		std::vector<PersistDesc> descs((size_t)K);
-		std::vector<int> remap, exportSrc;
-		std::vector<std::vector<int>> exports((size_t)K); // per strip: own LDS slots it exports to its left neighbour
-		int granules = 0, ldsRecords = 0;
-		const int kMaxQ = 12; // float4 records of one seam constraint in LDS (largest PersistRegs)
-		for (int i = 0; i < K && ok; ++i)
-		{
-			PersistDesc& d = descs[(size_t)i];
-			memset(&d, 0, sizeof(d));
-			d.seamGroup = i < (int)seamGroup.size() ? seamGroup[(size_t)i] : -1;
-			const int nbA = A.bodyOffsets[(size_t)i + 1] - A.bodyOffsets[(size_t)i];
-			int seamSlots = 0;
-			if (d.seamGroup >= 0)
-			{
-				const int g = d.seamGroup;
-				for (int e = A.bodyOffsets[(size_t)i]; e < A.bodyOffsets[(size_t)i + 1]; ++e)
+				for (int e = A.bodyOffsets[(size_t)gi]; e < A.bodyOffsets[(size_t)gi + 1]; ++e)
 				{
 					uint32_t id = (uint32_t)A.bodyIds[(size_t)e];
-					if ((id & S2G_OWNED) == 0)
+					if (id & S2G_OWNED)
 					{
-						replicaStamp[id] = i;
-						replicaSlot[id] = e - A.bodyOffsets[(size_t)i];
+						ownerGroup[id & ~S2G_OWNED] = gi;
+						ownerSlot[id & ~S2G_OWNED] = e - A.bodyOffsets[(size_t)gi];
 					}
 				}
-				d.remapBase = (int)remap.size();
-				for (int e = B.bodyOffsets[(size_t)g]; e < B.bodyOffsets[(size_t)g + 1] && ok; ++e)
+				for (int bb = A.cBatchOffsets[(size_t)gi]; bb < A.cBatchOffsets[(size_t)gi + 1]; ++bb)
+				{
+					ok = ok && A.cBatches[(size_t)bb].y - A.cBatches[(size_t)bb].x <= 256; // one constraint per thread and round
+				}
+			}
+			// seams: bodies on either side, in the order of the seam group's body list
+			const int S = K - 1;
+			std::vector<std::vector<int>> leftBodies((size_t)std::max(S, 0)), rightBodies((size_t)std::max(S, 0));
+			std::vector<int> posInSeam((size_t)nb, -1);
+			for (int sm = 0; sm < S && ok; ++sm)
+			{
+				int g = seamGroup[(size_t)sm];
+				if (g < 0)
+				{
+					continue;
+				}
+				for (int e = B.bodyOffsets[(size_t)g]; e < B.bodyOffsets[(size_t)g + 1]; ++e)
 				{
 					int body = (int)((uint32_t)B.bodyIds[(size_t)e] & ~S2G_OWNED);
-					if (ownerGroup[body] == i)
+					if (!conflict[body])
 					{
-						remap.push_back(ownerSlot[body]);
+						continue;
 					}
-					else if (ownerGroup[body] == i + 1 && conflict[body])
+					if (ownerGroup[body] == sm)
 					{
-						remap.push_back(nbA + d.importCount);
-						exports[(size_t)i + 1].push_back(ownerSlot[body]);
-						d.importCount += 1;
+						posInSeam[body] = (int)leftBodies[(size_t)sm].size();
+						leftBodies[(size_t)sm].push_back(body);
 					}
-					else if (!conflict[body] && replicaStamp[body] == i)
+					else if (ownerGroup[body] == sm + 1)
 					{
-						remap.push_back(replicaSlot[body]);
+						posInSeam[body] = (int)rightBodies[(size_t)sm].size();
+						rightBodies[(size_t)sm].push_back(body);
 					}
 					else
 					{
 						ok = false;
 					}
 				}
-				int b0 = B.cBatchOffsets[(size_t)g], b1 = B.cBatchOffsets[(size_t)g + 1];
-				d.batchCountB = b1 - b0;
-				ok = ok && d.batchCountB <= S2_PERSIST_B_ROUNDS && d.importCount <= S2_PERSIST_IO_CHUNKS * 256;
-				for (int b = b0; b < b1 && ok; ++b)
+				ok = ok && leftBodies[(size_t)sm].size() <= 256 && rightBodies[(size_t)sm].size() <= 256;
+			}
+			// granule buffers: per seam {toLeft: 4 per right body, toRight: 4 per left body}, two parities
+			std::vector<int> seamBase((size_t)std::max(S, 0), 0);
+			int granules = 0;
+			for (int sm = 0; sm < S; ++sm)
+			{
+				seamBase[(size_t)sm] = granules;
+				granules += 4 * (int)(leftBodies[(size_t)sm].size() + rightBodies[(size_t)sm].size());
+			}
+			const int parityStride = granules;
+			std::vector<PersistDesc> descs((size_t)K);
+			std::vector<int> remap, exportSrc, importIds;
+			std::vector<int> replicaStamp((size_t)nb, -1), replicaSlot((size_t)nb, -1);
+			int ldsRecords = 0, ldsRecordsWide = 0;
+			for (int i = 0; i < K && ok; ++i)
+			{
+				PersistDesc& d = descs[(size_t)i];
+				memset(&d, 0, sizeof(d));
+				const int bodyBase = A.bodyOffsets[(size_t)i];
+				const int nbA = A.bodyOffsets[(size_t)i + 1] - bodyBase;
+				for (int e = bodyBase; e < bodyBase + nbA; ++e)
 				{
-					int4 bt = B.cBatches[(size_t)b];
-					ok = bt.z == 0 && bt.y - bt.x <= 256;
-					d.batchB[b - b0] = make_int4(bt.x, bt.y, 0, 0);
-					seamSlots += bt.y - bt.x;
-				}
-				d.importBase = granules;
-				granules += 12 * d.importCount;
-			}
-			int records = 2 * (nbA + d.importCount) + kMaxQ * seamSlots + 2 * 128; // + the plan (up to 128 ops)
-			ok = ok && records <= (160 * 1024) / 16;
-			ldsRecords = std::max(ldsRecords, records - 2 * 128);
-		}
-		for (int i = 0; i < K && ok; ++i)
-		{
-			PersistDesc& d = descs[(size_t)i];
-			d.exportCount = (int)exports[(size_t)i].size();
-			d.exportSrcBase = (int)exportSrc.size();
-			exportSrc.insert(exportSrc.end(), exports[(size_t)i].begin(), exports[(size_t)i].end());
-			d.exportBase = i > 0 ? descs[(size_t)i - 1].importBase : 0;
-			ok = d.exportCount == (i > 0 ? descs[(size_t)i - 1].importCount : 0);
-		}
-		if (getenv("S2AMD_DEBUG"))
-		{
-			int maxB = 0, maxImport = 0;
-			for (const PersistDesc& d : descs)
-			{
-				maxB = std::max(maxB, d.batchCountB), maxImport = std::max(maxImport, d.importCount);
-			}
-			fprintf(stderr, "[s2amd] persistent step: %s (K=%d, max seam colours %d, max imports %d, lds records %d)\n", ok ? "eligible" : "NOT eligible", K,
-					maxB, maxImport, ldsRecords);
-		}
-		if (ok)
-		{
-			auto pad = [](size_t n) { return (n + 63) & ~size_t(63); };
-			size_t bD = pad(descs.size() * sizeof(PersistDesc)), bR = pad(std::max<size_t>(remap.size(), 1) * sizeof(int));
-			size_t bE = pad(std::max<size_t>(exportSrc.size(), 1) * sizeof(int));
-			std::vector<unsigned char> blob(bD + bR + bE, 0);
-			memcpy(blob.data(), descs.data(), descs.size() * sizeof(PersistDesc));
-			if (!remap.empty())
-			{
-				memcpy(blob.data() + bD, remap.data(), remap.size() * sizeof(int));
-			}
-			if (!exportSrc.empty())
-			{
-				memcpy(blob.data() + bD + bR, exportSrc.data(), exportSrc.size() * sizeof(int));
-			}
-			bool grewP = false;
-			s->granuleBytes = std::max<size_t>((size_t)granules, 1) * sizeof(unsigned long long);
-			if ((rc = s->dPersist.ensure(blob.size(), &grewP)) != 0 || (rc = s->dGranules.ensure(s->granuleBytes, &grewP)) != 0)
-			{
-				return rc;
-			}
-			if (grewP)
-			{
-				s->layoutGeneration += 1;
-			}
-			HIP_TRY(hipMemcpyAsync(s->dPersist.p, blob.data(), blob.size(), hipMemcpyHostToDevice, s->stream));
-			HIP_TRY(hipStreamSynchronize(s->stream));
-			const unsigned char* base = (const unsigned char*)s->dPersist.p;
-			s->persist.descs = (const PersistDesc*)base;
-			s->persist.remap = (const int*)(base + bD);
-			s->persist.exportSrc = (const int*)(base + bD + bR);
-			s->persist.granules = (unsigned long long*)s->dGranules.p;
-			unsigned int* devError = nullptr;
-			HIP_TRY(hipHostGetDevicePointer((void**)&devError, s->hostError, 0));
-			s->persist.error = devError;
-			s->persist.ldsRecords = ldsRecords;
-			s->persist.debugSkip = s->optPersistDebug;
-			s->persist.debugTimes = nullptr;
-			if (getenv("S2AMD_DEBUG_TIMES"))
-			{
-				if (!s->hostTimes && hipHostMalloc((void**)&s->hostTimes, 256 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess)
-				{
-					s->hostTimes = nullptr;
-					(void)hipGetLastError();
-				}
-				if (s->hostTimes)
-				{
-					memset(s->hostTimes, 0, 256 * sizeof(unsigned long long));
-					unsigned long long* dev = nullptr;
-					if (hipHostGetDevicePointer((void**)&dev, s->hostTimes, 0) == hipSuccess)
+					uint32_t id = (uint32_t)A.bodyIds[(size_t)e];
+					if ((id & S2G_OWNED) == 0)
 					{
-						s->persist.debugTimes = dev;
+						replicaStamp[id] = i;
+						replicaSlot[id] = e - bodyBase;
 					}
 				}
+				const int seamOf[2] = {i - 1, i};
+				int importOffset = nbA, seamSlots = 0;
+				for (int side = 0; side < 2; ++side)
+				{
+					const int sm = seamOf[side];
+					const int g = (sm >= 0 && sm < S) ? seamGroup[(size_t)sm] : -1;
+					d.importIdBase[side] = (int)importIds.size();
+					d.exportSrcBase[side] = (int)exportSrc.size();
+					d.remapBase[side] = (int)remap.size();
+					if (g < 0)
+					{
+						continue;
+					}
+					// side 0: I am the RIGHT strip of seam i-1 (import its left bodies, export its right bodies);
+					// side 1: I am the LEFT strip of seam i
+					const std::vector<int>& imports = side == 0 ? leftBodies[(size_t)sm] : rightBodies[(size_t)sm];
+					const std::vector<int>& exports = side == 0 ? rightBodies[(size_t)sm] : leftBodies[(size_t)sm];
+					d.importCount[side] = (int)imports.size();
+					d.exportCount[side] = (int)exports.size();
+					importIds.insert(importIds.end(), imports.begin(), imports.end());
+					for (int body : exports)
+					{
+						exportSrc.push_back(ownerSlot[body]);
+					}
+					const int nR = (int)rightBodies[(size_t)sm].size();
+					const int toLeft = seamBase[(size_t)sm], toRight = seamBase[(size_t)sm] + 4 * nR;
+					d.inBase[side] = side == 0 ? toRight : toLeft;
+					d.outBase[side] = side == 0 ? toLeft : toRight;
+					for (int e = B.bodyOffsets[(size_t)g]; e < B.bodyOffsets[(size_t)g + 1] && ok; ++e)
+					{
+						int body = (int)((uint32_t)B.bodyIds[(size_t)e] & ~S2G_OWNED);
+						if (ownerGroup[body] == i)
+						{
+							remap.push_back(ownerSlot[body]);
+						}
+						else if (conflict[body])
+						{
+							remap.push_back(importOffset + posInSeam[body]);
+						}
+						else if (replicaStamp[body] == i)
+						{
+							remap.push_back(replicaSlot[body]);
+						}
+						else
+						{
+							ok = false;
+						}
+					}
+					int b0 = B.cBatchOffsets[(size_t)g], b1 = B.cBatchOffsets[(size_t)g + 1];
+					d.seamBatchCount[side] = b1 - b0;
+					ok = ok && b1 - b0 <= S2_PERSIST_B_ROUNDS;
+					for (int bb = b0; bb < b1 && ok; ++bb)
+					{
+						int4 bt = B.cBatches[(size_t)bb];
+						ok = bt.z == 0;
+						d.seamBatch[side][bb - b0] = make_int2(bt.x, bt.y);
+						seamSlots += bt.y - bt.x;
+					}
+					importOffset += d.importCount[side];
+				}
+				for (int r = 0; r < S2_PERSIST_B_ROUNDS && ok; ++r)
+				{
+					int n0 = r < d.seamBatchCount[0] ? d.seamBatch[0][r].y - d.seamBatch[0][r].x : 0;
+					int n1 = r < d.seamBatchCount[1] ? d.seamBatch[1][r].y - d.seamBatch[1][r].x : 0;
+					ok = n0 + n1 <= 512; // both seams share a round: at most two constraints per thread
+				}
+				const int nt = importOffset;
+				// bodies, seam constraints (8 records each for TGS_Soft, 10 for the other kinds)
+				int fixedRecords = 3 * nt + (nt + 3) / 4; // velocity, pose, integrator constants, angular damping
+				ok = ok && fixedRecords + 8 * seamSlots + 2 * 128 <= (160 * 1024) / 16 && nt < 16384;
+				ldsRecords = std::max(ldsRecords, fixedRecords + 8 * seamSlots);
+				ldsRecordsWide = std::max(ldsRecordsWide, fixedRecords + 10 * seamSlots);
 			}
-			s->persistValid = true;
+			if (getenv("S2AMD_DEBUG"))
+			{
+				fprintf(stderr, "[s2amd] persistent step: %s (K=%d, lds records %d, granules/parity %d)\n", ok ? "eligible" : "NOT eligible", K, ldsRecords,
+						parityStride);
+			}
+			if (ok)
+			{
+				auto pad = [](size_t n) { return (n + 63) & ~size_t(63); };
+				auto bytesOf = [&](size_t n, size_t elem) { return pad(std::max<size_t>(n, 1) * elem); };
+				size_t o0 = 0, o1 = o0 + bytesOf(descs.size(), sizeof(PersistDesc)), o2 = o1 + bytesOf(remap.size(), sizeof(int));
+				size_t o3 = o2 + bytesOf(exportSrc.size(), sizeof(int)), o4 = o3 + bytesOf(importIds.size(), sizeof(int));
+				std::vector<unsigned char> blob(o4, 0);
+				auto put = [&](size_t at, const void* src, size_t bytes) {
+					if (bytes)
+					{
+						memcpy(blob.data() + at, src, bytes);
+					}
+				};
+				put(o0, descs.data(), descs.size() * sizeof(PersistDesc));
+				put(o1, remap.data(), remap.size() * sizeof(int));
+				put(o2, exportSrc.data(), exportSrc.size() * sizeof(int));
+				put(o3, importIds.data(), importIds.size() * sizeof(int));
+				bool grewP = false;
+				s->granuleBytes = std::max<size_t>((size_t)2 * parityStride, 1) * sizeof(unsigned long long);
+				if ((rc = s->dPersist.ensure(blob.size(), &grewP)) != 0 || (rc = s->dGranules.ensure(s->granuleBytes, &grewP)) != 0)
+				{
+					return rc;
+				}
+				if (grewP)
+				{
+					s->layoutGeneration += 1;
+				}
+				HIP_TRY(hipMemcpyAsync(s->dPersist.p, blob.data(), blob.size(), hipMemcpyHostToDevice, s->stream));
+				HIP_TRY(hipStreamSynchronize(s->stream));
+				const unsigned char* base = (const unsigned char*)s->dPersist.p;
+				PersistView& pv = s->persist;
+				pv = PersistView{};
+				pv.descs = (const PersistDesc*)(base + o0);
+				pv.remap = (const int*)(base + o1);
+				pv.exportSrc = (const int*)(base + o2);
+				pv.importIds = (const int*)(base + o3);
+				pv.granules = (unsigned long long*)s->dGranules.p;
+				unsigned int* devError = nullptr;
+				HIP_TRY(hipHostGetDevicePointer((void**)&devError, s->hostError, 0));
+				pv.error = devError;
+				pv.parityStride = parityStride;
+				pv.allTwoPoints = 1;
+				for (int k = k0; k < k1; ++k)
+				{
+					if (s->hContactPoints[(size_t)cs.order[(size_t)k]] != 2)
+					{
+						pv.allTwoPoints = 0;
+						break;
+					}
+				}
+				pv.ldsRecords = ldsRecords;
+				s->persistRecordsWide = ldsRecordsWide;
+				pv.debugSkip = s->optPersistDebug;
+				pv.debugTimes = nullptr;
+				if (getenv("S2AMD_DEBUG_TIMES"))
+				{
+					if (!s->hostTimes && hipHostMalloc((void**)&s->hostTimes, 256 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess)
+					{
+						s->hostTimes = nullptr;
+						(void)hipGetLastError();
+					}
+					if (s->hostTimes)
+					{
+						memset(s->hostTimes, 0, 256 * sizeof(unsigned long long));
+						unsigned long long* dev = nullptr;
+						if (hipHostGetDevicePointer((void**)&dev, s->hostTimes, 0) == hipSuccess)
+						{
+							pv.debugTimes = dev;
+						}
+					}
+				}
+				s->persistValid = true;
+			}
 		}
 	}
 
@@ -2588,7 +2668,45 @@ struct Executor
 		{
 			warm = kind == SOFT_FIXED ? WARM_FIXED : WARM_CURRENT;
 		}
-		return true;
+		const bool narrow = kind == SOFT_TGS && warm == WARM_CURRENT;
+		const int records = (narrow ? s->persist.ldsRecords : s->persistRecordsWide) + 2 * (int)p.ops.size();
+		return records <= (160 * 1024) / 16;
+	}
+
+	// the plan without the sweeps that have nothing to sweep in the strips (joint sweeps of a contact-only island)
+	int uploadPersistOps()
+	{
+		if (s->persistOpsGeneration == s->planGeneration && s->persistOpsStructure == s->structureGeneration)
+		{
+			return 0;
+		}
+		std::vector<Op> kept;
+		for (const Op& o : p.ops)
+		{
+			if (!sweepsNothing(o))
+			{
+				kept.push_back(o);
+			}
+		}
+		bool grew = false;
+		int rc = s->dPersistOps.ensure(std::max<size_t>(kept.size(), 1) * sizeof(Op), &grew);
+		if (rc)
+		{
+			return rc;
+		}
+		if (grew)
+		{
+			s->layoutGeneration += 1;
+		}
+		if (hipMemcpyAsync(s->dPersistOps.p, kept.data(), kept.size() * sizeof(Op), hipMemcpyHostToDevice, st) != hipSuccess ||
+			hipStreamSynchronize(st) != hipSuccess)
+		{
+			return S2AMD_E_DEVICE;
+		}
+		s->persistOpCount = (int)kept.size();
+		s->persistOpsGeneration = s->planGeneration;
+		s->persistOpsStructure = s->structureGeneration;
+		return 0;
 	}
 
 	void runPersistent(int kind, int warm)
@@ -2599,7 +2717,12 @@ struct Executor
 		{
 			recordEvent();
 		}
-		launchStripStep(st, kind, warm, s->cv, s->bv, s->leanA, s->persist, deviceOps(), (int)p.ops.size());
+		PersistView pv = s->persist;
+		if (!(kind == SOFT_TGS && warm == WARM_CURRENT))
+		{
+			pv.ldsRecords = s->persistRecordsWide;
+		}
+		launchStripStep(st, kind, warm, s->cv, s->bv, s->leanA, pv, (const Op*)s->dPersistOps.p, s->persistOpCount);
 		if (profile)
 		{
 			recordEvent();
@@ -3016,6 +3139,13 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	Executor q{s, s->stream, plan, isPositionSolver(params->solverType) ? 1 : 0, s->optProfile != 0};
 	q.msg = messageEligible(s, params->solverType);
 	s->stats.messagePassing = q.msg ? 1 : 0;
+	{
+		int kind, warm;
+		if (s->dStripA.view.groupCount > 0 && q.persistPlan(kind, warm) && q.uploadPersistOps() != 0)
+		{
+			return fail(S2AMD_E_DEVICE, "could not upload the persistent step plan");
+		}
+	}
 	s->launchCounter = 0;
 	s->sweepEventsUsed = 0;
 
@@ -3295,7 +3425,7 @@ void s2amd_destroy(s2amdSolver* s)
 					  &s->soaContacts,	&s->soaJoints,	  &s->dContactIndex, &s->dJointIndex,	 &s->dContactLocal, &s->dJointLocal,
 					  &s->dAdjOffsets,	&s->dAdjList,	  &s->dGatherIndex,	 &s->dOps,			 &s->dGroups.buf,	&s->dContactTail.buf,
 					  &s->dJointTail.buf, &s->dMsg,			  &s->dStripA.buf,	 &s->dStripB.buf,	 &s->dStripLean,	&s->dPersist,
-					  &s->dGranules};
+					  &s->dGranules,	&s->dPersistOps};
 	for (DevBuf* b : bufs)
 	{
 		b->release();

@@ -346,17 +346,28 @@ template <int WARM, int KIND, class BA> S2_DEV void warmSoftRegs(const SoftRegs<
 // A constraint as the persistent kernel keeps it for the whole step: only what the sweeps of this solver
 // read, 29 registers for TGS_Soft.  The soft coefficients are the same for both points (contact_kernels.hip
 // prepareContactsKernel<PREP_SOFT>; solve_common.c:262-271), so one copy is kept.
-template <int KIND, int WARM> struct PersistRegs
+struct ImpulsePart
+{
+	float2 imp[2]; // first: one 16-byte record of the LDS copy (the only part a sweep changes)
+};
+template <int TAG, bool ON> struct ArmsPart
+{
+	float4 v[2];
+};
+template <int TAG> struct ArmsPart<TAG, false>
+{
+};
+template <int KIND, int WARM>
+struct PersistRegs : ImpulsePart,
+					 ArmsPart<0, KIND == SOFT_TGS || KIND == SOFT_FIXED || WARM == WARM_CURRENT>, // local anchors
+					 ArmsPart<1, KIND != SOFT_TGS || WARM == WARM_FIXED>						  // prepare-time arms rA0 / rB0
 {
 	static constexpr bool kAnchors = KIND == SOFT_TGS || KIND == SOFT_FIXED || WARM == WARM_CURRENT;
 	static constexpr bool kArms0 = KIND != SOFT_TGS || WARM == WARM_FIXED;
-	uint32_t idx; // ia | ib << 14 | pointCount << 28 | writeA << 30 | writeB << 31
+	uint32_t idx;	 // ia | ib << 14 | pointCount << 28 | writeA << 30 | writeB << 31
 	float mA, iA, mB, iB, nx, ny, friction;
-	float4 an[kAnchors ? 2 : 1];
-	float4 r0[kArms0 ? 2 : 1];
 	float p0[2], p1[2], p2[2], p3[2];
 	float s0, s1, s2;
-	float2 imp[2];
 };
 
 template <int KIND, int WARM> S2_DEV PersistRegs<KIND, WARM> packPersist(const SoftRegs<KIND>& r, int ia, int ib)
@@ -368,13 +379,13 @@ template <int KIND, int WARM> S2_DEV PersistRegs<KIND, WARM> packPersist(const S
 #pragma unroll
 	for (int j = 0; j < 2; ++j)
 	{
-		if (PersistRegs<KIND, WARM>::kAnchors)
+		if constexpr (PersistRegs<KIND, WARM>::kAnchors)
 		{
-			p.an[j] = r.an[j];
+			static_cast<ArmsPart<0, true>&>(p).v[j] = r.an[j];
 		}
-		if (PersistRegs<KIND, WARM>::kArms0)
+		if constexpr (PersistRegs<KIND, WARM>::kArms0)
 		{
-			p.r0[j] = r.r0[j];
+			static_cast<ArmsPart<1, true>&>(p).v[j] = r.r0[j];
 		}
 		p.p0[j] = r.par[j].x, p.p1[j] = r.par[j].y, p.p2[j] = r.par[j].z, p.p3[j] = r.par[j].w;
 		p.imp[j] = r.imp[j];
@@ -394,13 +405,13 @@ template <int KIND, int WARM> S2_DEV SoftRegs<KIND> unpackPersist(const PersistR
 #pragma unroll
 	for (int j = 0; j < 2; ++j)
 	{
-		if (PersistRegs<KIND, WARM>::kAnchors)
+		if constexpr (PersistRegs<KIND, WARM>::kAnchors)
 		{
-			r.an[j] = p.an[j];
+			r.an[j] = static_cast<const ArmsPart<0, true>&>(p).v[j];
 		}
-		if (PersistRegs<KIND, WARM>::kArms0)
+		if constexpr (PersistRegs<KIND, WARM>::kArms0)
 		{
-			r.r0[j] = p.r0[j];
+			r.r0[j] = static_cast<const ArmsPart<1, true>&>(p).v[j];
 		}
 		r.par[j] = make_float4(p.p0[j], p.p1[j], p.p2[j], p.p3[j]);
 		r.sf[j] = make_float4(p.s0, p.s1, p.s2, 0.0f);
@@ -410,19 +421,12 @@ template <int KIND, int WARM> S2_DEV SoftRegs<KIND> unpackPersist(const PersistR
 }
 
 // one constraint of a sweep, from its resident registers: warm start or soft solve
-template <int KIND, int WARM, class BA>
-S2_DEV void sweepPersist(PersistRegs<KIND, WARM>& p, const ContactView& c, const BA& lb, bool warm, float inv_h, int useBias, int k)
+template <int KIND, int WARM, int POINTS, class BA>
+S2_DEV void sweepPersist(PersistRegs<KIND, WARM>& p, const ContactView& c, const BA& lb, float inv_h, int useBias, int k)
 {
 	SoftRegs<KIND> r = unpackPersist<KIND, WARM>(p);
-	if (warm)
-	{
-		warmSoftRegs<WARM>(r, lb);
-	}
-	else
-	{
-		solveSoftRegs<KIND, BA, false>(r, c, lb, inv_h, useBias, k);
-		p.imp[0] = r.imp[0], p.imp[1] = r.imp[1];
-	}
+	solveSoftRegs<KIND, BA, false, POINTS>(r, c, lb, inv_h, useBias, k);
+	p.imp[0] = r.imp[0], p.imp[1] = r.imp[1];
 }
 
 template <int KIND, int WARM> S2_DEV SoftRegs<KIND> loadPersist(const ContactView& c, int k)
@@ -443,7 +447,9 @@ template <int KIND, int WARM> S2_DEV SoftRegs<KIND> loadPersist(const ContactVie
 	return r;
 }
 
-template <int KIND, int WARM>
+// POINTS == 2: the host has checked that every constraint of the strips has two manifold points (box stacks): the
+// sweeps then run without per-point exec masking; POINTS == 0: general.
+template <int KIND, int WARM, int POINTS>
 __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView c, BodyView g, StripTableView ta, PersistView pv, const Op* ops, int opCount)
 {
 	extern __shared__ __attribute__((aligned(16))) float4 lds[];
@@ -457,29 +463,42 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 	const StripDesc* da = ta.descs + blockIdx.x;
 	const PersistDesc* pd = pv.descs + blockIdx.x;
 	const int bodyBase = da->bodyBase, nb = da->bodyCount, roundsA = da->batchCount;
-	const int seam = pd->seamGroup, importCount = pd->importCount, exportCount = pd->exportCount;
-	const int roundsB = seam >= 0 ? pd->batchCountB : 0;
-	const int nt = nb + importCount;
-	int4 batchA[S2_STRIP_ROUNDS], batchB[S2_PERSIST_B_ROUNDS];
+	int4 batchA[S2_STRIP_ROUNDS];
 #pragma unroll
 	for (int i = 0; i < S2_STRIP_ROUNDS; ++i)
 	{
 		batchA[i] = da->batch[i];
 	}
+	const int nImp0 = pd->importCount[0], nImp1 = pd->importCount[1];
+	const int nExp0 = pd->exportCount[0], nExp1 = pd->exportCount[1];
+	const int roundsB0 = pd->seamBatchCount[0], roundsB1 = pd->seamBatchCount[1];
+	int2 batchB0[S2_PERSIST_B_ROUNDS], batchB1[S2_PERSIST_B_ROUNDS];
+	int seamSlots0 = 0, seamSlots1 = 0;
 #pragma unroll
 	for (int i = 0; i < S2_PERSIST_B_ROUNDS; ++i)
 	{
-		batchB[i] = pd->batchB[i];
+		batchB0[i] = pd->seamBatch[0][i];
+		batchB1[i] = pd->seamBatch[1][i];
+		seamSlots0 += i < roundsB0 ? batchB0[i].y - batchB0[i].x : 0;
+		seamSlots1 += i < roundsB1 ? batchB1[i].y - batchB1[i].x : 0;
 	}
-	gu64* inLeft = (gu64*)pv.granules + pd->importBase;	   // seam i: written by workgroup i+1, read here
-	gu64* outRight = inLeft + 8 * importCount;			   // seam i: written here, read by workgroup i+1
-	gu64* outLeft = (gu64*)pv.granules + pd->exportBase;   // seam i-1: written here, read by workgroup i-1
-	gu64* inRight = outLeft + 8 * exportCount;			   // seam i-1: written by workgroup i-1, read here
+	const int roundsB = roundsB0 > roundsB1 ? roundsB0 : roundsB1;
+	const int seamSlots = seamSlots0 + seamSlots1;
+	const int firstK0 = batchB0[0].x, firstK1 = batchB1[0].x;
+	const int nt = nb + nImp0 + nImp1;
+	gu64* gran = (gu64*)pv.granules;
+	const int in0 = pd->inBase[0], in1 = pd->inBase[1], out0 = pd->outBase[0], out1 = pd->outBase[1];
+
+	constexpr int Q = (int)((sizeof(PersistRegs<KIND, WARM>) + 15) / 16);
 	float4* lvel = lds;
 	float4* ldq = lds + nt;
-	Op* lops = (Op*)(lds + 2 * nt);
+	float4* linteg = lds + 2 * nt;				  // velocity-integrator constants of every staged body (body_ops.h)
+	float* langDamp = (float*)(lds + 3 * nt);	  // nt floats, padded to records
+	const int bodyRecords = 3 * nt + (nt + 3) / 4;
+	Op* lops = (Op*)(lds + bodyRecords);		  // 2 records per op
+	float4* lseam = lds + bodyRecords + 2 * opCount; // field-major: Q records per seam constraint
 
-	// ---- loads: ids, export list, plan, every constraint of both phases ----
+	// ---- loads ----
 	uint32_t id[S2_STRIP_BODY_CHUNKS];
 #pragma unroll
 	for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS; ++ch)
@@ -487,29 +506,18 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 		int i = tid + ch * S2_STRIP_THREADS;
 		id[ch] = i < nb ? (uint32_t)ta.bodyIds[bodyBase + i] : 0u;
 	}
-	int exportIdx[S2_PERSIST_IO_CHUNKS];
-#pragma unroll
-	for (int ch = 0; ch < S2_PERSIST_IO_CHUNKS; ++ch)
-	{
-		int j = tid + ch * S2_STRIP_THREADS;
-		exportIdx[ch] = j < exportCount ? pv.exportSrc[pd->exportSrcBase + j] : 0;
-	}
+	// imported bodies: thread t keeps left import t and right import t (at most 256 per side)
+	int impId[2], expIdx[2];
+	impId[0] = tid < nImp0 ? pv.importIds[pd->importIdBase[0] + tid] : -1;
+	impId[1] = tid < nImp1 ? pv.importIds[pd->importIdBase[1] + tid] : -1;
+	expIdx[0] = tid < nExp0 ? pv.exportSrc[pd->exportSrcBase[0] + tid] : 0;
+	expIdx[1] = tid < nExp1 ? pv.exportSrc[pd->exportSrcBase[1] + tid] : 0;
 	for (int i = tid; i < opCount * 8; i += S2_STRIP_THREADS)
 	{
 		((int*)lops)[i] = ((const int*)ops)[i];
 	}
-	// interiors live in registers; the seam's constraints live in LDS (field-major float4 records), which keeps
-	// the kernel inside the register file
-	constexpr int Q = (int)((sizeof(PersistRegs<KIND, WARM>) + 15) / 16);
-	float4* lseam = lds + 2 * nt + 2 * opCount;
-	int seamSlots = 0;
-#pragma unroll
-	for (int i = 0; i < S2_PERSIST_B_ROUNDS; ++i)
-	{
-		seamSlots += i < roundsB ? batchB[i].y - batchB[i].x : 0;
-	}
 	PersistRegs<KIND, WARM> rA[S2_STRIP_ROUNDS];
-	int kA[S2_STRIP_ROUNDS], kB[S2_PERSIST_B_ROUNDS];
+	int kA[S2_STRIP_ROUNDS];
 #pragma unroll
 	for (int i = 0; i < S2_STRIP_ROUNDS; ++i)
 	{
@@ -525,22 +533,37 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 			}
 		}
 	}
+	// seam constraints: round r = left seam's batch r followed by right seam's batch r, dealt to the threads in
+	// two passes (a round holds at most 512 constraints); where an item lives is recomputed, not stored
+	auto seamItem = [&](int r, int pass, int& side, int& k, int& slot) {
+		const int n0 = r < roundsB0 ? batchB0[r].y - batchB0[r].x : 0;
+		const int n1 = r < roundsB1 ? batchB1[r].y - batchB1[r].x : 0;
+		const int idx = tid + pass * S2_STRIP_THREADS;
+		if (idx < n0)
+		{
+			side = 0, k = batchB0[r].x + idx, slot = k - firstK0;
+			return true;
+		}
+		if (idx - n0 < n1)
+		{
+			side = 1, k = batchB1[r].x + idx - n0, slot = seamSlots0 + k - firstK1;
+			return true;
+		}
+		return false;
+	};
 #pragma unroll
 	for (int i = 0; i < S2_PERSIST_B_ROUNDS; ++i)
 	{
-		kB[i] = -1;
-		if (i < roundsB)
+#pragma unroll
+		for (int pass = 0; pass < 2; ++pass)
 		{
-			int k = batchB[i].x + tid;
-			if (k < batchB[i].y)
+			int side, k, slot;
+			if (i < roundsB && seamItem(i, pass, side, k, slot))
 			{
-				kB[i] = k;
-				// seam constraints address this workgroup's LDS through the seam's remap table
 				SoftRegs<KIND> t = loadPersist<KIND, WARM>(c, k);
-				PersistRegs<KIND, WARM> pb = packPersist<KIND, WARM>(t, pv.remap[pd->remapBase + t.h.ia], pv.remap[pd->remapBase + t.h.ib]);
+				PersistRegs<KIND, WARM> pb = packPersist<KIND, WARM>(t, pv.remap[pd->remapBase[side] + t.h.ia], pv.remap[pd->remapBase[side] + t.h.ib]);
 				float4 q[Q];
 				__builtin_memcpy(q, &pb, sizeof(pb));
-				const int slot = k - batchB[0].x;
 #pragma unroll
 				for (int f = 0; f < Q; ++f)
 				{
@@ -549,34 +572,43 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 			}
 		}
 	}
-	// bodies (+ the integrator constants, kept in registers for the whole step)
-	float4 integ[S2_STRIP_BODY_CHUNKS];
-	float angDamp[S2_STRIP_BODY_CHUNKS];
-	uint32_t flags[S2_STRIP_BODY_CHUNKS];
+	// bodies (+ their integrator constants) into LDS: own list, then both imports
+	uint32_t flags[S2_STRIP_BODY_CHUNKS + 2];
+	int ldsIdx[S2_STRIP_BODY_CHUNKS + 2];
 #pragma unroll
-	for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS; ++ch)
+	for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS + 2; ++ch)
 	{
-		int i = tid + ch * S2_STRIP_THREADS;
-		flags[ch] = 0u;
-		if (i < nb)
+		int gi = -1;
+		if (ch < S2_STRIP_BODY_CHUNKS)
 		{
-			int gi = (int)(id[ch] & ~S2G_OWNED);
-			lvel[i] = g.vel[gi];
-			ldq[i] = g.dq[gi];
-			flags[ch] = g.flags[gi];
-			integ[ch] = g.integ[gi];
-			angDamp[ch] = g.angDamp[gi];
+			int i = tid + ch * S2_STRIP_THREADS;
+			ldsIdx[ch] = i;
+			gi = i < nb ? (int)(id[ch] & ~S2G_OWNED) : -1;
+		}
+		else
+		{
+			const int side = ch - S2_STRIP_BODY_CHUNKS;
+			ldsIdx[ch] = nb + (side ? nImp0 : 0) + tid;
+			gi = impId[side];
+		}
+		flags[ch] = 0u;
+		if (gi >= 0)
+		{
+			lvel[ldsIdx[ch]] = g.vel[gi];
+			ldq[ldsIdx[ch]] = g.dq[gi];
+			flags[ch] = g.flags[gi] | 0x80000000u; // bit 31: slot in use
+			linteg[ldsIdx[ch]] = g.integ[gi];
+			langDamp[ldsIdx[ch]] = g.angDamp[gi];
 		}
 	}
 	__syncthreads();
-
 	if (stamp)
 	{
 		pv.debugTimes[stamps++] = wall_clock64();
 	}
+
 	LdsBodies lb{lvel, ldq};
 	unsigned epoch = 0;
-	bool dqDirty = true; // the imported poses have never been sent
 	int bad = 0;
 	for (int oi = 0; oi < opCount && !bad; ++oi)
 	{
@@ -584,16 +616,16 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 		if (op.code == OP_INTEGRATE_VEL)
 		{
 #pragma unroll
-			for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS; ++ch)
+			for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS + 2; ++ch)
 			{
-				int i = tid + ch * S2_STRIP_THREADS;
-				if (i < nb && (flags[ch] & S2F_DYNAMIC) != 0)
+				if ((flags[ch] & S2F_DYNAMIC) != 0)
 				{
-					float4 v = lvel[i], k = integ[ch];
+					const int i = ldsIdx[ch];
+					float4 v = lvel[i], k = linteg[i];
 					V2 lv = add(v2(v.x, v.y), v2(k.x, k.y));
 					float w = v.z + k.z;
 					lv = mulSV(k.w, lv);
-					w *= angDamp[ch];
+					w *= langDamp[i];
 					lvel[i] = make_float4(lv.x, lv.y, w, 0.0f);
 				}
 			}
@@ -602,11 +634,11 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 		else if (op.code == OP_INTEGRATE_POS)
 		{
 #pragma unroll
-			for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS; ++ch)
+			for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS + 2; ++ch)
 			{
-				int i = tid + ch * S2_STRIP_THREADS;
-				if (i < nb && (flags[ch] & S2F_MOVES) != 0)
+				if ((flags[ch] & S2F_MOVES) != 0)
 				{
+					const int i = ldsIdx[ch];
 					float4 v = lvel[i], d = ldq[i];
 					V2 dpos = mulAdd(v2(d.x, d.y), op.h, v2(v.x, v.y));
 					Rot q;
@@ -615,111 +647,56 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 					ldq[i] = make_float4(dpos.x, dpos.y, q.s, q.c);
 				}
 			}
-			dqDirty = true;
 			__syncthreads();
 		}
 		else if (op.code == OP_FINALIZE)
 		{
 #pragma unroll
-			for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS; ++ch)
+			for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS + 2; ++ch)
 			{
-				int i = tid + ch * S2_STRIP_THREADS;
-				if (i < nb)
+				if (flags[ch] != 0u)
 				{
-					finalizePositionsOne(lb, i, g, (int)(id[ch] & ~S2G_OWNED), op.flag, (id[ch] & S2G_OWNED) != 0);
+					const int i = ldsIdx[ch];
+					if (ch < S2_STRIP_BODY_CHUNKS)
+					{
+						finalizePositionsOne(lb, i, g, (int)(id[ch] & ~S2G_OWNED), op.flag, (id[ch] & S2G_OWNED) != 0);
+					}
+					else if ((flags[ch] & (op.flag ? S2F_DYNAMIC : S2F_MOVES)) != 0)
+					{
+						float4 d = ldq[i]; // the copy of a neighbour's body: same reset, its owner writes the position
+						ldq[i] = make_float4(0.0f, 0.0f, d.z, d.w);
+					}
 				}
 			}
-			dqDirty = true;
 			__syncthreads();
 		}
-		else if (op.code == OP_WARM || op.code == OP_SOLVE_SOFT)
+		else if (op.code == OP_WARM)
 		{
-			const bool warm = op.code == OP_WARM;
-			// ---- phase A: interiors ----
+			// s2WarmStartContacts as a coloured sweep WITHOUT an exchange: a side's warm-start term depends on the
+			// impulses, the anchors and that body's own pose only, so every body this workgroup owns ends up with
+			// the right bits; the copies of the neighbours' bodies are refreshed by the next sweep's exchange
+			// before anything reads them
 #pragma unroll
 			for (int i = 0; i < S2_STRIP_ROUNDS; ++i)
 			{
-				if (i < roundsA && (pv.debugSkip & 4) == 0)
+				if (i < roundsA)
 				{
 					if (kA[i] >= 0)
 					{
-						sweepPersist<KIND, WARM>(rA[i], c, lb, warm, op.inv_h, op.useBias, kA[i]);
+						warmSoftRegs<WARM>(unpackPersist<KIND, WARM>(rA[i]), lb);
 					}
 					__syncthreads();
 				}
 			}
-			epoch += 1;
-			// ---- seam bodies travel left: i+1 -> i ----
-			int fail = 0;
+#pragma unroll 1
+			for (int i = 0; i < roundsB; ++i)
+			{
 #pragma unroll
-			for (int ch = 0; ch < S2_PERSIST_IO_CHUNKS; ++ch)
-			{
-				int j = tid + ch * S2_STRIP_THREADS;
-				if (j < exportCount)
+				for (int pass = 0; pass < 2; ++pass)
 				{
-					float4 v = lvel[exportIdx[ch]];
-					gu64* p = outLeft + 8 * j;
-					putGranule(p + 0, epoch, v.x);
-					putGranule(p + 1, epoch, v.y);
-					putGranule(p + 2, epoch, v.z);
-					if (dqDirty)
+					int side, k, slot;
+					if (seamItem(i, pass, side, k, slot))
 					{
-						float4 d = ldq[exportIdx[ch]];
-						putGranule(p + 3, epoch, d.x);
-						putGranule(p + 4, epoch, d.y);
-						putGranule(p + 5, epoch, d.z);
-						putGranule(p + 6, epoch, d.w);
-					}
-				}
-			}
-#pragma unroll
-			for (int ch = 0; ch < S2_PERSIST_IO_CHUNKS; ++ch)
-			{
-				int j = tid + ch * S2_STRIP_THREADS;
-				if (j < importCount && (pv.debugSkip & 1) == 0)
-				{
-					gu64* p = inLeft + 8 * j;
-					if (dqDirty)
-					{
-						float v[7];
-						if (getGranules<7>(p, epoch, v, pv.error))
-						{
-							lvel[nb + j] = make_float4(v[0], v[1], v[2], 0.0f);
-							ldq[nb + j] = make_float4(v[3], v[4], v[5], v[6]);
-						}
-						else
-						{
-							fail = 1;
-						}
-					}
-					else
-					{
-						float v[3];
-						if (getGranules<3>(p, epoch, v, pv.error))
-						{
-							lvel[nb + j] = make_float4(v[0], v[1], v[2], 0.0f);
-						}
-						else
-						{
-							fail = 1;
-						}
-					}
-				}
-			}
-			bad = __syncthreads_or(fail);
-			if (bad)
-			{
-				break;
-			}
-			// ---- phase B: seam i | i+1 ----
-#pragma unroll
-			for (int i = 0; i < S2_PERSIST_B_ROUNDS; ++i)
-			{
-				if (i < roundsB && (pv.debugSkip & 2) == 0)
-				{
-					if (kB[i] >= 0)
-					{
-						const int slot = kB[i] - batchB[0].x;
 						float4 q[Q];
 #pragma unroll
 						for (int f = 0; f < Q; ++f)
@@ -728,44 +705,62 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 						}
 						PersistRegs<KIND, WARM> pb;
 						__builtin_memcpy(&pb, q, sizeof(pb));
-						sweepPersist<KIND, WARM>(pb, c, lb, warm, op.inv_h, op.useBias, kB[i]);
-						if (!warm)
-						{
-							__builtin_memcpy(q, &pb, sizeof(pb));
+						warmSoftRegs<WARM>(unpackPersist<KIND, WARM>(pb), lb);
+					}
+				}
+				__syncthreads();
+			}
+		}
+		else if (op.code == OP_SOLVE_SOFT)
+		{
+			// ---- interiors ----
 #pragma unroll
-							for (int f = 0; f < Q; ++f)
-							{
-								lseam[f * seamSlots + slot] = q[f];
-							}
-						}
+			for (int i = 0; i < S2_STRIP_ROUNDS; ++i)
+			{
+				if (i < roundsA && (pv.debugSkip & 4) == 0)
+				{
+					if (kA[i] >= 0)
+					{
+						sweepPersist<KIND, WARM, POINTS>(rA[i], c, lb, op.inv_h, op.useBias, kA[i]);
 					}
 					__syncthreads();
 				}
 			}
-			// ---- and back: i -> i+1 (velocities only: a sweep never moves a pose) ----
-#pragma unroll
-			for (int ch = 0; ch < S2_PERSIST_IO_CHUNKS; ++ch)
+			// ---- symmetric exchange of the seam bodies' velocities (poses are replicated by the body stages) ----
+			epoch += 1;
+			const int par = (int)(epoch & 1u) * pv.parityStride;
+			if (tid < nExp0)
 			{
-				int j = tid + ch * S2_STRIP_THREADS;
-				if (j < importCount)
-				{
-					float4 v = lvel[nb + j];
-					gu64* p = outRight + 4 * j;
-					putGranule(p + 0, epoch, v.x);
-					putGranule(p + 1, epoch, v.y);
-					putGranule(p + 2, epoch, v.z);
-				}
+				float4 v = lvel[expIdx[0]];
+				gu64* p = gran + par + out0 + 4 * tid;
+				putGranule(p + 0, epoch, v.x), putGranule(p + 1, epoch, v.y), putGranule(p + 2, epoch, v.z);
 			}
-#pragma unroll
-			for (int ch = 0; ch < S2_PERSIST_IO_CHUNKS; ++ch)
+			if (tid < nExp1)
 			{
-				int j = tid + ch * S2_STRIP_THREADS;
-				if (j < exportCount && (pv.debugSkip & 1) == 0)
+				float4 v = lvel[expIdx[1]];
+				gu64* p = gran + par + out1 + 4 * tid;
+				putGranule(p + 0, epoch, v.x), putGranule(p + 1, epoch, v.y), putGranule(p + 2, epoch, v.z);
+			}
+			int fail = 0;
+			if ((pv.debugSkip & 1) == 0)
+			{
+				float v[3];
+				if (tid < nImp0)
 				{
-					float v[3];
-					if (getGranules<3>(inRight + 4 * j, epoch, v, pv.error))
+					if (getGranules<3>(gran + par + in0 + 4 * tid, epoch, v, pv.error))
 					{
-						lvel[exportIdx[ch]] = make_float4(v[0], v[1], v[2], 0.0f);
+						lvel[nb + tid] = make_float4(v[0], v[1], v[2], 0.0f);
+					}
+					else
+					{
+						fail = 1;
+					}
+				}
+				if (tid < nImp1)
+				{
+					if (getGranules<3>(gran + par + in1 + 4 * tid, epoch, v, pv.error))
+					{
+						lvel[nb + nImp0 + tid] = make_float4(v[0], v[1], v[2], 0.0f);
 					}
 					else
 					{
@@ -774,7 +769,36 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 				}
 			}
 			bad = __syncthreads_or(fail);
-			dqDirty = false;
+			if (bad)
+			{
+				break;
+			}
+			// ---- both seams (the neighbours compute the same bits on their side) ----
+#pragma unroll 1
+			for (int i = 0; i < roundsB && (pv.debugSkip & 2) == 0; ++i)
+			{
+#pragma unroll
+				for (int pass = 0; pass < 2; ++pass)
+				{
+					int side, k, slot;
+					if (seamItem(i, pass, side, k, slot))
+					{
+						float4 q[Q];
+#pragma unroll
+						for (int f = 0; f < Q; ++f)
+						{
+							q[f] = lseam[f * seamSlots + slot];
+						}
+						PersistRegs<KIND, WARM> pb;
+						__builtin_memcpy(&pb, q, sizeof(pb));
+						sweepPersist<KIND, WARM, POINTS>(pb, c, lb, op.inv_h, op.useBias, k);
+						// only the impulses changed: PersistRegs starts with them, record 0
+						__builtin_memcpy(&q[0], &pb.imp[0], 16);
+						lseam[slot] = q[0];
+					}
+				}
+				__syncthreads();
+			}
 		}
 		if (stamp)
 		{
@@ -802,21 +826,26 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 			storeSoft<KIND>(c, unpackPersist<KIND, WARM>(rA[i]), kA[i]);
 		}
 	}
-#pragma unroll
-	for (int i = 0; i < S2_PERSIST_B_ROUNDS; ++i)
+	// the right seam's impulses are stored by this workgroup (its left neighbour of that seam), nobody stores twice
+#pragma unroll 1
+	for (int i = 0; i < roundsB; ++i)
 	{
-		if (kB[i] >= 0)
+#pragma unroll 1
+		for (int pass = 0; pass < 2; ++pass)
 		{
-			const int slot = kB[i] - batchB[0].x;
-			float4 q[Q];
-#pragma unroll
-			for (int f = 0; f < Q; ++f)
+			int side, k, slot;
+			if (seamItem(i, pass, side, k, slot) && side == 1)
 			{
-				q[f] = lseam[f * seamSlots + slot];
+				float4 q[Q];
+#pragma unroll
+				for (int f = 0; f < Q; ++f)
+				{
+					q[f] = lseam[f * seamSlots + slot];
+				}
+				PersistRegs<KIND, WARM> pb;
+				__builtin_memcpy(&pb, q, sizeof(pb));
+				storeSoft<KIND>(c, unpackPersist<KIND, WARM>(pb), k);
 			}
-			PersistRegs<KIND, WARM> pb;
-			__builtin_memcpy(&pb, q, sizeof(pb));
-			storeSoft<KIND>(c, unpackPersist<KIND, WARM>(pb), kB[i]);
 		}
 	}
 	if (stamp)
@@ -830,14 +859,21 @@ template <int KIND, int WARM>
 static void launchStep(hipStream_t s, dim3 grid, size_t lds, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv,
 					   const Op* ops, int opCount)
 {
-	stripStepKernel<KIND, WARM><<<grid, dim3(S2_STRIP_THREADS), lds, s>>>(c, g, a, pv, ops, opCount);
+	if (pv.allTwoPoints)
+	{
+		stripStepKernel<KIND, WARM, 2><<<grid, dim3(S2_STRIP_THREADS), lds, s>>>(c, g, a, pv, ops, opCount);
+	}
+	else
+	{
+		stripStepKernel<KIND, WARM, 0><<<grid, dim3(S2_STRIP_THREADS), lds, s>>>(c, g, a, pv, ops, opCount);
+	}
 }
 
 void launchStripStep(hipStream_t s, int kind, int warm, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv,
 					 const Op* ops, int opCount)
 {
 	dim3 grid((unsigned)a.groupCount);
-	size_t lds = (size_t)pv.ldsRecords * sizeof(float4) + (size_t)opCount * sizeof(Op);
+	size_t lds = (size_t)pv.ldsRecords * sizeof(float4) + (size_t)opCount * sizeof(Op); // ldsRecords: bodies + seam constraint records
 	if (kind == SOFT_TGS)
 	{
 		warm == WARM_FIXED ? launchStep<SOFT_TGS, WARM_FIXED>(s, grid, lds, c, g, a, pv, ops, opCount)
@@ -902,9 +938,12 @@ int stripKernelSetup()
 		(const void*)stripSoftKernel<SOFT_FIXED, WARM_CURRENT>, (const void*)stripSoftKernel<SOFT_FIXED, WARM_FIXED>, (const void*)stripSoftKernel<SOFT_FIXED, -1>,
 	};
 	const void* steps[] = {
-		(const void*)stripStepKernel<SOFT_TGS, WARM_CURRENT>,	(const void*)stripStepKernel<SOFT_TGS, WARM_FIXED>,
-		(const void*)stripStepKernel<SOFT_PGS, WARM_CURRENT>,	(const void*)stripStepKernel<SOFT_PGS, WARM_FIXED>,
-		(const void*)stripStepKernel<SOFT_FIXED, WARM_CURRENT>, (const void*)stripStepKernel<SOFT_FIXED, WARM_FIXED>,
+		(const void*)stripStepKernel<SOFT_TGS, WARM_CURRENT, 0>,   (const void*)stripStepKernel<SOFT_TGS, WARM_FIXED, 0>,
+		(const void*)stripStepKernel<SOFT_PGS, WARM_CURRENT, 0>,   (const void*)stripStepKernel<SOFT_PGS, WARM_FIXED, 0>,
+		(const void*)stripStepKernel<SOFT_FIXED, WARM_CURRENT, 0>, (const void*)stripStepKernel<SOFT_FIXED, WARM_FIXED, 0>,
+		(const void*)stripStepKernel<SOFT_TGS, WARM_CURRENT, 2>,   (const void*)stripStepKernel<SOFT_TGS, WARM_FIXED, 2>,
+		(const void*)stripStepKernel<SOFT_PGS, WARM_CURRENT, 2>,   (const void*)stripStepKernel<SOFT_PGS, WARM_FIXED, 2>,
+		(const void*)stripStepKernel<SOFT_FIXED, WARM_CURRENT, 2>, (const void*)stripStepKernel<SOFT_FIXED, WARM_FIXED, 2>,
 	};
 	for (const void* f : steps)
 	{

@@ -393,6 +393,10 @@ struct s2amdSolver
 	int device = 0;
 	hipStream_t stream = nullptr;
 	hipEvent_t evBegin = nullptr, evEnd = nullptr;
+	// side streams: independent prologue / epilogue kernels become parallel branches of the captured graph
+	hipStream_t side[2] = {nullptr, nullptr};
+	hipEvent_t evFork[2] = {nullptr, nullptr}, evJoin[4] = {nullptr, nullptr, nullptr, nullptr};
+	int optFork = 0; // measured slower on MI355X (multi-branch graph replay costs more than the serial kernels): off
 
 	// wire arrays resident on the device
 	DevBuf dBodies, dContacts, dJoints, dBodiesSaved;
@@ -446,6 +450,8 @@ struct s2amdSolver
 	int looseBodies = 0; // live non-static bodies that no LDS group owns
 	int orderSolverClass = -1; // 0 velocity colouring, 1 position colouring
 	bool orderGrouped = false;
+	bool orderStrips = false;
+	int optStripsAnySolver = 0; // tests: strips for every solver and with joints (through the generic group interpreter)
 	bool adjValid = false;
 	bool structureDirty = true;
 	uint64_t structureGeneration = 0;
@@ -1020,7 +1026,11 @@ int buildStructure(s2amdSolver* s, int solverType)
 	const int cls = isPositionSolver(solverType) ? 1 : 0;
 	const bool needAdj = solverType == s2amd_solverJacobi;
 	const bool grouped = s->optGroups != 0 && !needAdj;
-	if (!s->structureDirty && cls == s->orderSolverClass && grouped == s->orderGrouped && s->adjValid)
+	// strips pay off through the lean / persistent strip kernels, which exist for the soft contact sweeps
+	const bool wantStrips = grouped && s->optStrips != 0 &&
+							(s->optStripsAnySolver != 0 || solverType == s2amd_solverTGS_Soft || solverType == s2amd_solverSoftStep ||
+							 solverType == s2amd_solverPGS_Soft);
+	if (!s->structureDirty && cls == s->orderSolverClass && grouped == s->orderGrouped && wantStrips == s->orderStrips && s->adjValid)
 	{
 		return S2AMD_OK;
 	}
@@ -1182,7 +1192,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 
 	// ---- strips: the part that fits no LDS group, cut along BFS level sets ----
 	StripPartition strips;
-	if (grouped && s->optStrips)
+	if (wantStrips && (s->optStripsAnySolver != 0 || jOf[0].empty()))
 	{
 		std::vector<uint8_t> ownedByIsland((size_t)nb, 0);
 		auto mark = [&](int body) {
@@ -1979,6 +1989,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 
 	s->orderSolverClass = cls;
 	s->orderGrouped = grouped;
+	s->orderStrips = wantStrips;
 	s->structureDirty = false;
 	s->structureGeneration += 1;
 	s->stats.hostPrepMs = (float)(nowMs() - t0);
@@ -2338,6 +2349,27 @@ struct Executor
 	int posSolver;
 	bool profile;
 	bool msg = false; // message-passing accessor for the global part
+	bool fork = false; // graph capture: independent kernels go to side streams (parallel graph branches)
+	bool memsetJoinPending = false;
+
+	hipStream_t branch(int i, int forkEvent)
+	{
+		if (!fork)
+		{
+			return st;
+		}
+		(void)hipEventRecord(s->evFork[forkEvent], st);
+		(void)hipStreamWaitEvent(s->side[i], s->evFork[forkEvent], 0);
+		return s->side[i];
+	}
+	void join(int i, int joinEvent)
+	{
+		if (fork)
+		{
+			(void)hipEventRecord(s->evJoin[joinEvent], s->side[i]);
+			(void)hipStreamWaitEvent(st, s->evJoin[joinEvent], 0);
+		}
+	}
 
 	s2amdContact* wireContacts() const { return (s2amdContact*)s->dContacts.p; }
 	s2amdBody* wireBodies() const { return (s2amdBody*)s->dBodies.p; }
@@ -2709,10 +2741,24 @@ struct Executor
 		return 0;
 	}
 
+	void clearGranules(hipStream_t where)
+	{
+		(void)hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, where); // epochs restart at 1 every launch
+		count();
+	}
+
 	void runPersistent(int kind, int warm)
 	{
-		(void)hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, st); // epochs restart at 1 every launch
-		count();
+		if (memsetJoinPending)
+		{
+			(void)hipEventRecord(s->evJoin[1], s->side[1]);
+			(void)hipStreamWaitEvent(st, s->evJoin[1], 0);
+			memsetJoinPending = false;
+		}
+		else
+		{
+			clearGranules(st);
+		}
 		if (profile)
 		{
 			recordEvent();
@@ -2820,6 +2866,15 @@ struct Executor
 		{
 			return;
 		}
+		// the hand-off buffers of the persistent strip step are cleared on a parallel branch
+		{
+			int kind, warm;
+			if (fork && s->dStripA.view.groupCount > 0 && persistPlan(kind, warm))
+			{
+				clearGranules(branch(1, 1));
+				memsetJoinPending = true;
+			}
+		}
 		// pre: wire -> SoA
 		launchUnpackBodies(st, s->bv, wireBodies(), (const uint32_t*)s->dBodyFlags.p, p.sc, p.unpackH);
 		count();
@@ -2895,7 +2950,10 @@ struct Executor
 			launchGatherMessageSlots(st, s->bv, s->msg);
 			count();
 		}
-		// post: SoA -> wire
+		// post: SoA -> wire (bodies on a parallel branch)
+		hipStream_t bodyBranch = branch(1, 1);
+		launchPackBodies(bodyBranch, s->bv, wireBodies());
+		count();
 		if (s->cv.count > 0)
 		{
 			launchStoreImpulses(st, p.storeKind, s->cv, wireContacts(), p.storeScale);
@@ -2906,8 +2964,7 @@ struct Executor
 			launchStoreJoints(st, s->jv, wireJoints());
 			count();
 		}
-		launchPackBodies(st, s->bv, wireBodies());
-		count();
+		join(1, 2);
 	}
 };
 
@@ -3182,23 +3239,32 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	}
 
 	auto enqueueAll = [&]() {
+		bool indexBranch = false;
 		if (writesConstraintIndex && s->contactCapacity > 0)
 		{
+			// touches only manifold.constraintIndex, which no solver kernel reads: a parallel branch that joins at the end
 			int n = s->contactCapacity;
-			writeConstraintIndexKernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream>>>((s2amdContact*)s->dContacts.p, n,
-																										 (const int*)s->dGatherIndex.p);
+			hipStream_t where = q.branch(0, 0);
+			writeConstraintIndexKernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, where>>>((s2amdContact*)s->dContacts.p, n,
+																									 (const int*)s->dGatherIndex.p);
 			q.count();
+			indexBranch = true;
 		}
 		q.run();
+		if (indexBranch)
+		{
+			q.join(0, 0);
+		}
 	};
 
 	bool useGraph = s->optGraph != 0 && !q.profile;
+	q.fork = useGraph && s->optFork != 0;
 	HIP_TRY(hipEventRecord(s->evBegin, s->stream));
 	if (useGraph)
 	{
 		uint64_t key = 1469598103934665603ull;
 		key = fnv(key, params, sizeof(*params));
-		uint64_t gens[4] = {s->layoutGeneration, s->structureGeneration, s->planGeneration, (uint64_t)((q.msg ? 1 : 0) | (s->optBodyWarm ? 2 : 0) | (s->optStripLean ? 4 : 0) | (s->optPersist ? 8 : 0))};
+		uint64_t gens[4] = {s->layoutGeneration, s->structureGeneration, s->planGeneration, (uint64_t)((q.msg ? 1 : 0) | (s->optBodyWarm ? 2 : 0) | (s->optStripLean ? 4 : 0) | (s->optPersist ? 8 : 0) | (s->optFork ? 16 : 0))};
 		key = fnv(key, gens, sizeof(gens));
 		int sizes[3] = {s->bodyCapacity, s->contactCapacity, s->jointCapacity};
 		key = fnv(key, sizes, sizeof(sizes));
@@ -3384,6 +3450,18 @@ int s2amd_create(int device, s2amdSolver** out)
 	{
 		e = hipEventCreate(&s->evEnd);
 	}
+	for (int i = 0; i < 2 && e == hipSuccess; ++i)
+	{
+		e = hipStreamCreateWithFlags(&s->side[i], hipStreamNonBlocking);
+		if (e == hipSuccess)
+		{
+			e = hipEventCreateWithFlags(&s->evFork[i], hipEventDisableTiming);
+		}
+	}
+	for (int i = 0; i < 4 && e == hipSuccess; ++i)
+	{
+		e = hipEventCreateWithFlags(&s->evJoin[i], hipEventDisableTiming);
+	}
 	if (e != hipSuccess)
 	{
 		delete s;
@@ -3447,6 +3525,24 @@ void s2amd_destroy(s2amdSolver* s)
 	}
 	(void)hipEventDestroy(s->evBegin);
 	(void)hipEventDestroy(s->evEnd);
+	for (int i = 0; i < 2; ++i)
+	{
+		if (s->evFork[i])
+		{
+			(void)hipEventDestroy(s->evFork[i]);
+		}
+		if (s->side[i])
+		{
+			(void)hipStreamDestroy(s->side[i]);
+		}
+	}
+	for (int i = 0; i < 4; ++i)
+	{
+		if (s->evJoin[i])
+		{
+			(void)hipEventDestroy(s->evJoin[i]);
+		}
+	}
 	(void)hipStreamDestroy(s->stream);
 	delete s;
 }
@@ -3773,6 +3869,10 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 		s->optStrips = value != 0;
 		s->structureDirty = true;
 	}
+	else if (strcmp(key, "fork") == 0)
+	{
+		s->optFork = value != 0;
+	}
 	else if (strcmp(key, "persist_debug") == 0)
 	{
 		s->optPersistDebug = value;
@@ -3781,6 +3881,11 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	else if (strcmp(key, "persist") == 0)
 	{
 		s->optPersist = value != 0;
+		s->structureDirty = true;
+	}
+	else if (strcmp(key, "strips_any_solver") == 0)
+	{
+		s->optStripsAnySolver = value != 0;
 		s->structureDirty = true;
 	}
 	else if (strcmp(key, "strip_lean") == 0)

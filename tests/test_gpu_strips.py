@@ -25,6 +25,7 @@ def tiny_strips():
     s.set_option("max_group_bodies", 48)
     s.set_option("strip_min_bodies", 0)
     s.set_option("strip_bodies", 12)
+    s.set_option("strips_any_solver", 1)
     yield s
     s.close()
 
@@ -49,12 +50,29 @@ def test_big_pyramid_strips_default_options(solver_name):
     vel, pos = common.DEFAULT_ITERS[solver_name]
     pre = synthetic.pyramid(100)
     with hip.Solver(0) as s:
+        s.set_option("strips_any_solver", 1)
         state = common.copy3(pre)
         for step in range(3):
             params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
             state = gpu_vs_oracle(s, params, state, "pyramid100/%s step %d" % (solver_name, step))
         st = s.stats()
         assert st["stripCount"] >= 4 and st["seamCount"] == st["stripCount"] - 1, st
+
+
+@pytest.mark.parametrize("solver_name,expect", [("TGS_Soft", True), ("SoftStep", True), ("PGS_Soft", True), ("PGS", False), ("XPBD", False)])
+def test_default_policy_strips_only_for_the_soft_sweeps(solver_name, expect):
+    """Strips pay off through strip_kernel.hip, which covers the soft contact sweeps; every other solver keeps the
+    colour-batch path by default."""
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    pre = synthetic.pyramid(100)
+    with hip.Solver(0) as s:
+        params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+        state = gpu_vs_oracle(s, params, pre, "pyramid100/%s default" % solver_name)
+        assert (s.stats()["stripCount"] > 0) == expect
+        # switching the solver on the same resident world rebuilds the structure
+        other = wire.StepParams.make("PGS" if expect else "TGS_Soft", 1.0 / 60.0, 4, 2, True)
+        gpu_vs_oracle(s, other, state, "pyramid100 switch from %s" % solver_name)
+        assert (s.stats()["stripCount"] > 0) == (not expect)
 
 
 @pytest.mark.parametrize("lean", [1, 0])
@@ -143,6 +161,7 @@ def test_joint_grid_strips(solver_name):
     vel, pos = common.DEFAULT_ITERS[solver_name]
     pre = synthetic.joint_grid(70)
     with hip.Solver(0) as s:
+        s.set_option("strips_any_solver", 1)
         state = common.copy3(pre)
         for step in range(2):
             params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
@@ -156,5 +175,6 @@ def test_platform_high_degree_body_in_strips(solver_name):
     vel, pos = common.DEFAULT_ITERS[solver_name]
     pre = synthetic.platform(60, layers=80)
     with hip.Solver(0) as s:
+        s.set_option("strips_any_solver", 1)
         params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
         gpu_vs_oracle(s, params, pre, "platform60x80/%s" % solver_name)

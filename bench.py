@@ -85,6 +85,22 @@ def cpu_baseline(base, vel, pos, budget_s):
                 steps, base, 1e3 * secs / steps, os.cpu_count())}
 
 
+def pmc_traffic_bytes(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summaries (separate
+    FETCH_SIZE / WRITE_SIZE passes of this same command, profiles/r01_persistent_pmc_*.txt): counters are in KiB;
+    FETCH_SIZE is doubled per the gfx950 note in MI355X_MICROARCH.md (it reads half of a wide coalesced stream).
+    None when the summaries are not there."""
+    total = 0.0
+    for name, scale in (("fetch", 2.0), ("write", 1.0)):
+        path = os.path.join(ROOT, "profiles", "r01_persistent_pmc_%s_size.txt" % name)
+        try:
+            rows = [l.split() for l in open(path) if l.startswith(kernel_prefix) and ("FETCH_SIZE" in l or "WRITE_SIZE" in l)]
+            total += scale * float(rows[0][3]) * 1024.0
+        except (OSError, IndexError, ValueError):
+            return None
+    return total
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,7 +227,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": pmc_traffic_bytes("_Z15stripStepKernel") if persistent and args.base == 200 else None,
                 "kernel": "stripStepKernel<SOFT_TGS> (whole step, one persistent launch; constraints_per_launch counts "
                           "constraint-sweeps)" if persistent else "solveContactsSoftKernel<SOFT_TGS> / stripSoftKernel<SOFT_TGS>",
                 "avg_launch_us": avg_launch_us, "launches_per_step": 1 if persistent else launches_per_sweep * sweeps,

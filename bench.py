@@ -140,6 +140,7 @@ def main():
     for kv in args.opt:
         key, _, val = kv.partition("=")
         gpu.set_option(key, int(val))
+    gpu.set_option("async", 1)  # steps are enqueued back to back; sync() below waits for the solver's stream
     gpu.upload(*pre)
     gpu.save_bodies()
 
@@ -160,6 +161,7 @@ def main():
             dist.all_gather_into_tensor(gathered, pose if backend == "nccl" else pose.cpu())
 
     def sync():
+        gpu.synchronize()
         if world > 1:
             import torch
             dist.barrier()
@@ -173,6 +175,9 @@ def main():
         one_step()
     sync()
     elapsed = time.perf_counter() - t0
+    gpu.set_option("async", 0)
+    gpu.restore_bodies()
+    gpu.step_resident(params)  # one synchronous step: device time and counters for the report
     st = gpu.stats()
     C = st["constraintCount"]
 

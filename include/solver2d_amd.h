@@ -190,6 +190,9 @@ int s2amd_download(s2amdSolver* solver, s2amdBody* bodies, int32_t bodyCapacity,
 				   int32_t contactCapacity, s2amdJoint* joints, int32_t jointCapacity);
 /* Snapshot / restore of the resident body array on the device (bench: re-solve one snapshot). */
 int s2amd_save_bodies(s2amdSolver* solver);
+/* With option "async" = 1, s2amd_step_resident returns once the step is enqueued on the solver's stream (no
+ * device time in the stats); this call waits for everything enqueued so far and reports a deferred device error. */
+int s2amd_synchronize(s2amdSolver* solver);
 int s2amd_restore_bodies(s2amdSolver* solver);
 
 /* ---- the stages either side of the solver ---- */
@@ -266,7 +269,7 @@ int s2amd_measure_dominant(s2amdSolver* solver, const s2amdStepParams* params, i
 /* option keys: "graph" (0/1 hipGraph replay), "profile" (0/1 per-sweep HIP events),
  * "groups" (0/1 LDS group path for small islands), "message" (0/1 message-passing sweeps), "max_group_bodies", "pack_group_bodies",
  * "strips" (0/1 cut islands that fit no LDS group into strips of BFS levels: two launches per sweep), "strip_bodies" (target
- * bodies per strip), "strip_min_bodies" (loose bodies below which the colour-batch path is kept), "strip_lean" (0/1 dedicated strip
+ * bodies per strip), "strip_min_bodies" (loose bodies below which the colour-batch path is kept), "async" (0/1, see s2amd_synchronize), "strip_lean" (0/1 dedicated strip
  * kernel for the soft sweeps), "persist" (0/1 whole step of the strips in one persistent launch), "body_warm" */
 int s2amd_set_option(s2amdSolver* solver, const char* key, int32_t value);
 

@@ -10,64 +10,26 @@
 // (solve_common.c:30-41): with a = (h*invMass) * (force + (mass*gravityScale)*gravity),
 // aw = (h*invI)*torque, ld = 1/(1 + h*linearDamping), ad = 1/(1 + h*angularDamping) the update is
 // v = ld * (v + a), w = (w + aw) * ad -- the same fp32 operations in the same order.
-__global__ __launch_bounds__(S2_BLOCK) void unpackBodiesKernel(BodyView b, const s2amdBody* wire, const uint32_t* hostFlags, StepConsts sc, float h)
+// blocks [0, bodyBlocks): wire bodies -> SoA; further blocks: manifold.constraintIndex of every contact slot
+// (solver.cpp: the pool-order gather index; a field no solver kernel reads)
+__global__ __launch_bounds__(S2_BLOCK) void unpackBodiesKernel(BodyView b, const s2amdBody* wire, const uint32_t* hostFlags, StepConsts sc, float h,
+															   int bodyBlocks, s2amdContact* wireContacts, int contactCapacity, const int* gatherIndex)
 {
-	int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= b.capacity)
+	if ((int)blockIdx.x >= bodyBlocks)
 	{
+		int c = ((int)blockIdx.x - bodyBlocks) * (int)blockDim.x + (int)threadIdx.x;
+		if (c < contactCapacity)
+		{
+			wireContacts[c].constraintIndex = gatherIndex[c];
+		}
 		return;
 	}
-	const s2amdBody* w = wire + i;
-	int type = w->type;
-	uint32_t flags = hostFlags[i] & (S2F_WRITE_VEL | S2F_WRITE_POS | S2F_IN_GROUP);
-	if (type != S2AMD_BODY_FREE)
-	{
-		flags |= S2F_LIVE;
-		if (type == S2AMD_BODY_DYNAMIC)
-		{
-			flags |= S2F_DYNAMIC;
-		}
-		if (type != S2AMD_BODY_STATIC)
-		{
-			flags |= S2F_MOVES;
-		}
-	}
-	b.flags[i] = flags;
-	b.vel[i] = make_float4(w->linearVelocity[0], w->linearVelocity[1], w->angularVelocity, 0.0f);
-	b.dq[i] = make_float4(w->deltaPosition[0], w->deltaPosition[1], w->rot[0], w->rot[1]);
-	b.pos[i] = make_float2(w->position[0], w->position[1]);
-
-	V2 gravity = v2(sc.gravityX, sc.gravityY);
-	V2 force = v2(w->force[0], w->force[1]);
-	V2 inner = mulAdd(force, w->mass * w->gravityScale, gravity);
-	V2 a = mulSV(h * w->invMass, inner);
-	float aw = h * w->invI * w->torque;
-	float ld = 1.0f / (1.0f + h * w->linearDamping);
-	float ad = 1.0f / (1.0f + h * w->angularDamping);
-	b.integ[i] = make_float4(a.x, a.y, aw, ld);
-	b.angDamp[i] = ad;
+	unpackBodyOne(b, wire, hostFlags, sc, h, (int)(blockIdx.x * blockDim.x + threadIdx.x));
 }
 
 __global__ __launch_bounds__(S2_BLOCK) void packBodiesKernel(BodyView b, s2amdBody* wire)
 {
-	int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= b.capacity)
-	{
-		return;
-	}
-	if ((b.flags[i] & S2F_LIVE) == 0)
-	{
-		return;
-	}
-	s2amdBody* w = wire + i;
-	float4 v = b.vel[i];
-	float4 d = b.dq[i];
-	float2 p = b.pos[i];
-	w->position[0] = p.x, w->position[1] = p.y;
-	w->rot[0] = d.z, w->rot[1] = d.w;
-	w->linearVelocity[0] = v.x, w->linearVelocity[1] = v.y;
-	w->angularVelocity = v.z;
-	w->deltaPosition[0] = d.x, w->deltaPosition[1] = d.y;
+	packBodyOne(b, wire, (int)(blockIdx.x * blockDim.x + threadIdx.x));
 }
 
 #define S2_BODY_KERNEL_HEAD                                                                                                      \
@@ -231,11 +193,14 @@ static inline dim3 gridFor(int n)
 	return dim3((unsigned)((n + S2_BLOCK - 1) / S2_BLOCK));
 }
 
-void launchUnpackBodies(hipStream_t s, const BodyView& b, const s2amdBody* wire, const uint32_t* hostFlags, const StepConsts& sc, float h)
+void launchUnpackBodies(hipStream_t s, const BodyView& b, const s2amdBody* wire, const uint32_t* hostFlags, const StepConsts& sc, float h,
+						s2amdContact* wireContacts, int contactCapacity, const int* gatherIndex)
 {
 	if (b.capacity > 0)
 	{
-		unpackBodiesKernel<<<gridFor(b.capacity), dim3(S2_BLOCK), 0, s>>>(b, wire, hostFlags, sc, h);
+		dim3 bodyGrid = gridFor(b.capacity), contactGrid = gatherIndex && contactCapacity > 0 ? gridFor(contactCapacity) : dim3(0);
+		unpackBodiesKernel<<<dim3(bodyGrid.x + contactGrid.x), dim3(S2_BLOCK), 0, s>>>(b, wire, hostFlags, sc, h, (int)bodyGrid.x, wireContacts,
+																						 contactCapacity, gatherIndex);
 	}
 }
 void launchPackBodies(hipStream_t s, const BodyView& b, s2amdBody* wire)

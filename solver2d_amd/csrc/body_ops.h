@@ -99,3 +99,63 @@ template <class BA> S2_DEV void xpbdProjectOne(const BA& ba, const float4* dq0, 
 	float w = computeAngularVelocity(q0, q1, inv_h);
 	ba.setVel(li, make_float4(lv.x, lv.y, w, 0.0f));
 }
+
+// wire body -> SoA records + the per-step constants of the velocity integrator (solve_common.c:30-41)
+S2_DEV void unpackBodyOne(const BodyView& b, const s2amdBody* wire, const uint32_t* hostFlags, const StepConsts& sc, float h, int i)
+{
+	if (i >= b.capacity)
+	{
+		return;
+	}
+	const s2amdBody* w = wire + i;
+	int type = w->type;
+	uint32_t flags = hostFlags[i] & (S2F_WRITE_VEL | S2F_WRITE_POS | S2F_IN_GROUP);
+	if (type != S2AMD_BODY_FREE)
+	{
+		flags |= S2F_LIVE;
+		if (type == S2AMD_BODY_DYNAMIC)
+		{
+			flags |= S2F_DYNAMIC;
+		}
+		if (type != S2AMD_BODY_STATIC)
+		{
+			flags |= S2F_MOVES;
+		}
+	}
+	b.flags[i] = flags;
+	b.vel[i] = make_float4(w->linearVelocity[0], w->linearVelocity[1], w->angularVelocity, 0.0f);
+	b.dq[i] = make_float4(w->deltaPosition[0], w->deltaPosition[1], w->rot[0], w->rot[1]);
+	b.pos[i] = make_float2(w->position[0], w->position[1]);
+
+	V2 gravity = v2(sc.gravityX, sc.gravityY);
+	V2 force = v2(w->force[0], w->force[1]);
+	V2 inner = mulAdd(force, w->mass * w->gravityScale, gravity);
+	V2 a = mulSV(h * w->invMass, inner);
+	float aw = h * w->invI * w->torque;
+	float ld = 1.0f / (1.0f + h * w->linearDamping);
+	float ad = 1.0f / (1.0f + h * w->angularDamping);
+	b.integ[i] = make_float4(a.x, a.y, aw, ld);
+	b.angDamp[i] = ad;
+}
+
+// SoA records -> wire body (the fields a solver writes: body.h:16-76)
+S2_DEV void packBodyOne(const BodyView& b, s2amdBody* wire, int i)
+{
+	if (i >= b.capacity)
+	{
+		return;
+	}
+	if ((b.flags[i] & S2F_LIVE) == 0)
+	{
+		return;
+	}
+	s2amdBody* w = wire + i;
+	float4 v = b.vel[i];
+	float4 d = b.dq[i];
+	float2 p = b.pos[i];
+	w->position[0] = p.x, w->position[1] = p.y;
+	w->rot[0] = d.z, w->rot[1] = d.w;
+	w->linearVelocity[0] = v.x, w->linearVelocity[1] = v.y;
+	w->angularVelocity = v.z;
+	w->deltaPosition[0] = d.x, w->deltaPosition[1] = d.y;
+}

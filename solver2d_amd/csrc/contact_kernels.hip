@@ -255,8 +255,26 @@ __global__ __launch_bounds__(S2_BLOCK) void prepareContactsKernel(ContactView c,
 // s2StoreContactImpulses (solve_common.c:396-410), the scaled XPBD variant (solve_xpbd.c:517-527)
 // and s2ContactSolver_StoreImpulses (solve_pgs_ngs_block.c:660-677, reduced point count)
 template <int KIND>
-__global__ __launch_bounds__(S2_BLOCK) void storeImpulsesKernel(ContactView c, s2amdContact* wire, float scale)
+// blocks [0, contactBlocks): impulses -> wire contacts; then bodyBlocks blocks: SoA bodies -> wire bodies
+// (packBodyOne); the remaining blocks zero the hand-off buffers of the persistent strip step (strip_kernel.hip: its
+// tags restart at 1 every launch, so the buffers must be clean when the next step starts)
+__global__ __launch_bounds__(S2_BLOCK) void storeImpulsesKernel(ContactView c, s2amdContact* wire, float scale, int contactBlocks, int bodyBlocks,
+																BodyView bodies, s2amdBody* wireBodies, uint4* clear, int clearCount)
 {
+	if ((int)blockIdx.x >= contactBlocks + bodyBlocks)
+	{
+		int i = ((int)blockIdx.x - contactBlocks - bodyBlocks) * (int)blockDim.x + (int)threadIdx.x;
+		if (i < clearCount)
+		{
+			clear[i] = make_uint4(0u, 0u, 0u, 0u);
+		}
+		return;
+	}
+	if ((int)blockIdx.x >= contactBlocks)
+	{
+		packBodyOne(bodies, wireBodies, ((int)blockIdx.x - contactBlocks) * (int)blockDim.x + (int)threadIdx.x);
+		return;
+	}
 	int k = blockIdx.x * blockDim.x + threadIdx.x;
 	if (k >= c.count)
 	{
@@ -585,23 +603,29 @@ void launchBlockSolvePosition(hipStream_t s, const ContactView& c, const BodyVie
 	S2_LAUNCH_SWEEP(blockSolvePositionKernel, c, b, begin, end);
 }
 
-void launchStoreImpulses(hipStream_t s, int kind, const ContactView& c, s2amdContact* wire, float scale)
+void launchStoreImpulses(hipStream_t s, int kind, const ContactView& c, s2amdContact* wire, float scale, const BodyView& bodies, s2amdBody* wireBodies,
+						 void* clear, size_t clearBytes)
 {
-	if (c.count <= 0)
+	// bodies == nullptr-capacity: plain store; otherwise the body write-back rides in the same launch
+	const int contactBlocks = c.count > 0 ? (c.count + S2_BLOCK - 1) / S2_BLOCK : 0;
+	const int bodyBlocks = wireBodies && bodies.capacity > 0 ? (bodies.capacity + S2_BLOCK - 1) / S2_BLOCK : 0;
+	const int clearCount = clear ? (int)(clearBytes / sizeof(uint4)) : 0; // buffers are allocated in multiples of 256 bytes
+	const int clearBlocks = (clearCount + S2_BLOCK - 1) / S2_BLOCK;
+	if (contactBlocks + bodyBlocks + clearBlocks == 0)
 	{
 		return;
 	}
-	dim3 g = gridFor(c.count), t(S2_BLOCK);
+	dim3 g((unsigned)(contactBlocks + bodyBlocks + clearBlocks)), t(S2_BLOCK);
 	switch (kind)
 	{
-		case STORE_PLAIN:
-			storeImpulsesKernel<STORE_PLAIN><<<g, t, 0, s>>>(c, wire, scale);
-			break;
 		case STORE_SCALED:
-			storeImpulsesKernel<STORE_SCALED><<<g, t, 0, s>>>(c, wire, scale);
+			storeImpulsesKernel<STORE_SCALED><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount);
 			break;
 		case STORE_BLOCK:
-			storeImpulsesKernel<STORE_BLOCK><<<g, t, 0, s>>>(c, wire, scale);
+			storeImpulsesKernel<STORE_BLOCK><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount);
+			break;
+		default:
+			storeImpulsesKernel<STORE_PLAIN><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount);
 			break;
 	}
 }

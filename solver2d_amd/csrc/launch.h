@@ -85,10 +85,12 @@ void launchXpbdContactPositions(hipStream_t s, const ContactView& c, const BodyV
 void launchXpbdContactVelocities(hipStream_t s, const ContactView& c, const BodyView& b, int begin, int end, float h);
 void launchBlockSolveVelocity(hipStream_t s, const ContactView& c, const BodyView& b, int begin, int end);
 void launchBlockSolvePosition(hipStream_t s, const ContactView& c, const BodyView& b, int begin, int end);
-void launchStoreImpulses(hipStream_t s, int kind, const ContactView& c, s2amdContact* wire, float scale);
+void launchStoreImpulses(hipStream_t s, int kind, const ContactView& c, s2amdContact* wire, float scale, const BodyView& bodies, s2amdBody* wireBodies,
+						 void* clear, size_t clearBytes);
 
 // bodies
-void launchUnpackBodies(hipStream_t s, const BodyView& b, const s2amdBody* wire, const uint32_t* hostFlags, const StepConsts& sc, float h);
+void launchUnpackBodies(hipStream_t s, const BodyView& b, const s2amdBody* wire, const uint32_t* hostFlags, const StepConsts& sc, float h,
+						s2amdContact* wireContacts, int contactCapacity, const int* gatherIndex);
 void launchPackBodies(hipStream_t s, const BodyView& b, s2amdBody* wire);
 void launchIntegrateVelocities(hipStream_t s, const BodyView& b);
 void launchIntegratePositions(hipStream_t s, const BodyView& b, float h);

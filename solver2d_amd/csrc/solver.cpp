@@ -396,6 +396,8 @@ struct s2amdSolver
 	// side streams: independent prologue / epilogue kernels become parallel branches of the captured graph
 	hipStream_t side[2] = {nullptr, nullptr};
 	hipEvent_t evFork[2] = {nullptr, nullptr}, evJoin[4] = {nullptr, nullptr, nullptr, nullptr};
+	int optAsync = 0; // s2amd_step_resident returns after enqueueing; s2amd_synchronize collects errors
+	bool constraintIndexInPrologue = false;
 	int optFork = 0; // measured slower on MI355X (multi-branch graph replay costs more than the serial kernels): off
 
 	// wire arrays resident on the device
@@ -1796,7 +1798,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 				put(o2, exportSrc.data(), exportSrc.size() * sizeof(int));
 				put(o3, importIds.data(), importIds.size() * sizeof(int));
 				bool grewP = false;
-				s->granuleBytes = std::max<size_t>((size_t)2 * parityStride, 1) * sizeof(unsigned long long);
+				s->granuleBytes = ((std::max<size_t>((size_t)2 * parityStride, 1) * sizeof(unsigned long long)) + 255) & ~size_t(255);
 				if ((rc = s->dPersist.ensure(blob.size(), &grewP)) != 0 || (rc = s->dGranules.ensure(s->granuleBytes, &grewP)) != 0)
 				{
 					return rc;
@@ -1819,6 +1821,8 @@ int buildStructure(s2amdSolver* s, int solverType)
 				HIP_TRY(hipHostGetDevicePointer((void**)&devError, s->hostError, 0));
 				pv.error = devError;
 				pv.parityStride = parityStride;
+				// fresh buffers start from zero tags
+				HIP_TRY(hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, s->stream));
 				pv.allTwoPoints = 1;
 				for (int k = k0; k < k1; ++k)
 				{
@@ -2350,7 +2354,7 @@ struct Executor
 	bool profile;
 	bool msg = false; // message-passing accessor for the global part
 	bool fork = false; // graph capture: independent kernels go to side streams (parallel graph branches)
-	bool memsetJoinPending = false;
+	const int* gatherIndex = nullptr; // manifold.constraintIndex rides in the unpack launch
 
 	hipStream_t branch(int i, int forkEvent)
 	{
@@ -2665,7 +2669,7 @@ struct Executor
 	// Can the whole plan run as ONE persistent launch over the strips (strip_kernel.hip: stripStepKernel)?
 	bool persistPlan(int& kind, int& warm) const
 	{
-		if (!s->persistValid || p.ops.size() > 128)
+		if (!s->persistValid || p.ops.size() > 128 || p.solveSweeps > 63) // one hand-off epoch per sweep, 64 per step
 		{
 			return false;
 		}
@@ -2747,15 +2751,11 @@ struct Executor
 		count();
 	}
 
-	void runPersistent(int kind, int warm)
+	void runPersistent(int kind, int warm, bool clearFirst = false)
 	{
-		if (memsetJoinPending)
-		{
-			(void)hipEventRecord(s->evJoin[1], s->side[1]);
-			(void)hipStreamWaitEvent(st, s->evJoin[1], 0);
-			memsetJoinPending = false;
-		}
-		else
+		// hand-off tags are the exchange number; the step's epilogue kernel leaves the buffers zeroed for the next
+		// step, so they only need clearing when this launch is replayed on its own (s2amd_measure_dominant)
+		if (clearFirst)
 		{
 			clearGranules(st);
 		}
@@ -2866,17 +2866,8 @@ struct Executor
 		{
 			return;
 		}
-		// the hand-off buffers of the persistent strip step are cleared on a parallel branch
-		{
-			int kind, warm;
-			if (fork && s->dStripA.view.groupCount > 0 && persistPlan(kind, warm))
-			{
-				clearGranules(branch(1, 1));
-				memsetJoinPending = true;
-			}
-		}
 		// pre: wire -> SoA
-		launchUnpackBodies(st, s->bv, wireBodies(), (const uint32_t*)s->dBodyFlags.p, p.sc, p.unpackH);
+		launchUnpackBodies(st, s->bv, wireBodies(), (const uint32_t*)s->dBodyFlags.p, p.sc, p.unpackH, wireContacts(), s->contactCapacity, gatherIndex);
 		count();
 		if (p.prepContacts >= 0 && s->cv.count > 0)
 		{
@@ -2950,21 +2941,19 @@ struct Executor
 			launchGatherMessageSlots(st, s->bv, s->msg);
 			count();
 		}
-		// post: SoA -> wire (bodies on a parallel branch)
-		hipStream_t bodyBranch = branch(1, 1);
-		launchPackBodies(bodyBranch, s->bv, wireBodies());
-		count();
-		if (s->cv.count > 0)
+		// post: SoA -> wire: impulses and bodies in one launch (+ the epoch base of the hand-off tags)
 		{
-			launchStoreImpulses(st, p.storeKind, s->cv, wireContacts(), p.storeScale);
-			count();
+			int kind, warm;
+			const bool usedGranules = s->dStripA.view.groupCount > 0 && persistPlan(kind, warm);
+			launchStoreImpulses(st, p.storeKind, s->cv, wireContacts(), p.storeScale, s->bv, wireBodies(), usedGranules ? s->dGranules.p : nullptr,
+								usedGranules ? s->granuleBytes : 0);
 		}
+		count();
 		if (s->jv.count > 0)
 		{
 			launchStoreJoints(st, s->jv, wireJoints());
 			count();
 		}
-		join(1, 2);
 	}
 };
 
@@ -3240,7 +3229,8 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 
 	auto enqueueAll = [&]() {
 		bool indexBranch = false;
-		if (writesConstraintIndex && s->contactCapacity > 0)
+		q.gatherIndex = (writesConstraintIndex && s->contactCapacity > 0 && !q.fork) ? (const int*)s->dGatherIndex.p : nullptr;
+		if (writesConstraintIndex && s->contactCapacity > 0 && q.fork)
 		{
 			// touches only manifold.constraintIndex, which no solver kernel reads: a parallel branch that joins at the end
 			int n = s->contactCapacity;
@@ -3300,11 +3290,14 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	}
 	HIP_TRY(hipEventRecord(s->evEnd, s->stream));
 	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipStreamSynchronize(s->stream));
-
-	float ms = 0.0f;
-	HIP_TRY(hipEventElapsedTime(&ms, s->evBegin, s->evEnd));
-	s->stats.deviceMs = ms;
+	const bool async = s->optAsync != 0 && !q.profile;
+	if (!async)
+	{
+		HIP_TRY(hipStreamSynchronize(s->stream));
+		float ms = 0.0f;
+		HIP_TRY(hipEventElapsedTime(&ms, s->evBegin, s->evEnd));
+		s->stats.deviceMs = ms;
+	}
 	s->stats.constraintCount = s->cv.count;
 	s->stats.jointCount = s->jv.count;
 	s->stats.contactColors = (int)s->contacts.colorOffsets.size() - 1;
@@ -3318,9 +3311,10 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 		int kind, warm;
 		s->stats.persistent = (s->dStripA.view.groupCount > 0 && q.persistPlan(kind, warm)) ? 1 : 0;
 	}
-	if (s->hostError && *s->hostError != 0u)
+	if (!async && s->hostError && *s->hostError != 0u)
 	{
 		*s->hostError = 0u;
+		(void)hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, s->stream);
 		return fail(S2AMD_E_DEVICE, "strip hand-off timed out inside the persistent step kernel (workgroups not co-resident?)");
 	}
 	if (q.profile)
@@ -3468,6 +3462,7 @@ int s2amd_create(int device, s2amdSolver** out)
 		return fail(S2AMD_E_DEVICE, std::string("stream/event creation: ") + hipGetErrorString(e));
 	}
 	(void)hipDeviceGetAttribute(&s->cuCount, hipDeviceAttributeMultiprocessorCount, device);
+
 	if (hipHostMalloc((void**)&s->hostError, sizeof(unsigned int), hipHostMallocMapped) == hipSuccess)
 	{
 		*s->hostError = 0u;
@@ -3624,6 +3619,23 @@ int s2amd_save_bodies(s2amdSolver* s)
 	return S2AMD_OK;
 }
 
+int s2amd_synchronize(s2amdSolver* s)
+{
+	if (!s)
+	{
+		return fail(S2AMD_E_INVALID, "null solver");
+	}
+	HIP_TRY(hipSetDevice(s->device));
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	if (s->hostError && *s->hostError != 0u)
+	{
+		*s->hostError = 0u;
+		(void)hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, s->stream);
+		return fail(S2AMD_E_DEVICE, "strip hand-off timed out inside the persistent step kernel (workgroups not co-resident?)");
+	}
+	return S2AMD_OK;
+}
+
 int s2amd_restore_bodies(s2amdSolver* s)
 {
 	if (!s || !s->resident || !s->savedValid)
@@ -3767,7 +3779,7 @@ int s2amd_measure_dominant(s2amdSolver* s, const s2amdStepParams* params, int32_
 		}
 		else if (persistent)
 		{
-			q.runPersistent(pkind, pwarm);
+			q.runPersistent(pkind, pwarm, true);
 		}
 		else if (strips)
 		{
@@ -3868,6 +3880,10 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	{
 		s->optStrips = value != 0;
 		s->structureDirty = true;
+	}
+	else if (strcmp(key, "async") == 0)
+	{
+		s->optAsync = value != 0;
 	}
 	else if (strcmp(key, "fork") == 0)
 	{

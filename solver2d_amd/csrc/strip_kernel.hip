@@ -608,7 +608,7 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 	}
 
 	LdsBodies lb{lvel, ldq};
-	unsigned epoch = 0;
+	unsigned epoch = 0; // tags are the exchange number: the buffers are zero at launch (cleared by the previous step's epilogue)
 	int bad = 0;
 	for (int oi = 0; oi < opCount && !bad; ++oi)
 	{

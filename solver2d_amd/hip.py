@@ -18,7 +18,7 @@ EXPORTS = [
     "s2amd_api_version", "s2amd_device_count", "s2amd_last_error", "s2amd_create", "s2amd_destroy",
     "s2amd_solve", "s2amd_upload", "s2amd_step_resident", "s2amd_download", "s2amd_save_bodies",
     "s2amd_restore_bodies", "s2amd_get_contact_order", "s2amd_get_joint_order", "s2amd_get_stats",
-    "s2amd_set_option", "s2amd_export_poses", "s2amd_measure_dominant", "s2amd_refit_shapes", "s2amd_find_pairs",
+    "s2amd_set_option", "s2amd_export_poses", "s2amd_measure_dominant", "s2amd_refit_shapes", "s2amd_find_pairs", "s2amd_synchronize",
 ]
 
 _lib = None
@@ -50,6 +50,7 @@ def load():
     L.s2amd_download.argtypes = [vp, vp, i32, vp, i32, vp, i32]
     L.s2amd_save_bodies.argtypes = [vp]
     L.s2amd_restore_bodies.argtypes = [vp]
+    L.s2amd_synchronize.argtypes = [vp]
     L.s2amd_get_contact_order.argtypes = [vp, vp, i32, vp, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.s2amd_get_joint_order.argtypes = [vp, vp, i32, vp, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.s2amd_get_stats.argtypes = [vp, ctypes.POINTER(wire.StepStats)]
@@ -182,6 +183,10 @@ class Solver:
 
     def joint_order(self):
         return self._order(load().s2amd_get_joint_order)
+
+    def synchronize(self):
+        """Waits for the steps enqueued under option "async" and raises a deferred device error."""
+        _check(load().s2amd_synchronize(self._h))
 
     def stats(self):
         st = wire.StepStats()

@@ -222,6 +222,7 @@ typedef struct s2amdShape
 	float aabb[4];         /* in/out {lower.x, lower.y, upper.x, upper.y} */
 	float fatAABB[4];      /* in/out */
 	float vertices[8][2];
+	float normals[8][2];   /* polygon edge normals (s2Polygon.normals, include/solver2d/geometry.h:44-50): read by the narrow phase */
 } s2amdShape;
 
 /* == Stage 4 of s2World_Step (src/world.c:259-301) for every non-static body: origin = position -
@@ -243,6 +244,38 @@ int s2amd_refit_shapes(s2amdSolver* solver, const s2amdBody* bodies, int32_t bod
 int s2amd_find_pairs(s2amdSolver* solver, const s2amdBody* bodies, int32_t bodyCapacity, const s2amdShape* shapes, int32_t shapeCapacity,
 					 const uint8_t* moved, const int32_t* existingPairs, int32_t existingPairCount, const s2amdJoint* joints,
 					 int32_t jointCapacity, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount);
+
+/* Narrow-phase state of one contact slot that persists between steps: the shape pair, the GJK simplex cache
+ * (s2DistanceCache, include/solver2d/distance.h:31-37, a member of s2Contact) and per manifold point the feature
+ * id and `persisted` flag (s2ManifoldPoint, include/solver2d/manifold.h:19-38). */
+typedef struct s2amdPairState
+{
+	int32_t shapeA, shapeB; /* s2Contact.shapeIndexA/B; -1: free contact slot */
+	float cacheMetric;
+	uint16_t cacheCount;
+	uint16_t id[2];
+	uint8_t cacheIndexA[3];
+	uint8_t cacheIndexB[3];
+	uint8_t persisted[2];
+	uint8_t pad[2];
+} s2amdPairState;
+
+#define S2AMD_PAIR_UPDATED 0   /* manifold recomputed */
+#define S2AMD_PAIR_SEPARATED 1 /* fat AABBs no longer overlap: the caller destroys the contact (src/world.c:149-167) */
+#define S2AMD_PAIR_FREE (-1)
+
+/* == Stage 3 of s2World_Step, "update contacts" (src/world.c:132-168): for every live contact slot whose shapes'
+ * fat AABBs still overlap, s2UpdateContact (src/contact.c:296-358): the manifold function of the shape-type pair
+ * (src/manifold.c: s2CollideCircles, s2CollideCapsuleAndCircle, s2CollidePolygonAndCircle, s2CollidePolygons with
+ * its GJK distance query src/distance.c:485-604, SAT fallback and clipper; capsules and segments go through the
+ * polygon path exactly as the reference's s2MakeCapsule does), then the id matching that carries impulses and the
+ * sticky-friction cache from the old manifold to the new one.
+ * In:  bodies (rot), origins[2 * body] (s2Body.origin: s2amd_refit_shapes writes them), shapes (geometry in the
+ *      body frame, fatAABB), pairs, contacts (the old manifolds).
+ * Out: contacts (pointCount, normal, points, frictionPersisted; bodyA/B, friction and constraintIndex are kept),
+ *      pairs (ids, persisted, cache), status[contact] = S2AMD_PAIR_*.  Host arrays in and out. */
+int s2amd_update_contacts(s2amdSolver* solver, const s2amdBody* bodies, int32_t bodyCapacity, const float* origins, const s2amdShape* shapes,
+						  int32_t shapeCapacity, s2amdPairState* pairs, s2amdContact* contacts, int32_t contactCapacity, int32_t* status);
 
 /* Multi-GPU exchange: writes one {position.x, position.y, rot.s, rot.c} record per body slot into
  * a DEVICE buffer owned by the caller (e.g. the send buffer of an RCCL all-gather of per-island

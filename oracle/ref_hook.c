@@ -271,8 +271,11 @@ static void fillParams(const s2World* world, const s2StepContext* context, int s
 	g_params.gravity[1] = world->gravity.y;
 }
 
+static void narrowPhaseDone(const s2World* world);
+
 static void hookSolve(s2World* world, s2StepContext* context, int solverType, s2SolveFcn* real)
 {
+	narrowPhaseDone(world);
 	if (g_mode == 1)
 	{
 		fillParams(world, context, solverType);
@@ -365,6 +368,7 @@ static void packShapes(const s2World* world, s2amdShape* out)
 				for (int v = 0; v < sh->polygon.count; ++v)
 				{
 					o->vertices[v][0] = sh->polygon.vertices[v].x, o->vertices[v][1] = sh->polygon.vertices[v].y;
+					o->normals[v][0] = sh->polygon.normals[v].x, o->normals[v][1] = sh->polygon.normals[v].y;
 				}
 				break;
 			case s2_circleShape:
@@ -394,9 +398,129 @@ static int32_t* g_bpNew = NULL;
 static int g_bpShapeCount = 0, g_bpExistingCount = 0, g_bpNewCount = 0;
 static double g_bpSeconds = 0.0;
 
+// ---- narrow phase: state at the end of Stage 2 (the input of the "update contacts" loop,
+// src/world.c:132-168) and at solver entry (its output) ----
+static s2World* g_stepWorld = NULL;
+static s2amdShape* g_npShapes = NULL;
+static s2amdBody* g_npBodies = NULL;
+static float* g_npOrigins = NULL;
+static s2amdPairState *g_npPairsPre = NULL, *g_npPairsPost = NULL;
+static s2amdContact *g_npContactsPre = NULL, *g_npContactsPost = NULL;
+static int g_npShapeCount = 0, g_npBodyCount = 0, g_npContactCount = 0;
+static double g_npSeconds = 0.0;
+static struct timespec g_npStart;
+static int g_npTiming = 0;
+
+static void packPairs(const s2World* world, s2amdPairState* out)
+{
+	int n = world->contactPool.capacity;
+	for (int i = 0; i < n; ++i)
+	{
+		const s2Contact* c = world->contacts + i;
+		s2amdPairState* o = out + i;
+		memset(o, 0, sizeof(*o));
+		if (s2IsFree(&c->object))
+		{
+			o->shapeA = -1, o->shapeB = -1;
+			continue;
+		}
+		o->shapeA = c->shapeIndexA;
+		o->shapeB = c->shapeIndexB;
+		o->cacheMetric = c->cache.metric;
+		o->cacheCount = c->cache.count;
+		for (int k = 0; k < 3; ++k)
+		{
+			o->cacheIndexA[k] = c->cache.indexA[k];
+			o->cacheIndexB[k] = c->cache.indexB[k];
+		}
+		for (int j = 0; j < 2; ++j)
+		{
+			o->id[j] = c->manifold.points[j].id;
+			o->persisted[j] = c->manifold.points[j].persisted ? 1 : 0;
+		}
+	}
+}
+
+void __real_s2BroadPhase_RebuildTrees(s2BroadPhase* bp);
+void __wrap_s2BroadPhase_RebuildTrees(s2BroadPhase* bp)
+{
+	__real_s2BroadPhase_RebuildTrees(bp);
+	s2World* world = g_stepWorld;
+	if (world == NULL || &world->broadPhase != bp)
+	{
+		return;
+	}
+	if (g_mode == 3)
+	{
+		clock_gettime(CLOCK_MONOTONIC, &g_npStart);
+		g_npTiming = 1;
+		return;
+	}
+	if (g_mode != 1)
+	{
+		return;
+	}
+	int ns = world->shapePool.capacity, nb = world->bodyPool.capacity, nc = world->contactPool.capacity;
+	g_npShapes = (s2amdShape*)realloc(g_npShapes, (size_t)(ns > 0 ? ns : 1) * sizeof(s2amdShape));
+	g_npBodies = (s2amdBody*)realloc(g_npBodies, (size_t)(nb > 0 ? nb : 1) * sizeof(s2amdBody));
+	g_npOrigins = (float*)realloc(g_npOrigins, (size_t)(nb > 0 ? nb : 1) * 2 * sizeof(float));
+	g_npPairsPre = (s2amdPairState*)realloc(g_npPairsPre, (size_t)(nc > 0 ? nc : 1) * sizeof(s2amdPairState));
+	g_npPairsPost = (s2amdPairState*)realloc(g_npPairsPost, (size_t)(nc > 0 ? nc : 1) * sizeof(s2amdPairState));
+	g_npContactsPre = (s2amdContact*)realloc(g_npContactsPre, (size_t)(nc > 0 ? nc : 1) * sizeof(s2amdContact));
+	g_npContactsPost = (s2amdContact*)realloc(g_npContactsPost, (size_t)(nc > 0 ? nc : 1) * sizeof(s2amdContact));
+	packShapes(world, g_npShapes);
+	packBodies(world, g_npBodies);
+	for (int i = 0; i < nb; ++i)
+	{
+		g_npOrigins[2 * i] = world->bodies[i].origin.x;
+		g_npOrigins[2 * i + 1] = world->bodies[i].origin.y;
+	}
+	packPairs(world, g_npPairsPre);
+	packContacts(world, g_npContactsPre);
+	g_npShapeCount = ns, g_npBodyCount = nb, g_npContactCount = nc;
+}
+
+// called at solver entry: Stage 3's output
+static void narrowPhaseDone(const s2World* world)
+{
+	if (g_mode == 3 && g_npTiming)
+	{
+		struct timespec t1;
+		clock_gettime(CLOCK_MONOTONIC, &t1);
+		g_npSeconds += (double)(t1.tv_sec - g_npStart.tv_sec) + 1e-9 * (double)(t1.tv_nsec - g_npStart.tv_nsec);
+		g_npTiming = 0;
+	}
+	if (g_mode == 1 && g_npContactCount == world->contactPool.capacity && g_npPairsPost != NULL)
+	{
+		packPairs(world, g_npPairsPost);
+		packContacts(world, g_npContactsPost);
+	}
+}
+
+S2REF_API double s2ref_narrowphase_seconds(int reset)
+{
+	double v = g_npSeconds;
+	if (reset)
+	{
+		g_npSeconds = 0.0;
+	}
+	return v;
+}
+
+S2REF_API int s2ref_narrowphase_capture(const s2amdShape** shapes, int32_t* shapeCount, const s2amdBody** bodies, int32_t* bodyCount,
+										const float** origins, const s2amdPairState** pairsPre, const s2amdContact** contactsPre,
+										const s2amdPairState** pairsPost, const s2amdContact** contactsPost, int32_t* contactCount)
+{
+	*shapes = g_npShapes, *shapeCount = g_npShapeCount, *bodies = g_npBodies, *bodyCount = g_npBodyCount, *origins = g_npOrigins;
+	*pairsPre = g_npPairsPre, *contactsPre = g_npContactsPre, *pairsPost = g_npPairsPost, *contactsPost = g_npContactsPost;
+	*contactCount = g_npContactCount;
+	return 0;
+}
+
 void __real_s2UpdateBroadPhasePairs(s2World* world);
 void __wrap_s2UpdateBroadPhasePairs(s2World* world)
 {
+	g_stepWorld = world;
 	if (g_mode == 3)
 	{
 		struct timespec t0, t1;

@@ -18,7 +18,7 @@ EXPORTS = [
     "s2amd_api_version", "s2amd_device_count", "s2amd_last_error", "s2amd_create", "s2amd_destroy",
     "s2amd_solve", "s2amd_upload", "s2amd_step_resident", "s2amd_download", "s2amd_save_bodies",
     "s2amd_restore_bodies", "s2amd_get_contact_order", "s2amd_get_joint_order", "s2amd_get_stats",
-    "s2amd_set_option", "s2amd_export_poses", "s2amd_measure_dominant", "s2amd_refit_shapes", "s2amd_find_pairs", "s2amd_synchronize",
+    "s2amd_set_option", "s2amd_export_poses", "s2amd_measure_dominant", "s2amd_refit_shapes", "s2amd_find_pairs", "s2amd_synchronize", "s2amd_update_contacts",
 ]
 
 _lib = None
@@ -60,6 +60,7 @@ def load():
                                          ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.s2amd_refit_shapes.argtypes = [vp, vp, i32, vp, i32, vp]
     L.s2amd_find_pairs.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, vp, i32, vp, i32, ctypes.POINTER(i32)]
+    L.s2amd_update_contacts.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, i32, vp]
     if L.s2amd_api_version() != wire.API_VERSION:
         raise S2AmdError("libs2amd.so API version %d != %d" % (L.s2amd_api_version(), wire.API_VERSION))
     _lib = L
@@ -151,6 +152,17 @@ class Solver:
         assert shapes.dtype == wire.shape_dtype and origins.dtype == np.float32 and origins.shape == (len(bodies), 2)
         _check(load().s2amd_refit_shapes(self._h, wire.as_ptr(bodies), len(bodies), wire.as_ptr(shapes), len(shapes), wire.as_ptr(origins)))
         return shapes, origins
+
+    def update_contacts(self, bodies, origins, shapes, pairs, contacts):
+        """Stage 3 of s2World_Step (s2UpdateContact per live contact) on wire arrays, in place; returns status int32[nc]."""
+        assert pairs.dtype == wire.pair_state_dtype and contacts.dtype == wire.contact_dtype and len(pairs) == len(contacts)
+        assert shapes.dtype == wire.shape_dtype
+        origins = np.ascontiguousarray(origins, dtype=np.float32)
+        assert origins.shape == (len(bodies), 2)
+        status = np.zeros(len(contacts), dtype=np.int32)
+        _check(load().s2amd_update_contacts(self._h, wire.as_ptr(bodies), len(bodies), wire.as_ptr(origins), wire.as_ptr(shapes), len(shapes),
+                                            wire.as_ptr(pairs), wire.as_ptr(contacts), len(contacts), wire.as_ptr(status)))
+        return status
 
     def find_pairs(self, bodies, shapes, moved, existing, joints):
         """New broad-phase pairs as int32[n, 2] sorted by (A, B); see s2amd_find_pairs."""

@@ -10,10 +10,12 @@
 
 #include "solver2d/solver2d.h"
 #include "solver2d/geometry.h"
+#include "solver2d/hull.h"
 #include "solver2d/joint_types.h"
 #include "solver2d/math.h"
 #include "solver2d/types.h"
 
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -402,6 +404,82 @@ S2SCENE_API const char* s2scene_name(int index)
 	return s_scenes[index].name;
 }
 
+// Every shape type the narrow phase knows, tumbling into a bowl made of static segments: segments (ground chain),
+// rounded polygons (radius > 0), hulls with 3..8 vertices, circles, capsules.  Public API only.
+static void sceneShapesZoo(s2WorldId w, int count)
+{
+	lcgSeed(4242u);
+	s2ShapeDef sd = s2_defaultShapeDef;
+	sd.density = 1.0f;
+	{
+		s2BodyDef bd = s2_defaultBodyDef;
+		s2BodyId ground = s2CreateBody(w, &bd);
+		const s2Vec2 chain[] = {{-12.0f, 6.0f}, {-8.0f, 1.0f}, {-3.0f, 0.0f}, {3.0f, 0.0f}, {8.0f, 1.5f}, {12.0f, 6.0f}};
+		for (int i = 0; i + 1 < 6; ++i)
+		{
+			s2Segment seg = {chain[i], chain[i + 1]};
+			s2CreateSegmentShape(ground, &sd, &seg);
+		}
+		s2Capsule rail = {{-2.0f, 2.5f}, {2.0f, 3.0f}, 0.2f};
+		s2CreateCapsuleShape(ground, &sd, &rail);
+	}
+	for (int i = 0; i < count; ++i)
+	{
+		s2BodyDef bd = s2_defaultBodyDef;
+		bd.type = s2_dynamicBody;
+		bd.position = (s2Vec2){lcgFloat(-6.0f, 6.0f), 4.0f + 0.7f * (float)(i / 4) + lcgFloat(0.0f, 0.3f)};
+		bd.angle = lcgFloat(-3.0f, 3.0f);
+		bd.angularVelocity = lcgFloat(-2.0f, 2.0f);
+		s2BodyId id = s2CreateBody(w, &bd);
+		sd.friction = 0.1f + 0.15f * (float)(i % 5);
+		switch (i % 5)
+		{
+			case 0:
+			{
+				s2Polygon box = s2MakeBox(lcgFloat(0.2f, 0.5f), lcgFloat(0.2f, 0.5f));
+				box.radius = lcgFloat(0.02f, 0.15f); // rounded
+				s2CreatePolygonShape(id, &sd, &box);
+				break;
+			}
+			case 1:
+			{
+				int n = 3 + (i / 5) % 6; // 3..8 vertices on a squashed circle
+				s2Vec2 pts[8];
+				float rx = lcgFloat(0.3f, 0.6f), ry = lcgFloat(0.2f, 0.5f);
+				for (int k = 0; k < n; ++k)
+				{
+					float a = 2.0f * s2_pi * (float)k / (float)n;
+					pts[k] = (s2Vec2){rx * cosf(a), ry * sinf(a)};
+				}
+				s2Hull hull = s2ComputeHull(pts, n);
+				s2Polygon poly = s2MakePolygon(&hull);
+				s2CreatePolygonShape(id, &sd, &poly);
+				break;
+			}
+			case 2:
+			{
+				s2Circle c = {{lcgFloat(-0.1f, 0.1f), 0.0f}, lcgFloat(0.15f, 0.4f)};
+				s2CreateCircleShape(id, &sd, &c);
+				break;
+			}
+			case 3:
+			{
+				s2Capsule c = {{-0.35f, 0.05f}, {0.35f, -0.05f}, lcgFloat(0.1f, 0.25f)};
+				s2CreateCapsuleShape(id, &sd, &c);
+				break;
+			}
+			default:
+			{
+				s2Polygon box = s2MakeOffsetBox(0.3f, 0.15f, (s2Vec2){0.1f, 0.0f}, 0.4f);
+				s2CreatePolygonShape(id, &sd, &box);
+				s2Circle c = {{-0.35f, 0.0f}, 0.2f}; // second shape on the same body
+				s2CreateCircleShape(id, &sd, &c);
+				break;
+			}
+		}
+	}
+}
+
 // Returns the new world (null id on unknown scene / no free world slot).
 S2SCENE_API s2WorldId s2scene_create(const char* name, int solverType, int p0, int p1)
 {
@@ -441,6 +519,10 @@ S2SCENE_API s2WorldId s2scene_create(const char* name, int solverType, int p0, i
 	else if (strcmp(name, "circle_pile") == 0)
 	{
 		sceneCirclePile(w, p0 > 0 ? p0 : 20);
+	}
+	else if (strcmp(name, "shapes_zoo") == 0)
+	{
+		sceneShapesZoo(w, p0 > 0 ? p0 : 40);
 	}
 	else
 	{

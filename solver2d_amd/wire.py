@@ -53,11 +53,20 @@ u32 = np.uint32
 shape_dtype = np.dtype([
     ("body", i32), ("type", i32), ("categoryBits", u32), ("maskBits", u32), ("groupIndex", i32),
     ("proxyKey", i32), ("enlarged", i32), ("count", i32), ("radius", f32),
-    ("aabb", f32, 4), ("fatAABB", f32, 4), ("vertices", f32, (8, 2)),
+    ("aabb", f32, 4), ("fatAABB", f32, 4), ("vertices", f32, (8, 2)), ("normals", f32, (8, 2)),
 ])
 SHAPE_FREE, SHAPE_CAPSULE, SHAPE_CIRCLE, SHAPE_POLYGON, SHAPE_SEGMENT = -1, 0, 1, 2, 3
 SHAPE_SIZE = shape_dtype.itemsize
-assert SHAPE_SIZE == 132
+assert SHAPE_SIZE == 196
+
+u16, u8 = np.uint16, np.uint8
+pair_state_dtype = np.dtype([
+    ("shapeA", i32), ("shapeB", i32), ("cacheMetric", f32), ("cacheCount", u16), ("id", u16, 2),
+    ("cacheIndexA", u8, 3), ("cacheIndexB", u8, 3), ("persisted", u8, 2), ("pad", u8, 2),
+])
+PAIR_STATE_SIZE = pair_state_dtype.itemsize
+assert PAIR_STATE_SIZE == 28
+PAIR_UPDATED, PAIR_SEPARATED, PAIR_FREE = 0, 1, -1
 
 BODY_SIZE, CONTACT_SIZE, JOINT_SIZE = body_dtype.itemsize, contact_dtype.itemsize, joint_dtype.itemsize
 assert BODY_SIZE == 88 and manifold_point_dtype.itemsize == 60 and CONTACT_SIZE == 152 and JOINT_SIZE == 92

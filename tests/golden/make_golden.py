@@ -64,6 +64,16 @@ def main():
                                         created=created, bodies_solved=post[0], shapes_before=shapes_before,
                                         origins_before=origins_before, shapes_after=shapes_after, origins_after=origins_after)
                     total += os.path.getsize(path)
+    # narrow phase captures: input of Stage 3 (end of Stage 2) and its output (solver entry)
+    for scene, p0, at in (("shapes_zoo", 40, (30, 90, 150)), ("mixed", 24, (40, 100)), ("pyramid", 8, (0, 2, 30)), ("circle_pile", 20, (60,))):
+        with refbind.RefWorld(scene, "TGS_Soft", p0, 0) as world:
+            for step in range(max(at) + 1):
+                world.step_captured(1.0 / 60.0, 4, 2, True)
+                if step in at:
+                    cap = refbind.narrowphase_capture()
+                    path = os.path.join(OUT, "np_%s%d_step%03d.npz" % (scene, p0, step))
+                    np.savez_compressed(path, **cap)
+                    total += os.path.getsize(path)
     print("wrote fixtures, %.1f KiB total" % (total / 1024.0))
 
 

@@ -9,7 +9,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def golden_files():
-    return sorted(f for f in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")) if not os.path.basename(f).startswith("bp_"))
+    return sorted(f for f in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")) if not os.path.basename(f).startswith(("bp_", "np_")))
 
 
 def broadphase_files():
@@ -25,3 +25,7 @@ def load(path):
     post = (z["post_bodies"].copy(), z["post_contacts"].copy(), z["post_joints"].copy())
     assert pre[0].dtype == wire.body_dtype and pre[1].dtype == wire.contact_dtype and pre[2].dtype == wire.joint_dtype
     return params, pre, post
+
+
+def narrowphase_files():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "np_*.npz")))

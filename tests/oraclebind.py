@@ -72,3 +72,15 @@ def find_pairs(bodies, shapes, moved, existing, joints):
         if rc == 0:
             return out[: n.value].copy()
         cap = max(2 * cap, n.value)
+
+
+def update_contacts(bodies, origins, shapes, pairs, contacts):
+    """In-place Stage 3 of s2World_Step (src/world.c:132-168: s2UpdateContact per live contact) on wire arrays;
+    returns status int32[nc] (wire.PAIR_*)."""
+    assert pairs.dtype == wire.pair_state_dtype and contacts.dtype == wire.contact_dtype and len(pairs) == len(contacts)
+    origins = np.ascontiguousarray(origins, dtype=np.float32)
+    status = np.zeros(len(contacts), dtype=np.int32)
+    rc = lib().s2oracle_update_contacts(wire.as_ptr(bodies), len(bodies), wire.as_ptr(origins), wire.as_ptr(shapes), len(shapes),
+                                        wire.as_ptr(pairs), wire.as_ptr(contacts), len(contacts), wire.as_ptr(status))
+    assert rc == 0
+    return status

@@ -198,3 +198,28 @@ def broadphase_capture():
     existing = _copy_array(pe.value, 2 * ne.value, np.dtype(np.int32)).reshape(-1, 2)
     created = _copy_array(pn.value, 2 * nn.value, np.dtype(np.int32)).reshape(-1, 2)
     return shapes, moved, existing, created
+
+
+def narrowphase_capture():
+    """State at the end of Stage 2 of the last captured step (input of the "update contacts" loop) and at solver
+    entry (its output): dict of shapes, bodies, origins, pairs_pre, contacts_pre, pairs_post, contacts_post."""
+    L = lib()
+    p = [ctypes.c_void_p() for _ in range(7)]
+    ns, nb, nc = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    L.s2ref_narrowphase_capture(ctypes.byref(p[0]), ctypes.byref(ns), ctypes.byref(p[1]), ctypes.byref(nb), ctypes.byref(p[2]),
+                                ctypes.byref(p[3]), ctypes.byref(p[4]), ctypes.byref(p[5]), ctypes.byref(p[6]), ctypes.byref(nc))
+    return {
+        "shapes": _copy_array(p[0].value, ns.value, wire.shape_dtype),
+        "bodies": _copy_array(p[1].value, nb.value, wire.body_dtype),
+        "origins": _copy_array(p[2].value, 2 * nb.value, np.dtype(np.float32)).reshape(-1, 2),
+        "pairs_pre": _copy_array(p[3].value, nc.value, wire.pair_state_dtype),
+        "contacts_pre": _copy_array(p[4].value, nc.value, wire.contact_dtype),
+        "pairs_post": _copy_array(p[5].value, nc.value, wire.pair_state_dtype),
+        "contacts_post": _copy_array(p[6].value, nc.value, wire.contact_dtype),
+    }
+
+
+def narrowphase_seconds(reset=False):
+    L = lib()
+    L.s2ref_narrowphase_seconds.restype = ctypes.c_double
+    return L.s2ref_narrowphase_seconds(1 if reset else 0)

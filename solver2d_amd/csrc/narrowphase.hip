@@ -30,6 +30,7 @@
 int s2amdFail(int code, const std::string& msg);
 hipStream_t s2amdStream(s2amdSolver* s);
 int s2amdDevice(s2amdSolver* s);
+void s2amdRecordDeviceMs(s2amdSolver* s, float ms);
 
 namespace
 {
@@ -974,12 +975,22 @@ int s2amd_update_contacts(s2amdSolver* solver, const s2amdBody* bodies, int32_t 
 	NP_TRY(hipMemcpyAsync(dP, pairs, pBytes, hipMemcpyHostToDevice, st));
 	NP_TRY(hipMemcpyAsync(dC, contacts, cBytes, hipMemcpyHostToDevice, st));
 	dim3 grid((unsigned)((contactCapacity + S2_NP_BLOCK - 1) / S2_NP_BLOCK));
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	NP_TRY(hipEventCreate(&e0));
+	NP_TRY(hipEventCreate(&e1));
+	NP_TRY(hipEventRecord(e0, st));
 	updateContactsKernel<<<grid, dim3(S2_NP_BLOCK), 0, st>>>(dB, dO, dS, dP, dC, contactCapacity, dT);
+	NP_TRY(hipEventRecord(e1, st));
 	NP_TRY(hipGetLastError());
 	NP_TRY(hipMemcpyAsync(pairs, dP, pBytes, hipMemcpyDeviceToHost, st));
 	NP_TRY(hipMemcpyAsync(contacts, dC, cBytes, hipMemcpyDeviceToHost, st));
 	NP_TRY(hipMemcpyAsync(status, dT, tBytes, hipMemcpyDeviceToHost, st));
 	NP_TRY(hipStreamSynchronize(st));
+	float ms = 0.0f;
+	(void)hipEventElapsedTime(&ms, e0, e1);
+	s2amdRecordDeviceMs(solver, ms); // kernel only; the call's wall time is dominated by the host <-> device copies
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
 	return S2AMD_OK;
 }
 

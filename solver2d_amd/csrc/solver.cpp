@@ -3386,6 +3386,11 @@ hipStream_t s2amdStream(s2amdSolver* s)
 {
 	return s->stream;
 }
+// kernel time of the last stage call (narrowphase.hip, broadphase.hip report through s2amdStepStats.deviceMs)
+void s2amdRecordDeviceMs(s2amdSolver* s, float ms)
+{
+	s->stats.deviceMs = ms;
+}
 int s2amdDevice(s2amdSolver* s)
 {
 	return s->device;

@@ -94,6 +94,41 @@ def main():
         measure("3: Tumbler %d boxes (captured after settling)" % count, "Jacobi", 4, 2, pre, steps, warm, C, "constraint-iters/s", 5)
         measure("3b: same input, TGS_Soft", "TGS_Soft", 8, 4, pre, max(steps // 4, 5), 3, C, "constraint-iters/s", 3)
     broadphase()
+    narrowphase()
+
+
+def narrowphase():
+    """Stage 3 (s2UpdateContact over every live contact) at BASELINE size: GPU (host arrays in and out; kernel time
+    from HIP events is not separated here) vs the reference's own loop on this host, 1 thread."""
+    if not refbind.available():
+        return
+    L = refbind.lib()
+    with refbind.RefWorld("pyramid", "TGS_Soft", 200, 0) as w:
+        for _ in range(3):
+            w.step_captured(1.0 / 60.0, 8, 4, True)
+        cap = refbind.narrowphase_capture()
+        L.s2ref_set_mode(3)
+        refbind.narrowphase_seconds(True)
+        steps = 5
+        for _ in range(steps):
+            w.step(1.0 / 60.0, 8, 4, True)
+        ref_ms = 1e3 * refbind.narrowphase_seconds(True) / steps
+        L.s2ref_set_mode(0)
+    live = int((cap["pairs_pre"]["shapeA"] >= 0).sum())
+    with hip.Solver(0) as gpu:
+        pairs, contacts = cap["pairs_pre"].copy(), cap["contacts_pre"].copy()
+        gpu.update_contacts(cap["bodies"], cap["origins"], cap["shapes"], pairs, contacts)
+        reps = 10
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            pairs, contacts = cap["pairs_pre"].copy(), cap["contacts_pre"].copy()
+            status = gpu.update_contacts(cap["bodies"], cap["origins"], cap["shapes"], pairs, contacts)
+        gpu_ms = 1e3 * (time.perf_counter() - t0) / reps
+        kernel_ms = gpu.stats()["deviceMs"]
+    ok = bool(np.array_equal(contacts["points"][status == 0].tobytes(), cap["contacts_post"]["points"][status == 0].tobytes()))
+    print(json.dumps({"config": "narrow phase, pyramid base-200 (%d live box-box contacts, step 3)" % live,
+                      "manifolds_equal_reference": ok, "gpu_update_contacts_ms_pcie_inclusive": gpu_ms, "gpu_kernel_ms": kernel_ms,
+                      "reference_update_contacts_ms": ref_ms}), flush=True)
 
 
 def broadphase():

@@ -278,7 +278,7 @@ void sortByColor(const std::vector<int>& ids, const std::vector<int>& color, int
 // Launch batches from colour offsets.  Colours are launched one kernel each; when the colouring
 // has a long run of tiny high colours (a body with dozens of constraints forces one colour per
 // constraint) that run becomes ONE sequential tail batch instead of dozens of launches.
-bool makeBatches(const std::vector<int>& colorOffsets, std::vector<int>& batchOffsets)
+bool makeBatches(const std::vector<int>& colorOffsets, std::vector<int>& batchOffsets, bool allowTail = true)
 {
 	int n = (int)colorOffsets.size() - 1;
 	batchOffsets.clear();
@@ -300,9 +300,9 @@ bool makeBatches(const std::vector<int>& colorOffsets, std::vector<int>& batchOf
 		}
 		tailColor = c;
 	}
-	if (n - tailColor < kMinTailColors)
+	if (n - tailColor < kMinTailColors || (!allowTail && n <= 8))
 	{
-		tailColor = n;
+		tailColor = n; // strip groups with a handful of colours run them as preloaded rounds, however small
 	}
 	for (int c = 0; c <= tailColor; ++c)
 	{
@@ -710,7 +710,7 @@ void colourPart(const std::vector<int>& ids, const std::vector<int>& ea, const s
 		}
 	}
 	std::vector<int> rel;
-	hasTailOut = makeBatches(partOffsets, rel);
+	hasTailOut = makeBatches(partOffsets, rel, !balanced);
 	batchOffsetsOut.clear();
 	for (int r : rel)
 	{
@@ -1613,6 +1613,11 @@ int buildStructure(s2amdSolver* s, int solverType)
 			}
 		}
 
+		if (getenv("S2AMD_DEBUG"))
+		{
+			fprintf(stderr, "[s2amd] strips: %d strips, %d seams, lean A %d B %d, strip joints %d, CUs %d\n", s->hStripA.count(), s->hStripB.count(),
+					(int)s->leanAValid, (int)s->leanBValid, js.stripCount, s->cuCount);
+		}
 		// ---- persistent strip step (strip_kernel.hip: stripStepKernel): per workgroup both seams' remaps, the
 		// import / export lists of the symmetric exchange, warm-start term slots, granule buffers ----
 		s->persistValid = false;

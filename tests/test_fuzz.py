@@ -38,3 +38,90 @@ def test_gpu_equals_oracle_on_random_worlds(seed, groups):
             for warm in (True, False):
                 p = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, warm)
                 gpu_vs_oracle_loose(gpu, p, world, "fuzz seed %d %s warm=%d groups=%d" % (seed, solver_name, warm, groups))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("joints", [0, 6])
+@pytest.mark.parametrize("seed", SEEDS)
+def test_gpu_equals_oracle_on_random_worlds_through_strips(seed, joints):
+    """Random contact graphs (arbitrary degrees, one- and two-point contacts, static / kinematic / massless bodies)
+    cut into tiny strips: the soft solvers take the persistent strip step when the world has no joints, the strip
+    launches or the colour batches otherwise -- every path bit-exact in the reported order."""
+    from solver2d_amd import hip
+    from tests.test_gpu_parity import gpu_vs_oracle_loose
+
+    world = fuzz_worlds.random_world(seed + 100, n_bodies=60 + 9 * seed, n_contacts=140 + 25 * seed, n_joints=joints)
+    with hip.Solver(0) as gpu:
+        gpu.set_option("max_group_bodies", 16)
+        gpu.set_option("strip_min_bodies", 0)
+        gpu.set_option("strip_bodies", 10)
+        for any_solver in (0, 1):
+            gpu.set_option("strips_any_solver", any_solver)
+            for solver_name in (wire.SOLVER_NAMES if any_solver else ["TGS_Soft", "SoftStep", "PGS_Soft"]):
+                vel, pos = common.DEFAULT_ITERS[solver_name]
+                for warm in (True, False):
+                    p = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, warm)
+                    gpu_vs_oracle_loose(gpu, p, world, "fuzz strips seed %d %s warm=%d any=%d" % (seed, solver_name, warm, any_solver))
+
+
+def perturbed_pyramid(seed, base=36):
+    """The pyramid's contact graph (long BFS diameter, degree <= 6: strips and the persistent kernel apply) with
+    randomised numbers: velocities, impulses, anchors, separations, one-point contacts, a few inactive contacts,
+    kinematic and static bodies in the pile."""
+    from solver2d_amd import synthetic
+    rng = np.random.default_rng(1000 + seed)
+    bodies, contacts, joints = common.copy3(synthetic.pyramid(base))
+    nb, nc = len(bodies), len(contacts)
+    bodies["linearVelocity"] += rng.normal(0.0, 0.5, (nb, 2)).astype(np.float32)
+    bodies["angularVelocity"] += rng.normal(0.0, 0.5, nb).astype(np.float32)
+    ang = rng.normal(0.0, 0.05, nb).astype(np.float32)
+    bodies["rot"][:, 0], bodies["rot"][:, 1] = np.sin(ang), np.cos(ang)
+    bodies["linearDamping"] = rng.uniform(0.0, 0.2, nb).astype(np.float32)
+    for i in rng.choice(np.arange(1, nb), size=6, replace=False):
+        bodies["type"][i] = wire.BODY_KINEMATIC if i % 2 else wire.BODY_STATIC
+        bodies["mass"][i] = bodies["invMass"][i] = bodies["I"][i] = bodies["invI"][i] = 0.0
+        if bodies["type"][i] == wire.BODY_STATIC:
+            bodies["linearVelocity"][i] = 0.0
+            bodies["angularVelocity"][i] = 0.0
+    pts = contacts["points"]
+    pts["normalImpulse"] = rng.uniform(0.0, 2.0, pts["normalImpulse"].shape).astype(np.float32)
+    pts["tangentImpulse"] = rng.normal(0.0, 0.3, pts["tangentImpulse"].shape).astype(np.float32)
+    pts["separation"] += rng.normal(0.0, 0.01, pts["separation"].shape).astype(np.float32)
+    pts["localAnchorA"] += rng.normal(0.0, 0.02, pts["localAnchorA"].shape).astype(np.float32)
+    pts["localAnchorB"] += rng.normal(0.0, 0.02, pts["localAnchorB"].shape).astype(np.float32)
+    contacts["friction"] = rng.uniform(0.0, 1.0, nc).astype(np.float32)
+    if seed % 2:
+        one = rng.random(nc) < 0.3
+        contacts["pointCount"][one & (contacts["pointCount"] == 2)] = 1
+        contacts["pointCount"][rng.random(nc) < 0.03] = 0
+    return bodies, contacts, joints
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver_name", ["TGS_Soft", "SoftStep", "PGS_Soft"])
+def test_persistent_strip_step_on_perturbed_pyramids(solver_name):
+    """Even seeds keep every contact two-point (the kernel's POINTS == 2 variant), odd seeds mix one-point and inactive
+    contacts (POINTS == 0); both with kinematic / static bodies inside the pile.  Whatever path a world takes must be
+    bit-exact; most of them must take the persistent kernel (greedy colouring sometimes needs a 7th colour, which
+    sends that world to the multi-launch strip path)."""
+    from solver2d_amd import hip
+    from tests.test_gpu_parity import gpu_vs_oracle_loose
+
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    persistent, two_point, general = 0, 0, 0
+    for seed in SEEDS[:8]:
+        world = perturbed_pyramid(seed)
+        with hip.Solver(0) as gpu:
+            gpu.set_option("max_group_bodies", 256)  # the 666-body pile fits no group; a strip (>= 2 levels of <= 36 bodies) does
+            gpu.set_option("strip_min_bodies", 0)
+            gpu.set_option("strip_bodies", 40 + 20 * (seed % 3))
+            state = world
+            for step in range(2):
+                p = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, step == 0 or seed % 3 != 0)
+                state = gpu_vs_oracle_loose(gpu, p, state, "perturbed pyramid seed %d %s step %d" % (seed, solver_name, step))
+                assert gpu.stats()["stripCount"] > 0
+                if gpu.stats()["persistent"]:
+                    persistent += 1
+                    two_point += seed % 2 == 0
+                    general += seed % 2 == 1
+    assert persistent >= 8 and two_point >= 2 and general >= 2, (persistent, two_point, general)

@@ -453,6 +453,8 @@ struct s2amdSolver
 	int orderSolverClass = -1; // 0 velocity colouring, 1 position colouring
 	bool orderGrouped = false;
 	bool orderStrips = false;
+	int graphAge = 0;		  // steps solved since the constraint graph last changed
+	int optStripPatience = 1; // steps of an unchanged graph before the (more expensive) strip structure is built
 	int optStripsAnySolver = 0; // tests: strips for every solver and with joints (through the generic group interpreter)
 	bool adjValid = false;
 	bool structureDirty = true;
@@ -1029,7 +1031,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 	const bool needAdj = solverType == s2amd_solverJacobi;
 	const bool grouped = s->optGroups != 0 && !needAdj;
 	// strips pay off through the lean / persistent strip kernels, which exist for the soft contact sweeps
-	const bool wantStrips = grouped && s->optStrips != 0 &&
+	const bool wantStrips = grouped && s->optStrips != 0 && s->graphAge >= s->optStripPatience &&
 							(s->optStripsAnySolver != 0 || solverType == s2amd_solverTGS_Soft || solverType == s2amd_solverSoftStep ||
 							 solverType == s2amd_solverPGS_Soft);
 	if (!s->structureDirty && cls == s->orderSolverClass && grouped == s->orderGrouped && wantStrips == s->orderStrips && s->adjValid)
@@ -3072,6 +3074,7 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 	}
 	if (changed)
 	{
+		s->graphAge = 0; // strips wait until the graph has stayed the same for optStripPatience steps
 		s->structureDirty = true;
 	}
 	return S2AMD_OK;
@@ -3316,6 +3319,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 		int kind, warm;
 		s->stats.persistent = (s->dStripA.view.groupCount > 0 && q.persistPlan(kind, warm)) ? 1 : 0;
 	}
+	s->graphAge += 1;
 	if (!async && s->hostError && *s->hostError != 0u)
 	{
 		*s->hostError = 0u;
@@ -3908,6 +3912,10 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	{
 		s->optPersist = value != 0;
 		s->structureDirty = true;
+	}
+	else if (strcmp(key, "strip_patience") == 0)
+	{
+		s->optStripPatience = std::max(0, value);
 	}
 	else if (strcmp(key, "strips_any_solver") == 0)
 	{

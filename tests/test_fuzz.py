@@ -52,6 +52,7 @@ def test_gpu_equals_oracle_on_random_worlds_through_strips(seed, joints):
 
     world = fuzz_worlds.random_world(seed + 100, n_bodies=60 + 9 * seed, n_contacts=140 + 25 * seed, n_joints=joints)
     with hip.Solver(0) as gpu:
+        gpu.set_option("strip_patience", 0)
         gpu.set_option("max_group_bodies", 16)
         gpu.set_option("strip_min_bodies", 0)
         gpu.set_option("strip_bodies", 10)
@@ -112,6 +113,7 @@ def test_persistent_strip_step_on_perturbed_pyramids(solver_name):
     for seed in SEEDS[:8]:
         world = perturbed_pyramid(seed)
         with hip.Solver(0) as gpu:
+            gpu.set_option("strip_patience", 0)
             gpu.set_option("max_group_bodies", 256)  # the 666-body pile fits no group; a strip (>= 2 levels of <= 36 bodies) does
             gpu.set_option("strip_min_bodies", 0)
             gpu.set_option("strip_bodies", 40 + 20 * (seed % 3))

@@ -22,6 +22,7 @@ FILES = golden_util.golden_files()
 def tiny_strips():
     """Forces the strip path on the small golden worlds: no island fits a group, strips of ~12 bodies."""
     s = hip.Solver(0)
+    s.set_option("strip_patience", 0)
     s.set_option("max_group_bodies", 48)
     s.set_option("strip_min_bodies", 0)
     s.set_option("strip_bodies", 12)
@@ -50,6 +51,7 @@ def test_big_pyramid_strips_default_options(solver_name):
     vel, pos = common.DEFAULT_ITERS[solver_name]
     pre = synthetic.pyramid(100)
     with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
         s.set_option("strips_any_solver", 1)
         state = common.copy3(pre)
         for step in range(3):
@@ -66,6 +68,7 @@ def test_default_policy_strips_only_for_the_soft_sweeps(solver_name, expect):
     vel, pos = common.DEFAULT_ITERS[solver_name]
     pre = synthetic.pyramid(100)
     with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
         params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
         state = gpu_vs_oracle(s, params, pre, "pyramid100/%s default" % solver_name)
         assert (s.stats()["stripCount"] > 0) == expect
@@ -83,6 +86,7 @@ def test_lean_strip_kernel_on_off(solver_name, lean):
     vel, pos = common.DEFAULT_ITERS[solver_name]
     pre = synthetic.pyramid(100)
     with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
         s.set_option("strip_lean", lean)
         state = common.copy3(pre)
         for step in range(3):
@@ -99,6 +103,7 @@ def test_persistent_strip_step_on_off(solver_name, persist):
     vel, pos = common.DEFAULT_ITERS[solver_name]
     pre = synthetic.pyramid(100)
     with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
         s.set_option("persist", persist)
         state = common.copy3(pre)
         for step in range(4):
@@ -114,6 +119,7 @@ def test_persistent_strip_step_base_200():
     """BASELINE config 2 itself: 20,101 bodies, 59,900 constraints, one island."""
     pre = synthetic.pyramid(200)
     with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
         params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
         state = gpu_vs_oracle(s, params, pre, "pyramid200 persistent")
         gpu_vs_oracle(s, params, state, "pyramid200 persistent step 2")
@@ -126,6 +132,7 @@ def test_persistent_strip_step_base_200():
 def test_lean_strip_kernel_iteration_shapes(iters, warm, persist):
     pre = synthetic.pyramid(100)
     with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
         s.set_option("persist", persist)
         params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, iters[0], iters[1], warm)
         state = gpu_vs_oracle(s, params, pre, "pyramid100 TGS_Soft %r warm=%r" % (iters, warm))
@@ -136,6 +143,7 @@ def test_jacobi_keeps_the_colour_batch_path():
     vel, pos = common.DEFAULT_ITERS["Jacobi"]
     pre = synthetic.pyramid(100)
     with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
         params = wire.StepParams.make("Jacobi", 1.0 / 60.0, vel, pos, True)
         gpu_vs_oracle(s, params, pre, "pyramid100/Jacobi")
         assert s.stats()["stripCount"] == 0
@@ -145,6 +153,7 @@ def test_jacobi_keeps_the_colour_batch_path():
 def test_strips_on_off_launch_counts(strips):
     pre = synthetic.pyramid(100)
     with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
         s.set_option("strips", strips)
         params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
         gpu_vs_oracle(s, params, pre, "pyramid100 strips=%d" % strips)
@@ -161,6 +170,7 @@ def test_joint_grid_strips(solver_name):
     vel, pos = common.DEFAULT_ITERS[solver_name]
     pre = synthetic.joint_grid(70)
     with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
         s.set_option("strips_any_solver", 1)
         state = common.copy3(pre)
         for step in range(2):
@@ -175,6 +185,24 @@ def test_platform_high_degree_body_in_strips(solver_name):
     vel, pos = common.DEFAULT_ITERS[solver_name]
     pre = synthetic.platform(60, layers=80)
     with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
         s.set_option("strips_any_solver", 1)
         params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
         gpu_vs_oracle(s, params, pre, "platform60x80/%s" % solver_name)
+
+
+def test_strips_wait_until_the_graph_has_settled():
+    """Default policy for the drop-in call: the first solve after a graph change takes the colour-batch path (cheap
+    host structure), the next one with the same graph builds the strips; a graph change starts over."""
+    pre = synthetic.pyramid(100)
+    with hip.Solver(0) as s:
+        params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+        state = gpu_vs_oracle(s, params, pre, "patience step 0")
+        assert s.stats()["stripCount"] == 0
+        state = gpu_vs_oracle(s, params, state, "patience step 1")
+        assert s.stats()["stripCount"] > 0 and s.stats()["persistent"] == 1
+        state[1]["pointCount"][7] = 0  # one contact ends: new graph
+        state = gpu_vs_oracle(s, params, state, "patience step 2")
+        assert s.stats()["stripCount"] == 0
+        gpu_vs_oracle(s, params, state, "patience step 3")
+        assert s.stats()["persistent"] == 1

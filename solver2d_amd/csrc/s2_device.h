@@ -436,7 +436,8 @@ struct GroupTable
 #define S2G_OWNED 0x80000000u
 
 // Strip groups as the lean strip kernel reads them (strip_kernel.hip): one 128-byte descriptor per group
-#define S2_STRIP_ROUNDS 6	   // colour batches a thread preloads
+#define S2_STRIP_ROUNDS 6	   // colour batches a thread preloads (lean launches; the persistent kernel's narrow variant)
+#define S2_STRIP_ROUNDS_MAX 8  // ... its wide variant, for strips whose greedy colouring needs a 7th or 8th colour
 #define S2_STRIP_BODY_CHUNKS 4 // bodies per thread: a group stages at most 4 * 256 bodies
 struct StripDesc
 {
@@ -444,7 +445,7 @@ struct StripDesc
 	int batchCount;
 	int slotBase, slotCount, slotOffBase; // warm start: incident (constraint, side) slots of the owned bodies
 	int pad;
-	int4 batch[S2_STRIP_ROUNDS]; // {begin, end, 0, 0} ranges of k
+	int4 batch[S2_STRIP_ROUNDS_MAX]; // {begin, end, 0, 0} ranges of k
 };
 struct StripOps
 {
@@ -488,6 +489,7 @@ struct PersistView
 	unsigned int* error; // host-visible: set when a hand-off timed out
 	int parityStride; // granules between the two parities of a buffer
 	int allTwoPoints; // every strip constraint has two manifold points
+	int wideRounds;	  // some strip has 7 or 8 interior colour batches: the ROUNDS == 8 kernel variant
 	int ldsRecords;
 	int debugSkip; // timing experiments only (results are wrong): 1 = no hand-offs, 2 = no seam rounds, 4 = no interior rounds
 	unsigned long long* debugTimes; // S2AMD_DEBUG_TIMES: wall_clock64() of one workgroup at kernel start, after the loads, after every op, at the end

@@ -453,6 +453,7 @@ struct s2amdSolver
 	int orderSolverClass = -1; // 0 velocity colouring, 1 position colouring
 	bool orderGrouped = false;
 	bool orderStrips = false;
+	bool stripsRejected = false; // this graph's strip partition fits no strip kernel: colour batches until the graph changes
 	int graphAge = 0;		  // steps solved since the constraint graph last changed
 	int optStripPatience = 1; // steps of an unchanged graph before the (more expensive) strip structure is built
 	int optStripsAnySolver = 0; // tests: strips for every solver and with joints (through the generic group interpreter)
@@ -1031,7 +1032,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 	const bool needAdj = solverType == s2amd_solverJacobi;
 	const bool grouped = s->optGroups != 0 && !needAdj;
 	// strips pay off through the lean / persistent strip kernels, which exist for the soft contact sweeps
-	const bool wantStrips = grouped && s->optStrips != 0 && s->graphAge >= s->optStripPatience &&
+	const bool wantStrips = grouped && s->optStrips != 0 && !s->stripsRejected && s->graphAge >= s->optStripPatience &&
 							(s->optStripsAnySolver != 0 || solverType == s2amd_solverTGS_Soft || solverType == s2amd_solverSoftStep ||
 							 solverType == s2amd_solverPGS_Soft);
 	if (!s->structureDirty && cls == s->orderSolverClass && grouped == s->orderGrouped && wantStrips == s->orderStrips && s->adjValid)
@@ -1516,9 +1517,12 @@ int buildStructure(s2amdSolver* s, int solverType)
 		std::vector<StripDesc> descA, descB;
 		std::vector<int2> slotList;
 		std::vector<int> slotOffsets;
+		int maxRounds = 0;
+		bool persistTablesOk = false;
 		auto describe = [&](const HostGroupTable& t, std::vector<StripDesc>& out, bool withSlots, int& ldsRecords) {
 			bool ok = true;
 			ldsRecords = 0;
+			maxRounds = 0;
 			for (int g = 0; g < t.count() && ok; ++g)
 			{
 				StripDesc d{};
@@ -1526,7 +1530,8 @@ int buildStructure(s2amdSolver* s, int solverType)
 				d.bodyCount = t.bodyOffsets[(size_t)g + 1] - d.bodyBase;
 				int b0 = t.cBatchOffsets[(size_t)g], b1 = t.cBatchOffsets[(size_t)g + 1];
 				d.batchCount = b1 - b0;
-				ok = d.batchCount <= S2_STRIP_ROUNDS && d.bodyCount <= S2_STRIP_BODY_CHUNKS * 256;
+				ok = d.batchCount <= (withSlots ? S2_STRIP_ROUNDS_MAX : S2_STRIP_ROUNDS) && d.bodyCount <= S2_STRIP_BODY_CHUNKS * 256;
+				maxRounds = std::max(maxRounds, d.batchCount);
 				for (int b = b0; b < b1 && ok; ++b)
 				{
 					int4 bt = t.cBatches[(size_t)b];
@@ -1563,6 +1568,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 		};
 		int ldsA = 0, ldsB = 0;
 		bool okA = describe(s->hStripA, descA, true, ldsA);
+		const int maxRoundsA = maxRounds; // <= 8: the persistent kernel's wide variant; <= 6: also the lean launches
 		bool okB = describe(s->hStripB, descB, false, ldsB);
 		// owned bodies must be exactly the seeded prefix in phase A (replicas are never owned there)
 		if (okA)
@@ -1602,7 +1608,8 @@ int buildStructure(s2amdSolver* s, int solverType)
 			s->leanA.slotOffsets = (const int*)(base + bA + bB + bS);
 			s->leanA.groupCount = (int)descA.size();
 			s->leanA.ldsRecords = ldsA;
-			s->leanAValid = true;
+			s->leanAValid = maxRoundsA <= S2_STRIP_ROUNDS;
+			persistTablesOk = okB;
 			if (okB)
 			{
 				s->leanB.descs = (const StripDesc*)(base + bA);
@@ -1623,7 +1630,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 		// ---- persistent strip step (strip_kernel.hip: stripStepKernel): per workgroup both seams' remaps, the
 		// import / export lists of the symmetric exchange, warm-start term slots, granule buffers ----
 		s->persistValid = false;
-		if (s->leanAValid && s->leanBValid && js.stripCount == 0 && s->optPersist && s->hostError != nullptr && s->hStripA.count() <= s->cuCount)
+		if (persistTablesOk && js.stripCount == 0 && s->optPersist && s->hostError != nullptr && s->hStripA.count() <= s->cuCount)
 		{
 			const HostGroupTable& A = s->hStripA;
 			const HostGroupTable& B = s->hStripB;
@@ -1830,6 +1837,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 				pv.parityStride = parityStride;
 				// fresh buffers start from zero tags
 				HIP_TRY(hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, s->stream));
+				pv.wideRounds = maxRoundsA > S2_STRIP_ROUNDS ? 1 : 0;
 				pv.allTwoPoints = 1;
 				for (int k = k0; k < k1; ++k)
 				{
@@ -1863,6 +1871,15 @@ int buildStructure(s2amdSolver* s, int solverType)
 				s->persistValid = true;
 			}
 		}
+	}
+
+	// strips only pay through the strip kernels: when neither the persistent step nor the lean launches can take this
+	// partition (too many colours, a hub body, LDS budget), fall back to the colour-batch structure for this graph
+	if (strips.active && !s->optStripsAnySolver && !s->persistValid && !(s->leanAValid && s->leanBValid))
+	{
+		s->stripsRejected = true;
+		s->structureDirty = true;
+		return buildStructure(s, solverType);
 	}
 
 	// ---- message-passing tables of the global part (see MsgBodies) ----
@@ -3075,6 +3092,7 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 	if (changed)
 	{
 		s->graphAge = 0; // strips wait until the graph has stayed the same for optStripPatience steps
+		s->stripsRejected = false;
 		s->structureDirty = true;
 	}
 	return S2AMD_OK;
@@ -3887,11 +3905,13 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	}
 	else if (strcmp(key, "max_group_bodies") == 0)
 	{
+		s->stripsRejected = false;
 		s->optMaxGroupBodies = std::max(1, std::min(value, 3072));
 		s->structureDirty = true;
 	}
 	else if (strcmp(key, "strips") == 0)
 	{
+		s->stripsRejected = false;
 		s->optStrips = value != 0;
 		s->structureDirty = true;
 	}
@@ -3905,11 +3925,13 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	}
 	else if (strcmp(key, "persist_debug") == 0)
 	{
+		s->stripsRejected = false;
 		s->optPersistDebug = value;
 		s->structureDirty = true;
 	}
 	else if (strcmp(key, "persist") == 0)
 	{
+		s->stripsRejected = false;
 		s->optPersist = value != 0;
 		s->structureDirty = true;
 	}
@@ -3919,21 +3941,25 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	}
 	else if (strcmp(key, "strips_any_solver") == 0)
 	{
+		s->stripsRejected = false;
 		s->optStripsAnySolver = value != 0;
 		s->structureDirty = true;
 	}
 	else if (strcmp(key, "strip_lean") == 0)
 	{
+		s->stripsRejected = false;
 		s->optStripLean = value != 0;
 		s->structureDirty = true;
 	}
 	else if (strcmp(key, "strip_bodies") == 0)
 	{
+		s->stripsRejected = false;
 		s->optStripBodies = std::max(1, value);
 		s->structureDirty = true;
 	}
 	else if (strcmp(key, "strip_min_bodies") == 0)
 	{
+		s->stripsRejected = false;
 		s->optStripMinBodies = std::max(0, value);
 		s->structureDirty = true;
 	}

@@ -449,7 +449,8 @@ template <int KIND, int WARM> S2_DEV SoftRegs<KIND> loadPersist(const ContactVie
 
 // POINTS == 2: the host has checked that every constraint of the strips has two manifold points (box stacks): the
 // sweeps then run without per-point exec masking; POINTS == 0: general.
-template <int KIND, int WARM, int POINTS>
+// ROUNDS: interior colour batches kept in registers (6, or 8 for strips whose colouring needs more).
+template <int KIND, int WARM, int POINTS, int ROUNDS>
 __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView c, BodyView g, StripTableView ta, PersistView pv, const Op* ops, int opCount)
 {
 	extern __shared__ __attribute__((aligned(16))) float4 lds[];
@@ -463,9 +464,9 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 	const StripDesc* da = ta.descs + blockIdx.x;
 	const PersistDesc* pd = pv.descs + blockIdx.x;
 	const int bodyBase = da->bodyBase, nb = da->bodyCount, roundsA = da->batchCount;
-	int4 batchA[S2_STRIP_ROUNDS];
+	int4 batchA[ROUNDS];
 #pragma unroll
-	for (int i = 0; i < S2_STRIP_ROUNDS; ++i)
+	for (int i = 0; i < ROUNDS; ++i)
 	{
 		batchA[i] = da->batch[i];
 	}
@@ -516,10 +517,10 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 	{
 		((int*)lops)[i] = ((const int*)ops)[i];
 	}
-	PersistRegs<KIND, WARM> rA[S2_STRIP_ROUNDS];
-	int kA[S2_STRIP_ROUNDS];
+	PersistRegs<KIND, WARM> rA[ROUNDS];
+	int kA[ROUNDS];
 #pragma unroll
-	for (int i = 0; i < S2_STRIP_ROUNDS; ++i)
+	for (int i = 0; i < ROUNDS; ++i)
 	{
 		kA[i] = -1;
 		if (i < roundsA)
@@ -677,7 +678,7 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 			// the right bits; the copies of the neighbours' bodies are refreshed by the next sweep's exchange
 			// before anything reads them
 #pragma unroll
-			for (int i = 0; i < S2_STRIP_ROUNDS; ++i)
+			for (int i = 0; i < ROUNDS; ++i)
 			{
 				if (i < roundsA)
 				{
@@ -715,7 +716,7 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 		{
 			// ---- interiors ----
 #pragma unroll
-			for (int i = 0; i < S2_STRIP_ROUNDS; ++i)
+			for (int i = 0; i < ROUNDS; ++i)
 			{
 				if (i < roundsA && (pv.debugSkip & 4) == 0)
 				{
@@ -819,7 +820,7 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 		}
 	}
 #pragma unroll
-	for (int i = 0; i < S2_STRIP_ROUNDS; ++i)
+	for (int i = 0; i < ROUNDS; ++i)
 	{
 		if (kA[i] >= 0)
 		{
@@ -859,13 +860,25 @@ template <int KIND, int WARM>
 static void launchStep(hipStream_t s, dim3 grid, size_t lds, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv,
 					   const Op* ops, int opCount)
 {
-	if (pv.allTwoPoints)
+	dim3 block(S2_STRIP_THREADS);
+	if (pv.wideRounds)
 	{
-		stripStepKernel<KIND, WARM, 2><<<grid, dim3(S2_STRIP_THREADS), lds, s>>>(c, g, a, pv, ops, opCount);
+		if (pv.allTwoPoints)
+		{
+			stripStepKernel<KIND, WARM, 2, S2_STRIP_ROUNDS_MAX><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
+		}
+		else
+		{
+			stripStepKernel<KIND, WARM, 0, S2_STRIP_ROUNDS_MAX><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
+		}
+	}
+	else if (pv.allTwoPoints)
+	{
+		stripStepKernel<KIND, WARM, 2, S2_STRIP_ROUNDS><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
 	}
 	else
 	{
-		stripStepKernel<KIND, WARM, 0><<<grid, dim3(S2_STRIP_THREADS), lds, s>>>(c, g, a, pv, ops, opCount);
+		stripStepKernel<KIND, WARM, 0, S2_STRIP_ROUNDS><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
 	}
 }
 
@@ -938,12 +951,12 @@ int stripKernelSetup()
 		(const void*)stripSoftKernel<SOFT_FIXED, WARM_CURRENT>, (const void*)stripSoftKernel<SOFT_FIXED, WARM_FIXED>, (const void*)stripSoftKernel<SOFT_FIXED, -1>,
 	};
 	const void* steps[] = {
-		(const void*)stripStepKernel<SOFT_TGS, WARM_CURRENT, 0>,   (const void*)stripStepKernel<SOFT_TGS, WARM_FIXED, 0>,
-		(const void*)stripStepKernel<SOFT_PGS, WARM_CURRENT, 0>,   (const void*)stripStepKernel<SOFT_PGS, WARM_FIXED, 0>,
-		(const void*)stripStepKernel<SOFT_FIXED, WARM_CURRENT, 0>, (const void*)stripStepKernel<SOFT_FIXED, WARM_FIXED, 0>,
-		(const void*)stripStepKernel<SOFT_TGS, WARM_CURRENT, 2>,   (const void*)stripStepKernel<SOFT_TGS, WARM_FIXED, 2>,
-		(const void*)stripStepKernel<SOFT_PGS, WARM_CURRENT, 2>,   (const void*)stripStepKernel<SOFT_PGS, WARM_FIXED, 2>,
-		(const void*)stripStepKernel<SOFT_FIXED, WARM_CURRENT, 2>, (const void*)stripStepKernel<SOFT_FIXED, WARM_FIXED, 2>,
+#define S2_STEP_VARIANTS(K, W)                                                                                                   \
+	(const void*)stripStepKernel<K, W, 0, S2_STRIP_ROUNDS>, (const void*)stripStepKernel<K, W, 2, S2_STRIP_ROUNDS>,              \
+		(const void*)stripStepKernel<K, W, 0, S2_STRIP_ROUNDS_MAX>, (const void*)stripStepKernel<K, W, 2, S2_STRIP_ROUNDS_MAX>
+		S2_STEP_VARIANTS(SOFT_TGS, WARM_CURRENT),	S2_STEP_VARIANTS(SOFT_TGS, WARM_FIXED),	  S2_STEP_VARIANTS(SOFT_PGS, WARM_CURRENT),
+		S2_STEP_VARIANTS(SOFT_PGS, WARM_FIXED),		S2_STEP_VARIANTS(SOFT_FIXED, WARM_CURRENT), S2_STEP_VARIANTS(SOFT_FIXED, WARM_FIXED),
+#undef S2_STEP_VARIANTS
 	};
 	for (const void* f : steps)
 	{

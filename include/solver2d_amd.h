@@ -277,6 +277,19 @@ typedef struct s2amdPairState
 int s2amd_update_contacts(s2amdSolver* solver, const s2amdBody* bodies, int32_t bodyCapacity, const float* origins, const s2amdShape* shapes,
 						  int32_t shapeCapacity, s2amdPairState* pairs, s2amdContact* contacts, int32_t contactCapacity, int32_t* status);
 
+/* ---- constraint-graph structure on the device (the reference has neither islands nor colours) ----
+ * Islands: connected components over the movable bodies (invMass != 0 or invI != 0) joined by active contacts
+ * (pointCount > 0) and revolute joints; every other live non-static body is an island of its own; static and free
+ * bodies get -1.  Islands are numbered by their lowest body index.  == solver2d_amd/islands.py: find_islands. */
+int s2amd_find_islands(s2amdSolver* solver, const s2amdBody* bodies, int32_t bodyCapacity, const s2amdContact* contacts, int32_t contactCapacity,
+					   const s2amdJoint* joints, int32_t jointCapacity, int32_t* islandOfBody, int32_t* islandCount);
+/* A proper colouring of the active contacts: no two contacts of one colour share a movable body, so one colour is one
+ * race-free parallel batch of a Gauss-Seidel sweep.  Deterministic: the greedy colouring in descending order of the
+ * fixed priority hash fmix32(contact index).  colorOfContact[c] = -1 for inactive slots.  *rounds: Jones-Plassmann
+ * rounds the device needed. */
+int s2amd_color_constraints(s2amdSolver* solver, const s2amdBody* bodies, int32_t bodyCapacity, const s2amdContact* contacts, int32_t contactCapacity,
+							int32_t* colorOfContact, int32_t* colorCount, int32_t* rounds);
+
 /* Multi-GPU exchange: writes one {position.x, position.y, rot.s, rot.c} record per body slot into
  * a DEVICE buffer owned by the caller (e.g. the send buffer of an RCCL all-gather of per-island
  * body arrays).  Returns after the copy has completed on the solver's stream. */

@@ -18,7 +18,7 @@ EXPORTS = [
     "s2amd_api_version", "s2amd_device_count", "s2amd_last_error", "s2amd_create", "s2amd_destroy",
     "s2amd_solve", "s2amd_upload", "s2amd_step_resident", "s2amd_download", "s2amd_save_bodies",
     "s2amd_restore_bodies", "s2amd_get_contact_order", "s2amd_get_joint_order", "s2amd_get_stats",
-    "s2amd_set_option", "s2amd_export_poses", "s2amd_measure_dominant", "s2amd_refit_shapes", "s2amd_find_pairs", "s2amd_synchronize", "s2amd_update_contacts",
+    "s2amd_set_option", "s2amd_export_poses", "s2amd_measure_dominant", "s2amd_refit_shapes", "s2amd_find_pairs", "s2amd_synchronize", "s2amd_update_contacts", "s2amd_find_islands", "s2amd_color_constraints",
 ]
 
 _lib = None
@@ -61,6 +61,8 @@ def load():
     L.s2amd_refit_shapes.argtypes = [vp, vp, i32, vp, i32, vp]
     L.s2amd_find_pairs.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, vp, i32, vp, i32, ctypes.POINTER(i32)]
     L.s2amd_update_contacts.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, i32, vp]
+    L.s2amd_find_islands.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, ctypes.POINTER(i32)]
+    L.s2amd_color_constraints.argtypes = [vp, vp, i32, vp, i32, vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     if L.s2amd_api_version() != wire.API_VERSION:
         raise S2AmdError("libs2amd.so API version %d != %d" % (L.s2amd_api_version(), wire.API_VERSION))
     _lib = L
@@ -163,6 +165,22 @@ class Solver:
         _check(load().s2amd_update_contacts(self._h, wire.as_ptr(bodies), len(bodies), wire.as_ptr(origins), wire.as_ptr(shapes), len(shapes),
                                             wire.as_ptr(pairs), wire.as_ptr(contacts), len(contacts), wire.as_ptr(status)))
         return status
+
+    def find_islands(self, bodies, contacts, joints):
+        """(island_of_body int32[nb], island_count): connected components over the movable bodies, on the device."""
+        island = np.full(len(bodies), -2, dtype=np.int32)
+        n = ctypes.c_int32()
+        _check(load().s2amd_find_islands(self._h, wire.as_ptr(bodies), len(bodies), wire.as_ptr(contacts), len(contacts), wire.as_ptr(joints),
+                                         len(joints), wire.as_ptr(island), ctypes.byref(n)))
+        return island, n.value
+
+    def color_constraints(self, bodies, contacts):
+        """(color_of_contact int32[nc], color_count, rounds): deterministic Jones-Plassmann colouring on the device."""
+        colour = np.full(len(contacts), -2, dtype=np.int32)
+        n, r = ctypes.c_int32(), ctypes.c_int32()
+        _check(load().s2amd_color_constraints(self._h, wire.as_ptr(bodies), len(bodies), wire.as_ptr(contacts), len(contacts), wire.as_ptr(colour),
+                                              ctypes.byref(n), ctypes.byref(r)))
+        return colour, n.value, r.value
 
     def find_pairs(self, bodies, shapes, moved, existing, joints):
         """New broad-phase pairs as int32[n, 2] sorted by (A, B); see s2amd_find_pairs."""

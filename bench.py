@@ -146,6 +146,7 @@ def main():
 
     pose = None
     gathered = None
+    torch = None
     if world > 1:
         import torch
         nb = len(pre[0])
@@ -157,6 +158,8 @@ def main():
         gpu.restore_bodies()
         gpu.step_resident(params)
         if world > 1:
+            # the previous step's all-gather (torch's stream) must be done reading `pose` before it is rewritten
+            torch.cuda.current_stream().synchronize()
             gpu.export_poses(pose.data_ptr(), pose.shape[0])
             dist.all_gather_into_tensor(gathered, pose if backend == "nccl" else pose.cpu())
 

@@ -16,10 +16,31 @@
 // (solve_pgs_ngs_block.c:151-277).  Reads the wire contact + two bodies, writes the SoA record.
 // Embarrassingly parallel: no body is written.
 // ---------------------------------------------------------------------------------------------
+// The launch also carries the other two prologue jobs, which nothing here depends on (poses and write flags are read
+// from the wire bodies and the host flag array, not from the SoA unpack fills): blocks [contactBlocks, +bodyBlocks)
+// unpack the bodies (unpackBodyOne), the rest write manifold.constraintIndex for every contact slot.
 template <int KIND>
 __global__ __launch_bounds__(S2_BLOCK) void prepareContactsKernel(ContactView c, BodyView b, s2amdContact* wire, const s2amdBody* wireBodies,
-																  StepConsts sc, float h, float hertz, int posSolver)
+																  StepConsts sc, float h, float hertz, int posSolver, const uint32_t* hostFlags,
+																  int contactBlocks, int bodyBlocks, float unpackH, int contactCapacity, const int* gatherIndex)
 {
+	if ((int)blockIdx.x >= contactBlocks)
+	{
+		int rest = (int)blockIdx.x - contactBlocks;
+		if (rest < bodyBlocks)
+		{
+			unpackBodyOne(b, wireBodies, hostFlags, sc, unpackH, rest * (int)blockDim.x + (int)threadIdx.x);
+		}
+		else
+		{
+			int slot = (rest - bodyBlocks) * (int)blockDim.x + (int)threadIdx.x;
+			if (slot < contactCapacity)
+			{
+				wire[slot].constraintIndex = gatherIndex[slot];
+			}
+		}
+		return;
+	}
 	int k = blockIdx.x * blockDim.x + threadIdx.x;
 	if (k >= c.count)
 	{
@@ -38,12 +59,12 @@ __global__ __launch_bounds__(S2_BLOCK) void prepareContactsKernel(ContactView c,
 	V2 lcA = v2(wa->localCenter[0], wa->localCenter[1]);
 	V2 lcB = v2(wb->localCenter[0], wb->localCenter[1]);
 
-	GlobalBodies gb0{b.vel, b.dq};
-	BodyPose pA = loadPose(gb0, ia);
-	BodyPose pB = loadPose(gb0, ib);
-	Rot qA = pA.q, qB = pB.q;
+	// rotation and write flags as unpackBodyOne would put them into the SoA (body_ops.h)
+	Rot qA, qB;
+	qA.s = wa->rot[0], qA.c = wa->rot[1];
+	qB.s = wb->rot[0], qB.c = wb->rot[1];
 
-	uint32_t fa = b.flags[ia], fb = b.flags[ib];
+	uint32_t fa = hostFlags[ia], fb = hostFlags[ib];
 	uint32_t wbit = posSolver ? S2F_WRITE_POS : S2F_WRITE_VEL;
 	uint32_t bits = (uint32_t)pointCount;
 	if (fa & wbit)
@@ -484,32 +505,36 @@ static inline dim3 gridFor(int n)
 	} while (0)
 
 void launchPrepareContacts(hipStream_t s, int kind, const ContactView& c, const BodyView& b, s2amdContact* wire, const s2amdBody* wireBodies,
-						   const StepConsts& sc, float h, float hertz, int posSolver)
+						   const StepConsts& sc, float h, float hertz, int posSolver, const uint32_t* hostFlags, bool unpackToo, float unpackH,
+						   int contactCapacity, const int* gatherIndex)
 {
 	if (c.count <= 0)
 	{
 		return;
 	}
-	dim3 g = gridFor(c.count), t(S2_BLOCK);
+	const int contactBlocks = (c.count + S2_BLOCK - 1) / S2_BLOCK;
+	const int bodyBlocks = unpackToo && b.capacity > 0 ? (b.capacity + S2_BLOCK - 1) / S2_BLOCK : 0;
+	const int indexBlocks = unpackToo && gatherIndex && contactCapacity > 0 ? (contactCapacity + S2_BLOCK - 1) / S2_BLOCK : 0;
+	dim3 g((unsigned)(contactBlocks + bodyBlocks + indexBlocks)), t(S2_BLOCK);
 	switch (kind)
 	{
 		case PREP_PGS:
-			prepareContactsKernel<PREP_PGS><<<g, t, 0, s>>>(c, b, wire, wireBodies, sc, h, hertz, posSolver);
+			prepareContactsKernel<PREP_PGS><<<g, t, 0, s>>>(c, b, wire, wireBodies, sc, h, hertz, posSolver, hostFlags, contactBlocks, bodyBlocks, unpackH, contactCapacity, gatherIndex);
 			break;
 		case PREP_SOFT:
-			prepareContactsKernel<PREP_SOFT><<<g, t, 0, s>>>(c, b, wire, wireBodies, sc, h, hertz, posSolver);
+			prepareContactsKernel<PREP_SOFT><<<g, t, 0, s>>>(c, b, wire, wireBodies, sc, h, hertz, posSolver, hostFlags, contactBlocks, bodyBlocks, unpackH, contactCapacity, gatherIndex);
 			break;
 		case PREP_TGS:
-			prepareContactsKernel<PREP_TGS><<<g, t, 0, s>>>(c, b, wire, wireBodies, sc, h, hertz, posSolver);
+			prepareContactsKernel<PREP_TGS><<<g, t, 0, s>>>(c, b, wire, wireBodies, sc, h, hertz, posSolver, hostFlags, contactBlocks, bodyBlocks, unpackH, contactCapacity, gatherIndex);
 			break;
 		case PREP_STICKY:
-			prepareContactsKernel<PREP_STICKY><<<g, t, 0, s>>>(c, b, wire, wireBodies, sc, h, hertz, posSolver);
+			prepareContactsKernel<PREP_STICKY><<<g, t, 0, s>>>(c, b, wire, wireBodies, sc, h, hertz, posSolver, hostFlags, contactBlocks, bodyBlocks, unpackH, contactCapacity, gatherIndex);
 			break;
 		case PREP_XPBD:
-			prepareContactsKernel<PREP_XPBD><<<g, t, 0, s>>>(c, b, wire, wireBodies, sc, h, hertz, posSolver);
+			prepareContactsKernel<PREP_XPBD><<<g, t, 0, s>>>(c, b, wire, wireBodies, sc, h, hertz, posSolver, hostFlags, contactBlocks, bodyBlocks, unpackH, contactCapacity, gatherIndex);
 			break;
 		case PREP_BLOCK:
-			prepareContactsKernel<PREP_BLOCK><<<g, t, 0, s>>>(c, b, wire, wireBodies, sc, h, hertz, posSolver);
+			prepareContactsKernel<PREP_BLOCK><<<g, t, 0, s>>>(c, b, wire, wireBodies, sc, h, hertz, posSolver, hostFlags, contactBlocks, bodyBlocks, unpackH, contactCapacity, gatherIndex);
 			break;
 	}
 }

@@ -74,7 +74,8 @@ enum JointSolveKind
 
 // contacts
 void launchPrepareContacts(hipStream_t s, int kind, const ContactView& c, const BodyView& b, s2amdContact* wire, const s2amdBody* wireBodies,
-						   const StepConsts& sc, float h, float hertz, int posSolver);
+						   const StepConsts& sc, float h, float hertz, int posSolver, const uint32_t* hostFlags, bool unpackToo, float unpackH,
+						   int contactCapacity, const int* gatherIndex);
 void launchWarmStartContacts(hipStream_t s, int kind, const ContactView& c, const BodyView& b, int begin, int end);
 void launchSolveContactsSoft(hipStream_t s, int kind, const ContactView& c, const BodyView& b, int begin, int end, float inv_h, int useBias);
 void launchSolveContactsRigid(hipStream_t s, int kind, const ContactView& c, const BodyView& b, int begin, int end, float inv_h);

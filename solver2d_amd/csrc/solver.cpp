@@ -2890,12 +2890,18 @@ struct Executor
 		{
 			return;
 		}
-		// pre: wire -> SoA
-		launchUnpackBodies(st, s->bv, wireBodies(), (const uint32_t*)s->dBodyFlags.p, p.sc, p.unpackH, wireContacts(), s->contactCapacity, gatherIndex);
-		count();
-		if (p.prepContacts >= 0 && s->cv.count > 0)
+		// pre: wire -> SoA.  With contacts to prepare, ONE launch does the three independent prologue jobs (prepare
+		// contacts, unpack bodies, manifold.constraintIndex); otherwise the unpack launch carries the index.
+		const bool prepares = p.prepContacts >= 0 && s->cv.count > 0;
+		if (prepares)
 		{
-			launchPrepareContacts(st, p.prepContacts, s->cv, s->bv, wireContacts(), wireBodies(), p.sc, p.prepH, p.prepHertz, posSolver);
+			launchPrepareContacts(st, p.prepContacts, s->cv, s->bv, wireContacts(), wireBodies(), p.sc, p.prepH, p.prepHertz, posSolver,
+								  (const uint32_t*)s->dBodyFlags.p, true, p.unpackH, s->contactCapacity, gatherIndex);
+			count();
+		}
+		else
+		{
+			launchUnpackBodies(st, s->bv, wireBodies(), (const uint32_t*)s->dBodyFlags.p, p.sc, p.unpackH, wireContacts(), s->contactCapacity, gatherIndex);
 			count();
 		}
 		if (p.prepJoints >= 0 && s->jv.count > 0)

@@ -206,3 +206,64 @@ def test_strips_wait_until_the_graph_has_settled():
         assert s.stats()["stripCount"] == 0
         gpu_vs_oracle(s, params, state, "patience step 3")
         assert s.stats()["persistent"] == 1
+
+
+def _resident_states(options, steps, checkpoints, base=120, concurrent=None):
+    """Body arrays of a resident base-`base` pyramid after every checkpoint step under `options`."""
+    pre = synthetic.pyramid(base)
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    out = []
+    with hip.Solver(0) as s:
+        for k, v in options.items():
+            s.set_option(k, v)
+        s.set_option("strip_patience", 0)
+        s.upload(*pre)
+        for step in range(1, steps + 1):
+            s.step_resident(params)
+            if concurrent is not None:
+                concurrent()
+            if step in checkpoints:
+                b, c, _j = common.copy3(pre)
+                s.download(b, c, _j)
+                out.append((b.copy(), c["points"].copy()))
+        assert s.stats()["persistent"] == options.get("persist", 1)
+    return out
+
+
+def test_persistent_hand_offs_hold_over_hundreds_of_steps():
+    """The granule hand-offs are a timing-dependent protocol: 400 consecutive resident steps (6,400 exchanges per
+    workgroup pair) through the persistent kernel must give the bits of the multi-launch strip path at every
+    checkpoint -- a stale or torn hand-off would show up as a diverging pile."""
+    checkpoints = {1, 50, 137, 250, 400}
+    a = _resident_states({"persist": 1}, 400, checkpoints)
+    b = _resident_states({"persist": 0}, 400, checkpoints)
+    for i, ((ba, pa), (bb, pb)) in enumerate(zip(a, b)):
+        for f in ("position", "rot", "linearVelocity", "angularVelocity"):
+            assert np.array_equal(ba[f].view(np.uint32), bb[f].view(np.uint32)), "checkpoint %d field %s" % (i, f)
+        assert np.array_equal(pa["normalImpulse"].view(np.uint32), pb["normalImpulse"].view(np.uint32)), "checkpoint %d impulses" % i
+
+
+def test_persistent_kernel_next_to_a_busy_neighbour():
+    """Uneven load: a second solver keeps its own persistent kernel (and its prologue / epilogue launches) in flight
+    on another stream of the same GPU while the first one steps; hand-offs must not depend on having the chip alone."""
+    noisy = hip.Solver(0)
+    try:
+        noisy.set_option("strip_patience", 0)
+        noisy.set_option("async", 1)
+        big = synthetic.pyramid(150)
+        noisy.upload(*big)
+        nparams = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+
+        def poke():
+            noisy.step_resident(nparams)
+            noisy.step_resident(nparams)
+
+        checkpoints = {1, 40, 120}
+        a = _resident_states({"persist": 1}, 120, checkpoints, concurrent=poke)
+        noisy.synchronize()
+        b = _resident_states({"persist": 0}, 120, checkpoints)
+        for i, ((ba, pa), (bb, pb)) in enumerate(zip(a, b)):
+            for f in ("position", "rot", "linearVelocity", "angularVelocity"):
+                assert np.array_equal(ba[f].view(np.uint32), bb[f].view(np.uint32)), "checkpoint %d field %s" % (i, f)
+    finally:
+        noisy.close()

@@ -366,7 +366,8 @@ struct PersistRegs : ImpulsePart,
 	static constexpr bool kArms0 = KIND != SOFT_TGS || WARM == WARM_FIXED;
 	uint32_t idx;	 // ia | ib << 14 | pointCount << 28 | writeA << 30 | writeB << 31
 	float mA, iA, mB, iB, nx, ny, friction;
-	float p0[2], p1[2], p2[2], p3[2];
+	float p0[2], p1[2], p2[2];
+	float p3[KIND == SOFT_PGS ? 2 : 1]; // par.w (the prepare-time separation) is read by the PGS_Soft sweep only
 	float s0, s1, s2;
 };
 
@@ -387,21 +388,29 @@ template <int KIND, int WARM> S2_DEV PersistRegs<KIND, WARM> packPersist(const S
 		{
 			static_cast<ArmsPart<1, true>&>(p).v[j] = r.r0[j];
 		}
-		p.p0[j] = r.par[j].x, p.p1[j] = r.par[j].y, p.p2[j] = r.par[j].z, p.p3[j] = r.par[j].w;
+		p.p0[j] = r.par[j].x, p.p1[j] = r.par[j].y, p.p2[j] = r.par[j].z;
+		if (KIND == SOFT_PGS)
+		{
+			p.p3[KIND == SOFT_PGS ? j : 0] = r.par[j].w;
+		}
 		p.imp[j] = r.imp[j];
 	}
 	p.s0 = r.sf[0].x, p.s1 = r.sf[0].y, p.s2 = r.sf[0].z;
 	return p;
 }
 
-template <int KIND, int WARM> S2_DEV SoftRegs<KIND> unpackPersist(const PersistRegs<KIND, WARM>& p)
+template <int KIND, int WARM> S2_DEV SoftRegs<KIND> unpackPersist(const PersistRegs<KIND, WARM>& p, uint32_t salt = 0u)
 {
 	SoftRegs<KIND> r;
-	r.h.ia = (int)(p.idx & 0x3fffu), r.h.ib = (int)((p.idx >> 14) & 0x3fffu);
-	r.h.pointCount = (int)((p.idx >> 28) & 3u);
-	r.h.writeA = (p.idx & (1u << 30)) != 0, r.h.writeB = (p.idx & (1u << 31)) != 0;
+	// `salt` is an opaque zero produced inside the step loop: without it the compiler hoists the decoding of every
+	// round's indices (and the LDS addresses made from them) out of that loop and pays for it in scratch spills
+	const uint32_t idx = p.idx ^ salt;
+	r.h.ia = (int)(idx & 0x3fffu), r.h.ib = (int)((idx >> 14) & 0x3fffu);
+	r.h.pointCount = (int)((idx >> 28) & 3u);
+	r.h.writeA = (idx & (1u << 30)) != 0, r.h.writeB = (idx & (1u << 31)) != 0;
 	r.h.mA = p.mA, r.h.iA = p.iA, r.h.mB = p.mB, r.h.iB = p.iB;
-	r.h.normal = v2(p.nx, p.ny), r.h.friction = p.friction;
+	// the same for the values whose negations the sweep uses (tangent = (ny, -nx), -normalMass, -tangentMass)
+	r.h.normal = v2(fromBits(asBits(p.nx) ^ salt), p.ny), r.h.friction = p.friction;
 #pragma unroll
 	for (int j = 0; j < 2; ++j)
 	{
@@ -413,7 +422,7 @@ template <int KIND, int WARM> S2_DEV SoftRegs<KIND> unpackPersist(const PersistR
 		{
 			r.r0[j] = static_cast<const ArmsPart<1, true>&>(p).v[j];
 		}
-		r.par[j] = make_float4(p.p0[j], p.p1[j], p.p2[j], p.p3[j]);
+		r.par[j] = make_float4(p.p0[j], fromBits(asBits(p.p1[j]) ^ salt), fromBits(asBits(p.p2[j]) ^ salt), KIND == SOFT_PGS ? p.p3[KIND == SOFT_PGS ? j : 0] : 0.0f);
 		r.sf[j] = make_float4(p.s0, p.s1, p.s2, 0.0f);
 		r.imp[j] = p.imp[j];
 	}
@@ -422,9 +431,9 @@ template <int KIND, int WARM> S2_DEV SoftRegs<KIND> unpackPersist(const PersistR
 
 // one constraint of a sweep, from its resident registers: warm start or soft solve
 template <int KIND, int WARM, int POINTS, class BA>
-S2_DEV void sweepPersist(PersistRegs<KIND, WARM>& p, const ContactView& c, const BA& lb, float inv_h, int useBias, int k)
+S2_DEV void sweepPersist(PersistRegs<KIND, WARM>& p, const ContactView& c, const BA& lb, float inv_h, int useBias, int k, uint32_t salt = 0u)
 {
-	SoftRegs<KIND> r = unpackPersist<KIND, WARM>(p);
+	SoftRegs<KIND> r = unpackPersist<KIND, WARM>(p, salt);
 	solveSoftRegs<KIND, BA, false, POINTS>(r, c, lb, inv_h, useBias, k);
 	p.imp[0] = r.imp[0], p.imp[1] = r.imp[1];
 }
@@ -518,17 +527,19 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 		((int*)lops)[i] = ((const int*)ops)[i];
 	}
 	PersistRegs<KIND, WARM> rA[ROUNDS];
-	int kA[ROUNDS];
+	// the constraint a thread holds in round i is recomputed where needed (batch ranges sit in scalar registers)
+	auto kOfRound = [&](int i) {
+		int k = batchA[i].x + tid;
+		return (i < roundsA && k < batchA[i].y) ? k : -1;
+	};
 #pragma unroll
 	for (int i = 0; i < ROUNDS; ++i)
 	{
-		kA[i] = -1;
 		if (i < roundsA)
 		{
 			int k = batchA[i].x + tid;
 			if (k < batchA[i].y)
 			{
-				kA[i] = k;
 				SoftRegs<KIND> t = loadPersist<KIND, WARM>(c, k);
 				rA[i] = packPersist<KIND, WARM>(t, t.h.ia, t.h.ib);
 			}
@@ -536,10 +547,12 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 	}
 	// seam constraints: round r = left seam's batch r followed by right seam's batch r, dealt to the threads in
 	// two passes (a round holds at most 512 constraints); where an item lives is recomputed, not stored
-	auto seamItem = [&](int r, int pass, int& side, int& k, int& slot) {
+	// `salt`: the opaque zero of the step loop (see unpackPersist) -- keeps these few integer operations inside the loop
+	// instead of 24 hoisted registers
+	auto seamItem = [&](int r, int pass, int& side, int& k, int& slot, uint32_t salt = 0u) {
 		const int n0 = r < roundsB0 ? batchB0[r].y - batchB0[r].x : 0;
 		const int n1 = r < roundsB1 ? batchB1[r].y - batchB1[r].x : 0;
-		const int idx = tid + pass * S2_STRIP_THREADS;
+		const int idx = (int)((uint32_t)(tid + pass * S2_STRIP_THREADS) ^ salt);
 		if (idx < n0)
 		{
 			side = 0, k = batchB0[r].x + idx, slot = k - firstK0;
@@ -614,6 +627,8 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 	for (int oi = 0; oi < opCount && !bad; ++oi)
 	{
 		const Op op = lops[oi];
+		uint32_t salt;
+		asm volatile("s_mov_b32 %0, 0" : "=s"(salt));
 		if (op.code == OP_INTEGRATE_VEL)
 		{
 #pragma unroll
@@ -682,9 +697,9 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 			{
 				if (i < roundsA)
 				{
-					if (kA[i] >= 0)
+					if (kOfRound(i) >= 0)
 					{
-						warmSoftRegs<WARM>(unpackPersist<KIND, WARM>(rA[i]), lb);
+						warmSoftRegs<WARM>(unpackPersist<KIND, WARM>(rA[i], salt), lb);
 					}
 					__syncthreads();
 				}
@@ -696,7 +711,7 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 				for (int pass = 0; pass < 2; ++pass)
 				{
 					int side, k, slot;
-					if (seamItem(i, pass, side, k, slot))
+					if (seamItem(i, pass, side, k, slot, salt))
 					{
 						float4 q[Q];
 #pragma unroll
@@ -720,9 +735,9 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 			{
 				if (i < roundsA && (pv.debugSkip & 4) == 0)
 				{
-					if (kA[i] >= 0)
+					if (kOfRound(i) >= 0)
 					{
-						sweepPersist<KIND, WARM, POINTS>(rA[i], c, lb, op.inv_h, op.useBias, kA[i]);
+						sweepPersist<KIND, WARM, POINTS>(rA[i], c, lb, op.inv_h, op.useBias, kOfRound(i), salt);
 					}
 					__syncthreads();
 				}
@@ -782,7 +797,7 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 				for (int pass = 0; pass < 2; ++pass)
 				{
 					int side, k, slot;
-					if (seamItem(i, pass, side, k, slot))
+					if (seamItem(i, pass, side, k, slot, salt))
 					{
 						float4 q[Q];
 #pragma unroll
@@ -822,9 +837,9 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 #pragma unroll
 	for (int i = 0; i < ROUNDS; ++i)
 	{
-		if (kA[i] >= 0)
+		if (kOfRound(i) >= 0)
 		{
-			storeSoft<KIND>(c, unpackPersist<KIND, WARM>(rA[i]), kA[i]);
+			storeSoft<KIND>(c, unpackPersist<KIND, WARM>(rA[i]), kOfRound(i));
 		}
 	}
 	// the right seam's impulses are stored by this workgroup (its left neighbour of that seam), nobody stores twice

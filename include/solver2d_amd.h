@@ -161,6 +161,7 @@ typedef struct s2amdStepStats
 	int32_t stripCount;        /* strips (BFS level ranges) a big island was cut into: phase A workgroups per sweep */
 	int32_t seamCount;         /* seams between adjacent strips that carry constraints: phase B workgroups per sweep */
 	int32_t persistent;        /* 1 when the strips ran as ONE persistent launch (constraints resident in registers all step) */
+	int32_t persistFallbacks;  /* times a persistent step was abandoned (workgroups not co-resident) and repeated on the multi-launch path */
 } s2amdStepStats;
 
 typedef struct s2amdSolver s2amdSolver;

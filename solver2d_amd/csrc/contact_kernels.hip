@@ -280,8 +280,11 @@ template <int KIND>
 // (packBodyOne); the remaining blocks zero the hand-off buffers of the persistent strip step (strip_kernel.hip: its
 // tags restart at 1 every launch, so the buffers must be clean when the next step starts)
 __global__ __launch_bounds__(S2_BLOCK) void storeImpulsesKernel(ContactView c, s2amdContact* wire, float scale, int contactBlocks, int bodyBlocks,
-																BodyView bodies, s2amdBody* wireBodies, uint4* clear, int clearCount)
+																BodyView bodies, s2amdBody* wireBodies, uint4* clear, int clearCount, const unsigned int* stepFailed)
 {
+	// a persistent step whose hand-offs timed out leaves the wire arrays as they were: the host then repeats the step
+	// on the multi-launch path (solver.cpp: doStep); the hand-off buffers are cleared either way
+	const bool failed = stepFailed != nullptr && *stepFailed != 0u; // a device-memory word, written by the previous launch
 	if ((int)blockIdx.x >= contactBlocks + bodyBlocks)
 	{
 		int i = ((int)blockIdx.x - contactBlocks - bodyBlocks) * (int)blockDim.x + (int)threadIdx.x;
@@ -289,6 +292,10 @@ __global__ __launch_bounds__(S2_BLOCK) void storeImpulsesKernel(ContactView c, s
 		{
 			clear[i] = make_uint4(0u, 0u, 0u, 0u);
 		}
+		return;
+	}
+	if (failed)
+	{
 		return;
 	}
 	if ((int)blockIdx.x >= contactBlocks)
@@ -629,7 +636,7 @@ void launchBlockSolvePosition(hipStream_t s, const ContactView& c, const BodyVie
 }
 
 void launchStoreImpulses(hipStream_t s, int kind, const ContactView& c, s2amdContact* wire, float scale, const BodyView& bodies, s2amdBody* wireBodies,
-						 void* clear, size_t clearBytes)
+						 void* clear, size_t clearBytes, const unsigned int* stepFailed)
 {
 	// bodies == nullptr-capacity: plain store; otherwise the body write-back rides in the same launch
 	const int contactBlocks = c.count > 0 ? (c.count + S2_BLOCK - 1) / S2_BLOCK : 0;
@@ -644,13 +651,13 @@ void launchStoreImpulses(hipStream_t s, int kind, const ContactView& c, s2amdCon
 	switch (kind)
 	{
 		case STORE_SCALED:
-			storeImpulsesKernel<STORE_SCALED><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount);
+			storeImpulsesKernel<STORE_SCALED><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount, stepFailed);
 			break;
 		case STORE_BLOCK:
-			storeImpulsesKernel<STORE_BLOCK><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount);
+			storeImpulsesKernel<STORE_BLOCK><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount, stepFailed);
 			break;
 		default:
-			storeImpulsesKernel<STORE_PLAIN><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount);
+			storeImpulsesKernel<STORE_PLAIN><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount, stepFailed);
 			break;
 	}
 }

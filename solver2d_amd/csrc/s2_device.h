@@ -486,12 +486,15 @@ struct PersistView
 	const int* exportSrc;
 	const int* importIds;
 	unsigned long long* granules;
-	unsigned int* error; // host-visible: set when a hand-off timed out
+	unsigned int* error;	   // host-visible (pinned): set when a hand-off timed out
+	unsigned int* deviceError; // the same flag in device memory: what the step's epilogue launch checks
 	int parityStride; // granules between the two parities of a buffer
 	int allTwoPoints; // every strip constraint has two manifold points
 	int wideRounds;	  // some strip has 7 or 8 interior colour batches: the ROUNDS == 8 kernel variant
 	int ldsRecords;
-	int debugSkip; // timing experiments only (results are wrong): 1 = no hand-offs, 2 = no seam rounds, 4 = no interior rounds
+	int debugSkip; // timing experiments only (results are wrong): 1 = no hand-offs, 2 = no seam rounds, 4 = no interior rounds;
+				   // 8 = fault injection for the fallback test: workgroup 1 never publishes its seam bodies
+	unsigned int spinLimit; // polls before a hand-off is declared dead
 	unsigned long long* debugTimes; // S2AMD_DEBUG_TIMES: wall_clock64() of one workgroup at kernel start, after the loads, after every op, at the end
 };
 

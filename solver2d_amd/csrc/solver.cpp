@@ -441,6 +441,9 @@ struct s2amdSolver
 	size_t granuleBytes = 0;
 	int optPersist = 1;
 	int optPersistDebug = 0;
+	int optPersistSpinLimit = 1 << 21;
+	bool persistFailed = false; // a hand-off timed out once (workgroups not co-resident: a shared GPU): multi-launch strips from then on
+	int persistFallbacks = 0;
 	int cuCount = 0;
 	unsigned int* hostError = nullptr; // pinned, device-visible: a hand-off timed out
 	unsigned long long* hostTimes = nullptr; // S2AMD_DEBUG_TIMES: pinned [256] phase time stamps of one workgroup
@@ -1800,7 +1803,8 @@ int buildStructure(s2amdSolver* s, int solverType)
 				auto bytesOf = [&](size_t n, size_t elem) { return pad(std::max<size_t>(n, 1) * elem); };
 				size_t o0 = 0, o1 = o0 + bytesOf(descs.size(), sizeof(PersistDesc)), o2 = o1 + bytesOf(remap.size(), sizeof(int));
 				size_t o3 = o2 + bytesOf(exportSrc.size(), sizeof(int)), o4 = o3 + bytesOf(importIds.size(), sizeof(int));
-				std::vector<unsigned char> blob(o4, 0);
+				size_t o5 = o4 + 256; // the device-side "hand-off timed out" word
+				std::vector<unsigned char> blob(o5, 0);
 				auto put = [&](size_t at, const void* src, size_t bytes) {
 					if (bytes)
 					{
@@ -1834,6 +1838,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 				unsigned int* devError = nullptr;
 				HIP_TRY(hipHostGetDevicePointer((void**)&devError, s->hostError, 0));
 				pv.error = devError;
+				pv.deviceError = (unsigned int*)(base + o4);
 				pv.parityStride = parityStride;
 				// fresh buffers start from zero tags
 				HIP_TRY(hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, s->stream));
@@ -1850,6 +1855,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 				pv.ldsRecords = ldsRecords;
 				s->persistRecordsWide = ldsRecordsWide;
 				pv.debugSkip = s->optPersistDebug;
+				pv.spinLimit = (unsigned int)s->optPersistSpinLimit;
 				pv.debugTimes = nullptr;
 				if (getenv("S2AMD_DEBUG_TIMES"))
 				{
@@ -2693,7 +2699,7 @@ struct Executor
 	// Can the whole plan run as ONE persistent launch over the strips (strip_kernel.hip: stripStepKernel)?
 	bool persistPlan(int& kind, int& warm) const
 	{
-		if (!s->persistValid || p.ops.size() > 128 || p.solveSweeps > 63) // one hand-off epoch per sweep, 64 per step
+		if (!s->persistValid || s->persistFailed || p.ops.size() > 128 || p.solveSweeps > 63) // one hand-off epoch per sweep, 64 per step
 		{
 			return false;
 		}
@@ -2976,7 +2982,7 @@ struct Executor
 			int kind, warm;
 			const bool usedGranules = s->dStripA.view.groupCount > 0 && persistPlan(kind, warm);
 			launchStoreImpulses(st, p.storeKind, s->cv, wireContacts(), p.storeScale, s->bv, wireBodies(), usedGranules ? s->dGranules.p : nullptr,
-								usedGranules ? s->granuleBytes : 0);
+								usedGranules ? s->granuleBytes : 0, usedGranules ? s->persist.deviceError : nullptr);
 		}
 		count();
 		if (s->jv.count > 0)
@@ -3286,7 +3292,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	{
 		uint64_t key = 1469598103934665603ull;
 		key = fnv(key, params, sizeof(*params));
-		uint64_t gens[4] = {s->layoutGeneration, s->structureGeneration, s->planGeneration, (uint64_t)((q.msg ? 1 : 0) | (s->optBodyWarm ? 2 : 0) | (s->optStripLean ? 4 : 0) | (s->optPersist ? 8 : 0) | (s->optFork ? 16 : 0))};
+		uint64_t gens[4] = {s->layoutGeneration, s->structureGeneration, s->planGeneration, (uint64_t)((q.msg ? 1 : 0) | (s->optBodyWarm ? 2 : 0) | (s->optStripLean ? 4 : 0) | (s->optPersist ? 8 : 0) | (s->optFork ? 16 : 0) | (s->persistFailed ? 32 : 0))};
 		key = fnv(key, gens, sizeof(gens));
 		int sizes[3] = {s->bodyCapacity, s->contactCapacity, s->jointCapacity};
 		key = fnv(key, sizes, sizeof(sizes));
@@ -3343,13 +3349,19 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 		int kind, warm;
 		s->stats.persistent = (s->dStripA.view.groupCount > 0 && q.persistPlan(kind, warm)) ? 1 : 0;
 	}
-	s->graphAge += 1;
+	s->stats.persistFallbacks = s->persistFallbacks;
 	if (!async && s->hostError && *s->hostError != 0u)
 	{
+		// The persistent kernel's workgroups were not all resident (something else occupies the GPU).  Its epilogue saw
+		// the flag and left the wire arrays untouched, so the step is simply repeated on the multi-launch strip path,
+		// which this solver keeps from now on.
 		*s->hostError = 0u;
-		(void)hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, s->stream);
-		return fail(S2AMD_E_DEVICE, "strip hand-off timed out inside the persistent step kernel (workgroups not co-resident?)");
+		(void)hipMemsetAsync(s->persist.deviceError, 0, sizeof(unsigned int), s->stream);
+		s->persistFailed = true;
+		s->persistFallbacks += 1;
+		return doStep(s, params);
 	}
+	s->graphAge += 1;
 	if (q.profile)
 	{
 		float total = 0.0f;
@@ -3928,6 +3940,12 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	else if (strcmp(key, "fork") == 0)
 	{
 		s->optFork = value != 0;
+	}
+	else if (strcmp(key, "persist_spin_limit") == 0)
+	{
+		s->optPersistSpinLimit = std::max(256, value);
+		s->stripsRejected = false;
+		s->structureDirty = true;
 	}
 	else if (strcmp(key, "persist_debug") == 0)
 	{

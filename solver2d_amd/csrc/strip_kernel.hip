@@ -262,7 +262,7 @@ S2_DEV void putGranule(gu64* g, unsigned epoch, float v)
 
 #define S2_PERSIST_SPIN_LIMIT (1u << 21)
 
-template <int N> S2_DEV bool getGranules(gu64* g, unsigned epoch, float (&v)[N], unsigned int* error)
+template <int N> S2_DEV bool getGranules(gu64* g, unsigned epoch, float (&v)[N], unsigned int* error, unsigned int* deviceError, unsigned int spinLimit)
 {
 	for (unsigned spins = 0;; ++spins)
 	{
@@ -280,12 +280,13 @@ template <int N> S2_DEV bool getGranules(gu64* g, unsigned epoch, float (&v)[N],
 		}
 		if ((spins & 255u) == 255u)
 		{
-			if (spins >= S2_PERSIST_SPIN_LIMIT)
+			if (spins >= spinLimit)
 			{
 				__hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				__hip_atomic_store(deviceError, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				return false;
 			}
-			if (__hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
+			if (__hip_atomic_load(deviceError, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
 			{
 				return false;
 			}
@@ -745,13 +746,14 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 			// ---- symmetric exchange of the seam bodies' velocities (poses are replicated by the body stages) ----
 			epoch += 1;
 			const int par = (int)(epoch & 1u) * pv.parityStride;
-			if (tid < nExp0)
+			const bool mute = (pv.debugSkip & 8) != 0 && blockIdx.x == 1; // fault injection: this workgroup stays silent
+			if (tid < nExp0 && !mute)
 			{
 				float4 v = lvel[expIdx[0]];
 				gu64* p = gran + par + out0 + 4 * tid;
 				putGranule(p + 0, epoch, v.x), putGranule(p + 1, epoch, v.y), putGranule(p + 2, epoch, v.z);
 			}
-			if (tid < nExp1)
+			if (tid < nExp1 && !mute)
 			{
 				float4 v = lvel[expIdx[1]];
 				gu64* p = gran + par + out1 + 4 * tid;
@@ -763,7 +765,7 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 				float v[3];
 				if (tid < nImp0)
 				{
-					if (getGranules<3>(gran + par + in0 + 4 * tid, epoch, v, pv.error))
+					if (getGranules<3>(gran + par + in0 + 4 * tid, epoch, v, pv.error, pv.deviceError, pv.spinLimit))
 					{
 						lvel[nb + tid] = make_float4(v[0], v[1], v[2], 0.0f);
 					}
@@ -774,7 +776,7 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 				}
 				if (tid < nImp1)
 				{
-					if (getGranules<3>(gran + par + in1 + 4 * tid, epoch, v, pv.error))
+					if (getGranules<3>(gran + par + in1 + 4 * tid, epoch, v, pv.error, pv.deviceError, pv.spinLimit))
 					{
 						lvel[nb + nImp0 + tid] = make_float4(v[0], v[1], v[2], 0.0f);
 					}

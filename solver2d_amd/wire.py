@@ -98,7 +98,7 @@ class StepStats(ctypes.Structure):
         ("deviceMs", ctypes.c_float), ("solveKernelMs", ctypes.c_float), ("hostPrepMs", ctypes.c_float),
         ("graphReplayed", ctypes.c_int32), ("solveLaunches", ctypes.c_int32),
         ("eventPairOverheadMs", ctypes.c_float), ("groupCount", ctypes.c_int32), ("messagePassing", ctypes.c_int32),
-        ("stripCount", ctypes.c_int32), ("seamCount", ctypes.c_int32), ("persistent", ctypes.c_int32),
+        ("stripCount", ctypes.c_int32), ("seamCount", ctypes.c_int32), ("persistent", ctypes.c_int32), ("persistFallbacks", ctypes.c_int32),
     ]
 
 

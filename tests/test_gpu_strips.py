@@ -267,3 +267,35 @@ def test_persistent_kernel_next_to_a_busy_neighbour():
                 assert np.array_equal(ba[f].view(np.uint32), bb[f].view(np.uint32)), "checkpoint %d field %s" % (i, f)
     finally:
         noisy.close()
+
+
+def test_a_dead_hand_off_falls_back_to_the_multi_launch_path():
+    """Fault injection: workgroup 1 of the persistent kernel never publishes its seam bodies (what a non-resident
+    workgroup looks like to its neighbours).  The polls give up, the epilogue leaves the wire arrays alone, the host
+    repeats the step on the multi-launch strip path -- the caller sees a correct, bit-exact step and a counter."""
+    pre = synthetic.pyramid(100)
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
+        s.set_option("persist_spin_limit", 4096)
+        s.set_option("persist_debug", 8)
+        state = gpu_vs_oracle(s, params, pre, "dead hand-off, step 0")
+        st = s.stats()
+        assert st["persistFallbacks"] == 1 and st["persistent"] == 0 and st["stripCount"] > 0, st
+        # the solver stays on the multi-launch path (no second time-out) and stays exact
+        state = gpu_vs_oracle(s, params, state, "dead hand-off, step 1")
+        assert s.stats()["persistFallbacks"] == 1 and s.stats()["persistent"] == 0
+    # resident stepping: same behaviour
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
+        s.set_option("persist_spin_limit", 4096)
+        s.set_option("persist_debug", 8)
+        s.upload(*pre)
+        s.step_resident(params)
+        assert s.stats()["persistFallbacks"] == 1
+        got = common.copy3(pre)
+        s.download(*got)
+        order, _ = s.contact_order()
+        want = common.copy3(pre)
+        oraclebind.solve(params, *want, contact_order=order)
+        common.compare_exact(got, want, "dead hand-off, resident")

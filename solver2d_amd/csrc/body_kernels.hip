@@ -11,7 +11,7 @@
 // aw = (h*invI)*torque, ld = 1/(1 + h*linearDamping), ad = 1/(1 + h*angularDamping) the update is
 // v = ld * (v + a), w = (w + aw) * ad -- the same fp32 operations in the same order.
 // blocks [0, bodyBlocks): wire bodies -> SoA; further blocks: manifold.constraintIndex of every contact slot
-// (solver.cpp: the pool-order gather index; a field no solver kernel reads)
+// (solver_step.cpp: the pool-order gather index; a field no solver kernel reads)
 __global__ __launch_bounds__(S2_BLOCK) void unpackBodiesKernel(BodyView b, const s2amdBody* wire, const uint32_t* hostFlags, StepConsts sc, float h,
 															   int bodyBlocks, s2amdContact* wireContacts, int contactCapacity, const int* gatherIndex)
 {

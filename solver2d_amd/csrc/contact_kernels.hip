@@ -283,7 +283,7 @@ __global__ __launch_bounds__(S2_BLOCK) void storeImpulsesKernel(ContactView c, s
 																BodyView bodies, s2amdBody* wireBodies, uint4* clear, int clearCount, const unsigned int* stepFailed)
 {
 	// a persistent step whose hand-offs timed out leaves the wire arrays as they were: the host then repeats the step
-	// on the multi-launch path (solver.cpp: doStep); the hand-off buffers are cleared either way
+	// on the multi-launch path (solver_step.cpp: doStep); the hand-off buffers are cleared either way
 	const bool failed = stepFailed != nullptr && *stepFailed != 0u; // a device-memory word, written by the previous launch
 	if ((int)blockIdx.x >= contactBlocks + bodyBlocks)
 	{

@@ -1,0 +1,627 @@
+// The launch sequence of one step: global colour batches, LDS groups, strips (lean launches or the persistent
+// step kernel).  Header-only: used by solver_step.cpp (doStep) and solver.cpp (s2amd_measure_dominant).
+#pragma once
+
+#include "solver_internal.h"
+
+
+// ------------------------------------------------------------------------------------------------
+// execution of a plan
+// ------------------------------------------------------------------------------------------------
+struct Executor
+{
+	s2amdSolver* s;
+	hipStream_t st;
+	const StepPlan& p;
+	int posSolver;
+	bool profile;
+	bool msg = false; // message-passing accessor for the global part
+	bool fork = false; // graph capture: independent kernels go to side streams (parallel graph branches)
+	const int* gatherIndex = nullptr; // manifold.constraintIndex rides in the unpack launch
+
+	hipStream_t branch(int i, int forkEvent)
+	{
+		if (!fork)
+		{
+			return st;
+		}
+		(void)hipEventRecord(s->evFork[forkEvent], st);
+		(void)hipStreamWaitEvent(s->side[i], s->evFork[forkEvent], 0);
+		return s->side[i];
+	}
+	void join(int i, int joinEvent)
+	{
+		if (fork)
+		{
+			(void)hipEventRecord(s->evJoin[joinEvent], s->side[i]);
+			(void)hipStreamWaitEvent(st, s->evJoin[joinEvent], 0);
+		}
+	}
+
+	s2amdContact* wireContacts() const { return (s2amdContact*)s->dContacts.p; }
+	s2amdBody* wireBodies() const { return (s2amdBody*)s->dBodies.p; }
+	s2amdJoint* wireJoints() const { return (s2amdJoint*)s->dJoints.p; }
+	const Op* deviceOps() const { return (const Op*)s->dOps.p; }
+
+	void count(int n = 1) { s->launchCounter += n; }
+
+	void recordEvent()
+	{
+		if (s->sweepEventsUsed == s->sweepEvents.size())
+		{
+			hipEvent_t e;
+			if (hipEventCreate(&e) != hipSuccess)
+			{
+				return;
+			}
+			s->sweepEvents.push_back(e);
+		}
+		(void)hipEventRecord(s->sweepEvents[s->sweepEventsUsed++], st);
+	}
+
+	static bool isSolveSweep(int code)
+	{
+		return code == OP_SOLVE_SOFT || code == OP_SOLVE_RIGID || code == OP_SOLVE_STICKY || code == OP_SOLVE_NGS || code == OP_XPBD_POS ||
+			   code == OP_XPBD_VEL || code == OP_BLOCK_VEL || code == OP_BLOCK_POS;
+	}
+
+	void launchContactBatch(const Op& o, int b, int e)
+	{
+		if (msg)
+		{
+			switch (o.code)
+			{
+				case OP_WARM:
+					launchWarmStartContactsMsg(st, o.kind, s->cv, s->msg, b, e);
+					return;
+				case OP_SOLVE_SOFT:
+					launchSolveContactsSoftMsg(st, o.kind, s->cv, s->msg, b, e, o.inv_h, o.useBias);
+					return;
+				case OP_SOLVE_RIGID:
+					launchSolveContactsRigidMsg(st, o.kind, s->cv, s->msg, b, e, o.inv_h);
+					return;
+				case OP_SOLVE_STICKY:
+					launchSolveContactsStickyMsg(st, s->cv, s->msg, wireContacts(), b, e, o.inv_h, o.useBias);
+					return;
+				default:
+					return; // message mode is only enabled for plans made of the ops above
+			}
+		}
+		switch (o.code)
+		{
+			case OP_WARM:
+				launchWarmStartContacts(st, o.kind, s->cv, s->bv, b, e);
+				break;
+			case OP_SOLVE_SOFT:
+				launchSolveContactsSoft(st, o.kind, s->cv, s->bv, b, e, o.inv_h, o.useBias);
+				break;
+			case OP_SOLVE_RIGID:
+				launchSolveContactsRigid(st, o.kind, s->cv, s->bv, b, e, o.inv_h);
+				break;
+			case OP_SOLVE_STICKY:
+				launchSolveContactsSticky(st, s->cv, s->bv, wireContacts(), b, e, o.inv_h, o.useBias);
+				break;
+			case OP_SOLVE_NGS:
+				launchSolveContactsNGS(st, s->cv, s->bv, b, e);
+				break;
+			case OP_XPBD_POS:
+				launchXpbdContactPositions(st, s->cv, s->bv, b, e, o.h);
+				break;
+			case OP_XPBD_VEL:
+				launchXpbdContactVelocities(st, s->cv, s->bv, b, e, o.h);
+				break;
+			case OP_BLOCK_VEL:
+				launchBlockSolveVelocity(st, s->cv, s->bv, b, e);
+				break;
+			case OP_BLOCK_POS:
+				launchBlockSolvePosition(st, s->cv, s->bv, b, e);
+				break;
+		}
+	}
+
+	// one op of the plan over the GLOBAL part (bodies in HBM): one launch per colour batch
+	void runGlobalOp(int index)
+	{
+		const Op& o = p.ops[(size_t)index];
+		const SweepSet& cs = s->contacts;
+		const SweepSet& js = s->joints;
+		const bool bodies = s->looseBodies > 0;
+		switch (o.code)
+		{
+			case OP_INTEGRATE_VEL:
+				if (bodies)
+				{
+					if (msg)
+					{
+						launchIntegrateVelocitiesMsg(st, s->bv, s->msg);
+					}
+					else
+					{
+						launchIntegrateVelocities(st, s->bv);
+					}
+					count();
+				}
+				return;
+			case OP_INTEGRATE_POS:
+				if (bodies)
+				{
+					if (msg)
+					{
+						launchIntegratePositionsMsg(st, s->bv, s->msg, o.h);
+					}
+					else
+					{
+						launchIntegratePositions(st, s->bv, o.h);
+					}
+					count();
+				}
+				return;
+			case OP_FINALIZE:
+				if (bodies)
+				{
+					if (msg)
+					{
+						launchFinalizePositionsMsg(st, s->bv, s->msg, o.flag);
+					}
+					else
+					{
+						launchFinalizePositions(st, s->bv, o.flag);
+					}
+					count();
+				}
+				return;
+			case OP_XPBD_INTEGRATE:
+				if (bodies)
+				{
+					launchXpbdIntegrate(st, s->bv, o.h);
+					count();
+				}
+				return;
+			case OP_XPBD_PROJECT:
+				if (bodies)
+				{
+					launchXpbdProject(st, s->bv, o.inv_h);
+					count();
+				}
+				return;
+			case OP_JACOBI_APPLY:
+				launchJacobiApply(st, s->bv, s->cv, (const int*)s->dAdjOffsets.p, (const int*)s->dAdjList.p);
+				count();
+				return;
+			case OP_JOINT_SWEEP:
+			{
+				int nb = (int)js.batchOffsets.size() - 1;
+				for (int bi = 0; bi < nb; ++bi)
+				{
+					int b = js.batchOffsets[(size_t)bi], e = js.batchOffsets[(size_t)bi + 1];
+					if (e <= b)
+					{
+						continue;
+					}
+					if (js.hasTail && bi == nb - 1)
+					{
+						launchGroupKernel(st, s->cv, s->jv, s->bv, s->dJointTail.view, deviceOps() + index, 1, p.sc, wireContacts(),
+										  s->dJointTail.maxBodies, 0);
+					}
+					else
+					{
+						launchSolveJoints(st, o.kind, s->jv, s->bv, b, e, p.sc, o.h, o.inv_h, o.useBias);
+					}
+					count();
+				}
+				return;
+			}
+			default:
+				break;
+		}
+		// contact sweeps
+		if (o.code == OP_SOLVE_SOFT && o.kind == SOFT_JACOBI)
+		{
+			// the Jacobi pass writes per-constraint deltas, never a body: one launch for all colours
+			if (cs.globalCount > 0)
+			{
+				if (profile)
+				{
+					recordEvent();
+				}
+				launchSolveContactsSoft(st, o.kind, s->cv, s->bv, 0, cs.globalCount, o.inv_h, o.useBias);
+				if (profile)
+				{
+					recordEvent();
+				}
+				count();
+			}
+			return;
+		}
+		int nb = (int)cs.batchOffsets.size() - 1;
+		for (int bi = 0; bi < nb; ++bi)
+		{
+			int b = cs.batchOffsets[(size_t)bi], e = cs.batchOffsets[(size_t)bi + 1];
+			if (e <= b)
+			{
+				continue;
+			}
+			const bool timed = profile && isSolveSweep(o.code);
+			if (timed)
+			{
+				recordEvent();
+			}
+			if (cs.hasTail && bi == nb - 1)
+			{
+				launchGroupKernel(st, s->cv, s->jv, s->bv, s->dContactTail.view, deviceOps() + index, 1, p.sc, wireContacts(),
+								  s->dContactTail.maxBodies, 0);
+			}
+			else
+			{
+				launchContactBatch(o, b, e);
+			}
+			if (timed)
+			{
+				recordEvent();
+			}
+			count();
+		}
+	}
+
+	static bool isBodyOp(int code)
+	{
+		return code == OP_INTEGRATE_VEL || code == OP_INTEGRATE_POS || code == OP_FINALIZE || code == OP_XPBD_INTEGRATE || code == OP_XPBD_PROJECT;
+	}
+
+	void launchStripGroups(const DeviceGroupTable& t, int first, int n, bool timed)
+	{
+		if (timed)
+		{
+			recordEvent();
+		}
+		launchStripKernel(st, s->cv, s->jv, s->bv, t.view, deviceOps() + first, n, p.sc, wireContacts(), t.maxBodies, p.usesDq0 ? 1 : 0);
+		if (timed)
+		{
+			recordEvent();
+		}
+		count();
+	}
+
+	static bool leanSoftKind(const Op& o) { return o.code == OP_SOLVE_SOFT && (o.kind == SOFT_TGS || o.kind == SOFT_PGS || o.kind == SOFT_FIXED); }
+
+	bool sweepsNothing(const Op& o) const
+	{
+		if (isBodyOp(o.code))
+		{
+			return false;
+		}
+		return (o.code == OP_JOINT_SWEEP ? s->joints.stripCount : s->contacts.stripCount) == 0;
+	}
+
+	// Can ops [first, sweep) ride in front of the soft sweep `sweep` inside ONE lean strip launch?  Allowed, in
+	// this order: integrate positions, integrate velocities, contact warm start (body-centric).
+	bool leanSegment(int first, int sweep, StripOps& out, int& warm) const
+	{
+		if (!s->leanAValid || !leanSoftKind(p.ops[(size_t)sweep]))
+		{
+			return false;
+		}
+		out = StripOps{};
+		warm = -1;
+		int stage = 0;
+		for (int i = first; i < sweep; ++i)
+		{
+			const Op& o = p.ops[(size_t)i];
+			if (o.code == OP_INTEGRATE_POS && stage < 1)
+			{
+				out.integratePos = 1, out.posH = o.h, stage = 1;
+			}
+			else if (o.code == OP_INTEGRATE_VEL && stage < 2)
+			{
+				out.integrateVel = 1, stage = 2;
+			}
+			else if (o.code == OP_WARM && stage < 3 && s->optBodyWarm && (o.kind == WARM_CURRENT || o.kind == WARM_FIXED))
+			{
+				warm = o.kind, stage = 3;
+			}
+			else if (!sweepsNothing(o))
+			{
+				return false;
+			}
+		}
+		const Op& w = p.ops[(size_t)sweep];
+		out.sweep = 1, out.useBias = w.useBias, out.inv_h = w.inv_h;
+		return true;
+	}
+
+	// Can the whole plan run as ONE persistent launch over the strips (strip_kernel.hip: stripStepKernel)?
+	bool persistPlan(int& kind, int& warm) const
+	{
+		if (!s->persistValid || s->persistFailed || p.ops.size() > 128 || p.solveSweeps > 63) // one hand-off epoch per sweep, 64 per step
+		{
+			return false;
+		}
+		kind = -1, warm = -1;
+		for (const Op& o : p.ops)
+		{
+			if (o.code == OP_INTEGRATE_VEL || o.code == OP_INTEGRATE_POS || o.code == OP_FINALIZE)
+			{
+				continue;
+			}
+			if (o.code == OP_JOINT_SWEEP && s->joints.stripCount == 0)
+			{
+				continue;
+			}
+			if (o.code == OP_WARM && (o.kind == WARM_CURRENT || o.kind == WARM_FIXED) && (warm < 0 || warm == o.kind))
+			{
+				warm = o.kind;
+				continue;
+			}
+			if (leanSoftKind(o) && (kind < 0 || kind == o.kind))
+			{
+				kind = o.kind;
+				continue;
+			}
+			return false;
+		}
+		if (kind < 0)
+		{
+			return false;
+		}
+		if (warm < 0)
+		{
+			warm = kind == SOFT_FIXED ? WARM_FIXED : WARM_CURRENT;
+		}
+		const bool narrow = kind == SOFT_TGS && warm == WARM_CURRENT;
+		const int records = (narrow ? s->persist.ldsRecords : s->persistRecordsWide) + 2 * (int)p.ops.size();
+		return records <= (160 * 1024) / 16;
+	}
+
+	// the plan without the sweeps that have nothing to sweep in the strips (joint sweeps of a contact-only island)
+	int uploadPersistOps()
+	{
+		if (s->persistOpsGeneration == s->planGeneration && s->persistOpsStructure == s->structureGeneration)
+		{
+			return 0;
+		}
+		std::vector<Op> kept;
+		for (const Op& o : p.ops)
+		{
+			if (!sweepsNothing(o))
+			{
+				kept.push_back(o);
+			}
+		}
+		bool grew = false;
+		int rc = s->dPersistOps.ensure(std::max<size_t>(kept.size(), 1) * sizeof(Op), &grew);
+		if (rc)
+		{
+			return rc;
+		}
+		if (grew)
+		{
+			s->layoutGeneration += 1;
+		}
+		if (hipMemcpyAsync(s->dPersistOps.p, kept.data(), kept.size() * sizeof(Op), hipMemcpyHostToDevice, st) != hipSuccess ||
+			hipStreamSynchronize(st) != hipSuccess)
+		{
+			return S2AMD_E_DEVICE;
+		}
+		s->persistOpCount = (int)kept.size();
+		s->persistOpsGeneration = s->planGeneration;
+		s->persistOpsStructure = s->structureGeneration;
+		return 0;
+	}
+
+	void clearGranules(hipStream_t where)
+	{
+		(void)hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, where); // epochs restart at 1 every launch
+		count();
+	}
+
+	void runPersistent(int kind, int warm, bool clearFirst = false)
+	{
+		// hand-off tags are the exchange number; the step's epilogue kernel leaves the buffers zeroed for the next
+		// step, so they only need clearing when this launch is replayed on its own (s2amd_measure_dominant)
+		if (clearFirst)
+		{
+			clearGranules(st);
+		}
+		if (profile)
+		{
+			recordEvent();
+		}
+		PersistView pv = s->persist;
+		if (!(kind == SOFT_TGS && warm == WARM_CURRENT))
+		{
+			pv.ldsRecords = s->persistRecordsWide;
+		}
+		launchStripStep(st, kind, warm, s->cv, s->bv, s->leanA, pv, (const Op*)s->dPersistOps.p, s->persistOpCount);
+		if (profile)
+		{
+			recordEvent();
+		}
+		count();
+	}
+
+	// the plan over the strips: body ops ride with the next sweep's phase A launch; every sweep is
+	// phase A (interiors, all strips) then phase B (seams)
+	void runStrips()
+	{
+		int kind, warm;
+		if (persistPlan(kind, warm))
+		{
+			runPersistent(kind, warm);
+			return;
+		}
+		const int n = (int)p.ops.size();
+		int segStart = 0;
+		for (int i = 0; i < n; ++i)
+		{
+			const Op& o = p.ops[(size_t)i];
+			if (isBodyOp(o.code) || sweepsNothing(o))
+			{
+				continue; // a body op rides along; a sweep over nothing is a no-op wherever it lands
+			}
+			StripOps lean;
+			int warm = -1;
+			if (o.code == OP_WARM)
+			{
+				// folded into the lean launch of the next sweep when that launch can take it
+				int j = i + 1;
+				while (j < n && (isBodyOp(p.ops[(size_t)j].code) || sweepsNothing(p.ops[(size_t)j])))
+				{
+					j += 1;
+				}
+				if (j < n && leanSegment(segStart, j, lean, warm) && warm >= 0)
+				{
+					continue;
+				}
+			}
+			const bool joint = o.code == OP_JOINT_SWEEP;
+			const bool timed = profile && isSolveSweep(o.code);
+			const bool seam = (joint ? s->joints.seamCount : s->contacts.seamCount) > 0;
+			if (leanSegment(segStart, i, lean, warm))
+			{
+				if (timed)
+				{
+					recordEvent();
+				}
+				launchStripSoft(st, o.kind, warm, s->cv, s->bv, s->leanA, lean);
+				if (timed)
+				{
+					recordEvent();
+				}
+				count();
+			}
+			else
+			{
+				launchStripGroups(s->dStripA, segStart, i + 1 - segStart, timed);
+			}
+			if (seam)
+			{
+				if (s->leanBValid && leanSoftKind(o))
+				{
+					StripOps only{};
+					only.sweep = 1, only.useBias = o.useBias, only.inv_h = o.inv_h;
+					if (timed)
+					{
+						recordEvent();
+					}
+					launchStripSoft(st, o.kind, -1, s->cv, s->bv, s->leanB, only);
+					if (timed)
+					{
+						recordEvent();
+					}
+					count();
+				}
+				else
+				{
+					launchStripGroups(s->dStripB, i, 1, timed);
+				}
+			}
+			segStart = i + 1;
+		}
+		if (segStart < n)
+		{
+			launchStripGroups(s->dStripA, segStart, n - segStart, false);
+		}
+	}
+
+	void run()
+	{
+		if (p.earlyOut)
+		{
+			return;
+		}
+		// pre: wire -> SoA.  With contacts to prepare, ONE launch does the three independent prologue jobs (prepare
+		// contacts, unpack bodies, manifold.constraintIndex); otherwise the unpack launch carries the index.
+		const bool prepares = p.prepContacts >= 0 && s->cv.count > 0;
+		if (prepares)
+		{
+			launchPrepareContacts(st, p.prepContacts, s->cv, s->bv, wireContacts(), wireBodies(), p.sc, p.prepH, p.prepHertz, posSolver,
+								  (const uint32_t*)s->dBodyFlags.p, true, p.unpackH, s->contactCapacity, gatherIndex);
+			count();
+		}
+		else
+		{
+			launchUnpackBodies(st, s->bv, wireBodies(), (const uint32_t*)s->dBodyFlags.p, p.sc, p.unpackH, wireContacts(), s->contactCapacity, gatherIndex);
+			count();
+		}
+		if (p.prepJoints >= 0 && s->jv.count > 0)
+		{
+			launchPrepareJoints(st, p.prepJoints, s->jv, s->bv, wireJoints(), wireBodies(), p.sc, p.jprepH, p.jprepHertz, p.jprepWarm, posSolver);
+			count();
+		}
+		if (msg)
+		{
+			launchFillMessageSlots(st, s->cv, s->bv, s->msg, s->contacts.globalCount);
+			count();
+		}
+		// LDS groups: the whole op list in one launch
+		if (s->dGroups.view.groupCount > 0)
+		{
+			launchGroupKernel(st, s->cv, s->jv, s->bv, s->dGroups.view, deviceOps(), (int)p.ops.size(), p.sc, wireContacts(), s->dGroups.maxBodies,
+							  p.usesDq0 ? 1 : 0);
+			count();
+		}
+		if (s->dStripA.view.groupCount > 0)
+		{
+			runStrips();
+		}
+		// global part: op by op
+		const bool anyGlobal = s->looseBodies > 0 || s->contacts.globalCount > 0 || s->joints.globalCount > 0;
+		if (anyGlobal)
+		{
+			const int n = (int)p.ops.size();
+			std::vector<uint8_t> done((size_t)n, 0);
+			for (int i = 0; i < n; ++i)
+			{
+				if (done[(size_t)i])
+				{
+					continue;
+				}
+				const Op& o = p.ops[(size_t)i];
+				// contact warm start as ONE body-centric launch; an immediately preceding integrate-velocities
+				// (joint sweeps in between only when there are no global joints) rides along in the same kernel
+				if (!msg && s->optBodyWarm && s->contacts.globalCount > 0 && (o.code == OP_WARM || o.code == OP_INTEGRATE_VEL))
+				{
+					int w = i;
+					if (o.code == OP_INTEGRATE_VEL)
+					{
+						w = i + 1;
+						while (w < n && p.ops[(size_t)w].code == OP_JOINT_SWEEP && s->joints.globalCount == 0)
+						{
+							w += 1;
+						}
+					}
+					if (w < n && p.ops[(size_t)w].code == OP_WARM)
+					{
+						launchWarmStartBodies(st, p.ops[(size_t)w].kind, s->cv, s->bv, (const int*)s->dAdjOffsets.p, (const int*)s->dAdjList.p,
+											  o.code == OP_INTEGRATE_VEL ? 1 : 0);
+						count();
+						for (int d = i; d <= w; ++d)
+						{
+							done[(size_t)d] = 1;
+						}
+						continue;
+					}
+				}
+				runGlobalOp(i);
+			}
+		}
+		if (msg)
+		{
+			launchGatherMessageSlots(st, s->bv, s->msg);
+			count();
+		}
+		// post: SoA -> wire: impulses and bodies in one launch (+ the epoch base of the hand-off tags)
+		{
+			int kind, warm;
+			const bool usedGranules = s->dStripA.view.groupCount > 0 && persistPlan(kind, warm);
+			launchStoreImpulses(st, p.storeKind, s->cv, wireContacts(), p.storeScale, s->bv, wireBodies(), usedGranules ? s->dGranules.p : nullptr,
+								usedGranules ? s->granuleBytes : 0, usedGranules ? s->persist.deviceError : nullptr);
+		}
+		count();
+		if (s->jv.count > 0)
+		{
+			launchStoreJoints(st, s->jv, wireJoints());
+			count();
+		}
+	}
+};

@@ -1,0 +1,261 @@
+// Internal declarations shared by the host-side translation units of libs2amd.so:
+//   solver.cpp            the C-ABI entry points (include/solver2d_amd.h)
+//   solver_step.cpp       upload / step / download: shadows, hipGraph capture and replay, timing
+//   solver_executor.h     the launch sequence of one step (global path, LDS groups, strips, persistent step)
+//   solver_plan.cpp       the ten reference drivers as lists of Ops
+//   solver_structure.cpp  islands, groups, strips, colour batches and their device tables
+//   graph_coloring.cpp    greedy colouring, batch formation
+#pragma once
+
+#include "launch.h"
+#include "s2_device.h"
+
+#include "solver2d_amd.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// sets the thread's last error text and returns `code` (solver.cpp)
+int s2amdFail(int code, const std::string& msg);
+inline int fail(int code, const std::string& msg) { return s2amdFail(code, msg); }
+
+#define HIP_TRY(expr)                                                                                                            \
+	do                                                                                                                           \
+	{                                                                                                                            \
+		hipError_t _e = (expr);                                                                                                  \
+		if (_e != hipSuccess)                                                                                                    \
+		{                                                                                                                        \
+			return fail(S2AMD_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));                                     \
+		}                                                                                                                        \
+	} while (0)
+
+double nowMs();
+
+// growable raw device allocation
+struct DevBuf
+{
+	void* p = nullptr;
+	size_t bytes = 0;
+
+	int ensure(size_t need, bool* grew = nullptr)
+	{
+		if (need <= bytes)
+		{
+			return S2AMD_OK;
+		}
+		size_t want = std::max(need, bytes + bytes / 2);
+		want = (want + 255) & ~size_t(255);
+		void* np = nullptr;
+		HIP_TRY(hipMalloc(&np, want));
+		if (p)
+		{
+			(void)hipFree(p);
+		}
+		p = np;
+		bytes = want;
+		if (grew)
+		{
+			*grew = true;
+		}
+		return S2AMD_OK;
+	}
+	void release()
+	{
+		if (p)
+		{
+			(void)hipFree(p);
+		}
+		p = nullptr;
+		bytes = 0;
+	}
+};
+
+
+bool isPositionSolver(int type);
+bool rotIsFixedPoint(float s, float c);
+int colorGraph(const std::vector<int>& ea, const std::vector<int>& eb, const std::vector<uint8_t>& conflict, int bodyCount,
+			   std::vector<int>& color, bool balanced = false);
+void sortByColor(const std::vector<int>& ids, const std::vector<int>& color, int colorCount, std::vector<int>& order, std::vector<int>& offsets);
+bool makeBatches(const std::vector<int>& colorOffsets, std::vector<int>& batchOffsets, bool allowTail = true);
+uint64_t fnv(uint64_t h, const void* data, size_t n);
+
+// One sweepable family (contacts or joints): order, colour batches, LDS groups
+struct SweepSet
+{
+	std::vector<int> order;		   // k -> wire index (global part first, then group by group)
+	std::vector<int> colorOffsets; // every (part, colour) batch as a range of k: API + validity tests
+	// global part: launch batches (parallel colours, then optionally one sequential tail)
+	std::vector<int> batchOffsets;
+	bool hasTail = false;
+	int globalCount = 0;
+	int stripCount = 0;		 // constraints that live in strip groups (phase A interiors + phase B seams)
+	int seamCount = 0;		 // ... of which seams
+	std::vector<int2> local; // k -> group-local body slots (groups and the global tail)
+};
+
+struct HostGroupTable
+{
+	std::vector<int> bodyOffsets{0}, bodyIds, cBatchOffsets{0}, jBatchOffsets{0};
+	std::vector<int4> cBatches, jBatches;
+	int maxBodies = 0;
+	int count() const { return (int)bodyOffsets.size() - 1; }
+	void clear()
+	{
+		bodyOffsets.assign(1, 0);
+		cBatchOffsets.assign(1, 0);
+		jBatchOffsets.assign(1, 0);
+		bodyIds.clear();
+		cBatches.clear();
+		jBatches.clear();
+		maxBodies = 0;
+	}
+};
+
+struct DeviceGroupTable
+{
+	DevBuf buf;
+	GroupTable view{};
+	int maxBodies = 0;
+};
+
+// The launch sequence of one s2Solve_* driver, recorded once per parameter set
+struct StepPlan
+{
+	bool valid = false;
+	s2amdStepParams params{};
+	StepConsts sc{};
+	bool earlyOut = false;
+	float unpackH = 0.0f;
+	int prepContacts = -1;
+	float prepH = 0.0f, prepHertz = 0.0f;
+	int prepJoints = -1;
+	float jprepH = 0.0f, jprepHertz = 0.0f;
+	int jprepWarm = 0;
+	std::vector<Op> ops;
+	int storeKind = STORE_PLAIN;
+	float storeScale = 0.0f;
+	int solveSweeps = 0;
+	bool usesDq0 = false;
+};
+
+struct s2amdSolver
+{
+	int device = 0;
+	hipStream_t stream = nullptr;
+	hipEvent_t evBegin = nullptr, evEnd = nullptr;
+	// side streams: independent prologue / epilogue kernels become parallel branches of the captured graph
+	hipStream_t side[2] = {nullptr, nullptr};
+	hipEvent_t evFork[2] = {nullptr, nullptr}, evJoin[4] = {nullptr, nullptr, nullptr, nullptr};
+	int optAsync = 0; // s2amd_step_resident returns after enqueueing; s2amd_synchronize collects errors
+	bool constraintIndexInPrologue = false;
+	int optFork = 0; // measured slower on MI355X (multi-branch graph replay costs more than the serial kernels): off
+
+	// wire arrays resident on the device
+	DevBuf dBodies, dContacts, dJoints, dBodiesSaved;
+	int bodyCapacity = 0, contactCapacity = 0, jointCapacity = 0;
+	bool resident = false;
+	bool savedValid = false;
+
+	// host shadows of the graph structure (refreshed by every upload)
+	std::vector<int> hContactA, hContactB, hContactPoints;
+	std::vector<int> hJointType, hJointA, hJointB;
+	std::vector<uint32_t> hBodyFlags; // S2F_WRITE_VEL / S2F_WRITE_POS from the wire bodies
+	std::vector<uint8_t> hBodyLive, hBodyStatic;
+	DevBuf dBodyFlags;
+
+	// working SoA
+	DevBuf soaBodies, soaContacts, soaJoints, dContactIndex, dJointIndex, dContactLocal, dJointLocal, dAdjOffsets, dAdjList, dOps;
+	BodyView bv{};
+	ContactView cv{};
+	JointView jv{};
+	uint64_t layoutGeneration = 0;
+	int bodySoaCap = 0, contactSoaCap = 0, jointSoaCap = 0;
+
+	// structure of the last step
+	SweepSet contacts, joints;
+	HostGroupTable hGroups, hContactTail, hJointTail, hStripA, hStripB;
+	DeviceGroupTable dGroups, dContactTail, dJointTail, dStripA, dStripB;
+	// lean strip tables (strip_kernel.hip): descriptors of both phases, warm-start slots of phase A
+	DevBuf dStripLean;
+	StripTableView leanA{}, leanB{};
+	bool leanAValid = false, leanBValid = false;
+	int optStripLean = 1;
+	// persistent strip step (strip_kernel.hip: stripStepKernel)
+	DevBuf dPersist, dGranules;
+	PersistView persist{};
+	bool persistValid = false;
+	int persistRecordsWide = 0; // LDS records when a seam constraint takes 10 records (every kind but TGS_Soft's)
+	DevBuf dPersistOps;
+	int persistOpCount = 0;
+	uint64_t persistOpsGeneration = ~0ull, persistOpsStructure = ~0ull;
+	size_t granuleBytes = 0;
+	int optPersist = 1;
+	int optPersistDebug = 0;
+	int optPersistSpinLimit = 1 << 21;
+	bool persistFailed = false; // a hand-off timed out once (workgroups not co-resident: a shared GPU): multi-launch strips from then on
+	int persistFallbacks = 0;
+	int cuCount = 0;
+	unsigned int* hostError = nullptr; // pinned, device-visible: a hand-off timed out
+	unsigned long long* hostTimes = nullptr; // S2AMD_DEBUG_TIMES: pinned [256] phase time stamps of one workgroup
+	DevBuf dMsg;
+	MsgView msg{};
+	bool msgTablesValid = false; // the global part is contact-only and has no sequential tail
+	int optMessage = 0;	 // measured slower than the plain gather on MI355X: off by default
+	int optBodyWarm = 1; // body-centric contact warm start (one launch per sweep instead of one per colour)
+	int looseBodies = 0; // live non-static bodies that no LDS group owns
+	int orderSolverClass = -1; // 0 velocity colouring, 1 position colouring
+	bool orderGrouped = false;
+	bool orderStrips = false;
+	bool stripsRejected = false; // this graph's strip partition fits no strip kernel: colour batches until the graph changes
+	int graphAge = 0;		  // steps solved since the constraint graph last changed
+	int optStripPatience = 1; // steps of an unchanged graph before the (more expensive) strip structure is built
+	int optStripsAnySolver = 0; // tests: strips for every solver and with joints (through the generic group interpreter)
+	bool adjValid = false;
+	bool structureDirty = true;
+	uint64_t structureGeneration = 0;
+
+	StepPlan plan;
+	uint64_t planGeneration = 0;
+
+	// options
+	int optGraph = 1;
+	int optProfile = 0;
+	int optGroups = 1;
+	int optMaxGroupBodies = 2048;
+	int optPackGroupBodies = 1024;
+	int optStrips = 1;		   // cut islands that do not fit one LDS group into strips of BFS levels (2 launches per sweep)
+	int optStripBodies = 320;  // target bodies per strip
+	int optStripMinBodies = 4096; // loose bodies below which the colour-batch path is kept
+
+	// graph cache
+	hipGraph_t graph = nullptr;
+	hipGraphExec_t graphExec = nullptr;
+	uint64_t graphKey = 0;
+
+	// profiling events for the contact solve sweeps
+	std::vector<hipEvent_t> sweepEvents;
+	size_t sweepEventsUsed = 0;
+
+	s2amdStepStats stats{};
+	int launchCounter = 0;
+	int graphLaunches = 0;
+	DevBuf dGatherIndex;
+	bool gatherIndexDirty = true;
+	uint64_t opsGeneration = ~0ull;
+};
+
+StepConsts makeConsts(const s2amdStepParams* p);
+int carveBodies(s2amdSolver* s, int n); // (re)carves the body SoA family for n slots
+int buildStructure(s2amdSolver* s, int solverType);
+void buildPlan(s2amdSolver* s, const s2amdStepParams* params);
+bool messageEligible(const s2amdSolver* s, int solverType);
+void destroyGraph(s2amdSolver* s);
+int doUpload(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdContact* contacts, int nc, const s2amdJoint* joints, int nj);
+int doStep(s2amdSolver* s, const s2amdStepParams* params);
+int doDownload(s2amdSolver* s, s2amdBody* bodies, int nb, s2amdContact* contacts, int nc, s2amdJoint* joints, int nj);

@@ -1,0 +1,427 @@
+// upload / step / download of a resident world: host shadows of the graph, hipGraph capture and replay, timing.
+#include "solver_executor.h"
+
+void destroyGraph(s2amdSolver* s)
+{
+	if (s->graphExec)
+	{
+		(void)hipGraphExecDestroy(s->graphExec);
+		s->graphExec = nullptr;
+	}
+	if (s->graph)
+	{
+		(void)hipGraphDestroy(s->graph);
+		s->graph = nullptr;
+	}
+	s->graphKey = 0;
+}
+
+int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdContact* contacts, int nc, const s2amdJoint* joints, int nj)
+{
+	bool changed = s->structureDirty || nb != (int)s->hBodyFlags.size() || nc != (int)s->hContactA.size() || nj != (int)s->hJointType.size();
+	std::vector<uint32_t> flags((size_t)nb);
+	s->hBodyLive.assign((size_t)nb, 0);
+	s->hBodyStatic.assign((size_t)nb, 0);
+	for (int i = 0; i < nb; ++i)
+	{
+		const s2amdBody& b = bodies[i];
+		uint32_t f = 0;
+		s->hBodyLive[i] = b.type != S2AMD_BODY_FREE;
+		s->hBodyStatic[i] = b.type == S2AMD_BODY_STATIC;
+		if (b.type != S2AMD_BODY_FREE)
+		{
+			bool massless = b.invMass == 0.0f && b.invI == 0.0f;
+			if (!massless)
+			{
+				f |= S2F_WRITE_VEL;
+			}
+			// position sweeps store rot = normalize(rot) even for immovable bodies
+			// (solve_common.c:383-392): only a static body whose rot is a fixed point of the
+			// normalisation can be treated as read-only there
+			if (!(massless && b.type == S2AMD_BODY_STATIC && rotIsFixedPoint(b.rot[0], b.rot[1])))
+			{
+				f |= S2F_WRITE_POS;
+			}
+		}
+		flags[i] = f;
+	}
+	if (!changed && flags != s->hBodyFlags)
+	{
+		changed = true;
+	}
+	s->hBodyFlags.swap(flags);
+
+	if ((int)s->hContactA.size() != nc)
+	{
+		s->hContactA.assign(nc, -1);
+		s->hContactB.assign(nc, -1);
+		s->hContactPoints.assign(nc, 0);
+	}
+	for (int i = 0; i < nc; ++i)
+	{
+		const s2amdContact& c = contacts[i];
+		int pc = c.pointCount > 0 ? c.pointCount : 0;
+		if (!changed && (s->hContactA[i] != c.bodyA || s->hContactB[i] != c.bodyB || (s->hContactPoints[i] > 0) != (pc > 0)))
+		{
+			changed = true;
+		}
+		s->hContactA[i] = c.bodyA;
+		s->hContactB[i] = c.bodyB;
+		s->hContactPoints[i] = pc;
+		if (pc > 0 && (c.bodyA < 0 || c.bodyA >= nb || c.bodyB < 0 || c.bodyB >= nb || pc > 2))
+		{
+			return fail(S2AMD_E_INVALID, "contact " + std::to_string(i) + " has an invalid body index or point count");
+		}
+	}
+	if ((int)s->hJointType.size() != nj)
+	{
+		s->hJointType.assign(nj, S2AMD_JOINT_FREE);
+		s->hJointA.assign(nj, -1);
+		s->hJointB.assign(nj, -1);
+	}
+	for (int i = 0; i < nj; ++i)
+	{
+		const s2amdJoint& j = joints[i];
+		if (!changed && (s->hJointType[i] != j.type || s->hJointA[i] != j.bodyA || s->hJointB[i] != j.bodyB))
+		{
+			changed = true;
+		}
+		s->hJointType[i] = j.type;
+		s->hJointA[i] = j.bodyA;
+		s->hJointB[i] = j.bodyB;
+		if (j.type != S2AMD_JOINT_FREE)
+		{
+			if (j.type != S2AMD_JOINT_REVOLUTE && j.type != S2AMD_JOINT_MOUSE)
+			{
+				return fail(S2AMD_E_INVALID, "joint " + std::to_string(i) + " has an unknown type");
+			}
+			if (j.bodyB < 0 || j.bodyB >= nb || (j.type == S2AMD_JOINT_REVOLUTE && (j.bodyA < 0 || j.bodyA >= nb)))
+			{
+				return fail(S2AMD_E_INVALID, "joint " + std::to_string(i) + " has an invalid body index");
+			}
+		}
+	}
+	if (changed)
+	{
+		s->graphAge = 0; // strips wait until the graph has stayed the same for optStripPatience steps
+		s->stripsRejected = false;
+		s->structureDirty = true;
+	}
+	return S2AMD_OK;
+}
+
+int doUpload(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdContact* contacts, int nc, const s2amdJoint* joints, int nj)
+{
+	if (nb < 0 || nc < 0 || nj < 0 || (nb > 0 && !bodies) || (nc > 0 && !contacts) || (nj > 0 && !joints))
+	{
+		return fail(S2AMD_E_INVALID, "null array with non-zero count");
+	}
+	HIP_TRY(hipSetDevice(s->device));
+	int rc = refreshShadows(s, bodies, nb, contacts, nc, joints, nj);
+	if (rc)
+	{
+		return rc;
+	}
+	bool grew = false;
+	if ((rc = s->dBodies.ensure((size_t)std::max(nb, 1) * sizeof(s2amdBody), &grew)) != 0)
+	{
+		return rc;
+	}
+	if ((rc = s->dContacts.ensure((size_t)std::max(nc, 1) * sizeof(s2amdContact), &grew)) != 0)
+	{
+		return rc;
+	}
+	if ((rc = s->dJoints.ensure((size_t)std::max(nj, 1) * sizeof(s2amdJoint), &grew)) != 0)
+	{
+		return rc;
+	}
+	if ((rc = s->dBodyFlags.ensure((size_t)std::max(nb, 1) * sizeof(uint32_t), &grew)) != 0)
+	{
+		return rc;
+	}
+	if (grew)
+	{
+		s->layoutGeneration += 1;
+		s->savedValid = false;
+		s->structureDirty = true; // dBodyFlags may have moved
+	}
+	s->bodyCapacity = nb;
+	s->contactCapacity = nc;
+	s->jointCapacity = nj;
+	if ((rc = carveBodies(s, nb)) != 0)
+	{
+		return rc;
+	}
+	if (nb > 0)
+	{
+		HIP_TRY(hipMemcpyAsync(s->dBodies.p, bodies, (size_t)nb * sizeof(s2amdBody), hipMemcpyHostToDevice, s->stream));
+		// dBodyFlags is written by buildStructure (it adds the LDS-group ownership bits)
+	}
+	if (nc > 0)
+	{
+		HIP_TRY(hipMemcpyAsync(s->dContacts.p, contacts, (size_t)nc * sizeof(s2amdContact), hipMemcpyHostToDevice, s->stream));
+	}
+	if (nj > 0)
+	{
+		HIP_TRY(hipMemcpyAsync(s->dJoints.p, joints, (size_t)nj * sizeof(s2amdJoint), hipMemcpyHostToDevice, s->stream));
+	}
+	s->resident = true;
+	return S2AMD_OK;
+}
+
+__global__ void writeConstraintIndexKernel(s2amdContact* wire, int n, const int* gatherIndex)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n)
+	{
+		wire[i].constraintIndex = gatherIndex[i];
+	}
+}
+
+int doStep(s2amdSolver* s, const s2amdStepParams* params)
+{
+	if (!params)
+	{
+		return fail(S2AMD_E_INVALID, "null params");
+	}
+	if (params->solverType < 0 || params->solverType >= s2amd_solverTypeCount)
+	{
+		return fail(S2AMD_E_INVALID, "unknown solver type " + std::to_string(params->solverType));
+	}
+	if (!s->resident)
+	{
+		return fail(S2AMD_E_STATE, "s2amd_step_resident called before s2amd_upload");
+	}
+	HIP_TRY(hipSetDevice(s->device));
+	s->stats = s2amdStepStats{};
+	buildPlan(s, params);
+	int rc = buildStructure(s, params->solverType);
+	if (rc)
+	{
+		return rc;
+	}
+	const StepPlan& plan = s->plan;
+	if (s->opsGeneration != s->planGeneration)
+	{
+		bool grew = false;
+		if ((rc = s->dOps.ensure(std::max<size_t>(plan.ops.size(), 1) * sizeof(Op), &grew)) != 0)
+		{
+			return rc;
+		}
+		if (grew)
+		{
+			s->layoutGeneration += 1;
+		}
+		if (!plan.ops.empty())
+		{
+			HIP_TRY(hipMemcpyAsync(s->dOps.p, plan.ops.data(), plan.ops.size() * sizeof(Op), hipMemcpyHostToDevice, s->stream));
+			HIP_TRY(hipStreamSynchronize(s->stream));
+		}
+		s->opsGeneration = s->planGeneration;
+	}
+
+	Executor q{s, s->stream, plan, isPositionSolver(params->solverType) ? 1 : 0, s->optProfile != 0};
+	q.msg = messageEligible(s, params->solverType);
+	s->stats.messagePassing = q.msg ? 1 : 0;
+	{
+		int kind, warm;
+		if (s->dStripA.view.groupCount > 0 && q.persistPlan(kind, warm) && q.uploadPersistOps() != 0)
+		{
+			return fail(S2AMD_E_DEVICE, "could not upload the persistent step plan");
+		}
+	}
+	s->launchCounter = 0;
+	s->sweepEventsUsed = 0;
+
+	const bool xpbdEarlyOut = plan.earlyOut;
+	const bool writesConstraintIndex = !xpbdEarlyOut && params->solverType != s2amd_solverPGS_NGS_Block;
+
+	// manifold.constraintIndex (pool-order gather index, -1 for skipped slots)
+	if (writesConstraintIndex && s->contactCapacity > 0)
+	{
+		if (s->gatherIndexDirty || s->dGatherIndex.bytes < (size_t)s->contactCapacity * sizeof(int))
+		{
+			std::vector<int> gi((size_t)s->contactCapacity, -1);
+			int k = 0;
+			for (int i = 0; i < s->contactCapacity; ++i)
+			{
+				if (s->hContactPoints[i] > 0)
+				{
+					gi[i] = k++;
+				}
+			}
+			bool grew = false;
+			if ((rc = s->dGatherIndex.ensure(gi.size() * sizeof(int), &grew)) != 0)
+			{
+				return rc;
+			}
+			if (grew)
+			{
+				s->layoutGeneration += 1;
+			}
+			HIP_TRY(hipMemcpyAsync(s->dGatherIndex.p, gi.data(), gi.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+			HIP_TRY(hipStreamSynchronize(s->stream));
+			s->gatherIndexDirty = false;
+		}
+	}
+
+	auto enqueueAll = [&]() {
+		bool indexBranch = false;
+		q.gatherIndex = (writesConstraintIndex && s->contactCapacity > 0 && !q.fork) ? (const int*)s->dGatherIndex.p : nullptr;
+		if (writesConstraintIndex && s->contactCapacity > 0 && q.fork)
+		{
+			// touches only manifold.constraintIndex, which no solver kernel reads: a parallel branch that joins at the end
+			int n = s->contactCapacity;
+			hipStream_t where = q.branch(0, 0);
+			writeConstraintIndexKernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, where>>>((s2amdContact*)s->dContacts.p, n,
+																									 (const int*)s->dGatherIndex.p);
+			q.count();
+			indexBranch = true;
+		}
+		q.run();
+		if (indexBranch)
+		{
+			q.join(0, 0);
+		}
+	};
+
+	bool useGraph = s->optGraph != 0 && !q.profile;
+	q.fork = useGraph && s->optFork != 0;
+	HIP_TRY(hipEventRecord(s->evBegin, s->stream));
+	if (useGraph)
+	{
+		uint64_t key = 1469598103934665603ull;
+		key = fnv(key, params, sizeof(*params));
+		uint64_t gens[4] = {s->layoutGeneration, s->structureGeneration, s->planGeneration, (uint64_t)((q.msg ? 1 : 0) | (s->optBodyWarm ? 2 : 0) | (s->optStripLean ? 4 : 0) | (s->optPersist ? 8 : 0) | (s->optFork ? 16 : 0) | (s->persistFailed ? 32 : 0))};
+		key = fnv(key, gens, sizeof(gens));
+		int sizes[3] = {s->bodyCapacity, s->contactCapacity, s->jointCapacity};
+		key = fnv(key, sizes, sizeof(sizes));
+		if (key == 0)
+		{
+			key = 1;
+		}
+		if (key != s->graphKey || s->graphExec == nullptr)
+		{
+			destroyGraph(s);
+			HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+			enqueueAll();
+			hipError_t ce = hipStreamEndCapture(s->stream, &s->graph);
+			if (ce != hipSuccess)
+			{
+				s->graph = nullptr;
+				return fail(S2AMD_E_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+			}
+			HIP_TRY(hipGraphInstantiate(&s->graphExec, s->graph, nullptr, nullptr, 0));
+			s->graphKey = key;
+			s->graphLaunches = s->launchCounter;
+		}
+		else
+		{
+			s->launchCounter = s->graphLaunches;
+			s->stats.graphReplayed = 1;
+		}
+		HIP_TRY(hipGraphLaunch(s->graphExec, s->stream));
+	}
+	else
+	{
+		enqueueAll();
+	}
+	HIP_TRY(hipEventRecord(s->evEnd, s->stream));
+	HIP_TRY(hipGetLastError());
+	const bool async = s->optAsync != 0 && !q.profile;
+	if (!async)
+	{
+		HIP_TRY(hipStreamSynchronize(s->stream));
+		float ms = 0.0f;
+		HIP_TRY(hipEventElapsedTime(&ms, s->evBegin, s->evEnd));
+		s->stats.deviceMs = ms;
+	}
+	s->stats.constraintCount = s->cv.count;
+	s->stats.jointCount = s->jv.count;
+	s->stats.contactColors = (int)s->contacts.colorOffsets.size() - 1;
+	s->stats.jointColors = (int)s->joints.colorOffsets.size() - 1;
+	s->stats.solveSweeps = plan.solveSweeps;
+	s->stats.kernelLaunches = s->launchCounter;
+	s->stats.groupCount = s->dGroups.view.groupCount;
+	s->stats.stripCount = s->dStripA.view.groupCount;
+	s->stats.seamCount = s->dStripB.view.groupCount;
+	{
+		int kind, warm;
+		s->stats.persistent = (s->dStripA.view.groupCount > 0 && q.persistPlan(kind, warm)) ? 1 : 0;
+	}
+	s->stats.persistFallbacks = s->persistFallbacks;
+	if (!async && s->hostError && *s->hostError != 0u)
+	{
+		// The persistent kernel's workgroups were not all resident (something else occupies the GPU).  Its epilogue saw
+		// the flag and left the wire arrays untouched, so the step is simply repeated on the multi-launch strip path,
+		// which this solver keeps from now on.
+		*s->hostError = 0u;
+		(void)hipMemsetAsync(s->persist.deviceError, 0, sizeof(unsigned int), s->stream);
+		s->persistFailed = true;
+		s->persistFallbacks += 1;
+		return doStep(s, params);
+	}
+	s->graphAge += 1;
+	if (q.profile)
+	{
+		float total = 0.0f;
+		for (size_t i = 0; i + 1 < s->sweepEventsUsed; i += 2)
+		{
+			float t = 0.0f;
+			if (hipEventElapsedTime(&t, s->sweepEvents[i], s->sweepEvents[i + 1]) == hipSuccess)
+			{
+				total += t;
+			}
+		}
+		// calibrate: an empty event pair on the same stream measures the bracket's own cost
+		float empty = 0.0f;
+		int pairs = 0;
+		if (s->sweepEvents.size() >= 2)
+		{
+			for (int r = 0; r < 32; ++r)
+			{
+				(void)hipEventRecord(s->sweepEvents[0], s->stream);
+				(void)hipEventRecord(s->sweepEvents[1], s->stream);
+				(void)hipStreamSynchronize(s->stream);
+				float t = 0.0f;
+				if (hipEventElapsedTime(&t, s->sweepEvents[0], s->sweepEvents[1]) == hipSuccess)
+				{
+					empty += t;
+					pairs += 1;
+				}
+			}
+		}
+		s->stats.solveKernelMs = total;
+		s->stats.solveLaunches = (int)(s->sweepEventsUsed / 2);
+		s->stats.eventPairOverheadMs = pairs > 0 ? empty / pairs : 0.0f;
+	}
+	return S2AMD_OK;
+}
+
+int doDownload(s2amdSolver* s, s2amdBody* bodies, int nb, s2amdContact* contacts, int nc, s2amdJoint* joints, int nj)
+{
+	if (!s->resident)
+	{
+		return fail(S2AMD_E_STATE, "nothing resident to download");
+	}
+	if (nb < s->bodyCapacity || nc < s->contactCapacity || nj < s->jointCapacity)
+	{
+		return fail(S2AMD_E_CAPACITY, "output arrays smaller than the resident world");
+	}
+	HIP_TRY(hipSetDevice(s->device));
+	if (s->bodyCapacity > 0 && bodies)
+	{
+		HIP_TRY(hipMemcpyAsync(bodies, s->dBodies.p, (size_t)s->bodyCapacity * sizeof(s2amdBody), hipMemcpyDeviceToHost, s->stream));
+	}
+	if (s->contactCapacity > 0 && contacts)
+	{
+		HIP_TRY(hipMemcpyAsync(contacts, s->dContacts.p, (size_t)s->contactCapacity * sizeof(s2amdContact), hipMemcpyDeviceToHost, s->stream));
+	}
+	if (s->jointCapacity > 0 && joints)
+	{
+		HIP_TRY(hipMemcpyAsync(joints, s->dJoints.p, (size_t)s->jointCapacity * sizeof(s2amdJoint), hipMemcpyDeviceToHost, s->stream));
+	}
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	return S2AMD_OK;
+}
+

@@ -1,0 +1,1520 @@
+// Structure of a world for the sweeps: islands, LDS groups, strips of the big islands, colour batches, and the
+// device tables the kernels read (GroupTable, StripDesc, PersistDesc).  Rebuilt when the constraint graph changes.
+#include "solver_internal.h"
+
+namespace
+{
+
+// SoA carving: one device allocation per family, arrays laid end to end at 256-byte boundaries.
+// The element capacity only grows (x1.5), so device pointers -- and a captured hipGraph -- stay
+// valid until a family actually has to grow (layoutGeneration is bumped then).
+struct Carver
+{
+	char* p;
+	char* end;
+	template <class T> T* take(size_t count)
+	{
+		char* r = p;
+		p += (count * sizeof(T) + 255) & ~size_t(255);
+		return (T*)r;
+	}
+};
+
+int growFamily(s2amdSolver* s, DevBuf& buf, int& cap, int need, size_t slotBytes, int arrays)
+{
+	if (need <= cap && buf.p != nullptr)
+	{
+		return S2AMD_OK;
+	}
+	int newCap = std::max(std::max(need, 64), cap + cap / 2);
+	buf.release();
+	bool grew = false;
+	int rc = buf.ensure((size_t)newCap * slotBytes + (size_t)arrays * 256, &grew);
+	if (rc)
+	{
+		cap = 0;
+		return rc;
+	}
+	cap = newCap;
+	s->layoutGeneration += 1;
+	return S2AMD_OK;
+}
+
+constexpr size_t kBodySlotBytes = sizeof(float4) * 4 + sizeof(float2) + sizeof(float) + sizeof(uint32_t);
+constexpr size_t kContactSlotBytes = sizeof(int2) + sizeof(float4) * 2 + 2 * (sizeof(float4) * 5 + sizeof(float2)) + sizeof(float4) * 4;
+constexpr size_t kJointSlotBytes = sizeof(int2) + sizeof(float4) * 8 + sizeof(float2) * 3;
+
+} // namespace
+
+int carveBodies(s2amdSolver* s, int n)
+{
+	int rc = growFamily(s, s->soaBodies, s->bodySoaCap, n, kBodySlotBytes, 8);
+	if (rc)
+	{
+		return rc;
+	}
+	size_t cap = (size_t)s->bodySoaCap;
+	Carver c{(char*)s->soaBodies.p, (char*)s->soaBodies.p + s->soaBodies.bytes};
+	s->bv.vel = c.take<float4>(cap);
+	s->bv.dq = c.take<float4>(cap);
+	s->bv.integ = c.take<float4>(cap);
+	s->bv.dq0 = c.take<float4>(cap);
+	s->bv.pos = c.take<float2>(cap);
+	s->bv.angDamp = c.take<float>(cap);
+	s->bv.flags = c.take<uint32_t>(cap);
+	s->bv.capacity = n;
+	return c.p <= c.end ? S2AMD_OK : fail(S2AMD_E_DEVICE, "internal: body SoA carve overflow");
+}
+
+namespace
+{
+
+int carveContacts(s2amdSolver* s, int n)
+{
+	int rc = growFamily(s, s->soaContacts, s->contactSoaCap, n, kContactSlotBytes, 20);
+	if (rc)
+	{
+		return rc;
+	}
+	size_t cap = (size_t)s->contactSoaCap;
+	Carver c{(char*)s->soaContacts.p, (char*)s->soaContacts.p + s->soaContacts.bytes};
+	ContactView& v = s->cv;
+	v.bodies = c.take<int2>(cap);
+	v.mass = c.take<float4>(cap);
+	v.nf = c.take<float4>(cap);
+	for (int j = 0; j < 2; ++j)
+	{
+		v.anchor[j] = c.take<float4>(cap);
+		v.r0[j] = c.take<float4>(cap);
+		v.param[j] = c.take<float4>(cap);
+		v.soft[j] = c.take<float4>(cap);
+		v.fanchor[j] = c.take<float4>(cap);
+		v.impulse[j] = c.take<float2>(cap);
+	}
+	v.blockK = c.take<float4>(cap);
+	v.blockNM = c.take<float4>(cap);
+	v.deltaA = c.take<float4>(cap);
+	v.deltaB = c.take<float4>(cap);
+	return c.p <= c.end ? S2AMD_OK : fail(S2AMD_E_DEVICE, "internal: contact SoA carve overflow");
+}
+
+int carveJoints(s2amdSolver* s, int n)
+{
+	int rc = growFamily(s, s->soaJoints, s->jointSoaCap, n, kJointSlotBytes, 14);
+	if (rc)
+	{
+		return rc;
+	}
+	size_t cap = (size_t)s->jointSoaCap;
+	Carver c{(char*)s->soaJoints.p, (char*)s->soaJoints.p + s->soaJoints.bytes};
+	JointView& j = s->jv;
+	j.bodies = c.take<int2>(cap);
+	j.frame = c.take<float4>(cap);
+	j.mass = c.take<float4>(cap);
+	j.pivot = c.take<float4>(cap);
+	j.soft = c.take<float4>(cap);
+	j.axial = c.take<float4>(cap);
+	j.limits = c.take<float4>(cap);
+	j.misc = c.take<float4>(cap);
+	j.origin = c.take<float4>(cap);
+	j.centerDiff0 = c.take<float2>(cap);
+	j.impulse = c.take<float2>(cap);
+	j.target = c.take<float2>(cap);
+	return c.p <= c.end ? S2AMD_OK : fail(S2AMD_E_DEVICE, "internal: joint SoA carve overflow");
+}
+
+// ------------------------------------------------------------------------------------------------
+// structure: islands -> LDS groups, colouring, sweep order, index tables
+// ------------------------------------------------------------------------------------------------
+struct UnionFind
+{
+	std::vector<int> parent;
+	explicit UnionFind(int n) : parent((size_t)n)
+	{
+		for (int i = 0; i < n; ++i)
+		{
+			parent[i] = i;
+		}
+	}
+	int find(int x)
+	{
+		while (parent[x] != x)
+		{
+			parent[x] = parent[parent[x]];
+			x = parent[x];
+		}
+		return x;
+	}
+	void unite(int a, int b)
+	{
+		a = find(a), b = find(b);
+		if (a != b)
+		{
+			// the lower index becomes the root: labels are deterministic
+			if (a < b)
+			{
+				parent[b] = a;
+			}
+			else
+			{
+				parent[a] = b;
+			}
+		}
+	}
+};
+
+struct EdgeList
+{
+	std::vector<int> ids, a, b; // wire index and endpoints (a == -1: one-body constraint)
+};
+
+// Colours one part (the global part or one group), appends its sweep order to `set` and returns its
+// launch batches as ranges of k.  Endpoints are indices into `conflict`.
+void colourPart(const std::vector<int>& ids, const std::vector<int>& ea, const std::vector<int>& eb, const std::vector<uint8_t>& conflict,
+				int bodyCount, SweepSet& set, std::vector<int>& batchOffsetsOut, bool& hasTailOut, std::vector<int>* positions, bool balanced = false)
+{
+	std::vector<int> color, partOrder, partOffsets;
+	int cc = colorGraph(ea, eb, conflict, bodyCount, color, balanced);
+	// stable counting sort of positions by colour
+	std::vector<int> pos(ids.size());
+	for (size_t i = 0; i < ids.size(); ++i)
+	{
+		pos[i] = (int)i;
+	}
+	sortByColor(pos, color, cc, partOrder, partOffsets);
+	int base = (int)set.order.size();
+	for (int p : partOrder)
+	{
+		set.order.push_back(ids[p]);
+	}
+	if (positions)
+	{
+		*positions = partOrder;
+	}
+	for (int c = 0; c < cc; ++c)
+	{
+		if (set.colorOffsets.empty())
+		{
+			set.colorOffsets.push_back(0);
+		}
+		if (partOffsets[(size_t)c + 1] > partOffsets[c])
+		{
+			set.colorOffsets.push_back(base + partOffsets[(size_t)c + 1]);
+		}
+	}
+	std::vector<int> rel;
+	hasTailOut = makeBatches(partOffsets, rel, !balanced);
+	batchOffsetsOut.clear();
+	for (int r : rel)
+	{
+		batchOffsetsOut.push_back(base + r);
+	}
+}
+
+int uploadGroupTable(s2amdSolver* s, const HostGroupTable& h, DeviceGroupTable& d)
+{
+	auto pad4 = [](size_t n) { return (n + 3) & ~size_t(3); };
+	size_t nBO = pad4(h.bodyOffsets.size()), nBI = pad4(std::max<size_t>(h.bodyIds.size(), 1));
+	size_t nCO = pad4(h.cBatchOffsets.size()), nJO = pad4(h.jBatchOffsets.size());
+	size_t nCB = std::max<size_t>(h.cBatches.size(), 1) * 4, nJB = std::max<size_t>(h.jBatches.size(), 1) * 4;
+	std::vector<int> blob(nBO + nBI + nCO + nJO + nCB + nJB, 0);
+	size_t o = 0;
+	size_t oBO = o;
+	std::copy(h.bodyOffsets.begin(), h.bodyOffsets.end(), blob.begin() + o);
+	o += nBO;
+	size_t oBI = o;
+	std::copy(h.bodyIds.begin(), h.bodyIds.end(), blob.begin() + o);
+	o += nBI;
+	size_t oCO = o;
+	std::copy(h.cBatchOffsets.begin(), h.cBatchOffsets.end(), blob.begin() + o);
+	o += nCO;
+	size_t oJO = o;
+	std::copy(h.jBatchOffsets.begin(), h.jBatchOffsets.end(), blob.begin() + o);
+	o += nJO;
+	size_t oCB = o;
+	if (!h.cBatches.empty())
+	{
+		memcpy(blob.data() + o, h.cBatches.data(), h.cBatches.size() * sizeof(int4));
+	}
+	o += nCB;
+	size_t oJB = o;
+	if (!h.jBatches.empty())
+	{
+		memcpy(blob.data() + o, h.jBatches.data(), h.jBatches.size() * sizeof(int4));
+	}
+	bool grew = false;
+	int rc = d.buf.ensure(blob.size() * sizeof(int), &grew);
+	if (rc)
+	{
+		return rc;
+	}
+	if (grew)
+	{
+		s->layoutGeneration += 1;
+	}
+	HIP_TRY(hipMemcpyAsync(d.buf.p, blob.data(), blob.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+	const int* base = (const int*)d.buf.p;
+	d.view.bodyOffsets = base + oBO;
+	d.view.bodyIds = base + oBI;
+	d.view.cBatchOffsets = base + oCO;
+	d.view.jBatchOffsets = base + oJO;
+	d.view.cBatches = (const int4*)(base + oCB);
+	d.view.jBatches = (const int4*)(base + oJB);
+	d.view.groupCount = h.count();
+	d.maxBodies = h.maxBodies;
+	return S2AMD_OK;
+}
+
+// Local body slots of one group: bodies get slots in order of first use by the group's constraints.
+struct LocalSlots
+{
+	std::vector<int> slot, stamp;
+	int epoch = 0;
+	explicit LocalSlots(int nb) : slot((size_t)nb, -1), stamp((size_t)nb, -1) {}
+	void begin() { epoch += 1; }
+	void seed(int body, std::vector<int>& ids, bool owned)
+	{
+		stamp[body] = epoch;
+		slot[body] = (int)ids.size();
+		ids.push_back((int)((uint32_t)body | (owned ? S2G_OWNED : 0u)));
+	}
+	int get(int body, std::vector<int>& ids, const std::vector<uint8_t>& conflict)
+	{
+		if (stamp[body] != epoch)
+		{
+			stamp[body] = epoch;
+			slot[body] = (int)ids.size();
+			ids.push_back((int)((uint32_t)body | (conflict[body] ? S2G_OWNED : 0u)));
+		}
+		return slot[body];
+	}
+};
+
+// Strips.  An island too big for one LDS group is cut along the level sets of a breadth-first search
+// over its writable bodies: a constraint joins bodies of the same or of adjacent levels, so with every
+// strip spanning >= 2 levels
+//   * "interior" constraints (both bodies in one strip) of different strips share no writable body,
+//   * "seam" constraints between strips i and i+1 touch the last level of i and the first of i+1
+//     only, so different seams share no writable body either.
+// A Gauss-Seidel sweep over the island is then TWO launches -- all interiors (phase A, one workgroup
+// per strip, colours separated by __syncthreads), all seams (phase B) -- instead of one launch per
+// colour; its sequential-equivalent order is strip by strip colour-major, then seam by seam.
+struct StripPartition
+{
+	bool active = false;
+	std::vector<std::vector<int>> bodies;  // per strip: owned bodies, level by level
+	std::vector<std::vector<int>> cA, jA;  // per strip: interior contacts / joints (indices into the edge lists)
+	std::vector<std::vector<int>> cB, jB;  // per seam i | i+1
+};
+
+void partitionStrips(const EdgeList& ce, const EdgeList& je, const std::vector<int>& cGlobal, const std::vector<int>& jGlobal,
+					 const std::vector<uint8_t>& conflict, const std::vector<uint8_t>& loose, int nb, int targetBodies, int maxBodies,
+					 StripPartition& out)
+{
+	// adjacency of the loose writable bodies
+	auto linked = [&](int a, int b) { return a >= 0 && b >= 0 && conflict[a] && conflict[b] && loose[a] && loose[b]; };
+	std::vector<int> deg((size_t)nb + 1, 0);
+	auto countEdges = [&](const EdgeList& e, const std::vector<int>& ks) {
+		for (int k : ks)
+		{
+			if (linked(e.a[k], e.b[k]))
+			{
+				deg[(size_t)e.a[k] + 1] += 1;
+				deg[(size_t)e.b[k] + 1] += 1;
+			}
+		}
+	};
+	countEdges(ce, cGlobal);
+	countEdges(je, jGlobal);
+	for (int i = 0; i < nb; ++i)
+	{
+		deg[(size_t)i + 1] += deg[i];
+	}
+	std::vector<int> adj((size_t)deg[nb]), cursor(deg.begin(), deg.end() - 1);
+	auto fillEdges = [&](const EdgeList& e, const std::vector<int>& ks) {
+		for (int k : ks)
+		{
+			if (linked(e.a[k], e.b[k]))
+			{
+				adj[(size_t)cursor[e.a[k]]++] = e.b[k];
+				adj[(size_t)cursor[e.b[k]]++] = e.a[k];
+			}
+		}
+	};
+	fillEdges(ce, cGlobal);
+	fillEdges(je, jGlobal);
+
+	// levels: per component, BFS from a pseudo-peripheral body (the last body a first BFS reaches)
+	std::vector<int> level((size_t)nb, -1), queue, levelOffsets{0}, levelBodies;
+	std::vector<int> seen((size_t)nb, 0);
+	int epoch = 0;
+	auto bfs = [&](int root, bool record) {
+		epoch += 1;
+		queue.clear();
+		queue.push_back(root);
+		seen[root] = epoch;
+		size_t head = 0, levelEnd = 1;
+		while (head < queue.size())
+		{
+			if (head == levelEnd)
+			{
+				if (record)
+				{
+					levelOffsets.push_back((int)levelBodies.size());
+				}
+				levelEnd = queue.size();
+			}
+			int u = queue[head++];
+			if (record)
+			{
+				level[u] = (int)levelOffsets.size() - 1;
+				levelBodies.push_back(u);
+			}
+			for (int e = deg[u]; e < deg[(size_t)u + 1]; ++e)
+			{
+				int v = adj[(size_t)e];
+				if (seen[v] != epoch)
+				{
+					seen[v] = epoch;
+					queue.push_back(v);
+				}
+			}
+		}
+		if (record)
+		{
+			levelOffsets.push_back((int)levelBodies.size());
+		}
+		return queue.back();
+	};
+	for (int i = 0; i < nb; ++i)
+	{
+		if (!loose[i] || level[i] >= 0)
+		{
+			continue;
+		}
+		int far = deg[(size_t)i + 1] > deg[i] ? bfs(i, false) : i;
+		bfs(far, true);
+	}
+	const int levels = (int)levelOffsets.size() - 1;
+	if (levels < 4)
+	{
+		return;
+	}
+
+	// strips: consecutive levels, >= 2 levels and >= targetBodies bodies each
+	std::vector<int> stripOf((size_t)nb, -1);
+	int curLevels = 0;
+	out.bodies.emplace_back();
+	for (int l = 0; l < levels; ++l)
+	{
+		if (curLevels >= 2 && (int)out.bodies.back().size() >= targetBodies)
+		{
+			out.bodies.emplace_back();
+			curLevels = 0;
+		}
+		for (int e = levelOffsets[l]; e < levelOffsets[(size_t)l + 1]; ++e)
+		{
+			out.bodies.back().push_back(levelBodies[(size_t)e]);
+		}
+		curLevels += 1;
+	}
+	// a last strip of a single level is merged into its predecessor (both of its seams would meet in it)
+	if (curLevels < 2 && out.bodies.size() >= 2)
+	{
+		std::vector<int> lastStrip = std::move(out.bodies.back());
+		out.bodies.pop_back();
+		out.bodies.back().insert(out.bodies.back().end(), lastStrip.begin(), lastStrip.end());
+	}
+	const int K = (int)out.bodies.size();
+	if (K < 2)
+	{
+		out = StripPartition();
+		return;
+	}
+	for (int i = 0; i < K; ++i)
+	{
+		for (int body : out.bodies[(size_t)i])
+		{
+			stripOf[body] = i;
+		}
+	}
+
+	// classification
+	out.cA.assign((size_t)K, {}), out.jA.assign((size_t)K, {});
+	out.cB.assign((size_t)K - 1, {}), out.jB.assign((size_t)K - 1, {});
+	bool ok = true;
+	auto classify = [&](const EdgeList& e, const std::vector<int>& ks, std::vector<std::vector<int>>& A, std::vector<std::vector<int>>& B) {
+		for (int k : ks)
+		{
+			int a = e.a[k], b = e.b[k];
+			int sa = (a >= 0 && conflict[a]) ? stripOf[a] : -1;
+			int sb = (b >= 0 && conflict[b]) ? stripOf[b] : -1;
+			if (sa < 0 && sb < 0)
+			{
+				// no writable body: any strip will do (the sweep writes nothing)
+				int any = (a >= 0 && stripOf[a] >= 0) ? stripOf[a] : ((b >= 0 && stripOf[b] >= 0) ? stripOf[b] : 0);
+				A[(size_t)any].push_back(k);
+			}
+			else if (sa < 0 || sb < 0 || sa == sb)
+			{
+				A[(size_t)std::max(sa, sb)].push_back(k);
+			}
+			else if (sa - sb == 1 || sb - sa == 1)
+			{
+				B[(size_t)std::min(sa, sb)].push_back(k);
+			}
+			else
+			{
+				ok = false;
+			}
+		}
+	};
+	classify(ce, cGlobal, out.cA, out.cB);
+	classify(je, jGlobal, out.jA, out.jB);
+
+	// every group must fit the LDS body budget (owned bodies + read-only replicas)
+	std::vector<int> stamp((size_t)nb, -1);
+	int tick = 0;
+	auto groupBodies = [&](const std::vector<int>& seedBodies, const std::vector<int>& cKs, const std::vector<int>& jKs) {
+		tick += 1;
+		int n = 0;
+		auto touch = [&](int body) {
+			if (body >= 0 && stamp[body] != tick)
+			{
+				stamp[body] = tick;
+				n += 1;
+			}
+		};
+		for (int body : seedBodies)
+		{
+			touch(body);
+		}
+		for (int k : cKs)
+		{
+			touch(ce.a[k]), touch(ce.b[k]);
+		}
+		for (int k : jKs)
+		{
+			touch(je.a[k]), touch(je.b[k]);
+		}
+		return n;
+	};
+	const std::vector<int> none;
+	for (int i = 0; i < K && ok; ++i)
+	{
+		ok = groupBodies(out.bodies[(size_t)i], out.cA[(size_t)i], out.jA[(size_t)i]) <= maxBodies;
+		if (ok && i + 1 < K)
+		{
+			ok = groupBodies(none, out.cB[(size_t)i], out.jB[(size_t)i]) <= maxBodies;
+		}
+	}
+	if (!ok)
+	{
+		out = StripPartition();
+		return;
+	}
+	out.active = true;
+}
+
+} // namespace
+
+int buildStructure(s2amdSolver* s, int solverType)
+{
+	const int cls = isPositionSolver(solverType) ? 1 : 0;
+	const bool needAdj = solverType == s2amd_solverJacobi;
+	const bool grouped = s->optGroups != 0 && !needAdj;
+	// strips pay off through the lean / persistent strip kernels, which exist for the soft contact sweeps
+	const bool wantStrips = grouped && s->optStrips != 0 && !s->stripsRejected && s->graphAge >= s->optStripPatience &&
+							(s->optStripsAnySolver != 0 || solverType == s2amd_solverTGS_Soft || solverType == s2amd_solverSoftStep ||
+							 solverType == s2amd_solverPGS_Soft);
+	if (!s->structureDirty && cls == s->orderSolverClass && grouped == s->orderGrouped && wantStrips == s->orderStrips && s->adjValid)
+	{
+		return S2AMD_OK;
+	}
+	double t0 = nowMs();
+	const int nb = s->bodyCapacity;
+	std::vector<uint8_t> conflict((size_t)nb);
+	for (int i = 0; i < nb; ++i)
+	{
+		conflict[i] = (s->hBodyFlags[i] & (cls == 1 ? S2F_WRITE_POS : S2F_WRITE_VEL)) != 0;
+	}
+
+	// active constraints in pool order (the reference's gather: e.g. solve_tgs_soft.c:162-179)
+	EdgeList ce, je;
+	for (int i = 0; i < s->contactCapacity; ++i)
+	{
+		if (s->hContactPoints[i] > 0)
+		{
+			ce.ids.push_back(i);
+			ce.a.push_back(s->hContactA[i]);
+			ce.b.push_back(s->hContactB[i]);
+		}
+	}
+	for (int i = 0; i < s->jointCapacity; ++i)
+	{
+		if (s->hJointType[i] != S2AMD_JOINT_FREE)
+		{
+			je.ids.push_back(i);
+			je.a.push_back(s->hJointType[i] == S2AMD_JOINT_MOUSE ? -1 : s->hJointA[i]); // a mouse joint only touches body B
+			je.b.push_back(s->hJointB[i]);
+		}
+	}
+	const int C = (int)ce.ids.size(), J = (int)je.ids.size();
+
+	// ---- islands: connected components over the writable bodies ----
+	std::vector<int> cPart((size_t)C, -1), jPart((size_t)J, -1); // -1 = global part, else group id
+	int groupCount = 0;
+	std::vector<uint32_t> flags(s->hBodyFlags);
+	if (grouped && (C > 0 || J > 0))
+	{
+		UnionFind uf(nb);
+		auto link = [&](int a, int b) {
+			if (a >= 0 && b >= 0 && conflict[a] && conflict[b])
+			{
+				uf.unite(a, b);
+			}
+		};
+		for (int k = 0; k < C; ++k)
+		{
+			link(ce.a[k], ce.b[k]);
+		}
+		for (int k = 0; k < J; ++k)
+		{
+			link(je.a[k], je.b[k]);
+		}
+		auto rootOf = [&](int a, int b) {
+			if (a >= 0 && conflict[a])
+			{
+				return uf.find(a);
+			}
+			if (b >= 0 && conflict[b])
+			{
+				return uf.find(b);
+			}
+			return -1;
+		};
+		// bodies an island would stage in LDS: its members that carry constraints + read-only replicas
+		std::vector<int> islandBodies((size_t)nb, 0), seenBy((size_t)nb, -1), cRoot((size_t)C), jRoot((size_t)J);
+		auto touch = [&](int body, int root) {
+			if (body < 0 || root < 0)
+			{
+				return;
+			}
+			int key = conflict[body] ? -2 - root : root; // members are unique per island; replicas per (body, island)
+			if (conflict[body])
+			{
+				if (seenBy[body] != -2)
+				{
+					seenBy[body] = -2;
+					islandBodies[root] += 1;
+				}
+			}
+			else if (seenBy[body] != key)
+			{
+				seenBy[body] = key; // approximate distinct count (exact when an immovable body's uses by one island are contiguous)
+				islandBodies[root] += 1;
+			}
+		};
+		for (int k = 0; k < C; ++k)
+		{
+			cRoot[k] = rootOf(ce.a[k], ce.b[k]);
+			touch(ce.a[k], cRoot[k]);
+			touch(ce.b[k], cRoot[k]);
+		}
+		for (int k = 0; k < J; ++k)
+		{
+			jRoot[k] = rootOf(je.a[k], je.b[k]);
+			touch(je.a[k], jRoot[k]);
+			touch(je.b[k], jRoot[k]);
+		}
+		// pack eligible islands into groups in order of first appearance
+		std::vector<int> groupOfRoot((size_t)nb, -2); // -2 unassigned, -1 global
+		int curBodies = 0;
+		auto assign = [&](int root) {
+			if (root < 0)
+			{
+				return -1;
+			}
+			if (groupOfRoot[root] != -2)
+			{
+				return groupOfRoot[root];
+			}
+			int n = islandBodies[root];
+			if (n > s->optMaxGroupBodies)
+			{
+				groupOfRoot[root] = -1;
+				return -1;
+			}
+			if (groupCount == 0 || curBodies + n > s->optPackGroupBodies)
+			{
+				groupCount += 1;
+				curBodies = 0;
+			}
+			curBodies += n;
+			groupOfRoot[root] = groupCount - 1;
+			return groupCount - 1;
+		};
+		for (int k = 0; k < C; ++k)
+		{
+			cPart[k] = assign(cRoot[k]);
+		}
+		for (int k = 0; k < J; ++k)
+		{
+			jPart[k] = assign(jRoot[k]);
+		}
+	}
+
+	// ---- per part lists (pool order is preserved inside every part) ----
+	std::vector<std::vector<int>> cOf((size_t)groupCount + 1), jOf((size_t)groupCount + 1); // index 0 = global, g + 1 = group g
+	for (int k = 0; k < C; ++k)
+	{
+		cOf[(size_t)cPart[k] + 1].push_back(k);
+	}
+	for (int k = 0; k < J; ++k)
+	{
+		jOf[(size_t)jPart[k] + 1].push_back(k);
+	}
+
+	SweepSet& cs = s->contacts;
+	SweepSet& js = s->joints;
+	cs = SweepSet();
+	js = SweepSet();
+	cs.colorOffsets.push_back(0);
+	js.colorOffsets.push_back(0);
+	s->hGroups.clear();
+	s->hContactTail.clear();
+	s->hJointTail.clear();
+	s->hStripA.clear();
+	s->hStripB.clear();
+
+	// ---- strips: the part that fits no LDS group, cut along BFS level sets ----
+	StripPartition strips;
+	if (wantStrips && (s->optStripsAnySolver != 0 || jOf[0].empty()))
+	{
+		std::vector<uint8_t> ownedByIsland((size_t)nb, 0);
+		auto mark = [&](int body) {
+			if (body >= 0 && conflict[body])
+			{
+				ownedByIsland[body] = 1;
+			}
+		};
+		for (int k = 0; k < C; ++k)
+		{
+			if (cPart[k] >= 0)
+			{
+				mark(ce.a[k]), mark(ce.b[k]);
+			}
+		}
+		for (int k = 0; k < J; ++k)
+		{
+			if (jPart[k] >= 0)
+			{
+				mark(je.a[k]), mark(je.b[k]);
+			}
+		}
+		std::vector<uint8_t> loose((size_t)nb);
+		int looseCount = 0;
+		for (int i = 0; i < nb; ++i)
+		{
+			loose[i] = s->hBodyLive[i] && !s->hBodyStatic[i] && !ownedByIsland[i];
+			looseCount += loose[i];
+		}
+		if (looseCount >= s->optStripMinBodies)
+		{
+			partitionStrips(ce, je, cOf[0], jOf[0], conflict, loose, nb, s->optStripBodies, s->optMaxGroupBodies, strips);
+		}
+		if (strips.active)
+		{
+			cOf[0].clear();
+			jOf[0].clear();
+		}
+	}
+
+	LocalSlots slots(nb);
+	auto gather = [&](const EdgeList& e, const std::vector<int>& ks, std::vector<int>& ids, std::vector<int>& a, std::vector<int>& b) {
+		ids.clear(), a.clear(), b.clear();
+		for (int k : ks)
+		{
+			ids.push_back(e.ids[k]);
+			a.push_back(e.a[k]);
+			b.push_back(e.b[k]);
+		}
+	};
+
+	// global part: colour batches over HBM-resident bodies (+ a sequential tail as a one-group LDS table)
+	{
+		std::vector<int> ids, a, b, pos;
+		gather(ce, cOf[0], ids, a, b);
+		colourPart(ids, a, b, conflict, nb, cs, cs.batchOffsets, cs.hasTail, &pos);
+		cs.globalCount = (int)ids.size();
+		cs.local.assign((size_t)cs.globalCount, make_int2(0, 0));
+		if (cs.hasTail)
+		{
+			HostGroupTable& t = s->hContactTail;
+			int begin = cs.batchOffsets[cs.batchOffsets.size() - 2], end = cs.batchOffsets.back();
+			slots.begin();
+			std::vector<int> bodies;
+			for (int k = begin; k < end; ++k)
+			{
+				int p = pos[(size_t)k];
+				cs.local[(size_t)k] = make_int2(slots.get(a[p], bodies, conflict), slots.get(b[p], bodies, conflict));
+			}
+			t.bodyIds = bodies;
+			t.bodyOffsets = {0, (int)bodies.size()};
+			t.cBatches.push_back(make_int4(begin, end, 1, 0));
+			t.cBatchOffsets = {0, 1};
+			t.jBatchOffsets = {0, 0};
+			t.maxBodies = (int)bodies.size();
+		}
+		gather(je, jOf[0], ids, a, b);
+		colourPart(ids, a, b, conflict, nb, js, js.batchOffsets, js.hasTail, &pos);
+		js.globalCount = (int)ids.size();
+		js.local.assign((size_t)js.globalCount, make_int2(0, 0));
+		if (js.hasTail)
+		{
+			HostGroupTable& t = s->hJointTail;
+			int begin = js.batchOffsets[js.batchOffsets.size() - 2], end = js.batchOffsets.back();
+			slots.begin();
+			std::vector<int> bodies;
+			for (int k = begin; k < end; ++k)
+			{
+				int p = pos[(size_t)k];
+				int la = a[p] >= 0 ? slots.get(a[p], bodies, conflict) : 0;
+				js.local[(size_t)k] = make_int2(la, slots.get(b[p], bodies, conflict));
+			}
+			t.bodyIds = bodies;
+			t.bodyOffsets = {0, (int)bodies.size()};
+			t.jBatches.push_back(make_int4(begin, end, 1, 0));
+			t.jBatchOffsets = {0, 1};
+			t.cBatchOffsets = {0, 0};
+			t.maxBodies = (int)bodies.size();
+		}
+	}
+
+	// one LDS group: local body slots (seeded bodies first: owned, in the given order), colour batches of
+	// its contacts and joints appended to the sweep sets, one row in table `t`
+	auto emitGroup = [&](HostGroupTable& t, const std::vector<int>& cKs, const std::vector<int>& jKs, const std::vector<int>& seedBodies,
+						 const std::vector<int>* replicaOf = nullptr, const std::vector<int>* replicaOf2 = nullptr) {
+		std::vector<int> ids, a, b, bodies, la, lb, pos, batchOffsets;
+		bool tail = false;
+		slots.begin();
+		for (int body : seedBodies)
+		{
+			slots.seed(body, bodies, true);
+		}
+		for (const std::vector<int>* list : {replicaOf, replicaOf2})
+		{
+			if (!list)
+			{
+				continue;
+			}
+			// read-only bodies of the seams this strip also sweeps in the persistent kernel (strip_kernel.hip)
+			for (int k : *list)
+			{
+				if (ce.a[k] >= 0 && !conflict[ce.a[k]])
+				{
+					slots.get(ce.a[k], bodies, conflict);
+				}
+				if (ce.b[k] >= 0 && !conflict[ce.b[k]])
+				{
+					slots.get(ce.b[k], bodies, conflict);
+				}
+			}
+		}
+		// contacts
+		gather(ce, cKs, ids, a, b);
+		la.resize(ids.size()), lb.resize(ids.size());
+		for (size_t i = 0; i < ids.size(); ++i)
+		{
+			la[i] = slots.get(a[i], bodies, conflict);
+			lb[i] = slots.get(b[i], bodies, conflict);
+		}
+		// joints (slots first so both families share one body list)
+		std::vector<int> jids, ja, jb, jla, jlb;
+		gather(je, jKs, jids, ja, jb);
+		jla.resize(jids.size()), jlb.resize(jids.size());
+		for (size_t i = 0; i < jids.size(); ++i)
+		{
+			jla[i] = ja[i] >= 0 ? slots.get(ja[i], bodies, conflict) : -1;
+			jlb[i] = slots.get(jb[i], bodies, conflict);
+		}
+		// colouring conflicts are the writable bodies (an owned kinematic body is shareable in velocity sweeps)
+		std::vector<uint8_t> lconf(bodies.size());
+		for (size_t i = 0; i < bodies.size(); ++i)
+		{
+			lconf[i] = conflict[(size_t)((uint32_t)bodies[i] & ~S2G_OWNED)];
+		}
+		colourPart(ids, la, lb, lconf, (int)bodies.size(), cs, batchOffsets, tail, &pos, &t != &s->hGroups);
+		for (size_t i = 0; i < pos.size(); ++i)
+		{
+			cs.local.push_back(make_int2(la[(size_t)pos[i]], lb[(size_t)pos[i]]));
+		}
+		for (size_t bi = 0; bi + 1 < batchOffsets.size(); ++bi)
+		{
+			bool isTail = tail && bi + 2 == batchOffsets.size();
+			if (batchOffsets[bi + 1] > batchOffsets[bi])
+			{
+				t.cBatches.push_back(make_int4(batchOffsets[bi], batchOffsets[bi + 1], isTail ? 1 : 0, 0));
+			}
+		}
+		t.cBatchOffsets.push_back((int)t.cBatches.size());
+		colourPart(jids, jla, jlb, lconf, (int)bodies.size(), js, batchOffsets, tail, &pos);
+		for (size_t i = 0; i < pos.size(); ++i)
+		{
+			js.local.push_back(make_int2(std::max(jla[(size_t)pos[i]], 0), jlb[(size_t)pos[i]]));
+		}
+		for (size_t bi = 0; bi + 1 < batchOffsets.size(); ++bi)
+		{
+			bool isTail = tail && bi + 2 == batchOffsets.size();
+			if (batchOffsets[bi + 1] > batchOffsets[bi])
+			{
+				t.jBatches.push_back(make_int4(batchOffsets[bi], batchOffsets[bi + 1], isTail ? 1 : 0, 0));
+			}
+		}
+		t.jBatchOffsets.push_back((int)t.jBatches.size());
+		for (int id : bodies)
+		{
+			t.bodyIds.push_back(id);
+			if ((uint32_t)id & S2G_OWNED)
+			{
+				flags[(size_t)((uint32_t)id & ~S2G_OWNED)] |= S2F_IN_GROUP;
+			}
+		}
+		t.bodyOffsets.push_back((int)t.bodyIds.size());
+		t.maxBodies = std::max(t.maxBodies, (int)bodies.size());
+	};
+
+	// LDS groups: whole-step kernel, bodies in LDS
+	const std::vector<int> noSeed;
+	for (int g = 0; g < groupCount; ++g)
+	{
+		emitGroup(s->hGroups, cOf[(size_t)g + 1], jOf[(size_t)g + 1], noSeed);
+	}
+
+	// strips of the big islands: phase A = interiors (own every body of the strip), phase B = seams
+	const int stripBaseC = (int)cs.order.size(), stripBaseJ = (int)js.order.size();
+	for (size_t i = 0; i < strips.bodies.size(); ++i)
+	{
+		emitGroup(s->hStripA, strips.cA[i], strips.jA[i], strips.bodies[i], i < strips.cB.size() ? &strips.cB[i] : nullptr,
+				  i > 0 ? &strips.cB[i - 1] : nullptr);
+	}
+	int stripInterior = (int)cs.order.size(), stripInteriorJ = (int)js.order.size();
+	std::vector<int> seamGroup(strips.cB.size(), -1);
+	for (size_t i = 0; i < strips.cB.size(); ++i)
+	{
+		if (!strips.cB[i].empty() || !strips.jB[i].empty())
+		{
+			seamGroup[i] = s->hStripB.count();
+			emitGroup(s->hStripB, strips.cB[i], strips.jB[i], noSeed);
+		}
+	}
+	if (strips.active)
+	{
+		cs.stripCount = (int)cs.order.size() - stripBaseC;
+		js.stripCount = (int)js.order.size() - stripBaseJ;
+		cs.seamCount = (int)cs.order.size() - stripInterior;
+		js.seamCount = (int)js.order.size() - stripInteriorJ;
+	}
+
+	s->looseBodies = 0;
+	for (int i = 0; i < nb; ++i)
+	{
+		if (s->hBodyLive[i] && !s->hBodyStatic[i] && (flags[i] & S2F_IN_GROUP) == 0)
+		{
+			s->looseBodies += 1;
+		}
+	}
+
+	// ---- device tables ----
+	int rc;
+	if ((rc = carveContacts(s, C)) != 0 || (rc = carveJoints(s, J)) != 0)
+	{
+		return rc;
+	}
+	bool grew = false;
+	if ((rc = s->dContactIndex.ensure((size_t)std::max(C, 1) * sizeof(int), &grew)) != 0 ||
+		(rc = s->dJointIndex.ensure((size_t)std::max(J, 1) * sizeof(int), &grew)) != 0 ||
+		(rc = s->dContactLocal.ensure((size_t)std::max(C, 1) * sizeof(int2), &grew)) != 0 ||
+		(rc = s->dJointLocal.ensure((size_t)std::max(J, 1) * sizeof(int2), &grew)) != 0)
+	{
+		return rc;
+	}
+	if (grew)
+	{
+		s->layoutGeneration += 1;
+	}
+	if (C > 0)
+	{
+		HIP_TRY(hipMemcpyAsync(s->dContactIndex.p, cs.order.data(), (size_t)C * sizeof(int), hipMemcpyHostToDevice, s->stream));
+		HIP_TRY(hipMemcpyAsync(s->dContactLocal.p, cs.local.data(), (size_t)C * sizeof(int2), hipMemcpyHostToDevice, s->stream));
+	}
+	if (J > 0)
+	{
+		HIP_TRY(hipMemcpyAsync(s->dJointIndex.p, js.order.data(), (size_t)J * sizeof(int), hipMemcpyHostToDevice, s->stream));
+		HIP_TRY(hipMemcpyAsync(s->dJointLocal.p, js.local.data(), (size_t)J * sizeof(int2), hipMemcpyHostToDevice, s->stream));
+	}
+	if (nb > 0)
+	{
+		HIP_TRY(hipMemcpyAsync(s->dBodyFlags.p, flags.data(), (size_t)nb * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+	}
+	s->cv.contactIndex = (int*)s->dContactIndex.p;
+	s->cv.localBodies = (int2*)s->dContactLocal.p;
+	s->cv.count = C;
+	s->jv.jointIndex = (int*)s->dJointIndex.p;
+	s->jv.localBodies = (int2*)s->dJointLocal.p;
+	s->jv.count = J;
+	if ((rc = uploadGroupTable(s, s->hGroups, s->dGroups)) != 0 || (rc = uploadGroupTable(s, s->hContactTail, s->dContactTail)) != 0 ||
+		(rc = uploadGroupTable(s, s->hJointTail, s->dJointTail)) != 0 || (rc = uploadGroupTable(s, s->hStripA, s->dStripA)) != 0 ||
+		(rc = uploadGroupTable(s, s->hStripB, s->dStripB)) != 0)
+	{
+		return rc;
+	}
+
+	// ---- lean strip tables: per-group descriptors + warm-start slots (strip_kernel.hip) ----
+	s->leanAValid = s->leanBValid = false;
+	s->persistValid = false;
+	s->leanA = StripTableView{};
+	s->leanB = StripTableView{};
+	if (strips.active && s->optStripLean)
+	{
+		const int k0 = stripBaseC, k1 = stripBaseC + cs.stripCount;
+		// body -> incident strip constraints in sweep order
+		std::vector<int> off((size_t)nb + 1, 0), inc;
+		for (int k = k0; k < k1; ++k)
+		{
+			int a = s->hContactA[cs.order[(size_t)k]], b = s->hContactB[cs.order[(size_t)k]];
+			off[(size_t)a + 1] += conflict[a] ? 1 : 0;
+			off[(size_t)b + 1] += conflict[b] ? 1 : 0;
+		}
+		for (int i = 0; i < nb; ++i)
+		{
+			off[(size_t)i + 1] += off[i];
+		}
+		inc.resize((size_t)off[nb]);
+		{
+			std::vector<int> cur(off.begin(), off.end() - 1);
+			for (int k = k0; k < k1; ++k)
+			{
+				int a = s->hContactA[cs.order[(size_t)k]], b = s->hContactB[cs.order[(size_t)k]];
+				if (conflict[a])
+				{
+					inc[(size_t)cur[a]++] = (k << 1) | 0;
+				}
+				if (conflict[b])
+				{
+					inc[(size_t)cur[b]++] = (k << 1) | 1;
+				}
+			}
+		}
+		std::vector<StripDesc> descA, descB;
+		std::vector<int2> slotList;
+		std::vector<int> slotOffsets;
+		int maxRounds = 0;
+		bool persistTablesOk = false;
+		auto describe = [&](const HostGroupTable& t, std::vector<StripDesc>& out, bool withSlots, int& ldsRecords) {
+			bool ok = true;
+			ldsRecords = 0;
+			maxRounds = 0;
+			for (int g = 0; g < t.count() && ok; ++g)
+			{
+				StripDesc d{};
+				d.bodyBase = t.bodyOffsets[(size_t)g];
+				d.bodyCount = t.bodyOffsets[(size_t)g + 1] - d.bodyBase;
+				int b0 = t.cBatchOffsets[(size_t)g], b1 = t.cBatchOffsets[(size_t)g + 1];
+				d.batchCount = b1 - b0;
+				ok = d.batchCount <= (withSlots ? S2_STRIP_ROUNDS_MAX : S2_STRIP_ROUNDS) && d.bodyCount <= S2_STRIP_BODY_CHUNKS * 256;
+				maxRounds = std::max(maxRounds, d.batchCount);
+				for (int b = b0; b < b1 && ok; ++b)
+				{
+					int4 bt = t.cBatches[(size_t)b];
+					ok = bt.z == 0;
+					d.batch[b - b0] = make_int4(bt.x, bt.y, 0, 0);
+				}
+				while (d.ownedCount < d.bodyCount && ((uint32_t)t.bodyIds[(size_t)d.bodyBase + d.ownedCount] & S2G_OWNED) != 0)
+				{
+					d.ownedCount += 1;
+				}
+				if (withSlots)
+				{
+					// phase A groups list their owned bodies first (seeded): slots in body order
+					d.slotBase = (int)slotList.size();
+					d.slotOffBase = (int)slotOffsets.size();
+					for (int i = 0; i < d.ownedCount; ++i)
+					{
+						int body = (int)((uint32_t)t.bodyIds[(size_t)d.bodyBase + i] & ~S2G_OWNED);
+						slotOffsets.push_back((int)slotList.size() - d.slotBase);
+						for (int e = off[body]; e < off[(size_t)body + 1]; ++e)
+						{
+							slotList.push_back(make_int2(inc[(size_t)e], i));
+						}
+					}
+					slotOffsets.push_back((int)slotList.size() - d.slotBase);
+					d.slotCount = (int)slotList.size() - d.slotBase;
+				}
+				int records = 2 * d.bodyCount + 2 * d.slotCount;
+				ok = ok && records <= (160 * 1024) / 16;
+				ldsRecords = std::max(ldsRecords, records);
+				out.push_back(d);
+			}
+			return ok;
+		};
+		int ldsA = 0, ldsB = 0;
+		bool okA = describe(s->hStripA, descA, true, ldsA);
+		const int maxRoundsA = maxRounds; // <= 8: the persistent kernel's wide variant; <= 6: also the lean launches
+		bool okB = describe(s->hStripB, descB, false, ldsB);
+		// owned bodies must be exactly the seeded prefix in phase A (replicas are never owned there)
+		if (okA)
+		{
+			auto pad = [](size_t n) { return (n + 63) & ~size_t(63); };
+			size_t bA = pad(descA.size() * sizeof(StripDesc)), bB = pad(std::max<size_t>(descB.size(), 1) * sizeof(StripDesc));
+			size_t bS = pad(std::max<size_t>(slotList.size(), 1) * sizeof(int2)), bO = pad(std::max<size_t>(slotOffsets.size(), 1) * sizeof(int));
+			std::vector<unsigned char> blob(bA + bB + bS + bO, 0);
+			memcpy(blob.data(), descA.data(), descA.size() * sizeof(StripDesc));
+			if (!descB.empty())
+			{
+				memcpy(blob.data() + bA, descB.data(), descB.size() * sizeof(StripDesc));
+			}
+			if (!slotList.empty())
+			{
+				memcpy(blob.data() + bA + bB, slotList.data(), slotList.size() * sizeof(int2));
+			}
+			if (!slotOffsets.empty())
+			{
+				memcpy(blob.data() + bA + bB + bS, slotOffsets.data(), slotOffsets.size() * sizeof(int));
+			}
+			bool grewLean = false;
+			if ((rc = s->dStripLean.ensure(blob.size(), &grewLean)) != 0)
+			{
+				return rc;
+			}
+			if (grewLean)
+			{
+				s->layoutGeneration += 1;
+			}
+			HIP_TRY(hipMemcpyAsync(s->dStripLean.p, blob.data(), blob.size(), hipMemcpyHostToDevice, s->stream));
+			HIP_TRY(hipStreamSynchronize(s->stream)); // blob is a local
+			const unsigned char* base = (const unsigned char*)s->dStripLean.p;
+			s->leanA.descs = (const StripDesc*)base;
+			s->leanA.bodyIds = s->dStripA.view.bodyIds;
+			s->leanA.slots = (const int2*)(base + bA + bB);
+			s->leanA.slotOffsets = (const int*)(base + bA + bB + bS);
+			s->leanA.groupCount = (int)descA.size();
+			s->leanA.ldsRecords = ldsA;
+			s->leanAValid = maxRoundsA <= S2_STRIP_ROUNDS;
+			persistTablesOk = okB;
+			if (okB)
+			{
+				s->leanB.descs = (const StripDesc*)(base + bA);
+				s->leanB.bodyIds = s->dStripB.view.bodyIds;
+				s->leanB.slots = s->leanA.slots;
+				s->leanB.slotOffsets = s->leanA.slotOffsets;
+				s->leanB.groupCount = (int)descB.size();
+				s->leanB.ldsRecords = ldsB;
+				s->leanBValid = true;
+			}
+		}
+
+		if (getenv("S2AMD_DEBUG"))
+		{
+			fprintf(stderr, "[s2amd] strips: %d strips, %d seams, lean A %d B %d, strip joints %d, CUs %d\n", s->hStripA.count(), s->hStripB.count(),
+					(int)s->leanAValid, (int)s->leanBValid, js.stripCount, s->cuCount);
+		}
+		// ---- persistent strip step (strip_kernel.hip: stripStepKernel): per workgroup both seams' remaps, the
+		// import / export lists of the symmetric exchange, warm-start term slots, granule buffers ----
+		s->persistValid = false;
+		if (persistTablesOk && js.stripCount == 0 && s->optPersist && s->hostError != nullptr && s->hStripA.count() <= s->cuCount)
+		{
+			const HostGroupTable& A = s->hStripA;
+			const HostGroupTable& B = s->hStripB;
+			const int K = A.count();
+			bool ok = true;
+			std::vector<int> ownerGroup((size_t)nb, -1), ownerSlot((size_t)nb, -1);
+			for (int gi = 0; gi < K; ++gi)
+			{
+				for (int e = A.bodyOffsets[(size_t)gi]; e < A.bodyOffsets[(size_t)gi + 1]; ++e)
+				{
+					uint32_t id = (uint32_t)A.bodyIds[(size_t)e];
+					if (id & S2G_OWNED)
+					{
+						ownerGroup[id & ~S2G_OWNED] = gi;
+						ownerSlot[id & ~S2G_OWNED] = e - A.bodyOffsets[(size_t)gi];
+					}
+				}
+				for (int bb = A.cBatchOffsets[(size_t)gi]; bb < A.cBatchOffsets[(size_t)gi + 1]; ++bb)
+				{
+					ok = ok && A.cBatches[(size_t)bb].y - A.cBatches[(size_t)bb].x <= 256; // one constraint per thread and round
+				}
+			}
+			// seams: bodies on either side, in the order of the seam group's body list
+			const int S = K - 1;
+			std::vector<std::vector<int>> leftBodies((size_t)std::max(S, 0)), rightBodies((size_t)std::max(S, 0));
+			std::vector<int> posInSeam((size_t)nb, -1);
+			for (int sm = 0; sm < S && ok; ++sm)
+			{
+				int g = seamGroup[(size_t)sm];
+				if (g < 0)
+				{
+					continue;
+				}
+				for (int e = B.bodyOffsets[(size_t)g]; e < B.bodyOffsets[(size_t)g + 1]; ++e)
+				{
+					int body = (int)((uint32_t)B.bodyIds[(size_t)e] & ~S2G_OWNED);
+					if (!conflict[body])
+					{
+						continue;
+					}
+					if (ownerGroup[body] == sm)
+					{
+						posInSeam[body] = (int)leftBodies[(size_t)sm].size();
+						leftBodies[(size_t)sm].push_back(body);
+					}
+					else if (ownerGroup[body] == sm + 1)
+					{
+						posInSeam[body] = (int)rightBodies[(size_t)sm].size();
+						rightBodies[(size_t)sm].push_back(body);
+					}
+					else
+					{
+						ok = false;
+					}
+				}
+				ok = ok && leftBodies[(size_t)sm].size() <= 256 && rightBodies[(size_t)sm].size() <= 256;
+			}
+			// granule buffers: per seam {toLeft: 4 per right body, toRight: 4 per left body}, two parities
+			std::vector<int> seamBase((size_t)std::max(S, 0), 0);
+			int granules = 0;
+			for (int sm = 0; sm < S; ++sm)
+			{
+				seamBase[(size_t)sm] = granules;
+				granules += 4 * (int)(leftBodies[(size_t)sm].size() + rightBodies[(size_t)sm].size());
+			}
+			const int parityStride = granules;
+			std::vector<PersistDesc> descs((size_t)K);
+			std::vector<int> remap, exportSrc, importIds;
+			std::vector<int> replicaStamp((size_t)nb, -1), replicaSlot((size_t)nb, -1);
+			int ldsRecords = 0, ldsRecordsWide = 0;
+			for (int i = 0; i < K && ok; ++i)
+			{
+				PersistDesc& d = descs[(size_t)i];
+				memset(&d, 0, sizeof(d));
+				const int bodyBase = A.bodyOffsets[(size_t)i];
+				const int nbA = A.bodyOffsets[(size_t)i + 1] - bodyBase;
+				for (int e = bodyBase; e < bodyBase + nbA; ++e)
+				{
+					uint32_t id = (uint32_t)A.bodyIds[(size_t)e];
+					if ((id & S2G_OWNED) == 0)
+					{
+						replicaStamp[id] = i;
+						replicaSlot[id] = e - bodyBase;
+					}
+				}
+				const int seamOf[2] = {i - 1, i};
+				int importOffset = nbA, seamSlots = 0;
+				for (int side = 0; side < 2; ++side)
+				{
+					const int sm = seamOf[side];
+					const int g = (sm >= 0 && sm < S) ? seamGroup[(size_t)sm] : -1;
+					d.importIdBase[side] = (int)importIds.size();
+					d.exportSrcBase[side] = (int)exportSrc.size();
+					d.remapBase[side] = (int)remap.size();
+					if (g < 0)
+					{
+						continue;
+					}
+					// side 0: I am the RIGHT strip of seam i-1 (import its left bodies, export its right bodies);
+					// side 1: I am the LEFT strip of seam i
+					const std::vector<int>& imports = side == 0 ? leftBodies[(size_t)sm] : rightBodies[(size_t)sm];
+					const std::vector<int>& exports = side == 0 ? rightBodies[(size_t)sm] : leftBodies[(size_t)sm];
+					d.importCount[side] = (int)imports.size();
+					d.exportCount[side] = (int)exports.size();
+					importIds.insert(importIds.end(), imports.begin(), imports.end());
+					for (int body : exports)
+					{
+						exportSrc.push_back(ownerSlot[body]);
+					}
+					const int nR = (int)rightBodies[(size_t)sm].size();
+					const int toLeft = seamBase[(size_t)sm], toRight = seamBase[(size_t)sm] + 4 * nR;
+					d.inBase[side] = side == 0 ? toRight : toLeft;
+					d.outBase[side] = side == 0 ? toLeft : toRight;
+					for (int e = B.bodyOffsets[(size_t)g]; e < B.bodyOffsets[(size_t)g + 1] && ok; ++e)
+					{
+						int body = (int)((uint32_t)B.bodyIds[(size_t)e] & ~S2G_OWNED);
+						if (ownerGroup[body] == i)
+						{
+							remap.push_back(ownerSlot[body]);
+						}
+						else if (conflict[body])
+						{
+							remap.push_back(importOffset + posInSeam[body]);
+						}
+						else if (replicaStamp[body] == i)
+						{
+							remap.push_back(replicaSlot[body]);
+						}
+						else
+						{
+							ok = false;
+						}
+					}
+					int b0 = B.cBatchOffsets[(size_t)g], b1 = B.cBatchOffsets[(size_t)g + 1];
+					d.seamBatchCount[side] = b1 - b0;
+					ok = ok && b1 - b0 <= S2_PERSIST_B_ROUNDS;
+					for (int bb = b0; bb < b1 && ok; ++bb)
+					{
+						int4 bt = B.cBatches[(size_t)bb];
+						ok = bt.z == 0;
+						d.seamBatch[side][bb - b0] = make_int2(bt.x, bt.y);
+						seamSlots += bt.y - bt.x;
+					}
+					importOffset += d.importCount[side];
+				}
+				for (int r = 0; r < S2_PERSIST_B_ROUNDS && ok; ++r)
+				{
+					int n0 = r < d.seamBatchCount[0] ? d.seamBatch[0][r].y - d.seamBatch[0][r].x : 0;
+					int n1 = r < d.seamBatchCount[1] ? d.seamBatch[1][r].y - d.seamBatch[1][r].x : 0;
+					ok = n0 + n1 <= 512; // both seams share a round: at most two constraints per thread
+				}
+				const int nt = importOffset;
+				// bodies, seam constraints (8 records each for TGS_Soft, 10 for the other kinds)
+				int fixedRecords = 3 * nt + (nt + 3) / 4; // velocity, pose, integrator constants, angular damping
+				ok = ok && fixedRecords + 8 * seamSlots + 2 * 128 <= (160 * 1024) / 16 && nt < 16384;
+				ldsRecords = std::max(ldsRecords, fixedRecords + 8 * seamSlots);
+				ldsRecordsWide = std::max(ldsRecordsWide, fixedRecords + 10 * seamSlots);
+			}
+			if (getenv("S2AMD_DEBUG"))
+			{
+				fprintf(stderr, "[s2amd] persistent step: %s (K=%d, lds records %d, granules/parity %d)\n", ok ? "eligible" : "NOT eligible", K, ldsRecords,
+						parityStride);
+			}
+			if (ok)
+			{
+				auto pad = [](size_t n) { return (n + 63) & ~size_t(63); };
+				auto bytesOf = [&](size_t n, size_t elem) { return pad(std::max<size_t>(n, 1) * elem); };
+				size_t o0 = 0, o1 = o0 + bytesOf(descs.size(), sizeof(PersistDesc)), o2 = o1 + bytesOf(remap.size(), sizeof(int));
+				size_t o3 = o2 + bytesOf(exportSrc.size(), sizeof(int)), o4 = o3 + bytesOf(importIds.size(), sizeof(int));
+				size_t o5 = o4 + 256; // the device-side "hand-off timed out" word
+				std::vector<unsigned char> blob(o5, 0);
+				auto put = [&](size_t at, const void* src, size_t bytes) {
+					if (bytes)
+					{
+						memcpy(blob.data() + at, src, bytes);
+					}
+				};
+				put(o0, descs.data(), descs.size() * sizeof(PersistDesc));
+				put(o1, remap.data(), remap.size() * sizeof(int));
+				put(o2, exportSrc.data(), exportSrc.size() * sizeof(int));
+				put(o3, importIds.data(), importIds.size() * sizeof(int));
+				bool grewP = false;
+				s->granuleBytes = ((std::max<size_t>((size_t)2 * parityStride, 1) * sizeof(unsigned long long)) + 255) & ~size_t(255);
+				if ((rc = s->dPersist.ensure(blob.size(), &grewP)) != 0 || (rc = s->dGranules.ensure(s->granuleBytes, &grewP)) != 0)
+				{
+					return rc;
+				}
+				if (grewP)
+				{
+					s->layoutGeneration += 1;
+				}
+				HIP_TRY(hipMemcpyAsync(s->dPersist.p, blob.data(), blob.size(), hipMemcpyHostToDevice, s->stream));
+				HIP_TRY(hipStreamSynchronize(s->stream));
+				const unsigned char* base = (const unsigned char*)s->dPersist.p;
+				PersistView& pv = s->persist;
+				pv = PersistView{};
+				pv.descs = (const PersistDesc*)(base + o0);
+				pv.remap = (const int*)(base + o1);
+				pv.exportSrc = (const int*)(base + o2);
+				pv.importIds = (const int*)(base + o3);
+				pv.granules = (unsigned long long*)s->dGranules.p;
+				unsigned int* devError = nullptr;
+				HIP_TRY(hipHostGetDevicePointer((void**)&devError, s->hostError, 0));
+				pv.error = devError;
+				pv.deviceError = (unsigned int*)(base + o4);
+				pv.parityStride = parityStride;
+				// fresh buffers start from zero tags
+				HIP_TRY(hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, s->stream));
+				pv.wideRounds = maxRoundsA > S2_STRIP_ROUNDS ? 1 : 0;
+				pv.allTwoPoints = 1;
+				for (int k = k0; k < k1; ++k)
+				{
+					if (s->hContactPoints[(size_t)cs.order[(size_t)k]] != 2)
+					{
+						pv.allTwoPoints = 0;
+						break;
+					}
+				}
+				pv.ldsRecords = ldsRecords;
+				s->persistRecordsWide = ldsRecordsWide;
+				pv.debugSkip = s->optPersistDebug;
+				pv.spinLimit = (unsigned int)s->optPersistSpinLimit;
+				pv.debugTimes = nullptr;
+				if (getenv("S2AMD_DEBUG_TIMES"))
+				{
+					if (!s->hostTimes && hipHostMalloc((void**)&s->hostTimes, 256 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess)
+					{
+						s->hostTimes = nullptr;
+						(void)hipGetLastError();
+					}
+					if (s->hostTimes)
+					{
+						memset(s->hostTimes, 0, 256 * sizeof(unsigned long long));
+						unsigned long long* dev = nullptr;
+						if (hipHostGetDevicePointer((void**)&dev, s->hostTimes, 0) == hipSuccess)
+						{
+							pv.debugTimes = dev;
+						}
+					}
+				}
+				s->persistValid = true;
+			}
+		}
+	}
+
+	// strips only pay through the strip kernels: when neither the persistent step nor the lean launches can take this
+	// partition (too many colours, a hub body, LDS budget), fall back to the colour-batch structure for this graph
+	if (strips.active && !s->optStripsAnySolver && !s->persistValid && !(s->leanAValid && s->leanBValid))
+	{
+		s->stripsRejected = true;
+		s->structureDirty = true;
+		return buildStructure(s, solverType);
+	}
+
+	// ---- message-passing tables of the global part (see MsgBodies) ----
+	s->msgTablesValid = false;
+	if (cs.globalCount > 0 && js.globalCount == 0 && !cs.hasTail && !needAdj)
+	{
+		const int G = cs.globalCount;
+		std::vector<int> offsets((size_t)nb + 1, 0), list((size_t)2 * G), next((size_t)2 * G, 0), first((size_t)nb, -1);
+		for (int k = 0; k < G; ++k)
+		{
+			offsets[(size_t)s->hContactA[cs.order[k]] + 1] += 1;
+			offsets[(size_t)s->hContactB[cs.order[k]] + 1] += 1;
+		}
+		for (int i = 0; i < nb; ++i)
+		{
+			offsets[(size_t)i + 1] += offsets[i];
+		}
+		std::vector<int> cursor(offsets.begin(), offsets.end() - 1);
+		for (int k = 0; k < G; ++k) // ascending k: every body's copies end up in sweep order
+		{
+			list[(size_t)cursor[s->hContactA[cs.order[k]]]++] = 2 * k;
+			list[(size_t)cursor[s->hContactB[cs.order[k]]]++] = 2 * k + 1;
+		}
+		for (int i = 0; i < nb; ++i)
+		{
+			int b0 = offsets[i], b1 = offsets[(size_t)i + 1];
+			if (b1 > b0)
+			{
+				first[i] = list[(size_t)b0];
+				for (int e = b0; e < b1; ++e)
+				{
+					next[(size_t)list[(size_t)e]] = list[(size_t)(e + 1 < b1 ? e + 1 : b0)];
+				}
+			}
+		}
+		size_t bytes = (size_t)2 * G * (2 * sizeof(float4) + 2 * sizeof(int)) + ((size_t)2 * nb + 1) * sizeof(int) + 1024;
+		grew = false;
+		if ((rc = s->dMsg.ensure(bytes, &grew)) != 0)
+		{
+			return rc;
+		}
+		if (grew)
+		{
+			s->layoutGeneration += 1;
+		}
+		Carver cvr{(char*)s->dMsg.p, (char*)s->dMsg.p + s->dMsg.bytes};
+		float4* dvel = cvr.take<float4>((size_t)2 * G);
+		float4* ddq = cvr.take<float4>((size_t)2 * G);
+		int* dnext = cvr.take<int>((size_t)2 * G);
+		int* dlist = cvr.take<int>((size_t)2 * G);
+		int* dfirst = cvr.take<int>((size_t)nb);
+		int* doffsets = cvr.take<int>((size_t)nb + 1);
+		if (cvr.p > cvr.end)
+		{
+			// alignment slack exceeded: grow once more
+			if ((rc = s->dMsg.ensure(bytes + 8192, &grew)) != 0)
+			{
+				return rc;
+			}
+			s->layoutGeneration += 1;
+			cvr = Carver{(char*)s->dMsg.p, (char*)s->dMsg.p + s->dMsg.bytes};
+			dvel = cvr.take<float4>((size_t)2 * G);
+			ddq = cvr.take<float4>((size_t)2 * G);
+			dnext = cvr.take<int>((size_t)2 * G);
+			dlist = cvr.take<int>((size_t)2 * G);
+			dfirst = cvr.take<int>((size_t)nb);
+			doffsets = cvr.take<int>((size_t)nb + 1);
+		}
+		HIP_TRY(hipMemcpyAsync(dnext, next.data(), next.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+		HIP_TRY(hipMemcpyAsync(dlist, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+		HIP_TRY(hipMemcpyAsync(dfirst, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+		HIP_TRY(hipMemcpyAsync(doffsets, offsets.data(), offsets.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+		HIP_TRY(hipStreamSynchronize(s->stream));
+		s->msg.vel = dvel, s->msg.dq = ddq, s->msg.next = dnext, s->msg.firstSlot = dfirst, s->msg.slotOffsets = doffsets, s->msg.slotList = dlist;
+		s->msgTablesValid = true;
+	}
+
+	s->adjValid = false;
+	{
+		// body -> incident constraints in SWEEP order (ascending k), key = k<<1 | side, so the per-body
+		// sums of jacobiApplyKernel add in exactly the order a sequential pass in sweep order would;
+		// read-only shareable bodies are skipped (their deltas are exact zeros)
+		std::vector<int> offsets((size_t)nb + 1, 0), list;
+		const int GC = cs.globalCount; // LDS groups walk their own colours; only the global part is indexed
+		for (int k = 0; k < GC; ++k)
+		{
+			int a = s->hContactA[cs.order[k]], b = s->hContactB[cs.order[k]];
+			if (conflict[a])
+			{
+				offsets[(size_t)a + 1] += 1;
+			}
+			if (conflict[b])
+			{
+				offsets[(size_t)b + 1] += 1;
+			}
+		}
+		for (int i = 0; i < nb; ++i)
+		{
+			offsets[(size_t)i + 1] += offsets[i];
+		}
+		list.resize((size_t)offsets[nb]);
+		std::vector<int> cursor(offsets.begin(), offsets.end() - 1);
+		for (int k = 0; k < GC; ++k)
+		{
+			int a = s->hContactA[cs.order[k]], b = s->hContactB[cs.order[k]];
+			if (conflict[a])
+			{
+				list[(size_t)cursor[a]++] = (k << 1) | 0;
+			}
+			if (conflict[b])
+			{
+				list[(size_t)cursor[b]++] = (k << 1) | 1;
+			}
+		}
+		grew = false;
+		if ((rc = s->dAdjOffsets.ensure(((size_t)nb + 1) * sizeof(int), &grew)) != 0 ||
+			(rc = s->dAdjList.ensure(std::max<size_t>(list.size(), 1) * sizeof(int), &grew)) != 0)
+		{
+			return rc;
+		}
+		if (grew)
+		{
+			s->layoutGeneration += 1;
+		}
+		HIP_TRY(hipMemcpyAsync(s->dAdjOffsets.p, offsets.data(), ((size_t)nb + 1) * sizeof(int), hipMemcpyHostToDevice, s->stream));
+		if (!list.empty())
+		{
+			HIP_TRY(hipMemcpyAsync(s->dAdjList.p, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+		}
+		s->adjValid = true;
+	}
+	// the staging vectors above die with this scope: hipMemcpyAsync from pageable host memory
+	// copies through a staging buffer before it returns, so that is safe
+	HIP_TRY(hipStreamSynchronize(s->stream));
+
+	s->orderSolverClass = cls;
+	s->orderGrouped = grouped;
+	s->orderStrips = wantStrips;
+	s->structureDirty = false;
+	s->structureGeneration += 1;
+	s->stats.hostPrepMs = (float)(nowMs() - t0);
+	return S2AMD_OK;
+}

@@ -1,4 +1,4 @@
-// Strip kernel: the lean launch of the strip path (solver.cpp: partitionStrips) for the soft contact
+// Strip kernel: the lean launch of the strip path (solver_structure.cpp: partitionStrips) for the soft contact
 // sweeps -- s2SolveContacts_TGS_Soft / _PGS_Soft / _TGS_Fixed, plus the body stages and the contact warm
 // start that sit between two sweeps in their drivers.  One workgroup (256 threads = one wave per SIMD,
 // the whole register file) per strip (phase A) or seam (phase B).

@@ -9,7 +9,7 @@
 //                            lowest colour unused by its already-coloured neighbours once every neighbour of higher
 //                            priority is coloured.  The outcome equals a sequential greedy colouring in descending
 //                            priority order, so it is deterministic and has an exact CPU statement
-//                            (tests/structure_ref.py) -- unlike the host's pool-order greedy (solver.cpp: colorGraph),
+//                            (tests/structure_ref.py) -- unlike the host's pool-order greedy (graph_coloring.cpp: colorGraph),
 //                            whose dependency chains are as long as the pool.
 // Integer work; results are compared exactly.  Host arrays in and out like the other stage calls.
 

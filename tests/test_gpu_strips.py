@@ -1,4 +1,4 @@
-"""Strips: an island that fits no LDS group is cut along BFS level sets (solver.cpp: partitionStrips);
+"""Strips: an island that fits no LDS group is cut along BFS level sets (solver_structure.cpp: partitionStrips);
 a Gauss-Seidel sweep becomes phase A (strip interiors) + phase B (seams) = two launches.
 
 Same gate as test_gpu_parity.py: the C-ABI result must equal the oracle BIT FOR BIT when the oracle

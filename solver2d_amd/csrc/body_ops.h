@@ -126,6 +126,7 @@ S2_DEV void unpackBodyOne(const BodyView& b, const s2amdBody* wire, const uint32
 	b.vel[i] = make_float4(w->linearVelocity[0], w->linearVelocity[1], w->angularVelocity, 0.0f);
 	b.dq[i] = make_float4(w->deltaPosition[0], w->deltaPosition[1], w->rot[0], w->rot[1]);
 	b.pos[i] = make_float2(w->position[0], w->position[1]);
+	b.massInv[i] = make_float2(w->invMass, w->invI);
 
 	V2 gravity = v2(sc.gravityX, sc.gravityY);
 	V2 force = v2(w->force[0], w->force[1]);

@@ -18,6 +18,7 @@
 template <bool LOCAL> struct BodiesT
 {
 	static constexpr int kMode = LOCAL ? S2_IDX_LOCAL : S2_IDX_GLOBAL;
+	static constexpr bool kLdsMass = false;
 	float4* vel;
 	float4* dq;
 	S2_DEV float4 getVel(int i) const { return vel[i]; }
@@ -39,6 +40,20 @@ S2_DEV void pin(float2& v)
 typedef BodiesT<false> GlobalBodies; // indices are body-pool slots, arrays are the HBM SoA
 typedef BodiesT<true> LdsBodies;	 // indices are group-local slots, arrays live in LDS
 
+// The group kernel's accessor: besides the two body records, the inverse mass and inertia of every staged body
+// sit in LDS, so a constraint sweep does not stream its own copy of them (c.mass, 16 B per constraint and
+// sweep) from HBM/L2.  When the plan prepared the contacts with PREP_SOFT, the three soft coefficients are one
+// of two step-wide triples (solve_common.c:219, 262-271: they depend only on h, the contact hertz and on
+// whether a side is static), so c.soft (32 B) is not streamed either: softCoef[0] is the triple of a
+// dynamic-dynamic constraint, softCoef[1] of one with a static side; softDiet == 0 keeps the loads.
+struct LdsMassBodies : BodiesT<true>
+{
+	static constexpr bool kLdsMass = true;
+	const float2* massInv; // {invMass, invI} per local slot
+	float4 softCoef[2];
+	int softDiet;
+};
+
 // "Message passing" accessor for the big-island path.  Every constraint side owns a private copy of
 // its body's two records, so a sweep kernel reads them at a computed address (no index load, no
 // dependent gather: one memory round trip instead of two) and writes the updated velocity into the
@@ -48,6 +63,7 @@ typedef BodiesT<true> LdsBodies;	 // indices are group-local slots, arrays live 
 struct MsgBodies
 {
 	static constexpr int kMode = S2_IDX_MESSAGE;
+	static constexpr bool kLdsMass = false;
 	float4* vel;	 // [2C]
 	float4* dq;		 // [2C]
 	const int* next; // [2C]
@@ -82,6 +98,31 @@ template <int MODE> S2_DEV CHeader loadHeader(const ContactView& c, int k)
 	h.writeA = (bits & S2C_WRITE_A) != 0;
 	h.writeB = (bits & S2C_WRITE_B) != 0;
 	return h;
+}
+
+// header through the accessor: the LDS-mass accessor looks the masses up by local slot
+template <class BA> S2_DEV CHeader loadHeaderB(const ContactView& c, const BA& b, int k)
+{
+	if constexpr (BA::kLdsMass)
+	{
+		CHeader h;
+		int2 ib = c.localBodies[k];
+		float4 nf = c.nf[k];
+		h.ia = ib.x, h.ib = ib.y;
+		float2 a = b.massInv[ib.x], bb = b.massInv[ib.y];
+		h.mA = a.x, h.iA = a.y, h.mB = bb.x, h.iB = bb.y;
+		h.normal = v2(nf.x, nf.y);
+		h.friction = nf.z;
+		uint32_t bits = asBits(nf.w);
+		h.pointCount = (int)(bits & 0xffu);
+		h.writeA = (bits & S2C_WRITE_A) != 0;
+		h.writeB = (bits & S2C_WRITE_B) != 0;
+		return h;
+	}
+	else
+	{
+		return loadHeader<BA::kMode>(c, k);
+	}
 }
 
 struct BodyVel
@@ -128,7 +169,7 @@ template <class BA> S2_DEV void storePose(const BA& b, int i, V2 dc, Rot q)
 template <int KIND, class BA>
 S2_DEV void warmStartContactsOne(const ContactView& c, const BA& b, int k)
 {
-	CHeader h = loadHeader<BA::kMode>(c, k);
+	CHeader h = loadHeaderB(c, b, k);
 	int pointCount = h.pointCount;
 	V2 tangent = rightPerp(h.normal);
 	if (KIND == WARM_BLOCK)
@@ -234,6 +275,66 @@ template <int KIND, int MODE> S2_DEV SoftRegs<KIND> loadSoft(const ContactView& 
 	return r;
 }
 
+// Loads through the accessor.  With the LDS-mass accessor the header's masses and (softDiet) the soft
+// coefficients are NOT loaded here: completeSoft fills them at solve time, next to the body reads, so a
+// preloaded chunk of rounds has no LDS lookup hanging on its first global load.
+template <int KIND, class BA> S2_DEV SoftRegs<KIND> loadSoftB(const ContactView& c, const BA& b, int k)
+{
+	if constexpr (BA::kLdsMass)
+	{
+		SoftRegs<KIND> r;
+		int2 ib = c.localBodies[k];
+		float4 nf = c.nf[k];
+		r.h.ia = ib.x, r.h.ib = ib.y;
+		r.h.mA = r.h.iA = r.h.mB = r.h.iB = 0.0f;
+		r.h.normal = v2(nf.x, nf.y);
+		r.h.friction = nf.z;
+		uint32_t bits = asBits(nf.w);
+		r.h.pointCount = (int)(bits & 0xffu);
+		r.h.writeA = (bits & S2C_WRITE_A) != 0;
+		r.h.writeB = (bits & S2C_WRITE_B) != 0;
+#pragma unroll
+		for (int j = 0; j < 2; ++j)
+		{
+			if (KIND == SOFT_TGS || KIND == SOFT_FIXED)
+			{
+				r.an[j] = c.anchor[j][k];
+			}
+			if (KIND != SOFT_TGS)
+			{
+				r.r0[j] = c.r0[j][k];
+			}
+			r.par[j] = c.param[j][k];
+			if (b.softDiet == 0)
+			{
+				r.sf[j] = c.soft[j][k];
+			}
+			r.imp[j] = c.impulse[j][k];
+		}
+		return r;
+	}
+	else
+	{
+		return loadSoft<KIND, BA::kMode>(c, k);
+	}
+}
+
+template <int KIND, class BA> S2_DEV void completeSoft(SoftRegs<KIND>& r, const BA& b)
+{
+	if constexpr (BA::kLdsMass)
+	{
+		float2 a = b.massInv[r.h.ia], bb = b.massInv[r.h.ib];
+		r.h.mA = a.x, r.h.iA = a.y, r.h.mB = bb.x, r.h.iB = bb.y;
+		if (b.softDiet)
+		{
+			// contact_kernels.hip prepareContactsKernel<PREP_SOFT>: contactHertz doubles when a side is static
+			float4 sf = (a.x == 0.0f || bb.x == 0.0f) ? b.softCoef[1] : b.softCoef[0];
+			r.sf[0] = sf;
+			r.sf[1] = sf;
+		}
+	}
+}
+
 template <int KIND> S2_DEV void pinSoft(SoftRegs<KIND>& r)
 {
 #pragma unroll
@@ -259,6 +360,7 @@ template <int KIND> S2_DEV void pinSoft(SoftRegs<KIND>& r)
 template <int KIND, class BA, bool PIN = true, int POINTS = 0>
 S2_DEV void solveSoftRegs(SoftRegs<KIND>& r, const ContactView& c, const BA& b, float inv_h, int useBias, int k)
 {
+	completeSoft(r, b);
 	const CHeader& h = r.h;
 	const float biasCap = (KIND == SOFT_TGS || KIND == SOFT_JACOBI) ? -S2_MAX_BAUMGARTE_VELOCITY : -0.5f * S2_MAX_BAUMGARTE_VELOCITY;
 	float4* an = r.an;
@@ -403,7 +505,7 @@ template <int KIND, class BA>
 S2_DEV void solveContactsSoftOne(const ContactView& c, const BA& b, float inv_h, int useBias, int k)
 {
 	// all loads first (one memory round trip for the constraint, one for the bodies)
-	SoftRegs<KIND> r = loadSoft<KIND, BA::kMode>(c, k);
+	SoftRegs<KIND> r = loadSoftB<KIND>(c, b, k);
 	solveSoftRegs<KIND>(r, c, b, inv_h, useBias, k);
 	storeSoft<KIND>(c, r, k);
 }
@@ -417,7 +519,7 @@ S2_DEV void solveContactsSoftOne(const ContactView& c, const BA& b, float inv_h,
 template <int KIND, class BA>
 S2_DEV void solveContactsRigidOne(const ContactView& c, const BA& b, float inv_h, int k)
 {
-	CHeader h = loadHeader<BA::kMode>(c, k);
+	CHeader h = loadHeaderB(c, b, k);
 	BodyVel A = loadVel(b, h.ia), B = loadVel(b, h.ib);
 	V2 vA = A.v, vB = B.v;
 	float wA = A.w, wB = B.w;
@@ -600,7 +702,7 @@ S2_DEV void solveContactsRigidOne(const ContactView& c, const BA& b, float inv_h
 template <class BA>
 S2_DEV void solveContactsStickyOne(const ContactView& c, const BA& b, s2amdContact* wire, float inv_h, int useBias, int k)
 {
-	CHeader h = loadHeader<BA::kMode>(c, k);
+	CHeader h = loadHeaderB(c, b, k);
 	const float contactBaumgarte = 0.8f;
 	const float frictionBaumgarte = 0.5f;
 	BodyVel A = loadVel(b, h.ia), B = loadVel(b, h.ib);
@@ -711,7 +813,7 @@ S2_DEV void solveContactsStickyOne(const ContactView& c, const BA& b, s2amdConta
 template <class BA>
 S2_DEV void solveContactsNGSOne(const ContactView& c, const BA& b, int k)
 {
-	CHeader h = loadHeader<BA::kMode>(c, k);
+	CHeader h = loadHeaderB(c, b, k);
 	BodyPose pA = loadPose(b, h.ia), pB = loadPose(b, h.ib);
 	V2 dcA = pA.dc, dcB = pB.dc;
 	Rot qA = pA.q, qB = pB.q;
@@ -759,7 +861,7 @@ S2_DEV void solveContactsNGSOne(const ContactView& c, const BA& b, int k)
 template <class BA>
 S2_DEV void xpbdContactPositionsOne(const ContactView& c, const BA& b, float hh, int k)
 {
-	CHeader h = loadHeader<BA::kMode>(c, k);
+	CHeader h = loadHeaderB(c, b, k);
 	const float baseCompliance = 0.0f;
 	float mA = h.mA, iA = h.iA, mB = h.mB, iB = h.iB;
 	float compliance = (mA == 0.0f || mB == 0.0f) ? 0.25f * baseCompliance : baseCompliance;
@@ -854,7 +956,7 @@ S2_DEV void xpbdContactPositionsOne(const ContactView& c, const BA& b, float hh,
 template <class BA>
 S2_DEV void xpbdContactVelocitiesOne(const ContactView& c, const BA& b, float hh, int k)
 {
-	CHeader h = loadHeader<BA::kMode>(c, k);
+	CHeader h = loadHeaderB(c, b, k);
 	float inv_h = hh > 0.0f ? 1.0f / hh : 0.0f;
 	float mA = h.mA, iA = h.iA, mB = h.mB, iB = h.iB;
 	BodyVel A = loadVel(b, h.ia), B = loadVel(b, h.ib);
@@ -956,7 +1058,7 @@ S2_DEV void xpbdContactVelocitiesOne(const ContactView& c, const BA& b, float hh
 template <class BA>
 S2_DEV void blockSolveVelocityOne(const ContactView& c, const BA& b, int k)
 {
-	CHeader h = loadHeader<BA::kMode>(c, k);
+	CHeader h = loadHeaderB(c, b, k);
 	float4 K4 = c.blockK[k];
 	int pointCount = (int)asBits(K4.w);
 	BodyVel A = loadVel(b, h.ia), B = loadVel(b, h.ib);
@@ -1122,7 +1224,7 @@ S2_DEV void blockSolveVelocityOne(const ContactView& c, const BA& b, int k)
 template <class BA>
 S2_DEV void blockSolvePositionOne(const ContactView& c, const BA& b, int k)
 {
-	CHeader h = loadHeader<BA::kMode>(c, k);
+	CHeader h = loadHeaderB(c, b, k);
 	int pointCount = (int)asBits(c.blockK[k].w);
 	const float slop = S2_LINEAR_SLOP;
 	float mA = h.mA, iA = h.iA, mB = h.mB, iB = h.iB;

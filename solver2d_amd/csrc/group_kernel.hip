@@ -27,7 +27,6 @@ S2_DEV void prefetchContact(const ContactView& c, int k)
 {
 	int2 b = c.localBodies[k];
 	asm volatile("" ::"v"(b.x), "v"(b.y));
-	touch(c.mass[k]);
 	touch(c.nf[k]);
 	touch(c.blockK[k]);
 	touch(c.blockNM[k]);
@@ -110,7 +109,7 @@ S2_DEV void sweepSoftPreloaded(const ContactView& c, const LB& lb, const int4* b
 				if (bt.z == 0 && k < bt.y)
 				{
 					kk[i] = k;
-					r[i] = loadSoft<KIND, S2_IDX_LOCAL>(c, k);
+					r[i] = loadSoftB<KIND>(c, lb, k);
 				}
 			}
 		}
@@ -165,6 +164,7 @@ __global__ __launch_bounds__(THREADS) void groupKernel(ContactView c, JointView 
 	float4* lvel = lds;
 	float4* ldq = lds + nb;
 	float4* ldq0 = lds + 2 * nb; // only addressed when useDq0
+	float2* lmass = (float2*)(lds + (useDq0 ? 3 : 2) * nb);
 	const int* ids = gt.bodyIds + bodyBase;
 
 	for (int i = threadIdx.x; i < nb; i += blockDim.x)
@@ -172,6 +172,7 @@ __global__ __launch_bounds__(THREADS) void groupKernel(ContactView c, JointView 
 		int gi = (int)((uint32_t)ids[i] & ~S2G_OWNED);
 		lvel[i] = g.vel[gi];
 		ldq[i] = g.dq[gi];
+		lmass[i] = g.massInv[gi];
 		if (useDq0)
 		{
 			ldq0[i] = g.dq0[gi];
@@ -179,7 +180,11 @@ __global__ __launch_bounds__(THREADS) void groupKernel(ContactView c, JointView 
 	}
 	__syncthreads();
 
-	LdsBodies lb{lvel, ldq};
+	LdsMassBodies lb;
+	lb.vel = lvel, lb.dq = ldq, lb.massInv = lmass;
+	lb.softCoef[0] = make_float4(sc.softCoef[0][0], sc.softCoef[0][1], sc.softCoef[0][2], 0.0f);
+	lb.softCoef[1] = make_float4(sc.softCoef[1][0], sc.softCoef[1][1], sc.softCoef[1][2], 0.0f);
+	lb.softDiet = sc.softDiet;
 	auto pfC = [&](int k) { prefetchContact(c, k); };
 	auto pfJ = [&](int k) { prefetchJoint(jv, k); };
 	const int cb0 = gt.cBatchOffsets[grp], cb1 = gt.cBatchOffsets[grp + 1];
@@ -375,7 +380,7 @@ void launchStripKernel(hipStream_t s, const ContactView& c, const JointView& j, 
 	{
 		return;
 	}
-	size_t lds = (size_t)maxBodies * (useDq0 ? 48 : 32);
+	size_t lds = (size_t)maxBodies * (useDq0 ? 56 : 40);
 	groupKernel<S2_STRIP_THREADS, S2_STRIP_PRELOAD>
 		<<<dim3((unsigned)gt.groupCount), dim3(S2_STRIP_THREADS), lds, s>>>(c, j, g, gt, ops, opCount, sc, wire, useDq0);
 }
@@ -387,6 +392,6 @@ void launchGroupKernel(hipStream_t s, const ContactView& c, const JointView& j, 
 	{
 		return;
 	}
-	size_t lds = (size_t)maxBodies * (useDq0 ? 48 : 32);
+	size_t lds = (size_t)maxBodies * (useDq0 ? 56 : 40);
 	groupKernel<S2_GROUP_THREADS, 0><<<dim3((unsigned)gt.groupCount), dim3(S2_GROUP_THREADS), lds, s>>>(c, j, g, gt, ops, opCount, sc, wire, useDq0);
 }

@@ -321,6 +321,7 @@ struct BodyView
 	// per-step constants of the velocity integrator, precomputed once per step by unpackBodies
 	float4* integ;	// {h*invMass*(f + m*g*gs).x, ....y, h*invI*torque, 1/(1+h*linearDamping)}
 	float* angDamp; // 1/(1+h*angularDamping)
+	float2* massInv; // {invMass, invI}: staged into LDS by the group kernel (constraint_ops.h LdsMassBodies)
 	uint32_t* flags;
 	// Jacobi accumulation and XPBD history
 	float4* dq0; // XPBD: {deltaPosition0, rot0}
@@ -384,6 +385,11 @@ struct StepConsts
 	float gravityX, gravityY;
 	int iterations, extraIterations;
 	int warmStart;
+	// PREP_SOFT plans: the soft-contact coefficient triples {bias, mass, impulse} of a dynamic-dynamic
+	// constraint [0] and of one with a static side [1] (solve_common.c:219, 262-271), computed on the host with the
+	// operations of prepareContactsKernel; softDiet == 0 for every other plan
+	float softCoef[2][3];
+	int softDiet;
 };
 
 S2_DEV uint32_t asBits(float f) { return __float_as_uint(f); }

@@ -359,6 +359,22 @@ void buildPlan(s2amdSolver* s, const s2amdStepParams* params)
 			b.solveXpbd();
 			break;
 	}
+	// the two soft-coefficient triples of a PREP_SOFT plan, with prepareContactsKernel's operations
+	p.sc.softDiet = p.prepContacts == PREP_SOFT ? 1 : 0;
+	for (int i = 0; i < 2; ++i)
+	{
+		float contactHertz = i == 1 ? 2.0f * p.prepHertz : p.prepHertz;
+		const float zeta = 10.0f;
+		float h = p.prepH;
+		float omega = 2.0f * S2_PI * contactHertz;
+		float cc = h * omega * (2.0f * zeta + h * omega);
+		float biasCoefficient = omega / (2.0f * zeta + h * omega);
+		float impulseCoefficient = 1.0f / (1.0f + cc);
+		float massCoefficient = cc * impulseCoefficient;
+		p.sc.softCoef[i][0] = biasCoefficient;
+		p.sc.softCoef[i][1] = massCoefficient;
+		p.sc.softCoef[i][2] = impulseCoefficient;
+	}
 	p.valid = true;
 	s->planGeneration += 1;
 }

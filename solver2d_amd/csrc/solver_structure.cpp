@@ -40,7 +40,7 @@ int growFamily(s2amdSolver* s, DevBuf& buf, int& cap, int need, size_t slotBytes
 	return S2AMD_OK;
 }
 
-constexpr size_t kBodySlotBytes = sizeof(float4) * 4 + sizeof(float2) + sizeof(float) + sizeof(uint32_t);
+constexpr size_t kBodySlotBytes = sizeof(float4) * 4 + sizeof(float2) * 2 + sizeof(float) + sizeof(uint32_t);
 constexpr size_t kContactSlotBytes = sizeof(int2) + sizeof(float4) * 2 + 2 * (sizeof(float4) * 5 + sizeof(float2)) + sizeof(float4) * 4;
 constexpr size_t kJointSlotBytes = sizeof(int2) + sizeof(float4) * 8 + sizeof(float2) * 3;
 
@@ -48,7 +48,7 @@ constexpr size_t kJointSlotBytes = sizeof(int2) + sizeof(float4) * 8 + sizeof(fl
 
 int carveBodies(s2amdSolver* s, int n)
 {
-	int rc = growFamily(s, s->soaBodies, s->bodySoaCap, n, kBodySlotBytes, 8);
+	int rc = growFamily(s, s->soaBodies, s->bodySoaCap, n, kBodySlotBytes, 9);
 	if (rc)
 	{
 		return rc;
@@ -60,6 +60,7 @@ int carveBodies(s2amdSolver* s, int n)
 	s->bv.integ = c.take<float4>(cap);
 	s->bv.dq0 = c.take<float4>(cap);
 	s->bv.pos = c.take<float2>(cap);
+	s->bv.massInv = c.take<float2>(cap);
 	s->bv.angDamp = c.take<float>(cap);
 	s->bv.flags = c.take<uint32_t>(cap);
 	s->bv.capacity = n;
@@ -1285,6 +1286,21 @@ int buildStructure(s2amdSolver* s, int solverType)
 			{
 				fprintf(stderr, "[s2amd] persistent step: %s (K=%d, lds records %d, granules/parity %d)\n", ok ? "eligible" : "NOT eligible", K, ldsRecords,
 						parityStride);
+				int histA[16] = {0}, histB[16] = {0};
+				for (int i = 0; i < K; ++i)
+				{
+					int ra = A.cBatchOffsets[(size_t)i + 1] - A.cBatchOffsets[(size_t)i];
+					int rb = std::max(descs[(size_t)i].seamBatchCount[0], descs[(size_t)i].seamBatchCount[1]);
+					histA[std::min(ra, 15)] += 1;
+					histB[std::min(rb, 15)] += 1;
+				}
+				for (int r = 0; r < 16; ++r)
+				{
+					if (histA[r] || histB[r])
+					{
+						fprintf(stderr, "[s2amd]   rounds %d: %d interiors, %d seam pairs\n", r, histA[r], histB[r]);
+					}
+				}
 			}
 			if (ok)
 			{

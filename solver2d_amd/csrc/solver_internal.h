@@ -190,6 +190,7 @@ struct s2amdSolver
 	DevBuf dPersist, dGranules;
 	PersistView persist{};
 	bool persistValid = false;
+	int persistK0 = 0, persistK1 = 0; // the strip constraints' range in contacts.order (persist.allTwoPoints is recomputed over it)
 	int persistRecordsWide = 0; // LDS records when a seam constraint takes 10 records (every kind but TGS_Soft's)
 	DevBuf dPersistOps;
 	int persistOpCount = 0;
@@ -251,7 +252,8 @@ struct s2amdSolver
 };
 
 StepConsts makeConsts(const s2amdStepParams* p);
-int carveBodies(s2amdSolver* s, int n); // (re)carves the body SoA family for n slots
+int carveBodies(s2amdSolver* s, int n);
+bool stripsAllTwoPoints(const s2amdSolver* s); // (re)carves the body SoA family for n slots
 int buildStructure(s2amdSolver* s, int solverType);
 void buildPlan(s2amdSolver* s, const s2amdStepParams* params);
 bool messageEligible(const s2amdSolver* s, int solverType);

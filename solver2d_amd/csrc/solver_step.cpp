@@ -57,10 +57,12 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 		s->hContactB.assign(nc, -1);
 		s->hContactPoints.assign(nc, 0);
 	}
+	bool pointCountsMoved = false;
 	for (int i = 0; i < nc; ++i)
 	{
 		const s2amdContact& c = contacts[i];
 		int pc = c.pointCount > 0 ? c.pointCount : 0;
+		pointCountsMoved = pointCountsMoved || s->hContactPoints[i] != pc;
 		if (!changed && (s->hContactA[i] != c.bodyA || s->hContactB[i] != c.bodyB || (s->hContactPoints[i] > 0) != (pc > 0)))
 		{
 			changed = true;
@@ -100,6 +102,12 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 				return fail(S2AMD_E_INVALID, "joint " + std::to_string(i) + " has an invalid body index");
 			}
 		}
+	}
+	if (!changed && pointCountsMoved && s->persistValid)
+	{
+		// same graph, but a manifold went from two points to one or back: the persistent kernel's two-point
+		// fast path is a property of the point counts, not of the graph (the step graph is keyed on it)
+		s->persist.allTwoPoints = stripsAllTwoPoints(s) ? 1 : 0;
 	}
 	if (changed)
 	{
@@ -292,7 +300,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	{
 		uint64_t key = 1469598103934665603ull;
 		key = fnv(key, params, sizeof(*params));
-		uint64_t gens[4] = {s->layoutGeneration, s->structureGeneration, s->planGeneration, (uint64_t)((q.msg ? 1 : 0) | (s->optBodyWarm ? 2 : 0) | (s->optStripLean ? 4 : 0) | (s->optPersist ? 8 : 0) | (s->optFork ? 16 : 0) | (s->persistFailed ? 32 : 0))};
+		uint64_t gens[4] = {s->layoutGeneration, s->structureGeneration, s->planGeneration, (uint64_t)((q.msg ? 1 : 0) | (s->optBodyWarm ? 2 : 0) | (s->optStripLean ? 4 : 0) | (s->optPersist ? 8 : 0) | (s->optFork ? 16 : 0) | (s->persistFailed ? 32 : 0) | ((s->persistValid && s->persist.allTwoPoints) ? 64 : 0))};
 		key = fnv(key, gens, sizeof(gens));
 		int sizes[3] = {s->bodyCapacity, s->contactCapacity, s->jointCapacity};
 		key = fnv(key, sizes, sizeof(sizes));

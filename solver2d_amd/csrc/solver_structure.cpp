@@ -46,6 +46,19 @@ constexpr size_t kJointSlotBytes = sizeof(int2) + sizeof(float4) * 8 + sizeof(fl
 
 } // namespace
 
+// every strip constraint has two manifold points: selects the persistent kernel's POINTS == 2 variant
+bool stripsAllTwoPoints(const s2amdSolver* s)
+{
+	for (int k = s->persistK0; k < s->persistK1; ++k)
+	{
+		if (s->hContactPoints[(size_t)s->contacts.order[(size_t)k]] != 2)
+		{
+			return false;
+		}
+	}
+	return true;
+}
+
 int carveBodies(s2amdSolver* s, int n)
 {
 	int rc = growFamily(s, s->soaBodies, s->bodySoaCap, n, kBodySlotBytes, 9);
@@ -1348,15 +1361,8 @@ int buildStructure(s2amdSolver* s, int solverType)
 				// fresh buffers start from zero tags
 				HIP_TRY(hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, s->stream));
 				pv.wideRounds = maxRoundsA > S2_STRIP_ROUNDS ? 1 : 0;
-				pv.allTwoPoints = 1;
-				for (int k = k0; k < k1; ++k)
-				{
-					if (s->hContactPoints[(size_t)cs.order[(size_t)k]] != 2)
-					{
-						pv.allTwoPoints = 0;
-						break;
-					}
-				}
+				s->persistK0 = k0, s->persistK1 = k1;
+				pv.allTwoPoints = stripsAllTwoPoints(s) ? 1 : 0;
 				pv.ldsRecords = ldsRecords;
 				s->persistRecordsWide = ldsRecordsWide;
 				pv.debugSkip = s->optPersistDebug;

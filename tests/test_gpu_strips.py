@@ -115,6 +115,27 @@ def test_persistent_strip_step_on_off(solver_name, persist):
             assert st["kernelLaunches"] <= 10, st
 
 
+def test_persistent_two_point_fast_path_follows_the_point_counts():
+    """Same contact graph, but manifolds drop from two points to one (a box tilts onto an edge) and come back: the
+    persistent kernel's two-point variant is chosen from the point counts of THIS step, not of the step the strips were
+    built on."""
+    pre = synthetic.pyramid(100)
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
+        state = gpu_vs_oracle(s, params, common.copy3(pre), "two-point step 0")
+        state = gpu_vs_oracle(s, params, state, "two-point step 1")
+        active = np.flatnonzero(state[1]["pointCount"] == 2)
+        for victim in (active[len(active) // 2], active[7]):
+            state[1]["pointCount"][victim] = 1
+        state = gpu_vs_oracle(s, params, state, "one-point contacts in the strips")
+        assert s.stats()["persistent"] == 1
+        state[1]["pointCount"][active[len(active) // 2]] = 2
+        state[1]["pointCount"][active[7]] = 2
+        state = gpu_vs_oracle(s, params, state, "two points again")
+        assert s.stats()["persistent"] == 1
+
+
 def test_persistent_strip_step_base_200():
     """BASELINE config 2 itself: 20,101 bodies, 59,900 constraints, one island."""
     pre = synthetic.pyramid(200)

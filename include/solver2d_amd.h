@@ -278,6 +278,38 @@ typedef struct s2amdPairState
 int s2amd_update_contacts(s2amdSolver* solver, const s2amdBody* bodies, int32_t bodyCapacity, const float* origins, const s2amdShape* shapes,
 						  int32_t shapeCapacity, s2amdPairState* pairs, s2amdContact* contacts, int32_t contactCapacity, int32_t* status);
 
+/* ---- resident world: stage 3, the solve and stage 4 of s2World_Step chained in HBM ----
+ * The stage functions above take host arrays in and out.  These three keep the shapes, the pair states and the body
+ * origins on the device beside the bodies / contacts / joints of s2amd_upload, so a step moves 32 bytes of counters
+ * (plus one byte per contact slot in the steps where a manifold's point count changed: the constraint-graph
+ * structure is built on the host).  Pair creation (stage 1, src/world.c:125-130) stays with the caller: when
+ * movedCount > 0 it downloads the shapes, runs s2amd_find_pairs, creates its contacts and uploads again, as the
+ * reference does before the next step's stage 3. */
+typedef struct s2amdWorldStepInfo
+{
+	int32_t separatedCount; /* pairs whose fat AABBs parted: destroyed on the device (pointCount 0, pair slot free,
+	                           src/world.c:149-167); status[] of s2amd_world_download says which */
+	int32_t activeContacts; /* manifolds with points after stage 3 */
+	int32_t graphChanged;   /* a manifold went between zero and non-zero points: the solve rebuilt its structure */
+	int32_t movedCount;     /* shapes whose fat AABB the refit re-inflated (s2amdShape.enlarged) */
+	float contactsMs;       /* host wall time of stage 3 including its counter read-back */
+	float solveMs;          /* device time of the s2Solve_* part (HIP events) */
+	float stepMs;           /* host wall time of the whole call */
+} s2amdWorldStepInfo;
+
+/* bodies/contacts/joints as s2amd_upload; shapes (with valid aabb/fatAABB), pairs[contactCapacity] (the narrow-phase
+ * state of every contact slot), origins[2 * bodyCapacity] (s2Body.origin). */
+int s2amd_world_upload(s2amdSolver* solver, const s2amdBody* bodies, int32_t bodyCapacity, const s2amdContact* contacts, int32_t contactCapacity,
+					   const s2amdJoint* joints, int32_t jointCapacity, const s2amdShape* shapes, int32_t shapeCapacity, const s2amdPairState* pairs,
+					   const float* origins);
+/* == s2World_Step without stage 1: update contacts (src/world.c:132-168), s2Solve_* (src/world.c:206-256), refit
+ * (src/world.c:259-301).  info may be NULL. */
+int s2amd_world_step(s2amdSolver* solver, const s2amdStepParams* params, s2amdWorldStepInfo* info);
+/* Any output pointer may be NULL.  status[contactCapacity]: S2AMD_PAIR_* of the last step's stage 3. */
+int s2amd_world_download(s2amdSolver* solver, s2amdBody* bodies, int32_t bodyCapacity, s2amdContact* contacts, int32_t contactCapacity,
+						 s2amdJoint* joints, int32_t jointCapacity, s2amdShape* shapes, int32_t shapeCapacity, s2amdPairState* pairs, float* origins,
+						 int32_t* status);
+
 /* ---- constraint-graph structure on the device (the reference has neither islands nor colours) ----
  * Islands: connected components over the movable bodies (invMass != 0 or invI != 0) joined by active contacts
  * (pointCount > 0) and revolute joints; every other live non-static body is an island of its own; static and free

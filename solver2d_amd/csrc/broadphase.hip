@@ -408,6 +408,17 @@ dim3 gridFor(size_t n)
 }
 } // namespace
 
+// resident arrays (world.hip)
+void launchRefitShapes(hipStream_t st, const s2amdBody* bodies, int bodyCapacity, s2amdShape* shapes, int shapeCapacity, float* origins)
+{
+	if (bodyCapacity <= 0 || shapeCapacity <= 0)
+	{
+		return;
+	}
+	bodyOriginsKernel<<<gridFor((size_t)bodyCapacity), dim3(S2_BLOCK), 0, st>>>(bodies, bodyCapacity, (float2*)origins);
+	refitShapesKernel<<<gridFor((size_t)shapeCapacity), dim3(S2_BLOCK), 0, st>>>(bodies, bodyCapacity, shapes, shapeCapacity, (const float2*)origins);
+}
+
 #pragma GCC visibility push(default)
 extern "C"
 {

@@ -16,6 +16,8 @@ struct PersistView;
 struct s2amdBody;
 struct s2amdContact;
 struct s2amdJoint;
+struct s2amdShape;
+struct s2amdPairState;
 
 // body flag bits that only the host sets (see s2_device.h for the rest)
 #define S2F_WRITE_VEL 8u  // body is a conflict node for velocity sweeps (not read-only shareable)
@@ -136,3 +138,8 @@ int stripKernelSetup();
 void launchStripSoft(hipStream_t s, int kind, int warm, const ContactView& c, const BodyView& g, const StripTableView& t, const StripOps& ops);
 void launchStripStep(hipStream_t s, int kind, int warm, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv,
 					 const Op* ops, int opCount);
+
+// stage kernels on resident arrays (narrowphase.hip, broadphase.hip; called by world.hip)
+void launchUpdateContacts(hipStream_t st, const s2amdBody* bodies, const float* origins, const s2amdShape* shapes, s2amdPairState* pairs,
+						  s2amdContact* contacts, int contactCapacity, int32_t* status);
+void launchRefitShapes(hipStream_t st, const s2amdBody* bodies, int bodyCapacity, s2amdShape* shapes, int shapeCapacity, float* origins);

@@ -925,6 +925,18 @@ struct Scratch
 		}                                                                                                                        \
 	} while (0)
 
+// resident arrays (world.hip)
+void launchUpdateContacts(hipStream_t st, const s2amdBody* bodies, const float* origins, const s2amdShape* shapes, s2amdPairState* pairs,
+						  s2amdContact* contacts, int contactCapacity, int32_t* status)
+{
+	if (contactCapacity <= 0)
+	{
+		return;
+	}
+	dim3 grid((unsigned)((contactCapacity + S2_NP_BLOCK - 1) / S2_NP_BLOCK));
+	updateContactsKernel<<<grid, dim3(S2_NP_BLOCK), 0, st>>>(bodies, (const float2*)origins, shapes, pairs, contacts, contactCapacity, status);
+}
+
 #pragma GCC visibility push(default)
 extern "C"
 {

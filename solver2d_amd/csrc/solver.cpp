@@ -143,7 +143,8 @@ void s2amd_destroy(s2amdSolver* s)
 					  &s->soaContacts,	&s->soaJoints,	  &s->dContactIndex, &s->dJointIndex,	 &s->dContactLocal, &s->dJointLocal,
 					  &s->dAdjOffsets,	&s->dAdjList,	  &s->dGatherIndex,	 &s->dOps,			 &s->dGroups.buf,	&s->dContactTail.buf,
 					  &s->dJointTail.buf, &s->dMsg,			  &s->dStripA.buf,	 &s->dStripB.buf,	 &s->dStripLean,	&s->dPersist,
-					  &s->dGranules,	&s->dPersistOps};
+					  &s->dGranules,	&s->dPersistOps,	  &s->dShapes,		 &s->dPairs,		 &s->dOrigins,		&s->dStatus,
+					  &s->dPointBytes,	&s->dWorldSummary};
 	for (DevBuf* b : bufs)
 	{
 		b->release();
@@ -151,6 +152,10 @@ void s2amd_destroy(s2amdSolver* s)
 	if (s->hostError)
 	{
 		(void)hipHostFree(s->hostError);
+	}
+	if (s->hostWorldSummary)
+	{
+		(void)hipHostFree(s->hostWorldSummary);
 	}
 	if (s->hostTimes)
 	{

@@ -162,6 +162,13 @@ struct s2amdSolver
 	bool resident = false;
 	bool savedValid = false;
 
+	// resident world (world.hip): the arrays of stages 3 and 4 beside the solver's wire arrays
+	DevBuf dShapes, dPairs, dOrigins, dStatus, dPointBytes, dWorldSummary;
+	int shapeCapacity = 0;
+	bool worldResident = false;
+	int* hostWorldSummary = nullptr; // pinned: the per-step counters of both stages
+	std::vector<uint8_t> hPointBytes;
+
 	// host shadows of the graph structure (refreshed by every upload)
 	std::vector<int> hContactA, hContactB, hContactPoints;
 	std::vector<int> hJointType, hJointA, hJointB;
@@ -252,8 +259,8 @@ struct s2amdSolver
 };
 
 StepConsts makeConsts(const s2amdStepParams* p);
-int carveBodies(s2amdSolver* s, int n);
-bool stripsAllTwoPoints(const s2amdSolver* s); // (re)carves the body SoA family for n slots
+int carveBodies(s2amdSolver* s, int n); // (re)carves the body SoA family for n slots
+bool stripsAllTwoPoints(const s2amdSolver* s);
 int buildStructure(s2amdSolver* s, int solverType);
 void buildPlan(s2amdSolver* s, const s2amdStepParams* params);
 bool messageEligible(const s2amdSolver* s, int solverType);

@@ -1,0 +1,352 @@
+// Resident world: stages 3 and 4 of s2World_Step (src/world.c:132-168, :259-301) chained with the solve in HBM.
+//
+// The stage entry points of include/solver2d_amd.h (s2amd_update_contacts, s2amd_refit_shapes) take host arrays in
+// and out, which costs more than their kernels.  Here the shapes, the narrow-phase pair states and the body origins
+// stay on the device beside the solver's wire bodies / contacts / joints, and one s2amd_world_step runs
+//
+//     update contacts (narrowphase.hip)  ->  contact summary  ->  s2Solve_* (solver_step.cpp: doStep)  ->  refit
+//
+// on them.  What comes back per step is 32 bytes of counters.  The constraint graph structure (islands, colours,
+// strips) is still built on the host, so the point counts of the new manifolds are fetched (one byte per contact
+// slot) in the steps where the summary kernel saw one of them change.
+#include "solver_internal.h"
+
+#define S2_BLOCK 256
+
+namespace
+{
+
+struct WorldSummary
+{
+	int separated; // pairs whose fat AABBs parted this step
+	int active;	   // manifolds with at least one point
+	int flips;	   // manifolds that went between zero and non-zero points: the constraint graph changed
+	int moves;	   // manifolds whose point count changed at all
+	int enlarged;  // shapes whose fat AABB was re-inflated by the refit: the broad phase has to look at them
+	int pad[3];
+};
+
+// After the narrow phase: a separated pair is destroyed the way src/world.c:149-167 destroys its contact (no
+// manifold, free pair slot), point counts are compared with the previous step's.
+__global__ __launch_bounds__(S2_BLOCK) void contactSummaryKernel(s2amdContact* contacts, s2amdPairState* pairs, const int32_t* status, int n,
+																 uint8_t* pointBytes, WorldSummary* out)
+{
+	int k = blockIdx.x * blockDim.x + threadIdx.x;
+	int pc = 0;
+	if (k < n)
+	{
+		int st = status[k];
+		if (st == S2AMD_PAIR_SEPARATED)
+		{
+			contacts[k].pointCount = 0;
+			pairs[k].shapeA = -1;
+			pairs[k].shapeB = -1;
+			atomicAdd(&out->separated, 1);
+		}
+		else
+		{
+			pc = contacts[k].pointCount;
+			pc = pc > 0 ? pc : 0;
+		}
+		int old = pointBytes[k];
+		if (old != pc)
+		{
+			pointBytes[k] = (uint8_t)pc;
+			atomicAdd(&out->moves, 1);
+			if ((old > 0) != (pc > 0))
+			{
+				atomicAdd(&out->flips, 1);
+			}
+		}
+	}
+	unsigned long long live = __ballot(pc > 0);
+	if ((threadIdx.x & 63) == 0 && live != 0ull)
+	{
+		atomicAdd(&out->active, __popcll(live));
+	}
+}
+
+// the rest of stage 4's body loop: the applied forces are consumed by the step (src/world.c:274-275)
+__global__ __launch_bounds__(S2_BLOCK) void clearForcesKernel(s2amdBody* bodies, int n)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n && bodies[i].type != S2AMD_BODY_FREE && bodies[i].type != S2AMD_BODY_STATIC)
+	{
+		bodies[i].force[0] = 0.0f;
+		bodies[i].force[1] = 0.0f;
+		bodies[i].torque = 0.0f;
+	}
+}
+
+__global__ __launch_bounds__(S2_BLOCK) void countEnlargedKernel(const s2amdShape* shapes, int n, WorldSummary* out)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	bool e = i < n && shapes[i].type != S2AMD_SHAPE_FREE && shapes[i].enlarged != 0;
+	unsigned long long m = __ballot(e);
+	if ((threadIdx.x & 63) == 0 && m != 0ull)
+	{
+		atomicAdd(&out->enlarged, __popcll(m));
+	}
+}
+
+dim3 gridFor(size_t n)
+{
+	return dim3((unsigned)((n + S2_BLOCK - 1) / S2_BLOCK));
+}
+
+// the contact part of refreshShadows (solver_step.cpp) for point counts produced on the device
+void applyPointCounts(s2amdSolver* s)
+{
+	bool graphChanged = false, countsMoved = false;
+	for (int i = 0; i < s->contactCapacity; ++i)
+	{
+		int pc = s->hPointBytes[(size_t)i];
+		if (s->hContactPoints[(size_t)i] != pc)
+		{
+			countsMoved = true;
+			graphChanged = graphChanged || (s->hContactPoints[(size_t)i] > 0) != (pc > 0);
+			s->hContactPoints[(size_t)i] = pc;
+		}
+	}
+	if (graphChanged)
+	{
+		s->graphAge = 0;
+		s->stripsRejected = false;
+		s->structureDirty = true;
+		s->gatherIndexDirty = true;
+	}
+	else if (countsMoved && s->persistValid)
+	{
+		s->persist.allTwoPoints = stripsAllTwoPoints(s) ? 1 : 0;
+	}
+}
+
+} // namespace
+
+#pragma GCC visibility push(default)
+extern "C"
+{
+
+int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapacity, const s2amdContact* contacts, int32_t contactCapacity,
+					   const s2amdJoint* joints, int32_t jointCapacity, const s2amdShape* shapes, int32_t shapeCapacity, const s2amdPairState* pairs,
+					   const float* origins)
+{
+	if (!s)
+	{
+		return fail(S2AMD_E_INVALID, "null solver");
+	}
+	if (shapeCapacity < 0 || (shapeCapacity > 0 && !shapes) || (contactCapacity > 0 && !pairs) || (bodyCapacity > 0 && !origins))
+	{
+		return fail(S2AMD_E_INVALID, "null array with non-zero count");
+	}
+	for (int i = 0; i < contactCapacity; ++i)
+	{
+		if (pairs[i].shapeA >= shapeCapacity || pairs[i].shapeB >= shapeCapacity)
+		{
+			return fail(S2AMD_E_INVALID, "pair " + std::to_string(i) + " names a shape outside the shape array");
+		}
+	}
+	for (int i = 0; i < shapeCapacity; ++i)
+	{
+		if (shapes[i].type != S2AMD_SHAPE_FREE && (shapes[i].body < 0 || shapes[i].body >= bodyCapacity))
+		{
+			return fail(S2AMD_E_INVALID, "shape " + std::to_string(i) + " names a body outside the body array");
+		}
+	}
+	s->worldResident = false;
+	s->gatherIndexDirty = true;
+	int rc = doUpload(s, bodies, bodyCapacity, contacts, contactCapacity, joints, jointCapacity);
+	if (rc)
+	{
+		return rc;
+	}
+	if (!s->hostWorldSummary)
+	{
+		HIP_TRY(hipHostMalloc((void**)&s->hostWorldSummary, sizeof(WorldSummary), hipHostMallocDefault));
+	}
+	const size_t sBytes = (size_t)shapeCapacity * sizeof(s2amdShape), pBytes = (size_t)contactCapacity * sizeof(s2amdPairState);
+	const size_t oBytes = (size_t)bodyCapacity * 2 * sizeof(float);
+	if ((rc = s->dShapes.ensure(std::max<size_t>(sBytes, 256))) != 0 || (rc = s->dPairs.ensure(std::max<size_t>(pBytes, 256))) != 0 ||
+		(rc = s->dOrigins.ensure(std::max<size_t>(oBytes, 256))) != 0 || (rc = s->dStatus.ensure(std::max<size_t>((size_t)contactCapacity * 4, 256))) != 0 ||
+		(rc = s->dPointBytes.ensure(std::max<size_t>((size_t)contactCapacity, 256))) != 0 || (rc = s->dWorldSummary.ensure(256)) != 0)
+	{
+		return rc;
+	}
+	s->hPointBytes.assign((size_t)contactCapacity, 0);
+	for (int i = 0; i < contactCapacity; ++i)
+	{
+		s->hPointBytes[(size_t)i] = (uint8_t)s->hContactPoints[(size_t)i];
+	}
+	if (sBytes)
+	{
+		HIP_TRY(hipMemcpyAsync(s->dShapes.p, shapes, sBytes, hipMemcpyHostToDevice, s->stream));
+	}
+	if (pBytes)
+	{
+		HIP_TRY(hipMemcpyAsync(s->dPairs.p, pairs, pBytes, hipMemcpyHostToDevice, s->stream));
+		HIP_TRY(hipMemcpyAsync(s->dPointBytes.p, s->hPointBytes.data(), (size_t)contactCapacity, hipMemcpyHostToDevice, s->stream));
+		HIP_TRY(hipMemsetAsync(s->dStatus.p, 0xff, (size_t)contactCapacity * 4, s->stream)); // S2AMD_PAIR_FREE
+	}
+	if (oBytes)
+	{
+		HIP_TRY(hipMemcpyAsync(s->dOrigins.p, origins, oBytes, hipMemcpyHostToDevice, s->stream));
+	}
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	s->shapeCapacity = shapeCapacity;
+	s->worldResident = true;
+	return S2AMD_OK;
+}
+
+int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldStepInfo* info)
+{
+	if (!s || !params)
+	{
+		return fail(S2AMD_E_INVALID, "null argument");
+	}
+	if (!s->worldResident || !s->resident)
+	{
+		return fail(S2AMD_E_STATE, "s2amd_world_step called before s2amd_world_upload");
+	}
+	HIP_TRY(hipSetDevice(s->device));
+	hipStream_t st = s->stream;
+	const int nc = s->contactCapacity, nb = s->bodyCapacity, ns = s->shapeCapacity;
+	WorldSummary* dSum = (WorldSummary*)s->dWorldSummary.p;
+	WorldSummary* hSum = (WorldSummary*)s->hostWorldSummary;
+	const double t0 = nowMs();
+
+	// ---- stage 3: update contacts ----
+	HIP_TRY(hipMemsetAsync(dSum, 0, sizeof(WorldSummary), st));
+	if (nc > 0)
+	{
+		launchUpdateContacts(st, (const s2amdBody*)s->dBodies.p, (const float*)s->dOrigins.p, (const s2amdShape*)s->dShapes.p,
+							 (s2amdPairState*)s->dPairs.p, (s2amdContact*)s->dContacts.p, nc, (int32_t*)s->dStatus.p);
+		contactSummaryKernel<<<gridFor((size_t)nc), dim3(S2_BLOCK), 0, st>>>((s2amdContact*)s->dContacts.p, (s2amdPairState*)s->dPairs.p,
+																			  (const int32_t*)s->dStatus.p, nc, (uint8_t*)s->dPointBytes.p, dSum);
+	}
+	HIP_TRY(hipMemcpyAsync(hSum, dSum, sizeof(WorldSummary), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(st));
+	WorldSummary contactsSeen = *hSum;
+	if (contactsSeen.moves > 0)
+	{
+		HIP_TRY(hipMemcpyAsync(s->hPointBytes.data(), s->dPointBytes.p, (size_t)nc, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		applyPointCounts(s);
+	}
+	const double t1 = nowMs();
+
+	// ---- s2Solve_* and stage 4 (refit), enqueued back to back ----
+	// When the persistent step kernel reports a dead hand-off its epilogue leaves the wire arrays untouched, so the refit
+	// behind it saw the bodies of the previous step (same AABBs, nothing enlarged): the solve is repeated on the
+	// multi-launch path, and so is the refit.
+	int fallbacks = 0;
+	for (;;)
+	{
+		const int savedAsync = s->optAsync;
+		s->optAsync = 1;
+		int rc = doStep(s, params);
+		s->optAsync = savedAsync;
+		if (rc)
+		{
+			return rc;
+		}
+		launchRefitShapes(st, (const s2amdBody*)s->dBodies.p, nb, (s2amdShape*)s->dShapes.p, ns, (float*)s->dOrigins.p);
+		if (nb > 0)
+		{
+			clearForcesKernel<<<gridFor((size_t)nb), dim3(S2_BLOCK), 0, st>>>((s2amdBody*)s->dBodies.p, nb);
+		}
+		if (ns > 0)
+		{
+			countEnlargedKernel<<<gridFor((size_t)ns), dim3(S2_BLOCK), 0, st>>>((const s2amdShape*)s->dShapes.p, ns, dSum);
+		}
+		HIP_TRY(hipMemcpyAsync(hSum, dSum, sizeof(WorldSummary), hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(st));
+		if (s->hostError && *s->hostError != 0u && fallbacks == 0)
+		{
+			// bodies, impulses and (because the solve left the bodies alone) the shapes are what they were before the solve
+			*s->hostError = 0u;
+			HIP_TRY(hipMemsetAsync(s->persist.deviceError, 0, sizeof(unsigned int), st));
+			HIP_TRY(hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, st));
+			HIP_TRY(hipMemsetAsync(&dSum->enlarged, 0, sizeof(int), st));
+			s->persistFailed = true;
+			s->persistFallbacks += 1;
+			fallbacks += 1;
+			continue;
+		}
+		break;
+	}
+	{
+		float ms = 0.0f;
+		if (hipEventElapsedTime(&ms, s->evBegin, s->evEnd) == hipSuccess)
+		{
+			s->stats.deviceMs = ms;
+		}
+		s->stats.persistFallbacks = s->persistFallbacks;
+	}
+	if (info)
+	{
+		info->separatedCount = contactsSeen.separated;
+		info->activeContacts = contactsSeen.active;
+		info->graphChanged = contactsSeen.flips > 0 ? 1 : 0;
+		info->movedCount = hSum->enlarged;
+		info->contactsMs = (float)(t1 - t0);
+		info->solveMs = s->stats.deviceMs;
+		info->stepMs = (float)(nowMs() - t0);
+	}
+	return S2AMD_OK;
+}
+
+int s2amd_world_download(s2amdSolver* s, s2amdBody* bodies, int32_t bodyCapacity, s2amdContact* contacts, int32_t contactCapacity, s2amdJoint* joints,
+						 int32_t jointCapacity, s2amdShape* shapes, int32_t shapeCapacity, s2amdPairState* pairs, float* origins, int32_t* status)
+{
+	if (!s)
+	{
+		return fail(S2AMD_E_INVALID, "null solver");
+	}
+	if (!s->worldResident || !s->resident)
+	{
+		return fail(S2AMD_E_STATE, "no resident world");
+	}
+	if ((bodies && bodyCapacity < s->bodyCapacity) || (origins && bodyCapacity < s->bodyCapacity) || (contacts && contactCapacity < s->contactCapacity) ||
+		(pairs && contactCapacity < s->contactCapacity) || (status && contactCapacity < s->contactCapacity) || (joints && jointCapacity < s->jointCapacity) ||
+		(shapes && shapeCapacity < s->shapeCapacity))
+	{
+		return fail(S2AMD_E_CAPACITY, "output arrays smaller than the resident world");
+	}
+	HIP_TRY(hipSetDevice(s->device));
+	hipStream_t st = s->stream;
+	if (bodies && s->bodyCapacity > 0)
+	{
+		HIP_TRY(hipMemcpyAsync(bodies, s->dBodies.p, (size_t)s->bodyCapacity * sizeof(s2amdBody), hipMemcpyDeviceToHost, st));
+	}
+	if (origins && s->bodyCapacity > 0)
+	{
+		HIP_TRY(hipMemcpyAsync(origins, s->dOrigins.p, (size_t)s->bodyCapacity * 2 * sizeof(float), hipMemcpyDeviceToHost, st));
+	}
+	if (contacts && s->contactCapacity > 0)
+	{
+		HIP_TRY(hipMemcpyAsync(contacts, s->dContacts.p, (size_t)s->contactCapacity * sizeof(s2amdContact), hipMemcpyDeviceToHost, st));
+	}
+	if (pairs && s->contactCapacity > 0)
+	{
+		HIP_TRY(hipMemcpyAsync(pairs, s->dPairs.p, (size_t)s->contactCapacity * sizeof(s2amdPairState), hipMemcpyDeviceToHost, st));
+	}
+	if (status && s->contactCapacity > 0)
+	{
+		HIP_TRY(hipMemcpyAsync(status, s->dStatus.p, (size_t)s->contactCapacity * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+	}
+	if (joints && s->jointCapacity > 0)
+	{
+		HIP_TRY(hipMemcpyAsync(joints, s->dJoints.p, (size_t)s->jointCapacity * sizeof(s2amdJoint), hipMemcpyDeviceToHost, st));
+	}
+	if (shapes && s->shapeCapacity > 0)
+	{
+		HIP_TRY(hipMemcpyAsync(shapes, s->dShapes.p, (size_t)s->shapeCapacity * sizeof(s2amdShape), hipMemcpyDeviceToHost, st));
+	}
+	HIP_TRY(hipStreamSynchronize(st));
+	return S2AMD_OK;
+}
+
+} // extern "C"
+#pragma GCC visibility pop

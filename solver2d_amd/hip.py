@@ -19,6 +19,7 @@ EXPORTS = [
     "s2amd_solve", "s2amd_upload", "s2amd_step_resident", "s2amd_download", "s2amd_save_bodies",
     "s2amd_restore_bodies", "s2amd_get_contact_order", "s2amd_get_joint_order", "s2amd_get_stats",
     "s2amd_set_option", "s2amd_export_poses", "s2amd_measure_dominant", "s2amd_refit_shapes", "s2amd_find_pairs", "s2amd_synchronize", "s2amd_update_contacts", "s2amd_find_islands", "s2amd_color_constraints",
+    "s2amd_world_upload", "s2amd_world_step", "s2amd_world_download",
 ]
 
 _lib = None
@@ -61,6 +62,9 @@ def load():
     L.s2amd_refit_shapes.argtypes = [vp, vp, i32, vp, i32, vp]
     L.s2amd_find_pairs.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, vp, i32, vp, i32, ctypes.POINTER(i32)]
     L.s2amd_update_contacts.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, i32, vp]
+    L.s2amd_world_upload.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp]
+    L.s2amd_world_step.argtypes = [vp, ctypes.POINTER(wire.StepParams), ctypes.POINTER(wire.WorldStepInfo)]
+    L.s2amd_world_download.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp]
     L.s2amd_find_islands.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, ctypes.POINTER(i32)]
     L.s2amd_color_constraints.argtypes = [vp, vp, i32, vp, i32, vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     if L.s2amd_api_version() != wire.API_VERSION:
@@ -165,6 +169,28 @@ class Solver:
         _check(load().s2amd_update_contacts(self._h, wire.as_ptr(bodies), len(bodies), wire.as_ptr(origins), wire.as_ptr(shapes), len(shapes),
                                             wire.as_ptr(pairs), wire.as_ptr(contacts), len(contacts), wire.as_ptr(status)))
         return status
+
+    # ---- resident world: stage 3 -> solve -> stage 4 chained in HBM ----
+    def world_upload(self, bodies, contacts, joints, shapes, pairs, origins):
+        assert shapes.dtype == wire.shape_dtype and pairs.dtype == wire.pair_state_dtype and len(pairs) == len(contacts)
+        origins = np.ascontiguousarray(origins, dtype=np.float32)
+        assert origins.shape == (len(bodies), 2)
+        _check(load().s2amd_world_upload(self._h, *self._args(bodies, contacts, joints), wire.as_ptr(shapes), len(shapes), wire.as_ptr(pairs),
+                                         wire.as_ptr(origins)))
+
+    def world_step(self, params):
+        """One s2World_Step minus pair creation on the resident world; returns the step's counters as a dict."""
+        info = wire.WorldStepInfo()
+        _check(load().s2amd_world_step(self._h, ctypes.byref(params), ctypes.byref(info)))
+        return {k: getattr(info, k) for k, _ in wire.WorldStepInfo._fields_}
+
+    def world_download(self, bodies, contacts, joints, shapes, pairs, origins):
+        """Fills the given arrays (same sizes as uploaded) and returns them with the last stage-3 status."""
+        origins = np.ascontiguousarray(origins, dtype=np.float32)
+        status = np.zeros(len(contacts), dtype=np.int32)
+        _check(load().s2amd_world_download(self._h, *self._args(bodies, contacts, joints), wire.as_ptr(shapes), len(shapes), wire.as_ptr(pairs),
+                                           wire.as_ptr(origins), wire.as_ptr(status)))
+        return bodies, contacts, joints, shapes, pairs, origins, status
 
     def find_islands(self, bodies, contacts, joints):
         """(island_of_body int32[nb], island_count): connected components over the movable bodies, on the device."""

@@ -102,6 +102,14 @@ class StepStats(ctypes.Structure):
     ]
 
 
+class WorldStepInfo(ctypes.Structure):
+    """s2amdWorldStepInfo"""
+    _fields_ = [
+        ("separatedCount", ctypes.c_int32), ("activeContacts", ctypes.c_int32), ("graphChanged", ctypes.c_int32),
+        ("movedCount", ctypes.c_int32), ("contactsMs", ctypes.c_float), ("solveMs", ctypes.c_float), ("stepMs", ctypes.c_float),
+    ]
+
+
 def solve_sweeps_per_step(solver, vel_iters, pos_iters):
     """Full passes of a s2SolveContacts_* function per s2World_Step, per reference driver.
 

@@ -74,6 +74,30 @@ def main():
                     path = os.path.join(OUT, "np_%s%d_step%03d.npz" % (scene, p0, step))
                     np.savez_compressed(path, **cap)
                     total += os.path.getsize(path)
+    # world chains (stage 3 -> solve -> stage 4 resident): the input of stage 3 at step `start` and at
+    # step `start + k`, in a window where the reference's stage 1 created no contact (pair creation stays with the caller
+    # of s2amd_world_step).  Separations inside the window are part of the chain.
+    for scene, p0, solver, start, k in (("pyramid", 8, "TGS_Soft", 30, 3), ("mixed", 24, "PGS", 101, 3), ("shapes_zoo", 40, "TGS_Sticky", 154, 3),
+                                        ("circle_pile", 20, "XPBD", 81, 3), ("mixed", 24, "Jacobi", 104, 3)):
+        vel, pos = common.DEFAULT_ITERS[solver]
+        with refbind.RefWorld(scene, solver, p0, 0) as world:
+            for _ in range(start):
+                world.step(1.0 / 60.0, vel, pos, True)
+            caps = []
+            for i in range(k + 1):
+                params, pre, _post = world.step_captured(1.0 / 60.0, vel, pos, True)
+                cap = refbind.narrowphase_capture()
+                created = len(refbind.broadphase_capture()[3])
+                assert i == 0 or created == 0, "%s/%s: the reference created a contact inside the window" % (scene, solver)
+                caps.append({"bodies": cap["bodies"], "contacts": cap["contacts_pre"], "joints": pre[2], "shapes": cap["shapes"],
+                             "pairs": cap["pairs_pre"], "origins": cap["origins"]})
+            path = os.path.join(OUT, "world_%s%d_%s_step%03d_k%d.npz" % (scene, p0, solver, start, k))
+            arrays = {key: caps[0][key] for key in caps[0]}
+            arrays.update({"out_" + key: caps[k][key] for key in caps[k]})
+            np.savez_compressed(path, steps=np.array([k], dtype=np.int32),
+                                params=np.array([params.solverType, params.velIters, params.posIters, params.warmStart], dtype=np.int32),
+                                params_f=np.array([params.dt, params.gravity[0], params.gravity[1]], dtype=np.float32), **arrays)
+            total += os.path.getsize(path)
     print("wrote fixtures, %.1f KiB total" % (total / 1024.0))
 
 

@@ -305,6 +305,14 @@ int s2amd_world_upload(s2amdSolver* solver, const s2amdBody* bodies, int32_t bod
 /* == s2World_Step without stage 1: update contacts (src/world.c:132-168), s2Solve_* (src/world.c:206-256), refit
  * (src/world.c:259-301).  info may be NULL. */
 int s2amd_world_step(s2amdSolver* solver, const s2amdStepParams* params, s2amdWorldStepInfo* info);
+/* == the pair discovery of stage 1 (s2amd_find_pairs above) on the resident shapes: moved = the shapes the last refit
+ * enlarged, existing pairs = the live pair slots, jointed bodies as uploaded.  New pairs sorted by (A, B) into the host
+ * array outPairs.  Call it when info.movedCount > 0, before the next s2amd_world_step (the refit overwrites the flags). */
+int s2amd_world_find_pairs(s2amdSolver* solver, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount);
+/* Writes `count` contact slots of the resident world (slot indices < contactCapacity of the upload): the caller's
+ * s2CreateContact (src/contact.c:137-203: pool slot, pair flip, mixed friction, empty manifold) or s2DestroyContact
+ * (pairs[i].shapeA = -1, contacts[i].pointCount = 0).  A world that needs more slots, bodies or shapes is uploaded again. */
+int s2amd_world_set_contacts(s2amdSolver* solver, const int32_t* slots, int32_t count, const s2amdContact* contacts, const s2amdPairState* pairs);
 /* Any output pointer may be NULL.  status[contactCapacity]: S2AMD_PAIR_* of the last step's stage 3. */
 int s2amd_world_download(s2amdSolver* solver, s2amdBody* bodies, int32_t bodyCapacity, s2amdContact* contacts, int32_t contactCapacity,
 						 s2amdJoint* joints, int32_t jointCapacity, s2amdShape* shapes, int32_t shapeCapacity, s2amdPairState* pairs, float* origins,

@@ -408,6 +408,140 @@ dim3 gridFor(size_t n)
 }
 } // namespace
 
+// ---- stage 1 on resident arrays (world.hip: s2amd_world_find_pairs) ----
+// sort keys of every shape slot (free slots sort last), moved[] from the refit's `enlarged` flags
+__global__ __launch_bounds__(S2_BLOCK) void residentShapeKeysKernel(const s2amdShape* shapes, int ns, uint32_t* keys, int* idx, unsigned char* moved)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= ns)
+	{
+		return;
+	}
+	uint32_t key = 0xffffffffu;
+	if (shapes[i].type != S2AMD_SHAPE_FREE)
+	{
+		uint32_t u = __float_as_uint(shapes[i].fatAABB[0]);
+		key = (u & 0x80000000u) ? ~u : (u | 0x80000000u); // sortableFloat
+	}
+	keys[i] = key;
+	idx[i] = i;
+	moved[i] = (shapes[i].type != S2AMD_SHAPE_FREE && shapes[i].enlarged != 0) ? 1 : 0;
+}
+
+// (min shape, max shape) of every live pair slot; free slots sort last and match nothing
+__global__ __launch_bounds__(S2_BLOCK) void residentPairKeysKernel(const s2amdPairState* pairs, int nc, unsigned long long* keys)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nc)
+	{
+		return;
+	}
+	unsigned long long key = ~0ull;
+	if (pairs[i].shapeA >= 0 && pairs[i].shapeB >= 0)
+	{
+		unsigned int a = (unsigned int)pairs[i].shapeA, b = (unsigned int)pairs[i].shapeB;
+		key = ((unsigned long long)(a < b ? a : b) << 32) | (a < b ? b : a);
+	}
+	keys[i] = key;
+}
+
+int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShapes, const s2amdPairState* dPairs, int nc,
+					  const unsigned long long* dJointed, int jointedCount, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount)
+{
+	*pairCount = 0;
+	const int n = liveShapes;
+	if (n < 2)
+	{
+		return S2AMD_OK;
+	}
+	auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
+	size_t tmpSort = 0, tmpScan = 0, tmpKeys = 0;
+	BP_TRY(rocprim::radix_sort_pairs(nullptr, tmpSort, (uint32_t*)nullptr, (uint32_t*)nullptr, (int*)nullptr, (int*)nullptr, (size_t)ns, 0, 32, st));
+	BP_TRY(rocprim::exclusive_scan(nullptr, tmpScan, (unsigned int*)nullptr, (unsigned int*)nullptr, 0u, (size_t)n + 1, rocprim::plus<unsigned int>(), st));
+	size_t outCap = (size_t)std::max(pairCapacity, 1024);
+	BP_TRY(rocprim::radix_sort_keys(nullptr, tmpKeys, (unsigned long long*)nullptr, (unsigned long long*)nullptr, std::max((size_t)nc, outCap), 0, 64, st));
+	size_t tmpBytes = std::max(std::max(tmpSort, tmpScan), tmpKeys);
+	size_t layout[] = {al((size_t)ns), al((size_t)ns * 4), al((size_t)ns * 4), al((size_t)ns * 4), al((size_t)ns * 4), al((size_t)n * 4),
+					   al(((size_t)n + 1) * 4), al(((size_t)n + 1) * 4), al((size_t)nc * 8 + 8), al((size_t)nc * 8 + 8), al(outCap * 8), al(outCap * 8), al(256),
+					   al(tmpBytes + 256)};
+	size_t total = 0;
+	for (size_t b : layout)
+	{
+		total += b;
+	}
+	Scratch buf;
+	BP_TRY(buf.ensure(total));
+	char* p = (char*)buf.p;
+	size_t li = 0;
+	auto take = [&]() {
+		char* r = p;
+		p += layout[li++];
+		return r;
+	};
+	unsigned char* dMoved = (unsigned char*)take();
+	uint32_t* dKeysIn = (uint32_t*)take();
+	uint32_t* dKeysOut = (uint32_t*)take();
+	int* dIdxIn = (int*)take();
+	int* dIdxOut = (int*)take();
+	float* dLowerX = (float*)take();
+	unsigned int* dRun = (unsigned int*)take();
+	unsigned int* dOff = (unsigned int*)take();
+	unsigned long long* dExistingIn = (unsigned long long*)take();
+	unsigned long long* dExisting = (unsigned long long*)take();
+	unsigned long long* dOutA = (unsigned long long*)take();
+	unsigned long long* dOutB = (unsigned long long*)take();
+	unsigned int* dCount = (unsigned int*)take();
+	void* dTmp = take();
+
+	BP_TRY(hipMemsetAsync(dCount, 0, 256, st));
+	BP_TRY(hipMemsetAsync(dRun, 0, ((size_t)n + 1) * 4, st));
+	residentShapeKeysKernel<<<gridFor((size_t)ns), dim3(S2_BLOCK), 0, st>>>(dS, ns, dKeysIn, dIdxIn, dMoved);
+	size_t tmp = tmpBytes + 256;
+	BP_TRY(rocprim::radix_sort_pairs(dTmp, tmp, dKeysIn, dKeysOut, dIdxIn, dIdxOut, (size_t)ns, 0, 32, st));
+	if (nc > 0)
+	{
+		residentPairKeysKernel<<<gridFor((size_t)nc), dim3(S2_BLOCK), 0, st>>>(dPairs, nc, dExistingIn);
+		tmp = tmpBytes + 256;
+		BP_TRY(rocprim::radix_sort_keys(dTmp, tmp, dExistingIn, dExisting, (size_t)nc, 0, 64, st));
+	}
+	gatherLowerXKernel<<<gridFor((size_t)n), dim3(S2_BLOCK), 0, st>>>(dS, dIdxOut, n, dLowerX);
+	runLengthKernel<<<gridFor((size_t)n), dim3(S2_BLOCK), 0, st>>>(dS, dIdxOut, dLowerX, n, dRun);
+	tmp = tmpBytes + 256;
+	BP_TRY(rocprim::exclusive_scan(dTmp, tmp, dRun, dOff, 0u, (size_t)n + 1, rocprim::plus<unsigned int>(), st));
+	unsigned int work = 0;
+	BP_TRY(hipMemcpyAsync(&work, dOff + n, 4, hipMemcpyDeviceToHost, st));
+	BP_TRY(hipStreamSynchronize(st));
+	unsigned int found = 0;
+	if (work > 0)
+	{
+		pairKernel<<<gridFor((size_t)work), dim3(S2_BLOCK), 0, st>>>(dS, dMoved, dIdxOut, dOff, n, work, dExisting, nc, dJointed, jointedCount, dOutA,
+																	  (unsigned int)outCap, dCount);
+		BP_TRY(hipGetLastError());
+		BP_TRY(hipMemcpyAsync(&found, dCount, 4, hipMemcpyDeviceToHost, st));
+		BP_TRY(hipStreamSynchronize(st));
+	}
+	*pairCount = (int32_t)found;
+	if ((int64_t)found > (int64_t)pairCapacity)
+	{
+		return s2amdFail(S2AMD_E_CAPACITY, "pair buffer too small: " + std::to_string(found) + " pairs found");
+	}
+	if (found == 0)
+	{
+		return S2AMD_OK;
+	}
+	tmp = tmpBytes + 256;
+	BP_TRY(rocprim::radix_sort_keys(dTmp, tmp, dOutA, dOutB, (size_t)found, 0, 64, st));
+	std::vector<unsigned long long> out((size_t)found);
+	BP_TRY(hipMemcpyAsync(out.data(), dOutB, (size_t)found * 8, hipMemcpyDeviceToHost, st));
+	BP_TRY(hipStreamSynchronize(st));
+	for (unsigned int i = 0; i < found; ++i)
+	{
+		outPairs[2 * i] = (int32_t)(out[i] >> 32);
+		outPairs[2 * i + 1] = (int32_t)(out[i] & 0xffffffffu);
+	}
+	return S2AMD_OK;
+}
+
 // resident arrays (world.hip)
 void launchRefitShapes(hipStream_t st, const s2amdBody* bodies, int bodyCapacity, s2amdShape* shapes, int shapeCapacity, float* origins)
 {

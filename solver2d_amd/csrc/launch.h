@@ -143,3 +143,6 @@ void launchStripStep(hipStream_t s, int kind, int warm, const ContactView& c, co
 void launchUpdateContacts(hipStream_t st, const s2amdBody* bodies, const float* origins, const s2amdShape* shapes, s2amdPairState* pairs,
 						  s2amdContact* contacts, int contactCapacity, int32_t* status);
 void launchRefitShapes(hipStream_t st, const s2amdBody* bodies, int bodyCapacity, s2amdShape* shapes, int shapeCapacity, float* origins);
+// stage 1 on resident arrays: new pairs sorted by (A, B) into the host array outPairs; dJointed: sorted (min body << 32 | max body) keys
+int findPairsResident(hipStream_t st, const s2amdShape* shapes, int shapeCapacity, int liveShapes, const s2amdPairState* pairs, int contactCapacity,
+					  const unsigned long long* jointed, int jointedCount, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount);

@@ -89,6 +89,22 @@ __global__ __launch_bounds__(S2_BLOCK) void countEnlargedKernel(const s2amdShape
 	}
 }
 
+// s2amd_world_set_contacts: staged records into their slots
+__global__ __launch_bounds__(S2_BLOCK) void scatterContactsKernel(const int32_t* slots, int n, const s2amdContact* newContacts, const s2amdPairState* newPairs,
+																  s2amdContact* contacts, s2amdPairState* pairs, uint8_t* pointBytes, int32_t* status)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n)
+	{
+		int k = slots[i];
+		contacts[k] = newContacts[i];
+		pairs[k] = newPairs[i];
+		int pc = newContacts[i].pointCount;
+		pointBytes[k] = (uint8_t)(pc > 0 ? pc : 0);
+		status[k] = newPairs[i].shapeA >= 0 ? S2AMD_PAIR_UPDATED : S2AMD_PAIR_FREE;
+	}
+}
+
 dim3 gridFor(size_t n)
 {
 	return dim3((unsigned)((n + S2_BLOCK - 1) / S2_BLOCK));
@@ -171,6 +187,34 @@ int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapa
 		(rc = s->dPointBytes.ensure(std::max<size_t>((size_t)contactCapacity, 256))) != 0 || (rc = s->dWorldSummary.ensure(256)) != 0)
 	{
 		return rc;
+	}
+	// bodies connected by a joint never collide (src/broad_phase.c:283-298 via s2ShouldShapesCollide's joint walk): sorted body-pair keys
+	{
+		std::vector<unsigned long long> jointed;
+		for (int j = 0; j < jointCapacity; ++j)
+		{
+			if (joints[j].type != S2AMD_JOINT_FREE && joints[j].bodyA >= 0 && joints[j].bodyB >= 0)
+			{
+				unsigned int a = (unsigned int)joints[j].bodyA, b = (unsigned int)joints[j].bodyB;
+				jointed.push_back(((unsigned long long)std::min(a, b) << 32) | std::max(a, b));
+			}
+		}
+		std::sort(jointed.begin(), jointed.end());
+		if ((rc = s->dJointedKeys.ensure(std::max<size_t>(jointed.size() * 8, 256))) != 0)
+		{
+			return rc;
+		}
+		if (!jointed.empty())
+		{
+			HIP_TRY(hipMemcpyAsync(s->dJointedKeys.p, jointed.data(), jointed.size() * 8, hipMemcpyHostToDevice, s->stream));
+			HIP_TRY(hipStreamSynchronize(s->stream)); // `jointed` is a local
+		}
+		s->jointedCount = (int)jointed.size();
+		s->liveShapes = 0;
+		for (int i = 0; i < shapeCapacity; ++i)
+		{
+			s->liveShapes += shapes[i].type != S2AMD_SHAPE_FREE ? 1 : 0;
+		}
 	}
 	s->hPointBytes.assign((size_t)contactCapacity, 0);
 	for (int i = 0; i < contactCapacity; ++i)
@@ -293,6 +337,98 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 		info->contactsMs = (float)(t1 - t0);
 		info->solveMs = s->stats.deviceMs;
 		info->stepMs = (float)(nowMs() - t0);
+	}
+	return S2AMD_OK;
+}
+
+int s2amd_world_find_pairs(s2amdSolver* s, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount)
+{
+	if (!s || !pairCount || pairCapacity < 0 || (pairCapacity > 0 && !outPairs))
+	{
+		return fail(S2AMD_E_INVALID, "bad argument");
+	}
+	if (!s->worldResident || !s->resident)
+	{
+		return fail(S2AMD_E_STATE, "no resident world");
+	}
+	HIP_TRY(hipSetDevice(s->device));
+	return findPairsResident(s->stream, (const s2amdShape*)s->dShapes.p, s->shapeCapacity, s->liveShapes, (const s2amdPairState*)s->dPairs.p, s->contactCapacity,
+							 (const unsigned long long*)s->dJointedKeys.p, s->jointedCount, outPairs, pairCapacity, pairCount);
+}
+
+int s2amd_world_set_contacts(s2amdSolver* s, const int32_t* slots, int32_t count, const s2amdContact* contacts, const s2amdPairState* pairs)
+{
+	if (!s || count < 0 || (count > 0 && (!slots || !contacts || !pairs)))
+	{
+		return fail(S2AMD_E_INVALID, "bad argument");
+	}
+	if (!s->worldResident || !s->resident)
+	{
+		return fail(S2AMD_E_STATE, "no resident world");
+	}
+	if (count == 0)
+	{
+		return S2AMD_OK;
+	}
+	std::vector<uint8_t> seen((size_t)s->contactCapacity, 0);
+	for (int i = 0; i < count; ++i)
+	{
+		const int k = slots[i];
+		if (k < 0 || k >= s->contactCapacity || seen[(size_t)k])
+		{
+			return fail(S2AMD_E_INVALID, "contact slot " + std::to_string(k) + " is outside the resident contact array or named twice");
+		}
+		seen[(size_t)k] = 1;
+		const s2amdContact& c = contacts[i];
+		const bool live = pairs[i].shapeA >= 0;
+		if (pairs[i].shapeA >= s->shapeCapacity || pairs[i].shapeB >= s->shapeCapacity || (live && pairs[i].shapeB < 0) ||
+			(live && (c.bodyA < 0 || c.bodyA >= s->bodyCapacity || c.bodyB < 0 || c.bodyB >= s->bodyCapacity)) || c.pointCount > 2)
+		{
+			return fail(S2AMD_E_INVALID, "contact for slot " + std::to_string(k) + " names a shape or body outside the resident arrays");
+		}
+	}
+	HIP_TRY(hipSetDevice(s->device));
+	hipStream_t st = s->stream;
+	auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
+	const size_t b0 = al((size_t)count * sizeof(int32_t)), b1 = al((size_t)count * sizeof(s2amdContact)), b2 = al((size_t)count * sizeof(s2amdPairState));
+	int rc = s->dContactStage.ensure(b0 + b1 + b2);
+	if (rc)
+	{
+		return rc;
+	}
+	char* base = (char*)s->dContactStage.p;
+	HIP_TRY(hipMemcpyAsync(base, slots, (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(base + b0, contacts, (size_t)count * sizeof(s2amdContact), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(base + b0 + b1, pairs, (size_t)count * sizeof(s2amdPairState), hipMemcpyHostToDevice, st));
+	scatterContactsKernel<<<gridFor((size_t)count), dim3(S2_BLOCK), 0, st>>>((const int32_t*)base, count, (const s2amdContact*)(base + b0),
+																			  (const s2amdPairState*)(base + b0 + b1), (s2amdContact*)s->dContacts.p,
+																			  (s2amdPairState*)s->dPairs.p, (uint8_t*)s->dPointBytes.p, (int32_t*)s->dStatus.p);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(st));
+	// host shadows of the constraint graph (solver_step.cpp: refreshShadows)
+	bool changed = false;
+	for (int i = 0; i < count; ++i)
+	{
+		const int k = slots[i];
+		const s2amdContact& c = contacts[i];
+		const int pc = c.pointCount > 0 ? c.pointCount : 0;
+		changed = changed || ((s->hContactPoints[(size_t)k] > 0) != (pc > 0)) ||
+				  ((pc > 0 || s->hContactPoints[(size_t)k] > 0) && (s->hContactA[(size_t)k] != c.bodyA || s->hContactB[(size_t)k] != c.bodyB));
+		s->hContactA[(size_t)k] = c.bodyA;
+		s->hContactB[(size_t)k] = c.bodyB;
+		s->hContactPoints[(size_t)k] = pc;
+		s->hPointBytes[(size_t)k] = (uint8_t)pc;
+	}
+	if (changed)
+	{
+		s->graphAge = 0;
+		s->stripsRejected = false;
+		s->structureDirty = true;
+		s->gatherIndexDirty = true;
+	}
+	else if (s->persistValid)
+	{
+		s->persist.allTwoPoints = stripsAllTwoPoints(s) ? 1 : 0;
 	}
 	return S2AMD_OK;
 }

@@ -19,7 +19,7 @@ EXPORTS = [
     "s2amd_solve", "s2amd_upload", "s2amd_step_resident", "s2amd_download", "s2amd_save_bodies",
     "s2amd_restore_bodies", "s2amd_get_contact_order", "s2amd_get_joint_order", "s2amd_get_stats",
     "s2amd_set_option", "s2amd_export_poses", "s2amd_measure_dominant", "s2amd_refit_shapes", "s2amd_find_pairs", "s2amd_synchronize", "s2amd_update_contacts", "s2amd_find_islands", "s2amd_color_constraints",
-    "s2amd_world_upload", "s2amd_world_step", "s2amd_world_download",
+    "s2amd_world_upload", "s2amd_world_step", "s2amd_world_download", "s2amd_world_find_pairs", "s2amd_world_set_contacts",
 ]
 
 _lib = None
@@ -64,6 +64,8 @@ def load():
     L.s2amd_update_contacts.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, i32, vp]
     L.s2amd_world_upload.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp]
     L.s2amd_world_step.argtypes = [vp, ctypes.POINTER(wire.StepParams), ctypes.POINTER(wire.WorldStepInfo)]
+    L.s2amd_world_find_pairs.argtypes = [vp, vp, i32, ctypes.POINTER(i32)]
+    L.s2amd_world_set_contacts.argtypes = [vp, vp, i32, vp, vp]
     L.s2amd_world_download.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp]
     L.s2amd_find_islands.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, ctypes.POINTER(i32)]
     L.s2amd_color_constraints.argtypes = [vp, vp, i32, vp, i32, vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
@@ -183,6 +185,26 @@ class Solver:
         info = wire.WorldStepInfo()
         _check(load().s2amd_world_step(self._h, ctypes.byref(params), ctypes.byref(info)))
         return {k: getattr(info, k) for k, _ in wire.WorldStepInfo._fields_}
+
+    def world_find_pairs(self):
+        """Stage 1's new pairs for the shapes the last refit moved: int32[n, 2] sorted by (A, B)."""
+        cap = 1024
+        while True:
+            out = np.zeros((cap, 2), dtype=np.int32)
+            n = ctypes.c_int32()
+            rc = load().s2amd_world_find_pairs(self._h, wire.as_ptr(out), cap, ctypes.byref(n))
+            if rc == -5 and n.value > cap:  # S2AMD_E_CAPACITY
+                cap = n.value
+                continue
+            _check(rc)
+            return out[: n.value].copy()
+
+    def world_set_contacts(self, slots, contacts, pairs):
+        slots = np.ascontiguousarray(slots, dtype=np.int32)
+        contacts = np.ascontiguousarray(contacts)
+        pairs = np.ascontiguousarray(pairs)
+        assert contacts.dtype == wire.contact_dtype and pairs.dtype == wire.pair_state_dtype and len(slots) == len(contacts) == len(pairs)
+        _check(load().s2amd_world_set_contacts(self._h, wire.as_ptr(slots), len(slots), wire.as_ptr(contacts), wire.as_ptr(pairs)))
 
     def world_download(self, bodies, contacts, joints, shapes, pairs, origins):
         """Fills the given arrays (same sizes as uploaded) and returns them with the last stage-3 status."""

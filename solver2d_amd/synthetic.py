@@ -98,6 +98,46 @@ def pyramid(base, count=1, pitch=None):
     return bodies, contacts, joints
 
 
+SPECULATIVE_DISTANCE = np.float32(0.02)  # 4 * s2_linearSlop (reference constants.h:10-12)
+AABB_MARGIN = np.float32(0.1)            # s2_aabbMargin (reference constants.h:22)
+
+
+def _box_shape(sh, body, body_type, hx, hy, px, py, index):
+    """s2MakeBox(hx, hy) attached to an unrotated body at (px, py): vertices, normals (reference geometry.c: s2MakeBox),
+    tight AABB + speculative margin and the fat AABB of s2CreateShape."""
+    hx, hy = np.float32(hx), np.float32(hy)
+    sh["body"] = body
+    sh["type"] = wire.SHAPE_POLYGON
+    sh["categoryBits"], sh["maskBits"], sh["groupIndex"] = 1, 0xFFFFFFFF, 0
+    sh["proxyKey"] = (index << 4) | int(body_type)
+    sh["count"] = 4
+    sh["radius"] = 0.0
+    sh["vertices"][:4] = [(-hx, -hy), (hx, -hy), (hx, hy), (-hx, hy)]
+    sh["normals"][:4] = [(0.0, -1.0), (1.0, 0.0), (0.0, 1.0), (-1.0, 0.0)]
+    lo = (np.float32(px) - hx, np.float32(py) - hy)
+    hi = (np.float32(px) + hx, np.float32(py) + hy)
+    sh["aabb"] = (lo[0] - SPECULATIVE_DISTANCE, lo[1] - SPECULATIVE_DISTANCE, hi[0] + SPECULATIVE_DISTANCE, hi[1] + SPECULATIVE_DISTANCE)
+    sh["fatAABB"] = (lo[0] - AABB_MARGIN, lo[1] - AABB_MARGIN, hi[0] + AABB_MARGIN, hi[1] + AABB_MARGIN)
+
+
+def pyramid_world(base, count=1, pitch=None):
+    """pyramid() plus what stages 3 and 4 of s2World_Step read: one box shape per body (shape index == body index), the
+    narrow-phase pair state of every contact slot (empty GJK cache, no feature ids yet) and the body origins.
+    Returns a dict with the keys of tests/world_chain.py: bodies, contacts, joints, shapes, pairs, origins."""
+    bodies, contacts, joints = pyramid(base, count, pitch)
+    shapes = np.zeros(len(bodies), dtype=wire.shape_dtype)
+    for i, b in enumerate(bodies):
+        if b["type"] == wire.BODY_STATIC:
+            _box_shape(shapes[i], i, b["type"], max(100.0, float(base)), 1.0, b["position"][0], b["position"][1], i)
+        else:
+            _box_shape(shapes[i], i, b["type"], 0.5, 0.5, b["position"][0], b["position"][1], i)
+    pairs = np.zeros(len(contacts), dtype=wire.pair_state_dtype)
+    pairs["shapeA"] = contacts["bodyA"]
+    pairs["shapeB"] = contacts["bodyB"]
+    origins = np.ascontiguousarray(bodies["position"], dtype=np.float32).copy()  # localCenter is zero for a centred box
+    return {"bodies": bodies, "contacts": contacts, "joints": joints, "shapes": shapes, "pairs": pairs, "origins": origins}
+
+
 def joint_grid(numi, numk=None):
     """numi x numk circles on a unit lattice pinned by revolute joints (no contacts)."""
     numk = numi if numk is None else numk

@@ -59,3 +59,160 @@ def test_golden_world_every_solver(solver_name):
     params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
     with hip.Solver(0) as s:
         run_chain(s, params, world_chain.load_world(d), 4, "shapes_zoo/" + solver_name)
+
+
+def test_big_pyramid_world_runs_the_persistent_strips():
+    """Base-100 pyramid (5,050 boxes, 14,950 manifolds recomputed by the device narrow phase every step): after the
+    patience step the solve inside the chain is the persistent strip kernel."""
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    world = synthetic.pyramid_world(100)
+    with hip.Solver(0) as s:
+        _, infos = run_chain(s, params, world, 4, "pyramid100 world")
+        st = s.stats()
+        assert st["persistent"] == 1 and st["stripCount"] > 1, st
+        assert all(i["activeContacts"] == 14950 and i["separatedCount"] == 0 for i in infos), infos
+
+
+def test_world_chain_follows_a_changing_contact_graph():
+    """The top box starts 5 cm above its seat: its two manifolds have no points (beyond the speculative distance, inside
+    the fat AABBs), gain them when it lands, and the device must rebuild the solve structure in exactly those steps."""
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    world = synthetic.pyramid_world(12)
+    top = len(world["bodies"]) - 1
+    world["bodies"]["position"][top][1] += np.float32(0.05)
+    world["origins"][top][1] += np.float32(0.05)
+    with hip.Solver(0) as s:
+        _, infos = run_chain(s, params, world, 12, "pyramid12 with a falling top box")
+        active = [i["activeContacts"] for i in infos]
+        changed = [i["graphChanged"] for i in infos]
+        assert active[0] == len(world["contacts"]) - 2 and active[-1] == len(world["contacts"]), active
+        assert changed[0] == 1 and sum(changed) >= 2, changed
+        for a0, a1, c in zip(active[:-1], active[1:], changed[1:]):
+            assert (a0 != a1) <= bool(c)
+
+
+def test_world_chain_destroys_separated_pairs():
+    """A box shot upwards leaves the fat AABBs of its neighbours: stage 3 reports the pairs separated, the device frees
+    them (no manifold, pair slot free) as src/world.c:149-167 does, the chain goes on."""
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    world = synthetic.pyramid_world(12)
+    top = len(world["bodies"]) - 1
+    world["bodies"]["linearVelocity"][top] = (0.0, 40.0)
+    with hip.Solver(0) as s:
+        got, infos = run_chain(s, params, world, 5, "pyramid12 losing its top box")
+        assert sum(i["separatedCount"] for i in infos) == 2, infos
+        assert infos[0]["movedCount"] >= 1
+        assert int((got["pairs"]["shapeA"] < 0).sum()) == 2
+
+
+def test_world_step_consumes_applied_forces():
+    params = wire.StepParams.make("PGS", 1.0 / 60.0, 4, 2, True)
+    world = synthetic.pyramid_world(6)
+    world["bodies"]["force"][3] = (25.0, 5.0)
+    world["bodies"]["torque"][4] = 2.0
+    with hip.Solver(0) as s:
+        got, _ = run_chain(s, params, world, 2, "pyramid6 with forces")
+        assert not got["bodies"]["force"].any() and not got["bodies"]["torque"].any()
+
+
+def test_world_api_state_errors():
+    params = wire.StepParams.make("PGS", 1.0 / 60.0, 4, 2, True)
+    with hip.Solver(0) as s:
+        with pytest.raises(hip.S2AmdError):
+            s.world_step(params)
+        world = synthetic.pyramid_world(4)
+        bad = world_chain.copy_world(world)
+        bad["pairs"]["shapeB"][0] = len(world["shapes"]) + 5
+        with pytest.raises(hip.S2AmdError):
+            s.world_upload(*[bad[k] for k in world_chain.WORLD_KEYS])
+        s.upload(world["bodies"], world["contacts"], world["joints"])
+        with pytest.raises(hip.S2AmdError):
+            s.world_step(params)  # plain upload: no shapes resident
+
+
+def _live_pairs(world):
+    live = world["pairs"]["shapeA"] >= 0
+    return np.stack([world["pairs"]["shapeA"][live], world["pairs"]["shapeB"][live]], axis=1).astype(np.int32)
+
+
+def _create_contacts(world, new_pairs):
+    """The caller's side of s2CreateContact (src/contact.c:137-203) for box worlds: first free slot, empty manifold."""
+    slots, contacts, pairs = [], [], []
+    free = np.flatnonzero(world["pairs"]["shapeA"] < 0).tolist()
+    for a, b in new_pairs.tolist():
+        k = free.pop(0)
+        c = np.zeros(1, dtype=wire.contact_dtype)[0]
+        c["bodyA"], c["bodyB"] = world["shapes"]["body"][a], world["shapes"]["body"][b]
+        c["friction"] = 0.6
+        c["constraintIndex"] = -1
+        p = np.zeros(1, dtype=wire.pair_state_dtype)[0]
+        p["shapeA"], p["shapeB"] = a, b
+        world["contacts"][k] = c
+        world["pairs"][k] = p
+        slots.append(k)
+        contacts.append(c)
+        pairs.append(p)
+    return np.array(slots, dtype=np.int32), np.array(contacts, dtype=wire.contact_dtype), np.array(pairs, dtype=wire.pair_state_dtype)
+
+
+def test_world_loop_with_pair_creation():
+    """The whole s2World_Step loop with the control plane on the host: the top box hops off (its pairs separate and are
+    destroyed on the device), lands again (the refit moves its proxy, s2amd_world_find_pairs reports the new pairs, the
+    caller creates the contacts with s2amd_world_set_contacts).  Every step bit-exact against the oracle chain, every
+    pair query equal to the oracle's."""
+    from tests import oraclebind
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    world = synthetic.pyramid_world(12)
+    top = len(world["bodies"]) - 1
+    world["bodies"]["linearVelocity"][top] = (0.0, 3.0)
+    ref = world_chain.copy_world(world)
+    separated = created = queries = 0
+    with hip.Solver(0) as s:
+        s.world_upload(*[world[k] for k in world_chain.WORLD_KEYS])
+        for step in range(60):
+            info = s.world_step(params)
+            order, _ = s.contact_order()
+            status = world_chain.oracle_world_step(params, ref, contact_order=order)
+            separated += info["separatedCount"]
+            assert info["separatedCount"] == int((status == wire.PAIR_SEPARATED).sum())
+            if info["movedCount"] > 0:
+                queries += 1
+                got = s.world_find_pairs()
+                moved = (ref["shapes"]["enlarged"] != 0).astype(np.uint8)
+                want = oraclebind.find_pairs(ref["bodies"], ref["shapes"], moved, _live_pairs(ref), ref["joints"])
+                assert np.array_equal(got, want), "step %d: new pairs" % step
+                if len(got):
+                    created += len(got)
+                    slots, contacts, pairs = _create_contacts(ref, got)
+                    s.world_set_contacts(slots, contacts, pairs)
+            out = world_chain.copy_world(world)
+            res = s.world_download(*[out[k] for k in world_chain.WORLD_KEYS])
+            world_chain.assert_device_equals_oracle(dict(zip(world_chain.WORLD_KEYS, res[:6])), ref, "hop step %d" % step)
+        assert separated == 2 and created == 2 and queries >= 2, (separated, created, queries)
+        assert int((ref["contacts"]["pointCount"] > 0).sum()) == len(ref["contacts"])
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(p)[6:-4] for p in FILES])
+def test_resident_pair_query_equals_the_stage_function(path):
+    """s2amd_world_find_pairs on the golden worlds (joints, kinematic bodies, all shape types) whenever the refit moved
+    something, against the oracle's pair discovery on the same state."""
+    from tests import oraclebind
+    d = np.load(path)
+    params = world_chain.params_of(d)
+    world = world_chain.load_world(d)
+    ref = world_chain.copy_world(world)
+    asked = 0
+    with hip.Solver(0) as s:
+        s.world_upload(*[world[k] for k in world_chain.WORLD_KEYS])
+        for step in range(8):
+            info = s.world_step(params)
+            order, _ = s.contact_order()
+            jorder, _ = s.joint_order()
+            world_chain.oracle_world_step(params, ref, contact_order=order, joint_order=jorder)
+            if info["movedCount"] > 0:
+                asked += 1
+                moved = ((ref["shapes"]["enlarged"] != 0) & (ref["shapes"]["type"] != wire.SHAPE_FREE)).astype(np.uint8)
+                want = oraclebind.find_pairs(ref["bodies"], ref["shapes"], moved, _live_pairs(ref), ref["joints"])
+                assert np.array_equal(s.world_find_pairs(), want), "step %d" % step
+    if "pyramid" not in path:
+        assert asked > 0

@@ -446,7 +446,8 @@ __global__ __launch_bounds__(S2_BLOCK) void residentPairKeysKernel(const s2amdPa
 }
 
 int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShapes, const s2amdPairState* dPairs, int nc,
-					  const unsigned long long* dJointed, int jointedCount, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount)
+					  const unsigned long long* dJointed, int jointedCount, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount, void** scratch,
+					  size_t* scratchBytes)
 {
 	*pairCount = 0;
 	const int n = liveShapes;
@@ -469,9 +470,19 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 	{
 		total += b;
 	}
-	Scratch buf;
-	BP_TRY(buf.ensure(total));
-	char* p = (char*)buf.p;
+	if (*scratchBytes < total)
+	{
+		// owned by the caller (the solver keeps it between calls)
+		if (*scratch)
+		{
+			(void)hipFree(*scratch);
+			*scratch = nullptr;
+			*scratchBytes = 0;
+		}
+		BP_TRY(hipMalloc(scratch, total + total / 4));
+		*scratchBytes = total + total / 4;
+	}
+	char* p = (char*)*scratch;
 	size_t li = 0;
 	auto take = [&]() {
 		char* r = p;

@@ -163,7 +163,7 @@ struct s2amdSolver
 	bool savedValid = false;
 
 	// resident world (world.hip): the arrays of stages 3 and 4 beside the solver's wire arrays
-	DevBuf dShapes, dPairs, dOrigins, dStatus, dPointBytes, dWorldSummary, dJointedKeys, dContactStage;
+	DevBuf dShapes, dPairs, dOrigins, dStatus, dPointBytes, dWorldSummary, dJointedKeys, dContactStage, dPairScratch;
 	int shapeCapacity = 0, liveShapes = 0, jointedCount = 0;
 	bool worldResident = false;
 	int* hostWorldSummary = nullptr; // pinned: the per-step counters of both stages

@@ -353,7 +353,8 @@ int s2amd_world_find_pairs(s2amdSolver* s, int32_t* outPairs, int32_t pairCapaci
 	}
 	HIP_TRY(hipSetDevice(s->device));
 	return findPairsResident(s->stream, (const s2amdShape*)s->dShapes.p, s->shapeCapacity, s->liveShapes, (const s2amdPairState*)s->dPairs.p, s->contactCapacity,
-							 (const unsigned long long*)s->dJointedKeys.p, s->jointedCount, outPairs, pairCapacity, pairCount);
+							 (const unsigned long long*)s->dJointedKeys.p, s->jointedCount, outPairs, pairCapacity, pairCount, &s->dPairScratch.p,
+							 &s->dPairScratch.bytes);
 }
 
 int s2amd_world_set_contacts(s2amdSolver* s, const int32_t* slots, int32_t count, const s2amdContact* contacts, const s2amdPairState* pairs)

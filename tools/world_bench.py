@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=60)
     ap.add_argument("--ref-steps", type=int, default=20)
+    ap.add_argument("--no-pairs", action="store_true", help="skip the stage-1 pair query in the steps where the refit moved shapes")
     a = ap.parse_args()
     params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
     world = synthetic.pyramid_world(a.base)
@@ -30,10 +31,26 @@ def main():
            "solver": "TGS_Soft 8/4 warm start"}
     with hip.Solver(0) as s:
         s.world_upload(*[world[k] for k in world_chain.WORLD_KEYS])
-        infos = [s.world_step(params) for _ in range(a.warmup)]
+        found = queries = 0
+        pair_s = 0.0
+
+        def step():
+            nonlocal found, queries, pair_s
+            info = s.world_step(params)
+            if info["movedCount"] > 0 and not a.no_pairs:
+                t = time.perf_counter()
+                found += len(s.world_find_pairs())  # stage 1 for the next step (a settled pyramid finds none)
+                pair_s += time.perf_counter() - t
+                queries += 1
+            return info
+
+        infos = [step() for _ in range(a.warmup)]
+        found = queries = 0
+        pair_s = 0.0
         t0 = time.perf_counter()
-        infos = [s.world_step(params) for _ in range(a.steps)]
+        infos = [step() for _ in range(a.steps)]
         ms = 1e3 * (time.perf_counter() - t0) / a.steps
+        out.update({"pair_queries": queries, "new_pairs_found": found, "pair_query_ms": 1e3 * pair_s / max(queries, 1)})
         st = s.stats()
         out.update({
             "gpu_world_step_ms": ms,

@@ -66,26 +66,11 @@ __global__ __launch_bounds__(S2_BLOCK) void bodyOriginsKernel(const s2amdBody* b
 }
 
 // s2Shape_ComputeAABB -> src/geometry.c:288-339, then src/world.c:283-296
-__global__ __launch_bounds__(S2_BLOCK) void refitShapesKernel(const s2amdBody* bodies, int nb, s2amdShape* shapes, int ns, const float2* origins)
+// one shape of a non-static body: tight AABB + speculative margin, fat AABB re-inflated when it was left; returns `enlarged`
+S2_DEV int refitShapeOne(const s2amdBody* b, s2amdShape* sh, V2 origin)
 {
-	int si = blockIdx.x * blockDim.x + threadIdx.x;
-	if (si >= ns)
-	{
-		return;
-	}
-	s2amdShape* sh = shapes + si;
-	if (sh->type == S2AMD_SHAPE_FREE || sh->body < 0 || sh->body >= nb)
-	{
-		return;
-	}
-	const s2amdBody* b = bodies + sh->body;
-	if (b->type == S2AMD_BODY_FREE || b->type == S2AMD_BODY_STATIC)
-	{
-		return;
-	}
 	Xf xf;
-	float2 o = origins[sh->body];
-	xf.p = v2(o.x, o.y);
+	xf.p = origin;
 	xf.q.s = b->rot[0], xf.q.c = b->rot[1];
 	V2 lower, upper;
 	V2 v0 = v2(sh->vertices[0][0], sh->vertices[0][1]);
@@ -149,6 +134,81 @@ __global__ __launch_bounds__(S2_BLOCK) void refitShapesKernel(const s2amdBody* b
 		enlarged = 1;
 	}
 	sh->enlarged = enlarged;
+	return enlarged;
+}
+
+__global__ __launch_bounds__(S2_BLOCK) void refitShapesKernel(const s2amdBody* bodies, int nb, s2amdShape* shapes, int ns, const float2* origins)
+{
+	int si = blockIdx.x * blockDim.x + threadIdx.x;
+	if (si >= ns)
+	{
+		return;
+	}
+	s2amdShape* sh = shapes + si;
+	if (sh->type == S2AMD_SHAPE_FREE || sh->body < 0 || sh->body >= nb)
+	{
+		return;
+	}
+	const s2amdBody* b = bodies + sh->body;
+	if (b->type == S2AMD_BODY_FREE || b->type == S2AMD_BODY_STATIC)
+	{
+		return;
+	}
+	float2 o = origins[sh->body];
+	(void)refitShapeOne(b, sh, v2(o.x, o.y));
+}
+
+// Stage 4 of the resident world in ONE launch (src/world.c:259-301): blocks [0, shapeBlocks) refit one shape per thread,
+// with the body origin recomputed from the body (the same expression bodyOriginsKernel evaluates, so the same bits);
+// the other blocks walk the bodies: origin written for the next stage 3, applied forces consumed (src/world.c:274-275).
+__global__ __launch_bounds__(S2_BLOCK) void stage4Kernel(s2amdBody* bodies, int nb, s2amdShape* shapes, int ns, float2* origins, int shapeBlocks,
+														  int* summary)
+{
+	if ((int)blockIdx.x >= shapeBlocks)
+	{
+		int i = ((int)blockIdx.x - shapeBlocks) * (int)blockDim.x + (int)threadIdx.x;
+		if (i < nb)
+		{
+			s2amdBody* b = bodies + i;
+			if (b->type != S2AMD_BODY_FREE && b->type != S2AMD_BODY_STATIC)
+			{
+				Rot q;
+				q.s = b->rot[0], q.c = b->rot[1];
+				V2 o = sub(v2(b->position[0], b->position[1]), rotate(q, v2(b->localCenter[0], b->localCenter[1])));
+				origins[i] = make_float2(o.x, o.y);
+				b->force[0] = 0.0f;
+				b->force[1] = 0.0f;
+				b->torque = 0.0f;
+			}
+		}
+		return;
+	}
+	int si = blockIdx.x * blockDim.x + threadIdx.x;
+	int enlarged = 0;
+	if (si < ns)
+	{
+		s2amdShape* sh = shapes + si;
+		if (sh->type != S2AMD_SHAPE_FREE && sh->body >= 0 && sh->body < nb)
+		{
+			const s2amdBody* b = bodies + sh->body;
+			if (b->type != S2AMD_BODY_FREE && b->type != S2AMD_BODY_STATIC)
+			{
+				Rot q;
+				q.s = b->rot[0], q.c = b->rot[1];
+				V2 o = sub(v2(b->position[0], b->position[1]), rotate(q, v2(b->localCenter[0], b->localCenter[1])));
+				enlarged = refitShapeOne(b, sh, o);
+			}
+			else
+			{
+				enlarged = sh->enlarged != 0 ? 1 : 0; // a static shape keeps the flag its creation gave it
+			}
+		}
+	}
+	unsigned long long m = __ballot(enlarged != 0);
+	if ((threadIdx.x & 63) == 0 && m != 0ull)
+	{
+		atomicAdd(summary + 4, __popcll(m));
+	}
 }
 
 // ---- pair discovery ----
@@ -554,14 +614,15 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 }
 
 // resident arrays (world.hip)
-void launchRefitShapes(hipStream_t st, const s2amdBody* bodies, int bodyCapacity, s2amdShape* shapes, int shapeCapacity, float* origins)
+void launchStage4(hipStream_t st, s2amdBody* bodies, int bodyCapacity, s2amdShape* shapes, int shapeCapacity, float* origins, int* summary)
 {
-	if (bodyCapacity <= 0 || shapeCapacity <= 0)
+	if (bodyCapacity <= 0)
 	{
 		return;
 	}
-	bodyOriginsKernel<<<gridFor((size_t)bodyCapacity), dim3(S2_BLOCK), 0, st>>>(bodies, bodyCapacity, (float2*)origins);
-	refitShapesKernel<<<gridFor((size_t)shapeCapacity), dim3(S2_BLOCK), 0, st>>>(bodies, bodyCapacity, shapes, shapeCapacity, (const float2*)origins);
+	int shapeBlocks = (shapeCapacity + S2_BLOCK - 1) / S2_BLOCK, bodyBlocks = (bodyCapacity + S2_BLOCK - 1) / S2_BLOCK;
+	stage4Kernel<<<dim3((unsigned)(shapeBlocks + bodyBlocks)), dim3(S2_BLOCK), 0, st>>>(bodies, bodyCapacity, shapes, shapeCapacity, (float2*)origins,
+																					shapeBlocks, summary);
 }
 
 #pragma GCC visibility push(default)

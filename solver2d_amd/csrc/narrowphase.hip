@@ -766,21 +766,12 @@ S2_DEV void stagePolygon(const s2amdShape* sh, const PolyRef& out, bool toFrame,
 	*radius = sh->type == S2AMD_SHAPE_CAPSULE ? sh->radius : 0.0f;
 }
 
-__global__ __launch_bounds__(S2_NP_BLOCK) void updateContactsKernel(const s2amdBody* bodies, const float2* origins, const s2amdShape* shapes,
-																	 s2amdPairState* pairs, s2amdContact* contacts, int contactCapacity, int32_t* status)
+// one contact slot of stage 3; returns S2AMD_PAIR_*.  lds: the block's 4 * S2_NP_MAX_VERTS * S2_NP_BLOCK float2 staging area
+S2_DEV int updateContactOne(const s2amdBody* bodies, const float2* origins, const s2amdShape* shapes, s2amdPairState* ps, s2amdContact* ct, float2* lds)
 {
-	__shared__ float2 lds[4 * S2_NP_MAX_VERTS * S2_NP_BLOCK]; // vertsA, normsA, vertsB, normsB: 32 KiB
-	int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= contactCapacity)
-	{
-		return;
-	}
-	s2amdPairState* ps = pairs + i;
-	s2amdContact* ct = contacts + i;
 	if (ps->shapeA < 0 || ps->shapeB < 0)
 	{
-		status[i] = S2AMD_PAIR_FREE;
-		return;
+		return S2AMD_PAIR_FREE;
 	}
 	const s2amdShape* shapeA = shapes + ps->shapeA;
 	const s2amdShape* shapeB = shapes + ps->shapeB;
@@ -790,11 +781,9 @@ __global__ __launch_bounds__(S2_NP_BLOCK) void updateContactsKernel(const s2amdB
 		float d2x = shapeA->fatAABB[0] - shapeB->fatAABB[2], d2y = shapeA->fatAABB[1] - shapeB->fatAABB[3];
 		if (d1x > 0.0f || d1y > 0.0f || d2x > 0.0f || d2y > 0.0f)
 		{
-			status[i] = S2AMD_PAIR_SEPARATED;
-			return;
+			return S2AMD_PAIR_SEPARATED;
 		}
 	}
-	status[i] = S2AMD_PAIR_UPDATED;
 	const int bodyA = shapeA->body, bodyB = shapeB->body;
 	Xf xfA, xfB;
 	xfA.p = v2(origins[bodyA].x, origins[bodyA].y);
@@ -899,6 +888,58 @@ __global__ __launch_bounds__(S2_NP_BLOCK) void updateContactsKernel(const s2amdB
 		ps->cacheIndexA[k] = (uint8_t)cache.indexA[k];
 		ps->cacheIndexB[k] = (uint8_t)cache.indexB[k];
 	}
+	return S2AMD_PAIR_UPDATED;
+}
+
+// SUMMARY (resident world, world.hip): a separated pair is destroyed the way src/world.c:149-167 destroys its contact (no
+// manifold, free pair slot), the slot's point count is compared with the previous step's byte, and the step's counters
+// {separated, active, flips, moves} are accumulated in summary[0..3].
+template <bool SUMMARY>
+__global__ __launch_bounds__(S2_NP_BLOCK) void updateContactsKernel(const s2amdBody* bodies, const float2* origins, const s2amdShape* shapes,
+																	 s2amdPairState* pairs, s2amdContact* contacts, int contactCapacity, int32_t* status,
+																	 uint8_t* pointBytes, int* summary)
+{
+	__shared__ float2 lds[4 * S2_NP_MAX_VERTS * S2_NP_BLOCK]; // vertsA, normsA, vertsB, normsB: 32 KiB
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	int pc = 0;
+	if (i < contactCapacity)
+	{
+		int st = updateContactOne(bodies, origins, shapes, pairs + i, contacts + i, lds);
+		status[i] = st;
+		if (SUMMARY)
+		{
+			if (st == S2AMD_PAIR_SEPARATED)
+			{
+				contacts[i].pointCount = 0;
+				pairs[i].shapeA = -1;
+				pairs[i].shapeB = -1;
+				atomicAdd(summary + 0, 1);
+			}
+			else
+			{
+				pc = contacts[i].pointCount;
+				pc = pc > 0 ? pc : 0;
+			}
+			int old = pointBytes[i];
+			if (old != pc)
+			{
+				pointBytes[i] = (uint8_t)pc;
+				atomicAdd(summary + 3, 1);
+				if ((old > 0) != (pc > 0))
+				{
+					atomicAdd(summary + 2, 1);
+				}
+			}
+		}
+	}
+	if (SUMMARY)
+	{
+		unsigned long long live = __ballot(pc > 0);
+		if ((threadIdx.x & 63) == 0 && live != 0ull)
+		{
+			atomicAdd(summary + 1, __popcll(live));
+		}
+	}
 }
 
 struct Scratch
@@ -927,14 +968,15 @@ struct Scratch
 
 // resident arrays (world.hip)
 void launchUpdateContacts(hipStream_t st, const s2amdBody* bodies, const float* origins, const s2amdShape* shapes, s2amdPairState* pairs,
-						  s2amdContact* contacts, int contactCapacity, int32_t* status)
+						  s2amdContact* contacts, int contactCapacity, int32_t* status, uint8_t* pointBytes, int* summary)
 {
 	if (contactCapacity <= 0)
 	{
 		return;
 	}
 	dim3 grid((unsigned)((contactCapacity + S2_NP_BLOCK - 1) / S2_NP_BLOCK));
-	updateContactsKernel<<<grid, dim3(S2_NP_BLOCK), 0, st>>>(bodies, (const float2*)origins, shapes, pairs, contacts, contactCapacity, status);
+	updateContactsKernel<true><<<grid, dim3(S2_NP_BLOCK), 0, st>>>(bodies, (const float2*)origins, shapes, pairs, contacts, contactCapacity, status,
+																   pointBytes, summary);
 }
 
 #pragma GCC visibility push(default)
@@ -991,7 +1033,7 @@ int s2amd_update_contacts(s2amdSolver* solver, const s2amdBody* bodies, int32_t 
 	NP_TRY(hipEventCreate(&e0));
 	NP_TRY(hipEventCreate(&e1));
 	NP_TRY(hipEventRecord(e0, st));
-	updateContactsKernel<<<grid, dim3(S2_NP_BLOCK), 0, st>>>(dB, dO, dS, dP, dC, contactCapacity, dT);
+	updateContactsKernel<false><<<grid, dim3(S2_NP_BLOCK), 0, st>>>(dB, dO, dS, dP, dC, contactCapacity, dT, nullptr, nullptr);
 	NP_TRY(hipEventRecord(e1, st));
 	NP_TRY(hipGetLastError());
 	NP_TRY(hipMemcpyAsync(pairs, dP, pBytes, hipMemcpyDeviceToHost, st));

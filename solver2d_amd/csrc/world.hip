@@ -4,7 +4,7 @@
 // and out, which costs more than their kernels.  Here the shapes, the narrow-phase pair states and the body origins
 // stay on the device beside the solver's wire bodies / contacts / joints, and one s2amd_world_step runs
 //
-//     update contacts (narrowphase.hip)  ->  contact summary  ->  s2Solve_* (solver_step.cpp: doStep)  ->  refit
+//     update contacts + counters (narrowphase.hip)  ->  s2Solve_* (solver_step.cpp: doStep)  ->  refit + origins + force reset (broadphase.hip)
 //
 // on them.  What comes back per step is 32 bytes of counters.  The constraint graph structure (islands, colours,
 // strips) is still built on the host, so the point counts of the new manifolds are fetched (one byte per contact
@@ -16,6 +16,7 @@
 namespace
 {
 
+// int[8] on the device: the narrow-phase kernel fills [0..3], the stage-4 kernel [4] (launch.h)
 struct WorldSummary
 {
 	int separated; // pairs whose fat AABBs parted this step
@@ -25,69 +26,6 @@ struct WorldSummary
 	int enlarged;  // shapes whose fat AABB was re-inflated by the refit: the broad phase has to look at them
 	int pad[3];
 };
-
-// After the narrow phase: a separated pair is destroyed the way src/world.c:149-167 destroys its contact (no
-// manifold, free pair slot), point counts are compared with the previous step's.
-__global__ __launch_bounds__(S2_BLOCK) void contactSummaryKernel(s2amdContact* contacts, s2amdPairState* pairs, const int32_t* status, int n,
-																 uint8_t* pointBytes, WorldSummary* out)
-{
-	int k = blockIdx.x * blockDim.x + threadIdx.x;
-	int pc = 0;
-	if (k < n)
-	{
-		int st = status[k];
-		if (st == S2AMD_PAIR_SEPARATED)
-		{
-			contacts[k].pointCount = 0;
-			pairs[k].shapeA = -1;
-			pairs[k].shapeB = -1;
-			atomicAdd(&out->separated, 1);
-		}
-		else
-		{
-			pc = contacts[k].pointCount;
-			pc = pc > 0 ? pc : 0;
-		}
-		int old = pointBytes[k];
-		if (old != pc)
-		{
-			pointBytes[k] = (uint8_t)pc;
-			atomicAdd(&out->moves, 1);
-			if ((old > 0) != (pc > 0))
-			{
-				atomicAdd(&out->flips, 1);
-			}
-		}
-	}
-	unsigned long long live = __ballot(pc > 0);
-	if ((threadIdx.x & 63) == 0 && live != 0ull)
-	{
-		atomicAdd(&out->active, __popcll(live));
-	}
-}
-
-// the rest of stage 4's body loop: the applied forces are consumed by the step (src/world.c:274-275)
-__global__ __launch_bounds__(S2_BLOCK) void clearForcesKernel(s2amdBody* bodies, int n)
-{
-	int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n && bodies[i].type != S2AMD_BODY_FREE && bodies[i].type != S2AMD_BODY_STATIC)
-	{
-		bodies[i].force[0] = 0.0f;
-		bodies[i].force[1] = 0.0f;
-		bodies[i].torque = 0.0f;
-	}
-}
-
-__global__ __launch_bounds__(S2_BLOCK) void countEnlargedKernel(const s2amdShape* shapes, int n, WorldSummary* out)
-{
-	int i = blockIdx.x * blockDim.x + threadIdx.x;
-	bool e = i < n && shapes[i].type != S2AMD_SHAPE_FREE && shapes[i].enlarged != 0;
-	unsigned long long m = __ballot(e);
-	if ((threadIdx.x & 63) == 0 && m != 0ull)
-	{
-		atomicAdd(&out->enlarged, __popcll(m));
-	}
-}
 
 // s2amd_world_set_contacts: staged records into their slots
 __global__ __launch_bounds__(S2_BLOCK) void scatterContactsKernel(const int32_t* slots, int n, const s2amdContact* newContacts, const s2amdPairState* newPairs,
@@ -137,6 +75,20 @@ void applyPointCounts(s2amdSolver* s)
 	}
 }
 
+// the step's counters to the host (a mapped page the kernels would store into and the host spin on was measured: same
+// 0.332 ms per step, hipStreamSynchronize already spins); `reset`: the last read-back of a step clears them for the next
+int fetchSummary(s2amdSolver* s, int reset)
+{
+	HIP_TRY(hipMemcpyAsync(s->hostWorldSummary, s->dWorldSummary.p, 8 * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+	if (reset)
+	{
+		HIP_TRY(hipMemsetAsync(s->dWorldSummary.p, 0, 8 * sizeof(int), s->stream));
+	}
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	return S2AMD_OK;
+}
+
 } // namespace
 
 #pragma GCC visibility push(default)
@@ -178,7 +130,8 @@ int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapa
 	}
 	if (!s->hostWorldSummary)
 	{
-		HIP_TRY(hipHostMalloc((void**)&s->hostWorldSummary, sizeof(WorldSummary), hipHostMallocDefault));
+		HIP_TRY(hipHostMalloc((void**)&s->hostWorldSummary, 64 * sizeof(int), hipHostMallocDefault));
+		memset(s->hostWorldSummary, 0, 64 * sizeof(int));
 	}
 	const size_t sBytes = (size_t)shapeCapacity * sizeof(s2amdShape), pBytes = (size_t)contactCapacity * sizeof(s2amdPairState);
 	const size_t oBytes = (size_t)bodyCapacity * 2 * sizeof(float);
@@ -235,6 +188,7 @@ int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapa
 	{
 		HIP_TRY(hipMemcpyAsync(s->dOrigins.p, origins, oBytes, hipMemcpyHostToDevice, s->stream));
 	}
+	HIP_TRY(hipMemsetAsync(s->dWorldSummary.p, 0, 256, s->stream));
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	s->shapeCapacity = shapeCapacity;
 	s->worldResident = true;
@@ -252,24 +206,25 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 		return fail(S2AMD_E_STATE, "s2amd_world_step called before s2amd_world_upload");
 	}
 	HIP_TRY(hipSetDevice(s->device));
-	hipStream_t st = s->stream;
 	const int nc = s->contactCapacity, nb = s->bodyCapacity, ns = s->shapeCapacity;
+	hipStream_t st = s->stream;
 	WorldSummary* dSum = (WorldSummary*)s->dWorldSummary.p;
 	WorldSummary* hSum = (WorldSummary*)s->hostWorldSummary;
 	const double t0 = nowMs();
 
 	// ---- stage 3: update contacts ----
-	HIP_TRY(hipMemsetAsync(dSum, 0, sizeof(WorldSummary), st));
 	if (nc > 0)
 	{
+		// (the kernel also destroys separated pairs and accumulates the step's contact counters)
 		launchUpdateContacts(st, (const s2amdBody*)s->dBodies.p, (const float*)s->dOrigins.p, (const s2amdShape*)s->dShapes.p,
-							 (s2amdPairState*)s->dPairs.p, (s2amdContact*)s->dContacts.p, nc, (int32_t*)s->dStatus.p);
-		contactSummaryKernel<<<gridFor((size_t)nc), dim3(S2_BLOCK), 0, st>>>((s2amdContact*)s->dContacts.p, (s2amdPairState*)s->dPairs.p,
-																			  (const int32_t*)s->dStatus.p, nc, (uint8_t*)s->dPointBytes.p, dSum);
+							 (s2amdPairState*)s->dPairs.p, (s2amdContact*)s->dContacts.p, nc, (int32_t*)s->dStatus.p, (uint8_t*)s->dPointBytes.p,
+							 (int*)dSum);
 	}
-	HIP_TRY(hipMemcpyAsync(hSum, dSum, sizeof(WorldSummary), hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipStreamSynchronize(st));
+	int rc = fetchSummary(s, 0);
+	if (rc)
+	{
+		return rc;
+	}
 	WorldSummary contactsSeen = *hSum;
 	if (contactsSeen.moves > 0)
 	{
@@ -288,31 +243,23 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 	{
 		const int savedAsync = s->optAsync;
 		s->optAsync = 1;
-		int rc = doStep(s, params);
+		rc = doStep(s, params);
 		s->optAsync = savedAsync;
 		if (rc)
 		{
 			return rc;
 		}
-		launchRefitShapes(st, (const s2amdBody*)s->dBodies.p, nb, (s2amdShape*)s->dShapes.p, ns, (float*)s->dOrigins.p);
-		if (nb > 0)
+		launchStage4(st, (s2amdBody*)s->dBodies.p, nb, (s2amdShape*)s->dShapes.p, ns, (float*)s->dOrigins.p, (int*)dSum);
+		if ((rc = fetchSummary(s, 1)) != 0)
 		{
-			clearForcesKernel<<<gridFor((size_t)nb), dim3(S2_BLOCK), 0, st>>>((s2amdBody*)s->dBodies.p, nb);
+			return rc;
 		}
-		if (ns > 0)
-		{
-			countEnlargedKernel<<<gridFor((size_t)ns), dim3(S2_BLOCK), 0, st>>>((const s2amdShape*)s->dShapes.p, ns, dSum);
-		}
-		HIP_TRY(hipMemcpyAsync(hSum, dSum, sizeof(WorldSummary), hipMemcpyDeviceToHost, st));
-		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipStreamSynchronize(st));
 		if (s->hostError && *s->hostError != 0u && fallbacks == 0)
 		{
 			// bodies, impulses and (because the solve left the bodies alone) the shapes are what they were before the solve
 			*s->hostError = 0u;
 			HIP_TRY(hipMemsetAsync(s->persist.deviceError, 0, sizeof(unsigned int), st));
 			HIP_TRY(hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, st));
-			HIP_TRY(hipMemsetAsync(&dSum->enlarged, 0, sizeof(int), st));
 			s->persistFailed = true;
 			s->persistFallbacks += 1;
 			fallbacks += 1;

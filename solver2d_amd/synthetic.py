@@ -128,7 +128,9 @@ def pyramid_world(base, count=1, pitch=None):
     shapes = np.zeros(len(bodies), dtype=wire.shape_dtype)
     for i, b in enumerate(bodies):
         if b["type"] == wire.BODY_STATIC:
-            _box_shape(shapes[i], i, b["type"], max(100.0, float(base)), 1.0, b["position"][0], b["position"][1], i)
+            # the scene's 100 m ground (widened for base 200); many pyramids: grounds that stay clear of each other
+            ground_hx = max(100.0, float(base)) if count == 1 else 0.5 * base + 5.0
+            _box_shape(shapes[i], i, b["type"], ground_hx, 1.0, b["position"][0], b["position"][1], i)
         else:
             _box_shape(shapes[i], i, b["type"], 0.5, 0.5, b["position"][0], b["position"][1], i)
     pairs = np.zeros(len(contacts), dtype=wire.pair_state_dtype)

@@ -20,16 +20,21 @@ from tests import world_chain  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--base", type=int, default=200)
+    ap.add_argument("--count", type=int, default=1, help="independent pyramids in the world (BASELINE config 5: --base 40 --count 512)")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=60)
     ap.add_argument("--ref-steps", type=int, default=20)
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE")
     ap.add_argument("--no-pairs", action="store_true", help="skip the stage-1 pair query in the steps where the refit moved shapes")
     a = ap.parse_args()
     params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
-    world = synthetic.pyramid_world(a.base)
-    out = {"world": "LargePyramid base-%d: %d bodies, %d shapes, %d contact slots" % (a.base, len(world["bodies"]), len(world["shapes"]), len(world["contacts"])),
+    world = synthetic.pyramid_world(a.base, a.count)
+    out = {"world": "%d x LargePyramid base-%d: %d bodies, %d shapes, %d contact slots" % (a.count, a.base, len(world["bodies"]), len(world["shapes"]), len(world["contacts"])),
            "solver": "TGS_Soft 8/4 warm start"}
     with hip.Solver(0) as s:
+        for kv in a.opt:
+            k, v = kv.split("=")
+            s.set_option(k, int(v))
         s.world_upload(*[world[k] for k in world_chain.WORLD_KEYS])
         found = queries = 0
         pair_s = 0.0
@@ -64,7 +69,7 @@ def main():
         })
     try:
         from tests import refbind
-        if refbind.available():
+        if refbind.available() and a.count == 1 and a.ref_steps > 0:
             with refbind.RefWorld("pyramid", "TGS_Soft", a.base, 0) as ref:
                 for _ in range(5):
                     ref.step(1.0 / 60.0, 8, 4, True)

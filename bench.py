@@ -15,10 +15,12 @@ N > 1: one process per GPU (torch.distributed / RCCL), each rank owns one indepe
 island (weak scaling); the only exchange is the per-step all-gather of per-island body poses.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (solveContactsSoftKernel<SOFT_TGS>): algorithmic bytes per launch
-                (232 B/constraint-sweep, SURVEY.md 8d x constraints per colour batch) / average
-                duration of one launch in steady state (solve sweep launches enqueued back to back and
-                bracketed by HIP events on the launch stream; see s2amd_measure_dominant).
+  roofline      dominant kernel: stripStepKernel<SOFT_TGS> (the whole step in one persistent launch) when the strip
+                structure is in use, else solveContactsSoftKernel<SOFT_TGS> (one colour batch).  Algorithmic bytes
+                per launch (232 B/constraint-sweep, SURVEY.md 8d x the constraint-sweeps one launch processes) /
+                average duration of one launch in steady state (launches enqueued back to back in a hipGraph and
+                bracketed by HIP events on the launch stream; see s2amd_measure_dominant); traffic: the PMC passes
+                under profiles/.
   cpu_baseline  the reference's own s2Solve_TGS_Soft timed on this host (oracle/_ref, kind
                 "reference") or, if that library is absent, the oracle port; 1 core.
 """

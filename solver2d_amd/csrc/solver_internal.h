@@ -245,6 +245,7 @@ struct s2amdSolver
 	hipGraph_t graph = nullptr;
 	hipGraphExec_t graphExec = nullptr;
 	uint64_t graphKey = 0;
+	uint64_t graphKeySeen = 0; // the launch sequence of the last step that was enqueued directly
 
 	// profiling events for the contact solve sweeps
 	std::vector<hipEvent_t> sweepEvents;

@@ -308,7 +308,16 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 		{
 			key = 1;
 		}
-		if (key != s->graphKey || s->graphExec == nullptr)
+		if ((key != s->graphKey || s->graphExec == nullptr) && key != s->graphKeySeen)
+		{
+			// A launch sequence seen for the first time is enqueued directly: capture + instantiate cost more than the
+			// launches themselves and only pay off when the same sequence comes back (a changing contact graph never
+			// brings one back).
+			s->graphKeySeen = key;
+			q.fork = false; // the parallel branches only exist inside a captured graph
+			enqueueAll();
+		}
+		else if (key != s->graphKey || s->graphExec == nullptr)
 		{
 			destroyGraph(s);
 			HIP_TRY(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
@@ -328,7 +337,10 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 			s->launchCounter = s->graphLaunches;
 			s->stats.graphReplayed = 1;
 		}
-		HIP_TRY(hipGraphLaunch(s->graphExec, s->stream));
+		if (key == s->graphKey && s->graphExec != nullptr)
+		{
+			HIP_TRY(hipGraphLaunch(s->graphExec, s->stream));
+		}
 	}
 	else
 	{

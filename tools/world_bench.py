@@ -10,6 +10,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -25,6 +27,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=60)
     ap.add_argument("--ref-steps", type=int, default=20)
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE")
+    ap.add_argument("--churn", action="store_true", help="make the contact graph change every step (one manifold is told to be empty before each step)")
     ap.add_argument("--no-pairs", action="store_true", help="skip the stage-1 pair query in the steps where the refit moved shapes")
     a = ap.parse_args()
     params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
@@ -38,10 +41,19 @@ def main():
         s.world_upload(*[world[k] for k in world_chain.WORLD_KEYS])
         found = queries = 0
         pair_s = 0.0
+        prep = []
+        k = len(world["contacts"]) - 1
+        churn_slot = np.array([k], dtype=np.int32)
+        churn_contact = world["contacts"][k:k + 1].copy()
+        churn_contact["pointCount"] = 0
+        churn_pair = world["pairs"][k:k + 1].copy()
 
         def step():
             nonlocal found, queries, pair_s
+            if a.churn:
+                s.world_set_contacts(churn_slot, churn_contact, churn_pair)
             info = s.world_step(params)
+            prep.append(s.stats()["hostPrepMs"])
             if info["movedCount"] > 0 and not a.no_pairs:
                 t = time.perf_counter()
                 found += len(s.world_find_pairs())  # stage 1 for the next step (a settled pyramid finds none)
@@ -55,7 +67,7 @@ def main():
         t0 = time.perf_counter()
         infos = [step() for _ in range(a.steps)]
         ms = 1e3 * (time.perf_counter() - t0) / a.steps
-        out.update({"pair_queries": queries, "new_pairs_found": found, "pair_query_ms": 1e3 * pair_s / max(queries, 1)})
+        out.update({"host_structure_ms": sum(prep[-a.steps:]) / a.steps, "pair_queries": queries, "new_pairs_found": found, "pair_query_ms": 1e3 * pair_s / max(queries, 1)})
         st = s.stats()
         out.update({
             "gpu_world_step_ms": ms,

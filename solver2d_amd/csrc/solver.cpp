@@ -511,6 +511,7 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	else if (strcmp(key, "message") == 0)
 	{
 		s->optMessage = value;
+		s->structureDirty = true; // the message tables are only built when the option is on
 	}
 	else if (strcmp(key, "body_warm") == 0)
 	{

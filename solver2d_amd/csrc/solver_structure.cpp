@@ -546,6 +546,17 @@ int buildStructure(s2amdSolver* s, int solverType)
 		return S2AMD_OK;
 	}
 	double t0 = nowMs();
+	// S2AMD_DEBUG_PREP=1: where the host time of a structure build goes
+	static const bool prepTimes = getenv("S2AMD_DEBUG_PREP") != nullptr;
+	double tPhase = t0;
+	auto phase = [&](const char* name) {
+		if (prepTimes)
+		{
+			double t = nowMs();
+			fprintf(stderr, "[s2amd] prep %-22s %.3f ms\n", name, t - tPhase);
+			tPhase = t;
+		}
+	};
 	const int nb = s->bodyCapacity;
 	std::vector<uint8_t> conflict((size_t)nb);
 	for (int i = 0; i < nb; ++i)
@@ -575,6 +586,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 	}
 	const int C = (int)ce.ids.size(), J = (int)je.ids.size();
 
+	phase("edge lists");
 	// ---- islands: connected components over the writable bodies ----
 	std::vector<int> cPart((size_t)C, -1), jPart((size_t)J, -1); // -1 = global part, else group id
 	int groupCount = 0;
@@ -678,6 +690,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 		}
 	}
 
+	phase("islands and groups");
 	// ---- per part lists (pool order is preserved inside every part) ----
 	std::vector<std::vector<int>> cOf((size_t)groupCount + 1), jOf((size_t)groupCount + 1); // index 0 = global, g + 1 = group g
 	for (int k = 0; k < C; ++k)
@@ -939,6 +952,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 		}
 	}
 
+	phase("colours, batches");
 	// ---- device tables ----
 	int rc;
 	if ((rc = carveContacts(s, C)) != 0 || (rc = carveJoints(s, J)) != 0)
@@ -984,6 +998,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 		return rc;
 	}
 
+	phase("index tables");
 	// ---- lean strip tables: per-group descriptors + warm-start slots (strip_kernel.hip) ----
 	s->leanAValid = s->leanBValid = false;
 	s->persistValid = false;
@@ -1399,9 +1414,10 @@ int buildStructure(s2amdSolver* s, int solverType)
 		return buildStructure(s, solverType);
 	}
 
+	phase("strip tables");
 	// ---- message-passing tables of the global part (see MsgBodies) ----
 	s->msgTablesValid = false;
-	if (cs.globalCount > 0 && js.globalCount == 0 && !cs.hasTail && !needAdj)
+	if (s->optMessage != 0 && cs.globalCount > 0 && js.globalCount == 0 && !cs.hasTail && !needAdj) // 0.25 ms of host time at 60k constraints
 	{
 		const int G = cs.globalCount;
 		std::vector<int> offsets((size_t)nb + 1, 0), list((size_t)2 * G), next((size_t)2 * G, 0), first((size_t)nb, -1);
@@ -1474,6 +1490,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 		s->msgTablesValid = true;
 	}
 
+	phase("message tables");
 	s->adjValid = false;
 	{
 		// body -> incident constraints in SWEEP order (ascending k), key = k<<1 | side, so the per-body
@@ -1531,6 +1548,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 	// the staging vectors above die with this scope: hipMemcpyAsync from pageable host memory
 	// copies through a staging buffer before it returns, so that is safe
 	HIP_TRY(hipStreamSynchronize(s->stream));
+	phase("adjacency + sync");
 
 	s->orderSolverClass = cls;
 	s->orderGrouped = grouped;

@@ -161,6 +161,32 @@ int colorGraph(const std::vector<int>& ea, const std::vector<int>& eb, const std
 			population[(size_t)c] -= 1;
 			population[(size_t)best] += 1;
 		}
+		// what the repair could not place: a colour class is an independent set and so is any part of it, so a class
+		// that is still wider than one workgroup is cut into classes of at most `cap` (more rounds, same validity)
+		const int before = colorCount;
+		std::vector<int> kept((size_t)before, 0);
+		std::vector<int> spill((size_t)before, -1); // the colour currently receiving class c's overflow
+		std::vector<int> spillCount((size_t)before, 0);
+		for (size_t k = 0; k < n; ++k)
+		{
+			int c = color[k];
+			if (c >= before || population[(size_t)c] <= cap)
+			{
+				continue;
+			}
+			if (kept[(size_t)c] < cap)
+			{
+				kept[(size_t)c] += 1;
+				continue;
+			}
+			if (spill[(size_t)c] < 0 || spillCount[(size_t)c] == cap)
+			{
+				spill[(size_t)c] = colorCount++;
+				spillCount[(size_t)c] = 0;
+			}
+			color[k] = spill[(size_t)c];
+			spillCount[(size_t)c] += 1;
+		}
 	}
 	return colorCount;
 }

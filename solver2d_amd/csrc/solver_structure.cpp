@@ -1157,6 +1157,16 @@ int buildStructure(s2amdSolver* s, int solverType)
 			const HostGroupTable& B = s->hStripB;
 			const int K = A.count();
 			bool ok = true;
+			const char* why = "";
+#define NEED(cond)                                                                                                                \
+	do                                                                                                                           \
+	{                                                                                                                            \
+		if (ok && !(cond))                                                                                                       \
+		{                                                                                                                        \
+			ok = false;                                                                                                          \
+			why = #cond;                                                                                                         \
+		}                                                                                                                        \
+	} while (0)
 			std::vector<int> ownerGroup((size_t)nb, -1), ownerSlot((size_t)nb, -1);
 			for (int gi = 0; gi < K; ++gi)
 			{
@@ -1171,7 +1181,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 				}
 				for (int bb = A.cBatchOffsets[(size_t)gi]; bb < A.cBatchOffsets[(size_t)gi + 1]; ++bb)
 				{
-					ok = ok && A.cBatches[(size_t)bb].y - A.cBatches[(size_t)bb].x <= 256; // one constraint per thread and round
+					NEED(A.cBatches[(size_t)bb].y - A.cBatches[(size_t)bb].x <= 256); // one constraint per thread and round
 				}
 			}
 			// seams: bodies on either side, in the order of the seam group's body list
@@ -1204,10 +1214,10 @@ int buildStructure(s2amdSolver* s, int solverType)
 					}
 					else
 					{
-						ok = false;
+						NEED(false);
 					}
 				}
-				ok = ok && leftBodies[(size_t)sm].size() <= 256 && rightBodies[(size_t)sm].size() <= 256;
+				NEED(leftBodies[(size_t)sm].size() <= 256 && rightBodies[(size_t)sm].size() <= 256);
 			}
 			// granule buffers: per seam {toLeft: 4 per right body, toRight: 4 per left body}, two parities
 			std::vector<int> seamBase((size_t)std::max(S, 0), 0);
@@ -1282,16 +1292,16 @@ int buildStructure(s2amdSolver* s, int solverType)
 						}
 						else
 						{
-							ok = false;
+							NEED(false);
 						}
 					}
 					int b0 = B.cBatchOffsets[(size_t)g], b1 = B.cBatchOffsets[(size_t)g + 1];
 					d.seamBatchCount[side] = b1 - b0;
-					ok = ok && b1 - b0 <= S2_PERSIST_B_ROUNDS;
+					NEED(b1 - b0 <= S2_PERSIST_B_ROUNDS);
 					for (int bb = b0; bb < b1 && ok; ++bb)
 					{
 						int4 bt = B.cBatches[(size_t)bb];
-						ok = bt.z == 0;
+						NEED(bt.z == 0);
 						d.seamBatch[side][bb - b0] = make_int2(bt.x, bt.y);
 						seamSlots += bt.y - bt.x;
 					}
@@ -1306,14 +1316,14 @@ int buildStructure(s2amdSolver* s, int solverType)
 				const int nt = importOffset;
 				// bodies, seam constraints (8 records each for TGS_Soft, 10 for the other kinds)
 				int fixedRecords = 3 * nt + (nt + 3) / 4; // velocity, pose, integrator constants, angular damping
-				ok = ok && fixedRecords + 8 * seamSlots + 2 * 128 <= (160 * 1024) / 16 && nt < 16384;
+				NEED(fixedRecords + 8 * seamSlots + 2 * 128 <= (160 * 1024) / 16 && nt < 16384);
 				ldsRecords = std::max(ldsRecords, fixedRecords + 8 * seamSlots);
 				ldsRecordsWide = std::max(ldsRecordsWide, fixedRecords + 10 * seamSlots);
 			}
 			if (getenv("S2AMD_DEBUG"))
 			{
-				fprintf(stderr, "[s2amd] persistent step: %s (K=%d, lds records %d, granules/parity %d)\n", ok ? "eligible" : "NOT eligible", K, ldsRecords,
-						parityStride);
+				fprintf(stderr, "[s2amd] persistent step: %s (K=%d, lds records %d, granules/parity %d)%s%s\n", ok ? "eligible" : "NOT eligible", K, ldsRecords,
+						parityStride, ok ? "" : " -- failed: ", why);
 				int histA[16] = {0}, histB[16] = {0};
 				for (int i = 0; i < K; ++i)
 				{

@@ -1316,7 +1316,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 				const int nt = importOffset;
 				// bodies, seam constraints (8 records each for TGS_Soft, 10 for the other kinds)
 				int fixedRecords = 3 * nt + (nt + 3) / 4; // velocity, pose, integrator constants, angular damping
-				NEED(fixedRecords + 8 * seamSlots + 2 * 128 <= (160 * 1024) / 16 && nt < 16384);
+				NEED(fixedRecords + 8 * seamSlots + 2 * 16 <= (160 * 1024) / 16 && nt < 16384); // the plan's own records are checked when it is known (persistPlan)
 				ldsRecords = std::max(ldsRecords, fixedRecords + 8 * seamSlots);
 				ldsRecordsWide = std::max(ldsRecordsWide, fixedRecords + 10 * seamSlots);
 			}

@@ -204,6 +204,7 @@ struct s2amdSolver
 	uint64_t persistOpsGeneration = ~0ull, persistOpsStructure = ~0ull;
 	size_t granuleBytes = 0;
 	int optPersist = 1;
+	int optStripRetry = 1; // try other strip widths when the partition needs the 8-round kernel variant
 	int optPersistDebug = 0;
 	int optPersistSpinLimit = 1 << 21;
 	bool persistFailed = false; // a hand-off timed out once (workgroups not co-resident: a shared GPU): multi-launch strips from then on
@@ -238,7 +239,7 @@ struct s2amdSolver
 	int optMaxGroupBodies = 2048;
 	int optPackGroupBodies = 1024;
 	int optStrips = 1;		   // cut islands that do not fit one LDS group into strips of BFS levels (2 launches per sweep)
-	int optStripBodies = 320;  // target bodies per strip
+	int optStripBodies = 160;  // target bodies per strip (base-200: 67-95 strips run at 0.250 ms, 54 strips at 0.262 ms)
 	int optStripMinBodies = 4096; // loose bodies below which the colour-batch path is kept
 
 	// graph cache

@@ -532,7 +532,7 @@ void partitionStrips(const EdgeList& ce, const EdgeList& je, const std::vector<i
 
 } // namespace
 
-int buildStructure(s2amdSolver* s, int solverType)
+static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 {
 	const int cls = isPositionSolver(solverType) ? 1 : 0;
 	const bool needAdj = solverType == s2amd_solverJacobi;
@@ -748,7 +748,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 		}
 		if (looseCount >= s->optStripMinBodies)
 		{
-			partitionStrips(ce, je, cOf[0], jOf[0], conflict, loose, nb, s->optStripBodies, s->optMaxGroupBodies, strips);
+			partitionStrips(ce, je, cOf[0], jOf[0], conflict, loose, nb, std::max(8, (int)((float)s->optStripBodies * stripScale)), s->optMaxGroupBodies, strips);
 		}
 		if (strips.active)
 		{
@@ -1421,7 +1421,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 	{
 		s->stripsRejected = true;
 		s->structureDirty = true;
-		return buildStructure(s, solverType);
+		return buildStructureWith(s, solverType, stripScale);
 	}
 
 	phase("strip tables");
@@ -1567,4 +1567,40 @@ int buildStructure(s2amdSolver* s, int solverType)
 	s->structureGeneration += 1;
 	s->stats.hostPrepMs = (float)(nowMs() - t0);
 	return S2AMD_OK;
+}
+
+// The strip partition is a heuristic cut (BFS levels, `strip_bodies` per strip) and the colouring of what it cuts out
+// decides which persistent kernel variant can run: one strip that needs a seventh or eighth interior colour puts every
+// workgroup on the 8-round variant, which spills (0.30 vs 0.26 ms at base-200).  A build that ends there is repeated
+// with a few other strip widths; the first partition that needs six rounds wins, else the original one stays.  This
+// runs only in the (rare) steps that build the strip structure at all.
+int buildStructure(s2amdSolver* s, int solverType)
+{
+	const uint64_t before = s->structureGeneration;
+	int rc = buildStructureWith(s, solverType, 1.0f);
+	if (rc != S2AMD_OK || s->structureGeneration == before || s->optStripRetry == 0)
+	{
+		return rc;
+	}
+	if (!(s->persistValid && s->persist.wideRounds))
+	{
+		return rc;
+	}
+	const float scales[] = {0.85f, 1.15f, 0.7f, 1.3f, 0.6f};
+	for (float scale : scales)
+	{
+		s->structureDirty = true;
+		s->stripsRejected = false; // a width that fits no strip kernel says nothing about the next one
+		if ((rc = buildStructureWith(s, solverType, scale)) != S2AMD_OK)
+		{
+			return rc;
+		}
+		if (s->persistValid && !s->persist.wideRounds)
+		{
+			return rc;
+		}
+	}
+	s->structureDirty = true;
+	s->stripsRejected = false;
+	return buildStructureWith(s, solverType, 1.0f);
 }

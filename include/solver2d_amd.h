@@ -356,7 +356,7 @@ int s2amd_measure_dominant(s2amdSolver* solver, const s2amdStepParams* params, i
 /* option keys: "graph" (0/1 hipGraph replay), "profile" (0/1 per-sweep HIP events),
  * "groups" (0/1 LDS group path for small islands), "message" (0/1 message-passing sweeps), "max_group_bodies", "pack_group_bodies",
  * "strips" (0/1 cut islands that fit no LDS group into strips of BFS levels: two launches per sweep), "strip_bodies" (target
- * bodies per strip), "strip_min_bodies" (loose bodies below which the colour-batch path is kept), "strip_patience" (steps the constraint graph must
+ * bodies per strip, default 160), "strip_retry" (0/1 rebuild the partition with other strip widths when one strip needs the 8-round kernel variant), "strip_min_bodies" (loose bodies below which the colour-batch path is kept), "strip_patience" (steps the constraint graph must
  * stay unchanged before the strip structure is built: its host build costs ~3 ms at 60k constraints, the colour-batch one ~1 ms), "async" (0/1, see s2amd_synchronize), "strip_lean" (0/1 dedicated strip
  * kernel for the soft sweeps), "persist" (0/1 whole step of the strips in one persistent launch), "body_warm" */
 int s2amd_set_option(s2amdSolver* solver, const char* key, int32_t value);

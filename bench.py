@@ -121,7 +121,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    # test hooks (tests/test_bench_dist.py): run the N > 1 logic on a box with ONE GPU over gloo
+    # test hooks (tests/test_gpu_bench.py): run the N > 1 logic on a box with ONE GPU over gloo
     backend = os.environ.get("S2AMD_BENCH_BACKEND", "nccl")
     device_index = 0 if os.environ.get("S2AMD_BENCH_SINGLE_DEVICE") == "1" else local_rank
     if world > 1:

@@ -162,12 +162,36 @@ __global__ __launch_bounds__(S2_BLOCK) void jacobiApplyKernel(BodyView b, Contac
 	int begin = adjOffsets[i], end = adjOffsets[i + 1];
 	V2 dv = v2(0.0f, 0.0f);
 	float dw = 0.0f;
-	for (int e = begin; e < end; ++e)
+	// The additions are sequential by contract; the loads are not: a body with hundreds of constraints (the drum of
+	// the Tumbler scene touches 230 boxes) would otherwise pay one memory round trip per constraint, 40 us per launch.
+	// CHUNK loads are in flight at once, then added in list order.
+	constexpr int CHUNK = 16;
+	for (int e = begin; e < end; e += CHUNK)
 	{
-		int key = adjList[e];
-		float4 d = (key & 1) ? c.deltaB[key >> 1] : c.deltaA[key >> 1];
-		dv = add(dv, v2(d.x, d.y));
-		dw += d.z;
+		int key[CHUNK];
+		float4 d[CHUNK];
+#pragma unroll
+		for (int u = 0; u < CHUNK; ++u)
+		{
+			key[u] = e + u < end ? adjList[e + u] : -1;
+		}
+#pragma unroll
+		for (int u = 0; u < CHUNK; ++u)
+		{
+			if (key[u] >= 0)
+			{
+				d[u] = (key[u] & 1) ? c.deltaB[key[u] >> 1] : c.deltaA[key[u] >> 1];
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < CHUNK; ++u)
+		{
+			if (key[u] >= 0)
+			{
+				dv = add(dv, v2(d[u].x, d[u].y));
+				dw += d[u].z;
+			}
+		}
 	}
 	float4 v = b.vel[i];
 	V2 lv = add(v2(v.x, v.y), dv);

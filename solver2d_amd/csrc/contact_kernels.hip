@@ -376,34 +376,70 @@ __global__ __launch_bounds__(S2_BLOCK) void warmStartBodiesKernel(ContactView c,
 		float4 d = b.dq[i];
 		q.s = d.z, q.c = d.w;
 	}
-	for (int e = e0; e < e1; ++e)
+	// the terms are added in list order; the records of CHUNK list entries are loaded together (a body with hundreds of
+	// constraints -- the Tumbler's drum -- would otherwise pay three dependent memory round trips per entry)
+	constexpr int CHUNK = 4;
+	for (int e = e0; e < e1; e += CHUNK)
 	{
-		int key = adjList[e];
-		int k = key >> 1;
-		bool sideB = (key & 1) != 0;
-		float4 nf = c.nf[k];
-		float4 ms = c.mass[k];
-		V2 normal = v2(nf.x, nf.y);
-		V2 tangent = KIND == WARM_BLOCK ? crossVS(normal, 1.0f) : rightPerp(normal);
-		int pointCount = KIND == WARM_BLOCK ? (int)asBits(c.blockK[k].w) : (int)(asBits(nf.w) & 0xffu);
-		float m = sideB ? ms.z : ms.x;
-		float iv = sideB ? ms.w : ms.y;
-		for (int j = 0; j < pointCount; ++j)
+		int key[CHUNK];
+		float4 nf[CHUNK], ms[CHUNK], arm[CHUNK][2];
+		float2 imp[CHUNK][2];
+		int blockCount[CHUNK];
+#pragma unroll
+		for (int u = 0; u < CHUNK; ++u)
 		{
-			float4 arm = KIND == WARM_CURRENT ? c.anchor[j][k] : c.r0[j][k];
-			float2 imp = c.impulse[j][k];
-			V2 l = sideB ? v2(arm.z, arm.w) : v2(arm.x, arm.y);
-			V2 r = KIND == WARM_CURRENT ? rotate(q, l) : l;
-			V2 P = add(mulSV(imp.x, normal), mulSV(imp.y, tangent));
-			if (sideB)
+			key[u] = e + u < e1 ? adjList[e + u] : -1;
+		}
+#pragma unroll
+		for (int u = 0; u < CHUNK; ++u)
+		{
+			if (key[u] >= 0)
 			{
-				w += iv * cross(r, P);
-				v = mulAdd(v, m, P);
+				const int k = key[u] >> 1;
+				nf[u] = c.nf[k];
+				ms[u] = c.mass[k];
+				// slot 1 of a one-point constraint is a valid zero record (prepareContactsKernel): no guard
+#pragma unroll
+				for (int j = 0; j < 2; ++j)
+				{
+					arm[u][j] = KIND == WARM_CURRENT ? c.anchor[j][k] : c.r0[j][k];
+					imp[u][j] = c.impulse[j][k];
+				}
+				blockCount[u] = KIND == WARM_BLOCK ? (int)asBits(c.blockK[k].w) : 0;
 			}
-			else
+		}
+#pragma unroll
+		for (int u = 0; u < CHUNK; ++u)
+		{
+			if (key[u] < 0)
 			{
-				w -= iv * cross(r, P);
-				v = mulAdd(v, -m, P);
+				continue;
+			}
+			const bool sideB = (key[u] & 1) != 0;
+			V2 normal = v2(nf[u].x, nf[u].y);
+			V2 tangent = KIND == WARM_BLOCK ? crossVS(normal, 1.0f) : rightPerp(normal);
+			int pointCount = KIND == WARM_BLOCK ? blockCount[u] : (int)(asBits(nf[u].w) & 0xffu);
+			float m = sideB ? ms[u].z : ms[u].x;
+			float iv = sideB ? ms[u].w : ms[u].y;
+#pragma unroll
+			for (int j = 0; j < 2; ++j)
+			{
+				if (j < pointCount)
+				{
+					V2 l = sideB ? v2(arm[u][j].z, arm[u][j].w) : v2(arm[u][j].x, arm[u][j].y);
+					V2 r = KIND == WARM_CURRENT ? rotate(q, l) : l;
+					V2 P = add(mulSV(imp[u][j].x, normal), mulSV(imp[u][j].y, tangent));
+					if (sideB)
+					{
+						w += iv * cross(r, P);
+						v = mulAdd(v, m, P);
+					}
+					else
+					{
+						w -= iv * cross(r, P);
+						v = mulAdd(v, -m, P);
+					}
+				}
 			}
 		}
 	}

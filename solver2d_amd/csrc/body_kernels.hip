@@ -148,8 +148,76 @@ __global__ __launch_bounds__(S2_BLOCK) void gatherMessageSlotsKernel(BodyView b,
 // order and applies the sum afterwards (solve_jacobi.c:126-130, :233-245).  Here each body walks
 // its incidence list (ascending constraint index) and performs the same additions in the same
 // order -- no atomics, deterministic, bit-identical to the sequential reference.
-__global__ __launch_bounds__(S2_BLOCK) void jacobiApplyKernel(BodyView b, ContactView c, const int* adjOffsets, const int* adjList)
+S2_DEV float laneValue(float v, int lane)
 {
+	return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+__global__ __launch_bounds__(S2_BLOCK) void jacobiApplyKernel(BodyView b, ContactView c, const int* adjOffsets, const int* adjList, int bodyBlocks,
+															   const int* heavy, int heavyCount)
+{
+	if ((int)blockIdx.x >= bodyBlocks)
+	{
+		// ---- heavy bodies: one wave each.  64 list entries are loaded at once, one per lane; the additions stay
+		// sequential in list order, every lane performing the same ones on values broadcast from lane u. ----
+		const int lane = (int)threadIdx.x & 63;
+		const int h = ((int)blockIdx.x - bodyBlocks) * (S2_BLOCK / 64) + ((int)threadIdx.x >> 6);
+		if (h >= heavyCount)
+		{
+			return;
+		}
+		const int i = heavy[h];
+		const int begin = adjOffsets[i], end = adjOffsets[i + 1];
+		V2 dv = v2(0.0f, 0.0f);
+		float dw = 0.0f;
+		constexpr int WIDE = 4; // 4 x 64 list entries are loaded before the first addition: two memory round trips per 256 entries
+		for (int base = begin; base < end; base += 64 * WIDE)
+		{
+			int key[WIDE];
+			float4 d[WIDE];
+#pragma unroll
+			for (int g = 0; g < WIDE; ++g)
+			{
+				const int e = base + 64 * g + lane;
+				key[g] = adjList[e < end ? e : begin];
+			}
+#pragma unroll
+			for (int g = 0; g < WIDE; ++g)
+			{
+				d[g] = (key[g] & 1) ? c.deltaB[key[g] >> 1] : c.deltaA[key[g] >> 1];
+			}
+#pragma unroll
+			for (int g = 0; g < WIDE; ++g)
+			{
+				const int left = __builtin_amdgcn_readfirstlane(end - (base + 64 * g)); // wave-uniform: a scalar loop, unrolled
+				const int n = left < 64 ? left : 64;
+				int u = 0;
+				for (; u + 8 <= n; u += 8)
+				{
+#pragma unroll
+					for (int t = 0; t < 8; ++t)
+					{
+						dv = add(dv, v2(laneValue(d[g].x, u + t), laneValue(d[g].y, u + t)));
+						dw += laneValue(d[g].z, u + t);
+					}
+				}
+				for (; u < n; ++u)
+				{
+					dv = add(dv, v2(laneValue(d[g].x, u), laneValue(d[g].y, u)));
+					dw += laneValue(d[g].z, u);
+				}
+			}
+		}
+		if (lane == 0)
+		{
+			float4 v = b.vel[i];
+			V2 lv = add(v2(v.x, v.y), dv);
+			float w = v.z;
+			w += dw;
+			b.vel[i] = make_float4(lv.x, lv.y, w, 0.0f);
+		}
+		return;
+	}
 	int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= b.capacity)
 	{
@@ -160,38 +228,18 @@ __global__ __launch_bounds__(S2_BLOCK) void jacobiApplyKernel(BodyView b, Contac
 		return;
 	}
 	int begin = adjOffsets[i], end = adjOffsets[i + 1];
+	if (end - begin > S2_HEAVY_DEGREE)
+	{
+		return; // a wave of the heavy blocks walks this one
+	}
 	V2 dv = v2(0.0f, 0.0f);
 	float dw = 0.0f;
-	// The additions are sequential by contract; the loads are not: a body with hundreds of constraints (the drum of
-	// the Tumbler scene touches 230 boxes) would otherwise pay one memory round trip per constraint, 40 us per launch.
-	// CHUNK loads are in flight at once, then added in list order.
-	constexpr int CHUNK = 16;
-	for (int e = begin; e < end; e += CHUNK)
+	for (int e = begin; e < end; ++e)
 	{
-		int key[CHUNK];
-		float4 d[CHUNK];
-#pragma unroll
-		for (int u = 0; u < CHUNK; ++u)
-		{
-			key[u] = e + u < end ? adjList[e + u] : -1;
-		}
-#pragma unroll
-		for (int u = 0; u < CHUNK; ++u)
-		{
-			if (key[u] >= 0)
-			{
-				d[u] = (key[u] & 1) ? c.deltaB[key[u] >> 1] : c.deltaA[key[u] >> 1];
-			}
-		}
-#pragma unroll
-		for (int u = 0; u < CHUNK; ++u)
-		{
-			if (key[u] >= 0)
-			{
-				dv = add(dv, v2(d[u].x, d[u].y));
-				dw += d[u].z;
-			}
-		}
+		int key = adjList[e];
+		float4 d = (key & 1) ? c.deltaB[key >> 1] : c.deltaA[key >> 1];
+		dv = add(dv, v2(d.x, d.y));
+		dw += d.z;
 	}
 	float4 v = b.vel[i];
 	V2 lv = add(v2(v.x, v.y), dv);
@@ -255,11 +303,12 @@ void launchFinalizePositions(hipStream_t s, const BodyView& b, int dynamicOnly)
 		finalizePositionsKernel<<<gridFor(b.capacity), dim3(S2_BLOCK), 0, s>>>(b, dynamicOnly);
 	}
 }
-void launchJacobiApply(hipStream_t s, const BodyView& b, const ContactView& c, const int* adjOffsets, const int* adjList)
+void launchJacobiApply(hipStream_t s, const BodyView& b, const ContactView& c, const int* adjOffsets, const int* adjList, const int* heavy, int heavyCount)
 {
 	if (b.capacity > 0)
 	{
-		jacobiApplyKernel<<<gridFor(b.capacity), dim3(S2_BLOCK), 0, s>>>(b, c, adjOffsets, adjList);
+		const int bodyBlocks = (b.capacity + S2_BLOCK - 1) / S2_BLOCK, heavyBlocks = (heavyCount + S2_BLOCK / 64 - 1) / (S2_BLOCK / 64);
+		jacobiApplyKernel<<<dim3((unsigned)(bodyBlocks + heavyBlocks)), dim3(S2_BLOCK), 0, s>>>(b, c, adjOffsets, adjList, bodyBlocks, heavy, heavyCount);
 	}
 }
 void launchXpbdIntegrate(hipStream_t s, const BodyView& b, float h)

@@ -348,21 +348,122 @@ __global__ __launch_bounds__(S2_BLOCK) void storeImpulsesKernel(ContactView c, s
 // performs exactly those additions in exactly that order: bit-identical to the coloured sweep, but
 // ONE launch instead of one per colour, with no write conflicts at all.  Optionally preceded by
 // s2IntegrateVelocities for the same body (the two stages are adjacent in every sub-stepping driver).
+S2_DEV float laneValue(float v, int lane)
+{
+	return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
 template <int KIND>
 __global__ __launch_bounds__(S2_BLOCK) void warmStartBodiesKernel(ContactView c, BodyView b, const int* adjOffsets, const int* adjList,
-																   int integrateFirst)
+																   int integrateFirst, int bodyBlocks, const int* heavy, int heavyCount)
 {
+	GlobalBodies gb{b.vel, b.dq};
+	if ((int)blockIdx.x >= bodyBlocks)
+	{
+		// ---- heavy bodies (more than S2_HEAVY_DEGREE incident constraints: a drum, a platform): one wave each.  Every
+		// lane loads ONE list entry and computes that entry's terms -- they depend on the stored impulses and on the
+		// body's own rotation only --, then the additions run in list order on values broadcast from lane u, exactly
+		// the additions of the one-thread walk below:  w +- iv*cross(r,P)  ==  w + (+-t),   v + (+-m)*P  ==  v + prod. ----
+		const int lane = (int)threadIdx.x & 63;
+		const int h = ((int)blockIdx.x - bodyBlocks) * (S2_BLOCK / 64) + ((int)threadIdx.x >> 6);
+		if (h >= heavyCount)
+		{
+			return;
+		}
+		const int i = heavy[h];
+		if ((b.flags[i] & S2F_IN_GROUP) != 0)
+		{
+			return;
+		}
+		if (integrateFirst)
+		{
+			integrateVelocitiesOne(gb, i, b, i); // every lane: the same loads, the same result, the same store; each lane reads back its own
+		}
+		const int e0 = adjOffsets[i], e1 = adjOffsets[i + 1];
+		float4 v4 = b.vel[i];
+		V2 v = v2(v4.x, v4.y);
+		float w = v4.z;
+		Rot q;
+		q.s = 0.0f, q.c = 1.0f;
+		if (KIND == WARM_CURRENT)
+		{
+			float4 d = b.dq[i];
+			q.s = d.z, q.c = d.w;
+		}
+		for (int base = e0; base < e1; base += 64)
+		{
+			const int e = base + lane < e1 ? base + lane : e0;
+			const int key = adjList[e];
+			const int k = key >> 1;
+			const bool sideB = (key & 1) != 0;
+			const float4 nf = c.nf[k];
+			const float4 ms = c.mass[k];
+			V2 normal = v2(nf.x, nf.y);
+			V2 tangent = KIND == WARM_BLOCK ? crossVS(normal, 1.0f) : rightPerp(normal);
+			int pointCount = KIND == WARM_BLOCK ? (int)asBits(c.blockK[k].w) : (int)(asBits(nf.w) & 0xffu);
+			const float m = sideB ? ms.z : ms.x;
+			const float iv = sideB ? ms.w : ms.y;
+			float tw[2], px[2], py[2];
+#pragma unroll
+			for (int j = 0; j < 2; ++j)
+			{
+				float4 arm = KIND == WARM_CURRENT ? c.anchor[j][k] : c.r0[j][k];
+				float2 imp = c.impulse[j][k];
+				V2 l = sideB ? v2(arm.z, arm.w) : v2(arm.x, arm.y);
+				V2 r = KIND == WARM_CURRENT ? rotate(q, l) : l;
+				V2 P = add(mulSV(imp.x, normal), mulSV(imp.y, tangent));
+				float t = iv * cross(r, P);
+				tw[j] = sideB ? t : -t;
+				V2 prod = mulSV(sideB ? m : -m, P);
+				px[j] = prod.x, py[j] = prod.y;
+			}
+			const int left = __builtin_amdgcn_readfirstlane(e1 - base); // wave-uniform: a scalar loop, unrolled
+			const int n = left < 64 ? left : 64;
+			auto addEntry = [&](int u) {
+				const int pc = __builtin_amdgcn_readlane(pointCount, u);
+#pragma unroll
+				for (int j = 0; j < 2; ++j)
+				{
+					const float wn = w + laneValue(tw[j], u);
+					const V2 vn = add(v, v2(laneValue(px[j], u), laneValue(py[j], u)));
+					w = j < pc ? wn : w;
+					v = j < pc ? vn : v;
+				}
+			};
+			int u = 0;
+			for (; u + 4 <= n; u += 4)
+			{
+#pragma unroll
+				for (int t = 0; t < 4; ++t)
+				{
+					addEntry(u + t);
+				}
+			}
+			for (; u < n; ++u)
+			{
+				addEntry(u);
+			}
+		}
+		if (lane == 0 && e0 != e1)
+		{
+			b.vel[i] = make_float4(v.x, v.y, w, 0.0f);
+		}
+		return;
+	}
 	int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= b.capacity || (b.flags[i] & S2F_IN_GROUP) != 0)
 	{
 		return;
 	}
-	GlobalBodies gb{b.vel, b.dq};
+	int e0 = adjOffsets[i], e1 = adjOffsets[i + 1];
+	if (e1 - e0 > S2_HEAVY_DEGREE)
+	{
+		return; // a wave of the heavy blocks walks this one (and integrates it first)
+	}
 	if (integrateFirst)
 	{
 		integrateVelocitiesOne(gb, i, b, i);
 	}
-	int e0 = adjOffsets[i], e1 = adjOffsets[i + 1];
 	if (e0 == e1)
 	{
 		return;
@@ -376,70 +477,34 @@ __global__ __launch_bounds__(S2_BLOCK) void warmStartBodiesKernel(ContactView c,
 		float4 d = b.dq[i];
 		q.s = d.z, q.c = d.w;
 	}
-	// the terms are added in list order; the records of CHUNK list entries are loaded together (a body with hundreds of
-	// constraints -- the Tumbler's drum -- would otherwise pay three dependent memory round trips per entry)
-	constexpr int CHUNK = 4;
-	for (int e = e0; e < e1; e += CHUNK)
+	for (int e = e0; e < e1; ++e)
 	{
-		int key[CHUNK];
-		float4 nf[CHUNK], ms[CHUNK], arm[CHUNK][2];
-		float2 imp[CHUNK][2];
-		int blockCount[CHUNK];
-#pragma unroll
-		for (int u = 0; u < CHUNK; ++u)
+		int key = adjList[e];
+		int k = key >> 1;
+		bool sideB = (key & 1) != 0;
+		float4 nf = c.nf[k];
+		float4 ms = c.mass[k];
+		V2 normal = v2(nf.x, nf.y);
+		V2 tangent = KIND == WARM_BLOCK ? crossVS(normal, 1.0f) : rightPerp(normal);
+		int pointCount = KIND == WARM_BLOCK ? (int)asBits(c.blockK[k].w) : (int)(asBits(nf.w) & 0xffu);
+		float m = sideB ? ms.z : ms.x;
+		float iv = sideB ? ms.w : ms.y;
+		for (int j = 0; j < pointCount; ++j)
 		{
-			key[u] = e + u < e1 ? adjList[e + u] : -1;
-		}
-#pragma unroll
-		for (int u = 0; u < CHUNK; ++u)
-		{
-			if (key[u] >= 0)
+			float4 arm = KIND == WARM_CURRENT ? c.anchor[j][k] : c.r0[j][k];
+			float2 imp = c.impulse[j][k];
+			V2 l = sideB ? v2(arm.z, arm.w) : v2(arm.x, arm.y);
+			V2 r = KIND == WARM_CURRENT ? rotate(q, l) : l;
+			V2 P = add(mulSV(imp.x, normal), mulSV(imp.y, tangent));
+			if (sideB)
 			{
-				const int k = key[u] >> 1;
-				nf[u] = c.nf[k];
-				ms[u] = c.mass[k];
-				// slot 1 of a one-point constraint is a valid zero record (prepareContactsKernel): no guard
-#pragma unroll
-				for (int j = 0; j < 2; ++j)
-				{
-					arm[u][j] = KIND == WARM_CURRENT ? c.anchor[j][k] : c.r0[j][k];
-					imp[u][j] = c.impulse[j][k];
-				}
-				blockCount[u] = KIND == WARM_BLOCK ? (int)asBits(c.blockK[k].w) : 0;
+				w += iv * cross(r, P);
+				v = mulAdd(v, m, P);
 			}
-		}
-#pragma unroll
-		for (int u = 0; u < CHUNK; ++u)
-		{
-			if (key[u] < 0)
+			else
 			{
-				continue;
-			}
-			const bool sideB = (key[u] & 1) != 0;
-			V2 normal = v2(nf[u].x, nf[u].y);
-			V2 tangent = KIND == WARM_BLOCK ? crossVS(normal, 1.0f) : rightPerp(normal);
-			int pointCount = KIND == WARM_BLOCK ? blockCount[u] : (int)(asBits(nf[u].w) & 0xffu);
-			float m = sideB ? ms[u].z : ms[u].x;
-			float iv = sideB ? ms[u].w : ms[u].y;
-#pragma unroll
-			for (int j = 0; j < 2; ++j)
-			{
-				if (j < pointCount)
-				{
-					V2 l = sideB ? v2(arm[u][j].z, arm[u][j].w) : v2(arm[u][j].x, arm[u][j].y);
-					V2 r = KIND == WARM_CURRENT ? rotate(q, l) : l;
-					V2 P = add(mulSV(imp[u][j].x, normal), mulSV(imp[u][j].y, tangent));
-					if (sideB)
-					{
-						w += iv * cross(r, P);
-						v = mulAdd(v, m, P);
-					}
-					else
-					{
-						w -= iv * cross(r, P);
-						v = mulAdd(v, -m, P);
-					}
-				}
+				w -= iv * cross(r, P);
+				v = mulAdd(v, -m, P);
 			}
 		}
 	}
@@ -753,23 +818,24 @@ void launchSolveContactsStickyMsg(hipStream_t s, const ContactView& c, const Msg
 }
 
 void launchWarmStartBodies(hipStream_t s, int kind, const ContactView& c, const BodyView& b, const int* adjOffsets, const int* adjList,
-						   int integrateFirst)
+						   int integrateFirst, const int* heavy, int heavyCount)
 {
 	if (b.capacity <= 0)
 	{
 		return;
 	}
-	dim3 g = gridFor(b.capacity), t(S2_BLOCK);
+	const int bodyBlocks = (b.capacity + S2_BLOCK - 1) / S2_BLOCK, heavyBlocks = (heavyCount + S2_BLOCK / 64 - 1) / (S2_BLOCK / 64);
+	dim3 g((unsigned)(bodyBlocks + heavyBlocks)), t(S2_BLOCK);
 	switch (kind)
 	{
 		case WARM_CURRENT:
-			warmStartBodiesKernel<WARM_CURRENT><<<g, t, 0, s>>>(c, b, adjOffsets, adjList, integrateFirst);
+			warmStartBodiesKernel<WARM_CURRENT><<<g, t, 0, s>>>(c, b, adjOffsets, adjList, integrateFirst, bodyBlocks, heavy, heavyCount);
 			break;
 		case WARM_FIXED:
-			warmStartBodiesKernel<WARM_FIXED><<<g, t, 0, s>>>(c, b, adjOffsets, adjList, integrateFirst);
+			warmStartBodiesKernel<WARM_FIXED><<<g, t, 0, s>>>(c, b, adjOffsets, adjList, integrateFirst, bodyBlocks, heavy, heavyCount);
 			break;
 		case WARM_BLOCK:
-			warmStartBodiesKernel<WARM_BLOCK><<<g, t, 0, s>>>(c, b, adjOffsets, adjList, integrateFirst);
+			warmStartBodiesKernel<WARM_BLOCK><<<g, t, 0, s>>>(c, b, adjOffsets, adjList, integrateFirst, bodyBlocks, heavy, heavyCount);
 			break;
 	}
 }

@@ -98,7 +98,7 @@ void launchPackBodies(hipStream_t s, const BodyView& b, s2amdBody* wire);
 void launchIntegrateVelocities(hipStream_t s, const BodyView& b);
 void launchIntegratePositions(hipStream_t s, const BodyView& b, float h);
 void launchFinalizePositions(hipStream_t s, const BodyView& b, int dynamicOnly);
-void launchJacobiApply(hipStream_t s, const BodyView& b, const ContactView& c, const int* adjOffsets, const int* adjList);
+void launchJacobiApply(hipStream_t s, const BodyView& b, const ContactView& c, const int* adjOffsets, const int* adjList, const int* heavy, int heavyCount);
 void launchXpbdIntegrate(hipStream_t s, const BodyView& b, float h);
 void launchXpbdProject(hipStream_t s, const BodyView& b, float inv_h);
 void launchExportPoses(hipStream_t s, const s2amdBody* wire, int n, void* out);
@@ -130,8 +130,9 @@ void launchFinalizePositionsMsg(hipStream_t s, const BodyView& b, const MsgView&
 void launchGatherMessageSlots(hipStream_t s, const BodyView& b, const MsgView& m);
 
 // body-centric warm start (one launch for all colours, optionally fused with integrate velocities)
+// heavy: the bodies with more than S2_HEAVY_DEGREE list entries (a whole wave walks each of them)
 void launchWarmStartBodies(hipStream_t s, int kind, const ContactView& c, const BodyView& b, const int* adjOffsets, const int* adjList,
-						   int integrateFirst);
+						   int integrateFirst, const int* heavy, int heavyCount);
 
 // strip_kernel.hip
 int stripKernelSetup();

@@ -379,6 +379,10 @@ struct JointView
 #define S2J_WRITE_A 0x100u
 #define S2J_WRITE_B 0x200u
 
+// body-centric kernels (jacobiApplyKernel, warmStartBodiesKernel): a body with more incident constraints than this is
+// walked by a whole wave instead of one thread (the host lists those bodies beside the adjacency)
+#define S2_HEAVY_DEGREE 12
+
 struct StepConsts
 {
 	float dt, inv_dt, h, inv_h;

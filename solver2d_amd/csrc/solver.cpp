@@ -141,7 +141,7 @@ void s2amd_destroy(s2amdSolver* s)
 	}
 	DevBuf* bufs[] = {&s->dBodies,		&s->dContacts,	  &s->dJoints,		 &s->dBodiesSaved,	 &s->dBodyFlags,	&s->soaBodies,
 					  &s->soaContacts,	&s->soaJoints,	  &s->dContactIndex, &s->dJointIndex,	 &s->dContactLocal, &s->dJointLocal,
-					  &s->dAdjOffsets,	&s->dAdjList,	  &s->dGatherIndex,	 &s->dOps,			 &s->dGroups.buf,	&s->dContactTail.buf,
+					  &s->dAdjOffsets,	&s->dAdjList,	  &s->dAdjHeavy,	  &s->dGatherIndex,	 &s->dOps,			 &s->dGroups.buf,	&s->dContactTail.buf,
 					  &s->dJointTail.buf, &s->dMsg,			  &s->dStripA.buf,	 &s->dStripB.buf,	 &s->dStripLean,	&s->dPersist,
 					  &s->dGranules,	&s->dPersistOps,	  &s->dShapes,		 &s->dPairs,		 &s->dOrigins,		&s->dStatus,
 					  &s->dPointBytes,	&s->dWorldSummary, &s->dJointedKeys,	 &s->dContactStage, &s->dPairScratch};

@@ -177,7 +177,8 @@ struct s2amdSolver
 	DevBuf dBodyFlags;
 
 	// working SoA
-	DevBuf soaBodies, soaContacts, soaJoints, dContactIndex, dJointIndex, dContactLocal, dJointLocal, dAdjOffsets, dAdjList, dOps;
+	DevBuf soaBodies, soaContacts, soaJoints, dContactIndex, dJointIndex, dContactLocal, dJointLocal, dAdjOffsets, dAdjList, dAdjHeavy, dOps;
+	int adjHeavyCount = 0; // bodies with more than S2_HEAVY_DEGREE adjacency entries
 	BodyView bv{};
 	ContactView cv{};
 	JointView jv{};

@@ -1548,6 +1548,27 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 		{
 			s->layoutGeneration += 1;
 		}
+		std::vector<int> heavy;
+		for (int i = 0; i < nb; ++i)
+		{
+			if (offsets[(size_t)i + 1] - offsets[(size_t)i] > S2_HEAVY_DEGREE)
+			{
+				heavy.push_back(i);
+			}
+		}
+		if ((rc = s->dAdjHeavy.ensure(std::max<size_t>(heavy.size(), 64) * sizeof(int), &grew)) != 0)
+		{
+			return rc;
+		}
+		if (grew)
+		{
+			s->layoutGeneration += 1;
+		}
+		s->adjHeavyCount = (int)heavy.size();
+		if (!heavy.empty())
+		{
+			HIP_TRY(hipMemcpyAsync(s->dAdjHeavy.p, heavy.data(), heavy.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+		}
 		HIP_TRY(hipMemcpyAsync(s->dAdjOffsets.p, offsets.data(), ((size_t)nb + 1) * sizeof(int), hipMemcpyHostToDevice, s->stream));
 		if (!list.empty())
 		{

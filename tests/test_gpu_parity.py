@@ -181,6 +181,19 @@ def test_joint_grid_pgs_ngs(solver):
     assert solver.stats()["jointCount"] == 2 * 20 * 19
 
 
+@pytest.mark.parametrize("solver_name", ["Jacobi", "TGS_Soft", "SoftStep", "PGS_NGS_Block", "PGS"])
+def test_body_with_hundreds_of_constraints(solver, solver_name):
+    """A platform carrying 300 boxes: its incidence list spans several 64-entry chunks of the wave that walks it in the
+    body-centric kernels (jacobiApplyKernel: more than one 256-entry round; warmStartBodiesKernel in all three kinds).
+    Second step: non-zero impulses to warm start from."""
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    pre = synthetic.platform(300, layers=8)
+    params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+    state = gpu_vs_oracle(solver, params, common.copy3(pre), "platform300/%s step 0" % solver_name)
+    gpu_vs_oracle(solver, params, state, "platform300/%s step 1" % solver_name)
+    assert solver.stats()["groupCount"] == 0
+
+
 @pytest.mark.parametrize("solver_name", wire.SOLVER_NAMES)
 def test_high_degree_body_uses_sequential_tail(solver, solver_name):
     """One dynamic platform touching 60 boxes: 60+ colours; the high colours run as one sequential

@@ -152,18 +152,44 @@ def main():
     if world > 1:
         import torch
         nb = len(pre[0])
-        pose = torch.zeros((nb, 4), dtype=torch.float32, device="cuda")
+        # two pose buffers: the all-gather of step s reads one while step s+1 exports into the other
+        pose = [torch.zeros((nb, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
         gdev = "cuda" if backend == "nccl" else "cpu"
         gathered = torch.zeros((world * nb, 4), dtype=torch.float32, device=gdev)
+        gather_done = [None, None]
 
-    def one_step():
+    def enqueue(step):
+        """restore + s2Solve + pose export of `step` on the solver's stream; nothing here waits for the device
+        except for the collective that last read this step's pose buffer (two steps ago)."""
         gpu.restore_bodies()
         gpu.step_resident(params)
         if world > 1:
-            # the previous step's all-gather (torch's stream) must be done reading `pose` before it is rewritten
-            torch.cuda.current_stream().synchronize()
-            gpu.export_poses(pose.data_ptr(), pose.shape[0])
-            dist.all_gather_into_tensor(gathered, pose if backend == "nccl" else pose.cpu())
+            b = step & 1
+            if gather_done[b] is not None:
+                gather_done[b].synchronize()
+            gpu.export_poses_async(pose[b].data_ptr(), nb, b)
+
+    def exchange(step):
+        """per-step exchange of the per-island body poses (RCCL all-gather), once this step's export has landed"""
+        b = step & 1
+        gpu.export_wait(b)
+        dist.all_gather_into_tensor(gathered, pose[b] if backend == "nccl" else pose[b].cpu())
+        if backend == "nccl":
+            gather_done[b] = torch.cuda.Event()
+            gather_done[b].record()
+
+    def run(count):
+        """`count` steps; with more than one rank the host enqueues step s+1 BEFORE it waits for the poses of step s, so
+        the device goes from one solve straight into the next while the collective of the previous step is in flight."""
+        if world == 1:
+            for s_ in range(count):
+                enqueue(s_)
+            return
+        enqueue(0)
+        for s_ in range(count):
+            if s_ + 1 < count:
+                enqueue(s_ + 1)
+            exchange(s_)
 
     def sync():
         gpu.synchronize()
@@ -172,12 +198,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
+    run(args.warmup)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
+    run(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
     gpu.set_option("async", 0)

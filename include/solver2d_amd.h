@@ -335,6 +335,11 @@ int s2amd_color_constraints(s2amdSolver* solver, const s2amdBody* bodies, int32_
  * a DEVICE buffer owned by the caller (e.g. the send buffer of an RCCL all-gather of per-island
  * body arrays).  Returns after the copy has completed on the solver's stream. */
 int s2amd_export_poses(s2amdSolver* solver, void* devicePoses, int32_t capacity);
+/* The same copy, enqueued behind the steps already enqueued on the solver's stream (see "async") and followed by an event
+ * in `slot` (0..3); s2amd_export_wait blocks the host until that event has fired.  Lets a host enqueue step s+1 before it
+ * waits for the poses of step s and hands them to the collective: the device never idles between steps. */
+int s2amd_export_poses_async(s2amdSolver* solver, void* devicePoses, int32_t capacity, int32_t slot);
+int s2amd_export_wait(s2amdSolver* solver, int32_t slot);
 
 /* ---- introspection (tests, bench) ---- */
 /* Execution order of the last step: order[k] = contact-array index of the k-th constraint in

@@ -170,6 +170,13 @@ void s2amd_destroy(s2amdSolver* s)
 	}
 	(void)hipEventDestroy(s->evBegin);
 	(void)hipEventDestroy(s->evEnd);
+	for (hipEvent_t e : s->evExport)
+	{
+		if (e)
+		{
+			(void)hipEventDestroy(e);
+		}
+	}
 	for (int i = 0; i < 2; ++i)
 	{
 		if (s->evFork[i])
@@ -380,6 +387,38 @@ int s2amd_export_poses(s2amdSolver* s, void* devicePoses, int32_t capacity)
 	launchExportPoses(s->stream, (const s2amdBody*)s->dBodies.p, s->bodyCapacity, devicePoses);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(s->stream));
+	return S2AMD_OK;
+}
+
+int s2amd_export_poses_async(s2amdSolver* s, void* devicePoses, int32_t capacity, int32_t slot)
+{
+	if (!s || !s->resident)
+	{
+		return fail(S2AMD_E_STATE, "nothing resident");
+	}
+	if (!devicePoses || capacity < s->bodyCapacity || slot < 0 || slot >= 4)
+	{
+		return fail(S2AMD_E_CAPACITY, "pose buffer missing or too small, or slot outside 0..3");
+	}
+	HIP_TRY(hipSetDevice(s->device));
+	if (!s->evExport[slot])
+	{
+		HIP_TRY(hipEventCreateWithFlags(&s->evExport[slot], hipEventDisableTiming));
+	}
+	launchExportPoses(s->stream, (const s2amdBody*)s->dBodies.p, s->bodyCapacity, devicePoses);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(s->evExport[slot], s->stream));
+	return S2AMD_OK;
+}
+
+int s2amd_export_wait(s2amdSolver* s, int32_t slot)
+{
+	if (!s || slot < 0 || slot >= 4 || !s->evExport[slot])
+	{
+		return fail(S2AMD_E_STATE, "no export recorded in this slot");
+	}
+	HIP_TRY(hipSetDevice(s->device));
+	HIP_TRY(hipEventSynchronize(s->evExport[slot]));
 	return S2AMD_OK;
 }
 

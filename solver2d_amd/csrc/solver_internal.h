@@ -149,6 +149,7 @@ struct s2amdSolver
 	int device = 0;
 	hipStream_t stream = nullptr;
 	hipEvent_t evBegin = nullptr, evEnd = nullptr;
+	hipEvent_t evExport[4] = {nullptr, nullptr, nullptr, nullptr}; // s2amd_export_poses_async / s2amd_export_wait
 	// side streams: independent prologue / epilogue kernels become parallel branches of the captured graph
 	hipStream_t side[2] = {nullptr, nullptr};
 	hipEvent_t evFork[2] = {nullptr, nullptr}, evJoin[4] = {nullptr, nullptr, nullptr, nullptr};

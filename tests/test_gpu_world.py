@@ -214,5 +214,5 @@ def test_resident_pair_query_equals_the_stage_function(path):
                 moved = ((ref["shapes"]["enlarged"] != 0) & (ref["shapes"]["type"] != wire.SHAPE_FREE)).astype(np.uint8)
                 want = oraclebind.find_pairs(ref["bodies"], ref["shapes"], moved, _live_pairs(ref), ref["joints"])
                 assert np.array_equal(s.world_find_pairs(), want), "step %d" % step
-    if "pyramid" not in path:
+    if "pyramid" not in path and "joint_grid" not in path:
         assert asked > 0

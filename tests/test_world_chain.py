@@ -15,7 +15,7 @@ FILES = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__))
 
 
 def test_fixtures_present():
-    assert len(FILES) >= 5
+    assert len(FILES) >= 7
 
 
 @pytest.mark.parametrize("path", FILES, ids=[os.path.basename(p)[6:-4] for p in FILES])
@@ -29,5 +29,5 @@ def test_oracle_chain_equals_reference(path):
         status = world_chain.oracle_world_step(params, world)
         separated += int((status == wire.PAIR_SEPARATED).sum())
     world_chain.assert_worlds_equal(world, want, os.path.basename(path))
-    if "pyramid" not in path:
+    if "pyramid" not in path and "joint_grid" not in path:
         assert separated > 0, "the window was chosen to contain a separation"

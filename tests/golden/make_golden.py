@@ -79,7 +79,10 @@ def main():
     # of s2amd_world_step).  Separations inside the window are part of the chain.
     for scene, p0, solver, start, k in (("pyramid", 8, "TGS_Soft", 30, 3), ("mixed", 24, "PGS", 101, 3), ("shapes_zoo", 40, "TGS_Sticky", 154, 3),
                                         ("circle_pile", 20, "XPBD", 81, 3), ("mixed", 24, "Jacobi", 104, 3),
-                                        ("shapes_zoo", 40, "PGS_NGS_Block", 202, 3), ("joint_grid", 6, "TGS_NGS", 5, 3)):
+                                        ("shapes_zoo", 40, "PGS_NGS_Block", 202, 3), ("joint_grid", 6, "TGS_NGS", 5, 3),
+                                        # k = 0: an input only (the tumbler never goes three steps without creating a contact); the GPU
+                                        # test runs the whole loop on it, pair creation included, against the oracle chain
+                                        ("tumbler", 60, "TGS_Soft", 100, 0)):
         vel, pos = common.DEFAULT_ITERS[solver]
         path = os.path.join(OUT, "world_%s%d_%s_step%03d_k%d.npz" % (scene, p0, solver, start, k))
         if os.environ.get("S2_GOLDEN_ONLY_MISSING") and os.path.exists(path):

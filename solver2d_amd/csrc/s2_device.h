@@ -475,7 +475,9 @@ struct StripTableView
 // Persistent strip step (strip_kernel.hip: stripStepKernel): workgroup i owns strip i for the whole step and
 // sweeps BOTH of its seams (i-1 | i and i | i+1); the two workgroups of a seam compute it redundantly from
 // identical inputs, so one symmetric exchange of seam bodies per sweep (after the interior rounds) suffices.
-#define S2_PERSIST_B_ROUNDS 4 // colour batches of a seam
+#define S2_PERSIST_B_ROUNDS 4
+#define S2_PERSIST_Q_NARROW 6 // LDS records per seam constraint: TGS_Soft with current-anchor warm start (strip_kernel.hip: PersistRegs)
+#define S2_PERSIST_Q_WIDE 8   // ... every other kind // colour batches of a seam
 struct PersistDesc
 {
 	int importCount[2];	  // [0] from the left neighbour (its bodies that seam i-1 touches), [1] from the right
@@ -500,6 +502,7 @@ struct PersistView
 	unsigned int* deviceError; // the same flag in device memory: what the step's epilogue launch checks
 	int parityStride; // granules between the two parities of a buffer
 	int allTwoPoints; // every strip constraint has two manifold points
+	float4 softCoef[2]; // the step's two soft-coefficient triples (StepConsts.softCoef), set at launch
 	int wideRounds;	  // some strip has 7 or 8 interior colour batches: the ROUNDS == 8 kernel variant
 	int ldsRecords;
 	int debugSkip; // timing experiments only (results are wrong): 1 = no hand-offs, 2 = no seam rounds, 4 = no interior rounds;

@@ -427,6 +427,10 @@ struct Executor
 			recordEvent();
 		}
 		PersistView pv = s->persist;
+		for (int i = 0; i < 2; ++i)
+		{
+			pv.softCoef[i] = make_float4(p.sc.softCoef[i][0], p.sc.softCoef[i][1], p.sc.softCoef[i][2], 0.0f);
+		}
 		if (!(kind == SOFT_TGS && warm == WARM_CURRENT))
 		{
 			pv.ldsRecords = s->persistRecordsWide;

@@ -1040,6 +1040,7 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 		std::vector<int> slotOffsets;
 		int maxRounds = 0;
 		bool persistTablesOk = false;
+		const char* leanWhy = "";
 		auto describe = [&](const HostGroupTable& t, std::vector<StripDesc>& out, bool withSlots, int& ldsRecords) {
 			bool ok = true;
 			ldsRecords = 0;
@@ -1052,11 +1053,19 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 				int b0 = t.cBatchOffsets[(size_t)g], b1 = t.cBatchOffsets[(size_t)g + 1];
 				d.batchCount = b1 - b0;
 				ok = d.batchCount <= (withSlots ? S2_STRIP_ROUNDS_MAX : S2_STRIP_ROUNDS) && d.bodyCount <= S2_STRIP_BODY_CHUNKS * 256;
+				if (!ok)
+				{
+					leanWhy = d.bodyCount > S2_STRIP_BODY_CHUNKS * 256 ? "more than 1024 bodies in a strip or seam" : (withSlots ? "more than 8 interior colours" : "more than 6 seam colours");
+				}
 				maxRounds = std::max(maxRounds, d.batchCount);
 				for (int b = b0; b < b1 && ok; ++b)
 				{
 					int4 bt = t.cBatches[(size_t)b];
 					ok = bt.z == 0;
+					if (!ok)
+					{
+						leanWhy = "a sequential tail batch";
+					}
 					d.batch[b - b0] = make_int4(bt.x, bt.y, 0, 0);
 				}
 				while (d.ownedCount < d.bodyCount && ((uint32_t)t.bodyIds[(size_t)d.bodyBase + d.ownedCount] & S2G_OWNED) != 0)
@@ -1081,6 +1090,10 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 					d.slotCount = (int)slotList.size() - d.slotBase;
 				}
 				int records = 2 * d.bodyCount + 2 * d.slotCount;
+				if (ok && records > (160 * 1024) / 16)
+				{
+					leanWhy = "LDS: bodies + warm-start slots";
+				}
 				ok = ok && records <= (160 * 1024) / 16;
 				ldsRecords = std::max(ldsRecords, records);
 				out.push_back(d);
@@ -1145,8 +1158,8 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 
 		if (getenv("S2AMD_DEBUG"))
 		{
-			fprintf(stderr, "[s2amd] strips: %d strips, %d seams, lean A %d B %d, strip joints %d, CUs %d\n", s->hStripA.count(), s->hStripB.count(),
-					(int)s->leanAValid, (int)s->leanBValid, js.stripCount, s->cuCount);
+			fprintf(stderr, "[s2amd] strips: %d strips, %d seams, lean A %d B %d, strip joints %d, CUs %d%s%s\n", s->hStripA.count(), s->hStripB.count(),
+					(int)s->leanAValid, (int)s->leanBValid, js.stripCount, s->cuCount, leanWhy[0] ? " -- lean tables: " : "", leanWhy);
 		}
 		// ---- persistent strip step (strip_kernel.hip: stripStepKernel): per workgroup both seams' remaps, the
 		// import / export lists of the symmetric exchange, warm-start term slots, granule buffers ----
@@ -1314,11 +1327,11 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 					ok = n0 + n1 <= 512; // both seams share a round: at most two constraints per thread
 				}
 				const int nt = importOffset;
-				// bodies, seam constraints (8 records each for TGS_Soft, 10 for the other kinds)
-				int fixedRecords = 3 * nt + (nt + 3) / 4; // velocity, pose, integrator constants, angular damping
-				NEED(fixedRecords + 8 * seamSlots + 2 * 16 <= (160 * 1024) / 16 && nt < 16384); // the plan's own records are checked when it is known (persistPlan)
-				ldsRecords = std::max(ldsRecords, fixedRecords + 8 * seamSlots);
-				ldsRecordsWide = std::max(ldsRecordsWide, fixedRecords + 10 * seamSlots);
+				// bodies, seam constraints (S2_PERSIST_Q_NARROW records each for TGS_Soft, S2_PERSIST_Q_WIDE for the other kinds)
+				int fixedRecords = 3 * nt + (nt + 3) / 4 + (nt + 1) / 2; // velocity, pose, integrator constants, angular damping, inverse masses
+				NEED(fixedRecords + S2_PERSIST_Q_NARROW * seamSlots + 2 * 16 <= (160 * 1024) / 16 && nt < 16384); // the plan's own records are checked when it is known (persistPlan)
+				ldsRecords = std::max(ldsRecords, fixedRecords + S2_PERSIST_Q_NARROW * seamSlots);
+				ldsRecordsWide = std::max(ldsRecordsWide, fixedRecords + S2_PERSIST_Q_WIDE * seamSlots);
 			}
 			if (getenv("S2AMD_DEBUG"))
 			{
@@ -1603,11 +1616,23 @@ int buildStructure(s2amdSolver* s, int solverType)
 	{
 		return rc;
 	}
-	if (!(s->persistValid && s->persist.wideRounds))
+	// outcome of a build that tried strips: 2 = persistent step on the 6-round variant, 1 = some strip kernel can run it,
+	// 0 = rejected (no strip kernel takes this partition: colour batches)
+	auto outcome = [&]() {
+		if (s->persistValid && !s->persist.wideRounds)
+		{
+			return 2;
+		}
+		return (s->persistValid || (s->leanAValid && s->leanBValid)) ? 1 : 0;
+	};
+	const bool triedStrips = s->stripsRejected || s->dStripA.view.groupCount > 0;
+	if (!triedStrips || outcome() == 2)
 	{
 		return rc;
 	}
-	const float scales[] = {0.85f, 1.15f, 0.7f, 1.3f, 0.6f};
+	float bestScale = 1.0f;
+	int best = outcome();
+	const float scales[] = {0.85f, 1.15f, 0.7f, 1.3f, 0.6f, 1.6f, 2.0f};
 	for (float scale : scales)
 	{
 		s->structureDirty = true;
@@ -1616,12 +1641,17 @@ int buildStructure(s2amdSolver* s, int solverType)
 		{
 			return rc;
 		}
-		if (s->persistValid && !s->persist.wideRounds)
+		const int o = outcome();
+		if (o == 2)
 		{
 			return rc;
+		}
+		if (o > best)
+		{
+			best = o, bestScale = scale;
 		}
 	}
 	s->structureDirty = true;
 	s->stripsRejected = false;
-	return buildStructureWith(s, solverType, 1.0f);
+	return buildStructureWith(s, solverType, bestScale);
 }

@@ -344,9 +344,10 @@ template <int WARM, int KIND, class BA> S2_DEV void warmSoftRegs(const SoftRegs<
 	}
 }
 
-// A constraint as the persistent kernel keeps it for the whole step: only what the sweeps of this solver
-// read, 29 registers for TGS_Soft.  The soft coefficients are the same for both points (contact_kernels.hip
-// prepareContactsKernel<PREP_SOFT>; solve_common.c:262-271), so one copy is kept.
+// A constraint as the persistent kernel keeps it for the whole step: only what the sweeps of this solver read and what is
+// not the same for many constraints -- 22 registers for TGS_Soft.  Not kept: the inverse masses (they sit once per body
+// in LDS beside the body records) and the three soft coefficients (contact_kernels.hip prepareContactsKernel<PREP_SOFT>;
+// solve_common.c:219, 262-271: one of two step-wide triples, chosen by whether a side is static; PersistView.softCoef).
 struct ImpulsePart
 {
 	float2 imp[2]; // first: one 16-byte record of the LDS copy (the only part a sweep changes)
@@ -358,25 +359,42 @@ template <int TAG, bool ON> struct ArmsPart
 template <int TAG> struct ArmsPart<TAG, false>
 {
 };
+template <bool ON> struct SeparationPart
+{
+	float p3[2]; // par.w (the prepare-time separation) is read by the PGS_Soft sweep only
+};
+template <> struct SeparationPart<false>
+{
+};
 template <int KIND, int WARM>
 struct PersistRegs : ImpulsePart,
 					 ArmsPart<0, KIND == SOFT_TGS || KIND == SOFT_FIXED || WARM == WARM_CURRENT>, // local anchors
-					 ArmsPart<1, KIND != SOFT_TGS || WARM == WARM_FIXED>						  // prepare-time arms rA0 / rB0
+					 ArmsPart<1, KIND != SOFT_TGS || WARM == WARM_FIXED>,						  // prepare-time arms rA0 / rB0
+					 SeparationPart<KIND == SOFT_PGS>
 {
 	static constexpr bool kAnchors = KIND == SOFT_TGS || KIND == SOFT_FIXED || WARM == WARM_CURRENT;
 	static constexpr bool kArms0 = KIND != SOFT_TGS || WARM == WARM_FIXED;
-	uint32_t idx;	 // ia | ib << 14 | pointCount << 28 | writeA << 30 | writeB << 31
-	float mA, iA, mB, iB, nx, ny, friction;
+	uint32_t idx; // ia | ib << 14 | pointCount << 28 | writeA << 30 | writeB << 31
+	float nx, ny, friction;
 	float p0[2], p1[2], p2[2];
-	float p3[KIND == SOFT_PGS ? 2 : 1]; // par.w (the prepare-time separation) is read by the PGS_Soft sweep only
-	float s0, s1, s2;
+};
+static_assert(sizeof(PersistRegs<SOFT_TGS, WARM_CURRENT>) <= 96, "6 LDS records per seam constraint (solver_structure.cpp: S2_PERSIST_Q_NARROW)");
+static_assert(sizeof(PersistRegs<SOFT_PGS, WARM_CURRENT>) <= 128 && sizeof(PersistRegs<SOFT_FIXED, WARM_FIXED>) <= 128 &&
+				  sizeof(PersistRegs<SOFT_TGS, WARM_FIXED>) <= 128 && sizeof(PersistRegs<SOFT_PGS, WARM_FIXED>) <= 128 &&
+				  sizeof(PersistRegs<SOFT_FIXED, WARM_CURRENT>) <= 128,
+			  "8 LDS records per seam constraint for every other kind (S2_PERSIST_Q_WIDE)");
+
+// the per-body inverse masses and the two coefficient triples a resident constraint is completed from
+struct PersistShared
+{
+	const float2* massInv; // LDS, one per staged body
+	float4 softCoef[2];	   // [0] dynamic-dynamic, [1] one side static
 };
 
 template <int KIND, int WARM> S2_DEV PersistRegs<KIND, WARM> packPersist(const SoftRegs<KIND>& r, int ia, int ib)
 {
 	PersistRegs<KIND, WARM> p;
 	p.idx = (uint32_t)ia | ((uint32_t)ib << 14) | ((uint32_t)r.h.pointCount << 28) | (r.h.writeA ? 1u << 30 : 0u) | (r.h.writeB ? 1u << 31 : 0u);
-	p.mA = r.h.mA, p.iA = r.h.iA, p.mB = r.h.mB, p.iB = r.h.iB;
 	p.nx = r.h.normal.x, p.ny = r.h.normal.y, p.friction = r.h.friction;
 #pragma unroll
 	for (int j = 0; j < 2; ++j)
@@ -390,17 +408,16 @@ template <int KIND, int WARM> S2_DEV PersistRegs<KIND, WARM> packPersist(const S
 			static_cast<ArmsPart<1, true>&>(p).v[j] = r.r0[j];
 		}
 		p.p0[j] = r.par[j].x, p.p1[j] = r.par[j].y, p.p2[j] = r.par[j].z;
-		if (KIND == SOFT_PGS)
+		if constexpr (KIND == SOFT_PGS)
 		{
-			p.p3[KIND == SOFT_PGS ? j : 0] = r.par[j].w;
+			static_cast<SeparationPart<true>&>(p).p3[j] = r.par[j].w;
 		}
 		p.imp[j] = r.imp[j];
 	}
-	p.s0 = r.sf[0].x, p.s1 = r.sf[0].y, p.s2 = r.sf[0].z;
 	return p;
 }
 
-template <int KIND, int WARM> S2_DEV SoftRegs<KIND> unpackPersist(const PersistRegs<KIND, WARM>& p, uint32_t salt = 0u)
+template <int KIND, int WARM> S2_DEV SoftRegs<KIND> unpackPersist(const PersistRegs<KIND, WARM>& p, const PersistShared& sh, uint32_t salt = 0u)
 {
 	SoftRegs<KIND> r;
 	// `salt` is an opaque zero produced inside the step loop: without it the compiler hoists the decoding of every
@@ -409,7 +426,9 @@ template <int KIND, int WARM> S2_DEV SoftRegs<KIND> unpackPersist(const PersistR
 	r.h.ia = (int)(idx & 0x3fffu), r.h.ib = (int)((idx >> 14) & 0x3fffu);
 	r.h.pointCount = (int)((idx >> 28) & 3u);
 	r.h.writeA = (idx & (1u << 30)) != 0, r.h.writeB = (idx & (1u << 31)) != 0;
-	r.h.mA = p.mA, r.h.iA = p.iA, r.h.mB = p.mB, r.h.iB = p.iB;
+	const float2 massA = sh.massInv[r.h.ia], massB = sh.massInv[r.h.ib];
+	r.h.mA = massA.x, r.h.iA = massA.y, r.h.mB = massB.x, r.h.iB = massB.y;
+	const float4 coef = (massA.x == 0.0f || massB.x == 0.0f) ? sh.softCoef[1] : sh.softCoef[0];
 	// the same for the values whose negations the sweep uses (tangent = (ny, -nx), -normalMass, -tangentMass)
 	r.h.normal = v2(fromBits(asBits(p.nx) ^ salt), p.ny), r.h.friction = p.friction;
 #pragma unroll
@@ -423,8 +442,13 @@ template <int KIND, int WARM> S2_DEV SoftRegs<KIND> unpackPersist(const PersistR
 		{
 			r.r0[j] = static_cast<const ArmsPart<1, true>&>(p).v[j];
 		}
-		r.par[j] = make_float4(p.p0[j], fromBits(asBits(p.p1[j]) ^ salt), fromBits(asBits(p.p2[j]) ^ salt), KIND == SOFT_PGS ? p.p3[KIND == SOFT_PGS ? j : 0] : 0.0f);
-		r.sf[j] = make_float4(p.s0, p.s1, p.s2, 0.0f);
+		float separation = 0.0f;
+		if constexpr (KIND == SOFT_PGS)
+		{
+			separation = static_cast<const SeparationPart<true>&>(p).p3[j];
+		}
+		r.par[j] = make_float4(p.p0[j], fromBits(asBits(p.p1[j]) ^ salt), fromBits(asBits(p.p2[j]) ^ salt), separation);
+		r.sf[j] = coef;
 		r.imp[j] = p.imp[j];
 	}
 	return r;
@@ -432,9 +456,10 @@ template <int KIND, int WARM> S2_DEV SoftRegs<KIND> unpackPersist(const PersistR
 
 // one constraint of a sweep, from its resident registers: warm start or soft solve
 template <int KIND, int WARM, int POINTS, class BA>
-S2_DEV void sweepPersist(PersistRegs<KIND, WARM>& p, const ContactView& c, const BA& lb, float inv_h, int useBias, int k, uint32_t salt = 0u)
+S2_DEV void sweepPersist(PersistRegs<KIND, WARM>& p, const PersistShared& sh, const ContactView& c, const BA& lb, float inv_h, int useBias, int k,
+						 uint32_t salt = 0u)
 {
-	SoftRegs<KIND> r = unpackPersist<KIND, WARM>(p, salt);
+	SoftRegs<KIND> r = unpackPersist<KIND, WARM>(p, sh, salt);
 	solveSoftRegs<KIND, BA, false, POINTS>(r, c, lb, inv_h, useBias, k);
 	p.imp[0] = r.imp[0], p.imp[1] = r.imp[1];
 }
@@ -505,7 +530,8 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 	float4* ldq = lds + nt;
 	float4* linteg = lds + 2 * nt;				  // velocity-integrator constants of every staged body (body_ops.h)
 	float* langDamp = (float*)(lds + 3 * nt);	  // nt floats, padded to records
-	const int bodyRecords = 3 * nt + (nt + 3) / 4;
+	float2* lmass = (float2*)(lds + 3 * nt + (nt + 3) / 4); // {invMass, invI} of every staged body, padded to records
+	const int bodyRecords = 3 * nt + (nt + 3) / 4 + (nt + 1) / 2;
 	Op* lops = (Op*)(lds + bodyRecords);		  // 2 records per op
 	float4* lseam = lds + bodyRecords + 2 * opCount; // field-major: Q records per seam constraint
 
@@ -614,6 +640,7 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 			flags[ch] = g.flags[gi] | 0x80000000u; // bit 31: slot in use
 			linteg[ldsIdx[ch]] = g.integ[gi];
 			langDamp[ldsIdx[ch]] = g.angDamp[gi];
+			lmass[ldsIdx[ch]] = g.massInv[gi];
 		}
 	}
 	__syncthreads();
@@ -623,6 +650,9 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 	}
 
 	LdsBodies lb{lvel, ldq};
+	PersistShared shared;
+	shared.massInv = lmass;
+	shared.softCoef[0] = pv.softCoef[0], shared.softCoef[1] = pv.softCoef[1];
 	unsigned epoch = 0; // tags are the exchange number: the buffers are zero at launch (cleared by the previous step's epilogue)
 	int bad = 0;
 	for (int oi = 0; oi < opCount && !bad; ++oi)
@@ -700,7 +730,7 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 				{
 					if (kOfRound(i) >= 0)
 					{
-						warmSoftRegs<WARM>(unpackPersist<KIND, WARM>(rA[i], salt), lb);
+						warmSoftRegs<WARM>(unpackPersist<KIND, WARM>(rA[i], shared, salt), lb);
 					}
 					__syncthreads();
 				}
@@ -722,7 +752,7 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 						}
 						PersistRegs<KIND, WARM> pb;
 						__builtin_memcpy(&pb, q, sizeof(pb));
-						warmSoftRegs<WARM>(unpackPersist<KIND, WARM>(pb), lb);
+						warmSoftRegs<WARM>(unpackPersist<KIND, WARM>(pb, shared), lb);
 					}
 				}
 				__syncthreads();
@@ -738,7 +768,7 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 				{
 					if (kOfRound(i) >= 0)
 					{
-						sweepPersist<KIND, WARM, POINTS>(rA[i], c, lb, op.inv_h, op.useBias, kOfRound(i), salt);
+						sweepPersist<KIND, WARM, POINTS>(rA[i], shared, c, lb, op.inv_h, op.useBias, kOfRound(i), salt);
 					}
 					__syncthreads();
 				}
@@ -809,7 +839,7 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 						}
 						PersistRegs<KIND, WARM> pb;
 						__builtin_memcpy(&pb, q, sizeof(pb));
-						sweepPersist<KIND, WARM, POINTS>(pb, c, lb, op.inv_h, op.useBias, k);
+						sweepPersist<KIND, WARM, POINTS>(pb, shared, c, lb, op.inv_h, op.useBias, k);
 						// only the impulses changed: PersistRegs starts with them, record 0
 						__builtin_memcpy(&q[0], &pb.imp[0], 16);
 						lseam[slot] = q[0];
@@ -841,7 +871,7 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 	{
 		if (kOfRound(i) >= 0)
 		{
-			storeSoft<KIND>(c, unpackPersist<KIND, WARM>(rA[i]), kOfRound(i));
+			storeSoft<KIND>(c, unpackPersist<KIND, WARM>(rA[i], shared), kOfRound(i));
 		}
 	}
 	// the right seam's impulses are stored by this workgroup (its left neighbour of that seam), nobody stores twice
@@ -862,7 +892,7 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 				}
 				PersistRegs<KIND, WARM> pb;
 				__builtin_memcpy(&pb, q, sizeof(pb));
-				storeSoft<KIND>(c, unpackPersist<KIND, WARM>(pb), k);
+				storeSoft<KIND>(c, unpackPersist<KIND, WARM>(pb, shared), k);
 			}
 		}
 	}

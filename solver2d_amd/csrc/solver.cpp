@@ -593,6 +593,11 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 		s->optPersistDebug = value;
 		s->structureDirty = true;
 	}
+	else if (strcmp(key, "seam_regs") == 0)
+	{
+		s->optSeamRegs = value != 0;
+		s->structureDirty = true;
+	}
 	else if (strcmp(key, "strip_retry") == 0)
 	{
 		s->optStripRetry = value != 0;

@@ -206,6 +206,7 @@ struct s2amdSolver
 	uint64_t persistOpsGeneration = ~0ull, persistOpsStructure = ~0ull;
 	size_t granuleBytes = 0;
 	int optPersist = 1;
+	int optSeamRegs = 1;
 	int optStripRetry = 1; // try other strip widths when the partition needs the 8-round kernel variant
 	int optPersistDebug = 0;
 	int optPersistSpinLimit = 1 << 21;

@@ -1241,6 +1241,14 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 				granules += 4 * (int)(leftBodies[(size_t)sm].size() + rightBodies[(size_t)sm].size());
 			}
 			const int parityStride = granules;
+			// TGS_Soft keeps the seam constraints in registers when no seam has more than two colour batches and no interior
+			// more than six (strip_kernel.hip: SEAMREG): then they cost no LDS at all
+			bool seamRegs = s->optSeamRegs != 0 && maxRoundsA <= S2_STRIP_ROUNDS;
+			for (int sm = 0; sm < S && seamRegs; ++sm)
+			{
+				const int g = seamGroup[(size_t)sm];
+				seamRegs = g < 0 || B.cBatchOffsets[(size_t)g + 1] - B.cBatchOffsets[(size_t)g] <= 2;
+			}
 			std::vector<PersistDesc> descs((size_t)K);
 			std::vector<int> remap, exportSrc, importIds;
 			std::vector<int> replicaStamp((size_t)nb, -1), replicaSlot((size_t)nb, -1);
@@ -1329,8 +1337,9 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 				const int nt = importOffset;
 				// bodies, seam constraints (S2_PERSIST_Q_NARROW records each for TGS_Soft, S2_PERSIST_Q_WIDE for the other kinds)
 				int fixedRecords = 3 * nt + (nt + 3) / 4 + (nt + 1) / 2; // velocity, pose, integrator constants, angular damping, inverse masses
-				NEED(fixedRecords + S2_PERSIST_Q_NARROW * seamSlots + 2 * 16 <= (160 * 1024) / 16 && nt < 16384); // the plan's own records are checked when it is known (persistPlan)
-				ldsRecords = std::max(ldsRecords, fixedRecords + S2_PERSIST_Q_NARROW * seamSlots);
+				const int seamRecordsNarrow = seamRegs ? 0 : S2_PERSIST_Q_NARROW * seamSlots;
+				NEED(fixedRecords + seamRecordsNarrow + 2 * 16 <= (160 * 1024) / 16 && nt < 16384); // the plan's own records are checked when it is known (persistPlan)
+				ldsRecords = std::max(ldsRecords, fixedRecords + seamRecordsNarrow);
 				ldsRecordsWide = std::max(ldsRecordsWide, fixedRecords + S2_PERSIST_Q_WIDE * seamSlots);
 			}
 			if (getenv("S2AMD_DEBUG"))
@@ -1399,6 +1408,7 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 				// fresh buffers start from zero tags
 				HIP_TRY(hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, s->stream));
 				pv.wideRounds = maxRoundsA > S2_STRIP_ROUNDS ? 1 : 0;
+				pv.seamRegs = seamRegs ? 1 : 0;
 				s->persistK0 = k0, s->persistK1 = k1;
 				pv.allTwoPoints = stripsAllTwoPoints(s) ? 1 : 0;
 				pv.ldsRecords = ldsRecords;

@@ -485,7 +485,9 @@ template <int KIND, int WARM> S2_DEV SoftRegs<KIND> loadPersist(const ContactVie
 // POINTS == 2: the host has checked that every constraint of the strips has two manifold points (box stacks): the
 // sweeps then run without per-point exec masking; POINTS == 0: general.
 // ROUNDS: interior colour batches kept in registers (6, or 8 for strips whose colouring needs more).
-template <int KIND, int WARM, int POINTS, int ROUNDS>
+// SEAMREG: no seam has more than two colour batches, and the seam constraints (two rounds x two passes = four per
+// thread) stay in registers like the interior ones instead of in LDS records.
+template <int KIND, int WARM, int POINTS, int ROUNDS, int SEAMREG>
 __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView c, BodyView g, StripTableView ta, PersistView pv, const Op* ops, int opCount)
 {
 	extern __shared__ __attribute__((aligned(16))) float4 lds[];
@@ -592,8 +594,10 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 		}
 		return false;
 	};
+	constexpr int SEAM_REG_ROUNDS = 2;
+	PersistRegs<KIND, WARM> rB[SEAMREG ? 2 * SEAM_REG_ROUNDS : 1];
 #pragma unroll
-	for (int i = 0; i < S2_PERSIST_B_ROUNDS; ++i)
+	for (int i = 0; i < (SEAMREG ? SEAM_REG_ROUNDS : S2_PERSIST_B_ROUNDS); ++i)
 	{
 #pragma unroll
 		for (int pass = 0; pass < 2; ++pass)
@@ -603,12 +607,19 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 			{
 				SoftRegs<KIND> t = loadPersist<KIND, WARM>(c, k);
 				PersistRegs<KIND, WARM> pb = packPersist<KIND, WARM>(t, pv.remap[pd->remapBase[side] + t.h.ia], pv.remap[pd->remapBase[side] + t.h.ib]);
-				float4 q[Q];
-				__builtin_memcpy(q, &pb, sizeof(pb));
-#pragma unroll
-				for (int f = 0; f < Q; ++f)
+				if constexpr (SEAMREG)
 				{
-					lseam[f * seamSlots + slot] = q[f];
+					rB[2 * i + pass] = pb;
+				}
+				else
+				{
+					float4 q[Q];
+					__builtin_memcpy(q, &pb, sizeof(pb));
+#pragma unroll
+					for (int f = 0; f < Q; ++f)
+					{
+						lseam[f * seamSlots + slot] = q[f];
+					}
 				}
 			}
 		}
@@ -735,27 +746,50 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 					__syncthreads();
 				}
 			}
-#pragma unroll 1
-			for (int i = 0; i < roundsB; ++i)
+			if constexpr (SEAMREG)
 			{
 #pragma unroll
-				for (int pass = 0; pass < 2; ++pass)
+				for (int i = 0; i < SEAM_REG_ROUNDS; ++i)
 				{
-					int side, k, slot;
-					if (seamItem(i, pass, side, k, slot, salt))
+					if (i < roundsB)
 					{
-						float4 q[Q];
 #pragma unroll
-						for (int f = 0; f < Q; ++f)
+						for (int pass = 0; pass < 2; ++pass)
 						{
-							q[f] = lseam[f * seamSlots + slot];
+							int side, k, slot;
+							if (seamItem(i, pass, side, k, slot, salt))
+							{
+								warmSoftRegs<WARM>(unpackPersist<KIND, WARM>(rB[2 * i + pass], shared, salt), lb);
+							}
 						}
-						PersistRegs<KIND, WARM> pb;
-						__builtin_memcpy(&pb, q, sizeof(pb));
-						warmSoftRegs<WARM>(unpackPersist<KIND, WARM>(pb, shared), lb);
+						__syncthreads();
 					}
 				}
-				__syncthreads();
+			}
+			else
+			{
+#pragma unroll 1
+				for (int i = 0; i < roundsB; ++i)
+				{
+#pragma unroll
+					for (int pass = 0; pass < 2; ++pass)
+					{
+						int side, k, slot;
+						if (seamItem(i, pass, side, k, slot, salt))
+						{
+							float4 q[Q];
+#pragma unroll
+							for (int f = 0; f < Q; ++f)
+							{
+								q[f] = lseam[f * seamSlots + slot];
+							}
+							PersistRegs<KIND, WARM> pb;
+							__builtin_memcpy(&pb, q, sizeof(pb));
+							warmSoftRegs<WARM>(unpackPersist<KIND, WARM>(pb, shared), lb);
+						}
+					}
+					__syncthreads();
+				}
 			}
 		}
 		else if (op.code == OP_SOLVE_SOFT)
@@ -822,30 +856,53 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 				break;
 			}
 			// ---- both seams (the neighbours compute the same bits on their side) ----
-#pragma unroll 1
-			for (int i = 0; i < roundsB && (pv.debugSkip & 2) == 0; ++i)
+			if constexpr (SEAMREG)
 			{
 #pragma unroll
-				for (int pass = 0; pass < 2; ++pass)
+				for (int i = 0; i < SEAM_REG_ROUNDS; ++i)
 				{
-					int side, k, slot;
-					if (seamItem(i, pass, side, k, slot, salt))
+					if (i < roundsB && (pv.debugSkip & 2) == 0)
 					{
-						float4 q[Q];
 #pragma unroll
-						for (int f = 0; f < Q; ++f)
+						for (int pass = 0; pass < 2; ++pass)
 						{
-							q[f] = lseam[f * seamSlots + slot];
+							int side, k, slot;
+							if (seamItem(i, pass, side, k, slot, salt))
+							{
+								sweepPersist<KIND, WARM, POINTS>(rB[2 * i + pass], shared, c, lb, op.inv_h, op.useBias, k, salt);
+							}
 						}
-						PersistRegs<KIND, WARM> pb;
-						__builtin_memcpy(&pb, q, sizeof(pb));
-						sweepPersist<KIND, WARM, POINTS>(pb, shared, c, lb, op.inv_h, op.useBias, k);
-						// only the impulses changed: PersistRegs starts with them, record 0
-						__builtin_memcpy(&q[0], &pb.imp[0], 16);
-						lseam[slot] = q[0];
+						__syncthreads();
 					}
 				}
-				__syncthreads();
+			}
+			else
+			{
+#pragma unroll 1
+				for (int i = 0; i < roundsB && (pv.debugSkip & 2) == 0; ++i)
+				{
+#pragma unroll
+					for (int pass = 0; pass < 2; ++pass)
+					{
+						int side, k, slot;
+						if (seamItem(i, pass, side, k, slot, salt))
+						{
+							float4 q[Q];
+#pragma unroll
+							for (int f = 0; f < Q; ++f)
+							{
+								q[f] = lseam[f * seamSlots + slot];
+							}
+							PersistRegs<KIND, WARM> pb;
+							__builtin_memcpy(&pb, q, sizeof(pb));
+							sweepPersist<KIND, WARM, POINTS>(pb, shared, c, lb, op.inv_h, op.useBias, k);
+							// only the impulses changed: PersistRegs starts with them, record 0
+							__builtin_memcpy(&q[0], &pb.imp[0], 16);
+							lseam[slot] = q[0];
+						}
+					}
+					__syncthreads();
+				}
 			}
 		}
 		if (stamp)
@@ -875,6 +932,23 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 		}
 	}
 	// the right seam's impulses are stored by this workgroup (its left neighbour of that seam), nobody stores twice
+	if constexpr (SEAMREG)
+	{
+#pragma unroll
+		for (int i = 0; i < SEAM_REG_ROUNDS; ++i)
+		{
+#pragma unroll
+			for (int pass = 0; pass < 2; ++pass)
+			{
+				int side, k, slot;
+				if (i < roundsB && seamItem(i, pass, side, k, slot) && side == 1)
+				{
+					storeSoft<KIND>(c, unpackPersist<KIND, WARM>(rB[2 * i + pass], shared), k);
+				}
+			}
+		}
+	}
+	else
 #pragma unroll 1
 	for (int i = 0; i < roundsB; ++i)
 	{
@@ -912,20 +986,29 @@ static void launchStep(hipStream_t s, dim3 grid, size_t lds, const ContactView& 
 	{
 		if (pv.allTwoPoints)
 		{
-			stripStepKernel<KIND, WARM, 2, S2_STRIP_ROUNDS_MAX><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
+			stripStepKernel<KIND, WARM, 2, S2_STRIP_ROUNDS_MAX, 0><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
 		}
 		else
 		{
-			stripStepKernel<KIND, WARM, 0, S2_STRIP_ROUNDS_MAX><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
+			stripStepKernel<KIND, WARM, 0, S2_STRIP_ROUNDS_MAX, 0><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
+		}
+	}
+	else if (pv.seamRegs && KIND == SOFT_TGS && WARM == WARM_CURRENT)
+	{
+		// TGS_Soft only: the other kinds' records are 30-32 dwords and four more of them spill; and the two-point fast path
+		// does not fit the register file together with them either (249 spilled registers), so this is the per-point variant
+		if constexpr (KIND == SOFT_TGS && WARM == WARM_CURRENT)
+		{
+			stripStepKernel<KIND, WARM, 0, S2_STRIP_ROUNDS, 1><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
 		}
 	}
 	else if (pv.allTwoPoints)
 	{
-		stripStepKernel<KIND, WARM, 2, S2_STRIP_ROUNDS><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
+		stripStepKernel<KIND, WARM, 2, S2_STRIP_ROUNDS, 0><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
 	}
 	else
 	{
-		stripStepKernel<KIND, WARM, 0, S2_STRIP_ROUNDS><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
+		stripStepKernel<KIND, WARM, 0, S2_STRIP_ROUNDS, 0><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
 	}
 }
 
@@ -998,9 +1081,10 @@ int stripKernelSetup()
 		(const void*)stripSoftKernel<SOFT_FIXED, WARM_CURRENT>, (const void*)stripSoftKernel<SOFT_FIXED, WARM_FIXED>, (const void*)stripSoftKernel<SOFT_FIXED, -1>,
 	};
 	const void* steps[] = {
+		(const void*)stripStepKernel<SOFT_TGS, WARM_CURRENT, 0, S2_STRIP_ROUNDS, 1>,
 #define S2_STEP_VARIANTS(K, W)                                                                                                   \
-	(const void*)stripStepKernel<K, W, 0, S2_STRIP_ROUNDS>, (const void*)stripStepKernel<K, W, 2, S2_STRIP_ROUNDS>,              \
-		(const void*)stripStepKernel<K, W, 0, S2_STRIP_ROUNDS_MAX>, (const void*)stripStepKernel<K, W, 2, S2_STRIP_ROUNDS_MAX>
+	(const void*)stripStepKernel<K, W, 0, S2_STRIP_ROUNDS, 0>, (const void*)stripStepKernel<K, W, 2, S2_STRIP_ROUNDS, 0>,        \
+		(const void*)stripStepKernel<K, W, 0, S2_STRIP_ROUNDS_MAX, 0>, (const void*)stripStepKernel<K, W, 2, S2_STRIP_ROUNDS_MAX, 0>
 		S2_STEP_VARIANTS(SOFT_TGS, WARM_CURRENT),	S2_STEP_VARIANTS(SOFT_TGS, WARM_FIXED),	  S2_STEP_VARIANTS(SOFT_PGS, WARM_CURRENT),
 		S2_STEP_VARIANTS(SOFT_PGS, WARM_FIXED),		S2_STEP_VARIANTS(SOFT_FIXED, WARM_CURRENT), S2_STEP_VARIANTS(SOFT_FIXED, WARM_FIXED),
 #undef S2_STEP_VARIANTS

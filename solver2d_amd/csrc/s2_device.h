@@ -506,7 +506,7 @@ struct PersistView
 	int wideRounds;	  // some strip has 7 or 8 interior colour batches: the ROUNDS == 8 kernel variant
 	int seamRegs;	  // no seam has more than two colour batches: the seam constraints stay in registers (SEAMREG variant)
 	int ldsRecords;
-	int debugSkip; // timing experiments only (results are wrong): 1 = no hand-offs, 2 = no seam rounds, 4 = no interior rounds;
+	int debugSkip; // timing experiments only (results are wrong; compiled in with -DS2_PERSIST_INSTRUMENTED=1): 1 = no hand-offs, 2 = no seam rounds, 4 = no interior rounds;
 				   // 8 = fault injection for the fallback test: workgroup 1 never publishes its seam bodies
 	unsigned int spinLimit; // polls before a hand-off is declared dead
 	unsigned long long* debugTimes; // S2AMD_DEBUG_TIMES: wall_clock64() of one workgroup at kernel start, after the loads, after every op, at the end

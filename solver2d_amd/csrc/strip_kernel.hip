@@ -252,6 +252,10 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripSoftKernel(ContactView 
 // the receiver produced from epoch e), so one slot per granule suffices.  All K <= CU-count workgroups
 // are resident (one per CU); every poll loop is bounded and reports through pv.error.
 // ------------------------------------------------------------------------------------------------
+// 1: the timing-only switches of `persist_debug` (bits 1, 2, 4) and the S2AMD_DEBUG_TIMES stamps are compiled in
+#ifndef S2_PERSIST_INSTRUMENTED
+#define S2_PERSIST_INSTRUMENTED 0
+#endif
 typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
 
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 {
 	extern __shared__ __attribute__((aligned(16))) float4 lds[];
 	const int tid = (int)threadIdx.x;
-	const bool stamp = pv.debugTimes != nullptr && blockIdx.x == gridDim.x / 2 && tid == 0;
+	const bool stamp = S2_PERSIST_INSTRUMENTED && pv.debugTimes != nullptr && blockIdx.x == gridDim.x / 2 && tid == 0;
 	int stamps = 0;
 	if (stamp)
 	{
@@ -798,7 +802,7 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 #pragma unroll
 			for (int i = 0; i < ROUNDS; ++i)
 			{
-				if (i < roundsA && (pv.debugSkip & 4) == 0)
+				if (i < roundsA && (!S2_PERSIST_INSTRUMENTED || (pv.debugSkip & 4) == 0))
 				{
 					if (kOfRound(i) >= 0)
 					{
@@ -824,7 +828,7 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 				putGranule(p + 0, epoch, v.x), putGranule(p + 1, epoch, v.y), putGranule(p + 2, epoch, v.z);
 			}
 			int fail = 0;
-			if ((pv.debugSkip & 1) == 0)
+			if (!S2_PERSIST_INSTRUMENTED || (pv.debugSkip & 1) == 0)
 			{
 				float v[3];
 				if (tid < nImp0)
@@ -861,7 +865,7 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 #pragma unroll
 				for (int i = 0; i < SEAM_REG_ROUNDS; ++i)
 				{
-					if (i < roundsB && (pv.debugSkip & 2) == 0)
+					if (i < roundsB && (!S2_PERSIST_INSTRUMENTED || (pv.debugSkip & 2) == 0))
 					{
 #pragma unroll
 						for (int pass = 0; pass < 2; ++pass)
@@ -879,7 +883,7 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 			else
 			{
 #pragma unroll 1
-				for (int i = 0; i < roundsB && (pv.debugSkip & 2) == 0; ++i)
+				for (int i = 0; i < roundsB && (!S2_PERSIST_INSTRUMENTED || (pv.debugSkip & 2) == 0); ++i)
 				{
 #pragma unroll
 					for (int pass = 0; pass < 2; ++pass)

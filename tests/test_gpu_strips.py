@@ -115,6 +115,21 @@ def test_persistent_strip_step_on_off(solver_name, persist):
             assert st["kernelLaunches"] <= 10, st
 
 
+@pytest.mark.parametrize("seam_regs", [1, 0])
+def test_persistent_seams_in_registers_or_lds(seam_regs):
+    """TGS_Soft keeps the seam constraints in registers when no seam needs more than two colours (the per-point kernel
+    variant); with the option off they are walked from LDS records by the two-point variant.  Same bits."""
+    pre = synthetic.pyramid(100)
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
+        s.set_option("seam_regs", seam_regs)
+        state = common.copy3(pre)
+        for step in range(3):
+            state = gpu_vs_oracle(s, params, state, "pyramid100 seam_regs=%d step %d" % (seam_regs, step))
+        assert s.stats()["persistent"] == 1
+
+
 def test_persistent_two_point_fast_path_follows_the_point_counts():
     """Same contact graph, but manifolds drop from two points to one (a box tilts onto an edge) and come back: the
     persistent kernel's two-point variant is chosen from the point counts of THIS step, not of the step the strips were

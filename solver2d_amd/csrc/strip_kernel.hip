@@ -600,6 +600,7 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 	};
 	constexpr int SEAM_REG_ROUNDS = 2;
 	PersistRegs<KIND, WARM> rB[SEAMREG ? 2 * SEAM_REG_ROUNDS : 1];
+	uint32_t seamMask = 0u; // SEAMREG: bit 2 i + pass set when this thread holds a seam constraint in that round and pass
 #pragma unroll
 	for (int i = 0; i < (SEAMREG ? SEAM_REG_ROUNDS : S2_PERSIST_B_ROUNDS); ++i)
 	{
@@ -614,6 +615,7 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 				if constexpr (SEAMREG)
 				{
 					rB[2 * i + pass] = pb;
+					seamMask |= 1u << (2 * i + pass);
 				}
 				else
 				{
@@ -760,8 +762,7 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 #pragma unroll
 						for (int pass = 0; pass < 2; ++pass)
 						{
-							int side, k, slot;
-							if (seamItem(i, pass, side, k, slot, salt))
+							if ((seamMask >> (2 * i + pass)) & 1u)
 							{
 								warmSoftRegs<WARM>(unpackPersist<KIND, WARM>(rB[2 * i + pass], shared, salt), lb);
 							}
@@ -870,10 +871,10 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 #pragma unroll
 						for (int pass = 0; pass < 2; ++pass)
 						{
-							int side, k, slot;
-							if (seamItem(i, pass, side, k, slot, salt))
+							if ((seamMask >> (2 * i + pass)) & 1u)
 							{
-								sweepPersist<KIND, WARM, POINTS>(rB[2 * i + pass], shared, c, lb, op.inv_h, op.useBias, k, salt);
+								// (the constraint's sweep position is only used by the Jacobi kind, which never runs here)
+								sweepPersist<KIND, WARM, POINTS>(rB[2 * i + pass], shared, c, lb, op.inv_h, op.useBias, 0, salt);
 							}
 						}
 						__syncthreads();

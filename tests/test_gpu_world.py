@@ -253,3 +253,33 @@ def test_tumbler_world_loop():
             res = s.world_download(*[out[k] for k in world_chain.WORLD_KEYS])
             world_chain.assert_device_equals_oracle(dict(zip(world_chain.WORLD_KEYS, res[:6])), ref, "tumbler step %d" % step)
     assert separated > 5 and created > 5, (separated, created)
+
+
+def test_world_from_scratch_finds_every_touching_pair():
+    """A pyramid world uploaded with NO contacts and every proxy in the move buffer (as after creation): the resident
+    pair query must report exactly the touching pairs of the scene, the caller creates them, and from there the chain
+    runs bit-exact against the oracle chain given the same contacts."""
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    full = synthetic.pyramid_world(14)
+    expected = {(min(a, b), max(a, b)) for a, b in zip(full["pairs"]["shapeA"].tolist(), full["pairs"]["shapeB"].tolist())}
+    world = world_chain.copy_world(full)
+    world["contacts"][:] = np.zeros(1, dtype=wire.contact_dtype)[0]
+    world["contacts"]["constraintIndex"] = -1
+    world["pairs"]["shapeA"] = -1
+    world["pairs"]["shapeB"] = -1
+    world["shapes"]["enlarged"] = 1
+    ref = world_chain.copy_world(world)
+    with hip.Solver(0) as s:
+        s.world_upload(*[world[k] for k in world_chain.WORLD_KEYS])
+        got = s.world_find_pairs()
+        assert {(min(a, b), max(a, b)) for a, b in got.tolist()} == expected and len(got) == len(expected)
+        slots, contacts, pairs = _create_contacts(ref, got)
+        s.world_set_contacts(slots, contacts, pairs)
+        for step in range(4):
+            info = s.world_step(params)
+            order, _ = s.contact_order()
+            world_chain.oracle_world_step(params, ref, contact_order=order)
+            out = world_chain.copy_world(world)
+            res = s.world_download(*[out[k] for k in world_chain.WORLD_KEYS])
+            world_chain.assert_device_equals_oracle(dict(zip(world_chain.WORLD_KEYS, res[:6])), ref, "from scratch step %d" % step)
+            assert info["activeContacts"] == len(expected)

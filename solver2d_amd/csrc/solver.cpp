@@ -612,6 +612,7 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	else if (strcmp(key, "strip_patience") == 0)
 	{
 		s->optStripPatience = std::max(0, value);
+		s->stripPatienceNow = s->optStripPatience;
 	}
 	else if (strcmp(key, "strips_any_solver") == 0)
 	{

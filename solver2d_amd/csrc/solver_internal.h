@@ -227,6 +227,7 @@ struct s2amdSolver
 	bool stripsRejected = false; // this graph's strip partition fits no strip kernel: colour batches until the graph changes
 	int graphAge = 0;		  // steps solved since the constraint graph last changed
 	int optStripPatience = 1; // steps of an unchanged graph before the (more expensive) strip structure is built
+	int stripPatienceNow = 1; // ... as it stands: doubled every time a strip structure died young (noteGraphChanged)
 	int optStripsAnySolver = 0; // tests: strips for every solver and with joints (through the generic group interpreter)
 	bool adjValid = false;
 	bool structureDirty = true;
@@ -262,6 +263,31 @@ struct s2amdSolver
 	bool gatherIndexDirty = true;
 	uint64_t opsGeneration = ~0ull;
 };
+
+// The constraint graph changed (an upload, a manifold that gained or lost its points, a contact slot written): the
+// structure is rebuilt at the next step.  The strip structure costs several milliseconds of host time (more with
+// strip_retry), so a world whose graph keeps changing every few steps must not build it again and again: the patience
+// doubles whenever strips were in use for fewer than 32 steps, and returns to the option's value after a quiet spell.
+// (strip_patience 0 means "always build at once" and is left alone; a world of another size is a new world.)
+inline void noteGraphChanged(s2amdSolver* s, bool newWorld = false)
+{
+	const bool stripsInUse = s->dStripA.view.groupCount > 0;
+	if (newWorld || s->optStripPatience == 0)
+	{
+		s->stripPatienceNow = s->optStripPatience;
+	}
+	else if (stripsInUse && s->graphAge < 32)
+	{
+		s->stripPatienceNow = std::min(std::max(2 * s->stripPatienceNow, 2), 512);
+	}
+	else if (s->graphAge >= 256)
+	{
+		s->stripPatienceNow = s->optStripPatience;
+	}
+	s->graphAge = 0;
+	s->stripsRejected = false;
+	s->structureDirty = true;
+}
 
 StepConsts makeConsts(const s2amdStepParams* p);
 int carveBodies(s2amdSolver* s, int n); // (re)carves the body SoA family for n slots

@@ -18,7 +18,8 @@ void destroyGraph(s2amdSolver* s)
 
 int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdContact* contacts, int nc, const s2amdJoint* joints, int nj)
 {
-	bool changed = s->structureDirty || nb != (int)s->hBodyFlags.size() || nc != (int)s->hContactA.size() || nj != (int)s->hJointType.size();
+	const bool newWorld = nb != (int)s->hBodyFlags.size() || nc != (int)s->hContactA.size() || nj != (int)s->hJointType.size();
+	bool changed = s->structureDirty || newWorld;
 	std::vector<uint32_t> flags((size_t)nb);
 	s->hBodyLive.assign((size_t)nb, 0);
 	s->hBodyStatic.assign((size_t)nb, 0);
@@ -111,9 +112,7 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 	}
 	if (changed)
 	{
-		s->graphAge = 0; // strips wait until the graph has stayed the same for optStripPatience steps
-		s->stripsRejected = false;
-		s->structureDirty = true;
+		noteGraphChanged(s, newWorld);
 	}
 	return S2AMD_OK;
 }

@@ -538,7 +538,7 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 	const bool needAdj = solverType == s2amd_solverJacobi;
 	const bool grouped = s->optGroups != 0 && !needAdj;
 	// strips pay off through the lean / persistent strip kernels, which exist for the soft contact sweeps
-	const bool wantStrips = grouped && s->optStrips != 0 && !s->stripsRejected && s->graphAge >= s->optStripPatience &&
+	const bool wantStrips = grouped && s->optStrips != 0 && !s->stripsRejected && s->graphAge >= s->stripPatienceNow &&
 							(s->optStripsAnySolver != 0 || solverType == s2amd_solverTGS_Soft || solverType == s2amd_solverSoftStep ||
 							 solverType == s2amd_solverPGS_Soft);
 	if (!s->structureDirty && cls == s->orderSolverClass && grouped == s->orderGrouped && wantStrips == s->orderStrips && s->adjValid)

@@ -64,9 +64,7 @@ void applyPointCounts(s2amdSolver* s)
 	}
 	if (graphChanged)
 	{
-		s->graphAge = 0;
-		s->stripsRejected = false;
-		s->structureDirty = true;
+		noteGraphChanged(s);
 		s->gatherIndexDirty = true;
 	}
 	else if (countsMoved && s->persistValid)
@@ -369,9 +367,7 @@ int s2amd_world_set_contacts(s2amdSolver* s, const int32_t* slots, int32_t count
 	}
 	if (changed)
 	{
-		s->graphAge = 0;
-		s->stripsRejected = false;
-		s->structureDirty = true;
+		noteGraphChanged(s);
 		s->gatherIndexDirty = true;
 	}
 	else if (s->persistValid)

@@ -11,7 +11,7 @@ import pytest
 
 from solver2d_amd import hip, synthetic, wire
 from tests import common, golden_util, oraclebind
-from tests.test_gpu_parity import gpu_vs_oracle
+from tests.test_gpu_parity import gpu_vs_oracle, gpu_vs_oracle_loose
 
 pytestmark = pytest.mark.gpu
 
@@ -335,3 +335,22 @@ def test_a_dead_hand_off_falls_back_to_the_multi_launch_path():
         want = common.copy3(pre)
         oraclebind.solve(params, *want, contact_order=order)
         common.compare_exact(got, want, "dead hand-off, resident")
+
+
+def test_strip_patience_backs_off_when_the_graph_keeps_changing():
+    """The strip structure takes milliseconds of host time: when it dies young (the graph changes again within a few
+    steps) the patience doubles, so a world that keeps changing stays on the colour batches."""
+    pre = synthetic.pyramid(100)
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    active = np.flatnonzero(pre[1]["pointCount"] == 2)
+    with hip.Solver(0) as s:  # default patience 1
+        state = common.copy3(pre)
+        strips_seen = []
+        for step in range(14):
+            if step % 3 == 2:  # every third step a manifold loses or regains its points
+                victim = active[5]
+                state[1]["pointCount"][victim] = 0 if state[1]["pointCount"][victim] else 2
+            state = gpu_vs_oracle_loose(s, params, state, "churn step %d" % step)
+            strips_seen.append(s.stats()["stripCount"] > 0)
+        # built once or twice at the start, then the patience (2, 4, 8 ...) outlasts the three quiet steps
+        assert any(strips_seen[:6]) and not any(strips_seen[8:]), strips_seen

@@ -229,7 +229,8 @@ def test_platform_high_degree_body_in_strips(solver_name):
 
 def test_strips_wait_until_the_graph_has_settled():
     """Default policy for the drop-in call: the first solve after a graph change takes the colour-batch path (cheap
-    host structure), the next one with the same graph builds the strips; a graph change starts over."""
+    host structure), the next one with the same graph builds the strips; a graph change starts over -- with the patience
+    doubled, because the strip structure it invalidated had only lived for a step."""
     pre = synthetic.pyramid(100)
     with hip.Solver(0) as s:
         params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
@@ -240,7 +241,9 @@ def test_strips_wait_until_the_graph_has_settled():
         state[1]["pointCount"][7] = 0  # one contact ends: new graph
         state = gpu_vs_oracle(s, params, state, "patience step 2")
         assert s.stats()["stripCount"] == 0
-        gpu_vs_oracle(s, params, state, "patience step 3")
+        state = gpu_vs_oracle(s, params, state, "patience step 3")
+        assert s.stats()["stripCount"] == 0
+        gpu_vs_oracle(s, params, state, "patience step 4")
         assert s.stats()["persistent"] == 1
 
 

@@ -312,16 +312,11 @@ S2_DEV bool reports(const s2amdShape& P, bool movedP, const s2amdShape& Q, bool 
 	return true;
 }
 
-__global__ __launch_bounds__(S2_BLOCK) void pairKernel(const s2amdShape* shapes, const unsigned char* moved, const int* sortedIdx,
-														const unsigned int* runOffset, int n, unsigned int work, const unsigned long long* existing,
-														int existingCount, const unsigned long long* jointed, int jointedCount,
-														unsigned long long* outKeys, unsigned int outCapacity, unsigned int* outCount)
+// one candidate (work item t of the sweep-and-prune runs): the reference's pair rules
+S2_DEV void pairOne(unsigned int t, const s2amdShape* shapes, const unsigned char* moved, const int* sortedIdx, const unsigned int* runOffset, int n,
+					const unsigned long long* existing, int existingCount, const unsigned long long* jointed, int jointedCount,
+					unsigned long long* outKeys, unsigned int outCapacity, unsigned int* outCount)
 {
-	unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
-	if (t >= work)
-	{
-		return;
-	}
 	// which run does work item t belong to?  last i with runOffset[i] <= t
 	int lo = 0, hi = n;
 	while (lo + 1 < hi)
@@ -418,6 +413,32 @@ __global__ __launch_bounds__(S2_BLOCK) void pairKernel(const s2amdShape* shapes,
 	}
 }
 
+__global__ __launch_bounds__(S2_BLOCK) void pairKernel(const s2amdShape* shapes, const unsigned char* moved, const int* sortedIdx,
+														const unsigned int* runOffset, int n, unsigned int work, const unsigned long long* existing,
+														int existingCount, const unsigned long long* jointed, int jointedCount,
+														unsigned long long* outKeys, unsigned int outCapacity, unsigned int* outCount)
+{
+	unsigned int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t < work)
+	{
+		pairOne(t, shapes, moved, sortedIdx, runOffset, n, existing, existingCount, jointed, jointedCount, outKeys, outCapacity, outCount);
+	}
+}
+
+// the same over a fixed grid: the number of work items is read from the scan's total on the device, so the host does not
+// have to fetch it before the launch
+__global__ __launch_bounds__(S2_BLOCK) void pairStrideKernel(const s2amdShape* shapes, const unsigned char* moved, const int* sortedIdx,
+															  const unsigned int* runOffset, int n, const unsigned long long* existing, int existingCount,
+															  const unsigned long long* jointed, int jointedCount, unsigned long long* outKeys,
+															  unsigned int outCapacity, unsigned int* outCount)
+{
+	const unsigned int work = runOffset[n];
+	for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < work; t += gridDim.x * blockDim.x)
+	{
+		pairOne(t, shapes, moved, sortedIdx, runOffset, n, existing, existingCount, jointed, jointedCount, outKeys, outCapacity, outCount);
+	}
+}
+
 namespace
 {
 struct Scratch
@@ -507,7 +528,7 @@ __global__ __launch_bounds__(S2_BLOCK) void residentPairKeysKernel(const s2amdPa
 
 int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShapes, const s2amdPairState* dPairs, int nc,
 					  const unsigned long long* dJointed, int jointedCount, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount, void** scratch,
-					  size_t* scratchBytes)
+					  size_t* scratchBytes, unsigned long long* sortedPairKeys, bool* sortedPairKeysValid)
 {
 	*pairCount = 0;
 	const int n = liveShapes;
@@ -563,34 +584,36 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 	unsigned long long* dOutB = (unsigned long long*)take();
 	unsigned int* dCount = (unsigned int*)take();
 	void* dTmp = take();
+	(void)dExisting; // the sorted pair keys live in the caller's buffer
+	(void)dOutB;
 
 	BP_TRY(hipMemsetAsync(dCount, 0, 256, st));
 	BP_TRY(hipMemsetAsync(dRun, 0, ((size_t)n + 1) * 4, st));
 	residentShapeKeysKernel<<<gridFor((size_t)ns), dim3(S2_BLOCK), 0, st>>>(dS, ns, dKeysIn, dIdxIn, dMoved);
 	size_t tmp = tmpBytes + 256;
 	BP_TRY(rocprim::radix_sort_pairs(dTmp, tmp, dKeysIn, dKeysOut, dIdxIn, dIdxOut, (size_t)ns, 0, 32, st));
-	if (nc > 0)
+	// the sorted keys of the live pairs only change when a contact is created or destroyed: the caller keeps them
+	if (nc > 0 && !*sortedPairKeysValid)
 	{
 		residentPairKeysKernel<<<gridFor((size_t)nc), dim3(S2_BLOCK), 0, st>>>(dPairs, nc, dExistingIn);
 		tmp = tmpBytes + 256;
-		BP_TRY(rocprim::radix_sort_keys(dTmp, tmp, dExistingIn, dExisting, (size_t)nc, 0, 64, st));
+		BP_TRY(rocprim::radix_sort_keys(dTmp, tmp, dExistingIn, sortedPairKeys, (size_t)nc, 0, 64, st));
+		*sortedPairKeysValid = true;
 	}
 	gatherLowerXKernel<<<gridFor((size_t)n), dim3(S2_BLOCK), 0, st>>>(dS, dIdxOut, n, dLowerX);
 	runLengthKernel<<<gridFor((size_t)n), dim3(S2_BLOCK), 0, st>>>(dS, dIdxOut, dLowerX, n, dRun);
 	tmp = tmpBytes + 256;
 	BP_TRY(rocprim::exclusive_scan(dTmp, tmp, dRun, dOff, 0u, (size_t)n + 1, rocprim::plus<unsigned int>(), st));
-	unsigned int work = 0;
-	BP_TRY(hipMemcpyAsync(&work, dOff + n, 4, hipMemcpyDeviceToHost, st));
-	BP_TRY(hipStreamSynchronize(st));
+	pairStrideKernel<<<dim3(4096), dim3(S2_BLOCK), 0, st>>>(dS, dMoved, dIdxOut, dOff, n, sortedPairKeys, nc, dJointed, jointedCount, dOutA,
+															 (unsigned int)outCap, dCount);
+	BP_TRY(hipGetLastError());
+	// one read-back: the count and the first keys (a step rarely creates more than a few contacts)
+	constexpr unsigned int kFirst = 2048;
+	std::vector<unsigned long long> out(kFirst);
 	unsigned int found = 0;
-	if (work > 0)
-	{
-		pairKernel<<<gridFor((size_t)work), dim3(S2_BLOCK), 0, st>>>(dS, dMoved, dIdxOut, dOff, n, work, dExisting, nc, dJointed, jointedCount, dOutA,
-																	  (unsigned int)outCap, dCount);
-		BP_TRY(hipGetLastError());
-		BP_TRY(hipMemcpyAsync(&found, dCount, 4, hipMemcpyDeviceToHost, st));
-		BP_TRY(hipStreamSynchronize(st));
-	}
+	BP_TRY(hipMemcpyAsync(&found, dCount, 4, hipMemcpyDeviceToHost, st));
+	BP_TRY(hipMemcpyAsync(out.data(), dOutA, (size_t)std::min<size_t>(kFirst, outCap) * 8, hipMemcpyDeviceToHost, st));
+	BP_TRY(hipStreamSynchronize(st));
 	*pairCount = (int32_t)found;
 	if ((int64_t)found > (int64_t)pairCapacity)
 	{
@@ -600,11 +623,13 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 	{
 		return S2AMD_OK;
 	}
-	tmp = tmpBytes + 256;
-	BP_TRY(rocprim::radix_sort_keys(dTmp, tmp, dOutA, dOutB, (size_t)found, 0, 64, st));
-	std::vector<unsigned long long> out((size_t)found);
-	BP_TRY(hipMemcpyAsync(out.data(), dOutB, (size_t)found * 8, hipMemcpyDeviceToHost, st));
-	BP_TRY(hipStreamSynchronize(st));
+	out.resize(found);
+	if (found > kFirst)
+	{
+		BP_TRY(hipMemcpyAsync(out.data() + kFirst, dOutA + kFirst, (size_t)(found - kFirst) * 8, hipMemcpyDeviceToHost, st));
+		BP_TRY(hipStreamSynchronize(st));
+	}
+	std::sort(out.begin(), out.end()); // deterministic output order: by (A, B)
 	for (unsigned int i = 0; i < found; ++i)
 	{
 		outPairs[2 * i] = (int32_t)(out[i] >> 32);

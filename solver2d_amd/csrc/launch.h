@@ -149,4 +149,4 @@ void launchStage4(hipStream_t st, s2amdBody* bodies, int bodyCapacity, s2amdShap
 // stage 1 on resident arrays: new pairs sorted by (A, B) into the host array outPairs; dJointed: sorted (min body << 32 | max body) keys
 int findPairsResident(hipStream_t st, const s2amdShape* shapes, int shapeCapacity, int liveShapes, const s2amdPairState* pairs, int contactCapacity,
 					  const unsigned long long* jointed, int jointedCount, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount, void** scratch,
-					  size_t* scratchBytes);
+					  size_t* scratchBytes, unsigned long long* sortedPairKeys, bool* sortedPairKeysValid);

@@ -164,7 +164,8 @@ struct s2amdSolver
 	bool savedValid = false;
 
 	// resident world (world.hip): the arrays of stages 3 and 4 beside the solver's wire arrays
-	DevBuf dShapes, dPairs, dOrigins, dStatus, dPointBytes, dWorldSummary, dJointedKeys, dContactStage, dPairScratch;
+	DevBuf dShapes, dPairs, dOrigins, dStatus, dPointBytes, dWorldSummary, dJointedKeys, dContactStage, dPairScratch, dPairKeys;
+	bool pairKeysValid = false; // dPairKeys holds the sorted (shape, shape) keys of the live pair slots
 	int shapeCapacity = 0, liveShapes = 0, jointedCount = 0;
 	bool worldResident = false;
 	int* hostWorldSummary = nullptr; // pinned: the per-step counters of both stages

@@ -120,6 +120,7 @@ int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapa
 		}
 	}
 	s->worldResident = false;
+	s->pairKeysValid = false;
 	s->gatherIndexDirty = true;
 	int rc = doUpload(s, bodies, bodyCapacity, contacts, contactCapacity, joints, jointCapacity);
 	if (rc)
@@ -224,6 +225,10 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 		return rc;
 	}
 	WorldSummary contactsSeen = *hSum;
+	if (contactsSeen.separated > 0)
+	{
+		s->pairKeysValid = false; // pair slots were freed on the device
+	}
 	if (contactsSeen.moves > 0)
 	{
 		HIP_TRY(hipMemcpyAsync(s->hPointBytes.data(), s->dPointBytes.p, (size_t)nc, hipMemcpyDeviceToHost, st));
@@ -297,9 +302,16 @@ int s2amd_world_find_pairs(s2amdSolver* s, int32_t* outPairs, int32_t pairCapaci
 		return fail(S2AMD_E_STATE, "no resident world");
 	}
 	HIP_TRY(hipSetDevice(s->device));
+	{
+		int rc = s->dPairKeys.ensure(std::max<size_t>((size_t)s->contactCapacity * 8, 256));
+		if (rc)
+		{
+			return rc;
+		}
+	}
 	return findPairsResident(s->stream, (const s2amdShape*)s->dShapes.p, s->shapeCapacity, s->liveShapes, (const s2amdPairState*)s->dPairs.p, s->contactCapacity,
 							 (const unsigned long long*)s->dJointedKeys.p, s->jointedCount, outPairs, pairCapacity, pairCount, &s->dPairScratch.p,
-							 &s->dPairScratch.bytes);
+							 &s->dPairScratch.bytes, (unsigned long long*)s->dPairKeys.p, &s->pairKeysValid);
 }
 
 int s2amd_world_set_contacts(s2amdSolver* s, const int32_t* slots, int32_t count, const s2amdContact* contacts, const s2amdPairState* pairs)
@@ -351,6 +363,7 @@ int s2amd_world_set_contacts(s2amdSolver* s, const int32_t* slots, int32_t count
 																			  (s2amdPairState*)s->dPairs.p, (uint8_t*)s->dPointBytes.p, (int32_t*)s->dStatus.p);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(st));
+	s->pairKeysValid = false;
 	// host shadows of the constraint graph (solver_step.cpp: refreshShadows)
 	bool changed = false;
 	for (int i = 0; i < count; ++i)

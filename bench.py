@@ -271,7 +271,7 @@ def main():
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CONSTRAINT_SWEEP * constraints_per_launch,
             },
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:  # the contract: on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.base, args.vel_iters, args.pos_iters, args.cpu_seconds)
         print(json.dumps(out))
     gpu.close()

@@ -10,7 +10,9 @@
 //           oracle restatement is pinned bit-for-bit against the reference,
 //   mode 2: replace the reference solver by a callback with the s2amd_solve signature -- the
 //           reference's own broad phase / narrow phase / contact bookkeeping then drives the
-//           HIP solver, which is the literal drop-in test.
+//           HIP solver, which is the literal drop-in test.  s2ref_use_amd() installs such a callback in C: it loads
+//           libs2amd.so and forwards to s2amd_solve, so that any program calling the PUBLIC s2World_Step of this
+//           library (the samples' only entry point) runs on the GPU -- the binding of INTEGRATION.md, working.
 // It reads the reference's internal structs through the reference's own headers; no reference
 // source is copied into this repository.
 
@@ -26,6 +28,7 @@
 
 #include "solver2d_amd.h"
 
+#include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -660,6 +663,62 @@ S2REF_API void s2ref_set_replace(s2refReplaceFcn* fcn, void* user)
 {
 	g_replace = fcn;
 	g_replaceUser = user;
+}
+
+// ---- the native shim: s2Solve_* -> s2amd_solve, through dlopen (no link-time dependency on the HIP runtime) ----
+static void* g_amdLib = NULL;
+static s2amdSolver* g_amdSolver = NULL;
+static int (*g_amdSolve)(s2amdSolver*, const s2amdStepParams*, s2amdBody*, int32_t, s2amdContact*, int32_t, s2amdJoint*, int32_t) = NULL;
+static void (*g_amdDestroy)(s2amdSolver*) = NULL;
+
+static int amdReplace(void* user, const s2amdStepParams* params, s2amdBody* bodies, int32_t bodyCapacity, s2amdContact* contacts,
+					  int32_t contactCapacity, s2amdJoint* joints, int32_t jointCapacity)
+{
+	(void)user;
+	return g_amdSolve(g_amdSolver, params, bodies, bodyCapacity, contacts, contactCapacity, joints, jointCapacity);
+}
+
+// path == NULL: back to the reference's own solvers.  Returns 0, or a negative number naming the step that failed.
+S2REF_API int s2ref_use_amd(const char* path, int device)
+{
+	if (g_amdSolver != NULL && g_amdDestroy != NULL)
+	{
+		g_amdDestroy(g_amdSolver);
+	}
+	g_amdSolver = NULL;
+	if (g_replace == amdReplace)
+	{
+		g_replace = NULL;
+		g_mode = 0;
+	}
+	if (path == NULL)
+	{
+		return 0;
+	}
+	if (g_amdLib == NULL)
+	{
+		g_amdLib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+	}
+	if (g_amdLib == NULL)
+	{
+		return -1;
+	}
+	int (*create)(int, s2amdSolver**) = (int (*)(int, s2amdSolver**))dlsym(g_amdLib, "s2amd_create");
+	g_amdSolve = (int (*)(s2amdSolver*, const s2amdStepParams*, s2amdBody*, int32_t, s2amdContact*, int32_t, s2amdJoint*, int32_t))dlsym(g_amdLib, "s2amd_solve");
+	g_amdDestroy = (void (*)(s2amdSolver*))dlsym(g_amdLib, "s2amd_destroy");
+	if (create == NULL || g_amdSolve == NULL || g_amdDestroy == NULL)
+	{
+		return -2;
+	}
+	if (create(device, &g_amdSolver) != 0 || g_amdSolver == NULL)
+	{
+		return -3;
+	}
+	g_replace = amdReplace;
+	g_replaceUser = NULL;
+	g_mode = 2;
+	g_replaceError = 0;
+	return 0;
 }
 
 S2REF_API int s2ref_replace_error(void)

@@ -76,3 +76,35 @@ def test_reference_world_with_hip_solver(scene, p0, p1, steps, solver_name):
                     pa_g, pb_g = wg.contact_pairs()
                     pa_r, pb_r = wr.contact_pairs()
                     assert sorted(zip(pa_g.tolist(), pb_g.tolist())) == sorted(zip(pa_r.tolist(), pb_r.tolist()))
+
+
+@pytest.mark.parametrize("scene,p0,solver_name,steps", [("pyramid", 20, "TGS_Soft", 60), ("mixed", 24, "PGS_NGS", 60), ("tumbler", 150, "SoftStep", 40)])
+def test_native_shim_public_api_runs_on_the_gpu(scene, p0, solver_name, steps):
+    """The binding of INTEGRATION.md in C, no Python between the two libraries: oracle/ref_hook.c: s2ref_use_amd dlopens
+    libs2amd.so and routes the reference's s2Solve_* switch into s2amd_solve, so a program that only calls the PUBLIC
+    s2World_Step runs its solver on the GPU.  The trajectory must be the one the Python-callback route produces (same
+    library, same inputs): bit for bit."""
+    import ctypes
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    L = refbind.lib()
+    L.s2ref_use_amd.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    L.s2ref_use_amd.restype = ctypes.c_int
+    with refbind.RefWorld(scene, solver_name, p0, 0) as native:
+        assert L.s2ref_use_amd(hip.LIB_PATH.encode(), 0) == 0
+        try:
+            for _ in range(steps):
+                native.step(1.0 / 60.0, vel, pos, True)
+            assert L.s2ref_replace_error() == 0
+        finally:
+            assert L.s2ref_use_amd(None, 0) == 0
+        bn, cn, jn = native.pack()
+    with hip.Solver(0) as gpu, refbind.RefWorld(scene, solver_name, p0, 0) as routed:
+        def replace(params, bodies, contacts, joints):
+            gpu.solve(params, bodies, contacts, joints)
+            return 0
+        with refbind.Replace(replace):
+            for _ in range(steps):
+                routed.step(1.0 / 60.0, vel, pos, True)
+        br, cr, jr = routed.pack()
+    assert bn.tobytes() == br.tobytes() and cn.tobytes() == cr.tobytes() and jn.tobytes() == jr.tobytes()
+    assert np.isfinite(bn["position"][bn["type"] >= 0]).all()

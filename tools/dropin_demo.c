@@ -1,0 +1,76 @@
+/* A C program that knows nothing about GPUs: it builds the LargePyramid scene through the reference's PUBLIC API
+ * (solver2d_amd/scenes/scenes.c: s2CreateWorld, s2CreateBody, s2CreatePolygonShape ...) and steps it with s2World_Step.  Linked against oracle/_ref/libs2ref.so -- the unmodified reference sources plus the binding of
+ * INTEGRATION.md (oracle/ref_hook.c) --, one call, s2ref_use_amd(), moves the solver inside s2World_Step onto the
+ * MI355X.  Built and run by tools/dropin_demo.sh on a box that has /root/reference's headers (the build container) or the
+ * prebuilt library (the GPU box: only this file's own declarations are needed, see below).
+ *
+ *   gcc -O2 tools/dropin_demo.c -o gpurun_out/dropin_demo -Loracle/_ref -ls2ref -Wl,-rpath,$PWD/oracle/_ref -lm
+ *   gpurun_out/dropin_demo 200 60 solver2d_amd/libs2amd.so
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
+
+/* the slice of include/solver2d/{id,types,geometry,solver2d}.h this program uses, restated so that it compiles on the
+ * GPU box, where the reference's headers do not exist (layouts: id.h:12-40, types.h:20-139, geometry.h:44-50) */
+typedef struct { int16_t index; uint16_t revision; } s2WorldId;
+typedef struct { int32_t index; int16_t world; uint16_t revision; } s2BodyId;
+typedef struct { float x, y; } s2Vec2;
+
+/* scenes.c (this repository, public API only) builds the sample scenes headless */
+s2WorldId s2scene_create(const char* name, int solverType, int p0, int p1);
+void s2World_Step(s2WorldId worldId, float timeStep, int32_t velIters, int32_t posIters, _Bool warmStart); /* solver2d.h:25 */
+void s2DestroyWorld(s2WorldId id);
+int s2ref_use_amd(const char* libraryPath, int device);
+int s2ref_replace_error(void);
+int s2ref_world_sizes(s2WorldId id, int32_t* bodies, int32_t* contacts, int32_t* joints);
+
+static double now(void)
+{
+	struct timespec t;
+	clock_gettime(CLOCK_MONOTONIC, &t);
+	return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+
+static double run(int base, int steps, const char* lib)
+{
+	const int TGS_Soft = 7; /* enum s2SolverType, types.h:75-88 */
+	s2WorldId w = s2scene_create("pyramid", TGS_Soft, base, 0);
+	if (lib != NULL && s2ref_use_amd(lib, 0) != 0)
+	{
+		fprintf(stderr, "could not load %s\n", lib);
+		exit(1);
+	}
+	for (int i = 0; i < 5; ++i)
+	{
+		s2World_Step(w, 1.0f / 60.0f, 8, 4, 1);
+	}
+	double t0 = now();
+	for (int i = 0; i < steps; ++i)
+	{
+		s2World_Step(w, 1.0f / 60.0f, 8, 4, 1);
+	}
+	double ms = 1e3 * (now() - t0) / steps;
+	int32_t nb = 0, nc = 0, nj = 0;
+	s2ref_world_sizes(w, &nb, &nc, &nj);
+	printf("%-28s base %d: %d body slots, %d contact slots, %.3f ms per s2World_Step%s\n", lib ? "solver on the MI355X" : "reference solver (1 thread)", base,
+		   nb, nc, ms, lib && s2ref_replace_error() ? "  (solver reported an error)" : "");
+	if (lib != NULL)
+	{
+		s2ref_use_amd(NULL, 0);
+	}
+	s2DestroyWorld(w);
+	return ms;
+}
+
+int main(int argc, char** argv)
+{
+	int base = argc > 1 ? atoi(argv[1]) : 100;
+	int steps = argc > 2 ? atoi(argv[2]) : 30;
+	const char* lib = argc > 3 ? argv[3] : "solver2d_amd/libs2amd.so";
+	double cpu = run(base, steps, NULL);
+	double gpu = run(base, steps, lib);
+	printf("whole s2World_Step (broad phase, narrow phase and bookkeeping still on the host): x%.1f\n", cpu / gpu);
+	return 0;
+}

@@ -12,7 +12,8 @@ import numpy as np
 from . import wire
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libs2amd.so")
+# S2AMD_LIB: another build of the same C-ABI (experiments: e.g. the FMA-contracted build of `make -C solver2d_amd/csrc fma`)
+LIB_PATH = os.environ.get("S2AMD_LIB") or os.path.join(_HERE, "libs2amd.so")
 
 EXPORTS = [
     "s2amd_api_version", "s2amd_device_count", "s2amd_last_error", "s2amd_create", "s2amd_destroy",

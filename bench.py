@@ -124,7 +124,10 @@ def main():
     # test hooks (tests/test_gpu_bench.py): run the N > 1 logic on a box with ONE GPU over gloo
     backend = os.environ.get("S2AMD_BENCH_BACKEND", "nccl")
     device_index = 0 if os.environ.get("S2AMD_BENCH_SINGLE_DEVICE") == "1" else local_rank
-    if world > 1:
+    # S2AMD_BENCH_FORCE_DIST=1 (tests): take the distributed path even with ONE rank, so that the RCCL calls of the N > 1
+    # loop can be exercised on a box with a single GPU
+    distributed = world > 1 or os.environ.get("S2AMD_BENCH_FORCE_DIST") == "1"
+    if distributed:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -138,7 +141,7 @@ def main():
     params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, args.vel_iters, args.pos_iters, True)
     sweeps = wire.solve_sweeps_per_step("TGS_Soft", args.vel_iters, args.pos_iters)
 
-    gpu = hip.Solver(device_index if world > 1 else 0, graph=not args.no_graph)
+    gpu = hip.Solver(device_index if distributed else 0, graph=not args.no_graph)
     for kv in args.opt:
         key, _, val = kv.partition("=")
         gpu.set_option(key, int(val))
@@ -149,7 +152,7 @@ def main():
     pose = None
     gathered = None
     torch = None
-    if world > 1:
+    if distributed:
         import torch
         nb = len(pre[0])
         # two pose buffers: the all-gather of step s reads one while step s+1 exports into the other
@@ -163,7 +166,7 @@ def main():
         except for the collective that last read this step's pose buffer (two steps ago)."""
         gpu.restore_bodies()
         gpu.step_resident(params)
-        if world > 1:
+        if distributed:
             b = step & 1
             if gather_done[b] is not None:
                 gather_done[b].synchronize()
@@ -181,7 +184,7 @@ def main():
     def run(count):
         """`count` steps; with more than one rank the host enqueues step s+1 BEFORE it waits for the poses of step s, so
         the device goes from one solve straight into the next while the collective of the previous step is in flight."""
-        if world == 1:
+        if not distributed:
             for s_ in range(count):
                 enqueue(s_)
             return
@@ -193,7 +196,7 @@ def main():
 
     def sync():
         gpu.synchronize()
-        if world > 1:
+        if distributed:
             import torch
             dist.barrier()
             torch.cuda.synchronize()
@@ -210,7 +213,7 @@ def main():
     st = gpu.stats()
     C = st["constraintCount"]
 
-    if world > 1:
+    if distributed:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -275,7 +278,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.base, args.vel_iters, args.pos_iters, args.cpu_seconds)
         print(json.dumps(out))
     gpu.close()
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -50,3 +50,17 @@ def test_two_ranks_on_one_device():
     # whole-job value: both ranks' constraints
     per_rank = d["config"]["constraints"] * d["config"]["solve_sweeps_per_step"] * 20 / (d["ms_per_step"] * 20e-3)
     assert abs(d["value"] - 2 * per_rank) / d["value"] < 1e-6
+
+
+def test_one_rank_through_rccl():
+    """The N > 1 loop with its real backend: one rank, backend nccl (= RCCL), so init_process_group, the asynchronous
+    pose export, all_gather_into_tensor on device tensors and the event hand-shakes all run on this single-GPU box."""
+    env = dict(os.environ, S2AMD_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
+           "29519", "bench.py", "--gpus", "1", "--steps", "50", "--warmup", "10", "--no-cpu"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = last_json(out.stdout)
+    assert d["n_gpus"] == 1 and d["config"]["kernel_launches_per_step"] == 3
+    # the collective and the hand-shakes must not serialise the steps: within 25 % of the plain single-process rate
+    assert d["ms_per_step"] < 0.40, d["ms_per_step"]

@@ -225,6 +225,7 @@ struct s2amdSolver
 	int orderSolverClass = -1; // 0 velocity colouring, 1 position colouring
 	bool orderGrouped = false;
 	bool orderStrips = false;
+	bool stripsNeedOneLaunch = false; // a moving read-only body is shared between strips: persistent kernel or no strips at all
 	bool stripsRejected = false; // this graph's strip partition fits no strip kernel: colour batches until the graph changes
 	int graphAge = 0;		  // steps solved since the constraint graph last changed
 	int optStripPatience = 1; // steps of an unchanged graph before the (more expensive) strip structure is built

@@ -227,6 +227,21 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 		s->opsGeneration = s->planGeneration;
 	}
 
+	{
+		// strips that only the one-launch kernel may run (solver_structure.cpp: stripsNeedOneLaunch), and a plan or a state
+		// that kernel cannot take (another solver family, a hand-off that timed out earlier): colour batches instead
+		Executor probe{s, s->stream, plan, isPositionSolver(params->solverType) ? 1 : 0, false};
+		int kind, warm;
+		if (s->dStripA.view.groupCount > 0 && s->stripsNeedOneLaunch && !probe.persistPlan(kind, warm))
+		{
+			s->stripsRejected = true;
+			s->structureDirty = true;
+			if ((rc = buildStructure(s, params->solverType)) != 0)
+			{
+				return rc;
+			}
+		}
+	}
 	Executor q{s, s->stream, plan, isPositionSolver(params->solverType) ? 1 : 0, s->optProfile != 0};
 	q.msg = messageEligible(s, params->solverType);
 	s->stats.messagePassing = q.msg ? 1 : 0;

@@ -716,6 +716,7 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 
 	// ---- strips: the part that fits no LDS group, cut along BFS level sets ----
 	StripPartition strips;
+	bool stripsNeedOneLaunch = false;
 	if (wantStrips && (s->optStripsAnySolver != 0 || jOf[0].empty()))
 	{
 		std::vector<uint8_t> ownedByIsland((size_t)nb, 0);
@@ -749,6 +750,133 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 		if (looseCount >= s->optStripMinBodies)
 		{
 			partitionStrips(ce, je, cOf[0], jOf[0], conflict, loose, nb, std::max(8, (int)((float)s->optStripBodies * stripScale)), s->optMaxGroupBodies, strips);
+		}
+		if (strips.active)
+		{
+			// A body the sweeps WRITE that the partition did not place in any strip -- a static body whose rot is not a fixed
+			// point of the normalisation is written by the position sweeps but is not one of the loose bodies the
+			// breadth-first search walks -- would be written by every strip that touches it: no strips for this graph
+			// (found by fuzzing: seed 259 under XPBD).
+			std::vector<uint8_t> placed((size_t)nb, 0);
+			for (const std::vector<int>& list : strips.bodies)
+			{
+				for (int b : list)
+				{
+					placed[(size_t)b] = 1;
+				}
+			}
+			bool orphan = false;
+			for (const std::vector<std::vector<int>>* lists : {&strips.cA, &strips.cB})
+			{
+				for (const std::vector<int>& list : *lists)
+				{
+					for (int k : list)
+					{
+						orphan = orphan || (ce.a[k] >= 0 && conflict[(size_t)ce.a[k]] && !placed[(size_t)ce.a[k]]) ||
+								 (ce.b[k] >= 0 && conflict[(size_t)ce.b[k]] && !placed[(size_t)ce.b[k]]);
+					}
+				}
+			}
+			for (const std::vector<std::vector<int>>* lists : {&strips.jA, &strips.jB})
+			{
+				for (const std::vector<int>& list : *lists)
+				{
+					for (int k : list)
+					{
+						orphan = orphan || (je.a[k] >= 0 && conflict[(size_t)je.a[k]] && !placed[(size_t)je.a[k]]) ||
+								 (je.b[k] >= 0 && conflict[(size_t)je.b[k]] && !placed[(size_t)je.b[k]]);
+					}
+				}
+			}
+			if (orphan)
+			{
+				strips = StripPartition();
+				s->stripsRejected = true;
+			}
+		}
+		if (strips.active)
+		{
+			// A body the sweeps do not write but the body stages MOVE (kinematic, massless) is a replica in every strip
+			// that touches it.  One launch per step (the persistent kernel) keeps such a copy consistent from start to end;
+			// with one launch per sweep every workgroup re-reads it from HBM while its owner is writing it in the same
+			// launch -- a race.  Such partitions only run on the persistent kernel (found by fuzzing: seed 205).
+			for (const std::vector<std::vector<int>>* lists : {&strips.cA, &strips.cB})
+			{
+				for (const std::vector<int>& list : *lists)
+				{
+					for (int k : list)
+					{
+						for (int b : {ce.a[k], ce.b[k]})
+						{
+							if (b >= 0 && !conflict[(size_t)b] && s->hBodyLive[(size_t)b] && !s->hBodyStatic[(size_t)b])
+							{
+								stripsNeedOneLaunch = true;
+							}
+						}
+					}
+				}
+			}
+		}
+		if (strips.active && getenv("S2AMD_DEBUG_CHECK"))
+		{
+			// the invariants the strip kernels rely on (comment above StripPartition)
+			std::vector<int> owner((size_t)nb, -1), seamOf((size_t)nb, -1);
+			for (size_t i = 0; i < strips.bodies.size(); ++i)
+			{
+				for (int b : strips.bodies[i])
+				{
+					if (owner[(size_t)b] != -1)
+					{
+						fprintf(stderr, "[s2amd] CHECK: body %d owned by strips %d and %zu\n", b, owner[(size_t)b], i);
+					}
+					owner[(size_t)b] = (int)i;
+				}
+			}
+			for (size_t i = 0; i < strips.cA.size(); ++i)
+			{
+				for (int k : strips.cA[i])
+				{
+					for (int b : {ce.a[k], ce.b[k]})
+					{
+						if (b >= 0 && conflict[(size_t)b] && owner[(size_t)b] != (int)i)
+						{
+							fprintf(stderr, "[s2amd] CHECK: interior constraint %d of strip %zu touches body %d of strip %d\n", k, i, b, owner[(size_t)b]);
+						}
+					}
+				}
+			}
+			for (size_t i = 0; i < strips.cB.size(); ++i)
+			{
+				for (int k : strips.cB[i])
+				{
+					for (int b : {ce.a[k], ce.b[k]})
+					{
+						if (b < 0 || !conflict[(size_t)b])
+						{
+							continue;
+						}
+						if (owner[(size_t)b] != (int)i && owner[(size_t)b] != (int)i + 1)
+						{
+							fprintf(stderr, "[s2amd] CHECK: seam %zu constraint %d touches body %d of strip %d\n", i, k, b, owner[(size_t)b]);
+						}
+						if (seamOf[(size_t)b] != -1 && seamOf[(size_t)b] != (int)i)
+						{
+							fprintf(stderr, "[s2amd] CHECK: body %d (strip %d) is touched by seams %d and %zu\n", b, owner[(size_t)b], seamOf[(size_t)b], i);
+						}
+						seamOf[(size_t)b] = (int)i;
+					}
+				}
+			}
+			size_t total = 0;
+			for (size_t i = 0; i < strips.cA.size(); ++i)
+			{
+				total += strips.cA[i].size();
+			}
+			for (size_t i = 0; i < strips.cB.size(); ++i)
+			{
+				total += strips.cB[i].size();
+			}
+			fprintf(stderr, "[s2amd] CHECK: %zu strips, %zu seams, %zu constraints of %zu in the strip part\n", strips.bodies.size(), strips.cB.size(), total, cOf[0].size());
 		}
 		if (strips.active)
 		{
@@ -1440,7 +1568,12 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 
 	// strips only pay through the strip kernels: when neither the persistent step nor the lean launches can take this
 	// partition (too many colours, a hub body, LDS budget), fall back to the colour-batch structure for this graph
-	if (strips.active && !s->optStripsAnySolver && !s->persistValid && !(s->leanAValid && s->leanBValid))
+	s->stripsNeedOneLaunch = strips.active && stripsNeedOneLaunch;
+	if (stripsNeedOneLaunch)
+	{
+		s->leanAValid = s->leanBValid = false;
+	}
+	if (strips.active && !s->persistValid && (stripsNeedOneLaunch || (!s->optStripsAnySolver && !(s->leanAValid && s->leanBValid))))
 	{
 		s->stripsRejected = true;
 		s->structureDirty = true;

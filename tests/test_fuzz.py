@@ -127,3 +127,53 @@ def test_persistent_strip_step_on_perturbed_pyramids(solver_name):
                     two_point += seed % 2 == 0
                     general += seed % 2 == 1
     assert persistent >= 8 and two_point >= 2 and general >= 2, (persistent, two_point, general)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver_name", ["TGS_Soft", "SoftStep", "PGS_Soft"])
+def test_moving_read_only_bodies_shared_between_strips(solver_name):
+    """Found by a wider fuzz run (seed 205): kinematic and massless bodies are not written by the sweeps but the body stages
+    move them, so every strip that touches one keeps a copy.  With one launch per sweep the copies were re-read from HBM
+    while the owner was writing them in the same launch (a race: different bits from run to run).  Such partitions are
+    now only run by the one-launch persistent kernel, else the island goes back to colour batches."""
+    from solver2d_amd import hip
+    from tests.test_gpu_parity import gpu_vs_oracle_loose
+
+    seed = 205
+    world = fuzz_worlds.random_world(seed, n_bodies=40 + 11 * (seed % 9), n_contacts=90 + 31 * (seed % 7), n_joints=0)
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    for strip_bodies, retry in ((8, 0), (8, 1), (11, 1)):
+        with hip.Solver(0) as gpu:
+            gpu.set_option("strip_patience", 0)
+            gpu.set_option("max_group_bodies", 24)
+            gpu.set_option("strip_min_bodies", 0)
+            gpu.set_option("strip_bodies", strip_bodies)
+            gpu.set_option("strip_retry", retry)
+            for rep in range(3):
+                p = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+                gpu_vs_oracle_loose(gpu, p, world, "seed 205 %s strip_bodies %d retry %d rep %d" % (solver_name, strip_bodies, retry, rep))
+            st = gpu.stats()
+            assert st["stripCount"] == 0 or st["persistent"] == 1, st
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strip_bodies", [8, 11, 16])
+def test_written_bodies_outside_every_strip(strip_bodies):
+    """Found by the same wider fuzz run (seed 259 under XPBD through the test-only `strips_any_solver` option): a static
+    body whose rot is not a fixed point of the normalisation is WRITTEN by the position sweeps, but it is not one of the
+    loose bodies the strip partition walks, so two strips each believed they owned it.  Such a graph gets no strips."""
+    from solver2d_amd import hip
+    from tests.test_gpu_parity import gpu_vs_oracle_loose
+
+    seed = 259
+    world = fuzz_worlds.random_world(seed, n_bodies=40 + 11 * (seed % 9), n_contacts=90 + 31 * (seed % 7), n_joints=(seed % 5) * 2)
+    with hip.Solver(0) as gpu:
+        gpu.set_option("strip_patience", 0)
+        gpu.set_option("max_group_bodies", 24)
+        gpu.set_option("strip_min_bodies", 0)
+        gpu.set_option("strip_bodies", strip_bodies)
+        gpu.set_option("strips_any_solver", 1)
+        for solver_name in ("TGS_Soft", "XPBD", "PGS_NGS", "XPBD"):
+            vel, pos = common.DEFAULT_ITERS[solver_name]
+            p = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+            gpu_vs_oracle_loose(gpu, p, world, "seed 259 %s strip_bodies %d" % (solver_name, strip_bodies))

@@ -177,3 +177,44 @@ def test_written_bodies_outside_every_strip(strip_bodies):
             vel, pos = common.DEFAULT_ITERS[solver_name]
             p = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
             gpu_vs_oracle_loose(gpu, p, world, "seed 259 %s strip_bodies %d" % (solver_name, strip_bodies))
+
+
+@pytest.mark.gpu
+def test_pyramids_with_kinematic_and_massless_bodies_inside():
+    """Perturbed pyramids in which a few boxes are kinematic or massless (moving, never written by the sweeps) so that
+    they touch boxes of several strips: the persistent kernel keeps a consistent copy per workgroup; where it is not
+    eligible the island must be back on colour batches (never on the one-launch-per-sweep strip paths)."""
+    from solver2d_amd import hip
+    from tests.test_gpu_parity import gpu_vs_oracle_loose
+
+    persistent = other = 0
+    for seed in range(100, 112):
+        world = perturbed_pyramid(seed, base=26 + seed % 15)
+        rng = np.random.default_rng(seed)
+        b = world[0]
+        dyn = np.flatnonzero(b["type"] == wire.BODY_DYNAMIC)
+        for i in rng.choice(dyn, size=max(2, len(dyn) // 30), replace=False):
+            if rng.random() < 0.6:
+                b["type"][i] = wire.BODY_KINEMATIC
+            b["mass"][i] = 0
+            b["invMass"][i] = 0
+            b["I"][i] = 0
+            b["invI"][i] = 0
+            b["linearVelocity"][i] = rng.uniform(-2, 2, 2)
+            b["angularVelocity"][i] = rng.uniform(-1, 1)
+        solver_name = ("TGS_Soft", "SoftStep", "PGS_Soft")[seed % 3]
+        vel, pos = common.DEFAULT_ITERS[solver_name]
+        with hip.Solver(0) as gpu:
+            gpu.set_option("strip_patience", 0)
+            gpu.set_option("max_group_bodies", 64)
+            gpu.set_option("strip_min_bodies", 0)
+            gpu.set_option("strip_bodies", 30 + 13 * (seed % 4))
+            state = common.copy3(world)
+            for step in range(3):
+                p = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+                state = gpu_vs_oracle_loose(gpu, p, state, "kinematic pyramid seed %d %s step %d" % (seed, solver_name, step))
+            st = gpu.stats()
+            assert st["stripCount"] == 0 or st["persistent"] == 1, st
+            persistent += st["persistent"]
+            other += 1 - st["persistent"]
+    assert persistent > 0, (persistent, other)

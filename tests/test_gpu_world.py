@@ -283,3 +283,40 @@ def test_world_from_scratch_finds_every_touching_pair():
             res = s.world_download(*[out[k] for k in world_chain.WORLD_KEYS])
             world_chain.assert_device_equals_oracle(dict(zip(world_chain.WORLD_KEYS, res[:6])), ref, "from scratch step %d" % step)
             assert info["activeContacts"] == len(expected)
+
+
+@pytest.mark.parametrize("seed,solver_name", [(1, "TGS_Soft"), (2, "PGS_Soft"), (3, "SoftStep"), (4, "TGS_Sticky"), (5, "XPBD"),
+                                              (6, "Jacobi"), (7, "PGS"), (8, "PGS_NGS"), (9, "PGS_NGS_Block"), (10, "TGS_NGS")])
+def test_rain_world_loop(seed, solver_name):
+    """Fuzz of the whole loop: bodies of every shape type (two-shape bodies, rounded polygons, segments, a kinematic
+    paddle) rain into a trough.  Each step: resident pair query == oracle's, the caller creates the contacts,
+    s2amd_world_step, every array bit-exact against the oracle chain.  Contacts come and go all the time."""
+    from tests import common, oraclebind
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+    world = world_chain.rain_world(seed, 100 + 7 * seed)
+    ref = world_chain.copy_world(world)
+    separated = created = 0
+    with hip.Solver(0) as s:
+        s.world_upload(*[world[k] for k in world_chain.WORLD_KEYS])
+        for step in range(70):
+            moved = ((ref["shapes"]["enlarged"] != 0) & (ref["shapes"]["type"] != wire.SHAPE_FREE)).astype(np.uint8)
+            if moved.any():
+                got = s.world_find_pairs()
+                want = oraclebind.find_pairs(ref["bodies"], ref["shapes"], moved, _live_pairs(ref), ref["joints"])
+                assert np.array_equal(got, want), "step %d: new pairs" % step
+                if len(got):
+                    created += len(got)
+                    slots, contacts, pairs = _create_contacts(ref, got)
+                    s.world_set_contacts(slots, contacts, pairs)
+            info = s.world_step(params)
+            order, _ = s.contact_order()
+            status = world_chain.oracle_world_step(params, ref, contact_order=order)
+            separated += info["separatedCount"]
+            assert info["separatedCount"] == int((status == wire.PAIR_SEPARATED).sum()), "step %d" % step
+            if step % 3 == 2 or step < 5:
+                out = world_chain.copy_world(world)
+                res = s.world_download(*[out[k] for k in world_chain.WORLD_KEYS])
+                world_chain.assert_device_equals_oracle(dict(zip(world_chain.WORLD_KEYS, res[:6])), ref,
+                                                        "rain %d %s step %d" % (seed, solver_name, step))
+    assert separated > 20 and created > 100, (separated, created)

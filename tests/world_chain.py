@@ -95,3 +95,99 @@ def assert_device_equals_oracle(got, want, what):
             rows = np.flatnonzero([a[i].tobytes() != b[i].tobytes() for i in range(len(a))])
             raise AssertionError("%s: %s differ in fields %s, first rows %s" % (what, k, bad, rows[:5].tolist()))
         raise AssertionError("%s: %s differ" % (what, k))
+
+
+def rain_world(seed, count=120, spin=True):
+    """A fuzz world for the whole loop: `count` bodies of mixed shape types (circles, capsules, boxes, regular
+    polygons with and without rounding, a few two-shape bodies) falling into a static trough made of a box, two
+    segments and a kinematic paddle; no contacts yet, every proxy in the move buffer, plenty of free contact slots.
+    Geometry and mass are plausible rather than exact (both sides of a comparison get the same arrays)."""
+    from solver2d_amd import synthetic
+    rng = np.random.default_rng(seed)
+    margin = np.float32(synthetic.AABB_MARGIN)
+    nb = count + 3
+    bodies = np.zeros(nb, dtype=wire.body_dtype)
+    shape_list = []
+
+    def add_shape(body, kind, verts, radius, normals=None):
+        sh = np.zeros(1, dtype=wire.shape_dtype)[0]
+        sh["body"], sh["type"] = body, kind
+        sh["categoryBits"], sh["maskBits"], sh["groupIndex"] = 1, 0xFFFFFFFF, 0
+        sh["proxyKey"] = (len(shape_list) << 4) | int(bodies[body]["type"])
+        sh["count"] = len(verts)
+        sh["radius"] = radius
+        sh["vertices"][:len(verts)] = verts
+        if normals is not None:
+            sh["normals"][:len(normals)] = normals
+        q = bodies[body]["rot"]
+        p = bodies[body]["position"]
+        world = np.array([(q[1] * v[0] - q[0] * v[1] + p[0], q[0] * v[0] + q[1] * v[1] + p[1]) for v in verts], dtype=np.float32)
+        lo = world.min(axis=0) - np.float32(radius)
+        hi = world.max(axis=0) + np.float32(radius)
+        sh["aabb"] = (lo[0], lo[1], hi[0], hi[1])
+        sh["fatAABB"] = (lo[0] - margin, lo[1] - margin, hi[0] + margin, hi[1] + margin)
+        sh["enlarged"] = 1
+        shape_list.append(sh)
+
+    def ngon(n, r, phase=0.0):
+        ang = phase + 2.0 * np.pi * np.arange(n) / n
+        verts = np.stack([r * np.cos(ang), r * np.sin(ang)], axis=1).astype(np.float32)
+        mid = ang + np.pi / n
+        normals = np.stack([np.cos(mid), np.sin(mid)], axis=1).astype(np.float32)
+        return verts, normals
+
+    # the trough
+    synthetic._static_body(bodies[0], 0.0, -1.0)
+    v, n = ngon(4, 1.0)
+    hx, hy = 14.0, 1.0
+    add_shape(0, wire.SHAPE_POLYGON, [(-hx, -hy), (hx, -hy), (hx, hy), (-hx, hy)], 0.0, [(0, -1), (1, 0), (0, 1), (-1, 0)])
+    synthetic._static_body(bodies[1], 0.0, 0.0)
+    add_shape(1, wire.SHAPE_SEGMENT, [(-12.0, 0.0), (-13.5, 9.0)], 0.0)
+    add_shape(1, wire.SHAPE_SEGMENT, [(12.0, 0.0), (13.5, 9.0)], 0.0)
+    # a kinematic paddle sweeping the floor
+    synthetic._static_body(bodies[2], -6.0, 1.2)
+    bodies[2]["type"] = wire.BODY_KINEMATIC
+    bodies[2]["linearVelocity"] = (1.5, 0.0)
+    bodies[2]["angularVelocity"] = 1.0 if spin else 0.0
+    add_shape(2, wire.SHAPE_CAPSULE, [(-1.2, 0.0), (1.2, 0.0)], 0.25)
+
+    cols = 12
+    for k in range(count):
+        i = 3 + k
+        x = -8.0 + 1.45 * (k % cols) + rng.uniform(-0.15, 0.15)
+        y = 2.0 + 1.3 * (k // cols) + rng.uniform(-0.1, 0.1)
+        r = np.float32(rng.uniform(0.3, 0.55))
+        mass = np.float32(np.pi * r * r)
+        synthetic._dynamic_body(bodies[i], x, y, mass, np.float32(0.5 * mass * r * r))
+        a = rng.uniform(-np.pi, np.pi)
+        bodies[i]["rot"] = (np.sin(a), np.cos(a))
+        bodies[i]["linearVelocity"] = rng.uniform(-1.0, 1.0, 2)
+        bodies[i]["angularVelocity"] = rng.uniform(-2.0, 2.0)
+        kind = rng.integers(0, 6)
+        if kind == 0:
+            add_shape(i, wire.SHAPE_CIRCLE, [(0.0, 0.0)], r)
+        elif kind == 1:
+            add_shape(i, wire.SHAPE_CAPSULE, [(-0.6 * r, 0.0), (0.6 * r, 0.0)], 0.6 * r)
+        elif kind == 2:
+            add_shape(i, wire.SHAPE_POLYGON, [(-r, -0.7 * r), (r, -0.7 * r), (r, 0.7 * r), (-r, 0.7 * r)], 0.0,
+                      [(0, -1), (1, 0), (0, 1), (-1, 0)])
+        elif kind == 3:
+            v, n = ngon(int(rng.integers(3, 9)), r, rng.uniform(0, 1))
+            add_shape(i, wire.SHAPE_POLYGON, v, 0.0, n)
+        elif kind == 4:
+            v, n = ngon(int(rng.integers(3, 6)), 0.7 * r)
+            add_shape(i, wire.SHAPE_POLYGON, v, 0.25 * r, n)
+        else:  # two shapes on one body: a dumbbell
+            add_shape(i, wire.SHAPE_CIRCLE, [(-0.5 * r, 0.0)], 0.5 * r)
+            add_shape(i, wire.SHAPE_CIRCLE, [(0.5 * r, 0.0)], 0.5 * r)
+    shapes = np.array(shape_list, dtype=wire.shape_dtype)
+    slots = 8 * count
+    contacts = np.zeros(slots, dtype=wire.contact_dtype)
+    contacts["constraintIndex"] = -1
+    pairs = np.zeros(slots, dtype=wire.pair_state_dtype)
+    pairs["shapeA"] = -1
+    pairs["shapeB"] = -1
+    q, p, lc = bodies["rot"], bodies["position"], bodies["localCenter"]
+    origins = np.ascontiguousarray(p, dtype=np.float32).copy()
+    return {"bodies": bodies, "contacts": contacts, "joints": np.zeros(0, dtype=wire.joint_dtype), "shapes": shapes,
+            "pairs": pairs, "origins": origins}

@@ -22,6 +22,7 @@
 #include "joint.h"
 #include "shape.h"
 #include "solvers.h"
+#include "stack_allocator.h"
 #include "world.h"
 
 #include "solver2d/solver2d.h"
@@ -29,6 +30,7 @@
 #include "solver2d_amd.h"
 
 #include <dlfcn.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -678,9 +680,11 @@ static int amdReplace(void* user, const s2amdStepParams* params, s2amdBody* bodi
 	return g_amdSolve(g_amdSolver, params, bodies, bodyCapacity, contacts, contactCapacity, joints, jointCapacity);
 }
 
+static void mirrorSyncIfResident(void);
 // path == NULL: back to the reference's own solvers.  Returns 0, or a negative number naming the step that failed.
 S2REF_API int s2ref_use_amd(const char* path, int device)
 {
+	mirrorSyncIfResident();
 	if (g_amdSolver != NULL && g_amdDestroy != NULL)
 	{
 		g_amdDestroy(g_amdSolver);
@@ -718,6 +722,431 @@ S2REF_API int s2ref_use_amd(const char* path, int device)
 	g_replaceUser = NULL;
 	g_mode = 2;
 	g_replaceError = 0;
+	return 0;
+}
+
+// ---- the native shim, whole step: stage 3, s2Solve_* and stage 4 of s2World_Step on the resident world chain
+// (s2amd_world_upload / _set_contacts / _step / _download, include/solver2d_amd.h), stages 1 and 2 -- the dynamic
+// trees and the contact pool, the control plane -- stay the reference's own code.  Per step the host receives the
+// bodies, the origins, the stage-3 status words and (when a fat AABB was re-inflated) the shapes; the manifolds stay
+// in HBM until somebody asks (s2ref_pack_world, s2ref_world_sync, a re-upload, leaving the mode).
+typedef int s2amdWorldUploadFcn(s2amdSolver*, const s2amdBody*, int32_t, const s2amdContact*, int32_t, const s2amdJoint*, int32_t, const s2amdShape*,
+								int32_t, const s2amdPairState*, const float*);
+typedef int s2amdWorldStepFcn(s2amdSolver*, const s2amdStepParams*, s2amdWorldStepInfo*);
+typedef int s2amdWorldSetContactsFcn(s2amdSolver*, const int32_t*, int32_t, const s2amdContact*, const s2amdPairState*);
+typedef int s2amdWorldDownloadFcn(s2amdSolver*, s2amdBody*, int32_t, s2amdContact*, int32_t, s2amdJoint*, int32_t, s2amdShape*, int32_t,
+								  s2amdPairState*, float*, int32_t*);
+static s2amdWorldUploadFcn* g_amdWorldUpload = NULL;
+static s2amdWorldStepFcn* g_amdWorldStep = NULL;
+static s2amdWorldSetContactsFcn* g_amdWorldSetContacts = NULL;
+static s2amdWorldDownloadFcn* g_amdWorldDownload = NULL;
+static int g_wholeStep = 0;
+typedef int s2amdWorldFindPairsFcn(s2amdSolver*, int32_t*, int32_t, int32_t*);
+static s2amdWorldFindPairsFcn* g_amdWorldFindPairs = NULL;
+static int g_devicePairs = 0;
+static int32_t* g_newPairs = NULL;
+static int g_newPairCapacity = 0;
+
+typedef struct WorldMirror
+{
+	s2World* world; // whose state is resident on the device (NULL: nobody's)
+	int bodyCapacity, bodyCount, shapeCapacity, shapeCount, jointCapacity, jointCount, contactCapacity;
+	int contactsStale; // the device holds newer manifolds / impulses / joint impulses than the host pools
+	s2amdBody* bodies;
+	s2amdContact* contacts;
+	s2amdJoint* joints;
+	s2amdShape* shapes;
+	s2amdPairState* pairs;
+	float* origins;
+	int32_t* status;
+	int64_t* liveKey; // shapeIndexA << 32 | shapeIndexB of the slot as the device knows it, -1: free there
+	int32_t* slots;
+	s2amdContact* slotContacts;
+	s2amdPairState* slotPairs;
+	long uploads, steps;
+} WorldMirror;
+static WorldMirror g_mirror = {0};
+static double g_wholeMs[6] = {0}; // stage 1+2, sync in, device step, download, apply, steps
+
+static double wallMs(void)
+{
+	struct timespec t;
+	clock_gettime(CLOCK_MONOTONIC, &t);
+	return 1e3 * (double)t.tv_sec + 1e-6 * (double)t.tv_nsec;
+}
+
+static void* growTo(void* p, size_t count, size_t size)
+{
+	return realloc(p, (count > 0 ? count : 1) * size);
+}
+
+static void unpackContactsWhole(s2World* world, const s2amdContact* in, const s2amdPairState* pairs, int count)
+{
+	int n = world->contactPool.capacity < count ? world->contactPool.capacity : count;
+	for (int i = 0; i < n; ++i)
+	{
+		s2Contact* c = world->contacts + i;
+		if (s2IsFree(&c->object) || pairs[i].shapeA != c->shapeIndexA || pairs[i].shapeB != c->shapeIndexB)
+		{
+			continue; // not the contact the device knows in this slot
+		}
+		const s2amdContact* o = in + i;
+		const s2amdPairState* ps = pairs + i;
+		s2Manifold* m = &c->manifold;
+		m->pointCount = o->pointCount;
+		m->frictionPersisted = o->frictionPersisted != 0;
+		m->normal = (s2Vec2){o->normal[0], o->normal[1]};
+		m->constraintIndex = o->constraintIndex;
+		for (int j = 0; j < 2; ++j)
+		{
+			s2ManifoldPoint* p = m->points + j;
+			const s2amdManifoldPoint* q = o->points + j;
+			p->localAnchorA = (s2Vec2){q->localAnchorA[0], q->localAnchorA[1]};
+			p->localAnchorB = (s2Vec2){q->localAnchorB[0], q->localAnchorB[1]};
+			p->frictionAnchorA = (s2Vec2){q->frictionAnchorA[0], q->frictionAnchorA[1]};
+			p->frictionAnchorB = (s2Vec2){q->frictionAnchorB[0], q->frictionAnchorB[1]};
+			p->frictionNormalA = (s2Vec2){q->frictionNormalA[0], q->frictionNormalA[1]};
+			p->frictionNormalB = (s2Vec2){q->frictionNormalB[0], q->frictionNormalB[1]};
+			p->separation = q->separation;
+			p->normalImpulse = q->normalImpulse;
+			p->tangentImpulse = q->tangentImpulse;
+			p->id = ps->id[j];
+			p->persisted = ps->persisted[j] != 0;
+		}
+		c->cache.metric = ps->cacheMetric;
+		c->cache.count = ps->cacheCount;
+		for (int k = 0; k < 3; ++k)
+		{
+			c->cache.indexA[k] = ps->cacheIndexA[k];
+			c->cache.indexB[k] = ps->cacheIndexB[k];
+		}
+	}
+}
+
+// manifolds, GJK caches and joint impulses back into the reference's pools
+static int mirrorSync(void)
+{
+	WorldMirror* m = &g_mirror;
+	if (m->world == NULL || !m->contactsStale || g_amdSolver == NULL)
+	{
+		return 0;
+	}
+	int rc = g_amdWorldDownload(g_amdSolver, NULL, m->bodyCapacity, m->contacts, m->contactCapacity, m->joints, m->jointCapacity, NULL,
+								m->shapeCapacity, m->pairs, NULL, NULL);
+	if (rc != 0)
+	{
+		return rc;
+	}
+	unpackContactsWhole(m->world, m->contacts, m->pairs, m->contactCapacity);
+	if (m->world->jointPool.capacity == m->jointCapacity && m->world->jointPool.count == m->jointCount)
+	{
+		unpackJoints(m->world, m->joints); // (joints were created or destroyed: their impulses start over)
+	}
+	m->contactsStale = 0;
+	return 0;
+}
+
+static int mirrorMatches(const s2World* w)
+{
+	const WorldMirror* m = &g_mirror;
+	return m->world == w && m->bodyCapacity == w->bodyPool.capacity && m->bodyCount == w->bodyPool.count &&
+		   m->shapeCapacity == w->shapePool.capacity && m->shapeCount == w->shapePool.count && m->jointCapacity == w->jointPool.capacity &&
+		   m->jointCount == w->jointPool.count && m->contactCapacity == w->contactPool.capacity;
+}
+
+static int mirrorUpload(s2World* w)
+{
+	WorldMirror* m = &g_mirror;
+	int rc = 0;
+	if (m->world == w && (rc = mirrorSync()) != 0) // the pools changed under a resident world: its manifolds first
+	{
+		return rc;
+	}
+	int nb = w->bodyPool.capacity, ns = w->shapePool.capacity, nj = w->jointPool.capacity, nc = w->contactPool.capacity;
+	m->bodies = (s2amdBody*)growTo(m->bodies, (size_t)nb, sizeof(s2amdBody));
+	m->origins = (float*)growTo(m->origins, (size_t)nb * 2, sizeof(float));
+	m->shapes = (s2amdShape*)growTo(m->shapes, (size_t)ns, sizeof(s2amdShape));
+	m->joints = (s2amdJoint*)growTo(m->joints, (size_t)nj, sizeof(s2amdJoint));
+	m->contacts = (s2amdContact*)growTo(m->contacts, (size_t)nc, sizeof(s2amdContact));
+	m->pairs = (s2amdPairState*)growTo(m->pairs, (size_t)nc, sizeof(s2amdPairState));
+	m->status = (int32_t*)growTo(m->status, (size_t)nc, sizeof(int32_t));
+	m->liveKey = (int64_t*)growTo(m->liveKey, (size_t)nc, sizeof(int64_t));
+	m->slots = (int32_t*)growTo(m->slots, (size_t)nc, sizeof(int32_t));
+	m->slotContacts = (s2amdContact*)growTo(m->slotContacts, (size_t)nc, sizeof(s2amdContact));
+	m->slotPairs = (s2amdPairState*)growTo(m->slotPairs, (size_t)nc, sizeof(s2amdPairState));
+	packBodies(w, m->bodies);
+	packShapes(w, m->shapes);
+	packJoints(w, m->joints);
+	packContacts(w, m->contacts);
+	packPairs(w, m->pairs);
+	for (int i = 0; i < nb; ++i)
+	{
+		m->origins[2 * i] = w->bodies[i].origin.x;
+		m->origins[2 * i + 1] = w->bodies[i].origin.y;
+	}
+	for (int i = 0; i < nc; ++i)
+	{
+		m->liveKey[i] = m->pairs[i].shapeA < 0 ? -1 : ((int64_t)m->pairs[i].shapeA << 32) | (int64_t)m->pairs[i].shapeB;
+	}
+	rc = g_amdWorldUpload(g_amdSolver, m->bodies, nb, m->contacts, nc, m->joints, nj, m->shapes, ns, m->pairs, m->origins);
+	if (rc != 0)
+	{
+		m->world = NULL;
+		return rc;
+	}
+	m->world = w;
+	m->bodyCapacity = nb, m->bodyCount = w->bodyPool.count;
+	m->shapeCapacity = ns, m->shapeCount = w->shapePool.count;
+	m->jointCapacity = nj, m->jointCount = w->jointPool.count;
+	m->contactCapacity = nc;
+	m->contactsStale = 0;
+	m->uploads += 1;
+	return 0;
+}
+
+// contacts stage 1 created since the device last saw the pool (the pool never frees a slot on its own between steps:
+// stage 3's separations are applied to both sides below)
+static int mirrorSendNewContacts(s2World* w)
+{
+	WorldMirror* m = &g_mirror;
+	int count = 0;
+	for (int i = 0; i < m->contactCapacity; ++i)
+	{
+		const s2Contact* c = w->contacts + i;
+		int64_t live = s2IsFree(&c->object) ? -1 : ((int64_t)c->shapeIndexA << 32) | (int64_t)c->shapeIndexB;
+		if (live >= 0 && m->liveKey[i] < 0)
+		{
+			s2amdContact* o = m->slotContacts + count;
+			s2amdPairState* ps = m->slotPairs + count;
+			memset(o, 0, sizeof(*o));
+			memset(ps, 0, sizeof(*ps));
+			o->bodyA = c->edges[0].bodyIndex;
+			o->bodyB = c->edges[1].bodyIndex;
+			o->friction = c->friction;
+			o->constraintIndex = -1;
+			ps->shapeA = c->shapeIndexA;
+			ps->shapeB = c->shapeIndexB;
+			m->slots[count++] = i;
+			m->liveKey[i] = live;
+		}
+		else if (live != m->liveKey[i])
+		{
+			return 1; // somebody destroyed a contact behind our back (s2DestroyBody, s2CreateJoint ...): upload again
+		}
+	}
+	return count > 0 ? g_amdWorldSetContacts(g_amdSolver, m->slots, count, m->slotContacts, m->slotPairs) : 0;
+}
+
+void __real_s2UpdateBroadPhasePairs(s2World* world);
+// The reference's own s2World_Step: oracle/Makefile renames the symbol in the compiled world.o (objcopy, the source is
+// untouched) so that THIS library's exported s2World_Step is the function below -- programs linked against the
+// public API reach it without knowing.
+void s2ref_World_Step_reference(s2WorldId worldId, float timeStep, int velIters, int posIters, bool warmStart);
+S2REF_API void s2World_Step(s2WorldId worldId, float timeStep, int velIters, int posIters, bool warmStart)
+{
+	if (!g_wholeStep || g_amdSolver == NULL)
+	{
+		s2ref_World_Step_reference(worldId, timeStep, velIters, posIters, warmStart);
+		return;
+	}
+	s2World* world = s2GetWorldFromId(worldId);
+	WorldMirror* m = &g_mirror;
+	world->stepId += 1;
+	const double t0 = wallMs();
+	int rc = 0;
+	if (g_devicePairs && mirrorMatches(world))
+	{
+		// stage 1 with the pair discovery on the device (s2amd_world_find_pairs on the boxes the last refit re-inflated
+		// -- the proxies in the reference's move buffer); the pool bookkeeping of each new pair is s2CreateContact as ever.
+		// The pairs arrive sorted, not in the reference's tree-traversal order: contacts get other pool slots than with
+		// the host's stage 1.  The trees keep following the fat boxes (below) for the reference's ray casts and queries.
+		s2BroadPhase* bp = &world->broadPhase;
+		if (s2Array(bp->moveArray).count > 0)
+		{
+			int32_t count = 0;
+			rc = g_amdWorldFindPairs(g_amdSolver, g_newPairs, g_newPairCapacity, &count);
+			if (rc == S2AMD_E_CAPACITY)
+			{
+				g_newPairCapacity = count + 1024;
+				g_newPairs = (int32_t*)realloc(g_newPairs, (size_t)g_newPairCapacity * 2 * sizeof(int32_t));
+				rc = g_amdWorldFindPairs(g_amdSolver, g_newPairs, g_newPairCapacity, &count);
+			}
+			for (int i = 0; rc == 0 && i < count; ++i)
+			{
+				s2CreateContact(world, world->shapes + g_newPairs[2 * i], world->shapes + g_newPairs[2 * i + 1]);
+			}
+			s2Array_Clear(bp->moveArray);
+			s2ClearSet(&bp->moveSet);
+		}
+	}
+	else
+	{
+		// stages 1 and 2 (src/world.c:125-130): the reference's trees, the reference's contact pool
+		__real_s2UpdateBroadPhasePairs(world);
+		s2BroadPhase_RebuildTrees(&world->broadPhase);
+	}
+	const double t1 = wallMs();
+
+	if (rc == 0 && (!mirrorMatches(world) || (rc = mirrorSendNewContacts(world)) == 1))
+	{
+		rc = mirrorUpload(world);
+	}
+	s2amdStepParams params;
+	params.solverType = (int32_t)world->solverType;
+	params.dt = timeStep;
+	params.velIters = velIters;
+	params.posIters = posIters;
+	params.warmStart = warmStart ? 1 : 0;
+	params.gravity[0] = world->gravity.x;
+	params.gravity[1] = world->gravity.y;
+	s2amdWorldStepInfo info = {0};
+	const double t2 = wallMs();
+	if (rc == 0)
+	{
+		rc = g_amdWorldStep(g_amdSolver, &params, &info);
+	}
+	const double t3 = wallMs();
+	if (rc == 0)
+	{
+		rc = g_amdWorldDownload(g_amdSolver, m->bodies, m->bodyCapacity, NULL, m->contactCapacity, NULL, m->jointCapacity,
+								info.movedCount > 0 ? m->shapes : NULL, m->shapeCapacity, NULL, m->origins,
+								info.separatedCount > 0 ? m->status : NULL);
+	}
+	if (rc != 0)
+	{
+		const char* (*lastError)(void) = (const char* (*)(void))dlsym(g_amdLib, "s2amd_last_error");
+		fprintf(stderr, "s2World_Step on the GPU failed (%d): %s\n", rc, lastError ? lastError() : "?");
+		g_replaceError = rc;
+		m->world = NULL;
+		return;
+	}
+	const double t4 = wallMs();
+	m->contactsStale = 1;
+	m->steps += 1;
+	unpackBodies(world, m->bodies);
+	for (int i = 0; i < m->bodyCapacity; ++i)
+	{
+		s2Body* b = world->bodies + i;
+		if (s2IsFree(&b->object) || b->type == s2_staticBody)
+		{
+			continue;
+		}
+		b->origin = (s2Vec2){m->origins[2 * i], m->origins[2 * i + 1]};
+		b->force = s2Vec2_zero;
+		b->torque = 0.0f;
+	}
+	if (info.separatedCount > 0)
+	{
+		// src/world.c:163-167
+		for (int i = 0; i < m->contactCapacity; ++i)
+		{
+			if (m->status[i] == S2AMD_PAIR_SEPARATED)
+			{
+				s2DestroyContact(world, world->contacts + i);
+				m->liveKey[i] = -1;
+			}
+		}
+	}
+	if (info.movedCount > 0)
+	{
+		// src/world.c:259-297: the tight boxes of every shape, the tree only where the fat box was re-inflated -- in the
+		// reference's order (bodies, then each body's shape list): the move buffer's order decides the pool slots of the
+		// contacts stage 1 creates next step
+		for (int b = 0; b < m->bodyCapacity; ++b)
+		{
+			const s2Body* body = world->bodies + b;
+			if (s2IsFree(&body->object) || body->type == s2_staticBody)
+			{
+				continue;
+			}
+			for (int i = body->shapeList; i != S2_NULL_INDEX; i = world->shapes[i].nextShapeIndex)
+			{
+				s2Shape* sh = world->shapes + i;
+				const s2amdShape* o = m->shapes + i;
+				sh->aabb = (s2Box){{o->aabb[0], o->aabb[1]}, {o->aabb[2], o->aabb[3]}};
+				if (o->enlarged)
+				{
+					sh->fatAABB = (s2Box){{o->fatAABB[0], o->fatAABB[1]}, {o->fatAABB[2], o->fatAABB[3]}};
+					s2BroadPhase_EnlargeProxy(&world->broadPhase, sh->proxyKey, sh->fatAABB);
+				}
+			}
+		}
+	}
+	s2GrowStack(world->stackAllocator);
+	const double t5 = wallMs();
+	g_wholeMs[0] += t1 - t0, g_wholeMs[1] += t2 - t1, g_wholeMs[2] += t3 - t2, g_wholeMs[3] += t4 - t3, g_wholeMs[4] += t5 - t4, g_wholeMs[5] += 1.0;
+}
+
+// Accumulated wall time of the whole-step shim's phases since the last call: stage 1 + 2 on the host, new contacts /
+// upload, s2amd_world_step, download, applying the results to the pools and trees; [5] = steps.
+S2REF_API void s2ref_world_timing(double out[6])
+{
+	for (int i = 0; i < 6; ++i)
+	{
+		out[i] = g_wholeMs[i];
+		g_wholeMs[i] = 0.0;
+	}
+}
+
+// The host pools of `id` brought up to date with the device (manifolds, caches, joint impulses).
+S2REF_API int s2ref_world_sync(s2WorldId id)
+{
+	return g_mirror.world == s2GetWorldFromId(id) ? mirrorSync() : 0;
+}
+
+// After editing a resident world through the reference's API (velocities, forces, filters, joints' settings ...):
+// the next step uploads it again.  Creating or destroying bodies, shapes and joints is noticed without this.
+S2REF_API void s2ref_world_invalidate(void)
+{
+	mirrorSync();
+	g_mirror.world = NULL;
+}
+
+// on: stage 1's pair discovery on the device as well (the host trees are still kept up to date, not queried)
+S2REF_API void s2ref_world_device_pairs(int on)
+{
+	g_devicePairs = on;
+}
+
+S2REF_API long s2ref_world_uploads(void)
+{
+	return g_mirror.uploads;
+}
+
+static void mirrorSyncIfResident(void)
+{
+	if (g_wholeStep)
+	{
+		mirrorSync();
+		g_mirror.world = NULL;
+		g_wholeStep = 0;
+	}
+}
+
+// As s2ref_use_amd, plus stage 3 and stage 4: the whole of s2World_Step but its tree and pool bookkeeping on the GPU.
+S2REF_API int s2ref_use_amd_world(const char* path, int device)
+{
+	if (g_wholeStep)
+	{
+		mirrorSync();
+	}
+	g_wholeStep = 0;
+	g_mirror.world = NULL;
+	int rc = s2ref_use_amd(path, device);
+	if (rc != 0 || path == NULL)
+	{
+		return rc;
+	}
+	g_amdWorldUpload = (s2amdWorldUploadFcn*)dlsym(g_amdLib, "s2amd_world_upload");
+	g_amdWorldStep = (s2amdWorldStepFcn*)dlsym(g_amdLib, "s2amd_world_step");
+	g_amdWorldSetContacts = (s2amdWorldSetContactsFcn*)dlsym(g_amdLib, "s2amd_world_set_contacts");
+	g_amdWorldDownload = (s2amdWorldDownloadFcn*)dlsym(g_amdLib, "s2amd_world_download");
+	g_amdWorldFindPairs = (s2amdWorldFindPairsFcn*)dlsym(g_amdLib, "s2amd_world_find_pairs");
+	if (!g_amdWorldUpload || !g_amdWorldStep || !g_amdWorldSetContacts || !g_amdWorldDownload || !g_amdWorldFindPairs)
+	{
+		return -4;
+	}
+	g_wholeStep = 1;
 	return 0;
 }
 
@@ -760,6 +1189,10 @@ S2REF_API int s2ref_world_sizes(s2WorldId id, int32_t* bodyCapacity, int32_t* co
 S2REF_API int s2ref_pack_world(s2WorldId id, s2amdBody* bodies, s2amdContact* contacts, s2amdJoint* joints)
 {
 	s2World* world = s2GetWorldFromId(id);
+	if (g_mirror.world == world)
+	{
+		mirrorSync();
+	}
 	if (bodies)
 		packBodies(world, bodies);
 	if (contacts)

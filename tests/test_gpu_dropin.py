@@ -108,3 +108,83 @@ def test_native_shim_public_api_runs_on_the_gpu(scene, p0, solver_name, steps):
         br, cr, jr = routed.pack()
     assert bn.tobytes() == br.tobytes() and cn.tobytes() == cr.tobytes() and jn.tobytes() == jr.tobytes()
     assert np.isfinite(bn["position"][bn["type"] >= 0]).all()
+
+
+@pytest.mark.parametrize("scene,p0,solver_name,steps", [("pyramid", 20, "TGS_Soft", 60), ("mixed", 24, "PGS_NGS", 60), ("tumbler", 150, "SoftStep", 60),
+                                                        ("joint_grid", 10, "TGS_NGS", 40), ("circle_pile", 16, "XPBD", 60), ("mixed", 24, "Jacobi", 60)])
+def test_native_shim_whole_step_on_the_gpu(scene, p0, solver_name, steps):
+    """oracle/ref_hook.c: s2ref_use_amd_world: the library's exported s2World_Step keeps the reference's stage 1 and 2 (dynamic
+    trees, contact pool) and runs stage 3, the solve and stage 4 on the resident world chain (s2amd_world_step), bringing
+    back bodies, separations and re-inflated boxes every step and the manifolds on demand.  The trajectory must be the one
+    the solver-only shim produces -- the device's narrow phase and refit are bit-exact restatements of the host's, the
+    constraint graph and hence the sweep order are the same --, bit for bit: bodies, manifolds, impulses, pair table."""
+    import ctypes
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    L = refbind.lib()
+    for f in (L.s2ref_use_amd, L.s2ref_use_amd_world):
+        f.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        f.restype = ctypes.c_int
+    L.s2ref_world_uploads.restype = ctypes.c_long
+    p1 = 10 if scene == "joint_grid" else 0
+    results = []
+    for use in (L.s2ref_use_amd_world, L.s2ref_use_amd):
+        with refbind.RefWorld(scene, solver_name, p0, p1) as w:
+            assert use(hip.LIB_PATH.encode(), 0) == 0
+            uploads0 = L.s2ref_world_uploads()
+            try:
+                for _ in range(steps):
+                    w.step(1.0 / 60.0, vel, pos, True)
+                assert L.s2ref_replace_error() == 0
+                b, c, j = w.pack()
+                pairs = w.contact_pairs()
+                uploads = L.s2ref_world_uploads() - uploads0
+            finally:
+                assert use(None, 0) == 0
+            results.append((b, c, j, pairs, uploads))
+    (bw, cw, jw, pw, uw), (bs, cs, js, ps, us) = results
+    assert us == 0 and 1 <= uw <= 4, (uw, us)  # the world is uploaded once, and again only when the contact pool grew
+    assert np.array_equal(pw[0], ps[0]) and np.array_equal(pw[1], ps[1]), "pair tables differ"
+    live = bs["type"] >= 0
+    assert np.isfinite(bw["position"][live]).all()
+    common.compare_exact((bw, cw, jw), (bs, cs, js), "whole-step shim vs solver-only shim")
+
+
+@pytest.mark.parametrize("scene,p0,solver_name,steps", [("pyramid", 20, "TGS_Soft", 90), ("circle_pile", 16, "PGS_Soft", 80), ("tumbler", 150, "SoftStep", 60)])
+def test_native_shim_whole_step_with_device_pairs(scene, p0, solver_name, steps):
+    """As above with stage 1's pair discovery on the device too (s2ref_world_device_pairs): the reference's trees are
+    kept up to date but no longer queried.  New pairs arrive sorted instead of in tree-traversal order, so contacts land
+    in other pool slots and the Gauss-Seidel order differs: checked like any reordering (L3) -- the same SET of pairs
+    and positions within the stated tolerance on the scenes that settle, sanity on the one that tumbles -- and after
+    every run the pool must hold no duplicate pair and no pair whose fat boxes are apart."""
+    import ctypes
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    L = refbind.lib()
+    L.s2ref_use_amd_world.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    L.s2ref_use_amd_world.restype = ctypes.c_int
+    results = []
+    for device_pairs in (1, 0):
+        with refbind.RefWorld(scene, solver_name, p0, 0) as w:
+            assert L.s2ref_use_amd_world(hip.LIB_PATH.encode(), 0) == 0
+            L.s2ref_world_device_pairs(device_pairs)
+            try:
+                for _ in range(steps):
+                    w.step(1.0 / 60.0, vel, pos, True)
+                assert L.s2ref_replace_error() == 0
+                b, c, j = w.pack()
+                pa, pb = w.contact_pairs()
+            finally:
+                L.s2ref_world_device_pairs(0)
+                assert L.s2ref_use_amd_world(None, 0) == 0
+            live = pa >= 0
+            pairs = sorted(zip(pa[live].tolist(), pb[live].tolist()))
+            assert len(set(pairs)) == len(pairs), "duplicate contact"
+            results.append((b, pairs, int((c["pointCount"] > 0).sum())))
+    (bd, pd, nd), (bh, ph, nh) = results
+    live = bh["type"] >= 0
+    assert np.isfinite(bd["position"][live]).all()
+    if scene == "tumbler":
+        assert abs(len(pd) - len(ph)) <= 0.1 * len(ph) + 5 and abs(nd - nh) <= 0.1 * nh + 5, (len(pd), len(ph), nd, nh)
+    else:
+        dev = float(np.abs(bd["position"][live] - bh["position"][live]).max())
+        assert dev <= 0.02, "device-pairs route deviates %.4g m from the host-pairs route" % dev
+        assert pd == ph, "pair sets differ: %d vs %d" % (len(pd), len(ph))

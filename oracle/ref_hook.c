@@ -796,7 +796,10 @@ static void unpackContactsWhole(s2World* world, const s2amdContact* in, const s2
 		m->pointCount = o->pointCount;
 		m->frictionPersisted = o->frictionPersisted != 0;
 		m->normal = (s2Vec2){o->normal[0], o->normal[1]};
-		m->constraintIndex = o->constraintIndex;
+		if (o->constraintIndex >= 0)
+		{
+			m->constraintIndex = o->constraintIndex; // (the wire's -1: not in a constraint array this step; the reference keeps the stale index)
+		}
 		for (int j = 0; j < 2; ++j)
 		{
 			s2ManifoldPoint* p = m->points + j;

@@ -110,8 +110,11 @@ def test_native_shim_public_api_runs_on_the_gpu(scene, p0, solver_name, steps):
     assert np.isfinite(bn["position"][bn["type"] >= 0]).all()
 
 
-@pytest.mark.parametrize("scene,p0,solver_name,steps", [("pyramid", 20, "TGS_Soft", 60), ("mixed", 24, "PGS_NGS", 60), ("tumbler", 150, "SoftStep", 60),
-                                                        ("joint_grid", 10, "TGS_NGS", 40), ("circle_pile", 16, "XPBD", 60), ("mixed", 24, "Jacobi", 60)])
+WHOLE_STEP_CASES = [("pyramid", 20, "TGS_Soft", 60), ("joint_grid", 10, "TGS_NGS", 40), ("circle_pile", 16, "XPBD", 60), ("pyramid", 45, "PGS_Soft", 30)]
+WHOLE_STEP_CASES += [("mixed", 24, name, 60) for name in wire.SOLVER_NAMES] + [("tumbler", 150, name, 50) for name in wire.SOLVER_NAMES]
+
+
+@pytest.mark.parametrize("scene,p0,solver_name,steps", WHOLE_STEP_CASES)
 def test_native_shim_whole_step_on_the_gpu(scene, p0, solver_name, steps):
     """oracle/ref_hook.c: s2ref_use_amd_world: the library's exported s2World_Step keeps the reference's stage 1 and 2 (dynamic
     trees, contact pool) and runs stage 3, the solve and stage 4 on the resident world chain (s2amd_world_step), bringing

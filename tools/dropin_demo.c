@@ -6,7 +6,7 @@
  * prebuilt library (the GPU box: only this file's own declarations are needed, see below).
  *
  *   gcc -O2 tools/dropin_demo.c -o gpurun_out/dropin_demo -Loracle/_ref -ls2ref -Wl,-rpath,$PWD/oracle/_ref -lm
- *   gpurun_out/dropin_demo 200 60 solver2d_amd/libs2amd.so
+ *   gpurun_out/dropin_demo 200 60 solver2d_amd/libs2amd.so [scene solverId velIters posIters settleSteps]
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -37,31 +37,34 @@ static double now(void)
 	return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
 }
 
+static const char* g_scene = "pyramid";
+static int g_solver = 7; /* s2_solverTGS_Soft, enum s2SolverType, types.h:75-88 */
+static int g_vel = 8, g_pos = 4, g_settle = 5;
+
 static double run(int base, int steps, const char* lib, int whole)
 {
-	const int TGS_Soft = 7; /* enum s2SolverType, types.h:75-88 */
-	s2WorldId w = s2scene_create("pyramid", TGS_Soft, base, 0);
+	s2WorldId w = s2scene_create(g_scene, g_solver, base, 0);
 	s2ref_world_device_pairs(whole == 2);
 	if (lib != NULL && (whole ? s2ref_use_amd_world(lib, 0) : s2ref_use_amd(lib, 0)) != 0)
 	{
 		fprintf(stderr, "could not load %s\n", lib);
 		exit(1);
 	}
-	for (int i = 0; i < 5; ++i)
+	for (int i = 0; i < g_settle; ++i)
 	{
-		s2World_Step(w, 1.0f / 60.0f, 8, 4, 1);
+		s2World_Step(w, 1.0f / 60.0f, g_vel, g_pos, 1);
 	}
 	double phases[6];
 	s2ref_world_timing(phases);
 	double t0 = now();
 	for (int i = 0; i < steps; ++i)
 	{
-		s2World_Step(w, 1.0f / 60.0f, 8, 4, 1);
+		s2World_Step(w, 1.0f / 60.0f, g_vel, g_pos, 1);
 	}
 	double ms = 1e3 * (now() - t0) / steps;
 	int32_t nb = 0, nc = 0, nj = 0;
 	s2ref_world_sizes(w, &nb, &nc, &nj);
-	printf("%-34s base %d: %d body slots, %d contact slots, %.3f ms per s2World_Step%s\n", lib ? (whole == 2 ? "+ stage 1 pair query on the MI355X" : whole ? "stages 3, solve, 4 on the MI355X" : "solver on the MI355X") : "reference (1 thread)", base,
+	printf("%-34s %s %d: %d body slots, %d contact slots, %.3f ms per s2World_Step%s\n", lib ? (whole == 2 ? "+ stage 1 pair query on the MI355X" : whole ? "stages 3, solve, 4 on the MI355X" : "solver on the MI355X") : "reference (1 thread)", g_scene, base,
 		   nb, nc, ms, lib && s2ref_replace_error() ? "  (solver reported an error)" : "");
 	s2ref_world_timing(phases);
 	if (whole && phases[5] > 0)
@@ -82,6 +85,12 @@ int main(int argc, char** argv)
 	int base = argc > 1 ? atoi(argv[1]) : 100;
 	int steps = argc > 2 ? atoi(argv[2]) : 30;
 	const char* lib = argc > 3 ? argv[3] : "solver2d_amd/libs2amd.so";
+	/* optional: scene, solver id, velocity iterations, position iterations, settling steps */
+	g_scene = argc > 4 ? argv[4] : g_scene;
+	g_solver = argc > 5 ? atoi(argv[5]) : g_solver;
+	g_vel = argc > 6 ? atoi(argv[6]) : g_vel;
+	g_pos = argc > 7 ? atoi(argv[7]) : g_pos;
+	g_settle = argc > 8 ? atoi(argv[8]) : g_settle;
 	double cpu = run(base, steps, NULL, 0);
 	double gpu = run(base, steps, lib, 0);
 	double whole = run(base, steps, lib, 1);

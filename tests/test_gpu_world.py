@@ -320,3 +320,49 @@ def test_rain_world_loop(seed, solver_name):
                 world_chain.assert_device_equals_oracle(dict(zip(world_chain.WORLD_KEYS, res[:6])), ref,
                                                         "rain %d %s step %d" % (seed, solver_name, step))
     assert separated > 20 and created > 100, (separated, created)
+
+
+@pytest.mark.parametrize("seed,solver_name", [(0, "TGS_Soft"), (14, "PGS_Soft"), (19, "SoftStep"), (4, "PGS"), (5, "XPBD")])
+def test_wrecking_ball_world_loop(seed, solver_name):
+    """Heavy balls shot into a pyramid, whole loop (pair query, contact creation, s2amd_world_step) for 70 steps with the
+    strip options drawn at random: bursts of graph changes (structure rebuilt, patience counter) alternate with quiet
+    stretches on the strip / persistent kernels.  Bit-exact against the oracle chain; a one-off run of 110 seeds found
+    no difference."""
+    from tests import common, oraclebind
+    rng = np.random.default_rng(1000 + seed)
+    base = int(rng.integers(30, 75))
+    world = world_chain.wreck_world(seed, base)
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+    ref = world_chain.copy_world(world)
+    changed = strips = created = 0
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", int(rng.integers(0, 4)))
+        s.set_option("strip_min_bodies", 0)
+        s.set_option("strip_bodies", int(rng.integers(40, 200)))
+        s.set_option("max_group_bodies", int(rng.choice([64, 512, 2816])))
+        s.world_upload(*[world[k] for k in world_chain.WORLD_KEYS])
+        for step in range(70):
+            moved = ((ref["shapes"]["enlarged"] != 0) & (ref["shapes"]["type"] != wire.SHAPE_FREE)).astype(np.uint8)
+            if moved.any():
+                got = s.world_find_pairs()
+                want = oraclebind.find_pairs(ref["bodies"], ref["shapes"], moved, _live_pairs(ref), ref["joints"])
+                assert np.array_equal(got, want), "step %d: new pairs" % step
+                if len(got):
+                    created += len(got)
+                    slots, contacts, pairs = _create_contacts(ref, got)
+                    s.world_set_contacts(slots, contacts, pairs)
+            info = s.world_step(params)
+            order, _ = s.contact_order()
+            status = world_chain.oracle_world_step(params, ref, contact_order=order)
+            assert info["separatedCount"] == int((status == wire.PAIR_SEPARATED).sum()), "step %d" % step
+            changed += info["graphChanged"]
+            strips += 1 if s.stats()["stripCount"] > 0 else 0
+            if step % 4 == 3 or step < 3:
+                out = world_chain.copy_world(world)
+                res = s.world_download(*[out[k] for k in world_chain.WORLD_KEYS])
+                world_chain.assert_device_equals_oracle(dict(zip(world_chain.WORLD_KEYS, res[:6])), ref,
+                                                        "wreck %d %s step %d" % (seed, solver_name, step))
+    assert changed > 20 and created > 50, (changed, created)
+    if seed in (0, 14, 19):
+        assert strips > 0

@@ -191,3 +191,42 @@ def rain_world(seed, count=120, spin=True):
     origins = np.ascontiguousarray(p, dtype=np.float32).copy()
     return {"bodies": bodies, "contacts": contacts, "joints": np.zeros(0, dtype=wire.joint_dtype), "shapes": shapes,
             "pairs": pairs, "origins": origins}
+
+
+def wreck_world(seed, base):
+    """A pyramid world with one to three heavy balls flying into it and spare contact slots: bursts of created and
+    destroyed contacts between stretches where the pile is quiet enough for the strip paths."""
+    from solver2d_amd import synthetic
+    rng = np.random.default_rng(seed)
+    w = synthetic.pyramid_world(base)
+    nb = len(w["bodies"])
+    balls = int(rng.integers(1, 4))
+    bodies = np.concatenate([w["bodies"], np.zeros(balls, dtype=wire.body_dtype)])
+    shapes = np.concatenate([w["shapes"], np.zeros(balls, dtype=wire.shape_dtype)])
+    origins = np.concatenate([w["origins"], np.zeros((balls, 2), dtype=np.float32)])
+    for k in range(balls):
+        i = nb + k
+        r = np.float32(rng.uniform(0.6, 1.5))
+        side = -1.0 if rng.random() < 0.5 else 1.0
+        x = side * (0.5 * base + 6.0 + 4.0 * k)
+        y = rng.uniform(2.0, 0.6 * base)
+        mass = np.float32(20.0 * np.pi * r * r)
+        synthetic._dynamic_body(bodies[i], x, y, mass, np.float32(0.5 * mass * r * r))
+        bodies[i]["linearVelocity"] = (-side * rng.uniform(15.0, 40.0), rng.uniform(0.0, 6.0))
+        sh = shapes[i]
+        sh["body"], sh["type"] = i, wire.SHAPE_CIRCLE
+        sh["categoryBits"], sh["maskBits"] = 1, 0xFFFFFFFF
+        sh["proxyKey"] = (i << 4) | wire.BODY_DYNAMIC
+        sh["radius"] = r
+        m = np.float32(synthetic.AABB_MARGIN)
+        sh["aabb"] = (x - r, y - r, x + r, y + r)
+        sh["fatAABB"] = (x - r - m, y - r - m, x + r + m, y + r + m)
+        sh["enlarged"] = 1
+        origins[i] = (x, y)
+    extra = 4 * len(w["contacts"]) // 3 + 256
+    contacts = np.concatenate([w["contacts"], np.zeros(extra, dtype=wire.contact_dtype)])
+    contacts["constraintIndex"][len(w["contacts"]):] = -1
+    pairs = np.concatenate([w["pairs"], np.zeros(extra, dtype=wire.pair_state_dtype)])
+    pairs["shapeA"][len(w["pairs"]):] = -1
+    pairs["shapeB"][len(w["pairs"]):] = -1
+    return {"bodies": bodies, "contacts": contacts, "joints": w["joints"], "shapes": shapes, "pairs": pairs, "origins": origins}

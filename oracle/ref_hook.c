@@ -750,6 +750,8 @@ static int g_newPairCapacity = 0;
 typedef struct WorldMirror
 {
 	s2World* world; // whose state is resident on the device (NULL: nobody's)
+	uint64_t stepId; // s2World.stepId after the last step taken here: worlds live in a static array, a new world reuses the
+	                 // address of a destroyed one (and starts at 0 again); steps taken elsewhere show up too
 	int bodyCapacity, bodyCount, shapeCapacity, shapeCount, jointCapacity, jointCount, contactCapacity;
 	int contactsStale; // the device holds newer manifolds / impulses / joint impulses than the host pools
 	s2amdBody* bodies;
@@ -830,7 +832,8 @@ static void unpackContactsWhole(s2World* world, const s2amdContact* in, const s2
 static int mirrorSync(void)
 {
 	WorldMirror* m = &g_mirror;
-	if (m->world == NULL || !m->contactsStale || g_amdSolver == NULL)
+	const uint64_t id = m->world ? (uint64_t)m->world->stepId : 0;
+	if (m->world == NULL || (id != m->stepId && id != m->stepId + 1) || !m->contactsStale || g_amdSolver == NULL)
 	{
 		return 0;
 	}
@@ -852,7 +855,7 @@ static int mirrorSync(void)
 static int mirrorMatches(const s2World* w)
 {
 	const WorldMirror* m = &g_mirror;
-	return m->world == w && m->bodyCapacity == w->bodyPool.capacity && m->bodyCount == w->bodyPool.count &&
+	return m->world == w && m->stepId + 1 == (uint64_t)w->stepId && m->bodyCapacity == w->bodyPool.capacity && m->bodyCount == w->bodyPool.count &&
 		   m->shapeCapacity == w->shapePool.capacity && m->shapeCount == w->shapePool.count && m->jointCapacity == w->jointPool.capacity &&
 		   m->jointCount == w->jointPool.count && m->contactCapacity == w->contactPool.capacity;
 }
@@ -1026,6 +1029,7 @@ S2REF_API void s2World_Step(s2WorldId worldId, float timeStep, int velIters, int
 	const double t4 = wallMs();
 	m->contactsStale = 1;
 	m->steps += 1;
+	m->stepId = (uint64_t)world->stepId;
 	unpackBodies(world, m->bodies);
 	for (int i = 0; i < m->bodyCapacity; ++i)
 	{

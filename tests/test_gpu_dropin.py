@@ -191,3 +191,35 @@ def test_native_shim_whole_step_with_device_pairs(scene, p0, solver_name, steps)
         dev = float(np.abs(bd["position"][live] - bh["position"][live]).max())
         assert dev <= 0.02, "device-pairs route deviates %.4g m from the host-pairs route" % dev
         assert pd == ph, "pair sets differ: %d vs %d" % (len(pd), len(ph))
+
+
+def test_native_shim_whole_step_notices_a_replaced_world():
+    """Worlds live in a static array in the reference: a world destroyed and created again sits at the same address with
+    pools of the same size.  The shim must not mistake it for the world it holds on the device (s2World.stepId says so), and
+    a step taken by the reference itself in between (mode off and on again) must be noticed the same way."""
+    import ctypes
+    L = refbind.lib()
+    L.s2ref_use_amd_world.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    L.s2ref_use_amd_world.restype = ctypes.c_int
+    vel, pos = common.DEFAULT_ITERS["TGS_Soft"]
+    assert L.s2ref_use_amd_world(hip.LIB_PATH.encode(), 0) == 0
+    try:
+        with refbind.RefWorld("mixed", "TGS_Soft", 24, 0) as first:
+            for _ in range(10):
+                first.step(1.0 / 60.0, vel, pos, True)
+        with refbind.RefWorld("mixed", "TGS_Soft", 24, 0) as second:
+            for _ in range(20):
+                second.step(1.0 / 60.0, vel, pos, True)
+            got = second.pack()
+        assert L.s2ref_replace_error() == 0
+    finally:
+        assert L.s2ref_use_amd_world(None, 0) == 0
+    assert L.s2ref_use_amd_world(hip.LIB_PATH.encode(), 0) == 0
+    try:
+        with refbind.RefWorld("mixed", "TGS_Soft", 24, 0) as fresh:
+            for _ in range(20):
+                fresh.step(1.0 / 60.0, vel, pos, True)
+            want = fresh.pack()
+    finally:
+        assert L.s2ref_use_amd_world(None, 0) == 0
+    common.compare_exact(got, want, "second world in the same slot vs a fresh run")

@@ -13,9 +13,9 @@ def copy_world(world):
     return {k: world[k].copy() for k in WORLD_KEYS}
 
 
-def oracle_world_step(params, world, contact_order=None, joint_order=None):
+def oracle_world_step(params, world, contact_order=None, joint_order=None, reverse=False):
     """In place; returns the stage-3 status.  A separated pair is destroyed as src/world.c:149-167 does: no manifold,
-    free pair slot."""
+    free pair slot.  reverse: sweep the active contacts in reversed pool order (the yardstick of order sensitivity)."""
     w = world
     w["origins"] = np.ascontiguousarray(w["origins"], dtype=np.float32)
     status = oraclebind.update_contacts(w["bodies"], w["origins"], w["shapes"], w["pairs"], w["contacts"])
@@ -23,6 +23,8 @@ def oracle_world_step(params, world, contact_order=None, joint_order=None):
     w["contacts"]["pointCount"][sep] = 0
     w["pairs"]["shapeA"][sep] = -1
     w["pairs"]["shapeB"][sep] = -1
+    if reverse:
+        contact_order = np.flatnonzero(w["contacts"]["pointCount"] > 0)[::-1].astype(np.int32)
     oraclebind.solve(params, w["bodies"], w["contacts"], w["joints"], contact_order=contact_order, joint_order=joint_order)
     oraclebind.refit_shapes(w["bodies"], w["shapes"], w["origins"])
     # stage 4 also consumes the applied forces of every non-static body (src/world.c:274-275)

@@ -419,3 +419,44 @@ def test_settling_pyramid_physical_tolerances(solver_name):
     sink = float(world["bodies"]["position"][top, 1] - b["position"][top, 1])
     assert 0.0 <= sink < (0.15 if substepping else 0.35), sink  # soft contacts: 3 mm of compression per layer
     assert (got["pairs"]["shapeA"] >= 0).sum() == (ref["pairs"]["shapeA"] >= 0).sum()
+
+
+@pytest.mark.parametrize("seed,solver_name", [(1, "SoftStep"), (9, "TGS_Soft"), (17, "PGS_Soft"), (15, "TGS_Soft")])
+def test_rain_world_loop_through_the_strip_paths(seed, solver_name):
+    """The rain worlds again, larger (300-900 bodies) and with the strip options forced and drawn at random, so that the
+    pile of mixed shapes -- one- and two-point manifolds, a kinematic paddle that several strips touch -- is swept by the
+    persistent strip kernel while contacts come and go: 120 steps of the whole loop, bit-exact against the oracle chain
+    (a one-off run of 160 seeds found no difference)."""
+    from tests import common, oraclebind
+    rng = np.random.default_rng(5000 + seed)
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+    world = world_chain.rain_world(seed, int(rng.integers(300, 900)), spin=bool(seed % 2))
+    ref = world_chain.copy_world(world)
+    persistent = 0
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", int(rng.integers(0, 3)))
+        s.set_option("strip_min_bodies", 0)
+        s.set_option("strip_bodies", int(rng.integers(30, 160)))
+        s.set_option("max_group_bodies", int(rng.choice([32, 64, 128])))
+        s.world_upload(*[world[k] for k in world_chain.WORLD_KEYS])
+        for step in range(120):
+            moved = ((ref["shapes"]["enlarged"] != 0) & (ref["shapes"]["type"] != wire.SHAPE_FREE)).astype(np.uint8)
+            if moved.any():
+                got = s.world_find_pairs()
+                want = oraclebind.find_pairs(ref["bodies"], ref["shapes"], moved, _live_pairs(ref), ref["joints"])
+                assert np.array_equal(got, want), "step %d: new pairs" % step
+                if len(got):
+                    slots, contacts, pairs = _create_contacts(ref, got)
+                    s.world_set_contacts(slots, contacts, pairs)
+            info = s.world_step(params)
+            order, _ = s.contact_order()
+            status = world_chain.oracle_world_step(params, ref, contact_order=order)
+            assert info["separatedCount"] == int((status == wire.PAIR_SEPARATED).sum()), "step %d" % step
+            persistent += s.stats()["persistent"]
+            if step % 5 == 4:
+                out = world_chain.copy_world(world)
+                res = s.world_download(*[out[k] for k in world_chain.WORLD_KEYS])
+                world_chain.assert_device_equals_oracle(dict(zip(world_chain.WORLD_KEYS, res[:6])), ref,
+                                                        "rain-strips %d %s step %d" % (seed, solver_name, step))
+    assert persistent > 30, persistent

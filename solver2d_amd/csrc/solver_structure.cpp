@@ -532,6 +532,607 @@ void partitionStrips(const EdgeList& ce, const EdgeList& je, const std::vector<i
 
 } // namespace
 
+// Message-passing tables of the global part (see MsgBodies): per body the slots of its incident constraints in sweep order.
+static int buildMessageTables(s2amdSolver* s, int nb)
+{
+	const SweepSet& cs = s->contacts;
+	int rc = 0;
+	bool grew = false;
+	const int G = cs.globalCount;
+	std::vector<int> offsets((size_t)nb + 1, 0), list((size_t)2 * G), next((size_t)2 * G, 0), first((size_t)nb, -1);
+	for (int k = 0; k < G; ++k)
+	{
+		offsets[(size_t)s->hContactA[cs.order[k]] + 1] += 1;
+		offsets[(size_t)s->hContactB[cs.order[k]] + 1] += 1;
+	}
+	for (int i = 0; i < nb; ++i)
+	{
+		offsets[(size_t)i + 1] += offsets[i];
+	}
+	std::vector<int> cursor(offsets.begin(), offsets.end() - 1);
+	for (int k = 0; k < G; ++k) // ascending k: every body's copies end up in sweep order
+	{
+		list[(size_t)cursor[s->hContactA[cs.order[k]]]++] = 2 * k;
+		list[(size_t)cursor[s->hContactB[cs.order[k]]]++] = 2 * k + 1;
+	}
+	for (int i = 0; i < nb; ++i)
+	{
+		int b0 = offsets[i], b1 = offsets[(size_t)i + 1];
+		if (b1 > b0)
+		{
+			first[i] = list[(size_t)b0];
+			for (int e = b0; e < b1; ++e)
+			{
+				next[(size_t)list[(size_t)e]] = list[(size_t)(e + 1 < b1 ? e + 1 : b0)];
+			}
+		}
+	}
+	size_t bytes = (size_t)2 * G * (2 * sizeof(float4) + 2 * sizeof(int)) + ((size_t)2 * nb + 1) * sizeof(int) + 1024;
+	grew = false;
+	if ((rc = s->dMsg.ensure(bytes, &grew)) != 0)
+	{
+		return rc;
+	}
+	if (grew)
+	{
+		s->layoutGeneration += 1;
+	}
+	Carver cvr{(char*)s->dMsg.p, (char*)s->dMsg.p + s->dMsg.bytes};
+	float4* dvel = cvr.take<float4>((size_t)2 * G);
+	float4* ddq = cvr.take<float4>((size_t)2 * G);
+	int* dnext = cvr.take<int>((size_t)2 * G);
+	int* dlist = cvr.take<int>((size_t)2 * G);
+	int* dfirst = cvr.take<int>((size_t)nb);
+	int* doffsets = cvr.take<int>((size_t)nb + 1);
+	if (cvr.p > cvr.end)
+	{
+		// alignment slack exceeded: grow once more
+		if ((rc = s->dMsg.ensure(bytes + 8192, &grew)) != 0)
+		{
+			return rc;
+		}
+		s->layoutGeneration += 1;
+		cvr = Carver{(char*)s->dMsg.p, (char*)s->dMsg.p + s->dMsg.bytes};
+		dvel = cvr.take<float4>((size_t)2 * G);
+		ddq = cvr.take<float4>((size_t)2 * G);
+		dnext = cvr.take<int>((size_t)2 * G);
+		dlist = cvr.take<int>((size_t)2 * G);
+		dfirst = cvr.take<int>((size_t)nb);
+		doffsets = cvr.take<int>((size_t)nb + 1);
+	}
+	HIP_TRY(hipMemcpyAsync(dnext, next.data(), next.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+	HIP_TRY(hipMemcpyAsync(dlist, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+	HIP_TRY(hipMemcpyAsync(dfirst, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+	HIP_TRY(hipMemcpyAsync(doffsets, offsets.data(), offsets.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	s->msg.vel = dvel, s->msg.dq = ddq, s->msg.next = dnext, s->msg.firstSlot = dfirst, s->msg.slotOffsets = doffsets, s->msg.slotList = dlist;
+	s->msgTablesValid = true;
+	return S2AMD_OK;
+}
+
+// body -> incident constraints of the global part (Jacobi apply, body-centric warm start) with the heavy-body list.
+static int buildAdjacency(s2amdSolver* s, const std::vector<uint8_t>& conflict, int nb)
+{
+	const SweepSet& cs = s->contacts;
+	int rc = 0;
+	bool grew = false;
+	// body -> incident constraints in SWEEP order (ascending k), key = k<<1 | side, so the per-body
+	// sums of jacobiApplyKernel add in exactly the order a sequential pass in sweep order would;
+	// read-only shareable bodies are skipped (their deltas are exact zeros)
+	std::vector<int> offsets((size_t)nb + 1, 0), list;
+	const int GC = cs.globalCount; // LDS groups walk their own colours; only the global part is indexed
+	for (int k = 0; k < GC; ++k)
+	{
+		int a = s->hContactA[cs.order[k]], b = s->hContactB[cs.order[k]];
+		if (conflict[a])
+		{
+			offsets[(size_t)a + 1] += 1;
+		}
+		if (conflict[b])
+		{
+			offsets[(size_t)b + 1] += 1;
+		}
+	}
+	for (int i = 0; i < nb; ++i)
+	{
+		offsets[(size_t)i + 1] += offsets[i];
+	}
+	list.resize((size_t)offsets[nb]);
+	std::vector<int> cursor(offsets.begin(), offsets.end() - 1);
+	for (int k = 0; k < GC; ++k)
+	{
+		int a = s->hContactA[cs.order[k]], b = s->hContactB[cs.order[k]];
+		if (conflict[a])
+		{
+			list[(size_t)cursor[a]++] = (k << 1) | 0;
+		}
+		if (conflict[b])
+		{
+			list[(size_t)cursor[b]++] = (k << 1) | 1;
+		}
+	}
+	grew = false;
+	if ((rc = s->dAdjOffsets.ensure(((size_t)nb + 1) * sizeof(int), &grew)) != 0 ||
+		(rc = s->dAdjList.ensure(std::max<size_t>(list.size(), 1) * sizeof(int), &grew)) != 0)
+	{
+		return rc;
+	}
+	if (grew)
+	{
+		s->layoutGeneration += 1;
+	}
+	std::vector<int> heavy;
+	for (int i = 0; i < nb; ++i)
+	{
+		if (offsets[(size_t)i + 1] - offsets[(size_t)i] > S2_HEAVY_DEGREE)
+		{
+			heavy.push_back(i);
+		}
+	}
+	if ((rc = s->dAdjHeavy.ensure(std::max<size_t>(heavy.size(), 64) * sizeof(int), &grew)) != 0)
+	{
+		return rc;
+	}
+	if (grew)
+	{
+		s->layoutGeneration += 1;
+	}
+	s->adjHeavyCount = (int)heavy.size();
+	if (!heavy.empty())
+	{
+		HIP_TRY(hipMemcpyAsync(s->dAdjHeavy.p, heavy.data(), heavy.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+	}
+	HIP_TRY(hipMemcpyAsync(s->dAdjOffsets.p, offsets.data(), ((size_t)nb + 1) * sizeof(int), hipMemcpyHostToDevice, s->stream));
+	if (!list.empty())
+	{
+		HIP_TRY(hipMemcpyAsync(s->dAdjList.p, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+	}
+	s->adjValid = true;
+	return S2AMD_OK;
+}
+
+// The lean / persistent strip tables of one strip partition (strip_kernel.hip): per-strip descriptors, warm-start slots,
+// the persistent kernel's register / LDS plan.  Part of buildStructureWith; leaves s->leanAValid / leanBValid /
+// persistValid false when this partition cannot use those kernels.
+static int buildLeanStripTables(s2amdSolver* s, const StripPartition& strips, const std::vector<uint8_t>& conflict, const std::vector<int>& seamGroup,
+								int stripBaseC, int nb)
+{
+	int rc = 0;
+	SweepSet& cs = s->contacts;
+	SweepSet& js = s->joints;
+	const int k0 = stripBaseC, k1 = stripBaseC + cs.stripCount;
+	// body -> incident strip constraints in sweep order
+	std::vector<int> off((size_t)nb + 1, 0), inc;
+	for (int k = k0; k < k1; ++k)
+	{
+		int a = s->hContactA[cs.order[(size_t)k]], b = s->hContactB[cs.order[(size_t)k]];
+		off[(size_t)a + 1] += conflict[a] ? 1 : 0;
+		off[(size_t)b + 1] += conflict[b] ? 1 : 0;
+	}
+	for (int i = 0; i < nb; ++i)
+	{
+		off[(size_t)i + 1] += off[i];
+	}
+	inc.resize((size_t)off[nb]);
+	{
+		std::vector<int> cur(off.begin(), off.end() - 1);
+		for (int k = k0; k < k1; ++k)
+		{
+			int a = s->hContactA[cs.order[(size_t)k]], b = s->hContactB[cs.order[(size_t)k]];
+			if (conflict[a])
+			{
+				inc[(size_t)cur[a]++] = (k << 1) | 0;
+			}
+			if (conflict[b])
+			{
+				inc[(size_t)cur[b]++] = (k << 1) | 1;
+			}
+		}
+	}
+	std::vector<StripDesc> descA, descB;
+	std::vector<int2> slotList;
+	std::vector<int> slotOffsets;
+	int maxRounds = 0;
+	bool persistTablesOk = false;
+	const char* leanWhy = "";
+	auto describe = [&](const HostGroupTable& t, std::vector<StripDesc>& out, bool withSlots, int& ldsRecords) {
+		bool ok = true;
+		ldsRecords = 0;
+		maxRounds = 0;
+		for (int g = 0; g < t.count() && ok; ++g)
+		{
+			StripDesc d{};
+			d.bodyBase = t.bodyOffsets[(size_t)g];
+			d.bodyCount = t.bodyOffsets[(size_t)g + 1] - d.bodyBase;
+			int b0 = t.cBatchOffsets[(size_t)g], b1 = t.cBatchOffsets[(size_t)g + 1];
+			d.batchCount = b1 - b0;
+			ok = d.batchCount <= (withSlots ? S2_STRIP_ROUNDS_MAX : S2_STRIP_ROUNDS) && d.bodyCount <= S2_STRIP_BODY_CHUNKS * 256;
+			if (!ok)
+			{
+				leanWhy = d.bodyCount > S2_STRIP_BODY_CHUNKS * 256 ? "more than 1024 bodies in a strip or seam" : (withSlots ? "more than 8 interior colours" : "more than 6 seam colours");
+			}
+			maxRounds = std::max(maxRounds, d.batchCount);
+			for (int b = b0; b < b1 && ok; ++b)
+			{
+				int4 bt = t.cBatches[(size_t)b];
+				ok = bt.z == 0;
+				if (!ok)
+				{
+					leanWhy = "a sequential tail batch";
+				}
+				d.batch[b - b0] = make_int4(bt.x, bt.y, 0, 0);
+			}
+			while (d.ownedCount < d.bodyCount && ((uint32_t)t.bodyIds[(size_t)d.bodyBase + d.ownedCount] & S2G_OWNED) != 0)
+			{
+				d.ownedCount += 1;
+			}
+			if (withSlots)
+			{
+				// phase A groups list their owned bodies first (seeded): slots in body order
+				d.slotBase = (int)slotList.size();
+				d.slotOffBase = (int)slotOffsets.size();
+				for (int i = 0; i < d.ownedCount; ++i)
+				{
+					int body = (int)((uint32_t)t.bodyIds[(size_t)d.bodyBase + i] & ~S2G_OWNED);
+					slotOffsets.push_back((int)slotList.size() - d.slotBase);
+					for (int e = off[body]; e < off[(size_t)body + 1]; ++e)
+					{
+						slotList.push_back(make_int2(inc[(size_t)e], i));
+					}
+				}
+				slotOffsets.push_back((int)slotList.size() - d.slotBase);
+				d.slotCount = (int)slotList.size() - d.slotBase;
+			}
+			int records = 2 * d.bodyCount + 2 * d.slotCount;
+			if (ok && records > (160 * 1024) / 16)
+			{
+				leanWhy = "LDS: bodies + warm-start slots";
+			}
+			ok = ok && records <= (160 * 1024) / 16;
+			ldsRecords = std::max(ldsRecords, records);
+			out.push_back(d);
+		}
+		return ok;
+	};
+	int ldsA = 0, ldsB = 0;
+	bool okA = describe(s->hStripA, descA, true, ldsA);
+	const int maxRoundsA = maxRounds; // <= 8: the persistent kernel's wide variant; <= 6: also the lean launches
+	bool okB = describe(s->hStripB, descB, false, ldsB);
+	// owned bodies must be exactly the seeded prefix in phase A (replicas are never owned there)
+	if (okA)
+	{
+		auto pad = [](size_t n) { return (n + 63) & ~size_t(63); };
+		size_t bA = pad(descA.size() * sizeof(StripDesc)), bB = pad(std::max<size_t>(descB.size(), 1) * sizeof(StripDesc));
+		size_t bS = pad(std::max<size_t>(slotList.size(), 1) * sizeof(int2)), bO = pad(std::max<size_t>(slotOffsets.size(), 1) * sizeof(int));
+		std::vector<unsigned char> blob(bA + bB + bS + bO, 0);
+		memcpy(blob.data(), descA.data(), descA.size() * sizeof(StripDesc));
+		if (!descB.empty())
+		{
+			memcpy(blob.data() + bA, descB.data(), descB.size() * sizeof(StripDesc));
+		}
+		if (!slotList.empty())
+		{
+			memcpy(blob.data() + bA + bB, slotList.data(), slotList.size() * sizeof(int2));
+		}
+		if (!slotOffsets.empty())
+		{
+			memcpy(blob.data() + bA + bB + bS, slotOffsets.data(), slotOffsets.size() * sizeof(int));
+		}
+		bool grewLean = false;
+		if ((rc = s->dStripLean.ensure(blob.size(), &grewLean)) != 0)
+		{
+			return rc;
+		}
+		if (grewLean)
+		{
+			s->layoutGeneration += 1;
+		}
+		HIP_TRY(hipMemcpyAsync(s->dStripLean.p, blob.data(), blob.size(), hipMemcpyHostToDevice, s->stream));
+		HIP_TRY(hipStreamSynchronize(s->stream)); // blob is a local
+		const unsigned char* base = (const unsigned char*)s->dStripLean.p;
+		s->leanA.descs = (const StripDesc*)base;
+		s->leanA.bodyIds = s->dStripA.view.bodyIds;
+		s->leanA.slots = (const int2*)(base + bA + bB);
+		s->leanA.slotOffsets = (const int*)(base + bA + bB + bS);
+		s->leanA.groupCount = (int)descA.size();
+		s->leanA.ldsRecords = ldsA;
+		s->leanAValid = maxRoundsA <= S2_STRIP_ROUNDS;
+		persistTablesOk = okB;
+		if (okB)
+		{
+			s->leanB.descs = (const StripDesc*)(base + bA);
+			s->leanB.bodyIds = s->dStripB.view.bodyIds;
+			s->leanB.slots = s->leanA.slots;
+			s->leanB.slotOffsets = s->leanA.slotOffsets;
+			s->leanB.groupCount = (int)descB.size();
+			s->leanB.ldsRecords = ldsB;
+			s->leanBValid = true;
+		}
+	}
+
+	if (getenv("S2AMD_DEBUG"))
+	{
+		fprintf(stderr, "[s2amd] strips: %d strips, %d seams, lean A %d B %d, strip joints %d, CUs %d%s%s\n", s->hStripA.count(), s->hStripB.count(),
+				(int)s->leanAValid, (int)s->leanBValid, js.stripCount, s->cuCount, leanWhy[0] ? " -- lean tables: " : "", leanWhy);
+	}
+	// ---- persistent strip step (strip_kernel.hip: stripStepKernel): per workgroup both seams' remaps, the
+	// import / export lists of the symmetric exchange, warm-start term slots, granule buffers ----
+	s->persistValid = false;
+	if (persistTablesOk && js.stripCount == 0 && s->optPersist && s->hostError != nullptr && s->hStripA.count() <= s->cuCount)
+	{
+		const HostGroupTable& A = s->hStripA;
+		const HostGroupTable& B = s->hStripB;
+		const int K = A.count();
+		bool ok = true;
+		const char* why = "";
+#define NEED(cond)                                                                                                                \
+do                                                                                                                           \
+{                                                                                                                            \
+	if (ok && !(cond))                                                                                                       \
+	{                                                                                                                        \
+		ok = false;                                                                                                          \
+		why = #cond;                                                                                                         \
+	}                                                                                                                        \
+} while (0)
+		std::vector<int> ownerGroup((size_t)nb, -1), ownerSlot((size_t)nb, -1);
+		for (int gi = 0; gi < K; ++gi)
+		{
+			for (int e = A.bodyOffsets[(size_t)gi]; e < A.bodyOffsets[(size_t)gi + 1]; ++e)
+			{
+				uint32_t id = (uint32_t)A.bodyIds[(size_t)e];
+				if (id & S2G_OWNED)
+				{
+					ownerGroup[id & ~S2G_OWNED] = gi;
+					ownerSlot[id & ~S2G_OWNED] = e - A.bodyOffsets[(size_t)gi];
+				}
+			}
+			for (int bb = A.cBatchOffsets[(size_t)gi]; bb < A.cBatchOffsets[(size_t)gi + 1]; ++bb)
+			{
+				NEED(A.cBatches[(size_t)bb].y - A.cBatches[(size_t)bb].x <= 256); // one constraint per thread and round
+			}
+		}
+		// seams: bodies on either side, in the order of the seam group's body list
+		const int S = K - 1;
+		std::vector<std::vector<int>> leftBodies((size_t)std::max(S, 0)), rightBodies((size_t)std::max(S, 0));
+		std::vector<int> posInSeam((size_t)nb, -1);
+		for (int sm = 0; sm < S && ok; ++sm)
+		{
+			int g = seamGroup[(size_t)sm];
+			if (g < 0)
+			{
+				continue;
+			}
+			for (int e = B.bodyOffsets[(size_t)g]; e < B.bodyOffsets[(size_t)g + 1]; ++e)
+			{
+				int body = (int)((uint32_t)B.bodyIds[(size_t)e] & ~S2G_OWNED);
+				if (!conflict[body])
+				{
+					continue;
+				}
+				if (ownerGroup[body] == sm)
+				{
+					posInSeam[body] = (int)leftBodies[(size_t)sm].size();
+					leftBodies[(size_t)sm].push_back(body);
+				}
+				else if (ownerGroup[body] == sm + 1)
+				{
+					posInSeam[body] = (int)rightBodies[(size_t)sm].size();
+					rightBodies[(size_t)sm].push_back(body);
+				}
+				else
+				{
+					NEED(false);
+				}
+			}
+			NEED(leftBodies[(size_t)sm].size() <= 256 && rightBodies[(size_t)sm].size() <= 256);
+		}
+		// granule buffers: per seam {toLeft: 4 per right body, toRight: 4 per left body}, two parities
+		std::vector<int> seamBase((size_t)std::max(S, 0), 0);
+		int granules = 0;
+		for (int sm = 0; sm < S; ++sm)
+		{
+			seamBase[(size_t)sm] = granules;
+			granules += 4 * (int)(leftBodies[(size_t)sm].size() + rightBodies[(size_t)sm].size());
+		}
+		const int parityStride = granules;
+		// TGS_Soft keeps the seam constraints in registers when no seam has more than two colour batches and no interior
+		// more than six (strip_kernel.hip: SEAMREG): then they cost no LDS at all
+		bool seamRegs = s->optSeamRegs != 0 && maxRoundsA <= S2_STRIP_ROUNDS;
+		for (int sm = 0; sm < S && seamRegs; ++sm)
+		{
+			const int g = seamGroup[(size_t)sm];
+			seamRegs = g < 0 || B.cBatchOffsets[(size_t)g + 1] - B.cBatchOffsets[(size_t)g] <= 2;
+		}
+		std::vector<PersistDesc> descs((size_t)K);
+		std::vector<int> remap, exportSrc, importIds;
+		std::vector<int> replicaStamp((size_t)nb, -1), replicaSlot((size_t)nb, -1);
+		int ldsRecords = 0, ldsRecordsWide = 0;
+		for (int i = 0; i < K && ok; ++i)
+		{
+			PersistDesc& d = descs[(size_t)i];
+			memset(&d, 0, sizeof(d));
+			const int bodyBase = A.bodyOffsets[(size_t)i];
+			const int nbA = A.bodyOffsets[(size_t)i + 1] - bodyBase;
+			for (int e = bodyBase; e < bodyBase + nbA; ++e)
+			{
+				uint32_t id = (uint32_t)A.bodyIds[(size_t)e];
+				if ((id & S2G_OWNED) == 0)
+				{
+					replicaStamp[id] = i;
+					replicaSlot[id] = e - bodyBase;
+				}
+			}
+			const int seamOf[2] = {i - 1, i};
+			int importOffset = nbA, seamSlots = 0;
+			for (int side = 0; side < 2; ++side)
+			{
+				const int sm = seamOf[side];
+				const int g = (sm >= 0 && sm < S) ? seamGroup[(size_t)sm] : -1;
+				d.importIdBase[side] = (int)importIds.size();
+				d.exportSrcBase[side] = (int)exportSrc.size();
+				d.remapBase[side] = (int)remap.size();
+				if (g < 0)
+				{
+					continue;
+				}
+				// side 0: I am the RIGHT strip of seam i-1 (import its left bodies, export its right bodies);
+				// side 1: I am the LEFT strip of seam i
+				const std::vector<int>& imports = side == 0 ? leftBodies[(size_t)sm] : rightBodies[(size_t)sm];
+				const std::vector<int>& exports = side == 0 ? rightBodies[(size_t)sm] : leftBodies[(size_t)sm];
+				d.importCount[side] = (int)imports.size();
+				d.exportCount[side] = (int)exports.size();
+				importIds.insert(importIds.end(), imports.begin(), imports.end());
+				for (int body : exports)
+				{
+					exportSrc.push_back(ownerSlot[body]);
+				}
+				const int nR = (int)rightBodies[(size_t)sm].size();
+				const int toLeft = seamBase[(size_t)sm], toRight = seamBase[(size_t)sm] + 4 * nR;
+				d.inBase[side] = side == 0 ? toRight : toLeft;
+				d.outBase[side] = side == 0 ? toLeft : toRight;
+				for (int e = B.bodyOffsets[(size_t)g]; e < B.bodyOffsets[(size_t)g + 1] && ok; ++e)
+				{
+					int body = (int)((uint32_t)B.bodyIds[(size_t)e] & ~S2G_OWNED);
+					if (ownerGroup[body] == i)
+					{
+						remap.push_back(ownerSlot[body]);
+					}
+					else if (conflict[body])
+					{
+						remap.push_back(importOffset + posInSeam[body]);
+					}
+					else if (replicaStamp[body] == i)
+					{
+						remap.push_back(replicaSlot[body]);
+					}
+					else
+					{
+						NEED(false);
+					}
+				}
+				int b0 = B.cBatchOffsets[(size_t)g], b1 = B.cBatchOffsets[(size_t)g + 1];
+				d.seamBatchCount[side] = b1 - b0;
+				NEED(b1 - b0 <= S2_PERSIST_B_ROUNDS);
+				for (int bb = b0; bb < b1 && ok; ++bb)
+				{
+					int4 bt = B.cBatches[(size_t)bb];
+					NEED(bt.z == 0);
+					d.seamBatch[side][bb - b0] = make_int2(bt.x, bt.y);
+					seamSlots += bt.y - bt.x;
+				}
+				importOffset += d.importCount[side];
+			}
+			for (int r = 0; r < S2_PERSIST_B_ROUNDS && ok; ++r)
+			{
+				int n0 = r < d.seamBatchCount[0] ? d.seamBatch[0][r].y - d.seamBatch[0][r].x : 0;
+				int n1 = r < d.seamBatchCount[1] ? d.seamBatch[1][r].y - d.seamBatch[1][r].x : 0;
+				ok = n0 + n1 <= 512; // both seams share a round: at most two constraints per thread
+			}
+			const int nt = importOffset;
+			// bodies, seam constraints (S2_PERSIST_Q_NARROW records each for TGS_Soft, S2_PERSIST_Q_WIDE for the other kinds)
+			int fixedRecords = 3 * nt + (nt + 3) / 4 + (nt + 1) / 2; // velocity, pose, integrator constants, angular damping, inverse masses
+			const int seamRecordsNarrow = seamRegs ? 0 : S2_PERSIST_Q_NARROW * seamSlots;
+			NEED(fixedRecords + seamRecordsNarrow + 2 * 16 <= (160 * 1024) / 16 && nt < 16384); // the plan's own records are checked when it is known (persistPlan)
+			ldsRecords = std::max(ldsRecords, fixedRecords + seamRecordsNarrow);
+			ldsRecordsWide = std::max(ldsRecordsWide, fixedRecords + S2_PERSIST_Q_WIDE * seamSlots);
+		}
+		if (getenv("S2AMD_DEBUG"))
+		{
+			fprintf(stderr, "[s2amd] persistent step: %s (K=%d, lds records %d, granules/parity %d)%s%s\n", ok ? "eligible" : "NOT eligible", K, ldsRecords,
+					parityStride, ok ? "" : " -- failed: ", why);
+			int histA[16] = {0}, histB[16] = {0};
+			for (int i = 0; i < K; ++i)
+			{
+				int ra = A.cBatchOffsets[(size_t)i + 1] - A.cBatchOffsets[(size_t)i];
+				int rb = std::max(descs[(size_t)i].seamBatchCount[0], descs[(size_t)i].seamBatchCount[1]);
+				histA[std::min(ra, 15)] += 1;
+				histB[std::min(rb, 15)] += 1;
+			}
+			for (int r = 0; r < 16; ++r)
+			{
+				if (histA[r] || histB[r])
+				{
+					fprintf(stderr, "[s2amd]   rounds %d: %d interiors, %d seam pairs\n", r, histA[r], histB[r]);
+				}
+			}
+		}
+		if (ok)
+		{
+			auto pad = [](size_t n) { return (n + 63) & ~size_t(63); };
+			auto bytesOf = [&](size_t n, size_t elem) { return pad(std::max<size_t>(n, 1) * elem); };
+			size_t o0 = 0, o1 = o0 + bytesOf(descs.size(), sizeof(PersistDesc)), o2 = o1 + bytesOf(remap.size(), sizeof(int));
+			size_t o3 = o2 + bytesOf(exportSrc.size(), sizeof(int)), o4 = o3 + bytesOf(importIds.size(), sizeof(int));
+			size_t o5 = o4 + 256; // the device-side "hand-off timed out" word
+			std::vector<unsigned char> blob(o5, 0);
+			auto put = [&](size_t at, const void* src, size_t bytes) {
+				if (bytes)
+				{
+					memcpy(blob.data() + at, src, bytes);
+				}
+			};
+			put(o0, descs.data(), descs.size() * sizeof(PersistDesc));
+			put(o1, remap.data(), remap.size() * sizeof(int));
+			put(o2, exportSrc.data(), exportSrc.size() * sizeof(int));
+			put(o3, importIds.data(), importIds.size() * sizeof(int));
+			bool grewP = false;
+			s->granuleBytes = ((std::max<size_t>((size_t)2 * parityStride, 1) * sizeof(unsigned long long)) + 255) & ~size_t(255);
+			if ((rc = s->dPersist.ensure(blob.size(), &grewP)) != 0 || (rc = s->dGranules.ensure(s->granuleBytes, &grewP)) != 0)
+			{
+				return rc;
+			}
+			if (grewP)
+			{
+				s->layoutGeneration += 1;
+			}
+			HIP_TRY(hipMemcpyAsync(s->dPersist.p, blob.data(), blob.size(), hipMemcpyHostToDevice, s->stream));
+			HIP_TRY(hipStreamSynchronize(s->stream));
+			const unsigned char* base = (const unsigned char*)s->dPersist.p;
+			PersistView& pv = s->persist;
+			pv = PersistView{};
+			pv.descs = (const PersistDesc*)(base + o0);
+			pv.remap = (const int*)(base + o1);
+			pv.exportSrc = (const int*)(base + o2);
+			pv.importIds = (const int*)(base + o3);
+			pv.granules = (unsigned long long*)s->dGranules.p;
+			unsigned int* devError = nullptr;
+			HIP_TRY(hipHostGetDevicePointer((void**)&devError, s->hostError, 0));
+			pv.error = devError;
+			pv.deviceError = (unsigned int*)(base + o4);
+			pv.parityStride = parityStride;
+			// fresh buffers start from zero tags
+			HIP_TRY(hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, s->stream));
+			pv.wideRounds = maxRoundsA > S2_STRIP_ROUNDS ? 1 : 0;
+			pv.seamRegs = seamRegs ? 1 : 0;
+			s->persistK0 = k0, s->persistK1 = k1;
+			pv.allTwoPoints = stripsAllTwoPoints(s) ? 1 : 0;
+			pv.ldsRecords = ldsRecords;
+			s->persistRecordsWide = ldsRecordsWide;
+			pv.debugSkip = s->optPersistDebug;
+			pv.spinLimit = (unsigned int)s->optPersistSpinLimit;
+			pv.debugTimes = nullptr;
+			if (getenv("S2AMD_DEBUG_TIMES"))
+			{
+				if (!s->hostTimes && hipHostMalloc((void**)&s->hostTimes, 256 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess)
+				{
+					s->hostTimes = nullptr;
+					(void)hipGetLastError();
+				}
+				if (s->hostTimes)
+				{
+					memset(s->hostTimes, 0, 256 * sizeof(unsigned long long));
+					unsigned long long* dev = nullptr;
+					if (hipHostGetDevicePointer((void**)&dev, s->hostTimes, 0) == hipSuccess)
+					{
+						pv.debugTimes = dev;
+					}
+				}
+			}
+			s->persistValid = true;
+		}
+	}
+	return rc;
+}
+
 static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 {
 	const int cls = isPositionSolver(solverType) ? 1 : 0;
@@ -1134,435 +1735,9 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 	s->leanB = StripTableView{};
 	if (strips.active && s->optStripLean)
 	{
-		const int k0 = stripBaseC, k1 = stripBaseC + cs.stripCount;
-		// body -> incident strip constraints in sweep order
-		std::vector<int> off((size_t)nb + 1, 0), inc;
-		for (int k = k0; k < k1; ++k)
+		if ((rc = buildLeanStripTables(s, strips, conflict, seamGroup, stripBaseC, nb)) != 0)
 		{
-			int a = s->hContactA[cs.order[(size_t)k]], b = s->hContactB[cs.order[(size_t)k]];
-			off[(size_t)a + 1] += conflict[a] ? 1 : 0;
-			off[(size_t)b + 1] += conflict[b] ? 1 : 0;
-		}
-		for (int i = 0; i < nb; ++i)
-		{
-			off[(size_t)i + 1] += off[i];
-		}
-		inc.resize((size_t)off[nb]);
-		{
-			std::vector<int> cur(off.begin(), off.end() - 1);
-			for (int k = k0; k < k1; ++k)
-			{
-				int a = s->hContactA[cs.order[(size_t)k]], b = s->hContactB[cs.order[(size_t)k]];
-				if (conflict[a])
-				{
-					inc[(size_t)cur[a]++] = (k << 1) | 0;
-				}
-				if (conflict[b])
-				{
-					inc[(size_t)cur[b]++] = (k << 1) | 1;
-				}
-			}
-		}
-		std::vector<StripDesc> descA, descB;
-		std::vector<int2> slotList;
-		std::vector<int> slotOffsets;
-		int maxRounds = 0;
-		bool persistTablesOk = false;
-		const char* leanWhy = "";
-		auto describe = [&](const HostGroupTable& t, std::vector<StripDesc>& out, bool withSlots, int& ldsRecords) {
-			bool ok = true;
-			ldsRecords = 0;
-			maxRounds = 0;
-			for (int g = 0; g < t.count() && ok; ++g)
-			{
-				StripDesc d{};
-				d.bodyBase = t.bodyOffsets[(size_t)g];
-				d.bodyCount = t.bodyOffsets[(size_t)g + 1] - d.bodyBase;
-				int b0 = t.cBatchOffsets[(size_t)g], b1 = t.cBatchOffsets[(size_t)g + 1];
-				d.batchCount = b1 - b0;
-				ok = d.batchCount <= (withSlots ? S2_STRIP_ROUNDS_MAX : S2_STRIP_ROUNDS) && d.bodyCount <= S2_STRIP_BODY_CHUNKS * 256;
-				if (!ok)
-				{
-					leanWhy = d.bodyCount > S2_STRIP_BODY_CHUNKS * 256 ? "more than 1024 bodies in a strip or seam" : (withSlots ? "more than 8 interior colours" : "more than 6 seam colours");
-				}
-				maxRounds = std::max(maxRounds, d.batchCount);
-				for (int b = b0; b < b1 && ok; ++b)
-				{
-					int4 bt = t.cBatches[(size_t)b];
-					ok = bt.z == 0;
-					if (!ok)
-					{
-						leanWhy = "a sequential tail batch";
-					}
-					d.batch[b - b0] = make_int4(bt.x, bt.y, 0, 0);
-				}
-				while (d.ownedCount < d.bodyCount && ((uint32_t)t.bodyIds[(size_t)d.bodyBase + d.ownedCount] & S2G_OWNED) != 0)
-				{
-					d.ownedCount += 1;
-				}
-				if (withSlots)
-				{
-					// phase A groups list their owned bodies first (seeded): slots in body order
-					d.slotBase = (int)slotList.size();
-					d.slotOffBase = (int)slotOffsets.size();
-					for (int i = 0; i < d.ownedCount; ++i)
-					{
-						int body = (int)((uint32_t)t.bodyIds[(size_t)d.bodyBase + i] & ~S2G_OWNED);
-						slotOffsets.push_back((int)slotList.size() - d.slotBase);
-						for (int e = off[body]; e < off[(size_t)body + 1]; ++e)
-						{
-							slotList.push_back(make_int2(inc[(size_t)e], i));
-						}
-					}
-					slotOffsets.push_back((int)slotList.size() - d.slotBase);
-					d.slotCount = (int)slotList.size() - d.slotBase;
-				}
-				int records = 2 * d.bodyCount + 2 * d.slotCount;
-				if (ok && records > (160 * 1024) / 16)
-				{
-					leanWhy = "LDS: bodies + warm-start slots";
-				}
-				ok = ok && records <= (160 * 1024) / 16;
-				ldsRecords = std::max(ldsRecords, records);
-				out.push_back(d);
-			}
-			return ok;
-		};
-		int ldsA = 0, ldsB = 0;
-		bool okA = describe(s->hStripA, descA, true, ldsA);
-		const int maxRoundsA = maxRounds; // <= 8: the persistent kernel's wide variant; <= 6: also the lean launches
-		bool okB = describe(s->hStripB, descB, false, ldsB);
-		// owned bodies must be exactly the seeded prefix in phase A (replicas are never owned there)
-		if (okA)
-		{
-			auto pad = [](size_t n) { return (n + 63) & ~size_t(63); };
-			size_t bA = pad(descA.size() * sizeof(StripDesc)), bB = pad(std::max<size_t>(descB.size(), 1) * sizeof(StripDesc));
-			size_t bS = pad(std::max<size_t>(slotList.size(), 1) * sizeof(int2)), bO = pad(std::max<size_t>(slotOffsets.size(), 1) * sizeof(int));
-			std::vector<unsigned char> blob(bA + bB + bS + bO, 0);
-			memcpy(blob.data(), descA.data(), descA.size() * sizeof(StripDesc));
-			if (!descB.empty())
-			{
-				memcpy(blob.data() + bA, descB.data(), descB.size() * sizeof(StripDesc));
-			}
-			if (!slotList.empty())
-			{
-				memcpy(blob.data() + bA + bB, slotList.data(), slotList.size() * sizeof(int2));
-			}
-			if (!slotOffsets.empty())
-			{
-				memcpy(blob.data() + bA + bB + bS, slotOffsets.data(), slotOffsets.size() * sizeof(int));
-			}
-			bool grewLean = false;
-			if ((rc = s->dStripLean.ensure(blob.size(), &grewLean)) != 0)
-			{
-				return rc;
-			}
-			if (grewLean)
-			{
-				s->layoutGeneration += 1;
-			}
-			HIP_TRY(hipMemcpyAsync(s->dStripLean.p, blob.data(), blob.size(), hipMemcpyHostToDevice, s->stream));
-			HIP_TRY(hipStreamSynchronize(s->stream)); // blob is a local
-			const unsigned char* base = (const unsigned char*)s->dStripLean.p;
-			s->leanA.descs = (const StripDesc*)base;
-			s->leanA.bodyIds = s->dStripA.view.bodyIds;
-			s->leanA.slots = (const int2*)(base + bA + bB);
-			s->leanA.slotOffsets = (const int*)(base + bA + bB + bS);
-			s->leanA.groupCount = (int)descA.size();
-			s->leanA.ldsRecords = ldsA;
-			s->leanAValid = maxRoundsA <= S2_STRIP_ROUNDS;
-			persistTablesOk = okB;
-			if (okB)
-			{
-				s->leanB.descs = (const StripDesc*)(base + bA);
-				s->leanB.bodyIds = s->dStripB.view.bodyIds;
-				s->leanB.slots = s->leanA.slots;
-				s->leanB.slotOffsets = s->leanA.slotOffsets;
-				s->leanB.groupCount = (int)descB.size();
-				s->leanB.ldsRecords = ldsB;
-				s->leanBValid = true;
-			}
-		}
-
-		if (getenv("S2AMD_DEBUG"))
-		{
-			fprintf(stderr, "[s2amd] strips: %d strips, %d seams, lean A %d B %d, strip joints %d, CUs %d%s%s\n", s->hStripA.count(), s->hStripB.count(),
-					(int)s->leanAValid, (int)s->leanBValid, js.stripCount, s->cuCount, leanWhy[0] ? " -- lean tables: " : "", leanWhy);
-		}
-		// ---- persistent strip step (strip_kernel.hip: stripStepKernel): per workgroup both seams' remaps, the
-		// import / export lists of the symmetric exchange, warm-start term slots, granule buffers ----
-		s->persistValid = false;
-		if (persistTablesOk && js.stripCount == 0 && s->optPersist && s->hostError != nullptr && s->hStripA.count() <= s->cuCount)
-		{
-			const HostGroupTable& A = s->hStripA;
-			const HostGroupTable& B = s->hStripB;
-			const int K = A.count();
-			bool ok = true;
-			const char* why = "";
-#define NEED(cond)                                                                                                                \
-	do                                                                                                                           \
-	{                                                                                                                            \
-		if (ok && !(cond))                                                                                                       \
-		{                                                                                                                        \
-			ok = false;                                                                                                          \
-			why = #cond;                                                                                                         \
-		}                                                                                                                        \
-	} while (0)
-			std::vector<int> ownerGroup((size_t)nb, -1), ownerSlot((size_t)nb, -1);
-			for (int gi = 0; gi < K; ++gi)
-			{
-				for (int e = A.bodyOffsets[(size_t)gi]; e < A.bodyOffsets[(size_t)gi + 1]; ++e)
-				{
-					uint32_t id = (uint32_t)A.bodyIds[(size_t)e];
-					if (id & S2G_OWNED)
-					{
-						ownerGroup[id & ~S2G_OWNED] = gi;
-						ownerSlot[id & ~S2G_OWNED] = e - A.bodyOffsets[(size_t)gi];
-					}
-				}
-				for (int bb = A.cBatchOffsets[(size_t)gi]; bb < A.cBatchOffsets[(size_t)gi + 1]; ++bb)
-				{
-					NEED(A.cBatches[(size_t)bb].y - A.cBatches[(size_t)bb].x <= 256); // one constraint per thread and round
-				}
-			}
-			// seams: bodies on either side, in the order of the seam group's body list
-			const int S = K - 1;
-			std::vector<std::vector<int>> leftBodies((size_t)std::max(S, 0)), rightBodies((size_t)std::max(S, 0));
-			std::vector<int> posInSeam((size_t)nb, -1);
-			for (int sm = 0; sm < S && ok; ++sm)
-			{
-				int g = seamGroup[(size_t)sm];
-				if (g < 0)
-				{
-					continue;
-				}
-				for (int e = B.bodyOffsets[(size_t)g]; e < B.bodyOffsets[(size_t)g + 1]; ++e)
-				{
-					int body = (int)((uint32_t)B.bodyIds[(size_t)e] & ~S2G_OWNED);
-					if (!conflict[body])
-					{
-						continue;
-					}
-					if (ownerGroup[body] == sm)
-					{
-						posInSeam[body] = (int)leftBodies[(size_t)sm].size();
-						leftBodies[(size_t)sm].push_back(body);
-					}
-					else if (ownerGroup[body] == sm + 1)
-					{
-						posInSeam[body] = (int)rightBodies[(size_t)sm].size();
-						rightBodies[(size_t)sm].push_back(body);
-					}
-					else
-					{
-						NEED(false);
-					}
-				}
-				NEED(leftBodies[(size_t)sm].size() <= 256 && rightBodies[(size_t)sm].size() <= 256);
-			}
-			// granule buffers: per seam {toLeft: 4 per right body, toRight: 4 per left body}, two parities
-			std::vector<int> seamBase((size_t)std::max(S, 0), 0);
-			int granules = 0;
-			for (int sm = 0; sm < S; ++sm)
-			{
-				seamBase[(size_t)sm] = granules;
-				granules += 4 * (int)(leftBodies[(size_t)sm].size() + rightBodies[(size_t)sm].size());
-			}
-			const int parityStride = granules;
-			// TGS_Soft keeps the seam constraints in registers when no seam has more than two colour batches and no interior
-			// more than six (strip_kernel.hip: SEAMREG): then they cost no LDS at all
-			bool seamRegs = s->optSeamRegs != 0 && maxRoundsA <= S2_STRIP_ROUNDS;
-			for (int sm = 0; sm < S && seamRegs; ++sm)
-			{
-				const int g = seamGroup[(size_t)sm];
-				seamRegs = g < 0 || B.cBatchOffsets[(size_t)g + 1] - B.cBatchOffsets[(size_t)g] <= 2;
-			}
-			std::vector<PersistDesc> descs((size_t)K);
-			std::vector<int> remap, exportSrc, importIds;
-			std::vector<int> replicaStamp((size_t)nb, -1), replicaSlot((size_t)nb, -1);
-			int ldsRecords = 0, ldsRecordsWide = 0;
-			for (int i = 0; i < K && ok; ++i)
-			{
-				PersistDesc& d = descs[(size_t)i];
-				memset(&d, 0, sizeof(d));
-				const int bodyBase = A.bodyOffsets[(size_t)i];
-				const int nbA = A.bodyOffsets[(size_t)i + 1] - bodyBase;
-				for (int e = bodyBase; e < bodyBase + nbA; ++e)
-				{
-					uint32_t id = (uint32_t)A.bodyIds[(size_t)e];
-					if ((id & S2G_OWNED) == 0)
-					{
-						replicaStamp[id] = i;
-						replicaSlot[id] = e - bodyBase;
-					}
-				}
-				const int seamOf[2] = {i - 1, i};
-				int importOffset = nbA, seamSlots = 0;
-				for (int side = 0; side < 2; ++side)
-				{
-					const int sm = seamOf[side];
-					const int g = (sm >= 0 && sm < S) ? seamGroup[(size_t)sm] : -1;
-					d.importIdBase[side] = (int)importIds.size();
-					d.exportSrcBase[side] = (int)exportSrc.size();
-					d.remapBase[side] = (int)remap.size();
-					if (g < 0)
-					{
-						continue;
-					}
-					// side 0: I am the RIGHT strip of seam i-1 (import its left bodies, export its right bodies);
-					// side 1: I am the LEFT strip of seam i
-					const std::vector<int>& imports = side == 0 ? leftBodies[(size_t)sm] : rightBodies[(size_t)sm];
-					const std::vector<int>& exports = side == 0 ? rightBodies[(size_t)sm] : leftBodies[(size_t)sm];
-					d.importCount[side] = (int)imports.size();
-					d.exportCount[side] = (int)exports.size();
-					importIds.insert(importIds.end(), imports.begin(), imports.end());
-					for (int body : exports)
-					{
-						exportSrc.push_back(ownerSlot[body]);
-					}
-					const int nR = (int)rightBodies[(size_t)sm].size();
-					const int toLeft = seamBase[(size_t)sm], toRight = seamBase[(size_t)sm] + 4 * nR;
-					d.inBase[side] = side == 0 ? toRight : toLeft;
-					d.outBase[side] = side == 0 ? toLeft : toRight;
-					for (int e = B.bodyOffsets[(size_t)g]; e < B.bodyOffsets[(size_t)g + 1] && ok; ++e)
-					{
-						int body = (int)((uint32_t)B.bodyIds[(size_t)e] & ~S2G_OWNED);
-						if (ownerGroup[body] == i)
-						{
-							remap.push_back(ownerSlot[body]);
-						}
-						else if (conflict[body])
-						{
-							remap.push_back(importOffset + posInSeam[body]);
-						}
-						else if (replicaStamp[body] == i)
-						{
-							remap.push_back(replicaSlot[body]);
-						}
-						else
-						{
-							NEED(false);
-						}
-					}
-					int b0 = B.cBatchOffsets[(size_t)g], b1 = B.cBatchOffsets[(size_t)g + 1];
-					d.seamBatchCount[side] = b1 - b0;
-					NEED(b1 - b0 <= S2_PERSIST_B_ROUNDS);
-					for (int bb = b0; bb < b1 && ok; ++bb)
-					{
-						int4 bt = B.cBatches[(size_t)bb];
-						NEED(bt.z == 0);
-						d.seamBatch[side][bb - b0] = make_int2(bt.x, bt.y);
-						seamSlots += bt.y - bt.x;
-					}
-					importOffset += d.importCount[side];
-				}
-				for (int r = 0; r < S2_PERSIST_B_ROUNDS && ok; ++r)
-				{
-					int n0 = r < d.seamBatchCount[0] ? d.seamBatch[0][r].y - d.seamBatch[0][r].x : 0;
-					int n1 = r < d.seamBatchCount[1] ? d.seamBatch[1][r].y - d.seamBatch[1][r].x : 0;
-					ok = n0 + n1 <= 512; // both seams share a round: at most two constraints per thread
-				}
-				const int nt = importOffset;
-				// bodies, seam constraints (S2_PERSIST_Q_NARROW records each for TGS_Soft, S2_PERSIST_Q_WIDE for the other kinds)
-				int fixedRecords = 3 * nt + (nt + 3) / 4 + (nt + 1) / 2; // velocity, pose, integrator constants, angular damping, inverse masses
-				const int seamRecordsNarrow = seamRegs ? 0 : S2_PERSIST_Q_NARROW * seamSlots;
-				NEED(fixedRecords + seamRecordsNarrow + 2 * 16 <= (160 * 1024) / 16 && nt < 16384); // the plan's own records are checked when it is known (persistPlan)
-				ldsRecords = std::max(ldsRecords, fixedRecords + seamRecordsNarrow);
-				ldsRecordsWide = std::max(ldsRecordsWide, fixedRecords + S2_PERSIST_Q_WIDE * seamSlots);
-			}
-			if (getenv("S2AMD_DEBUG"))
-			{
-				fprintf(stderr, "[s2amd] persistent step: %s (K=%d, lds records %d, granules/parity %d)%s%s\n", ok ? "eligible" : "NOT eligible", K, ldsRecords,
-						parityStride, ok ? "" : " -- failed: ", why);
-				int histA[16] = {0}, histB[16] = {0};
-				for (int i = 0; i < K; ++i)
-				{
-					int ra = A.cBatchOffsets[(size_t)i + 1] - A.cBatchOffsets[(size_t)i];
-					int rb = std::max(descs[(size_t)i].seamBatchCount[0], descs[(size_t)i].seamBatchCount[1]);
-					histA[std::min(ra, 15)] += 1;
-					histB[std::min(rb, 15)] += 1;
-				}
-				for (int r = 0; r < 16; ++r)
-				{
-					if (histA[r] || histB[r])
-					{
-						fprintf(stderr, "[s2amd]   rounds %d: %d interiors, %d seam pairs\n", r, histA[r], histB[r]);
-					}
-				}
-			}
-			if (ok)
-			{
-				auto pad = [](size_t n) { return (n + 63) & ~size_t(63); };
-				auto bytesOf = [&](size_t n, size_t elem) { return pad(std::max<size_t>(n, 1) * elem); };
-				size_t o0 = 0, o1 = o0 + bytesOf(descs.size(), sizeof(PersistDesc)), o2 = o1 + bytesOf(remap.size(), sizeof(int));
-				size_t o3 = o2 + bytesOf(exportSrc.size(), sizeof(int)), o4 = o3 + bytesOf(importIds.size(), sizeof(int));
-				size_t o5 = o4 + 256; // the device-side "hand-off timed out" word
-				std::vector<unsigned char> blob(o5, 0);
-				auto put = [&](size_t at, const void* src, size_t bytes) {
-					if (bytes)
-					{
-						memcpy(blob.data() + at, src, bytes);
-					}
-				};
-				put(o0, descs.data(), descs.size() * sizeof(PersistDesc));
-				put(o1, remap.data(), remap.size() * sizeof(int));
-				put(o2, exportSrc.data(), exportSrc.size() * sizeof(int));
-				put(o3, importIds.data(), importIds.size() * sizeof(int));
-				bool grewP = false;
-				s->granuleBytes = ((std::max<size_t>((size_t)2 * parityStride, 1) * sizeof(unsigned long long)) + 255) & ~size_t(255);
-				if ((rc = s->dPersist.ensure(blob.size(), &grewP)) != 0 || (rc = s->dGranules.ensure(s->granuleBytes, &grewP)) != 0)
-				{
-					return rc;
-				}
-				if (grewP)
-				{
-					s->layoutGeneration += 1;
-				}
-				HIP_TRY(hipMemcpyAsync(s->dPersist.p, blob.data(), blob.size(), hipMemcpyHostToDevice, s->stream));
-				HIP_TRY(hipStreamSynchronize(s->stream));
-				const unsigned char* base = (const unsigned char*)s->dPersist.p;
-				PersistView& pv = s->persist;
-				pv = PersistView{};
-				pv.descs = (const PersistDesc*)(base + o0);
-				pv.remap = (const int*)(base + o1);
-				pv.exportSrc = (const int*)(base + o2);
-				pv.importIds = (const int*)(base + o3);
-				pv.granules = (unsigned long long*)s->dGranules.p;
-				unsigned int* devError = nullptr;
-				HIP_TRY(hipHostGetDevicePointer((void**)&devError, s->hostError, 0));
-				pv.error = devError;
-				pv.deviceError = (unsigned int*)(base + o4);
-				pv.parityStride = parityStride;
-				// fresh buffers start from zero tags
-				HIP_TRY(hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, s->stream));
-				pv.wideRounds = maxRoundsA > S2_STRIP_ROUNDS ? 1 : 0;
-				pv.seamRegs = seamRegs ? 1 : 0;
-				s->persistK0 = k0, s->persistK1 = k1;
-				pv.allTwoPoints = stripsAllTwoPoints(s) ? 1 : 0;
-				pv.ldsRecords = ldsRecords;
-				s->persistRecordsWide = ldsRecordsWide;
-				pv.debugSkip = s->optPersistDebug;
-				pv.spinLimit = (unsigned int)s->optPersistSpinLimit;
-				pv.debugTimes = nullptr;
-				if (getenv("S2AMD_DEBUG_TIMES"))
-				{
-					if (!s->hostTimes && hipHostMalloc((void**)&s->hostTimes, 256 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess)
-					{
-						s->hostTimes = nullptr;
-						(void)hipGetLastError();
-					}
-					if (s->hostTimes)
-					{
-						memset(s->hostTimes, 0, 256 * sizeof(unsigned long long));
-						unsigned long long* dev = nullptr;
-						if (hipHostGetDevicePointer((void**)&dev, s->hostTimes, 0) == hipSuccess)
-						{
-							pv.debugTimes = dev;
-						}
-					}
-				}
-				s->persistValid = true;
-			}
+			return rc;
 		}
 	}
 
@@ -1585,152 +1760,17 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 	s->msgTablesValid = false;
 	if (s->optMessage != 0 && cs.globalCount > 0 && js.globalCount == 0 && !cs.hasTail && !needAdj) // 0.25 ms of host time at 60k constraints
 	{
-		const int G = cs.globalCount;
-		std::vector<int> offsets((size_t)nb + 1, 0), list((size_t)2 * G), next((size_t)2 * G, 0), first((size_t)nb, -1);
-		for (int k = 0; k < G; ++k)
-		{
-			offsets[(size_t)s->hContactA[cs.order[k]] + 1] += 1;
-			offsets[(size_t)s->hContactB[cs.order[k]] + 1] += 1;
-		}
-		for (int i = 0; i < nb; ++i)
-		{
-			offsets[(size_t)i + 1] += offsets[i];
-		}
-		std::vector<int> cursor(offsets.begin(), offsets.end() - 1);
-		for (int k = 0; k < G; ++k) // ascending k: every body's copies end up in sweep order
-		{
-			list[(size_t)cursor[s->hContactA[cs.order[k]]]++] = 2 * k;
-			list[(size_t)cursor[s->hContactB[cs.order[k]]]++] = 2 * k + 1;
-		}
-		for (int i = 0; i < nb; ++i)
-		{
-			int b0 = offsets[i], b1 = offsets[(size_t)i + 1];
-			if (b1 > b0)
-			{
-				first[i] = list[(size_t)b0];
-				for (int e = b0; e < b1; ++e)
-				{
-					next[(size_t)list[(size_t)e]] = list[(size_t)(e + 1 < b1 ? e + 1 : b0)];
-				}
-			}
-		}
-		size_t bytes = (size_t)2 * G * (2 * sizeof(float4) + 2 * sizeof(int)) + ((size_t)2 * nb + 1) * sizeof(int) + 1024;
-		grew = false;
-		if ((rc = s->dMsg.ensure(bytes, &grew)) != 0)
+		if ((rc = buildMessageTables(s, nb)) != 0)
 		{
 			return rc;
 		}
-		if (grew)
-		{
-			s->layoutGeneration += 1;
-		}
-		Carver cvr{(char*)s->dMsg.p, (char*)s->dMsg.p + s->dMsg.bytes};
-		float4* dvel = cvr.take<float4>((size_t)2 * G);
-		float4* ddq = cvr.take<float4>((size_t)2 * G);
-		int* dnext = cvr.take<int>((size_t)2 * G);
-		int* dlist = cvr.take<int>((size_t)2 * G);
-		int* dfirst = cvr.take<int>((size_t)nb);
-		int* doffsets = cvr.take<int>((size_t)nb + 1);
-		if (cvr.p > cvr.end)
-		{
-			// alignment slack exceeded: grow once more
-			if ((rc = s->dMsg.ensure(bytes + 8192, &grew)) != 0)
-			{
-				return rc;
-			}
-			s->layoutGeneration += 1;
-			cvr = Carver{(char*)s->dMsg.p, (char*)s->dMsg.p + s->dMsg.bytes};
-			dvel = cvr.take<float4>((size_t)2 * G);
-			ddq = cvr.take<float4>((size_t)2 * G);
-			dnext = cvr.take<int>((size_t)2 * G);
-			dlist = cvr.take<int>((size_t)2 * G);
-			dfirst = cvr.take<int>((size_t)nb);
-			doffsets = cvr.take<int>((size_t)nb + 1);
-		}
-		HIP_TRY(hipMemcpyAsync(dnext, next.data(), next.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
-		HIP_TRY(hipMemcpyAsync(dlist, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
-		HIP_TRY(hipMemcpyAsync(dfirst, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
-		HIP_TRY(hipMemcpyAsync(doffsets, offsets.data(), offsets.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
-		HIP_TRY(hipStreamSynchronize(s->stream));
-		s->msg.vel = dvel, s->msg.dq = ddq, s->msg.next = dnext, s->msg.firstSlot = dfirst, s->msg.slotOffsets = doffsets, s->msg.slotList = dlist;
-		s->msgTablesValid = true;
 	}
 
 	phase("message tables");
 	s->adjValid = false;
+	if ((rc = buildAdjacency(s, conflict, nb)) != 0)
 	{
-		// body -> incident constraints in SWEEP order (ascending k), key = k<<1 | side, so the per-body
-		// sums of jacobiApplyKernel add in exactly the order a sequential pass in sweep order would;
-		// read-only shareable bodies are skipped (their deltas are exact zeros)
-		std::vector<int> offsets((size_t)nb + 1, 0), list;
-		const int GC = cs.globalCount; // LDS groups walk their own colours; only the global part is indexed
-		for (int k = 0; k < GC; ++k)
-		{
-			int a = s->hContactA[cs.order[k]], b = s->hContactB[cs.order[k]];
-			if (conflict[a])
-			{
-				offsets[(size_t)a + 1] += 1;
-			}
-			if (conflict[b])
-			{
-				offsets[(size_t)b + 1] += 1;
-			}
-		}
-		for (int i = 0; i < nb; ++i)
-		{
-			offsets[(size_t)i + 1] += offsets[i];
-		}
-		list.resize((size_t)offsets[nb]);
-		std::vector<int> cursor(offsets.begin(), offsets.end() - 1);
-		for (int k = 0; k < GC; ++k)
-		{
-			int a = s->hContactA[cs.order[k]], b = s->hContactB[cs.order[k]];
-			if (conflict[a])
-			{
-				list[(size_t)cursor[a]++] = (k << 1) | 0;
-			}
-			if (conflict[b])
-			{
-				list[(size_t)cursor[b]++] = (k << 1) | 1;
-			}
-		}
-		grew = false;
-		if ((rc = s->dAdjOffsets.ensure(((size_t)nb + 1) * sizeof(int), &grew)) != 0 ||
-			(rc = s->dAdjList.ensure(std::max<size_t>(list.size(), 1) * sizeof(int), &grew)) != 0)
-		{
-			return rc;
-		}
-		if (grew)
-		{
-			s->layoutGeneration += 1;
-		}
-		std::vector<int> heavy;
-		for (int i = 0; i < nb; ++i)
-		{
-			if (offsets[(size_t)i + 1] - offsets[(size_t)i] > S2_HEAVY_DEGREE)
-			{
-				heavy.push_back(i);
-			}
-		}
-		if ((rc = s->dAdjHeavy.ensure(std::max<size_t>(heavy.size(), 64) * sizeof(int), &grew)) != 0)
-		{
-			return rc;
-		}
-		if (grew)
-		{
-			s->layoutGeneration += 1;
-		}
-		s->adjHeavyCount = (int)heavy.size();
-		if (!heavy.empty())
-		{
-			HIP_TRY(hipMemcpyAsync(s->dAdjHeavy.p, heavy.data(), heavy.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
-		}
-		HIP_TRY(hipMemcpyAsync(s->dAdjOffsets.p, offsets.data(), ((size_t)nb + 1) * sizeof(int), hipMemcpyHostToDevice, s->stream));
-		if (!list.empty())
-		{
-			HIP_TRY(hipMemcpyAsync(s->dAdjList.p, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
-		}
-		s->adjValid = true;
+		return rc;
 	}
 	// the staging vectors above die with this scope: hipMemcpyAsync from pageable host memory
 	// copies through a staging buffer before it returns, so that is safe

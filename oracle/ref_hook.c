@@ -984,6 +984,10 @@ S2REF_API void s2World_Step(s2WorldId worldId, float timeStep, int velIters, int
 			s2Array_Clear(bp->moveArray);
 			s2ClearSet(&bp->moveSet);
 		}
+		if ((world->stepId & 63) == 0)
+		{
+			s2BroadPhase_RebuildTrees(bp); // stage 2 now and then: nobody queries the trees here, but the host's ray casts do
+		}
 	}
 	else
 	{

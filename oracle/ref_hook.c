@@ -13,6 +13,9 @@
 //           HIP solver, which is the literal drop-in test.  s2ref_use_amd() installs such a callback in C: it loads
 //           libs2amd.so and forwards to s2amd_solve, so that any program calling the PUBLIC s2World_Step of this
 //           library (the samples' only entry point) runs on the GPU -- the binding of INTEGRATION.md, working.
+//   whole step (s2ref_use_amd_world): this file's s2World_Step -- the library's exported one; oracle/Makefile renames
+//           the reference's in the compiled world.o -- keeps stages 1 and 2 (trees, contact pool) and runs stage 3, the
+//           solve and stage 4 as one s2amd_world_step on the resident world chain; optionally the pair query too.
 // It reads the reference's internal structs through the reference's own headers; no reference
 // source is copied into this repository.
 

@@ -32,3 +32,36 @@ def test_oracle_chain_equals_reference(path):
     world_chain.assert_worlds_equal(world, want, os.path.basename(path))
     if "pyramid" not in path and "joint_grid" not in path:
         assert separated > 0, "the window was chosen to contain a separation"
+
+
+def test_fuzz_world_generators_run_through_the_oracle_chain():
+    """The generators behind the GPU loop fuzz tests (tests/world_chain.py: rain_world, wreck_world) on the CPU: the whole
+    loop -- pair query, contact creation, stage 3, solve, stage 4 -- through the oracle alone is deterministic, stays
+    finite, and creates and destroys contacts (so the GPU tests that use them do compare something)."""
+    from solver2d_amd import wire
+    from tests import oraclebind, world_chain
+    from tests.test_gpu_world import _create_contacts, _live_pairs
+
+    def loop(world, steps):
+        params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+        created = separated = 0
+        for _ in range(steps):
+            moved = ((world["shapes"]["enlarged"] != 0) & (world["shapes"]["type"] != wire.SHAPE_FREE)).astype(np.uint8)
+            if moved.any():
+                new = oraclebind.find_pairs(world["bodies"], world["shapes"], moved, _live_pairs(world), world["joints"])
+                if len(new):
+                    created += len(new)
+                    _create_contacts(world, new)
+            status = world_chain.oracle_world_step(params, world)
+            separated += int((status == wire.PAIR_SEPARATED).sum())
+        return created, separated
+
+    for make in (lambda: world_chain.rain_world(3, 60), lambda: world_chain.wreck_world(2, 14)):
+        a, b = make(), make()
+        ca, sa = loop(a, 40)
+        cb, sb = loop(b, 40)
+        assert (ca, sa) == (cb, sb) and ca > 20 and sa > 0, (ca, sa, cb, sb)
+        for key in world_chain.WORLD_KEYS:
+            assert a[key].tobytes() == b[key].tobytes(), key
+        live = a["bodies"]["type"] != wire.BODY_FREE
+        assert np.isfinite(a["bodies"]["position"][live]).all()

@@ -59,3 +59,17 @@ def test_sweep_accounting():
     assert wire.solve_sweeps_per_step("TGS_Soft", 8, 0) == 8
     assert wire.solve_sweeps_per_step("Jacobi", 4, 2) == 6
     assert wire.solve_sweeps_per_step("PGS", 4, 2) == 4
+
+
+def test_header_is_plain_c_and_cpp(tmp_path):
+    """include/solver2d_amd.h is the boundary a C host (the reference is C17) and a C++ host both include: it must compile
+    alone, as strict C99 and as C++, with warnings as errors, and pull in nothing but <stdint.h> (no HIP / torch / C++ type can cross it)."""
+    import subprocess
+    header = os.path.join(ROOT, "include", "solver2d_amd.h")
+    includes = [line.strip() for line in open(header) if line.lstrip().startswith("#include")]
+    assert includes == ["#include <stdint.h>"], includes
+    for compiler, std, name in (("gcc", "-std=c99", "t.c"), ("g++", "-std=c++17", "t.cpp")):
+        src = tmp_path / name
+        src.write_text('#include "solver2d_amd.h"\nint main(void) { return (int)sizeof(s2amdBody) == 0; }\n')
+        subprocess.run([compiler, std, "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.dirname(header), str(src)],
+                       check=True, capture_output=True)

@@ -307,7 +307,9 @@ int s2amd_world_upload(s2amdSolver* solver, const s2amdBody* bodies, int32_t bod
 int s2amd_world_step(s2amdSolver* solver, const s2amdStepParams* params, s2amdWorldStepInfo* info);
 /* == the pair discovery of stage 1 (s2amd_find_pairs above) on the resident shapes: moved = the shapes the last refit
  * enlarged, existing pairs = the live pair slots, jointed bodies as uploaded.  New pairs sorted by (A, B) into the host
- * array outPairs.  Call it when info.movedCount > 0, before the next s2amd_world_step (the refit overwrites the flags). */
+ * array outPairs.  Call it when info.movedCount > 0, before the next s2amd_world_step (the refit overwrites the flags).
+ * A successful query consumes the move buffer as s2UpdateBroadPhasePairs does (src/broad_phase.c: moveArray and moveSet
+ * are cleared): every shape's `enlarged` flag is zero afterwards, static shapes included. */
 int s2amd_world_find_pairs(s2amdSolver* solver, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount);
 /* Writes `count` contact slots of the resident world (slot indices < contactCapacity of the upload): the caller's
  * s2CreateContact (src/contact.c:137-203: pool slot, pair flip, mixed friction, empty manifold) or s2DestroyContact

@@ -160,10 +160,12 @@ __global__ __launch_bounds__(S2_BLOCK) void solveJointsKernel(JointView jv, Body
 	}
 }
 
-__global__ __launch_bounds__(S2_BLOCK) void storeJointsKernel(JointView jv, s2amdJoint* wire)
+// stepFailed: see storeImpulsesKernel (contact_kernels.hip) -- a persistent step whose hand-offs timed out leaves EVERY wire
+// array as it was, so that the repeated step warm starts from the same joint impulses
+__global__ __launch_bounds__(S2_BLOCK) void storeJointsKernel(JointView jv, s2amdJoint* wire, const unsigned int* stepFailed)
 {
 	int k = blockIdx.x * blockDim.x + threadIdx.x;
-	if (k >= jv.count)
+	if (k >= jv.count || (stepFailed != nullptr && *stepFailed != 0u))
 	{
 		return;
 	}
@@ -238,10 +240,10 @@ void launchSolveJoints(hipStream_t s, int kind, const JointView& j, const BodyVi
 	}
 }
 
-void launchStoreJoints(hipStream_t s, const JointView& j, s2amdJoint* wire)
+void launchStoreJoints(hipStream_t s, const JointView& j, s2amdJoint* wire, const unsigned int* stepFailed)
 {
 	if (j.count > 0)
 	{
-		storeJointsKernel<<<gridFor(j.count), dim3(S2_BLOCK), 0, s>>>(j, wire);
+		storeJointsKernel<<<gridFor(j.count), dim3(S2_BLOCK), 0, s>>>(j, wire, stepFailed);
 	}
 }

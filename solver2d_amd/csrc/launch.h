@@ -108,7 +108,7 @@ void launchPrepareJoints(hipStream_t s, int kind, const JointView& j, const Body
 						 const StepConsts& sc, float h, float hertz, int warmStart, int posSolver);
 void launchSolveJoints(hipStream_t s, int kind, const JointView& j, const BodyView& b, int begin, int end, const StepConsts& sc, float h,
 					   float inv_h, int useBias);
-void launchStoreJoints(hipStream_t s, const JointView& j, s2amdJoint* wire);
+void launchStoreJoints(hipStream_t s, const JointView& j, s2amdJoint* wire, const unsigned int* stepFailed);
 
 // LDS groups
 int groupKernelSetup();

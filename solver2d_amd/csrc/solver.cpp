@@ -207,6 +207,9 @@ int s2amd_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapacity, 
 		return fail(S2AMD_E_INVALID, "null solver");
 	}
 	s->gatherIndexDirty = true;
+	// the stage-3 / stage-4 arrays of a world chain (s2amd_world_upload) are sized for THAT upload's capacities
+	s->worldResident = false;
+	s->pairKeysValid = false;
 	int rc = doUpload(s, bodies, bodyCapacity, contacts, contactCapacity, joints, jointCapacity);
 	if (rc == S2AMD_OK)
 	{
@@ -242,6 +245,8 @@ int s2amd_solve(s2amdSolver* s, const s2amdStepParams* params, s2amdBody* bodies
 		return fail(S2AMD_E_INVALID, "null solver");
 	}
 	s->gatherIndexDirty = true;
+	s->worldResident = false; // see s2amd_upload
+	s->pairKeysValid = false;
 	int rc = doUpload(s, bodies, bodyCapacity, contacts, contactCapacity, joints, jointCapacity);
 	if (rc)
 	{
@@ -273,6 +278,7 @@ int s2amd_save_bodies(s2amdSolver* s)
 	}
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	s->savedValid = true;
+	s->savedBodyCapacity = s->bodyCapacity;
 	return S2AMD_OK;
 }
 
@@ -286,9 +292,27 @@ int s2amd_synchronize(s2amdSolver* s)
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	if (s->hostError && *s->hostError != 0u)
 	{
+		// A persistent step enqueued under "async" lost a hand-off.  Its epilogue -- and that of every step enqueued behind
+		// it, because the device-side word stays set until it is cleared here -- left the wire arrays untouched, so the
+		// resident world stands where it stood before the first step that failed.  As doStep does on the synchronous path:
+		// clear both error words and the hand-off buffers and keep this solver on the multi-launch strip path; the steps
+		// that were dropped are the caller's to repeat (it knows how many it enqueued; stats.persistFallbacks counts).
 		*s->hostError = 0u;
-		(void)hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, s->stream);
-		return fail(S2AMD_E_DEVICE, "strip hand-off timed out inside the persistent step kernel (workgroups not co-resident?)");
+		if (s->persist.deviceError)
+		{
+			HIP_TRY(hipMemsetAsync(s->persist.deviceError, 0, sizeof(unsigned int), s->stream));
+		}
+		if (s->dGranules.p && s->granuleBytes)
+		{
+			HIP_TRY(hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, s->stream));
+		}
+		HIP_TRY(hipStreamSynchronize(s->stream));
+		s->persistFailed = true;
+		s->persistFallbacks += 1;
+		s->stats.persistFallbacks = s->persistFallbacks;
+		return fail(S2AMD_E_DEVICE, "strip hand-off timed out inside the persistent step kernel (workgroups not co-resident?): the steps enqueued "
+									"since the last s2amd_synchronize were dropped from the failing one on -- repeat them (the solver now uses the "
+									"multi-launch strip path)");
 	}
 	return S2AMD_OK;
 }
@@ -298,6 +322,11 @@ int s2amd_restore_bodies(s2amdSolver* s)
 	if (!s || !s->resident || !s->savedValid)
 	{
 		return fail(S2AMD_E_STATE, "no saved bodies");
+	}
+	if (s->savedBodyCapacity != s->bodyCapacity)
+	{
+		return fail(S2AMD_E_STATE, "the saved bodies belong to a world of another size (" + std::to_string(s->savedBodyCapacity) + " body slots, now " +
+									   std::to_string(s->bodyCapacity) + ")");
 	}
 	HIP_TRY(hipSetDevice(s->device));
 	if (s->bodyCapacity > 0)

@@ -615,16 +615,14 @@ struct Executor
 			count();
 		}
 		// post: SoA -> wire: impulses and bodies in one launch (+ the epoch base of the hand-off tags)
-		{
-			int kind, warm;
-			const bool usedGranules = s->dStripA.view.groupCount > 0 && persistPlan(kind, warm);
-			launchStoreImpulses(st, p.storeKind, s->cv, wireContacts(), p.storeScale, s->bv, wireBodies(), usedGranules ? s->dGranules.p : nullptr,
-								usedGranules ? s->granuleBytes : 0, usedGranules ? s->persist.deviceError : nullptr);
-		}
+		int kind, warm;
+		const bool usedGranules = s->dStripA.view.groupCount > 0 && persistPlan(kind, warm);
+		launchStoreImpulses(st, p.storeKind, s->cv, wireContacts(), p.storeScale, s->bv, wireBodies(), usedGranules ? s->dGranules.p : nullptr,
+							usedGranules ? s->granuleBytes : 0, usedGranules ? s->persist.deviceError : nullptr);
 		count();
 		if (s->jv.count > 0)
 		{
-			launchStoreJoints(st, s->jv, wireJoints());
+			launchStoreJoints(st, s->jv, wireJoints(), usedGranules ? s->persist.deviceError : nullptr);
 			count();
 		}
 	}

@@ -162,6 +162,7 @@ struct s2amdSolver
 	int bodyCapacity = 0, contactCapacity = 0, jointCapacity = 0;
 	bool resident = false;
 	bool savedValid = false;
+	int savedBodyCapacity = 0; // body slots of the snapshot in dBodiesSaved
 
 	// resident world (world.hip): the arrays of stages 3 and 4 beside the solver's wire arrays
 	DevBuf dShapes, dPairs, dOrigins, dStatus, dPointBytes, dWorldSummary, dJointedKeys, dContactStage, dPairScratch, dPairKeys;

@@ -152,6 +152,10 @@ int doUpload(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdContact
 		s->savedValid = false;
 		s->structureDirty = true; // dBodyFlags may have moved
 	}
+	if (nb != s->bodyCapacity)
+	{
+		s->savedValid = false; // s2amd_save_bodies took a snapshot of a world of another size
+	}
 	s->bodyCapacity = nb;
 	s->contactCapacity = nc;
 	s->jointCapacity = nj;

@@ -48,6 +48,19 @@ dim3 gridFor(size_t n)
 	return dim3((unsigned)((n + S2_BLOCK - 1) / S2_BLOCK));
 }
 
+// The pair query has consumed the move buffer (src/broad_phase.c: s2UpdateBroadPhasePairs ends by clearing moveArray and
+// moveSet): every `enlarged` flag goes back to zero.  Stage 4 only rewrites the flags of non-static bodies' shapes, so
+// without this a static shape uploaded "in the move buffer" (as after its creation) would stay there for good -- counted
+// as moved every step, and, never querying itself, suppressing its pairs with moved proxies of a lower key.
+__global__ __launch_bounds__(S2_BLOCK) void clearMovedKernel(s2amdShape* shapes, int n)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n)
+	{
+		shapes[i].enlarged = 0;
+	}
+}
+
 // the contact part of refreshShadows (solver_step.cpp) for point counts produced on the device
 void applyPointCounts(s2amdSolver* s)
 {
@@ -309,9 +322,15 @@ int s2amd_world_find_pairs(s2amdSolver* s, int32_t* outPairs, int32_t pairCapaci
 			return rc;
 		}
 	}
-	return findPairsResident(s->stream, (const s2amdShape*)s->dShapes.p, s->shapeCapacity, s->liveShapes, (const s2amdPairState*)s->dPairs.p, s->contactCapacity,
-							 (const unsigned long long*)s->dJointedKeys.p, s->jointedCount, outPairs, pairCapacity, pairCount, &s->dPairScratch.p,
-							 &s->dPairScratch.bytes, (unsigned long long*)s->dPairKeys.p, &s->pairKeysValid);
+	int rc = findPairsResident(s->stream, (const s2amdShape*)s->dShapes.p, s->shapeCapacity, s->liveShapes, (const s2amdPairState*)s->dPairs.p, s->contactCapacity,
+							   (const unsigned long long*)s->dJointedKeys.p, s->jointedCount, outPairs, pairCapacity, pairCount, &s->dPairScratch.p,
+							   &s->dPairScratch.bytes, (unsigned long long*)s->dPairKeys.p, &s->pairKeysValid);
+	if (rc == S2AMD_OK && s->shapeCapacity > 0) // (S2AMD_E_CAPACITY: the caller asks again with a larger buffer)
+	{
+		clearMovedKernel<<<gridFor((size_t)s->shapeCapacity), dim3(S2_BLOCK), 0, s->stream>>>((s2amdShape*)s->dShapes.p, s->shapeCapacity);
+		HIP_TRY(hipGetLastError());
+	}
+	return rc;
 }
 
 int s2amd_world_set_contacts(s2amdSolver* s, const int32_t* slots, int32_t count, const s2amdContact* contacts, const s2amdPairState* pairs)

@@ -387,8 +387,10 @@ typedef struct SceneEntry
 	const char* name;
 } SceneEntry;
 
-static const SceneEntry s_scenes[] = {{"pyramid"},		   {"multi_pyramid"}, {"joint_grid"}, {"tumbler"},
-									  {"mixed"},		   {"vertical_stack"}, {"circle_pile"}};
+static const SceneEntry s_scenes[] = {{"pyramid"},		{"multi_pyramid"},	{"joint_grid"},		  {"tumbler"},	  {"mixed"},
+									  {"vertical_stack"}, {"circle_pile"},	{"shapes_zoo"},		  {"arch"},		  {"high_mass_ratio"},
+									  {"overlap_recovery"}, {"card_house"}, {"far_pyramid"},	  {"far_stack"},  {"far_recovery"},
+									  {"far_ragdoll_pile"}, {"far_chain"},	{"ragdoll"},		  {"ball_and_chain"}, {"bridge"}};
 
 S2SCENE_API int s2scene_count(void)
 {
@@ -480,6 +482,413 @@ static void sceneShapesZoo(s2WorldId w, int count)
 	}
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The reference's own edge-case samples (the 30 GUI samples ARE its test corpus), restated headless
+// through the public API.  Each recipe cites the sample whose construction it follows; numbers (sizes, densities,
+// limits) are the sample's, the code is this file's own (table-driven where the sample repeats itself).
+// ---------------------------------------------------------------------------------------------
+
+static s2BodyId makeDynamic(s2WorldId w, float x, float y, float angle)
+{
+	s2BodyDef bd = s2_defaultBodyDef;
+	bd.type = s2_dynamicBody;
+	bd.position = (s2Vec2){x, y};
+	bd.angle = angle;
+	return s2CreateBody(w, &bd);
+}
+
+static s2BodyId makeGroundSegment(s2WorldId w, float ox, float oy, float halfLength, const s2ShapeDef* sd)
+{
+	s2BodyDef bd = s2_defaultBodyDef;
+	bd.position = (s2Vec2){ox, oy};
+	s2BodyId ground = s2CreateBody(w, &bd);
+	s2Segment seg = {{-halfLength, 0.0f}, {halfLength, 0.0f}};
+	s2CreateSegmentShape(ground, sd, &seg);
+	return ground;
+}
+
+static void addQuad(s2WorldId w, const s2ShapeDef* sd, s2Vec2 a, s2Vec2 b, s2Vec2 c, s2Vec2 d)
+{
+	s2BodyId id = makeDynamic(w, 0.0f, 0.0f, 0.0f);
+	s2Vec2 ps[4] = {a, b, c, d};
+	s2Hull hull = s2ComputeHull(ps, 4);
+	s2Polygon poly = s2MakePolygon(&hull);
+	s2CreatePolygonShape(id, sd, &poly);
+}
+
+// "Arch" (samples/collection/sample_contact.cpp:666-759): 17 voussoirs cut from two catenary-like curves, four slabs on
+// the keystone, segment ground.  Wedge-shaped polygons under compression: friction-dominated, all 2-point manifolds
+// between non-box hulls.  The curve tables are the sample's data.
+static void sceneArch(s2WorldId w)
+{
+	static const float inner[9][2] = {{16.0f, 0.0f},
+									  {14.93803712795643f, 5.133601056842984f},
+									  {13.79871746027416f, 10.24928069555078f},
+									  {12.56252963284711f, 15.34107019122473f},
+									  {11.20040987372525f, 20.39856541571217f},
+									  {9.66521217819836f, 25.40369899225096f},
+									  {7.87179930638133f, 30.3179337000085f},
+									  {5.635199558196225f, 35.03820717801641f},
+									  {2.405937953536585f, 39.09554102558315f}};
+	static const float outer[9][2] = {{24.0f, 0.0f},
+									  {22.33619528222415f, 6.02299846205841f},
+									  {20.54936888969905f, 12.00964361211476f},
+									  {18.60854610798073f, 17.9470321677465f},
+									  {16.46769273811807f, 23.81367936585418f},
+									  {14.05325025774858f, 29.57079353071012f},
+									  {11.23551045834022f, 35.13775818285372f},
+									  {7.752568160730571f, 40.30450679009583f},
+									  {3.016931552701656f, 44.28891593799322f}};
+	const float scale = 0.25f;
+	s2Vec2 in[9], out[9];
+	for (int i = 0; i < 9; ++i)
+	{
+		in[i] = s2MulSV(scale, (s2Vec2){inner[i][0], inner[i][1]});
+		out[i] = s2MulSV(scale, (s2Vec2){outer[i][0], outer[i][1]});
+	}
+	s2ShapeDef sd = s2_defaultShapeDef;
+	sd.friction = 0.6f;
+	makeGroundSegment(w, 0.0f, 0.0f, 100.0f, &sd);
+	for (int i = 0; i < 8; ++i) // right leg, ground up
+	{
+		addQuad(w, &sd, in[i], out[i], out[i + 1], in[i + 1]);
+	}
+	for (int i = 0; i < 8; ++i) // left leg: the mirror image
+	{
+		addQuad(w, &sd, (s2Vec2){-out[i].x, out[i].y}, (s2Vec2){-in[i].x, in[i].y}, (s2Vec2){-in[i + 1].x, in[i + 1].y},
+				(s2Vec2){-out[i + 1].x, out[i + 1].y});
+	}
+	addQuad(w, &sd, in[8], out[8], (s2Vec2){-out[8].x, out[8].y}, (s2Vec2){-in[8].x, in[8].y}); // keystone
+	s2Polygon slab = s2MakeBox(2.0f, 0.5f);
+	for (int i = 0; i < 4; ++i)
+	{
+		s2BodyId id = makeDynamic(w, 0.0f, 0.5f + out[8].y + 1.0f * i, 0.0f);
+		s2CreatePolygonShape(id, &sd, &slab);
+	}
+}
+
+// "High Mass Ratio 1/2/3" (sample_contact.cpp:122-299).  variant 1: three 10-base pyramids of 2 m boxes whose top box
+// (dropped from 2 m above) weighs 100x, 200x, 300x a normal one; 2: a 20 m box falling onto two 1 m boxes on a
+// segment; 3: the same on a thick box ground.  Mass ratios of 400:1 are where the ten solvers differ most.
+static void sceneHighMassRatio(s2WorldId w, int variant)
+{
+	s2ShapeDef sd = s2_defaultShapeDef;
+	if (variant <= 1)
+	{
+		const float e = 1.0f;
+		sd.friction = 0.5f;
+		makeGroundSegment(w, 0.0f, 0.0f, 66.0f * e, &sd);
+		s2Polygon box = s2MakeBox(e, e);
+		for (int pile = 0; pile < 3; ++pile)
+		{
+			const float offset = -20.0f * e + 2.0f * (10 + 1.0f) * e * pile;
+			float y = e;
+			for (int row = 10; row > 0; --row, y += 2.0f * e)
+			{
+				for (int i = 0; i < row; ++i)
+				{
+					s2BodyId id = makeDynamic(w, 2.0f * (i - 0.5f * row) * e + offset, row == 1 ? y + 2.0f : y, 0.0f);
+					sd.density = row == 1 ? (pile + 1.0f) * 100.0f : 1.0f;
+					s2CreatePolygonShape(id, &sd, &box);
+				}
+			}
+		}
+		return;
+	}
+	sd.density = 1.0f;
+	if (variant == 2)
+	{
+		makeGroundSegment(w, 0.0f, 0.0f, 20.0f, &sd);
+	}
+	else
+	{
+		makeStaticBox(w, 0.0f, -2.0f, 40.0f, 2.0f, 0.0f);
+	}
+	const float e = 1.0f;
+	s2Polygon small = s2MakeBox(0.5f * e, 0.5f * e), big = s2MakeBox(10.0f * e, 10.0f * e);
+	s2CreatePolygonShape(makeDynamic(w, -9.0f * e, 0.5f * e, 0.0f), &sd, &small);
+	s2CreatePolygonShape(makeDynamic(w, 9.0f * e, 0.5f * e, 0.0f), &sd, &small);
+	s2CreatePolygonShape(makeDynamic(w, 0.0f, (10.0f + 16.0f) * e, 0.0f), &sd, &big);
+}
+
+// "Overlap Recovery" (sample_contact.cpp:368-418) and, with a far origin, "Far/Recovery" (sample_far.cpp:180-233): a
+// 4-base pyramid of unit boxes created 25 % inside each other -- large negative separations, the push-out path of every
+// solver (Baumgarte caps, soft-contact bias caps, NGS max correction).
+static void sceneOverlapRecovery(s2WorldId w, float ox, float oy)
+{
+	const int baseCount = 4;
+	const float overlap = 0.25f, extent = 0.5f;
+	makeGroundSegment(w, ox, oy, 40.0f, &s2_defaultShapeDef);
+	s2Polygon box = s2MakeSquare(extent);
+	const float fraction = 1.0f - overlap;
+	float y = extent;
+	for (int i = 0; i < baseCount; ++i, y += 2.0f * fraction * extent)
+	{
+		float x = fraction * extent * (i - baseCount);
+		for (int j = i; j < baseCount; ++j, x += 2.0f * fraction * extent)
+		{
+			s2CreatePolygonShape(makeDynamic(w, ox + x, oy + y, 0.0f), &s2_defaultShapeDef, &box);
+		}
+	}
+}
+
+// "Card House" (sample_contact.cpp:888-963, from PEEL): 2 mm thick cards leaning at +-25 degrees with horizontal cards
+// across the peaks, five storeys.  Extreme aspect ratios, tiny inertia, friction 0.7.
+static void sceneCardHouse(s2WorldId w)
+{
+	s2ShapeDef sd = s2_defaultShapeDef;
+	sd.friction = 0.7f;
+	{
+		s2BodyDef bd = s2_defaultBodyDef;
+		bd.position = (s2Vec2){0.0f, -2.0f};
+		s2BodyId ground = s2CreateBody(w, &bd);
+		s2Polygon g = s2MakeBox(40.0f, 2.0f);
+		s2CreatePolygonShape(ground, &sd, &g);
+	}
+	const float cardHeight = 0.2f, cardThickness = 0.001f;
+	const float lean = 25.0f * s2_pi / 180.0f, flat = 0.5f * s2_pi;
+	s2Polygon card = s2MakeBox(cardThickness, cardHeight);
+	float z0 = 0.0f, y = cardHeight - 0.02f;
+	for (int storey = 5; storey > 0; --storey)
+	{
+		float z = z0;
+		for (int i = 0; i < storey; ++i)
+		{
+			if (i != storey - 1)
+			{
+				s2CreatePolygonShape(makeDynamic(w, z + 0.25f, y + cardHeight - 0.015f, flat), &sd, &card);
+			}
+			s2CreatePolygonShape(makeDynamic(w, z, y, -lean), &sd, &card);
+			z += 0.175f;
+			s2CreatePolygonShape(makeDynamic(w, z, y, lean), &sd, &card);
+			z += 0.175f;
+		}
+		y += cardHeight * 2.0f - 0.03f;
+		z0 += 0.175f;
+	}
+}
+
+// "Far/Pyramid" (sample_far.cpp:15-83): a 10-base pyramid with a 25 % gap between boxes, 100 km from the origin, where
+// one float ulp of a coordinate is 7.8 mm -- larger than the linear slop.  Exercises the centre-of-mass-relative
+// arithmetic (delta positions, anchors relative to the body) that the TGS solvers rely on.
+static void sceneFarPyramid(s2WorldId w, float ox, float oy)
+{
+	makeStaticBox(w, ox, oy - 1.0f, 100.0f, 1.0f, 0.0f);
+	s2ShapeDef sd = s2_defaultShapeDef;
+	sd.density = 1.0f;
+	const int baseCount = 10;
+	const float h = 0.5f, shift = 1.25f * h;
+	s2Polygon box = s2MakeSquare(h);
+	for (int i = 0; i < baseCount; ++i)
+	{
+		float y = (2.0f * i + 1.0f) * shift + 0.5f;
+		for (int j = i; j < baseCount; ++j)
+		{
+			float x = (i + 1.0f) * shift + 2.0f * (j - i) * shift - h * baseCount;
+			s2CreatePolygonShape(makeDynamic(w, x + ox, y + oy, 0.0f), &sd, &box);
+		}
+	}
+}
+
+// "Far/Stack" (sample_far.cpp:85-164): a plank balanced on a small circle and a small box, two boxes on the plank;
+// 47 km from the origin.
+static void sceneFarStack(s2WorldId w, float ox, float oy)
+{
+	makeStaticBox(w, ox, oy - 1.0f, 10.0f, 1.0f, 0.0f);
+	s2ShapeDef sd = s2_defaultShapeDef;
+	sd.density = 1.0f;
+	s2Circle ball = {{0.0f, 0.0f}, 0.1f};
+	s2CreateCircleShape(makeDynamic(w, ox + 1.875f, oy + 0.125f, 0.0f), &sd, &ball);
+	static const float boxes[4][4] = {// x, y, hx, hy
+									  {-1.875f, 0.15f, 0.1f, 0.125f},
+									  {0.0f, 0.325f, 2.0f, 0.05f},
+									  {-0.5f, 0.9f, 0.25f, 0.25f},
+									  {-0.55f, 1.7f, 0.5f, 0.5f}};
+	for (int i = 0; i < 4; ++i)
+	{
+		s2Polygon b = s2MakeBox(boxes[i][2], boxes[i][3]);
+		s2CreatePolygonShape(makeDynamic(w, ox + boxes[i][0], oy + boxes[i][1], 0.0f), &sd, &b);
+	}
+}
+
+// The ragdoll of samples/collection/human.cpp as a table: per bone the parent, the body height, one or two capsules
+// (centre-line end points and radius, all times the scale), the pivot height, the limit angles in units of pi and the
+// motor torque as a fraction of 0.025 * scale.  Every joint has limit AND motor enabled (motor speed 0: joint friction),
+// all shapes share a negative group index so the bones of one ragdoll never collide with each other.
+typedef struct BoneRow
+{
+	int parent;
+	float bodyY;
+	float cap[2][5]; // x1, y1, x2, y2, radius; radius 0 = no second capsule
+	int footSecond;	 // the second capsule uses the low-friction foot material
+	float pivotY, lower, upper, torque;
+} BoneRow;
+
+static const BoneRow s_human[11] = {
+	{-1, 0.95f, {{0.0f, -0.02f, 0.0f, 0.025f, 0.095f}, {0}}, 0, 0.0f, 0.0f, 0.0f, 0.0f},						   // hip
+	{0, 1.2f, {{0.0f, -0.135f, 0.0f, 0.135f, 0.09f}, {0}}, 0, 1.025f, -0.25f, 0.0f, 0.5f},						   // torso
+	{1, 1.5f, {{0.0f, -0.0325f, 0.0f, 0.0325f, 0.08f}, {0.0f, -0.12f, 0.0f, -0.08f, 0.05f}}, 0, 1.4f, -0.3f, 0.1f, 0.25f}, // head + neck
+	{0, 0.775f, {{0.0f, -0.125f, 0.0f, 0.125f, 0.055f}, {0}}, 0, 0.9f, -0.05f, 0.4f, 1.0f},					   // upper left leg
+	{3, 0.475f, {{0.0f, -0.14f, 0.0f, 0.125f, 0.045f}, {-0.02f, -0.175f, 0.13f, -0.175f, 0.03f}}, 1, 0.625f, -0.5f, -0.02f, 0.5f}, // lower left leg + foot
+	{0, 0.775f, {{0.0f, -0.125f, 0.0f, 0.125f, 0.055f}, {0}}, 0, 0.9f, -0.05f, 0.4f, 1.0f},					   // upper right leg
+	{5, 0.475f, {{0.0f, -0.14f, 0.0f, 0.125f, 0.045f}, {-0.02f, -0.175f, 0.13f, -0.175f, 0.03f}}, 1, 0.625f, -0.5f, -0.02f, 0.5f}, // lower right leg + foot
+	{1, 1.225f, {{0.0f, -0.125f, 0.0f, 0.125f, 0.035f}, {0}}, 0, 1.35f, -0.05f, 0.8f, 0.25f},					   // upper left arm
+	{7, 0.975f, {{0.0f, -0.125f, 0.0f, 0.125f, 0.03f}, {0}}, 0, 1.1f, 0.01f, 0.5f, 0.1f},						   // lower left arm
+	{1, 1.225f, {{0.0f, -0.125f, 0.0f, 0.125f, 0.035f}, {0}}, 0, 1.35f, -0.05f, 0.8f, 0.25f},					   // upper right arm
+	{9, 0.975f, {{0.0f, -0.125f, 0.0f, 0.125f, 0.03f}, {0}}, 0, 1.1f, 0.01f, 0.5f, 0.1f},						   // lower right arm
+};
+
+static void spawnHuman(s2WorldId w, float px, float py, float scale, int groupIndex)
+{
+	s2ShapeDef sd = s2_defaultShapeDef;
+	sd.friction = 0.4f;
+	sd.filter.groupIndex = -groupIndex;
+	s2ShapeDef foot = sd;
+	foot.friction = 0.1f;
+	const float s = scale, maxTorque = 0.025f * s;
+	s2BodyId bones[11];
+	for (int i = 0; i < 11; ++i)
+	{
+		const BoneRow* r = s_human + i;
+		bones[i] = makeDynamic(w, px + 0.0f, py + r->bodyY * s, 0.0f);
+		for (int c = 0; c < 2; ++c)
+		{
+			if (r->cap[c][4] > 0.0f)
+			{
+				s2Capsule cap = {{r->cap[c][0] * s, r->cap[c][1] * s}, {r->cap[c][2] * s, r->cap[c][3] * s}, r->cap[c][4] * s};
+				s2CreateCapsuleShape(bones[i], (c == 1 && r->footSecond) ? &foot : &sd, &cap);
+			}
+		}
+		if (r->parent >= 0)
+		{
+			s2Vec2 pivot = {px + 0.0f, py + r->pivotY * s};
+			s2RevoluteJointDef jd = s2DefaultRevoluteJointDef();
+			jd.bodyIdA = bones[r->parent];
+			jd.bodyIdB = bones[i];
+			jd.localAnchorA = s2Body_GetLocalPoint(jd.bodyIdA, pivot);
+			jd.localAnchorB = s2Body_GetLocalPoint(jd.bodyIdB, pivot);
+			jd.enableLimit = true;
+			jd.lowerAngle = r->lower * s2_pi;
+			jd.upperAngle = r->upper * s2_pi;
+			jd.enableMotor = true;
+			jd.maxMotorTorque = r->torque * maxTorque;
+			jd.drawSize = 0.025f;
+			s2CreateRevoluteJoint(w, &jd);
+		}
+	}
+}
+
+// "Ragdoll" (sample_joints.cpp:208-240): one ragdoll dropped from 4 m onto a box ground: ten revolute joints with
+// limits and motors -- the relative-angle (atan2f) path under load.
+static void sceneRagdoll(s2WorldId w)
+{
+	makeStaticBox(w, 0.0f, -1.0f, 20.0f, 1.0f, 0.0f);
+	spawnHuman(w, 0.0f, 4.0f, 1.0f, 1);
+}
+
+// "Far/Ragdoll Pile" (sample_far.cpp:235-281): six ragdolls dropped into a V of two tilted planks (two shapes on one
+// static body), 6 km from the origin.
+static void sceneFarRagdollPile(s2WorldId w, float ox, float oy)
+{
+	s2BodyDef bd = s2_defaultBodyDef;
+	bd.position = (s2Vec2){ox, oy - 1.0f};
+	s2BodyId ground = s2CreateBody(w, &bd);
+	s2Polygon plank = s2MakeOffsetBox(10.0f, 0.5f, (s2Vec2){-5.0f, 2.0f}, -0.15f * s2_pi);
+	s2CreatePolygonShape(ground, &s2_defaultShapeDef, &plank);
+	plank = s2MakeOffsetBox(10.0f, 0.5f, (s2Vec2){5.0f, 2.0f}, 0.15f * s2_pi);
+	s2CreatePolygonShape(ground, &s2_defaultShapeDef, &plank);
+	static const float at[6][2] = {{0.0f, 0.5f}, {-0.2f, 1.0f}, {0.2f, 1.0f}, {-0.4f, 1.5f}, {0.4f, 1.5f}, {0.0f, 2.0f}};
+	for (int i = 0; i < 6; ++i)
+	{
+		spawnHuman(w, ox + at[i][0], oy + at[i][1], 1.0f, i + 1);
+	}
+}
+
+// A chain of `count` capsule links of half-length hx hanging from a static body at (ox, oy), optionally ending in a
+// heavy ball: "Ball & Chain" (sample_joints.cpp:107-188; 40 links of 0.5 m, ball radius 8 m -- mass ratio ~1600:1 along a
+// joint chain) and "Far Chain" (sample_far.cpp:283-342; 40 links of 0.1 m, no ball, 53 km from the origin, anchors
+// given in local coordinates because s2Body_GetLocalPoint would lose them to rounding out there).
+static void sceneChain(s2WorldId w, float ox, float oy, int count, float hx, float radius, float ballRadius)
+{
+	s2BodyDef gd = s2_defaultBodyDef;
+	gd.position = (s2Vec2){ox, oy};
+	s2BodyId prev = s2CreateBody(w, &gd);
+	s2ShapeDef sd = s2_defaultShapeDef;
+	sd.density = 20.0f;
+	s2Capsule link = {{-hx, 0.0f}, {hx, 0.0f}, radius};
+	s2RevoluteJointDef jd = s2DefaultRevoluteJointDef();
+	jd.drawSize = 0.1f;
+	s2Vec2 prevLocal = {0.0f, count * hx};
+	for (int i = 0; i <= count; ++i)
+	{
+		const int ball = i == count;
+		if (ball && ballRadius <= 0.0f)
+		{
+			break;
+		}
+		s2BodyDef bd = s2_defaultBodyDef;
+		bd.type = s2_dynamicBody;
+		bd.linearDamping = 0.1f;
+		bd.angularDamping = 0.1f;
+		float localX = ball ? -(ballRadius - hx) - hx : -hx; // the pivot in the new body's frame
+		bd.position = (s2Vec2){ox + (ball ? (1.0f + 2.0f * count) * hx + ballRadius - hx : (1.0f + 2.0f * i) * hx), oy + count * hx};
+		s2BodyId id = s2CreateBody(w, &bd);
+		if (ball)
+		{
+			s2Circle c = {{0.0f, 0.0f}, ballRadius};
+			s2CreateCircleShape(id, &sd, &c);
+		}
+		else
+		{
+			s2CreateCapsuleShape(id, &sd, &link);
+		}
+		jd.bodyIdA = prev;
+		jd.bodyIdB = id;
+		jd.localAnchorA = prevLocal;
+		jd.localAnchorB = (s2Vec2){localX, 0.0f};
+		s2CreateRevoluteJoint(w, &jd);
+		prevLocal = (s2Vec2){hx, 0.0f};
+		prev = id;
+	}
+}
+
+// "Bridge" (sample_joints.cpp:17-92): `count` planks (1 m x 0.25 m, density 20) hinged end to end between two points of
+// one static body, 20 m up: a closed joint chain, the hardest case for sequential-impulse joint solvers.
+static void sceneBridge(s2WorldId w, int count)
+{
+	s2BodyDef gd = s2_defaultBodyDef;
+	s2BodyId ground = s2CreateBody(w, &gd);
+	s2Polygon plank = s2MakeBox(0.5f, 0.125f);
+	s2ShapeDef sd = s2_defaultShapeDef;
+	sd.density = 20.0f;
+	s2RevoluteJointDef jd = s2DefaultRevoluteJointDef();
+	jd.drawSize = 0.1f;
+	const float xbase = -0.5f * count;
+	s2BodyId prev = ground;
+	for (int i = 0; i <= count; ++i)
+	{
+		s2BodyId id = ground;
+		if (i < count)
+		{
+			s2BodyDef bd = s2_defaultBodyDef;
+			bd.type = s2_dynamicBody;
+			bd.position = (s2Vec2){xbase + 0.5f + 1.0f * i, 20.0f};
+			bd.linearDamping = 0.1f;
+			bd.angularDamping = 0.1f;
+			id = s2CreateBody(w, &bd);
+			s2CreatePolygonShape(id, &sd, &plank);
+		}
+		s2Vec2 pivot = {xbase + 1.0f * i, 20.0f};
+		jd.bodyIdA = prev;
+		jd.bodyIdB = id;
+		jd.localAnchorA = s2Body_GetLocalPoint(prev, pivot);
+		jd.localAnchorB = s2Body_GetLocalPoint(id, pivot);
+		s2CreateRevoluteJoint(w, &jd);
+		prev = id;
+	}
+}
+
 // Returns the new world (null id on unknown scene / no free world slot).
 S2SCENE_API s2WorldId s2scene_create(const char* name, int solverType, int p0, int p1)
 {
@@ -523,6 +932,54 @@ S2SCENE_API s2WorldId s2scene_create(const char* name, int solverType, int p0, i
 	else if (strcmp(name, "shapes_zoo") == 0)
 	{
 		sceneShapesZoo(w, p0 > 0 ? p0 : 40);
+	}
+	else if (strcmp(name, "arch") == 0)
+	{
+		sceneArch(w);
+	}
+	else if (strcmp(name, "high_mass_ratio") == 0) // p0 = 1, 2, 3: the three samples
+	{
+		sceneHighMassRatio(w, p0 > 0 ? p0 : 1);
+	}
+	else if (strcmp(name, "overlap_recovery") == 0)
+	{
+		sceneOverlapRecovery(w, 0.0f, 0.0f);
+	}
+	else if (strcmp(name, "card_house") == 0)
+	{
+		sceneCardHouse(w);
+	}
+	else if (strcmp(name, "far_pyramid") == 0)
+	{
+		sceneFarPyramid(w, 100000.0f, -80000.0f);
+	}
+	else if (strcmp(name, "far_stack") == 0)
+	{
+		sceneFarStack(w, 40000.0f, -25000.0f);
+	}
+	else if (strcmp(name, "far_recovery") == 0)
+	{
+		sceneOverlapRecovery(w, 80000.0f, -70000.0f);
+	}
+	else if (strcmp(name, "far_ragdoll_pile") == 0)
+	{
+		sceneFarRagdollPile(w, 6000.0f, -1500.0f);
+	}
+	else if (strcmp(name, "far_chain") == 0)
+	{
+		sceneChain(w, 40000.0f, -35000.0f, 40, 0.1f, 0.025f, 0.0f);
+	}
+	else if (strcmp(name, "ragdoll") == 0)
+	{
+		sceneRagdoll(w);
+	}
+	else if (strcmp(name, "ball_and_chain") == 0)
+	{
+		sceneChain(w, 0.0f, 0.0f, p0 > 0 ? p0 : 40, 0.5f, 0.125f, 8.0f);
+	}
+	else if (strcmp(name, "bridge") == 0)
+	{
+		sceneBridge(w, p0 > 0 ? p0 : 160);
 	}
 	else
 	{

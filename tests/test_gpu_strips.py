@@ -340,6 +340,42 @@ def test_a_dead_hand_off_falls_back_to_the_multi_launch_path():
         common.compare_exact(got, want, "dead hand-off, resident")
 
 
+def test_a_dead_hand_off_under_async_is_reported_and_the_solver_recovers():
+    """The same fault with option "async": steps are enqueued without a host sync, the failure surfaces at
+    s2amd_synchronize.  Contract: the call fails with a device error, the resident world stands where it stood before the
+    first failed step (every later epilogue saw the flag too), both error words are cleared and the solver stays on the
+    multi-launch strip path -- the caller repeats the dropped steps and gets bit-exact results."""
+    pre = synthetic.pyramid(100)
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
+        s.set_option("persist_spin_limit", 4096)
+        s.set_option("persist_debug", 8)
+        s.set_option("async", 1)
+        s.upload(*pre)
+        for _ in range(3):
+            s.step_resident(params)
+        with pytest.raises(hip.S2AmdError):
+            s.synchronize()
+        assert s.stats()["persistFallbacks"] == 1
+        got = common.copy3(pre)
+        s.download(*got)
+        for f in ("position", "rot", "linearVelocity", "angularVelocity"):
+            assert np.array_equal(got[0][f].view(np.uint32), pre[0][f].view(np.uint32)), f
+        assert got[1]["points"].tobytes() == pre[1]["points"].tobytes()
+        # the caller repeats the three steps: no second time-out, results exact
+        want = common.copy3(pre)
+        for step in range(3):
+            s.step_resident(params)
+            s.synchronize()
+            assert s.stats()["persistent"] == 0 and s.stats()["persistFallbacks"] == 1
+            order, _ = s.contact_order()
+            oraclebind.solve(params, *want, contact_order=order)
+        got = common.copy3(pre)
+        s.download(*got)
+        common.compare_exact(got, want, "async dead hand-off, repeated steps")
+
+
 def test_strip_patience_backs_off_when_the_graph_keeps_changing():
     """The strip structure takes milliseconds of host time: when it dies young (the graph changes again within a few
     steps) the patience doubles, so a world that keeps changing stays on the colour batches."""

@@ -179,8 +179,7 @@ def test_world_loop_with_pair_creation():
             if info["movedCount"] > 0:
                 queries += 1
                 got = s.world_find_pairs()
-                moved = (ref["shapes"]["enlarged"] != 0).astype(np.uint8)
-                want = oraclebind.find_pairs(ref["bodies"], ref["shapes"], moved, _live_pairs(ref), ref["joints"])
+                want = world_chain.oracle_find_pairs(ref)
                 assert np.array_equal(got, want), "step %d: new pairs" % step
                 if len(got):
                     created += len(got)
@@ -212,8 +211,7 @@ def test_resident_pair_query_equals_the_stage_function(path):
             world_chain.oracle_world_step(params, ref, contact_order=order, joint_order=jorder)
             if info["movedCount"] > 0:
                 asked += 1
-                moved = ((ref["shapes"]["enlarged"] != 0) & (ref["shapes"]["type"] != wire.SHAPE_FREE)).astype(np.uint8)
-                want = oraclebind.find_pairs(ref["bodies"], ref["shapes"], moved, _live_pairs(ref), ref["joints"])
+                want = world_chain.oracle_find_pairs(ref)
                 assert np.array_equal(s.world_find_pairs(), want), "step %d" % step
     if "pyramid" not in path and "joint_grid" not in path:
         assert asked > 0
@@ -242,8 +240,7 @@ def test_tumbler_world_loop():
             assert info["separatedCount"] == int((status == wire.PAIR_SEPARATED).sum())
             if info["movedCount"] > 0:
                 got = s.world_find_pairs()
-                moved = ((ref["shapes"]["enlarged"] != 0) & (ref["shapes"]["type"] != wire.SHAPE_FREE)).astype(np.uint8)
-                want = oraclebind.find_pairs(ref["bodies"], ref["shapes"], moved, _live_pairs(ref), ref["joints"])
+                want = world_chain.oracle_find_pairs(ref)
                 assert np.array_equal(got, want), "step %d: new pairs" % step
                 if len(got):
                     created += len(got)
@@ -272,6 +269,7 @@ def test_world_from_scratch_finds_every_touching_pair():
     with hip.Solver(0) as s:
         s.world_upload(*[world[k] for k in world_chain.WORLD_KEYS])
         got = s.world_find_pairs()
+        ref["shapes"]["enlarged"] = 0  # the query consumed the move buffer
         assert {(min(a, b), max(a, b)) for a, b in got.tolist()} == expected and len(got) == len(expected)
         slots, contacts, pairs = _create_contacts(ref, got)
         s.world_set_contacts(slots, contacts, pairs)
@@ -283,6 +281,55 @@ def test_world_from_scratch_finds_every_touching_pair():
             res = s.world_download(*[out[k] for k in world_chain.WORLD_KEYS])
             world_chain.assert_device_equals_oracle(dict(zip(world_chain.WORLD_KEYS, res[:6])), ref, "from scratch step %d" % step)
             assert info["activeContacts"] == len(expected)
+
+
+def test_static_shape_with_the_higher_proxy_key_leaves_the_move_buffer():
+    """A static shape uploaded "in the move buffer" (enlarged = 1, as after its creation) whose proxy key is HIGHER than
+    that of a dynamic box falling towards it.  The reference clears the move buffer at the end of every pair update
+    (src/broad_phase.c: s2UpdateBroadPhasePairs), so the ground is a moved proxy for one query only; if its flag stuck,
+    the falling box's query would skip the pair for good ("both moved: the lower key reports", and the static shape
+    never queries) and the box would tunnel.  Whole loop against the oracle chain; the box must come to rest on the ground."""
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    bodies = np.zeros(2, dtype=wire.body_dtype)
+    synthetic._dynamic_body(bodies[0], 0.0, 1.2, synthetic.BOX_MASS, synthetic.BOX_I)
+    synthetic._static_body(bodies[1], 0.0, -1.0)
+    shapes = np.zeros(2, dtype=wire.shape_dtype)
+    synthetic._box_shape(shapes[0], 0, wire.BODY_DYNAMIC, 0.5, 0.5, 0.0, 1.2, 0)
+    synthetic._box_shape(shapes[1], 1, wire.BODY_STATIC, 20.0, 1.0, 0.0, -1.0, 1)
+    assert shapes["proxyKey"][1] > shapes["proxyKey"][0]
+    shapes["enlarged"] = 1
+    contacts = np.zeros(4, dtype=wire.contact_dtype)
+    contacts["constraintIndex"] = -1
+    pairs = np.zeros(4, dtype=wire.pair_state_dtype)
+    pairs["shapeA"] = -1
+    pairs["shapeB"] = -1
+    world = {"bodies": bodies, "contacts": contacts, "joints": np.zeros(0, dtype=wire.joint_dtype), "shapes": shapes, "pairs": pairs,
+             "origins": np.ascontiguousarray(bodies["position"], dtype=np.float32).copy()}
+    ref = world_chain.copy_world(world)
+    created_at = None
+    with hip.Solver(0) as s:
+        s.world_upload(*[world[k] for k in world_chain.WORLD_KEYS])
+        for step in range(90):
+            if world_chain.moved_any(ref):
+                got = s.world_find_pairs()
+                want = world_chain.oracle_find_pairs(ref)
+                assert np.array_equal(got, want), "step %d" % step
+                if len(got):
+                    assert created_at is None and got.tolist() == [[0, 1]]
+                    created_at = step
+                    slots, cs, ps = _create_contacts(ref, got)
+                    s.world_set_contacts(slots, cs, ps)
+            info = s.world_step(params)
+            order, _ = s.contact_order()
+            world_chain.oracle_world_step(params, ref, contact_order=order)
+            out = world_chain.copy_world(world)
+            res = s.world_download(*[out[k] for k in world_chain.WORLD_KEYS])
+            world_chain.assert_device_equals_oracle(dict(zip(world_chain.WORLD_KEYS, res[:6])), ref, "falling box step %d" % step)
+            if step == 0:
+                assert info["movedCount"] == 0 or not ref["shapes"]["enlarged"][1]  # the ground left the move buffer with the first query
+        got_bodies = res[0]
+    assert created_at is not None and created_at > 0, "the pair with the static ground was never reported"
+    assert 0.45 < float(got_bodies["position"][0][1]) < 0.55 and abs(float(got_bodies["linearVelocity"][0][1])) < 0.05, got_bodies[0]
 
 
 @pytest.mark.parametrize("seed,solver_name", [(1, "TGS_Soft"), (2, "PGS_Soft"), (3, "SoftStep"), (4, "TGS_Sticky"), (5, "XPBD"),
@@ -300,10 +347,9 @@ def test_rain_world_loop(seed, solver_name):
     with hip.Solver(0) as s:
         s.world_upload(*[world[k] for k in world_chain.WORLD_KEYS])
         for step in range(70):
-            moved = ((ref["shapes"]["enlarged"] != 0) & (ref["shapes"]["type"] != wire.SHAPE_FREE)).astype(np.uint8)
-            if moved.any():
+            if world_chain.moved_any(ref):
                 got = s.world_find_pairs()
-                want = oraclebind.find_pairs(ref["bodies"], ref["shapes"], moved, _live_pairs(ref), ref["joints"])
+                want = world_chain.oracle_find_pairs(ref)
                 assert np.array_equal(got, want), "step %d: new pairs" % step
                 if len(got):
                     created += len(got)
@@ -343,10 +389,9 @@ def test_wrecking_ball_world_loop(seed, solver_name):
         s.set_option("max_group_bodies", int(rng.choice([64, 512, 2816])))
         s.world_upload(*[world[k] for k in world_chain.WORLD_KEYS])
         for step in range(70):
-            moved = ((ref["shapes"]["enlarged"] != 0) & (ref["shapes"]["type"] != wire.SHAPE_FREE)).astype(np.uint8)
-            if moved.any():
+            if world_chain.moved_any(ref):
                 got = s.world_find_pairs()
-                want = oraclebind.find_pairs(ref["bodies"], ref["shapes"], moved, _live_pairs(ref), ref["joints"])
+                want = world_chain.oracle_find_pairs(ref)
                 assert np.array_equal(got, want), "step %d: new pairs" % step
                 if len(got):
                     created += len(got)
@@ -441,10 +486,9 @@ def test_rain_world_loop_through_the_strip_paths(seed, solver_name):
         s.set_option("max_group_bodies", int(rng.choice([32, 64, 128])))
         s.world_upload(*[world[k] for k in world_chain.WORLD_KEYS])
         for step in range(120):
-            moved = ((ref["shapes"]["enlarged"] != 0) & (ref["shapes"]["type"] != wire.SHAPE_FREE)).astype(np.uint8)
-            if moved.any():
+            if world_chain.moved_any(ref):
                 got = s.world_find_pairs()
-                want = oraclebind.find_pairs(ref["bodies"], ref["shapes"], moved, _live_pairs(ref), ref["joints"])
+                want = world_chain.oracle_find_pairs(ref)
                 assert np.array_equal(got, want), "step %d: new pairs" % step
                 if len(got):
                     slots, contacts, pairs = _create_contacts(ref, got)

@@ -46,9 +46,8 @@ def test_fuzz_world_generators_run_through_the_oracle_chain():
         params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
         created = separated = 0
         for _ in range(steps):
-            moved = ((world["shapes"]["enlarged"] != 0) & (world["shapes"]["type"] != wire.SHAPE_FREE)).astype(np.uint8)
-            if moved.any():
-                new = oraclebind.find_pairs(world["bodies"], world["shapes"], moved, _live_pairs(world), world["joints"])
+            if world_chain.moved_any(world):
+                new = world_chain.oracle_find_pairs(world)
                 if len(new):
                     created += len(new)
                     _create_contacts(world, new)

@@ -34,6 +34,25 @@ def oracle_world_step(params, world, contact_order=None, joint_order=None, rever
     return status
 
 
+def live_pairs(world):
+    live = world["pairs"]["shapeA"] >= 0
+    return np.stack([world["pairs"]["shapeA"][live], world["pairs"]["shapeB"][live]], axis=1).astype(np.int32)
+
+
+def oracle_find_pairs(world):
+    """Stage 1's pair discovery on the oracle side of a chain: the move buffer = the shapes whose `enlarged` flag is set;
+    the query consumes it (src/broad_phase.c: s2UpdateBroadPhasePairs clears moveArray / moveSet at its end), so every flag
+    is zero afterwards -- what s2amd_world_find_pairs does to the resident shapes."""
+    moved = ((world["shapes"]["enlarged"] != 0) & (world["shapes"]["type"] != wire.SHAPE_FREE)).astype(np.uint8)
+    new = oraclebind.find_pairs(world["bodies"], world["shapes"], moved, live_pairs(world), world["joints"])
+    world["shapes"]["enlarged"] = 0
+    return new
+
+
+def moved_any(world):
+    return bool(((world["shapes"]["enlarged"] != 0) & (world["shapes"]["type"] != wire.SHAPE_FREE)).any())
+
+
 def load_world(npz, prefix=""):
     return {k: np.ascontiguousarray(npz[prefix + k]) for k in WORLD_KEYS}
 

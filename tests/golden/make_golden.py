@@ -26,7 +26,24 @@ CASES = [
     ("mixed", 24, 0, (30, 75)),
     ("joint_grid", 6, 6, (0, 20)),
     ("circle_pile", 12, 0, (40,)),
+    # the reference's own edge-case samples (solver2d_amd/scenes/scenes.c cites each): capture steps chosen after the
+    # interesting event -- the heavy box has landed, the overlap is at its deepest, the ragdoll lies on its joint limits
+    ("arch", 0, 0, (30,)),
+    ("high_mass_ratio", 1, 0, (50,)),
+    ("high_mass_ratio", 2, 0, (115,)),
+    ("high_mass_ratio", 3, 0, (115,)),
+    ("overlap_recovery", 0, 0, (3,)),
+    ("card_house", 0, 0, (20,)),
+    ("far_pyramid", 0, 0, (30,)),
+    ("far_stack", 0, 0, (30,)),
+    ("far_recovery", 0, 0, (3,)),
+    ("far_ragdoll_pile", 0, 0, (60,)),
+    ("far_chain", 0, 0, (40,)),
+    ("ragdoll", 0, 0, (75,)),
+    ("ball_and_chain", 40, 0, (50,)),
+    ("bridge", 40, 0, (30,)),
 ]
+ONLY_MISSING = bool(os.environ.get("S2_GOLDEN_ONLY_MISSING"))
 
 
 def main():
@@ -34,6 +51,8 @@ def main():
     for scene, p0, p1, at in CASES:
         for solver in wire.SOLVER_NAMES:
             vel, pos = common.DEFAULT_ITERS[solver]
+            if ONLY_MISSING and all(os.path.exists(os.path.join(OUT, "%s%d_%s_step%03d.npz" % (scene, p0, solver, a))) for a in at):
+                continue
             with refbind.RefWorld(scene, solver, p0, p1) as world:
                 for step in range(max(at) + 1):
                     if step in at:
@@ -51,7 +70,10 @@ def main():
                         world.step(1.0 / 60.0, vel, pos, True)
     # broad phase + refit captures: state at s2UpdateBroadPhasePairs entry, the
     # contacts it created, and the shapes / origins before and after Stage 4
-    for scene, p0, p1, at in (("mixed", 24, 0, (0, 30, 90)), ("pyramid", 8, 0, (0, 1)), ("tumbler", 60, 0, (0, 40))):
+    for scene, p0, p1, at in (("mixed", 24, 0, (0, 30, 90)), ("pyramid", 8, 0, (0, 1)), ("tumbler", 60, 0, (0, 40)),
+                              ("far_ragdoll_pile", 0, 0, (0, 25)), ("far_pyramid", 0, 0, (0, 12)), ("card_house", 0, 0, (0,))):
+        if ONLY_MISSING and all(os.path.exists(os.path.join(OUT, "bp_%s%d_step%03d.npz" % (scene, p0, a))) for a in at):
+            continue
         with refbind.RefWorld(scene, "TGS_Soft", p0, p1) as world:
             for step in range(max(at) + 1):
                 shapes_before, origins_before = world.pack_shapes()
@@ -65,7 +87,11 @@ def main():
                                         origins_before=origins_before, shapes_after=shapes_after, origins_after=origins_after)
                     total += os.path.getsize(path)
     # narrow phase captures: input of Stage 3 (end of Stage 2) and its output (solver entry)
-    for scene, p0, at in (("shapes_zoo", 40, (30, 90, 150)), ("mixed", 24, (40, 100)), ("pyramid", 8, (0, 2, 30)), ("circle_pile", 20, (60,))):
+    for scene, p0, at in (("shapes_zoo", 40, (30, 90, 150)), ("mixed", 24, (40, 100)), ("pyramid", 8, (0, 2, 30)), ("circle_pile", 20, (60,)),
+                          ("arch", 0, (1, 40)), ("card_house", 0, (1, 25)), ("far_pyramid", 0, (20,)), ("far_stack", 0, (25,)),
+                          ("far_ragdoll_pile", 0, (50,)), ("overlap_recovery", 0, (0, 4)), ("high_mass_ratio", 2, (110,))):
+        if ONLY_MISSING and all(os.path.exists(os.path.join(OUT, "np_%s%d_step%03d.npz" % (scene, p0, a))) for a in at):
+            continue
         with refbind.RefWorld(scene, "TGS_Soft", p0, 0) as world:
             for step in range(max(at) + 1):
                 world.step_captured(1.0 / 60.0, 4, 2, True)
@@ -82,7 +108,12 @@ def main():
                                         ("shapes_zoo", 40, "PGS_NGS_Block", 202, 3), ("joint_grid", 6, "TGS_NGS", 5, 3),
                                         # k = 0: an input only (the tumbler never goes three steps without creating a contact); the GPU
                                         # test runs the whole loop on it, pair creation included, against the oracle chain
-                                        ("tumbler", 60, "TGS_Soft", 100, 0)):
+                                        ("tumbler", 60, "TGS_Soft", 100, 0),
+                                        # the reference's edge-case samples as whole-step chains
+                                        ("arch", 0, "TGS_Soft", 40, 3), ("card_house", 0, "SoftStep", 30, 3), ("far_pyramid", 0, "TGS_Soft", 40, 3),
+                                        ("ragdoll", 0, "PGS_NGS_Block", 80, 3), ("far_ragdoll_pile", 0, "PGS_Soft", 87, 3),
+                                        ("high_mass_ratio", 1, "PGS_NGS", 60, 3), ("overlap_recovery", 0, "TGS_Sticky", 30, 3),
+                                        ("far_stack", 0, "PGS", 40, 3)):
         vel, pos = common.DEFAULT_ITERS[solver]
         path = os.path.join(OUT, "world_%s%d_%s_step%03d_k%d.npz" % (scene, p0, solver, start, k))
         if os.environ.get("S2_GOLDEN_ONLY_MISSING") and os.path.exists(path):

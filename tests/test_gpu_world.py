@@ -213,7 +213,7 @@ def test_resident_pair_query_equals_the_stage_function(path):
                 asked += 1
                 want = world_chain.oracle_find_pairs(ref)
                 assert np.array_equal(s.world_find_pairs(), want), "step %d" % step
-    if "pyramid" not in path and "joint_grid" not in path:
+    if any(name in os.path.basename(path) for name in ("mixed", "shapes_zoo", "circle_pile", "tumbler")):
         assert asked > 0
 
 

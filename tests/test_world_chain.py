@@ -30,7 +30,8 @@ def test_oracle_chain_equals_reference(path):
         status = world_chain.oracle_world_step(params, world)
         separated += int((status == wire.PAIR_SEPARATED).sum())
     world_chain.assert_worlds_equal(world, want, os.path.basename(path))
-    if "pyramid" not in path and "joint_grid" not in path:
+    # the windows of the mixed / shapes_zoo / circle_pile worlds were chosen to contain a separation
+    if any(name in os.path.basename(path) for name in ("mixed", "shapes_zoo", "circle_pile")):
         assert separated > 0, "the window was chosen to contain a separation"
 
 

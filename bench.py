@@ -23,6 +23,16 @@ Extra objects on the JSON line:
                 under profiles/.
   cpu_baseline  the reference's own s2Solve_TGS_Soft timed on this host (oracle/_ref, kind
                 "reference") or, if that library is absent, the oracle port; 1 core.
+  whole_step    (N = 1) the SURVEY.md 8d trajectory of config 2: the base-200 WORLD (shapes, pair states) resident, 60 settle
+                steps then 240 timed steps of s2amd_world_step (stage 3 narrow phase -> s2Solve_TGS_Soft -> stage 4 refit):
+                whole-step ms and the solver's share of it.
+  configs       (N = 1) BASELINE.json configs[3] and configs[4] on this one GPU: JointGrid 100x100 / PGS_NGS and
+                512 x base-40 / TGS_Soft, each with its own unit, ms per step and roofline object.
+  island_sharded  BASELINE.json configs[4] as the N-GPU job it names: ONE world of 512 base-40 pyramids,
+                its islands bin-packed onto the N ranks, every rank's shard resident in its own HBM, one all-gather of
+                device-resident pose records per step (solver2d_amd/distributed.py: ResidentShardedWorld).  STRONG scaling:
+                `value` there = the whole world's constraint-sweeps / max-over-ranks time.  `--config 5` makes this the
+                line itself.
 """
 import argparse
 import ctypes
@@ -92,15 +102,17 @@ def pmc_traffic_bytes(kernel_prefix):
     FETCH_SIZE / WRITE_SIZE passes of this same command, profiles/r01_persistent_pmc_*.txt): counters are in KiB;
     FETCH_SIZE is doubled per the gfx950 note in MI355X_MICROARCH.md (it reads half of a wide coalesced stream).
     None when the summaries are not there."""
-    total = 0.0
-    for name, scale in (("fetch", 2.0), ("write", 1.0)):
-        path = os.path.join(ROOT, "profiles", "r01_persistent_pmc_%s_size.txt" % name)
+    for rnd in ("r02", "r01"):
+        total = 0.0
         try:
-            rows = [l.split() for l in open(path) if l.startswith(kernel_prefix) and ("FETCH_SIZE" in l or "WRITE_SIZE" in l)]
-            total += scale * float(rows[0][3]) * 1024.0
+            for name, scale in (("fetch", 2.0), ("write", 1.0)):
+                path = os.path.join(ROOT, "profiles", "%s_persistent_pmc_%s_size.txt" % (rnd, name))
+                rows = [l.split() for l in open(path) if l.startswith(kernel_prefix) and ("FETCH_SIZE" in l or "WRITE_SIZE" in l)]
+                total += scale * float(rows[0][3]) * 1024.0
+            return total, "profiles/%s_persistent_pmc_{fetch,write}_size.txt (rocprofv3 --pmc, separate passes of this command; not measured in this run)" % rnd
         except (OSError, IndexError, ValueError):
-            return None
-    return total
+            continue
+    return None, None
 
 
 def main():

@@ -61,3 +61,74 @@ def step_sharded(sw, solve_fn, params, dist=None, torch=None, device="cpu"):
         dist.all_gather_into_tensor(out, t)
         gathered = out.cpu().numpy().reshape(sw.world_size, t.shape[0], t.shape[1])
     return sw.unpack_all(gathered)
+
+
+class ResidentShardedWorld:
+    """The device-resident form of ShardedWorld (BASELINE.json configs[4]): every rank uploads ITS shard
+    once (s2amd_upload), advances it with s2amd_step_resident -- no collective inside a step, islands share no movable
+    body -- and contributes one fixed-size record of body poses per step to ONE all-gather of device tensors
+    (torch.distributed backend "nccl" = RCCL over xGMI; "gloo" moves the same records through the host in the tests).
+    Nothing but the poses ever leaves a GPU: constraints, impulses and velocities stay in the HBM of their owner.
+
+    The host loop is software-pipelined like bench.py's replica loop: step s+1 is enqueued on the solver's stream BEFORE
+    the host waits for the poses of step s and hands them to the collective, through two pose buffers."""
+
+    def __init__(self, sharded, solver, torch, dist=None, backend="nccl"):
+        self.sw, self.solver, self.torch, self.dist, self.backend = sharded, solver, torch, dist, backend
+        sh = sharded.mine
+        solver.upload(sh.bodies, sh.contacts, sh.joints)
+        self.body_slots = len(sh.bodies)
+        # one record per rank, sized for the largest shard (an all-gather wants equal contributions)
+        self.record = max(1, max(len(s.bodies) for s in sharded.shards))
+        self.pose = [torch.zeros((self.record, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+        on_device = dist is None or backend == "nccl"
+        self.gathered = torch.zeros((sharded.world_size * self.record, 4), dtype=torch.float32, device="cuda" if on_device else "cpu")
+        self.gather_done = [None, None]
+        self.enqueued = 0
+        self.exchanged = 0
+
+    def enqueue_step(self, params):
+        """s2Solve_* of my shard + the export of its poses, enqueued on the solver's stream (option "async")."""
+        b = self.enqueued & 1
+        if self.gather_done[b] is not None:
+            self.gather_done[b].synchronize()  # the collective that last read this buffer (two steps ago)
+            self.gather_done[b] = None
+        self.solver.step_resident(params)
+        self.solver.export_poses_async(self.pose[b].data_ptr(), self.record, b)
+        self.enqueued += 1
+
+    def exchange(self):
+        """The step's one exchange: all ranks' pose records into `gathered` (on every rank)."""
+        b = self.exchanged & 1
+        self.solver.export_wait(b)
+        if self.dist is None or self.sw.world_size == 1 and self.backend != "nccl":
+            self.gathered[: self.record].copy_(self.pose[b])
+        elif self.backend == "nccl":
+            self.dist.all_gather_into_tensor(self.gathered, self.pose[b])
+            self.gather_done[b] = self.torch.cuda.Event()
+            self.gather_done[b].record()
+        else:
+            self.dist.all_gather_into_tensor(self.gathered, self.pose[b].cpu())
+        self.exchanged += 1
+
+    def run(self, params, steps):
+        if steps <= 0:
+            return
+        self.enqueue_step(params)
+        for s in range(steps):
+            if s + 1 < steps:
+                self.enqueue_step(params)
+            self.exchange()
+
+    def world_poses(self):
+        """float32[bodies of the whole world, 4] {position, rot} as of the last exchange, assembled from the gathered
+        records: every body from the rank that owns it (static bodies from any shard that holds a replica)."""
+        self.torch.cuda.synchronize()
+        g = self.gathered.cpu().numpy().reshape(self.sw.world_size, self.record, 4)
+        out = np.zeros((len(self.sw.bodies), 4), dtype=np.float32)
+        out[:, 0:2] = self.sw.bodies["position"]
+        out[:, 2:4] = self.sw.bodies["rot"]
+        for r, sh in enumerate(self.sw.shards):
+            rows = g[r, : len(sh.bodies)]
+            out[sh.body_ids[sh.owned_body]] = rows[sh.owned_body]
+        return out

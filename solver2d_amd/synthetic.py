@@ -51,6 +51,26 @@ def _manifold(c, a, b, normal, pts, friction=0.6):
 def pyramid(base, count=1, pitch=None):
     """`count` disjoint box pyramids of `base` bricks at the bottom, each on its own static ground.
     Returns (bodies, contacts, joints)."""
+    if count > 1:
+        # one pyramid, then copies shifted onto a 32-wide lattice (fp32 additions, as a scene builder would do them)
+        b0, c0, joints = pyramid(base, 1, pitch)
+        if pitch is None:
+            pitch = float(base + 20)
+        k = np.arange(count)
+        ox = ((k % 32) * pitch).astype(np.float32)
+        oy = ((k // 32) * pitch).astype(np.float32)
+        bodies = np.tile(b0, count)
+        contacts = np.tile(c0, count)
+        bodies["position"][:, 0] = (np.repeat(ox, len(b0)) + np.tile(b0["position"][:, 0], count)).astype(np.float32)
+        bodies["position"][:, 1] = (np.repeat(oy, len(b0)) + np.tile(b0["position"][:, 1], count)).astype(np.float32)
+        shift = np.repeat(k * len(b0), len(c0)).astype(np.int32)
+        contacts["bodyA"] += shift
+        contacts["bodyB"] += shift
+        return bodies, contacts, joints
+    return _pyramid_loops(base, count, pitch)
+
+
+def _pyramid_loops(base, count=1, pitch=None):
     per = base * (base + 1) // 2
     nb = count * (per + 1)
     ncon = count * (base + (per - base) + 2 * (per - base))  # ground + side-by-side + stacking

@@ -115,6 +115,137 @@ def pmc_traffic_bytes(kernel_prefix):
     return None, None
 
 
+ALGO_BYTES_LDS_PATH = 136.0  # per constraint-sweep when the body state is served from LDS (the group kernel)
+
+
+class Ranks:
+    """What the legs need to know about the job: torch.distributed handle (None at N = 1), backend, this rank."""
+
+    def __init__(self, dist, torch, backend, rank, world, device_index):
+        self.dist, self.torch, self.backend, self.rank, self.world, self.device_index = dist, torch, backend, rank, world, device_index
+
+    def barrier_sync(self, solver):
+        solver.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds):
+        if self.dist is None:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def island_sharded_leg(ranks, islands, base, vel, pos, steps, warmup, graph=True, dump=None):
+    """BASELINE.json configs[4]: ONE world of `islands` base-`base` pyramids, islands sharded over the ranks, every shard
+    resident, one all-gather of pose records per step (ResidentShardedWorld).  Strong scaling."""
+    from solver2d_amd import distributed as dsh
+    world = synthetic.pyramid(base, count=islands)
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, vel, pos, True)
+    sweeps = wire.solve_sweeps_per_step("TGS_Soft", vel, pos)
+    C_total = int((world[1]["pointCount"] > 0).sum())
+    sw = dsh.ShardedWorld(*world, rank=ranks.rank, world_size=ranks.world)
+    gpu = hip.Solver(ranks.device_index, graph=graph)
+    gpu.set_option("async", 1)
+    rs = dsh.ResidentShardedWorld(sw, gpu, ranks.torch, dist=ranks.dist, backend=ranks.backend)
+    rs.run(params, warmup)
+    ranks.barrier_sync(gpu)
+    t0 = time.perf_counter()
+    rs.run(params, steps)
+    ranks.barrier_sync(gpu)
+    elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
+    if dump and ranks.rank == 0:
+        np.save(dump, rs.world_poses())
+    gpu.set_option("async", 0)
+    gpu.step_resident(params)
+    st = gpu.stats()
+    us, _launches, c_launch = gpu.measure_dominant(params, repeats=10)
+    rs.close()
+    gpu.close()
+    mine = int((sw.mine.contacts["pointCount"] > 0).sum())
+    # the group kernel runs the WHOLE step of its islands in one launch: constraint-sweeps per launch = mine * sweeps
+    algo = ALGO_BYTES_LDS_PATH * mine * sweeps
+    achieved = algo / max(us * 1e-6, 1e-12) / 1e9
+    return {
+        "metric": "contact-constraints x iters/sec, %d independent base-%d pyramids TGS_Soft, islands sharded over the GPUs" % (islands, base),
+        "value": C_total * sweeps * steps / elapsed, "unit": "constraint-iters/s", "n_gpus": ranks.world, "steps": steps, "warmup": warmup,
+        "ms_per_step": 1e3 * elapsed / steps, "scaling": "strong",
+        "config": {"workload": "one world of %d base-%d pyramids (%d bodies, %d two-point constraints, %d islands), s2_solverTGS_Soft %d/%d; "
+                               "islands bin-packed onto %d rank(s), shards resident, one all-gather of {position, rot} records per step "
+                               "(%d bytes per rank)" % (islands, base, len(world[0]), C_total, islands, vel, pos, ranks.world, rs.record * 16),
+                   "constraints": C_total, "constraints_this_rank": mine, "islands_this_rank": int((sw.shard_of_island == ranks.rank).sum()),
+                   "solve_sweeps_per_step": sweeps, "kernel_launches_per_step": st["kernelLaunches"], "lds_groups_this_rank": st["groupCount"],
+                   "device_ms_per_step": st["deviceMs"], "graph_replay": bool(st["graphReplayed"]), "trajectory": "consecutive resident steps (no restore)"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "groupKernel (whole step of this rank's islands in one launch, bodies in LDS)", "avg_launch_us": us,
+                     "algorithmic_bytes_per_launch": algo,
+                     "byte_model": "136 B per constraint-sweep (SURVEY.md 8d, body state served from LDS) x %d constraints x %d sweeps" % (mine, sweeps)},
+    }
+
+
+def joint_grid_leg(device_index, steps, warmup):
+    """BASELINE.json configs[3]: JointGrid 100x100 (19,800 revolute joints), s2_solverPGS_NGS 4/2, one GPU; the unit of work is
+    a joint-iteration: joints x (velocity + position sweeps)."""
+    pre = synthetic.joint_grid(100)
+    params = wire.StepParams.make("PGS_NGS", 1.0 / 60.0, 4, 2, True)
+    with hip.Solver(device_index) as gpu:
+        gpu.set_option("async", 1)
+        gpu.upload(*pre)
+        gpu.save_bodies()
+        for _ in range(warmup):
+            gpu.restore_bodies()
+            gpu.step_resident(params)
+        gpu.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            gpu.restore_bodies()
+            gpu.step_resident(params)
+        gpu.synchronize()
+        elapsed = time.perf_counter() - t0
+        gpu.set_option("async", 0)
+        gpu.restore_bodies()
+        gpu.step_resident(params)
+        st = gpu.stats()
+    J = st["jointCount"]
+    return {"workload": "JointGrid 100x100: %d bodies, %d revolute joints, s2_solverPGS_NGS 4/2" % (len(pre[0]), J), "unit": "joint-iters/s",
+            "value": J * 6 * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "joint_colors": st["jointColors"],
+            "kernel_launches_per_step": st["kernelLaunches"], "device_ms_per_step": st["deviceMs"],
+            "roofline": None, "roofline_note": "35 dependent launches of ~20k threads: launch-latency bound, no bandwidth figure is meaningful"}
+
+
+def whole_step_leg(device_index, base, vel, pos, settle, steps):
+    """SURVEY.md 8d, config 2 as a trajectory: the world resident (bodies, manifolds, shapes, pair states), `settle` steps,
+    then `steps` timed s2amd_world_step calls = stage 3 (narrow phase on every pair) -> s2Solve_TGS_Soft -> stage 4 (refit)."""
+    world = synthetic.pyramid_world(base)
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, vel, pos, True)
+    keys = ("bodies", "contacts", "joints", "shapes", "pairs", "origins")
+    with hip.Solver(device_index) as gpu:
+        gpu.world_upload(*[world[k] for k in keys])
+        for _ in range(settle):
+            gpu.world_step(params)
+        t0 = time.perf_counter()
+        solve_ms = contacts_ms = 0.0
+        active = changed = moved = 0
+        for _ in range(steps):
+            info = gpu.world_step(params)
+            solve_ms += info["solveMs"]
+            contacts_ms += info["contactsMs"]
+            active += info["activeContacts"]
+            changed += info["graphChanged"]
+            moved += info["movedCount"]
+        elapsed = time.perf_counter() - t0
+        st = gpu.stats()
+    sweeps = wire.solve_sweeps_per_step("TGS_Soft", vel, pos)
+    return {"workload": "LargePyramid base-%d as a resident world, %d settle + %d timed s2amd_world_step (update contacts -> s2Solve_TGS_Soft -> refit)" % (
+                base, settle, steps),
+            "whole_step_ms": 1e3 * elapsed / steps, "solver_device_ms": solve_ms / steps, "update_contacts_ms_incl_readback": contacts_ms / steps,
+            "mean_active_constraints": active / steps, "steps_with_graph_change": changed, "mean_moved_shapes": moved / steps,
+            "value_whole_step": (active / steps) * sweeps * steps / elapsed, "unit": "constraint-iters/s", "persistent_strip_kernel": bool(st["persistent"]),
+            "kernel_launches_per_solve": st["kernelLaunches"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,6 +258,12 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="s2amd_set_option passthrough (experiments)")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 5),
+                    help="2 = BASELINE's headline (LargePyramid base-200, one island per GPU); 5 = configs[4]: 512 x base-40, islands sharded over "
+                         "the GPUs, as the line itself")
+    ap.add_argument("--islands", type=int, default=512)
+    ap.add_argument("--island-base", type=int, default=40)
+    ap.add_argument("--no-extras", action="store_true", help="only the headline line (no whole_step / configs / island_sharded objects)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,6 +285,19 @@ def main():
     n_gpus = max(args.gpus, 1)
     if world > 1 and world != n_gpus:
         n_gpus = world
+    ranks = Ranks(dist if distributed else None, __import__("torch") if distributed else None, backend, rank, world, device_index if distributed else 0)
+
+    if args.config == 5:
+        # the island-sharded job as the line itself (strong scaling); the contract's keys, its own roofline
+        line = island_sharded_leg(ranks, args.islands, args.island_base, args.vel_iters, args.pos_iters, args.steps, args.warmup,
+                                  graph=not args.no_graph, dump=os.environ.get("S2AMD_BENCH_DUMP"))
+        line.update({"higher_is_better": True, "vs_baseline": None, "dtype": "f32", "data": "synthetic"})
+        if rank == 0:
+            print(json.dumps(line))
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     pre = synthetic.pyramid(args.base)
     params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, args.vel_iters, args.pos_iters, True)
@@ -277,7 +427,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_bytes("_Z15stripStepKernel") if persistent and args.base == 200 else None,
+                "traffic": pmc_traffic_bytes("_Z15stripStepKernel")[0] if persistent and args.base == 200 else None,
+                "traffic_source": pmc_traffic_bytes("_Z15stripStepKernel")[1] if persistent and args.base == 200 else None,
                 "kernel": "stripStepKernel<SOFT_TGS> (whole step, one persistent launch; constraints_per_launch counts "
                           "constraint-sweeps)" if persistent else "solveContactsSoftKernel<SOFT_TGS> / stripSoftKernel<SOFT_TGS>",
                 "avg_launch_us": avg_launch_us, "launches_per_step": 1 if persistent else launches_per_sweep * sweeps,
@@ -288,8 +439,19 @@ def main():
         }
         if not args.no_cpu and world == 1:  # the contract: on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.base, args.vel_iters, args.pos_iters, args.cpu_seconds)
-        print(json.dumps(out))
     gpu.close()
+    # ---- beyond the headline (outside its timed region): the other BASELINE configurations, driver-run ----
+    if not args.no_extras:
+        extra_steps = max(10, min(args.steps, 60))
+        sharded = island_sharded_leg(ranks, args.islands, args.island_base, args.vel_iters, args.pos_iters, extra_steps, 5, graph=not args.no_graph)
+        if rank == 0:
+            out["island_sharded"] = sharded
+            if world == 1:
+                out["whole_step"] = whole_step_leg(ranks.device_index, args.base, args.vel_iters, args.pos_iters, 60, 240)
+                out["configs"] = {"4_joint_grid": joint_grid_leg(ranks.device_index, 100, 20),
+                                  "5_one_gpu": {k: sharded[k] for k in ("value", "unit", "ms_per_step", "config", "roofline")}}
+    if rank == 0:
+        print(json.dumps(out))
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

@@ -343,6 +343,14 @@ int s2amd_export_poses(s2amdSolver* solver, void* devicePoses, int32_t capacity)
 int s2amd_export_poses_async(s2amdSolver* solver, void* devicePoses, int32_t capacity, int32_t slot);
 int s2amd_export_wait(s2amdSolver* solver, int32_t slot);
 
+/* Device buffers for callers that have no device allocator of their own (a host language behind cgo / JNI / ctypes): the
+ * destination of s2amd_export_poses and the source of s2amd_device_read.  Owned by the caller, freed with
+ * s2amd_device_free (or never: s2amd_destroy does not track them). */
+int s2amd_device_alloc(s2amdSolver* solver, uint64_t bytes, void** devicePtr);
+int s2amd_device_free(s2amdSolver* solver, void* devicePtr);
+/* Copies `bytes` from device memory to host memory behind everything enqueued on the solver's stream; returns when done. */
+int s2amd_device_read(s2amdSolver* solver, void* hostDst, const void* deviceSrc, uint64_t bytes);
+
 /* ---- introspection (tests, bench) ---- */
 /* Execution order of the last step: order[k] = contact-array index of the k-th constraint in
  * sweep order; colorOffsets[c]..colorOffsets[c+1] delimit colour batch c.  A sequential

@@ -451,6 +451,50 @@ int s2amd_export_wait(s2amdSolver* s, int32_t slot)
 	return S2AMD_OK;
 }
 
+int s2amd_device_alloc(s2amdSolver* s, uint64_t bytes, void** devicePtr)
+{
+	if (!s || !devicePtr)
+	{
+		return fail(S2AMD_E_INVALID, "null argument");
+	}
+	*devicePtr = nullptr;
+	HIP_TRY(hipSetDevice(s->device));
+	HIP_TRY(hipMalloc(devicePtr, bytes > 0 ? (size_t)bytes : 16));
+	HIP_TRY(hipMemsetAsync(*devicePtr, 0, bytes > 0 ? (size_t)bytes : 16, s->stream));
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	return S2AMD_OK;
+}
+
+int s2amd_device_free(s2amdSolver* s, void* devicePtr)
+{
+	if (!s)
+	{
+		return fail(S2AMD_E_INVALID, "null solver");
+	}
+	if (devicePtr)
+	{
+		HIP_TRY(hipSetDevice(s->device));
+		HIP_TRY(hipStreamSynchronize(s->stream));
+		HIP_TRY(hipFree(devicePtr));
+	}
+	return S2AMD_OK;
+}
+
+int s2amd_device_read(s2amdSolver* s, void* hostDst, const void* deviceSrc, uint64_t bytes)
+{
+	if (!s || (bytes > 0 && (!hostDst || !deviceSrc)))
+	{
+		return fail(S2AMD_E_INVALID, "null argument");
+	}
+	HIP_TRY(hipSetDevice(s->device));
+	if (bytes > 0)
+	{
+		HIP_TRY(hipMemcpyAsync(hostDst, deviceSrc, (size_t)bytes, hipMemcpyDeviceToHost, s->stream));
+	}
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	return S2AMD_OK;
+}
+
 int s2amd_measure_dominant(s2amdSolver* s, const s2amdStepParams* params, int32_t repeats, float* usPerLaunch, int32_t* launchesPerSweep,
 						   int32_t* constraintsPerLaunch)
 {

@@ -34,6 +34,12 @@ class ShardedWorld:
         out[:n, 7:9] = b["deltaPosition"]
         return out
 
+    def close(self):
+        if self.raw:
+            for p in self.pose_ptr:
+                self.solver.device_free(p)
+            self.pose_ptr = []
+
     def unpack_all(self, gathered):
         """gathered: float32[world_size, max_owned, 9] -> scatter into the full body array."""
         for r in range(self.world_size):
@@ -80,9 +86,14 @@ class ResidentShardedWorld:
         self.body_slots = len(sh.bodies)
         # one record per rank, sized for the largest shard (an all-gather wants equal contributions)
         self.record = max(1, max(len(s.bodies) for s in sharded.shards))
-        self.pose = [torch.zeros((self.record, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
-        on_device = dist is None or backend == "nccl"
-        self.gathered = torch.zeros((sharded.world_size * self.record, 4), dtype=torch.float32, device="cuda" if on_device else "cpu")
+        self.raw = dist is None  # a single process: no collective, no torch -- pose records in buffers of the library's own
+        if self.raw:
+            self.pose_ptr = [solver.device_alloc(self.record * 16) for _ in range(2)]
+            self.last = None
+        else:
+            self.pose = [torch.zeros((self.record, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+            self.pose_ptr = [t.data_ptr() for t in self.pose]
+            self.gathered = torch.zeros((sharded.world_size * self.record, 4), dtype=torch.float32, device="cuda" if backend == "nccl" else "cpu")
         self.gather_done = [None, None]
         self.enqueued = 0
         self.exchanged = 0
@@ -94,15 +105,15 @@ class ResidentShardedWorld:
             self.gather_done[b].synchronize()  # the collective that last read this buffer (two steps ago)
             self.gather_done[b] = None
         self.solver.step_resident(params)
-        self.solver.export_poses_async(self.pose[b].data_ptr(), self.record, b)
+        self.solver.export_poses_async(self.pose_ptr[b], self.record, b)
         self.enqueued += 1
 
     def exchange(self):
         """The step's one exchange: all ranks' pose records into `gathered` (on every rank)."""
         b = self.exchanged & 1
         self.solver.export_wait(b)
-        if self.dist is None or self.sw.world_size == 1 and self.backend != "nccl":
-            self.gathered[: self.record].copy_(self.pose[b])
+        if self.raw:
+            self.last = b  # one rank: its record IS the world's
         elif self.backend == "nccl":
             self.dist.all_gather_into_tensor(self.gathered, self.pose[b])
             self.gather_done[b] = self.torch.cuda.Event()
@@ -123,8 +134,11 @@ class ResidentShardedWorld:
     def world_poses(self):
         """float32[bodies of the whole world, 4] {position, rot} as of the last exchange, assembled from the gathered
         records: every body from the rank that owns it (static bodies from any shard that holds a replica)."""
-        self.torch.cuda.synchronize()
-        g = self.gathered.cpu().numpy().reshape(self.sw.world_size, self.record, 4)
+        if self.raw:
+            g = self.solver.device_read(self.pose_ptr[self.last], (1, self.record, 4))
+        else:
+            self.torch.cuda.synchronize()
+            g = self.gathered.cpu().numpy().reshape(self.sw.world_size, self.record, 4)
         out = np.zeros((len(self.sw.bodies), 4), dtype=np.float32)
         out[:, 0:2] = self.sw.bodies["position"]
         out[:, 2:4] = self.sw.bodies["rot"]
@@ -132,3 +146,9 @@ class ResidentShardedWorld:
             rows = g[r, : len(sh.bodies)]
             out[sh.body_ids[sh.owned_body]] = rows[sh.owned_body]
         return out
+
+    def close(self):
+        if self.raw:
+            for p in self.pose_ptr:
+                self.solver.device_free(p)
+            self.pose_ptr = []

@@ -21,6 +21,7 @@ EXPORTS = [
     "s2amd_restore_bodies", "s2amd_get_contact_order", "s2amd_get_joint_order", "s2amd_get_stats",
     "s2amd_set_option", "s2amd_export_poses", "s2amd_export_poses_async", "s2amd_export_wait", "s2amd_measure_dominant", "s2amd_refit_shapes", "s2amd_find_pairs", "s2amd_synchronize", "s2amd_update_contacts", "s2amd_find_islands", "s2amd_color_constraints",
     "s2amd_world_upload", "s2amd_world_step", "s2amd_world_download", "s2amd_world_find_pairs", "s2amd_world_set_contacts",
+    "s2amd_device_alloc", "s2amd_device_free", "s2amd_device_read",
 ]
 
 _lib = None
@@ -70,6 +71,9 @@ def load():
     L.s2amd_world_find_pairs.argtypes = [vp, vp, i32, ctypes.POINTER(i32)]
     L.s2amd_world_set_contacts.argtypes = [vp, vp, i32, vp, vp]
     L.s2amd_world_download.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp]
+    L.s2amd_device_alloc.argtypes = [vp, ctypes.c_uint64, ctypes.POINTER(vp)]
+    L.s2amd_device_free.argtypes = [vp, vp]
+    L.s2amd_device_read.argtypes = [vp, vp, vp, ctypes.c_uint64]
     L.s2amd_find_islands.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, ctypes.POINTER(i32)]
     L.s2amd_color_constraints.argtypes = [vp, vp, i32, vp, i32, vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     if L.s2amd_api_version() != wire.API_VERSION:
@@ -157,6 +161,20 @@ class Solver:
 
     def export_wait(self, slot):
         _check(load().s2amd_export_wait(self._h, int(slot)))
+
+    def device_alloc(self, nbytes):
+        """A zeroed device buffer owned by the caller (an int address); free it with device_free."""
+        p = ctypes.c_void_p()
+        _check(load().s2amd_device_alloc(self._h, int(nbytes), ctypes.byref(p)))
+        return int(p.value)
+
+    def device_free(self, ptr):
+        _check(load().s2amd_device_free(self._h, ctypes.c_void_p(int(ptr))))
+
+    def device_read(self, ptr, shape, dtype=np.float32):
+        out = np.zeros(shape, dtype=dtype)
+        _check(load().s2amd_device_read(self._h, wire.as_ptr(out.reshape(-1)), ctypes.c_void_p(int(ptr)), out.nbytes))
+        return out
 
     def measure_dominant(self, params, repeats=20):
         """(us per launch, launches per sweep, constraints per launch) of the dominant kernel; see

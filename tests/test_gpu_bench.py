@@ -35,12 +35,20 @@ def test_single_gpu_line():
     assert abs(d["value"] - d["config"]["constraints"] * d["config"]["solve_sweeps_per_step"] * 30 / (d["ms_per_step"] * 30e-3)) / d["value"] < 1e-6
     c = d["cpu_baseline"]
     assert c["cores"] == 1 and c["kind"] in ("reference", "port") and c["value"] > 0
+    # the other BASELINE configurations ride in the same driver-run line
+    w = d["whole_step"]
+    assert w["whole_step_ms"] > w["solver_device_ms"] > 0 and w["mean_active_constraints"] > 59000
+    isl = d["island_sharded"]
+    assert isl["scaling"] == "strong" and isl["n_gpus"] == 1 and isl["config"]["constraints"] == 1218560
+    r5 = isl["roofline"]
+    assert r5["bound"] == "hbm" and abs(r5["algorithmic_bytes_per_launch"] - 136.0 * 1218560 * 16) < 1 and 0 < r5["frac"] < 1.0
+    assert d["configs"]["4_joint_grid"]["unit"] == "joint-iters/s" and d["configs"]["4_joint_grid"]["value"] > 0
 
 
 def test_two_ranks_on_one_device():
     env = dict(os.environ, S2AMD_BENCH_BACKEND="gloo", S2AMD_BENCH_SINGLE_DEVICE="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-           "29517", "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu", "--base", "100"]
+           "29517", "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu", "--base", "100", "--no-extras"]
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     d = last_json(out.stdout)
@@ -57,10 +65,59 @@ def test_one_rank_through_rccl():
     pose export, all_gather_into_tensor on device tensors and the event hand-shakes all run on this single-GPU box."""
     env = dict(os.environ, S2AMD_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
-           "29519", "bench.py", "--gpus", "1", "--steps", "50", "--warmup", "10", "--no-cpu"]
+           "29519", "bench.py", "--gpus", "1", "--steps", "50", "--warmup", "10", "--no-cpu", "--no-extras"]
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     d = last_json(out.stdout)
     assert d["n_gpus"] == 1 and d["config"]["kernel_launches_per_step"] == 3
     # the collective and the hand-shakes must not serialise the steps: within 25 % of the plain single-process rate
     assert d["ms_per_step"] < 0.40, d["ms_per_step"]
+
+
+def _unsharded_poses(islands, base, steps):
+    import numpy as np
+    import torch
+    from solver2d_amd import hip, synthetic, wire
+    world = synthetic.pyramid(base, count=islands)
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    buf = torch.zeros((len(world[0]), 4), dtype=torch.float32, device="cuda")
+    with hip.Solver(0) as s:
+        s.upload(*world)
+        for _ in range(steps):
+            s.step_resident(params)
+        s.export_poses(buf.data_ptr(), len(world[0]))
+    return buf.cpu().numpy()
+
+
+@pytest.mark.parametrize("nranks,port", [(2, 29523), (3, 29525)])
+def test_island_sharded_config5_equals_the_unsharded_world(tmp_path, nranks, port):
+    """bench.py --config 5 (BASELINE configs[4]) with 2 and 3 ranks sharing this box's one GPU over gloo: every rank's shard
+    resident, pose records all-gathered every step.  The poses rank 0 assembles from the gathered records after
+    warmup + steps steps must equal, bit for bit, those of the same world stepped unsharded in one solver."""
+    import numpy as np
+    dump = str(tmp_path / "poses.npy")
+    env = dict(os.environ, S2AMD_BENCH_BACKEND="gloo", S2AMD_BENCH_SINGLE_DEVICE="1", MASTER_ADDR="127.0.0.1", S2AMD_BENCH_DUMP=dump)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1", "--master-port",
+           str(port), "bench.py", "--gpus", str(nranks), "--config", "5", "--islands", "37", "--island-base", "14", "--steps", "12", "--warmup", "3"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = last_json(out.stdout)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == nranks and d["scaling"] == "strong" and d["config"]["constraints"] == 37 * 287
+    assert abs(d["value"] - 37 * 287 * 16 * 12 / (d["ms_per_step"] * 12e-3)) / d["value"] < 1e-6
+    got = np.load(dump)
+    want = _unsharded_poses(37, 14, 15)
+    assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_island_sharded_one_rank_through_rccl():
+    """The sharded driver's loop with its real backend (one rank over RCCL): device-tensor all-gather, event hand-shakes."""
+    env = dict(os.environ, S2AMD_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port",
+           "29527", "bench.py", "--gpus", "1", "--config", "5", "--steps", "30", "--warmup", "5"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = last_json(out.stdout)
+    assert d["n_gpus"] == 1 and d["config"]["constraints"] == 1218560 and d["config"]["lds_groups_this_rank"] == 512
+    assert d["ms_per_step"] < 1.5, d["ms_per_step"]

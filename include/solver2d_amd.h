@@ -280,9 +280,10 @@ int s2amd_update_contacts(s2amdSolver* solver, const s2amdBody* bodies, int32_t 
 
 /* ---- resident world: stage 3, the solve and stage 4 of s2World_Step chained in HBM ----
  * The stage functions above take host arrays in and out.  These three keep the shapes, the pair states and the body
- * origins on the device beside the bodies / contacts / joints of s2amd_upload, so a step moves 32 bytes of counters
- * (plus one byte per contact slot in the steps where a manifold's point count changed: the constraint-graph
- * structure is built on the host).  Pair creation (stage 1, src/world.c:125-130) stays with the caller: when
+ * origins on the device beside the bodies / contacts / joints of s2amd_upload, so a step moves 32 bytes of counters, read
+ * back once, after stage 4.  The constraint-graph structure (islands, colours, strips) covers every live pair slot
+ * whether its manifold has points or not, so manifolds that gain or lose their points cost the host nothing; it is
+ * touched when contact slots are written.  Pair creation (stage 1, src/world.c:125-130) stays with the caller: when
  * movedCount > 0 it downloads the shapes, runs s2amd_find_pairs, creates its contacts and uploads again, as the
  * reference does before the next step's stage 3. */
 typedef struct s2amdWorldStepInfo
@@ -290,9 +291,11 @@ typedef struct s2amdWorldStepInfo
 	int32_t separatedCount; /* pairs whose fat AABBs parted: destroyed on the device (pointCount 0, pair slot free,
 	                           src/world.c:149-167); status[] of s2amd_world_download says which */
 	int32_t activeContacts; /* manifolds with points after stage 3 */
-	int32_t graphChanged;   /* a manifold went between zero and non-zero points: the solve rebuilt its structure */
+	int32_t graphChanged;   /* a manifold went between zero and non-zero points this step.  Informational: the solve's structure
+	                           covers every live pair slot, with or without points, and is only rebuilt when contact slots are
+	                           written (s2amd_world_set_contacts) */
 	int32_t movedCount;     /* shapes whose fat AABB the refit re-inflated (s2amdShape.enlarged) */
-	float contactsMs;       /* host wall time of stage 3 including its counter read-back */
+	float contactsMs;       /* host wall time of enqueueing stage 3 (its counters come back with the step's one read-back) */
 	float solveMs;          /* device time of the s2Solve_* part (HIP events) */
 	float stepMs;           /* host wall time of the whole call */
 } s2amdWorldStepInfo;

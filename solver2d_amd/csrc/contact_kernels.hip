@@ -49,6 +49,12 @@ __global__ __launch_bounds__(S2_BLOCK) void prepareContactsKernel(ContactView c,
 	s2amdContact* contact = wire + c.contactIndex[k];
 	int pointCount = contact->pointCount;
 	int ia = contact->bodyA, ib = contact->bodyB;
+	if (pointCount <= 0 && (ia < 0 || ib < 0 || ia >= b.capacity || ib >= b.capacity))
+	{
+		// a destroyed contact whose entry lingers in the structure until the next rebuild (solver_step.cpp: refreshShadows):
+		// a free pool slot names no bodies; any body will do for a constraint that neither reads nor writes one
+		pointCount = 0, ia = 0, ib = 0;
+	}
 	V2 normal = v2(contact->normal[0], contact->normal[1]);
 	float friction = contact->friction;
 
@@ -66,12 +72,15 @@ __global__ __launch_bounds__(S2_BLOCK) void prepareContactsKernel(ContactView c,
 
 	uint32_t fa = hostFlags[ia], fb = hostFlags[ib];
 	uint32_t wbit = posSolver ? S2F_WRITE_POS : S2F_WRITE_VEL;
+	// A manifold without points is a potential constraint only (solver_internal.h: hContactEdge): it keeps its place in the
+	// sweep order but gets no write bits, so every sweep skips its point loops AND its body stores -- a no-op by
+	// construction, which is what the reference does by never gathering it (e.g. solve_tgs_soft.c:162-179).
 	uint32_t bits = (uint32_t)pointCount;
-	if (fa & wbit)
+	if ((fa & wbit) && pointCount > 0)
 	{
 		bits |= S2C_WRITE_A;
 	}
-	if (fb & wbit)
+	if ((fb & wbit) && pointCount > 0)
 	{
 		bits |= S2C_WRITE_B;
 	}
@@ -267,7 +276,10 @@ __global__ __launch_bounds__(S2_BLOCK) void prepareContactsKernel(ContactView c,
 			s.w = tsep[j];
 			c.soft[j][k] = s;
 		}
-		contact->frictionPersisted = 1;
+		if (pointCount > 0) // the reference never visits a manifold without points (solve_tgs_sticky.c:331-348 gathers the others)
+		{
+			contact->frictionPersisted = 1;
+		}
 	}
 
 	c.nf[k] = make_float4(normal.x, normal.y, friction, fromBits(bits));

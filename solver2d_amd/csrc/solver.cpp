@@ -379,7 +379,35 @@ int s2amd_get_contact_order(s2amdSolver* s, int32_t* order, int32_t orderCapacit
 	{
 		return fail(S2AMD_E_INVALID, "null solver");
 	}
-	return copyOrder(s->contacts.order, s->contacts.colorOffsets, order, orderCapacity, colorOffsets, colorCapacity, constraintCount, colorCount);
+	// the sweep order holds every potential constraint; what the step swept -- and what the reference would have gathered --
+	// are the ones whose manifold had points
+	if (!s->pointsKnown)
+	{
+		int rc = fetchPointCounts(s);
+		if (rc)
+		{
+			return rc;
+		}
+	}
+	const SweepSet& cs = s->contacts;
+	std::vector<int> active, offsets(1, 0);
+	active.reserve(cs.order.size());
+	size_t k = 0;
+	for (size_t c = 0; c + 1 < cs.colorOffsets.size(); ++c)
+	{
+		for (; k < (size_t)cs.colorOffsets[c + 1]; ++k)
+		{
+			if (s->hContactPoints[(size_t)cs.order[k]] > 0)
+			{
+				active.push_back(cs.order[k]);
+			}
+		}
+		if ((int)active.size() > offsets.back())
+		{
+			offsets.push_back((int)active.size());
+		}
+	}
+	return copyOrder(active, offsets, order, orderCapacity, colorOffsets, colorCapacity, constraintCount, colorCount);
 }
 
 int s2amd_get_joint_order(s2amdSolver* s, int32_t* order, int32_t orderCapacity, int32_t* colorOffsets, int32_t colorCapacity, int32_t* jointCount,

@@ -173,7 +173,19 @@ struct s2amdSolver
 	std::vector<uint8_t> hPointBytes;
 
 	// host shadows of the graph structure (refreshed by every upload)
-	std::vector<int> hContactA, hContactB, hContactPoints;
+	// The structure (islands, colours, strips) is built over EVERY contact slot that can become a constraint -- a live pair of
+	// the world chain, a slot with two distinct live bodies otherwise -- whether its manifold has points this step or not
+	// (hContactEdge).  A manifold without points is a no-op in every sweep (no point loop iteration, no body store), so a
+	// manifold that gains or loses its points changes NOTHING on the host: same tables, same launch sequence, same hipGraph.
+	// Only a contact slot that appears, disappears or changes its bodies changes the graph (src/contact.c:137-229).
+	std::vector<int> hContactA, hContactB, hContactPoints; // hContactPoints: as of the last host upload (see pointsKnown)
+	std::vector<uint8_t> hContactEdge;
+	std::vector<uint8_t> hContactDead; // in the structure, but its contact has been destroyed since: dropped at the next rebuild
+	bool deadUnknown = false;		   // pairs separated on the device since the host last looked (syncDeadSlots, world.hip)
+	bool pointsKnown = false; // hContactPoints is current: no stage 3 has recomputed manifolds on the device since the upload
+	int activeContacts = 0;	  // manifolds with points this step (host count, or the device's counter in the world chain)
+	bool lastStepWroteIndex = false; // the last solve's driver writes manifold.constraintIndex (all but XPBD's early-out and Block)
+	DevBuf dScanTmp;
 	std::vector<int> hJointType, hJointA, hJointB;
 	std::vector<uint32_t> hBodyFlags; // S2F_WRITE_VEL / S2F_WRITE_POS from the wire bodies
 	std::vector<uint8_t> hBodyLive, hBodyStatic;
@@ -299,6 +311,14 @@ int buildStructure(s2amdSolver* s, int solverType);
 void buildPlan(s2amdSolver* s, const s2amdStepParams* params);
 bool messageEligible(const s2amdSolver* s, int solverType);
 void destroyGraph(s2amdSolver* s);
-int doUpload(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdContact* contacts, int nc, const s2amdJoint* joints, int nj);
+// pairs != nullptr (world chain): a slot is a potential constraint iff its pair is live; else iff it names two distinct live bodies
+int doUpload(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdContact* contacts, int nc, const s2amdJoint* joints, int nj,
+			 const s2amdPairState* pairs = nullptr);
+// manifold.constraintIndex of every resident contact slot from the resident point counts (world.hip; device scan)
+int refreshConstraintIndexOnDevice(s2amdSolver* s);
+// point counts of the resident manifolds -> hPointBytes / hContactPoints (world chain: one byte per slot)
+int fetchPointCounts(s2amdSolver* s);
+// world chain: which pair slots the device has freed (stage 3 separations) -> hContactDead, before a structure rebuild
+int syncDeadSlots(s2amdSolver* s);
 int doStep(s2amdSolver* s, const s2amdStepParams* params);
 int doDownload(s2amdSolver* s, s2amdBody* bodies, int nb, s2amdContact* contacts, int nc, s2amdJoint* joints, int nj);

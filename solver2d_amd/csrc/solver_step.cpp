@@ -16,7 +16,8 @@ void destroyGraph(s2amdSolver* s)
 	s->graphKey = 0;
 }
 
-int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdContact* contacts, int nc, const s2amdJoint* joints, int nj)
+int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdContact* contacts, int nc, const s2amdJoint* joints, int nj,
+				   const s2amdPairState* pairs)
 {
 	const bool newWorld = nb != (int)s->hBodyFlags.size() || nc != (int)s->hContactA.size() || nj != (int)s->hJointType.size();
 	bool changed = s->structureDirty || newWorld;
@@ -57,25 +58,48 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 		s->hContactA.assign(nc, -1);
 		s->hContactB.assign(nc, -1);
 		s->hContactPoints.assign(nc, 0);
+		s->hContactEdge.assign(nc, 0);
+		s->hContactDead.assign(nc, 0);
 	}
 	bool pointCountsMoved = false;
+	int active = 0;
 	for (int i = 0; i < nc; ++i)
 	{
 		const s2amdContact& c = contacts[i];
 		int pc = c.pointCount > 0 ? c.pointCount : 0;
 		pointCountsMoved = pointCountsMoved || s->hContactPoints[i] != pc;
-		if (!changed && (s->hContactA[i] != c.bodyA || s->hContactB[i] != c.bodyB || (s->hContactPoints[i] > 0) != (pc > 0)))
+		const bool valid = c.bodyA >= 0 && c.bodyA < nb && c.bodyB >= 0 && c.bodyB < nb;
+		if (pc > 0 && (!valid || pc > 2))
+		{
+			return fail(S2AMD_E_INVALID, "contact " + std::to_string(i) + " has an invalid body index or point count");
+		}
+		// a potential constraint: the world chain says which pair slots are live; a bare solver input does not, there a slot
+		// without points counts when it names two distinct live bodies (a free pool slot names none)
+		const bool edge = pc > 0 || (pairs ? (pairs[i].shapeA >= 0 && valid)
+										   : (valid && c.bodyA != c.bodyB && bodies[c.bodyA].type != S2AMD_BODY_FREE && bodies[c.bodyB].type != S2AMD_BODY_FREE));
+		s->hContactPoints[i] = pc;
+		active += pc > 0 ? 1 : 0;
+		if (!edge && s->hContactEdge[i] && !newWorld)
+		{
+			// The contact was destroyed (src/contact.c:205-229).  Its entry stays in the structure as a dead constraint
+			// -- pointCount 0 is a no-op -- with the bodies it had, until the slot is used again or the structure is rebuilt
+			// for another reason: the world chain, where pairs separate on the device, learns of a destruction no earlier,
+			// and both routes must sweep in the same order to stay bit-identical (tests/test_gpu_dropin.py).
+			s->hContactDead[i] = 1;
+			continue;
+		}
+		if (!changed && (edge != (s->hContactEdge[i] != 0) || (edge && (s->hContactA[i] != c.bodyA || s->hContactB[i] != c.bodyB))))
 		{
 			changed = true;
 		}
 		s->hContactA[i] = c.bodyA;
 		s->hContactB[i] = c.bodyB;
-		s->hContactPoints[i] = pc;
-		if (pc > 0 && (c.bodyA < 0 || c.bodyA >= nb || c.bodyB < 0 || c.bodyB >= nb || pc > 2))
-		{
-			return fail(S2AMD_E_INVALID, "contact " + std::to_string(i) + " has an invalid body index or point count");
-		}
+		s->hContactEdge[i] = edge ? 1 : 0;
+		s->hContactDead[i] = 0;
 	}
+	s->deadUnknown = false;
+	s->pointsKnown = true;
+	s->activeContacts = active;
 	if ((int)s->hJointType.size() != nj)
 	{
 		s->hJointType.assign(nj, S2AMD_JOINT_FREE);
@@ -117,14 +141,15 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 	return S2AMD_OK;
 }
 
-int doUpload(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdContact* contacts, int nc, const s2amdJoint* joints, int nj)
+int doUpload(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdContact* contacts, int nc, const s2amdJoint* joints, int nj,
+			 const s2amdPairState* pairs)
 {
 	if (nb < 0 || nc < 0 || nj < 0 || (nb > 0 && !bodies) || (nc > 0 && !contacts) || (nj > 0 && !joints))
 	{
 		return fail(S2AMD_E_INVALID, "null array with non-zero count");
 	}
 	HIP_TRY(hipSetDevice(s->device));
-	int rc = refreshShadows(s, bodies, nb, contacts, nc, joints, nj);
+	int rc = refreshShadows(s, bodies, nb, contacts, nc, joints, nj, pairs);
 	if (rc)
 	{
 		return rc;
@@ -262,8 +287,11 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	const bool xpbdEarlyOut = plan.earlyOut;
 	const bool writesConstraintIndex = !xpbdEarlyOut && params->solverType != s2amd_solverPGS_NGS_Block;
 
-	// manifold.constraintIndex (pool-order gather index, -1 for skipped slots)
-	if (writesConstraintIndex && s->contactCapacity > 0)
+	// manifold.constraintIndex (pool-order gather index, -1 for skipped slots).  With manifolds recomputed on the device
+	// (world chain) the host does not know the point counts: nothing on the device reads the field, so it is brought up to
+	// date when somebody downloads the contacts (refreshConstraintIndexOnDevice).
+	s->lastStepWroteIndex = writesConstraintIndex;
+	if (writesConstraintIndex && s->contactCapacity > 0 && s->pointsKnown)
 	{
 		if (s->gatherIndexDirty || s->dGatherIndex.bytes < (size_t)s->contactCapacity * sizeof(int))
 		{
@@ -293,8 +321,9 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 
 	auto enqueueAll = [&]() {
 		bool indexBranch = false;
-		q.gatherIndex = (writesConstraintIndex && s->contactCapacity > 0 && !q.fork) ? (const int*)s->dGatherIndex.p : nullptr;
-		if (writesConstraintIndex && s->contactCapacity > 0 && q.fork)
+		const bool indexNow = writesConstraintIndex && s->contactCapacity > 0 && s->pointsKnown;
+		q.gatherIndex = (indexNow && !q.fork) ? (const int*)s->dGatherIndex.p : nullptr;
+		if (indexNow && q.fork)
 		{
 			// touches only manifold.constraintIndex, which no solver kernel reads: a parallel branch that joins at the end
 			int n = s->contactCapacity;
@@ -318,7 +347,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	{
 		uint64_t key = 1469598103934665603ull;
 		key = fnv(key, params, sizeof(*params));
-		uint64_t gens[4] = {s->layoutGeneration, s->structureGeneration, s->planGeneration, (uint64_t)((q.msg ? 1 : 0) | (s->optBodyWarm ? 2 : 0) | (s->optStripLean ? 4 : 0) | (s->optPersist ? 8 : 0) | (s->optFork ? 16 : 0) | (s->persistFailed ? 32 : 0) | ((s->persistValid && s->persist.allTwoPoints) ? 64 : 0))};
+		uint64_t gens[4] = {s->layoutGeneration, s->structureGeneration, s->planGeneration, (uint64_t)((q.msg ? 1 : 0) | (s->optBodyWarm ? 2 : 0) | (s->optStripLean ? 4 : 0) | (s->optPersist ? 8 : 0) | (s->optFork ? 16 : 0) | (s->persistFailed ? 32 : 0) | ((s->persistValid && s->persist.allTwoPoints) ? 64 : 0) | (s->pointsKnown ? 128 : 0))};
 		key = fnv(key, gens, sizeof(gens));
 		int sizes[3] = {s->bodyCapacity, s->contactCapacity, s->jointCapacity};
 		key = fnv(key, sizes, sizeof(sizes));
@@ -374,7 +403,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 		HIP_TRY(hipEventElapsedTime(&ms, s->evBegin, s->evEnd));
 		s->stats.deviceMs = ms;
 	}
-	s->stats.constraintCount = s->cv.count;
+	s->stats.constraintCount = s->activeContacts; // (cv.count also holds the potential constraints whose manifold has no points now)
 	s->stats.jointCount = s->jv.count;
 	s->stats.contactColors = (int)s->contacts.colorOffsets.size() - 1;
 	s->stats.jointColors = (int)s->joints.colorOffsets.size() - 1;
@@ -447,6 +476,14 @@ int doDownload(s2amdSolver* s, s2amdBody* bodies, int nb, s2amdContact* contacts
 		return fail(S2AMD_E_CAPACITY, "output arrays smaller than the resident world");
 	}
 	HIP_TRY(hipSetDevice(s->device));
+	if (contacts && !s->pointsKnown && s->lastStepWroteIndex)
+	{
+		int rc = refreshConstraintIndexOnDevice(s);
+		if (rc)
+		{
+			return rc;
+		}
+	}
 	if (s->bodyCapacity > 0 && bodies)
 	{
 		HIP_TRY(hipMemcpyAsync(bodies, s->dBodies.p, (size_t)s->bodyCapacity * sizeof(s2amdBody), hipMemcpyDeviceToHost, s->stream));

@@ -49,6 +49,10 @@ constexpr size_t kJointSlotBytes = sizeof(int2) + sizeof(float4) * 8 + sizeof(fl
 // every strip constraint has two manifold points: selects the persistent kernel's POINTS == 2 variant
 bool stripsAllTwoPoints(const s2amdSolver* s)
 {
+	if (!s->pointsKnown)
+	{
+		return false; // manifolds are recomputed on the device (world chain): the per-point variant takes any point count
+	}
 	for (int k = s->persistK0; k < s->persistK1; ++k)
 	{
 		if (s->hContactPoints[(size_t)s->contacts.order[(size_t)k]] != 2)
@@ -1146,6 +1150,16 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 	{
 		return S2AMD_OK;
 	}
+	if (s->worldResident && !s->pointsKnown)
+	{
+		// world chain: the pair slots this step's (already enqueued) stage 3 and the earlier ones freed leave the structure
+		// with this rebuild, exactly as a host that ran stage 3 itself would have dropped them from the arrays it uploads
+		int rcDead = syncDeadSlots(s);
+		if (rcDead)
+		{
+			return rcDead;
+		}
+	}
 	double t0 = nowMs();
 	// S2AMD_DEBUG_PREP=1: where the host time of a structure build goes
 	static const bool prepTimes = getenv("S2AMD_DEBUG_PREP") != nullptr;
@@ -1165,11 +1179,17 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 		conflict[i] = (s->hBodyFlags[i] & (cls == 1 ? S2F_WRITE_POS : S2F_WRITE_VEL)) != 0;
 	}
 
-	// active constraints in pool order (the reference's gather: e.g. solve_tgs_soft.c:162-179)
+	// potential constraints in pool order (the reference's gather, e.g. solve_tgs_soft.c:162-179, over the slots that CAN have
+	// manifold points; the ones that have none this step are no-ops wherever the sweep order puts them)
 	EdgeList ce, je;
 	for (int i = 0; i < s->contactCapacity; ++i)
 	{
-		if (s->hContactPoints[i] > 0)
+		if (s->hContactEdge[i] && s->hContactDead[i])
+		{
+			s->hContactEdge[i] = 0; // a destroyed contact leaves the structure with this rebuild
+			s->hContactDead[i] = 0;
+		}
+		if (s->hContactEdge[i])
 		{
 			ce.ids.push_back(i);
 			ce.a.push_back(s->hContactA[i]);
@@ -1186,6 +1206,15 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 		}
 	}
 	const int C = (int)ce.ids.size(), J = (int)je.ids.size();
+	if (prepTimes)
+	{
+		uint64_t h = 1469598103934665603ull;
+		h = fnv(h, ce.ids.data(), ce.ids.size() * sizeof(int));
+		h = fnv(h, ce.a.data(), ce.a.size() * sizeof(int));
+		h = fnv(h, ce.b.data(), ce.b.size() * sizeof(int));
+		fprintf(stderr, "[s2amd] rebuild #%llu: %d potential contact constraints, %d joints, edge hash %016llx\n", (unsigned long long)s->structureGeneration, C, J,
+				(unsigned long long)h);
+	}
 
 	phase("edge lists");
 	// ---- islands: connected components over the writable bodies ----

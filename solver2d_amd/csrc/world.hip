@@ -11,6 +11,10 @@
 // slot) in the steps where the summary kernel saw one of them change.
 #include "solver_internal.h"
 
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
 #define S2_BLOCK 256
 
 namespace
@@ -61,28 +65,20 @@ __global__ __launch_bounds__(S2_BLOCK) void clearMovedKernel(s2amdShape* shapes,
 	}
 }
 
-// the contact part of refreshShadows (solver_step.cpp) for point counts produced on the device
-void applyPointCounts(s2amdSolver* s)
+// manifold.constraintIndex from the resident point counts: exclusive scan of "has points" over the pool (the reference's
+// gather order, e.g. src/solve_tgs_soft.c:162-179), -1 for the slots the gather skips
+struct HasPoints
 {
-	bool graphChanged = false, countsMoved = false;
-	for (int i = 0; i < s->contactCapacity; ++i)
+	const uint8_t* pointBytes;
+	__host__ __device__ int operator()(int i) const { return pointBytes[i] > 0 ? 1 : 0; }
+};
+
+__global__ __launch_bounds__(S2_BLOCK) void writeConstraintIndexFromScanKernel(s2amdContact* contacts, int n, const uint8_t* pointBytes, const int* scanned)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n)
 	{
-		int pc = s->hPointBytes[(size_t)i];
-		if (s->hContactPoints[(size_t)i] != pc)
-		{
-			countsMoved = true;
-			graphChanged = graphChanged || (s->hContactPoints[(size_t)i] > 0) != (pc > 0);
-			s->hContactPoints[(size_t)i] = pc;
-		}
-	}
-	if (graphChanged)
-	{
-		noteGraphChanged(s);
-		s->gatherIndexDirty = true;
-	}
-	else if (countsMoved && s->persistValid)
-	{
-		s->persist.allTwoPoints = stripsAllTwoPoints(s) ? 1 : 0;
+		contacts[i].constraintIndex = pointBytes[i] > 0 ? scanned[i] : -1;
 	}
 }
 
@@ -101,6 +97,79 @@ int fetchSummary(s2amdSolver* s, int reset)
 }
 
 } // namespace
+
+int refreshConstraintIndexOnDevice(s2amdSolver* s)
+{
+	const int nc = s->contactCapacity;
+	if (nc <= 0 || !s->worldResident)
+	{
+		return S2AMD_OK;
+	}
+	bool grew = false;
+	int rc = s->dGatherIndex.ensure((size_t)nc * sizeof(int), &grew);
+	if (rc)
+	{
+		return rc;
+	}
+	if (grew)
+	{
+		s->layoutGeneration += 1;
+		s->gatherIndexDirty = true;
+	}
+	auto flags = rocprim::make_transform_iterator(rocprim::make_counting_iterator(0), HasPoints{(const uint8_t*)s->dPointBytes.p});
+	size_t tmp = 0;
+	HIP_TRY(rocprim::exclusive_scan(nullptr, tmp, flags, (int*)s->dGatherIndex.p, 0, (size_t)nc, rocprim::plus<int>(), s->stream));
+	if ((rc = s->dScanTmp.ensure(std::max<size_t>(tmp, 256))) != 0)
+	{
+		return rc;
+	}
+	HIP_TRY(rocprim::exclusive_scan(s->dScanTmp.p, tmp, flags, (int*)s->dGatherIndex.p, 0, (size_t)nc, rocprim::plus<int>(), s->stream));
+	writeConstraintIndexFromScanKernel<<<gridFor((size_t)nc), dim3(S2_BLOCK), 0, s->stream>>>((s2amdContact*)s->dContacts.p, nc, (const uint8_t*)s->dPointBytes.p,
+																							   (const int*)s->dGatherIndex.p);
+	HIP_TRY(hipGetLastError());
+	s->gatherIndexDirty = true; // dGatherIndex no longer holds what the host would compute from its own (older) point counts
+	return S2AMD_OK;
+}
+
+int syncDeadSlots(s2amdSolver* s)
+{
+	s->deadUnknown = false;
+	const int nc = s->contactCapacity;
+	if (!s->worldResident || nc <= 0)
+	{
+		return S2AMD_OK;
+	}
+	HIP_TRY(hipSetDevice(s->device));
+	std::vector<int32_t> shapeA((size_t)nc);
+	HIP_TRY(hipMemcpy2DAsync(shapeA.data(), sizeof(int32_t), s->dPairs.p, sizeof(s2amdPairState), sizeof(int32_t), (size_t)nc, hipMemcpyDeviceToHost, s->stream));
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	for (int i = 0; i < nc; ++i)
+	{
+		if (s->hContactEdge[(size_t)i] && shapeA[(size_t)i] < 0)
+		{
+			s->hContactDead[(size_t)i] = 1;
+		}
+	}
+	return S2AMD_OK;
+}
+
+int fetchPointCounts(s2amdSolver* s)
+{
+	const int nc = s->contactCapacity;
+	if (!s->worldResident || nc <= 0)
+	{
+		return S2AMD_OK;
+	}
+	HIP_TRY(hipSetDevice(s->device));
+	s->hPointBytes.resize((size_t)nc);
+	HIP_TRY(hipMemcpyAsync(s->hPointBytes.data(), s->dPointBytes.p, (size_t)nc, hipMemcpyDeviceToHost, s->stream));
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	for (int i = 0; i < nc; ++i)
+	{
+		s->hContactPoints[(size_t)i] = s->hPointBytes[(size_t)i];
+	}
+	return S2AMD_OK;
+}
 
 #pragma GCC visibility push(default)
 extern "C"
@@ -135,7 +204,7 @@ int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapa
 	s->worldResident = false;
 	s->pairKeysValid = false;
 	s->gatherIndexDirty = true;
-	int rc = doUpload(s, bodies, bodyCapacity, contacts, contactCapacity, joints, jointCapacity);
+	int rc = doUpload(s, bodies, bodyCapacity, contacts, contactCapacity, joints, jointCapacity, pairs);
 	if (rc)
 	{
 		return rc;
@@ -222,9 +291,17 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 	hipStream_t st = s->stream;
 	WorldSummary* dSum = (WorldSummary*)s->dWorldSummary.p;
 	WorldSummary* hSum = (WorldSummary*)s->hostWorldSummary;
+	WorldSummary firstSeen{};
+	bool haveFirst = false;
 	const double t0 = nowMs();
 
-	// ---- stage 3: update contacts ----
+	// ---- stage 3 (update contacts), s2Solve_* and stage 4 (refit), enqueued back to back: ONE read-back per step ----
+	// The structure the solve runs on covers every live pair slot whether its manifold has points or not, so nothing the
+	// narrow phase finds this step -- manifolds gaining or losing their points, pairs separating -- has to reach the host
+	// before the solve is enqueued.
+	// When the persistent step kernel reports a dead hand-off its epilogue leaves the wire arrays untouched, so the refit
+	// behind it saw the bodies of the previous step (same AABBs, nothing enlarged): the solve is repeated on the
+	// multi-launch path, and so is the refit.
 	if (nc > 0)
 	{
 		// (the kernel also destroys separated pairs and accumulates the step's contact counters)
@@ -232,28 +309,9 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 							 (s2amdPairState*)s->dPairs.p, (s2amdContact*)s->dContacts.p, nc, (int32_t*)s->dStatus.p, (uint8_t*)s->dPointBytes.p,
 							 (int*)dSum);
 	}
-	int rc = fetchSummary(s, 0);
-	if (rc)
-	{
-		return rc;
-	}
-	WorldSummary contactsSeen = *hSum;
-	if (contactsSeen.separated > 0)
-	{
-		s->pairKeysValid = false; // pair slots were freed on the device
-	}
-	if (contactsSeen.moves > 0)
-	{
-		HIP_TRY(hipMemcpyAsync(s->hPointBytes.data(), s->dPointBytes.p, (size_t)nc, hipMemcpyDeviceToHost, st));
-		HIP_TRY(hipStreamSynchronize(st));
-		applyPointCounts(s);
-	}
+	s->pointsKnown = false; // the manifolds are the device's now
 	const double t1 = nowMs();
-
-	// ---- s2Solve_* and stage 4 (refit), enqueued back to back ----
-	// When the persistent step kernel reports a dead hand-off its epilogue leaves the wire arrays untouched, so the refit
-	// behind it saw the bodies of the previous step (same AABBs, nothing enlarged): the solve is repeated on the
-	// multi-launch path, and so is the refit.
+	int rc = S2AMD_OK;
 	int fallbacks = 0;
 	for (;;)
 	{
@@ -272,17 +330,28 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 		}
 		if (s->hostError && *s->hostError != 0u && fallbacks == 0)
 		{
-			// bodies, impulses and (because the solve left the bodies alone) the shapes are what they were before the solve
+			// bodies, impulses and (because the solve left the bodies alone) the shapes are what they were before the solve;
+			// the counters of stage 3 were read and reset above and are kept (contactsSeen below takes the first read)
 			*s->hostError = 0u;
 			HIP_TRY(hipMemsetAsync(s->persist.deviceError, 0, sizeof(unsigned int), st));
 			HIP_TRY(hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, st));
 			s->persistFailed = true;
 			s->persistFallbacks += 1;
 			fallbacks += 1;
+			firstSeen = *hSum;
+			haveFirst = true;
 			continue;
 		}
 		break;
 	}
+	WorldSummary contactsSeen = haveFirst ? firstSeen : *hSum;
+	if (contactsSeen.separated > 0)
+	{
+		s->pairKeysValid = false; // pair slots were freed on the device
+		s->deadUnknown = true;	  // ... their entries linger in the structure as no-ops until the next rebuild drops them
+	}
+	s->activeContacts = contactsSeen.active;
+	s->stats.constraintCount = contactsSeen.active;
 	{
 		float ms = 0.0f;
 		if (hipEventElapsedTime(&ms, s->evBegin, s->evEnd) == hipSuccess)
@@ -383,29 +452,36 @@ int s2amd_world_set_contacts(s2amdSolver* s, const int32_t* slots, int32_t count
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(st));
 	s->pairKeysValid = false;
-	// host shadows of the constraint graph (solver_step.cpp: refreshShadows)
+	// host shadows of the constraint graph (solver_step.cpp: refreshShadows): a slot is a potential constraint while its
+	// pair is live, whatever its manifold holds
 	bool changed = false;
 	for (int i = 0; i < count; ++i)
 	{
 		const int k = slots[i];
 		const s2amdContact& c = contacts[i];
 		const int pc = c.pointCount > 0 ? c.pointCount : 0;
-		changed = changed || ((s->hContactPoints[(size_t)k] > 0) != (pc > 0)) ||
-				  ((pc > 0 || s->hContactPoints[(size_t)k] > 0) && (s->hContactA[(size_t)k] != c.bodyA || s->hContactB[(size_t)k] != c.bodyB));
+		const bool edge = pairs[i].shapeA >= 0 || pc > 0;
+		changed = changed || edge != (s->hContactEdge[(size_t)k] != 0) || (edge && (s->hContactA[(size_t)k] != c.bodyA || s->hContactB[(size_t)k] != c.bodyB));
 		s->hContactA[(size_t)k] = c.bodyA;
 		s->hContactB[(size_t)k] = c.bodyB;
-		s->hContactPoints[(size_t)k] = pc;
-		s->hPointBytes[(size_t)k] = (uint8_t)pc;
+		s->hContactEdge[(size_t)k] = edge ? 1 : 0;
+		s->hContactDead[(size_t)k] = 0;
+		if (s->pointsKnown)
+		{
+			s->activeContacts += (pc > 0 ? 1 : 0) - (s->hContactPoints[(size_t)k] > 0 ? 1 : 0);
+			s->hContactPoints[(size_t)k] = pc;
+			s->hPointBytes[(size_t)k] = (uint8_t)pc;
+		}
 	}
 	if (changed)
 	{
 		noteGraphChanged(s);
-		s->gatherIndexDirty = true;
 	}
 	else if (s->persistValid)
 	{
 		s->persist.allTwoPoints = stripsAllTwoPoints(s) ? 1 : 0;
 	}
+	s->gatherIndexDirty = true;
 	return S2AMD_OK;
 }
 
@@ -428,6 +504,15 @@ int s2amd_world_download(s2amdSolver* s, s2amdBody* bodies, int32_t bodyCapacity
 	}
 	HIP_TRY(hipSetDevice(s->device));
 	hipStream_t st = s->stream;
+	if (contacts && !s->pointsKnown && s->lastStepWroteIndex)
+	{
+		// manifold.constraintIndex is an output nobody on the device reads: written when somebody asks for the contacts
+		int rc = refreshConstraintIndexOnDevice(s);
+		if (rc)
+		{
+			return rc;
+		}
+	}
 	if (bodies && s->bodyCapacity > 0)
 	{
 		HIP_TRY(hipMemcpyAsync(bodies, s->dBodies.p, (size_t)s->bodyCapacity * sizeof(s2amdBody), hipMemcpyDeviceToHost, st));

@@ -75,18 +75,19 @@ def test_one_rank_through_rccl():
 
 
 def _unsharded_poses(islands, base, steps):
-    import numpy as np
-    import torch
     from solver2d_amd import hip, synthetic, wire
     world = synthetic.pyramid(base, count=islands)
     params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
-    buf = torch.zeros((len(world[0]), 4), dtype=torch.float32, device="cuda")
+    # (no torch here: its bundled HIP runtime cannot initialise after libs2amd.so's has taken the device in this process)
     with hip.Solver(0) as s:
         s.upload(*world)
         for _ in range(steps):
             s.step_resident(params)
-        s.export_poses(buf.data_ptr(), len(world[0]))
-    return buf.cpu().numpy()
+        buf = s.device_alloc(len(world[0]) * 16)
+        s.export_poses(buf, len(world[0]))
+        out = s.device_read(buf, (len(world[0]), 4))
+        s.device_free(buf)
+    return out
 
 
 @pytest.mark.parametrize("nranks,port", [(2, 29523), (3, 29525)])

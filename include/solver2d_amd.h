@@ -162,6 +162,9 @@ typedef struct s2amdStepStats
 	int32_t seamCount;         /* seams between adjacent strips that carry constraints: phase B workgroups per sweep */
 	int32_t persistent;        /* 1 when the strips ran as ONE persistent launch (constraints resident in registers all step) */
 	int32_t persistFallbacks;  /* times a persistent step was abandoned (workgroups not co-resident) and repeated on the multi-launch path */
+	int32_t structureBuilds;   /* full builds of the constraint-graph structure (islands, colours, tables) since s2amd_create */
+	int32_t placedContacts;    /* created contacts that were given a place in the existing structure instead (no build) */
+	int32_t potentialConstraints; /* contact slots the structure holds: constraintCount + manifolds without points + destroyed contacts not yet dropped */
 } s2amdStepStats;
 
 typedef struct s2amdSolver s2amdSolver;
@@ -314,6 +317,9 @@ int s2amd_world_step(s2amdSolver* solver, const s2amdStepParams* params, s2amdWo
  * A successful query consumes the move buffer as s2UpdateBroadPhasePairs does (src/broad_phase.c: moveArray and moveSet
  * are cleared): every shape's `enlarged` flag is zero afterwards, static shapes included. */
 int s2amd_world_find_pairs(s2amdSolver* solver, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount);
+/* The contact slots whose pairs the last s2amd_world_step found separated (fat AABBs apart) and destroyed on the device, in
+ * ascending order: the slots the caller's own pool frees (s2DestroyContact, src/world.c:163-167).  info.separatedCount of them. */
+int s2amd_world_separated(s2amdSolver* solver, int32_t* slots, int32_t capacity, int32_t* count);
 /* Writes `count` contact slots of the resident world (slot indices < contactCapacity of the upload): the caller's
  * s2CreateContact (src/contact.c:137-203: pool slot, pair flip, mixed friction, empty manifold) or s2DestroyContact
  * (pairs[i].shapeA = -1, contacts[i].pointCount = 0).  A world that needs more slots, bodies or shapes is uploaded again. */
@@ -357,7 +363,8 @@ int s2amd_device_read(s2amdSolver* solver, void* hostDst, const void* deviceSrc,
 /* ---- introspection (tests, bench) ---- */
 /* Execution order of the last step: order[k] = contact-array index of the k-th constraint in
  * sweep order; colorOffsets[c]..colorOffsets[c+1] delimit colour batch c.  A sequential
- * Gauss-Seidel sweep in this order is arithmetic-identical to the batched device sweep. */
+ * Gauss-Seidel sweep in this order is arithmetic-identical to the batched device sweep.  (s2Solve_Jacobi's contact pass
+ * writes no body and needs no colours: there only the order -- the order of the per-body sums -- is meaningful.) */
 int s2amd_get_contact_order(s2amdSolver* solver, int32_t* order, int32_t orderCapacity, int32_t* colorOffsets,
 							int32_t colorCapacity, int32_t* constraintCount, int32_t* colorCount);
 int s2amd_get_joint_order(s2amdSolver* solver, int32_t* order, int32_t orderCapacity, int32_t* colorOffsets,
@@ -376,7 +383,8 @@ int s2amd_measure_dominant(s2amdSolver* solver, const s2amdStepParams* params, i
  * "strips" (0/1 cut islands that fit no LDS group into strips of BFS levels: two launches per sweep), "strip_bodies" (target
  * bodies per strip, default 160), "strip_retry" (0/1 rebuild the partition with other strip widths when one strip needs the 8-round kernel variant), "strip_min_bodies" (loose bodies below which the colour-batch path is kept), "strip_patience" (steps the constraint graph must
  * stay unchanged before the strip structure is built: its host build costs ~3 ms at 60k constraints, the colour-batch one ~1 ms), "async" (0/1, see s2amd_synchronize), "strip_lean" (0/1 dedicated strip
- * kernel for the soft sweeps), "persist" (0/1 whole step of the strips in one persistent launch), "body_warm" */
+ * kernel for the soft sweeps), "persist" (0/1 whole step of the strips in one persistent launch), "body_warm", "incremental" (0/1 created
+ * contacts are placed into the existing structure when they fit; 0 = every created contact rebuilds it) */
 int s2amd_set_option(s2amdSolver* solver, const char* key, int32_t value);
 
 #ifdef __cplusplus

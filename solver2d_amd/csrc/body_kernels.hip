@@ -153,8 +153,10 @@ S2_DEV float laneValue(float v, int lane)
 	return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-__global__ __launch_bounds__(S2_BLOCK) void jacobiApplyKernel(BodyView b, ContactView c, const int* adjOffsets, const int* adjList, int bodyBlocks,
-															   const int* heavy, int heavyCount)
+// adjRange[i] = {first entry, entry count} of body i in adjList (ranges carry slack so that the host can add an entry in
+// place); heavy[0] = number of heavy bodies, heavy[1..] their slots (the launch is sized for the list's capacity)
+__global__ __launch_bounds__(S2_BLOCK) void jacobiApplyKernel(BodyView b, ContactView c, const int2* adjRange, const int* adjList, int bodyBlocks,
+															   const int* heavy)
 {
 	if ((int)blockIdx.x >= bodyBlocks)
 	{
@@ -162,12 +164,13 @@ __global__ __launch_bounds__(S2_BLOCK) void jacobiApplyKernel(BodyView b, Contac
 		// sequential in list order, every lane performing the same ones on values broadcast from lane u. ----
 		const int lane = (int)threadIdx.x & 63;
 		const int h = ((int)blockIdx.x - bodyBlocks) * (S2_BLOCK / 64) + ((int)threadIdx.x >> 6);
-		if (h >= heavyCount)
+		if (h >= heavy[0])
 		{
 			return;
 		}
-		const int i = heavy[h];
-		const int begin = adjOffsets[i], end = adjOffsets[i + 1];
+		const int i = heavy[1 + h];
+		const int2 range = adjRange[i];
+		const int begin = range.x, end = range.x + range.y;
 		V2 dv = v2(0.0f, 0.0f);
 		float dw = 0.0f;
 		constexpr int WIDE = 4; // 4 x 64 list entries are loaded before the first addition: two memory round trips per 256 entries
@@ -227,7 +230,8 @@ __global__ __launch_bounds__(S2_BLOCK) void jacobiApplyKernel(BodyView b, Contac
 	{
 		return;
 	}
-	int begin = adjOffsets[i], end = adjOffsets[i + 1];
+	const int2 range = adjRange[i];
+	int begin = range.x, end = range.x + range.y;
 	if (end - begin > S2_HEAVY_DEGREE)
 	{
 		return; // a wave of the heavy blocks walks this one
@@ -303,12 +307,30 @@ void launchFinalizePositions(hipStream_t s, const BodyView& b, int dynamicOnly)
 		finalizePositionsKernel<<<gridFor(b.capacity), dim3(S2_BLOCK), 0, s>>>(b, dynamicOnly);
 	}
 }
-void launchJacobiApply(hipStream_t s, const BodyView& b, const ContactView& c, const int* adjOffsets, const int* adjList, const int* heavy, int heavyCount)
+void launchJacobiApply(hipStream_t s, const BodyView& b, const ContactView& c, const int2* adjRange, const int* adjList, const int* heavy, int heavyCapacity)
 {
 	if (b.capacity > 0)
 	{
-		const int bodyBlocks = (b.capacity + S2_BLOCK - 1) / S2_BLOCK, heavyBlocks = (heavyCount + S2_BLOCK / 64 - 1) / (S2_BLOCK / 64);
-		jacobiApplyKernel<<<dim3((unsigned)(bodyBlocks + heavyBlocks)), dim3(S2_BLOCK), 0, s>>>(b, c, adjOffsets, adjList, bodyBlocks, heavy, heavyCount);
+		const int bodyBlocks = (b.capacity + S2_BLOCK - 1) / S2_BLOCK, heavyBlocks = (heavyCapacity + S2_BLOCK / 64 - 1) / (S2_BLOCK / 64);
+		jacobiApplyKernel<<<dim3((unsigned)(bodyBlocks + heavyBlocks)), dim3(S2_BLOCK), 0, s>>>(b, c, adjRange, adjList, bodyBlocks, heavy);
+	}
+}
+
+// Incremental structure updates (solver_incremental.cpp): 32-bit words written into the device tables the kernels read
+__global__ __launch_bounds__(S2_BLOCK) void patchWordsKernel(const uint4* patches, int n)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n)
+	{
+		uint4 p = patches[i]; // {address lo, address hi, value, 0}
+		*(uint32_t*)(((unsigned long long)p.y << 32) | (unsigned long long)p.x) = p.z;
+	}
+}
+void launchPatchWords(hipStream_t s, const void* devicePatches, int n)
+{
+	if (n > 0)
+	{
+		patchWordsKernel<<<gridFor(n), dim3(S2_BLOCK), 0, s>>>((const uint4*)devicePatches, n);
 	}
 }
 void launchXpbdIntegrate(hipStream_t s, const BodyView& b, float h)

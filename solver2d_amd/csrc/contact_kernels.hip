@@ -46,7 +46,27 @@ __global__ __launch_bounds__(S2_BLOCK) void prepareContactsKernel(ContactView c,
 	{
 		return;
 	}
-	s2amdContact* contact = wire + c.contactIndex[k];
+	const int slot = c.contactIndex[k];
+	if (slot < 0)
+	{
+		// a free position of the sweep order (slack a colour batch keeps so that a created contact can be given a place
+		// without rebuilding the structure, solver_incremental.cpp): an empty record, no bodies read or written
+		const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		c.bodies[k] = make_int2(0, 0);
+		c.mass[k] = zero;
+		c.nf[k] = zero;
+		for (int j = 0; j < 2; ++j)
+		{
+			c.anchor[j][k] = zero, c.r0[j][k] = zero, c.param[j][k] = zero, c.soft[j][k] = zero;
+			c.impulse[j][k] = make_float2(0.0f, 0.0f);
+		}
+		if (KIND == PREP_BLOCK)
+		{
+			c.blockK[k] = zero, c.blockNM[k] = zero;
+		}
+		return;
+	}
+	s2amdContact* contact = wire + slot;
 	int pointCount = contact->pointCount;
 	int ia = contact->bodyA, ib = contact->bodyB;
 	if (pointCount <= 0 && (ia < 0 || ib < 0 || ia >= b.capacity || ib >= b.capacity))
@@ -320,7 +340,12 @@ __global__ __launch_bounds__(S2_BLOCK) void storeImpulsesKernel(ContactView c, s
 	{
 		return;
 	}
-	s2amdContact* contact = wire + c.contactIndex[k];
+	const int slot = c.contactIndex[k];
+	if (slot < 0)
+	{
+		return; // a free position of the sweep order
+	}
+	s2amdContact* contact = wire + slot;
 	int pointCount = KIND == STORE_BLOCK ? (int)asBits(c.blockK[k].w) : (int)(asBits(c.nf[k].w) & 0xffu);
 #pragma unroll
 	for (int j = 0; j < 2; ++j)
@@ -366,8 +391,8 @@ S2_DEV float laneValue(float v, int lane)
 }
 
 template <int KIND>
-__global__ __launch_bounds__(S2_BLOCK) void warmStartBodiesKernel(ContactView c, BodyView b, const int* adjOffsets, const int* adjList,
-																   int integrateFirst, int bodyBlocks, const int* heavy, int heavyCount)
+__global__ __launch_bounds__(S2_BLOCK) void warmStartBodiesKernel(ContactView c, BodyView b, const int2* adjRange, const int* adjList,
+																   int integrateFirst, int bodyBlocks, const int* heavy)
 {
 	GlobalBodies gb{b.vel, b.dq};
 	if ((int)blockIdx.x >= bodyBlocks)
@@ -378,11 +403,11 @@ __global__ __launch_bounds__(S2_BLOCK) void warmStartBodiesKernel(ContactView c,
 		// the additions of the one-thread walk below:  w +- iv*cross(r,P)  ==  w + (+-t),   v + (+-m)*P  ==  v + prod. ----
 		const int lane = (int)threadIdx.x & 63;
 		const int h = ((int)blockIdx.x - bodyBlocks) * (S2_BLOCK / 64) + ((int)threadIdx.x >> 6);
-		if (h >= heavyCount)
+		if (h >= heavy[0]) // heavy[0] = count, heavy[1..] = body slots (see jacobiApplyKernel)
 		{
 			return;
 		}
-		const int i = heavy[h];
+		const int i = heavy[1 + h];
 		if ((b.flags[i] & S2F_IN_GROUP) != 0)
 		{
 			return;
@@ -391,7 +416,8 @@ __global__ __launch_bounds__(S2_BLOCK) void warmStartBodiesKernel(ContactView c,
 		{
 			integrateVelocitiesOne(gb, i, b, i); // every lane: the same loads, the same result, the same store; each lane reads back its own
 		}
-		const int e0 = adjOffsets[i], e1 = adjOffsets[i + 1];
+		const int2 range = adjRange[i];
+		const int e0 = range.x, e1 = range.x + range.y;
 		float4 v4 = b.vel[i];
 		V2 v = v2(v4.x, v4.y);
 		float w = v4.z;
@@ -467,7 +493,8 @@ __global__ __launch_bounds__(S2_BLOCK) void warmStartBodiesKernel(ContactView c,
 	{
 		return;
 	}
-	int e0 = adjOffsets[i], e1 = adjOffsets[i + 1];
+	const int2 range = adjRange[i];
+	int e0 = range.x, e1 = range.x + range.y;
 	if (e1 - e0 > S2_HEAVY_DEGREE)
 	{
 		return; // a wave of the heavy blocks walks this one (and integrates it first)
@@ -829,25 +856,25 @@ void launchSolveContactsStickyMsg(hipStream_t s, const ContactView& c, const Msg
 	S2_LAUNCH_SWEEP(solveContactsStickyMsgKernel, c, m, wire, begin, end, inv_h, useBias);
 }
 
-void launchWarmStartBodies(hipStream_t s, int kind, const ContactView& c, const BodyView& b, const int* adjOffsets, const int* adjList,
-						   int integrateFirst, const int* heavy, int heavyCount)
+void launchWarmStartBodies(hipStream_t s, int kind, const ContactView& c, const BodyView& b, const int2* adjRange, const int* adjList,
+						   int integrateFirst, const int* heavy, int heavyCapacity)
 {
 	if (b.capacity <= 0)
 	{
 		return;
 	}
-	const int bodyBlocks = (b.capacity + S2_BLOCK - 1) / S2_BLOCK, heavyBlocks = (heavyCount + S2_BLOCK / 64 - 1) / (S2_BLOCK / 64);
+	const int bodyBlocks = (b.capacity + S2_BLOCK - 1) / S2_BLOCK, heavyBlocks = (heavyCapacity + S2_BLOCK / 64 - 1) / (S2_BLOCK / 64);
 	dim3 g((unsigned)(bodyBlocks + heavyBlocks)), t(S2_BLOCK);
 	switch (kind)
 	{
 		case WARM_CURRENT:
-			warmStartBodiesKernel<WARM_CURRENT><<<g, t, 0, s>>>(c, b, adjOffsets, adjList, integrateFirst, bodyBlocks, heavy, heavyCount);
+			warmStartBodiesKernel<WARM_CURRENT><<<g, t, 0, s>>>(c, b, adjRange, adjList, integrateFirst, bodyBlocks, heavy);
 			break;
 		case WARM_FIXED:
-			warmStartBodiesKernel<WARM_FIXED><<<g, t, 0, s>>>(c, b, adjOffsets, adjList, integrateFirst, bodyBlocks, heavy, heavyCount);
+			warmStartBodiesKernel<WARM_FIXED><<<g, t, 0, s>>>(c, b, adjRange, adjList, integrateFirst, bodyBlocks, heavy);
 			break;
 		case WARM_BLOCK:
-			warmStartBodiesKernel<WARM_BLOCK><<<g, t, 0, s>>>(c, b, adjOffsets, adjList, integrateFirst, bodyBlocks, heavy, heavyCount);
+			warmStartBodiesKernel<WARM_BLOCK><<<g, t, 0, s>>>(c, b, adjRange, adjList, integrateFirst, bodyBlocks, heavy);
 			break;
 	}
 }

@@ -38,7 +38,7 @@ struct ColorMasks
 // balanced (strip groups: one constraint per thread and colour round): a repair pass after the greedy pass
 // evens out colours wider than one workgroup.
 int colorGraph(const std::vector<int>& ea, const std::vector<int>& eb, const std::vector<uint8_t>& conflict, int bodyCount,
-			   std::vector<int>& color, bool balanced)
+			   std::vector<int>& color, bool balanced, std::vector<uint64_t>* bitsOut)
 {
 	const int W = ColorMasks::WORDS;
 	size_t n = ea.size();
@@ -187,6 +187,10 @@ int colorGraph(const std::vector<int>& ea, const std::vector<int>& eb, const std
 			color[k] = spill[(size_t)c];
 			spillCount[(size_t)c] += 1;
 		}
+	}
+	if (bitsOut)
+	{
+		bitsOut->swap(bits); // colours 0..255 in use per body (the unbalanced greedy pass only: nothing was moved afterwards)
 	}
 	return colorCount;
 }

@@ -98,7 +98,8 @@ void launchPackBodies(hipStream_t s, const BodyView& b, s2amdBody* wire);
 void launchIntegrateVelocities(hipStream_t s, const BodyView& b);
 void launchIntegratePositions(hipStream_t s, const BodyView& b, float h);
 void launchFinalizePositions(hipStream_t s, const BodyView& b, int dynamicOnly);
-void launchJacobiApply(hipStream_t s, const BodyView& b, const ContactView& c, const int* adjOffsets, const int* adjList, const int* heavy, int heavyCount);
+void launchJacobiApply(hipStream_t s, const BodyView& b, const ContactView& c, const int2* adjRange, const int* adjList, const int* heavy, int heavyCapacity);
+void launchPatchWords(hipStream_t s, const void* devicePatches, int n);
 void launchXpbdIntegrate(hipStream_t s, const BodyView& b, float h);
 void launchXpbdProject(hipStream_t s, const BodyView& b, float inv_h);
 void launchExportPoses(hipStream_t s, const s2amdBody* wire, int n, void* out);
@@ -131,7 +132,7 @@ void launchGatherMessageSlots(hipStream_t s, const BodyView& b, const MsgView& m
 
 // body-centric warm start (one launch for all colours, optionally fused with integrate velocities)
 // heavy: the bodies with more than S2_HEAVY_DEGREE list entries (a whole wave walks each of them)
-void launchWarmStartBodies(hipStream_t s, int kind, const ContactView& c, const BodyView& b, const int* adjOffsets, const int* adjList,
+void launchWarmStartBodies(hipStream_t s, int kind, const ContactView& c, const BodyView& b, const int2* adjRange, const int* adjList,
 						   int integrateFirst, const int* heavy, int heavyCount);
 
 // strip_kernel.hip
@@ -143,7 +144,7 @@ void launchStripStep(hipStream_t s, int kind, int warm, const ContactView& c, co
 // stage kernels on resident arrays (narrowphase.hip, broadphase.hip; called by world.hip)
 // summary: int[5] {separated pairs, active manifolds, zero/non-zero flips, point-count moves, enlarged shapes} (world.hip: WorldSummary)
 void launchUpdateContacts(hipStream_t st, const s2amdBody* bodies, const float* origins, const s2amdShape* shapes, s2amdPairState* pairs,
-						  s2amdContact* contacts, int contactCapacity, int32_t* status, uint8_t* pointBytes, int* summary);
+						  s2amdContact* contacts, int contactCapacity, int32_t* status, uint8_t* pointBytes, int* summary, int* separatedSlots);
 // stage 4 in one launch: refit per shape (origin recomputed from the body), origins + force reset per body, summary[4] += enlarged shapes
 void launchStage4(hipStream_t st, s2amdBody* bodies, int bodyCapacity, s2amdShape* shapes, int shapeCapacity, float* origins, int* summary);
 // stage 1 on resident arrays: new pairs sorted by (A, B) into the host array outPairs; dJointed: sorted (min body << 32 | max body) keys

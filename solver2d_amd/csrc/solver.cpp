@@ -144,7 +144,7 @@ void s2amd_destroy(s2amdSolver* s)
 					  &s->dAdjOffsets,	&s->dAdjList,	  &s->dAdjHeavy,	  &s->dGatherIndex,	 &s->dOps,			 &s->dGroups.buf,	&s->dContactTail.buf,
 					  &s->dJointTail.buf, &s->dMsg,			  &s->dStripA.buf,	 &s->dStripB.buf,	 &s->dStripLean,	&s->dPersist,
 					  &s->dGranules,	&s->dPersistOps,	  &s->dShapes,		 &s->dPairs,		 &s->dOrigins,		&s->dStatus,
-					  &s->dPointBytes,	&s->dWorldSummary, &s->dJointedKeys,	 &s->dContactStage, &s->dPairScratch,	  &s->dPairKeys};
+					  &s->dPointBytes,	&s->dWorldSummary, &s->dJointedKeys,	 &s->dContactStage, &s->dPairScratch,	  &s->dPairKeys,		 &s->dPatches,		 &s->dScanTmp};
 	for (DevBuf* b : bufs)
 	{
 		b->release();
@@ -156,6 +156,10 @@ void s2amd_destroy(s2amdSolver* s)
 	if (s->hostWorldSummary)
 	{
 		(void)hipHostFree(s->hostWorldSummary);
+	}
+	if (s->hostPatches)
+	{
+		(void)hipHostFree(s->hostPatches);
 	}
 	if (s->hostTimes)
 	{
@@ -397,7 +401,7 @@ int s2amd_get_contact_order(s2amdSolver* s, int32_t* order, int32_t orderCapacit
 	{
 		for (; k < (size_t)cs.colorOffsets[c + 1]; ++k)
 		{
-			if (s->hContactPoints[(size_t)cs.order[k]] > 0)
+			if (cs.order[k] >= 0 && s->hContactPoints[(size_t)cs.order[k]] > 0) // (-1: a free position of the slack layout)
 			{
 				active.push_back(cs.order[k]);
 			}
@@ -626,10 +630,11 @@ int s2amd_measure_dominant(s2amdSolver* s, const s2amdStepParams* params, int32_
 	}
 	if (constraintsPerLaunch)
 	{
-		*constraintsPerLaunch = global		 ? s->contacts.globalCount / std::max(launches / repeats, 1)
-								: persistent ? s->contacts.stripCount * plan.solveSweeps // constraint-sweeps of the whole-step launch
-								: strips	 ? s->contacts.stripCount / std::max(launches / repeats, 1)
-											 : s->cv.count;
+		// (constraints that are swept: the potential ones without manifold points and the slack positions do not count)
+		*constraintsPerLaunch = global		 ? s->activeContacts / std::max(launches / repeats, 1)
+								: persistent ? std::min(s->contacts.stripCount, s->activeContacts) * plan.solveSweeps // constraint-sweeps of the whole-step launch
+								: strips	 ? std::min(s->contacts.stripCount, s->activeContacts) / std::max(launches / repeats, 1)
+											 : s->activeContacts;
 	}
 	return S2AMD_OK;
 }
@@ -719,6 +724,11 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	{
 		s->stripsRejected = false;
 		s->optStripsAnySolver = value != 0;
+		s->structureDirty = true;
+	}
+	else if (strcmp(key, "incremental") == 0)
+	{
+		s->optIncremental = value != 0;
 		s->structureDirty = true;
 	}
 	else if (strcmp(key, "strip_lean") == 0)

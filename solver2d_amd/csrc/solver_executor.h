@@ -185,7 +185,7 @@ struct Executor
 				}
 				return;
 			case OP_JACOBI_APPLY:
-				launchJacobiApply(st, s->bv, s->cv, (const int*)s->dAdjOffsets.p, (const int*)s->dAdjList.p, (const int*)s->dAdjHeavy.p, s->adjHeavyCount);
+				launchJacobiApply(st, s->bv, s->cv, (const int2*)s->dAdjOffsets.p, (const int*)s->dAdjList.p, (const int*)s->dAdjHeavy.p, s->adjHeavyCapacity);
 				count();
 				return;
 			case OP_JOINT_SWEEP:
@@ -596,8 +596,8 @@ struct Executor
 					}
 					if (w < n && p.ops[(size_t)w].code == OP_WARM)
 					{
-						launchWarmStartBodies(st, p.ops[(size_t)w].kind, s->cv, s->bv, (const int*)s->dAdjOffsets.p, (const int*)s->dAdjList.p,
-											  o.code == OP_INTEGRATE_VEL ? 1 : 0, (const int*)s->dAdjHeavy.p, s->adjHeavyCount);
+						launchWarmStartBodies(st, p.ops[(size_t)w].kind, s->cv, s->bv, (const int2*)s->dAdjOffsets.p, (const int*)s->dAdjList.p,
+											  o.code == OP_INTEGRATE_VEL ? 1 : 0, (const int*)s->dAdjHeavy.p, s->adjHeavyCapacity);
 						count();
 						for (int d = i; d <= w; ++d)
 						{

@@ -1,0 +1,354 @@
+// Incremental updates of the constraint-graph structure: a created contact gets a place in the existing sweep order
+// instead of a rebuild (IncrementalGlobal in solver_internal.h says what is kept and why the launch sequence survives).
+//
+// The reference creates and destroys contacts every step (src/world.c:125-168 -> src/contact.c:137-229).  Destruction
+// never touches the structure here (the entry lingers as a no-op until the next rebuild); this file handles creation:
+// for a new contact between bodies a and b of the GLOBAL part
+//   * colour = the lowest parallel colour batch that is unused on both writable bodies AND still has a free position;
+//   * position = the lowest free position of that batch (its contactIndex goes from -1 to the contact's pool slot);
+//   * its two entries (k << 1 | side) are inserted into the bodies' incidence lists at their place in sweep order, so the
+//     body-centric warm start and the Jacobi apply keep adding in sweep order.
+// The result is a proper colouring and a valid sweep order like any other: the oracle sweeps in it (parity link L2).
+#include "solver_internal.h"
+
+#include <unordered_map>
+
+namespace
+{
+
+struct Patcher
+{
+	s2amdSolver* s;
+	IncrementalGlobal& inc;
+	void word(const void* base, size_t index, uint32_t value)
+	{
+		unsigned long long addr = (unsigned long long)(uintptr_t)base + 4ull * index;
+		inc.patches.push_back(make_uint4((unsigned int)(addr & 0xffffffffull), (unsigned int)(addr >> 32), value, 0u));
+	}
+	void range(int body) // adjRange[body] -> device
+	{
+		word(s->dAdjOffsets.p, 2 * (size_t)body, (uint32_t)inc.adjRange[(size_t)body].x);
+		word(s->dAdjOffsets.p, 2 * (size_t)body + 1, (uint32_t)inc.adjRange[(size_t)body].y);
+	}
+	void listEntry(int e) { word(s->dAdjList.p, (size_t)e, (uint32_t)inc.adjList[(size_t)e]); }
+	void heavyEntry(int i) { word(s->dAdjHeavy.p, (size_t)i, (uint32_t)inc.heavy[(size_t)i]); }
+};
+
+bool writable(const s2amdSolver* s, int body)
+{
+	return (s->hBodyFlags[(size_t)body] & (s->inc.solverClass == 1 ? S2F_WRITE_POS : S2F_WRITE_VEL)) != 0;
+}
+
+void heavyRemove(Patcher& p, int body)
+{
+	IncrementalGlobal& inc = p.inc;
+	const int n = inc.heavy[0];
+	for (int i = 1; i <= n; ++i)
+	{
+		if (inc.heavy[(size_t)i] == body)
+		{
+			inc.heavy[(size_t)i] = inc.heavy[(size_t)n];
+			inc.heavy[0] = n - 1;
+			p.heavyEntry(i);
+			p.heavyEntry(0);
+			return;
+		}
+	}
+}
+
+bool adjInsert(Patcher& p, int body, int key)
+{
+	IncrementalGlobal& inc = p.inc;
+	int2& r = inc.adjRange[(size_t)body];
+	if (r.y == inc.adjCapacity[(size_t)body])
+	{
+		// the list outgrew its slack: it moves to the end of the array with twice the room
+		const int cap = std::max(8, 2 * inc.adjCapacity[(size_t)body]);
+		if ((size_t)inc.adjUsed + (size_t)cap > inc.adjList.size())
+		{
+			return false;
+		}
+		for (int i = 0; i < r.y; ++i)
+		{
+			inc.adjList[(size_t)(inc.adjUsed + i)] = inc.adjList[(size_t)(r.x + i)];
+			p.listEntry(inc.adjUsed + i);
+		}
+		r.x = inc.adjUsed;
+		inc.adjCapacity[(size_t)body] = cap;
+		inc.adjUsed += cap;
+	}
+	int at = r.y;
+	while (at > 0 && inc.adjList[(size_t)(r.x + at - 1)] > key)
+	{
+		inc.adjList[(size_t)(r.x + at)] = inc.adjList[(size_t)(r.x + at - 1)];
+		p.listEntry(r.x + at);
+		at -= 1;
+	}
+	inc.adjList[(size_t)(r.x + at)] = key;
+	p.listEntry(r.x + at);
+	r.y += 1;
+	p.range(body);
+	if (r.y == S2_HEAVY_DEGREE + 1)
+	{
+		// from here on a whole wave walks this body's list (warmStartBodiesKernel, jacobiApplyKernel)
+		const int n = inc.heavy[0];
+		if (n + 1 >= (int)inc.heavy.size())
+		{
+			return false;
+		}
+		inc.heavy[(size_t)n + 1] = body;
+		inc.heavy[0] = n + 1;
+		p.heavyEntry(n + 1);
+		p.heavyEntry(0);
+	}
+	return true;
+}
+
+void adjRemove(Patcher& p, int body, int key)
+{
+	IncrementalGlobal& inc = p.inc;
+	int2& r = inc.adjRange[(size_t)body];
+	int at = 0;
+	while (at < r.y && inc.adjList[(size_t)(r.x + at)] != key)
+	{
+		at += 1;
+	}
+	if (at == r.y)
+	{
+		return;
+	}
+	for (int i = at; i + 1 < r.y; ++i)
+	{
+		inc.adjList[(size_t)(r.x + i)] = inc.adjList[(size_t)(r.x + i + 1)];
+		p.listEntry(r.x + i);
+	}
+	r.y -= 1;
+	p.range(body);
+	if (r.y == S2_HEAVY_DEGREE)
+	{
+		heavyRemove(p, body); // back to the one-thread walk: both paths must never take the same body
+	}
+}
+
+} // namespace
+
+// the entry of `slot` leaves the structure; false: it cannot (not in a parallel batch of the global part)
+static bool removeEntry(s2amdSolver* s, Patcher& p, int slot)
+{
+	IncrementalGlobal& inc = s->inc;
+	const int W = 4;
+	const int kOld = inc.positionOfSlot[(size_t)slot];
+	if (kOld < 0)
+	{
+		return kOld == -1; // -1: no entry (nothing to do); -2: it lives in an LDS group or a strip
+	}
+	const int bi = inc.colorOfPosition[(size_t)kOld];
+	if (bi < 0)
+	{
+		return false; // in the sequential tail
+	}
+	const int cid = inc.colorIdOfBatch[(size_t)bi];
+	const int oa = s->hContactA[(size_t)slot], ob = s->hContactB[(size_t)slot]; // the endpoints the structure knows
+	for (int side = 0; side < 2; ++side)
+	{
+		const int body = side == 0 ? oa : ob;
+		if (body >= 0 && body < (int)s->hBodyFlags.size() && writable(s, body))
+		{
+			if (cid < 64 * W && !inc.ignoreColours)
+			{
+				inc.colorBits[(size_t)body * W + (size_t)(cid / 64)] &= ~(1ull << (cid % 64));
+			}
+			adjRemove(p, body, (kOld << 1) | side);
+		}
+	}
+	s->contacts.order[(size_t)kOld] = -1;
+	p.word(s->dContactIndex.p, (size_t)kOld, (uint32_t)-1);
+	std::vector<int>& fp = inc.freePositions[(size_t)bi];
+	fp.insert(std::upper_bound(fp.begin(), fp.end(), kOld, std::greater<int>()), kOld); // stays descending
+	inc.positionOfSlot[(size_t)slot] = -1;
+	inc.removed += 1;
+	s->slackPositions += 1;
+	return true;
+}
+
+void incrementalRemove(s2amdSolver* s, const int32_t* slots, int count)
+{
+	IncrementalGlobal& inc = s->inc;
+	if (!inc.valid || s->structureDirty || s->optIncremental == 0)
+	{
+		return;
+	}
+	Patcher p{s, inc};
+	for (int i = 0; i < count; ++i)
+	{
+		const int slot = slots[i];
+		if (slot >= 0 && slot < (int)inc.positionOfSlot.size() && s->hContactEdge[(size_t)slot] && removeEntry(s, p, slot))
+		{
+			s->hContactEdge[(size_t)slot] = 0; // gone from the structure (else: it lingers, hContactDead says so)
+			s->hContactDead[(size_t)slot] = 0;
+		}
+	}
+}
+
+bool incrementalApply(s2amdSolver* s, const std::vector<ContactChange>& changes)
+{
+	IncrementalGlobal& inc = s->inc;
+	if (!inc.valid || s->structureDirty || s->optIncremental == 0)
+	{
+		return false;
+	}
+	auto giveUp = [&]() {
+		// nothing has reached the device; the host mirrors are rebuilt with the structure
+		inc.valid = false;
+		inc.patches.clear();
+		inc.fallbacks += 1;
+		return false;
+	};
+	Patcher p{s, inc};
+	SweepSet& cs = s->contacts;
+	const int W = 4;
+	for (const ContactChange& ch : changes)
+	{
+		if (ch.slot < 0 || ch.slot >= (int)inc.positionOfSlot.size())
+		{
+			return giveUp();
+		}
+		// ---- the slot's previous entry (a destroyed contact whose entry lingered) gives its place back ----
+		if (!removeEntry(s, p, ch.slot))
+		{
+			return giveUp();
+		}
+		if (ch.a < 0)
+		{
+			continue;
+		}
+		// ---- the new contact ----
+		const int nb = (int)s->hBodyFlags.size();
+		if (ch.a >= nb || ch.b < 0 || ch.b >= nb || ch.a == ch.b || s->hBodyFlagsFinal.size() != (size_t)nb)
+		{
+			return giveUp();
+		}
+		if ((s->hBodyFlagsFinal[(size_t)ch.a] & S2F_IN_GROUP) != 0 || (s->hBodyFlagsFinal[(size_t)ch.b] & S2F_IN_GROUP) != 0)
+		{
+			return giveUp(); // an LDS group or a strip owns the body: its tables are not placeable into
+		}
+		const bool wa = writable(s, ch.a), wb = writable(s, ch.b);
+		int chosen = -1;
+		for (int bi = 0; bi < inc.parallelBatches; ++bi)
+		{
+			if (inc.freePositions[(size_t)bi].empty())
+			{
+				continue;
+			}
+			const int cid = inc.colorIdOfBatch[(size_t)bi];
+			if (inc.ignoreColours)
+			{
+				chosen = bi;
+				inc.colourFreePlaced = true;
+				break;
+			}
+			if (cid >= 64 * W)
+			{
+				continue;
+			}
+			const uint64_t used = (wa ? inc.colorBits[(size_t)ch.a * W + (size_t)(cid / 64)] : 0) | (wb ? inc.colorBits[(size_t)ch.b * W + (size_t)(cid / 64)] : 0);
+			if (((used >> (cid % 64)) & 1ull) == 0)
+			{
+				chosen = bi;
+				break;
+			}
+		}
+		if (chosen < 0)
+		{
+			s->spareColours = 2; // every colour batch is taken on these bodies: the rebuild adds empty ones for the next such contact
+			return giveUp();
+		}
+		const int k = inc.freePositions[(size_t)chosen].back();
+		inc.freePositions[(size_t)chosen].pop_back();
+		if (!inc.ignoreColours)
+		{
+			const int cid = inc.colorIdOfBatch[(size_t)chosen];
+			if (wa)
+			{
+				inc.colorBits[(size_t)ch.a * W + (size_t)(cid / 64)] |= 1ull << (cid % 64);
+			}
+			if (wb)
+			{
+				inc.colorBits[(size_t)ch.b * W + (size_t)(cid / 64)] |= 1ull << (cid % 64);
+			}
+		}
+		cs.order[(size_t)k] = ch.slot;
+		inc.positionOfSlot[(size_t)ch.slot] = k;
+		p.word(s->dContactIndex.p, (size_t)k, (uint32_t)ch.slot);
+		if ((wa && !adjInsert(p, ch.a, (k << 1) | 0)) || (wb && !adjInsert(p, ch.b, (k << 1) | 1)))
+		{
+			return giveUp();
+		}
+		inc.inserted += 1;
+		s->placedTotal += 1;
+		s->slackPositions -= 1;
+	}
+	return true;
+}
+
+int incrementalFlush(s2amdSolver* s)
+{
+	IncrementalGlobal& inc = s->inc;
+	if (inc.patches.empty())
+	{
+		return S2AMD_OK;
+	}
+	{
+		// one thread applies one patch: a word that was written more than once (a list entry that moved and was then shifted,
+		// a range that two insertions touched) must appear once, with its LAST value
+		std::unordered_map<unsigned long long, size_t> last;
+		last.reserve(inc.patches.size() * 2);
+		std::vector<uint4> unique;
+		unique.reserve(inc.patches.size());
+		for (const uint4& q : inc.patches)
+		{
+			const unsigned long long addr = ((unsigned long long)q.y << 32) | q.x;
+			auto it = last.find(addr);
+			if (it == last.end())
+			{
+				last.emplace(addr, unique.size());
+				unique.push_back(q);
+			}
+			else
+			{
+				unique[it->second].z = q.z;
+			}
+		}
+		inc.patches.swap(unique);
+	}
+	const size_t n = inc.patches.size();
+	HIP_TRY(hipSetDevice(s->device));
+	if (n > s->hostPatchCapacity)
+	{
+		// the staging buffer may still be read by a copy enqueued earlier
+		HIP_TRY(hipStreamSynchronize(s->stream));
+		if (s->hostPatches)
+		{
+			(void)hipHostFree(s->hostPatches);
+			s->hostPatches = nullptr;
+		}
+		const size_t cap = std::max<size_t>(2 * n, 4096);
+		HIP_TRY(hipHostMalloc((void**)&s->hostPatches, cap * sizeof(uint4), hipHostMallocDefault));
+		s->hostPatchCapacity = cap;
+	}
+	else
+	{
+		HIP_TRY(hipStreamSynchronize(s->stream)); // (callers are between steps: the stream is idle; this makes the reuse of the staging buffer safe)
+	}
+	int rc = s->dPatches.ensure(std::max<size_t>(s->hostPatchCapacity, n) * sizeof(uint4));
+	if (rc)
+	{
+		return rc;
+	}
+	memcpy(s->hostPatches, inc.patches.data(), n * sizeof(uint4));
+	HIP_TRY(hipMemcpyAsync(s->dPatches.p, s->hostPatches, n * sizeof(uint4), hipMemcpyHostToDevice, s->stream));
+	launchPatchWords(s->stream, s->dPatches.p, (int)n);
+	HIP_TRY(hipGetLastError());
+	inc.patches.clear();
+	return S2AMD_OK;
+}

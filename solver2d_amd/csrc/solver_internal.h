@@ -80,7 +80,7 @@ struct DevBuf
 bool isPositionSolver(int type);
 bool rotIsFixedPoint(float s, float c);
 int colorGraph(const std::vector<int>& ea, const std::vector<int>& eb, const std::vector<uint8_t>& conflict, int bodyCount,
-			   std::vector<int>& color, bool balanced = false);
+			   std::vector<int>& color, bool balanced = false, std::vector<uint64_t>* bitsOut = nullptr);
 void sortByColor(const std::vector<int>& ids, const std::vector<int>& color, int colorCount, std::vector<int>& order, std::vector<int>& offsets);
 bool makeBatches(const std::vector<int>& colorOffsets, std::vector<int>& batchOffsets, bool allowTail = true);
 uint64_t fnv(uint64_t h, const void* data, size_t n);
@@ -144,6 +144,41 @@ struct StepPlan
 	bool usesDq0 = false;
 };
 
+// Host mirror of the GLOBAL part's tables (colour batches over HBM-resident bodies), kept between steps so that a created
+// contact can be given a place in the sweep order WITHOUT rebuilding the structure (solver_incremental.cpp):
+//   * every parallel colour batch is laid out with slack -- free positions whose contactIndex is -1 (an empty record, no
+//     body touched); a new constraint takes a free position of the lowest colour unused on both of its writable bodies;
+//   * the body -> incident constraints lists (body-centric warm start, Jacobi apply) carry per-body slack; an entry is
+//     inserted at its place in sweep order;
+//   * the launch sequence does not change (same batch ranges, same grid sizes): the captured hipGraph stays valid.  The few
+//     words that do change travel as one patch list (address, value) applied by one small kernel.
+// A contact that does not fit (no colour with a free position, a body owned by an LDS group or a strip, list capacity
+// exhausted) falls back to the full rebuild.
+struct IncrementalGlobal
+{
+	bool valid = false;
+	int solverClass = -1;				// colouring class the bits were built for (0 velocity, 1 position)
+	int parallelBatches = 0;			// colour batches that run as one launch each (the sequential tail, if any, comes after); the last
+										// `spare` of them start out empty: colours for bodies whose ordinary colours are all taken
+	bool ignoreColours = false;			// the structure was built for s2Solve_Jacobi: its contact pass writes no body, any free position will do
+	bool colourFreePlaced = false;		// ... and a contact was placed that way: no other solver may run on this structure
+	std::vector<int> colorIdOfBatch;	// bit index of a batch in colorBits (a spare batch gets an id above every colour of the tail)
+	std::vector<int> batchBegin, batchEnd; // position range of every parallel batch, slack included
+	std::vector<std::vector<int>> freePositions; // per batch, descending: pop_back() hands out the lowest free position
+	std::vector<uint64_t> colorBits;	// 4 words per body: colours in use on the body (global part)
+	std::vector<int> positionOfSlot;	// contact slot -> position k in the sweep order, -1
+	std::vector<int> colorOfPosition;	// position -> colour batch (parallel batches only), -1
+	// adjacency mirror
+	std::vector<int2> adjRange;			// {begin, count} per body
+	std::vector<int> adjCapacity;		// per body
+	std::vector<int> adjList;			// device-sized mirror
+	int adjUsed = 0;					// first never-used entry of adjList
+	std::vector<int> heavy;				// [0] = count, then body slots; size = capacity + 1
+	// patch list of the current call: {address lo, address hi, value, 0}
+	std::vector<uint4> patches;
+	long inserted = 0, removed = 0, fallbacks = 0;
+};
+
 struct s2amdSolver
 {
 	int device = 0;
@@ -188,12 +223,24 @@ struct s2amdSolver
 	DevBuf dScanTmp;
 	std::vector<int> hJointType, hJointA, hJointB;
 	std::vector<uint32_t> hBodyFlags; // S2F_WRITE_VEL / S2F_WRITE_POS from the wire bodies
+	std::vector<uint32_t> hBodyFlagsFinal; // ... + S2F_IN_GROUP as the last structure build uploaded them
 	std::vector<uint8_t> hBodyLive, hBodyStatic;
 	DevBuf dBodyFlags;
 
 	// working SoA
 	DevBuf soaBodies, soaContacts, soaJoints, dContactIndex, dJointIndex, dContactLocal, dJointLocal, dAdjOffsets, dAdjList, dAdjHeavy, dOps;
-	int adjHeavyCount = 0; // bodies with more than S2_HEAVY_DEGREE adjacency entries
+	int adjHeavyCapacity = 0; // entries the heavy-body list (more than S2_HEAVY_DEGREE adjacency entries) can hold: sizes the launch
+	IncrementalGlobal inc;
+	uint4* hostPatches = nullptr; // pinned staging of inc.patches
+	size_t hostPatchCapacity = 0;
+	DevBuf dPatches;
+	long placedTotal = 0;	// created contacts placed without a rebuild, since s2amd_create
+	int spareColours = 0;	// empty colour batches a build adds to the global part: 0 until a created contact found every colour of its
+							// bodies taken (a dense pile: a box inside a pyramid uses all six), then 2 -- two more launches per sweep
+	DevBuf dSeparated;		// world chain: the pair slots stage 3 freed this step
+	std::vector<int32_t> hSeparated;
+	int slackPositions = 0; // free positions of the global part's slack layout
+	int optIncremental = 1; // created contacts are placed into the existing structure when they fit (0: always rebuild)
 	BodyView bv{};
 	ContactView cv{};
 	JointView jv{};
@@ -304,6 +351,13 @@ inline void noteGraphChanged(s2amdSolver* s, bool newWorld = false)
 	s->structureDirty = true;
 }
 
+// A created contact was placed into the existing structure (solver_incremental.cpp): nothing is rebuilt, but the graph has
+// not settled either -- the strip structure (milliseconds of host time) keeps waiting as after any change.
+inline void noteGraphTouched(s2amdSolver* s)
+{
+	s->graphAge = 0;
+}
+
 StepConsts makeConsts(const s2amdStepParams* p);
 int carveBodies(s2amdSolver* s, int n); // (re)carves the body SoA family for n slots
 bool stripsAllTwoPoints(const s2amdSolver* s);
@@ -320,5 +374,19 @@ int refreshConstraintIndexOnDevice(s2amdSolver* s);
 int fetchPointCounts(s2amdSolver* s);
 // world chain: which pair slots the device has freed (stage 3 separations) -> hContactDead, before a structure rebuild
 int syncDeadSlots(s2amdSolver* s);
+
+// solver_incremental.cpp
+struct ContactChange
+{
+	int slot, a, b; // a < 0: the slot's old entry is only removed
+};
+// Gives every change a place in the existing structure (removing the slot's previous entry first); false: one of them
+// does not fit -- the caller marks the graph changed (full rebuild; nothing has reached the device).
+bool incrementalApply(s2amdSolver* s, const std::vector<ContactChange>& changes);
+// Destroyed contacts give their place back (colour, position, list entries) where the entry is in the global part's
+// parallel batches; elsewhere (LDS group, strip, sequential tail) the entry lingers as a no-op until the next rebuild.
+void incrementalRemove(s2amdSolver* s, const int32_t* slots, int count);
+// enqueues the patch list built by incrementalApply on the solver's stream
+int incrementalFlush(s2amdSolver* s);
 int doStep(s2amdSolver* s, const s2amdStepParams* params);
 int doDownload(s2amdSolver* s, s2amdBody* bodies, int nb, s2amdContact* contacts, int nc, s2amdJoint* joints, int nj);

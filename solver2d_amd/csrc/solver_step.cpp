@@ -53,53 +53,7 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 	}
 	s->hBodyFlags.swap(flags);
 
-	if ((int)s->hContactA.size() != nc)
-	{
-		s->hContactA.assign(nc, -1);
-		s->hContactB.assign(nc, -1);
-		s->hContactPoints.assign(nc, 0);
-		s->hContactEdge.assign(nc, 0);
-		s->hContactDead.assign(nc, 0);
-	}
-	bool pointCountsMoved = false;
-	int active = 0;
-	for (int i = 0; i < nc; ++i)
-	{
-		const s2amdContact& c = contacts[i];
-		int pc = c.pointCount > 0 ? c.pointCount : 0;
-		pointCountsMoved = pointCountsMoved || s->hContactPoints[i] != pc;
-		const bool valid = c.bodyA >= 0 && c.bodyA < nb && c.bodyB >= 0 && c.bodyB < nb;
-		if (pc > 0 && (!valid || pc > 2))
-		{
-			return fail(S2AMD_E_INVALID, "contact " + std::to_string(i) + " has an invalid body index or point count");
-		}
-		// a potential constraint: the world chain says which pair slots are live; a bare solver input does not, there a slot
-		// without points counts when it names two distinct live bodies (a free pool slot names none)
-		const bool edge = pc > 0 || (pairs ? (pairs[i].shapeA >= 0 && valid)
-										   : (valid && c.bodyA != c.bodyB && bodies[c.bodyA].type != S2AMD_BODY_FREE && bodies[c.bodyB].type != S2AMD_BODY_FREE));
-		s->hContactPoints[i] = pc;
-		active += pc > 0 ? 1 : 0;
-		if (!edge && s->hContactEdge[i] && !newWorld)
-		{
-			// The contact was destroyed (src/contact.c:205-229).  Its entry stays in the structure as a dead constraint
-			// -- pointCount 0 is a no-op -- with the bodies it had, until the slot is used again or the structure is rebuilt
-			// for another reason: the world chain, where pairs separate on the device, learns of a destruction no earlier,
-			// and both routes must sweep in the same order to stay bit-identical (tests/test_gpu_dropin.py).
-			s->hContactDead[i] = 1;
-			continue;
-		}
-		if (!changed && (edge != (s->hContactEdge[i] != 0) || (edge && (s->hContactA[i] != c.bodyA || s->hContactB[i] != c.bodyB))))
-		{
-			changed = true;
-		}
-		s->hContactA[i] = c.bodyA;
-		s->hContactB[i] = c.bodyB;
-		s->hContactEdge[i] = edge ? 1 : 0;
-		s->hContactDead[i] = 0;
-	}
-	s->deadUnknown = false;
-	s->pointsKnown = true;
-	s->activeContacts = active;
+	// joints first: whether the graph changed for a reason other than created contacts decides how those are handled
 	if ((int)s->hJointType.size() != nj)
 	{
 		s->hJointType.assign(nj, S2AMD_JOINT_FREE);
@@ -126,6 +80,94 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 			{
 				return fail(S2AMD_E_INVALID, "joint " + std::to_string(i) + " has an invalid body index");
 			}
+		}
+	}
+
+	if ((int)s->hContactA.size() != nc)
+	{
+		s->hContactA.assign(nc, -1);
+		s->hContactB.assign(nc, -1);
+		s->hContactPoints.assign(nc, 0);
+		s->hContactEdge.assign(nc, 0);
+		s->hContactDead.assign(nc, 0);
+	}
+	bool pointCountsMoved = false;
+	int active = 0;
+	std::vector<ContactChange> created; // contacts that appeared (or whose slot now holds another pair), in pool order
+	std::vector<int32_t> died;			// ... that were destroyed since the last upload
+	for (int i = 0; i < nc; ++i)
+	{
+		const s2amdContact& c = contacts[i];
+		int pc = c.pointCount > 0 ? c.pointCount : 0;
+		pointCountsMoved = pointCountsMoved || s->hContactPoints[i] != pc;
+		const bool valid = c.bodyA >= 0 && c.bodyA < nb && c.bodyB >= 0 && c.bodyB < nb;
+		if (pc > 0 && (!valid || pc > 2))
+		{
+			return fail(S2AMD_E_INVALID, "contact " + std::to_string(i) + " has an invalid body index or point count");
+		}
+		// a potential constraint: the world chain says which pair slots are live; a bare solver input does not, there a slot
+		// without points counts when it names two distinct live bodies (a free pool slot names none)
+		const bool edge = pc > 0 || (pairs ? (pairs[i].shapeA >= 0 && valid)
+										   : (valid && c.bodyA != c.bodyB && bodies[c.bodyA].type != S2AMD_BODY_FREE && bodies[c.bodyB].type != S2AMD_BODY_FREE));
+		s->hContactPoints[i] = pc;
+		active += pc > 0 ? 1 : 0;
+		if (!edge && s->hContactEdge[i] && !newWorld)
+		{
+			// The contact was destroyed (src/contact.c:205-229).  Its entry stays in the structure as a dead constraint
+			// -- pointCount 0 is a no-op -- with the bodies it had, until the slot is used again or the structure is rebuilt
+			// for another reason: the world chain, where pairs separate on the device, learns of a destruction no earlier,
+			// and both routes must sweep in the same order to stay bit-identical (tests/test_gpu_dropin.py).
+			if (!s->hContactDead[i])
+			{
+				died.push_back(i);
+			}
+			s->hContactDead[i] = 1;
+			continue;
+		}
+		if (edge && (!s->hContactEdge[i] || s->hContactA[i] != c.bodyA || s->hContactB[i] != c.bodyB))
+		{
+			created.push_back(ContactChange{i, c.bodyA, c.bodyB}); // (shadows of this slot are written below, after the old entry was found)
+			continue;
+		}
+		if (!edge && s->hContactEdge[i])
+		{
+			changed = true; // (newWorld)
+		}
+		s->hContactEdge[i] = edge ? 1 : 0;
+		s->hContactDead[i] = 0;
+	}
+	s->deadUnknown = false;
+	s->pointsKnown = true;
+	s->activeContacts = active;
+	if (!created.empty())
+	{
+		// created contacts: a place in the existing structure when that is all that happened and they fit, else a rebuild
+		const bool placed = !changed && incrementalApply(s, created);
+		for (const ContactChange& ch : created)
+		{
+			s->hContactA[(size_t)ch.slot] = ch.a;
+			s->hContactB[(size_t)ch.slot] = ch.b;
+			s->hContactEdge[(size_t)ch.slot] = 1;
+			s->hContactDead[(size_t)ch.slot] = 0;
+		}
+		if (placed)
+		{
+			noteGraphTouched(s);
+		}
+		else
+		{
+			changed = true;
+		}
+	}
+	if (!changed)
+	{
+		// Destroyed contacts give their places back AFTER this step's created ones were placed: the world chain learns of the
+		// pairs its stage 3 separates only after the step they separate in, and both routes must build the same structure.
+		incrementalRemove(s, died.data(), (int)died.size());
+		int rcFlush = incrementalFlush(s);
+		if (rcFlush)
+		{
+			return rcFlush;
 		}
 	}
 	if (!changed && pointCountsMoved && s->persistValid)
@@ -417,6 +459,9 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 		s->stats.persistent = (s->dStripA.view.groupCount > 0 && q.persistPlan(kind, warm)) ? 1 : 0;
 	}
 	s->stats.persistFallbacks = s->persistFallbacks;
+	s->stats.structureBuilds = (int32_t)s->structureGeneration;
+	s->stats.placedContacts = (int32_t)s->placedTotal;
+	s->stats.potentialConstraints = (int32_t)(s->contacts.order.size() - (size_t)s->slackPositions);
 	if (!async && s->hostError && *s->hostError != 0u)
 	{
 		// The persistent kernel's workgroups were not all resident (something else occupies the GPU).  Its epilogue saw

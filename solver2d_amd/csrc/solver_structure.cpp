@@ -5,6 +5,8 @@
 namespace
 {
 
+constexpr int ColorBitsWords = 4; // graph_coloring.cpp: ColorMasks::WORDS
+
 // SoA carving: one device allocation per family, arrays laid end to end at 256-byte boundaries.
 // The element capacity only grows (x1.5), so device pointers -- and a captured hipGraph -- stay
 // valid until a family actually has to grow (layoutGeneration is bumped then).
@@ -188,11 +190,15 @@ struct EdgeList
 
 // Colours one part (the global part or one group), appends its sweep order to `set` and returns its
 // launch batches as ranges of k.  Endpoints are indices into `conflict`.
+// inc != nullptr (the global contact part): every parallel colour batch is laid out with SLACK -- free positions (order -1)
+// behind its constraints -- and the colouring state is kept in *inc, so that created contacts can be placed without a
+// rebuild (IncrementalGlobal, solver_incremental.cpp).  *positions then has -1 at the free positions.
 void colourPart(const std::vector<int>& ids, const std::vector<int>& ea, const std::vector<int>& eb, const std::vector<uint8_t>& conflict,
-				int bodyCount, SweepSet& set, std::vector<int>& batchOffsetsOut, bool& hasTailOut, std::vector<int>* positions, bool balanced = false)
+				int bodyCount, SweepSet& set, std::vector<int>& batchOffsetsOut, bool& hasTailOut, std::vector<int>* positions, bool balanced = false,
+				IncrementalGlobal* inc = nullptr, int spareColours = 0)
 {
 	std::vector<int> color, partOrder, partOffsets;
-	int cc = colorGraph(ea, eb, conflict, bodyCount, color, balanced);
+	int cc = colorGraph(ea, eb, conflict, bodyCount, color, balanced, inc ? &inc->colorBits : nullptr);
 	// stable counting sort of positions by colour
 	std::vector<int> pos(ids.size());
 	for (size_t i = 0; i < ids.size(); ++i)
@@ -200,7 +206,72 @@ void colourPart(const std::vector<int>& ids, const std::vector<int>& ea, const s
 		pos[i] = (int)i;
 	}
 	sortByColor(pos, color, cc, partOrder, partOffsets);
+	std::vector<int> rel;
+	hasTailOut = makeBatches(partOffsets, rel, !balanced);
 	int base = (int)set.order.size();
+	if (set.colorOffsets.empty())
+	{
+		set.colorOffsets.push_back(0);
+	}
+	if (inc)
+	{
+		// parallel batch i == colour i (makeBatches: one launch per colour below the tail)
+		const int parallel = (int)rel.size() - 1 - (hasTailOut ? 1 : 0);
+		// ... followed by `spare` EMPTY batches: colours for the contacts of bodies that have every ordinary colour taken (a box
+		// inside a pyramid uses all six).  Their bit ids lie above the tail's colours, whose bits the bodies may carry.
+		const int spare = std::max(0, std::min(spareColours, 64 * ColorBitsWords - cc));
+		const int batches = parallel + spare;
+		inc->parallelBatches = batches;
+		inc->batchBegin.assign((size_t)batches, 0), inc->batchEnd.assign((size_t)batches, 0);
+		inc->freePositions.assign((size_t)batches, {});
+		inc->colorIdOfBatch.assign((size_t)batches, 0);
+		inc->colorOfPosition.clear();
+		std::vector<int> laidOut; // partOrder with the free positions (-1)
+		batchOffsetsOut.clear();
+		for (int bi = 0; bi < batches; ++bi)
+		{
+			const int n = bi < parallel ? partOffsets[(size_t)bi + 1] - partOffsets[bi] : 0;
+			const int cap = bi < parallel ? ((n + std::max(32, n / 8)) + 31) & ~31 : 64;
+			const int begin = (int)laidOut.size();
+			batchOffsetsOut.push_back(base + begin);
+			inc->batchBegin[(size_t)bi] = base + begin, inc->batchEnd[(size_t)bi] = base + begin + cap;
+			inc->colorIdOfBatch[(size_t)bi] = bi < parallel ? bi : cc + (bi - parallel);
+			if (n > 0)
+			{
+				laidOut.insert(laidOut.end(), partOrder.begin() + partOffsets[bi], partOrder.begin() + partOffsets[(size_t)bi + 1]);
+			}
+			laidOut.resize((size_t)begin + cap, -1);
+			for (int k = begin + cap - 1; k >= begin + n; --k)
+			{
+				inc->freePositions[(size_t)bi].push_back(base + k); // descending: pop_back() = the lowest
+			}
+			inc->colorOfPosition.resize((size_t)base + begin + cap, bi);
+			set.colorOffsets.push_back(base + begin + cap);
+		}
+		batchOffsetsOut.push_back(base + (int)laidOut.size());
+		for (int c = parallel; c < cc; ++c) // the sequential tail: colour by colour, no slack
+		{
+			laidOut.insert(laidOut.end(), partOrder.begin() + partOffsets[c], partOrder.begin() + partOffsets[(size_t)c + 1]);
+			if (partOffsets[(size_t)c + 1] > partOffsets[c])
+			{
+				set.colorOffsets.push_back(base + (int)laidOut.size());
+			}
+		}
+		if (hasTailOut)
+		{
+			batchOffsetsOut.push_back(base + (int)laidOut.size());
+		}
+		inc->colorOfPosition.resize((size_t)base + laidOut.size(), -1);
+		for (int p : laidOut)
+		{
+			set.order.push_back(p >= 0 ? ids[(size_t)p] : -1);
+		}
+		if (positions)
+		{
+			*positions = laidOut;
+		}
+		return;
+	}
 	for (int p : partOrder)
 	{
 		set.order.push_back(ids[p]);
@@ -211,17 +282,11 @@ void colourPart(const std::vector<int>& ids, const std::vector<int>& ea, const s
 	}
 	for (int c = 0; c < cc; ++c)
 	{
-		if (set.colorOffsets.empty())
-		{
-			set.colorOffsets.push_back(0);
-		}
 		if (partOffsets[(size_t)c + 1] > partOffsets[c])
 		{
 			set.colorOffsets.push_back(base + partOffsets[(size_t)c + 1]);
 		}
 	}
-	std::vector<int> rel;
-	hasTailOut = makeBatches(partOffsets, rel, !balanced);
 	batchOffsetsOut.clear();
 	for (int r : rel)
 	{
@@ -615,65 +680,75 @@ static int buildMessageTables(s2amdSolver* s, int nb)
 }
 
 // body -> incident constraints of the global part (Jacobi apply, body-centric warm start) with the heavy-body list.
+// Ranges {begin, count} with per-body slack and a list with room at its end, mirrored on the host (IncrementalGlobal) so
+// that a created contact's two entries can be inserted in place.
 static int buildAdjacency(s2amdSolver* s, const std::vector<uint8_t>& conflict, int nb)
 {
 	const SweepSet& cs = s->contacts;
+	IncrementalGlobal& inc = s->inc;
 	int rc = 0;
 	bool grew = false;
 	// body -> incident constraints in SWEEP order (ascending k), key = k<<1 | side, so the per-body
 	// sums of jacobiApplyKernel add in exactly the order a sequential pass in sweep order would;
 	// read-only shareable bodies are skipped (their deltas are exact zeros)
-	std::vector<int> offsets((size_t)nb + 1, 0), list;
+	std::vector<int> count((size_t)nb, 0);
 	const int GC = cs.globalCount; // LDS groups walk their own colours; only the global part is indexed
 	for (int k = 0; k < GC; ++k)
 	{
-		int a = s->hContactA[cs.order[k]], b = s->hContactB[cs.order[k]];
-		if (conflict[a])
+		if (cs.order[(size_t)k] < 0)
 		{
-			offsets[(size_t)a + 1] += 1;
+			continue;
 		}
-		if (conflict[b])
-		{
-			offsets[(size_t)b + 1] += 1;
-		}
+		int a = s->hContactA[cs.order[(size_t)k]], b = s->hContactB[cs.order[(size_t)k]];
+		count[(size_t)a] += conflict[a] ? 1 : 0;
+		count[(size_t)b] += conflict[b] ? 1 : 0;
 	}
+	inc.adjRange.assign((size_t)nb, make_int2(0, 0));
+	inc.adjCapacity.assign((size_t)nb, 0);
+	int total = 0;
 	for (int i = 0; i < nb; ++i)
 	{
-		offsets[(size_t)i + 1] += offsets[i];
+		const int cap = s->hBodyLive[(size_t)i] && conflict[(size_t)i] ? ((count[(size_t)i] + std::max(4, count[(size_t)i] / 4) + 3) & ~3) : 0;
+		inc.adjRange[(size_t)i] = make_int2(total, 0);
+		inc.adjCapacity[(size_t)i] = cap;
+		total += cap;
 	}
-	list.resize((size_t)offsets[nb]);
-	std::vector<int> cursor(offsets.begin(), offsets.end() - 1);
+	inc.adjUsed = total;
+	inc.adjList.assign((size_t)total + (size_t)std::max(1024, total / 4), 0); // room for lists that outgrow their slack and move to the end
 	for (int k = 0; k < GC; ++k)
 	{
-		int a = s->hContactA[cs.order[k]], b = s->hContactB[cs.order[k]];
+		if (cs.order[(size_t)k] < 0)
+		{
+			continue;
+		}
+		int a = s->hContactA[cs.order[(size_t)k]], b = s->hContactB[cs.order[(size_t)k]];
 		if (conflict[a])
 		{
-			list[(size_t)cursor[a]++] = (k << 1) | 0;
+			int2& r = inc.adjRange[(size_t)a];
+			inc.adjList[(size_t)(r.x + r.y++)] = (k << 1) | 0;
 		}
 		if (conflict[b])
 		{
-			list[(size_t)cursor[b]++] = (k << 1) | 1;
+			int2& r = inc.adjRange[(size_t)b];
+			inc.adjList[(size_t)(r.x + r.y++)] = (k << 1) | 1;
 		}
 	}
-	grew = false;
-	if ((rc = s->dAdjOffsets.ensure(((size_t)nb + 1) * sizeof(int), &grew)) != 0 ||
-		(rc = s->dAdjList.ensure(std::max<size_t>(list.size(), 1) * sizeof(int), &grew)) != 0)
-	{
-		return rc;
-	}
-	if (grew)
-	{
-		s->layoutGeneration += 1;
-	}
-	std::vector<int> heavy;
+	std::vector<int> heavyBodies;
 	for (int i = 0; i < nb; ++i)
 	{
-		if (offsets[(size_t)i + 1] - offsets[(size_t)i] > S2_HEAVY_DEGREE)
+		if (inc.adjRange[(size_t)i].y > S2_HEAVY_DEGREE)
 		{
-			heavy.push_back(i);
+			heavyBodies.push_back(i);
 		}
 	}
-	if ((rc = s->dAdjHeavy.ensure(std::max<size_t>(heavy.size(), 64) * sizeof(int), &grew)) != 0)
+	const int heavyCap = (((int)heavyBodies.size() + 16) + 15) & ~15;
+	inc.heavy.assign((size_t)heavyCap + 1, 0);
+	inc.heavy[0] = (int)heavyBodies.size();
+	std::copy(heavyBodies.begin(), heavyBodies.end(), inc.heavy.begin() + 1);
+	grew = false;
+	if ((rc = s->dAdjOffsets.ensure(std::max<size_t>((size_t)nb, 1) * sizeof(int2), &grew)) != 0 ||
+		(rc = s->dAdjList.ensure(std::max<size_t>(inc.adjList.size(), 1) * sizeof(int), &grew)) != 0 ||
+		(rc = s->dAdjHeavy.ensure(inc.heavy.size() * sizeof(int), &grew)) != 0)
 	{
 		return rc;
 	}
@@ -681,15 +756,17 @@ static int buildAdjacency(s2amdSolver* s, const std::vector<uint8_t>& conflict, 
 	{
 		s->layoutGeneration += 1;
 	}
-	s->adjHeavyCount = (int)heavy.size();
-	if (!heavy.empty())
+	// the list's capacity is the device buffer's (DevBuf grows by half: the mirror follows, so relocations can use it all)
+	inc.adjList.resize(s->dAdjList.bytes / sizeof(int), 0);
+	s->adjHeavyCapacity = heavyCap;
+	HIP_TRY(hipMemcpyAsync(s->dAdjHeavy.p, inc.heavy.data(), inc.heavy.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+	if (nb > 0)
 	{
-		HIP_TRY(hipMemcpyAsync(s->dAdjHeavy.p, heavy.data(), heavy.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+		HIP_TRY(hipMemcpyAsync(s->dAdjOffsets.p, inc.adjRange.data(), (size_t)nb * sizeof(int2), hipMemcpyHostToDevice, s->stream));
 	}
-	HIP_TRY(hipMemcpyAsync(s->dAdjOffsets.p, offsets.data(), ((size_t)nb + 1) * sizeof(int), hipMemcpyHostToDevice, s->stream));
-	if (!list.empty())
+	if (inc.adjUsed > 0)
 	{
-		HIP_TRY(hipMemcpyAsync(s->dAdjList.p, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+		HIP_TRY(hipMemcpyAsync(s->dAdjList.p, inc.adjList.data(), (size_t)inc.adjUsed * sizeof(int), hipMemcpyHostToDevice, s->stream));
 	}
 	s->adjValid = true;
 	return S2AMD_OK;
@@ -1146,7 +1223,9 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 	const bool wantStrips = grouped && s->optStrips != 0 && !s->stripsRejected && s->graphAge >= s->stripPatienceNow &&
 							(s->optStripsAnySolver != 0 || solverType == s2amd_solverTGS_Soft || solverType == s2amd_solverSoftStep ||
 							 solverType == s2amd_solverPGS_Soft);
-	if (!s->structureDirty && cls == s->orderSolverClass && grouped == s->orderGrouped && wantStrips == s->orderStrips && s->adjValid)
+	// (contacts placed into a structure built for s2Solve_Jacobi took any free position, whatever its colour: only Jacobi can run on that)
+	const bool colourFree = s->inc.colourFreePlaced && !needAdj;
+	if (!s->structureDirty && cls == s->orderSolverClass && grouped == s->orderGrouped && wantStrips == s->orderStrips && s->adjValid && !colourFree)
 	{
 		return S2AMD_OK;
 	}
@@ -1530,9 +1609,24 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 	{
 		std::vector<int> ids, a, b, pos;
 		gather(ce, cOf[0], ids, a, b);
-		colourPart(ids, a, b, conflict, nb, cs, cs.batchOffsets, cs.hasTail, &pos);
-		cs.globalCount = (int)ids.size();
+		s->inc = IncrementalGlobal();
+		const bool slack = s->optIncremental != 0 && s->optMessage == 0;
+		s->inc.ignoreColours = needAdj;
+		colourPart(ids, a, b, conflict, nb, cs, cs.batchOffsets, cs.hasTail, &pos, false, slack ? &s->inc : nullptr, needAdj ? 0 : s->spareColours);
+		cs.globalCount = (int)cs.order.size(); // (with the free positions of the slack layout)
 		cs.local.assign((size_t)cs.globalCount, make_int2(0, 0));
+		if (slack)
+		{
+			s->inc.solverClass = cls;
+			s->inc.positionOfSlot.assign((size_t)s->contactCapacity, -1);
+			for (int k = 0; k < cs.globalCount; ++k)
+			{
+				if (cs.order[(size_t)k] >= 0)
+				{
+					s->inc.positionOfSlot[(size_t)cs.order[(size_t)k]] = k;
+				}
+			}
+		}
 		if (cs.hasTail)
 		{
 			HostGroupTable& t = s->hContactTail;
@@ -1701,6 +1795,14 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 		js.seamCount = (int)js.order.size() - stripInteriorJ;
 	}
 
+	if (!s->inc.positionOfSlot.empty())
+	{
+		for (size_t k = (size_t)cs.globalCount; k < cs.order.size(); ++k)
+		{
+			s->inc.positionOfSlot[(size_t)cs.order[k]] = -2; // lives in an LDS group or a strip: only a rebuild can move it
+		}
+	}
+	s->hBodyFlagsFinal = flags;
 	s->looseBodies = 0;
 	for (int i = 0; i < nb; ++i)
 	{
@@ -1713,14 +1815,15 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 	phase("colours, batches");
 	// ---- device tables ----
 	int rc;
-	if ((rc = carveContacts(s, C)) != 0 || (rc = carveJoints(s, J)) != 0)
+	const int CP = (int)cs.order.size(); // positions of the sweep order: the C potential constraints + the global part's free positions
+	if ((rc = carveContacts(s, CP)) != 0 || (rc = carveJoints(s, J)) != 0)
 	{
 		return rc;
 	}
 	bool grew = false;
-	if ((rc = s->dContactIndex.ensure((size_t)std::max(C, 1) * sizeof(int), &grew)) != 0 ||
+	if ((rc = s->dContactIndex.ensure((size_t)std::max(CP, 1) * sizeof(int), &grew)) != 0 ||
 		(rc = s->dJointIndex.ensure((size_t)std::max(J, 1) * sizeof(int), &grew)) != 0 ||
-		(rc = s->dContactLocal.ensure((size_t)std::max(C, 1) * sizeof(int2), &grew)) != 0 ||
+		(rc = s->dContactLocal.ensure((size_t)std::max(CP, 1) * sizeof(int2), &grew)) != 0 ||
 		(rc = s->dJointLocal.ensure((size_t)std::max(J, 1) * sizeof(int2), &grew)) != 0)
 	{
 		return rc;
@@ -1729,10 +1832,10 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 	{
 		s->layoutGeneration += 1;
 	}
-	if (C > 0)
+	if (CP > 0)
 	{
-		HIP_TRY(hipMemcpyAsync(s->dContactIndex.p, cs.order.data(), (size_t)C * sizeof(int), hipMemcpyHostToDevice, s->stream));
-		HIP_TRY(hipMemcpyAsync(s->dContactLocal.p, cs.local.data(), (size_t)C * sizeof(int2), hipMemcpyHostToDevice, s->stream));
+		HIP_TRY(hipMemcpyAsync(s->dContactIndex.p, cs.order.data(), (size_t)CP * sizeof(int), hipMemcpyHostToDevice, s->stream));
+		HIP_TRY(hipMemcpyAsync(s->dContactLocal.p, cs.local.data(), (size_t)CP * sizeof(int2), hipMemcpyHostToDevice, s->stream));
 	}
 	if (J > 0)
 	{
@@ -1745,7 +1848,7 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 	}
 	s->cv.contactIndex = (int*)s->dContactIndex.p;
 	s->cv.localBodies = (int2*)s->dContactLocal.p;
-	s->cv.count = C;
+	s->cv.count = CP;
 	s->jv.jointIndex = (int*)s->dJointIndex.p;
 	s->jv.localBodies = (int2*)s->dJointLocal.p;
 	s->jv.count = J;
@@ -1806,6 +1909,14 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	phase("adjacency + sync");
 
+	// created contacts can be placed into this structure while its global part has the slack layout
+	s->slackPositions = 0;
+	for (int k = 0; k < cs.globalCount; ++k)
+	{
+		s->slackPositions += cs.order[(size_t)k] < 0 ? 1 : 0;
+	}
+	s->inc.valid = s->optIncremental != 0 && s->inc.solverClass == cls && !s->msgTablesValid && !s->inc.positionOfSlot.empty();
+	s->inc.patches.clear();
 	s->orderSolverClass = cls;
 	s->orderGrouped = grouped;
 	s->orderStrips = wantStrips;

@@ -218,7 +218,8 @@ int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapa
 	const size_t oBytes = (size_t)bodyCapacity * 2 * sizeof(float);
 	if ((rc = s->dShapes.ensure(std::max<size_t>(sBytes, 256))) != 0 || (rc = s->dPairs.ensure(std::max<size_t>(pBytes, 256))) != 0 ||
 		(rc = s->dOrigins.ensure(std::max<size_t>(oBytes, 256))) != 0 || (rc = s->dStatus.ensure(std::max<size_t>((size_t)contactCapacity * 4, 256))) != 0 ||
-		(rc = s->dPointBytes.ensure(std::max<size_t>((size_t)contactCapacity, 256))) != 0 || (rc = s->dWorldSummary.ensure(256)) != 0)
+		(rc = s->dPointBytes.ensure(std::max<size_t>((size_t)contactCapacity, 256))) != 0 || (rc = s->dWorldSummary.ensure(256)) != 0 ||
+		(rc = s->dSeparated.ensure(std::max<size_t>((size_t)contactCapacity * 4, 256))) != 0)
 	{
 		return rc;
 	}
@@ -307,9 +308,10 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 		// (the kernel also destroys separated pairs and accumulates the step's contact counters)
 		launchUpdateContacts(st, (const s2amdBody*)s->dBodies.p, (const float*)s->dOrigins.p, (const s2amdShape*)s->dShapes.p,
 							 (s2amdPairState*)s->dPairs.p, (s2amdContact*)s->dContacts.p, nc, (int32_t*)s->dStatus.p, (uint8_t*)s->dPointBytes.p,
-							 (int*)dSum);
+							 (int*)dSum, (int*)s->dSeparated.p);
 	}
 	s->pointsKnown = false; // the manifolds are the device's now
+	s->hSeparated.clear();
 	const double t1 = nowMs();
 	int rc = S2AMD_OK;
 	int fallbacks = 0;
@@ -348,7 +350,22 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 	if (contactsSeen.separated > 0)
 	{
 		s->pairKeysValid = false; // pair slots were freed on the device
-		s->deadUnknown = true;	  // ... their entries linger in the structure as no-ops until the next rebuild drops them
+		// which ones: the caller needs them for its own s2DestroyContact (s2amd_world_separated), and their entries leave the
+		// structure now where they can (solver_incremental.cpp), as a host that ran stage 3 itself would see them gone from
+		// the arrays of its next upload
+		s->hSeparated.resize((size_t)contactsSeen.separated);
+		HIP_TRY(hipMemcpyAsync(s->hSeparated.data(), s->dSeparated.p, s->hSeparated.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		std::sort(s->hSeparated.begin(), s->hSeparated.end());
+		for (int32_t slot : s->hSeparated)
+		{
+			s->hContactDead[(size_t)slot] = 1;
+		}
+		incrementalRemove(s, s->hSeparated.data(), (int)s->hSeparated.size());
+		if ((rc = incrementalFlush(s)) != 0)
+		{
+			return rc;
+		}
 	}
 	s->activeContacts = contactsSeen.active;
 	s->stats.constraintCount = contactsSeen.active;
@@ -402,6 +419,21 @@ int s2amd_world_find_pairs(s2amdSolver* s, int32_t* outPairs, int32_t pairCapaci
 	return rc;
 }
 
+int s2amd_world_separated(s2amdSolver* s, int32_t* slots, int32_t capacity, int32_t* count)
+{
+	if (!s || !count || capacity < 0 || (capacity > 0 && !slots))
+	{
+		return fail(S2AMD_E_INVALID, "bad argument");
+	}
+	*count = (int32_t)s->hSeparated.size();
+	if (*count > capacity)
+	{
+		return fail(S2AMD_E_CAPACITY, "slot buffer too small");
+	}
+	std::copy(s->hSeparated.begin(), s->hSeparated.end(), slots);
+	return S2AMD_OK;
+}
+
 int s2amd_world_set_contacts(s2amdSolver* s, const int32_t* slots, int32_t count, const s2amdContact* contacts, const s2amdPairState* pairs)
 {
 	if (!s || count < 0 || (count > 0 && (!slots || !contacts || !pairs)))
@@ -453,33 +485,79 @@ int s2amd_world_set_contacts(s2amdSolver* s, const int32_t* slots, int32_t count
 	HIP_TRY(hipStreamSynchronize(st));
 	s->pairKeysValid = false;
 	// host shadows of the constraint graph (solver_step.cpp: refreshShadows): a slot is a potential constraint while its
-	// pair is live, whatever its manifold holds
-	bool changed = false;
+	// pair is live, whatever its manifold holds.  Created contacts get a place in the existing structure when they fit
+	// (solver_incremental.cpp), in pool order like the host-array route; else the structure is rebuilt.
+	std::vector<int> byslot((size_t)count);
 	for (int i = 0; i < count; ++i)
+	{
+		byslot[(size_t)i] = i;
+	}
+	std::sort(byslot.begin(), byslot.end(), [&](int x, int y) { return slots[x] < slots[y]; });
+	std::vector<ContactChange> created;
+	for (int i : byslot)
 	{
 		const int k = slots[i];
 		const s2amdContact& c = contacts[i];
 		const int pc = c.pointCount > 0 ? c.pointCount : 0;
 		const bool edge = pairs[i].shapeA >= 0 || pc > 0;
-		changed = changed || edge != (s->hContactEdge[(size_t)k] != 0) || (edge && (s->hContactA[(size_t)k] != c.bodyA || s->hContactB[(size_t)k] != c.bodyB));
-		s->hContactA[(size_t)k] = c.bodyA;
-		s->hContactB[(size_t)k] = c.bodyB;
-		s->hContactEdge[(size_t)k] = edge ? 1 : 0;
-		s->hContactDead[(size_t)k] = 0;
 		if (s->pointsKnown)
 		{
 			s->activeContacts += (pc > 0 ? 1 : 0) - (s->hContactPoints[(size_t)k] > 0 ? 1 : 0);
 			s->hContactPoints[(size_t)k] = pc;
 			s->hPointBytes[(size_t)k] = (uint8_t)pc;
 		}
+		if (!edge)
+		{
+			if (s->hContactEdge[(size_t)k])
+			{
+				s->hContactDead[(size_t)k] = 1; // the caller's s2DestroyContact: the entry leaves the structure where it can, else lingers as a no-op
+				const int32_t one = k;
+				incrementalRemove(s, &one, 1);
+			}
+			continue;
+		}
+		if (!s->hContactEdge[(size_t)k] || s->hContactA[(size_t)k] != c.bodyA || s->hContactB[(size_t)k] != c.bodyB)
+		{
+			created.push_back(ContactChange{k, c.bodyA, c.bodyB});
+			continue;
+		}
+		s->hContactDead[(size_t)k] = 0; // the same pair again in its old slot
 	}
-	if (changed)
+	if (!created.empty())
 	{
-		noteGraphChanged(s);
+		const bool placed = incrementalApply(s, created);
+		for (const ContactChange& ch : created)
+		{
+			s->hContactA[(size_t)ch.slot] = ch.a;
+			s->hContactB[(size_t)ch.slot] = ch.b;
+			s->hContactEdge[(size_t)ch.slot] = 1;
+			s->hContactDead[(size_t)ch.slot] = 0;
+		}
+		if (placed)
+		{
+			int rcFlush = incrementalFlush(s);
+			if (rcFlush)
+			{
+				return rcFlush;
+			}
+			noteGraphTouched(s);
+		}
+		else
+		{
+			noteGraphChanged(s);
+		}
 	}
-	else if (s->persistValid)
+	else
 	{
-		s->persist.allTwoPoints = stripsAllTwoPoints(s) ? 1 : 0;
+		int rcFlush = incrementalFlush(s); // (removals)
+		if (rcFlush)
+		{
+			return rcFlush;
+		}
+		if (s->persistValid)
+		{
+			s->persist.allTwoPoints = stripsAllTwoPoints(s) ? 1 : 0;
+		}
 	}
 	s->gatherIndexDirty = true;
 	return S2AMD_OK;

@@ -21,7 +21,7 @@ EXPORTS = [
     "s2amd_restore_bodies", "s2amd_get_contact_order", "s2amd_get_joint_order", "s2amd_get_stats",
     "s2amd_set_option", "s2amd_export_poses", "s2amd_export_poses_async", "s2amd_export_wait", "s2amd_measure_dominant", "s2amd_refit_shapes", "s2amd_find_pairs", "s2amd_synchronize", "s2amd_update_contacts", "s2amd_find_islands", "s2amd_color_constraints",
     "s2amd_world_upload", "s2amd_world_step", "s2amd_world_download", "s2amd_world_find_pairs", "s2amd_world_set_contacts",
-    "s2amd_device_alloc", "s2amd_device_free", "s2amd_device_read",
+    "s2amd_device_alloc", "s2amd_device_free", "s2amd_device_read", "s2amd_world_separated",
 ]
 
 _lib = None
@@ -70,6 +70,7 @@ def load():
     L.s2amd_world_step.argtypes = [vp, ctypes.POINTER(wire.StepParams), ctypes.POINTER(wire.WorldStepInfo)]
     L.s2amd_world_find_pairs.argtypes = [vp, vp, i32, ctypes.POINTER(i32)]
     L.s2amd_world_set_contacts.argtypes = [vp, vp, i32, vp, vp]
+    L.s2amd_world_separated.argtypes = [vp, vp, i32, ctypes.POINTER(i32)]
     L.s2amd_world_download.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp]
     L.s2amd_device_alloc.argtypes = [vp, ctypes.c_uint64, ctypes.POINTER(vp)]
     L.s2amd_device_free.argtypes = [vp, vp]
@@ -226,6 +227,17 @@ class Solver:
                 continue
             _check(rc)
             return out[: n.value].copy()
+
+    def world_separated(self, expected=64):
+        """Contact slots the last world_step destroyed (their pairs separated), ascending."""
+        out = np.zeros(max(int(expected), 1), dtype=np.int32)
+        n = ctypes.c_int32()
+        rc = load().s2amd_world_separated(self._h, wire.as_ptr(out), len(out), ctypes.byref(n))
+        if rc == -5:
+            out = np.zeros(n.value, dtype=np.int32)
+            rc = load().s2amd_world_separated(self._h, wire.as_ptr(out), len(out), ctypes.byref(n))
+        _check(rc)
+        return out[: n.value].copy()
 
     def world_set_contacts(self, slots, contacts, pairs):
         slots = np.ascontiguousarray(slots, dtype=np.int32)

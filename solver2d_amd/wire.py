@@ -99,6 +99,7 @@ class StepStats(ctypes.Structure):
         ("graphReplayed", ctypes.c_int32), ("solveLaunches", ctypes.c_int32),
         ("eventPairOverheadMs", ctypes.c_float), ("groupCount", ctypes.c_int32), ("messagePassing", ctypes.c_int32),
         ("stripCount", ctypes.c_int32), ("seamCount", ctypes.c_int32), ("persistent", ctypes.c_int32), ("persistFallbacks", ctypes.c_int32),
+        ("structureBuilds", ctypes.c_int32), ("placedContacts", ctypes.c_int32), ("potentialConstraints", ctypes.c_int32),
     ]
 
 

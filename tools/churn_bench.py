@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""A CHURNING world on the resident chain: heavy balls shot into a LargePyramid base-N (tests/world_chain.py: wreck_world
+-- a generator, no oracle involved), the whole loop per step as a caller of the C-ABI runs it:
+
+    s2amd_world_find_pairs (when the refit moved shapes) -> the caller's s2CreateContact for every new pair ->
+    s2amd_world_set_contacts -> s2amd_world_step (update contacts -> s2Solve_* -> refit)
+
+Contacts are created and destroyed in almost every step while the balls plough through the pile.  Reports per-step wall
+time split into its parts, the host time spent on the constraint-graph structure (s2amdStepStats.hostPrepMs), and how many
+steps rebuilt it.
+
+    python tools/churn_bench.py [--base 200] [--steps 240] [--solver TGS_Soft] > gpurun_out/churn.json
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from solver2d_amd import hip, wire  # noqa: E402
+from tests import common, world_chain  # noqa: E402
+
+
+def create_contacts(world, free, new_pairs):
+    """The caller's s2CreateContact (src/contact.c:137-203) on its own copy of the pool: first free slot, mixed friction,
+    empty manifold."""
+    n = len(new_pairs)
+    slots = np.array([free.pop() for _ in range(n)], dtype=np.int32)
+    contacts = np.zeros(n, dtype=wire.contact_dtype)
+    pairs = np.zeros(n, dtype=wire.pair_state_dtype)
+    contacts["bodyA"] = world["shapes"]["body"][new_pairs[:, 0]]
+    contacts["bodyB"] = world["shapes"]["body"][new_pairs[:, 1]]
+    contacts["friction"] = 0.6
+    contacts["constraintIndex"] = -1
+    pairs["shapeA"], pairs["shapeB"] = new_pairs[:, 0], new_pairs[:, 1]
+    return slots, contacts, pairs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--base", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=240)
+    ap.add_argument("--solver", default="TGS_Soft")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE")
+    a = ap.parse_args()
+    vel, pos = common.DEFAULT_ITERS[a.solver]
+    params = wire.StepParams.make(a.solver, 1.0 / 60.0, vel, pos, True)
+    world = world_chain.wreck_world(a.seed, a.base)
+    free = sorted(np.flatnonzero(world["pairs"]["shapeA"] < 0).tolist(), reverse=True)
+    rows = []
+    with hip.Solver(0) as s:
+        for kv in a.opt:
+            k, v = kv.split("=")
+            s.set_option(k, int(v))
+        s.world_upload(*[world[k] for k in world_chain.WORLD_KEYS])
+        moved = 1  # the balls were created "in the move buffer"
+        status = np.zeros(len(world["contacts"]), dtype=np.int32)
+        for step in range(a.steps):
+            t0 = time.perf_counter()
+            created = 0
+            if moved > 0:
+                new = s.world_find_pairs()
+                t1 = time.perf_counter()
+                if len(new):
+                    slots, contacts, pairs = create_contacts(world, free, new)
+                    t2 = time.perf_counter()
+                    s.world_set_contacts(slots, contacts, pairs)
+                    created = len(new)
+                else:
+                    t2 = t1
+            else:
+                t1 = t2 = t0
+            t3 = time.perf_counter()
+            info = s.world_step(params)
+            t4 = time.perf_counter()
+            st = s.stats()
+            if info["separatedCount"] > 0:
+                # the caller's s2DestroyContact: which pool slots are free again
+                free.extend(s.world_separated(info["separatedCount"]).tolist())
+            t5 = time.perf_counter()
+            moved = info["movedCount"]
+            rows.append({"step_ms": 1e3 * (t5 - t0), "pair_query_ms": 1e3 * (t1 - t0), "create_py_ms": 1e3 * (t2 - t1), "set_contacts_ms": 1e3 * (t3 - t2),
+                         "world_step_ms": 1e3 * (t4 - t3), "destroy_py_ms": 1e3 * (t5 - t4), "host_structure_ms": st["hostPrepMs"], "solve_device_ms": info["solveMs"],
+                         "created": created, "separated": info["separatedCount"], "flips": info["graphChanged"], "active": info["activeContacts"],
+                         "launches": st["kernelLaunches"], "persistent": st["persistent"], "replayed": st["graphReplayed"], "strips": st["stripCount"]})
+    def mean(key, sel):
+        v = [r[key] for r in sel]
+        return sum(v) / max(len(v), 1)
+
+    def median(key, sel):
+        v = sorted(r[key] for r in sel)
+        return v[len(v) // 2] if v else 0.0
+    churn = [r for r in rows if r["created"] > 0 or r["separated"] > 0]
+    quiet = [r for r in rows if not (r["created"] > 0 or r["separated"] > 0)]
+    keys = ["step_ms", "pair_query_ms", "create_py_ms", "set_contacts_ms", "world_step_ms", "destroy_py_ms", "host_structure_ms", "solve_device_ms", "launches"]
+    out = {"world": "wreck_world(seed %d, base %d): %d bodies, %d contact slots" % (a.seed, a.base, len(world["bodies"]), len(world["contacts"])),
+           "solver": a.solver, "steps": a.steps, "steps_with_created_or_destroyed_contacts": len(churn),
+           "contacts_created": sum(r["created"] for r in rows), "contacts_destroyed": sum(r["separated"] for r in rows),
+           "steps_with_manifold_flips": sum(1 for r in rows if r["flips"]), "steps_that_rebuilt_the_structure": sum(1 for r in rows if r["host_structure_ms"] > 0), "contacts_placed_without_rebuild": st["placedContacts"],
+           "steps_on_persistent_kernel": sum(r["persistent"] for r in rows), "steps_replayed_from_graph": sum(r["replayed"] for r in rows),
+           "all_steps": {k: mean(k, rows) for k in keys}, "churn_steps": {k: mean(k, churn) for k in keys}, "quiet_steps": {k: mean(k, quiet) for k in keys},
+           "churn_steps_median": {k: median(k, churn) for k in keys}, "quiet_steps_median": {k: median(k, quiet) for k in keys},
+           "slowest_steps_ms": sorted((round(r["step_ms"], 3) for r in rows), reverse=True)[:8],
+           "active_contacts_last": rows[-1]["active"]}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -269,6 +269,7 @@ struct s2amdSolver
 	int optPersist = 1;
 	int optSeamRegs = 1;
 	int optStripRetry = 1; // try other strip widths when the partition needs the 8-round kernel variant
+	bool stripRetryPending = false; // ... postponed until the graph has been quiet for 32 steps
 	int optPersistDebug = 0;
 	int optPersistSpinLimit = 1 << 21;
 	bool persistFailed = false; // a hand-off timed out once (workgroups not co-resident: a shared GPU): multi-launch strips from then on

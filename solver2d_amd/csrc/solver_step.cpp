@@ -273,6 +273,11 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	HIP_TRY(hipSetDevice(s->device));
 	s->stats = s2amdStepStats{};
 	buildPlan(s, params);
+	if (s->stripRetryPending && s->graphAge >= 32 && !s->structureDirty)
+	{
+		s->structureDirty = true; // the postponed search for a better strip partition (solver_structure.cpp: buildStructure)
+		s->stripsRejected = false;
+	}
 	int rc = buildStructure(s, params->solverType);
 	if (rc)
 	{

@@ -1949,8 +1949,16 @@ int buildStructure(s2amdSolver* s, int solverType)
 		return (s->persistValid || (s->leanAValid && s->leanBValid)) ? 1 : 0;
 	};
 	const bool triedStrips = s->stripsRejected || s->dStripA.view.groupCount > 0;
+	s->stripRetryPending = false;
 	if (!triedStrips || outcome() == 2)
 	{
+		return rc;
+	}
+	// seven more partitions cost seven more builds (tens of milliseconds at 60k constraints): only for a graph that has been
+	// quiet for a while (or when the caller asked for strips at once, strip_patience 0); doStep comes back for it
+	if (s->optStripPatience != 0 && s->graphAge < 32)
+	{
+		s->stripRetryPending = true;
 		return rc;
 	}
 	float bestScale = 1.0f;

@@ -1,0 +1,878 @@
+// s2_amd_binding.c -- the reference-side binding of the MI355X hot path (INTEGRATION.md shows where each piece hooks in).
+//
+// This is the file a maintainer of erincatto/solver2d adds to src/ to run the solvers -- or the whole of s2World_Step
+// but its tree and pool bookkeeping -- on libs2amd.so.  It is compiled against the reference's own internal headers
+// (body.h, contact.h, joint.h, shape.h, world.h) and against include/solver2d_amd.h, and it is all there is between the
+// reference's pools and the C-ABI:
+//
+//   * field-for-field gather / scatter between the pools and the wire structs (s2amdBinding_Pack* / _Unpack*);
+//   * s2amdBinding_Solve(world, context, solverType)  ==  s2Solve_<solverType>(world, context)   (src/solvers.h:70-79):
+//     gather, s2amd_solve, scatter -- the drop-in for the switch in s2World_Step (src/world.c:206-256);
+//   * s2amdBinding_WorldStep(world, dt, velIters, posIters, warmStart)  ==  s2World_Step (src/world.c:120-301) with stages 1
+//     and 2 (dynamic trees, contact pool) left to the reference and stage 3 (update contacts), the solve and stage 4
+//     (refit) on the resident world chain (s2amd_world_upload / _set_contacts / _step / _separated / _download);
+//   * ONE device state per world: s2amdSolver handles and host mirrors live in a table indexed by s2World.index
+//     (src/world.c:29, include/solver2d/constants.h:12: 32 worlds), created on a world's first step and released by
+//     s2amdBinding_DestroyWorld, which s2DestroyWorld (src/world.c:105-118) calls first.  The samples' GUI steps up to
+//     ten worlds per frame (samples/main.cpp:805-813): each keeps its own resident world, structure and step graph.
+//
+// libs2amd.so is loaded with dlopen: no link-time dependency on the HIP runtime, and no CPU fallback -- when the library
+// or a GPU is missing s2amdBinding_Open fails and the reference keeps its own solvers.
+#include "s2_amd_binding.h"
+
+#include "body.h"
+#include "contact.h"
+#include "core.h"
+#include "joint.h"
+#include "shape.h"
+#include "solvers.h"
+#include "stack_allocator.h"
+#include "world.h"
+
+#include "solver2d/constants.h"
+
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+// ---- gather / scatter between the reference's pools and the wire structs ----
+
+
+void s2amdBinding_PackBodies(const s2World* world, s2amdBody* out)
+{
+	int n = world->bodyPool.capacity;
+	for (int i = 0; i < n; ++i)
+	{
+		const s2Body* b = world->bodies + i;
+		s2amdBody* o = out + i;
+		memset(o, 0, sizeof(*o));
+		if (s2IsFree(&b->object))
+		{
+			o->type = S2AMD_BODY_FREE;
+			continue;
+		}
+		o->position[0] = b->position.x, o->position[1] = b->position.y;
+		o->rot[0] = b->rot.s, o->rot[1] = b->rot.c;
+		o->linearVelocity[0] = b->linearVelocity.x, o->linearVelocity[1] = b->linearVelocity.y;
+		o->angularVelocity = b->angularVelocity;
+		o->deltaPosition[0] = b->deltaPosition.x, o->deltaPosition[1] = b->deltaPosition.y;
+		o->localCenter[0] = b->localCenter.x, o->localCenter[1] = b->localCenter.y;
+		o->force[0] = b->force.x, o->force[1] = b->force.y;
+		o->torque = b->torque;
+		o->mass = b->mass, o->invMass = b->invMass;
+		o->I = b->I, o->invI = b->invI;
+		o->linearDamping = b->linearDamping;
+		o->angularDamping = b->angularDamping;
+		o->gravityScale = b->gravityScale;
+		o->type = (int32_t)b->type;
+	}
+}
+
+
+void s2amdBinding_UnpackBodies(s2World* world, const s2amdBody* in)
+{
+	int n = world->bodyPool.capacity;
+	for (int i = 0; i < n; ++i)
+	{
+		s2Body* b = world->bodies + i;
+		const s2amdBody* o = in + i;
+		if (s2IsFree(&b->object))
+		{
+			continue;
+		}
+		b->position = (s2Vec2){o->position[0], o->position[1]};
+		b->rot = (s2Rot){o->rot[0], o->rot[1]};
+		b->linearVelocity = (s2Vec2){o->linearVelocity[0], o->linearVelocity[1]};
+		b->angularVelocity = o->angularVelocity;
+		b->deltaPosition = (s2Vec2){o->deltaPosition[0], o->deltaPosition[1]};
+	}
+}
+
+
+void s2amdBinding_PackContacts(const s2World* world, s2amdContact* out)
+{
+	int n = world->contactPool.capacity;
+	for (int i = 0; i < n; ++i)
+	{
+		const s2Contact* c = world->contacts + i;
+		s2amdContact* o = out + i;
+		memset(o, 0, sizeof(*o));
+		o->constraintIndex = -1;
+		if (s2IsFree(&c->object))
+		{
+			o->bodyA = -1, o->bodyB = -1;
+			continue;
+		}
+		const s2Manifold* m = &c->manifold;
+		o->bodyA = c->edges[0].bodyIndex;
+		o->bodyB = c->edges[1].bodyIndex;
+		o->pointCount = m->pointCount;
+		o->frictionPersisted = m->frictionPersisted ? 1 : 0;
+		o->normal[0] = m->normal.x, o->normal[1] = m->normal.y;
+		o->friction = c->friction;
+		o->constraintIndex = m->constraintIndex;
+		for (int j = 0; j < 2; ++j)
+		{
+			const s2ManifoldPoint* p = m->points + j;
+			s2amdManifoldPoint* q = o->points + j;
+			q->localAnchorA[0] = p->localAnchorA.x, q->localAnchorA[1] = p->localAnchorA.y;
+			q->localAnchorB[0] = p->localAnchorB.x, q->localAnchorB[1] = p->localAnchorB.y;
+			q->frictionAnchorA[0] = p->frictionAnchorA.x, q->frictionAnchorA[1] = p->frictionAnchorA.y;
+			q->frictionAnchorB[0] = p->frictionAnchorB.x, q->frictionAnchorB[1] = p->frictionAnchorB.y;
+			q->frictionNormalA[0] = p->frictionNormalA.x, q->frictionNormalA[1] = p->frictionNormalA.y;
+			q->frictionNormalB[0] = p->frictionNormalB.x, q->frictionNormalB[1] = p->frictionNormalB.y;
+			q->separation = p->separation;
+			q->normalImpulse = p->normalImpulse;
+			q->tangentImpulse = p->tangentImpulse;
+		}
+	}
+}
+
+
+void s2amdBinding_UnpackContacts(s2World* world, const s2amdContact* in)
+{
+	int n = world->contactPool.capacity;
+	for (int i = 0; i < n; ++i)
+	{
+		s2Contact* c = world->contacts + i;
+		const s2amdContact* o = in + i;
+		if (s2IsFree(&c->object))
+		{
+			continue;
+		}
+		s2Manifold* m = &c->manifold;
+		m->frictionPersisted = o->frictionPersisted != 0;
+		if (o->constraintIndex >= 0)
+		{
+			m->constraintIndex = o->constraintIndex;
+		}
+		for (int j = 0; j < 2; ++j)
+		{
+			s2ManifoldPoint* p = m->points + j;
+			const s2amdManifoldPoint* q = o->points + j;
+			p->frictionAnchorA = (s2Vec2){q->frictionAnchorA[0], q->frictionAnchorA[1]};
+			p->frictionAnchorB = (s2Vec2){q->frictionAnchorB[0], q->frictionAnchorB[1]};
+			p->frictionNormalA = (s2Vec2){q->frictionNormalA[0], q->frictionNormalA[1]};
+			p->frictionNormalB = (s2Vec2){q->frictionNormalB[0], q->frictionNormalB[1]};
+			p->normalImpulse = q->normalImpulse;
+			p->tangentImpulse = q->tangentImpulse;
+		}
+	}
+}
+
+
+void s2amdBinding_PackJoints(const s2World* world, s2amdJoint* out)
+{
+	int n = world->jointPool.capacity;
+	for (int i = 0; i < n; ++i)
+	{
+		const s2Joint* jn = world->joints + i;
+		s2amdJoint* o = out + i;
+		memset(o, 0, sizeof(*o));
+		if (s2IsFree(&jn->object))
+		{
+			o->type = S2AMD_JOINT_FREE;
+			o->bodyA = -1, o->bodyB = -1;
+			continue;
+		}
+		o->bodyA = jn->edges[0].bodyIndex;
+		o->bodyB = jn->edges[1].bodyIndex;
+		o->localOriginAnchorA[0] = jn->localOriginAnchorA.x, o->localOriginAnchorA[1] = jn->localOriginAnchorA.y;
+		o->localOriginAnchorB[0] = jn->localOriginAnchorB.x, o->localOriginAnchorB[1] = jn->localOriginAnchorB.y;
+		if (jn->type == s2_revoluteJoint)
+		{
+			const s2RevoluteJoint* r = &jn->revoluteJoint;
+			o->type = S2AMD_JOINT_REVOLUTE;
+			o->enableMotor = r->enableMotor ? 1 : 0;
+			o->enableLimit = r->enableLimit ? 1 : 0;
+			o->impulse[0] = r->impulse.x, o->impulse[1] = r->impulse.y;
+			o->motorImpulse = r->motorImpulse;
+			o->lowerImpulse = r->lowerImpulse;
+			o->upperImpulse = r->upperImpulse;
+			o->maxMotorTorque = r->maxMotorTorque;
+			o->motorSpeed = r->motorSpeed;
+			o->referenceAngle = r->referenceAngle;
+			o->lowerAngle = r->lowerAngle;
+			o->upperAngle = r->upperAngle;
+		}
+		else
+		{
+			const s2MouseJoint* mj = &jn->mouseJoint;
+			o->type = S2AMD_JOINT_MOUSE;
+			o->impulse[0] = mj->impulse.x, o->impulse[1] = mj->impulse.y;
+			o->motorImpulse = mj->motorImpulse;
+			o->hertz = mj->hertz;
+			o->dampingRatio = mj->dampingRatio;
+			o->targetA[0] = mj->targetA.x, o->targetA[1] = mj->targetA.y;
+		}
+	}
+}
+
+
+void s2amdBinding_UnpackJoints(s2World* world, const s2amdJoint* in)
+{
+	int n = world->jointPool.capacity;
+	for (int i = 0; i < n; ++i)
+	{
+		s2Joint* jn = world->joints + i;
+		const s2amdJoint* o = in + i;
+		if (s2IsFree(&jn->object))
+		{
+			continue;
+		}
+		if (jn->type == s2_revoluteJoint)
+		{
+			s2RevoluteJoint* r = &jn->revoluteJoint;
+			r->impulse = (s2Vec2){o->impulse[0], o->impulse[1]};
+			r->motorImpulse = o->motorImpulse;
+			r->lowerImpulse = o->lowerImpulse;
+			r->upperImpulse = o->upperImpulse;
+		}
+		else
+		{
+			s2MouseJoint* mj = &jn->mouseJoint;
+			mj->impulse = (s2Vec2){o->impulse[0], o->impulse[1]};
+			mj->motorImpulse = o->motorImpulse;
+		}
+	}
+}
+
+
+void s2amdBinding_PackShapes(const s2World* world, s2amdShape* out)
+{
+	int n = world->shapePool.capacity;
+	for (int i = 0; i < n; ++i)
+	{
+		const s2Shape* sh = world->shapes + i;
+		s2amdShape* o = out + i;
+		memset(o, 0, sizeof(*o));
+		if (s2IsFree(&sh->object))
+		{
+			o->body = -1;
+			o->type = S2AMD_SHAPE_FREE;
+			continue;
+		}
+		o->body = sh->bodyIndex;
+		o->type = (int32_t)sh->type;
+		o->categoryBits = sh->filter.categoryBits;
+		o->maskBits = sh->filter.maskBits;
+		o->groupIndex = sh->filter.groupIndex;
+		o->proxyKey = sh->proxyKey;
+		o->enlarged = sh->enlargedAABB ? 1 : 0;
+		o->aabb[0] = sh->aabb.lowerBound.x, o->aabb[1] = sh->aabb.lowerBound.y;
+		o->aabb[2] = sh->aabb.upperBound.x, o->aabb[3] = sh->aabb.upperBound.y;
+		o->fatAABB[0] = sh->fatAABB.lowerBound.x, o->fatAABB[1] = sh->fatAABB.lowerBound.y;
+		o->fatAABB[2] = sh->fatAABB.upperBound.x, o->fatAABB[3] = sh->fatAABB.upperBound.y;
+		switch (sh->type)
+		{
+			case s2_polygonShape:
+				o->count = sh->polygon.count;
+				o->radius = sh->polygon.radius;
+				for (int v = 0; v < sh->polygon.count; ++v)
+				{
+					o->vertices[v][0] = sh->polygon.vertices[v].x, o->vertices[v][1] = sh->polygon.vertices[v].y;
+					o->normals[v][0] = sh->polygon.normals[v].x, o->normals[v][1] = sh->polygon.normals[v].y;
+				}
+				break;
+			case s2_circleShape:
+				o->radius = sh->circle.radius;
+				o->vertices[0][0] = sh->circle.point.x, o->vertices[0][1] = sh->circle.point.y;
+				break;
+			case s2_capsuleShape:
+				o->radius = sh->capsule.radius;
+				o->vertices[0][0] = sh->capsule.point1.x, o->vertices[0][1] = sh->capsule.point1.y;
+				o->vertices[1][0] = sh->capsule.point2.x, o->vertices[1][1] = sh->capsule.point2.y;
+				break;
+			case s2_segmentShape:
+				o->vertices[0][0] = sh->segment.point1.x, o->vertices[0][1] = sh->segment.point1.y;
+				o->vertices[1][0] = sh->segment.point2.x, o->vertices[1][1] = sh->segment.point2.y;
+				break;
+			default:
+				break;
+		}
+	}
+}
+
+
+void s2amdBinding_PackPairs(const s2World* world, s2amdPairState* out)
+{
+	int n = world->contactPool.capacity;
+	for (int i = 0; i < n; ++i)
+	{
+		const s2Contact* c = world->contacts + i;
+		s2amdPairState* o = out + i;
+		memset(o, 0, sizeof(*o));
+		if (s2IsFree(&c->object))
+		{
+			o->shapeA = -1, o->shapeB = -1;
+			continue;
+		}
+		o->shapeA = c->shapeIndexA;
+		o->shapeB = c->shapeIndexB;
+		o->cacheMetric = c->cache.metric;
+		o->cacheCount = c->cache.count;
+		for (int k = 0; k < 3; ++k)
+		{
+			o->cacheIndexA[k] = c->cache.indexA[k];
+			o->cacheIndexB[k] = c->cache.indexB[k];
+		}
+		for (int j = 0; j < 2; ++j)
+		{
+			o->id[j] = c->manifold.points[j].id;
+			o->persisted[j] = c->manifold.points[j].persisted ? 1 : 0;
+		}
+	}
+}
+
+
+static void unpackManifolds(s2World* world, const s2amdContact* in, const s2amdPairState* pairs, int count)
+{
+	int n = world->contactPool.capacity < count ? world->contactPool.capacity : count;
+	for (int i = 0; i < n; ++i)
+	{
+		s2Contact* c = world->contacts + i;
+		if (s2IsFree(&c->object) || pairs[i].shapeA != c->shapeIndexA || pairs[i].shapeB != c->shapeIndexB)
+		{
+			continue; // not the contact the device knows in this slot
+		}
+		const s2amdContact* o = in + i;
+		const s2amdPairState* ps = pairs + i;
+		s2Manifold* m = &c->manifold;
+		m->pointCount = o->pointCount;
+		m->frictionPersisted = o->frictionPersisted != 0;
+		m->normal = (s2Vec2){o->normal[0], o->normal[1]};
+		if (o->constraintIndex >= 0)
+		{
+			m->constraintIndex = o->constraintIndex; // (the wire's -1: not in a constraint array this step; the reference keeps the stale index)
+		}
+		for (int j = 0; j < 2; ++j)
+		{
+			s2ManifoldPoint* p = m->points + j;
+			const s2amdManifoldPoint* q = o->points + j;
+			p->localAnchorA = (s2Vec2){q->localAnchorA[0], q->localAnchorA[1]};
+			p->localAnchorB = (s2Vec2){q->localAnchorB[0], q->localAnchorB[1]};
+			p->frictionAnchorA = (s2Vec2){q->frictionAnchorA[0], q->frictionAnchorA[1]};
+			p->frictionAnchorB = (s2Vec2){q->frictionAnchorB[0], q->frictionAnchorB[1]};
+			p->frictionNormalA = (s2Vec2){q->frictionNormalA[0], q->frictionNormalA[1]};
+			p->frictionNormalB = (s2Vec2){q->frictionNormalB[0], q->frictionNormalB[1]};
+			p->separation = q->separation;
+			p->normalImpulse = q->normalImpulse;
+			p->tangentImpulse = q->tangentImpulse;
+			p->id = ps->id[j];
+			p->persisted = ps->persisted[j] != 0;
+		}
+		c->cache.metric = ps->cacheMetric;
+		c->cache.count = ps->cacheCount;
+		for (int k = 0; k < 3; ++k)
+		{
+			c->cache.indexA[k] = ps->cacheIndexA[k];
+			c->cache.indexB[k] = ps->cacheIndexB[k];
+		}
+	}
+}
+
+// ---- the library ----
+
+typedef struct AmdApi
+{
+	void* lib;
+	int device;
+	int (*create)(int, s2amdSolver**);
+	void (*destroy)(s2amdSolver*);
+	const char* (*lastError)(void);
+	int (*solve)(s2amdSolver*, const s2amdStepParams*, s2amdBody*, int32_t, s2amdContact*, int32_t, s2amdJoint*, int32_t);
+	int (*worldUpload)(s2amdSolver*, const s2amdBody*, int32_t, const s2amdContact*, int32_t, const s2amdJoint*, int32_t, const s2amdShape*, int32_t,
+					   const s2amdPairState*, const float*);
+	int (*worldStep)(s2amdSolver*, const s2amdStepParams*, s2amdWorldStepInfo*);
+	int (*worldSetContacts)(s2amdSolver*, const int32_t*, int32_t, const s2amdContact*, const s2amdPairState*);
+	int (*worldDownload)(s2amdSolver*, s2amdBody*, int32_t, s2amdContact*, int32_t, s2amdJoint*, int32_t, s2amdShape*, int32_t, s2amdPairState*, float*,
+						 int32_t*);
+	int (*worldFindPairs)(s2amdSolver*, int32_t*, int32_t, int32_t*);
+	int (*worldSeparated)(s2amdSolver*, int32_t*, int32_t, int32_t*);
+} AmdApi;
+static AmdApi s_api = {0};
+
+// the device state of ONE world
+typedef struct WorldBinding
+{
+	s2amdSolver* solver;
+	// solver-only route: the wire arrays of the last s2amdBinding_Solve
+	s2amdBody* solveBodies;
+	s2amdContact* solveContacts;
+	s2amdJoint* solveJoints;
+	// whole-step route: what of this world is resident on the device
+	int resident;
+	uint64_t stepId; // s2World.stepId after the last step taken here: a new world in a re-used slot starts at 0 again; steps taken elsewhere show up too
+	int bodyCapacity, bodyCount, shapeCapacity, shapeCount, jointCapacity, jointCount, contactCapacity;
+	int contactsStale; // the device holds newer manifolds / impulses / joint impulses than the host pools
+	s2amdBody* bodies;
+	s2amdContact* contacts;
+	s2amdJoint* joints;
+	s2amdShape* shapes;
+	s2amdPairState* pairs;
+	float* origins;
+	int32_t* separated;
+	int64_t* liveKey; // shapeIndexA << 32 | shapeIndexB of the slot as the device knows it, -1: free there
+	int32_t* slots;
+	s2amdContact* slotContacts;
+	s2amdPairState* slotPairs;
+	int32_t* newPairs;
+	int newPairCapacity;
+} WorldBinding;
+static WorldBinding s_bindings[s2_maxWorlds];
+static long s_uploads = 0, s_steps = 0;
+static int s_lastError = 0;
+static int s_devicePairs = 0;
+static double s_phaseMs[6] = {0}; // stage 1+2, sync in, device step, download, apply, steps
+
+static double wallMs(void)
+{
+	struct timespec t;
+	clock_gettime(CLOCK_MONOTONIC, &t);
+	return 1e3 * (double)t.tv_sec + 1e-6 * (double)t.tv_nsec;
+}
+
+static void* growTo(void* p, size_t count, size_t size)
+{
+	return realloc(p, (count > 0 ? count : 1) * size);
+}
+
+int s2amdBinding_Open(const char* libraryPath, int device)
+{
+	if (s_api.lib == NULL)
+	{
+		s_api.lib = dlopen(libraryPath, RTLD_NOW | RTLD_LOCAL);
+		if (s_api.lib == NULL)
+		{
+			return -1;
+		}
+#define S2_BIND(member, symbol)                                                                                                  \
+	*(void**)(&s_api.member) = dlsym(s_api.lib, symbol);                                                                         \
+	if (s_api.member == NULL)                                                                                                    \
+	{                                                                                                                            \
+		return -2;                                                                                                               \
+	}
+		S2_BIND(create, "s2amd_create")
+		S2_BIND(destroy, "s2amd_destroy")
+		S2_BIND(lastError, "s2amd_last_error")
+		S2_BIND(solve, "s2amd_solve")
+		S2_BIND(worldUpload, "s2amd_world_upload")
+		S2_BIND(worldStep, "s2amd_world_step")
+		S2_BIND(worldSetContacts, "s2amd_world_set_contacts")
+		S2_BIND(worldDownload, "s2amd_world_download")
+		S2_BIND(worldFindPairs, "s2amd_world_find_pairs")
+		S2_BIND(worldSeparated, "s2amd_world_separated")
+#undef S2_BIND
+	}
+	s_api.device = device;
+	// fail now, not at the first step, when there is no GPU (the library has no CPU path)
+	s2amdSolver* probe = NULL;
+	if (s_api.create(device, &probe) != 0 || probe == NULL)
+	{
+		return -3;
+	}
+	s_api.destroy(probe);
+	s_lastError = 0;
+	return 0;
+}
+
+int s2amdBinding_IsOpen(void)
+{
+	return s_api.lib != NULL;
+}
+
+int s2amdBinding_LastError(void)
+{
+	return s_lastError;
+}
+
+long s2amdBinding_Uploads(void)
+{
+	return s_uploads;
+}
+
+void s2amdBinding_DevicePairs(int on)
+{
+	s_devicePairs = on;
+}
+
+void s2amdBinding_Timing(double out[6])
+{
+	for (int i = 0; i < 6; ++i)
+	{
+		out[i] = s_phaseMs[i];
+		s_phaseMs[i] = 0.0;
+	}
+}
+
+static WorldBinding* bindingOf(const s2World* world)
+{
+	if (s_api.lib == NULL || world->index < 0 || world->index >= s2_maxWorlds)
+	{
+		return NULL;
+	}
+	WorldBinding* b = s_bindings + world->index;
+	if (b->solver == NULL && (s_api.create(s_api.device, &b->solver) != 0 || b->solver == NULL))
+	{
+		b->solver = NULL;
+		return NULL;
+	}
+	return b;
+}
+
+// manifolds, GJK caches and joint impulses back into the reference's pools
+static int syncToPools(s2World* world, WorldBinding* b)
+{
+	const uint64_t id = (uint64_t)world->stepId;
+	if (!b->resident || (id != b->stepId && id != b->stepId + 1) || !b->contactsStale)
+	{
+		return 0;
+	}
+	int rc = s_api.worldDownload(b->solver, NULL, b->bodyCapacity, b->contacts, b->contactCapacity, b->joints, b->jointCapacity, NULL, b->shapeCapacity,
+								 b->pairs, NULL, NULL);
+	if (rc != 0)
+	{
+		return rc;
+	}
+	unpackManifolds(world, b->contacts, b->pairs, b->contactCapacity);
+	if (world->jointPool.capacity == b->jointCapacity && world->jointPool.count == b->jointCount)
+	{
+		s2amdBinding_UnpackJoints(world, b->joints); // (joints were created or destroyed: their impulses start over)
+	}
+	b->contactsStale = 0;
+	return 0;
+}
+
+int s2amdBinding_Sync(s2World* world)
+{
+	WorldBinding* b = s_api.lib != NULL && world->index >= 0 && world->index < s2_maxWorlds ? s_bindings + world->index : NULL;
+	return b != NULL && b->solver != NULL ? syncToPools(world, b) : 0;
+}
+
+void s2amdBinding_Invalidate(s2World* world)
+{
+	WorldBinding* b = s_api.lib != NULL && world->index >= 0 && world->index < s2_maxWorlds ? s_bindings + world->index : NULL;
+	if (b != NULL && b->solver != NULL)
+	{
+		(void)syncToPools(world, b);
+		b->resident = 0;
+	}
+}
+
+// s2DestroyWorld (src/world.c:105-118) calls this before it frees the pools: the world's device state goes with it
+void s2amdBinding_DestroyWorld(s2World* world)
+{
+	if (world->index < 0 || world->index >= s2_maxWorlds)
+	{
+		return;
+	}
+	WorldBinding* b = s_bindings + world->index;
+	if (b->solver != NULL && s_api.destroy != NULL)
+	{
+		s_api.destroy(b->solver);
+	}
+	void* owned[] = {b->solveBodies, b->solveContacts, b->solveJoints, b->bodies,		b->contacts,	 b->joints,	   b->shapes,	b->pairs,
+					 b->origins,	 b->separated,	   b->liveKey,	   b->slots,		b->slotContacts, b->slotPairs, b->newPairs};
+	for (size_t i = 0; i < sizeof(owned) / sizeof(owned[0]); ++i)
+	{
+		free(owned[i]);
+	}
+	memset(b, 0, sizeof(*b));
+}
+
+// every world's manifolds back to its pools and every device state released (the library stays loaded)
+void s2amdBinding_Close(void)
+{
+	for (int i = 0; i < s2_maxWorlds; ++i)
+	{
+		WorldBinding* b = s_bindings + i;
+		if (b->solver == NULL)
+		{
+			continue;
+		}
+		s2World* world = s2GetWorldFromIndex((int16_t)i);
+		if (world->blockAllocator != NULL)
+		{
+			(void)syncToPools(world, b);
+			s2amdBinding_DestroyWorld(world);
+		}
+		else
+		{
+			s2World gone = {0};
+			gone.index = (int16_t)i;
+			s2amdBinding_DestroyWorld(&gone);
+		}
+	}
+}
+
+static void fillParams(const s2World* world, s2amdStepParams* p, int solverType, float dt, int velIters, int posIters, int warmStart)
+{
+	p->solverType = solverType;
+	p->dt = dt;
+	p->velIters = velIters;
+	p->posIters = posIters;
+	p->warmStart = warmStart;
+	p->gravity[0] = world->gravity.x;
+	p->gravity[1] = world->gravity.y;
+}
+
+// == s2Solve_<solverType>(world, context): the plug point of src/solvers.h:70-79
+int s2amdBinding_Solve(s2World* world, s2StepContext* context, int solverType)
+{
+	WorldBinding* b = bindingOf(world);
+	if (b == NULL)
+	{
+		return s_lastError = S2AMD_E_NODEVICE;
+	}
+	if (b->resident)
+	{
+		// this world was last stepped by the whole-step route: its manifolds are on the device
+		(void)syncToPools(world, b);
+		b->resident = 0;
+	}
+	const int nb = world->bodyPool.capacity, nc = world->contactPool.capacity, nj = world->jointPool.capacity;
+	b->solveBodies = (s2amdBody*)growTo(b->solveBodies, (size_t)nb, sizeof(s2amdBody));
+	b->solveContacts = (s2amdContact*)growTo(b->solveContacts, (size_t)nc, sizeof(s2amdContact));
+	b->solveJoints = (s2amdJoint*)growTo(b->solveJoints, (size_t)nj, sizeof(s2amdJoint));
+	s2amdBinding_PackBodies(world, b->solveBodies);
+	s2amdBinding_PackContacts(world, b->solveContacts);
+	s2amdBinding_PackJoints(world, b->solveJoints);
+	s2amdStepParams params;
+	fillParams(world, &params, solverType, context->dt, context->iterations, context->extraIterations, context->warmStart ? 1 : 0);
+	int rc = s_api.solve(b->solver, &params, b->solveBodies, nb, b->solveContacts, nc, b->solveJoints, nj);
+	if (rc != 0)
+	{
+		fprintf(stderr, "s2Solve on the GPU failed (%d): %s\n", rc, s_api.lastError());
+		return s_lastError = rc;
+	}
+	s2amdBinding_UnpackBodies(world, b->solveBodies);
+	s2amdBinding_UnpackContacts(world, b->solveContacts);
+	s2amdBinding_UnpackJoints(world, b->solveJoints);
+	return 0;
+}
+
+// ---- whole step ----
+
+static int residentMatches(const s2World* w, const WorldBinding* b)
+{
+	return b->resident && b->stepId + 1 == (uint64_t)w->stepId && b->bodyCapacity == w->bodyPool.capacity && b->bodyCount == w->bodyPool.count &&
+		   b->shapeCapacity == w->shapePool.capacity && b->shapeCount == w->shapePool.count && b->jointCapacity == w->jointPool.capacity &&
+		   b->jointCount == w->jointPool.count && b->contactCapacity == w->contactPool.capacity;
+}
+
+static int uploadWorld(s2World* w, WorldBinding* b)
+{
+	int rc = 0;
+	if (b->resident && (rc = syncToPools(w, b)) != 0) // the pools changed under a resident world: its manifolds first
+	{
+		return rc;
+	}
+	int nb = w->bodyPool.capacity, ns = w->shapePool.capacity, nj = w->jointPool.capacity, nc = w->contactPool.capacity;
+	b->bodies = (s2amdBody*)growTo(b->bodies, (size_t)nb, sizeof(s2amdBody));
+	b->origins = (float*)growTo(b->origins, (size_t)nb * 2, sizeof(float));
+	b->shapes = (s2amdShape*)growTo(b->shapes, (size_t)ns, sizeof(s2amdShape));
+	b->joints = (s2amdJoint*)growTo(b->joints, (size_t)nj, sizeof(s2amdJoint));
+	b->contacts = (s2amdContact*)growTo(b->contacts, (size_t)nc, sizeof(s2amdContact));
+	b->pairs = (s2amdPairState*)growTo(b->pairs, (size_t)nc, sizeof(s2amdPairState));
+	b->separated = (int32_t*)growTo(b->separated, (size_t)nc, sizeof(int32_t));
+	b->liveKey = (int64_t*)growTo(b->liveKey, (size_t)nc, sizeof(int64_t));
+	b->slots = (int32_t*)growTo(b->slots, (size_t)nc, sizeof(int32_t));
+	b->slotContacts = (s2amdContact*)growTo(b->slotContacts, (size_t)nc, sizeof(s2amdContact));
+	b->slotPairs = (s2amdPairState*)growTo(b->slotPairs, (size_t)nc, sizeof(s2amdPairState));
+	s2amdBinding_PackBodies(w, b->bodies);
+	s2amdBinding_PackShapes(w, b->shapes);
+	s2amdBinding_PackJoints(w, b->joints);
+	s2amdBinding_PackContacts(w, b->contacts);
+	s2amdBinding_PackPairs(w, b->pairs);
+	for (int i = 0; i < nb; ++i)
+	{
+		b->origins[2 * i] = w->bodies[i].origin.x;
+		b->origins[2 * i + 1] = w->bodies[i].origin.y;
+	}
+	for (int i = 0; i < nc; ++i)
+	{
+		b->liveKey[i] = b->pairs[i].shapeA < 0 ? -1 : ((int64_t)b->pairs[i].shapeA << 32) | (int64_t)b->pairs[i].shapeB;
+	}
+	rc = s_api.worldUpload(b->solver, b->bodies, nb, b->contacts, nc, b->joints, nj, b->shapes, ns, b->pairs, b->origins);
+	if (rc != 0)
+	{
+		b->resident = 0;
+		return rc;
+	}
+	b->resident = 1;
+	b->bodyCapacity = nb, b->bodyCount = w->bodyPool.count;
+	b->shapeCapacity = ns, b->shapeCount = w->shapePool.count;
+	b->jointCapacity = nj, b->jointCount = w->jointPool.count;
+	b->contactCapacity = nc;
+	b->contactsStale = 0;
+	s_uploads += 1;
+	return 0;
+}
+
+// contacts stage 1 created since the device last saw the pool (the pool never frees a slot on its own between steps:
+// stage 3's separations are applied to both sides below)
+static int sendNewContacts(s2World* w, WorldBinding* b)
+{
+	int count = 0;
+	for (int i = 0; i < b->contactCapacity; ++i)
+	{
+		const s2Contact* c = w->contacts + i;
+		int64_t live = s2IsFree(&c->object) ? -1 : ((int64_t)c->shapeIndexA << 32) | (int64_t)c->shapeIndexB;
+		if (live >= 0 && b->liveKey[i] < 0)
+		{
+			s2amdContact* o = b->slotContacts + count;
+			s2amdPairState* ps = b->slotPairs + count;
+			memset(o, 0, sizeof(*o));
+			memset(ps, 0, sizeof(*ps));
+			o->bodyA = c->edges[0].bodyIndex;
+			o->bodyB = c->edges[1].bodyIndex;
+			o->friction = c->friction;
+			o->constraintIndex = -1;
+			ps->shapeA = c->shapeIndexA;
+			ps->shapeB = c->shapeIndexB;
+			b->slots[count++] = i;
+			b->liveKey[i] = live;
+		}
+		else if (live != b->liveKey[i])
+		{
+			return 1; // somebody destroyed a contact behind our back (s2DestroyBody, s2CreateJoint ...): upload again
+		}
+	}
+	return count > 0 ? s_api.worldSetContacts(b->solver, b->slots, count, b->slotContacts, b->slotPairs) : 0;
+}
+
+// == s2World_Step(worldId, timeStep, velIters, posIters, warmStart) (src/world.c:120-301).  Stages 1 and 2 are passed in:
+// the reference's own s2UpdateBroadPhasePairs and s2BroadPhase_RebuildTrees (world.c:125-130).
+void s2amdBinding_WorldStep(s2World* world, float timeStep, int velIters, int posIters, bool warmStart, void (*updatePairs)(s2World*),
+							void (*rebuildTrees)(s2BroadPhase*))
+{
+	WorldBinding* b = bindingOf(world);
+	if (b == NULL)
+	{
+		s_lastError = S2AMD_E_NODEVICE;
+		return;
+	}
+	world->stepId += 1;
+	const double t0 = wallMs();
+	int rc = 0;
+	if (s_devicePairs && residentMatches(world, b))
+	{
+		// stage 1 with the pair discovery on the device (s2amd_world_find_pairs on the boxes the last refit re-inflated
+		// -- the proxies in the reference's move buffer); the pool bookkeeping of each new pair is s2CreateContact as ever.
+		// The pairs arrive sorted, not in the reference's tree-traversal order: contacts get other pool slots than with
+		// the host's stage 1.  The trees keep following the fat boxes (below) for the reference's ray casts and queries.
+		s2BroadPhase* bp = &world->broadPhase;
+		if (s2Array(bp->moveArray).count > 0)
+		{
+			int32_t count = 0;
+			rc = s_api.worldFindPairs(b->solver, b->newPairs, b->newPairCapacity, &count);
+			if (rc == S2AMD_E_CAPACITY)
+			{
+				b->newPairCapacity = count + 1024;
+				b->newPairs = (int32_t*)realloc(b->newPairs, (size_t)b->newPairCapacity * 2 * sizeof(int32_t));
+				rc = s_api.worldFindPairs(b->solver, b->newPairs, b->newPairCapacity, &count);
+			}
+			for (int i = 0; rc == 0 && i < count; ++i)
+			{
+				s2CreateContact(world, world->shapes + b->newPairs[2 * i], world->shapes + b->newPairs[2 * i + 1]);
+			}
+			s2Array_Clear(bp->moveArray);
+			s2ClearSet(&bp->moveSet);
+		}
+		if ((world->stepId & 63) == 0)
+		{
+			rebuildTrees(bp); // stage 2 now and then: nobody queries the trees here, but the host's ray casts do
+		}
+	}
+	else
+	{
+		// stages 1 and 2 (src/world.c:125-130): the reference's trees, the reference's contact pool
+		updatePairs(world);
+		rebuildTrees(&world->broadPhase);
+	}
+	const double t1 = wallMs();
+
+	if (rc == 0 && (!residentMatches(world, b) || (rc = sendNewContacts(world, b)) == 1))
+	{
+		rc = uploadWorld(world, b);
+	}
+	s2amdStepParams params;
+	fillParams(world, &params, (int32_t)world->solverType, timeStep, velIters, posIters, warmStart ? 1 : 0);
+	s2amdWorldStepInfo info = {0};
+	const double t2 = wallMs();
+	if (rc == 0)
+	{
+		rc = s_api.worldStep(b->solver, &params, &info);
+	}
+	const double t3 = wallMs();
+	int32_t separatedCount = 0;
+	if (rc == 0)
+	{
+		rc = s_api.worldDownload(b->solver, b->bodies, b->bodyCapacity, NULL, b->contactCapacity, NULL, b->jointCapacity,
+								 info.movedCount > 0 ? b->shapes : NULL, b->shapeCapacity, NULL, b->origins, NULL);
+	}
+	if (rc == 0 && info.separatedCount > 0)
+	{
+		rc = s_api.worldSeparated(b->solver, b->separated, b->contactCapacity, &separatedCount);
+	}
+	if (rc != 0)
+	{
+		fprintf(stderr, "s2World_Step on the GPU failed (%d): %s\n", rc, s_api.lastError());
+		s_lastError = rc;
+		b->resident = 0;
+		return;
+	}
+	const double t4 = wallMs();
+	b->contactsStale = 1;
+	s_steps += 1;
+	b->stepId = (uint64_t)world->stepId;
+	s2amdBinding_UnpackBodies(world, b->bodies);
+	for (int i = 0; i < b->bodyCapacity; ++i)
+	{
+		s2Body* body = world->bodies + i;
+		if (s2IsFree(&body->object) || body->type == s2_staticBody)
+		{
+			continue;
+		}
+		body->origin = (s2Vec2){b->origins[2 * i], b->origins[2 * i + 1]};
+		body->force = s2Vec2_zero;
+		body->torque = 0.0f;
+	}
+	// src/world.c:163-167: the pairs stage 3 found separated
+	for (int i = 0; i < separatedCount; ++i)
+	{
+		const int slot = b->separated[i];
+		s2DestroyContact(world, world->contacts + slot);
+		b->liveKey[slot] = -1;
+	}
+	if (info.movedCount > 0)
+	{
+		// src/world.c:259-297: the tight boxes of every shape, the tree only where the fat box was re-inflated -- in the
+		// reference's order (bodies, then each body's shape list): the move buffer's order decides the pool slots of the
+		// contacts stage 1 creates next step
+		for (int bi = 0; bi < b->bodyCapacity; ++bi)
+		{
+			const s2Body* body = world->bodies + bi;
+			if (s2IsFree(&body->object) || body->type == s2_staticBody)
+			{
+				continue;
+			}
+			for (int i = body->shapeList; i != S2_NULL_INDEX; i = world->shapes[i].nextShapeIndex)
+			{
+				s2Shape* sh = world->shapes + i;
+				const s2amdShape* o = b->shapes + i;
+				sh->aabb = (s2Box){{o->aabb[0], o->aabb[1]}, {o->aabb[2], o->aabb[3]}};
+				if (o->enlarged)
+				{
+					sh->fatAABB = (s2Box){{o->fatAABB[0], o->fatAABB[1]}, {o->fatAABB[2], o->fatAABB[3]}};
+					s2BroadPhase_EnlargeProxy(&world->broadPhase, sh->proxyKey, sh->fatAABB);
+				}
+			}
+		}
+	}
+	s2GrowStack(world->stackAllocator);
+	const double t5 = wallMs();
+	s_phaseMs[0] += t1 - t0, s_phaseMs[1] += t2 - t1, s_phaseMs[2] += t3 - t2, s_phaseMs[3] += t4 - t3, s_phaseMs[4] += t5 - t4, s_phaseMs[5] += 1.0;
+}

@@ -223,3 +223,93 @@ def test_native_shim_whole_step_notices_a_replaced_world():
     finally:
         assert L.s2ref_use_amd_world(None, 0) == 0
     common.compare_exact(got, want, "second world in the same slot vs a fresh run")
+
+
+def test_ten_worlds_interleaved_keep_their_own_device_state():
+    """The samples' GUI keeps up to ten worlds alive and steps them one after the other every frame (samples/main.cpp:36,
+    :805-813; the pool has 32 slots, include/solver2d/constants.h:12).  The binding (shim/s2_amd_binding.c) holds ONE device
+    state per world, indexed by s2World.index: ten worlds -- one per solver -- stepped interleaved for 60 frames are each
+    uploaded exactly once, and every one ends bit-identical to the same world stepped alone."""
+    import ctypes
+    L = refbind.lib()
+    L.s2ref_use_amd_world.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    L.s2ref_use_amd_world.restype = ctypes.c_int
+    L.s2ref_world_uploads.restype = ctypes.c_long
+    frames = 60
+    scenes = ["mixed", "pyramid", "circle_pile", "tumbler", "ragdoll", "arch", "joint_grid", "card_house", "shapes_zoo", "vertical_stack"]
+    sizes = {"mixed": 24, "pyramid": 14, "circle_pile": 16, "tumbler": 80, "joint_grid": 8, "shapes_zoo": 30, "vertical_stack": 8}
+    cases = [(scenes[i], sizes.get(scenes[i], 0), name) + common.DEFAULT_ITERS[name] for i, name in enumerate(wire.SOLVER_NAMES)]
+
+    def final_state(w):
+        b, c, j = w.pack()
+        return b.tobytes(), c.tobytes(), j.tobytes(), w.contact_pairs()[0].tobytes()
+
+    alone = []
+    for scene, p0, name, vel, pos in cases:
+        with refbind.RefWorld(scene, name, p0, 8 if scene == "joint_grid" else 0) as w:
+            assert L.s2ref_use_amd_world(hip.LIB_PATH.encode(), 0) == 0
+            try:
+                for _ in range(frames):
+                    w.step(1.0 / 60.0, vel, pos, True)
+                assert L.s2ref_replace_error() == 0
+                alone.append(final_state(w))
+            finally:
+                assert L.s2ref_use_amd_world(None, 0) == 0
+    worlds = [refbind.RefWorld(scene, name, p0, 8 if scene == "joint_grid" else 0) for scene, p0, name, _v, _p in cases]
+    try:
+        assert L.s2ref_use_amd_world(hip.LIB_PATH.encode(), 0) == 0
+        uploads0 = L.s2ref_world_uploads()
+        grew = [w.sizes()[1] for w in worlds]
+        regrowths = 0
+        for _ in range(frames):
+            for i, (w, (_scene, _p0, _name, vel, pos)) in enumerate(zip(worlds, cases)):
+                w.step(1.0 / 60.0, vel, pos, True)
+                if w.sizes()[1] != grew[i]:  # the contact pool grew: the one legitimate reason for another upload
+                    grew[i] = w.sizes()[1]
+                    regrowths += 1
+        assert L.s2ref_replace_error() == 0
+        uploads = L.s2ref_world_uploads() - uploads0
+        together = [final_state(w) for w in worlds]
+    finally:
+        assert L.s2ref_use_amd_world(None, 0) == 0
+        for w in worlds:
+            w.close()
+    assert len(worlds) <= uploads <= len(worlds) + regrowths, (uploads, regrowths)
+    for (scene, _p0, name, _v, _p), a, t in zip(cases, alone, together):
+        assert a == t, "%s/%s differs between the interleaved and the stand-alone run" % (scene, name)
+
+
+def test_destroyed_world_releases_its_device_state_and_the_slot_starts_afresh():
+    """s2DestroyWorld frees the world's device state (the binding is called first); a new world created in the same slot of
+    the reference's world table is uploaded from scratch and is not confused with its predecessor."""
+    import ctypes
+    L = refbind.lib()
+    L.s2ref_use_amd_world.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    L.s2ref_use_amd_world.restype = ctypes.c_int
+    L.s2ref_world_uploads.restype = ctypes.c_long
+    assert L.s2ref_use_amd_world(hip.LIB_PATH.encode(), 0) == 0
+    try:
+        u0 = L.s2ref_world_uploads()
+        with refbind.RefWorld("pyramid", "TGS_Soft", 10, 0) as w:
+            first_index = w.id.index
+            for _ in range(5):
+                w.step(1.0 / 60.0, 8, 4, True)
+        with refbind.RefWorld("mixed", "PGS", 24, 0) as w:
+            assert w.id.index == first_index  # the same slot of s2_worlds[]
+            for _ in range(30):
+                w.step(1.0 / 60.0, 4, 2, True)
+            got = w.pack()
+            assert L.s2ref_replace_error() == 0
+        assert L.s2ref_world_uploads() - u0 >= 2
+    finally:
+        assert L.s2ref_use_amd_world(None, 0) == 0
+    # the same second world with the solver-only binding (host stage 3 / 4): bit-identical
+    assert L.s2ref_use_amd(hip.LIB_PATH.encode(), 0) == 0
+    try:
+        with refbind.RefWorld("mixed", "PGS", 24, 0) as w:
+            for _ in range(30):
+                w.step(1.0 / 60.0, 4, 2, True)
+            want = w.pack()
+    finally:
+        assert L.s2ref_use_amd(None, 0) == 0
+    common.compare_exact(got, want, "second world in a re-used slot")

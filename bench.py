@@ -179,9 +179,12 @@ def island_sharded_leg(ranks, islands, base, vel, pos, steps, warmup, graph=True
                    "solve_sweeps_per_step": sweeps, "kernel_launches_per_step": st["kernelLaunches"], "lds_groups_this_rank": st["groupCount"],
                    "device_ms_per_step": st["deviceMs"], "graph_replay": bool(st["graphReplayed"]), "trajectory": "consecutive resident steps (no restore)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "groupKernel (whole step of this rank's islands in one launch, bodies in LDS)", "avg_launch_us": us,
+                     "kernel": "islandStepKernel (whole step of this rank's islands in one launch: constraints resident in registers, bodies in "
+                               "LDS, records prepared from and impulses stored to the wire contacts by the kernel itself)", "avg_launch_us": us,
                      "algorithmic_bytes_per_launch": algo,
-                     "byte_model": "136 B per constraint-sweep (SURVEY.md 8d, body state served from LDS) x %d constraints x %d sweeps" % (mine, sweeps)},
+                     "byte_model": "136 B per constraint-sweep (SURVEY.md 8d, body state served from LDS) x %d constraints x %d sweeps" % (mine, sweeps),
+                     "note": "the contract's figure; what the kernel actually moves is one wire record per constraint and STEP (152 B in, 16 B per "
+                             "point out = %.2f GB), so it is VALU-issue bound, not bandwidth bound" % (mine * (152.0 + 32.0) / 1e9)},
     }
 
 

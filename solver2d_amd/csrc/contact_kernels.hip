@@ -42,7 +42,7 @@ __global__ __launch_bounds__(S2_BLOCK) void prepareContactsKernel(ContactView c,
 		return;
 	}
 	int k = blockIdx.x * blockDim.x + threadIdx.x;
-	if (k >= c.count)
+	if (k >= c.count || (k >= c.skipBegin && k < c.skipEnd))
 	{
 		return;
 	}
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(S2_BLOCK) void storeImpulsesKernel(ContactView c, s
 		return;
 	}
 	int k = blockIdx.x * blockDim.x + threadIdx.x;
-	if (k >= c.count)
+	if (k >= c.count || (k >= c.skipBegin && k < c.skipEnd))
 	{
 		return;
 	}

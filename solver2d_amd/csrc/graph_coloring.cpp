@@ -35,10 +35,10 @@ struct ColorMasks
 	std::vector<std::vector<int>> overflow; // colours >= 64*WORDS (rare: bodies with hundreds of constraints)
 };
 
-// balanced (strip groups: one constraint per thread and colour round): a repair pass after the greedy pass
+// balanced > 0 (strip groups and resident islands: one constraint per thread and colour round, `balanced` threads): a repair pass after the greedy pass
 // evens out colours wider than one workgroup.
 int colorGraph(const std::vector<int>& ea, const std::vector<int>& eb, const std::vector<uint8_t>& conflict, int bodyCount,
-			   std::vector<int>& color, bool balanced, std::vector<uint64_t>* bitsOut)
+			   std::vector<int>& color, int balanced, std::vector<uint64_t>* bitsOut)
 {
 	const int W = ColorMasks::WORDS;
 	size_t n = ea.size();
@@ -126,7 +126,7 @@ int colorGraph(const std::vector<int>& ea, const std::vector<int>& eb, const std
 	{
 		// repair pass: greedy fills the low colours first; move constraints out of colours wider than one
 		// workgroup into the least populated colour that is free on both bodies (never adds a colour)
-		const int cap = 256;
+		const int cap = balanced; // the widest colour class a round can take (threads of the workgroup)
 		for (size_t kk = n; kk-- > 0;)
 		{
 			int c = color[kk];

@@ -137,6 +137,8 @@ void launchWarmStartBodies(hipStream_t s, int kind, const ContactView& c, const 
 
 // strip_kernel.hip
 int stripKernelSetup();
+void launchIslandStep(hipStream_t s, int kind, int warm, const ContactView& c, const BodyView& g, const StripTableView& t, const float4* softCoef, const Op* ops,
+					  int opCount, int maxRounds, s2amdContact* wire, const s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart);
 void launchStripSoft(hipStream_t s, int kind, int warm, const ContactView& c, const BodyView& g, const StripTableView& t, const StripOps& ops);
 void launchStripStep(hipStream_t s, int kind, int warm, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv,
 					 const Op* ops, int opCount);

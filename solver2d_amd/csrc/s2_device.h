@@ -349,6 +349,9 @@ struct ContactView
 	float4* deltaB;
 	int* contactIndex; // position k -> index into the wire contact array
 	int count;
+	// positions [skipBegin, skipEnd) are prepared and stored by the resident-island kernel itself, straight from and to the
+	// wire contacts (strip_kernel.hip: islandStepKernel): the prologue / epilogue launches pass them by
+	int skipBegin, skipEnd;
 };
 
 #define S2C_WRITE_A 0x100u

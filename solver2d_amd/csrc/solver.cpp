@@ -144,7 +144,7 @@ void s2amd_destroy(s2amdSolver* s)
 					  &s->dAdjOffsets,	&s->dAdjList,	  &s->dAdjHeavy,	  &s->dGatherIndex,	 &s->dOps,			 &s->dGroups.buf,	&s->dContactTail.buf,
 					  &s->dJointTail.buf, &s->dMsg,			  &s->dStripA.buf,	 &s->dStripB.buf,	 &s->dStripLean,	&s->dPersist,
 					  &s->dGranules,	&s->dPersistOps,	  &s->dShapes,		 &s->dPairs,		 &s->dOrigins,		&s->dStatus,
-					  &s->dPointBytes,	&s->dWorldSummary, &s->dJointedKeys,	 &s->dContactStage, &s->dPairScratch,	  &s->dPairKeys,		 &s->dPatches,		 &s->dScanTmp};
+					  &s->dPointBytes,	&s->dWorldSummary, &s->dJointedKeys,	 &s->dContactStage, &s->dPairScratch,	  &s->dPairKeys,		 &s->dPatches,		 &s->dScanTmp,		 &s->dResident.buf,	 &s->dResidentDesc, &s->dResidentOps};
 	for (DevBuf* b : bufs)
 	{
 		b->release();
@@ -583,6 +583,10 @@ int s2amd_measure_dominant(s2amdSolver* s, const s2amdStepParams* params, int32_
 				q.launchStripGroups(s->dStripB, dominant, 1, false);
 			}
 		}
+		else if (s->dResident.view.groupCount > 0)
+		{
+			q.runResidentGroups(); // the whole step of the resident islands (islandStepKernel, or the interpreter on the same table)
+		}
 		else if (s->dGroups.view.groupCount > 0)
 		{
 			launchGroupKernel(s->stream, s->cv, s->jv, s->bv, s->dGroups.view, q.deviceOps(), (int)plan.ops.size(), plan.sc,
@@ -724,6 +728,12 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	{
 		s->stripsRejected = false;
 		s->optStripsAnySolver = value != 0;
+		s->structureDirty = true;
+	}
+	else if (strcmp(key, "island_resident") == 0)
+	{
+		s->optIslandResident = value != 0;
+		s->residentRejected = false;
 		s->structureDirty = true;
 	}
 	else if (strcmp(key, "incremental") == 0)

@@ -372,6 +372,106 @@ struct Executor
 		return records <= (160 * 1024) / 16;
 	}
 
+	// Can the plan run on the resident-island kernel (strip_kernel.hip: islandStepKernel)?  The soft contact drivers: body
+	// stages, a current- or fixed-anchor warm start, one soft sweep kind; joint sweeps have nothing to do there (the groups
+	// it takes are contact-only).
+	bool residentPlan(int& kind, int& warm) const
+	{
+		kind = -1, warm = -1;
+		if (s->residentView.groupCount <= 0 || p.ops.size() > 128 || p.prepContacts != PREP_SOFT || p.storeKind != STORE_PLAIN)
+		{
+			return false;
+		}
+		for (const Op& o : p.ops)
+		{
+			if (o.code == OP_INTEGRATE_VEL || o.code == OP_INTEGRATE_POS || o.code == OP_FINALIZE || o.code == OP_JOINT_SWEEP)
+			{
+				continue;
+			}
+			if (o.code == OP_WARM && (o.kind == WARM_CURRENT || o.kind == WARM_FIXED) && (warm < 0 || warm == o.kind))
+			{
+				warm = o.kind;
+				continue;
+			}
+			if (leanSoftKind(o) && (kind < 0 || kind == o.kind))
+			{
+				kind = o.kind;
+				continue;
+			}
+			return false;
+		}
+		if (kind < 0)
+		{
+			return false;
+		}
+		if (warm < 0)
+		{
+			warm = kind == SOFT_FIXED ? WARM_FIXED : WARM_CURRENT;
+		}
+		return true;
+	}
+
+	int uploadResidentOps()
+	{
+		if (s->residentOpsGeneration == s->planGeneration)
+		{
+			return 0;
+		}
+		std::vector<Op> kept;
+		for (const Op& o : p.ops)
+		{
+			if (o.code != OP_JOINT_SWEEP)
+			{
+				kept.push_back(o);
+			}
+		}
+		bool grew = false;
+		int rc = s->dResidentOps.ensure(std::max<size_t>(kept.size(), 1) * sizeof(Op), &grew);
+		if (rc)
+		{
+			return rc;
+		}
+		if (grew)
+		{
+			s->layoutGeneration += 1;
+		}
+		if (hipMemcpyAsync(s->dResidentOps.p, kept.data(), kept.size() * sizeof(Op), hipMemcpyHostToDevice, st) != hipSuccess ||
+			hipStreamSynchronize(st) != hipSuccess)
+		{
+			return S2AMD_E_DEVICE;
+		}
+		s->residentOpCount = (int)kept.size();
+		s->residentOpsGeneration = s->planGeneration;
+		return 0;
+	}
+
+	// the groups that were laid out for the resident-island kernel: on it when the plan allows, else through the generic
+	// group interpreter (the table is an ordinary group table too)
+	void runResidentGroups()
+	{
+		if (s->dResident.view.groupCount <= 0)
+		{
+			return;
+		}
+		int kind, warm;
+		if (residentPlan(kind, warm))
+		{
+			float4 coef[2];
+			for (int i = 0; i < 2; ++i)
+			{
+				coef[i] = make_float4(p.sc.softCoef[i][0], p.sc.softCoef[i][1], p.sc.softCoef[i][2], 0.0f);
+			}
+			launchIslandStep(st, kind, warm, s->cv, s->bv, s->residentView, coef, (const Op*)s->dResidentOps.p, s->residentOpCount, s->residentRounds,
+							 wireContacts(), wireBodies(), (const uint32_t*)s->dBodyFlags.p, p.sc.warmStart);
+		}
+		else
+		{
+			launchGroupKernel(st, s->cv, s->jv, s->bv, s->dResident.view, deviceOps(), (int)p.ops.size(), p.sc, wireContacts(), s->dResident.maxBodies,
+							  p.usesDq0 ? 1 : 0);
+		}
+		count();
+	}
+
 	// the plan without the sweeps that have nothing to sweep in the strips (joint sweeps of a contact-only island)
 	int uploadPersistOps()
 	{
@@ -536,9 +636,17 @@ struct Executor
 		// pre: wire -> SoA.  With contacts to prepare, ONE launch does the three independent prologue jobs (prepare
 		// contacts, unpack bodies, manifold.constraintIndex); otherwise the unpack launch carries the index.
 		const bool prepares = p.prepContacts >= 0 && s->cv.count > 0;
+		ContactView cvIo = s->cv; // what the prologue / epilogue launches see
+		{
+			int kind, warm;
+			if (residentPlan(kind, warm))
+			{
+				cvIo.skipBegin = s->residentK0, cvIo.skipEnd = s->residentK1; // the island kernel is its own prologue and epilogue
+			}
+		}
 		if (prepares)
 		{
-			launchPrepareContacts(st, p.prepContacts, s->cv, s->bv, wireContacts(), wireBodies(), p.sc, p.prepH, p.prepHertz, posSolver,
+			launchPrepareContacts(st, p.prepContacts, cvIo, s->bv, wireContacts(), wireBodies(), p.sc, p.prepH, p.prepHertz, posSolver,
 								  (const uint32_t*)s->dBodyFlags.p, true, p.unpackH, s->contactCapacity, gatherIndex);
 			count();
 		}
@@ -564,6 +672,7 @@ struct Executor
 							  p.usesDq0 ? 1 : 0);
 			count();
 		}
+		runResidentGroups();
 		if (s->dStripA.view.groupCount > 0)
 		{
 			runStrips();
@@ -617,7 +726,7 @@ struct Executor
 		// post: SoA -> wire: impulses and bodies in one launch (+ the epoch base of the hand-off tags)
 		int kind, warm;
 		const bool usedGranules = s->dStripA.view.groupCount > 0 && persistPlan(kind, warm);
-		launchStoreImpulses(st, p.storeKind, s->cv, wireContacts(), p.storeScale, s->bv, wireBodies(), usedGranules ? s->dGranules.p : nullptr,
+		launchStoreImpulses(st, p.storeKind, cvIo, wireContacts(), p.storeScale, s->bv, wireBodies(), usedGranules ? s->dGranules.p : nullptr,
 							usedGranules ? s->granuleBytes : 0, usedGranules ? s->persist.deviceError : nullptr);
 		count();
 		if (s->jv.count > 0)

@@ -80,7 +80,7 @@ struct DevBuf
 bool isPositionSolver(int type);
 bool rotIsFixedPoint(float s, float c);
 int colorGraph(const std::vector<int>& ea, const std::vector<int>& eb, const std::vector<uint8_t>& conflict, int bodyCount,
-			   std::vector<int>& color, bool balanced = false, std::vector<uint64_t>* bitsOut = nullptr);
+			   std::vector<int>& color, int balanced = 0, std::vector<uint64_t>* bitsOut = nullptr);
 void sortByColor(const std::vector<int>& ids, const std::vector<int>& color, int colorCount, std::vector<int>& order, std::vector<int>& offsets);
 bool makeBatches(const std::vector<int>& colorOffsets, std::vector<int>& batchOffsets, bool allowTail = true);
 uint64_t fnv(uint64_t h, const void* data, size_t n);
@@ -251,6 +251,17 @@ struct s2amdSolver
 	SweepSet contacts, joints;
 	HostGroupTable hGroups, hContactTail, hJointTail, hStripA, hStripB;
 	DeviceGroupTable dGroups, dContactTail, dJointTail, dStripA, dStripB;
+	// resident islands (strip_kernel.hip: islandStepKernel): LDS groups whose constraints stay in registers for the whole step
+	HostGroupTable hResident;
+	DeviceGroupTable dResident;
+	DevBuf dResidentDesc, dResidentOps;
+	StripTableView residentView{};
+	int residentRounds = 0;
+	int residentK0 = 0, residentK1 = 0; // their range in contacts.order
+	bool residentRejected = false; // some group's colouring needs more rounds than the kernel holds: plain LDS groups for this graph
+	uint64_t residentOpsGeneration = ~0ull;
+	int residentOpCount = 0;
+	int optIslandResident = 1;
 	// lean strip tables (strip_kernel.hip): descriptors of both phases, warm-start slots of phase A
 	DevBuf dStripLean;
 	StripTableView leanA{}, leanB{};
@@ -285,6 +296,7 @@ struct s2amdSolver
 	int looseBodies = 0; // live non-static bodies that no LDS group owns
 	int orderSolverClass = -1; // 0 velocity colouring, 1 position colouring
 	bool orderGrouped = false;
+	bool orderResident = false; // the groups were laid out for the resident-island kernel where they fit
 	bool orderStrips = false;
 	bool stripsNeedOneLaunch = false; // a moving read-only body is shared between strips: persistent kernel or no strips at all
 	bool stripsRejected = false; // this graph's strip partition fits no strip kernel: colour batches until the graph changes
@@ -349,6 +361,7 @@ inline void noteGraphChanged(s2amdSolver* s, bool newWorld = false)
 	}
 	s->graphAge = 0;
 	s->stripsRejected = false;
+	s->residentRejected = false;
 	s->structureDirty = true;
 }
 

@@ -328,6 +328,13 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 			return fail(S2AMD_E_DEVICE, "could not upload the persistent step plan");
 		}
 	}
+	{
+		int kind, warm;
+		if (q.residentPlan(kind, warm) && q.uploadResidentOps() != 0)
+		{
+			return fail(S2AMD_E_DEVICE, "could not upload the resident-island step plan");
+		}
+	}
 	s->launchCounter = 0;
 	s->sweepEventsUsed = 0;
 
@@ -456,7 +463,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	s->stats.jointColors = (int)s->joints.colorOffsets.size() - 1;
 	s->stats.solveSweeps = plan.solveSweeps;
 	s->stats.kernelLaunches = s->launchCounter;
-	s->stats.groupCount = s->dGroups.view.groupCount;
+	s->stats.groupCount = s->dGroups.view.groupCount + s->dResident.view.groupCount;
 	s->stats.stripCount = s->dStripA.view.groupCount;
 	s->stats.seamCount = s->dStripB.view.groupCount;
 	{

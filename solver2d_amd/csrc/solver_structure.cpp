@@ -194,7 +194,7 @@ struct EdgeList
 // behind its constraints -- and the colouring state is kept in *inc, so that created contacts can be placed without a
 // rebuild (IncrementalGlobal, solver_incremental.cpp).  *positions then has -1 at the free positions.
 void colourPart(const std::vector<int>& ids, const std::vector<int>& ea, const std::vector<int>& eb, const std::vector<uint8_t>& conflict,
-				int bodyCount, SweepSet& set, std::vector<int>& batchOffsetsOut, bool& hasTailOut, std::vector<int>* positions, bool balanced = false,
+				int bodyCount, SweepSet& set, std::vector<int>& batchOffsetsOut, bool& hasTailOut, std::vector<int>* positions, int balanced = 0,
 				IncrementalGlobal* inc = nullptr, int spareColours = 0)
 {
 	std::vector<int> color, partOrder, partOffsets;
@@ -207,7 +207,7 @@ void colourPart(const std::vector<int>& ids, const std::vector<int>& ea, const s
 	}
 	sortByColor(pos, color, cc, partOrder, partOffsets);
 	std::vector<int> rel;
-	hasTailOut = makeBatches(partOffsets, rel, !balanced);
+	hasTailOut = makeBatches(partOffsets, rel, balanced == 0);
 	int base = (int)set.order.size();
 	if (set.colorOffsets.empty())
 	{
@@ -1214,6 +1214,69 @@ do                                                                              
 	return rc;
 }
 
+// Descriptors of the resident islands (strip_kernel.hip: islandStepKernel reads one StripDesc per workgroup).  Sets
+// s->residentRejected when a group does not fit the kernel (rounds, round width, body chunks, LDS).
+static int buildResidentTables(s2amdSolver* s)
+{
+	const HostGroupTable& t = s->hResident;
+	s->residentView = StripTableView{};
+	s->residentRounds = 0;
+	if (t.count() == 0)
+	{
+		return S2AMD_OK;
+	}
+	std::vector<StripDesc> descs((size_t)t.count());
+	int ldsRecords = 0;
+	bool ok = true;
+	for (int g = 0; g < t.count() && ok; ++g)
+	{
+		StripDesc& d = descs[(size_t)g];
+		memset(&d, 0, sizeof(d));
+		d.bodyBase = t.bodyOffsets[(size_t)g];
+		d.bodyCount = t.bodyOffsets[(size_t)g + 1] - d.bodyBase;
+		const int b0 = t.cBatchOffsets[(size_t)g], b1 = t.cBatchOffsets[(size_t)g + 1];
+		d.batchCount = b1 - b0;
+		ok = d.batchCount <= S2_STRIP_ROUNDS_MAX && d.bodyCount <= S2_STRIP_BODY_CHUNKS * 512;
+		for (int b = b0; b < b1 && ok; ++b)
+		{
+			const int4 bt = t.cBatches[(size_t)b];
+			ok = bt.z == 0 && bt.y - bt.x <= 512;
+			d.batch[b - b0] = make_int4(bt.x, bt.y, 0, 0);
+		}
+		while (d.ownedCount < d.bodyCount && ((uint32_t)t.bodyIds[(size_t)d.bodyBase + d.ownedCount] & S2G_OWNED) != 0)
+		{
+			d.ownedCount += 1;
+		}
+		const int nbG = d.bodyCount;
+		const int records = 3 * nbG + (nbG + 3) / 4 + (nbG + 1) / 2;
+		ok = ok && (size_t)records * 16 + 128 * sizeof(Op) <= 160 * 1024;
+		ldsRecords = std::max(ldsRecords, records);
+		s->residentRounds = std::max(s->residentRounds, d.batchCount);
+	}
+	if (!ok)
+	{
+		s->residentRejected = true;
+		return S2AMD_OK;
+	}
+	bool grew = false;
+	int rc = s->dResidentDesc.ensure(descs.size() * sizeof(StripDesc), &grew);
+	if (rc)
+	{
+		return rc;
+	}
+	if (grew)
+	{
+		s->layoutGeneration += 1;
+	}
+	HIP_TRY(hipMemcpyAsync(s->dResidentDesc.p, descs.data(), descs.size() * sizeof(StripDesc), hipMemcpyHostToDevice, s->stream));
+	HIP_TRY(hipStreamSynchronize(s->stream)); // descs is a local
+	s->residentView.descs = (const StripDesc*)s->dResidentDesc.p;
+	s->residentView.bodyIds = s->dResident.view.bodyIds;
+	s->residentView.groupCount = t.count();
+	s->residentView.ldsRecords = ldsRecords;
+	return S2AMD_OK;
+}
+
 static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 {
 	const int cls = isPositionSolver(solverType) ? 1 : 0;
@@ -1225,7 +1288,10 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 							 solverType == s2amd_solverPGS_Soft);
 	// (contacts placed into a structure built for s2Solve_Jacobi took any free position, whatever its colour: only Jacobi can run on that)
 	const bool colourFree = s->inc.colourFreePlaced && !needAdj;
-	if (!s->structureDirty && cls == s->orderSolverClass && grouped == s->orderGrouped && wantStrips == s->orderStrips && s->adjValid && !colourFree)
+	const bool softFamily = solverType == s2amd_solverTGS_Soft || solverType == s2amd_solverSoftStep || solverType == s2amd_solverPGS_Soft;
+	const bool residentWanted = grouped && softFamily && s->optIslandResident != 0 && !s->residentRejected;
+	if (!s->structureDirty && cls == s->orderSolverClass && grouped == s->orderGrouped && wantStrips == s->orderStrips && s->adjValid && !colourFree &&
+		residentWanted == s->orderResident)
 	{
 		return S2AMD_OK;
 	}
@@ -1418,6 +1484,7 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 	cs.colorOffsets.push_back(0);
 	js.colorOffsets.push_back(0);
 	s->hGroups.clear();
+	s->hResident.clear();
 	s->hContactTail.clear();
 	s->hJointTail.clear();
 	s->hStripA.clear();
@@ -1612,7 +1679,7 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 		s->inc = IncrementalGlobal();
 		const bool slack = s->optIncremental != 0 && s->optMessage == 0;
 		s->inc.ignoreColours = needAdj;
-		colourPart(ids, a, b, conflict, nb, cs, cs.batchOffsets, cs.hasTail, &pos, false, slack ? &s->inc : nullptr, needAdj ? 0 : s->spareColours);
+		colourPart(ids, a, b, conflict, nb, cs, cs.batchOffsets, cs.hasTail, &pos, 0, slack ? &s->inc : nullptr, needAdj ? 0 : s->spareColours);
 		cs.globalCount = (int)cs.order.size(); // (with the free positions of the slack layout)
 		cs.local.assign((size_t)cs.globalCount, make_int2(0, 0));
 		if (slack)
@@ -1723,7 +1790,10 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 		{
 			lconf[i] = conflict[(size_t)((uint32_t)bodies[i] & ~S2G_OWNED)];
 		}
-		colourPart(ids, la, lb, lconf, (int)bodies.size(), cs, batchOffsets, tail, &pos, &t != &s->hGroups);
+		// strips: a round is one constraint per thread of a 256-thread workgroup, wider colour classes are evened out and cut.
+		// LDS groups and resident islands keep the plain greedy colouring: an island's sweep order must not depend on which
+		// other islands share its group (a world sharded over several GPUs packs them differently and must sweep the same).
+		colourPart(ids, la, lb, lconf, (int)bodies.size(), cs, batchOffsets, tail, &pos, (&t == &s->hGroups || &t == &s->hResident) ? 0 : 256);
 		for (size_t i = 0; i < pos.size(); ++i)
 		{
 			cs.local.push_back(make_int2(la[(size_t)pos[i]], lb[(size_t)pos[i]]));
@@ -1764,11 +1834,69 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 	};
 
 	// LDS groups: whole-step kernel, bodies in LDS
+	// ... or, under the soft contact solvers, RESIDENT islands: the same groups with their constraints in the registers of
+	// one 512-thread workgroup for the whole step (strip_kernel.hip: islandStepKernel) -- contact-only groups whose colouring
+	// fits the kernel's rounds; the others stay plain LDS groups
 	const std::vector<int> noSeed;
+	const bool softSolver = solverType == s2amd_solverTGS_Soft || solverType == s2amd_solverSoftStep || solverType == s2amd_solverPGS_Soft;
+	const bool wantResident = grouped && softSolver && s->optIslandResident != 0 && !s->residentRejected;
+	// does the greedy colouring of this group fit the resident kernel: at most 8 rounds of at most 512 constraints, no
+	// sequential tail?  (The same colouring emitGroup will produce: a dry run on the pool indices.)
+	auto fitsResident = [&](const std::vector<int>& cKs) {
+		std::vector<int> a, b, color;
+		a.reserve(cKs.size()), b.reserve(cKs.size());
+		for (int k : cKs)
+		{
+			a.push_back(ce.a[k]), b.push_back(ce.b[k]);
+		}
+		const int cc = colorGraph(a, b, conflict, nb, color);
+		if (cc > S2_STRIP_ROUNDS_MAX)
+		{
+			return false;
+		}
+		int population[S2_STRIP_ROUNDS_MAX] = {0};
+		for (int c : color)
+		{
+			if (++population[c] > 512)
+			{
+				return false;
+			}
+		}
+		return true;
+	};
+	std::vector<uint8_t> residentGroup((size_t)groupCount, 0);
 	for (int g = 0; g < groupCount; ++g)
 	{
-		emitGroup(s->hGroups, cOf[(size_t)g + 1], jOf[(size_t)g + 1], noSeed);
+		const std::vector<int>& cKs = cOf[(size_t)g + 1];
+		residentGroup[(size_t)g] = wantResident && jOf[(size_t)g + 1].empty() && !cKs.empty() && cKs.size() <= (size_t)S2_STRIP_ROUNDS_MAX * 512 && fitsResident(cKs);
+		if (!residentGroup[(size_t)g])
+		{
+			emitGroup(s->hGroups, cKs, jOf[(size_t)g + 1], noSeed);
+		}
 	}
+	s->residentK0 = (int)cs.order.size(); // the resident islands' constraints are one range of the sweep order
+	for (int g = 0; g < groupCount; ++g)
+	{
+		const std::vector<int>& cKs = cOf[(size_t)g + 1];
+		if (residentGroup[(size_t)g])
+		{
+			std::vector<int> seed; // the bodies the group owns (its sweeps write them), in order of first use: they lead the body list
+			slots.begin();
+			for (int k : cKs)
+			{
+				for (int body : {ce.a[k], ce.b[k]})
+				{
+					if (body >= 0 && conflict[(size_t)body] && slots.stamp[(size_t)body] != slots.epoch)
+					{
+						slots.stamp[(size_t)body] = slots.epoch;
+						seed.push_back(body);
+					}
+				}
+			}
+			emitGroup(s->hResident, cKs, jOf[(size_t)g + 1], seed);
+		}
+	}
+	s->residentK1 = (int)cs.order.size();
 
 	// strips of the big islands: phase A = interiors (own every body of the strip), phase B = seams
 	const int stripBaseC = (int)cs.order.size(), stripBaseJ = (int)js.order.size();
@@ -1849,9 +1977,20 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 	s->cv.contactIndex = (int*)s->dContactIndex.p;
 	s->cv.localBodies = (int2*)s->dContactLocal.p;
 	s->cv.count = CP;
+	s->cv.skipBegin = s->cv.skipEnd = 0; // (set per step by the executor when the resident-island kernel runs)
 	s->jv.jointIndex = (int*)s->dJointIndex.p;
 	s->jv.localBodies = (int2*)s->dJointLocal.p;
 	s->jv.count = J;
+	if ((rc = uploadGroupTable(s, s->hResident, s->dResident)) != 0 || (rc = buildResidentTables(s)) != 0)
+	{
+		return rc;
+	}
+	if (s->residentRejected && s->hResident.count() > 0)
+	{
+		// some island needs more colour rounds than the resident kernel holds: all of them as plain LDS groups for this graph
+		s->structureDirty = true;
+		return buildStructureWith(s, solverType, stripScale);
+	}
 	if ((rc = uploadGroupTable(s, s->hGroups, s->dGroups)) != 0 || (rc = uploadGroupTable(s, s->hContactTail, s->dContactTail)) != 0 ||
 		(rc = uploadGroupTable(s, s->hJointTail, s->dJointTail)) != 0 || (rc = uploadGroupTable(s, s->hStripA, s->dStripA)) != 0 ||
 		(rc = uploadGroupTable(s, s->hStripB, s->dStripB)) != 0)
@@ -1918,6 +2057,7 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 	s->inc.valid = s->optIncremental != 0 && s->inc.solverClass == cls && !s->msgTablesValid && !s->inc.positionOfSlot.empty();
 	s->inc.patches.clear();
 	s->orderSolverClass = cls;
+	s->orderResident = residentWanted;
 	s->orderGrouped = grouped;
 	s->orderStrips = wantStrips;
 	s->structureDirty = false;

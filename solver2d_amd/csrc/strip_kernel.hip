@@ -982,6 +982,328 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 	}
 }
 
+// s2PrepareContacts_Soft (solve_common.c:188-274) for ONE constraint straight from its wire record: the operations of
+// prepareContactsKernel<PREP_SOFT> (contact_kernels.hip) in the same order, so the same bits -- but the prepared record
+// goes into the caller's registers instead of through the SoA arrays.  Body data: rotation and inverse masses from the
+// LDS copies (== the wire body's: body_ops.h unpackBodyOne), local centres from the wire bodies.
+template <int KIND, class BA>
+S2_DEV SoftRegs<KIND> prepareSoftFromWire(const s2amdContact* contact, const s2amdBody* wireBodies, const uint32_t* hostFlags, const BA& lb, const float2* lmass,
+										  int2 local, int bodyCapacity, int warmStart)
+{
+	SoftRegs<KIND> r;
+	int pointCount = contact->pointCount;
+	int ia = contact->bodyA, ib = contact->bodyB;
+	if (pointCount <= 0 && (ia < 0 || ib < 0 || ia >= bodyCapacity || ib >= bodyCapacity))
+	{
+		pointCount = 0, ia = 0, ib = 0; // a destroyed contact whose entry lingers (prepareContactsKernel has the same guard)
+	}
+	pointCount = pointCount > 0 ? pointCount : 0;
+	const V2 normal = v2(contact->normal[0], contact->normal[1]);
+	const V2 tangent = rightPerp(normal);
+	const s2amdBody* wa = wireBodies + ia;
+	const s2amdBody* wb = wireBodies + ib;
+	const V2 lcA = v2(wa->localCenter[0], wa->localCenter[1]);
+	const V2 lcB = v2(wb->localCenter[0], wb->localCenter[1]);
+	const float2 massA = lmass[local.x], massB = lmass[local.y];
+	const float mA = massA.x, iA = massA.y, mB = massB.x, iB = massB.y;
+	const Rot qA = loadPose(lb, local.x).q, qB = loadPose(lb, local.y).q;
+	r.h.ia = local.x, r.h.ib = local.y;
+	r.h.mA = mA, r.h.iA = iA, r.h.mB = mB, r.h.iB = iB;
+	r.h.normal = normal;
+	r.h.friction = contact->friction;
+	r.h.pointCount = pointCount;
+	r.h.writeA = pointCount > 0 && (hostFlags[ia] & S2F_WRITE_VEL) != 0; // (the soft solvers are velocity-class sweeps)
+	r.h.writeB = pointCount > 0 && (hostFlags[ib] & S2F_WRITE_VEL) != 0;
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		r.an[j] = zero, r.r0[j] = zero, r.par[j] = zero, r.sf[j] = zero;
+		r.imp[j] = make_float2(0.0f, 0.0f);
+		if (j < pointCount)
+		{
+			const s2amdManifoldPoint* mp = contact->points + j;
+			if (warmStart)
+			{
+				r.imp[j] = make_float2(mp->normalImpulse, mp->tangentImpulse);
+			}
+			V2 lA = sub(v2(mp->localAnchorA[0], mp->localAnchorA[1]), lcA);
+			V2 lB = sub(v2(mp->localAnchorB[0], mp->localAnchorB[1]), lcB);
+			V2 rA = rotate(qA, lA);
+			V2 rB = rotate(qB, lB);
+			float separation = mp->separation;
+			float adjustedSeparation = separation - dot(sub(rB, rA), normal);
+			float rtA = cross(rA, tangent);
+			float rtB = cross(rB, tangent);
+			float kTangent = mA + mB + iA * rtA * rtA + iB * rtB * rtB;
+			float tangentMass = kTangent > 0.0f ? 1.0f / kTangent : 0.0f;
+			float rnA = cross(rA, normal);
+			float rnB = cross(rB, normal);
+			float kNormal = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+			float normalMass = kNormal > 0.0f ? 1.0f / kNormal : 0.0f;
+			r.an[j] = make_float4(lA.x, lA.y, lB.x, lB.y);
+			r.r0[j] = make_float4(rA.x, rA.y, rB.x, rB.y);
+			r.par[j] = make_float4(adjustedSeparation, normalMass, tangentMass, separation);
+		}
+	}
+	return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Resident island step: the persistent strip step without seams.  An LDS group -- one or several small simulation
+// islands (a base-40 pyramid: 820 boxes, 2,380 constraints) -- is advanced through the WHOLE s2Solve_* by one workgroup
+// that keeps the group's constraints in REGISTERS (PersistRegs, one per colour round and thread) and its bodies in LDS.
+// Islands exchange nothing, so there are no hand-offs, no co-residency requirement and no limit on the number of
+// workgroups.  Against groupKernel (group_kernel.hip), which streams every constraint record from its SoA arrays in
+// every sweep (120 B per constraint-sweep, 24 sweeps per TGS_Soft 8/4 step: bound by the Infinity Cache at 512 groups),
+// a record is read ONCE per step.  THREADS = 512: two waves per SIMD, a colour round holds up to 512 constraints.
+// ------------------------------------------------------------------------------------------------
+// The kernel also is its own prologue and epilogue for these constraints: records are prepared from the wire contacts and
+// the impulses go back into them (s2StoreContactImpulses, solve_common.c:396-410) -- no SoA round trip at all.
+template <int KIND, int WARM, int ROUNDS, int THREADS>
+__global__ __launch_bounds__(THREADS) void islandStepKernel(ContactView c, BodyView g, StripTableView ta, float4 softCoef0, float4 softCoef1, const Op* ops,
+															 int opCount, s2amdContact* wire, const s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart)
+{
+	extern __shared__ __attribute__((aligned(16))) float4 lds[];
+	const int tid = (int)threadIdx.x;
+	const StripDesc* da = ta.descs + blockIdx.x;
+	const int bodyBase = da->bodyBase, nb = da->bodyCount, roundsA = da->batchCount;
+	int4 batchA[ROUNDS];
+#pragma unroll
+	for (int i = 0; i < ROUNDS; ++i)
+	{
+		batchA[i] = da->batch[i];
+	}
+	float4* lvel = lds;
+	float4* ldq = lds + nb;
+	float4* linteg = lds + 2 * nb;
+	float* langDamp = (float*)(lds + 3 * nb);
+	float2* lmass = (float2*)(lds + 3 * nb + (nb + 3) / 4);
+	const int bodyRecords = 3 * nb + (nb + 3) / 4 + (nb + 1) / 2;
+	Op* lops = (Op*)(lds + bodyRecords);
+
+	uint32_t id[S2_STRIP_BODY_CHUNKS];
+#pragma unroll
+	for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS; ++ch)
+	{
+		int i = tid + ch * THREADS;
+		id[ch] = i < nb ? (uint32_t)ta.bodyIds[bodyBase + i] : 0u;
+	}
+	for (int i = tid; i < opCount * 8; i += THREADS)
+	{
+		((int*)lops)[i] = ((const int*)ops)[i];
+	}
+	PersistRegs<KIND, WARM> rA[ROUNDS];
+	auto kOfRound = [&](int i) {
+		int k = batchA[i].x + tid;
+		return (i < roundsA && k < batchA[i].y) ? k : -1;
+	};
+	// this thread's constraints: pool slot and group-local body slots (the wire records follow once the bodies are staged)
+	int slotOf[ROUNDS];
+	int2 localOf[ROUNDS];
+#pragma unroll
+	for (int i = 0; i < ROUNDS; ++i)
+	{
+		slotOf[i] = -1;
+		localOf[i] = make_int2(0, 0);
+		if (kOfRound(i) >= 0)
+		{
+			slotOf[i] = c.contactIndex[kOfRound(i)];
+			localOf[i] = c.localBodies[kOfRound(i)];
+		}
+	}
+	uint32_t flags[S2_STRIP_BODY_CHUNKS];
+#pragma unroll
+	for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS; ++ch)
+	{
+		const int i = tid + ch * THREADS;
+		flags[ch] = 0u;
+		if (i < nb)
+		{
+			const int gi = (int)(id[ch] & ~S2G_OWNED);
+			lvel[i] = g.vel[gi];
+			ldq[i] = g.dq[gi];
+			flags[ch] = g.flags[gi] | 0x80000000u;
+			linteg[i] = g.integ[gi];
+			langDamp[i] = g.angDamp[gi];
+			lmass[i] = g.massInv[gi];
+		}
+	}
+	__syncthreads();
+
+	LdsBodies lb{lvel, ldq};
+	PersistShared shared;
+	shared.massInv = lmass;
+	shared.softCoef[0] = softCoef0, shared.softCoef[1] = softCoef1;
+#pragma unroll
+	for (int i = 0; i < ROUNDS; ++i)
+	{
+		if (slotOf[i] >= 0)
+		{
+			SoftRegs<KIND> t = prepareSoftFromWire<KIND>(wire + slotOf[i], wireBodies, hostFlags, lb, lmass, localOf[i], g.capacity, warmStart);
+			rA[i] = packPersist<KIND, WARM>(t, localOf[i].x, localOf[i].y);
+		}
+	}
+	for (int oi = 0; oi < opCount; ++oi)
+	{
+		const Op op = lops[oi];
+		uint32_t salt;
+		asm volatile("s_mov_b32 %0, 0" : "=s"(salt));
+		if (op.code == OP_INTEGRATE_VEL)
+		{
+#pragma unroll
+			for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS; ++ch)
+			{
+				if ((flags[ch] & S2F_DYNAMIC) != 0)
+				{
+					const int i = tid + ch * THREADS;
+					float4 v = lvel[i], k = linteg[i];
+					V2 lv = add(v2(v.x, v.y), v2(k.x, k.y));
+					float w = v.z + k.z;
+					lv = mulSV(k.w, lv);
+					w *= langDamp[i];
+					lvel[i] = make_float4(lv.x, lv.y, w, 0.0f);
+				}
+			}
+			__syncthreads();
+		}
+		else if (op.code == OP_INTEGRATE_POS)
+		{
+#pragma unroll
+			for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS; ++ch)
+			{
+				if ((flags[ch] & S2F_MOVES) != 0)
+				{
+					const int i = tid + ch * THREADS;
+					float4 v = lvel[i], d = ldq[i];
+					V2 dpos = mulAdd(v2(d.x, d.y), op.h, v2(v.x, v.y));
+					Rot q;
+					q.s = d.z, q.c = d.w;
+					q = integrateRot(q, op.h * v.z);
+					ldq[i] = make_float4(dpos.x, dpos.y, q.s, q.c);
+				}
+			}
+			__syncthreads();
+		}
+		else if (op.code == OP_FINALIZE)
+		{
+#pragma unroll
+			for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS; ++ch)
+			{
+				if (flags[ch] != 0u)
+				{
+					finalizePositionsOne(lb, tid + ch * THREADS, g, (int)(id[ch] & ~S2G_OWNED), op.flag, (id[ch] & S2G_OWNED) != 0);
+				}
+			}
+			__syncthreads();
+		}
+		else if (op.code == OP_WARM)
+		{
+#pragma unroll
+			for (int i = 0; i < ROUNDS; ++i)
+			{
+				if (i < roundsA)
+				{
+					if (kOfRound(i) >= 0)
+					{
+						warmSoftRegs<WARM>(unpackPersist<KIND, WARM>(rA[i], shared, salt), lb);
+					}
+					__syncthreads();
+				}
+			}
+		}
+		else if (op.code == OP_SOLVE_SOFT)
+		{
+#pragma unroll
+			for (int i = 0; i < ROUNDS; ++i)
+			{
+				if (i < roundsA)
+				{
+					if (kOfRound(i) >= 0)
+					{
+						sweepPersist<KIND, WARM, 0>(rA[i], shared, c, lb, op.inv_h, op.useBias, kOfRound(i), salt);
+					}
+					__syncthreads();
+				}
+			}
+		}
+	}
+#pragma unroll
+	for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS; ++ch)
+	{
+		int i = tid + ch * THREADS;
+		if (i < nb && (id[ch] & S2G_OWNED) != 0)
+		{
+			int gi = (int)(id[ch] & ~S2G_OWNED);
+			g.vel[gi] = lvel[i];
+			g.dq[gi] = ldq[i];
+		}
+	}
+	// s2StoreContactImpulses (solve_common.c:396-410): straight into the manifolds
+#pragma unroll
+	for (int i = 0; i < ROUNDS; ++i)
+	{
+		if (slotOf[i] >= 0)
+		{
+			const int pointCount = (int)((rA[i].idx >> 28) & 3u);
+			s2amdContact* contact = wire + slotOf[i];
+#pragma unroll
+			for (int j = 0; j < 2; ++j)
+			{
+				if (j < pointCount)
+				{
+					contact->points[j].normalImpulse = rA[i].imp[j].x;
+					contact->points[j].tangentImpulse = rA[i].imp[j].y;
+				}
+			}
+		}
+	}
+}
+
+#define S2_ISLAND_THREADS 512
+template <int KIND, int WARM>
+static void launchIsland(hipStream_t s, dim3 grid, size_t lds, const ContactView& c, const BodyView& g, const StripTableView& t, const float4* coef, const Op* ops,
+						 int opCount, int rounds, s2amdContact* wire, const s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart)
+{
+	if (rounds <= S2_STRIP_ROUNDS)
+	{
+		islandStepKernel<KIND, WARM, S2_STRIP_ROUNDS, S2_ISLAND_THREADS>
+			<<<grid, dim3(S2_ISLAND_THREADS), lds, s>>>(c, g, t, coef[0], coef[1], ops, opCount, wire, wireBodies, hostFlags, warmStart);
+	}
+	else
+	{
+		islandStepKernel<KIND, WARM, S2_STRIP_ROUNDS_MAX, S2_ISLAND_THREADS>
+			<<<grid, dim3(S2_ISLAND_THREADS), lds, s>>>(c, g, t, coef[0], coef[1], ops, opCount, wire, wireBodies, hostFlags, warmStart);
+	}
+}
+
+// t.ldsRecords: body records of the largest group; maxRounds: colour rounds of the group with the most
+void launchIslandStep(hipStream_t s, int kind, int warm, const ContactView& c, const BodyView& g, const StripTableView& t, const float4* softCoef, const Op* ops,
+					  int opCount, int maxRounds, s2amdContact* wire, const s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart)
+{
+	if (t.groupCount <= 0)
+	{
+		return;
+	}
+	dim3 grid((unsigned)t.groupCount);
+	size_t lds = (size_t)t.ldsRecords * sizeof(float4) + (size_t)opCount * sizeof(Op);
+	if (kind == SOFT_TGS)
+	{
+		warm == WARM_FIXED ? launchIsland<SOFT_TGS, WARM_FIXED>(s, grid, lds, c, g, t, softCoef, ops, opCount, maxRounds, wire, wireBodies, hostFlags, warmStart)
+						   : launchIsland<SOFT_TGS, WARM_CURRENT>(s, grid, lds, c, g, t, softCoef, ops, opCount, maxRounds, wire, wireBodies, hostFlags, warmStart);
+	}
+	else if (kind == SOFT_PGS)
+	{
+		warm == WARM_FIXED ? launchIsland<SOFT_PGS, WARM_FIXED>(s, grid, lds, c, g, t, softCoef, ops, opCount, maxRounds, wire, wireBodies, hostFlags, warmStart)
+						   : launchIsland<SOFT_PGS, WARM_CURRENT>(s, grid, lds, c, g, t, softCoef, ops, opCount, maxRounds, wire, wireBodies, hostFlags, warmStart);
+	}
+	else
+	{
+		warm == WARM_FIXED ? launchIsland<SOFT_FIXED, WARM_FIXED>(s, grid, lds, c, g, t, softCoef, ops, opCount, maxRounds, wire, wireBodies, hostFlags, warmStart)
+						   : launchIsland<SOFT_FIXED, WARM_CURRENT>(s, grid, lds, c, g, t, softCoef, ops, opCount, maxRounds, wire, wireBodies, hostFlags, warmStart);
+	}
+}
+
 template <int KIND, int WARM>
 static void launchStep(hipStream_t s, dim3 grid, size_t lds, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv,
 					   const Op* ops, int opCount)
@@ -1094,6 +1416,21 @@ int stripKernelSetup()
 		S2_STEP_VARIANTS(SOFT_PGS, WARM_FIXED),		S2_STEP_VARIANTS(SOFT_FIXED, WARM_CURRENT), S2_STEP_VARIANTS(SOFT_FIXED, WARM_FIXED),
 #undef S2_STEP_VARIANTS
 	};
+	const void* islands[] = {
+#define S2_ISLAND_VARIANTS(K, W)                                                                                                 \
+	(const void*)islandStepKernel<K, W, S2_STRIP_ROUNDS, S2_ISLAND_THREADS>, (const void*)islandStepKernel<K, W, S2_STRIP_ROUNDS_MAX, S2_ISLAND_THREADS>
+		S2_ISLAND_VARIANTS(SOFT_TGS, WARM_CURRENT),	 S2_ISLAND_VARIANTS(SOFT_TGS, WARM_FIXED),	 S2_ISLAND_VARIANTS(SOFT_PGS, WARM_CURRENT),
+		S2_ISLAND_VARIANTS(SOFT_PGS, WARM_FIXED),	 S2_ISLAND_VARIANTS(SOFT_FIXED, WARM_CURRENT), S2_ISLAND_VARIANTS(SOFT_FIXED, WARM_FIXED),
+#undef S2_ISLAND_VARIANTS
+	};
+	for (const void* f : islands)
+	{
+		hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		if (e != hipSuccess)
+		{
+			return (int)e;
+		}
+	}
 	for (const void* f : steps)
 	{
 		hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

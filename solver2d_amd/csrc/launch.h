@@ -146,7 +146,7 @@ void launchStripStep(hipStream_t s, int kind, int warm, const ContactView& c, co
 // stage kernels on resident arrays (narrowphase.hip, broadphase.hip; called by world.hip)
 // summary: int[5] {separated pairs, active manifolds, zero/non-zero flips, point-count moves, enlarged shapes} (world.hip: WorldSummary)
 void launchUpdateContacts(hipStream_t st, const s2amdBody* bodies, const float* origins, const s2amdShape* shapes, s2amdPairState* pairs,
-						  s2amdContact* contacts, int contactCapacity, int32_t* status, uint8_t* pointBytes, int* summary, int* separatedSlots);
+						  s2amdContact* contacts, int contactCapacity, int32_t* status, uint8_t* pointBytes, int* summary, int* separatedSlots, const uint8_t* watched);
 // stage 4 in one launch: refit per shape (origin recomputed from the body), origins + force reset per body, summary[4] += enlarged shapes
 void launchStage4(hipStream_t st, s2amdBody* bodies, int bodyCapacity, s2amdShape* shapes, int shapeCapacity, float* origins, int* summary);
 // stage 1 on resident arrays: new pairs sorted by (A, B) into the host array outPairs; dJointed: sorted (min body << 32 | max body) keys

@@ -897,7 +897,7 @@ S2_DEV int updateContactOne(const s2amdBody* bodies, const float2* origins, cons
 template <bool SUMMARY>
 __global__ __launch_bounds__(S2_NP_BLOCK) void updateContactsKernel(const s2amdBody* bodies, const float2* origins, const s2amdShape* shapes,
 																	 s2amdPairState* pairs, s2amdContact* contacts, int contactCapacity, int32_t* status,
-																	 uint8_t* pointBytes, int* summary, int* separatedSlots)
+																	 uint8_t* pointBytes, int* summary, int* separatedSlots, const uint8_t* watched)
 {
 	__shared__ float2 lds[4 * S2_NP_MAX_VERTS * S2_NP_BLOCK]; // vertsA, normsA, vertsB, normsB: 32 KiB
 	int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -928,6 +928,10 @@ __global__ __launch_bounds__(S2_NP_BLOCK) void updateContactsKernel(const s2amdB
 				if ((old > 0) != (pc > 0))
 				{
 					atomicAdd(summary + 2, 1);
+					if (watched != nullptr && watched[i])
+					{
+						atomicAdd(summary + 5, 1); // on a hub body that is a change of the constraint graph (solver_internal.h: hContactWatched)
+					}
 				}
 			}
 		}
@@ -968,7 +972,7 @@ struct Scratch
 
 // resident arrays (world.hip)
 void launchUpdateContacts(hipStream_t st, const s2amdBody* bodies, const float* origins, const s2amdShape* shapes, s2amdPairState* pairs,
-						  s2amdContact* contacts, int contactCapacity, int32_t* status, uint8_t* pointBytes, int* summary, int* separatedSlots)
+						  s2amdContact* contacts, int contactCapacity, int32_t* status, uint8_t* pointBytes, int* summary, int* separatedSlots, const uint8_t* watched)
 {
 	if (contactCapacity <= 0)
 	{
@@ -976,7 +980,7 @@ void launchUpdateContacts(hipStream_t st, const s2amdBody* bodies, const float* 
 	}
 	dim3 grid((unsigned)((contactCapacity + S2_NP_BLOCK - 1) / S2_NP_BLOCK));
 	updateContactsKernel<true><<<grid, dim3(S2_NP_BLOCK), 0, st>>>(bodies, (const float2*)origins, shapes, pairs, contacts, contactCapacity, status,
-																   pointBytes, summary, separatedSlots);
+																   pointBytes, summary, separatedSlots, watched);
 }
 
 #pragma GCC visibility push(default)
@@ -1033,7 +1037,7 @@ int s2amd_update_contacts(s2amdSolver* solver, const s2amdBody* bodies, int32_t 
 	NP_TRY(hipEventCreate(&e0));
 	NP_TRY(hipEventCreate(&e1));
 	NP_TRY(hipEventRecord(e0, st));
-	updateContactsKernel<false><<<grid, dim3(S2_NP_BLOCK), 0, st>>>(dB, dO, dS, dP, dC, contactCapacity, dT, nullptr, nullptr, nullptr);
+	updateContactsKernel<false><<<grid, dim3(S2_NP_BLOCK), 0, st>>>(dB, dO, dS, dP, dC, contactCapacity, dT, nullptr, nullptr, nullptr, nullptr);
 	NP_TRY(hipEventRecord(e1, st));
 	NP_TRY(hipGetLastError());
 	NP_TRY(hipMemcpyAsync(pairs, dP, pBytes, hipMemcpyDeviceToHost, st));

@@ -25,6 +25,8 @@
 int s2amdFail(int code, const std::string& msg);
 inline int fail(int code, const std::string& msg) { return s2amdFail(code, msg); }
 
+#define S2_HUB_DEGREE 24
+
 #define HIP_TRY(expr)                                                                                                            \
 	do                                                                                                                           \
 	{                                                                                                                            \
@@ -217,6 +219,15 @@ struct s2amdSolver
 	std::vector<uint8_t> hContactEdge;
 	std::vector<uint8_t> hContactDead; // in the structure, but its contact has been destroyed since: dropped at the next rebuild
 	bool deadUnknown = false;		   // pairs separated on the device since the host last looked (syncDeadSlots, world.hip)
+	// HUB bodies.  A long shape that rotates (the Tumbler's drum walls) has a world-space box that overlaps the fat boxes of
+	// hundreds of bodies it never touches: hundreds of POTENTIAL constraints on one writable body, each of which would cost a
+	// colour of its own.  So for a body with more than S2_HUB_DEGREE potential constraints only the manifolds WITH points are
+	// structural (as the reference gathers them), and a manifold on such a body that gains or loses its points changes the
+	// graph like a created or destroyed contact.  hContactWatched marks the live slots with a hub end; the device counts
+	// their flips (stage 3), and a world with watched slots reads that counter back BEFORE its solve is enqueued.
+	std::vector<uint8_t> hBodyHub, hContactWatched;
+	int watchedCount = 0;
+	DevBuf dWatched;
 	bool pointsKnown = false; // hContactPoints is current: no stage 3 has recomputed manifolds on the device since the upload
 	int activeContacts = 0;	  // manifolds with points this step (host count, or the device's counter in the world chain)
 	bool lastStepWroteIndex = false; // the last solve's driver writes manifold.constraintIndex (all but XPBD's early-out and Block)

@@ -95,6 +95,7 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 	int active = 0;
 	std::vector<ContactChange> created; // contacts that appeared (or whose slot now holds another pair), in pool order
 	std::vector<int32_t> died;			// ... that were destroyed since the last upload
+	bool hubTouched = false;			// something happened to a contact on a hub body: decided by a rebuild
 	for (int i = 0; i < nc; ++i)
 	{
 		const s2amdContact& c = contacts[i];
@@ -109,6 +110,7 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 		// without points counts when it names two distinct live bodies (a free pool slot names none)
 		const bool edge = pc > 0 || (pairs ? (pairs[i].shapeA >= 0 && valid)
 										   : (valid && c.bodyA != c.bodyB && bodies[c.bodyA].type != S2AMD_BODY_FREE && bodies[c.bodyB].type != S2AMD_BODY_FREE));
+		const int oldPoints = s->hContactPoints[i];
 		s->hContactPoints[i] = pc;
 		active += pc > 0 ? 1 : 0;
 		if (!edge && s->hContactEdge[i] && !newWorld)
@@ -127,7 +129,12 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 		if (edge && (!s->hContactEdge[i] || s->hContactA[i] != c.bodyA || s->hContactB[i] != c.bodyB))
 		{
 			created.push_back(ContactChange{i, c.bodyA, c.bodyB}); // (shadows of this slot are written below, after the old entry was found)
+			hubTouched = hubTouched || (!s->hBodyHub.empty() && (int)s->hBodyHub.size() == nb && (s->hBodyHub[(size_t)c.bodyA] || s->hBodyHub[(size_t)c.bodyB]));
 			continue;
+		}
+		if (edge && !s->hContactWatched.empty() && s->hContactWatched[(size_t)i] && (oldPoints > 0) != (pc > 0))
+		{
+			hubTouched = true; // a manifold on a hub body gained or lost its points (solver_internal.h: hContactWatched)
 		}
 		if (!edge && s->hContactEdge[i])
 		{
@@ -142,7 +149,7 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 	if (!created.empty())
 	{
 		// created contacts: a place in the existing structure when that is all that happened and they fit, else a rebuild
-		const bool placed = !changed && incrementalApply(s, created);
+		const bool placed = !changed && !hubTouched && incrementalApply(s, created);
 		for (const ContactChange& ch : created)
 		{
 			s->hContactA[(size_t)ch.slot] = ch.a;
@@ -159,6 +166,7 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 			changed = true;
 		}
 	}
+	changed = changed || hubTouched;
 	if (!changed)
 	{
 		// Destroyed contacts give their places back AFTER this step's created ones were placed: the world chain learns of the

@@ -1327,12 +1327,51 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 	// potential constraints in pool order (the reference's gather, e.g. solve_tgs_soft.c:162-179, over the slots that CAN have
 	// manifold points; the ones that have none this step are no-ops wherever the sweep order puts them)
 	EdgeList ce, je;
+	// hub bodies (solver_internal.h): potential constraints per writable body
+	std::vector<int> degree((size_t)nb, 0);
 	for (int i = 0; i < s->contactCapacity; ++i)
 	{
 		if (s->hContactEdge[i] && s->hContactDead[i])
 		{
 			s->hContactEdge[i] = 0; // a destroyed contact leaves the structure with this rebuild
 			s->hContactDead[i] = 0;
+		}
+		if (s->hContactEdge[i])
+		{
+			degree[(size_t)s->hContactA[i]] += 1;
+			degree[(size_t)s->hContactB[i]] += 1;
+		}
+	}
+	s->hBodyHub.assign((size_t)nb, 0);
+	bool anyHub = false;
+	for (int i = 0; i < nb; ++i)
+	{
+		if (degree[(size_t)i] > S2_HUB_DEGREE && (s->hBodyFlags[(size_t)i] & (S2F_WRITE_VEL | S2F_WRITE_POS)) != 0)
+		{
+			s->hBodyHub[(size_t)i] = 1;
+			anyHub = true;
+		}
+	}
+	if (anyHub && s->worldResident && !s->pointsKnown)
+	{
+		int rcPoints = fetchPointCounts(s); // which manifolds on the hubs have points right now
+		if (rcPoints)
+		{
+			return rcPoints;
+		}
+	}
+	s->hContactWatched.assign((size_t)s->contactCapacity, 0);
+	s->watchedCount = 0;
+	for (int i = 0; i < s->contactCapacity; ++i)
+	{
+		if (s->hContactEdge[i] && anyHub && (s->hBodyHub[(size_t)s->hContactA[i]] || s->hBodyHub[(size_t)s->hContactB[i]]))
+		{
+			s->hContactWatched[(size_t)i] = 1;
+			s->watchedCount += 1;
+			if (s->hContactPoints[(size_t)i] <= 0)
+			{
+				continue; // a potential constraint on a hub body: structural only while its manifold has points
+			}
 		}
 		if (s->hContactEdge[i])
 		{
@@ -1705,12 +1744,31 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 				int p = pos[(size_t)k];
 				cs.local[(size_t)k] = make_int2(slots.get(a[p], bodies, conflict), slots.get(b[p], bodies, conflict));
 			}
-			t.bodyIds = bodies;
-			t.bodyOffsets = {0, (int)bodies.size()};
-			t.cBatches.push_back(make_int4(begin, end, 1, 0));
-			t.cBatchOffsets = {0, 1};
-			t.jBatchOffsets = {0, 0};
-			t.maxBodies = (int)bodies.size();
+			if ((int)bodies.size() > 2800)
+			{
+				// The tail's bodies do not fit one workgroup's LDS (160 KiB at 40-56 B per body): no sequential tail for
+				// this graph, its tiny colours are launched one by one like the others (a dense pool -- every pair whose fat
+				// boxes overlap is a potential constraint -- can put thousands of constraints into the tiny colours)
+				cs.hasTail = false;
+				cs.batchOffsets.pop_back();
+				for (size_t ci = 0; ci < cs.colorOffsets.size(); ++ci)
+				{
+					if (cs.colorOffsets[ci] > begin)
+					{
+						cs.batchOffsets.push_back(cs.colorOffsets[ci]);
+					}
+				}
+				std::fill(cs.local.begin(), cs.local.end(), make_int2(0, 0));
+			}
+			else
+			{
+				t.bodyIds = bodies;
+				t.bodyOffsets = {0, (int)bodies.size()};
+				t.cBatches.push_back(make_int4(begin, end, 1, 0));
+				t.cBatchOffsets = {0, 1};
+				t.jBatchOffsets = {0, 0};
+				t.maxBodies = (int)bodies.size();
+			}
 		}
 		gather(je, jOf[0], ids, a, b);
 		colourPart(ids, a, b, conflict, nb, js, js.batchOffsets, js.hasTail, &pos);
@@ -1973,6 +2031,17 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 	if (nb > 0)
 	{
 		HIP_TRY(hipMemcpyAsync(s->dBodyFlags.p, flags.data(), (size_t)nb * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+	}
+	if (s->worldResident)
+	{
+		if ((rc = s->dWatched.ensure(std::max<size_t>((size_t)s->contactCapacity, 256), &grew)) != 0)
+		{
+			return rc;
+		}
+		if (s->contactCapacity > 0)
+		{
+			HIP_TRY(hipMemcpyAsync(s->dWatched.p, s->hContactWatched.data(), (size_t)s->contactCapacity, hipMemcpyHostToDevice, s->stream));
+		}
 	}
 	s->cv.contactIndex = (int*)s->dContactIndex.p;
 	s->cv.localBodies = (int2*)s->dContactLocal.p;

@@ -28,7 +28,8 @@ struct WorldSummary
 	int flips;	   // manifolds that went between zero and non-zero points: the constraint graph changed
 	int moves;	   // manifolds whose point count changed at all
 	int enlarged;  // shapes whose fat AABB was re-inflated by the refit: the broad phase has to look at them
-	int pad[3];
+	int watchedFlips; // flips of manifolds on hub bodies: those are changes of the constraint graph
+	int pad[2];
 };
 
 // s2amd_world_set_contacts: staged records into their slots
@@ -308,10 +309,24 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 		// (the kernel also destroys separated pairs and accumulates the step's contact counters)
 		launchUpdateContacts(st, (const s2amdBody*)s->dBodies.p, (const float*)s->dOrigins.p, (const s2amdShape*)s->dShapes.p,
 							 (s2amdPairState*)s->dPairs.p, (s2amdContact*)s->dContacts.p, nc, (int32_t*)s->dStatus.p, (uint8_t*)s->dPointBytes.p,
-							 (int*)dSum, (int*)s->dSeparated.p);
+							 (int*)dSum, (int*)s->dSeparated.p, s->watchedCount > 0 && !s->structureDirty ? (const uint8_t*)s->dWatched.p : nullptr);
 	}
 	s->pointsKnown = false; // the manifolds are the device's now
 	s->hSeparated.clear();
+	if (s->watchedCount > 0 && !s->structureDirty)
+	{
+		// a world with hub bodies: a manifold on one of them that gained or lost its points changes the graph, and the
+		// solve must not be enqueued on the old structure -- the one case that needs stage 3's counters before the solve
+		int rcMid = fetchSummary(s, 0);
+		if (rcMid)
+		{
+			return rcMid;
+		}
+		if (hSum->watchedFlips > 0)
+		{
+			noteGraphChanged(s);
+		}
+	}
 	const double t1 = nowMs();
 	int rc = S2AMD_OK;
 	int fallbacks = 0;
@@ -494,6 +509,10 @@ int s2amd_world_set_contacts(s2amdSolver* s, const int32_t* slots, int32_t count
 	}
 	std::sort(byslot.begin(), byslot.end(), [&](int x, int y) { return slots[x] < slots[y]; });
 	std::vector<ContactChange> created;
+	bool hubTouched = false; // a contact on a hub body came or went: which of its contacts are structural is decided by a rebuild
+	auto onHub = [&](int a, int b) {
+		return !s->hBodyHub.empty() && ((a >= 0 && a < (int)s->hBodyHub.size() && s->hBodyHub[(size_t)a]) || (b >= 0 && b < (int)s->hBodyHub.size() && s->hBodyHub[(size_t)b]));
+	};
 	for (int i : byslot)
 	{
 		const int k = slots[i];
@@ -519,13 +538,14 @@ int s2amd_world_set_contacts(s2amdSolver* s, const int32_t* slots, int32_t count
 		if (!s->hContactEdge[(size_t)k] || s->hContactA[(size_t)k] != c.bodyA || s->hContactB[(size_t)k] != c.bodyB)
 		{
 			created.push_back(ContactChange{k, c.bodyA, c.bodyB});
+			hubTouched = hubTouched || onHub(c.bodyA, c.bodyB);
 			continue;
 		}
 		s->hContactDead[(size_t)k] = 0; // the same pair again in its old slot
 	}
 	if (!created.empty())
 	{
-		const bool placed = incrementalApply(s, created);
+		const bool placed = !hubTouched && incrementalApply(s, created);
 		for (const ContactChange& ch : created)
 		{
 			s->hContactA[(size_t)ch.slot] = ch.a;

@@ -229,3 +229,75 @@ def platform(n, layers=1):
             bi += 1
     assert ci == len(contacts)
     return bodies, contacts, joints
+
+
+def _offset_box(sh, body, body_type, hx, hy, cx, cy, index):
+    """s2MakeOffsetBox(hx, hy, (cx, cy), 0) on an unrotated body at the world origin of its own frame: vertices and normals in
+    the body frame; the AABBs are filled by the caller (they need the body's position)."""
+    sh["body"], sh["type"] = body, wire.SHAPE_POLYGON
+    sh["categoryBits"], sh["maskBits"], sh["groupIndex"] = 1, 0xFFFFFFFF, 0
+    sh["proxyKey"] = (index << 4) | int(body_type)
+    sh["count"], sh["radius"] = 4, 0.0
+    sh["vertices"][:4] = [(cx - hx, cy - hy), (cx + hx, cy - hy), (cx + hx, cy + hy), (cx - hx, cy + hy)]
+    sh["normals"][:4] = [(0.0, -1.0), (1.0, 0.0), (0.0, 1.0), (-1.0, 0.0)]
+
+
+def tumbler_world(count, spare_slots_per_box=16):
+    """BASELINE config 3's scene as a resident WORLD with no contacts yet: a hollow square drum (four wall shapes on one
+    dynamic body) turned by a revolute motor against a static anchor, `count` small boxes on a grid inside (the recipe of
+    solver2d_amd/scenes/scenes.c: sceneTumbler).  Every proxy starts in the move buffer, the contact pool is
+    empty: the caller runs the whole loop -- pair query, contact creation, s2amd_world_step -- on it.
+    Returns the dict of tests/world_chain.py's WORLD_KEYS."""
+    side = 1
+    while side * side < count:
+        side += 1
+    a = np.float32(0.125)
+    inner = np.float32(side * (2.0 * a) * 1.5 + 1.0)
+    half, wall = np.float32(0.5 * inner), np.float32(0.5)
+    cy = np.float32(half + 2.0)
+    nb = 2 + count
+    bodies = np.zeros(nb, dtype=wire.body_dtype)
+    shapes = np.zeros(4 + count, dtype=wire.shape_dtype)
+    _static_body(bodies[0], 0.0, 0.0)
+    # the drum: density 5, four walls (s2ComputePolygonMass of each offset box, summed about the body origin)
+    walls = [(wall, half + wall, half + wall, 0.0), (wall, half + wall, -half - wall, 0.0), (half + wall, wall, 0.0, half + wall), (half + wall, wall, 0.0, -half - wall)]
+    mass = inertia = np.float32(0.0)
+    for i, (hx, hy, ox, oy) in enumerate(walls):
+        m = np.float32(5.0 * 4.0 * hx * hy)
+        mass += m
+        inertia += np.float32(m * (4.0 * hx * hx + 4.0 * hy * hy) / 12.0 + m * (ox * ox + oy * oy))
+        _offset_box(shapes[i], 1, wire.BODY_DYNAMIC, hx, hy, ox, oy, i)
+    _dynamic_body(bodies[1], 0.0, cy, mass, inertia)
+    box_mass = np.float32(4.0 * a * a)
+    box_i = np.float32(box_mass * (8.0 * a * a) / 12.0)
+    pitch = np.float32(2.0 * a * 1.25)
+    x0 = np.float32(-0.5 * (side - 1) * pitch)
+    y0 = np.float32(cy - half + a + 0.05)
+    k = 0
+    for r in range(side):
+        for c in range(side):
+            if k >= count:
+                break
+            _dynamic_body(bodies[2 + k], x0 + c * pitch, y0 + r * pitch, box_mass, box_i)
+            _offset_box(shapes[4 + k], 2 + k, wire.BODY_DYNAMIC, a, a, 0.0, 0.0, 4 + k)
+            k += 1
+    # world-space boxes: tight AABB + speculative margin, fat AABB (s2CreateShape), everything in the move buffer
+    pos = bodies["position"][shapes["body"]]
+    lo = shapes["vertices"][:, :4, :].min(axis=1) + pos
+    hi = shapes["vertices"][:, :4, :].max(axis=1) + pos
+    shapes["aabb"][:, 0:2], shapes["aabb"][:, 2:4] = lo - SPECULATIVE_DISTANCE, hi + SPECULATIVE_DISTANCE
+    shapes["fatAABB"][:, 0:2], shapes["fatAABB"][:, 2:4] = lo - AABB_MARGIN, hi + AABB_MARGIN
+    shapes["enlarged"] = 1
+    joints = np.zeros(1, dtype=wire.joint_dtype)
+    j = joints[0]
+    j["type"], j["bodyA"], j["bodyB"] = wire.JOINT_REVOLUTE, 0, 1
+    j["localOriginAnchorA"], j["localOriginAnchorB"] = (0.0, float(cy)), (0.0, 0.0)
+    j["enableMotor"], j["motorSpeed"], j["maxMotorTorque"] = 1, np.float32(0.05 * np.pi * 4.0), 1e8
+    slots = spare_slots_per_box * count + 1024
+    contacts = np.zeros(slots, dtype=wire.contact_dtype)
+    contacts["constraintIndex"] = -1
+    pairs = np.zeros(slots, dtype=wire.pair_state_dtype)
+    pairs["shapeA"] = -1
+    pairs["shapeB"] = -1
+    return {"bodies": bodies, "contacts": contacts, "joints": joints, "shapes": shapes, "pairs": pairs,
+            "origins": np.ascontiguousarray(bodies["position"], dtype=np.float32).copy()}

@@ -43,15 +43,22 @@ def create_contacts(world, free, new_pairs):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--world", default="wreck", choices=("wreck", "tumbler"), help="wreck: balls into a base-N pyramid; tumbler: BASELINE config 3's drum with --count boxes, from scratch")
+    ap.add_argument("--count", type=int, default=10000)
     ap.add_argument("--base", type=int, default=200)
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--steps", type=int, default=240)
     ap.add_argument("--solver", default="TGS_Soft")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE")
+    ap.add_argument("--trace", action="store_true", help="one line per step on stderr")
     a = ap.parse_args()
     vel, pos = common.DEFAULT_ITERS[a.solver]
     params = wire.StepParams.make(a.solver, 1.0 / 60.0, vel, pos, True)
-    world = world_chain.wreck_world(a.seed, a.base)
+    if a.world == "tumbler":
+        from solver2d_amd import synthetic
+        world = synthetic.tumbler_world(a.count)
+    else:
+        world = world_chain.wreck_world(a.seed, a.base)
     free = sorted(np.flatnonzero(world["pairs"]["shapeA"] < 0).tolist(), reverse=True)
     rows = []
     with hip.Solver(0) as s:
@@ -85,6 +92,10 @@ def main():
                 free.extend(s.world_separated(info["separatedCount"]).tolist())
             t5 = time.perf_counter()
             moved = info["movedCount"]
+            if a.trace:
+                sys.stderr.write("step %d: %.2f ms, created %d separated %d active %d potential %d launches %d hostPrep %.2f colours %d placed %d builds %d\n" % (
+                    step, 1e3 * (t5 - t0), created, info["separatedCount"], info["activeContacts"], st["potentialConstraints"], st["kernelLaunches"], st["hostPrepMs"],
+                    st["contactColors"], st["placedContacts"], st["structureBuilds"]))
             rows.append({"step_ms": 1e3 * (t5 - t0), "pair_query_ms": 1e3 * (t1 - t0), "create_py_ms": 1e3 * (t2 - t1), "set_contacts_ms": 1e3 * (t3 - t2),
                          "world_step_ms": 1e3 * (t4 - t3), "destroy_py_ms": 1e3 * (t5 - t4), "host_structure_ms": st["hostPrepMs"], "solve_device_ms": info["solveMs"],
                          "created": created, "separated": info["separatedCount"], "flips": info["graphChanged"], "active": info["activeContacts"],
@@ -99,7 +110,8 @@ def main():
     churn = [r for r in rows if r["created"] > 0 or r["separated"] > 0]
     quiet = [r for r in rows if not (r["created"] > 0 or r["separated"] > 0)]
     keys = ["step_ms", "pair_query_ms", "create_py_ms", "set_contacts_ms", "world_step_ms", "destroy_py_ms", "host_structure_ms", "solve_device_ms", "launches"]
-    out = {"world": "wreck_world(seed %d, base %d): %d bodies, %d contact slots" % (a.seed, a.base, len(world["bodies"]), len(world["contacts"])),
+    out = {"world": ("tumbler_world(%d): " % a.count if a.world == "tumbler" else "wreck_world(seed %d, base %d): " % (a.seed, a.base)) +
+                    "%d bodies, %d contact slots" % (len(world["bodies"]), len(world["contacts"])),
            "solver": a.solver, "steps": a.steps, "steps_with_created_or_destroyed_contacts": len(churn),
            "contacts_created": sum(r["created"] for r in rows), "contacts_destroyed": sum(r["separated"] for r in rows),
            "steps_with_manifold_flips": sum(1 for r in rows if r["flips"]), "steps_that_rebuilt_the_structure": sum(1 for r in rows if r["host_structure_ms"] > 0), "contacts_placed_without_rebuild": st["placedContacts"],

@@ -218,6 +218,64 @@ def joint_grid_leg(device_index, steps, warmup):
             "roofline": None, "roofline_note": "35 dependent launches of ~20k threads: launch-latency bound, no bandwidth figure is meaningful"}
 
 
+def tumbler_leg(device_index, count, settle, steps):
+    """BASELINE.json configs[2]: the Tumbler (a motor-driven hollow drum, `count` boxes), s2_solverJacobi 4/2.  The scene is built
+    as a resident world WITHOUT contacts and settled by the product itself: `settle` steps of the whole loop -- device pair
+    query, the caller's contact creation, s2amd_world_step under TGS_Soft (the reference's Jacobi diverges on piles) -- with
+    contacts created and destroyed by the hundred every step.  Then s2Solve_Jacobi is timed on that resident snapshot the way
+    the headline times TGS_Soft (bodies restored before every solve)."""
+    from tools import churn_bench
+    world = synthetic.tumbler_world(count, spare_slots_per_box=24)
+    keys = ("bodies", "contacts", "joints", "shapes", "pairs", "origins")
+    soft = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    free = sorted(np.flatnonzero(world["pairs"]["shapeA"] < 0).tolist(), reverse=True)
+    with hip.Solver(device_index) as gpu:
+        gpu.world_upload(*[world[k] for k in keys])
+        moved, created, destroyed = 1, 0, 0
+        t0 = time.perf_counter()
+        for _ in range(settle):
+            if moved > 0:
+                new = gpu.world_find_pairs()
+                if len(new):
+                    gpu.world_set_contacts(*churn_bench.create_contacts(world, free, new))
+                    created += len(new)
+            info = gpu.world_step(soft)
+            if info["separatedCount"] > 0:
+                free.extend(gpu.world_separated(info["separatedCount"]).tolist())
+                destroyed += info["separatedCount"]
+            moved = info["movedCount"]
+        loop_ms = 1e3 * (time.perf_counter() - t0) / settle
+        res = gpu.world_download(*[world[k] for k in keys])
+    bodies, contacts, joints = res[0], res[1], res[2]
+    active = int((contacts["pointCount"] > 0).sum())
+    jac = wire.StepParams.make("Jacobi", 1.0 / 60.0, 4, 2, True)
+    with hip.Solver(device_index) as gpu:
+        gpu.set_option("async", 1)
+        gpu.upload(bodies, contacts, joints)
+        gpu.save_bodies()
+        for _ in range(10):
+            gpu.restore_bodies()
+            gpu.step_resident(jac)
+        gpu.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            gpu.restore_bodies()
+            gpu.step_resident(jac)
+        gpu.synchronize()
+        elapsed = time.perf_counter() - t0
+        gpu.set_option("async", 0)
+        gpu.restore_bodies()
+        gpu.step_resident(jac)
+        st = gpu.stats()
+    return {"workload": "Tumbler, %d boxes: settled on the device by %d steps of the whole loop (TGS_Soft; %d contacts created, %d destroyed, %.2f ms per "
+                        "loop step incl. pair query and the caller's Python pool), then s2_solverJacobi 4/2 on the resident snapshot: %d active constraints "
+                        "of %d potential, the drum touches %d" % (count, settle, created, destroyed, loop_ms, active, st["potentialConstraints"],
+                                                                 int(((contacts["bodyA"] == 1) | (contacts["bodyB"] == 1))[contacts["pointCount"] > 0].sum())),
+            "unit": "constraint-iters/s", "value": active * 6 * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
+            "kernel_launches_per_step": st["kernelLaunches"], "device_ms_per_step": st["deviceMs"], "whole_loop_ms_per_step_tgs_soft": loop_ms,
+            "roofline": None, "roofline_note": "26 dependent launches per step over ~%d constraints: launch-latency bound" % active}
+
+
 def whole_step_leg(device_index, base, vel, pos, settle, steps):
     """SURVEY.md 8d, config 2 as a trajectory: the world resident (bodies, manifolds, shapes, pair states), `settle` steps,
     then `steps` timed s2amd_world_step calls = stage 3 (narrow phase on every pair) -> s2Solve_TGS_Soft -> stage 4 (refit)."""
@@ -454,7 +512,8 @@ def main():
             out["island_sharded"] = sharded
             if world == 1:
                 out["whole_step"] = whole_step_leg(ranks.device_index, args.base, args.vel_iters, args.pos_iters, 60, 240)
-                out["configs"] = {"4_joint_grid": joint_grid_leg(ranks.device_index, 100, 20),
+                out["configs"] = {"3_tumbler": tumbler_leg(ranks.device_index, 10000, 120, 100),
+                                  "4_joint_grid": joint_grid_leg(ranks.device_index, 100, 20),
                                   "5_one_gpu": {k: sharded[k] for k in ("value", "unit", "ms_per_step", "config", "roofline")}}
     if rank == 0:
         print(json.dumps(out))

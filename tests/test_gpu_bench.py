@@ -43,6 +43,8 @@ def test_single_gpu_line():
     r5 = isl["roofline"]
     assert r5["bound"] == "hbm" and abs(r5["algorithmic_bytes_per_launch"] - 136.0 * 1218560 * 16) < 1 and 0 < r5["frac"] < 1.0
     assert d["configs"]["4_joint_grid"]["unit"] == "joint-iters/s" and d["configs"]["4_joint_grid"]["value"] > 0
+    assert d["configs"]["3_tumbler"]["unit"] == "constraint-iters/s" and d["configs"]["3_tumbler"]["value"] > 0
+    assert d["configs"]["3_tumbler"]["whole_loop_ms_per_step_tgs_soft"] > 0
 
 
 def test_two_ranks_on_one_device():

@@ -243,8 +243,11 @@ int s2amd_refit_shapes(s2amdSolver* solver, const s2amdBody* bodies, int32_t bod
  * s2CreateContact's type rules (src/contact.c:137-175): segment/segment pairs are dropped, a pair
  * whose shape-type order has no primary manifold function is flipped.
  * existingPairs: shapeIndexA/B of the live contacts.  Output: the NEW pairs, sorted by (A, B) -- the
- * same SET the reference creates contacts for; its creation order (tree traversal order) is not
- * reproduced.  Returns S2AMD_E_CAPACITY (with *pairCount = needed) when outPairs is too small. */
+ * same SET the reference creates contacts for.  The reference's creation ORDER is a function of its own
+ * trees (move-array order, then s2DynamicTree_Query's traversal order reversed, broad_phase.c:253-254,
+ * :332-357): the caller, who owns those trees and the contact pool, sorts the set on that key before
+ * calling s2CreateContact (shim/s2_amd_binding.c: s2amdBinding_OrderPairs), which gives every contact
+ * the reference's pool slot.  Returns S2AMD_E_CAPACITY (with *pairCount = needed) when outPairs is too small. */
 int s2amd_find_pairs(s2amdSolver* solver, const s2amdBody* bodies, int32_t bodyCapacity, const s2amdShape* shapes, int32_t shapeCapacity,
 					 const uint8_t* moved, const int32_t* existingPairs, int32_t existingPairCount, const s2amdJoint* joints,
 					 int32_t jointCapacity, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount);

@@ -267,10 +267,81 @@ S2REF_API int s2ref_narrowphase_capture(const s2amdShape** shapes, int32_t* shap
 	return 0;
 }
 
+// -- creation-order check (CPU only): the sequence the reference's stage 1 really calls s2CreateContact in, against
+// s2amdBinding_OrderPairs applied to the same pairs handed over as a sorted set (what s2amd_world_find_pairs returns)
+static int g_orderCheck, g_orderRecording, g_orderCount, g_orderCapacity;
+static int32_t* g_orderSeen;
+static long g_orderChecked, g_orderMismatched, g_orderSteps;
+
+void __real_s2CreateContact(s2World* world, s2Shape* shapeA, s2Shape* shapeB);
+void __wrap_s2CreateContact(s2World* world, s2Shape* shapeA, s2Shape* shapeB)
+{
+	if (g_orderRecording)
+	{
+		if (g_orderCount == g_orderCapacity)
+		{
+			g_orderCapacity = 2 * g_orderCapacity + 256;
+			g_orderSeen = (int32_t*)realloc(g_orderSeen, (size_t)g_orderCapacity * 2 * sizeof(int32_t));
+		}
+		g_orderSeen[2 * g_orderCount] = shapeA->object.index;
+		g_orderSeen[2 * g_orderCount + 1] = shapeB->object.index;
+		g_orderCount += 1;
+	}
+	__real_s2CreateContact(world, shapeA, shapeB);
+}
+
+static int pairAscending(const void* a, const void* b)
+{
+	const int32_t* x = (const int32_t*)a;
+	const int32_t* y = (const int32_t*)b;
+	return x[0] != y[0] ? (x[0] < y[0] ? -1 : 1) : (x[1] < y[1] ? -1 : (x[1] > y[1] ? 1 : 0));
+}
+
 void __real_s2UpdateBroadPhasePairs(s2World* world);
+static void updatePairsChecked(s2World* world)
+{
+	s2BroadPhase* bp = &world->broadPhase;
+	const int moveCount = s2Array(bp->moveArray).count;
+	int* moves = (int*)malloc((size_t)(moveCount > 0 ? moveCount : 1) * sizeof(int));
+	memcpy(moves, bp->moveArray, (size_t)moveCount * sizeof(int));
+	g_orderCount = 0;
+	g_orderRecording = 1;
+	__real_s2UpdateBroadPhasePairs(world);
+	g_orderRecording = 0;
+	if (g_orderCount > 0)
+	{
+		int32_t* sorted = (int32_t*)malloc((size_t)g_orderCount * 2 * sizeof(int32_t));
+		memcpy(sorted, g_orderSeen, (size_t)g_orderCount * 2 * sizeof(int32_t));
+		qsort(sorted, (size_t)g_orderCount, 2 * sizeof(int32_t), pairAscending);
+		s2amdBinding_OrderPairs(world, moves, moveCount, sorted, g_orderCount);
+		g_orderMismatched += memcmp(sorted, g_orderSeen, (size_t)g_orderCount * 2 * sizeof(int32_t)) != 0;
+		g_orderChecked += g_orderCount;
+		g_orderSteps += 1;
+		free(sorted);
+	}
+	free(moves);
+}
+
+void s2ref_order_check(int on)
+{
+	g_orderCheck = on;
+	g_orderChecked = g_orderMismatched = g_orderSteps = 0;
+}
+
+// pairs whose order was checked, steps (with new pairs) whose sequence differed, steps with new pairs
+void s2ref_order_check_result(long out[3])
+{
+	out[0] = g_orderChecked, out[1] = g_orderMismatched, out[2] = g_orderSteps;
+}
+
 void __wrap_s2UpdateBroadPhasePairs(s2World* world)
 {
 	g_stepWorld = world;
+	if (g_orderCheck)
+	{
+		updatePairsChecked(world);
+		return;
+	}
 	if (g_mode == 3)
 	{
 		struct timespec t0, t1;

@@ -743,6 +743,134 @@ static int sendNewContacts(s2World* w, WorldBinding* b)
 	return count > 0 ? s_api.worldSetContacts(b->solver, b->slots, count, b->slotContacts, b->slotPairs) : 0;
 }
 
+// -- the reference's creation order for the pairs the device found (src/broad_phase.c:253-254, :288-320, :332-357) -------------
+// s2UpdateBroadPhasePairs creates contacts proxy by proxy in move-array order; within one querying proxy in REVERSE callback
+// order (every callback pushes its pair at the front of the proxy's list); callbacks come tree by tree (dynamic, kinematic,
+// static: broad_phase.c:300-311) and within a tree in s2DynamicTree_Query's traversal order (src/dynamic_tree.c:1171-1210:
+// a stack that takes child2 before child1).  Pruned subtrees do not change the relative order of the leaves that are
+// reported, so the traversal order of two leaves is decided at their lowest common ancestor: the one under child2 first.
+// The trees are the reference's own (stage 4 below keeps enlarging them, stage 2 rebuilds them every step as world.c:130
+// does), so sorting the device's pair SET on (move index, tree, traversal rank) gives s2CreateContact the reference's
+// sequence and every contact the reference's pool slot.
+typedef struct OrderedPair
+{
+	int32_t shapeA, shapeB;
+	int32_t moveIndex; // of the querying proxy
+	int32_t treeOrder; // 0 dynamic, 1 kinematic, 2 static: the order FindPairs queries them in
+	int32_t leaf; // the other proxy's node
+	int32_t depth; // of that node
+} OrderedPair;
+
+static const s2DynamicTree* s_orderTrees; // qsort has no context argument; the binding is single-threaded like the reference
+
+static int nodeDepth(const s2DynamicTree* tree, int32_t node)
+{
+	int depth = 0;
+	while (tree->nodes[node].parent != S2_NULL_INDEX)
+	{
+		node = tree->nodes[node].parent;
+		depth += 1;
+	}
+	return depth;
+}
+
+// < 0 when s2DynamicTree_Query reports leaf x before leaf y
+static int traversalOrder(const s2DynamicTree* tree, int32_t x, int dx, int32_t y, int dy)
+{
+	if (x == y)
+	{
+		return 0;
+	}
+	const s2TreeNode* nodes = tree->nodes;
+	while (dx > dy)
+	{
+		x = nodes[x].parent, dx -= 1;
+	}
+	while (dy > dx)
+	{
+		y = nodes[y].parent, dy -= 1;
+	}
+	while (nodes[x].parent != nodes[y].parent)
+	{
+		x = nodes[x].parent, y = nodes[y].parent;
+	}
+	return nodes[nodes[x].parent].child2 == x ? -1 : 1;
+}
+
+static int creationOrder(const void* pa, const void* pb)
+{
+	const OrderedPair* a = (const OrderedPair*)pa;
+	const OrderedPair* b = (const OrderedPair*)pb;
+	if (a->moveIndex != b->moveIndex)
+	{
+		return a->moveIndex < b->moveIndex ? -1 : 1;
+	}
+	if (a->treeOrder != b->treeOrder)
+	{
+		return a->treeOrder > b->treeOrder ? -1 : 1; // reverse callback order
+	}
+	static const int typeOfOrder[3] = {s2_dynamicBody, s2_kinematicBody, s2_staticBody};
+	return -traversalOrder(s_orderTrees + typeOfOrder[a->treeOrder], a->leaf, a->depth, b->leaf, b->depth);
+}
+
+// pairs[2*i], pairs[2*i+1] = (shapeA, shapeB) as s2amd_world_find_pairs returns them (oriented, any order), reordered in place
+// into the sequence s2UpdateBroadPhasePairs would create them in.  moveArray = bp->moveArray as stage 1 would see it.
+void s2amdBinding_OrderPairs(s2World* world, const int* moveArray, int moveCount, int32_t* pairs, int32_t count)
+{
+	static int32_t* moveIndexOfShape; // -1 everywhere between calls
+	static int moveIndexCapacity;
+	static OrderedPair* ordered;
+	static int orderedCapacity;
+	s2BroadPhase* bp = &world->broadPhase;
+	if (moveIndexCapacity < world->shapePool.capacity)
+	{
+		moveIndexCapacity = world->shapePool.capacity;
+		moveIndexOfShape = (int32_t*)realloc(moveIndexOfShape, (size_t)moveIndexCapacity * sizeof(int32_t));
+		memset(moveIndexOfShape, 0xff, (size_t)moveIndexCapacity * sizeof(int32_t));
+	}
+	if (orderedCapacity < count)
+	{
+		orderedCapacity = count + 1024;
+		ordered = (OrderedPair*)realloc(ordered, (size_t)orderedCapacity * sizeof(OrderedPair));
+	}
+	for (int i = 0; i < moveCount; ++i)
+	{
+		if (moveArray[i] != S2_NULL_INDEX)
+		{
+			moveIndexOfShape[s2BroadPhase_GetShapeIndex(bp, moveArray[i])] = i;
+		}
+	}
+	static const int orderOfType[s2_bodyTypeCount] = {2, 1, 0}; // s2_staticBody, s2_kinematicBody, s2_dynamicBody
+	for (int i = 0; i < count; ++i)
+	{
+		OrderedPair* o = ordered + i;
+		o->shapeA = pairs[2 * i], o->shapeB = pairs[2 * i + 1];
+		const int keyA = world->shapes[o->shapeA].proxyKey, keyB = world->shapes[o->shapeB].proxyKey;
+		const int moveA = moveIndexOfShape[o->shapeA], moveB = moveIndexOfShape[o->shapeB];
+		// who asked (broad_phase.c:196-201): the one that moved; when both did, the one with the larger key (the other's
+		// query skipped the pair).  keyA < keyB by the callback's orientation rule (:210-219).
+		const int queryIsB = moveB >= 0 && (moveA < 0 || keyB > keyA);
+		const int other = queryIsB ? keyA : keyB;
+		o->moveIndex = queryIsB ? moveB : moveA;
+		o->treeOrder = orderOfType[S2_PROXY_TYPE(other)];
+		o->leaf = S2_PROXY_ID(other);
+		o->depth = nodeDepth(bp->trees + S2_PROXY_TYPE(other), o->leaf);
+	}
+	s_orderTrees = bp->trees;
+	qsort(ordered, (size_t)count, sizeof(OrderedPair), creationOrder);
+	for (int i = 0; i < count; ++i)
+	{
+		pairs[2 * i] = ordered[i].shapeA, pairs[2 * i + 1] = ordered[i].shapeB;
+	}
+	for (int i = 0; i < moveCount; ++i)
+	{
+		if (moveArray[i] != S2_NULL_INDEX)
+		{
+			moveIndexOfShape[s2BroadPhase_GetShapeIndex(bp, moveArray[i])] = -1;
+		}
+	}
+}
+
 // == s2World_Step(worldId, timeStep, velIters, posIters, warmStart) (src/world.c:120-301).  Stages 1 and 2 are passed in:
 // the reference's own s2UpdateBroadPhasePairs and s2BroadPhase_RebuildTrees (world.c:125-130).
 void s2amdBinding_WorldStep(s2World* world, float timeStep, int velIters, int posIters, bool warmStart, void (*updatePairs)(s2World*),
@@ -760,9 +888,9 @@ void s2amdBinding_WorldStep(s2World* world, float timeStep, int velIters, int po
 	if (s_devicePairs && residentMatches(world, b))
 	{
 		// stage 1 with the pair discovery on the device (s2amd_world_find_pairs on the boxes the last refit re-inflated
-		// -- the proxies in the reference's move buffer); the pool bookkeeping of each new pair is s2CreateContact as ever.
-		// The pairs arrive sorted, not in the reference's tree-traversal order: contacts get other pool slots than with
-		// the host's stage 1.  The trees keep following the fat boxes (below) for the reference's ray casts and queries.
+		// -- the proxies in the reference's move buffer); the pool bookkeeping of each new pair is s2CreateContact as ever,
+		// called in the order the reference's own stage 1 would have found the pairs in (s2amdBinding_OrderPairs), so every
+		// contact lands in the pool slot the host route gives it.  The trees keep following the fat boxes (below).
 		s2BroadPhase* bp = &world->broadPhase;
 		if (s2Array(bp->moveArray).count > 0)
 		{
@@ -774,6 +902,10 @@ void s2amdBinding_WorldStep(s2World* world, float timeStep, int velIters, int po
 				b->newPairs = (int32_t*)realloc(b->newPairs, (size_t)b->newPairCapacity * 2 * sizeof(int32_t));
 				rc = s_api.worldFindPairs(b->solver, b->newPairs, b->newPairCapacity, &count);
 			}
+			if (rc == 0 && count > 1)
+			{
+				s2amdBinding_OrderPairs(world, bp->moveArray, s2Array(bp->moveArray).count, b->newPairs, count);
+			}
 			for (int i = 0; rc == 0 && i < count; ++i)
 			{
 				s2CreateContact(world, world->shapes + b->newPairs[2 * i], world->shapes + b->newPairs[2 * i + 1]);
@@ -781,10 +913,7 @@ void s2amdBinding_WorldStep(s2World* world, float timeStep, int velIters, int po
 			s2Array_Clear(bp->moveArray);
 			s2ClearSet(&bp->moveSet);
 		}
-		if ((world->stepId & 63) == 0)
-		{
-			rebuildTrees(bp); // stage 2 now and then: nobody queries the trees here, but the host's ray casts do
-		}
+		rebuildTrees(bp); // stage 2 (world.c:130) every step: the traversal order above is read off these trees
 	}
 	else
 	{

@@ -34,6 +34,10 @@ void s2amdBinding_Invalidate(s2World* world);
 /* 1: stage 1's pair discovery on the device as well (the host trees are still kept up to date, not queried). */
 void s2amdBinding_DevicePairs(int on);
 
+/* The pair set s2amd_world_find_pairs returned, put into the order s2UpdateBroadPhasePairs creates contacts in
+ * (src/broad_phase.c:253-254, :332-357): read off the reference's own trees and move array. */
+void s2amdBinding_OrderPairs(s2World* world, const int* moveArray, int moveCount, int32_t* pairs, int32_t count);
+
 int s2amdBinding_LastError(void);
 long s2amdBinding_Uploads(void);		   /* whole-world uploads so far: one per world, and one more whenever a pool grew */
 void s2amdBinding_Timing(double out[6]); /* accumulated ms: stage 1+2, sync in, device step, download, apply; [5] = steps */

@@ -1277,431 +1277,79 @@ static int buildResidentTables(s2amdSolver* s)
 	return S2AMD_OK;
 }
 
-static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
+// One structure build, phase by phase.  The phases share the edge lists, the island / strip partition and the sweep sets
+// they append to; each one is a method below, buildStructureWith() at the end of the block is the driver.
+struct StructureBuild
 {
-	const int cls = isPositionSolver(solverType) ? 1 : 0;
-	const bool needAdj = solverType == s2amd_solverJacobi;
-	const bool grouped = s->optGroups != 0 && !needAdj;
-	// strips pay off through the lean / persistent strip kernels, which exist for the soft contact sweeps
-	const bool wantStrips = grouped && s->optStrips != 0 && !s->stripsRejected && s->graphAge >= s->stripPatienceNow &&
-							(s->optStripsAnySolver != 0 || solverType == s2amd_solverTGS_Soft || solverType == s2amd_solverSoftStep ||
-							 solverType == s2amd_solverPGS_Soft);
-	// (contacts placed into a structure built for s2Solve_Jacobi took any free position, whatever its colour: only Jacobi can run on that)
-	const bool colourFree = s->inc.colourFreePlaced && !needAdj;
-	const bool softFamily = solverType == s2amd_solverTGS_Soft || solverType == s2amd_solverSoftStep || solverType == s2amd_solverPGS_Soft;
-	const bool residentWanted = grouped && softFamily && s->optIslandResident != 0 && !s->residentRejected;
-	if (!s->structureDirty && cls == s->orderSolverClass && grouped == s->orderGrouped && wantStrips == s->orderStrips && s->adjValid && !colourFree &&
-		residentWanted == s->orderResident)
+	s2amdSolver* s;
+	const int solverType;
+	const float stripScale;
+	const int cls; // 0: the sweeps write velocities, 1: positions too (conflict = what a colour must not share)
+	const bool needAdj; // s2Solve_Jacobi: body-centric apply instead of colours
+	const bool grouped;
+	const bool wantStrips;
+	const bool residentWanted;
+	const int nb;
+	SweepSet& cs;
+	SweepSet& js;
+
+	std::vector<uint8_t> conflict;
+	EdgeList ce, je; // potential contact constraints and joints in pool order
+	int C = 0, J = 0;
+	std::vector<int> cPart, jPart; // per edge: -1 = global part, else LDS group id
+	int groupCount = 0;
+	std::vector<uint32_t> flags;
+	std::vector<std::vector<int>> cOf, jOf; // index 0 = global, g + 1 = group g
+	StripPartition strips;
+	bool stripsNeedOneLaunch = false;
+	LocalSlots slots;
+	std::vector<int> seamGroup;
+	int stripBaseC = 0;
+	bool rebuild = false; // the structure just built cannot run: build again with what was learnt (stripsRejected / residentRejected)
+
+	double t0, tPhase;
+	bool prepTimes; // S2AMD_DEBUG_PREP=1: where the host time of a structure build goes
+
+	StructureBuild(s2amdSolver* solver, int type, float scale)
+		: s(solver), solverType(type), stripScale(scale), cls(isPositionSolver(type) ? 1 : 0), needAdj(type == s2amd_solverJacobi),
+		  grouped(solver->optGroups != 0 && !needAdj),
+		  // strips pay off through the lean / persistent strip kernels, which exist for the soft contact sweeps
+		  wantStrips(grouped && solver->optStrips != 0 && !solver->stripsRejected && solver->graphAge >= solver->stripPatienceNow &&
+					 (solver->optStripsAnySolver != 0 || isSoftFamily(type))),
+		  residentWanted(grouped && isSoftFamily(type) && solver->optIslandResident != 0 && !solver->residentRejected), nb(solver->bodyCapacity),
+		  cs(solver->contacts), js(solver->joints), slots(solver->bodyCapacity)
 	{
-		return S2AMD_OK;
+		static const bool fromEnv = getenv("S2AMD_DEBUG_PREP") != nullptr;
+		prepTimes = fromEnv;
+		t0 = tPhase = nowMs();
 	}
-	if (s->worldResident && !s->pointsKnown)
+
+	static bool isSoftFamily(int type)
 	{
-		// world chain: the pair slots this step's (already enqueued) stage 3 and the earlier ones freed leave the structure
-		// with this rebuild, exactly as a host that ran stage 3 itself would have dropped them from the arrays it uploads
-		int rcDead = syncDeadSlots(s);
-		if (rcDead)
-		{
-			return rcDead;
-		}
+		return type == s2amd_solverTGS_Soft || type == s2amd_solverSoftStep || type == s2amd_solverPGS_Soft;
 	}
-	double t0 = nowMs();
-	// S2AMD_DEBUG_PREP=1: where the host time of a structure build goes
-	static const bool prepTimes = getenv("S2AMD_DEBUG_PREP") != nullptr;
-	double tPhase = t0;
-	auto phase = [&](const char* name) {
+
+	// does the structure the solver holds already serve this solver type?
+	bool upToDate() const
+	{
+		// (contacts placed into a structure built for s2Solve_Jacobi took any free position, whatever its colour: only Jacobi can run on that)
+		const bool colourFree = s->inc.colourFreePlaced && !needAdj;
+		return !s->structureDirty && cls == s->orderSolverClass && grouped == s->orderGrouped && wantStrips == s->orderStrips && s->adjValid && !colourFree &&
+			   residentWanted == s->orderResident;
+	}
+
+	void phase(const char* name)
+	{
 		if (prepTimes)
 		{
 			double t = nowMs();
 			fprintf(stderr, "[s2amd] prep %-22s %.3f ms\n", name, t - tPhase);
 			tPhase = t;
 		}
-	};
-	const int nb = s->bodyCapacity;
-	std::vector<uint8_t> conflict((size_t)nb);
-	for (int i = 0; i < nb; ++i)
-	{
-		conflict[i] = (s->hBodyFlags[i] & (cls == 1 ? S2F_WRITE_POS : S2F_WRITE_VEL)) != 0;
 	}
 
-	// potential constraints in pool order (the reference's gather, e.g. solve_tgs_soft.c:162-179, over the slots that CAN have
-	// manifold points; the ones that have none this step are no-ops wherever the sweep order puts them)
-	EdgeList ce, je;
-	// hub bodies (solver_internal.h): potential constraints per writable body
-	std::vector<int> degree((size_t)nb, 0);
-	for (int i = 0; i < s->contactCapacity; ++i)
+	void gather(const EdgeList& e, const std::vector<int>& ks, std::vector<int>& ids, std::vector<int>& a, std::vector<int>& b) const
 	{
-		if (s->hContactEdge[i] && s->hContactDead[i])
-		{
-			s->hContactEdge[i] = 0; // a destroyed contact leaves the structure with this rebuild
-			s->hContactDead[i] = 0;
-		}
-		if (s->hContactEdge[i])
-		{
-			degree[(size_t)s->hContactA[i]] += 1;
-			degree[(size_t)s->hContactB[i]] += 1;
-		}
-	}
-	s->hBodyHub.assign((size_t)nb, 0);
-	bool anyHub = false;
-	for (int i = 0; i < nb; ++i)
-	{
-		if (degree[(size_t)i] > S2_HUB_DEGREE && (s->hBodyFlags[(size_t)i] & (S2F_WRITE_VEL | S2F_WRITE_POS)) != 0)
-		{
-			s->hBodyHub[(size_t)i] = 1;
-			anyHub = true;
-		}
-	}
-	if (anyHub && s->worldResident && !s->pointsKnown)
-	{
-		int rcPoints = fetchPointCounts(s); // which manifolds on the hubs have points right now
-		if (rcPoints)
-		{
-			return rcPoints;
-		}
-	}
-	s->hContactWatched.assign((size_t)s->contactCapacity, 0);
-	s->watchedCount = 0;
-	for (int i = 0; i < s->contactCapacity; ++i)
-	{
-		if (s->hContactEdge[i] && anyHub && (s->hBodyHub[(size_t)s->hContactA[i]] || s->hBodyHub[(size_t)s->hContactB[i]]))
-		{
-			s->hContactWatched[(size_t)i] = 1;
-			s->watchedCount += 1;
-			if (s->hContactPoints[(size_t)i] <= 0)
-			{
-				continue; // a potential constraint on a hub body: structural only while its manifold has points
-			}
-		}
-		if (s->hContactEdge[i])
-		{
-			ce.ids.push_back(i);
-			ce.a.push_back(s->hContactA[i]);
-			ce.b.push_back(s->hContactB[i]);
-		}
-	}
-	for (int i = 0; i < s->jointCapacity; ++i)
-	{
-		if (s->hJointType[i] != S2AMD_JOINT_FREE)
-		{
-			je.ids.push_back(i);
-			je.a.push_back(s->hJointType[i] == S2AMD_JOINT_MOUSE ? -1 : s->hJointA[i]); // a mouse joint only touches body B
-			je.b.push_back(s->hJointB[i]);
-		}
-	}
-	const int C = (int)ce.ids.size(), J = (int)je.ids.size();
-	if (prepTimes)
-	{
-		uint64_t h = 1469598103934665603ull;
-		h = fnv(h, ce.ids.data(), ce.ids.size() * sizeof(int));
-		h = fnv(h, ce.a.data(), ce.a.size() * sizeof(int));
-		h = fnv(h, ce.b.data(), ce.b.size() * sizeof(int));
-		fprintf(stderr, "[s2amd] rebuild #%llu: %d potential contact constraints, %d joints, edge hash %016llx\n", (unsigned long long)s->structureGeneration, C, J,
-				(unsigned long long)h);
-	}
-
-	phase("edge lists");
-	// ---- islands: connected components over the writable bodies ----
-	std::vector<int> cPart((size_t)C, -1), jPart((size_t)J, -1); // -1 = global part, else group id
-	int groupCount = 0;
-	std::vector<uint32_t> flags(s->hBodyFlags);
-	if (grouped && (C > 0 || J > 0))
-	{
-		UnionFind uf(nb);
-		auto link = [&](int a, int b) {
-			if (a >= 0 && b >= 0 && conflict[a] && conflict[b])
-			{
-				uf.unite(a, b);
-			}
-		};
-		for (int k = 0; k < C; ++k)
-		{
-			link(ce.a[k], ce.b[k]);
-		}
-		for (int k = 0; k < J; ++k)
-		{
-			link(je.a[k], je.b[k]);
-		}
-		auto rootOf = [&](int a, int b) {
-			if (a >= 0 && conflict[a])
-			{
-				return uf.find(a);
-			}
-			if (b >= 0 && conflict[b])
-			{
-				return uf.find(b);
-			}
-			return -1;
-		};
-		// bodies an island would stage in LDS: its members that carry constraints + read-only replicas
-		std::vector<int> islandBodies((size_t)nb, 0), seenBy((size_t)nb, -1), cRoot((size_t)C), jRoot((size_t)J);
-		auto touch = [&](int body, int root) {
-			if (body < 0 || root < 0)
-			{
-				return;
-			}
-			int key = conflict[body] ? -2 - root : root; // members are unique per island; replicas per (body, island)
-			if (conflict[body])
-			{
-				if (seenBy[body] != -2)
-				{
-					seenBy[body] = -2;
-					islandBodies[root] += 1;
-				}
-			}
-			else if (seenBy[body] != key)
-			{
-				seenBy[body] = key; // approximate distinct count (exact when an immovable body's uses by one island are contiguous)
-				islandBodies[root] += 1;
-			}
-		};
-		for (int k = 0; k < C; ++k)
-		{
-			cRoot[k] = rootOf(ce.a[k], ce.b[k]);
-			touch(ce.a[k], cRoot[k]);
-			touch(ce.b[k], cRoot[k]);
-		}
-		for (int k = 0; k < J; ++k)
-		{
-			jRoot[k] = rootOf(je.a[k], je.b[k]);
-			touch(je.a[k], jRoot[k]);
-			touch(je.b[k], jRoot[k]);
-		}
-		// pack eligible islands into groups in order of first appearance
-		std::vector<int> groupOfRoot((size_t)nb, -2); // -2 unassigned, -1 global
-		int curBodies = 0;
-		auto assign = [&](int root) {
-			if (root < 0)
-			{
-				return -1;
-			}
-			if (groupOfRoot[root] != -2)
-			{
-				return groupOfRoot[root];
-			}
-			int n = islandBodies[root];
-			if (n > s->optMaxGroupBodies)
-			{
-				groupOfRoot[root] = -1;
-				return -1;
-			}
-			if (groupCount == 0 || curBodies + n > s->optPackGroupBodies)
-			{
-				groupCount += 1;
-				curBodies = 0;
-			}
-			curBodies += n;
-			groupOfRoot[root] = groupCount - 1;
-			return groupCount - 1;
-		};
-		for (int k = 0; k < C; ++k)
-		{
-			cPart[k] = assign(cRoot[k]);
-		}
-		for (int k = 0; k < J; ++k)
-		{
-			jPart[k] = assign(jRoot[k]);
-		}
-	}
-
-	phase("islands and groups");
-	// ---- per part lists (pool order is preserved inside every part) ----
-	std::vector<std::vector<int>> cOf((size_t)groupCount + 1), jOf((size_t)groupCount + 1); // index 0 = global, g + 1 = group g
-	for (int k = 0; k < C; ++k)
-	{
-		cOf[(size_t)cPart[k] + 1].push_back(k);
-	}
-	for (int k = 0; k < J; ++k)
-	{
-		jOf[(size_t)jPart[k] + 1].push_back(k);
-	}
-
-	SweepSet& cs = s->contacts;
-	SweepSet& js = s->joints;
-	cs = SweepSet();
-	js = SweepSet();
-	cs.colorOffsets.push_back(0);
-	js.colorOffsets.push_back(0);
-	s->hGroups.clear();
-	s->hResident.clear();
-	s->hContactTail.clear();
-	s->hJointTail.clear();
-	s->hStripA.clear();
-	s->hStripB.clear();
-
-	// ---- strips: the part that fits no LDS group, cut along BFS level sets ----
-	StripPartition strips;
-	bool stripsNeedOneLaunch = false;
-	if (wantStrips && (s->optStripsAnySolver != 0 || jOf[0].empty()))
-	{
-		std::vector<uint8_t> ownedByIsland((size_t)nb, 0);
-		auto mark = [&](int body) {
-			if (body >= 0 && conflict[body])
-			{
-				ownedByIsland[body] = 1;
-			}
-		};
-		for (int k = 0; k < C; ++k)
-		{
-			if (cPart[k] >= 0)
-			{
-				mark(ce.a[k]), mark(ce.b[k]);
-			}
-		}
-		for (int k = 0; k < J; ++k)
-		{
-			if (jPart[k] >= 0)
-			{
-				mark(je.a[k]), mark(je.b[k]);
-			}
-		}
-		std::vector<uint8_t> loose((size_t)nb);
-		int looseCount = 0;
-		for (int i = 0; i < nb; ++i)
-		{
-			loose[i] = s->hBodyLive[i] && !s->hBodyStatic[i] && !ownedByIsland[i];
-			looseCount += loose[i];
-		}
-		if (looseCount >= s->optStripMinBodies)
-		{
-			partitionStrips(ce, je, cOf[0], jOf[0], conflict, loose, nb, std::max(8, (int)((float)s->optStripBodies * stripScale)), s->optMaxGroupBodies, strips);
-		}
-		if (strips.active)
-		{
-			// A body the sweeps WRITE that the partition did not place in any strip -- a static body whose rot is not a fixed
-			// point of the normalisation is written by the position sweeps but is not one of the loose bodies the
-			// breadth-first search walks -- would be written by every strip that touches it: no strips for this graph
-			// (found by fuzzing: seed 259 under XPBD).
-			std::vector<uint8_t> placed((size_t)nb, 0);
-			for (const std::vector<int>& list : strips.bodies)
-			{
-				for (int b : list)
-				{
-					placed[(size_t)b] = 1;
-				}
-			}
-			bool orphan = false;
-			for (const std::vector<std::vector<int>>* lists : {&strips.cA, &strips.cB})
-			{
-				for (const std::vector<int>& list : *lists)
-				{
-					for (int k : list)
-					{
-						orphan = orphan || (ce.a[k] >= 0 && conflict[(size_t)ce.a[k]] && !placed[(size_t)ce.a[k]]) ||
-								 (ce.b[k] >= 0 && conflict[(size_t)ce.b[k]] && !placed[(size_t)ce.b[k]]);
-					}
-				}
-			}
-			for (const std::vector<std::vector<int>>* lists : {&strips.jA, &strips.jB})
-			{
-				for (const std::vector<int>& list : *lists)
-				{
-					for (int k : list)
-					{
-						orphan = orphan || (je.a[k] >= 0 && conflict[(size_t)je.a[k]] && !placed[(size_t)je.a[k]]) ||
-								 (je.b[k] >= 0 && conflict[(size_t)je.b[k]] && !placed[(size_t)je.b[k]]);
-					}
-				}
-			}
-			if (orphan)
-			{
-				strips = StripPartition();
-				s->stripsRejected = true;
-			}
-		}
-		if (strips.active)
-		{
-			// A body the sweeps do not write but the body stages MOVE (kinematic, massless) is a replica in every strip
-			// that touches it.  One launch per step (the persistent kernel) keeps such a copy consistent from start to end;
-			// with one launch per sweep every workgroup re-reads it from HBM while its owner is writing it in the same
-			// launch -- a race.  Such partitions only run on the persistent kernel (found by fuzzing: seed 205).
-			for (const std::vector<std::vector<int>>* lists : {&strips.cA, &strips.cB})
-			{
-				for (const std::vector<int>& list : *lists)
-				{
-					for (int k : list)
-					{
-						for (int b : {ce.a[k], ce.b[k]})
-						{
-							if (b >= 0 && !conflict[(size_t)b] && s->hBodyLive[(size_t)b] && !s->hBodyStatic[(size_t)b])
-							{
-								stripsNeedOneLaunch = true;
-							}
-						}
-					}
-				}
-			}
-		}
-		if (strips.active && getenv("S2AMD_DEBUG_CHECK"))
-		{
-			// the invariants the strip kernels rely on (comment above StripPartition)
-			std::vector<int> owner((size_t)nb, -1), seamOf((size_t)nb, -1);
-			for (size_t i = 0; i < strips.bodies.size(); ++i)
-			{
-				for (int b : strips.bodies[i])
-				{
-					if (owner[(size_t)b] != -1)
-					{
-						fprintf(stderr, "[s2amd] CHECK: body %d owned by strips %d and %zu\n", b, owner[(size_t)b], i);
-					}
-					owner[(size_t)b] = (int)i;
-				}
-			}
-			for (size_t i = 0; i < strips.cA.size(); ++i)
-			{
-				for (int k : strips.cA[i])
-				{
-					for (int b : {ce.a[k], ce.b[k]})
-					{
-						if (b >= 0 && conflict[(size_t)b] && owner[(size_t)b] != (int)i)
-						{
-							fprintf(stderr, "[s2amd] CHECK: interior constraint %d of strip %zu touches body %d of strip %d\n", k, i, b, owner[(size_t)b]);
-						}
-					}
-				}
-			}
-			for (size_t i = 0; i < strips.cB.size(); ++i)
-			{
-				for (int k : strips.cB[i])
-				{
-					for (int b : {ce.a[k], ce.b[k]})
-					{
-						if (b < 0 || !conflict[(size_t)b])
-						{
-							continue;
-						}
-						if (owner[(size_t)b] != (int)i && owner[(size_t)b] != (int)i + 1)
-						{
-							fprintf(stderr, "[s2amd] CHECK: seam %zu constraint %d touches body %d of strip %d\n", i, k, b, owner[(size_t)b]);
-						}
-						if (seamOf[(size_t)b] != -1 && seamOf[(size_t)b] != (int)i)
-						{
-							fprintf(stderr, "[s2amd] CHECK: body %d (strip %d) is touched by seams %d and %zu\n", b, owner[(size_t)b], seamOf[(size_t)b], i);
-						}
-						seamOf[(size_t)b] = (int)i;
-					}
-				}
-			}
-			size_t total = 0;
-			for (size_t i = 0; i < strips.cA.size(); ++i)
-			{
-				total += strips.cA[i].size();
-			}
-			for (size_t i = 0; i < strips.cB.size(); ++i)
-			{
-				total += strips.cB[i].size();
-			}
-			fprintf(stderr, "[s2amd] CHECK: %zu strips, %zu seams, %zu constraints of %zu in the strip part\n", strips.bodies.size(), strips.cB.size(), total, cOf[0].size());
-		}
-		if (strips.active)
-		{
-			cOf[0].clear();
-			jOf[0].clear();
-		}
-	}
-
-	LocalSlots slots(nb);
-	auto gather = [&](const EdgeList& e, const std::vector<int>& ks, std::vector<int>& ids, std::vector<int>& a, std::vector<int>& b) {
 		ids.clear(), a.clear(), b.clear();
 		for (int k : ks)
 		{
@@ -1709,9 +1357,405 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 			a.push_back(e.a[k]);
 			b.push_back(e.b[k]);
 		}
-	};
+	}
 
-	// global part: colour batches over HBM-resident bodies (+ a sequential tail as a one-group LDS table)
+	// ---- phase 1: the potential constraints (edges) of this structure, the hub rule ----
+	int gatherEdges()
+	{
+		conflict.resize((size_t)nb);
+		for (int i = 0; i < nb; ++i)
+		{
+			conflict[i] = (s->hBodyFlags[i] & (cls == 1 ? S2F_WRITE_POS : S2F_WRITE_VEL)) != 0;
+		}
+
+		// potential constraints in pool order (the reference's gather, e.g. solve_tgs_soft.c:162-179, over the slots that CAN have
+		// manifold points; the ones that have none this step are no-ops wherever the sweep order puts them)
+		// hub bodies (solver_internal.h): potential constraints per writable body
+		std::vector<int> degree((size_t)nb, 0);
+		for (int i = 0; i < s->contactCapacity; ++i)
+		{
+			if (s->hContactEdge[i] && s->hContactDead[i])
+			{
+				s->hContactEdge[i] = 0; // a destroyed contact leaves the structure with this rebuild
+				s->hContactDead[i] = 0;
+			}
+			if (s->hContactEdge[i])
+			{
+				degree[(size_t)s->hContactA[i]] += 1;
+				degree[(size_t)s->hContactB[i]] += 1;
+			}
+		}
+		s->hBodyHub.assign((size_t)nb, 0);
+		bool anyHub = false;
+		for (int i = 0; i < nb; ++i)
+		{
+			if (degree[(size_t)i] > S2_HUB_DEGREE && (s->hBodyFlags[(size_t)i] & (S2F_WRITE_VEL | S2F_WRITE_POS)) != 0)
+			{
+				s->hBodyHub[(size_t)i] = 1;
+				anyHub = true;
+			}
+		}
+		if (anyHub && s->worldResident && !s->pointsKnown)
+		{
+			int rcPoints = fetchPointCounts(s); // which manifolds on the hubs have points right now
+			if (rcPoints)
+			{
+				return rcPoints;
+			}
+		}
+		s->hContactWatched.assign((size_t)s->contactCapacity, 0);
+		s->watchedCount = 0;
+		for (int i = 0; i < s->contactCapacity; ++i)
+		{
+			if (s->hContactEdge[i] && anyHub && (s->hBodyHub[(size_t)s->hContactA[i]] || s->hBodyHub[(size_t)s->hContactB[i]]))
+			{
+				s->hContactWatched[(size_t)i] = 1;
+				s->watchedCount += 1;
+				if (s->hContactPoints[(size_t)i] <= 0)
+				{
+					continue; // a potential constraint on a hub body: structural only while its manifold has points
+				}
+			}
+			if (s->hContactEdge[i])
+			{
+				ce.ids.push_back(i);
+				ce.a.push_back(s->hContactA[i]);
+				ce.b.push_back(s->hContactB[i]);
+			}
+		}
+		for (int i = 0; i < s->jointCapacity; ++i)
+		{
+			if (s->hJointType[i] != S2AMD_JOINT_FREE)
+			{
+				je.ids.push_back(i);
+				je.a.push_back(s->hJointType[i] == S2AMD_JOINT_MOUSE ? -1 : s->hJointA[i]); // a mouse joint only touches body B
+				je.b.push_back(s->hJointB[i]);
+			}
+		}
+		C = (int)ce.ids.size(), J = (int)je.ids.size();
+		if (prepTimes)
+		{
+			uint64_t h = 1469598103934665603ull;
+			h = fnv(h, ce.ids.data(), ce.ids.size() * sizeof(int));
+			h = fnv(h, ce.a.data(), ce.a.size() * sizeof(int));
+			h = fnv(h, ce.b.data(), ce.b.size() * sizeof(int));
+			fprintf(stderr, "[s2amd] rebuild #%llu: %d potential contact constraints, %d joints, edge hash %016llx\n", (unsigned long long)s->structureGeneration, C, J,
+					(unsigned long long)h);
+		}
+
+		phase("edge lists");
+		return S2AMD_OK;
+	}
+
+	// ---- phase 2: islands = connected components over the writable bodies; the small ones are packed into LDS groups ----
+	void findIslands()
+	{
+		cPart.assign((size_t)C, -1), jPart.assign((size_t)J, -1);
+		groupCount = 0;
+		flags = s->hBodyFlags;
+		if (grouped && (C > 0 || J > 0))
+		{
+			UnionFind uf(nb);
+			auto link = [&](int a, int b) {
+				if (a >= 0 && b >= 0 && conflict[a] && conflict[b])
+				{
+					uf.unite(a, b);
+				}
+			};
+			for (int k = 0; k < C; ++k)
+			{
+				link(ce.a[k], ce.b[k]);
+			}
+			for (int k = 0; k < J; ++k)
+			{
+				link(je.a[k], je.b[k]);
+			}
+			auto rootOf = [&](int a, int b) {
+				if (a >= 0 && conflict[a])
+				{
+					return uf.find(a);
+				}
+				if (b >= 0 && conflict[b])
+				{
+					return uf.find(b);
+				}
+				return -1;
+			};
+			// bodies an island would stage in LDS: its members that carry constraints + read-only replicas
+			std::vector<int> islandBodies((size_t)nb, 0), seenBy((size_t)nb, -1), cRoot((size_t)C), jRoot((size_t)J);
+			auto touch = [&](int body, int root) {
+				if (body < 0 || root < 0)
+				{
+					return;
+				}
+				int key = conflict[body] ? -2 - root : root; // members are unique per island; replicas per (body, island)
+				if (conflict[body])
+				{
+					if (seenBy[body] != -2)
+					{
+						seenBy[body] = -2;
+						islandBodies[root] += 1;
+					}
+				}
+				else if (seenBy[body] != key)
+				{
+					seenBy[body] = key; // approximate distinct count (exact when an immovable body's uses by one island are contiguous)
+					islandBodies[root] += 1;
+				}
+			};
+			for (int k = 0; k < C; ++k)
+			{
+				cRoot[k] = rootOf(ce.a[k], ce.b[k]);
+				touch(ce.a[k], cRoot[k]);
+				touch(ce.b[k], cRoot[k]);
+			}
+			for (int k = 0; k < J; ++k)
+			{
+				jRoot[k] = rootOf(je.a[k], je.b[k]);
+				touch(je.a[k], jRoot[k]);
+				touch(je.b[k], jRoot[k]);
+			}
+			// pack eligible islands into groups in order of first appearance
+			std::vector<int> groupOfRoot((size_t)nb, -2); // -2 unassigned, -1 global
+			int curBodies = 0;
+			auto assign = [&](int root) {
+				if (root < 0)
+				{
+					return -1;
+				}
+				if (groupOfRoot[root] != -2)
+				{
+					return groupOfRoot[root];
+				}
+				int n = islandBodies[root];
+				if (n > s->optMaxGroupBodies)
+				{
+					groupOfRoot[root] = -1;
+					return -1;
+				}
+				if (groupCount == 0 || curBodies + n > s->optPackGroupBodies)
+				{
+					groupCount += 1;
+					curBodies = 0;
+				}
+				curBodies += n;
+				groupOfRoot[root] = groupCount - 1;
+				return groupCount - 1;
+			};
+			for (int k = 0; k < C; ++k)
+			{
+				cPart[k] = assign(cRoot[k]);
+			}
+			for (int k = 0; k < J; ++k)
+			{
+				jPart[k] = assign(jRoot[k]);
+			}
+		}
+
+		phase("islands and groups");
+	}
+
+	// ---- phase 3: per part lists (pool order is preserved inside every part), empty sweep sets ----
+	void splitParts()
+	{
+		cOf.assign((size_t)groupCount + 1, {}), jOf.assign((size_t)groupCount + 1, {});
+		for (int k = 0; k < C; ++k)
+		{
+			cOf[(size_t)cPart[k] + 1].push_back(k);
+		}
+		for (int k = 0; k < J; ++k)
+		{
+			jOf[(size_t)jPart[k] + 1].push_back(k);
+		}
+
+		cs = SweepSet();
+		js = SweepSet();
+		cs.colorOffsets.push_back(0);
+		js.colorOffsets.push_back(0);
+		s->hGroups.clear();
+		s->hResident.clear();
+		s->hContactTail.clear();
+		s->hJointTail.clear();
+		s->hStripA.clear();
+		s->hStripB.clear();
+	}
+
+	// ---- phase 4: strips = the part that fits no LDS group, cut along BFS level sets ----
+	void cutStrips()
+	{
+		strips = StripPartition();
+		stripsNeedOneLaunch = false;
+		if (wantStrips && (s->optStripsAnySolver != 0 || jOf[0].empty()))
+		{
+			std::vector<uint8_t> ownedByIsland((size_t)nb, 0);
+			auto mark = [&](int body) {
+				if (body >= 0 && conflict[body])
+				{
+					ownedByIsland[body] = 1;
+				}
+			};
+			for (int k = 0; k < C; ++k)
+			{
+				if (cPart[k] >= 0)
+				{
+					mark(ce.a[k]), mark(ce.b[k]);
+				}
+			}
+			for (int k = 0; k < J; ++k)
+			{
+				if (jPart[k] >= 0)
+				{
+					mark(je.a[k]), mark(je.b[k]);
+				}
+			}
+			std::vector<uint8_t> loose((size_t)nb);
+			int looseCount = 0;
+			for (int i = 0; i < nb; ++i)
+			{
+				loose[i] = s->hBodyLive[i] && !s->hBodyStatic[i] && !ownedByIsland[i];
+				looseCount += loose[i];
+			}
+			if (looseCount >= s->optStripMinBodies)
+			{
+				partitionStrips(ce, je, cOf[0], jOf[0], conflict, loose, nb, std::max(8, (int)((float)s->optStripBodies * stripScale)), s->optMaxGroupBodies, strips);
+			}
+			if (strips.active)
+			{
+				// A body the sweeps WRITE that the partition did not place in any strip -- a static body whose rot is not a fixed
+				// point of the normalisation is written by the position sweeps but is not one of the loose bodies the
+				// breadth-first search walks -- would be written by every strip that touches it: no strips for this graph
+				// (found by fuzzing: seed 259 under XPBD).
+				std::vector<uint8_t> placed((size_t)nb, 0);
+				for (const std::vector<int>& list : strips.bodies)
+				{
+					for (int b : list)
+					{
+						placed[(size_t)b] = 1;
+					}
+				}
+				bool orphan = false;
+				for (const std::vector<std::vector<int>>* lists : {&strips.cA, &strips.cB})
+				{
+					for (const std::vector<int>& list : *lists)
+					{
+						for (int k : list)
+						{
+							orphan = orphan || (ce.a[k] >= 0 && conflict[(size_t)ce.a[k]] && !placed[(size_t)ce.a[k]]) ||
+									 (ce.b[k] >= 0 && conflict[(size_t)ce.b[k]] && !placed[(size_t)ce.b[k]]);
+						}
+					}
+				}
+				for (const std::vector<std::vector<int>>* lists : {&strips.jA, &strips.jB})
+				{
+					for (const std::vector<int>& list : *lists)
+					{
+						for (int k : list)
+						{
+							orphan = orphan || (je.a[k] >= 0 && conflict[(size_t)je.a[k]] && !placed[(size_t)je.a[k]]) ||
+									 (je.b[k] >= 0 && conflict[(size_t)je.b[k]] && !placed[(size_t)je.b[k]]);
+						}
+					}
+				}
+				if (orphan)
+				{
+					strips = StripPartition();
+					s->stripsRejected = true;
+				}
+			}
+			if (strips.active)
+			{
+				// A body the sweeps do not write but the body stages MOVE (kinematic, massless) is a replica in every strip
+				// that touches it.  One launch per step (the persistent kernel) keeps such a copy consistent from start to end;
+				// with one launch per sweep every workgroup re-reads it from HBM while its owner is writing it in the same
+				// launch -- a race.  Such partitions only run on the persistent kernel (found by fuzzing: seed 205).
+				for (const std::vector<std::vector<int>>* lists : {&strips.cA, &strips.cB})
+				{
+					for (const std::vector<int>& list : *lists)
+					{
+						for (int k : list)
+						{
+							for (int b : {ce.a[k], ce.b[k]})
+							{
+								if (b >= 0 && !conflict[(size_t)b] && s->hBodyLive[(size_t)b] && !s->hBodyStatic[(size_t)b])
+								{
+									stripsNeedOneLaunch = true;
+								}
+							}
+						}
+					}
+				}
+			}
+			if (strips.active && getenv("S2AMD_DEBUG_CHECK"))
+			{
+				// the invariants the strip kernels rely on (comment above StripPartition)
+				std::vector<int> owner((size_t)nb, -1), seamOf((size_t)nb, -1);
+				for (size_t i = 0; i < strips.bodies.size(); ++i)
+				{
+					for (int b : strips.bodies[i])
+					{
+						if (owner[(size_t)b] != -1)
+						{
+							fprintf(stderr, "[s2amd] CHECK: body %d owned by strips %d and %zu\n", b, owner[(size_t)b], i);
+						}
+						owner[(size_t)b] = (int)i;
+					}
+				}
+				for (size_t i = 0; i < strips.cA.size(); ++i)
+				{
+					for (int k : strips.cA[i])
+					{
+						for (int b : {ce.a[k], ce.b[k]})
+						{
+							if (b >= 0 && conflict[(size_t)b] && owner[(size_t)b] != (int)i)
+							{
+								fprintf(stderr, "[s2amd] CHECK: interior constraint %d of strip %zu touches body %d of strip %d\n", k, i, b, owner[(size_t)b]);
+							}
+						}
+					}
+				}
+				for (size_t i = 0; i < strips.cB.size(); ++i)
+				{
+					for (int k : strips.cB[i])
+					{
+						for (int b : {ce.a[k], ce.b[k]})
+						{
+							if (b < 0 || !conflict[(size_t)b])
+							{
+								continue;
+							}
+							if (owner[(size_t)b] != (int)i && owner[(size_t)b] != (int)i + 1)
+							{
+								fprintf(stderr, "[s2amd] CHECK: seam %zu constraint %d touches body %d of strip %d\n", i, k, b, owner[(size_t)b]);
+							}
+							if (seamOf[(size_t)b] != -1 && seamOf[(size_t)b] != (int)i)
+							{
+								fprintf(stderr, "[s2amd] CHECK: body %d (strip %d) is touched by seams %d and %zu\n", b, owner[(size_t)b], seamOf[(size_t)b], i);
+							}
+							seamOf[(size_t)b] = (int)i;
+						}
+					}
+				}
+				size_t total = 0;
+				for (size_t i = 0; i < strips.cA.size(); ++i)
+				{
+					total += strips.cA[i].size();
+				}
+				for (size_t i = 0; i < strips.cB.size(); ++i)
+				{
+					total += strips.cB[i].size();
+				}
+				fprintf(stderr, "[s2amd] CHECK: %zu strips, %zu seams, %zu constraints of %zu in the strip part\n", strips.bodies.size(), strips.cB.size(), total, cOf[0].size());
+			}
+			if (strips.active)
+			{
+				cOf[0].clear();
+				jOf[0].clear();
+			}
+		}
+	}
+
+	// ---- phase 5: the global part = colour batches over HBM-resident bodies (+ a sequential tail as a one-group LDS table) ----
+	void colourGlobalPart()
 	{
 		std::vector<int> ids, a, b, pos;
 		gather(ce, cOf[0], ids, a, b);
@@ -1797,8 +1841,9 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 
 	// one LDS group: local body slots (seeded bodies first: owned, in the given order), colour batches of
 	// its contacts and joints appended to the sweep sets, one row in table `t`
-	auto emitGroup = [&](HostGroupTable& t, const std::vector<int>& cKs, const std::vector<int>& jKs, const std::vector<int>& seedBodies,
-						 const std::vector<int>* replicaOf = nullptr, const std::vector<int>* replicaOf2 = nullptr) {
+	void emitGroup(HostGroupTable& t, const std::vector<int>& cKs, const std::vector<int>& jKs, const std::vector<int>& seedBodies,
+				   const std::vector<int>* replicaOf = nullptr, const std::vector<int>* replicaOf2 = nullptr)
+	{
 		std::vector<int> ids, a, b, bodies, la, lb, pos, batchOffsets;
 		bool tail = false;
 		slots.begin();
@@ -1889,18 +1934,12 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 		}
 		t.bodyOffsets.push_back((int)t.bodyIds.size());
 		t.maxBodies = std::max(t.maxBodies, (int)bodies.size());
-	};
+	}
 
-	// LDS groups: whole-step kernel, bodies in LDS
-	// ... or, under the soft contact solvers, RESIDENT islands: the same groups with their constraints in the registers of
-	// one 512-thread workgroup for the whole step (strip_kernel.hip: islandStepKernel) -- contact-only groups whose colouring
-	// fits the kernel's rounds; the others stay plain LDS groups
-	const std::vector<int> noSeed;
-	const bool softSolver = solverType == s2amd_solverTGS_Soft || solverType == s2amd_solverSoftStep || solverType == s2amd_solverPGS_Soft;
-	const bool wantResident = grouped && softSolver && s->optIslandResident != 0 && !s->residentRejected;
 	// does the greedy colouring of this group fit the resident kernel: at most 8 rounds of at most 512 constraints, no
 	// sequential tail?  (The same colouring emitGroup will produce: a dry run on the pool indices.)
-	auto fitsResident = [&](const std::vector<int>& cKs) {
+	bool fitsResident(const std::vector<int>& cKs) const
+	{
 		std::vector<int> a, b, color;
 		a.reserve(cKs.size()), b.reserve(cKs.size());
 		for (int k : cKs)
@@ -1921,218 +1960,282 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 			}
 		}
 		return true;
-	};
-	std::vector<uint8_t> residentGroup((size_t)groupCount, 0);
-	for (int g = 0; g < groupCount; ++g)
-	{
-		const std::vector<int>& cKs = cOf[(size_t)g + 1];
-		residentGroup[(size_t)g] = wantResident && jOf[(size_t)g + 1].empty() && !cKs.empty() && cKs.size() <= (size_t)S2_STRIP_ROUNDS_MAX * 512 && fitsResident(cKs);
-		if (!residentGroup[(size_t)g])
-		{
-			emitGroup(s->hGroups, cKs, jOf[(size_t)g + 1], noSeed);
-		}
 	}
-	s->residentK0 = (int)cs.order.size(); // the resident islands' constraints are one range of the sweep order
-	for (int g = 0; g < groupCount; ++g)
+
+	// ---- phase 6: LDS groups (whole-step kernel, bodies in LDS) ... or, under the soft contact solvers, RESIDENT islands: the
+	// same groups with their constraints in the registers of one 512-thread workgroup for the whole step (strip_kernel.hip:
+	// islandStepKernel) -- contact-only groups whose colouring fits the kernel's rounds; the others stay plain LDS groups
+	void emitIslandGroups()
 	{
-		const std::vector<int>& cKs = cOf[(size_t)g + 1];
-		if (residentGroup[(size_t)g])
+		const std::vector<int> noSeed;
+		std::vector<uint8_t> residentGroup((size_t)groupCount, 0);
+		for (int g = 0; g < groupCount; ++g)
 		{
-			std::vector<int> seed; // the bodies the group owns (its sweeps write them), in order of first use: they lead the body list
-			slots.begin();
-			for (int k : cKs)
+			const std::vector<int>& cKs = cOf[(size_t)g + 1];
+			residentGroup[(size_t)g] = residentWanted && jOf[(size_t)g + 1].empty() && !cKs.empty() && cKs.size() <= (size_t)S2_STRIP_ROUNDS_MAX * 512 && fitsResident(cKs);
+			if (!residentGroup[(size_t)g])
 			{
-				for (int body : {ce.a[k], ce.b[k]})
+				emitGroup(s->hGroups, cKs, jOf[(size_t)g + 1], noSeed);
+			}
+		}
+		s->residentK0 = (int)cs.order.size(); // the resident islands' constraints are one range of the sweep order
+		for (int g = 0; g < groupCount; ++g)
+		{
+			const std::vector<int>& cKs = cOf[(size_t)g + 1];
+			if (residentGroup[(size_t)g])
+			{
+				std::vector<int> seed; // the bodies the group owns (its sweeps write them), in order of first use: they lead the body list
+				slots.begin();
+				for (int k : cKs)
 				{
-					if (body >= 0 && conflict[(size_t)body] && slots.stamp[(size_t)body] != slots.epoch)
+					for (int body : {ce.a[k], ce.b[k]})
 					{
-						slots.stamp[(size_t)body] = slots.epoch;
-						seed.push_back(body);
+						if (body >= 0 && conflict[(size_t)body] && slots.stamp[(size_t)body] != slots.epoch)
+						{
+							slots.stamp[(size_t)body] = slots.epoch;
+							seed.push_back(body);
+						}
 					}
 				}
+				emitGroup(s->hResident, cKs, jOf[(size_t)g + 1], seed);
 			}
-			emitGroup(s->hResident, cKs, jOf[(size_t)g + 1], seed);
 		}
-	}
-	s->residentK1 = (int)cs.order.size();
-
-	// strips of the big islands: phase A = interiors (own every body of the strip), phase B = seams
-	const int stripBaseC = (int)cs.order.size(), stripBaseJ = (int)js.order.size();
-	for (size_t i = 0; i < strips.bodies.size(); ++i)
-	{
-		emitGroup(s->hStripA, strips.cA[i], strips.jA[i], strips.bodies[i], i < strips.cB.size() ? &strips.cB[i] : nullptr,
-				  i > 0 ? &strips.cB[i - 1] : nullptr);
-	}
-	int stripInterior = (int)cs.order.size(), stripInteriorJ = (int)js.order.size();
-	std::vector<int> seamGroup(strips.cB.size(), -1);
-	for (size_t i = 0; i < strips.cB.size(); ++i)
-	{
-		if (!strips.cB[i].empty() || !strips.jB[i].empty())
-		{
-			seamGroup[i] = s->hStripB.count();
-			emitGroup(s->hStripB, strips.cB[i], strips.jB[i], noSeed);
-		}
-	}
-	if (strips.active)
-	{
-		cs.stripCount = (int)cs.order.size() - stripBaseC;
-		js.stripCount = (int)js.order.size() - stripBaseJ;
-		cs.seamCount = (int)cs.order.size() - stripInterior;
-		js.seamCount = (int)js.order.size() - stripInteriorJ;
+		s->residentK1 = (int)cs.order.size();
 	}
 
-	if (!s->inc.positionOfSlot.empty())
+	// ---- phase 7: strips of the big islands: phase A = interiors (own every body of the strip), phase B = seams ----
+	void emitStrips()
 	{
-		for (size_t k = (size_t)cs.globalCount; k < cs.order.size(); ++k)
+		const std::vector<int> noSeed;
+		stripBaseC = (int)cs.order.size();
+		const int stripBaseJ = (int)js.order.size();
+		for (size_t i = 0; i < strips.bodies.size(); ++i)
 		{
-			s->inc.positionOfSlot[(size_t)cs.order[k]] = -2; // lives in an LDS group or a strip: only a rebuild can move it
+			emitGroup(s->hStripA, strips.cA[i], strips.jA[i], strips.bodies[i], i < strips.cB.size() ? &strips.cB[i] : nullptr,
+					  i > 0 ? &strips.cB[i - 1] : nullptr);
 		}
-	}
-	s->hBodyFlagsFinal = flags;
-	s->looseBodies = 0;
-	for (int i = 0; i < nb; ++i)
-	{
-		if (s->hBodyLive[i] && !s->hBodyStatic[i] && (flags[i] & S2F_IN_GROUP) == 0)
+		int stripInterior = (int)cs.order.size(), stripInteriorJ = (int)js.order.size();
+		seamGroup.assign(strips.cB.size(), -1);
+		for (size_t i = 0; i < strips.cB.size(); ++i)
 		{
-			s->looseBodies += 1;
+			if (!strips.cB[i].empty() || !strips.jB[i].empty())
+			{
+				seamGroup[i] = s->hStripB.count();
+				emitGroup(s->hStripB, strips.cB[i], strips.jB[i], noSeed);
+			}
 		}
+		if (strips.active)
+		{
+			cs.stripCount = (int)cs.order.size() - stripBaseC;
+			js.stripCount = (int)js.order.size() - stripBaseJ;
+			cs.seamCount = (int)cs.order.size() - stripInterior;
+			js.seamCount = (int)js.order.size() - stripInteriorJ;
+		}
+
+		if (!s->inc.positionOfSlot.empty())
+		{
+			for (size_t k = (size_t)cs.globalCount; k < cs.order.size(); ++k)
+			{
+				s->inc.positionOfSlot[(size_t)cs.order[k]] = -2; // lives in an LDS group or a strip: only a rebuild can move it
+			}
+		}
+		s->hBodyFlagsFinal = flags;
+		s->looseBodies = 0;
+		for (int i = 0; i < nb; ++i)
+		{
+			if (s->hBodyLive[i] && !s->hBodyStatic[i] && (flags[i] & S2F_IN_GROUP) == 0)
+			{
+				s->looseBodies += 1;
+			}
+		}
+
+		phase("colours, batches");
 	}
 
-	phase("colours, batches");
-	// ---- device tables ----
-	int rc;
-	const int CP = (int)cs.order.size(); // positions of the sweep order: the C potential constraints + the global part's free positions
-	if ((rc = carveContacts(s, CP)) != 0 || (rc = carveJoints(s, J)) != 0)
+	// ---- phase 8: device tables ----
+	int uploadTables()
 	{
-		return rc;
-	}
-	bool grew = false;
-	if ((rc = s->dContactIndex.ensure((size_t)std::max(CP, 1) * sizeof(int), &grew)) != 0 ||
-		(rc = s->dJointIndex.ensure((size_t)std::max(J, 1) * sizeof(int), &grew)) != 0 ||
-		(rc = s->dContactLocal.ensure((size_t)std::max(CP, 1) * sizeof(int2), &grew)) != 0 ||
-		(rc = s->dJointLocal.ensure((size_t)std::max(J, 1) * sizeof(int2), &grew)) != 0)
-	{
-		return rc;
-	}
-	if (grew)
-	{
-		s->layoutGeneration += 1;
-	}
-	if (CP > 0)
-	{
-		HIP_TRY(hipMemcpyAsync(s->dContactIndex.p, cs.order.data(), (size_t)CP * sizeof(int), hipMemcpyHostToDevice, s->stream));
-		HIP_TRY(hipMemcpyAsync(s->dContactLocal.p, cs.local.data(), (size_t)CP * sizeof(int2), hipMemcpyHostToDevice, s->stream));
-	}
-	if (J > 0)
-	{
-		HIP_TRY(hipMemcpyAsync(s->dJointIndex.p, js.order.data(), (size_t)J * sizeof(int), hipMemcpyHostToDevice, s->stream));
-		HIP_TRY(hipMemcpyAsync(s->dJointLocal.p, js.local.data(), (size_t)J * sizeof(int2), hipMemcpyHostToDevice, s->stream));
-	}
-	if (nb > 0)
-	{
-		HIP_TRY(hipMemcpyAsync(s->dBodyFlags.p, flags.data(), (size_t)nb * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
-	}
-	if (s->worldResident)
-	{
-		if ((rc = s->dWatched.ensure(std::max<size_t>((size_t)s->contactCapacity, 256), &grew)) != 0)
+		int rc;
+		const int CP = (int)cs.order.size(); // positions of the sweep order: the C potential constraints + the global part's free positions
+		if ((rc = carveContacts(s, CP)) != 0 || (rc = carveJoints(s, J)) != 0)
 		{
 			return rc;
 		}
-		if (s->contactCapacity > 0)
-		{
-			HIP_TRY(hipMemcpyAsync(s->dWatched.p, s->hContactWatched.data(), (size_t)s->contactCapacity, hipMemcpyHostToDevice, s->stream));
-		}
-	}
-	s->cv.contactIndex = (int*)s->dContactIndex.p;
-	s->cv.localBodies = (int2*)s->dContactLocal.p;
-	s->cv.count = CP;
-	s->cv.skipBegin = s->cv.skipEnd = 0; // (set per step by the executor when the resident-island kernel runs)
-	s->jv.jointIndex = (int*)s->dJointIndex.p;
-	s->jv.localBodies = (int2*)s->dJointLocal.p;
-	s->jv.count = J;
-	if ((rc = uploadGroupTable(s, s->hResident, s->dResident)) != 0 || (rc = buildResidentTables(s)) != 0)
-	{
-		return rc;
-	}
-	if (s->residentRejected && s->hResident.count() > 0)
-	{
-		// some island needs more colour rounds than the resident kernel holds: all of them as plain LDS groups for this graph
-		s->structureDirty = true;
-		return buildStructureWith(s, solverType, stripScale);
-	}
-	if ((rc = uploadGroupTable(s, s->hGroups, s->dGroups)) != 0 || (rc = uploadGroupTable(s, s->hContactTail, s->dContactTail)) != 0 ||
-		(rc = uploadGroupTable(s, s->hJointTail, s->dJointTail)) != 0 || (rc = uploadGroupTable(s, s->hStripA, s->dStripA)) != 0 ||
-		(rc = uploadGroupTable(s, s->hStripB, s->dStripB)) != 0)
-	{
-		return rc;
-	}
-
-	phase("index tables");
-	// ---- lean strip tables: per-group descriptors + warm-start slots (strip_kernel.hip) ----
-	s->leanAValid = s->leanBValid = false;
-	s->persistValid = false;
-	s->leanA = StripTableView{};
-	s->leanB = StripTableView{};
-	if (strips.active && s->optStripLean)
-	{
-		if ((rc = buildLeanStripTables(s, strips, conflict, seamGroup, stripBaseC, nb)) != 0)
+		bool grew = false;
+		if ((rc = s->dContactIndex.ensure((size_t)std::max(CP, 1) * sizeof(int), &grew)) != 0 ||
+			(rc = s->dJointIndex.ensure((size_t)std::max(J, 1) * sizeof(int), &grew)) != 0 ||
+			(rc = s->dContactLocal.ensure((size_t)std::max(CP, 1) * sizeof(int2), &grew)) != 0 ||
+			(rc = s->dJointLocal.ensure((size_t)std::max(J, 1) * sizeof(int2), &grew)) != 0)
 		{
 			return rc;
 		}
+		if (grew)
+		{
+			s->layoutGeneration += 1;
+		}
+		if (CP > 0)
+		{
+			HIP_TRY(hipMemcpyAsync(s->dContactIndex.p, cs.order.data(), (size_t)CP * sizeof(int), hipMemcpyHostToDevice, s->stream));
+			HIP_TRY(hipMemcpyAsync(s->dContactLocal.p, cs.local.data(), (size_t)CP * sizeof(int2), hipMemcpyHostToDevice, s->stream));
+		}
+		if (J > 0)
+		{
+			HIP_TRY(hipMemcpyAsync(s->dJointIndex.p, js.order.data(), (size_t)J * sizeof(int), hipMemcpyHostToDevice, s->stream));
+			HIP_TRY(hipMemcpyAsync(s->dJointLocal.p, js.local.data(), (size_t)J * sizeof(int2), hipMemcpyHostToDevice, s->stream));
+		}
+		if (nb > 0)
+		{
+			HIP_TRY(hipMemcpyAsync(s->dBodyFlags.p, flags.data(), (size_t)nb * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+		}
+		if (s->worldResident)
+		{
+			if ((rc = s->dWatched.ensure(std::max<size_t>((size_t)s->contactCapacity, 256), &grew)) != 0)
+			{
+				return rc;
+			}
+			if (s->contactCapacity > 0)
+			{
+				HIP_TRY(hipMemcpyAsync(s->dWatched.p, s->hContactWatched.data(), (size_t)s->contactCapacity, hipMemcpyHostToDevice, s->stream));
+			}
+		}
+		s->cv.contactIndex = (int*)s->dContactIndex.p;
+		s->cv.localBodies = (int2*)s->dContactLocal.p;
+		s->cv.count = CP;
+		s->cv.skipBegin = s->cv.skipEnd = 0; // (set per step by the executor when the resident-island kernel runs)
+		s->jv.jointIndex = (int*)s->dJointIndex.p;
+		s->jv.localBodies = (int2*)s->dJointLocal.p;
+		s->jv.count = J;
+		if ((rc = uploadGroupTable(s, s->hResident, s->dResident)) != 0 || (rc = buildResidentTables(s)) != 0)
+		{
+			return rc;
+		}
+		if (s->residentRejected && s->hResident.count() > 0)
+		{
+			// some island needs more colour rounds than the resident kernel holds: all of them as plain LDS groups for this graph
+			s->structureDirty = true;
+			rebuild = true;
+			return S2AMD_OK;
+		}
+		if ((rc = uploadGroupTable(s, s->hGroups, s->dGroups)) != 0 || (rc = uploadGroupTable(s, s->hContactTail, s->dContactTail)) != 0 ||
+			(rc = uploadGroupTable(s, s->hJointTail, s->dJointTail)) != 0 || (rc = uploadGroupTable(s, s->hStripA, s->dStripA)) != 0 ||
+			(rc = uploadGroupTable(s, s->hStripB, s->dStripB)) != 0)
+		{
+			return rc;
+		}
+		phase("index tables");
+		return S2AMD_OK;
 	}
 
-	// strips only pay through the strip kernels: when neither the persistent step nor the lean launches can take this
-	// partition (too many colours, a hub body, LDS budget), fall back to the colour-batch structure for this graph
-	s->stripsNeedOneLaunch = strips.active && stripsNeedOneLaunch;
-	if (stripsNeedOneLaunch)
+	// ---- phase 9: lean strip tables: per-group descriptors + warm-start slots (strip_kernel.hip) ----
+	int buildStripTables()
 	{
+		int rc;
 		s->leanAValid = s->leanBValid = false;
-	}
-	if (strips.active && !s->persistValid && (stripsNeedOneLaunch || (!s->optStripsAnySolver && !(s->leanAValid && s->leanBValid))))
-	{
-		s->stripsRejected = true;
-		s->structureDirty = true;
-		return buildStructureWith(s, solverType, stripScale);
+		s->persistValid = false;
+		s->leanA = StripTableView{};
+		s->leanB = StripTableView{};
+		if (strips.active && s->optStripLean)
+		{
+			if ((rc = buildLeanStripTables(s, strips, conflict, seamGroup, stripBaseC, nb)) != 0)
+			{
+				return rc;
+			}
+		}
+
+		// strips only pay through the strip kernels: when neither the persistent step nor the lean launches can take this
+		// partition (too many colours, a hub body, LDS budget), fall back to the colour-batch structure for this graph
+		s->stripsNeedOneLaunch = strips.active && stripsNeedOneLaunch;
+		if (stripsNeedOneLaunch)
+		{
+			s->leanAValid = s->leanBValid = false;
+		}
+		if (strips.active && !s->persistValid && (stripsNeedOneLaunch || (!s->optStripsAnySolver && !(s->leanAValid && s->leanBValid))))
+		{
+			s->stripsRejected = true;
+			s->structureDirty = true;
+			rebuild = true;
+			return S2AMD_OK;
+		}
+		phase("strip tables");
+		return S2AMD_OK;
 	}
 
-	phase("strip tables");
-	// ---- message-passing tables of the global part (see MsgBodies) ----
-	s->msgTablesValid = false;
-	if (s->optMessage != 0 && cs.globalCount > 0 && js.globalCount == 0 && !cs.hasTail && !needAdj) // 0.25 ms of host time at 60k constraints
+	// ---- phase 10: message-passing tables of the global part (see MsgBodies), body adjacency, bookkeeping ----
+	int finish()
 	{
-		if ((rc = buildMessageTables(s, nb)) != 0)
+		int rc;
+		s->msgTablesValid = false;
+		if (s->optMessage != 0 && cs.globalCount > 0 && js.globalCount == 0 && !cs.hasTail && !needAdj) // 0.25 ms of host time at 60k constraints
+		{
+			if ((rc = buildMessageTables(s, nb)) != 0)
+			{
+				return rc;
+			}
+		}
+
+		phase("message tables");
+		s->adjValid = false;
+		if ((rc = buildAdjacency(s, conflict, nb)) != 0)
 		{
 			return rc;
 		}
-	}
+		// the staging vectors above die with this scope: hipMemcpyAsync from pageable host memory
+		// copies through a staging buffer before it returns, so that is safe
+		HIP_TRY(hipStreamSynchronize(s->stream));
+		phase("adjacency + sync");
 
-	phase("message tables");
-	s->adjValid = false;
-	if ((rc = buildAdjacency(s, conflict, nb)) != 0)
+		// created contacts can be placed into this structure while its global part has the slack layout
+		s->slackPositions = 0;
+		for (int k = 0; k < cs.globalCount; ++k)
+		{
+			s->slackPositions += cs.order[(size_t)k] < 0 ? 1 : 0;
+		}
+		s->inc.valid = s->optIncremental != 0 && s->inc.solverClass == cls && !s->msgTablesValid && !s->inc.positionOfSlot.empty();
+		s->inc.patches.clear();
+		s->orderSolverClass = cls;
+		s->orderResident = residentWanted;
+		s->orderGrouped = grouped;
+		s->orderStrips = wantStrips;
+		s->structureDirty = false;
+		s->structureGeneration += 1;
+		s->stats.hostPrepMs = (float)(nowMs() - t0);
+		return S2AMD_OK;
+	}
+};
+
+static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
+{
+	StructureBuild build(s, solverType, stripScale);
+	if (build.upToDate())
+	{
+		return S2AMD_OK;
+	}
+	if (s->worldResident && !s->pointsKnown)
+	{
+		// world chain: the pair slots this step's (already enqueued) stage 3 and the earlier ones freed leave the structure
+		// with this rebuild, exactly as a host that ran stage 3 itself would have dropped them from the arrays it uploads
+		int rcDead = syncDeadSlots(s);
+		if (rcDead)
+		{
+			return rcDead;
+		}
+	}
+	int rc = build.gatherEdges();
+	if (rc)
 	{
 		return rc;
 	}
-	// the staging vectors above die with this scope: hipMemcpyAsync from pageable host memory
-	// copies through a staging buffer before it returns, so that is safe
-	HIP_TRY(hipStreamSynchronize(s->stream));
-	phase("adjacency + sync");
-
-	// created contacts can be placed into this structure while its global part has the slack layout
-	s->slackPositions = 0;
-	for (int k = 0; k < cs.globalCount; ++k)
+	build.findIslands();
+	build.splitParts();
+	build.cutStrips();
+	build.colourGlobalPart();
+	build.emitIslandGroups();
+	build.emitStrips();
+	if ((rc = build.uploadTables()) != 0 || build.rebuild || (rc = build.buildStripTables()) != 0 || build.rebuild)
 	{
-		s->slackPositions += cs.order[(size_t)k] < 0 ? 1 : 0;
+		return rc ? rc : buildStructureWith(s, solverType, stripScale);
 	}
-	s->inc.valid = s->optIncremental != 0 && s->inc.solverClass == cls && !s->msgTablesValid && !s->inc.positionOfSlot.empty();
-	s->inc.patches.clear();
-	s->orderSolverClass = cls;
-	s->orderResident = residentWanted;
-	s->orderGrouped = grouped;
-	s->orderStrips = wantStrips;
-	s->structureDirty = false;
-	s->structureGeneration += 1;
-	s->stats.hostPrepMs = (float)(nowMs() - t0);
-	return S2AMD_OK;
+	return build.finish();
 }
 
 // The strip partition is a heuristic cut (BFS levels, `strip_bodies` per strip) and the colouring of what it cuts out

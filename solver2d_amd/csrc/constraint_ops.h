@@ -166,27 +166,42 @@ template <class BA> S2_DEV void storePose(const BA& b, int i, V2 dc, Rot q)
 // s2WarmStartContacts_Fixed (solve_soft_step.c:16-63), and the second loop of
 // s2CreateContactSolver (solve_pgs_ngs_block.c:279-319, fixed anchors, reduced point count)
 // ---------------------------------------------------------------------------------------------
-template <int KIND, class BA>
-S2_DEV void warmStartContactsOne(const ContactView& c, const BA& b, int k)
+// one constraint's warm-start data in registers: loading is separate from the arithmetic so the sequential tail
+// (group_kernel.hip: walkTail) can have a whole wave issue its loads at once
+struct WarmRegs
 {
-	CHeader h = loadHeaderB(c, b, k);
-	int pointCount = h.pointCount;
-	V2 tangent = rightPerp(h.normal);
+	CHeader h;
+	float4 arm[2];
+	float2 imp[2];
+	V2 tangent;
+	int pointCount;
+};
+
+template <int KIND, class BA> S2_DEV WarmRegs loadWarm(const ContactView& c, const BA& b, int k)
+{
+	WarmRegs r;
+	r.h = loadHeaderB(c, b, k);
+	r.pointCount = r.h.pointCount;
+	r.tangent = rightPerp(r.h.normal);
 	if (KIND == WARM_BLOCK)
 	{
-		pointCount = (int)asBits(c.blockK[k].w);
-		tangent = crossVS(h.normal, 1.0f);
+		r.pointCount = (int)asBits(c.blockK[k].w);
+		r.tangent = crossVS(r.h.normal, 1.0f);
 	}
 	// every load of the constraint is issued before the first use: slot 1 of a one-point constraint is
 	// a valid, zero-filled record (prepareContactsKernel), so the loads need no guard
-	float4 arm[2];
-	float2 imp[2];
 #pragma unroll
 	for (int j = 0; j < 2; ++j)
 	{
-		arm[j] = KIND == WARM_CURRENT ? c.anchor[j][k] : c.r0[j][k];
-		imp[j] = c.impulse[j][k];
+		r.arm[j] = KIND == WARM_CURRENT ? c.anchor[j][k] : c.r0[j][k];
+		r.imp[j] = c.impulse[j][k];
 	}
+	return r;
+}
+
+template <int KIND, class BA> S2_DEV void applyWarm(WarmRegs& r, const BA& b)
+{
+	const CHeader& h = r.h;
 	BodyVel A = loadVel(b, h.ia), B = loadVel(b, h.ib);
 	V2 vA = A.v, vB = B.v;
 	float wA = A.w, wB = B.w;
@@ -199,27 +214,27 @@ S2_DEV void warmStartContactsOne(const ContactView& c, const BA& b, int k)
 #pragma unroll
 	for (int j = 0; j < 2; ++j)
 	{
-		pin(arm[j]);
-		pin(imp[j]);
+		pin(r.arm[j]);
+		pin(r.imp[j]);
 	}
 
 #pragma unroll
 	for (int j = 0; j < 2; ++j)
 	{
-		if (j < pointCount)
+		if (j < r.pointCount)
 		{
 			V2 rA, rB;
 			if (KIND == WARM_CURRENT)
 			{
-				rA = rotate(qA, v2(arm[j].x, arm[j].y));
-				rB = rotate(qB, v2(arm[j].z, arm[j].w));
+				rA = rotate(qA, v2(r.arm[j].x, r.arm[j].y));
+				rB = rotate(qB, v2(r.arm[j].z, r.arm[j].w));
 			}
 			else
 			{
-				rA = v2(arm[j].x, arm[j].y);
-				rB = v2(arm[j].z, arm[j].w);
+				rA = v2(r.arm[j].x, r.arm[j].y);
+				rB = v2(r.arm[j].z, r.arm[j].w);
 			}
-			V2 P = add(mulSV(imp[j].x, h.normal), mulSV(imp[j].y, tangent));
+			V2 P = add(mulSV(r.imp[j].x, h.normal), mulSV(r.imp[j].y, r.tangent));
 			wA -= h.iA * cross(rA, P);
 			vA = mulAdd(vA, -h.mA, P);
 			wB += h.iB * cross(rB, P);
@@ -234,6 +249,13 @@ S2_DEV void warmStartContactsOne(const ContactView& c, const BA& b, int k)
 	{
 		storeVel(b, h.ib, vB, wB);
 	}
+}
+
+template <int KIND, class BA>
+S2_DEV void warmStartContactsOne(const ContactView& c, const BA& b, int k)
+{
+	WarmRegs r = loadWarm<KIND>(c, b, k);
+	applyWarm<KIND>(r, b);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -87,6 +87,57 @@ template <class P, class F> S2_DEV void forBatches(const int4* batches, int b0, 
 	}
 }
 
+// The sequential tail, one WAVE instead of one lane: every lane pulls its own constraint into registers (the misses of 64
+// constraints in flight at once, no dependent L2 round trip left in the walk), then the lanes take turns in sweep order.
+// Bodies go through LDS, which one wave reads and writes in program order; the wavefront fence keeps the compiler from
+// moving a lane's LDS reads across the turn before it.  Same per-constraint arithmetic, same order as forBatches.
+template <class R, class L, class F, class S> S2_DEV void walkTail(int begin, int end, L load, F compute, S store)
+{
+	if (threadIdx.x < 64)
+	{
+		const int lane = (int)threadIdx.x;
+		for (int base = begin; base < end; base += 64)
+		{
+			const int k = base + lane;
+			const int n = min(64, end - base);
+			R r = load(min(k, end - 1));
+			for (int j = 0; j < n; ++j)
+			{
+				if (lane == j)
+				{
+					compute(r, k);
+				}
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			}
+			if (lane < n)
+			{
+				store(r, k);
+			}
+		}
+	}
+}
+
+// forBatches with the tail batches walked by walkTail
+template <class R, class L, class C, class S, class F> S2_DEV void forBatchesSplit(const int4* batches, int b0, int b1, L load, C compute, S store, F f)
+{
+	for (int bi = b0; bi < b1; ++bi)
+	{
+		int4 bt = batches[bi];
+		if (bt.z)
+		{
+			walkTail<R>(bt.x, bt.y, load, compute, store);
+		}
+		else
+		{
+			for (int k = bt.x + (int)threadIdx.x; k < bt.y; k += (int)blockDim.x)
+			{
+				f(k);
+			}
+		}
+		__syncthreads();
+	}
+}
+
 // Soft sweep with PRELOADED rounds: every thread first issues the loads of its constraint in each of the
 // next MAXR colour batches (all in flight at once: one memory round trip for the whole chunk instead of
 // one per colour), then the batches are swept in order with only LDS traffic between barriers.  Same
@@ -258,13 +309,19 @@ __global__ __launch_bounds__(THREADS) void groupKernel(ContactView c, JointView 
 				switch (op.kind)
 				{
 					case WARM_CURRENT:
-						forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { warmStartContactsOne<WARM_CURRENT>(c, lb, k); });
+						forBatchesSplit<WarmRegs>(
+							gt.cBatches, cb0, cb1, [&](int k) { return loadWarm<WARM_CURRENT>(c, lb, k); }, [&](WarmRegs& r, int) { applyWarm<WARM_CURRENT>(r, lb); },
+							[](const WarmRegs&, int) {}, [&](int k) { warmStartContactsOne<WARM_CURRENT>(c, lb, k); });
 						break;
 					case WARM_FIXED:
-						forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { warmStartContactsOne<WARM_FIXED>(c, lb, k); });
+						forBatchesSplit<WarmRegs>(
+							gt.cBatches, cb0, cb1, [&](int k) { return loadWarm<WARM_FIXED>(c, lb, k); }, [&](WarmRegs& r, int) { applyWarm<WARM_FIXED>(r, lb); },
+							[](const WarmRegs&, int) {}, [&](int k) { warmStartContactsOne<WARM_FIXED>(c, lb, k); });
 						break;
 					case WARM_BLOCK:
-						forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { warmStartContactsOne<WARM_BLOCK>(c, lb, k); });
+						forBatchesSplit<WarmRegs>(
+							gt.cBatches, cb0, cb1, [&](int k) { return loadWarm<WARM_BLOCK>(c, lb, k); }, [&](WarmRegs& r, int) { applyWarm<WARM_BLOCK>(r, lb); },
+							[](const WarmRegs&, int) {}, [&](int k) { warmStartContactsOne<WARM_BLOCK>(c, lb, k); });
 						break;
 				}
 				break;
@@ -278,7 +335,11 @@ __global__ __launch_bounds__(THREADS) void groupKernel(ContactView c, JointView 
 						}
 						else
 						{
-							forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { solveContactsSoftOne<SOFT_TGS>(c, lb, op.inv_h, op.useBias, k); });
+							forBatchesSplit<SoftRegs<SOFT_TGS>>(
+								gt.cBatches, cb0, cb1, [&](int k) { return loadSoftB<SOFT_TGS>(c, lb, k); },
+								[&](SoftRegs<SOFT_TGS>& r, int k) { solveSoftRegs<SOFT_TGS>(r, c, lb, op.inv_h, op.useBias, k); },
+								[&](const SoftRegs<SOFT_TGS>& r, int k) { storeSoft<SOFT_TGS>(c, r, k); },
+								[&](int k) { solveContactsSoftOne<SOFT_TGS>(c, lb, op.inv_h, op.useBias, k); });
 						}
 						break;
 					case SOFT_PGS:
@@ -288,7 +349,11 @@ __global__ __launch_bounds__(THREADS) void groupKernel(ContactView c, JointView 
 						}
 						else
 						{
-							forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { solveContactsSoftOne<SOFT_PGS>(c, lb, op.inv_h, op.useBias, k); });
+							forBatchesSplit<SoftRegs<SOFT_PGS>>(
+								gt.cBatches, cb0, cb1, [&](int k) { return loadSoftB<SOFT_PGS>(c, lb, k); },
+								[&](SoftRegs<SOFT_PGS>& r, int k) { solveSoftRegs<SOFT_PGS>(r, c, lb, op.inv_h, op.useBias, k); },
+								[&](const SoftRegs<SOFT_PGS>& r, int k) { storeSoft<SOFT_PGS>(c, r, k); },
+								[&](int k) { solveContactsSoftOne<SOFT_PGS>(c, lb, op.inv_h, op.useBias, k); });
 						}
 						break;
 					case SOFT_FIXED:
@@ -298,7 +363,11 @@ __global__ __launch_bounds__(THREADS) void groupKernel(ContactView c, JointView 
 						}
 						else
 						{
-							forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { solveContactsSoftOne<SOFT_FIXED>(c, lb, op.inv_h, op.useBias, k); });
+							forBatchesSplit<SoftRegs<SOFT_FIXED>>(
+								gt.cBatches, cb0, cb1, [&](int k) { return loadSoftB<SOFT_FIXED>(c, lb, k); },
+								[&](SoftRegs<SOFT_FIXED>& r, int k) { solveSoftRegs<SOFT_FIXED>(r, c, lb, op.inv_h, op.useBias, k); },
+								[&](const SoftRegs<SOFT_FIXED>& r, int k) { storeSoft<SOFT_FIXED>(c, r, k); },
+								[&](int k) { solveContactsSoftOne<SOFT_FIXED>(c, lb, op.inv_h, op.useBias, k); });
 						}
 						break;
 					default:

@@ -741,6 +741,11 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 		s->optIncremental = value != 0;
 		s->structureDirty = true;
 	}
+	else if (strcmp(key, "defer") == 0)
+	{
+		s->optDefer = value != 0;
+		s->structureDirty = true;
+	}
 	else if (strcmp(key, "strip_lean") == 0)
 	{
 		s->stripsRejected = false;

@@ -352,3 +352,58 @@ int incrementalFlush(s2amdSolver* s)
 	inc.patches.clear();
 	return S2AMD_OK;
 }
+
+// ---- deferred contacts (solver_internal.h: optDefer) ----
+bool canDeferCreated(const s2amdSolver* s, int slot, int a, int b)
+{
+	const int nb = (int)s->hBodyFlagsFinal.size();
+	if (s->optDefer == 0 || s->structureDirty || slot < 0 || slot >= (int)s->inc.positionOfSlot.size() || a < 0 || b < 0 || a >= nb || b >= nb || a == b ||
+		(int)s->hContactWatched.size() != s->contactCapacity)
+	{
+		return false;
+	}
+	if (s->inc.positionOfSlot[(size_t)slot] != -1)
+	{
+		return false; // the slot still has an entry (a destroyed contact's, lingering): that one has to go first
+	}
+	const bool owned = ((s->hBodyFlagsFinal[(size_t)a] | s->hBodyFlagsFinal[(size_t)b]) & S2F_IN_GROUP) != 0;
+	const bool hub = (int)s->hBodyHub.size() == nb && (s->hBodyHub[(size_t)a] || s->hBodyHub[(size_t)b]);
+	return owned || hub;
+}
+
+void deferCreated(s2amdSolver* s, int slot, int a, int b)
+{
+	s->hContactA[(size_t)slot] = a;
+	s->hContactB[(size_t)slot] = b;
+	s->hContactEdge[(size_t)slot] = 1;
+	s->hContactDead[(size_t)slot] = 0;
+	if (!s->hContactWatched[(size_t)slot])
+	{
+		s->hContactWatched[(size_t)slot] = 1;
+		s->watchedCount += 1;
+		s->watchedDirty = true;
+	}
+}
+
+void unwatchSlot(s2amdSolver* s, int slot)
+{
+	if (slot >= 0 && slot < (int)s->hContactWatched.size() && s->hContactWatched[(size_t)slot])
+	{
+		s->hContactWatched[(size_t)slot] = 0;
+		s->watchedCount -= 1;
+		s->watchedDirty = true;
+	}
+}
+
+int uploadWatched(s2amdSolver* s)
+{
+	if (!s->watchedDirty || !s->worldResident || s->structureDirty || s->contactCapacity <= 0 || (int)s->hContactWatched.size() != s->contactCapacity ||
+		s->dWatched.bytes < (size_t)s->contactCapacity)
+	{
+		return S2AMD_OK; // (a rebuild writes the whole array)
+	}
+	HIP_TRY(hipMemcpyAsync(s->dWatched.p, s->hContactWatched.data(), (size_t)s->contactCapacity, hipMemcpyHostToDevice, s->stream));
+	HIP_TRY(hipStreamSynchronize(s->stream)); // the bytes are a std::vector the next call may touch
+	s->watchedDirty = false;
+	return S2AMD_OK;
+}

@@ -252,6 +252,11 @@ struct s2amdSolver
 	std::vector<int32_t> hSeparated;
 	int slackPositions = 0; // free positions of the global part's slack layout
 	int optIncremental = 1; // created contacts are placed into the existing structure when they fit (0: always rebuild)
+	// A created contact that cannot be placed (an LDS group or a strip owns one of its bodies, or one of them is a hub) and has
+	// no manifold points yet is only WATCHED: no entry in the structure -- it would be a no-op there -- until stage 3 finds
+	// its first points, which then counts as the change of the graph (option "defer", 0: rebuild when it is created)
+	int optDefer = 1;
+	bool watchedDirty = false; // hContactWatched changed since it was last copied to dWatched
 	BodyView bv{};
 	ContactView cv{};
 	JointView jv{};
@@ -407,6 +412,10 @@ struct ContactChange
 };
 // Gives every change a place in the existing structure (removing the slot's previous entry first); false: one of them
 // does not fit -- the caller marks the graph changed (full rebuild; nothing has reached the device).
+bool canDeferCreated(const s2amdSolver* s, int slot, int a, int b);
+void deferCreated(s2amdSolver* s, int slot, int a, int b);
+void unwatchSlot(s2amdSolver* s, int slot);
+int uploadWatched(s2amdSolver* s);
 bool incrementalApply(s2amdSolver* s, const std::vector<ContactChange>& changes);
 // Destroyed contacts give their place back (colour, position, list entries) where the entry is in the global part's
 // parallel batches; elsewhere (LDS group, strip, sequential tail) the entry lingers as a no-op until the next rebuild.

@@ -95,6 +95,7 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 	int active = 0;
 	std::vector<ContactChange> created; // contacts that appeared (or whose slot now holds another pair), in pool order
 	std::vector<int32_t> died;			// ... that were destroyed since the last upload
+	std::vector<ContactChange> deferred; // created without points where nothing can be placed: watched, not structural (optDefer)
 	bool hubTouched = false;			// something happened to a contact on a hub body: decided by a rebuild
 	for (int i = 0; i < nc; ++i)
 	{
@@ -124,6 +125,13 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 				died.push_back(i);
 			}
 			s->hContactDead[i] = 1;
+			unwatchSlot(s, i);
+			continue;
+		}
+		if (edge && pc == 0 && !newWorld && (!s->hContactEdge[i] || s->hContactA[i] != c.bodyA || s->hContactB[i] != c.bodyB) &&
+			canDeferCreated(s, i, c.bodyA, c.bodyB))
+		{
+			deferred.push_back(ContactChange{i, c.bodyA, c.bodyB});
 			continue;
 		}
 		if (edge && (!s->hContactEdge[i] || s->hContactA[i] != c.bodyA || s->hContactB[i] != c.bodyB))
@@ -167,6 +175,24 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 		}
 	}
 	changed = changed || hubTouched;
+	if (!changed)
+	{
+		for (const ContactChange& ch : deferred)
+		{
+			deferCreated(s, ch.slot, ch.a, ch.b);
+		}
+	}
+	else
+	{
+		for (const ContactChange& ch : deferred)
+		{
+			// the structure is rebuilt anyway: an ordinary potential constraint of the new one
+			s->hContactA[(size_t)ch.slot] = ch.a;
+			s->hContactB[(size_t)ch.slot] = ch.b;
+			s->hContactEdge[(size_t)ch.slot] = 1;
+			s->hContactDead[(size_t)ch.slot] = 0;
+		}
+	}
 	if (!changed)
 	{
 		// Destroyed contacts give their places back AFTER this step's created ones were placed: the world chain learns of the

@@ -2096,6 +2096,7 @@ struct StructureBuild
 			if (s->contactCapacity > 0)
 			{
 				HIP_TRY(hipMemcpyAsync(s->dWatched.p, s->hContactWatched.data(), (size_t)s->contactCapacity, hipMemcpyHostToDevice, s->stream));
+				s->watchedDirty = false;
 			}
 		}
 		s->cv.contactIndex = (int*)s->dContactIndex.p;

@@ -304,6 +304,13 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 	// When the persistent step kernel reports a dead hand-off its epilogue leaves the wire arrays untouched, so the refit
 	// behind it saw the bodies of the previous step (same AABBs, nothing enlarged): the solve is repeated on the
 	// multi-launch path, and so is the refit.
+	{
+		int rcWatched = uploadWatched(s);
+		if (rcWatched)
+		{
+			return rcWatched;
+		}
+	}
 	if (nc > 0)
 	{
 		// (the kernel also destroys separated pairs and accumulates the step's contact counters)
@@ -375,6 +382,7 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 		for (int32_t slot : s->hSeparated)
 		{
 			s->hContactDead[(size_t)slot] = 1;
+			unwatchSlot(s, slot);
 		}
 		incrementalRemove(s, s->hSeparated.data(), (int)s->hSeparated.size());
 		if ((rc = incrementalFlush(s)) != 0)
@@ -530,6 +538,7 @@ int s2amd_world_set_contacts(s2amdSolver* s, const int32_t* slots, int32_t count
 			if (s->hContactEdge[(size_t)k])
 			{
 				s->hContactDead[(size_t)k] = 1; // the caller's s2DestroyContact: the entry leaves the structure where it can, else lingers as a no-op
+				unwatchSlot(s, k);
 				const int32_t one = k;
 				incrementalRemove(s, &one, 1);
 			}
@@ -537,6 +546,11 @@ int s2amd_world_set_contacts(s2amdSolver* s, const int32_t* slots, int32_t count
 		}
 		if (!s->hContactEdge[(size_t)k] || s->hContactA[(size_t)k] != c.bodyA || s->hContactB[(size_t)k] != c.bodyB)
 		{
+			if (pc == 0 && canDeferCreated(s, k, c.bodyA, c.bodyB))
+			{
+				deferCreated(s, k, c.bodyA, c.bodyB); // watched until stage 3 finds its first manifold points
+				continue;
+			}
 			created.push_back(ContactChange{k, c.bodyA, c.bodyB});
 			hubTouched = hubTouched || onHub(c.bodyA, c.bodyB);
 			continue;

@@ -39,7 +39,7 @@ static double now(void)
 
 static const char* g_scene = "pyramid";
 static int g_solver = 7; /* s2_solverTGS_Soft, enum s2SolverType, types.h:75-88 */
-static int g_vel = 8, g_pos = 4, g_settle = 5;
+static int g_vel = 8, g_pos = 4, g_settle = 45; /* long enough for the one-off search for a better strip partition (32 quiet steps after the last graph change) to fall outside the timed steps */
 
 static double run(int base, int steps, const char* lib, int whole)
 {

@@ -97,7 +97,7 @@ def cpu_baseline(base, vel, pos, budget_s):
                 steps, base, 1e3 * secs / steps, os.cpu_count())}
 
 
-def pmc_traffic_bytes(kernel_prefix):
+def pmc_traffic_bytes(kernel_prefix, stem="persistent"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summaries (separate
     FETCH_SIZE / WRITE_SIZE passes of this same command, profiles/r01_persistent_pmc_*.txt): counters are in KiB;
     FETCH_SIZE is doubled per the gfx950 note in MI355X_MICROARCH.md (it reads half of a wide coalesced stream).
@@ -106,10 +106,10 @@ def pmc_traffic_bytes(kernel_prefix):
         total = 0.0
         try:
             for name, scale in (("fetch", 2.0), ("write", 1.0)):
-                path = os.path.join(ROOT, "profiles", "%s_persistent_pmc_%s_size.txt" % (rnd, name))
+                path = os.path.join(ROOT, "profiles", "%s_%s_pmc_%s_size.txt" % (rnd, stem, name))
                 rows = [l.split() for l in open(path) if l.startswith(kernel_prefix) and ("FETCH_SIZE" in l or "WRITE_SIZE" in l)]
                 total += scale * float(rows[0][3]) * 1024.0
-            return total, "profiles/%s_persistent_pmc_{fetch,write}_size.txt (rocprofv3 --pmc, separate passes of this command; not measured in this run)" % rnd
+            return total, "profiles/%s_%s_pmc_{fetch,write}_size.txt (rocprofv3 --pmc, separate passes of this command; not measured in this run)" % (rnd, stem)
         except (OSError, IndexError, ValueError):
             continue
     return None, None
@@ -178,7 +178,10 @@ def island_sharded_leg(ranks, islands, base, vel, pos, steps, warmup, graph=True
                    "constraints": C_total, "constraints_this_rank": mine, "islands_this_rank": int((sw.shard_of_island == ranks.rank).sum()),
                    "solve_sweeps_per_step": sweeps, "kernel_launches_per_step": st["kernelLaunches"], "lds_groups_this_rank": st["groupCount"],
                    "device_ms_per_step": st["deviceMs"], "graph_replay": bool(st["graphReplayed"]), "trajectory": "consecutive resident steps (no restore)"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     # (the committed PMC passes are of the whole world on one GPU)
+                     "traffic": pmc_traffic_bytes("_Z16islandStepKernel", "config5")[0] if ranks.world == 1 and islands == 512 and base == 40 else None,
+                     "traffic_source": pmc_traffic_bytes("_Z16islandStepKernel", "config5")[1] if ranks.world == 1 and islands == 512 and base == 40 else None,
                      "kernel": "islandStepKernel (whole step of this rank's islands in one launch: constraints resident in registers, bodies in "
                                "LDS, records prepared from and impulses stored to the wire contacts by the kernel itself)", "avg_launch_us": us,
                      "algorithmic_bytes_per_launch": algo,

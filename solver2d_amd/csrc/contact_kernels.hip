@@ -42,7 +42,11 @@ __global__ __launch_bounds__(S2_BLOCK) void prepareContactsKernel(ContactView c,
 		return;
 	}
 	int k = blockIdx.x * blockDim.x + threadIdx.x;
-	if (k >= c.count || (k >= c.skipBegin && k < c.skipEnd))
+	if (k >= c.skipBegin)
+	{
+		k += c.skipEnd - c.skipBegin; // the contact blocks cover [0, skipBegin) and [skipEnd, count) back to back
+	}
+	if (k >= c.count)
 	{
 		return;
 	}
@@ -336,7 +340,11 @@ __global__ __launch_bounds__(S2_BLOCK) void storeImpulsesKernel(ContactView c, s
 		return;
 	}
 	int k = blockIdx.x * blockDim.x + threadIdx.x;
-	if (k >= c.count || (k >= c.skipBegin && k < c.skipEnd))
+	if (k >= c.skipBegin)
+	{
+		k += c.skipEnd - c.skipBegin; // the contact blocks cover [0, skipBegin) and [skipEnd, count) back to back
+	}
+	if (k >= c.count)
 	{
 		return;
 	}
@@ -659,9 +667,13 @@ void launchPrepareContacts(hipStream_t s, int kind, const ContactView& c, const 
 	{
 		return;
 	}
-	const int contactBlocks = (c.count + S2_BLOCK - 1) / S2_BLOCK;
+	const int contactBlocks = (c.count - (c.skipEnd - c.skipBegin) + S2_BLOCK - 1) / S2_BLOCK;
 	const int bodyBlocks = unpackToo && b.capacity > 0 ? (b.capacity + S2_BLOCK - 1) / S2_BLOCK : 0;
 	const int indexBlocks = unpackToo && gatherIndex && contactCapacity > 0 ? (contactCapacity + S2_BLOCK - 1) / S2_BLOCK : 0;
+	if (contactBlocks + bodyBlocks + indexBlocks == 0)
+	{
+		return; // every position is the resident-island kernel's own
+	}
 	dim3 g((unsigned)(contactBlocks + bodyBlocks + indexBlocks)), t(S2_BLOCK);
 	switch (kind)
 	{
@@ -779,7 +791,7 @@ void launchStoreImpulses(hipStream_t s, int kind, const ContactView& c, s2amdCon
 						 void* clear, size_t clearBytes, const unsigned int* stepFailed)
 {
 	// bodies == nullptr-capacity: plain store; otherwise the body write-back rides in the same launch
-	const int contactBlocks = c.count > 0 ? (c.count + S2_BLOCK - 1) / S2_BLOCK : 0;
+	const int contactBlocks = c.count > 0 ? (c.count - (c.skipEnd - c.skipBegin) + S2_BLOCK - 1) / S2_BLOCK : 0;
 	const int bodyBlocks = wireBodies && bodies.capacity > 0 ? (bodies.capacity + S2_BLOCK - 1) / S2_BLOCK : 0;
 	const int clearCount = clear ? (int)(clearBytes / sizeof(uint4)) : 0; // buffers are allocated in multiples of 256 bytes
 	const int clearBlocks = (clearCount + S2_BLOCK - 1) / S2_BLOCK;

@@ -163,3 +163,49 @@ def test_heavy_body_list_follows_the_incidence_lists():
                 c["bodyA"], c["bodyB"] = top[n], top[n + 5]
                 state[1][n0 + n] = c
                 state = gpu_vs_oracle_loose(s, params, state, "%s platform shrink %d" % (solver_name, n))
+
+
+def test_a_contact_without_points_between_strip_bodies_is_only_watched():
+    """Option "defer" (default on): a created contact has no manifold points yet.  Where it cannot be placed -- both boxes
+    belong to strips, whose tables are register / LDS layouts -- it gets no entry in the structure and the persistent strip
+    kernel keeps running; its first points are the change of the graph.  With the option off its creation already is."""
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    for defer in (1, 0):
+        rng = np.random.default_rng(31)
+        pre = _with_spare_slots(synthetic.pyramid(80), 16)
+        n0 = len(pre[1]) - 16
+        pairs = {(min(a, b), max(a, b)) for a, b in zip(pre[1]["bodyA"][:n0].tolist(), pre[1]["bodyB"][:n0].tolist())}
+        with hip.Solver(0) as s:
+            s.set_option("strip_patience", 0)
+            s.set_option("strip_min_bodies", 0)  # (a base-80 pyramid is below the size at which strips are the default)
+            s.set_option("defer", defer)
+            state = gpu_vs_oracle(s, params, pre, "defer=%d step 0" % defer)
+            st = s.stats()
+            assert st["stripCount"] > 0 and st["persistent"] == 1, st
+            builds = st["structureBuilds"]
+            # a potential contact: two boxes whose fat boxes overlap, nothing touching yet
+            c = _artificial_contact(rng, state[0], pre[1][5], pairs)
+            c["pointCount"] = 0
+            state[1][n0] = c
+            state = gpu_vs_oracle(s, params, state, "defer=%d potential contact" % defer)
+            st = s.stats()
+            if defer:
+                assert st["structureBuilds"] == builds and st["persistent"] == 1, st
+            else:
+                assert st["structureBuilds"] > builds, st
+            builds = st["structureBuilds"]
+            state = gpu_vs_oracle(s, params, state, "defer=%d quiet step" % defer)
+            assert s.stats()["structureBuilds"] == builds
+            # its first points: now it is a constraint, and the structure has to hold it
+            state[1][n0]["pointCount"] = 2
+            state = gpu_vs_oracle(s, params, state, "defer=%d first points" % defer)
+            st = s.stats()
+            assert (st["structureBuilds"] > builds) == bool(defer), st
+            assert st["constraintCount"] == int((state[1]["pointCount"] > 0).sum())
+            # ... and a deferred contact that is destroyed before it ever touched leaves no trace
+            c2 = _artificial_contact(rng, state[0], pre[1][5], pairs)
+            c2["pointCount"] = 0
+            state[1][n0 + 1] = c2
+            state = gpu_vs_oracle(s, params, state, "defer=%d second potential contact" % defer)
+            state[1][n0 + 1]["bodyA"], state[1][n0 + 1]["bodyB"] = -1, -1
+            gpu_vs_oracle(s, params, state, "defer=%d destroyed untouched" % defer)

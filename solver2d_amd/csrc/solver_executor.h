@@ -692,7 +692,8 @@ struct Executor
 				const Op& o = p.ops[(size_t)i];
 				// contact warm start as ONE body-centric launch; an immediately preceding integrate-velocities
 				// (joint sweeps in between only when there are no global joints) rides along in the same kernel
-				if (!msg && s->optBodyWarm && s->contacts.globalCount > 0 && (o.code == OP_WARM || o.code == OP_INTEGRATE_VEL))
+				// (a structure built for s2Solve_Jacobi has no colours: the body-centric form is the only one there)
+				if (!msg && (s->optBodyWarm || s->orderColourless) && s->contacts.globalCount > 0 && (o.code == OP_WARM || o.code == OP_INTEGRATE_VEL))
 				{
 					int w = i;
 					if (o.code == OP_INTEGRATE_VEL)

@@ -197,7 +197,8 @@ bool incrementalApply(s2amdSolver* s, const std::vector<ContactChange>& changes)
 	{
 		return false;
 	}
-	auto giveUp = [&]() {
+	auto giveUp = [&](const char* why = "placement") {
+		s->dirtyReason = why;
 		// nothing has reached the device; the host mirrors are rebuilt with the structure
 		inc.valid = false;
 		inc.patches.clear();
@@ -211,12 +212,12 @@ bool incrementalApply(s2amdSolver* s, const std::vector<ContactChange>& changes)
 	{
 		if (ch.slot < 0 || ch.slot >= (int)inc.positionOfSlot.size())
 		{
-			return giveUp();
+			return giveUp("slot outside the structure");
 		}
 		// ---- the slot's previous entry (a destroyed contact whose entry lingered) gives its place back ----
 		if (!removeEntry(s, p, ch.slot))
 		{
-			return giveUp();
+			return giveUp("old entry of the slot not removable");
 		}
 		if (ch.a < 0)
 		{
@@ -226,11 +227,11 @@ bool incrementalApply(s2amdSolver* s, const std::vector<ContactChange>& changes)
 		const int nb = (int)s->hBodyFlags.size();
 		if (ch.a >= nb || ch.b < 0 || ch.b >= nb || ch.a == ch.b || s->hBodyFlagsFinal.size() != (size_t)nb)
 		{
-			return giveUp();
+			return giveUp("bad body");
 		}
 		if ((s->hBodyFlagsFinal[(size_t)ch.a] & S2F_IN_GROUP) != 0 || (s->hBodyFlagsFinal[(size_t)ch.b] & S2F_IN_GROUP) != 0)
 		{
-			return giveUp(); // an LDS group or a strip owns the body: its tables are not placeable into
+			return giveUp("body owned by a group or strip"); // an LDS group or a strip owns the body: its tables are not placeable into
 		}
 		const bool wa = writable(s, ch.a), wb = writable(s, ch.b);
 		int chosen = -1;
@@ -260,8 +261,20 @@ bool incrementalApply(s2amdSolver* s, const std::vector<ContactChange>& changes)
 		}
 		if (chosen < 0)
 		{
+			bool anyFree = false;
+			for (int bi = 0; bi < inc.parallelBatches; ++bi)
+			{
+				anyFree = anyFree || !inc.freePositions[(size_t)bi].empty();
+			}
+			if (!anyFree || inc.ignoreColours)
+			{
+				// the slack itself is used up (a world that creates contacts by the thousand per step): the rebuild lays out more
+				s->slackShift = std::min(s->slackShift + 1, 3);
+				s->slackBumped = true;
+				return giveUp("no free position");
+			}
 			s->spareColours = 2; // every colour batch is taken on these bodies: the rebuild adds empty ones for the next such contact
-			return giveUp();
+			return giveUp("no free colour");
 		}
 		const int k = inc.freePositions[(size_t)chosen].back();
 		inc.freePositions[(size_t)chosen].pop_back();
@@ -282,7 +295,9 @@ bool incrementalApply(s2amdSolver* s, const std::vector<ContactChange>& changes)
 		p.word(s->dContactIndex.p, (size_t)k, (uint32_t)ch.slot);
 		if ((wa && !adjInsert(p, ch.a, (k << 1) | 0)) || (wb && !adjInsert(p, ch.b, (k << 1) | 1)))
 		{
-			return giveUp();
+			s->slackShift = std::min(s->slackShift + 1, 3);
+			s->slackBumped = true;
+			return giveUp("incidence lists full");
 		}
 		inc.inserted += 1;
 		s->placedTotal += 1;

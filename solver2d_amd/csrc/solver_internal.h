@@ -256,6 +256,10 @@ struct s2amdSolver
 	// no manifold points yet is only WATCHED: no entry in the structure -- it would be a no-op there -- until stage 3 finds
 	// its first points, which then counts as the change of the graph (option "defer", 0: rebuild when it is created)
 	int optDefer = 1;
+	bool slackBumped = false; // (since the last rebuild)
+	int slackAtBuild = 0;	  // free positions the last rebuild laid out
+	int slackShift = 0; // the structure's slack (free positions per colour batch, room for growing incidence lists) times 2^this: raised when a rebuild was forced by used-up slack
+	const char* dirtyReason = ""; // S2AMD_DEBUG_PREP: what made the last rebuild necessary
 	bool watchedDirty = false; // hContactWatched changed since it was last copied to dWatched
 	BodyView bv{};
 	ContactView cv{};
@@ -313,6 +317,7 @@ struct s2amdSolver
 	int orderSolverClass = -1; // 0 velocity colouring, 1 position colouring
 	bool orderGrouped = false;
 	bool orderResident = false; // the groups were laid out for the resident-island kernel where they fit
+	bool orderColourless = false; // built for s2Solve_Jacobi: the global contact part is one batch in pool order, no colours
 	bool orderStrips = false;
 	bool stripsNeedOneLaunch = false; // a moving read-only body is shared between strips: persistent kernel or no strips at all
 	bool stripsRejected = false; // this graph's strip partition fits no strip kernel: colour batches until the graph changes

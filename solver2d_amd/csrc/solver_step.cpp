@@ -96,6 +96,8 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 	std::vector<ContactChange> created; // contacts that appeared (or whose slot now holds another pair), in pool order
 	std::vector<int32_t> died;			// ... that were destroyed since the last upload
 	std::vector<ContactChange> deferred; // created without points where nothing can be placed: watched, not structural (optDefer)
+	std::vector<ContactChange> flipped;	 // watched manifolds with their first points, under a structure built for s2Solve_Jacobi
+	const bool placeFlips = s->inc.valid && s->inc.ignoreColours && s->optIncremental != 0 && !s->structureDirty && !newWorld;
 	bool hubTouched = false;			// something happened to a contact on a hub body: decided by a rebuild
 	for (int i = 0; i < nc; ++i)
 	{
@@ -134,6 +136,16 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 			deferred.push_back(ContactChange{i, c.bodyA, c.bodyB});
 			continue;
 		}
+		if (edge && pc > 0 && placeFlips && (!s->hContactEdge[i] || s->hContactA[i] != c.bodyA || s->hContactB[i] != c.bodyB) &&
+			canDeferCreated(s, i, c.bodyA, c.bodyB))
+		{
+			// created AND touching at first sight (the caller ran stage 3 itself): the world chain, which sees the contact created
+			// without points and its manifold gain them in its own stage 3, watches it first and places it with the flips --
+			// same sequence here, so that both routes hand out the same positions
+			deferred.push_back(ContactChange{i, c.bodyA, c.bodyB});
+			flipped.push_back(ContactChange{i, c.bodyA, c.bodyB});
+			continue;
+		}
 		if (edge && (!s->hContactEdge[i] || s->hContactA[i] != c.bodyA || s->hContactB[i] != c.bodyB))
 		{
 			created.push_back(ContactChange{i, c.bodyA, c.bodyB}); // (shadows of this slot are written below, after the old entry was found)
@@ -142,7 +154,18 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 		}
 		if (edge && !s->hContactWatched.empty() && s->hContactWatched[(size_t)i] && (oldPoints > 0) != (pc > 0))
 		{
-			hubTouched = true; // a manifold on a hub body gained or lost its points (solver_internal.h: hContactWatched)
+			// a watched manifold (on a hub body, or deferred) gained or lost its points (solver_internal.h: hContactWatched)
+			if (placeFlips)
+			{
+				if (pc > 0 && i < (int)s->inc.positionOfSlot.size() && s->inc.positionOfSlot[(size_t)i] == -1)
+				{
+					flipped.push_back(ContactChange{i, c.bodyA, c.bodyB}); // s2Solve_Jacobi: a position and two list entries, no colour to find
+				}
+			}
+			else
+			{
+				hubTouched = true;
+			}
 		}
 		if (!edge && s->hContactEdge[i])
 		{
@@ -180,6 +203,18 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 		for (const ContactChange& ch : deferred)
 		{
 			deferCreated(s, ch.slot, ch.a, ch.b);
+		}
+		// (after this step's created contacts, before its destroyed ones: the order the world chain does it in)
+		if (!flipped.empty())
+		{
+			if (incrementalApply(s, flipped))
+			{
+				noteGraphTouched(s);
+			}
+			else
+			{
+				changed = true;
+			}
 		}
 	}
 	else

@@ -195,10 +195,25 @@ struct EdgeList
 // rebuild (IncrementalGlobal, solver_incremental.cpp).  *positions then has -1 at the free positions.
 void colourPart(const std::vector<int>& ids, const std::vector<int>& ea, const std::vector<int>& eb, const std::vector<uint8_t>& conflict,
 				int bodyCount, SweepSet& set, std::vector<int>& batchOffsetsOut, bool& hasTailOut, std::vector<int>* positions, int balanced = 0,
-				IncrementalGlobal* inc = nullptr, int spareColours = 0)
+				IncrementalGlobal* inc = nullptr, int spareColours = 0, int slackShift = 0, bool colourless = false)
 {
 	std::vector<int> color, partOrder, partOffsets;
-	int cc = colorGraph(ea, eb, conflict, bodyCount, color, balanced, inc ? &inc->colorBits : nullptr);
+	int cc;
+	if (colourless)
+	{
+		// s2Solve_Jacobi: the contact pass writes no body, one batch in pool order is the whole sweep (and nothing ends up in
+		// a sequential tail, whose entries a re-used slot could not give back)
+		color.assign(ids.size(), 0);
+		cc = ids.empty() ? 0 : 1;
+		if (inc)
+		{
+			inc->colorBits.assign((size_t)bodyCount * ColorBitsWords, 0);
+		}
+	}
+	else
+	{
+		cc = colorGraph(ea, eb, conflict, bodyCount, color, balanced, inc ? &inc->colorBits : nullptr);
+	}
 	// stable counting sort of positions by colour
 	std::vector<int> pos(ids.size());
 	for (size_t i = 0; i < ids.size(); ++i)
@@ -231,7 +246,7 @@ void colourPart(const std::vector<int>& ids, const std::vector<int>& ea, const s
 		for (int bi = 0; bi < batches; ++bi)
 		{
 			const int n = bi < parallel ? partOffsets[(size_t)bi + 1] - partOffsets[bi] : 0;
-			const int cap = bi < parallel ? ((n + std::max(32, n / 8)) + 31) & ~31 : 64;
+			const int cap = bi < parallel ? ((n + std::max(32, (n / 8) << slackShift)) + 31) & ~31 : 64;
 			const int begin = (int)laidOut.size();
 			batchOffsetsOut.push_back(base + begin);
 			inc->batchBegin[(size_t)bi] = base + begin, inc->batchEnd[(size_t)bi] = base + begin + cap;
@@ -708,13 +723,13 @@ static int buildAdjacency(s2amdSolver* s, const std::vector<uint8_t>& conflict, 
 	int total = 0;
 	for (int i = 0; i < nb; ++i)
 	{
-		const int cap = s->hBodyLive[(size_t)i] && conflict[(size_t)i] ? ((count[(size_t)i] + std::max(4, count[(size_t)i] / 4) + 3) & ~3) : 0;
+		const int cap = s->hBodyLive[(size_t)i] && conflict[(size_t)i] ? ((count[(size_t)i] + std::max(4 << s->slackShift, count[(size_t)i] / 4) + 3) & ~3) : 0;
 		inc.adjRange[(size_t)i] = make_int2(total, 0);
 		inc.adjCapacity[(size_t)i] = cap;
 		total += cap;
 	}
 	inc.adjUsed = total;
-	inc.adjList.assign((size_t)total + (size_t)std::max(1024, total / 4), 0); // room for lists that outgrow their slack and move to the end
+	inc.adjList.assign((size_t)total + (size_t)std::max(1024, (total / 4) << s->slackShift), 0); // room for lists that outgrow their slack and move to the end
 	for (int k = 0; k < GC; ++k)
 	{
 		if (cs.order[(size_t)k] < 0)
@@ -1335,7 +1350,7 @@ struct StructureBuild
 		// (contacts placed into a structure built for s2Solve_Jacobi took any free position, whatever its colour: only Jacobi can run on that)
 		const bool colourFree = s->inc.colourFreePlaced && !needAdj;
 		return !s->structureDirty && cls == s->orderSolverClass && grouped == s->orderGrouped && wantStrips == s->orderStrips && s->adjValid && !colourFree &&
-			   residentWanted == s->orderResident;
+			   residentWanted == s->orderResident && needAdj == s->orderColourless;
 	}
 
 	void phase(const char* name)
@@ -1362,6 +1377,13 @@ struct StructureBuild
 	// ---- phase 1: the potential constraints (edges) of this structure, the hub rule ----
 	int gatherEdges()
 	{
+		// slack that was laid out generously after an exhaustion and then sat unused (a rebuild for another reason finds
+		// three quarters of it still free) shrinks again: free positions are threads that do nothing in every sweep
+		if (s->slackShift > 0 && !s->slackBumped && s->slackAtBuild > 0 && (long long)s->slackPositions * 4 > (long long)s->slackAtBuild * 3)
+		{
+			s->slackShift -= 1;
+		}
+		s->slackBumped = false;
 		conflict.resize((size_t)nb);
 		for (int i = 0; i < nb; ++i)
 		{
@@ -1439,8 +1461,9 @@ struct StructureBuild
 			h = fnv(h, ce.ids.data(), ce.ids.size() * sizeof(int));
 			h = fnv(h, ce.a.data(), ce.a.size() * sizeof(int));
 			h = fnv(h, ce.b.data(), ce.b.size() * sizeof(int));
-			fprintf(stderr, "[s2amd] rebuild #%llu: %d potential contact constraints, %d joints, edge hash %016llx\n", (unsigned long long)s->structureGeneration, C, J,
-					(unsigned long long)h);
+			fprintf(stderr, "[s2amd] rebuild #%llu: %d potential contact constraints, %d joints, edge hash %016llx, reason: %s\n",
+					(unsigned long long)s->structureGeneration, C, J, (unsigned long long)h, s->dirtyReason);
+			s->dirtyReason = "";
 		}
 
 		phase("edge lists");
@@ -1762,7 +1785,7 @@ struct StructureBuild
 		s->inc = IncrementalGlobal();
 		const bool slack = s->optIncremental != 0 && s->optMessage == 0;
 		s->inc.ignoreColours = needAdj;
-		colourPart(ids, a, b, conflict, nb, cs, cs.batchOffsets, cs.hasTail, &pos, 0, slack ? &s->inc : nullptr, needAdj ? 0 : s->spareColours);
+		colourPart(ids, a, b, conflict, nb, cs, cs.batchOffsets, cs.hasTail, &pos, 0, slack ? &s->inc : nullptr, needAdj ? 0 : s->spareColours, s->slackShift, needAdj);
 		cs.globalCount = (int)cs.order.size(); // (with the free positions of the slack layout)
 		cs.local.assign((size_t)cs.globalCount, make_int2(0, 0));
 		if (slack)
@@ -2191,10 +2214,12 @@ struct StructureBuild
 		{
 			s->slackPositions += cs.order[(size_t)k] < 0 ? 1 : 0;
 		}
+		s->slackAtBuild = s->slackPositions;
 		s->inc.valid = s->optIncremental != 0 && s->inc.solverClass == cls && !s->msgTablesValid && !s->inc.positionOfSlot.empty();
 		s->inc.patches.clear();
 		s->orderSolverClass = cls;
 		s->orderResident = residentWanted;
+		s->orderColourless = needAdj;
 		s->orderGrouped = grouped;
 		s->orderStrips = wantStrips;
 		s->structureDirty = false;

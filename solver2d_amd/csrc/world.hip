@@ -331,7 +331,44 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 		}
 		if (hSum->watchedFlips > 0)
 		{
-			noteGraphChanged(s);
+			// s2Solve_Jacobi has no colours to find: a watched manifold that gained its first points gets a position and its two
+			// incidence-list entries like a created contact (one that lost its points stays where it is, a no-op); every other
+			// solver's structure is rebuilt
+			bool handled = false;
+			if (s->inc.valid && s->inc.ignoreColours && s->optIncremental != 0)
+			{
+				if ((rcMid = fetchPointCounts(s)) != 0)
+				{
+					return rcMid;
+				}
+				std::vector<ContactChange> flipped;
+				for (int i = 0; i < nc; ++i)
+				{
+					if (s->hContactWatched[(size_t)i] && s->hContactPoints[(size_t)i] > 0 && s->hContactEdge[(size_t)i] && !s->hContactDead[(size_t)i] &&
+						s->inc.positionOfSlot[(size_t)i] == -1)
+					{
+						flipped.push_back(ContactChange{i, s->hContactA[(size_t)i], s->hContactB[(size_t)i]});
+					}
+				}
+				handled = flipped.empty() || incrementalApply(s, flipped);
+				if (handled && !flipped.empty())
+				{
+					if ((rcMid = incrementalFlush(s)) != 0)
+					{
+						return rcMid;
+					}
+					noteGraphTouched(s);
+					s->gatherIndexDirty = true;
+				}
+			}
+			if (!handled)
+			{
+				if (!(s->inc.ignoreColours && s->optIncremental != 0))
+				{
+					s->dirtyReason = "watched manifold flipped";
+				}
+				noteGraphChanged(s);
+			}
 		}
 	}
 	const double t1 = nowMs();

@@ -25,11 +25,15 @@ def solver():
     s.close()
 
 
-def check_order_is_valid(order, offsets, contacts, bodies):
-    """Every active contact appears exactly once; inside one colour batch no dynamic body repeats."""
+def check_order_is_valid(order, offsets, contacts, bodies, colourless=False):
+    """Every active contact appears exactly once; inside one colour batch no dynamic body repeats (s2Solve_Jacobi's contact
+    pass writes no body -- solve_jacobi.c:21-132 accumulates per-constraint deltas -- so its sweep is one batch in pool
+    order and has no colours to check)."""
     active = np.flatnonzero(contacts["pointCount"] > 0)
     assert sorted(order.tolist()) == active.tolist()
     assert offsets[0] == 0 and offsets[-1] == len(order)
+    if colourless:
+        return
     movable = (bodies["invMass"] != 0) | (bodies["invI"] != 0)
     for c in range(len(offsets) - 1):
         ids = order[offsets[c]:offsets[c + 1]]
@@ -43,7 +47,7 @@ def gpu_vs_oracle(solver, params, pre, what):
     solver.solve(params, *got)
     order, offsets = solver.contact_order()
     jorder, joffsets = solver.joint_order()
-    check_order_is_valid(order, offsets, pre[1], pre[0])
+    check_order_is_valid(order, offsets, pre[1], pre[0], colourless=params.solverType == wire.SOLVER_ID["Jacobi"])
     want = common.copy3(pre)
     oraclebind.solve(params, *want, contact_order=order, joint_order=jorder)
     common.compare_exact(got, want, what)
@@ -138,7 +142,8 @@ def test_big_island_with_high_degree_body_uses_global_tail(solver, solver_name):
     params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
     gpu_vs_oracle(solver, params, pre, "platform60x40/%s" % solver_name)
     st = solver.stats()
-    assert st["groupCount"] == 0 and st["contactColors"] >= 60
+    # (s2Solve_Jacobi's contact pass has no colours: one batch, the platform's 60 contacts are a long incidence list)
+    assert st["groupCount"] == 0 and st["contactColors"] >= (1 if solver_name == "Jacobi" else 60)
 
 
 @pytest.mark.parametrize("solver_name", wire.SOLVER_NAMES)
@@ -205,7 +210,7 @@ def test_high_degree_body_uses_sequential_tail(solver, solver_name):
         params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
         state = gpu_vs_oracle(solver, params, state, "platform60/%s step %d" % (solver_name, step))
     st = solver.stats()
-    assert st["contactColors"] >= 60
+    assert st["contactColors"] >= (1 if solver_name == "Jacobi" else 60)  # (no colours under s2Solve_Jacobi)
     if solver_name != "Jacobi":
         assert st["groupCount"] == 1 and st["kernelLaunches"] <= 8
 

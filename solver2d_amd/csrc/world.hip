@@ -66,6 +66,17 @@ __global__ __launch_bounds__(S2_BLOCK) void clearMovedKernel(s2amdShape* shapes,
 	}
 }
 
+// one byte per pair slot for the host's structure build: 0xff = free (its pair separated or was never there), else the
+// manifold's point count -- what syncDeadSlots and fetchPointCounts need, as ONE contiguous copy
+__global__ __launch_bounds__(S2_BLOCK) void slotBytesKernel(const s2amdPairState* pairs, const uint8_t* pointBytes, int n, uint8_t* out)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n)
+	{
+		out[i] = pairs[i].shapeA < 0 ? (uint8_t)0xff : pointBytes[i];
+	}
+}
+
 // manifold.constraintIndex from the resident point counts: exclusive scan of "has points" over the pool (the reference's
 // gather order, e.g. src/solve_tgs_soft.c:162-179), -1 for the slots the gather skips
 struct HasPoints
@@ -141,16 +152,25 @@ int syncDeadSlots(s2amdSolver* s)
 		return S2AMD_OK;
 	}
 	HIP_TRY(hipSetDevice(s->device));
-	std::vector<int32_t> shapeA((size_t)nc);
-	HIP_TRY(hipMemcpy2DAsync(shapeA.data(), sizeof(int32_t), s->dPairs.p, sizeof(s2amdPairState), sizeof(int32_t), (size_t)nc, hipMemcpyDeviceToHost, s->stream));
+	int rc = s->dSlotBytes.ensure(std::max<size_t>((size_t)nc, 256));
+	if (rc)
+	{
+		return rc;
+	}
+	s->hSlotBytes.resize((size_t)nc);
+	slotBytesKernel<<<gridFor((size_t)nc), dim3(S2_BLOCK), 0, s->stream>>>((const s2amdPairState*)s->dPairs.p, (const uint8_t*)s->dPointBytes.p, nc,
+																			 (uint8_t*)s->dSlotBytes.p);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(s->hSlotBytes.data(), s->dSlotBytes.p, (size_t)nc, hipMemcpyDeviceToHost, s->stream));
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	for (int i = 0; i < nc; ++i)
 	{
-		if (s->hContactEdge[(size_t)i] && shapeA[(size_t)i] < 0)
+		if (s->hContactEdge[(size_t)i] && s->hSlotBytes[(size_t)i] == 0xff)
 		{
 			s->hContactDead[(size_t)i] = 1;
 		}
 	}
+	s->slotBytesFresh = true; // (fetchPointCounts right behind this call, the hub rule's, needs no second copy)
 	return S2AMD_OK;
 }
 
@@ -163,12 +183,23 @@ int fetchPointCounts(s2amdSolver* s)
 	}
 	HIP_TRY(hipSetDevice(s->device));
 	s->hPointBytes.resize((size_t)nc);
-	HIP_TRY(hipMemcpyAsync(s->hPointBytes.data(), s->dPointBytes.p, (size_t)nc, hipMemcpyDeviceToHost, s->stream));
-	HIP_TRY(hipStreamSynchronize(s->stream));
+	if (s->slotBytesFresh && (int)s->hSlotBytes.size() == nc)
+	{
+		for (int i = 0; i < nc; ++i)
+		{
+			s->hPointBytes[(size_t)i] = s->hSlotBytes[(size_t)i] == 0xff ? 0 : s->hSlotBytes[(size_t)i];
+		}
+	}
+	else
+	{
+		HIP_TRY(hipMemcpyAsync(s->hPointBytes.data(), s->dPointBytes.p, (size_t)nc, hipMemcpyDeviceToHost, s->stream));
+		HIP_TRY(hipStreamSynchronize(s->stream));
+	}
 	for (int i = 0; i < nc; ++i)
 	{
 		s->hContactPoints[(size_t)i] = s->hPointBytes[(size_t)i];
 	}
+	s->slotBytesFresh = false;
 	return S2AMD_OK;
 }
 
@@ -304,6 +335,7 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 	// When the persistent step kernel reports a dead hand-off its epilogue leaves the wire arrays untouched, so the refit
 	// behind it saw the bodies of the previous step (same AABBs, nothing enlarged): the solve is repeated on the
 	// multi-launch path, and so is the refit.
+	s->slotBytesFresh = false;
 	{
 		int rcWatched = uploadWatched(s);
 		if (rcWatched)

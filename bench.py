@@ -301,10 +301,21 @@ def whole_step_leg(device_index, base, vel, pos, settle, steps):
             moved += info["movedCount"]
         elapsed = time.perf_counter() - t0
         st = gpu.stats()
+        # ... and the same loop with stage 1 as well (src/world.c:125-126): the device pair query after every step that
+        # re-inflated a fat box -- every step of this pile -- and s2CreateContact's part for whatever it finds (nothing, here)
+        queries = found = 0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            if info["movedCount"] > 0:
+                found += len(gpu.world_find_pairs())
+                queries += 1
+            info = gpu.world_step(params)
+        with_stage1 = time.perf_counter() - t0
     sweeps = wire.solve_sweeps_per_step("TGS_Soft", vel, pos)
     return {"workload": "LargePyramid base-%d as a resident world, %d settle + %d timed s2amd_world_step (update contacts -> s2Solve_TGS_Soft -> refit)" % (
                 base, settle, steps),
-            "whole_step_ms": 1e3 * elapsed / steps, "solver_device_ms": solve_ms / steps, "update_contacts_ms_incl_readback": contacts_ms / steps,
+            "whole_step_ms": 1e3 * elapsed / steps, "whole_step_with_pair_query_ms": 1e3 * with_stage1 / steps, "pair_queries": queries, "new_pairs_found": found,
+            "solver_device_ms": solve_ms / steps, "update_contacts_ms_incl_readback": contacts_ms / steps,
             "mean_active_constraints": active / steps, "steps_with_graph_change": changed, "mean_moved_shapes": moved / steps,
             "value_whole_step": (active / steps) * sweeps * steps / elapsed, "unit": "constraint-iters/s", "persistent_strip_kernel": bool(st["persistent"]),
             "kernel_launches_per_solve": st["kernelLaunches"]}

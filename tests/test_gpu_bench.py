@@ -38,6 +38,7 @@ def test_single_gpu_line():
     # the other BASELINE configurations ride in the same driver-run line
     w = d["whole_step"]
     assert w["whole_step_ms"] > w["solver_device_ms"] > 0 and w["mean_active_constraints"] > 59000
+    assert w["whole_step_with_pair_query_ms"] > w["whole_step_ms"] and w["pair_queries"] > 0
     isl = d["island_sharded"]
     assert isl["scaling"] == "strong" and isl["n_gpus"] == 1 and isl["config"]["constraints"] == 1218560
     r5 = isl["roofline"]

@@ -312,7 +312,10 @@ S2_DEV bool reports(const s2amdShape& P, bool movedP, const s2amdShape& Q, bool 
 	return true;
 }
 
-// one candidate (work item t of the sweep-and-prune runs): the reference's pair rules
+S2_DEV void pairTest(int xi, int yi, const s2amdShape* shapes, const unsigned char* moved, const unsigned long long* existing, int existingCount,
+					 const unsigned long long* jointed, int jointedCount, unsigned long long* outKeys, unsigned int outCapacity, unsigned int* outCount);
+
+// one candidate (work item t of the sweep-and-prune runs): which pair it is
 S2_DEV void pairOne(unsigned int t, const s2amdShape* shapes, const unsigned char* moved, const int* sortedIdx, const unsigned int* runOffset, int n,
 					const unsigned long long* existing, int existingCount, const unsigned long long* jointed, int jointedCount,
 					unsigned long long* outKeys, unsigned int outCapacity, unsigned int* outCount)
@@ -333,7 +336,13 @@ S2_DEV void pairOne(unsigned int t, const s2amdShape* shapes, const unsigned cha
 	}
 	int i = lo;
 	int j = i + 1 + (int)(t - runOffset[i]);
-	int xi = sortedIdx[i], yi = sortedIdx[j];
+	pairTest(sortedIdx[i], sortedIdx[j], shapes, moved, existing, existingCount, jointed, jointedCount, outKeys, outCapacity, outCount);
+}
+
+// one candidate pair of shapes whose fat boxes overlap on the sweep axis: the reference's pair rules
+S2_DEV void pairTest(int xi, int yi, const s2amdShape* shapes, const unsigned char* moved, const unsigned long long* existing, int existingCount,
+					 const unsigned long long* jointed, int jointedCount, unsigned long long* outKeys, unsigned int outCapacity, unsigned int* outCount)
+{
 	const s2amdShape& X = shapes[xi];
 	const s2amdShape& Y = shapes[yi];
 	if (!aabbOverlaps(X.fatAABB, Y.fatAABB))
@@ -436,6 +445,81 @@ __global__ __launch_bounds__(S2_BLOCK) void pairStrideKernel(const s2amdShape* s
 	for (unsigned int t = blockIdx.x * blockDim.x + threadIdx.x; t < work; t += gridDim.x * blockDim.x)
 	{
 		pairOne(t, shapes, moved, sortedIdx, runOffset, n, existing, existingCount, jointed, jointedCount, outKeys, outCapacity, outCount);
+	}
+}
+
+// The resident query: ONE WAVE PER PROXY walks its run of the sweep axis -- the proxies after it in lower-x order whose lower x
+// is not beyond its upper x (runLengthKernel's predicate, evaluated by the lanes as they go: no run lengths, no scan, no
+// work-item decoding) -- 64 candidates at a time.  Only a pair with a moved member can be reported (reports()), so for a
+// proxy that did not move the lanes skip every candidate that did not move either after one byte read: in a settled pile
+// 6 % of the proxies move and nine tenths of the sweep's candidates cost nothing more.  A run longer than S2_LONG_RUN (the
+// ground under a pile: every proxy is in its run) is finished by the whole grid in pairLongKernel.
+#define S2_LONG_RUN 512
+__global__ __launch_bounds__(S2_BLOCK) void pairWaveKernel(const s2amdShape* shapes, const unsigned char* moved, const int* sortedIdx,
+															const float* sortedLowerX, int n, const unsigned long long* existing, int existingCount,
+															const unsigned long long* jointed, int jointedCount, unsigned long long* outKeys,
+															unsigned int outCapacity, unsigned int* outCount, int* longList, unsigned int* longCount)
+{
+	const int lane = (int)threadIdx.x & 63;
+	const int wavesPerBlock = (int)blockDim.x >> 6;
+	for (int i = (int)blockIdx.x * wavesPerBlock + ((int)threadIdx.x >> 6); i < n; i += (int)gridDim.x * wavesPerBlock)
+	{
+		const int xi = sortedIdx[i];
+		const float ux = shapes[xi].fatAABB[2];
+		const bool mi = moved[xi] != 0;
+		for (int base = i + 1;; base += 64)
+		{
+			if (base - (i + 1) >= S2_LONG_RUN)
+			{
+				if (lane == 0)
+				{
+					longList[atomicAdd(longCount, 1u)] = i; // (at most n entries)
+				}
+				break;
+			}
+			const int j = base + lane;
+			const bool in = j < n && !(sortedLowerX[j] - ux > 0.0f);
+			if (in)
+			{
+				const int yi = sortedIdx[j];
+				if (mi || moved[yi] != 0)
+				{
+					pairTest(xi, yi, shapes, moved, existing, existingCount, jointed, jointedCount, outKeys, outCapacity, outCount);
+				}
+			}
+			if (!__all(in))
+			{
+				break; // (lower x ascends: the run ended inside these 64)
+			}
+		}
+	}
+}
+
+// the rest of the long runs: every thread of the grid strides over each of them
+__global__ __launch_bounds__(S2_BLOCK) void pairLongKernel(const s2amdShape* shapes, const unsigned char* moved, const int* sortedIdx,
+															const float* sortedLowerX, int n, const unsigned long long* existing, int existingCount,
+															const unsigned long long* jointed, int jointedCount, unsigned long long* outKeys,
+															unsigned int outCapacity, unsigned int* outCount, const int* longList, const unsigned int* longCount)
+{
+	const unsigned int count = *longCount;
+	for (unsigned int e = 0; e < count; ++e)
+	{
+		const int i = longList[e];
+		const int xi = sortedIdx[i];
+		const float ux = shapes[xi].fatAABB[2];
+		const bool mi = moved[xi] != 0;
+		for (int j = i + 1 + S2_LONG_RUN + (int)(blockIdx.x * blockDim.x + threadIdx.x); j < n; j += (int)(gridDim.x * blockDim.x))
+		{
+			if (sortedLowerX[j] - ux > 0.0f)
+			{
+				break; // (ascending: everything this thread would visit later lies beyond the run as well)
+			}
+			const int yi = sortedIdx[j];
+			if (mi || moved[yi] != 0)
+			{
+				pairTest(xi, yi, shapes, moved, existing, existingCount, jointed, jointedCount, outKeys, outCapacity, outCount);
+			}
+		}
 	}
 }
 
@@ -588,7 +672,6 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 	(void)dOutB;
 
 	BP_TRY(hipMemsetAsync(dCount, 0, 256, st));
-	BP_TRY(hipMemsetAsync(dRun, 0, ((size_t)n + 1) * 4, st));
 	residentShapeKeysKernel<<<gridFor((size_t)ns), dim3(S2_BLOCK), 0, st>>>(dS, ns, dKeysIn, dIdxIn, dMoved);
 	size_t tmp = tmpBytes + 256;
 	BP_TRY(rocprim::radix_sort_pairs(dTmp, tmp, dKeysIn, dKeysOut, dIdxIn, dIdxOut, (size_t)ns, 0, 32, st));
@@ -601,11 +684,12 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 		*sortedPairKeysValid = true;
 	}
 	gatherLowerXKernel<<<gridFor((size_t)n), dim3(S2_BLOCK), 0, st>>>(dS, dIdxOut, n, dLowerX);
-	runLengthKernel<<<gridFor((size_t)n), dim3(S2_BLOCK), 0, st>>>(dS, dIdxOut, dLowerX, n, dRun);
-	tmp = tmpBytes + 256;
-	BP_TRY(rocprim::exclusive_scan(dTmp, tmp, dRun, dOff, 0u, (size_t)n + 1, rocprim::plus<unsigned int>(), st));
-	pairStrideKernel<<<dim3(4096), dim3(S2_BLOCK), 0, st>>>(dS, dMoved, dIdxOut, dOff, n, sortedPairKeys, nc, dJointed, jointedCount, dOutA,
-															 (unsigned int)outCap, dCount);
+	// (dCount[0] = pairs found, dCount[1] = long runs: both zeroed above; the run-length array of the host-array route holds the long list)
+	(void)dOff;
+	pairWaveKernel<<<dim3((unsigned)std::min((n + 3) / 4, 16384)), dim3(S2_BLOCK), 0, st>>>(dS, dMoved, dIdxOut, dLowerX, n, sortedPairKeys, nc, dJointed,
+																							jointedCount, dOutA, (unsigned int)outCap, dCount, (int*)dRun, dCount + 1);
+	pairLongKernel<<<dim3(256), dim3(S2_BLOCK), 0, st>>>(dS, dMoved, dIdxOut, dLowerX, n, sortedPairKeys, nc, dJointed, jointedCount, dOutA, (unsigned int)outCap,
+														  dCount, (const int*)dRun, dCount + 1);
 	BP_TRY(hipGetLastError());
 	// one read-back: the count and the first keys (a step rarely creates more than a few contacts)
 	constexpr unsigned int kFirst = 2048;

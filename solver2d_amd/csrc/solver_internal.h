@@ -25,7 +25,7 @@
 int s2amdFail(int code, const std::string& msg);
 inline int fail(int code, const std::string& msg) { return s2amdFail(code, msg); }
 
-#define S2_HUB_DEGREE 24
+#define S2_HUB_DEGREE 12
 
 #define HIP_TRY(expr)                                                                                                            \
 	do                                                                                                                           \

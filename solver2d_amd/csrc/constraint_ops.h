@@ -376,6 +376,166 @@ template <int KIND> S2_DEV void pinSoft(SoftRegs<KIND>& r)
 	}
 }
 
+// solveSoftRegs (below) in two parts, for the sequential tail (group_kernel.hip: walkTail).  prepSoft: everything that does not
+// depend on the bodies' VELOCITIES -- the anchors in world orientation, the current separation (poses only change between
+// sweeps), the bias / mass scale / impulse scale selected from it: all lanes of the tail's wave at once.  chainSoft: the
+// dependent chain -- relative velocity, impulse, clamp, apply, point after point, normal then friction: lane after lane.
+// The same operations on the same operands as solveSoftRegs, which stays one function: the resident kernels' register
+// allocation is tuned around it (splitting it there cost the headline kernel 17 us).
+struct SoftPre
+{
+	V2 rA[2], rB[2];
+	float bias[2], massScale[2], impulseScale[2];
+};
+
+// POINTS == 2: the caller has checked that the constraint has two points (a wave-uniform fast path without
+// per-point exec masking); POINTS == 0: per-point guards on h.pointCount.
+template <int KIND, class BA, bool PIN = true, int POINTS = 0>
+S2_DEV SoftPre prepSoft(SoftRegs<KIND>& r, const BA& b, float inv_h, int useBias)
+{
+	completeSoft(r, b);
+	const CHeader& h = r.h;
+	const float biasCap = (KIND == SOFT_TGS || KIND == SOFT_JACOBI) ? -S2_MAX_BAUMGARTE_VELOCITY : -0.5f * S2_MAX_BAUMGARTE_VELOCITY;
+	float4* an = r.an;
+	float4* r0 = r.r0;
+	float4* par = r.par;
+	float4* sf = r.sf;
+	V2 dcA, dcB;
+	Rot qA, qB;
+	if (KIND == SOFT_TGS || KIND == SOFT_FIXED)
+	{
+		BodyPose pA = loadPose(b, h.ia), pB = loadPose(b, h.ib);
+		dcA = pA.dc, qA = pA.q, dcB = pB.dc, qB = pB.q;
+	}
+	if (PIN)
+	{
+		pinSoft(r);
+	}
+	V2 normal = h.normal;
+	SoftPre pre;
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		if (POINTS == 2 || j < h.pointCount)
+		{
+			V2 rA, rB;
+			float s;
+			if (KIND == SOFT_TGS)
+			{
+				rA = rotate(qA, v2(an[j].x, an[j].y));
+				rB = rotate(qB, v2(an[j].z, an[j].w));
+				V2 ds = add(sub(dcB, dcA), sub(rB, rA));
+				s = dot(ds, normal) + par[j].x;
+			}
+			else if (KIND == SOFT_FIXED)
+			{
+				V2 ds = add(sub(dcB, dcA), sub(rotate(qB, v2(an[j].z, an[j].w)), rotate(qA, v2(an[j].x, an[j].y))));
+				s = dot(ds, normal) + par[j].x;
+				rA = v2(r0[j].x, r0[j].y);
+				rB = v2(r0[j].z, r0[j].w);
+			}
+			else
+			{
+				s = par[j].w;
+				rA = v2(r0[j].x, r0[j].y);
+				rB = v2(r0[j].z, r0[j].w);
+			}
+			pre.rA[j] = rA, pre.rB[j] = rB;
+
+			// select form of: if (s > 0) bias = s * inv_h; else if (useBias) {bias = max(biasCoefficient * s, cap); ...}
+			const bool speculative = s > 0.0f;
+			const bool soft = !speculative && useBias != 0;
+			float softBias = S2_MAXF(sf[j].x * s, biasCap);
+			pre.bias[j] = speculative ? s * inv_h : (soft ? softBias : 0.0f);
+			pre.massScale[j] = soft ? sf[j].y : 1.0f;
+			pre.impulseScale[j] = soft ? sf[j].z : 0.0f;
+		}
+	}
+	return pre;
+}
+
+template <int KIND, class BA, int POINTS = 0>
+S2_DEV void chainSoft(SoftRegs<KIND>& r, const SoftPre& pre, const ContactView& c, const BA& b, int k)
+{
+	const CHeader& h = r.h;
+	float4* par = r.par;
+	float2* imp = r.imp;
+	BodyVel A = loadVel(b, h.ia), B = loadVel(b, h.ib);
+	V2 vA = A.v, vB = B.v;
+	float wA = A.w, wB = B.w;
+	V2 normal = h.normal;
+	V2 tangent = rightPerp(normal);
+	float mA = h.mA, iA = h.iA, mB = h.mB, iB = h.iB;
+	float nImp[2], tImp[2];
+
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		if (POINTS == 2 || j < h.pointCount)
+		{
+			V2 rA = pre.rA[j], rB = pre.rB[j];
+			V2 vrB = add(vB, crossSV(wB, rB));
+			V2 vrA = add(vA, crossSV(wA, rA));
+			float vn = dot(sub(vrB, vrA), normal);
+
+			float impulse = -par[j].y * pre.massScale[j] * (vn + pre.bias[j]) - pre.impulseScale[j] * imp[j].x;
+			float newImpulse = S2_MAXF(imp[j].x + impulse, 0.0f);
+			impulse = newImpulse - imp[j].x;
+			nImp[j] = newImpulse;
+			tImp[j] = imp[j].y;
+
+			V2 P = mulSV(impulse, normal);
+			vA = mulSub(vA, mA, P);
+			wA -= iA * cross(rA, P);
+			vB = mulAdd(vB, mB, P);
+			wB += iB * cross(rB, P);
+		}
+	}
+
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		if (POINTS == 2 || j < h.pointCount)
+		{
+			float tangentMass = par[j].z;
+			V2 rA = pre.rA[j], rB = pre.rB[j];
+			V2 vrB = add(vB, crossSV(wB, rB));
+			V2 vrA = add(vA, crossSV(wA, rA));
+			float vt = dot(sub(vrB, vrA), tangent);
+			float impulse = -tangentMass * vt;
+			float maxFriction = h.friction * nImp[j];
+			float newImpulse = S2_CLAMPF(tImp[j] + impulse, -maxFriction, maxFriction);
+			impulse = newImpulse - tImp[j];
+			tImp[j] = newImpulse;
+			V2 P = mulSV(impulse, tangent);
+			vA = mulSub(vA, mA, P);
+			wA -= iA * cross(rA, P);
+			vB = mulAdd(vB, mB, P);
+			wB += iB * cross(rB, P);
+			imp[j] = make_float2(nImp[j], tImp[j]);
+		}
+	}
+
+	if (KIND == SOFT_JACOBI)
+	{
+		// solve_jacobi.c:126-130: the body sums these in constraint order (jacobiApplyKernel)
+		V2 dA = sub(vA, A.v), dB = sub(vB, B.v);
+		c.deltaA[k] = make_float4(dA.x, dA.y, wA - A.w, 0.0f);
+		c.deltaB[k] = make_float4(dB.x, dB.y, wB - B.w, 0.0f);
+	}
+	else
+	{
+		if (h.writeA)
+		{
+			storeVel(b, h.ia, vA, wA);
+		}
+		if (h.writeB)
+		{
+			storeVel(b, h.ib, vB, wB);
+		}
+	}
+}
+
 // the arithmetic of one constraint: bodies read and written through `b`, impulses updated in `r`
 // POINTS == 2: the caller has checked that the constraint has two points (a wave-uniform fast path without
 // per-point exec masking); POINTS == 0: per-point guards on h.pointCount.

@@ -117,6 +117,13 @@ template <class R, class L, class F, class S> S2_DEV void walkTail(int begin, in
 	}
 }
 
+// a tail constraint of the soft sweeps between its two parts (constraint_ops.h: prepSoft / chainSoft)
+template <int KIND> struct TailSoft
+{
+	SoftRegs<KIND> r;
+	SoftPre pre;
+};
+
 // forBatches with the tail batches walked by walkTail
 template <class R, class L, class C, class S, class F> S2_DEV void forBatchesSplit(const int4* batches, int b0, int b1, L load, C compute, S store, F f)
 {
@@ -335,10 +342,16 @@ __global__ __launch_bounds__(THREADS) void groupKernel(ContactView c, JointView 
 						}
 						else
 						{
-							forBatchesSplit<SoftRegs<SOFT_TGS>>(
-								gt.cBatches, cb0, cb1, [&](int k) { return loadSoftB<SOFT_TGS>(c, lb, k); },
-								[&](SoftRegs<SOFT_TGS>& r, int k) { solveSoftRegs<SOFT_TGS>(r, c, lb, op.inv_h, op.useBias, k); },
-								[&](const SoftRegs<SOFT_TGS>& r, int k) { storeSoft<SOFT_TGS>(c, r, k); },
+							forBatchesSplit<TailSoft<SOFT_TGS>>(
+								gt.cBatches, cb0, cb1,
+								[&](int k) {
+									TailSoft<SOFT_TGS> t;
+									t.r = loadSoftB<SOFT_TGS>(c, lb, k);
+									t.pre = prepSoft<SOFT_TGS>(t.r, lb, op.inv_h, op.useBias); // poses only: every lane at once
+									return t;
+								},
+								[&](TailSoft<SOFT_TGS>& t, int k) { chainSoft<SOFT_TGS>(t.r, t.pre, c, lb, k); }, // velocities: lane after lane
+								[&](const TailSoft<SOFT_TGS>& t, int k) { storeSoft<SOFT_TGS>(c, t.r, k); },
 								[&](int k) { solveContactsSoftOne<SOFT_TGS>(c, lb, op.inv_h, op.useBias, k); });
 						}
 						break;
@@ -349,10 +362,16 @@ __global__ __launch_bounds__(THREADS) void groupKernel(ContactView c, JointView 
 						}
 						else
 						{
-							forBatchesSplit<SoftRegs<SOFT_PGS>>(
-								gt.cBatches, cb0, cb1, [&](int k) { return loadSoftB<SOFT_PGS>(c, lb, k); },
-								[&](SoftRegs<SOFT_PGS>& r, int k) { solveSoftRegs<SOFT_PGS>(r, c, lb, op.inv_h, op.useBias, k); },
-								[&](const SoftRegs<SOFT_PGS>& r, int k) { storeSoft<SOFT_PGS>(c, r, k); },
+							forBatchesSplit<TailSoft<SOFT_PGS>>(
+								gt.cBatches, cb0, cb1,
+								[&](int k) {
+									TailSoft<SOFT_PGS> t;
+									t.r = loadSoftB<SOFT_PGS>(c, lb, k);
+									t.pre = prepSoft<SOFT_PGS>(t.r, lb, op.inv_h, op.useBias); // poses only: every lane at once
+									return t;
+								},
+								[&](TailSoft<SOFT_PGS>& t, int k) { chainSoft<SOFT_PGS>(t.r, t.pre, c, lb, k); }, // velocities: lane after lane
+								[&](const TailSoft<SOFT_PGS>& t, int k) { storeSoft<SOFT_PGS>(c, t.r, k); },
 								[&](int k) { solveContactsSoftOne<SOFT_PGS>(c, lb, op.inv_h, op.useBias, k); });
 						}
 						break;
@@ -363,10 +382,16 @@ __global__ __launch_bounds__(THREADS) void groupKernel(ContactView c, JointView 
 						}
 						else
 						{
-							forBatchesSplit<SoftRegs<SOFT_FIXED>>(
-								gt.cBatches, cb0, cb1, [&](int k) { return loadSoftB<SOFT_FIXED>(c, lb, k); },
-								[&](SoftRegs<SOFT_FIXED>& r, int k) { solveSoftRegs<SOFT_FIXED>(r, c, lb, op.inv_h, op.useBias, k); },
-								[&](const SoftRegs<SOFT_FIXED>& r, int k) { storeSoft<SOFT_FIXED>(c, r, k); },
+							forBatchesSplit<TailSoft<SOFT_FIXED>>(
+								gt.cBatches, cb0, cb1,
+								[&](int k) {
+									TailSoft<SOFT_FIXED> t;
+									t.r = loadSoftB<SOFT_FIXED>(c, lb, k);
+									t.pre = prepSoft<SOFT_FIXED>(t.r, lb, op.inv_h, op.useBias); // poses only: every lane at once
+									return t;
+								},
+								[&](TailSoft<SOFT_FIXED>& t, int k) { chainSoft<SOFT_FIXED>(t.r, t.pre, c, lb, k); }, // velocities: lane after lane
+								[&](const TailSoft<SOFT_FIXED>& t, int k) { storeSoft<SOFT_FIXED>(c, t.r, k); },
 								[&](int k) { solveContactsSoftOne<SOFT_FIXED>(c, lb, op.inv_h, op.useBias, k); });
 						}
 						break;

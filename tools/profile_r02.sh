@@ -12,9 +12,9 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/p2_write -o pmc -- $B > $O/p2_wr
 rocprofv3 --kernel-trace --stats -d $O/p2_c5 -o trace -- python $R/bench.py --config 5 --steps 60 --warmup 10 > $O/p2_c5.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/p2_c5_fetch -o pmc -- python $R/bench.py --config 5 --steps 60 --warmup 10 > $O/p2_c5_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/p2_c5_write -o pmc -- python $R/bench.py --config 5 --steps 60 --warmup 10 > $O/p2_c5_write.log 2>&1
-rocprofv3 --kernel-trace --stats -d $O/p2_churn -o trace -- python $R/tools/churn_bench.py > $O/p2_churn.log 2>&1
+# (rocprofv3 segfaults on tools/churn_bench.py on this image: no churn trace)
 cd $R
-for d in p2_stats p2_fetch p2_write p2_c5 p2_c5_fetch p2_c5_write p2_churn; do
+for d in p2_stats p2_fetch p2_write p2_c5 p2_c5_fetch p2_c5_write; do
   db=$(find $O/$d -name "*_results.db" | head -1)
   [ -n "$db" ] && python tools/rocpd_summary.py $db > $O/$d.txt
 done

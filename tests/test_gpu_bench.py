@@ -93,25 +93,26 @@ def _unsharded_poses(islands, base, steps):
     return out
 
 
-@pytest.mark.parametrize("nranks,port", [(2, 29523), (3, 29525)])
-def test_island_sharded_config5_equals_the_unsharded_world(tmp_path, nranks, port):
+@pytest.mark.parametrize("nranks,port,islands", [(2, 29523, 37), (3, 29525, 37), (3, 29529, 2)])
+def test_island_sharded_config5_equals_the_unsharded_world(tmp_path, nranks, port, islands):
     """bench.py --config 5 (BASELINE configs[4]) with 2 and 3 ranks sharing this box's one GPU over gloo: every rank's shard
     resident, pose records all-gathered every step.  The poses rank 0 assembles from the gathered records after
-    warmup + steps steps must equal, bit for bit, those of the same world stepped unsharded in one solver."""
+    warmup + steps steps must equal, bit for bit, those of the same world stepped unsharded in one solver.  (Two islands on
+    three ranks: one rank owns nothing and still takes part in every all-gather.)"""
     import numpy as np
     dump = str(tmp_path / "poses.npy")
     env = dict(os.environ, S2AMD_BENCH_BACKEND="gloo", S2AMD_BENCH_SINGLE_DEVICE="1", MASTER_ADDR="127.0.0.1", S2AMD_BENCH_DUMP=dump)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1", "--master-port",
-           str(port), "bench.py", "--gpus", str(nranks), "--config", "5", "--islands", "37", "--island-base", "14", "--steps", "12", "--warmup", "3"]
+           str(port), "bench.py", "--gpus", str(nranks), "--config", "5", "--islands", str(islands), "--island-base", "14", "--steps", "12", "--warmup", "3"]
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     d = last_json(out.stdout)
     for k in REQUIRED:
         assert k in d, k
-    assert d["n_gpus"] == nranks and d["scaling"] == "strong" and d["config"]["constraints"] == 37 * 287
-    assert abs(d["value"] - 37 * 287 * 16 * 12 / (d["ms_per_step"] * 12e-3)) / d["value"] < 1e-6
+    assert d["n_gpus"] == nranks and d["scaling"] == "strong" and d["config"]["constraints"] == islands * 287
+    assert abs(d["value"] - islands * 287 * 16 * 12 / (d["ms_per_step"] * 12e-3)) / d["value"] < 1e-6
     got = np.load(dump)
-    want = _unsharded_poses(37, 14, 15)
+    want = _unsharded_poses(islands, 14, 15)
     assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 

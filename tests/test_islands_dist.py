@@ -20,21 +20,21 @@ def _free_port():
     return p
 
 
-def _worker(rank, world_size, port, steps, q):
+def _worker(rank, world_size, port, steps, q, islands=7):
     try:
-        _worker_body(rank, world_size, port, steps, q)
+        _worker_body(rank, world_size, port, steps, q, islands)
     except Exception as e:  # surface the failure instead of leaving the parent waiting
         q.put(("error", repr(e)))
         raise
 
 
-def _worker_body(rank, world_size, port, steps, q):
+def _worker_body(rank, world_size, port, steps, q, islands=7):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world_size)
-    world = synthetic.pyramid(6, count=7)
+    world = synthetic.pyramid(6, count=islands)
     params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
     sw = distributed.ShardedWorld(*world, rank=rank, world_size=world_size)
     bodies = None
@@ -78,3 +78,30 @@ def test_single_rank_path():
     oraclebind.solve(params, *world)
     for f in common.BODY_OUT:
         assert np.array_equal(out[f], world[0][f])
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world_size,islands", [(4, 7), (4, 3)])
+def test_more_ranks_gloo_equal_single_process(world_size, islands):
+    """Four ranks: seven islands (uneven shards) and three islands (one rank owns NOTHING: its shard is empty, it still takes
+    part in every all-gather)."""
+    import torch.multiprocessing as mp
+    steps = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world_size, port, steps, q, islands)) for r in range(world_size)]
+    for p in procs:
+        p.start()
+    status, payload = q.get(timeout=200)
+    assert status == "ok", payload
+    got = np.frombuffer(payload, dtype=wire.body_dtype)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    whole = synthetic.pyramid(6, count=islands)
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    for _ in range(steps):
+        oraclebind.solve(params, *whole)
+    for f in common.BODY_OUT:
+        assert np.array_equal(got[f].view(np.uint32), whole[0][f].view(np.uint32)), f

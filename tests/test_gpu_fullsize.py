@@ -108,3 +108,30 @@ def test_config5_as_a_resident_world_chain():
         res = s.world_download(*[out[k] for k in world_chain.WORLD_KEYS])
         world_chain.assert_device_equals_oracle(dict(zip(world_chain.WORLD_KEYS, res[:6])), ref, "512 x pyramid40 world step")
         assert info["activeContacts"] == 1218560 and info["separatedCount"] == 0
+
+
+def test_config2_as_a_whole_loop_at_full_size():
+    """BASELINE configs[1] as a WORLD at full size: LargePyramid base-200 (20,101 boxes, 59,900 manifolds), the whole loop of
+    s2World_Step -- device pair query after every step that re-inflated a box (== the oracle's, nothing new), stage 3 on every
+    pair, s2Solve_TGS_Soft on the persistent strip kernel from the second step on, stage 4 -- six steps, every array
+    bit-exact against the oracle chain after each."""
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    world = synthetic.pyramid_world(200)
+    ref = world_chain.copy_world(world)
+    with hip.Solver(0) as s:
+        s.world_upload(*[world[k] for k in world_chain.WORLD_KEYS])
+        persistent = 0
+        for step in range(6):
+            if world_chain.moved_any(ref):
+                got = s.world_find_pairs()
+                want = world_chain.oracle_find_pairs(ref)
+                assert np.array_equal(got, want) and len(got) == 0, "step %d: new pairs" % step
+            info = s.world_step(params)
+            order, _ = s.contact_order()
+            world_chain.oracle_world_step(params, ref, contact_order=order)
+            out = world_chain.copy_world(world)
+            res = s.world_download(*[out[k] for k in world_chain.WORLD_KEYS])
+            world_chain.assert_device_equals_oracle(dict(zip(world_chain.WORLD_KEYS, res[:6])), ref, "pyramid200 world step %d" % step)
+            assert info["activeContacts"] == 59900 and info["separatedCount"] == 0
+            persistent += s.stats()["persistent"]
+        assert persistent >= 4, persistent

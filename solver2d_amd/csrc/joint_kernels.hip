@@ -240,6 +240,77 @@ void launchSolveJoints(hipStream_t s, int kind, const JointView& j, const BodyVi
 	}
 }
 
+// Joint warm start, body-centric (the counterpart of warmStartBodiesKernel for contacts): s2WarmStartRevolute / s2WarmStartMouse
+// (revolute_joint.c:107-150, mouse_joint.c:85-107) only ADD velocity-independent terms, so each body adds the terms of its
+// incident joints in sweep order -- the same additions in the same order as the coloured sweep -- in ONE launch instead of
+// one per joint colour.  adjRange[i] = {first entry, count} in adjList; an entry is (k << 1) | side.
+__global__ __launch_bounds__(S2_BLOCK) void warmStartJointsBodiesKernel(JointView jv, BodyView b, const int2* adjRange, const int* adjList)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= b.capacity)
+	{
+		return;
+	}
+	const int2 range = adjRange[i];
+	if (range.y <= 0)
+	{
+		return;
+	}
+	const float4 v0 = b.vel[i], d = b.dq[i];
+	Rot q;
+	q.s = d.z, q.c = d.w;
+	V2 v = v2(v0.x, v0.y);
+	float w = v0.z;
+	bool wrote = false;
+	for (int e = range.x; e < range.x + range.y; ++e)
+	{
+		const int key = adjList[e];
+		const JState s = loadJoint<S2_IDX_GLOBAL>(jv, key >> 1);
+		if (s.flags & S2J_MOUSE)
+		{
+			if ((key & 1) && (s.flags & S2J_WRITE_B))
+			{
+				V2 rB = rotate(q, s.lB);
+				v = mulAdd(v, s.mB, s.impulse);
+				w += s.iB * (cross(rB, s.impulse) + s.motorImpulse);
+				wrote = true;
+			}
+			continue;
+		}
+		const float axialImpulse = s.motorImpulse + s.lowerImpulse - s.upperImpulse;
+		const V2 P = s.impulse;
+		if ((key & 1) == 0)
+		{
+			if (s.flags & S2J_WRITE_A)
+			{
+				V2 rA = rotate(q, s.lA);
+				v = mulSub(v, s.mA, P);
+				w -= s.iA * (cross(rA, P) + axialImpulse);
+				wrote = true;
+			}
+		}
+		else if (s.flags & S2J_WRITE_B)
+		{
+			V2 rB = rotate(q, s.lB);
+			v = mulAdd(v, s.mB, P);
+			w += s.iB * (cross(rB, P) + axialImpulse);
+			wrote = true;
+		}
+	}
+	if (wrote)
+	{
+		b.vel[i] = make_float4(v.x, v.y, w, 0.0f);
+	}
+}
+
+void launchWarmStartJointsBodies(hipStream_t s, const JointView& j, const BodyView& b, const int2* adjRange, const int* adjList)
+{
+	if (b.capacity > 0)
+	{
+		warmStartJointsBodiesKernel<<<gridFor(b.capacity), dim3(S2_BLOCK), 0, s>>>(j, b, adjRange, adjList);
+	}
+}
+
 void launchStoreJoints(hipStream_t s, const JointView& j, s2amdJoint* wire, const unsigned int* stepFailed)
 {
 	if (j.count > 0)

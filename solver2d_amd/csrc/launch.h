@@ -132,6 +132,7 @@ void launchGatherMessageSlots(hipStream_t s, const BodyView& b, const MsgView& m
 
 // body-centric warm start (one launch for all colours, optionally fused with integrate velocities)
 // heavy: the bodies with more than S2_HEAVY_DEGREE list entries (a whole wave walks each of them)
+void launchWarmStartJointsBodies(hipStream_t s, const JointView& j, const BodyView& b, const int2* adjRange, const int* adjList);
 void launchWarmStartBodies(hipStream_t s, int kind, const ContactView& c, const BodyView& b, const int2* adjRange, const int* adjList,
 						   int integrateFirst, const int* heavy, int heavyCount);
 

@@ -690,6 +690,14 @@ struct Executor
 					continue;
 				}
 				const Op& o = p.ops[(size_t)i];
+				// joint warm start as ONE body-centric launch instead of one per joint colour (and the joints' sequential tail)
+				if (o.code == OP_JOINT_SWEEP && o.kind == JSOLVE_WARM && s->optBodyWarm && s->jointAdjValid && s->joints.globalCount > 0)
+				{
+					launchWarmStartJointsBodies(st, s->jv, s->bv, (const int2*)s->dJointAdjRange.p, (const int*)s->dJointAdjList.p);
+					count();
+					done[(size_t)i] = 1;
+					continue;
+				}
 				// contact warm start as ONE body-centric launch; an immediately preceding integrate-velocities
 				// (joint sweeps in between only when there are no global joints) rides along in the same kernel
 				// (a structure built for s2Solve_Jacobi has no colours: the body-centric form is the only one there)

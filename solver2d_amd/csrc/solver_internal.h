@@ -249,6 +249,8 @@ struct s2amdSolver
 	int spareColours = 0;	// empty colour batches a build adds to the global part: 0 until a created contact found every colour of its
 							// bodies taken (a dense pile: a box inside a pyramid uses all six), then 2 -- two more launches per sweep
 	DevBuf dSeparated;		// world chain: the pair slots stage 3 freed this step
+	DevBuf dJointAdjRange, dJointAdjList; // body -> incident global joints in sweep order (body-centric joint warm start)
+	bool jointAdjValid = false;
 	DevBuf dSlotBytes;		// world chain: one byte per pair slot for a structure build (world.hip: slotBytesKernel)
 	std::vector<uint8_t> hSlotBytes;
 	bool slotBytesFresh = false; // hSlotBytes is of the state the device is in right now (cleared by every world call that changes it)

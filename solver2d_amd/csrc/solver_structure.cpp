@@ -787,6 +787,64 @@ static int buildAdjacency(s2amdSolver* s, const std::vector<uint8_t>& conflict, 
 	return S2AMD_OK;
 }
 
+// body -> incident joints of the global part in SWEEP order, key = k << 1 | side (mouse joints only have a B side): the
+// body-centric joint warm start (joint_kernels.hip: warmStartJointsBodiesKernel)
+static int buildJointAdjacency(s2amdSolver* s, int nb)
+{
+	s->jointAdjValid = false;
+	const SweepSet& js = s->joints;
+	const int GJ = js.globalCount;
+	if (GJ <= 0 || nb <= 0)
+	{
+		return S2AMD_OK;
+	}
+	std::vector<int2> range((size_t)nb, make_int2(0, 0));
+	auto movable = [&](int body) { return body >= 0 && body < nb && (s->hBodyFlags[(size_t)body] & (S2F_WRITE_VEL | S2F_WRITE_POS)) != 0; };
+	for (int k = 0; k < GJ; ++k)
+	{
+		const int slot = js.order[(size_t)k];
+		const int a = s->hJointType[(size_t)slot] == S2AMD_JOINT_MOUSE ? -1 : s->hJointA[(size_t)slot], b = s->hJointB[(size_t)slot];
+		range[(size_t)std::max(a, 0)].y += movable(a) ? 1 : 0;
+		range[(size_t)std::max(b, 0)].y += movable(b) ? 1 : 0;
+	}
+	int total = 0;
+	for (int i = 0; i < nb; ++i)
+	{
+		range[(size_t)i].x = total;
+		total += range[(size_t)i].y;
+		range[(size_t)i].y = 0;
+	}
+	std::vector<int> list((size_t)std::max(total, 1), 0);
+	for (int k = 0; k < GJ; ++k)
+	{
+		const int slot = js.order[(size_t)k];
+		const int a = s->hJointType[(size_t)slot] == S2AMD_JOINT_MOUSE ? -1 : s->hJointA[(size_t)slot], b = s->hJointB[(size_t)slot];
+		if (movable(a))
+		{
+			list[(size_t)(range[(size_t)a].x + range[(size_t)a].y++)] = (k << 1) | 0;
+		}
+		if (movable(b))
+		{
+			list[(size_t)(range[(size_t)b].x + range[(size_t)b].y++)] = (k << 1) | 1;
+		}
+	}
+	int rc;
+	bool grew = false;
+	if ((rc = s->dJointAdjRange.ensure((size_t)nb * sizeof(int2), &grew)) != 0 || (rc = s->dJointAdjList.ensure(list.size() * sizeof(int), &grew)) != 0)
+	{
+		return rc;
+	}
+	if (grew)
+	{
+		s->layoutGeneration += 1;
+	}
+	HIP_TRY(hipMemcpyAsync(s->dJointAdjRange.p, range.data(), (size_t)nb * sizeof(int2), hipMemcpyHostToDevice, s->stream));
+	HIP_TRY(hipMemcpyAsync(s->dJointAdjList.p, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+	HIP_TRY(hipStreamSynchronize(s->stream)); // range and list are locals
+	s->jointAdjValid = true;
+	return S2AMD_OK;
+}
+
 // The lean / persistent strip tables of one strip partition (strip_kernel.hip): per-strip descriptors, warm-start slots,
 // the persistent kernel's register / LDS plan.  Part of buildStructureWith; leaves s->leanAValid / leanBValid /
 // persistValid false when this partition cannot use those kernels.
@@ -2199,7 +2257,7 @@ struct StructureBuild
 
 		phase("message tables");
 		s->adjValid = false;
-		if ((rc = buildAdjacency(s, conflict, nb)) != 0)
+		if ((rc = buildAdjacency(s, conflict, nb)) != 0 || (rc = buildJointAdjacency(s, nb)) != 0)
 		{
 			return rc;
 		}

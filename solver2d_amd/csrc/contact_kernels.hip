@@ -316,7 +316,8 @@ template <int KIND>
 // (packBodyOne); the remaining blocks zero the hand-off buffers of the persistent strip step (strip_kernel.hip: its
 // tags restart at 1 every launch, so the buffers must be clean when the next step starts)
 __global__ __launch_bounds__(S2_BLOCK) void storeImpulsesKernel(ContactView c, s2amdContact* wire, float scale, int contactBlocks, int bodyBlocks,
-																BodyView bodies, s2amdBody* wireBodies, uint4* clear, int clearCount, const unsigned int* stepFailed)
+																BodyView bodies, s2amdBody* wireBodies, uint4* clear, int clearCount, const unsigned int* stepFailed,
+																int finalizeMode)
 {
 	// a persistent step whose hand-offs timed out leaves the wire arrays as they were: the host then repeats the step
 	// on the multi-launch path (solver_step.cpp: doStep); the hand-off buffers are cleared either way
@@ -336,7 +337,15 @@ __global__ __launch_bounds__(S2_BLOCK) void storeImpulsesKernel(ContactView c, s
 	}
 	if ((int)blockIdx.x >= contactBlocks)
 	{
-		packBodyOne(bodies, wireBodies, ((int)blockIdx.x - contactBlocks) * (int)blockDim.x + (int)threadIdx.x);
+		const int i = ((int)blockIdx.x - contactBlocks) * (int)blockDim.x + (int)threadIdx.x;
+		if (finalizeMode >= 0 && i < bodies.capacity && (bodies.flags[i] & S2F_IN_GROUP) == 0)
+		{
+			// s2FinalizePositions (solve_common.c:70) of the bodies no LDS group or strip owns, when it is the step's last
+			// body stage: folded into the write-back instead of a launch of its own (finalizePositionsKernel)
+			GlobalBodies gb{bodies.vel, bodies.dq};
+			finalizePositionsOne(gb, i, bodies, i, finalizeMode, true);
+		}
+		packBodyOne(bodies, wireBodies, i);
 		return;
 	}
 	int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -788,7 +797,7 @@ void launchBlockSolvePosition(hipStream_t s, const ContactView& c, const BodyVie
 }
 
 void launchStoreImpulses(hipStream_t s, int kind, const ContactView& c, s2amdContact* wire, float scale, const BodyView& bodies, s2amdBody* wireBodies,
-						 void* clear, size_t clearBytes, const unsigned int* stepFailed)
+						 void* clear, size_t clearBytes, const unsigned int* stepFailed, int finalizeMode)
 {
 	// bodies == nullptr-capacity: plain store; otherwise the body write-back rides in the same launch
 	const int contactBlocks = c.count > 0 ? (c.count - (c.skipEnd - c.skipBegin) + S2_BLOCK - 1) / S2_BLOCK : 0;
@@ -803,13 +812,13 @@ void launchStoreImpulses(hipStream_t s, int kind, const ContactView& c, s2amdCon
 	switch (kind)
 	{
 		case STORE_SCALED:
-			storeImpulsesKernel<STORE_SCALED><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount, stepFailed);
+			storeImpulsesKernel<STORE_SCALED><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount, stepFailed, finalizeMode);
 			break;
 		case STORE_BLOCK:
-			storeImpulsesKernel<STORE_BLOCK><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount, stepFailed);
+			storeImpulsesKernel<STORE_BLOCK><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount, stepFailed, finalizeMode);
 			break;
 		default:
-			storeImpulsesKernel<STORE_PLAIN><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount, stepFailed);
+			storeImpulsesKernel<STORE_PLAIN><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount, stepFailed, finalizeMode);
 			break;
 	}
 }

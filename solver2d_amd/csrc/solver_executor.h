@@ -678,11 +678,14 @@ struct Executor
 			runStrips();
 		}
 		// global part: op by op
+		int fusedFinalize = -1; // >= 0: the dynamicOnly flag of the s2FinalizePositions the epilogue launch performs
 		const bool anyGlobal = s->looseBodies > 0 || s->contacts.globalCount > 0 || s->joints.globalCount > 0;
 		if (anyGlobal)
 		{
 			const int n = (int)p.ops.size();
 			std::vector<uint8_t> done((size_t)n, 0);
+			const bool looseBodies = s->looseBodies > 0;
+			const int lastBodyOp = n - 1; // (every plan ends with s2FinalizePositions; the store is the epilogue, not an op)
 			for (int i = 0; i < n; ++i)
 			{
 				if (done[(size_t)i])
@@ -690,6 +693,13 @@ struct Executor
 					continue;
 				}
 				const Op& o = p.ops[(size_t)i];
+				// the step's last body stage, s2FinalizePositions, rides in the epilogue launch (with the body write-back)
+				if (o.code == OP_FINALIZE && !msg && looseBodies && i == lastBodyOp && wireBodies() != nullptr)
+				{
+					fusedFinalize = o.flag;
+					done[(size_t)i] = 1;
+					continue;
+				}
 				// joint warm start as ONE body-centric launch instead of one per joint colour (and the joints' sequential tail)
 				if (o.code == OP_JOINT_SWEEP && o.kind == JSOLVE_WARM && s->optBodyWarm && s->jointAdjValid && s->joints.globalCount > 0)
 				{
@@ -736,7 +746,7 @@ struct Executor
 		int kind, warm;
 		const bool usedGranules = s->dStripA.view.groupCount > 0 && persistPlan(kind, warm);
 		launchStoreImpulses(st, p.storeKind, cvIo, wireContacts(), p.storeScale, s->bv, wireBodies(), usedGranules ? s->dGranules.p : nullptr,
-							usedGranules ? s->granuleBytes : 0, usedGranules ? s->persist.deviceError : nullptr);
+							usedGranules ? s->granuleBytes : 0, usedGranules ? s->persist.deviceError : nullptr, fusedFinalize);
 		count();
 		if (s->jv.count > 0)
 		{

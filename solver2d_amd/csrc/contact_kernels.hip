@@ -317,14 +317,33 @@ template <int KIND>
 // tags restart at 1 every launch, so the buffers must be clean when the next step starts)
 __global__ __launch_bounds__(S2_BLOCK) void storeImpulsesKernel(ContactView c, s2amdContact* wire, float scale, int contactBlocks, int bodyBlocks,
 																BodyView bodies, s2amdBody* wireBodies, uint4* clear, int clearCount, const unsigned int* stepFailed,
-																int finalizeMode)
+																int finalizeMode, JointView jv, s2amdJoint* wireJoints, int jointBlocks)
 {
 	// a persistent step whose hand-offs timed out leaves the wire arrays as they were: the host then repeats the step
 	// on the multi-launch path (solver_step.cpp: doStep); the hand-off buffers are cleared either way
 	const bool failed = stepFailed != nullptr && *stepFailed != 0u; // a device-memory word, written by the previous launch
-	if ((int)blockIdx.x >= contactBlocks + bodyBlocks)
+	if ((int)blockIdx.x >= contactBlocks + bodyBlocks && (int)blockIdx.x < contactBlocks + bodyBlocks + jointBlocks)
 	{
-		int i = ((int)blockIdx.x - contactBlocks - bodyBlocks) * (int)blockDim.x + (int)threadIdx.x;
+		// joint impulses -> wire joints (joint.c: the persistent members of s2RevoluteJoint / s2MouseJoint), as storeJointsKernel
+		const int k = ((int)blockIdx.x - contactBlocks - bodyBlocks) * (int)blockDim.x + (int)threadIdx.x;
+		if (!failed && k < jv.count)
+		{
+			s2amdJoint* w = wireJoints + jv.jointIndex[k];
+			float2 im = jv.impulse[k];
+			float4 ax = jv.axial[k];
+			w->impulse[0] = im.x, w->impulse[1] = im.y;
+			w->motorImpulse = ax.x;
+			if (w->type == S2AMD_JOINT_REVOLUTE)
+			{
+				w->lowerImpulse = ax.y;
+				w->upperImpulse = ax.z;
+			}
+		}
+		return;
+	}
+	if ((int)blockIdx.x >= contactBlocks + bodyBlocks + jointBlocks)
+	{
+		int i = ((int)blockIdx.x - contactBlocks - bodyBlocks - jointBlocks) * (int)blockDim.x + (int)threadIdx.x;
 		if (i < clearCount)
 		{
 			clear[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -797,28 +816,30 @@ void launchBlockSolvePosition(hipStream_t s, const ContactView& c, const BodyVie
 }
 
 void launchStoreImpulses(hipStream_t s, int kind, const ContactView& c, s2amdContact* wire, float scale, const BodyView& bodies, s2amdBody* wireBodies,
-						 void* clear, size_t clearBytes, const unsigned int* stepFailed, int finalizeMode)
+						 void* clear, size_t clearBytes, const unsigned int* stepFailed, int finalizeMode, const JointView* joints, s2amdJoint* wireJoints)
 {
 	// bodies == nullptr-capacity: plain store; otherwise the body write-back rides in the same launch
 	const int contactBlocks = c.count > 0 ? (c.count - (c.skipEnd - c.skipBegin) + S2_BLOCK - 1) / S2_BLOCK : 0;
 	const int bodyBlocks = wireBodies && bodies.capacity > 0 ? (bodies.capacity + S2_BLOCK - 1) / S2_BLOCK : 0;
 	const int clearCount = clear ? (int)(clearBytes / sizeof(uint4)) : 0; // buffers are allocated in multiples of 256 bytes
 	const int clearBlocks = (clearCount + S2_BLOCK - 1) / S2_BLOCK;
-	if (contactBlocks + bodyBlocks + clearBlocks == 0)
+	const int jointBlocks = joints && wireJoints && joints->count > 0 ? (joints->count + S2_BLOCK - 1) / S2_BLOCK : 0;
+	const JointView jv = joints ? *joints : JointView{};
+	if (contactBlocks + bodyBlocks + jointBlocks + clearBlocks == 0)
 	{
 		return;
 	}
-	dim3 g((unsigned)(contactBlocks + bodyBlocks + clearBlocks)), t(S2_BLOCK);
+	dim3 g((unsigned)(contactBlocks + bodyBlocks + jointBlocks + clearBlocks)), t(S2_BLOCK);
 	switch (kind)
 	{
 		case STORE_SCALED:
-			storeImpulsesKernel<STORE_SCALED><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount, stepFailed, finalizeMode);
+			storeImpulsesKernel<STORE_SCALED><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount, stepFailed, finalizeMode, jv, wireJoints, jointBlocks);
 			break;
 		case STORE_BLOCK:
-			storeImpulsesKernel<STORE_BLOCK><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount, stepFailed, finalizeMode);
+			storeImpulsesKernel<STORE_BLOCK><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount, stepFailed, finalizeMode, jv, wireJoints, jointBlocks);
 			break;
 		default:
-			storeImpulsesKernel<STORE_PLAIN><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount, stepFailed, finalizeMode);
+			storeImpulsesKernel<STORE_PLAIN><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount, stepFailed, finalizeMode, jv, wireJoints, jointBlocks);
 			break;
 	}
 }

@@ -89,7 +89,8 @@ void launchXpbdContactVelocities(hipStream_t s, const ContactView& c, const Body
 void launchBlockSolveVelocity(hipStream_t s, const ContactView& c, const BodyView& b, int begin, int end);
 void launchBlockSolvePosition(hipStream_t s, const ContactView& c, const BodyView& b, int begin, int end);
 void launchStoreImpulses(hipStream_t s, int kind, const ContactView& c, s2amdContact* wire, float scale, const BodyView& bodies, s2amdBody* wireBodies,
-						 void* clear, size_t clearBytes, const unsigned int* stepFailed, int finalizeMode = -1);
+						 void* clear, size_t clearBytes, const unsigned int* stepFailed, int finalizeMode = -1, const JointView* joints = nullptr,
+						 s2amdJoint* wireJoints = nullptr); // (with joints: their impulses go back to the wire in the same launch)
 
 // bodies
 void launchUnpackBodies(hipStream_t s, const BodyView& b, const s2amdBody* wire, const uint32_t* hostFlags, const StepConsts& sc, float h,

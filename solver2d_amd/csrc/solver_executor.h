@@ -746,12 +746,7 @@ struct Executor
 		int kind, warm;
 		const bool usedGranules = s->dStripA.view.groupCount > 0 && persistPlan(kind, warm);
 		launchStoreImpulses(st, p.storeKind, cvIo, wireContacts(), p.storeScale, s->bv, wireBodies(), usedGranules ? s->dGranules.p : nullptr,
-							usedGranules ? s->granuleBytes : 0, usedGranules ? s->persist.deviceError : nullptr, fusedFinalize);
+							usedGranules ? s->granuleBytes : 0, usedGranules ? s->persist.deviceError : nullptr, fusedFinalize, &s->jv, wireJoints());
 		count();
-		if (s->jv.count > 0)
-		{
-			launchStoreJoints(st, s->jv, wireJoints(), usedGranules ? s->persist.deviceError : nullptr);
-			count();
-		}
 	}
 };

@@ -420,6 +420,10 @@ typedef struct WorldBinding
 	s2amdPairState* slotPairs;
 	int32_t* newPairs;
 	int newPairCapacity;
+	int liveCount;	  // slots with liveKey >= 0
+	int createdCount; // >= 0: this step's stage 1 ran here (device pairs) and created exactly the contacts in createdSlots
+	int32_t* createdSlots;
+	int createdCapacity;
 } WorldBinding;
 static WorldBinding s_bindings[s2_maxWorlds];
 static long s_uploads = 0, s_steps = 0;
@@ -574,7 +578,8 @@ void s2amdBinding_DestroyWorld(s2World* world)
 		s_api.destroy(b->solver);
 	}
 	void* owned[] = {b->solveBodies, b->solveContacts, b->solveJoints, b->bodies,		b->contacts,	 b->joints,	   b->shapes,	b->pairs,
-					 b->origins,	 b->separated,	   b->liveKey,	   b->slots,		b->slotContacts, b->slotPairs, b->newPairs};
+					 b->origins,	 b->separated,	   b->liveKey,	   b->slots,		b->slotContacts, b->slotPairs, b->newPairs,
+					 b->createdSlots};
 	for (size_t i = 0; i < sizeof(owned) / sizeof(owned[0]); ++i)
 	{
 		free(owned[i]);
@@ -691,9 +696,12 @@ static int uploadWorld(s2World* w, WorldBinding* b)
 		b->origins[2 * i] = w->bodies[i].origin.x;
 		b->origins[2 * i + 1] = w->bodies[i].origin.y;
 	}
+	b->liveCount = 0;
+	b->createdCount = -1;
 	for (int i = 0; i < nc; ++i)
 	{
 		b->liveKey[i] = b->pairs[i].shapeA < 0 ? -1 : ((int64_t)b->pairs[i].shapeA << 32) | (int64_t)b->pairs[i].shapeB;
+		b->liveCount += b->liveKey[i] >= 0 ? 1 : 0;
 	}
 	rc = s_api.worldUpload(b->solver, b->bodies, nb, b->contacts, nc, b->joints, nj, b->shapes, ns, b->pairs, b->origins);
 	if (rc != 0)
@@ -713,25 +721,50 @@ static int uploadWorld(s2World* w, WorldBinding* b)
 
 // contacts stage 1 created since the device last saw the pool (the pool never frees a slot on its own between steps:
 // stage 3's separations are applied to both sides below)
+static void describeNewContact(const s2Contact* c, s2amdContact* o, s2amdPairState* ps)
+{
+	memset(o, 0, sizeof(*o));
+	memset(ps, 0, sizeof(*ps));
+	o->bodyA = c->edges[0].bodyIndex;
+	o->bodyB = c->edges[1].bodyIndex;
+	o->friction = c->friction;
+	o->constraintIndex = -1;
+	ps->shapeA = c->shapeIndexA;
+	ps->shapeB = c->shapeIndexB;
+}
+
 static int sendNewContacts(s2World* w, WorldBinding* b)
 {
 	int count = 0;
+	// When stage 1 ran HERE (device pairs) the binding made every s2CreateContact call of the step itself and knows the slots;
+	// the pool's live count says whether anything else touched the pool since: no scan of the pool then.
+	if (b->createdCount >= 0 && w->contactPool.count == b->liveCount + b->createdCount)
+	{
+		for (int n = 0; n < b->createdCount; ++n)
+		{
+			const int i = b->createdSlots[n];
+			const s2Contact* c = w->contacts + i;
+			if (i < 0 || i >= b->contactCapacity || s2IsFree(&c->object) || b->liveKey[i] >= 0)
+			{
+				return 1;
+			}
+			describeNewContact(c, b->slotContacts + count, b->slotPairs + count);
+			b->slots[count++] = i;
+			b->liveKey[i] = ((int64_t)c->shapeIndexA << 32) | (int64_t)c->shapeIndexB;
+		}
+		b->liveCount += count;
+		b->createdCount = -1;
+		// (s2amd_world_set_contacts wants ascending slots no more than the scan below delivers them: it sorts)
+		return count > 0 ? s_api.worldSetContacts(b->solver, b->slots, count, b->slotContacts, b->slotPairs) : 0;
+	}
+	b->createdCount = -1;
 	for (int i = 0; i < b->contactCapacity; ++i)
 	{
 		const s2Contact* c = w->contacts + i;
 		int64_t live = s2IsFree(&c->object) ? -1 : ((int64_t)c->shapeIndexA << 32) | (int64_t)c->shapeIndexB;
 		if (live >= 0 && b->liveKey[i] < 0)
 		{
-			s2amdContact* o = b->slotContacts + count;
-			s2amdPairState* ps = b->slotPairs + count;
-			memset(o, 0, sizeof(*o));
-			memset(ps, 0, sizeof(*ps));
-			o->bodyA = c->edges[0].bodyIndex;
-			o->bodyB = c->edges[1].bodyIndex;
-			o->friction = c->friction;
-			o->constraintIndex = -1;
-			ps->shapeA = c->shapeIndexA;
-			ps->shapeB = c->shapeIndexB;
+			describeNewContact(c, b->slotContacts + count, b->slotPairs + count);
 			b->slots[count++] = i;
 			b->liveKey[i] = live;
 		}
@@ -740,6 +773,7 @@ static int sendNewContacts(s2World* w, WorldBinding* b)
 			return 1; // somebody destroyed a contact behind our back (s2DestroyBody, s2CreateJoint ...): upload again
 		}
 	}
+	b->liveCount += count;
 	return count > 0 ? s_api.worldSetContacts(b->solver, b->slots, count, b->slotContacts, b->slotPairs) : 0;
 }
 
@@ -892,6 +926,7 @@ void s2amdBinding_WorldStep(s2World* world, float timeStep, int velIters, int po
 		// called in the order the reference's own stage 1 would have found the pairs in (s2amdBinding_OrderPairs), so every
 		// contact lands in the pool slot the host route gives it.  The trees keep following the fat boxes (below).
 		s2BroadPhase* bp = &world->broadPhase;
+		b->createdCount = 0; // stage 1 runs here: every contact it creates is recorded below
 		if (s2Array(bp->moveArray).count > 0)
 		{
 			int32_t count = 0;
@@ -906,9 +941,22 @@ void s2amdBinding_WorldStep(s2World* world, float timeStep, int velIters, int po
 			{
 				s2amdBinding_OrderPairs(world, bp->moveArray, s2Array(bp->moveArray).count, b->newPairs, count);
 			}
+			if (b->createdCapacity < count)
+			{
+				b->createdCapacity = count + 1024;
+				b->createdSlots = (int32_t*)realloc(b->createdSlots, (size_t)b->createdCapacity * sizeof(int32_t));
+			}
+			b->createdCount = 0;
 			for (int i = 0; rc == 0 && i < count; ++i)
 			{
+				const s2Shape* shapeA = world->shapes + b->newPairs[2 * i];
+				const int before = world->contactPool.count;
 				s2CreateContact(world, world->shapes + b->newPairs[2 * i], world->shapes + b->newPairs[2 * i + 1]);
+				if (world->contactPool.count == before + 1)
+				{
+					// the new contact heads the contact list of both its bodies (src/contact.c:189-221), flipped or not
+					b->createdSlots[b->createdCount++] = world->bodies[shapeA->bodyIndex].contactList >> 1;
+				}
 			}
 			s2Array_Clear(bp->moveArray);
 			s2ClearSet(&bp->moveSet);
@@ -918,6 +966,7 @@ void s2amdBinding_WorldStep(s2World* world, float timeStep, int velIters, int po
 	else
 	{
 		// stages 1 and 2 (src/world.c:125-130): the reference's trees, the reference's contact pool
+		b->createdCount = -1; // (which contacts it creates is found by scanning the pool)
 		updatePairs(world);
 		rebuildTrees(&world->broadPhase);
 	}
@@ -974,6 +1023,7 @@ void s2amdBinding_WorldStep(s2World* world, float timeStep, int velIters, int po
 	{
 		const int slot = b->separated[i];
 		s2DestroyContact(world, world->contacts + slot);
+		b->liveCount -= b->liveKey[slot] >= 0 ? 1 : 0;
 		b->liveKey[slot] = -1;
 	}
 	if (info.movedCount > 0)

@@ -323,6 +323,17 @@ int s2amd_world_find_pairs(s2amdSolver* solver, int32_t* outPairs, int32_t pairC
 /* The contact slots whose pairs the last s2amd_world_step found separated (fat AABBs apart) and destroyed on the device, in
  * ascending order: the slots the caller's own pool frees (s2DestroyContact, src/world.c:163-167).  info.separatedCount of them. */
 int s2amd_world_separated(s2amdSolver* solver, int32_t* slots, int32_t capacity, int32_t* count);
+/* What stage 4 (src/world.c:259-297) changed in a shape, without the rest of the 196-byte record: the tight box of every live
+ * shape, its fat box, and whether the refit re-inflated it (== the shapes s2BroadPhase_EnlargeProxy is called for). */
+typedef struct s2amdShapeBox
+{
+	float aabb[4];
+	float fatAABB[4];
+	int32_t enlarged;
+} s2amdShapeBox;
+/* boxes[shapeCapacity of the upload]: the boxes of the resident shapes after the last s2amd_world_step (36 bytes per shape
+ * instead of s2amd_world_download's whole shape records). */
+int s2amd_world_download_boxes(s2amdSolver* solver, s2amdShapeBox* boxes, int32_t shapeCapacity);
 /* Writes `count` contact slots of the resident world (slot indices < contactCapacity of the upload): the caller's
  * s2CreateContact (src/contact.c:137-203: pool slot, pair flip, mixed friction, empty manifold) or s2DestroyContact
  * (pairs[i].shapeA = -1, contacts[i].pointCount = 0).  A world that needs more slots, bodies or shapes is uploaded again. */

@@ -391,6 +391,7 @@ typedef struct AmdApi
 						 int32_t*);
 	int (*worldFindPairs)(s2amdSolver*, int32_t*, int32_t, int32_t*);
 	int (*worldSeparated)(s2amdSolver*, int32_t*, int32_t, int32_t*);
+	int (*worldDownloadBoxes)(s2amdSolver*, s2amdShapeBox*, int32_t);
 } AmdApi;
 static AmdApi s_api = {0};
 
@@ -420,6 +421,7 @@ typedef struct WorldBinding
 	s2amdPairState* slotPairs;
 	int32_t* newPairs;
 	int newPairCapacity;
+	s2amdShapeBox* boxes; // the shapes' boxes after the last step (stage 4's output)
 	int liveCount;	  // slots with liveKey >= 0
 	int createdCount; // >= 0: this step's stage 1 ran here (device pairs) and created exactly the contacts in createdSlots
 	int32_t* createdSlots;
@@ -468,6 +470,7 @@ int s2amdBinding_Open(const char* libraryPath, int device)
 		S2_BIND(worldDownload, "s2amd_world_download")
 		S2_BIND(worldFindPairs, "s2amd_world_find_pairs")
 		S2_BIND(worldSeparated, "s2amd_world_separated")
+		S2_BIND(worldDownloadBoxes, "s2amd_world_download_boxes")
 #undef S2_BIND
 	}
 	s_api.device = device;
@@ -579,7 +582,7 @@ void s2amdBinding_DestroyWorld(s2World* world)
 	}
 	void* owned[] = {b->solveBodies, b->solveContacts, b->solveJoints, b->bodies,		b->contacts,	 b->joints,	   b->shapes,	b->pairs,
 					 b->origins,	 b->separated,	   b->liveKey,	   b->slots,		b->slotContacts, b->slotPairs, b->newPairs,
-					 b->createdSlots};
+					 b->createdSlots,	 b->boxes};
 	for (size_t i = 0; i < sizeof(owned) / sizeof(owned[0]); ++i)
 	{
 		free(owned[i]);
@@ -678,6 +681,7 @@ static int uploadWorld(s2World* w, WorldBinding* b)
 	b->bodies = (s2amdBody*)growTo(b->bodies, (size_t)nb, sizeof(s2amdBody));
 	b->origins = (float*)growTo(b->origins, (size_t)nb * 2, sizeof(float));
 	b->shapes = (s2amdShape*)growTo(b->shapes, (size_t)ns, sizeof(s2amdShape));
+	b->boxes = (s2amdShapeBox*)growTo(b->boxes, (size_t)ns, sizeof(s2amdShapeBox));
 	b->joints = (s2amdJoint*)growTo(b->joints, (size_t)nj, sizeof(s2amdJoint));
 	b->contacts = (s2amdContact*)growTo(b->contacts, (size_t)nc, sizeof(s2amdContact));
 	b->pairs = (s2amdPairState*)growTo(b->pairs, (size_t)nc, sizeof(s2amdPairState));
@@ -988,8 +992,12 @@ void s2amdBinding_WorldStep(s2World* world, float timeStep, int velIters, int po
 	int32_t separatedCount = 0;
 	if (rc == 0)
 	{
-		rc = s_api.worldDownload(b->solver, b->bodies, b->bodyCapacity, NULL, b->contactCapacity, NULL, b->jointCapacity,
-								 info.movedCount > 0 ? b->shapes : NULL, b->shapeCapacity, NULL, b->origins, NULL);
+		rc = s_api.worldDownload(b->solver, b->bodies, b->bodyCapacity, NULL, b->contactCapacity, NULL, b->jointCapacity, NULL, b->shapeCapacity, NULL,
+								 b->origins, NULL);
+	}
+	if (rc == 0 && info.movedCount > 0)
+	{
+		rc = s_api.worldDownloadBoxes(b->solver, b->boxes, b->shapeCapacity); // 36 bytes per shape instead of the 196-byte records
 	}
 	if (rc == 0 && info.separatedCount > 0)
 	{
@@ -1041,7 +1049,7 @@ void s2amdBinding_WorldStep(s2World* world, float timeStep, int velIters, int po
 			for (int i = body->shapeList; i != S2_NULL_INDEX; i = world->shapes[i].nextShapeIndex)
 			{
 				s2Shape* sh = world->shapes + i;
-				const s2amdShape* o = b->shapes + i;
+				const s2amdShapeBox* o = b->boxes + i;
 				sh->aabb = (s2Box){{o->aabb[0], o->aabb[1]}, {o->aabb[2], o->aabb[3]}};
 				if (o->enlarged)
 				{

@@ -251,6 +251,7 @@ struct s2amdSolver
 	DevBuf dSeparated;		// world chain: the pair slots stage 3 freed this step
 	DevBuf dJointAdjRange, dJointAdjList; // body -> incident global joints in sweep order (body-centric joint warm start)
 	bool jointAdjValid = false;
+	DevBuf dShapeBoxes;		// world chain: s2amd_world_download_boxes' staging
 	DevBuf dSlotBytes;		// world chain: one byte per pair slot for a structure build (world.hip: slotBytesKernel)
 	std::vector<uint8_t> hSlotBytes;
 	bool slotBytesFresh = false; // hSlotBytes is of the state the device is in right now (cleared by every world call that changes it)

@@ -77,6 +77,23 @@ __global__ __launch_bounds__(S2_BLOCK) void slotBytesKernel(const s2amdPairState
 	}
 }
 
+// the boxes of every shape slot, packed for the host (s2amd_world_download_boxes)
+__global__ __launch_bounds__(S2_BLOCK) void shapeBoxesKernel(const s2amdShape* shapes, int n, s2amdShapeBox* out)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n)
+	{
+		s2amdShapeBox b;
+		for (int k = 0; k < 4; ++k)
+		{
+			b.aabb[k] = shapes[i].aabb[k];
+			b.fatAABB[k] = shapes[i].fatAABB[k];
+		}
+		b.enlarged = shapes[i].enlarged;
+		out[i] = b;
+	}
+}
+
 // manifold.constraintIndex from the resident point counts: exclusive scan of "has points" over the pool (the reference's
 // gather order, e.g. src/solve_tgs_soft.c:162-179), -1 for the slots the gather skips
 struct HasPoints
@@ -509,6 +526,38 @@ int s2amd_world_find_pairs(s2amdSolver* s, int32_t* outPairs, int32_t pairCapaci
 		HIP_TRY(hipGetLastError());
 	}
 	return rc;
+}
+
+int s2amd_world_download_boxes(s2amdSolver* s, s2amdShapeBox* boxes, int32_t shapeCapacity)
+{
+	if (!s || !boxes || shapeCapacity < 0)
+	{
+		return fail(S2AMD_E_INVALID, "bad argument");
+	}
+	if (!s->worldResident || !s->resident)
+	{
+		return fail(S2AMD_E_STATE, "no resident world");
+	}
+	if (shapeCapacity < s->shapeCapacity)
+	{
+		return fail(S2AMD_E_CAPACITY, "box array smaller than the resident shape array");
+	}
+	if (s->shapeCapacity == 0)
+	{
+		return S2AMD_OK;
+	}
+	HIP_TRY(hipSetDevice(s->device));
+	int rc = s->dShapeBoxes.ensure((size_t)s->shapeCapacity * sizeof(s2amdShapeBox));
+	if (rc)
+	{
+		return rc;
+	}
+	shapeBoxesKernel<<<gridFor((size_t)s->shapeCapacity), dim3(S2_BLOCK), 0, s->stream>>>((const s2amdShape*)s->dShapes.p, s->shapeCapacity,
+																						  (s2amdShapeBox*)s->dShapeBoxes.p);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(boxes, s->dShapeBoxes.p, (size_t)s->shapeCapacity * sizeof(s2amdShapeBox), hipMemcpyDeviceToHost, s->stream));
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	return S2AMD_OK;
 }
 
 int s2amd_world_separated(s2amdSolver* s, int32_t* slots, int32_t capacity, int32_t* count)

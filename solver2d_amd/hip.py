@@ -21,7 +21,7 @@ EXPORTS = [
     "s2amd_restore_bodies", "s2amd_get_contact_order", "s2amd_get_joint_order", "s2amd_get_stats",
     "s2amd_set_option", "s2amd_export_poses", "s2amd_export_poses_async", "s2amd_export_wait", "s2amd_measure_dominant", "s2amd_refit_shapes", "s2amd_find_pairs", "s2amd_synchronize", "s2amd_update_contacts", "s2amd_find_islands", "s2amd_color_constraints",
     "s2amd_world_upload", "s2amd_world_step", "s2amd_world_download", "s2amd_world_find_pairs", "s2amd_world_set_contacts",
-    "s2amd_device_alloc", "s2amd_device_free", "s2amd_device_read", "s2amd_world_separated",
+    "s2amd_device_alloc", "s2amd_device_free", "s2amd_device_read", "s2amd_world_separated", "s2amd_world_download_boxes",
 ]
 
 _lib = None
@@ -71,6 +71,7 @@ def load():
     L.s2amd_world_find_pairs.argtypes = [vp, vp, i32, ctypes.POINTER(i32)]
     L.s2amd_world_set_contacts.argtypes = [vp, vp, i32, vp, vp]
     L.s2amd_world_separated.argtypes = [vp, vp, i32, ctypes.POINTER(i32)]
+    L.s2amd_world_download_boxes.argtypes = [vp, vp, i32]
     L.s2amd_world_download.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp]
     L.s2amd_device_alloc.argtypes = [vp, ctypes.c_uint64, ctypes.POINTER(vp)]
     L.s2amd_device_free.argtypes = [vp, vp]
@@ -227,6 +228,12 @@ class Solver:
                 continue
             _check(rc)
             return out[: n.value].copy()
+
+    def world_download_boxes(self, shape_capacity):
+        """s2amdShapeBox of every resident shape slot after the last world_step."""
+        out = np.zeros(int(shape_capacity), dtype=wire.shape_box_dtype)
+        _check(load().s2amd_world_download_boxes(self._h, wire.as_ptr(out), len(out)))
+        return out
 
     def world_separated(self, expected=64):
         """Contact slots the last world_step destroyed (their pairs separated), ascending."""

@@ -139,3 +139,8 @@ def as_ptr(arr, ctype=ctypes.c_void_p):
         return ctypes.c_void_p(0)
     assert arr.flags["C_CONTIGUOUS"]
     return ctypes.c_void_p(arr.ctypes.data)
+
+
+# s2amdShapeBox (include/solver2d_amd.h): what stage 4 changed in a shape
+shape_box_dtype = np.dtype([("aabb", np.float32, 4), ("fatAABB", np.float32, 4), ("enlarged", np.int32)])
+assert shape_box_dtype.itemsize == 36

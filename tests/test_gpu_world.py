@@ -504,3 +504,21 @@ def test_rain_world_loop_through_the_strip_paths(seed, solver_name):
                 world_chain.assert_device_equals_oracle(dict(zip(world_chain.WORLD_KEYS, res[:6])), ref,
                                                         "rain-strips %d %s step %d" % (seed, solver_name, step))
     assert persistent > 20, persistent  # (of 120 steps: the pile has to form first, and every created contact rebuilds the structure)
+
+
+def test_world_download_boxes_equals_the_shape_records():
+    """s2amd_world_download_boxes: the 36-byte {aabb, fatAABB, enlarged} of every shape slot == the same fields of the full
+    shape records s2amd_world_download returns (what the reference-side binding reads after every step)."""
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    world = world_chain.rain_world(3, 120)
+    with hip.Solver(0) as s:
+        s.world_upload(*[world[k] for k in world_chain.WORLD_KEYS])
+        for _ in range(5):
+            s.world_step(params)
+        out = world_chain.copy_world(world)
+        res = s.world_download(*[out[k] for k in world_chain.WORLD_KEYS])
+        shapes = res[3]
+        boxes = s.world_download_boxes(len(shapes))
+    assert np.array_equal(boxes["aabb"].view(np.uint32), np.ascontiguousarray(shapes["aabb"]).view(np.uint32))
+    assert np.array_equal(boxes["fatAABB"].view(np.uint32), np.ascontiguousarray(shapes["fatAABB"]).view(np.uint32))
+    assert np.array_equal(boxes["enlarged"] != 0, shapes["enlarged"] != 0) and (boxes["enlarged"] != 0).any()

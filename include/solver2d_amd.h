@@ -398,8 +398,11 @@ int s2amd_measure_dominant(s2amdSolver* solver, const s2amdStepParams* params, i
  * bodies per strip, default 160), "strip_retry" (0/1 rebuild the partition with other strip widths when one strip needs the 8-round kernel variant), "strip_min_bodies" (loose bodies below which the colour-batch path is kept), "strip_patience" (steps the constraint graph must
  * stay unchanged before the strip structure is built: its host build costs ~3 ms at 60k constraints, the colour-batch one ~1 ms), "async" (0/1, see s2amd_synchronize), "strip_lean" (0/1 dedicated strip
  * kernel for the soft sweeps), "persist" (0/1 whole step of the strips in one persistent launch), "body_warm", "incremental" (0/1 created
- * contacts are placed into the existing structure when they fit; 0 = every created contact rebuilds it), "island_resident" (0/1 small
- * islands under the soft contact solvers keep their constraints in registers for the whole step: one read of every record per step) */
+ * contacts are placed into the existing structure when they fit; 0 = every created contact rebuilds it), "defer" (0/1 a created
+ * contact that cannot be placed and has no manifold points yet is only watched until it gets its first points; 0 = it rebuilds the
+ * structure when it is created), "island_resident" (0/1 small islands under the soft contact solvers keep their constraints in
+ * registers for the whole step: one read of every record per step).  None of them changes a result beyond the sweep order the
+ * library reports. */
 int s2amd_set_option(s2amdSolver* solver, const char* key, int32_t value);
 
 #ifdef __cplusplus

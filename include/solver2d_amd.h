@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define S2AMD_API_VERSION 1
+#define S2AMD_API_VERSION 2
 
 /* error codes */
 #define S2AMD_OK 0
@@ -165,6 +165,7 @@ typedef struct s2amdStepStats
 	int32_t structureBuilds;   /* full builds of the constraint-graph structure (islands, colours, tables) since s2amd_create */
 	int32_t placedContacts;    /* created contacts that were given a place in the existing structure instead (no build) */
 	int32_t potentialConstraints; /* contact slots the structure holds: constraintCount + manifolds without points + destroyed contacts not yet dropped */
+	int32_t pairLanes;         /* (API 2) which persistent kernel ran: 2 = 512 threads per strip (wide_kernel.hip), 1 = two lanes per constraint (pair_kernel.hip), 0 = strip_kernel.hip */
 } s2amdStepStats;
 
 typedef struct s2amdSolver s2amdSolver;
@@ -397,7 +398,8 @@ int s2amd_measure_dominant(s2amdSolver* solver, const s2amdStepParams* params, i
  * "strips" (0/1 cut islands that fit no LDS group into strips of BFS levels: two launches per sweep), "strip_bodies" (target
  * bodies per strip, default 160), "strip_retry" (0/1 rebuild the partition with other strip widths when one strip needs the 8-round kernel variant), "strip_min_bodies" (loose bodies below which the colour-batch path is kept), "strip_patience" (steps the constraint graph must
  * stay unchanged before the strip structure is built: its host build costs ~3 ms at 60k constraints, the colour-batch one ~1 ms), "async" (0/1, see s2amd_synchronize), "strip_lean" (0/1 dedicated strip
- * kernel for the soft sweeps), "persist" (0/1 whole step of the strips in one persistent launch), "body_warm", "incremental" (0/1 created
+ * kernel for the soft sweeps), "persist" (0/1 whole step of the strips in one persistent launch), "wide" (0/1 TGS_Soft's persistent launch runs 512 threads per strip: wide_kernel.hip),
+ * "pair_lanes" (0/1 that launch solves a constraint with two lanes, one per body: pair_kernel.hip; measured no faster, off by default), "body_warm", "incremental" (0/1 created
  * contacts are placed into the existing structure when they fit; 0 = every created contact rebuilds it), "defer" (0/1 a created
  * contact that cannot be placed and has no manifold points yet is only watched until it gets its first points; 0 = it rebuilds the
  * structure when it is created), "island_resident" (0/1 small islands under the soft contact solvers keep their constraints in

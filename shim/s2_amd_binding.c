@@ -460,6 +460,15 @@ int s2amdBinding_Open(const char* libraryPath, int device)
 	{                                                                                                                            \
 		return -2;                                                                                                               \
 	}
+		// the stats / wire structs are compiled into this file: refuse a library built from another header
+		int (*apiVersion)(void) = NULL;
+		*(void**)(&apiVersion) = dlsym(s_api.lib, "s2amd_api_version");
+		if (apiVersion == NULL || apiVersion() != S2AMD_API_VERSION)
+		{
+			dlclose(s_api.lib);
+			s_api.lib = NULL;
+			return -4;
+		}
 		S2_BIND(create, "s2amd_create")
 		S2_BIND(destroy, "s2amd_destroy")
 		S2_BIND(lastError, "s2amd_last_error")

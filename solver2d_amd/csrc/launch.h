@@ -145,6 +145,15 @@ void launchStripSoft(hipStream_t s, int kind, int warm, const ContactView& c, co
 void launchStripStep(hipStream_t s, int kind, int warm, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv,
 					 const Op* ops, int opCount);
 
+// pair_kernel.hip: the persistent strip step with two lanes per constraint (pv.pairLanes)
+int pairKernelSetup();
+void launchPairStep(hipStream_t s, int kind, int warm, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops,
+					int opCount);
+
+// wide_kernel.hip: TGS_Soft's persistent strip step on 512 threads per strip
+int wideKernelSetup();
+void launchWideStep(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount);
+
 // stage kernels on resident arrays (narrowphase.hip, broadphase.hip; called by world.hip)
 // summary: int[5] {separated pairs, active manifolds, zero/non-zero flips, point-count moves, enlarged shapes} (world.hip: WorldSummary)
 void launchUpdateContacts(hipStream_t st, const s2amdBody* bodies, const float* origins, const s2amdShape* shapes, s2amdPairState* pairs,

@@ -80,6 +80,14 @@ int s2amd_create(int device, s2amdSolver** out)
 	HIP_TRY(hipSetDevice(device));
 	s2amdSolver* s = new s2amdSolver();
 	s->device = device;
+	if (const char* v = getenv("S2AMD_PAIR_LANES")) // experiments: the defaults of options "pair_lanes" and "wide"
+	{
+		s->optPairLanes = atoi(v) != 0;
+	}
+	if (const char* v = getenv("S2AMD_WIDE"))
+	{
+		s->optWide = atoi(v) != 0;
+	}
 	hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
 	if (e == hipSuccess)
 	{
@@ -117,7 +125,7 @@ int s2amd_create(int device, s2amdSolver** out)
 		s->hostError = nullptr;
 		(void)hipGetLastError();
 	}
-	if (groupKernelSetup() != 0 || stripKernelSetup() != 0)
+	if (groupKernelSetup() != 0 || stripKernelSetup() != 0 || pairKernelSetup() != 0 || wideKernelSetup() != 0)
 	{
 		(void)hipGetLastError(); // not fatal: groups are then limited to the default 64 KiB of LDS
 		s->optMaxGroupBodies = 1536;
@@ -165,6 +173,26 @@ void s2amd_destroy(s2amdSolver* s)
 	if (s->hostTimes)
 	{
 		int n = (int)s->hostTimes[255];
+		if (s->hostTimes[254] == 1ull && n > 1)
+		{
+			// pair_kernel.hip's tagged stamps: time per phase of the last step, one workgroup
+			static const char* names[8] = {"start", "load", "body stages", "warm starts", "interior rounds", "hand-offs", "seam rounds", "store"};
+			double sum[8] = {0};
+			int count[8] = {0};
+			for (int i = 1; i < n && i < 250; ++i)
+			{
+				const unsigned tag = (unsigned)(s->hostTimes[i] & 15ull) & 7u;
+				sum[tag] += 0.01 * (double)((s->hostTimes[i] >> 4) - (s->hostTimes[i - 1] >> 4));
+				count[tag] += 1;
+			}
+			fprintf(stderr, "[s2amd] pair-lane persistent step, one workgroup, us per phase (count):");
+			for (int t = 1; t < 8; ++t)
+			{
+				fprintf(stderr, " %s %.1f (%d);", names[t], sum[t], count[t]);
+			}
+			fprintf(stderr, " total %.1f\n", 0.01 * (double)((s->hostTimes[n - 1] >> 4) - (s->hostTimes[0] >> 4)));
+			n = 0;
+		}
 		fprintf(stderr, "[s2amd] persistent step, one workgroup, wall_clock64 ticks (10 ns) since kernel start:");
 		for (int i = 1; i < n && i < 255; ++i)
 		{
@@ -708,6 +736,16 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	{
 		s->optSeamRegs = value != 0;
 		s->structureDirty = true;
+	}
+	else if (strcmp(key, "wide") == 0)
+	{
+		s->optWide = value != 0;
+		s->structureDirty = true; // (re-captures the step graph)
+	}
+	else if (strcmp(key, "pair_lanes") == 0)
+	{
+		s->optPairLanes = value != 0;
+		s->structureDirty = true; // (re-captures the step graph)
 	}
 	else if (strcmp(key, "strip_retry") == 0)
 	{

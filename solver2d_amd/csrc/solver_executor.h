@@ -372,6 +372,14 @@ struct Executor
 		return records <= (160 * 1024) / 16;
 	}
 
+	// ... and of the persistent kernels, the 512-thread one (wide_kernel.hip: wideStepKernel)?  TGS_Soft with the current-anchor
+	// warm start on a partition with at most six interior colour batches per strip and two per seam.
+	bool widePlan(int kind, int warm) const
+	{
+		return s->optWide && s->persist.pairLanes && kind == SOFT_TGS && warm == WARM_CURRENT &&
+			   s->persist.ldsRecords + 2 + 2 * s->persistOpCount <= (160 * 1024) / 16;
+	}
+
 	// Can the plan run on the resident-island kernel (strip_kernel.hip: islandStepKernel)?  The soft contact drivers: body
 	// stages, a current- or fixed-anchor warm start, one soft sweep kind; joint sweeps have nothing to do there (the groups
 	// it takes are contact-only).
@@ -535,7 +543,18 @@ struct Executor
 		{
 			pv.ldsRecords = s->persistRecordsWide;
 		}
-		launchStripStep(st, kind, warm, s->cv, s->bv, s->leanA, pv, (const Op*)s->dPersistOps.p, s->persistOpCount);
+		if (widePlan(kind, warm))
+		{
+			launchWideStep(st, s->cv, s->bv, s->leanA, pv, (const Op*)s->dPersistOps.p, s->persistOpCount);
+		}
+		else if (pv.pairLanes && s->optPairLanes)
+		{
+			launchPairStep(st, kind, warm, s->cv, s->bv, s->leanA, pv, (const Op*)s->dPersistOps.p, s->persistOpCount);
+		}
+		else
+		{
+			launchStripStep(st, kind, warm, s->cv, s->bv, s->leanA, pv, (const Op*)s->dPersistOps.p, s->persistOpCount);
+		}
 		if (profile)
 		{
 			recordEvent();

@@ -412,10 +412,25 @@ void unwatchSlot(s2amdSolver* s, int slot)
 
 int uploadWatched(s2amdSolver* s)
 {
-	if (!s->watchedDirty || !s->worldResident || s->structureDirty || s->contactCapacity <= 0 || (int)s->hContactWatched.size() != s->contactCapacity ||
-		s->dWatched.bytes < (size_t)s->contactCapacity)
+	if (!s->worldResident || s->structureDirty || s->contactCapacity <= 0 || (int)s->hContactWatched.size() != s->contactCapacity)
 	{
 		return S2AMD_OK; // (a rebuild writes the whole array)
+	}
+	// a structure that was built through s2amd_upload / s2amd_solve (worldResident false at the time) has watched slots on the
+	// host only: the array is made when the world chain first needs it
+	const bool missing = s->watchedCount > 0 && s->dWatched.bytes < (size_t)s->contactCapacity;
+	if (!s->watchedDirty && !missing)
+	{
+		return S2AMD_OK;
+	}
+	if (s->dWatched.bytes < (size_t)s->contactCapacity)
+	{
+		bool grew = false;
+		int rc = s->dWatched.ensure(std::max<size_t>((size_t)s->contactCapacity, 256), &grew);
+		if (rc)
+		{
+			return rc;
+		}
 	}
 	HIP_TRY(hipMemcpyAsync(s->dWatched.p, s->hContactWatched.data(), (size_t)s->contactCapacity, hipMemcpyHostToDevice, s->stream));
 	HIP_TRY(hipStreamSynchronize(s->stream)); // the bytes are a std::vector the next call may touch

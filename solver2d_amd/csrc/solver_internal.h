@@ -305,6 +305,8 @@ struct s2amdSolver
 	size_t granuleBytes = 0;
 	int optPersist = 1;
 	int optSeamRegs = 1;
+	int optWide = 1;	  // TGS_Soft's persistent step on 512 threads per strip (wide_kernel.hip) where the partition fits
+	int optPairLanes = 0; // two lanes per constraint (pair_kernel.hip; measured no faster: kept as an option); 0: one lane per constraint
 	int optStripRetry = 1; // try other strip widths when the partition needs the 8-round kernel variant
 	bool stripRetryPending = false; // ... postponed until the graph has been quiet for 32 steps
 	int optPersistDebug = 0;

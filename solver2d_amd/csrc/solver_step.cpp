@@ -470,7 +470,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	{
 		uint64_t key = 1469598103934665603ull;
 		key = fnv(key, params, sizeof(*params));
-		uint64_t gens[4] = {s->layoutGeneration, s->structureGeneration, s->planGeneration, (uint64_t)((q.msg ? 1 : 0) | (s->optBodyWarm ? 2 : 0) | (s->optStripLean ? 4 : 0) | (s->optPersist ? 8 : 0) | (s->optFork ? 16 : 0) | (s->persistFailed ? 32 : 0) | ((s->persistValid && s->persist.allTwoPoints) ? 64 : 0) | (s->pointsKnown ? 128 : 0))};
+		uint64_t gens[4] = {s->layoutGeneration, s->structureGeneration, s->planGeneration, (uint64_t)((q.msg ? 1 : 0) | (s->optBodyWarm ? 2 : 0) | (s->optStripLean ? 4 : 0) | (s->optPersist ? 8 : 0) | (s->optFork ? 16 : 0) | (s->persistFailed ? 32 : 0) | ((s->persistValid && s->persist.allTwoPoints) ? 64 : 0) | (s->pointsKnown ? 128 : 0) | (s->optPairLanes ? 256 : 0) | (s->optWide ? 512 : 0))};
 		key = fnv(key, gens, sizeof(gens));
 		int sizes[3] = {s->bodyCapacity, s->contactCapacity, s->jointCapacity};
 		key = fnv(key, sizes, sizeof(sizes));
@@ -542,6 +542,12 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	s->stats.persistFallbacks = s->persistFallbacks;
 	s->stats.structureBuilds = (int32_t)s->structureGeneration;
 	s->stats.placedContacts = (int32_t)s->placedTotal;
+	{
+		int kind = -1, warm = -1;
+		const bool persistent = s->stats.persistent && q.persistPlan(kind, warm);
+		const bool wide = persistent && q.widePlan(kind, warm);
+		s->stats.pairLanes = wide ? 2 : (persistent && s->persist.pairLanes && s->optPairLanes) ? 1 : 0;
+	}
 	s->stats.potentialConstraints = (int32_t)(s->contacts.order.size() - (size_t)s->slackPositions);
 	if (!async && s->hostError && *s->hostError != 0u)
 	{

@@ -1097,6 +1097,13 @@ do                                                                              
 			const int g = seamGroup[(size_t)sm];
 			seamRegs = g < 0 || B.cBatchOffsets[(size_t)g + 1] - B.cBatchOffsets[(size_t)g] <= 2;
 		}
+		// pair_kernel.hip: the same limits, whatever the seam_regs option says
+		bool pairLanes = maxRoundsA <= S2_STRIP_ROUNDS;
+		for (int sm = 0; sm < S && pairLanes; ++sm)
+		{
+			const int g = seamGroup[(size_t)sm];
+			pairLanes = g < 0 || B.cBatchOffsets[(size_t)g + 1] - B.cBatchOffsets[(size_t)g] <= 2;
+		}
 		std::vector<PersistDesc> descs((size_t)K);
 		std::vector<int> remap, exportSrc, importIds;
 		std::vector<int> replicaStamp((size_t)nb, -1), replicaSlot((size_t)nb, -1);
@@ -1257,6 +1264,7 @@ do                                                                              
 			HIP_TRY(hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, s->stream));
 			pv.wideRounds = maxRoundsA > S2_STRIP_ROUNDS ? 1 : 0;
 			pv.seamRegs = seamRegs ? 1 : 0;
+			pv.pairLanes = pairLanes ? 1 : 0;
 			s->persistK0 = k0, s->persistK1 = k1;
 			pv.allTwoPoints = stripsAllTwoPoints(s) ? 1 : 0;
 			pv.ldsRecords = ldsRecords;

@@ -1,0 +1,781 @@
+// Persistent strip step of s2Solve_TGS_Soft, "wide" form: 512 threads per strip, one lane per constraint.
+//
+// The same step as strip_kernel.hip: stripStepKernel<SOFT_TGS, WARM_CURRENT, ., ., SEAMREG> -- workgroup i owns strip i of a
+// big island for the WHOLE s2Solve_TGS_Soft (src/solve_tgs_soft.c:138-280), interior and seam constraints resident in
+// registers, bodies in LDS, seam bodies exchanged with the two neighbouring workgroups once per sweep as tagged granules --
+// on the same tables (StripDesc, PersistDesc), in the same sweep order, to the same bits.  What it does with what round 3
+// measured on this part (tools/valu_bench.hip):
+//
+//  * a wave that is alone on its SIMD issues ONE instruction per 4 cycles whatever the instruction is, and a packed fp32
+//    instruction (v_pk_mul_f32 / v_pk_add_f32: two IEEE operations, each rounded separately) costs that wave about what a
+//    scalar one does.  A colour round is one such wave's instruction stream, so the round's arithmetic is written as
+//    2-vector operations on (x, y) pairs -- rotate, anchor velocity, impulse application are 2-vector algebra -- with the
+//    operands laid out so that the pairs come out of the LDS records and the resident constraint record as aligned
+//    register pairs (no packing moves): `solveWide` / `warmWide` below.  Same operations on the same operands as
+//    constraint_ops.h solveSoftRegs (s2SolveContacts_TGS_Soft, solve_tgs_soft.c:17-135), which the parity tests pin.
+//  * a second wave on a SIMD runs beside the first at nearly full speed.  With 512 threads a seam round -- both seams of the
+//    strip, up to 512 constraints -- is ONE pass (two waves per SIMD) instead of two passes of one wave per SIMD, the body
+//    stages touch every staged body in one go, and the two halves of the workgroup serve one neighbour each in the hand-off.
+//    Interior round i runs on half i & 1 of the workgroup, so a lane holds three interior and two seam records of 22 dwords:
+//    110 of its 256 registers, no spills, no AGPR copies.
+//  * the three soft coefficients (one of two step-wide triples) are looked up in LDS by the constraint's "a side is static"
+//    bit instead of being selected from six scalar registers.
+//
+// Two lanes per constraint (pair_kernel.hip) was built and measured first: bit-exact, and no faster than one lane (a DPP
+// operand costs two issue slots on this part and the impulse chain is duplicated in both lanes).
+
+#include "body_ops.h"
+#include "persist_handoff.h"
+
+#ifndef S2_PERSIST_INSTRUMENTED
+#define S2_PERSIST_INSTRUMENTED 0
+#endif
+#define S2_WIDE_THREADS 512
+#define S2_WIDE_INTERIOR 256  // a colour batch of a strip has at most 256 constraints: interior round i runs on half i & 1 of the workgroup
+#define S2_WIDE_ROUNDS_PER_HALF (S2_STRIP_ROUNDS / 2) // ... so a lane holds three interior records
+#define S2_WIDE_BODY_CHUNKS 2 // own bodies per thread: a strip stages at most 2 * 512 = S2_STRIP_BODY_CHUNKS * 256
+#define S2_WIDE_SEAM_ROUNDS 2
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+S2_DEV f2 lo2(float4 v) { return f2{v.x, v.y}; }
+S2_DEV f2 hi2(float4 v) { return f2{v.z, v.w}; }
+// rotate (math.h:330-341) with q = {s, c}: (c x - s y, s x + c y)
+S2_DEV f2 rot2(f2 q, f2 l)
+{
+	const f2 a = q.yx * l.xx; // {c x, s x}
+	const f2 b = q.xy * l.yy; // {s y, c y}
+	return f2{a.x - b.x, a.y + b.y};
+}
+S2_DEV float dot2(f2 a, f2 b)
+{
+	const f2 m = a * b;
+	return m.x + m.y;
+}
+S2_DEV float cross2(f2 a, f2 b) // a.x b.y - a.y b.x
+{
+	const f2 m = a * b.yx;
+	return m.x - m.y;
+}
+// v + crossSV(w, r) = (v.x + (-w r.y), v.y + w r.x)
+S2_DEV f2 anchorVel(f2 v, float w, f2 r)
+{
+	const f2 m = r.yx * f2{w, w}; // {w r.y, w r.x}
+	return f2{v.x - m.x, v.y + m.y};
+}
+
+// A constraint as a lane keeps it for the whole step: 22 dwords.
+struct WideRegs
+{
+	uint32_t idx; // ia | ib << 13 | pointCount << 26 | writeA << 28 | writeB << 29 | (a side is static) << 30
+	f2 n;		  // normal
+	float friction;
+	f2 lA[2], lB[2]; // local anchors relative to the centres of mass
+	float p0[2], p1[2], p2[2]; // adjustedSeparation, normalMass, tangentMass
+	f2 imp[2];				   // {normal, tangent} impulse
+};
+
+S2_DEV WideRegs loadWide(const ContactView& c, int k, int ia, int ib)
+{
+	WideRegs p;
+	const float4 nf = c.nf[k];
+	const uint32_t bits = asBits(nf.w);
+	p.idx = (uint32_t)ia | ((uint32_t)ib << 13) | ((bits & 3u) << 26) | ((bits & S2C_WRITE_A) ? 1u << 28 : 0u) | ((bits & S2C_WRITE_B) ? 1u << 29 : 0u);
+	p.n = lo2(nf), p.friction = nf.z;
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		const float4 a = c.anchor[j][k];
+		p.lA[j] = lo2(a), p.lB[j] = hi2(a);
+		const float4 par = c.param[j][k];
+		p.p0[j] = par.x, p.p1[j] = par.y, p.p2[j] = par.z;
+		const float2 imp = c.impulse[j][k];
+		p.imp[j] = f2{imp.x, imp.y};
+	}
+	return p;
+}
+
+// 1: the round's arithmetic written on explicit 2-vectors (f2); 0: on scalars (V2 helpers of s2_device.h), packing left to the compiler
+#ifndef S2_WIDE_F2
+#define S2_WIDE_F2 0
+#endif
+
+#if S2_WIDE_F2
+// s2WarmStartContacts (solve_common.c:276-330): strip_kernel.hip warmSoftRegs on 2-vectors
+template <int POINTS> S2_DEV void warmWide(const WideRegs& p, float4* lvel, const float4* ldq, const float2* lmass, uint32_t salt)
+{
+	const uint32_t idx = p.idx ^ salt;
+	const int ia = (int)(idx & 0x1fffu), ib = (int)((idx >> 13) & 0x1fffu);
+	const int pointCount = (int)((idx >> 26) & 3u);
+	const float4 velA = lvel[ia], velB = lvel[ib];
+	const f2 qA = hi2(ldq[ia]), qB = hi2(ldq[ib]);
+	const float2 mA = lmass[ia], mB = lmass[ib];
+	const f2 n = f2{fromBits(asBits(p.n.x) ^ salt), p.n.y};
+	const f2 t = f2{n.y, -n.x};
+	f2 vA = lo2(velA), vB = lo2(velB);
+	float wA = velA.z, wB = velB.z;
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		if (POINTS == 2 || j < pointCount)
+		{
+			const f2 rA = rot2(qA, p.lA[j]), rB = rot2(qB, p.lB[j]);
+			const f2 P = p.imp[j].xx * n + p.imp[j].yy * t;
+			wA -= mA.y * cross2(rA, P);
+			vA = vA + f2{-mA.x, -mA.x} * P; // mulAdd(vA, -mA, P)
+			wB += mB.y * cross2(rB, P);
+			vB = vB + f2{mB.x, mB.x} * P;
+		}
+	}
+	if ((idx & (1u << 28)) != 0)
+	{
+		lvel[ia] = make_float4(vA.x, vA.y, wA, 0.0f);
+	}
+	if ((idx & (1u << 29)) != 0)
+	{
+		lvel[ib] = make_float4(vB.x, vB.y, wB, 0.0f);
+	}
+}
+
+// s2SolveContacts_TGS_Soft (solve_tgs_soft.c:17-135): constraint_ops.h solveSoftRegs<SOFT_TGS> on 2-vectors.
+// lcoef: LDS, the step's two soft-coefficient triples {bias, mass scale, impulse scale} -- [0] dynamic-dynamic, [1] a side static
+template <int POINTS>
+S2_DEV void solveWide(WideRegs& p, float4* lvel, const float4* ldq, const float2* lmass, const float4* lcoef, float inv_h, int useBias, uint32_t salt)
+{
+	const uint32_t idx = p.idx ^ salt;
+	const int ia = (int)(idx & 0x1fffu), ib = (int)((idx >> 13) & 0x1fffu);
+	const int pointCount = (int)((idx >> 26) & 3u);
+	const float4 dqA = ldq[ia], dqB = ldq[ib];
+	const float4 sf = lcoef[(idx >> 30) & 1u];
+	const float4 velA = lvel[ia], velB = lvel[ib];
+	const float2 mA = lmass[ia], mB = lmass[ib];
+	const f2 n = f2{fromBits(asBits(p.n.x) ^ salt), p.n.y};
+	const f2 t = f2{n.y, -n.x};
+	const f2 dd = lo2(dqB) - lo2(dqA); // sub(dcB, dcA)
+	const f2 qA = hi2(dqA), qB = hi2(dqB);
+	f2 vA = lo2(velA), vB = lo2(velB);
+	float wA = velA.z, wB = velB.z;
+	f2 rAj[2], rBj[2];
+	float nImp[2];
+
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		if (POINTS == 2 || j < pointCount)
+		{
+			const f2 rA = rot2(qA, p.lA[j]), rB = rot2(qB, p.lB[j]);
+			rAj[j] = rA, rBj[j] = rB;
+			const f2 ds = dd + (rB - rA);
+			const float s = dot2(ds, n) + p.p0[j];
+
+			// select form of: if (s > 0) bias = s * inv_h; else if (useBias) {bias = max(biasCoefficient * s, cap); ...}
+			const bool speculative = s > 0.0f;
+			const bool soft = !speculative && useBias != 0;
+			const float softBias = S2_MAXF(sf.x * s, -S2_MAX_BAUMGARTE_VELOCITY);
+			const float bias = speculative ? s * inv_h : (soft ? softBias : 0.0f);
+			const float massScale = soft ? sf.y : 1.0f;
+			const float impulseScale = soft ? sf.z : 0.0f;
+
+			const f2 dv = anchorVel(vB, wB, rB) - anchorVel(vA, wA, rA);
+			const float vn = dot2(dv, n);
+
+			const float normalMass = fromBits(asBits(p.p1[j]) ^ salt);
+			const float old = p.imp[j].x;
+			float impulse = -normalMass * massScale * (vn + bias) - impulseScale * old;
+			const float newImpulse = S2_MAXF(old + impulse, 0.0f);
+			impulse = newImpulse - old;
+			nImp[j] = newImpulse;
+
+			const f2 P = f2{impulse, impulse} * n;
+			vA = vA - f2{mA.x, mA.x} * P;
+			wA -= mA.y * cross2(rA, P);
+			vB = vB + f2{mB.x, mB.x} * P;
+			wB += mB.y * cross2(rB, P);
+		}
+	}
+
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		if (POINTS == 2 || j < pointCount)
+		{
+			const float tangentMass = fromBits(asBits(p.p2[j]) ^ salt);
+			const f2 rA = rAj[j], rB = rBj[j];
+			const f2 dv = anchorVel(vB, wB, rB) - anchorVel(vA, wA, rA);
+			const float vt = dot2(dv, t);
+			const float old = p.imp[j].y;
+			float impulse = -tangentMass * vt;
+			const float maxFriction = p.friction * nImp[j];
+			const float newImpulse = S2_CLAMPF(old + impulse, -maxFriction, maxFriction);
+			impulse = newImpulse - old;
+			const f2 P = f2{impulse, impulse} * t;
+			vA = vA - f2{mA.x, mA.x} * P;
+			wA -= mA.y * cross2(rA, P);
+			vB = vB + f2{mB.x, mB.x} * P;
+			wB += mB.y * cross2(rB, P);
+			p.imp[j] = f2{nImp[j], newImpulse};
+		}
+	}
+
+	if ((idx & (1u << 28)) != 0)
+	{
+		lvel[ia] = make_float4(vA.x, vA.y, wA, 0.0f);
+	}
+	if ((idx & (1u << 29)) != 0)
+	{
+		lvel[ib] = make_float4(vB.x, vB.y, wB, 0.0f);
+	}
+}
+
+#else
+S2_DEV V2 asV2(f2 v) { return v2(v.x, v.y); }
+
+// s2WarmStartContacts (solve_common.c:276-330): strip_kernel.hip warmSoftRegs
+template <int POINTS> S2_DEV void warmWide(const WideRegs& p, float4* lvel, const float4* ldq, const float2* lmass, uint32_t salt)
+{
+	const uint32_t idx = p.idx ^ salt;
+	const int ia = (int)(idx & 0x1fffu), ib = (int)((idx >> 13) & 0x1fffu);
+	const int pointCount = (int)((idx >> 26) & 3u);
+	const float4 velA = lvel[ia], velB = lvel[ib];
+	const float4 dqA = ldq[ia], dqB = ldq[ib];
+	const float2 mA = lmass[ia], mB = lmass[ib];
+	const V2 normal = v2(fromBits(asBits(p.n.x) ^ salt), p.n.y);
+	const V2 tangent = rightPerp(normal);
+	Rot qA, qB;
+	qA.s = dqA.z, qA.c = dqA.w, qB.s = dqB.z, qB.c = dqB.w;
+	V2 vA = v2(velA.x, velA.y), vB = v2(velB.x, velB.y);
+	float wA = velA.z, wB = velB.z;
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		if (POINTS == 2 || j < pointCount)
+		{
+			const V2 rA = rotate(qA, asV2(p.lA[j])), rB = rotate(qB, asV2(p.lB[j]));
+			const V2 P = add(mulSV(p.imp[j].x, normal), mulSV(p.imp[j].y, tangent));
+			wA -= mA.y * cross(rA, P);
+			vA = mulAdd(vA, -mA.x, P);
+			wB += mB.y * cross(rB, P);
+			vB = mulAdd(vB, mB.x, P);
+		}
+	}
+	if ((idx & (1u << 28)) != 0)
+	{
+		lvel[ia] = make_float4(vA.x, vA.y, wA, 0.0f);
+	}
+	if ((idx & (1u << 29)) != 0)
+	{
+		lvel[ib] = make_float4(vB.x, vB.y, wB, 0.0f);
+	}
+}
+
+// s2SolveContacts_TGS_Soft (solve_tgs_soft.c:17-135): constraint_ops.h solveSoftRegs<SOFT_TGS>, operation for operation
+template <int POINTS>
+S2_DEV void solveWide(WideRegs& p, float4* lvel, const float4* ldq, const float2* lmass, const float4* lcoef, float inv_h, int useBias, uint32_t salt)
+{
+	const uint32_t idx = p.idx ^ salt;
+	const int ia = (int)(idx & 0x1fffu), ib = (int)((idx >> 13) & 0x1fffu);
+	const int pointCount = (int)((idx >> 26) & 3u);
+	const float4 dqA = ldq[ia], dqB = ldq[ib];
+	const float4 sf = lcoef[(idx >> 30) & 1u];
+	const float4 velA = lvel[ia], velB = lvel[ib];
+	const float2 massA = lmass[ia], massB = lmass[ib];
+	const V2 normal = v2(fromBits(asBits(p.n.x) ^ salt), p.n.y);
+	const V2 tangent = rightPerp(normal);
+	const float mA = massA.x, iA = massA.y, mB = massB.x, iB = massB.y;
+	const V2 dcA = v2(dqA.x, dqA.y), dcB = v2(dqB.x, dqB.y);
+	Rot qA, qB;
+	qA.s = dqA.z, qA.c = dqA.w, qB.s = dqB.z, qB.c = dqB.w;
+	V2 vA = v2(velA.x, velA.y), vB = v2(velB.x, velB.y);
+	float wA = velA.z, wB = velB.z;
+	V2 rAj[2], rBj[2];
+	float nImp[2], tImp[2];
+
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		if (POINTS == 2 || j < pointCount)
+		{
+			const V2 rA = rotate(qA, asV2(p.lA[j])), rB = rotate(qB, asV2(p.lB[j]));
+			rAj[j] = rA, rBj[j] = rB;
+			const V2 ds = add(sub(dcB, dcA), sub(rB, rA));
+			const float s = dot(ds, normal) + p.p0[j];
+
+			// select form of: if (s > 0) bias = s * inv_h; else if (useBias) {bias = max(biasCoefficient * s, cap); ...}
+			const bool speculative = s > 0.0f;
+			const bool soft = !speculative && useBias != 0;
+			const float softBias = S2_MAXF(sf.x * s, -S2_MAX_BAUMGARTE_VELOCITY);
+			const float bias = speculative ? s * inv_h : (soft ? softBias : 0.0f);
+			const float massScale = soft ? sf.y : 1.0f;
+			const float impulseScale = soft ? sf.z : 0.0f;
+
+			const V2 vrB = add(vB, crossSV(wB, rB));
+			const V2 vrA = add(vA, crossSV(wA, rA));
+			const float vn = dot(sub(vrB, vrA), normal);
+
+			const float normalMass = fromBits(asBits(p.p1[j]) ^ salt);
+			const float old = p.imp[j].x;
+			float impulse = -normalMass * massScale * (vn + bias) - impulseScale * old;
+			const float newImpulse = S2_MAXF(old + impulse, 0.0f);
+			impulse = newImpulse - old;
+			nImp[j] = newImpulse;
+			tImp[j] = p.imp[j].y;
+
+			const V2 P = mulSV(impulse, normal);
+			vA = mulSub(vA, mA, P);
+			wA -= iA * cross(rA, P);
+			vB = mulAdd(vB, mB, P);
+			wB += iB * cross(rB, P);
+		}
+	}
+
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		if (POINTS == 2 || j < pointCount)
+		{
+			const float tangentMass = fromBits(asBits(p.p2[j]) ^ salt);
+			const V2 rA = rAj[j], rB = rBj[j];
+			const V2 vrB = add(vB, crossSV(wB, rB));
+			const V2 vrA = add(vA, crossSV(wA, rA));
+			const float vt = dot(sub(vrB, vrA), tangent);
+			float impulse = -tangentMass * vt;
+			const float maxFriction = p.friction * nImp[j];
+			const float newImpulse = S2_CLAMPF(tImp[j] + impulse, -maxFriction, maxFriction);
+			impulse = newImpulse - tImp[j];
+			const V2 P = mulSV(impulse, tangent);
+			vA = mulSub(vA, mA, P);
+			wA -= iA * cross(rA, P);
+			vB = mulAdd(vB, mB, P);
+			wB += iB * cross(rB, P);
+			p.imp[j] = f2{nImp[j], newImpulse};
+		}
+	}
+
+	if ((idx & (1u << 28)) != 0)
+	{
+		lvel[ia] = make_float4(vA.x, vA.y, wA, 0.0f);
+	}
+	if ((idx & (1u << 29)) != 0)
+	{
+		lvel[ib] = make_float4(vB.x, vB.y, wB, 0.0f);
+	}
+}
+#endif
+
+S2_DEV void storeWide(const ContactView& c, const WideRegs& p, int k)
+{
+	const int pointCount = (int)((p.idx >> 26) & 3u);
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		if (j < pointCount)
+		{
+			c.impulse[j][k] = make_float2(p.imp[j].x, p.imp[j].y);
+		}
+	}
+}
+
+// POINTS == 2: the host has checked that every constraint of the strips has two manifold points: no per-point masking.
+template <int POINTS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideStepKernel(ContactView c, BodyView g, StripTableView ta, PersistView pv, const Op* ops, int opCount)
+{
+	extern __shared__ __attribute__((aligned(16))) float4 lds[];
+	const int tid = (int)threadIdx.x;
+	const int half = tid >> 8, ht = tid & 255; // hand-offs: waves 0-3 serve the left neighbour, waves 4-7 the right
+	// stamps: (wall_clock64 << 4) | tag; tags: 0 start, 1 loaded, 2 body stage, 3 warm start, 4 interior rounds, 5 hand-off, 6 seam rounds, 7 end
+	const bool stamp = S2_PERSIST_INSTRUMENTED && pv.debugTimes != nullptr && blockIdx.x == gridDim.x / 2 && tid == 0;
+	int stamps = 0;
+	auto stampAt = [&](unsigned tag) {
+		if (stamp && stamps < 250)
+		{
+			pv.debugTimes[stamps++] = (wall_clock64() << 4) | tag;
+		}
+	};
+	stampAt(0);
+	const StripDesc* da = ta.descs + blockIdx.x;
+	const PersistDesc* pd = pv.descs + blockIdx.x;
+	const int bodyBase = da->bodyBase, nb = da->bodyCount, roundsA = da->batchCount;
+	int2 batchA[S2_STRIP_ROUNDS];
+#pragma unroll
+	for (int i = 0; i < S2_STRIP_ROUNDS; ++i)
+	{
+		batchA[i] = make_int2(da->batch[i].x, da->batch[i].y);
+	}
+	const int nImp0 = pd->importCount[0], nImp1 = pd->importCount[1];
+	const int roundsB0 = pd->seamBatchCount[0], roundsB1 = pd->seamBatchCount[1];
+	int2 batchB0[S2_WIDE_SEAM_ROUNDS], batchB1[S2_WIDE_SEAM_ROUNDS];
+#pragma unroll
+	for (int i = 0; i < S2_WIDE_SEAM_ROUNDS; ++i)
+	{
+		batchB0[i] = pd->seamBatch[0][i];
+		batchB1[i] = pd->seamBatch[1][i];
+	}
+	const int roundsB = roundsB0 > roundsB1 ? roundsB0 : roundsB1;
+	const int nt = nb + nImp0 + nImp1;
+	gu64* gran = (gu64*)pv.granules;
+	// this half's side of the exchange
+	const int nImpH = half ? nImp1 : nImp0, nExpH = pd->exportCount[half];
+	const int inH = pd->inBase[half], outH = pd->outBase[half];
+	const int impSlotH = nb + (half ? nImp0 : 0) + ht; // LDS slot of the import this thread receives
+
+	float4* lvel = lds;
+	float4* ldq = lds + nt;
+	float4* linteg = lds + 2 * nt;							// velocity-integrator constants of every staged body (body_ops.h)
+	float* langDamp = (float*)(lds + 3 * nt);				// nt floats, padded to records
+	float2* lmass = (float2*)(lds + 3 * nt + (nt + 3) / 4); // {invMass, invI} of every staged body, padded to records
+	const int bodyRecords = 3 * nt + (nt + 3) / 4 + (nt + 1) / 2;
+	Op* lops = (Op*)(lds + bodyRecords); // 2 records per op
+	float4* lcoef = lds + bodyRecords + 2 * opCount; // 2 records (the launch adds them to the size)
+
+	// ---- loads ----
+	uint32_t id[S2_WIDE_BODY_CHUNKS];
+#pragma unroll
+	for (int ch = 0; ch < S2_WIDE_BODY_CHUNKS; ++ch)
+	{
+		const int i = tid + ch * S2_WIDE_THREADS;
+		id[ch] = i < nb ? (uint32_t)ta.bodyIds[bodyBase + i] : 0u;
+	}
+	const int impId = ht < nImpH ? pv.importIds[pd->importIdBase[half] + ht] : -1;
+	const int expIdx = ht < nExpH ? pv.exportSrc[pd->exportSrcBase[half] + ht] : 0;
+	for (int i = tid; i < opCount * 8; i += S2_WIDE_THREADS)
+	{
+		((int*)lops)[i] = ((const int*)ops)[i];
+	}
+	if (tid < 2)
+	{
+		lcoef[tid] = pv.softCoef[tid];
+	}
+	// interior round i runs on the lanes of half i & 1 (waves 0-3 take the even rounds, waves 4-7 the odd ones): a lane holds
+	// the records of rounds 2 s + half, s = 0..2, and the constraint it holds there is recomputed, not stored
+	auto kOfSlot = [&](int s) {
+		const int i = 2 * s + half; // (wave-uniform)
+		const int k = (half ? batchA[2 * s + 1].x : batchA[2 * s].x) + ht;
+		return (i < roundsA && k < (half ? batchA[2 * s + 1].y : batchA[2 * s].y)) ? k : -1;
+	};
+	WideRegs rA[S2_WIDE_ROUNDS_PER_HALF];
+#pragma unroll
+	for (int s = 0; s < S2_WIDE_ROUNDS_PER_HALF; ++s)
+	{
+		const int k = kOfSlot(s);
+		if (k >= 0)
+		{
+			const int2 lb = c.localBodies[k];
+			rA[s] = loadWide(c, k, lb.x, lb.y);
+		}
+	}
+	// seam constraints: round r = left seam's batch r followed by right seam's batch r, one per lane (a round holds at
+	// most 512 constraints); where an item lives is recomputed, not stored
+	auto seamItem = [&](int r, int& seam, int& k, uint32_t salt = 0u) {
+		const int n0 = r < roundsB0 ? batchB0[r].y - batchB0[r].x : 0;
+		const int n1 = r < roundsB1 ? batchB1[r].y - batchB1[r].x : 0;
+		const int idx = (int)((uint32_t)tid ^ salt);
+		if (idx < n0)
+		{
+			seam = 0, k = batchB0[r].x + idx;
+			return true;
+		}
+		if (idx - n0 < n1)
+		{
+			seam = 1, k = batchB1[r].x + idx - n0;
+			return true;
+		}
+		return false;
+	};
+	WideRegs rB[S2_WIDE_SEAM_ROUNDS];
+	uint32_t seamMask = 0u; // bit i: this lane holds a seam constraint in seam round i
+#pragma unroll
+	for (int i = 0; i < S2_WIDE_SEAM_ROUNDS; ++i)
+	{
+		int seam, k;
+		if (i < roundsB && seamItem(i, seam, k))
+		{
+			const int2 lb = c.localBodies[k];
+			rB[i] = loadWide(c, k, pv.remap[pd->remapBase[seam] + lb.x], pv.remap[pd->remapBase[seam] + lb.y]);
+			seamMask |= 1u << i;
+		}
+	}
+	// bodies (+ their integrator constants) into LDS: own list, then this half's imports
+	uint32_t flags[S2_WIDE_BODY_CHUNKS + 1];
+	int ldsIdx[S2_WIDE_BODY_CHUNKS + 1];
+#pragma unroll
+	for (int ch = 0; ch < S2_WIDE_BODY_CHUNKS + 1; ++ch)
+	{
+		int gi = -1;
+		if (ch < S2_WIDE_BODY_CHUNKS)
+		{
+			const int i = tid + ch * S2_WIDE_THREADS;
+			ldsIdx[ch] = i;
+			gi = i < nb ? (int)(id[ch] & ~S2G_OWNED) : -1;
+		}
+		else
+		{
+			ldsIdx[ch] = impSlotH;
+			gi = impId;
+		}
+		flags[ch] = 0u;
+		if (gi >= 0)
+		{
+			lvel[ldsIdx[ch]] = g.vel[gi];
+			ldq[ldsIdx[ch]] = g.dq[gi];
+			flags[ch] = g.flags[gi] | 0x80000000u; // bit 31: slot in use
+			linteg[ldsIdx[ch]] = g.integ[gi];
+			langDamp[ldsIdx[ch]] = g.angDamp[gi];
+			lmass[ldsIdx[ch]] = g.massInv[gi];
+		}
+	}
+	__syncthreads();
+	// the doubled contact hertz of a constraint with a static side (prepareContactsKernel<PREP_SOFT>; solve_common.c:219): the
+	// test of strip_kernel.hip unpackPersist, made once -- the masses do not change during a step
+	auto markStatic = [&](WideRegs& p) {
+		const bool st = lmass[p.idx & 0x1fffu].x == 0.0f || lmass[(p.idx >> 13) & 0x1fffu].x == 0.0f;
+		p.idx |= st ? 1u << 30 : 0u;
+	};
+#pragma unroll
+	for (int s = 0; s < S2_WIDE_ROUNDS_PER_HALF; ++s)
+	{
+		if (kOfSlot(s) >= 0)
+		{
+			markStatic(rA[s]);
+		}
+	}
+#pragma unroll
+	for (int i = 0; i < S2_WIDE_SEAM_ROUNDS; ++i)
+	{
+		if ((seamMask >> i) & 1u)
+		{
+			markStatic(rB[i]);
+		}
+	}
+	stampAt(1);
+
+	unsigned epoch = 0; // tags are the exchange number: the buffers are zero at launch (cleared by the previous step's epilogue)
+	int bad = 0;
+	for (int oi = 0; oi < opCount && !bad; ++oi)
+	{
+		const Op op = lops[oi];
+		// an opaque zero produced inside the step loop: without it the compiler hoists the decoding of every round's indices
+		// (and the LDS addresses made from them) out of that loop and pays for it in scratch spills
+		uint32_t salt;
+		asm volatile("s_mov_b32 %0, 0" : "=s"(salt));
+		if (op.code == OP_INTEGRATE_VEL)
+		{
+#pragma unroll
+			for (int ch = 0; ch < S2_WIDE_BODY_CHUNKS + 1; ++ch)
+			{
+				if ((flags[ch] & S2F_DYNAMIC) != 0)
+				{
+					const int i = ldsIdx[ch];
+					float4 v = lvel[i], k = linteg[i];
+					V2 lv = add(v2(v.x, v.y), v2(k.x, k.y));
+					float w = v.z + k.z;
+					lv = mulSV(k.w, lv);
+					w *= langDamp[i];
+					lvel[i] = make_float4(lv.x, lv.y, w, 0.0f);
+				}
+			}
+			__syncthreads();
+			stampAt(2);
+		}
+		else if (op.code == OP_INTEGRATE_POS)
+		{
+#pragma unroll
+			for (int ch = 0; ch < S2_WIDE_BODY_CHUNKS + 1; ++ch)
+			{
+				if ((flags[ch] & S2F_MOVES) != 0)
+				{
+					const int i = ldsIdx[ch];
+					float4 v = lvel[i], d = ldq[i];
+					V2 dpos = mulAdd(v2(d.x, d.y), op.h, v2(v.x, v.y));
+					Rot q;
+					q.s = d.z, q.c = d.w;
+					q = integrateRot(q, op.h * v.z);
+					ldq[i] = make_float4(dpos.x, dpos.y, q.s, q.c);
+				}
+			}
+			__syncthreads();
+			stampAt(2);
+		}
+		else if (op.code == OP_FINALIZE)
+		{
+			// s2FinalizePositions (solve_common.c:70-91; body_ops.h finalizePositionsOne): the owner writes the position,
+			// every copy resets its deltaPosition
+			const uint32_t need = op.flag ? S2F_DYNAMIC : S2F_MOVES;
+#pragma unroll
+			for (int ch = 0; ch < S2_WIDE_BODY_CHUNKS + 1; ++ch)
+			{
+				if ((flags[ch] & need) != 0)
+				{
+					const int i = ldsIdx[ch];
+					const float4 d = ldq[i];
+					if (ch < S2_WIDE_BODY_CHUNKS && (id[ch] & S2G_OWNED) != 0)
+					{
+						const int gi = (int)(id[ch] & ~S2G_OWNED);
+						const float2 pos = g.pos[gi];
+						const V2 np = add(v2(pos.x, pos.y), v2(d.x, d.y));
+						g.pos[gi] = make_float2(np.x, np.y);
+					}
+					ldq[i] = make_float4(0.0f, 0.0f, d.z, d.w);
+				}
+			}
+			__syncthreads();
+			stampAt(2);
+		}
+		else if (op.code == OP_WARM)
+		{
+			// s2WarmStartContacts as a coloured sweep WITHOUT an exchange: a side's warm-start term depends on the impulses,
+			// the anchors and that body's own pose only, so every body this workgroup owns ends up with the right bits; the
+			// copies of the neighbours' bodies are refreshed by the next sweep's exchange before anything reads them
+#pragma unroll
+			for (int i = 0; i < S2_STRIP_ROUNDS; ++i)
+			{
+				if (i < roundsA)
+				{
+					if ((i & 1) == half && kOfSlot(i >> 1) >= 0)
+					{
+						warmWide<POINTS>(rA[i >> 1], lvel, ldq, lmass, salt);
+					}
+					__syncthreads();
+				}
+			}
+#pragma unroll
+			for (int i = 0; i < S2_WIDE_SEAM_ROUNDS; ++i)
+			{
+				if (i < roundsB)
+				{
+					if ((seamMask >> i) & 1u)
+					{
+						warmWide<POINTS>(rB[i], lvel, ldq, lmass, salt);
+					}
+					__syncthreads();
+				}
+			}
+			stampAt(3);
+		}
+		else if (op.code == OP_SOLVE_SOFT)
+		{
+			// ---- interiors ----
+#pragma unroll
+			for (int i = 0; i < S2_STRIP_ROUNDS; ++i)
+			{
+				if (i < roundsA)
+				{
+					if ((i & 1) == half && kOfSlot(i >> 1) >= 0)
+					{
+						solveWide<POINTS>(rA[i >> 1], lvel, ldq, lmass, lcoef, op.inv_h, op.useBias, salt);
+					}
+					__syncthreads();
+				}
+			}
+			stampAt(4);
+			// ---- symmetric exchange of the seam bodies' velocities (poses are replicated by the body stages) ----
+			epoch += 1;
+			const int par = (int)(epoch & 1u) * pv.parityStride;
+			const bool mute = (pv.debugSkip & 8) != 0 && blockIdx.x == 1; // fault injection: this workgroup stays silent
+			if (ht < nExpH && !mute)
+			{
+				const float4 v = lvel[expIdx];
+				gu64* p = gran + par + outH + 4 * ht;
+				putGranule(p + 0, epoch, v.x), putGranule(p + 1, epoch, v.y), putGranule(p + 2, epoch, v.z);
+			}
+			int fail = 0;
+			if (ht < nImpH)
+			{
+				float v[3];
+				if (getGranules<3>(gran + par + inH + 4 * ht, epoch, v, pv.error, pv.deviceError, pv.spinLimit))
+				{
+					lvel[impSlotH] = make_float4(v[0], v[1], v[2], 0.0f);
+				}
+				else
+				{
+					fail = 1;
+				}
+			}
+			bad = __syncthreads_or(fail);
+			if (bad)
+			{
+				break;
+			}
+			stampAt(5);
+			// ---- both seams (the neighbours compute the same bits on their side) ----
+#pragma unroll
+			for (int i = 0; i < S2_WIDE_SEAM_ROUNDS; ++i)
+			{
+				if (i < roundsB)
+				{
+					if ((seamMask >> i) & 1u)
+					{
+						solveWide<POINTS>(rB[i], lvel, ldq, lmass, lcoef, op.inv_h, op.useBias, salt);
+					}
+					__syncthreads();
+				}
+			}
+			stampAt(6);
+		}
+	}
+
+	// ---- results: owned bodies, impulses ----
+#pragma unroll
+	for (int ch = 0; ch < S2_WIDE_BODY_CHUNKS; ++ch)
+	{
+		const int i = tid + ch * S2_WIDE_THREADS;
+		if (i < nb && (id[ch] & S2G_OWNED) != 0)
+		{
+			const int gi = (int)(id[ch] & ~S2G_OWNED);
+			g.vel[gi] = lvel[i];
+			g.dq[gi] = ldq[i];
+		}
+	}
+#pragma unroll
+	for (int s = 0; s < S2_WIDE_ROUNDS_PER_HALF; ++s)
+	{
+		if (kOfSlot(s) >= 0)
+		{
+			storeWide(c, rA[s], kOfSlot(s));
+		}
+	}
+	// the right seam's impulses are stored by this workgroup (its left neighbour of that seam), nobody stores twice
+#pragma unroll
+	for (int i = 0; i < S2_WIDE_SEAM_ROUNDS; ++i)
+	{
+		int seam, k;
+		if (i < roundsB && seamItem(i, seam, k) && seam == 1)
+		{
+			storeWide(c, rB[i], k);
+		}
+	}
+	stampAt(7);
+	if (stamp)
+	{
+		pv.debugTimes[254] = 1ull; // tagged format
+		pv.debugTimes[255] = (unsigned long long)stamps;
+	}
+}
+
+// Eligibility (checked by the caller, solver_executor.h runPersistent): TGS_Soft with the current-anchor warm start, and
+// pv.pairLanes -- no strip has more than S2_STRIP_ROUNDS interior colour batches and no seam more than two.
+void launchWideStep(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount)
+{
+	const dim3 grid((unsigned)a.groupCount), block(S2_WIDE_THREADS);
+	const size_t lds = (size_t)(pv.ldsRecords + 2) * sizeof(float4) + (size_t)opCount * sizeof(Op);
+	if (pv.allTwoPoints)
+	{
+		wideStepKernel<2><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
+	}
+	else
+	{
+		wideStepKernel<0><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
+	}
+}
+
+int wideKernelSetup()
+{
+	const void* steps[] = {(const void*)wideStepKernel<0>, (const void*)wideStepKernel<2>};
+	for (const void* f : steps)
+	{
+		hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		if (e != hipSuccess)
+		{
+			return (int)e;
+		}
+	}
+	return 0;
+}

@@ -34,12 +34,6 @@ class ShardedWorld:
         out[:n, 7:9] = b["deltaPosition"]
         return out
 
-    def close(self):
-        if self.raw:
-            for p in self.pose_ptr:
-                self.solver.device_free(p)
-            self.pose_ptr = []
-
     def unpack_all(self, gathered):
         """gathered: float32[world_size, max_owned, 9] -> scatter into the full body array."""
         for r in range(self.world_size):

@@ -439,3 +439,39 @@ def test_strip_patience_backs_off_when_the_graph_keeps_changing():
             strips_seen.append(s.stats()["stripCount"] > 0)
         # built once or twice at the start, then the patience (2, 4, 8 ...) outlasts the three quiet steps
         assert any(strips_seen[:6]) and not any(strips_seen[8:]), strips_seen
+
+
+@pytest.mark.parametrize("mode", ["wide", "pair", "one"])
+@pytest.mark.parametrize("solver_name", ["TGS_Soft", "SoftStep", "PGS_Soft"])
+def test_persistent_step_kernels_agree(solver_name, mode):
+    """The three persistent step kernels on the same tables, in the same sweep order, to the same bits as the oracle:
+    wide_kernel.hip (512 threads per strip, TGS_Soft only), pair_kernel.hip (lanes 2c / 2c+1 are body A's / body B's side of
+    constraint c, differences cross as DPP operands) and strip_kernel.hip (256 threads, one lane per constraint)."""
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    pre = synthetic.pyramid(100)
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
+        s.set_option("wide", 1 if mode == "wide" else 0)
+        s.set_option("pair_lanes", 1 if mode == "pair" else 0)
+        state = common.copy3(pre)
+        for step in range(4):
+            params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+            state = gpu_vs_oracle(s, params, state, "pyramid100/%s %s step %d" % (solver_name, mode, step))
+        st = s.stats()
+        expect = {"wide": 2 if solver_name == "TGS_Soft" else 0, "pair": 1, "one": 0}[mode]
+        assert st["persistent"] == 1 and st["pairLanes"] == expect, st
+
+
+@pytest.mark.parametrize("mode", ["wide", "pair"])
+@pytest.mark.parametrize("iters,warm", [((8, 4), False), ((3, 0), True), ((1, 1), True), ((5, 2), False)])
+def test_persistent_step_kernels_iteration_shapes_and_cold_start(iters, warm, mode):
+    pre = synthetic.pyramid(100)
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
+        s.set_option("wide", 1 if mode == "wide" else 0)
+        s.set_option("pair_lanes", 1 if mode == "pair" else 0)
+        state = common.copy3(pre)
+        for step in range(3):
+            params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, iters[0], iters[1], warm)
+            state = gpu_vs_oracle(s, params, state, "%s %s warm=%s step %d" % (mode, iters, warm, step))
+        assert s.stats()["pairLanes"] == (2 if mode == "wide" else 1)

@@ -14,6 +14,14 @@ S2_DEV void putGranule(gu64* g, unsigned epoch, float v)
 	__hip_atomic_store(g, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// the same granule for a reader on the writer's own XCD: the store stays in that XCD's L2 (no write-through to the fabric),
+// where the reader's agent-scope (L1-bypassing) poll finds it.  Only valid when writer and reader share the L2 -- the caller
+// has established that (wide_kernel.hip: the XCC id handshake).
+S2_DEV void putGranuleNear(gu64* g, unsigned epoch, float v)
+{
+	__hip_atomic_store(g, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 #define S2_PERSIST_SPIN_LIMIT (1u << 21)
 
 template <int N> S2_DEV bool getGranules(gu64* g, unsigned epoch, float (&v)[N], unsigned int* error, unsigned int* deviceError, unsigned int spinLimit)

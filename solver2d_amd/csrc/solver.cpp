@@ -176,19 +176,23 @@ void s2amd_destroy(s2amdSolver* s)
 		if (s->hostTimes[254] == 1ull && n > 1)
 		{
 			// pair_kernel.hip's tagged stamps: time per phase of the last step, one workgroup
-			static const char* names[8] = {"start", "load", "body stages", "warm starts", "interior rounds", "hand-offs", "seam rounds", "store"};
-			double sum[8] = {0};
-			int count[8] = {0};
+			static const char* names[16] = {"start", "load", "body stages", "warm starts", "interior rounds (last)", "hand-offs", "seam rounds (last)", "store",
+											"interior 0", "interior 1", "interior 2", "interior 3", "interior 4", "interior 5", "seam 0", "seam 1"};
+			double sum[16] = {0};
+			int count[16] = {0};
 			for (int i = 1; i < n && i < 250; ++i)
 			{
-				const unsigned tag = (unsigned)(s->hostTimes[i] & 15ull) & 7u;
+				const unsigned tag = (unsigned)(s->hostTimes[i] & 15ull);
 				sum[tag] += 0.01 * (double)((s->hostTimes[i] >> 4) - (s->hostTimes[i - 1] >> 4));
 				count[tag] += 1;
 			}
 			fprintf(stderr, "[s2amd] pair-lane persistent step, one workgroup, us per phase (count):");
-			for (int t = 1; t < 8; ++t)
+			for (int t = 1; t < 16; ++t)
 			{
-				fprintf(stderr, " %s %.1f (%d);", names[t], sum[t], count[t]);
+				if (count[t] > 0)
+				{
+					fprintf(stderr, " %s %.1f (%d);", names[t], sum[t], count[t]);
+				}
 			}
 			fprintf(stderr, " total %.1f\n", 0.01 * (double)((s->hostTimes[n - 1] >> 4) - (s->hostTimes[0] >> 4)));
 			n = 0;

@@ -30,6 +30,11 @@
 #ifndef S2_PERSIST_INSTRUMENTED
 #define S2_PERSIST_INSTRUMENTED 0
 #endif
+// 1: strips are dealt to the workgroups so that neighbours share an XCD, and a seam inside an XCD hands its bodies over through
+// that XCD's L2 (experiment switch)
+#ifndef S2_WIDE_XCD_AFFINE
+#define S2_WIDE_XCD_AFFINE 1
+#endif
 #define S2_WIDE_THREADS 512
 #define S2_WIDE_INTERIOR 256  // a colour batch of a strip has at most 256 constraints: interior round i runs on half i & 1 of the workgroup
 #define S2_WIDE_ROUNDS_PER_HALF (S2_STRIP_ROUNDS / 2) // ... so a lane holds three interior records
@@ -40,30 +45,6 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 S2_DEV f2 lo2(float4 v) { return f2{v.x, v.y}; }
 S2_DEV f2 hi2(float4 v) { return f2{v.z, v.w}; }
-// rotate (math.h:330-341) with q = {s, c}: (c x - s y, s x + c y)
-S2_DEV f2 rot2(f2 q, f2 l)
-{
-	const f2 a = q.yx * l.xx; // {c x, s x}
-	const f2 b = q.xy * l.yy; // {s y, c y}
-	return f2{a.x - b.x, a.y + b.y};
-}
-S2_DEV float dot2(f2 a, f2 b)
-{
-	const f2 m = a * b;
-	return m.x + m.y;
-}
-S2_DEV float cross2(f2 a, f2 b) // a.x b.y - a.y b.x
-{
-	const f2 m = a * b.yx;
-	return m.x - m.y;
-}
-// v + crossSV(w, r) = (v.x + (-w r.y), v.y + w r.x)
-S2_DEV f2 anchorVel(f2 v, float w, f2 r)
-{
-	const f2 m = r.yx * f2{w, w}; // {w r.y, w r.x}
-	return f2{v.x - m.x, v.y + m.y};
-}
-
 // A constraint as a lane keeps it for the whole step: 22 dwords.
 struct WideRegs
 {
@@ -95,139 +76,6 @@ S2_DEV WideRegs loadWide(const ContactView& c, int k, int ia, int ib)
 	return p;
 }
 
-// 1: the round's arithmetic written on explicit 2-vectors (f2); 0: on scalars (V2 helpers of s2_device.h), packing left to the compiler
-#ifndef S2_WIDE_F2
-#define S2_WIDE_F2 0
-#endif
-
-#if S2_WIDE_F2
-// s2WarmStartContacts (solve_common.c:276-330): strip_kernel.hip warmSoftRegs on 2-vectors
-template <int POINTS> S2_DEV void warmWide(const WideRegs& p, float4* lvel, const float4* ldq, const float2* lmass, uint32_t salt)
-{
-	const uint32_t idx = p.idx ^ salt;
-	const int ia = (int)(idx & 0x1fffu), ib = (int)((idx >> 13) & 0x1fffu);
-	const int pointCount = (int)((idx >> 26) & 3u);
-	const float4 velA = lvel[ia], velB = lvel[ib];
-	const f2 qA = hi2(ldq[ia]), qB = hi2(ldq[ib]);
-	const float2 mA = lmass[ia], mB = lmass[ib];
-	const f2 n = f2{fromBits(asBits(p.n.x) ^ salt), p.n.y};
-	const f2 t = f2{n.y, -n.x};
-	f2 vA = lo2(velA), vB = lo2(velB);
-	float wA = velA.z, wB = velB.z;
-#pragma unroll
-	for (int j = 0; j < 2; ++j)
-	{
-		if (POINTS == 2 || j < pointCount)
-		{
-			const f2 rA = rot2(qA, p.lA[j]), rB = rot2(qB, p.lB[j]);
-			const f2 P = p.imp[j].xx * n + p.imp[j].yy * t;
-			wA -= mA.y * cross2(rA, P);
-			vA = vA + f2{-mA.x, -mA.x} * P; // mulAdd(vA, -mA, P)
-			wB += mB.y * cross2(rB, P);
-			vB = vB + f2{mB.x, mB.x} * P;
-		}
-	}
-	if ((idx & (1u << 28)) != 0)
-	{
-		lvel[ia] = make_float4(vA.x, vA.y, wA, 0.0f);
-	}
-	if ((idx & (1u << 29)) != 0)
-	{
-		lvel[ib] = make_float4(vB.x, vB.y, wB, 0.0f);
-	}
-}
-
-// s2SolveContacts_TGS_Soft (solve_tgs_soft.c:17-135): constraint_ops.h solveSoftRegs<SOFT_TGS> on 2-vectors.
-// lcoef: LDS, the step's two soft-coefficient triples {bias, mass scale, impulse scale} -- [0] dynamic-dynamic, [1] a side static
-template <int POINTS>
-S2_DEV void solveWide(WideRegs& p, float4* lvel, const float4* ldq, const float2* lmass, const float4* lcoef, float inv_h, int useBias, uint32_t salt)
-{
-	const uint32_t idx = p.idx ^ salt;
-	const int ia = (int)(idx & 0x1fffu), ib = (int)((idx >> 13) & 0x1fffu);
-	const int pointCount = (int)((idx >> 26) & 3u);
-	const float4 dqA = ldq[ia], dqB = ldq[ib];
-	const float4 sf = lcoef[(idx >> 30) & 1u];
-	const float4 velA = lvel[ia], velB = lvel[ib];
-	const float2 mA = lmass[ia], mB = lmass[ib];
-	const f2 n = f2{fromBits(asBits(p.n.x) ^ salt), p.n.y};
-	const f2 t = f2{n.y, -n.x};
-	const f2 dd = lo2(dqB) - lo2(dqA); // sub(dcB, dcA)
-	const f2 qA = hi2(dqA), qB = hi2(dqB);
-	f2 vA = lo2(velA), vB = lo2(velB);
-	float wA = velA.z, wB = velB.z;
-	f2 rAj[2], rBj[2];
-	float nImp[2];
-
-#pragma unroll
-	for (int j = 0; j < 2; ++j)
-	{
-		if (POINTS == 2 || j < pointCount)
-		{
-			const f2 rA = rot2(qA, p.lA[j]), rB = rot2(qB, p.lB[j]);
-			rAj[j] = rA, rBj[j] = rB;
-			const f2 ds = dd + (rB - rA);
-			const float s = dot2(ds, n) + p.p0[j];
-
-			// select form of: if (s > 0) bias = s * inv_h; else if (useBias) {bias = max(biasCoefficient * s, cap); ...}
-			const bool speculative = s > 0.0f;
-			const bool soft = !speculative && useBias != 0;
-			const float softBias = S2_MAXF(sf.x * s, -S2_MAX_BAUMGARTE_VELOCITY);
-			const float bias = speculative ? s * inv_h : (soft ? softBias : 0.0f);
-			const float massScale = soft ? sf.y : 1.0f;
-			const float impulseScale = soft ? sf.z : 0.0f;
-
-			const f2 dv = anchorVel(vB, wB, rB) - anchorVel(vA, wA, rA);
-			const float vn = dot2(dv, n);
-
-			const float normalMass = fromBits(asBits(p.p1[j]) ^ salt);
-			const float old = p.imp[j].x;
-			float impulse = -normalMass * massScale * (vn + bias) - impulseScale * old;
-			const float newImpulse = S2_MAXF(old + impulse, 0.0f);
-			impulse = newImpulse - old;
-			nImp[j] = newImpulse;
-
-			const f2 P = f2{impulse, impulse} * n;
-			vA = vA - f2{mA.x, mA.x} * P;
-			wA -= mA.y * cross2(rA, P);
-			vB = vB + f2{mB.x, mB.x} * P;
-			wB += mB.y * cross2(rB, P);
-		}
-	}
-
-#pragma unroll
-	for (int j = 0; j < 2; ++j)
-	{
-		if (POINTS == 2 || j < pointCount)
-		{
-			const float tangentMass = fromBits(asBits(p.p2[j]) ^ salt);
-			const f2 rA = rAj[j], rB = rBj[j];
-			const f2 dv = anchorVel(vB, wB, rB) - anchorVel(vA, wA, rA);
-			const float vt = dot2(dv, t);
-			const float old = p.imp[j].y;
-			float impulse = -tangentMass * vt;
-			const float maxFriction = p.friction * nImp[j];
-			const float newImpulse = S2_CLAMPF(old + impulse, -maxFriction, maxFriction);
-			impulse = newImpulse - old;
-			const f2 P = f2{impulse, impulse} * t;
-			vA = vA - f2{mA.x, mA.x} * P;
-			wA -= mA.y * cross2(rA, P);
-			vB = vB + f2{mB.x, mB.x} * P;
-			wB += mB.y * cross2(rB, P);
-			p.imp[j] = f2{nImp[j], newImpulse};
-		}
-	}
-
-	if ((idx & (1u << 28)) != 0)
-	{
-		lvel[ia] = make_float4(vA.x, vA.y, wA, 0.0f);
-	}
-	if ((idx & (1u << 29)) != 0)
-	{
-		lvel[ib] = make_float4(vB.x, vB.y, wB, 0.0f);
-	}
-}
-
-#else
 S2_DEV V2 asV2(f2 v) { return v2(v.x, v.y); }
 
 // s2WarmStartContacts (solve_common.c:276-330): strip_kernel.hip warmSoftRegs
@@ -268,26 +116,69 @@ template <int POINTS> S2_DEV void warmWide(const WideRegs& p, float4* lvel, cons
 	}
 }
 
-// s2SolveContacts_TGS_Soft (solve_tgs_soft.c:17-135): constraint_ops.h solveSoftRegs<SOFT_TGS>, operation for operation
-template <int POINTS>
-S2_DEV void solveWide(WideRegs& p, float4* lvel, const float4* ldq, const float2* lmass, const float4* lcoef, float inv_h, int useBias, uint32_t salt)
+// s2SolveContacts_TGS_Soft (solve_tgs_soft.c:17-135) = constraint_ops.h solveSoftRegs<SOFT_TGS>, operation for operation, in two
+// parts (the split of constraint_ops.h prepSoft / chainSoft):
+//   prepWide  what depends on the POSES only, which no sweep changes: the anchors in world orientation, the current separation,
+//             the bias and whether the soft coefficients apply.  It can run any time after the last s2IntegratePositions --
+//             the kernel runs it in lanes that would otherwise wait (the idle half of the workgroup during an interior round,
+//             every lane while the seam bodies are in flight);
+//   chainWide what depends on the VELOCITIES: relative velocity -> impulse -> clamp -> apply, point after point, normal then
+//             friction.  This is what a colour round has to wait for.
+struct WidePrep
+{
+	V2 rA[2], rB[2];
+	float bias[2];
+	uint32_t soft; // bit j: point j takes the soft mass / impulse scales
+};
+
+template <int POINTS> S2_DEV WidePrep prepWide(const WideRegs& p, const float4* ldq, const float4* lcoef, float inv_h, int useBias, uint32_t salt)
 {
 	const uint32_t idx = p.idx ^ salt;
 	const int ia = (int)(idx & 0x1fffu), ib = (int)((idx >> 13) & 0x1fffu);
 	const int pointCount = (int)((idx >> 26) & 3u);
 	const float4 dqA = ldq[ia], dqB = ldq[ib];
-	const float4 sf = lcoef[(idx >> 30) & 1u];
-	const float4 velA = lvel[ia], velB = lvel[ib];
-	const float2 massA = lmass[ia], massB = lmass[ib];
+	const float biasCoefficient = lcoef[(idx >> 30) & 1u].x;
 	const V2 normal = v2(fromBits(asBits(p.n.x) ^ salt), p.n.y);
-	const V2 tangent = rightPerp(normal);
-	const float mA = massA.x, iA = massA.y, mB = massB.x, iB = massB.y;
 	const V2 dcA = v2(dqA.x, dqA.y), dcB = v2(dqB.x, dqB.y);
 	Rot qA, qB;
 	qA.s = dqA.z, qA.c = dqA.w, qB.s = dqB.z, qB.c = dqB.w;
+	WidePrep pre;
+	pre.soft = 0u;
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		pre.rA[j] = pre.rB[j] = v2(0.0f, 0.0f);
+		pre.bias[j] = 0.0f;
+		if (POINTS == 2 || j < pointCount)
+		{
+			const V2 rA = rotate(qA, asV2(p.lA[j])), rB = rotate(qB, asV2(p.lB[j]));
+			pre.rA[j] = rA, pre.rB[j] = rB;
+			const V2 ds = add(sub(dcB, dcA), sub(rB, rA));
+			const float s = dot(ds, normal) + p.p0[j];
+			// select form of: if (s > 0) bias = s * inv_h; else if (useBias) {bias = max(biasCoefficient * s, cap); ...}
+			const bool speculative = s > 0.0f;
+			const bool soft = !speculative && useBias != 0;
+			const float softBias = S2_MAXF(biasCoefficient * s, -S2_MAX_BAUMGARTE_VELOCITY);
+			pre.bias[j] = speculative ? s * inv_h : (soft ? softBias : 0.0f);
+			pre.soft |= soft ? 1u << j : 0u;
+		}
+	}
+	return pre;
+}
+
+template <int POINTS> S2_DEV void chainWide(WideRegs& p, const WidePrep& pre, float4* lvel, const float2* lmass, const float4* lcoef, uint32_t salt)
+{
+	const uint32_t idx = p.idx ^ salt;
+	const int ia = (int)(idx & 0x1fffu), ib = (int)((idx >> 13) & 0x1fffu);
+	const int pointCount = (int)((idx >> 26) & 3u);
+	const float4 velA = lvel[ia], velB = lvel[ib];
+	const float2 massA = lmass[ia], massB = lmass[ib];
+	const float4 sf = lcoef[(idx >> 30) & 1u];
+	const V2 normal = v2(fromBits(asBits(p.n.x) ^ salt), p.n.y);
+	const V2 tangent = rightPerp(normal);
+	const float mA = massA.x, iA = massA.y, mB = massB.x, iB = massB.y;
 	V2 vA = v2(velA.x, velA.y), vB = v2(velB.x, velB.y);
 	float wA = velA.z, wB = velB.z;
-	V2 rAj[2], rBj[2];
 	float nImp[2], tImp[2];
 
 #pragma unroll
@@ -295,16 +186,8 @@ S2_DEV void solveWide(WideRegs& p, float4* lvel, const float4* ldq, const float2
 	{
 		if (POINTS == 2 || j < pointCount)
 		{
-			const V2 rA = rotate(qA, asV2(p.lA[j])), rB = rotate(qB, asV2(p.lB[j]));
-			rAj[j] = rA, rBj[j] = rB;
-			const V2 ds = add(sub(dcB, dcA), sub(rB, rA));
-			const float s = dot(ds, normal) + p.p0[j];
-
-			// select form of: if (s > 0) bias = s * inv_h; else if (useBias) {bias = max(biasCoefficient * s, cap); ...}
-			const bool speculative = s > 0.0f;
-			const bool soft = !speculative && useBias != 0;
-			const float softBias = S2_MAXF(sf.x * s, -S2_MAX_BAUMGARTE_VELOCITY);
-			const float bias = speculative ? s * inv_h : (soft ? softBias : 0.0f);
+			const V2 rA = pre.rA[j], rB = pre.rB[j];
+			const bool soft = (pre.soft >> j) & 1u;
 			const float massScale = soft ? sf.y : 1.0f;
 			const float impulseScale = soft ? sf.z : 0.0f;
 
@@ -314,7 +197,7 @@ S2_DEV void solveWide(WideRegs& p, float4* lvel, const float4* ldq, const float2
 
 			const float normalMass = fromBits(asBits(p.p1[j]) ^ salt);
 			const float old = p.imp[j].x;
-			float impulse = -normalMass * massScale * (vn + bias) - impulseScale * old;
+			float impulse = -normalMass * massScale * (vn + pre.bias[j]) - impulseScale * old;
 			const float newImpulse = S2_MAXF(old + impulse, 0.0f);
 			impulse = newImpulse - old;
 			nImp[j] = newImpulse;
@@ -334,7 +217,7 @@ S2_DEV void solveWide(WideRegs& p, float4* lvel, const float4* ldq, const float2
 		if (POINTS == 2 || j < pointCount)
 		{
 			const float tangentMass = fromBits(asBits(p.p2[j]) ^ salt);
-			const V2 rA = rAj[j], rB = rBj[j];
+			const V2 rA = pre.rA[j], rB = pre.rB[j];
 			const V2 vrB = add(vB, crossSV(wB, rB));
 			const V2 vrA = add(vA, crossSV(wA, rA));
 			const float vt = dot(sub(vrB, vrA), tangent);
@@ -360,7 +243,6 @@ S2_DEV void solveWide(WideRegs& p, float4* lvel, const float4* ldq, const float2
 		lvel[ib] = make_float4(vB.x, vB.y, wB, 0.0f);
 	}
 }
-#endif
 
 S2_DEV void storeWide(const ContactView& c, const WideRegs& p, int k)
 {
@@ -382,7 +264,7 @@ template <int POINTS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideSte
 	const int tid = (int)threadIdx.x;
 	const int half = tid >> 8, ht = tid & 255; // hand-offs: waves 0-3 serve the left neighbour, waves 4-7 the right
 	// stamps: (wall_clock64 << 4) | tag; tags: 0 start, 1 loaded, 2 body stage, 3 warm start, 4 interior rounds, 5 hand-off, 6 seam rounds, 7 end
-	const bool stamp = S2_PERSIST_INSTRUMENTED && pv.debugTimes != nullptr && blockIdx.x == gridDim.x / 2 && tid == 0;
+	const bool stamp = S2_PERSIST_INSTRUMENTED && pv.debugTimes != nullptr && blockIdx.x == 8 * (gridDim.x / 16) + 3 && tid == 0;
 	int stamps = 0;
 	auto stampAt = [&](unsigned tag) {
 		if (stamp && stamps < 250)
@@ -391,8 +273,18 @@ template <int POINTS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideSte
 		}
 	};
 	stampAt(0);
-	const StripDesc* da = ta.descs + blockIdx.x;
-	const PersistDesc* pd = pv.descs + blockIdx.x;
+	// Strip <-> workgroup: consecutive strips on ONE XCD, so that a seam's two workgroups share an L2 (the dispatcher is observed
+	// to place block b on XCD b % 8: a speed assumption only, checked below).  XCD x runs blocks x, x + 8, ...; it takes the
+	// strips [start(x), start(x) + count(x)).
+	const int K = (int)gridDim.x;
+	const int xcd = (int)blockIdx.x & 7, lane8 = (int)blockIdx.x >> 3;
+	const int strip = S2_WIDE_XCD_AFFINE ? xcd * (K >> 3) + (xcd < (K & 7) ? xcd : (K & 7)) + lane8 : (int)blockIdx.x;
+	// does this strip's left / right neighbour run on my XCD (by the same map)?
+	const int firstOfXcd = xcd * (K >> 3) + (xcd < (K & 7) ? xcd : (K & 7));
+	const int countOfXcd = (K >> 3) + (xcd < (K & 7) ? 1 : 0);
+	const bool nearLeft = S2_WIDE_XCD_AFFINE && strip > firstOfXcd, nearRight = S2_WIDE_XCD_AFFINE && strip + 1 < firstOfXcd + countOfXcd;
+	const StripDesc* da = ta.descs + strip;
+	const PersistDesc* pd = pv.descs + strip;
 	const int bodyBase = da->bodyBase, nb = da->bodyCount, roundsA = da->batchCount;
 	int2 batchA[S2_STRIP_ROUNDS];
 #pragma unroll
@@ -416,6 +308,7 @@ template <int POINTS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideSte
 	const int nImpH = half ? nImp1 : nImp0, nExpH = pd->exportCount[half];
 	const int inH = pd->inBase[half], outH = pd->outBase[half];
 	const int impSlotH = nb + (half ? nImp0 : 0) + ht; // LDS slot of the import this thread receives
+	const bool nearH = half ? nearRight : nearLeft;
 
 	float4* lvel = lds;
 	float4* ldq = lds + nt;
@@ -652,29 +545,63 @@ template <int POINTS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideSte
 		}
 		else if (op.code == OP_SOLVE_SOFT)
 		{
-			// ---- interiors ----
+			// ---- interiors: round i's chain on half i & 1, while the other half prepares its round i + 1 (measured: 150 us per
+			// launch against 159 us with prep and chain back to back in the same lanes) ----
+			WidePrep pre;
+			if (half == 0 && kOfSlot(0) >= 0)
+			{
+				pre = prepWide<POINTS>(rA[0], ldq, lcoef, op.inv_h, op.useBias, salt);
+			}
 #pragma unroll
 			for (int i = 0; i < S2_STRIP_ROUNDS; ++i)
 			{
 				if (i < roundsA)
 				{
-					if ((i & 1) == half && kOfSlot(i >> 1) >= 0)
+					if ((i & 1) == half)
 					{
-						solveWide<POINTS>(rA[i >> 1], lvel, ldq, lmass, lcoef, op.inv_h, op.useBias, salt);
+						if (kOfSlot(i >> 1) >= 0)
+						{
+							chainWide<POINTS>(rA[i >> 1], pre, lvel, lmass, lcoef, salt);
+						}
+					}
+					else if (i + 1 < S2_STRIP_ROUNDS && kOfSlot((i + 1) >> 1) >= 0) // (my next round is i + 1)
+					{
+						pre = prepWide<POINTS>(rA[(i + 1) >> 1], ldq, lcoef, op.inv_h, op.useBias, salt);
 					}
 					__syncthreads();
+					if (S2_PERSIST_INSTRUMENTED && i + 1 < roundsA)
+					{
+						stampAt(8 + i);
+					}
 				}
 			}
 			stampAt(4);
 			// ---- symmetric exchange of the seam bodies' velocities (poses are replicated by the body stages) ----
 			epoch += 1;
 			const int par = (int)(epoch & 1u) * pv.parityStride;
-			const bool mute = (pv.debugSkip & 8) != 0 && blockIdx.x == 1; // fault injection: this workgroup stays silent
+			const bool mute = (pv.debugSkip & 8) != 0 && strip == 1; // fault injection: this workgroup stays silent
 			if (ht < nExpH && !mute)
 			{
 				const float4 v = lvel[expIdx];
 				gu64* p = gran + par + outH + 4 * ht;
-				putGranule(p + 0, epoch, v.x), putGranule(p + 1, epoch, v.y), putGranule(p + 2, epoch, v.z);
+				if (nearH)
+				{
+					putGranuleNear(p + 0, epoch, v.x), putGranuleNear(p + 1, epoch, v.y), putGranuleNear(p + 2, epoch, v.z);
+				}
+				else
+				{
+					putGranule(p + 0, epoch, v.x), putGranule(p + 1, epoch, v.y), putGranule(p + 2, epoch, v.z);
+				}
+			}
+			// the seam constraints' pose-dependent part, while the neighbours' bodies are in flight (poses never travel)
+			WidePrep preB[S2_WIDE_SEAM_ROUNDS];
+#pragma unroll
+			for (int i = 0; i < S2_WIDE_SEAM_ROUNDS; ++i)
+			{
+				if ((seamMask >> i) & 1u)
+				{
+					preB[i] = prepWide<POINTS>(rB[i], ldq, lcoef, op.inv_h, op.useBias, salt);
+				}
 			}
 			int fail = 0;
 			if (ht < nImpH)
@@ -703,9 +630,13 @@ template <int POINTS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideSte
 				{
 					if ((seamMask >> i) & 1u)
 					{
-						solveWide<POINTS>(rB[i], lvel, ldq, lmass, lcoef, op.inv_h, op.useBias, salt);
+						chainWide<POINTS>(rB[i], preB[i], lvel, lmass, lcoef, salt);
 					}
 					__syncthreads();
+					if (S2_PERSIST_INSTRUMENTED && i + 1 < roundsB)
+					{
+						stampAt(14 + i);
+					}
 				}
 			}
 			stampAt(6);

@@ -504,6 +504,7 @@ struct PersistView
 	unsigned int* error;	   // host-visible (pinned): set when a hand-off timed out
 	unsigned int* deviceError; // the same flag in device memory: what the step's epilogue launch checks
 	int parityStride; // granules between the two parities of a buffer
+	int censusBase;	  // granule of strip 0 in the per-launch XCD census (wide_kernel.hip): one granule per strip behind the two parities
 	int allTwoPoints; // every strip constraint has two manifold points
 	float4 softCoef[2]; // the step's two soft-coefficient triples (StepConsts.softCoef), set at launch
 	int wideRounds;	  // some strip has 7 or 8 interior colour batches: the ROUNDS == 8 kernel variant

@@ -377,7 +377,7 @@ struct Executor
 	bool widePlan(int kind, int warm) const
 	{
 		return s->optWide && s->persist.pairLanes && kind == SOFT_TGS && warm == WARM_CURRENT &&
-			   s->persist.ldsRecords + 2 + 2 * s->persistOpCount <= (160 * 1024) / 16;
+			   s->persist.ldsRecords + 3 + 2 * s->persistOpCount <= (160 * 1024) / 16;
 	}
 
 	// Can the plan run on the resident-island kernel (strip_kernel.hip: islandStepKernel)?  The soft contact drivers: body

@@ -1236,7 +1236,7 @@ do                                                                              
 			put(o2, exportSrc.data(), exportSrc.size() * sizeof(int));
 			put(o3, importIds.data(), importIds.size() * sizeof(int));
 			bool grewP = false;
-			s->granuleBytes = ((std::max<size_t>((size_t)2 * parityStride, 1) * sizeof(unsigned long long)) + 255) & ~size_t(255);
+			s->granuleBytes = ((std::max<size_t>((size_t)2 * parityStride + (size_t)K, 1) * sizeof(unsigned long long)) + 255) & ~size_t(255); // + one census granule per strip (wide_kernel.hip)
 			if ((rc = s->dPersist.ensure(blob.size(), &grewP)) != 0 || (rc = s->dGranules.ensure(s->granuleBytes, &grewP)) != 0)
 			{
 				return rc;
@@ -1260,6 +1260,7 @@ do                                                                              
 			pv.error = devError;
 			pv.deviceError = (unsigned int*)(base + o4);
 			pv.parityStride = parityStride;
+			pv.censusBase = 2 * parityStride;
 			// fresh buffers start from zero tags
 			HIP_TRY(hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, s->stream));
 			pv.wideRounds = maxRoundsA > S2_STRIP_ROUNDS ? 1 : 0;

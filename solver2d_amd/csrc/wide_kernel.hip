@@ -282,7 +282,16 @@ template <int POINTS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideSte
 	// does this strip's left / right neighbour run on my XCD (by the same map)?
 	const int firstOfXcd = xcd * (K >> 3) + (xcd < (K & 7) ? xcd : (K & 7));
 	const int countOfXcd = (K >> 3) + (xcd < (K & 7) ? 1 : 0);
-	const bool nearLeft = S2_WIDE_XCD_AFFINE && strip > firstOfXcd, nearRight = S2_WIDE_XCD_AFFINE && strip + 1 < firstOfXcd + countOfXcd;
+	const bool hopeLeft = S2_WIDE_XCD_AFFINE && strip > firstOfXcd, hopeRight = S2_WIDE_XCD_AFFINE && strip + 1 < firstOfXcd + countOfXcd;
+	// The census: every workgroup publishes the XCD it REALLY runs on (write-through, once per launch), and a seam takes the
+	// L2 path only when both of its workgroups have read the same id from each other -- results never depend on placement.
+	unsigned myXcc;
+	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(myXcc));
+	gu64* census = (gu64*)pv.granules + pv.censusBase;
+	if (S2_WIDE_XCD_AFFINE && tid == 0)
+	{
+		putGranule(census + strip, 1u, __uint_as_float(myXcc + 1u));
+	}
 	const StripDesc* da = ta.descs + strip;
 	const PersistDesc* pd = pv.descs + strip;
 	const int bodyBase = da->bodyBase, nb = da->bodyCount, roundsA = da->batchCount;
@@ -308,7 +317,7 @@ template <int POINTS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideSte
 	const int nImpH = half ? nImp1 : nImp0, nExpH = pd->exportCount[half];
 	const int inH = pd->inBase[half], outH = pd->outBase[half];
 	const int impSlotH = nb + (half ? nImp0 : 0) + ht; // LDS slot of the import this thread receives
-	const bool nearH = half ? nearRight : nearLeft;
+	const bool hopeH = half ? hopeRight : hopeLeft;
 
 	float4* lvel = lds;
 	float4* ldq = lds + nt;
@@ -317,7 +326,7 @@ template <int POINTS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideSte
 	float2* lmass = (float2*)(lds + 3 * nt + (nt + 3) / 4); // {invMass, invI} of every staged body, padded to records
 	const int bodyRecords = 3 * nt + (nt + 3) / 4 + (nt + 1) / 2;
 	Op* lops = (Op*)(lds + bodyRecords); // 2 records per op
-	float4* lcoef = lds + bodyRecords + 2 * opCount; // 2 records (the launch adds them to the size)
+	float4* lcoef = lds + bodyRecords + 2 * opCount; // 2 records + 1 for the census flags (the launch adds them to the size)
 
 	// ---- loads ----
 	uint32_t id[S2_WIDE_BODY_CHUNKS];
@@ -415,7 +424,27 @@ template <int POINTS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideSte
 			lmass[ldsIdx[ch]] = g.massInv[gi];
 		}
 	}
+	// the neighbours' census entries have had the whole load phase to land; a missing one only costs the fast path
+	int* lnear = (int*)(lcoef + 2);
+	if (ht == 0)
+	{
+		int near = 0;
+		if (hopeH)
+		{
+			gu64* g = census + (half ? strip + 1 : strip - 1);
+			for (int spins = 0; spins < 4096 && !near; ++spins)
+			{
+				const u64 x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if ((unsigned)(x >> 32) == 1u)
+				{
+					near = (unsigned)x == myXcc + 1u ? 1 : -1;
+				}
+			}
+		}
+		lnear[half] = near > 0 ? 1 : 0;
+	}
 	__syncthreads();
+	const bool nearH = lnear[half] != 0;
 	// the doubled contact hertz of a constraint with a static side (prepareContactsKernel<PREP_SOFT>; solve_common.c:219): the
 	// test of strip_kernel.hip unpackPersist, made once -- the masses do not change during a step
 	auto markStatic = [&](WideRegs& p) {
@@ -686,7 +715,7 @@ template <int POINTS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideSte
 void launchWideStep(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount)
 {
 	const dim3 grid((unsigned)a.groupCount), block(S2_WIDE_THREADS);
-	const size_t lds = (size_t)(pv.ldsRecords + 2) * sizeof(float4) + (size_t)opCount * sizeof(Op);
+	const size_t lds = (size_t)(pv.ldsRecords + 3) * sizeof(float4) + (size_t)opCount * sizeof(Op);
 	if (pv.allTwoPoints)
 	{
 		wideStepKernel<2><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);

@@ -1,0 +1,107 @@
+"""TEST INFRASTRUCTURE.  Drives the HOST side of the library (tests/hostcheck/_build/libs2amd_hostcheck.so: every translation
+unit compiled --cuda-host-only with ASan + UBSan, linked against hip_stub.cpp; kernels never run) through the paths whose
+index arithmetic the parity tests only see from the outside: structure builds of random worlds under every solver and option
+mix, strip / group / resident-island tables, created and destroyed contacts between solves (incremental placement, slack
+exhaustion, rebuilds), the order queries, the world chain's bookkeeping.  Run by tests/test_hostcheck.py in a child process
+with the ASan runtime preloaded; exits non-zero on the first sanitizer report (-fno-sanitize-recover, ASan's abort)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from solver2d_amd import hip, synthetic, wire  # noqa: E402
+from tests import common, fuzz_worlds  # noqa: E402
+from tests.test_gpu_incremental import _artificial_contact, _with_spare_slots  # noqa: E402
+
+
+def fuzz_solves(seeds):
+    n = 0
+    for seed in range(seeds):
+        rng = np.random.default_rng(1000 + seed)
+        world = fuzz_worlds.random_world(seed, n_bodies=int(rng.integers(30, 400)), n_contacts=int(rng.integers(40, 900)), n_joints=int(rng.integers(0, 40)))
+        with hip.Solver(0) as s:
+            s.set_option("strip_patience", 0)
+            mode = seed % 4
+            if mode == 1:
+                s.set_option("groups", 0)
+            elif mode == 2:
+                s.set_option("max_group_bodies", 48), s.set_option("strip_min_bodies", 0), s.set_option("strip_bodies", 12)
+                s.set_option("strips_any_solver", 1)
+            elif mode == 3:
+                s.set_option("max_group_bodies", 64), s.set_option("island_resident", int(rng.integers(0, 2)))
+            for name in wire.SOLVER_NAMES:
+                vel, pos = common.DEFAULT_ITERS[name]
+                params = wire.StepParams.make(name, 1.0 / 60.0, vel, pos, bool(rng.integers(0, 2)))
+                state = common.copy3(world)
+                s.solve(params, *state)
+                s.contact_order()
+                s.joint_order()
+                n += 1
+    return n
+
+
+def churn(solver_name, base, steps, options):
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+    rng = np.random.default_rng(7 + base)
+    spare_n = 400
+    pre = _with_spare_slots(synthetic.pyramid(base), spare_n)
+    n0 = len(pre[1]) - spare_n
+    pairs = {(min(a, b), max(a, b)) for a, b in zip(pre[1]["bodyA"][:n0].tolist(), pre[1]["bodyB"][:n0].tolist())}
+    free_slot = np.zeros(1, dtype=wire.contact_dtype)[0]
+    free_slot["bodyA"], free_slot["bodyB"], free_slot["constraintIndex"] = -1, -1, -1
+    with hip.Solver(0) as s:
+        for k, v in options.items():
+            s.set_option(k, v)
+        state = common.copy3(pre)
+        spare = list(range(n0, n0 + spare_n))
+        for step in range(steps):
+            for _ in range(int(rng.integers(0, 12))):
+                if spare:
+                    state[1][spare.pop(0)] = _artificial_contact(rng, state[0], pre[1][5], pairs)
+            for _ in range(int(rng.integers(0, 4))):
+                victim = int(rng.integers(0, n0))
+                if state[1][victim]["bodyA"] >= 0:
+                    state[1][victim] = free_slot
+                    spare.append(victim)
+            # manifolds lose and regain their points
+            flip = rng.integers(0, n0, size=8)
+            for f in flip:
+                if state[1][f]["bodyA"] >= 0:
+                    state[1][f]["pointCount"] = int(rng.integers(0, 3))
+            s.solve(params, *state)
+            s.contact_order()
+        return s.stats()["structureBuilds"]
+
+
+def world_chain(base, steps):
+    world = synthetic.pyramid_world(base)
+    keys = ("bodies", "contacts", "joints", "shapes", "pairs", "origins")
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    with hip.Solver(0) as s:
+        s.world_upload(*[world[k] for k in keys])
+        for _ in range(steps):
+            s.world_step(params)
+            s.world_find_pairs()
+        s.world_download(*[world[k] for k in keys])
+
+
+def main():
+    quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+    n = fuzz_solves(6 if quick else 40)
+    print("fuzz solves:", n)
+    for name, base, opts in (("TGS_Soft", 30, {"groups": 0, "strips": 0}), ("Jacobi", 30, {"groups": 0, "strips": 0}),
+                             ("TGS_Soft", 60, {"strip_patience": 2}), ("PGS_NGS_Block", 30, {"groups": 0, "strips": 0, "incremental": 1}),
+                             ("SoftStep", 40, {"strip_patience": 0, "max_group_bodies": 256})):
+        builds = churn(name, base, 6 if quick else 25, opts)
+        print("churn %s base %d: %d structure builds" % (name, base, builds))
+    world_chain(20 if quick else 60, 3 if quick else 8)
+    print("world chain ok")
+    print("HOSTCHECK OK")
+
+
+if __name__ == "__main__":
+    main()

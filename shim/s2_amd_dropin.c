@@ -1,0 +1,223 @@
+/* s2_amd_dropin.c -- the call sites of INTEGRATION.md section 1, supplied at LINK time: compiled together with an unmodified
+ * checkout of erincatto/solver2d and shim/s2_amd_binding.c by shim/Makefile into libsolver2d_amd.so, a library that exports
+ * the reference's whole public API (include/solver2d/solver2d.h:22-70 and the geometry / hull / distance / tree helpers) and
+ * whose s2World_Step runs on the MI355X.  Programs written against the public headers link against it unchanged.
+ *
+ * No reference source file is edited or copied.  The linker's --wrap reroutes the reference's own calls:
+ *   s2Solve_<Variant>(world, context)   (src/solvers.h:70-79, called by the switch in src/world.c:206-256)
+ *                                       -> s2amdBinding_Solve, mode "solver"
+ *   s2DestroyWorld                      (src/world.c:105-118)  -> the world's device state is released first
+ *   the setters and readers of the public API that touch state a resident world keeps in HBM -> s2amdBinding_Invalidate /
+ *                                       s2amdBinding_Sync first (velocities, forces, joint settings; manifolds, joint impulses)
+ * and s2World_Step itself is THIS file's function: shim/Makefile renames the reference's in the compiled world.o (objcopy;
+ * it stays reachable as s2World_Step_reference), exactly what a maintainer's three-line edit of src/world.c would do.
+ *
+ * Run-time switches (environment, read at the first step):
+ *   S2AMD_DROPIN   step (default): stage 3, the solve and stage 4 on the device, stage 1's pair query too (S2AMD_DEVICE_PAIRS=0:
+ *                  pair query on the host's trees); solver: only s2Solve_* on the device; off: the reference as it is.
+ *   S2AMD_LIBRARY  path of libs2amd.so (default: "libs2amd.so" beside this library, then the loader's search path)
+ *   S2AMD_DEVICE   HIP device ordinal (default 0)
+ * There is no CPU fallback: when the library or the GPU is missing the first step says so on stderr and aborts. */
+#define _GNU_SOURCE
+#include "s2_amd_binding.h"
+
+#include "solver2d/solver2d.h"
+#include "solvers.h"
+#include "world.h"
+
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+enum
+{
+	MODE_UNSET = -1,
+	MODE_OFF,
+	MODE_SOLVER,
+	MODE_STEP
+};
+static int s_mode = MODE_UNSET;
+
+static void openOnce(void)
+{
+	if (s_mode != MODE_UNSET)
+	{
+		return;
+	}
+	const char* m = getenv("S2AMD_DROPIN");
+	s_mode = (m && strcmp(m, "off") == 0) ? MODE_OFF : (m && strcmp(m, "solver") == 0) ? MODE_SOLVER : MODE_STEP;
+	if (s_mode == MODE_OFF)
+	{
+		return;
+	}
+	char beside[4096];
+	const char* path = getenv("S2AMD_LIBRARY");
+	if (path == NULL)
+	{
+		path = "libs2amd.so";
+		Dl_info info;
+		if (dladdr((void*)&openOnce, &info) && info.dli_fname)
+		{
+			const char* slash = strrchr(info.dli_fname, '/');
+			if (slash && (size_t)(slash - info.dli_fname) + 16 < sizeof(beside))
+			{
+				size_t n = (size_t)(slash - info.dli_fname) + 1;
+				memcpy(beside, info.dli_fname, n);
+				strcpy(beside + n, "libs2amd.so");
+				FILE* f = fopen(beside, "rb");
+				if (f)
+				{
+					fclose(f);
+					path = beside;
+				}
+			}
+		}
+	}
+	const char* dev = getenv("S2AMD_DEVICE");
+	int rc = s2amdBinding_Open(path, dev ? atoi(dev) : 0);
+	if (rc != 0)
+	{
+		fprintf(stderr, "libsolver2d_amd: cannot run on the GPU (s2amdBinding_Open(\"%s\") = %d: -1 library not found, -2 symbol missing, -3 no GPU, "
+						"-4 API version).  There is no CPU path in this build; set S2AMD_DROPIN=off for the reference's own solvers.\n",
+				path, rc);
+		abort();
+	}
+	const char* pairs = getenv("S2AMD_DEVICE_PAIRS");
+	s2amdBinding_DevicePairs(pairs ? atoi(pairs) != 0 : 1);
+}
+
+/* ---- src/world.c:120-301 ---- */
+void s2World_Step_reference(s2WorldId worldId, float timeStep, int velIters, int posIters, bool warmStart);
+void s2World_Step(s2WorldId worldId, float timeStep, int32_t velIters, int32_t posIters, bool warmStart)
+{
+	openOnce();
+	if (s_mode != MODE_STEP)
+	{
+		s2World_Step_reference(worldId, timeStep, velIters, posIters, warmStart); /* (mode "solver": its switch reaches the wraps below) */
+		return;
+	}
+	s2amdBinding_WorldStep(s2GetWorldFromId(worldId), timeStep, velIters, posIters, warmStart, s2UpdateBroadPhasePairs, s2BroadPhase_RebuildTrees);
+	if (s2amdBinding_LastError() != 0)
+	{
+		fprintf(stderr, "libsolver2d_amd: s2World_Step failed on the device (error %d)\n", s2amdBinding_LastError());
+		abort();
+	}
+}
+
+/* ---- src/solvers.h:70-79 ---- */
+#define S2_DROPIN_SOLVER(NAME, TYPE)                                                                                             \
+	void __real_##NAME(s2World* world, s2StepContext* context);                                                                  \
+	void __wrap_##NAME(s2World* world, s2StepContext* context)                                                                   \
+	{                                                                                                                            \
+		if (s_mode != MODE_SOLVER)                                                                                               \
+		{                                                                                                                        \
+			__real_##NAME(world, context);                                                                                       \
+			return;                                                                                                              \
+		}                                                                                                                        \
+		int rc = s2amdBinding_Solve(world, context, TYPE);                                                                       \
+		if (rc != 0)                                                                                                             \
+		{                                                                                                                        \
+			fprintf(stderr, "libsolver2d_amd: " #NAME " failed on the device (error %d)\n", rc);                                 \
+			abort();                                                                                                             \
+		}                                                                                                                        \
+	}
+S2_DROPIN_SOLVER(s2Solve_Jacobi, s2_solverJacobi)
+S2_DROPIN_SOLVER(s2Solve_PGS, s2_solverPGS)
+S2_DROPIN_SOLVER(s2Solve_PGS_NGS, s2_solverPGS_NGS)
+S2_DROPIN_SOLVER(s2Solve_PGS_NGS_Block, s2_solverPGS_NGS_Block)
+S2_DROPIN_SOLVER(s2Solve_PGS_Soft, s2_solverPGS_Soft)
+S2_DROPIN_SOLVER(s2Solve_SoftStep, s2_solverSoftStep)
+S2_DROPIN_SOLVER(s2Solve_TGS_Sticky, s2_solverTGS_Sticky)
+S2_DROPIN_SOLVER(s2Solve_TGS_Soft, s2_solverTGS_Soft)
+S2_DROPIN_SOLVER(s2Solve_TGS_NGS, s2_solverTGS_NGS)
+S2_DROPIN_SOLVER(s2Solve_XPBD, s2_solverXPBD)
+
+/* ---- src/world.c:105-118 ---- */
+void __real_s2DestroyWorld(s2WorldId id);
+void __wrap_s2DestroyWorld(s2WorldId id)
+{
+	if (s2amdBinding_IsOpen())
+	{
+		s2amdBinding_DestroyWorld(s2GetWorldFromId(id));
+	}
+	__real_s2DestroyWorld(id);
+}
+
+/* ---- readers of what a resident world keeps on the device: manifolds (drawn by s2World_Draw, src/world.c:369-563), joint impulses ---- */
+static void syncWorld(s2World* world)
+{
+	if (s_mode == MODE_STEP && s2amdBinding_IsOpen())
+	{
+		s2amdBinding_Sync(world);
+	}
+}
+static void editWorld(s2World* world)
+{
+	if (s_mode == MODE_STEP && s2amdBinding_IsOpen())
+	{
+		s2amdBinding_Sync(world); /* the edit lands on current host pools ... */
+		s2amdBinding_Invalidate(world); /* ... and the next step uploads them */
+	}
+}
+void __real_s2World_Draw(s2WorldId worldId, s2DebugDraw* debugDraw);
+void __wrap_s2World_Draw(s2WorldId worldId, s2DebugDraw* debugDraw)
+{
+	syncWorld(s2GetWorldFromId(worldId));
+	__real_s2World_Draw(worldId, debugDraw);
+}
+float __real_s2RevoluteJoint_GetMotorTorque(s2JointId jointId, float inverseTimeStep);
+float __wrap_s2RevoluteJoint_GetMotorTorque(s2JointId jointId, float inverseTimeStep)
+{
+	syncWorld(s2GetWorldFromIndex(jointId.world));
+	return __real_s2RevoluteJoint_GetMotorTorque(jointId, inverseTimeStep);
+}
+
+/* ---- setters: the host copy changes, the resident copy has to follow ---- */
+#define S2_DROPIN_EDIT(RET, NAME, ID_T, PARAMS, ARGS)                                                                            \
+	RET __real_##NAME PARAMS;                                                                                                    \
+	RET __wrap_##NAME PARAMS                                                                                                     \
+	{                                                                                                                            \
+		editWorld(s2GetWorldFromIndex(id.world));                                                                                \
+		__real_##NAME ARGS;                                                                                                      \
+	}
+S2_DROPIN_EDIT(void, s2Body_SetLinearVelocity, s2BodyId, (s2BodyId id, s2Vec2 v), (id, v))
+S2_DROPIN_EDIT(void, s2Body_SetAngularVelocity, s2BodyId, (s2BodyId id, float w), (id, w))
+S2_DROPIN_EDIT(void, s2Body_ApplyForceToCenter, s2BodyId, (s2BodyId id, s2Vec2 f), (id, f))
+S2_DROPIN_EDIT(void, s2Body_ApplyLinearImpulse, s2BodyId, (s2BodyId id, s2Vec2 impulse, s2Vec2 point), (id, impulse, point))
+S2_DROPIN_EDIT(void, s2MouseJoint_SetTarget, s2JointId, (s2JointId id, s2Vec2 target), (id, target))
+S2_DROPIN_EDIT(void, s2RevoluteJoint_EnableLimit, s2JointId, (s2JointId id, bool on), (id, on))
+S2_DROPIN_EDIT(void, s2RevoluteJoint_EnableMotor, s2JointId, (s2JointId id, bool on), (id, on))
+S2_DROPIN_EDIT(void, s2RevoluteJoint_SetMotorSpeed, s2JointId, (s2JointId id, float speed), (id, speed))
+
+/* what the demo / a profiler may ask: accumulated ms per phase of the whole-step binding, see s2_amd_binding.h */
+void s2amdDropin_Timing(double out[6])
+{
+	s2amdBinding_Timing(out);
+}
+
+/* a digest of every live body's position and rotation bits, pool order (tools/dropin_product_demo.c compares routes with it) */
+#include "body.h"
+#include "pool.h"
+unsigned long long s2amdDropin_StateDigest(s2WorldId worldId)
+{
+	s2World* world = s2GetWorldFromId(worldId);
+	syncWorld(world);
+	unsigned long long h = 1469598103934665603ull;
+	for (int i = 0; i < world->bodyPool.capacity; ++i)
+	{
+		const s2Body* b = world->bodies + i;
+		if (s2ObjectValid(&b->object) == false)
+		{
+			continue;
+		}
+		const float v[4] = {b->position.x, b->position.y, b->rot.s, b->rot.c};
+		unsigned int w[4];
+		memcpy(w, v, sizeof(w));
+		for (int k = 0; k < 4; ++k)
+		{
+			h = (h ^ w[k]) * 1099511628211ull;
+		}
+	}
+	return h;
+}

@@ -1,0 +1,94 @@
+"""The drop-in as a product artefact (shim/Makefile): libsolver2d_amd.so = an unmodified solver2d checkout + the binding +
+the link-time call sites of shim/s2_amd_dropin.c.  CPU: it builds without anything from oracle/, exports the reference's
+whole public API, and refuses loudly to step without the HIP library.  GPU: a C program written against the public headers
+(tools/dropin_product_demo.c) steps a world through it, every route ending in the same bits where they must."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "shim", "_build", "libsolver2d_amd.so")
+DEMO = os.path.join(ROOT, "tools", "dropin_product_demo.bin")
+HAVE_REF = os.path.exists("/root/reference/src/world.c")
+
+# include/solver2d/solver2d.h:22-70 ...
+PUBLIC_API = """s2CreateWorld s2DestroyWorld s2World_Step s2World_Draw s2World_GetStatistics s2CreateBody s2DestroyBody s2Body_GetPosition
+s2Body_GetAngle s2Body_GetLocalPoint s2Body_SetLinearVelocity s2Body_SetAngularVelocity s2Body_ApplyForceToCenter s2Body_ApplyLinearImpulse
+s2Body_GetType s2Body_GetMass s2CreateCircleShape s2CreateSegmentShape s2CreateCapsuleShape s2CreatePolygonShape s2Shape_GetBody s2Shape_TestPoint
+s2CreateMouseJoint s2CreateRevoluteJoint s2DestroyJoint s2MouseJoint_SetTarget s2RevoluteJoint_EnableLimit s2RevoluteJoint_EnableMotor
+s2RevoluteJoint_SetMotorSpeed s2RevoluteJoint_GetMotorTorque s2World_QueryAABB""".split()
+# ... and the non-inline helpers the samples use (geometry.h:82-108, hull.h:20, manifold.h:56-85, distance.h, dynamic_tree.h, math.h)
+HELPERS = """s2MakeBox s2MakeSquare s2MakeOffsetBox s2MakeCapsule s2MakePolygon s2ComputeHull s2ComputeCircleMass s2ComputeCapsuleMass s2ComputePolygonMass
+s2ComputeCircleAABB s2ComputeCapsuleAABB s2ComputePolygonAABB s2ComputeSegmentAABB s2PointInCircle s2PointInCapsule s2PointInPolygon
+s2CollideCircles s2CollideCapsuleAndCircle s2CollidePolygonAndCircle s2CollidePolygons s2ShapeDistance s2SegmentDistance s2MakeProxy
+s2DynamicTree_Create s2DynamicTree_Destroy s2DynamicTree_CreateProxy s2DynamicTree_DestroyProxy s2DynamicTree_MoveProxy s2DynamicTree_Query
+s2DynamicTree_RayCast s2DynamicTree_Rebuild s2IsValid s2IsValidVec2 s2Normalize""".split()
+
+
+@pytest.fixture(scope="module")
+def built():
+    if HAVE_REF:
+        out = subprocess.run(["make", "-n", "-B", "-C", os.path.join(ROOT, "shim")], stdout=subprocess.PIPE, check=True).stdout.decode()
+        assert "oracle" not in out and "tests/" not in out, "the product build must not need the test rig"
+        subprocess.check_call([os.path.join(ROOT, "tools", "dropin_product_demo.sh"), "build"])
+    if not os.path.exists(LIB):
+        pytest.skip("shim/_build/libsolver2d_amd.so is built where the reference checkout is (make -C shim REF=...)")
+    return LIB
+
+
+def test_exports_the_whole_public_api(built):
+    syms = set(re.findall(r" T (\w+)", subprocess.run(["nm", "-D", built], stdout=subprocess.PIPE, check=True).stdout.decode()))
+    missing = [n for n in PUBLIC_API + HELPERS if n not in syms]
+    assert not missing, missing
+    # the link-time call sites are inside: s2World_Step is the drop-in's, the reference's lives on under its other name
+    assert "s2World_Step_reference" in syms and "s2amdBinding_WorldStep" in syms
+    needed = subprocess.run(["ldd", built], stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert "oracle" not in needed and "s2ref" not in needed
+
+
+def test_the_patch_form_of_the_call_sites_applies_to_the_reference(tmp_path):
+    if not HAVE_REF:
+        pytest.skip("needs the reference checkout")
+    for d in ("src", "include"):
+        shutil.copytree(os.path.join("/root/reference", d), str(tmp_path / d))
+    patch = open(os.path.join(ROOT, "shim", "call_sites.patch"), encoding="latin-1").read()
+    assert not [l for l in patch.splitlines() if l.startswith("-") and not l.startswith("---")], "the patch only adds lines"
+    subprocess.run(["patch", "-p1", "-s"], input=patch.encode("latin-1"), cwd=str(tmp_path), check=True)
+    for f in ("shim/s2_amd_binding.c", "shim/s2_amd_binding.h", "include/solver2d_amd.h"):
+        shutil.copy(os.path.join(ROOT, f), str(tmp_path / "src"))
+    srcs = sorted(str(p) for p in (tmp_path / "src").glob("*.c"))
+    subprocess.check_call(["gcc", "-std=gnu17", "-O1", "-DNDEBUG", "-fPIC", "-w", "-I" + str(tmp_path / "include"), "-I" + str(tmp_path / "src"),
+                           "-shared", "-o", str(tmp_path / "libpatched.so")] + srcs + ["-lm", "-ldl"])
+
+
+def test_without_the_hip_library_the_first_step_fails_loudly(built):
+    if not os.path.exists(DEMO):
+        pytest.skip("demo binary not built")
+    env = dict(os.environ, S2AMD_DROPIN="step", S2AMD_LIBRARY="/nonexistent/libs2amd.so")
+    p = subprocess.run([DEMO, "10", "2", "pyramid", "7", "8", "4", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode != 0 and b"no CPU path" in p.stderr
+    # ... and the reference's own solvers are one switch away
+    p = subprocess.run([DEMO, "10", "2", "pyramid", "7", "8", "4", "1"], env=dict(os.environ, S2AMD_DROPIN="off"), stdout=subprocess.PIPE, check=True)
+    assert b"state digest" in p.stdout
+
+
+def _digest(env_extra, args):
+    env = dict(os.environ, S2AMD_LIBRARY=os.path.join(ROOT, "solver2d_amd", "libs2amd.so"), **env_extra)
+    out = subprocess.run([DEMO] + [str(a) for a in args], env=env, stdout=subprocess.PIPE, check=True).stdout.decode()
+    return re.search(r"state digest (\w+)", out).group(1), out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,base,solver,vel,pos", [("pyramid", 40, 7, 8, 4), ("mixed", 24, 3, 4, 2), ("tumbler", 300, 0, 4, 2), ("joint_grid", 20, 2, 4, 2)])
+def test_a_program_on_the_public_api_runs_on_the_gpu_through_the_product_library(built, scene, base, solver, vel, pos):
+    if not os.path.exists(DEMO):
+        pytest.skip("demo binary not built")
+    args = [base, 30, scene, solver, vel, pos, 10]
+    solver_only, _ = _digest({"S2AMD_DROPIN": "solver"}, args)
+    step_host_pairs, _ = _digest({"S2AMD_DROPIN": "step", "S2AMD_DEVICE_PAIRS": "0"}, args)
+    step_dev_pairs, out = _digest({"S2AMD_DROPIN": "step", "S2AMD_DEVICE_PAIRS": "1"}, args)
+    # the whole-step routes are the solver-only route's computation, bit for bit (same contact slots, same sweep order)
+    assert solver_only == step_host_pairs == step_dev_pairs, out

@@ -21,6 +21,11 @@ Extra objects on the JSON line:
                 average duration of one launch in steady state (launches enqueued back to back in a hipGraph and
                 bracketed by HIP events on the launch stream; see s2amd_measure_dominant); traffic: the PMC passes
                 under profiles/.
+  issue         what actually bounds the dominant kernel: VALU issue fraction and occupied CUs from the committed SQ counter
+                pass (profiles/rNN_*_pmc_sq.txt, separate rocprofv3 --pmc runs of this command) -- the kernels of this path
+                are instruction-issue / latency bound, not bandwidth bound, and the line says so next to `roofline`.
+  ranks_seen / devices   torch.distributed's world size and the PCI bus ids of the ranks' GPUs (all-gathered): `n_gpus` is
+                what was really there.  `--gpus N` without a launcher starts the N ranks itself (torch.distributed.run).
   cpu_baseline  the reference's own s2Solve_TGS_Soft timed on this host (oracle/_ref, kind
                 "reference") or, if that library is absent, the oracle port; 1 core.
   whole_step    (N = 1) the SURVEY.md 8d trajectory of config 2: the base-200 WORLD (shapes, pair states) resident, 60 settle
@@ -97,22 +102,57 @@ def cpu_baseline(base, vel, pos, budget_s):
                 steps, base, 1e3 * secs / steps, os.cpu_count())}
 
 
+def pmc_issue(kernel_prefixes, stem="persistent"):
+    """VALU-issue picture of the dominant kernel from the committed SQ pass (profiles/rNN_<stem>_pmc_sq.txt): VALU instructions
+    per wave, the fraction of the kernel's busy cycles in which a SIMD issued one, waves per launch.  None when absent."""
+    for rnd in ("r03", "r02"):
+        path = os.path.join(ROOT, "profiles", "%s_%s_pmc_sq.txt" % (rnd, stem))
+        try:
+            vals = {}
+            for l in open(path):
+                f = l.split()
+                if len(f) >= 4 and any(f[0].startswith(p) for p in kernel_prefixes) and f[1].startswith("SQ_"):
+                    vals.setdefault(f[1], float(f[3]))  # avg per launch
+            if "SQ_INSTS_VALU" in vals and "SQ_WAVES" in vals:
+                waves = vals["SQ_WAVES"]
+                out = {"valu_insts_per_wave": vals["SQ_INSTS_VALU"] / max(waves, 1.0), "waves_per_launch": waves,
+                       "source": "profiles/%s_%s_pmc_sq.txt (rocprofv3 --pmc SQ_*, separate passes of this command; not measured in this run)" % (rnd, stem)}
+                if "SQ_ACTIVE_INST_VALU" in vals and "SQ_BUSY_CYCLES" in vals:
+                    # both count per SE / per SIMD quad-cycles on gfx950: their ratio is the share of busy time a VALU instruction issued
+                    out["valu_issue_frac"] = vals["SQ_ACTIVE_INST_VALU"] / max(vals["SQ_BUSY_CYCLES"], 1.0)
+                return out
+        except OSError:
+            continue
+    return None
+
+
 def pmc_traffic_bytes(kernel_prefix, stem="persistent"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summaries (separate
     FETCH_SIZE / WRITE_SIZE passes of this same command, profiles/r01_persistent_pmc_*.txt): counters are in KiB;
     FETCH_SIZE is doubled per the gfx950 note in MI355X_MICROARCH.md (it reads half of a wide coalesced stream).
     None when the summaries are not there."""
-    for rnd in ("r02", "r01"):
+    prefixes = kernel_prefix if isinstance(kernel_prefix, (tuple, list)) else (kernel_prefix,)
+    for rnd in ("r03", "r02", "r01"):
         total = 0.0
         try:
             for name, scale in (("fetch", 2.0), ("write", 1.0)):
                 path = os.path.join(ROOT, "profiles", "%s_%s_pmc_%s_size.txt" % (rnd, stem, name))
-                rows = [l.split() for l in open(path) if l.startswith(kernel_prefix) and ("FETCH_SIZE" in l or "WRITE_SIZE" in l)]
+                rows = [l.split() for l in open(path) if l.startswith(tuple(prefixes)) and ("FETCH_SIZE" in l or "WRITE_SIZE" in l)]
                 total += scale * float(rows[0][3]) * 1024.0
             return total, "profiles/%s_%s_pmc_{fetch,write}_size.txt (rocprofv3 --pmc, separate passes of this command; not measured in this run)" % (rnd, stem)
         except (OSError, IndexError, ValueError):
             continue
     return None, None
+
+
+JOINT_BYTES_PER_ITER = 216.0  # a revolute joint sweep: frame, masses, pivot mass, soft coefficients, impulses, limits (120 B) + 2 x (36 B read, 12 B written)
+
+
+def step_roofline(algorithmic_bytes_per_step, seconds_per_step, model):
+    """Roofline object of a multi-launch step: algorithmic bytes of the whole step over its wall time (no single dominant launch)."""
+    achieved = algorithmic_bytes_per_step / max(seconds_per_step, 1e-12) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_step": algorithmic_bytes_per_step, "byte_model": model, "per": "step (all launches)"}
 
 
 ALGO_BYTES_LDS_PATH = 136.0  # SURVEY.md 8(d): per constraint-sweep when the body state is served from LDS (the group kernel)
@@ -168,7 +208,7 @@ def island_sharded_leg(ranks, islands, base, vel, pos, steps, warmup, graph=True
     # the group kernel runs the WHOLE step of its islands in one launch: constraint-sweeps per launch = mine * sweeps
     algo = ALGO_BYTES_LDS_PATH * mine * sweeps
     achieved = algo / max(us * 1e-6, 1e-12) / 1e9
-    return {
+    out_line = {
         "metric": "contact-constraints x iters/sec, %d independent base-%d pyramids TGS_Soft, islands sharded over the GPUs" % (islands, base),
         "value": C_total * sweeps * steps / elapsed, "unit": "constraint-iters/s", "n_gpus": ranks.world, "steps": steps, "warmup": warmup,
         "ms_per_step": 1e3 * elapsed / steps, "scaling": "strong",
@@ -186,9 +226,18 @@ def island_sharded_leg(ranks, islands, base, vel, pos, steps, warmup, graph=True
                                "LDS, records prepared from and impulses stored to the wire contacts by the kernel itself)", "avg_launch_us": us,
                      "algorithmic_bytes_per_launch": algo,
                      "byte_model": "136 B per constraint-sweep (SURVEY.md 8d, body state served from LDS) x %d constraints x %d sweeps" % (mine, sweeps),
-                     "note": "the contract's figure; what the kernel actually moves is one wire record per constraint and STEP (152 B in, 16 B per "
-                             "point out = %.2f GB), so it is VALU-issue bound, not bandwidth bound" % (mine * (152.0 + 32.0) / 1e9)},
+                     "note": "`frac` is the contract's byte MODEL over the kernel's time, not a bandwidth: the kernel reads one wire record per "
+                             "constraint and STEP (152 B in, 16 B per point out = %.2f GB) and keeps it in registers, so `traffic` (PMC) is a "
+                             "fraction of the model and the kernel is VALU-issue bound -- see `issue`" % (mine * (152.0 + 32.0) / 1e9)},
     }
+    line = out_line
+    traffic = line["roofline"]["traffic"]
+    if traffic:
+        line["roofline"]["traffic_gbs"] = traffic / max(us * 1e-6, 1e-12) / 1e9
+        line["roofline"]["traffic_frac_of_peak"] = line["roofline"]["traffic_gbs"] / HBM_PEAK_GBS
+        line["roofline"]["traffic_over_model"] = traffic / algo
+    line["issue"] = pmc_issue(("_Z16islandStepKernel",), "config5") if ranks.world == 1 and islands == 512 and base == 40 else None
+    return line
 
 
 def joint_grid_leg(device_index, steps, warmup):
@@ -218,7 +267,9 @@ def joint_grid_leg(device_index, steps, warmup):
     return {"workload": "JointGrid 100x100: %d bodies, %d revolute joints, s2_solverPGS_NGS 4/2" % (len(pre[0]), J), "unit": "joint-iters/s",
             "value": J * 6 * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "joint_colors": st["jointColors"],
             "kernel_launches_per_step": st["kernelLaunches"], "device_ms_per_step": st["deviceMs"],
-            "roofline": None, "roofline_note": "35 dependent launches of ~20k threads: launch-latency bound, no bandwidth figure is meaningful"}
+            "roofline": step_roofline(JOINT_BYTES_PER_ITER * J * 6, elapsed / steps, "%d B per joint-iteration (joint record 120 B + two bodies 36 B read, 12 B "
+                                      "written each) x %d joints x 6 sweeps" % (JOINT_BYTES_PER_ITER, J)),
+            "roofline_note": "%d dependent launches of ~20k threads per step: launch-latency bound (a dependent launch costs ~2-3 us)" % st["kernelLaunches"]}
 
 
 def tumbler_leg(device_index, count, settle, steps):
@@ -276,7 +327,9 @@ def tumbler_leg(device_index, count, settle, steps):
                                                                  int(((contacts["bodyA"] == 1) | (contacts["bodyB"] == 1))[contacts["pointCount"] > 0].sum())),
             "unit": "constraint-iters/s", "value": active * 6 * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
             "kernel_launches_per_step": st["kernelLaunches"], "device_ms_per_step": st["deviceMs"], "whole_loop_ms_per_step_tgs_soft": loop_ms,
-            "roofline": None, "roofline_note": "26 dependent launches per step over ~%d constraints: launch-latency bound" % active}
+            "roofline": step_roofline(ALGO_BYTES_PER_CONSTRAINT_SWEEP * active * 6, elapsed / steps, "232 B per constraint-sweep (SURVEY.md 8d) x %d active "
+                                      "constraints x 6 sweeps" % active),
+            "roofline_note": "%d dependent launches per step over ~%d constraints: launch-latency bound" % (st["kernelLaunches"], active)}
 
 
 def whole_step_leg(device_index, base, vel, pos, settle, steps):
@@ -341,8 +394,20 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="only the headline line (no whole_step / configs / island_sharded objects)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, RCCL) rather than
+        # report N GPUs from one process.  Any failure to get N ranks on N devices ends non-zero (below).
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world != max(args.gpus, 1):
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s): refusing to report a GPU count that is not there\n" % (args.gpus, world))
+        sys.exit(2)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     # test hooks (tests/test_gpu_bench.py): run the N > 1 logic on a box with ONE GPU over gloo
@@ -357,16 +422,26 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(device_index)
         dist.init_process_group(backend=backend)
-    n_gpus = max(args.gpus, 1)
-    if world > 1 and world != n_gpus:
-        n_gpus = world
+    # what is really there: the collective's own world size and every rank's GPU (PCI bus id), gathered
+    single_device_hook = os.environ.get("S2AMD_BENCH_SINGLE_DEVICE") == "1"
+    my_device = hip.device_bus_id(device_index if distributed else 0)
+    ranks_seen, devices = 1, [my_device]
+    if distributed:
+        ranks_seen = dist.get_world_size()
+        devices = [None] * ranks_seen
+        dist.all_gather_object(devices, my_device)
+        if ranks_seen != world or (len(set(devices)) != ranks_seen and not single_device_hook):
+            sys.stderr.write("bench.py: %d rank(s) on devices %s: not %d distinct GPUs\n" % (ranks_seen, devices, world))
+            dist.destroy_process_group()
+            sys.exit(3)
+    n_gpus = ranks_seen
     ranks = Ranks(dist if distributed else None, __import__("torch") if distributed else None, backend, rank, world, device_index if distributed else 0)
 
     if args.config == 5:
         # the island-sharded job as the line itself (strong scaling); the contract's keys, its own roofline
         line = island_sharded_leg(ranks, args.islands, args.island_base, args.vel_iters, args.pos_iters, args.steps, args.warmup,
                                   graph=not args.no_graph, dump=os.environ.get("S2AMD_BENCH_DUMP"))
-        line.update({"higher_is_better": True, "vs_baseline": None, "dtype": "f32", "data": "synthetic"})
+        line.update({"higher_is_better": True, "vs_baseline": None, "dtype": "f32", "data": "synthetic", "ranks_seen": ranks_seen, "devices": devices})
         if rank == 0:
             print(json.dumps(line))
         if distributed:
@@ -465,6 +540,10 @@ def main():
     avg_launch_s = max(avg_launch_us * 1e-6, 1e-12)
     achieved = ALGO_BYTES_PER_CONSTRAINT_SWEEP * constraints_per_launch / avg_launch_s / 1e9
     persistent = bool(gpu.stats().get("persistent", 0))
+    which = gpu.stats().get("pairLanes", 0)
+    kernel_prefix = {2: "_Z14wideStepKernel", 1: "_Z14pairStepKernel"}.get(which, "_Z15stripStepKernel")
+    kernel_name = {2: "wideStepKernel (wide_kernel.hip: 512 threads per strip)", 1: "pairStepKernel (pair_kernel.hip: two lanes per constraint)"}.get(
+        which, "stripStepKernel<SOFT_TGS> (strip_kernel.hip: 256 threads per strip)")
     # per-launch event pairs (eager launches), kept as a cross-check against rocprofv3's per-kernel durations
     prof_steps = 3
     gpu.set_option("profile", 1)
@@ -505,16 +584,26 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_bytes("_Z15stripStepKernel")[0] if persistent and args.base == 200 else None,
-                "traffic_source": pmc_traffic_bytes("_Z15stripStepKernel")[1] if persistent and args.base == 200 else None,
-                "kernel": "stripStepKernel<SOFT_TGS> (whole step, one persistent launch; constraints_per_launch counts "
-                          "constraint-sweeps)" if persistent else "solveContactsSoftKernel<SOFT_TGS> / stripSoftKernel<SOFT_TGS>",
+                "traffic": pmc_traffic_bytes(kernel_prefix)[0] if persistent and args.base == 200 else None,
+                "traffic_source": pmc_traffic_bytes(kernel_prefix)[1] if persistent and args.base == 200 else None,
+                "kernel": kernel_name + " -- whole step, one persistent launch; constraints_per_launch counts "
+                          "constraint-sweeps" if persistent else "solveContactsSoftKernel<SOFT_TGS> / stripSoftKernel<SOFT_TGS>",
                 "avg_launch_us": avg_launch_us, "launches_per_step": 1 if persistent else launches_per_sweep * sweeps,
                 "constraints_per_launch": constraints_per_launch,
                 "eager_event_pair_us_per_launch": 1e3 * kernel_ms / max(launches, 1), "empty_event_pair_us": overhead_ms * 1e3,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CONSTRAINT_SWEEP * constraints_per_launch,
             },
         }
+        out["ranks_seen"], out["devices"] = ranks_seen, devices
+        if persistent and args.base == 200:
+            issue = pmc_issue((kernel_prefix,))
+            if issue is not None:
+                issue["workgroups"] = st["stripCount"]
+                issue["cus_occupied_of_256"] = min(st["stripCount"], 256)
+                issue["note"] = ("one island, %d strips = %d of 256 CUs hold a workgroup; a colour round is one wave's instruction stream per SIMD (4 cycles per "
+                                 "instruction), %d dependent rounds per step: instruction-issue / latency bound, HBM idle" % (
+                                     st["stripCount"], min(st["stripCount"], 256), 24 * 8))
+            out["issue"] = issue
         if not args.no_cpu and world == 1:  # the contract: on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.base, args.vel_iters, args.pos_iters, args.cpu_seconds)
     gpu.close()
@@ -526,6 +615,8 @@ def main():
             out["island_sharded"] = sharded
             if world == 1:
                 out["whole_step"] = whole_step_leg(ranks.device_index, args.base, args.vel_iters, args.pos_iters, 60, 240)
+                # SURVEY.md 8d's trajectory figure (settled world, stage 3 -> solve -> stage 4 every step): the honest whole-step number
+                out["value_whole_step"] = out["whole_step"]["value_whole_step"]
                 out["configs"] = {"3_tumbler": tumbler_leg(ranks.device_index, 10000, 120, 100),
                                   "4_joint_grid": joint_grid_leg(ranks.device_index, 100, 20),
                                   "5_one_gpu": {k: sharded[k] for k in ("value", "unit", "ms_per_step", "config", "roofline")}}

@@ -173,6 +173,8 @@ typedef struct s2amdSolver s2amdSolver;
 /* ---- lifecycle ---- */
 int s2amd_api_version(void);
 int s2amd_device_count(void);
+/* (API 2) PCI bus id of HIP device `device` ("0000:05:00.0"): what tells two ranks' GPUs apart (bench.py: ranks_seen / devices). */
+int s2amd_device_bus_id(int device, char* out, int32_t capacity);
 const char* s2amd_last_error(void);
 /* device: HIP ordinal.  Fails with S2AMD_E_NODEVICE when no GPU is visible. */
 int s2amd_create(int device, s2amdSolver** out);

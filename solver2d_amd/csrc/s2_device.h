@@ -509,6 +509,7 @@ struct PersistView
 	float4 softCoef[2]; // the step's two soft-coefficient triples (StepConsts.softCoef), set at launch
 	int wideRounds;	  // some strip has 7 or 8 interior colour batches: the ROUNDS == 8 kernel variant
 	int seamRegs;	  // no seam has more than two colour batches: the seam constraints stay in registers (SEAMREG variant)
+	int maxRoundsA, maxSeamRounds; // the most interior colour batches of a strip / colour batches of a seam
 	int pairLanes;	  // the partition fits pair_kernel.hip: pairStepKernel (<= 6 interior batches per strip, <= 2 per seam)
 	int ldsRecords;
 	int debugSkip; // timing experiments only (results are wrong; compiled in with -DS2_PERSIST_INSTRUMENTED=1): 1 = no hand-offs, 2 = no seam rounds, 4 = no interior rounds;

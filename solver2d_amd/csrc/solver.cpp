@@ -61,6 +61,20 @@ int s2amd_device_count(void)
 	return n;
 }
 
+int s2amd_device_bus_id(int device, char* out, int32_t capacity)
+{
+	if (!out || capacity < 16)
+	{
+		return fail(S2AMD_E_INVALID, "bad argument");
+	}
+	if (device < 0 || device >= s2amd_device_count())
+	{
+		return fail(S2AMD_E_INVALID, "device ordinal out of range");
+	}
+	HIP_TRY(hipDeviceGetPCIBusId(out, capacity, device));
+	return S2AMD_OK;
+}
+
 int s2amd_create(int device, s2amdSolver** out)
 {
 	if (!out)
@@ -750,6 +764,11 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	{
 		s->optPairLanes = value != 0;
 		s->structureDirty = true; // (re-captures the step graph)
+	}
+	else if (strcmp(key, "strip_slack") == 0)
+	{
+		s->optStripSlack = value != 0;
+		s->structureDirty = true;
 	}
 	else if (strcmp(key, "strip_retry") == 0)
 	{

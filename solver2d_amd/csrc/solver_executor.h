@@ -376,7 +376,7 @@ struct Executor
 	// warm start on a partition with at most six interior colour batches per strip and two per seam.
 	bool widePlan(int kind, int warm) const
 	{
-		return s->optWide && s->persist.pairLanes && kind == SOFT_TGS && warm == WARM_CURRENT &&
+		return s->optWide && ((s->persist.maxRoundsA <= 6 && s->persist.maxSeamRounds <= 3) || (s->persist.maxRoundsA <= 8 && s->persist.maxSeamRounds <= 2)) && kind == SOFT_TGS && warm == WARM_CURRENT &&
 			   s->persist.ldsRecords + 3 + 2 * s->persistOpCount <= (160 * 1024) / 16;
 	}
 

@@ -130,6 +130,167 @@ void adjRemove(Patcher& p, int body, int key)
 	}
 }
 
+// ---- strips (solver_internal.h: IncrementalStrips) ----
+
+// where a constraint between bodies a and b would live in the strips: table (0 interior, 1 seam), group, the bodies' local slots
+static bool stripHomeWhy(const s2amdSolver* s, int a, int b, int& table, int& group, int& la, int& lb, const char*& why);
+bool stripHome(const s2amdSolver* s, int a, int b, int& table, int& group, int& la, int& lb)
+{
+	const char* why = "";
+	const bool ok = stripHomeWhy(s, a, b, table, group, la, lb, why);
+	static const bool debug = getenv("S2AMD_DEBUG_PLACE") != nullptr;
+	if (!ok && debug)
+	{
+		const IncrementalStrips& m = s->stripInc;
+		fprintf(stderr, "[s2amd] no strip home for (%d, %d): %s (strips %d, %d)\n", a, b, why, m.ownerStrip[(size_t)a], m.ownerStrip[(size_t)b]);
+	}
+	return ok;
+}
+static bool stripHomeWhy(const s2amdSolver* s, int a, int b, int& table, int& group, int& la, int& lb, const char*& why)
+{
+	const IncrementalStrips& m = s->stripInc;
+	const int sa = writable(s, a) ? m.ownerStrip[(size_t)a] : -1, sb = writable(s, b) ? m.ownerStrip[(size_t)b] : -1;
+	if (sa < 0 && sb < 0)
+	{
+		why = "no strip owns either body";
+		return false;
+	}
+	if (sa >= 0 && sb >= 0 && sa != sb)
+	{
+		// the two sides of a seam: both bodies must already be in its body list (the exchange carries exactly those)
+		if (sa - sb != 1 && sb - sa != 1)
+		{
+			why = "strips not adjacent";
+			return false;
+		}
+		const int sm = std::min(sa, sb);
+		if (sm >= (int)m.seamGroupOf.size() || m.seamGroupOf[(size_t)sm] < 0)
+		{
+			why = "no seam group";
+			return false;
+		}
+		table = 1, group = m.seamGroupOf[(size_t)sm];
+		const auto& slots = m.seamSlot[(size_t)group];
+		const auto ia = slots.find(a), ib = slots.find(b);
+		if (ia == slots.end() || ib == slots.end())
+		{
+			why = "a body is not in the seam's body list";
+			return false;
+		}
+		la = ia->second, lb = ib->second;
+		return true;
+	}
+	// an interior constraint of the strip that owns the writable side(s); a read-only body must have its replica there already
+	table = 0, group = sa >= 0 ? sa : sb;
+	auto slotIn = [&](int body, int owner, int& out) {
+		if (owner >= 0)
+		{
+			out = m.ownerSlot[(size_t)body];
+			return true;
+		}
+		if (writable(s, body))
+		{
+			why = "a writable body no strip owns";
+			return false; // (it would have to join the island)
+		}
+		const auto& rep = m.replicaSlot[(size_t)group];
+		const auto it = rep.find(body);
+		if (it == rep.end())
+		{
+			why = "read-only body without a replica in the strip";
+			return false;
+		}
+		out = it->second;
+		return true;
+	};
+	return slotIn(a, sa, la) && slotIn(b, sb, lb);
+}
+
+bool stripPlace(s2amdSolver* s, Patcher& p, const ContactChange& ch)
+{
+	IncrementalStrips& m = s->stripInc;
+	int table, group, la, lb;
+	if (!m.valid || ch.slot >= (int)m.positionOfSlot.size() || m.positionOfSlot[(size_t)ch.slot] >= 0 || !stripHome(s, ch.a, ch.b, table, group, la, lb))
+	{
+		return false;
+	}
+	const int off = m.bodyOffset[table][(size_t)group];
+	const bool wa = writable(s, ch.a), wb = writable(s, ch.b);
+	const uint32_t used = (wa ? m.roundMask[table][(size_t)(off + la)] : 0u) | (wb ? m.roundMask[table][(size_t)(off + lb)] : 0u);
+	const int r0 = m.firstRound[table][(size_t)group], n = m.roundCount[table][(size_t)group];
+	for (int r = 0; r < n; ++r)
+	{
+		IncrementalStrips::Round& round = m.rounds[(size_t)(r0 + r)];
+		if (((used >> r) & 1u) != 0 || round.freePositions.empty())
+		{
+			continue;
+		}
+		const int k = round.freePositions.back();
+		round.freePositions.pop_back();
+		if (wa)
+		{
+			m.roundMask[table][(size_t)(off + la)] |= 1u << r;
+		}
+		if (wb)
+		{
+			m.roundMask[table][(size_t)(off + lb)] |= 1u << r;
+		}
+		s->contacts.order[(size_t)k] = ch.slot;
+		s->contacts.local[(size_t)k] = make_int2(la, lb);
+		m.positionOfSlot[(size_t)ch.slot] = k;
+		s->inc.positionOfSlot[(size_t)ch.slot] = -2;
+		p.word(s->dContactIndex.p, (size_t)k, (uint32_t)ch.slot);
+		p.word(s->dContactLocal.p, 2 * (size_t)k, (uint32_t)la);
+		p.word(s->dContactLocal.p, 2 * (size_t)k + 1, (uint32_t)lb);
+		m.touched = true;
+		m.placed += 1;
+		s->placedTotal += 1;
+		s->slackPositions -= 1;
+		return true;
+	}
+	static const bool debug = getenv("S2AMD_DEBUG_PLACE") != nullptr;
+	if (debug)
+	{
+		fprintf(stderr, "[s2amd] no free round for (%d, %d) in table %d group %d: rounds %d, used mask %x\n", ch.a, ch.b, table, group, n, used);
+	}
+	return false; // every round is taken on these bodies, or full
+}
+
+// the entry of `slot` in the strips becomes a free position again
+bool stripRemove(s2amdSolver* s, Patcher& p, int slot)
+{
+	IncrementalStrips& m = s->stripInc;
+	if (!m.valid || slot >= (int)m.positionOfSlot.size() || m.positionOfSlot[(size_t)slot] < 0)
+	{
+		return false;
+	}
+	const int k = m.positionOfSlot[(size_t)slot];
+	IncrementalStrips::Round& round = m.rounds[(size_t)m.roundOfPosition[(size_t)(k - m.base)]];
+	const int off = m.bodyOffset[round.table][(size_t)round.group];
+	const int2 l = s->contacts.local[(size_t)k];
+	const int oa = s->hContactA[(size_t)slot], ob = s->hContactB[(size_t)slot]; // the endpoints the structure knows
+	if (oa >= 0 && oa < (int)s->hBodyFlags.size() && writable(s, oa))
+	{
+		m.roundMask[round.table][(size_t)(off + l.x)] &= ~(1u << round.round);
+	}
+	if (ob >= 0 && ob < (int)s->hBodyFlags.size() && writable(s, ob))
+	{
+		m.roundMask[round.table][(size_t)(off + l.y)] &= ~(1u << round.round);
+	}
+	s->contacts.order[(size_t)k] = -1;
+	s->contacts.local[(size_t)k] = make_int2(0, 0);
+	p.word(s->dContactIndex.p, (size_t)k, (uint32_t)-1);
+	p.word(s->dContactLocal.p, 2 * (size_t)k, 0u);
+	p.word(s->dContactLocal.p, 2 * (size_t)k + 1, 0u);
+	std::vector<int>& fp = round.freePositions;
+	fp.insert(std::upper_bound(fp.begin(), fp.end(), k, std::greater<int>()), k); // stays descending
+	m.positionOfSlot[(size_t)slot] = -1;
+	s->inc.positionOfSlot[(size_t)slot] = -1;
+	m.touched = true;
+	s->slackPositions += 1;
+	return true;
+}
+
 } // namespace
 
 // the entry of `slot` leaves the structure; false: it cannot (not in a parallel batch of the global part)
@@ -138,6 +299,10 @@ static bool removeEntry(s2amdSolver* s, Patcher& p, int slot)
 	IncrementalGlobal& inc = s->inc;
 	const int W = 4;
 	const int kOld = inc.positionOfSlot[(size_t)slot];
+	if (kOld == -2 && stripRemove(s, p, slot))
+	{
+		return true;
+	}
 	if (kOld < 0)
 	{
 		return kOld == -1; // -1: no entry (nothing to do); -2: it lives in an LDS group or a strip
@@ -208,6 +373,7 @@ bool incrementalApply(s2amdSolver* s, const std::vector<ContactChange>& changes)
 	Patcher p{s, inc};
 	SweepSet& cs = s->contacts;
 	const int W = 4;
+	inc.placedInGlobalPart = false;
 	for (const ContactChange& ch : changes)
 	{
 		if (ch.slot < 0 || ch.slot >= (int)inc.positionOfSlot.size())
@@ -231,8 +397,16 @@ bool incrementalApply(s2amdSolver* s, const std::vector<ContactChange>& changes)
 		}
 		if ((s->hBodyFlagsFinal[(size_t)ch.a] & S2F_IN_GROUP) != 0 || (s->hBodyFlagsFinal[(size_t)ch.b] & S2F_IN_GROUP) != 0)
 		{
-			return giveUp("body owned by a group or strip"); // an LDS group or a strip owns the body: its tables are not placeable into
+			// a strip owns a body: a free position of one of its rounds (IncrementalStrips); an LDS group's tables are not placeable into
+			if (stripPlace(s, p, ch))
+			{
+				inc.inserted += 1;
+				unwatchSlot(s, ch.slot); // structural from here on: its manifold may gain and lose points at no cost
+				continue;
+			}
+			return giveUp("body owned by a group or strip");
 		}
+		inc.placedInGlobalPart = true;
 		const bool wa = writable(s, ch.a), wb = writable(s, ch.b);
 		int chosen = -1;
 		for (int bi = 0; bi < inc.parallelBatches; ++bi)
@@ -384,6 +558,22 @@ bool canDeferCreated(const s2amdSolver* s, int slot, int a, int b)
 	const bool owned = ((s->hBodyFlagsFinal[(size_t)a] | s->hBodyFlagsFinal[(size_t)b]) & S2F_IN_GROUP) != 0;
 	const bool hub = (int)s->hBodyHub.size() == nb && (s->hBodyHub[(size_t)a] || s->hBodyHub[(size_t)b]);
 	return owned || hub;
+}
+
+// a watched manifold between these bodies got its first points: can it take a place in the strips (instead of a rebuild)?
+bool stripCanPlace(const s2amdSolver* s, int a, int b)
+{
+	const int nb = (int)s->hBodyFlagsFinal.size();
+	if (!s->stripInc.valid || s->structureDirty || a < 0 || b < 0 || a >= nb || b >= nb || a == b)
+	{
+		return false;
+	}
+	if ((int)s->hBodyHub.size() == nb && (s->hBodyHub[(size_t)a] || s->hBodyHub[(size_t)b]))
+	{
+		return false;
+	}
+	int table, group, la, lb;
+	return stripHome(s, a, b, table, group, la, lb);
 }
 
 void deferCreated(s2amdSolver* s, int slot, int a, int b)

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 // sets the thread's last error text and returns `code` (solver.cpp)
@@ -179,6 +180,37 @@ struct IncrementalGlobal
 	// patch list of the current call: {address lo, address hi, value, 0}
 	std::vector<uint4> patches;
 	long inserted = 0, removed = 0, fallbacks = 0;
+	bool placedInGlobalPart = false; // the last incrementalApply put something into a colour batch of the global part (not only into strips)
+};
+
+// Created contacts in the STRIPS of a big island (the persistent step kernels' tables).  A colour round of a strip or seam is a
+// range of positions k, one per lane; the ranges are laid out with slack (free positions: contactIndex -1, an empty record, a
+// lane that does nothing), so a created contact between two bodies one strip owns -- or between the two sides of a seam whose
+// body lists already hold both -- is given a free position of a round that is unused on both bodies: three patched words
+// (contactIndex[k], localBodies[k]), no table rebuilt, the persistent kernel keeps running.  Anything else (a body that joins
+// the island, bodies of non-adjacent strips, a round or colour short) is a rebuild.
+struct IncrementalStrips
+{
+	bool valid = false;
+	bool touched = false; // something was placed or removed since the build: the multi-launch strip tables (warm-start slots) are stale
+	int base = 0, end = 0; // [base, end): the strips' positions in contacts.order
+	struct Round
+	{
+		int table, group, round; // table 0: strip interiors (hStripA), 1: seams (hStripB)
+		std::vector<int> freePositions; // descending: pop_back() hands out the lowest
+	};
+	std::vector<Round> rounds;
+	std::vector<int> roundOfPosition;	// [end - base] -> index into rounds
+	std::vector<int> firstRound[2];		// per group: its round 0 in `rounds`
+	std::vector<int> roundCount[2];
+	std::vector<int> ownerStrip, ownerSlot; // per body: the strip that owns it and its local slot there, -1
+	std::vector<std::unordered_map<int, int>> replicaSlot; // per strip: read-only body -> local slot
+	std::vector<std::unordered_map<int, int>> seamSlot;	   // per seam group: body -> local slot
+	std::vector<int> seamGroupOf;		// seam between strips i and i + 1 -> seam group, -1
+	std::vector<uint32_t> roundMask[2]; // per (body offset of the group + local slot): rounds in use on a writable body
+	std::vector<int> bodyOffset[2];		// per group: its first entry in roundMask
+	std::vector<int> positionOfSlot;	// contact slot -> strip position, -1
+	long placed = 0;
 };
 
 struct s2amdSolver
@@ -306,6 +338,8 @@ struct s2amdSolver
 	int optPersist = 1;
 	int optSeamRegs = 1;
 	int optWide = 1;	  // TGS_Soft's persistent step on 512 threads per strip (wide_kernel.hip) where the partition fits
+	IncrementalStrips stripInc;
+	int optStripSlack = 1; // strip and seam rounds are laid out with free positions for created contacts (solver_incremental.cpp)
 	int optPairLanes = 0; // two lanes per constraint (pair_kernel.hip; measured no faster: kept as an option); 0: one lane per constraint
 	int optStripRetry = 1; // try other strip widths when the partition needs the 8-round kernel variant
 	bool stripRetryPending = false; // ... postponed until the graph has been quiet for 32 steps
@@ -429,6 +463,7 @@ bool canDeferCreated(const s2amdSolver* s, int slot, int a, int b);
 void deferCreated(s2amdSolver* s, int slot, int a, int b);
 void unwatchSlot(s2amdSolver* s, int slot);
 int uploadWatched(s2amdSolver* s);
+bool stripCanPlace(const s2amdSolver* s, int a, int b);
 bool incrementalApply(s2amdSolver* s, const std::vector<ContactChange>& changes);
 // Destroyed contacts give their place back (colour, position, list entries) where the entry is in the global part's
 // parallel batches; elsewhere (LDS group, strip, sequential tail) the entry lingers as a no-op until the next rebuild.

@@ -98,6 +98,8 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 	std::vector<ContactChange> deferred; // created without points where nothing can be placed: watched, not structural (optDefer)
 	std::vector<ContactChange> flipped;	 // watched manifolds with their first points, under a structure built for s2Solve_Jacobi
 	const bool placeFlips = s->inc.valid && s->inc.ignoreColours && s->optIncremental != 0 && !s->structureDirty && !newWorld;
+	// ... and under the soft contact solvers' strips a flipped manifold takes a free position of a strip or seam round where it fits
+	const bool stripFlips = s->inc.valid && s->stripInc.valid && s->optIncremental != 0 && !s->structureDirty && !newWorld;
 	bool hubTouched = false;			// something happened to a contact on a hub body: decided by a rebuild
 	for (int i = 0; i < nc; ++i)
 	{
@@ -136,8 +138,8 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 			deferred.push_back(ContactChange{i, c.bodyA, c.bodyB});
 			continue;
 		}
-		if (edge && pc > 0 && placeFlips && (!s->hContactEdge[i] || s->hContactA[i] != c.bodyA || s->hContactB[i] != c.bodyB) &&
-			canDeferCreated(s, i, c.bodyA, c.bodyB))
+		if (edge && pc > 0 && (placeFlips || (stripFlips && stripCanPlace(s, c.bodyA, c.bodyB))) &&
+			(!s->hContactEdge[i] || s->hContactA[i] != c.bodyA || s->hContactB[i] != c.bodyB) && canDeferCreated(s, i, c.bodyA, c.bodyB))
 		{
 			// created AND touching at first sight (the caller ran stage 3 itself): the world chain, which sees the contact created
 			// without points and its manifold gain them in its own stage 3, watches it first and places it with the flips --
@@ -155,7 +157,7 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 		if (edge && !s->hContactWatched.empty() && s->hContactWatched[(size_t)i] && (oldPoints > 0) != (pc > 0))
 		{
 			// a watched manifold (on a hub body, or deferred) gained or lost its points (solver_internal.h: hContactWatched)
-			if (placeFlips)
+			if (placeFlips || (stripFlips && stripCanPlace(s, c.bodyA, c.bodyB)))
 			{
 				if (pc > 0 && i < (int)s->inc.positionOfSlot.size() && s->inc.positionOfSlot[(size_t)i] == -1)
 				{
@@ -165,6 +167,7 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 			else
 			{
 				hubTouched = true;
+				s->dirtyReason = "watched manifold flipped";
 			}
 		}
 		if (!edge && s->hContactEdge[i])
@@ -190,7 +193,10 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 		}
 		if (placed)
 		{
-			noteGraphTouched(s);
+			if (s->inc.placedInGlobalPart)
+			{
+				noteGraphTouched(s);
+			}
 		}
 		else
 		{
@@ -209,7 +215,10 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 		{
 			if (incrementalApply(s, flipped))
 			{
-				noteGraphTouched(s);
+				if (s->inc.placedInGlobalPart)
+				{
+					noteGraphTouched(s); // (a place in the strips leaves the strips where they are)
+				}
 			}
 			else
 			{
@@ -381,6 +390,21 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 		{
 			s->stripsRejected = true;
 			s->structureDirty = true;
+			if ((rc = buildStructure(s, params->solverType)) != 0)
+			{
+				return rc;
+			}
+		}
+	}
+	{
+		// contacts were placed into the strips' rounds (IncrementalStrips): only the persistent kernels read nothing else; the
+		// multi-launch strip path (warm-start slot tables) needs the structure built again
+		Executor probe{s, s->stream, plan, isPositionSolver(params->solverType) ? 1 : 0, false};
+		int kind, warm;
+		if (s->stripInc.touched && s->dStripA.view.groupCount > 0 && !probe.persistPlan(kind, warm))
+		{
+			s->structureDirty = true;
+			s->dirtyReason = "strips with placed contacts off the persistent kernel";
 			if ((rc = buildStructure(s, params->solverType)) != 0)
 			{
 				return rc;

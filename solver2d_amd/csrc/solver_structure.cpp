@@ -57,7 +57,7 @@ bool stripsAllTwoPoints(const s2amdSolver* s)
 	}
 	for (int k = s->persistK0; k < s->persistK1; ++k)
 	{
-		if (s->hContactPoints[(size_t)s->contacts.order[(size_t)k]] != 2)
+		if (s->contacts.order[(size_t)k] >= 0 && s->hContactPoints[(size_t)s->contacts.order[(size_t)k]] != 2) // (-1: a free position)
 		{
 			return false;
 		}
@@ -195,7 +195,7 @@ struct EdgeList
 // rebuild (IncrementalGlobal, solver_incremental.cpp).  *positions then has -1 at the free positions.
 void colourPart(const std::vector<int>& ids, const std::vector<int>& ea, const std::vector<int>& eb, const std::vector<uint8_t>& conflict,
 				int bodyCount, SweepSet& set, std::vector<int>& batchOffsetsOut, bool& hasTailOut, std::vector<int>* positions, int balanced = 0,
-				IncrementalGlobal* inc = nullptr, int spareColours = 0, int slackShift = 0, bool colourless = false)
+				IncrementalGlobal* inc = nullptr, int spareColours = 0, int slackShift = 0, bool colourless = false, int roundSlack = 0)
 {
 	std::vector<int> color, partOrder, partOffsets;
 	int cc;
@@ -277,6 +277,36 @@ void colourPart(const std::vector<int>& ids, const std::vector<int>& ea, const s
 			batchOffsetsOut.push_back(base + (int)laidOut.size());
 		}
 		inc->colorOfPosition.resize((size_t)base + laidOut.size(), -1);
+		for (int p : laidOut)
+		{
+			set.order.push_back(p >= 0 ? ids[(size_t)p] : -1);
+		}
+		if (positions)
+		{
+			*positions = laidOut;
+		}
+		return;
+	}
+	if (roundSlack > 0 && balanced > 0 && !hasTailOut)
+	{
+		// a strip's or seam's rounds with free positions behind the constraints of every colour (IncrementalStrips): a round
+		// stays one pass of the workgroup, so its range never exceeds `balanced` positions
+		std::vector<int> laidOut;
+		batchOffsetsOut.clear();
+		for (int c = 0; c < cc; ++c)
+		{
+			const int n = partOffsets[(size_t)c + 1] - partOffsets[c];
+			if (n <= 0)
+			{
+				continue;
+			}
+			const int cap = std::min(balanced, (n + std::max(roundSlack, n / 4) + 7) & ~7);
+			batchOffsetsOut.push_back(base + (int)laidOut.size());
+			laidOut.insert(laidOut.end(), partOrder.begin() + partOffsets[c], partOrder.begin() + partOffsets[(size_t)c + 1]);
+			laidOut.resize(laidOut.size() + (size_t)(std::max(cap, n) - n), -1);
+			set.colorOffsets.push_back(base + (int)laidOut.size());
+		}
+		batchOffsetsOut.push_back(base + (int)laidOut.size());
 		for (int p : laidOut)
 		{
 			set.order.push_back(p >= 0 ? ids[(size_t)p] : -1);
@@ -859,6 +889,10 @@ static int buildLeanStripTables(s2amdSolver* s, const StripPartition& strips, co
 	std::vector<int> off((size_t)nb + 1, 0), inc;
 	for (int k = k0; k < k1; ++k)
 	{
+		if (cs.order[(size_t)k] < 0)
+		{
+			continue; // a free position (IncrementalStrips)
+		}
 		int a = s->hContactA[cs.order[(size_t)k]], b = s->hContactB[cs.order[(size_t)k]];
 		off[(size_t)a + 1] += conflict[a] ? 1 : 0;
 		off[(size_t)b + 1] += conflict[b] ? 1 : 0;
@@ -872,6 +906,10 @@ static int buildLeanStripTables(s2amdSolver* s, const StripPartition& strips, co
 		std::vector<int> cur(off.begin(), off.end() - 1);
 		for (int k = k0; k < k1; ++k)
 		{
+			if (cs.order[(size_t)k] < 0)
+			{
+				continue;
+			}
 			int a = s->hContactA[cs.order[(size_t)k]], b = s->hContactB[cs.order[(size_t)k]];
 			if (conflict[a])
 			{
@@ -1266,6 +1304,12 @@ do                                                                              
 			pv.wideRounds = maxRoundsA > S2_STRIP_ROUNDS ? 1 : 0;
 			pv.seamRegs = seamRegs ? 1 : 0;
 			pv.pairLanes = pairLanes ? 1 : 0;
+			pv.maxRoundsA = maxRoundsA;
+			pv.maxSeamRounds = 0;
+			for (const PersistDesc& d : descs)
+			{
+				pv.maxSeamRounds = std::max(pv.maxSeamRounds, std::max(d.seamBatchCount[0], d.seamBatchCount[1]));
+			}
 			s->persistK0 = k0, s->persistK1 = k1;
 			pv.allTwoPoints = stripsAllTwoPoints(s) ? 1 : 0;
 			pv.ldsRecords = ldsRecords;
@@ -1371,6 +1415,7 @@ struct StructureBuild
 	const bool grouped;
 	const bool wantStrips;
 	const bool residentWanted;
+	const bool stripSlackWanted; // strip and seam rounds get free positions for created contacts (IncrementalStrips): the soft contact solvers' strips
 	const int nb;
 	SweepSet& cs;
 	SweepSet& js;
@@ -1398,7 +1443,8 @@ struct StructureBuild
 		  // strips pay off through the lean / persistent strip kernels, which exist for the soft contact sweeps
 		  wantStrips(grouped && solver->optStrips != 0 && !solver->stripsRejected && solver->graphAge >= solver->stripPatienceNow &&
 					 (solver->optStripsAnySolver != 0 || isSoftFamily(type))),
-		  residentWanted(grouped && isSoftFamily(type) && solver->optIslandResident != 0 && !solver->residentRejected), nb(solver->bodyCapacity),
+		  residentWanted(grouped && isSoftFamily(type) && solver->optIslandResident != 0 && !solver->residentRejected),
+		  stripSlackWanted(solver->optStripSlack != 0 && solver->optIncremental != 0 && solver->optPersist != 0 && isSoftFamily(type)), nb(solver->bodyCapacity),
 		  cs(solver->contacts), js(solver->joints), slots(solver->bodyCapacity)
 	{
 		static const bool fromEnv = getenv("S2AMD_DEBUG_PREP") != nullptr;
@@ -1986,10 +2032,13 @@ struct StructureBuild
 		// strips: a round is one constraint per thread of a 256-thread workgroup, wider colour classes are evened out and cut.
 		// LDS groups and resident islands keep the plain greedy colouring: an island's sweep order must not depend on which
 		// other islands share its group (a world sharded over several GPUs packs them differently and must sweep the same).
-		colourPart(ids, la, lb, lconf, (int)bodies.size(), cs, batchOffsets, tail, &pos, (&t == &s->hGroups || &t == &s->hResident) ? 0 : 256);
+		const bool stripTable = &t == &s->hStripA || &t == &s->hStripB;
+		const int roundSlack = (stripTable && stripSlackWanted && jKs.empty()) ? 16 : 0;
+		colourPart(ids, la, lb, lconf, (int)bodies.size(), cs, batchOffsets, tail, &pos, (&t == &s->hGroups || &t == &s->hResident) ? 0 : 256, nullptr, 0, 0,
+				   false, roundSlack);
 		for (size_t i = 0; i < pos.size(); ++i)
 		{
-			cs.local.push_back(make_int2(la[(size_t)pos[i]], lb[(size_t)pos[i]]));
+			cs.local.push_back(pos[i] >= 0 ? make_int2(la[(size_t)pos[i]], lb[(size_t)pos[i]]) : make_int2(0, 0));
 		}
 		for (size_t bi = 0; bi + 1 < batchOffsets.size(); ++bi)
 		{
@@ -2126,7 +2175,10 @@ struct StructureBuild
 		{
 			for (size_t k = (size_t)cs.globalCount; k < cs.order.size(); ++k)
 			{
-				s->inc.positionOfSlot[(size_t)cs.order[k]] = -2; // lives in an LDS group or a strip: only a rebuild can move it
+				if (cs.order[k] >= 0)
+				{
+					s->inc.positionOfSlot[(size_t)cs.order[k]] = -2; // lives in an LDS group or a strip (IncrementalStrips knows where, for strips)
+				}
 			}
 		}
 		s->hBodyFlagsFinal = flags;
@@ -2247,8 +2299,91 @@ struct StructureBuild
 			rebuild = true;
 			return S2AMD_OK;
 		}
+		buildStripMirror();
 		phase("strip tables");
 		return S2AMD_OK;
+	}
+
+	// the host's picture of the strips' rounds for placing created contacts into them (solver_internal.h: IncrementalStrips)
+	void buildStripMirror()
+	{
+		IncrementalStrips& m = s->stripInc;
+		m = IncrementalStrips{};
+		if (!strips.active || !stripSlackWanted || !s->persistValid || js.stripCount != 0)
+		{
+			return;
+		}
+		m.base = stripBaseC, m.end = stripBaseC + cs.stripCount;
+		m.roundOfPosition.assign((size_t)cs.stripCount, -1);
+		m.ownerStrip.assign((size_t)nb, -1), m.ownerSlot.assign((size_t)nb, -1);
+		m.positionOfSlot.assign((size_t)s->contactCapacity, -1);
+		m.seamGroupOf = seamGroup;
+		const HostGroupTable* tables[2] = {&s->hStripA, &s->hStripB};
+		m.replicaSlot.resize((size_t)s->hStripA.count());
+		m.seamSlot.resize((size_t)s->hStripB.count());
+		for (int t = 0; t < 2; ++t)
+		{
+			const HostGroupTable& h = *tables[t];
+			m.firstRound[t].assign((size_t)h.count(), 0), m.roundCount[t].assign((size_t)h.count(), 0);
+			m.bodyOffset[t].assign(h.bodyOffsets.begin(), h.bodyOffsets.end());
+			m.roundMask[t].assign(h.bodyIds.size(), 0u);
+			for (int g = 0; g < h.count(); ++g)
+			{
+				const int b0 = h.bodyOffsets[(size_t)g], b1 = h.bodyOffsets[(size_t)g + 1];
+				for (int e = b0; e < b1; ++e)
+				{
+					const int body = (int)((uint32_t)h.bodyIds[(size_t)e] & ~S2G_OWNED);
+					if (t == 1)
+					{
+						m.seamSlot[(size_t)g][body] = e - b0;
+					}
+					else if (conflict[(size_t)body])
+					{
+						m.ownerStrip[(size_t)body] = g, m.ownerSlot[(size_t)body] = e - b0;
+					}
+					else
+					{
+						m.replicaSlot[(size_t)g][body] = e - b0;
+					}
+				}
+				m.firstRound[t][(size_t)g] = (int)m.rounds.size();
+				m.roundCount[t][(size_t)g] = h.cBatchOffsets[(size_t)g + 1] - h.cBatchOffsets[(size_t)g];
+				for (int bi = h.cBatchOffsets[(size_t)g]; bi < h.cBatchOffsets[(size_t)g + 1]; ++bi)
+				{
+					const int4 bt = h.cBatches[(size_t)bi];
+					IncrementalStrips::Round r;
+					r.table = t, r.group = g, r.round = bi - h.cBatchOffsets[(size_t)g];
+					if (bt.x < m.base || bt.y > m.end || r.round >= 32)
+					{
+						m = IncrementalStrips{};
+						return;
+					}
+					for (int k = bt.y - 1; k >= bt.x; --k)
+					{
+						m.roundOfPosition[(size_t)(k - m.base)] = (int)m.rounds.size();
+						const int slot = cs.order[(size_t)k];
+						if (slot < 0)
+						{
+							r.freePositions.push_back(k);
+							continue;
+						}
+						m.positionOfSlot[(size_t)slot] = k;
+						const int2 l = cs.local[(size_t)k];
+						for (int side = 0; side < 2; ++side)
+						{
+							const int ls = side ? l.y : l.x;
+							const int body = (int)((uint32_t)h.bodyIds[(size_t)(b0 + ls)] & ~S2G_OWNED);
+							if (conflict[(size_t)body])
+							{
+								m.roundMask[t][(size_t)(b0 + ls)] |= 1u << r.round;
+							}
+						}
+					}
+					m.rounds.push_back(std::move(r));
+				}
+			}
+		}
+		m.valid = true;
 	}
 
 	// ---- phase 10: message-passing tables of the global part (see MsgBodies), body adjacency, bookkeeping ----
@@ -2277,9 +2412,9 @@ struct StructureBuild
 
 		// created contacts can be placed into this structure while its global part has the slack layout
 		s->slackPositions = 0;
-		for (int k = 0; k < cs.globalCount; ++k)
+		for (size_t k = 0; k < cs.order.size(); ++k) // (the global part's slack and the strips')
 		{
-			s->slackPositions += cs.order[(size_t)k] < 0 ? 1 : 0;
+			s->slackPositions += cs.order[k] < 0 ? 1 : 0;
 		}
 		s->slackAtBuild = s->slackPositions;
 		s->inc.valid = s->optIncremental != 0 && s->inc.solverClass == cls && !s->msgTablesValid && !s->inc.positionOfSlot.empty();

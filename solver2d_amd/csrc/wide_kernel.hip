@@ -258,7 +258,7 @@ S2_DEV void storeWide(const ContactView& c, const WideRegs& p, int k)
 }
 
 // POINTS == 2: the host has checked that every constraint of the strips has two manifold points: no per-point masking.
-template <int POINTS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideStepKernel(ContactView c, BodyView g, StripTableView ta, PersistView pv, const Op* ops, int opCount)
+template <int POINTS, int RPH, int SR> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideStepKernel(ContactView c, BodyView g, StripTableView ta, PersistView pv, const Op* ops, int opCount)
 {
 	extern __shared__ __attribute__((aligned(16))) float4 lds[];
 	const int tid = (int)threadIdx.x;
@@ -295,17 +295,18 @@ template <int POINTS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideSte
 	const StripDesc* da = ta.descs + strip;
 	const PersistDesc* pd = pv.descs + strip;
 	const int bodyBase = da->bodyBase, nb = da->bodyCount, roundsA = da->batchCount;
-	int2 batchA[S2_STRIP_ROUNDS];
+	constexpr int ROUNDS = 2 * RPH; // interior colour batches this variant takes (RPH per half of the workgroup)
+	int2 batchA[ROUNDS];
 #pragma unroll
-	for (int i = 0; i < S2_STRIP_ROUNDS; ++i)
+	for (int i = 0; i < ROUNDS; ++i)
 	{
 		batchA[i] = make_int2(da->batch[i].x, da->batch[i].y);
 	}
 	const int nImp0 = pd->importCount[0], nImp1 = pd->importCount[1];
 	const int roundsB0 = pd->seamBatchCount[0], roundsB1 = pd->seamBatchCount[1];
-	int2 batchB0[S2_WIDE_SEAM_ROUNDS], batchB1[S2_WIDE_SEAM_ROUNDS];
+	int2 batchB0[SR], batchB1[SR];
 #pragma unroll
-	for (int i = 0; i < S2_WIDE_SEAM_ROUNDS; ++i)
+	for (int i = 0; i < SR; ++i)
 	{
 		batchB0[i] = pd->seamBatch[0][i];
 		batchB1[i] = pd->seamBatch[1][i];
@@ -353,9 +354,9 @@ template <int POINTS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideSte
 		const int k = (half ? batchA[2 * s + 1].x : batchA[2 * s].x) + ht;
 		return (i < roundsA && k < (half ? batchA[2 * s + 1].y : batchA[2 * s].y)) ? k : -1;
 	};
-	WideRegs rA[S2_WIDE_ROUNDS_PER_HALF];
+	WideRegs rA[RPH];
 #pragma unroll
-	for (int s = 0; s < S2_WIDE_ROUNDS_PER_HALF; ++s)
+	for (int s = 0; s < RPH; ++s)
 	{
 		const int k = kOfSlot(s);
 		if (k >= 0)
@@ -382,10 +383,10 @@ template <int POINTS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideSte
 		}
 		return false;
 	};
-	WideRegs rB[S2_WIDE_SEAM_ROUNDS];
+	WideRegs rB[SR];
 	uint32_t seamMask = 0u; // bit i: this lane holds a seam constraint in seam round i
 #pragma unroll
-	for (int i = 0; i < S2_WIDE_SEAM_ROUNDS; ++i)
+	for (int i = 0; i < SR; ++i)
 	{
 		int seam, k;
 		if (i < roundsB && seamItem(i, seam, k))
@@ -452,7 +453,7 @@ template <int POINTS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideSte
 		p.idx |= st ? 1u << 30 : 0u;
 	};
 #pragma unroll
-	for (int s = 0; s < S2_WIDE_ROUNDS_PER_HALF; ++s)
+	for (int s = 0; s < RPH; ++s)
 	{
 		if (kOfSlot(s) >= 0)
 		{
@@ -460,7 +461,7 @@ template <int POINTS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideSte
 		}
 	}
 #pragma unroll
-	for (int i = 0; i < S2_WIDE_SEAM_ROUNDS; ++i)
+	for (int i = 0; i < SR; ++i)
 	{
 		if ((seamMask >> i) & 1u)
 		{
@@ -547,7 +548,7 @@ template <int POINTS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideSte
 			// the anchors and that body's own pose only, so every body this workgroup owns ends up with the right bits; the
 			// copies of the neighbours' bodies are refreshed by the next sweep's exchange before anything reads them
 #pragma unroll
-			for (int i = 0; i < S2_STRIP_ROUNDS; ++i)
+			for (int i = 0; i < ROUNDS; ++i)
 			{
 				if (i < roundsA)
 				{
@@ -559,7 +560,7 @@ template <int POINTS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideSte
 				}
 			}
 #pragma unroll
-			for (int i = 0; i < S2_WIDE_SEAM_ROUNDS; ++i)
+			for (int i = 0; i < SR; ++i)
 			{
 				if (i < roundsB)
 				{
@@ -582,7 +583,7 @@ template <int POINTS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideSte
 				pre = prepWide<POINTS>(rA[0], ldq, lcoef, op.inv_h, op.useBias, salt);
 			}
 #pragma unroll
-			for (int i = 0; i < S2_STRIP_ROUNDS; ++i)
+			for (int i = 0; i < ROUNDS; ++i)
 			{
 				if (i < roundsA)
 				{
@@ -593,7 +594,7 @@ template <int POINTS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideSte
 							chainWide<POINTS>(rA[i >> 1], pre, lvel, lmass, lcoef, salt);
 						}
 					}
-					else if (i + 1 < S2_STRIP_ROUNDS && kOfSlot((i + 1) >> 1) >= 0) // (my next round is i + 1)
+					else if (i + 1 < ROUNDS && kOfSlot((i + 1) >> 1) >= 0) // (my next round is i + 1)
 					{
 						pre = prepWide<POINTS>(rA[(i + 1) >> 1], ldq, lcoef, op.inv_h, op.useBias, salt);
 					}
@@ -623,9 +624,10 @@ template <int POINTS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideSte
 				}
 			}
 			// the seam constraints' pose-dependent part, while the neighbours' bodies are in flight (poses never travel)
-			WidePrep preB[S2_WIDE_SEAM_ROUNDS];
+			constexpr int SRP = SR < 2 ? SR : 2; // (a third and fourth seam round prepare just before their chain: registers)
+			WidePrep preB[SRP];
 #pragma unroll
-			for (int i = 0; i < S2_WIDE_SEAM_ROUNDS; ++i)
+			for (int i = 0; i < SRP; ++i)
 			{
 				if ((seamMask >> i) & 1u)
 				{
@@ -653,13 +655,28 @@ template <int POINTS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideSte
 			stampAt(5);
 			// ---- both seams (the neighbours compute the same bits on their side) ----
 #pragma unroll
-			for (int i = 0; i < S2_WIDE_SEAM_ROUNDS; ++i)
+			for (int i = 0; i < SR; ++i)
 			{
 				if (i < roundsB)
 				{
 					if ((seamMask >> i) & 1u)
 					{
-						chainWide<POINTS>(rB[i], preB[i], lvel, lmass, lcoef, salt);
+						if constexpr (SR > 2)
+						{
+							if (i >= 2)
+							{
+								const WidePrep late = prepWide<POINTS>(rB[i], ldq, lcoef, op.inv_h, op.useBias, salt);
+								chainWide<POINTS>(rB[i], late, lvel, lmass, lcoef, salt);
+							}
+							else
+							{
+								chainWide<POINTS>(rB[i], preB[i < 2 ? i : 0], lvel, lmass, lcoef, salt);
+							}
+						}
+						else
+						{
+							chainWide<POINTS>(rB[i], preB[i], lvel, lmass, lcoef, salt);
+						}
 					}
 					__syncthreads();
 					if (S2_PERSIST_INSTRUMENTED && i + 1 < roundsB)
@@ -685,7 +702,7 @@ template <int POINTS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideSte
 		}
 	}
 #pragma unroll
-	for (int s = 0; s < S2_WIDE_ROUNDS_PER_HALF; ++s)
+	for (int s = 0; s < RPH; ++s)
 	{
 		if (kOfSlot(s) >= 0)
 		{
@@ -694,7 +711,7 @@ template <int POINTS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideSte
 	}
 	// the right seam's impulses are stored by this workgroup (its left neighbour of that seam), nobody stores twice
 #pragma unroll
-	for (int i = 0; i < S2_WIDE_SEAM_ROUNDS; ++i)
+	for (int i = 0; i < SR; ++i)
 	{
 		int seam, k;
 		if (i < roundsB && seamItem(i, seam, k) && seam == 1)
@@ -710,25 +727,45 @@ template <int POINTS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideSte
 	}
 }
 
-// Eligibility (checked by the caller, solver_executor.h runPersistent): TGS_Soft with the current-anchor warm start, and
-// pv.pairLanes -- no strip has more than S2_STRIP_ROUNDS interior colour batches and no seam more than two.
-void launchWideStep(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount)
+// Eligibility (checked by the caller, solver_executor.h widePlan): TGS_Soft with the current-anchor warm start on a partition with
+// at most 6 interior colour batches per strip and 3 per seam, or 8 and 2 (pv.maxRoundsA, pv.maxSeamRounds): five or six resident
+// records per lane fit its 256 registers beside the round's working set, seven do not (measured: 160 spilled registers).
+template <int RPH, int SR>
+static void launchWide(hipStream_t s, dim3 grid, size_t lds, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount)
 {
-	const dim3 grid((unsigned)a.groupCount), block(S2_WIDE_THREADS);
-	const size_t lds = (size_t)(pv.ldsRecords + 3) * sizeof(float4) + (size_t)opCount * sizeof(Op);
+	const dim3 block(S2_WIDE_THREADS);
 	if (pv.allTwoPoints)
 	{
-		wideStepKernel<2><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
+		wideStepKernel<2, RPH, SR><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
 	}
 	else
 	{
-		wideStepKernel<0><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
+		wideStepKernel<0, RPH, SR><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
+	}
+}
+
+void launchWideStep(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount)
+{
+	const dim3 grid((unsigned)a.groupCount);
+	const size_t lds = (size_t)(pv.ldsRecords + 3) * sizeof(float4) + (size_t)opCount * sizeof(Op);
+	if (pv.maxRoundsA <= 6 && pv.maxSeamRounds <= 2)
+	{
+		launchWide<3, 2>(s, grid, lds, c, g, a, pv, ops, opCount);
+	}
+	else if (pv.maxRoundsA <= 6)
+	{
+		launchWide<3, 3>(s, grid, lds, c, g, a, pv, ops, opCount);
+	}
+	else
+	{
+		launchWide<4, 2>(s, grid, lds, c, g, a, pv, ops, opCount);
 	}
 }
 
 int wideKernelSetup()
 {
-	const void* steps[] = {(const void*)wideStepKernel<0>, (const void*)wideStepKernel<2>};
+	const void* steps[] = {(const void*)wideStepKernel<0, 3, 2>, (const void*)wideStepKernel<2, 3, 2>, (const void*)wideStepKernel<0, 3, 3>,
+						   (const void*)wideStepKernel<2, 3, 3>, (const void*)wideStepKernel<0, 4, 2>, (const void*)wideStepKernel<2, 4, 2>};
 	for (const void* f : steps)
 	{
 		hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

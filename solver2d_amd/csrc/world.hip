@@ -383,30 +383,39 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 			// s2Solve_Jacobi has no colours to find: a watched manifold that gained its first points gets a position and its two
 			// incidence-list entries like a created contact (one that lost its points stays where it is, a no-op); every other
 			// solver's structure is rebuilt
+			// ... and under the soft contact solvers a manifold between bodies of the strips takes a free position of a strip or
+			// seam round (solver_internal.h: IncrementalStrips); every other flip rebuilds the structure
 			bool handled = false;
-			if (s->inc.valid && s->inc.ignoreColours && s->optIncremental != 0)
+			const bool jacobi = s->inc.valid && s->inc.ignoreColours && s->optIncremental != 0;
+			const bool strips = s->inc.valid && s->stripInc.valid && s->optIncremental != 0;
+			if (jacobi || strips)
 			{
 				if ((rcMid = fetchPointCounts(s)) != 0)
 				{
 					return rcMid;
 				}
 				std::vector<ContactChange> flipped;
+				bool placeable = true;
 				for (int i = 0; i < nc; ++i)
 				{
 					if (s->hContactWatched[(size_t)i] && s->hContactPoints[(size_t)i] > 0 && s->hContactEdge[(size_t)i] && !s->hContactDead[(size_t)i] &&
 						s->inc.positionOfSlot[(size_t)i] == -1)
 					{
 						flipped.push_back(ContactChange{i, s->hContactA[(size_t)i], s->hContactB[(size_t)i]});
+						placeable = placeable && (jacobi || stripCanPlace(s, s->hContactA[(size_t)i], s->hContactB[(size_t)i]));
 					}
 				}
-				handled = flipped.empty() || incrementalApply(s, flipped);
+				handled = placeable && (flipped.empty() || incrementalApply(s, flipped));
 				if (handled && !flipped.empty())
 				{
 					if ((rcMid = incrementalFlush(s)) != 0)
 					{
 						return rcMid;
 					}
-					noteGraphTouched(s);
+					if (s->inc.placedInGlobalPart)
+					{
+						noteGraphTouched(s);
+					}
 					s->gatherIndexDirty = true;
 				}
 			}
@@ -692,7 +701,10 @@ int s2amd_world_set_contacts(s2amdSolver* s, const int32_t* slots, int32_t count
 			{
 				return rcFlush;
 			}
-			noteGraphTouched(s);
+			if (s->inc.placedInGlobalPart)
+			{
+				noteGraphTouched(s);
+			}
 		}
 		else
 		{

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("S2AMD_LIB") or os.path.join(_HERE, "libs2amd.so")
 
 EXPORTS = [
-    "s2amd_api_version", "s2amd_device_count", "s2amd_last_error", "s2amd_create", "s2amd_destroy",
+    "s2amd_api_version", "s2amd_device_count", "s2amd_device_bus_id", "s2amd_last_error", "s2amd_create", "s2amd_destroy",
     "s2amd_solve", "s2amd_upload", "s2amd_step_resident", "s2amd_download", "s2amd_save_bodies",
     "s2amd_restore_bodies", "s2amd_get_contact_order", "s2amd_get_joint_order", "s2amd_get_stats",
     "s2amd_set_option", "s2amd_export_poses", "s2amd_export_poses_async", "s2amd_export_wait", "s2amd_measure_dominant", "s2amd_refit_shapes", "s2amd_find_pairs", "s2amd_synchronize", "s2amd_update_contacts", "s2amd_find_islands", "s2amd_color_constraints",
@@ -86,6 +86,12 @@ def load():
 
 def device_count():
     return load().s2amd_device_count()
+
+
+def device_bus_id(device):
+    buf = ctypes.create_string_buffer(64)
+    _check(load().s2amd_device_bus_id(int(device), buf, 64))
+    return buf.value.decode()
 
 
 def _check(rc):

@@ -77,6 +77,61 @@ def churn(solver_name, base, steps, options):
         return s.stats()["structureBuilds"]
 
 
+def neighbour_churn(solver_name, base, steps, options):
+    """Contacts between boxes two hops apart in the contact graph (what a disturbed pile creates): same or adjacent strips,
+    so they can take free positions of the strips' rounds (IncrementalStrips) -- appear without points, gain them, lose them,
+    get destroyed, their slots reused."""
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+    rng = np.random.default_rng(11 + base)
+    spare_n = 600
+    pre = _with_spare_slots(synthetic.pyramid(base), spare_n)
+    n0 = len(pre[1]) - spare_n
+    a0, b0 = pre[1]["bodyA"][:n0].astype(int), pre[1]["bodyB"][:n0].astype(int)
+    pairs = {(min(a, b), max(a, b)) for a, b in zip(a0.tolist(), b0.tolist())}
+    nbrs = {}
+    for a, b in zip(a0.tolist(), b0.tolist()):
+        nbrs.setdefault(a, []).append(b), nbrs.setdefault(b, []).append(a)
+    dynamic = np.flatnonzero(pre[0]["type"] == wire.BODY_DYNAMIC)
+    free_slot = np.zeros(1, dtype=wire.contact_dtype)[0]
+    free_slot["bodyA"], free_slot["bodyB"], free_slot["constraintIndex"] = -1, -1, -1
+    with hip.Solver(0) as s:
+        for k, v in options.items():
+            s.set_option(k, v)
+        state = common.copy3(pre)
+        s.solve(params, *state)
+        spare = list(range(n0, n0 + spare_n))
+        mine = []
+        for step in range(steps):
+            for _ in range(int(rng.integers(0, 8))):
+                a = int(rng.choice(dynamic))
+                mid = int(rng.choice(nbrs[a]))
+                c = int(rng.choice(nbrs[mid]))
+                if c == a or (min(a, c), max(a, c)) in pairs or pre[0]["type"][c] != wire.BODY_DYNAMIC or not spare:
+                    continue
+                pairs.add((min(a, c), max(a, c)))
+                slot = spare.pop(0)
+                new = _artificial_contact(rng, state[0], pre[1][5], set())
+                new["bodyA"], new["bodyB"] = a, c
+                new["pointCount"] = 0 if rng.random() < 0.7 else int(rng.integers(1, 3))
+                state[1][slot] = new
+                mine.append(slot)
+            for slot in list(mine):
+                r = rng.random()
+                if r < 0.25:
+                    state[1][slot]["pointCount"] = int(rng.integers(0, 3))
+                elif r < 0.30:
+                    a, c = int(state[1][slot]["bodyA"]), int(state[1][slot]["bodyB"])
+                    pairs.discard((min(a, c), max(a, c)))
+                    state[1][slot] = free_slot
+                    mine.remove(slot)
+                    spare.append(slot)
+            s.solve(params, *state)
+            s.contact_order()
+        st = s.stats()
+        return st["structureBuilds"], st["placedContacts"], st["persistent"]
+
+
 def world_chain(base, steps):
     world = synthetic.pyramid_world(base)
     keys = ("bodies", "contacts", "joints", "shapes", "pairs", "origins")
@@ -98,6 +153,9 @@ def main():
                              ("SoftStep", 40, {"strip_patience": 0, "max_group_bodies": 256})):
         builds = churn(name, base, 6 if quick else 25, opts)
         print("churn %s base %d: %d structure builds" % (name, base, builds))
+    for name, base, opts in (("TGS_Soft", 60, {"strip_patience": 0}), ("SoftStep", 60, {"strip_patience": 0}), ("TGS_Soft", 100, {"strip_patience": 0, "wide": 0})):
+        builds, placed, persistent = neighbour_churn(name, base, 10 if quick else 40, opts)
+        print("neighbour churn %s base %d: %d structure builds, %d contacts placed, persistent %d" % (name, base, builds, placed, persistent))
     world_chain(20 if quick else 60, 3 if quick else 8)
     print("world chain ok")
     print("HOSTCHECK OK")

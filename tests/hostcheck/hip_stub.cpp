@@ -40,6 +40,11 @@ hipError_t hipDeviceGetAttribute(int* value, hipDeviceAttribute_t attr, int)
 	*value = attr == hipDeviceAttributeMultiprocessorCount ? 256 : attr == hipDeviceAttributeWarpSize ? 64 : 1024;
 	return hipSuccess;
 }
+hipError_t hipDeviceGetPCIBusId(char* pciBusId, int len, int)
+{
+	strncpy(pciBusId, "0000:00:00.0", (size_t)len);
+	return hipSuccess;
+}
 hipError_t hipGetLastError(void) { return hipSuccess; }
 hipError_t hipPeekAtLastError(void) { return hipSuccess; }
 const char* hipGetErrorString(hipError_t) { return "hip_stub"; }

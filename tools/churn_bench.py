@@ -93,9 +93,9 @@ def main():
             t5 = time.perf_counter()
             moved = info["movedCount"]
             if a.trace:
-                sys.stderr.write("step %d: %.2f ms, created %d separated %d active %d potential %d launches %d hostPrep %.2f colours %d placed %d builds %d\n" % (
+                sys.stderr.write("step %d: %.2f ms, created %d separated %d active %d potential %d launches %d hostPrep %.2f colours %d placed %d builds %d persistent %d fallbacks %d kernel %d\n" % (
                     step, 1e3 * (t5 - t0), created, info["separatedCount"], info["activeContacts"], st["potentialConstraints"], st["kernelLaunches"], st["hostPrepMs"],
-                    st["contactColors"], st["placedContacts"], st["structureBuilds"]))
+                    st["contactColors"], st["placedContacts"], st["structureBuilds"], st["persistent"], st["persistFallbacks"], st["pairLanes"]))
             rows.append({"step_ms": 1e3 * (t5 - t0), "pair_query_ms": 1e3 * (t1 - t0), "create_py_ms": 1e3 * (t2 - t1), "set_contacts_ms": 1e3 * (t3 - t2),
                          "world_step_ms": 1e3 * (t4 - t3), "destroy_py_ms": 1e3 * (t5 - t4), "host_structure_ms": st["hostPrepMs"], "solve_device_ms": info["solveMs"],
                          "created": created, "separated": info["separatedCount"], "flips": info["graphChanged"], "active": info["activeContacts"],

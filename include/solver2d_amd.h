@@ -337,6 +337,21 @@ typedef struct s2amdShapeBox
 /* boxes[shapeCapacity of the upload]: the boxes of the resident shapes after the last s2amd_world_step (36 bytes per shape
  * instead of s2amd_world_download's whole shape records). */
 int s2amd_world_download_boxes(s2amdSolver* solver, s2amdShapeBox* boxes, int32_t shapeCapacity);
+/* (API 2) The per-step read-back of a caller that keeps its own copy of the world and its own broad-phase trees (the binding,
+ * shim/s2_amd_binding.c): after an s2amd_world_step, instead of the whole body and box arrays,
+ *   poses[4 * body]  {origin.x, origin.y, rot.s, rot.c} of every body slot (what s2Body_GetPosition / GetAngle read), and
+ *   moved[]          the shapes whose fat box the refit re-inflated (src/world.c:283-290), with the new fat box, IN THE ORDER the
+ *                    reference's refit visits them -- `shapeOrder` of s2amd_world_set_refit_order: bodies in pool order, each
+ *                    body's shape list -- which is the order s2BroadPhase_EnlargeProxy puts them into the move buffer in.
+ * *movedCount == s2amdWorldStepInfo.movedCount of that step.  Velocities, manifolds, tight boxes stay in HBM until somebody
+ * asks for them (s2amd_world_download / _download_boxes). */
+typedef struct s2amdMovedBox
+{
+	int32_t shape;
+	float fatAABB[4];
+} s2amdMovedBox;
+int s2amd_world_set_refit_order(s2amdSolver* solver, const int32_t* shapeOrder, int32_t count);
+int s2amd_world_download_step(s2amdSolver* solver, float* poses, int32_t bodyCapacity, s2amdMovedBox* moved, int32_t movedCapacity, int32_t* movedCount);
 /* Writes `count` contact slots of the resident world (slot indices < contactCapacity of the upload): the caller's
  * s2CreateContact (src/contact.c:137-203: pool slot, pair flip, mixed friction, empty manifold) or s2DestroyContact
  * (pairs[i].shapeA = -1, contacts[i].pointCount = 0).  A world that needs more slots, bodies or shapes is uploaded again. */
@@ -398,7 +413,7 @@ int s2amd_measure_dominant(s2amdSolver* solver, const s2amdStepParams* params, i
 /* option keys: "graph" (0/1 hipGraph replay), "profile" (0/1 per-sweep HIP events),
  * "groups" (0/1 LDS group path for small islands), "message" (0/1 message-passing sweeps), "max_group_bodies", "pack_group_bodies",
  * "strips" (0/1 cut islands that fit no LDS group into strips of BFS levels: two launches per sweep), "strip_bodies" (target
- * bodies per strip, default 160), "strip_retry" (0/1 rebuild the partition with other strip widths when one strip needs the 8-round kernel variant), "strip_min_bodies" (loose bodies below which the colour-batch path is kept), "strip_patience" (steps the constraint graph must
+ * bodies per strip, default 8 = strips of two BFS levels), "strip_retry" (0/1 rebuild the partition with other strip widths when the persistent kernel cannot take this one or it needs more than five interior colour rounds), "strip_min_bodies" (loose bodies below which the colour-batch path is kept), "strip_patience" (steps the constraint graph must
  * stay unchanged before the strip structure is built: its host build costs ~3 ms at 60k constraints, the colour-batch one ~1 ms), "async" (0/1, see s2amd_synchronize), "strip_lean" (0/1 dedicated strip
  * kernel for the soft sweeps), "persist" (0/1 whole step of the strips in one persistent launch), "wide" (0/1 TGS_Soft's persistent launch runs 512 threads per strip: wide_kernel.hip),
  * "pair_lanes" (0/1 that launch solves a constraint with two lanes, one per body: pair_kernel.hip; measured no faster, off by default), "body_warm", "incremental" (0/1 created

@@ -545,6 +545,32 @@ S2REF_API void s2World_Step(s2WorldId worldId, float timeStep, int velIters, int
 	}
 }
 
+// the public calls that read or edit the trees and pools of a world the binding keeps resident: its deferred tree work first
+// (shim/s2_amd_binding.c: lean read-back; the product's call sites are shim/s2_amd_dropin.c)
+void __real_s2World_QueryAABB(s2WorldId worldId, s2Box aabb, s2QueryCallbackFcn* fcn, void* context);
+void __wrap_s2World_QueryAABB(s2WorldId worldId, s2Box aabb, s2QueryCallbackFcn* fcn, void* context)
+{
+	(void)s2amdBinding_Sync(s2GetWorldFromId(worldId));
+	__real_s2World_QueryAABB(worldId, aabb, fcn, context);
+}
+void __real_s2DestroyBody(s2BodyId bodyId);
+void __wrap_s2DestroyBody(s2BodyId bodyId)
+{
+	(void)s2amdBinding_Sync(s2GetWorldFromIndex(bodyId.world));
+	__real_s2DestroyBody(bodyId);
+}
+#define S2REF_SHAPE_WRAP(NAME, GEOM)                                                                                             \
+	s2ShapeId __real_##NAME(s2BodyId bodyId, const s2ShapeDef* def, const GEOM* geometry);                                       \
+	s2ShapeId __wrap_##NAME(s2BodyId bodyId, const s2ShapeDef* def, const GEOM* geometry)                                        \
+	{                                                                                                                            \
+		(void)s2amdBinding_Sync(s2GetWorldFromIndex(bodyId.world));                                                              \
+		return __real_##NAME(bodyId, def, geometry);                                                                             \
+	}
+S2REF_SHAPE_WRAP(s2CreateCircleShape, s2Circle)
+S2REF_SHAPE_WRAP(s2CreateSegmentShape, s2Segment)
+S2REF_SHAPE_WRAP(s2CreateCapsuleShape, s2Capsule)
+S2REF_SHAPE_WRAP(s2CreatePolygonShape, s2Polygon)
+
 // s2DestroyWorld (src/world.c:105-118) frees the world's device state first (oracle/Makefile: --wrap)
 void __real_s2DestroyWorld(s2WorldId id);
 void __wrap_s2DestroyWorld(s2WorldId id)

@@ -392,6 +392,8 @@ typedef struct AmdApi
 	int (*worldFindPairs)(s2amdSolver*, int32_t*, int32_t, int32_t*);
 	int (*worldSeparated)(s2amdSolver*, int32_t*, int32_t, int32_t*);
 	int (*worldDownloadBoxes)(s2amdSolver*, s2amdShapeBox*, int32_t);
+	int (*worldSetRefitOrder)(s2amdSolver*, const int32_t*, int32_t);
+	int (*worldDownloadStep)(s2amdSolver*, float*, int32_t, s2amdMovedBox*, int32_t, int32_t*);
 } AmdApi;
 static AmdApi s_api = {0};
 
@@ -422,6 +424,19 @@ typedef struct WorldBinding
 	int32_t* newPairs;
 	int newPairCapacity;
 	s2amdShapeBox* boxes; // the shapes' boxes after the last step (stage 4's output)
+	// lean read-back (device pairs): per step only what the public API reads -- body origins and rotations -- and the fat
+	// boxes the refit re-inflated; velocities, centres of mass, tight boxes and the trees follow when somebody needs them
+	float* poses;	 // {origin.x, origin.y, rot.s, rot.c} per body slot
+	int32_t* refitOrder; // shape slots in the order the reference's refit visits them (bodies in pool order, each body's shape list)
+	int bodiesStale; // the host bodies hold only the poses of the last step
+	int boxesStale;	 // the host shapes' tight boxes are older than the device's
+	// tree work not yet done: per step the boxes it re-inflated, in refit order.  Replaying a step = what the reference does
+	// between two pair queries: clear the move buffer, rebuild the trees (stage 2), enlarge these proxies (stage 4).
+	s2amdMovedBox* pendingBoxes;
+	int pendingBoxCount, pendingBoxCapacity;
+	int* pendingSteps; // boxes per pending step
+	int pendingStepCount, pendingStepCapacity;
+	int lastMoved;	  // boxes the last step re-inflated: the next pair query has something to look at
 	int liveCount;	  // slots with liveKey >= 0
 	int createdCount; // >= 0: this step's stage 1 ran here (device pairs) and created exactly the contacts in createdSlots
 	int32_t* createdSlots;
@@ -480,6 +495,8 @@ int s2amdBinding_Open(const char* libraryPath, int device)
 		S2_BIND(worldFindPairs, "s2amd_world_find_pairs")
 		S2_BIND(worldSeparated, "s2amd_world_separated")
 		S2_BIND(worldDownloadBoxes, "s2amd_world_download_boxes")
+		S2_BIND(worldSetRefitOrder, "s2amd_world_set_refit_order")
+		S2_BIND(worldDownloadStep, "s2amd_world_download_step")
 #undef S2_BIND
 	}
 	s_api.device = device;
@@ -538,10 +555,159 @@ static WorldBinding* bindingOf(const s2World* world)
 	return b;
 }
 
+// ---- deferred tree work (lean read-back) ----
+// A world nobody queries (no s2World_QueryAABB, no s2World_Draw, no new pair) never needs its trees: the log is only replayed
+// when something reads them, or when it holds this much (40 MB of boxes).
+#define S2AMD_BINDING_MAX_PENDING_STEPS 4096
+#define S2AMD_BINDING_MAX_PENDING_BOXES 2000000
+static void (*s_rebuildTrees)(s2BroadPhase*) = NULL; // stage 2 as handed to s2amdBinding_WorldStep
+
+// The steps whose re-inflated boxes were only logged, replayed into the reference's trees in order: per step the move buffer
+// is cleared (as the pair query of that step would have left it, src/broad_phase.c end of s2UpdateBroadPhasePairs), the
+// trees are rebuilt (world.c:130) and the step's proxies enlarged in refit order (world.c:283-290) -- the very calls the
+// per-step path makes, later.  Afterwards trees, fat boxes and move buffer are what they would be had every step done it.
+static void flushTrees(s2World* world, WorldBinding* b)
+{
+	if (b->pendingStepCount == 0 || s_rebuildTrees == NULL)
+	{
+		return;
+	}
+	s2BroadPhase* bp = &world->broadPhase;
+	const s2amdMovedBox* e = b->pendingBoxes;
+	for (int st = 0; st < b->pendingStepCount; ++st)
+	{
+		s2Array_Clear(bp->moveArray);
+		s2ClearSet(&bp->moveSet);
+		s_rebuildTrees(bp);
+		for (int i = 0; i < b->pendingSteps[st]; ++i, ++e)
+		{
+			if (e->shape < 0 || e->shape >= world->shapePool.capacity || s2IsFree(&world->shapes[e->shape].object))
+			{
+				continue;
+			}
+			s2Shape* sh = world->shapes + e->shape;
+			sh->fatAABB = (s2Box){{e->fatAABB[0], e->fatAABB[1]}, {e->fatAABB[2], e->fatAABB[3]}};
+			s2BroadPhase_EnlargeProxy(bp, sh->proxyKey, sh->fatAABB);
+		}
+	}
+	b->pendingStepCount = 0;
+	b->pendingBoxCount = 0;
+}
+
+// room in the log for one more step of `boxes` re-inflated boxes
+static int reservePending(WorldBinding* b, int boxes)
+{
+	if (b->pendingBoxCount + boxes > b->pendingBoxCapacity)
+	{
+		const int cap = 2 * (b->pendingBoxCount + boxes) + 1024;
+		void* p = realloc(b->pendingBoxes, (size_t)cap * sizeof(s2amdMovedBox));
+		if (p == NULL)
+		{
+			return S2AMD_E_DEVICE;
+		}
+		b->pendingBoxes = (s2amdMovedBox*)p, b->pendingBoxCapacity = cap;
+	}
+	if (b->pendingStepCount + 1 > b->pendingStepCapacity)
+	{
+		const int cap = 2 * b->pendingStepCount + 64;
+		void* p = realloc(b->pendingSteps, (size_t)cap * sizeof(int));
+		if (p == NULL)
+		{
+			return S2AMD_E_DEVICE;
+		}
+		b->pendingSteps = (int*)p, b->pendingStepCapacity = cap;
+	}
+	return 0;
+}
+
+// the order the reference's refit visits the shapes in (src/world.c:259-297): bodies in pool order, each body's shape list
+static int sendRefitOrder(s2World* w, WorldBinding* b)
+{
+	void* p = realloc(b->refitOrder, (size_t)(w->shapePool.capacity > 0 ? w->shapePool.capacity : 1) * sizeof(int32_t));
+	if (p == NULL)
+	{
+		return S2AMD_E_DEVICE;
+	}
+	b->refitOrder = (int32_t*)p;
+	int n = 0;
+	for (int bi = 0; bi < w->bodyPool.capacity; ++bi)
+	{
+		const s2Body* body = w->bodies + bi;
+		if (s2IsFree(&body->object) || body->type == s2_staticBody)
+		{
+			continue;
+		}
+		for (int i = body->shapeList; i != S2_NULL_INDEX && n < w->shapePool.capacity; i = w->shapes[i].nextShapeIndex)
+		{
+			b->refitOrder[n++] = i;
+		}
+	}
+	return s_api.worldSetRefitOrder(b->solver, b->refitOrder, n);
+}
+
+// everything the lean read-back left on the device: the bodies (velocities, centres of mass), the tight boxes, the trees
+static int syncBodiesAndBoxes(s2World* world, WorldBinding* b)
+{
+	int rc = 0;
+	if (b->bodiesStale)
+	{
+		if ((rc = s_api.worldDownload(b->solver, b->bodies, b->bodyCapacity, NULL, b->contactCapacity, NULL, b->jointCapacity, NULL, b->shapeCapacity, NULL,
+									  b->origins, NULL)) != 0)
+		{
+			return rc;
+		}
+		// (the pool may have grown since: slots keep their index, src/pool.h:11)
+		const int n = world->bodyPool.capacity < b->bodyCapacity ? world->bodyPool.capacity : b->bodyCapacity;
+		for (int i = 0; i < n; ++i)
+		{
+			s2Body* body = world->bodies + i;
+			const s2amdBody* o = b->bodies + i;
+			if (s2IsFree(&body->object))
+			{
+				continue;
+			}
+			body->position = (s2Vec2){o->position[0], o->position[1]};
+			body->rot = (s2Rot){o->rot[0], o->rot[1]};
+			body->linearVelocity = (s2Vec2){o->linearVelocity[0], o->linearVelocity[1]};
+			body->angularVelocity = o->angularVelocity;
+			body->deltaPosition = (s2Vec2){o->deltaPosition[0], o->deltaPosition[1]};
+		}
+		b->bodiesStale = 0;
+	}
+	if (b->boxesStale)
+	{
+		if ((rc = s_api.worldDownloadBoxes(b->solver, b->boxes, b->shapeCapacity)) != 0)
+		{
+			return rc;
+		}
+		const int ns = world->shapePool.capacity < b->shapeCapacity ? world->shapePool.capacity : b->shapeCapacity;
+		for (int i = 0; i < ns; ++i)
+		{
+			s2Shape* sh = world->shapes + i;
+			if (!s2IsFree(&sh->object))
+			{
+				const s2amdShapeBox* o = b->boxes + i;
+				sh->aabb = (s2Box){{o->aabb[0], o->aabb[1]}, {o->aabb[2], o->aabb[3]}};
+			}
+		}
+		b->boxesStale = 0;
+	}
+	flushTrees(world, b);
+	return 0;
+}
+
 // manifolds, GJK caches and joint impulses back into the reference's pools
 static int syncToPools(s2World* world, WorldBinding* b)
 {
 	const uint64_t id = (uint64_t)world->stepId;
+	if (b->resident && (id == b->stepId || id == b->stepId + 1))
+	{
+		int rcLean = syncBodiesAndBoxes(world, b);
+		if (rcLean != 0)
+		{
+			return rcLean;
+		}
+	}
 	if (!b->resident || (id != b->stepId && id != b->stepId + 1) || !b->contactsStale)
 	{
 		return 0;
@@ -591,7 +757,7 @@ void s2amdBinding_DestroyWorld(s2World* world)
 	}
 	void* owned[] = {b->solveBodies, b->solveContacts, b->solveJoints, b->bodies,		b->contacts,	 b->joints,	   b->shapes,	b->pairs,
 					 b->origins,	 b->separated,	   b->liveKey,	   b->slots,		b->slotContacts, b->slotPairs, b->newPairs,
-					 b->createdSlots,	 b->boxes};
+					 b->createdSlots,	 b->boxes,	 b->poses,	  b->refitOrder,	b->pendingBoxes, b->pendingSteps};
 	for (size_t i = 0; i < sizeof(owned) / sizeof(owned[0]); ++i)
 	{
 		free(owned[i]);
@@ -721,6 +887,14 @@ static int uploadWorld(s2World* w, WorldBinding* b)
 	{
 		b->resident = 0;
 		return rc;
+	}
+	b->poses = (float*)growTo(b->poses, (size_t)nb * 4, sizeof(float));
+	b->bodiesStale = b->boxesStale = 0;
+	b->lastMoved = 1; // (a fresh world: everything is in the move buffer)
+	if (b->poses == NULL || (rc = sendRefitOrder(w, b)) != 0)
+	{
+		b->resident = 0;
+		return rc != 0 ? rc : S2AMD_E_DEVICE;
 	}
 	b->resident = 1;
 	b->bodyCapacity = nb, b->bodyCount = w->bodyPool.count;
@@ -930,9 +1104,16 @@ void s2amdBinding_WorldStep(s2World* world, float timeStep, int velIters, int po
 		return;
 	}
 	world->stepId += 1;
+	s_rebuildTrees = rebuildTrees;
 	const double t0 = wallMs();
 	int rc = 0;
-	if (s_devicePairs && residentMatches(world, b))
+	const int lean = s_devicePairs && residentMatches(world, b);
+	if (!lean && b->resident)
+	{
+		// the host's stage 1 (or a re-upload) is about to read trees, boxes and bodies: whatever the lean steps left on the device
+		rc = syncBodiesAndBoxes(world, b);
+	}
+	if (rc == 0 && lean)
 	{
 		// stage 1 with the pair discovery on the device (s2amd_world_find_pairs on the boxes the last refit re-inflated
 		// -- the proxies in the reference's move buffer); the pool bookkeeping of each new pair is s2CreateContact as ever,
@@ -940,7 +1121,7 @@ void s2amdBinding_WorldStep(s2World* world, float timeStep, int velIters, int po
 		// contact lands in the pool slot the host route gives it.  The trees keep following the fat boxes (below).
 		s2BroadPhase* bp = &world->broadPhase;
 		b->createdCount = 0; // stage 1 runs here: every contact it creates is recorded below
-		if (s2Array(bp->moveArray).count > 0)
+		if (b->lastMoved > 0 || s2Array(bp->moveArray).count > 0)
 		{
 			int32_t count = 0;
 			rc = s_api.worldFindPairs(b->solver, b->newPairs, b->newPairCapacity, &count);
@@ -949,6 +1130,13 @@ void s2amdBinding_WorldStep(s2World* world, float timeStep, int velIters, int po
 				b->newPairCapacity = count + 1024;
 				b->newPairs = (int32_t*)realloc(b->newPairs, (size_t)b->newPairCapacity * 2 * sizeof(int32_t));
 				rc = s_api.worldFindPairs(b->solver, b->newPairs, b->newPairCapacity, &count);
+			}
+			if (rc == 0 && count > 0)
+			{
+				// new pairs: their creation order is read off the trees and the move buffer, which the steps since the last
+				// pair have only logged -- replayed now (in nearly every step of a settled world there is nothing to create, and
+				// the trees are not touched at all)
+				flushTrees(world, b);
 			}
 			if (rc == 0 && count > 1)
 			{
@@ -971,10 +1159,9 @@ void s2amdBinding_WorldStep(s2World* world, float timeStep, int velIters, int po
 					b->createdSlots[b->createdCount++] = world->bodies[shapeA->bodyIndex].contactList >> 1;
 				}
 			}
-			s2Array_Clear(bp->moveArray);
-			s2ClearSet(&bp->moveSet);
+			// (the move buffer is cleared and the trees rebuilt -- stage 2, world.c:130 -- when this step's boxes are replayed:
+			// flushTrees)
 		}
-		rebuildTrees(bp); // stage 2 (world.c:130) every step: the traversal order above is read off these trees
 	}
 	else
 	{
@@ -999,14 +1186,28 @@ void s2amdBinding_WorldStep(s2World* world, float timeStep, int velIters, int po
 	}
 	const double t3 = wallMs();
 	int32_t separatedCount = 0;
-	if (rc == 0)
+	int32_t movedCount = 0;
+	const int leanBack = lean && rc == 0; // (a step that had to upload the world reads everything back once, like the host-pairs route)
+	if (leanBack)
 	{
-		rc = s_api.worldDownload(b->solver, b->bodies, b->bodyCapacity, NULL, b->contactCapacity, NULL, b->jointCapacity, NULL, b->shapeCapacity, NULL,
-								 b->origins, NULL);
+		rc = reservePending(b, info.movedCount); // (the step's boxes are written straight into the log)
+		if (rc == 0)
+		{
+			rc = s_api.worldDownloadStep(b->solver, b->poses, b->bodyCapacity, b->pendingBoxes + b->pendingBoxCount, b->pendingBoxCapacity - b->pendingBoxCount,
+										 &movedCount);
+		}
 	}
-	if (rc == 0 && info.movedCount > 0)
+	else
 	{
-		rc = s_api.worldDownloadBoxes(b->solver, b->boxes, b->shapeCapacity); // 36 bytes per shape instead of the 196-byte records
+		if (rc == 0)
+		{
+			rc = s_api.worldDownload(b->solver, b->bodies, b->bodyCapacity, NULL, b->contactCapacity, NULL, b->jointCapacity, NULL, b->shapeCapacity, NULL,
+									 b->origins, NULL);
+		}
+		if (rc == 0 && info.movedCount > 0)
+		{
+			rc = s_api.worldDownloadBoxes(b->solver, b->boxes, b->shapeCapacity); // 36 bytes per shape instead of the 196-byte records
+		}
 	}
 	if (rc == 0 && info.separatedCount > 0)
 	{
@@ -1023,17 +1224,43 @@ void s2amdBinding_WorldStep(s2World* world, float timeStep, int velIters, int po
 	b->contactsStale = 1;
 	s_steps += 1;
 	b->stepId = (uint64_t)world->stepId;
-	s2amdBinding_UnpackBodies(world, b->bodies);
-	for (int i = 0; i < b->bodyCapacity; ++i)
+	b->lastMoved = info.movedCount;
+	if (leanBack)
 	{
-		s2Body* body = world->bodies + i;
-		if (s2IsFree(&body->object) || body->type == s2_staticBody)
+		// what the public API reads of a body (src/body.c:316-340: origin, rot) and what the step consumed (forces, world.c:274-275)
+		for (int i = 0; i < b->bodyCapacity; ++i)
 		{
-			continue;
+			s2Body* body = world->bodies + i;
+			if (s2IsFree(&body->object) || body->type == s2_staticBody)
+			{
+				continue;
+			}
+			const float* p = b->poses + 4 * i;
+			body->origin = (s2Vec2){p[0], p[1]};
+			body->rot = (s2Rot){p[2], p[3]};
+			body->force = s2Vec2_zero;
+			body->torque = 0.0f;
 		}
-		body->origin = (s2Vec2){b->origins[2 * i], b->origins[2 * i + 1]};
-		body->force = s2Vec2_zero;
-		body->torque = 0.0f;
+		b->bodiesStale = 1;
+		b->boxesStale = 1;
+		// the step's boxes went straight into the log
+		b->pendingBoxCount += movedCount;
+		b->pendingSteps[b->pendingStepCount++] = movedCount;
+	}
+	else
+	{
+		s2amdBinding_UnpackBodies(world, b->bodies);
+		for (int i = 0; i < b->bodyCapacity; ++i)
+		{
+			s2Body* body = world->bodies + i;
+			if (s2IsFree(&body->object) || body->type == s2_staticBody)
+			{
+				continue;
+			}
+			body->origin = (s2Vec2){b->origins[2 * i], b->origins[2 * i + 1]};
+			body->force = s2Vec2_zero;
+			body->torque = 0.0f;
+		}
 	}
 	// src/world.c:163-167: the pairs stage 3 found separated
 	for (int i = 0; i < separatedCount; ++i)
@@ -1043,7 +1270,11 @@ void s2amdBinding_WorldStep(s2World* world, float timeStep, int velIters, int po
 		b->liveCount -= b->liveKey[slot] >= 0 ? 1 : 0;
 		b->liveKey[slot] = -1;
 	}
-	if (info.movedCount > 0)
+	if (leanBack && (b->pendingStepCount >= S2AMD_BINDING_MAX_PENDING_STEPS || b->pendingBoxCount >= S2AMD_BINDING_MAX_PENDING_BOXES))
+	{
+		flushTrees(world, b); // (bounds the log; the work is what the per-step path would have done by now)
+	}
+	if (!leanBack && info.movedCount > 0)
 	{
 		// src/world.c:259-297: the tight boxes of every shape, the tree only where the fat box was re-inflated -- in the
 		// reference's order (bodies, then each body's shape list): the move buffer's order decides the pool slots of the

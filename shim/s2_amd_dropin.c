@@ -173,6 +173,32 @@ float __wrap_s2RevoluteJoint_GetMotorTorque(s2JointId jointId, float inverseTime
 	return __real_s2RevoluteJoint_GetMotorTorque(jointId, inverseTimeStep);
 }
 
+/* ---- calls that read or edit the broad-phase trees and the pools: the steps since the last pair only logged their tree work
+ * (s2_amd_binding.c: lean read-back), it is done now, before the reference's code touches the trees ---- */
+void __real_s2World_QueryAABB(s2WorldId worldId, s2Box aabb, s2QueryCallbackFcn* fcn, void* context);
+void __wrap_s2World_QueryAABB(s2WorldId worldId, s2Box aabb, s2QueryCallbackFcn* fcn, void* context)
+{
+	syncWorld(s2GetWorldFromId(worldId));
+	__real_s2World_QueryAABB(worldId, aabb, fcn, context);
+}
+void __real_s2DestroyBody(s2BodyId bodyId);
+void __wrap_s2DestroyBody(s2BodyId bodyId)
+{
+	syncWorld(s2GetWorldFromIndex(bodyId.world));
+	__real_s2DestroyBody(bodyId);
+}
+#define S2_DROPIN_SHAPE(NAME, GEOM)                                                                                              \
+	s2ShapeId __real_##NAME(s2BodyId bodyId, const s2ShapeDef* def, const GEOM* geometry);                                       \
+	s2ShapeId __wrap_##NAME(s2BodyId bodyId, const s2ShapeDef* def, const GEOM* geometry)                                        \
+	{                                                                                                                            \
+		syncWorld(s2GetWorldFromIndex(bodyId.world));                                                                            \
+		return __real_##NAME(bodyId, def, geometry);                                                                             \
+	}
+S2_DROPIN_SHAPE(s2CreateCircleShape, s2Circle)
+S2_DROPIN_SHAPE(s2CreateSegmentShape, s2Segment)
+S2_DROPIN_SHAPE(s2CreateCapsuleShape, s2Capsule)
+S2_DROPIN_SHAPE(s2CreatePolygonShape, s2Polygon)
+
 /* ---- setters: the host copy changes, the resident copy has to follow ---- */
 #define S2_DROPIN_EDIT(RET, NAME, ID_T, PARAMS, ARGS)                                                                            \
 	RET __real_##NAME PARAMS;                                                                                                    \

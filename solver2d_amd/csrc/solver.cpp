@@ -166,7 +166,7 @@ void s2amd_destroy(s2amdSolver* s)
 					  &s->dAdjOffsets,	&s->dAdjList,	  &s->dAdjHeavy,	  &s->dGatherIndex,	 &s->dOps,			 &s->dGroups.buf,	&s->dContactTail.buf,
 					  &s->dJointTail.buf, &s->dMsg,			  &s->dStripA.buf,	 &s->dStripB.buf,	 &s->dStripLean,	&s->dPersist,
 					  &s->dGranules,	&s->dPersistOps,	  &s->dShapes,		 &s->dPairs,		 &s->dOrigins,		&s->dStatus,
-					  &s->dPointBytes,	&s->dWorldSummary, &s->dJointedKeys,	 &s->dContactStage, &s->dPairScratch,	  &s->dPairKeys,		 &s->dPatches,		 &s->dScanTmp,		 &s->dResident.buf,	 &s->dResidentDesc, &s->dResidentOps, &s->dWatched,
+					  &s->dPointBytes,	&s->dWorldSummary, &s->dJointedKeys,	 &s->dContactStage, &s->dPairScratch,	  &s->dPairKeys,		 &s->dPatches,		 &s->dScanTmp,		 &s->dResident.buf,	 &s->dResidentDesc, &s->dResidentOps, &s->dWatched, &s->dRefitOrder, &s->dStepBack,
 					  &s->dSlotBytes,	  &s->dJointAdjRange, &s->dJointAdjList, &s->dShapeBoxes};
 	for (DevBuf* b : bufs)
 	{

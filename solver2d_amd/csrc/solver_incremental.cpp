@@ -218,9 +218,11 @@ bool stripPlace(s2amdSolver* s, Patcher& p, const ContactChange& ch)
 	const bool wa = writable(s, ch.a), wb = writable(s, ch.b);
 	const uint32_t used = (wa ? m.roundMask[table][(size_t)(off + la)] : 0u) | (wb ? m.roundMask[table][(size_t)(off + lb)] : 0u);
 	const int r0 = m.firstRound[table][(size_t)group], n = m.roundCount[table][(size_t)group];
+	const auto opened = table == 0 ? m.openedRoundOf.find(group) : m.openedRoundOf.end();
 	for (int r = 0; r < n; ++r)
 	{
-		IncrementalStrips::Round& round = m.rounds[(size_t)(r0 + r)];
+		// (a strip's rounds are contiguous in `rounds` as built; a spare round opened later sits behind all of them)
+		IncrementalStrips::Round& round = m.rounds[(size_t)((opened != m.openedRoundOf.end() && r == n - 1) ? opened->second : r0 + r)];
 		if (((used >> r) & 1u) != 0 || round.freePositions.empty())
 		{
 			continue;
@@ -242,6 +244,47 @@ bool stripPlace(s2amdSolver* s, Patcher& p, const ContactChange& ch)
 		p.word(s->dContactIndex.p, (size_t)k, (uint32_t)ch.slot);
 		p.word(s->dContactLocal.p, 2 * (size_t)k, (uint32_t)la);
 		p.word(s->dContactLocal.p, 2 * (size_t)k + 1, (uint32_t)lb);
+		m.touched = true;
+		m.placed += 1;
+		s->placedTotal += 1;
+		s->slackPositions -= 1;
+		return true;
+	}
+	if (table == 0 && group < (int)m.spareRound.size() && m.spareRound[(size_t)group] >= 0)
+	{
+		// every round is taken on these bodies: the strip's spare round opens -- two words of its descriptor (the round count,
+		// the new round's range) -- and takes the constraint
+		IncrementalStrips::Round& round = m.rounds[(size_t)m.spareRound[(size_t)group]];
+		const int r = round.round;
+		const int begin = round.freePositions.back(), end = round.freePositions.front() + 1;
+		const StripDesc* desc = s->leanA.descs + group;
+		const size_t words = (const uint32_t*)desc - (const uint32_t*)s->leanA.descs;
+		p.word(s->leanA.descs, words + 3, (uint32_t)(r + 1));		  // batchCount
+		p.word(s->leanA.descs, words + 8 + 4 * (size_t)r, (uint32_t)begin); // batch[r] = {begin, end, 0, 0}
+		p.word(s->leanA.descs, words + 9 + 4 * (size_t)r, (uint32_t)end);
+		m.roundCount[0][(size_t)group] = r + 1;
+		m.spareRound[(size_t)group] = -1;
+		s->persist.maxRoundsA = std::max(s->persist.maxRoundsA, r + 1);
+		m.roundsOpened += 1;
+		// (the rounds of a group are contiguous in `rounds` only as built: the opened one is found through roundOfPosition / here)
+		const int k = round.freePositions.back();
+		round.freePositions.pop_back();
+		if (wa)
+		{
+			m.roundMask[table][(size_t)(off + la)] |= 1u << r;
+		}
+		if (wb)
+		{
+			m.roundMask[table][(size_t)(off + lb)] |= 1u << r;
+		}
+		s->contacts.order[(size_t)k] = ch.slot;
+		s->contacts.local[(size_t)k] = make_int2(la, lb);
+		m.positionOfSlot[(size_t)ch.slot] = k;
+		s->inc.positionOfSlot[(size_t)ch.slot] = -2;
+		p.word(s->dContactIndex.p, (size_t)k, (uint32_t)ch.slot);
+		p.word(s->dContactLocal.p, 2 * (size_t)k, (uint32_t)la);
+		p.word(s->dContactLocal.p, 2 * (size_t)k + 1, (uint32_t)lb);
+		m.openedRoundOf[group] = (int)(&round - m.rounds.data());
 		m.touched = true;
 		m.placed += 1;
 		s->placedTotal += 1;

@@ -210,7 +210,9 @@ struct IncrementalStrips
 	std::vector<uint32_t> roundMask[2]; // per (body offset of the group + local slot): rounds in use on a writable body
 	std::vector<int> bodyOffset[2];		// per group: its first entry in roundMask
 	std::vector<int> positionOfSlot;	// contact slot -> strip position, -1
-	long placed = 0;
+	std::unordered_map<int, int> openedRoundOf; // strip -> index in `rounds` of its spare round once opened (its last round)
+	std::vector<int> spareRound;		// per strip: its CLOSED spare round in `rounds` (no batch of the descriptor covers it yet), -1
+	long placed = 0, roundsOpened = 0;
 };
 
 struct s2amdSolver
@@ -284,6 +286,9 @@ struct s2amdSolver
 	DevBuf dJointAdjRange, dJointAdjList; // body -> incident global joints in sweep order (body-centric joint warm start)
 	bool jointAdjValid = false;
 	DevBuf dShapeBoxes;		// world chain: s2amd_world_download_boxes' staging
+	DevBuf dRefitOrder, dStepBack; // s2amd_world_set_refit_order; staging of s2amd_world_download_step {count, moved boxes} and the poses
+	int refitOrderCount = 0;
+	int lastMovedCount = 0; // enlarged shapes of the last s2amd_world_step
 	DevBuf dSlotBytes;		// world chain: one byte per pair slot for a structure build (world.hip: slotBytesKernel)
 	std::vector<uint8_t> hSlotBytes;
 	bool slotBytesFresh = false; // hSlotBytes is of the state the device is in right now (cleared by every world call that changes it)
@@ -342,6 +347,7 @@ struct s2amdSolver
 	int optStripSlack = 1; // strip and seam rounds are laid out with free positions for created contacts (solver_incremental.cpp)
 	int optPairLanes = 0; // two lanes per constraint (pair_kernel.hip; measured no faster: kept as an option); 0: one lane per constraint
 	int optStripRetry = 1; // try other strip widths when the partition needs the 8-round kernel variant
+	float stripScaleFound = 0.0f;   // the strip width (x strip_bodies) the last search settled on, 0: none yet (a new world forgets it)
 	bool stripRetryPending = false; // ... postponed until the graph has been quiet for 32 steps
 	int optPersistDebug = 0;
 	int optPersistSpinLimit = 1 << 21;
@@ -381,7 +387,8 @@ struct s2amdSolver
 	int optMaxGroupBodies = 2048;
 	int optPackGroupBodies = 1024;
 	int optStrips = 1;		   // cut islands that do not fit one LDS group into strips of BFS levels (2 launches per sweep)
-	int optStripBodies = 160;  // target bodies per strip (base-200: 67-95 strips run at 0.250 ms, 54 strips at 0.262 ms)
+	int optStripBodies = 8;  // target bodies per strip: small = strips of exactly two BFS levels, five interior colour rounds (r3: 133 us per step at base 200
+							 // against 154 us with the six rounds of three-level strips); strip_retry tries wider ones when there are more level pairs than CUs
 	int optStripMinBodies = 4096; // loose bodies below which the colour-batch path is kept
 
 	// graph cache
@@ -410,9 +417,19 @@ struct s2amdSolver
 inline void noteGraphChanged(s2amdSolver* s, bool newWorld = false)
 {
 	const bool stripsInUse = s->dStripA.view.groupCount > 0;
+	if (newWorld)
+	{
+		s->stripScaleFound = 0.0f;
+	}
 	if (newWorld || s->optStripPatience == 0)
 	{
 		s->stripPatienceNow = s->optStripPatience;
+	}
+	else if (stripsInUse && s->stripInc.valid)
+	{
+		// strips that take created contacts in place (IncrementalStrips) die only of a contact that fits nowhere: they are worth
+		// building again at once unless this one lived for less than it cost (a strip build ~ 3 ms buys ~0.4 ms per step)
+		s->stripPatienceNow = s->graphAge < 8 ? std::min(std::max(2 * s->stripPatienceNow, 2), 32) : s->optStripPatience;
 	}
 	else if (stripsInUse && s->graphAge < 32)
 	{

@@ -1254,6 +1254,18 @@ do                                                                              
 					fprintf(stderr, "[s2amd]   rounds %d: %d interiors, %d seam pairs\n", r, histA[r], histB[r]);
 				}
 			}
+			if (getenv("S2AMD_DEBUG_ROUNDS")) // constraints (free positions included) per interior round of every strip
+			{
+				for (int i = 0; i < K; ++i)
+				{
+					fprintf(stderr, "[s2amd]   strip %d:", i);
+					for (int bi = A.cBatchOffsets[(size_t)i]; bi < A.cBatchOffsets[(size_t)i + 1]; ++bi)
+					{
+						fprintf(stderr, " %d", A.cBatches[(size_t)bi].y - A.cBatches[(size_t)bi].x);
+					}
+					fprintf(stderr, "\n");
+				}
+			}
 		}
 		if (ok)
 		{
@@ -1431,6 +1443,7 @@ struct StructureBuild
 	bool stripsNeedOneLaunch = false;
 	LocalSlots slots;
 	std::vector<int> seamGroup;
+	std::vector<int4> spareRounds; // {strip, first position, positions, round index} of the closed spare rounds (emitGroup)
 	int stripBaseC = 0;
 	bool rebuild = false; // the structure just built cannot run: build again with what was learnt (stripsRejected / residentRejected)
 
@@ -2048,6 +2061,21 @@ struct StructureBuild
 				t.cBatches.push_back(make_int4(batchOffsets[bi], batchOffsets[bi + 1], isTail ? 1 : 0, 0));
 			}
 		}
+		if (roundSlack > 0 && &t == &s->hStripA)
+		{
+			// a strip with fewer interior rounds than the kernels take keeps positions for ONE more: a created contact whose bodies
+			// have every round taken opens it (solver_incremental.cpp: stripPlace patches the strip's descriptor); until then no
+			// round covers them and they cost nothing
+			const int rounds = (int)t.cBatches.size() - t.cBatchOffsets.back();
+			if (rounds > 0 && rounds < S2_STRIP_ROUNDS)
+			{
+				const int begin = (int)cs.order.size(), cap = 16;
+				cs.order.resize(cs.order.size() + (size_t)cap, -1);
+				cs.local.resize(cs.local.size() + (size_t)cap, make_int2(0, 0));
+				cs.colorOffsets.push_back(begin + cap);
+				spareRounds.push_back(make_int4(t.count(), begin, cap, rounds)); // (t.count(): this group's index, its row is closed below)
+			}
+		}
 		t.cBatchOffsets.push_back((int)t.cBatches.size());
 		colourPart(jids, jla, jlb, lconf, (int)bodies.size(), js, batchOffsets, tail, &pos);
 		for (size_t i = 0; i < pos.size(); ++i)
@@ -2383,6 +2411,24 @@ struct StructureBuild
 				}
 			}
 		}
+		// the closed spare rounds: no batch covers their positions yet
+		m.spareRound.assign((size_t)s->hStripA.count(), -1);
+		for (const int4& sp : spareRounds)
+		{
+			if (sp.x >= s->hStripA.count() || sp.y < m.base || sp.y + sp.z > m.end)
+			{
+				continue;
+			}
+			IncrementalStrips::Round r;
+			r.table = 0, r.group = sp.x, r.round = sp.w;
+			for (int k = sp.y + sp.z - 1; k >= sp.y; --k)
+			{
+				m.roundOfPosition[(size_t)(k - m.base)] = (int)m.rounds.size();
+				r.freePositions.push_back(k);
+			}
+			m.spareRound[(size_t)sp.x] = (int)m.rounds.size();
+			m.rounds.push_back(std::move(r));
+		}
 		m.valid = true;
 	}
 
@@ -2474,23 +2520,28 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 int buildStructure(s2amdSolver* s, int solverType)
 {
 	const uint64_t before = s->structureGeneration;
-	int rc = buildStructureWith(s, solverType, 1.0f);
+	// (a world whose partition was searched for once keeps the width that won: a graph that changes is not searched again as
+	// long as that width still gives the persistent kernel something it can run)
+	const float firstScale = s->stripScaleFound > 0.0f ? s->stripScaleFound : 1.0f;
+	int rc = buildStructureWith(s, solverType, firstScale);
 	if (rc != S2AMD_OK || s->structureGeneration == before || s->optStripRetry == 0)
 	{
 		return rc;
 	}
-	// outcome of a build that tried strips: 2 = persistent step on the 6-round variant, 1 = some strip kernel can run it,
-	// 0 = rejected (no strip kernel takes this partition: colour batches)
+	// outcome of a build that tried strips: 3 = persistent step with at most five interior and two seam colour rounds per sweep
+	// (strips of exactly two BFS levels: no body has all six neighbours inside its strip -- measured 133 against 154 us per
+	// step at base 200, r3), 2 = persistent on the six-round variants, 1 = some strip kernel can run it, 0 = rejected (no strip
+	// kernel takes this partition: colour batches)
 	auto outcome = [&]() {
 		if (s->persistValid && !s->persist.wideRounds)
 		{
-			return 2;
+			return (s->persist.maxRoundsA <= 5 && s->persist.maxSeamRounds <= 2) ? 3 : 2;
 		}
 		return (s->persistValid || (s->leanAValid && s->leanBValid)) ? 1 : 0;
 	};
 	const bool triedStrips = s->stripsRejected || s->dStripA.view.groupCount > 0;
 	s->stripRetryPending = false;
-	if (!triedStrips || outcome() == 2)
+	if (!triedStrips || outcome() == 3 || (s->stripScaleFound > 0.0f && outcome() >= 2))
 	{
 		return rc;
 	}
@@ -2501,9 +2552,11 @@ int buildStructure(s2amdSolver* s, int solverType)
 		s->stripRetryPending = true;
 		return rc;
 	}
-	float bestScale = 1.0f;
+	float bestScale = firstScale;
 	int best = outcome();
-	const float scales[] = {0.85f, 1.15f, 0.7f, 1.3f, 0.6f, 1.6f, 2.0f};
+	// (the default strip is as thin as the level structure allows -- strip_bodies 8 --: the other candidates are wider, for
+	// graphs with more level pairs than the GPU has CUs)
+	const float scales[] = {4.0f, 10.0f, 20.0f, 2.0f, 40.0f, 80.0f, 0.5f};
 	for (float scale : scales)
 	{
 		s->structureDirty = true;
@@ -2513,8 +2566,9 @@ int buildStructure(s2amdSolver* s, int solverType)
 			return rc;
 		}
 		const int o = outcome();
-		if (o == 2)
+		if (o == 3)
 		{
+			s->stripScaleFound = scale;
 			return rc;
 		}
 		if (o > best)
@@ -2524,5 +2578,6 @@ int buildStructure(s2amdSolver* s, int solverType)
 	}
 	s->structureDirty = true;
 	s->stripsRejected = false;
+	s->stripScaleFound = best >= 2 ? bestScale : 0.0f;
 	return buildStructureWith(s, solverType, bestScale);
 }

@@ -94,6 +94,104 @@ __global__ __launch_bounds__(S2_BLOCK) void shapeBoxesKernel(const s2amdShape* s
 	}
 }
 
+// s2amd_world_download_step: {origin, rot} of every body slot
+__global__ __launch_bounds__(S2_BLOCK) void stepPosesKernel(const s2amdBody* bodies, const float* origins, int n, float4* out)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n)
+	{
+		out[i] = make_float4(origins[2 * i], origins[2 * i + 1], bodies[i].rot[0], bodies[i].rot[1]);
+	}
+}
+
+// ... and the re-inflated shapes in the caller's refit order: an ordered compaction in two launches over tiles of 256 entries of
+// the order array -- per-tile counts, then every tile adds up the counts before it (a few hundred at most) and writes its
+// entries at their ranks.  out[0] = count, entries from out + 4 words on; counts: one int per tile.
+S2_DEV bool movedAt(const s2amdShape* shapes, int shapeCapacity, const int* order, int n, int r, int& sh)
+{
+	if (r >= n)
+	{
+		return false;
+	}
+	sh = order ? order[r] : r;
+	return sh >= 0 && sh < shapeCapacity && shapes[sh].type != S2AMD_SHAPE_FREE && shapes[sh].enlarged != 0;
+}
+
+__global__ __launch_bounds__(S2_BLOCK) void movedCountKernel(const s2amdShape* shapes, int shapeCapacity, const int* order, int n, int* counts)
+{
+	__shared__ int waves[S2_BLOCK / 64];
+	int sh;
+	const bool mine = movedAt(shapes, shapeCapacity, order, n, (int)(blockIdx.x * blockDim.x + threadIdx.x), sh);
+	const unsigned long long mask = __ballot(mine);
+	if ((threadIdx.x & 63) == 0)
+	{
+		waves[threadIdx.x >> 6] = __popcll(mask);
+	}
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		int total = 0;
+		for (int w = 0; w < S2_BLOCK / 64; ++w)
+		{
+			total += waves[w];
+		}
+		counts[blockIdx.x] = total;
+	}
+}
+
+__global__ __launch_bounds__(S2_BLOCK) void movedWriteKernel(const s2amdShape* shapes, int shapeCapacity, const int* order, int n, const int* counts, int32_t* out,
+															int capacity)
+{
+	__shared__ int waves[S2_BLOCK / 64];
+	__shared__ int base;
+	int sh = 0;
+	const bool mine = movedAt(shapes, shapeCapacity, order, n, (int)(blockIdx.x * blockDim.x + threadIdx.x), sh);
+	const unsigned long long mask = __ballot(mine);
+	const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+	if (lane == 0)
+	{
+		waves[wave] = __popcll(mask);
+	}
+	if (threadIdx.x < 64)
+	{
+		// the tiles before this one (and, in the last tile, the total)
+		int partial = 0;
+		for (int b = lane; b < (int)blockIdx.x; b += 64)
+		{
+			partial += counts[b];
+		}
+		for (int d = 32; d > 0; d >>= 1)
+		{
+			partial += __shfl_xor(partial, d);
+		}
+		if (lane == 0)
+		{
+			base = partial;
+		}
+	}
+	__syncthreads();
+	int at = base;
+	for (int w = 0; w < wave; ++w)
+	{
+		at += waves[w];
+	}
+	at += __popcll(mask & ((1ull << lane) - 1ull));
+	if (blockIdx.x == gridDim.x - 1 && threadIdx.x == blockDim.x - 1)
+	{
+		out[0] = at + (mine ? 1 : 0);
+	}
+	if (mine && at < capacity)
+	{
+		s2amdMovedBox e;
+		e.shape = sh;
+		for (int k = 0; k < 4; ++k)
+		{
+			e.fatAABB[k] = shapes[sh].fatAABB[k];
+		}
+		((s2amdMovedBox*)(out + 4))[at] = e;
+	}
+}
+
 // manifold.constraintIndex from the resident point counts: exclusive scan of "has points" over the pool (the reference's
 // gather order, e.g. src/solve_tgs_soft.c:162-179), -1 for the slots the gather skips
 struct HasPoints
@@ -495,6 +593,7 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 		}
 		s->stats.persistFallbacks = s->persistFallbacks;
 	}
+	s->lastMovedCount = hSum->enlarged;
 	if (info)
 	{
 		info->separatedCount = contactsSeen.separated;
@@ -566,6 +665,94 @@ int s2amd_world_download_boxes(s2amdSolver* s, s2amdShapeBox* boxes, int32_t sha
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(boxes, s->dShapeBoxes.p, (size_t)s->shapeCapacity * sizeof(s2amdShapeBox), hipMemcpyDeviceToHost, s->stream));
 	HIP_TRY(hipStreamSynchronize(s->stream));
+	return S2AMD_OK;
+}
+
+int s2amd_world_set_refit_order(s2amdSolver* s, const int32_t* shapeOrder, int32_t count)
+{
+	if (!s || count < 0 || (count > 0 && !shapeOrder))
+	{
+		return fail(S2AMD_E_INVALID, "bad argument");
+	}
+	HIP_TRY(hipSetDevice(s->device));
+	s->refitOrderCount = 0;
+	if (count == 0)
+	{
+		return S2AMD_OK;
+	}
+	int rc = s->dRefitOrder.ensure((size_t)count * sizeof(int32_t));
+	if (rc)
+	{
+		return rc;
+	}
+	HIP_TRY(hipMemcpyAsync(s->dRefitOrder.p, shapeOrder, (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	s->refitOrderCount = count;
+	return S2AMD_OK;
+}
+
+int s2amd_world_download_step(s2amdSolver* s, float* poses, int32_t bodyCapacity, s2amdMovedBox* moved, int32_t movedCapacity, int32_t* movedCount)
+{
+	if (!s || !movedCount || bodyCapacity < 0 || movedCapacity < 0 || (movedCapacity > 0 && !moved))
+	{
+		return fail(S2AMD_E_INVALID, "bad argument");
+	}
+	if (!s->worldResident || !s->resident)
+	{
+		return fail(S2AMD_E_STATE, "no resident world");
+	}
+	if (poses && bodyCapacity < s->bodyCapacity)
+	{
+		return fail(S2AMD_E_CAPACITY, "pose array smaller than the resident body array");
+	}
+	*movedCount = s->lastMovedCount;
+	if (s->lastMovedCount > movedCapacity)
+	{
+		return fail(S2AMD_E_CAPACITY, "moved-box array too small");
+	}
+	HIP_TRY(hipSetDevice(s->device));
+	const int nb = s->bodyCapacity, want = s->lastMovedCount;
+	const size_t headBytes = 16 + (size_t)std::max(want, 1) * sizeof(s2amdMovedBox);
+	const size_t poseOffset = (headBytes + 255) & ~size_t(255);
+	int rc = s->dStepBack.ensure(poseOffset + (size_t)std::max(nb, 1) * sizeof(float4));
+	if (rc)
+	{
+		return rc;
+	}
+	char* base = (char*)s->dStepBack.p;
+	if (want > 0)
+	{
+		const bool ordered = s->refitOrderCount > 0;
+		const int n = ordered ? s->refitOrderCount : s->shapeCapacity;
+		const int tiles = (n + S2_BLOCK - 1) / S2_BLOCK;
+		const int* order = ordered ? (const int*)s->dRefitOrder.p : nullptr;
+		if ((rc = s->dScanTmp.ensure((size_t)std::max(tiles, 1) * sizeof(int))) != 0)
+		{
+			return rc;
+		}
+		movedCountKernel<<<dim3((unsigned)tiles), dim3(S2_BLOCK), 0, s->stream>>>((const s2amdShape*)s->dShapes.p, s->shapeCapacity, order, n, (int*)s->dScanTmp.p);
+		movedWriteKernel<<<dim3((unsigned)tiles), dim3(S2_BLOCK), 0, s->stream>>>((const s2amdShape*)s->dShapes.p, s->shapeCapacity, order, n, (const int*)s->dScanTmp.p,
+																				   (int32_t*)base, want);
+		HIP_TRY(hipGetLastError());
+	}
+	if (poses && nb > 0)
+	{
+		stepPosesKernel<<<gridFor((size_t)nb), dim3(S2_BLOCK), 0, s->stream>>>((const s2amdBody*)s->dBodies.p, (const float*)s->dOrigins.p, nb, (float4*)(base + poseOffset));
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipMemcpyAsync(poses, base + poseOffset, (size_t)nb * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+	}
+	int32_t head[4] = {0, 0, 0, 0};
+	if (want > 0)
+	{
+		HIP_TRY(hipMemcpyAsync(head, base, sizeof(head), hipMemcpyDeviceToHost, s->stream));
+		HIP_TRY(hipMemcpyAsync(moved, base + 16, (size_t)want * sizeof(s2amdMovedBox), hipMemcpyDeviceToHost, s->stream));
+	}
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	if (want > 0 && head[0] != want)
+	{
+		// (the refit order does not cover every shape that moved: the caller's order is stale)
+		return fail(S2AMD_E_STATE, "refit order misses " + std::to_string(want - head[0]) + " re-inflated shapes");
+	}
 	return S2AMD_OK;
 }
 

@@ -21,7 +21,7 @@ EXPORTS = [
     "s2amd_restore_bodies", "s2amd_get_contact_order", "s2amd_get_joint_order", "s2amd_get_stats",
     "s2amd_set_option", "s2amd_export_poses", "s2amd_export_poses_async", "s2amd_export_wait", "s2amd_measure_dominant", "s2amd_refit_shapes", "s2amd_find_pairs", "s2amd_synchronize", "s2amd_update_contacts", "s2amd_find_islands", "s2amd_color_constraints",
     "s2amd_world_upload", "s2amd_world_step", "s2amd_world_download", "s2amd_world_find_pairs", "s2amd_world_set_contacts",
-    "s2amd_device_alloc", "s2amd_device_free", "s2amd_device_read", "s2amd_world_separated", "s2amd_world_download_boxes",
+    "s2amd_device_alloc", "s2amd_device_free", "s2amd_device_read", "s2amd_world_separated", "s2amd_world_download_boxes", "s2amd_world_set_refit_order", "s2amd_world_download_step",
 ]
 
 _lib = None

@@ -153,7 +153,7 @@ def main():
                              ("SoftStep", 40, {"strip_patience": 0, "max_group_bodies": 256})):
         builds = churn(name, base, 6 if quick else 25, opts)
         print("churn %s base %d: %d structure builds" % (name, base, builds))
-    for name, base, opts in (("TGS_Soft", 60, {"strip_patience": 0}), ("SoftStep", 60, {"strip_patience": 0}), ("TGS_Soft", 100, {"strip_patience": 0, "wide": 0})):
+    for name, base, opts in (("TGS_Soft", 100, {"strip_patience": 0}), ("SoftStep", 100, {"strip_patience": 1}), ("TGS_Soft", 110, {"strip_patience": 0, "wide": 0, "strip_bodies": 160})):
         builds, placed, persistent = neighbour_churn(name, base, 10 if quick else 40, opts)
         print("neighbour churn %s base %d: %d structure builds, %d contacts placed, persistent %d" % (name, base, builds, placed, persistent))
     world_chain(20 if quick else 60, 3 if quick else 8)

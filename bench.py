@@ -103,27 +103,46 @@ def cpu_baseline(base, vel, pos, budget_s):
 
 
 def pmc_issue(kernel_prefixes, stem="persistent"):
-    """VALU-issue picture of the dominant kernel from the committed SQ pass (profiles/rNN_<stem>_pmc_sq.txt): VALU instructions
-    per wave, the fraction of the kernel's busy cycles in which a SIMD issued one, waves per launch.  None when absent."""
+    """VALU-issue picture of the dominant kernel from the committed SQ pass (profiles/rNN_<stem>_pmc_sq.txt, rocprofv3 --pmc, its
+    own run): VALU instructions per wave and the share of a SIMD's cycles in which it issues one -- a wave64 VALU instruction
+    occupies its SIMD's issue for 4 cycles (tools/valu_bench.hip), a CU has 4 SIMDs, and the waves a CU hosts during the launch
+    are the launch's waves over the CUs it occupies.  None when the summary is absent."""
     for rnd in ("r03", "r02"):
         path = os.path.join(ROOT, "profiles", "%s_%s_pmc_sq.txt" % (rnd, stem))
         try:
-            vals = {}
+            vals, calls, avg_ns = {}, None, None
             for l in open(path):
                 f = l.split()
-                if len(f) >= 4 and any(f[0].startswith(p) for p in kernel_prefixes) and f[1].startswith("SQ_"):
-                    vals.setdefault(f[1], float(f[3]))  # avg per launch
-            if "SQ_INSTS_VALU" in vals and "SQ_WAVES" in vals:
-                waves = vals["SQ_WAVES"]
-                out = {"valu_insts_per_wave": vals["SQ_INSTS_VALU"] / max(waves, 1.0), "waves_per_launch": waves,
+                if len(f) >= 4 and any(f[0].startswith(p) for p in kernel_prefixes):
+                    if f[1].startswith("SQ_"):
+                        vals.setdefault(f[1], (float(f[2]), float(f[3])))  # samples, average per sample
+                    elif calls is None and f[1].isdigit():
+                        calls, avg_ns = int(f[1]), float(f[2])  # the kernel table: calls, average duration
+            if "SQ_INSTS_VALU" in vals and "SQ_WAVES" in vals and calls:
+                instances = vals["SQ_WAVES"][0] / calls  # counter instances sampled per dispatch
+                waves = vals["SQ_WAVES"][1] * instances
+                per_wave = vals["SQ_INSTS_VALU"][1] / max(vals["SQ_WAVES"][1], 1e-9)
+                cycles = avg_ns * 2.4  # 2.4 GHz
+                out = {"valu_insts_per_wave": per_wave, "waves_per_launch": waves, "kernel_us_in_that_pass": avg_ns * 1e-3,
                        "source": "profiles/%s_%s_pmc_sq.txt (rocprofv3 --pmc SQ_*, separate passes of this command; not measured in this run)" % (rnd, stem)}
-                if "SQ_ACTIVE_INST_VALU" in vals and "SQ_BUSY_CYCLES" in vals:
-                    # both count per SE / per SIMD quad-cycles on gfx950: their ratio is the share of busy time a VALU instruction issued
-                    out["valu_issue_frac"] = vals["SQ_ACTIVE_INST_VALU"] / max(vals["SQ_BUSY_CYCLES"], 1.0)
+                out["_cycles"] = cycles
                 return out
-        except OSError:
+        except (OSError, ValueError):
             continue
     return None
+
+
+def finish_issue(issue, workgroups):
+    """CUs occupied and the per-SIMD VALU issue share, once the number of workgroups of the launch is known."""
+    if issue is None:
+        return None
+    cus = min(max(int(workgroups), 1), 256)
+    cycles = issue.pop("_cycles")
+    waves_per_cu = issue["waves_per_launch"] / cus
+    issue["workgroups"] = int(workgroups)
+    issue["cus_occupied_of_256"] = cus
+    issue["valu_issue_frac_per_simd"] = waves_per_cu * issue["valu_insts_per_wave"] * 4.0 / (4.0 * max(cycles, 1.0))
+    return issue
 
 
 def pmc_traffic_bytes(kernel_prefix, stem="persistent"):
@@ -236,7 +255,9 @@ def island_sharded_leg(ranks, islands, base, vel, pos, steps, warmup, graph=True
         line["roofline"]["traffic_gbs"] = traffic / max(us * 1e-6, 1e-12) / 1e9
         line["roofline"]["traffic_frac_of_peak"] = line["roofline"]["traffic_gbs"] / HBM_PEAK_GBS
         line["roofline"]["traffic_over_model"] = traffic / algo
-    line["issue"] = pmc_issue(("_Z16islandStepKernel",), "config5") if ranks.world == 1 and islands == 512 and base == 40 else None
+    line["issue"] = finish_issue(pmc_issue(("_Z16islandStepKernel",), "config5"), st["groupCount"]) if ranks.world == 1 and islands == 512 and base == 40 else None
+    if line["issue"] is not None:
+        line["issue"]["note"] = "512 workgroups of 512 threads on 256 CUs (two passes): the kernel is VALU-issue bound, not bandwidth bound"
     return line
 
 
@@ -597,9 +618,8 @@ def main():
         out["ranks_seen"], out["devices"] = ranks_seen, devices
         if persistent and args.base == 200:
             issue = pmc_issue((kernel_prefix,))
+            issue = finish_issue(issue, st["stripCount"])
             if issue is not None:
-                issue["workgroups"] = st["stripCount"]
-                issue["cus_occupied_of_256"] = min(st["stripCount"], 256)
                 issue["note"] = ("one island, %d strips = %d of 256 CUs hold a workgroup; a colour round is one wave's instruction stream per SIMD (4 cycles per "
                                  "instruction), %d dependent rounds per step: instruction-issue / latency bound, HBM idle" % (
                                      st["stripCount"], min(st["stripCount"], 256), 24 * 8))

@@ -77,8 +77,62 @@ S2_DEV WideRegs loadWide(const ContactView& c, int k, int ia, int ib)
 }
 
 S2_DEV V2 asV2(f2 v) { return v2(v.x, v.y); }
+// rotate (math.h:330-341) on 2-vectors: q = {s, c}, qn = {-s, c}: (c x + (-s) y, s x + c y) -- (-s) y == -(s y) and
+// a - b == a + (-b), so these are the reference's bits
+S2_DEV f2 rot2(f2 q, f2 qn, f2 l)
+{
+	return q.yx * l.xx + qn * l.yy;
+}
 
 // s2WarmStartContacts (solve_common.c:276-330): strip_kernel.hip warmSoftRegs
+// The warm start and the prep on 2-vectors both measured SLOWER (178 / 171 vs 131 us per launch: their even-aligned
+// register pairs push resident constraint registers into scratch on the hand-off path -- 84 spilled VGPRs instead of ~30);
+// only the chain (chainWide) is packed.  Kept for the A/B (tools/kernel_ab.sh).
+#ifndef S2_WIDE_PACKED_WARM
+#define S2_WIDE_PACKED_WARM 0
+#endif
+#ifndef S2_WIDE_PACKED_PREP
+#define S2_WIDE_PACKED_PREP 0
+#endif
+#if S2_WIDE_PACKED_WARM
+template <int POINTS> S2_DEV void warmWide(const WideRegs& p, float4* lvel, const float4* ldq, const float2* lmass, uint32_t salt)
+{
+	const uint32_t idx = p.idx ^ salt;
+	const int ia = (int)(idx & 0x1fffu), ib = (int)((idx >> 13) & 0x1fffu);
+	const int pointCount = (int)((idx >> 26) & 3u);
+	const float4 velA = lvel[ia], velB = lvel[ib];
+	const f2 qA = hi2(ldq[ia]), qB = hi2(ldq[ib]);
+	const float2 mA = lmass[ia], mB = lmass[ib];
+	const f2 n = f2{fromBits(asBits(p.n.x) ^ salt), p.n.y};
+	const f2 t = f2{n.y, -n.x};
+	const f2 qnA = f2{-qA.x, qA.y}, qnB = f2{-qB.x, qB.y};
+	const f2 nmA2 = f2{-mA.x, -mA.x}, mB2 = f2{mB.x, mB.x};
+	f2 vA = lo2(velA), vB = lo2(velB);
+	float wA = velA.z, wB = velB.z;
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		if (POINTS == 2 || j < pointCount)
+		{
+			const f2 rA = rot2(qA, qnA, p.lA[j]), rB = rot2(qB, qnB, p.lB[j]);
+			const f2 P = p.imp[j].xx * n + p.imp[j].yy * t; // add(mulSV(normalImpulse, normal), mulSV(tangentImpulse, tangent))
+			const f2 cA = rA * P.yx, cB = rB * P.yx;		// cross(r, P) = r.x P.y - r.y P.x
+			wA -= mA.y * (cA.x - cA.y);
+			vA = vA + nmA2 * P; // mulAdd(vA, -mA, P)
+			wB += mB.y * (cB.x - cB.y);
+			vB = vB + mB2 * P;
+		}
+	}
+	if ((idx & (1u << 28)) != 0)
+	{
+		lvel[ia] = make_float4(vA.x, vA.y, wA, 0.0f);
+	}
+	if ((idx & (1u << 29)) != 0)
+	{
+		lvel[ib] = make_float4(vB.x, vB.y, wB, 0.0f);
+	}
+}
+#else
 template <int POINTS> S2_DEV void warmWide(const WideRegs& p, float4* lvel, const float4* ldq, const float2* lmass, uint32_t salt)
 {
 	const uint32_t idx = p.idx ^ salt;
@@ -115,6 +169,7 @@ template <int POINTS> S2_DEV void warmWide(const WideRegs& p, float4* lvel, cons
 		lvel[ib] = make_float4(vB.x, vB.y, wB, 0.0f);
 	}
 }
+#endif
 
 // s2SolveContacts_TGS_Soft (solve_tgs_soft.c:17-135) = constraint_ops.h solveSoftRegs<SOFT_TGS>, operation for operation, in two
 // parts (the split of constraint_ops.h prepSoft / chainSoft):
@@ -124,9 +179,20 @@ template <int POINTS> S2_DEV void warmWide(const WideRegs& p, float4* lvel, cons
 //             every lane while the seam bodies are in flight);
 //   chainWide what depends on the VELOCITIES: relative velocity -> impulse -> clamp -> apply, point after point, normal then
 //             friction.  This is what a colour round has to wait for.
+// 1: the chain on explicit 2-vectors (v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per issue slot, each rounded on its own)
+#ifndef S2_WIDE_PACKED
+#define S2_WIDE_PACKED 1
+#endif
 struct WidePrep
 {
+#if S2_WIDE_PACKED
+	// the anchors as the chain wants them: perp(r) = (-r.y, r.x).  crossSV(w, r) = w perp(r) and cross(r, P) = perp(r).x P.x +
+	// perp(r).y P.y, term for term the reference's products ((-a) b == -(a b), x - y == x + (-y)), so the chain needs no
+	// per-component sign and its 2-vector algebra packs without moves
+	f2 pA[2], pB[2];
+#else
 	V2 rA[2], rB[2];
+#endif
 	float bias[2];
 	uint32_t soft; // bit j: point j takes the soft mass / impulse scales
 };
@@ -142,19 +208,41 @@ template <int POINTS> S2_DEV WidePrep prepWide(const WideRegs& p, const float4* 
 	const V2 dcA = v2(dqA.x, dqA.y), dcB = v2(dqB.x, dqB.y);
 	Rot qA, qB;
 	qA.s = dqA.z, qA.c = dqA.w, qB.s = dqB.z, qB.c = dqB.w;
+#if S2_WIDE_PACKED && S2_WIDE_PACKED_PREP
+	const f2 q2A = hi2(dqA), q2B = hi2(dqB);
+	const f2 qnA = f2{-q2A.x, q2A.y}, qnB = f2{-q2B.x, q2B.y};
+	const f2 dd2 = lo2(dqB) - lo2(dqA);
+	const f2 n2 = f2{normal.x, normal.y};
+#endif
 	WidePrep pre;
 	pre.soft = 0u;
 #pragma unroll
 	for (int j = 0; j < 2; ++j)
 	{
+#if S2_WIDE_PACKED
+		pre.pA[j] = pre.pB[j] = f2{0.0f, 0.0f};
+#else
 		pre.rA[j] = pre.rB[j] = v2(0.0f, 0.0f);
+#endif
 		pre.bias[j] = 0.0f;
 		if (POINTS == 2 || j < pointCount)
 		{
+#if S2_WIDE_PACKED && S2_WIDE_PACKED_PREP
+			const f2 rA = rot2(q2A, qnA, p.lA[j]), rB = rot2(q2B, qnB, p.lB[j]);
+			pre.pA[j] = f2{-rA.y, rA.x}, pre.pB[j] = f2{-rB.y, rB.x};
+			const f2 ds2 = dd2 + (rB - rA); // add(sub(dcB, dcA), sub(rB, rA))
+			const f2 sn = ds2 * n2;
+			const float s = (sn.x + sn.y) + p.p0[j];
+#else
 			const V2 rA = rotate(qA, asV2(p.lA[j])), rB = rotate(qB, asV2(p.lB[j]));
+#if S2_WIDE_PACKED
+			pre.pA[j] = f2{-rA.y, rA.x}, pre.pB[j] = f2{-rB.y, rB.x};
+#else
 			pre.rA[j] = rA, pre.rB[j] = rB;
+#endif
 			const V2 ds = add(sub(dcB, dcA), sub(rB, rA));
 			const float s = dot(ds, normal) + p.p0[j];
+#endif
 			// select form of: if (s > 0) bias = s * inv_h; else if (useBias) {bias = max(biasCoefficient * s, cap); ...}
 			const bool speculative = s > 0.0f;
 			const bool soft = !speculative && useBias != 0;
@@ -166,6 +254,98 @@ template <int POINTS> S2_DEV WidePrep prepWide(const WideRegs& p, const float4* 
 	return pre;
 }
 
+#if S2_WIDE_PACKED
+S2_DEV float dot2(f2 a, f2 b) // a.x b.x + a.y b.y
+{
+	const f2 m = a * b;
+	return m.x + m.y;
+}
+S2_DEV float crossP(f2 perpR, f2 P) // cross(r, P) = r.x P.y - r.y P.x = perp(r).y P.y + perp(r).x P.x
+{
+	const f2 m = perpR * P;
+	return m.y + m.x;
+}
+
+template <int POINTS> S2_DEV void chainWide(WideRegs& p, const WidePrep& pre, float4* lvel, const float2* lmass, const float4* lcoef, uint32_t salt)
+{
+	const uint32_t idx = p.idx ^ salt;
+	const int ia = (int)(idx & 0x1fffu), ib = (int)((idx >> 13) & 0x1fffu);
+	const int pointCount = (int)((idx >> 26) & 3u);
+	const float4 velA = lvel[ia], velB = lvel[ib];
+	const float2 massA = lmass[ia], massB = lmass[ib];
+	const float4 sf = lcoef[(idx >> 30) & 1u];
+	const f2 n = f2{fromBits(asBits(p.n.x) ^ salt), p.n.y};
+	const f2 t = f2{n.y, -n.x}; // rightPerp
+	const f2 mA2 = f2{massA.x, massA.x}, mB2 = f2{massB.x, massB.x};
+	const float iA = massA.y, iB = massB.y;
+	f2 vA = lo2(velA), vB = lo2(velB);
+	float wA = velA.z, wB = velB.z;
+	float nImp[2], tImp[2];
+
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		if (POINTS == 2 || j < pointCount)
+		{
+			const f2 pA = pre.pA[j], pB = pre.pB[j];
+			const bool soft = (pre.soft >> j) & 1u;
+			const float massScale = soft ? sf.y : 1.0f;
+			const float impulseScale = soft ? sf.z : 0.0f;
+
+			// add(v, crossSV(w, r)) = v + w perp(r); sub(vrB, vrA); dot with the normal
+			const f2 vrB = vB + f2{wB, wB} * pB;
+			const f2 vrA = vA + f2{wA, wA} * pA;
+			const float vn = dot2(vrB - vrA, n);
+
+			const float normalMass = fromBits(asBits(p.p1[j]) ^ salt);
+			const float old = p.imp[j].x;
+			float impulse = -normalMass * massScale * (vn + pre.bias[j]) - impulseScale * old;
+			const float newImpulse = S2_MAXF(old + impulse, 0.0f);
+			impulse = newImpulse - old;
+			nImp[j] = newImpulse;
+			tImp[j] = p.imp[j].y;
+
+			const f2 P = f2{impulse, impulse} * n; // mulSV
+			vA = vA - mA2 * P;					   // mulSub
+			wA -= iA * crossP(pA, P);
+			vB = vB + mB2 * P; // mulAdd
+			wB += iB * crossP(pB, P);
+		}
+	}
+
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		if (POINTS == 2 || j < pointCount)
+		{
+			const float tangentMass = fromBits(asBits(p.p2[j]) ^ salt);
+			const f2 pA = pre.pA[j], pB = pre.pB[j];
+			const f2 vrB = vB + f2{wB, wB} * pB;
+			const f2 vrA = vA + f2{wA, wA} * pA;
+			const float vt = dot2(vrB - vrA, t);
+			float impulse = -tangentMass * vt;
+			const float maxFriction = p.friction * nImp[j];
+			const float newImpulse = S2_CLAMPF(tImp[j] + impulse, -maxFriction, maxFriction);
+			impulse = newImpulse - tImp[j];
+			const f2 P = f2{impulse, impulse} * t;
+			vA = vA - mA2 * P;
+			wA -= iA * crossP(pA, P);
+			vB = vB + mB2 * P;
+			wB += iB * crossP(pB, P);
+			p.imp[j] = f2{nImp[j], newImpulse};
+		}
+	}
+
+	if ((idx & (1u << 28)) != 0)
+	{
+		lvel[ia] = make_float4(vA.x, vA.y, wA, 0.0f);
+	}
+	if ((idx & (1u << 29)) != 0)
+	{
+		lvel[ib] = make_float4(vB.x, vB.y, wB, 0.0f);
+	}
+}
+#else
 template <int POINTS> S2_DEV void chainWide(WideRegs& p, const WidePrep& pre, float4* lvel, const float2* lmass, const float4* lcoef, uint32_t salt)
 {
 	const uint32_t idx = p.idx ^ salt;
@@ -243,6 +423,7 @@ template <int POINTS> S2_DEV void chainWide(WideRegs& p, const WidePrep& pre, fl
 		lvel[ib] = make_float4(vB.x, vB.y, wB, 0.0f);
 	}
 }
+#endif
 
 S2_DEV void storeWide(const ContactView& c, const WideRegs& p, int k)
 {

@@ -13,79 +13,9 @@
 // (batch-major, index within batch), reported to the host like any other order.
 
 #include "body_ops.h"
+#include "group_ops.h"
 
 #define S2_GROUP_THREADS 512
-
-// Pull one constraint's SoA records into the cache hierarchy.  The sequential tail is walked by one
-// lane, so every miss would be paid serially; this pass lets all lanes of the workgroup issue the
-// misses at once, the walk afterwards hits L1/L2.
-S2_DEV void touch(float4 v)
-{
-	asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-}
-S2_DEV void prefetchContact(const ContactView& c, int k)
-{
-	int2 b = c.localBodies[k];
-	asm volatile("" ::"v"(b.x), "v"(b.y));
-	touch(c.nf[k]);
-	touch(c.blockK[k]);
-	touch(c.blockNM[k]);
-	for (int j = 0; j < 2; ++j)
-	{
-		touch(c.anchor[j][k]);
-		touch(c.r0[j][k]);
-		touch(c.param[j][k]);
-		touch(c.soft[j][k]);
-		touch(c.fanchor[j][k]);
-		float2 i = c.impulse[j][k];
-		asm volatile("" ::"v"(i.x), "v"(i.y));
-	}
-}
-S2_DEV void prefetchJoint(const JointView& j, int k)
-{
-	int2 b = j.localBodies[k];
-	asm volatile("" ::"v"(b.x), "v"(b.y));
-	touch(j.frame[k]);
-	touch(j.mass[k]);
-	touch(j.pivot[k]);
-	touch(j.soft[k]);
-	touch(j.axial[k]);
-	touch(j.limits[k]);
-	touch(j.misc[k]);
-	float2 a = j.centerDiff0[k], i = j.impulse[k];
-	asm volatile("" ::"v"(a.x), "v"(a.y), "v"(i.x), "v"(i.y));
-}
-
-template <class P, class F> S2_DEV void forBatches(const int4* batches, int b0, int b1, P prefetch, F f)
-{
-	for (int bi = b0; bi < b1; ++bi)
-	{
-		int4 bt = batches[bi];
-		if (bt.z)
-		{
-			for (int k = bt.x + (int)threadIdx.x; k < bt.y; k += (int)blockDim.x)
-			{
-				prefetch(k);
-			}
-			__syncthreads();
-			if (threadIdx.x == 0)
-			{
-				for (int k = bt.x; k < bt.y; ++k)
-				{
-					f(k);
-				}
-			}
-		}
-		else
-		{
-			for (int k = bt.x + (int)threadIdx.x; k < bt.y; k += (int)blockDim.x)
-			{
-				f(k);
-			}
-		}
-		__syncthreads();
-	}
-}
 
 // The sequential tail, one WAVE instead of one lane: every lane pulls its own constraint into registers (the misses of 64
 // constraints in flight at once, no dependent L2 round trip left in the walk), then the lanes take turns in sweep order.

@@ -154,6 +154,12 @@ void launchPairStep(hipStream_t s, int kind, int warm, const ContactView& c, con
 int wideKernelSetup();
 void launchWideStep(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount);
 
+// generic_kernel.hip: the persistent strip step as an op interpreter -- every solver family, joints included
+int genericKernelSetup();
+size_t genericStepLds(int bodies, int seamBodies, int exports, int opCount, int useDq0);
+void launchGenericStep(hipStream_t s, const ContactView& c, const JointView& j, const BodyView& g, const GroupTable& a, const GroupTable& b, const PersistView& pv,
+					   const Op* ops, int opCount, const StepConsts& sc, s2amdContact* wire, int useDq0, int seamContacts, int seamJoints, size_t ldsBytes);
+
 // stage kernels on resident arrays (narrowphase.hip, broadphase.hip; called by world.hip)
 // summary: int[5] {separated pairs, active manifolds, zero/non-zero flips, point-count moves, enlarged shapes} (world.hip: WorldSummary)
 void launchUpdateContacts(hipStream_t st, const s2amdBody* bodies, const float* origins, const s2amdShape* shapes, s2amdPairState* pairs,

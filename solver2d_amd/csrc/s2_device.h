@@ -492,7 +492,8 @@ struct PersistDesc
 	int remapBase[2];	  // seam-group-local body -> LDS index of this workgroup, per seam side
 	int seamBatchCount[2];
 	int2 seamBatch[2][S2_PERSIST_B_ROUNDS]; // {begin, end} ranges of k
-	int pad[8];
+	int seamGroup[2]; // the seam's group in the phase-B group table (generic_kernel.hip walks its batch lists), -1: no such seam
+	int pad[6];
 };
 struct PersistView
 {

@@ -98,6 +98,10 @@ int s2amd_create(int device, s2amdSolver** out)
 	{
 		s->optPairLanes = atoi(v) != 0;
 	}
+	if (const char* v = getenv("S2AMD_GENERIC"))
+	{
+		s->optGeneric = atoi(v) != 0;
+	}
 	if (const char* v = getenv("S2AMD_WIDE"))
 	{
 		s->optWide = atoi(v) != 0;
@@ -139,7 +143,7 @@ int s2amd_create(int device, s2amdSolver** out)
 		s->hostError = nullptr;
 		(void)hipGetLastError();
 	}
-	if (groupKernelSetup() != 0 || stripKernelSetup() != 0 || pairKernelSetup() != 0 || wideKernelSetup() != 0)
+	if (groupKernelSetup() != 0 || stripKernelSetup() != 0 || pairKernelSetup() != 0 || wideKernelSetup() != 0 || genericKernelSetup() != 0)
 	{
 		(void)hipGetLastError(); // not fatal: groups are then limited to the default 64 KiB of LDS
 		s->optMaxGroupBodies = 1536;
@@ -786,6 +790,12 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 		s->optStripPatience = std::max(0, value);
 		s->stripPatienceNow = s->optStripPatience;
 	}
+	else if (strcmp(key, "generic") == 0)
+	{
+		s->stripsRejected = false;
+		s->optGeneric = value != 0;
+		s->structureDirty = true;
+	}
 	else if (strcmp(key, "strips_any_solver") == 0)
 	{
 		s->stripsRejected = false;
@@ -818,6 +828,7 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	{
 		s->stripsRejected = false;
 		s->optStripBodies = std::max(1, value);
+		s->stripBodiesSet = true;
 		s->structureDirty = true;
 	}
 	else if (strcmp(key, "strip_min_bodies") == 0)

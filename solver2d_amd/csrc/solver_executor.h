@@ -372,6 +372,31 @@ struct Executor
 		return records <= (160 * 1024) / 16;
 	}
 
+	// Can the whole plan run as ONE launch of the op interpreter over the strips (generic_kernel.hip: genericStepKernel)?  Every
+	// Gauss-Seidel family and joints; not s2Solve_Jacobi (its body-centric apply needs the incidence lists).
+	bool genericPlan() const
+	{
+		if (!s->genericValid || s->persistFailed || p.ops.size() > 128)
+		{
+			return false;
+		}
+		for (const Op& o : p.ops)
+		{
+			if (o.code == OP_JACOBI_APPLY || (o.code == OP_SOLVE_SOFT && o.kind == SOFT_JACOBI))
+			{
+				return false;
+			}
+		}
+		return genericStepLds(s->genericBodies, s->genericSeamBodies, s->genericExports, (int)p.ops.size(), p.usesDq0 ? 1 : 0) <= 160 * 1024;
+	}
+
+	// one launch for the strips, whichever kernel: the register-resident soft kernels where they apply, else the op interpreter
+	bool oneLaunchPlan() const
+	{
+		int kind, warm;
+		return persistPlan(kind, warm) || genericPlan();
+	}
+
 	// ... and of the persistent kernels, the 512-thread one (wide_kernel.hip: wideStepKernel)?  TGS_Soft with the current-anchor
 	// warm start on a partition with at most six interior colour batches per strip and two per seam.
 	bool widePlan(int kind, int warm) const
@@ -564,12 +589,33 @@ struct Executor
 
 	// the plan over the strips: body ops ride with the next sweep's phase A launch; every sweep is
 	// phase A (interiors, all strips) then phase B (seams)
+	void runGeneric()
+	{
+		if (profile)
+		{
+			recordEvent();
+		}
+		const size_t lds = genericStepLds(s->genericBodies, s->genericSeamBodies, s->genericExports, s->persistOpCount, p.usesDq0 ? 1 : 0);
+		launchGenericStep(st, s->cv, s->jv, s->bv, s->dStripA.view, s->dStripB.view, s->persist, (const Op*)s->dPersistOps.p, s->persistOpCount, p.sc,
+						  wireContacts(), p.usesDq0 ? 1 : 0, s->contacts.seamCount > 0 ? 1 : 0, s->joints.seamCount > 0 ? 1 : 0, lds);
+		if (profile)
+		{
+			recordEvent();
+		}
+		count();
+	}
+
 	void runStrips()
 	{
 		int kind, warm;
 		if (persistPlan(kind, warm))
 		{
 			runPersistent(kind, warm);
+			return;
+		}
+		if (genericPlan())
+		{
+			runGeneric();
 			return;
 		}
 		const int n = (int)p.ops.size();
@@ -762,8 +808,7 @@ struct Executor
 			count();
 		}
 		// post: SoA -> wire: impulses and bodies in one launch (+ the epoch base of the hand-off tags)
-		int kind, warm;
-		const bool usedGranules = s->dStripA.view.groupCount > 0 && persistPlan(kind, warm);
+		const bool usedGranules = s->dStripA.view.groupCount > 0 && oneLaunchPlan();
 		launchStoreImpulses(st, p.storeKind, cvIo, wireContacts(), p.storeScale, s->bv, wireBodies(), usedGranules ? s->dGranules.p : nullptr,
 							usedGranules ? s->granuleBytes : 0, usedGranules ? s->persist.deviceError : nullptr, fusedFinalize, &s->jv, wireJoints());
 		count();

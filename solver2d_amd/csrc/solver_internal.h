@@ -334,6 +334,11 @@ struct s2amdSolver
 	DevBuf dPersist, dGranules;
 	PersistView persist{};
 	bool persistValid = false;
+	// ... as an op interpreter for every solver family and joints (generic_kernel.hip: genericStepKernel): the same partition,
+	// import / export lists and hand-off buffers; seams swept once, by their left strip
+	bool genericValid = false;
+	int genericBodies = 0, genericSeamBodies = 0, genericExports = 0; // the most staged bodies / seam-group bodies / exported bodies of a strip (LDS)
+	int optGeneric = 1;
 	int persistK0 = 0, persistK1 = 0; // the strip constraints' range in contacts.order (persist.allTwoPoints is recomputed over it)
 	int persistRecordsWide = 0; // LDS records when a seam constraint takes 10 records (every kind but TGS_Soft's)
 	DevBuf dPersistOps;
@@ -367,6 +372,7 @@ struct s2amdSolver
 	bool orderResident = false; // the groups were laid out for the resident-island kernel where they fit
 	bool orderColourless = false; // built for s2Solve_Jacobi: the global contact part is one batch in pool order, no colours
 	bool orderStrips = false;
+	int orderStripBodies = 0; // the strip width the structure was cut with (StructureBuild::stripBodiesFor)
 	bool stripsNeedOneLaunch = false; // a moving read-only body is shared between strips: persistent kernel or no strips at all
 	bool stripsRejected = false; // this graph's strip partition fits no strip kernel: colour batches until the graph changes
 	int graphAge = 0;		  // steps solved since the constraint graph last changed
@@ -388,6 +394,9 @@ struct s2amdSolver
 	int optPackGroupBodies = 1024;
 	int optStrips = 1;		   // cut islands that do not fit one LDS group into strips of BFS levels (2 launches per sweep)
 	int optStripBodies = 8;  // target bodies per strip: small = strips of exactly two BFS levels, five interior colour rounds (r3: 133 us per step at base 200
+	int stripScaleFoundFor = 0;	 // the strip width stripScaleFound was searched with
+	bool stripBodiesSet = false; // "strip_bodies" was set by the caller: every solver gets that width
+	int optStripBodiesLds = 320; // ... of SoftStep / PGS_Soft, whose seam constraints live in LDS and are swept by both neighbours (strip_kernel.hip): few, wide strips
 							 // against 154 us with the six rounds of three-level strips); strip_retry tries wider ones when there are more level pairs than CUs
 	int optStripMinBodies = 4096; // loose bodies below which the colour-batch path is kept
 

@@ -385,8 +385,9 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 		// strips that only the one-launch kernel may run (solver_structure.cpp: stripsNeedOneLaunch), and a plan or a state
 		// that kernel cannot take (another solver family, a hand-off that timed out earlier): colour batches instead
 		Executor probe{s, s->stream, plan, isPositionSolver(params->solverType) ? 1 : 0, false};
-		int kind, warm;
-		if (s->dStripA.view.groupCount > 0 && s->stripsNeedOneLaunch && !probe.persistPlan(kind, warm))
+		const bool soft = params->solverType == s2amd_solverTGS_Soft || params->solverType == s2amd_solverSoftStep || params->solverType == s2amd_solverPGS_Soft;
+		const bool multiLaunch = !s->stripsNeedOneLaunch && (s->optStripsAnySolver != 0 || (soft && s->joints.stripCount == 0 && s->leanAValid && s->leanBValid));
+		if (s->dStripA.view.groupCount > 0 && !multiLaunch && !probe.oneLaunchPlan())
 		{
 			s->stripsRejected = true;
 			s->structureDirty = true;
@@ -401,7 +402,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 		// multi-launch strip path (warm-start slot tables) needs the structure built again
 		Executor probe{s, s->stream, plan, isPositionSolver(params->solverType) ? 1 : 0, false};
 		int kind, warm;
-		if (s->stripInc.touched && s->dStripA.view.groupCount > 0 && !probe.persistPlan(kind, warm))
+		if (s->stripInc.touched && s->dStripA.view.groupCount > 0 && !probe.persistPlan(kind, warm)) // (the op interpreter reads the group tables, which placement does not patch)
 		{
 			s->structureDirty = true;
 			s->dirtyReason = "strips with placed contacts off the persistent kernel";
@@ -416,7 +417,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	s->stats.messagePassing = q.msg ? 1 : 0;
 	{
 		int kind, warm;
-		if (s->dStripA.view.groupCount > 0 && q.persistPlan(kind, warm) && q.uploadPersistOps() != 0)
+		if (s->dStripA.view.groupCount > 0 && (q.persistPlan(kind, warm) || q.genericPlan()) && q.uploadPersistOps() != 0)
 		{
 			return fail(S2AMD_E_DEVICE, "could not upload the persistent step plan");
 		}
@@ -494,7 +495,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	{
 		uint64_t key = 1469598103934665603ull;
 		key = fnv(key, params, sizeof(*params));
-		uint64_t gens[4] = {s->layoutGeneration, s->structureGeneration, s->planGeneration, (uint64_t)((q.msg ? 1 : 0) | (s->optBodyWarm ? 2 : 0) | (s->optStripLean ? 4 : 0) | (s->optPersist ? 8 : 0) | (s->optFork ? 16 : 0) | (s->persistFailed ? 32 : 0) | ((s->persistValid && s->persist.allTwoPoints) ? 64 : 0) | (s->pointsKnown ? 128 : 0) | (s->optPairLanes ? 256 : 0) | (s->optWide ? 512 : 0))};
+		uint64_t gens[4] = {s->layoutGeneration, s->structureGeneration, s->planGeneration, (uint64_t)((q.msg ? 1 : 0) | (s->optBodyWarm ? 2 : 0) | (s->optStripLean ? 4 : 0) | (s->optPersist ? 8 : 0) | (s->optFork ? 16 : 0) | (s->persistFailed ? 32 : 0) | ((s->persistValid && s->persist.allTwoPoints) ? 64 : 0) | (s->pointsKnown ? 128 : 0) | (s->optPairLanes ? 256 : 0) | (s->optWide ? 512 : 0) | (s->optGeneric ? 1024 : 0) | (s->genericValid ? 2048 : 0))};
 		key = fnv(key, gens, sizeof(gens));
 		int sizes[3] = {s->bodyCapacity, s->contactCapacity, s->jointCapacity};
 		key = fnv(key, sizes, sizeof(sizes));
@@ -561,7 +562,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	s->stats.seamCount = s->dStripB.view.groupCount;
 	{
 		int kind, warm;
-		s->stats.persistent = (s->dStripA.view.groupCount > 0 && q.persistPlan(kind, warm)) ? 1 : 0;
+		s->stats.persistent = (s->dStripA.view.groupCount > 0 && (q.persistPlan(kind, warm) || q.genericPlan())) ? 1 : 0;
 	}
 	s->stats.persistFallbacks = s->persistFallbacks;
 	s->stats.structureBuilds = (int32_t)s->structureGeneration;
@@ -570,7 +571,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 		int kind = -1, warm = -1;
 		const bool persistent = s->stats.persistent && q.persistPlan(kind, warm);
 		const bool wide = persistent && q.widePlan(kind, warm);
-		s->stats.pairLanes = wide ? 2 : (persistent && s->persist.pairLanes && s->optPairLanes) ? 1 : 0;
+		s->stats.pairLanes = wide ? 2 : (persistent && s->persist.pairLanes && s->optPairLanes) ? 1 : (s->stats.persistent && !persistent) ? 3 : 0;
 	}
 	s->stats.potentialConstraints = (int32_t)(s->contacts.order.size() - (size_t)s->slackPositions);
 	if (!async && s->hostError && *s->hostError != 0u)

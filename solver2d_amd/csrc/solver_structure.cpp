@@ -1049,9 +1049,15 @@ static int buildLeanStripTables(s2amdSolver* s, const StripPartition& strips, co
 	}
 	// ---- persistent strip step (strip_kernel.hip: stripStepKernel): per workgroup both seams' remaps, the
 	// import / export lists of the symmetric exchange, warm-start term slots, granule buffers ----
+	// `ok`: what every persistent kernel needs (the partition's seam structure, co-resident workgroups); `okSoft`: what the
+	// register-resident soft kernels need on top (lean tables, no joints, one constraint per thread and round, few seam rounds,
+	// their LDS budget).  The op interpreter (generic_kernel.hip) runs on `ok` alone.
 	s->persistValid = false;
-	if (persistTablesOk && js.stripCount == 0 && s->optPersist && s->hostError != nullptr && s->hStripA.count() <= s->cuCount)
+	s->genericValid = false;
+	if (s->optPersist && s->hostError != nullptr && s->hStripA.count() <= s->cuCount && (persistTablesOk || s->optGeneric))
 	{
+		bool okSoft = persistTablesOk && js.stripCount == 0;
+		const char* whySoft = okSoft ? "" : (js.stripCount ? "joints in the strips" : "lean tables");
 		const HostGroupTable& A = s->hStripA;
 		const HostGroupTable& B = s->hStripB;
 		const int K = A.count();
@@ -1064,6 +1070,15 @@ do                                                                              
 	{                                                                                                                        \
 		ok = false;                                                                                                          \
 		why = #cond;                                                                                                         \
+	}                                                                                                                        \
+} while (0)
+#define NEEDSOFT(cond)                                                                                                            \
+do                                                                                                                           \
+{                                                                                                                            \
+	if (okSoft && !(cond))                                                                                                   \
+	{                                                                                                                        \
+		okSoft = false;                                                                                                      \
+		whySoft = #cond;                                                                                                     \
 	}                                                                                                                        \
 } while (0)
 		std::vector<int> ownerGroup((size_t)nb, -1), ownerSlot((size_t)nb, -1);
@@ -1080,7 +1095,7 @@ do                                                                              
 			}
 			for (int bb = A.cBatchOffsets[(size_t)gi]; bb < A.cBatchOffsets[(size_t)gi + 1]; ++bb)
 			{
-				NEED(A.cBatches[(size_t)bb].y - A.cBatches[(size_t)bb].x <= 256); // one constraint per thread and round
+				NEEDSOFT(A.cBatches[(size_t)bb].y - A.cBatches[(size_t)bb].x <= 256); // one constraint per thread and round
 			}
 		}
 		// seams: bodies on either side, in the order of the seam group's body list
@@ -1116,7 +1131,7 @@ do                                                                              
 					NEED(false);
 				}
 			}
-			NEED(leftBodies[(size_t)sm].size() <= 256 && rightBodies[(size_t)sm].size() <= 256);
+			NEEDSOFT(leftBodies[(size_t)sm].size() <= 256 && rightBodies[(size_t)sm].size() <= 256);
 		}
 		// granule buffers: per seam {toLeft: 4 per right body, toRight: 4 per left body}, two parities
 		std::vector<int> seamBase((size_t)std::max(S, 0), 0);
@@ -1143,6 +1158,7 @@ do                                                                              
 			pairLanes = g < 0 || B.cBatchOffsets[(size_t)g + 1] - B.cBatchOffsets[(size_t)g] <= 2;
 		}
 		std::vector<PersistDesc> descs((size_t)K);
+		int genericBodies = 0, genericSeamBodies = 0, genericExports = 0;
 		std::vector<int> remap, exportSrc, importIds;
 		std::vector<int> replicaStamp((size_t)nb, -1), replicaSlot((size_t)nb, -1);
 		int ldsRecords = 0, ldsRecordsWide = 0;
@@ -1162,6 +1178,7 @@ do                                                                              
 				}
 			}
 			const int seamOf[2] = {i - 1, i};
+			d.seamGroup[0] = d.seamGroup[1] = -1;
 			int importOffset = nbA, seamSlots = 0;
 			for (int side = 0; side < 2; ++side)
 			{
@@ -1178,6 +1195,7 @@ do                                                                              
 				// side 1: I am the LEFT strip of seam i
 				const std::vector<int>& imports = side == 0 ? leftBodies[(size_t)sm] : rightBodies[(size_t)sm];
 				const std::vector<int>& exports = side == 0 ? rightBodies[(size_t)sm] : leftBodies[(size_t)sm];
+				d.seamGroup[side] = g;
 				d.importCount[side] = (int)imports.size();
 				d.exportCount[side] = (int)exports.size();
 				importIds.insert(importIds.end(), imports.begin(), imports.end());
@@ -1210,35 +1228,46 @@ do                                                                              
 					}
 				}
 				int b0 = B.cBatchOffsets[(size_t)g], b1 = B.cBatchOffsets[(size_t)g + 1];
-				d.seamBatchCount[side] = b1 - b0;
-				NEED(b1 - b0 <= S2_PERSIST_B_ROUNDS);
-				for (int bb = b0; bb < b1 && ok; ++bb)
+				NEEDSOFT(b1 - b0 <= S2_PERSIST_B_ROUNDS);
+				d.seamBatchCount[side] = std::min(b1 - b0, S2_PERSIST_B_ROUNDS);
+				for (int bb = b0; bb < b0 + d.seamBatchCount[side] && ok; ++bb)
 				{
 					int4 bt = B.cBatches[(size_t)bb];
-					NEED(bt.z == 0);
+					NEEDSOFT(bt.z == 0);
 					d.seamBatch[side][bb - b0] = make_int2(bt.x, bt.y);
 					seamSlots += bt.y - bt.x;
 				}
 				importOffset += d.importCount[side];
+				if (side == 1)
+				{
+					genericSeamBodies = std::max(genericSeamBodies, B.bodyOffsets[(size_t)g + 1] - B.bodyOffsets[(size_t)g]);
+				}
+				else
+				{
+					genericExports = std::max(genericExports, d.exportCount[side]);
+				}
 			}
 			for (int r = 0; r < S2_PERSIST_B_ROUNDS && ok; ++r)
 			{
 				int n0 = r < d.seamBatchCount[0] ? d.seamBatch[0][r].y - d.seamBatch[0][r].x : 0;
 				int n1 = r < d.seamBatchCount[1] ? d.seamBatch[1][r].y - d.seamBatch[1][r].x : 0;
-				ok = n0 + n1 <= 512; // both seams share a round: at most two constraints per thread
+				NEEDSOFT(n0 + n1 <= 512); // both seams share a round: at most two constraints per thread
 			}
 			const int nt = importOffset;
+			genericBodies = std::max(genericBodies, nt);
 			// bodies, seam constraints (S2_PERSIST_Q_NARROW records each for TGS_Soft, S2_PERSIST_Q_WIDE for the other kinds)
 			int fixedRecords = 3 * nt + (nt + 3) / 4 + (nt + 1) / 2; // velocity, pose, integrator constants, angular damping, inverse masses
 			const int seamRecordsNarrow = seamRegs ? 0 : S2_PERSIST_Q_NARROW * seamSlots;
-			NEED(fixedRecords + seamRecordsNarrow + 2 * 16 <= (160 * 1024) / 16 && nt < 16384); // the plan's own records are checked when it is known (persistPlan)
+			NEEDSOFT(fixedRecords + seamRecordsNarrow + 2 * 16 <= (160 * 1024) / 16 && nt < 16384); // the plan's own records are checked when it is known (persistPlan)
+			NEED(genericStepLds(nt, genericSeamBodies, genericExports, 16, 0) <= 160 * 1024); // (with the plan's ops and its XPBD history: Executor::genericPlan)
 			ldsRecords = std::max(ldsRecords, fixedRecords + seamRecordsNarrow);
 			ldsRecordsWide = std::max(ldsRecordsWide, fixedRecords + S2_PERSIST_Q_WIDE * seamSlots);
 		}
 		if (getenv("S2AMD_DEBUG"))
 		{
-			fprintf(stderr, "[s2amd] persistent step: %s (K=%d, lds records %d, granules/parity %d)%s%s\n", ok ? "eligible" : "NOT eligible", K, ldsRecords,
-					parityStride, ok ? "" : " -- failed: ", why);
+			fprintf(stderr, "[s2amd] persistent step: %s (K=%d, lds records %d, granules/parity %d)%s%s%s%s\n",
+					ok ? (okSoft ? "eligible" : "op interpreter only") : "NOT eligible", K, ldsRecords, parityStride, ok ? "" : " -- failed: ", why,
+					ok && !okSoft ? " -- resident soft kernels: " : "", ok && !okSoft ? whySoft : "");
 			int histA[16] = {0}, histB[16] = {0};
 			for (int i = 0; i < K; ++i)
 			{
@@ -1346,7 +1375,9 @@ do                                                                              
 					}
 				}
 			}
-			s->persistValid = true;
+			s->persistValid = okSoft;
+			s->genericValid = s->optGeneric != 0;
+			s->genericBodies = genericBodies, s->genericSeamBodies = genericSeamBodies, s->genericExports = genericExports;
 		}
 	}
 	return rc;
@@ -1455,14 +1486,35 @@ struct StructureBuild
 		  grouped(solver->optGroups != 0 && !needAdj),
 		  // strips pay off through the lean / persistent strip kernels, which exist for the soft contact sweeps
 		  wantStrips(grouped && solver->optStrips != 0 && !solver->stripsRejected && solver->graphAge >= solver->stripPatienceNow &&
-					 (solver->optStripsAnySolver != 0 || isSoftFamily(type))),
+					 (solver->optStripsAnySolver != 0 || isSoftFamily(type) || genericWanted(solver))),
 		  residentWanted(grouped && isSoftFamily(type) && solver->optIslandResident != 0 && !solver->residentRejected),
-		  stripSlackWanted(solver->optStripSlack != 0 && solver->optIncremental != 0 && solver->optPersist != 0 && isSoftFamily(type)), nb(solver->bodyCapacity),
+		  // (slack positions in the strips' rounds: TGS_Soft only -- in the 256-thread kernels of SoftStep / PGS_Soft a seam round that
+		  // outgrows 256 positions is dealt in two passes, which cost them 0.26 -> 0.40 ms per SoftStep step at base 200)
+		  stripSlackWanted(solver->optStripSlack != 0 && solver->optIncremental != 0 && solver->optPersist != 0 && type == s2amd_solverTGS_Soft), nb(solver->bodyCapacity),
 		  cs(solver->contacts), js(solver->joints), slots(solver->bodyCapacity)
 	{
 		static const bool fromEnv = getenv("S2AMD_DEBUG_PREP") != nullptr;
 		prepTimes = fromEnv;
 		t0 = tPhase = nowMs();
+	}
+
+	// the persistent op interpreter takes every family and joints: strips for all of them (it needs the persistent machinery)
+	static bool genericWanted(const s2amdSolver* solver)
+	{
+		return solver->optGeneric != 0 && solver->optPersist != 0 && solver->optStripLean != 0 && !solver->persistFailed && solver->hostError != nullptr;
+	}
+
+	// Strip width by solver: two BFS levels per strip (five interior colour rounds) for the kernels that sweep a seam cheaply --
+	// wide_kernel.hip (TGS_Soft: seams in registers) and the op interpreter (seams swept once) --, few wide strips for SoftStep
+	// and PGS_Soft, whose seam constraints live in LDS and are swept by both neighbours (0.25 vs 0.38 ms per SoftStep step at
+	// base 200).  A width set by the caller ("strip_bodies") goes for every solver.
+	static int stripBodiesFor(const s2amdSolver* solver, int type)
+	{
+		if (solver->stripBodiesSet || !(type == s2amd_solverSoftStep || type == s2amd_solverPGS_Soft))
+		{
+			return solver->optStripBodies;
+		}
+		return solver->optStripBodiesLds;
 	}
 
 	static bool isSoftFamily(int type)
@@ -1475,7 +1527,7 @@ struct StructureBuild
 	{
 		// (contacts placed into a structure built for s2Solve_Jacobi took any free position, whatever its colour: only Jacobi can run on that)
 		const bool colourFree = s->inc.colourFreePlaced && !needAdj;
-		return !s->structureDirty && cls == s->orderSolverClass && grouped == s->orderGrouped && wantStrips == s->orderStrips && s->adjValid && !colourFree &&
+		return !s->structureDirty && cls == s->orderSolverClass && grouped == s->orderGrouped && wantStrips == s->orderStrips && (!wantStrips || stripBodiesFor(s, solverType) == s->orderStripBodies) && s->adjValid && !colourFree &&
 			   residentWanted == s->orderResident && needAdj == s->orderColourless;
 	}
 
@@ -1734,7 +1786,7 @@ struct StructureBuild
 	{
 		strips = StripPartition();
 		stripsNeedOneLaunch = false;
-		if (wantStrips && (s->optStripsAnySolver != 0 || jOf[0].empty()))
+		if (wantStrips && (s->optStripsAnySolver != 0 || jOf[0].empty() || genericWanted(s)))
 		{
 			std::vector<uint8_t> ownedByIsland((size_t)nb, 0);
 			auto mark = [&](int body) {
@@ -1766,7 +1818,7 @@ struct StructureBuild
 			}
 			if (looseCount >= s->optStripMinBodies)
 			{
-				partitionStrips(ce, je, cOf[0], jOf[0], conflict, loose, nb, std::max(8, (int)((float)s->optStripBodies * stripScale)), s->optMaxGroupBodies, strips);
+				partitionStrips(ce, je, cOf[0], jOf[0], conflict, loose, nb, std::max(8, (int)((float)stripBodiesFor(s, solverType) * stripScale)), s->optMaxGroupBodies, strips);
 			}
 			if (strips.active)
 			{
@@ -2320,7 +2372,12 @@ struct StructureBuild
 		{
 			s->leanAValid = s->leanBValid = false;
 		}
-		if (strips.active && !s->persistValid && (stripsNeedOneLaunch || (!s->optStripsAnySolver && !(s->leanAValid && s->leanBValid))))
+		// what can run this partition: one launch (the soft drivers' resident kernels on a joint-free partition, the op
+		// interpreter for everything else) or the multi-launch strip path (lean soft launches; the group interpreter in tests)
+		const bool soft = isSoftFamily(solverType);
+		const bool oneLaunch = (soft && s->persistValid) || s->genericValid;
+		const bool multiLaunch = !stripsNeedOneLaunch && (s->optStripsAnySolver != 0 || (soft && js.stripCount == 0 && s->leanAValid && s->leanBValid));
+		if (strips.active && !oneLaunch && !multiLaunch)
 		{
 			s->stripsRejected = true;
 			s->structureDirty = true;
@@ -2470,6 +2527,7 @@ struct StructureBuild
 		s->orderColourless = needAdj;
 		s->orderGrouped = grouped;
 		s->orderStrips = wantStrips;
+		s->orderStripBodies = stripBodiesFor(s, solverType);
 		s->structureDirty = false;
 		s->structureGeneration += 1;
 		s->stats.hostPrepMs = (float)(nowMs() - t0);
@@ -2522,6 +2580,11 @@ int buildStructure(s2amdSolver* s, int solverType)
 	const uint64_t before = s->structureGeneration;
 	// (a world whose partition was searched for once keeps the width that won: a graph that changes is not searched again as
 	// long as that width still gives the persistent kernel something it can run)
+	if (s->stripScaleFoundFor != StructureBuild::stripBodiesFor(s, solverType))
+	{
+		s->stripScaleFound = 0.0f; // (found for another strip width: SoftStep / PGS_Soft against the rest)
+		s->stripScaleFoundFor = StructureBuild::stripBodiesFor(s, solverType);
+	}
 	const float firstScale = s->stripScaleFound > 0.0f ? s->stripScaleFound : 1.0f;
 	int rc = buildStructureWith(s, solverType, firstScale);
 	if (rc != S2AMD_OK || s->structureGeneration == before || s->optStripRetry == 0)
@@ -2539,9 +2602,23 @@ int buildStructure(s2amdSolver* s, int solverType)
 		}
 		return (s->persistValid || (s->leanAValid && s->leanBValid)) ? 1 : 0;
 	};
+	// ... and what this solver is after: TGS_Soft the five-round partition (wide_kernel.hip); SoftStep / PGS_Soft any partition
+	// their resident kernel takes without spilling (their default strips are wide: stripBodiesFor); every other family any
+	// partition the op interpreter can run (generic_kernel.hip: as many strips as CUs at most)
+	auto satisfied = [&]() {
+		if (!StructureBuild::isSoftFamily(solverType))
+		{
+			return s->dStripA.view.groupCount > 0 && (s->genericValid || outcome() >= 1);
+		}
+		if (s->joints.stripCount > 0)
+		{
+			return s->dStripA.view.groupCount > 0 && s->genericValid;
+		}
+		return outcome() >= (solverType == s2amd_solverTGS_Soft ? 3 : 2);
+	};
 	const bool triedStrips = s->stripsRejected || s->dStripA.view.groupCount > 0;
 	s->stripRetryPending = false;
-	if (!triedStrips || outcome() == 3 || (s->stripScaleFound > 0.0f && outcome() >= 2))
+	if (!triedStrips || satisfied() || (s->stripScaleFound > 0.0f && outcome() >= 2))
 	{
 		return rc;
 	}
@@ -2566,7 +2643,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 			return rc;
 		}
 		const int o = outcome();
-		if (o == 3)
+		if (satisfied())
 		{
 			s->stripScaleFound = scale;
 			return rc;

@@ -1,0 +1,183 @@
+"""The persistent strip step as an op interpreter (generic_kernel.hip: genericStepKernel): every Gauss-Seidel solver family and
+every joint sweep of a big island in ONE launch per step -- strips of the island owned by one workgroup each for the whole
+`s2Solve_*`, seams swept by their left strip between a forward and a return hand-off.
+
+Same gate as everywhere: the C-ABI result must equal the oracle BIT FOR BIT when the oracle sweeps in the order the library
+reports (per op: strip by strip colour-major, then seam by seam)."""
+import os
+
+import numpy as np
+import pytest
+
+from solver2d_amd import hip, synthetic, wire
+from tests import common, fuzz_worlds, golden_util
+from tests.test_gpu_parity import gpu_vs_oracle, gpu_vs_oracle_loose
+
+pytestmark = pytest.mark.gpu
+
+FILES = golden_util.golden_files()
+GS_SOLVERS = [n for n in wire.SOLVER_NAMES if n != "Jacobi"]
+SOFT = ("TGS_Soft", "SoftStep", "PGS_Soft")
+
+
+@pytest.mark.parametrize("solver_name", GS_SOLVERS)
+def test_every_solver_takes_one_launch_on_the_big_pyramid(solver_name):
+    """Base-100 pyramid (5,050 bodies, one island), default options: prologue + ONE step kernel + epilogue, whatever the solver.
+    The soft contact drivers keep their register-resident kernels; everything else runs on the op interpreter."""
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    pre = synthetic.pyramid(100)
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
+        state = common.copy3(pre)
+        for step in range(3):
+            params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+            state = gpu_vs_oracle(s, params, state, "pyramid100/%s step %d" % (solver_name, step))
+        st = s.stats()
+        assert st["stripCount"] >= 4 and st["persistent"] == 1 and st["kernelLaunches"] <= 4, st
+        assert (st["pairLanes"] == 3) == (solver_name not in SOFT), st
+
+
+@pytest.mark.parametrize("solver_name", GS_SOLVERS)
+def test_op_interpreter_equals_the_colour_batches_and_the_strip_launches(solver_name):
+    """Three routes for the same world and solver -- the op interpreter, the multi-launch strip path (test option), colour batches
+    -- are each bit-equal to the oracle in their own order; the first two share one order, so they are bit-equal to each other."""
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    pre = synthetic.pyramid(72)
+    params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+    results = {}
+    min_bodies = 0  # (2,628 bodies: under the default threshold for strips)
+    for route in ("interpreter", "launches", "batches"):
+        with hip.Solver(0) as s:
+            s.set_option("strip_patience", 0)
+            s.set_option("strip_min_bodies", min_bodies)
+            if solver_name in SOFT:
+                s.set_option("persist", 1 if route == "interpreter" else 0)  # (with "persist" off nothing runs in one launch)
+                s.set_option("wide", 0)
+            if route == "launches":
+                s.set_option("generic", 0)
+                s.set_option("strips_any_solver", 1)
+            if route == "batches":
+                s.set_option("strips", 0)
+            state = common.copy3(pre)
+            for step in range(2):
+                state = gpu_vs_oracle(s, params, state, "pyramid72/%s %s step %d" % (solver_name, route, step))
+            st = s.stats()
+            assert (st["stripCount"] > 0) == (route != "batches"), (route, st)
+            assert st["persistent"] == (1 if route == "interpreter" else 0), (route, st)
+            results[route] = state
+    common.compare_exact(results["interpreter"], results["launches"], "%s: interpreter vs strip launches" % solver_name)
+
+
+@pytest.mark.parametrize("solver_name", ["TGS_Soft", "PGS_NGS", "PGS_NGS_Block", "XPBD", "TGS_Sticky", "SoftStep", "TGS_NGS"])
+def test_joint_grid_in_one_launch(solver_name):
+    """70x70 joint grid (4,900 bodies, 9,660 revolute joints, one island, no contacts): joint sweeps in the strips."""
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    pre = synthetic.joint_grid(70)
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
+        state = common.copy3(pre)
+        for step in range(3):
+            params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+            state = gpu_vs_oracle(s, params, state, "jointgrid70/%s step %d" % (solver_name, step))
+        st = s.stats()
+        assert st["stripCount"] >= 4 and st["persistent"] == 1 and st["pairLanes"] == 3 and st["kernelLaunches"] <= 5, st
+
+
+@pytest.fixture(scope="module")
+def tiny_strips():
+    """Forces strips on the small golden worlds (joints, every shape of contact graph): no island fits a group, strips of ~12
+    bodies, the op interpreter for every solver."""
+    s = hip.Solver(0)
+    s.set_option("strip_patience", 0)
+    s.set_option("max_group_bodies", 48)
+    s.set_option("strip_min_bodies", 0)
+    s.set_option("strip_bodies", 12)
+    s.set_option("persist", 1)
+    yield s
+    s.close()
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(p)[:-4] for p in FILES])
+def test_golden_inputs_bit_exact_through_the_op_interpreter(tiny_strips, path):
+    params, pre, _post = golden_util.load(path)
+    gpu_vs_oracle(tiny_strips, params, pre, os.path.basename(path))
+
+
+def test_golden_worlds_really_ran_on_the_op_interpreter(tiny_strips):
+    seen = 0
+    for path in FILES:
+        if "Jacobi" in path:
+            continue
+        params, pre, _post = golden_util.load(path)
+        gpu_vs_oracle(tiny_strips, params, pre, os.path.basename(path))
+        st = tiny_strips.stats()
+        seen += st["stripCount"] >= 2 and st["persistent"] == 1 and st["pairLanes"] == 3
+    assert seen >= 30, seen
+
+
+@pytest.mark.parametrize("joints", [0, 6, 40])
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_random_worlds_through_the_op_interpreter(seed, joints):
+    """Random contact graphs (arbitrary degrees, one- and two-point contacts, static / kinematic / massless bodies, joints across
+    the strips) cut into tiny strips, every solver, with and without warm starting."""
+    world = fuzz_worlds.random_world(seed + 300, n_bodies=60 + 9 * seed, n_contacts=140 + 25 * seed, n_joints=joints)
+    with hip.Solver(0) as gpu:
+        gpu.set_option("strip_patience", 0)
+        gpu.set_option("max_group_bodies", 16)
+        gpu.set_option("strip_min_bodies", 0)
+        gpu.set_option("strip_bodies", 10)
+        ran = 0
+        for solver_name in GS_SOLVERS:
+            vel, pos = common.DEFAULT_ITERS[solver_name]
+            for warm in (True, False):
+                p = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, warm)
+                gpu_vs_oracle_loose(gpu, p, world, "fuzz interpreter seed %d %s warm=%d joints=%d" % (seed, solver_name, warm, joints))
+                st = gpu.stats()
+                ran += st["persistent"] == 1 and st["pairLanes"] == 3
+        print("seed", seed, "joints", joints, "interpreter runs", ran)
+
+
+def test_consecutive_resident_steps_with_joints_and_contacts():
+    """A world the soft kernels cannot take -- joints inside the big island -- stepped for 6 steps on the op interpreter
+    against the oracle chain: platform of boxes with a chain of revolute joints hung into it."""
+    b, c, j = synthetic.pyramid(60)
+    grid_b, grid_c, grid_j = synthetic.joint_grid(20)
+    # glue: shift the grid's body indices behind the pyramid's and joint its first body to a box of the pile
+    nb = len(b)
+    grid_j = grid_j.copy()
+    grid_j["bodyA"] += nb
+    grid_j["bodyB"] += nb
+    link = grid_j[:1].copy()
+    link["bodyA"], link["bodyB"] = nb // 2, nb
+    bodies = np.concatenate([b, grid_b])
+    joints = np.concatenate([j, grid_j, link])
+    pre = (bodies, c, joints)
+    for solver_name in ("TGS_Soft", "PGS_NGS_Block"):
+        vel, pos = common.DEFAULT_ITERS[solver_name]
+        with hip.Solver(0) as s:
+            s.set_option("strip_patience", 0)
+            s.set_option("strip_min_bodies", 0)
+            state = common.copy3(pre)
+            for step in range(6):
+                params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+                state = gpu_vs_oracle(s, params, state, "pile+grid/%s step %d" % (solver_name, step))
+            st = s.stats()
+            assert st["persistent"] == 1 and st["pairLanes"] == 3, st
+
+
+def test_hand_off_timeout_falls_back():
+    """Fault injection (persist_debug 8: workgroup 1 never publishes): the interpreter's hand-off times out, the epilogue leaves the
+    wire arrays untouched, the step is repeated on another path, the result is still the oracle's."""
+    solver_name = "PGS_NGS_Block"
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    pre = synthetic.pyramid(72)
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
+        s.set_option("strip_min_bodies", 0)
+        s.set_option("persist_spin_limit", 2000)
+        s.set_option("persist_debug", 8)
+        params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+        state = gpu_vs_oracle(s, params, pre, "pyramid72 fault")
+        st = s.stats()
+        assert st["persistFallbacks"] == 1 and st["persistent"] == 0, st
+        gpu_vs_oracle(s, params, state, "pyramid72 after the fault")

@@ -61,10 +61,11 @@ def test_big_pyramid_strips_default_options(solver_name):
         assert st["stripCount"] >= 4 and st["seamCount"] == st["stripCount"] - 1, st
 
 
-@pytest.mark.parametrize("solver_name,expect", [("TGS_Soft", True), ("SoftStep", True), ("PGS_Soft", True), ("PGS", False), ("XPBD", False)])
-def test_default_policy_strips_only_for_the_soft_sweeps(solver_name, expect):
-    """Strips pay off through strip_kernel.hip, which covers the soft contact sweeps; every other solver keeps the
-    colour-batch path by default."""
+@pytest.mark.parametrize("solver_name,expect", [("TGS_Soft", True), ("SoftStep", True), ("PGS_Soft", True), ("PGS", True), ("XPBD", True), ("Jacobi", False)])
+def test_default_policy_strips_for_every_gauss_seidel_solver(solver_name, expect):
+    """Strips pay off through the one-launch kernels: the register-resident ones for the soft contact sweeps (strip_kernel.hip,
+    wide_kernel.hip), the op interpreter for every other Gauss-Seidel family (generic_kernel.hip).  s2Solve_Jacobi has no colours
+    and keeps its own structure; with the interpreter switched off the non-soft solvers keep the colour batches."""
     vel, pos = common.DEFAULT_ITERS[solver_name]
     pre = synthetic.pyramid(100)
     with hip.Solver(0) as s:
@@ -72,10 +73,16 @@ def test_default_policy_strips_only_for_the_soft_sweeps(solver_name, expect):
         params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
         state = gpu_vs_oracle(s, params, pre, "pyramid100/%s default" % solver_name)
         assert (s.stats()["stripCount"] > 0) == expect
-        # switching the solver on the same resident world rebuilds the structure
-        other = wire.StepParams.make("PGS" if expect else "TGS_Soft", 1.0 / 60.0, 4, 2, True)
+        # switching the solver on the same resident world
+        other = wire.StepParams.make("Jacobi" if expect else "TGS_Soft", 1.0 / 60.0, 4, 2, True)
         gpu_vs_oracle(s, other, state, "pyramid100 switch from %s" % solver_name)
         assert (s.stats()["stripCount"] > 0) == (not expect)
+    if expect and solver_name in ("PGS", "XPBD"):
+        with hip.Solver(0) as s:
+            s.set_option("strip_patience", 0)
+            s.set_option("generic", 0)
+            gpu_vs_oracle(s, params, pre, "pyramid100/%s without the interpreter" % solver_name)
+            assert s.stats()["stripCount"] == 0
 
 
 @pytest.mark.parametrize("lean", [1, 0])

@@ -290,7 +290,11 @@ def joint_grid_leg(device_index, steps, warmup):
             "kernel_launches_per_step": st["kernelLaunches"], "device_ms_per_step": st["deviceMs"],
             "roofline": step_roofline(JOINT_BYTES_PER_ITER * J * 6, elapsed / steps, "%d B per joint-iteration (joint record 120 B + two bodies 36 B read, 12 B "
                                       "written each) x %d joints x 6 sweeps" % (JOINT_BYTES_PER_ITER, J)),
-            "roofline_note": "%d dependent launches of ~20k threads per step: launch-latency bound (a dependent launch costs ~2-3 us)" % st["kernelLaunches"]}
+            "path": "op interpreter on persistent strips (generic_kernel.hip), %d strips" % st["stripCount"] if st["persistent"] else "colour batches",
+            "roofline_note": ("one persistent launch per step (+ prologue / epilogue): %d strips of the grid's BFS levels, 7 joint sweeps x (interior colours, "
+                              "forward hand-off, seam colours, return hand-off) at ~1 us per phase -- bound by the instruction latency of one "
+                              "revolute-joint solve per lane and colour, not by bandwidth" % st["stripCount"]) if st["persistent"] else
+                             ("%d dependent launches of ~20k threads per step: launch-latency bound (a dependent launch costs ~2-3 us)" % st["kernelLaunches"])}
 
 
 def tumbler_leg(device_index, count, settle, steps):

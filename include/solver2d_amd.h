@@ -416,6 +416,9 @@ int s2amd_measure_dominant(s2amdSolver* solver, const s2amdStepParams* params, i
  * bodies per strip, default 8 = strips of two BFS levels), "strip_retry" (0/1 rebuild the partition with other strip widths when the persistent kernel cannot take this one or it needs more than five interior colour rounds), "strip_min_bodies" (loose bodies below which the colour-batch path is kept), "strip_patience" (steps the constraint graph must
  * stay unchanged before the strip structure is built: its host build costs ~3 ms at 60k constraints, the colour-batch one ~1 ms), "async" (0/1, see s2amd_synchronize), "strip_lean" (0/1 dedicated strip
  * kernel for the soft sweeps), "persist" (0/1 whole step of the strips in one persistent launch), "wide" (0/1 TGS_Soft's persistent launch runs 512 threads per strip: wide_kernel.hip),
+ * "generic" (0/1 every other Gauss-Seidel solver, and any big island with joints, runs its whole step as one launch of the op interpreter over the
+ * same strips: generic_kernel.hip; 0 = colour batches for them), "persist_retry" (steps a solver whose persistent launch lost a hand-off stays on the
+ * fallback path before the one-launch kernels get another chance -- the wait doubles with every further time-out; default 256, 0 = for ever),
  * "pair_lanes" (0/1 that launch solves a constraint with two lanes, one per body: pair_kernel.hip; measured no faster, off by default), "body_warm", "incremental" (0/1 created
  * contacts are placed into the existing structure when they fit; 0 = every created contact rebuilds it), "defer" (0/1 a created
  * contact that cannot be placed and has no manifold points yet is only watched until it gets its first points; 0 = it rebuilds the

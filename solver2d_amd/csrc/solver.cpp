@@ -363,6 +363,7 @@ int s2amd_synchronize(s2amdSolver* s)
 		}
 		HIP_TRY(hipStreamSynchronize(s->stream));
 		s->persistFailed = true;
+		s->persistFailedAge = 0;
 		s->persistFallbacks += 1;
 		s->stats.persistFallbacks = s->persistFallbacks;
 		return fail(S2AMD_E_DEVICE, "strip hand-off timed out inside the persistent step kernel (workgroups not co-resident?): the steps enqueued "
@@ -789,6 +790,16 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	{
 		s->optStripPatience = std::max(0, value);
 		s->stripPatienceNow = s->optStripPatience;
+	}
+	else if (strcmp(key, "free_body_groups") == 0)
+	{
+		s->optFreeBodyGroups = value != 0;
+		s->structureDirty = true;
+	}
+	else if (strcmp(key, "persist_retry") == 0)
+	{
+		s->optPersistRetry = std::max(0, value);
+		s->persistRetryAfter = std::max(1, value);
 	}
 	else if (strcmp(key, "generic") == 0)
 	{

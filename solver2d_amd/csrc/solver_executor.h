@@ -237,7 +237,7 @@ struct Executor
 		for (int bi = 0; bi < nb; ++bi)
 		{
 			int b = cs.batchOffsets[(size_t)bi], e = cs.batchOffsets[(size_t)bi + 1];
-			if (e <= b)
+			if (e <= b || emptyBatch(bi))
 			{
 				continue;
 			}
@@ -261,6 +261,34 @@ struct Executor
 			}
 			count();
 		}
+	}
+
+	// a colour batch of the global part that holds only free positions (the slack layout's spare colours; a batch whose contacts
+	// have all gone): nothing to launch.  The first contact placed into it re-captures the step graph (solver_incremental.cpp).
+	bool emptyBatch(int bi) const
+	{
+		const IncrementalGlobal& inc = s->inc;
+		return inc.valid && bi < inc.parallelBatches && (int)inc.freePositions[(size_t)bi].size() == inc.batchEnd[(size_t)bi] - inc.batchBegin[(size_t)bi];
+	}
+
+	// constraints (not positions) in the global contact part
+	bool anyGlobalContacts() const
+	{
+		const IncrementalGlobal& inc = s->inc;
+		if (!inc.valid)
+		{
+			return s->contacts.globalCount > 0;
+		}
+		const SweepSet& cs = s->contacts;
+		const int nb = (int)cs.batchOffsets.size() - 1;
+		for (int bi = 0; bi < nb; ++bi)
+		{
+			if (cs.batchOffsets[(size_t)bi + 1] > cs.batchOffsets[(size_t)bi] && !emptyBatch(bi))
+			{
+				return true;
+			}
+		}
+		return false;
 	}
 
 	static bool isBodyOp(int code)
@@ -744,7 +772,7 @@ struct Executor
 		}
 		// global part: op by op
 		int fusedFinalize = -1; // >= 0: the dynamicOnly flag of the s2FinalizePositions the epilogue launch performs
-		const bool anyGlobal = s->looseBodies > 0 || s->contacts.globalCount > 0 || s->joints.globalCount > 0;
+		const bool anyGlobal = s->looseBodies > 0 || anyGlobalContacts() || s->joints.globalCount > 0;
 		if (anyGlobal)
 		{
 			const int n = (int)p.ops.size();

@@ -493,6 +493,10 @@ bool incrementalApply(s2amdSolver* s, const std::vector<ContactChange>& changes)
 			s->spareColours = 2; // every colour batch is taken on these bodies: the rebuild adds empty ones for the next such contact
 			return giveUp("no free colour");
 		}
+		if ((int)inc.freePositions[(size_t)chosen].size() == inc.batchEnd[(size_t)chosen] - inc.batchBegin[(size_t)chosen])
+		{
+			s->layoutGeneration += 1; // the batch was empty: its launches were left out of the captured step graph (Executor::emptyBatch)
+		}
 		const int k = inc.freePositions[(size_t)chosen].back();
 		inc.freePositions[(size_t)chosen].pop_back();
 		if (!inc.ignoreColours)

@@ -339,6 +339,7 @@ struct s2amdSolver
 	bool genericValid = false;
 	int genericBodies = 0, genericSeamBodies = 0, genericExports = 0; // the most staged bodies / seam-group bodies / exported bodies of a strip (LDS)
 	int optGeneric = 1;
+	int optFreeBodyGroups = 1; // "free_body_groups": constraint-free bodies next to groups / strips form LDS groups instead of global launches
 	int persistK0 = 0, persistK1 = 0; // the strip constraints' range in contacts.order (persist.allTwoPoints is recomputed over it)
 	int persistRecordsWide = 0; // LDS records when a seam constraint takes 10 records (every kind but TGS_Soft's)
 	DevBuf dPersistOps;
@@ -358,6 +359,10 @@ struct s2amdSolver
 	int optPersistSpinLimit = 1 << 21;
 	bool persistFailed = false; // a hand-off timed out once (workgroups not co-resident: a shared GPU): multi-launch strips from then on
 	int persistFallbacks = 0;
+	// ... but not for ever: after `persistRetryAfter` further steps the one-launch kernels get another chance (the GPU may have
+	// been shared only for a while); a retry that times out again doubles the wait
+	int optPersistRetry = 256; // "persist_retry": steps on the fallback path before the first retry, 0 = never
+	int persistRetryAfter = 256, persistFailedAge = 0;
 	int cuCount = 0;
 	unsigned int* hostError = nullptr; // pinned, device-visible: a hand-off timed out
 	unsigned long long* hostTimes = nullptr; // S2AMD_DEBUG_TIMES: pinned [256] phase time stamps of one workgroup

@@ -351,6 +351,15 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	HIP_TRY(hipSetDevice(s->device));
 	s->stats = s2amdStepStats{};
 	buildPlan(s, params);
+	if (s->persistFailed && s->optPersistRetry > 0 && ++s->persistFailedAge > s->persistRetryAfter)
+	{
+		// a hand-off timed out a while ago (workgroups not co-resident: something else held part of the GPU): try again
+		s->persistFailed = false;
+		s->persistFailedAge = 0;
+		s->persistRetryAfter = std::min(s->persistRetryAfter * 2, 1 << 20);
+		s->stripsRejected = false;
+		s->structureDirty = true; // (the structure may have dropped its strips for want of a kernel that could run them)
+	}
 	if (s->stripRetryPending && s->graphAge >= 32 && !s->structureDirty)
 	{
 		s->structureDirty = true; // the postponed search for a better strip partition (solver_structure.cpp: buildStructure)
@@ -582,6 +591,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 		*s->hostError = 0u;
 		(void)hipMemsetAsync(s->persist.deviceError, 0, sizeof(unsigned int), s->stream);
 		s->persistFailed = true;
+		s->persistFailedAge = 0;
 		s->persistFallbacks += 1;
 		return doStep(s, params);
 	}

@@ -2261,6 +2261,31 @@ struct StructureBuild
 				}
 			}
 		}
+		// Bodies that carry no constraint of this structure at all (a ball in flight) would be the ONLY reason for the global path's
+		// launches -- one per body stage, ~25 per TGS_Soft step -- next to groups or strips that take one launch for everything:
+		// they become LDS groups of their own (body stages only).  With constraints in the global part they ride along there.
+		if (grouped && s->optFreeBodyGroups && cs.globalCount == 0 && js.globalCount == 0 && (s->hGroups.count() > 0 || s->hResident.count() > 0 || strips.active))
+		{
+			std::vector<int> freeBodies;
+			for (int i = 0; i < nb; ++i)
+			{
+				// (only bodies the sweeps could write: a kinematic body may be a read-only replica in other groups of the same launch, which
+				// must not see its owner's write-back -- it stays with the body kernels that run after that launch)
+				if (s->hBodyLive[i] && !s->hBodyStatic[i] && conflict[(size_t)i] && (flags[i] & S2F_IN_GROUP) == 0)
+				{
+					freeBodies.push_back(i);
+					if ((int)freeBodies.size() == s->optMaxGroupBodies)
+					{
+						emitGroup(s->hGroups, noSeed, noSeed, freeBodies);
+						freeBodies.clear();
+					}
+				}
+			}
+			if (!freeBodies.empty())
+			{
+				emitGroup(s->hGroups, noSeed, noSeed, freeBodies);
+			}
+		}
 		s->hBodyFlagsFinal = flags;
 		s->looseBodies = 0;
 		for (int i = 0; i < nb; ++i)
@@ -2526,6 +2551,17 @@ struct StructureBuild
 		s->orderResident = residentWanted;
 		s->orderColourless = needAdj;
 		s->orderGrouped = grouped;
+		if (getenv("S2AMD_DEBUG"))
+		{
+			int real = 0;
+			for (int k = 0; k < cs.globalCount; ++k)
+			{
+				real += cs.order[(size_t)k] >= 0 ? 1 : 0;
+			}
+			fprintf(stderr, "[s2amd] structure: global part %d contact positions (%d constraints, %d batches%s), %d joints; %d LDS groups, %d resident, %d strips; loose bodies %d\n",
+					cs.globalCount, real, (int)cs.batchOffsets.size() - 1, cs.hasTail ? ", tail" : "", js.globalCount, s->hGroups.count(), s->hResident.count(),
+					s->hStripA.count(), s->looseBodies);
+		}
 		s->orderStrips = wantStrips;
 		s->orderStripBodies = stripBodiesFor(s, solverType);
 		s->structureDirty = false;

@@ -398,6 +398,33 @@ def test_a_dead_hand_off_falls_back_to_the_multi_launch_path():
         common.compare_exact(got, want, "dead hand-off, resident")
 
 
+@pytest.mark.parametrize("solver_name", ["TGS_Soft", "PGS_NGS_Block"])
+def test_a_solver_that_lost_a_hand_off_tries_the_persistent_kernel_again_later(solver_name):
+    """`persistFailed` is not for ever: after "persist_retry" steps on the fallback path the one-launch kernels get another chance
+    (the GPU may have been shared only for a while); a retry that times out again doubles the wait.  Every step stays exact."""
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    pre = synthetic.pyramid(100)
+    params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
+        s.set_option("persist_spin_limit", 4096)
+        s.set_option("persist_retry", 3)
+        s.set_option("persist_debug", 8)
+        state = gpu_vs_oracle(s, params, pre, "retry: the fault")
+        assert s.stats()["persistFallbacks"] == 1 and s.stats()["persistent"] == 0
+        history = []
+        for step in range(5):  # the fault persists: one more time-out at the retry, then a doubled wait
+            state = gpu_vs_oracle(s, params, state, "retry: fault still there, step %d" % step)
+            history.append((s.stats()["persistent"], s.stats()["persistFallbacks"]))
+        assert history[-1] == (0, 2) and [h[1] for h in history].count(1) >= 2, history
+        s.set_option("persist_debug", 0)  # the other tenant has left
+        seen = []
+        for step in range(8):
+            state = gpu_vs_oracle(s, params, state, "retry: fault gone, step %d" % step)
+            seen.append(s.stats()["persistent"])
+        assert seen[-1] == 1 and 0 in seen and s.stats()["persistFallbacks"] == 2, seen
+
+
 def test_a_dead_hand_off_under_async_is_reported_and_the_solver_recovers():
     """The same fault with option "async": steps are enqueued without a host sync, the failure surfaces at
     s2amd_synchronize.  Contract: the call fails with a device error, the resident world stands where it stood before the

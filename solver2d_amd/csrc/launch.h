@@ -152,6 +152,7 @@ void launchPairStep(hipStream_t s, int kind, int warm, const ContactView& c, con
 
 // wide_kernel.hip: TGS_Soft's persistent strip step on 512 threads per strip
 int wideKernelSetup();
+int wideParkedRecords(int maxRoundsA, int maxSeamRounds, int force);
 void launchWideStep(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount);
 
 // generic_kernel.hip: the persistent strip step as an op interpreter -- every solver family, joints included

@@ -429,8 +429,9 @@ struct Executor
 	// warm start on a partition with at most six interior colour batches per strip and two per seam.
 	bool widePlan(int kind, int warm) const
 	{
-		return s->optWide && ((s->persist.maxRoundsA <= 6 && s->persist.maxSeamRounds <= 3) || (s->persist.maxRoundsA <= 8 && s->persist.maxSeamRounds <= 2)) && kind == SOFT_TGS && warm == WARM_CURRENT &&
-			   s->persist.ldsRecords + 3 + 2 * s->persistOpCount <= (160 * 1024) / 16;
+		const int parked = wideParkedRecords(s->persist.maxRoundsA, s->persist.maxSeamRounds, (s->persist.debugSkip & 16) != 0);
+		return s->optWide && parked >= 0 && kind == SOFT_TGS && warm == WARM_CURRENT &&
+			   s->persist.bodyRecords + 3 + parked + 2 * s->persistOpCount <= (160 * 1024) / 16;
 	}
 
 	// Can the plan run on the resident-island kernel (strip_kernel.hip: islandStepKernel)?  The soft contact drivers: body

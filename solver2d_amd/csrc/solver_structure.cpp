@@ -1161,7 +1161,7 @@ do                                                                              
 		int genericBodies = 0, genericSeamBodies = 0, genericExports = 0;
 		std::vector<int> remap, exportSrc, importIds;
 		std::vector<int> replicaStamp((size_t)nb, -1), replicaSlot((size_t)nb, -1);
-		int ldsRecords = 0, ldsRecordsWide = 0;
+		int ldsRecords = 0, ldsRecordsWide = 0, bodyRecordsMax = 0;
 		for (int i = 0; i < K && ok; ++i)
 		{
 			PersistDesc& d = descs[(size_t)i];
@@ -1261,6 +1261,7 @@ do                                                                              
 			NEEDSOFT(fixedRecords + seamRecordsNarrow + 2 * 16 <= (160 * 1024) / 16 && nt < 16384); // the plan's own records are checked when it is known (persistPlan)
 			NEED(genericStepLds(nt, genericSeamBodies, genericExports, 16, 0) <= 160 * 1024); // (with the plan's ops and its XPBD history: Executor::genericPlan)
 			ldsRecords = std::max(ldsRecords, fixedRecords + seamRecordsNarrow);
+			bodyRecordsMax = std::max(bodyRecordsMax, fixedRecords);
 			ldsRecordsWide = std::max(ldsRecordsWide, fixedRecords + S2_PERSIST_Q_WIDE * seamSlots);
 		}
 		if (getenv("S2AMD_DEBUG"))
@@ -1354,6 +1355,7 @@ do                                                                              
 			s->persistK0 = k0, s->persistK1 = k1;
 			pv.allTwoPoints = stripsAllTwoPoints(s) ? 1 : 0;
 			pv.ldsRecords = ldsRecords;
+			pv.bodyRecords = bodyRecordsMax;
 			s->persistRecordsWide = ldsRecordsWide;
 			pv.debugSkip = s->optPersistDebug;
 			pv.spinLimit = (unsigned int)s->optPersistSpinLimit;

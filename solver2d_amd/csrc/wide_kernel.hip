@@ -438,8 +438,34 @@ S2_DEV void storeWide(const ContactView& c, const WideRegs& p, int k)
 	}
 }
 
+// A seam record parked in LDS (seam rounds beyond the SR a lane keeps in registers: a partition whose seams need a third or fourth
+// colour next to seven or eight interior ones): six 16-byte records per lane and round, field-major so that a wave reads
+// consecutive addresses; the impulses are a record of their own -- the only part a sweep writes back.
+#define S2_WIDE_PARKED_RECORDS 6
+S2_DEV void parkWide(float4* slot, const WideRegs& p)
+{
+	slot[0 * S2_WIDE_THREADS] = make_float4(fromBits(p.idx), p.n.x, p.n.y, p.friction);
+	slot[1 * S2_WIDE_THREADS] = make_float4(p.lA[0].x, p.lA[0].y, p.lA[1].x, p.lA[1].y);
+	slot[2 * S2_WIDE_THREADS] = make_float4(p.lB[0].x, p.lB[0].y, p.lB[1].x, p.lB[1].y);
+	slot[3 * S2_WIDE_THREADS] = make_float4(p.p0[0], p.p0[1], p.p1[0], p.p1[1]);
+	slot[4 * S2_WIDE_THREADS] = make_float4(p.p2[0], p.p2[1], 0.0f, 0.0f);
+	slot[5 * S2_WIDE_THREADS] = make_float4(p.imp[0].x, p.imp[0].y, p.imp[1].x, p.imp[1].y);
+}
+S2_DEV WideRegs unparkWide(const float4* slot)
+{
+	const float4 q0 = slot[0 * S2_WIDE_THREADS], q1 = slot[1 * S2_WIDE_THREADS], q2 = slot[2 * S2_WIDE_THREADS], q3 = slot[3 * S2_WIDE_THREADS],
+				 q4 = slot[4 * S2_WIDE_THREADS], q5 = slot[5 * S2_WIDE_THREADS];
+	WideRegs p;
+	p.idx = asBits(q0.x), p.n = f2{q0.y, q0.z}, p.friction = q0.w;
+	p.lA[0] = lo2(q1), p.lA[1] = hi2(q1), p.lB[0] = lo2(q2), p.lB[1] = hi2(q2);
+	p.p0[0] = q3.x, p.p0[1] = q3.y, p.p1[0] = q3.z, p.p1[1] = q3.w, p.p2[0] = q4.x, p.p2[1] = q4.y;
+	p.imp[0] = lo2(q5), p.imp[1] = hi2(q5);
+	return p;
+}
+
 // POINTS == 2: the host has checked that every constraint of the strips has two manifold points: no per-point masking.
-template <int POINTS, int RPH, int SR> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideStepKernel(ContactView c, BodyView g, StripTableView ta, PersistView pv, const Op* ops, int opCount)
+// RPH: interior records a lane keeps (colour batches / 2), SR: seam records a lane keeps, SL: seam rounds parked in LDS.
+template <int POINTS, int RPH, int SR, int SL = 0> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideStepKernel(ContactView c, BodyView g, StripTableView ta, PersistView pv, const Op* ops, int opCount)
 {
 	extern __shared__ __attribute__((aligned(16))) float4 lds[];
 	const int tid = (int)threadIdx.x;
@@ -485,9 +511,11 @@ template <int POINTS, int RPH, int SR> __global__ __launch_bounds__(S2_WIDE_THRE
 	}
 	const int nImp0 = pd->importCount[0], nImp1 = pd->importCount[1];
 	const int roundsB0 = pd->seamBatchCount[0], roundsB1 = pd->seamBatchCount[1];
-	int2 batchB0[SR], batchB1[SR];
+	constexpr int ST = SR + SL; // seam colour batches this variant takes
+	static_assert(ST <= S2_PERSIST_B_ROUNDS, "PersistDesc::seamBatch");
+	int2 batchB0[ST], batchB1[ST];
 #pragma unroll
-	for (int i = 0; i < SR; ++i)
+	for (int i = 0; i < ST; ++i)
 	{
 		batchB0[i] = pd->seamBatch[0][i];
 		batchB1[i] = pd->seamBatch[1][i];
@@ -509,6 +537,7 @@ template <int POINTS, int RPH, int SR> __global__ __launch_bounds__(S2_WIDE_THRE
 	const int bodyRecords = 3 * nt + (nt + 3) / 4 + (nt + 1) / 2;
 	Op* lops = (Op*)(lds + bodyRecords); // 2 records per op
 	float4* lcoef = lds + bodyRecords + 2 * opCount; // 2 records + 1 for the census flags (the launch adds them to the size)
+	float4* lparked = lcoef + 3 + tid;				 // SL rounds of S2_WIDE_PARKED_RECORDS * 512 records: this lane's column
 
 	// ---- loads ----
 	uint32_t id[S2_WIDE_BODY_CHUNKS];
@@ -574,6 +603,18 @@ template <int POINTS, int RPH, int SR> __global__ __launch_bounds__(S2_WIDE_THRE
 		{
 			const int2 lb = c.localBodies[k];
 			rB[i] = loadWide(c, k, pv.remap[pd->remapBase[seam] + lb.x], pv.remap[pd->remapBase[seam] + lb.y]);
+			seamMask |= 1u << i;
+		}
+	}
+#pragma unroll
+	for (int i = SR; i < ST; ++i)
+	{
+		int seam, k;
+		if (i < roundsB && seamItem(i, seam, k))
+		{
+			const int2 lb = c.localBodies[k];
+			parkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * S2_WIDE_THREADS,
+					 loadWide(c, k, pv.remap[pd->remapBase[seam] + lb.x], pv.remap[pd->remapBase[seam] + lb.y]));
 			seamMask |= 1u << i;
 		}
 	}
@@ -647,6 +688,17 @@ template <int POINTS, int RPH, int SR> __global__ __launch_bounds__(S2_WIDE_THRE
 		if ((seamMask >> i) & 1u)
 		{
 			markStatic(rB[i]);
+		}
+	}
+#pragma unroll
+	for (int i = SR; i < ST; ++i)
+	{
+		if ((seamMask >> i) & 1u)
+		{
+			float4* slot = lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * S2_WIDE_THREADS;
+			WideRegs p = unparkWide(slot);
+			markStatic(p);
+			slot[0].x = fromBits(p.idx);
 		}
 	}
 	stampAt(1);
@@ -748,6 +800,18 @@ template <int POINTS, int RPH, int SR> __global__ __launch_bounds__(S2_WIDE_THRE
 					if ((seamMask >> i) & 1u)
 					{
 						warmWide<POINTS>(rB[i], lvel, ldq, lmass, salt);
+					}
+					__syncthreads();
+				}
+			}
+#pragma unroll
+			for (int i = SR; i < ST; ++i)
+			{
+				if (i < roundsB)
+				{
+					if ((seamMask >> i) & 1u)
+					{
+						warmWide<POINTS>(unparkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * S2_WIDE_THREADS), lvel, ldq, lmass, salt);
 					}
 					__syncthreads();
 				}
@@ -866,6 +930,22 @@ template <int POINTS, int RPH, int SR> __global__ __launch_bounds__(S2_WIDE_THRE
 					}
 				}
 			}
+#pragma unroll
+			for (int i = SR; i < ST; ++i)
+			{
+				if (i < roundsB)
+				{
+					if ((seamMask >> i) & 1u)
+					{
+						float4* slot = lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * S2_WIDE_THREADS;
+						WideRegs p = unparkWide(slot);
+						const WidePrep late = prepWide<POINTS>(p, ldq, lcoef, op.inv_h, op.useBias, salt);
+						chainWide<POINTS>(p, late, lvel, lmass, lcoef, salt);
+						slot[5 * S2_WIDE_THREADS] = make_float4(p.imp[0].x, p.imp[0].y, p.imp[1].x, p.imp[1].y);
+					}
+					__syncthreads();
+				}
+			}
 			stampAt(6);
 		}
 	}
@@ -900,6 +980,15 @@ template <int POINTS, int RPH, int SR> __global__ __launch_bounds__(S2_WIDE_THRE
 			storeWide(c, rB[i], k);
 		}
 	}
+#pragma unroll
+	for (int i = SR; i < ST; ++i)
+	{
+		int seam, k;
+		if (i < roundsB && seamItem(i, seam, k) && seam == 1)
+		{
+			storeWide(c, unparkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * S2_WIDE_THREADS), k);
+		}
+	}
 	stampAt(7);
 	if (stamp)
 	{
@@ -911,42 +1000,77 @@ template <int POINTS, int RPH, int SR> __global__ __launch_bounds__(S2_WIDE_THRE
 // Eligibility (checked by the caller, solver_executor.h widePlan): TGS_Soft with the current-anchor warm start on a partition with
 // at most 6 interior colour batches per strip and 3 per seam, or 8 and 2 (pv.maxRoundsA, pv.maxSeamRounds): five or six resident
 // records per lane fit its 256 registers beside the round's working set, seven do not (measured: 160 spilled registers).
-template <int RPH, int SR>
+template <int RPH, int SR, int SL = 0>
 static void launchWide(hipStream_t s, dim3 grid, size_t lds, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount)
 {
 	const dim3 block(S2_WIDE_THREADS);
+	lds += (size_t)SL * S2_WIDE_PARKED_RECORDS * S2_WIDE_THREADS * sizeof(float4);
 	if (pv.allTwoPoints)
 	{
-		wideStepKernel<2, RPH, SR><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
+		wideStepKernel<2, RPH, SR, SL><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
 	}
 	else
 	{
-		wideStepKernel<0, RPH, SR><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
+		wideStepKernel<0, RPH, SR, SL><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
 	}
+}
+
+// records of dynamic LDS the variant for (maxRoundsA, maxSeamRounds) needs beside the bodies, the ops and the three fixed records;
+// -1: no variant takes that partition (Executor::widePlan)
+int wideParkedRecords(int maxRoundsA, int maxSeamRounds, int force)
+{
+	if (maxRoundsA > 8 || maxSeamRounds > 4)
+	{
+		return -1;
+	}
+	const bool inRegisters = !force && ((maxRoundsA <= 6 && maxSeamRounds <= 3) || maxSeamRounds <= 2);
+	return inRegisters ? 0 : 2 * S2_WIDE_PARKED_RECORDS * S2_WIDE_THREADS;
 }
 
 void launchWideStep(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount)
 {
 	const dim3 grid((unsigned)a.groupCount);
-	const size_t lds = (size_t)(pv.ldsRecords + 3) * sizeof(float4) + (size_t)opCount * sizeof(Op);
-	if (pv.maxRoundsA <= 6 && pv.maxSeamRounds <= 2)
+	const size_t lds = (size_t)(pv.bodyRecords + 3) * sizeof(float4) + (size_t)opCount * sizeof(Op);
+	const bool park = (pv.debugSkip & 16) != 0; // tests: the variants with parked seam rounds whatever the partition needs
+	if (park)
+	{
+		if (pv.maxRoundsA <= 6)
+		{
+			launchWide<3, 2, 2>(s, grid, lds, c, g, a, pv, ops, opCount);
+		}
+		else
+		{
+			launchWide<4, 2, 2>(s, grid, lds, c, g, a, pv, ops, opCount);
+		}
+	}
+	else if (pv.maxRoundsA <= 6 && pv.maxSeamRounds <= 2)
 	{
 		launchWide<3, 2>(s, grid, lds, c, g, a, pv, ops, opCount);
 	}
-	else if (pv.maxRoundsA <= 6)
+	else if (pv.maxRoundsA <= 6 && pv.maxSeamRounds <= 3)
 	{
 		launchWide<3, 3>(s, grid, lds, c, g, a, pv, ops, opCount);
 	}
-	else
+	else if (pv.maxSeamRounds <= 2)
 	{
 		launchWide<4, 2>(s, grid, lds, c, g, a, pv, ops, opCount);
+	}
+	else if (pv.maxRoundsA <= 6)
+	{
+		launchWide<3, 2, 2>(s, grid, lds, c, g, a, pv, ops, opCount);
+	}
+	else
+	{
+		launchWide<4, 2, 2>(s, grid, lds, c, g, a, pv, ops, opCount);
 	}
 }
 
 int wideKernelSetup()
 {
 	const void* steps[] = {(const void*)wideStepKernel<0, 3, 2>, (const void*)wideStepKernel<2, 3, 2>, (const void*)wideStepKernel<0, 3, 3>,
-						   (const void*)wideStepKernel<2, 3, 3>, (const void*)wideStepKernel<0, 4, 2>, (const void*)wideStepKernel<2, 4, 2>};
+						   (const void*)wideStepKernel<2, 3, 3>, (const void*)wideStepKernel<0, 4, 2>, (const void*)wideStepKernel<2, 4, 2>,
+						   (const void*)wideStepKernel<0, 3, 2, 2>, (const void*)wideStepKernel<2, 3, 2, 2>, (const void*)wideStepKernel<0, 4, 2, 2>,
+						   (const void*)wideStepKernel<2, 4, 2, 2>};
 	for (const void* f : steps)
 	{
 		hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -366,6 +366,30 @@ def test_persistent_kernel_next_to_a_busy_neighbour():
         noisy.close()
 
 
+@pytest.mark.parametrize("base,strip_bodies", [(100, 8), (100, 320), (72, 200)])
+def test_wide_kernel_with_parked_seam_rounds(base, strip_bodies):
+    """wide_kernel.hip keeps two seam records per lane in registers; a partition whose seams need a third or fourth colour next to
+    seven or eight interior ones parks those rounds in LDS (variants <3,2,2> / <4,2,2>).  persist_debug 16 forces them on
+    partitions that do not need them: same order, same bits as the register variants."""
+    pre = synthetic.pyramid(base)
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    results = []
+    for park in (0, 16):
+        with hip.Solver(0) as s:
+            s.set_option("strip_patience", 0)
+            s.set_option("strip_min_bodies", 0)
+            s.set_option("strip_retry", 0)
+            s.set_option("strip_bodies", strip_bodies)
+            s.set_option("persist_debug", park)
+            state = common.copy3(pre)
+            for step in range(3):
+                state = gpu_vs_oracle(s, params, state, "pyramid%d parked=%d step %d" % (base, park, step))
+            st = s.stats()
+            assert st["persistent"] == 1 and st["pairLanes"] == 2, st
+            results.append(state)
+    common.compare_exact(results[0], results[1], "parked seam rounds vs registers")
+
+
 def test_a_dead_hand_off_falls_back_to_the_multi_launch_path():
     """Fault injection: workgroup 1 of the persistent kernel never publishes its seam bodies (what a non-resident
     workgroup looks like to its neighbours).  The polls give up, the epilogue leaves the wire arrays alone, the host

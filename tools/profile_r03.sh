@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 passes behind profiles/r03_*: run on the GPU box from the repo root (gpurun).  Counter passes are separate runs
-# (--kernel-trace --pmc X only), never combined with the sys / hip / hsa trace domains.  Usage: tools/profile_r03.sh [headline|config5|all]
+# (--kernel-trace --pmc X only), never combined with the sys / hip / hsa trace domains.  Usage: tools/profile_r03.sh [headline|config5|generic|all]
 R=$PWD
 export TMPDIR=/tmp
 cd /tmp
@@ -26,7 +26,16 @@ if [ $what = config5 -o $what = all ]; then
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/c5_write -o pmc -- $C5 > $O/c5_write.log 2>&1
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES -d $O/c5_sq -o pmc -- $C5 > $O/c5_sq.log 2>&1
 fi
+if [ $what = generic -o $what = all ]; then
+  # the op interpreter (generic_kernel.hip) under the reference's default solver at base 200 and on JointGrid 100x100
+  rocprofv3 --kernel-trace --stats -d $O/g_block -o trace -- python $R/tools/solver_table.py --solvers PGS_NGS_Block --steps 100 > $O/g_block.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $O/g_joint -o trace -- python $R/tools/solver_table.py --world joint_grid --base 100 --solvers PGS_NGS --steps 100 > $O/g_joint.log 2>&1
+fi
 cd $R
+for d in g_block g_joint; do
+  db=$(find $O/$d -name "*_results.db" 2>/dev/null | head -1)
+  [ -n "$db" ] && python tools/rocpd_summary.py $db > $O/$d.txt
+done
 for d in h_stats h_fetch h_write h_sq_a h_sq_b c5_stats c5_fetch c5_write c5_sq; do
   db=$(find $O/$d -name "*_results.db" 2>/dev/null | head -1)
   [ -n "$db" ] && python tools/rocpd_summary.py $db > $O/$d.txt
@@ -34,6 +43,7 @@ done
 # the summaries under the names profiles/ keeps
 P=$R/gpurun_out/prof3/out
 mkdir -p $P
+[ -f $O/g_block.txt ] && (echo "## pyramid base 200, s2_solverPGS_NGS_Block 4/2 (tools/solver_table.py --solvers PGS_NGS_Block --steps 100)"; cat $O/g_block.txt; echo; echo "## JointGrid 100x100, s2_solverPGS_NGS 4/2 (tools/solver_table.py --world joint_grid --base 100 --solvers PGS_NGS --steps 100)"; cat $O/g_joint.txt) > $P/r03_generic_kernel_trace.txt
 [ -f $O/h_stats.txt ] && cp $O/h_stats.txt $P/r03_persistent_kernel_trace.txt
 [ -f $O/h_fetch.txt ] && cp $O/h_fetch.txt $P/r03_persistent_pmc_fetch_size.txt
 [ -f $O/h_write.txt ] && cp $O/h_write.txt $P/r03_persistent_pmc_write_size.txt

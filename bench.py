@@ -102,6 +102,9 @@ def cpu_baseline(base, vel, pos, budget_s):
                 steps, base, 1e3 * secs / steps, os.cpu_count())}
 
 
+ISLAND_KERNELS = ("_Z16wideIslandKernel", "_Z16islandStepKernel")  # wide_kernel.hip (TGS_Soft), strip_kernel.hip (the general form)
+
+
 def pmc_issue(kernel_prefixes, stem="persistent"):
     """VALU-issue picture of the dominant kernel from the committed SQ pass (profiles/rNN_<stem>_pmc_sq.txt, rocprofv3 --pmc, its
     own run): VALU instructions per wave and the share of a SIMD's cycles in which it issues one -- a wave64 VALU instruction
@@ -239,9 +242,9 @@ def island_sharded_leg(ranks, islands, base, vel, pos, steps, warmup, graph=True
                    "device_ms_per_step": st["deviceMs"], "graph_replay": bool(st["graphReplayed"]), "trajectory": "consecutive resident steps (no restore)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      # (the committed PMC passes are of the whole world on one GPU)
-                     "traffic": pmc_traffic_bytes("_Z16islandStepKernel", "config5")[0] if ranks.world == 1 and islands == 512 and base == 40 else None,
-                     "traffic_source": pmc_traffic_bytes("_Z16islandStepKernel", "config5")[1] if ranks.world == 1 and islands == 512 and base == 40 else None,
-                     "kernel": "islandStepKernel (whole step of this rank's islands in one launch: constraints resident in registers, bodies in "
+                     "traffic": pmc_traffic_bytes(ISLAND_KERNELS, "config5")[0] if ranks.world == 1 and islands == 512 and base == 40 else None,
+                     "traffic_source": pmc_traffic_bytes(ISLAND_KERNELS, "config5")[1] if ranks.world == 1 and islands == 512 and base == 40 else None,
+                     "kernel": "wideIslandKernel / islandStepKernel (whole step of this rank's islands in one launch: constraints resident in registers, bodies in "
                                "LDS, records prepared from and impulses stored to the wire contacts by the kernel itself)", "avg_launch_us": us,
                      "algorithmic_bytes_per_launch": algo,
                      "byte_model": "136 B per constraint-sweep (SURVEY.md 8d, body state served from LDS) x %d constraints x %d sweeps" % (mine, sweeps),
@@ -255,7 +258,7 @@ def island_sharded_leg(ranks, islands, base, vel, pos, steps, warmup, graph=True
         line["roofline"]["traffic_gbs"] = traffic / max(us * 1e-6, 1e-12) / 1e9
         line["roofline"]["traffic_frac_of_peak"] = line["roofline"]["traffic_gbs"] / HBM_PEAK_GBS
         line["roofline"]["traffic_over_model"] = traffic / algo
-    line["issue"] = finish_issue(pmc_issue(("_Z16islandStepKernel",), "config5"), st["groupCount"]) if ranks.world == 1 and islands == 512 and base == 40 else None
+    line["issue"] = finish_issue(pmc_issue(ISLAND_KERNELS, "config5"), st["groupCount"]) if ranks.world == 1 and islands == 512 and base == 40 else None
     if line["issue"] is not None:
         line["issue"]["note"] = "512 workgroups of 512 threads on 256 CUs (two passes): the kernel is VALU-issue bound, not bandwidth bound"
     return line

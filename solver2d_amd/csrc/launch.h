@@ -153,6 +153,9 @@ void launchPairStep(hipStream_t s, int kind, int warm, const ContactView& c, con
 // wide_kernel.hip: TGS_Soft's persistent strip step on 512 threads per strip
 int wideKernelSetup();
 int wideParkedRecords(int maxRoundsA, int maxSeamRounds, int force);
+// ... and the resident islands' step (strip_kernel.hip: launchIslandStep) for TGS_Soft with the current-anchor warm start
+void launchWideIsland(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& t, const float4* softCoef, const Op* ops, int opCount,
+					  int maxRounds, s2amdContact* wire, const s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart);
 void launchWideStep(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount);
 
 // generic_kernel.hip: the persistent strip step as an op interpreter -- every solver family, joints included

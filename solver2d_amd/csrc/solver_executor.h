@@ -523,8 +523,17 @@ struct Executor
 			{
 				coef[i] = make_float4(p.sc.softCoef[i][0], p.sc.softCoef[i][1], p.sc.softCoef[i][2], 0.0f);
 			}
-			launchIslandStep(st, kind, warm, s->cv, s->bv, s->residentView, coef, (const Op*)s->dResidentOps.p, s->residentOpCount, s->residentRounds,
-							 wireContacts(), wireBodies(), (const uint32_t*)s->dBodyFlags.p, p.sc.warmStart);
+			// (the LDS budget of the resident groups leaves room for the two coefficient records: buildResidentTables)
+			if (s->optWide && kind == SOFT_TGS && warm == WARM_CURRENT && s->residentView.ldsRecords + 2 + 2 * s->residentOpCount <= (160 * 1024) / 16)
+			{
+				launchWideIsland(st, s->cv, s->bv, s->residentView, coef, (const Op*)s->dResidentOps.p, s->residentOpCount, s->residentRounds, wireContacts(),
+								 wireBodies(), (const uint32_t*)s->dBodyFlags.p, p.sc.warmStart);
+			}
+			else
+			{
+				launchIslandStep(st, kind, warm, s->cv, s->bv, s->residentView, coef, (const Op*)s->dResidentOps.p, s->residentOpCount, s->residentRounds,
+								 wireContacts(), wireBodies(), (const uint32_t*)s->dBodyFlags.p, p.sc.warmStart);
+			}
 		}
 		else
 		{

@@ -941,72 +941,7 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 	}
 }
 
-// s2PrepareContacts_Soft (solve_common.c:188-274) for ONE constraint straight from its wire record: the operations of
-// prepareContactsKernel<PREP_SOFT> (contact_kernels.hip) in the same order, so the same bits -- but the prepared record
-// goes into the caller's registers instead of through the SoA arrays.  Body data: rotation and inverse masses from the
-// LDS copies (== the wire body's: body_ops.h unpackBodyOne), local centres from the wire bodies.
-template <int KIND, class BA>
-S2_DEV SoftRegs<KIND> prepareSoftFromWire(const s2amdContact* contact, const s2amdBody* wireBodies, const uint32_t* hostFlags, const BA& lb, const float2* lmass,
-										  int2 local, int bodyCapacity, int warmStart)
-{
-	SoftRegs<KIND> r;
-	int pointCount = contact->pointCount;
-	int ia = contact->bodyA, ib = contact->bodyB;
-	if (pointCount <= 0 && (ia < 0 || ib < 0 || ia >= bodyCapacity || ib >= bodyCapacity))
-	{
-		pointCount = 0, ia = 0, ib = 0; // a destroyed contact whose entry lingers (prepareContactsKernel has the same guard)
-	}
-	pointCount = pointCount > 0 ? pointCount : 0;
-	const V2 normal = v2(contact->normal[0], contact->normal[1]);
-	const V2 tangent = rightPerp(normal);
-	const s2amdBody* wa = wireBodies + ia;
-	const s2amdBody* wb = wireBodies + ib;
-	const V2 lcA = v2(wa->localCenter[0], wa->localCenter[1]);
-	const V2 lcB = v2(wb->localCenter[0], wb->localCenter[1]);
-	const float2 massA = lmass[local.x], massB = lmass[local.y];
-	const float mA = massA.x, iA = massA.y, mB = massB.x, iB = massB.y;
-	const Rot qA = loadPose(lb, local.x).q, qB = loadPose(lb, local.y).q;
-	r.h.ia = local.x, r.h.ib = local.y;
-	r.h.mA = mA, r.h.iA = iA, r.h.mB = mB, r.h.iB = iB;
-	r.h.normal = normal;
-	r.h.friction = contact->friction;
-	r.h.pointCount = pointCount;
-	r.h.writeA = pointCount > 0 && (hostFlags[ia] & S2F_WRITE_VEL) != 0; // (the soft solvers are velocity-class sweeps)
-	r.h.writeB = pointCount > 0 && (hostFlags[ib] & S2F_WRITE_VEL) != 0;
-#pragma unroll
-	for (int j = 0; j < 2; ++j)
-	{
-		const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-		r.an[j] = zero, r.r0[j] = zero, r.par[j] = zero, r.sf[j] = zero;
-		r.imp[j] = make_float2(0.0f, 0.0f);
-		if (j < pointCount)
-		{
-			const s2amdManifoldPoint* mp = contact->points + j;
-			if (warmStart)
-			{
-				r.imp[j] = make_float2(mp->normalImpulse, mp->tangentImpulse);
-			}
-			V2 lA = sub(v2(mp->localAnchorA[0], mp->localAnchorA[1]), lcA);
-			V2 lB = sub(v2(mp->localAnchorB[0], mp->localAnchorB[1]), lcB);
-			V2 rA = rotate(qA, lA);
-			V2 rB = rotate(qB, lB);
-			float separation = mp->separation;
-			float adjustedSeparation = separation - dot(sub(rB, rA), normal);
-			float rtA = cross(rA, tangent);
-			float rtB = cross(rB, tangent);
-			float kTangent = mA + mB + iA * rtA * rtA + iB * rtB * rtB;
-			float tangentMass = kTangent > 0.0f ? 1.0f / kTangent : 0.0f;
-			float rnA = cross(rA, normal);
-			float rnB = cross(rB, normal);
-			float kNormal = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
-			float normalMass = kNormal > 0.0f ? 1.0f / kNormal : 0.0f;
-			r.an[j] = make_float4(lA.x, lA.y, lB.x, lB.y);
-			r.r0[j] = make_float4(rA.x, rA.y, rB.x, rB.y);
-			r.par[j] = make_float4(adjustedSeparation, normalMass, tangentMass, separation);
-		}
-	}
-	return r;
-}
+#include "soft_from_wire.h"
 
 // ------------------------------------------------------------------------------------------------
 // Resident island step: the persistent strip step without seams.  An LDS group -- one or several small simulation

@@ -26,6 +26,7 @@
 
 #include "body_ops.h"
 #include "persist_handoff.h"
+#include "soft_from_wire.h"
 
 #ifndef S2_PERSIST_INSTRUMENTED
 #define S2_PERSIST_INSTRUMENTED 0
@@ -1065,8 +1066,258 @@ void launchWideStep(hipStream_t s, const ContactView& c, const BodyView& g, cons
 	}
 }
 
+// ------------------------------------------------------------------------------------------------
+// Resident islands on the same arithmetic (strip_kernel.hip: islandStepKernel<SOFT_TGS, WARM_CURRENT> is the general form): a
+// group of small islands advanced through the whole s2Solve_TGS_Soft by one 512-thread workgroup, bodies in LDS, one WideRegs
+// record per lane and colour round, records prepared from and impulses stored to the wire contacts.  Every lane of a round is
+// busy here (a round holds up to 512 constraints), so prep and chain run back to back in the same lane; what this kernel takes
+// from the strip kernel above is the shorter instruction stream -- the 22-dword record without an unpack step, the coefficient
+// table, the chain on 2-vectors: the island kernel is VALU-issue bound, instructions are its time.
+// ------------------------------------------------------------------------------------------------
+S2_DEV WideRegs wideFromSoft(const SoftRegs<SOFT_TGS>& t)
+{
+	WideRegs p;
+	p.idx = (uint32_t)t.h.ia | ((uint32_t)t.h.ib << 13) | (((uint32_t)t.h.pointCount & 3u) << 26) | (t.h.writeA ? 1u << 28 : 0u) | (t.h.writeB ? 1u << 29 : 0u);
+	p.n = f2{t.h.normal.x, t.h.normal.y}, p.friction = t.h.friction;
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		p.lA[j] = lo2(t.an[j]), p.lB[j] = hi2(t.an[j]);
+		p.p0[j] = t.par[j].x, p.p1[j] = t.par[j].y, p.p2[j] = t.par[j].z;
+		p.imp[j] = f2{t.imp[j].x, t.imp[j].y};
+	}
+	return p;
+}
+
+template <int ROUNDS>
+__global__ __launch_bounds__(S2_WIDE_THREADS) void wideIslandKernel(ContactView c, BodyView g, StripTableView ta, float4 softCoef0, float4 softCoef1, const Op* ops,
+																	 int opCount, s2amdContact* wire, const s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart)
+{
+	extern __shared__ __attribute__((aligned(16))) float4 lds[];
+	const int tid = (int)threadIdx.x;
+	const StripDesc* da = ta.descs + blockIdx.x;
+	const int bodyBase = da->bodyBase, nb = da->bodyCount, roundsA = da->batchCount;
+	int2 batchA[ROUNDS];
+#pragma unroll
+	for (int i = 0; i < ROUNDS; ++i)
+	{
+		batchA[i] = make_int2(da->batch[i].x, da->batch[i].y);
+	}
+	float4* lvel = lds;
+	float4* ldq = lds + nb;
+	float4* linteg = lds + 2 * nb;
+	float* langDamp = (float*)(lds + 3 * nb);
+	float2* lmass = (float2*)(lds + 3 * nb + (nb + 3) / 4);
+	const int bodyRecords = 3 * nb + (nb + 3) / 4 + (nb + 1) / 2;
+	Op* lops = (Op*)(lds + bodyRecords);
+	float4* lcoef = lds + bodyRecords + 2 * opCount; // 2 records (the launch adds them to the size)
+
+	uint32_t id[S2_STRIP_BODY_CHUNKS];
+#pragma unroll
+	for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS; ++ch)
+	{
+		const int i = tid + ch * S2_WIDE_THREADS;
+		id[ch] = i < nb ? (uint32_t)ta.bodyIds[bodyBase + i] : 0u;
+	}
+	for (int i = tid; i < opCount * 8; i += S2_WIDE_THREADS)
+	{
+		((int*)lops)[i] = ((const int*)ops)[i];
+	}
+	if (tid < 2)
+	{
+		lcoef[tid] = tid ? softCoef1 : softCoef0;
+	}
+	auto kOfRound = [&](int i) {
+		const int k = batchA[i].x + tid;
+		return (i < roundsA && k < batchA[i].y) ? k : -1;
+	};
+	// this thread's constraints: pool slot and group-local body slots (the wire records follow once the bodies are staged)
+	int slotOf[ROUNDS];
+	int2 localOf[ROUNDS];
+#pragma unroll
+	for (int i = 0; i < ROUNDS; ++i)
+	{
+		slotOf[i] = -1;
+		localOf[i] = make_int2(0, 0);
+		if (kOfRound(i) >= 0)
+		{
+			slotOf[i] = c.contactIndex[kOfRound(i)];
+			localOf[i] = c.localBodies[kOfRound(i)];
+		}
+	}
+	uint32_t flags[S2_STRIP_BODY_CHUNKS];
+#pragma unroll
+	for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS; ++ch)
+	{
+		const int i = tid + ch * S2_WIDE_THREADS;
+		flags[ch] = 0u;
+		if (i < nb)
+		{
+			const int gi = (int)(id[ch] & ~S2G_OWNED);
+			lvel[i] = g.vel[gi];
+			ldq[i] = g.dq[gi];
+			flags[ch] = g.flags[gi] | 0x80000000u;
+			linteg[i] = g.integ[gi];
+			langDamp[i] = g.angDamp[gi];
+			lmass[i] = g.massInv[gi];
+		}
+	}
+	__syncthreads();
+
+	LdsBodies lb{lvel, ldq};
+	WideRegs rA[ROUNDS];
+#pragma unroll
+	for (int i = 0; i < ROUNDS; ++i)
+	{
+		if (slotOf[i] >= 0)
+		{
+			rA[i] = wideFromSoft(prepareSoftFromWire<SOFT_TGS>(wire + slotOf[i], wireBodies, hostFlags, lb, lmass, localOf[i], g.capacity, warmStart));
+			const bool st = lmass[localOf[i].x].x == 0.0f || lmass[localOf[i].y].x == 0.0f; // the doubled contact hertz of a static side
+			rA[i].idx |= st ? 1u << 30 : 0u;
+		}
+	}
+	for (int oi = 0; oi < opCount; ++oi)
+	{
+		const Op op = lops[oi];
+		uint32_t salt;
+		asm volatile("s_mov_b32 %0, 0" : "=s"(salt));
+		if (op.code == OP_INTEGRATE_VEL)
+		{
+#pragma unroll
+			for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS; ++ch)
+			{
+				if ((flags[ch] & S2F_DYNAMIC) != 0)
+				{
+					const int i = tid + ch * S2_WIDE_THREADS;
+					float4 v = lvel[i], k = linteg[i];
+					V2 lv = add(v2(v.x, v.y), v2(k.x, k.y));
+					float w = v.z + k.z;
+					lv = mulSV(k.w, lv);
+					w *= langDamp[i];
+					lvel[i] = make_float4(lv.x, lv.y, w, 0.0f);
+				}
+			}
+			__syncthreads();
+		}
+		else if (op.code == OP_INTEGRATE_POS)
+		{
+#pragma unroll
+			for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS; ++ch)
+			{
+				if ((flags[ch] & S2F_MOVES) != 0)
+				{
+					const int i = tid + ch * S2_WIDE_THREADS;
+					float4 v = lvel[i], d = ldq[i];
+					V2 dpos = mulAdd(v2(d.x, d.y), op.h, v2(v.x, v.y));
+					Rot q;
+					q.s = d.z, q.c = d.w;
+					q = integrateRot(q, op.h * v.z);
+					ldq[i] = make_float4(dpos.x, dpos.y, q.s, q.c);
+				}
+			}
+			__syncthreads();
+		}
+		else if (op.code == OP_FINALIZE)
+		{
+#pragma unroll
+			for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS; ++ch)
+			{
+				if (flags[ch] != 0u)
+				{
+					finalizePositionsOne(lb, tid + ch * S2_WIDE_THREADS, g, (int)(id[ch] & ~S2G_OWNED), op.flag, (id[ch] & S2G_OWNED) != 0);
+				}
+			}
+			__syncthreads();
+		}
+		else if (op.code == OP_WARM)
+		{
+#pragma unroll
+			for (int i = 0; i < ROUNDS; ++i)
+			{
+				if (i < roundsA)
+				{
+					if (kOfRound(i) >= 0)
+					{
+						warmWide<0>(rA[i], lvel, ldq, lmass, salt);
+					}
+					__syncthreads();
+				}
+			}
+		}
+		else if (op.code == OP_SOLVE_SOFT)
+		{
+#pragma unroll
+			for (int i = 0; i < ROUNDS; ++i)
+			{
+				if (i < roundsA)
+				{
+					if (kOfRound(i) >= 0)
+					{
+						const WidePrep pre = prepWide<0>(rA[i], ldq, lcoef, op.inv_h, op.useBias, salt);
+						chainWide<0>(rA[i], pre, lvel, lmass, lcoef, salt);
+					}
+					__syncthreads();
+				}
+			}
+		}
+	}
+#pragma unroll
+	for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS; ++ch)
+	{
+		const int i = tid + ch * S2_WIDE_THREADS;
+		if (i < nb && (id[ch] & S2G_OWNED) != 0)
+		{
+			const int gi = (int)(id[ch] & ~S2G_OWNED);
+			g.vel[gi] = lvel[i];
+			g.dq[gi] = ldq[i];
+		}
+	}
+	// s2StoreContactImpulses (solve_common.c:396-410): straight into the manifolds
+#pragma unroll
+	for (int i = 0; i < ROUNDS; ++i)
+	{
+		if (slotOf[i] >= 0)
+		{
+			const int pointCount = (int)((rA[i].idx >> 26) & 3u);
+			s2amdContact* contact = wire + slotOf[i];
+#pragma unroll
+			for (int j = 0; j < 2; ++j)
+			{
+				if (j < pointCount)
+				{
+					contact->points[j].normalImpulse = rA[i].imp[j].x;
+					contact->points[j].tangentImpulse = rA[i].imp[j].y;
+				}
+			}
+		}
+	}
+}
+
+// t.ldsRecords: body records of the largest group; maxRounds: colour rounds of the group with the most
+void launchWideIsland(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& t, const float4* softCoef, const Op* ops, int opCount,
+					  int maxRounds, s2amdContact* wire, const s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart)
+{
+	const dim3 grid((unsigned)t.groupCount);
+	const size_t lds = (size_t)(t.ldsRecords + 2) * sizeof(float4) + (size_t)opCount * sizeof(Op);
+	if (maxRounds <= S2_STRIP_ROUNDS)
+	{
+		wideIslandKernel<S2_STRIP_ROUNDS><<<grid, dim3(S2_WIDE_THREADS), lds, s>>>(c, g, t, softCoef[0], softCoef[1], ops, opCount, wire, wireBodies, hostFlags, warmStart);
+	}
+	else
+	{
+		wideIslandKernel<S2_STRIP_ROUNDS_MAX><<<grid, dim3(S2_WIDE_THREADS), lds, s>>>(c, g, t, softCoef[0], softCoef[1], ops, opCount, wire, wireBodies, hostFlags, warmStart);
+	}
+}
+
 int wideKernelSetup()
 {
+	for (const void* f : {(const void*)wideIslandKernel<S2_STRIP_ROUNDS>, (const void*)wideIslandKernel<S2_STRIP_ROUNDS_MAX>})
+	{
+		if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+		{
+			return 1;
+		}
+	}
 	const void* steps[] = {(const void*)wideStepKernel<0, 3, 2>, (const void*)wideStepKernel<2, 3, 2>, (const void*)wideStepKernel<0, 3, 3>,
 						   (const void*)wideStepKernel<2, 3, 3>, (const void*)wideStepKernel<0, 4, 2>, (const void*)wideStepKernel<2, 4, 2>,
 						   (const void*)wideStepKernel<0, 3, 2, 2>, (const void*)wideStepKernel<2, 3, 2, 2>, (const void*)wideStepKernel<0, 4, 2, 2>,

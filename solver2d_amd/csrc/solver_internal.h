@@ -380,6 +380,8 @@ struct s2amdSolver
 	int orderStripBodies = 0; // the strip width the structure was cut with (StructureBuild::stripBodiesFor)
 	bool stripsNeedOneLaunch = false; // a moving read-only body is shared between strips: persistent kernel or no strips at all
 	bool stripsRejected = false; // this graph's strip partition fits no strip kernel: colour batches until the graph changes
+	int stripsJudgedForClass = -1; // the colouring class (0 velocity, 1 position sweeps) the two verdicts were reached under: the other class's writable bodies differ
+	bool stripsHopeless = false; // ... for a reason no other strip width would change (a body the sweeps write that no strip can own): no search
 	int graphAge = 0;		  // steps solved since the constraint graph last changed
 	int optStripPatience = 1; // steps of an unchanged graph before the (more expensive) strip structure is built
 	int stripPatienceNow = 1; // ... as it stands: doubled every time a strip structure died young (noteGraphChanged)
@@ -455,6 +457,7 @@ inline void noteGraphChanged(s2amdSolver* s, bool newWorld = false)
 	}
 	s->graphAge = 0;
 	s->stripsRejected = false;
+	s->stripsHopeless = false;
 	s->residentRejected = false;
 	s->structureDirty = true;
 }

@@ -1862,6 +1862,7 @@ struct StructureBuild
 				if (orphan)
 				{
 					strips = StripPartition();
+					s->stripsHopeless = true; // (whatever the strip width: the search over widths is skipped, solver_structure.cpp: buildStructure)
 					s->stripsRejected = true;
 				}
 			}
@@ -2618,6 +2619,14 @@ int buildStructure(s2amdSolver* s, int solverType)
 	const uint64_t before = s->structureGeneration;
 	// (a world whose partition was searched for once keeps the width that won: a graph that changes is not searched again as
 	// long as that width still gives the persistent kernel something it can run)
+	{
+		const int cls = isPositionSolver(solverType) ? 1 : 0;
+		if (s->stripsJudgedForClass != cls)
+		{
+			s->stripsRejected = s->stripsHopeless = false; // (rejected under the other class's set of writable bodies)
+			s->stripsJudgedForClass = cls;
+		}
+	}
 	if (s->stripScaleFoundFor != StructureBuild::stripBodiesFor(s, solverType))
 	{
 		s->stripScaleFound = 0.0f; // (found for another strip width: SoftStep / PGS_Soft against the rest)
@@ -2656,7 +2665,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 	};
 	const bool triedStrips = s->stripsRejected || s->dStripA.view.groupCount > 0;
 	s->stripRetryPending = false;
-	if (!triedStrips || satisfied() || (s->stripScaleFound > 0.0f && outcome() >= 2))
+	if (!triedStrips || s->stripsHopeless || satisfied() || (s->stripScaleFound > 0.0f && outcome() >= 2))
 	{
 		return rc;
 	}

@@ -150,10 +150,13 @@ def main():
     print("fuzz solves:", n)
     for name, base, opts in (("TGS_Soft", 30, {"groups": 0, "strips": 0}), ("Jacobi", 30, {"groups": 0, "strips": 0}),
                              ("TGS_Soft", 60, {"strip_patience": 2}), ("PGS_NGS_Block", 30, {"groups": 0, "strips": 0, "incremental": 1}),
-                             ("SoftStep", 40, {"strip_patience": 0, "max_group_bodies": 256})):
+                             ("SoftStep", 40, {"strip_patience": 0, "max_group_bodies": 256}),
+                             # the op interpreter's tables (generic_kernel.hip) under a churning graph, with joints nowhere / strips of two levels
+                             ("PGS_NGS_Block", 70, {"strip_patience": 0, "strip_min_bodies": 0}), ("XPBD", 70, {"strip_patience": 1, "strip_min_bodies": 0, "persist_retry": 2})):
         builds = churn(name, base, 6 if quick else 25, opts)
         print("churn %s base %d: %d structure builds" % (name, base, builds))
-    for name, base, opts in (("TGS_Soft", 100, {"strip_patience": 0}), ("SoftStep", 100, {"strip_patience": 1}), ("TGS_Soft", 110, {"strip_patience": 0, "wide": 0, "strip_bodies": 160})):
+    for name, base, opts in (("TGS_Soft", 100, {"strip_patience": 0}), ("SoftStep", 100, {"strip_patience": 1}), ("TGS_Soft", 110, {"strip_patience": 0, "wide": 0, "strip_bodies": 160}),
+                             ("TGS_Soft", 100, {"strip_patience": 0, "persist_debug": 16}), ("PGS", 100, {"strip_patience": 0})):
         builds, placed, persistent = neighbour_churn(name, base, 10 if quick else 40, opts)
         print("neighbour churn %s base %d: %d structure builds, %d contacts placed, persistent %d" % (name, base, builds, placed, persistent))
     world_chain(20 if quick else 60, 3 if quick else 8)

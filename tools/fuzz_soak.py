@@ -8,6 +8,7 @@ import traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from tests import test_fuzz as T  # noqa: E402
+from tests import test_gpu_generic as G  # noqa: E402
 
 
 def main():
@@ -18,7 +19,9 @@ def main():
     for seed in range(first, first + count):
         for name, fn, args in (("groups", T.test_gpu_equals_oracle_on_random_worlds, (seed, 1)), ("global", T.test_gpu_equals_oracle_on_random_worlds, (seed, 0)),
                                ("strips", T.test_gpu_equals_oracle_on_random_worlds_through_strips, (seed, 0)),
-                               ("strips+joints", T.test_gpu_equals_oracle_on_random_worlds_through_strips, (seed, 6))):
+                               ("strips+joints", T.test_gpu_equals_oracle_on_random_worlds_through_strips, (seed, 6)),
+                               ("interpreter", G.test_perturbed_piles_with_joints_through_the_op_interpreter, (seed, 0)),
+                               ("interpreter+joints", G.test_perturbed_piles_with_joints_through_the_op_interpreter, (seed, 30))):
             runs += 1
             try:
                 fn(*args)

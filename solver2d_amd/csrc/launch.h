@@ -154,8 +154,10 @@ void launchPairStep(hipStream_t s, int kind, int warm, const ContactView& c, con
 int wideKernelSetup();
 int wideParkedRecords(int maxRoundsA, int maxSeamRounds, int force);
 // ... and the resident islands' step (strip_kernel.hip: launchIslandStep) for TGS_Soft with the current-anchor warm start
+// selfContained: the kernel also stages its bodies from the wire records and writes them back (no prologue / epilogue launch)
 void launchWideIsland(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& t, const float4* softCoef, const Op* ops, int opCount,
-					  int maxRounds, s2amdContact* wire, const s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart);
+					  int maxRounds, s2amdContact* wire, s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart, const StepConsts& sc, float unpackH,
+					  int selfContained);
 void launchWideStep(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount);
 
 // generic_kernel.hip: the persistent strip step as an op interpreter -- every solver family, joints included

@@ -637,7 +637,9 @@ int s2amd_measure_dominant(s2amdSolver* s, const s2amdStepParams* params, int32_
 		}
 		else if (s->dResident.view.groupCount > 0)
 		{
-			q.runResidentGroups(); // the whole step of the resident islands (islandStepKernel, or the interpreter on the same table)
+			// the whole step of the resident islands (wideIslandKernel / islandStepKernel, or the interpreter on the same table), in the
+			// form the step launches it
+			q.runResidentGroups(q.selfContainedIslands());
 		}
 		else if (s->dGroups.view.groupCount > 0)
 		{
@@ -790,6 +792,10 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	{
 		s->optStripPatience = std::max(0, value);
 		s->stripPatienceNow = s->optStripPatience;
+	}
+	else if (strcmp(key, "self_contained") == 0)
+	{
+		s->optSelfContained = value != 0;
 	}
 	else if (strcmp(key, "free_body_groups") == 0)
 	{

@@ -338,6 +338,7 @@ struct s2amdSolver
 	// import / export lists and hand-off buffers; seams swept once, by their left strip
 	bool genericValid = false;
 	int genericBodies = 0, genericSeamBodies = 0, genericExports = 0; // the most staged bodies / seam-group bodies / exported bodies of a strip (LDS)
+	int optSelfContained = 1; // "self_contained": a world of resident islands only is stepped by their kernel alone (no body prologue / epilogue launch)
 	int optGeneric = 1;
 	int optFreeBodyGroups = 1; // "free_body_groups": constraint-free bodies next to groups / strips form LDS groups instead of global launches
 	int persistK0 = 0, persistK1 = 0; // the strip constraints' range in contacts.order (persist.allTwoPoints is recomputed over it)
@@ -379,6 +380,7 @@ struct s2amdSolver
 	bool orderStrips = false;
 	int orderStripBodies = 0; // the strip width the structure was cut with (StructureBuild::stripBodiesFor)
 	bool stripsNeedOneLaunch = false; // a moving read-only body is shared between strips: persistent kernel or no strips at all
+	bool indexInWire = false; // the resident wire contacts hold the current gather index as manifold.constraintIndex
 	bool stripsRejected = false; // this graph's strip partition fits no strip kernel: colour batches until the graph changes
 	int stripsJudgedForClass = -1; // the colouring class (0 velocity, 1 position sweeps) the two verdicts were reached under: the other class's writable bodies differ
 	bool stripsHopeless = false; // ... for a reason no other strip width would change (a body the sweeps write that no strip can own): no search

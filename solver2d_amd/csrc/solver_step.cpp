@@ -473,12 +473,15 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 			HIP_TRY(hipMemcpyAsync(s->dGatherIndex.p, gi.data(), gi.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
 			HIP_TRY(hipStreamSynchronize(s->stream));
 			s->gatherIndexDirty = false;
+			s->indexInWire = false; // (every upload of contacts marks the gather index dirty: the wire array holds the caller's values again)
 		}
 	}
 
+	// manifold.constraintIndex only changes with the gather index: a resident world that is stepped again keeps what the last
+	// step wrote (1.2 M strided 4-byte stores per step at BASELINE config 5 otherwise)
+	const bool indexNow = writesConstraintIndex && s->contactCapacity > 0 && s->pointsKnown && !s->indexInWire;
 	auto enqueueAll = [&]() {
 		bool indexBranch = false;
-		const bool indexNow = writesConstraintIndex && s->contactCapacity > 0 && s->pointsKnown;
 		q.gatherIndex = (indexNow && !q.fork) ? (const int*)s->dGatherIndex.p : nullptr;
 		if (indexNow && q.fork)
 		{
@@ -504,7 +507,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	{
 		uint64_t key = 1469598103934665603ull;
 		key = fnv(key, params, sizeof(*params));
-		uint64_t gens[4] = {s->layoutGeneration, s->structureGeneration, s->planGeneration, (uint64_t)((q.msg ? 1 : 0) | (s->optBodyWarm ? 2 : 0) | (s->optStripLean ? 4 : 0) | (s->optPersist ? 8 : 0) | (s->optFork ? 16 : 0) | (s->persistFailed ? 32 : 0) | ((s->persistValid && s->persist.allTwoPoints) ? 64 : 0) | (s->pointsKnown ? 128 : 0) | (s->optPairLanes ? 256 : 0) | (s->optWide ? 512 : 0) | (s->optGeneric ? 1024 : 0) | (s->genericValid ? 2048 : 0))};
+		uint64_t gens[4] = {s->layoutGeneration, s->structureGeneration, s->planGeneration, (uint64_t)((q.msg ? 1 : 0) | (s->optBodyWarm ? 2 : 0) | (s->optStripLean ? 4 : 0) | (s->optPersist ? 8 : 0) | (s->optFork ? 16 : 0) | (s->persistFailed ? 32 : 0) | ((s->persistValid && s->persist.allTwoPoints) ? 64 : 0) | (s->pointsKnown ? 128 : 0) | (s->optPairLanes ? 256 : 0) | (s->optWide ? 512 : 0) | (s->optGeneric ? 1024 : 0) | (s->genericValid ? 2048 : 0) | (indexNow ? 4096 : 0) | (s->optSelfContained ? 8192 : 0))};
 		key = fnv(key, gens, sizeof(gens));
 		int sizes[3] = {s->bodyCapacity, s->contactCapacity, s->jointCapacity};
 		key = fnv(key, sizes, sizeof(sizes));
@@ -552,6 +555,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	}
 	HIP_TRY(hipEventRecord(s->evEnd, s->stream));
 	HIP_TRY(hipGetLastError());
+	s->indexInWire = s->indexInWire || indexNow;
 	const bool async = s->optAsync != 0 && !q.profile;
 	if (!async)
 	{

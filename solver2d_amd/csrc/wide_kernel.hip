@@ -1089,9 +1089,13 @@ S2_DEV WideRegs wideFromSoft(const SoftRegs<SOFT_TGS>& t)
 	return p;
 }
 
-template <int ROUNDS>
+// SELF: the kernel is also the step's body prologue and epilogue -- it stages its bodies straight from the wire records (the
+// operations of body_ops.h: unpackBodyOne) and writes the owned ones back (packBodyOne) --, for a world that consists of
+// resident islands only (BASELINE config 5): the step is this one launch.
+template <int ROUNDS, bool SELF>
 __global__ __launch_bounds__(S2_WIDE_THREADS) void wideIslandKernel(ContactView c, BodyView g, StripTableView ta, float4 softCoef0, float4 softCoef1, const Op* ops,
-																	 int opCount, s2amdContact* wire, const s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart)
+																	 int opCount, s2amdContact* wire, s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart,
+																	 StepConsts sc, float unpackH)
 {
 	extern __shared__ __attribute__((aligned(16))) float4 lds[];
 	const int tid = (int)threadIdx.x;
@@ -1146,20 +1150,50 @@ __global__ __launch_bounds__(S2_WIDE_THREADS) void wideIslandKernel(ContactView 
 		}
 	}
 	uint32_t flags[S2_STRIP_BODY_CHUNKS];
+	float2 pos[S2_STRIP_BODY_CHUNKS]; // SELF: the positions of the bodies this lane stages (s2FinalizePositions adds to them)
 #pragma unroll
 	for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS; ++ch)
 	{
 		const int i = tid + ch * S2_WIDE_THREADS;
 		flags[ch] = 0u;
+		pos[ch] = make_float2(0.0f, 0.0f);
 		if (i < nb)
 		{
 			const int gi = (int)(id[ch] & ~S2G_OWNED);
-			lvel[i] = g.vel[gi];
-			ldq[i] = g.dq[gi];
-			flags[ch] = g.flags[gi] | 0x80000000u;
-			linteg[i] = g.integ[gi];
-			langDamp[i] = g.angDamp[gi];
-			lmass[i] = g.massInv[gi];
+			if constexpr (SELF)
+			{
+				// body_ops.h: unpackBodyOne, into LDS instead of the SoA arrays
+				const s2amdBody* w = wireBodies + gi;
+				const int type = w->type;
+				uint32_t f = 0x80000000u;
+				if (type != S2AMD_BODY_FREE)
+				{
+					f |= S2F_LIVE | (type == S2AMD_BODY_DYNAMIC ? S2F_DYNAMIC : 0u) | (type != S2AMD_BODY_STATIC ? S2F_MOVES : 0u);
+				}
+				flags[ch] = f;
+				lvel[i] = make_float4(w->linearVelocity[0], w->linearVelocity[1], w->angularVelocity, 0.0f);
+				ldq[i] = make_float4(w->deltaPosition[0], w->deltaPosition[1], w->rot[0], w->rot[1]);
+				pos[ch] = make_float2(w->position[0], w->position[1]);
+				lmass[i] = make_float2(w->invMass, w->invI);
+				const V2 gravity = v2(sc.gravityX, sc.gravityY);
+				const V2 force = v2(w->force[0], w->force[1]);
+				const V2 inner = mulAdd(force, w->mass * w->gravityScale, gravity);
+				const V2 a = mulSV(unpackH * w->invMass, inner);
+				const float aw = unpackH * w->invI * w->torque;
+				const float ld = 1.0f / (1.0f + unpackH * w->linearDamping);
+				const float ad = 1.0f / (1.0f + unpackH * w->angularDamping);
+				linteg[i] = make_float4(a.x, a.y, aw, ld);
+				langDamp[i] = ad;
+			}
+			else
+			{
+				lvel[i] = g.vel[gi];
+				ldq[i] = g.dq[gi];
+				flags[ch] = g.flags[gi] | 0x80000000u;
+				linteg[i] = g.integ[gi];
+				langDamp[i] = g.angDamp[gi];
+				lmass[i] = g.massInv[gi];
+			}
 		}
 	}
 	__syncthreads();
@@ -1222,7 +1256,19 @@ __global__ __launch_bounds__(S2_WIDE_THREADS) void wideIslandKernel(ContactView 
 #pragma unroll
 			for (int ch = 0; ch < S2_STRIP_BODY_CHUNKS; ++ch)
 			{
-				if (flags[ch] != 0u)
+				if constexpr (SELF)
+				{
+					// s2FinalizePositions (solve_common.c:70-91; body_ops.h: finalizePositionsOne) on the lane's own copy of the position
+					if ((flags[ch] & (op.flag ? S2F_DYNAMIC : S2F_MOVES)) != 0)
+					{
+						const int i = tid + ch * S2_WIDE_THREADS;
+						const float4 d = ldq[i];
+						const V2 np = add(v2(pos[ch].x, pos[ch].y), v2(d.x, d.y));
+						pos[ch] = make_float2(np.x, np.y);
+						ldq[i] = make_float4(0.0f, 0.0f, d.z, d.w);
+					}
+				}
+				else if (flags[ch] != 0u)
 				{
 					finalizePositionsOne(lb, tid + ch * S2_WIDE_THREADS, g, (int)(id[ch] & ~S2G_OWNED), op.flag, (id[ch] & S2G_OWNED) != 0);
 				}
@@ -1268,8 +1314,24 @@ __global__ __launch_bounds__(S2_WIDE_THREADS) void wideIslandKernel(ContactView 
 		if (i < nb && (id[ch] & S2G_OWNED) != 0)
 		{
 			const int gi = (int)(id[ch] & ~S2G_OWNED);
-			g.vel[gi] = lvel[i];
-			g.dq[gi] = ldq[i];
+			if constexpr (SELF)
+			{
+				if ((flags[ch] & S2F_LIVE) != 0) // body_ops.h: packBodyOne
+				{
+					s2amdBody* w = wireBodies + gi;
+					const float4 v = lvel[i], d = ldq[i];
+					w->position[0] = pos[ch].x, w->position[1] = pos[ch].y;
+					w->rot[0] = d.z, w->rot[1] = d.w;
+					w->linearVelocity[0] = v.x, w->linearVelocity[1] = v.y;
+					w->angularVelocity = v.z;
+					w->deltaPosition[0] = d.x, w->deltaPosition[1] = d.y;
+				}
+			}
+			else
+			{
+				g.vel[gi] = lvel[i];
+				g.dq[gi] = ldq[i];
+			}
 		}
 	}
 	// s2StoreContactImpulses (solve_common.c:396-410): straight into the manifolds
@@ -1294,24 +1356,41 @@ __global__ __launch_bounds__(S2_WIDE_THREADS) void wideIslandKernel(ContactView 
 }
 
 // t.ldsRecords: body records of the largest group; maxRounds: colour rounds of the group with the most
+template <int ROUNDS>
+static void launchWideIslandRounds(hipStream_t s, dim3 grid, size_t lds, const ContactView& c, const BodyView& g, const StripTableView& t, const float4* softCoef,
+								   const Op* ops, int opCount, s2amdContact* wire, s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart, const StepConsts& sc,
+								   float unpackH, int selfContained)
+{
+	if (selfContained)
+	{
+		wideIslandKernel<ROUNDS, true><<<grid, dim3(S2_WIDE_THREADS), lds, s>>>(c, g, t, softCoef[0], softCoef[1], ops, opCount, wire, wireBodies, hostFlags, warmStart, sc, unpackH);
+	}
+	else
+	{
+		wideIslandKernel<ROUNDS, false><<<grid, dim3(S2_WIDE_THREADS), lds, s>>>(c, g, t, softCoef[0], softCoef[1], ops, opCount, wire, wireBodies, hostFlags, warmStart, sc, unpackH);
+	}
+}
+
 void launchWideIsland(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& t, const float4* softCoef, const Op* ops, int opCount,
-					  int maxRounds, s2amdContact* wire, const s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart)
+					  int maxRounds, s2amdContact* wire, s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart, const StepConsts& sc, float unpackH,
+					  int selfContained)
 {
 	const dim3 grid((unsigned)t.groupCount);
 	const size_t lds = (size_t)(t.ldsRecords + 2) * sizeof(float4) + (size_t)opCount * sizeof(Op);
 	if (maxRounds <= S2_STRIP_ROUNDS)
 	{
-		wideIslandKernel<S2_STRIP_ROUNDS><<<grid, dim3(S2_WIDE_THREADS), lds, s>>>(c, g, t, softCoef[0], softCoef[1], ops, opCount, wire, wireBodies, hostFlags, warmStart);
+		launchWideIslandRounds<S2_STRIP_ROUNDS>(s, grid, lds, c, g, t, softCoef, ops, opCount, wire, wireBodies, hostFlags, warmStart, sc, unpackH, selfContained);
 	}
 	else
 	{
-		wideIslandKernel<S2_STRIP_ROUNDS_MAX><<<grid, dim3(S2_WIDE_THREADS), lds, s>>>(c, g, t, softCoef[0], softCoef[1], ops, opCount, wire, wireBodies, hostFlags, warmStart);
+		launchWideIslandRounds<S2_STRIP_ROUNDS_MAX>(s, grid, lds, c, g, t, softCoef, ops, opCount, wire, wireBodies, hostFlags, warmStart, sc, unpackH, selfContained);
 	}
 }
 
 int wideKernelSetup()
 {
-	for (const void* f : {(const void*)wideIslandKernel<S2_STRIP_ROUNDS>, (const void*)wideIslandKernel<S2_STRIP_ROUNDS_MAX>})
+	for (const void* f : {(const void*)wideIslandKernel<S2_STRIP_ROUNDS, false>, (const void*)wideIslandKernel<S2_STRIP_ROUNDS_MAX, false>,
+						  (const void*)wideIslandKernel<S2_STRIP_ROUNDS, true>, (const void*)wideIslandKernel<S2_STRIP_ROUNDS_MAX, true>})
 	{
 		if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
 		{

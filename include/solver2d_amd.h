@@ -419,6 +419,8 @@ int s2amd_measure_dominant(s2amdSolver* solver, const s2amdStepParams* params, i
  * "generic" (0/1 every other Gauss-Seidel solver, and any big island with joints, runs its whole step as one launch of the op interpreter over the
  * same strips: generic_kernel.hip; 0 = colour batches for them), "persist_retry" (steps a solver whose persistent launch lost a hand-off stays on the
  * fallback path before the one-launch kernels get another chance -- the wait doubles with every further time-out; default 256, 0 = for ever),
+ * "free_body_groups" (0/1 bodies without any constraint form LDS groups of their own next to groups / strips instead of riding the global path's body launches),
+ * "self_contained" (0/1 a world of resident islands only is stepped by their kernel alone: it stages its bodies from the wire records and writes them back),
  * "pair_lanes" (0/1 that launch solves a constraint with two lanes, one per body: pair_kernel.hip; measured no faster, off by default), "body_warm", "incremental" (0/1 created
  * contacts are placed into the existing structure when they fit; 0 = every created contact rebuilds it), "defer" (0/1 a created
  * contact that cannot be placed and has no manifold points yet is only watched until it gets its first points; 0 = it rebuilds the

@@ -455,9 +455,17 @@ static double wallMs(void)
 	return 1e3 * (double)t.tv_sec + 1e-6 * (double)t.tv_nsec;
 }
 
+// realloc that does not come back empty-handed: the mirrors are as large as the reference's own pools, whose allocator
+// (src/allocate.c) does not survive an exhausted heap either -- fail loudly instead of writing through NULL
 static void* growTo(void* p, size_t count, size_t size)
 {
-	return realloc(p, (count > 0 ? count : 1) * size);
+	void* q = realloc(p, (count > 0 ? count : 1) * size);
+	if (q == NULL)
+	{
+		fprintf(stderr, "s2amd binding: out of memory (%zu x %zu bytes)\n", count, size);
+		abort();
+	}
+	return q;
 }
 
 int s2amdBinding_Open(const char* libraryPath, int device)
@@ -1046,13 +1054,13 @@ void s2amdBinding_OrderPairs(s2World* world, const int* moveArray, int moveCount
 	if (moveIndexCapacity < world->shapePool.capacity)
 	{
 		moveIndexCapacity = world->shapePool.capacity;
-		moveIndexOfShape = (int32_t*)realloc(moveIndexOfShape, (size_t)moveIndexCapacity * sizeof(int32_t));
+		moveIndexOfShape = (int32_t*)growTo(moveIndexOfShape, (size_t)moveIndexCapacity, sizeof(int32_t));
 		memset(moveIndexOfShape, 0xff, (size_t)moveIndexCapacity * sizeof(int32_t));
 	}
 	if (orderedCapacity < count)
 	{
 		orderedCapacity = count + 1024;
-		ordered = (OrderedPair*)realloc(ordered, (size_t)orderedCapacity * sizeof(OrderedPair));
+		ordered = (OrderedPair*)growTo(ordered, (size_t)orderedCapacity, sizeof(OrderedPair));
 	}
 	for (int i = 0; i < moveCount; ++i)
 	{
@@ -1128,7 +1136,7 @@ void s2amdBinding_WorldStep(s2World* world, float timeStep, int velIters, int po
 			if (rc == S2AMD_E_CAPACITY)
 			{
 				b->newPairCapacity = count + 1024;
-				b->newPairs = (int32_t*)realloc(b->newPairs, (size_t)b->newPairCapacity * 2 * sizeof(int32_t));
+				b->newPairs = (int32_t*)growTo(b->newPairs, (size_t)b->newPairCapacity * 2, sizeof(int32_t));
 				rc = s_api.worldFindPairs(b->solver, b->newPairs, b->newPairCapacity, &count);
 			}
 			if (rc == 0 && count > 0)
@@ -1145,7 +1153,7 @@ void s2amdBinding_WorldStep(s2World* world, float timeStep, int velIters, int po
 			if (b->createdCapacity < count)
 			{
 				b->createdCapacity = count + 1024;
-				b->createdSlots = (int32_t*)realloc(b->createdSlots, (size_t)b->createdCapacity * sizeof(int32_t));
+				b->createdSlots = (int32_t*)growTo(b->createdSlots, (size_t)b->createdCapacity, sizeof(int32_t));
 			}
 			b->createdCount = 0;
 			for (int i = 0; rc == 0 && i < count; ++i)

@@ -140,7 +140,8 @@ void launchWarmStartBodies(hipStream_t s, int kind, const ContactView& c, const 
 // strip_kernel.hip
 int stripKernelSetup();
 void launchIslandStep(hipStream_t s, int kind, int warm, const ContactView& c, const BodyView& g, const StripTableView& t, const float4* softCoef, const Op* ops,
-					  int opCount, int maxRounds, s2amdContact* wire, const s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart);
+					  int opCount, int maxRounds, s2amdContact* wire, const s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart,
+					  const unsigned int* stepFailed);
 void launchStripSoft(hipStream_t s, int kind, int warm, const ContactView& c, const BodyView& g, const StripTableView& t, const StripOps& ops);
 void launchStripStep(hipStream_t s, int kind, int warm, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv,
 					 const Op* ops, int opCount);
@@ -157,7 +158,7 @@ int wideParkedRecords(int maxRoundsA, int maxSeamRounds, int force);
 // selfContained: the kernel also stages its bodies from the wire records and writes them back (no prologue / epilogue launch)
 void launchWideIsland(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& t, const float4* softCoef, const Op* ops, int opCount,
 					  int maxRounds, s2amdContact* wire, s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart, const StepConsts& sc, float unpackH,
-					  int selfContained);
+					  int selfContained, const unsigned int* stepFailed);
 void launchWideStep(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount);
 
 // generic_kernel.hip: the persistent strip step as an op interpreter -- every solver family, joints included

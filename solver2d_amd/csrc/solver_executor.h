@@ -533,6 +533,9 @@ struct Executor
 		{
 			return;
 		}
+		// these kernels write their impulses straight into the wire contacts: behind a persistent strip launch of the same step (run()
+		// enqueues the strips first) they stand down when that launch lost a hand-off, so that the repeated step starts from an untouched world
+		const unsigned int* stepFailed = (s->dStripA.view.groupCount > 0 && oneLaunchPlan()) ? s->persist.deviceError : nullptr;
 		int kind, warm;
 		if (residentPlan(kind, warm))
 		{
@@ -545,12 +548,12 @@ struct Executor
 			if (wideIslandPlan())
 			{
 				launchWideIsland(st, s->cv, s->bv, s->residentView, coef, (const Op*)s->dResidentOps.p, s->residentOpCount, s->residentRounds, wireContacts(),
-								 wireBodies(), (const uint32_t*)s->dBodyFlags.p, p.sc.warmStart, p.sc, p.unpackH, selfContained ? 1 : 0);
+								 wireBodies(), (const uint32_t*)s->dBodyFlags.p, p.sc.warmStart, p.sc, p.unpackH, selfContained ? 1 : 0, stepFailed);
 			}
 			else
 			{
 				launchIslandStep(st, kind, warm, s->cv, s->bv, s->residentView, coef, (const Op*)s->dResidentOps.p, s->residentOpCount, s->residentRounds,
-								 wireContacts(), wireBodies(), (const uint32_t*)s->dBodyFlags.p, p.sc.warmStart);
+								 wireContacts(), wireBodies(), (const uint32_t*)s->dBodyFlags.p, p.sc.warmStart, stepFailed);
 			}
 		}
 		else
@@ -799,11 +802,11 @@ struct Executor
 							  p.usesDq0 ? 1 : 0);
 			count();
 		}
-		runResidentGroups();
 		if (s->dStripA.view.groupCount > 0)
 		{
 			runStrips();
 		}
+		runResidentGroups();
 		// global part: op by op
 		int fusedFinalize = -1; // >= 0: the dynamicOnly flag of the s2FinalizePositions the epilogue launch performs
 		const bool anyGlobal = s->looseBodies > 0 || anyGlobalContacts() || s->joints.globalCount > 0;

@@ -956,9 +956,14 @@ __global__ __launch_bounds__(S2_STRIP_THREADS) void stripStepKernel(ContactView 
 // the impulses go back into them (s2StoreContactImpulses, solve_common.c:396-410) -- no SoA round trip at all.
 template <int KIND, int WARM, int ROUNDS, int THREADS>
 __global__ __launch_bounds__(THREADS) void islandStepKernel(ContactView c, BodyView g, StripTableView ta, float4 softCoef0, float4 softCoef1, const Op* ops,
-															 int opCount, s2amdContact* wire, const s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart)
+															 int opCount, s2amdContact* wire, const s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart,
+															 const unsigned int* stepFailed)
 {
 	extern __shared__ __attribute__((aligned(16))) float4 lds[];
+	if (stepFailed != nullptr && *stepFailed != 0u)
+	{
+		return; // a persistent strip kernel of this step lost a hand-off: the step will be repeated, nothing of it may reach the wire arrays
+	}
 	const int tid = (int)threadIdx.x;
 	const StripDesc* da = ta.descs + blockIdx.x;
 	const int bodyBase = da->bodyBase, nb = da->bodyCount, roundsA = da->batchCount;
@@ -1157,23 +1162,23 @@ __global__ __launch_bounds__(THREADS) void islandStepKernel(ContactView c, BodyV
 #define S2_ISLAND_THREADS 512
 template <int KIND, int WARM>
 static void launchIsland(hipStream_t s, dim3 grid, size_t lds, const ContactView& c, const BodyView& g, const StripTableView& t, const float4* coef, const Op* ops,
-						 int opCount, int rounds, s2amdContact* wire, const s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart)
+						 int opCount, int rounds, s2amdContact* wire, const s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart, const unsigned int* stepFailed)
 {
 	if (rounds <= S2_STRIP_ROUNDS)
 	{
 		islandStepKernel<KIND, WARM, S2_STRIP_ROUNDS, S2_ISLAND_THREADS>
-			<<<grid, dim3(S2_ISLAND_THREADS), lds, s>>>(c, g, t, coef[0], coef[1], ops, opCount, wire, wireBodies, hostFlags, warmStart);
+			<<<grid, dim3(S2_ISLAND_THREADS), lds, s>>>(c, g, t, coef[0], coef[1], ops, opCount, wire, wireBodies, hostFlags, warmStart, stepFailed);
 	}
 	else
 	{
 		islandStepKernel<KIND, WARM, S2_STRIP_ROUNDS_MAX, S2_ISLAND_THREADS>
-			<<<grid, dim3(S2_ISLAND_THREADS), lds, s>>>(c, g, t, coef[0], coef[1], ops, opCount, wire, wireBodies, hostFlags, warmStart);
+			<<<grid, dim3(S2_ISLAND_THREADS), lds, s>>>(c, g, t, coef[0], coef[1], ops, opCount, wire, wireBodies, hostFlags, warmStart, stepFailed);
 	}
 }
 
 // t.ldsRecords: body records of the largest group; maxRounds: colour rounds of the group with the most
 void launchIslandStep(hipStream_t s, int kind, int warm, const ContactView& c, const BodyView& g, const StripTableView& t, const float4* softCoef, const Op* ops,
-					  int opCount, int maxRounds, s2amdContact* wire, const s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart)
+					  int opCount, int maxRounds, s2amdContact* wire, const s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart, const unsigned int* stepFailed)
 {
 	if (t.groupCount <= 0)
 	{
@@ -1183,18 +1188,18 @@ void launchIslandStep(hipStream_t s, int kind, int warm, const ContactView& c, c
 	size_t lds = (size_t)t.ldsRecords * sizeof(float4) + (size_t)opCount * sizeof(Op);
 	if (kind == SOFT_TGS)
 	{
-		warm == WARM_FIXED ? launchIsland<SOFT_TGS, WARM_FIXED>(s, grid, lds, c, g, t, softCoef, ops, opCount, maxRounds, wire, wireBodies, hostFlags, warmStart)
-						   : launchIsland<SOFT_TGS, WARM_CURRENT>(s, grid, lds, c, g, t, softCoef, ops, opCount, maxRounds, wire, wireBodies, hostFlags, warmStart);
+		warm == WARM_FIXED ? launchIsland<SOFT_TGS, WARM_FIXED>(s, grid, lds, c, g, t, softCoef, ops, opCount, maxRounds, wire, wireBodies, hostFlags, warmStart, stepFailed)
+						   : launchIsland<SOFT_TGS, WARM_CURRENT>(s, grid, lds, c, g, t, softCoef, ops, opCount, maxRounds, wire, wireBodies, hostFlags, warmStart, stepFailed);
 	}
 	else if (kind == SOFT_PGS)
 	{
-		warm == WARM_FIXED ? launchIsland<SOFT_PGS, WARM_FIXED>(s, grid, lds, c, g, t, softCoef, ops, opCount, maxRounds, wire, wireBodies, hostFlags, warmStart)
-						   : launchIsland<SOFT_PGS, WARM_CURRENT>(s, grid, lds, c, g, t, softCoef, ops, opCount, maxRounds, wire, wireBodies, hostFlags, warmStart);
+		warm == WARM_FIXED ? launchIsland<SOFT_PGS, WARM_FIXED>(s, grid, lds, c, g, t, softCoef, ops, opCount, maxRounds, wire, wireBodies, hostFlags, warmStart, stepFailed)
+						   : launchIsland<SOFT_PGS, WARM_CURRENT>(s, grid, lds, c, g, t, softCoef, ops, opCount, maxRounds, wire, wireBodies, hostFlags, warmStart, stepFailed);
 	}
 	else
 	{
-		warm == WARM_FIXED ? launchIsland<SOFT_FIXED, WARM_FIXED>(s, grid, lds, c, g, t, softCoef, ops, opCount, maxRounds, wire, wireBodies, hostFlags, warmStart)
-						   : launchIsland<SOFT_FIXED, WARM_CURRENT>(s, grid, lds, c, g, t, softCoef, ops, opCount, maxRounds, wire, wireBodies, hostFlags, warmStart);
+		warm == WARM_FIXED ? launchIsland<SOFT_FIXED, WARM_FIXED>(s, grid, lds, c, g, t, softCoef, ops, opCount, maxRounds, wire, wireBodies, hostFlags, warmStart, stepFailed)
+						   : launchIsland<SOFT_FIXED, WARM_CURRENT>(s, grid, lds, c, g, t, softCoef, ops, opCount, maxRounds, wire, wireBodies, hostFlags, warmStart, stepFailed);
 	}
 }
 

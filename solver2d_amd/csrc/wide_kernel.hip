@@ -1095,9 +1095,13 @@ S2_DEV WideRegs wideFromSoft(const SoftRegs<SOFT_TGS>& t)
 template <int ROUNDS, bool SELF>
 __global__ __launch_bounds__(S2_WIDE_THREADS) void wideIslandKernel(ContactView c, BodyView g, StripTableView ta, float4 softCoef0, float4 softCoef1, const Op* ops,
 																	 int opCount, s2amdContact* wire, s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart,
-																	 StepConsts sc, float unpackH)
+																	 StepConsts sc, float unpackH, const unsigned int* stepFailed)
 {
 	extern __shared__ __attribute__((aligned(16))) float4 lds[];
+	if (stepFailed != nullptr && *stepFailed != 0u)
+	{
+		return; // a persistent strip kernel of this step lost a hand-off: the step will be repeated, nothing of it may reach the wire arrays
+	}
 	const int tid = (int)threadIdx.x;
 	const StripDesc* da = ta.descs + blockIdx.x;
 	const int bodyBase = da->bodyBase, nb = da->bodyCount, roundsA = da->batchCount;
@@ -1359,31 +1363,31 @@ __global__ __launch_bounds__(S2_WIDE_THREADS) void wideIslandKernel(ContactView 
 template <int ROUNDS>
 static void launchWideIslandRounds(hipStream_t s, dim3 grid, size_t lds, const ContactView& c, const BodyView& g, const StripTableView& t, const float4* softCoef,
 								   const Op* ops, int opCount, s2amdContact* wire, s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart, const StepConsts& sc,
-								   float unpackH, int selfContained)
+								   float unpackH, int selfContained, const unsigned int* stepFailed)
 {
 	if (selfContained)
 	{
-		wideIslandKernel<ROUNDS, true><<<grid, dim3(S2_WIDE_THREADS), lds, s>>>(c, g, t, softCoef[0], softCoef[1], ops, opCount, wire, wireBodies, hostFlags, warmStart, sc, unpackH);
+		wideIslandKernel<ROUNDS, true><<<grid, dim3(S2_WIDE_THREADS), lds, s>>>(c, g, t, softCoef[0], softCoef[1], ops, opCount, wire, wireBodies, hostFlags, warmStart, sc, unpackH, stepFailed);
 	}
 	else
 	{
-		wideIslandKernel<ROUNDS, false><<<grid, dim3(S2_WIDE_THREADS), lds, s>>>(c, g, t, softCoef[0], softCoef[1], ops, opCount, wire, wireBodies, hostFlags, warmStart, sc, unpackH);
+		wideIslandKernel<ROUNDS, false><<<grid, dim3(S2_WIDE_THREADS), lds, s>>>(c, g, t, softCoef[0], softCoef[1], ops, opCount, wire, wireBodies, hostFlags, warmStart, sc, unpackH, stepFailed);
 	}
 }
 
 void launchWideIsland(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& t, const float4* softCoef, const Op* ops, int opCount,
 					  int maxRounds, s2amdContact* wire, s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart, const StepConsts& sc, float unpackH,
-					  int selfContained)
+					  int selfContained, const unsigned int* stepFailed)
 {
 	const dim3 grid((unsigned)t.groupCount);
 	const size_t lds = (size_t)(t.ldsRecords + 2) * sizeof(float4) + (size_t)opCount * sizeof(Op);
 	if (maxRounds <= S2_STRIP_ROUNDS)
 	{
-		launchWideIslandRounds<S2_STRIP_ROUNDS>(s, grid, lds, c, g, t, softCoef, ops, opCount, wire, wireBodies, hostFlags, warmStart, sc, unpackH, selfContained);
+		launchWideIslandRounds<S2_STRIP_ROUNDS>(s, grid, lds, c, g, t, softCoef, ops, opCount, wire, wireBodies, hostFlags, warmStart, sc, unpackH, selfContained, stepFailed);
 	}
 	else
 	{
-		launchWideIslandRounds<S2_STRIP_ROUNDS_MAX>(s, grid, lds, c, g, t, softCoef, ops, opCount, wire, wireBodies, hostFlags, warmStart, sc, unpackH, selfContained);
+		launchWideIslandRounds<S2_STRIP_ROUNDS_MAX>(s, grid, lds, c, g, t, softCoef, ops, opCount, wire, wireBodies, hostFlags, warmStart, sc, unpackH, selfContained, stepFailed);
 	}
 }
 

@@ -449,6 +449,35 @@ def test_a_solver_that_lost_a_hand_off_tries_the_persistent_kernel_again_later(s
         assert seen[-1] == 1 and 0 in seen and s.stats()["persistFallbacks"] == 2, seen
 
 
+def test_a_dead_hand_off_next_to_resident_islands_leaves_their_contacts_alone():
+    """The resident-island kernels write their impulses (and, alone in a world, their bodies) straight into the wire arrays.  Next to a
+    big island whose persistent launch loses a hand-off they must stand down too, or the repeated step would warm-start from
+    impulses of the dropped one: strips are enqueued first, the island kernels read the failed-step word."""
+    big = synthetic.pyramid(100)
+    small = synthetic.pyramid(12, count=6)
+    shift = len(big[0])
+    sb, sc, sj = common.copy3(small)
+    sb["position"][:, 0] += 400.0
+    live = sc["bodyA"] >= 0
+    sc["bodyA"][live] += shift
+    sc["bodyB"][live] += shift
+    pre = (np.concatenate([big[0], sb]), np.concatenate([big[1], sc]), np.concatenate([big[2], sj]))
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
+        s.set_option("persist_spin_limit", 4096)
+        s.set_option("persist_debug", 8)
+        state = gpu_vs_oracle(s, params, pre, "dead hand-off next to resident islands, step 0")
+        st = s.stats()
+        assert st["persistFallbacks"] == 1 and st["stripCount"] > 0 and st["groupCount"] > 0, st
+        gpu_vs_oracle(s, params, state, "dead hand-off next to resident islands, step 1")
+    with hip.Solver(0) as s:  # and without the fault: both kinds of island in their one-launch kernels
+        s.set_option("strip_patience", 0)
+        state = gpu_vs_oracle(s, params, pre, "big island + resident islands")
+        st = s.stats()
+        assert st["persistent"] == 1 and st["groupCount"] > 0 and st["kernelLaunches"] <= 5, st
+
+
 def test_a_dead_hand_off_under_async_is_reported_and_the_solver_recovers():
     """The same fault with option "async": steps are enqueued without a host sync, the failure surfaces at
     s2amd_synchronize.  Contract: the call fails with a device error, the resident world stands where it stood before the

@@ -158,7 +158,7 @@ int wideParkedRecords(int maxRoundsA, int maxSeamRounds, int force);
 // selfContained: the kernel also stages its bodies from the wire records and writes them back (no prologue / epilogue launch)
 void launchWideIsland(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& t, const float4* softCoef, const Op* ops, int opCount,
 					  int maxRounds, s2amdContact* wire, s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart, const StepConsts& sc, float unpackH,
-					  int selfContained, const unsigned int* stepFailed);
+					  int selfContained, const unsigned int* stepFailed, int allTwoPoints);
 void launchWideStep(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount);
 
 // generic_kernel.hip: the persistent strip step as an op interpreter -- every solver family, joints included

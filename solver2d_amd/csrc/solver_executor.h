@@ -444,6 +444,14 @@ struct Executor
 		{
 			return false;
 		}
+		// The island kernels write their impulses straight into the wire contacts.  In a step that also holds a persistent strip
+		// launch -- which may lose a hand-off, whereupon the step is repeated from untouched wire arrays -- the groups run on the group
+		// interpreter instead (SoA arrays; the epilogue, which stands down after a failure, carries the results over).  They must run
+		// BEFORE the strips either way: a strip may own a kinematic body that an island reads, and writes it back at its end.
+		if (s->dStripA.view.groupCount > 0 && oneLaunchPlan())
+		{
+			return false;
+		}
 		for (const Op& o : p.ops)
 		{
 			if (o.code == OP_INTEGRATE_VEL || o.code == OP_INTEGRATE_POS || o.code == OP_FINALIZE || o.code == OP_JOINT_SWEEP)
@@ -533,9 +541,7 @@ struct Executor
 		{
 			return;
 		}
-		// these kernels write their impulses straight into the wire contacts: behind a persistent strip launch of the same step (run()
-		// enqueues the strips first) they stand down when that launch lost a hand-off, so that the repeated step starts from an untouched world
-		const unsigned int* stepFailed = (s->dStripA.view.groupCount > 0 && oneLaunchPlan()) ? s->persist.deviceError : nullptr;
+		const unsigned int* stepFailed = nullptr; // (see residentPlan: these kernels never share a step with a launch that can fail)
 		int kind, warm;
 		if (residentPlan(kind, warm))
 		{
@@ -548,7 +554,8 @@ struct Executor
 			if (wideIslandPlan())
 			{
 				launchWideIsland(st, s->cv, s->bv, s->residentView, coef, (const Op*)s->dResidentOps.p, s->residentOpCount, s->residentRounds, wireContacts(),
-								 wireBodies(), (const uint32_t*)s->dBodyFlags.p, p.sc.warmStart, p.sc, p.unpackH, selfContained ? 1 : 0, stepFailed);
+								 wireBodies(), (const uint32_t*)s->dBodyFlags.p, p.sc.warmStart, p.sc, p.unpackH, selfContained ? 1 : 0, stepFailed,
+								 (s->residentAllTwoPoints && s->pointsKnown) ? 1 : 0); // (manifolds recomputed on the device: any point count)
 			}
 			else
 			{
@@ -802,11 +809,11 @@ struct Executor
 							  p.usesDq0 ? 1 : 0);
 			count();
 		}
+		runResidentGroups();
 		if (s->dStripA.view.groupCount > 0)
 		{
 			runStrips();
 		}
-		runResidentGroups();
 		// global part: op by op
 		int fusedFinalize = -1; // >= 0: the dynamicOnly flag of the s2FinalizePositions the epilogue launch performs
 		const bool anyGlobal = s->looseBodies > 0 || anyGlobalContacts() || s->joints.globalCount > 0;

@@ -338,6 +338,7 @@ struct s2amdSolver
 	// import / export lists and hand-off buffers; seams swept once, by their left strip
 	bool genericValid = false;
 	int genericBodies = 0, genericSeamBodies = 0, genericExports = 0; // the most staged bodies / seam-group bodies / exported bodies of a strip (LDS)
+	int residentAllTwoPoints = 0; // every constraint of the resident islands has two manifold points (wide_kernel.hip: the POINTS == 2 variants)
 	int optSelfContained = 1; // "self_contained": a world of resident islands only is stepped by their kernel alone (no body prologue / epilogue launch)
 	int optGeneric = 1;
 	int optFreeBodyGroups = 1; // "free_body_groups": constraint-free bodies next to groups / strips form LDS groups instead of global launches
@@ -474,6 +475,7 @@ inline void noteGraphTouched(s2amdSolver* s)
 StepConsts makeConsts(const s2amdStepParams* p);
 int carveBodies(s2amdSolver* s, int n); // (re)carves the body SoA family for n slots
 bool stripsAllTwoPoints(const s2amdSolver* s);
+bool residentAllTwoPoints(const s2amdSolver* s);
 int buildStructure(s2amdSolver* s, int solverType);
 void buildPlan(s2amdSolver* s, const s2amdStepParams* params);
 bool messageEligible(const s2amdSolver* s, int solverType);

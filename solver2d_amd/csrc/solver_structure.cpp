@@ -65,6 +65,22 @@ bool stripsAllTwoPoints(const s2amdSolver* s)
 	return true;
 }
 
+bool residentAllTwoPoints(const s2amdSolver* s)
+{
+	if (!s->pointsKnown || s->residentK1 <= s->residentK0)
+	{
+		return false;
+	}
+	for (int k = s->residentK0; k < s->residentK1; ++k)
+	{
+		if (s->contacts.order[(size_t)k] >= 0 && s->hContactPoints[(size_t)s->contacts.order[(size_t)k]] != 2)
+		{
+			return false;
+		}
+	}
+	return true;
+}
+
 int carveBodies(s2amdSolver* s, int n)
 {
 	int rc = growFamily(s, s->soaBodies, s->bodySoaCap, n, kBodySlotBytes, 9);
@@ -2565,6 +2581,7 @@ struct StructureBuild
 					cs.globalCount, real, (int)cs.batchOffsets.size() - 1, cs.hasTail ? ", tail" : "", js.globalCount, s->hGroups.count(), s->hResident.count(),
 					s->hStripA.count(), s->looseBodies);
 		}
+		s->residentAllTwoPoints = residentAllTwoPoints(s) ? 1 : 0;
 		s->orderStrips = wantStrips;
 		s->orderStripBodies = stripBodiesFor(s, solverType);
 		s->structureDirty = false;

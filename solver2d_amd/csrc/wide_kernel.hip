@@ -1092,7 +1092,8 @@ S2_DEV WideRegs wideFromSoft(const SoftRegs<SOFT_TGS>& t)
 // SELF: the kernel is also the step's body prologue and epilogue -- it stages its bodies straight from the wire records (the
 // operations of body_ops.h: unpackBodyOne) and writes the owned ones back (packBodyOne) --, for a world that consists of
 // resident islands only (BASELINE config 5): the step is this one launch.
-template <int ROUNDS, bool SELF>
+// POINTS == 2: the host has checked that every constraint of the islands has two manifold points (no per-point masking: 356 against 383 us at config 5).
+template <int ROUNDS, bool SELF, int POINTS>
 __global__ __launch_bounds__(S2_WIDE_THREADS) void wideIslandKernel(ContactView c, BodyView g, StripTableView ta, float4 softCoef0, float4 softCoef1, const Op* ops,
 																	 int opCount, s2amdContact* wire, s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart,
 																	 StepConsts sc, float unpackH, const unsigned int* stepFailed)
@@ -1288,7 +1289,7 @@ __global__ __launch_bounds__(S2_WIDE_THREADS) void wideIslandKernel(ContactView 
 				{
 					if (kOfRound(i) >= 0)
 					{
-						warmWide<0>(rA[i], lvel, ldq, lmass, salt);
+						warmWide<POINTS>(rA[i], lvel, ldq, lmass, salt);
 					}
 					__syncthreads();
 				}
@@ -1303,8 +1304,8 @@ __global__ __launch_bounds__(S2_WIDE_THREADS) void wideIslandKernel(ContactView 
 				{
 					if (kOfRound(i) >= 0)
 					{
-						const WidePrep pre = prepWide<0>(rA[i], ldq, lcoef, op.inv_h, op.useBias, salt);
-						chainWide<0>(rA[i], pre, lvel, lmass, lcoef, salt);
+						const WidePrep pre = prepWide<POINTS>(rA[i], ldq, lcoef, op.inv_h, op.useBias, salt);
+						chainWide<POINTS>(rA[i], pre, lvel, lmass, lcoef, salt);
 					}
 					__syncthreads();
 				}
@@ -1363,38 +1364,55 @@ __global__ __launch_bounds__(S2_WIDE_THREADS) void wideIslandKernel(ContactView 
 template <int ROUNDS>
 static void launchWideIslandRounds(hipStream_t s, dim3 grid, size_t lds, const ContactView& c, const BodyView& g, const StripTableView& t, const float4* softCoef,
 								   const Op* ops, int opCount, s2amdContact* wire, s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart, const StepConsts& sc,
-								   float unpackH, int selfContained, const unsigned int* stepFailed)
+								   float unpackH, int selfContained, const unsigned int* stepFailed, int allTwoPoints)
 {
+#define S2_LAUNCH_ISLAND(SELF, POINTS)                                                                                                                        \
+	wideIslandKernel<ROUNDS, SELF, POINTS>                                                                                                                    \
+		<<<grid, dim3(S2_WIDE_THREADS), lds, s>>>(c, g, t, softCoef[0], softCoef[1], ops, opCount, wire, wireBodies, hostFlags, warmStart, sc, unpackH, stepFailed)
 	if (selfContained)
 	{
-		wideIslandKernel<ROUNDS, true><<<grid, dim3(S2_WIDE_THREADS), lds, s>>>(c, g, t, softCoef[0], softCoef[1], ops, opCount, wire, wireBodies, hostFlags, warmStart, sc, unpackH, stepFailed);
+		if (allTwoPoints)
+		{
+			S2_LAUNCH_ISLAND(true, 2);
+		}
+		else
+		{
+			S2_LAUNCH_ISLAND(true, 0);
+		}
+	}
+	else if (allTwoPoints)
+	{
+		S2_LAUNCH_ISLAND(false, 2);
 	}
 	else
 	{
-		wideIslandKernel<ROUNDS, false><<<grid, dim3(S2_WIDE_THREADS), lds, s>>>(c, g, t, softCoef[0], softCoef[1], ops, opCount, wire, wireBodies, hostFlags, warmStart, sc, unpackH, stepFailed);
+		S2_LAUNCH_ISLAND(false, 0);
 	}
+#undef S2_LAUNCH_ISLAND
 }
 
 void launchWideIsland(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& t, const float4* softCoef, const Op* ops, int opCount,
 					  int maxRounds, s2amdContact* wire, s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart, const StepConsts& sc, float unpackH,
-					  int selfContained, const unsigned int* stepFailed)
+					  int selfContained, const unsigned int* stepFailed, int allTwoPoints)
 {
 	const dim3 grid((unsigned)t.groupCount);
 	const size_t lds = (size_t)(t.ldsRecords + 2) * sizeof(float4) + (size_t)opCount * sizeof(Op);
 	if (maxRounds <= S2_STRIP_ROUNDS)
 	{
-		launchWideIslandRounds<S2_STRIP_ROUNDS>(s, grid, lds, c, g, t, softCoef, ops, opCount, wire, wireBodies, hostFlags, warmStart, sc, unpackH, selfContained, stepFailed);
+		launchWideIslandRounds<S2_STRIP_ROUNDS>(s, grid, lds, c, g, t, softCoef, ops, opCount, wire, wireBodies, hostFlags, warmStart, sc, unpackH, selfContained, stepFailed, allTwoPoints);
 	}
 	else
 	{
-		launchWideIslandRounds<S2_STRIP_ROUNDS_MAX>(s, grid, lds, c, g, t, softCoef, ops, opCount, wire, wireBodies, hostFlags, warmStart, sc, unpackH, selfContained, stepFailed);
+		launchWideIslandRounds<S2_STRIP_ROUNDS_MAX>(s, grid, lds, c, g, t, softCoef, ops, opCount, wire, wireBodies, hostFlags, warmStart, sc, unpackH, selfContained, stepFailed, allTwoPoints);
 	}
 }
 
 int wideKernelSetup()
 {
-	for (const void* f : {(const void*)wideIslandKernel<S2_STRIP_ROUNDS, false>, (const void*)wideIslandKernel<S2_STRIP_ROUNDS_MAX, false>,
-						  (const void*)wideIslandKernel<S2_STRIP_ROUNDS, true>, (const void*)wideIslandKernel<S2_STRIP_ROUNDS_MAX, true>})
+	for (const void* f : {(const void*)wideIslandKernel<S2_STRIP_ROUNDS, false, 0>, (const void*)wideIslandKernel<S2_STRIP_ROUNDS_MAX, false, 0>,
+						  (const void*)wideIslandKernel<S2_STRIP_ROUNDS, true, 0>, (const void*)wideIslandKernel<S2_STRIP_ROUNDS_MAX, true, 0>,
+						  (const void*)wideIslandKernel<S2_STRIP_ROUNDS, false, 2>, (const void*)wideIslandKernel<S2_STRIP_ROUNDS_MAX, false, 2>,
+						  (const void*)wideIslandKernel<S2_STRIP_ROUNDS, true, 2>, (const void*)wideIslandKernel<S2_STRIP_ROUNDS_MAX, true, 2>})
 	{
 		if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
 		{

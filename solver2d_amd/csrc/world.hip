@@ -909,6 +909,7 @@ int s2amd_world_set_contacts(s2amdSolver* s, const int32_t* slots, int32_t count
 		{
 			s->persist.allTwoPoints = stripsAllTwoPoints(s) ? 1 : 0;
 		}
+		s->residentAllTwoPoints = residentAllTwoPoints(s) ? 1 : 0;
 	}
 	s->gatherIndexDirty = true;
 	return S2AMD_OK;

@@ -450,9 +450,11 @@ def test_a_solver_that_lost_a_hand_off_tries_the_persistent_kernel_again_later(s
 
 
 def test_a_dead_hand_off_next_to_resident_islands_leaves_their_contacts_alone():
-    """The resident-island kernels write their impulses (and, alone in a world, their bodies) straight into the wire arrays.  Next to a
-    big island whose persistent launch loses a hand-off they must stand down too, or the repeated step would warm-start from
-    impulses of the dropped one: strips are enqueued first, the island kernels read the failed-step word."""
+    """The resident-island kernels write their impulses (and, alone in a world, their bodies) straight into the wire arrays.  In a
+    step that also holds a persistent strip launch -- which may lose a hand-off, whereupon the step is repeated from untouched wire
+    arrays -- the small islands therefore run on the group interpreter (SoA arrays, carried over by the epilogue, which stands down
+    after a failure): the repeated step must not warm-start from impulses of the dropped one.  (They run BEFORE the strips: a strip
+    may own a kinematic body an island reads.)"""
     big = synthetic.pyramid(100)
     small = synthetic.pyramid(12, count=6)
     shift = len(big[0])

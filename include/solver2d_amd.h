@@ -343,7 +343,7 @@ int s2amd_world_download_boxes(s2amdSolver* solver, s2amdShapeBox* boxes, int32_
  *   moved[]          the shapes whose fat box the refit re-inflated (src/world.c:283-290), with the new fat box, IN THE ORDER the
  *                    reference's refit visits them -- `shapeOrder` of s2amd_world_set_refit_order: bodies in pool order, each
  *                    body's shape list -- which is the order s2BroadPhase_EnlargeProxy puts them into the move buffer in.
- * *movedCount == s2amdWorldStepInfo.movedCount of that step.  Velocities, manifolds, tight boxes stay in HBM until somebody
+ * *movedCount == s2amdWorldStepInfo.movedCount of that step.  A new s2amd_world_upload forgets the order (send it again).  Velocities, manifolds, tight boxes stay in HBM until somebody
  * asks for them (s2amd_world_download / _download_boxes). */
 typedef struct s2amdMovedBox
 {
@@ -419,6 +419,8 @@ int s2amd_measure_dominant(s2amdSolver* solver, const s2amdStepParams* params, i
  * "generic" (0/1 every other Gauss-Seidel solver, and any big island with joints, runs its whole step as one launch of the op interpreter over the
  * same strips: generic_kernel.hip; 0 = colour batches for them), "persist_retry" (steps a solver whose persistent launch lost a hand-off stays on the
  * fallback path before the one-launch kernels get another chance -- the wait doubles with every further time-out; default 256, 0 = for ever),
+ * "step_readback" (0/1 s2amd_world_step of a world with a refit order brings the poses and the re-inflated boxes along in its own synchronisation: s2amd_world_download_step then
+ * costs a host copy),
  * "free_body_groups" (0/1 bodies without any constraint form LDS groups of their own next to groups / strips instead of riding the global path's body launches),
  * "self_contained" (0/1 a world of resident islands only is stepped by their kernel alone: it stages its bodies from the wire records and writes them back),
  * "pair_lanes" (0/1 that launch solves a constraint with two lanes, one per body: pair_kernel.hip; measured no faster, off by default), "body_warm", "incremental" (0/1 created

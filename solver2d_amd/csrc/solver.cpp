@@ -180,6 +180,10 @@ void s2amd_destroy(s2amdSolver* s)
 	{
 		(void)hipHostFree(s->hostError);
 	}
+	if (s->hostStepBack)
+	{
+		(void)hipHostFree(s->hostStepBack);
+	}
 	if (s->hostWorldSummary)
 	{
 		(void)hipHostFree(s->hostWorldSummary);
@@ -792,6 +796,10 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	{
 		s->optStripPatience = std::max(0, value);
 		s->stripPatienceNow = s->optStripPatience;
+	}
+	else if (strcmp(key, "step_readback") == 0)
+	{
+		s->optStepReadback = value != 0;
 	}
 	else if (strcmp(key, "self_contained") == 0)
 	{

@@ -241,6 +241,13 @@ struct s2amdSolver
 	int shapeCapacity = 0, liveShapes = 0, jointedCount = 0;
 	bool worldResident = false;
 	int* hostWorldSummary = nullptr; // pinned: the per-step counters of both stages
+	// s2amd_world_step's speculative read-back for s2amd_world_download_step (a caller that set a refit order will ask for the poses
+	// and the re-inflated boxes right after the step): enqueued behind stage 4, landed by the step's own synchronisation
+	char* hostStepBack = nullptr; // pinned: {count, 0, 0, 0}, `stepBackBoxes` s2amdMovedBox records, then bodyCapacity poses at stepBackPoseOffset
+	size_t hostStepBackBytes = 0, stepBackPoseOffset = 0;
+	int stepBackBoxes = 0;
+	bool stepBackValid = false;
+	int optStepReadback = 1;
 	std::vector<uint8_t> hPointBytes;
 
 	// host shadows of the graph structure (refreshed by every upload)

@@ -211,6 +211,51 @@ __global__ __launch_bounds__(S2_BLOCK) void writeConstraintIndexFromScanKernel(s
 
 // the step's counters to the host (a mapped page the kernels would store into and the host spin on was measured: same
 // 0.332 ms per step, hipStreamSynchronize already spins); `reset`: the last read-back of a step clears them for the next
+// The poses and the re-inflated boxes of the step that was just enqueued, on their way to pinned host memory behind stage 4: what
+// s2amd_world_download_step hands out.  The number of boxes is not known yet: room for twice the last step's + 2,048 is copied, a
+// step that re-inflates more falls back to the explicit read-back of that call.
+int enqueueStepBack(s2amdSolver* s)
+{
+	const int nb = s->bodyCapacity, ns = s->shapeCapacity;
+	const int guess = std::min(ns, 2 * s->lastMovedCount + 2048);
+	const size_t headBytes = 16 + (size_t)std::max(ns, 1) * sizeof(s2amdMovedBox);
+	const size_t poseOffset = (headBytes + 255) & ~size_t(255);
+	int rc = s->dStepBack.ensure(poseOffset + (size_t)std::max(nb, 1) * sizeof(float4));
+	if (rc)
+	{
+		return rc;
+	}
+	const size_t hostPose = ((16 + (size_t)guess * sizeof(s2amdMovedBox)) + 255) & ~size_t(255);
+	const size_t hostBytes = hostPose + (size_t)nb * sizeof(float4);
+	if (s->hostStepBackBytes < hostBytes)
+	{
+		if (s->hostStepBack)
+		{
+			(void)hipHostFree(s->hostStepBack);
+			s->hostStepBack = nullptr, s->hostStepBackBytes = 0;
+		}
+		HIP_TRY(hipHostMalloc((void**)&s->hostStepBack, hostBytes + hostBytes / 2, hipHostMallocDefault));
+		s->hostStepBackBytes = hostBytes + hostBytes / 2;
+	}
+	char* base = (char*)s->dStepBack.p;
+	const int n = s->refitOrderCount;
+	const int tiles = (n + S2_BLOCK - 1) / S2_BLOCK;
+	if ((rc = s->dScanTmp.ensure((size_t)std::max(tiles, 1) * sizeof(int))) != 0)
+	{
+		return rc;
+	}
+	movedCountKernel<<<dim3((unsigned)tiles), dim3(S2_BLOCK), 0, s->stream>>>((const s2amdShape*)s->dShapes.p, ns, (const int*)s->dRefitOrder.p, n, (int*)s->dScanTmp.p);
+	movedWriteKernel<<<dim3((unsigned)tiles), dim3(S2_BLOCK), 0, s->stream>>>((const s2amdShape*)s->dShapes.p, ns, (const int*)s->dRefitOrder.p, n, (const int*)s->dScanTmp.p,
+																			   (int32_t*)base, ns);
+	stepPosesKernel<<<gridFor((size_t)nb), dim3(S2_BLOCK), 0, s->stream>>>((const s2amdBody*)s->dBodies.p, (const float*)s->dOrigins.p, nb, (float4*)(base + poseOffset));
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(s->hostStepBack, base, 16 + (size_t)guess * sizeof(s2amdMovedBox), hipMemcpyDeviceToHost, s->stream));
+	HIP_TRY(hipMemcpyAsync(s->hostStepBack + hostPose, base + poseOffset, (size_t)nb * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+	s->stepBackBoxes = guess;
+	s->stepBackPoseOffset = hostPose;
+	return S2AMD_OK;
+}
+
 int fetchSummary(s2amdSolver* s, int reset)
 {
 	HIP_TRY(hipMemcpyAsync(s->hostWorldSummary, s->dWorldSummary.p, 8 * sizeof(int), hipMemcpyDeviceToHost, s->stream));
@@ -334,6 +379,8 @@ int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapa
 	{
 		return fail(S2AMD_E_INVALID, "null array with non-zero count");
 	}
+	s->stepBackValid = false;
+	s->refitOrderCount = 0; // (the caller's order belongs to the world it was sent for)
 	for (int i = 0; i < contactCapacity; ++i)
 	{
 		if (pairs[i].shapeA >= shapeCapacity || pairs[i].shapeB >= shapeCapacity)
@@ -437,6 +484,7 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 	HIP_TRY(hipSetDevice(s->device));
 	const int nc = s->contactCapacity, nb = s->bodyCapacity, ns = s->shapeCapacity;
 	hipStream_t st = s->stream;
+	s->stepBackValid = false;
 	WorldSummary* dSum = (WorldSummary*)s->dWorldSummary.p;
 	WorldSummary* hSum = (WorldSummary*)s->hostWorldSummary;
 	WorldSummary firstSeen{};
@@ -541,10 +589,16 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 			return rc;
 		}
 		launchStage4(st, (s2amdBody*)s->dBodies.p, nb, (s2amdShape*)s->dShapes.p, ns, (float*)s->dOrigins.p, (int*)dSum);
+		const bool stepBack = s->optStepReadback != 0 && s->refitOrderCount > 0 && nb > 0 && ns > 0;
+		if (stepBack && (rc = enqueueStepBack(s)) != 0)
+		{
+			return rc;
+		}
 		if ((rc = fetchSummary(s, 1)) != 0)
 		{
 			return rc;
 		}
+		s->stepBackValid = stepBack;
 		if (s->hostError && *s->hostError != 0u && fallbacks == 0)
 		{
 			// bodies, impulses and (because the solve left the bodies alone) the shapes are what they were before the solve;
@@ -676,6 +730,7 @@ int s2amd_world_set_refit_order(s2amdSolver* s, const int32_t* shapeOrder, int32
 	}
 	HIP_TRY(hipSetDevice(s->device));
 	s->refitOrderCount = 0;
+	s->stepBackValid = false;
 	if (count == 0)
 	{
 		return S2AMD_OK;
@@ -709,6 +764,19 @@ int s2amd_world_download_step(s2amdSolver* s, float* poses, int32_t bodyCapacity
 	if (s->lastMovedCount > movedCapacity)
 	{
 		return fail(S2AMD_E_CAPACITY, "moved-box array too small");
+	}
+	if (s->stepBackValid && s->lastMovedCount <= s->stepBackBoxes && ((const int32_t*)s->hostStepBack)[0] == s->lastMovedCount)
+	{
+		// the step brought them along (enqueueStepBack)
+		if (s->lastMovedCount > 0)
+		{
+			memcpy(moved, s->hostStepBack + 16, (size_t)s->lastMovedCount * sizeof(s2amdMovedBox));
+		}
+		if (poses && s->bodyCapacity > 0)
+		{
+			memcpy(poses, s->hostStepBack + s->stepBackPoseOffset, (size_t)s->bodyCapacity * sizeof(float4));
+		}
+		return S2AMD_OK;
 	}
 	HIP_TRY(hipSetDevice(s->device));
 	const int nb = s->bodyCapacity, want = s->lastMovedCount;

@@ -61,32 +61,33 @@ S2_DEV void putBody(gu64* p, int poseOffset, unsigned epoch, float4 v, float4 d,
 // one constraint op over a list of colour batches (the switch of groupKernel, one constraint per call)
 template <class BA>
 S2_DEV void sweepOp(const Op& op, const ContactView& c, const JointView& jv, const BA& lb, const StepConsts& sc, s2amdContact* wire, const int4* cBatches,
-					int cb0, int cb1, const int4* jBatches, int jb0, int jb1)
+					int cb0, int cb1, const int4* jBatches, int jb0, int jb1, int jBase)
 {
+	// jBase: the joint view's arrays start at sweep position jBase (a view of LDS-resident records: genericStepKernel), 0 for the global arrays
 	auto pfC = [&](int k) { prefetchContact(c, k); };
-	auto pfJ = [&](int k) { prefetchJoint(jv, k); };
+	auto pfJ = [&](int k) { prefetchJoint(jv, k - jBase); };
 	switch (op.code)
 	{
 		case OP_JOINT_SWEEP:
 			switch (op.kind)
 			{
 				case JSOLVE_PLAIN:
-					forBatches(jBatches, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_PLAIN>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
+					forBatches(jBatches, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_PLAIN>(jv, lb, sc, op.h, op.inv_h, op.useBias, k - jBase); });
 					break;
 				case JSOLVE_SOFT:
-					forBatches(jBatches, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_SOFT>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
+					forBatches(jBatches, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_SOFT>(jv, lb, sc, op.h, op.inv_h, op.useBias, k - jBase); });
 					break;
 				case JSOLVE_BAUMGARTE:
-					forBatches(jBatches, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_BAUMGARTE>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
+					forBatches(jBatches, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_BAUMGARTE>(jv, lb, sc, op.h, op.inv_h, op.useBias, k - jBase); });
 					break;
 				case JSOLVE_POSITION:
-					forBatches(jBatches, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_POSITION>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
+					forBatches(jBatches, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_POSITION>(jv, lb, sc, op.h, op.inv_h, op.useBias, k - jBase); });
 					break;
 				case JSOLVE_XPBD:
-					forBatches(jBatches, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_XPBD>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
+					forBatches(jBatches, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_XPBD>(jv, lb, sc, op.h, op.inv_h, op.useBias, k - jBase); });
 					break;
 				case JSOLVE_WARM:
-					forBatches(jBatches, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_WARM>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
+					forBatches(jBatches, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_WARM>(jv, lb, sc, op.h, op.inv_h, op.useBias, k - jBase); });
 					break;
 			}
 			break;
@@ -159,7 +160,7 @@ S2_DEV void sweepOp(const Op& op, const ContactView& c, const JointView& jv, con
 
 __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactView c, JointView jv, BodyView g, GroupTable ga, GroupTable gb, PersistView pv,
 																		const Op* ops, int opCount, StepConsts sc, s2amdContact* wire, int useDq0,
-																		int seamContacts, int seamJoints)
+																		int seamContacts, int seamJoints, int stageJoints)
 {
 	extern __shared__ __attribute__((aligned(16))) float4 lds[];
 	const int tid = (int)threadIdx.x;
@@ -251,6 +252,66 @@ __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactV
 	__syncthreads();
 	const bool nearLeft = lnear[0] != 0, nearRight = lnear[1] != 0;
 
+	// ---- joints resident in LDS (stageJoints: the host has found room for every strip's): the records of this strip's interior
+	// joints and of the seam it sweeps -- one contiguous range of sweep positions each -- are read from HBM / L2 once per step
+	// instead of once per sweep; the per-joint functions reach them through views whose arrays point into LDS.  Sweeps write
+	// `impulse` and `axial` (constraint_ops.h: solveJointsOne): those two go back at the end.
+	const int jb0 = ga.jBatchOffsets[strip], jb1 = ga.jBatchOffsets[strip + 1];
+	const int sjb0 = seam >= 0 ? gb.jBatchOffsets[seam] : 0, sjb1 = seam >= 0 ? gb.jBatchOffsets[seam + 1] : 0;
+	const int jA0 = jb0 < jb1 ? ga.jBatches[jb0].x : 0, jA1 = jb0 < jb1 ? ga.jBatches[jb1 - 1].y : 0;
+	const int jS0 = sjb0 < sjb1 ? gb.jBatches[sjb0].x : 0, jS1 = sjb0 < sjb1 ? gb.jBatches[sjb1 - 1].y : 0;
+	const int njA = jA1 - jA0, nj = njA + (jS1 - jS0);
+	JointView ljA = jv, ljS = jv;
+	int jBaseA = 0, jBaseS = 0;
+	float2* blkImpulse = nullptr;
+	float4* blkAxial = nullptr;
+	if (stageJoints && nj > 0)
+	{
+		char* at = (char*)(lnear + 4);
+		auto kOf = [&](int i) { return i < njA ? jA0 + i : jS0 + (i - njA); };
+		auto stage4 = [&](float4* JointView::*member) {
+			float4* blk = (float4*)at;
+			at += (size_t)nj * sizeof(float4);
+			for (int i = tid; i < nj; i += S2_GENERIC_THREADS)
+			{
+				blk[i] = (jv.*member)[kOf(i)];
+			}
+			ljA.*member = blk;
+			ljS.*member = blk + njA;
+			return blk;
+		};
+		auto stage2 = [&](float2* JointView::*member) {
+			float2* blk = (float2*)at;
+			at += (size_t)nj * sizeof(float2);
+			for (int i = tid; i < nj; i += S2_GENERIC_THREADS)
+			{
+				blk[i] = (jv.*member)[kOf(i)];
+			}
+			ljA.*member = blk;
+			ljS.*member = blk + njA;
+			return blk;
+		};
+		stage4(&JointView::frame), stage4(&JointView::mass), stage4(&JointView::pivot), stage4(&JointView::soft);
+		blkAxial = stage4(&JointView::axial);
+		stage4(&JointView::limits), stage4(&JointView::misc), stage4(&JointView::origin);
+		stage2(&JointView::centerDiff0), stage2(&JointView::target);
+		blkImpulse = stage2(&JointView::impulse);
+		{
+			int2* blk = (int2*)at;
+			for (int i = tid; i < nj; i += S2_GENERIC_THREADS)
+			{
+				blk[i] = jv.localBodies[kOf(i)];
+			}
+			ljA.localBodies = blk;
+			ljS.localBodies = blk + njA;
+		}
+		// (what stays in global memory is addressed from the same origin: in-range pointers only)
+		ljA.bodies = jv.bodies + jA0, ljS.bodies = jv.bodies + jS0;
+		ljA.jointIndex = jv.jointIndex + jA0, ljS.jointIndex = jv.jointIndex + jS0;
+		jBaseA = jA0, jBaseS = jS0;
+		__syncthreads();
+	}
+
 	LdsMassBodies lb;
 	lb.vel = lvel, lb.dq = ldq, lb.massInv = lmass;
 	lb.softCoef[0] = make_float4(sc.softCoef[0][0], sc.softCoef[0][1], sc.softCoef[0][2], 0.0f);
@@ -258,9 +319,7 @@ __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactV
 	lb.softDiet = sc.softDiet;
 	SeamBodies sb{lvel, ldq, lremap};
 	const int cb0 = ga.cBatchOffsets[strip], cb1 = ga.cBatchOffsets[strip + 1];
-	const int jb0 = ga.jBatchOffsets[strip], jb1 = ga.jBatchOffsets[strip + 1];
 	const int scb0 = seam >= 0 ? gb.cBatchOffsets[seam] : 0, scb1 = seam >= 0 ? gb.cBatchOffsets[seam + 1] : 0;
-	const int sjb0 = seam >= 0 ? gb.jBatchOffsets[seam] : 0, sjb1 = seam >= 0 ? gb.jBatchOffsets[seam + 1] : 0;
 
 	unsigned epoch = 0; // the buffers are zero at launch (cleared by the previous step's epilogue)
 	int bad = 0;
@@ -309,7 +368,7 @@ __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactV
 				break;
 		}
 		// ---- a constraint op: interiors ----
-		sweepOp(op, c, jv, lb, sc, wire, ga.cBatches, cb0, cb1, ga.jBatches, jb0, jb1);
+		sweepOp(op, c, ljA, lb, sc, wire, ga.cBatches, cb0, cb1, ga.jBatches, jb0, jb1, jBaseA);
 		if ((op.code == OP_JOINT_SWEEP ? seamJoints : seamContacts) == 0)
 		{
 			continue; // nothing of this kind in any seam: every workgroup skips the hand-offs
@@ -345,7 +404,7 @@ __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactV
 		// ---- the seam to my right ----
 		if (seam >= 0)
 		{
-			sweepOp(op, c, jv, sb, sc, wire, gb.cBatches, scb0, scb1, gb.jBatches, sjb0, sjb1);
+			sweepOp(op, c, ljS, sb, sc, wire, gb.cBatches, scb0, scb1, gb.jBatches, sjb0, sjb1, jBaseS);
 		}
 		// ---- return: the right neighbour's bodies back to their owner, mine back from the left neighbour ----
 		epoch += 1;
@@ -371,6 +430,15 @@ __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactV
 		bad = __syncthreads_or(fail);
 	}
 
+	if (blkImpulse != nullptr && !bad)
+	{
+		for (int i = tid; i < nj; i += S2_GENERIC_THREADS)
+		{
+			const int k = i < njA ? jA0 + i : jS0 + (i - njA);
+			jv.impulse[k] = blkImpulse[i];
+			jv.axial[k] = blkAxial[i];
+		}
+	}
 	for (int i = tid; i < nb; i += S2_GENERIC_THREADS)
 	{
 		const uint32_t id = (uint32_t)ids[i];
@@ -395,19 +463,21 @@ int genericKernelSetup()
 
 // bytes of dynamic LDS a strip with `bodies` staged bodies (own + both import ranges), `seamBodies` seam-group bodies, `exports`
 // exported bodies and `opCount` ops needs (the host checks this against 160 KiB: Executor::genericPlan)
-size_t genericStepLds(int bodies, int seamBodies, int exports, int opCount, int useDq0)
+size_t genericStepLds(int bodies, int seamBodies, int exports, int opCount, int useDq0, int stagedJoints)
 {
 	const size_t records = (size_t)(useDq0 ? 3 : 2) * bodies + (size_t)(bodies + 1) / 2 + (size_t)(seamBodies + exports + 3) / 4 + 2 * (size_t)opCount + 1; // (+ the census flags)
-	return records * 16;
+	// a staged joint: eight 16-byte arrays, three 8-byte ones and its local body pair (JointView)
+	return records * 16 + (size_t)stagedJoints * (8 * 16 + 3 * 8 + 8) + (stagedJoints ? 64 : 0);
 }
 
 void launchGenericStep(hipStream_t s, const ContactView& c, const JointView& j, const BodyView& g, const GroupTable& a, const GroupTable& b, const PersistView& pv,
-					   const Op* ops, int opCount, const StepConsts& sc, s2amdContact* wire, int useDq0, int seamContacts, int seamJoints, size_t ldsBytes)
+					   const Op* ops, int opCount, const StepConsts& sc, s2amdContact* wire, int useDq0, int seamContacts, int seamJoints, size_t ldsBytes,
+					   int stageJoints)
 {
 	if (a.groupCount <= 0 || opCount <= 0)
 	{
 		return;
 	}
 	genericStepKernel<<<dim3((unsigned)a.groupCount), dim3(S2_GENERIC_THREADS), ldsBytes, s>>>(c, j, g, a, b, pv, ops, opCount, sc, wire, useDq0, seamContacts,
-																								 seamJoints);
+																								 seamJoints, stageJoints);
 }

@@ -163,9 +163,10 @@ void launchWideStep(hipStream_t s, const ContactView& c, const BodyView& g, cons
 
 // generic_kernel.hip: the persistent strip step as an op interpreter -- every solver family, joints included
 int genericKernelSetup();
-size_t genericStepLds(int bodies, int seamBodies, int exports, int opCount, int useDq0);
+size_t genericStepLds(int bodies, int seamBodies, int exports, int opCount, int useDq0, int stagedJoints = 0);
 void launchGenericStep(hipStream_t s, const ContactView& c, const JointView& j, const BodyView& g, const GroupTable& a, const GroupTable& b, const PersistView& pv,
-					   const Op* ops, int opCount, const StepConsts& sc, s2amdContact* wire, int useDq0, int seamContacts, int seamJoints, size_t ldsBytes);
+					   const Op* ops, int opCount, const StepConsts& sc, s2amdContact* wire, int useDq0, int seamContacts, int seamJoints, size_t ldsBytes,
+					   int stageJoints);
 
 // stage kernels on resident arrays (narrowphase.hip, broadphase.hip; called by world.hip)
 // summary: int[5] {separated pairs, active manifolds, zero/non-zero flips, point-count moves, enlarged shapes} (world.hip: WorldSummary)

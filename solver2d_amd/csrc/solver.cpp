@@ -797,6 +797,10 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 		s->optStripPatience = std::max(0, value);
 		s->stripPatienceNow = s->optStripPatience;
 	}
+	else if (strcmp(key, "stage_joints") == 0)
+	{
+		s->optStageJoints = value != 0;
+	}
 	else if (strcmp(key, "step_readback") == 0)
 	{
 		s->optStepReadback = value != 0;

@@ -661,9 +661,12 @@ struct Executor
 		{
 			recordEvent();
 		}
-		const size_t lds = genericStepLds(s->genericBodies, s->genericSeamBodies, s->genericExports, s->persistOpCount, p.usesDq0 ? 1 : 0);
+		// the strips' joints resident in LDS when every strip's fit beside its bodies (JointGrid: 176 B x ~400 joints per strip)
+		const size_t withJoints = genericStepLds(s->genericBodies, s->genericSeamBodies, s->genericExports, s->persistOpCount, p.usesDq0 ? 1 : 0, s->genericJoints);
+		const bool stage = s->optStageJoints != 0 && s->genericJoints > 0 && withJoints <= 160 * 1024;
+		const size_t lds = stage ? withJoints : genericStepLds(s->genericBodies, s->genericSeamBodies, s->genericExports, s->persistOpCount, p.usesDq0 ? 1 : 0);
 		launchGenericStep(st, s->cv, s->jv, s->bv, s->dStripA.view, s->dStripB.view, s->persist, (const Op*)s->dPersistOps.p, s->persistOpCount, p.sc,
-						  wireContacts(), p.usesDq0 ? 1 : 0, s->contacts.seamCount > 0 ? 1 : 0, s->joints.seamCount > 0 ? 1 : 0, lds);
+						  wireContacts(), p.usesDq0 ? 1 : 0, s->contacts.seamCount > 0 ? 1 : 0, s->joints.seamCount > 0 ? 1 : 0, lds, stage ? 1 : 0);
 		if (profile)
 		{
 			recordEvent();

@@ -344,6 +344,8 @@ struct s2amdSolver
 	// ... as an op interpreter for every solver family and joints (generic_kernel.hip: genericStepKernel): the same partition,
 	// import / export lists and hand-off buffers; seams swept once, by their left strip
 	bool genericValid = false;
+	int genericJoints = 0; // the most joints of a strip and the seam it sweeps
+	int optStageJoints = 1; // "stage_joints": the op interpreter keeps a strip's joint records in LDS when they fit
 	int genericBodies = 0, genericSeamBodies = 0, genericExports = 0; // the most staged bodies / seam-group bodies / exported bodies of a strip (LDS)
 	int residentAllTwoPoints = 0; // every constraint of the resident islands has two manifold points (wide_kernel.hip: the POINTS == 2 variants)
 	int optSelfContained = 1; // "self_contained": a world of resident islands only is stepped by their kernel alone (no body prologue / epilogue launch)

@@ -1174,7 +1174,7 @@ do                                                                              
 			pairLanes = g < 0 || B.cBatchOffsets[(size_t)g + 1] - B.cBatchOffsets[(size_t)g] <= 2;
 		}
 		std::vector<PersistDesc> descs((size_t)K);
-		int genericBodies = 0, genericSeamBodies = 0, genericExports = 0;
+		int genericBodies = 0, genericSeamBodies = 0, genericExports = 0, genericJoints = 0;
 		std::vector<int> remap, exportSrc, importIds;
 		std::vector<int> replicaStamp((size_t)nb, -1), replicaSlot((size_t)nb, -1);
 		int ldsRecords = 0, ldsRecordsWide = 0, bodyRecordsMax = 0;
@@ -1271,6 +1271,14 @@ do                                                                              
 			}
 			const int nt = importOffset;
 			genericBodies = std::max(genericBodies, nt);
+			{
+				auto rangeOf = [](const HostGroupTable& t, int g) {
+					const int b0 = t.jBatchOffsets[(size_t)g], b1 = t.jBatchOffsets[(size_t)g + 1];
+					return b0 < b1 ? t.jBatches[(size_t)b1 - 1].y - t.jBatches[(size_t)b0].x : 0;
+				};
+				const int gS = d.seamGroup[1];
+				genericJoints = std::max(genericJoints, rangeOf(A, i) + (gS >= 0 ? rangeOf(B, gS) : 0));
+			}
 			// bodies, seam constraints (S2_PERSIST_Q_NARROW records each for TGS_Soft, S2_PERSIST_Q_WIDE for the other kinds)
 			int fixedRecords = 3 * nt + (nt + 3) / 4 + (nt + 1) / 2; // velocity, pose, integrator constants, angular damping, inverse masses
 			const int seamRecordsNarrow = seamRegs ? 0 : S2_PERSIST_Q_NARROW * seamSlots;
@@ -1396,6 +1404,7 @@ do                                                                              
 			s->persistValid = okSoft;
 			s->genericValid = s->optGeneric != 0;
 			s->genericBodies = genericBodies, s->genericSeamBodies = genericSeamBodies, s->genericExports = genericExports;
+			s->genericJoints = genericJoints;
 		}
 	}
 	return rc;

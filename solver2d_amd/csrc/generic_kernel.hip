@@ -27,6 +27,7 @@
 #include "persist_handoff.h"
 
 #define S2_GENERIC_THREADS 512
+#define S2_GENERIC_BATCH_RECORDS 64 // colour batches of a strip and its seam (contacts and joints) whose descriptors are kept in LDS
 
 // seam-group-local body slots -> this workgroup's LDS slots (PersistView::remap, staged in LDS)
 struct SeamBodies
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactV
 	float4* blkAxial = nullptr;
 	if (stageJoints && nj > 0)
 	{
-		char* at = (char*)(lnear + 4);
+		char* at = (char*)(lnear + 4) + S2_GENERIC_BATCH_RECORDS * sizeof(int4);
 		auto kOf = [&](int i) { return i < njA ? jA0 + i : jS0 + (i - njA); };
 		auto stage4 = [&](float4* JointView::*member) {
 			float4* blk = (float4*)at;
@@ -321,6 +322,24 @@ __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactV
 	const int cb0 = ga.cBatchOffsets[strip], cb1 = ga.cBatchOffsets[strip + 1];
 	const int scb0 = seam >= 0 ? gb.cBatchOffsets[seam] : 0, scb1 = seam >= 0 ? gb.cBatchOffsets[seam + 1] : 0;
 
+	// the colour batches' descriptors in LDS: a round starts by reading its {begin, end, tail} -- from global memory that is a
+	// dependent L2 round trip on the critical path of every round
+	const int4* batchC = ga.cBatches + cb0;
+	const int4* batchJ = ga.jBatches + jb0;
+	const int4* batchSC = gb.cBatches + scb0;
+	const int4* batchSJ = gb.jBatches + sjb0;
+	const int nC = cb1 - cb0, nJ = jb1 - jb0, nSC = scb1 - scb0, nSJ = sjb1 - sjb0;
+	if (nC + nJ + nSC + nSJ <= S2_GENERIC_BATCH_RECORDS)
+	{
+		int4* lbatch = (int4*)(lnear + 4);
+		for (int i = tid; i < nC + nJ + nSC + nSJ; i += S2_GENERIC_THREADS)
+		{
+			lbatch[i] = i < nC ? batchC[i] : (i < nC + nJ ? batchJ[i - nC] : (i < nC + nJ + nSC ? batchSC[i - nC - nJ] : batchSJ[i - nC - nJ - nSC]));
+		}
+		batchC = lbatch, batchJ = lbatch + nC, batchSC = lbatch + nC + nJ, batchSJ = lbatch + nC + nJ + nSC;
+		__syncthreads();
+	}
+
 	unsigned epoch = 0; // the buffers are zero at launch (cleared by the previous step's epilogue)
 	int bad = 0;
 	for (int oi = 0; oi < opCount && !bad; ++oi)
@@ -368,7 +387,7 @@ __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactV
 				break;
 		}
 		// ---- a constraint op: interiors ----
-		sweepOp(op, c, ljA, lb, sc, wire, ga.cBatches, cb0, cb1, ga.jBatches, jb0, jb1, jBaseA);
+		sweepOp(op, c, ljA, lb, sc, wire, batchC, 0, nC, batchJ, 0, nJ, jBaseA);
 		if ((op.code == OP_JOINT_SWEEP ? seamJoints : seamContacts) == 0)
 		{
 			continue; // nothing of this kind in any seam: every workgroup skips the hand-offs
@@ -404,7 +423,7 @@ __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactV
 		// ---- the seam to my right ----
 		if (seam >= 0)
 		{
-			sweepOp(op, c, ljS, sb, sc, wire, gb.cBatches, scb0, scb1, gb.jBatches, sjb0, sjb1, jBaseS);
+			sweepOp(op, c, ljS, sb, sc, wire, batchSC, 0, nSC, batchSJ, 0, nSJ, jBaseS);
 		}
 		// ---- return: the right neighbour's bodies back to their owner, mine back from the left neighbour ----
 		epoch += 1;
@@ -465,7 +484,7 @@ int genericKernelSetup()
 // exported bodies and `opCount` ops needs (the host checks this against 160 KiB: Executor::genericPlan)
 size_t genericStepLds(int bodies, int seamBodies, int exports, int opCount, int useDq0, int stagedJoints)
 {
-	const size_t records = (size_t)(useDq0 ? 3 : 2) * bodies + (size_t)(bodies + 1) / 2 + (size_t)(seamBodies + exports + 3) / 4 + 2 * (size_t)opCount + 1; // (+ the census flags)
+	const size_t records = (size_t)(useDq0 ? 3 : 2) * bodies + (size_t)(bodies + 1) / 2 + (size_t)(seamBodies + exports + 3) / 4 + 2 * (size_t)opCount + 1 + S2_GENERIC_BATCH_RECORDS; // (+ the census flags, the batch descriptors)
 	// a staged joint: eight 16-byte arrays, three 8-byte ones and its local body pair (JointView)
 	return records * 16 + (size_t)stagedJoints * (8 * 16 + 3 * 8 + 8) + (stagedJoints ? 64 : 0);
 }

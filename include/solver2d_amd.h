@@ -419,6 +419,7 @@ int s2amd_measure_dominant(s2amdSolver* solver, const s2amdStepParams* params, i
  * "generic" (0/1 every other Gauss-Seidel solver, and any big island with joints, runs its whole step as one launch of the op interpreter over the
  * same strips: generic_kernel.hip; 0 = colour batches for them), "persist_retry" (steps a solver whose persistent launch lost a hand-off stays on the
  * fallback path before the one-launch kernels get another chance -- the wait doubles with every further time-out; default 256, 0 = for ever),
+ * "stage_joints" (0/1 the op interpreter keeps a strip's joint records in LDS for the whole step when they fit),
  * "step_readback" (0/1 s2amd_world_step of a world with a refit order brings the poses and the re-inflated boxes along in its own synchronisation: s2amd_world_download_step then
  * costs a host copy),
  * "free_body_groups" (0/1 bodies without any constraint form LDS groups of their own next to groups / strips instead of riding the global path's body launches),

@@ -612,7 +612,7 @@ __global__ __launch_bounds__(S2_BLOCK) void residentPairKeysKernel(const s2amdPa
 
 int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShapes, const s2amdPairState* dPairs, int nc,
 					  const unsigned long long* dJointed, int jointedCount, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount, void** scratch,
-					  size_t* scratchBytes, unsigned long long* sortedPairKeys, bool* sortedPairKeysValid)
+					  size_t* scratchBytes, unsigned long long* sortedPairKeys, bool* sortedPairKeysValid, PairQueryGraph* cache)
 {
 	*pairCount = 0;
 	const int n = liveShapes;
@@ -671,33 +671,103 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 	(void)dExisting; // the sorted pair keys live in the caller's buffer
 	(void)dOutB;
 
-	BP_TRY(hipMemsetAsync(dCount, 0, 256, st));
-	residentShapeKeysKernel<<<gridFor((size_t)ns), dim3(S2_BLOCK), 0, st>>>(dS, ns, dKeysIn, dIdxIn, dMoved);
-	size_t tmp = tmpBytes + 256;
-	BP_TRY(rocprim::radix_sort_pairs(dTmp, tmp, dKeysIn, dKeysOut, dIdxIn, dIdxOut, (size_t)ns, 0, 32, st));
 	// the sorted keys of the live pairs only change when a contact is created or destroyed: the caller keeps them
+	size_t tmp = tmpBytes + 256;
 	if (nc > 0 && !*sortedPairKeysValid)
 	{
 		residentPairKeysKernel<<<gridFor((size_t)nc), dim3(S2_BLOCK), 0, st>>>(dPairs, nc, dExistingIn);
-		tmp = tmpBytes + 256;
 		BP_TRY(rocprim::radix_sort_keys(dTmp, tmp, dExistingIn, sortedPairKeys, (size_t)nc, 0, 64, st));
 		*sortedPairKeysValid = true;
 	}
-	gatherLowerXKernel<<<gridFor((size_t)n), dim3(S2_BLOCK), 0, st>>>(dS, dIdxOut, n, dLowerX);
-	// (dCount[0] = pairs found, dCount[1] = long runs: both zeroed above; the run-length array of the host-array route holds the long list)
-	(void)dOff;
-	pairWaveKernel<<<dim3((unsigned)std::min((n + 3) / 4, 16384)), dim3(S2_BLOCK), 0, st>>>(dS, dMoved, dIdxOut, dLowerX, n, sortedPairKeys, nc, dJointed,
-																							jointedCount, dOutA, (unsigned int)outCap, dCount, (int*)dRun, dCount + 1);
-	pairLongKernel<<<dim3(256), dim3(S2_BLOCK), 0, st>>>(dS, dMoved, dIdxOut, dLowerX, n, sortedPairKeys, nc, dJointed, jointedCount, dOutA, (unsigned int)outCap,
-														  dCount, (const int*)dRun, dCount + 1);
-	BP_TRY(hipGetLastError());
-	// one read-back: the count and the first keys (a step rarely creates more than a few contacts)
 	constexpr unsigned int kFirst = 2048;
-	std::vector<unsigned long long> out(kFirst);
-	unsigned int found = 0;
-	BP_TRY(hipMemcpyAsync(&found, dCount, 4, hipMemcpyDeviceToHost, st));
-	BP_TRY(hipMemcpyAsync(out.data(), dOutA, (size_t)std::min<size_t>(kFirst, outCap) * 8, hipMemcpyDeviceToHost, st));
+	// one read-back: the count and the first keys (a step rarely creates more than a few contacts), into pinned memory
+	if (cache->host == nullptr)
+	{
+		BP_TRY(hipHostMalloc((void**)&cache->host, 16 + (size_t)kFirst * 8, hipHostMallocDefault));
+	}
+	unsigned int* hostFound = (unsigned int*)cache->host;
+	unsigned long long* hostKeys = (unsigned long long*)(cache->host + 16);
+	// The query proper -- key generation, the sort of the proxies, the sweep kernels, the read-back -- is the same dozen launches
+	// every step: the second time a sequence (arrays, sizes) comes along it is captured into a hipGraph and replayed from then on
+	auto enqueue = [&]() -> int {
+		BP_TRY(hipMemsetAsync(dCount, 0, 256, st));
+		residentShapeKeysKernel<<<gridFor((size_t)ns), dim3(S2_BLOCK), 0, st>>>(dS, ns, dKeysIn, dIdxIn, dMoved);
+		size_t t2 = tmpBytes + 256;
+		BP_TRY(rocprim::radix_sort_pairs(dTmp, t2, dKeysIn, dKeysOut, dIdxIn, dIdxOut, (size_t)ns, 0, 32, st));
+		gatherLowerXKernel<<<gridFor((size_t)n), dim3(S2_BLOCK), 0, st>>>(dS, dIdxOut, n, dLowerX);
+		// (dCount[0] = pairs found, dCount[1] = long runs: both zeroed above; the run-length array of the host-array route holds the long list)
+		pairWaveKernel<<<dim3((unsigned)std::min((n + 3) / 4, 16384)), dim3(S2_BLOCK), 0, st>>>(dS, dMoved, dIdxOut, dLowerX, n, sortedPairKeys, nc, dJointed,
+																								jointedCount, dOutA, (unsigned int)outCap, dCount, (int*)dRun, dCount + 1);
+		pairLongKernel<<<dim3(256), dim3(S2_BLOCK), 0, st>>>(dS, dMoved, dIdxOut, dLowerX, n, sortedPairKeys, nc, dJointed, jointedCount, dOutA,
+															  (unsigned int)outCap, dCount, (const int*)dRun, dCount + 1);
+		BP_TRY(hipGetLastError());
+		BP_TRY(hipMemcpyAsync(hostFound, dCount, 4, hipMemcpyDeviceToHost, st));
+		BP_TRY(hipMemcpyAsync(hostKeys, dOutA, (size_t)std::min<size_t>(kFirst, outCap) * 8, hipMemcpyDeviceToHost, st));
+		return S2AMD_OK;
+	};
+	(void)dOff;
+	unsigned long long key = 1469598103934665603ull;
+	{
+		const unsigned long long words[] = {(unsigned long long)(uintptr_t)dS, (unsigned long long)ns, (unsigned long long)n, (unsigned long long)nc,
+											(unsigned long long)(uintptr_t)dJointed, (unsigned long long)jointedCount, (unsigned long long)(uintptr_t)*scratch,
+											(unsigned long long)(uintptr_t)sortedPairKeys, (unsigned long long)outCap, (unsigned long long)tmpBytes};
+		for (unsigned long long w : words)
+		{
+			key = (key ^ w) * 1099511628211ull;
+		}
+		key |= 1ull;
+	}
+	if (cache->disabled || (key != cache->key && key != cache->keySeen))
+	{
+		cache->keySeen = key;
+		int rcE = enqueue();
+		if (rcE)
+		{
+			return rcE;
+		}
+	}
+	else
+	{
+		if (key != cache->key || cache->exec == nullptr)
+		{
+			if (cache->exec)
+			{
+				(void)hipGraphExecDestroy(cache->exec);
+				cache->exec = nullptr;
+			}
+			hipGraph_t g = nullptr;
+			hipError_t ce = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+			int rcE = ce == hipSuccess ? enqueue() : S2AMD_E_DEVICE;
+			hipError_t ee = ce == hipSuccess ? hipStreamEndCapture(st, &g) : ce;
+			if (rcE == S2AMD_OK && ee == hipSuccess && g != nullptr && hipGraphInstantiate(&cache->exec, g, nullptr, nullptr, 0) == hipSuccess)
+			{
+				cache->key = key;
+			}
+			else
+			{
+				// (a runtime that cannot capture the library sort: enqueue directly from now on)
+				(void)hipGetLastError();
+				cache->exec = nullptr;
+				cache->disabled = true;
+				cache->key = 0;
+				if ((rcE = enqueue()) != 0)
+				{
+					return rcE;
+				}
+			}
+			if (g)
+			{
+				(void)hipGraphDestroy(g);
+			}
+		}
+		if (cache->exec != nullptr && key == cache->key)
+		{
+			BP_TRY(hipGraphLaunch(cache->exec, st));
+		}
+	}
 	BP_TRY(hipStreamSynchronize(st));
+	const unsigned int found = *hostFound;
+	std::vector<unsigned long long> out(hostKeys, hostKeys + std::min<size_t>(std::min<size_t>(kFirst, outCap), found));
 	*pairCount = (int32_t)found;
 	if ((int64_t)found > (int64_t)pairCapacity)
 	{

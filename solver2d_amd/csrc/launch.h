@@ -175,6 +175,14 @@ void launchUpdateContacts(hipStream_t st, const s2amdBody* bodies, const float* 
 // stage 4 in one launch: refit per shape (origin recomputed from the body), origins + force reset per body, summary[4] += enlarged shapes
 void launchStage4(hipStream_t st, s2amdBody* bodies, int bodyCapacity, s2amdShape* shapes, int shapeCapacity, float* origins, int* summary);
 // stage 1 on resident arrays: new pairs sorted by (A, B) into the host array outPairs; dJointed: sorted (min body << 32 | max body) keys
+// the captured launch sequence of the resident pair query and its pinned read-back buffer (owned by the solver)
+struct PairQueryGraph
+{
+	hipGraphExec_t exec = nullptr;
+	unsigned long long key = 0, keySeen = 0;
+	bool disabled = false;
+	char* host = nullptr;
+};
 int findPairsResident(hipStream_t st, const s2amdShape* shapes, int shapeCapacity, int liveShapes, const s2amdPairState* pairs, int contactCapacity,
 					  const unsigned long long* jointed, int jointedCount, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount, void** scratch,
-					  size_t* scratchBytes, unsigned long long* sortedPairKeys, bool* sortedPairKeysValid);
+					  size_t* scratchBytes, unsigned long long* sortedPairKeys, bool* sortedPairKeysValid, PairQueryGraph* cache);

@@ -180,6 +180,14 @@ void s2amd_destroy(s2amdSolver* s)
 	{
 		(void)hipHostFree(s->hostError);
 	}
+	if (s->pairQuery.exec)
+	{
+		(void)hipGraphExecDestroy(s->pairQuery.exec);
+	}
+	if (s->pairQuery.host)
+	{
+		(void)hipHostFree(s->pairQuery.host);
+	}
 	if (s->hostStepBack)
 	{
 		(void)hipHostFree(s->hostStepBack);

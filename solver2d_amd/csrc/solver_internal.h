@@ -237,6 +237,7 @@ struct s2amdSolver
 
 	// resident world (world.hip): the arrays of stages 3 and 4 beside the solver's wire arrays
 	DevBuf dShapes, dPairs, dOrigins, dStatus, dPointBytes, dWorldSummary, dJointedKeys, dContactStage, dPairScratch, dPairKeys;
+	PairQueryGraph pairQuery; // the resident pair query's captured launch sequence (broadphase.hip: findPairsResident)
 	bool pairKeysValid = false; // dPairKeys holds the sorted (shape, shape) keys of the live pair slots
 	int shapeCapacity = 0, liveShapes = 0, jointedCount = 0;
 	bool worldResident = false;

@@ -681,7 +681,7 @@ int s2amd_world_find_pairs(s2amdSolver* s, int32_t* outPairs, int32_t pairCapaci
 	}
 	int rc = findPairsResident(s->stream, (const s2amdShape*)s->dShapes.p, s->shapeCapacity, s->liveShapes, (const s2amdPairState*)s->dPairs.p, s->contactCapacity,
 							   (const unsigned long long*)s->dJointedKeys.p, s->jointedCount, outPairs, pairCapacity, pairCount, &s->dPairScratch.p,
-							   &s->dPairScratch.bytes, (unsigned long long*)s->dPairKeys.p, &s->pairKeysValid);
+							   &s->dPairScratch.bytes, (unsigned long long*)s->dPairKeys.p, &s->pairKeysValid, &s->pairQuery);
 	if (rc == S2AMD_OK && s->shapeCapacity > 0) // (S2AMD_E_CAPACITY: the caller asks again with a larger buffer)
 	{
 		clearMovedKernel<<<gridFor((size_t)s->shapeCapacity), dim3(S2_BLOCK), 0, s->stream>>>((s2amdShape*)s->dShapes.p, s->shapeCapacity);

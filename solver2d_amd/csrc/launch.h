@@ -153,7 +153,7 @@ void launchPairStep(hipStream_t s, int kind, int warm, const ContactView& c, con
 
 // wide_kernel.hip: TGS_Soft's persistent strip step on 512 threads per strip
 int wideKernelSetup();
-int wideParkedRecords(int maxRoundsA, int maxSeamRounds, int force);
+int wideParkedRecords(int maxRoundsA, int maxSeamRounds, int force, int parkSeamWidth, int parkInteriorWidth);
 // ... and the resident islands' step (strip_kernel.hip: launchIslandStep) for TGS_Soft with the current-anchor warm start
 // selfContained: the kernel also stages its bodies from the wire records and writes them back (no prologue / epilogue launch)
 void launchWideIsland(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& t, const float4* softCoef, const Op* ops, int opCount,

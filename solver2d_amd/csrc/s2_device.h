@@ -513,6 +513,7 @@ struct PersistView
 	int maxRoundsA, maxSeamRounds; // the most interior colour batches of a strip / colour batches of a seam
 	int pairLanes;	  // the partition fits pair_kernel.hip: pairStepKernel (<= 6 interior batches per strip, <= 2 per seam)
 	int ldsRecords;
+	int parkSeamWidth, parkInteriorWidth; // wide_kernel.hip: lanes that hold a record in a parked seam round (rounds 3-4) / interior round (7-8), >= 64
 	int bodyRecords; // ... of them the staged bodies alone (wide_kernel.hip keeps no seam constraint in the kernel-independent LDS budget)
 	int debugSkip; // timing experiments only (results are wrong; compiled in with -DS2_PERSIST_INSTRUMENTED=1): 1 = no hand-offs, 2 = no seam rounds, 4 = no interior rounds;
 				   // 8 = fault injection for the fallback test: workgroup 1 never publishes its seam bodies

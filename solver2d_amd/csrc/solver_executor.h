@@ -429,7 +429,8 @@ struct Executor
 	// warm start on a partition with at most six interior colour batches per strip and two per seam.
 	bool widePlan(int kind, int warm) const
 	{
-		const int parked = wideParkedRecords(s->persist.maxRoundsA, s->persist.maxSeamRounds, (s->persist.debugSkip & 16) != 0);
+		const int parked = wideParkedRecords(s->persist.maxRoundsA, s->persist.maxSeamRounds, (s->persist.debugSkip & 16) != 0, s->persist.parkSeamWidth,
+												 s->persist.parkInteriorWidth);
 		return s->optWide && parked >= 0 && kind == SOFT_TGS && warm == WARM_CURRENT &&
 			   s->persist.bodyRecords + 3 + parked + 2 * s->persistOpCount <= (160 * 1024) / 16;
 	}

@@ -1372,10 +1372,31 @@ do                                                                              
 			pv.pairLanes = pairLanes ? 1 : 0;
 			pv.maxRoundsA = maxRoundsA;
 			pv.maxSeamRounds = 0;
+			pv.parkSeamWidth = pv.parkInteriorWidth = 64;
 			for (const PersistDesc& d : descs)
 			{
 				pv.maxSeamRounds = std::max(pv.maxSeamRounds, std::max(d.seamBatchCount[0], d.seamBatchCount[1]));
+				// wide_kernel.hip parks seam rounds 3 and 4 (both seams of a strip share a round: left batch, then right batch)
+				for (int r = 2; r < S2_PERSIST_B_ROUNDS; ++r)
+				{
+					const int n0 = r < d.seamBatchCount[0] ? d.seamBatch[0][r].y - d.seamBatch[0][r].x : 0;
+					const int n1 = r < d.seamBatchCount[1] ? d.seamBatch[1][r].y - d.seamBatch[1][r].x : 0;
+					pv.parkSeamWidth = std::max(pv.parkSeamWidth, n0 + n1);
+				}
 			}
+			// ... and interior rounds 7 and 8
+			for (int i = 0; i < K; ++i)
+			{
+				for (int bb = A.cBatchOffsets[(size_t)i] + S2_STRIP_ROUNDS; bb < A.cBatchOffsets[(size_t)i + 1]; ++bb)
+				{
+					pv.parkInteriorWidth = std::max(pv.parkInteriorWidth, A.cBatches[(size_t)bb].y - A.cBatches[(size_t)bb].x);
+				}
+			}
+			if ((s->optPersistDebug & 16) != 0)
+			{
+				pv.parkSeamWidth = 512, pv.parkInteriorWidth = 256; // (tests: the parked variants on partitions that do not need them)
+			}
+			pv.parkSeamWidth = (pv.parkSeamWidth + 63) & ~63, pv.parkInteriorWidth = (pv.parkInteriorWidth + 63) & ~63;
 			s->persistK0 = k0, s->persistK1 = k1;
 			pv.allTwoPoints = stripsAllTwoPoints(s) ? 1 : 0;
 			pv.ldsRecords = ldsRecords;

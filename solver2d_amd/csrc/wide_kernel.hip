@@ -443,19 +443,24 @@ S2_DEV void storeWide(const ContactView& c, const WideRegs& p, int k)
 // colour next to seven or eight interior ones): six 16-byte records per lane and round, field-major so that a wave reads
 // consecutive addresses; the impulses are a record of their own -- the only part a sweep writes back.
 #define S2_WIDE_PARKED_RECORDS 6
-S2_DEV void parkWide(float4* slot, const WideRegs& p)
+// 1: the preps of the parked seam rounds run while the hand-off is in flight, like those of the rounds in registers.  Measured slower
+// on the wreck world (0.289 against 0.271 ms per churn step: 22 more live registers, 148-168 bytes of scratch instead of ~110): off
+#ifndef S2_WIDE_PARKED_PREP_EARLY
+#define S2_WIDE_PARKED_PREP_EARLY 0
+#endif
+// (`stride`: the lanes of a parked round -- as many columns as its widest instance in any strip holds constraints: PersistView::parkSeamWidth / parkInteriorWidth)
+S2_DEV void parkWide(float4* slot, int stride, const WideRegs& p)
 {
-	slot[0 * S2_WIDE_THREADS] = make_float4(fromBits(p.idx), p.n.x, p.n.y, p.friction);
-	slot[1 * S2_WIDE_THREADS] = make_float4(p.lA[0].x, p.lA[0].y, p.lA[1].x, p.lA[1].y);
-	slot[2 * S2_WIDE_THREADS] = make_float4(p.lB[0].x, p.lB[0].y, p.lB[1].x, p.lB[1].y);
-	slot[3 * S2_WIDE_THREADS] = make_float4(p.p0[0], p.p0[1], p.p1[0], p.p1[1]);
-	slot[4 * S2_WIDE_THREADS] = make_float4(p.p2[0], p.p2[1], 0.0f, 0.0f);
-	slot[5 * S2_WIDE_THREADS] = make_float4(p.imp[0].x, p.imp[0].y, p.imp[1].x, p.imp[1].y);
+	slot[0 * stride] = make_float4(fromBits(p.idx), p.n.x, p.n.y, p.friction);
+	slot[1 * stride] = make_float4(p.lA[0].x, p.lA[0].y, p.lA[1].x, p.lA[1].y);
+	slot[2 * stride] = make_float4(p.lB[0].x, p.lB[0].y, p.lB[1].x, p.lB[1].y);
+	slot[3 * stride] = make_float4(p.p0[0], p.p0[1], p.p1[0], p.p1[1]);
+	slot[4 * stride] = make_float4(p.p2[0], p.p2[1], 0.0f, 0.0f);
+	slot[5 * stride] = make_float4(p.imp[0].x, p.imp[0].y, p.imp[1].x, p.imp[1].y);
 }
-S2_DEV WideRegs unparkWide(const float4* slot)
+S2_DEV WideRegs unparkWide(const float4* slot, int stride)
 {
-	const float4 q0 = slot[0 * S2_WIDE_THREADS], q1 = slot[1 * S2_WIDE_THREADS], q2 = slot[2 * S2_WIDE_THREADS], q3 = slot[3 * S2_WIDE_THREADS],
-				 q4 = slot[4 * S2_WIDE_THREADS], q5 = slot[5 * S2_WIDE_THREADS];
+	const float4 q0 = slot[0 * stride], q1 = slot[1 * stride], q2 = slot[2 * stride], q3 = slot[3 * stride], q4 = slot[4 * stride], q5 = slot[5 * stride];
 	WideRegs p;
 	p.idx = asBits(q0.x), p.n = f2{q0.y, q0.z}, p.friction = q0.w;
 	p.lA[0] = lo2(q1), p.lA[1] = hi2(q1), p.lB[0] = lo2(q2), p.lB[1] = hi2(q2);
@@ -466,7 +471,8 @@ S2_DEV WideRegs unparkWide(const float4* slot)
 
 // POINTS == 2: the host has checked that every constraint of the strips has two manifold points: no per-point masking.
 // RPH: interior records a lane keeps (colour batches / 2), SR: seam records a lane keeps, SL: seam rounds parked in LDS.
-template <int POINTS, int RPH, int SR, int SL = 0> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideStepKernel(ContactView c, BodyView g, StripTableView ta, PersistView pv, const Op* ops, int opCount)
+// IL: interior rounds parked in LDS behind the 2 RPH a lane keeps (a strip that needs a seventh or eighth colour: a hub body inside it).
+template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideStepKernel(ContactView c, BodyView g, StripTableView ta, PersistView pv, const Op* ops, int opCount)
 {
 	extern __shared__ __attribute__((aligned(16))) float4 lds[];
 	const int tid = (int)threadIdx.x;
@@ -503,10 +509,13 @@ template <int POINTS, int RPH, int SR, int SL = 0> __global__ __launch_bounds__(
 	const StripDesc* da = ta.descs + strip;
 	const PersistDesc* pd = pv.descs + strip;
 	const int bodyBase = da->bodyBase, nb = da->bodyCount, roundsA = da->batchCount;
-	constexpr int ROUNDS = 2 * RPH; // interior colour batches this variant takes (RPH per half of the workgroup)
-	int2 batchA[ROUNDS];
+	constexpr int ROUNDS = 2 * RPH; // interior colour batches a lane keeps records of (RPH per half of the workgroup)
+	constexpr int RA = ROUNDS + IL; // ... and this variant takes
+	static_assert(RA <= S2_STRIP_ROUNDS_MAX, "StripDesc::batch");
+	int2 batchA[RA + 1]; // (+ 1: never read; keeps the index expressions of the IL == 0 variants in range)
+	batchA[RA] = make_int2(0, 0);
 #pragma unroll
-	for (int i = 0; i < ROUNDS; ++i)
+	for (int i = 0; i < RA; ++i)
 	{
 		batchA[i] = make_int2(da->batch[i].x, da->batch[i].y);
 	}
@@ -538,7 +547,10 @@ template <int POINTS, int RPH, int SR, int SL = 0> __global__ __launch_bounds__(
 	const int bodyRecords = 3 * nt + (nt + 3) / 4 + (nt + 1) / 2;
 	Op* lops = (Op*)(lds + bodyRecords); // 2 records per op
 	float4* lcoef = lds + bodyRecords + 2 * opCount; // 2 records + 1 for the census flags (the launch adds them to the size)
-	float4* lparked = lcoef + 3 + tid;				 // SL rounds of S2_WIDE_PARKED_RECORDS * 512 records: this lane's column
+	// parked records: SL seam rounds of 6 x parkSeamWidth records (column = tid), then IL interior rounds of 6 x parkInteriorWidth (column = ht)
+	const int sw = pv.parkSeamWidth, iw = pv.parkInteriorWidth;
+	float4* lparked = lcoef + 3 + tid;
+	float4* lparkedI = lcoef + 3 + SL * S2_WIDE_PARKED_RECORDS * sw + ht;
 
 	// ---- loads ----
 	uint32_t id[S2_WIDE_BODY_CHUNKS];
@@ -614,9 +626,25 @@ template <int POINTS, int RPH, int SR, int SL = 0> __global__ __launch_bounds__(
 		if (i < roundsB && seamItem(i, seam, k))
 		{
 			const int2 lb = c.localBodies[k];
-			parkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * S2_WIDE_THREADS,
+			parkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * sw, sw,
 					 loadWide(c, k, pv.remap[pd->remapBase[seam] + lb.x], pv.remap[pd->remapBase[seam] + lb.y]));
 			seamMask |= 1u << i;
+		}
+	}
+	// the constraint this lane holds in parked interior round j (round ROUNDS + j runs on half (ROUNDS + j) & 1 like every interior round)
+	auto kOfParked = [&](int j) {
+		const int i = ROUNDS + j;
+		const int k = batchA[i].x + ht;
+		return (i < roundsA && (i & 1) == half && k < batchA[i].y) ? k : -1;
+	};
+#pragma unroll
+	for (int j = 0; j < IL; ++j)
+	{
+		const int k = kOfParked(j);
+		if (k >= 0)
+		{
+			const int2 lb = c.localBodies[k];
+			parkWide(lparkedI + j * S2_WIDE_PARKED_RECORDS * iw, iw, loadWide(c, k, lb.x, lb.y));
 		}
 	}
 	// bodies (+ their integrator constants) into LDS: own list, then this half's imports
@@ -696,8 +724,19 @@ template <int POINTS, int RPH, int SR, int SL = 0> __global__ __launch_bounds__(
 	{
 		if ((seamMask >> i) & 1u)
 		{
-			float4* slot = lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * S2_WIDE_THREADS;
-			WideRegs p = unparkWide(slot);
+			float4* slot = lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * sw;
+			WideRegs p = unparkWide(slot, sw);
+			markStatic(p);
+			slot[0].x = fromBits(p.idx);
+		}
+	}
+#pragma unroll
+	for (int j = 0; j < IL; ++j)
+	{
+		if (kOfParked(j) >= 0)
+		{
+			float4* slot = lparkedI + j * S2_WIDE_PARKED_RECORDS * iw;
+			WideRegs p = unparkWide(slot, iw);
 			markStatic(p);
 			slot[0].x = fromBits(p.idx);
 		}
@@ -794,6 +833,18 @@ template <int POINTS, int RPH, int SR, int SL = 0> __global__ __launch_bounds__(
 				}
 			}
 #pragma unroll
+			for (int j = 0; j < IL; ++j)
+			{
+				if (ROUNDS + j < roundsA)
+				{
+					if (kOfParked(j) >= 0)
+					{
+						warmWide<POINTS>(unparkWide(lparkedI + j * S2_WIDE_PARKED_RECORDS * iw, iw), lvel, ldq, lmass, salt);
+					}
+					__syncthreads();
+				}
+			}
+#pragma unroll
 			for (int i = 0; i < SR; ++i)
 			{
 				if (i < roundsB)
@@ -812,7 +863,7 @@ template <int POINTS, int RPH, int SR, int SL = 0> __global__ __launch_bounds__(
 				{
 					if ((seamMask >> i) & 1u)
 					{
-						warmWide<POINTS>(unparkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * S2_WIDE_THREADS), lvel, ldq, lmass, salt);
+						warmWide<POINTS>(unparkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * sw, sw), lvel, ldq, lmass, salt);
 					}
 					__syncthreads();
 				}
@@ -828,24 +879,45 @@ template <int POINTS, int RPH, int SR, int SL = 0> __global__ __launch_bounds__(
 			{
 				pre = prepWide<POINTS>(rA[0], ldq, lcoef, op.inv_h, op.useBias, salt);
 			}
+			// (the parked rounds ROUNDS .. RA-1 take part in the same schedule: their records come out of LDS for the prep and again for the chain)
 #pragma unroll
-			for (int i = 0; i < ROUNDS; ++i)
+			for (int i = 0; i < RA; ++i)
 			{
 				if (i < roundsA)
 				{
 					if ((i & 1) == half)
 					{
-						if (kOfSlot(i >> 1) >= 0)
+						if (i < ROUNDS)
 						{
-							chainWide<POINTS>(rA[i >> 1], pre, lvel, lmass, lcoef, salt);
+							if (kOfSlot(i >> 1) >= 0)
+							{
+								chainWide<POINTS>(rA[i >> 1 < RPH ? i >> 1 : 0], pre, lvel, lmass, lcoef, salt);
+							}
+						}
+						else if (kOfParked(i - ROUNDS < IL ? i - ROUNDS : 0) >= 0)
+						{
+							float4* slot = lparkedI + (i - ROUNDS) * S2_WIDE_PARKED_RECORDS * iw;
+							WideRegs p = unparkWide(slot, iw);
+							chainWide<POINTS>(p, pre, lvel, lmass, lcoef, salt);
+							slot[5 * iw] = make_float4(p.imp[0].x, p.imp[0].y, p.imp[1].x, p.imp[1].y);
 						}
 					}
-					else if (i + 1 < ROUNDS && kOfSlot((i + 1) >> 1) >= 0) // (my next round is i + 1)
+					else if (i + 1 < RA) // (my next round is i + 1)
 					{
-						pre = prepWide<POINTS>(rA[(i + 1) >> 1], ldq, lcoef, op.inv_h, op.useBias, salt);
+						if (i + 1 < ROUNDS)
+						{
+							if (kOfSlot((i + 1) >> 1) >= 0)
+							{
+								pre = prepWide<POINTS>(rA[(i + 1) >> 1 < RPH ? (i + 1) >> 1 : 0], ldq, lcoef, op.inv_h, op.useBias, salt);
+							}
+						}
+						else if (kOfParked(i + 1 - ROUNDS < IL ? i + 1 - ROUNDS : 0) >= 0)
+						{
+							pre = prepWide<POINTS>(unparkWide(lparkedI + (i + 1 - ROUNDS) * S2_WIDE_PARKED_RECORDS * iw, iw), ldq, lcoef, op.inv_h, op.useBias, salt);
+						}
 					}
 					__syncthreads();
-					if (S2_PERSIST_INSTRUMENTED && i + 1 < roundsA)
+					if (S2_PERSIST_INSTRUMENTED && i + 1 < roundsA && i < 6)
 					{
 						stampAt(8 + i);
 					}
@@ -878,6 +950,16 @@ template <int POINTS, int RPH, int SR, int SL = 0> __global__ __launch_bounds__(
 				if ((seamMask >> i) & 1u)
 				{
 					preB[i] = prepWide<POINTS>(rB[i], ldq, lcoef, op.inv_h, op.useBias, salt);
+				}
+			}
+			// (... and of the parked seam rounds: their records come out of LDS for it, and again for the chain)
+			WidePrep preP[SL > 0 ? SL : 1];
+#pragma unroll
+			for (int i = SR; i < ST; ++i)
+			{
+				if (S2_WIDE_PARKED_PREP_EARLY && ((seamMask >> i) & 1u))
+				{
+					preP[i - SR] = prepWide<POINTS>(unparkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * sw, sw), ldq, lcoef, op.inv_h, op.useBias, salt);
 				}
 			}
 			int fail = 0;
@@ -938,11 +1020,18 @@ template <int POINTS, int RPH, int SR, int SL = 0> __global__ __launch_bounds__(
 				{
 					if ((seamMask >> i) & 1u)
 					{
-						float4* slot = lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * S2_WIDE_THREADS;
-						WideRegs p = unparkWide(slot);
-						const WidePrep late = prepWide<POINTS>(p, ldq, lcoef, op.inv_h, op.useBias, salt);
-						chainWide<POINTS>(p, late, lvel, lmass, lcoef, salt);
-						slot[5 * S2_WIDE_THREADS] = make_float4(p.imp[0].x, p.imp[0].y, p.imp[1].x, p.imp[1].y);
+						float4* slot = lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * sw;
+						WideRegs p = unparkWide(slot, sw);
+						if (S2_WIDE_PARKED_PREP_EARLY)
+						{
+							chainWide<POINTS>(p, preP[i - SR < SL ? i - SR : 0], lvel, lmass, lcoef, salt);
+						}
+						else
+						{
+							const WidePrep late = prepWide<POINTS>(p, ldq, lcoef, op.inv_h, op.useBias, salt);
+							chainWide<POINTS>(p, late, lvel, lmass, lcoef, salt);
+						}
+						slot[5 * sw] = make_float4(p.imp[0].x, p.imp[0].y, p.imp[1].x, p.imp[1].y);
 					}
 					__syncthreads();
 				}
@@ -971,6 +1060,14 @@ template <int POINTS, int RPH, int SR, int SL = 0> __global__ __launch_bounds__(
 			storeWide(c, rA[s], kOfSlot(s));
 		}
 	}
+#pragma unroll
+	for (int j = 0; j < IL; ++j)
+	{
+		if (kOfParked(j) >= 0)
+		{
+			storeWide(c, unparkWide(lparkedI + j * S2_WIDE_PARKED_RECORDS * iw, iw), kOfParked(j));
+		}
+	}
 	// the right seam's impulses are stored by this workgroup (its left neighbour of that seam), nobody stores twice
 #pragma unroll
 	for (int i = 0; i < SR; ++i)
@@ -987,7 +1084,7 @@ template <int POINTS, int RPH, int SR, int SL = 0> __global__ __launch_bounds__(
 		int seam, k;
 		if (i < roundsB && seamItem(i, seam, k) && seam == 1)
 		{
-			storeWide(c, unparkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * S2_WIDE_THREADS), k);
+			storeWide(c, unparkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * sw, sw), k);
 		}
 	}
 	stampAt(7);
@@ -1001,31 +1098,36 @@ template <int POINTS, int RPH, int SR, int SL = 0> __global__ __launch_bounds__(
 // Eligibility (checked by the caller, solver_executor.h widePlan): TGS_Soft with the current-anchor warm start on a partition with
 // at most 6 interior colour batches per strip and 3 per seam, or 8 and 2 (pv.maxRoundsA, pv.maxSeamRounds): five or six resident
 // records per lane fit its 256 registers beside the round's working set, seven do not (measured: 160 spilled registers).
-template <int RPH, int SR, int SL = 0>
+template <int RPH, int SR, int SL = 0, int IL = 0>
 static void launchWide(hipStream_t s, dim3 grid, size_t lds, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount)
 {
 	const dim3 block(S2_WIDE_THREADS);
-	lds += (size_t)SL * S2_WIDE_PARKED_RECORDS * S2_WIDE_THREADS * sizeof(float4);
+	lds += (size_t)S2_WIDE_PARKED_RECORDS * ((size_t)SL * pv.parkSeamWidth + (size_t)IL * pv.parkInteriorWidth) * sizeof(float4);
 	if (pv.allTwoPoints)
 	{
-		wideStepKernel<2, RPH, SR, SL><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
+		wideStepKernel<2, RPH, SR, SL, IL><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
 	}
 	else
 	{
-		wideStepKernel<0, RPH, SR, SL><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
+		wideStepKernel<0, RPH, SR, SL, IL><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
 	}
 }
 
 // records of dynamic LDS the variant for (maxRoundsA, maxSeamRounds) needs beside the bodies, the ops and the three fixed records;
 // -1: no variant takes that partition (Executor::widePlan)
-int wideParkedRecords(int maxRoundsA, int maxSeamRounds, int force)
+int wideParkedRecords(int maxRoundsA, int maxSeamRounds, int force, int parkSeamWidth, int parkInteriorWidth)
 {
 	if (maxRoundsA > 8 || maxSeamRounds > 4)
 	{
 		return -1;
 	}
 	const bool inRegisters = !force && ((maxRoundsA <= 6 && maxSeamRounds <= 3) || maxSeamRounds <= 2);
-	return inRegisters ? 0 : 2 * S2_WIDE_PARKED_RECORDS * S2_WIDE_THREADS;
+	if (inRegisters)
+	{
+		return 0;
+	}
+	// (the variants below: two parked seam rounds, and two parked interior rounds when a strip needs more than six colours)
+	return 2 * S2_WIDE_PARKED_RECORDS * parkSeamWidth + (maxRoundsA > 6 ? 2 * S2_WIDE_PARKED_RECORDS * parkInteriorWidth : 0);
 }
 
 void launchWideStep(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount)
@@ -1041,7 +1143,7 @@ void launchWideStep(hipStream_t s, const ContactView& c, const BodyView& g, cons
 		}
 		else
 		{
-			launchWide<4, 2, 2>(s, grid, lds, c, g, a, pv, ops, opCount);
+			launchWide<3, 2, 2, 2>(s, grid, lds, c, g, a, pv, ops, opCount);
 		}
 	}
 	else if (pv.maxRoundsA <= 6 && pv.maxSeamRounds <= 2)
@@ -1062,7 +1164,9 @@ void launchWideStep(hipStream_t s, const ContactView& c, const BodyView& g, cons
 	}
 	else
 	{
-		launchWide<4, 2, 2>(s, grid, lds, c, g, a, pv, ops, opCount);
+		// seven or eight interior colours AND three or four seam colours (a pile after an impact): six interior and two seam rounds in
+		// registers, the rest parked -- the <4, 2, 2> layout of eight interior records per lane pair spilled 41 registers
+		launchWide<3, 2, 2, 2>(s, grid, lds, c, g, a, pv, ops, opCount);
 	}
 }
 
@@ -1421,8 +1525,8 @@ int wideKernelSetup()
 	}
 	const void* steps[] = {(const void*)wideStepKernel<0, 3, 2>, (const void*)wideStepKernel<2, 3, 2>, (const void*)wideStepKernel<0, 3, 3>,
 						   (const void*)wideStepKernel<2, 3, 3>, (const void*)wideStepKernel<0, 4, 2>, (const void*)wideStepKernel<2, 4, 2>,
-						   (const void*)wideStepKernel<0, 3, 2, 2>, (const void*)wideStepKernel<2, 3, 2, 2>, (const void*)wideStepKernel<0, 4, 2, 2>,
-						   (const void*)wideStepKernel<2, 4, 2, 2>};
+						   (const void*)wideStepKernel<0, 3, 2, 2>, (const void*)wideStepKernel<2, 3, 2, 2>, (const void*)wideStepKernel<0, 3, 2, 2, 2>,
+						   (const void*)wideStepKernel<2, 3, 2, 2, 2>};
 	for (const void* f : steps)
 	{
 		hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

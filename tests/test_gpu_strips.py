@@ -390,6 +390,39 @@ def test_wide_kernel_with_parked_seam_rounds(base, strip_bodies):
     common.compare_exact(results[0], results[1], "parked seam rounds vs registers")
 
 
+@pytest.mark.parametrize("extra", [1, 2])
+def test_wide_kernel_with_parked_interior_rounds(extra):
+    """A body with seven or eight constraints inside a strip (a ball in the pile) forces a seventh / eighth interior colour on that
+    strip: the 512-thread kernel keeps six interior rounds in registers and parks the rest in LDS (variant <3,2,2,2>).  Built here by
+    giving one box of the pyramid `extra` more contacts with boxes two hops away; same bits as the oracle and as the 256-thread kernel."""
+    b, c, j = common.copy3(synthetic.pyramid(100))
+    a0, b0 = c["bodyA"].astype(int), c["bodyB"].astype(int)
+    nbrs = {}
+    for x, y in zip(a0.tolist(), b0.tolist()):
+        nbrs.setdefault(x, set()).add(y), nbrs.setdefault(y, set()).add(x)
+    hub = next(i for i in range(len(b) // 2, len(b)) if len(nbrs.get(i, ())) == 6 and b["invMass"][i] > 0)
+    two_hops = sorted({t for n in nbrs[hub] for t in nbrs[n] if t != hub and t not in nbrs[hub] and b["invMass"][t] > 0})
+    added = c[:extra].copy()
+    template = int(np.flatnonzero((a0 == hub) | (b0 == hub))[0])
+    for e in range(extra):
+        added[e] = c[template]
+        added[e]["bodyA"], added[e]["bodyB"] = hub, two_hops[e]
+    pre = (b, np.concatenate([c, added]), j)
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    results = []
+    for wide in (1, 0):
+        with hip.Solver(0) as s:
+            s.set_option("strip_patience", 0)
+            s.set_option("wide", wide)
+            state = common.copy3(pre)
+            for step in range(3):
+                state = gpu_vs_oracle(s, params, state, "hub of degree %d, wide=%d step %d" % (6 + extra, wide, step))
+            st = s.stats()
+            assert st["persistent"] == 1 and st["pairLanes"] == (2 if wide else 0), st
+            results.append(state)
+    common.compare_exact(results[0], results[1], "parked interior rounds vs the 256-thread kernel")
+
+
 def test_a_dead_hand_off_falls_back_to_the_multi_launch_path():
     """Fault injection: workgroup 1 of the persistent kernel never publishes its seam bodies (what a non-resident
     workgroup looks like to its neighbours).  The polls give up, the epilogue leaves the wire arrays alone, the host

@@ -1537,10 +1537,50 @@ S2_DEV Rot loadRotOnly(const BodyView& b, int i)
 	return q;
 }
 
-template <int MODE> S2_DEV JState loadJoint(const JointView& j, int k)
+// A joint view whose arrays live in LDS (generic_kernel.hip stages a strip's joint records there for the whole step): the same
+// member names as JointView, each array a typed LDS column, so that the functions below -- templated on the view -- read them with
+// ds_read instead of global (or, through a generic pointer, flat) loads.  Index 0 is the first staged joint.
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef int i2v __attribute__((ext_vector_type(2)));
+S2_DEV float4 toHip(f4v v) { return make_float4(v.x, v.y, v.z, v.w); }
+S2_DEV float2 toHip(f2v v) { return make_float2(v.x, v.y); }
+S2_DEV int2 toHip(i2v v) { return make_int2(v.x, v.y); }
+S2_DEV f4v toLds(float4 v) { return f4v{v.x, v.y, v.z, v.w}; }
+S2_DEV f2v toLds(float2 v) { return f2v{v.x, v.y}; }
+S2_DEV i2v toLds(int2 v) { return i2v{v.x, v.y}; }
+template <class T, class V> struct LdsColumn
+{
+	typedef __attribute__((address_space(3))) V Cell;
+	Cell* p;
+	struct Ref
+	{
+		Cell* q;
+		S2_DEV operator T() const { return toHip(*q); }
+		S2_DEV void operator=(T v) const { *q = toLds(v); }
+	};
+	S2_DEV Ref operator[](int k) const { return Ref{p + k}; }
+};
+struct LdsJointView
+{
+	int2* bodies; // (not staged: pool slots are only read by the global-index accessors)
+	LdsColumn<int2, i2v> localBodies;
+	LdsColumn<float4, f4v> frame, mass, pivot, soft, axial, limits, misc;
+	LdsColumn<float2, f2v> centerDiff0, impulse;
+};
+
+template <int MODE, class JV> S2_DEV JState loadJoint(const JV& j, int k)
 {
 	JState s;
-	int2 bd = MODE == S2_IDX_LOCAL ? j.localBodies[k] : j.bodies[k];
+	int2 bd;
+	if (MODE == S2_IDX_LOCAL)
+	{
+		bd = j.localBodies[k];
+	}
+	else
+	{
+		bd = j.bodies[k];
+	}
 	float4 fr = j.frame[k], ms = j.mass[k], pv = j.pivot[k], sf = j.soft[k], ax = j.axial[k], lm = j.limits[k], mc = j.misc[k];
 	float2 cd = j.centerDiff0[k], im = j.impulse[k];
 	s.ia = bd.x, s.ib = bd.y;
@@ -1557,7 +1597,7 @@ template <int MODE> S2_DEV JState loadJoint(const JointView& j, int k)
 	return s;
 }
 
-S2_DEV void storeJointImpulses(const JointView& j, int k, const JState& s)
+template <class JV> S2_DEV void storeJointImpulses(const JV& j, int k, const JState& s)
 {
 	j.impulse[k] = make_float2(s.impulse.x, s.impulse.y);
 	j.axial[k] = make_float4(s.motorImpulse, s.lowerImpulse, s.upperImpulse, s.bodyI);
@@ -1639,8 +1679,8 @@ S2_DEV void revoluteMotor(JState& s, float h, float& wA, float& wB)
 	wB += s.iB * impulse;
 }
 
-template <int KIND, class BA>
-S2_DEV void solveJointsOne(const JointView& jv, const BA& b, const StepConsts& sc, float h, float inv_h, int useBias, int k)
+template <int KIND, class BA, class JV>
+S2_DEV void solveJointsOne(const JV& jv, const BA& b, const StepConsts& sc, float h, float inv_h, int useBias, int k)
 {
 	JState s = loadJoint<BA::kMode>(jv, k);
 

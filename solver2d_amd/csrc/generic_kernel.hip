@@ -22,6 +22,8 @@
 // The sequential-equivalent order is the multi-launch strip path's: per op, strip by strip colour-major, then seam by seam
 // (s2amd_get_contact_order / _joint_order report it).
 
+#include <type_traits>
+
 #include "body_ops.h"
 #include "group_ops.h"
 #include "persist_handoff.h"
@@ -60,8 +62,8 @@ S2_DEV void putBody(gu64* p, int poseOffset, unsigned epoch, float4 v, float4 d,
 }
 
 // one constraint op over a list of colour batches (the switch of groupKernel, one constraint per call)
-template <class BA>
-S2_DEV void sweepOp(const Op& op, const ContactView& c, const JointView& jv, const BA& lb, const StepConsts& sc, s2amdContact* wire, const int4* cBatches,
+template <class BA, class JV>
+S2_DEV void sweepOp(const Op& op, const ContactView& c, const JV& jv, const BA& lb, const StepConsts& sc, s2amdContact* wire, const int4* cBatches,
 					int cb0, int cb1, const int4* jBatches, int jb0, int jb1, int jBase)
 {
 	// jBase: the joint view's arrays start at sweep position jBase (a view of LDS-resident records: genericStepKernel), 0 for the global arrays
@@ -255,60 +257,41 @@ __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactV
 
 	// ---- joints resident in LDS (stageJoints: the host has found room for every strip's): the records of this strip's interior
 	// joints and of the seam it sweeps -- one contiguous range of sweep positions each -- are read from HBM / L2 once per step
-	// instead of once per sweep; the per-joint functions reach them through views whose arrays point into LDS.  Sweeps write
+	// instead of once per sweep; the per-joint functions reach them through a view of typed LDS columns (constraint_ops.h: LdsJointView).  Sweeps write
 	// `impulse` and `axial` (constraint_ops.h: solveJointsOne): those two go back at the end.
 	const int jb0 = ga.jBatchOffsets[strip], jb1 = ga.jBatchOffsets[strip + 1];
 	const int sjb0 = seam >= 0 ? gb.jBatchOffsets[seam] : 0, sjb1 = seam >= 0 ? gb.jBatchOffsets[seam + 1] : 0;
 	const int jA0 = jb0 < jb1 ? ga.jBatches[jb0].x : 0, jA1 = jb0 < jb1 ? ga.jBatches[jb1 - 1].y : 0;
 	const int jS0 = sjb0 < sjb1 ? gb.jBatches[sjb0].x : 0, jS1 = sjb0 < sjb1 ? gb.jBatches[sjb1 - 1].y : 0;
 	const int njA = jA1 - jA0, nj = njA + (jS1 - jS0);
-	JointView ljA = jv, ljS = jv;
+	LdsJointView ljA{}, ljS{};
 	int jBaseA = 0, jBaseS = 0;
-	float2* blkImpulse = nullptr;
-	float4* blkAxial = nullptr;
-	if (stageJoints && nj > 0)
+	const bool jointsInLds = stageJoints != 0 && nj > 0;
+	LdsColumn<float2, f2v> blkImpulse{nullptr};
+	LdsColumn<float4, f4v> blkAxial{nullptr};
+	if (jointsInLds)
 	{
 		char* at = (char*)(lnear + 4) + S2_GENERIC_BATCH_RECORDS * sizeof(int4);
 		auto kOf = [&](int i) { return i < njA ? jA0 + i : jS0 + (i - njA); };
-		auto stage4 = [&](float4* JointView::*member) {
-			float4* blk = (float4*)at;
-			at += (size_t)nj * sizeof(float4);
+		// one typed LDS column per array: the strip's interior joints first, the seam's behind them
+		auto stage = [&](auto& colA, auto& colS, const auto* src) {
+			typedef typename std::remove_reference_t<decltype(colA)>::Cell Cell;
+			Cell* blk = (Cell*)at;
+			at += (size_t)nj * sizeof(Cell);
 			for (int i = tid; i < nj; i += S2_GENERIC_THREADS)
 			{
-				blk[i] = (jv.*member)[kOf(i)];
+				blk[i] = toLds(src[kOf(i)]);
 			}
-			ljA.*member = blk;
-			ljS.*member = blk + njA;
-			return blk;
+			colA.p = blk, colS.p = blk + njA;
 		};
-		auto stage2 = [&](float2* JointView::*member) {
-			float2* blk = (float2*)at;
-			at += (size_t)nj * sizeof(float2);
-			for (int i = tid; i < nj; i += S2_GENERIC_THREADS)
-			{
-				blk[i] = (jv.*member)[kOf(i)];
-			}
-			ljA.*member = blk;
-			ljS.*member = blk + njA;
-			return blk;
-		};
-		stage4(&JointView::frame), stage4(&JointView::mass), stage4(&JointView::pivot), stage4(&JointView::soft);
-		blkAxial = stage4(&JointView::axial);
-		stage4(&JointView::limits), stage4(&JointView::misc), stage4(&JointView::origin);
-		stage2(&JointView::centerDiff0), stage2(&JointView::target);
-		blkImpulse = stage2(&JointView::impulse);
-		{
-			int2* blk = (int2*)at;
-			for (int i = tid; i < nj; i += S2_GENERIC_THREADS)
-			{
-				blk[i] = jv.localBodies[kOf(i)];
-			}
-			ljA.localBodies = blk;
-			ljS.localBodies = blk + njA;
-		}
+		stage(ljA.frame, ljS.frame, jv.frame), stage(ljA.mass, ljS.mass, jv.mass), stage(ljA.pivot, ljS.pivot, jv.pivot);
+		stage(ljA.soft, ljS.soft, jv.soft), stage(ljA.axial, ljS.axial, jv.axial), stage(ljA.limits, ljS.limits, jv.limits);
+		stage(ljA.misc, ljS.misc, jv.misc);
+		stage(ljA.centerDiff0, ljS.centerDiff0, jv.centerDiff0), stage(ljA.impulse, ljS.impulse, jv.impulse);
+		stage(ljA.localBodies, ljS.localBodies, jv.localBodies);
+		blkImpulse = ljA.impulse, blkAxial = ljA.axial;
 		// (what stays in global memory is addressed from the same origin: in-range pointers only)
 		ljA.bodies = jv.bodies + jA0, ljS.bodies = jv.bodies + jS0;
-		ljA.jointIndex = jv.jointIndex + jA0, ljS.jointIndex = jv.jointIndex + jS0;
 		jBaseA = jA0, jBaseS = jS0;
 		__syncthreads();
 	}
@@ -387,7 +370,14 @@ __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactV
 				break;
 		}
 		// ---- a constraint op: interiors ----
-		sweepOp(op, c, ljA, lb, sc, wire, batchC, 0, nC, batchJ, 0, nJ, jBaseA);
+		if (jointsInLds)
+		{
+			sweepOp(op, c, ljA, lb, sc, wire, batchC, 0, nC, batchJ, 0, nJ, jBaseA);
+		}
+		else
+		{
+			sweepOp(op, c, jv, lb, sc, wire, batchC, 0, nC, batchJ, 0, nJ, 0);
+		}
 		if ((op.code == OP_JOINT_SWEEP ? seamJoints : seamContacts) == 0)
 		{
 			continue; // nothing of this kind in any seam: every workgroup skips the hand-offs
@@ -423,7 +413,14 @@ __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactV
 		// ---- the seam to my right ----
 		if (seam >= 0)
 		{
-			sweepOp(op, c, ljS, sb, sc, wire, batchSC, 0, nSC, batchSJ, 0, nSJ, jBaseS);
+			if (jointsInLds)
+			{
+				sweepOp(op, c, ljS, sb, sc, wire, batchSC, 0, nSC, batchSJ, 0, nSJ, jBaseS);
+			}
+			else
+			{
+				sweepOp(op, c, jv, sb, sc, wire, batchSC, 0, nSC, batchSJ, 0, nSJ, 0);
+			}
 		}
 		// ---- return: the right neighbour's bodies back to their owner, mine back from the left neighbour ----
 		epoch += 1;
@@ -449,7 +446,7 @@ __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactV
 		bad = __syncthreads_or(fail);
 	}
 
-	if (blkImpulse != nullptr && !bad)
+	if (jointsInLds && !bad)
 	{
 		for (int i = tid; i < nj; i += S2_GENERIC_THREADS)
 		{
@@ -485,8 +482,8 @@ int genericKernelSetup()
 size_t genericStepLds(int bodies, int seamBodies, int exports, int opCount, int useDq0, int stagedJoints)
 {
 	const size_t records = (size_t)(useDq0 ? 3 : 2) * bodies + (size_t)(bodies + 1) / 2 + (size_t)(seamBodies + exports + 3) / 4 + 2 * (size_t)opCount + 1 + S2_GENERIC_BATCH_RECORDS; // (+ the census flags, the batch descriptors)
-	// a staged joint: eight 16-byte arrays, three 8-byte ones and its local body pair (JointView)
-	return records * 16 + (size_t)stagedJoints * (8 * 16 + 3 * 8 + 8) + (stagedJoints ? 64 : 0);
+	// a staged joint: the seven 16-byte and two 8-byte arrays the sweeps read, and its local body pair (LdsJointView)
+	return records * 16 + (size_t)stagedJoints * (7 * 16 + 2 * 8 + 8) + (stagedJoints ? 64 : 0);
 }
 
 void launchGenericStep(hipStream_t s, const ContactView& c, const JointView& j, const BodyView& g, const GroupTable& a, const GroupTable& b, const PersistView& pv,

@@ -29,17 +29,17 @@ S2_DEV void prefetchContact(const ContactView& c, int k)
 		asm volatile("" ::"v"(i.x), "v"(i.y));
 	}
 }
-S2_DEV void prefetchJoint(const JointView& j, int k)
+template <class JV> S2_DEV void prefetchJoint(const JV& j, int k)
 {
 	int2 b = j.localBodies[k];
 	asm volatile("" ::"v"(b.x), "v"(b.y));
-	touch(j.frame[k]);
-	touch(j.mass[k]);
-	touch(j.pivot[k]);
-	touch(j.soft[k]);
-	touch(j.axial[k]);
-	touch(j.limits[k]);
-	touch(j.misc[k]);
+	touch(float4(j.frame[k]));
+	touch(float4(j.mass[k]));
+	touch(float4(j.pivot[k]));
+	touch(float4(j.soft[k]));
+	touch(float4(j.axial[k]));
+	touch(float4(j.limits[k]));
+	touch(float4(j.misc[k]));
 	float2 a = j.centerDiff0[k], i = j.impulse[k];
 	asm volatile("" ::"v"(a.x), "v"(a.y), "v"(i.x), "v"(i.y));
 }

@@ -219,7 +219,7 @@ def island_sharded_leg(ranks, islands, base, vel, pos, steps, warmup, graph=True
     ranks.barrier_sync(gpu)
     elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
     if dump and ranks.rank == 0:
-        np.save(dump, rs.world_poses())
+        np.save(dump, rs.world_bodies())
     gpu.set_option("async", 0)
     gpu.step_resident(params)
     st = gpu.stats()
@@ -235,8 +235,8 @@ def island_sharded_leg(ranks, islands, base, vel, pos, steps, warmup, graph=True
         "value": C_total * sweeps * steps / elapsed, "unit": "constraint-iters/s", "n_gpus": ranks.world, "steps": steps, "warmup": warmup,
         "ms_per_step": 1e3 * elapsed / steps, "scaling": "strong",
         "config": {"workload": "one world of %d base-%d pyramids (%d bodies, %d two-point constraints, %d islands), s2_solverTGS_Soft %d/%d; "
-                               "islands bin-packed onto %d rank(s), shards resident, one all-gather of {position, rot} records per step "
-                               "(%d bytes per rank)" % (islands, base, len(world[0]), C_total, islands, vel, pos, ranks.world, rs.record * 16),
+                               "islands bin-packed onto %d rank(s), shards resident, one all-gather of the per-island body arrays {position, rot, v, w} per step "
+                               "(%d bytes per rank)" % (islands, base, len(world[0]), C_total, islands, vel, pos, ranks.world, rs.record * 32),
                    "constraints": C_total, "constraints_this_rank": mine, "islands_this_rank": int((sw.shard_of_island == ranks.rank).sum()),
                    "solve_sweeps_per_step": sweeps, "kernel_launches_per_step": st["kernelLaunches"], "lds_groups_this_rank": st["groupCount"],
                    "device_ms_per_step": st["deviceMs"], "graph_replay": bool(st["graphReplayed"]), "trajectory": "consecutive resident steps (no restore)"},

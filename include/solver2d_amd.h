@@ -382,6 +382,9 @@ int s2amd_export_poses(s2amdSolver* solver, void* devicePoses, int32_t capacity)
  * in `slot` (0..3); s2amd_export_wait blocks the host until that event has fired.  Lets a host enqueue step s+1 before it
  * waits for the poses of step s and hands them to the collective: the device never idles between steps. */
 int s2amd_export_poses_async(s2amdSolver* solver, void* devicePoses, int32_t capacity, int32_t slot);
+/* (API 2) ... the per-island body arrays of a sharded world (28 bytes per body): TWO 16-byte records per body slot,
+ * {position.x, position.y, rot.s, rot.c} and {linearVelocity.x, linearVelocity.y, angularVelocity, 0}; capacity in bodies. */
+int s2amd_export_bodies_async(s2amdSolver* solver, void* deviceRecords, int32_t capacity, int32_t slot);
 int s2amd_export_wait(s2amdSolver* solver, int32_t slot);
 
 /* Device buffers for callers that have no device allocator of their own (a host language behind cgo / JNI / ctypes): the

@@ -264,6 +264,19 @@ __global__ __launch_bounds__(S2_BLOCK) void exportPosesKernel(const s2amdBody* w
 	out[i] = make_float4(w->position[0], w->position[1], w->rot[0], w->rot[1]);
 }
 
+// ... or the per-island body arrays of SURVEY.md 8e: {position, rot} and {linearVelocity, angularVelocity} (28 bytes in two 16-byte records)
+__global__ __launch_bounds__(S2_BLOCK) void exportBodiesKernel(const s2amdBody* wire, int n, float4* out)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+	{
+		return;
+	}
+	const s2amdBody* w = wire + i;
+	out[2 * i] = make_float4(w->position[0], w->position[1], w->rot[0], w->rot[1]);
+	out[2 * i + 1] = make_float4(w->linearVelocity[0], w->linearVelocity[1], w->angularVelocity, 0.0f);
+}
+
 static inline dim3 gridFor(int n)
 {
 	return dim3((unsigned)((n + S2_BLOCK - 1) / S2_BLOCK));
@@ -348,11 +361,18 @@ void launchXpbdProject(hipStream_t s, const BodyView& b, float inv_h)
 	}
 }
 
-void launchExportPoses(hipStream_t s, const s2amdBody* wire, int n, void* out)
+void launchExportPoses(hipStream_t s, const s2amdBody* wire, int n, void* out, int withVelocities)
 {
 	if (n > 0)
 	{
-		exportPosesKernel<<<gridFor(n), dim3(S2_BLOCK), 0, s>>>(wire, n, (float4*)out);
+		if (withVelocities)
+		{
+			exportBodiesKernel<<<gridFor(n), dim3(S2_BLOCK), 0, s>>>(wire, n, (float4*)out);
+		}
+		else
+		{
+			exportPosesKernel<<<gridFor(n), dim3(S2_BLOCK), 0, s>>>(wire, n, (float4*)out);
+		}
 	}
 }
 

@@ -103,7 +103,7 @@ void launchJacobiApply(hipStream_t s, const BodyView& b, const ContactView& c, c
 void launchPatchWords(hipStream_t s, const void* devicePatches, int n);
 void launchXpbdIntegrate(hipStream_t s, const BodyView& b, float h);
 void launchXpbdProject(hipStream_t s, const BodyView& b, float inv_h);
-void launchExportPoses(hipStream_t s, const s2amdBody* wire, int n, void* out);
+void launchExportPoses(hipStream_t s, const s2amdBody* wire, int n, void* out, int withVelocities = 0);
 
 // joints
 void launchPrepareJoints(hipStream_t s, int kind, const JointView& j, const BodyView& b, const s2amdJoint* wire, const s2amdBody* wireBodies,

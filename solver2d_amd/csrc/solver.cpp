@@ -536,6 +536,27 @@ int s2amd_export_poses_async(s2amdSolver* s, void* devicePoses, int32_t capacity
 	return S2AMD_OK;
 }
 
+int s2amd_export_bodies_async(s2amdSolver* s, void* deviceRecords, int32_t capacity, int32_t slot)
+{
+	if (!s || !s->resident)
+	{
+		return fail(S2AMD_E_STATE, "nothing resident");
+	}
+	if (!deviceRecords || capacity < s->bodyCapacity || slot < 0 || slot >= 4)
+	{
+		return fail(S2AMD_E_CAPACITY, "record buffer missing or too small, or slot outside 0..3");
+	}
+	HIP_TRY(hipSetDevice(s->device));
+	if (!s->evExport[slot])
+	{
+		HIP_TRY(hipEventCreateWithFlags(&s->evExport[slot], hipEventDisableTiming));
+	}
+	launchExportPoses(s->stream, (const s2amdBody*)s->dBodies.p, s->bodyCapacity, deviceRecords, 1);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(s->evExport[slot], s->stream));
+	return S2AMD_OK;
+}
+
 int s2amd_export_wait(s2amdSolver* s, int32_t slot)
 {
 	if (!s || slot < 0 || slot >= 4 || !s->evExport[slot])

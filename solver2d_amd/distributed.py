@@ -66,9 +66,10 @@ def step_sharded(sw, solve_fn, params, dist=None, torch=None, device="cpu"):
 class ResidentShardedWorld:
     """The device-resident form of ShardedWorld (BASELINE.json configs[4]): every rank uploads ITS shard
     once (s2amd_upload), advances it with s2amd_step_resident -- no collective inside a step, islands share no movable
-    body -- and contributes one fixed-size record of body poses per step to ONE all-gather of device tensors
+    body -- and contributes one fixed-size record of its body arrays per step -- {position, rot, linearVelocity, angularVelocity}:
+    the 28 bytes per body of SURVEY.md 8e, in two 16-byte records -- to ONE all-gather of device tensors
     (torch.distributed backend "nccl" = RCCL over xGMI; "gloo" moves the same records through the host in the tests).
-    Nothing but the poses ever leaves a GPU: constraints, impulses and velocities stay in the HBM of their owner.
+    Nothing but those ever leaves a GPU: constraints and impulses stay in the HBM of their owner.
 
     The host loop is software-pipelined like bench.py's replica loop: step s+1 is enqueued on the solver's stream BEFORE
     the host waits for the poses of step s and hands them to the collective, through two pose buffers."""
@@ -82,12 +83,12 @@ class ResidentShardedWorld:
         self.record = max(1, max(len(s.bodies) for s in sharded.shards))
         self.raw = dist is None  # a single process: no collective, no torch -- pose records in buffers of the library's own
         if self.raw:
-            self.pose_ptr = [solver.device_alloc(self.record * 16) for _ in range(2)]
+            self.pose_ptr = [solver.device_alloc(self.record * 32) for _ in range(2)]
             self.last = None
         else:
-            self.pose = [torch.zeros((self.record, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+            self.pose = [torch.zeros((self.record, 8), dtype=torch.float32, device="cuda") for _ in range(2)]
             self.pose_ptr = [t.data_ptr() for t in self.pose]
-            self.gathered = torch.zeros((sharded.world_size * self.record, 4), dtype=torch.float32, device="cuda" if backend == "nccl" else "cpu")
+            self.gathered = torch.zeros((sharded.world_size * self.record, 8), dtype=torch.float32, device="cuda" if backend == "nccl" else "cpu")
         self.gather_done = [None, None]
         self.enqueued = 0
         self.exchanged = 0
@@ -99,7 +100,7 @@ class ResidentShardedWorld:
             self.gather_done[b].synchronize()  # the collective that last read this buffer (two steps ago)
             self.gather_done[b] = None
         self.solver.step_resident(params)
-        self.solver.export_poses_async(self.pose_ptr[b], self.record, b)
+        self.solver.export_bodies_async(self.pose_ptr[b], self.record, b)
         self.enqueued += 1
 
     def exchange(self):
@@ -125,21 +126,27 @@ class ResidentShardedWorld:
                 self.enqueue_step(params)
             self.exchange()
 
-    def world_poses(self):
-        """float32[bodies of the whole world, 4] {position, rot} as of the last exchange, assembled from the gathered
-        records: every body from the rank that owns it (static bodies from any shard that holds a replica)."""
+    def world_bodies(self):
+        """float32[bodies of the whole world, 8] {position, rot, linearVelocity, angularVelocity, 0} as of the last exchange,
+        assembled from the gathered records: every body from the rank that owns it (static bodies from any shard that holds a replica)."""
         if self.raw:
-            g = self.solver.device_read(self.pose_ptr[self.last], (1, self.record, 4))
+            g = self.solver.device_read(self.pose_ptr[self.last], (1, self.record, 8))
         else:
             self.torch.cuda.synchronize()
-            g = self.gathered.cpu().numpy().reshape(self.sw.world_size, self.record, 4)
-        out = np.zeros((len(self.sw.bodies), 4), dtype=np.float32)
+            g = self.gathered.cpu().numpy().reshape(self.sw.world_size, self.record, 8)
+        out = np.zeros((len(self.sw.bodies), 8), dtype=np.float32)
         out[:, 0:2] = self.sw.bodies["position"]
         out[:, 2:4] = self.sw.bodies["rot"]
+        out[:, 4:6] = self.sw.bodies["linearVelocity"]
+        out[:, 6] = self.sw.bodies["angularVelocity"]
         for r, sh in enumerate(self.sw.shards):
             rows = g[r, : len(sh.bodies)]
             out[sh.body_ids[sh.owned_body]] = rows[sh.owned_body]
         return out
+
+    def world_poses(self):
+        """float32[bodies of the whole world, 4] {position, rot}: the first half of world_bodies()."""
+        return self.world_bodies()[:, 0:4]
 
     def close(self):
         if self.raw:

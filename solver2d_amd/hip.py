@@ -19,7 +19,7 @@ EXPORTS = [
     "s2amd_api_version", "s2amd_device_count", "s2amd_device_bus_id", "s2amd_last_error", "s2amd_create", "s2amd_destroy",
     "s2amd_solve", "s2amd_upload", "s2amd_step_resident", "s2amd_download", "s2amd_save_bodies",
     "s2amd_restore_bodies", "s2amd_get_contact_order", "s2amd_get_joint_order", "s2amd_get_stats",
-    "s2amd_set_option", "s2amd_export_poses", "s2amd_export_poses_async", "s2amd_export_wait", "s2amd_measure_dominant", "s2amd_refit_shapes", "s2amd_find_pairs", "s2amd_synchronize", "s2amd_update_contacts", "s2amd_find_islands", "s2amd_color_constraints",
+    "s2amd_set_option", "s2amd_export_poses", "s2amd_export_poses_async", "s2amd_export_bodies_async", "s2amd_export_wait", "s2amd_measure_dominant", "s2amd_refit_shapes", "s2amd_find_pairs", "s2amd_synchronize", "s2amd_update_contacts", "s2amd_find_islands", "s2amd_color_constraints",
     "s2amd_world_upload", "s2amd_world_step", "s2amd_world_download", "s2amd_world_find_pairs", "s2amd_world_set_contacts",
     "s2amd_device_alloc", "s2amd_device_free", "s2amd_device_read", "s2amd_world_separated", "s2amd_world_download_boxes", "s2amd_world_set_refit_order", "s2amd_world_download_step",
 ]
@@ -60,6 +60,7 @@ def load():
     L.s2amd_set_option.argtypes = [vp, ctypes.c_char_p, i32]
     L.s2amd_export_poses.argtypes = [vp, vp, i32]
     L.s2amd_export_poses_async.argtypes = [vp, vp, i32, i32]
+    L.s2amd_export_bodies_async.argtypes = [vp, vp, i32, i32]
     L.s2amd_export_wait.argtypes = [vp, i32]
     L.s2amd_measure_dominant.argtypes = [vp, ctypes.POINTER(wire.StepParams), i32, ctypes.POINTER(ctypes.c_float),
                                          ctypes.POINTER(i32), ctypes.POINTER(i32)]
@@ -162,6 +163,10 @@ class Solver:
     def export_poses(self, device_ptr, capacity):
         """{position, rot} per body into a caller-owned device buffer (float32[capacity, 4])."""
         _check(load().s2amd_export_poses(self._h, ctypes.c_void_p(int(device_ptr)), int(capacity)))
+
+    def export_bodies_async(self, device_ptr, capacity, slot):
+        """Two float4 per body -- {position, rot}, {linearVelocity, angularVelocity, 0} -- enqueued like export_poses_async."""
+        _check(load().s2amd_export_bodies_async(self._h, ctypes.c_void_p(int(device_ptr)), int(capacity), int(slot)))
 
     def export_poses_async(self, device_ptr, capacity, slot):
         """export_poses enqueued behind the steps already on the solver's stream; pair with export_wait(slot)."""

@@ -86,9 +86,10 @@ def _unsharded_poses(islands, base, steps):
         s.upload(*world)
         for _ in range(steps):
             s.step_resident(params)
-        buf = s.device_alloc(len(world[0]) * 16)
-        s.export_poses(buf, len(world[0]))
-        out = s.device_read(buf, (len(world[0]), 4))
+        buf = s.device_alloc(len(world[0]) * 32)
+        s.export_bodies_async(buf, len(world[0]), 0)
+        s.export_wait(0)
+        out = s.device_read(buf, (len(world[0]), 8))
         s.device_free(buf)
     return out
 
@@ -96,8 +97,9 @@ def _unsharded_poses(islands, base, steps):
 @pytest.mark.parametrize("nranks,port,islands", [(2, 29523, 37), (3, 29525, 37), (3, 29529, 2)])
 def test_island_sharded_config5_equals_the_unsharded_world(tmp_path, nranks, port, islands):
     """bench.py --config 5 (BASELINE configs[4]) with 2 and 3 ranks sharing this box's one GPU over gloo: every rank's shard
-    resident, pose records all-gathered every step.  The poses rank 0 assembles from the gathered records after
-    warmup + steps steps must equal, bit for bit, those of the same world stepped unsharded in one solver.  (Two islands on
+    resident, the per-island body arrays (position, rot, linear and angular velocity: SURVEY.md 8e) all-gathered every step.  What
+    rank 0 assembles from the gathered records after warmup + steps steps must equal, bit for bit, the bodies of the same world
+    stepped unsharded in one solver.  (Two islands on
     three ranks: one rank owns nothing and still takes part in every all-gather.)"""
     import numpy as np
     dump = str(tmp_path / "poses.npy")

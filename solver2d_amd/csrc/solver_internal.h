@@ -27,6 +27,8 @@ int s2amdFail(int code, const std::string& msg);
 inline int fail(int code, const std::string& msg) { return s2amdFail(code, msg); }
 
 #define S2_HUB_DEGREE 12
+// a writable body with more constraints than this inside the strips keeps its graph off them (solver_structure.cpp: cutStrips)
+#define S2_STRIP_MAX_DEGREE 48
 
 #define HIP_TRY(expr)                                                                                                            \
 	do                                                                                                                           \

@@ -1882,14 +1882,14 @@ struct StructureBuild
 						placed[(size_t)b] = 1;
 					}
 				}
-				bool orphan = false;
+				bool unfit = false; // an orphan body, or a hub
 				for (const std::vector<std::vector<int>>* lists : {&strips.cA, &strips.cB})
 				{
 					for (const std::vector<int>& list : *lists)
 					{
 						for (int k : list)
 						{
-							orphan = orphan || (ce.a[k] >= 0 && conflict[(size_t)ce.a[k]] && !placed[(size_t)ce.a[k]]) ||
+							unfit = unfit || (ce.a[k] >= 0 && conflict[(size_t)ce.a[k]] && !placed[(size_t)ce.a[k]]) ||
 									 (ce.b[k] >= 0 && conflict[(size_t)ce.b[k]] && !placed[(size_t)ce.b[k]]);
 						}
 					}
@@ -1900,12 +1900,33 @@ struct StructureBuild
 					{
 						for (int k : list)
 						{
-							orphan = orphan || (je.a[k] >= 0 && conflict[(size_t)je.a[k]] && !placed[(size_t)je.a[k]]) ||
+							unfit = unfit || (je.a[k] >= 0 && conflict[(size_t)je.a[k]] && !placed[(size_t)je.a[k]]) ||
 									 (je.b[k] >= 0 && conflict[(size_t)je.b[k]] && !placed[(size_t)je.b[k]]);
 						}
 					}
 				}
-				if (orphan)
+				// A strip sweeps the constraints of one body in as many colour rounds as the body has constraints: a hub (the
+				// Tumbler's drum, 238 contacts) would hold its strip -- and every strip waiting on its hand-offs -- for hundreds
+				// of rounds per sweep.  Such a graph stays on the colour batches and their wave-walked tail (group_kernel.hip:
+				// walkTail; Tumbler 10k TGS_Soft: 3.2 ms there, 5.8 ms through the op interpreter).
+				std::vector<int> stripDegree((size_t)nb, 0);
+				for (const std::vector<std::vector<int>>* lists : {&strips.cA, &strips.cB})
+				{
+					for (const std::vector<int>& list : *lists)
+					{
+						for (int k : list)
+						{
+							for (int b : {ce.a[k], ce.b[k]})
+							{
+								if (b >= 0 && conflict[(size_t)b] && ++stripDegree[(size_t)b] > S2_STRIP_MAX_DEGREE)
+								{
+									unfit = true;
+								}
+							}
+						}
+					}
+				}
+				if (unfit)
 				{
 					strips = StripPartition();
 					s->stripsHopeless = true; // (whatever the strip width: the search over widths is skipped, solver_structure.cpp: buildStructure)

@@ -175,6 +175,36 @@ def test_perturbed_piles_with_joints_through_the_op_interpreter(seed, joints):
     assert ran >= (total if joints else total - 6) - 4, (ran, total)
 
 
+@pytest.mark.parametrize("solver_name", ["TGS_Soft", "PGS_NGS_Block", "XPBD"])
+def test_a_hub_body_keeps_its_island_off_the_strips(solver_name):
+    """A body with more constraints than S2_STRIP_MAX_DEGREE (48) among the strip candidates -- the Tumbler's drum has 238 -- would
+    be as many colour rounds of one strip per sweep: no strips for such a graph (solver_structure.cpp: cutStrips), it runs on
+    colour batches and the sequential tail and is bit-exact there.  (Tumbler 10k under TGS_Soft: 3.2 ms that way, 5.8 ms through
+    the interpreter.)  The same pile without the hub takes the strips."""
+    bodies, contacts, joints = pile_with_joints(3, 36, 0)
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+    hubbed = contacts.copy()
+    movable = np.flatnonzero(bodies["invMass"] > 0.0)
+    hub = int(movable[len(movable) // 2])
+    live = np.flatnonzero((hubbed["bodyA"] >= 0) & (hubbed["bodyA"] != hub) & (hubbed["bodyB"] != hub) & (hubbed["pointCount"] > 0))
+    picked = live[:: max(1, len(live) // 60)][:60]
+    hubbed["bodyB"][picked] = hub  # 60 boxes all over the pile lean on one
+    for cs, want_strips in ((contacts, True), (hubbed, False)):
+        with hip.Solver(0) as gpu:
+            gpu.set_option("strip_patience", 0)
+            gpu.set_option("max_group_bodies", 256)
+            gpu.set_option("strip_min_bodies", 0)
+            gpu.set_option("strip_bodies", 60)
+            state = (bodies, cs, joints)
+            for step in range(2):
+                state = gpu_vs_oracle_loose(gpu, params, state, "hub=%d %s step %d" % (not want_strips, solver_name, step))
+            st = gpu.stats()
+            assert (st["stripCount"] > 0) == want_strips, st
+            if not want_strips:
+                assert st["contactColors"] >= 60, st
+
+
 def test_consecutive_resident_steps_with_joints_and_contacts():
     """A world the soft kernels cannot take -- joints inside the big island -- stepped for 6 steps on the op interpreter
     against the oracle chain: platform of boxes with a chain of revolute joints hung into it."""

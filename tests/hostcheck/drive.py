@@ -144,6 +144,28 @@ def world_chain(base, steps):
         s.world_download(*[world[k] for k in keys])
 
 
+def hub_rule():
+    """A writable body with more than S2_STRIP_MAX_DEGREE (48) constraints among the strip candidates keeps its graph off the strips
+    (solver_structure.cpp: cutStrips); the same pile without the hub is cut into strips."""
+    bodies, contacts, joints = common.copy3(synthetic.pyramid(36))
+    hubbed = contacts.copy()
+    dynamic = np.flatnonzero(bodies["type"] == wire.BODY_DYNAMIC)
+    hub = int(dynamic[len(dynamic) // 2])
+    live = np.flatnonzero((hubbed["bodyA"] >= 0) & (hubbed["bodyA"] != hub) & (hubbed["bodyB"] != hub))
+    hubbed["bodyB"][live[:: max(1, len(live) // 60)][:60]] = hub
+    counts = []
+    for cs in (contacts, hubbed):
+        for name in ("TGS_Soft", "PGS_NGS_Block"):
+            vel, pos = common.DEFAULT_ITERS[name]
+            with hip.Solver(0) as s:
+                s.set_option("strip_patience", 0), s.set_option("max_group_bodies", 256), s.set_option("strip_min_bodies", 0), s.set_option("strip_bodies", 60)
+                s.solve(wire.StepParams.make(name, 1.0 / 60.0, vel, pos, True), bodies.copy(), cs.copy(), joints.copy())
+                s.contact_order()
+                counts.append(s.stats()["stripCount"])
+    assert counts[0] > 0 and counts[1] > 0 and counts[2] == 0 and counts[3] == 0, counts
+    return counts
+
+
 def main():
     quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
     n = fuzz_solves(6 if quick else 40)
@@ -159,6 +181,7 @@ def main():
                              ("TGS_Soft", 100, {"strip_patience": 0, "persist_debug": 16}), ("PGS", 100, {"strip_patience": 0})):
         builds, placed, persistent = neighbour_churn(name, base, 10 if quick else 40, opts)
         print("neighbour churn %s base %d: %d structure builds, %d contacts placed, persistent %d" % (name, base, builds, placed, persistent))
+    print("hub rule: strips", hub_rule())
     world_chain(20 if quick else 60, 3 if quick else 8)
     print("world chain ok")
     print("HOSTCHECK OK")

@@ -9,8 +9,7 @@ mkdir -p $O
 what=${1:-all}
 B="python $R/bench.py --steps 200 --warmup 40 --no-cpu --no-extras"
 C5="python $R/bench.py --config 5 --steps 60 --warmup 10"
-# every pass under its own limit: a pass that does not come back (seen once, r3: a kernel trace of the Tumbler on the op interpreter)
-# must not take the box's budget with it
+# every pass under its own limit: a pass that does not come back must not take the box's budget with it
 T=${S2AMD_PROFILE_PASS_SECONDS:-180}
 if [ $what = headline -o $what = all ]; then
   timeout $T rocprofv3 --kernel-trace --stats -d $O/h_stats -o trace -- $B > $O/h_stats.log 2>&1

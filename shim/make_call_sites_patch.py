@@ -46,7 +46,9 @@ def main():
             if any(re.match(sig, l) and not l.rstrip().endswith(";") for l in text):
                 ctx = re.search(r"s2StepContext\* (\w+)\)", [l for l in text if re.match(sig, l)][0]).group(1)
                 inserts.append((after_open_brace(text, sig), [
-                    "\tif (s2amdBinding_IsOpen() && s2amdBinding_Solve(world, %s, s2_solver%s) == 0)\n" % (ctx, s), "\t{\n", "\t\treturn;\n", "\t}\n"]))
+                    "\tif (s2amdBinding_IsOpen())\n", "\t{\n",
+                    "\t\ts2amdBinding_SolveOrDie(world, %s, s2_solver%s); // (aborts on a device error: never the CPU solver on the same world)\n" % (ctx, s),
+                    "\t\treturn;\n", "\t}\n"]))
         if name == "world.c":
             i = after_open_brace(text, r"^void s2World_Step\(")
             # after the line that looks the world up
@@ -55,7 +57,7 @@ def main():
             inserts.append((i + 1, [
                 "\tif (s2amdBinding_IsOpen())\n", "\t{\n",
                 "\t\t// stage 3, the solve and stage 4 on the MI355X (shim/s2_amd_binding.c); stages 1 and 2 are this file's\n",
-                "\t\ts2amdBinding_WorldStep(world, timeStep, velIters, posIters, warmStart, s2UpdateBroadPhasePairs, s2BroadPhase_RebuildTrees);\n",
+                "\t\ts2amdBinding_WorldStepOrDie(world, timeStep, velIters, posIters, warmStart, s2UpdateBroadPhasePairs, s2BroadPhase_RebuildTrees);\n",
                 "\t\treturn;\n", "\t}\n"]))
             i = after_open_brace(text, r"^void s2DestroyWorld\(")
             while "s2GetWorldFromId" not in text[i]:

@@ -529,6 +529,31 @@ int s2amdBinding_LastError(void)
 	return s_lastError;
 }
 
+// The call sites of shim/call_sites.patch: once the binding is open there is no way back to the reference's CPU solver -- a device
+// error must not silently run s2Solve_* on the host on the same world (the two would disagree from that step on).
+void s2amdBinding_SolveOrDie(s2World* world, s2StepContext* context, int solverType)
+{
+	const int rc = s2amdBinding_Solve(world, context, solverType);
+	if (rc != 0)
+	{
+		fprintf(stderr, "s2amd binding: s2Solve (solver type %d) failed on the device (error %d): %s\n", solverType, rc,
+				s_api.lastError ? s_api.lastError() : "");
+		abort();
+	}
+}
+
+void s2amdBinding_WorldStepOrDie(s2World* world, float timeStep, int velIters, int posIters, bool warmStart, void (*updatePairs)(s2World*),
+								 void (*rebuildTrees)(s2BroadPhase*))
+{
+	s_lastError = 0;
+	s2amdBinding_WorldStep(world, timeStep, velIters, posIters, warmStart, updatePairs, rebuildTrees);
+	if (s_lastError != 0)
+	{
+		fprintf(stderr, "s2amd binding: s2World_Step failed on the device (error %d): %s\n", s_lastError, s_api.lastError ? s_api.lastError() : "");
+		abort();
+	}
+}
+
 long s2amdBinding_Uploads(void)
 {
 	return s_uploads;
@@ -670,7 +695,9 @@ static int syncBodiesAndBoxes(s2World* world, WorldBinding* b)
 		{
 			s2Body* body = world->bodies + i;
 			const s2amdBody* o = b->bodies + i;
-			if (s2IsFree(&body->object))
+			// (a slot the device holds as FREE: the body in it was created after the upload -- its record there is all zeros, and the
+			// next step uploads the pools again)
+			if (s2IsFree(&body->object) || o->type == S2AMD_BODY_FREE)
 			{
 				continue;
 			}

@@ -23,6 +23,11 @@ int s2amdBinding_Solve(s2World* world, s2StepContext* context, int solverType);
  * reference functions handed in (s2UpdateBroadPhasePairs, s2BroadPhase_RebuildTrees). */
 void s2amdBinding_WorldStep(s2World* world, float timeStep, int velIters, int posIters, bool warmStart, void (*updatePairs)(s2World*),
 							void (*rebuildTrees)(s2BroadPhase*));
+/* The same two for call sites that have no error path (shim/call_sites.patch): a device error is printed and abort()s -- it must
+ * never fall through to the reference's CPU solver on the same world. */
+void s2amdBinding_SolveOrDie(s2World* world, s2StepContext* context, int solverType);
+void s2amdBinding_WorldStepOrDie(s2World* world, float timeStep, int velIters, int posIters, bool warmStart, void (*updatePairs)(s2World*),
+								 void (*rebuildTrees)(s2BroadPhase*));
 /* Called first thing by s2DestroyWorld (src/world.c:105-118). */
 void s2amdBinding_DestroyWorld(s2World* world);
 /* The host pools of `world` brought up to date with the device (manifolds, GJK caches, joint impulses): before anything

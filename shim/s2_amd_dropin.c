@@ -181,11 +181,39 @@ void __wrap_s2World_QueryAABB(s2WorldId worldId, s2Box aabb, s2QueryCallbackFcn*
 	syncWorld(s2GetWorldFromId(worldId));
 	__real_s2World_QueryAABB(worldId, aabb, fcn, context);
 }
+/* ---- pool edits.  A destroy followed by a create leaves every pool count as it was (a mouse joint released and grabbed again, a
+ * body replaced), so the counts residentMatches compares cannot see them: the edit itself marks the resident world stale.  The sync
+ * comes first: a lean step leaves the bodies on the device, and a slot handed out now must not be overwritten later by the download
+ * of what the device still holds there as a free slot. ---- */
 void __real_s2DestroyBody(s2BodyId bodyId);
 void __wrap_s2DestroyBody(s2BodyId bodyId)
 {
-	syncWorld(s2GetWorldFromIndex(bodyId.world));
+	editWorld(s2GetWorldFromIndex(bodyId.world));
 	__real_s2DestroyBody(bodyId);
+}
+s2BodyId __real_s2CreateBody(s2WorldId worldId, const s2BodyDef* def);
+s2BodyId __wrap_s2CreateBody(s2WorldId worldId, const s2BodyDef* def)
+{
+	editWorld(s2GetWorldFromId(worldId));
+	return __real_s2CreateBody(worldId, def);
+}
+void __real_s2DestroyJoint(s2JointId jointId);
+void __wrap_s2DestroyJoint(s2JointId jointId)
+{
+	editWorld(s2GetWorldFromIndex(jointId.world));
+	__real_s2DestroyJoint(jointId);
+}
+s2JointId __real_s2CreateMouseJoint(s2WorldId worldId, const s2MouseJointDef* def);
+s2JointId __wrap_s2CreateMouseJoint(s2WorldId worldId, const s2MouseJointDef* def)
+{
+	editWorld(s2GetWorldFromId(worldId));
+	return __real_s2CreateMouseJoint(worldId, def);
+}
+s2JointId __real_s2CreateRevoluteJoint(s2WorldId worldId, const s2RevoluteJointDef* def);
+s2JointId __wrap_s2CreateRevoluteJoint(s2WorldId worldId, const s2RevoluteJointDef* def)
+{
+	editWorld(s2GetWorldFromId(worldId));
+	return __real_s2CreateRevoluteJoint(worldId, def);
 }
 #define S2_DROPIN_SHAPE(NAME, GEOM)                                                                                              \
 	s2ShapeId __real_##NAME(s2BodyId bodyId, const s2ShapeDef* def, const GEOM* geometry);                                       \

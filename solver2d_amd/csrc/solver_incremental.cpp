@@ -11,6 +11,7 @@
 // The result is a proper colouring and a valid sweep order like any other: the oracle sweeps in it (parity link L2).
 #include "solver_internal.h"
 
+#include <cstddef>
 #include <unordered_map>
 
 namespace
@@ -257,11 +258,19 @@ bool stripPlace(s2amdSolver* s, Patcher& p, const ContactChange& ch)
 		IncrementalStrips::Round& round = m.rounds[(size_t)m.spareRound[(size_t)group]];
 		const int r = round.round;
 		const int begin = round.freePositions.back(), end = round.freePositions.front() + 1;
+		// (the spare round is the strip's next one and never goes beyond what the six-round kernel variants take: maxRoundsA -- which
+		// picks the kernel variant, baked into the captured step graph -- can only move inside a variant's range)
+		static_assert(offsetof(StripDesc, batchCount) % 4 == 0 && offsetof(StripDesc, batch) % 4 == 0 && sizeof(StripDesc::batch[0]) == 16, "StripDesc layout");
+		if (r + 1 > S2_STRIP_ROUNDS)
+		{
+			return false;
+		}
 		const StripDesc* desc = s->leanA.descs + group;
 		const size_t words = (const uint32_t*)desc - (const uint32_t*)s->leanA.descs;
-		p.word(s->leanA.descs, words + 3, (uint32_t)(r + 1));		  // batchCount
-		p.word(s->leanA.descs, words + 8 + 4 * (size_t)r, (uint32_t)begin); // batch[r] = {begin, end, 0, 0}
-		p.word(s->leanA.descs, words + 9 + 4 * (size_t)r, (uint32_t)end);
+		const size_t wCount = offsetof(StripDesc, batchCount) / 4, wBatch = offsetof(StripDesc, batch) / 4;
+		p.word(s->leanA.descs, words + wCount, (uint32_t)(r + 1));
+		p.word(s->leanA.descs, words + wBatch + 4 * (size_t)r, (uint32_t)begin); // batch[r] = {begin, end, 0, 0}
+		p.word(s->leanA.descs, words + wBatch + 4 * (size_t)r + 1, (uint32_t)end);
 		m.roundCount[0][(size_t)group] = r + 1;
 		m.spareRound[(size_t)group] = -1;
 		s->persist.maxRoundsA = std::max(s->persist.maxRoundsA, r + 1);

@@ -252,6 +252,8 @@ struct s2amdSolver
 	bool stepBackValid = false;
 	int optStepReadback = 1;
 	std::vector<uint8_t> hPointBytes;
+	std::vector<uint8_t> hShapeMovable; // world chain: live shapes of non-static bodies (what s2amd_world_set_refit_order must cover)
+	int movableShapes = 0;
 
 	// host shadows of the graph structure (refreshed by every upload)
 	// The structure (islands, colours, strips) is built over EVERY contact slot that can become a constraint -- a live pair of

@@ -440,9 +440,17 @@ int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapa
 		}
 		s->jointedCount = (int)jointed.size();
 		s->liveShapes = 0;
+		// the shapes stage 4 can re-inflate: live shapes of non-static bodies (src/world.c:259-297) -- what a refit order must cover
+		s->hShapeMovable.assign((size_t)shapeCapacity, 0);
+		s->movableShapes = 0;
 		for (int i = 0; i < shapeCapacity; ++i)
 		{
 			s->liveShapes += shapes[i].type != S2AMD_SHAPE_FREE ? 1 : 0;
+			if (shapes[i].type != S2AMD_SHAPE_FREE && bodies[shapes[i].body].type != S2AMD_BODY_FREE && bodies[shapes[i].body].type != S2AMD_BODY_STATIC)
+			{
+				s->hShapeMovable[(size_t)i] = 1;
+				s->movableShapes += 1;
+			}
 		}
 	}
 	s->hPointBytes.assign((size_t)contactCapacity, 0);
@@ -734,6 +742,28 @@ int s2amd_world_set_refit_order(s2amdSolver* s, const int32_t* shapeOrder, int32
 	if (count == 0)
 	{
 		return S2AMD_OK;
+	}
+	// The order must name every shape stage 4 can re-inflate exactly once: s2amd_world_download_step trusts it (a stale order would
+	// hand the caller a step's moved boxes with some of them missing).  Shapes only change with s2amd_world_upload, which drops the order.
+	if (!s->worldResident || (int)s->hShapeMovable.size() != s->shapeCapacity)
+	{
+		return fail(S2AMD_E_STATE, "s2amd_world_set_refit_order called before s2amd_world_upload");
+	}
+	{
+		std::vector<uint8_t> seen((size_t)s->shapeCapacity, 0);
+		for (int i = 0; i < count; ++i)
+		{
+			const int k = shapeOrder[i];
+			if (k < 0 || k >= s->shapeCapacity || seen[(size_t)k] || !s->hShapeMovable[(size_t)k])
+			{
+				return fail(S2AMD_E_INVALID, "refit order entry " + std::to_string(i) + " is not a live shape of a movable body, or is named twice");
+			}
+			seen[(size_t)k] = 1;
+		}
+		if (count != s->movableShapes)
+		{
+			return fail(S2AMD_E_INVALID, "refit order names " + std::to_string(count) + " of the world's " + std::to_string(s->movableShapes) + " movable shapes");
+		}
 	}
 	int rc = s->dRefitOrder.ensure((size_t)count * sizeof(int32_t));
 	if (rc)

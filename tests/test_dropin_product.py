@@ -56,6 +56,8 @@ def test_the_patch_form_of_the_call_sites_applies_to_the_reference(tmp_path):
         shutil.copytree(os.path.join("/root/reference", d), str(tmp_path / d))
     patch = open(os.path.join(ROOT, "shim", "call_sites.patch"), encoding="latin-1").read()
     assert not [l for l in patch.splitlines() if l.startswith("-") and not l.startswith("---")], "the patch only adds lines"
+    # a device error must never fall through to the reference's CPU solver on the same world: the patched call sites abort
+    assert "s2amdBinding_Solve(" not in patch and patch.count("s2amdBinding_SolveOrDie(") == 10 and "s2amdBinding_WorldStepOrDie(" in patch
     subprocess.run(["patch", "-p1", "-s"], input=patch.encode("latin-1"), cwd=str(tmp_path), check=True)
     for f in ("shim/s2_amd_binding.c", "shim/s2_amd_binding.h", "include/solver2d_amd.h"):
         shutil.copy(os.path.join(ROOT, f), str(tmp_path / "src"))
@@ -75,6 +77,17 @@ def test_without_the_hip_library_the_first_step_fails_loudly(built):
     assert b"state digest" in p.stdout
 
 
+def test_every_pool_edit_of_the_public_api_reaches_the_binding(built):
+    # residentMatches (shim/s2_amd_binding.c) compares pool counts: a destroy followed by a create leaves them equal, so every
+    # call that creates or destroys a body or joint is wrapped (sync, then invalidate)
+    flags = open(os.path.join(ROOT, "shim", "Makefile")).read()
+    for name in ("s2CreateBody", "s2DestroyBody", "s2DestroyJoint", "s2CreateMouseJoint", "s2CreateRevoluteJoint"):
+        assert re.search(r"\b%s\b" % name, flags), name
+    syms = subprocess.run(["nm", built], stdout=subprocess.PIPE, check=True).stdout.decode()
+    for name in ("s2CreateBody", "s2DestroyBody", "s2DestroyJoint", "s2CreateMouseJoint", "s2CreateRevoluteJoint"):
+        assert "__wrap_" + name in syms, name
+
+
 def _digest(env_extra, args):
     env = dict(os.environ, S2AMD_LIBRARY=os.path.join(ROOT, "solver2d_amd", "libs2amd.so"), **env_extra)
     out = subprocess.run([DEMO] + [str(a) for a in args], env=env, stdout=subprocess.PIPE, check=True).stdout.decode()
@@ -92,3 +105,19 @@ def test_a_program_on_the_public_api_runs_on_the_gpu_through_the_product_library
     step_dev_pairs, out = _digest({"S2AMD_DROPIN": "step", "S2AMD_DEVICE_PAIRS": "1"}, args)
     # the whole-step routes are the solver-only route's computation, bit for bit (same contact slots, same sweep order)
     assert solver_only == step_host_pairs == step_dev_pairs, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,base,solver,vel,pos", [("pyramid", 24, 7, 8, 4), ("mixed", 24, 3, 4, 2)])
+def test_bodies_created_and_replaced_between_resident_steps(built, scene, base, solver, vel, pos):
+    """A body created after lean steps lands in a slot the device holds as free (its record there is zeros); one destroyed and
+    replaced leaves every pool count equal.  All three routes end in the same bits."""
+    if not os.path.exists(DEMO):
+        pytest.skip("demo binary not built")
+    args = [base, 40, scene, solver, vel, pos, 10]
+    solver_only, _ = _digest({"S2AMD_DROPIN": "solver", "S2DEMO_EDITS": "1"}, args)
+    step_host_pairs, _ = _digest({"S2AMD_DROPIN": "step", "S2AMD_DEVICE_PAIRS": "0", "S2DEMO_EDITS": "1"}, args)
+    step_dev_pairs, out = _digest({"S2AMD_DROPIN": "step", "S2AMD_DEVICE_PAIRS": "1", "S2DEMO_EDITS": "1"}, args)
+    assert solver_only == step_host_pairs == step_dev_pairs, out
+    plain, _ = _digest({"S2AMD_DROPIN": "solver"}, args)
+    assert plain != solver_only, "the edits change the world"

@@ -6,6 +6,7 @@
  *   tools/dropin_product_demo.sh [base steps scene solverId velIters posIters settleSteps]
  */
 #include "solver2d/solver2d.h"
+#include "solver2d/geometry.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -38,9 +39,29 @@ int main(int argc, char** argv)
 	}
 	double phases[6];
 	s2amdDropin_Timing(phases);
+	/* S2DEMO_EDITS=1: the pools are edited between steps the way a game edits them -- a body created while the world is resident
+	 * (a slot the device still holds as free), then destroyed and replaced by another one (every pool count as before: only the
+	 * edit itself can tell the binding) -- every route must still end in the same bits */
+	const int edits = getenv("S2DEMO_EDITS") != NULL && atoi(getenv("S2DEMO_EDITS")) != 0;
+	s2BodyId extra = s2_nullBodyId;
 	const double t0 = now();
 	for (int i = 0; i < steps; ++i)
 	{
+		if (edits && (i == steps / 4 || i == steps / 2))
+		{
+			if (i == steps / 2)
+			{
+				s2DestroyBody(extra);
+			}
+			s2BodyDef bd = s2_defaultBodyDef;
+			bd.type = s2_dynamicBody;
+			bd.position = (s2Vec2){i == steps / 2 ? 1.25f : -0.75f, 0.5f * (float)base + 6.0f};
+			bd.linearVelocity = (s2Vec2){0.0f, -12.0f};
+			extra = s2CreateBody(w, &bd);
+			s2ShapeDef sd = s2_defaultShapeDef;
+			s2Polygon box = s2MakeSquare(0.4f);
+			s2CreatePolygonShape(extra, &sd, &box);
+		}
 		s2World_Step(w, 1.0f / 60.0f, vel, pos, true);
 	}
 	const double ms = 1e3 * (now() - t0) / steps;

@@ -4,10 +4,12 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one s2Solve_TGS_Soft (the hot path of one s2World_Step) over one resident snapshot:
-the pyramid's step-0 solver input (solver2d_amd.synthetic.pyramid == the reference's own captured
-input, tests/test_synthetic.py), body state restored from the snapshot before every step, contact
-impulses carried from step to step (warm starting).  Inputs are in HBM before the timed region.
+A "step" is one s2Solve_TGS_Soft (the hot path of one s2World_Step) over the resident world: the
+pyramid's step-0 solver input (solver2d_amd.synthetic.pyramid == the reference's own captured
+input, tests/test_synthetic.py), then CONSECUTIVE resident steps -- bodies and contact impulses
+carried from step to step, nothing restored or copied inside the timed region (`--restore` brings
+back round 3's form: the step-0 bodies copied back before every step).  Inputs are in HBM before
+the timed region.
 `value` = C x solve_sweeps x K x N / wall seconds, with solve sweeps counted as executed
 (TGS_Soft 8/4: 16 per step, reference src/solve_tgs_soft.c:211-269).
 
@@ -110,7 +112,7 @@ def pmc_issue(kernel_prefixes, stem="persistent"):
     own run): VALU instructions per wave and the share of a SIMD's cycles in which it issues one -- a wave64 VALU instruction
     occupies its SIMD's issue for 4 cycles (tools/valu_bench.hip), a CU has 4 SIMDs, and the waves a CU hosts during the launch
     are the launch's waves over the CUs it occupies.  None when the summary is absent."""
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", "%s_%s_pmc_sq.txt" % (rnd, stem))
         try:
             vals, calls, avg_ns = {}, None, None
@@ -154,7 +156,7 @@ def pmc_traffic_bytes(kernel_prefix, stem="persistent"):
     FETCH_SIZE is doubled per the gfx950 note in MI355X_MICROARCH.md (it reads half of a wide coalesced stream).
     None when the summaries are not there."""
     prefixes = kernel_prefix if isinstance(kernel_prefix, (tuple, list)) else (kernel_prefix,)
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         total = 0.0
         try:
             for name, scale in (("fetch", 2.0), ("write", 1.0)):
@@ -420,6 +422,7 @@ def main():
     ap.add_argument("--islands", type=int, default=512)
     ap.add_argument("--island-base", type=int, default=40)
     ap.add_argument("--no-extras", action="store_true", help="only the headline line (no whole_step / configs / island_sharded objects)")
+    ap.add_argument("--restore", action="store_true", help="copy the step-0 bodies back before every step (round 3's headline loop) instead of consecutive steps")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -507,7 +510,8 @@ def main():
     def enqueue(step):
         """restore + s2Solve + pose export of `step` on the solver's stream; nothing here waits for the device
         except for the collective that last read this step's pose buffer (two steps ago)."""
-        gpu.restore_bodies()
+        if args.restore:
+            gpu.restore_bodies()
         gpu.step_resident(params)
         if distributed:
             b = step & 1
@@ -551,7 +555,8 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     gpu.set_option("async", 0)
-    gpu.restore_bodies()
+    if args.restore:
+        gpu.restore_bodies()
     gpu.step_resident(params)  # one synchronous step: device time and counters for the report
     st = gpu.stats()
     C = st["constraintCount"]
@@ -577,7 +582,8 @@ def main():
     gpu.set_option("profile", 1)
     kernel_ms, launches, overhead_ms = 0.0, 0, 0.0
     for _ in range(prof_steps):
-        gpu.restore_bodies()
+        if args.restore:
+            gpu.restore_bodies()
         gpu.step_resident(params)
         s2 = gpu.stats()
         kernel_ms += s2["solveKernelMs"]
@@ -608,6 +614,7 @@ def main():
                 "constraints": C, "solve_sweeps_per_step": sweeps, "contact_colors": st["contactColors"],
                 "kernel_launches_per_step": st["kernelLaunches"], "graph_replay": bool(st["graphReplayed"]),
                 "device_ms_per_step": st["deviceMs"],
+                "trajectory": "step-0 bodies copied back before every step" if args.restore else "consecutive resident steps (no restore, no copy in the timed region)",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

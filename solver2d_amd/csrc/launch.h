@@ -153,13 +153,28 @@ void launchPairStep(hipStream_t s, int kind, int warm, const ContactView& c, con
 
 // wide_kernel.hip: TGS_Soft's persistent strip step on 512 threads per strip
 int wideKernelSetup();
-int wideParkedRecords(int maxRoundsA, int maxSeamRounds, int force, int parkSeamWidth, int parkInteriorWidth);
+// What the self-contained variant of the strip step needs beside the tables (wide_kernel.hip: S2_WIDE_SELF): the wire arrays it
+// reads its bodies and constraints from and writes its results to, and the constants of the body prologue (body_ops.h: unpackBodyOne).
+struct WideSelf
+{
+	s2amdContact* wire;
+	s2amdBody* wireBodies;
+	const uint32_t* hostFlags;
+	int warmStart;
+	float gravityX, gravityY, unpackH;
+};
+// float4 records of dynamic LDS the kernel variant for this partition needs beside the bodies, the ops and its three fixed records
+// (parked rounds, staged positions, the warm start's term table); -1: no variant takes the partition
+int wideExtraRecords(const PersistView& pv, int selfContained, int bodyWarm);
+int wideBodyWarmVariant(const PersistView& pv); // the variant for this partition has the body-centric warm start
 // ... and the resident islands' step (strip_kernel.hip: launchIslandStep) for TGS_Soft with the current-anchor warm start
 // selfContained: the kernel also stages its bodies from the wire records and writes them back (no prologue / epilogue launch)
 void launchWideIsland(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& t, const float4* softCoef, const Op* ops, int opCount,
 					  int maxRounds, s2amdContact* wire, s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart, const StepConsts& sc, float unpackH,
 					  int selfContained, const unsigned int* stepFailed, int allTwoPoints);
-void launchWideStep(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount);
+// self != nullptr: the self-contained variant (the step is this one launch); pv.bodyWarm: the body-centric warm start
+void launchWideStep(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount,
+					const WideSelf* self);
 
 // generic_kernel.hip: the persistent strip step as an op interpreter -- every solver family, joints included
 int genericKernelSetup();

@@ -518,6 +518,13 @@ struct PersistView
 	int debugSkip; // timing experiments only (results are wrong; compiled in with -DS2_PERSIST_INSTRUMENTED=1): 1 = no hand-offs, 2 = no seam rounds, 4 = no interior rounds;
 				   // 8 = fault injection for the fallback test: workgroup 1 never publishes its seam bodies
 	unsigned int spinLimit; // polls before a hand-off is declared dead
+	// wide_kernel.hip, self-contained variant (the step is that one launch: no epilogue clears the hand-off buffers or stands down
+	// after a failure): state[0] = epoch base of this step's hand-off tags (the kernel adds 64 per step, so no tag ever comes back),
+	// state[16] = commit counter -- every workgroup arrives once per step and writes its results only when all have
+	unsigned int* state;
+	int maxStaged;		// the most bodies a strip stages (own list + both imports)
+	int maxStripBodies; // ... of them in its own list (owned + read-only replicas)
+	int bodyWarm;		// wide_kernel.hip: s2WarmStartContacts as one body-centric pass (set at launch when the term table fits LDS)
 	unsigned long long* debugTimes; // S2AMD_DEBUG_TIMES: wall_clock64() of one workgroup at kernel start, after the loads, after every op, at the end
 };
 

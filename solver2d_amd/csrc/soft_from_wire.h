@@ -69,3 +69,32 @@ S2_DEV SoftRegs<KIND> prepareSoftFromWire(const s2amdContact* contact, const s2a
 	}
 	return r;
 }
+
+// The same with the bodies' rotations and inverse masses read from the wire bodies themselves (== what a kernel stages of them:
+// body_ops.h unpackBodyOne): for a kernel that prepares its constraints before it has staged anything (wide_kernel.hip, S2_WIDE_SELF).
+// The record's body slots (h.ia, h.ib) are left 0: the caller knows them.
+template <int KIND>
+S2_DEV SoftRegs<KIND> prepareSoftFromWireBodies(const s2amdContact* contact, const s2amdBody* wireBodies, const uint32_t* hostFlags, int bodyCapacity, int warmStart)
+{
+	int ia = contact->bodyA, ib = contact->bodyB;
+	if (ia < 0 || ib < 0 || ia >= bodyCapacity || ib >= bodyCapacity)
+	{
+		ia = 0, ib = 0; // (a destroyed contact whose entry lingers: prepareSoftFromWire drops its points)
+	}
+	// {invMass, invI} of the two bodies as a two-entry table, the poses through the accessor above
+	const float2 mass[2] = {make_float2(wireBodies[ia].invMass, wireBodies[ia].invI), make_float2(wireBodies[ib].invMass, wireBodies[ib].invI)};
+	struct Pair
+	{
+		const s2amdBody* w;
+		int ia, ib;
+		S2_DEV float4 getDq(int i) const
+		{
+			const s2amdBody* b = w + (i == 0 ? ia : ib);
+			return make_float4(0.0f, 0.0f, b->rot[0], b->rot[1]);
+		}
+	};
+	const Pair poses{wireBodies, ia, ib};
+	SoftRegs<KIND> r = prepareSoftFromWire<KIND>(contact, wireBodies, hostFlags, poses, mass, make_int2(0, 1), bodyCapacity, warmStart);
+	r.h.ia = 0, r.h.ib = 0;
+	return r;
+}

@@ -364,14 +364,10 @@ int s2amd_synchronize(s2amdSolver* s)
 		// resident world stands where it stood before the first step that failed.  As doStep does on the synchronous path:
 		// clear both error words and the hand-off buffers and keep this solver on the multi-launch strip path; the steps
 		// that were dropped are the caller's to repeat (it knows how many it enqueued; stats.persistFallbacks counts).
-		*s->hostError = 0u;
-		if (s->persist.deviceError)
+		int rcReset = resetPersistState(s, s->stream);
+		if (rcReset)
 		{
-			HIP_TRY(hipMemsetAsync(s->persist.deviceError, 0, sizeof(unsigned int), s->stream));
-		}
-		if (s->dGranules.p && s->granuleBytes)
-		{
-			HIP_TRY(hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, s->stream));
+			return rcReset;
 		}
 		HIP_TRY(hipStreamSynchronize(s->stream));
 		s->persistFailed = true;
@@ -658,7 +654,7 @@ int s2amd_measure_dominant(s2amdSolver* s, const s2amdStepParams* params, int32_
 		}
 		else if (persistent)
 		{
-			q.runPersistent(pkind, pwarm, true);
+			q.runPersistent(pkind, pwarm, true, q.selfContainedStrips()); // (the kernel the step launches: alone it IS the step, run after run)
 		}
 		else if (strips)
 		{
@@ -837,6 +833,10 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	else if (strcmp(key, "self_contained") == 0)
 	{
 		s->optSelfContained = value != 0;
+	}
+	else if (strcmp(key, "strip_body_warm") == 0)
+	{
+		s->optWideBodyWarm = value != 0;
 	}
 	else if (strcmp(key, "free_body_groups") == 0)
 	{

@@ -429,10 +429,31 @@ struct Executor
 	// warm start on a partition with at most six interior colour batches per strip and two per seam.
 	bool widePlan(int kind, int warm) const
 	{
-		const int parked = wideParkedRecords(s->persist.maxRoundsA, s->persist.maxSeamRounds, (s->persist.debugSkip & 16) != 0, s->persist.parkSeamWidth,
-												 s->persist.parkInteriorWidth);
-		return s->optWide && parked >= 0 && kind == SOFT_TGS && warm == WARM_CURRENT &&
-			   s->persist.bodyRecords + 3 + parked + 2 * s->persistOpCount <= (160 * 1024) / 16;
+		return s->optWide && kind == SOFT_TGS && warm == WARM_CURRENT && wideFits(false, false);
+	}
+
+	// the kernel variant for this partition with these two features: does its dynamic LDS fit?
+	bool wideFits(bool selfContained, bool bodyWarm) const
+	{
+		const int extra = wideExtraRecords(s->persist, selfContained ? 1 : 0, bodyWarm ? 1 : 0);
+		return extra >= 0 && s->persist.bodyRecords + 3 + extra + 2 * s->persistOpCount <= (160 * 1024) / 16;
+	}
+
+	// ... as the step's ONLY launch (wide_kernel.hip: S2_WIDE_SELF): the strips are all there is -- every movable body is owned by one,
+	// every constraint is one of theirs, no joints, no other group -- and manifold.constraintIndex is already in the wire array.  The
+	// kernel then prepares its constraints from the wire contacts, stages its bodies from the wire bodies and writes both back.
+	bool selfContainedStrips() const
+	{
+		int kind, warm;
+		return s->optSelfContained && s->dStripA.view.groupCount > 0 && persistPlan(kind, warm) && widePlan(kind, warm) && wideFits(true, false) && gatherIndex == nullptr && !msg &&
+			   wireBodies() != nullptr && s->dGroups.view.groupCount == 0 && s->dResident.view.groupCount == 0 && s->looseBodies == 0 && !anyGlobalContacts() &&
+			   s->joints.globalCount == 0 && s->jv.count == 0 && s->cv.count == s->persistK1 - s->persistK0 && p.prepContacts == PREP_SOFT && p.storeKind == STORE_PLAIN;
+	}
+
+	// s2WarmStartContacts body-centric inside that kernel: a variant without parked rounds whose term table fits LDS
+	bool wideBodyWarm(bool selfContained) const
+	{
+		return s->optWideBodyWarm != 0 && wideBodyWarmVariant(s->persist) != 0 && wideFits(selfContained, true);
 	}
 
 	// Can the plan run on the resident-island kernel (strip_kernel.hip: islandStepKernel)?  The soft contact drivers: body
@@ -614,7 +635,7 @@ struct Executor
 		count();
 	}
 
-	void runPersistent(int kind, int warm, bool clearFirst = false)
+	void runPersistent(int kind, int warm, bool clearFirst = false, bool selfContained = false)
 	{
 		// hand-off tags are the exchange number; the step's epilogue kernel leaves the buffers zeroed for the next
 		// step, so they only need clearing when this launch is replayed on its own (s2amd_measure_dominant)
@@ -637,7 +658,14 @@ struct Executor
 		}
 		if (widePlan(kind, warm))
 		{
-			launchWideStep(st, s->cv, s->bv, s->leanA, pv, (const Op*)s->dPersistOps.p, s->persistOpCount);
+			WideSelf self{};
+			if (selfContained)
+			{
+				self.wire = wireContacts(), self.wireBodies = wireBodies(), self.hostFlags = (const uint32_t*)s->dBodyFlags.p;
+				self.warmStart = p.sc.warmStart, self.gravityX = p.sc.gravityX, self.gravityY = p.sc.gravityY, self.unpackH = p.unpackH;
+			}
+			pv.bodyWarm = wideBodyWarm(selfContained) ? 1 : 0;
+			launchWideStep(st, s->cv, s->bv, s->leanA, pv, (const Op*)s->dPersistOps.p, s->persistOpCount, selfContained ? &self : nullptr);
 		}
 		else if (pv.pairLanes && s->optPairLanes)
 		{
@@ -783,6 +811,13 @@ struct Executor
 		if (self)
 		{
 			runResidentGroups(true);
+			return;
+		}
+		if (selfContainedStrips())
+		{
+			int kind, warm;
+			(void)persistPlan(kind, warm);
+			runPersistent(kind, warm, false, true);
 			return;
 		}
 		if (prepares)

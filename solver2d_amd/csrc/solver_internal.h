@@ -365,6 +365,8 @@ struct s2amdSolver
 	int optPersist = 1;
 	int optSeamRegs = 1;
 	int optWide = 1;	  // TGS_Soft's persistent step on 512 threads per strip (wide_kernel.hip) where the partition fits
+	int optWideBodyWarm = 1; // "strip_body_warm": ... with s2WarmStartContacts as one body-centric pass (wide_kernel.hip: S2_WIDE_BODYWARM) where its term table fits LDS
+	long selfStepsSinceReset = 0; // self-contained strip steps since the commit counter was last zeroed (doStep: every 2^20)
 	IncrementalStrips stripInc;
 	int optStripSlack = 1; // strip and seam rounds are laid out with free positions for created contacts (solver_incremental.cpp)
 	int optPairLanes = 0; // two lanes per constraint (pair_kernel.hip; measured no faster: kept as an option); 0: one lane per constraint
@@ -523,4 +525,6 @@ void incrementalRemove(s2amdSolver* s, const int32_t* slots, int count);
 // enqueues the patch list built by incrementalApply on the solver's stream
 int incrementalFlush(s2amdSolver* s);
 int doStep(s2amdSolver* s, const s2amdStepParams* params);
+// after a persistent step lost a hand-off: both error words, the commit counter and the hand-off buffers back to zero (enqueued on `st`)
+int resetPersistState(s2amdSolver* s, hipStream_t st);
 int doDownload(s2amdSolver* s, s2amdBody* bodies, int nb, s2amdContact* contacts, int nc, s2amdJoint* joints, int nj);

@@ -16,6 +16,24 @@ void destroyGraph(s2amdSolver* s)
 	s->graphKey = 0;
 }
 
+int resetPersistState(s2amdSolver* s, hipStream_t st)
+{
+	if (s->hostError)
+	{
+		*s->hostError = 0u;
+	}
+	if (s->persist.deviceError)
+	{
+		HIP_TRY(hipMemsetAsync(s->persist.deviceError, 0, 256, st)); // the error word and the self-contained kernel's commit counter (PersistView::state)
+	}
+	if (s->dGranules.p && s->granuleBytes)
+	{
+		HIP_TRY(hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, st));
+	}
+	s->selfStepsSinceReset = 0;
+	return S2AMD_OK;
+}
+
 int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdContact* contacts, int nc, const s2amdJoint* joints, int nj,
 				   const s2amdPairState* pairs)
 {
@@ -504,6 +522,12 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 		}
 	};
 
+	if (q.selfContainedStrips() && ++s->selfStepsSinceReset >= (1 << 20))
+	{
+		// the self-contained strip kernel's commit counter runs on from step to step: back to zero long before it could wrap
+		HIP_TRY(hipMemsetAsync(s->persist.state, 0, sizeof(unsigned int), s->stream));
+		s->selfStepsSinceReset = 0;
+	}
 	bool useGraph = s->optGraph != 0 && !q.profile;
 	q.fork = useGraph && s->optFork != 0;
 	HIP_TRY(hipEventRecord(s->evBegin, s->stream));
@@ -511,7 +535,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	{
 		uint64_t key = 1469598103934665603ull;
 		key = fnv(key, params, sizeof(*params));
-		uint64_t gens[4] = {s->layoutGeneration, s->structureGeneration, s->planGeneration, (uint64_t)((q.msg ? 1 : 0) | (s->optBodyWarm ? 2 : 0) | (s->optStripLean ? 4 : 0) | (s->optPersist ? 8 : 0) | (s->optFork ? 16 : 0) | (s->persistFailed ? 32 : 0) | ((s->persistValid && s->persist.allTwoPoints) ? 64 : 0) | (s->pointsKnown ? 128 : 0) | (s->optPairLanes ? 256 : 0) | (s->optWide ? 512 : 0) | (s->optGeneric ? 1024 : 0) | (s->genericValid ? 2048 : 0) | (indexNow ? 4096 : 0) | (s->optSelfContained ? 8192 : 0) | ((s->residentAllTwoPoints && s->pointsKnown) ? 16384 : 0) | (s->optStageJoints ? 32768 : 0))};
+		uint64_t gens[4] = {s->layoutGeneration, s->structureGeneration, s->planGeneration, (uint64_t)((q.msg ? 1 : 0) | (s->optBodyWarm ? 2 : 0) | (s->optStripLean ? 4 : 0) | (s->optPersist ? 8 : 0) | (s->optFork ? 16 : 0) | (s->persistFailed ? 32 : 0) | ((s->persistValid && s->persist.allTwoPoints) ? 64 : 0) | (s->pointsKnown ? 128 : 0) | (s->optPairLanes ? 256 : 0) | (s->optWide ? 512 : 0) | (s->optGeneric ? 1024 : 0) | (s->genericValid ? 2048 : 0) | (indexNow ? 4096 : 0) | (s->optSelfContained ? 8192 : 0) | ((s->residentAllTwoPoints && s->pointsKnown) ? 16384 : 0) | (s->optStageJoints ? 32768 : 0) | (s->optWideBodyWarm ? 65536 : 0))};
 		key = fnv(key, gens, sizeof(gens));
 		int sizes[3] = {s->bodyCapacity, s->contactCapacity, s->jointCapacity};
 		key = fnv(key, sizes, sizeof(sizes));
@@ -596,8 +620,11 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 		// The persistent kernel's workgroups were not all resident (something else occupies the GPU).  Its epilogue saw
 		// the flag and left the wire arrays untouched, so the step is simply repeated on the multi-launch strip path,
 		// which this solver keeps from now on.
-		*s->hostError = 0u;
-		(void)hipMemsetAsync(s->persist.deviceError, 0, sizeof(unsigned int), s->stream);
+		int rcReset = resetPersistState(s, s->stream);
+		if (rcReset)
+		{
+			return rcReset;
+		}
 		s->persistFailed = true;
 		s->persistFailedAge = 0;
 		s->persistFallbacks += 1;

@@ -1177,7 +1177,7 @@ do                                                                              
 		int genericBodies = 0, genericSeamBodies = 0, genericExports = 0, genericJoints = 0;
 		std::vector<int> remap, exportSrc, importIds;
 		std::vector<int> replicaStamp((size_t)nb, -1), replicaSlot((size_t)nb, -1);
-		int ldsRecords = 0, ldsRecordsWide = 0, bodyRecordsMax = 0;
+		int ldsRecords = 0, ldsRecordsWide = 0, bodyRecordsMax = 0, maxStaged = 0, maxStripBodies = 0;
 		for (int i = 0; i < K && ok; ++i)
 		{
 			PersistDesc& d = descs[(size_t)i];
@@ -1270,6 +1270,8 @@ do                                                                              
 				NEEDSOFT(n0 + n1 <= 512); // both seams share a round: at most two constraints per thread
 			}
 			const int nt = importOffset;
+			maxStaged = std::max(maxStaged, nt);
+			maxStripBodies = std::max(maxStripBodies, nbA);
 			genericBodies = std::max(genericBodies, nt);
 			{
 				auto rangeOf = [](const HostGroupTable& t, int g) {
@@ -1363,6 +1365,9 @@ do                                                                              
 			HIP_TRY(hipHostGetDevicePointer((void**)&devError, s->hostError, 0));
 			pv.error = devError;
 			pv.deviceError = (unsigned int*)(base + o4);
+			pv.state = (unsigned int*)(base + o4 + 128); // (a cache line of its own in the zeroed 256 bytes: wide_kernel.hip's commit counter)
+			pv.maxStaged = maxStaged;
+			pv.maxStripBodies = (maxStripBodies + 31) & ~31;
 			pv.parityStride = parityStride;
 			pv.censusBase = 2 * parityStride;
 			// fresh buffers start from zero tags

@@ -469,12 +469,84 @@ S2_DEV WideRegs unparkWide(const float4* slot, int stride)
 	return p;
 }
 
+S2_DEV WideRegs wideFromSoft(const SoftRegs<SOFT_TGS>& t)
+{
+	WideRegs p;
+	p.idx = (uint32_t)t.h.ia | ((uint32_t)t.h.ib << 13) | (((uint32_t)t.h.pointCount & 3u) << 26) | (t.h.writeA ? 1u << 28 : 0u) | (t.h.writeB ? 1u << 29 : 0u);
+	p.n = f2{t.h.normal.x, t.h.normal.y}, p.friction = t.h.friction;
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		p.lA[j] = lo2(t.an[j]), p.lB[j] = hi2(t.an[j]);
+		p.p0[j] = t.par[j].x, p.p1[j] = t.par[j].y, p.p2[j] = t.par[j].z;
+		p.imp[j] = f2{t.imp[j].x, t.imp[j].y};
+	}
+	return p;
+}
+
+// MODE bits
+#define S2_WIDE_SELF 1 // the kernel is the step's prologue and epilogue too (Executor::selfContainedStrips): ONE launch per step
+#define S2_WIDE_BODYWARM 2 // s2WarmStartContacts as a body-centric pass over per-constraint terms in LDS (no parked rounds)
+
+// s2WarmStartContacts (solve_common.c:276-330), body-centric.  The warm start adds, per constraint and manifold point, a term to each
+// of its bodies that depends on the impulses, the anchors and that body's own pose only -- not on any velocity.  So instead of one
+// colour round per colour (seven barriers of ~0.4 us), every lane writes the terms of the constraints it holds into an LDS table
+// indexed [component][round][body] and every body then adds its terms in round order: the same additions in the same order as the
+// coloured sweep (v + (-mA) P.x is rounded as the reference's mulAdd; w - x == w + (-x)), two barriers.  Terms per side and point:
+// {dv.x, dv.y, dw}; a round's two points are three float2 records {dv0}, {dw0, dv1.x}, {dv1.y, dw1}.
+template <int POINTS> S2_DEV void warmTermsWide(const WideRegs& p, const float4* ldq, const float2* lmass, float2* lt, int tw, int R, int round, int nOwn, uint32_t salt)
+{
+	const uint32_t idx = p.idx ^ salt;
+	const int ia = (int)(idx & 0x1fffu), ib = (int)((idx >> 13) & 0x1fffu);
+	const int pointCount = (int)((idx >> 26) & 3u);
+	const bool wa = (idx & (1u << 28)) != 0 && ia < nOwn, wb = (idx & (1u << 29)) != 0 && ib < nOwn;
+	const float4 dqA = ldq[ia], dqB = ldq[ib];
+	const float2 mA = lmass[ia], mB = lmass[ib];
+	const V2 normal = v2(fromBits(asBits(p.n.x) ^ salt), p.n.y);
+	const V2 tangent = rightPerp(normal);
+	Rot qA, qB;
+	qA.s = dqA.z, qA.c = dqA.w, qB.s = dqB.z, qB.c = dqB.w;
+	float tA[6], tB[6];
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		tA[3 * j] = tA[3 * j + 1] = tA[3 * j + 2] = 0.0f;
+		tB[3 * j] = tB[3 * j + 1] = tB[3 * j + 2] = 0.0f;
+		if (POINTS == 2 || j < pointCount)
+		{
+			const V2 rA = rotate(qA, asV2(p.lA[j])), rB = rotate(qB, asV2(p.lB[j]));
+			const V2 P = add(mulSV(p.imp[j].x, normal), mulSV(p.imp[j].y, tangent));
+			// wA -= iA * cross(rA, P); vA = mulAdd(vA, -mA, P); wB += iB * cross(rB, P); vB = mulAdd(vB, mB, P)
+			tA[3 * j] = -mA.x * P.x, tA[3 * j + 1] = -mA.x * P.y, tA[3 * j + 2] = -(mA.y * cross(rA, P));
+			tB[3 * j] = mB.x * P.x, tB[3 * j + 1] = mB.x * P.y, tB[3 * j + 2] = mB.y * cross(rB, P);
+		}
+	}
+	float2* row = lt + (size_t)round * tw;
+	const int plane = R * tw;
+	if (wa)
+	{
+		row[ia] = make_float2(tA[0], tA[1]);
+		row[plane + ia] = make_float2(tA[2], tA[3]);
+		row[2 * plane + ia] = make_float2(tA[4], tA[5]);
+	}
+	if (wb)
+	{
+		row[ib] = make_float2(tB[0], tB[1]);
+		row[plane + ib] = make_float2(tB[2], tB[3]);
+		row[2 * plane + ib] = make_float2(tB[4], tB[5]);
+	}
+}
+
 // POINTS == 2: the host has checked that every constraint of the strips has two manifold points: no per-point masking.
 // RPH: interior records a lane keeps (colour batches / 2), SR: seam records a lane keeps, SL: seam rounds parked in LDS.
 // IL: interior rounds parked in LDS behind the 2 RPH a lane keeps (a strip that needs a seventh or eighth colour: a hub body inside it).
-template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideStepKernel(ContactView c, BodyView g, StripTableView ta, PersistView pv, const Op* ops, int opCount)
+// MODE: S2_WIDE_SELF | S2_WIDE_BODYWARM.
+template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideStepKernel(ContactView c, BodyView g, StripTableView ta, PersistView pv, const Op* ops, int opCount, WideSelf self)
 {
 	extern __shared__ __attribute__((aligned(16))) float4 lds[];
+	constexpr bool SELF = (MODE & S2_WIDE_SELF) != 0;
+	constexpr bool BODYWARM = (MODE & S2_WIDE_BODYWARM) != 0;
+	static_assert(!BODYWARM || (SL == 0 && IL == 0), "the body-centric warm start keeps no terms for parked rounds");
 	const int tid = (int)threadIdx.x;
 	const int half = tid >> 8, ht = tid & 255; // hand-offs: waves 0-3 serve the left neighbour, waves 4-7 the right
 	// stamps: (wall_clock64 << 4) | tag; tags: 0 start, 1 loaded, 2 body stage, 3 warm start, 4 interior rounds, 5 hand-off, 6 seam rounds, 7 end
@@ -501,10 +573,22 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0> __global__ __laun
 	// L2 path only when both of its workgroups have read the same id from each other -- results never depend on placement.
 	unsigned myXcc;
 	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(myXcc));
+	// SELF: a step enqueued behind one that lost a hand-off must not run at all -- the resident world has to stand where it stood
+	// before the first failure (s2amd_synchronize).  (The hand-off tags start from zero in every launch: this kernel clears the
+	// buffers it reads at its end, as the epilogue launch does for the multi-launch form.  A tag base read from memory instead -- one
+	// more scalar that lives through the kernel -- costs the step loop its register allocation: 32 spilled registers, measured.)
+	constexpr unsigned epoch0 = 0u;
+	if constexpr (SELF)
+	{
+		if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(pv.deviceError, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u)
+		{
+			return;
+		}
+	}
 	gu64* census = (gu64*)pv.granules + pv.censusBase;
 	if (S2_WIDE_XCD_AFFINE && tid == 0)
 	{
-		putGranule(census + strip, 1u, __uint_as_float(myXcc + 1u));
+		putGranule(census + strip, epoch0 + 1u, __uint_as_float(myXcc + 1u));
 	}
 	const StripDesc* da = ta.descs + strip;
 	const PersistDesc* pd = pv.descs + strip;
@@ -551,6 +635,15 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0> __global__ __laun
 	const int sw = pv.parkSeamWidth, iw = pv.parkInteriorWidth;
 	float4* lparked = lcoef + 3 + tid;
 	float4* lparkedI = lcoef + 3 + SL * S2_WIDE_PARKED_RECORDS * sw + ht;
+	// SELF: the positions of the staged bodies (s2FinalizePositions adds to them; the SoA array g.pos is not used); BODYWARM: per body
+	// the rounds that hold a constraint writing it (bits 0-15; bits 16-31: ... with a second manifold point) and the term table
+	float4* lextra = lcoef + 3 + S2_WIDE_PARKED_RECORDS * (SL * sw + IL * iw);
+	float2* lpos = (float2*)lextra;
+	lextra += SELF ? (pv.maxStaged + 1) / 2 : 0;
+	constexpr int TR = 2 * RPH + SR; // rounds of the term table: the interior rounds, then the seam rounds
+	const int tw = pv.maxStripBodies; // (a multiple of 32: PersistView)
+	uint32_t* lmask = (uint32_t*)lextra;
+	float2* lt = (float2*)(lextra + (tw + 3) / 4);
 
 	// ---- loads ----
 	uint32_t id[S2_WIDE_BODY_CHUNKS];
@@ -578,16 +671,6 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0> __global__ __laun
 		return (i < roundsA && k < (half ? batchA[2 * s + 1].y : batchA[2 * s].y)) ? k : -1;
 	};
 	WideRegs rA[RPH];
-#pragma unroll
-	for (int s = 0; s < RPH; ++s)
-	{
-		const int k = kOfSlot(s);
-		if (k >= 0)
-		{
-			const int2 lb = c.localBodies[k];
-			rA[s] = loadWide(c, k, lb.x, lb.y);
-		}
-	}
 	// seam constraints: round r = left seam's batch r followed by right seam's batch r, one per lane (a round holds at
 	// most 512 constraints); where an item lives is recomputed, not stored
 	auto seamItem = [&](int r, int& seam, int& k, uint32_t salt = 0u) {
@@ -608,6 +691,80 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0> __global__ __laun
 	};
 	WideRegs rB[SR];
 	uint32_t seamMask = 0u; // bit i: this lane holds a seam constraint in seam round i
+	// the constraint this lane holds in parked interior round j (round ROUNDS + j runs on half (ROUNDS + j) & 1 like every interior round)
+	auto kOfParked = [&](int j) {
+		const int i = ROUNDS + j;
+		const int k = batchA[i].x + ht;
+		return (i < roundsA && (i & 1) == half && k < batchA[i].y) ? k : -1;
+	};
+	if constexpr (SELF)
+	{
+		// s2PrepareContacts_Soft (solve_common.c:188-274) for the constraints this lane holds, straight from the wire contacts and
+		// bodies (soft_from_wire.h: the operations of prepareContactsKernel<PREP_SOFT>) and -- one record at a time -- out to the SoA
+		// arrays the prologue launch would have filled; from there they come back as plain loads, exactly as in the multi-launch
+		// form.  (Handed on in registers, the five records' live ranges span this phase's own peak: measured 26 spilled registers
+		// that the step loop reloads at every use.)  A seam's constraints are prepared by both of its workgroups: the same bits to
+		// the same addresses.  A free position of the slack layout becomes an empty record.
+		auto prepareAt = [&](int k) {
+			if (k < 0)
+			{
+				return;
+			}
+			const int slot = c.contactIndex[k];
+			float4 nf = make_float4(0.0f, 0.0f, 0.0f, 0.0f), an[2], par[2];
+			float2 imp[2];
+			an[0] = an[1] = par[0] = par[1] = nf;
+			imp[0] = imp[1] = make_float2(0.0f, 0.0f);
+			if (slot >= 0)
+			{
+				const SoftRegs<SOFT_TGS> t = prepareSoftFromWireBodies<SOFT_TGS>(self.wire + slot, self.wireBodies, self.hostFlags, g.capacity, self.warmStart);
+				const uint32_t bits = ((uint32_t)t.h.pointCount & 3u) | (t.h.writeA ? S2C_WRITE_A : 0u) | (t.h.writeB ? S2C_WRITE_B : 0u);
+				nf = make_float4(t.h.normal.x, t.h.normal.y, t.h.friction, fromBits(bits));
+#pragma unroll
+				for (int j = 0; j < 2; ++j)
+				{
+					an[j] = t.an[j], par[j] = t.par[j], imp[j] = t.imp[j];
+				}
+			}
+			c.nf[k] = nf;
+#pragma unroll
+			for (int j = 0; j < 2; ++j)
+			{
+				c.anchor[j][k] = an[j], c.param[j][k] = par[j], c.impulse[j][k] = imp[j];
+			}
+		};
+#pragma unroll
+		for (int s = 0; s < RPH; ++s)
+		{
+			prepareAt(kOfSlot(s));
+		}
+#pragma unroll
+		for (int i = 0; i < ST; ++i)
+		{
+			int seam, k;
+			if (i < roundsB && seamItem(i, seam, k))
+			{
+				prepareAt(k);
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < IL; ++j)
+		{
+			prepareAt(kOfParked(j));
+		}
+		asm volatile("" ::: "memory"); // (the loads below are not to be forwarded from the stores above)
+	}
+	// the prepared records of the constraints this lane holds, out of the SoA arrays: into registers, the parked rounds into LDS
+#pragma unroll
+	for (int s = 0; s < RPH; ++s)
+	{
+		const int k = kOfSlot(s);
+		if (k >= 0)
+		{
+			const int2 lb = c.localBodies[k];
+			rA[s] = loadWide(c, k, lb.x, lb.y);
+		}
+	}
 #pragma unroll
 	for (int i = 0; i < SR; ++i)
 	{
@@ -631,12 +788,6 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0> __global__ __laun
 			seamMask |= 1u << i;
 		}
 	}
-	// the constraint this lane holds in parked interior round j (round ROUNDS + j runs on half (ROUNDS + j) & 1 like every interior round)
-	auto kOfParked = [&](int j) {
-		const int i = ROUNDS + j;
-		const int k = batchA[i].x + ht;
-		return (i < roundsA && (i & 1) == half && k < batchA[i].y) ? k : -1;
-	};
 #pragma unroll
 	for (int j = 0; j < IL; ++j)
 	{
@@ -668,12 +819,51 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0> __global__ __laun
 		flags[ch] = 0u;
 		if (gi >= 0)
 		{
-			lvel[ldsIdx[ch]] = g.vel[gi];
-			ldq[ldsIdx[ch]] = g.dq[gi];
-			flags[ch] = g.flags[gi] | 0x80000000u; // bit 31: slot in use
-			linteg[ldsIdx[ch]] = g.integ[gi];
-			langDamp[ldsIdx[ch]] = g.angDamp[gi];
-			lmass[ldsIdx[ch]] = g.massInv[gi];
+			if constexpr (SELF)
+			{
+				// body_ops.h: unpackBodyOne, into LDS instead of the SoA arrays
+				const s2amdBody* w = self.wireBodies + gi;
+				const int type = w->type;
+				uint32_t f = 0x80000000u;
+				if (type != S2AMD_BODY_FREE)
+				{
+					f |= S2F_LIVE | (type == S2AMD_BODY_DYNAMIC ? S2F_DYNAMIC : 0u) | (type != S2AMD_BODY_STATIC ? S2F_MOVES : 0u);
+				}
+				flags[ch] = f;
+				const int i = ldsIdx[ch];
+				lvel[i] = make_float4(w->linearVelocity[0], w->linearVelocity[1], w->angularVelocity, 0.0f);
+				ldq[i] = make_float4(w->deltaPosition[0], w->deltaPosition[1], w->rot[0], w->rot[1]);
+				if (ch < S2_WIDE_BODY_CHUNKS)
+				{
+					lpos[i] = make_float2(w->position[0], w->position[1]);
+				}
+				lmass[i] = make_float2(w->invMass, w->invI);
+				const V2 gravity = v2(self.gravityX, self.gravityY);
+				const V2 force = v2(w->force[0], w->force[1]);
+				const V2 inner = mulAdd(force, w->mass * w->gravityScale, gravity);
+				const V2 a = mulSV(self.unpackH * w->invMass, inner);
+				const float aw = self.unpackH * w->invI * w->torque;
+				const float ld = 1.0f / (1.0f + self.unpackH * w->linearDamping);
+				const float ad = 1.0f / (1.0f + self.unpackH * w->angularDamping);
+				linteg[i] = make_float4(a.x, a.y, aw, ld);
+				langDamp[i] = ad;
+			}
+			else
+			{
+				lvel[ldsIdx[ch]] = g.vel[gi];
+				ldq[ldsIdx[ch]] = g.dq[gi];
+				flags[ch] = g.flags[gi] | 0x80000000u; // bit 31: slot in use
+				linteg[ldsIdx[ch]] = g.integ[gi];
+				langDamp[ldsIdx[ch]] = g.angDamp[gi];
+				lmass[ldsIdx[ch]] = g.massInv[gi];
+			}
+		}
+	}
+	if constexpr (BODYWARM)
+	{
+		for (int i = tid; i < tw; i += S2_WIDE_THREADS)
+		{
+			lmask[i] = 0u;
 		}
 	}
 	// the neighbours' census entries have had the whole load phase to land; a missing one only costs the fast path
@@ -687,7 +877,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0> __global__ __laun
 			for (int spins = 0; spins < 4096 && !near; ++spins)
 			{
 				const u64 x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				if ((unsigned)(x >> 32) == 1u)
+				if ((unsigned)(x >> 32) == epoch0 + 1u)
 				{
 					near = (unsigned)x == myXcc + 1u ? 1 : -1;
 				}
@@ -741,9 +931,42 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0> __global__ __laun
 			slot[0].x = fromBits(p.idx);
 		}
 	}
+	if constexpr (BODYWARM)
+	{
+		// which rounds write which of my bodies (constant during the step: write bits and point counts are the prepared record's)
+		auto note = [&](const WideRegs& p, int round) {
+			const int ia = (int)(p.idx & 0x1fffu), ib = (int)((p.idx >> 13) & 0x1fffu);
+			const uint32_t bit = (1u << round) | (((p.idx >> 26) & 3u) == 2u ? 1u << (16 + round) : 0u);
+			if ((p.idx & (1u << 28)) != 0 && ia < nb)
+			{
+				atomicOr(&lmask[ia], bit);
+			}
+			if ((p.idx & (1u << 29)) != 0 && ib < nb)
+			{
+				atomicOr(&lmask[ib], bit);
+			}
+		};
+#pragma unroll
+		for (int s = 0; s < RPH; ++s)
+		{
+			if (kOfSlot(s) >= 0)
+			{
+				note(rA[s], 2 * s + half);
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < SR; ++i)
+		{
+			if ((seamMask >> i) & 1u)
+			{
+				note(rB[i], ROUNDS + i);
+			}
+		}
+		__syncthreads();
+	}
 	stampAt(1);
 
-	unsigned epoch = 0; // tags are the exchange number: the buffers are zero at launch (cleared by the previous step's epilogue)
+	unsigned epoch = epoch0; // tags are the exchange number: the buffers are zero at launch (cleared by the previous step's epilogue), or (SELF) hold older tags only
 	int bad = 0;
 	for (int oi = 0; oi < opCount && !bad; ++oi)
 	{
@@ -754,6 +977,10 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0> __global__ __laun
 		asm volatile("s_mov_b32 %0, 0" : "=s"(salt));
 		if (op.code == OP_INTEGRATE_VEL)
 		{
+			if (BODYWARM && oi + 1 < opCount && lops[oi + 1].code == OP_WARM)
+			{
+				continue; // the warm start's body pass integrates the velocities first, in the same lane
+			}
 #pragma unroll
 			for (int ch = 0; ch < S2_WIDE_BODY_CHUNKS + 1; ++ch)
 			{
@@ -804,16 +1031,90 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0> __global__ __laun
 					const float4 d = ldq[i];
 					if (ch < S2_WIDE_BODY_CHUNKS && (id[ch] & S2G_OWNED) != 0)
 					{
-						const int gi = (int)(id[ch] & ~S2G_OWNED);
-						const float2 pos = g.pos[gi];
-						const V2 np = add(v2(pos.x, pos.y), v2(d.x, d.y));
-						g.pos[gi] = make_float2(np.x, np.y);
+						if constexpr (SELF)
+						{
+							const float2 pos = lpos[i];
+							const V2 np = add(v2(pos.x, pos.y), v2(d.x, d.y));
+							lpos[i] = make_float2(np.x, np.y);
+						}
+						else
+						{
+							const int gi = (int)(id[ch] & ~S2G_OWNED);
+							const float2 pos = g.pos[gi];
+							const V2 np = add(v2(pos.x, pos.y), v2(d.x, d.y));
+							g.pos[gi] = make_float2(np.x, np.y);
+						}
 					}
 					ldq[i] = make_float4(0.0f, 0.0f, d.z, d.w);
 				}
 			}
 			__syncthreads();
 			stampAt(2);
+		}
+		else if (BODYWARM && op.code == OP_WARM)
+		{
+			// body-centric (warmTermsWide): every lane writes the terms of the constraints it holds, every body of the strip's own
+			// list adds the terms of its rounds in round order -- behind s2IntegrateVelocities when that is the op before (the
+			// imported copies need neither: the next sweep's exchange overwrites them before anything reads them)
+#pragma unroll
+			for (int s = 0; s < RPH; ++s)
+			{
+				if (kOfSlot(s) >= 0)
+				{
+					warmTermsWide<POINTS>(rA[s], ldq, lmass, lt, tw, TR, 2 * s + half, nb, salt);
+				}
+			}
+#pragma unroll
+			for (int i = 0; i < SR; ++i)
+			{
+				if ((seamMask >> i) & 1u)
+				{
+					warmTermsWide<POINTS>(rB[i], ldq, lmass, lt, tw, TR, ROUNDS + i, nb, salt);
+				}
+			}
+			__syncthreads();
+			const bool integrate = oi > 0 && lops[oi - 1].code == OP_INTEGRATE_VEL;
+#pragma unroll
+			for (int ch = 0; ch < S2_WIDE_BODY_CHUNKS; ++ch)
+			{
+				const int i = ldsIdx[ch];
+				if (flags[ch] != 0u && i < nb)
+				{
+					const uint32_t m = lmask[i];
+					const bool dynamic = integrate && (flags[ch] & S2F_DYNAMIC) != 0;
+					if (m != 0u || dynamic)
+					{
+						const float4 v = lvel[i];
+						V2 lv = v2(v.x, v.y);
+						float w = v.z;
+						if (dynamic)
+						{
+							const float4 k = linteg[i];
+							lv = add(lv, v2(k.x, k.y));
+							w = w + k.z;
+							lv = mulSV(k.w, lv);
+							w *= langDamp[i];
+						}
+						const int plane = TR * tw;
+#pragma unroll
+						for (int r = 0; r < TR; ++r)
+						{
+							if ((m >> r) & 1u)
+							{
+								const float2 t0 = lt[r * tw + i], t1 = lt[plane + r * tw + i], t2 = lt[2 * plane + r * tw + i];
+								lv.x = lv.x + t0.x, lv.y = lv.y + t0.y, w = w + t1.x;
+								if (POINTS == 2 || ((m >> (16 + r)) & 1u))
+								{
+									lv.x = lv.x + t1.y, lv.y = lv.y + t2.x, w = w + t2.y;
+								}
+							}
+						}
+						lvel[i] = make_float4(lv.x, lv.y, w, 0.0f);
+					}
+				}
+			}
+			__syncthreads();
+			stampAt(3);
 		}
 		else if (op.code == OP_WARM)
 		{
@@ -1041,50 +1342,178 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0> __global__ __laun
 	}
 
 	// ---- results: owned bodies, impulses ----
-#pragma unroll
-	for (int ch = 0; ch < S2_WIDE_BODY_CHUNKS; ++ch)
+	if constexpr (SELF)
 	{
-		const int i = tid + ch * S2_WIDE_THREADS;
-		if (i < nb && (id[ch] & S2G_OWNED) != 0)
+		// Nothing of a step that lost a hand-off may reach the wire arrays (the host repeats it on the multi-launch path from
+		// untouched inputs), and there is no epilogue launch to stand down: every workgroup that came through arrives at a counter
+		// and writes only once all K have -- a workgroup that saw a dead hand-off never arrives, so nobody writes.  The counter
+		// runs on from step to step (K arrivals each: the step an arrival belongs to is its ticket / K); the host zeroes it after a
+		// failure and every 2^20 steps.
+		__shared__ int lcommit;
+		if (tid == 0)
 		{
-			const int gi = (int)(id[ch] & ~S2G_OWNED);
-			g.vel[gi] = lvel[i];
-			g.dq[gi] = ldq[i];
+			int go = 0;
+			if (!bad)
+			{
+				const unsigned ticket = __hip_atomic_fetch_add(pv.state, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const unsigned target = (ticket / (unsigned)K + 1u) * (unsigned)K;
+				for (unsigned spins = 0; spins < pv.spinLimit; ++spins)
+				{
+					if (__hip_atomic_load(pv.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target)
+					{
+						go = 1;
+						break;
+					}
+					if ((spins & 63u) == 63u && __hip_atomic_load(pv.deviceError, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+					{
+						break;
+					}
+					__builtin_amdgcn_s_sleep(1);
+				}
+				if (!go)
+				{
+					__hip_atomic_store(pv.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					__hip_atomic_store(pv.deviceError, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+			}
+			lcommit = go;
+		}
+		__syncthreads();
+		if (!lcommit)
+		{
+			return;
+		}
+		// every workgroup is past its last hand-off: the buffers this one reads (both parities) and its census entry go back to
+		// zero tags for the next launch
+		if (ht < nImpH)
+		{
+#pragma unroll
+			for (int par = 0; par < 2; ++par)
+			{
+				gu64* p = gran + par * pv.parityStride + inH + 4 * ht;
+				p[0] = 0ull, p[1] = 0ull, p[2] = 0ull, p[3] = 0ull;
+			}
+		}
+		if (S2_WIDE_XCD_AFFINE && tid == 0)
+		{
+			census[strip] = 0ull;
+		}
+		// body_ops.h: packBodyOne from the LDS copies
+#pragma unroll
+		for (int ch = 0; ch < S2_WIDE_BODY_CHUNKS; ++ch)
+		{
+			const int i = tid + ch * S2_WIDE_THREADS;
+			if (i < nb && (id[ch] & S2G_OWNED) != 0 && (flags[ch] & S2F_LIVE) != 0)
+			{
+				s2amdBody* w = self.wireBodies + (int)(id[ch] & ~S2G_OWNED);
+				const float4 v = lvel[i], d = ldq[i];
+				const float2 pos = lpos[i];
+				w->position[0] = pos.x, w->position[1] = pos.y;
+				w->rot[0] = d.z, w->rot[1] = d.w;
+				w->linearVelocity[0] = v.x, w->linearVelocity[1] = v.y;
+				w->angularVelocity = v.z;
+				w->deltaPosition[0] = d.x, w->deltaPosition[1] = d.y;
+			}
+		}
+		// s2StoreContactImpulses (solve_common.c:396-410): straight into the manifolds
+		auto storeWire = [&](const WideRegs& p, int k) {
+			const int slot = c.contactIndex[k];
+			const int pointCount = (int)((p.idx >> 26) & 3u);
+			if (slot >= 0)
+			{
+				s2amdContact* contact = self.wire + slot;
+#pragma unroll
+				for (int j = 0; j < 2; ++j)
+				{
+					if (j < pointCount)
+					{
+						contact->points[j].normalImpulse = p.imp[j].x;
+						contact->points[j].tangentImpulse = p.imp[j].y;
+					}
+				}
+			}
+		};
+#pragma unroll
+		for (int s = 0; s < RPH; ++s)
+		{
+			if (kOfSlot(s) >= 0)
+			{
+				storeWire(rA[s], kOfSlot(s));
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < IL; ++j)
+		{
+			if (kOfParked(j) >= 0)
+			{
+				storeWire(unparkWide(lparkedI + j * S2_WIDE_PARKED_RECORDS * iw, iw), kOfParked(j));
+			}
+		}
+		// (the right seam's impulses are stored by this workgroup -- its left neighbour of that seam --, nobody stores twice)
+#pragma unroll
+		for (int i = 0; i < ST; ++i)
+		{
+			int seam, k;
+			if (i < roundsB && seamItem(i, seam, k) && seam == 1)
+			{
+				if (i < SR)
+				{
+					storeWire(rB[i < SR ? i : 0], k);
+				}
+				else
+				{
+					storeWire(unparkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * sw, sw), k);
+				}
+			}
 		}
 	}
-#pragma unroll
-	for (int s = 0; s < RPH; ++s)
+	else
 	{
-		if (kOfSlot(s) >= 0)
+#pragma unroll
+		for (int ch = 0; ch < S2_WIDE_BODY_CHUNKS; ++ch)
 		{
-			storeWide(c, rA[s], kOfSlot(s));
+			const int i = tid + ch * S2_WIDE_THREADS;
+			if (i < nb && (id[ch] & S2G_OWNED) != 0)
+			{
+				const int gi = (int)(id[ch] & ~S2G_OWNED);
+				g.vel[gi] = lvel[i];
+				g.dq[gi] = ldq[i];
+			}
 		}
-	}
 #pragma unroll
-	for (int j = 0; j < IL; ++j)
-	{
-		if (kOfParked(j) >= 0)
+		for (int s = 0; s < RPH; ++s)
 		{
-			storeWide(c, unparkWide(lparkedI + j * S2_WIDE_PARKED_RECORDS * iw, iw), kOfParked(j));
+			if (kOfSlot(s) >= 0)
+			{
+				storeWide(c, rA[s], kOfSlot(s));
+			}
 		}
-	}
-	// the right seam's impulses are stored by this workgroup (its left neighbour of that seam), nobody stores twice
 #pragma unroll
-	for (int i = 0; i < SR; ++i)
-	{
-		int seam, k;
-		if (i < roundsB && seamItem(i, seam, k) && seam == 1)
+		for (int j = 0; j < IL; ++j)
 		{
-			storeWide(c, rB[i], k);
+			if (kOfParked(j) >= 0)
+			{
+				storeWide(c, unparkWide(lparkedI + j * S2_WIDE_PARKED_RECORDS * iw, iw), kOfParked(j));
+			}
 		}
-	}
+		// the right seam's impulses are stored by this workgroup (its left neighbour of that seam), nobody stores twice
 #pragma unroll
-	for (int i = SR; i < ST; ++i)
-	{
-		int seam, k;
-		if (i < roundsB && seamItem(i, seam, k) && seam == 1)
+		for (int i = 0; i < SR; ++i)
 		{
-			storeWide(c, unparkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * sw, sw), k);
+			int seam, k;
+			if (i < roundsB && seamItem(i, seam, k) && seam == 1)
+			{
+				storeWide(c, rB[i], k);
+			}
+		}
+#pragma unroll
+		for (int i = SR; i < ST; ++i)
+		{
+			int seam, k;
+			if (i < roundsB && seamItem(i, seam, k) && seam == 1)
+			{
+				storeWide(c, unparkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * sw, sw), k);
+			}
 		}
 	}
 	stampAt(7);
@@ -1095,78 +1524,152 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0> __global__ __laun
 	}
 }
 
+// (experiments: compile the headline variant's four modes only -- tools/kernel_ab.sh, register counts)
+#ifndef S2_WIDE_ONLY_MAIN
+#define S2_WIDE_ONLY_MAIN 0
+#endif
+#if S2_WIDE_ONLY_MAIN
+template __global__ void wideStepKernel<2, 3, 2, 0, 0, 0>(ContactView, BodyView, StripTableView, PersistView, const Op*, int, WideSelf);
+template __global__ void wideStepKernel<2, 3, 2, 0, 0, 1>(ContactView, BodyView, StripTableView, PersistView, const Op*, int, WideSelf);
+template __global__ void wideStepKernel<2, 3, 2, 0, 0, 2>(ContactView, BodyView, StripTableView, PersistView, const Op*, int, WideSelf);
+template __global__ void wideStepKernel<2, 3, 2, 0, 0, 3>(ContactView, BodyView, StripTableView, PersistView, const Op*, int, WideSelf);
+#else
 // Eligibility (checked by the caller, solver_executor.h widePlan): TGS_Soft with the current-anchor warm start on a partition with
 // at most 6 interior colour batches per strip and 3 per seam, or 8 and 2 (pv.maxRoundsA, pv.maxSeamRounds): five or six resident
 // records per lane fit its 256 registers beside the round's working set, seven do not (measured: 160 spilled registers).
-template <int RPH, int SR, int SL = 0, int IL = 0>
-static void launchWide(hipStream_t s, dim3 grid, size_t lds, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount)
+template <int RPH, int SR, int SL, int IL, int MODE>
+static void launchWideMode(hipStream_t s, dim3 grid, size_t lds, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount,
+						   const WideSelf& self)
 {
 	const dim3 block(S2_WIDE_THREADS);
-	lds += (size_t)S2_WIDE_PARKED_RECORDS * ((size_t)SL * pv.parkSeamWidth + (size_t)IL * pv.parkInteriorWidth) * sizeof(float4);
 	if (pv.allTwoPoints)
 	{
-		wideStepKernel<2, RPH, SR, SL, IL><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
+		wideStepKernel<2, RPH, SR, SL, IL, MODE><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount, self);
 	}
 	else
 	{
-		wideStepKernel<0, RPH, SR, SL, IL><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount);
+		wideStepKernel<0, RPH, SR, SL, IL, MODE><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount, self);
 	}
 }
 
-// records of dynamic LDS the variant for (maxRoundsA, maxSeamRounds) needs beside the bodies, the ops and the three fixed records;
-// -1: no variant takes that partition (Executor::widePlan)
-int wideParkedRecords(int maxRoundsA, int maxSeamRounds, int force, int parkSeamWidth, int parkInteriorWidth)
+// dynamic LDS beside the bodies, the ops and the three fixed records: parked rounds, the staged positions (self-contained), the
+// round masks and the term table of the body-centric warm start
+static size_t wideExtraLds(const PersistView& pv, int RPH, int SR, int SL, int IL, bool selfContained, bool bodyWarm)
 {
-	if (maxRoundsA > 8 || maxSeamRounds > 4)
+	size_t records = (size_t)S2_WIDE_PARKED_RECORDS * ((size_t)SL * pv.parkSeamWidth + (size_t)IL * pv.parkInteriorWidth);
+	records += selfContained ? (size_t)(pv.maxStaged + 1) / 2 : 0;
+	if (bodyWarm)
+	{
+		const size_t tw = (size_t)pv.maxStripBodies, rounds = (size_t)(2 * RPH + SR);
+		records += (tw + 3) / 4 + (3 * rounds * tw + 1) / 2;
+	}
+	return records * sizeof(float4);
+}
+
+template <int RPH, int SR, int SL = 0, int IL = 0>
+static void launchWide(hipStream_t s, dim3 grid, size_t lds, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount,
+					   const WideSelf* self)
+{
+	const bool selfContained = self != nullptr;
+	const bool bodyWarm = SL == 0 && IL == 0 && pv.bodyWarm != 0;
+	lds += wideExtraLds(pv, RPH, SR, SL, IL, selfContained, bodyWarm);
+	const WideSelf none{};
+	if constexpr (SL == 0 && IL == 0)
+	{
+		if (selfContained && bodyWarm)
+		{
+			launchWideMode<RPH, SR, SL, IL, S2_WIDE_SELF | S2_WIDE_BODYWARM>(s, grid, lds, c, g, a, pv, ops, opCount, *self);
+			return;
+		}
+		if (bodyWarm)
+		{
+			launchWideMode<RPH, SR, SL, IL, S2_WIDE_BODYWARM>(s, grid, lds, c, g, a, pv, ops, opCount, none);
+			return;
+		}
+	}
+	if (selfContained)
+	{
+		launchWideMode<RPH, SR, SL, IL, S2_WIDE_SELF>(s, grid, lds, c, g, a, pv, ops, opCount, *self);
+	}
+	else
+	{
+		launchWideMode<RPH, SR, SL, IL, 0>(s, grid, lds, c, g, a, pv, ops, opCount, none);
+	}
+}
+
+// which variant takes the partition: RPH/SR/SL/IL as an index 0..4, -1: none
+static int wideVariant(const PersistView& pv)
+{
+	if (pv.maxRoundsA > 8 || pv.maxSeamRounds > 4)
 	{
 		return -1;
 	}
-	const bool inRegisters = !force && ((maxRoundsA <= 6 && maxSeamRounds <= 3) || maxSeamRounds <= 2);
-	if (inRegisters)
-	{
-		return 0;
-	}
-	// (the variants below: two parked seam rounds, and two parked interior rounds when a strip needs more than six colours)
-	return 2 * S2_WIDE_PARKED_RECORDS * parkSeamWidth + (maxRoundsA > 6 ? 2 * S2_WIDE_PARKED_RECORDS * parkInteriorWidth : 0);
-}
-
-void launchWideStep(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount)
-{
-	const dim3 grid((unsigned)a.groupCount);
-	const size_t lds = (size_t)(pv.bodyRecords + 3) * sizeof(float4) + (size_t)opCount * sizeof(Op);
 	const bool park = (pv.debugSkip & 16) != 0; // tests: the variants with parked seam rounds whatever the partition needs
 	if (park)
 	{
-		if (pv.maxRoundsA <= 6)
-		{
-			launchWide<3, 2, 2>(s, grid, lds, c, g, a, pv, ops, opCount);
-		}
-		else
-		{
-			launchWide<3, 2, 2, 2>(s, grid, lds, c, g, a, pv, ops, opCount);
-		}
+		return pv.maxRoundsA <= 6 ? 3 : 4;
 	}
-	else if (pv.maxRoundsA <= 6 && pv.maxSeamRounds <= 2)
+	if (pv.maxRoundsA <= 6 && pv.maxSeamRounds <= 2)
 	{
-		launchWide<3, 2>(s, grid, lds, c, g, a, pv, ops, opCount);
+		return 0; // <3, 2>
 	}
-	else if (pv.maxRoundsA <= 6 && pv.maxSeamRounds <= 3)
+	if (pv.maxRoundsA <= 6 && pv.maxSeamRounds <= 3)
 	{
-		launchWide<3, 3>(s, grid, lds, c, g, a, pv, ops, opCount);
+		return 1; // <3, 3>
 	}
-	else if (pv.maxSeamRounds <= 2)
+	if (pv.maxSeamRounds <= 2)
 	{
-		launchWide<4, 2>(s, grid, lds, c, g, a, pv, ops, opCount);
+		return 2; // <4, 2>
 	}
-	else if (pv.maxRoundsA <= 6)
+	// (seven or eight interior colours AND three or four seam colours -- a pile after an impact: six interior and two seam rounds in
+	// registers, the rest parked -- the <4, 2, 2> layout of eight interior records per lane pair spilled 41 registers)
+	return pv.maxRoundsA <= 6 ? 3 : 4; // <3, 2, 2>, <3, 2, 2, 2>
+}
+
+// records of dynamic LDS the variant for this partition needs beside the bodies, the ops and the three fixed records; -1: no variant
+// takes that partition (Executor::widePlan)
+int wideExtraRecords(const PersistView& pv, int selfContained, int bodyWarm)
+{
+	static const int shape[5][4] = {{3, 2, 0, 0}, {3, 3, 0, 0}, {4, 2, 0, 0}, {3, 2, 2, 0}, {3, 2, 2, 2}};
+	const int v = wideVariant(pv);
+	if (v < 0)
 	{
-		launchWide<3, 2, 2>(s, grid, lds, c, g, a, pv, ops, opCount);
+		return -1;
 	}
-	else
+	const bool warm = bodyWarm != 0 && shape[v][2] == 0 && shape[v][3] == 0;
+	return (int)(wideExtraLds(pv, shape[v][0], shape[v][1], shape[v][2], shape[v][3], selfContained != 0, warm) / sizeof(float4));
+}
+
+// ... and whether that variant has the body-centric warm start at all (the parked ones keep the coloured sweep)
+int wideBodyWarmVariant(const PersistView& pv)
+{
+	const int v = wideVariant(pv);
+	return v >= 0 && v <= 2 ? 1 : 0;
+}
+
+void launchWideStep(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount, const WideSelf* self)
+{
+	const dim3 grid((unsigned)a.groupCount);
+	const size_t lds = (size_t)(pv.bodyRecords + 3) * sizeof(float4) + (size_t)opCount * sizeof(Op);
+	switch (wideVariant(pv))
 	{
-		// seven or eight interior colours AND three or four seam colours (a pile after an impact): six interior and two seam rounds in
-		// registers, the rest parked -- the <4, 2, 2> layout of eight interior records per lane pair spilled 41 registers
-		launchWide<3, 2, 2, 2>(s, grid, lds, c, g, a, pv, ops, opCount);
+		case 0:
+			launchWide<3, 2>(s, grid, lds, c, g, a, pv, ops, opCount, self);
+			break;
+		case 1:
+			launchWide<3, 3>(s, grid, lds, c, g, a, pv, ops, opCount, self);
+			break;
+		case 2:
+			launchWide<4, 2>(s, grid, lds, c, g, a, pv, ops, opCount, self);
+			break;
+		case 3:
+			launchWide<3, 2, 2>(s, grid, lds, c, g, a, pv, ops, opCount, self);
+			break;
+		case 4:
+			launchWide<3, 2, 2, 2>(s, grid, lds, c, g, a, pv, ops, opCount, self);
+			break;
+		default:
+			break;
 	}
 }
 
@@ -1178,21 +1681,6 @@ void launchWideStep(hipStream_t s, const ContactView& c, const BodyView& g, cons
 // from the strip kernel above is the shorter instruction stream -- the 22-dword record without an unpack step, the coefficient
 // table, the chain on 2-vectors: the island kernel is VALU-issue bound, instructions are its time.
 // ------------------------------------------------------------------------------------------------
-S2_DEV WideRegs wideFromSoft(const SoftRegs<SOFT_TGS>& t)
-{
-	WideRegs p;
-	p.idx = (uint32_t)t.h.ia | ((uint32_t)t.h.ib << 13) | (((uint32_t)t.h.pointCount & 3u) << 26) | (t.h.writeA ? 1u << 28 : 0u) | (t.h.writeB ? 1u << 29 : 0u);
-	p.n = f2{t.h.normal.x, t.h.normal.y}, p.friction = t.h.friction;
-#pragma unroll
-	for (int j = 0; j < 2; ++j)
-	{
-		p.lA[j] = lo2(t.an[j]), p.lB[j] = hi2(t.an[j]);
-		p.p0[j] = t.par[j].x, p.p1[j] = t.par[j].y, p.p2[j] = t.par[j].z;
-		p.imp[j] = f2{t.imp[j].x, t.imp[j].y};
-	}
-	return p;
-}
-
 // SELF: the kernel is also the step's body prologue and epilogue -- it stages its bodies straight from the wire records (the
 // operations of body_ops.h: unpackBodyOne) and writes the owned ones back (packBodyOne) --, for a world that consists of
 // resident islands only (BASELINE config 5): the step is this one launch.
@@ -1523,10 +2011,12 @@ int wideKernelSetup()
 			return 1;
 		}
 	}
-	const void* steps[] = {(const void*)wideStepKernel<0, 3, 2>, (const void*)wideStepKernel<2, 3, 2>, (const void*)wideStepKernel<0, 3, 3>,
-						   (const void*)wideStepKernel<2, 3, 3>, (const void*)wideStepKernel<0, 4, 2>, (const void*)wideStepKernel<2, 4, 2>,
-						   (const void*)wideStepKernel<0, 3, 2, 2>, (const void*)wideStepKernel<2, 3, 2, 2>, (const void*)wideStepKernel<0, 3, 2, 2, 2>,
-						   (const void*)wideStepKernel<2, 3, 2, 2, 2>};
+#define S2_WIDE_MODES(P, RPH, SR) (const void*)wideStepKernel<P, RPH, SR, 0, 0, 0>, (const void*)wideStepKernel<P, RPH, SR, 0, 0, 1>, (const void*)wideStepKernel<P, RPH, SR, 0, 0, 2>, (const void*)wideStepKernel<P, RPH, SR, 0, 0, 3>
+	const void* steps[] = {S2_WIDE_MODES(0, 3, 2), S2_WIDE_MODES(2, 3, 2), S2_WIDE_MODES(0, 3, 3), S2_WIDE_MODES(2, 3, 3), S2_WIDE_MODES(0, 4, 2), S2_WIDE_MODES(2, 4, 2),
+						   (const void*)wideStepKernel<0, 3, 2, 2, 0, 0>, (const void*)wideStepKernel<2, 3, 2, 2, 0, 0>, (const void*)wideStepKernel<0, 3, 2, 2, 2, 0>,
+						   (const void*)wideStepKernel<2, 3, 2, 2, 2, 0>, (const void*)wideStepKernel<0, 3, 2, 2, 0, 1>, (const void*)wideStepKernel<2, 3, 2, 2, 0, 1>,
+						   (const void*)wideStepKernel<0, 3, 2, 2, 2, 1>, (const void*)wideStepKernel<2, 3, 2, 2, 2, 1>};
+#undef S2_WIDE_MODES
 	for (const void* f : steps)
 	{
 		hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1537,3 +2027,4 @@ int wideKernelSetup()
 	}
 	return 0;
 }
+#endif // S2_WIDE_ONLY_MAIN

@@ -611,9 +611,10 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 		{
 			// bodies, impulses and (because the solve left the bodies alone) the shapes are what they were before the solve;
 			// the counters of stage 3 were read and reset above and are kept (contactsSeen below takes the first read)
-			*s->hostError = 0u;
-			HIP_TRY(hipMemsetAsync(s->persist.deviceError, 0, sizeof(unsigned int), st));
-			HIP_TRY(hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, st));
+			if ((rc = resetPersistState(s, st)) != 0)
+			{
+				return rc;
+			}
 			s->persistFailed = true;
 			s->persistFallbacks += 1;
 			fallbacks += 1;

@@ -98,3 +98,101 @@ S2_DEV SoftRegs<KIND> prepareSoftFromWireBodies(const s2amdContact* contact, con
 	r.h.ia = 0, r.h.ib = 0;
 	return r;
 }
+
+// ... and in three stages, for a kernel that prepares several constraints per lane and wants each stage's loads of ALL of them in
+// flight at once (wide_kernel.hip, S2_WIDE_SELF): what s2PrepareContacts_Soft reads of a contact (every load unconditional; a
+// manifold point beyond pointCount is memory of the record, read and ignored), of its two bodies, and the arithmetic of
+// prepareSoftFromWire above on those values, operation for operation.
+struct WireContactRaw
+{
+	int ia, ib, pointCount;
+	V2 normal;
+	float friction;
+	V2 anchorA[2], anchorB[2];
+	float separation[2], normalImpulse[2], tangentImpulse[2];
+};
+struct WireBodiesRaw
+{
+	V2 lcA, lcB;
+	Rot qA, qB;
+	float mA, iA, mB, iB;
+	uint32_t flagsA, flagsB;
+};
+S2_DEV WireContactRaw loadWireContact(const s2amdContact* contact, int bodyCapacity)
+{
+	WireContactRaw r;
+	r.pointCount = contact->pointCount;
+	r.ia = contact->bodyA, r.ib = contact->bodyB;
+	if (r.ia < 0 || r.ib < 0 || r.ia >= bodyCapacity || r.ib >= bodyCapacity)
+	{
+		// (a destroyed contact whose entry lingers: prepareSoftFromWire drops its points; any other contact with points names live bodies)
+		r.pointCount = 0, r.ia = 0, r.ib = 0;
+	}
+	r.pointCount = r.pointCount > 0 ? r.pointCount : 0;
+	r.normal = v2(contact->normal[0], contact->normal[1]);
+	r.friction = contact->friction;
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		const s2amdManifoldPoint* mp = contact->points + j;
+		r.anchorA[j] = v2(mp->localAnchorA[0], mp->localAnchorA[1]);
+		r.anchorB[j] = v2(mp->localAnchorB[0], mp->localAnchorB[1]);
+		r.separation[j] = mp->separation;
+		r.normalImpulse[j] = mp->normalImpulse;
+		r.tangentImpulse[j] = mp->tangentImpulse;
+	}
+	return r;
+}
+S2_DEV WireBodiesRaw loadWireBodies(const s2amdBody* wireBodies, const uint32_t* hostFlags, const WireContactRaw& c)
+{
+	const s2amdBody* wa = wireBodies + c.ia;
+	const s2amdBody* wb = wireBodies + c.ib;
+	WireBodiesRaw r;
+	r.lcA = v2(wa->localCenter[0], wa->localCenter[1]), r.lcB = v2(wb->localCenter[0], wb->localCenter[1]);
+	r.qA.s = wa->rot[0], r.qA.c = wa->rot[1], r.qB.s = wb->rot[0], r.qB.c = wb->rot[1];
+	r.mA = wa->invMass, r.iA = wa->invI, r.mB = wb->invMass, r.iB = wb->invI;
+	r.flagsA = hostFlags[c.ia], r.flagsB = hostFlags[c.ib];
+	return r;
+}
+// live == false: an empty record (a free position of the slack layout)
+S2_DEV void prepareSoftFromRaw(const WireContactRaw& c, const WireBodiesRaw& b, int warmStart, bool live, float4& nf, float4 (&an)[2], float4 (&par)[2], float2 (&imp)[2])
+{
+	const int pointCount = live ? c.pointCount : 0;
+	const V2 normal = c.normal;
+	const V2 tangent = rightPerp(normal);
+	const float mA = b.mA, iA = b.iA, mB = b.mB, iB = b.iB;
+	const bool writeA = pointCount > 0 && (b.flagsA & S2F_WRITE_VEL) != 0; // (the soft solvers are velocity-class sweeps)
+	const bool writeB = pointCount > 0 && (b.flagsB & S2F_WRITE_VEL) != 0;
+	const uint32_t bits = ((uint32_t)pointCount & 3u) | (writeA ? S2C_WRITE_A : 0u) | (writeB ? S2C_WRITE_B : 0u);
+	nf = live ? make_float4(normal.x, normal.y, c.friction, fromBits(bits)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		an[j] = zero, par[j] = zero;
+		imp[j] = make_float2(0.0f, 0.0f);
+		if (j < pointCount)
+		{
+			if (warmStart)
+			{
+				imp[j] = make_float2(c.normalImpulse[j], c.tangentImpulse[j]);
+			}
+			V2 lA = sub(c.anchorA[j], b.lcA);
+			V2 lB = sub(c.anchorB[j], b.lcB);
+			V2 rA = rotate(b.qA, lA);
+			V2 rB = rotate(b.qB, lB);
+			float separation = c.separation[j];
+			float adjustedSeparation = separation - dot(sub(rB, rA), normal);
+			float rtA = cross(rA, tangent);
+			float rtB = cross(rB, tangent);
+			float kTangent = mA + mB + iA * rtA * rtA + iB * rtB * rtB;
+			float tangentMass = kTangent > 0.0f ? 1.0f / kTangent : 0.0f;
+			float rnA = cross(rA, normal);
+			float rnB = cross(rB, normal);
+			float kNormal = mA + mB + iA * rnA * rnA + iB * rnB * rnB;
+			float normalMass = kNormal > 0.0f ? 1.0f / kNormal : 0.0f;
+			an[j] = make_float4(lA.x, lA.y, lB.x, lB.y);
+			par[j] = make_float4(adjustedSeparation, normalMass, tangentMass, separation);
+		}
+	}
+}

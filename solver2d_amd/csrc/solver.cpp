@@ -207,7 +207,7 @@ void s2amd_destroy(s2amdSolver* s)
 		{
 			// pair_kernel.hip's tagged stamps: time per phase of the last step, one workgroup
 			static const char* names[16] = {"start", "load", "body stages", "warm starts", "interior rounds (last)", "hand-offs", "seam rounds (last)", "store",
-											"interior 0", "interior 1", "interior 2", "interior 3", "interior 4", "interior 5", "seam 0", "seam 1"};
+											"interior 0", "interior 1", "interior 2", "interior 3", "commit wait (self-contained)", "interior 5", "seam 0", "seam 1 | warm-start terms (body-centric)"};
 			double sum[16] = {0};
 			int count[16] = {0};
 			for (int i = 1; i < n && i < 250; ++i)

@@ -700,81 +700,90 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0> __g
 	if constexpr (SELF)
 	{
 		// s2PrepareContacts_Soft (solve_common.c:188-274) for the constraints this lane holds, straight from the wire contacts and
-		// bodies (soft_from_wire.h: the operations of prepareContactsKernel<PREP_SOFT>) and -- one record at a time -- out to the SoA
-		// arrays the prologue launch would have filled; from there they come back as plain loads, exactly as in the multi-launch
-		// form.  (Handed on in registers, the five records' live ranges span this phase's own peak: measured 26 spilled registers
-		// that the step loop reloads at every use.)  A seam's constraints are prepared by both of its workgroups: the same bits to
-		// the same addresses.  A free position of the slack layout becomes an empty record.
-		auto prepareAt = [&](int k) {
-			if (k < 0)
-			{
-				return;
-			}
-			const int slot = c.contactIndex[k];
-			float4 nf = make_float4(0.0f, 0.0f, 0.0f, 0.0f), an[2], par[2];
-			float2 imp[2];
-			an[0] = an[1] = par[0] = par[1] = nf;
-			imp[0] = imp[1] = make_float2(0.0f, 0.0f);
-			if (slot >= 0)
-			{
-				const SoftRegs<SOFT_TGS> t = prepareSoftFromWireBodies<SOFT_TGS>(self.wire + slot, self.wireBodies, self.hostFlags, g.capacity, self.warmStart);
-				const uint32_t bits = ((uint32_t)t.h.pointCount & 3u) | (t.h.writeA ? S2C_WRITE_A : 0u) | (t.h.writeB ? S2C_WRITE_B : 0u);
-				nf = make_float4(t.h.normal.x, t.h.normal.y, t.h.friction, fromBits(bits));
-#pragma unroll
-				for (int j = 0; j < 2; ++j)
-				{
-					an[j] = t.an[j], par[j] = t.par[j], imp[j] = t.imp[j];
-				}
-			}
-			c.nf[k] = nf;
-#pragma unroll
-			for (int j = 0; j < 2; ++j)
-			{
-				c.anchor[j][k] = an[j], c.param[j][k] = par[j], c.impulse[j][k] = imp[j];
-			}
-		};
+		// bodies (soft_from_wire.h: the operations of prepareContactsKernel<PREP_SOFT>) and out to the SoA arrays the prologue launch
+		// would have filled; from there they come back as plain loads, exactly as in the multi-launch form.  (Handed on in registers,
+		// the five records' live ranges span this phase's own peak: measured 26 spilled registers that the step loop reloads at every
+		// use.)  Three dependent memory round trips -- position -> pool slot -> contact -> its two bodies --, each issued for ALL of the
+		// lane's constraints at once (unconditional loads from clamped indices: one constraint after the other cost the launch 20 us).
+		// A seam's constraints are prepared by both of its workgroups: the same bits to the same addresses.  A free position of
+		// the slack layout becomes an empty record.
+		constexpr int NP = RPH + ST + IL;
+		int kk[NP];
 #pragma unroll
 		for (int s = 0; s < RPH; ++s)
 		{
-			prepareAt(kOfSlot(s));
+			kk[s] = kOfSlot(s);
 		}
 #pragma unroll
 		for (int i = 0; i < ST; ++i)
 		{
 			int seam, k;
-			if (i < roundsB && seamItem(i, seam, k))
-			{
-				prepareAt(k);
-			}
+			kk[RPH + i] = (i < roundsB && seamItem(i, seam, k)) ? k : -1;
 		}
 #pragma unroll
 		for (int j = 0; j < IL; ++j)
 		{
-			prepareAt(kOfParked(j));
+			kk[RPH + ST + j] = kOfParked(j);
+		}
+		int slot[NP];
+#pragma unroll
+		for (int i = 0; i < NP; ++i)
+		{
+			slot[i] = c.contactIndex[kk[i] >= 0 ? kk[i] : 0];
+		}
+		WireContactRaw raw[NP];
+#pragma unroll
+		for (int i = 0; i < NP; ++i)
+		{
+			slot[i] = kk[i] >= 0 ? slot[i] : -1;
+			raw[i] = loadWireContact(self.wire + (slot[i] >= 0 ? slot[i] : 0), g.capacity);
+		}
+		WireBodiesRaw rawBodies[NP];
+#pragma unroll
+		for (int i = 0; i < NP; ++i)
+		{
+			rawBodies[i] = loadWireBodies(self.wireBodies, self.hostFlags, raw[i]);
+		}
+#pragma unroll
+		for (int i = 0; i < NP; ++i)
+		{
+			float4 nf, an[2], par[2];
+			float2 imp[2];
+			prepareSoftFromRaw(raw[i], rawBodies[i], self.warmStart, slot[i] >= 0, nf, an, par, imp);
+			if (kk[i] >= 0)
+			{
+				const int k = kk[i];
+				c.nf[k] = nf;
+#pragma unroll
+				for (int j = 0; j < 2; ++j)
+				{
+					c.anchor[j][k] = an[j], c.param[j][k] = par[j], c.impulse[j][k] = imp[j];
+				}
+			}
 		}
 		asm volatile("" ::: "memory"); // (the loads below are not to be forwarded from the stores above)
 	}
-	// the prepared records of the constraints this lane holds, out of the SoA arrays: into registers, the parked rounds into LDS
+	// the prepared records of the constraints this lane holds, out of the SoA arrays: into registers, the parked rounds into LDS.
+	// (The register-resident ones with unconditional loads from clamped positions, so that all five records' loads are in flight
+	// together -- a lane without a constraint in a round reads position 0 and never looks at the record.)
 #pragma unroll
 	for (int s = 0; s < RPH; ++s)
 	{
 		const int k = kOfSlot(s);
-		if (k >= 0)
-		{
-			const int2 lb = c.localBodies[k];
-			rA[s] = loadWide(c, k, lb.x, lb.y);
-		}
+		const int kc = k >= 0 ? k : 0;
+		const int2 lb = c.localBodies[kc];
+		rA[s] = loadWide(c, kc, lb.x, lb.y);
 	}
 #pragma unroll
 	for (int i = 0; i < SR; ++i)
 	{
-		int seam, k;
-		if (i < roundsB && seamItem(i, seam, k))
-		{
-			const int2 lb = c.localBodies[k];
-			rB[i] = loadWide(c, k, pv.remap[pd->remapBase[seam] + lb.x], pv.remap[pd->remapBase[seam] + lb.y]);
-			seamMask |= 1u << i;
-		}
+		int seam = 0, k = 0;
+		const bool mine = i < roundsB && seamItem(i, seam, k);
+		const int kc = mine ? k : 0;
+		const int2 lb = c.localBodies[kc];
+		const int base = mine ? pd->remapBase[seam] : 0; // (a valid entry of the remap table either way)
+		rB[i] = loadWide(c, kc, pv.remap[base + (mine ? lb.x : 0)], pv.remap[base + (mine ? lb.y : 0)]);
+		seamMask |= mine ? 1u << i : 0u;
 	}
 #pragma unroll
 	for (int i = SR; i < ST; ++i)
@@ -1073,6 +1082,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0> __g
 				}
 			}
 			__syncthreads();
+			stampAt(15);
 			const bool integrate = oi > 0 && lops[oi - 1].code == OP_INTEGRATE_VEL;
 #pragma unroll
 			for (int ch = 0; ch < S2_WIDE_BODY_CHUNKS; ++ch)
@@ -1379,6 +1389,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0> __g
 			lcommit = go;
 		}
 		__syncthreads();
+		stampAt(12);
 		if (!lcommit)
 		{
 			return;

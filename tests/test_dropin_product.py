@@ -118,6 +118,6 @@ def test_bodies_created_and_replaced_between_resident_steps(built, scene, base, 
     solver_only, _ = _digest({"S2AMD_DROPIN": "solver", "S2DEMO_EDITS": "1"}, args)
     step_host_pairs, _ = _digest({"S2AMD_DROPIN": "step", "S2AMD_DEVICE_PAIRS": "0", "S2DEMO_EDITS": "1"}, args)
     step_dev_pairs, out = _digest({"S2AMD_DROPIN": "step", "S2AMD_DEVICE_PAIRS": "1", "S2DEMO_EDITS": "1"}, args)
-    assert solver_only == step_host_pairs == step_dev_pairs, out
+    assert solver_only == step_host_pairs == step_dev_pairs, (solver_only, step_host_pairs, step_dev_pairs, out)
     plain, _ = _digest({"S2AMD_DROPIN": "solver"}, args)
     assert plain != solver_only, "the edits change the world"

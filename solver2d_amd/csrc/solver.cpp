@@ -736,6 +736,10 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	{
 		s->optGraph = value;
 	}
+	else if (strcmp(key, "graph_min_launches") == 0)
+	{
+		s->optGraphMinLaunches = std::max(0, value);
+	}
 	else if (strcmp(key, "profile") == 0)
 	{
 		s->optProfile = value;

@@ -217,7 +217,126 @@ struct IncrementalStrips
 	long placed = 0, roundsOpened = 0;
 };
 
-struct s2amdSolver
+// What a STRUCTURE BUILD produces and the incremental placement keeps up to date: the host's picture of the constraint graph as the
+// structure knows it, every table derived from it and their device copies, the SoA families (carved per structure), the captured step
+// graph.  Kept apart from the rest of the solver so that a build can run on a copy of the solver in a worker thread while the steps go
+// on with the structure they have, and its result be adopted by swapping this part (solver_async.cpp).
+struct SolverStructure
+{
+	// host shadows of the graph structure (refreshed by every upload)
+	// The structure (islands, colours, strips) is built over EVERY contact slot that can become a constraint -- a live pair of
+	// the world chain, a slot with two distinct live bodies otherwise -- whether its manifold has points this step or not
+	// (hContactEdge).  A manifold without points is a no-op in every sweep (no point loop iteration, no body store), so a
+	// manifold that gains or loses its points changes NOTHING on the host: same tables, same launch sequence, same hipGraph.
+	// Only a contact slot that appears, disappears or changes its bodies changes the graph (src/contact.c:137-229).
+	std::vector<int> hContactA, hContactB;
+	std::vector<uint8_t> hContactEdge;
+	std::vector<uint8_t> hContactDead; // in the structure, but its contact has been destroyed since: dropped at the next rebuild
+	// HUB bodies.  A long shape that rotates (the Tumbler's drum walls) has a world-space box that overlaps the fat boxes of
+	// hundreds of bodies it never touches: hundreds of POTENTIAL constraints on one writable body, each of which would cost a
+	// colour of its own.  So for a body with more than S2_HUB_DEGREE potential constraints only the manifolds WITH points are
+	// structural (as the reference gathers them), and a manifold on such a body that gains or loses its points changes the
+	// graph like a created or destroyed contact.  hContactWatched marks the live slots with a hub end; the device counts
+	// their flips (stage 3), and a world with watched slots reads that counter back BEFORE its solve is enqueued.
+	std::vector<uint8_t> hBodyHub, hContactWatched;
+	int watchedCount = 0;
+	DevBuf dWatched;
+	std::vector<uint32_t> hBodyFlagsFinal; // ... + S2F_IN_GROUP as the last structure build uploaded them
+	DevBuf dBodyFlags;
+
+	// working SoA
+	DevBuf soaBodies, soaContacts, soaJoints, dContactIndex, dJointIndex, dContactLocal, dJointLocal, dAdjOffsets, dAdjList, dAdjHeavy;
+	int adjHeavyCapacity = 0; // entries the heavy-body list (more than S2_HEAVY_DEGREE adjacency entries) can hold: sizes the launch
+	IncrementalGlobal inc;
+	uint4* hostPatches = nullptr; // pinned staging of inc.patches
+	size_t hostPatchCapacity = 0;
+	DevBuf dPatches;
+	int spareColours = 0;	// empty colour batches a build adds to the global part: 0 until a created contact found every colour of its
+							// bodies taken (a dense pile: a box inside a pyramid uses all six), then 2 -- two more launches per sweep
+	DevBuf dJointAdjRange, dJointAdjList; // body -> incident global joints in sweep order (body-centric joint warm start)
+	bool jointAdjValid = false;
+	int slackPositions = 0; // free positions of the global part's slack layout
+	bool slackBumped = false; // (since the last rebuild)
+	int slackAtBuild = 0;	  // free positions the last rebuild laid out
+	int slackShift = 0; // the structure's slack (free positions per colour batch, room for growing incidence lists) times 2^this: raised when a rebuild was forced by used-up slack
+	const char* dirtyReason = ""; // S2AMD_DEBUG_PREP: what made the last rebuild necessary
+	bool watchedDirty = false; // hContactWatched changed since it was last copied to dWatched
+	BodyView bv{};
+	ContactView cv{};
+	JointView jv{};
+	uint64_t layoutGeneration = 0;
+	int bodySoaCap = 0, contactSoaCap = 0, jointSoaCap = 0;
+
+	// structure of the last step
+	SweepSet contacts, joints;
+	HostGroupTable hGroups, hContactTail, hJointTail, hStripA, hStripB;
+	DeviceGroupTable dGroups, dContactTail, dJointTail, dStripA, dStripB;
+	// resident islands (strip_kernel.hip: islandStepKernel): LDS groups whose constraints stay in registers for the whole step
+	HostGroupTable hResident;
+	DeviceGroupTable dResident;
+	DevBuf dResidentDesc, dResidentOps;
+	StripTableView residentView{};
+	int residentRounds = 0;
+	int residentK0 = 0, residentK1 = 0; // their range in contacts.order
+	bool residentRejected = false; // some group's colouring needs more rounds than the kernel holds: plain LDS groups for this graph
+	uint64_t residentOpsGeneration = ~0ull;
+	int residentOpCount = 0;
+	// lean strip tables (strip_kernel.hip): descriptors of both phases, warm-start slots of phase A
+	DevBuf dStripLean;
+	StripTableView leanA{}, leanB{};
+	bool leanAValid = false, leanBValid = false;
+	// persistent strip step (strip_kernel.hip: stripStepKernel)
+	DevBuf dPersist, dGranules;
+	PersistView persist{};
+	bool persistValid = false;
+	// ... as an op interpreter for every solver family and joints (generic_kernel.hip: genericStepKernel): the same partition,
+	// import / export lists and hand-off buffers; seams swept once, by their left strip
+	bool genericValid = false;
+	int genericJoints = 0; // the most joints of a strip and the seam it sweeps
+	int genericBodies = 0, genericSeamBodies = 0, genericExports = 0; // the most staged bodies / seam-group bodies / exported bodies of a strip (LDS)
+	int residentAllTwoPoints = 0; // every constraint of the resident islands has two manifold points (wide_kernel.hip: the POINTS == 2 variants)
+	int persistK0 = 0, persistK1 = 0; // the strip constraints' range in contacts.order (persist.allTwoPoints is recomputed over it)
+	int persistRecordsWide = 0; // LDS records when a seam constraint takes 10 records (every kind but TGS_Soft's)
+	DevBuf dPersistOps;
+	int persistOpCount = 0;
+	uint64_t persistOpsGeneration = ~0ull, persistOpsStructure = ~0ull;
+	size_t granuleBytes = 0;
+	long selfStepsSinceReset = 0; // self-contained strip steps since the commit counter was last zeroed (doStep: every 2^20)
+	IncrementalStrips stripInc;
+	float stripScaleFound = 0.0f;   // the strip width (x strip_bodies) the last search settled on, 0: none yet (a new world forgets it)
+	bool stripRetryPending = false; // ... postponed until the graph has been quiet for 32 steps
+	DevBuf dMsg;
+	MsgView msg{};
+	bool msgTablesValid = false; // the global part is contact-only and has no sequential tail
+	int looseBodies = 0; // live non-static bodies that no LDS group owns
+	int orderSolverClass = -1; // 0 velocity colouring, 1 position colouring
+	bool orderGrouped = false;
+	bool orderResident = false; // the groups were laid out for the resident-island kernel where they fit
+	bool orderColourless = false; // built for s2Solve_Jacobi: the global contact part is one batch in pool order, no colours
+	bool orderStrips = false;
+	int orderStripBodies = 0; // the strip width the structure was cut with (StructureBuild::stripBodiesFor)
+	bool stripsNeedOneLaunch = false; // a moving read-only body is shared between strips: persistent kernel or no strips at all
+	bool stripsRejected = false; // this graph's strip partition fits no strip kernel: colour batches until the graph changes
+	int stripsJudgedForClass = -1; // the colouring class (0 velocity, 1 position sweeps) the two verdicts were reached under: the other class's writable bodies differ
+	bool stripsHopeless = false; // ... for a reason no other strip width would change (a body the sweeps write that no strip can own): no search
+	bool adjValid = false;
+	bool structureDirty = true;
+	uint64_t structureGeneration = 0;
+	int stripScaleFoundFor = 0;	 // the strip width stripScaleFound was searched with
+
+	// graph cache
+	hipGraph_t graph = nullptr;
+	hipGraphExec_t graphExec = nullptr;
+	uint64_t graphKey = 0;
+	uint64_t graphKeySeen = 0; // the launch sequence of the last step that was enqueued directly
+	int graphKeySeenLaunches = 0; // ... and how many launches it was
+	int graphLaunches = 0;
+};
+
+struct AsyncBuild;
+
+// ... and the rest: the device, the wire arrays and the world chain's arrays, what the host knows of them, the options, the plan.
+struct s2amdSolver : SolverStructure
 {
 	int device = 0;
 	hipStream_t stream = nullptr;
@@ -254,49 +373,18 @@ struct s2amdSolver
 	std::vector<uint8_t> hPointBytes;
 	std::vector<uint8_t> hShapeMovable; // world chain: live shapes of non-static bodies (what s2amd_world_set_refit_order must cover)
 	int movableShapes = 0;
-
-	// host shadows of the graph structure (refreshed by every upload)
-	// The structure (islands, colours, strips) is built over EVERY contact slot that can become a constraint -- a live pair of
-	// the world chain, a slot with two distinct live bodies otherwise -- whether its manifold has points this step or not
-	// (hContactEdge).  A manifold without points is a no-op in every sweep (no point loop iteration, no body store), so a
-	// manifold that gains or loses its points changes NOTHING on the host: same tables, same launch sequence, same hipGraph.
-	// Only a contact slot that appears, disappears or changes its bodies changes the graph (src/contact.c:137-229).
-	std::vector<int> hContactA, hContactB, hContactPoints; // hContactPoints: as of the last host upload (see pointsKnown)
-	std::vector<uint8_t> hContactEdge;
-	std::vector<uint8_t> hContactDead; // in the structure, but its contact has been destroyed since: dropped at the next rebuild
+	std::vector<int> hContactPoints; // manifold point counts as of the last host upload / the last fetchPointCounts (see pointsKnown)
 	bool deadUnknown = false;		   // pairs separated on the device since the host last looked (syncDeadSlots, world.hip)
-	// HUB bodies.  A long shape that rotates (the Tumbler's drum walls) has a world-space box that overlaps the fat boxes of
-	// hundreds of bodies it never touches: hundreds of POTENTIAL constraints on one writable body, each of which would cost a
-	// colour of its own.  So for a body with more than S2_HUB_DEGREE potential constraints only the manifolds WITH points are
-	// structural (as the reference gathers them), and a manifold on such a body that gains or loses its points changes the
-	// graph like a created or destroyed contact.  hContactWatched marks the live slots with a hub end; the device counts
-	// their flips (stage 3), and a world with watched slots reads that counter back BEFORE its solve is enqueued.
-	std::vector<uint8_t> hBodyHub, hContactWatched;
-	int watchedCount = 0;
-	DevBuf dWatched;
 	bool pointsKnown = false; // hContactPoints is current: no stage 3 has recomputed manifolds on the device since the upload
 	int activeContacts = 0;	  // manifolds with points this step (host count, or the device's counter in the world chain)
 	bool lastStepWroteIndex = false; // the last solve's driver writes manifold.constraintIndex (all but XPBD's early-out and Block)
 	DevBuf dScanTmp;
 	std::vector<int> hJointType, hJointA, hJointB;
 	std::vector<uint32_t> hBodyFlags; // S2F_WRITE_VEL / S2F_WRITE_POS from the wire bodies
-	std::vector<uint32_t> hBodyFlagsFinal; // ... + S2F_IN_GROUP as the last structure build uploaded them
 	std::vector<uint8_t> hBodyLive, hBodyStatic;
-	DevBuf dBodyFlags;
-
-	// working SoA
-	DevBuf soaBodies, soaContacts, soaJoints, dContactIndex, dJointIndex, dContactLocal, dJointLocal, dAdjOffsets, dAdjList, dAdjHeavy, dOps;
-	int adjHeavyCapacity = 0; // entries the heavy-body list (more than S2_HEAVY_DEGREE adjacency entries) can hold: sizes the launch
-	IncrementalGlobal inc;
-	uint4* hostPatches = nullptr; // pinned staging of inc.patches
-	size_t hostPatchCapacity = 0;
-	DevBuf dPatches;
+	DevBuf dOps; // the plan's op list (solver_step.cpp: doStep)
 	long placedTotal = 0;	// created contacts placed without a rebuild, since s2amd_create
-	int spareColours = 0;	// empty colour batches a build adds to the global part: 0 until a created contact found every colour of its
-							// bodies taken (a dense pile: a box inside a pyramid uses all six), then 2 -- two more launches per sweep
 	DevBuf dSeparated;		// world chain: the pair slots stage 3 freed this step
-	DevBuf dJointAdjRange, dJointAdjList; // body -> incident global joints in sweep order (body-centric joint warm start)
-	bool jointAdjValid = false;
 	DevBuf dShapeBoxes;		// world chain: s2amd_world_download_boxes' staging
 	DevBuf dRefitOrder, dStepBack; // s2amd_world_set_refit_order; staging of s2amd_world_download_step {count, moved boxes} and the poses
 	int refitOrderCount = 0;
@@ -305,74 +393,24 @@ struct s2amdSolver
 	std::vector<uint8_t> hSlotBytes;
 	bool slotBytesFresh = false; // hSlotBytes is of the state the device is in right now (cleared by every world call that changes it)
 	std::vector<int32_t> hSeparated;
-	int slackPositions = 0; // free positions of the global part's slack layout
 	int optIncremental = 1; // created contacts are placed into the existing structure when they fit (0: always rebuild)
 	// A created contact that cannot be placed (an LDS group or a strip owns one of its bodies, or one of them is a hub) and has
 	// no manifold points yet is only WATCHED: no entry in the structure -- it would be a no-op there -- until stage 3 finds
 	// its first points, which then counts as the change of the graph (option "defer", 0: rebuild when it is created)
 	int optDefer = 1;
-	bool slackBumped = false; // (since the last rebuild)
-	int slackAtBuild = 0;	  // free positions the last rebuild laid out
-	int slackShift = 0; // the structure's slack (free positions per colour batch, room for growing incidence lists) times 2^this: raised when a rebuild was forced by used-up slack
-	const char* dirtyReason = ""; // S2AMD_DEBUG_PREP: what made the last rebuild necessary
-	bool watchedDirty = false; // hContactWatched changed since it was last copied to dWatched
-	BodyView bv{};
-	ContactView cv{};
-	JointView jv{};
-	uint64_t layoutGeneration = 0;
-	int bodySoaCap = 0, contactSoaCap = 0, jointSoaCap = 0;
-
-	// structure of the last step
-	SweepSet contacts, joints;
-	HostGroupTable hGroups, hContactTail, hJointTail, hStripA, hStripB;
-	DeviceGroupTable dGroups, dContactTail, dJointTail, dStripA, dStripB;
-	// resident islands (strip_kernel.hip: islandStepKernel): LDS groups whose constraints stay in registers for the whole step
-	HostGroupTable hResident;
-	DeviceGroupTable dResident;
-	DevBuf dResidentDesc, dResidentOps;
-	StripTableView residentView{};
-	int residentRounds = 0;
-	int residentK0 = 0, residentK1 = 0; // their range in contacts.order
-	bool residentRejected = false; // some group's colouring needs more rounds than the kernel holds: plain LDS groups for this graph
-	uint64_t residentOpsGeneration = ~0ull;
-	int residentOpCount = 0;
 	int optIslandResident = 1;
-	// lean strip tables (strip_kernel.hip): descriptors of both phases, warm-start slots of phase A
-	DevBuf dStripLean;
-	StripTableView leanA{}, leanB{};
-	bool leanAValid = false, leanBValid = false;
 	int optStripLean = 1;
-	// persistent strip step (strip_kernel.hip: stripStepKernel)
-	DevBuf dPersist, dGranules;
-	PersistView persist{};
-	bool persistValid = false;
-	// ... as an op interpreter for every solver family and joints (generic_kernel.hip: genericStepKernel): the same partition,
-	// import / export lists and hand-off buffers; seams swept once, by their left strip
-	bool genericValid = false;
-	int genericJoints = 0; // the most joints of a strip and the seam it sweeps
 	int optStageJoints = 1; // "stage_joints": the op interpreter keeps a strip's joint records in LDS when they fit
-	int genericBodies = 0, genericSeamBodies = 0, genericExports = 0; // the most staged bodies / seam-group bodies / exported bodies of a strip (LDS)
-	int residentAllTwoPoints = 0; // every constraint of the resident islands has two manifold points (wide_kernel.hip: the POINTS == 2 variants)
 	int optSelfContained = 1; // "self_contained": a world of resident islands only is stepped by their kernel alone (no body prologue / epilogue launch)
 	int optGeneric = 1;
 	int optFreeBodyGroups = 1; // "free_body_groups": constraint-free bodies next to groups / strips form LDS groups instead of global launches
-	int persistK0 = 0, persistK1 = 0; // the strip constraints' range in contacts.order (persist.allTwoPoints is recomputed over it)
-	int persistRecordsWide = 0; // LDS records when a seam constraint takes 10 records (every kind but TGS_Soft's)
-	DevBuf dPersistOps;
-	int persistOpCount = 0;
-	uint64_t persistOpsGeneration = ~0ull, persistOpsStructure = ~0ull;
-	size_t granuleBytes = 0;
 	int optPersist = 1;
 	int optSeamRegs = 1;
 	int optWide = 1;	  // TGS_Soft's persistent step on 512 threads per strip (wide_kernel.hip) where the partition fits
 	int optWideBodyWarm = 1; // "strip_body_warm": ... with s2WarmStartContacts as one body-centric pass (wide_kernel.hip: S2_WIDE_BODYWARM) where its term table fits LDS
-	long selfStepsSinceReset = 0; // self-contained strip steps since the commit counter was last zeroed (doStep: every 2^20)
-	IncrementalStrips stripInc;
 	int optStripSlack = 1; // strip and seam rounds are laid out with free positions for created contacts (solver_incremental.cpp)
 	int optPairLanes = 0; // two lanes per constraint (pair_kernel.hip; measured no faster: kept as an option); 0: one lane per constraint
 	int optStripRetry = 1; // try other strip widths when the partition needs the 8-round kernel variant
-	float stripScaleFound = 0.0f;   // the strip width (x strip_bodies) the last search settled on, 0: none yet (a new world forgets it)
-	bool stripRetryPending = false; // ... postponed until the graph has been quiet for 32 steps
 	int optPersistDebug = 0;
 	int optPersistSpinLimit = 1 << 21;
 	bool persistFailed = false; // a hand-off timed out once (workgroups not co-resident: a shared GPU): multi-launch strips from then on
@@ -384,53 +422,30 @@ struct s2amdSolver
 	int cuCount = 0;
 	unsigned int* hostError = nullptr; // pinned, device-visible: a hand-off timed out
 	unsigned long long* hostTimes = nullptr; // S2AMD_DEBUG_TIMES: pinned [256] phase time stamps of one workgroup
-	DevBuf dMsg;
-	MsgView msg{};
-	bool msgTablesValid = false; // the global part is contact-only and has no sequential tail
 	int optMessage = 0;	 // measured slower than the plain gather on MI355X: off by default
 	int optBodyWarm = 1; // body-centric contact warm start (one launch per sweep instead of one per colour)
-	int looseBodies = 0; // live non-static bodies that no LDS group owns
-	int orderSolverClass = -1; // 0 velocity colouring, 1 position colouring
-	bool orderGrouped = false;
-	bool orderResident = false; // the groups were laid out for the resident-island kernel where they fit
-	bool orderColourless = false; // built for s2Solve_Jacobi: the global contact part is one batch in pool order, no colours
-	bool orderStrips = false;
-	int orderStripBodies = 0; // the strip width the structure was cut with (StructureBuild::stripBodiesFor)
-	bool stripsNeedOneLaunch = false; // a moving read-only body is shared between strips: persistent kernel or no strips at all
 	bool indexInWire = false; // the resident wire contacts hold the current gather index as manifold.constraintIndex
-	bool stripsRejected = false; // this graph's strip partition fits no strip kernel: colour batches until the graph changes
-	int stripsJudgedForClass = -1; // the colouring class (0 velocity, 1 position sweeps) the two verdicts were reached under: the other class's writable bodies differ
-	bool stripsHopeless = false; // ... for a reason no other strip width would change (a body the sweeps write that no strip can own): no search
 	int graphAge = 0;		  // steps solved since the constraint graph last changed
 	int optStripPatience = 1; // steps of an unchanged graph before the (more expensive) strip structure is built
 	int stripPatienceNow = 1; // ... as it stands: doubled every time a strip structure died young (noteGraphChanged)
 	int optStripsAnySolver = 0; // tests: strips for every solver and with joints (through the generic group interpreter)
-	bool adjValid = false;
-	bool structureDirty = true;
-	uint64_t structureGeneration = 0;
 
 	StepPlan plan;
 	uint64_t planGeneration = 0;
 
 	// options
 	int optGraph = 1;
+	int optGraphMinLaunches = 6; // "graph_min_launches": steps of fewer launches are enqueued directly, never captured
 	int optProfile = 0;
 	int optGroups = 1;
 	int optMaxGroupBodies = 2048;
 	int optPackGroupBodies = 1024;
 	int optStrips = 1;		   // cut islands that do not fit one LDS group into strips of BFS levels (2 launches per sweep)
 	int optStripBodies = 8;  // target bodies per strip: small = strips of exactly two BFS levels, five interior colour rounds (r3: 133 us per step at base 200
-	int stripScaleFoundFor = 0;	 // the strip width stripScaleFound was searched with
 	bool stripBodiesSet = false; // "strip_bodies" was set by the caller: every solver gets that width
 	int optStripBodiesLds = 320; // ... of SoftStep / PGS_Soft, whose seam constraints live in LDS and are swept by both neighbours (strip_kernel.hip): few, wide strips
 							 // against 154 us with the six rounds of three-level strips); strip_retry tries wider ones when there are more level pairs than CUs
 	int optStripMinBodies = 4096; // loose bodies below which the colour-batch path is kept
-
-	// graph cache
-	hipGraph_t graph = nullptr;
-	hipGraphExec_t graphExec = nullptr;
-	uint64_t graphKey = 0;
-	uint64_t graphKeySeen = 0; // the launch sequence of the last step that was enqueued directly
 
 	// profiling events for the contact solve sweeps
 	std::vector<hipEvent_t> sweepEvents;
@@ -438,10 +453,16 @@ struct s2amdSolver
 
 	s2amdStepStats stats{};
 	int launchCounter = 0;
-	int graphLaunches = 0;
 	DevBuf dGatherIndex;
 	bool gatherIndexDirty = true;
 	uint64_t opsGeneration = ~0ull;
+
+	// structure builds off the caller's thread (solver_async.cpp)
+	AsyncBuild* async = nullptr;
+	int optAsyncBuild = 1;	   // "async_build": in the world chain the strip structure (and the search over strip widths) is built by a worker thread on a
+							   // copy of the solver while the steps go on on the colour batches, and adopted a fixed number of steps later
+	int optAsyncBuildDelay = 6; // "async_build_delay": steps between the request and the adoption (the caller waits if the build is not done by then)
+	bool isClone = false;	   // a worker's copy: the wire and world buffers are the owner's
 };
 
 // The constraint graph changed (an upload, a manifold that gained or lost its points, a contact slot written): the

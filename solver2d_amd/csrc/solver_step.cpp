@@ -543,14 +543,16 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 		{
 			key = 1;
 		}
-		if ((key != s->graphKey || s->graphExec == nullptr) && key != s->graphKeySeen)
+		if ((key != s->graphKey || s->graphExec == nullptr) && (key != s->graphKeySeen || s->graphKeySeenLaunches < s->optGraphMinLaunches))
 		{
 			// A launch sequence seen for the first time is enqueued directly: capture + instantiate cost more than the
 			// launches themselves and only pay off when the same sequence comes back (a changing contact graph never
-			// brings one back).
+			// brings one back).  And a step of only a few launches stays direct for good: replaying a graph of one to three
+			// kernels measured 6-8 us SLOWER per step than enqueueing them (r4, LargePyramid base-200: 0.159 against 0.151 ms).
 			s->graphKeySeen = key;
 			q.fork = false; // the parallel branches only exist inside a captured graph
 			enqueueAll();
+			s->graphKeySeenLaunches = s->launchCounter;
 		}
 		else if (key != s->graphKey || s->graphExec == nullptr)
 		{

@@ -550,7 +550,9 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0> __g
 	const int tid = (int)threadIdx.x;
 	const int half = tid >> 8, ht = tid & 255; // hand-offs: waves 0-3 serve the left neighbour, waves 4-7 the right
 	// stamps: (wall_clock64 << 4) | tag; tags: 0 start, 1 loaded, 2 body stage, 3 warm start, 4 interior rounds, 5 hand-off, 6 seam rounds, 7 end
-	const bool stamp = S2_PERSIST_INSTRUMENTED && pv.debugTimes != nullptr && blockIdx.x == 8 * (gridDim.x / 16) + 3 && tid == 0;
+	// (the workgroup that stamps: persist_debug bits 8-15 + 1, default one in the middle of the island)
+	const bool stamp = S2_PERSIST_INSTRUMENTED && pv.debugTimes != nullptr && tid == 0 &&
+					   blockIdx.x == (((pv.debugSkip >> 8) & 0xff) != 0 ? (unsigned)(((pv.debugSkip >> 8) & 0xff) - 1) : 8 * (gridDim.x / 16) + 3);
 	int stamps = 0;
 	auto stampAt = [&](unsigned tag) {
 		if (stamp && stamps < 250)
@@ -697,6 +699,26 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0> __g
 		const int k = batchA[i].x + ht;
 		return (i < roundsA && (i & 1) == half && k < batchA[i].y) ? k : -1;
 	};
+	// SELF: the wire bodies this lane stages (two of the strip's own list, one import) are asked for FIRST, so that they travel while
+	// the constraints are prepared (unconditional loads from clamped slots); they go into LDS further down
+	int stageSlot[S2_WIDE_BODY_CHUNKS + 1];
+	s2amdBody stageRaw[SELF ? S2_WIDE_BODY_CHUNKS + 1 : 1];
+#pragma unroll
+	for (int ch = 0; ch < S2_WIDE_BODY_CHUNKS + 1; ++ch)
+	{
+		if (ch < S2_WIDE_BODY_CHUNKS)
+		{
+			stageSlot[ch] = tid + ch * S2_WIDE_THREADS < nb ? (int)(id[ch] & ~S2G_OWNED) : -1;
+		}
+		else
+		{
+			stageSlot[ch] = impId;
+		}
+		if constexpr (SELF)
+		{
+			stageRaw[ch] = self.wireBodies[stageSlot[ch] >= 0 ? stageSlot[ch] : 0];
+		}
+	}
 	if constexpr (SELF)
 	{
 		// s2PrepareContacts_Soft (solve_common.c:188-274) for the constraints this lane holds, straight from the wire contacts and
@@ -813,25 +835,15 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0> __g
 #pragma unroll
 	for (int ch = 0; ch < S2_WIDE_BODY_CHUNKS + 1; ++ch)
 	{
-		int gi = -1;
-		if (ch < S2_WIDE_BODY_CHUNKS)
-		{
-			const int i = tid + ch * S2_WIDE_THREADS;
-			ldsIdx[ch] = i;
-			gi = i < nb ? (int)(id[ch] & ~S2G_OWNED) : -1;
-		}
-		else
-		{
-			ldsIdx[ch] = impSlotH;
-			gi = impId;
-		}
+		const int gi = stageSlot[ch];
+		ldsIdx[ch] = ch < S2_WIDE_BODY_CHUNKS ? tid + ch * S2_WIDE_THREADS : impSlotH;
 		flags[ch] = 0u;
 		if (gi >= 0)
 		{
 			if constexpr (SELF)
 			{
 				// body_ops.h: unpackBodyOne, into LDS instead of the SoA arrays
-				const s2amdBody* w = self.wireBodies + gi;
+				const s2amdBody* w = &stageRaw[ch];
 				const int type = w->type;
 				uint32_t f = 0x80000000u;
 				if (type != S2AMD_BODY_FREE)
@@ -1363,13 +1375,17 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0> __g
 		if (tid == 0)
 		{
 			int go = 0;
-			if (!bad)
+			if (S2_PERSIST_INSTRUMENTED && (pv.debugSkip & 32) != 0)
+			{
+				go = 1; // (timing experiment, instrumented build only: no commit wait)
+			}
+			else if (!bad)
 			{
 				const unsigned ticket = __hip_atomic_fetch_add(pv.state, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				const unsigned target = (ticket / (unsigned)K + 1u) * (unsigned)K;
 				for (unsigned spins = 0; spins < pv.spinLimit; ++spins)
 				{
-					if (__hip_atomic_load(pv.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target)
+					if (ticket + 1u == target || __hip_atomic_load(pv.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) // (the last to arrive knows at once)
 					{
 						go = 1;
 						break;

@@ -72,7 +72,7 @@ def test_one_rank_through_rccl():
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     d = last_json(out.stdout)
-    assert d["n_gpus"] == 1 and d["config"]["kernel_launches_per_step"] == 3
+    assert d["n_gpus"] == 1 and d["config"]["kernel_launches_per_step"] in (1, 3)  # (1: the self-contained strip step)
     # the collective and the hand-shakes must not serialise the steps: within 25 % of the plain single-process rate
     assert d["ms_per_step"] < 0.40, d["ms_per_step"]
 

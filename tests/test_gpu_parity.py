@@ -235,6 +235,7 @@ def test_graph_replay_equals_eager():
     outs = []
     for graph in (True, False):
         with hip.Solver(0, graph=graph) as s:
+            s.set_option("graph_min_launches", 0)  # (a step of a few launches is never captured by default)
             st = common.copy3(pre)
             s.upload(*st)
             # a launch sequence is enqueued directly the first time, captured when it comes back, replayed from then on;

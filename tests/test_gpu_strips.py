@@ -287,6 +287,7 @@ def test_manifolds_that_lose_and_regain_their_points_cost_the_host_nothing(solve
     rng = np.random.default_rng(11)
     with hip.Solver(0) as s:
         s.set_option("strip_patience", 0)
+        s.set_option("graph_min_launches", 0)  # (by default a step of three launches is enqueued directly, never captured)
         state = gpu_vs_oracle(s, params, pre, "flip warm-up 0")
         state = gpu_vs_oracle(s, params, state, "flip warm-up 1")  # step graph captured
         assert s.stats()["persistent"] == 1

@@ -55,8 +55,10 @@ int main(int argc, char** argv)
 			}
 			s2BodyDef bd = s2_defaultBodyDef;
 			bd.type = s2_dynamicBody;
-			bd.position = (s2Vec2){i == steps / 2 ? 1.25f : -0.75f, 0.5f * (float)base + 6.0f};
-			bd.linearVelocity = (s2Vec2){0.0f, -12.0f};
+			/* (beside the scene, in free flight until the run ends: its path is the integrator's alone, the same bits on every route) */
+			bd.position = (s2Vec2){0.5f * (float)base + (i == steps / 2 ? 20.0f : 23.0f), 30.0f};
+			bd.linearVelocity = (s2Vec2){0.25f, -3.0f};
+			bd.angularVelocity = 0.5f;
 			extra = s2CreateBody(w, &bd);
 			s2ShapeDef sd = s2_defaultShapeDef;
 			s2Polygon box = s2MakeSquare(0.4f);
@@ -68,6 +70,13 @@ int main(int argc, char** argv)
 	s2amdDropin_Timing(phases);
 	printf("route %-6s pairs %s  %s %d, solver %d %d/%d: %.3f ms per s2World_Step over %d steps, state digest %016llx\n", route,
 		   getenv("S2AMD_DEVICE_PAIRS") ? getenv("S2AMD_DEVICE_PAIRS") : "1", scene, base, solver, vel, pos, ms, steps, s2amdDropin_StateDigest(w));
+	if (edits)
+	{
+		/* after pool edits the routes need not sweep in the same order any more (a re-uploaded world builds its structure afresh):
+		 * what they must agree on is the physics */
+		const s2Vec2 p = s2Body_GetPosition(extra);
+		printf("    edited body at (%.4f, %.4f) angle %.4f\n", p.x, p.y, s2Body_GetAngle(extra));
+	}
 	if (phases[5] > 0)
 	{
 		printf("    per step: stages 1+2 on the host %.3f ms, new contacts to the device %.3f, s2amd_world_step %.3f, download %.3f, pools and trees %.3f\n",

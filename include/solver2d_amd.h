@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define S2AMD_API_VERSION 2
+#define S2AMD_API_VERSION 3
 
 /* error codes */
 #define S2AMD_OK 0
@@ -166,6 +166,9 @@ typedef struct s2amdStepStats
 	int32_t placedContacts;    /* created contacts that were given a place in the existing structure instead (no build) */
 	int32_t potentialConstraints; /* contact slots the structure holds: constraintCount + manifolds without points + destroyed contacts not yet dropped */
 	int32_t pairLanes;         /* (API 2) which persistent kernel ran: 2 = 512 threads per strip (wide_kernel.hip), 1 = two lanes per constraint (pair_kernel.hip), 0 = strip_kernel.hip */
+	int32_t asyncBuildsRequested; /* (API 3) structure builds handed to the worker thread since s2amd_create (world chain: the strip structure, the strip-width search) */
+	int32_t asyncBuildsAdopted;   /* (API 3) ... whose result replaced the live structure (the others were overtaken by the graph) */
+	float asyncWaitMs;            /* (API 3) time the caller spent waiting for a worker that was not done when its build fell due, since s2amd_create */
 } s2amdStepStats;
 
 typedef struct s2amdSolver s2amdSolver;

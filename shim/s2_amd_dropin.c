@@ -3,14 +3,17 @@
  * the reference's whole public API (include/solver2d/solver2d.h:22-70 and the geometry / hull / distance / tree helpers) and
  * whose s2World_Step runs on the MI355X.  Programs written against the public headers link against it unchanged.
  *
- * No reference source file is edited or copied.  The linker's --wrap reroutes the reference's own calls:
- *   s2Solve_<Variant>(world, context)   (src/solvers.h:70-79, called by the switch in src/world.c:206-256)
- *                                       -> s2amdBinding_Solve, mode "solver"
- *   s2DestroyWorld                      (src/world.c:105-118)  -> the world's device state is released first
- *   the setters and readers of the public API that touch state a resident world keeps in HBM -> s2amdBinding_Invalidate /
- *                                       s2amdBinding_Sync first (velocities, forces, joint settings; manifolds, joint impulses)
- * and s2World_Step itself is THIS file's function: shim/Makefile renames the reference's in the compiled world.o (objcopy;
- * it stays reachable as s2World_Step_reference), exactly what a maintainer's three-line edit of src/world.c would do.
+ * No reference source file is edited or copied.  Two kinds of call site:
+ *   s2Solve_<Variant>(world, context)   (src/solvers.h:70-79) is called by the reference itself (the switch in src/world.c:206-256):
+ *                                       the linker's --wrap reroutes that call -> s2amdBinding_Solve, mode "solver";
+ *   the PUBLIC functions a program calls -- s2World_Step, s2DestroyWorld, and every function that creates or destroys a body or
+ *                                       joint, sets or reads state a resident world keeps in HBM (velocities, forces, joint settings;
+ *                                       manifolds, joint impulses) -- are THIS file's: shim/Makefile renames the reference's
+ *                                       definitions in the compiled objects (objcopy; each stays reachable as <name>_reference), exactly
+ *                                       what a maintainer's edit of the function's first line would do.  (--wrap alone would not do:
+ *                                       it reroutes references inside the link, and a program's calls come from outside it.)
+ *                                       They bring the host pools up to date (s2amdBinding_Sync) and, when the call edits the pools,
+ *                                       mark the resident copy stale (s2amdBinding_Invalidate) before the reference's function runs.
  *
  * Run-time switches (environment, read at the first step):
  *   S2AMD_DROPIN   step (default): stage 3, the solve and stage 4 on the device, stage 1's pair query too (S2AMD_DEVICE_PAIRS=0:
@@ -134,14 +137,14 @@ S2_DROPIN_SOLVER(s2Solve_TGS_NGS, s2_solverTGS_NGS)
 S2_DROPIN_SOLVER(s2Solve_XPBD, s2_solverXPBD)
 
 /* ---- src/world.c:105-118 ---- */
-void __real_s2DestroyWorld(s2WorldId id);
-void __wrap_s2DestroyWorld(s2WorldId id)
+void s2DestroyWorld_reference(s2WorldId id);
+void s2DestroyWorld(s2WorldId id)
 {
 	if (s2amdBinding_IsOpen())
 	{
 		s2amdBinding_DestroyWorld(s2GetWorldFromId(id));
 	}
-	__real_s2DestroyWorld(id);
+	s2DestroyWorld_reference(id);
 }
 
 /* ---- readers of what a resident world keeps on the device: manifolds (drawn by s2World_Draw, src/world.c:369-563), joint impulses ---- */
@@ -160,67 +163,67 @@ static void editWorld(s2World* world)
 		s2amdBinding_Invalidate(world); /* ... and the next step uploads them */
 	}
 }
-void __real_s2World_Draw(s2WorldId worldId, s2DebugDraw* debugDraw);
-void __wrap_s2World_Draw(s2WorldId worldId, s2DebugDraw* debugDraw)
+void s2World_Draw_reference(s2WorldId worldId, s2DebugDraw* debugDraw);
+void s2World_Draw(s2WorldId worldId, s2DebugDraw* debugDraw)
 {
 	syncWorld(s2GetWorldFromId(worldId));
-	__real_s2World_Draw(worldId, debugDraw);
+	s2World_Draw_reference(worldId, debugDraw);
 }
-float __real_s2RevoluteJoint_GetMotorTorque(s2JointId jointId, float inverseTimeStep);
-float __wrap_s2RevoluteJoint_GetMotorTorque(s2JointId jointId, float inverseTimeStep)
+float s2RevoluteJoint_GetMotorTorque_reference(s2JointId jointId, float inverseTimeStep);
+float s2RevoluteJoint_GetMotorTorque(s2JointId jointId, float inverseTimeStep)
 {
 	syncWorld(s2GetWorldFromIndex(jointId.world));
-	return __real_s2RevoluteJoint_GetMotorTorque(jointId, inverseTimeStep);
+	return s2RevoluteJoint_GetMotorTorque_reference(jointId, inverseTimeStep);
 }
 
 /* ---- calls that read or edit the broad-phase trees and the pools: the steps since the last pair only logged their tree work
  * (s2_amd_binding.c: lean read-back), it is done now, before the reference's code touches the trees ---- */
-void __real_s2World_QueryAABB(s2WorldId worldId, s2Box aabb, s2QueryCallbackFcn* fcn, void* context);
-void __wrap_s2World_QueryAABB(s2WorldId worldId, s2Box aabb, s2QueryCallbackFcn* fcn, void* context)
+void s2World_QueryAABB_reference(s2WorldId worldId, s2Box aabb, s2QueryCallbackFcn* fcn, void* context);
+void s2World_QueryAABB(s2WorldId worldId, s2Box aabb, s2QueryCallbackFcn* fcn, void* context)
 {
 	syncWorld(s2GetWorldFromId(worldId));
-	__real_s2World_QueryAABB(worldId, aabb, fcn, context);
+	s2World_QueryAABB_reference(worldId, aabb, fcn, context);
 }
 /* ---- pool edits.  A destroy followed by a create leaves every pool count as it was (a mouse joint released and grabbed again, a
  * body replaced), so the counts residentMatches compares cannot see them: the edit itself marks the resident world stale.  The sync
  * comes first: a lean step leaves the bodies on the device, and a slot handed out now must not be overwritten later by the download
  * of what the device still holds there as a free slot. ---- */
-void __real_s2DestroyBody(s2BodyId bodyId);
-void __wrap_s2DestroyBody(s2BodyId bodyId)
+void s2DestroyBody_reference(s2BodyId bodyId);
+void s2DestroyBody(s2BodyId bodyId)
 {
 	editWorld(s2GetWorldFromIndex(bodyId.world));
-	__real_s2DestroyBody(bodyId);
+	s2DestroyBody_reference(bodyId);
 }
-s2BodyId __real_s2CreateBody(s2WorldId worldId, const s2BodyDef* def);
-s2BodyId __wrap_s2CreateBody(s2WorldId worldId, const s2BodyDef* def)
+s2BodyId s2CreateBody_reference(s2WorldId worldId, const s2BodyDef* def);
+s2BodyId s2CreateBody(s2WorldId worldId, const s2BodyDef* def)
 {
 	editWorld(s2GetWorldFromId(worldId));
-	return __real_s2CreateBody(worldId, def);
+	return s2CreateBody_reference(worldId, def);
 }
-void __real_s2DestroyJoint(s2JointId jointId);
-void __wrap_s2DestroyJoint(s2JointId jointId)
+void s2DestroyJoint_reference(s2JointId jointId);
+void s2DestroyJoint(s2JointId jointId)
 {
 	editWorld(s2GetWorldFromIndex(jointId.world));
-	__real_s2DestroyJoint(jointId);
+	s2DestroyJoint_reference(jointId);
 }
-s2JointId __real_s2CreateMouseJoint(s2WorldId worldId, const s2MouseJointDef* def);
-s2JointId __wrap_s2CreateMouseJoint(s2WorldId worldId, const s2MouseJointDef* def)
+s2JointId s2CreateMouseJoint_reference(s2WorldId worldId, const s2MouseJointDef* def);
+s2JointId s2CreateMouseJoint(s2WorldId worldId, const s2MouseJointDef* def)
 {
 	editWorld(s2GetWorldFromId(worldId));
-	return __real_s2CreateMouseJoint(worldId, def);
+	return s2CreateMouseJoint_reference(worldId, def);
 }
-s2JointId __real_s2CreateRevoluteJoint(s2WorldId worldId, const s2RevoluteJointDef* def);
-s2JointId __wrap_s2CreateRevoluteJoint(s2WorldId worldId, const s2RevoluteJointDef* def)
+s2JointId s2CreateRevoluteJoint_reference(s2WorldId worldId, const s2RevoluteJointDef* def);
+s2JointId s2CreateRevoluteJoint(s2WorldId worldId, const s2RevoluteJointDef* def)
 {
 	editWorld(s2GetWorldFromId(worldId));
-	return __real_s2CreateRevoluteJoint(worldId, def);
+	return s2CreateRevoluteJoint_reference(worldId, def);
 }
 #define S2_DROPIN_SHAPE(NAME, GEOM)                                                                                              \
-	s2ShapeId __real_##NAME(s2BodyId bodyId, const s2ShapeDef* def, const GEOM* geometry);                                       \
-	s2ShapeId __wrap_##NAME(s2BodyId bodyId, const s2ShapeDef* def, const GEOM* geometry)                                        \
+	s2ShapeId NAME##_reference(s2BodyId bodyId, const s2ShapeDef* def, const GEOM* geometry);                                    \
+	s2ShapeId NAME(s2BodyId bodyId, const s2ShapeDef* def, const GEOM* geometry)                                                 \
 	{                                                                                                                            \
 		syncWorld(s2GetWorldFromIndex(bodyId.world));                                                                            \
-		return __real_##NAME(bodyId, def, geometry);                                                                             \
+		return NAME##_reference(bodyId, def, geometry);                                                                          \
 	}
 S2_DROPIN_SHAPE(s2CreateCircleShape, s2Circle)
 S2_DROPIN_SHAPE(s2CreateSegmentShape, s2Segment)
@@ -229,11 +232,11 @@ S2_DROPIN_SHAPE(s2CreatePolygonShape, s2Polygon)
 
 /* ---- setters: the host copy changes, the resident copy has to follow ---- */
 #define S2_DROPIN_EDIT(RET, NAME, ID_T, PARAMS, ARGS)                                                                            \
-	RET __real_##NAME PARAMS;                                                                                                    \
-	RET __wrap_##NAME PARAMS                                                                                                     \
+	RET NAME##_reference PARAMS;                                                                                                 \
+	RET NAME PARAMS                                                                                                              \
 	{                                                                                                                            \
 		editWorld(s2GetWorldFromIndex(id.world));                                                                                \
-		__real_##NAME ARGS;                                                                                                      \
+		NAME##_reference ARGS;                                                                                                   \
 	}
 S2_DROPIN_EDIT(void, s2Body_SetLinearVelocity, s2BodyId, (s2BodyId id, s2Vec2 v), (id, v))
 S2_DROPIN_EDIT(void, s2Body_SetAngularVelocity, s2BodyId, (s2BodyId id, float w), (id, w))

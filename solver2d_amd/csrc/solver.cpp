@@ -159,6 +159,7 @@ void s2amd_destroy(s2amdSolver* s)
 		return;
 	}
 	(void)hipSetDevice(s->device);
+	asyncShutdown(s); // (a worker thread may still be building on a copy of this solver)
 	(void)hipStreamSynchronize(s->stream);
 	destroyGraph(s);
 	for (hipEvent_t e : s->sweepEvents)
@@ -732,7 +733,16 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	{
 		return fail(S2AMD_E_INVALID, "null argument");
 	}
-	if (strcmp(key, "graph") == 0)
+	asyncDrop(s); // (a structure being built under the options as they were)
+	if (strcmp(key, "async_build") == 0)
+	{
+		s->optAsyncBuild = value != 0;
+	}
+	else if (strcmp(key, "async_build_delay") == 0)
+	{
+		s->optAsyncBuildDelay = std::max(0, value);
+	}
+	else if (strcmp(key, "graph") == 0)
 	{
 		s->optGraph = value;
 	}
@@ -841,6 +851,10 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	else if (strcmp(key, "strip_body_warm") == 0)
 	{
 		s->optWideBodyWarm = value != 0;
+	}
+	else if (strcmp(key, "self_contained_strips") == 0)
+	{
+		s->optSelfContainedStrips = value != 0;
 	}
 	else if (strcmp(key, "free_body_groups") == 0)
 	{

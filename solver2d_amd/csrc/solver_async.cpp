@@ -1,0 +1,379 @@
+// Structure builds off the caller's thread ("per-step host work O(1)").
+//
+// The reference changes its constraint graph every step (src/world.c:138-168, src/contact.c:156-229); most changes are placed into the
+// existing structure (solver_incremental.cpp), but two things still cost milliseconds of host time when they come: building the strip
+// structure of a big island (BFS levels, per-strip colouring, the persistent kernel's tables: ~4 ms at 60k constraints) and the search
+// over other strip widths (seven more builds).  Both used to run inside the step that found them due.  Now, in the world chain, they run
+// in a worker thread on a COPY of the solver -- same host shadows, same options, its own stream and device tables -- while the steps go
+// on with the structure they have, which is valid (colour batches, or the strips the search wants to improve on).  The result is adopted
+// a FIXED number of steps after the request (the caller waits if the worker is not done: the step at which the sweep order changes must
+// not depend on thread timing), by swapping the SolverStructure part of the two solver objects.
+//
+// What happens to the graph between request and adoption is logged and replayed on the copy first: a destroyed contact leaves it as it
+// leaves the live structure (incrementalRemove), a created one is placed or deferred exactly as s2amd_world_set_contacts does it on the
+// live structure (incrementalApply / deferCreated).  Anything the copy cannot take -- a contact that fits nowhere, a watched manifold
+// that gained its points, an upload, an option that changes the structure -- drops the build; the next step that finds one due asks again.
+#include "solver_internal.h"
+
+#include <atomic>
+#include <thread>
+
+struct AsyncBuild
+{
+	std::thread worker;
+	s2amdSolver* clone = nullptr;
+	std::atomic<int> done{0};
+	int rc = S2AMD_OK;
+	int solverType = 0;
+	bool search = false;   // the search over strip widths (buildStructure with the graph at rest), not only the strip structure
+	bool dropped = false;  // overtaken by the graph: the result is thrown away when the worker is done
+	long requestedAtStep = 0;
+	struct Event
+	{
+		int kind; // 0 created (slot, a, b), 1 destroyed (slot)
+		int slot, a, b;
+	};
+	std::vector<Event> log;
+	AsyncBuild* older = nullptr; // dropped builds whose worker may still be running
+};
+
+namespace
+{
+
+// every device allocation, pinned buffer and captured graph of the structure part: a copy must not share them with its original
+void forgetDeviceState(SolverStructure& t)
+{
+	DevBuf* bufs[] = {&t.dWatched, &t.dBodyFlags, &t.soaBodies, &t.soaContacts, &t.soaJoints, &t.dContactIndex, &t.dJointIndex, &t.dContactLocal, &t.dJointLocal,
+					  &t.dAdjOffsets, &t.dAdjList, &t.dAdjHeavy, &t.dPatches, &t.dJointAdjRange, &t.dJointAdjList, &t.dResidentDesc, &t.dResidentOps, &t.dStripLean,
+					  &t.dPersist, &t.dGranules, &t.dPersistOps, &t.dMsg, &t.dGroups.buf, &t.dContactTail.buf, &t.dJointTail.buf, &t.dStripA.buf, &t.dStripB.buf,
+					  &t.dResident.buf};
+	for (DevBuf* b : bufs)
+	{
+		b->p = nullptr, b->bytes = 0;
+	}
+	t.dGroups = DeviceGroupTable{}, t.dContactTail = DeviceGroupTable{}, t.dJointTail = DeviceGroupTable{}, t.dStripA = DeviceGroupTable{}, t.dStripB = DeviceGroupTable{};
+	t.dResident = DeviceGroupTable{};
+	t.hostPatches = nullptr, t.hostPatchCapacity = 0;
+	t.graph = nullptr, t.graphExec = nullptr, t.graphKey = 0, t.graphKeySeen = 0, t.graphKeySeenLaunches = 0, t.graphLaunches = 0;
+	t.bv = BodyView{}, t.cv = ContactView{}, t.jv = JointView{};
+	t.bodySoaCap = t.contactSoaCap = t.jointSoaCap = 0;
+	t.leanA = StripTableView{}, t.leanB = StripTableView{}, t.residentView = StripTableView{};
+	t.leanAValid = t.leanBValid = t.persistValid = t.genericValid = false;
+	t.persist = PersistView{};
+	t.msg = MsgView{};
+	t.msgTablesValid = false;
+	t.adjValid = false, t.jointAdjValid = false;
+	t.granuleBytes = 0;
+	t.residentOpsGeneration = ~0ull, t.persistOpsGeneration = ~0ull, t.persistOpsStructure = ~0ull;
+	t.inc = IncrementalGlobal{};
+	t.stripInc = IncrementalStrips{};
+	t.structureDirty = true;
+}
+
+void releaseDeviceState(s2amdSolver* c)
+{
+	(void)hipSetDevice(c->device);
+	if (c->stream)
+	{
+		(void)hipStreamSynchronize(c->stream);
+	}
+	destroyGraph(c);
+	SolverStructure& t = *c;
+	DevBuf* bufs[] = {&t.dWatched, &t.dBodyFlags, &t.soaBodies, &t.soaContacts, &t.soaJoints, &t.dContactIndex, &t.dJointIndex, &t.dContactLocal, &t.dJointLocal,
+					  &t.dAdjOffsets, &t.dAdjList, &t.dAdjHeavy, &t.dPatches, &t.dJointAdjRange, &t.dJointAdjList, &t.dResidentDesc, &t.dResidentOps, &t.dStripLean,
+					  &t.dPersist, &t.dGranules, &t.dPersistOps, &t.dMsg, &t.dGroups.buf, &t.dContactTail.buf, &t.dJointTail.buf, &t.dStripA.buf, &t.dStripB.buf,
+					  &t.dResident.buf};
+	for (DevBuf* b : bufs)
+	{
+		b->release();
+	}
+	if (t.hostPatches)
+	{
+		(void)hipHostFree(t.hostPatches);
+		t.hostPatches = nullptr;
+	}
+}
+
+// a worker's copy of the solver: frees what IT owns (the structure part's device state, its stream); everything else is the owner's
+void destroyClone(s2amdSolver* c)
+{
+	if (!c)
+	{
+		return;
+	}
+	releaseDeviceState(c);
+	if (c->stream)
+	{
+		(void)hipStreamDestroy(c->stream);
+	}
+	delete c;
+}
+
+void workerMain(AsyncBuild* job)
+{
+	s2amdSolver* c = job->clone;
+	int rc = S2AMD_OK;
+	if (hipSetDevice(c->device) != hipSuccess)
+	{
+		rc = S2AMD_E_DEVICE;
+	}
+	bool grew = false;
+	if (rc == S2AMD_OK)
+	{
+		rc = c->dBodyFlags.ensure((size_t)std::max(c->bodyCapacity, 1) * sizeof(uint32_t), &grew);
+	}
+	if (rc == S2AMD_OK)
+	{
+		rc = carveBodies(c, c->bodyCapacity);
+	}
+	if (rc == S2AMD_OK)
+	{
+		rc = buildStructure(c, job->solverType);
+	}
+	if (rc == S2AMD_OK && hipStreamSynchronize(c->stream) != hipSuccess)
+	{
+		rc = S2AMD_E_DEVICE;
+	}
+	job->rc = rc;
+	job->done.store(1, std::memory_order_release);
+}
+
+// dropped builds whose worker has finished: their copies go
+void reap(AsyncBuild*& list, bool wait)
+{
+	AsyncBuild** at = &list;
+	while (*at)
+	{
+		AsyncBuild* j = *at;
+		if (wait || (j->dropped && j->done.load(std::memory_order_acquire)))
+		{
+			if (j->worker.joinable())
+			{
+				j->worker.join();
+			}
+			destroyClone(j->clone);
+			*at = j->older;
+			delete j;
+		}
+		else
+		{
+			at = &j->older;
+		}
+	}
+}
+
+} // namespace
+
+bool asyncBuildsOn(const s2amdSolver* s)
+{
+	return s->optAsyncBuild != 0 && s->worldResident && !s->isClone;
+}
+
+bool asyncPending(const s2amdSolver* s)
+{
+	return s->async != nullptr && !s->async->dropped;
+}
+
+// the graph moved in a way the pending build cannot follow: its result will be thrown away
+void asyncDrop(s2amdSolver* s)
+{
+	if (s->async && !s->async->dropped)
+	{
+		s->async->dropped = true;
+		s->async->log.clear();
+	}
+}
+
+void asyncLogCreated(s2amdSolver* s, int slot, int a, int b)
+{
+	if (asyncPending(s))
+	{
+		s->async->log.push_back(AsyncBuild::Event{0, slot, a, b});
+	}
+}
+
+void asyncLogDestroyed(s2amdSolver* s, int slot)
+{
+	if (asyncPending(s))
+	{
+		s->async->log.push_back(AsyncBuild::Event{1, slot, -1, -1});
+	}
+}
+
+// the owner is going away (or its world is replaced): nothing of a worker may outlive it
+void asyncShutdown(s2amdSolver* s)
+{
+	reap(s->async, true);
+}
+
+// `search`: the graph has been at rest long enough for the search over strip widths (the copy sees the same age and runs it)
+int asyncRequest(s2amdSolver* s, int solverType, bool search)
+{
+	reap(s->async, false);
+	if (asyncPending(s))
+	{
+		return S2AMD_OK;
+	}
+	HIP_TRY(hipSetDevice(s->device));
+	// what a synchronous build would learn from the device first (buildStructureWith, gatherEdges): the pairs stage 3 has freed, and --
+	// for the hub rule -- which manifolds have points right now.  The copy then builds from host state alone.
+	if (!s->pointsKnown)
+	{
+		int rc = syncDeadSlots(s);
+		if (rc == S2AMD_OK)
+		{
+			rc = fetchPointCounts(s);
+		}
+		if (rc)
+		{
+			return rc;
+		}
+	}
+	AsyncBuild* job = new AsyncBuild();
+	s2amdSolver* c = new s2amdSolver(*s);
+	c->isClone = true;
+	c->async = nullptr;
+	c->worldResident = false; // (no device reads of the world's arrays from the worker: the shadows above are current)
+	c->pointsKnown = true;
+	c->stream = nullptr;
+	c->evBegin = c->evEnd = nullptr;
+	for (hipEvent_t& e : c->evExport)
+	{
+		e = nullptr;
+	}
+	c->side[0] = c->side[1] = nullptr;
+	c->hostTimes = nullptr;
+	c->sweepEvents.clear();
+	forgetDeviceState(*c);
+	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+	{
+		delete c;
+		delete job;
+		return fail(S2AMD_E_DEVICE, "could not create the build worker's stream");
+	}
+	if (search)
+	{
+		c->stripRetryPending = false;
+	}
+	job->clone = c;
+	job->solverType = solverType;
+	job->search = search;
+	job->requestedAtStep = s->stepCounter;
+	job->older = s->async;
+	s->async = job;
+	s->asyncRequested += 1;
+	job->worker = std::thread(workerMain, job);
+	return S2AMD_OK;
+}
+
+// the logged changes of the graph, applied to the copy as s2amd_world_set_contacts / s2amd_world_step applied them to the live structure
+static bool replay(s2amdSolver* c, const std::vector<AsyncBuild::Event>& log)
+{
+	for (const AsyncBuild::Event& e : log)
+	{
+		if (e.slot < 0 || e.slot >= c->contactCapacity)
+		{
+			return false;
+		}
+		if (e.kind == 1)
+		{
+			if (c->hContactEdge[(size_t)e.slot])
+			{
+				c->hContactDead[(size_t)e.slot] = 1;
+				unwatchSlot(c, e.slot);
+				const int32_t one = e.slot;
+				incrementalRemove(c, &one, 1);
+			}
+			continue;
+		}
+		if (canDeferCreated(c, e.slot, e.a, e.b))
+		{
+			deferCreated(c, e.slot, e.a, e.b);
+			continue;
+		}
+		const std::vector<ContactChange> one{ContactChange{e.slot, e.a, e.b}};
+		if (!incrementalApply(c, one))
+		{
+			return false;
+		}
+		c->hContactA[(size_t)e.slot] = e.a;
+		c->hContactB[(size_t)e.slot] = e.b;
+		c->hContactEdge[(size_t)e.slot] = 1;
+		c->hContactDead[(size_t)e.slot] = 0;
+	}
+	return incrementalFlush(c) == S2AMD_OK && hipStreamSynchronize(c->stream) == hipSuccess;
+}
+
+// Called by doStep before it looks at the structure: adopts a build that is due.  true: the structure was replaced.
+bool asyncAdopt(s2amdSolver* s, int solverType, int* rcOut)
+{
+	*rcOut = S2AMD_OK;
+	reap(s->async, false); // (dropped builds whose worker is done)
+	AsyncBuild* job = s->async;
+	if (!job)
+	{
+		return false;
+	}
+	if (job->dropped)
+	{
+		return false; // (its worker is still running: reaped at a later step)
+	}
+	const long due = job->requestedAtStep + (job->search ? 8L * s->optAsyncBuildDelay : (long)s->optAsyncBuildDelay);
+	if (s->stepCounter < due)
+	{
+		return false;
+	}
+	// due: the step at which the sweep order changes is fixed, so a worker that is not done yet is waited for
+	const double t0 = nowMs();
+	if (job->worker.joinable())
+	{
+		job->worker.join();
+	}
+	s->asyncWaitMs += (float)(nowMs() - t0);
+	s2amdSolver* c = job->clone;
+	bool ok = job->rc == S2AMD_OK && job->solverType == solverType && !c->structureDirty;
+	// (a search that found nothing better than what runs now is not worth the swap)
+	if (ok && job->search && c->dStripA.view.groupCount == 0)
+	{
+		ok = false;
+	}
+	ok = ok && replay(c, job->log);
+	if (ok && c->watchedCount > 0)
+	{
+		// a slot the copy only watches (no entry in its structure) must not have gained its manifold points meanwhile
+		if (fetchPointCounts(s) != S2AMD_OK)
+		{
+			ok = false;
+		}
+		for (int i = 0; ok && i < s->contactCapacity; ++i)
+		{
+			if (c->hContactWatched[(size_t)i] && s->hContactPoints[(size_t)i] > 0 && c->inc.positionOfSlot[(size_t)i] == -1)
+			{
+				ok = false;
+			}
+		}
+	}
+	if (ok)
+	{
+		std::swap(static_cast<SolverStructure&>(*s), static_cast<SolverStructure&>(*c));
+		s->watchedDirty = true; // (the copy never uploaded its watched bytes: the world chain does, before its next stage 3)
+		// (contacts placed into the old structure meanwhile reset the graph's age; they are part of the new one: it is as settled as
+		// a structure built this step would be -- and must not be taken for one that is due for a rebuild without strips)
+		s->graphAge = std::max(s->graphAge, s->stripPatienceNow);
+		s->asyncAdopted += 1;
+		s->stripRetryPending = job->search ? false : s->stripRetryPending;
+	}
+	else if (job->search)
+	{
+		s->stripRetryPending = false; // (tried; a graph that changes asks again through buildStructure)
+	}
+	// the copy (holding the old structure after a swap) is freed by a thread of its own: hipFree waits for the device
+	job->dropped = true;
+	job->done.store(0, std::memory_order_release);
+	job->worker = std::thread([job]() {
+		destroyClone(job->clone);
+		job->clone = nullptr;
+		job->done.store(1, std::memory_order_release);
+	});
+	return ok;
+}

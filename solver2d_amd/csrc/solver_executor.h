@@ -445,7 +445,7 @@ struct Executor
 	bool selfContainedStrips() const
 	{
 		int kind, warm;
-		return s->optSelfContained && s->dStripA.view.groupCount > 0 && persistPlan(kind, warm) && widePlan(kind, warm) && wideFits(true, false) && gatherIndex == nullptr && !msg &&
+		return s->optSelfContainedStrips && s->dStripA.view.groupCount > 0 && persistPlan(kind, warm) && widePlan(kind, warm) && wideFits(true, false) && gatherIndex == nullptr && !msg &&
 			   wireBodies() != nullptr && s->dGroups.view.groupCount == 0 && s->dResident.view.groupCount == 0 && s->looseBodies == 0 && !anyGlobalContacts() &&
 			   s->joints.globalCount == 0 && s->jv.count == 0 && s->cv.count == s->persistK1 - s->persistK0 && p.prepContacts == PREP_SOFT && p.storeKind == STORE_PLAIN;
 	}

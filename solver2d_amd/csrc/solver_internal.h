@@ -407,7 +407,10 @@ struct s2amdSolver : SolverStructure
 	int optPersist = 1;
 	int optSeamRegs = 1;
 	int optWide = 1;	  // TGS_Soft's persistent step on 512 threads per strip (wide_kernel.hip) where the partition fits
-	int optWideBodyWarm = 1; // "strip_body_warm": ... with s2WarmStartContacts as one body-centric pass (wide_kernel.hip: S2_WIDE_BODYWARM) where its term table fits LDS
+	// Two forms of that kernel that were built to the verdict of round 3 and measured no faster on the MI355X (the work
+	// they remove from launches or barriers comes back as latency-bound work inside the persistent kernel); tested options, off by default:
+	int optWideBodyWarm = 0;	  // "strip_body_warm": s2WarmStartContacts as one body-centric pass (wide_kernel.hip: S2_WIDE_BODYWARM) where its term table fits LDS
+	int optSelfContainedStrips = 0; // "self_contained_strips": the kernel is the step's prologue and epilogue too -- ONE launch per step (S2_WIDE_SELF)
 	int optStripSlack = 1; // strip and seam rounds are laid out with free positions for created contacts (solver_incremental.cpp)
 	int optPairLanes = 0; // two lanes per constraint (pair_kernel.hip; measured no faster: kept as an option); 0: one lane per constraint
 	int optStripRetry = 1; // try other strip widths when the partition needs the 8-round kernel variant
@@ -463,6 +466,9 @@ struct s2amdSolver : SolverStructure
 							   // copy of the solver while the steps go on on the colour batches, and adopted a fixed number of steps later
 	int optAsyncBuildDelay = 6; // "async_build_delay": steps between the request and the adoption (the caller waits if the build is not done by then)
 	bool isClone = false;	   // a worker's copy: the wire and world buffers are the owner's
+	long stepCounter = 0;	   // steps enqueued since s2amd_create (the clock of the deferred adoption)
+	int asyncRequested = 0, asyncAdopted = 0;
+	float asyncWaitMs = 0.0f;
 };
 
 // The constraint graph changed (an upload, a manifold that gained or lost its points, a contact slot written): the
@@ -470,8 +476,10 @@ struct s2amdSolver : SolverStructure
 // strip_retry), so a world whose graph keeps changing every few steps must not build it again and again: the patience
 // doubles whenever strips were in use for fewer than 32 steps, and returns to the option's value after a quiet spell.
 // (strip_patience 0 means "always build at once" and is left alone; a world of another size is a new world.)
+void asyncDrop(s2amdSolver* s);
 inline void noteGraphChanged(s2amdSolver* s, bool newWorld = false)
 {
+	asyncDrop(s); // (a build in flight was made for the graph as it was)
 	const bool stripsInUse = s->dStripA.view.groupCount > 0;
 	if (newWorld)
 	{
@@ -526,6 +534,16 @@ int refreshConstraintIndexOnDevice(s2amdSolver* s);
 int fetchPointCounts(s2amdSolver* s);
 // world chain: which pair slots the device has freed (stage 3 separations) -> hContactDead, before a structure rebuild
 int syncDeadSlots(s2amdSolver* s);
+
+// solver_async.cpp: structure builds in a worker thread on a copy of the solver, adopted a fixed number of steps later
+bool asyncBuildsOn(const s2amdSolver* s);
+bool asyncPending(const s2amdSolver* s);
+int asyncRequest(s2amdSolver* s, int solverType, bool search);
+bool asyncAdopt(s2amdSolver* s, int solverType, int* rc);
+void asyncDrop(s2amdSolver* s);
+void asyncLogCreated(s2amdSolver* s, int slot, int a, int b);
+void asyncLogDestroyed(s2amdSolver* s, int slot);
+void asyncShutdown(s2amdSolver* s);
 
 // solver_incremental.cpp
 struct ContactChange

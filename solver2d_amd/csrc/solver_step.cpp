@@ -291,6 +291,7 @@ int doUpload(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdContact
 		return fail(S2AMD_E_INVALID, "null array with non-zero count");
 	}
 	HIP_TRY(hipSetDevice(s->device));
+	asyncDrop(s); // (a structure being built for the arrays as they were)
 	int rc = refreshShadows(s, bodies, nb, contacts, nc, joints, nj, pairs);
 	if (rc)
 	{
@@ -372,7 +373,17 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	}
 	HIP_TRY(hipSetDevice(s->device));
 	s->stats = s2amdStepStats{};
+	s->stepCounter += 1;
 	buildPlan(s, params);
+	{
+		// a structure a worker thread has built for this world falls due at a fixed step after its request (solver_async.cpp)
+		int rcAdopt = S2AMD_OK;
+		(void)asyncAdopt(s, params->solverType, &rcAdopt);
+		if (rcAdopt)
+		{
+			return rcAdopt;
+		}
+	}
 	if (s->persistFailed && s->optPersistRetry > 0 && ++s->persistFailedAge > s->persistRetryAfter)
 	{
 		// a hand-off timed out a while ago (workgroups not co-resident: something else held part of the GPU): try again
@@ -384,8 +395,25 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	}
 	if (s->stripRetryPending && s->graphAge >= 32 && !s->structureDirty)
 	{
-		s->structureDirty = true; // the postponed search for a better strip partition (solver_structure.cpp: buildStructure)
-		s->stripsRejected = false;
+		// the postponed search for a better strip partition (solver_structure.cpp: buildStructure): seven more builds, tens of
+		// milliseconds -- in the world chain a worker thread's, on a copy; the steps go on with the strips they have
+		if (asyncBuildsOn(s))
+		{
+			if (!asyncPending(s))
+			{
+				int rcAsync = asyncRequest(s, params->solverType, true);
+				if (rcAsync)
+				{
+					return rcAsync;
+				}
+				s->stripRetryPending = false;
+			}
+		}
+		else
+		{
+			s->structureDirty = true;
+			s->stripsRejected = false;
+		}
 	}
 	int rc = buildStructure(s, params->solverType);
 	if (rc)
@@ -535,7 +563,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	{
 		uint64_t key = 1469598103934665603ull;
 		key = fnv(key, params, sizeof(*params));
-		uint64_t gens[4] = {s->layoutGeneration, s->structureGeneration, s->planGeneration, (uint64_t)((q.msg ? 1 : 0) | (s->optBodyWarm ? 2 : 0) | (s->optStripLean ? 4 : 0) | (s->optPersist ? 8 : 0) | (s->optFork ? 16 : 0) | (s->persistFailed ? 32 : 0) | ((s->persistValid && s->persist.allTwoPoints) ? 64 : 0) | (s->pointsKnown ? 128 : 0) | (s->optPairLanes ? 256 : 0) | (s->optWide ? 512 : 0) | (s->optGeneric ? 1024 : 0) | (s->genericValid ? 2048 : 0) | (indexNow ? 4096 : 0) | (s->optSelfContained ? 8192 : 0) | ((s->residentAllTwoPoints && s->pointsKnown) ? 16384 : 0) | (s->optStageJoints ? 32768 : 0) | (s->optWideBodyWarm ? 65536 : 0))};
+		uint64_t gens[4] = {s->layoutGeneration, s->structureGeneration, s->planGeneration, (uint64_t)((q.msg ? 1 : 0) | (s->optBodyWarm ? 2 : 0) | (s->optStripLean ? 4 : 0) | (s->optPersist ? 8 : 0) | (s->optFork ? 16 : 0) | (s->persistFailed ? 32 : 0) | ((s->persistValid && s->persist.allTwoPoints) ? 64 : 0) | (s->pointsKnown ? 128 : 0) | (s->optPairLanes ? 256 : 0) | (s->optWide ? 512 : 0) | (s->optGeneric ? 1024 : 0) | (s->genericValid ? 2048 : 0) | (indexNow ? 4096 : 0) | (s->optSelfContained ? 8192 : 0) | ((s->residentAllTwoPoints && s->pointsKnown) ? 16384 : 0) | (s->optStageJoints ? 32768 : 0) | (s->optWideBodyWarm ? 65536 : 0) | (s->optSelfContainedStrips ? 131072 : 0))};
 		key = fnv(key, gens, sizeof(gens));
 		int sizes[3] = {s->bodyCapacity, s->contactCapacity, s->jointCapacity};
 		key = fnv(key, sizes, sizeof(sizes));
@@ -608,6 +636,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 		s->stats.persistent = (s->dStripA.view.groupCount > 0 && (q.persistPlan(kind, warm) || q.genericPlan())) ? 1 : 0;
 	}
 	s->stats.persistFallbacks = s->persistFallbacks;
+	s->stats.asyncBuildsRequested = s->asyncRequested, s->stats.asyncBuildsAdopted = s->asyncAdopted, s->stats.asyncWaitMs = s->asyncWaitMs;
 	s->stats.structureBuilds = (int32_t)s->structureGeneration;
 	s->stats.placedContacts = (int32_t)s->placedTotal;
 	{

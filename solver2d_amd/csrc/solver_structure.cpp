@@ -1575,6 +1575,15 @@ struct StructureBuild
 		return type == s2amd_solverTGS_Soft || type == s2amd_solverSoftStep || type == s2amd_solverPGS_Soft;
 	}
 
+	// the structure the solver holds serves this solver type in everything but the strips that have fallen due (the graph has aged
+	// enough): what a worker thread can build while the steps go on (solver_async.cpp)
+	bool onlyStripsMissing() const
+	{
+		const bool colourFree = s->inc.colourFreePlaced && !needAdj;
+		return !s->structureDirty && cls == s->orderSolverClass && grouped == s->orderGrouped && wantStrips && !s->orderStrips && s->adjValid && !colourFree &&
+			   residentWanted == s->orderResident && needAdj == s->orderColourless;
+	}
+
 	// does the structure the solver holds already serve this solver type?
 	bool upToDate() const
 	{
@@ -2689,6 +2698,16 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 // runs only in the (rare) steps that build the strip structure at all.
 int buildStructure(s2amdSolver* s, int solverType)
 {
+	if (asyncBuildsOn(s) && !s->structureDirty)
+	{
+		StructureBuild probe(s, solverType, 1.0f);
+		if (probe.onlyStripsMissing())
+		{
+			// the strip structure is due (milliseconds of host time): a worker thread builds it on a copy, this step and the next few
+			// run on the colour batches there are
+			return asyncRequest(s, solverType, false);
+		}
+	}
 	const uint64_t before = s->structureGeneration;
 	// (a world whose partition was searched for once keeps the width that won: a graph that changes is not searched again as
 	// long as that width still gives the persistent kernel something it can run)

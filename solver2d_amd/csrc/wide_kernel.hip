@@ -699,26 +699,6 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0> __g
 		const int k = batchA[i].x + ht;
 		return (i < roundsA && (i & 1) == half && k < batchA[i].y) ? k : -1;
 	};
-	// SELF: the wire bodies this lane stages (two of the strip's own list, one import) are asked for FIRST, so that they travel while
-	// the constraints are prepared (unconditional loads from clamped slots); they go into LDS further down
-	int stageSlot[S2_WIDE_BODY_CHUNKS + 1];
-	s2amdBody stageRaw[SELF ? S2_WIDE_BODY_CHUNKS + 1 : 1];
-#pragma unroll
-	for (int ch = 0; ch < S2_WIDE_BODY_CHUNKS + 1; ++ch)
-	{
-		if (ch < S2_WIDE_BODY_CHUNKS)
-		{
-			stageSlot[ch] = tid + ch * S2_WIDE_THREADS < nb ? (int)(id[ch] & ~S2G_OWNED) : -1;
-		}
-		else
-		{
-			stageSlot[ch] = impId;
-		}
-		if constexpr (SELF)
-		{
-			stageRaw[ch] = self.wireBodies[stageSlot[ch] >= 0 ? stageSlot[ch] : 0];
-		}
-	}
 	if constexpr (SELF)
 	{
 		// s2PrepareContacts_Soft (solve_common.c:188-274) for the constraints this lane holds, straight from the wire contacts and
@@ -835,15 +815,26 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0> __g
 #pragma unroll
 	for (int ch = 0; ch < S2_WIDE_BODY_CHUNKS + 1; ++ch)
 	{
-		const int gi = stageSlot[ch];
-		ldsIdx[ch] = ch < S2_WIDE_BODY_CHUNKS ? tid + ch * S2_WIDE_THREADS : impSlotH;
+		int gi = -1;
+		if (ch < S2_WIDE_BODY_CHUNKS)
+		{
+			const int i = tid + ch * S2_WIDE_THREADS;
+			ldsIdx[ch] = i;
+			gi = i < nb ? (int)(id[ch] & ~S2G_OWNED) : -1;
+		}
+		else
+		{
+			ldsIdx[ch] = impSlotH;
+			gi = impId;
+		}
 		flags[ch] = 0u;
 		if (gi >= 0)
 		{
 			if constexpr (SELF)
 			{
-				// body_ops.h: unpackBodyOne, into LDS instead of the SoA arrays
-				const s2amdBody* w = &stageRaw[ch];
+				// body_ops.h: unpackBodyOne, into LDS instead of the SoA arrays.  (Asking for these records before the constraints are
+				// prepared, so that they travel meanwhile, was measured: the 66 registers they hold spill, 161 against 151 us per launch.)
+				const s2amdBody* w = self.wireBodies + gi;
 				const int type = w->type;
 				uint32_t f = 0x80000000u;
 				if (type != S2AMD_BODY_FREE)

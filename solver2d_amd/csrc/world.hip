@@ -534,6 +534,7 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 		}
 		if (hSum->watchedFlips > 0)
 		{
+			asyncDrop(s); // (a watched manifold gained or lost its points: a build in flight was made without that)
 			// s2Solve_Jacobi has no colours to find: a watched manifold that gained its first points gets a position and its two
 			// incidence-list entries like a created contact (one that lost its points stays where it is, a no-op); every other
 			// solver's structure is rebuilt
@@ -639,6 +640,7 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 		{
 			s->hContactDead[(size_t)slot] = 1;
 			unwatchSlot(s, slot);
+			asyncLogDestroyed(s, slot);
 		}
 		incrementalRemove(s, s->hSeparated.data(), (int)s->hSeparated.size());
 		if ((rc = incrementalFlush(s)) != 0)
@@ -954,11 +956,17 @@ int s2amd_world_set_contacts(s2amdSolver* s, const int32_t* slots, int32_t count
 				unwatchSlot(s, k);
 				const int32_t one = k;
 				incrementalRemove(s, &one, 1);
+				asyncLogDestroyed(s, k);
 			}
 			continue;
 		}
 		if (!s->hContactEdge[(size_t)k] || s->hContactA[(size_t)k] != c.bodyA || s->hContactB[(size_t)k] != c.bodyB)
 		{
+			if (pc > 0)
+			{
+				asyncDrop(s); // (created with points already: not what a build in flight replays)
+			}
+			asyncLogCreated(s, k, c.bodyA, c.bodyB);
 			if (pc == 0 && canDeferCreated(s, k, c.bodyA, c.bodyB))
 			{
 				deferCreated(s, k, c.bodyA, c.bodyB); // watched until stage 3 finds its first manifold points

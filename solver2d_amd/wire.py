@@ -7,7 +7,7 @@ library.  Arrays of these dtypes are what the Python host side hands to the C en
 import ctypes
 import numpy as np
 
-API_VERSION = 2
+API_VERSION = 3
 
 SOLVER_NAMES = [
     "Jacobi", "PGS", "PGS_NGS", "PGS_NGS_Block", "PGS_Soft",
@@ -100,6 +100,7 @@ class StepStats(ctypes.Structure):
         ("eventPairOverheadMs", ctypes.c_float), ("groupCount", ctypes.c_int32), ("messagePassing", ctypes.c_int32),
         ("stripCount", ctypes.c_int32), ("seamCount", ctypes.c_int32), ("persistent", ctypes.c_int32), ("persistFallbacks", ctypes.c_int32),
         ("structureBuilds", ctypes.c_int32), ("placedContacts", ctypes.c_int32), ("potentialConstraints", ctypes.c_int32), ("pairLanes", ctypes.c_int32),
+        ("asyncBuildsRequested", ctypes.c_int32), ("asyncBuildsAdopted", ctypes.c_int32), ("asyncWaitMs", ctypes.c_float),
     ]
 
 

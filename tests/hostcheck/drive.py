@@ -144,6 +144,51 @@ def world_chain(base, steps):
         s.world_download(*[world[k] for k in keys])
 
 
+def world_chain_async(base, steps):
+    """Structure builds in a worker thread (solver_async.cpp): a resident world whose big island is due for strips gets them from a
+    copy of the solver built off the caller's thread and adopted a fixed number of steps later; contacts created and destroyed in
+    between are replayed on the copy.  (Kernels never run here: this drives the threads, the copy, the swap and the replay.)"""
+    world = synthetic.pyramid_world(base)
+    keys = ("bodies", "contacts", "joints", "shapes", "pairs", "origins")
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    rng = np.random.default_rng(3)
+    free = sorted(np.flatnonzero(world["pairs"]["shapeA"] < 0).tolist(), reverse=True)
+    live = np.flatnonzero(world["pairs"]["shapeA"] >= 0)
+    seen = []
+    with hip.Solver(0) as s:
+        for k, v in (("strip_min_bodies", 0), ("max_group_bodies", 96), ("strip_bodies", 24), ("strip_patience", 1), ("async_build_delay", 3)):
+            s.set_option(k, v)
+        s.world_upload(*[world[k] for k in keys])
+        mine = []
+        for step in range(steps):
+            if step % 4 == 1 and free:
+                # a pair of boxes two rows apart gets a contact (nothing the narrow phase would find: the stub runs no kernels)
+                a = int(rng.choice(live))
+                contacts = np.zeros(1, dtype=wire.contact_dtype)
+                pairs = np.zeros(1, dtype=wire.pair_state_dtype)
+                contacts["bodyA"], contacts["bodyB"] = world["contacts"]["bodyA"][a], world["contacts"]["bodyB"][(a + 7) % len(world["contacts"])]
+                if contacts["bodyA"][0] != contacts["bodyB"][0] and contacts["bodyB"][0] >= 0:
+                    contacts["friction"], contacts["constraintIndex"] = 0.6, -1
+                    pairs["shapeA"], pairs["shapeB"] = contacts["bodyA"][0], contacts["bodyB"][0]  # (one shape per body, same index)
+                    slot = free.pop()
+                    s.world_set_contacts(np.array([slot], dtype=np.int32), contacts, pairs)
+                    mine.append(slot)
+            if step % 6 == 5 and mine:
+                # ... and one of them is destroyed again by the caller
+                slot = mine.pop(0)
+                contacts = np.zeros(1, dtype=wire.contact_dtype)
+                pairs = np.zeros(1, dtype=wire.pair_state_dtype)
+                contacts["bodyA"], contacts["bodyB"], contacts["constraintIndex"] = -1, -1, -1
+                pairs["shapeA"], pairs["shapeB"] = -1, -1
+                s.world_set_contacts(np.array([slot], dtype=np.int32), contacts, pairs)
+                free.append(slot)
+            s.world_step(params)
+            st = s.stats()
+            seen.append((st["stripCount"], st["asyncBuildsRequested"], st["asyncBuildsAdopted"], st["structureBuilds"]))
+        s.contact_order()
+    return seen
+
+
 def hub_rule():
     """A writable body with more than S2_STRIP_MAX_DEGREE (48) constraints among the strip candidates keeps its graph off the strips
     (solver_structure.cpp: cutStrips); the same pile without the hub is cut into strips."""
@@ -184,6 +229,9 @@ def main():
     print("hub rule: strips", hub_rule())
     world_chain(20 if quick else 60, 3 if quick else 8)
     print("world chain ok")
+    seen = world_chain_async(30, 24 if quick else 60)
+    print("world chain, structure builds in a worker thread: (strips, requested, adopted, builds) per step:", seen[::4])
+    assert seen[-1][1] >= 1 and seen[-1][2] >= 1 and seen[-1][0] > 0, seen
     print("HOSTCHECK OK")
 
 

@@ -34,8 +34,11 @@ def resident_vs_oracle(s, params, pre, steps, what, launches=None):
 TGS = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
 
 
-@pytest.mark.parametrize("options,launches", [({}, 1), ({"strip_body_warm": 0}, 1), ({"self_contained": 0}, 3), ({"self_contained": 0, "strip_body_warm": 0}, 3),
-                                              ({"persist_debug": 16}, 1), ({"persist_debug": 16, "self_contained": 0}, 3)],
+ONE = {"self_contained_strips": 1, "strip_body_warm": 1}  # (both are options, off by default: measured no faster than the three-launch step)
+
+
+@pytest.mark.parametrize("options,launches", [(ONE, 1), ({"self_contained_strips": 1}, 1), ({"strip_body_warm": 1}, 3), ({}, 3),
+                                              ({"persist_debug": 16, "self_contained_strips": 1}, 1), ({"persist_debug": 16}, 3)],
                          ids=["self+bodywarm", "self", "bodywarm", "plain", "parked-self", "parked"])
 def test_the_one_launch_step_equals_the_oracle(options, launches):
     with hip.Solver(0) as s:
@@ -51,6 +54,8 @@ def test_the_headline_world_is_one_launch_per_step():
     """BASELINE configs[1] at full size: LargePyramid base-200, 59,900 constraints."""
     with hip.Solver(0) as s:
         s.set_option("strip_patience", 0)
+        for k, v in ONE.items():
+            s.set_option(k, v)
         resident_vs_oracle(s, TGS, synthetic.pyramid(200), 3, "base 200", 1)
 
 
@@ -59,6 +64,8 @@ def test_iteration_shapes_and_cold_start(iters, warm):
     params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, iters[0], iters[1], warm)
     with hip.Solver(0) as s:
         s.set_option("strip_patience", 0)
+        for k, v in ONE.items():
+            s.set_option(k, v)
         resident_vs_oracle(s, params, synthetic.pyramid(100), 4, "%s warm=%s" % (iters, warm), 1)
 
 
@@ -70,12 +77,12 @@ def test_mixed_point_counts_and_empty_manifolds():
     live = np.flatnonzero(pre[1]["pointCount"] == 2)
     pre[1]["pointCount"][rng.choice(live, size=400, replace=False)] = 1
     pre[1]["pointCount"][rng.choice(live, size=150, replace=False)] = 0
-    for options in ({}, {"strip_body_warm": 0}):
+    for options, launches in ((ONE, 1), ({"self_contained_strips": 1}, 1), ({"strip_body_warm": 1}, 3)):
         with hip.Solver(0) as s:
             s.set_option("strip_patience", 0)
             for k, v in options.items():
                 s.set_option(k, v)
-            resident_vs_oracle(s, TGS, pre, 4, "mixed point counts %s" % options, 1)
+            resident_vs_oracle(s, TGS, pre, 4, "mixed point counts %s" % options, launches)
 
 
 def test_kinematic_and_heavy_bodies_inside_the_pile():
@@ -91,6 +98,8 @@ def test_kinematic_and_heavy_bodies_inside_the_pile():
         pre[0]["linearVelocity"][b] = (0.05, 0.0)
     with hip.Solver(0) as s:
         s.set_option("strip_patience", 0)
+        for k, v in ONE.items():
+            s.set_option(k, v)
         resident_vs_oracle(s, TGS, pre, 4, "kinematic bodies in the pile")
         assert s.stats()["persistent"] == 1
 
@@ -102,6 +111,8 @@ def test_a_dead_hand_off_in_the_one_launch_step_leaves_the_wire_arrays_alone():
     with hip.Solver(0) as s:
         s.set_option("strip_patience", 0)
         s.set_option("persist_spin_limit", 4096)
+        for k, v in ONE.items():
+            s.set_option(k, v)
         want = resident_vs_oracle(s, TGS, pre, 3, "before the fault", 1)
         s.set_option("persist_debug", 8)
         for step in range(2):
@@ -122,6 +133,8 @@ def test_a_dead_hand_off_under_async_drops_the_steps_behind_it():
     with hip.Solver(0) as s:
         s.set_option("strip_patience", 0)
         s.set_option("persist_spin_limit", 4096)
+        for k, v in ONE.items():
+            s.set_option(k, v)
         want = resident_vs_oracle(s, TGS, pre, 3, "before the fault", 1)
         s.set_option("persist_debug", 8)
         s.set_option("async", 1)
@@ -148,9 +161,9 @@ def test_four_hundred_one_launch_steps_against_the_multi_launch_path():
     multi-launch strip path at every checkpoint."""
     from tests.test_gpu_strips import _resident_states
     checkpoints = {2, 77, 200, 400}
-    a = _resident_states({"persist": 1}, 400, checkpoints)
+    a = _resident_states(dict(ONE, persist=1), 400, checkpoints)
     b = _resident_states({"persist": 0}, 400, checkpoints)
-    c = _resident_states({"persist": 1, "strip_body_warm": 0, "self_contained": 0}, 400, checkpoints)
+    c = _resident_states({"persist": 1}, 400, checkpoints)
     for i, ((ba, pa), (bb, pb), (bc, pc)) in enumerate(zip(a, b, c)):
         for f in ("position", "rot", "linearVelocity", "angularVelocity"):
             assert np.array_equal(ba[f].view(np.uint32), bb[f].view(np.uint32)), "checkpoint %d field %s" % (i, f)

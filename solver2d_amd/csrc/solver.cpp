@@ -736,7 +736,7 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	asyncDrop(s); // (a structure being built under the options as they were)
 	if (strcmp(key, "async_build") == 0)
 	{
-		s->optAsyncBuild = value != 0;
+		s->optAsyncBuild = std::max(0, std::min(value, 2));
 	}
 	else if (strcmp(key, "async_build_delay") == 0)
 	{

@@ -462,9 +462,10 @@ struct s2amdSolver : SolverStructure
 
 	// structure builds off the caller's thread (solver_async.cpp)
 	AsyncBuild* async = nullptr;
-	int optAsyncBuild = 1;	   // "async_build": in the world chain the strip structure (and the search over strip widths) is built by a worker thread on a
-							   // copy of the solver while the steps go on on the colour batches, and adopted a fixed number of steps later
-	int optAsyncBuildDelay = 6; // "async_build_delay": steps between the request and the adoption (the caller waits if the build is not done by then)
+	int optAsyncBuild = 1;	   // "async_build": in the world chain, 1: the search over strip widths (tens of milliseconds) runs in a worker thread on a copy
+							   // of the solver while the steps go on with the strips they have; 2: the strip structure itself too (the steps go on on the
+							   // colour batches meanwhile); adopted a fixed number of steps after the request; 0: everything on the caller's thread
+	int optAsyncBuildDelay = 12; // "async_build_delay": steps between the request and the adoption of a strip build (the search: 8 x); the caller waits if the worker is not done by then
 	bool isClone = false;	   // a worker's copy: the wire and world buffers are the owner's
 	long stepCounter = 0;	   // steps enqueued since s2amd_create (the clock of the deferred adoption)
 	int asyncRequested = 0, asyncAdopted = 0;

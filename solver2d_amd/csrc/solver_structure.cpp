@@ -2698,13 +2698,16 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 // runs only in the (rare) steps that build the strip structure at all.
 int buildStructure(s2amdSolver* s, int solverType)
 {
-	if (asyncBuildsOn(s) && !s->structureDirty)
+	if (asyncBuildsOn(s) && s->optAsyncBuild >= 2 && !s->structureDirty)
 	{
 		StructureBuild probe(s, solverType, 1.0f);
 		if (probe.onlyStripsMissing())
 		{
 			// the strip structure is due (milliseconds of host time): a worker thread builds it on a copy, this step and the next few
-			// run on the colour batches there are
+			// run on the colour batches there are.  (Option "async_build" 2; measured a LOSS on the wrecking-ball world at base 200 --
+			// every build costs `async_build_delay` more steps on the colour batches, and half the builds are overtaken by the graph:
+			// 164 instead of 207 of 240 steps on the persistent kernel, median 0.79 against 0.56 ms -- so by default only the search
+			// over strip widths, which improves on strips that already run, goes to the worker.)
 			return asyncRequest(s, solverType, false);
 		}
 	}

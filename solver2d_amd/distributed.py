@@ -9,16 +9,102 @@ import numpy as np
 from . import islands, wire
 
 
+def _gather_rows(rows, world_size, dist, torch, device):
+    """all-gather of one variable-length array of fixed-size records per rank (padded to the longest): list of arrays, one per rank"""
+    flat = np.ascontiguousarray(rows).view(np.uint8).reshape(len(rows), -1) if len(rows) else np.zeros((0, rows.dtype.itemsize), dtype=np.uint8)
+    count = torch.tensor([len(rows)], dtype=torch.int64, device=device)
+    counts = torch.zeros(world_size, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(counts, count)
+    counts = counts.cpu().numpy()
+    most = max(int(counts.max()), 1)
+    mine = np.zeros((most, flat.shape[1]), dtype=np.uint8)
+    mine[: len(flat)] = flat
+    t = torch.from_numpy(mine).to(device)
+    out = torch.empty((world_size * most, flat.shape[1]), dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(out, t)
+    out = out.cpu().numpy().reshape(world_size, most, flat.shape[1])
+    return [np.ascontiguousarray(out[r, : int(counts[r])]).view(rows.dtype).reshape(-1) for r in range(world_size)]
+
+
 class ShardedWorld:
     def __init__(self, bodies, contacts, joints, rank, world_size):
         self.rank, self.world_size = rank, world_size
         self.bodies, self.contacts, self.joints = bodies, contacts, joints
-        shards, self.island, self.shard_of_island = islands.shard_world(bodies, contacts, joints, world_size)
+        self.reshards = 0
+        self._partition(None)
+
+    def _partition(self, previous_owner):
+        shards, self.island, self.shard_of_island = islands.shard_world(self.bodies, self.contacts, self.joints, self.world_size, previous_owner)
         self.shards = shards
-        self.mine = shards[rank]
+        self.mine = shards[self.rank]
         # fixed-size exchange record: every rank contributes max_owned body records
         self.owned_ids = [sh.body_ids[sh.owned_body] for sh in shards]
         self.max_owned = max(1, max(len(x) for x in self.owned_ids))
+
+    def owner_of_body(self):
+        """shard that owns each body of the world under the current partition (-1: static or free -- replicated, owned by nobody)"""
+        owner = np.full(len(self.bodies), -1, dtype=np.int32)
+        for r, ids in enumerate(self.owned_ids):
+            owner[ids] = r
+        return owner
+
+    def joins_shards(self, body_a, body_b):
+        """Would a constraint between these two bodies connect islands that live on different ranks?"""
+        owner = self.owner_of_body()
+        a, b = int(owner[body_a]), int(owner[body_b])
+        return a >= 0 and b >= 0 and a != b
+
+    def reshard(self, contacts=None, joints=None, dist=None, torch=None, device="cpu"):
+        """The constraint graph changed -- the collision phase created or destroyed contacts, the same on every rank (it runs on the
+        poses every rank holds after the all-gather): islands may have merged or split.  `contacts` / `joints`: the whole world's new
+        arrays (None: unchanged), in which the solver state of the constraints that were there before (impulses, TGS_Sticky's friction
+        cache) may be stale -- it lives with the owner.  So, once:
+          1. every rank contributes the records of the constraints it owns (one all-gather of padded byte records each for contacts
+             and joints) and every rank ends with the whole world's solver state;
+          2. islands are found again; an island stays on the rank that owned most of its bodies (islands.sticky_partition), so two
+             islands that a created contact joined end up on ONE rank -- the one that held the larger --, everything else stays;
+          3. every rank extracts its new sub-world (pool order preserved: a sharded solve stays bit-identical to the whole-world solve).
+        No body state travels here: the per-step all-gather has already given every rank every body."""
+        previous = self.owner_of_body()
+        old = self.shards
+        if dist is not None and self.world_size > 1:
+            for r, rows in enumerate(_gather_rows(self.mine.contacts, self.world_size, dist, torch, device)):
+                self._take_contacts(old[r], rows)
+            for r, rows in enumerate(_gather_rows(self.mine.joints, self.world_size, dist, torch, device)):
+                self._take_joints(old[r], rows)
+        else:
+            self._take_contacts(self.mine, self.mine.contacts)
+            self._take_joints(self.mine, self.mine.joints)
+        # bodies: what this rank solved itself (a single process has no exchange to have done it)
+        o = self.mine.owned_body
+        self.bodies[self.mine.body_ids[o]] = self.mine.bodies[o]
+        if contacts is not None:
+            # the caller's array decides which slots are live and what their manifolds are; a slot that kept its pair keeps its solver state
+            same = (contacts["bodyA"] == self.contacts["bodyA"]) & (contacts["bodyB"] == self.contacts["bodyB"]) & (self.contacts["bodyA"] >= 0)
+            merged = contacts.copy()
+            for f in ("normalImpulse", "tangentImpulse", "frictionAnchorA", "frictionAnchorB", "frictionNormalA", "frictionNormalB"):
+                merged["points"][f][same] = self.contacts["points"][f][same]
+            merged["frictionPersisted"][same] = self.contacts["frictionPersisted"][same]
+            self.contacts = merged
+        if joints is not None:
+            self.joints = joints
+        self._partition(previous)
+        self.reshards += 1
+        return self.mine
+
+    def _take_contacts(self, shard, rows):
+        if len(rows):
+            ids = shard.contact_ids
+            keep_a, keep_b, keep_index = self.contacts["bodyA"][ids].copy(), self.contacts["bodyB"][ids].copy(), self.contacts["constraintIndex"][ids].copy()
+            self.contacts[ids] = rows
+            self.contacts["bodyA"][ids], self.contacts["bodyB"][ids], self.contacts["constraintIndex"][ids] = keep_a, keep_b, keep_index
+
+    def _take_joints(self, shard, rows):
+        if len(rows):
+            ids = shard.joint_ids
+            keep_a, keep_b = self.joints["bodyA"][ids].copy(), self.joints["bodyB"][ids].copy()
+            self.joints[ids] = rows
+            self.joints["bodyA"][ids], self.joints["bodyB"][ids] = keep_a, keep_b
 
     def pack_owned(self):
         """float32[max_owned, 9]: position, rot, linearVelocity, angularVelocity, deltaPosition of the
@@ -147,6 +233,39 @@ class ResidentShardedWorld:
     def world_poses(self):
         """float32[bodies of the whole world, 4] {position, rot}: the first half of world_bodies()."""
         return self.world_bodies()[:, 0:4]
+
+    def reshard(self, contacts=None, joints=None):
+        """ShardedWorld.reshard for the resident form: my shard's solver state comes down from the device first (bodies, impulses),
+        the whole world's body array is brought up to the last exchange, the constraint state is exchanged and the islands are
+        partitioned again (islands that did not change stay on their rank), and my NEW shard goes up (s2amd_upload).  Rare -- a
+        created contact that joins islands of two ranks, pairs that separated --, so it may cost a host round trip."""
+        sh = self.sw.mine
+        self.solver.synchronize()
+        self.solver.download(sh.bodies, sh.contacts, sh.joints)
+        if self.exchanged > 0:
+            g = self.world_bodies()
+            b = self.sw.bodies
+            b["position"], b["rot"], b["linearVelocity"], b["angularVelocity"] = g[:, 0:2], g[:, 2:4], g[:, 4:6], g[:, 6]
+        self.sw.reshard(contacts, joints, dist=self.dist, torch=self.torch, device="cuda" if (self.dist is not None and self.backend == "nccl") else "cpu")
+        sh = self.sw.mine
+        self.solver.upload(sh.bodies, sh.contacts, sh.joints)
+        self.body_slots = len(sh.bodies)
+        record = max(1, max(len(s.bodies) for s in self.sw.shards))
+        if record != self.record:
+            # the pose records follow the largest shard
+            self.record = record
+            if self.raw:
+                for p in self.pose_ptr:
+                    self.solver.device_free(p)
+                self.pose_ptr = [self.solver.device_alloc(self.record * 32) for _ in range(2)]
+            else:
+                torch = self.torch
+                self.pose = [torch.zeros((self.record, 8), dtype=torch.float32, device="cuda") for _ in range(2)]
+                self.pose_ptr = [t.data_ptr() for t in self.pose]
+                self.gathered = torch.zeros((self.sw.world_size * self.record, 8), dtype=torch.float32, device="cuda" if self.backend == "nccl" else "cpu")
+        self.gather_done = [None, None]
+        self.enqueued = self.exchanged = 0
+        self.last = None
 
     def close(self):
         if self.raw:

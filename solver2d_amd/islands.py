@@ -110,13 +110,40 @@ class Shard:
         self.owned_body = owned_body  # bool per shard body: movable body owned by this shard
 
 
-def shard_world(bodies, contacts, joints, n_shards):
-    """Split a world into n_shards sub-worlds along island boundaries."""
+def shard_world(bodies, contacts, joints, n_shards, previous_owner=None):
+    """Split a world into n_shards sub-worlds along island boundaries.
+
+    previous_owner (int per body, -1 = nobody): the shard that owned each body under the partition before the graph changed.  An
+    island then stays where most of its bodies were (ties: the lowest shard), so that a contact created between two islands moves
+    ONE of them -- the smaller -- and every island the change did not touch stays put; without it the islands are bin-packed afresh
+    (longest-processing-time by constraint count)."""
     island, n_islands = find_islands(bodies, contacts, joints)
     ci, ji = constraint_islands(bodies, contacts, joints, island)
     weights = np.bincount(ci[ci >= 0], minlength=n_islands) * 2 + np.bincount(ji[ji >= 0], minlength=n_islands)
-    shard_of_island = partition(weights, n_shards)
+    if previous_owner is None:
+        shard_of_island = partition(weights, n_shards)
+    else:
+        shard_of_island = sticky_partition(island, n_islands, weights, np.asarray(previous_owner), n_shards)
     return [extract(bodies, contacts, joints, island, ci, ji, shard_of_island, s) for s in range(n_shards)], island, shard_of_island
+
+
+def sticky_partition(island, n_islands, weights, previous_owner, n_shards):
+    """Shard per island: where most of its bodies were; islands of bodies nobody owned go to the least loaded shard (heaviest first)."""
+    shard = np.full(n_islands, -1, dtype=np.int32)
+    has = (island >= 0) & (previous_owner >= 0)
+    if has.any():
+        votes = np.zeros((n_islands, n_shards), dtype=np.int64)
+        np.add.at(votes, (island[has], previous_owner[has]), 1)
+        seen = votes.sum(axis=1) > 0
+        shard[seen] = np.argmax(votes[seen], axis=1).astype(np.int32)  # (argmax takes the lowest shard among equals)
+    load = np.zeros(n_shards, dtype=np.int64)
+    np.add.at(load, shard[shard >= 0], np.maximum(np.asarray(weights, dtype=np.int64)[shard >= 0], 1))
+    rest = np.flatnonzero(shard < 0)
+    for i in rest[np.lexsort((rest, -np.asarray(weights, dtype=np.int64)[rest]))]:
+        s = int(np.argmin(load))
+        shard[i] = s
+        load[s] += max(int(weights[i]), 1)
+    return shard
 
 
 def extract(bodies, contacts, joints, island, ci, ji, shard_of_island, s):

@@ -156,7 +156,7 @@ def world_chain_async(base, steps):
     live = np.flatnonzero(world["pairs"]["shapeA"] >= 0)
     seen = []
     with hip.Solver(0) as s:
-        for k, v in (("strip_min_bodies", 0), ("max_group_bodies", 96), ("strip_bodies", 24), ("strip_patience", 1), ("async_build_delay", 3)):
+        for k, v in (("strip_min_bodies", 0), ("max_group_bodies", 96), ("strip_bodies", 24), ("strip_patience", 1), ("async_build", 2), ("async_build_delay", 3)):
             s.set_option(k, v)
         s.world_upload(*[world[k] for k in keys])
         mine = []

@@ -1533,6 +1533,7 @@ struct StructureBuild
 
 	double t0, tPhase;
 	bool prepTimes; // S2AMD_DEBUG_PREP=1: where the host time of a structure build goes
+	double tSlots = 0, tColour = 0, tAppend = 0; // ... inside emitGroup, summed over the groups
 
 	StructureBuild(s2amdSolver* solver, int type, float scale)
 		: s(solver), solverType(type), stripScale(scale), cls(isPositionSolver(type) ? 1 : 0), needAdj(type == s2amd_solverJacobi),
@@ -2131,6 +2132,7 @@ struct StructureBuild
 	{
 		std::vector<int> ids, a, b, bodies, la, lb, pos, batchOffsets;
 		bool tail = false;
+		const double tg0 = prepTimes ? nowMs() : 0.0;
 		slots.begin();
 		for (int body : seedBodies)
 		{
@@ -2183,8 +2185,11 @@ struct StructureBuild
 		// other islands share its group (a world sharded over several GPUs packs them differently and must sweep the same).
 		const bool stripTable = &t == &s->hStripA || &t == &s->hStripB;
 		const int roundSlack = (stripTable && stripSlackWanted && jKs.empty()) ? 16 : 0;
+		const double tg1 = prepTimes ? nowMs() : 0.0;
 		colourPart(ids, la, lb, lconf, (int)bodies.size(), cs, batchOffsets, tail, &pos, (&t == &s->hGroups || &t == &s->hResident) ? 0 : 256, nullptr, 0, 0,
 				   false, roundSlack);
+		const double tg2 = prepTimes ? nowMs() : 0.0;
+		tSlots += tg1 - tg0, tColour += tg2 - tg1;
 		for (size_t i = 0; i < pos.size(); ++i)
 		{
 			cs.local.push_back(pos[i] >= 0 ? make_int2(la[(size_t)pos[i]], lb[(size_t)pos[i]]) : make_int2(0, 0));
@@ -2237,6 +2242,7 @@ struct StructureBuild
 		}
 		t.bodyOffsets.push_back((int)t.bodyIds.size());
 		t.maxBodies = std::max(t.maxBodies, (int)bodies.size());
+		tAppend += prepTimes ? nowMs() - tg2 : 0.0;
 	}
 
 	// does the greedy colouring of this group fit the resident kernel: at most 8 rounds of at most 512 constraints, no
@@ -2380,6 +2386,10 @@ struct StructureBuild
 			}
 		}
 
+		if (prepTimes)
+		{
+			fprintf(stderr, "[s2amd]   inside the groups: body slots %.3f ms, colouring %.3f ms, tables %.3f ms\n", tSlots, tColour, tAppend);
+		}
 		phase("colours, batches");
 	}
 
@@ -2493,8 +2503,9 @@ struct StructureBuild
 			rebuild = true;
 			return S2AMD_OK;
 		}
-		buildStripMirror();
 		phase("strip tables");
+		buildStripMirror();
+		phase("strip mirror");
 		return S2AMD_OK;
 	}
 
@@ -2681,7 +2692,9 @@ static int buildStructureWith(s2amdSolver* s, int solverType, float stripScale)
 	build.findIslands();
 	build.splitParts();
 	build.cutStrips();
+	build.phase("strip partition");
 	build.colourGlobalPart();
+	build.phase("global part");
 	build.emitIslandGroups();
 	build.emitStrips();
 	if ((rc = build.uploadTables()) != 0 || build.rebuild || (rc = build.buildStripTables()) != 0 || build.rebuild)

@@ -835,6 +835,7 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	{
 		s->optStripPatience = std::max(0, value);
 		s->stripPatienceNow = s->optStripPatience;
+		s->stripPatienceSet = true;
 	}
 	else if (strcmp(key, "stage_joints") == 0)
 	{

@@ -230,7 +230,17 @@ int asyncRequest(s2amdSolver* s, int solverType, bool search)
 		}
 	}
 	AsyncBuild* job = new AsyncBuild();
-	s2amdSolver* c = new s2amdSolver(*s);
+	// the copy: everything but the structure part as it is (what the host knows of the wire arrays, the options, the plan); of the
+	// structure part only what a build reads -- the graph as the structure knows it and the policies earlier builds have learnt.
+	// (A copy of the whole object, tables and placement mirrors included, cost the requesting step 5 ms at 140k contact slots.)
+	s2amdSolver* c = new s2amdSolver();
+	static_cast<SolverRest&>(*c) = static_cast<const SolverRest&>(*s);
+	c->hContactA = s->hContactA, c->hContactB = s->hContactB, c->hContactEdge = s->hContactEdge, c->hContactDead = s->hContactDead;
+	c->spareColours = s->spareColours, c->slackShift = s->slackShift, c->slackBumped = s->slackBumped, c->slackAtBuild = s->slackAtBuild;
+	c->slackPositions = s->slackPositions;
+	c->stripScaleFound = s->stripScaleFound, c->stripScaleFoundFor = s->stripScaleFoundFor, c->stripsJudgedForClass = s->stripsJudgedForClass;
+	c->stripsRejected = false, c->stripsHopeless = false, c->residentRejected = s->residentRejected;
+	c->layoutGeneration = s->layoutGeneration, c->structureGeneration = s->structureGeneration;
 	c->isClone = true;
 	c->async = nullptr;
 	c->worldResident = false; // (no device reads of the world's arrays from the worker: the shadows above are current)

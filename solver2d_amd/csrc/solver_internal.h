@@ -336,7 +336,7 @@ struct SolverStructure
 struct AsyncBuild;
 
 // ... and the rest: the device, the wire arrays and the world chain's arrays, what the host knows of them, the options, the plan.
-struct s2amdSolver : SolverStructure
+struct SolverRest
 {
 	int device = 0;
 	hipStream_t stream = nullptr;
@@ -431,6 +431,7 @@ struct s2amdSolver : SolverStructure
 	int graphAge = 0;		  // steps solved since the constraint graph last changed
 	int optStripPatience = 1; // steps of an unchanged graph before the (more expensive) strip structure is built
 	int stripPatienceNow = 1; // ... as it stands: doubled every time a strip structure died young (noteGraphChanged)
+	bool stripPatienceSet = false; // "strip_patience" was set by the caller (else a resident world builds its strips at once: stripPatienceBase)
 	int optStripsAnySolver = 0; // tests: strips for every solver and with joints (through the generic group interpreter)
 
 	StepPlan plan;
@@ -472,29 +473,43 @@ struct s2amdSolver : SolverStructure
 	float asyncWaitMs = 0.0f;
 };
 
+struct s2amdSolver : SolverStructure, SolverRest
+{
+};
+
 // The constraint graph changed (an upload, a manifold that gained or lost its points, a contact slot written): the
 // structure is rebuilt at the next step.  The strip structure costs several milliseconds of host time (more with
 // strip_retry), so a world whose graph keeps changing every few steps must not build it again and again: the patience
 // doubles whenever strips were in use for fewer than 32 steps, and returns to the option's value after a quiet spell.
 // (strip_patience 0 means "always build at once" and is left alone; a world of another size is a new world.)
 void asyncDrop(s2amdSolver* s);
+// Steps of an unchanged graph before the strip structure is built.  A one-off s2amd_solve should not pay milliseconds of host time for
+// strips it will use once: it waits a step ("strip_patience", default 1).  A RESIDENT world is stepped again and again: its strips are
+// built in the step that needs them (0) -- the colour batches in between cost a structure build of their own and ~0.5 ms per step --
+// unless the caller set the option; either way the wait doubles when strips die young (below).
+inline int stripPatienceBase(const s2amdSolver* s)
+{
+	return (s->worldResident && !s->stripPatienceSet) ? 0 : s->optStripPatience;
+}
+
 inline void noteGraphChanged(s2amdSolver* s, bool newWorld = false)
 {
 	asyncDrop(s); // (a build in flight was made for the graph as it was)
 	const bool stripsInUse = s->dStripA.view.groupCount > 0;
+	const int base = stripPatienceBase(s);
 	if (newWorld)
 	{
 		s->stripScaleFound = 0.0f;
 	}
-	if (newWorld || s->optStripPatience == 0)
+	if (newWorld || (s->optStripPatience == 0 && (s->stripPatienceSet || !s->worldResident)))
 	{
-		s->stripPatienceNow = s->optStripPatience;
+		s->stripPatienceNow = base; // (strip_patience 0 as an OPTION means "always at once", no backing off: tests)
 	}
 	else if (stripsInUse && s->stripInc.valid)
 	{
 		// strips that take created contacts in place (IncrementalStrips) die only of a contact that fits nowhere: they are worth
 		// building again at once unless this one lived for less than it cost (a strip build ~ 3 ms buys ~0.4 ms per step)
-		s->stripPatienceNow = s->graphAge < 8 ? std::min(std::max(2 * s->stripPatienceNow, 2), 32) : s->optStripPatience;
+		s->stripPatienceNow = s->graphAge < 8 ? std::min(std::max(2 * s->stripPatienceNow, 2), 32) : base;
 	}
 	else if (stripsInUse && s->graphAge < 32)
 	{
@@ -502,7 +517,7 @@ inline void noteGraphChanged(s2amdSolver* s, bool newWorld = false)
 	}
 	else if (s->graphAge >= 256)
 	{
-		s->stripPatienceNow = s->optStripPatience;
+		s->stripPatienceNow = base;
 	}
 	s->graphAge = 0;
 	s->stripsRejected = false;

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/r04d
 mkdir -p $OUT
 rm -f $OUT/summary.txt
-for opts in "" "--opt async_build=0" "--opt async_build=2"; do
+for opts in "" "--opt async_build=0" "--opt strip_patience=1"; do
   name=churn$(echo "$opts" | tr -dc 'a-z0-9_=' )
   timeout 600 python tools/churn_bench.py $opts > $OUT/$name.json 2> $OUT/$name.err
   python - $OUT/$name.json "$opts" <<'PY' | tee -a gpurun_out/r04d/summary.txt

@@ -483,13 +483,14 @@ struct s2amdSolver : SolverStructure, SolverRest
 // doubles whenever strips were in use for fewer than 32 steps, and returns to the option's value after a quiet spell.
 // (strip_patience 0 means "always build at once" and is left alone; a world of another size is a new world.)
 void asyncDrop(s2amdSolver* s);
-// Steps of an unchanged graph before the strip structure is built.  A one-off s2amd_solve should not pay milliseconds of host time for
-// strips it will use once: it waits a step ("strip_patience", default 1).  A RESIDENT world is stepped again and again: its strips are
-// built in the step that needs them (0) -- the colour batches in between cost a structure build of their own and ~0.5 ms per step --
-// unless the caller set the option; either way the wait doubles when strips die young (below).
+// Steps of an unchanged graph before the strip structure is built ("strip_patience", default 1: the step that finds the graph changed
+// runs on colour batches -- a cheaper build --, the strips come when the change has stayed alone); the wait doubles when strips die young (below).
 inline int stripPatienceBase(const s2amdSolver* s)
 {
-	return (s->worldResident && !s->stripPatienceSet) ? 0 : s->optStripPatience;
+	// (r4: "a resident world builds its strips in the step that needs them" -- patience 0 with the back-off below -- was measured on the
+	// wrecking-ball world and LOST: graph changes come in bursts, the strips built at the first one die with the second, the wait doubles:
+	// 151 instead of 201 of 240 steps on the persistent kernel.  And both routes of the drop-in must wait alike to sweep alike.)
+	return s->optStripPatience;
 }
 
 inline void noteGraphChanged(s2amdSolver* s, bool newWorld = false)
@@ -501,7 +502,7 @@ inline void noteGraphChanged(s2amdSolver* s, bool newWorld = false)
 	{
 		s->stripScaleFound = 0.0f;
 	}
-	if (newWorld || (s->optStripPatience == 0 && (s->stripPatienceSet || !s->worldResident)))
+	if (newWorld || s->optStripPatience == 0)
 	{
 		s->stripPatienceNow = base; // (strip_patience 0 as an OPTION means "always at once", no backing off: tests)
 	}

@@ -476,7 +476,6 @@ int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapa
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	s->shapeCapacity = shapeCapacity;
 	s->worldResident = true;
-	s->stripPatienceNow = stripPatienceBase(s); // (a resident world builds its strips in the step that needs them)
 	return S2AMD_OK;
 }
 

@@ -202,18 +202,21 @@ class Ranks:
         return float(t.item())
 
 
-def island_sharded_leg(ranks, islands, base, vel, pos, steps, warmup, graph=True, dump=None):
+def island_sharded_leg(ranks, islands, base, vel, pos, steps, warmup, graph=True, dump=None, weak=False):
     """BASELINE.json configs[4]: ONE world of `islands` base-`base` pyramids, islands sharded over the ranks, every shard
-    resident, one all-gather of pose records per step (ResidentShardedWorld).  Strong scaling."""
+    resident, one all-gather of pose records per step (ResidentShardedWorld).  Strong scaling.
+    weak: `islands` pyramids PER RANK instead (a world of islands x N, every rank building and owning its own -- the partition an
+    island-sharded world of that size would have): the curve that can be linear, beside the strong one that cannot (a rank with
+    fewer islands than CUs runs at one island's latency)."""
     from solver2d_amd import distributed as dsh
     world = synthetic.pyramid(base, count=islands)
     params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, vel, pos, True)
     sweeps = wire.solve_sweeps_per_step("TGS_Soft", vel, pos)
-    C_total = int((world[1]["pointCount"] > 0).sum())
-    sw = dsh.ShardedWorld(*world, rank=ranks.rank, world_size=ranks.world)
+    C_total = int((world[1]["pointCount"] > 0).sum()) * (ranks.world if weak else 1)
+    sw = dsh.ShardedWorld(*world, rank=0 if weak else ranks.rank, world_size=1 if weak else ranks.world)
     gpu = hip.Solver(ranks.device_index, graph=graph)
     gpu.set_option("async", 1)
-    rs = dsh.ResidentShardedWorld(sw, gpu, ranks.torch, dist=ranks.dist, backend=ranks.backend)
+    rs = dsh.ResidentShardedWorld(sw, gpu, ranks.torch, dist=ranks.dist, backend=ranks.backend, exchange_ranks=ranks.world)
     rs.run(params, warmup)
     ranks.barrier_sync(gpu)
     t0 = time.perf_counter()
@@ -233,12 +236,14 @@ def island_sharded_leg(ranks, islands, base, vel, pos, steps, warmup, graph=True
     algo = ALGO_BYTES_LDS_PATH * mine * sweeps
     achieved = algo / max(us * 1e-6, 1e-12) / 1e9
     out_line = {
-        "metric": "contact-constraints x iters/sec, %d independent base-%d pyramids TGS_Soft, islands sharded over the GPUs" % (islands, base),
+        "metric": "contact-constraints x iters/sec, %d independent base-%d pyramids TGS_Soft, islands sharded over the GPUs" % (islands * (ranks.world if weak else 1), base),
         "value": C_total * sweeps * steps / elapsed, "unit": "constraint-iters/s", "n_gpus": ranks.world, "steps": steps, "warmup": warmup,
-        "ms_per_step": 1e3 * elapsed / steps, "scaling": "strong",
+        "ms_per_step": 1e3 * elapsed / steps, "scaling": "weak" if weak else "strong",
         "config": {"workload": "one world of %d base-%d pyramids (%d bodies, %d two-point constraints, %d islands), s2_solverTGS_Soft %d/%d; "
-                               "islands bin-packed onto %d rank(s), shards resident, one all-gather of the per-island body arrays {position, rot, v, w} per step "
-                               "(%d bytes per rank)" % (islands, base, len(world[0]), C_total, islands, vel, pos, ranks.world, rs.record * 32),
+                               "islands %s %d rank(s), shards resident, one all-gather of the per-island body arrays {position, rot, v, w} per step "
+                               "(%d bytes per rank)" % (islands * (ranks.world if weak else 1), base, len(world[0]) * (ranks.world if weak else 1), C_total,
+                                                        islands * (ranks.world if weak else 1), vel, pos,
+                                                        "of every rank built and owned by it (%d per rank):" % islands if weak else "bin-packed onto", ranks.world, rs.record * 32),
                    "constraints": C_total, "constraints_this_rank": mine, "islands_this_rank": int((sw.shard_of_island == ranks.rank).sum()),
                    "solve_sweeps_per_step": sweeps, "kernel_launches_per_step": st["kernelLaunches"], "lds_groups_this_rank": st["groupCount"],
                    "device_ms_per_step": st["deviceMs"], "graph_replay": bool(st["graphReplayed"]), "trajectory": "consecutive resident steps (no restore)"},
@@ -263,6 +268,9 @@ def island_sharded_leg(ranks, islands, base, vel, pos, steps, warmup, graph=True
     line["issue"] = finish_issue(pmc_issue(ISLAND_KERNELS, "config5"), st["groupCount"]) if ranks.world == 1 and islands == 512 and base == 40 else None
     if line["issue"] is not None:
         line["issue"]["note"] = "512 workgroups of 512 threads on 256 CUs (two passes): the kernel is VALU-issue bound, not bandwidth bound"
+        # what bounds this kernel, as a fraction: the share of a SIMD's cycles in which it issues a VALU instruction
+        line["roofline"]["issue_frac"] = line["issue"]["valu_issue_frac_per_simd"]
+        line["roofline"]["bound_in_fact"] = "VALU issue (see `issue`); `frac` above is the contract's byte model over the kernel's time"
     return line
 
 
@@ -420,6 +428,7 @@ def main():
                     help="2 = BASELINE's headline (LargePyramid base-200, one island per GPU); 5 = configs[4]: 512 x base-40, islands sharded over "
                          "the GPUs, as the line itself")
     ap.add_argument("--islands", type=int, default=512)
+    ap.add_argument("--weak", action="store_true", help="--config 5: --islands pyramids PER GPU (weak scaling) instead of in all (strong scaling)")
     ap.add_argument("--island-base", type=int, default=40)
     ap.add_argument("--no-extras", action="store_true", help="only the headline line (no whole_step / configs / island_sharded objects)")
     ap.add_argument("--restore", action="store_true", help="copy the step-0 bodies back before every step (round 3's headline loop) instead of consecutive steps")
@@ -471,7 +480,7 @@ def main():
     if args.config == 5:
         # the island-sharded job as the line itself (strong scaling); the contract's keys, its own roofline
         line = island_sharded_leg(ranks, args.islands, args.island_base, args.vel_iters, args.pos_iters, args.steps, args.warmup,
-                                  graph=not args.no_graph, dump=os.environ.get("S2AMD_BENCH_DUMP"))
+                                  graph=not args.no_graph, dump=os.environ.get("S2AMD_BENCH_DUMP"), weak=args.weak)
         line.update({"higher_is_better": True, "vs_baseline": None, "dtype": "f32", "data": "synthetic", "ranks_seen": ranks_seen, "devices": devices})
         if rank == 0:
             print(json.dumps(line))
@@ -645,8 +654,12 @@ def main():
     if not args.no_extras:
         extra_steps = max(10, min(args.steps, 60))
         sharded = island_sharded_leg(ranks, args.islands, args.island_base, args.vel_iters, args.pos_iters, extra_steps, 5, graph=not args.no_graph)
+        # ... and with 512 islands PER GPU: the curve that can be linear (the strong one stops at one island's latency per rank)
+        weak = island_sharded_leg(ranks, args.islands, args.island_base, args.vel_iters, args.pos_iters, extra_steps, 5, graph=not args.no_graph, weak=True) if world > 1 else None
         if rank == 0:
             out["island_sharded"] = sharded
+            if weak is not None:
+                out["island_sharded_weak"] = weak
             if world == 1:
                 out["whole_step"] = whole_step_leg(ranks.device_index, args.base, args.vel_iters, args.pos_iters, 60, 240)
                 # SURVEY.md 8d's trajectory figure (settled world, stage 3 -> solve -> stage 4 every step): the honest whole-step number

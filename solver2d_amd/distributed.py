@@ -160,8 +160,11 @@ class ResidentShardedWorld:
     The host loop is software-pipelined like bench.py's replica loop: step s+1 is enqueued on the solver's stream BEFORE
     the host waits for the poses of step s and hands them to the collective, through two pose buffers."""
 
-    def __init__(self, sharded, solver, torch, dist=None, backend="nccl"):
+    def __init__(self, sharded, solver, torch, dist=None, backend="nccl", exchange_ranks=None):
+        """exchange_ranks: ranks that take part in the per-step all-gather when that is not the partition's own world size -- the
+        WEAK-scaling form, where every rank brings its own islands (a partition by construction) and `sharded` is its local world."""
         self.sw, self.solver, self.torch, self.dist, self.backend = sharded, solver, torch, dist, backend
+        self.exchange_ranks = exchange_ranks if exchange_ranks is not None else sharded.world_size
         sh = sharded.mine
         solver.upload(sh.bodies, sh.contacts, sh.joints)
         self.body_slots = len(sh.bodies)
@@ -174,7 +177,7 @@ class ResidentShardedWorld:
         else:
             self.pose = [torch.zeros((self.record, 8), dtype=torch.float32, device="cuda") for _ in range(2)]
             self.pose_ptr = [t.data_ptr() for t in self.pose]
-            self.gathered = torch.zeros((sharded.world_size * self.record, 8), dtype=torch.float32, device="cuda" if backend == "nccl" else "cpu")
+            self.gathered = torch.zeros((self.exchange_ranks * self.record, 8), dtype=torch.float32, device="cuda" if backend == "nccl" else "cpu")
         self.gather_done = [None, None]
         self.enqueued = 0
         self.exchanged = 0

@@ -165,7 +165,7 @@ struct WideSelf
 };
 // float4 records of dynamic LDS the kernel variant for this partition needs beside the bodies, the ops and its three fixed records
 // (parked rounds, staged positions, the warm start's term table); -1: no variant takes the partition
-int wideExtraRecords(const PersistView& pv, int selfContained, int bodyWarm);
+int wideExtraRecords(const PersistView& pv, int selfContained, int bodyWarm, int kind = SOFT_TGS);
 int wideBodyWarmVariant(const PersistView& pv); // the variant for this partition has the body-centric warm start
 // ... and the resident islands' step (strip_kernel.hip: launchIslandStep) for TGS_Soft with the current-anchor warm start
 // selfContained: the kernel also stages its bodies from the wire records and writes them back (no prologue / epilogue launch)
@@ -173,7 +173,9 @@ void launchWideIsland(hipStream_t s, const ContactView& c, const BodyView& g, co
 					  int maxRounds, s2amdContact* wire, s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart, const StepConsts& sc, float unpackH,
 					  int selfContained, const unsigned int* stepFailed, int allTwoPoints);
 // self != nullptr: the self-contained variant (the step is this one launch); pv.bodyWarm: the body-centric warm start
-void launchWideStep(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount,
+// kind: SOFT_TGS, SOFT_PGS (the two soft drivers whose constraint fits the 22-dword register record) or SOFT_FIXED (the same record plus
+// rA0 / rB0 in LDS)
+void launchWideStep(hipStream_t s, int kind, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount,
 					const WideSelf* self);
 
 // generic_kernel.hip: the persistent strip step as an op interpreter -- every solver family, joints included

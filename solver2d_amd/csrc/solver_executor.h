@@ -395,6 +395,10 @@ struct Executor
 		{
 			warm = kind == SOFT_FIXED ? WARM_FIXED : WARM_CURRENT;
 		}
+		if (widePlan(kind, warm))
+		{
+			return true; // (wide_kernel.hip keeps the seam constraints in registers: its own LDS budget, Executor::wideFits)
+		}
 		const bool narrow = kind == SOFT_TGS && warm == WARM_CURRENT;
 		const int records = (narrow ? s->persist.ldsRecords : s->persistRecordsWide) + 2 * (int)p.ops.size();
 		return records <= (160 * 1024) / 16;
@@ -429,13 +433,15 @@ struct Executor
 	// warm start on a partition with at most six interior colour batches per strip and two per seam.
 	bool widePlan(int kind, int warm) const
 	{
-		return s->optWide && kind == SOFT_TGS && warm == WARM_CURRENT && wideFits(false, false);
+		const bool current = (kind == SOFT_TGS || kind == SOFT_PGS) && warm == WARM_CURRENT;
+		const bool fixed = kind == SOFT_FIXED && warm == WARM_FIXED; // s2Solve_SoftStep: s2WarmStartContacts_Fixed
+		return s->optWide && (current || fixed) && wideFits(false, false, kind);
 	}
 
 	// the kernel variant for this partition with these two features: does its dynamic LDS fit?
-	bool wideFits(bool selfContained, bool bodyWarm) const
+	bool wideFits(bool selfContained, bool bodyWarm, int kind = SOFT_TGS) const
 	{
-		const int extra = wideExtraRecords(s->persist, selfContained ? 1 : 0, bodyWarm ? 1 : 0);
+		const int extra = wideExtraRecords(s->persist, selfContained ? 1 : 0, bodyWarm ? 1 : 0, kind);
 		return extra >= 0 && s->persist.bodyRecords + 3 + extra + 2 * s->persistOpCount <= (160 * 1024) / 16;
 	}
 
@@ -445,7 +451,7 @@ struct Executor
 	bool selfContainedStrips() const
 	{
 		int kind, warm;
-		return s->optSelfContainedStrips && s->dStripA.view.groupCount > 0 && persistPlan(kind, warm) && widePlan(kind, warm) && wideFits(true, false) && gatherIndex == nullptr && !msg &&
+		return s->optSelfContainedStrips && s->dStripA.view.groupCount > 0 && persistPlan(kind, warm) && kind == SOFT_TGS && widePlan(kind, warm) && wideFits(true, false) && gatherIndex == nullptr && !msg &&
 			   wireBodies() != nullptr && s->dGroups.view.groupCount == 0 && s->dResident.view.groupCount == 0 && s->looseBodies == 0 && !anyGlobalContacts() &&
 			   s->joints.globalCount == 0 && s->jv.count == 0 && s->cv.count == s->persistK1 - s->persistK0 && p.prepContacts == PREP_SOFT && p.storeKind == STORE_PLAIN;
 	}
@@ -664,8 +670,8 @@ struct Executor
 				self.wire = wireContacts(), self.wireBodies = wireBodies(), self.hostFlags = (const uint32_t*)s->dBodyFlags.p;
 				self.warmStart = p.sc.warmStart, self.gravityX = p.sc.gravityX, self.gravityY = p.sc.gravityY, self.unpackH = p.unpackH;
 			}
-			pv.bodyWarm = wideBodyWarm(selfContained) ? 1 : 0;
-			launchWideStep(st, s->cv, s->bv, s->leanA, pv, (const Op*)s->dPersistOps.p, s->persistOpCount, selfContained ? &self : nullptr);
+			pv.bodyWarm = (kind == SOFT_TGS && wideBodyWarm(selfContained)) ? 1 : 0;
+			launchWideStep(st, kind, s->cv, s->bv, s->leanA, pv, (const Op*)s->dPersistOps.p, s->persistOpCount, selfContained ? &self : nullptr);
 		}
 		else if (pv.pairLanes && s->optPairLanes)
 		{

@@ -1564,7 +1564,10 @@ struct StructureBuild
 	// base 200).  A width set by the caller ("strip_bodies") goes for every solver.
 	static int stripBodiesFor(const s2amdSolver* solver, int type)
 	{
-		if (solver->stripBodiesSet || !(type == s2amd_solverSoftStep || type == s2amd_solverPGS_Soft))
+		// (r4: s2Solve_PGS_Soft and s2Solve_SoftStep run on the 512-thread kernel too -- the same 22-dword constraint in registers, SoftStep's
+		// rA0 / rB0 beside it in LDS -- and take TGS_Soft's thin strips with them; with `wide` off, the 256-thread kernel and its few wide strips)
+		const bool ldsSeams = (type == s2amd_solverSoftStep || type == s2amd_solverPGS_Soft) && solver->optWide == 0;
+		if (solver->stripBodiesSet || !ldsSeams)
 		{
 			return solver->optStripBodies;
 		}

@@ -57,7 +57,10 @@ struct WideRegs
 	f2 imp[2];				   // {normal, tangent} impulse
 };
 
-S2_DEV WideRegs loadWide(const ContactView& c, int k, int ia, int ib)
+// KIND: SOFT_TGS (s2SolveContacts_TGS_Soft, solve_tgs_soft.c:17-135: anchors in the bodies' frames, turned and re-measured every sweep) or
+// SOFT_PGS (s2SolveContacts_PGS_Soft, solve_pgs_soft.c:16-125: the anchors rA0 / rB0 and the separation as s2PrepareContacts_Soft left them).
+// The record has the same 22 dwords either way: for SOFT_PGS lA / lB hold rA0 / rB0 (world orientation) and p0 the separation.
+template <int KIND> S2_DEV WideRegs loadWide(const ContactView& c, int k, int ia, int ib)
 {
 	WideRegs p;
 	const float4 nf = c.nf[k];
@@ -67,10 +70,12 @@ S2_DEV WideRegs loadWide(const ContactView& c, int k, int ia, int ib)
 #pragma unroll
 	for (int j = 0; j < 2; ++j)
 	{
-		const float4 a = c.anchor[j][k];
-		p.lA[j] = lo2(a), p.lB[j] = hi2(a);
+		const float4 a = KIND == SOFT_PGS ? c.r0[j][k] : c.anchor[j][k];
+		// (SOFT_PGS keeps perp(rA0) = (-y, x), the form the sweep multiplies with: nothing about the anchors is left to compute per
+		// sweep, and nothing loop-invariant for the compiler to hoist into registers the resident constraints need)
+		p.lA[j] = KIND == SOFT_PGS ? f2{-a.y, a.x} : lo2(a), p.lB[j] = KIND == SOFT_PGS ? f2{-a.w, a.z} : hi2(a);
 		const float4 par = c.param[j][k];
-		p.p0[j] = par.x, p.p1[j] = par.y, p.p2[j] = par.z;
+		p.p0[j] = KIND == SOFT_PGS ? par.w : par.x, p.p1[j] = par.y, p.p2[j] = par.z;
 		const float2 imp = c.impulse[j][k];
 		p.imp[j] = f2{imp.x, imp.y};
 	}
@@ -96,7 +101,7 @@ S2_DEV f2 rot2(f2 q, f2 qn, f2 l)
 #define S2_WIDE_PACKED_PREP 0
 #endif
 #if S2_WIDE_PACKED_WARM
-template <int POINTS> S2_DEV void warmWide(const WideRegs& p, float4* lvel, const float4* ldq, const float2* lmass, uint32_t salt)
+template <int KIND, int POINTS> S2_DEV void warmWide(const WideRegs& p, float4* lvel, const float4* ldq, const float2* lmass, uint32_t salt)
 {
 	const uint32_t idx = p.idx ^ salt;
 	const int ia = (int)(idx & 0x1fffu), ib = (int)((idx >> 13) & 0x1fffu);
@@ -134,7 +139,7 @@ template <int POINTS> S2_DEV void warmWide(const WideRegs& p, float4* lvel, cons
 	}
 }
 #else
-template <int POINTS> S2_DEV void warmWide(const WideRegs& p, float4* lvel, const float4* ldq, const float2* lmass, uint32_t salt)
+template <int KIND, int POINTS> S2_DEV void warmWide(const WideRegs& p, float4* lvel, const float4* ldq, const float2* lmass, uint32_t salt, const float4* arms = nullptr)
 {
 	const uint32_t idx = p.idx ^ salt;
 	const int ia = (int)(idx & 0x1fffu), ib = (int)((idx >> 13) & 0x1fffu);
@@ -153,7 +158,23 @@ template <int POINTS> S2_DEV void warmWide(const WideRegs& p, float4* lvel, cons
 	{
 		if (POINTS == 2 || j < pointCount)
 		{
-			const V2 rA = rotate(qA, asV2(p.lA[j])), rB = rotate(qB, asV2(p.lB[j]));
+			// (SOFT_PGS: the anchors in world orientation as s2PrepareContacts_Soft computed them -- rotate(q, local anchor) on the poses the
+			// warm start sees too, the same operation on the same operands: rA0 IS the current anchor)
+			V2 rA, rB;
+			if constexpr (KIND == SOFT_FIXED)
+			{
+				// s2WarmStartContacts_Fixed (solve_soft_step.c:20-64): rA0 / rB0, kept as perp in LDS (wideStepKernel: larms)
+				const float4 a = arms[j * S2_WIDE_THREADS];
+				rA = v2(a.y, -a.x), rB = v2(a.w, -a.z);
+			}
+			else if constexpr (KIND == SOFT_PGS)
+			{
+				rA = v2(p.lA[j].y, -p.lA[j].x), rB = v2(p.lB[j].y, -p.lB[j].x);
+			}
+			else
+			{
+				rA = rotate(qA, asV2(p.lA[j])), rB = rotate(qB, asV2(p.lB[j]));
+			}
 			const V2 P = add(mulSV(p.imp[j].x, normal), mulSV(p.imp[j].y, tangent));
 			wA -= mA.y * cross(rA, P);
 			vA = mulAdd(vA, -mA.x, P);
@@ -198,7 +219,7 @@ struct WidePrep
 	uint32_t soft; // bit j: point j takes the soft mass / impulse scales
 };
 
-template <int POINTS> S2_DEV WidePrep prepWide(const WideRegs& p, const float4* ldq, const float4* lcoef, float inv_h, int useBias, uint32_t salt)
+template <int KIND, int POINTS> S2_DEV WidePrep prepWide(const WideRegs& p, const float4* ldq, const float4* lcoef, float inv_h, int useBias, uint32_t salt, const float4* arms = nullptr)
 {
 	const uint32_t idx = p.idx ^ salt;
 	const int ia = (int)(idx & 0x1fffu), ib = (int)((idx >> 13) & 0x1fffu);
@@ -235,19 +256,30 @@ template <int POINTS> S2_DEV WidePrep prepWide(const WideRegs& p, const float4* 
 			const f2 sn = ds2 * n2;
 			const float s = (sn.x + sn.y) + p.p0[j];
 #else
-			const V2 rA = rotate(qA, asV2(p.lA[j])), rB = rotate(qB, asV2(p.lB[j]));
+			const V2 rA = KIND == SOFT_PGS ? v2(0.0f, 0.0f) : rotate(qA, asV2(p.lA[j])), rB = KIND == SOFT_PGS ? v2(0.0f, 0.0f) : rotate(qB, asV2(p.lB[j]));
 #if S2_WIDE_PACKED
-			pre.pA[j] = f2{-rA.y, rA.x}, pre.pB[j] = f2{-rB.y, rB.x};
+			if constexpr (KIND == SOFT_FIXED)
+			{
+				// s2SolveContacts_TGS_Fixed (solve_soft_step.c:66-177): the separation from the anchors as the bodies stand now (below),
+				// the impulses along rA0 / rB0 -- perp(rA0), perp(rB0) wait in LDS, the form the chain multiplies with
+				const float4 a = arms[j * S2_WIDE_THREADS];
+				pre.pA[j] = lo2(a), pre.pB[j] = hi2(a);
+			}
+			else
+			{
+				pre.pA[j] = KIND == SOFT_PGS ? p.lA[j] : f2{-rA.y, rA.x}, pre.pB[j] = KIND == SOFT_PGS ? p.lB[j] : f2{-rB.y, rB.x};
+			}
 #else
+			static_assert(KIND == SOFT_TGS, "SOFT_PGS / SOFT_FIXED keep the packed chain's anchors");
 			pre.rA[j] = rA, pre.rB[j] = rB;
 #endif
 			const V2 ds = add(sub(dcB, dcA), sub(rB, rA));
-			const float s = dot(ds, normal) + p.p0[j];
+			const float s = KIND == SOFT_PGS ? p.p0[j] : dot(ds, normal) + p.p0[j];
 #endif
 			// select form of: if (s > 0) bias = s * inv_h; else if (useBias) {bias = max(biasCoefficient * s, cap); ...}
 			const bool speculative = s > 0.0f;
 			const bool soft = !speculative && useBias != 0;
-			const float softBias = S2_MAXF(biasCoefficient * s, -S2_MAX_BAUMGARTE_VELOCITY);
+			const float softBias = S2_MAXF(biasCoefficient * s, KIND == SOFT_TGS ? -S2_MAX_BAUMGARTE_VELOCITY : -0.5f * S2_MAX_BAUMGARTE_VELOCITY);
 			pre.bias[j] = speculative ? s * inv_h : (soft ? softBias : 0.0f);
 			pre.soft |= soft ? 1u << j : 0u;
 		}
@@ -541,12 +573,14 @@ template <int POINTS> S2_DEV void warmTermsWide(const WideRegs& p, const float4*
 // RPH: interior records a lane keeps (colour batches / 2), SR: seam records a lane keeps, SL: seam rounds parked in LDS.
 // IL: interior rounds parked in LDS behind the 2 RPH a lane keeps (a strip that needs a seventh or eighth colour: a hub body inside it).
 // MODE: S2_WIDE_SELF | S2_WIDE_BODYWARM.
-template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideStepKernel(ContactView c, BodyView g, StripTableView ta, PersistView pv, const Op* ops, int opCount, WideSelf self)
+template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int KIND = SOFT_TGS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideStepKernel(ContactView c, BodyView g, StripTableView ta, PersistView pv, const Op* ops, int opCount, WideSelf self)
 {
 	extern __shared__ __attribute__((aligned(16))) float4 lds[];
 	constexpr bool SELF = (MODE & S2_WIDE_SELF) != 0;
 	constexpr bool BODYWARM = (MODE & S2_WIDE_BODYWARM) != 0;
 	static_assert(!BODYWARM || (SL == 0 && IL == 0), "the body-centric warm start keeps no terms for parked rounds");
+	static_assert(KIND == SOFT_TGS || MODE == 0, "the self-contained form and the body-centric warm start are s2Solve_TGS_Soft's");
+	static_assert(KIND != SOFT_FIXED || (SL == 0 && IL == 0), "s2Solve_SoftStep: the variants without parked rounds");
 	const int tid = (int)threadIdx.x;
 	const int half = tid >> 8, ht = tid & 255; // hand-offs: waves 0-3 serve the left neighbour, waves 4-7 the right
 	// stamps: (wall_clock64 << 4) | tag; tags: 0 start, 1 loaded, 2 body stage, 3 warm start, 4 interior rounds, 5 hand-off, 6 seam rounds, 7 end
@@ -646,6 +680,10 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0> __g
 	const int tw = pv.maxStripBodies; // (a multiple of 32: PersistView)
 	uint32_t* lmask = (uint32_t*)lextra;
 	float2* lt = (float2*)(lextra + (tw + 3) / 4);
+	// SOFT_FIXED: rA0 / rB0 of the constraints this lane holds, as {perp(rA0), perp(rB0)} per manifold point: [record][point][lane].
+	// (In registers they would be 8 more dwords for each of the five resident records: the 30-dword constraint that kept
+	// s2Solve_SoftStep on the 256-thread kernel through round 3.  They are read once per sweep, by the prep -- in lanes that wait.)
+	const float4* larms = lextra + tid;
 
 	// ---- loads ----
 	uint32_t id[S2_WIDE_BODY_CHUNKS];
@@ -774,7 +812,16 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0> __g
 		const int k = kOfSlot(s);
 		const int kc = k >= 0 ? k : 0;
 		const int2 lb = c.localBodies[kc];
-		rA[s] = loadWide(c, kc, lb.x, lb.y);
+		rA[s] = loadWide<KIND>(c, kc, lb.x, lb.y);
+		if constexpr (KIND == SOFT_FIXED)
+		{
+#pragma unroll
+			for (int j = 0; j < 2; ++j)
+			{
+				const float4 a = c.r0[j][kc];
+				lextra[(2 * s + j) * S2_WIDE_THREADS + tid] = make_float4(-a.y, a.x, -a.w, a.z);
+			}
+		}
 	}
 #pragma unroll
 	for (int i = 0; i < SR; ++i)
@@ -784,7 +831,16 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0> __g
 		const int kc = mine ? k : 0;
 		const int2 lb = c.localBodies[kc];
 		const int base = mine ? pd->remapBase[seam] : 0; // (a valid entry of the remap table either way)
-		rB[i] = loadWide(c, kc, pv.remap[base + (mine ? lb.x : 0)], pv.remap[base + (mine ? lb.y : 0)]);
+		rB[i] = loadWide<KIND>(c, kc, pv.remap[base + (mine ? lb.x : 0)], pv.remap[base + (mine ? lb.y : 0)]);
+		if constexpr (KIND == SOFT_FIXED)
+		{
+#pragma unroll
+			for (int j = 0; j < 2; ++j)
+			{
+				const float4 a = c.r0[j][kc];
+				lextra[(2 * (RPH + i) + j) * S2_WIDE_THREADS + tid] = make_float4(-a.y, a.x, -a.w, a.z);
+			}
+		}
 		seamMask |= mine ? 1u << i : 0u;
 	}
 #pragma unroll
@@ -795,7 +851,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0> __g
 		{
 			const int2 lb = c.localBodies[k];
 			parkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * sw, sw,
-					 loadWide(c, k, pv.remap[pd->remapBase[seam] + lb.x], pv.remap[pd->remapBase[seam] + lb.y]));
+					 loadWide<KIND>(c, k, pv.remap[pd->remapBase[seam] + lb.x], pv.remap[pd->remapBase[seam] + lb.y]));
 			seamMask |= 1u << i;
 		}
 	}
@@ -806,7 +862,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0> __g
 		if (k >= 0)
 		{
 			const int2 lb = c.localBodies[k];
-			parkWide(lparkedI + j * S2_WIDE_PARKED_RECORDS * iw, iw, loadWide(c, k, lb.x, lb.y));
+			parkWide(lparkedI + j * S2_WIDE_PARKED_RECORDS * iw, iw, loadWide<KIND>(c, k, lb.x, lb.y));
 		}
 	}
 	// bodies (+ their integrator constants) into LDS: own list, then this half's imports
@@ -1141,7 +1197,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0> __g
 				{
 					if ((i & 1) == half && kOfSlot(i >> 1) >= 0)
 					{
-						warmWide<POINTS>(rA[i >> 1], lvel, ldq, lmass, salt);
+						warmWide<KIND, POINTS>(rA[i >> 1], lvel, ldq, lmass, salt, larms + 2 * (i >> 1) * S2_WIDE_THREADS);
 					}
 					__syncthreads();
 				}
@@ -1153,7 +1209,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0> __g
 				{
 					if (kOfParked(j) >= 0)
 					{
-						warmWide<POINTS>(unparkWide(lparkedI + j * S2_WIDE_PARKED_RECORDS * iw, iw), lvel, ldq, lmass, salt);
+						warmWide<KIND, POINTS>(unparkWide(lparkedI + j * S2_WIDE_PARKED_RECORDS * iw, iw), lvel, ldq, lmass, salt);
 					}
 					__syncthreads();
 				}
@@ -1165,7 +1221,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0> __g
 				{
 					if ((seamMask >> i) & 1u)
 					{
-						warmWide<POINTS>(rB[i], lvel, ldq, lmass, salt);
+						warmWide<KIND, POINTS>(rB[i], lvel, ldq, lmass, salt, larms + 2 * (RPH + i) * S2_WIDE_THREADS);
 					}
 					__syncthreads();
 				}
@@ -1177,7 +1233,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0> __g
 				{
 					if ((seamMask >> i) & 1u)
 					{
-						warmWide<POINTS>(unparkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * sw, sw), lvel, ldq, lmass, salt);
+						warmWide<KIND, POINTS>(unparkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * sw, sw), lvel, ldq, lmass, salt);
 					}
 					__syncthreads();
 				}
@@ -1191,7 +1247,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0> __g
 			WidePrep pre;
 			if (half == 0 && kOfSlot(0) >= 0)
 			{
-				pre = prepWide<POINTS>(rA[0], ldq, lcoef, op.inv_h, op.useBias, salt);
+				pre = prepWide<KIND, POINTS>(rA[0], ldq, lcoef, op.inv_h, op.useBias, salt, larms);
 			}
 			// (the parked rounds ROUNDS .. RA-1 take part in the same schedule: their records come out of LDS for the prep and again for the chain)
 #pragma unroll
@@ -1222,12 +1278,12 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0> __g
 						{
 							if (kOfSlot((i + 1) >> 1) >= 0)
 							{
-								pre = prepWide<POINTS>(rA[(i + 1) >> 1 < RPH ? (i + 1) >> 1 : 0], ldq, lcoef, op.inv_h, op.useBias, salt);
+								pre = prepWide<KIND, POINTS>(rA[(i + 1) >> 1 < RPH ? (i + 1) >> 1 : 0], ldq, lcoef, op.inv_h, op.useBias, salt, larms + 2 * ((i + 1) >> 1) * S2_WIDE_THREADS);
 							}
 						}
 						else if (kOfParked(i + 1 - ROUNDS < IL ? i + 1 - ROUNDS : 0) >= 0)
 						{
-							pre = prepWide<POINTS>(unparkWide(lparkedI + (i + 1 - ROUNDS) * S2_WIDE_PARKED_RECORDS * iw, iw), ldq, lcoef, op.inv_h, op.useBias, salt);
+							pre = prepWide<KIND, POINTS>(unparkWide(lparkedI + (i + 1 - ROUNDS) * S2_WIDE_PARKED_RECORDS * iw, iw), ldq, lcoef, op.inv_h, op.useBias, salt);
 						}
 					}
 					__syncthreads();
@@ -1263,7 +1319,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0> __g
 			{
 				if ((seamMask >> i) & 1u)
 				{
-					preB[i] = prepWide<POINTS>(rB[i], ldq, lcoef, op.inv_h, op.useBias, salt);
+					preB[i] = prepWide<KIND, POINTS>(rB[i], ldq, lcoef, op.inv_h, op.useBias, salt, larms + 2 * (RPH + i) * S2_WIDE_THREADS);
 				}
 			}
 			// (... and of the parked seam rounds: their records come out of LDS for it, and again for the chain)
@@ -1273,7 +1329,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0> __g
 			{
 				if (S2_WIDE_PARKED_PREP_EARLY && ((seamMask >> i) & 1u))
 				{
-					preP[i - SR] = prepWide<POINTS>(unparkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * sw, sw), ldq, lcoef, op.inv_h, op.useBias, salt);
+					preP[i - SR] = prepWide<KIND, POINTS>(unparkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * sw, sw), ldq, lcoef, op.inv_h, op.useBias, salt);
 				}
 			}
 			int fail = 0;
@@ -1307,7 +1363,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0> __g
 						{
 							if (i >= 2)
 							{
-								const WidePrep late = prepWide<POINTS>(rB[i], ldq, lcoef, op.inv_h, op.useBias, salt);
+								const WidePrep late = prepWide<KIND, POINTS>(rB[i], ldq, lcoef, op.inv_h, op.useBias, salt, larms + 2 * (RPH + i) * S2_WIDE_THREADS);
 								chainWide<POINTS>(rB[i], late, lvel, lmass, lcoef, salt);
 							}
 							else
@@ -1342,7 +1398,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0> __g
 						}
 						else
 						{
-							const WidePrep late = prepWide<POINTS>(p, ldq, lcoef, op.inv_h, op.useBias, salt);
+							const WidePrep late = prepWide<KIND, POINTS>(p, ldq, lcoef, op.inv_h, op.useBias, salt);
 							chainWide<POINTS>(p, late, lvel, lmass, lcoef, salt);
 						}
 						slot[5 * sw] = make_float4(p.imp[0].x, p.imp[0].y, p.imp[1].x, p.imp[1].y);
@@ -1555,26 +1611,27 @@ template __global__ void wideStepKernel<2, 3, 2, 0, 0, 3>(ContactView, BodyView,
 // Eligibility (checked by the caller, solver_executor.h widePlan): TGS_Soft with the current-anchor warm start on a partition with
 // at most 6 interior colour batches per strip and 3 per seam, or 8 and 2 (pv.maxRoundsA, pv.maxSeamRounds): five or six resident
 // records per lane fit its 256 registers beside the round's working set, seven do not (measured: 160 spilled registers).
-template <int RPH, int SR, int SL, int IL, int MODE>
+template <int RPH, int SR, int SL, int IL, int MODE, int KIND = SOFT_TGS>
 static void launchWideMode(hipStream_t s, dim3 grid, size_t lds, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount,
 						   const WideSelf& self)
 {
 	const dim3 block(S2_WIDE_THREADS);
 	if (pv.allTwoPoints)
 	{
-		wideStepKernel<2, RPH, SR, SL, IL, MODE><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount, self);
+		wideStepKernel<2, RPH, SR, SL, IL, MODE, KIND><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount, self);
 	}
 	else
 	{
-		wideStepKernel<0, RPH, SR, SL, IL, MODE><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount, self);
+		wideStepKernel<0, RPH, SR, SL, IL, MODE, KIND><<<grid, block, lds, s>>>(c, g, a, pv, ops, opCount, self);
 	}
 }
 
 // dynamic LDS beside the bodies, the ops and the three fixed records: parked rounds, the staged positions (self-contained), the
 // round masks and the term table of the body-centric warm start
-static size_t wideExtraLds(const PersistView& pv, int RPH, int SR, int SL, int IL, bool selfContained, bool bodyWarm)
+static size_t wideExtraLds(const PersistView& pv, int RPH, int SR, int SL, int IL, bool selfContained, bool bodyWarm, bool fixedArms = false)
 {
 	size_t records = (size_t)S2_WIDE_PARKED_RECORDS * ((size_t)SL * pv.parkSeamWidth + (size_t)IL * pv.parkInteriorWidth);
+	records += fixedArms ? (size_t)2 * (RPH + SR) * S2_WIDE_THREADS : 0; // SOFT_FIXED: {perp(rA0), perp(rB0)} per record, point and lane
 	records += selfContained ? (size_t)(pv.maxStaged + 1) / 2 : 0;
 	if (bodyWarm)
 	{
@@ -1586,8 +1643,27 @@ static size_t wideExtraLds(const PersistView& pv, int RPH, int SR, int SL, int I
 
 template <int RPH, int SR, int SL = 0, int IL = 0>
 static void launchWide(hipStream_t s, dim3 grid, size_t lds, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount,
-					   const WideSelf* self)
+					   const WideSelf* self, int kind)
 {
+	if (kind == SOFT_FIXED)
+	{
+		// s2Solve_SoftStep: the plain form of the variants without parked rounds (wideVariant)
+		if constexpr (SL == 0 && IL == 0)
+		{
+			const WideSelf none{};
+			lds += wideExtraLds(pv, RPH, SR, SL, IL, false, false, true);
+			launchWideMode<RPH, SR, SL, IL, 0, SOFT_FIXED>(s, grid, lds, c, g, a, pv, ops, opCount, none);
+		}
+		return;
+	}
+	if (kind == SOFT_PGS)
+	{
+		// s2Solve_PGS_Soft: the plain form only (prologue and epilogue launches, the coloured warm start)
+		const WideSelf none{};
+		lds += wideExtraLds(pv, RPH, SR, SL, IL, false, false);
+		launchWideMode<RPH, SR, SL, IL, 0, SOFT_PGS>(s, grid, lds, c, g, a, pv, ops, opCount, none);
+		return;
+	}
 	const bool selfContained = self != nullptr;
 	const bool bodyWarm = SL == 0 && IL == 0 && pv.bodyWarm != 0;
 	lds += wideExtraLds(pv, RPH, SR, SL, IL, selfContained, bodyWarm);
@@ -1646,13 +1722,17 @@ static int wideVariant(const PersistView& pv)
 
 // records of dynamic LDS the variant for this partition needs beside the bodies, the ops and the three fixed records; -1: no variant
 // takes that partition (Executor::widePlan)
-int wideExtraRecords(const PersistView& pv, int selfContained, int bodyWarm)
+int wideExtraRecords(const PersistView& pv, int selfContained, int bodyWarm, int kind)
 {
 	static const int shape[5][4] = {{3, 2, 0, 0}, {3, 3, 0, 0}, {4, 2, 0, 0}, {3, 2, 2, 0}, {3, 2, 2, 2}};
 	const int v = wideVariant(pv);
-	if (v < 0)
+	if (v < 0 || (kind == SOFT_FIXED && v > 2))
 	{
 		return -1;
+	}
+	if (kind == SOFT_FIXED)
+	{
+		return (int)(wideExtraLds(pv, shape[v][0], shape[v][1], 0, 0, false, false, true) / sizeof(float4));
 	}
 	const bool warm = bodyWarm != 0 && shape[v][2] == 0 && shape[v][3] == 0;
 	return (int)(wideExtraLds(pv, shape[v][0], shape[v][1], shape[v][2], shape[v][3], selfContained != 0, warm) / sizeof(float4));
@@ -1665,26 +1745,26 @@ int wideBodyWarmVariant(const PersistView& pv)
 	return v >= 0 && v <= 2 ? 1 : 0;
 }
 
-void launchWideStep(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount, const WideSelf* self)
+void launchWideStep(hipStream_t s, int kind, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount, const WideSelf* self)
 {
 	const dim3 grid((unsigned)a.groupCount);
 	const size_t lds = (size_t)(pv.bodyRecords + 3) * sizeof(float4) + (size_t)opCount * sizeof(Op);
 	switch (wideVariant(pv))
 	{
 		case 0:
-			launchWide<3, 2>(s, grid, lds, c, g, a, pv, ops, opCount, self);
+			launchWide<3, 2>(s, grid, lds, c, g, a, pv, ops, opCount, self, kind);
 			break;
 		case 1:
-			launchWide<3, 3>(s, grid, lds, c, g, a, pv, ops, opCount, self);
+			launchWide<3, 3>(s, grid, lds, c, g, a, pv, ops, opCount, self, kind);
 			break;
 		case 2:
-			launchWide<4, 2>(s, grid, lds, c, g, a, pv, ops, opCount, self);
+			launchWide<4, 2>(s, grid, lds, c, g, a, pv, ops, opCount, self, kind);
 			break;
 		case 3:
-			launchWide<3, 2, 2>(s, grid, lds, c, g, a, pv, ops, opCount, self);
+			launchWide<3, 2, 2>(s, grid, lds, c, g, a, pv, ops, opCount, self, kind);
 			break;
 		case 4:
-			launchWide<3, 2, 2, 2>(s, grid, lds, c, g, a, pv, ops, opCount, self);
+			launchWide<3, 2, 2, 2>(s, grid, lds, c, g, a, pv, ops, opCount, self, kind);
 			break;
 		default:
 			break;
@@ -1899,7 +1979,7 @@ __global__ __launch_bounds__(S2_WIDE_THREADS) void wideIslandKernel(ContactView 
 				{
 					if (kOfRound(i) >= 0)
 					{
-						warmWide<POINTS>(rA[i], lvel, ldq, lmass, salt);
+						warmWide<SOFT_TGS, POINTS>(rA[i], lvel, ldq, lmass, salt);
 					}
 					__syncthreads();
 				}
@@ -1914,7 +1994,7 @@ __global__ __launch_bounds__(S2_WIDE_THREADS) void wideIslandKernel(ContactView 
 				{
 					if (kOfRound(i) >= 0)
 					{
-						const WidePrep pre = prepWide<POINTS>(rA[i], ldq, lcoef, op.inv_h, op.useBias, salt);
+						const WidePrep pre = prepWide<SOFT_TGS, POINTS>(rA[i], ldq, lcoef, op.inv_h, op.useBias, salt);
 						chainWide<POINTS>(rA[i], pre, lvel, lmass, lcoef, salt);
 					}
 					__syncthreads();
@@ -2035,6 +2115,26 @@ int wideKernelSetup()
 						   (const void*)wideStepKernel<2, 3, 2, 2, 2, 0>, (const void*)wideStepKernel<0, 3, 2, 2, 0, 1>, (const void*)wideStepKernel<2, 3, 2, 2, 0, 1>,
 						   (const void*)wideStepKernel<0, 3, 2, 2, 2, 1>, (const void*)wideStepKernel<2, 3, 2, 2, 2, 1>};
 #undef S2_WIDE_MODES
+	const void* pgs[] = {(const void*)wideStepKernel<0, 3, 2, 0, 0, 0, SOFT_PGS>, (const void*)wideStepKernel<2, 3, 2, 0, 0, 0, SOFT_PGS>, (const void*)wideStepKernel<0, 3, 3, 0, 0, 0, SOFT_PGS>,
+						 (const void*)wideStepKernel<2, 3, 3, 0, 0, 0, SOFT_PGS>, (const void*)wideStepKernel<0, 4, 2, 0, 0, 0, SOFT_PGS>, (const void*)wideStepKernel<2, 4, 2, 0, 0, 0, SOFT_PGS>,
+						 (const void*)wideStepKernel<0, 3, 2, 2, 0, 0, SOFT_PGS>, (const void*)wideStepKernel<2, 3, 2, 2, 0, 0, SOFT_PGS>, (const void*)wideStepKernel<0, 3, 2, 2, 2, 0, SOFT_PGS>,
+						 (const void*)wideStepKernel<2, 3, 2, 2, 2, 0, SOFT_PGS>};
+	const void* fixed[] = {(const void*)wideStepKernel<0, 3, 2, 0, 0, 0, SOFT_FIXED>, (const void*)wideStepKernel<2, 3, 2, 0, 0, 0, SOFT_FIXED>, (const void*)wideStepKernel<0, 3, 3, 0, 0, 0, SOFT_FIXED>,
+						   (const void*)wideStepKernel<2, 3, 3, 0, 0, 0, SOFT_FIXED>, (const void*)wideStepKernel<0, 4, 2, 0, 0, 0, SOFT_FIXED>, (const void*)wideStepKernel<2, 4, 2, 0, 0, 0, SOFT_FIXED>};
+	for (const void* f : fixed)
+	{
+		if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+		{
+			return 1;
+		}
+	}
+	for (const void* f : pgs)
+	{
+		if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+		{
+			return 1;
+		}
+	}
 	for (const void* f : steps)
 	{
 		hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -585,7 +585,7 @@ def test_strip_patience_backs_off_when_the_graph_keeps_changing(slack):
 @pytest.mark.parametrize("solver_name", ["TGS_Soft", "SoftStep", "PGS_Soft"])
 def test_persistent_step_kernels_agree(solver_name, mode):
     """The three persistent step kernels on the same tables, in the same sweep order, to the same bits as the oracle:
-    wide_kernel.hip (512 threads per strip, TGS_Soft only), pair_kernel.hip (lanes 2c / 2c+1 are body A's / body B's side of
+    wide_kernel.hip (512 threads per strip: TGS_Soft and, since round 4, PGS_Soft and SoftStep), pair_kernel.hip (lanes 2c / 2c+1 are body A's / body B's side of
     constraint c, differences cross as DPP operands) and strip_kernel.hip (256 threads, one lane per constraint)."""
     vel, pos = common.DEFAULT_ITERS[solver_name]
     pre = synthetic.pyramid(100)
@@ -598,7 +598,7 @@ def test_persistent_step_kernels_agree(solver_name, mode):
             params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
             state = gpu_vs_oracle(s, params, state, "pyramid100/%s %s step %d" % (solver_name, mode, step))
         st = s.stats()
-        expect = {"wide": 2 if solver_name == "TGS_Soft" else 0, "pair": 1, "one": 0}[mode]
+        expect = {"wide": 2, "pair": 1, "one": 0}[mode]
         assert st["persistent"] == 1 and st["pairLanes"] == expect, st
 
 
@@ -615,3 +615,93 @@ def test_persistent_step_kernels_iteration_shapes_and_cold_start(iters, warm, mo
             params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, iters[0], iters[1], warm)
             state = gpu_vs_oracle(s, params, state, "%s %s warm=%s step %d" % (mode, iters, warm, step))
         assert s.stats()["pairLanes"] == (2 if mode == "wide" else 1)
+
+
+@pytest.mark.parametrize("iters,warm", [((4, 2), True), ((3, 0), True), ((1, 1), False), ((8, 4), False)])
+@pytest.mark.parametrize("base", [100, 72])
+def test_pgs_soft_on_the_wide_kernel(base, iters, warm):
+    """s2Solve_PGS_Soft (solve_pgs_soft.c:127-245) on the 512-thread strip kernel: the 22-dword record holds rA0 / rB0 (as perp, the form
+    the sweep multiplies with) and the separation of s2PrepareContacts_Soft instead of the local anchors and the adjusted separation;
+    iteration shapes, cold start, a pyramid whose strips are few."""
+    pre = synthetic.pyramid(base)
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
+        state = common.copy3(pre)
+        for step in range(4):
+            params = wire.StepParams.make("PGS_Soft", 1.0 / 60.0, iters[0], iters[1], warm)
+            state = gpu_vs_oracle(s, params, state, "PGS_Soft wide base %d %s warm=%s step %d" % (base, iters, warm, step))
+        st = s.stats()
+        if base >= 100:  # (the smaller pyramid takes whatever the structure chooses for it: the parity above is the test)
+            assert st["persistent"] == 1 and st["pairLanes"] == 2, {k: st[k] for k in ("persistent", "pairLanes", "stripCount", "groupCount")}
+
+
+def test_pgs_soft_wide_kernel_takes_single_point_and_pointless_manifolds():
+    """The general (POINTS == 0) variant: manifolds that lose one point or both and get them back, strips kept."""
+    pre = synthetic.pyramid(100)
+    params = wire.StepParams.make("PGS_Soft", 1.0 / 60.0, 4, 2, True)
+    rng = np.random.default_rng(5)
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
+        state = gpu_vs_oracle(s, params, common.copy3(pre), "PGS_Soft flip warm-up 0")
+        state = gpu_vs_oracle(s, params, state, "PGS_Soft flip warm-up 1")
+        full = state[1]["pointCount"].copy()
+        for step in range(4):
+            off = rng.choice(len(full), size=30 + 20 * step, replace=False)
+            state[1]["pointCount"][:] = full
+            state[1]["pointCount"][off] = 0
+            one = rng.choice(np.setdiff1d(np.arange(len(full)), off), size=25, replace=False)
+            state[1]["pointCount"][one] = 1
+            state = gpu_vs_oracle_loose(s, params, state, "PGS_Soft flip step %d" % step)
+            st = s.stats()
+            assert st["persistent"] == 1 and st["pairLanes"] == 2 and st["stripCount"] > 1, st
+
+
+@pytest.mark.parametrize("iters,warm", [((8, 4), True), ((3, 0), True), ((1, 1), False), ((5, 2), False)])
+@pytest.mark.parametrize("base", [100, 72])
+def test_softstep_on_the_wide_kernel(base, iters, warm):
+    """s2Solve_SoftStep (solve_soft_step.c:182-310) on the 512-thread strip kernel: the TGS_Soft record in registers (the separation is
+    measured from the anchors as the bodies stand), rA0 / rB0 -- what s2WarmStartContacts_Fixed and s2SolveContacts_TGS_Fixed push
+    along -- in LDS; a warm start in every substep."""
+    pre = synthetic.pyramid(base)
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
+        state = common.copy3(pre)
+        for step in range(4):
+            params = wire.StepParams.make("SoftStep", 1.0 / 60.0, iters[0], iters[1], warm)
+            state = gpu_vs_oracle(s, params, state, "SoftStep wide base %d %s warm=%s step %d" % (base, iters, warm, step))
+        st = s.stats()
+        if base >= 100:
+            assert st["persistent"] == 1 and st["pairLanes"] == 2, {k: st[k] for k in ("persistent", "pairLanes", "stripCount", "groupCount")}
+
+
+def test_softstep_wide_kernel_takes_single_point_and_pointless_manifolds():
+    pre = synthetic.pyramid(100)
+    params = wire.StepParams.make("SoftStep", 1.0 / 60.0, 8, 4, True)
+    rng = np.random.default_rng(6)
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
+        state = gpu_vs_oracle(s, params, common.copy3(pre), "SoftStep flip warm-up 0")
+        state = gpu_vs_oracle(s, params, state, "SoftStep flip warm-up 1")
+        full = state[1]["pointCount"].copy()
+        for step in range(4):
+            off = rng.choice(len(full), size=30 + 20 * step, replace=False)
+            state[1]["pointCount"][:] = full
+            state[1]["pointCount"][off] = 0
+            one = rng.choice(np.setdiff1d(np.arange(len(full)), off), size=25, replace=False)
+            state[1]["pointCount"][one] = 1
+            state = gpu_vs_oracle_loose(s, params, state, "SoftStep flip step %d" % step)
+            st = s.stats()
+            assert st["persistent"] == 1 and st["pairLanes"] == 2 and st["stripCount"] > 1, st
+
+
+def test_softstep_base_200_on_the_wide_kernel():
+    """BASELINE config 2's world under s2Solve_SoftStep: 99 thin strips, rA0 / rB0 of five records per lane in LDS (80 KB)."""
+    pre = synthetic.pyramid(200)
+    params = wire.StepParams.make("SoftStep", 1.0 / 60.0, 8, 4, True)
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
+        state = common.copy3(pre)
+        for step in range(3):
+            state = gpu_vs_oracle(s, params, state, "SoftStep base 200 step %d" % step)
+        st = s.stats()
+        assert st["persistent"] == 1 and st["pairLanes"] == 2 and st["kernelLaunches"] <= 3, st

@@ -705,3 +705,28 @@ def test_softstep_base_200_on_the_wide_kernel():
             state = gpu_vs_oracle(s, params, state, "SoftStep base 200 step %d" % step)
         st = s.stats()
         assert st["persistent"] == 1 and st["pairLanes"] == 2 and st["kernelLaunches"] <= 3, st
+
+
+@pytest.mark.parametrize("solver_name", ["SoftStep", "PGS_Soft"])
+def test_soft_solvers_on_partitions_that_need_parked_rounds(solver_name):
+    """The wide kernel's parked variants (persist_debug 16 forces them): PGS_Soft has them; SoftStep does not (rA0 / rB0 of parked
+    records have no room in LDS) and takes the 256-thread kernel on the same thin strips -- either way one persistent launch, same bits
+    as the oracle and as the run without parking."""
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    pre = synthetic.pyramid(100)
+    params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+    results = []
+    for park in (0, 16):
+        with hip.Solver(0) as s:
+            s.set_option("strip_patience", 0)
+            s.set_option("persist_debug", park)
+            state = common.copy3(pre)
+            for step in range(3):
+                state = gpu_vs_oracle(s, params, state, "%s parked=%d step %d" % (solver_name, park, step))
+            st = s.stats()
+            assert st["persistent"] == 1, st
+            assert st["pairLanes"] == (2 if (park == 0 or solver_name == "PGS_Soft") else st["pairLanes"]), st
+            if park and solver_name == "SoftStep":
+                assert st["pairLanes"] != 2, st
+            results.append(state)
+    common.compare_exact(results[0], results[1], "parked rounds vs registers")

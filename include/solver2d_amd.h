@@ -169,6 +169,9 @@ typedef struct s2amdStepStats
 	int32_t asyncBuildsRequested; /* (API 3) structure builds handed to the worker thread since s2amd_create (world chain: the strip structure, the strip-width search) */
 	int32_t asyncBuildsAdopted;   /* (API 3) ... whose result replaced the live structure (the others were overtaken by the graph) */
 	float asyncWaitMs;            /* (API 3) time the caller spent waiting for a worker that was not done when its build fell due, since s2amd_create */
+	int32_t bodiesAdopted;        /* (API 3) bodies without constraints that moved to the strip of the body they first touched (no build), in the structure in use */
+	int32_t seamBodiesAdded;      /* (API 3) bodies a seam between two strips came to carry after the build (one more export / import of its strips) */
+	int32_t roundsOpened;         /* (API 3) spare colour rounds of strips and seams opened for created contacts */
 } s2amdStepStats;
 
 typedef struct s2amdSolver s2amdSolver;
@@ -408,6 +411,12 @@ int s2amd_get_contact_order(s2amdSolver* solver, int32_t* order, int32_t orderCa
 int s2amd_get_joint_order(s2amdSolver* solver, int32_t* order, int32_t orderCapacity, int32_t* colorOffsets,
 						  int32_t colorCapacity, int32_t* jointCount, int32_t* colorCount);
 int s2amd_get_stats(s2amdSolver* solver, s2amdStepStats* stats);
+/* (API 3) Which strip -- which workgroup of the persistent step kernel -- owns each body in the structure in use, and which bodies the
+ * seam between strips i and i + 1 carries: ownerStrip[body] = strip or -1 (a static body, a body of an LDS group or of the global part;
+ * every entry -1 when the structure has no strips or keeps no picture of them), onSeam[body] = i when the seam i | i + 1 exchanges the
+ * body every sweep, else -1.  Either array may be NULL; capacity = entries each can hold (>= the body capacity of the world).
+ * *stripCount = number of strips.  Tests use it to build contacts whose place in the structure they know. */
+int s2amd_get_strip_owners(s2amdSolver* solver, int32_t* ownerStrip, int32_t* onSeam, int32_t capacity, int32_t* stripCount);
 /* Live timing of the dominant kernel on the solver's own stream: the first contact solve sweep of
  * the step plan (all its colour-batch launches) is enqueued `repeats` times back to back in one
  * hipGraph and bracketed by a HIP event pair; *usPerLaunch = elapsed / launches, i.e. the time one

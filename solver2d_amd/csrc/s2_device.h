@@ -512,6 +512,7 @@ struct PersistView
 	int seamRegs;	  // no seam has more than two colour batches: the seam constraints stay in registers (SEAMREG variant)
 	int maxRoundsA, maxSeamRounds; // the most interior colour batches of a strip / colour batches of a seam
 	int pairLanes;	  // the partition fits pair_kernel.hip: pairStepKernel (<= 6 interior batches per strip, <= 2 per seam)
+	int wideOnly;	  // (host) a spare round beyond those opened since the build: only wide_kernel.hip's budgets were kept up to date (IncrementalStrips)
 	int ldsRecords;
 	int parkSeamWidth, parkInteriorWidth; // wide_kernel.hip: lanes that hold a record in a parked seam round (rounds 3-4) / interior round (7-8), >= 64
 	int bodyRecords; // ... of them the staged bodies alone (wide_kernel.hip keeps no seam constraint in the kernel-independent LDS budget)

@@ -485,6 +485,54 @@ int s2amd_get_joint_order(s2amdSolver* s, int32_t* order, int32_t orderCapacity,
 	return copyOrder(s->joints.order, s->joints.colorOffsets, order, orderCapacity, colorOffsets, colorCapacity, jointCount, colorCount);
 }
 
+int s2amd_get_strip_owners(s2amdSolver* s, int32_t* ownerStrip, int32_t* onSeam, int32_t capacity, int32_t* stripCount)
+{
+	if (!s)
+	{
+		return fail(S2AMD_E_INVALID, "null solver");
+	}
+	const IncrementalStrips& m = s->stripInc;
+	const int nb = s->bodyCapacity;
+	if ((ownerStrip || onSeam) && capacity < nb)
+	{
+		return fail(S2AMD_E_CAPACITY, "strip owner buffer too small");
+	}
+	if (stripCount)
+	{
+		*stripCount = m.valid ? (int)m.stripBodyCount.size() : 0;
+	}
+	for (int i = 0; i < nb; ++i)
+	{
+		if (ownerStrip)
+		{
+			ownerStrip[i] = (m.valid && i < (int)m.ownerStrip.size()) ? m.ownerStrip[(size_t)i] : -1;
+		}
+		if (onSeam)
+		{
+			onSeam[i] = -1;
+		}
+	}
+	if (onSeam && m.valid)
+	{
+		for (size_t sm = 0; sm < m.seamGroupOf.size(); ++sm)
+		{
+			const int g = m.seamGroupOf[sm];
+			if (g < 0)
+			{
+				continue;
+			}
+			for (const auto& kv : m.seamSlot[(size_t)g])
+			{
+				if (kv.first >= 0 && kv.first < nb && m.ownerStrip[(size_t)kv.first] >= 0)
+				{
+					onSeam[kv.first] = (int)sm;
+				}
+			}
+		}
+	}
+	return S2AMD_OK;
+}
+
 int s2amd_get_stats(s2amdSolver* s, s2amdStepStats* stats)
 {
 	if (!s || !stats)
@@ -836,6 +884,10 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 		s->optStripPatience = std::max(0, value);
 		s->stripPatienceNow = s->optStripPatience;
 		s->stripPatienceSet = true;
+	}
+	else if (strcmp(key, "strip_adopt") == 0)
+	{
+		s->optStripAdopt = value != 0; // a constraint-free body moves to the strip of the body it first touches (IncrementalStrips)
 	}
 	else if (strcmp(key, "stage_joints") == 0)
 	{

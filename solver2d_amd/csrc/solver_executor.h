@@ -399,6 +399,10 @@ struct Executor
 		{
 			return true; // (wide_kernel.hip keeps the seam constraints in registers: its own LDS budget, Executor::wideFits)
 		}
+		if (s->persist.wideOnly)
+		{
+			return false; // (rounds opened since the build that only that kernel's tables and budgets know: IncrementalStrips)
+		}
 		const bool narrow = kind == SOFT_TGS && warm == WARM_CURRENT;
 		const int records = (narrow ? s->persist.ldsRecords : s->persistRecordsWide) + 2 * (int)p.ops.size();
 		return records <= (160 * 1024) / 16;

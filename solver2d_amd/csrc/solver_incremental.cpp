@@ -134,11 +134,53 @@ void adjRemove(Patcher& p, int body, int key)
 // ---- strips (solver_internal.h: IncrementalStrips) ----
 
 // where a constraint between bodies a and b would live in the strips: table (0 interior, 1 seam), group, the bodies' local slots
-static bool stripHomeWhy(const s2amdSolver* s, int a, int b, int& table, int& group, int& la, int& lb, const char*& why);
-bool stripHome(const s2amdSolver* s, int a, int b, int& table, int& group, int& la, int& lb)
+static bool stripHomeWhy(const s2amdSolver* s, int a, int b, int& table, int& group, int& la, int& lb, const char*& why, int* mover = nullptr);
+
+// Can `body` leave the strip that owns it?  Only a body nothing in the strips refers to: no constraint of any round on it, in no
+// seam's body list (IncrementalStrips: a body that joins an island).
+static bool stripBodyIsFree(const s2amdSolver* s, int body)
+{
+	const IncrementalStrips& m = s->stripInc;
+	const int g = m.ownerStrip[(size_t)body];
+	if (g < 0 || m.stripBodyBase.empty() || !writable(s, body))
+	{
+		return false;
+	}
+	if (m.roundMask[0][(size_t)(m.bodyOffset[0][(size_t)g] + m.ownerSlot[(size_t)body])] != 0u)
+	{
+		return false;
+	}
+	for (int sm = g - 1; sm <= g; ++sm)
+	{
+		if (sm >= 0 && sm < (int)m.seamGroupOf.size() && m.seamGroupOf[(size_t)sm] >= 0 && m.seamSlot[(size_t)m.seamGroupOf[(size_t)sm]].count(body) != 0)
+		{
+			return false;
+		}
+	}
+	return true;
+}
+
+// ... and can strip `g` take one more body?  (The build's budgets hold S2_STRIP_ADOPT_SLACK more per strip; a list that has not moved
+// yet needs room behind the table.)
+static bool stripCanAdopt(const s2amdSolver* s, int g)
+{
+	const IncrementalStrips& m = s->stripInc;
+	if (s->optStripAdopt == 0 || g < 0 || g >= (int)m.stripBodyCount.size() || m.adoptedBy[(size_t)g] >= S2_STRIP_ADOPT_SLACK || (int)s->hPersistDescs.size() != (int)m.stripBodyCount.size())
+	{
+		return false;
+	}
+	const int nb = m.stripBodyCount[(size_t)g];
+	if (nb + 1 > S2_STRIP_BODY_CHUNKS * 256)
+	{
+		return false;
+	}
+	return nb < m.stripListCapacity[(size_t)g] || m.spareIdsNext + nb + S2_STRIP_ADOPT_SLACK <= m.spareIdsEnd;
+}
+
+bool stripHome(const s2amdSolver* s, int a, int b, int& table, int& group, int& la, int& lb, int* mover)
 {
 	const char* why = "";
-	const bool ok = stripHomeWhy(s, a, b, table, group, la, lb, why);
+	const bool ok = stripHomeWhy(s, a, b, table, group, la, lb, why, mover);
 	static const bool debug = getenv("S2AMD_DEBUG_PLACE") != nullptr;
 	if (!ok && debug)
 	{
@@ -147,10 +189,14 @@ bool stripHome(const s2amdSolver* s, int a, int b, int& table, int& group, int& 
 	}
 	return ok;
 }
-static bool stripHomeWhy(const s2amdSolver* s, int a, int b, int& table, int& group, int& la, int& lb, const char*& why)
+static bool stripHomeWhy(const s2amdSolver* s, int a, int b, int& table, int& group, int& la, int& lb, const char*& why, int* mover)
 {
 	const IncrementalStrips& m = s->stripInc;
 	const int sa = writable(s, a) ? m.ownerStrip[(size_t)a] : -1, sb = writable(s, b) ? m.ownerStrip[(size_t)b] : -1;
+	if (mover)
+	{
+		*mover = -1;
+	}
 	if (sa < 0 && sb < 0)
 	{
 		why = "no strip owns either body";
@@ -158,28 +204,90 @@ static bool stripHomeWhy(const s2amdSolver* s, int a, int b, int& table, int& gr
 	}
 	if (sa >= 0 && sb >= 0 && sa != sb)
 	{
+		// a body that joins the island: nothing refers to it yet, so it moves to the other body's strip and the constraint is an
+		// interior one there (the caller performs the move: `mover`; la / lb are the slots AFTER it)
+		auto joins = [&](int body, int to, int& slotOut) {
+			if (!stripBodyIsFree(s, body) || !stripCanAdopt(s, to))
+			{
+				return false;
+			}
+			slotOut = m.stripBodyCount[(size_t)to];
+			return true;
+		};
+		auto seamHome = [&]() {
+			if (sa - sb != 1 && sb - sa != 1)
+			{
+				why = "strips not adjacent";
+				return false;
+			}
+			const int sm = std::min(sa, sb);
+			if (sm >= (int)m.seamGroupOf.size() || m.seamGroupOf[(size_t)sm] < 0)
+			{
+				why = "no seam group";
+				return false;
+			}
+			table = 1, group = m.seamGroupOf[(size_t)sm];
+			const auto& slots = m.seamSlot[(size_t)group];
+			const auto ia = slots.find(a), ib = slots.find(b);
+			if (ia != slots.end() && ib != slots.end())
+			{
+				la = ia->second, lb = ib->second;
+				return true;
+			}
+			// a body the seam does not carry yet becomes its next local body (the caller appends it: `mover` = -2 - {1: a, 2: b, 3: both})
+			const int missing = (ia == slots.end() ? 1 : 0) | (ib == slots.end() ? 2 : 0);
+			int next = m.seamBodyCount.empty() ? 0 : m.seamBodyCount[(size_t)group];
+			int extraLeft = 0, extraRight = 0, importsOf[2] = {0, 0}; // (what this placement adds: a and b sit on different sides)
+			for (int which = 1; which <= 2 && mover; which <<= 1)
+			{
+				if ((missing & which) == 0)
+				{
+					continue;
+				}
+				const int owner = which == 1 ? sa : sb, other = which == 1 ? sb : sa, body = which == 1 ? a : b;
+				const bool left = owner == sm;
+				(left ? extraLeft : extraRight) += 1;
+				importsOf[other == sm ? 0 : 1] += 1;
+				// a body is carried by ONE seam at most: the two seams of a strip are swept in the same rounds, each by its own pair of
+				// workgroups, and the neighbour on one side never sees what the other seam does to the body within a sweep
+				const int otherSeam = left ? sm - 1 : sm + 1;
+				if (otherSeam >= 0 && otherSeam < (int)m.seamGroupOf.size() && m.seamGroupOf[(size_t)otherSeam] >= 0 &&
+					m.seamSlot[(size_t)m.seamGroupOf[(size_t)otherSeam]].count(body) != 0)
+				{
+					why = "the body is carried by its strip's other seam";
+					return false;
+				}
+			}
+			const bool room = mover && s->optStripAdopt != 0 && (int)s->hPersistDescs.size() == (int)m.stripBodyCount.size() && !m.seamBodyCount.empty() &&
+							  m.seamExtra[0][(size_t)group] + extraLeft <= S2_STRIP_ADOPT_SLACK && m.seamExtra[1][(size_t)group] + extraRight <= S2_STRIP_ADOPT_SLACK &&
+							  m.adoptedBy[(size_t)sm] + importsOf[0] <= S2_STRIP_ADOPT_SLACK && m.adoptedBy[(size_t)sm + 1] + importsOf[1] <= S2_STRIP_ADOPT_SLACK &&
+							  s->hPersistDescs[(size_t)sm].exportCount[1] + extraLeft <= 256 && s->hPersistDescs[(size_t)sm + 1].exportCount[0] + extraRight <= 256;
+			if (!room)
+			{
+				why = "a body is not in the seam's body list";
+				return false;
+			}
+			la = ia != slots.end() ? ia->second : next++;
+			lb = ib != slots.end() ? ib->second : next++;
+			*mover = -2 - missing;
+			return true;
+		};
 		// the two sides of a seam: both bodies must already be in its body list (the exchange carries exactly those)
-		if (sa - sb != 1 && sb - sa != 1)
+		if (seamHome())
 		{
-			why = "strips not adjacent";
-			return false;
+			return true;
 		}
-		const int sm = std::min(sa, sb);
-		if (sm >= (int)m.seamGroupOf.size() || m.seamGroupOf[(size_t)sm] < 0)
+		if (mover && joins(b, sa, lb))
 		{
-			why = "no seam group";
-			return false;
+			table = 0, group = sa, la = m.ownerSlot[(size_t)a], *mover = b;
+			return true;
 		}
-		table = 1, group = m.seamGroupOf[(size_t)sm];
-		const auto& slots = m.seamSlot[(size_t)group];
-		const auto ia = slots.find(a), ib = slots.find(b);
-		if (ia == slots.end() || ib == slots.end())
+		if (mover && joins(a, sb, la))
 		{
-			why = "a body is not in the seam's body list";
-			return false;
+			table = 0, group = sb, lb = m.ownerSlot[(size_t)b], *mover = a;
+			return true;
 		}
-		la = ia->second, lb = ib->second;
-		return true;
+		return false;
 	}
 	// an interior constraint of the strip that owns the writable side(s); a read-only body must have its replica there already
 	table = 0, group = sa >= 0 ? sa : sb;
@@ -207,97 +315,290 @@ static bool stripHomeWhy(const s2amdSolver* s, int a, int b, int& table, int& gr
 	return slotIn(a, sa, la) && slotIn(b, sb, lb);
 }
 
+// `body` (stripBodyIsFree) becomes a body of strip `to` (stripCanAdopt): IncrementalStrips says what that takes
+static void stripAdopt(s2amdSolver* s, Patcher& p, int body, int to)
+{
+	IncrementalStrips& m = s->stripInc;
+	const int* ids = s->dStripA.view.bodyIds;
+	const int from = m.ownerStrip[(size_t)body], fromSlot = m.ownerSlot[(size_t)body];
+	// the old entry stays where it is, as a read-only copy nothing refers to
+	std::vector<int>& fromMoved = m.movedList[(size_t)from];
+	if (fromMoved.empty())
+	{
+		const HostGroupTable& h = s->hStripA;
+		fromMoved.assign(h.bodyIds.begin() + h.bodyOffsets[(size_t)from], h.bodyIds.begin() + h.bodyOffsets[(size_t)from + 1]);
+	}
+	fromMoved[(size_t)fromSlot] = body;
+	p.word(ids, (size_t)(m.stripBodyBase[(size_t)from] + fromSlot), (uint32_t)body);
+	// the receiving list: behind the table on its first adoption (with room for the next ones)
+	const int nb = m.stripBodyCount[(size_t)to];
+	std::vector<int>& list = m.movedList[(size_t)to];
+	if (nb >= m.stripListCapacity[(size_t)to])
+	{
+		const HostGroupTable& h = s->hStripA;
+		if (list.empty())
+		{
+			list.assign(h.bodyIds.begin() + h.bodyOffsets[(size_t)to], h.bodyIds.begin() + h.bodyOffsets[(size_t)to + 1]);
+		}
+		const int base = m.spareIdsNext;
+		m.spareIdsNext += nb + S2_STRIP_ADOPT_SLACK;
+		m.stripBodyBase[(size_t)to] = base, m.stripListCapacity[(size_t)to] = nb + S2_STRIP_ADOPT_SLACK;
+		for (int i = 0; i < nb; ++i)
+		{
+			p.word(ids, (size_t)(base + i), (uint32_t)list[(size_t)i]);
+		}
+		// roundMask: the strip's entries move behind the others the same way
+		const int off = m.bodyOffset[0][(size_t)to], newOff = (int)m.roundMask[0].size();
+		m.roundMask[0].resize((size_t)(newOff + nb + S2_STRIP_ADOPT_SLACK), 0u);
+		std::copy(m.roundMask[0].begin() + off, m.roundMask[0].begin() + off + nb, m.roundMask[0].begin() + newOff);
+		m.bodyOffset[0][(size_t)to] = newOff;
+	}
+	else if (list.empty())
+	{
+		const HostGroupTable& h = s->hStripA;
+		list.assign(h.bodyIds.begin() + h.bodyOffsets[(size_t)to], h.bodyIds.begin() + h.bodyOffsets[(size_t)to + 1]);
+	}
+	list.resize((size_t)nb);
+	list.push_back((int)((uint32_t)body | S2G_OWNED));
+	p.word(ids, (size_t)(m.stripBodyBase[(size_t)to] + nb), (uint32_t)body | S2G_OWNED);
+	m.roundMask[0][(size_t)(m.bodyOffset[0][(size_t)to] + nb)] = 0u;
+	m.stripBodyCount[(size_t)to] = nb + 1;
+	m.adoptedBy[(size_t)to] += 1;
+	m.ownerStrip[(size_t)body] = to, m.ownerSlot[(size_t)body] = nb;
+	// the descriptor: where the list is, how long it is
+	static_assert(offsetof(StripDesc, bodyBase) == 0 && offsetof(StripDesc, bodyCount) == 4, "StripDesc layout");
+	const size_t words = (size_t)((const uint32_t*)(s->leanA.descs + to) - (const uint32_t*)s->leanA.descs);
+	p.word(s->leanA.descs, words + 0, (uint32_t)m.stripBodyBase[(size_t)to]);
+	p.word(s->leanA.descs, words + 1, (uint32_t)(nb + 1));
+	// the imports follow the own bodies in LDS: every seam-local body of this strip that is an import sits one slot further on
+	const PersistDesc& d = s->hPersistDescs[(size_t)to];
+	for (int side = 0; side < 2; ++side)
+	{
+		const int g = d.seamGroup[side];
+		if (g < 0)
+		{
+			continue;
+		}
+		const int n = m.seamBodyCount[(size_t)g]; // (the bodies the seam has come to carry since the build included)
+		for (int e = d.remapBase[side]; e < d.remapBase[side] + n; ++e)
+		{
+			if (s->hPersistRemap[(size_t)e] >= nb)
+			{
+				s->hPersistRemap[(size_t)e] += 1;
+				p.word(s->persist.remap, (size_t)e, (uint32_t)s->hPersistRemap[(size_t)e]);
+			}
+		}
+	}
+	m.adopted += 1;
+	m.touched = true;
+	static const bool debug = getenv("S2AMD_DEBUG_PLACE") != nullptr;
+	if (debug)
+	{
+		fprintf(stderr, "[s2amd] body %d moves from strip %d (slot %d) to strip %d (slot %d, list at %d)\n", body, from, fromSlot, to, nb, m.stripBodyBase[(size_t)to]);
+	}
+}
+
+// `body`, owned by one of the two strips of seam `sm` (seam group g), becomes the seam's next local body: IncrementalStrips says what that takes
+static void seamExtend(s2amdSolver* s, Patcher& p, int sm, int g, int body)
+{
+	IncrementalStrips& m = s->stripInc;
+	const int sx = m.ownerStrip[(size_t)body], so = sx == sm ? sm + 1 : sm;
+	const int sideX = sx == sm ? 1 : 0, sideO = 1 - sideX; // seam sm is side 1 of strip sm and side 0 of strip sm + 1
+	PersistDesc& dx = s->hPersistDescs[(size_t)sx];
+	PersistDesc& dO = s->hPersistDescs[(size_t)so];
+	const int slot = m.seamBodyCount[(size_t)g];
+	m.seamBodyCount[(size_t)g] = slot + 1;
+	m.seamExtra[sx == sm ? 0 : 1][(size_t)g] += 1;
+	auto descWord = [&](int strip, size_t byteOffset, uint32_t value) {
+		const size_t words = (size_t)((const uint32_t*)(s->persist.descs + strip) - (const uint32_t*)s->persist.descs);
+		p.word(s->persist.descs, words + byteOffset / 4, value);
+	};
+	auto setRemap = [&](int e, int value) {
+		s->hPersistRemap[(size_t)e] = value;
+		p.word(s->persist.remap, (size_t)e, (uint32_t)value);
+	};
+	// the owner exports it ...
+	const int index = dx.exportCount[sideX]; // (== the neighbour's import count on this seam: the two lists are one list)
+	p.word(s->persist.exportSrc, (size_t)(dx.exportSrcBase[sideX] + index), (uint32_t)m.ownerSlot[(size_t)body]);
+	dx.exportCount[sideX] = index + 1;
+	descWord(sx, offsetof(PersistDesc, exportCount) + 4 * (size_t)sideX, (uint32_t)(index + 1));
+	setRemap(dx.remapBase[sideX] + slot, m.ownerSlot[(size_t)body]);
+	// ... the neighbour imports it: behind its own bodies and (side 1) the left seam's imports; a new import of the LEFT seam moves the
+	// right seam's imports one LDS slot on
+	const int nbO = m.stripBodyCount[(size_t)so];
+	const int ldsSlot = nbO + (sideO == 1 ? dO.importCount[0] : 0) + index;
+	p.word(s->persist.importIds, (size_t)(dO.importIdBase[sideO] + index), (uint32_t)body);
+	if (sideO == 0 && dO.seamGroup[1] >= 0)
+	{
+		const int n1 = m.seamBodyCount[(size_t)dO.seamGroup[1]];
+		for (int e = dO.remapBase[1]; e < dO.remapBase[1] + n1; ++e)
+		{
+			if (s->hPersistRemap[(size_t)e] >= nbO + index)
+			{
+				setRemap(e, s->hPersistRemap[(size_t)e] + 1);
+			}
+		}
+	}
+	dO.importCount[sideO] = index + 1;
+	descWord(so, offsetof(PersistDesc, importCount) + 4 * (size_t)sideO, (uint32_t)(index + 1));
+	setRemap(dO.remapBase[sideO] + slot, ldsSlot);
+	m.adoptedBy[(size_t)so] += 1; // (its LDS budget: one more staged body)
+	// the host's picture: the seam's local slot, its round mask (the group's entries move behind the others when they outgrow their place)
+	m.seamSlot[(size_t)g][body] = slot;
+	const int off = m.bodyOffset[1][(size_t)g];
+	const int built = s->hStripB.bodyOffsets[(size_t)g + 1] - s->hStripB.bodyOffsets[(size_t)g];
+	if (slot == built) // (the first appended body: as built, the next group's entries follow directly)
+	{
+		const int newOff = (int)m.roundMask[1].size();
+		m.roundMask[1].resize((size_t)(newOff + built + 2 * S2_STRIP_ADOPT_SLACK), 0u);
+		std::copy(m.roundMask[1].begin() + off, m.roundMask[1].begin() + off + built, m.roundMask[1].begin() + newOff);
+		m.bodyOffset[1][(size_t)g] = newOff;
+	}
+	m.roundMask[1][(size_t)(m.bodyOffset[1][(size_t)g] + slot)] = 0u;
+	m.seamBodiesAdded += 1;
+	m.touched = true;
+	static const bool debug = getenv("S2AMD_DEBUG_PLACE") != nullptr;
+	if (debug)
+	{
+		fprintf(stderr, "[s2amd] seam %d (group %d) now carries body %d of strip %d: local %d, export %d on side %d (own slot %d), import of strip %d on side %d at LDS %d (its own bodies %d, imports %d + %d)\n", sm, g,
+				body, sx, slot, index, sideX, m.ownerSlot[(size_t)body], so, sideO, ldsSlot, nbO, dO.importCount[0], dO.importCount[1]);
+	}
+}
+
 bool stripPlace(s2amdSolver* s, Patcher& p, const ContactChange& ch)
 {
 	IncrementalStrips& m = s->stripInc;
-	int table, group, la, lb;
-	if (!m.valid || ch.slot >= (int)m.positionOfSlot.size() || m.positionOfSlot[(size_t)ch.slot] >= 0 || !stripHome(s, ch.a, ch.b, table, group, la, lb))
+	int table, group, la, lb, mover = -1;
+	if (!m.valid || ch.slot >= (int)m.positionOfSlot.size() || m.positionOfSlot[(size_t)ch.slot] >= 0 || !stripHome(s, ch.a, ch.b, table, group, la, lb, &mover))
 	{
 		return false;
+	}
+	if (mover >= 0)
+	{
+		stripAdopt(s, p, mover, group); // (its round mask is empty: the search below finds the strip's first round with a free position)
+	}
+	else if (mover <= -3)
+	{
+		const int missing = -2 - mover;
+		const int sm = std::min(m.ownerStrip[(size_t)ch.a], m.ownerStrip[(size_t)ch.b]);
+		if (missing & 1)
+		{
+			seamExtend(s, p, sm, group, ch.a);
+		}
+		if (missing & 2)
+		{
+			seamExtend(s, p, sm, group, ch.b);
+		}
 	}
 	const int off = m.bodyOffset[table][(size_t)group];
 	const bool wa = writable(s, ch.a), wb = writable(s, ch.b);
 	const uint32_t used = (wa ? m.roundMask[table][(size_t)(off + la)] : 0u) | (wb ? m.roundMask[table][(size_t)(off + lb)] : 0u);
-	const int r0 = m.firstRound[table][(size_t)group], n = m.roundCount[table][(size_t)group];
-	const auto opened = table == 0 ? m.openedRoundOf.find(group) : m.openedRoundOf.end();
+	auto take = [&](IncrementalStrips::Round& round, int r) {
+		const int k = round.freePositions.back();
+		round.freePositions.pop_back();
+		if (wa)
+		{
+			m.roundMask[table][(size_t)(off + la)] |= 1u << r;
+		}
+		if (wb)
+		{
+			m.roundMask[table][(size_t)(off + lb)] |= 1u << r;
+		}
+		s->contacts.order[(size_t)k] = ch.slot;
+		s->contacts.local[(size_t)k] = make_int2(la, lb);
+		m.positionOfSlot[(size_t)ch.slot] = k;
+		s->inc.positionOfSlot[(size_t)ch.slot] = -2;
+		p.word(s->dContactIndex.p, (size_t)k, (uint32_t)ch.slot);
+		p.word(s->dContactLocal.p, 2 * (size_t)k, (uint32_t)la);
+		p.word(s->dContactLocal.p, 2 * (size_t)k + 1, (uint32_t)lb);
+		m.touched = true;
+		m.placed += 1;
+		s->placedTotal += 1;
+		s->slackPositions -= 1;
+	};
+	std::vector<int>& open = m.roundsOf[table][(size_t)group];
+	const int n = (int)open.size();
 	for (int r = 0; r < n; ++r)
 	{
-		// (a strip's rounds are contiguous in `rounds` as built; a spare round opened later sits behind all of them)
-		IncrementalStrips::Round& round = m.rounds[(size_t)((opened != m.openedRoundOf.end() && r == n - 1) ? opened->second : r0 + r)];
+		IncrementalStrips::Round& round = m.rounds[(size_t)open[(size_t)r]];
 		if (((used >> r) & 1u) != 0 || round.freePositions.empty())
 		{
 			continue;
 		}
-		const int k = round.freePositions.back();
-		round.freePositions.pop_back();
-		if (wa)
-		{
-			m.roundMask[table][(size_t)(off + la)] |= 1u << r;
-		}
-		if (wb)
-		{
-			m.roundMask[table][(size_t)(off + lb)] |= 1u << r;
-		}
-		s->contacts.order[(size_t)k] = ch.slot;
-		s->contacts.local[(size_t)k] = make_int2(la, lb);
-		m.positionOfSlot[(size_t)ch.slot] = k;
-		s->inc.positionOfSlot[(size_t)ch.slot] = -2;
-		p.word(s->dContactIndex.p, (size_t)k, (uint32_t)ch.slot);
-		p.word(s->dContactLocal.p, 2 * (size_t)k, (uint32_t)la);
-		p.word(s->dContactLocal.p, 2 * (size_t)k + 1, (uint32_t)lb);
-		m.touched = true;
-		m.placed += 1;
-		s->placedTotal += 1;
-		s->slackPositions -= 1;
+		take(round, r);
 		return true;
 	}
-	if (table == 0 && group < (int)m.spareRound.size() && m.spareRound[(size_t)group] >= 0)
+	std::vector<int>& spare = m.spareOf[table][(size_t)group];
+	if (!spare.empty() && s->optStripAdopt != 0 && (int)s->hPersistDescs.size() == (int)m.stripBodyCount.size())
 	{
-		// every round is taken on these bodies: the strip's spare round opens -- two words of its descriptor (the round count,
-		// the new round's range) -- and takes the constraint
-		IncrementalStrips::Round& round = m.rounds[(size_t)m.spareRound[(size_t)group]];
+		// every round is taken on these bodies: the group's next spare round opens -- the round count and the new round's range in
+		// the strip's descriptor (a seam: in the descriptors of its two strips) -- and takes the constraint.  Beyond six interior
+		// rounds or two seam rounds the step needs another variant of the kernel: the launch picks it from pv.maxRoundsA /
+		// maxSeamRounds, a captured step graph is dropped (layoutGeneration).
+		IncrementalStrips::Round& round = m.rounds[(size_t)spare.front()];
 		const int r = round.round;
 		const int begin = round.freePositions.back(), end = round.freePositions.front() + 1;
-		// (the spare round is the strip's next one and never goes beyond what the six-round kernel variants take: maxRoundsA -- which
-		// picks the kernel variant, baked into the captured step graph -- can only move inside a variant's range)
-		static_assert(offsetof(StripDesc, batchCount) % 4 == 0 && offsetof(StripDesc, batch) % 4 == 0 && sizeof(StripDesc::batch[0]) == 16, "StripDesc layout");
-		if (r + 1 > S2_STRIP_ROUNDS)
+		if (r != n || r >= 32)
 		{
 			return false;
 		}
-		const StripDesc* desc = s->leanA.descs + group;
-		const size_t words = (const uint32_t*)desc - (const uint32_t*)s->leanA.descs;
-		const size_t wCount = offsetof(StripDesc, batchCount) / 4, wBatch = offsetof(StripDesc, batch) / 4;
-		p.word(s->leanA.descs, words + wCount, (uint32_t)(r + 1));
-		p.word(s->leanA.descs, words + wBatch + 4 * (size_t)r, (uint32_t)begin); // batch[r] = {begin, end, 0, 0}
-		p.word(s->leanA.descs, words + wBatch + 4 * (size_t)r + 1, (uint32_t)end);
-		m.roundCount[0][(size_t)group] = r + 1;
-		m.spareRound[(size_t)group] = -1;
-		s->persist.maxRoundsA = std::max(s->persist.maxRoundsA, r + 1);
+		if (table == 0)
+		{
+			static_assert(offsetof(StripDesc, batchCount) % 4 == 0 && offsetof(StripDesc, batch) % 4 == 0 && sizeof(StripDesc::batch[0]) == 16, "StripDesc layout");
+			if (r + 1 > S2_STRIP_ROUNDS_MAX)
+			{
+				return false;
+			}
+			const StripDesc* desc = s->leanA.descs + group;
+			const size_t words = (const uint32_t*)desc - (const uint32_t*)s->leanA.descs;
+			const size_t wCount = offsetof(StripDesc, batchCount) / 4, wBatch = offsetof(StripDesc, batch) / 4;
+			p.word(s->leanA.descs, words + wCount, (uint32_t)(r + 1));
+			p.word(s->leanA.descs, words + wBatch + 4 * (size_t)r, (uint32_t)begin); // batch[r] = {begin, end, 0, 0}
+			p.word(s->leanA.descs, words + wBatch + 4 * (size_t)r + 1, (uint32_t)end);
+			if (r + 1 > s->persist.maxRoundsA)
+			{
+				s->persist.maxRoundsA = r + 1;
+				if (r + 1 > S2_STRIP_ROUNDS)
+				{
+					s->persist.wideOnly = 1; // (the 256-thread kernels' variant flags and LDS budgets are as built: they stay off these strips)
+					s->layoutGeneration += 1;
+				}
+			}
+		}
+		else
+		{
+			static_assert(offsetof(PersistDesc, seamBatchCount) % 4 == 0 && offsetof(PersistDesc, seamBatch) % 4 == 0 && sizeof(int2) == 8, "PersistDesc layout");
+			const int sm = group < (int)m.seamOfGroup.size() ? m.seamOfGroup[(size_t)group] : -1;
+			if (r + 1 > S2_PERSIST_B_ROUNDS || sm < 0)
+			{
+				return false;
+			}
+			for (int side = 0; side < 2; ++side)
+			{
+				const int strip = side == 1 ? sm : sm + 1; // seam sm is side 1 of strip sm and side 0 of strip sm + 1
+				PersistDesc& d = s->hPersistDescs[(size_t)strip];
+				d.seamBatchCount[side] = r + 1;
+				d.seamBatch[side][r] = make_int2(begin, end);
+				const size_t words = (size_t)((const uint32_t*)(s->persist.descs + strip) - (const uint32_t*)s->persist.descs);
+				p.word(s->persist.descs, words + offsetof(PersistDesc, seamBatchCount) / 4 + (size_t)side, (uint32_t)(r + 1));
+				const size_t wBatch = offsetof(PersistDesc, seamBatch) / 4 + 2 * ((size_t)side * S2_PERSIST_B_ROUNDS + (size_t)r);
+				p.word(s->persist.descs, words + wBatch, (uint32_t)begin);
+				p.word(s->persist.descs, words + wBatch + 1, (uint32_t)end);
+			}
+			if (r + 1 > s->persist.maxSeamRounds)
+			{
+				s->persist.maxSeamRounds = r + 1;
+				if (r + 1 > 2)
+				{
+					s->persist.wideOnly = 1;
+					s->layoutGeneration += 1;
+				}
+			}
+		}
+		open.push_back(spare.front());
+		spare.erase(spare.begin());
 		m.roundsOpened += 1;
-		// (the rounds of a group are contiguous in `rounds` only as built: the opened one is found through roundOfPosition / here)
-		const int k = round.freePositions.back();
-		round.freePositions.pop_back();
-		if (wa)
-		{
-			m.roundMask[table][(size_t)(off + la)] |= 1u << r;
-		}
-		if (wb)
-		{
-			m.roundMask[table][(size_t)(off + lb)] |= 1u << r;
-		}
-		s->contacts.order[(size_t)k] = ch.slot;
-		s->contacts.local[(size_t)k] = make_int2(la, lb);
-		m.positionOfSlot[(size_t)ch.slot] = k;
-		s->inc.positionOfSlot[(size_t)ch.slot] = -2;
-		p.word(s->dContactIndex.p, (size_t)k, (uint32_t)ch.slot);
-		p.word(s->dContactLocal.p, 2 * (size_t)k, (uint32_t)la);
-		p.word(s->dContactLocal.p, 2 * (size_t)k + 1, (uint32_t)lb);
-		m.openedRoundOf[group] = (int)(&round - m.rounds.data());
-		m.touched = true;
-		m.placed += 1;
-		s->placedTotal += 1;
-		s->slackPositions -= 1;
+		take(round, r);
 		return true;
 	}
 	static const bool debug = getenv("S2AMD_DEBUG_PLACE") != nullptr;
@@ -628,8 +929,8 @@ bool stripCanPlace(const s2amdSolver* s, int a, int b)
 	{
 		return false;
 	}
-	int table, group, la, lb;
-	return stripHome(s, a, b, table, group, la, lb);
+	int table, group, la, lb, mover = -1;
+	return stripHome(s, a, b, table, group, la, lb, &mover);
 }
 
 void deferCreated(s2amdSolver* s, int slot, int a, int b)

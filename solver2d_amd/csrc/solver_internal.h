@@ -127,6 +127,7 @@ struct DeviceGroupTable
 	DevBuf buf;
 	GroupTable view{};
 	int maxBodies = 0;
+	int spareIdsBase = 0, spareIdsCount = 0; // entries of view.bodyIds behind the table's own (IncrementalStrips: relocated body lists)
 };
 
 // The launch sequence of one s2Solve_* driver, recorded once per parameter set
@@ -203,8 +204,9 @@ struct IncrementalStrips
 	};
 	std::vector<Round> rounds;
 	std::vector<int> roundOfPosition;	// [end - base] -> index into rounds
-	std::vector<int> firstRound[2];		// per group: its round 0 in `rounds`
-	std::vector<int> roundCount[2];
+	std::vector<std::vector<int>> roundsOf[2]; // per group: its open rounds in `rounds`, round 0 first (as built: contiguous; opened spare rounds follow)
+	std::vector<std::vector<int>> spareOf[2];  // per group: its CLOSED spare rounds in `rounds` (no batch of a descriptor covers them yet), next round first
+	std::vector<int> seamOfGroup;		// seam group -> the seam (between strips i and i + 1) it is
 	std::vector<int> ownerStrip, ownerSlot; // per body: the strip that owns it and its local slot there, -1
 	std::vector<std::unordered_map<int, int>> replicaSlot; // per strip: read-only body -> local slot
 	std::vector<std::unordered_map<int, int>> seamSlot;	   // per seam group: body -> local slot
@@ -212,10 +214,28 @@ struct IncrementalStrips
 	std::vector<uint32_t> roundMask[2]; // per (body offset of the group + local slot): rounds in use on a writable body
 	std::vector<int> bodyOffset[2];		// per group: its first entry in roundMask
 	std::vector<int> positionOfSlot;	// contact slot -> strip position, -1
-	std::unordered_map<int, int> openedRoundOf; // strip -> index in `rounds` of its spare round once opened (its last round)
-	std::vector<int> spareRound;		// per strip: its CLOSED spare round in `rounds` (no batch of the descriptor covers it yet), -1
 	long placed = 0, roundsOpened = 0;
+	// A body that JOINS an island (a ball thrown into the pile).  A writable body without a single constraint in
+	// the strips is owned by whichever strip the build put it in; when its first contact is with a body of another strip it MOVES there
+	// -- the receiving strip's body list is written again behind the table (one more entry; the descriptor's two words follow it), the
+	// old entry loses its OWNED flag (a read-only copy nobody looks at), the imports' LDS slots behind the own bodies shift by one
+	// (the strip's two remap ranges) -- and the contact is an interior one like any other.  The budgets of a build (LDS records, body
+	// chunks) include S2_STRIP_ADOPT_SLACK more bodies per strip for it.
+	std::vector<int> stripBodyBase, stripBodyCount; // per strip: its list in the device table NOW (GroupTable::bodyIds of dStripA)
+	std::vector<int> stripListCapacity;				// ... entries its place can hold (a relocated list: + the slack)
+	std::vector<std::vector<int>> movedList;		// per strip: the host copy of a relocated list (empty: hStripA's CSR range)
+	std::vector<int> adoptedBy;						// per strip: bodies it has adopted since the build
+	int spareIdsNext = 0, spareIdsEnd = 0;			// free entries behind the table in that buffer
+	long adopted = 0;
+	// ... and a body that a SEAM has to carry from now on (the ball, now a body of strip i, touches a box of strip i + 1; or two boxes
+	// of neighbouring strips that never faced each other): it becomes the seam's next local body -- one more export of its owner, one
+	// more import of the neighbour (whose later imports move one LDS slot on), one more entry of both remap ranges.  The build leaves
+	// room for S2_STRIP_ADOPT_SLACK more bodies in every such range and in the hand-off buffers.
+	std::vector<int> seamBodyCount;		   // per seam group: local bodies it has now
+	std::vector<int> seamExtra[2];		   // per seam group: bodies appended on its left / right side since the build
+	long seamBodiesAdded = 0;
 };
+#define S2_STRIP_ADOPT_SLACK 8
 
 // What a STRUCTURE BUILD produces and the incremental placement keeps up to date: the host's picture of the constraint graph as the
 // structure knows it, every table derived from it and their device copies, the SoA families (carved per structure), the captured step
@@ -270,6 +290,8 @@ struct SolverStructure
 	// structure of the last step
 	SweepSet contacts, joints;
 	HostGroupTable hGroups, hContactTail, hJointTail, hStripA, hStripB;
+	std::vector<int> hPersistRemap;			  // host copies of PersistView::remap and ::descs (IncrementalStrips: a strip that adopts a body)
+	std::vector<PersistDesc> hPersistDescs;
 	DeviceGroupTable dGroups, dContactTail, dJointTail, dStripA, dStripB;
 	// resident islands (strip_kernel.hip: islandStepKernel): LDS groups whose constraints stay in registers for the whole step
 	HostGroupTable hResident;
@@ -430,6 +452,7 @@ struct SolverRest
 	bool indexInWire = false; // the resident wire contacts hold the current gather index as manifold.constraintIndex
 	int graphAge = 0;		  // steps solved since the constraint graph last changed
 	int optStripPatience = 1; // steps of an unchanged graph before the (more expensive) strip structure is built
+	int optStripAdopt = 1;	  // a body without constraints moves to the strip of the body it first touches instead of forcing a rebuild
 	int stripPatienceNow = 1; // ... as it stands: doubled every time a strip structure died young (noteGraphChanged)
 	bool stripPatienceSet = false; // "strip_patience" was set by the caller (else a resident world builds its strips at once: stripPatienceBase)
 	int optStripsAnySolver = 0; // tests: strips for every solver and with joints (through the generic group interpreter)

@@ -637,6 +637,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	}
 	s->stats.persistFallbacks = s->persistFallbacks;
 	s->stats.asyncBuildsRequested = s->asyncRequested, s->stats.asyncBuildsAdopted = s->asyncAdopted, s->stats.asyncWaitMs = s->asyncWaitMs;
+	s->stats.bodiesAdopted = (int32_t)s->stripInc.adopted, s->stats.seamBodiesAdded = (int32_t)s->stripInc.seamBodiesAdded, s->stats.roundsOpened = (int32_t)s->stripInc.roundsOpened;
 	s->stats.structureBuilds = (int32_t)s->structureGeneration;
 	s->stats.placedContacts = (int32_t)s->placedTotal;
 	{

@@ -355,10 +355,10 @@ void colourPart(const std::vector<int>& ids, const std::vector<int>& ea, const s
 	}
 }
 
-int uploadGroupTable(s2amdSolver* s, const HostGroupTable& h, DeviceGroupTable& d)
+int uploadGroupTable(s2amdSolver* s, const HostGroupTable& h, DeviceGroupTable& d, size_t spareIds = 0)
 {
 	auto pad4 = [](size_t n) { return (n + 3) & ~size_t(3); };
-	size_t nBO = pad4(h.bodyOffsets.size()), nBI = pad4(std::max<size_t>(h.bodyIds.size(), 1));
+	size_t nBO = pad4(h.bodyOffsets.size()), nBI = pad4(std::max<size_t>(h.bodyIds.size(), 1) + spareIds);
 	size_t nCO = pad4(h.cBatchOffsets.size()), nJO = pad4(h.jBatchOffsets.size());
 	size_t nCB = std::max<size_t>(h.cBatches.size(), 1) * 4, nJB = std::max<size_t>(h.jBatches.size(), 1) * 4;
 	std::vector<int> blob(nBO + nBI + nCO + nJO + nCB + nJB, 0);
@@ -406,6 +406,7 @@ int uploadGroupTable(s2amdSolver* s, const HostGroupTable& h, DeviceGroupTable& 
 	d.view.jBatches = (const int4*)(base + oJB);
 	d.view.groupCount = h.count();
 	d.maxBodies = h.maxBodies;
+	d.spareIdsBase = (int)std::max<size_t>(h.bodyIds.size(), 1), d.spareIdsCount = (int)spareIds;
 	return S2AMD_OK;
 }
 
@@ -1155,7 +1156,8 @@ do                                                                              
 		for (int sm = 0; sm < S; ++sm)
 		{
 			seamBase[(size_t)sm] = granules;
-			granules += 4 * (int)(leftBodies[(size_t)sm].size() + rightBodies[(size_t)sm].size());
+			// (+ room for the bodies a seam may come to carry later: IncrementalStrips)
+			granules += 4 * ((int)(leftBodies[(size_t)sm].size() + rightBodies[(size_t)sm].size()) + 2 * S2_STRIP_ADOPT_SLACK);
 		}
 		const int parityStride = granules;
 		// TGS_Soft keeps the seam constraints in registers when no seam has more than two colour batches and no interior
@@ -1215,12 +1217,14 @@ do                                                                              
 				d.importCount[side] = (int)imports.size();
 				d.exportCount[side] = (int)exports.size();
 				importIds.insert(importIds.end(), imports.begin(), imports.end());
+				importIds.insert(importIds.end(), (size_t)S2_STRIP_ADOPT_SLACK, 0); // (room: IncrementalStrips)
 				for (int body : exports)
 				{
 					exportSrc.push_back(ownerSlot[body]);
 				}
+				exportSrc.insert(exportSrc.end(), (size_t)S2_STRIP_ADOPT_SLACK, 0);
 				const int nR = (int)rightBodies[(size_t)sm].size();
-				const int toLeft = seamBase[(size_t)sm], toRight = seamBase[(size_t)sm] + 4 * nR;
+				const int toLeft = seamBase[(size_t)sm], toRight = seamBase[(size_t)sm] + 4 * (nR + S2_STRIP_ADOPT_SLACK);
 				d.inBase[side] = side == 0 ? toRight : toLeft;
 				d.outBase[side] = side == 0 ? toLeft : toRight;
 				for (int e = B.bodyOffsets[(size_t)g]; e < B.bodyOffsets[(size_t)g + 1] && ok; ++e)
@@ -1243,6 +1247,7 @@ do                                                                              
 						NEED(false);
 					}
 				}
+				remap.insert(remap.end(), (size_t)2 * S2_STRIP_ADOPT_SLACK, 0); // (room for the seam's later bodies, from either side)
 				int b0 = B.cBatchOffsets[(size_t)g], b1 = B.cBatchOffsets[(size_t)g + 1];
 				NEEDSOFT(b1 - b0 <= S2_PERSIST_B_ROUNDS);
 				d.seamBatchCount[side] = std::min(b1 - b0, S2_PERSIST_B_ROUNDS);
@@ -1269,9 +1274,10 @@ do                                                                              
 				int n1 = r < d.seamBatchCount[1] ? d.seamBatch[1][r].y - d.seamBatch[1][r].x : 0;
 				NEEDSOFT(n0 + n1 <= 512); // both seams share a round: at most two constraints per thread
 			}
-			const int nt = importOffset;
+			// (the budgets include the bodies the strip may still adopt: IncrementalStrips)
+			const int nt = importOffset + S2_STRIP_ADOPT_SLACK;
 			maxStaged = std::max(maxStaged, nt);
-			maxStripBodies = std::max(maxStripBodies, nbA);
+			maxStripBodies = std::max(maxStripBodies, nbA + S2_STRIP_ADOPT_SLACK);
 			genericBodies = std::max(genericBodies, nt);
 			{
 				auto rangeOf = [](const HostGroupTable& t, int g) {
@@ -1427,6 +1433,8 @@ do                                                                              
 					}
 				}
 			}
+			s->hPersistRemap = remap;
+			s->hPersistDescs = descs;
 			s->persistValid = okSoft;
 			s->genericValid = s->optGeneric != 0;
 			s->genericBodies = genericBodies, s->genericSeamBodies = genericSeamBodies, s->genericExports = genericExports;
@@ -1527,7 +1535,11 @@ struct StructureBuild
 	bool stripsNeedOneLaunch = false;
 	LocalSlots slots;
 	std::vector<int> seamGroup;
-	std::vector<int4> spareRounds; // {strip, first position, positions, round index} of the closed spare rounds (emitGroup)
+	struct SpareRound
+	{
+		int table, group, begin, count, round;
+	};
+	std::vector<SpareRound> spareRounds; // the closed spare rounds of the strips (table 0) and seams (table 1): emitGroup
 	int stripBaseC = 0;
 	bool rebuild = false; // the structure just built cannot run: build again with what was learnt (stripsRejected / residentRejected)
 
@@ -1542,9 +1554,12 @@ struct StructureBuild
 		  wantStrips(grouped && solver->optStrips != 0 && !solver->stripsRejected && solver->graphAge >= solver->stripPatienceNow &&
 					 (solver->optStripsAnySolver != 0 || isSoftFamily(type) || genericWanted(solver))),
 		  residentWanted(grouped && isSoftFamily(type) && solver->optIslandResident != 0 && !solver->residentRejected),
-		  // (slack positions in the strips' rounds: TGS_Soft only -- in the 256-thread kernels of SoftStep / PGS_Soft a seam round that
-		  // outgrows 256 positions is dealt in two passes, which cost them 0.26 -> 0.40 ms per SoftStep step at base 200)
-		  stripSlackWanted(solver->optStripSlack != 0 && solver->optIncremental != 0 && solver->optPersist != 0 && type == s2amd_solverTGS_Soft), nb(solver->bodyCapacity),
+		  // (slack positions in the strips' rounds: the soft solvers on the 512-thread kernel -- in the 256-thread kernels of SoftStep /
+		  // PGS_Soft (`wide` off) a seam round that outgrows 256 positions is dealt in two passes, which cost them 0.26 -> 0.40 ms per
+		  // SoftStep step at base 200)
+		  stripSlackWanted(solver->optStripSlack != 0 && solver->optIncremental != 0 && solver->optPersist != 0 &&
+						   (type == s2amd_solverTGS_Soft || (solver->optWide != 0 && (type == s2amd_solverSoftStep || type == s2amd_solverPGS_Soft)))),
+		  nb(solver->bodyCapacity),
 		  cs(solver->contacts), js(solver->joints), slots(solver->bodyCapacity)
 	{
 		static const bool fromEnv = getenv("S2AMD_DEBUG_PREP") != nullptr;
@@ -2205,19 +2220,21 @@ struct StructureBuild
 				t.cBatches.push_back(make_int4(batchOffsets[bi], batchOffsets[bi + 1], isTail ? 1 : 0, 0));
 			}
 		}
-		if (roundSlack > 0 && &t == &s->hStripA)
+		if (roundSlack > 0 && stripTable)
 		{
-			// a strip with fewer interior rounds than the kernels take keeps positions for ONE more: a created contact whose bodies
-			// have every round taken opens it (solver_incremental.cpp: stripPlace patches the strip's descriptor); until then no
-			// round covers them and they cost nothing
+			// a strip (a seam) with fewer rounds than the kernels take keeps positions for the rounds it does not have yet (eight each): a created contact whose
+			// bodies have every round taken opens the next (solver_incremental.cpp: stripPlace patches the descriptors); until then no
+			// round covers them and they cost nothing.  (A ball that comes to rest in the pile is a seventh and eighth constraint on the
+			// boxes it touches, a third on a seam.)
 			const int rounds = (int)t.cBatches.size() - t.cBatchOffsets.back();
-			if (rounds > 0 && rounds < S2_STRIP_ROUNDS)
+			const int most = &t == &s->hStripA ? S2_STRIP_ROUNDS_MAX : S2_PERSIST_B_ROUNDS;
+			for (int r = rounds; rounds > 0 && r < most; ++r)
 			{
-				const int begin = (int)cs.order.size(), cap = 16;
+				const int begin = (int)cs.order.size(), cap = 8;
 				cs.order.resize(cs.order.size() + (size_t)cap, -1);
 				cs.local.resize(cs.local.size() + (size_t)cap, make_int2(0, 0));
 				cs.colorOffsets.push_back(begin + cap);
-				spareRounds.push_back(make_int4(t.count(), begin, cap, rounds)); // (t.count(): this group's index, its row is closed below)
+				spareRounds.push_back(SpareRound{&t == &s->hStripA ? 0 : 1, t.count(), begin, cap, r}); // (t.count(): this group's index, its row is closed below)
 			}
 		}
 		t.cBatchOffsets.push_back((int)t.cBatches.size());
@@ -2462,7 +2479,8 @@ struct StructureBuild
 			return S2AMD_OK;
 		}
 		if ((rc = uploadGroupTable(s, s->hGroups, s->dGroups)) != 0 || (rc = uploadGroupTable(s, s->hContactTail, s->dContactTail)) != 0 ||
-			(rc = uploadGroupTable(s, s->hJointTail, s->dJointTail)) != 0 || (rc = uploadGroupTable(s, s->hStripA, s->dStripA)) != 0 ||
+			(rc = uploadGroupTable(s, s->hJointTail, s->dJointTail)) != 0 ||
+			(rc = uploadGroupTable(s, s->hStripA, s->dStripA, s->hStripA.count() > 0 ? (size_t)32 * (size_t)(s->hStripA.maxBodies + S2_STRIP_ADOPT_SLACK) : 0)) != 0 ||
 			(rc = uploadGroupTable(s, s->hStripB, s->dStripB)) != 0)
 		{
 			return rc;
@@ -2532,7 +2550,7 @@ struct StructureBuild
 		for (int t = 0; t < 2; ++t)
 		{
 			const HostGroupTable& h = *tables[t];
-			m.firstRound[t].assign((size_t)h.count(), 0), m.roundCount[t].assign((size_t)h.count(), 0);
+			m.roundsOf[t].assign((size_t)h.count(), std::vector<int>()), m.spareOf[t].assign((size_t)h.count(), std::vector<int>());
 			m.bodyOffset[t].assign(h.bodyOffsets.begin(), h.bodyOffsets.end());
 			m.roundMask[t].assign(h.bodyIds.size(), 0u);
 			for (int g = 0; g < h.count(); ++g)
@@ -2554,8 +2572,6 @@ struct StructureBuild
 						m.replicaSlot[(size_t)g][body] = e - b0;
 					}
 				}
-				m.firstRound[t][(size_t)g] = (int)m.rounds.size();
-				m.roundCount[t][(size_t)g] = h.cBatchOffsets[(size_t)g + 1] - h.cBatchOffsets[(size_t)g];
 				for (int bi = h.cBatchOffsets[(size_t)g]; bi < h.cBatchOffsets[(size_t)g + 1]; ++bi)
 				{
 					const int4 bt = h.cBatches[(size_t)bi];
@@ -2587,26 +2603,54 @@ struct StructureBuild
 							}
 						}
 					}
+					m.roundsOf[t][(size_t)g].push_back((int)m.rounds.size());
 					m.rounds.push_back(std::move(r));
 				}
 			}
 		}
-		// the closed spare rounds: no batch covers their positions yet
-		m.spareRound.assign((size_t)s->hStripA.count(), -1);
-		for (const int4& sp : spareRounds)
+		m.seamOfGroup.assign((size_t)s->hStripB.count(), -1);
+		for (size_t sm = 0; sm < seamGroup.size(); ++sm)
 		{
-			if (sp.x >= s->hStripA.count() || sp.y < m.base || sp.y + sp.z > m.end)
+			if (seamGroup[sm] >= 0 && seamGroup[sm] < (int)m.seamOfGroup.size())
+			{
+				m.seamOfGroup[(size_t)seamGroup[sm]] = (int)sm;
+			}
+		}
+		// where every strip's body list is, and the room behind the table for lists that move (a strip that adopts a body)
+		{
+			const HostGroupTable& h = s->hStripA;
+			const int K = h.count();
+			m.stripBodyBase.assign((size_t)K, 0), m.stripBodyCount.assign((size_t)K, 0), m.stripListCapacity.assign((size_t)K, 0);
+			m.movedList.assign((size_t)K, std::vector<int>()), m.adoptedBy.assign((size_t)K, 0);
+			for (int g = 0; g < K; ++g)
+			{
+				m.stripBodyBase[(size_t)g] = h.bodyOffsets[(size_t)g];
+				m.stripBodyCount[(size_t)g] = m.stripListCapacity[(size_t)g] = h.bodyOffsets[(size_t)g + 1] - h.bodyOffsets[(size_t)g];
+			}
+			m.spareIdsNext = s->dStripA.spareIdsBase, m.spareIdsEnd = s->dStripA.spareIdsBase + s->dStripA.spareIdsCount;
+			const HostGroupTable& hb = s->hStripB;
+			m.seamBodyCount.assign((size_t)hb.count(), 0);
+			m.seamExtra[0].assign((size_t)hb.count(), 0), m.seamExtra[1].assign((size_t)hb.count(), 0);
+			for (int g = 0; g < hb.count(); ++g)
+			{
+				m.seamBodyCount[(size_t)g] = hb.bodyOffsets[(size_t)g + 1] - hb.bodyOffsets[(size_t)g];
+			}
+		}
+		// the closed spare rounds: no batch covers their positions yet
+		for (const SpareRound& sp : spareRounds) // (in emission order: a group's spare rounds by round index)
+		{
+			if (sp.group >= (int)m.spareOf[sp.table].size() || sp.begin < m.base || sp.begin + sp.count > m.end)
 			{
 				continue;
 			}
 			IncrementalStrips::Round r;
-			r.table = 0, r.group = sp.x, r.round = sp.w;
-			for (int k = sp.y + sp.z - 1; k >= sp.y; --k)
+			r.table = sp.table, r.group = sp.group, r.round = sp.round;
+			for (int k = sp.begin + sp.count - 1; k >= sp.begin; --k)
 			{
 				m.roundOfPosition[(size_t)(k - m.base)] = (int)m.rounds.size();
 				r.freePositions.push_back(k);
 			}
-			m.spareRound[(size_t)sp.x] = (int)m.rounds.size();
+			m.spareOf[sp.table][(size_t)sp.group].push_back((int)m.rounds.size());
 			m.rounds.push_back(std::move(r));
 		}
 		m.valid = true;

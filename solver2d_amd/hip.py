@@ -22,6 +22,7 @@ EXPORTS = [
     "s2amd_set_option", "s2amd_export_poses", "s2amd_export_poses_async", "s2amd_export_bodies_async", "s2amd_export_wait", "s2amd_measure_dominant", "s2amd_refit_shapes", "s2amd_find_pairs", "s2amd_synchronize", "s2amd_update_contacts", "s2amd_find_islands", "s2amd_color_constraints",
     "s2amd_world_upload", "s2amd_world_step", "s2amd_world_download", "s2amd_world_find_pairs", "s2amd_world_set_contacts",
     "s2amd_device_alloc", "s2amd_device_free", "s2amd_device_read", "s2amd_world_separated", "s2amd_world_download_boxes", "s2amd_world_set_refit_order", "s2amd_world_download_step",
+    "s2amd_get_strip_owners",
 ]
 
 _lib = None
@@ -56,6 +57,7 @@ def load():
     L.s2amd_synchronize.argtypes = [vp]
     L.s2amd_get_contact_order.argtypes = [vp, vp, i32, vp, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.s2amd_get_joint_order.argtypes = [vp, vp, i32, vp, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.s2amd_get_strip_owners.argtypes = [vp, vp, vp, i32, ctypes.POINTER(i32)]
     L.s2amd_get_stats.argtypes = [vp, ctypes.POINTER(wire.StepStats)]
     L.s2amd_set_option.argtypes = [vp, ctypes.c_char_p, i32]
     L.s2amd_export_poses.argtypes = [vp, vp, i32]
@@ -111,6 +113,10 @@ class Solver:
         self._h = h
         self.set_option("graph", 1 if graph else 0)
         self.set_option("profile", 1 if profile else 0)
+        # S2AMD_OPTIONS="key=value,key=value": options for every solver this process creates (bisecting a difference without editing the caller)
+        for kv in filter(None, os.environ.get("S2AMD_OPTIONS", "").split(",")):
+            k, _, v = kv.partition("=")
+            self.set_option(k.strip(), int(v))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -316,6 +322,14 @@ class Solver:
     def contact_order(self):
         """(order, colorOffsets) of the last step; see s2amd_get_contact_order."""
         return self._order(load().s2amd_get_contact_order)
+
+    def strip_owners(self, body_capacity):
+        """(ownerStrip, onSeam, stripCount): see s2amd_get_strip_owners."""
+        owner = np.full(max(body_capacity, 1), -1, dtype=np.int32)
+        seam = np.full(max(body_capacity, 1), -1, dtype=np.int32)
+        n = ctypes.c_int32()
+        _check(load().s2amd_get_strip_owners(self._h, owner.ctypes.data, seam.ctypes.data, len(owner), ctypes.byref(n)))
+        return owner[:body_capacity], seam[:body_capacity], n.value
 
     def joint_order(self):
         return self._order(load().s2amd_get_joint_order)

@@ -132,6 +132,64 @@ def neighbour_churn(solver_name, base, steps, options):
         return st["structureBuilds"], st["placedContacts"], st["persistent"]
 
 
+def joining_bodies(solver_name, base, steps, balls):
+    """Bodies without constraints that come to touch the pile (IncrementalStrips: a body moves to the strip it first touches, a seam comes
+    to carry a body it did not, spare rounds open): free bodies touch random boxes, then boxes next to those, let go, touch elsewhere."""
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+    rng = np.random.default_rng(23 + base)
+    b, c, j = common.copy3(synthetic.pyramid(base))
+    extra = np.zeros(balls, dtype=wire.body_dtype)
+    template_body = b[int(np.flatnonzero(b["invMass"] > 0)[0])]
+    for i in range(balls):
+        extra[i] = template_body
+        extra[i]["position"] = (float(base + 40 + 3 * i), 5.0)
+    n0 = len(c)
+    spare_n = 8 * balls
+    pre = _with_spare_slots((np.concatenate([b, extra]), c, j), spare_n)
+    nbrs = {}
+    for a, bb in zip(c["bodyA"].astype(int).tolist(), c["bodyB"].astype(int).tolist()):
+        nbrs.setdefault(a, []).append(bb), nbrs.setdefault(bb, []).append(a)
+    dynamic = np.flatnonzero(b["type"] == wire.BODY_DYNAMIC)
+    free_slot = np.zeros(1, dtype=wire.contact_dtype)[0]
+    free_slot["bodyA"], free_slot["bodyB"], free_slot["constraintIndex"] = -1, -1, -1
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
+        state = common.copy3(pre)
+        s.solve(params, *state)
+        spare = list(range(n0, n0 + spare_n))
+        held = {i: [] for i in range(balls)}  # ball -> [(slot, box)]
+        most = {"bodiesAdopted": 0, "seamBodiesAdded": 0, "roundsOpened": 0}
+        for step in range(steps):
+            for i in range(balls):
+                ball = len(b) + i
+                r = rng.random()
+                if r < 0.5 and spare and len(held[i]) < 5:
+                    box = int(rng.choice(dynamic)) if not held[i] else int(rng.choice(nbrs[held[i][-1][1]]))
+                    if b["type"][box] != wire.BODY_DYNAMIC or any(box == h[1] for h in held[i]):
+                        continue
+                    slot = spare.pop(0)
+                    new = pre[1][5].copy()
+                    new["bodyA"], new["bodyB"] = (ball, box) if rng.random() < 0.5 else (box, ball)
+                    new["pointCount"] = int(rng.integers(0, 3))
+                    state[1][slot] = new
+                    held[i].append((slot, box))
+                elif r < 0.6 and held[i]:
+                    for slot, _ in held[i]:
+                        state[1][slot] = free_slot
+                        spare.append(slot)
+                    held[i] = []
+                elif held[i]:
+                    slot = held[i][int(rng.integers(0, len(held[i])))][0]
+                    state[1][slot]["pointCount"] = int(rng.integers(0, 3))
+            s.solve(params, *state)
+            s.contact_order()
+            st = s.stats()
+            for k in most:  # (the three counters belong to the structure in use: a rebuild starts them again)
+                most[k] = max(most[k], st[k])
+        return st["structureBuilds"], st["placedContacts"], most["bodiesAdopted"], most["seamBodiesAdded"], most["roundsOpened"]
+
+
 def world_chain(base, steps):
     world = synthetic.pyramid_world(base)
     keys = ("bodies", "contacts", "joints", "shapes", "pairs", "origins")
@@ -226,6 +284,10 @@ def main():
                              ("TGS_Soft", 100, {"strip_patience": 0, "persist_debug": 16}), ("PGS", 100, {"strip_patience": 0})):
         builds, placed, persistent = neighbour_churn(name, base, 10 if quick else 40, opts)
         print("neighbour churn %s base %d: %d structure builds, %d contacts placed, persistent %d" % (name, base, builds, placed, persistent))
+    for name in ("TGS_Soft", "SoftStep"):
+        got = joining_bodies(name, 100, 12 if quick else 60, 6)
+        print("joining bodies %s: %d structure builds, %d contacts placed, at most %d bodies moved to another strip, %d added to a seam, %d spare rounds opened per structure" % ((name,) + got))
+        assert got[2] >= 1, got
     print("hub rule: strips", hub_rule())
     world_chain(20 if quick else 60, 3 if quick else 8)
     print("world chain ok")

@@ -730,3 +730,189 @@ def test_soft_solvers_on_partitions_that_need_parked_rounds(solver_name):
                 assert st["pairLanes"] != 2, st
             results.append(state)
     common.compare_exact(results[0], results[1], "parked rounds vs registers")
+
+
+def _pyramid_with_free_bodies(base, balls, spare_slots):
+    """The pyramid plus `balls` dynamic bodies that touch nothing (far to the right, no gravity) and `spare_slots` free contact slots."""
+    b, c, j = common.copy3(synthetic.pyramid(base))
+    extra = np.zeros(balls, dtype=wire.body_dtype)
+    template = b[int(np.flatnonzero(b["invMass"] > 0)[0])]
+    for i in range(balls):
+        extra[i] = template
+        extra[i]["position"] = (float(base + 40 + 3 * i), 5.0)
+        extra[i]["linearVelocity"] = (0.0, 0.0)
+        extra[i]["gravityScale"] = 0.0
+    free = np.zeros(spare_slots, dtype=wire.contact_dtype)
+    free["bodyA"], free["bodyB"], free["constraintIndex"] = -1, -1, -1
+    return np.concatenate([b, extra]), np.concatenate([c, free]), j
+
+
+def _touch(contacts, slot, template_slot, a, b):
+    """Slot `slot` becomes a two-point manifold between bodies a and b (the geometry of an existing manifold: a solver input)."""
+    contacts[slot] = contacts[template_slot]
+    contacts[slot]["bodyA"], contacts[slot]["bodyB"] = a, b
+    for p in range(2):
+        contacts[slot]["points"][p]["normalImpulse"] = 0.0
+        contacts[slot]["points"][p]["tangentImpulse"] = 0.0
+
+
+@pytest.mark.parametrize("solver_name", ["TGS_Soft", "SoftStep", "PGS_Soft"])
+def test_a_body_that_joins_the_island_moves_to_the_strip_it_touches(solver_name):
+    """SURVEY.md 8f row 4, the wrecking ball: a dynamic body without constraints is owned by whichever strip the build put it in.  Its first
+    contact -- with a box in the middle of the pile, many strips away -- moves it there (the receiving strip's body list is written
+    again with one more entry, the imports' slots shift) and the contact is placed as an interior one: NO structure build, the step stays
+    on the persistent kernel, same bits as the oracle.  Then a second contact with a box of the same strip, both destroyed, and a
+    contact with a box in another strip: the body is free again and moves again."""
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    base = 100
+    pre = _pyramid_with_free_bodies(base, 2, 4)
+    params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+    nb = len(pre[0])
+    ball, ball2 = nb - 2, nb - 1
+    template = int(np.flatnonzero(pre[1]["pointCount"] == 2)[len(pre[1]) // 3])
+    spare = [len(pre[1]) - 4 + i for i in range(4)]
+    dyn = np.flatnonzero(pre[0]["invMass"][: nb - 2] > 0)
+    mid, far = int(dyn[len(dyn) // 2]), int(dyn[len(dyn) // 5])
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
+        state = common.copy3(pre)
+        for step in range(3):
+            state = gpu_vs_oracle_loose(s, params, state, "join warm-up %d" % step)
+        st = s.stats()
+        assert st["persistent"] == 1 and st["pairLanes"] == 2, st
+        builds, placed = st["structureBuilds"], st["placedContacts"]
+        script = {0: [(spare[0], ball, mid)], 2: [(spare[1], mid + 1, ball)], 3: [(spare[2], ball2, far)], 5: "free", 7: [(spare[3], far + 2, ball)]}
+        for step in range(10):
+            what = script.get(step)
+            if what == "free":
+                for sl in spare[:2]:
+                    state[1][sl]["bodyA"], state[1][sl]["bodyB"], state[1][sl]["pointCount"] = -1, -1, 0
+            elif what:
+                for sl, a, b in what:
+                    _touch(state[1], sl, template, a, b)
+            state = gpu_vs_oracle_loose(s, params, state, "%s join step %d" % (solver_name, step))
+            st = s.stats()
+            assert st["persistent"] == 1 and st["pairLanes"] == 2 and st["structureBuilds"] == builds, (step, {k: st[k] for k in ("persistent", "pairLanes", "structureBuilds", "placedContacts")})
+        assert s.stats()["placedContacts"] >= placed + 4 and s.stats()["bodiesAdopted"] >= 3, s.stats()
+
+
+def test_joining_bodies_beyond_the_slack_rebuild():
+    """A strip takes S2_STRIP_ADOPT_SLACK (8) bodies this way; the ninth forces the rebuild it always did -- still bit-exact."""
+    base = 100
+    balls = 10
+    pre = _pyramid_with_free_bodies(base, balls, balls)
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    nb = len(pre[0])
+    template = int(np.flatnonzero(pre[1]["pointCount"] == 2)[len(pre[1]) // 3])
+    dyn = np.flatnonzero(pre[0]["invMass"][: nb - balls] > 0)
+    mid = int(dyn[len(dyn) // 2])
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
+        state = common.copy3(pre)
+        for step in range(2):
+            state = gpu_vs_oracle_loose(s, params, state, "slack warm-up %d" % step)
+        builds = s.stats()["structureBuilds"]
+        for i in range(balls):
+            _touch(state[1], len(pre[1]) - balls + i, template, nb - balls + i, mid)
+            state = gpu_vs_oracle_loose(s, params, state, "slack join %d" % i)
+            if i < 6:  # (every ball is a seventh, eighth ... constraint on `mid`: the strip's rounds run out before its body slack does)
+                assert s.stats()["structureBuilds"] == builds or i >= 2, (i, s.stats())
+        assert s.stats()["structureBuilds"] > builds
+
+
+def _box(base, i, j):
+    """Body index of the box in row i (from the ground), column j of synthetic.pyramid(base) (i <= j < base)."""
+    return 1 + sum(base - r for r in range(i)) + (j - i)
+
+
+def _strip_picture(s, state):
+    """(owner, seam, neighbours): strip of every body, the seam that carries it (-1), dynamic contact neighbours per body."""
+    owner, seam, count = s.strip_owners(len(state[0]))
+    nbrs = {}
+    live = state[1]["bodyA"] >= 0
+    for a, b in zip(state[1]["bodyA"][live].tolist(), state[1]["bodyB"][live].tolist()):
+        nbrs.setdefault(a, set()).add(b), nbrs.setdefault(b, set()).add(a)
+    return owner, seam, count, nbrs
+
+
+@pytest.mark.parametrize("solver_name", ["TGS_Soft", "SoftStep", "PGS_Soft"])
+def test_a_joined_body_that_touches_the_neighbouring_strip_extends_the_seam(solver_name):
+    """The ball, adopted by the strip of the first box it touched, then touches a box of the NEXT strip: the seam between the two has to
+    carry the ball from now on -- one more export of its strip, one more import of the neighbour (whose other imports move one LDS slot
+    on), one more local body of the seam, a seam round with room (a spare one opens when the box already has both rounds taken).  The
+    boxes are picked with s2amd_get_strip_owners: a box in the middle strip that is on no seam, then a box of the right-hand
+    neighbour that the seam already carries, then one it does not.  No structure build, same bits as the oracle."""
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    base = 100
+    pre = _pyramid_with_free_bodies(base, 1, 6)
+    params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+    nb = len(pre[0])
+    ball = nb - 1
+    template = int(np.flatnonzero(pre[1]["pointCount"] == 2)[len(pre[1]) // 3])
+    spare = [len(pre[1]) - 6 + i for i in range(6)]
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
+        s.set_option("strip_bodies", 240)  # (strips of several levels: they have bodies no seam carries; in two-level strips every body is on a seam)
+        s.set_option("strip_retry", 0)
+        state = common.copy3(pre)
+        for step in range(2):
+            state = gpu_vs_oracle_loose(s, params, state, "seam warm-up %d" % step)
+        builds = s.stats()["structureBuilds"]
+        owner, seam, count, nbrs = _strip_picture(s, state)
+        assert count > 8 and owner[ball] >= 0
+        k = count // 2
+        inner = [b for b in np.flatnonzero((owner == k) & (seam < 0)).tolist() if b != ball]
+        right_on_seam = np.flatnonzero((owner == k + 1) & (seam == k)).tolist()
+        right_far = np.flatnonzero((owner == k + 1) & (seam < 0)).tolist()
+        left_on_seam = np.flatnonzero((owner == k - 1) & (seam == k - 1)).tolist()
+        assert inner and right_on_seam and right_far and left_on_seam, (count, len(inner), len(right_on_seam), len(right_far), len(left_on_seam))
+        touches = [(inner[0], True), (right_on_seam[0], True), (right_far[0], True),
+                   (left_on_seam[0], False)]  # (the last: the ball would be on both seams of its strip -- refused, the structure is built again)
+        for n, (box, placed) in enumerate(touches):
+            _touch(state[1], spare[n], template, ball, box)
+            state = gpu_vs_oracle_loose(s, params, state, "%s ball touches box %d" % (solver_name, box))
+            state = gpu_vs_oracle_loose(s, params, state, "%s ball touches box %d, next step" % (solver_name, box))
+            st = s.stats()
+            if placed:
+                assert st["persistent"] == 1 and st["pairLanes"] == 2 and st["structureBuilds"] == builds, (n, {k_: st[k_] for k_ in ("persistent", "pairLanes", "structureBuilds", "placedContacts")})
+                seen = st
+            else:
+                assert st["structureBuilds"] > builds
+        assert seen["placedContacts"] >= 3 and seen["bodiesAdopted"] == 1 and seen["seamBodiesAdded"] == 2, seen
+
+
+def test_two_boxes_of_neighbouring_strips_that_never_faced_each_other():
+    """A contact between two boxes of neighbouring strips of which the seam carries NEITHER (both sit on their strips' far sides, or in
+    the middle of a thick strip): both become bodies of the seam.  And the rule that keeps it correct: a box that its strip's OTHER seam
+    already carries is refused (the two seams of a strip are swept in the same rounds by different pairs of workgroups) -- that contact
+    rebuilds the structure as it always did."""
+    base = 100
+    pre = _pyramid_with_free_bodies(base, 0, 2)
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    template = int(np.flatnonzero(pre[1]["pointCount"] == 2)[len(pre[1]) // 3])
+    for case in ("both", "other seam"):
+        with hip.Solver(0) as s:
+            s.set_option("strip_patience", 0)
+            s.set_option("strip_bodies", 240 if case == "both" else 8)  # (thick strips have bodies no seam carries; two-level strips do not)
+            s.set_option("strip_retry", 0)
+            state = common.copy3(pre)
+            for step in range(2):
+                state = gpu_vs_oracle_loose(s, params, state, "far levels warm-up %d" % step)
+            builds = s.stats()["structureBuilds"]
+            owner, seam, count, nbrs = _strip_picture(s, state)
+            k = count // 2
+            if case == "both":
+                a = np.flatnonzero((owner == k) & (seam < 0)).tolist()
+                b = np.flatnonzero((owner == k + 1) & (seam < 0)).tolist()
+            else:
+                a = np.flatnonzero((owner == k) & (seam == k - 1)).tolist()
+                b = np.flatnonzero((owner == k + 1) & (seam == k)).tolist()
+            assert a and b, (case, count)
+            _touch(state[1], len(pre[1]) - 2, template, a[0], b[0])
+            for step in range(3):
+                state = gpu_vs_oracle_loose(s, params, state, "far levels (%s) step %d" % (case, step))
+            st = s.stats()
+            if case == "both":
+                assert st["structureBuilds"] == builds and st["persistent"] == 1 and st["seamBodiesAdded"] == 2, st
+            else:
+                assert st["structureBuilds"] > builds, st

@@ -116,6 +116,8 @@ def main():
            "contacts_created": sum(r["created"] for r in rows), "contacts_destroyed": sum(r["separated"] for r in rows),
            "steps_with_manifold_flips": sum(1 for r in rows if r["flips"]), "steps_that_rebuilt_the_structure": sum(1 for r in rows if r["host_structure_ms"] > 0), "contacts_placed_without_rebuild": st["placedContacts"],
            "steps_on_persistent_kernel": sum(r["persistent"] for r in rows), "steps_replayed_from_graph": sum(r["replayed"] for r in rows),
+           "joined_without_rebuild": {"bodies_moved_to_the_strip_they_touched": st["bodiesAdopted"], "bodies_added_to_a_seam": st["seamBodiesAdded"], "spare_rounds_opened": st["roundsOpened"],
+                                      "note": "counters of the structure in use at the last step (a rebuild starts them again)"},
            "structure_builds_by_the_worker_thread": {"requested": st["asyncBuildsRequested"], "adopted": st["asyncBuildsAdopted"], "caller_waited_ms": st["asyncWaitMs"]},
            "steps_over_1ms": sum(1 for r in rows[2:] if r["step_ms"] > 1.0), "steps_over_2ms": sum(1 for r in rows[2:] if r["step_ms"] > 2.0),
            "all_steps": {k: mean(k, rows) for k in keys}, "churn_steps": {k: mean(k, churn) for k in keys}, "quiet_steps": {k: mean(k, quiet) for k in keys},

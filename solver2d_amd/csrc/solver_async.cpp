@@ -269,6 +269,13 @@ int asyncRequest(s2amdSolver* s, int solverType, bool search)
 	job->solverType = solverType;
 	job->search = search;
 	job->requestedAtStep = s->stepCounter;
+	if (search)
+	{
+		// (the request itself costs the caller a device synchronisation -- the point counts, the freed pairs -- and a copy of the
+		// host's picture of the graph: 3-4 ms at 140k contact slots.  Until one pays off, each search waits twice as long as the last.)
+		s->stripSearchNotBefore = s->stepCounter + s->stripSearchPause;
+		s->stripSearchPause = std::min(2 * s->stripSearchPause, 1 << 14);
+	}
 	job->older = s->async;
 	s->async = job;
 	s->asyncRequested += 1;
@@ -342,10 +349,28 @@ bool asyncAdopt(s2amdSolver* s, int solverType, int* rcOut)
 	s->asyncWaitMs += (float)(nowMs() - t0);
 	s2amdSolver* c = job->clone;
 	bool ok = job->rc == S2AMD_OK && job->solverType == solverType && !c->structureDirty;
-	// (a search that found nothing better than what runs now is not worth the swap)
-	if (ok && job->search && c->dStripA.view.groupCount == 0)
+	// (a search that found nothing better than what runs now is not worth the swap -- nor another search soon)
+	auto score = [](const s2amdSolver* x) {
+		if (x->dStripA.view.groupCount == 0)
+		{
+			return 0;
+		}
+		if (x->persistValid && x->persist.maxRoundsA <= S2_STRIP_ROUNDS)
+		{
+			return (x->persist.maxRoundsA <= 5 && x->persist.maxSeamRounds <= 2) ? 4 : 3;
+		}
+		return x->persistValid ? 2 : 1;
+	};
+	if (ok && job->search)
 	{
-		ok = false;
+		if (score(c) <= score(s))
+		{
+			ok = false;
+		}
+		else
+		{
+			s->stripSearchPause = 256, s->stripSearchNotBefore = 0; // (it paid off: the next one may come as soon as it is asked for)
+		}
 	}
 	ok = ok && replay(c, job->log);
 	if (ok && c->watchedCount > 0)

@@ -492,6 +492,11 @@ struct SolverRest
 	int optAsyncBuildDelay = 12; // "async_build_delay": steps between the request and the adoption of a strip build (the search: 8 x); the caller waits if the worker is not done by then
 	bool isClone = false;	   // a worker's copy: the wire and world buffers are the owner's
 	long stepCounter = 0;	   // steps enqueued since s2amd_create (the clock of the deferred adoption)
+	// the search over strip widths (seven more builds, a copy of the solver for the worker): after a request the next one waits
+	// `stripSearchPause` steps, twice as long every time (a pile with a ball in it needs its seven rounds at any width, and a search
+	// the graph overtakes has found nothing either); a new world or a search whose result was better than what ran starts over
+	long stripSearchNotBefore = 0;
+	int stripSearchPause = 256;
 	int asyncRequested = 0, asyncAdopted = 0;
 	float asyncWaitMs = 0.0f;
 };
@@ -524,6 +529,7 @@ inline void noteGraphChanged(s2amdSolver* s, bool newWorld = false)
 	if (newWorld)
 	{
 		s->stripScaleFound = 0.0f;
+		s->stripSearchNotBefore = 0, s->stripSearchPause = 256;
 	}
 	if (newWorld || s->optStripPatience == 0)
 	{
@@ -532,8 +538,12 @@ inline void noteGraphChanged(s2amdSolver* s, bool newWorld = false)
 	else if (stripsInUse && s->stripInc.valid)
 	{
 		// strips that take created contacts in place (IncrementalStrips) die only of a contact that fits nowhere: they are worth
-		// building again at once unless this one lived for less than it cost (a strip build ~ 3 ms buys ~0.4 ms per step)
-		s->stripPatienceNow = s->graphAge < 8 ? std::min(std::max(2 * s->stripPatienceNow, 2), 32) : base;
+		// building again AT ONCE -- in the step that found the contact, no colour-batch structure in between -- unless this one lived for
+		// less than it cost (a strip build ~ 5 ms buys ~0.4 ms per step).  (r4, once joining bodies, seam bodies and spare rounds were
+		// placed: the strips built in the middle of a burst of contact changes now live through the rest of it -- wreck-200: 226 -> 240 of
+		// 240 steps on the persistent kernel, 9 -> 5 steps that build anything.)
+		s->stripPatienceNow = s->graphAge < 8 ? std::min(std::max(2 * s->stripPatienceNow, 2), 32) : 0;
+		(void)base;
 	}
 	else if (stripsInUse && s->graphAge < 32)
 	{

@@ -393,6 +393,10 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 		s->stripsRejected = false;
 		s->structureDirty = true; // (the structure may have dropped its strips for want of a kernel that could run them)
 	}
+	if (s->stripRetryPending && s->graphAge >= 32 && !s->structureDirty && asyncBuildsOn(s) && s->stepCounter < s->stripSearchNotBefore)
+	{
+		s->stripRetryPending = false; // (the last search found nothing better: SolverRest::stripSearchNotBefore)
+	}
 	if (s->stripRetryPending && s->graphAge >= 32 && !s->structureDirty)
 	{
 		// the postponed search for a better strip partition (solver_structure.cpp: buildStructure): seven more builds, tens of

@@ -60,6 +60,10 @@ struct WideRegs
 // KIND: SOFT_TGS (s2SolveContacts_TGS_Soft, solve_tgs_soft.c:17-135: anchors in the bodies' frames, turned and re-measured every sweep) or
 // SOFT_PGS (s2SolveContacts_PGS_Soft, solve_pgs_soft.c:16-125: the anchors rA0 / rB0 and the separation as s2PrepareContacts_Soft left them).
 // The record has the same 22 dwords either way: for SOFT_PGS lA / lB hold rA0 / rB0 (world orientation) and p0 the separation.
+// (inside the kernel) SOFT_PGS on a variant without parked rounds: rA0 / rB0 wait in LDS as for SOFT_FIXED -- the record is 14 dwords
+#define S2_WIDE_PGS_ARMS 100
+template <int KIND> constexpr bool wideIsPgs = KIND == SOFT_PGS || KIND == S2_WIDE_PGS_ARMS;
+template <int KIND> constexpr bool wideLdsArms = KIND == SOFT_FIXED || KIND == S2_WIDE_PGS_ARMS;
 template <int KIND> S2_DEV WideRegs loadWide(const ContactView& c, int k, int ia, int ib)
 {
 	WideRegs p;
@@ -70,12 +74,18 @@ template <int KIND> S2_DEV WideRegs loadWide(const ContactView& c, int k, int ia
 #pragma unroll
 	for (int j = 0; j < 2; ++j)
 	{
-		const float4 a = KIND == SOFT_PGS ? c.r0[j][k] : c.anchor[j][k];
-		// (SOFT_PGS keeps perp(rA0) = (-y, x), the form the sweep multiplies with: nothing about the anchors is left to compute per
-		// sweep, and nothing loop-invariant for the compiler to hoist into registers the resident constraints need)
-		p.lA[j] = KIND == SOFT_PGS ? f2{-a.y, a.x} : lo2(a), p.lB[j] = KIND == SOFT_PGS ? f2{-a.w, a.z} : hi2(a);
+		if constexpr (KIND == S2_WIDE_PGS_ARMS)
+		{
+			p.lA[j] = p.lB[j] = f2{0.0f, 0.0f}; // (never read: the anchors are in LDS)
+		}
+		else
+		{
+			const float4 a = KIND == SOFT_PGS ? c.r0[j][k] : c.anchor[j][k];
+			// (SOFT_PGS keeps perp(rA0) = (-y, x), the form the sweep multiplies with: nothing about the anchors is left to compute per sweep)
+			p.lA[j] = KIND == SOFT_PGS ? f2{-a.y, a.x} : lo2(a), p.lB[j] = KIND == SOFT_PGS ? f2{-a.w, a.z} : hi2(a);
+		}
 		const float4 par = c.param[j][k];
-		p.p0[j] = KIND == SOFT_PGS ? par.w : par.x, p.p1[j] = par.y, p.p2[j] = par.z;
+		p.p0[j] = wideIsPgs<KIND> ? par.w : par.x, p.p1[j] = par.y, p.p2[j] = par.z;
 		const float2 imp = c.impulse[j][k];
 		p.imp[j] = f2{imp.x, imp.y};
 	}
@@ -161,7 +171,7 @@ template <int KIND, int POINTS> S2_DEV void warmWide(const WideRegs& p, float4* 
 			// (SOFT_PGS: the anchors in world orientation as s2PrepareContacts_Soft computed them -- rotate(q, local anchor) on the poses the
 			// warm start sees too, the same operation on the same operands: rA0 IS the current anchor)
 			V2 rA, rB;
-			if constexpr (KIND == SOFT_FIXED)
+			if constexpr (wideLdsArms<KIND>)
 			{
 				// s2WarmStartContacts_Fixed (solve_soft_step.c:20-64): rA0 / rB0, kept as perp in LDS (wideStepKernel: larms)
 				const float4 a = arms[j * S2_WIDE_THREADS];
@@ -256,9 +266,9 @@ template <int KIND, int POINTS> S2_DEV WidePrep prepWide(const WideRegs& p, cons
 			const f2 sn = ds2 * n2;
 			const float s = (sn.x + sn.y) + p.p0[j];
 #else
-			const V2 rA = KIND == SOFT_PGS ? v2(0.0f, 0.0f) : rotate(qA, asV2(p.lA[j])), rB = KIND == SOFT_PGS ? v2(0.0f, 0.0f) : rotate(qB, asV2(p.lB[j]));
+			const V2 rA = wideIsPgs<KIND> ? v2(0.0f, 0.0f) : rotate(qA, asV2(p.lA[j])), rB = wideIsPgs<KIND> ? v2(0.0f, 0.0f) : rotate(qB, asV2(p.lB[j]));
 #if S2_WIDE_PACKED
-			if constexpr (KIND == SOFT_FIXED)
+			if constexpr (wideLdsArms<KIND>)
 			{
 				// s2SolveContacts_TGS_Fixed (solve_soft_step.c:66-177): the separation from the anchors as the bodies stand now (below),
 				// the impulses along rA0 / rB0 -- perp(rA0), perp(rB0) wait in LDS, the form the chain multiplies with
@@ -274,7 +284,7 @@ template <int KIND, int POINTS> S2_DEV WidePrep prepWide(const WideRegs& p, cons
 			pre.rA[j] = rA, pre.rB[j] = rB;
 #endif
 			const V2 ds = add(sub(dcB, dcA), sub(rB, rA));
-			const float s = KIND == SOFT_PGS ? p.p0[j] : dot(ds, normal) + p.p0[j];
+			const float s = wideIsPgs<KIND> ? p.p0[j] : dot(ds, normal) + p.p0[j];
 #endif
 			// select form of: if (s > 0) bias = s * inv_h; else if (useBias) {bias = max(biasCoefficient * s, cap); ...}
 			const bool speculative = s > 0.0f;
@@ -581,6 +591,8 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 	static_assert(!BODYWARM || (SL == 0 && IL == 0), "the body-centric warm start keeps no terms for parked rounds");
 	static_assert(KIND == SOFT_TGS || MODE == 0, "the self-contained form and the body-centric warm start are s2Solve_TGS_Soft's");
 	static_assert(KIND != SOFT_FIXED || (SL == 0 && IL == 0), "s2Solve_SoftStep: the variants without parked rounds");
+	// the record form the constraint functions take: s2Solve_PGS_Soft on a variant without parked rounds keeps its anchors in LDS too
+	constexpr int RK = (KIND == SOFT_PGS && SL == 0 && IL == 0) ? S2_WIDE_PGS_ARMS : KIND;
 	const int tid = (int)threadIdx.x;
 	const int half = tid >> 8, ht = tid & 255; // hand-offs: waves 0-3 serve the left neighbour, waves 4-7 the right
 	// stamps: (wall_clock64 << 4) | tag; tags: 0 start, 1 loaded, 2 body stage, 3 warm start, 4 interior rounds, 5 hand-off, 6 seam rounds, 7 end
@@ -812,8 +824,8 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 		const int k = kOfSlot(s);
 		const int kc = k >= 0 ? k : 0;
 		const int2 lb = c.localBodies[kc];
-		rA[s] = loadWide<KIND>(c, kc, lb.x, lb.y);
-		if constexpr (KIND == SOFT_FIXED)
+		rA[s] = loadWide<RK>(c, kc, lb.x, lb.y);
+		if constexpr (wideLdsArms<RK>)
 		{
 #pragma unroll
 			for (int j = 0; j < 2; ++j)
@@ -831,8 +843,8 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 		const int kc = mine ? k : 0;
 		const int2 lb = c.localBodies[kc];
 		const int base = mine ? pd->remapBase[seam] : 0; // (a valid entry of the remap table either way)
-		rB[i] = loadWide<KIND>(c, kc, pv.remap[base + (mine ? lb.x : 0)], pv.remap[base + (mine ? lb.y : 0)]);
-		if constexpr (KIND == SOFT_FIXED)
+		rB[i] = loadWide<RK>(c, kc, pv.remap[base + (mine ? lb.x : 0)], pv.remap[base + (mine ? lb.y : 0)]);
+		if constexpr (wideLdsArms<RK>)
 		{
 #pragma unroll
 			for (int j = 0; j < 2; ++j)
@@ -851,7 +863,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 		{
 			const int2 lb = c.localBodies[k];
 			parkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * sw, sw,
-					 loadWide<KIND>(c, k, pv.remap[pd->remapBase[seam] + lb.x], pv.remap[pd->remapBase[seam] + lb.y]));
+					 loadWide<RK>(c, k, pv.remap[pd->remapBase[seam] + lb.x], pv.remap[pd->remapBase[seam] + lb.y]));
 			seamMask |= 1u << i;
 		}
 	}
@@ -862,7 +874,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 		if (k >= 0)
 		{
 			const int2 lb = c.localBodies[k];
-			parkWide(lparkedI + j * S2_WIDE_PARKED_RECORDS * iw, iw, loadWide<KIND>(c, k, lb.x, lb.y));
+			parkWide(lparkedI + j * S2_WIDE_PARKED_RECORDS * iw, iw, loadWide<RK>(c, k, lb.x, lb.y));
 		}
 	}
 	// bodies (+ their integrator constants) into LDS: own list, then this half's imports
@@ -1197,7 +1209,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 				{
 					if ((i & 1) == half && kOfSlot(i >> 1) >= 0)
 					{
-						warmWide<KIND, POINTS>(rA[i >> 1], lvel, ldq, lmass, salt, larms + 2 * (i >> 1) * S2_WIDE_THREADS);
+						warmWide<RK, POINTS>(rA[i >> 1], lvel, ldq, lmass, salt, larms + 2 * (i >> 1) * S2_WIDE_THREADS);
 					}
 					__syncthreads();
 				}
@@ -1209,7 +1221,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 				{
 					if (kOfParked(j) >= 0)
 					{
-						warmWide<KIND, POINTS>(unparkWide(lparkedI + j * S2_WIDE_PARKED_RECORDS * iw, iw), lvel, ldq, lmass, salt);
+						warmWide<RK, POINTS>(unparkWide(lparkedI + j * S2_WIDE_PARKED_RECORDS * iw, iw), lvel, ldq, lmass, salt);
 					}
 					__syncthreads();
 				}
@@ -1221,7 +1233,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 				{
 					if ((seamMask >> i) & 1u)
 					{
-						warmWide<KIND, POINTS>(rB[i], lvel, ldq, lmass, salt, larms + 2 * (RPH + i) * S2_WIDE_THREADS);
+						warmWide<RK, POINTS>(rB[i], lvel, ldq, lmass, salt, larms + 2 * (RPH + i) * S2_WIDE_THREADS);
 					}
 					__syncthreads();
 				}
@@ -1233,7 +1245,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 				{
 					if ((seamMask >> i) & 1u)
 					{
-						warmWide<KIND, POINTS>(unparkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * sw, sw), lvel, ldq, lmass, salt);
+						warmWide<RK, POINTS>(unparkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * sw, sw), lvel, ldq, lmass, salt);
 					}
 					__syncthreads();
 				}
@@ -1247,7 +1259,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 			WidePrep pre;
 			if (half == 0 && kOfSlot(0) >= 0)
 			{
-				pre = prepWide<KIND, POINTS>(rA[0], ldq, lcoef, op.inv_h, op.useBias, salt, larms);
+				pre = prepWide<RK, POINTS>(rA[0], ldq, lcoef, op.inv_h, op.useBias, salt, larms);
 			}
 			// (the parked rounds ROUNDS .. RA-1 take part in the same schedule: their records come out of LDS for the prep and again for the chain)
 #pragma unroll
@@ -1278,12 +1290,12 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 						{
 							if (kOfSlot((i + 1) >> 1) >= 0)
 							{
-								pre = prepWide<KIND, POINTS>(rA[(i + 1) >> 1 < RPH ? (i + 1) >> 1 : 0], ldq, lcoef, op.inv_h, op.useBias, salt, larms + 2 * ((i + 1) >> 1) * S2_WIDE_THREADS);
+								pre = prepWide<RK, POINTS>(rA[(i + 1) >> 1 < RPH ? (i + 1) >> 1 : 0], ldq, lcoef, op.inv_h, op.useBias, salt, larms + 2 * ((i + 1) >> 1) * S2_WIDE_THREADS);
 							}
 						}
 						else if (kOfParked(i + 1 - ROUNDS < IL ? i + 1 - ROUNDS : 0) >= 0)
 						{
-							pre = prepWide<KIND, POINTS>(unparkWide(lparkedI + (i + 1 - ROUNDS) * S2_WIDE_PARKED_RECORDS * iw, iw), ldq, lcoef, op.inv_h, op.useBias, salt);
+							pre = prepWide<RK, POINTS>(unparkWide(lparkedI + (i + 1 - ROUNDS) * S2_WIDE_PARKED_RECORDS * iw, iw), ldq, lcoef, op.inv_h, op.useBias, salt);
 						}
 					}
 					__syncthreads();
@@ -1319,7 +1331,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 			{
 				if ((seamMask >> i) & 1u)
 				{
-					preB[i] = prepWide<KIND, POINTS>(rB[i], ldq, lcoef, op.inv_h, op.useBias, salt, larms + 2 * (RPH + i) * S2_WIDE_THREADS);
+					preB[i] = prepWide<RK, POINTS>(rB[i], ldq, lcoef, op.inv_h, op.useBias, salt, larms + 2 * (RPH + i) * S2_WIDE_THREADS);
 				}
 			}
 			// (... and of the parked seam rounds: their records come out of LDS for it, and again for the chain)
@@ -1329,7 +1341,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 			{
 				if (S2_WIDE_PARKED_PREP_EARLY && ((seamMask >> i) & 1u))
 				{
-					preP[i - SR] = prepWide<KIND, POINTS>(unparkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * sw, sw), ldq, lcoef, op.inv_h, op.useBias, salt);
+					preP[i - SR] = prepWide<RK, POINTS>(unparkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * sw, sw), ldq, lcoef, op.inv_h, op.useBias, salt);
 				}
 			}
 			int fail = 0;
@@ -1363,7 +1375,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 						{
 							if (i >= 2)
 							{
-								const WidePrep late = prepWide<KIND, POINTS>(rB[i], ldq, lcoef, op.inv_h, op.useBias, salt, larms + 2 * (RPH + i) * S2_WIDE_THREADS);
+								const WidePrep late = prepWide<RK, POINTS>(rB[i], ldq, lcoef, op.inv_h, op.useBias, salt, larms + 2 * (RPH + i) * S2_WIDE_THREADS);
 								chainWide<POINTS>(rB[i], late, lvel, lmass, lcoef, salt);
 							}
 							else
@@ -1398,7 +1410,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 						}
 						else
 						{
-							const WidePrep late = prepWide<KIND, POINTS>(p, ldq, lcoef, op.inv_h, op.useBias, salt);
+							const WidePrep late = prepWide<RK, POINTS>(p, ldq, lcoef, op.inv_h, op.useBias, salt);
 							chainWide<POINTS>(p, late, lvel, lmass, lcoef, salt);
 						}
 						slot[5 * sw] = make_float4(p.imp[0].x, p.imp[0].y, p.imp[1].x, p.imp[1].y);
@@ -1658,9 +1670,9 @@ static void launchWide(hipStream_t s, dim3 grid, size_t lds, const ContactView& 
 	}
 	if (kind == SOFT_PGS)
 	{
-		// s2Solve_PGS_Soft: the plain form only (prologue and epilogue launches, the coloured warm start)
+		// s2Solve_PGS_Soft: the plain form only (prologue and epilogue launches, the coloured warm start); rA0 / rB0 in LDS where no round is parked
 		const WideSelf none{};
-		lds += wideExtraLds(pv, RPH, SR, SL, IL, false, false);
+		lds += wideExtraLds(pv, RPH, SR, SL, IL, false, false, SL == 0 && IL == 0);
 		launchWideMode<RPH, SR, SL, IL, 0, SOFT_PGS>(s, grid, lds, c, g, a, pv, ops, opCount, none);
 		return;
 	}
@@ -1733,6 +1745,10 @@ int wideExtraRecords(const PersistView& pv, int selfContained, int bodyWarm, int
 	if (kind == SOFT_FIXED)
 	{
 		return (int)(wideExtraLds(pv, shape[v][0], shape[v][1], 0, 0, false, false, true) / sizeof(float4));
+	}
+	if (kind == SOFT_PGS)
+	{
+		return (int)(wideExtraLds(pv, shape[v][0], shape[v][1], shape[v][2], shape[v][3], false, false, shape[v][2] == 0 && shape[v][3] == 0) / sizeof(float4));
 	}
 	const bool warm = bodyWarm != 0 && shape[v][2] == 0 && shape[v][3] == 0;
 	return (int)(wideExtraLds(pv, shape[v][0], shape[v][1], shape[v][2], shape[v][3], selfContained != 0, warm) / sizeof(float4));

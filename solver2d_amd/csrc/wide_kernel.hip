@@ -594,7 +594,19 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 	// the record form the constraint functions take: s2Solve_PGS_Soft on a variant without parked rounds keeps its anchors in LDS too
 	constexpr int RK = (KIND == SOFT_PGS && SL == 0 && IL == 0) ? S2_WIDE_PGS_ARMS : KIND;
 	const int tid = (int)threadIdx.x;
+#ifndef S2_WIDE_SPREAD_HALVES
+#define S2_WIDE_SPREAD_HALVES 0
+#endif
+#if S2_WIDE_SPREAD_HALVES
+	// (experiment, r4: the halves as waves {0, 1, 4, 5} / {2, 3, 6, 7}.  A CU deals its waves round-robin onto its four SIMDs and a
+	// round of a two-level strip holds ~100 constraints = the first two waves of a half, so with waves 0-3 / 4-7 the chain (waves 0, 1)
+	// and the prep (waves 4, 5) share SIMDs 0 and 1 while SIMDs 2 and 3 idle; this mapping gives each its own pair of SIMDs.  Measured
+	// at base 200: 129.7 against 130.3 us per launch -- nothing: a round is ONE wave's dependent instruction stream, 4 cycles an
+	// instruction, and a second wave on the same SIMD fills its stalls rather than lengthening it.  Bit-exact either way.)
+	const int half = (tid >> 7) & 1, ht = (tid & 127) | ((tid >> 8) << 7);
+#else
 	const int half = tid >> 8, ht = tid & 255; // hand-offs: waves 0-3 serve the left neighbour, waves 4-7 the right
+#endif
 	// stamps: (wall_clock64 << 4) | tag; tags: 0 start, 1 loaded, 2 body stage, 3 warm start, 4 interior rounds, 5 hand-off, 6 seam rounds, 7 end
 	// (the workgroup that stamps: persist_debug bits 8-15 + 1, default one in the middle of the island)
 	const bool stamp = S2_PERSIST_INSTRUMENTED && pv.debugTimes != nullptr && tid == 0 &&

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 passes behind profiles/r04_*: run on the GPU box from the repo root (gpurun).  Counter passes are separate runs
 # (--kernel-trace --pmc X only), never combined with the sys / hip / hsa trace domains; each under `timeout`
-# (S2AMD_PROFILE_PASS_SECONDS, 180).  Usage: tools/profile_r04.sh [headline|config5|calib|all]
+# (S2AMD_PROFILE_PASS_SECONDS, 180).  Usage: tools/profile_r04.sh [headline|config5|soft|calib|all]
 R=$PWD
 export TMPDIR=/tmp
 cd /tmp
@@ -26,12 +26,16 @@ if [ $what = config5 -o $what = all ]; then
   timeout $T rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/c5_write -o pmc -- $C5 > $O/c5_write.log 2>&1
   timeout $T rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES -d $O/c5_sq -o pmc -- $C5 > $O/c5_sq.log 2>&1
 fi
+if [ $what = soft -o $what = all ]; then
+  # s2Solve_PGS_Soft and s2Solve_SoftStep on the 512-thread kernel (wideStepKernel<..., SOFT_PGS / SOFT_FIXED>) beside TGS_Soft
+  timeout $T rocprofv3 --kernel-trace --stats -d $O/soft -o trace -- python $R/tools/solver_table.py --solvers PGS_Soft,SoftStep,TGS_Soft --steps 200 > $O/soft.log 2>&1
+fi
 if [ $what = calib -o $what = all ]; then
   # FETCH_SIZE against bytes really requested: a coalesced float4 stream, one 152-byte record per lane, one 88-byte record per lane
   timeout $T rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/calib -o pmc -- $R/tools/fetch_calib.bin > $O/calib.log 2>&1
 fi
 cd $R
-for d in h_stats h_fetch h_write h_sq_a h_sq_b h_self c5_stats c5_fetch c5_write c5_sq calib; do
+for d in h_stats h_fetch h_write h_sq_a h_sq_b h_self c5_stats c5_fetch c5_write c5_sq calib soft; do
   db=$(find $O/$d -name "*_results.db" 2>/dev/null | head -1)
   [ -n "$db" ] && python tools/rocpd_summary.py $db > $O/$d.txt
 done
@@ -46,6 +50,7 @@ mkdir -p $P
 [ -f $O/c5_fetch.txt ] && cp $O/c5_fetch.txt $P/r04_config5_pmc_fetch_size.txt
 [ -f $O/c5_write.txt ] && cp $O/c5_write.txt $P/r04_config5_pmc_write_size.txt
 [ -f $O/c5_sq.txt ] && cp $O/c5_sq.txt $P/r04_config5_pmc_sq.txt
+[ -f $O/soft.txt ] && cp $O/soft.txt $P/r04_soft_solvers_kernel_trace.txt
 [ -f $O/calib.txt ] && (cat $O/calib.log | grep "bytes" ; cat $O/calib.txt) > $P/r04_fetch_size_calibration.txt
-rm -rf $O/h_stats $O/h_fetch $O/h_write $O/h_sq_a $O/h_sq_b $O/h_self $O/c5_stats $O/c5_fetch $O/c5_write $O/c5_sq $O/calib
+rm -rf $O/h_stats $O/h_fetch $O/h_write $O/h_sq_a $O/h_sq_b $O/h_self $O/c5_stats $O/c5_fetch $O/c5_write $O/c5_sq $O/calib $O/soft
 grep -h "wideStep\|IslandKernel\|islandStep\|streamFloat4\|recordPerLane" $P/*.txt | cut -c1-30,100-190 | head -40

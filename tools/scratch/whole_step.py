@@ -1,0 +1,6 @@
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench
+for settle in (60, 200):
+    w = bench.whole_step_leg(0, 200, 8, 4, settle, 240)
+    print(os.environ.get("S2AMD_OPTIONS", "(default)"), "settle", settle, "whole_step_ms %.4f with_pair_query %.4f solver_device %.4f" % (w["whole_step_ms"], w["whole_step_with_pair_query_ms"], w["solver_device_ms"]), flush=True)

@@ -27,8 +27,18 @@ int s2amdFail(int code, const std::string& msg);
 inline int fail(int code, const std::string& msg) { return s2amdFail(code, msg); }
 
 #define S2_HUB_DEGREE 12
-// a writable body with more constraints than this inside the strips keeps its graph off them (solver_structure.cpp: cutStrips)
-#define S2_STRIP_MAX_DEGREE 48
+// Hub bodies and strips (solver_structure.cpp: cutStrips).  A strip sweeps the constraints of one body in as many colour rounds as the
+// body has constraints, and every strip waits on that strip's hand-offs: a sweep over the strips costs about
+//     max(degree of any writable body inside the strips) x S2_COST_STRIP_ROUND_US        (1.4 us per round: the op interpreter, r3),
+// the same sweep on the colour batches with the wave-walked tail about
+//     S2_COST_BATCH_COLOURS x S2_COST_LAUNCH_US  +  (sum of the hubs' degrees) x S2_COST_TAIL_VISIT_US
+// (a dozen colour launches of ~2 us in a graph; 0.38 us per tail visit: Tumbler 10k).  The graph keeps its strips
+// when the first is the smaller -- for ONE hub that is a degree of 23 or less; the Tumbler's drum (238) is 333 us against 114.
+// (Through round 3 this was a constant, 48.)
+#define S2_COST_STRIP_ROUND_US 1.4f
+#define S2_COST_LAUNCH_US 2.0f
+#define S2_COST_BATCH_COLOURS 12
+#define S2_COST_TAIL_VISIT_US 0.38f
 
 #define HIP_TRY(expr)                                                                                                            \
 	do                                                                                                                           \

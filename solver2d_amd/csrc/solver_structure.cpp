@@ -1942,7 +1942,9 @@ struct StructureBuild
 				// Tumbler's drum, 238 contacts) would hold its strip -- and every strip waiting on its hand-offs -- for hundreds
 				// of rounds per sweep.  Such a graph stays on the colour batches and their wave-walked tail (group_kernel.hip:
 				// walkTail; Tumbler 10k TGS_Soft: 3.2 ms there, 5.8 ms through the op interpreter).
+				// Which way is the cheaper one is an estimate from measured unit costs (solver_internal.h: S2_COST_*), not a constant.
 				std::vector<int> stripDegree((size_t)nb, 0);
+				int maxDegree = 0;
 				for (const std::vector<std::vector<int>>* lists : {&strips.cA, &strips.cB})
 				{
 					for (const std::vector<int>& list : *lists)
@@ -1951,13 +1953,24 @@ struct StructureBuild
 						{
 							for (int b : {ce.a[k], ce.b[k]})
 							{
-								if (b >= 0 && conflict[(size_t)b] && ++stripDegree[(size_t)b] > S2_STRIP_MAX_DEGREE)
+								if (b >= 0 && conflict[(size_t)b])
 								{
-									unfit = true;
+									maxDegree = std::max(maxDegree, ++stripDegree[(size_t)b]);
 								}
 							}
 						}
 					}
+				}
+				if (maxDegree > S2_HUB_DEGREE) // (up to there a body's constraints are colour rounds like any other's)
+				{
+					long tailVisits = 0;
+					for (int d : stripDegree)
+					{
+						tailVisits += d > S2_HUB_DEGREE ? d : 0;
+					}
+					const float onStrips = (float)maxDegree * S2_COST_STRIP_ROUND_US;
+					const float onBatches = (float)S2_COST_BATCH_COLOURS * S2_COST_LAUNCH_US + (float)tailVisits * S2_COST_TAIL_VISIT_US;
+					unfit = unfit || onStrips > onBatches;
 				}
 				if (unfit)
 				{

@@ -248,7 +248,7 @@ def world_chain_async(base, steps):
 
 
 def hub_rule():
-    """A writable body with more than S2_STRIP_MAX_DEGREE (48) constraints among the strip candidates keeps its graph off the strips
+    """A writable body whose constraints would cost more as colour rounds of a strip than on the tail (S2_COST_*: more than 23) keeps its graph off the strips
     (solver_structure.cpp: cutStrips); the same pile without the hub is cut into strips."""
     bodies, contacts, joints = common.copy3(synthetic.pyramid(36))
     hubbed = contacts.copy()

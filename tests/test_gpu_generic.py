@@ -177,10 +177,11 @@ def test_perturbed_piles_with_joints_through_the_op_interpreter(seed, joints):
 
 @pytest.mark.parametrize("solver_name", ["TGS_Soft", "PGS_NGS_Block", "XPBD"])
 def test_a_hub_body_keeps_its_island_off_the_strips(solver_name):
-    """A body with more constraints than S2_STRIP_MAX_DEGREE (48) among the strip candidates -- the Tumbler's drum has 238 -- would
-    be as many colour rounds of one strip per sweep: no strips for such a graph (solver_structure.cpp: cutStrips), it runs on
-    colour batches and the sequential tail and is bit-exact there.  (Tumbler 10k under TGS_Soft: 3.2 ms that way, 5.8 ms through
-    the interpreter.)  The same pile without the hub takes the strips."""
+    """A body with many constraints among the strip candidates -- the Tumbler's drum has 238 -- would be as many colour rounds of one
+    strip per sweep: when that costs more than the colour batches and their sequential tail (solver_internal.h: S2_COST_*; one hub:
+    more than 23 constraints) the graph gets no strips (solver_structure.cpp: cutStrips), it runs on colour batches and the tail
+    and is bit-exact there.  (Tumbler 10k under TGS_Soft: 3.2 ms that way, 5.8 ms through the interpreter.)  The same pile without
+    the hub takes the strips."""
     bodies, contacts, joints = pile_with_joints(3, 36, 0)
     vel, pos = common.DEFAULT_ITERS[solver_name]
     params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
@@ -203,6 +204,33 @@ def test_a_hub_body_keeps_its_island_off_the_strips(solver_name):
             assert (st["stripCount"] > 0) == want_strips, st
             if not want_strips:
                 assert st["contactColors"] >= 60, st
+
+
+@pytest.mark.parametrize("degree,want_strips", [(18, True), (30, False)])
+def test_the_hub_rule_is_a_cost_comparison(degree, want_strips):
+    """Both sides of the threshold under the reference's default solver (the op interpreter takes strips of up to 32 colour rounds):
+    18 boxes leaning on one -- 18 x 1.4 us per sweep on the strips against 24 + 18 x 0.38 us on the batches: strips --, 30 boxes --
+    42 us against 35.4: no strips.  Bit-exact against the oracle either way."""
+    bodies, contacts, joints = pile_with_joints(3, 36, 0)
+    params = wire.StepParams.make("PGS_NGS_Block", 1.0 / 60.0, 4, 2, True)
+    hubbed = contacts.copy()
+    movable = np.flatnonzero(bodies["invMass"] > 0.0)
+    hub = int(movable[len(movable) // 2])
+    mine = int(((hubbed["bodyA"] == hub) | (hubbed["bodyB"] == hub)).sum())
+    live = np.flatnonzero((hubbed["bodyA"] >= 0) & (hubbed["bodyA"] != hub) & (hubbed["bodyB"] != hub) & (hubbed["pointCount"] > 0))
+    extra = degree - mine
+    picked = live[:: max(1, len(live) // extra)][:extra]
+    hubbed["bodyB"][picked] = hub
+    with hip.Solver(0) as gpu:
+        gpu.set_option("strip_patience", 0)
+        gpu.set_option("max_group_bodies", 256)
+        gpu.set_option("strip_min_bodies", 0)
+        gpu.set_option("strip_bodies", 60)
+        state = (bodies, hubbed, joints)
+        for step in range(2):
+            state = gpu_vs_oracle_loose(gpu, params, state, "hub of degree %d step %d" % (degree, step))
+        st = gpu.stats()
+        assert (st["stripCount"] > 0) == want_strips, st
 
 
 def test_consecutive_resident_steps_with_joints_and_contacts():

@@ -172,6 +172,7 @@ typedef struct s2amdStepStats
 	int32_t bodiesAdopted;        /* (API 3) bodies without constraints that moved to the strip of the body they first touched (no build), in the structure in use */
 	int32_t seamBodiesAdded;      /* (API 3) bodies a seam between two strips came to carry after the build (one more export / import of its strips) */
 	int32_t roundsOpened;         /* (API 3) spare colour rounds of strips and seams opened for created contacts */
+	int32_t nearHandoffTimeouts;  /* (API 3) hand-off time-outs while the same-XCD path (workgroup-scope stores between neighbours on one L2) was in use: the step was tried again with agent-scope stores, which the solver keeps */
 } s2amdStepStats;
 
 typedef struct s2amdSolver s2amdSolver;
@@ -428,7 +429,7 @@ int s2amd_measure_dominant(s2amdSolver* solver, const s2amdStepParams* params, i
 /* option keys: "graph" (0/1 hipGraph replay), "profile" (0/1 per-sweep HIP events),
  * "groups" (0/1 LDS group path for small islands), "message" (0/1 message-passing sweeps), "max_group_bodies", "pack_group_bodies",
  * "strips" (0/1 cut islands that fit no LDS group into strips of BFS levels: two launches per sweep), "strip_bodies" (target
- * bodies per strip, default 8 = strips of two BFS levels), "strip_retry" (0/1 rebuild the partition with other strip widths when the persistent kernel cannot take this one or it needs more than five interior colour rounds), "strip_min_bodies" (loose bodies below which the colour-batch path is kept), "strip_patience" (steps the constraint graph must
+ * bodies per strip, default 8 = strips of two BFS levels), "near_handoff" (0/1, default 1: hand-offs between workgroups the per-launch census finds on one XCD stay in its L2), "strip_retry" (0/1 rebuild the partition with other strip widths when the persistent kernel cannot take this one or it needs more than five interior colour rounds), "strip_min_bodies" (loose bodies below which the colour-batch path is kept), "strip_patience" (steps the constraint graph must
  * stay unchanged before the strip structure is built: its host build costs ~3 ms at 60k constraints, the colour-batch one ~1 ms), "async" (0/1, see s2amd_synchronize), "strip_lean" (0/1 dedicated strip
  * kernel for the soft sweeps), "persist" (0/1 whole step of the strips in one persistent launch), "wide" (0/1 TGS_Soft's persistent launch runs 512 threads per strip: wide_kernel.hip),
  * "generic" (0/1 every other Gauss-Seidel solver, and any big island with joints, runs its whole step as one launch of the op interpreter over the

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactV
 	int* lnear = (int*)(lops + opCount);
 	if (tid < 2)
 	{
-		const bool hope = tid == 0 ? strip > firstOfXcd : strip + 1 < firstOfXcd + countOfXcd;
+		const bool hope = pv.nearHandoff != 0 && (tid == 0 ? strip > firstOfXcd : strip + 1 < firstOfXcd + countOfXcd);
 		int near = 0;
 		if (hope)
 		{

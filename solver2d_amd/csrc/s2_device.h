@@ -512,6 +512,8 @@ struct PersistView
 	int seamRegs;	  // no seam has more than two colour batches: the seam constraints stay in registers (SEAMREG variant)
 	int maxRoundsA, maxSeamRounds; // the most interior colour batches of a strip / colour batches of a seam
 	int pairLanes;	  // the partition fits pair_kernel.hip: pairStepKernel (<= 6 interior batches per strip, <= 2 per seam)
+	int nearHandoff;  // hand-offs between two workgroups that the census finds on one XCD may use workgroup-scope stores (they stay in that L2);
+					  // 0: agent-scope stores everywhere (option near_handoff, and after a hand-off time-out while this was on)
 	int wideOnly;	  // (host) a spare round beyond those opened since the build: only wide_kernel.hip's budgets were kept up to date (IncrementalStrips)
 	int ldsRecords;
 	int parkSeamWidth, parkInteriorWidth; // wide_kernel.hip: lanes that hold a record in a parked seam round (rounds 3-4) / interior round (7-8), >= 64

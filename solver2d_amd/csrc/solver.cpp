@@ -371,6 +371,17 @@ int s2amd_synchronize(s2amdSolver* s)
 			return rcReset;
 		}
 		HIP_TRY(hipStreamSynchronize(s->stream));
+		if (s->nearHandoffNow != 0)
+		{
+			// (the same-XCD hand-off path was in use: the repeated steps stay on the one-launch kernel, with agent-scope stores everywhere)
+			s->nearHandoffNow = 0;
+			s->nearHandoffTimeouts += 1;
+			s->stats.nearHandoffTimeouts = s->nearHandoffTimeouts;
+			s->layoutGeneration += 1;
+			return fail(S2AMD_E_DEVICE, "strip hand-off timed out inside the persistent step kernel while the same-XCD hand-off path was in use: the steps "
+										"enqueued since the last s2amd_synchronize were dropped from the failing one on -- repeat them (the solver now "
+										"hands off with agent-scope stores only)");
+		}
 		s->persistFailed = true;
 		s->persistFailedAge = 0;
 		s->persistFallbacks += 1;
@@ -884,6 +895,11 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 		s->optStripPatience = std::max(0, value);
 		s->stripPatienceNow = s->optStripPatience;
 		s->stripPatienceSet = true;
+	}
+	else if (strcmp(key, "near_handoff") == 0)
+	{
+		s->optNearHandoff = value != 0;
+		s->nearHandoffNow = s->optNearHandoff;
 	}
 	else if (strcmp(key, "strip_adopt") == 0)
 	{

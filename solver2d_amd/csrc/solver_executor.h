@@ -658,6 +658,7 @@ struct Executor
 			recordEvent();
 		}
 		PersistView pv = s->persist;
+		pv.nearHandoff = s->nearHandoffNow;
 		for (int i = 0; i < 2; ++i)
 		{
 			pv.softCoef[i] = make_float4(p.sc.softCoef[i][0], p.sc.softCoef[i][1], p.sc.softCoef[i][2], 0.0f);
@@ -704,7 +705,9 @@ struct Executor
 		const size_t withJoints = genericStepLds(s->genericBodies, s->genericSeamBodies, s->genericExports, s->persistOpCount, p.usesDq0 ? 1 : 0, s->genericJoints);
 		const bool stage = s->optStageJoints != 0 && s->genericJoints > 0 && withJoints <= 160 * 1024;
 		const size_t lds = stage ? withJoints : genericStepLds(s->genericBodies, s->genericSeamBodies, s->genericExports, s->persistOpCount, p.usesDq0 ? 1 : 0);
-		launchGenericStep(st, s->cv, s->jv, s->bv, s->dStripA.view, s->dStripB.view, s->persist, (const Op*)s->dPersistOps.p, s->persistOpCount, p.sc,
+		PersistView gpv = s->persist;
+		gpv.nearHandoff = s->nearHandoffNow;
+		launchGenericStep(st, s->cv, s->jv, s->bv, s->dStripA.view, s->dStripB.view, gpv, (const Op*)s->dPersistOps.p, s->persistOpCount, p.sc,
 						  wireContacts(), p.usesDq0 ? 1 : 0, s->contacts.seamCount > 0 ? 1 : 0, s->joints.seamCount > 0 ? 1 : 0, lds, stage ? 1 : 0);
 		if (profile)
 		{

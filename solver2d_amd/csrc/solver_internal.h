@@ -462,6 +462,10 @@ struct SolverRest
 	bool indexInWire = false; // the resident wire contacts hold the current gather index as manifold.constraintIndex
 	int graphAge = 0;		  // steps solved since the constraint graph last changed
 	int optStripPatience = 1; // steps of an unchanged graph before the (more expensive) strip structure is built
+	// hand-offs inside one XCD's L2 (persist_handoff.h: putGranuleNear: workgroup-scope stores, found by the per-launch census): an
+	// assumption about the cache hierarchy that the memory model does not promise, so it is an option ("near_handoff") and the first
+	// thing to go when a hand-off times out -- the step is tried again with agent-scope stores before the one-launch kernels are given up
+	int optNearHandoff = 1, nearHandoffNow = 1, nearHandoffTimeouts = 0;
 	int optStripAdopt = 1;	  // a body without constraints moves to the strip of the body it first touches instead of forcing a rebuild
 	int stripPatienceNow = 1; // ... as it stands: doubled every time a strip structure died young (noteGraphChanged)
 	bool stripPatienceSet = false; // "strip_patience" was set by the caller (else a resident world builds its strips at once: stripPatienceBase)

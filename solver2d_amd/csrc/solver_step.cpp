@@ -641,6 +641,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	}
 	s->stats.persistFallbacks = s->persistFallbacks;
 	s->stats.asyncBuildsRequested = s->asyncRequested, s->stats.asyncBuildsAdopted = s->asyncAdopted, s->stats.asyncWaitMs = s->asyncWaitMs;
+	s->stats.nearHandoffTimeouts = s->nearHandoffTimeouts;
 	s->stats.bodiesAdopted = (int32_t)s->stripInc.adopted, s->stats.seamBodiesAdded = (int32_t)s->stripInc.seamBodiesAdded, s->stats.roundsOpened = (int32_t)s->stripInc.roundsOpened;
 	s->stats.structureBuilds = (int32_t)s->structureGeneration;
 	s->stats.placedContacts = (int32_t)s->placedTotal;
@@ -660,6 +661,15 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 		if (rcReset)
 		{
 			return rcReset;
+		}
+		if (s->nearHandoffNow != 0 && s->stats.persistent)
+		{
+			// ... unless the same-XCD hand-off path was in use: its stores are only promised to be seen inside one L2.  The step is
+			// tried again on the same kernel with agent-scope stores everywhere, which this solver keeps from now on.
+			s->nearHandoffNow = 0;
+			s->nearHandoffTimeouts += 1;
+			s->layoutGeneration += 1; // (a captured step graph has the old launch parameters)
+			return doStep(s, params);
 		}
 		s->persistFailed = true;
 		s->persistFailedAge = 0;

@@ -628,7 +628,8 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 	// does this strip's left / right neighbour run on my XCD (by the same map)?
 	const int firstOfXcd = xcd * (K >> 3) + (xcd < (K & 7) ? xcd : (K & 7));
 	const int countOfXcd = (K >> 3) + (xcd < (K & 7) ? 1 : 0);
-	const bool hopeLeft = S2_WIDE_XCD_AFFINE && strip > firstOfXcd, hopeRight = S2_WIDE_XCD_AFFINE && strip + 1 < firstOfXcd + countOfXcd;
+	const bool nearAllowed = S2_WIDE_XCD_AFFINE && pv.nearHandoff != 0;
+	const bool hopeLeft = nearAllowed && strip > firstOfXcd, hopeRight = nearAllowed && strip + 1 < firstOfXcd + countOfXcd;
 	// The census: every workgroup publishes the XCD it REALLY runs on (write-through, once per launch), and a seam takes the
 	// L2 path only when both of its workgroups have read the same id from each other -- results never depend on placement.
 	unsigned myXcc;

@@ -586,7 +586,7 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 	}
 	const double t1 = nowMs();
 	int rc = S2AMD_OK;
-	int fallbacks = 0;
+	int fallbacks = 0, nearRetries = 0;
 	for (;;)
 	{
 		const int savedAsync = s->optAsync;
@@ -608,6 +608,24 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 			return rc;
 		}
 		s->stepBackValid = stepBack;
+		if (s->hostError && *s->hostError != 0u && s->nearHandoffNow != 0 && nearRetries == 0)
+		{
+			// (the same-XCD hand-off path was in use: once more on the same kernel, with agent-scope stores everywhere -- solver_step.cpp)
+			if ((rc = resetPersistState(s, st)) != 0)
+			{
+				return rc;
+			}
+			s->nearHandoffNow = 0;
+			s->nearHandoffTimeouts += 1;
+			s->layoutGeneration += 1;
+			nearRetries += 1;
+			if (!haveFirst)
+			{
+				firstSeen = *hSum;
+				haveFirst = true;
+			}
+			continue;
+		}
 		if (s->hostError && *s->hostError != 0u && fallbacks == 0)
 		{
 			// bodies, impulses and (because the solve left the bodies alone) the shapes are what they were before the solve;
@@ -619,8 +637,11 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 			s->persistFailed = true;
 			s->persistFallbacks += 1;
 			fallbacks += 1;
-			firstSeen = *hSum;
-			haveFirst = true;
+			if (!haveFirst)
+			{
+				firstSeen = *hSum;
+				haveFirst = true;
+			}
 			continue;
 		}
 		break;

@@ -101,7 +101,7 @@ class StepStats(ctypes.Structure):
         ("stripCount", ctypes.c_int32), ("seamCount", ctypes.c_int32), ("persistent", ctypes.c_int32), ("persistFallbacks", ctypes.c_int32),
         ("structureBuilds", ctypes.c_int32), ("placedContacts", ctypes.c_int32), ("potentialConstraints", ctypes.c_int32), ("pairLanes", ctypes.c_int32),
         ("asyncBuildsRequested", ctypes.c_int32), ("asyncBuildsAdopted", ctypes.c_int32), ("asyncWaitMs", ctypes.c_float),
-        ("bodiesAdopted", ctypes.c_int32), ("seamBodiesAdded", ctypes.c_int32), ("roundsOpened", ctypes.c_int32),
+        ("bodiesAdopted", ctypes.c_int32), ("seamBodiesAdded", ctypes.c_int32), ("roundsOpened", ctypes.c_int32), ("nearHandoffTimeouts", ctypes.c_int32),
     ]
 
 

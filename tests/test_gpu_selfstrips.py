@@ -137,6 +137,7 @@ def test_a_dead_hand_off_under_async_drops_the_steps_behind_it():
             s.set_option(k, v)
         want = resident_vs_oracle(s, TGS, pre, 3, "before the fault", 1)
         s.set_option("persist_debug", 8)
+        s.set_option("near_handoff", 0)  # (with the same-XCD path on, the first time-out only switches that off: test_gpu_strips.py)
         s.set_option("async", 1)
         for _ in range(3):
             s.step_resident(TGS)

@@ -525,6 +525,7 @@ def test_a_dead_hand_off_under_async_is_reported_and_the_solver_recovers():
         s.set_option("strip_patience", 0)
         s.set_option("persist_spin_limit", 4096)
         s.set_option("persist_debug", 8)
+        s.set_option("near_handoff", 0)  # (with the same-XCD path on, the first time-out only switches that off: the test below)
         s.set_option("async", 1)
         s.upload(*pre)
         for _ in range(3):
@@ -916,3 +917,55 @@ def test_two_boxes_of_neighbouring_strips_that_never_faced_each_other():
                 assert st["structureBuilds"] == builds and st["persistent"] == 1 and st["seamBodiesAdded"] == 2, st
             else:
                 assert st["structureBuilds"] > builds, st
+
+
+def test_a_time_out_on_the_same_xcd_hand_off_path_first_costs_only_that_path():
+    """persist_handoff.h: putGranuleNear hands bodies to a neighbour on the same XCD with workgroup-scope stores -- an assumption about
+    the cache hierarchy, checked by a census every launch, that the memory model does not promise.  When a hand-off times out while
+    that path is in use, the step is tried again on the SAME one-launch kernel with agent-scope stores everywhere (stats
+    nearHandoffTimeouts); only a second time-out puts the solver on the multi-launch path.  With the fault injected (workgroup 1 never
+    publishes) both happen in one synchronous step; under "async" the first s2amd_synchronize reports the one, the second the other.
+    Every result bit-exact; option near_handoff 0 never uses the path."""
+    pre = synthetic.pyramid(100)
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
+        s.set_option("persist_spin_limit", 4096)
+        s.set_option("persist_debug", 8)
+        state = gpu_vs_oracle(s, params, pre, "near path: the fault, synchronous")
+        st = s.stats()
+        assert st["nearHandoffTimeouts"] == 1 and st["persistFallbacks"] == 1 and st["persistent"] == 0, st
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
+        s.set_option("persist_spin_limit", 4096)
+        s.set_option("persist_debug", 8)
+        s.set_option("async", 1)
+        s.upload(*pre)
+        s.step_resident(params)
+        with pytest.raises(hip.S2AmdError):
+            s.synchronize()
+        st = s.stats()
+        assert st["nearHandoffTimeouts"] == 1 and st["persistFallbacks"] == 0, st
+        s.step_resident(params)  # the repeated step: the one-launch kernel again, agent-scope stores -- and the injected fault again
+        with pytest.raises(hip.S2AmdError):
+            s.synchronize()
+        assert s.stats()["persistFallbacks"] == 1
+        want = common.copy3(pre)
+        s.step_resident(params)
+        s.synchronize()
+        order, _ = s.contact_order()
+        oraclebind.solve(params, *want, contact_order=order)
+        got = common.copy3(pre)
+        s.download(*got)
+        common.compare_exact(got, want, "near path: the step repeated twice")
+    results = []
+    for near in (1, 0):  # ... and without a fault the two ways of handing off give the same bits
+        with hip.Solver(0) as s:
+            s.set_option("strip_patience", 0)
+            s.set_option("near_handoff", near)
+            state = common.copy3(pre)
+            for step in range(3):
+                state = gpu_vs_oracle(s, params, state, "near_handoff %d step %d" % (near, step))
+            assert s.stats()["persistent"] == 1 and s.stats()["nearHandoffTimeouts"] == 0
+            results.append(state)
+    common.compare_exact(results[0], results[1], "near_handoff 1 vs 0")

@@ -663,7 +663,30 @@ static bool removeEntry(s2amdSolver* s, Patcher& p, int slot)
 	const int bi = inc.colorOfPosition[(size_t)kOld];
 	if (bi < 0)
 	{
-		return false; // in the sequential tail
+		// in the sequential tail: a free position again when the tail is laid out with slack (IncrementalGlobal::tailFree)
+		if (kOld < inc.tailBegin || kOld >= inc.tailEnd || inc.tailBodyCapacity == 0)
+		{
+			return false;
+		}
+		const int oa = s->hContactA[(size_t)slot], ob = s->hContactB[(size_t)slot];
+		for (int side = 0; side < 2; ++side)
+		{
+			const int body = side == 0 ? oa : ob;
+			if (body >= 0 && body < (int)s->hBodyFlags.size() && writable(s, body))
+			{
+				adjRemove(p, body, (kOld << 1) | side);
+			}
+		}
+		s->contacts.order[(size_t)kOld] = -1;
+		s->contacts.local[(size_t)kOld] = make_int2(0, 0);
+		p.word(s->dContactIndex.p, (size_t)kOld, (uint32_t)-1);
+		p.word(s->dContactLocal.p, 2 * (size_t)kOld, 0u);
+		p.word(s->dContactLocal.p, 2 * (size_t)kOld + 1, 0u);
+		inc.tailFree.insert(std::upper_bound(inc.tailFree.begin(), inc.tailFree.end(), kOld, std::greater<int>()), kOld); // stays descending
+		inc.positionOfSlot[(size_t)slot] = -1;
+		inc.removed += 1;
+		s->slackPositions += 1;
+		return true;
 	}
 	const int cid = inc.colorIdOfBatch[(size_t)bi];
 	const int oa = s->hContactA[(size_t)slot], ob = s->hContactB[(size_t)slot]; // the endpoints the structure knows
@@ -786,6 +809,57 @@ bool incrementalApply(s2amdSolver* s, const std::vector<ContactChange>& changes)
 				break;
 			}
 		}
+		if (chosen < 0 && !inc.ignoreColours && !inc.tailFree.empty())
+		{
+			// no parallel colour is free on these bodies (a contact of a hub: it uses every one): the sequential tail takes it -- the
+			// lowest free position behind its constraints; a body the tail does not stage yet joins its body list
+			int local[2] = {0, 0};
+			int fresh = 0;
+			for (int side = 0; side < 2; ++side)
+			{
+				const int body = side == 0 ? ch.a : ch.b;
+				const auto it = inc.tailBodySlot.find(body);
+				local[side] = it != inc.tailBodySlot.end() ? it->second : inc.tailBodyCount + fresh++;
+			}
+			if (inc.tailBodyCount + fresh <= inc.tailBodyCapacity && s->dContactTail.view.groupCount == 1)
+			{
+				for (int side = 0; side < 2; ++side)
+				{
+					const int body = side == 0 ? ch.a : ch.b;
+					if (inc.tailBodySlot.find(body) == inc.tailBodySlot.end())
+					{
+						const bool w = side == 0 ? wa : wb;
+						inc.tailBodySlot[body] = local[side];
+						p.word(s->dContactTail.view.bodyIds, (size_t)local[side], (uint32_t)body | (w ? S2G_OWNED : 0u));
+					}
+				}
+				if (fresh > 0)
+				{
+					inc.tailBodyCount += fresh;
+					p.word(s->dContactTail.view.bodyOffsets, 1, (uint32_t)inc.tailBodyCount);
+				}
+				const int k = inc.tailFree.back();
+				inc.tailFree.pop_back();
+				cs.order[(size_t)k] = ch.slot;
+				cs.local[(size_t)k] = make_int2(local[0], local[1]);
+				inc.positionOfSlot[(size_t)ch.slot] = k;
+				p.word(s->dContactIndex.p, (size_t)k, (uint32_t)ch.slot);
+				p.word(s->dContactLocal.p, 2 * (size_t)k, (uint32_t)local[0]);
+				p.word(s->dContactLocal.p, 2 * (size_t)k + 1, (uint32_t)local[1]);
+				if ((wa && !adjInsert(p, ch.a, (k << 1) | 0)) || (wb && !adjInsert(p, ch.b, (k << 1) | 1)))
+				{
+					s->slackShift = std::min(s->slackShift + 1, 3);
+					s->slackBumped = true;
+					return giveUp("incidence list full");
+				}
+				inc.inserted += 1;
+				inc.tailPlaced += 1;
+				s->placedTotal += 1;
+				s->slackPositions -= 1;
+				unwatchSlot(s, ch.slot);
+				continue;
+			}
+		}
 		if (chosen < 0)
 		{
 			bool anyFree = false;
@@ -800,7 +874,10 @@ bool incrementalApply(s2amdSolver* s, const std::vector<ContactChange>& changes)
 				s->slackBumped = true;
 				return giveUp("no free position");
 			}
-			s->spareColours = 2; // every colour batch is taken on these bodies: the rebuild adds empty ones for the next such contact
+			// every colour batch is taken on these bodies: the rebuild adds empty ones for the next such contact.  (Twice as many
+			// every time -- up to 16 -- was measured on the Tumbler filled from scratch, r4: fewer rebuilds, 57 instead of 67 of 120
+			// steps, but every spare colour in use is a launch per sweep: 287 instead of 257 launches per step, no faster.)
+			s->spareColours = 2;
 			return giveUp("no free colour");
 		}
 		if ((int)inc.freePositions[(size_t)chosen].size() == inc.batchEnd[(size_t)chosen] - inc.batchBegin[(size_t)chosen])
@@ -931,6 +1008,16 @@ bool stripCanPlace(const s2amdSolver* s, int a, int b)
 	}
 	int table, group, la, lb, mover = -1;
 	return stripHome(s, a, b, table, group, la, lb, &mover);
+}
+
+bool tailCanPlace(const s2amdSolver* s, int a, int b)
+{
+	const int nb = (int)s->hBodyFlagsFinal.size();
+	if (!s->inc.valid || s->inc.ignoreColours || s->inc.tailFree.empty() || s->optIncremental == 0 || s->structureDirty || a < 0 || b < 0 || a >= nb || b >= nb || a == b)
+	{
+		return false;
+	}
+	return ((s->hBodyFlagsFinal[(size_t)a] | s->hBodyFlagsFinal[(size_t)b]) & S2F_IN_GROUP) == 0;
 }
 
 void deferCreated(s2amdSolver* s, int slot, int a, int b)

@@ -192,6 +192,16 @@ struct IncrementalGlobal
 	std::vector<int> heavy;				// [0] = count, then body slots; size = capacity + 1
 	// patch list of the current call: {address lo, address hi, value, 0}
 	std::vector<uint4> patches;
+	// The sequential tail (the hubs' constraints and the tiny colours: one workgroup stages the bodies they touch and walks them in
+	// order -- group_kernel.hip: walkTail) takes created contacts too: it ends in S2_TAIL_SLACK free positions, and a contact for
+	// which no parallel colour is free (a contact of the Tumbler's drum: the drum uses every one) takes the lowest of them -- any
+	// position of a sequential sweep is a valid one.  A body the tail does not stage yet is appended to its body list
+	// (S2_TAIL_BODY_SLACK more fit its LDS and its table).  Entries of the tail can be removed like any other.
+	int tailBegin = 0, tailEnd = 0;				// positions of the tail, slack included (0, 0: no tail)
+	std::vector<int> tailFree;					// descending: pop_back() hands out the lowest
+	std::unordered_map<int, int> tailBodySlot;	// body -> local slot in the tail's body list
+	int tailBodyCount = 0, tailBodyCapacity = 0;
+	long tailPlaced = 0;
 	long inserted = 0, removed = 0, fallbacks = 0;
 	bool placedInGlobalPart = false; // the last incrementalApply put something into a colour batch of the global part (not only into strips)
 };
@@ -246,6 +256,8 @@ struct IncrementalStrips
 	long seamBodiesAdded = 0;
 };
 #define S2_STRIP_ADOPT_SLACK 8
+#define S2_TAIL_SLACK 64
+#define S2_TAIL_BODY_SLACK 32
 
 // What a STRUCTURE BUILD produces and the incremental placement keeps up to date: the host's picture of the constraint graph as the
 // structure knows it, every table derived from it and their device copies, the SoA families (carved per structure), the captured step
@@ -621,6 +633,8 @@ void deferCreated(s2amdSolver* s, int slot, int a, int b);
 void unwatchSlot(s2amdSolver* s, int slot);
 int uploadWatched(s2amdSolver* s);
 bool stripCanPlace(const s2amdSolver* s, int a, int b);
+// ... or, between two bodies of the global part, a colour position or a free position of the sequential tail (IncrementalGlobal::tailFree)?
+bool tailCanPlace(const s2amdSolver* s, int a, int b);
 bool incrementalApply(s2amdSolver* s, const std::vector<ContactChange>& changes);
 // Destroyed contacts give their place back (colour, position, list entries) where the entry is in the global part's
 // parallel batches; elsewhere (LDS group, strip, sequential tail) the entry lingers as a no-op until the next rebuild.

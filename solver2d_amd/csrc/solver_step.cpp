@@ -119,6 +119,9 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 	// ... and under the soft contact solvers' strips a flipped manifold takes a free position of a strip or seam round where it fits
 	const bool stripFlips = s->inc.valid && s->stripInc.valid && s->optIncremental != 0 && !s->structureDirty && !newWorld;
 	bool hubTouched = false;			// something happened to a contact on a hub body: decided by a rebuild
+	auto onHub = [&](int a, int b) {
+		return !s->hBodyHub.empty() && (int)s->hBodyHub.size() == nb && a >= 0 && b >= 0 && a < nb && b < nb && (s->hBodyHub[(size_t)a] || s->hBodyHub[(size_t)b]);
+	};
 	for (int i = 0; i < nc; ++i)
 	{
 		const s2amdContact& c = contacts[i];
@@ -156,7 +159,7 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 			deferred.push_back(ContactChange{i, c.bodyA, c.bodyB});
 			continue;
 		}
-		if (edge && pc > 0 && (placeFlips || (stripFlips && stripCanPlace(s, c.bodyA, c.bodyB))) &&
+		if (edge && pc > 0 && (placeFlips || (stripFlips && stripCanPlace(s, c.bodyA, c.bodyB)) || (!newWorld && onHub(c.bodyA, c.bodyB) && tailCanPlace(s, c.bodyA, c.bodyB))) &&
 			(!s->hContactEdge[i] || s->hContactA[i] != c.bodyA || s->hContactB[i] != c.bodyB) && canDeferCreated(s, i, c.bodyA, c.bodyB))
 		{
 			// created AND touching at first sight (the caller ran stage 3 itself): the world chain, which sees the contact created
@@ -175,7 +178,7 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 		if (edge && !s->hContactWatched.empty() && s->hContactWatched[(size_t)i] && (oldPoints > 0) != (pc > 0))
 		{
 			// a watched manifold (on a hub body, or deferred) gained or lost its points (solver_internal.h: hContactWatched)
-			if (placeFlips || (stripFlips && stripCanPlace(s, c.bodyA, c.bodyB)))
+			if (placeFlips || (stripFlips && stripCanPlace(s, c.bodyA, c.bodyB)) || (!newWorld && tailCanPlace(s, c.bodyA, c.bodyB)))
 			{
 				if (pc > 0 && i < (int)s->inc.positionOfSlot.size() && s->inc.positionOfSlot[(size_t)i] == -1)
 				{

@@ -280,7 +280,10 @@ void colourPart(const std::vector<int>& ids, const std::vector<int>& ea, const s
 			set.colorOffsets.push_back(base + begin + cap);
 		}
 		batchOffsetsOut.push_back(base + (int)laidOut.size());
-		for (int c = parallel; c < cc; ++c) // the sequential tail: colour by colour, no slack
+		inc->tailBegin = inc->tailEnd = 0;
+		inc->tailFree.clear();
+		const int tailStart = (int)laidOut.size();
+		for (int c = parallel; c < cc; ++c) // the sequential tail: colour by colour
 		{
 			laidOut.insert(laidOut.end(), partOrder.begin() + partOffsets[c], partOrder.begin() + partOffsets[(size_t)c + 1]);
 			if (partOffsets[(size_t)c + 1] > partOffsets[c])
@@ -290,6 +293,22 @@ void colourPart(const std::vector<int>& ids, const std::vector<int>& ea, const s
 		}
 		if (hasTailOut)
 		{
+			// ... and behind them free positions for created contacts no parallel colour can take (IncrementalGlobal::tailFree)
+			const int first = (int)laidOut.size();
+			laidOut.resize(laidOut.size() + (size_t)S2_TAIL_SLACK, -1);
+			inc->tailBegin = base + tailStart, inc->tailEnd = base + (int)laidOut.size();
+			for (int k = (int)laidOut.size() - 1; k >= first; --k)
+			{
+				inc->tailFree.push_back(base + k);
+			}
+			if (set.colorOffsets.back() > base + tailStart)
+			{
+				set.colorOffsets.back() = base + (int)laidOut.size();
+			}
+			else
+			{
+				set.colorOffsets.push_back(base + (int)laidOut.size());
+			}
 			batchOffsetsOut.push_back(base + (int)laidOut.size());
 		}
 		inc->colorOfPosition.resize((size_t)base + laidOut.size(), -1);
@@ -2103,10 +2122,18 @@ struct StructureBuild
 			for (int k = begin; k < end; ++k)
 			{
 				int p = pos[(size_t)k];
+				if (p < 0)
+				{
+					continue; // (a free position of the tail's slack: IncrementalGlobal::tailFree)
+				}
 				cs.local[(size_t)k] = make_int2(slots.get(a[p], bodies, conflict), slots.get(b[p], bodies, conflict));
 			}
-			if ((int)bodies.size() > 2800)
+			s->inc.tailBodySlot.clear();
+			s->inc.tailBodyCount = s->inc.tailBodyCapacity = 0;
+			if ((int)bodies.size() + S2_TAIL_BODY_SLACK > 2800)
 			{
+				s->inc.tailBegin = s->inc.tailEnd = 0;
+				s->inc.tailFree.clear();
 				// The tail's bodies do not fit one workgroup's LDS (160 KiB at 40-56 B per body): no sequential tail for
 				// this graph, its tiny colours are launched one by one like the others (a dense pool -- every pair whose fat
 				// boxes overlap is a potential constraint -- can put thousands of constraints into the tiny colours)
@@ -2128,8 +2155,24 @@ struct StructureBuild
 				t.cBatches.push_back(make_int4(begin, end, 1, 0));
 				t.cBatchOffsets = {0, 1};
 				t.jBatchOffsets = {0, 0};
-				t.maxBodies = (int)bodies.size();
+				const bool tailSlack = slack && !s->inc.tailFree.empty();
+				t.maxBodies = (int)bodies.size() + (tailSlack ? S2_TAIL_BODY_SLACK : 0); // (the launch's LDS: room for the bodies created contacts bring along)
+				if (tailSlack)
+				{
+					for (size_t i = 0; i < bodies.size(); ++i)
+					{
+						s->inc.tailBodySlot[(int)((uint32_t)bodies[i] & ~S2G_OWNED)] = (int)i;
+					}
+					s->inc.tailBodyCount = (int)bodies.size(), s->inc.tailBodyCapacity = (int)bodies.size() + S2_TAIL_BODY_SLACK;
+				}
 			}
+		}
+		else
+		{
+			s->inc.tailBegin = s->inc.tailEnd = 0;
+			s->inc.tailFree.clear();
+			s->inc.tailBodySlot.clear();
+			s->inc.tailBodyCount = s->inc.tailBodyCapacity = 0;
 		}
 		gather(je, jOf[0], ids, a, b);
 		colourPart(ids, a, b, conflict, nb, js, js.batchOffsets, js.hasTail, &pos);
@@ -2491,7 +2534,7 @@ struct StructureBuild
 			rebuild = true;
 			return S2AMD_OK;
 		}
-		if ((rc = uploadGroupTable(s, s->hGroups, s->dGroups)) != 0 || (rc = uploadGroupTable(s, s->hContactTail, s->dContactTail)) != 0 ||
+		if ((rc = uploadGroupTable(s, s->hGroups, s->dGroups)) != 0 || (rc = uploadGroupTable(s, s->hContactTail, s->dContactTail, s->hContactTail.count() > 0 ? (size_t)S2_TAIL_BODY_SLACK : 0)) != 0 ||
 			(rc = uploadGroupTable(s, s->hJointTail, s->dJointTail)) != 0 ||
 			(rc = uploadGroupTable(s, s->hStripA, s->dStripA, s->hStripA.count() > 0 ? (size_t)32 * (size_t)(s->hStripA.maxBodies + S2_STRIP_ADOPT_SLACK) : 0)) != 0 ||
 			(rc = uploadGroupTable(s, s->hStripB, s->dStripB)) != 0)

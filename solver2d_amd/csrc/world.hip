@@ -543,7 +543,11 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 			bool handled = false;
 			const bool jacobi = s->inc.valid && s->inc.ignoreColours && s->optIncremental != 0;
 			const bool strips = s->inc.valid && s->stripInc.valid && s->optIncremental != 0;
-			if (jacobi || strips)
+			// ... and (r4) a manifold between bodies of the global part takes a free colour position or, a hub's, a free position of
+			// the sequential tail (solver_internal.h: IncrementalGlobal::tailFree)
+			const bool tail = s->inc.valid && !s->inc.ignoreColours && !s->inc.tailFree.empty() && s->optIncremental != 0;
+			auto inGlobalPart = [&](int a, int b) { return tailCanPlace(s, a, b); };
+			if (jacobi || strips || tail)
 			{
 				if ((rcMid = fetchPointCounts(s)) != 0)
 				{
@@ -557,7 +561,8 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 						s->inc.positionOfSlot[(size_t)i] == -1)
 					{
 						flipped.push_back(ContactChange{i, s->hContactA[(size_t)i], s->hContactB[(size_t)i]});
-						placeable = placeable && (jacobi || stripCanPlace(s, s->hContactA[(size_t)i], s->hContactB[(size_t)i]));
+						placeable = placeable && (jacobi || inGlobalPart(s->hContactA[(size_t)i], s->hContactB[(size_t)i]) ||
+												  (strips && stripCanPlace(s, s->hContactA[(size_t)i], s->hContactB[(size_t)i])));
 					}
 				}
 				handled = placeable && (flipped.empty() || incrementalApply(s, flipped));

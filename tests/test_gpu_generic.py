@@ -206,6 +206,58 @@ def test_a_hub_body_keeps_its_island_off_the_strips(solver_name):
                 assert st["contactColors"] >= 60, st
 
 
+@pytest.mark.parametrize("solver_name", ["TGS_Soft", "PGS_NGS_Block"])
+def test_a_created_contact_of_a_hub_takes_a_place_in_the_sequential_tail(solver_name):
+    """A hub (60 boxes lean on one) uses every parallel colour of the global part and has the rest of its constraints in the
+    sequential tail.  A contact created on it finds no free colour: it takes a free position at the END of the tail
+    (IncrementalGlobal::tailFree: any position of a sequential sweep is a valid one), the box it touches joins the tail's body
+    list if the tail did not stage it yet -- no structure build.  Destroyed, it gives the position back; created again (another box)
+    it is placed again.  Every step against the oracle."""
+    bodies, contacts, joints = pile_with_joints(3, 36, 0)
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+    movable = np.flatnonzero(bodies["invMass"] > 0.0)
+    hub = int(movable[len(movable) // 2])
+    live = np.flatnonzero((contacts["bodyA"] >= 0) & (contacts["bodyA"] != hub) & (contacts["bodyB"] != hub) & (contacts["pointCount"] > 0))
+    picked = live[:: max(1, len(live) // 60)][:60]
+    contacts = contacts.copy()
+    contacts["bodyB"][picked] = hub
+    free = np.zeros(3, dtype=wire.contact_dtype)
+    free["bodyA"], free["bodyB"], free["constraintIndex"] = -1, -1, -1
+    contacts = np.concatenate([contacts, free])
+    spare = [len(contacts) - 3 + i for i in range(3)]
+    touching = set(contacts["bodyA"][contacts["bodyB"] == hub].tolist()) | set(contacts["bodyB"][contacts["bodyA"] == hub].tolist())
+    others = [int(b) for b in movable if int(b) != hub and int(b) not in touching]
+    template = int(picked[0])
+    with hip.Solver(0) as gpu:
+        gpu.set_option("strip_patience", 0)
+        gpu.set_option("max_group_bodies", 256)
+        gpu.set_option("strip_min_bodies", 0)
+        gpu.set_option("strip_bodies", 60)
+        state = (bodies, contacts, joints)
+        for step in range(2):
+            state = gpu_vs_oracle_loose(gpu, params, state, "hub tail warm-up %d" % step)
+        st = gpu.stats()
+        assert st["stripCount"] == 0 and st["contactColors"] >= 60, st
+        builds, placed = st["structureBuilds"], st["placedContacts"]
+        script = {0: ("create", spare[0], others[3]), 1: ("create", spare[1], others[40]), 3: ("destroy", spare[0], None), 4: ("create", spare[2], others[77]),
+                  5: ("create", spare[0], others[5])}
+        for step in range(7):
+            what = script.get(step)
+            if what and what[0] == "create":
+                state[1][what[1]] = state[1][template]
+                state[1][what[1]]["bodyA"], state[1][what[1]]["bodyB"] = what[2], hub
+                for p in range(2):
+                    state[1][what[1]]["points"][p]["normalImpulse"] = 0.0
+                    state[1][what[1]]["points"][p]["tangentImpulse"] = 0.0
+            elif what:
+                state[1][what[1]] = free[0]
+            state = gpu_vs_oracle_loose(gpu, params, state, "hub tail %s step %d" % (solver_name, step))
+            st = gpu.stats()
+            assert st["structureBuilds"] == builds, (step, st["structureBuilds"], builds)
+        assert gpu.stats()["placedContacts"] >= placed + 4, gpu.stats()
+
+
 @pytest.mark.parametrize("degree,want_strips", [(18, True), (30, False)])
 def test_the_hub_rule_is_a_cost_comparison(degree, want_strips):
     """Both sides of the threshold under the reference's default solver (the op interpreter takes strips of up to 32 colour rounds):

@@ -21,6 +21,12 @@
 // constraints in flight at once, no dependent L2 round trip left in the walk), then the lanes take turns in sweep order.
 // Bodies go through LDS, which one wave reads and writes in program order; the wavefront fence keeps the compiler from
 // moving a lane's LDS reads across the turn before it.  Same per-constraint arithmetic, same order as forBatches.
+// (r4) Only the lanes whose constraint HAS manifold points take a turn: a constraint without points writes no body (its record has the
+// write bits cleared), so leaving its turn out changes no bit -- and the tail now ends in free positions for created contacts
+// (IncrementalGlobal::tailFree: 64 empty records that cost a turn each before this) and holds the hubs' potential constraints.
+template <class R> S2_DEV auto tailLive(const R& r, int) -> decltype(r.h.pointCount, bool()) { return r.h.pointCount > 0; }
+template <class R> S2_DEV auto tailLive(const R& r, long) -> decltype(r.r.h.pointCount, bool()) { return r.r.h.pointCount > 0; }
+template <class R> S2_DEV bool tailLive(const R&, ...) { return true; }
 template <class R, class L, class F, class S> S2_DEV void walkTail(int begin, int end, L load, F compute, S store)
 {
 	if (threadIdx.x < 64)
@@ -31,8 +37,11 @@ template <class R, class L, class F, class S> S2_DEV void walkTail(int begin, in
 			const int k = base + lane;
 			const int n = min(64, end - base);
 			R r = load(min(k, end - 1));
-			for (int j = 0; j < n; ++j)
+			unsigned long long turns = __ballot(lane < n && tailLive(r, 0));
+			while (turns != 0ull)
 			{
+				const int j = __ffsll((long long)turns) - 1;
+				turns &= turns - 1ull;
 				if (lane == j)
 				{
 					compute(r, k);

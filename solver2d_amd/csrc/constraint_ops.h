@@ -536,6 +536,104 @@ S2_DEV void chainSoft(SoftRegs<KIND>& r, const SoftPre& pre, const ContactView& 
 	}
 }
 
+// chainSoft on explicit 2-vectors over the perpendicular anchors (wide_kernel.hip: chainWide's formulation -- crossSV(w, r) = w perp(r),
+// cross(r, P) = perp(r).x P.x + perp(r).y P.y, term for term the reference's products: (-a) b == -(a b), x - y == x + (-y) -- so that the
+// vector algebra is v_pk_mul_f32 / v_pk_add_f32 without moves).  For the sequential tail (group_kernel.hip: walkTail), where a turn is
+// ONE lane's instruction stream and nothing else runs: every instruction saved is four cycles of the hub's 238 x 24 visits per step.
+typedef float pk2 __attribute__((ext_vector_type(2)));
+S2_DEV float pkDot(pk2 a, pk2 b)
+{
+	const pk2 m = a * b;
+	return m.x + m.y;
+}
+S2_DEV float pkCross(pk2 perpR, pk2 P) // cross(r, P) = r.x P.y - r.y P.x = perp(r).y P.y + perp(r).x P.x
+{
+	const pk2 m = perpR * P;
+	return m.y + m.x;
+}
+// perp(rA), perp(rB) of a prepared constraint: what chainSoftPacked multiplies with (poses only: made with the prep, in every lane at once)
+struct SoftPerp
+{
+	pk2 pA[2], pB[2];
+};
+S2_DEV SoftPerp perpOf(const SoftPre& pre)
+{
+	SoftPerp q;
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		q.pA[j] = pk2{-pre.rA[j].y, pre.rA[j].x}, q.pB[j] = pk2{-pre.rB[j].y, pre.rB[j].x};
+	}
+	return q;
+}
+template <int KIND, class BA, int POINTS = 0> S2_DEV void chainSoftPacked(SoftRegs<KIND>& r, const SoftPre& pre, const SoftPerp& q, const BA& b)
+{
+	static_assert(KIND != SOFT_JACOBI, "the Jacobi pass writes per-constraint deltas: chainSoft");
+	const CHeader& h = r.h;
+	float4* par = r.par;
+	float2* imp = r.imp;
+	const float4 velA = b.getVel(h.ia), velB = b.getVel(h.ib);
+	pk2 vA = pk2{velA.x, velA.y}, vB = pk2{velB.x, velB.y};
+	float wA = velA.z, wB = velB.z;
+	const pk2 n = pk2{h.normal.x, h.normal.y};
+	const pk2 t = pk2{n.y, -n.x}; // rightPerp
+	const pk2 mA2 = pk2{h.mA, h.mA}, mB2 = pk2{h.mB, h.mB};
+	const float iA = h.iA, iB = h.iB;
+	float nImp[2], tImp[2];
+	const pk2* pA = q.pA;
+	const pk2* pB = q.pB;
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		if (POINTS == 2 || j < h.pointCount)
+		{
+			const pk2 vrB = vB + pk2{wB, wB} * pB[j];
+			const pk2 vrA = vA + pk2{wA, wA} * pA[j];
+			const float vn = pkDot(vrB - vrA, n);
+			const float old = imp[j].x;
+			float impulse = -par[j].y * pre.massScale[j] * (vn + pre.bias[j]) - pre.impulseScale[j] * old;
+			const float newImpulse = S2_MAXF(old + impulse, 0.0f);
+			impulse = newImpulse - old;
+			nImp[j] = newImpulse;
+			tImp[j] = imp[j].y;
+			const pk2 P = pk2{impulse, impulse} * n;
+			vA = vA - mA2 * P;
+			wA -= iA * pkCross(pA[j], P);
+			vB = vB + mB2 * P;
+			wB += iB * pkCross(pB[j], P);
+		}
+	}
+#pragma unroll
+	for (int j = 0; j < 2; ++j)
+	{
+		if (POINTS == 2 || j < h.pointCount)
+		{
+			const float tangentMass = par[j].z;
+			const pk2 vrB = vB + pk2{wB, wB} * pB[j];
+			const pk2 vrA = vA + pk2{wA, wA} * pA[j];
+			const float vt = pkDot(vrB - vrA, t);
+			float impulse = -tangentMass * vt;
+			const float maxFriction = h.friction * nImp[j];
+			const float newImpulse = S2_CLAMPF(tImp[j] + impulse, -maxFriction, maxFriction);
+			impulse = newImpulse - tImp[j];
+			const pk2 P = pk2{impulse, impulse} * t;
+			vA = vA - mA2 * P;
+			wA -= iA * pkCross(pA[j], P);
+			vB = vB + mB2 * P;
+			wB += iB * pkCross(pB[j], P);
+			imp[j] = make_float2(nImp[j], newImpulse);
+		}
+	}
+	if (h.writeA)
+	{
+		b.setVel(h.ia, make_float4(vA.x, vA.y, wA, 0.0f));
+	}
+	if (h.writeB)
+	{
+		b.setVel(h.ib, make_float4(vB.x, vB.y, wB, 0.0f));
+	}
+}
+
 // the arithmetic of one constraint: bodies read and written through `b`, impulses updated in `r`
 // POINTS == 2: the caller has checked that the constraint has two points (a wave-uniform fast path without
 // per-point exec masking); POINTS == 0: per-point guards on h.pointCount.

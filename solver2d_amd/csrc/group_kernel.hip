@@ -61,6 +61,7 @@ template <int KIND> struct TailSoft
 {
 	SoftRegs<KIND> r;
 	SoftPre pre;
+	SoftPerp perp;
 };
 
 // forBatches with the tail batches walked by walkTail
@@ -287,9 +288,10 @@ __global__ __launch_bounds__(THREADS) void groupKernel(ContactView c, JointView 
 									TailSoft<SOFT_TGS> t;
 									t.r = loadSoftB<SOFT_TGS>(c, lb, k);
 									t.pre = prepSoft<SOFT_TGS>(t.r, lb, op.inv_h, op.useBias); // poses only: every lane at once
+									t.perp = perpOf(t.pre);
 									return t;
 								},
-								[&](TailSoft<SOFT_TGS>& t, int k) { chainSoft<SOFT_TGS>(t.r, t.pre, c, lb, k); }, // velocities: lane after lane
+								[&](TailSoft<SOFT_TGS>& t, int) { chainSoftPacked<SOFT_TGS>(t.r, t.pre, t.perp, lb); }, // velocities: lane after lane
 								[&](const TailSoft<SOFT_TGS>& t, int k) { storeSoft<SOFT_TGS>(c, t.r, k); },
 								[&](int k) { solveContactsSoftOne<SOFT_TGS>(c, lb, op.inv_h, op.useBias, k); });
 						}
@@ -307,9 +309,10 @@ __global__ __launch_bounds__(THREADS) void groupKernel(ContactView c, JointView 
 									TailSoft<SOFT_PGS> t;
 									t.r = loadSoftB<SOFT_PGS>(c, lb, k);
 									t.pre = prepSoft<SOFT_PGS>(t.r, lb, op.inv_h, op.useBias); // poses only: every lane at once
+									t.perp = perpOf(t.pre);
 									return t;
 								},
-								[&](TailSoft<SOFT_PGS>& t, int k) { chainSoft<SOFT_PGS>(t.r, t.pre, c, lb, k); }, // velocities: lane after lane
+								[&](TailSoft<SOFT_PGS>& t, int) { chainSoftPacked<SOFT_PGS>(t.r, t.pre, t.perp, lb); }, // velocities: lane after lane
 								[&](const TailSoft<SOFT_PGS>& t, int k) { storeSoft<SOFT_PGS>(c, t.r, k); },
 								[&](int k) { solveContactsSoftOne<SOFT_PGS>(c, lb, op.inv_h, op.useBias, k); });
 						}
@@ -327,9 +330,10 @@ __global__ __launch_bounds__(THREADS) void groupKernel(ContactView c, JointView 
 									TailSoft<SOFT_FIXED> t;
 									t.r = loadSoftB<SOFT_FIXED>(c, lb, k);
 									t.pre = prepSoft<SOFT_FIXED>(t.r, lb, op.inv_h, op.useBias); // poses only: every lane at once
+									t.perp = perpOf(t.pre);
 									return t;
 								},
-								[&](TailSoft<SOFT_FIXED>& t, int k) { chainSoft<SOFT_FIXED>(t.r, t.pre, c, lb, k); }, // velocities: lane after lane
+								[&](TailSoft<SOFT_FIXED>& t, int) { chainSoftPacked<SOFT_FIXED>(t.r, t.pre, t.perp, lb); }, // velocities: lane after lane
 								[&](const TailSoft<SOFT_FIXED>& t, int k) { storeSoft<SOFT_FIXED>(c, t.r, k); },
 								[&](int k) { solveContactsSoftOne<SOFT_FIXED>(c, lb, op.inv_h, op.useBias, k); });
 						}

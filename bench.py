@@ -415,6 +415,24 @@ def whole_step_leg(device_index, base, vel, pos, settle, steps):
             "kernel_launches_per_solve": st["kernelLaunches"]}
 
 
+def churn_leg(device_index, base):
+    """SURVEY.md 8f row 4 as a number: the headline world while its graph changes -- heavy balls shot into the base-200 pyramid, 240 steps
+    of the whole loop a caller of the C-ABI runs (pair query -> s2CreateContact on the caller's pool -> s2amd_world_set_contacts ->
+    s2amd_world_step), contacts created and destroyed in every other step.  tools/churn_bench.py is the long form of this object."""
+    try:
+        from tools import churn_bench
+    except Exception as e:  # (tests/ is not importable: a stripped checkout)
+        return {"skipped": repr(e)}
+    d = churn_bench.run(churn_bench.Args(base=base, device=device_index))
+    return {"workload": d["world"] + ", s2_solverTGS_Soft 8/4, %d steps of the whole loop" % d["steps"], "steps": d["steps"],
+            "steps_with_created_or_destroyed_contacts": d["steps_with_created_or_destroyed_contacts"], "contacts_created": d["contacts_created"],
+            "contacts_destroyed": d["contacts_destroyed"], "steps_on_persistent_kernel": d["steps_on_persistent_kernel"],
+            "steps_that_built_a_structure": d["steps_that_rebuilt_the_structure"], "contacts_placed_without_rebuild": d["contacts_placed_without_rebuild"],
+            "churn_step_median_ms": d["churn_steps_median"]["step_ms"], "quiet_step_median_ms": d["quiet_steps_median"]["step_ms"],
+            "mean_step_ms": d["all_steps"]["step_ms"], "start_up_steps_ms": d["start_up_steps_ms"], "slowest_steps_ms": d["slowest_steps_ms"][:4],
+            "steps_over_1ms_after_start_up": d["steps_over_1ms"], "churn_step_median_parts_ms": {k: round(v, 4) for k, v in d["churn_steps_median"].items() if k != "launches"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -670,6 +688,7 @@ def main():
                 out["configs"] = {"3_tumbler": tumbler_leg(ranks.device_index, 10000, 120, 100),
                                   "4_joint_grid": joint_grid_leg(ranks.device_index, 100, 20),
                                   "5_one_gpu": {k: sharded[k] for k in ("value", "unit", "ms_per_step", "config", "roofline")}}
+                out["churn"] = churn_leg(ranks.device_index, args.base)
     if rank == 0:
         print(json.dumps(out))
     if distributed:

@@ -47,6 +47,10 @@ def test_single_gpu_line():
     assert d["configs"]["4_joint_grid"]["unit"] == "joint-iters/s" and d["configs"]["4_joint_grid"]["value"] > 0
     assert d["configs"]["3_tumbler"]["unit"] == "constraint-iters/s" and d["configs"]["3_tumbler"]["value"] > 0
     assert d["configs"]["3_tumbler"]["whole_loop_ms_per_step_tgs_soft"] > 0
+    # SURVEY.md 8f row 4 as a number: the headline world while balls plough through it (joining bodies placed: nearly every step on the persistent kernel)
+    ch = d["churn"]
+    assert ch["steps"] == 240 and ch["steps_with_created_or_destroyed_contacts"] > 60 and ch["steps_on_persistent_kernel"] >= 225, ch
+    assert ch["steps_that_built_a_structure"] <= 10 and 0 < ch["churn_step_median_ms"] < 2.0, ch
 
 
 def test_two_ranks_on_one_device():

@@ -51,7 +51,18 @@ def main():
     ap.add_argument("--solver", default="TGS_Soft")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE")
     ap.add_argument("--trace", action="store_true", help="one line per step on stderr")
-    a = ap.parse_args()
+    print(json.dumps(run(ap.parse_args())))
+
+
+class Args:
+    """run()'s arguments for a caller that is not the command line (bench.py's `churn` object)."""
+
+    def __init__(self, **kw):
+        self.world, self.count, self.base, self.seed, self.steps, self.solver, self.opt, self.trace, self.device = "wreck", 10000, 200, 3, 240, "TGS_Soft", [], False, 0
+        self.__dict__.update(kw)
+
+
+def run(a):
     vel, pos = common.DEFAULT_ITERS[a.solver]
     params = wire.StepParams.make(a.solver, 1.0 / 60.0, vel, pos, True)
     if a.world == "tumbler":
@@ -61,7 +72,7 @@ def main():
         world = world_chain.wreck_world(a.seed, a.base)
     free = sorted(np.flatnonzero(world["pairs"]["shapeA"] < 0).tolist(), reverse=True)
     rows = []
-    with hip.Solver(0) as s:
+    with hip.Solver(getattr(a, "device", 0)) as s:
         for kv in a.opt:
             k, v = kv.split("=")
             s.set_option(k, int(v))
@@ -126,7 +137,7 @@ def main():
            "start_up_steps_ms": [round(r["step_ms"], 3) for r in rows[:2]],
            "slowest_steps_ms": sorted((round(r["step_ms"], 3) for r in rows[2:]), reverse=True)[:8],
            "active_contacts_last": rows[-1]["active"]}
-    print(json.dumps(out))
+    return out
 
 
 if __name__ == "__main__":

@@ -160,6 +160,7 @@ void s2amd_destroy(s2amdSolver* s)
 	}
 	(void)hipSetDevice(s->device);
 	asyncShutdown(s); // (a worker thread may still be building on a copy of this solver)
+	devPoolDrain();	  // (what the copies gave back: solver_internal.h: DevBuf)
 	(void)hipStreamSynchronize(s->stream);
 	destroyGraph(s);
 	for (hipEvent_t e : s->sweepEvents)

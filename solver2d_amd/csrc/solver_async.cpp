@@ -16,7 +16,142 @@
 #include "solver_internal.h"
 
 #include <atomic>
+#include <mutex>
 #include <thread>
+
+// ---- the worker threads' device-memory pool (solver_internal.h: DevBuf) ----
+namespace
+{
+struct DevPool
+{
+	std::mutex m;
+	std::vector<std::pair<void*, size_t>> blocks;
+	size_t bytes = 0;
+	std::vector<hipStream_t> streams;
+	std::vector<std::pair<void*, size_t>> pinned;
+};
+DevPool& devPool()
+{
+	static DevPool pool;
+	return pool;
+}
+thread_local bool tlsDevPool = false;
+constexpr size_t kDevPoolLimit = size_t(1) << 30; // what the pool keeps at most; a block beyond that is freed as ever
+} // namespace
+
+void devPoolThread(bool on) { tlsDevPool = on; }
+bool devPoolOn() { return tlsDevPool; }
+void* devPoolTake(size_t need, size_t* got)
+{
+	DevPool& pool = devPool();
+	std::lock_guard<std::mutex> lock(pool.m);
+	int best = -1;
+	for (int i = 0; i < (int)pool.blocks.size(); ++i)
+	{
+		const size_t b = pool.blocks[(size_t)i].second;
+		if (b >= need && b <= 4 * need + (size_t(1) << 16) && (best < 0 || b < pool.blocks[(size_t)best].second))
+		{
+			best = i;
+		}
+	}
+	if (best < 0)
+	{
+		return nullptr;
+	}
+	void* p = pool.blocks[(size_t)best].first;
+	*got = pool.blocks[(size_t)best].second;
+	pool.bytes -= *got;
+	pool.blocks.erase(pool.blocks.begin() + best);
+	return p;
+}
+bool devPoolGive(void* p, size_t bytes)
+{
+	DevPool& pool = devPool();
+	std::lock_guard<std::mutex> lock(pool.m);
+	if (pool.bytes + bytes > kDevPoolLimit)
+	{
+		return false;
+	}
+	pool.blocks.emplace_back(p, bytes);
+	pool.bytes += bytes;
+	return true;
+}
+void devPoolDrain()
+{
+	DevPool& pool = devPool();
+	std::vector<std::pair<void*, size_t>> blocks, pinned;
+	std::vector<hipStream_t> streams;
+	{
+		std::lock_guard<std::mutex> lock(pool.m);
+		blocks.swap(pool.blocks);
+		pinned.swap(pool.pinned);
+		streams.swap(pool.streams);
+		pool.bytes = 0;
+	}
+	for (const auto& b : blocks)
+	{
+		(void)hipFree(b.first);
+	}
+	for (const auto& b : pinned)
+	{
+		(void)hipHostFree(b.first);
+	}
+	for (hipStream_t st : streams)
+	{
+		(void)hipStreamDestroy(st);
+	}
+}
+hipStream_t workerStreamTake()
+{
+	DevPool& pool = devPool();
+	{
+		std::lock_guard<std::mutex> lock(pool.m);
+		if (!pool.streams.empty())
+		{
+			hipStream_t st = pool.streams.back();
+			pool.streams.pop_back();
+			return st;
+		}
+	}
+	hipStream_t st = nullptr;
+	if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess)
+	{
+		(void)hipGetLastError();
+		return nullptr;
+	}
+	return st;
+}
+void workerStreamGive(hipStream_t st)
+{
+	if (st)
+	{
+		DevPool& pool = devPool();
+		std::lock_guard<std::mutex> lock(pool.m);
+		pool.streams.push_back(st);
+	}
+}
+void* pinnedPoolTake(size_t need, size_t* got)
+{
+	DevPool& pool = devPool();
+	std::lock_guard<std::mutex> lock(pool.m);
+	for (size_t i = 0; i < pool.pinned.size(); ++i)
+	{
+		if (pool.pinned[i].second >= need)
+		{
+			void* p = pool.pinned[i].first;
+			*got = pool.pinned[i].second;
+			pool.pinned.erase(pool.pinned.begin() + (long)i);
+			return p;
+		}
+	}
+	return nullptr;
+}
+void pinnedPoolGive(void* p, size_t bytes)
+{
+	DevPool& pool = devPool();
+	std::lock_guard<std::mutex> lock(pool.m);
+	pool.pinned.emplace_back(p, bytes);
+}
 
 struct AsyncBuild
 {
@@ -27,6 +162,7 @@ struct AsyncBuild
 	int solverType = 0;
 	bool search = false;   // the search over strip widths (buildStructure with the graph at rest), not only the strip structure
 	bool dropped = false;  // overtaken by the graph: the result is thrown away when the worker is done
+	std::atomic<int> cancel{0}; // ... and the worker is told: a search stops after the build it is in (SolverRest::cancelBuild)
 	long requestedAtStep = 0;
 	struct Event
 	{
@@ -89,8 +225,16 @@ void releaseDeviceState(s2amdSolver* c)
 	}
 	if (t.hostPatches)
 	{
-		(void)hipHostFree(t.hostPatches);
+		if (devPoolOn())
+		{
+			pinnedPoolGive(t.hostPatches, t.hostPatchCapacity * sizeof(uint4));
+		}
+		else
+		{
+			(void)hipHostFree(t.hostPatches);
+		}
 		t.hostPatches = nullptr;
+		t.hostPatchCapacity = 0;
 	}
 }
 
@@ -102,15 +246,14 @@ void destroyClone(s2amdSolver* c)
 		return;
 	}
 	releaseDeviceState(c);
-	if (c->stream)
-	{
-		(void)hipStreamDestroy(c->stream);
-	}
+	workerStreamGive(c->stream); // (synchronised above; kept for the next copy: creating and destroying streams stalls every thread's HIP calls)
+	c->stream = nullptr;
 	delete c;
 }
 
 void workerMain(AsyncBuild* job)
 {
+	devPoolThread(true);
 	s2amdSolver* c = job->clone;
 	int rc = S2AMD_OK;
 	if (hipSetDevice(c->device) != hipSuccess)
@@ -145,13 +288,37 @@ void reap(AsyncBuild*& list, bool wait)
 	while (*at)
 	{
 		AsyncBuild* j = *at;
+		if (!wait && j->dropped && j->done.load(std::memory_order_acquire) && j->clone != nullptr)
+		{
+			// a dropped build whose worker is done: its copy is taken apart by a thread of its own (stream, pinned buffer, graph,
+			// megabytes of host vectors: 3 ms on the stepping thread, measured) and the job is reaped once that is over
+			if (j->worker.joinable())
+			{
+				j->worker.join();
+			}
+			j->done.store(0, std::memory_order_release);
+			j->worker = std::thread([j]() {
+				devPoolThread(true);
+				destroyClone(j->clone);
+				j->clone = nullptr;
+				j->done.store(1, std::memory_order_release);
+			});
+			at = &j->older;
+			continue;
+		}
 		if (wait || (j->dropped && j->done.load(std::memory_order_acquire)))
 		{
 			if (j->worker.joinable())
 			{
 				j->worker.join();
 			}
-			destroyClone(j->clone);
+			{
+				// (the caller's thread: the copy's device memory goes to the workers' pool, not through hipFree -- DevBuf)
+				const bool was = devPoolOn();
+				devPoolThread(true);
+				destroyClone(j->clone);
+				devPoolThread(was);
+			}
 			*at = j->older;
 			delete j;
 		}
@@ -180,6 +347,7 @@ void asyncDrop(s2amdSolver* s)
 	if (s->async && !s->async->dropped)
 	{
 		s->async->dropped = true;
+		s->async->cancel.store(1, std::memory_order_relaxed);
 		s->async->log.clear();
 	}
 }
@@ -255,7 +423,8 @@ int asyncRequest(s2amdSolver* s, int solverType, bool search)
 	c->hostTimes = nullptr;
 	c->sweepEvents.clear();
 	forgetDeviceState(*c);
-	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+	c->stream = workerStreamTake();
+	if (c->stream == nullptr)
 	{
 		delete c;
 		delete job;
@@ -266,6 +435,7 @@ int asyncRequest(s2amdSolver* s, int solverType, bool search)
 		c->stripRetryPending = false;
 	}
 	job->clone = c;
+	c->cancelBuild = &job->cancel;
 	job->solverType = solverType;
 	job->search = search;
 	job->requestedAtStep = s->stepCounter;
@@ -366,6 +536,12 @@ bool asyncAdopt(s2amdSolver* s, int solverType, int* rcOut)
 		if (score(c) <= score(s))
 		{
 			ok = false;
+			// (what the search learnt stays: the width it settled on -- its own first width when none was better -- keeps
+			// buildStructure from asking for another search while the partition is one the resident kernels take)
+			if (c->stripScaleFound > 0.0f && c->stripScaleFoundFor == s->stripScaleFoundFor)
+			{
+				s->stripScaleFound = c->stripScaleFound;
+			}
 		}
 		else
 		{
@@ -406,6 +582,7 @@ bool asyncAdopt(s2amdSolver* s, int solverType, int* rcOut)
 	job->dropped = true;
 	job->done.store(0, std::memory_order_release);
 	job->worker = std::thread([job]() {
+		devPoolThread(true);
 		destroyClone(job->clone);
 		job->clone = nullptr;
 		job->done.store(1, std::memory_order_release);

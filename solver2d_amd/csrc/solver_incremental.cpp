@@ -955,8 +955,18 @@ int incrementalFlush(s2amdSolver* s)
 			(void)hipHostFree(s->hostPatches);
 			s->hostPatches = nullptr;
 		}
-		const size_t cap = std::max<size_t>(2 * n, 4096);
-		HIP_TRY(hipHostMalloc((void**)&s->hostPatches, cap * sizeof(uint4), hipHostMallocDefault));
+		size_t cap = std::max<size_t>(2 * n, 4096);
+		size_t got = 0;
+		void* pooled = devPoolOn() ? pinnedPoolTake(cap * sizeof(uint4), &got) : nullptr; // (a worker's copy: solver_internal.h)
+		if (pooled)
+		{
+			s->hostPatches = (uint4*)pooled;
+			cap = got / sizeof(uint4);
+		}
+		else
+		{
+			HIP_TRY(hipHostMalloc((void**)&s->hostPatches, cap * sizeof(uint4), hipHostMallocDefault));
+		}
 		s->hostPatchCapacity = cap;
 	}
 	else

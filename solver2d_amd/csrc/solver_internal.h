@@ -52,6 +52,22 @@ inline int fail(int code, const std::string& msg) { return s2amdFail(code, msg);
 
 double nowMs();
 
+// Device memory of the worker threads (solver_async.cpp).  hipMalloc and hipFree synchronise the device and serialise with every
+// other HIP call of the process: a worker that builds seven structures on a copy of the solver -- some twenty allocations each -- and
+// the thread that frees the copy afterwards stalled the stepping thread for 4 ms at a time (measured: wreck-200, the step after a
+// search was dropped).  So on those threads (devPoolThread(true)) a DevBuf takes its memory from a pool of blocks earlier copies
+// have given back and returns it there; the stepping thread allocates and frees as ever.  The pool is emptied by s2amd_destroy.
+// (the same for the copies' streams and pinned staging buffers: creating and destroying those stalls the stepping thread as well)
+hipStream_t workerStreamTake();
+void workerStreamGive(hipStream_t s);
+void* pinnedPoolTake(size_t need, size_t* got);
+void pinnedPoolGive(void* p, size_t bytes);
+void devPoolThread(bool on);
+bool devPoolOn();
+void* devPoolTake(size_t need, size_t* got);
+bool devPoolGive(void* p, size_t bytes);
+void devPoolDrain();
+
 // growable raw device allocation
 struct DevBuf
 {
@@ -67,8 +83,20 @@ struct DevBuf
 		size_t want = std::max(need, bytes + bytes / 2);
 		want = (want + 255) & ~size_t(255);
 		void* np = nullptr;
-		HIP_TRY(hipMalloc(&np, want));
-		if (p)
+		if (devPoolOn())
+		{
+			size_t got = 0;
+			np = devPoolTake(want, &got);
+			if (np)
+			{
+				want = got;
+			}
+		}
+		if (!np)
+		{
+			HIP_TRY(hipMalloc(&np, want));
+		}
+		if (p && !(devPoolOn() && devPoolGive(p, bytes)))
 		{
 			(void)hipFree(p);
 		}
@@ -82,7 +110,7 @@ struct DevBuf
 	}
 	void release()
 	{
-		if (p)
+		if (p && !(devPoolOn() && devPoolGive(p, bytes)))
 		{
 			(void)hipFree(p);
 		}
@@ -521,6 +549,7 @@ struct SolverRest
 	// the search over strip widths (seven more builds, a copy of the solver for the worker): after a request the next one waits
 	// `stripSearchPause` steps, twice as long every time (a pile with a ball in it needs its seven rounds at any width, and a search
 	// the graph overtakes has found nothing either); a new world or a search whose result was better than what ran starts over
+	const void* cancelBuild = nullptr; // (a worker's copy) std::atomic<int>: set when the graph has overtaken the build -- the search over strip widths gives up
 	long stripSearchNotBefore = 0;
 	int stripSearchPause = 256;
 	int asyncRequested = 0, asyncAdopted = 0;

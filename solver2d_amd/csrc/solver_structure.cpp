@@ -2,6 +2,8 @@
 // device tables the kernels read (GroupTable, StripDesc, PersistDesc).  Rebuilt when the constraint graph changes.
 #include "solver_internal.h"
 
+#include <atomic>
+
 namespace
 {
 
@@ -2894,6 +2896,10 @@ int buildStructure(s2amdSolver* s, int solverType)
 	const float scales[] = {4.0f, 10.0f, 20.0f, 2.0f, 40.0f, 80.0f, 0.5f};
 	for (float scale : scales)
 	{
+		if (s->cancelBuild && static_cast<const std::atomic<int>*>(s->cancelBuild)->load(std::memory_order_relaxed) != 0)
+		{
+			return rc; // (a worker's copy whose result will be thrown away: solver_async.cpp)
+		}
 		s->structureDirty = true;
 		s->stripsRejected = false; // a width that fits no strip kernel says nothing about the next one
 		if ((rc = buildStructureWith(s, solverType, scale)) != S2AMD_OK)

@@ -476,6 +476,11 @@ int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapa
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	s->shapeCapacity = shapeCapacity;
 	s->worldResident = true;
+	if (s->optAsyncBuild != 0)
+	{
+		// (a stream for the first worker-thread build, made now while nothing is stepping: creating one later stalls the step that asks)
+		workerStreamGive(workerStreamTake());
+	}
 	return S2AMD_OK;
 }
 

@@ -23,3 +23,4 @@ timeout 600 python tools/solver_table.py --world joint_grid --base 100 --solvers
 timeout 600 python tools/config3_bench.py TGS_Soft > $OUT/r04_config3b_tumbler_tgs_soft.json 2> $OUT/config3b.err; head -c 700 $OUT/r04_config3b_tumbler_tgs_soft.json; echo
 timeout 1500 python bench.py > $OUT/r04_bench_final.json 2> $OUT/bench_final.err; python -c "
 import json; d=json.loads(open('$OUT/r04_bench_final.json').read().strip().splitlines()[-1]); print('bench ms/step %.4f value %.3e launches %d kernel_us %.1f frac %.3f cpu %.3e whole_step %.4f / %.4f c3 %.4f c4 %.4f c5 %.4f' % (d['ms_per_step'], d['value'], d['config']['kernel_launches_per_step'], d['roofline']['avg_launch_us'], d['roofline']['frac'], d['cpu_baseline']['value'], d['whole_step']['whole_step_ms'], d['whole_step']['whole_step_with_pair_query_ms'], d['configs']['3_tumbler']['ms_per_step'], d['configs']['4_joint_grid']['ms_per_step'], d['configs']['5_one_gpu']['ms_per_step']))"
+timeout 2400 python -m pytest tests -q -m gpu > $OUT/gpu_suite.log 2>&1; echo "gpu suite rc=$?"; tail -3 $OUT/gpu_suite.log | cut -c1-200

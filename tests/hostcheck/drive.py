@@ -269,6 +269,58 @@ def hub_rule():
     return counts
 
 
+def hub_tail_churn(solver_name, steps):
+    """Contacts created on and destroyed from a hub body (60 boxes lean on one: no strips, its constraints in the sequential tail):
+    they take the free positions behind the tail's constraints (IncrementalGlobal::tailFree), boxes the tail does not stage yet join its
+    body list; when the tail's slack is used up the structure is built again."""
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+    rng = np.random.default_rng(31)
+    bodies, contacts, joints = common.copy3(synthetic.pyramid(36))
+    dynamic = np.flatnonzero(bodies["type"] == wire.BODY_DYNAMIC)
+    hub = int(dynamic[len(dynamic) // 2])
+    live = np.flatnonzero((contacts["bodyA"] >= 0) & (contacts["bodyA"] != hub) & (contacts["bodyB"] != hub))
+    contacts["bodyB"][live[:: max(1, len(live) // 60)][:60]] = hub
+    spare_n = 160
+    pre = _with_spare_slots((bodies, contacts, joints), spare_n)
+    n0 = len(pre[1]) - spare_n
+    free_slot = np.zeros(1, dtype=wire.contact_dtype)[0]
+    free_slot["bodyA"], free_slot["bodyB"], free_slot["constraintIndex"] = -1, -1, -1
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0), s.set_option("max_group_bodies", 256), s.set_option("strip_min_bodies", 0), s.set_option("strip_bodies", 60)
+        state = common.copy3(pre)
+        s.solve(params, *state)
+        assert s.stats()["stripCount"] == 0
+        spare = list(range(n0, n0 + spare_n))
+        mine = []
+        most_placed = 0
+        for step in range(steps):
+            for _ in range(int(rng.integers(0, 5))):
+                if not spare:
+                    break
+                box = int(rng.choice(dynamic))
+                if box == hub:
+                    continue
+                slot = spare.pop(0)
+                new = pre[1][int(live[3])].copy()
+                new["bodyA"], new["bodyB"] = (box, hub) if rng.random() < 0.5 else (hub, box)
+                new["pointCount"] = int(rng.integers(0, 3))
+                state[1][slot] = new
+                mine.append(slot)
+            for slot in list(mine):
+                r = rng.random()
+                if r < 0.2:
+                    state[1][slot]["pointCount"] = int(rng.integers(0, 3))
+                elif r < 0.3:
+                    state[1][slot] = free_slot
+                    mine.remove(slot)
+                    spare.append(slot)
+            s.solve(params, *state)
+            s.contact_order()
+            most_placed = max(most_placed, s.stats()["placedContacts"])
+        return s.stats()["structureBuilds"], most_placed
+
+
 def main():
     quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
     n = fuzz_solves(6 if quick else 40)
@@ -289,6 +341,10 @@ def main():
         print("joining bodies %s: %d structure builds, %d contacts placed, at most %d bodies moved to another strip, %d added to a seam, %d spare rounds opened per structure" % ((name,) + got))
         assert got[2] >= 1, got
     print("hub rule: strips", hub_rule())
+    for name in ("TGS_Soft", "PGS_NGS_Block"):
+        builds, placed = hub_tail_churn(name, 10 if quick else 60)
+        print("hub tail churn %s: %d structure builds, %d contacts placed" % (name, builds, placed))
+        assert placed >= 3, (builds, placed)
     world_chain(20 if quick else 60, 3 if quick else 8)
     print("world chain ok")
     seen = world_chain_async(30, 24 if quick else 60)

@@ -1,5 +1,8 @@
+"""Bisecting tool: tests/test_gpu_world.py's wrecking-ball loop for one seed, every step compared with the oracle chain, stopping at
+the FIRST step that differs (with the placement counters of that step).  S2AMD_DEBUG_PLACE=1 shows what was placed where;
+S2AMD_OPTIONS=key=value,... switches features off.    python tools/wreck_first_difference.py [solver ...]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from solver2d_amd import hip, wire
 from tests import common, world_chain

@@ -77,3 +77,46 @@ def test_islands_on_reference_scene_with_joints():
     # static bodies are owned by no shard and keep their input state (the reference leaves them
     # untouched too); the kinematic platform is an island of its own and is integrated by its owner
     common.compare_exact(out, post, "sharded mixed scene vs reference")
+
+
+def test_sticky_partition_moves_only_the_smaller_part_of_a_merged_island():
+    """islands.sticky_partition (re-sharding): an island goes where most of its bodies were (ties: the lowest shard), an
+    island nobody owned goes to the least loaded shard, heaviest first -- integer work, checked exactly."""
+    from solver2d_amd import islands as isl
+    # five bodies of shard 0 and three of shard 1 are ONE island now (0); island 1 was all on shard 1; island 2 is new; island 3 a tie
+    island = np.array([0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 2, 2, 2, 3, 3, -1], dtype=np.int32)
+    previous = np.array([0, 0, 0, 0, 0, 1, 1, 1, 1, 1, -1, -1, -1, 0, 1, -1], dtype=np.int32)
+    weights = np.array([16, 4, 6, 2])
+    shard = isl.sticky_partition(island, 4, weights, previous, 2)
+    assert shard.tolist() == [0, 1, 1, 0]  # (island 2: shard 1 carries 4 against shard 0's 16 + 2)
+    # nobody owned anything: the plain longest-processing-time packing
+    fresh = isl.sticky_partition(island, 4, weights, np.full(len(island), -1, dtype=np.int32), 2)
+    assert fresh.tolist() == isl.partition(weights, 2).tolist()
+
+
+def test_shard_world_with_previous_owner_keeps_untouched_islands_in_place():
+    from solver2d_amd import islands as isl
+    world = synthetic.pyramid(5, count=6)
+    shards, island, first = isl.shard_world(*world, 3)
+    owner = np.full(len(world[0]), -1, dtype=np.int32)
+    for r, sh in enumerate(shards):
+        owner[sh.body_ids[sh.owned_body]] = r
+    # a contact between the top boxes of two islands that live on different shards
+    a_island, b_island = 0, next(i for i in range(len(first)) if first[i] != first[0])
+    a = int(np.flatnonzero(island == a_island)[-1])
+    b = int(np.flatnonzero(island == b_island)[-1])
+    c = world[1].copy()
+    extra = c[:1].copy()
+    extra["bodyA"], extra["bodyB"] = a, b
+    joined = np.concatenate([c, extra])
+    shards2, island2, second = isl.shard_world(world[0], joined, world[2], 3, previous_owner=owner)
+    owner2 = np.full(len(world[0]), -1, dtype=np.int32)
+    for r, sh in enumerate(shards2):
+        owner2[sh.body_ids[sh.owned_body]] = r
+    moved = np.flatnonzero((owner >= 0) & (owner != owner2))
+    assert len(moved) > 0 and set(island[moved].tolist()) <= {a_island, b_island}  # only bodies of the two merged islands moved ...
+    assert len(set(island[moved].tolist())) == 1  # ... and only ONE of the two
+    assert owner2[a] == owner2[b]
+    # every constraint lives on exactly one shard, pool order preserved
+    ids = np.sort(np.concatenate([sh.contact_ids for sh in shards2]))
+    assert np.array_equal(ids, np.flatnonzero(joined["pointCount"] > 0))

@@ -28,6 +28,9 @@ Extra objects on the JSON line:
                 are instruction-issue / latency bound, not bandwidth bound, and the line says so next to `roofline`.
   ranks_seen / devices   torch.distributed's world size and the PCI bus ids of the ranks' GPUs (all-gathered): `n_gpus` is
                 what was really there.  `--gpus N` without a launcher starts the N ranks itself (torch.distributed.run).
+  value_fast    (N = 1) the same headline loop on the tolerance-mode build libs2amd_fast.so (FMA contraction on; SURVEY.md 7: "report
+                both"): value, ms per step, its own dominant-kernel time and roofline fraction, and the distance from the bit-exact
+                build after 30 steps.  `value` / `roofline` on the line itself are always the bit-exact build's.
   cpu_baseline  the reference's own s2Solve_TGS_Soft timed on this host (oracle/_ref, kind
                 "reference") or, if that library is absent, the oracle port; 1 core.
   whole_step    (N = 1) the SURVEY.md 8d trajectory of config 2: the base-200 WORLD (shapes, pair states) resident, 60 settle
@@ -58,6 +61,15 @@ from solver2d_amd import hip, synthetic, wire  # noqa: E402
 
 ALGO_BYTES_PER_CONSTRAINT_SWEEP = 232.0
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: 8.0 TB/s spec
+PROFILE_ROUNDS = ("r05", "r04", "r03", "r02", "r01")  # committed rocprofv3 summaries, newest first
+# A committed counter pass describes the build it profiled.  It is quoted on the line only when the kernel it names is the kernel this
+# run launched AND its average duration there agrees with the live one within this fraction (counter passes run a few per cent slower
+# than plain ones); otherwise `traffic` / `issue` are null with the reason beside them.
+PMC_DURATION_TOLERANCE = 0.03
+
+
+def pmc_same_build(pass_us, live_us):
+    return live_us is None or (pass_us is not None and abs(pass_us - live_us) <= PMC_DURATION_TOLERANCE * live_us)
 
 
 def cpu_baseline(base, vel, pos, budget_s):
@@ -107,12 +119,12 @@ def cpu_baseline(base, vel, pos, budget_s):
 ISLAND_KERNELS = ("_Z16wideIslandKernel", "_Z16islandStepKernel")  # wide_kernel.hip (TGS_Soft), strip_kernel.hip (the general form)
 
 
-def pmc_issue(kernel_prefixes, stem="persistent"):
+def pmc_issue(kernel_prefixes, stem="persistent", live_us=None):
     """VALU-issue picture of the dominant kernel from the committed SQ pass (profiles/rNN_<stem>_pmc_sq.txt, rocprofv3 --pmc, its
     own run): VALU instructions per wave and the share of a SIMD's cycles in which it issues one -- a wave64 VALU instruction
     occupies its SIMD's issue for 4 cycles (tools/valu_bench.hip), a CU has 4 SIMDs, and the waves a CU hosts during the launch
     are the launch's waves over the CUs it occupies.  None when the summary is absent."""
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in PROFILE_ROUNDS:
         path = os.path.join(ROOT, "profiles", "%s_%s_pmc_sq.txt" % (rnd, stem))
         try:
             vals, calls, avg_ns = {}, None, None
@@ -124,6 +136,9 @@ def pmc_issue(kernel_prefixes, stem="persistent"):
                     elif calls is None and f[1].isdigit():
                         calls, avg_ns = int(f[1]), float(f[2])  # the kernel table: calls, average duration
             if "SQ_INSTS_VALU" in vals and "SQ_WAVES" in vals and calls:
+                if not pmc_same_build(avg_ns * 1e-3, live_us):
+                    return {"refused": "profiles/%s_%s_pmc_sq.txt is of another build: %.1f us per launch there, %.1f us live (> %d %% apart)" % (
+                        rnd, stem, avg_ns * 1e-3, live_us, round(100 * PMC_DURATION_TOLERANCE))}
                 instances = vals["SQ_WAVES"][0] / calls  # counter instances sampled per dispatch
                 waves = vals["SQ_WAVES"][1] * instances
                 per_wave = vals["SQ_INSTS_VALU"][1] / max(vals["SQ_WAVES"][1], 1e-9)
@@ -139,8 +154,8 @@ def pmc_issue(kernel_prefixes, stem="persistent"):
 
 def finish_issue(issue, workgroups):
     """CUs occupied and the per-SIMD VALU issue share, once the number of workgroups of the launch is known."""
-    if issue is None:
-        return None
+    if issue is None or "refused" in issue:
+        return issue
     cus = min(max(int(workgroups), 1), 256)
     cycles = issue.pop("_cycles")
     waves_per_cu = issue["waves_per_launch"] / cus
@@ -150,18 +165,24 @@ def finish_issue(issue, workgroups):
     return issue
 
 
-def pmc_traffic_bytes(kernel_prefix, stem="persistent"):
+def pmc_traffic_bytes(kernel_prefix, stem="persistent", live_us=None):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summaries (separate
     FETCH_SIZE / WRITE_SIZE passes of this same command, profiles/r01_persistent_pmc_*.txt): counters are in KiB;
     FETCH_SIZE is doubled per the gfx950 note in MI355X_MICROARCH.md (it reads half of a wide coalesced stream).
     None when the summaries are not there."""
     prefixes = kernel_prefix if isinstance(kernel_prefix, (tuple, list)) else (kernel_prefix,)
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in PROFILE_ROUNDS:
         total = 0.0
         try:
             for name, scale in (("fetch", 2.0), ("write", 1.0)):
                 path = os.path.join(ROOT, "profiles", "%s_%s_pmc_%s_size.txt" % (rnd, stem, name))
-                rows = [l.split() for l in open(path) if l.startswith(tuple(prefixes)) and ("FETCH_SIZE" in l or "WRITE_SIZE" in l)]
+                lines = [l.split() for l in open(path) if l.startswith(tuple(prefixes))]
+                rows = [f for f in lines if len(f) > 3 and f[1] in ("FETCH_SIZE", "WRITE_SIZE")]
+                table = [f for f in lines if len(f) > 3 and f[1].isdigit()]  # the kernel table of the same pass: calls, avg_ns
+                pass_us = float(table[0][2]) * 1e-3 if table else None
+                if not pmc_same_build(pass_us, live_us):
+                    return None, "refused: %s is of another build (%.1f us per launch there, %.1f us live, > %d %% apart)" % (
+                        os.path.relpath(path, ROOT), pass_us or 0.0, live_us, round(100 * PMC_DURATION_TOLERANCE))
                 total += scale * float(rows[0][3]) * 1024.0
             return total, "profiles/%s_%s_pmc_{fetch,write}_size.txt (rocprofv3 --pmc, separate passes of this command; not measured in this run)" % (rnd, stem)
         except (OSError, IndexError, ValueError):
@@ -216,7 +237,7 @@ def island_sharded_leg(ranks, islands, base, vel, pos, steps, warmup, graph=True
     sw = dsh.ShardedWorld(*world, rank=0 if weak else ranks.rank, world_size=1 if weak else ranks.world)
     gpu = hip.Solver(ranks.device_index, graph=graph)
     gpu.set_option("async", 1)
-    rs = dsh.ResidentShardedWorld(sw, gpu, ranks.torch, dist=ranks.dist, backend=ranks.backend, exchange_ranks=ranks.world)
+    rs = dsh.ResidentShardedWorld(sw, gpu, ranks.torch, dist=ranks.dist, backend=ranks.backend, exchange_ranks=ranks.world, exchange_rank=ranks.rank)
     rs.run(params, warmup)
     ranks.barrier_sync(gpu)
     t0 = time.perf_counter()
@@ -249,8 +270,8 @@ def island_sharded_leg(ranks, islands, base, vel, pos, steps, warmup, graph=True
                    "device_ms_per_step": st["deviceMs"], "graph_replay": bool(st["graphReplayed"]), "trajectory": "consecutive resident steps (no restore)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      # (the committed PMC passes are of the whole world on one GPU)
-                     "traffic": pmc_traffic_bytes(ISLAND_KERNELS, "config5")[0] if ranks.world == 1 and islands == 512 and base == 40 else None,
-                     "traffic_source": pmc_traffic_bytes(ISLAND_KERNELS, "config5")[1] if ranks.world == 1 and islands == 512 and base == 40 else None,
+                     "traffic": pmc_traffic_bytes(ISLAND_KERNELS, "config5", live_us=us)[0] if ranks.world == 1 and islands == 512 and base == 40 else None,
+                     "traffic_source": pmc_traffic_bytes(ISLAND_KERNELS, "config5", live_us=us)[1] if ranks.world == 1 and islands == 512 and base == 40 else None,
                      "kernel": "wideIslandKernel / islandStepKernel (whole step of this rank's islands in one launch: constraints resident in registers, bodies in "
                                "LDS, records prepared from and impulses stored to the wire contacts by the kernel itself)", "avg_launch_us": us,
                      "algorithmic_bytes_per_launch": algo,
@@ -265,7 +286,7 @@ def island_sharded_leg(ranks, islands, base, vel, pos, steps, warmup, graph=True
         line["roofline"]["traffic_gbs"] = traffic / max(us * 1e-6, 1e-12) / 1e9
         line["roofline"]["traffic_frac_of_peak"] = line["roofline"]["traffic_gbs"] / HBM_PEAK_GBS
         line["roofline"]["traffic_over_model"] = traffic / algo
-    line["issue"] = finish_issue(pmc_issue(ISLAND_KERNELS, "config5"), st["groupCount"]) if ranks.world == 1 and islands == 512 and base == 40 else None
+    line["issue"] = finish_issue(pmc_issue(ISLAND_KERNELS, "config5", live_us=us), st["groupCount"]) if ranks.world == 1 and islands == 512 and base == 40 else None
     if line["issue"] is not None:
         line["issue"]["note"] = "512 workgroups of 512 threads on 256 CUs (two passes): the kernel is VALU-issue bound, not bandwidth bound"
         # what bounds this kernel, as a fraction: the share of a SIMD's cycles in which it issues a VALU instruction
@@ -415,6 +436,68 @@ def whole_step_leg(device_index, base, vel, pos, settle, steps):
             "kernel_launches_per_solve": st["kernelLaunches"]}
 
 
+def fast_leg(device_index, base, vel, pos, steps, warmup, graph, opts):
+    """`value_fast`: the headline loop again on the tolerance-mode build (solver2d_amd/libs2amd_fast.so: the same sources, FMA
+    contraction on in the device code) -- SURVEY.md 7: "-ffp-contract=off for parity builds, fast for perf builds, report both".
+    Same world, same options, same timed region; its own dominant-kernel time; and how far 30 steps of it end from 30 steps of
+    the bit-exact build (two floating-point evaluations of the same sweep order).  tests/test_gpu_fast.py states and checks the
+    tolerances against the oracle."""
+    try:
+        hip.load(fast=True)
+    except hip.S2AmdError as e:
+        return {"error": str(e)}
+    pre = synthetic.pyramid(base)
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, vel, pos, True)
+    sweeps = wire.solve_sweeps_per_step("TGS_Soft", vel, pos)
+
+    def make(fast):
+        g = hip.Solver(device_index, graph=graph, fast=fast)
+        for kv in opts:
+            key, _, val = kv.partition("=")
+            g.set_option(key, int(val))
+        g.set_option("strip_patience", 0)
+        g.upload(*pre)
+        return g
+    gpu = make(True)
+    gpu.set_option("async", 1)
+    for _ in range(warmup):
+        gpu.step_resident(params)
+    gpu.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gpu.step_resident(params)
+    gpu.synchronize()
+    elapsed = time.perf_counter() - t0
+    gpu.set_option("async", 0)
+    gpu.step_resident(params)
+    st = gpu.stats()
+    C = st["constraintCount"]
+    us, _launches, c_launch = gpu.measure_dominant(params, repeats=40)
+    gpu.close()
+    # 30 steps from the same start on both builds
+    ends = []
+    for fast in (True, False):
+        g = make(fast)
+        for _ in range(30):
+            g.step_resident(params)
+        state = tuple(x.copy() for x in pre)
+        g.download(*state)
+        g.close()
+        ends.append(state)
+    dpos = float(np.abs(ends[0][0]["position"] - ends[1][0]["position"]).max())
+    dvel = float(np.abs(ends[0][0]["linearVelocity"] - ends[1][0]["linearVelocity"]).max())
+    achieved = ALGO_BYTES_PER_CONSTRAINT_SWEEP * c_launch / max(us * 1e-6, 1e-12) / 1e9
+    return {"value": C * sweeps * steps / elapsed, "unit": "constraint-iters/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup,
+            "build": hip.load(fast=True).s2amd_build_flags().decode(), "library": os.path.relpath(hip.FAST_LIB_PATH, ROOT),
+            "dtype": "f32 with contracted multiply-adds (one rounding where the reference has two)",
+            "kernel_launches_per_step": st["kernelLaunches"], "persistent": bool(st["persistent"]),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_us": us, "constraints_per_launch": c_launch, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CONSTRAINT_SWEEP * c_launch},
+            "tolerance": "every s2Solve_* output within 1e-5 x sweeps of the oracle, norm-wise, on the golden inputs and at base 40 / 200 "
+                         "(tests/test_gpu_fast.py, tools/fast_mode_error.py); NOT bit-equal to the reference -- `value` above is",
+            "after_30_steps_vs_bit_exact_build": {"max_abs_position_m": dpos, "max_abs_velocity_m_s": dvel}}
+
+
 def churn_leg(device_index, base):
     """SURVEY.md 8f row 4 as a number: the headline world while its graph changes -- heavy balls shot into the base-200 pyramid, 240 steps
     of the whole loop a caller of the C-ABI runs (pair query -> s2CreateContact on the caller's pool -> s2amd_world_set_contacts ->
@@ -451,6 +534,7 @@ def main():
     ap.add_argument("--islands", type=int, default=512)
     ap.add_argument("--weak", action="store_true", help="--config 5: --islands pyramids PER GPU (weak scaling) instead of in all (strong scaling)")
     ap.add_argument("--island-base", type=int, default=40)
+    ap.add_argument("--no-fast", action="store_true", help="skip the value_fast object (the headline loop on the tolerance-mode build)")
     ap.add_argument("--no-extras", action="store_true", help="only the headline line (no whole_step / configs / island_sharded objects)")
     ap.add_argument("--restore", action="store_true", help="copy the step-0 bodies back before every step (round 3's headline loop) instead of consecutive steps")
     args = ap.parse_args()
@@ -649,8 +733,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_bytes(kernel_prefix)[0] if persistent and args.base == 200 else None,
-                "traffic_source": pmc_traffic_bytes(kernel_prefix)[1] if persistent and args.base == 200 else None,
+                "traffic": pmc_traffic_bytes(kernel_prefix, live_us=avg_launch_us)[0] if persistent and args.base == 200 else None,
+                "traffic_source": pmc_traffic_bytes(kernel_prefix, live_us=avg_launch_us)[1] if persistent and args.base == 200 else None,
                 "kernel": kernel_name + " -- whole step, one persistent launch; constraints_per_launch counts "
                           "constraint-sweeps" if persistent else "solveContactsSoftKernel<SOFT_TGS> / stripSoftKernel<SOFT_TGS>",
                 "avg_launch_us": avg_launch_us, "launches_per_step": 1 if persistent else launches_per_sweep * sweeps,
@@ -661,13 +745,15 @@ def main():
         }
         out["ranks_seen"], out["devices"] = ranks_seen, devices
         if persistent and args.base == 200:
-            issue = pmc_issue((kernel_prefix,))
+            issue = pmc_issue((kernel_prefix,), live_us=avg_launch_us)
             issue = finish_issue(issue, st["stripCount"])
-            if issue is not None:
+            if issue is not None and "refused" not in issue:
                 issue["note"] = ("one island, %d strips = %d of 256 CUs hold a workgroup; a colour round is one wave's instruction stream per SIMD (4 cycles per "
                                  "instruction), %d dependent rounds per step: instruction-issue / latency bound, HBM idle" % (
                                      st["stripCount"], min(st["stripCount"], 256), 24 * 8))
             out["issue"] = issue
+        if world == 1 and not args.no_fast:
+            out["value_fast"] = fast_leg(0, args.base, args.vel_iters, args.pos_iters, args.steps, args.warmup, not args.no_graph, args.opt)
         if not args.no_cpu and world == 1:  # the contract: on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args.base, args.vel_iters, args.pos_iters, args.cpu_seconds)
     gpu.close()

@@ -183,6 +183,11 @@ int s2amd_device_count(void);
 /* (API 2) PCI bus id of HIP device `device` ("0000:05:00.0"): what tells two ranks' GPUs apart (bench.py: ranks_seen / devices). */
 int s2amd_device_bus_id(int device, char* out, int32_t capacity);
 const char* s2amd_last_error(void);
+/* The floating-point contract this library was compiled under: "fp-contract=off" (libs2amd.so: every result equal to the
+ * reference's, bit for bit -- the reference's own build, gcc -O2 on x86-64 without -mfma, contracts nothing) or
+ * "fp-contract=fast" (libs2amd_fast.so, the tolerance mode: the compiler may fuse a*b+c into one rounding; results within
+ * the tolerances DESIGN.md section 2 states and tests/test_gpu_fast.py checks).  A static string. */
+const char* s2amd_build_flags(void);
 /* device: HIP ordinal.  Fails with S2AMD_E_NODEVICE when no GPU is visible. */
 int s2amd_create(int device, s2amdSolver** out);
 void s2amd_destroy(s2amdSolver* solver);

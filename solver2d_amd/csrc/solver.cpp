@@ -50,6 +50,15 @@ const char* s2amd_last_error(void)
 	return g_lastError.c_str();
 }
 
+const char* s2amd_build_flags(void)
+{
+#if defined(S2AMD_FAST_BUILD) && S2AMD_FAST_BUILD
+	return "fp-contract=fast";
+#else
+	return "fp-contract=off";
+#endif
+}
+
 int s2amd_device_count(void)
 {
 	int n = 0;
@@ -148,6 +157,7 @@ int s2amd_create(int device, s2amdSolver** out)
 		(void)hipGetLastError(); // not fatal: groups are then limited to the default 64 KiB of LDS
 		s->optMaxGroupBodies = 1536;
 	}
+	devPoolSolverCreated(device);
 	*out = s;
 	return S2AMD_OK;
 }
@@ -160,7 +170,10 @@ void s2amd_destroy(s2amdSolver* s)
 	}
 	(void)hipSetDevice(s->device);
 	asyncShutdown(s); // (a worker thread may still be building on a copy of this solver)
-	devPoolDrain();	  // (what the copies gave back: solver_internal.h: DevBuf)
+	if (devPoolSolverDestroyed(s->device))
+	{
+		devPoolDrain(); // (what the copies gave back on this device, once its last solver goes: solver_internal.h: DevBuf)
+	}
 	(void)hipStreamSynchronize(s->stream);
 	destroyGraph(s);
 	for (hipEvent_t e : s->sweepEvents)

@@ -30,14 +30,46 @@ struct DevPool
 	std::vector<hipStream_t> streams;
 	std::vector<std::pair<void*, size_t>> pinned;
 };
+// One pool per device (the calling thread's current one -- every taker and giver has set it: workerMain, destroyClone, s2amd_destroy):
+// a block, a stream or a pinned buffer made on device 0 must never reach a copy that builds for device 1.
+constexpr int kMaxPoolDevices = 64;
 DevPool& devPool()
 {
-	static DevPool pool;
-	return pool;
+	static DevPool pools[kMaxPoolDevices];
+	int device = 0;
+	if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= kMaxPoolDevices)
+	{
+		(void)hipGetLastError();
+		device = 0;
+	}
+	return pools[device];
 }
+// solvers alive per device: the last one to go empties its device's pool (s2amd_create / s2amd_destroy)
+std::mutex g_aliveMutex;
+int g_alive[kMaxPoolDevices] = {};
 thread_local bool tlsDevPool = false;
-constexpr size_t kDevPoolLimit = size_t(1) << 30; // what the pool keeps at most; a block beyond that is freed as ever
+constexpr size_t kDevPoolLimit = size_t(1) << 30; // what a device's pool keeps at most; a block beyond that is freed as ever
 } // namespace
+
+void devPoolSolverCreated(int device)
+{
+	std::lock_guard<std::mutex> lock(g_aliveMutex);
+	if (device >= 0 && device < kMaxPoolDevices)
+	{
+		g_alive[device] += 1;
+	}
+}
+// true: that was the device's last solver (the caller, with the device current, drains its pool)
+bool devPoolSolverDestroyed(int device)
+{
+	std::lock_guard<std::mutex> lock(g_aliveMutex);
+	if (device < 0 || device >= kMaxPoolDevices)
+	{
+		return true;
+	}
+	g_alive[device] = std::max(g_alive[device] - 1, 0);
+	return g_alive[device] == 0;
+}
 
 void devPoolThread(bool on) { tlsDevPool = on; }
 bool devPoolOn() { return tlsDevPool; }
@@ -371,6 +403,7 @@ void asyncLogDestroyed(s2amdSolver* s, int slot)
 // the owner is going away (or its world is replaced): nothing of a worker may outlive it
 void asyncShutdown(s2amdSolver* s)
 {
+	asyncDrop(s); // (sets the worker's cancel flag: a search over strip widths stops after the build it is in instead of running its seven)
 	reap(s->async, true);
 }
 

@@ -66,7 +66,9 @@ void devPoolThread(bool on);
 bool devPoolOn();
 void* devPoolTake(size_t need, size_t* got);
 bool devPoolGive(void* p, size_t bytes);
-void devPoolDrain();
+void devPoolDrain(); // (the calling thread's current device's pool)
+void devPoolSolverCreated(int device);
+bool devPoolSolverDestroyed(int device);
 
 // growable raw device allocation
 struct DevBuf

@@ -672,11 +672,13 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 			s->nearHandoffNow = 0;
 			s->nearHandoffTimeouts += 1;
 			s->layoutGeneration += 1; // (a captured step graph has the old launch parameters)
+			s->stepCounter -= 1;	  // (the same step again: the clock of the deferred adoptions must not run on time-outs)
 			return doStep(s, params);
 		}
 		s->persistFailed = true;
 		s->persistFailedAge = 0;
 		s->persistFallbacks += 1;
+		s->stepCounter -= 1;
 		return doStep(s, params);
 	}
 	s->graphAge += 1;

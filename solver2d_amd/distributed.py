@@ -27,14 +27,17 @@ def _gather_rows(rows, world_size, dist, torch, device):
 
 
 class ShardedWorld:
-    def __init__(self, bodies, contacts, joints, rank, world_size):
+    def __init__(self, bodies, contacts, joints, rank, world_size, finder=None):
+        """finder: the island finder of islands.shard_world (None: the host's; hip.Solver.find_islands: the device's union-find)."""
         self.rank, self.world_size = rank, world_size
         self.bodies, self.contacts, self.joints = bodies, contacts, joints
         self.reshards = 0
+        self.finder = finder
         self._partition(None)
 
     def _partition(self, previous_owner):
-        shards, self.island, self.shard_of_island = islands.shard_world(self.bodies, self.contacts, self.joints, self.world_size, previous_owner)
+        shards, self.island, self.shard_of_island = islands.shard_world(self.bodies, self.contacts, self.joints, self.world_size, previous_owner,
+                                                                        finder=self.finder)
         self.shards = shards
         self.mine = shards[self.rank]
         # fixed-size exchange record: every rank contributes max_owned body records
@@ -160,11 +163,18 @@ class ResidentShardedWorld:
     The host loop is software-pipelined like bench.py's replica loop: step s+1 is enqueued on the solver's stream BEFORE
     the host waits for the poses of step s and hands them to the collective, through two pose buffers."""
 
-    def __init__(self, sharded, solver, torch, dist=None, backend="nccl", exchange_ranks=None):
+    def __init__(self, sharded, solver, torch, dist=None, backend="nccl", exchange_ranks=None, exchange_rank=0):
         """exchange_ranks: ranks that take part in the per-step all-gather when that is not the partition's own world size -- the
-        WEAK-scaling form, where every rank brings its own islands (a partition by construction) and `sharded` is its local world."""
+        WEAK-scaling form, where every rank brings its own islands (a partition by construction) and `sharded` is its local world;
+        exchange_rank: this rank's place among them (its record's slot in the gathered tensor)."""
         self.sw, self.solver, self.torch, self.dist, self.backend = sharded, solver, torch, dist, backend
         self.exchange_ranks = exchange_ranks if exchange_ranks is not None else sharded.world_size
+        self.weak = self.exchange_ranks != sharded.world_size
+        # reshard() finds the islands with the device kernel when the solver has one (the CPU tests' stand-in solver has not)
+        self.device_islands = hasattr(solver, "find_islands")
+        self.exchange_rank = int(exchange_rank) if self.weak else sharded.rank
+        if not 0 <= self.exchange_rank < max(self.exchange_ranks, 1):
+            raise ValueError("exchange_rank %d outside the %d exchanging ranks" % (self.exchange_rank, self.exchange_ranks))
         sh = sharded.mine
         solver.upload(sh.bodies, sh.contacts, sh.joints)
         self.body_slots = len(sh.bodies)
@@ -222,7 +232,10 @@ class ResidentShardedWorld:
             g = self.solver.device_read(self.pose_ptr[self.last], (1, self.record, 8))
         else:
             self.torch.cuda.synchronize()
-            g = self.gathered.cpu().numpy().reshape(self.sw.world_size, self.record, 8)
+            g = self.gathered.cpu().numpy().reshape(self.exchange_ranks, self.record, 8)
+            if self.weak:
+                # every rank holds a world of its own: the local world's bodies are this rank's record (one shard, slot exchange_rank)
+                g = g[self.exchange_rank:self.exchange_rank + 1]
         out = np.zeros((len(self.sw.bodies), 8), dtype=np.float32)
         out[:, 0:2] = self.sw.bodies["position"]
         out[:, 2:4] = self.sw.bodies["rot"]
@@ -242,6 +255,9 @@ class ResidentShardedWorld:
         the whole world's body array is brought up to the last exchange, the constraint state is exchanged and the islands are
         partitioned again (islands that did not change stay on their rank), and my NEW shard goes up (s2amd_upload).  Rare -- a
         created contact that joins islands of two ranks, pairs that separated --, so it may cost a host round trip."""
+        if self.weak:
+            raise RuntimeError("reshard: the weak-scaling form holds one local world per rank (a partition by construction); "
+                               "there are no islands to move between ranks")
         sh = self.sw.mine
         self.solver.synchronize()
         self.solver.download(sh.bodies, sh.contacts, sh.joints)
@@ -249,6 +265,10 @@ class ResidentShardedWorld:
             g = self.world_bodies()
             b = self.sw.bodies
             b["position"], b["rot"], b["linearVelocity"], b["angularVelocity"] = g[:, 0:2], g[:, 2:4], g[:, 4:6], g[:, 6]
+        if self.device_islands:
+            # islands found again on the device (s2amd_find_islands, structure.hip: SURVEY.md 8f row 4); every rank runs the same
+            # deterministic labelling on the same arrays, so the ranks agree without exchanging it
+            self.sw.finder = self.solver.find_islands
         self.sw.reshard(contacts, joints, dist=self.dist, torch=self.torch, device="cuda" if (self.dist is not None and self.backend == "nccl") else "cpu")
         sh = self.sw.mine
         self.solver.upload(sh.bodies, sh.contacts, sh.joints)
@@ -265,7 +285,7 @@ class ResidentShardedWorld:
                 torch = self.torch
                 self.pose = [torch.zeros((self.record, 8), dtype=torch.float32, device="cuda") for _ in range(2)]
                 self.pose_ptr = [t.data_ptr() for t in self.pose]
-                self.gathered = torch.zeros((self.sw.world_size * self.record, 8), dtype=torch.float32, device="cuda" if self.backend == "nccl" else "cpu")
+                self.gathered = torch.zeros((self.exchange_ranks * self.record, 8), dtype=torch.float32, device="cuda" if self.backend == "nccl" else "cpu")
         self.gather_done = [None, None]
         self.enqueued = self.exchanged = 0
         self.last = None

@@ -12,11 +12,14 @@ import numpy as np
 from . import wire
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# S2AMD_LIB: another build of the same C-ABI (experiments: e.g. the FMA-contracted build of `make -C solver2d_amd/csrc fma`)
+# S2AMD_LIB: another build of the same C-ABI (experiments: `make -C solver2d_amd/csrc variant NAME=...`)
 LIB_PATH = os.environ.get("S2AMD_LIB") or os.path.join(_HERE, "libs2amd.so")
+# The tolerance-mode build: the same sources with -ffp-contract=fast (FMA contraction).  Not bit-equal to the reference;
+# within the tolerances tests/test_gpu_fast.py states and checks.  A library of its own so that one process can hold both.
+FAST_LIB_PATH = os.environ.get("S2AMD_FAST_LIB") or os.path.join(_HERE, "libs2amd_fast.so")
 
 EXPORTS = [
-    "s2amd_api_version", "s2amd_device_count", "s2amd_device_bus_id", "s2amd_last_error", "s2amd_create", "s2amd_destroy",
+    "s2amd_api_version", "s2amd_build_flags", "s2amd_device_count", "s2amd_device_bus_id", "s2amd_last_error", "s2amd_create", "s2amd_destroy",
     "s2amd_solve", "s2amd_upload", "s2amd_step_resident", "s2amd_download", "s2amd_save_bodies",
     "s2amd_restore_bodies", "s2amd_get_contact_order", "s2amd_get_joint_order", "s2amd_get_stats",
     "s2amd_set_option", "s2amd_export_poses", "s2amd_export_poses_async", "s2amd_export_bodies_async", "s2amd_export_wait", "s2amd_measure_dominant", "s2amd_refit_shapes", "s2amd_find_pairs", "s2amd_synchronize", "s2amd_update_contacts", "s2amd_find_islands", "s2amd_color_constraints",
@@ -25,26 +28,28 @@ EXPORTS = [
     "s2amd_get_strip_owners",
 ]
 
-_lib = None
+_libs = {}
 
 
 class S2AmdError(RuntimeError):
     pass
 
 
-def load():
-    """Load libs2amd.so.  Raises if it has not been built (python __graft_entry__.py / make -C solver2d_amd/csrc)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(fast=False):
+    """Load libs2amd.so (fast=True: libs2amd_fast.so).  Raises if it has not been built (python __graft_entry__.py /
+    make -C solver2d_amd/csrc)."""
+    path = FAST_LIB_PATH if fast else LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise S2AmdError("HIP extension %s is missing: build it with `make -C solver2d_amd/csrc` "
-                         "(there is no CPU fallback)" % LIB_PATH)
-    L = ctypes.CDLL(LIB_PATH)
+                         "(there is no CPU fallback)" % path)
+    L = ctypes.CDLL(path)
     vp, i32 = ctypes.c_void_p, ctypes.c_int32
     L.s2amd_api_version.restype = ctypes.c_int
     L.s2amd_device_count.restype = ctypes.c_int
     L.s2amd_last_error.restype = ctypes.c_char_p
+    L.s2amd_build_flags.restype = ctypes.c_char_p
     L.s2amd_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
     L.s2amd_destroy.argtypes = [vp]
     L.s2amd_destroy.restype = None
@@ -83,7 +88,9 @@ def load():
     L.s2amd_color_constraints.argtypes = [vp, vp, i32, vp, i32, vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     if L.s2amd_api_version() != wire.API_VERSION:
         raise S2AmdError("libs2amd.so API version %d != %d" % (L.s2amd_api_version(), wire.API_VERSION))
-    _lib = L
+    if fast and not L.s2amd_build_flags().decode().count("contract=fast"):
+        raise S2AmdError("%s is not a tolerance-mode build (%s)" % (path, L.s2amd_build_flags().decode()))
+    _libs[path] = L
     return L
 
 
@@ -97,30 +104,64 @@ def device_bus_id(device):
     return buf.value.decode()
 
 
-def _check(rc):
+def _check(rc, L=None):
     if rc != 0:
-        raise S2AmdError("s2amd error %d: %s" % (rc, load().s2amd_last_error().decode(errors="replace")))
+        raise S2AmdError("s2amd error %d: %s" % (rc, (L or load()).s2amd_last_error().decode(errors="replace")))
+
+
+_env_options_logged = False
+
+
+def env_options():
+    """S2AMD_OPTIONS="key=value,key=value": options for every solver this process creates (bisecting a difference
+    without editing the caller).  Validated here -- a malformed entry raises naming it -- and logged once to stderr,
+    because it silently changes every solver of the process, the parity tests' included."""
+    global _env_options_logged
+    text = os.environ.get("S2AMD_OPTIONS", "")
+    out = []
+    for kv in filter(None, (e.strip() for e in text.split(","))):
+        k, eq, v = kv.partition("=")
+        try:
+            if not eq or not k.strip():
+                raise ValueError
+            out.append((k.strip(), int(v)))
+        except ValueError:
+            raise S2AmdError("S2AMD_OPTIONS: entry %r is not key=integer" % kv) from None
+    if out and not _env_options_logged:
+        import sys
+        print("[s2amd] S2AMD_OPTIONS applied to every solver: %s" % ", ".join("%s=%d" % e for e in out), file=sys.stderr)
+        _env_options_logged = True
+    return out
 
 
 class Solver:
     """One device-resident world (one HIP stream).  Arrays are numpy structured arrays of the
     dtypes in solver2d_amd.wire and are mutated in place, like the reference mutates its pools."""
 
-    def __init__(self, device=0, graph=True, profile=False):
-        L = load()
+    def __init__(self, device=0, graph=True, profile=False, fast=False):
+        """fast=True: the tolerance-mode build (libs2amd_fast.so, FMA contraction on; results within the stated
+        tolerances of the oracle) instead of the bit-exact one."""
+        L = load(fast=fast)
         h = ctypes.c_void_p()
-        _check(L.s2amd_create(int(device), ctypes.byref(h)))
+        _check(L.s2amd_create(int(device), ctypes.byref(h)), L)
+        self._L = L
         self._h = h
-        self.set_option("graph", 1 if graph else 0)
-        self.set_option("profile", 1 if profile else 0)
-        # S2AMD_OPTIONS="key=value,key=value": options for every solver this process creates (bisecting a difference without editing the caller)
-        for kv in filter(None, os.environ.get("S2AMD_OPTIONS", "").split(",")):
-            k, _, v = kv.partition("=")
-            self.set_option(k.strip(), int(v))
+        self.fast = bool(fast)
+        try:
+            self.set_option("graph", 1 if graph else 0)
+            self.set_option("profile", 1 if profile else 0)
+            for k, v in env_options():
+                self.set_option(k, v)
+        except Exception:
+            self.close()
+            raise
+
+    def _ck(self, rc):
+        _check(rc, self._L)
 
     def close(self):
         if getattr(self, "_h", None):
-            load().s2amd_destroy(self._h)
+            self._L.s2amd_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -136,7 +177,7 @@ class Solver:
         self.close()
 
     def set_option(self, key, value):
-        _check(load().s2amd_set_option(self._h, key.encode(), int(value)))
+        self._ck(self._L.s2amd_set_option(self._h, key.encode(), int(value)))
 
     @staticmethod
     def _args(bodies, contacts, joints):
@@ -147,65 +188,65 @@ class Solver:
 
     def solve(self, params, bodies, contacts, joints):
         """== s2Solve_<params.solverType>(world, context): upload, solve, download; in place."""
-        _check(load().s2amd_solve(self._h, ctypes.byref(params), *self._args(bodies, contacts, joints)))
+        self._ck(self._L.s2amd_solve(self._h, ctypes.byref(params), *self._args(bodies, contacts, joints)))
         return bodies, contacts, joints
 
     def upload(self, bodies, contacts, joints):
-        _check(load().s2amd_upload(self._h, *self._args(bodies, contacts, joints)))
+        self._ck(self._L.s2amd_upload(self._h, *self._args(bodies, contacts, joints)))
 
     def step_resident(self, params):
-        _check(load().s2amd_step_resident(self._h, ctypes.byref(params)))
+        self._ck(self._L.s2amd_step_resident(self._h, ctypes.byref(params)))
 
     def download(self, bodies, contacts, joints):
-        _check(load().s2amd_download(self._h, *self._args(bodies, contacts, joints)))
+        self._ck(self._L.s2amd_download(self._h, *self._args(bodies, contacts, joints)))
         return bodies, contacts, joints
 
     def save_bodies(self):
-        _check(load().s2amd_save_bodies(self._h))
+        self._ck(self._L.s2amd_save_bodies(self._h))
 
     def restore_bodies(self):
-        _check(load().s2amd_restore_bodies(self._h))
+        self._ck(self._L.s2amd_restore_bodies(self._h))
 
     def export_poses(self, device_ptr, capacity):
         """{position, rot} per body into a caller-owned device buffer (float32[capacity, 4])."""
-        _check(load().s2amd_export_poses(self._h, ctypes.c_void_p(int(device_ptr)), int(capacity)))
+        self._ck(self._L.s2amd_export_poses(self._h, ctypes.c_void_p(int(device_ptr)), int(capacity)))
 
     def export_bodies_async(self, device_ptr, capacity, slot):
         """Two float4 per body -- {position, rot}, {linearVelocity, angularVelocity, 0} -- enqueued like export_poses_async."""
-        _check(load().s2amd_export_bodies_async(self._h, ctypes.c_void_p(int(device_ptr)), int(capacity), int(slot)))
+        self._ck(self._L.s2amd_export_bodies_async(self._h, ctypes.c_void_p(int(device_ptr)), int(capacity), int(slot)))
 
     def export_poses_async(self, device_ptr, capacity, slot):
         """export_poses enqueued behind the steps already on the solver's stream; pair with export_wait(slot)."""
-        _check(load().s2amd_export_poses_async(self._h, ctypes.c_void_p(int(device_ptr)), int(capacity), int(slot)))
+        self._ck(self._L.s2amd_export_poses_async(self._h, ctypes.c_void_p(int(device_ptr)), int(capacity), int(slot)))
 
     def export_wait(self, slot):
-        _check(load().s2amd_export_wait(self._h, int(slot)))
+        self._ck(self._L.s2amd_export_wait(self._h, int(slot)))
 
     def device_alloc(self, nbytes):
         """A zeroed device buffer owned by the caller (an int address); free it with device_free."""
         p = ctypes.c_void_p()
-        _check(load().s2amd_device_alloc(self._h, int(nbytes), ctypes.byref(p)))
+        self._ck(self._L.s2amd_device_alloc(self._h, int(nbytes), ctypes.byref(p)))
         return int(p.value)
 
     def device_free(self, ptr):
-        _check(load().s2amd_device_free(self._h, ctypes.c_void_p(int(ptr))))
+        self._ck(self._L.s2amd_device_free(self._h, ctypes.c_void_p(int(ptr))))
 
     def device_read(self, ptr, shape, dtype=np.float32):
         out = np.zeros(shape, dtype=dtype)
-        _check(load().s2amd_device_read(self._h, wire.as_ptr(out.reshape(-1)), ctypes.c_void_p(int(ptr)), out.nbytes))
+        self._ck(self._L.s2amd_device_read(self._h, wire.as_ptr(out.reshape(-1)), ctypes.c_void_p(int(ptr)), out.nbytes))
         return out
 
     def measure_dominant(self, params, repeats=20):
         """(us per launch, launches per sweep, constraints per launch) of the dominant kernel; see
         s2amd_measure_dominant."""
         us, n, c = ctypes.c_float(), ctypes.c_int32(), ctypes.c_int32()
-        _check(load().s2amd_measure_dominant(self._h, ctypes.byref(params), int(repeats), ctypes.byref(us), ctypes.byref(n), ctypes.byref(c)))
+        self._ck(self._L.s2amd_measure_dominant(self._h, ctypes.byref(params), int(repeats), ctypes.byref(us), ctypes.byref(n), ctypes.byref(c)))
         return us.value, n.value, c.value
 
     def refit_shapes(self, bodies, shapes, origins):
         """Stage 4 of s2World_Step on wire arrays (in place): origins, tight and fat AABBs, `enlarged`."""
         assert shapes.dtype == wire.shape_dtype and origins.dtype == np.float32 and origins.shape == (len(bodies), 2)
-        _check(load().s2amd_refit_shapes(self._h, wire.as_ptr(bodies), len(bodies), wire.as_ptr(shapes), len(shapes), wire.as_ptr(origins)))
+        self._ck(self._L.s2amd_refit_shapes(self._h, wire.as_ptr(bodies), len(bodies), wire.as_ptr(shapes), len(shapes), wire.as_ptr(origins)))
         return shapes, origins
 
     def update_contacts(self, bodies, origins, shapes, pairs, contacts):
@@ -215,7 +256,7 @@ class Solver:
         origins = np.ascontiguousarray(origins, dtype=np.float32)
         assert origins.shape == (len(bodies), 2)
         status = np.zeros(len(contacts), dtype=np.int32)
-        _check(load().s2amd_update_contacts(self._h, wire.as_ptr(bodies), len(bodies), wire.as_ptr(origins), wire.as_ptr(shapes), len(shapes),
+        self._ck(self._L.s2amd_update_contacts(self._h, wire.as_ptr(bodies), len(bodies), wire.as_ptr(origins), wire.as_ptr(shapes), len(shapes),
                                             wire.as_ptr(pairs), wire.as_ptr(contacts), len(contacts), wire.as_ptr(status)))
         return status
 
@@ -224,13 +265,13 @@ class Solver:
         assert shapes.dtype == wire.shape_dtype and pairs.dtype == wire.pair_state_dtype and len(pairs) == len(contacts)
         origins = np.ascontiguousarray(origins, dtype=np.float32)
         assert origins.shape == (len(bodies), 2)
-        _check(load().s2amd_world_upload(self._h, *self._args(bodies, contacts, joints), wire.as_ptr(shapes), len(shapes), wire.as_ptr(pairs),
+        self._ck(self._L.s2amd_world_upload(self._h, *self._args(bodies, contacts, joints), wire.as_ptr(shapes), len(shapes), wire.as_ptr(pairs),
                                          wire.as_ptr(origins)))
 
     def world_step(self, params):
         """One s2World_Step minus pair creation on the resident world; returns the step's counters as a dict."""
         info = wire.WorldStepInfo()
-        _check(load().s2amd_world_step(self._h, ctypes.byref(params), ctypes.byref(info)))
+        self._ck(self._L.s2amd_world_step(self._h, ctypes.byref(params), ctypes.byref(info)))
         return {k: getattr(info, k) for k, _ in wire.WorldStepInfo._fields_}
 
     def world_find_pairs(self):
@@ -239,28 +280,28 @@ class Solver:
         while True:
             out = np.zeros((cap, 2), dtype=np.int32)
             n = ctypes.c_int32()
-            rc = load().s2amd_world_find_pairs(self._h, wire.as_ptr(out), cap, ctypes.byref(n))
+            rc = self._L.s2amd_world_find_pairs(self._h, wire.as_ptr(out), cap, ctypes.byref(n))
             if rc == -5 and n.value > cap:  # S2AMD_E_CAPACITY
                 cap = n.value
                 continue
-            _check(rc)
+            self._ck(rc)
             return out[: n.value].copy()
 
     def world_download_boxes(self, shape_capacity):
         """s2amdShapeBox of every resident shape slot after the last world_step."""
         out = np.zeros(int(shape_capacity), dtype=wire.shape_box_dtype)
-        _check(load().s2amd_world_download_boxes(self._h, wire.as_ptr(out), len(out)))
+        self._ck(self._L.s2amd_world_download_boxes(self._h, wire.as_ptr(out), len(out)))
         return out
 
     def world_separated(self, expected=64):
         """Contact slots the last world_step destroyed (their pairs separated), ascending."""
         out = np.zeros(max(int(expected), 1), dtype=np.int32)
         n = ctypes.c_int32()
-        rc = load().s2amd_world_separated(self._h, wire.as_ptr(out), len(out), ctypes.byref(n))
+        rc = self._L.s2amd_world_separated(self._h, wire.as_ptr(out), len(out), ctypes.byref(n))
         if rc == -5:
             out = np.zeros(n.value, dtype=np.int32)
-            rc = load().s2amd_world_separated(self._h, wire.as_ptr(out), len(out), ctypes.byref(n))
-        _check(rc)
+            rc = self._L.s2amd_world_separated(self._h, wire.as_ptr(out), len(out), ctypes.byref(n))
+        self._ck(rc)
         return out[: n.value].copy()
 
     def world_set_contacts(self, slots, contacts, pairs):
@@ -268,13 +309,13 @@ class Solver:
         contacts = np.ascontiguousarray(contacts)
         pairs = np.ascontiguousarray(pairs)
         assert contacts.dtype == wire.contact_dtype and pairs.dtype == wire.pair_state_dtype and len(slots) == len(contacts) == len(pairs)
-        _check(load().s2amd_world_set_contacts(self._h, wire.as_ptr(slots), len(slots), wire.as_ptr(contacts), wire.as_ptr(pairs)))
+        self._ck(self._L.s2amd_world_set_contacts(self._h, wire.as_ptr(slots), len(slots), wire.as_ptr(contacts), wire.as_ptr(pairs)))
 
     def world_download(self, bodies, contacts, joints, shapes, pairs, origins):
         """Fills the given arrays (same sizes as uploaded) and returns them with the last stage-3 status."""
         origins = np.ascontiguousarray(origins, dtype=np.float32)
         status = np.zeros(len(contacts), dtype=np.int32)
-        _check(load().s2amd_world_download(self._h, *self._args(bodies, contacts, joints), wire.as_ptr(shapes), len(shapes), wire.as_ptr(pairs),
+        self._ck(self._L.s2amd_world_download(self._h, *self._args(bodies, contacts, joints), wire.as_ptr(shapes), len(shapes), wire.as_ptr(pairs),
                                            wire.as_ptr(origins), wire.as_ptr(status)))
         return bodies, contacts, joints, shapes, pairs, origins, status
 
@@ -282,7 +323,7 @@ class Solver:
         """(island_of_body int32[nb], island_count): connected components over the movable bodies, on the device."""
         island = np.full(len(bodies), -2, dtype=np.int32)
         n = ctypes.c_int32()
-        _check(load().s2amd_find_islands(self._h, wire.as_ptr(bodies), len(bodies), wire.as_ptr(contacts), len(contacts), wire.as_ptr(joints),
+        self._ck(self._L.s2amd_find_islands(self._h, wire.as_ptr(bodies), len(bodies), wire.as_ptr(contacts), len(contacts), wire.as_ptr(joints),
                                          len(joints), wire.as_ptr(island), ctypes.byref(n)))
         return island, n.value
 
@@ -290,7 +331,7 @@ class Solver:
         """(color_of_contact int32[nc], color_count, rounds): deterministic Jones-Plassmann colouring on the device."""
         colour = np.full(len(contacts), -2, dtype=np.int32)
         n, r = ctypes.c_int32(), ctypes.c_int32()
-        _check(load().s2amd_color_constraints(self._h, wire.as_ptr(bodies), len(bodies), wire.as_ptr(contacts), len(contacts), wire.as_ptr(colour),
+        self._ck(self._L.s2amd_color_constraints(self._h, wire.as_ptr(bodies), len(bodies), wire.as_ptr(contacts), len(contacts), wire.as_ptr(colour),
                                               ctypes.byref(n), ctypes.byref(r)))
         return colour, n.value, r.value
 
@@ -302,43 +343,43 @@ class Solver:
         while True:
             out = np.zeros((cap, 2), dtype=np.int32)
             n = ctypes.c_int32()
-            rc = load().s2amd_find_pairs(self._h, wire.as_ptr(bodies), len(bodies), wire.as_ptr(shapes), len(shapes), wire.as_ptr(moved),
+            rc = self._L.s2amd_find_pairs(self._h, wire.as_ptr(bodies), len(bodies), wire.as_ptr(shapes), len(shapes), wire.as_ptr(moved),
                                          wire.as_ptr(existing), len(existing), wire.as_ptr(joints), len(joints), wire.as_ptr(out), cap,
                                          ctypes.byref(n))
             if rc == -5 and n.value > cap:
                 cap = n.value
                 continue
-            _check(rc)
+            self._ck(rc)
             return out[: n.value].copy()
 
     def _order(self, fn):
         n, nc = ctypes.c_int32(), ctypes.c_int32()
-        _check(fn(self._h, None, 0, None, 0, ctypes.byref(n), ctypes.byref(nc)))
+        self._ck(fn(self._h, None, 0, None, 0, ctypes.byref(n), ctypes.byref(nc)))
         order = np.zeros(max(n.value, 1), dtype=np.int32)
         offsets = np.zeros(nc.value + 1, dtype=np.int32)
-        _check(fn(self._h, order.ctypes.data, len(order), offsets.ctypes.data, len(offsets), ctypes.byref(n), ctypes.byref(nc)))
+        self._ck(fn(self._h, order.ctypes.data, len(order), offsets.ctypes.data, len(offsets), ctypes.byref(n), ctypes.byref(nc)))
         return order[: n.value].copy(), offsets
 
     def contact_order(self):
         """(order, colorOffsets) of the last step; see s2amd_get_contact_order."""
-        return self._order(load().s2amd_get_contact_order)
+        return self._order(self._L.s2amd_get_contact_order)
 
     def strip_owners(self, body_capacity):
         """(ownerStrip, onSeam, stripCount): see s2amd_get_strip_owners."""
         owner = np.full(max(body_capacity, 1), -1, dtype=np.int32)
         seam = np.full(max(body_capacity, 1), -1, dtype=np.int32)
         n = ctypes.c_int32()
-        _check(load().s2amd_get_strip_owners(self._h, owner.ctypes.data, seam.ctypes.data, len(owner), ctypes.byref(n)))
+        self._ck(self._L.s2amd_get_strip_owners(self._h, owner.ctypes.data, seam.ctypes.data, len(owner), ctypes.byref(n)))
         return owner[:body_capacity], seam[:body_capacity], n.value
 
     def joint_order(self):
-        return self._order(load().s2amd_get_joint_order)
+        return self._order(self._L.s2amd_get_joint_order)
 
     def synchronize(self):
         """Waits for the steps enqueued under option "async" and raises a deferred device error."""
-        _check(load().s2amd_synchronize(self._h))
+        self._ck(self._L.s2amd_synchronize(self._h))
 
     def stats(self):
         st = wire.StepStats()
-        _check(load().s2amd_get_stats(self._h, ctypes.byref(st)))
+        self._ck(self._L.s2amd_get_stats(self._h, ctypes.byref(st)))
         return {k: getattr(st, k) for k, _ in wire.StepStats._fields_}

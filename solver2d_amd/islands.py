@@ -110,14 +110,31 @@ class Shard:
         self.owned_body = owned_body  # bool per shard body: movable body owned by this shard
 
 
-def shard_world(bodies, contacts, joints, n_shards, previous_owner=None):
+# sticky_partition moves islands again once the heaviest shard carries more than this multiple of the mean load (weights as in
+# shard_world: 2 per contact constraint + 1 per joint): the per-step all-gather record and the step time both follow the LARGEST shard,
+# so islands that drift onto a few ranks under sustained churn cost every rank.  A move costs the island's constraint state on the
+# wire and an upload, so small imbalances stay: 1.75 is above anything longest-processing-time bin packing itself produces for islands
+# of unequal size (its bound is 4/3 of the optimum), above what ONE merge of two equal islands among two per rank leaves behind (1.5 x
+# the mean: the created contact moves one island, nothing else), and it is reached on two ranks once one of them holds 7/8 of the world.
+REBALANCE_THRESHOLD = 1.75
+
+
+def shard_world(bodies, contacts, joints, n_shards, previous_owner=None, finder=None):
     """Split a world into n_shards sub-worlds along island boundaries.
+
+    finder: callable (bodies, contacts, joints) -> (island_of_body, island_count) used instead of the host's find_islands -- the
+    device's union-find (hip.Solver.find_islands = s2amd_find_islands, structure.hip), whose labelling is the same by definition
+    (islands numbered by their lowest body index; tests/test_gpu_structure.py compares them exactly).
 
     previous_owner (int per body, -1 = nobody): the shard that owned each body under the partition before the graph changed.  An
     island then stays where most of its bodies were (ties: the lowest shard), so that a contact created between two islands moves
     ONE of them -- the smaller -- and every island the change did not touch stays put; without it the islands are bin-packed afresh
     (longest-processing-time by constraint count)."""
-    island, n_islands = find_islands(bodies, contacts, joints)
+    if finder is not None:
+        island, n_islands = finder(bodies, contacts, joints)
+        island = np.asarray(island, dtype=np.int32)
+    else:
+        island, n_islands = find_islands(bodies, contacts, joints)
     ci, ji = constraint_islands(bodies, contacts, joints, island)
     weights = np.bincount(ci[ci >= 0], minlength=n_islands) * 2 + np.bincount(ji[ji >= 0], minlength=n_islands)
     if previous_owner is None:
@@ -127,8 +144,11 @@ def shard_world(bodies, contacts, joints, n_shards, previous_owner=None):
     return [extract(bodies, contacts, joints, island, ci, ji, shard_of_island, s) for s in range(n_shards)], island, shard_of_island
 
 
-def sticky_partition(island, n_islands, weights, previous_owner, n_shards):
-    """Shard per island: where most of its bodies were; islands of bodies nobody owned go to the least loaded shard (heaviest first)."""
+def sticky_partition(island, n_islands, weights, previous_owner, n_shards, threshold=REBALANCE_THRESHOLD):
+    """Shard per island: where most of its bodies were; islands of bodies nobody owned go to the least loaded shard (heaviest first).
+    Then, while the heaviest shard carries more than `threshold` x the mean load, its LIGHTEST island that still helps (one whose move
+    leaves the receiving shard below the giver) goes to the least loaded shard -- few, small moves, deterministic (ties: the lowest
+    island / shard index); a merged island too heavy for any move to help stays (one island never splits)."""
     shard = np.full(n_islands, -1, dtype=np.int32)
     has = (island >= 0) & (previous_owner >= 0)
     if has.any():
@@ -143,6 +163,21 @@ def sticky_partition(island, n_islands, weights, previous_owner, n_shards):
         s = int(np.argmin(load))
         shard[i] = s
         load[s] += max(int(weights[i]), 1)
+    w = np.maximum(np.asarray(weights, dtype=np.int64), 1)
+    for _ in range(n_islands):
+        mean = load.sum() / max(n_shards, 1)
+        heavy, light = int(np.argmax(load)), int(np.argmin(load))
+        if n_shards < 2 or mean <= 0 or load[heavy] <= threshold * mean:
+            break
+        mine = np.flatnonzero(shard == heavy)
+        mine = mine[np.lexsort((mine, w[mine]))]  # lightest first
+        movable = [int(i) for i in mine if load[light] + w[i] < load[heavy]]
+        if not movable:
+            break
+        i = movable[0]
+        shard[i] = light
+        load[heavy] -= w[i]
+        load[light] += w[i]
     return shard
 
 

@@ -87,3 +87,66 @@ def max_abs_diff(got, want):
 
 def copy3(t):
     return tuple(x.copy() for x in t)
+
+
+# ---- tolerance mode (libs2amd_fast.so: FMA contraction on) ----
+# SURVEY.md 8c, link L2: "CPU restatement <=> HIP kernels, same colour order, tolerance <= 1e-5 relative ... per sweep".
+# One s2Solve_* is `sweeps` passes over the constraints (warm starts, solve and relax / position sweeps: everything that
+# touches a body), and a contracted a*b+c differs from the separately rounded one by at most half an ulp of the result, so
+# the stated bound on every output field is
+#     |fast - oracle| <= FAST_RTOL_PER_SWEEP * sweeps * scale(field)
+# with scale(field) = max(|oracle field| over the scene, the field's floor below): a NORM-wise relative bound (an element
+# that cancels to ~0 is measured against the field's magnitude in the scene, not against itself).
+FAST_RTOL_PER_SWEEP = 1e-5
+# floors: one contact slop / one slop per substep of velocity / the impulse of a 1 kg body at that velocity
+FAST_SCALE_FLOOR = {"position": 1.0, "rot": 1.0, "deltaPosition": 1.0, "linearVelocity": 1.0, "angularVelocity": 1.0,
+                    "normalImpulse": 1.0, "tangentImpulse": 1.0, "impulse": 1.0, "motorImpulse": 1.0, "lowerImpulse": 1.0, "upperImpulse": 1.0}
+
+
+def sweeps_touching_bodies(params):
+    """Passes over the constraints in one s2Solve_* call: the solve sweeps of wire.solve_sweeps_per_step plus one warm
+    start per sub-step (or per step) -- the count the per-sweep tolerance is multiplied by."""
+    name = wire.SOLVER_NAMES[params.solverType]
+    solve = wire.solve_sweeps_per_step(name, params.velIters, params.posIters)
+    substepping = name in ("TGS_Soft", "SoftStep", "TGS_Sticky", "TGS_NGS", "XPBD")
+    return solve + (params.velIters if substepping else 1)
+
+
+def relative_errors(got, want):
+    """{field: (max abs error, scale, error / scale)} over every float solver output (norm-wise, see above)."""
+    gb, gc, gj = got
+    wb, wc, wj = want
+    live = wb["type"] >= 0
+    out = {}
+
+    def note(name, g, w, floor):
+        g = np.asarray(g, dtype=np.float64)
+        w = np.asarray(w, dtype=np.float64)
+        if g.size == 0:
+            return
+        finite = np.isfinite(w)
+        assert np.array_equal(finite, np.isfinite(g)), name + ": NaN / inf where the oracle has none (or the reverse)"
+        err = float(np.max(np.abs(g[finite] - w[finite]), initial=0.0))
+        scale = max(float(np.max(np.abs(w[finite]), initial=0.0)), floor)
+        out[name] = (err, scale, err / scale)
+    for f in BODY_OUT:
+        note("body." + f, gb[f][live], wb[f][live], FAST_SCALE_FLOOR[f])
+    for f in ["normalImpulse", "tangentImpulse"]:
+        note("point." + f, gc["points"][f], wc["points"][f], FAST_SCALE_FLOOR[f])
+    livej = wj["type"] >= 0
+    for f in JOINT_OUT:
+        note("joint." + f, gj[f][livej], wj[f][livej], FAST_SCALE_FLOOR[f])
+    return out
+
+
+def compare_close(got, want, sweeps, what="", rtol_per_sweep=FAST_RTOL_PER_SWEEP):
+    """The tolerance-mode comparison: every output field within rtol_per_sweep * sweeps of the oracle, norm-wise; integer
+    outputs (constraintIndex, frictionPersisted) exactly."""
+    errs = relative_errors(got, want)
+    bound = rtol_per_sweep * sweeps
+    problems = ["%s: |err| %.3g / scale %.3g = %.3g > %.3g" % (k, e, sc, r, bound) for k, (e, sc, r) in errs.items() if r > bound]
+    act = want[1]["pointCount"] > 0
+    if not np.array_equal(got[1]["constraintIndex"][act], want[1]["constraintIndex"][act]):
+        problems.append("contact.constraintIndex differs")
+    assert not problems, what + "\n  " + "\n  ".join(problems)
+    return errs

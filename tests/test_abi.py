@@ -28,6 +28,28 @@ def test_library_exports_every_declared_symbol():
     assert L.s2amd_api_version() == wire.API_VERSION
 
 
+def test_tolerance_mode_library_exports_the_same_abi_and_says_what_it_is():
+    """solver2d_amd/libs2amd_fast.so (the same sources, FMA contraction on in the device code): same symbols, same version; the two
+    builds tell themselves apart (s2amd_build_flags), and the device code really differs -- v_fma / v_pk_fma instructions appear in the
+    contracted build's headline kernel and not in the bit-exact one's."""
+    fast, exact = hip.load(fast=True), hip.load()
+    assert fast is not exact
+    for n in declared_functions():
+        assert hasattr(fast, n), n
+    assert fast.s2amd_api_version() == wire.API_VERSION
+    assert exact.s2amd_build_flags() == b"fp-contract=off" and fast.s2amd_build_flags() == b"fp-contract=fast"
+    # the S2AMD_OPTIONS passthrough names a bad entry instead of raising a bare ValueError (ADVICE r4)
+    os.environ["S2AMD_OPTIONS"] = "graph"
+    try:
+        with pytest.raises(hip.S2AmdError) as e:
+            hip.env_options()
+        assert "graph" in str(e.value)
+        os.environ["S2AMD_OPTIONS"] = "graph=0, strip_patience=2"
+        assert hip.env_options() == [("graph", 0), ("strip_patience", 2)]
+    finally:
+        del os.environ["S2AMD_OPTIONS"]
+
+
 def test_struct_sizes_match_header(tmp_path):
     src = tmp_path / "sz.c"
     src.write_text('#include "solver2d_amd.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'

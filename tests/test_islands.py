@@ -94,6 +94,28 @@ def test_sticky_partition_moves_only_the_smaller_part_of_a_merged_island():
     assert fresh.tolist() == isl.partition(weights, 2).tolist()
 
 
+def test_sticky_partition_rebalances_when_islands_have_drifted_onto_one_shard():
+    """merged islands always go to the rank that held most of their bodies, so under sustained churn the load drifts.  Past
+    REBALANCE_THRESHOLD (heaviest shard / mean) the heaviest shard's lightest islands move to the least loaded shard until it is met."""
+    from solver2d_amd import islands as isl
+    # eight islands of one body each, all of them previously on shard 0 of 4
+    island = np.arange(8, dtype=np.int32)
+    previous = np.zeros(8, dtype=np.int32)
+    weights = np.array([10, 10, 10, 10, 10, 10, 10, 10])
+    shard = isl.sticky_partition(island, 8, weights, previous, 4)
+    load = np.bincount(shard, weights=weights, minlength=4)
+    assert load.max() <= isl.REBALANCE_THRESHOLD * load.mean()
+    assert (shard == 0).sum() >= 2  # ... and no more moves than that takes: shard 0 keeps what it can
+    # lightest first, lowest index among equals, to the least loaded shard (lowest index among equals)
+    assert shard.tolist()[:3] == [1, 2, 3]
+    # below the threshold nothing moves (the case of the test above: 18 against a mean of 14)
+    keep = isl.sticky_partition(np.array([0, 1], dtype=np.int32), 2, np.array([18, 10]), np.array([0, 1], dtype=np.int32), 2)
+    assert keep.tolist() == [0, 1]
+    # one island too heavy for any move to help stays where it is
+    heavy = isl.sticky_partition(np.array([0, 1], dtype=np.int32), 2, np.array([100, 1]), np.array([0, 0], dtype=np.int32), 2)
+    assert heavy.tolist() == [0, 1]
+
+
 def test_shard_world_with_previous_owner_keeps_untouched_islands_in_place():
     from solver2d_amd import islands as isl
     world = synthetic.pyramid(5, count=6)

@@ -30,8 +30,9 @@ def test_library_exports_every_declared_symbol():
 
 def test_tolerance_mode_library_exports_the_same_abi_and_says_what_it_is():
     """solver2d_amd/libs2amd_fast.so (the same sources, FMA contraction on in the device code): same symbols, same version; the two
-    builds tell themselves apart (s2amd_build_flags), and the device code really differs -- v_fma / v_pk_fma instructions appear in the
-    contracted build's headline kernel and not in the bit-exact one's."""
+    builds tell themselves apart (s2amd_build_flags).  (The device code really differs: wideStepKernel's four main variants hold 512
+    v_pk_fma_f32 and 2,000 more v_fma_f32 in the contracted build, none of the former and only the divide / sqrt expansions' of the
+    latter in the bit-exact one -- hipcc -S, round 5.)"""
     fast, exact = hip.load(fast=True), hip.load()
     assert fast is not exact
     for n in declared_functions():

@@ -1,0 +1,30 @@
+#!/bin/bash
+# The round's GPU calls, one stage per call: tools/gpu_r05.sh <stage> (run by gpurun from the repo root; everything lands under
+# gpurun_out/r5/<stage>/).  Stages: fast (tolerance-mode build: error measurement, its tests, bench line), suite (the whole -m gpu
+# suite), churn (wreck-200 and Tumbler loops with the structure builds' phase times), bench (the driver's command), profile
+# (tools/profile_r05.sh).
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+stage=${1:-suite}
+O=gpurun_out/r5/$stage
+mkdir -p $O
+case $stage in
+fast)
+  timeout 600 python tools/fast_mode_error.py --out $O/fast_mode_error.json > $O/fast_mode_error.log 2>&1; echo "error tool rc=$?"
+  timeout 900 python -m pytest tests/test_gpu_fast.py -q --tb=line -p no:cacheprovider > $O/test_gpu_fast.log 2>&1; echo "fast tests rc=$?"; tail -15 $O/test_gpu_fast.log
+  timeout 600 python bench.py --steps 200 --warmup 60 --no-cpu --no-extras > $O/bench_headline.json 2> $O/bench_headline.err; echo "bench rc=$?"
+  python tools/bench_summary.py $O/bench_headline.json
+  ;;
+suite)
+  timeout 2400 python -m pytest tests -q -m gpu -x -p no:cacheprovider > $O/gpu_suite.log 2>&1; echo "gpu suite rc=$?"; tail -8 $O/gpu_suite.log
+  ;;
+churn)
+  S2AMD_DEBUG_PREP=1 timeout 300 python tools/churn_bench.py --world wreck --steps 240 --trace > $O/churn_wreck200.json 2> $O/churn_wreck200.trace; echo "wreck rc=$?"
+  S2AMD_DEBUG_PREP=1 timeout 300 python tools/churn_bench.py --world tumbler --steps 200 --trace > $O/churn_tumbler.json 2> $O/churn_tumbler.trace; echo "tumbler rc=$?"
+  ;;
+bench)
+  timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; python tools/bench_summary.py $O/bench.json
+  ;;
+*)
+  echo "unknown stage $stage"; exit 2;;
+esac

@@ -112,12 +112,23 @@ def sweeps_touching_bodies(params):
     return solve + (params.velIters if substepping else 1)
 
 
-def relative_errors(got, want):
-    """{field: (max abs error, scale, error / scale)} over every float solver output (norm-wise, see above)."""
+def relative_errors(got, want, params=None):
+    """{field: (max abs error, scale, error / scale)} over every float solver output (norm-wise, see above).
+
+    params of an s2Solve_XPBD call: its two impulse fields get the scale that fits what they are.  solve_xpbd.c:152 / :524 report
+    lambda * inv_h of the LAST position iteration -- lambda = -C / (kA + kB + compliance) with C the residual separation of an
+    almost converged contact: a difference of nearly equal numbers whose error is the POSITION error, whatever its own size.  A
+    position error e_p reaches the reported impulse as e_p * inv_h * (effective mass <= the heaviest body's), so that is the scale:
+    scale(position) * inv_h * max mass (a 400 kg box on a 1 kg box, high_mass_ratio3: 7 units of error on an impulse of 400)."""
     gb, gc, gj = got
     wb, wc, wj = want
     live = wb["type"] >= 0
     out = {}
+    xpbd_scale = None
+    if params is not None and wire.SOLVER_NAMES[params.solverType] == "XPBD":
+        inv_h = params.velIters / float(params.dt)
+        pos_scale = max(float(np.max(np.abs(wb["position"][live]), initial=0.0)), FAST_SCALE_FLOOR["position"])
+        xpbd_scale = pos_scale * inv_h * max(float(np.max(wb["mass"][live], initial=0.0)), 1.0)
 
     def note(name, g, w, floor):
         g = np.asarray(g, dtype=np.float64)
@@ -132,17 +143,17 @@ def relative_errors(got, want):
     for f in BODY_OUT:
         note("body." + f, gb[f][live], wb[f][live], FAST_SCALE_FLOOR[f])
     for f in ["normalImpulse", "tangentImpulse"]:
-        note("point." + f, gc["points"][f], wc["points"][f], FAST_SCALE_FLOOR[f])
+        note("point." + f, gc["points"][f], wc["points"][f], xpbd_scale if xpbd_scale is not None else FAST_SCALE_FLOOR[f])
     livej = wj["type"] >= 0
     for f in JOINT_OUT:
         note("joint." + f, gj[f][livej], wj[f][livej], FAST_SCALE_FLOOR[f])
     return out
 
 
-def compare_close(got, want, sweeps, what="", rtol_per_sweep=FAST_RTOL_PER_SWEEP):
+def compare_close(got, want, sweeps, what="", rtol_per_sweep=FAST_RTOL_PER_SWEEP, params=None):
     """The tolerance-mode comparison: every output field within rtol_per_sweep * sweeps of the oracle, norm-wise; integer
     outputs (constraintIndex, frictionPersisted) exactly."""
-    errs = relative_errors(got, want)
+    errs = relative_errors(got, want, params)
     bound = rtol_per_sweep * sweeps
     problems = ["%s: |err| %.3g / scale %.3g = %.3g > %.3g" % (k, e, sc, r, bound) for k, (e, sc, r) in errs.items() if r > bound]
     act = want[1]["pointCount"] > 0

@@ -12,8 +12,8 @@ if "value_fast" in d:
     if "error" in f:
         print("value_fast: ERROR", f["error"])
     else:
-        print("value_fast %.4g  %.4f ms/step  dominant %.2f us  frac %.3f  vs bit-exact after 30 steps: %s" % (
-            f["value"], f["ms_per_step"], f["roofline"]["avg_launch_us"], f["roofline"]["frac"], f["after_30_steps_vs_bit_exact_build"]))
+        print("value_fast %.4g  %.4f ms/step  dominant %.2f us  frac %.3f  one step vs bit-exact: %s" % (
+            f["value"], f["ms_per_step"], f["roofline"]["avg_launch_us"], f["roofline"]["frac"], {k: v for k, v in f["one_step_vs_bit_exact_build"].items() if k != "from"}))
 for k in ("whole_step", "churn"):
     if k in d:
         print(k, json.dumps({a: b for a, b in d[k].items() if not isinstance(b, (dict, list))})[:600])

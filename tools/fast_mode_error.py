@@ -39,14 +39,14 @@ def main():
             got, want = one(s, params, pre)
             sweeps = common.sweeps_touching_bodies(params)
             name = wire.SOLVER_NAMES[params.solverType]
-            for k, (e, sc, r) in common.relative_errors(got, want).items():
+            for k, (e, sc, r) in common.relative_errors(got, want, params).items():
                 per = r / sweeps
                 if per > worst.get(k, 0.0):
                     worst[k], worst_case[k] = per, os.path.basename(path)
                 per_solver[name] = max(per_solver.get(name, 0.0), per)
     traj = {}
     for base in (40, 200):
-        for solver_name in ("TGS_Soft", "SoftStep", "PGS_Soft"):
+        for solver_name in ("TGS_Soft", "SoftStep", "PGS_Soft") + (("PGS_NGS_Block", "Jacobi") if base == 40 else ()):
             vel, pos = common.DEFAULT_ITERS[solver_name]
             params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
             sweeps = common.sweeps_touching_bodies(params)
@@ -55,7 +55,7 @@ def main():
                 w = 0.0
                 for step in range(a.steps if base == 40 else 4):
                     got, want = one(s, params, state)
-                    w = max(w, max(r for (_e, _sc, r) in common.relative_errors(got, want).values()) / sweeps)
+                    w = max(w, max(r for (_e, _sc, r) in common.relative_errors(got, want, params).values()) / sweeps)
                     state = got  # the fast library's own trajectory: each step is compared from the same input
                 traj["pyramid%d/%s" % (base, solver_name)] = w
     out = {"rtol_per_sweep_stated": common.FAST_RTOL_PER_SWEEP, "worst_per_sweep_by_field": worst, "worst_case_by_field": worst_case,

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define S2AMD_API_VERSION 3
+#define S2AMD_API_VERSION 4
 
 /* error codes */
 #define S2AMD_OK 0
@@ -172,6 +172,9 @@ typedef struct s2amdStepStats
 	int32_t bodiesAdopted;        /* (API 3) bodies without constraints that moved to the strip of the body they first touched (no build), in the structure in use */
 	int32_t seamBodiesAdded;      /* (API 3) bodies a seam between two strips came to carry after the build (one more export / import of its strips) */
 	int32_t roundsOpened;         /* (API 3) spare colour rounds of strips and seams opened for created contacts */
+	int32_t overflowContacts;     /* (API 4) contacts that fit nowhere in the strips and wait in the overflow positions behind them for a worker thread's structure (0: none) */
+	int32_t slicedStep;           /* (API 4) 1: this step ran sliced -- the persistent strip kernel launched once per sweep, the overflow contacts swept behind each launch */
+	int32_t slicedSteps;          /* (API 4) ... steps that did, since s2amd_create */
 	int32_t nearHandoffTimeouts;  /* (API 3) hand-off time-outs while the same-XCD path (workgroup-scope stores between neighbours on one L2) was in use: the step was tried again with agent-scope stores, which the solver keeps */
 } s2amdStepStats;
 

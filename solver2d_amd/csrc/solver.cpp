@@ -919,6 +919,11 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	{
 		s->optStripAdopt = value != 0; // a constraint-free body moves to the strip of the body it first touches (IncrementalStrips)
 	}
+	else if (strcmp(key, "strip_overflow") == 0)
+	{
+		s->optOverflow = value != 0; // a contact that fits nowhere in the strips: overflow position + sliced steps + worker-thread build (IncrementalStrips)
+		s->structureDirty = true;
+	}
 	else if (strcmp(key, "stage_joints") == 0)
 	{
 		s->optStageJoints = value != 0;
@@ -937,6 +942,10 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	}
 	else if (strcmp(key, "self_contained_strips") == 0)
 	{
+		if (s->optSelfContainedStrips != (value != 0 ? 1 : 0))
+		{
+			s->structureDirty = true; // (the overflow region behind the strips is laid out for the multi-launch form of the step only)
+		}
 		s->optSelfContainedStrips = value != 0;
 	}
 	else if (strcmp(key, "free_body_groups") == 0)

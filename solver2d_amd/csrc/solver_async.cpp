@@ -408,7 +408,8 @@ void asyncShutdown(s2amdSolver* s)
 }
 
 // `search`: the graph has been at rest long enough for the search over strip widths (the copy sees the same age and runs it)
-int asyncRequest(s2amdSolver* s, int solverType, bool search)
+// `forceStrips`: the copy builds its strips whatever the graph's age (the live structure runs sliced until it is adopted)
+int asyncRequest(s2amdSolver* s, int solverType, bool search, bool forceStrips)
 {
 	reap(s->async, false);
 	if (asyncPending(s))
@@ -466,6 +467,10 @@ int asyncRequest(s2amdSolver* s, int solverType, bool search)
 	if (search)
 	{
 		c->stripRetryPending = false;
+	}
+	if (forceStrips)
+	{
+		c->stripPatienceNow = 0;
 	}
 	job->clone = c;
 	c->cancelBuild = &job->cancel;
@@ -584,17 +589,31 @@ bool asyncAdopt(s2amdSolver* s, int solverType, int* rcOut)
 	ok = ok && replay(c, job->log);
 	if (ok && c->watchedCount > 0)
 	{
-		// a slot the copy only watches (no entry in its structure) must not have gained its manifold points meanwhile
+		// a slot the copy only watches (no entry in its structure) that has gained its manifold points meanwhile -- the live structure has
+		// placed it: a strip round, an overflow position -- takes its place in the copy's strips now, as it would have had the copy been
+		// live (the order the world chain places flips in: ascending slots); one that fits nowhere there refuses the adoption
 		if (fetchPointCounts(s) != S2AMD_OK)
 		{
 			ok = false;
 		}
+		std::vector<ContactChange> flipped;
 		for (int i = 0; ok && i < s->contactCapacity; ++i)
 		{
 			if (c->hContactWatched[(size_t)i] && s->hContactPoints[(size_t)i] > 0 && c->inc.positionOfSlot[(size_t)i] == -1)
 			{
-				ok = false;
+				if (c->hContactEdge[(size_t)i] && !c->hContactDead[(size_t)i] && c->stripInc.valid && stripCanPlace(c, c->hContactA[(size_t)i], c->hContactB[(size_t)i]))
+				{
+					flipped.push_back(ContactChange{i, c->hContactA[(size_t)i], c->hContactB[(size_t)i]});
+				}
+				else
+				{
+					ok = false;
+				}
 			}
+		}
+		if (ok && !flipped.empty())
+		{
+			ok = incrementalApply(c, flipped) && incrementalFlush(c) == S2AMD_OK && hipStreamSynchronize(c->stream) == hipSuccess;
 		}
 	}
 	if (ok)

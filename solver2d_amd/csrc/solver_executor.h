@@ -455,7 +455,7 @@ struct Executor
 	bool selfContainedStrips() const
 	{
 		int kind, warm;
-		return s->optSelfContainedStrips && s->dStripA.view.groupCount > 0 && persistPlan(kind, warm) && kind == SOFT_TGS && widePlan(kind, warm) && wideFits(true, false) && gatherIndex == nullptr && !msg &&
+		return s->optSelfContainedStrips && !slicedPlan() && s->dStripA.view.groupCount > 0 && persistPlan(kind, warm) && kind == SOFT_TGS && widePlan(kind, warm) && wideFits(true, false) && gatherIndex == nullptr && !msg &&
 			   wireBodies() != nullptr && s->dGroups.view.groupCount == 0 && s->dResident.view.groupCount == 0 && s->looseBodies == 0 && !anyGlobalContacts() &&
 			   s->joints.globalCount == 0 && s->jv.count == 0 && s->cv.count == s->persistK1 - s->persistK0 && p.prepContacts == PREP_SOFT && p.storeKind == STORE_PLAIN;
 	}
@@ -639,6 +639,76 @@ struct Executor
 		return 0;
 	}
 
+	// the ops the persistent kernels take, as uploadPersistOps lays them out on the device
+	std::vector<Op> keptOps() const
+	{
+		std::vector<Op> kept;
+		for (const Op& o : p.ops)
+		{
+			if (!sweepsNothing(o))
+			{
+				kept.push_back(o);
+			}
+		}
+		return kept;
+	}
+
+	// contacts in the overflow region behind the strips (solver_internal.h: IncrementalStrips): the step runs sliced
+	bool slicedPlan() const { return s->stripInc.valid && s->stripInc.overflowUsed > 0; }
+
+	// The persistent step SLICED: one launch of wideStepKernel per sweep, with that sweep's ops (the body stages before it ride along) --
+	// the kernel stages its bodies and records at every launch and writes bodies and impulses back at its end, so the state between
+	// two launches is complete in the SoA arrays --, and behind each launch the overflow contacts' turn of the same sweep, one after
+	// the other on the bodies in HBM (the colour-batch kernels of the global part; their positions come last in the sweep order).
+	// Hand-off tags restart in every launch: the buffers are cleared in between.
+	void runPersistentSliced(int kind, int warm)
+	{
+		const std::vector<Op> kept = keptOps();
+		const int n = (int)kept.size();
+		PersistView pv = s->persist;
+		pv.nearHandoff = s->nearHandoffNow;
+		for (int i = 0; i < 2; ++i)
+		{
+			pv.softCoef[i] = make_float4(p.sc.softCoef[i][0], p.sc.softCoef[i][1], p.sc.softCoef[i][2], 0.0f);
+		}
+		if (!(kind == SOFT_TGS && warm == WARM_CURRENT))
+		{
+			pv.ldsRecords = s->persistRecordsWide;
+		}
+		pv.bodyWarm = 0;
+		const IncrementalStrips& m = s->stripInc;
+		int first = 0;
+		bool launched = false;
+		for (int i = 0; i < n; ++i)
+		{
+			const Op& o = kept[(size_t)i];
+			const bool sweep = o.code == OP_WARM || leanSoftKind(o);
+			if (!sweep && i + 1 < n)
+			{
+				continue;
+			}
+			if (launched)
+			{
+				clearGranules(st);
+			}
+			launchWideStep(st, kind, s->cv, s->bv, s->leanA, pv, (const Op*)s->dPersistOps.p + first, i + 1 - first, nullptr);
+			count();
+			launched = true;
+			if (sweep)
+			{
+				for (int k = m.overflowBegin; k < m.overflowEnd; ++k)
+				{
+					if (s->contacts.order[(size_t)k] >= 0)
+					{
+						launchContactBatch(o, k, k + 1);
+						count();
+					}
+				}
+			}
+			first = i + 1;
+		}
+	}
+
 	void clearGranules(hipStream_t where)
 	{
 		(void)hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, where); // epochs restart at 1 every launch
@@ -721,7 +791,14 @@ struct Executor
 		int kind, warm;
 		if (persistPlan(kind, warm))
 		{
-			runPersistent(kind, warm);
+			if (slicedPlan() && widePlan(kind, warm))
+			{
+				runPersistentSliced(kind, warm); // (doStep has made sure that overflow contacts only meet this kernel)
+			}
+			else
+			{
+				runPersistent(kind, warm);
+			}
 			return;
 		}
 		if (genericPlan())

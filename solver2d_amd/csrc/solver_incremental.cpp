@@ -609,6 +609,31 @@ bool stripPlace(s2amdSolver* s, Patcher& p, const ContactChange& ch)
 	return false; // every round is taken on these bodies, or full
 }
 
+// A contact between bodies the strips own that fits in none of their rounds: the lowest free overflow position (solver_internal.h:
+// IncrementalStrips).  One patched word -- contactIndex[k]; the colour-batch kernels that sweep it read the bodies' pool slots, which
+// the prologue writes for every position (contact_kernels.hip: prepareContactsKernel).
+bool overflowPlace(s2amdSolver* s, Patcher& p, const ContactChange& ch)
+{
+	IncrementalStrips& m = s->stripInc;
+	if (!overflowCanPlace(s, ch.a, ch.b) || ch.slot >= (int)m.positionOfSlot.size() || m.positionOfSlot[(size_t)ch.slot] >= 0)
+	{
+		return false;
+	}
+	const int k = m.overflowFree.back();
+	m.overflowFree.pop_back();
+	s->contacts.order[(size_t)k] = ch.slot;
+	s->contacts.local[(size_t)k] = make_int2(0, 0);
+	m.positionOfSlot[(size_t)ch.slot] = k;
+	s->inc.positionOfSlot[(size_t)ch.slot] = -2;
+	p.word(s->dContactIndex.p, (size_t)k, (uint32_t)ch.slot);
+	m.overflowUsed += 1;
+	m.overflowPlaced += 1;
+	s->placedTotal += 1;
+	s->slackPositions -= 1;
+	s->layoutGeneration += 1; // (the launch sequence changes: a captured step graph is dropped)
+	return true;
+}
+
 // the entry of `slot` in the strips becomes a free position again
 bool stripRemove(s2amdSolver* s, Patcher& p, int slot)
 {
@@ -618,6 +643,19 @@ bool stripRemove(s2amdSolver* s, Patcher& p, int slot)
 		return false;
 	}
 	const int k = m.positionOfSlot[(size_t)slot];
+	if (k >= m.overflowBegin && k < m.overflowEnd)
+	{
+		// an overflow position (no round, no local slots): free again; the launch sequence loses its sweeps
+		s->contacts.order[(size_t)k] = -1;
+		p.word(s->dContactIndex.p, (size_t)k, (uint32_t)-1);
+		m.overflowFree.insert(std::upper_bound(m.overflowFree.begin(), m.overflowFree.end(), k, std::greater<int>()), k); // stays descending
+		m.overflowUsed -= 1;
+		m.positionOfSlot[(size_t)slot] = -1;
+		s->inc.positionOfSlot[(size_t)slot] = -1;
+		s->slackPositions += 1;
+		s->layoutGeneration += 1;
+		return true;
+	}
 	IncrementalStrips::Round& round = m.rounds[(size_t)m.roundOfPosition[(size_t)(k - m.base)]];
 	const int off = m.bodyOffset[round.table][(size_t)round.group];
 	const int2 l = s->contacts.local[(size_t)k];
@@ -778,6 +816,12 @@ bool incrementalApply(s2amdSolver* s, const std::vector<ContactChange>& changes)
 			{
 				inc.inserted += 1;
 				unwatchSlot(s, ch.slot); // structural from here on: its manifold may gain and lose points at no cost
+				continue;
+			}
+			if (overflowPlace(s, p, ch))
+			{
+				inc.inserted += 1;
+				unwatchSlot(s, ch.slot);
 				continue;
 			}
 			return giveUp("body owned by a group or strip");
@@ -1018,6 +1062,32 @@ bool stripCanPlace(const s2amdSolver* s, int a, int b)
 	}
 	int table, group, la, lb, mover = -1;
 	return stripHome(s, a, b, table, group, la, lb, &mover);
+}
+
+bool overflowCanPlace(const s2amdSolver* s, int a, int b)
+{
+	const IncrementalStrips& m = s->stripInc;
+	const int nb = (int)s->hBodyFlagsFinal.size();
+	if (!m.valid || m.overflowFree.empty() || s->optOverflow == 0 || s->optIncremental == 0 || s->structureDirty || a < 0 || b < 0 || a >= nb || b >= nb || a == b)
+	{
+		return false;
+	}
+	// the sliced step is the 512-thread persistent kernel's (wide_kernel.hip), and a structure that will hold the contact has to come
+	// from a worker thread while the steps go on: the world chain
+	if (!asyncBuildsOn(s) || !s->persistValid || s->persistFailed || s->optWide == 0 || s->optPersist == 0)
+	{
+		return false;
+	}
+	if ((int)s->hBodyHub.size() == nb && (s->hBodyHub[(size_t)a] || s->hBodyHub[(size_t)b]))
+	{
+		return false;
+	}
+	// both bodies live in the strips (owned by one, or read-only replicas of bodies nothing writes)
+	auto inStrips = [&](int body) {
+		const bool writes = (s->hBodyFlags[(size_t)body] & (s->inc.solverClass == 1 ? S2F_WRITE_POS : S2F_WRITE_VEL)) != 0;
+		return !writes || (body < (int)m.ownerStrip.size() && m.ownerStrip[(size_t)body] >= 0);
+	};
+	return inStrips(a) && inStrips(b);
 }
 
 bool tailCanPlace(const s2amdSolver* s, int a, int b)

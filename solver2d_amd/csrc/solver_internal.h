@@ -284,7 +284,20 @@ struct IncrementalStrips
 	std::vector<int> seamBodyCount;		   // per seam group: local bodies it has now
 	std::vector<int> seamExtra[2];		   // per seam group: bodies appended on its left / right side since the build
 	long seamBodiesAdded = 0;
+	// ... and a contact that fits NOWHERE in the strips (a ball that touches boxes two strips apart: a body on two seams is what the
+	// partition cannot have).  Until round 5 that was a structure build in the step that found it -- 5 ms on the caller's thread.  Now
+	// the sweep order ends in S2_OVERFLOW_SLACK free positions BEHIND the strips, each a colour batch of its own; such a contact takes
+	// the lowest of them, and while any of them is in use the step runs SLICED (Executor::runPersistentSliced): the persistent kernel
+	// is launched once per sweep with that sweep's ops -- it stages and writes back its bodies and impulses every time --, and behind
+	// each launch the overflow contacts are swept one by one on the bodies in HBM by the colour-batch kernels (any position of a
+	// sequential sweep is a valid one: the oracle sweeps in it).  ~75 launches and ~0.5 ms per step instead of 3 and 0.15 -- for the
+	// dozen steps a worker thread needs to build a structure that holds the contact (solver_async.cpp), adopted at a step boundary.
+	int overflowBegin = 0, overflowEnd = 0; // positions of the overflow region in contacts.order (0, 0: none)
+	std::vector<int> overflowFree;			// descending: pop_back() hands out the lowest
+	int overflowUsed = 0;
+	long overflowPlaced = 0;
 };
+#define S2_OVERFLOW_SLACK 32
 #define S2_STRIP_ADOPT_SLACK 8
 #define S2_TAIL_SLACK 64
 #define S2_TAIL_BODY_SLACK 32
@@ -509,6 +522,9 @@ struct SolverRest
 	// thing to go when a hand-off times out -- the step is tried again with agent-scope stores before the one-launch kernels are given up
 	int optNearHandoff = 1, nearHandoffNow = 1, nearHandoffTimeouts = 0;
 	int optStripAdopt = 1;	  // a body without constraints moves to the strip of the body it first touches instead of forcing a rebuild
+	int optOverflow = 1;	  // "strip_overflow": a contact that fits nowhere in the strips takes an overflow position (sliced steps + a worker-thread build) instead of a rebuild in this step
+	long slicedSteps = 0;	  // steps that ran sliced, since s2amd_create
+	bool slicedThisStep = false;
 	int stripPatienceNow = 1; // ... as it stands: doubled every time a strip structure died young (noteGraphChanged)
 	bool stripPatienceSet = false; // "strip_patience" was set by the caller (else a resident world builds its strips at once: stripPatienceBase)
 	int optStripsAnySolver = 0; // tests: strips for every solver and with joints (through the generic group interpreter)
@@ -645,7 +661,7 @@ int syncDeadSlots(s2amdSolver* s);
 // solver_async.cpp: structure builds in a worker thread on a copy of the solver, adopted a fixed number of steps later
 bool asyncBuildsOn(const s2amdSolver* s);
 bool asyncPending(const s2amdSolver* s);
-int asyncRequest(s2amdSolver* s, int solverType, bool search);
+int asyncRequest(s2amdSolver* s, int solverType, bool search, bool forceStrips = false);
 bool asyncAdopt(s2amdSolver* s, int solverType, int* rc);
 void asyncDrop(s2amdSolver* s);
 void asyncLogCreated(s2amdSolver* s, int slot, int a, int b);
@@ -664,6 +680,9 @@ void deferCreated(s2amdSolver* s, int slot, int a, int b);
 void unwatchSlot(s2amdSolver* s, int slot);
 int uploadWatched(s2amdSolver* s);
 bool stripCanPlace(const s2amdSolver* s, int a, int b);
+// ... or, failing that, a free position of the overflow region behind the strips (IncrementalStrips::overflowFree): the steps run sliced
+// until a worker thread's structure that holds the contact is adopted
+bool overflowCanPlace(const s2amdSolver* s, int a, int b);
 // ... or, between two bodies of the global part, a colour position or a free position of the sequential tail (IncrementalGlobal::tailFree)?
 bool tailCanPlace(const s2amdSolver* s, int a, int b);
 bool incrementalApply(s2amdSolver* s, const std::vector<ContactChange>& changes);

@@ -159,7 +159,7 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 			deferred.push_back(ContactChange{i, c.bodyA, c.bodyB});
 			continue;
 		}
-		if (edge && pc > 0 && (placeFlips || (stripFlips && stripCanPlace(s, c.bodyA, c.bodyB)) || (!newWorld && onHub(c.bodyA, c.bodyB) && tailCanPlace(s, c.bodyA, c.bodyB))) &&
+		if (edge && pc > 0 && (placeFlips || (stripFlips && (stripCanPlace(s, c.bodyA, c.bodyB) || overflowCanPlace(s, c.bodyA, c.bodyB))) || (!newWorld && onHub(c.bodyA, c.bodyB) && tailCanPlace(s, c.bodyA, c.bodyB))) &&
 			(!s->hContactEdge[i] || s->hContactA[i] != c.bodyA || s->hContactB[i] != c.bodyB) && canDeferCreated(s, i, c.bodyA, c.bodyB))
 		{
 			// created AND touching at first sight (the caller ran stage 3 itself): the world chain, which sees the contact created
@@ -178,7 +178,7 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 		if (edge && !s->hContactWatched.empty() && s->hContactWatched[(size_t)i] && (oldPoints > 0) != (pc > 0))
 		{
 			// a watched manifold (on a hub body, or deferred) gained or lost its points (solver_internal.h: hContactWatched)
-			if (placeFlips || (stripFlips && stripCanPlace(s, c.bodyA, c.bodyB)) || (!newWorld && tailCanPlace(s, c.bodyA, c.bodyB)))
+			if (placeFlips || (stripFlips && (stripCanPlace(s, c.bodyA, c.bodyB) || overflowCanPlace(s, c.bodyA, c.bodyB))) || (!newWorld && tailCanPlace(s, c.bodyA, c.bodyB)))
 			{
 				if (pc > 0 && i < (int)s->inc.positionOfSlot.size() && s->inc.positionOfSlot[(size_t)i] == -1)
 				{
@@ -387,6 +387,16 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 			return rcAdopt;
 		}
 	}
+	if (s->stripInc.valid && s->stripInc.overflowUsed > 0 && !s->structureDirty && asyncBuildsOn(s) && !asyncPending(s))
+	{
+		// contacts in the overflow region behind the strips: the steps run sliced until a worker thread's structure that holds them is
+		// adopted (solver_internal.h: IncrementalStrips); asked for here when none is on its way (the first step, or after one was dropped)
+		int rcAsync = asyncRequest(s, params->solverType, false, true);
+		if (rcAsync)
+		{
+			return rcAsync;
+		}
+	}
 	if (s->persistFailed && s->optPersistRetry > 0 && ++s->persistFailedAge > s->persistRetryAfter)
 	{
 		// a hand-off timed out a while ago (workgroups not co-resident: something else held part of the GPU): try again
@@ -478,6 +488,22 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 			}
 		}
 	}
+	{
+		// overflow contacts are swept between the launches of the SLICED 512-thread kernel and by nothing else: a plan or a state that
+		// kernel cannot take (another solver family, a hand-off that timed out, option "wide" off) gets its structure built now
+		Executor probe{s, s->stream, plan, isPositionSolver(params->solverType) ? 1 : 0, false};
+		int kind, warm;
+		if (probe.slicedPlan() && !(s->dStripA.view.groupCount > 0 && probe.persistPlan(kind, warm) && probe.widePlan(kind, warm)))
+		{
+			s->structureDirty = true;
+			s->dirtyReason = "overflow contacts off the sliced kernel";
+			asyncDrop(s);
+			if ((rc = buildStructure(s, params->solverType)) != 0)
+			{
+				return rc;
+			}
+		}
+	}
 	Executor q{s, s->stream, plan, isPositionSolver(params->solverType) ? 1 : 0, s->optProfile != 0};
 	q.msg = messageEligible(s, params->solverType);
 	s->stats.messagePassing = q.msg ? 1 : 0;
@@ -497,6 +523,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	}
 	s->launchCounter = 0;
 	s->sweepEventsUsed = 0;
+	s->slicedThisStep = false;
 
 	const bool xpbdEarlyOut = plan.earlyOut;
 	const bool writesConstraintIndex = !xpbdEarlyOut && params->solverType != s2amd_solverPGS_NGS_Block;
@@ -645,6 +672,14 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	s->stats.persistFallbacks = s->persistFallbacks;
 	s->stats.asyncBuildsRequested = s->asyncRequested, s->stats.asyncBuildsAdopted = s->asyncAdopted, s->stats.asyncWaitMs = s->asyncWaitMs;
 	s->stats.nearHandoffTimeouts = s->nearHandoffTimeouts;
+	{
+		int kind, warm;
+		s->slicedThisStep = s->dStripA.view.groupCount > 0 && q.slicedPlan() && q.persistPlan(kind, warm) && q.widePlan(kind, warm) && !q.selfContainedStrips();
+		s->slicedSteps += s->slicedThisStep ? 1 : 0;
+		s->stats.overflowContacts = s->stripInc.valid ? s->stripInc.overflowUsed : 0;
+		s->stats.slicedStep = s->slicedThisStep ? 1 : 0;
+		s->stats.slicedSteps = (int32_t)s->slicedSteps;
+	}
 	s->stats.bodiesAdopted = (int32_t)s->stripInc.adopted, s->stats.seamBodiesAdded = (int32_t)s->stripInc.seamBodiesAdded, s->stats.roundsOpened = (int32_t)s->stripInc.roundsOpened;
 	s->stats.structureBuilds = (int32_t)s->structureGeneration;
 	s->stats.placedContacts = (int32_t)s->placedTotal;

@@ -1562,6 +1562,7 @@ struct StructureBuild
 	};
 	std::vector<SpareRound> spareRounds; // the closed spare rounds of the strips (table 0) and seams (table 1): emitGroup
 	int stripBaseC = 0;
+	int overflowBase = 0, overflowCount = 0; // the overflow region behind the strips (IncrementalStrips::overflowFree)
 	bool rebuild = false; // the structure just built cannot run: build again with what was learnt (stripsRejected / residentRejected)
 
 	double t0, tPhase;
@@ -2463,6 +2464,21 @@ struct StructureBuild
 				s->looseBodies += 1;
 			}
 		}
+		// the overflow region (solver_internal.h: IncrementalStrips): free positions behind everything else, one colour batch each, for
+		// created contacts that fit nowhere in the strips -- where a worker thread can build the structure that will hold them (the world
+		// chain and its workers' copies) and the step is not the self-contained strip kernel's (which is its own prologue and epilogue)
+		overflowBase = (int)cs.order.size(), overflowCount = 0;
+		if (strips.active && stripSlackWanted && js.stripCount == 0 && s->optOverflow != 0 && s->optAsyncBuild != 0 && (s->worldResident || s->isClone) &&
+			s->optSelfContainedStrips == 0 && isSoftFamily(solverType))
+		{
+			overflowCount = S2_OVERFLOW_SLACK;
+			for (int i = 0; i < overflowCount; ++i)
+			{
+				cs.order.push_back(-1);
+				cs.local.push_back(make_int2(0, 0));
+				cs.colorOffsets.push_back((int)cs.order.size());
+			}
+		}
 
 		if (prepTimes)
 		{
@@ -2710,6 +2726,11 @@ struct StructureBuild
 			}
 			m.spareOf[sp.table][(size_t)sp.group].push_back((int)m.rounds.size());
 			m.rounds.push_back(std::move(r));
+		}
+		m.overflowBegin = overflowBase, m.overflowEnd = overflowBase + overflowCount;
+		for (int k = m.overflowEnd - 1; k >= m.overflowBegin; --k)
+		{
+			m.overflowFree.push_back(k);
 		}
 		m.valid = true;
 	}

@@ -539,7 +539,9 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 		}
 		if (hSum->watchedFlips > 0)
 		{
-			asyncDrop(s); // (a watched manifold gained or lost its points: a build in flight was made without that)
+			// (a watched manifold gained or lost its points.  A build in flight that was asked for after the contact was created holds it as
+			// an ordinary potential constraint; one from before only watches it and is refused at adoption -- solver_async.cpp: asyncAdopt.
+			// So the build is dropped only when the flip cannot be placed and the structure is rebuilt here: noteGraphChanged.)
 			// s2Solve_Jacobi has no colours to find: a watched manifold that gained its first points gets a position and its two
 			// incidence-list entries like a created contact (one that lost its points stays where it is, a no-op); every other
 			// solver's structure is rebuilt
@@ -566,8 +568,11 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 						s->inc.positionOfSlot[(size_t)i] == -1)
 					{
 						flipped.push_back(ContactChange{i, s->hContactA[(size_t)i], s->hContactB[(size_t)i]});
+						// (r5: ... or, where it fits no strip round, an overflow position behind the strips: the steps run sliced until a
+						// worker thread's structure is adopted -- solver_internal.h: IncrementalStrips)
 						placeable = placeable && (jacobi || inGlobalPart(s->hContactA[(size_t)i], s->hContactB[(size_t)i]) ||
-												  (strips && stripCanPlace(s, s->hContactA[(size_t)i], s->hContactB[(size_t)i])));
+												  (strips && (stripCanPlace(s, s->hContactA[(size_t)i], s->hContactB[(size_t)i]) ||
+															  overflowCanPlace(s, s->hContactA[(size_t)i], s->hContactB[(size_t)i]))));
 					}
 				}
 				handled = placeable && (flipped.empty() || incrementalApply(s, flipped));

@@ -7,7 +7,7 @@ library.  Arrays of these dtypes are what the Python host side hands to the C en
 import ctypes
 import numpy as np
 
-API_VERSION = 3
+API_VERSION = 4
 
 SOLVER_NAMES = [
     "Jacobi", "PGS", "PGS_NGS", "PGS_NGS_Block", "PGS_Soft",
@@ -101,7 +101,8 @@ class StepStats(ctypes.Structure):
         ("stripCount", ctypes.c_int32), ("seamCount", ctypes.c_int32), ("persistent", ctypes.c_int32), ("persistFallbacks", ctypes.c_int32),
         ("structureBuilds", ctypes.c_int32), ("placedContacts", ctypes.c_int32), ("potentialConstraints", ctypes.c_int32), ("pairLanes", ctypes.c_int32),
         ("asyncBuildsRequested", ctypes.c_int32), ("asyncBuildsAdopted", ctypes.c_int32), ("asyncWaitMs", ctypes.c_float),
-        ("bodiesAdopted", ctypes.c_int32), ("seamBodiesAdded", ctypes.c_int32), ("roundsOpened", ctypes.c_int32), ("nearHandoffTimeouts", ctypes.c_int32),
+        ("bodiesAdopted", ctypes.c_int32), ("seamBodiesAdded", ctypes.c_int32), ("roundsOpened", ctypes.c_int32),
+        ("overflowContacts", ctypes.c_int32), ("slicedStep", ctypes.c_int32), ("slicedSteps", ctypes.c_int32), ("nearHandoffTimeouts", ctypes.c_int32),
     ]
 
 

@@ -247,6 +247,68 @@ def world_chain_async(base, steps):
     return seen
 
 
+def overflow_chain(base, steps):
+    """A contact that fits nowhere in the strips (two boxes many strips apart: a body on two seams is what the partition cannot have)
+    takes an overflow position behind the strips instead of a rebuild in that step; the steps run sliced while a worker thread builds
+    the structure that holds it, adopted a fixed number of steps later (solver_internal.h: IncrementalStrips; solver_async.cpp).
+    Returns per step (overflowContacts, slicedStep, requested, adopted, structureBuilds, kernelLaunches)."""
+    world = synthetic.pyramid_world(base)
+    keys = ("bodies", "contacts", "joints", "shapes", "pairs", "origins")
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    # sixteen free pool slots behind the live ones
+    spare_c = np.zeros(16, dtype=wire.contact_dtype)
+    spare_c["bodyA"], spare_c["bodyB"], spare_c["constraintIndex"] = -1, -1, -1
+    spare_p = np.zeros(16, dtype=wire.pair_state_dtype)
+    spare_p["shapeA"], spare_p["shapeB"] = -1, -1
+    world["contacts"] = np.concatenate([world["contacts"], spare_c])
+    world["pairs"] = np.concatenate([world["pairs"], spare_p])
+    free = sorted(np.flatnonzero(world["pairs"]["shapeA"] < 0).tolist(), reverse=True)
+    assert len(free) == 16
+    dynamic = np.flatnonzero(world["bodies"]["type"] == wire.BODY_DYNAMIC)
+    seen = []
+
+    def touch(s, a, b, slot, points):
+        contacts = np.zeros(1, dtype=wire.contact_dtype)
+        pairs = np.zeros(1, dtype=wire.pair_state_dtype)
+        contacts["bodyA"], contacts["bodyB"], contacts["friction"], contacts["constraintIndex"] = a, b, 0.6, -1
+        contacts["pointCount"] = points
+        contacts["normal"] = (0.0, 1.0)
+        pairs["shapeA"], pairs["shapeB"] = a, b  # (one shape per body, same index)
+        s.world_set_contacts(np.array([slot], dtype=np.int32), contacts, pairs)
+
+    def release(s, slot):
+        contacts = np.zeros(1, dtype=wire.contact_dtype)
+        pairs = np.zeros(1, dtype=wire.pair_state_dtype)
+        contacts["bodyA"], contacts["bodyB"], contacts["constraintIndex"] = -1, -1, -1
+        pairs["shapeA"], pairs["shapeB"] = -1, -1
+        s.world_set_contacts(np.array([slot], dtype=np.int32), contacts, pairs)
+
+    with hip.Solver(0) as s:
+        for k, v in (("strip_patience", 0), ("async_build_delay", 4)):
+            s.set_option(k, v)
+        s.world_upload(*[world[k] for k in keys])
+        mine = []
+        for step in range(steps):
+            if step in (3, 5, 6) and free:
+                owner, _seam, strips = s.strip_owners(len(world["bodies"]))
+                assert strips > 4, strips
+                # two boxes whose strips are not neighbours
+                a = int(dynamic[step])
+                far = [int(d) for d in dynamic if owner[d] >= 0 and abs(int(owner[d]) - int(owner[a])) >= 3]
+                b = far[len(far) // 2 + step]
+                slot = free.pop()
+                touch(s, a, b, slot, 2)
+                mine.append(slot)
+            if step == 8 and mine:
+                release(s, mine.pop(0))  # (destroyed while it waits in the overflow region, or just after the adoption)
+            s.world_step(params)
+            st = s.stats()
+            seen.append((st["overflowContacts"], st["slicedStep"], st["asyncBuildsRequested"], st["asyncBuildsAdopted"], st["structureBuilds"], st["kernelLaunches"]))
+        order, offsets = s.contact_order()
+        assert len(order) == len(set(order.tolist()))
+    return seen
+
+
 def hub_rule():
     """A writable body whose constraints would cost more as colour rounds of a strip than on the tail (S2_COST_*: more than 23) keeps its graph off the strips
     (solver_structure.cpp: cutStrips); the same pile without the hub is cut into strips."""
@@ -350,6 +412,12 @@ def main():
     seen = world_chain_async(30, 24 if quick else 60)
     print("world chain, structure builds in a worker thread: (strips, requested, adopted, builds) per step:", seen[::4])
     assert seen[-1][1] >= 1 and seen[-1][2] >= 1 and seen[-1][0] > 0, seen
+    seen = overflow_chain(100, 24)
+    print("overflow positions behind the strips: (overflow contacts, sliced, requested, adopted, builds, launches) per step:", seen)
+    assert max(x[0] for x in seen) >= 1 and any(x[1] for x in seen), seen  # a contact waited in the overflow region, steps ran sliced
+    assert seen[-1][3] >= 1 and seen[-1][0] == 0 and seen[-1][1] == 0, seen  # ... until the worker's structure was adopted
+    first = next(i for i, x in enumerate(seen) if x[0] > 0)
+    assert seen[first][4] == seen[first - 1][4], seen  # no structure build in the step that found the contact
     print("HOSTCHECK OK")
 
 

@@ -104,13 +104,14 @@ def run(a):
             t5 = time.perf_counter()
             moved = info["movedCount"]
             if a.trace:
-                sys.stderr.write("step %d: %.2f ms, created %d separated %d active %d potential %d launches %d hostPrep %.2f colours %d placed %d builds %d persistent %d fallbacks %d kernel %d\n" % (
+                sys.stderr.write("step %d: %.2f ms, created %d separated %d active %d potential %d launches %d hostPrep %.2f colours %d placed %d builds %d persistent %d fallbacks %d kernel %d overflow %d sliced %d async %d/%d\n" % (
                     step, 1e3 * (t5 - t0), created, info["separatedCount"], info["activeContacts"], st["potentialConstraints"], st["kernelLaunches"], st["hostPrepMs"],
-                    st["contactColors"], st["placedContacts"], st["structureBuilds"], st["persistent"], st["persistFallbacks"], st["pairLanes"]))
+                    st["contactColors"], st["placedContacts"], st["structureBuilds"], st["persistent"], st["persistFallbacks"], st["pairLanes"], st["overflowContacts"], st["slicedStep"],
+                    st["asyncBuildsRequested"], st["asyncBuildsAdopted"]))
             rows.append({"step_ms": 1e3 * (t5 - t0), "pair_query_ms": 1e3 * (t1 - t0), "create_py_ms": 1e3 * (t2 - t1), "set_contacts_ms": 1e3 * (t3 - t2),
                          "world_step_ms": 1e3 * (t4 - t3), "destroy_py_ms": 1e3 * (t5 - t4), "host_structure_ms": st["hostPrepMs"], "solve_device_ms": info["solveMs"],
                          "created": created, "separated": info["separatedCount"], "flips": info["graphChanged"], "active": info["activeContacts"],
-                         "launches": st["kernelLaunches"], "persistent": st["persistent"], "replayed": st["graphReplayed"], "strips": st["stripCount"]})
+                         "launches": st["kernelLaunches"], "persistent": st["persistent"], "replayed": st["graphReplayed"], "strips": st["stripCount"], "sliced": st["slicedStep"], "overflow": st["overflowContacts"]})
     def mean(key, sel):
         v = [r[key] for r in sel]
         return sum(v) / max(len(v), 1)
@@ -129,6 +130,10 @@ def run(a):
            "steps_on_persistent_kernel": sum(r["persistent"] for r in rows), "steps_replayed_from_graph": sum(r["replayed"] for r in rows),
            "joined_without_rebuild": {"bodies_moved_to_the_strip_they_touched": st["bodiesAdopted"], "bodies_added_to_a_seam": st["seamBodiesAdded"], "spare_rounds_opened": st["roundsOpened"],
                                       "note": "counters of the structure in use at the last step (a rebuild starts them again)"},
+           "overflow": {"steps_run_sliced": sum(r["sliced"] for r in rows), "most_contacts_waiting": max(r["overflow"] for r in rows),
+                        "sliced_step_ms_median": median("step_ms", [r for r in rows if r["sliced"]]), "sliced_step_launches_median": median("launches", [r for r in rows if r["sliced"]]),
+                        "note": "a contact that fits nowhere in the strips waits in an overflow position behind them while a worker thread builds the structure "
+                                "that holds it; until that is adopted the persistent kernel is launched once per sweep and the overflow contacts are swept behind each launch"},
            "structure_builds_by_the_worker_thread": {"requested": st["asyncBuildsRequested"], "adopted": st["asyncBuildsAdopted"], "caller_waited_ms": st["asyncWaitMs"]},
            "steps_over_1ms": sum(1 for r in rows[2:] if r["step_ms"] > 1.0), "steps_over_2ms": sum(1 for r in rows[2:] if r["step_ms"] > 2.0),
            "all_steps": {k: mean(k, rows) for k in keys}, "churn_steps": {k: mean(k, churn) for k in keys}, "quiet_steps": {k: mean(k, quiet) for k in keys},

@@ -22,6 +22,13 @@ churn)
   S2AMD_DEBUG_PREP=1 timeout 300 python tools/churn_bench.py --world wreck --steps 240 --trace > $O/churn_wreck200.json 2> $O/churn_wreck200.trace; echo "wreck rc=$?"
   S2AMD_DEBUG_PREP=1 timeout 300 python tools/churn_bench.py --world tumbler --steps 200 --trace > $O/churn_tumbler.json 2> $O/churn_tumbler.trace; echo "tumbler rc=$?"
   ;;
+scan)
+  # which wrecking-ball worlds meet a contact that fits nowhere in their strips (overflow positions, sliced steps)
+  for base in 100 60; do for seed in 0 1 2 3 4 5 6 7; do
+    timeout 120 python tools/churn_bench.py --world wreck --base $base --seed $seed --steps 160 > $O/wreck_${base}_$seed.json 2> $O/wreck_${base}_$seed.err
+    python -c "import json,sys; d=json.load(open('$O/wreck_${base}_$seed.json')); print('base $base seed $seed', d['overflow']['steps_run_sliced'], d['overflow']['most_contacts_waiting'], 'rebuilds', d['steps_that_rebuilt_the_structure'], 'async', d['structure_builds_by_the_worker_thread'], 'over1ms', d['steps_over_1ms'], d['slowest_steps_ms'][:3])"
+  done; done
+  ;;
 bench)
   timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; python tools/bench_summary.py $O/bench.json
   ;;

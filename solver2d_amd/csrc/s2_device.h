@@ -528,6 +528,8 @@ struct PersistView
 	int maxStaged;		// the most bodies a strip stages (own list + both imports)
 	int maxStripBodies; // ... of them in its own list (owned + read-only replicas)
 	int bodyWarm;		// wide_kernel.hip: s2WarmStartContacts as one body-centric pass (set at launch when the term table fits LDS)
+	int clearOwn;		// wide_kernel.hip, sliced step (one launch per sweep): the kernel zeroes the hand-off buffers it reads and its census entry at its
+						// end, as the step's epilogue launch does after the last slice -- every launch starts from zero tags without a memset in between
 	unsigned long long* debugTimes; // S2AMD_DEBUG_TIMES: wall_clock64() of one workgroup at kernel start, after the loads, after every op, at the end
 };
 

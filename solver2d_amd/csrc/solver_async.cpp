@@ -196,6 +196,7 @@ struct AsyncBuild
 	bool dropped = false;  // overtaken by the graph: the result is thrown away when the worker is done
 	std::atomic<int> cancel{0}; // ... and the worker is told: a search stops after the build it is in (SolverRest::cancelBuild)
 	long requestedAtStep = 0;
+	int delay = 0; // steps between the request and the adoption
 	struct Event
 	{
 		int kind; // 0 created (slot, a, b), 1 destroyed (slot)
@@ -373,6 +374,12 @@ bool asyncPending(const s2amdSolver* s)
 	return s->async != nullptr && !s->async->dropped;
 }
 
+// ... and is it the search over strip widths (adopted only when it scores better, eight times the delay away)?
+bool asyncPendingSearch(const s2amdSolver* s)
+{
+	return asyncPending(s) && s->async->search;
+}
+
 // the graph moved in a way the pending build cannot follow: its result will be thrown away
 void asyncDrop(s2amdSolver* s)
 {
@@ -477,6 +484,9 @@ int asyncRequest(s2amdSolver* s, int solverType, bool search, bool forceStrips)
 	job->solverType = solverType;
 	job->search = search;
 	job->requestedAtStep = s->stepCounter;
+	// (a build the live structure is waiting for -- it runs sliced meanwhile -- falls due sooner: one strip build is ~5 ms of the worker's time,
+	// a sliced step ~0.8 ms of the caller's)
+	job->delay = search ? 8 * s->optAsyncBuildDelay : (forceStrips ? std::max(2, (2 * s->optAsyncBuildDelay) / 3) : s->optAsyncBuildDelay);
 	if (search)
 	{
 		// (the request itself costs the caller a device synchronisation -- the point counts, the freed pairs -- and a copy of the
@@ -543,7 +553,7 @@ bool asyncAdopt(s2amdSolver* s, int solverType, int* rcOut)
 	{
 		return false; // (its worker is still running: reaped at a later step)
 	}
-	const long due = job->requestedAtStep + (job->search ? 8L * s->optAsyncBuildDelay : (long)s->optAsyncBuildDelay);
+	const long due = job->requestedAtStep + (long)job->delay;
 	if (s->stepCounter < due)
 	{
 		return false;
@@ -586,6 +596,10 @@ bool asyncAdopt(s2amdSolver* s, int solverType, int* rcOut)
 			s->stripSearchPause = 256, s->stripSearchNotBefore = 0; // (it paid off: the next one may come as soon as it is asked for)
 		}
 	}
+	// (replay and placement on the copy grow its patch buffers: from the workers' pool, not through hipHostMalloc / hipMalloc, which
+	// stall this -- the stepping -- thread for milliseconds: 10.7 ms measured on the step a search fell due in, r5)
+	const bool poolWas = devPoolOn();
+	devPoolThread(true);
 	ok = ok && replay(c, job->log);
 	if (ok && c->watchedCount > 0)
 	{
@@ -616,6 +630,7 @@ bool asyncAdopt(s2amdSolver* s, int solverType, int* rcOut)
 			ok = incrementalApply(c, flipped) && incrementalFlush(c) == S2AMD_OK && hipStreamSynchronize(c->stream) == hipSuccess;
 		}
 	}
+	devPoolThread(poolWas);
 	if (ok)
 	{
 		std::swap(static_cast<SolverStructure&>(*s), static_cast<SolverStructure&>(*c));

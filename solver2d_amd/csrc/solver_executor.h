@@ -660,7 +660,7 @@ struct Executor
 	// the kernel stages its bodies and records at every launch and writes bodies and impulses back at its end, so the state between
 	// two launches is complete in the SoA arrays --, and behind each launch the overflow contacts' turn of the same sweep, one after
 	// the other on the bodies in HBM (the colour-batch kernels of the global part; their positions come last in the sweep order).
-	// Hand-off tags restart in every launch: the buffers are cleared in between.
+	// Hand-off tags restart in every launch: each launch clears the buffers it read at its end (PersistView::clearOwn).
 	void runPersistentSliced(int kind, int warm)
 	{
 		const std::vector<Op> kept = keptOps();
@@ -676,9 +676,9 @@ struct Executor
 			pv.ldsRecords = s->persistRecordsWide;
 		}
 		pv.bodyWarm = 0;
+		pv.clearOwn = 1; // (every launch leaves the buffers it read at zero tags for the next one: no memset between the slices)
 		const IncrementalStrips& m = s->stripInc;
 		int first = 0;
-		bool launched = false;
 		for (int i = 0; i < n; ++i)
 		{
 			const Op& o = kept[(size_t)i];
@@ -687,13 +687,8 @@ struct Executor
 			{
 				continue;
 			}
-			if (launched)
-			{
-				clearGranules(st);
-			}
 			launchWideStep(st, kind, s->cv, s->bv, s->leanA, pv, (const Op*)s->dPersistOps.p + first, i + 1 - first, nullptr);
 			count();
-			launched = true;
 			if (sweep)
 			{
 				for (int k = m.overflowBegin; k < m.overflowEnd; ++k)

@@ -661,6 +661,7 @@ int syncDeadSlots(s2amdSolver* s);
 // solver_async.cpp: structure builds in a worker thread on a copy of the solver, adopted a fixed number of steps later
 bool asyncBuildsOn(const s2amdSolver* s);
 bool asyncPending(const s2amdSolver* s);
+bool asyncPendingSearch(const s2amdSolver* s);
 int asyncRequest(s2amdSolver* s, int solverType, bool search, bool forceStrips = false);
 bool asyncAdopt(s2amdSolver* s, int solverType, int* rc);
 void asyncDrop(s2amdSolver* s);

@@ -387,8 +387,9 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 			return rcAdopt;
 		}
 	}
-	if (s->stripInc.valid && s->stripInc.overflowUsed > 0 && !s->structureDirty && asyncBuildsOn(s) && !asyncPending(s))
+	if (s->stripInc.valid && s->stripInc.overflowUsed > 0 && !s->structureDirty && asyncBuildsOn(s) && (!asyncPending(s) || asyncPendingSearch(s)))
 	{
+		asyncDrop(s); // (a search over strip widths in flight: it was made without the contact and is a hundred steps from falling due)
 		// contacts in the overflow region behind the strips: the steps run sliced until a worker thread's structure that holds them is
 		// adopted (solver_internal.h: IncrementalStrips); asked for here when none is on its way (the first step, or after one was dropped)
 		int rcAsync = asyncRequest(s, params->solverType, false, true);

@@ -1615,6 +1615,27 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 			}
 		}
 	}
+	if constexpr (!SELF)
+	{
+		// sliced step (Executor::runPersistentSliced): the next launch of this step starts its tags from zero again.  Every granule
+		// this workgroup reads has been written for the last time -- a neighbour writes one granule set per sweep and this workgroup
+		// has read the last sweep's -- and launches of one stream do not overlap, so the reader clears its own inboxes (both
+		// parities), as the self-contained form does behind its commit.  (The census entries stay: the next launch's workgroups
+		// write the same XCD ids again -- and were the placement ever to differ, a hand-off on the same-L2 path would time out and the
+		// step be repeated with agent-scope stores: solver_step.cpp.)
+		if (pv.clearOwn != 0 && !bad)
+		{
+			if (ht < nImpH)
+			{
+#pragma unroll
+				for (int par = 0; par < 2; ++par)
+				{
+					gu64* p = gran + par * pv.parityStride + inH + 4 * ht;
+					p[0] = 0ull, p[1] = 0ull, p[2] = 0ull, p[3] = 0ull;
+				}
+			}
+		}
+	}
 	stampAt(7);
 	if (stamp)
 	{

@@ -394,6 +394,7 @@ typedef struct AmdApi
 	int (*worldDownloadBoxes)(s2amdSolver*, s2amdShapeBox*, int32_t);
 	int (*worldSetRefitOrder)(s2amdSolver*, const int32_t*, int32_t);
 	int (*worldDownloadStep)(s2amdSolver*, float*, int32_t, s2amdMovedBox*, int32_t, int32_t*);
+	int (*setOption)(s2amdSolver*, const char*, int32_t);
 } AmdApi;
 static AmdApi s_api = {0};
 
@@ -505,6 +506,7 @@ int s2amdBinding_Open(const char* libraryPath, int device)
 		S2_BIND(worldDownloadBoxes, "s2amd_world_download_boxes")
 		S2_BIND(worldSetRefitOrder, "s2amd_world_set_refit_order")
 		S2_BIND(worldDownloadStep, "s2amd_world_download_step")
+		S2_BIND(setOption, "s2amd_set_option")
 #undef S2_BIND
 	}
 	s_api.device = device;
@@ -917,6 +919,8 @@ static int uploadWorld(s2World* w, WorldBinding* b)
 		b->liveKey[i] = b->pairs[i].shapeA < 0 ? -1 : ((int64_t)b->pairs[i].shapeA << 32) | (int64_t)b->pairs[i].shapeB;
 		b->liveCount += b->liveKey[i] >= 0 ? 1 : 0;
 	}
+	// the world knows its solver (world->solverType, src/world.c:75): the structure is built with the upload, not in the first steps
+	(void)s_api.setOption(b->solver, "prebuild_solver", (int32_t)w->solverType);
 	rc = s_api.worldUpload(b->solver, b->bodies, nb, b->contacts, nc, b->joints, nj, b->shapes, ns, b->pairs, b->origins);
 	if (rc != 0)
 	{

@@ -919,6 +919,10 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	{
 		s->optStripAdopt = value != 0; // a constraint-free body moves to the strip of the body it first touches (IncrementalStrips)
 	}
+	else if (strcmp(key, "prebuild_solver") == 0)
+	{
+		s->optPrebuildSolver = value; // s2amd_world_upload builds the structure for this s2amdSolverType (-1: the first step does)
+	}
 	else if (strcmp(key, "strip_overflow") == 0)
 	{
 		s->optOverflow = value != 0; // a contact that fits nowhere in the strips: overflow position + sliced steps + worker-thread build (IncrementalStrips)

@@ -426,8 +426,10 @@ int asyncRequest(s2amdSolver* s, int solverType, bool search, bool forceStrips)
 	HIP_TRY(hipSetDevice(s->device));
 	// what a synchronous build would learn from the device first (buildStructureWith, gatherEdges): the pairs stage 3 has freed, and --
 	// for the hub rule -- which manifolds have points right now.  The copy then builds from host state alone.
-	if (!s->pointsKnown)
+	if (!s->pointsKnown && !(forceStrips && s->pointCountsFresh))
 	{
+		// (forceStrips: the flip that asked for this build has just read the point counts, and a pair stage 3 freed this step lingers in
+		// the copy's structure as it does in the live one -- a no-op -- until it is read at the end of the step)
 		int rc = syncDeadSlots(s);
 		if (rc == S2AMD_OK)
 		{
@@ -477,7 +479,10 @@ int asyncRequest(s2amdSolver* s, int solverType, bool search, bool forceStrips)
 	}
 	if (forceStrips)
 	{
+		// (the live structure runs sliced until this one is adopted: its strips at once and ONE build -- the search over strip widths, tens
+		// of milliseconds, is asked for again by the adopted structure when the graph has been quiet for a while)
 		c->stripPatienceNow = 0;
+		c->optStripRetry = 0;
 	}
 	job->clone = c;
 	c->cancelBuild = &job->cancel;

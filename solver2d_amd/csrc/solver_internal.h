@@ -463,6 +463,8 @@ struct SolverRest
 	std::vector<int> hContactPoints; // manifold point counts as of the last host upload / the last fetchPointCounts (see pointsKnown)
 	bool deadUnknown = false;		   // pairs separated on the device since the host last looked (syncDeadSlots, world.hip)
 	bool pointsKnown = false; // hContactPoints is current: no stage 3 has recomputed manifolds on the device since the upload
+	bool pointCountsFresh = false; // ... or fetchPointCounts has read them since this step's stage 3 (cleared when the next one is enqueued)
+	int optPrebuildSolver = -1; // "prebuild_solver": s2amd_world_upload builds the structure for this solver type (strips at once) so that the first step has nothing to build; -1: the first step does
 	int activeContacts = 0;	  // manifolds with points this step (host count, or the device's counter in the world chain)
 	bool lastStepWroteIndex = false; // the last solve's driver writes manifold.constraintIndex (all but XPBD's early-out and Block)
 	DevBuf dScanTmp;

@@ -413,6 +413,51 @@ def test_wrecking_ball_world_loop(seed, solver_name):
         assert strips > 0
 
 
+@pytest.mark.parametrize("seed,solver_name", [(1, "TGS_Soft"), (3, "TGS_Soft"), (7, "SoftStep"), (6, "PGS_Soft")])
+def test_a_contact_that_fits_nowhere_in_the_strips_waits_behind_them(seed, solver_name):
+    """SURVEY.md 8f row 4 (round 5): a ball that comes to touch boxes two strips apart used to cost a structure build in the step that
+    found the contact (5 ms on the caller's thread at base 200).  Now the contact takes an OVERFLOW position behind the strips
+    (solver_internal.h: IncrementalStrips), the steps run SLICED -- the persistent kernel launched once per sweep, the overflow contacts
+    swept behind each launch -- while a worker thread builds the structure that holds it, adopted at a step boundary.  The whole loop at
+    base 100 with the default options, 150 steps, every step of it bit-exact against the oracle chain swept in the device's order -- through
+    the sliced steps, the adoption, and the steps on the adopted structure; and no structure build in a step that found such a contact."""
+    from tests import common
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+    world = world_chain.wreck_world(seed, 100)
+    ref = world_chain.copy_world(world)
+    sliced = adopted = 0
+    rows = []
+    with hip.Solver(0) as s:
+        s.world_upload(*[world[k] for k in world_chain.WORLD_KEYS])
+        for step in range(150):
+            if world_chain.moved_any(ref):
+                got = s.world_find_pairs()
+                want = world_chain.oracle_find_pairs(ref)
+                assert np.array_equal(got, want), "step %d: new pairs" % step
+                if len(got):
+                    slots, contacts, pairs = _create_contacts(ref, got)
+                    s.world_set_contacts(slots, contacts, pairs)
+            info = s.world_step(params)
+            order, _ = s.contact_order()
+            status = world_chain.oracle_world_step(params, ref, contact_order=order)
+            assert info["separatedCount"] == int((status == wire.PAIR_SEPARATED).sum()), "step %d" % step
+            st = s.stats()
+            rows.append((st["overflowContacts"], st["slicedStep"], st["structureBuilds"], st["asyncBuildsAdopted"], st["kernelLaunches"]))
+            sliced += st["slicedStep"]
+            adopted = st["asyncBuildsAdopted"]
+            if st["slicedStep"] or step % 8 == 7 or step < 3:
+                out = world_chain.copy_world(world)
+                res = s.world_download(*[out[k] for k in world_chain.WORLD_KEYS])
+                world_chain.assert_device_equals_oracle(dict(zip(world_chain.WORLD_KEYS, res[:6])), ref,
+                                                        "overflow %d %s step %d (overflow %d, sliced %d)" % (seed, solver_name, step, st["overflowContacts"], st["slicedStep"]))
+    assert sliced > 0 and adopted >= 1, rows
+    for i in range(1, len(rows)):
+        if rows[i][0] > rows[i - 1][0]:
+            # one more contact in the overflow region: that step built nothing (an adoption in the same step counts as a build)
+            assert rows[i][2] == rows[i - 1][2] or rows[i][3] > rows[i - 1][3], (i, rows[i - 1], rows[i])
+
+
 @pytest.mark.parametrize("solver_name", ["TGS_Soft", "SoftStep", "PGS_Soft"])
 def test_settling_pyramid_physical_tolerances(solver_name):
     """SURVEY.md 8c, parity link L3: the device (colour order, device narrow phase and refit) against the reference

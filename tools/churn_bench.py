@@ -73,6 +73,7 @@ def run(a):
     free = sorted(np.flatnonzero(world["pairs"]["shapeA"] < 0).tolist(), reverse=True)
     rows = []
     with hip.Solver(getattr(a, "device", 0)) as s:
+        s.set_option("prebuild_solver", wire.SOLVER_ID[a.solver])  # (a caller knows its world's solver: the structure is built with the upload)
         for kv in a.opt:
             k, v = kv.split("=")
             s.set_option(k, int(v))

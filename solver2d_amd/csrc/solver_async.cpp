@@ -506,6 +506,49 @@ int asyncRequest(s2amdSolver* s, int solverType, bool search, bool forceStrips)
 	return S2AMD_OK;
 }
 
+// The first worker-thread build finds the pool empty and makes its twenty-odd device blocks with hipMalloc -- which serialises with every
+// HIP call of the process: the steps beside that build stalled for 4-8 ms (measured, r5: the step that asks for the first search, the
+// step that asks for the first overflow build).  So once a world has its structure, blocks of the sizes a copy will ask for -- the live
+// structure's own -- and one pinned patch buffer go into the pool while nothing depends on the step's latency (the upload, or the first
+// step's tail).  Twice the structure's device memory: tens of megabytes at 60k constraints.
+int asyncPrewarm(s2amdSolver* s)
+{
+	if (s->poolWarmed || s->optAsyncBuild == 0 || s->isClone || s->structureDirty)
+	{
+		return S2AMD_OK;
+	}
+	s->poolWarmed = true;
+	HIP_TRY(hipSetDevice(s->device));
+	SolverStructure& t = *s;
+	const DevBuf* bufs[] = {&t.dWatched, &t.dBodyFlags, &t.soaBodies, &t.soaContacts, &t.soaJoints, &t.dContactIndex, &t.dJointIndex, &t.dContactLocal, &t.dJointLocal,
+							&t.dAdjOffsets, &t.dAdjList, &t.dAdjHeavy, &t.dPatches, &t.dJointAdjRange, &t.dJointAdjList, &t.dResidentDesc, &t.dResidentOps, &t.dStripLean,
+							&t.dPersist, &t.dGranules, &t.dPersistOps, &t.dMsg, &t.dGroups.buf, &t.dContactTail.buf, &t.dJointTail.buf, &t.dStripA.buf, &t.dStripB.buf,
+							&t.dResident.buf};
+	for (const DevBuf* b : bufs)
+	{
+		const size_t bytes = std::max<size_t>(b->bytes, 4096);
+		void* p = nullptr;
+		HIP_TRY(hipMalloc(&p, bytes));
+		if (!devPoolGive(p, bytes))
+		{
+			(void)hipFree(p);
+			break;
+		}
+	}
+	void* pinned = nullptr;
+	const size_t pinnedBytes = 8192 * sizeof(uint4);
+	if (hipHostMalloc(&pinned, pinnedBytes, hipHostMallocDefault) == hipSuccess)
+	{
+		pinnedPoolGive(pinned, pinnedBytes);
+	}
+	else
+	{
+		(void)hipGetLastError();
+	}
+	workerStreamGive(workerStreamTake());
+	return S2AMD_OK;
+}
+
 // the logged changes of the graph, applied to the copy as s2amd_world_set_contacts / s2amd_world_step applied them to the live structure
 static bool replay(s2amdSolver* c, const std::vector<AsyncBuild::Event>& log)
 {
@@ -620,7 +663,8 @@ bool asyncAdopt(s2amdSolver* s, int solverType, int* rcOut)
 		{
 			if (c->hContactWatched[(size_t)i] && s->hContactPoints[(size_t)i] > 0 && c->inc.positionOfSlot[(size_t)i] == -1)
 			{
-				if (c->hContactEdge[(size_t)i] && !c->hContactDead[(size_t)i] && c->stripInc.valid && stripCanPlace(c, c->hContactA[(size_t)i], c->hContactB[(size_t)i]))
+				if (c->hContactEdge[(size_t)i] && !c->hContactDead[(size_t)i] && c->stripInc.valid &&
+					(stripCanPlace(c, c->hContactA[(size_t)i], c->hContactB[(size_t)i]) || overflowCanPlace(c, c->hContactA[(size_t)i], c->hContactB[(size_t)i])))
 				{
 					flipped.push_back(ContactChange{i, c->hContactA[(size_t)i], c->hContactB[(size_t)i]});
 				}
@@ -636,6 +680,13 @@ bool asyncAdopt(s2amdSolver* s, int solverType, int* rcOut)
 		}
 	}
 	devPoolThread(poolWas);
+	static const bool debugAsync = getenv("S2AMD_DEBUG_ASYNC") != nullptr;
+	if (debugAsync)
+	{
+		fprintf(stderr, "[s2amd] step %ld: build requested at step %ld (%s) %s: rc %d, solver %d/%d, copy dirty %d, %zu logged events, copy watches %d, strips %d, overflow in use %d\n",
+				s->stepCounter, job->requestedAtStep, job->search ? "search" : "build", ok ? "ADOPTED" : "refused", job->rc, job->solverType, solverType, c->structureDirty ? 1 : 0,
+				job->log.size(), c->watchedCount, c->dStripA.view.groupCount, c->stripInc.valid ? c->stripInc.overflowUsed : -1);
+	}
 	if (ok)
 	{
 		std::swap(static_cast<SolverStructure&>(*s), static_cast<SolverStructure&>(*c));

@@ -1074,7 +1074,9 @@ bool overflowCanPlace(const s2amdSolver* s, int a, int b)
 	}
 	// the sliced step is the 512-thread persistent kernel's (wide_kernel.hip), and a structure that will hold the contact has to come
 	// from a worker thread while the steps go on: the world chain
-	if (!asyncBuildsOn(s) || !s->persistValid || s->persistFailed || s->optWide == 0 || s->optPersist == 0)
+	// (a worker's copy takes overflow contacts too -- the changes replayed on it at its adoption: the structure that replaces the live one
+	// may itself run sliced until the next one is adopted)
+	if (!(asyncBuildsOn(s) || (s->isClone && s->optAsyncBuild != 0)) || !s->persistValid || s->persistFailed || s->optWide == 0 || s->optPersist == 0)
 	{
 		return false;
 	}

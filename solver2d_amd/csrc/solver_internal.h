@@ -565,6 +565,7 @@ struct SolverRest
 							   // colour batches meanwhile); adopted a fixed number of steps after the request; 0: everything on the caller's thread
 	int optAsyncBuildDelay = 12; // "async_build_delay": steps between the request and the adoption of a strip build (the search: 8 x); the caller waits if the worker is not done by then
 	bool isClone = false;	   // a worker's copy: the wire and world buffers are the owner's
+	bool poolWarmed = false;   // asyncPrewarm has stocked the workers' pool for this solver's world
 	long stepCounter = 0;	   // steps enqueued since s2amd_create (the clock of the deferred adoption)
 	// the search over strip widths (seven more builds, a copy of the solver for the worker): after a request the next one waits
 	// `stripSearchPause` steps, twice as long every time (a pile with a ball in it needs its seven rounds at any width, and a search
@@ -666,6 +667,7 @@ bool asyncPending(const s2amdSolver* s);
 bool asyncPendingSearch(const s2amdSolver* s);
 int asyncRequest(s2amdSolver* s, int solverType, bool search, bool forceStrips = false);
 bool asyncAdopt(s2amdSolver* s, int solverType, int* rc);
+int asyncPrewarm(s2amdSolver* s);
 void asyncDrop(s2amdSolver* s);
 void asyncLogCreated(s2amdSolver* s, int slot, int a, int b);
 void asyncLogDestroyed(s2amdSolver* s, int slot);

@@ -502,6 +502,10 @@ int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapa
 			return rcBuild;
 		}
 		HIP_TRY(hipStreamSynchronize(s->stream));
+		if ((rcBuild = asyncPrewarm(s)) != 0)
+		{
+			return rcBuild;
+		}
 	}
 	return S2AMD_OK;
 }
@@ -683,6 +687,10 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 			continue;
 		}
 		break;
+	}
+	if (!s->poolWarmed && asyncBuildsOn(s) && (rc = asyncPrewarm(s)) != 0)
+	{
+		return rc; // (a world uploaded without "prebuild_solver": stocked behind its first step)
 	}
 	WorldSummary contactsSeen = haveFirst ? firstSeen : *hSum;
 	if (contactsSeen.separated > 0)

@@ -451,7 +451,8 @@ def test_a_contact_that_fits_nowhere_in_the_strips_waits_behind_them(seed, solve
                 res = s.world_download(*[out[k] for k in world_chain.WORLD_KEYS])
                 world_chain.assert_device_equals_oracle(dict(zip(world_chain.WORLD_KEYS, res[:6])), ref,
                                                         "overflow %d %s step %d (overflow %d, sliced %d)" % (seed, solver_name, step, st["overflowContacts"], st["slicedStep"]))
-    assert sliced > 0 and adopted >= 1, rows
+    changes = [(i, r) for i, r in enumerate(rows) if i == 0 or r[:4] != rows[i - 1][:4]]  # (step, row) wherever anything but the launch count moved
+    assert sliced > 0 and adopted >= 1, str(changes)
     for i in range(1, len(rows)):
         if rows[i][0] > rows[i - 1][0]:
             # one more contact in the overflow region: that step built nothing (an adoption in the same step counts as a build)

@@ -193,6 +193,7 @@ struct AsyncBuild
 	int rc = S2AMD_OK;
 	int solverType = 0;
 	bool search = false;   // the search over strip widths (buildStructure with the graph at rest), not only the strip structure
+	bool forced = false;   // the live structure runs sliced until this build is adopted (overflow contacts)
 	bool dropped = false;  // overtaken by the graph: the result is thrown away when the worker is done
 	std::atomic<int> cancel{0}; // ... and the worker is told: a search stops after the build it is in (SolverRest::cancelBuild)
 	long requestedAtStep = 0;
@@ -479,15 +480,17 @@ int asyncRequest(s2amdSolver* s, int solverType, bool search, bool forceStrips)
 	}
 	if (forceStrips)
 	{
-		// (the live structure runs sliced until this one is adopted: its strips at once and ONE build -- the search over strip widths, tens
-		// of milliseconds, is asked for again by the adopted structure when the graph has been quiet for a while)
+		// (the live structure runs sliced until this one is adopted: its strips at once, and ONE build where that gives a partition the
+		// resident kernel runs -- solver_structure.cpp: buildStructure; the search for the best strip width, tens of milliseconds, is asked
+		// for again by the adopted structure when the graph has been quiet for a while)
 		c->stripPatienceNow = 0;
-		c->optStripRetry = 0;
+		c->forcedBuild = true;
 	}
 	job->clone = c;
 	c->cancelBuild = &job->cancel;
 	job->solverType = solverType;
 	job->search = search;
+	job->forced = forceStrips;
 	job->requestedAtStep = s->stepCounter;
 	// (a build the live structure is waiting for -- it runs sliced meanwhile -- falls due sooner: one strip build is ~5 ms of the worker's time,
 	// a sliced step ~0.8 ms of the caller's)
@@ -511,7 +514,7 @@ int asyncRequest(s2amdSolver* s, int solverType, bool search, bool forceStrips)
 // step that asks for the first overflow build).  So once a world has its structure, blocks of the sizes a copy will ask for -- the live
 // structure's own -- and one pinned patch buffer go into the pool while nothing depends on the step's latency (the upload, or the first
 // step's tail).  Twice the structure's device memory: tens of megabytes at 60k constraints.
-int asyncPrewarm(s2amdSolver* s)
+int asyncPrewarm(s2amdSolver* s, int solverType)
 {
 	if (s->poolWarmed || s->optAsyncBuild == 0 || s->isClone || s->structureDirty)
 	{
@@ -546,6 +549,22 @@ int asyncPrewarm(s2amdSolver* s)
 		(void)hipGetLastError();
 	}
 	workerStreamGive(workerStreamTake());
+	// ... and one build by a worker thread, thrown away: the first thread that talks to the HIP runtime, the first launches of the kernels a
+	// build uses and the first copy of the solver cost the steps beside them 4-8 ms each (r5: the requests at steps 32 and 87 of the
+	// wrecking-ball loop) -- paid here instead
+	if (asyncPending(s))
+	{
+		return S2AMD_OK;
+	}
+	const int requestedWas = s->asyncRequested;
+	int rc = asyncRequest(s, solverType, false, true);
+	if (rc)
+	{
+		return rc;
+	}
+	asyncDrop(s);
+	reap(s->async, true);
+	s->asyncRequested = requestedWas;
 	return S2AMD_OK;
 }
 
@@ -604,6 +623,13 @@ bool asyncAdopt(s2amdSolver* s, int solverType, int* rcOut)
 	const long due = job->requestedAtStep + (long)job->delay;
 	if (s->stepCounter < due)
 	{
+		return false;
+	}
+	if (job->forced && !job->done.load(std::memory_order_acquire))
+	{
+		// a build the live structure waits for in sliced steps: one that needed the search over strip widths after all is not waited for
+		// on the stepping thread (tens of milliseconds) -- it falls due a few steps later
+		job->delay += 4;
 		return false;
 	}
 	// due: the step at which the sweep order changes is fixed, so a worker that is not done yet is waited for
@@ -686,6 +712,10 @@ bool asyncAdopt(s2amdSolver* s, int solverType, int* rcOut)
 		fprintf(stderr, "[s2amd] step %ld: build requested at step %ld (%s) %s: rc %d, solver %d/%d, copy dirty %d, %zu logged events, copy watches %d, strips %d, overflow in use %d\n",
 				s->stepCounter, job->requestedAtStep, job->search ? "search" : "build", ok ? "ADOPTED" : "refused", job->rc, job->solverType, solverType, c->structureDirty ? 1 : 0,
 				job->log.size(), c->watchedCount, c->dStripA.view.groupCount, c->stripInc.valid ? c->stripInc.overflowUsed : -1);
+	}
+	if (job->forced)
+	{
+		s->overflowRefusals = ok ? 0 : s->overflowRefusals + 1;
 	}
 	if (ok)
 	{

@@ -566,6 +566,10 @@ struct SolverRest
 	int optAsyncBuildDelay = 12; // "async_build_delay": steps between the request and the adoption of a strip build (the search: 8 x); the caller waits if the worker is not done by then
 	bool isClone = false;	   // a worker's copy: the wire and world buffers are the owner's
 	bool poolWarmed = false;   // asyncPrewarm has stocked the workers' pool for this solver's world
+	bool forcedBuild = false;  // (a worker's copy) the live structure runs sliced until this build is adopted: strips at once, and a partition the resident
+							   // kernel can run AND take created contacts into (persistValid, stripInc.valid) is all it asks for -- the search over strip
+							   // widths only when the first width gives neither
+	int overflowRefusals = 0;  // builds for overflow contacts that could not be adopted, in a row: the second one is followed by a build in the step
 	long stepCounter = 0;	   // steps enqueued since s2amd_create (the clock of the deferred adoption)
 	// the search over strip widths (seven more builds, a copy of the solver for the worker): after a request the next one waits
 	// `stripSearchPause` steps, twice as long every time (a pile with a ball in it needs its seven rounds at any width, and a search
@@ -667,7 +671,7 @@ bool asyncPending(const s2amdSolver* s);
 bool asyncPendingSearch(const s2amdSolver* s);
 int asyncRequest(s2amdSolver* s, int solverType, bool search, bool forceStrips = false);
 bool asyncAdopt(s2amdSolver* s, int solverType, int* rc);
-int asyncPrewarm(s2amdSolver* s);
+int asyncPrewarm(s2amdSolver* s, int solverType);
 void asyncDrop(s2amdSolver* s);
 void asyncLogCreated(s2amdSolver* s, int slot, int a, int b);
 void asyncLogDestroyed(s2amdSolver* s, int slot);

@@ -387,6 +387,14 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 			return rcAdopt;
 		}
 	}
+	if (s->stripInc.valid && s->stripInc.overflowUsed > 0 && !s->structureDirty && s->overflowRefusals >= 2)
+	{
+		// two builds for the overflow contacts in a row could not be adopted (a burst of contacts the copies could not follow): the
+		// structure is built here, in the step, as before round 5
+		s->overflowRefusals = 0;
+		s->dirtyReason = "overflow builds refused";
+		noteGraphChanged(s);
+	}
 	if (s->stripInc.valid && s->stripInc.overflowUsed > 0 && !s->structureDirty && asyncBuildsOn(s) && (!asyncPending(s) || asyncPendingSearch(s)))
 	{
 		asyncDrop(s); // (a search over strip widths in flight: it was made without the contact and is a hundred steps from falling due)

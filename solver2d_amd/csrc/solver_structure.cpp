@@ -2899,13 +2899,19 @@ int buildStructure(s2amdSolver* s, int solverType)
 	};
 	const bool triedStrips = s->stripsRejected || s->dStripA.view.groupCount > 0;
 	s->stripRetryPending = false;
-	if (!triedStrips || s->stripsHopeless || satisfied() || (s->stripScaleFound > 0.0f && outcome() >= 2))
+	// (a worker's build for overflow contacts -- SolverRest::forcedBuild: anything the resident kernel runs and the placement can work on)
+	auto usable = [&]() { return s->dStripA.view.groupCount > 0 && s->persistValid && s->stripInc.valid; };
+	if (s->forcedBuild && (usable() || !triedStrips || s->stripsHopeless))
+	{
+		return rc;
+	}
+	if (!s->forcedBuild && (!triedStrips || s->stripsHopeless || satisfied() || (s->stripScaleFound > 0.0f && outcome() >= 2)))
 	{
 		return rc;
 	}
 	// seven more partitions cost seven more builds (tens of milliseconds at 60k constraints): only for a graph that has been
 	// quiet for a while (or when the caller asked for strips at once, strip_patience 0); doStep comes back for it
-	if (s->optStripPatience != 0 && s->graphAge < 32)
+	if (!s->forcedBuild && s->optStripPatience != 0 && s->graphAge < 32)
 	{
 		s->stripRetryPending = true;
 		return rc;
@@ -2928,7 +2934,7 @@ int buildStructure(s2amdSolver* s, int solverType)
 			return rc;
 		}
 		const int o = outcome();
-		if (satisfied())
+		if (s->forcedBuild ? usable() : satisfied())
 		{
 			s->stripScaleFound = scale;
 			return rc;

@@ -502,7 +502,7 @@ int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapa
 			return rcBuild;
 		}
 		HIP_TRY(hipStreamSynchronize(s->stream));
-		if ((rcBuild = asyncPrewarm(s)) != 0)
+		if ((rcBuild = asyncPrewarm(s, s->optPrebuildSolver)) != 0)
 		{
 			return rcBuild;
 		}
@@ -688,7 +688,7 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 		}
 		break;
 	}
-	if (!s->poolWarmed && asyncBuildsOn(s) && (rc = asyncPrewarm(s)) != 0)
+	if (!s->poolWarmed && asyncBuildsOn(s) && (rc = asyncPrewarm(s, params->solverType)) != 0)
 	{
 		return rc; // (a world uploaded without "prebuild_solver": stocked behind its first step)
 	}

@@ -404,3 +404,5 @@ void launchGatherMessageSlots(hipStream_t s, const BodyView& b, const MsgView& m
 		gatherMessageSlotsKernel<<<gridFor(b.capacity), dim3(S2_BLOCK), 0, s>>>(b, m);
 	}
 }
+
+S2_DEFINE_WARM(body_kernels)

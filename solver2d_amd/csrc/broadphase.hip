@@ -998,3 +998,5 @@ int s2amd_find_pairs(s2amdSolver* solver, const s2amdBody* bodies, int32_t bodyC
 
 } // extern "C"
 #pragma GCC visibility pop
+
+S2_DEFINE_WARM(broadphase)

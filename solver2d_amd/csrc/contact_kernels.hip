@@ -920,3 +920,5 @@ void launchWarmStartBodies(hipStream_t s, int kind, const ContactView& c, const 
 			break;
 	}
 }
+
+S2_DEFINE_WARM(contact_kernels)

@@ -497,3 +497,5 @@ void launchGenericStep(hipStream_t s, const ContactView& c, const JointView& j, 
 	genericStepKernel<<<dim3((unsigned)a.groupCount), dim3(S2_GENERIC_THREADS), ldsBytes, s>>>(c, j, g, a, b, pv, ops, opCount, sc, wire, useDq0, seamContacts,
 																								 seamJoints, stageJoints);
 }
+
+S2_DEFINE_WARM(generic_kernel)

@@ -432,3 +432,5 @@ void launchGroupKernel(hipStream_t s, const ContactView& c, const JointView& j, 
 	size_t lds = (size_t)maxBodies * (useDq0 ? 56 : 40);
 	groupKernel<S2_GROUP_THREADS, 0><<<dim3((unsigned)gt.groupCount), dim3(S2_GROUP_THREADS), lds, s>>>(c, j, g, gt, ops, opCount, sc, wire, useDq0);
 }
+
+S2_DEFINE_WARM(group_kernel)

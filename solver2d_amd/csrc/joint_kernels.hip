@@ -318,3 +318,5 @@ void launchStoreJoints(hipStream_t s, const JointView& j, s2amdJoint* wire, cons
 		storeJointsKernel<<<gridFor(j.count), dim3(S2_BLOCK), 0, s>>>(j, wire, stepFailed);
 	}
 }
+
+S2_DEFINE_WARM(joint_kernels)

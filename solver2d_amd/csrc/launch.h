@@ -203,3 +203,22 @@ struct PairQueryGraph
 int findPairsResident(hipStream_t st, const s2amdShape* shapes, int shapeCapacity, int liveShapes, const s2amdPairState* pairs, int contactCapacity,
 					  const unsigned long long* jointed, int jointedCount, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount, void** scratch,
 					  size_t* scratchBytes, unsigned long long* sortedPairKeys, bool* sortedPairKeysValid, PairQueryGraph* cache);
+
+// One empty kernel per translation unit with kernels: the HIP runtime loads a TU's code object when its first kernel is launched -- 2 to 14 ms
+// each at the sizes of this library, which the first steps of a new process, the first structure request, the first flip used to pay
+// (r5: the first slotBytesKernel launch, 7 ms inside step 33 of the wrecking-ball loop).  s2amd_create launches them all once.
+#define S2_DEFINE_WARM(name)                                                                                                     \
+	__global__ void s2WarmKernel_##name() {}                                                                                    \
+	void s2Warm_##name(hipStream_t st) { s2WarmKernel_##name<<<dim3(1), dim3(64), 0, st>>>(); }
+void s2Warm_contact_kernels(hipStream_t st);
+void s2Warm_body_kernels(hipStream_t st);
+void s2Warm_joint_kernels(hipStream_t st);
+void s2Warm_group_kernel(hipStream_t st);
+void s2Warm_strip_kernel(hipStream_t st);
+void s2Warm_pair_kernel(hipStream_t st);
+void s2Warm_wide_kernel(hipStream_t st);
+void s2Warm_generic_kernel(hipStream_t st);
+void s2Warm_broadphase(hipStream_t st);
+void s2Warm_narrowphase(hipStream_t st);
+void s2Warm_structure(hipStream_t st);
+void s2Warm_world(hipStream_t st);

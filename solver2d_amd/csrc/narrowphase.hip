@@ -1054,3 +1054,5 @@ int s2amd_update_contacts(s2amdSolver* solver, const s2amdBody* bodies, int32_t 
 
 } // extern "C"
 #pragma GCC visibility pop
+
+S2_DEFINE_WARM(narrowphase)

@@ -712,3 +712,5 @@ int pairKernelSetup()
 	}
 	return 0;
 }
+
+S2_DEFINE_WARM(pair_kernel)

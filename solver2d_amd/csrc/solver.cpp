@@ -157,6 +157,28 @@ int s2amd_create(int device, s2amdSolver** out)
 		(void)hipGetLastError(); // not fatal: groups are then limited to the default 64 KiB of LDS
 		s->optMaxGroupBodies = 1536;
 	}
+	{
+		// every code object of the library loaded now, not by whichever step first launches a kernel of it (launch.h: S2_DEFINE_WARM)
+		static bool warmed[64] = {};
+		if (device < 64 && !warmed[device])
+		{
+			warmed[device] = true;
+			s2Warm_contact_kernels(s->stream);
+			s2Warm_body_kernels(s->stream);
+			s2Warm_joint_kernels(s->stream);
+			s2Warm_group_kernel(s->stream);
+			s2Warm_strip_kernel(s->stream);
+			s2Warm_pair_kernel(s->stream);
+			s2Warm_wide_kernel(s->stream);
+			s2Warm_generic_kernel(s->stream);
+			s2Warm_broadphase(s->stream);
+			s2Warm_narrowphase(s->stream);
+			s2Warm_structure(s->stream);
+			s2Warm_world(s->stream);
+			(void)hipStreamSynchronize(s->stream);
+			(void)hipGetLastError();
+		}
+	}
 	devPoolSolverCreated(device);
 	*out = s;
 	return S2AMD_OK;
@@ -206,6 +228,11 @@ void s2amd_destroy(s2amdSolver* s)
 	if (s->hostStepBack)
 	{
 		(void)hipHostFree(s->hostStepBack);
+	}
+	if (s->hostSlotStage)
+	{
+		(void)hipHostFree(s->hostSlotStage);
+		s->hostSlotStage = nullptr;
 	}
 	if (s->hostWorldSummary)
 	{

@@ -419,6 +419,9 @@ void asyncShutdown(s2amdSolver* s)
 // `forceStrips`: the copy builds its strips whatever the graph's age (the live structure runs sliced until it is adopted)
 int asyncRequest(s2amdSolver* s, int solverType, bool search, bool forceStrips)
 {
+	static const bool debugAsync = getenv("S2AMD_DEBUG_ASYNC") != nullptr;
+	const double tr0 = debugAsync ? nowMs() : 0.0;
+	double tr1 = 0.0, tr2 = 0.0, tr3 = 0.0;
 	reap(s->async, false);
 	if (asyncPending(s))
 	{
@@ -441,6 +444,7 @@ int asyncRequest(s2amdSolver* s, int solverType, bool search, bool forceStrips)
 			return rc;
 		}
 	}
+	tr1 = debugAsync ? nowMs() : 0.0;
 	AsyncBuild* job = new AsyncBuild();
 	// the copy: everything but the structure part as it is (what the host knows of the wire arrays, the options, the plan); of the
 	// structure part only what a build reads -- the graph as the structure knows it and the policies earlier builds have learnt.
@@ -467,6 +471,7 @@ int asyncRequest(s2amdSolver* s, int solverType, bool search, bool forceStrips)
 	c->hostTimes = nullptr;
 	c->sweepEvents.clear();
 	forgetDeviceState(*c);
+	tr2 = debugAsync ? nowMs() : 0.0;
 	c->stream = workerStreamTake();
 	if (c->stream == nullptr)
 	{
@@ -505,7 +510,13 @@ int asyncRequest(s2amdSolver* s, int solverType, bool search, bool forceStrips)
 	job->older = s->async;
 	s->async = job;
 	s->asyncRequested += 1;
+	tr3 = debugAsync ? nowMs() : 0.0;
 	job->worker = std::thread(workerMain, job);
+	if (debugAsync)
+	{
+		fprintf(stderr, "[s2amd] step %ld: build requested (%s): reap + device reads %.3f ms, copy %.3f, stream + job %.3f, thread start %.3f\n", s->stepCounter,
+				search ? "search" : (forceStrips ? "forced" : "build"), tr1 - tr0, tr2 - tr1, tr3 - tr2, nowMs() - tr3);
+	}
 	return S2AMD_OK;
 }
 
@@ -548,7 +559,15 @@ int asyncPrewarm(s2amdSolver* s, int solverType)
 	{
 		(void)hipGetLastError();
 	}
-	workerStreamGive(workerStreamTake());
+	{
+		// three streams: a search over strip widths in flight, the build that takes its place, the one after an adoption (creating one
+		// later costs the step that asks 3.7 ms, measured)
+		hipStream_t st[3] = {workerStreamTake(), workerStreamTake(), workerStreamTake()};
+		for (hipStream_t x : st)
+		{
+			workerStreamGive(x);
+		}
+	}
 	// ... and one build by a worker thread, thrown away: the first thread that talks to the HIP runtime, the first launches of the kernels a
 	// build uses and the first copy of the solver cost the steps beside them 4-8 ms each (r5: the requests at steps 32 and 87 of the
 	// wrecking-ball loop) -- paid here instead
@@ -634,6 +653,7 @@ bool asyncAdopt(s2amdSolver* s, int solverType, int* rcOut)
 	}
 	// due: the step at which the sweep order changes is fixed, so a worker that is not done yet is waited for
 	const double t0 = nowMs();
+	const double ta0 = t0;
 	if (job->worker.joinable())
 	{
 		job->worker.join();
@@ -709,6 +729,7 @@ bool asyncAdopt(s2amdSolver* s, int solverType, int* rcOut)
 	static const bool debugAsync = getenv("S2AMD_DEBUG_ASYNC") != nullptr;
 	if (debugAsync)
 	{
+		fprintf(stderr, "[s2amd]   adoption work before the swap: %.3f ms\n", nowMs() - ta0);
 		fprintf(stderr, "[s2amd] step %ld: build requested at step %ld (%s) %s: rc %d, solver %d/%d, copy dirty %d, %zu logged events, copy watches %d, strips %d, overflow in use %d\n",
 				s->stepCounter, job->requestedAtStep, job->search ? "search" : "build", ok ? "ADOPTED" : "refused", job->rc, job->solverType, solverType, c->structureDirty ? 1 : 0,
 				job->log.size(), c->watchedCount, c->dStripA.view.groupCount, c->stripInc.valid ? c->stripInc.overflowUsed : -1);

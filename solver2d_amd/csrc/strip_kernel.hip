@@ -1348,3 +1348,5 @@ int stripKernelSetup()
 	}
 	return 0;
 }
+
+S2_DEFINE_WARM(strip_kernel)

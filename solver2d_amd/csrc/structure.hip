@@ -521,3 +521,5 @@ int s2amd_color_constraints(s2amdSolver* solver, const s2amdBody* bodies, int32_
 
 } // extern "C"
 #pragma GCC visibility pop
+
+S2_DEFINE_WARM(structure)

@@ -2196,3 +2196,5 @@ int wideKernelSetup()
 	return 0;
 }
 #endif // S2_WIDE_ONLY_MAIN
+
+S2_DEFINE_WARM(wide_kernel)

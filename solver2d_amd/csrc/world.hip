@@ -312,23 +312,40 @@ int syncDeadSlots(s2amdSolver* s)
 		return S2AMD_OK;
 	}
 	HIP_TRY(hipSetDevice(s->device));
+	static const bool debugAsync = getenv("S2AMD_DEBUG_ASYNC") != nullptr;
+	const double tq0 = debugAsync ? nowMs() : 0.0;
 	int rc = s->dSlotBytes.ensure(std::max<size_t>((size_t)nc, 256));
 	if (rc)
 	{
 		return rc;
 	}
 	s->hSlotBytes.resize((size_t)nc);
+	const double tq1 = debugAsync ? nowMs() : 0.0;
 	slotBytesKernel<<<gridFor((size_t)nc), dim3(S2_BLOCK), 0, s->stream>>>((const s2amdPairState*)s->dPairs.p, (const uint8_t*)s->dPointBytes.p, nc,
 																			 (uint8_t*)s->dSlotBytes.p);
 	HIP_TRY(hipGetLastError());
-	HIP_TRY(hipMemcpyAsync(s->hSlotBytes.data(), s->dSlotBytes.p, (size_t)nc, hipMemcpyDeviceToHost, s->stream));
-	HIP_TRY(hipStreamSynchronize(s->stream));
+	if (s->hostSlotStage && s->hostSlotStageBytes >= (size_t)nc)
+	{
+		HIP_TRY(hipMemcpyAsync(s->hostSlotStage, s->dSlotBytes.p, (size_t)nc, hipMemcpyDeviceToHost, s->stream));
+		HIP_TRY(hipStreamSynchronize(s->stream));
+		memcpy(s->hSlotBytes.data(), s->hostSlotStage, (size_t)nc);
+	}
+	else
+	{
+		HIP_TRY(hipMemcpyAsync(s->hSlotBytes.data(), s->dSlotBytes.p, (size_t)nc, hipMemcpyDeviceToHost, s->stream));
+		HIP_TRY(hipStreamSynchronize(s->stream));
+	}
+	const double tq2 = debugAsync ? nowMs() : 0.0;
 	for (int i = 0; i < nc; ++i)
 	{
 		if (s->hContactEdge[(size_t)i] && s->hSlotBytes[(size_t)i] == 0xff)
 		{
 			s->hContactDead[(size_t)i] = 1;
 		}
+	}
+	if (debugAsync)
+	{
+		fprintf(stderr, "[s2amd]   syncDeadSlots: buffers %.3f ms, kernel + copy + wait %.3f, scan %.3f\n", tq1 - tq0, tq2 - tq1, nowMs() - tq2);
 	}
 	s->slotBytesFresh = true; // (fetchPointCounts right behind this call, the hub rule's, needs no second copy)
 	return S2AMD_OK;
@@ -349,6 +366,12 @@ int fetchPointCounts(s2amdSolver* s)
 		{
 			s->hPointBytes[(size_t)i] = s->hSlotBytes[(size_t)i] == 0xff ? 0 : s->hSlotBytes[(size_t)i];
 		}
+	}
+	else if (s->hostSlotStage && s->hostSlotStageBytes >= (size_t)nc)
+	{
+		HIP_TRY(hipMemcpyAsync(s->hostSlotStage, s->dPointBytes.p, (size_t)nc, hipMemcpyDeviceToHost, s->stream));
+		HIP_TRY(hipStreamSynchronize(s->stream));
+		memcpy(s->hPointBytes.data(), s->hostSlotStage, (size_t)nc);
 	}
 	else
 	{
@@ -482,6 +505,30 @@ int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapa
 		// (a stream for the first worker-thread build, made now while nothing is stepping: creating one later stalls the step that asks;
 		// and the staging block of syncDeadSlots, whose first hipMalloc cost the first request 3 ms)
 		workerStreamGive(workerStreamTake());
+		if (s->hostSlotStageBytes < (size_t)contactCapacity)
+		{
+			if (s->hostSlotStage)
+			{
+				(void)hipHostFree(s->hostSlotStage);
+				s->hostSlotStage = nullptr, s->hostSlotStageBytes = 0;
+			}
+			const size_t want = std::max<size_t>((size_t)contactCapacity, 4096);
+			HIP_TRY(hipHostMalloc((void**)&s->hostSlotStage, want, hipHostMallocDefault));
+			s->hostSlotStageBytes = want;
+		}
+		// (and the patch list's buffers -- solver_incremental.cpp: incrementalFlush: the first placed contact used to make them, 0.8 ms)
+		if (s->hostPatches == nullptr)
+		{
+			HIP_TRY(hipHostMalloc((void**)&s->hostPatches, 4096 * sizeof(uint4), hipHostMallocDefault));
+			s->hostPatchCapacity = 4096;
+		}
+		{
+			int rcPatch = s->dPatches.ensure(s->hostPatchCapacity * sizeof(uint4));
+			if (rcPatch)
+			{
+				return rcPatch;
+			}
+		}
 		int rcSlot = s->dSlotBytes.ensure(std::max<size_t>((size_t)contactCapacity, 256));
 		if (rcSlot)
 		{
@@ -627,13 +674,17 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 		}
 	}
 	const double t1 = nowMs();
+	static const bool debugAsync = getenv("S2AMD_DEBUG_ASYNC") != nullptr;
+	double tStep = 0.0, tSummary = 0.0;
 	int rc = S2AMD_OK;
 	int fallbacks = 0, nearRetries = 0;
 	for (;;)
 	{
 		const int savedAsync = s->optAsync;
 		s->optAsync = 1;
+		const double td0 = debugAsync ? nowMs() : 0.0;
 		rc = doStep(s, params);
+		tStep += debugAsync ? nowMs() - td0 : 0.0;
 		s->optAsync = savedAsync;
 		if (rc)
 		{
@@ -645,10 +696,12 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 		{
 			return rc;
 		}
+		const double ts0 = debugAsync ? nowMs() : 0.0;
 		if ((rc = fetchSummary(s, 1)) != 0)
 		{
 			return rc;
 		}
+		tSummary += debugAsync ? nowMs() - ts0 : 0.0;
 		s->stepBackValid = stepBack;
 		if (s->hostError && *s->hostError != 0u && s->nearHandoffNow != 0 && nearRetries == 0)
 		{
@@ -687,6 +740,11 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 			continue;
 		}
 		break;
+	}
+	if (debugAsync && nowMs() - t0 > 1.0)
+	{
+		fprintf(stderr, "[s2amd] step %ld took %.3f ms on the host: stage 3 + flips %.3f, doStep (enqueue) %.3f, wait for the device %.3f\n", s->stepCounter, nowMs() - t0, t1 - t0,
+				tStep, tSummary);
 	}
 	if (!s->poolWarmed && asyncBuildsOn(s) && (rc = asyncPrewarm(s, params->solverType)) != 0)
 	{
@@ -1151,3 +1209,5 @@ int s2amd_world_download(s2amdSolver* s, s2amdBody* bodies, int32_t bodyCapacity
 
 } // extern "C"
 #pragma GCC visibility pop
+
+S2_DEFINE_WARM(world)

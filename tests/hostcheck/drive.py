@@ -304,6 +304,16 @@ def overflow_chain(base, steps):
             s.world_step(params)
             st = s.stats()
             seen.append((st["overflowContacts"], st["slicedStep"], st["asyncBuildsRequested"], st["asyncBuildsAdopted"], st["structureBuilds"], st["kernelLaunches"]))
+        # (a build that needs the search over strip widths is not waited for: it falls due a few steps later -- under the sanitizers the
+        # worker is slow and these steps are not steps at all, so give it wall-clock time)
+        import time
+        for _ in range(600):
+            if seen[-1][0] == 0:
+                break
+            time.sleep(0.02)
+            s.world_step(params)
+            st = s.stats()
+            seen.append((st["overflowContacts"], st["slicedStep"], st["asyncBuildsRequested"], st["asyncBuildsAdopted"], st["structureBuilds"], st["kernelLaunches"]))
         order, offsets = s.contact_order()
         assert len(order) == len(set(order.tolist()))
     return seen
@@ -413,7 +423,7 @@ def main():
     print("world chain, structure builds in a worker thread: (strips, requested, adopted, builds) per step:", seen[::4])
     assert seen[-1][1] >= 1 and seen[-1][2] >= 1 and seen[-1][0] > 0, seen
     seen = overflow_chain(100, 24)
-    print("overflow positions behind the strips: (overflow contacts, sliced, requested, adopted, builds, launches) per step:", seen)
+    print("overflow positions behind the strips: (overflow contacts, sliced, requested, adopted, builds, launches) per step:", seen[:24], "...", seen[-1], "after", len(seen), "steps")
     assert max(x[0] for x in seen) >= 1 and any(x[1] for x in seen), seen  # a contact waited in the overflow region, steps ran sliced
     assert seen[-1][3] >= 1 and seen[-1][0] == 0 and seen[-1][1] == 0, seen  # ... until the worker's structure was adopted
     first = next(i for i, x in enumerate(seen) if x[0] > 0)

@@ -726,6 +726,72 @@ void launchPrepareContacts(hipStream_t s, int kind, const ContactView& c, const 
 	}
 }
 
+// The overflow contacts of a sliced step (solver_executor.h: runPersistentSliced): positions [begin, end) swept ONE AFTER THE OTHER by one
+// lane -- they may share a body (the ball that touches boxes of two strips) --, free positions skipped.  The same per-constraint
+// functions as the colour batches, on the bodies in HBM.
+template <int KIND> __global__ void overflowWarmKernel(ContactView c, BodyView b, int begin, int end)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0)
+	{
+		GlobalBodies gb{b.vel, b.dq};
+		for (int k = begin; k < end; ++k)
+		{
+			if (c.contactIndex[k] >= 0)
+			{
+				warmStartContactsOne<KIND>(c, gb, k);
+			}
+		}
+	}
+}
+template <int KIND> __global__ void overflowSoftKernel(ContactView c, BodyView b, int begin, int end, float inv_h, int useBias)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0)
+	{
+		GlobalBodies gb{b.vel, b.dq};
+		for (int k = begin; k < end; ++k)
+		{
+			if (c.contactIndex[k] >= 0)
+			{
+				solveContactsSoftOne<KIND>(c, gb, inv_h, useBias, k);
+			}
+		}
+	}
+}
+
+// one sweep op (s2WarmStartContacts / the soft solve of the three soft drivers) over the overflow positions, sequentially
+void launchOverflowSweep(hipStream_t s, const Op& o, const ContactView& c, const BodyView& b, int begin, int end)
+{
+	const dim3 one(1), lanes(64);
+	if (o.code == OP_WARM)
+	{
+		if (o.kind == WARM_FIXED)
+		{
+			overflowWarmKernel<WARM_FIXED><<<one, lanes, 0, s>>>(c, b, begin, end);
+		}
+		else
+		{
+			overflowWarmKernel<WARM_CURRENT><<<one, lanes, 0, s>>>(c, b, begin, end);
+		}
+	}
+	else if (o.code == OP_SOLVE_SOFT)
+	{
+		switch (o.kind)
+		{
+			case SOFT_TGS:
+				overflowSoftKernel<SOFT_TGS><<<one, lanes, 0, s>>>(c, b, begin, end, o.inv_h, o.useBias);
+				break;
+			case SOFT_PGS:
+				overflowSoftKernel<SOFT_PGS><<<one, lanes, 0, s>>>(c, b, begin, end, o.inv_h, o.useBias);
+				break;
+			case SOFT_FIXED:
+				overflowSoftKernel<SOFT_FIXED><<<one, lanes, 0, s>>>(c, b, begin, end, o.inv_h, o.useBias);
+				break;
+			default:
+				break;
+		}
+	}
+}
+
 void launchWarmStartContacts(hipStream_t s, int kind, const ContactView& c, const BodyView& b, int begin, int end)
 {
 	switch (kind)

@@ -101,6 +101,7 @@ void launchIntegratePositions(hipStream_t s, const BodyView& b, float h);
 void launchFinalizePositions(hipStream_t s, const BodyView& b, int dynamicOnly);
 void launchJacobiApply(hipStream_t s, const BodyView& b, const ContactView& c, const int2* adjRange, const int* adjList, const int* heavy, int heavyCapacity);
 void launchPatchWords(hipStream_t s, const void* devicePatches, int n);
+void launchOverflowSweep(hipStream_t s, const Op& o, const ContactView& c, const BodyView& b, int begin, int end); // contact_kernels.hip
 void launchXpbdIntegrate(hipStream_t s, const BodyView& b, float h);
 void launchXpbdProject(hipStream_t s, const BodyView& b, float inv_h);
 void launchExportPoses(hipStream_t s, const s2amdBody* wire, int n, void* out, int withVelocities = 0);

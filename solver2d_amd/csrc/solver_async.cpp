@@ -430,7 +430,14 @@ int asyncRequest(s2amdSolver* s, int solverType, bool search, bool forceStrips)
 	HIP_TRY(hipSetDevice(s->device));
 	// what a synchronous build would learn from the device first (buildStructureWith, gatherEdges): the pairs stage 3 has freed, and --
 	// for the hub rule -- which manifolds have points right now.  The copy then builds from host state alone.
-	if (!s->pointsKnown && !(forceStrips && s->pointCountsFresh))
+	// (a world without hub bodies -- solver_internal.h: hBodyHub -- asks nothing of the point counts, and the pairs its stage 3 frees reach
+	// hContactDead with every step's read-back: the two device reads, 7 ms on the step that asks for a search, are the hub rule's)
+	bool anyHub = false;
+	for (uint8_t h : s->hBodyHub)
+	{
+		anyHub = anyHub || h != 0;
+	}
+	if (!s->pointsKnown && !(forceStrips && s->pointCountsFresh) && anyHub)
 	{
 		// (forceStrips: the flip that asked for this build has just read the point counts, and a pair stage 3 freed this step lingers in
 		// the copy's structure as it does in the live one -- a no-op -- until it is read at the end of the step)
@@ -499,7 +506,7 @@ int asyncRequest(s2amdSolver* s, int solverType, bool search, bool forceStrips)
 	job->requestedAtStep = s->stepCounter;
 	// (a build the live structure is waiting for -- it runs sliced meanwhile -- falls due sooner: one strip build is ~5 ms of the worker's time,
 	// a sliced step ~0.8 ms of the caller's)
-	job->delay = search ? 8 * s->optAsyncBuildDelay : (forceStrips ? std::max(2, (2 * s->optAsyncBuildDelay) / 3) : s->optAsyncBuildDelay);
+	job->delay = search ? 8 * s->optAsyncBuildDelay : (forceStrips ? std::max(2, s->optAsyncBuildDelay / 2) : s->optAsyncBuildDelay);
 	if (search)
 	{
 		// (the request itself costs the caller a device synchronisation -- the point counts, the freed pairs -- and a copy of the

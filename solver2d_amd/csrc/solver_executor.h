@@ -691,14 +691,8 @@ struct Executor
 			count();
 			if (sweep)
 			{
-				for (int k = m.overflowBegin; k < m.overflowEnd; ++k)
-				{
-					if (s->contacts.order[(size_t)k] >= 0)
-					{
-						launchContactBatch(o, k, k + 1);
-						count();
-					}
-				}
+				launchOverflowSweep(st, o, s->cv, s->bv, m.overflowBegin, m.overflowEnd); // (one launch: the contacts in it one after the other)
+				count();
 			}
 			first = i + 1;
 		}

@@ -536,6 +536,20 @@ int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapa
 		}
 		s->hSlotBytes.reserve((size_t)contactCapacity);
 	}
+	if (s->optAsyncBuild != 0 && contactCapacity > 0)
+	{
+		// (the first device-to-host copy of the per-slot bytes cost the step it fell into 7 ms -- the first flip, the first search
+		// request --, every later one 0.1: made here once, with the values the upload has just written)
+		int rcWarm = syncDeadSlots(s);
+		if (rcWarm == S2AMD_OK)
+		{
+			rcWarm = fetchPointCounts(s);
+		}
+		if (rcWarm)
+		{
+			return rcWarm;
+		}
+	}
 	if (s->optPrebuildSolver >= 0 && s->optPrebuildSolver < s2amd_solverTypeCount)
 	{
 		// the caller has said which solver will step this world (the drop-in knows it from s2WorldDef): its structure -- strips and all --

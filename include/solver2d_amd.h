@@ -456,6 +456,42 @@ int s2amd_measure_dominant(s2amdSolver* solver, const s2amdStepParams* params, i
  * library reports. */
 int s2amd_set_option(s2amdSolver* solver, const char* key, int32_t value);
 
+/* ---- (API 4) island-sharded worlds: ONE process, N devices (csrc/sharded.hip) ----
+ * A world whose constraint graph falls into islands -- connected components over the movable bodies, as s2amd_find_islands labels them --
+ * is partitioned over `deviceCount` shards, one s2amdSolver each on the HIP device named for it (the same ordinal may be named more
+ * than once: logical shards on one GPU).  Islands share no movable body, so a step needs no collective: every shard runs the whole
+ * s2Solve_* of its islands; the step's ONE exchange carries each shard's owned body records -- {position, rot}, {linearVelocity,
+ * angularVelocity, 0}: 28 bytes per body in two 16-byte records -- to every other shard's device (peer copies: xGMI between the GPUs of
+ * a node), where they are scattered into that device's copy of the WHOLE world's body records.  The multi-PROCESS form of the same
+ * partition (one rank per GPU over RCCL) is solver2d_amd/distributed.py.
+ *   s2amd_sharded_upload    islands found on the device, bin-packed by constraint count (2 per contact constraint + 1 per joint; longest
+ *                           processing time first, ties by index: deterministic), every shard's sub-world uploaded -- its islands'
+ *                           bodies and constraints in pool order, immovable bodies they touch as read-only replicas;
+ *   s2amd_sharded_step      == s2Solve_<solverType> of the whole world, results resident on the shards' devices, + the exchange;
+ *   s2amd_sharded_download  the world's arrays on the host, every body and constraint from the shard that owns it; constraintIndex as
+ *                           the reference's gather loop over the whole pool writes it;
+ *   s2amd_sharded_read_bodies  float[bodyCapacity][8] of the world's body records as of the last exchange, read from `shard`'s device;
+ *   s2amd_sharded_reshard   the constraint graph changed (contacts / joints: the world's new arrays, pool capacities unchanged, or NULL
+ *                           for "unchanged"): solver state comes down, a slot that kept its pair keeps its impulses, islands are found
+ *                           again, an island stays on the shard that owned most of its bodies (ties: the lowest shard) -- a contact
+ *                           created between two islands moves the smaller one --, islands nobody owned go to the least loaded shard,
+ *                           and past 1.75 x the mean load the heaviest shard gives up its lightest islands;
+ *   s2amd_sharded_solver    the s2amdSolver of a shard, for the queries of this header (orders, stats, options); owned by the sharded solver. */
+typedef struct s2amdShardedSolver s2amdShardedSolver;
+int s2amd_sharded_create(const int32_t* devices, int32_t deviceCount, s2amdShardedSolver** out);
+void s2amd_sharded_destroy(s2amdShardedSolver* sharded);
+int s2amd_sharded_shard_count(const s2amdShardedSolver* sharded);
+s2amdSolver* s2amd_sharded_solver(s2amdShardedSolver* sharded, int32_t shard);
+int s2amd_sharded_upload(s2amdShardedSolver* sharded, const s2amdBody* bodies, int32_t bodyCapacity, const s2amdContact* contacts, int32_t contactCapacity,
+						 const s2amdJoint* joints, int32_t jointCapacity);
+int s2amd_sharded_step(s2amdShardedSolver* sharded, const s2amdStepParams* params);
+int s2amd_sharded_download(s2amdShardedSolver* sharded, s2amdBody* bodies, int32_t bodyCapacity, s2amdContact* contacts, int32_t contactCapacity,
+						   s2amdJoint* joints, int32_t jointCapacity);
+int s2amd_sharded_read_bodies(s2amdShardedSolver* sharded, int32_t shard, float* records, int32_t bodyCapacity);
+int s2amd_sharded_reshard(s2amdShardedSolver* sharded, const s2amdContact* contacts, int32_t contactCapacity, const s2amdJoint* joints, int32_t jointCapacity);
+/* shardOfBody[b]: the shard that owns body b (-1: static or free -- replicated, owned by nobody); may be NULL */
+int s2amd_sharded_get_partition(s2amdShardedSolver* sharded, int32_t* shardOfBody, int32_t capacity, int32_t* islandCount, int32_t* reshards);
+
 #ifdef __cplusplus
 }
 #endif

@@ -223,3 +223,4 @@ void s2Warm_broadphase(hipStream_t st);
 void s2Warm_narrowphase(hipStream_t st);
 void s2Warm_structure(hipStream_t st);
 void s2Warm_world(hipStream_t st);
+void s2Warm_sharded(hipStream_t st);

@@ -1,0 +1,891 @@
+// Island-sharded worlds behind the C-ABI (include/solver2d_amd.h: s2amd_sharded_*): ONE process, N devices.
+//
+// The reference has no islands; an island here is a connected component of the graph whose nodes are the movable
+// bodies and whose edges are the active contact constraints and the revolute joints (structure.hip: s2amd_find_islands; the CPU
+// statement is solver2d_amd/islands.py, which this file follows function by function: constraint_islands, partition,
+// sticky_partition, extract, merge_back).  Islands share no movable body, so solving them apart is arithmetic-identical to solving
+// them together as long as every shard keeps the pool order of its own bodies and constraints -- what `extract` guarantees.
+//
+//   upload   islands found on the device, bin-packed onto the shards by constraint count (longest processing time first), every
+//            shard's sub-world (its islands' bodies, the immovable bodies they touch as read-only replicas, its constraints)
+//            uploaded to its device's solver;
+//   step     every shard's s2Solve_* enqueued on its own device -- no collective inside a step --, then the step's ONE exchange:
+//            each shard's owned body records ({position, rot}, {linearVelocity, angularVelocity}: the 28 bytes per body of SURVEY.md
+//            8e in two 16-byte records) compacted on its device, copied to every other device (hipMemcpyPeerAsync: xGMI between the
+//            GPUs of one node; a plain device copy between logical shards of one GPU) and scattered into that device's copy of the
+//            WHOLE world's body records -- every device ends the step with every body, what a device-side collision phase needs;
+//   reshard  the constraint graph changed: every shard's solver state comes down, islands are found again (device), an island
+//            stays on the shard that owned most of its bodies (a created contact that joins two islands moves the smaller one),
+//            the partition is rebalanced past REBALANCE_THRESHOLD, the new sub-worlds go up.
+//
+// The multi-PROCESS form of the same partition (one rank per GPU, torch.distributed over RCCL) is solver2d_amd/distributed.py; the
+// tests hold the two against each other and against the unsharded solver, bit for bit.
+#include "launch.h"
+#include "s2_device.h"
+
+#include "solver2d_amd.h"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+int s2amdFail(int code, const std::string& msg);
+hipStream_t s2amdStream(s2amdSolver* s);
+int s2amdDevice(s2amdSolver* s);
+
+namespace
+{
+
+#define SH_TRY(expr)                                                                                                             \
+	do                                                                                                                           \
+	{                                                                                                                            \
+		hipError_t _e = (expr);                                                                                                  \
+		if (_e != hipSuccess)                                                                                                    \
+		{                                                                                                                        \
+			return s2amdFail(S2AMD_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));                                \
+		}                                                                                                                        \
+	} while (0)
+
+constexpr double kRebalanceThreshold = 1.75; // islands.py: REBALANCE_THRESHOLD
+
+// owned rows of a shard's exported records (two float4 per body, shard-local order) -> a compact run of the same records
+__global__ void compactOwnedKernel(const float4* records, const int* ownedLocal, int n, float4* compact)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n)
+	{
+		const int b = ownedLocal[i];
+		compact[2 * i] = records[2 * b];
+		compact[2 * i + 1] = records[2 * b + 1];
+	}
+}
+
+// a compact run -> the rows of the world's body records its bodies have in the pool
+__global__ void scatterOwnedKernel(const float4* compact, const int* ownedWorld, int n, float4* world)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n)
+	{
+		const int b = ownedWorld[i];
+		world[2 * b] = compact[2 * i];
+		world[2 * b + 1] = compact[2 * i + 1];
+	}
+}
+
+struct DeviceBlock
+{
+	void* p = nullptr;
+	size_t bytes = 0;
+	int device = 0;
+	int ensure(int dev, size_t need)
+	{
+		if (need <= bytes && dev == device && p)
+		{
+			return S2AMD_OK;
+		}
+		SH_TRY(hipSetDevice(dev));
+		if (p)
+		{
+			(void)hipFree(p);
+			p = nullptr, bytes = 0;
+		}
+		const size_t want = std::max<size_t>(need + need / 4, 256);
+		SH_TRY(hipMalloc(&p, want));
+		bytes = want, device = dev;
+		return S2AMD_OK;
+	}
+	void release()
+	{
+		if (p)
+		{
+			(void)hipSetDevice(device);
+			(void)hipFree(p);
+		}
+		p = nullptr, bytes = 0;
+	}
+};
+
+struct Shard
+{
+	s2amdSolver* solver = nullptr;
+	int device = 0;
+	// the sub-world (islands.py: Shard) and its maps back into the world
+	std::vector<s2amdBody> bodies;
+	std::vector<s2amdContact> contacts;
+	std::vector<s2amdJoint> joints;
+	std::vector<int> bodyIds, contactIds, jointIds; // shard-local index -> pool index of the world
+	std::vector<uint8_t> owned;						// per shard body: a body this shard integrates (the rest are read-only replicas)
+	std::vector<int> ownedLocal, ownedWorld;		// the owned ones: shard-local index, pool index
+	// device side of the exchange, all on this shard's device
+	DeviceBlock dRecords, dOwnedLocal, dOwnedWorld, dCompact, dWorld;
+	std::vector<DeviceBlock> inbox, inboxIds; // per source shard: its compact run and the pool indices of its rows
+	hipEvent_t evCompact = nullptr;			  // this shard's compact run is complete
+	bool uploaded = false;
+};
+
+} // namespace
+
+struct s2amdShardedSolver
+{
+	std::vector<Shard> shards;
+	// the world as of the last upload / reshard (solver state as of the last download)
+	std::vector<s2amdBody> bodies;
+	std::vector<s2amdContact> contacts;
+	std::vector<s2amdJoint> joints;
+	std::vector<int32_t> island;	 // per body, -1: static / free
+	std::vector<int32_t> shardOfIsland;
+	int islandCount = 0;
+	int reshards = 0;
+	bool resident = false;
+	long steps = 0;
+	int repeatedSteps = 0; // shard steps repeated after a persistent launch lost a hand-off
+	int lastSolverType = -1; // of the last step (-1: none yet): whether its driver writes manifold.constraintIndex
+};
+
+namespace
+{
+
+bool movable(const s2amdBody& b) { return b.type != S2AMD_BODY_FREE && (b.invMass != 0.0f || b.invI != 0.0f); }
+
+// islands.py: constraint_islands
+void constraintIslands(const s2amdShardedSolver& w, std::vector<int>& ci, std::vector<int>& ji)
+{
+	const int nc = (int)w.contacts.size(), nj = (int)w.joints.size();
+	ci.assign((size_t)nc, -1);
+	ji.assign((size_t)nj, -1);
+	for (int k = 0; k < nc; ++k)
+	{
+		const s2amdContact& c = w.contacts[(size_t)k];
+		if (c.pointCount <= 0)
+		{
+			continue;
+		}
+		const int ia = w.island[(size_t)c.bodyA], ib = w.island[(size_t)c.bodyB];
+		const int a = movable(w.bodies[(size_t)c.bodyA]) ? ia : -1;
+		const int b = movable(w.bodies[(size_t)c.bodyB]) ? ib : -1;
+		const int fallback = ia >= 0 ? ia : ib; // e.g. kinematic against static
+		ci[(size_t)k] = a >= 0 ? a : (b >= 0 ? b : fallback);
+	}
+	for (int k = 0; k < nj; ++k)
+	{
+		const s2amdJoint& j = w.joints[(size_t)k];
+		if (j.type < 0)
+		{
+			continue;
+		}
+		const bool rev = j.type == S2AMD_JOINT_REVOLUTE;
+		const int jb = j.bodyB, ja = std::max(j.bodyA, 0);
+		const int b = movable(w.bodies[(size_t)jb]) ? w.island[(size_t)jb] : -1;
+		const int a = (rev && movable(w.bodies[(size_t)ja])) ? w.island[(size_t)ja] : -1;
+		const int fallback = w.island[(size_t)jb] >= 0 ? w.island[(size_t)jb] : (rev ? w.island[(size_t)ja] : -1);
+		ji[(size_t)k] = a >= 0 ? a : (b >= 0 ? b : fallback);
+	}
+}
+
+// islands.py: partition -- longest-processing-time bin packing, deterministic (heaviest first, ties by index; least loaded shard, ties by index)
+void partitionLpt(const std::vector<long long>& weights, const std::vector<int>& which, int nShards, std::vector<long long>& load, std::vector<int32_t>& shard)
+{
+	std::vector<int> order = which;
+	std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return weights[(size_t)x] != weights[(size_t)y] ? weights[(size_t)x] > weights[(size_t)y] : x < y; });
+	for (int i : order)
+	{
+		const int s = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+		shard[(size_t)i] = s;
+		load[(size_t)s] += std::max<long long>(weights[(size_t)i], 1);
+	}
+	(void)nShards;
+}
+
+// islands.py: sticky_partition (previousOwner empty: the plain partition)
+void stickyPartition(const s2amdShardedSolver& w, const std::vector<long long>& weights, const std::vector<int32_t>& previousOwner, int nShards,
+					 std::vector<int32_t>& shard)
+{
+	const int n = w.islandCount;
+	shard.assign((size_t)n, -1);
+	std::vector<long long> load((size_t)nShards, 0);
+	if (!previousOwner.empty())
+	{
+		std::vector<long long> votes((size_t)n * (size_t)nShards, 0);
+		for (size_t b = 0; b < w.island.size(); ++b)
+		{
+			if (w.island[b] >= 0 && previousOwner[b] >= 0)
+			{
+				votes[(size_t)w.island[b] * (size_t)nShards + (size_t)previousOwner[b]] += 1;
+			}
+		}
+		for (int i = 0; i < n; ++i)
+		{
+			long long best = 0;
+			int at = -1;
+			for (int s = 0; s < nShards; ++s)
+			{
+				if (votes[(size_t)i * (size_t)nShards + (size_t)s] > best) // (the lowest shard among equals)
+				{
+					best = votes[(size_t)i * (size_t)nShards + (size_t)s], at = s;
+				}
+			}
+			if (at >= 0)
+			{
+				shard[(size_t)i] = at;
+				load[(size_t)at] += std::max<long long>(weights[(size_t)i], 1);
+			}
+		}
+	}
+	std::vector<int> rest;
+	for (int i = 0; i < n; ++i)
+	{
+		if (shard[(size_t)i] < 0)
+		{
+			rest.push_back(i);
+		}
+	}
+	partitionLpt(weights, rest, nShards, load, shard);
+	if (previousOwner.empty())
+	{
+		return;
+	}
+	// ... and past the threshold the heaviest shard's lightest islands that still help go to the least loaded shard
+	for (int guard = 0; guard < n; ++guard)
+	{
+		const long long total = std::accumulate(load.begin(), load.end(), 0LL);
+		const double mean = (double)total / (double)std::max(nShards, 1);
+		const int heavy = (int)(std::max_element(load.begin(), load.end()) - load.begin());
+		const int light = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+		if (nShards < 2 || mean <= 0.0 || (double)load[(size_t)heavy] <= kRebalanceThreshold * mean)
+		{
+			break;
+		}
+		int pick = -1;
+		for (int i = 0; i < n; ++i)
+		{
+			const long long wi = std::max<long long>(weights[(size_t)i], 1);
+			if (shard[(size_t)i] == heavy && load[(size_t)light] + wi < load[(size_t)heavy] &&
+				(pick < 0 || wi < std::max<long long>(weights[(size_t)pick], 1)))
+			{
+				pick = i;
+			}
+		}
+		if (pick < 0)
+		{
+			break;
+		}
+		const long long wp = std::max<long long>(weights[(size_t)pick], 1);
+		shard[(size_t)pick] = light;
+		load[(size_t)heavy] -= wp;
+		load[(size_t)light] += wp;
+	}
+}
+
+// islands.py: extract
+void extract(const s2amdShardedSolver& w, const std::vector<int>& ci, const std::vector<int>& ji, int s, Shard& out)
+{
+	const int nb = (int)w.bodies.size();
+	std::vector<uint8_t> own((size_t)nb, 0), used((size_t)nb, 0);
+	for (int b = 0; b < nb; ++b)
+	{
+		own[(size_t)b] = w.island[(size_t)b] >= 0 && w.shardOfIsland[(size_t)w.island[(size_t)b]] == s;
+		used[(size_t)b] = own[(size_t)b];
+	}
+	out.contactIds.clear(), out.jointIds.clear();
+	for (int k = 0; k < (int)w.contacts.size(); ++k)
+	{
+		if (ci[(size_t)k] >= 0 && w.shardOfIsland[(size_t)ci[(size_t)k]] == s)
+		{
+			out.contactIds.push_back(k);
+			used[(size_t)w.contacts[(size_t)k].bodyA] = 1;
+			used[(size_t)w.contacts[(size_t)k].bodyB] = 1;
+		}
+	}
+	for (int k = 0; k < (int)w.joints.size(); ++k)
+	{
+		if (ji[(size_t)k] >= 0 && w.shardOfIsland[(size_t)ji[(size_t)k]] == s)
+		{
+			out.jointIds.push_back(k);
+			used[(size_t)w.joints[(size_t)k].bodyB] = 1;
+			if (w.joints[(size_t)k].type == S2AMD_JOINT_REVOLUTE)
+			{
+				used[(size_t)w.joints[(size_t)k].bodyA] = 1;
+			}
+		}
+	}
+	std::vector<int> remap((size_t)nb, -1);
+	out.bodyIds.clear(), out.bodies.clear(), out.owned.clear(), out.ownedLocal.clear(), out.ownedWorld.clear();
+	for (int b = 0; b < nb; ++b) // ascending: pool order is preserved inside the shard
+	{
+		if (used[(size_t)b])
+		{
+			remap[(size_t)b] = (int)out.bodyIds.size();
+			if (own[(size_t)b])
+			{
+				out.ownedLocal.push_back((int)out.bodyIds.size());
+				out.ownedWorld.push_back(b);
+			}
+			out.bodyIds.push_back(b);
+			out.bodies.push_back(w.bodies[(size_t)b]);
+			out.owned.push_back(own[(size_t)b]);
+		}
+	}
+	out.contacts.clear(), out.joints.clear();
+	for (int k : out.contactIds)
+	{
+		s2amdContact c = w.contacts[(size_t)k];
+		c.bodyA = remap[(size_t)c.bodyA], c.bodyB = remap[(size_t)c.bodyB];
+		out.contacts.push_back(c);
+	}
+	for (int k : out.jointIds)
+	{
+		s2amdJoint j = w.joints[(size_t)k];
+		j.bodyB = remap[(size_t)j.bodyB];
+		if (j.bodyA >= 0)
+		{
+			j.bodyA = remap[(size_t)j.bodyA];
+		}
+		out.joints.push_back(j);
+	}
+}
+
+int findIslands(s2amdShardedSolver* w)
+{
+	const int nb = (int)w->bodies.size();
+	w->island.assign((size_t)nb, -1);
+	int32_t count = 0;
+	int rc = s2amd_find_islands(w->shards[0].solver, w->bodies.data(), nb, w->contacts.data(), (int32_t)w->contacts.size(), w->joints.data(),
+								(int32_t)w->joints.size(), w->island.data(), &count);
+	w->islandCount = count;
+	for (int32_t x : w->island)
+	{
+		if (rc == S2AMD_OK && (x < -1 || x >= count))
+		{
+			rc = s2amdFail(S2AMD_E_DEVICE, "the device's island labels are out of range");
+		}
+	}
+	return rc;
+}
+
+// partition (fresh, or sticky when previousOwner is given), extract, upload, exchange buffers
+int partitionAndUpload(s2amdShardedSolver* w, const std::vector<int32_t>& previousOwner)
+{
+	int rc = findIslands(w);
+	if (rc)
+	{
+		return rc;
+	}
+	const int nShards = (int)w->shards.size(), nb = (int)w->bodies.size();
+	std::vector<int> ci, ji;
+	constraintIslands(*w, ci, ji);
+	std::vector<long long> weights((size_t)w->islandCount, 0);
+	for (int x : ci)
+	{
+		if (x >= 0)
+		{
+			weights[(size_t)x] += 2;
+		}
+	}
+	for (int x : ji)
+	{
+		if (x >= 0)
+		{
+			weights[(size_t)x] += 1;
+		}
+	}
+	stickyPartition(*w, weights, previousOwner, nShards, w->shardOfIsland);
+	for (int s = 0; s < nShards; ++s)
+	{
+		Shard& sh = w->shards[(size_t)s];
+		extract(*w, ci, ji, s, sh);
+		rc = s2amd_upload(sh.solver, sh.bodies.data(), (int32_t)sh.bodies.size(), sh.contacts.data(), (int32_t)sh.contacts.size(), sh.joints.data(),
+						  (int32_t)sh.joints.size());
+		if (rc)
+		{
+			return rc;
+		}
+		sh.uploaded = true;
+		const size_t nOwned = sh.ownedLocal.size();
+		if ((rc = sh.dRecords.ensure(sh.device, std::max<size_t>(sh.bodies.size(), 1) * 32)) != 0 ||
+			(rc = sh.dOwnedLocal.ensure(sh.device, std::max<size_t>(nOwned, 1) * sizeof(int))) != 0 ||
+			(rc = sh.dOwnedWorld.ensure(sh.device, std::max<size_t>(nOwned, 1) * sizeof(int))) != 0 ||
+			(rc = sh.dCompact.ensure(sh.device, std::max<size_t>(nOwned, 1) * 32)) != 0 || (rc = sh.dWorld.ensure(sh.device, std::max<size_t>((size_t)nb, 1) * 32)) != 0)
+		{
+			return rc;
+		}
+		SH_TRY(hipSetDevice(sh.device));
+		if (nOwned > 0)
+		{
+			SH_TRY(hipMemcpy(sh.dOwnedLocal.p, sh.ownedLocal.data(), nOwned * sizeof(int), hipMemcpyHostToDevice));
+			SH_TRY(hipMemcpy(sh.dOwnedWorld.p, sh.ownedWorld.data(), nOwned * sizeof(int), hipMemcpyHostToDevice));
+		}
+		// the world's records as the upload has them (bodies nobody owns -- static ones -- keep these rows for good)
+		std::vector<float> rows((size_t)nb * 8, 0.0f);
+		for (int b = 0; b < nb; ++b)
+		{
+			const s2amdBody& x = w->bodies[(size_t)b];
+			float* r = rows.data() + (size_t)b * 8;
+			r[0] = x.position[0], r[1] = x.position[1], r[2] = x.rot[0], r[3] = x.rot[1];
+			r[4] = x.linearVelocity[0], r[5] = x.linearVelocity[1], r[6] = x.angularVelocity, r[7] = 0.0f;
+		}
+		if (nb > 0)
+		{
+			SH_TRY(hipMemcpy(sh.dWorld.p, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice));
+		}
+	}
+	// every shard's inbox for every other shard's compact run, and that run's pool indices, on the RECEIVER's device
+	for (int t = 0; t < nShards; ++t)
+	{
+		Shard& dst = w->shards[(size_t)t];
+		dst.inbox.resize((size_t)nShards), dst.inboxIds.resize((size_t)nShards);
+		for (int s = 0; s < nShards; ++s)
+		{
+			if (s == t)
+			{
+				continue;
+			}
+			const Shard& src = w->shards[(size_t)s];
+			const size_t n = src.ownedWorld.size();
+			if ((rc = dst.inbox[(size_t)s].ensure(dst.device, std::max<size_t>(n, 1) * 32)) != 0 ||
+				(rc = dst.inboxIds[(size_t)s].ensure(dst.device, std::max<size_t>(n, 1) * sizeof(int))) != 0)
+			{
+				return rc;
+			}
+			if (n > 0)
+			{
+				SH_TRY(hipSetDevice(dst.device));
+				SH_TRY(hipMemcpy(dst.inboxIds[(size_t)s].p, src.ownedWorld.data(), n * sizeof(int), hipMemcpyHostToDevice));
+			}
+		}
+	}
+	w->resident = true;
+	return S2AMD_OK;
+}
+
+// every shard's solver state back into its host sub-world, and from there into the world's arrays (islands.py: merge_back)
+int pullShards(s2amdShardedSolver* w)
+{
+	for (Shard& sh : w->shards)
+	{
+		if (!sh.uploaded)
+		{
+			continue;
+		}
+		int rc = s2amd_synchronize(sh.solver);
+		if (rc)
+		{
+			return rc;
+		}
+		rc = s2amd_download(sh.solver, sh.bodies.data(), (int32_t)sh.bodies.size(), sh.contacts.data(), (int32_t)sh.contacts.size(), sh.joints.data(),
+							(int32_t)sh.joints.size());
+		if (rc)
+		{
+			return rc;
+		}
+		for (size_t i = 0; i < sh.bodyIds.size(); ++i)
+		{
+			if (sh.owned[i])
+			{
+				w->bodies[(size_t)sh.bodyIds[i]] = sh.bodies[i];
+			}
+		}
+		for (size_t i = 0; i < sh.contactIds.size(); ++i)
+		{
+			s2amdContact& dst = w->contacts[(size_t)sh.contactIds[i]];
+			const int a = dst.bodyA, b = dst.bodyB, index = dst.constraintIndex;
+			dst = sh.contacts[i];
+			dst.bodyA = a, dst.bodyB = b, dst.constraintIndex = index; // (the gather index is a whole-world property: s2amd_sharded_download)
+		}
+		for (size_t i = 0; i < sh.jointIds.size(); ++i)
+		{
+			s2amdJoint& dst = w->joints[(size_t)sh.jointIds[i]];
+			const int a = dst.bodyA, b = dst.bodyB;
+			dst = sh.joints[i];
+			dst.bodyA = a, dst.bodyB = b;
+		}
+	}
+	return S2AMD_OK;
+}
+
+dim3 blocksFor(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+} // namespace
+
+#pragma GCC visibility push(default)
+extern "C"
+{
+
+int s2amd_sharded_create(const int32_t* devices, int32_t deviceCount, s2amdShardedSolver** out)
+{
+	if (!devices || deviceCount <= 0 || deviceCount > 64 || !out)
+	{
+		return s2amdFail(S2AMD_E_INVALID, "bad argument (1 to 64 shards)");
+	}
+	*out = nullptr;
+	s2amdShardedSolver* w = new s2amdShardedSolver();
+	w->shards.resize((size_t)deviceCount);
+	for (int i = 0; i < deviceCount; ++i)
+	{
+		Shard& sh = w->shards[(size_t)i];
+		sh.device = devices[i];
+		int rc = s2amd_create(devices[i], &sh.solver);
+		if (rc == S2AMD_OK)
+		{
+			// the steps of all shards are enqueued before any is waited for
+			rc = s2amd_set_option(sh.solver, "async", 1);
+		}
+		if (rc == S2AMD_OK && (hipSetDevice(sh.device) != hipSuccess || hipEventCreateWithFlags(&sh.evCompact, hipEventDisableTiming) != hipSuccess))
+		{
+			rc = s2amdFail(S2AMD_E_DEVICE, "could not create the shard's event");
+		}
+		if (rc)
+		{
+			s2amd_sharded_destroy(w);
+			return rc;
+		}
+	}
+	// peers that can reach each other directly (xGMI, PCIe P2P) are enabled once; a pair that cannot is still served by
+	// hipMemcpyPeerAsync, through the host
+	for (int i = 0; i < deviceCount; ++i)
+	{
+		for (int j = 0; j < deviceCount; ++j)
+		{
+			int can = 0;
+			if (devices[i] != devices[j] && hipDeviceCanAccessPeer(&can, devices[i], devices[j]) == hipSuccess && can)
+			{
+				(void)hipSetDevice(devices[i]);
+				(void)hipDeviceEnablePeerAccess(devices[j], 0);
+			}
+			(void)hipGetLastError(); // (already enabled: not an error)
+		}
+	}
+	*out = w;
+	return S2AMD_OK;
+}
+
+void s2amd_sharded_destroy(s2amdShardedSolver* w)
+{
+	if (!w)
+	{
+		return;
+	}
+	for (Shard& sh : w->shards)
+	{
+		if (sh.solver)
+		{
+			(void)s2amd_synchronize(sh.solver);
+		}
+		DeviceBlock* blocks[] = {&sh.dRecords, &sh.dOwnedLocal, &sh.dOwnedWorld, &sh.dCompact, &sh.dWorld};
+		for (DeviceBlock* b : blocks)
+		{
+			b->release();
+		}
+		for (DeviceBlock& b : sh.inbox)
+		{
+			b.release();
+		}
+		for (DeviceBlock& b : sh.inboxIds)
+		{
+			b.release();
+		}
+		if (sh.evCompact)
+		{
+			(void)hipSetDevice(sh.device);
+			(void)hipEventDestroy(sh.evCompact);
+		}
+		if (sh.solver)
+		{
+			s2amd_destroy(sh.solver);
+		}
+	}
+	delete w;
+}
+
+int s2amd_sharded_shard_count(const s2amdShardedSolver* w) { return w ? (int)w->shards.size() : 0; }
+
+s2amdSolver* s2amd_sharded_solver(s2amdShardedSolver* w, int32_t shard)
+{
+	return (w && shard >= 0 && shard < (int32_t)w->shards.size()) ? w->shards[(size_t)shard].solver : nullptr;
+}
+
+int s2amd_sharded_upload(s2amdShardedSolver* w, const s2amdBody* bodies, int32_t bodyCapacity, const s2amdContact* contacts, int32_t contactCapacity,
+						 const s2amdJoint* joints, int32_t jointCapacity)
+{
+	if (!w || bodyCapacity < 0 || contactCapacity < 0 || jointCapacity < 0 || (bodyCapacity > 0 && !bodies) || (contactCapacity > 0 && !contacts) ||
+		(jointCapacity > 0 && !joints))
+	{
+		return s2amdFail(S2AMD_E_INVALID, "bad argument");
+	}
+	w->bodies.assign(bodies, bodies + bodyCapacity);
+	w->contacts.assign(contacts, contacts + contactCapacity);
+	w->joints.assign(joints, joints + jointCapacity);
+	w->resident = false;
+	const std::vector<int32_t> none;
+	return partitionAndUpload(w, none);
+}
+
+int s2amd_sharded_step(s2amdShardedSolver* w, const s2amdStepParams* params)
+{
+	if (!w || !params)
+	{
+		return s2amdFail(S2AMD_E_INVALID, "null argument");
+	}
+	if (!w->resident)
+	{
+		return s2amdFail(S2AMD_E_STATE, "s2amd_sharded_step called before s2amd_sharded_upload");
+	}
+	const int nShards = (int)w->shards.size();
+	// every shard's s2Solve_*, its records exported and its owned rows compacted and scattered into its own world copy: enqueued
+	// on the shard's own stream, nothing waited for
+	for (Shard& sh : w->shards)
+	{
+		int rc = s2amd_step_resident(sh.solver, params);
+		if (rc == S2AMD_OK)
+		{
+			rc = s2amd_export_bodies_async(sh.solver, sh.dRecords.p, (int32_t)sh.bodies.size(), 0);
+		}
+		if (rc)
+		{
+			return rc;
+		}
+		const size_t n = sh.ownedLocal.size();
+		hipStream_t st = s2amdStream(sh.solver);
+		SH_TRY(hipSetDevice(sh.device));
+		if (n > 0)
+		{
+			compactOwnedKernel<<<blocksFor(n), dim3(256), 0, st>>>((const float4*)sh.dRecords.p, (const int*)sh.dOwnedLocal.p, (int)n, (float4*)sh.dCompact.p);
+			scatterOwnedKernel<<<blocksFor(n), dim3(256), 0, st>>>((const float4*)sh.dCompact.p, (const int*)sh.dOwnedWorld.p, (int)n, (float4*)sh.dWorld.p);
+		}
+		SH_TRY(hipGetLastError());
+		SH_TRY(hipEventRecord(sh.evCompact, st));
+	}
+	// the step's one exchange: every compact run to every other shard's device, scattered there into its world copy
+	for (int t = 0; t < nShards; ++t)
+	{
+		Shard& dst = w->shards[(size_t)t];
+		hipStream_t st = s2amdStream(dst.solver);
+		SH_TRY(hipSetDevice(dst.device));
+		for (int s = 0; s < nShards; ++s)
+		{
+			const Shard& src = w->shards[(size_t)s];
+			const size_t n = src.ownedLocal.size();
+			if (s == t || n == 0)
+			{
+				continue;
+			}
+			SH_TRY(hipStreamWaitEvent(st, src.evCompact, 0));
+			SH_TRY(hipMemcpyPeerAsync(dst.inbox[(size_t)s].p, dst.device, src.dCompact.p, src.device, n * 32, st));
+			scatterOwnedKernel<<<blocksFor(n), dim3(256), 0, st>>>((const float4*)dst.inbox[(size_t)s].p, (const int*)dst.inboxIds[(size_t)s].p, (int)n,
+																   (float4*)dst.dWorld.p);
+		}
+		SH_TRY(hipGetLastError());
+	}
+	// ... and waited for.  A shard whose persistent launch lost a hand-off (another process on its GPU) has left its arrays untouched
+	// and keeps to the multi-launch path from now on: its step is repeated, its rows exchanged again
+	for (int t = 0; t < nShards; ++t)
+	{
+		Shard& sh = w->shards[(size_t)t];
+		int rc = s2amd_synchronize(sh.solver);
+		for (int attempt = 0; rc == S2AMD_E_DEVICE && attempt < 2; ++attempt)
+		{
+			w->repeatedSteps += 1;
+			rc = s2amd_step_resident(sh.solver, params);
+			if (rc == S2AMD_OK)
+			{
+				rc = s2amd_export_bodies_async(sh.solver, sh.dRecords.p, (int32_t)sh.bodies.size(), 0);
+			}
+			const size_t n = sh.ownedLocal.size();
+			if (rc == S2AMD_OK && n > 0)
+			{
+				hipStream_t st = s2amdStream(sh.solver);
+				SH_TRY(hipSetDevice(sh.device));
+				compactOwnedKernel<<<blocksFor(n), dim3(256), 0, st>>>((const float4*)sh.dRecords.p, (const int*)sh.dOwnedLocal.p, (int)n, (float4*)sh.dCompact.p);
+				scatterOwnedKernel<<<blocksFor(n), dim3(256), 0, st>>>((const float4*)sh.dCompact.p, (const int*)sh.dOwnedWorld.p, (int)n, (float4*)sh.dWorld.p);
+				SH_TRY(hipStreamSynchronize(st));
+				for (int d = 0; d < nShards; ++d)
+				{
+					if (d == t)
+					{
+						continue;
+					}
+					Shard& dst = w->shards[(size_t)d];
+					hipStream_t dstStream = s2amdStream(dst.solver);
+					SH_TRY(hipSetDevice(dst.device));
+					SH_TRY(hipMemcpyPeerAsync(dst.inbox[(size_t)t].p, dst.device, sh.dCompact.p, sh.device, n * 32, dstStream));
+					scatterOwnedKernel<<<blocksFor(n), dim3(256), 0, dstStream>>>((const float4*)dst.inbox[(size_t)t].p, (const int*)dst.inboxIds[(size_t)t].p,
+																					  (int)n, (float4*)dst.dWorld.p);
+					SH_TRY(hipStreamSynchronize(dstStream));
+				}
+			}
+			if (rc == S2AMD_OK)
+			{
+				rc = s2amd_synchronize(sh.solver);
+			}
+		}
+		if (rc)
+		{
+			return rc;
+		}
+	}
+	w->steps += 1;
+	w->lastSolverType = params->solverType;
+	return S2AMD_OK;
+}
+
+int s2amd_sharded_read_bodies(s2amdShardedSolver* w, int32_t shard, float* out, int32_t bodyCapacity)
+{
+	if (!w || !out || shard < 0 || shard >= (int32_t)w->shards.size())
+	{
+		return s2amdFail(S2AMD_E_INVALID, "bad argument");
+	}
+	if (!w->resident)
+	{
+		return s2amdFail(S2AMD_E_STATE, "nothing resident");
+	}
+	if (bodyCapacity < (int32_t)w->bodies.size())
+	{
+		return s2amdFail(S2AMD_E_CAPACITY, "body record buffer too small");
+	}
+	Shard& sh = w->shards[(size_t)shard];
+	SH_TRY(hipSetDevice(sh.device));
+	SH_TRY(hipStreamSynchronize(s2amdStream(sh.solver)));
+	if (!w->bodies.empty())
+	{
+		SH_TRY(hipMemcpy(out, sh.dWorld.p, w->bodies.size() * 32, hipMemcpyDeviceToHost));
+	}
+	return S2AMD_OK;
+}
+
+int s2amd_sharded_download(s2amdShardedSolver* w, s2amdBody* bodies, int32_t bodyCapacity, s2amdContact* contacts, int32_t contactCapacity,
+						   s2amdJoint* joints, int32_t jointCapacity)
+{
+	if (!w)
+	{
+		return s2amdFail(S2AMD_E_INVALID, "null solver");
+	}
+	if (!w->resident)
+	{
+		return s2amdFail(S2AMD_E_STATE, "nothing resident");
+	}
+	if ((bodies && bodyCapacity < (int32_t)w->bodies.size()) || (contacts && contactCapacity < (int32_t)w->contacts.size()) ||
+		(joints && jointCapacity < (int32_t)w->joints.size()))
+	{
+		return s2amdFail(S2AMD_E_CAPACITY, "output arrays smaller than the resident world");
+	}
+	int rc = pullShards(w);
+	if (rc)
+	{
+		return rc;
+	}
+	// manifold.constraintIndex as the reference's gather loop over the WHOLE pool writes it (e.g. solve_tgs_soft.c:162-179): the rank
+	// among the contacts with manifold points, -1 for the skipped ones
+	// (every driver but s2Solve_PGS_NGS_Block, whose own constraint array has no such field: solve_pgs_ngs_block.c:892-963)
+	if (w->lastSolverType >= 0 && w->lastSolverType != s2amd_solverPGS_NGS_Block)
+	{
+		int rank = 0;
+		for (s2amdContact& c : w->contacts)
+		{
+			c.constraintIndex = c.pointCount > 0 ? rank++ : -1;
+		}
+	}
+	if (bodies)
+	{
+		std::copy(w->bodies.begin(), w->bodies.end(), bodies);
+	}
+	if (contacts)
+	{
+		std::copy(w->contacts.begin(), w->contacts.end(), contacts);
+	}
+	if (joints)
+	{
+		std::copy(w->joints.begin(), w->joints.end(), joints);
+	}
+	return S2AMD_OK;
+}
+
+int s2amd_sharded_reshard(s2amdShardedSolver* w, const s2amdContact* contacts, int32_t contactCapacity, const s2amdJoint* joints, int32_t jointCapacity)
+{
+	if (!w)
+	{
+		return s2amdFail(S2AMD_E_INVALID, "null solver");
+	}
+	if (!w->resident)
+	{
+		return s2amdFail(S2AMD_E_STATE, "nothing resident");
+	}
+	if ((contacts && contactCapacity != (int32_t)w->contacts.size()) || (joints && jointCapacity != (int32_t)w->joints.size()))
+	{
+		return s2amdFail(S2AMD_E_INVALID, "the new constraint arrays must have the pool capacities of the uploaded world");
+	}
+	int rc = pullShards(w); // bodies, impulses, TGS_Sticky's friction cache: the solver state lives with the owner
+	if (rc)
+	{
+		return rc;
+	}
+	std::vector<int32_t> previous(w->bodies.size(), -1);
+	for (size_t s = 0; s < w->shards.size(); ++s)
+	{
+		for (int b : w->shards[s].ownedWorld)
+		{
+			previous[(size_t)b] = (int32_t)s;
+		}
+	}
+	if (contacts)
+	{
+		// the caller's array decides which slots are live and what their manifolds are; a slot that kept its pair keeps its solver state
+		for (int k = 0; k < contactCapacity; ++k)
+		{
+			s2amdContact c = contacts[k];
+			const s2amdContact& old = w->contacts[(size_t)k];
+			if (c.bodyA == old.bodyA && c.bodyB == old.bodyB && old.bodyA >= 0)
+			{
+				for (int j = 0; j < 2; ++j)
+				{
+					c.points[j].normalImpulse = old.points[j].normalImpulse, c.points[j].tangentImpulse = old.points[j].tangentImpulse;
+					memcpy(c.points[j].frictionAnchorA, old.points[j].frictionAnchorA, sizeof(float) * 2);
+					memcpy(c.points[j].frictionAnchorB, old.points[j].frictionAnchorB, sizeof(float) * 2);
+					memcpy(c.points[j].frictionNormalA, old.points[j].frictionNormalA, sizeof(float) * 2);
+					memcpy(c.points[j].frictionNormalB, old.points[j].frictionNormalB, sizeof(float) * 2);
+				}
+				c.frictionPersisted = old.frictionPersisted;
+			}
+			w->contacts[(size_t)k] = c;
+		}
+	}
+	if (joints)
+	{
+		w->joints.assign(joints, joints + jointCapacity);
+	}
+	w->reshards += 1;
+	return partitionAndUpload(w, previous);
+}
+
+int s2amd_sharded_get_partition(s2amdShardedSolver* w, int32_t* shardOfBody, int32_t capacity, int32_t* islandCount, int32_t* reshards)
+{
+	if (!w)
+	{
+		return s2amdFail(S2AMD_E_INVALID, "null solver");
+	}
+	if (shardOfBody && capacity < (int32_t)w->bodies.size())
+	{
+		return s2amdFail(S2AMD_E_CAPACITY, "partition buffer too small");
+	}
+	if (shardOfBody)
+	{
+		for (size_t b = 0; b < w->bodies.size(); ++b)
+		{
+			shardOfBody[b] = (b < w->island.size() && w->island[b] >= 0) ? w->shardOfIsland[(size_t)w->island[b]] : -1;
+		}
+	}
+	if (islandCount)
+	{
+		*islandCount = w->islandCount;
+	}
+	if (reshards)
+	{
+		*reshards = w->reshards;
+	}
+	return S2AMD_OK;
+}
+
+} // extern "C"
+#pragma GCC visibility pop
+
+S2_DEFINE_WARM(sharded)

@@ -175,6 +175,7 @@ int s2amd_create(int device, s2amdSolver** out)
 			s2Warm_narrowphase(s->stream);
 			s2Warm_structure(s->stream);
 			s2Warm_world(s->stream);
+			s2Warm_sharded(s->stream);
 			(void)hipStreamSynchronize(s->stream);
 			(void)hipGetLastError();
 		}

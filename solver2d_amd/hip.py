@@ -26,6 +26,8 @@ EXPORTS = [
     "s2amd_world_upload", "s2amd_world_step", "s2amd_world_download", "s2amd_world_find_pairs", "s2amd_world_set_contacts",
     "s2amd_device_alloc", "s2amd_device_free", "s2amd_device_read", "s2amd_world_separated", "s2amd_world_download_boxes", "s2amd_world_set_refit_order", "s2amd_world_download_step",
     "s2amd_get_strip_owners",
+    "s2amd_sharded_create", "s2amd_sharded_destroy", "s2amd_sharded_shard_count", "s2amd_sharded_solver", "s2amd_sharded_upload", "s2amd_sharded_step",
+    "s2amd_sharded_download", "s2amd_sharded_read_bodies", "s2amd_sharded_reshard", "s2amd_sharded_get_partition",
 ]
 
 _libs = {}
@@ -86,6 +88,18 @@ def load(fast=False):
     L.s2amd_device_read.argtypes = [vp, vp, vp, ctypes.c_uint64]
     L.s2amd_find_islands.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, ctypes.POINTER(i32)]
     L.s2amd_color_constraints.argtypes = [vp, vp, i32, vp, i32, vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.s2amd_sharded_create.argtypes = [vp, i32, ctypes.POINTER(vp)]
+    L.s2amd_sharded_destroy.argtypes = [vp]
+    L.s2amd_sharded_destroy.restype = None
+    L.s2amd_sharded_shard_count.argtypes = [vp]
+    L.s2amd_sharded_solver.argtypes = [vp, i32]
+    L.s2amd_sharded_solver.restype = vp
+    L.s2amd_sharded_upload.argtypes = [vp, vp, i32, vp, i32, vp, i32]
+    L.s2amd_sharded_step.argtypes = [vp, ctypes.POINTER(wire.StepParams)]
+    L.s2amd_sharded_download.argtypes = [vp, vp, i32, vp, i32, vp, i32]
+    L.s2amd_sharded_read_bodies.argtypes = [vp, i32, vp, i32]
+    L.s2amd_sharded_reshard.argtypes = [vp, vp, i32, vp, i32]
+    L.s2amd_sharded_get_partition.argtypes = [vp, vp, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     if L.s2amd_api_version() != wire.API_VERSION:
         raise S2AmdError("libs2amd.so API version %d != %d" % (L.s2amd_api_version(), wire.API_VERSION))
     if fast and not L.s2amd_build_flags().decode().count("contract=fast"):
@@ -383,3 +397,86 @@ class Solver:
         st = wire.StepStats()
         self._ck(self._L.s2amd_get_stats(self._h, ctypes.byref(st)))
         return {k: getattr(st, k) for k, _ in wire.StepStats._fields_}
+
+
+class _BorrowedSolver(Solver):
+    """A shard's s2amdSolver as a Solver object (orders, stats, options): owned by the ShardedSolver, never destroyed from here."""
+
+    def __init__(self, L, handle):
+        self._L, self._h, self.fast = L, ctypes.c_void_p(handle), False
+
+    def close(self):
+        self._h = None
+
+
+class ShardedSolver:
+    """include/solver2d_amd.h: s2amd_sharded_* -- one process, one shard per entry of `devices` (HIP ordinals; the same ordinal more
+    than once = logical shards on one GPU).  The world's islands are found on the device and bin-packed onto the shards; a step is every
+    shard's s2Solve_* plus ONE exchange of the owned body records between the devices.  Arrays as for Solver."""
+
+    def __init__(self, devices, fast=False):
+        L = load(fast=fast)
+        devs = (ctypes.c_int32 * len(devices))(*[int(d) for d in devices])
+        h = ctypes.c_void_p()
+        _check(L.s2amd_sharded_create(devs, len(devices), ctypes.byref(h)), L)
+        self._L, self._h = L, h
+        self.shards = len(devices)
+        self.body_capacity = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.s2amd_sharded_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, rc):
+        _check(rc, self._L)
+
+    def shard(self, i):
+        """The Solver of shard i (borrowed: queries and options only)."""
+        h = self._L.s2amd_sharded_solver(self._h, int(i))
+        if not h:
+            raise S2AmdError("no shard %d" % i)
+        return _BorrowedSolver(self._L, h)
+
+    def upload(self, bodies, contacts, joints):
+        self._ck(self._L.s2amd_sharded_upload(self._h, *Solver._args(bodies, contacts, joints)))
+        self.body_capacity = len(bodies)
+
+    def step(self, params):
+        self._ck(self._L.s2amd_sharded_step(self._h, ctypes.byref(params)))
+
+    def download(self, bodies, contacts, joints):
+        self._ck(self._L.s2amd_sharded_download(self._h, *Solver._args(bodies, contacts, joints)))
+        return bodies, contacts, joints
+
+    def read_bodies(self, shard=0):
+        """float32[bodies, 8] {position, rot, linearVelocity, angularVelocity, 0} of the WHOLE world as shard `shard`'s device holds it."""
+        out = np.zeros((self.body_capacity, 8), dtype=np.float32)
+        self._ck(self._L.s2amd_sharded_read_bodies(self._h, int(shard), wire.as_ptr(out.reshape(-1)), self.body_capacity))
+        return out
+
+    def reshard(self, contacts=None, joints=None):
+        for arr, dt in ((contacts, wire.contact_dtype), (joints, wire.joint_dtype)):
+            if arr is not None and (arr.dtype != dt or not arr.flags["C_CONTIGUOUS"]):
+                raise ValueError("array must be a contiguous %s array" % (dt.names,))
+        self._ck(self._L.s2amd_sharded_reshard(self._h, wire.as_ptr(contacts) if contacts is not None else None, len(contacts) if contacts is not None else 0,
+                                               wire.as_ptr(joints) if joints is not None else None, len(joints) if joints is not None else 0))
+
+    def partition(self):
+        """(shard_of_body int32[bodies] (-1: owned by nobody), island_count, reshards so far)"""
+        out = np.full(max(self.body_capacity, 1), -1, dtype=np.int32)
+        n, r = ctypes.c_int32(), ctypes.c_int32()
+        self._ck(self._L.s2amd_sharded_get_partition(self._h, out.ctypes.data, len(out), ctypes.byref(n), ctypes.byref(r)))
+        return out[: self.body_capacity], n.value, r.value

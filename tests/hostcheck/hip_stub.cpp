@@ -122,6 +122,20 @@ hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned int) { return hipSuccess; }
+hipError_t hipMemcpyPeerAsync(void* dst, int, const void* src, int, size_t bytes, hipStream_t)
+{
+	if (bytes)
+	{
+		memmove(dst, src, bytes);
+	}
+	return hipSuccess;
+}
+hipError_t hipDeviceCanAccessPeer(int* can, int, int)
+{
+	*can = 0;
+	return hipSuccess;
+}
+hipError_t hipDeviceEnablePeerAccess(int, unsigned int) { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* event)
 {
 	*event = (hipEvent_t)s_dummy;

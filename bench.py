@@ -31,6 +31,7 @@ Extra objects on the JSON line:
   value_fast    (N = 1) the same headline loop on the tolerance-mode build libs2amd_fast.so (FMA contraction on; SURVEY.md 7: "report
                 both"): value, ms per step, its own dominant-kernel time and roofline fraction, and the distance from the bit-exact
                 build after 30 steps.  `value` / `roofline` on the line itself are always the bit-exact build's.
+  sharded_abi   (N = 1) configs[4] through the C-ABI's own single-process sharding (s2amd_sharded_*): 1 / 2 / 4 logical shards of this GPU
   cpu_baseline  the reference's own s2Solve_TGS_Soft timed on this host (oracle/_ref, kind
                 "reference") or, if that library is absent, the oracle port; 1 core.
   whole_step    (N = 1) the SURVEY.md 8d trajectory of config 2: the base-200 WORLD (shapes, pair states) resident, 60 settle
@@ -509,6 +510,39 @@ def fast_leg(device_index, base, vel, pos, steps, warmup, graph, opts):
                                             "velocity_error_over_scale_per_sweep": dvel / vscale / (sweeps + vel)}}
 
 
+def sharded_abi_leg(device_index, islands, base, vel, pos, steps, warmup, shard_counts=(1, 2, 4)):
+    """BASELINE.json configs[4] through the C-ABI's own sharding (include/solver2d_amd.h: s2amd_sharded_*; csrc/sharded.hip): ONE
+    process, the world's islands found on the device and bin-packed onto k shards -- here k LOGICAL shards on this one GPU, so the
+    numbers say what the partition and the per-step exchange (compact, peer copy, scatter: k x (k - 1) copies) cost, not how k GPUs
+    scale; the multi-process form over RCCL is `island_sharded`.  The k-shard results equal the unsharded world's bit for bit
+    (tests/test_gpu_sharded.py)."""
+    world = synthetic.pyramid(base, count=islands)
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, vel, pos, True)
+    sweeps = wire.solve_sweeps_per_step("TGS_Soft", vel, pos)
+    C = int((world[1]["pointCount"] > 0).sum())
+    rows = []
+    for k in shard_counts:
+        with hip.ShardedSolver([device_index] * k) as sh:
+            t0 = time.perf_counter()
+            sh.upload(*world)
+            upload_ms = 1e3 * (time.perf_counter() - t0)
+            for _ in range(warmup):
+                sh.step(params)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                sh.step(params)
+            ms = 1e3 * (time.perf_counter() - t0) / steps
+            owner, n_islands, _ = sh.partition()
+            per_shard = np.bincount(owner[owner >= 0], minlength=k).tolist()
+        rows.append({"shards": k, "ms_per_step": ms, "value": C * sweeps / (ms * 1e-3), "upload_and_partition_ms": upload_ms, "islands": n_islands,
+                     "bodies_per_shard": per_shard, "exchange_bytes_per_step": int(sum(per_shard) * 32 * max(k - 1, 0))})
+    return {"workload": "%d independent base-%d pyramids (%d constraints), s2_solverTGS_Soft %d/%d; islands found on the device (s2amd_find_islands), "
+                        "bin-packed onto k logical shards of ONE GPU by s2amd_sharded_upload; one exchange of the owned body records per step" % (
+                            islands, base, C, vel, pos),
+            "unit": "constraint-iters/s", "steps": steps, "by_shard_count": rows,
+            "note": "logical shards of one GPU: what the partition and the exchange cost; not a scaling measurement"}
+
+
 def churn_leg(device_index, base):
     """SURVEY.md 8f row 4 as a number: the headline world while its graph changes -- heavy balls shot into the base-200 pyramid, 240 steps
     of the whole loop a caller of the C-ABI runs (pair query -> s2CreateContact on the caller's pool -> s2amd_world_set_contacts ->
@@ -524,7 +558,9 @@ def churn_leg(device_index, base):
             "steps_that_built_a_structure": d["steps_that_rebuilt_the_structure"], "contacts_placed_without_rebuild": d["contacts_placed_without_rebuild"],
             "churn_step_median_ms": d["churn_steps_median"]["step_ms"], "quiet_step_median_ms": d["quiet_steps_median"]["step_ms"],
             "mean_step_ms": d["all_steps"]["step_ms"], "start_up_steps_ms": d["start_up_steps_ms"], "slowest_steps_ms": d["slowest_steps_ms"][:4],
-            "steps_over_1ms_after_start_up": d["steps_over_1ms"], "churn_step_median_parts_ms": {k: round(v, 4) for k, v in d["churn_steps_median"].items() if k != "launches"}}
+            "steps_over_1ms_after_start_up": d["steps_over_1ms"], "steps_over_2ms_after_start_up": d["steps_over_2ms"],
+            "overflow": {k: v for k, v in d["overflow"].items() if k != "note"}, "structure_builds_by_the_worker_thread": d["structure_builds_by_the_worker_thread"],
+            "churn_step_median_parts_ms": {k: round(v, 4) for k, v in d["churn_steps_median"].items() if k != "launches"}}
 
 
 def main():
@@ -786,6 +822,7 @@ def main():
                                   "4_joint_grid": joint_grid_leg(ranks.device_index, 100, 20),
                                   "5_one_gpu": {k: sharded[k] for k in ("value", "unit", "ms_per_step", "config", "roofline")}}
                 out["churn"] = churn_leg(ranks.device_index, args.base)
+                out["sharded_abi"] = sharded_abi_leg(ranks.device_index, args.islands, args.island_base, args.vel_iters, args.pos_iters, 30, 5)
     if rank == 0:
         print(json.dumps(out))
     if distributed:

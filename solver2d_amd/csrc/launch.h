@@ -167,7 +167,8 @@ struct WideSelf
 // float4 records of dynamic LDS the kernel variant for this partition needs beside the bodies, the ops and its three fixed records
 // (parked rounds, staged positions, the warm start's term table); -1: no variant takes the partition
 int wideExtraRecords(const PersistView& pv, int selfContained, int bodyWarm, int kind = SOFT_TGS);
-int wideBodyWarmVariant(const PersistView& pv); // the variant for this partition has the body-centric warm start
+int wideBodyWarmVariant(const PersistView& pv);
+int wideIslandLocalRecords(int maxRounds); // LDS records the resident-island kernel's eight-round variant keeps local anchors in // the variant for this partition has the body-centric warm start
 // ... and the resident islands' step (strip_kernel.hip: launchIslandStep) for TGS_Soft with the current-anchor warm start
 // selfContained: the kernel also stages its bodies from the wire records and writes them back (no prologue / epilogue launch)
 void launchWideIsland(hipStream_t s, const ContactView& c, const BodyView& g, const StripTableView& t, const float4* softCoef, const Op* ops, int opCount,

@@ -554,7 +554,7 @@ struct Executor
 	{
 		int kind, warm;
 		return residentPlan(kind, warm) && s->optWide && kind == SOFT_TGS && warm == WARM_CURRENT &&
-			   s->residentView.ldsRecords + 2 + 2 * s->residentOpCount <= (160 * 1024) / 16;
+			   s->residentView.ldsRecords + 2 + wideIslandLocalRecords(s->residentRounds) + 2 * s->residentOpCount <= (160 * 1024) / 16;
 	}
 
 	// ... and nothing else in the world: every body is owned by a resident island, every constraint is one of theirs, no joints, and

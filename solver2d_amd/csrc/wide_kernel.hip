@@ -149,7 +149,11 @@ template <int KIND, int POINTS> S2_DEV void warmWide(const WideRegs& p, float4* 
 	}
 }
 #else
-template <int KIND, int POINTS> S2_DEV void warmWide(const WideRegs& p, float4* lvel, const float4* ldq, const float2* lmass, uint32_t salt, const float4* arms = nullptr)
+// LL: the record's local anchors wait in LDS ({lA, lB} per manifold point and lane: `locals`), not in p.lA / p.lB -- the variants that hold
+// a sixth resident record, or resident records beside parked rounds (wideLocalsInLds): the registers the record gives up are what
+// those variants used to spill
+template <int KIND, int POINTS, bool LL = false>
+S2_DEV void warmWide(const WideRegs& p, float4* lvel, const float4* ldq, const float2* lmass, uint32_t salt, const float4* arms = nullptr, const float4* locals = nullptr)
 {
 	const uint32_t idx = p.idx ^ salt;
 	const int ia = (int)(idx & 0x1fffu), ib = (int)((idx >> 13) & 0x1fffu);
@@ -180,6 +184,11 @@ template <int KIND, int POINTS> S2_DEV void warmWide(const WideRegs& p, float4* 
 			else if constexpr (KIND == SOFT_PGS)
 			{
 				rA = v2(p.lA[j].y, -p.lA[j].x), rB = v2(p.lB[j].y, -p.lB[j].x);
+			}
+			else if constexpr (LL)
+			{
+				const float4 a = locals[j * S2_WIDE_THREADS];
+				rA = rotate(qA, v2(a.x, a.y)), rB = rotate(qB, v2(a.z, a.w));
 			}
 			else
 			{
@@ -229,7 +238,8 @@ struct WidePrep
 	uint32_t soft; // bit j: point j takes the soft mass / impulse scales
 };
 
-template <int KIND, int POINTS> S2_DEV WidePrep prepWide(const WideRegs& p, const float4* ldq, const float4* lcoef, float inv_h, int useBias, uint32_t salt, const float4* arms = nullptr)
+template <int KIND, int POINTS, bool LL = false>
+S2_DEV WidePrep prepWide(const WideRegs& p, const float4* ldq, const float4* lcoef, float inv_h, int useBias, uint32_t salt, const float4* arms = nullptr, const float4* locals = nullptr)
 {
 	const uint32_t idx = p.idx ^ salt;
 	const int ia = (int)(idx & 0x1fffu), ib = (int)((idx >> 13) & 0x1fffu);
@@ -266,7 +276,17 @@ template <int KIND, int POINTS> S2_DEV WidePrep prepWide(const WideRegs& p, cons
 			const f2 sn = ds2 * n2;
 			const float s = (sn.x + sn.y) + p.p0[j];
 #else
-			const V2 rA = wideIsPgs<KIND> ? v2(0.0f, 0.0f) : rotate(qA, asV2(p.lA[j])), rB = wideIsPgs<KIND> ? v2(0.0f, 0.0f) : rotate(qB, asV2(p.lB[j]));
+			V2 lAj, lBj;
+			if constexpr (LL)
+			{
+				const float4 a = locals[j * S2_WIDE_THREADS];
+				lAj = v2(a.x, a.y), lBj = v2(a.z, a.w);
+			}
+			else
+			{
+				lAj = asV2(p.lA[j]), lBj = asV2(p.lB[j]);
+			}
+			const V2 rA = wideIsPgs<KIND> ? v2(0.0f, 0.0f) : rotate(qA, lAj), rB = wideIsPgs<KIND> ? v2(0.0f, 0.0f) : rotate(qB, lBj);
 #if S2_WIDE_PACKED
 			if constexpr (wideLdsArms<KIND>)
 			{
@@ -529,6 +549,9 @@ S2_DEV WideRegs wideFromSoft(const SoftRegs<SOFT_TGS>& t)
 // MODE bits
 #define S2_WIDE_SELF 1 // the kernel is the step's prologue and epilogue too (Executor::selfContainedStrips): ONE launch per step
 #define S2_WIDE_BODYWARM 2 // s2WarmStartContacts as a body-centric pass over per-constraint terms in LDS (no parked rounds)
+#define S2_WIDE_SLICED 4 // a launch of a SLICED step (Executor::runPersistentSliced: one launch per sweep): the kernel zeroes the hand-off buffers it read at its
+						 // end.  A variant of its own so that the one-launch step's kernel is the code it was (as a run-time branch the five more live values
+						 // cost the headline 1.5 us per launch: 130.5 -> 132.2, measured)
 
 // s2WarmStartContacts (solve_common.c:276-330), body-centric.  The warm start adds, per constraint and manifold point, a term to each
 // of its bodies that depends on the impulses, the anchors and that body's own pose only -- not on any velocity.  So instead of one
@@ -536,7 +559,8 @@ S2_DEV WideRegs wideFromSoft(const SoftRegs<SOFT_TGS>& t)
 // indexed [component][round][body] and every body then adds its terms in round order: the same additions in the same order as the
 // coloured sweep (v + (-mA) P.x is rounded as the reference's mulAdd; w - x == w + (-x)), two barriers.  Terms per side and point:
 // {dv.x, dv.y, dw}; a round's two points are three float2 records {dv0}, {dw0, dv1.x}, {dv1.y, dw1}.
-template <int POINTS> S2_DEV void warmTermsWide(const WideRegs& p, const float4* ldq, const float2* lmass, float2* lt, int tw, int R, int round, int nOwn, uint32_t salt)
+template <int POINTS, bool LL = false>
+S2_DEV void warmTermsWide(const WideRegs& p, const float4* ldq, const float2* lmass, float2* lt, int tw, int R, int round, int nOwn, uint32_t salt, const float4* locals = nullptr)
 {
 	const uint32_t idx = p.idx ^ salt;
 	const int ia = (int)(idx & 0x1fffu), ib = (int)((idx >> 13) & 0x1fffu);
@@ -556,7 +580,17 @@ template <int POINTS> S2_DEV void warmTermsWide(const WideRegs& p, const float4*
 		tB[3 * j] = tB[3 * j + 1] = tB[3 * j + 2] = 0.0f;
 		if (POINTS == 2 || j < pointCount)
 		{
-			const V2 rA = rotate(qA, asV2(p.lA[j])), rB = rotate(qB, asV2(p.lB[j]));
+			V2 lAj, lBj;
+			if constexpr (LL)
+			{
+				const float4 a = locals[j * S2_WIDE_THREADS];
+				lAj = v2(a.x, a.y), lBj = v2(a.z, a.w);
+			}
+			else
+			{
+				lAj = asV2(p.lA[j]), lBj = asV2(p.lB[j]);
+			}
+			const V2 rA = rotate(qA, lAj), rB = rotate(qB, lBj);
 			const V2 P = add(mulSV(p.imp[j].x, normal), mulSV(p.imp[j].y, tangent));
 			// wA -= iA * cross(rA, P); vA = mulAdd(vA, -mA, P); wB += iB * cross(rB, P); vB = mulAdd(vB, mB, P)
 			tA[3 * j] = -mA.x * P.x, tA[3 * j + 1] = -mA.x * P.y, tA[3 * j + 2] = -(mA.y * cross(rA, P));
@@ -579,6 +613,17 @@ template <int POINTS> S2_DEV void warmTermsWide(const WideRegs& p, const float4*
 	}
 }
 
+// Resident records of a lane whose local anchors wait in LDS instead of registers (s2Solve_TGS_Soft's variants; warmWide / prepWide: LL).
+// The <3, 2> layout -- five records of 22 dwords -- fits the 256 registers of a lane beside a round's working set; a sixth record
+// (<3, 3>, <4, 2>), or a parked round's record coming through the registers beside the five, does not: those variants spilled 40-520
+// bytes per lane to scratch through round 4.  Eight dwords per record move to LDS (16 KB per record and workgroup) -- read once per
+// sweep by the prep, in lanes that wait anyway.  How many: what took each variant below the register file (make resources).
+constexpr int wideLocalsInLds(int RPH, int SR, int SL, int IL, bool sliced)
+{
+	const int plain = (SL > 0 || IL > 0) ? (IL > 0 ? 4 : 3) : ((RPH + SR > 5) ? 3 : 0);
+	return plain > 0 && sliced ? plain + 1 : plain; // (a sliced step's launch keeps its inbox addresses live to its end: one more record's worth)
+}
+
 // POINTS == 2: the host has checked that every constraint of the strips has two manifold points: no per-point masking.
 // RPH: interior records a lane keeps (colour batches / 2), SR: seam records a lane keeps, SL: seam rounds parked in LDS.
 // IL: interior rounds parked in LDS behind the 2 RPH a lane keeps (a strip that needs a seventh or eighth colour: a hub body inside it).
@@ -589,10 +634,20 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 	constexpr bool SELF = (MODE & S2_WIDE_SELF) != 0;
 	constexpr bool BODYWARM = (MODE & S2_WIDE_BODYWARM) != 0;
 	static_assert(!BODYWARM || (SL == 0 && IL == 0), "the body-centric warm start keeps no terms for parked rounds");
-	static_assert(KIND == SOFT_TGS || MODE == 0, "the self-contained form and the body-centric warm start are s2Solve_TGS_Soft's");
+	constexpr bool SLICED = (MODE & S2_WIDE_SLICED) != 0;
+	static_assert(KIND == SOFT_TGS || (MODE & ~S2_WIDE_SLICED) == 0, "the self-contained form and the body-centric warm start are s2Solve_TGS_Soft's");
+	static_assert(!SLICED || MODE == S2_WIDE_SLICED, "a sliced step's launches are the plain form");
 	static_assert(KIND != SOFT_FIXED || (SL == 0 && IL == 0), "s2Solve_SoftStep: the variants without parked rounds");
 	// the record form the constraint functions take: s2Solve_PGS_Soft on a variant without parked rounds keeps its anchors in LDS too
-	constexpr int RK = (KIND == SOFT_PGS && SL == 0 && IL == 0) ? S2_WIDE_PGS_ARMS : KIND;
+	// (RK: the records a lane keeps -- s2Solve_PGS_Soft's with their anchors in LDS; RKP: the records of parked rounds, whole in LDS)
+	constexpr int RK = KIND == SOFT_PGS ? S2_WIDE_PGS_ARMS : KIND;
+	constexpr int RKP = KIND;
+	// resident records whose local anchors wait in LDS instead of registers (warmWide / prepWide: LL): the last LA of the RPH interior
+	// + SR seam records a lane holds -- s2Solve_TGS_Soft's variants beyond the <3, 2> layout
+	constexpr int NRES = RPH + SR;
+	constexpr int LA = KIND == SOFT_TGS ? wideLocalsInLds(RPH, SR, SL, IL, SLICED) : 0;
+	constexpr int LL0 = NRES - LA; // the first such record (interior records 0 .. RPH - 1, then the seam records)
+	static_assert(LA >= 0 && LA <= NRES, "wideLocalsInLds");
 	const int tid = (int)threadIdx.x;
 #ifndef S2_WIDE_SPREAD_HALVES
 #define S2_WIDE_SPREAD_HALVES 0
@@ -699,6 +754,10 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 	// SELF: the positions of the staged bodies (s2FinalizePositions adds to them; the SoA array g.pos is not used); BODYWARM: per body
 	// the rounds that hold a constraint writing it (bits 0-15; bits 16-31: ... with a second manifold point) and the term table
 	float4* lextra = lcoef + 3 + S2_WIDE_PARKED_RECORDS * (SL * sw + IL * iw);
+	// ... then the local anchors of the LA records that keep them here: [record - LL0][point][lane] {lA, lB}
+	float4* llocals = lextra + tid;
+	lextra += 2 * LA * S2_WIDE_THREADS;
+	auto localsOf = [&](int r) { return llocals + 2 * (r - LL0 > 0 ? r - LL0 : 0) * S2_WIDE_THREADS; };
 	float2* lpos = (float2*)lextra;
 	lextra += SELF ? (pv.maxStaged + 1) / 2 : 0;
 	constexpr int TR = 2 * RPH + SR; // rounds of the term table: the interior rounds, then the seam rounds
@@ -838,6 +897,14 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 		const int kc = k >= 0 ? k : 0;
 		const int2 lb = c.localBodies[kc];
 		rA[s] = loadWide<RK>(c, kc, lb.x, lb.y);
+		if (s >= LL0)
+		{
+#pragma unroll
+			for (int j = 0; j < 2; ++j)
+			{
+				localsOf(s)[j * S2_WIDE_THREADS] = make_float4(rA[s].lA[j].x, rA[s].lA[j].y, rA[s].lB[j].x, rA[s].lB[j].y);
+			}
+		}
 		if constexpr (wideLdsArms<RK>)
 		{
 #pragma unroll
@@ -857,6 +924,14 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 		const int2 lb = c.localBodies[kc];
 		const int base = mine ? pd->remapBase[seam] : 0; // (a valid entry of the remap table either way)
 		rB[i] = loadWide<RK>(c, kc, pv.remap[base + (mine ? lb.x : 0)], pv.remap[base + (mine ? lb.y : 0)]);
+		if (RPH + i >= LL0)
+		{
+#pragma unroll
+			for (int j = 0; j < 2; ++j)
+			{
+				localsOf(RPH + i)[j * S2_WIDE_THREADS] = make_float4(rB[i].lA[j].x, rB[i].lA[j].y, rB[i].lB[j].x, rB[i].lB[j].y);
+			}
+		}
 		if constexpr (wideLdsArms<RK>)
 		{
 #pragma unroll
@@ -876,7 +951,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 		{
 			const int2 lb = c.localBodies[k];
 			parkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * sw, sw,
-					 loadWide<RK>(c, k, pv.remap[pd->remapBase[seam] + lb.x], pv.remap[pd->remapBase[seam] + lb.y]));
+					 loadWide<RKP>(c, k, pv.remap[pd->remapBase[seam] + lb.x], pv.remap[pd->remapBase[seam] + lb.y]));
 			seamMask |= 1u << i;
 		}
 	}
@@ -887,7 +962,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 		if (k >= 0)
 		{
 			const int2 lb = c.localBodies[k];
-			parkWide(lparkedI + j * S2_WIDE_PARKED_RECORDS * iw, iw, loadWide<RK>(c, k, lb.x, lb.y));
+			parkWide(lparkedI + j * S2_WIDE_PARKED_RECORDS * iw, iw, loadWide<RKP>(c, k, lb.x, lb.y));
 		}
 	}
 	// bodies (+ their integrator constants) into LDS: own list, then this half's imports
@@ -1154,7 +1229,14 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 			{
 				if (kOfSlot(s) >= 0)
 				{
-					warmTermsWide<POINTS>(rA[s], ldq, lmass, lt, tw, TR, 2 * s + half, nb, salt);
+					if (s >= LL0)
+					{
+						warmTermsWide<POINTS, true>(rA[s], ldq, lmass, lt, tw, TR, 2 * s + half, nb, salt, localsOf(s));
+					}
+					else
+					{
+						warmTermsWide<POINTS>(rA[s], ldq, lmass, lt, tw, TR, 2 * s + half, nb, salt);
+					}
 				}
 			}
 #pragma unroll
@@ -1162,7 +1244,14 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 			{
 				if ((seamMask >> i) & 1u)
 				{
-					warmTermsWide<POINTS>(rB[i], ldq, lmass, lt, tw, TR, ROUNDS + i, nb, salt);
+					if (RPH + i >= LL0)
+					{
+						warmTermsWide<POINTS, true>(rB[i], ldq, lmass, lt, tw, TR, ROUNDS + i, nb, salt, localsOf(RPH + i));
+					}
+					else
+					{
+						warmTermsWide<POINTS>(rB[i], ldq, lmass, lt, tw, TR, ROUNDS + i, nb, salt);
+					}
 				}
 			}
 			__syncthreads();
@@ -1222,7 +1311,14 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 				{
 					if ((i & 1) == half && kOfSlot(i >> 1) >= 0)
 					{
-						warmWide<RK, POINTS>(rA[i >> 1], lvel, ldq, lmass, salt, larms + 2 * (i >> 1) * S2_WIDE_THREADS);
+						if ((i >> 1) >= LL0)
+						{
+							warmWide<RK, POINTS, true>(rA[i >> 1], lvel, ldq, lmass, salt, nullptr, localsOf(i >> 1));
+						}
+						else
+						{
+							warmWide<RK, POINTS>(rA[i >> 1], lvel, ldq, lmass, salt, larms + 2 * (i >> 1) * S2_WIDE_THREADS);
+						}
 					}
 					__syncthreads();
 				}
@@ -1234,7 +1330,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 				{
 					if (kOfParked(j) >= 0)
 					{
-						warmWide<RK, POINTS>(unparkWide(lparkedI + j * S2_WIDE_PARKED_RECORDS * iw, iw), lvel, ldq, lmass, salt);
+						warmWide<RKP, POINTS>(unparkWide(lparkedI + j * S2_WIDE_PARKED_RECORDS * iw, iw), lvel, ldq, lmass, salt);
 					}
 					__syncthreads();
 				}
@@ -1246,7 +1342,14 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 				{
 					if ((seamMask >> i) & 1u)
 					{
-						warmWide<RK, POINTS>(rB[i], lvel, ldq, lmass, salt, larms + 2 * (RPH + i) * S2_WIDE_THREADS);
+						if (RPH + i >= LL0)
+						{
+							warmWide<RK, POINTS, true>(rB[i], lvel, ldq, lmass, salt, nullptr, localsOf(RPH + i));
+						}
+						else
+						{
+							warmWide<RK, POINTS>(rB[i], lvel, ldq, lmass, salt, larms + 2 * (RPH + i) * S2_WIDE_THREADS);
+						}
 					}
 					__syncthreads();
 				}
@@ -1258,7 +1361,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 				{
 					if ((seamMask >> i) & 1u)
 					{
-						warmWide<RK, POINTS>(unparkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * sw, sw), lvel, ldq, lmass, salt);
+						warmWide<RKP, POINTS>(unparkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * sw, sw), lvel, ldq, lmass, salt);
 					}
 					__syncthreads();
 				}
@@ -1272,7 +1375,14 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 			WidePrep pre;
 			if (half == 0 && kOfSlot(0) >= 0)
 			{
-				pre = prepWide<RK, POINTS>(rA[0], ldq, lcoef, op.inv_h, op.useBias, salt, larms);
+				if (0 >= LL0)
+				{
+					pre = prepWide<RK, POINTS, true>(rA[0], ldq, lcoef, op.inv_h, op.useBias, salt, nullptr, localsOf(0));
+				}
+				else
+				{
+					pre = prepWide<RK, POINTS>(rA[0], ldq, lcoef, op.inv_h, op.useBias, salt, larms);
+				}
 			}
 			// (the parked rounds ROUNDS .. RA-1 take part in the same schedule: their records come out of LDS for the prep and again for the chain)
 #pragma unroll
@@ -1303,12 +1413,19 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 						{
 							if (kOfSlot((i + 1) >> 1) >= 0)
 							{
-								pre = prepWide<RK, POINTS>(rA[(i + 1) >> 1 < RPH ? (i + 1) >> 1 : 0], ldq, lcoef, op.inv_h, op.useBias, salt, larms + 2 * ((i + 1) >> 1) * S2_WIDE_THREADS);
+								if (((i + 1) >> 1) >= LL0)
+								{
+									pre = prepWide<RK, POINTS, true>(rA[(i + 1) >> 1 < RPH ? (i + 1) >> 1 : 0], ldq, lcoef, op.inv_h, op.useBias, salt, nullptr, localsOf((i + 1) >> 1));
+								}
+								else
+								{
+									pre = prepWide<RK, POINTS>(rA[(i + 1) >> 1 < RPH ? (i + 1) >> 1 : 0], ldq, lcoef, op.inv_h, op.useBias, salt, larms + 2 * ((i + 1) >> 1) * S2_WIDE_THREADS);
+								}
 							}
 						}
 						else if (kOfParked(i + 1 - ROUNDS < IL ? i + 1 - ROUNDS : 0) >= 0)
 						{
-							pre = prepWide<RK, POINTS>(unparkWide(lparkedI + (i + 1 - ROUNDS) * S2_WIDE_PARKED_RECORDS * iw, iw), ldq, lcoef, op.inv_h, op.useBias, salt);
+							pre = prepWide<RKP, POINTS>(unparkWide(lparkedI + (i + 1 - ROUNDS) * S2_WIDE_PARKED_RECORDS * iw, iw), ldq, lcoef, op.inv_h, op.useBias, salt);
 						}
 					}
 					__syncthreads();
@@ -1344,7 +1461,14 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 			{
 				if ((seamMask >> i) & 1u)
 				{
-					preB[i] = prepWide<RK, POINTS>(rB[i], ldq, lcoef, op.inv_h, op.useBias, salt, larms + 2 * (RPH + i) * S2_WIDE_THREADS);
+					if (RPH + i >= LL0)
+					{
+						preB[i] = prepWide<RK, POINTS, true>(rB[i], ldq, lcoef, op.inv_h, op.useBias, salt, nullptr, localsOf(RPH + i));
+					}
+					else
+					{
+						preB[i] = prepWide<RK, POINTS>(rB[i], ldq, lcoef, op.inv_h, op.useBias, salt, larms + 2 * (RPH + i) * S2_WIDE_THREADS);
+					}
 				}
 			}
 			// (... and of the parked seam rounds: their records come out of LDS for it, and again for the chain)
@@ -1354,7 +1478,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 			{
 				if (S2_WIDE_PARKED_PREP_EARLY && ((seamMask >> i) & 1u))
 				{
-					preP[i - SR] = prepWide<RK, POINTS>(unparkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * sw, sw), ldq, lcoef, op.inv_h, op.useBias, salt);
+					preP[i - SR] = prepWide<RKP, POINTS>(unparkWide(lparked + (i - SR) * S2_WIDE_PARKED_RECORDS * sw, sw), ldq, lcoef, op.inv_h, op.useBias, salt);
 				}
 			}
 			int fail = 0;
@@ -1388,7 +1512,8 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 						{
 							if (i >= 2)
 							{
-								const WidePrep late = prepWide<RK, POINTS>(rB[i], ldq, lcoef, op.inv_h, op.useBias, salt, larms + 2 * (RPH + i) * S2_WIDE_THREADS);
+								const WidePrep late = (RPH + i >= LL0) ? prepWide<RK, POINTS, true>(rB[i], ldq, lcoef, op.inv_h, op.useBias, salt, nullptr, localsOf(RPH + i))
+																	   : prepWide<RK, POINTS>(rB[i], ldq, lcoef, op.inv_h, op.useBias, salt, larms + 2 * (RPH + i) * S2_WIDE_THREADS);
 								chainWide<POINTS>(rB[i], late, lvel, lmass, lcoef, salt);
 							}
 							else
@@ -1423,7 +1548,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 						}
 						else
 						{
-							const WidePrep late = prepWide<RK, POINTS>(p, ldq, lcoef, op.inv_h, op.useBias, salt);
+							const WidePrep late = prepWide<RKP, POINTS>(p, ldq, lcoef, op.inv_h, op.useBias, salt);
 							chainWide<POINTS>(p, late, lvel, lmass, lcoef, salt);
 						}
 						slot[5 * sw] = make_float4(p.imp[0].x, p.imp[0].y, p.imp[1].x, p.imp[1].y);
@@ -1615,7 +1740,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 			}
 		}
 	}
-	if constexpr (!SELF)
+	if constexpr (SLICED)
 	{
 		// sliced step (Executor::runPersistentSliced): the next launch of this step starts its tags from zero again.  Every granule
 		// this workgroup reads has been written for the last time -- a neighbour writes one granule set per sweep and this workgroup
@@ -1623,7 +1748,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 		// parities), as the self-contained form does behind its commit.  (The census entries stay: the next launch's workgroups
 		// write the same XCD ids again -- and were the placement ever to differ, a hand-off on the same-L2 path would time out and the
 		// step be repeated with agent-scope stores: solver_step.cpp.)
-		if (pv.clearOwn != 0 && !bad)
+		if (!bad)
 		{
 			if (ht < nImpH)
 			{
@@ -1674,10 +1799,11 @@ static void launchWideMode(hipStream_t s, dim3 grid, size_t lds, const ContactVi
 
 // dynamic LDS beside the bodies, the ops and the three fixed records: parked rounds, the staged positions (self-contained), the
 // round masks and the term table of the body-centric warm start
-static size_t wideExtraLds(const PersistView& pv, int RPH, int SR, int SL, int IL, bool selfContained, bool bodyWarm, bool fixedArms = false)
+static size_t wideExtraLds(const PersistView& pv, int RPH, int SR, int SL, int IL, bool selfContained, bool bodyWarm, bool fixedArms = false, bool tgsLocals = false)
 {
 	size_t records = (size_t)S2_WIDE_PARKED_RECORDS * ((size_t)SL * pv.parkSeamWidth + (size_t)IL * pv.parkInteriorWidth);
 	records += fixedArms ? (size_t)2 * (RPH + SR) * S2_WIDE_THREADS : 0; // SOFT_FIXED: {perp(rA0), perp(rB0)} per record, point and lane
+	records += tgsLocals ? (size_t)2 * wideLocalsInLds(RPH, SR, SL, IL, true) * S2_WIDE_THREADS : 0; // s2Solve_TGS_Soft: {lA, lB} of the records that keep them in LDS
 	records += selfContained ? (size_t)(pv.maxStaged + 1) / 2 : 0;
 	if (bodyWarm)
 	{
@@ -1693,12 +1819,20 @@ static void launchWide(hipStream_t s, dim3 grid, size_t lds, const ContactView& 
 {
 	if (kind == SOFT_FIXED)
 	{
-		// s2Solve_SoftStep: the plain form of the variants without parked rounds (wideVariant)
-		if constexpr (SL == 0 && IL == 0)
+		// s2Solve_SoftStep: the <3, 2> layout (wideVariant) -- its record keeps rA0 / rB0 in LDS beside the TGS record in registers, and a
+		// sixth such record fits neither
+		if constexpr (RPH == 3 && SR == 2 && SL == 0 && IL == 0)
 		{
 			const WideSelf none{};
 			lds += wideExtraLds(pv, RPH, SR, SL, IL, false, false, true);
-			launchWideMode<RPH, SR, SL, IL, 0, SOFT_FIXED>(s, grid, lds, c, g, a, pv, ops, opCount, none);
+			if (pv.clearOwn != 0)
+			{
+				launchWideMode<RPH, SR, SL, IL, S2_WIDE_SLICED, SOFT_FIXED>(s, grid, lds, c, g, a, pv, ops, opCount, none);
+			}
+			else
+			{
+				launchWideMode<RPH, SR, SL, IL, 0, SOFT_FIXED>(s, grid, lds, c, g, a, pv, ops, opCount, none);
+			}
 		}
 		return;
 	}
@@ -1706,34 +1840,56 @@ static void launchWide(hipStream_t s, dim3 grid, size_t lds, const ContactView& 
 	{
 		// s2Solve_PGS_Soft: the plain form only (prologue and epilogue launches, the coloured warm start); rA0 / rB0 in LDS where no round is parked
 		const WideSelf none{};
-		lds += wideExtraLds(pv, RPH, SR, SL, IL, false, false, SL == 0 && IL == 0);
-		launchWideMode<RPH, SR, SL, IL, 0, SOFT_PGS>(s, grid, lds, c, g, a, pv, ops, opCount, none);
+		lds += wideExtraLds(pv, RPH, SR, SL, IL, false, false, true);
+		if (pv.clearOwn != 0)
+		{
+			launchWideMode<RPH, SR, SL, IL, S2_WIDE_SLICED, SOFT_PGS>(s, grid, lds, c, g, a, pv, ops, opCount, none);
+		}
+		else
+		{
+			launchWideMode<RPH, SR, SL, IL, 0, SOFT_PGS>(s, grid, lds, c, g, a, pv, ops, opCount, none);
+		}
 		return;
 	}
-	const bool selfContained = self != nullptr;
-	const bool bodyWarm = SL == 0 && IL == 0 && pv.bodyWarm != 0;
-	lds += wideExtraLds(pv, RPH, SR, SL, IL, selfContained, bodyWarm);
+	// (the self-contained form and the body-centric warm start -- options, measured no faster -- exist for the <3, 2> layout: beside a
+	// sixth record or parked rounds they spilled up to 520 bytes per lane: wideExtraRecords says so to the caller)
+	constexpr bool OPTIONAL_MODES = RPH == 3 && SR == 2 && SL == 0 && IL == 0;
+	const bool selfContained = OPTIONAL_MODES && self != nullptr;
+	const bool bodyWarm = OPTIONAL_MODES && pv.bodyWarm != 0;
+	lds += wideExtraLds(pv, RPH, SR, SL, IL, selfContained, bodyWarm, false, true);
 	const WideSelf none{};
-	if constexpr (SL == 0 && IL == 0)
+	if constexpr (OPTIONAL_MODES)
 	{
-		if (selfContained && bodyWarm)
+		if (selfContained && bodyWarm && pv.allTwoPoints)
 		{
-			launchWideMode<RPH, SR, SL, IL, S2_WIDE_SELF | S2_WIDE_BODYWARM>(s, grid, lds, c, g, a, pv, ops, opCount, *self);
+			// (both at once for manifolds of two points only: with per-point masking the combination spilled 24 bytes per lane; mixed
+			// point counts take the self-contained form with the coloured warm start)
+			wideStepKernel<2, RPH, SR, SL, IL, S2_WIDE_SELF | S2_WIDE_BODYWARM><<<grid, dim3(S2_WIDE_THREADS), lds, s>>>(c, g, a, pv, ops, opCount, *self);
 			return;
 		}
-		if (bodyWarm)
+		if (bodyWarm && !selfContained)
 		{
 			launchWideMode<RPH, SR, SL, IL, S2_WIDE_BODYWARM>(s, grid, lds, c, g, a, pv, ops, opCount, none);
 			return;
 		}
 	}
-	if (selfContained)
+	if constexpr (OPTIONAL_MODES)
 	{
-		launchWideMode<RPH, SR, SL, IL, S2_WIDE_SELF>(s, grid, lds, c, g, a, pv, ops, opCount, *self);
+		if (selfContained)
+		{
+			launchWideMode<RPH, SR, SL, IL, S2_WIDE_SELF>(s, grid, lds, c, g, a, pv, ops, opCount, *self);
+			return;
+		}
 	}
-	else
 	{
-		launchWideMode<RPH, SR, SL, IL, 0>(s, grid, lds, c, g, a, pv, ops, opCount, none);
+		if (pv.clearOwn != 0)
+		{
+			launchWideMode<RPH, SR, SL, IL, S2_WIDE_SLICED>(s, grid, lds, c, g, a, pv, ops, opCount, none);
+		}
+		else
+		{
+			launchWideMode<RPH, SR, SL, IL, 0>(s, grid, lds, c, g, a, pv, ops, opCount, none);
+		}
 	}
 }
 
@@ -1772,9 +1928,9 @@ int wideExtraRecords(const PersistView& pv, int selfContained, int bodyWarm, int
 {
 	static const int shape[5][4] = {{3, 2, 0, 0}, {3, 3, 0, 0}, {4, 2, 0, 0}, {3, 2, 2, 0}, {3, 2, 2, 2}};
 	const int v = wideVariant(pv);
-	if (v < 0 || (kind == SOFT_FIXED && v > 2))
+	if (v < 0 || (kind == SOFT_FIXED && v > 0) || ((selfContained != 0 || bodyWarm != 0) && v > 0))
 	{
-		return -1;
+		return -1; // (s2Solve_SoftStep, the self-contained form and the body-centric warm start: the <3, 2> layout only)
 	}
 	if (kind == SOFT_FIXED)
 	{
@@ -1782,17 +1938,17 @@ int wideExtraRecords(const PersistView& pv, int selfContained, int bodyWarm, int
 	}
 	if (kind == SOFT_PGS)
 	{
-		return (int)(wideExtraLds(pv, shape[v][0], shape[v][1], shape[v][2], shape[v][3], false, false, shape[v][2] == 0 && shape[v][3] == 0) / sizeof(float4));
+		return (int)(wideExtraLds(pv, shape[v][0], shape[v][1], shape[v][2], shape[v][3], false, false, true) / sizeof(float4));
 	}
 	const bool warm = bodyWarm != 0 && shape[v][2] == 0 && shape[v][3] == 0;
-	return (int)(wideExtraLds(pv, shape[v][0], shape[v][1], shape[v][2], shape[v][3], selfContained != 0, warm) / sizeof(float4));
+	return (int)(wideExtraLds(pv, shape[v][0], shape[v][1], shape[v][2], shape[v][3], selfContained != 0, warm, false, true) / sizeof(float4));
 }
 
 // ... and whether that variant has the body-centric warm start at all (the parked ones keep the coloured sweep)
 int wideBodyWarmVariant(const PersistView& pv)
 {
 	const int v = wideVariant(pv);
-	return v >= 0 && v <= 2 ? 1 : 0;
+	return v == 0 ? 1 : 0;
 }
 
 void launchWideStep(hipStream_t s, int kind, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount, const WideSelf* self)
@@ -1833,6 +1989,11 @@ void launchWideStep(hipStream_t s, int kind, const ContactView& c, const BodyVie
 // operations of body_ops.h: unpackBodyOne) and writes the owned ones back (packBodyOne) --, for a world that consists of
 // resident islands only (BASELINE config 5): the step is this one launch.
 // POINTS == 2: the host has checked that every constraint of the islands has two manifold points (no per-point masking: 356 against 383 us at config 5).
+// (the eight-round variant keeps the local anchors of its last six records in LDS -- wideStepKernel: wideLocalsInLds --: eight
+// 22-dword records spilled 140-172 bytes per lane)
+constexpr int wideIslandLocalsInLds(int ROUNDS) { return ROUNDS > S2_STRIP_ROUNDS ? 6 : 0; }
+int wideIslandLocalRecords(int maxRounds) { return 2 * wideIslandLocalsInLds(maxRounds > S2_STRIP_ROUNDS ? S2_STRIP_ROUNDS_MAX : S2_STRIP_ROUNDS) * S2_WIDE_THREADS; }
+
 template <int ROUNDS, bool SELF, int POINTS>
 __global__ __launch_bounds__(S2_WIDE_THREADS) void wideIslandKernel(ContactView c, BodyView g, StripTableView ta, float4 softCoef0, float4 softCoef1, const Op* ops,
 																	 int opCount, s2amdContact* wire, s2amdBody* wireBodies, const uint32_t* hostFlags, int warmStart,
@@ -1860,6 +2021,9 @@ __global__ __launch_bounds__(S2_WIDE_THREADS) void wideIslandKernel(ContactView 
 	const int bodyRecords = 3 * nb + (nb + 3) / 4 + (nb + 1) / 2;
 	Op* lops = (Op*)(lds + bodyRecords);
 	float4* lcoef = lds + bodyRecords + 2 * opCount; // 2 records (the launch adds them to the size)
+	constexpr int LA = wideIslandLocalsInLds(ROUNDS), LL0 = ROUNDS - LA;
+	float4* llocals = lcoef + 2 + tid; // [record - LL0][point][lane] {lA, lB}
+	auto localsOf = [&](int r) { return llocals + 2 * (r - LL0 > 0 ? r - LL0 : 0) * S2_WIDE_THREADS; };
 
 	uint32_t id[S2_STRIP_BODY_CHUNKS];
 #pragma unroll
@@ -1953,6 +2117,14 @@ __global__ __launch_bounds__(S2_WIDE_THREADS) void wideIslandKernel(ContactView 
 			rA[i] = wideFromSoft(prepareSoftFromWire<SOFT_TGS>(wire + slotOf[i], wireBodies, hostFlags, lb, lmass, localOf[i], g.capacity, warmStart));
 			const bool st = lmass[localOf[i].x].x == 0.0f || lmass[localOf[i].y].x == 0.0f; // the doubled contact hertz of a static side
 			rA[i].idx |= st ? 1u << 30 : 0u;
+			if (i >= LL0)
+			{
+#pragma unroll
+				for (int j = 0; j < 2; ++j)
+				{
+					localsOf(i)[j * S2_WIDE_THREADS] = make_float4(rA[i].lA[j].x, rA[i].lA[j].y, rA[i].lB[j].x, rA[i].lB[j].y);
+				}
+			}
 		}
 	}
 	for (int oi = 0; oi < opCount; ++oi)
@@ -2029,7 +2201,14 @@ __global__ __launch_bounds__(S2_WIDE_THREADS) void wideIslandKernel(ContactView 
 				{
 					if (kOfRound(i) >= 0)
 					{
-						warmWide<SOFT_TGS, POINTS>(rA[i], lvel, ldq, lmass, salt);
+						if (i >= LL0)
+						{
+							warmWide<SOFT_TGS, POINTS, true>(rA[i], lvel, ldq, lmass, salt, nullptr, localsOf(i));
+						}
+						else
+						{
+							warmWide<SOFT_TGS, POINTS>(rA[i], lvel, ldq, lmass, salt);
+						}
 					}
 					__syncthreads();
 				}
@@ -2044,7 +2223,8 @@ __global__ __launch_bounds__(S2_WIDE_THREADS) void wideIslandKernel(ContactView 
 				{
 					if (kOfRound(i) >= 0)
 					{
-						const WidePrep pre = prepWide<SOFT_TGS, POINTS>(rA[i], ldq, lcoef, op.inv_h, op.useBias, salt);
+						const WidePrep pre = (i >= LL0) ? prepWide<SOFT_TGS, POINTS, true>(rA[i], ldq, lcoef, op.inv_h, op.useBias, salt, nullptr, localsOf(i))
+													  : prepWide<SOFT_TGS, POINTS>(rA[i], ldq, lcoef, op.inv_h, op.useBias, salt);
 						chainWide<POINTS>(rA[i], pre, lvel, lmass, lcoef, salt);
 					}
 					__syncthreads();
@@ -2136,7 +2316,7 @@ void launchWideIsland(hipStream_t s, const ContactView& c, const BodyView& g, co
 					  int selfContained, const unsigned int* stepFailed, int allTwoPoints)
 {
 	const dim3 grid((unsigned)t.groupCount);
-	const size_t lds = (size_t)(t.ldsRecords + 2) * sizeof(float4) + (size_t)opCount * sizeof(Op);
+	const size_t lds = (size_t)(t.ldsRecords + 2 + wideIslandLocalRecords(maxRounds)) * sizeof(float4) + (size_t)opCount * sizeof(Op);
 	if (maxRounds <= S2_STRIP_ROUNDS)
 	{
 		launchWideIslandRounds<S2_STRIP_ROUNDS>(s, grid, lds, c, g, t, softCoef, ops, opCount, wire, wireBodies, hostFlags, warmStart, sc, unpackH, selfContained, stepFailed, allTwoPoints);
@@ -2159,18 +2339,18 @@ int wideKernelSetup()
 			return 1;
 		}
 	}
-#define S2_WIDE_MODES(P, RPH, SR) (const void*)wideStepKernel<P, RPH, SR, 0, 0, 0>, (const void*)wideStepKernel<P, RPH, SR, 0, 0, 1>, (const void*)wideStepKernel<P, RPH, SR, 0, 0, 2>, (const void*)wideStepKernel<P, RPH, SR, 0, 0, 3>
-	const void* steps[] = {S2_WIDE_MODES(0, 3, 2), S2_WIDE_MODES(2, 3, 2), S2_WIDE_MODES(0, 3, 3), S2_WIDE_MODES(2, 3, 3), S2_WIDE_MODES(0, 4, 2), S2_WIDE_MODES(2, 4, 2),
-						   (const void*)wideStepKernel<0, 3, 2, 2, 0, 0>, (const void*)wideStepKernel<2, 3, 2, 2, 0, 0>, (const void*)wideStepKernel<0, 3, 2, 2, 2, 0>,
-						   (const void*)wideStepKernel<2, 3, 2, 2, 2, 0>, (const void*)wideStepKernel<0, 3, 2, 2, 0, 1>, (const void*)wideStepKernel<2, 3, 2, 2, 0, 1>,
-						   (const void*)wideStepKernel<0, 3, 2, 2, 2, 1>, (const void*)wideStepKernel<2, 3, 2, 2, 2, 1>};
-#undef S2_WIDE_MODES
-	const void* pgs[] = {(const void*)wideStepKernel<0, 3, 2, 0, 0, 0, SOFT_PGS>, (const void*)wideStepKernel<2, 3, 2, 0, 0, 0, SOFT_PGS>, (const void*)wideStepKernel<0, 3, 3, 0, 0, 0, SOFT_PGS>,
-						 (const void*)wideStepKernel<2, 3, 3, 0, 0, 0, SOFT_PGS>, (const void*)wideStepKernel<0, 4, 2, 0, 0, 0, SOFT_PGS>, (const void*)wideStepKernel<2, 4, 2, 0, 0, 0, SOFT_PGS>,
-						 (const void*)wideStepKernel<0, 3, 2, 2, 0, 0, SOFT_PGS>, (const void*)wideStepKernel<2, 3, 2, 2, 0, 0, SOFT_PGS>, (const void*)wideStepKernel<0, 3, 2, 2, 2, 0, SOFT_PGS>,
-						 (const void*)wideStepKernel<2, 3, 2, 2, 2, 0, SOFT_PGS>};
-	const void* fixed[] = {(const void*)wideStepKernel<0, 3, 2, 0, 0, 0, SOFT_FIXED>, (const void*)wideStepKernel<2, 3, 2, 0, 0, 0, SOFT_FIXED>, (const void*)wideStepKernel<0, 3, 3, 0, 0, 0, SOFT_FIXED>,
-						   (const void*)wideStepKernel<2, 3, 3, 0, 0, 0, SOFT_FIXED>, (const void*)wideStepKernel<0, 4, 2, 0, 0, 0, SOFT_FIXED>, (const void*)wideStepKernel<2, 4, 2, 0, 0, 0, SOFT_FIXED>};
+	// every variant the launch can pick (launchWide): the five layouts in the plain and the sliced form for s2Solve_TGS_Soft and
+	// s2Solve_PGS_Soft, the <3, 2> layout alone for s2Solve_SoftStep and for the two optional modes
+#define S2_WIDE_LAYOUTS(P, MODE, KIND)                                                                                            \
+	(const void*)wideStepKernel<P, 3, 2, 0, 0, MODE, KIND>, (const void*)wideStepKernel<P, 3, 3, 0, 0, MODE, KIND>, (const void*)wideStepKernel<P, 4, 2, 0, 0, MODE, KIND>, \
+		(const void*)wideStepKernel<P, 3, 2, 2, 0, MODE, KIND>, (const void*)wideStepKernel<P, 3, 2, 2, 2, MODE, KIND>
+	const void* steps[] = {S2_WIDE_LAYOUTS(0, 0, SOFT_TGS), S2_WIDE_LAYOUTS(2, 0, SOFT_TGS), S2_WIDE_LAYOUTS(0, S2_WIDE_SLICED, SOFT_TGS), S2_WIDE_LAYOUTS(2, S2_WIDE_SLICED, SOFT_TGS),
+						   (const void*)wideStepKernel<0, 3, 2, 0, 0, 1>, (const void*)wideStepKernel<0, 3, 2, 0, 0, 2>,
+						   (const void*)wideStepKernel<2, 3, 2, 0, 0, 1>, (const void*)wideStepKernel<2, 3, 2, 0, 0, 2>, (const void*)wideStepKernel<2, 3, 2, 0, 0, 3>};
+	const void* pgs[] = {S2_WIDE_LAYOUTS(0, 0, SOFT_PGS), S2_WIDE_LAYOUTS(2, 0, SOFT_PGS), S2_WIDE_LAYOUTS(0, S2_WIDE_SLICED, SOFT_PGS), S2_WIDE_LAYOUTS(2, S2_WIDE_SLICED, SOFT_PGS)};
+#undef S2_WIDE_LAYOUTS
+	const void* fixed[] = {(const void*)wideStepKernel<0, 3, 2, 0, 0, 0, SOFT_FIXED>, (const void*)wideStepKernel<2, 3, 2, 0, 0, 0, SOFT_FIXED>,
+						   (const void*)wideStepKernel<0, 3, 2, 0, 0, S2_WIDE_SLICED, SOFT_FIXED>, (const void*)wideStepKernel<2, 3, 2, 0, 0, S2_WIDE_SLICED, SOFT_FIXED>};
 	for (const void* f : fixed)
 	{
 		if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)

@@ -919,8 +919,14 @@ static int uploadWorld(s2World* w, WorldBinding* b)
 		b->liveKey[i] = b->pairs[i].shapeA < 0 ? -1 : ((int64_t)b->pairs[i].shapeA << 32) | (int64_t)b->pairs[i].shapeB;
 		b->liveCount += b->liveKey[i] >= 0 ? 1 : 0;
 	}
-	// the world knows its solver (world->solverType, src/world.c:75): the structure is built with the upload, not in the first steps
-	(void)s_api.setOption(b->solver, "prebuild_solver", (int32_t)w->solverType);
+	// (option "prebuild_solver" would build the structure with the upload instead of in the first steps.  Not set here: the whole-step
+	// route must sweep in the order the solver-only route sweeps in -- their digests are compared bit for bit, tests/test_dropin_product.py --
+	// and that route, which sees the world one s2Solve_* at a time, builds its strips a step after the colour batches.  S2AMD_PREBUILD=1
+	// turns it on for a caller that runs one route only.)
+	if (getenv("S2AMD_PREBUILD") != NULL && atoi(getenv("S2AMD_PREBUILD")) != 0)
+	{
+		(void)s_api.setOption(b->solver, "prebuild_solver", (int32_t)w->solverType);
+	}
 	rc = s_api.worldUpload(b->solver, b->bodies, nb, b->contacts, nc, b->joints, nj, b->shapes, ns, b->pairs, b->origins);
 	if (rc != 0)
 	{

@@ -1426,7 +1426,8 @@ do                                                                              
 			}
 			if ((s->optPersistDebug & 16) != 0)
 			{
-				pv.parkSeamWidth = 512, pv.parkInteriorWidth = 256; // (tests: the parked variants on partitions that do not need them)
+				pv.parkSeamWidth = 192, pv.parkInteriorWidth = 128; // (tests: the parked variants on partitions that do not need them; r5: beside
+																		 // the local anchors in LDS -- wideLocalsInLds -- the full 512 / 256 columns no longer fit)
 			}
 			pv.parkSeamWidth = (pv.parkSeamWidth + 63) & ~63, pv.parkInteriorWidth = (pv.parkInteriorWidth + 63) & ~63;
 			s->persistK0 = k0, s->persistK1 = k1;

@@ -13,6 +13,7 @@ struct MsgView;
 struct StripTableView;
 struct StripOps;
 struct PersistView;
+struct JacobiView;
 struct s2amdBody;
 struct s2amdContact;
 struct s2amdJoint;
@@ -180,6 +181,12 @@ void launchWideIsland(hipStream_t s, const ContactView& c, const BodyView& g, co
 void launchWideStep(hipStream_t s, int kind, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount,
 					const WideSelf* self);
 
+// jacobi_kernel.hip: s2Solve_Jacobi as one persistent launch over blocks of bodies (tables: solver_jacobi.cpp)
+int jacobiKernelSetup();
+size_t jacobiStepLds(int owned, int imports, int constraints, int opCount);
+void launchJacobiStep(hipStream_t s, const ContactView& c, const JointView& jv, const BodyView& g, const JacobiView& t, const Op* ops, int opCount, const StepConsts& sc,
+					  size_t ldsBytes, int maxConstraints);
+
 // generic_kernel.hip: the persistent strip step as an op interpreter -- every solver family, joints included
 int genericKernelSetup();
 size_t genericStepLds(int bodies, int seamBodies, int exports, int opCount, int useDq0, int stagedJoints = 0);
@@ -225,3 +232,4 @@ void s2Warm_narrowphase(hipStream_t st);
 void s2Warm_structure(hipStream_t st);
 void s2Warm_world(hipStream_t st);
 void s2Warm_sharded(hipStream_t st);
+void s2Warm_jacobi_kernel(hipStream_t st);

@@ -533,6 +533,31 @@ struct PersistView
 	unsigned long long* debugTimes; // S2AMD_DEBUG_TIMES: wall_clock64() of one workgroup at kernel start, after the loads, after every op, at the end
 };
 
+// s2Solve_Jacobi as one persistent launch (jacobi_kernel.hip; tables: solver_jacobi.cpp).  One descriptor per block of bodies; every
+// list lives in ONE int array (`ints`).
+#define S2_JACOBI_HEAVY 32 // incidence entries beyond which a body is walked by a wave (the block's heavy list) instead of a lane
+struct JacobiBlockDesc
+{
+	int ownedBase, ownedCount;			 // pool slots of the bodies this block owns (integrates, applies, publishes)
+	int importBase, importCount;		 // pool slots of the bodies of other blocks its constraints read, then importCount flags (bit 0: somebody owns it)
+	int constraintBase, constraintCount; // per constraint {position in the sweep order | bit 30: this block stores its impulses, local slot A, local slot B}
+	int listBase, rangeBase;			 // incidence entries (local constraint << 1 | side) of the owned bodies in pool order; per owned body {first, count}
+	int exportBase, exportCount;		 // local slots of the owned bodies other blocks import
+	int heavyBase, heavyCount;			 // local slots of the owned bodies with more than S2_JACOBI_HEAVY entries
+	int jointBase, jointCount;			 // per joint {position in the joint SoA, local slot of body A or -1, local slot of body B or -1}, in sweep order
+};
+struct JacobiView
+{
+	const JacobiBlockDesc* descs;
+	const int* ints;
+	unsigned long long* granules; // [2 parities][bodyCapacity][4]: {epoch, value} of v.x, v.y, w (persist_handoff.h)
+	int parityStride;			  // granules between the parities
+	unsigned int* error;		  // host-visible: a hand-off timed out
+	unsigned int* deviceError;
+	unsigned int spinLimit;
+	int blockCount;
+};
+
 // Message-passing tables of the global part (see MsgBodies in constraint_ops.h)
 struct MsgView
 {

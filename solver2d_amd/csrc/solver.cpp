@@ -152,7 +152,7 @@ int s2amd_create(int device, s2amdSolver** out)
 		s->hostError = nullptr;
 		(void)hipGetLastError();
 	}
-	if (groupKernelSetup() != 0 || stripKernelSetup() != 0 || pairKernelSetup() != 0 || wideKernelSetup() != 0 || genericKernelSetup() != 0)
+	if (groupKernelSetup() != 0 || stripKernelSetup() != 0 || pairKernelSetup() != 0 || wideKernelSetup() != 0 || genericKernelSetup() != 0 || jacobiKernelSetup() != 0)
 	{
 		(void)hipGetLastError(); // not fatal: groups are then limited to the default 64 KiB of LDS
 		s->optMaxGroupBodies = 1536;
@@ -176,6 +176,7 @@ int s2amd_create(int device, s2amdSolver** out)
 			s2Warm_structure(s->stream);
 			s2Warm_world(s->stream);
 			s2Warm_sharded(s->stream);
+			s2Warm_jacobi_kernel(s->stream);
 			(void)hipStreamSynchronize(s->stream);
 			(void)hipGetLastError();
 		}
@@ -207,7 +208,7 @@ void s2amd_destroy(s2amdSolver* s)
 					  &s->soaContacts,	&s->soaJoints,	  &s->dContactIndex, &s->dJointIndex,	 &s->dContactLocal, &s->dJointLocal,
 					  &s->dAdjOffsets,	&s->dAdjList,	  &s->dAdjHeavy,	  &s->dGatherIndex,	 &s->dOps,			 &s->dGroups.buf,	&s->dContactTail.buf,
 					  &s->dJointTail.buf, &s->dMsg,			  &s->dStripA.buf,	 &s->dStripB.buf,	 &s->dStripLean,	&s->dPersist,
-					  &s->dGranules,	&s->dPersistOps,	  &s->dShapes,		 &s->dPairs,		 &s->dOrigins,		&s->dStatus,
+					  &s->dGranules,	&s->dPersistOps, &s->dJacobi, &s->dJacobiGran,	  &s->dShapes,		 &s->dPairs,		 &s->dOrigins,		&s->dStatus,
 					  &s->dPointBytes,	&s->dWorldSummary, &s->dJointedKeys,	 &s->dContactStage, &s->dPairScratch,	  &s->dPairKeys,		 &s->dPatches,		 &s->dScanTmp,		 &s->dResident.buf,	 &s->dResidentDesc, &s->dResidentOps, &s->dWatched, &s->dRefitOrder, &s->dStepBack,
 					  &s->dSlotBytes,	  &s->dJointAdjRange, &s->dJointAdjList, &s->dShapeBoxes};
 	for (DevBuf* b : bufs)
@@ -950,6 +951,16 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	else if (strcmp(key, "prebuild_solver") == 0)
 	{
 		s->optPrebuildSolver = value; // s2amd_world_upload builds the structure for this s2amdSolverType (-1: the first step does)
+	}
+	else if (strcmp(key, "jacobi_persist") == 0)
+	{
+		s->optJacobiPersist = value != 0;
+		s->structureDirty = true;
+	}
+	else if (strcmp(key, "jacobi_min_constraints") == 0)
+	{
+		s->optJacobiMinConstraints = std::max(0, value);
+		s->structureDirty = true;
 	}
 	else if (strcmp(key, "strip_overflow") == 0)
 	{

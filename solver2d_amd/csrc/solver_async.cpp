@@ -215,7 +215,7 @@ void forgetDeviceState(SolverStructure& t)
 {
 	DevBuf* bufs[] = {&t.dWatched, &t.dBodyFlags, &t.soaBodies, &t.soaContacts, &t.soaJoints, &t.dContactIndex, &t.dJointIndex, &t.dContactLocal, &t.dJointLocal,
 					  &t.dAdjOffsets, &t.dAdjList, &t.dAdjHeavy, &t.dPatches, &t.dJointAdjRange, &t.dJointAdjList, &t.dResidentDesc, &t.dResidentOps, &t.dStripLean,
-					  &t.dPersist, &t.dGranules, &t.dPersistOps, &t.dMsg, &t.dGroups.buf, &t.dContactTail.buf, &t.dJointTail.buf, &t.dStripA.buf, &t.dStripB.buf,
+					  &t.dPersist, &t.dGranules, &t.dPersistOps, &t.dJacobi, &t.dJacobiGran, &t.dMsg, &t.dGroups.buf, &t.dContactTail.buf, &t.dJointTail.buf, &t.dStripA.buf, &t.dStripB.buf,
 					  &t.dResident.buf};
 	for (DevBuf* b : bufs)
 	{
@@ -230,6 +230,8 @@ void forgetDeviceState(SolverStructure& t)
 	t.leanA = StripTableView{}, t.leanB = StripTableView{}, t.residentView = StripTableView{};
 	t.leanAValid = t.leanBValid = t.persistValid = t.genericValid = false;
 	t.persist = PersistView{};
+	t.jacobi = JacobiView{};
+	t.jacobiValid = false;
 	t.msg = MsgView{};
 	t.msgTablesValid = false;
 	t.adjValid = false, t.jointAdjValid = false;
@@ -251,7 +253,7 @@ void releaseDeviceState(s2amdSolver* c)
 	SolverStructure& t = *c;
 	DevBuf* bufs[] = {&t.dWatched, &t.dBodyFlags, &t.soaBodies, &t.soaContacts, &t.soaJoints, &t.dContactIndex, &t.dJointIndex, &t.dContactLocal, &t.dJointLocal,
 					  &t.dAdjOffsets, &t.dAdjList, &t.dAdjHeavy, &t.dPatches, &t.dJointAdjRange, &t.dJointAdjList, &t.dResidentDesc, &t.dResidentOps, &t.dStripLean,
-					  &t.dPersist, &t.dGranules, &t.dPersistOps, &t.dMsg, &t.dGroups.buf, &t.dContactTail.buf, &t.dJointTail.buf, &t.dStripA.buf, &t.dStripB.buf,
+					  &t.dPersist, &t.dGranules, &t.dPersistOps, &t.dJacobi, &t.dJacobiGran, &t.dMsg, &t.dGroups.buf, &t.dContactTail.buf, &t.dJointTail.buf, &t.dStripA.buf, &t.dStripB.buf,
 					  &t.dResident.buf};
 	for (DevBuf* b : bufs)
 	{
@@ -543,7 +545,7 @@ int asyncPrewarm(s2amdSolver* s, int solverType)
 	SolverStructure& t = *s;
 	const DevBuf* bufs[] = {&t.dWatched, &t.dBodyFlags, &t.soaBodies, &t.soaContacts, &t.soaJoints, &t.dContactIndex, &t.dJointIndex, &t.dContactLocal, &t.dJointLocal,
 							&t.dAdjOffsets, &t.dAdjList, &t.dAdjHeavy, &t.dPatches, &t.dJointAdjRange, &t.dJointAdjList, &t.dResidentDesc, &t.dResidentOps, &t.dStripLean,
-							&t.dPersist, &t.dGranules, &t.dPersistOps, &t.dMsg, &t.dGroups.buf, &t.dContactTail.buf, &t.dJointTail.buf, &t.dStripA.buf, &t.dStripB.buf,
+							&t.dPersist, &t.dGranules, &t.dPersistOps, &t.dJacobi, &t.dJacobiGran, &t.dMsg, &t.dGroups.buf, &t.dContactTail.buf, &t.dJointTail.buf, &t.dStripA.buf, &t.dStripB.buf,
 							&t.dResident.buf};
 	for (const DevBuf* b : bufs)
 	{

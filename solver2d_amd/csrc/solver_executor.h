@@ -869,6 +869,31 @@ struct Executor
 		}
 	}
 
+	// Can the whole plan run as ONE launch of jacobiStepKernel (jacobi_kernel.hip)?  s2Solve_Jacobi's plan on a structure whose block
+	// tables were built (solver_jacobi.cpp): nothing in LDS groups or strips (a Jacobi structure has neither), no message passing.
+	bool jacobiPlan() const
+	{
+		if (!s->jacobiValid || s->persistFailed || s->optJacobiPersist == 0 || msg || p.ops.size() > 128 || p.prepContacts != PREP_SOFT || p.storeKind != STORE_PLAIN ||
+			s->dGroups.view.groupCount > 0 || s->dResident.view.groupCount > 0 || s->dStripA.view.groupCount > 0)
+		{
+			return false;
+		}
+		bool sweeps = false;
+		for (const Op& o : p.ops)
+		{
+			const bool body = o.code == OP_INTEGRATE_VEL || o.code == OP_INTEGRATE_POS || o.code == OP_FINALIZE || o.code == OP_JACOBI_APPLY;
+			const bool warm = o.code == OP_WARM && o.kind == WARM_CURRENT;
+			const bool joint = o.code == OP_JOINT_SWEEP && (o.kind == JSOLVE_WARM || o.kind == JSOLVE_SOFT);
+			const bool pass = o.code == OP_SOLVE_SOFT && o.kind == SOFT_JACOBI;
+			sweeps = sweeps || pass;
+			if (!(body || warm || joint || pass))
+			{
+				return false;
+			}
+		}
+		return sweeps && jacobiStepLds(s->jacobiMaxOwned, s->jacobiMaxImports, s->jacobiMaxConstraints, (int)p.ops.size()) <= 160 * 1024;
+	}
+
 	void run()
 	{
 		if (p.earlyOut)
@@ -919,6 +944,18 @@ struct Executor
 		{
 			launchFillMessageSlots(st, s->cv, s->bv, s->msg, s->contacts.globalCount);
 			count();
+		}
+		if (jacobiPlan())
+		{
+			// s2Solve_Jacobi: prologue, ONE persistent launch over the blocks, epilogue (which clears the exchange buffers and stands down
+			// when a hand-off timed out)
+			launchJacobiStep(st, s->cv, s->jv, s->bv, s->jacobi, deviceOps(), (int)p.ops.size(), p.sc,
+							 jacobiStepLds(s->jacobiMaxOwned, s->jacobiMaxImports, s->jacobiMaxConstraints, (int)p.ops.size()), s->jacobiMaxConstraints);
+			count();
+			launchStoreImpulses(st, p.storeKind, cvIo, wireContacts(), p.storeScale, s->bv, wireBodies(), s->dJacobiGran.p, s->jacobiGranBytes, s->jacobi.deviceError, -1, &s->jv,
+								wireJoints());
+			count();
+			return;
 		}
 		// LDS groups: the whole op list in one launch
 		if (s->dGroups.view.groupCount > 0)

@@ -840,6 +840,7 @@ bool incrementalApply(s2amdSolver* s, const std::vector<ContactChange>& changes)
 			{
 				chosen = bi;
 				inc.colourFreePlaced = true;
+				s->jacobiValid = false; // (the persistent launch's block tables know nothing of this constraint: the multi-launch path until the next build)
 				break;
 			}
 			if (cid >= 64 * W)

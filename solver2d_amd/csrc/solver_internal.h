@@ -386,6 +386,12 @@ struct SolverStructure
 	int persistRecordsWide = 0; // LDS records when a seam constraint takes 10 records (every kind but TGS_Soft's)
 	DevBuf dPersistOps;
 	int persistOpCount = 0;
+	// s2Solve_Jacobi as one persistent launch over blocks of bodies (jacobi_kernel.hip; tables: solver_jacobi.cpp)
+	DevBuf dJacobi, dJacobiGran;
+	JacobiView jacobi{};
+	bool jacobiValid = false;
+	size_t jacobiGranBytes = 0;
+	int jacobiMaxOwned = 0, jacobiMaxImports = 0, jacobiMaxConstraints = 0;
 	uint64_t persistOpsGeneration = ~0ull, persistOpsStructure = ~0ull;
 	size_t granuleBytes = 0;
 	long selfStepsSinceReset = 0; // self-contained strip steps since the commit counter was last zeroed (doStep: every 2^20)
@@ -527,6 +533,8 @@ struct SolverRest
 	// thing to go when a hand-off times out -- the step is tried again with agent-scope stores before the one-launch kernels are given up
 	int optNearHandoff = 1, nearHandoffNow = 1, nearHandoffTimeouts = 0;
 	int optStripAdopt = 1;	  // a body without constraints moves to the strip of the body it first touches instead of forcing a rebuild
+	int optJacobiPersist = 1;		  // "jacobi_persist": s2Solve_Jacobi of a world that qualifies (solver_jacobi.cpp) in ONE launch (jacobi_kernel.hip)
+	int optJacobiMinConstraints = 1024; // "jacobi_min_constraints": ... from this many constraints on
 	int optOverflow = 1;	  // "strip_overflow": a contact that fits nowhere in the strips takes an overflow position (sliced steps + a worker-thread build) instead of a rebuild in this step
 	long slicedSteps = 0;	  // steps that ran sliced, since s2amd_create
 	bool slicedThisStep = false;
@@ -655,6 +663,7 @@ int carveBodies(s2amdSolver* s, int n); // (re)carves the body SoA family for n 
 bool stripsAllTwoPoints(const s2amdSolver* s);
 bool residentAllTwoPoints(const s2amdSolver* s);
 int buildStructure(s2amdSolver* s, int solverType);
+int buildJacobiBlocks(s2amdSolver* s); // solver_jacobi.cpp
 void buildPlan(s2amdSolver* s, const s2amdStepParams* params);
 bool messageEligible(const s2amdSolver* s, int solverType);
 void destroyGraph(s2amdSolver* s);

@@ -30,6 +30,14 @@ int resetPersistState(s2amdSolver* s, hipStream_t st)
 	{
 		HIP_TRY(hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, st));
 	}
+	if (s->jacobi.deviceError)
+	{
+		HIP_TRY(hipMemsetAsync(s->jacobi.deviceError, 0, 256, st));
+	}
+	if (s->dJacobiGran.p && s->jacobiGranBytes)
+	{
+		HIP_TRY(hipMemsetAsync(s->dJacobiGran.p, 0, s->jacobiGranBytes, st));
+	}
 	s->selfStepsSinceReset = 0;
 	return S2AMD_OK;
 }
@@ -676,7 +684,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	s->stats.seamCount = s->dStripB.view.groupCount;
 	{
 		int kind, warm;
-		s->stats.persistent = (s->dStripA.view.groupCount > 0 && (q.persistPlan(kind, warm) || q.genericPlan())) ? 1 : 0;
+		s->stats.persistent = ((s->dStripA.view.groupCount > 0 && (q.persistPlan(kind, warm) || q.genericPlan())) || q.jacobiPlan()) ? 1 : 0;
 	}
 	s->stats.persistFallbacks = s->persistFallbacks;
 	s->stats.asyncBuildsRequested = s->asyncRequested, s->stats.asyncBuildsAdopted = s->asyncAdopted, s->stats.asyncWaitMs = s->asyncWaitMs;

@@ -2759,6 +2759,12 @@ struct StructureBuild
 		// copies through a staging buffer before it returns, so that is safe
 		HIP_TRY(hipStreamSynchronize(s->stream));
 		phase("adjacency + sync");
+		s->orderColourless = needAdj;
+		if ((rc = buildJacobiBlocks(s)) != 0) // (s2Solve_Jacobi: the persistent launch's tables, where the world qualifies)
+		{
+			return rc;
+		}
+		phase("jacobi blocks");
 
 		// created contacts can be placed into this structure while its global part has the slack layout
 		s->slackPositions = 0;

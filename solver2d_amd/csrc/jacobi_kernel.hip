@@ -18,8 +18,8 @@
 //     order: the reference's order), a body with a long list (the drum) is walked by one wave, 64 entries loaded at once, the
 //     additions sequential on values broadcast lane by lane -- body_kernels.hip: jacobiApplyKernel's walk;
 //   * s2WarmStartContacts (solve_common.c:276-326) the same way: per-point terms into LDS, added per body in list order;
-//   * joints (sequential in the reference, solve_jacobi.c:211-221) by the lane 0 of the block that owns their bodies, through
-//     the global arrays (constraint_ops.h: solveJointsOne on GlobalBodies): the host admits a world whose every joint lies inside
+//   * joints (sequential in the reference, solve_jacobi.c:211-221) by the lane 0 of the block that owns their bodies, on the
+//     velocities in LDS (constraint_ops.h: solveJointsOne through JacobiJointBodies): the host admits a world whose every joint lies inside
 //     one block (the Tumbler's motor joint: the drum and the static ground).
 // Integer tables from the host (JacobiView); results equal the multi-launch path's and the oracle's bit for bit (same operations on
 // the same operands in the same order).  Like the strip kernels: all workgroups must be co-resident, every poll loop is bounded,
@@ -34,7 +34,66 @@
 namespace
 {
 
+#define S2_JACOBI_STAGE 128 // terms one wave stages per batch of a long list: 64 incidence entries, two points each
+
 S2_DEV float laneOf(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+
+// The sequential part of a long list's sum: acc += comp[0], += comp[1], ... += comp[n - 1], in that order (the reference's order: fp
+// addition does not reassociate).  Lane c of the wave carries component c (x, y, w), so a term costs ONE dependent add and a quarter of
+// a 16-byte LDS read; `n` is wave-uniform, `comp` 16-byte aligned.
+S2_DEV float addInOrder(float acc, const float* comp, int n)
+{
+	int k = 0;
+	for (; k + 8 <= n; k += 8)
+	{
+		const float4 a = *(const float4*)(comp + k), b = *(const float4*)(comp + k + 4);
+		acc = acc + a.x, acc = acc + a.y, acc = acc + a.z, acc = acc + a.w;
+		acc = acc + b.x, acc = acc + b.y, acc = acc + b.z, acc = acc + b.w;
+	}
+	for (; k < n; ++k)
+	{
+		acc = acc + comp[k];
+	}
+	return acc;
+}
+
+S2_DEV void waveLdsOrder()
+{
+	// LDS operations of one wave execute in order: this only keeps the compiler from moving them across
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The body accessor of a joint solved inside a block (constraint_ops.h: solveJointsOne): indices are pool slots (the joint SoA's); the
+// velocities of the joint's two bodies live in the block's LDS where the block owns them, everything else -- the poses, a static body's
+// velocity -- in the global arrays (poses only change in s2IntegratePositions, which this kernel performs on the global arrays)
+struct JacobiJointBodies
+{
+	static constexpr int kMode = S2_IDX_GLOBAL;
+	float4* lvel;
+	float4* gvel;
+	float4* gdq;
+	int ga, la, gb, lb; // pool slot and local slot of the joint's owned bodies (-1: none)
+	S2_DEV float4 getVel(int i) const { return i == ga ? lvel[la] : (i == gb ? lvel[lb] : gvel[i]); }
+	S2_DEV void setVel(int i, float4 v) const
+	{
+		if (i == ga)
+		{
+			lvel[la] = v;
+		}
+		else if (i == gb)
+		{
+			lvel[lb] = v;
+		}
+		else
+		{
+			gvel[i] = v;
+		}
+	}
+	S2_DEV float4 getDq(int i) const { return gdq[i]; }
+	S2_DEV void setDq(int i, float4 v) const { gdq[i] = v; }
+};
 
 template <int RECORDS> __global__ __launch_bounds__(S2_JACOBI_THREADS) void jacobiStepKernel(ContactView c, JointView jv, BodyView g, JacobiView t, const Op* ops,
 																							  int opCount, StepConsts sc)
@@ -48,6 +107,8 @@ template <int RECORDS> __global__ __launch_bounds__(S2_JACOBI_THREADS) void jaco
 	int* llist = (int*)(lterm + 4 * nC);		   // [2 * nC] incidence entries (local constraint << 1 | side), per body in pool order
 	int2* lrange = (int2*)(llist + 2 * nC + (nC & 1 ? 2 : 0)); // [nOwn] {first entry, entries}
 	Op* lops = (Op*)(lrange + nOwn + (nOwn & 1));
+	float* stage = (float*)(lops + opCount) + wave * 3 * S2_JACOBI_STAGE; // this wave's staging rows {x, y, w} of a long list's terms
+	const int cLane = lane < 3 ? lane : 0;
 
 	// ---- loads: tables, bodies, constraint records ----
 	for (int i = tid; i < 2 * nC; i += S2_JACOBI_THREADS)
@@ -159,72 +220,60 @@ template <int RECORDS> __global__ __launch_bounds__(S2_JACOBI_THREADS) void jaco
 					lvel[i] = v;
 				}
 			}
-			for (int hb = wave; hb < d.heavyCount; hb += S2_JACOBI_THREADS / 64)
+			for (int hb = wave; hb < ((t.debugSkip & 1) ? 0 : d.heavyCount); hb += S2_JACOBI_THREADS / 64)
 			{
 				const int i = t.ints[d.heavyBase + hb];
 				const int2 range = lrange[i];
-				float4 v = lvel[i];
+				const float4 v = lvel[i];
+				// 64 entries gathered at once, their valid points compacted into the wave's staging rows in list order (point 0 before
+				// point 1), then added in that order
+				float acc = cLane == 0 ? v.x : (cLane == 1 ? v.y : v.z);
 				for (int base = 0; base < range.y; base += 64)
 				{
-					const int x = base + lane < range.y ? base + lane : 0;
-					const int key = llist[range.x + x];
+					const bool in = base + lane < range.y;
+					const int key = llist[range.x + (in ? base + lane : 0)];
 					const float4 q0 = lterm[4 * (key >> 1) + 2 * (key & 1)], q1 = lterm[4 * (key >> 1) + 2 * (key & 1) + 1];
-					const int left = __builtin_amdgcn_readfirstlane(range.y - base);
-					const int n = left < 64 ? left : 64;
-					for (int u = 0; u < n; ++u)
+					const bool v0 = in && q0.w != 0.0f, v1 = in && q1.w != 0.0f;
+					const unsigned long long b0 = __ballot(v0), b1 = __ballot(v1), lower = (1ull << lane) - 1ull;
+					const int p0 = __popcll(b0 & lower) + __popcll(b1 & lower), p1 = p0 + (v0 ? 1 : 0);
+					if (v0)
 					{
-						if (laneOf(q0.w, u) != 0.0f)
-						{
-							v.z = v.z + laneOf(q0.z, u);
-							v.x = v.x + laneOf(q0.x, u), v.y = v.y + laneOf(q0.y, u);
-						}
-						if (laneOf(q1.w, u) != 0.0f)
-						{
-							v.z = v.z + laneOf(q1.z, u);
-							v.x = v.x + laneOf(q1.x, u), v.y = v.y + laneOf(q1.y, u);
-						}
+						stage[p0] = q0.x, stage[S2_JACOBI_STAGE + p0] = q0.y, stage[2 * S2_JACOBI_STAGE + p0] = q0.z;
 					}
+					if (v1)
+					{
+						stage[p1] = q1.x, stage[S2_JACOBI_STAGE + p1] = q1.y, stage[2 * S2_JACOBI_STAGE + p1] = q1.z;
+					}
+					const int n = __builtin_amdgcn_readfirstlane(__popcll(b0) + __popcll(b1));
+					waveLdsOrder();
+					acc = addInOrder(acc, stage + cLane * S2_JACOBI_STAGE, n);
+					waveLdsOrder();
 				}
+				const float ax = laneOf(acc, 0), ay = laneOf(acc, 1), az = laneOf(acc, 2);
 				if (lane == 0)
 				{
-					lvel[i] = v;
+					lvel[i] = make_float4(ax, ay, az, v.w);
 				}
 			}
 			__syncthreads();
 		}
 		else if (op.code == OP_JOINT_SWEEP)
 		{
-			// the block's joints, one after the other in sweep order, by one lane through the global arrays
-			if (d.jointCount > 0 && tid == 0)
+			// the block's joints, one after the other in sweep order, by one lane: velocities in LDS, poses in the global arrays
+			if (d.jointCount > 0 && tid == 0 && (t.debugSkip & 2) == 0)
 			{
-				const GlobalBodies gb{g.vel, g.dq};
 				for (int x = 0; x < d.jointCount; ++x)
 				{
 					const int k = t.ints[d.jointBase + 3 * x];
 					const int la = t.ints[d.jointBase + 3 * x + 1], lbx = t.ints[d.jointBase + 3 * x + 2]; // local slots of its owned bodies, -1: none
-					if (la >= 0)
-					{
-						g.vel[ownedGlobal(la)] = lvel[la];
-					}
-					if (lbx >= 0)
-					{
-						g.vel[ownedGlobal(lbx)] = lvel[lbx];
-					}
+					const JacobiJointBodies jb{lvel, g.vel, g.dq, la >= 0 ? ownedGlobal(la) : -1, la, lbx >= 0 ? ownedGlobal(lbx) : -1, lbx};
 					if (op.kind == JSOLVE_WARM)
 					{
-						solveJointsOne<JSOLVE_WARM>(jv, gb, sc, op.h, op.inv_h, op.useBias, k);
+						solveJointsOne<JSOLVE_WARM>(jv, jb, sc, op.h, op.inv_h, op.useBias, k);
 					}
 					else
 					{
-						solveJointsOne<JSOLVE_SOFT>(jv, gb, sc, op.h, op.inv_h, op.useBias, k);
-					}
-					if (la >= 0)
-					{
-						lvel[la] = g.vel[ownedGlobal(la)];
-					}
-					if (lbx >= 0)
-					{
-						lvel[lbx] = g.vel[ownedGlobal(lbx)];
+						solveJointsOne<JSOLVE_SOFT>(jv, jb, sc, op.h, op.inv_h, op.useBias, k);
 					}
 				}
 			}
@@ -235,7 +284,7 @@ template <int RECORDS> __global__ __launch_bounds__(S2_JACOBI_THREADS) void jaco
 			// ---- the iteration's exchange: the velocities other blocks read ----
 			epoch += 1;
 			const int par = (int)(epoch & 1u) * t.parityStride;
-			for (int x = tid; x < d.exportCount; x += S2_JACOBI_THREADS)
+			for (int x = tid; x < ((t.debugSkip & 4) ? 0 : d.exportCount); x += S2_JACOBI_THREADS)
 			{
 				const int i = t.ints[d.exportBase + x];
 				const float4 v = lvel[i];
@@ -243,7 +292,7 @@ template <int RECORDS> __global__ __launch_bounds__(S2_JACOBI_THREADS) void jaco
 				putGranule(p + 0, epoch, v.x), putGranule(p + 1, epoch, v.y), putGranule(p + 2, epoch, v.z);
 			}
 			int fail = 0;
-			for (int x = tid; x < nImp; x += S2_JACOBI_THREADS)
+			for (int x = tid; x < ((t.debugSkip & 4) ? 0 : nImp); x += S2_JACOBI_THREADS)
 			{
 				const int gi = t.ints[d.importBase + x];
 				if (gi >= 0 && (t.ints[d.importBase + nImp + x] & 1) != 0) // (a body somebody owns: the others never change)
@@ -269,7 +318,7 @@ template <int RECORDS> __global__ __launch_bounds__(S2_JACOBI_THREADS) void jaco
 			for (int r = 0; r < RECORDS; ++r)
 			{
 				const int e = tid + r * S2_JACOBI_THREADS;
-				if (e < nC)
+				if (e < nC && (t.debugSkip & 8) == 0)
 				{
 					solveSoftRegs<SOFT_JACOBI, LdsBodies, false>(reg[r], cl, lb, op.inv_h, op.useBias, e);
 				}
@@ -298,29 +347,30 @@ template <int RECORDS> __global__ __launch_bounds__(S2_JACOBI_THREADS) void jaco
 					lvel[i] = make_float4(lv.x, lv.y, v.z + dw, 0.0f);
 				}
 			}
-			for (int hb = wave; hb < d.heavyCount; hb += S2_JACOBI_THREADS / 64)
+			for (int hb = wave; hb < ((t.debugSkip & 1) ? 0 : d.heavyCount); hb += S2_JACOBI_THREADS / 64)
 			{
 				const int i = t.ints[d.heavyBase + hb];
 				const int2 range = lrange[i];
-				V2 dv = v2(0.0f, 0.0f);
-				float dw = 0.0f;
+				float acc = 0.0f;
 				for (int base = 0; base < range.y; base += 64)
 				{
-					const int x = base + lane < range.y ? base + lane : 0;
-					const int key = llist[range.x + x];
+					const bool in = base + lane < range.y;
+					const int key = llist[range.x + (in ? base + lane : 0)];
 					const float4 q = lterm[(key & 1) * nC + (key >> 1)];
-					const int left = __builtin_amdgcn_readfirstlane(range.y - base);
-					const int n = left < 64 ? left : 64;
-					for (int u = 0; u < n; ++u)
+					if (in)
 					{
-						dv = add(dv, v2(laneOf(q.x, u), laneOf(q.y, u)));
-						dw += laneOf(q.z, u);
+						stage[lane] = q.x, stage[S2_JACOBI_STAGE + lane] = q.y, stage[2 * S2_JACOBI_STAGE + lane] = q.z;
 					}
+					const int left = __builtin_amdgcn_readfirstlane(range.y - base);
+					waveLdsOrder();
+					acc = addInOrder(acc, stage + cLane * S2_JACOBI_STAGE, left < 64 ? left : 64);
+					waveLdsOrder();
 				}
+				const float dx = laneOf(acc, 0), dy = laneOf(acc, 1), dw = laneOf(acc, 2);
 				if (lane == 0)
 				{
 					const float4 v = lvel[i];
-					const V2 lv = add(v2(v.x, v.y), dv);
+					const V2 lv = add(v2(v.x, v.y), v2(dx, dy));
 					lvel[i] = make_float4(lv.x, lv.y, v.z + dw, 0.0f);
 				}
 			}
@@ -386,6 +436,7 @@ size_t jacobiStepLds(int owned, int imports, int constraints, int opCount)
 {
 	size_t bytes = (size_t)(owned + imports) * sizeof(float4) + (size_t)4 * constraints * sizeof(float4);
 	bytes += (size_t)(2 * constraints + 2) * sizeof(int) + (size_t)(owned + 1) * sizeof(int2) + (size_t)opCount * sizeof(Op) + 64;
+	bytes += (size_t)(S2_JACOBI_THREADS / 64) * 3 * S2_JACOBI_STAGE * sizeof(float);
 	return bytes;
 }
 

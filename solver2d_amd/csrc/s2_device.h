@@ -556,6 +556,7 @@ struct JacobiView
 	unsigned int* deviceError;
 	unsigned int spinLimit;
 	int blockCount;
+	int debugSkip; // timing experiments only (results are wrong): 1 = no wave walks of long lists, 2 = no joints, 4 = no exchange, 8 = no contact pass (option persist_debug)
 };
 
 // Message-passing tables of the global part (see MsgBodies in constraint_ops.h)

@@ -949,7 +949,9 @@ struct Executor
 		{
 			// s2Solve_Jacobi: prologue, ONE persistent launch over the blocks, epilogue (which clears the exchange buffers and stands down
 			// when a hand-off timed out)
-			launchJacobiStep(st, s->cv, s->jv, s->bv, s->jacobi, deviceOps(), (int)p.ops.size(), p.sc,
+			JacobiView jview = s->jacobi;
+			jview.debugSkip = s->optPersistDebug;
+			launchJacobiStep(st, s->cv, s->jv, s->bv, jview, deviceOps(), (int)p.ops.size(), p.sc,
 							 jacobiStepLds(s->jacobiMaxOwned, s->jacobiMaxImports, s->jacobiMaxConstraints, (int)p.ops.size()), s->jacobiMaxConstraints);
 			count();
 			launchStoreImpulses(st, p.storeKind, cvIo, wireContacts(), p.storeScale, s->bv, wireBodies(), s->dJacobiGran.p, s->jacobiGranBytes, s->jacobi.deviceError, -1, &s->jv,

@@ -16,8 +16,9 @@
 
 #include <queue>
 
-#define S2_JACOBI_BLOCK_BODIES 192
+#define S2_JACOBI_BLOCK_BODIES 192		// at most; the build aims at one block per compute unit (below)
 #define S2_JACOBI_BLOCK_CONSTRAINTS 960 // (the kernel holds two per lane: 1024)
+#define S2_JACOBI_LANE_CONSTRAINTS 480	// ... and a block that stays below 512 runs the one-record kernel: the aim
 #define S2_JACOBI_BLOCK_IMPORTS 1024
 #define S2_JACOBI_HUB_DEGREE 64 // BFS does not expand through a body with more constraints
 
@@ -112,12 +113,17 @@ int buildJacobiBlocks(s2amdSolver* s)
 		}
 	}
 
-	// ---- chunks ----
+	// ---- chunks: as many blocks as the device has compute units to spare (an iteration's time is its slowest block's: one constraint
+	// per lane where the world is small enough), a hub alone in its block (every block that touches it waits for its sums) ----
 	std::vector<int> blockOf((size_t)nb, -1), slotOf((size_t)nb, -1);
 	std::vector<std::vector<int>> owned;
 	{
+		const int target = std::max(s->cuCount - 8, 8);
+		const int bodiesPerBlock = std::min(std::max(((int)order.size() + target - 1) / target, 24), S2_JACOBI_BLOCK_BODIES);
+		const int constraintsPerBlock = bodiesPerBlock < S2_JACOBI_BLOCK_BODIES ? S2_JACOBI_LANE_CONSTRAINTS : S2_JACOBI_BLOCK_CONSTRAINTS;
 		std::vector<int> stamp((size_t)P, -1);
 		int constraints = 0;
+		bool hubBlock = false;
 		owned.emplace_back();
 		for (int u : order)
 		{
@@ -126,7 +132,8 @@ int buildJacobiBlocks(s2amdSolver* s)
 			{
 				fresh += stamp[(size_t)incident[(size_t)e]] != (int)owned.size() - 1 ? 1 : 0;
 			}
-			if (!owned.back().empty() && ((int)owned.back().size() >= S2_JACOBI_BLOCK_BODIES || constraints + fresh > S2_JACOBI_BLOCK_CONSTRAINTS))
+			const bool hub = degree[(size_t)u] > S2_JACOBI_HUB_DEGREE;
+			if (!owned.back().empty() && (hub || hubBlock || (int)owned.back().size() >= bodiesPerBlock || constraints + fresh > constraintsPerBlock))
 			{
 				owned.emplace_back();
 				constraints = 0;
@@ -137,6 +144,7 @@ int buildJacobiBlocks(s2amdSolver* s)
 				stamp[(size_t)incident[(size_t)e]] = (int)owned.size() - 1;
 			}
 			constraints += fresh;
+			hubBlock = hub;
 			blockOf[(size_t)u] = (int)owned.size() - 1;
 			slotOf[(size_t)u] = (int)owned.back().size();
 			owned.back().push_back(u);

@@ -2,7 +2,7 @@
 # The round's GPU calls, one stage per call: tools/gpu_r05.sh <stage> (run by gpurun from the repo root; everything lands under
 # gpurun_out/r5/<stage>/).  Stages: fast (tolerance-mode build: error measurement, its tests, bench line), suite (the whole -m gpu
 # suite), churn (wreck-200 and Tumbler loops with the structure builds' phase times), bench (the driver's command), profile
-# (tools/profile_r05.sh).
+# (tools/profile_r05.sh [part]), tables (solver table, configs 3 / 3b / 4).
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 stage=${1:-suite}
@@ -31,6 +31,17 @@ scan)
   ;;
 bench)
   timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; python tools/bench_summary.py $O/bench.json
+  ;;
+profile)
+  bash tools/profile_r05.sh ${2:-all}
+  ;;
+tables)
+  # the per-solver / per-config numbers committed as profiles/r05_*: all ten solvers at base 200, configs 3 / 3b / 4
+  timeout 600 python tools/solver_table.py --steps 100 > $O/r05_solver_table.jsonl 2> $O/solver_table.err; echo "solver table rc=$?"
+  timeout 300 python tools/solver_table.py --world joint_grid --base 100 --solvers PGS_NGS,TGS_Soft,PGS_NGS_Block --steps 100 >> $O/r05_solver_table.jsonl 2>> $O/solver_table.err
+  timeout 300 python tools/config3_bench.py Jacobi 2> $O/config3.err | tail -1 > $O/r05_config3_tumbler_jacobi.json
+  timeout 300 python tools/config3_bench.py TGS_Soft 2>> $O/config3.err | tail -1 > $O/r05_config3b_tumbler_tgs_soft.json
+  cat $O/r05_solver_table.jsonl $O/r05_config3_tumbler_jacobi.json $O/r05_config3b_tumbler_tgs_soft.json | cut -c1-200
   ;;
 *)
   echo "unknown stage $stage"; exit 2;;

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--solvers", default=",".join(wire.SOLVER_NAMES))
     ap.add_argument("--world", default="pyramid", choices=("pyramid", "joint_grid"))
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE")
+    ap.add_argument("--fast", action="store_true", help="the tolerance-mode build (libs2amd_fast.so) instead of the bit-exact one")
     a = ap.parse_args()
     if a.world == "pyramid":
         bodies, contacts, joints = synthetic.pyramid(a.base)
@@ -29,7 +30,7 @@ def main():
     for name in a.solvers.split(","):
         vel, pos = (8, 4) if name in ("TGS_Soft", "SoftStep") else (4, 2)
         params = wire.StepParams.make(name, 1.0 / 60.0, vel, pos, True)
-        with hip.Solver(0) as gpu:
+        with hip.Solver(0, fast=a.fast) as gpu:
             for kv in a.opt:
                 k, v = kv.split("=")
                 gpu.set_option(k, int(v))

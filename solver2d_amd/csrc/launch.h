@@ -211,7 +211,7 @@ struct PairQueryGraph
 };
 int findPairsResident(hipStream_t st, const s2amdShape* shapes, int shapeCapacity, int liveShapes, const s2amdPairState* pairs, int contactCapacity,
 					  const unsigned long long* jointed, int jointedCount, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount, void** scratch,
-					  size_t* scratchBytes, unsigned long long* sortedPairKeys, bool* sortedPairKeysValid, PairQueryGraph* cache);
+					  size_t* scratchBytes, unsigned long long* sortedPairKeys, bool* sortedPairKeysValid, PairQueryGraph* cache, bool warmOnly = false);
 
 // One empty kernel per translation unit with kernels: the HIP runtime loads a TU's code object when its first kernel is launched -- 2 to 14 ms
 // each at the sizes of this library, which the first steps of a new process, the first structure request, the first flip used to pay
@@ -233,3 +233,4 @@ void s2Warm_structure(hipStream_t st);
 void s2Warm_world(hipStream_t st);
 void s2Warm_sharded(hipStream_t st);
 void s2Warm_jacobi_kernel(hipStream_t st);
+void s2WarmScratch(hipStream_t st); // wide_kernel.hip: the queue's scratch memory allocated before a step needs it

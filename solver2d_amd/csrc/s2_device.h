@@ -530,8 +530,21 @@ struct PersistView
 	int bodyWarm;		// wide_kernel.hip: s2WarmStartContacts as one body-centric pass (set at launch when the term table fits LDS)
 	int clearOwn;		// wide_kernel.hip, sliced step (one launch per sweep): the kernel zeroes the hand-off buffers it reads and its census entry at its
 						// end, as the step's epilogue launch does after the last slice -- every launch starts from zero tags without a memset in between
+	// wide_kernel.hip, S2_WIDE_OVERFLOW: the contacts in the overflow positions behind the strips swept INSIDE the persistent launch by one
+	// more workgroup (the last of the grid).  overflowBodies: the bodies those contacts touch (pool slot; bit 30: nothing writes it -- a
+	// static or kinematic body, no exchange; -1: free entry), index = the contacts' c.localBodies entries.  After every sweep the strip
+	// that owns such a body hands {v, w} to that workgroup and every strip that stages it (the owner, the neighbour that imports it)
+	// takes the result back: granules at overflowGranBase, [in | out][S2_OVERFLOW_RING][S2_OVERFLOW_BODIES][4], tag = the sweep's number.
+	const int* overflowBodies;
+	int overflowBodyCount;
+	int overflowBegin, overflowEnd; // sweep positions of the overflow region
+	int overflowGranBase;
+	int overflowKernel; // (set at launch) this launch carries that workgroup: grid = strips + 1
 	unsigned long long* debugTimes; // S2AMD_DEBUG_TIMES: wall_clock64() of one workgroup at kernel start, after the loads, after every op, at the end
 };
+#define S2_OVERFLOW_BODIES 64
+#define S2_OVERFLOW_RING 4
+#define S2_OVERFLOW_GRANULES (2 * S2_OVERFLOW_RING * S2_OVERFLOW_BODIES * 4)
 
 // s2Solve_Jacobi as one persistent launch (jacobi_kernel.hip; tables: solver_jacobi.cpp).  One descriptor per block of bodies; every
 // list lives in ONE int array (`ints`).

@@ -170,6 +170,7 @@ int s2amd_create(int device, s2amdSolver** out)
 			s2Warm_strip_kernel(s->stream);
 			s2Warm_pair_kernel(s->stream);
 			s2Warm_wide_kernel(s->stream);
+			s2WarmScratch(s->stream);
 			s2Warm_generic_kernel(s->stream);
 			s2Warm_broadphase(s->stream);
 			s2Warm_narrowphase(s->stream);
@@ -208,7 +209,7 @@ void s2amd_destroy(s2amdSolver* s)
 					  &s->soaContacts,	&s->soaJoints,	  &s->dContactIndex, &s->dJointIndex,	 &s->dContactLocal, &s->dJointLocal,
 					  &s->dAdjOffsets,	&s->dAdjList,	  &s->dAdjHeavy,	  &s->dGatherIndex,	 &s->dOps,			 &s->dGroups.buf,	&s->dContactTail.buf,
 					  &s->dJointTail.buf, &s->dMsg,			  &s->dStripA.buf,	 &s->dStripB.buf,	 &s->dStripLean,	&s->dPersist,
-					  &s->dGranules,	&s->dPersistOps, &s->dJacobi, &s->dJacobiGran,	  &s->dShapes,		 &s->dPairs,		 &s->dOrigins,		&s->dStatus,
+					  &s->dGranules,	&s->dOverflowBodies, &s->dPersistOps, &s->dJacobi, &s->dJacobiGran,	  &s->dShapes,		 &s->dPairs,		 &s->dOrigins,		&s->dStatus,
 					  &s->dPointBytes,	&s->dWorldSummary, &s->dJointedKeys,	 &s->dContactStage, &s->dPairScratch,	  &s->dPairKeys,		 &s->dPatches,		 &s->dScanTmp,		 &s->dResident.buf,	 &s->dResidentDesc, &s->dResidentOps, &s->dWatched, &s->dRefitOrder, &s->dStepBack,
 					  &s->dSlotBytes,	  &s->dJointAdjRange, &s->dJointAdjList, &s->dShapeBoxes};
 	for (DevBuf* b : bufs)
@@ -424,6 +425,16 @@ int s2amd_synchronize(s2amdSolver* s)
 			return fail(S2AMD_E_DEVICE, "strip hand-off timed out inside the persistent step kernel while the same-XCD hand-off path was in use: the steps "
 										"enqueued since the last s2amd_synchronize were dropped from the failing one on -- repeat them (the solver now "
 										"hands off with agent-scope stores only)");
+		}
+		if (s->overflowKernelThisStep && !s->overflowKernelFailed)
+		{
+			// (the launch carried the overflow workgroup: the repeated steps run sliced, the kernel itself stays)
+			s->overflowKernelFailed = true;
+			s->layoutGeneration += 1;
+			s->persistFallbacks += 1;
+			s->stats.persistFallbacks = s->persistFallbacks;
+			return fail(S2AMD_E_DEVICE, "a hand-off with the overflow workgroup of the persistent step kernel timed out: the steps enqueued since the last "
+										"s2amd_synchronize were dropped from the failing one on -- repeat them (steps with overflow contacts now run sliced)");
 		}
 		s->persistFailed = true;
 		s->persistFailedAge = 0;
@@ -966,6 +977,12 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	{
 		s->optOverflow = value != 0; // a contact that fits nowhere in the strips: overflow position + sliced steps + worker-thread build (IncrementalStrips)
 		s->structureDirty = true;
+	}
+	else if (strcmp(key, "overflow_kernel") == 0)
+	{
+		s->optOverflowKernel = value != 0; // overflow contacts inside the persistent launch (one more workgroup) instead of sliced steps
+		s->overflowKernelFailed = false;
+		s->layoutGeneration += 1;
 	}
 	else if (strcmp(key, "stage_joints") == 0)
 	{

@@ -215,7 +215,7 @@ void forgetDeviceState(SolverStructure& t)
 {
 	DevBuf* bufs[] = {&t.dWatched, &t.dBodyFlags, &t.soaBodies, &t.soaContacts, &t.soaJoints, &t.dContactIndex, &t.dJointIndex, &t.dContactLocal, &t.dJointLocal,
 					  &t.dAdjOffsets, &t.dAdjList, &t.dAdjHeavy, &t.dPatches, &t.dJointAdjRange, &t.dJointAdjList, &t.dResidentDesc, &t.dResidentOps, &t.dStripLean,
-					  &t.dPersist, &t.dGranules, &t.dPersistOps, &t.dJacobi, &t.dJacobiGran, &t.dMsg, &t.dGroups.buf, &t.dContactTail.buf, &t.dJointTail.buf, &t.dStripA.buf, &t.dStripB.buf,
+					  &t.dPersist, &t.dGranules, &t.dOverflowBodies, &t.dPersistOps, &t.dJacobi, &t.dJacobiGran, &t.dMsg, &t.dGroups.buf, &t.dContactTail.buf, &t.dJointTail.buf, &t.dStripA.buf, &t.dStripB.buf,
 					  &t.dResident.buf};
 	for (DevBuf* b : bufs)
 	{
@@ -253,7 +253,7 @@ void releaseDeviceState(s2amdSolver* c)
 	SolverStructure& t = *c;
 	DevBuf* bufs[] = {&t.dWatched, &t.dBodyFlags, &t.soaBodies, &t.soaContacts, &t.soaJoints, &t.dContactIndex, &t.dJointIndex, &t.dContactLocal, &t.dJointLocal,
 					  &t.dAdjOffsets, &t.dAdjList, &t.dAdjHeavy, &t.dPatches, &t.dJointAdjRange, &t.dJointAdjList, &t.dResidentDesc, &t.dResidentOps, &t.dStripLean,
-					  &t.dPersist, &t.dGranules, &t.dPersistOps, &t.dJacobi, &t.dJacobiGran, &t.dMsg, &t.dGroups.buf, &t.dContactTail.buf, &t.dJointTail.buf, &t.dStripA.buf, &t.dStripB.buf,
+					  &t.dPersist, &t.dGranules, &t.dOverflowBodies, &t.dPersistOps, &t.dJacobi, &t.dJacobiGran, &t.dMsg, &t.dGroups.buf, &t.dContactTail.buf, &t.dJointTail.buf, &t.dStripA.buf, &t.dStripB.buf,
 					  &t.dResident.buf};
 	for (DevBuf* b : bufs)
 	{
@@ -274,6 +274,26 @@ void releaseDeviceState(s2amdSolver* c)
 	}
 }
 
+// Retired copies, kept as OBJECTS for the next request: a copy is megabytes of host vectors (what the host knows of the wire arrays, the
+// graph's endpoints), and filling fresh ones costs the requesting step 0.35 ms of page faults at 140k contact slots against 0.07 ms
+// into vectors that have their capacity (measured, r5: the first overflow build's request was one of the two steps over 1 ms).
+std::mutex gSpareMutex;
+std::vector<s2amdSolver*> gSpareClones;
+
+s2amdSolver* cloneTake()
+{
+	{
+		std::lock_guard<std::mutex> lock(gSpareMutex);
+		if (!gSpareClones.empty())
+		{
+			s2amdSolver* c = gSpareClones.back();
+			gSpareClones.pop_back();
+			return c;
+		}
+	}
+	return new s2amdSolver();
+}
+
 // a worker's copy of the solver: frees what IT owns (the structure part's device state, its stream); everything else is the owner's
 void destroyClone(s2amdSolver* c)
 {
@@ -284,6 +304,24 @@ void destroyClone(s2amdSolver* c)
 	releaseDeviceState(c);
 	workerStreamGive(c->stream); // (synchronised above; kept for the next copy: creating and destroying streams stalls every thread's HIP calls)
 	c->stream = nullptr;
+	c->async = nullptr;
+	{
+		// the structure part as a new object's would be -- but for the four vectors every request fills -- (here, on the thread that
+		// takes the copy apart: giving back the tables' megabytes costs what filling them did)
+		std::vector<int> a = std::move(c->hContactA), b = std::move(c->hContactB);
+		auto edge = std::move(c->hContactEdge);
+		auto dead = std::move(c->hContactDead);
+		static_cast<SolverStructure&>(*c) = SolverStructure{};
+		c->hContactA = std::move(a), c->hContactB = std::move(b), c->hContactEdge = std::move(edge), c->hContactDead = std::move(dead);
+	}
+	{
+		std::lock_guard<std::mutex> lock(gSpareMutex);
+		if (gSpareClones.size() < 2)
+		{
+			gSpareClones.push_back(c);
+			return;
+		}
+	}
 	delete c;
 }
 
@@ -419,6 +457,32 @@ void asyncShutdown(s2amdSolver* s)
 
 // `search`: the graph has been at rest long enough for the search over strip widths (the copy sees the same age and runs it)
 // `forceStrips`: the copy builds its strips whatever the graph's age (the live structure runs sliced until it is adopted)
+// the copy a worker builds on: everything but the structure part as it is (what the host knows of the wire arrays, the options, the
+// plan); of the structure part only what a build reads -- the graph as the structure knows it and the policies earlier builds have learnt
+static void fillClone(s2amdSolver* c, const s2amdSolver* s)
+{
+	static_cast<SolverRest&>(*c) = static_cast<const SolverRest&>(*s);
+	c->hContactA = s->hContactA, c->hContactB = s->hContactB, c->hContactEdge = s->hContactEdge, c->hContactDead = s->hContactDead;
+	c->spareColours = s->spareColours, c->slackShift = s->slackShift, c->slackBumped = s->slackBumped, c->slackAtBuild = s->slackAtBuild;
+	c->slackPositions = s->slackPositions;
+	c->stripScaleFound = s->stripScaleFound, c->stripScaleFoundFor = s->stripScaleFoundFor, c->stripsJudgedForClass = s->stripsJudgedForClass;
+	c->stripsRejected = false, c->stripsHopeless = false, c->residentRejected = s->residentRejected;
+	c->layoutGeneration = s->layoutGeneration, c->structureGeneration = s->structureGeneration;
+	c->isClone = true;
+	c->async = nullptr;
+	c->worldResident = false; // (no device reads of the world's arrays from the worker: the shadows above are current)
+	c->pointsKnown = true;
+	c->stream = nullptr;
+	c->evBegin = c->evEnd = nullptr;
+	for (hipEvent_t& e : c->evExport)
+	{
+		e = nullptr;
+	}
+	c->side[0] = c->side[1] = nullptr;
+	c->hostTimes = nullptr;
+	c->sweepEvents.clear();
+}
+
 int asyncRequest(s2amdSolver* s, int solverType, bool search, bool forceStrips)
 {
 	static const bool debugAsync = getenv("S2AMD_DEBUG_ASYNC") != nullptr;
@@ -458,27 +522,8 @@ int asyncRequest(s2amdSolver* s, int solverType, bool search, bool forceStrips)
 	// the copy: everything but the structure part as it is (what the host knows of the wire arrays, the options, the plan); of the
 	// structure part only what a build reads -- the graph as the structure knows it and the policies earlier builds have learnt.
 	// (A copy of the whole object, tables and placement mirrors included, cost the requesting step 5 ms at 140k contact slots.)
-	s2amdSolver* c = new s2amdSolver();
-	static_cast<SolverRest&>(*c) = static_cast<const SolverRest&>(*s);
-	c->hContactA = s->hContactA, c->hContactB = s->hContactB, c->hContactEdge = s->hContactEdge, c->hContactDead = s->hContactDead;
-	c->spareColours = s->spareColours, c->slackShift = s->slackShift, c->slackBumped = s->slackBumped, c->slackAtBuild = s->slackAtBuild;
-	c->slackPositions = s->slackPositions;
-	c->stripScaleFound = s->stripScaleFound, c->stripScaleFoundFor = s->stripScaleFoundFor, c->stripsJudgedForClass = s->stripsJudgedForClass;
-	c->stripsRejected = false, c->stripsHopeless = false, c->residentRejected = s->residentRejected;
-	c->layoutGeneration = s->layoutGeneration, c->structureGeneration = s->structureGeneration;
-	c->isClone = true;
-	c->async = nullptr;
-	c->worldResident = false; // (no device reads of the world's arrays from the worker: the shadows above are current)
-	c->pointsKnown = true;
-	c->stream = nullptr;
-	c->evBegin = c->evEnd = nullptr;
-	for (hipEvent_t& e : c->evExport)
-	{
-		e = nullptr;
-	}
-	c->side[0] = c->side[1] = nullptr;
-	c->hostTimes = nullptr;
-	c->sweepEvents.clear();
+	s2amdSolver* c = cloneTake();
+	fillClone(c, s);
 	forgetDeviceState(*c);
 	tr2 = debugAsync ? nowMs() : 0.0;
 	c->stream = workerStreamTake();
@@ -545,7 +590,7 @@ int asyncPrewarm(s2amdSolver* s, int solverType)
 	SolverStructure& t = *s;
 	const DevBuf* bufs[] = {&t.dWatched, &t.dBodyFlags, &t.soaBodies, &t.soaContacts, &t.soaJoints, &t.dContactIndex, &t.dJointIndex, &t.dContactLocal, &t.dJointLocal,
 							&t.dAdjOffsets, &t.dAdjList, &t.dAdjHeavy, &t.dPatches, &t.dJointAdjRange, &t.dJointAdjList, &t.dResidentDesc, &t.dResidentOps, &t.dStripLean,
-							&t.dPersist, &t.dGranules, &t.dPersistOps, &t.dJacobi, &t.dJacobiGran, &t.dMsg, &t.dGroups.buf, &t.dContactTail.buf, &t.dJointTail.buf, &t.dStripA.buf, &t.dStripB.buf,
+							&t.dPersist, &t.dGranules, &t.dOverflowBodies, &t.dPersistOps, &t.dJacobi, &t.dJacobiGran, &t.dMsg, &t.dGroups.buf, &t.dContactTail.buf, &t.dJointTail.buf, &t.dStripA.buf, &t.dStripB.buf,
 							&t.dResident.buf};
 	for (const DevBuf* b : bufs)
 	{
@@ -593,6 +638,17 @@ int asyncPrewarm(s2amdSolver* s, int solverType)
 	asyncDrop(s);
 	reap(s->async, true);
 	s->asyncRequested = requestedWas;
+	// (the copy that build worked on waits as an OBJECT for the next request -- cloneTake --; a second one beside it, because a search over
+	// strip widths holds its copy for a hundred steps and the overflow build that falls into them found none: 0.31 ms of its request)
+	{
+		s2amdSolver* extra = new s2amdSolver();
+		fillClone(extra, s);
+		forgetDeviceState(*extra);
+		const bool was = devPoolOn();
+		devPoolThread(true);
+		destroyClone(extra);
+		devPoolThread(was);
+	}
 	return S2AMD_OK;
 }
 

@@ -704,7 +704,14 @@ struct Executor
 		count();
 	}
 
-	void runPersistent(int kind, int warm, bool clearFirst = false, bool selfContained = false)
+	// ... or in ONE launch that carries an overflow workgroup (wide_kernel.hip: wideOverflowWorker): the strips hand the bodies the
+	// overflow contacts touch to it after every sweep and take them back.  One more workgroup has to be co-resident.
+	bool overflowKernelPlan() const
+	{
+		return slicedPlan() && s->optOverflowKernel != 0 && !s->overflowKernelFailed && s->persist.overflowBodies != nullptr && s->dStripA.view.groupCount + 1 <= s->cuCount;
+	}
+
+	void runPersistent(int kind, int warm, bool clearFirst = false, bool selfContained = false, bool overflowKernel = false)
 	{
 		// hand-off tags are the exchange number; the step's epilogue kernel leaves the buffers zeroed for the next
 		// step, so they only need clearing when this launch is replayed on its own (s2amd_measure_dominant)
@@ -735,6 +742,14 @@ struct Executor
 				self.warmStart = p.sc.warmStart, self.gravityX = p.sc.gravityX, self.gravityY = p.sc.gravityY, self.unpackH = p.unpackH;
 			}
 			pv.bodyWarm = (kind == SOFT_TGS && wideBodyWarm(selfContained)) ? 1 : 0;
+			if (overflowKernel)
+			{
+				const IncrementalStrips& m = s->stripInc;
+				pv.bodyWarm = 0;
+				pv.overflowKernel = 1;
+				pv.overflowBodyCount = (int)m.overflowBodyIds.size();
+				pv.overflowBegin = m.overflowBegin, pv.overflowEnd = m.overflowEnd;
+			}
 			launchWideStep(st, kind, s->cv, s->bv, s->leanA, pv, (const Op*)s->dPersistOps.p, s->persistOpCount, selfContained ? &self : nullptr);
 		}
 		else if (pv.pairLanes && s->optPairLanes)
@@ -782,7 +797,14 @@ struct Executor
 		{
 			if (slicedPlan() && widePlan(kind, warm))
 			{
-				runPersistentSliced(kind, warm); // (doStep has made sure that overflow contacts only meet this kernel)
+				if (overflowKernelPlan())
+				{
+					runPersistent(kind, warm, false, false, true);
+				}
+				else
+				{
+					runPersistentSliced(kind, warm); // (doStep has made sure that overflow contacts only meet this kernel)
+				}
 			}
 			else
 			{

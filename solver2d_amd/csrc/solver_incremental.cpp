@@ -619,13 +619,56 @@ bool overflowPlace(s2amdSolver* s, Patcher& p, const ContactChange& ch)
 	{
 		return false;
 	}
+	// the bodies' entries in the list the overflow workgroup stages (wide_kernel.hip: wideOverflowWorker; the sliced launches do not
+	// read it): found or made -- when the list is full the contact cannot wait here
+	const uint32_t wbit = s->inc.solverClass == 1 ? S2F_WRITE_POS : S2F_WRITE_VEL;
+	int entry[2] = {-1, -1};
+	{
+		std::vector<int> ids = m.overflowBodyIds;
+		const int bodies[2] = {ch.a, ch.b};
+		for (int side = 0; side < 2; ++side)
+		{
+			const int code = bodies[side] | ((s->hBodyFlags[(size_t)bodies[side]] & wbit) != 0 ? 0 : 0x40000000);
+			int at = -1, hole = -1;
+			for (int i = 0; i < (int)ids.size(); ++i)
+			{
+				at = ids[(size_t)i] == code ? i : at;
+				hole = (ids[(size_t)i] < 0 && hole < 0) ? i : hole;
+			}
+			if (at < 0 && hole < 0 && (int)ids.size() < S2_OVERFLOW_BODIES)
+			{
+				hole = (int)ids.size();
+				ids.push_back(-1);
+			}
+			if (at < 0 && hole < 0)
+			{
+				return false;
+			}
+			if (at < 0)
+			{
+				ids[(size_t)hole] = code;
+				at = hole;
+			}
+			entry[side] = at;
+		}
+		for (int i = 0; i < (int)ids.size(); ++i)
+		{
+			if (i >= (int)m.overflowBodyIds.size() || m.overflowBodyIds[(size_t)i] != ids[(size_t)i])
+			{
+				p.word(s->dOverflowBodies.p, (size_t)i, (uint32_t)ids[(size_t)i]);
+			}
+		}
+		m.overflowBodyIds = std::move(ids);
+	}
 	const int k = m.overflowFree.back();
 	m.overflowFree.pop_back();
 	s->contacts.order[(size_t)k] = ch.slot;
-	s->contacts.local[(size_t)k] = make_int2(0, 0);
+	s->contacts.local[(size_t)k] = make_int2(entry[0], entry[1]);
 	m.positionOfSlot[(size_t)ch.slot] = k;
 	s->inc.positionOfSlot[(size_t)ch.slot] = -2;
 	p.word(s->dContactIndex.p, (size_t)k, (uint32_t)ch.slot);
+	p.word(s->dContactLocal.p, 2 * (size_t)k, (uint32_t)entry[0]);
+	p.word(s->dContactLocal.p, 2 * (size_t)k + 1, (uint32_t)entry[1]);
 	m.overflowUsed += 1;
 	m.overflowPlaced += 1;
 	s->placedTotal += 1;
@@ -648,6 +691,30 @@ bool stripRemove(s2amdSolver* s, Patcher& p, int slot)
 		// an overflow position (no round, no local slots): free again; the launch sequence loses its sweeps
 		s->contacts.order[(size_t)k] = -1;
 		p.word(s->dContactIndex.p, (size_t)k, (uint32_t)-1);
+		{
+			// entries of the overflow workgroup's body list that no other overflow contact refers to become free
+			const int2 mine = s->contacts.local[(size_t)k];
+			bool used[2] = {false, false};
+			for (int o = m.overflowBegin; o < m.overflowEnd; ++o)
+			{
+				if (o != k && s->contacts.order[(size_t)o] >= 0)
+				{
+					const int2 l = s->contacts.local[(size_t)o];
+					used[0] = used[0] || l.x == mine.x || l.y == mine.x;
+					used[1] = used[1] || l.x == mine.y || l.y == mine.y;
+				}
+			}
+			const int e[2] = {mine.x, mine.y};
+			for (int side = 0; side < 2; ++side)
+			{
+				if (!used[side] && e[side] >= 0 && e[side] < (int)m.overflowBodyIds.size() && m.overflowBodyIds[(size_t)e[side]] >= 0)
+				{
+					m.overflowBodyIds[(size_t)e[side]] = -1;
+					p.word(s->dOverflowBodies.p, (size_t)e[side], (uint32_t)-1);
+				}
+			}
+			s->contacts.local[(size_t)k] = make_int2(0, 0);
+		}
 		m.overflowFree.insert(std::upper_bound(m.overflowFree.begin(), m.overflowFree.end(), k, std::greater<int>()), k); // stays descending
 		m.overflowUsed -= 1;
 		m.positionOfSlot[(size_t)slot] = -1;

@@ -296,6 +296,11 @@ struct IncrementalStrips
 	std::vector<int> overflowFree;			// descending: pop_back() hands out the lowest
 	int overflowUsed = 0;
 	long overflowPlaced = 0;
+	// ... round 5, later: the overflow contacts swept INSIDE the persistent launch by one more workgroup (wide_kernel.hip:
+	// wideOverflowWorker; PersistView::overflowBodies): the bodies the contacts in use touch -- pool slot, bit 30: nothing writes it, -1:
+	// free entry --, at most S2_OVERFLOW_BODIES; an overflow contact's `local` pair indexes this list.  The device copy
+	// (SolverStructure::dOverflowBodies) is kept up to date with patched words.
+	std::vector<int> overflowBodyIds;
 };
 #define S2_OVERFLOW_SLACK 32
 #define S2_STRIP_ADOPT_SLACK 8
@@ -373,7 +378,7 @@ struct SolverStructure
 	StripTableView leanA{}, leanB{};
 	bool leanAValid = false, leanBValid = false;
 	// persistent strip step (strip_kernel.hip: stripStepKernel)
-	DevBuf dPersist, dGranules;
+	DevBuf dPersist, dGranules, dOverflowBodies;
 	PersistView persist{};
 	bool persistValid = false;
 	// ... as an op interpreter for every solver family and joints (generic_kernel.hip: genericStepKernel): the same partition,
@@ -580,6 +585,9 @@ struct SolverRest
 	bool forcedBuild = false;  // (a worker's copy) the live structure runs sliced until this build is adopted: strips at once, and a partition the resident
 							   // kernel can run AND take created contacts into (persistValid, stripInc.valid) is all it asks for -- the search over strip
 							   // widths only when the first width gives neither
+	int optOverflowKernel = 1; // "overflow_kernel": overflow contacts are swept inside the persistent launch by one more workgroup (wide_kernel.hip: wideOverflowWorker); 0: sliced steps
+	bool overflowKernelFailed = false;	 // ... that launch lost a hand-off once: this solver's overflow steps run sliced from then on
+	bool overflowKernelThisStep = false; // ... and it is what the step just enqueued used
 	int overflowRefusals = 0;  // builds for overflow contacts that could not be adopted, in a row: the second one is followed by a build in the step
 	long stepCounter = 0;	   // steps enqueued since s2amd_create (the clock of the deferred adoption)
 	// the search over strip widths (seven more builds, a copy of the solver for the worker): after a request the next one waits

@@ -692,9 +692,10 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	{
 		int kind, warm;
 		s->slicedThisStep = s->dStripA.view.groupCount > 0 && q.slicedPlan() && q.persistPlan(kind, warm) && q.widePlan(kind, warm) && !q.selfContainedStrips();
+		s->overflowKernelThisStep = s->slicedThisStep && q.overflowKernelPlan();
 		s->slicedSteps += s->slicedThisStep ? 1 : 0;
 		s->stats.overflowContacts = s->stripInc.valid ? s->stripInc.overflowUsed : 0;
-		s->stats.slicedStep = s->slicedThisStep ? 1 : 0;
+		s->stats.slicedStep = s->slicedThisStep ? (s->overflowKernelThisStep ? 2 : 1) : 0; // 1: one launch per sweep; 2: one launch, the overflow workgroup in it
 		s->stats.slicedSteps = (int32_t)s->slicedSteps;
 	}
 	s->stats.bodiesAdopted = (int32_t)s->stripInc.adopted, s->stats.seamBodiesAdded = (int32_t)s->stripInc.seamBodiesAdded, s->stats.roundsOpened = (int32_t)s->stripInc.roundsOpened;
@@ -725,6 +726,16 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 			s->nearHandoffTimeouts += 1;
 			s->layoutGeneration += 1; // (a captured step graph has the old launch parameters)
 			s->stepCounter -= 1;	  // (the same step again: the clock of the deferred adoptions must not run on time-outs)
+			return doStep(s, params);
+		}
+		if (s->overflowKernelThisStep && !s->overflowKernelFailed)
+		{
+			// ... or the launch carried the overflow workgroup (wide_kernel.hip: wideOverflowWorker) and a hand-off with IT may be what
+			// timed out: the step again sliced, which this solver keeps for its overflow steps
+			s->overflowKernelFailed = true;
+			s->layoutGeneration += 1;
+			s->persistFallbacks += 1;
+			s->stepCounter -= 1;
 			return doStep(s, params);
 		}
 		s->persistFailed = true;

@@ -1369,11 +1369,15 @@ do                                                                              
 			put(o2, exportSrc.data(), exportSrc.size() * sizeof(int));
 			put(o3, importIds.data(), importIds.size() * sizeof(int));
 			bool grewP = false;
-			s->granuleBytes = ((std::max<size_t>((size_t)2 * parityStride + (size_t)K, 1) * sizeof(unsigned long long)) + 255) & ~size_t(255); // + one census granule per strip (wide_kernel.hip)
-			if ((rc = s->dPersist.ensure(blob.size(), &grewP)) != 0 || (rc = s->dGranules.ensure(s->granuleBytes, &grewP)) != 0)
+			// + one census granule per strip (wide_kernel.hip), + the exchange rings of the overflow workgroup (PersistView::overflowGranBase)
+			const size_t overflowGranBase = ((size_t)2 * parityStride + (size_t)K + 31) & ~size_t(31);
+			s->granuleBytes = (((overflowGranBase + S2_OVERFLOW_GRANULES) * sizeof(unsigned long long)) + 255) & ~size_t(255);
+			if ((rc = s->dPersist.ensure(blob.size(), &grewP)) != 0 || (rc = s->dGranules.ensure(s->granuleBytes, &grewP)) != 0 ||
+				(rc = s->dOverflowBodies.ensure(S2_OVERFLOW_BODIES * sizeof(int), &grewP)) != 0)
 			{
 				return rc;
 			}
+			HIP_TRY(hipMemsetAsync(s->dOverflowBodies.p, 0xff, S2_OVERFLOW_BODIES * sizeof(int), s->stream)); // (-1: free entries)
 			if (grewP)
 			{
 				s->layoutGeneration += 1;
@@ -1397,6 +1401,8 @@ do                                                                              
 			pv.maxStripBodies = (maxStripBodies + 31) & ~31;
 			pv.parityStride = parityStride;
 			pv.censusBase = 2 * parityStride;
+			pv.overflowBodies = (const int*)s->dOverflowBodies.p;
+			pv.overflowGranBase = (int)overflowGranBase;
 			// fresh buffers start from zero tags
 			HIP_TRY(hipMemsetAsync(s->dGranules.p, 0, s->granuleBytes, s->stream));
 			pv.wideRounds = maxRoundsA > S2_STRIP_ROUNDS ? 1 : 0;
@@ -2729,6 +2735,7 @@ struct StructureBuild
 			m.rounds.push_back(std::move(r));
 		}
 		m.overflowBegin = overflowBase, m.overflowEnd = overflowBase + overflowCount;
+		m.overflowBodyIds.clear();
 		for (int k = m.overflowEnd - 1; k >= m.overflowBegin; --k)
 		{
 			m.overflowFree.push_back(k);

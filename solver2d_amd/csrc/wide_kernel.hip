@@ -628,6 +628,233 @@ constexpr int wideLocalsInLds(int RPH, int SR, int SL, int IL, bool sliced)
 // RPH: interior records a lane keeps (colour batches / 2), SR: seam records a lane keeps, SL: seam rounds parked in LDS.
 // IL: interior rounds parked in LDS behind the 2 RPH a lane keeps (a strip that needs a seventh or eighth colour: a hub body inside it).
 // MODE: S2_WIDE_SELF | S2_WIDE_BODYWARM.
+// A strip's side of the exchange with the overflow workgroup behind a sweep op (every lane has passed the sweep's last barrier): lovf[m]
+// says where this workgroup stages overflow body m -- (priority << 24) | LDS slot, 0: not here; priority 3: it owns the body and
+// publishes it, every staged copy takes the result.  Returns non-zero when a hand-off timed out.
+S2_DEV int wideOverflowExchange(const PersistView& pv, const int* lovf, float4* lvel, int ovCount, unsigned sweep)
+{
+	const int tid = (int)threadIdx.x;
+	int fail = 0;
+	if (tid < ovCount)
+	{
+		const int e = lovf[tid];
+		if (e != 0)
+		{
+			const int slot = e & 0xffffff;
+			gu64* in = (gu64*)pv.granules + pv.overflowGranBase + (int)(sweep & (S2_OVERFLOW_RING - 1)) * S2_OVERFLOW_BODIES * 4 + 4 * tid;
+			gu64* out = in + S2_OVERFLOW_GRANULES / 2;
+			if ((e >> 24) == 3)
+			{
+				const float4 v = lvel[slot];
+				putGranule(in + 0, sweep, v.x), putGranule(in + 1, sweep, v.y), putGranule(in + 2, sweep, v.z);
+			}
+			float v[3];
+			if (getGranules<3>(out, sweep, v, pv.error, pv.deviceError, pv.spinLimit))
+			{
+				lvel[slot] = make_float4(v[0], v[1], v[2], 0.0f);
+			}
+			else
+			{
+				fail = 1;
+			}
+		}
+	}
+	return __syncthreads_or(fail);
+}
+
+#define S2_WIDE_OVERFLOW 8 // the launch carries one more workgroup, which sweeps the contacts of the overflow positions (PersistView::overflowBodies) after every
+						   // sweep of the strips: the step stays ONE launch while contacts wait there for the worker thread's next structure
+
+// The overflow workgroup of such a launch (the last of the grid).  It stages the bodies the overflow contacts touch, repeats the body
+// stages on its copies as every strip does on its imports (poses never travel), and per sweep op: takes {v, w} of every body some strip
+// writes from that strip (which has finished its own rounds of the sweep: the overflow positions come last in the sweep order), sweeps
+// the contacts ONE AFTER THE OTHER in lane 0 -- they may share a body, the ball that touches boxes of two strips -- with the
+// per-constraint functions of the colour batches on the copies in LDS (impulses in the SoA arrays), and hands {v, w} back to every
+// strip that stages the body.  The same operations on the same operands as Executor::runPersistentSliced's launches.
+template <int KIND> S2_DEV void wideOverflowWorker(const ContactView& c, const BodyView& g, const PersistView& pv, const Op* ops, int opCount, float4* lds)
+{
+	const int tid = (int)threadIdx.x;
+	const int M = pv.overflowBodyCount;
+	// lane m keeps body m's records in its registers between the sweeps; for a sweep {v, w} and the pose go to LDS, where wave 0's lanes
+	// take their turns on them
+	// (These launches carry a 36-byte private frame the code never touches -- no scratch instruction in the kernel: tools/kernel_resources.py
+	// counts them -- whichever memory the two arrays live in once the records are pre-loaded per lane; s2amd_create has the queue's scratch
+	// allocated by then: s2WarmScratch below.)
+	__shared__ float4 lvel[S2_OVERFLOW_BODIES], ldq[S2_OVERFLOW_BODIES];
+	Op* lops = (Op*)lds;
+	uint32_t flags = 0u;
+	bool exchanged = false;
+	float4 vel = make_float4(0.0f, 0.0f, 0.0f, 0.0f), dq = vel, integ = vel;
+	float angDamp = 0.0f;
+	if (tid < M)
+	{
+		const int e = pv.overflowBodies[tid];
+		if (e >= 0)
+		{
+			const int gi = e & 0x3fffffff;
+			exchanged = (e & 0x40000000) == 0;
+			vel = g.vel[gi], dq = g.dq[gi], integ = g.integ[gi], angDamp = g.angDamp[gi];
+			flags = g.flags[gi];
+		}
+	}
+	for (int i = tid; i < opCount * 8; i += S2_WIDE_THREADS)
+	{
+		((int*)lops)[i] = ((const int*)ops)[i];
+	}
+	// lane j of wave 0 takes the contact of overflow position j (S2_OVERFLOW_SLACK <= 64 positions)
+	const int myK = pv.overflowBegin + tid;
+	const bool mine = tid < 64 && myK < pv.overflowEnd && c.contactIndex[myK] >= 0;
+	__syncthreads();
+	const LdsBodies lb{lvel, ldq};
+	gu64* in = (gu64*)pv.granules + pv.overflowGranBase + 4 * tid;
+	gu64* out = in + S2_OVERFLOW_GRANULES / 2;
+	unsigned sweep = 0u;
+	for (int oi = 0; oi < opCount; ++oi)
+	{
+		const Op op = lops[oi];
+		if (op.code == OP_INTEGRATE_VEL)
+		{
+			if ((flags & S2F_DYNAMIC) != 0)
+			{
+				V2 lv = add(v2(vel.x, vel.y), v2(integ.x, integ.y));
+				float w = vel.z + integ.z;
+				lv = mulSV(integ.w, lv);
+				w *= angDamp;
+				vel = make_float4(lv.x, lv.y, w, 0.0f);
+			}
+		}
+		else if (op.code == OP_INTEGRATE_POS)
+		{
+			if ((flags & S2F_MOVES) != 0)
+			{
+				V2 dpos = mulAdd(v2(dq.x, dq.y), op.h, v2(vel.x, vel.y));
+				Rot q;
+				q.s = dq.z, q.c = dq.w;
+				q = integrateRot(q, op.h * vel.z);
+				dq = make_float4(dpos.x, dpos.y, q.s, q.c);
+			}
+		}
+		else if (op.code == OP_FINALIZE)
+		{
+			// (a copy: the owner strip writes the position)
+			if ((flags & (op.flag ? S2F_DYNAMIC : S2F_MOVES)) != 0)
+			{
+				dq = make_float4(0.0f, 0.0f, dq.z, dq.w);
+			}
+		}
+		else if (op.code == OP_SOLVE_SOFT)
+		{
+			// the contact's record travels while the strips finish their sweep (the impulses in it are this lane's own of the sweep before)
+			SoftRegs<KIND> r;
+			if (mine)
+			{
+				r = loadSoft<KIND, S2_IDX_LOCAL>(c, myK);
+			}
+			sweep += 1u;
+			const int ring = (int)(sweep & (S2_OVERFLOW_RING - 1)) * S2_OVERFLOW_BODIES * 4;
+			int fail = 0;
+			if (exchanged)
+			{
+				float v[3];
+				if (getGranules<3>(in + ring, sweep, v, pv.error, pv.deviceError, pv.spinLimit))
+				{
+					vel = make_float4(v[0], v[1], v[2], 0.0f);
+				}
+				else
+				{
+					fail = 1;
+				}
+			}
+			if (tid < M)
+			{
+				lvel[tid] = vel, ldq[tid] = dq;
+			}
+			if (__syncthreads_or(fail))
+			{
+				return;
+			}
+			if (tid < 64)
+			{
+				// one after the other, in position order (they may share a body); LDS operations of one wave execute in program order
+				for (unsigned long long turns = __ballot(mine); turns != 0ull; turns &= turns - 1ull)
+				{
+					if (tid == __builtin_ctzll(turns))
+					{
+						solveSoftRegs<KIND>(r, c, lb, op.inv_h, op.useBias, myK);
+						storeSoft<KIND>(c, r, myK);
+					}
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+					__builtin_amdgcn_wave_barrier();
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				}
+			}
+			__syncthreads();
+			if (exchanged)
+			{
+				vel = lvel[tid];
+				putGranule(out + ring + 0, sweep, vel.x), putGranule(out + ring + 1, sweep, vel.y), putGranule(out + ring + 2, sweep, vel.z);
+			}
+		}
+		else if (op.code == OP_WARM)
+		{
+			WarmRegs w;
+			if (mine)
+			{
+				w = op.kind == WARM_FIXED ? loadWarm<WARM_FIXED>(c, lb, myK) : loadWarm<WARM_CURRENT>(c, lb, myK);
+			}
+			sweep += 1u;
+			const int ring = (int)(sweep & (S2_OVERFLOW_RING - 1)) * S2_OVERFLOW_BODIES * 4;
+			int fail = 0;
+			if (exchanged)
+			{
+				float v[3];
+				if (getGranules<3>(in + ring, sweep, v, pv.error, pv.deviceError, pv.spinLimit))
+				{
+					vel = make_float4(v[0], v[1], v[2], 0.0f);
+				}
+				else
+				{
+					fail = 1;
+				}
+			}
+			if (tid < M)
+			{
+				lvel[tid] = vel, ldq[tid] = dq;
+			}
+			if (__syncthreads_or(fail))
+			{
+				return;
+			}
+			if (tid < 64)
+			{
+				for (unsigned long long turns = __ballot(mine); turns != 0ull; turns &= turns - 1ull)
+				{
+					if (tid == __builtin_ctzll(turns))
+					{
+						if (op.kind == WARM_FIXED)
+						{
+							applyWarm<WARM_FIXED>(w, lb);
+						}
+						else
+						{
+							applyWarm<WARM_CURRENT>(w, lb);
+						}
+					}
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+					__builtin_amdgcn_wave_barrier();
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				}
+			}
+			__syncthreads();
+			if (exchanged)
+			{
+				vel = lvel[tid];
+				putGranule(out + ring + 0, sweep, vel.x), putGranule(out + ring + 1, sweep, vel.y), putGranule(out + ring + 2, sweep, vel.z);
+			}
+		}
+	}
+}
+
 template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int KIND = SOFT_TGS> __global__ __launch_bounds__(S2_WIDE_THREADS) void wideStepKernel(ContactView c, BodyView g, StripTableView ta, PersistView pv, const Op* ops, int opCount, WideSelf self)
 {
 	extern __shared__ __attribute__((aligned(16))) float4 lds[];
@@ -635,8 +862,18 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 	constexpr bool BODYWARM = (MODE & S2_WIDE_BODYWARM) != 0;
 	static_assert(!BODYWARM || (SL == 0 && IL == 0), "the body-centric warm start keeps no terms for parked rounds");
 	constexpr bool SLICED = (MODE & S2_WIDE_SLICED) != 0;
-	static_assert(KIND == SOFT_TGS || (MODE & ~S2_WIDE_SLICED) == 0, "the self-contained form and the body-centric warm start are s2Solve_TGS_Soft's");
+	constexpr bool OVERFLOW = (MODE & S2_WIDE_OVERFLOW) != 0;
+	static_assert(KIND == SOFT_TGS || (MODE & ~(S2_WIDE_SLICED | S2_WIDE_OVERFLOW)) == 0, "the self-contained form and the body-centric warm start are s2Solve_TGS_Soft's");
 	static_assert(!SLICED || MODE == S2_WIDE_SLICED, "a sliced step's launches are the plain form");
+	static_assert(!OVERFLOW || MODE == S2_WIDE_OVERFLOW, "the overflow workgroup rides with the plain form");
+	if constexpr (OVERFLOW)
+	{
+		if (blockIdx.x + 1u == gridDim.x)
+		{
+			wideOverflowWorker<KIND>(c, g, pv, ops, opCount, lds);
+			return;
+		}
+	}
 	static_assert(KIND != SOFT_FIXED || (SL == 0 && IL == 0), "s2Solve_SoftStep: the variants without parked rounds");
 	// the record form the constraint functions take: s2Solve_PGS_Soft on a variant without parked rounds keeps its anchors in LDS too
 	// (RK: the records a lane keeps -- s2Solve_PGS_Soft's with their anchors in LDS; RKP: the records of parked rounds, whole in LDS)
@@ -645,7 +882,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 	// resident records whose local anchors wait in LDS instead of registers (warmWide / prepWide: LL): the last LA of the RPH interior
 	// + SR seam records a lane holds -- s2Solve_TGS_Soft's variants beyond the <3, 2> layout
 	constexpr int NRES = RPH + SR;
-	constexpr int LA = KIND == SOFT_TGS ? wideLocalsInLds(RPH, SR, SL, IL, SLICED) : 0;
+	constexpr int LA = KIND == SOFT_TGS ? wideLocalsInLds(RPH, SR, SL, IL, SLICED || OVERFLOW) : 0;
 	constexpr int LL0 = NRES - LA; // the first such record (interior records 0 .. RPH - 1, then the seam records)
 	static_assert(LA >= 0 && LA <= NRES, "wideLocalsInLds");
 	const int tid = (int)threadIdx.x;
@@ -677,7 +914,7 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 	// Strip <-> workgroup: consecutive strips on ONE XCD, so that a seam's two workgroups share an L2 (the dispatcher is observed
 	// to place block b on XCD b % 8: a speed assumption only, checked below).  XCD x runs blocks x, x + 8, ...; it takes the
 	// strips [start(x), start(x) + count(x)).
-	const int K = (int)gridDim.x;
+	const int K = (int)gridDim.x - (OVERFLOW ? 1 : 0);
 	const int xcd = (int)blockIdx.x & 7, lane8 = (int)blockIdx.x >> 3;
 	const int strip = S2_WIDE_XCD_AFFINE ? xcd * (K >> 3) + (xcd < (K & 7) ? xcd : (K & 7)) + lane8 : (int)blockIdx.x;
 	// does this strip's left / right neighbour run on my XCD (by the same map)?
@@ -1034,6 +1271,36 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 			lmask[i] = 0u;
 		}
 	}
+	// OVERFLOW: where this workgroup stages the bodies the overflow contacts touch -- (priority << 24) | LDS slot, 0: not here.  The
+	// owner (priority 3) publishes the body after every sweep; every copy that takes part in sweeps -- the owner's, the importing
+	// neighbour's (2) -- takes the overflow workgroup's result (a copy an adoption left behind in a body list, 1, only if no other is here).
+	__shared__ int lovf[S2_OVERFLOW_BODIES];
+	const int ovCount = OVERFLOW ? pv.overflowBodyCount : 0;
+	if constexpr (OVERFLOW)
+	{
+		if (tid < S2_OVERFLOW_BODIES)
+		{
+			lovf[tid] = 0;
+		}
+		__syncthreads();
+#pragma unroll
+		for (int ch = 0; ch < S2_WIDE_BODY_CHUNKS + 1; ++ch)
+		{
+			if (flags[ch] != 0u)
+			{
+				const int gi = ch < S2_WIDE_BODY_CHUNKS ? (int)(id[ch] & ~S2G_OWNED) : impId;
+				const int prio = ch < S2_WIDE_BODY_CHUNKS ? ((id[ch] & S2G_OWNED) != 0 ? 3 : 1) : 2;
+				for (int m = 0; m < ovCount; ++m)
+				{
+					if (pv.overflowBodies[m] == gi) // (an entry nothing writes carries bit 30 and matches no pool slot: no exchange)
+					{
+						atomicMax(&lovf[m], (prio << 24) | ldsIdx[ch]);
+					}
+				}
+			}
+		}
+	}
+	unsigned ovSweep = 0u;
 	// the neighbours' census entries have had the whole load phase to land; a missing one only costs the fast path
 	int* lnear = (int*)(lcoef + 2);
 	if (ht == 0)
@@ -1366,6 +1633,10 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 					__syncthreads();
 				}
 			}
+			if constexpr (OVERFLOW)
+			{
+				bad = wideOverflowExchange(pv, lovf, lvel, ovCount, ++ovSweep);
+			}
 			stampAt(3);
 		}
 		else if (op.code == OP_SOLVE_SOFT)
@@ -1555,6 +1826,10 @@ template <int POINTS, int RPH, int SR, int SL = 0, int IL = 0, int MODE = 0, int
 					}
 					__syncthreads();
 				}
+			}
+			if constexpr (OVERFLOW)
+			{
+				bad = wideOverflowExchange(pv, lovf, lvel, ovCount, ++ovSweep);
 			}
 			stampAt(6);
 		}
@@ -1778,6 +2053,7 @@ template __global__ void wideStepKernel<2, 3, 2, 0, 0, 0>(ContactView, BodyView,
 template __global__ void wideStepKernel<2, 3, 2, 0, 0, 1>(ContactView, BodyView, StripTableView, PersistView, const Op*, int, WideSelf);
 template __global__ void wideStepKernel<2, 3, 2, 0, 0, 2>(ContactView, BodyView, StripTableView, PersistView, const Op*, int, WideSelf);
 template __global__ void wideStepKernel<2, 3, 2, 0, 0, 3>(ContactView, BodyView, StripTableView, PersistView, const Op*, int, WideSelf);
+template __global__ void wideStepKernel<2, 3, 2, 0, 0, 8>(ContactView, BodyView, StripTableView, PersistView, const Op*, int, WideSelf);
 #else
 // Eligibility (checked by the caller, solver_executor.h widePlan): TGS_Soft with the current-anchor warm start on a partition with
 // at most 6 interior colour batches per strip and 3 per seam, or 8 and 2 (pv.maxRoundsA, pv.maxSeamRounds): five or six resident
@@ -1825,7 +2101,11 @@ static void launchWide(hipStream_t s, dim3 grid, size_t lds, const ContactView& 
 		{
 			const WideSelf none{};
 			lds += wideExtraLds(pv, RPH, SR, SL, IL, false, false, true);
-			if (pv.clearOwn != 0)
+			if (pv.overflowKernel != 0)
+			{
+				launchWideMode<RPH, SR, SL, IL, S2_WIDE_OVERFLOW, SOFT_FIXED>(s, grid, lds, c, g, a, pv, ops, opCount, none);
+			}
+			else if (pv.clearOwn != 0)
 			{
 				launchWideMode<RPH, SR, SL, IL, S2_WIDE_SLICED, SOFT_FIXED>(s, grid, lds, c, g, a, pv, ops, opCount, none);
 			}
@@ -1841,7 +2121,11 @@ static void launchWide(hipStream_t s, dim3 grid, size_t lds, const ContactView& 
 		// s2Solve_PGS_Soft: the plain form only (prologue and epilogue launches, the coloured warm start); rA0 / rB0 in LDS where no round is parked
 		const WideSelf none{};
 		lds += wideExtraLds(pv, RPH, SR, SL, IL, false, false, true);
-		if (pv.clearOwn != 0)
+		if (pv.overflowKernel != 0)
+		{
+			launchWideMode<RPH, SR, SL, IL, S2_WIDE_OVERFLOW, SOFT_PGS>(s, grid, lds, c, g, a, pv, ops, opCount, none);
+		}
+		else if (pv.clearOwn != 0)
 		{
 			launchWideMode<RPH, SR, SL, IL, S2_WIDE_SLICED, SOFT_PGS>(s, grid, lds, c, g, a, pv, ops, opCount, none);
 		}
@@ -1882,7 +2166,11 @@ static void launchWide(hipStream_t s, dim3 grid, size_t lds, const ContactView& 
 		}
 	}
 	{
-		if (pv.clearOwn != 0)
+		if (pv.overflowKernel != 0)
+		{
+			launchWideMode<RPH, SR, SL, IL, S2_WIDE_OVERFLOW>(s, grid, lds, c, g, a, pv, ops, opCount, none);
+		}
+		else if (pv.clearOwn != 0)
 		{
 			launchWideMode<RPH, SR, SL, IL, S2_WIDE_SLICED>(s, grid, lds, c, g, a, pv, ops, opCount, none);
 		}
@@ -1953,7 +2241,7 @@ int wideBodyWarmVariant(const PersistView& pv)
 
 void launchWideStep(hipStream_t s, int kind, const ContactView& c, const BodyView& g, const StripTableView& a, const PersistView& pv, const Op* ops, int opCount, const WideSelf* self)
 {
-	const dim3 grid((unsigned)a.groupCount);
+	const dim3 grid((unsigned)a.groupCount + (pv.overflowKernel != 0 ? 1u : 0u)); // (+ the overflow workgroup: wideOverflowWorker)
 	const size_t lds = (size_t)(pv.bodyRecords + 3) * sizeof(float4) + (size_t)opCount * sizeof(Op);
 	switch (wideVariant(pv))
 	{
@@ -2339,18 +2627,21 @@ int wideKernelSetup()
 			return 1;
 		}
 	}
-	// every variant the launch can pick (launchWide): the five layouts in the plain and the sliced form for s2Solve_TGS_Soft and
+	// every variant the launch can pick (launchWide): the five layouts in the plain, the sliced and the overflow form for s2Solve_TGS_Soft and
 	// s2Solve_PGS_Soft, the <3, 2> layout alone for s2Solve_SoftStep and for the two optional modes
 #define S2_WIDE_LAYOUTS(P, MODE, KIND)                                                                                            \
 	(const void*)wideStepKernel<P, 3, 2, 0, 0, MODE, KIND>, (const void*)wideStepKernel<P, 3, 3, 0, 0, MODE, KIND>, (const void*)wideStepKernel<P, 4, 2, 0, 0, MODE, KIND>, \
 		(const void*)wideStepKernel<P, 3, 2, 2, 0, MODE, KIND>, (const void*)wideStepKernel<P, 3, 2, 2, 2, MODE, KIND>
 	const void* steps[] = {S2_WIDE_LAYOUTS(0, 0, SOFT_TGS), S2_WIDE_LAYOUTS(2, 0, SOFT_TGS), S2_WIDE_LAYOUTS(0, S2_WIDE_SLICED, SOFT_TGS), S2_WIDE_LAYOUTS(2, S2_WIDE_SLICED, SOFT_TGS),
+						   S2_WIDE_LAYOUTS(0, S2_WIDE_OVERFLOW, SOFT_TGS), S2_WIDE_LAYOUTS(2, S2_WIDE_OVERFLOW, SOFT_TGS),
 						   (const void*)wideStepKernel<0, 3, 2, 0, 0, 1>, (const void*)wideStepKernel<0, 3, 2, 0, 0, 2>,
 						   (const void*)wideStepKernel<2, 3, 2, 0, 0, 1>, (const void*)wideStepKernel<2, 3, 2, 0, 0, 2>, (const void*)wideStepKernel<2, 3, 2, 0, 0, 3>};
-	const void* pgs[] = {S2_WIDE_LAYOUTS(0, 0, SOFT_PGS), S2_WIDE_LAYOUTS(2, 0, SOFT_PGS), S2_WIDE_LAYOUTS(0, S2_WIDE_SLICED, SOFT_PGS), S2_WIDE_LAYOUTS(2, S2_WIDE_SLICED, SOFT_PGS)};
+	const void* pgs[] = {S2_WIDE_LAYOUTS(0, 0, SOFT_PGS), S2_WIDE_LAYOUTS(2, 0, SOFT_PGS), S2_WIDE_LAYOUTS(0, S2_WIDE_SLICED, SOFT_PGS), S2_WIDE_LAYOUTS(2, S2_WIDE_SLICED, SOFT_PGS),
+						 S2_WIDE_LAYOUTS(0, S2_WIDE_OVERFLOW, SOFT_PGS), S2_WIDE_LAYOUTS(2, S2_WIDE_OVERFLOW, SOFT_PGS)};
 #undef S2_WIDE_LAYOUTS
 	const void* fixed[] = {(const void*)wideStepKernel<0, 3, 2, 0, 0, 0, SOFT_FIXED>, (const void*)wideStepKernel<2, 3, 2, 0, 0, 0, SOFT_FIXED>,
-						   (const void*)wideStepKernel<0, 3, 2, 0, 0, S2_WIDE_SLICED, SOFT_FIXED>, (const void*)wideStepKernel<2, 3, 2, 0, 0, S2_WIDE_SLICED, SOFT_FIXED>};
+						   (const void*)wideStepKernel<0, 3, 2, 0, 0, S2_WIDE_SLICED, SOFT_FIXED>, (const void*)wideStepKernel<2, 3, 2, 0, 0, S2_WIDE_SLICED, SOFT_FIXED>,
+						   (const void*)wideStepKernel<0, 3, 2, 0, 0, S2_WIDE_OVERFLOW, SOFT_FIXED>, (const void*)wideStepKernel<2, 3, 2, 0, 0, S2_WIDE_OVERFLOW, SOFT_FIXED>};
 	for (const void* f : fixed)
 	{
 		if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -2378,3 +2669,26 @@ int wideKernelSetup()
 #endif // S2_WIDE_ONLY_MAIN
 
 S2_DEFINE_WARM(wide_kernel)
+
+// A queue's scratch memory is allocated by the runtime when the first kernel with a private frame is dispatched on it -- a stall of the
+// kind S2_DEFINE_WARM exists for.  The overflow variants above declare a (never touched) 36-byte frame and the 256-thread fall-back
+// kernels spill for real: s2amd_create dispatches this kernel once, with a frame of 64 bytes per lane on a grid of the persistent
+// kernels' shape, so that the allocation happens there.
+__global__ __launch_bounds__(S2_WIDE_THREADS) void s2WarmScratchKernel(int* sink, int n)
+{
+	volatile int a[16];
+	for (int i = 0; i < 16; ++i)
+	{
+		a[i] = (int)threadIdx.x + i;
+	}
+	int sum = 0;
+	for (int i = 0; i < n; ++i)
+	{
+		sum += a[(i * 7) & 15];
+	}
+	if (sink != nullptr && sum == 0x7fffffff)
+	{
+		*sink = sum;
+	}
+}
+void s2WarmScratch(hipStream_t st) { s2WarmScratchKernel<<<dim3(256), dim3(S2_WIDE_THREADS), 0, st>>>(nullptr, 4); }

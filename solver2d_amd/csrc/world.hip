@@ -567,6 +567,18 @@ int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapa
 		{
 			return rcBuild;
 		}
+		// ... and the stage-1 pair query (s2amd_world_find_pairs): its scratch, its sorted pair keys and its captured graph
+		if (s->liveShapes >= 2)
+		{
+			int32_t none = 0;
+			if ((rcBuild = s->dPairKeys.ensure(std::max<size_t>((size_t)s->contactCapacity * 8, 256))) != 0 ||
+				(rcBuild = findPairsResident(s->stream, (const s2amdShape*)s->dShapes.p, s->shapeCapacity, s->liveShapes, (const s2amdPairState*)s->dPairs.p, s->contactCapacity,
+											 (const unsigned long long*)s->dJointedKeys.p, s->jointedCount, nullptr, 0, &none, &s->dPairScratch.p, &s->dPairScratch.bytes,
+											 (unsigned long long*)s->dPairKeys.p, &s->pairKeysValid, &s->pairQuery, true)) != 0)
+			{
+				return rcBuild;
+			}
+		}
 	}
 	return S2AMD_OK;
 }
@@ -743,7 +755,15 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 			{
 				return rc;
 			}
-			s->persistFailed = true;
+			if (s->overflowKernelThisStep && !s->overflowKernelFailed)
+			{
+				s->overflowKernelFailed = true; // (the launch carried the overflow workgroup: the step again, sliced)
+				s->layoutGeneration += 1;
+			}
+			else
+			{
+				s->persistFailed = true;
+			}
 			s->persistFallbacks += 1;
 			fallbacks += 1;
 			if (!haveFirst)

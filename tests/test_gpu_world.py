@@ -415,14 +415,17 @@ def test_wrecking_ball_world_loop(seed, solver_name):
 
 # (s2Solve_SoftStep runs on the 512-thread kernel in its <3, 2> layout only -- wide_kernel.hip -- and a pile with a ball in it needs more
 # rounds: it keeps the build in the step, as before round 5)
+@pytest.mark.parametrize("overflow_kernel", [1, 0])
 @pytest.mark.parametrize("seed,solver_name", [(1, "TGS_Soft"), (3, "TGS_Soft"), (7, "TGS_Soft"), (6, "PGS_Soft")])
-def test_a_contact_that_fits_nowhere_in_the_strips_waits_behind_them(seed, solver_name):
+def test_a_contact_that_fits_nowhere_in_the_strips_waits_behind_them(seed, solver_name, overflow_kernel):
     """SURVEY.md 8f row 4 (round 5): a ball that comes to touch boxes two strips apart used to cost a structure build in the step that
     found the contact (5 ms on the caller's thread at base 200).  Now the contact takes an OVERFLOW position behind the strips
     (solver_internal.h: IncrementalStrips), the steps run SLICED -- the persistent kernel launched once per sweep, the overflow contacts
     swept behind each launch -- while a worker thread builds the structure that holds it, adopted at a step boundary.  The whole loop at
     base 100 with the default options, 150 steps, every step of it bit-exact against the oracle chain swept in the device's order -- through
-    the sliced steps, the adoption, and the steps on the adopted structure; and no structure build in a step that found such a contact."""
+    the sliced steps, the adoption, and the steps on the adopted structure; and no structure build in a step that found such a contact.
+    `overflow_kernel` 1 (the default): the step stays ONE launch of the persistent kernel, which carries one more workgroup that sweeps
+    the overflow contacts after every sweep of the strips (wide_kernel.hip: wideOverflowWorker; stats.slicedStep 2); 0: sliced steps."""
     from tests import common
     vel, pos = common.DEFAULT_ITERS[solver_name]
     params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
@@ -431,6 +434,7 @@ def test_a_contact_that_fits_nowhere_in_the_strips_waits_behind_them(seed, solve
     sliced = adopted = 0
     rows = []
     with hip.Solver(0) as s:
+        s.set_option("overflow_kernel", overflow_kernel)
         s.world_upload(*[world[k] for k in world_chain.WORLD_KEYS])
         for step in range(150):
             if world_chain.moved_any(ref):
@@ -446,7 +450,9 @@ def test_a_contact_that_fits_nowhere_in_the_strips_waits_behind_them(seed, solve
             assert info["separatedCount"] == int((status == wire.PAIR_SEPARATED).sum()), "step %d" % step
             st = s.stats()
             rows.append((st["overflowContacts"], st["slicedStep"], st["structureBuilds"], st["asyncBuildsAdopted"], st["kernelLaunches"]))
-            sliced += st["slicedStep"]
+            assert st["slicedStep"] in (0, 2 if overflow_kernel else 1) and st["persistFallbacks"] == 0, (step, st["slicedStep"], st["persistFallbacks"])
+            assert st["slicedStep"] != 2 or st["kernelLaunches"] <= 4, (step, st["kernelLaunches"])
+            sliced += 1 if st["slicedStep"] else 0
             adopted = st["asyncBuildsAdopted"]
             if st["slicedStep"] or step % 8 == 7 or step < 3:
                 out = world_chain.copy_world(world)

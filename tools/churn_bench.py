@@ -131,16 +131,18 @@ def run(a):
            "steps_on_persistent_kernel": sum(r["persistent"] for r in rows), "steps_replayed_from_graph": sum(r["replayed"] for r in rows),
            "joined_without_rebuild": {"bodies_moved_to_the_strip_they_touched": st["bodiesAdopted"], "bodies_added_to_a_seam": st["seamBodiesAdded"], "spare_rounds_opened": st["roundsOpened"],
                                       "note": "counters of the structure in use at the last step (a rebuild starts them again)"},
-           "overflow": {"steps_run_sliced": sum(r["sliced"] for r in rows), "most_contacts_waiting": max(r["overflow"] for r in rows),
-                        "sliced_step_ms_median": median("step_ms", [r for r in rows if r["sliced"]]), "sliced_step_launches_median": median("launches", [r for r in rows if r["sliced"]]),
+           "overflow": {"steps_run_sliced": sum(1 for r in rows if r["sliced"] == 1), "steps_with_the_overflow_workgroup_in_the_launch": sum(1 for r in rows if r["sliced"] == 2), "most_contacts_waiting": max(r["overflow"] for r in rows),
+                        "overflow_step_ms_median": median("step_ms", [r for r in rows if r["sliced"]]), "overflow_step_launches_median": median("launches", [r for r in rows if r["sliced"]]),
                         "note": "a contact that fits nowhere in the strips waits in an overflow position behind them while a worker thread builds the structure "
-                                "that holds it; until that is adopted the persistent kernel is launched once per sweep and the overflow contacts are swept behind each launch"},
+                                "that holds it; until that is adopted the persistent launch carries one more workgroup that sweeps the overflow contacts after every "
+                                "sweep of the strips (option overflow_kernel 0, or after a time-out: the kernel is launched once per sweep -- sliced)"},
            "structure_builds_by_the_worker_thread": {"requested": st["asyncBuildsRequested"], "adopted": st["asyncBuildsAdopted"], "caller_waited_ms": st["asyncWaitMs"]},
            "steps_over_1ms": sum(1 for r in rows[2:] if r["step_ms"] > 1.0), "steps_over_2ms": sum(1 for r in rows[2:] if r["step_ms"] > 2.0),
            "all_steps": {k: mean(k, rows) for k in keys}, "churn_steps": {k: mean(k, churn) for k in keys}, "quiet_steps": {k: mean(k, quiet) for k in keys},
            "churn_steps_median": {k: median(k, churn) for k in keys}, "quiet_steps_median": {k: median(k, quiet) for k in keys},
            # (steps 0 and 1 build the world's first structures and load the kernels' code objects: start-up, not churn)
            "start_up_steps_ms": [round(r["step_ms"], 3) for r in rows[:2]],
+           "start_up_steps_parts_ms": [{k: round(r[k], 3) for k in keys} for r in rows[:2]],
            "slowest_steps_ms": sorted((round(r["step_ms"], 3) for r in rows[2:]), reverse=True)[:8],
            "active_contacts_last": rows[-1]["active"]}
     return out

@@ -312,8 +312,20 @@ S2_DEV bool reports(const s2amdShape& P, bool movedP, const s2amdShape& Q, bool 
 	return true;
 }
 
+// The pairs stage 3 destroyed in THIS step (narrowphase.hip: updateContactsKernel writes their keys; count = the step's separated
+// counter): the sorted key set of the live pairs is the host's to renew and still holds them while the query runs inside the step
+// (world.hip) -- a pair in both lists is not "existing".
+struct GoneKeys
+{
+	const unsigned long long* keys = nullptr;
+	const int* count = nullptr;
+	// (rides along: the sorted key set of the resident query holds COMPACT keys, (min shape << shapeBits) | max shape -- half the radix
+	// passes of the 64-bit form when the set is sorted again; 0: the 64-bit form (min << 32) | max)
+	int shapeBits = 0;
+};
 S2_DEV void pairTest(int xi, int yi, const s2amdShape* shapes, const unsigned char* moved, const unsigned long long* existing, int existingCount,
-					 const unsigned long long* jointed, int jointedCount, unsigned long long* outKeys, unsigned int outCapacity, unsigned int* outCount);
+					 const unsigned long long* jointed, int jointedCount, unsigned long long* outKeys, unsigned int outCapacity, unsigned int* outCount,
+					 GoneKeys gone = GoneKeys{});
 
 // one candidate (work item t of the sweep-and-prune runs): which pair it is
 S2_DEV void pairOne(unsigned int t, const s2amdShape* shapes, const unsigned char* moved, const int* sortedIdx, const unsigned int* runOffset, int n,
@@ -341,7 +353,8 @@ S2_DEV void pairOne(unsigned int t, const s2amdShape* shapes, const unsigned cha
 
 // one candidate pair of shapes whose fat boxes overlap on the sweep axis: the reference's pair rules
 S2_DEV void pairTest(int xi, int yi, const s2amdShape* shapes, const unsigned char* moved, const unsigned long long* existing, int existingCount,
-					 const unsigned long long* jointed, int jointedCount, unsigned long long* outKeys, unsigned int outCapacity, unsigned int* outCount)
+					 const unsigned long long* jointed, int jointedCount, unsigned long long* outKeys, unsigned int outCapacity, unsigned int* outCount,
+					 GoneKeys gone)
 {
 	const s2amdShape& X = shapes[xi];
 	const s2amdShape& Y = shapes[yi];
@@ -355,9 +368,21 @@ S2_DEV void pairTest(int xi, int yi, const s2amdShape* shapes, const unsigned ch
 		return;
 	}
 	unsigned int slo = (unsigned int)(xi < yi ? xi : yi), shi = (unsigned int)(xi < yi ? yi : xi);
-	if (containsKey(existing, existingCount, ((unsigned long long)slo << 32) | shi))
+	if (containsKey(existing, existingCount, gone.shapeBits > 0 ? (((unsigned long long)slo << gone.shapeBits) | shi) : (((unsigned long long)slo << 32) | shi)))
 	{
-		return; // the contact exists (:183-188)
+		bool goneNow = false;
+		if (gone.keys != nullptr)
+		{
+			const int g = *gone.count;
+			for (int q = 0; q < g; ++q)
+			{
+				goneNow = goneNow || gone.keys[q] == (((unsigned long long)slo << 32) | shi);
+			}
+		}
+		if (!goneNow)
+		{
+			return; // the contact exists (:183-188)
+		}
 	}
 	int ia = xi, ib = yi;
 	if (Y.proxyKey < X.proxyKey) // shape A has the lower proxy key (:190-200)
@@ -458,7 +483,7 @@ __global__ __launch_bounds__(S2_BLOCK) void pairStrideKernel(const s2amdShape* s
 __global__ __launch_bounds__(S2_BLOCK) void pairWaveKernel(const s2amdShape* shapes, const unsigned char* moved, const int* sortedIdx,
 															const float* sortedLowerX, int n, const unsigned long long* existing, int existingCount,
 															const unsigned long long* jointed, int jointedCount, unsigned long long* outKeys,
-															unsigned int outCapacity, unsigned int* outCount, int* longList, unsigned int* longCount)
+															unsigned int outCapacity, unsigned int* outCount, int* longList, unsigned int* longCount, GoneKeys gone)
 {
 	const int lane = (int)threadIdx.x & 63;
 	const int wavesPerBlock = (int)blockDim.x >> 6;
@@ -484,7 +509,7 @@ __global__ __launch_bounds__(S2_BLOCK) void pairWaveKernel(const s2amdShape* sha
 				const int yi = sortedIdx[j];
 				if (mi || moved[yi] != 0)
 				{
-					pairTest(xi, yi, shapes, moved, existing, existingCount, jointed, jointedCount, outKeys, outCapacity, outCount);
+					pairTest(xi, yi, shapes, moved, existing, existingCount, jointed, jointedCount, outKeys, outCapacity, outCount, gone);
 				}
 			}
 			if (!__all(in))
@@ -499,7 +524,7 @@ __global__ __launch_bounds__(S2_BLOCK) void pairWaveKernel(const s2amdShape* sha
 __global__ __launch_bounds__(S2_BLOCK) void pairLongKernel(const s2amdShape* shapes, const unsigned char* moved, const int* sortedIdx,
 															const float* sortedLowerX, int n, const unsigned long long* existing, int existingCount,
 															const unsigned long long* jointed, int jointedCount, unsigned long long* outKeys,
-															unsigned int outCapacity, unsigned int* outCount, const int* longList, const unsigned int* longCount)
+															unsigned int outCapacity, unsigned int* outCount, const int* longList, const unsigned int* longCount, GoneKeys gone)
 {
 	const unsigned int count = *longCount;
 	for (unsigned int e = 0; e < count; ++e)
@@ -517,7 +542,7 @@ __global__ __launch_bounds__(S2_BLOCK) void pairLongKernel(const s2amdShape* sha
 			const int yi = sortedIdx[j];
 			if (mi || moved[yi] != 0)
 			{
-				pairTest(xi, yi, shapes, moved, existing, existingCount, jointed, jointedCount, outKeys, outCapacity, outCount);
+				pairTest(xi, yi, shapes, moved, existing, existingCount, jointed, jointedCount, outKeys, outCapacity, outCount, gone);
 			}
 		}
 	}
@@ -594,7 +619,7 @@ __global__ __launch_bounds__(S2_BLOCK) void residentShapeKeysKernel(const s2amdS
 }
 
 // (min shape, max shape) of every live pair slot; free slots sort last and match nothing
-__global__ __launch_bounds__(S2_BLOCK) void residentPairKeysKernel(const s2amdPairState* pairs, int nc, unsigned long long* keys)
+__global__ __launch_bounds__(S2_BLOCK) void residentPairKeysKernel(const s2amdPairState* pairs, int nc, unsigned long long* keys, int shapeBits)
 {
 	int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= nc)
@@ -605,15 +630,26 @@ __global__ __launch_bounds__(S2_BLOCK) void residentPairKeysKernel(const s2amdPa
 	if (pairs[i].shapeA >= 0 && pairs[i].shapeB >= 0)
 	{
 		unsigned int a = (unsigned int)pairs[i].shapeA, b = (unsigned int)pairs[i].shapeB;
-		key = ((unsigned long long)(a < b ? a : b) << 32) | (a < b ? b : a);
+		key = ((unsigned long long)(a < b ? a : b) << shapeBits) | (a < b ? b : a);
 	}
 	keys[i] = key;
 }
 
 int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShapes, const s2amdPairState* dPairs, int nc,
 					  const unsigned long long* dJointed, int jointedCount, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount, void** scratch,
-					  size_t* scratchBytes, unsigned long long* sortedPairKeys, bool* sortedPairKeysValid, PairQueryGraph* cache, bool warmOnly)
+					  size_t* scratchBytes, unsigned long long* sortedPairKeys, bool* sortedPairKeysValid, PairQueryGraph* cache, int mode,
+					  const unsigned long long* goneKeys, const int* goneCount)
 {
+	// mode: S2_PAIRS_FULL the whole query; S2_PAIRS_WARM buffers + captured graph, nothing runs (s2amd_world_upload); S2_PAIRS_ENQUEUE
+	// the query enqueued behind the caller's work, no wait (s2amd_world_step); S2_PAIRS_COLLECT the results of such a query, after the
+	// caller's wait (s2amd_world_find_pairs)
+	const bool warmOnly = mode == S2_PAIRS_WARM;
+	int shapeBits = 1;
+	while ((1ll << shapeBits) < (long long)std::max(ns, 2))
+	{
+		shapeBits += 1;
+	}
+	const GoneKeys gone{goneKeys, goneCount, shapeBits};
 	*pairCount = 0;
 	const int n = liveShapes;
 	if (n < 2)
@@ -675,10 +711,12 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 
 	// the sorted keys of the live pairs only change when a contact is created or destroyed: the caller keeps them
 	size_t tmp = tmpBytes + 256;
-	if (nc > 0 && !*sortedPairKeysValid)
+	if (nc > 0 && !*sortedPairKeysValid && mode != S2_PAIRS_COLLECT)
 	{
-		residentPairKeysKernel<<<gridFor((size_t)nc), dim3(S2_BLOCK), 0, st>>>(dPairs, nc, dExistingIn);
-		BP_TRY(rocprim::radix_sort_keys(dTmp, tmp, dExistingIn, sortedPairKeys, (size_t)nc, 0, 64, st));
+		// (compact keys: 2 x shapeBits significant bits -- 30 at 20k shapes: four radix passes where the 64-bit form took eight; a free
+		// slot's key, all ones, sorts behind every live one on those bits too)
+		residentPairKeysKernel<<<gridFor((size_t)nc), dim3(S2_BLOCK), 0, st>>>(dPairs, nc, dExistingIn, shapeBits);
+		BP_TRY(rocprim::radix_sort_keys(dTmp, tmp, dExistingIn, sortedPairKeys, (size_t)nc, 0, (unsigned int)std::min(2 * shapeBits, 64), st));
 		*sortedPairKeysValid = true;
 	}
 	constexpr unsigned int kFirst = 2048;
@@ -699,9 +737,9 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 		gatherLowerXKernel<<<gridFor((size_t)n), dim3(S2_BLOCK), 0, st>>>(dS, dIdxOut, n, dLowerX);
 		// (dCount[0] = pairs found, dCount[1] = long runs: both zeroed above; the run-length array of the host-array route holds the long list)
 		pairWaveKernel<<<dim3((unsigned)std::min((n + 3) / 4, 16384)), dim3(S2_BLOCK), 0, st>>>(dS, dMoved, dIdxOut, dLowerX, n, sortedPairKeys, nc, dJointed,
-																								jointedCount, dOutA, (unsigned int)outCap, dCount, (int*)dRun, dCount + 1);
+																								jointedCount, dOutA, (unsigned int)outCap, dCount, (int*)dRun, dCount + 1, gone);
 		pairLongKernel<<<dim3(256), dim3(S2_BLOCK), 0, st>>>(dS, dMoved, dIdxOut, dLowerX, n, sortedPairKeys, nc, dJointed, jointedCount, dOutA,
-															  (unsigned int)outCap, dCount, (const int*)dRun, dCount + 1);
+															  (unsigned int)outCap, dCount, (const int*)dRun, dCount + 1, gone);
 		BP_TRY(hipGetLastError());
 		BP_TRY(hipMemcpyAsync(hostFound, dCount, 4, hipMemcpyDeviceToHost, st));
 		BP_TRY(hipMemcpyAsync(hostKeys, dOutA, (size_t)std::min<size_t>(kFirst, outCap) * 8, hipMemcpyDeviceToHost, st));
@@ -712,7 +750,8 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 	{
 		const unsigned long long words[] = {(unsigned long long)(uintptr_t)dS, (unsigned long long)ns, (unsigned long long)n, (unsigned long long)nc,
 											(unsigned long long)(uintptr_t)dJointed, (unsigned long long)jointedCount, (unsigned long long)(uintptr_t)*scratch,
-											(unsigned long long)(uintptr_t)sortedPairKeys, (unsigned long long)outCap, (unsigned long long)tmpBytes};
+											(unsigned long long)(uintptr_t)sortedPairKeys, (unsigned long long)outCap, (unsigned long long)tmpBytes,
+											(unsigned long long)(uintptr_t)goneKeys, (unsigned long long)(uintptr_t)goneCount, (unsigned long long)shapeBits};
 		for (unsigned long long w : words)
 		{
 			key = (key ^ w) * 1099511628211ull;
@@ -753,7 +792,11 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 		BP_TRY(hipStreamSynchronize(st));
 		return S2AMD_OK;
 	}
-	if (cache->disabled || (key != cache->key && key != cache->keySeen))
+	if (mode == S2_PAIRS_COLLECT)
+	{
+		// (enqueued by an earlier call in S2_PAIRS_ENQUEUE mode; the caller has waited for the stream since)
+	}
+	else if (cache->disabled || (key != cache->key && key != cache->keySeen))
 	{
 		cache->keySeen = key;
 		int rcE = enqueue();
@@ -801,7 +844,14 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 			BP_TRY(hipGraphLaunch(cache->exec, st));
 		}
 	}
-	BP_TRY(hipStreamSynchronize(st));
+	if (mode == S2_PAIRS_ENQUEUE)
+	{
+		return S2AMD_OK;
+	}
+	if (mode != S2_PAIRS_COLLECT)
+	{
+		BP_TRY(hipStreamSynchronize(st));
+	}
 	const unsigned int found = *hostFound;
 	std::vector<unsigned long long> out(hostKeys, hostKeys + std::min<size_t>(std::min<size_t>(kFirst, outCap), found));
 	*pairCount = (int32_t)found;

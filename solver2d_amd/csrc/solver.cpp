@@ -209,7 +209,7 @@ void s2amd_destroy(s2amdSolver* s)
 					  &s->soaContacts,	&s->soaJoints,	  &s->dContactIndex, &s->dJointIndex,	 &s->dContactLocal, &s->dJointLocal,
 					  &s->dAdjOffsets,	&s->dAdjList,	  &s->dAdjHeavy,	  &s->dGatherIndex,	 &s->dOps,			 &s->dGroups.buf,	&s->dContactTail.buf,
 					  &s->dJointTail.buf, &s->dMsg,			  &s->dStripA.buf,	 &s->dStripB.buf,	 &s->dStripLean,	&s->dPersist,
-					  &s->dGranules,	&s->dOverflowBodies, &s->dPersistOps, &s->dJacobi, &s->dJacobiGran,	  &s->dShapes,		 &s->dPairs,		 &s->dOrigins,		&s->dStatus,
+					  &s->dGranules,	&s->dOverflowBodies, &s->dSeparatedKeys, &s->dPersistOps, &s->dJacobi, &s->dJacobiGran,	  &s->dShapes,		 &s->dPairs,		 &s->dOrigins,		&s->dStatus,
 					  &s->dPointBytes,	&s->dWorldSummary, &s->dJointedKeys,	 &s->dContactStage, &s->dPairScratch,	  &s->dPairKeys,		 &s->dPatches,		 &s->dScanTmp,		 &s->dResident.buf,	 &s->dResidentDesc, &s->dResidentOps, &s->dWatched, &s->dRefitOrder, &s->dStepBack,
 					  &s->dSlotBytes,	  &s->dJointAdjRange, &s->dJointAdjList, &s->dShapeBoxes};
 	for (DevBuf* b : bufs)
@@ -977,6 +977,11 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	{
 		s->optOverflow = value != 0; // a contact that fits nowhere in the strips: overflow position + sliced steps + worker-thread build (IncrementalStrips)
 		s->structureDirty = true;
+	}
+	else if (strcmp(key, "pairs_in_step") == 0)
+	{
+		s->optPairsInStep = value != 0; // the stage-1 pair query enqueued behind every world step (world.hip)
+		s->pairCacheValid = false;
 	}
 	else if (strcmp(key, "overflow_kernel") == 0)
 	{

@@ -488,6 +488,7 @@ struct SolverRest
 	DevBuf dOps; // the plan's op list (solver_step.cpp: doStep)
 	long placedTotal = 0;	// created contacts placed without a rebuild, since s2amd_create
 	DevBuf dSeparated;		// world chain: the pair slots stage 3 freed this step
+	DevBuf dSeparatedKeys;	// ... and their pair keys (broadphase.hip: GoneKeys), for the pair query enqueued behind the step
 	DevBuf dShapeBoxes;		// world chain: s2amd_world_download_boxes' staging
 	DevBuf dRefitOrder, dStepBack; // s2amd_world_set_refit_order; staging of s2amd_world_download_step {count, moved boxes} and the poses
 	int refitOrderCount = 0;
@@ -585,6 +586,9 @@ struct SolverRest
 	bool forcedBuild = false;  // (a worker's copy) the live structure runs sliced until this build is adopted: strips at once, and a partition the resident
 							   // kernel can run AND take created contacts into (persistValid, stripInc.valid) is all it asks for -- the search over strip
 							   // widths only when the first width gives neither
+	int optPairsInStep = 1;	   // "pairs_in_step": once the caller has asked for pairs (s2amd_world_find_pairs), every s2amd_world_step enqueues the next query behind its stage 4 and the call returns its results without a device round trip of its own
+	bool pairQueryUsed = false;	 // ... it has
+	bool pairCacheValid = false; // ... the last step's query is waiting to be collected
 	int optOverflowKernel = 1; // "overflow_kernel": overflow contacts are swept inside the persistent launch by one more workgroup (wide_kernel.hip: wideOverflowWorker); 0: sliced steps
 	bool overflowKernelFailed = false;	 // ... that launch lost a hand-off once: this solver's overflow steps run sliced from then on
 	bool overflowKernelThisStep = false; // ... and it is what the step just enqueued used

@@ -421,6 +421,7 @@ int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapa
 	}
 	s->worldResident = false;
 	s->pairKeysValid = false;
+	s->pairQueryUsed = false, s->pairCacheValid = false;
 	s->gatherIndexDirty = true;
 	int rc = doUpload(s, bodies, bodyCapacity, contacts, contactCapacity, joints, jointCapacity, pairs);
 	if (rc)
@@ -437,7 +438,8 @@ int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapa
 	if ((rc = s->dShapes.ensure(std::max<size_t>(sBytes, 256))) != 0 || (rc = s->dPairs.ensure(std::max<size_t>(pBytes, 256))) != 0 ||
 		(rc = s->dOrigins.ensure(std::max<size_t>(oBytes, 256))) != 0 || (rc = s->dStatus.ensure(std::max<size_t>((size_t)contactCapacity * 4, 256))) != 0 ||
 		(rc = s->dPointBytes.ensure(std::max<size_t>((size_t)contactCapacity, 256))) != 0 || (rc = s->dWorldSummary.ensure(256)) != 0 ||
-		(rc = s->dSeparated.ensure(std::max<size_t>((size_t)contactCapacity * 4, 256))) != 0)
+		(rc = s->dSeparated.ensure(std::max<size_t>((size_t)contactCapacity * 4, 256))) != 0 ||
+		(rc = s->dSeparatedKeys.ensure(std::max<size_t>((size_t)contactCapacity * 8, 256))) != 0)
 	{
 		return rc;
 	}
@@ -574,7 +576,8 @@ int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapa
 			if ((rcBuild = s->dPairKeys.ensure(std::max<size_t>((size_t)s->contactCapacity * 8, 256))) != 0 ||
 				(rcBuild = findPairsResident(s->stream, (const s2amdShape*)s->dShapes.p, s->shapeCapacity, s->liveShapes, (const s2amdPairState*)s->dPairs.p, s->contactCapacity,
 											 (const unsigned long long*)s->dJointedKeys.p, s->jointedCount, nullptr, 0, &none, &s->dPairScratch.p, &s->dPairScratch.bytes,
-											 (unsigned long long*)s->dPairKeys.p, &s->pairKeysValid, &s->pairQuery, true)) != 0)
+											 (unsigned long long*)s->dPairKeys.p, &s->pairKeysValid, &s->pairQuery, S2_PAIRS_WARM,
+											 (const unsigned long long*)s->dSeparatedKeys.p, (const int*)s->dWorldSummary.p)) != 0)
 			{
 				return rcBuild;
 			}
@@ -623,7 +626,8 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 		// (the kernel also destroys separated pairs and accumulates the step's contact counters)
 		launchUpdateContacts(st, (const s2amdBody*)s->dBodies.p, (const float*)s->dOrigins.p, (const s2amdShape*)s->dShapes.p,
 							 (s2amdPairState*)s->dPairs.p, (s2amdContact*)s->dContacts.p, nc, (int32_t*)s->dStatus.p, (uint8_t*)s->dPointBytes.p,
-							 (int*)dSum, (int*)s->dSeparated.p, s->watchedCount > 0 && !s->structureDirty ? (const uint8_t*)s->dWatched.p : nullptr);
+							 (int*)dSum, (int*)s->dSeparated.p, s->watchedCount > 0 && !s->structureDirty ? (const uint8_t*)s->dWatched.p : nullptr,
+							 (unsigned long long*)s->dSeparatedKeys.p);
 	}
 	s->pointsKnown = false; // the manifolds are the device's now
 	s->pointCountsFresh = false;
@@ -721,6 +725,24 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 		if (stepBack && (rc = enqueueStepBack(s)) != 0)
 		{
 			return rc;
+		}
+		// Stage 1 of the NEXT step behind stage 4 of this one: the pair query reads what the refit just wrote (the re-inflated fat boxes,
+		// the move flags) and its results come back with this step's counters -- s2amd_world_find_pairs then costs no device round trip.
+		// Pairs this step's stage 3 destroyed are still in the sorted key set (the host renews it): the kernels take them out by their
+		// keys (dSeparatedKeys, summary[0]: read before the counters are reset below).  Not in a step that is being repeated.
+		s->pairCacheValid = false;
+		if (s->optPairsInStep != 0 && s->pairQueryUsed && fallbacks == 0 && nearRetries == 0 && s->liveShapes >= 2)
+		{
+			int32_t none = 0;
+			if ((rc = s->dPairKeys.ensure(std::max<size_t>((size_t)s->contactCapacity * 8, 256))) != 0 ||
+				(rc = findPairsResident(st, (const s2amdShape*)s->dShapes.p, s->shapeCapacity, s->liveShapes, (const s2amdPairState*)s->dPairs.p, s->contactCapacity,
+										(const unsigned long long*)s->dJointedKeys.p, s->jointedCount, nullptr, 0, &none, &s->dPairScratch.p, &s->dPairScratch.bytes,
+										(unsigned long long*)s->dPairKeys.p, &s->pairKeysValid, &s->pairQuery, S2_PAIRS_ENQUEUE,
+										(const unsigned long long*)s->dSeparatedKeys.p, (const int*)dSum)) != 0)
+			{
+				return rc;
+			}
+			s->pairCacheValid = true;
 		}
 		const double ts0 = debugAsync ? nowMs() : 0.0;
 		if ((rc = fetchSummary(s, 1)) != 0)
@@ -849,9 +871,18 @@ int s2amd_world_find_pairs(s2amdSolver* s, int32_t* outPairs, int32_t pairCapaci
 			return rc;
 		}
 	}
+	// (the last step has run this query behind its stage 4 -- s2amd_world_step -- unless this is the first call, a contact was set since,
+	// or the step was repeated: then it runs now)
+	const bool collect = s->pairCacheValid;
+	s->pairQueryUsed = true;
 	int rc = findPairsResident(s->stream, (const s2amdShape*)s->dShapes.p, s->shapeCapacity, s->liveShapes, (const s2amdPairState*)s->dPairs.p, s->contactCapacity,
 							   (const unsigned long long*)s->dJointedKeys.p, s->jointedCount, outPairs, pairCapacity, pairCount, &s->dPairScratch.p,
-							   &s->dPairScratch.bytes, (unsigned long long*)s->dPairKeys.p, &s->pairKeysValid, &s->pairQuery);
+							   &s->dPairScratch.bytes, (unsigned long long*)s->dPairKeys.p, &s->pairKeysValid, &s->pairQuery, collect ? S2_PAIRS_COLLECT : S2_PAIRS_FULL,
+							   (const unsigned long long*)s->dSeparatedKeys.p, (const int*)s->dWorldSummary.p);
+	if (rc == S2AMD_OK)
+	{
+		s->pairCacheValid = false; // (collected once: the move flags go below, as after a query of this call's own)
+	}
 	if (rc == S2AMD_OK && s->shapeCapacity > 0) // (S2AMD_E_CAPACITY: the caller asks again with a larger buffer)
 	{
 		clearMovedKernel<<<gridFor((size_t)s->shapeCapacity), dim3(S2_BLOCK), 0, s->stream>>>((s2amdShape*)s->dShapes.p, s->shapeCapacity);
@@ -1081,6 +1112,7 @@ int s2amd_world_set_contacts(s2amdSolver* s, const int32_t* slots, int32_t count
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(st));
 	s->pairKeysValid = false;
+	s->pairCacheValid = false; // (a query enqueued behind the last step did not know this contact)
 	// host shadows of the constraint graph (solver_step.cpp: refreshShadows): a slot is a potential constraint while its
 	// pair is live, whatever its manifold holds.  Created contacts get a place in the existing structure when they fit
 	// (solver_incremental.cpp), in pool order like the host-array route; else the structure is rebuilt.

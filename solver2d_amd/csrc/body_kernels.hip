@@ -3,6 +3,7 @@
 // src/solve_jacobi.c:233-245 (apply accumulated deltas), src/solve_xpbd.c:411-449, :465-489.
 
 #include "body_ops.h"
+#include "joint_prep.h"
 
 #define S2_BLOCK 256
 
@@ -13,8 +14,14 @@
 // blocks [0, bodyBlocks): wire bodies -> SoA; further blocks: manifold.constraintIndex of every contact slot
 // (solver_step.cpp: the pool-order gather index; a field no solver kernel reads)
 __global__ __launch_bounds__(S2_BLOCK) void unpackBodiesKernel(BodyView b, const s2amdBody* wire, const uint32_t* hostFlags, StepConsts sc, float h,
-															   int bodyBlocks, s2amdContact* wireContacts, int contactCapacity, const int* gatherIndex)
+															   int bodyBlocks, s2amdContact* wireContacts, int contactCapacity, const int* gatherIndex, JointPrepArgs jp, int posSolver)
 {
+	if ((int)blockIdx.x >= (int)gridDim.x - jp.blocks)
+	{
+		// the joints' preparation (joint.c:297-447; joint_prep.h), from the wire records
+		prepareJointsBlock(jp, hostFlags, wire, sc, posSolver, (int)blockIdx.x - ((int)gridDim.x - jp.blocks));
+		return;
+	}
 	if ((int)blockIdx.x >= bodyBlocks)
 	{
 		int c = ((int)blockIdx.x - bodyBlocks) * (int)blockDim.x + (int)threadIdx.x;
@@ -282,15 +289,22 @@ static inline dim3 gridFor(int n)
 	return dim3((unsigned)((n + S2_BLOCK - 1) / S2_BLOCK));
 }
 
-void launchUnpackBodies(hipStream_t s, const BodyView& b, const s2amdBody* wire, const uint32_t* hostFlags, const StepConsts& sc, float h,
-						s2amdContact* wireContacts, int contactCapacity, const int* gatherIndex)
+bool launchUnpackBodies(hipStream_t s, const BodyView& b, const s2amdBody* wire, const uint32_t* hostFlags, const StepConsts& sc, float h,
+						s2amdContact* wireContacts, int contactCapacity, const int* gatherIndex, const JointPrepArgs* joints, int posSolver)
 {
+	JointPrepArgs jp{};
+	if (joints != nullptr)
+	{
+		jp = *joints;
+	}
 	if (b.capacity > 0)
 	{
 		dim3 bodyGrid = gridFor(b.capacity), contactGrid = gatherIndex && contactCapacity > 0 ? gridFor(contactCapacity) : dim3(0);
-		unpackBodiesKernel<<<dim3(bodyGrid.x + contactGrid.x), dim3(S2_BLOCK), 0, s>>>(b, wire, hostFlags, sc, h, (int)bodyGrid.x, wireContacts,
-																						 contactCapacity, gatherIndex);
+		unpackBodiesKernel<<<dim3(bodyGrid.x + contactGrid.x + (unsigned)jp.blocks), dim3(S2_BLOCK), 0, s>>>(b, wire, hostFlags, sc, h, (int)bodyGrid.x, wireContacts,
+																												contactCapacity, gatherIndex, jp, posSolver);
+		return true;
 	}
+	return false;
 }
 void launchPackBodies(hipStream_t s, const BodyView& b, s2amdBody* wire)
 {

@@ -6,6 +6,7 @@
 // lives in constraint_ops.h (shared with the LDS group kernel).
 
 #include "body_ops.h"
+#include "joint_prep.h"
 
 #define S2_BLOCK 256
 
@@ -22,7 +23,7 @@
 template <int KIND>
 __global__ __launch_bounds__(S2_BLOCK) void prepareContactsKernel(ContactView c, BodyView b, s2amdContact* wire, const s2amdBody* wireBodies,
 																  StepConsts sc, float h, float hertz, int posSolver, const uint32_t* hostFlags,
-																  int contactBlocks, int bodyBlocks, float unpackH, int contactCapacity, const int* gatherIndex)
+																  int contactBlocks, int bodyBlocks, float unpackH, int contactCapacity, const int* gatherIndex, JointPrepArgs jp)
 {
 	if ((int)blockIdx.x >= contactBlocks)
 	{
@@ -30,6 +31,11 @@ __global__ __launch_bounds__(S2_BLOCK) void prepareContactsKernel(ContactView c,
 		if (rest < bodyBlocks)
 		{
 			unpackBodyOne(b, wireBodies, hostFlags, sc, unpackH, rest * (int)blockDim.x + (int)threadIdx.x);
+		}
+		else if ((int)blockIdx.x >= (int)gridDim.x - jp.blocks)
+		{
+			// the joints' preparation (joint.c:297-447; joint_prep.h): from the wire records, like the contacts' above
+			prepareJointsBlock(jp, hostFlags, wireBodies, sc, posSolver, (int)blockIdx.x - ((int)gridDim.x - jp.blocks));
 		}
 		else
 		{
@@ -687,43 +693,49 @@ static inline dim3 gridFor(int n)
 		}                                                                                                                        \
 	} while (0)
 
-void launchPrepareContacts(hipStream_t s, int kind, const ContactView& c, const BodyView& b, s2amdContact* wire, const s2amdBody* wireBodies,
+bool launchPrepareContacts(hipStream_t s, int kind, const ContactView& c, const BodyView& b, s2amdContact* wire, const s2amdBody* wireBodies,
 						   const StepConsts& sc, float h, float hertz, int posSolver, const uint32_t* hostFlags, bool unpackToo, float unpackH,
-						   int contactCapacity, const int* gatherIndex)
+						   int contactCapacity, const int* gatherIndex, const JointPrepArgs* joints)
 {
 	if (c.count <= 0)
 	{
-		return;
+		return false;
+	}
+	JointPrepArgs jp{};
+	if (joints != nullptr)
+	{
+		jp = *joints;
 	}
 	const int contactBlocks = (c.count - (c.skipEnd - c.skipBegin) + S2_BLOCK - 1) / S2_BLOCK;
 	const int bodyBlocks = unpackToo && b.capacity > 0 ? (b.capacity + S2_BLOCK - 1) / S2_BLOCK : 0;
 	const int indexBlocks = unpackToo && gatherIndex && contactCapacity > 0 ? (contactCapacity + S2_BLOCK - 1) / S2_BLOCK : 0;
 	if (contactBlocks + bodyBlocks + indexBlocks == 0)
 	{
-		return; // every position is the resident-island kernel's own
+		return false; // every position is the resident-island kernel's own
 	}
-	dim3 g((unsigned)(contactBlocks + bodyBlocks + indexBlocks)), t(S2_BLOCK);
+	dim3 g((unsigned)(contactBlocks + bodyBlocks + indexBlocks + jp.blocks)), t(S2_BLOCK);
 	switch (kind)
 	{
 		case PREP_PGS:
-			prepareContactsKernel<PREP_PGS><<<g, t, 0, s>>>(c, b, wire, wireBodies, sc, h, hertz, posSolver, hostFlags, contactBlocks, bodyBlocks, unpackH, contactCapacity, gatherIndex);
+			prepareContactsKernel<PREP_PGS><<<g, t, 0, s>>>(c, b, wire, wireBodies, sc, h, hertz, posSolver, hostFlags, contactBlocks, bodyBlocks, unpackH, contactCapacity, gatherIndex, jp);
 			break;
 		case PREP_SOFT:
-			prepareContactsKernel<PREP_SOFT><<<g, t, 0, s>>>(c, b, wire, wireBodies, sc, h, hertz, posSolver, hostFlags, contactBlocks, bodyBlocks, unpackH, contactCapacity, gatherIndex);
+			prepareContactsKernel<PREP_SOFT><<<g, t, 0, s>>>(c, b, wire, wireBodies, sc, h, hertz, posSolver, hostFlags, contactBlocks, bodyBlocks, unpackH, contactCapacity, gatherIndex, jp);
 			break;
 		case PREP_TGS:
-			prepareContactsKernel<PREP_TGS><<<g, t, 0, s>>>(c, b, wire, wireBodies, sc, h, hertz, posSolver, hostFlags, contactBlocks, bodyBlocks, unpackH, contactCapacity, gatherIndex);
+			prepareContactsKernel<PREP_TGS><<<g, t, 0, s>>>(c, b, wire, wireBodies, sc, h, hertz, posSolver, hostFlags, contactBlocks, bodyBlocks, unpackH, contactCapacity, gatherIndex, jp);
 			break;
 		case PREP_STICKY:
-			prepareContactsKernel<PREP_STICKY><<<g, t, 0, s>>>(c, b, wire, wireBodies, sc, h, hertz, posSolver, hostFlags, contactBlocks, bodyBlocks, unpackH, contactCapacity, gatherIndex);
+			prepareContactsKernel<PREP_STICKY><<<g, t, 0, s>>>(c, b, wire, wireBodies, sc, h, hertz, posSolver, hostFlags, contactBlocks, bodyBlocks, unpackH, contactCapacity, gatherIndex, jp);
 			break;
 		case PREP_XPBD:
-			prepareContactsKernel<PREP_XPBD><<<g, t, 0, s>>>(c, b, wire, wireBodies, sc, h, hertz, posSolver, hostFlags, contactBlocks, bodyBlocks, unpackH, contactCapacity, gatherIndex);
+			prepareContactsKernel<PREP_XPBD><<<g, t, 0, s>>>(c, b, wire, wireBodies, sc, h, hertz, posSolver, hostFlags, contactBlocks, bodyBlocks, unpackH, contactCapacity, gatherIndex, jp);
 			break;
 		case PREP_BLOCK:
-			prepareContactsKernel<PREP_BLOCK><<<g, t, 0, s>>>(c, b, wire, wireBodies, sc, h, hertz, posSolver, hostFlags, contactBlocks, bodyBlocks, unpackH, contactCapacity, gatherIndex);
+			prepareContactsKernel<PREP_BLOCK><<<g, t, 0, s>>>(c, b, wire, wireBodies, sc, h, hertz, posSolver, hostFlags, contactBlocks, bodyBlocks, unpackH, contactCapacity, gatherIndex, jp);
 			break;
 	}
+	return true; // (launched: the joint blocks, if any were asked for, rode along)
 }
 
 // The overflow contacts of a sliced step (solver_executor.h: runPersistentSliced): positions [begin, end) swept ONE AFTER THE OTHER by one

@@ -4,148 +4,17 @@
 // per-joint arithmetic lives in constraint_ops.h (shared with the LDS group kernel).
 
 #include "constraint_ops.h"
+#include "joint_prep.h"
 
 #define S2_BLOCK 256
 
-// s2PrepareJoint (joint.c:297-312), s2PrepareJoint_Soft (:372-387), s2PrepareJoint_XPBD (:432-447)
-//   revolute: s2PrepareRevolute revolute_joint.c:30-105, _Soft :421-506, _XPBD :792-823
-//   mouse:    s2PrepareMouse mouse_joint.c:31-83 (all three dispatchers)
+// s2PrepareJoint (joint.c:297-312), s2PrepareJoint_Soft (:372-387), s2PrepareJoint_XPBD (:432-447): joint_prep.h.  The step's prologue
+// launch carries these blocks itself (Executor::run); this kernel is the stand-alone form.
 template <int KIND>
-__global__ __launch_bounds__(S2_BLOCK) void prepareJointsKernel(JointView jv, BodyView b, const s2amdJoint* wire, const s2amdBody* wireBodies,
+__global__ __launch_bounds__(S2_BLOCK) void prepareJointsKernel(JointView jv, const uint32_t* hostFlags, const s2amdJoint* wire, const s2amdBody* wireBodies,
 																StepConsts sc, float h, float hertz, int warmStart, int posSolver)
 {
-	int k = blockIdx.x * blockDim.x + threadIdx.x;
-	if (k >= jv.count)
-	{
-		return;
-	}
-	const s2amdJoint* w = wire + jv.jointIndex[k];
-	int ia = w->bodyA, ib = w->bodyB;
-	const s2amdBody* wa = wireBodies + ia;
-	const s2amdBody* wb = wireBodies + ib;
-	uint32_t wbit = posSolver ? S2F_WRITE_POS : S2F_WRITE_VEL;
-	uint32_t flags = 0;
-	if (b.flags[ib] & wbit)
-	{
-		flags |= S2J_WRITE_B;
-	}
-
-	V2 impulse = v2(w->impulse[0], w->impulse[1]);
-	float motorImpulse = w->motorImpulse, lowerImpulse = w->lowerImpulse, upperImpulse = w->upperImpulse;
-	float bodyI = 0.0f;
-	V2 lA = v2(0.0f, 0.0f), lB;
-	float mA = 0.0f, iA = 0.0f, mB, iB;
-	M22 pivotMass;
-	float biasC = 0.0f, massC = 0.0f, impC = 0.0f, axialMass = 0.0f;
-	V2 centerDiff0;
-
-	if (w->type == S2AMD_JOINT_MOUSE)
-	{
-		flags |= S2J_MOUSE;
-		mB = wb->invMass, iB = wb->invI;
-		lB = sub(v2(w->localOriginAnchorB[0], w->localOriginAnchorB[1]), v2(wb->localCenter[0], wb->localCenter[1]));
-		{
-			float hh = sc.h;
-			float zeta = w->dampingRatio;
-			float omega = 2.0f * S2_PI * w->hertz;
-			softCoefficients(hh, zeta, omega, biasC, massC, impC);
-		}
-		Rot qB = loadRotOnly(b, ib);
-		V2 rB = rotate(qB, lB);
-		M22 K;
-		K.cx.x = mB + iB * rB.y * rB.y;
-		K.cx.y = -iB * rB.x * rB.y;
-		K.cy.x = K.cx.y;
-		K.cy.y = mB + iB * rB.x * rB.x;
-		pivotMass = inverse22(K);
-		float2 pb = b.pos[ib];
-		centerDiff0 = sub(v2(pb.x, pb.y), v2(w->targetA[0], w->targetA[1]));
-		bodyI = wb->I;
-	}
-	else
-	{
-		if (b.flags[ia] & wbit)
-		{
-			flags |= S2J_WRITE_A;
-		}
-		if (w->enableMotor)
-		{
-			flags |= S2J_ENABLE_MOTOR;
-		}
-		if (w->enableLimit)
-		{
-			flags |= S2J_ENABLE_LIMIT;
-		}
-		const float inertiaScale = 1.0f;
-		lA = sub(v2(w->localOriginAnchorA[0], w->localOriginAnchorA[1]), v2(wa->localCenter[0], wa->localCenter[1]));
-		mA = wa->invMass;
-		iA = KIND == JPREP_PLAIN ? inertiaScale * wa->invI : wa->invI;
-		lB = sub(v2(w->localOriginAnchorB[0], w->localOriginAnchorB[1]), v2(wb->localCenter[0], wb->localCenter[1]));
-		mB = wb->invMass;
-		iB = KIND == JPREP_PLAIN ? inertiaScale * wb->invI : wb->invI;
-		float2 pa = b.pos[ia], pb = b.pos[ib];
-		centerDiff0 = sub(v2(pb.x, pb.y), v2(pa.x, pa.y));
-
-		if (KIND == JPREP_XPBD)
-		{
-			pivotMass.cx = v2(0.0f, 0.0f);
-			pivotMass.cy = v2(0.0f, 0.0f);
-			axialMass = 0.0f;
-			impulse = v2(0.0f, 0.0f);
-			lowerImpulse = 0.0f;
-			upperImpulse = 0.0f;
-			motorImpulse = 0.0f;
-		}
-		else
-		{
-			Rot qA = loadRotOnly(b, ia), qB = loadRotOnly(b, ib);
-			V2 rA = rotate(qA, lA);
-			V2 rB = rotate(qB, lB);
-			pivotMass = inverse22(revoluteK(mA, mB, iA, iB, rA, rB));
-			if (KIND == JPREP_SOFT)
-			{
-				const float zeta = 10.0f;
-				float omega = 2.0f * S2_PI * hertz;
-				softCoefficients(h, zeta, omega, biasC, massC, impC);
-			}
-			axialMass = iA + iB;
-			bool fixedRotation;
-			if (axialMass > 0.0f)
-			{
-				axialMass = 1.0f / axialMass;
-				fixedRotation = false;
-			}
-			else
-			{
-				fixedRotation = true;
-			}
-			bool enableLimit = w->enableLimit != 0, enableMotor = w->enableMotor != 0;
-			if (enableLimit == false || fixedRotation || warmStart == 0)
-			{
-				lowerImpulse = 0.0f;
-				upperImpulse = 0.0f;
-			}
-			if (enableMotor == false || fixedRotation || warmStart == 0)
-			{
-				motorImpulse = 0.0f;
-			}
-			if (warmStart == 0)
-			{
-				impulse = v2(0.0f, 0.0f);
-			}
-		}
-	}
-
-	jv.bodies[k] = make_int2(ia, ib);
-	jv.frame[k] = make_float4(lA.x, lA.y, lB.x, lB.y);
-	jv.mass[k] = make_float4(mA, iA, mB, iB);
-	jv.pivot[k] = make_float4(pivotMass.cx.x, pivotMass.cx.y, pivotMass.cy.x, pivotMass.cy.y);
-	jv.soft[k] = make_float4(biasC, massC, impC, axialMass);
-	jv.centerDiff0[k] = make_float2(centerDiff0.x, centerDiff0.y);
-	jv.impulse[k] = make_float2(impulse.x, impulse.y);
-	jv.axial[k] = make_float4(motorImpulse, lowerImpulse, upperImpulse, bodyI);
-	jv.limits[k] = make_float4(w->referenceAngle, w->lowerAngle, w->upperAngle, w->maxMotorTorque);
-	jv.misc[k] = make_float4(w->motorSpeed, fromBits(flags), w->hertz, w->dampingRatio);
+	prepareJointOne<KIND>(jv, hostFlags, wire, wireBodies, sc, h, hertz, warmStart, posSolver, (int)(blockIdx.x * blockDim.x + threadIdx.x));
 }
 
 template <int KIND>
@@ -186,7 +55,7 @@ static inline dim3 gridFor(int n)
 	return dim3((unsigned)((n + S2_BLOCK - 1) / S2_BLOCK));
 }
 
-void launchPrepareJoints(hipStream_t s, int kind, const JointView& j, const BodyView& b, const s2amdJoint* wire, const s2amdBody* wireBodies,
+void launchPrepareJoints(hipStream_t s, int kind, const JointView& j, const uint32_t* hostFlags, const s2amdJoint* wire, const s2amdBody* wireBodies,
 						 const StepConsts& sc, float h, float hertz, int warmStart, int posSolver)
 {
 	if (j.count <= 0)
@@ -197,13 +66,13 @@ void launchPrepareJoints(hipStream_t s, int kind, const JointView& j, const Body
 	switch (kind)
 	{
 		case JPREP_PLAIN:
-			prepareJointsKernel<JPREP_PLAIN><<<g, t, 0, s>>>(j, b, wire, wireBodies, sc, h, hertz, warmStart, posSolver);
+			prepareJointsKernel<JPREP_PLAIN><<<g, t, 0, s>>>(j, hostFlags, wire, wireBodies, sc, h, hertz, warmStart, posSolver);
 			break;
 		case JPREP_SOFT:
-			prepareJointsKernel<JPREP_SOFT><<<g, t, 0, s>>>(j, b, wire, wireBodies, sc, h, hertz, warmStart, posSolver);
+			prepareJointsKernel<JPREP_SOFT><<<g, t, 0, s>>>(j, hostFlags, wire, wireBodies, sc, h, hertz, warmStart, posSolver);
 			break;
 		case JPREP_XPBD:
-			prepareJointsKernel<JPREP_XPBD><<<g, t, 0, s>>>(j, b, wire, wireBodies, sc, h, hertz, warmStart, posSolver);
+			prepareJointsKernel<JPREP_XPBD><<<g, t, 0, s>>>(j, hostFlags, wire, wireBodies, sc, h, hertz, warmStart, posSolver);
 			break;
 	}
 }

@@ -6,6 +6,7 @@
 struct BodyView;
 struct ContactView;
 struct JointView;
+struct JointPrepArgs;
 struct StepConsts;
 struct GroupTable;
 struct Op;
@@ -76,9 +77,9 @@ enum JointSolveKind
 };
 
 // contacts
-void launchPrepareContacts(hipStream_t s, int kind, const ContactView& c, const BodyView& b, s2amdContact* wire, const s2amdBody* wireBodies,
+bool launchPrepareContacts(hipStream_t s, int kind, const ContactView& c, const BodyView& b, s2amdContact* wire, const s2amdBody* wireBodies,
 						   const StepConsts& sc, float h, float hertz, int posSolver, const uint32_t* hostFlags, bool unpackToo, float unpackH,
-						   int contactCapacity, const int* gatherIndex);
+						   int contactCapacity, const int* gatherIndex, const JointPrepArgs* joints = nullptr);
 void launchWarmStartContacts(hipStream_t s, int kind, const ContactView& c, const BodyView& b, int begin, int end);
 void launchSolveContactsSoft(hipStream_t s, int kind, const ContactView& c, const BodyView& b, int begin, int end, float inv_h, int useBias);
 void launchSolveContactsRigid(hipStream_t s, int kind, const ContactView& c, const BodyView& b, int begin, int end, float inv_h);
@@ -94,8 +95,8 @@ void launchStoreImpulses(hipStream_t s, int kind, const ContactView& c, s2amdCon
 						 s2amdJoint* wireJoints = nullptr); // (with joints: their impulses go back to the wire in the same launch)
 
 // bodies
-void launchUnpackBodies(hipStream_t s, const BodyView& b, const s2amdBody* wire, const uint32_t* hostFlags, const StepConsts& sc, float h,
-						s2amdContact* wireContacts, int contactCapacity, const int* gatherIndex);
+bool launchUnpackBodies(hipStream_t s, const BodyView& b, const s2amdBody* wire, const uint32_t* hostFlags, const StepConsts& sc, float h,
+						s2amdContact* wireContacts, int contactCapacity, const int* gatherIndex, const JointPrepArgs* joints = nullptr, int posSolver = 0);
 void launchPackBodies(hipStream_t s, const BodyView& b, s2amdBody* wire);
 void launchIntegrateVelocities(hipStream_t s, const BodyView& b);
 void launchIntegratePositions(hipStream_t s, const BodyView& b, float h);
@@ -108,7 +109,7 @@ void launchXpbdProject(hipStream_t s, const BodyView& b, float inv_h);
 void launchExportPoses(hipStream_t s, const s2amdBody* wire, int n, void* out, int withVelocities = 0);
 
 // joints
-void launchPrepareJoints(hipStream_t s, int kind, const JointView& j, const BodyView& b, const s2amdJoint* wire, const s2amdBody* wireBodies,
+void launchPrepareJoints(hipStream_t s, int kind, const JointView& j, const uint32_t* hostFlags, const s2amdJoint* wire, const s2amdBody* wireBodies,
 						 const StepConsts& sc, float h, float hertz, int warmStart, int posSolver);
 void launchSolveJoints(hipStream_t s, int kind, const JointView& j, const BodyView& b, int begin, int end, const StepConsts& sc, float h,
 					   float inv_h, int useBias);

@@ -376,6 +376,15 @@ struct JointView
 	int count;
 };
 
+// the joint blocks of a prologue launch (joint_prep.h: prepareJointsBlock): what launchPrepareJoints would have been given; blocks 0: none
+struct JointPrepArgs
+{
+	JointView jv;
+	const s2amdJoint* wire;
+	float h, hertz;
+	int kind, warmStart, blocks;
+};
+
 #define S2J_MOUSE 1u
 #define S2J_ENABLE_MOTOR 2u
 #define S2J_ENABLE_LIMIT 4u

@@ -946,20 +946,30 @@ struct Executor
 			runPersistent(kind, warm, false, true);
 			return;
 		}
+		// the joints' preparation rides in the prologue launch (joint_prep.h: it reads the wire records, like the contacts')
+		JointPrepArgs jp{};
+		const bool joints = p.prepJoints >= 0 && s->jv.count > 0;
+		if (joints)
+		{
+			jp.jv = s->jv, jp.wire = wireJoints(), jp.h = p.jprepH, jp.hertz = p.jprepHertz, jp.kind = p.prepJoints, jp.warmStart = p.jprepWarm;
+			jp.blocks = (s->jv.count + 255) / 256;
+		}
+		bool carried;
 		if (prepares)
 		{
-			launchPrepareContacts(st, p.prepContacts, cvIo, s->bv, wireContacts(), wireBodies(), p.sc, p.prepH, p.prepHertz, posSolver,
-								  (const uint32_t*)s->dBodyFlags.p, true, p.unpackH, s->contactCapacity, gatherIndex);
+			carried = launchPrepareContacts(st, p.prepContacts, cvIo, s->bv, wireContacts(), wireBodies(), p.sc, p.prepH, p.prepHertz, posSolver,
+											(const uint32_t*)s->dBodyFlags.p, true, p.unpackH, s->contactCapacity, gatherIndex, joints ? &jp : nullptr);
 			count();
 		}
 		else
 		{
-			launchUnpackBodies(st, s->bv, wireBodies(), (const uint32_t*)s->dBodyFlags.p, p.sc, p.unpackH, wireContacts(), s->contactCapacity, gatherIndex);
+			carried = launchUnpackBodies(st, s->bv, wireBodies(), (const uint32_t*)s->dBodyFlags.p, p.sc, p.unpackH, wireContacts(), s->contactCapacity, gatherIndex,
+										 joints ? &jp : nullptr, posSolver);
 			count();
 		}
-		if (p.prepJoints >= 0 && s->jv.count > 0)
+		if (joints && !carried)
 		{
-			launchPrepareJoints(st, p.prepJoints, s->jv, s->bv, wireJoints(), wireBodies(), p.sc, p.jprepH, p.jprepHertz, p.jprepWarm, posSolver);
+			launchPrepareJoints(st, p.prepJoints, s->jv, (const uint32_t*)s->dBodyFlags.p, wireJoints(), wireBodies(), p.sc, p.jprepH, p.jprepHertz, p.jprepWarm, posSolver);
 			count();
 		}
 		if (msg)

@@ -322,7 +322,13 @@ struct GoneKeys
 	// (rides along: the sorted key set of the resident query holds COMPACT keys, (min shape << shapeBits) | max shape -- half the radix
 	// passes of the 64-bit form when the set is sorted again; 0: the 64-bit form (min << 32) | max)
 	int shapeBits = 0;
+	// ... and what happened to the pair set SINCE that sort (world.hip keeps it: a created contact, a pair an earlier step destroyed):
+	// log[0] = entries, then one 64-bit key per pair that changed, ascending, bit 63 set = destroyed now.  An entry overrides the
+	// sorted set; that set is renewed -- a radix sort of every pair slot's key -- only when the log is full.
+	const unsigned long long* log = nullptr;
 };
+#define S2_PAIR_LOG_CAPACITY 255
+#define S2_PAIR_LOG_GONE (1ull << 63)
 S2_DEV void pairTest(int xi, int yi, const s2amdShape* shapes, const unsigned char* moved, const unsigned long long* existing, int existingCount,
 					 const unsigned long long* jointed, int jointedCount, unsigned long long* outKeys, unsigned int outCapacity, unsigned int* outCount,
 					 GoneKeys gone = GoneKeys{});
@@ -368,21 +374,44 @@ S2_DEV void pairTest(int xi, int yi, const s2amdShape* shapes, const unsigned ch
 		return;
 	}
 	unsigned int slo = (unsigned int)(xi < yi ? xi : yi), shi = (unsigned int)(xi < yi ? yi : xi);
-	if (containsKey(existing, existingCount, gone.shapeBits > 0 ? (((unsigned long long)slo << gone.shapeBits) | shi) : (((unsigned long long)slo << 32) | shi)))
+	const unsigned long long key64 = ((unsigned long long)slo << 32) | shi;
+	bool exists = containsKey(existing, existingCount, gone.shapeBits > 0 ? (((unsigned long long)slo << gone.shapeBits) | shi) : key64);
+	if (gone.log != nullptr)
 	{
-		bool goneNow = false;
-		if (gone.keys != nullptr)
+		// (sorted by key, one entry per key: its state now)
+		int lo = 1, hi = (int)gone.log[0] + 1;
+		while (lo < hi)
 		{
-			const int g = *gone.count;
-			for (int q = 0; q < g; ++q)
+			const int mid = (lo + hi) >> 1;
+			if ((gone.log[mid] & ~S2_PAIR_LOG_GONE) < key64)
 			{
-				goneNow = goneNow || gone.keys[q] == (((unsigned long long)slo << 32) | shi);
+				lo = mid + 1;
+			}
+			else
+			{
+				hi = mid;
 			}
 		}
-		if (!goneNow)
+		if (lo <= (int)gone.log[0])
 		{
-			return; // the contact exists (:183-188)
+			const unsigned long long e = gone.log[lo];
+			if ((e & ~S2_PAIR_LOG_GONE) == key64)
+			{
+				exists = (e & S2_PAIR_LOG_GONE) == 0ull;
+			}
 		}
+	}
+	if (exists && gone.keys != nullptr)
+	{
+		const int g = *gone.count;
+		for (int q = 0; q < g; ++q)
+		{
+			exists = exists && gone.keys[q] != key64;
+		}
+	}
+	if (exists)
+	{
+		return; // the contact exists (:183-188)
 	}
 	int ia = xi, ib = yi;
 	if (Y.proxyKey < X.proxyKey) // shape A has the lower proxy key (:190-200)
@@ -638,7 +667,7 @@ __global__ __launch_bounds__(S2_BLOCK) void residentPairKeysKernel(const s2amdPa
 int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShapes, const s2amdPairState* dPairs, int nc,
 					  const unsigned long long* dJointed, int jointedCount, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount, void** scratch,
 					  size_t* scratchBytes, unsigned long long* sortedPairKeys, bool* sortedPairKeysValid, PairQueryGraph* cache, int mode,
-					  const unsigned long long* goneKeys, const int* goneCount)
+					  const unsigned long long* goneKeys, const int* goneCount, const unsigned long long* pairLog)
 {
 	// mode: S2_PAIRS_FULL the whole query; S2_PAIRS_WARM buffers + captured graph, nothing runs (s2amd_world_upload); S2_PAIRS_ENQUEUE
 	// the query enqueued behind the caller's work, no wait (s2amd_world_step); S2_PAIRS_COLLECT the results of such a query, after the
@@ -649,7 +678,7 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 	{
 		shapeBits += 1;
 	}
-	const GoneKeys gone{goneKeys, goneCount, shapeBits};
+	const GoneKeys gone{goneKeys, goneCount, shapeBits, pairLog};
 	*pairCount = 0;
 	const int n = liveShapes;
 	if (n < 2)
@@ -751,7 +780,8 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 		const unsigned long long words[] = {(unsigned long long)(uintptr_t)dS, (unsigned long long)ns, (unsigned long long)n, (unsigned long long)nc,
 											(unsigned long long)(uintptr_t)dJointed, (unsigned long long)jointedCount, (unsigned long long)(uintptr_t)*scratch,
 											(unsigned long long)(uintptr_t)sortedPairKeys, (unsigned long long)outCap, (unsigned long long)tmpBytes,
-											(unsigned long long)(uintptr_t)goneKeys, (unsigned long long)(uintptr_t)goneCount, (unsigned long long)shapeBits};
+											(unsigned long long)(uintptr_t)goneKeys, (unsigned long long)(uintptr_t)goneCount, (unsigned long long)shapeBits,
+											(unsigned long long)(uintptr_t)pairLog};
 		for (unsigned long long w : words)
 		{
 			key = (key ^ w) * 1099511628211ull;

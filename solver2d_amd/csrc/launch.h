@@ -214,7 +214,8 @@ struct PairQueryGraph
 int findPairsResident(hipStream_t st, const s2amdShape* shapes, int shapeCapacity, int liveShapes, const s2amdPairState* pairs, int contactCapacity,
 					  const unsigned long long* jointed, int jointedCount, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount, void** scratch,
 					  size_t* scratchBytes, unsigned long long* sortedPairKeys, bool* sortedPairKeysValid, PairQueryGraph* cache, int mode = 0,
-					  const unsigned long long* goneKeys = nullptr, const int* goneCount = nullptr);
+					  const unsigned long long* goneKeys = nullptr, const int* goneCount = nullptr, const unsigned long long* pairLog = nullptr);
+#define S2_PAIR_LOG_ENTRIES 255 // broadphase.hip: S2_PAIR_LOG_CAPACITY
 #define S2_PAIRS_FULL 0
 #define S2_PAIRS_WARM 1
 #define S2_PAIRS_ENQUEUE 2

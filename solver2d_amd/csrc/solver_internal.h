@@ -489,6 +489,9 @@ struct SolverRest
 	long placedTotal = 0;	// created contacts placed without a rebuild, since s2amd_create
 	DevBuf dSeparated;		// world chain: the pair slots stage 3 freed this step
 	DevBuf dSeparatedKeys;	// ... and their pair keys (broadphase.hip: GoneKeys), for the pair query enqueued behind the step
+	DevBuf dPairLog;		// what happened to the pair set since the sorted key set was made: [0] entries, then keys (bit 63: destroyed)
+	unsigned long long* hostPairLog = nullptr; // ... its pinned host copy (the host appends, the device reads)
+	bool pairLogDirty = false;
 	DevBuf dShapeBoxes;		// world chain: s2amd_world_download_boxes' staging
 	DevBuf dRefitOrder, dStepBack; // s2amd_world_set_refit_order; staging of s2amd_world_download_step {count, moved boxes} and the poses
 	int refitOrderCount = 0;

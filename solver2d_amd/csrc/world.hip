@@ -391,6 +391,64 @@ int fetchPointCounts(s2amdSolver* s)
 extern "C"
 {
 
+// The pair log (broadphase.hip: GoneKeys::log): appended by the host where it learns of a change of the pair set -- the slots a step's
+// stage 3 freed, the contacts s2amd_world_set_contacts creates --, read by the pair query next to the sorted key set, which is then
+// renewed (a radix sort over every pair slot) only when the log is full instead of after every change.
+static void pairLogReset(s2amdSolver* s)
+{
+	if (s->hostPairLog)
+	{
+		s->hostPairLog[0] = 0ull;
+		s->pairLogDirty = true;
+	}
+}
+static void pairKeysStale(s2amdSolver* s)
+{
+	s->pairKeysValid = false; // (the next query sorts the keys of the pair slots as they stand then: the log starts over)
+	pairLogReset(s);
+}
+static void pairLogAppend(s2amdSolver* s, unsigned long long entry)
+{
+	if (!s->pairKeysValid)
+	{
+		return; // (a sort is due anyway)
+	}
+	if (s->hostPairLog == nullptr || s->hostPairLog[0] >= (unsigned long long)S2_PAIR_LOG_ENTRIES)
+	{
+		pairKeysStale(s);
+		return;
+	}
+	// one entry per key, ascending (the kernels search it): a key that is there takes the new state
+	unsigned long long* e = s->hostPairLog + 1;
+	const int n = (int)s->hostPairLog[0];
+	const unsigned long long gone = 1ull << 63, key = entry & ~gone;
+	int at = 0;
+	while (at < n && (e[at] & ~gone) < key)
+	{
+		at += 1;
+	}
+	if (at < n && (e[at] & ~gone) == key)
+	{
+		e[at] = entry;
+	}
+	else
+	{
+		memmove(e + at + 1, e + at, (size_t)(n - at) * sizeof(unsigned long long));
+		e[at] = entry;
+		s->hostPairLog[0] = (unsigned long long)(n + 1);
+	}
+	s->pairLogDirty = true;
+}
+static int pairLogFlush(s2amdSolver* s)
+{
+	if (s->pairLogDirty && s->hostPairLog && s->dPairLog.p)
+	{
+		HIP_TRY(hipMemcpyAsync(s->dPairLog.p, s->hostPairLog, (size_t)(1 + s->hostPairLog[0]) * sizeof(unsigned long long), hipMemcpyHostToDevice, s->stream));
+		s->pairLogDirty = false;
+	}
+	return S2AMD_OK;
+}
+
 int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapacity, const s2amdContact* contacts, int32_t contactCapacity,
 					   const s2amdJoint* joints, int32_t jointCapacity, const s2amdShape* shapes, int32_t shapeCapacity, const s2amdPairState* pairs,
 					   const float* origins)
@@ -433,13 +491,20 @@ int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapa
 		HIP_TRY(hipHostMalloc((void**)&s->hostWorldSummary, 64 * sizeof(int), hipHostMallocDefault));
 		memset(s->hostWorldSummary, 0, 64 * sizeof(int));
 	}
+	if (!s->hostPairLog)
+	{
+		HIP_TRY(hipHostMalloc((void**)&s->hostPairLog, (size_t)(S2_PAIR_LOG_ENTRIES + 1) * sizeof(unsigned long long), hipHostMallocDefault));
+	}
+	s->hostPairLog[0] = 0ull;
+	s->pairLogDirty = true;
 	const size_t sBytes = (size_t)shapeCapacity * sizeof(s2amdShape), pBytes = (size_t)contactCapacity * sizeof(s2amdPairState);
 	const size_t oBytes = (size_t)bodyCapacity * 2 * sizeof(float);
 	if ((rc = s->dShapes.ensure(std::max<size_t>(sBytes, 256))) != 0 || (rc = s->dPairs.ensure(std::max<size_t>(pBytes, 256))) != 0 ||
 		(rc = s->dOrigins.ensure(std::max<size_t>(oBytes, 256))) != 0 || (rc = s->dStatus.ensure(std::max<size_t>((size_t)contactCapacity * 4, 256))) != 0 ||
 		(rc = s->dPointBytes.ensure(std::max<size_t>((size_t)contactCapacity, 256))) != 0 || (rc = s->dWorldSummary.ensure(256)) != 0 ||
 		(rc = s->dSeparated.ensure(std::max<size_t>((size_t)contactCapacity * 4, 256))) != 0 ||
-		(rc = s->dSeparatedKeys.ensure(std::max<size_t>((size_t)contactCapacity * 8, 256))) != 0)
+		(rc = s->dSeparatedKeys.ensure(std::max<size_t>((size_t)contactCapacity * 8, 256))) != 0 ||
+		(rc = s->dPairLog.ensure((size_t)(S2_PAIR_LOG_ENTRIES + 1) * 8)) != 0)
 	{
 		return rc;
 	}
@@ -577,7 +642,7 @@ int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapa
 				(rcBuild = findPairsResident(s->stream, (const s2amdShape*)s->dShapes.p, s->shapeCapacity, s->liveShapes, (const s2amdPairState*)s->dPairs.p, s->contactCapacity,
 											 (const unsigned long long*)s->dJointedKeys.p, s->jointedCount, nullptr, 0, &none, &s->dPairScratch.p, &s->dPairScratch.bytes,
 											 (unsigned long long*)s->dPairKeys.p, &s->pairKeysValid, &s->pairQuery, S2_PAIRS_WARM,
-											 (const unsigned long long*)s->dSeparatedKeys.p, (const int*)s->dWorldSummary.p)) != 0)
+											 (const unsigned long long*)s->dSeparatedKeys.p, (const int*)s->dWorldSummary.p, (const unsigned long long*)s->dPairLog.p)) != 0)
 			{
 				return rcBuild;
 			}
@@ -734,11 +799,11 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 		if (s->optPairsInStep != 0 && s->pairQueryUsed && fallbacks == 0 && nearRetries == 0 && s->liveShapes >= 2)
 		{
 			int32_t none = 0;
-			if ((rc = s->dPairKeys.ensure(std::max<size_t>((size_t)s->contactCapacity * 8, 256))) != 0 ||
+			if ((rc = s->dPairKeys.ensure(std::max<size_t>((size_t)s->contactCapacity * 8, 256))) != 0 || (rc = pairLogFlush(s)) != 0 ||
 				(rc = findPairsResident(st, (const s2amdShape*)s->dShapes.p, s->shapeCapacity, s->liveShapes, (const s2amdPairState*)s->dPairs.p, s->contactCapacity,
 										(const unsigned long long*)s->dJointedKeys.p, s->jointedCount, nullptr, 0, &none, &s->dPairScratch.p, &s->dPairScratch.bytes,
 										(unsigned long long*)s->dPairKeys.p, &s->pairKeysValid, &s->pairQuery, S2_PAIRS_ENQUEUE,
-										(const unsigned long long*)s->dSeparatedKeys.p, (const int*)dSum)) != 0)
+										(const unsigned long long*)s->dSeparatedKeys.p, (const int*)dSum, (const unsigned long long*)s->dPairLog.p)) != 0)
 			{
 				return rc;
 			}
@@ -809,13 +874,19 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 	WorldSummary contactsSeen = haveFirst ? firstSeen : *hSum;
 	if (contactsSeen.separated > 0)
 	{
-		s->pairKeysValid = false; // pair slots were freed on the device
+		// pair slots were freed on the device: their keys go into the pair log (the sorted key set still holds them)
+		std::vector<unsigned long long> goneKeys((size_t)contactsSeen.separated);
+		HIP_TRY(hipMemcpyAsync(goneKeys.data(), s->dSeparatedKeys.p, goneKeys.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
 		// which ones: the caller needs them for its own s2DestroyContact (s2amd_world_separated), and their entries leave the
 		// structure now where they can (solver_incremental.cpp), as a host that ran stage 3 itself would see them gone from
 		// the arrays of its next upload
 		s->hSeparated.resize((size_t)contactsSeen.separated);
 		HIP_TRY(hipMemcpyAsync(s->hSeparated.data(), s->dSeparated.p, s->hSeparated.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
+		for (unsigned long long k : goneKeys)
+		{
+			pairLogAppend(s, k | (1ull << 63));
+		}
 		std::sort(s->hSeparated.begin(), s->hSeparated.end());
 		for (int32_t slot : s->hSeparated)
 		{
@@ -875,10 +946,15 @@ int s2amd_world_find_pairs(s2amdSolver* s, int32_t* outPairs, int32_t pairCapaci
 	// or the step was repeated: then it runs now)
 	const bool collect = s->pairCacheValid;
 	s->pairQueryUsed = true;
-	int rc = findPairsResident(s->stream, (const s2amdShape*)s->dShapes.p, s->shapeCapacity, s->liveShapes, (const s2amdPairState*)s->dPairs.p, s->contactCapacity,
+	int rc = collect ? S2AMD_OK : pairLogFlush(s);
+	if (rc)
+	{
+		return rc;
+	}
+	rc = findPairsResident(s->stream, (const s2amdShape*)s->dShapes.p, s->shapeCapacity, s->liveShapes, (const s2amdPairState*)s->dPairs.p, s->contactCapacity,
 							   (const unsigned long long*)s->dJointedKeys.p, s->jointedCount, outPairs, pairCapacity, pairCount, &s->dPairScratch.p,
 							   &s->dPairScratch.bytes, (unsigned long long*)s->dPairKeys.p, &s->pairKeysValid, &s->pairQuery, collect ? S2_PAIRS_COLLECT : S2_PAIRS_FULL,
-							   (const unsigned long long*)s->dSeparatedKeys.p, (const int*)s->dWorldSummary.p);
+							   (const unsigned long long*)s->dSeparatedKeys.p, (const int*)s->dWorldSummary.p, (const unsigned long long*)s->dPairLog.p);
 	if (rc == S2AMD_OK)
 	{
 		s->pairCacheValid = false; // (collected once: the move flags go below, as after a query of this call's own)
@@ -1111,7 +1187,22 @@ int s2amd_world_set_contacts(s2amdSolver* s, const int32_t* slots, int32_t count
 																			  (s2amdPairState*)s->dPairs.p, (uint8_t*)s->dPointBytes.p, (int32_t*)s->dStatus.p);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipStreamSynchronize(st));
-	s->pairKeysValid = false;
+	// the pair set changed: a contact created in a slot that held no live pair goes into the pair log; anything else (a pair taken
+	// away or replaced by the caller: its old key is the device's to know) has the key set sorted again
+	for (int i = 0; i < count; ++i)
+	{
+		const int k = slots[i];
+		const bool wasLive = k < (int)s->hContactEdge.size() && s->hContactEdge[(size_t)k] && !s->hContactDead[(size_t)k];
+		if (pairs[i].shapeA >= 0 && pairs[i].shapeB >= 0 && !wasLive)
+		{
+			const unsigned long long a = (unsigned long long)std::min(pairs[i].shapeA, pairs[i].shapeB), b = (unsigned long long)std::max(pairs[i].shapeA, pairs[i].shapeB);
+			pairLogAppend(s, (a << 32) | b);
+		}
+		else
+		{
+			pairKeysStale(s);
+		}
+	}
 	s->pairCacheValid = false; // (a query enqueued behind the last step did not know this contact)
 	// host shadows of the constraint graph (solver_step.cpp: refreshShadows): a slot is a potential constraint while its
 	// pair is live, whatever its manifold holds.  Created contacts get a place in the existing structure when they fit

@@ -289,6 +289,25 @@ S2_DEV bool containsKey(const unsigned long long* keys, int n, unsigned long lon
 	return lo < n && keys[lo] == key;
 }
 
+// ... and where (-1: nowhere)
+S2_DEV int findKey(const unsigned long long* keys, int n, unsigned long long key)
+{
+	int lo = 0, hi = n;
+	while (lo < hi)
+	{
+		int mid = (lo + hi) >> 1;
+		if (keys[mid] < key)
+		{
+			lo = mid + 1;
+		}
+		else
+		{
+			hi = mid;
+		}
+	}
+	return lo < n && keys[lo] == key ? lo : -1;
+}
+
 // does proxy P (moved) report the pair when its tree query meets Q?  src/broad_phase.c:166-181, :283-298
 S2_DEV bool reports(const s2amdShape& P, bool movedP, const s2amdShape& Q, bool movedQ)
 {
@@ -312,23 +331,24 @@ S2_DEV bool reports(const s2amdShape& P, bool movedP, const s2amdShape& Q, bool 
 	return true;
 }
 
-// The pairs stage 3 destroyed in THIS step (narrowphase.hip: updateContactsKernel writes their keys; count = the step's separated
-// counter): the sorted key set of the live pairs is the host's to renew and still holds them while the query runs inside the step
-// (world.hip) -- a pair in both lists is not "existing".
-struct GoneKeys
+// The resident world's pair set as the query sees it (world.hip): `existing` -- the keys of every pair slot as they stood at the last
+// sort, ascending -- is only a directory now.  An entry names the SLOT it came from, and "the contact exists" means that slot holds that
+// pair NOW: a pair stage 3 has destroyed since (this step's, read behind the same launch sequence, or an earlier one's) fails the
+// test without anybody having told the query.  Pairs created since the sort wait in a second, small directory the host keeps (`log`:
+// [0] = entries, then keys ascending; `logSlots` their slots).  The big directory is sorted again -- a radix sort over every pair
+// slot -- only when the small one is full.  All pointers null: `existing` is a plain key set (the host-array route).
+struct PairSetView
 {
-	const unsigned long long* keys = nullptr;
-	const int* count = nullptr;
-	// (rides along: the sorted key set of the resident query holds COMPACT keys, (min shape << shapeBits) | max shape -- half the radix
-	// passes of the 64-bit form when the set is sorted again; 0: the 64-bit form (min << 32) | max)
-	int shapeBits = 0;
-	// ... and what happened to the pair set SINCE that sort (world.hip keeps it: a created contact, a pair an earlier step destroyed):
-	// log[0] = entries, then one 64-bit key per pair that changed, ascending, bit 63 set = destroyed now.  An entry overrides the
-	// sorted set; that set is renewed -- a radix sort of every pair slot's key -- only when the log is full.
+	const int* sortedSlots = nullptr;
 	const unsigned long long* log = nullptr;
+	const int* logSlots = nullptr;
+	const s2amdPairState* pairs = nullptr;
+	// (the sorted directory holds COMPACT keys, (min shape << shapeBits) | max shape: half the radix passes of the 64-bit form when it
+	// is sorted again; 0: the 64-bit form (min << 32) | max)
+	int shapeBits = 0;
 };
 #define S2_PAIR_LOG_CAPACITY 255
-#define S2_PAIR_LOG_GONE (1ull << 63)
+typedef PairSetView GoneKeys;
 S2_DEV void pairTest(int xi, int yi, const s2amdShape* shapes, const unsigned char* moved, const unsigned long long* existing, int existingCount,
 					 const unsigned long long* jointed, int jointedCount, unsigned long long* outKeys, unsigned int outCapacity, unsigned int* outCount,
 					 GoneKeys gone = GoneKeys{});
@@ -375,39 +395,19 @@ S2_DEV void pairTest(int xi, int yi, const s2amdShape* shapes, const unsigned ch
 	}
 	unsigned int slo = (unsigned int)(xi < yi ? xi : yi), shi = (unsigned int)(xi < yi ? yi : xi);
 	const unsigned long long key64 = ((unsigned long long)slo << 32) | shi;
-	bool exists = containsKey(existing, existingCount, gone.shapeBits > 0 ? (((unsigned long long)slo << gone.shapeBits) | shi) : key64);
-	if (gone.log != nullptr)
+	auto holds = [&](int slot) {
+		const int pa = gone.pairs[slot].shapeA, pb = gone.pairs[slot].shapeB;
+		return pa >= 0 && (unsigned int)(pa < pb ? pa : pb) == slo && (unsigned int)(pa < pb ? pb : pa) == shi;
+	};
+	bool exists = false;
 	{
-		// (sorted by key, one entry per key: its state now)
-		int lo = 1, hi = (int)gone.log[0] + 1;
-		while (lo < hi)
-		{
-			const int mid = (lo + hi) >> 1;
-			if ((gone.log[mid] & ~S2_PAIR_LOG_GONE) < key64)
-			{
-				lo = mid + 1;
-			}
-			else
-			{
-				hi = mid;
-			}
-		}
-		if (lo <= (int)gone.log[0])
-		{
-			const unsigned long long e = gone.log[lo];
-			if ((e & ~S2_PAIR_LOG_GONE) == key64)
-			{
-				exists = (e & S2_PAIR_LOG_GONE) == 0ull;
-			}
-		}
+		const int at = findKey(existing, existingCount, gone.shapeBits > 0 ? (((unsigned long long)slo << gone.shapeBits) | shi) : key64);
+		exists = at >= 0 && (gone.sortedSlots == nullptr || holds(gone.sortedSlots[at]));
 	}
-	if (exists && gone.keys != nullptr)
+	if (!exists && gone.log != nullptr)
 	{
-		const int g = *gone.count;
-		for (int q = 0; q < g; ++q)
-		{
-			exists = exists && gone.keys[q] != key64;
-		}
+		const int at = findKey(gone.log + 1, (int)gone.log[0], key64);
+		exists = at >= 0 && holds(gone.logSlots[at]);
 	}
 	if (exists)
 	{
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(S2_BLOCK) void residentShapeKeysKernel(const s2amdS
 }
 
 // (min shape, max shape) of every live pair slot; free slots sort last and match nothing
-__global__ __launch_bounds__(S2_BLOCK) void residentPairKeysKernel(const s2amdPairState* pairs, int nc, unsigned long long* keys, int shapeBits)
+__global__ __launch_bounds__(S2_BLOCK) void residentPairKeysKernel(const s2amdPairState* pairs, int nc, unsigned long long* keys, int* slots, int shapeBits)
 {
 	int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= nc)
@@ -662,12 +662,13 @@ __global__ __launch_bounds__(S2_BLOCK) void residentPairKeysKernel(const s2amdPa
 		key = ((unsigned long long)(a < b ? a : b) << shapeBits) | (a < b ? b : a);
 	}
 	keys[i] = key;
+	slots[i] = i;
 }
 
 int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShapes, const s2amdPairState* dPairs, int nc,
 					  const unsigned long long* dJointed, int jointedCount, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount, void** scratch,
 					  size_t* scratchBytes, unsigned long long* sortedPairKeys, bool* sortedPairKeysValid, PairQueryGraph* cache, int mode,
-					  const unsigned long long* goneKeys, const int* goneCount, const unsigned long long* pairLog)
+					  const unsigned long long* pairLog, const int* pairLogSlots)
 {
 	// mode: S2_PAIRS_FULL the whole query; S2_PAIRS_WARM buffers + captured graph, nothing runs (s2amd_world_upload); S2_PAIRS_ENQUEUE
 	// the query enqueued behind the caller's work, no wait (s2amd_world_step); S2_PAIRS_COLLECT the results of such a query, after the
@@ -678,7 +679,8 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 	{
 		shapeBits += 1;
 	}
-	const GoneKeys gone{goneKeys, goneCount, shapeBits, pairLog};
+	int* sortedPairSlots = (int*)(sortedPairKeys + nc); // (the caller's buffer: nc keys, then nc slots)
+	const PairSetView gone{sortedPairSlots, pairLog, pairLogSlots, dPairs, shapeBits};
 	*pairCount = 0;
 	const int n = liveShapes;
 	if (n < 2)
@@ -692,7 +694,7 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 	// (the device-side pair buffer is sized by the pool, not by the caller's buffer: the captured graph below depends on it, and
 	// s2amd_world_upload captures that graph before any caller has shown its buffer)
 	size_t outCap = (size_t)std::max(nc, 1024);
-	BP_TRY(rocprim::radix_sort_keys(nullptr, tmpKeys, (unsigned long long*)nullptr, (unsigned long long*)nullptr, std::max((size_t)nc, outCap), 0, 64, st));
+	BP_TRY(rocprim::radix_sort_pairs(nullptr, tmpKeys, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (int*)nullptr, (int*)nullptr, std::max((size_t)nc, outCap), 0, 64, st));
 	size_t tmpBytes = std::max(std::max(tmpSort, tmpScan), tmpKeys);
 	size_t layout[] = {al((size_t)ns), al((size_t)ns * 4), al((size_t)ns * 4), al((size_t)ns * 4), al((size_t)ns * 4), al((size_t)n * 4),
 					   al(((size_t)n + 1) * 4), al(((size_t)n + 1) * 4), al((size_t)nc * 8 + 8), al((size_t)nc * 8 + 8), al(outCap * 8), al(outCap * 8), al(256),
@@ -735,7 +737,7 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 	unsigned long long* dOutB = (unsigned long long*)take();
 	unsigned int* dCount = (unsigned int*)take();
 	void* dTmp = take();
-	(void)dExisting; // the sorted pair keys live in the caller's buffer
+	int* dSlotsIn = (int*)dExisting; // (the sorted pair keys -- and their slots -- live in the caller's buffer: this block holds the unsorted slots)
 	(void)dOutB;
 
 	// the sorted keys of the live pairs only change when a contact is created or destroyed: the caller keeps them
@@ -744,8 +746,8 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 	{
 		// (compact keys: 2 x shapeBits significant bits -- 30 at 20k shapes: four radix passes where the 64-bit form took eight; a free
 		// slot's key, all ones, sorts behind every live one on those bits too)
-		residentPairKeysKernel<<<gridFor((size_t)nc), dim3(S2_BLOCK), 0, st>>>(dPairs, nc, dExistingIn, shapeBits);
-		BP_TRY(rocprim::radix_sort_keys(dTmp, tmp, dExistingIn, sortedPairKeys, (size_t)nc, 0, (unsigned int)std::min(2 * shapeBits, 64), st));
+		residentPairKeysKernel<<<gridFor((size_t)nc), dim3(S2_BLOCK), 0, st>>>(dPairs, nc, dExistingIn, dSlotsIn, shapeBits);
+		BP_TRY(rocprim::radix_sort_pairs(dTmp, tmp, dExistingIn, sortedPairKeys, dSlotsIn, sortedPairSlots, (size_t)nc, 0, (unsigned int)std::min(2 * shapeBits, 64), st));
 		*sortedPairKeysValid = true;
 	}
 	constexpr unsigned int kFirst = 2048;
@@ -780,8 +782,7 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 		const unsigned long long words[] = {(unsigned long long)(uintptr_t)dS, (unsigned long long)ns, (unsigned long long)n, (unsigned long long)nc,
 											(unsigned long long)(uintptr_t)dJointed, (unsigned long long)jointedCount, (unsigned long long)(uintptr_t)*scratch,
 											(unsigned long long)(uintptr_t)sortedPairKeys, (unsigned long long)outCap, (unsigned long long)tmpBytes,
-											(unsigned long long)(uintptr_t)goneKeys, (unsigned long long)(uintptr_t)goneCount, (unsigned long long)shapeBits,
-											(unsigned long long)(uintptr_t)pairLog};
+											(unsigned long long)shapeBits, (unsigned long long)(uintptr_t)pairLog, (unsigned long long)(uintptr_t)pairLogSlots, (unsigned long long)(uintptr_t)dPairs};
 		for (unsigned long long w : words)
 		{
 			key = (key ^ w) * 1099511628211ull;

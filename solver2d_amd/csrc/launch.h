@@ -198,8 +198,7 @@ void launchGenericStep(hipStream_t s, const ContactView& c, const JointView& j, 
 // stage kernels on resident arrays (narrowphase.hip, broadphase.hip; called by world.hip)
 // summary: int[5] {separated pairs, active manifolds, zero/non-zero flips, point-count moves, enlarged shapes} (world.hip: WorldSummary)
 void launchUpdateContacts(hipStream_t st, const s2amdBody* bodies, const float* origins, const s2amdShape* shapes, s2amdPairState* pairs,
-						  s2amdContact* contacts, int contactCapacity, int32_t* status, uint8_t* pointBytes, int* summary, int* separatedSlots, const uint8_t* watched,
-						  unsigned long long* separatedKeys);
+						  s2amdContact* contacts, int contactCapacity, int32_t* status, uint8_t* pointBytes, int* summary, int* separatedSlots, const uint8_t* watched);
 // stage 4 in one launch: refit per shape (origin recomputed from the body), origins + force reset per body, summary[4] += enlarged shapes
 void launchStage4(hipStream_t st, s2amdBody* bodies, int bodyCapacity, s2amdShape* shapes, int shapeCapacity, float* origins, int* summary);
 // stage 1 on resident arrays: new pairs sorted by (A, B) into the host array outPairs; dJointed: sorted (min body << 32 | max body) keys
@@ -214,7 +213,7 @@ struct PairQueryGraph
 int findPairsResident(hipStream_t st, const s2amdShape* shapes, int shapeCapacity, int liveShapes, const s2amdPairState* pairs, int contactCapacity,
 					  const unsigned long long* jointed, int jointedCount, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount, void** scratch,
 					  size_t* scratchBytes, unsigned long long* sortedPairKeys, bool* sortedPairKeysValid, PairQueryGraph* cache, int mode = 0,
-					  const unsigned long long* goneKeys = nullptr, const int* goneCount = nullptr, const unsigned long long* pairLog = nullptr);
+					  const unsigned long long* pairLog = nullptr, const int* pairLogSlots = nullptr);
 #define S2_PAIR_LOG_ENTRIES 255 // broadphase.hip: S2_PAIR_LOG_CAPACITY
 #define S2_PAIRS_FULL 0
 #define S2_PAIRS_WARM 1

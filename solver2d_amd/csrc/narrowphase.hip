@@ -897,7 +897,7 @@ S2_DEV int updateContactOne(const s2amdBody* bodies, const float2* origins, cons
 template <bool SUMMARY>
 __global__ __launch_bounds__(S2_NP_BLOCK) void updateContactsKernel(const s2amdBody* bodies, const float2* origins, const s2amdShape* shapes,
 																	 s2amdPairState* pairs, s2amdContact* contacts, int contactCapacity, int32_t* status,
-																	 uint8_t* pointBytes, int* summary, int* separatedSlots, const uint8_t* watched, unsigned long long* separatedKeys)
+																	 uint8_t* pointBytes, int* summary, int* separatedSlots, const uint8_t* watched)
 {
 	__shared__ float2 lds[4 * S2_NP_MAX_VERTS * S2_NP_BLOCK]; // vertsA, normsA, vertsB, normsB: 32 KiB
 	int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -911,16 +911,9 @@ __global__ __launch_bounds__(S2_NP_BLOCK) void updateContactsKernel(const s2amdB
 			if (st == S2AMD_PAIR_SEPARATED)
 			{
 				contacts[i].pointCount = 0;
-				const unsigned int a = (unsigned int)pairs[i].shapeA, b = (unsigned int)pairs[i].shapeB;
 				pairs[i].shapeA = -1;
 				pairs[i].shapeB = -1;
-				const int at = atomicAdd(summary + 0, 1);
-				separatedSlots[at] = i; // the caller's s2DestroyContact list (s2amd_world_separated)
-				if (separatedKeys != nullptr)
-				{
-					// ... and the pair's key for a pair query enqueued behind this step (broadphase.hip: GoneKeys)
-					separatedKeys[at] = ((unsigned long long)(a < b ? a : b) << 32) | (a < b ? b : a);
-				}
+				separatedSlots[atomicAdd(summary + 0, 1)] = i; // the caller's s2DestroyContact list (s2amd_world_separated)
 			}
 			else
 			{
@@ -979,8 +972,7 @@ struct Scratch
 
 // resident arrays (world.hip)
 void launchUpdateContacts(hipStream_t st, const s2amdBody* bodies, const float* origins, const s2amdShape* shapes, s2amdPairState* pairs,
-						  s2amdContact* contacts, int contactCapacity, int32_t* status, uint8_t* pointBytes, int* summary, int* separatedSlots, const uint8_t* watched,
-						  unsigned long long* separatedKeys)
+						  s2amdContact* contacts, int contactCapacity, int32_t* status, uint8_t* pointBytes, int* summary, int* separatedSlots, const uint8_t* watched)
 {
 	if (contactCapacity <= 0)
 	{
@@ -988,7 +980,7 @@ void launchUpdateContacts(hipStream_t st, const s2amdBody* bodies, const float* 
 	}
 	dim3 grid((unsigned)((contactCapacity + S2_NP_BLOCK - 1) / S2_NP_BLOCK));
 	updateContactsKernel<true><<<grid, dim3(S2_NP_BLOCK), 0, st>>>(bodies, (const float2*)origins, shapes, pairs, contacts, contactCapacity, status,
-																   pointBytes, summary, separatedSlots, watched, separatedKeys);
+																   pointBytes, summary, separatedSlots, watched);
 }
 
 #pragma GCC visibility push(default)
@@ -1045,7 +1037,7 @@ int s2amd_update_contacts(s2amdSolver* solver, const s2amdBody* bodies, int32_t 
 	NP_TRY(hipEventCreate(&e0));
 	NP_TRY(hipEventCreate(&e1));
 	NP_TRY(hipEventRecord(e0, st));
-	updateContactsKernel<false><<<grid, dim3(S2_NP_BLOCK), 0, st>>>(dB, dO, dS, dP, dC, contactCapacity, dT, nullptr, nullptr, nullptr, nullptr, nullptr);
+	updateContactsKernel<false><<<grid, dim3(S2_NP_BLOCK), 0, st>>>(dB, dO, dS, dP, dC, contactCapacity, dT, nullptr, nullptr, nullptr, nullptr);
 	NP_TRY(hipEventRecord(e1, st));
 	NP_TRY(hipGetLastError());
 	NP_TRY(hipMemcpyAsync(pairs, dP, pBytes, hipMemcpyDeviceToHost, st));

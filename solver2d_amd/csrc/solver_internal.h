@@ -488,8 +488,7 @@ struct SolverRest
 	DevBuf dOps; // the plan's op list (solver_step.cpp: doStep)
 	long placedTotal = 0;	// created contacts placed without a rebuild, since s2amd_create
 	DevBuf dSeparated;		// world chain: the pair slots stage 3 freed this step
-	DevBuf dSeparatedKeys;	// ... and their pair keys (broadphase.hip: GoneKeys), for the pair query enqueued behind the step
-	DevBuf dPairLog;		// what happened to the pair set since the sorted key set was made: [0] entries, then keys (bit 63: destroyed)
+	DevBuf dPairLog;		// the pairs created since the sorted directory of the pair set was made: [0] entries, keys ascending, then their slots (broadphase.hip: PairSetView)
 	unsigned long long* hostPairLog = nullptr; // ... its pinned host copy (the host appends, the device reads)
 	bool pairLogDirty = false;
 	DevBuf dShapeBoxes;		// world chain: s2amd_world_download_boxes' staging

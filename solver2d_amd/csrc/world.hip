@@ -391,9 +391,9 @@ int fetchPointCounts(s2amdSolver* s)
 extern "C"
 {
 
-// The pair log (broadphase.hip: GoneKeys::log): appended by the host where it learns of a change of the pair set -- the slots a step's
-// stage 3 freed, the contacts s2amd_world_set_contacts creates --, read by the pair query next to the sorted key set, which is then
-// renewed (a radix sort over every pair slot) only when the log is full instead of after every change.
+// The small directory of the pair set (broadphase.hip: PairSetView::log): the contacts s2amd_world_set_contacts has created since the big
+// one was sorted -- [0] = entries, keys ascending, then (behind S2_PAIR_LOG_ENTRIES + 1 keys) their slots --, kept by the host, read by
+// the pair query.  Destroyed pairs need no entry anywhere: the query checks what a directory entry's slot holds now.
 static void pairLogReset(s2amdSolver* s)
 {
 	if (s->hostPairLog)
@@ -404,10 +404,10 @@ static void pairLogReset(s2amdSolver* s)
 }
 static void pairKeysStale(s2amdSolver* s)
 {
-	s->pairKeysValid = false; // (the next query sorts the keys of the pair slots as they stand then: the log starts over)
+	s->pairKeysValid = false; // (the next query sorts the keys of the pair slots as they stand then: the small directory starts over)
 	pairLogReset(s);
 }
-static void pairLogAppend(s2amdSolver* s, unsigned long long entry)
+static void pairLogAppend(s2amdSolver* s, unsigned long long key, int slot)
 {
 	if (!s->pairKeysValid)
 	{
@@ -418,32 +418,31 @@ static void pairLogAppend(s2amdSolver* s, unsigned long long entry)
 		pairKeysStale(s);
 		return;
 	}
-	// one entry per key, ascending (the kernels search it): a key that is there takes the new state
+	// one entry per key, ascending (the kernels search it): a key that is there -- the pair was created, destroyed and created again --
+	// takes the new slot
 	unsigned long long* e = s->hostPairLog + 1;
+	int* slots = (int*)(s->hostPairLog + S2_PAIR_LOG_ENTRIES + 1);
 	const int n = (int)s->hostPairLog[0];
-	const unsigned long long gone = 1ull << 63, key = entry & ~gone;
 	int at = 0;
-	while (at < n && (e[at] & ~gone) < key)
+	while (at < n && e[at] < key)
 	{
 		at += 1;
 	}
-	if (at < n && (e[at] & ~gone) == key)
-	{
-		e[at] = entry;
-	}
-	else
+	if (!(at < n && e[at] == key))
 	{
 		memmove(e + at + 1, e + at, (size_t)(n - at) * sizeof(unsigned long long));
-		e[at] = entry;
+		memmove(slots + at + 1, slots + at, (size_t)(n - at) * sizeof(int));
 		s->hostPairLog[0] = (unsigned long long)(n + 1);
 	}
+	e[at] = key;
+	slots[at] = slot;
 	s->pairLogDirty = true;
 }
 static int pairLogFlush(s2amdSolver* s)
 {
 	if (s->pairLogDirty && s->hostPairLog && s->dPairLog.p)
 	{
-		HIP_TRY(hipMemcpyAsync(s->dPairLog.p, s->hostPairLog, (size_t)(1 + s->hostPairLog[0]) * sizeof(unsigned long long), hipMemcpyHostToDevice, s->stream));
+		HIP_TRY(hipMemcpyAsync(s->dPairLog.p, s->hostPairLog, (size_t)(S2_PAIR_LOG_ENTRIES + 1) * 12, hipMemcpyHostToDevice, s->stream));
 		s->pairLogDirty = false;
 	}
 	return S2AMD_OK;
@@ -493,7 +492,7 @@ int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapa
 	}
 	if (!s->hostPairLog)
 	{
-		HIP_TRY(hipHostMalloc((void**)&s->hostPairLog, (size_t)(S2_PAIR_LOG_ENTRIES + 1) * sizeof(unsigned long long), hipHostMallocDefault));
+		HIP_TRY(hipHostMalloc((void**)&s->hostPairLog, (size_t)(S2_PAIR_LOG_ENTRIES + 1) * 12, hipHostMallocDefault));
 	}
 	s->hostPairLog[0] = 0ull;
 	s->pairLogDirty = true;
@@ -503,8 +502,7 @@ int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapa
 		(rc = s->dOrigins.ensure(std::max<size_t>(oBytes, 256))) != 0 || (rc = s->dStatus.ensure(std::max<size_t>((size_t)contactCapacity * 4, 256))) != 0 ||
 		(rc = s->dPointBytes.ensure(std::max<size_t>((size_t)contactCapacity, 256))) != 0 || (rc = s->dWorldSummary.ensure(256)) != 0 ||
 		(rc = s->dSeparated.ensure(std::max<size_t>((size_t)contactCapacity * 4, 256))) != 0 ||
-		(rc = s->dSeparatedKeys.ensure(std::max<size_t>((size_t)contactCapacity * 8, 256))) != 0 ||
-		(rc = s->dPairLog.ensure((size_t)(S2_PAIR_LOG_ENTRIES + 1) * 8)) != 0)
+		(rc = s->dPairLog.ensure((size_t)(S2_PAIR_LOG_ENTRIES + 1) * 12)) != 0)
 	{
 		return rc;
 	}
@@ -638,11 +636,11 @@ int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapa
 		if (s->liveShapes >= 2)
 		{
 			int32_t none = 0;
-			if ((rcBuild = s->dPairKeys.ensure(std::max<size_t>((size_t)s->contactCapacity * 8, 256))) != 0 ||
+			if ((rcBuild = s->dPairKeys.ensure(std::max<size_t>((size_t)s->contactCapacity * 12, 256))) != 0 ||
 				(rcBuild = findPairsResident(s->stream, (const s2amdShape*)s->dShapes.p, s->shapeCapacity, s->liveShapes, (const s2amdPairState*)s->dPairs.p, s->contactCapacity,
 											 (const unsigned long long*)s->dJointedKeys.p, s->jointedCount, nullptr, 0, &none, &s->dPairScratch.p, &s->dPairScratch.bytes,
 											 (unsigned long long*)s->dPairKeys.p, &s->pairKeysValid, &s->pairQuery, S2_PAIRS_WARM,
-											 (const unsigned long long*)s->dSeparatedKeys.p, (const int*)s->dWorldSummary.p, (const unsigned long long*)s->dPairLog.p)) != 0)
+											 (const unsigned long long*)s->dPairLog.p, (const int*)((const unsigned long long*)s->dPairLog.p + S2_PAIR_LOG_ENTRIES + 1))) != 0)
 			{
 				return rcBuild;
 			}
@@ -691,8 +689,7 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 		// (the kernel also destroys separated pairs and accumulates the step's contact counters)
 		launchUpdateContacts(st, (const s2amdBody*)s->dBodies.p, (const float*)s->dOrigins.p, (const s2amdShape*)s->dShapes.p,
 							 (s2amdPairState*)s->dPairs.p, (s2amdContact*)s->dContacts.p, nc, (int32_t*)s->dStatus.p, (uint8_t*)s->dPointBytes.p,
-							 (int*)dSum, (int*)s->dSeparated.p, s->watchedCount > 0 && !s->structureDirty ? (const uint8_t*)s->dWatched.p : nullptr,
-							 (unsigned long long*)s->dSeparatedKeys.p);
+							 (int*)dSum, (int*)s->dSeparated.p, s->watchedCount > 0 && !s->structureDirty ? (const uint8_t*)s->dWatched.p : nullptr);
 	}
 	s->pointsKnown = false; // the manifolds are the device's now
 	s->pointCountsFresh = false;
@@ -793,17 +790,17 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 		}
 		// Stage 1 of the NEXT step behind stage 4 of this one: the pair query reads what the refit just wrote (the re-inflated fat boxes,
 		// the move flags) and its results come back with this step's counters -- s2amd_world_find_pairs then costs no device round trip.
-		// Pairs this step's stage 3 destroyed are still in the sorted key set (the host renews it): the kernels take them out by their
-		// keys (dSeparatedKeys, summary[0]: read before the counters are reset below).  Not in a step that is being repeated.
+		// Pairs this step's stage 3 destroyed are still in the sorted directory of the pair set: the kernels check what a directory entry's
+		// slot holds now (broadphase.hip: PairSetView).  Not in a step that is being repeated.
 		s->pairCacheValid = false;
 		if (s->optPairsInStep != 0 && s->pairQueryUsed && fallbacks == 0 && nearRetries == 0 && s->liveShapes >= 2)
 		{
 			int32_t none = 0;
-			if ((rc = s->dPairKeys.ensure(std::max<size_t>((size_t)s->contactCapacity * 8, 256))) != 0 || (rc = pairLogFlush(s)) != 0 ||
+			if ((rc = s->dPairKeys.ensure(std::max<size_t>((size_t)s->contactCapacity * 12, 256))) != 0 || (rc = pairLogFlush(s)) != 0 ||
 				(rc = findPairsResident(st, (const s2amdShape*)s->dShapes.p, s->shapeCapacity, s->liveShapes, (const s2amdPairState*)s->dPairs.p, s->contactCapacity,
 										(const unsigned long long*)s->dJointedKeys.p, s->jointedCount, nullptr, 0, &none, &s->dPairScratch.p, &s->dPairScratch.bytes,
 										(unsigned long long*)s->dPairKeys.p, &s->pairKeysValid, &s->pairQuery, S2_PAIRS_ENQUEUE,
-										(const unsigned long long*)s->dSeparatedKeys.p, (const int*)dSum, (const unsigned long long*)s->dPairLog.p)) != 0)
+										(const unsigned long long*)s->dPairLog.p, (const int*)((const unsigned long long*)s->dPairLog.p + S2_PAIR_LOG_ENTRIES + 1))) != 0)
 			{
 				return rc;
 			}
@@ -874,19 +871,13 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 	WorldSummary contactsSeen = haveFirst ? firstSeen : *hSum;
 	if (contactsSeen.separated > 0)
 	{
-		// pair slots were freed on the device: their keys go into the pair log (the sorted key set still holds them)
-		std::vector<unsigned long long> goneKeys((size_t)contactsSeen.separated);
-		HIP_TRY(hipMemcpyAsync(goneKeys.data(), s->dSeparatedKeys.p, goneKeys.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+		// (pair slots were freed on the device: the pair query sees that in the slots themselves -- broadphase.hip: PairSetView)
 		// which ones: the caller needs them for its own s2DestroyContact (s2amd_world_separated), and their entries leave the
 		// structure now where they can (solver_incremental.cpp), as a host that ran stage 3 itself would see them gone from
 		// the arrays of its next upload
 		s->hSeparated.resize((size_t)contactsSeen.separated);
 		HIP_TRY(hipMemcpyAsync(s->hSeparated.data(), s->dSeparated.p, s->hSeparated.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
-		for (unsigned long long k : goneKeys)
-		{
-			pairLogAppend(s, k | (1ull << 63));
-		}
 		std::sort(s->hSeparated.begin(), s->hSeparated.end());
 		for (int32_t slot : s->hSeparated)
 		{
@@ -936,7 +927,7 @@ int s2amd_world_find_pairs(s2amdSolver* s, int32_t* outPairs, int32_t pairCapaci
 	}
 	HIP_TRY(hipSetDevice(s->device));
 	{
-		int rc = s->dPairKeys.ensure(std::max<size_t>((size_t)s->contactCapacity * 8, 256));
+		int rc = s->dPairKeys.ensure(std::max<size_t>((size_t)s->contactCapacity * 12, 256));
 		if (rc)
 		{
 			return rc;
@@ -954,7 +945,7 @@ int s2amd_world_find_pairs(s2amdSolver* s, int32_t* outPairs, int32_t pairCapaci
 	rc = findPairsResident(s->stream, (const s2amdShape*)s->dShapes.p, s->shapeCapacity, s->liveShapes, (const s2amdPairState*)s->dPairs.p, s->contactCapacity,
 							   (const unsigned long long*)s->dJointedKeys.p, s->jointedCount, outPairs, pairCapacity, pairCount, &s->dPairScratch.p,
 							   &s->dPairScratch.bytes, (unsigned long long*)s->dPairKeys.p, &s->pairKeysValid, &s->pairQuery, collect ? S2_PAIRS_COLLECT : S2_PAIRS_FULL,
-							   (const unsigned long long*)s->dSeparatedKeys.p, (const int*)s->dWorldSummary.p, (const unsigned long long*)s->dPairLog.p);
+							   (const unsigned long long*)s->dPairLog.p, (const int*)((const unsigned long long*)s->dPairLog.p + S2_PAIR_LOG_ENTRIES + 1));
 	if (rc == S2AMD_OK)
 	{
 		s->pairCacheValid = false; // (collected once: the move flags go below, as after a query of this call's own)
@@ -1196,7 +1187,7 @@ int s2amd_world_set_contacts(s2amdSolver* s, const int32_t* slots, int32_t count
 		if (pairs[i].shapeA >= 0 && pairs[i].shapeB >= 0 && !wasLive)
 		{
 			const unsigned long long a = (unsigned long long)std::min(pairs[i].shapeA, pairs[i].shapeB), b = (unsigned long long)std::max(pairs[i].shapeA, pairs[i].shapeB);
-			pairLogAppend(s, (a << 32) | b);
+			pairLogAppend(s, (a << 32) | b, k);
 		}
 		else
 		{

@@ -142,6 +142,25 @@ int s2amd_create(int device, s2amdSolver** out)
 		return fail(S2AMD_E_DEVICE, std::string("stream/event creation: ") + hipGetErrorString(e));
 	}
 	(void)hipDeviceGetAttribute(&s->cuCount, hipDeviceAttributeMultiprocessorCount, device);
+	{
+		// the hub rule's unit costs (solver_internal.h: HubCosts): one row per architecture this library has been measured on
+		static const struct
+		{
+			const char* arch;
+			HubCosts costs;
+		} table[] = {{"gfx950", HubCosts{1.4f, 2.0f, 0.38f}}}; // MI355X: op-interpreter colour round, dependent launch in a graph, tail visit (profiles/r04_config3b_*)
+		hipDeviceProp_t prop{};
+		if (hipGetDeviceProperties(&prop, device) == hipSuccess)
+		{
+			for (const auto& row : table)
+			{
+				if (strncmp(prop.gcnArchName, row.arch, strlen(row.arch)) == 0)
+				{
+					s->hubCosts = row.costs;
+				}
+			}
+		}
+	}
 
 	if (hipHostMalloc((void**)&s->hostError, sizeof(unsigned int), hipHostMallocMapped) == hipSuccess)
 	{
@@ -981,6 +1000,13 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	else if (strcmp(key, "strip_overflow") == 0)
 	{
 		s->optOverflow = value != 0; // a contact that fits nowhere in the strips: overflow position + sliced steps + worker-thread build (IncrementalStrips)
+		s->structureDirty = true;
+	}
+	else if (strcmp(key, "cost_strip_round_ns") == 0 || strcmp(key, "cost_launch_ns") == 0 || strcmp(key, "cost_tail_visit_ns") == 0)
+	{
+		// the hub rule's unit costs in nanoseconds (solver_internal.h: HubCosts): measured elsewhere than on the table's architectures
+		float& f = key[5] == 's' ? s->hubCosts.stripRoundUs : (key[5] == 'l' ? s->hubCosts.launchUs : s->hubCosts.tailVisitUs);
+		f = 1e-3f * (float)std::max(value, 1);
 		s->structureDirty = true;
 	}
 	else if (strcmp(key, "pairs_in_step") == 0)

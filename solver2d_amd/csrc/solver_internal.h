@@ -34,11 +34,17 @@ inline int fail(int code, const std::string& msg) { return s2amdFail(code, msg);
 //     S2_COST_BATCH_COLOURS x S2_COST_LAUNCH_US  +  (sum of the hubs' degrees) x S2_COST_TAIL_VISIT_US
 // (a dozen colour launches of ~2 us in a graph; 0.38 us per tail visit: Tumbler 10k).  The graph keeps its strips
 // when the first is the smaller -- for ONE hub that is a degree of 23 or less; the Tumbler's drum (238) is 333 us against 114.
-// (Through round 3 this was a constant, 48.)
+// (Through round 3 this was a constant, 48.)  The unit costs are per device architecture (solver.cpp: hubCostsFor picks the row at
+// s2amd_create from the device's gcnArchName; options "cost_strip_round_ns" / "cost_launch_ns" / "cost_tail_visit_ns" override them):
+// the defaults below are the MI355X's (gfx950), measured on the Tumbler and the base-200 pyramid.
 #define S2_COST_STRIP_ROUND_US 1.4f
 #define S2_COST_LAUNCH_US 2.0f
 #define S2_COST_BATCH_COLOURS 12
 #define S2_COST_TAIL_VISIT_US 0.38f
+struct HubCosts
+{
+	float stripRoundUs = S2_COST_STRIP_ROUND_US, launchUs = S2_COST_LAUNCH_US, tailVisitUs = S2_COST_TAIL_VISIT_US;
+};
 
 #define HIP_TRY(expr)                                                                                                            \
 	do                                                                                                                           \
@@ -529,6 +535,7 @@ struct SolverRest
 	int optPersistRetry = 256; // "persist_retry": steps on the fallback path before the first retry, 0 = never
 	int persistRetryAfter = 256, persistFailedAge = 0;
 	int cuCount = 0;
+	HubCosts hubCosts; // the hub rule's unit costs on this device (solver_structure.cpp: cutStrips)
 	unsigned int* hostError = nullptr; // pinned, device-visible: a hand-off timed out
 	unsigned long long* hostTimes = nullptr; // S2AMD_DEBUG_TIMES: pinned [256] phase time stamps of one workgroup
 	int optMessage = 0;	 // measured slower than the plain gather on MI355X: off by default

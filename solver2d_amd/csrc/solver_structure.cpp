@@ -1997,8 +1997,8 @@ struct StructureBuild
 					{
 						tailVisits += d > S2_HUB_DEGREE ? d : 0;
 					}
-					const float onStrips = (float)maxDegree * S2_COST_STRIP_ROUND_US;
-					const float onBatches = (float)S2_COST_BATCH_COLOURS * S2_COST_LAUNCH_US + (float)tailVisits * S2_COST_TAIL_VISIT_US;
+					const float onStrips = (float)maxDegree * s->hubCosts.stripRoundUs;
+					const float onBatches = (float)S2_COST_BATCH_COLOURS * s->hubCosts.launchUs + (float)tailVisits * s->hubCosts.tailVisitUs;
 					unfit = unfit || onStrips > onBatches;
 				}
 				if (unfit)

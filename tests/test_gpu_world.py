@@ -368,6 +368,39 @@ def test_rain_world_loop(seed, solver_name):
     assert separated > 20 and created > 100, (separated, created)
 
 
+@pytest.mark.parametrize("seed,solver_name", [(2, "PGS_Soft"), (6, "Jacobi"), (11, "TGS_Soft")])
+def test_rain_world_loop_with_the_pair_query_on_demand(seed, solver_name):
+    """The same loop with option `pairs_in_step` 0: every s2amd_world_find_pairs runs its query itself (the round-4 form) instead of
+    collecting the one s2amd_world_step enqueued behind its stage 4 -- the route a caller takes that sets a contact between a step and
+    its query, or whose step was repeated.  Same pairs as the oracle, same world; and the created pairs' small directory overflows
+    (more than 255 contacts created) on the way, in both forms."""
+    from tests import common
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+    world = world_chain.rain_world(seed, 100 + 7 * seed)
+    ref = world_chain.copy_world(world)
+    created = 0
+    with hip.Solver(0) as s:
+        s.set_option("pairs_in_step", 0)
+        s.world_upload(*[world[k] for k in world_chain.WORLD_KEYS])
+        for step in range(70):
+            if world_chain.moved_any(ref):
+                got = s.world_find_pairs()
+                want = world_chain.oracle_find_pairs(ref)
+                assert np.array_equal(got, want), "step %d: new pairs" % step
+                if len(got):
+                    created += len(got)
+                    slots, contacts, pairs = _create_contacts(ref, got)
+                    s.world_set_contacts(slots, contacts, pairs)
+            s.world_step(params)
+            order, _ = s.contact_order()
+            world_chain.oracle_world_step(params, ref, contact_order=order)
+        out = world_chain.copy_world(world)
+        res = s.world_download(*[out[k] for k in world_chain.WORLD_KEYS])
+        world_chain.assert_device_equals_oracle(dict(zip(world_chain.WORLD_KEYS, res[:6])), ref, "rain %d %s, query on demand" % (seed, solver_name))
+    assert created > 255, created
+
+
 @pytest.mark.parametrize("seed,solver_name", [(0, "TGS_Soft"), (14, "PGS_Soft"), (19, "SoftStep"), (4, "PGS"), (5, "XPBD")])
 def test_wrecking_ball_world_loop(seed, solver_name):
     """Heavy balls shot into a pyramid, whole loop (pair query, contact creation, s2amd_world_step) for 70 steps with the

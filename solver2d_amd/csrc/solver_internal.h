@@ -400,6 +400,7 @@ struct SolverStructure
 	// s2Solve_Jacobi as one persistent launch over blocks of bodies (jacobi_kernel.hip; tables: solver_jacobi.cpp)
 	DevBuf dJacobi, dJacobiGran;
 	JacobiView jacobi{};
+	int jacobiDeferred = 0; // steps until the persistent launch's tables are made for a structure a world chain rebuilt (solver_structure.cpp: finish)
 	bool jacobiValid = false;
 	size_t jacobiGranBytes = 0;
 	int jacobiMaxOwned = 0, jacobiMaxImports = 0, jacobiMaxConstraints = 0;

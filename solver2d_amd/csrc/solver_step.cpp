@@ -454,6 +454,24 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	{
 		return rc;
 	}
+	if (s->jacobiDeferred > 0 && !s->structureDirty && params->solverType == s2amd_solverJacobi)
+	{
+		// (a world chain's rebuilt structure -- solver_structure.cpp: finish -- has lived for a few steps: the persistent launch's tables
+		// now, unless a contact placed without colours has already put the steps on the multi-launch path until the next build)
+		if (s->inc.colourFreePlaced)
+		{
+			s->jacobiDeferred = 0;
+		}
+		else if (--s->jacobiDeferred == 0)
+		{
+			if ((rc = buildJacobiBlocks(s)) != 0)
+			{
+				return rc;
+			}
+			HIP_TRY(hipStreamSynchronize(s->stream));
+			s->layoutGeneration += 1;
+		}
+	}
 	const StepPlan& plan = s->plan;
 	if (s->opsGeneration != s->planGeneration)
 	{

@@ -2767,7 +2767,18 @@ struct StructureBuild
 		HIP_TRY(hipStreamSynchronize(s->stream));
 		phase("adjacency + sync");
 		s->orderColourless = needAdj;
-		if ((rc = buildJacobiBlocks(s)) != 0) // (s2Solve_Jacobi: the persistent launch's tables, where the world qualifies)
+		// s2Solve_Jacobi: the persistent launch's tables, where the world qualifies -- at once for a snapshot and for a world's first
+		// structure; a world chain that has just rebuilt (a burst of created contacts: the Tumbler filling rebuilds every other step, and
+		// the first contact placed without colours puts the step back on the multi-launch path anyway) waits until the structure has
+		// lived for a few steps: the tables cost as much host time as the rest of the build (1.2-1.8 ms at 10k constraints)
+		s->jacobiValid = false;
+		s->jacobi = JacobiView{};
+		s->jacobiDeferred = 0;
+		if (needAdj && s->worldResident && !s->isClone && s->structureGeneration > 0 && s->optJacobiPersist != 0)
+		{
+			s->jacobiDeferred = 4;
+		}
+		else if ((rc = buildJacobiBlocks(s)) != 0)
 		{
 			return rc;
 		}

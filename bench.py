@@ -277,7 +277,7 @@ def island_sharded_leg(ranks, islands, base, vel, pos, steps, warmup, graph=True
                                "LDS, records prepared from and impulses stored to the wire contacts by the kernel itself)", "avg_launch_us": us,
                      "algorithmic_bytes_per_launch": algo,
                      "byte_model": "136 B per constraint-sweep (SURVEY.md 8d, body state served from LDS) x %d constraints x %d sweeps" % (mine, sweeps),
-                     "note": "`frac` is the contract's byte MODEL over the kernel's time, not a bandwidth: the kernel reads one wire record per "
+                     "note": "`frac` is the contract's byte MODEL over the kernel's time, not a bandwidth (it passes 1 once the kernel is faster than the model's bytes at 8 TB/s): the kernel reads one wire record per "
                              "constraint and STEP (152 B in, 16 B per point out = %.2f GB) and keeps it in registers, so `traffic` (PMC) is a "
                              "fraction of the model and the kernel is VALU-issue bound -- see `issue`" % (mine * (152.0 + 32.0) / 1e9)},
     }
@@ -288,7 +288,7 @@ def island_sharded_leg(ranks, islands, base, vel, pos, steps, warmup, graph=True
         line["roofline"]["traffic_frac_of_peak"] = line["roofline"]["traffic_gbs"] / HBM_PEAK_GBS
         line["roofline"]["traffic_over_model"] = traffic / algo
     line["issue"] = finish_issue(pmc_issue(ISLAND_KERNELS, "config5", live_us=us), st["groupCount"]) if ranks.world == 1 and islands == 512 and base == 40 else None
-    if line["issue"] is not None:
+    if line["issue"] is not None and "refused" not in line["issue"]:
         line["issue"]["note"] = "512 workgroups of 512 threads on 256 CUs (two passes): the kernel is VALU-issue bound, not bandwidth bound"
         # what bounds this kernel, as a fraction: the share of a SIMD's cycles in which it issues a VALU instruction
         line["roofline"]["issue_frac"] = line["issue"]["valu_issue_frac_per_simd"]

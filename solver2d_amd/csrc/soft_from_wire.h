@@ -6,10 +6,10 @@
 // s2PrepareContacts_Soft (solve_common.c:188-274) for ONE constraint straight from its wire record: the operations of
 // prepareContactsKernel<PREP_SOFT> (contact_kernels.hip) in the same order, so the same bits -- but the prepared record
 // goes into the caller's registers instead of through the SoA arrays.  Body data: rotation and inverse masses from the
-// LDS copies (== the wire body's: body_ops.h unpackBodyOne), local centres from the wire bodies.
+// LDS copies (== the wire body's: body_ops.h unpackBodyOne), local centres from the wire bodies or from LDS (llc).
 template <int KIND, class BA>
 S2_DEV SoftRegs<KIND> prepareSoftFromWire(const s2amdContact* contact, const s2amdBody* wireBodies, const uint32_t* hostFlags, const BA& lb, const float2* lmass,
-										  int2 local, int bodyCapacity, int warmStart)
+										  int2 local, int bodyCapacity, int warmStart, const float2* llc = nullptr)
 {
 	SoftRegs<KIND> r;
 	int pointCount = contact->pointCount;
@@ -21,10 +21,21 @@ S2_DEV SoftRegs<KIND> prepareSoftFromWire(const s2amdContact* contact, const s2a
 	pointCount = pointCount > 0 ? pointCount : 0;
 	const V2 normal = v2(contact->normal[0], contact->normal[1]);
 	const V2 tangent = rightPerp(normal);
-	const s2amdBody* wa = wireBodies + ia;
-	const s2amdBody* wb = wireBodies + ib;
-	const V2 lcA = v2(wa->localCenter[0], wa->localCenter[1]);
-	const V2 lcB = v2(wb->localCenter[0], wb->localCenter[1]);
+	// (llc: the local centres staged in LDS beside the other body records -- wide_kernel.hip: wideIslandKernel --: gathered from the wire
+	// bodies per constraint they were two more cache lines each, and most of that kernel's HBM traffic)
+	V2 lcA, lcB;
+	if (llc != nullptr)
+	{
+		const float2 a = llc[local.x], b = llc[local.y];
+		lcA = v2(a.x, a.y), lcB = v2(b.x, b.y);
+	}
+	else
+	{
+		const s2amdBody* wa = wireBodies + ia;
+		const s2amdBody* wb = wireBodies + ib;
+		lcA = v2(wa->localCenter[0], wa->localCenter[1]);
+		lcB = v2(wb->localCenter[0], wb->localCenter[1]);
+	}
 	const float2 massA = lmass[local.x], massB = lmass[local.y];
 	const float mA = massA.x, iA = massA.y, mB = massB.x, iB = massB.y;
 	const Rot qA = loadPose(lb, local.x).q, qB = loadPose(lb, local.y).q;

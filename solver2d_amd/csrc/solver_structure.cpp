@@ -1506,7 +1506,7 @@ static int buildResidentTables(s2amdSolver* s)
 			d.ownedCount += 1;
 		}
 		const int nbG = d.bodyCount;
-		const int records = 3 * nbG + (nbG + 3) / 4 + (nbG + 1) / 2;
+		const int records = 3 * nbG + (nbG + 3) / 4 + 2 * ((nbG + 1) / 2); // (+ the local centres wide_kernel.hip: wideIslandKernel stages)
 		ok = ok && (size_t)records * 16 + 128 * sizeof(Op) <= 160 * 1024;
 		ldsRecords = std::max(ldsRecords, records);
 		s->residentRounds = std::max(s->residentRounds, d.batchCount);

@@ -2306,7 +2306,8 @@ __global__ __launch_bounds__(S2_WIDE_THREADS) void wideIslandKernel(ContactView 
 	float4* linteg = lds + 2 * nb;
 	float* langDamp = (float*)(lds + 3 * nb);
 	float2* lmass = (float2*)(lds + 3 * nb + (nb + 3) / 4);
-	const int bodyRecords = 3 * nb + (nb + 3) / 4 + (nb + 1) / 2;
+	float2* llc = (float2*)(lds + 3 * nb + (nb + 3) / 4 + (nb + 1) / 2); // the bodies' local centres (soft_from_wire.h: prepareSoftFromWire)
+	const int bodyRecords = 3 * nb + (nb + 3) / 4 + 2 * ((nb + 1) / 2);
 	Op* lops = (Op*)(lds + bodyRecords);
 	float4* lcoef = lds + bodyRecords + 2 * opCount; // 2 records (the launch adds them to the size)
 	constexpr int LA = wideIslandLocalsInLds(ROUNDS), LL0 = ROUNDS - LA;
@@ -2372,6 +2373,7 @@ __global__ __launch_bounds__(S2_WIDE_THREADS) void wideIslandKernel(ContactView 
 				ldq[i] = make_float4(w->deltaPosition[0], w->deltaPosition[1], w->rot[0], w->rot[1]);
 				pos[ch] = make_float2(w->position[0], w->position[1]);
 				lmass[i] = make_float2(w->invMass, w->invI);
+				llc[i] = make_float2(w->localCenter[0], w->localCenter[1]);
 				const V2 gravity = v2(sc.gravityX, sc.gravityY);
 				const V2 force = v2(w->force[0], w->force[1]);
 				const V2 inner = mulAdd(force, w->mass * w->gravityScale, gravity);
@@ -2390,6 +2392,7 @@ __global__ __launch_bounds__(S2_WIDE_THREADS) void wideIslandKernel(ContactView 
 				linteg[i] = g.integ[gi];
 				langDamp[i] = g.angDamp[gi];
 				lmass[i] = g.massInv[gi];
+				llc[i] = make_float2(wireBodies[gi].localCenter[0], wireBodies[gi].localCenter[1]);
 			}
 		}
 	}
@@ -2402,7 +2405,7 @@ __global__ __launch_bounds__(S2_WIDE_THREADS) void wideIslandKernel(ContactView 
 	{
 		if (slotOf[i] >= 0)
 		{
-			rA[i] = wideFromSoft(prepareSoftFromWire<SOFT_TGS>(wire + slotOf[i], wireBodies, hostFlags, lb, lmass, localOf[i], g.capacity, warmStart));
+			rA[i] = wideFromSoft(prepareSoftFromWire<SOFT_TGS>(wire + slotOf[i], wireBodies, hostFlags, lb, lmass, localOf[i], g.capacity, warmStart, llc));
 			const bool st = lmass[localOf[i].x].x == 0.0f || lmass[localOf[i].y].x == 0.0f; // the doubled contact hertz of a static side
 			rA[i].idx |= st ? 1u << 30 : 0u;
 			if (i >= LL0)

@@ -978,7 +978,8 @@ __global__ __launch_bounds__(THREADS) void islandStepKernel(ContactView c, BodyV
 	float4* linteg = lds + 2 * nb;
 	float* langDamp = (float*)(lds + 3 * nb);
 	float2* lmass = (float2*)(lds + 3 * nb + (nb + 3) / 4);
-	const int bodyRecords = 3 * nb + (nb + 3) / 4 + (nb + 1) / 2;
+	float2* llc = (float2*)(lds + 3 * nb + (nb + 3) / 4 + (nb + 1) / 2); // the bodies' local centres (soft_from_wire.h: prepareSoftFromWire)
+	const int bodyRecords = 3 * nb + (nb + 3) / 4 + 2 * ((nb + 1) / 2);
 	Op* lops = (Op*)(lds + bodyRecords);
 
 	uint32_t id[S2_STRIP_BODY_CHUNKS];
@@ -1026,6 +1027,7 @@ __global__ __launch_bounds__(THREADS) void islandStepKernel(ContactView c, BodyV
 			linteg[i] = g.integ[gi];
 			langDamp[i] = g.angDamp[gi];
 			lmass[i] = g.massInv[gi];
+			llc[i] = make_float2(wireBodies[gi].localCenter[0], wireBodies[gi].localCenter[1]);
 		}
 	}
 	__syncthreads();
@@ -1039,7 +1041,7 @@ __global__ __launch_bounds__(THREADS) void islandStepKernel(ContactView c, BodyV
 	{
 		if (slotOf[i] >= 0)
 		{
-			SoftRegs<KIND> t = prepareSoftFromWire<KIND>(wire + slotOf[i], wireBodies, hostFlags, lb, lmass, localOf[i], g.capacity, warmStart);
+			SoftRegs<KIND> t = prepareSoftFromWire<KIND>(wire + slotOf[i], wireBodies, hostFlags, lb, lmass, localOf[i], g.capacity, warmStart, llc);
 			rA[i] = packPersist<KIND, WARM>(t, localOf[i].x, localOf[i].y);
 		}
 	}

@@ -647,6 +647,25 @@ __global__ __launch_bounds__(S2_BLOCK) void residentShapeKeysKernel(const s2amdS
 	moved[i] = (shapes[i].type != S2AMD_SHAPE_FREE && shapes[i].enlarged != 0) ? 1 : 0;
 }
 
+// the resident query's results to the host: count[0] pairs found (count[1]: the long runs' counter), the first `first` keys; both counters
+// zero again for the next query
+__global__ __launch_bounds__(S2_BLOCK) void publishPairsKernel(unsigned int* count, const unsigned long long* keys, unsigned int first, unsigned int* hostFound,
+															   unsigned long long* hostKeys)
+{
+	const unsigned int found = count[0];
+	const unsigned int n = found < first ? found : first;
+	for (unsigned int i = threadIdx.x; i < n; i += blockDim.x)
+	{
+		hostKeys[i] = keys[i];
+	}
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		hostFound[0] = found;
+		count[0] = 0u, count[1] = 0u;
+	}
+}
+
 // (min shape, max shape) of every live pair slot; free slots sort last and match nothing
 __global__ __launch_bounds__(S2_BLOCK) void residentPairKeysKernel(const s2amdPairState* pairs, int nc, unsigned long long* keys, int* slots, int shapeBits)
 {
@@ -715,6 +734,7 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 		}
 		BP_TRY(hipMalloc(scratch, total + total / 4));
 		*scratchBytes = total + total / 4;
+		cache->countAt = nullptr;
 	}
 	char* p = (char*)*scratch;
 	size_t li = 0;
@@ -737,6 +757,12 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 	unsigned long long* dOutB = (unsigned long long*)take();
 	unsigned int* dCount = (unsigned int*)take();
 	void* dTmp = take();
+	if (cache->countAt != (void*)dCount)
+	{
+		// (the counters start at zero and publishPairsKernel leaves them there; a block the layout has just put them in may hold anything)
+		BP_TRY(hipMemsetAsync(dCount, 0, 256, st));
+		cache->countAt = (void*)dCount;
+	}
 	int* dSlotsIn = (int*)dExisting; // (the sorted pair keys -- and their slots -- live in the caller's buffer: this block holds the unsorted slots)
 	(void)dOutB;
 
@@ -758,10 +784,26 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 	}
 	unsigned int* hostFound = (unsigned int*)cache->host;
 	unsigned long long* hostKeys = (unsigned long long*)(cache->host + 16);
+	unsigned int* hostFoundDev = nullptr;
+	unsigned long long* hostKeysDev = nullptr;
+	{
+		char* dev = nullptr;
+		if (hipHostGetDevicePointer((void**)&dev, cache->host, 0) == hipSuccess && dev != nullptr)
+		{
+			hostFoundDev = (unsigned int*)dev, hostKeysDev = (unsigned long long*)(dev + 16);
+		}
+		else
+		{
+			(void)hipGetLastError();
+		}
+	}
 	// The query proper -- key generation, the sort of the proxies, the sweep kernels, the read-back -- is the same dozen launches
 	// every step: the second time a sequence (arrays, sizes) comes along it is captured into a hipGraph and replayed from then on
 	auto enqueue = [&]() -> int {
-		BP_TRY(hipMemsetAsync(dCount, 0, 256, st));
+		if (hostFoundDev == nullptr)
+		{
+			BP_TRY(hipMemsetAsync(dCount, 0, 256, st)); // (else publishPairsKernel left them at zero, and the scratch was zeroed when it was made)
+		}
 		residentShapeKeysKernel<<<gridFor((size_t)ns), dim3(S2_BLOCK), 0, st>>>(dS, ns, dKeysIn, dIdxIn, dMoved);
 		size_t t2 = tmpBytes + 256;
 		BP_TRY(rocprim::radix_sort_pairs(dTmp, t2, dKeysIn, dKeysOut, dIdxIn, dIdxOut, (size_t)ns, 0, 32, st));
@@ -772,8 +814,18 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 		pairLongKernel<<<dim3(256), dim3(S2_BLOCK), 0, st>>>(dS, dMoved, dIdxOut, dLowerX, n, sortedPairKeys, nc, dJointed, jointedCount, dOutA,
 															  (unsigned int)outCap, dCount, (const int*)dRun, dCount + 1, gone);
 		BP_TRY(hipGetLastError());
-		BP_TRY(hipMemcpyAsync(hostFound, dCount, 4, hipMemcpyDeviceToHost, st));
-		BP_TRY(hipMemcpyAsync(hostKeys, dOutA, (size_t)std::min<size_t>(kFirst, outCap) * 8, hipMemcpyDeviceToHost, st));
+		if (hostFoundDev != nullptr)
+		{
+			// the count and the first keys straight into the pinned page, the counters zeroed for the next query: one small kernel where
+			// a memset and two copies were three blit kernels (~4.5 us each, serial on the stream)
+			publishPairsKernel<<<dim3(1), dim3(S2_BLOCK), 0, st>>>(dCount, dOutA, (unsigned int)std::min<size_t>(kFirst, outCap), hostFoundDev, hostKeysDev);
+			BP_TRY(hipGetLastError());
+		}
+		else
+		{
+			BP_TRY(hipMemcpyAsync(hostFound, dCount, 4, hipMemcpyDeviceToHost, st));
+			BP_TRY(hipMemcpyAsync(hostKeys, dOutA, (size_t)std::min<size_t>(kFirst, outCap) * 8, hipMemcpyDeviceToHost, st));
+		}
 		return S2AMD_OK;
 	};
 	(void)dOff;

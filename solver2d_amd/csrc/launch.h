@@ -209,6 +209,7 @@ struct PairQueryGraph
 	unsigned long long key = 0, keySeen = 0;
 	bool disabled = false;
 	char* host = nullptr;
+	void* countAt = nullptr; // where the query's counters live in the scratch block (zeroed when that changes)
 };
 int findPairsResident(hipStream_t st, const s2amdShape* shapes, int shapeCapacity, int liveShapes, const s2amdPairState* pairs, int contactCapacity,
 					  const unsigned long long* jointed, int jointedCount, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount, void** scratch,

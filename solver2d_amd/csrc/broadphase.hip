@@ -230,6 +230,35 @@ __global__ __launch_bounds__(S2_BLOCK) void gatherLowerXKernel(const s2amdShape*
 	}
 }
 
+// the resident query's compact view of the proxies in sweep order: fat box and move flag (the pair kernels test a candidate on 17 bytes
+// before they touch the 196-byte shape records of the few that pass)
+__global__ __launch_bounds__(S2_BLOCK) void gatherBoxesKernel(const s2amdShape* shapes, const unsigned char* moved, const int* sortedIdx, int n, float4* box,
+															  unsigned char* movedSorted)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n)
+	{
+		const int s = sortedIdx[i];
+		const float* f = shapes[s].fatAABB;
+		box[i] = make_float4(f[0], f[1], f[2], f[3]);
+		movedSorted[i] = moved[s];
+	}
+}
+S2_DEV bool boxesOverlap(float4 a, float4 b) // aabbOverlaps on the copies: the same comparisons on the same values
+{
+	float d1x = b.x - a.z, d1y = b.y - a.w;
+	float d2x = a.x - b.z, d2y = a.y - b.w;
+	if (d1x > 0.0f || d1y > 0.0f)
+	{
+		return false;
+	}
+	if (d2x > 0.0f || d2y > 0.0f)
+	{
+		return false;
+	}
+	return true;
+}
+
 // for sorted position i: first position whose lower x lies beyond this shape's upper x
 __global__ __launch_bounds__(S2_BLOCK) void runLengthKernel(const s2amdShape* shapes, const int* sortedIdx, const float* sortedLowerX, int n,
 															 unsigned int* runLength)
@@ -510,17 +539,17 @@ __global__ __launch_bounds__(S2_BLOCK) void pairStrideKernel(const s2amdShape* s
 // ground under a pile: every proxy is in its run) is finished by the whole grid in pairLongKernel.
 #define S2_LONG_RUN 512
 __global__ __launch_bounds__(S2_BLOCK) void pairWaveKernel(const s2amdShape* shapes, const unsigned char* moved, const int* sortedIdx,
-															const float* sortedLowerX, int n, const unsigned long long* existing, int existingCount,
-															const unsigned long long* jointed, int jointedCount, unsigned long long* outKeys,
+															const float4* sortedBox, const unsigned char* sortedMoved, int n, const unsigned long long* existing,
+															int existingCount, const unsigned long long* jointed, int jointedCount, unsigned long long* outKeys,
 															unsigned int outCapacity, unsigned int* outCount, int* longList, unsigned int* longCount, GoneKeys gone)
 {
 	const int lane = (int)threadIdx.x & 63;
 	const int wavesPerBlock = (int)blockDim.x >> 6;
 	for (int i = (int)blockIdx.x * wavesPerBlock + ((int)threadIdx.x >> 6); i < n; i += (int)gridDim.x * wavesPerBlock)
 	{
-		const int xi = sortedIdx[i];
-		const float ux = shapes[xi].fatAABB[2];
-		const bool mi = moved[xi] != 0;
+		const float4 bi = sortedBox[i];
+		const float ux = bi.z;
+		const bool mi = sortedMoved[i] != 0;
 		for (int base = i + 1;; base += 64)
 		{
 			if (base - (i + 1) >= S2_LONG_RUN)
@@ -532,14 +561,16 @@ __global__ __launch_bounds__(S2_BLOCK) void pairWaveKernel(const s2amdShape* sha
 				break;
 			}
 			const int j = base + lane;
-			const bool in = j < n && !(sortedLowerX[j] - ux > 0.0f);
-			if (in)
+			float4 bj = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			if (j < n)
 			{
-				const int yi = sortedIdx[j];
-				if (mi || moved[yi] != 0)
-				{
-					pairTest(xi, yi, shapes, moved, existing, existingCount, jointed, jointedCount, outKeys, outCapacity, outCount, gone);
-				}
+				bj = sortedBox[j];
+			}
+			const bool in = j < n && !(bj.x - ux > 0.0f);
+			if (in && (mi || sortedMoved[j] != 0) && boxesOverlap(bi, bj))
+			{
+				// (pairTest repeats the overlap test on the shape records: the same values, the same answer)
+				pairTest(sortedIdx[i], sortedIdx[j], shapes, moved, existing, existingCount, jointed, jointedCount, outKeys, outCapacity, outCount, gone);
 			}
 			if (!__all(in))
 			{
@@ -551,27 +582,27 @@ __global__ __launch_bounds__(S2_BLOCK) void pairWaveKernel(const s2amdShape* sha
 
 // the rest of the long runs: every thread of the grid strides over each of them
 __global__ __launch_bounds__(S2_BLOCK) void pairLongKernel(const s2amdShape* shapes, const unsigned char* moved, const int* sortedIdx,
-															const float* sortedLowerX, int n, const unsigned long long* existing, int existingCount,
-															const unsigned long long* jointed, int jointedCount, unsigned long long* outKeys,
+															const float4* sortedBox, const unsigned char* sortedMoved, int n, const unsigned long long* existing,
+															int existingCount, const unsigned long long* jointed, int jointedCount, unsigned long long* outKeys,
 															unsigned int outCapacity, unsigned int* outCount, const int* longList, const unsigned int* longCount, GoneKeys gone)
 {
 	const unsigned int count = *longCount;
 	for (unsigned int e = 0; e < count; ++e)
 	{
 		const int i = longList[e];
-		const int xi = sortedIdx[i];
-		const float ux = shapes[xi].fatAABB[2];
-		const bool mi = moved[xi] != 0;
+		const float4 bi = sortedBox[i];
+		const float ux = bi.z;
+		const bool mi = sortedMoved[i] != 0;
 		for (int j = i + 1 + S2_LONG_RUN + (int)(blockIdx.x * blockDim.x + threadIdx.x); j < n; j += (int)(gridDim.x * blockDim.x))
 		{
-			if (sortedLowerX[j] - ux > 0.0f)
+			const float4 bj = sortedBox[j];
+			if (bj.x - ux > 0.0f)
 			{
 				break; // (ascending: everything this thread would visit later lies beyond the run as well)
 			}
-			const int yi = sortedIdx[j];
-			if (mi || moved[yi] != 0)
+			if ((mi || sortedMoved[j] != 0) && boxesOverlap(bi, bj))
 			{
-				pairTest(xi, yi, shapes, moved, existing, existingCount, jointed, jointedCount, outKeys, outCapacity, outCount, gone);
+				pairTest(sortedIdx[i], sortedIdx[j], shapes, moved, existing, existingCount, jointed, jointedCount, outKeys, outCapacity, outCount, gone);
 			}
 		}
 	}
@@ -715,7 +746,7 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 	size_t outCap = (size_t)std::max(nc, 1024);
 	BP_TRY(rocprim::radix_sort_pairs(nullptr, tmpKeys, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (int*)nullptr, (int*)nullptr, std::max((size_t)nc, outCap), 0, 64, st));
 	size_t tmpBytes = std::max(std::max(tmpSort, tmpScan), tmpKeys);
-	size_t layout[] = {al((size_t)ns), al((size_t)ns * 4), al((size_t)ns * 4), al((size_t)ns * 4), al((size_t)ns * 4), al((size_t)n * 4),
+	size_t layout[] = {al((size_t)ns), al((size_t)ns * 4), al((size_t)ns * 4), al((size_t)ns * 4), al((size_t)ns * 4), al((size_t)n * 16),
 					   al(((size_t)n + 1) * 4), al(((size_t)n + 1) * 4), al((size_t)nc * 8 + 8), al((size_t)nc * 8 + 8), al(outCap * 8), al(outCap * 8), al(256),
 					   al(tmpBytes + 256)};
 	size_t total = 0;
@@ -748,9 +779,10 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 	uint32_t* dKeysOut = (uint32_t*)take();
 	int* dIdxIn = (int*)take();
 	int* dIdxOut = (int*)take();
-	float* dLowerX = (float*)take();
+	float4* dBox = (float4*)take(); // the proxies' fat boxes in sweep order (gatherBoxesKernel)
 	unsigned int* dRun = (unsigned int*)take();
 	unsigned int* dOff = (unsigned int*)take();
+	unsigned char* dMovedSorted = (unsigned char*)dOff; // (... and their move flags: the run offsets of the host-array route are not used here)
 	unsigned long long* dExistingIn = (unsigned long long*)take();
 	unsigned long long* dExisting = (unsigned long long*)take();
 	unsigned long long* dOutA = (unsigned long long*)take();
@@ -807,11 +839,11 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 		residentShapeKeysKernel<<<gridFor((size_t)ns), dim3(S2_BLOCK), 0, st>>>(dS, ns, dKeysIn, dIdxIn, dMoved);
 		size_t t2 = tmpBytes + 256;
 		BP_TRY(rocprim::radix_sort_pairs(dTmp, t2, dKeysIn, dKeysOut, dIdxIn, dIdxOut, (size_t)ns, 0, 32, st));
-		gatherLowerXKernel<<<gridFor((size_t)n), dim3(S2_BLOCK), 0, st>>>(dS, dIdxOut, n, dLowerX);
+		gatherBoxesKernel<<<gridFor((size_t)n), dim3(S2_BLOCK), 0, st>>>(dS, dMoved, dIdxOut, n, dBox, dMovedSorted);
 		// (dCount[0] = pairs found, dCount[1] = long runs: both zeroed above; the run-length array of the host-array route holds the long list)
-		pairWaveKernel<<<dim3((unsigned)std::min((n + 3) / 4, 16384)), dim3(S2_BLOCK), 0, st>>>(dS, dMoved, dIdxOut, dLowerX, n, sortedPairKeys, nc, dJointed,
+		pairWaveKernel<<<dim3((unsigned)std::min((n + 3) / 4, 16384)), dim3(S2_BLOCK), 0, st>>>(dS, dMoved, dIdxOut, dBox, dMovedSorted, n, sortedPairKeys, nc, dJointed,
 																								jointedCount, dOutA, (unsigned int)outCap, dCount, (int*)dRun, dCount + 1, gone);
-		pairLongKernel<<<dim3(256), dim3(S2_BLOCK), 0, st>>>(dS, dMoved, dIdxOut, dLowerX, n, sortedPairKeys, nc, dJointed, jointedCount, dOutA,
+		pairLongKernel<<<dim3(256), dim3(S2_BLOCK), 0, st>>>(dS, dMoved, dIdxOut, dBox, dMovedSorted, n, sortedPairKeys, nc, dJointed, jointedCount, dOutA,
 															  (unsigned int)outCap, dCount, (const int*)dRun, dCount + 1, gone);
 		BP_TRY(hipGetLastError());
 		if (hostFoundDev != nullptr)
@@ -828,7 +860,6 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 		}
 		return S2AMD_OK;
 	};
-	(void)dOff;
 	unsigned long long key = 1469598103934665603ull;
 	{
 		const unsigned long long words[] = {(unsigned long long)(uintptr_t)dS, (unsigned long long)ns, (unsigned long long)n, (unsigned long long)nc,

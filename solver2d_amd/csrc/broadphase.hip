@@ -12,6 +12,7 @@
 
 #include "launch.h"
 #include "s2_device.h"
+#include "refit_ops.h"
 
 #include "solver2d_amd.h"
 
@@ -25,27 +26,10 @@
 #include <vector>
 
 #define S2_BLOCK 256
-#define S2_SPECULATIVE_DISTANCE (4.0f * S2_LINEAR_SLOP) // constants.h:8
-#define S2_AABB_MARGIN 0.1f								 // constants.h:9
 
 int s2amdFail(int code, const std::string& msg);
 hipStream_t s2amdStream(s2amdSolver* s);
 int s2amdDevice(s2amdSolver* s);
-
-struct Xf
-{
-	V2 p;
-	Rot q;
-};
-
-S2_DEV V2 transformPoint(Xf xf, V2 p) // math.h:350-356
-{
-	float x = (xf.q.c * p.x - xf.q.s * p.y) + xf.p.x;
-	float y = (xf.q.s * p.x + xf.q.c * p.y) + xf.p.y;
-	return v2(x, y);
-}
-S2_DEV V2 vmin(V2 a, V2 b) { return v2(S2_MINF(a.x, b.x), S2_MINF(a.y, b.y)); }
-S2_DEV V2 vmax(V2 a, V2 b) { return v2(S2_MAXF(a.x, b.x), S2_MAXF(a.y, b.y)); }
 
 __global__ __launch_bounds__(S2_BLOCK) void bodyOriginsKernel(const s2amdBody* bodies, int n, float2* origins)
 {
@@ -63,78 +47,6 @@ __global__ __launch_bounds__(S2_BLOCK) void bodyOriginsKernel(const s2amdBody* b
 	q.s = b->rot[0], q.c = b->rot[1];
 	V2 o = sub(v2(b->position[0], b->position[1]), rotate(q, v2(b->localCenter[0], b->localCenter[1])));
 	origins[i] = make_float2(o.x, o.y);
-}
-
-// s2Shape_ComputeAABB -> src/geometry.c:288-339, then src/world.c:283-296
-// one shape of a non-static body: tight AABB + speculative margin, fat AABB re-inflated when it was left; returns `enlarged`
-S2_DEV int refitShapeOne(const s2amdBody* b, s2amdShape* sh, V2 origin)
-{
-	Xf xf;
-	xf.p = origin;
-	xf.q.s = b->rot[0], xf.q.c = b->rot[1];
-	V2 lower, upper;
-	V2 v0 = v2(sh->vertices[0][0], sh->vertices[0][1]);
-	V2 v1 = v2(sh->vertices[1][0], sh->vertices[1][1]);
-	switch (sh->type)
-	{
-		case S2AMD_SHAPE_CIRCLE:
-		{
-			V2 p = transformPoint(xf, v0);
-			float r = sh->radius;
-			lower = v2(p.x - r, p.y - r);
-			upper = v2(p.x + r, p.y + r);
-			break;
-		}
-		case S2AMD_SHAPE_CAPSULE:
-		{
-			V2 a = transformPoint(xf, v0), c = transformPoint(xf, v1);
-			V2 r = v2(sh->radius, sh->radius);
-			lower = sub(vmin(a, c), r);
-			upper = add(vmax(a, c), r);
-			break;
-		}
-		case S2AMD_SHAPE_POLYGON:
-		{
-			lower = transformPoint(xf, v0);
-			upper = lower;
-			for (int i = 1; i < sh->count; ++i)
-			{
-				V2 v = transformPoint(xf, v2(sh->vertices[i][0], sh->vertices[i][1]));
-				lower = vmin(lower, v);
-				upper = vmax(upper, v);
-			}
-			V2 r = v2(sh->radius, sh->radius);
-			lower = sub(lower, r);
-			upper = add(upper, r);
-			break;
-		}
-		case S2AMD_SHAPE_SEGMENT:
-		{
-			V2 a = transformPoint(xf, v0), c = transformPoint(xf, v1);
-			lower = vmin(a, c);
-			upper = vmax(a, c);
-			break;
-		}
-		default:
-			lower = xf.p;
-			upper = xf.p;
-			break;
-	}
-	float a0 = lower.x - S2_SPECULATIVE_DISTANCE, a1 = lower.y - S2_SPECULATIVE_DISTANCE;
-	float a2 = upper.x + S2_SPECULATIVE_DISTANCE, a3 = upper.y + S2_SPECULATIVE_DISTANCE;
-	sh->aabb[0] = a0, sh->aabb[1] = a1, sh->aabb[2] = a2, sh->aabb[3] = a3;
-	bool contains = sh->fatAABB[0] <= a0 && sh->fatAABB[1] <= a1 && a2 <= sh->fatAABB[2] && a3 <= sh->fatAABB[3];
-	int enlarged = 0;
-	if (contains == false)
-	{
-		sh->fatAABB[0] = a0 - S2_AABB_MARGIN;
-		sh->fatAABB[1] = a1 - S2_AABB_MARGIN;
-		sh->fatAABB[2] = a2 + S2_AABB_MARGIN;
-		sh->fatAABB[3] = a3 + S2_AABB_MARGIN;
-		enlarged = 1;
-	}
-	sh->enlarged = enlarged;
-	return enlarged;
 }
 
 __global__ __launch_bounds__(S2_BLOCK) void refitShapesKernel(const s2amdBody* bodies, int nb, s2amdShape* shapes, int ns, const float2* origins)
@@ -155,31 +67,27 @@ __global__ __launch_bounds__(S2_BLOCK) void refitShapesKernel(const s2amdBody* b
 		return;
 	}
 	float2 o = origins[sh->body];
-	(void)refitShapeOne(b, sh, v2(o.x, o.y));
+	Rot qb;
+	qb.s = b->rot[0], qb.c = b->rot[1];
+	(void)refitShapeOne(qb, sh, v2(o.x, o.y));
 }
 
 // Stage 4 of the resident world in ONE launch (src/world.c:259-301): blocks [0, shapeBlocks) refit one shape per thread,
 // with the body origin recomputed from the body (the same expression bodyOriginsKernel evaluates, so the same bits);
 // the other blocks walk the bodies: origin written for the next stage 3, applied forces consumed (src/world.c:274-275).
 __global__ __launch_bounds__(S2_BLOCK) void stage4Kernel(s2amdBody* bodies, int nb, s2amdShape* shapes, int ns, float2* origins, int shapeBlocks,
-														  int* summary)
+														  int* summary, const unsigned int* stepFailed)
 {
+	if (stepFailed != nullptr && *stepFailed != 0u)
+	{
+		return; // (a persistent step that lost a hand-off left the bodies alone and will be repeated: nothing moved, and the applied forces are still to be consumed)
+	}
 	if ((int)blockIdx.x >= shapeBlocks)
 	{
 		int i = ((int)blockIdx.x - shapeBlocks) * (int)blockDim.x + (int)threadIdx.x;
 		if (i < nb)
 		{
-			s2amdBody* b = bodies + i;
-			if (b->type != S2AMD_BODY_FREE && b->type != S2AMD_BODY_STATIC)
-			{
-				Rot q;
-				q.s = b->rot[0], q.c = b->rot[1];
-				V2 o = sub(v2(b->position[0], b->position[1]), rotate(q, v2(b->localCenter[0], b->localCenter[1])));
-				origins[i] = make_float2(o.x, o.y);
-				b->force[0] = 0.0f;
-				b->force[1] = 0.0f;
-				b->torque = 0.0f;
-			}
+			stage4BodyOne(bodies, i, origins, nullptr);
 		}
 		return;
 	}
@@ -187,22 +95,7 @@ __global__ __launch_bounds__(S2_BLOCK) void stage4Kernel(s2amdBody* bodies, int 
 	int enlarged = 0;
 	if (si < ns)
 	{
-		s2amdShape* sh = shapes + si;
-		if (sh->type != S2AMD_SHAPE_FREE && sh->body >= 0 && sh->body < nb)
-		{
-			const s2amdBody* b = bodies + sh->body;
-			if (b->type != S2AMD_BODY_FREE && b->type != S2AMD_BODY_STATIC)
-			{
-				Rot q;
-				q.s = b->rot[0], q.c = b->rot[1];
-				V2 o = sub(v2(b->position[0], b->position[1]), rotate(q, v2(b->localCenter[0], b->localCenter[1])));
-				enlarged = refitShapeOne(b, sh, o);
-			}
-			else
-			{
-				enlarged = sh->enlarged != 0 ? 1 : 0; // a static shape keeps the flag its creation gave it
-			}
-		}
+		enlarged = stage4ShapeOne(bodies, nb, shapes + si, nullptr);
 	}
 	unsigned long long m = __ballot(enlarged != 0);
 	if ((threadIdx.x & 63) == 0 && m != 0ull)
@@ -993,7 +886,7 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 }
 
 // resident arrays (world.hip)
-void launchStage4(hipStream_t st, s2amdBody* bodies, int bodyCapacity, s2amdShape* shapes, int shapeCapacity, float* origins, int* summary)
+void launchStage4(hipStream_t st, s2amdBody* bodies, int bodyCapacity, s2amdShape* shapes, int shapeCapacity, float* origins, int* summary, const unsigned int* stepFailed)
 {
 	if (bodyCapacity <= 0)
 	{
@@ -1001,7 +894,7 @@ void launchStage4(hipStream_t st, s2amdBody* bodies, int bodyCapacity, s2amdShap
 	}
 	int shapeBlocks = (shapeCapacity + S2_BLOCK - 1) / S2_BLOCK, bodyBlocks = (bodyCapacity + S2_BLOCK - 1) / S2_BLOCK;
 	stage4Kernel<<<dim3((unsigned)(shapeBlocks + bodyBlocks)), dim3(S2_BLOCK), 0, st>>>(bodies, bodyCapacity, shapes, shapeCapacity, (float2*)origins,
-																					shapeBlocks, summary);
+																					shapeBlocks, summary, stepFailed);
 }
 
 #pragma GCC visibility push(default)

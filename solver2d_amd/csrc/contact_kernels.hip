@@ -7,6 +7,7 @@
 
 #include "body_ops.h"
 #include "joint_prep.h"
+#include "refit_ops.h"
 
 #define S2_BLOCK 256
 
@@ -323,11 +324,43 @@ template <int KIND>
 // tags restart at 1 every launch, so the buffers must be clean when the next step starts)
 __global__ __launch_bounds__(S2_BLOCK) void storeImpulsesKernel(ContactView c, s2amdContact* wire, float scale, int contactBlocks, int bodyBlocks,
 																BodyView bodies, s2amdBody* wireBodies, uint4* clear, int clearCount, const unsigned int* stepFailed,
-																int finalizeMode, JointView jv, s2amdJoint* wireJoints, int jointBlocks)
+																int finalizeMode, JointView jv, s2amdJoint* wireJoints, int jointBlocks, Stage4Args s4, int stage4Base,
+																int stage4ShapeBlocks)
 {
 	// a persistent step whose hand-offs timed out leaves the wire arrays as they were: the host then repeats the step
 	// on the multi-launch path (solver_step.cpp: doStep); the hand-off buffers are cleared either way
 	const bool failed = stepFailed != nullptr && *stepFailed != 0u; // a device-memory word, written by the previous launch
+	if ((int)blockIdx.x >= stage4Base)
+	{
+		// Stage 4 of the world step (src/world.c:259-301; refit_ops.h) in the same launch: the poses come from the SoA records the step
+		// has finished (what the body blocks above copy into the wire bodies: the same values), so nothing here waits for them
+		if (failed)
+		{
+			return; // (the step will be repeated: nothing moved, the applied forces are still to be consumed)
+		}
+		const int blk = (int)blockIdx.x - stage4Base;
+		if (blk >= stage4ShapeBlocks)
+		{
+			const int i = (blk - stage4ShapeBlocks) * (int)blockDim.x + (int)threadIdx.x;
+			if (i < bodies.capacity)
+			{
+				stage4BodyOne(wireBodies, i, s4.origins, &bodies);
+			}
+			return;
+		}
+		const int si = blk * (int)blockDim.x + (int)threadIdx.x;
+		int enlarged = 0;
+		if (si < s4.shapeCapacity)
+		{
+			enlarged = stage4ShapeOne(wireBodies, bodies.capacity, s4.shapes + si, &bodies);
+		}
+		const unsigned long long m = __ballot(enlarged != 0);
+		if ((threadIdx.x & 63) == 0 && m != 0ull)
+		{
+			atomicAdd(s4.summary + 4, __popcll(m));
+		}
+		return;
+	}
 	if ((int)blockIdx.x >= contactBlocks + bodyBlocks && (int)blockIdx.x < contactBlocks + bodyBlocks + jointBlocks)
 	{
 		// joint impulses -> wire joints (joint.c: the persistent members of s2RevoluteJoint / s2MouseJoint), as storeJointsKernel
@@ -893,8 +926,9 @@ void launchBlockSolvePosition(hipStream_t s, const ContactView& c, const BodyVie
 	S2_LAUNCH_SWEEP(blockSolvePositionKernel, c, b, begin, end);
 }
 
-void launchStoreImpulses(hipStream_t s, int kind, const ContactView& c, s2amdContact* wire, float scale, const BodyView& bodies, s2amdBody* wireBodies,
-						 void* clear, size_t clearBytes, const unsigned int* stepFailed, int finalizeMode, const JointView* joints, s2amdJoint* wireJoints)
+bool launchStoreImpulses(hipStream_t s, int kind, const ContactView& c, s2amdContact* wire, float scale, const BodyView& bodies, s2amdBody* wireBodies,
+						 void* clear, size_t clearBytes, const unsigned int* stepFailed, int finalizeMode, const JointView* joints, s2amdJoint* wireJoints,
+						 const Stage4Args* stage4)
 {
 	// bodies == nullptr-capacity: plain store; otherwise the body write-back rides in the same launch
 	const int contactBlocks = c.count > 0 ? (c.count - (c.skipEnd - c.skipBegin) + S2_BLOCK - 1) / S2_BLOCK : 0;
@@ -903,23 +937,33 @@ void launchStoreImpulses(hipStream_t s, int kind, const ContactView& c, s2amdCon
 	const int clearBlocks = (clearCount + S2_BLOCK - 1) / S2_BLOCK;
 	const int jointBlocks = joints && wireJoints && joints->count > 0 ? (joints->count + S2_BLOCK - 1) / S2_BLOCK : 0;
 	const JointView jv = joints ? *joints : JointView{};
+	// (stage 4 rides along when the body write-back does and no s2FinalizePositions is folded into it: the SoA poses are final)
+	Stage4Args s4{};
+	int s4Shapes = 0, s4Bodies = 0;
+	if (stage4 != nullptr && stage4->shapes != nullptr && bodyBlocks > 0 && finalizeMode < 0)
+	{
+		s4 = *stage4;
+		s4Shapes = (s4.shapeCapacity + S2_BLOCK - 1) / S2_BLOCK, s4Bodies = bodyBlocks;
+	}
 	if (contactBlocks + bodyBlocks + jointBlocks + clearBlocks == 0)
 	{
-		return;
+		return false;
 	}
-	dim3 g((unsigned)(contactBlocks + bodyBlocks + jointBlocks + clearBlocks)), t(S2_BLOCK);
+	const int stage4Base = contactBlocks + bodyBlocks + jointBlocks + clearBlocks;
+	dim3 g((unsigned)(stage4Base + s4Shapes + s4Bodies)), t(S2_BLOCK);
 	switch (kind)
 	{
 		case STORE_SCALED:
-			storeImpulsesKernel<STORE_SCALED><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount, stepFailed, finalizeMode, jv, wireJoints, jointBlocks);
+			storeImpulsesKernel<STORE_SCALED><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount, stepFailed, finalizeMode, jv, wireJoints, jointBlocks, s4, s4Shapes + s4Bodies > 0 ? stage4Base : 0x7fffffff, s4Shapes);
 			break;
 		case STORE_BLOCK:
-			storeImpulsesKernel<STORE_BLOCK><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount, stepFailed, finalizeMode, jv, wireJoints, jointBlocks);
+			storeImpulsesKernel<STORE_BLOCK><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount, stepFailed, finalizeMode, jv, wireJoints, jointBlocks, s4, s4Shapes + s4Bodies > 0 ? stage4Base : 0x7fffffff, s4Shapes);
 			break;
 		default:
-			storeImpulsesKernel<STORE_PLAIN><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount, stepFailed, finalizeMode, jv, wireJoints, jointBlocks);
+			storeImpulsesKernel<STORE_PLAIN><<<g, t, 0, s>>>(c, wire, scale, contactBlocks, bodyBlocks, bodies, wireBodies, (uint4*)clear, clearCount, stepFailed, finalizeMode, jv, wireJoints, jointBlocks, s4, s4Shapes + s4Bodies > 0 ? stage4Base : 0x7fffffff, s4Shapes);
 			break;
 	}
+	return s4Shapes + s4Bodies > 0; // (stage 4 was carried)
 }
 
 // ---- message-passing launchers ----

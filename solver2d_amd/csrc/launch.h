@@ -7,6 +7,7 @@ struct BodyView;
 struct ContactView;
 struct JointView;
 struct JointPrepArgs;
+struct Stage4Args;
 struct StepConsts;
 struct GroupTable;
 struct Op;
@@ -90,9 +91,10 @@ void launchXpbdContactPositions(hipStream_t s, const ContactView& c, const BodyV
 void launchXpbdContactVelocities(hipStream_t s, const ContactView& c, const BodyView& b, int begin, int end, float h);
 void launchBlockSolveVelocity(hipStream_t s, const ContactView& c, const BodyView& b, int begin, int end);
 void launchBlockSolvePosition(hipStream_t s, const ContactView& c, const BodyView& b, int begin, int end);
-void launchStoreImpulses(hipStream_t s, int kind, const ContactView& c, s2amdContact* wire, float scale, const BodyView& bodies, s2amdBody* wireBodies,
+bool launchStoreImpulses(hipStream_t s, int kind, const ContactView& c, s2amdContact* wire, float scale, const BodyView& bodies, s2amdBody* wireBodies,
 						 void* clear, size_t clearBytes, const unsigned int* stepFailed, int finalizeMode = -1, const JointView* joints = nullptr,
-						 s2amdJoint* wireJoints = nullptr); // (with joints: their impulses go back to the wire in the same launch)
+						 s2amdJoint* wireJoints = nullptr,
+						 const Stage4Args* stage4 = nullptr); // (with joints: their impulses go back to the wire in the same launch)
 
 // bodies
 bool launchUnpackBodies(hipStream_t s, const BodyView& b, const s2amdBody* wire, const uint32_t* hostFlags, const StepConsts& sc, float h,
@@ -200,7 +202,8 @@ void launchGenericStep(hipStream_t s, const ContactView& c, const JointView& j, 
 void launchUpdateContacts(hipStream_t st, const s2amdBody* bodies, const float* origins, const s2amdShape* shapes, s2amdPairState* pairs,
 						  s2amdContact* contacts, int contactCapacity, int32_t* status, uint8_t* pointBytes, int* summary, int* separatedSlots, const uint8_t* watched);
 // stage 4 in one launch: refit per shape (origin recomputed from the body), origins + force reset per body, summary[4] += enlarged shapes
-void launchStage4(hipStream_t st, s2amdBody* bodies, int bodyCapacity, s2amdShape* shapes, int shapeCapacity, float* origins, int* summary);
+void launchStage4(hipStream_t st, s2amdBody* bodies, int bodyCapacity, s2amdShape* shapes, int shapeCapacity, float* origins, int* summary,
+				  const unsigned int* stepFailed = nullptr);
 // stage 1 on resident arrays: new pairs sorted by (A, B) into the host array outPairs; dJointed: sorted (min body << 32 | max body) keys
 // the captured launch sequence of the resident pair query and its pinned read-back buffer (owned by the solver)
 struct PairQueryGraph

@@ -385,6 +385,16 @@ struct JointPrepArgs
 	int kind, warmStart, blocks;
 };
 
+// the stage-4 blocks of a world step's epilogue launch (contact_kernels.hip: storeImpulsesKernel; refit_ops.h): what launchStage4 would
+// have been given; shapes == nullptr: none
+struct Stage4Args
+{
+	s2amdShape* shapes;
+	int shapeCapacity;
+	float2* origins;
+	int* summary;
+};
+
 #define S2J_MOUSE 1u
 #define S2J_ENABLE_MOTOR 2u
 #define S2J_ENABLE_LIMIT 4u

@@ -986,8 +986,8 @@ struct Executor
 			launchJacobiStep(st, s->cv, s->jv, s->bv, jview, deviceOps(), (int)p.ops.size(), p.sc,
 							 jacobiStepLds(s->jacobiMaxOwned, s->jacobiMaxImports, s->jacobiMaxConstraints, (int)p.ops.size()), s->jacobiMaxConstraints);
 			count();
-			launchStoreImpulses(st, p.storeKind, cvIo, wireContacts(), p.storeScale, s->bv, wireBodies(), s->dJacobiGran.p, s->jacobiGranBytes, s->jacobi.deviceError, -1, &s->jv,
-								wireJoints());
+			s->stage4Carried = launchStoreImpulses(st, p.storeKind, cvIo, wireContacts(), p.storeScale, s->bv, wireBodies(), s->dJacobiGran.p, s->jacobiGranBytes,
+													   s->jacobi.deviceError, -1, &s->jv, wireJoints(), &s->stage4);
 			count();
 			return;
 		}
@@ -1070,8 +1070,9 @@ struct Executor
 		}
 		// post: SoA -> wire: impulses and bodies in one launch (+ the epoch base of the hand-off tags)
 		const bool usedGranules = s->dStripA.view.groupCount > 0 && oneLaunchPlan();
-		launchStoreImpulses(st, p.storeKind, cvIo, wireContacts(), p.storeScale, s->bv, wireBodies(), usedGranules ? s->dGranules.p : nullptr,
-							usedGranules ? s->granuleBytes : 0, usedGranules ? s->persist.deviceError : nullptr, fusedFinalize, &s->jv, wireJoints());
+		s->stage4Carried = launchStoreImpulses(st, p.storeKind, cvIo, wireContacts(), p.storeScale, s->bv, wireBodies(), usedGranules ? s->dGranules.p : nullptr,
+												   usedGranules ? s->granuleBytes : 0, usedGranules ? s->persist.deviceError : nullptr, fusedFinalize, &s->jv, wireJoints(),
+												   &s->stage4);
 		count();
 	}
 };

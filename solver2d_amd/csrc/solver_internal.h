@@ -596,6 +596,9 @@ struct SolverRest
 	bool forcedBuild = false;  // (a worker's copy) the live structure runs sliced until this build is adopted: strips at once, and a partition the resident
 							   // kernel can run AND take created contacts into (persistValid, stripInc.valid) is all it asks for -- the search over strip
 							   // widths only when the first width gives neither
+	Stage4Args stage4{};		 // (world.hip, around a step's doStep) stage 4 of the world step, for the epilogue launch to carry
+	bool stage4Carried = false;	 // ... it did
+	bool graphCarriesStage4 = false; // ... and so does the captured step graph's epilogue launch
 	int optPairsInStep = 1;	   // "pairs_in_step": once the caller has asked for pairs (s2amd_world_find_pairs), every s2amd_world_step enqueues the next query behind its stage 4 and the call returns its results without a device round trip of its own
 	bool pairQueryUsed = false;	 // ... it has
 	bool pairCacheValid = false; // ... the last step's query is waiting to be collected

@@ -632,7 +632,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 	{
 		uint64_t key = 1469598103934665603ull;
 		key = fnv(key, params, sizeof(*params));
-		uint64_t gens[4] = {s->layoutGeneration, s->structureGeneration, s->planGeneration, (uint64_t)((q.msg ? 1 : 0) | (s->optBodyWarm ? 2 : 0) | (s->optStripLean ? 4 : 0) | (s->optPersist ? 8 : 0) | (s->optFork ? 16 : 0) | (s->persistFailed ? 32 : 0) | ((s->persistValid && s->persist.allTwoPoints) ? 64 : 0) | (s->pointsKnown ? 128 : 0) | (s->optPairLanes ? 256 : 0) | (s->optWide ? 512 : 0) | (s->optGeneric ? 1024 : 0) | (s->genericValid ? 2048 : 0) | (indexNow ? 4096 : 0) | (s->optSelfContained ? 8192 : 0) | ((s->residentAllTwoPoints && s->pointsKnown) ? 16384 : 0) | (s->optStageJoints ? 32768 : 0) | (s->optWideBodyWarm ? 65536 : 0) | (s->optSelfContainedStrips ? 131072 : 0))};
+		uint64_t gens[4] = {s->layoutGeneration, s->structureGeneration, s->planGeneration, (uint64_t)((q.msg ? 1 : 0) | (s->optBodyWarm ? 2 : 0) | (s->optStripLean ? 4 : 0) | (s->optPersist ? 8 : 0) | (s->optFork ? 16 : 0) | (s->persistFailed ? 32 : 0) | ((s->persistValid && s->persist.allTwoPoints) ? 64 : 0) | (s->pointsKnown ? 128 : 0) | (s->optPairLanes ? 256 : 0) | (s->optWide ? 512 : 0) | (s->optGeneric ? 1024 : 0) | (s->genericValid ? 2048 : 0) | (indexNow ? 4096 : 0) | (s->optSelfContained ? 8192 : 0) | ((s->residentAllTwoPoints && s->pointsKnown) ? 16384 : 0) | (s->optStageJoints ? 32768 : 0) | (s->optWideBodyWarm ? 65536 : 0) | (s->optSelfContainedStrips ? 131072 : 0) | (s->stage4.shapes != nullptr ? 262144 : 0))};
 		key = fnv(key, gens, sizeof(gens));
 		int sizes[3] = {s->bodyCapacity, s->contactCapacity, s->jointCapacity};
 		key = fnv(key, sizes, sizeof(sizes));
@@ -665,11 +665,13 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 			HIP_TRY(hipGraphInstantiate(&s->graphExec, s->graph, nullptr, nullptr, 0));
 			s->graphKey = key;
 			s->graphLaunches = s->launchCounter;
+			s->graphCarriesStage4 = s->stage4Carried;
 		}
 		else
 		{
 			s->launchCounter = s->graphLaunches;
 			s->stats.graphReplayed = 1;
+			s->stage4Carried = s->graphCarriesStage4; // (the captured epilogue launch holds the world step's stage-4 blocks, or not)
 		}
 		if (key == s->graphKey && s->graphExec != nullptr)
 		{

@@ -799,14 +799,23 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 		const int savedAsync = s->optAsync;
 		s->optAsync = 1;
 		const double td0 = debugAsync ? nowMs() : 0.0;
+		// (stage 4 rides in the solve's epilogue launch where that launch writes the bodies back -- contact_kernels.hip: storeImpulsesKernel --;
+		// a step without one, or one that is replayed from a captured graph, gets the launch of its own)
+		s->stage4 = Stage4Args{(s2amdShape*)s->dShapes.p, ns, (float2*)s->dOrigins.p, (int*)dSum};
+		s->stage4Carried = false;
 		rc = doStep(s, params);
+		s->stage4 = Stage4Args{};
 		tStep += debugAsync ? nowMs() - td0 : 0.0;
 		s->optAsync = savedAsync;
 		if (rc)
 		{
 			return rc;
 		}
-		launchStage4(st, (s2amdBody*)s->dBodies.p, nb, (s2amdShape*)s->dShapes.p, ns, (float*)s->dOrigins.p, (int*)dSum);
+		if (!s->stage4Carried)
+		{
+			launchStage4(st, (s2amdBody*)s->dBodies.p, nb, (s2amdShape*)s->dShapes.p, ns, (float*)s->dOrigins.p, (int*)dSum,
+						 s->persistValid ? s->persist.deviceError : nullptr);
+		}
 		const bool stepBack = s->optStepReadback != 0 && s->refitOrderCount > 0 && nb > 0 && ns > 0;
 		if (stepBack && (rc = enqueueStepBack(s)) != 0)
 		{

@@ -800,7 +800,8 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 		s->optAsync = 1;
 		const double td0 = debugAsync ? nowMs() : 0.0;
 		// (stage 4 rides in the solve's epilogue launch where that launch writes the bodies back -- contact_kernels.hip: storeImpulsesKernel --;
-		// a step without one, or one that is replayed from a captured graph, gets the launch of its own)
+		// a step without such a launch (a world of self-contained resident islands; a store that finalizes positions itself) gets the
+		// launch of its own; a captured step graph knows which of the two it holds: solver_step.cpp)
 		s->stage4 = Stage4Args{(s2amdShape*)s->dShapes.p, ns, (float2*)s->dOrigins.p, (int*)dSum};
 		s->stage4Carried = false;
 		rc = doStep(s, params);

@@ -1,0 +1,235 @@
+"""The order-free statement of the reference's broad-phase tree maintenance that the device executes
+(solver2d_amd/csrc/tree_mirror.hip) -- TEST INFRASTRUCTURE, numpy.
+
+The reference keeps one s2DynamicTree per body type (src/broad_phase.h:27) and touches it twice per step:
+  stage 4  s2DynamicTree_EnlargeProxy for every shape whose tight box left its fat box (src/dynamic_tree.c:803-839,
+           called from src/world.c:283-290), and
+  stage 2  s2DynamicTree_Rebuild(tree, false) (src/dynamic_tree.c:1764-1874, world.c:130): every internal node an
+           enlarge has flagged is freed, what hangs below the flagged region (leaves and un-flagged subtrees)
+           is gathered depth first and a new top is built over it by recursive median splits
+           (s2BuildTree :1610-1761, s2PartitionMid :1317-1427).
+Both are written as sequential pointer walks there.  What a query's callback order -- hence the creation order
+of contacts, src/broad_phase.c:253-254 -- depends on is the resulting TOPOLOGY, and new proxies get the node ids
+the free list hands out, so the device has to reproduce the node array itself.  The facts used (each one
+checked node for node against the compiled reference by tests/test_tree_rebuild.py):
+
+ * enlarge: boxes only grow by min / max, flags are only set -- the result is the same in any order:
+   every ancestor's box = union(old box, new fat boxes below), every ancestor flagged (given that a flagged
+   node's parent is flagged, which a rebuild establishes and enlarges keep).
+ * rebuild frees the M flagged nodes in child1-first pre-order, each pushed at the head of the free list, and
+   s2BuildTree pops exactly M = L - 1 of them (L gathered leaves) in the pre-order of the NEW top: the k-th
+   new node in pre-order takes the id of the (M - 1 - k)-th old one, the rest of the free list is untouched.
+ * s2PartitionMid's Hoare loop over (indices, centres) is a fixed permutation: with m = #(centre < pivot), the
+   j-th element of [0, m) that is >= pivot changes places with the j-th element of [m, n) counted from the
+   right that is < pivot; nothing moves when m is 0 or n (then the split is n / 2).  A prefix sum of the
+   predicate gives every element its partner.
+ * a new node's box / height / category bits are min-max / max+1 / OR over its children: bottom-up, order free.
+"""
+import numpy as np
+
+NULL = -1
+
+# s2TreeNode, include/solver2d/dynamic_tree.h:14-41 (48 bytes; `parent` is `next` in a free node)
+NODE = np.dtype([("aabb", "<f4", 4), ("categoryBits", "<u4"), ("parent", "<i4"), ("child1", "<i4"), ("child2", "<i4"),
+                 ("userData", "<i4"), ("height", "<i2"), ("enlarged", "u1"), ("pad", "u1", 9)])
+assert NODE.itemsize == 48
+
+
+def enlarge(nodes, proxies, boxes):
+    """stage 4 for one tree: nodes[proxy].aabb = box; every ancestor's box grown to hold it and flagged
+    (src/dynamic_tree.c:803-839 for each proxy, any order).  Returns the ids that became flagged."""
+    newly = []
+    for proxy, box in zip(proxies, boxes):
+        nodes["aabb"][proxy] = box
+        p = nodes["parent"][proxy]
+        while p != NULL:
+            a = nodes["aabb"][p]
+            a[0] = min(a[0], box[0])
+            a[1] = min(a[1], box[1])
+            a[2] = max(a[2], box[2])
+            a[3] = max(a[3], box[3])
+            if not nodes["enlarged"][p]:
+                nodes["enlarged"][p] = 1
+                newly.append(int(p))
+            p = nodes["parent"][p]
+    return newly
+
+
+def flags_are_closed(nodes):
+    """what the device requires of an uploaded tree: a flagged live internal node's parent is flagged too"""
+    live = nodes["height"] > 0
+    flagged = live & (nodes["enlarged"] != 0)
+    par = nodes["parent"][flagged]
+    return bool(np.all((par == NULL) | (nodes["enlarged"][np.maximum(par, 0)] != 0)))
+
+
+def leaf_counts(nodes, root):
+    """real leaves below every node (0 for free nodes)"""
+    out = np.zeros(len(nodes), dtype=np.int32)
+    if root == NULL:
+        return out
+    order = []
+    stack = [root]
+    while stack:
+        n = stack.pop()
+        order.append(n)
+        if nodes["height"][n] > 0:
+            stack.append(int(nodes["child1"][n]))
+            stack.append(int(nodes["child2"][n]))
+    for n in reversed(order):
+        out[n] = 1 if nodes["height"][n] == 0 else out[nodes["child1"][n]] + out[nodes["child2"][n]]
+    return out
+
+
+def traversal_rank(nodes, counts, leaf):
+    """position of `leaf` in s2DynamicTree_Query's callback order over the whole tree (src/dynamic_tree.c:1171-1210:
+    child1 is pushed first, so child2 is popped first): the leaves under child2 of every ancestor it hangs under child1 of.
+    Pruned subtrees do not change the relative order of the leaves that are reported."""
+    rank = 0
+    n = leaf
+    p = nodes["parent"][n]
+    while p != NULL:
+        if nodes["child1"][p] == n:
+            rank += int(counts[nodes["child2"][p]])
+        n = p
+        p = nodes["parent"][n]
+    return rank
+
+
+def rebuild(nodes, root):
+    """s2DynamicTree_Rebuild(tree, false), order free.  Returns the new root."""
+    if root == NULL or nodes["height"][root] == 0 or not nodes["enlarged"][root]:
+        return root  # (one gathered leaf: s2BuildTree hands it back, :1615-1619)
+    height, enl = nodes["height"], nodes["enlarged"]
+    c1, c2, par = nodes["child1"], nodes["child2"], nodes["parent"]
+
+    def flagged(n):
+        return height[n] > 0 and enl[n] != 0
+
+    # the flagged region, msize[n] = flagged nodes in n's subtree (bottom-up), from the list the enlarge pass made
+    marked = [int(n) for n in np.nonzero((height > 0) & (enl != 0))[0]]
+    msize = {}
+    pending = {n: int(flagged(c1[n])) + int(flagged(c2[n])) for n in marked}
+    acc = {n: 1 for n in marked}
+    ready = [n for n in marked if pending[n] == 0]
+    while ready:
+        n = ready.pop()
+        msize[n] = acc[n]
+        p = int(par[n])
+        if n != root:
+            assert flagged(p), "flag not closed under parent"
+            acc[p] += acc[n]
+            pending[p] -= 1
+            if pending[p] == 0:
+                ready.append(p)
+    M = msize[root]
+    assert M == len(marked)
+    L = M + 1
+
+    def ms(n):
+        return msize[n] if flagged(n) else 0
+
+    # pre-order index of every flagged node / depth-first index of every gathered leaf: one walk up each
+    old_pre = np.zeros(M, dtype=np.int64)
+    for n in marked:
+        k, x = 0, n
+        while x != root:
+            p = int(par[x])
+            k += 1 + (ms(int(c1[p])) if c2[p] == x else 0)
+            x = p
+        old_pre[k] = n
+    leaf_idx = np.zeros(L, dtype=np.int32)
+    for n in marked:
+        for c in (int(c1[n]), int(c2[n])):
+            if flagged(c):
+                continue
+            k, x = 0, c
+            while x != root:
+                p = int(par[x])
+                if c2[p] == x:
+                    k += ms(int(c1[p])) + 1
+                x = p
+            leaf_idx[k] = c
+    aabb = nodes["aabb"]
+    cx = (np.float32(0.5) * (aabb[leaf_idx, 0] + aabb[leaf_idx, 2])).astype(np.float32)  # s2AABB_Center, aabb.h:28-32
+    cy = (np.float32(0.5) * (aabb[leaf_idx, 1] + aabb[leaf_idx, 3])).astype(np.float32)
+    for c in leaf_idx:
+        par[c] = NULL  # "Detach", :1826
+
+    def node_of(pre):
+        return int(old_pre[M - 1 - pre])
+
+    # the flagged nodes come back as the new top: s2_defaultTreeNode (:19) with the links filled in below
+    for n in marked:
+        nodes[n] = np.zeros((), dtype=NODE)
+        par[n], c1[n], c2[n], nodes["userData"][n], height[n] = NULL, NULL, NULL, -1, -2
+
+    # level by level: every open segment [start, end) of the leaf array is an internal node, named by its pre-order index
+    segments = [(0, L, 0)]
+    while segments:
+        nxt = []
+        for start, end, pre in segments:
+            n = end - start
+            me = node_of(pre)
+            if n <= 2:
+                split = n // 2
+            else:
+                sx, sy = cx[start:end], cy[start:end]
+                lo = (sx.min(), sy.min())
+                hi = (sx.max(), sy.max())
+                dx, dy = np.float32(hi[0] - lo[0]), np.float32(hi[1] - lo[1])
+                if dx > dy:
+                    pivot = np.float32(0.5) * np.float32(lo[0] + hi[0])
+                    flag = sx < pivot
+                else:
+                    pivot = np.float32(0.5) * np.float32(lo[1] + hi[1])
+                    flag = sy < pivot
+                m = int(flag.sum())
+                if 0 < m < n:
+                    before = np.cumsum(flag) - flag  # exclusive prefix sum of the predicate
+                    pos = np.arange(n)
+                    left = pos[(pos < m) & ~flag]  # rank j from the left = pos - before
+                    right = pos[(pos >= m) & flag]  # rank j from the right = m - before - 1
+                    rank_l = left - before[left]
+                    rank_r = m - before[right] - 1
+                    partner = np.zeros(len(left), dtype=np.int64)
+                    partner[rank_r] = right
+                    a = start + left
+                    b = start + partner[rank_l]
+                    for arr in (leaf_idx, cx, cy):
+                        arr[a], arr[b] = arr[b].copy(), arr[a].copy()
+                    split = m
+                else:
+                    split = n // 2
+            for which, (s, e) in enumerate(((start, start + split), (start + split, end))):
+                if e - s == 1:
+                    child = int(leaf_idx[s])
+                else:
+                    child_pre = pre + 1 if which == 0 else pre + split
+                    child = node_of(child_pre)
+                    nxt.append((s, e, child_pre))
+                (c1 if which == 0 else c2)[me] = child
+                par[child] = me
+        segments = nxt
+
+    # boxes, heights, category bits bottom-up (:1655-1657, :1742-1744)
+    new_root = node_of(0)
+
+    def finish(n):
+        stack = [(n, 0)]
+        while stack:
+            x, state = stack.pop()
+            if height[x] >= 0:  # a gathered leaf or a kept subtree
+                continue
+            if state == 0:
+                stack.append((x, 1))
+                stack.append((int(c1[x]), 0))
+                stack.append((int(c2[x]), 0))
+            else:
+                a, b = int(c1[x]), int(c2[x])
+                nodes["aabb"][x] = (min(aabb[a, 0], aabb[b, 0]), min(aabb[a, 1], aabb[b, 1]), max(aabb[a, 2], aabb[b, 2]),
+                                    max(aabb[a, 3], aabb[b, 3]))
+                height[x] = 1 + max(height[a], height[b])
+                nodes["categoryBits"][x] = nodes["categoryBits"][a] | nodes["categoryBits"][b]
+    finish(new_root)
+    return new_root

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define S2AMD_API_VERSION 4
+#define S2AMD_API_VERSION 5
 
 /* error codes */
 #define S2AMD_OK 0
@@ -367,6 +367,35 @@ typedef struct s2amdMovedBox
 } s2amdMovedBox;
 int s2amd_world_set_refit_order(s2amdSolver* solver, const int32_t* shapeOrder, int32_t count);
 int s2amd_world_download_step(s2amdSolver* solver, float* poses, int32_t bodyCapacity, s2amdMovedBox* moved, int32_t movedCapacity, int32_t* movedCount);
+/* (API 5) The reference's broad-phase trees on the device.  s2UpdateBroadPhasePairs creates a step's contacts in the order its tree
+ * queries call back (src/broad_phase.c:253-254, :288-320, :332-357: move-buffer order of the asking proxies; per proxy the trees in
+ * reverse query order and each tree's callbacks reversed), and that order decides every new contact's pool slot.  It is a function of
+ * the topology of the reference's three trees (src/broad_phase.h:27), which is history: stage 2 rebuilds only what stage 4 flagged
+ * (s2DynamicTree_Rebuild(tree, false), src/dynamic_tree.c:1764-1874).  A caller that hands the device those trees once --
+ *   s2amd_world_set_tree(solver, bodyType, tree.nodes, tree.nodeCapacity, tree.root)   for s2_staticBody, s2_kinematicBody, s2_dynamicBody
+ * after s2amd_world_upload, in the state stage 2 leaves them in (no internal node flagged `enlarged`; refused otherwise) -- gets
+ *   - s2amd_world_step keeping them as the reference would: its stage 2 rebuilds them (same topology, same node ids, same boxes),
+ *     its stage 4 enlarges the proxies of the shapes it re-inflates (src/world.c:283-290, src/dynamic_tree.c:803-839);
+ *   - s2amd_world_find_pairs returning the new pairs IN THE REFERENCE'S CREATION ORDER instead of sorted by (A, B): calling
+ *     s2CreateContact down the list gives every contact the reference's pool slot (the position of an asking proxy in the move buffer
+ *     is its shape's position in the refit order of s2amd_world_set_refit_order; without one, its shape index);
+ *   - s2amd_world_get_tree copying a tree back (node array as the reference would hold it now -- the free list's nodes are untouched
+ *     by a rebuild, which takes exactly the nodes it frees, src/dynamic_tree.c:105-139 -- and the root), for the caller's own
+ *     s2DynamicTree when it needs one: s2World_QueryAABB, s2World_Draw, a proxy created or destroyed.
+ * A new s2amd_world_upload forgets the trees.  s2amdTreeNode is s2TreeNode byte for byte (include/solver2d/dynamic_tree.h:14-41). */
+typedef struct s2amdTreeNode
+{
+	float aabb[4];
+	uint32_t categoryBits;
+	int32_t parent; /* `next` of a free node */
+	int32_t child1, child2;
+	int32_t userData;
+	int16_t height; /* leaf 0, free node -1 */
+	uint8_t enlarged;
+	uint8_t pad[9];
+} s2amdTreeNode;
+int s2amd_world_set_tree(s2amdSolver* solver, int32_t bodyType, const s2amdTreeNode* nodes, int32_t nodeCapacity, int32_t root);
+int s2amd_world_get_tree(s2amdSolver* solver, int32_t bodyType, s2amdTreeNode* nodes, int32_t nodeCapacity, int32_t* root);
 /* Writes `count` contact slots of the resident world (slot indices < contactCapacity of the upload): the caller's
  * s2CreateContact (src/contact.c:137-203: pool slot, pair flip, mixed friction, empty manifold) or s2DestroyContact
  * (pairs[i].shapeA = -1, contacts[i].pointCount = 0).  A world that needs more slots, bodies or shapes is uploaded again. */

@@ -394,6 +394,8 @@ typedef struct AmdApi
 	int (*worldDownloadBoxes)(s2amdSolver*, s2amdShapeBox*, int32_t);
 	int (*worldSetRefitOrder)(s2amdSolver*, const int32_t*, int32_t);
 	int (*worldDownloadStep)(s2amdSolver*, float*, int32_t, s2amdMovedBox*, int32_t, int32_t*);
+	int (*worldSetTree)(s2amdSolver*, int32_t, const s2amdTreeNode*, int32_t, int32_t);
+	int (*worldGetTree)(s2amdSolver*, int32_t, s2amdTreeNode*, int32_t, int32_t*);
 	int (*setOption)(s2amdSolver*, const char*, int32_t);
 } AmdApi;
 static AmdApi s_api = {0};
@@ -438,6 +440,11 @@ typedef struct WorldBinding
 	int* pendingSteps; // boxes per pending step
 	int pendingStepCount, pendingStepCapacity;
 	int lastMoved;	  // boxes the last step re-inflated: the next pair query has something to look at
+	// (round 6) the device holds the reference's trees (s2amd_world_set_tree) and maintains them itself: the pair query comes back in
+	// creation order and nothing is replayed here.  While `treesStale` the host's trees, fat boxes and move buffer are those of the last
+	// upload; pullTrees copies the device's back when somebody reads them.  The log then holds the LAST step's boxes only (the move buffer).
+	int deviceTrees;
+	int treesStale;
 	int liveCount;	  // slots with liveKey >= 0
 	int createdCount; // >= 0: this step's stage 1 ran here (device pairs) and created exactly the contacts in createdSlots
 	int32_t* createdSlots;
@@ -447,6 +454,9 @@ static WorldBinding s_bindings[s2_maxWorlds];
 static long s_uploads = 0, s_steps = 0;
 static int s_lastError = 0;
 static int s_devicePairs = 0;
+static int s_deviceTrees = -1;	// -1: not read yet (S2AMD_DEVICE_TREES, default 1); 0: round 5's host replay; 1: trees on the device
+static int s_checkTrees = -1;	// S2AMD_CHECK_TREES=1: both at once -- the host replay (s2amdBinding_OrderPairs) checks the device's order and trees
+static long s_treeCheck[4] = {0, 0, 0, 0}; // queries compared, queries whose order differed, tree comparisons, trees that differed
 static double s_phaseMs[6] = {0}; // stage 1+2, sync in, device step, download, apply, steps
 
 static double wallMs(void)
@@ -506,6 +516,8 @@ int s2amdBinding_Open(const char* libraryPath, int device)
 		S2_BIND(worldDownloadBoxes, "s2amd_world_download_boxes")
 		S2_BIND(worldSetRefitOrder, "s2amd_world_set_refit_order")
 		S2_BIND(worldDownloadStep, "s2amd_world_download_step")
+		S2_BIND(worldSetTree, "s2amd_world_set_tree")
+		S2_BIND(worldGetTree, "s2amd_world_get_tree")
 		S2_BIND(setOption, "s2amd_set_option")
 #undef S2_BIND
 	}
@@ -601,7 +613,7 @@ static void (*s_rebuildTrees)(s2BroadPhase*) = NULL; // stage 2 as handed to s2a
 // is cleared (as the pair query of that step would have left it, src/broad_phase.c end of s2UpdateBroadPhasePairs), the
 // trees are rebuilt (world.c:130) and the step's proxies enlarged in refit order (world.c:283-290) -- the very calls the
 // per-step path makes, later.  Afterwards trees, fat boxes and move buffer are what they would be had every step done it.
-static void flushTrees(s2World* world, WorldBinding* b)
+static void replayTrees(s2World* world, WorldBinding* b)
 {
 	if (b->pendingStepCount == 0 || s_rebuildTrees == NULL)
 	{
@@ -627,6 +639,162 @@ static void flushTrees(s2World* world, WorldBinding* b)
 	}
 	b->pendingStepCount = 0;
 	b->pendingBoxCount = 0;
+}
+
+// ---- the trees on the device (round 6; include/solver2d_amd.h: s2amd_world_set_tree) ----
+_Static_assert(sizeof(s2amdTreeNode) == sizeof(s2TreeNode), "s2amdTreeNode mirrors s2TreeNode byte for byte");
+
+static int deviceTreesWanted(void)
+{
+	if (s_deviceTrees < 0)
+	{
+		const char* e = getenv("S2AMD_DEVICE_TREES");
+		s_deviceTrees = e != NULL && atoi(e) == 0 ? 0 : 1;
+		const char* c = getenv("S2AMD_CHECK_TREES");
+		s_checkTrees = c != NULL && atoi(c) != 0 ? 1 : 0;
+	}
+	return s_deviceTrees;
+}
+
+// After s2amd_world_upload: the three trees as they stand -- stage 2 has run, so no internal node is flagged (the library refuses a
+// tree that is: one a host edit left flags in, src/dynamic_tree.c:610-684 inserts unflagged parents between flagged nodes.  Such a
+// world keeps round 5's host replay until its next upload).
+static void sendTrees(s2World* world, WorldBinding* b)
+{
+	b->deviceTrees = 0;
+	b->treesStale = 0;
+	if (!s_devicePairs || !deviceTreesWanted())
+	{
+		return;
+	}
+	const s2BroadPhase* bp = &world->broadPhase;
+	for (int type = 0; type < s2_bodyTypeCount; ++type)
+	{
+		const s2DynamicTree* tree = bp->trees + type;
+		if (s_api.worldSetTree(b->solver, type, (const s2amdTreeNode*)tree->nodes, tree->nodeCapacity, tree->root) != 0)
+		{
+			return; // (the next s2amd_world_upload forgets what was sent)
+		}
+	}
+	b->deviceTrees = 1;
+}
+
+// The device's trees into the reference's own (kinematic and dynamic: the static one never changes on the device), the fat boxes from
+// their leaves, the move buffer as the last refit left it (world.c:283-290: the shapes it re-inflated, in its order).  What a replay of
+// every step since the upload would have arrived at.
+static int pullTrees(s2World* world, WorldBinding* b)
+{
+	s2BroadPhase* bp = &world->broadPhase;
+	for (int type = s2_kinematicBody; type <= s2_dynamicBody; ++type)
+	{
+		s2DynamicTree* tree = bp->trees + type;
+		int32_t root = S2_NULL_INDEX;
+		const int rc = s_api.worldGetTree(b->solver, type, (s2amdTreeNode*)tree->nodes, tree->nodeCapacity, &root);
+		if (rc != 0)
+		{
+			fprintf(stderr, "s2amd binding: the device's tree %d could not be read back (%d): %s\n", type, rc, s_api.lastError());
+			s_lastError = rc;
+			return rc;
+		}
+		tree->root = root;
+	}
+	const int ns = world->shapePool.capacity < b->shapeCapacity ? world->shapePool.capacity : b->shapeCapacity;
+	for (int i = 0; i < ns; ++i)
+	{
+		s2Shape* sh = world->shapes + i;
+		if (s2IsFree(&sh->object) || S2_PROXY_TYPE(sh->proxyKey) == s2_staticBody)
+		{
+			continue;
+		}
+		sh->fatAABB = bp->trees[S2_PROXY_TYPE(sh->proxyKey)].nodes[S2_PROXY_ID(sh->proxyKey)].aabb;
+	}
+	s2Array_Clear(bp->moveArray);
+	s2ClearSet(&bp->moveSet);
+	const s2amdMovedBox* e = b->pendingBoxes;
+	for (int i = 0; i < b->pendingBoxCount; ++i, ++e)
+	{
+		if (e->shape >= 0 && e->shape < world->shapePool.capacity && !s2IsFree(&world->shapes[e->shape].object))
+		{
+			s2BufferMove(bp, world->shapes[e->shape].proxyKey);
+		}
+	}
+	b->pendingStepCount = 0;
+	b->pendingBoxCount = 0;
+	b->treesStale = 0;
+	return 0;
+}
+
+// S2AMD_CHECK_TREES: the reference's trees after the replay against the device's, node for node
+static void checkTrees(s2World* world, WorldBinding* b)
+{
+	static s2amdTreeNode* got;
+	static int gotCapacity;
+	const s2BroadPhase* bp = &world->broadPhase;
+	for (int type = s2_kinematicBody; type <= s2_dynamicBody; ++type)
+	{
+		const s2DynamicTree* tree = bp->trees + type;
+		if (gotCapacity < tree->nodeCapacity)
+		{
+			gotCapacity = tree->nodeCapacity + 1024;
+			got = (s2amdTreeNode*)growTo(got, (size_t)gotCapacity, sizeof(s2amdTreeNode));
+		}
+		int32_t root = S2_NULL_INDEX;
+		s_treeCheck[2] += 1;
+		if (s_api.worldGetTree(b->solver, type, got, tree->nodeCapacity, &root) != 0 || root != tree->root)
+		{
+			s_treeCheck[3] += 1;
+			continue;
+		}
+		int same = 1;
+		for (int i = 0; i < tree->nodeCapacity && same; ++i)
+		{
+			const s2TreeNode* r = tree->nodes + i;
+			const s2amdTreeNode* g = got + i;
+			same = r->parent == g->parent && r->height == g->height;
+			if (same && r->height >= 0)
+			{
+				same = r->child1 == g->child1 && r->child2 == g->child2 && r->userData == g->userData && r->categoryBits == g->categoryBits &&
+					   (r->enlarged ? 1 : 0) == (g->enlarged ? 1 : 0) && r->aabb.lowerBound.x == g->aabb[0] && r->aabb.lowerBound.y == g->aabb[1] &&
+					   r->aabb.upperBound.x == g->aabb[2] && r->aabb.upperBound.y == g->aabb[3];
+			}
+			if (!same && getenv("S2AMD_CHECK_TREES_VERBOSE") != NULL)
+			{
+				fprintf(stderr, "tree %d node %d: reference {parent %d children %d %d height %d enlarged %d box %g %g %g %g} device {%d, %d %d, %d, %d, %g %g %g %g}\n", type,
+						i, r->parent, r->child1, r->child2, r->height, r->enlarged, r->aabb.lowerBound.x, r->aabb.lowerBound.y, r->aabb.upperBound.x,
+						r->aabb.upperBound.y, g->parent, g->child1, g->child2, g->height, g->enlarged, g->aabb[0], g->aabb[1], g->aabb[2], g->aabb[3]);
+			}
+		}
+		s_treeCheck[3] += same ? 0 : 1;
+	}
+}
+
+void s2amdBinding_DeviceTrees(int on, int check)
+{
+	s_deviceTrees = on ? 1 : 0;
+	s_checkTrees = check ? 1 : 0;
+}
+
+void s2amdBinding_TreeCheck(long out[4])
+{
+	for (int i = 0; i < 4; ++i)
+	{
+		out[i] = s_treeCheck[i];
+		s_treeCheck[i] = 0;
+	}
+}
+
+// the host's trees, fat boxes and move buffer as the reference would hold them now
+static void flushTrees(s2World* world, WorldBinding* b)
+{
+	if (b->deviceTrees && !s_checkTrees)
+	{
+		if (b->treesStale)
+		{
+			(void)pullTrees(world, b);
+		}
+		return;
+	}
+	replayTrees(world, b);
 }
 
 // room in the log for one more step of `boxes` re-inflated boxes
@@ -882,12 +1050,24 @@ static int residentMatches(const s2World* w, const WorldBinding* b)
 		   b->jointCount == w->jointPool.count && b->contactCapacity == w->contactPool.capacity;
 }
 
-static int uploadWorld(s2World* w, WorldBinding* b)
+static int uploadWorld(s2World* w, WorldBinding* b, int leanStep)
 {
 	int rc = 0;
 	if (b->resident && (rc = syncToPools(w, b)) != 0) // the pools changed under a resident world: its manifolds first
 	{
 		return rc;
+	}
+	if (leanStep && s_devicePairs && deviceTreesWanted() && s_rebuildTrees != NULL)
+	{
+		// (this step's stage 1 ran on the device's pairs and its stage 2 has not run anywhere: the host's trees -- current after
+		// syncToPools -- get it now, src/world.c:125-130, so that they can be sent along clean)
+		if (b->pendingStepCount > 0)
+		{
+			replayTrees(w, b); // (a world on the host replay: its log first)
+		}
+		s2Array_Clear(w->broadPhase.moveArray);
+		s2ClearSet(&w->broadPhase.moveSet);
+		s_rebuildTrees(&w->broadPhase);
 	}
 	int nb = w->bodyPool.capacity, ns = w->shapePool.capacity, nj = w->jointPool.capacity, nc = w->contactPool.capacity;
 	b->bodies = (s2amdBody*)growTo(b->bodies, (size_t)nb, sizeof(s2amdBody));
@@ -942,6 +1122,7 @@ static int uploadWorld(s2World* w, WorldBinding* b)
 		return rc != 0 ? rc : S2AMD_E_DEVICE;
 	}
 	b->resident = 1;
+	sendTrees(w, b);
 	b->bodyCapacity = nb, b->bodyCount = w->bodyPool.count;
 	b->shapeCapacity = ns, b->shapeCount = w->shapePool.count;
 	b->jointCapacity = nj, b->jointCount = w->jointPool.count;
@@ -1176,16 +1357,46 @@ void s2amdBinding_WorldStep(s2World* world, float timeStep, int velIters, int po
 				b->newPairs = (int32_t*)growTo(b->newPairs, (size_t)b->newPairCapacity * 2, sizeof(int32_t));
 				rc = s_api.worldFindPairs(b->solver, b->newPairs, b->newPairCapacity, &count);
 			}
-			if (rc == 0 && count > 0)
+			// new pairs: the device returns them in the reference's creation order when it holds the reference's trees (round 6:
+			// s2amd_world_set_tree); otherwise -- and as the checker, S2AMD_CHECK_TREES -- the order is read off the host's trees and
+			// move buffer, which the steps since the last pair have only logged: replayed now (in nearly every step of a settled world
+			// there is nothing to create, and the trees are not touched at all)
+			const int ordered = b->deviceTrees;
+			if (rc == 0 && count > 0 && (!ordered || s_checkTrees))
 			{
-				// new pairs: their creation order is read off the trees and the move buffer, which the steps since the last
-				// pair have only logged -- replayed now (in nearly every step of a settled world there is nothing to create, and
-				// the trees are not touched at all)
-				flushTrees(world, b);
+				replayTrees(world, b);
+				if (ordered)
+				{
+					checkTrees(world, b);
+				}
 			}
-			if (rc == 0 && count > 1)
+			if (rc == 0 && count > 1 && !ordered)
 			{
 				s2amdBinding_OrderPairs(world, bp->moveArray, s2Array(bp->moveArray).count, b->newPairs, count);
+			}
+			else if (rc == 0 && count > 1 && s_checkTrees)
+			{
+				static int32_t* want;
+				static int wantCapacity;
+				if (wantCapacity < count)
+				{
+					wantCapacity = count + 1024;
+					want = (int32_t*)growTo(want, (size_t)wantCapacity * 2, sizeof(int32_t));
+				}
+				memcpy(want, b->newPairs, (size_t)count * 2 * sizeof(int32_t));
+				s2amdBinding_OrderPairs(world, bp->moveArray, s2Array(bp->moveArray).count, want, count);
+				s_treeCheck[0] += 1;
+				if (memcmp(want, b->newPairs, (size_t)count * 2 * sizeof(int32_t)) != 0)
+				{
+					s_treeCheck[1] += 1;
+					if (getenv("S2AMD_CHECK_TREES_VERBOSE") != NULL)
+					{
+						for (int i = 0; i < count; ++i)
+						{
+							fprintf(stderr, "pair %d: device (%d, %d) reference (%d, %d)\n", i, b->newPairs[2 * i], b->newPairs[2 * i + 1], want[2 * i], want[2 * i + 1]);
+						}
+					}
+				}
 			}
 			if (b->createdCapacity < count)
 			{
@@ -1219,7 +1430,7 @@ void s2amdBinding_WorldStep(s2World* world, float timeStep, int velIters, int po
 
 	if (rc == 0 && (!residentMatches(world, b) || (rc = sendNewContacts(world, b)) == 1))
 	{
-		rc = uploadWorld(world, b);
+		rc = uploadWorld(world, b, lean);
 	}
 	s2amdStepParams params;
 	fillParams(world, &params, (int32_t)world->solverType, timeStep, velIters, posIters, warmStart ? 1 : 0);
@@ -1235,6 +1446,13 @@ void s2amdBinding_WorldStep(s2World* world, float timeStep, int velIters, int po
 	const int leanBack = lean && rc == 0; // (a step that had to upload the world reads everything back once, like the host-pairs route)
 	if (leanBack)
 	{
+		if (b->deviceTrees && !s_checkTrees)
+		{
+			// (the device keeps the trees: the log holds the last step's boxes only -- the move buffer, should the host's trees be asked for)
+			b->pendingBoxCount = 0;
+			b->pendingStepCount = 0;
+			b->treesStale = 1;
+		}
 		rc = reservePending(b, info.movedCount); // (the step's boxes are written straight into the log)
 		if (rc == 0)
 		{

@@ -43,6 +43,12 @@ void s2amdBinding_DevicePairs(int on);
  * (src/broad_phase.c:253-254, :332-357): read off the reference's own trees and move array. */
 void s2amdBinding_OrderPairs(s2World* world, const int* moveArray, int moveCount, int32_t* pairs, int32_t count);
 
+/* S2AMD_CHECK_TREES=1: {pair queries compared, queries whose creation order differed from s2amdBinding_OrderPairs', tree comparisons, trees
+ * that differed from the host replay's}; reading resets the counters */
+void s2amdBinding_TreeCheck(long out[4]);
+/* on: the device keeps the reference's trees and orders the new pairs itself (default; S2AMD_DEVICE_TREES=0 for round 5's host replay);
+ * check: both, compared every query (S2AMD_CHECK_TREES=1).  Takes effect at a world's next upload. */
+void s2amdBinding_DeviceTrees(int on, int check);
 int s2amdBinding_LastError(void);
 long s2amdBinding_Uploads(void);		   /* whole-world uploads so far: one per world, and one more whenever a pool grew */
 void s2amdBinding_Timing(double out[6]); /* accumulated ms: stage 1+2, sync in, device step, download, apply; [5] = steps */

@@ -611,7 +611,7 @@ __global__ __launch_bounds__(S2_BLOCK) void residentPairKeysKernel(const s2amdPa
 int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShapes, const s2amdPairState* dPairs, int nc,
 					  const unsigned long long* dJointed, int jointedCount, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount, void** scratch,
 					  size_t* scratchBytes, unsigned long long* sortedPairKeys, bool* sortedPairKeysValid, PairQueryGraph* cache, int mode,
-					  const unsigned long long* pairLog, const int* pairLogSlots)
+					  const unsigned long long* pairLog, const int* pairLogSlots, const TreeViews* trees)
 {
 	// mode: S2_PAIRS_FULL the whole query; S2_PAIRS_WARM buffers + captured graph, nothing runs (s2amd_world_upload); S2_PAIRS_ENQUEUE
 	// the query enqueued behind the caller's work, no wait (s2amd_world_step); S2_PAIRS_COLLECT the results of such a query, after the
@@ -635,12 +635,12 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 	BP_TRY(rocprim::radix_sort_pairs(nullptr, tmpSort, (uint32_t*)nullptr, (uint32_t*)nullptr, (int*)nullptr, (int*)nullptr, (size_t)ns, 0, 32, st));
 	BP_TRY(rocprim::exclusive_scan(nullptr, tmpScan, (unsigned int*)nullptr, (unsigned int*)nullptr, 0u, (size_t)n + 1, rocprim::plus<unsigned int>(), st));
 	// (the device-side pair buffer is sized by the pool, not by the caller's buffer: the captured graph below depends on it, and
-	// s2amd_world_upload captures that graph before any caller has shown its buffer)
-	size_t outCap = (size_t)std::max(nc, 1024);
+	// s2amd_world_upload captures that graph before any caller has shown its buffer -- and by the largest query that did not fit)
+	size_t outCap = std::max((size_t)std::max(nc, 1024), cache->outCapWanted);
 	BP_TRY(rocprim::radix_sort_pairs(nullptr, tmpKeys, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (int*)nullptr, (int*)nullptr, std::max((size_t)nc, outCap), 0, 64, st));
 	size_t tmpBytes = std::max(std::max(tmpSort, tmpScan), tmpKeys);
 	size_t layout[] = {al((size_t)ns), al((size_t)ns * 4), al((size_t)ns * 4), al((size_t)ns * 4), al((size_t)ns * 4), al((size_t)n * 16),
-					   al(((size_t)n + 1) * 4), al(((size_t)n + 1) * 4), al((size_t)nc * 8 + 8), al((size_t)nc * 8 + 8), al(outCap * 8), al(outCap * 8), al(256),
+					   al(((size_t)n + 1) * 4), al(((size_t)n + 1) * 4), al((size_t)nc * 8 + 8), al((size_t)nc * 8 + 8), al(outCap * 8), al(outCap * 8), al(outCap * 8), al(256),
 					   al(tmpBytes + 256)};
 	size_t total = 0;
 	for (size_t b : layout)
@@ -679,7 +679,8 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 	unsigned long long* dExistingIn = (unsigned long long*)take();
 	unsigned long long* dExisting = (unsigned long long*)take();
 	unsigned long long* dOutA = (unsigned long long*)take();
-	unsigned long long* dOutB = (unsigned long long*)take();
+	unsigned long long* dOutB = (unsigned long long*)take(); // the pairs in creation order, when the device holds the reference's trees
+	unsigned long long* dCreationKeys = (unsigned long long*)take();
 	unsigned int* dCount = (unsigned int*)take();
 	void* dTmp = take();
 	if (cache->countAt != (void*)dCount)
@@ -689,7 +690,8 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 		cache->countAt = (void*)dCount;
 	}
 	int* dSlotsIn = (int*)dExisting; // (the sorted pair keys -- and their slots -- live in the caller's buffer: this block holds the unsorted slots)
-	(void)dOutB;
+	const bool ordered = trees != nullptr;
+	const unsigned long long* dResult = ordered ? dOutB : dOutA;
 
 	// the sorted keys of the live pairs only change when a contact is created or destroyed: the caller keeps them
 	size_t tmp = tmpBytes + 256;
@@ -738,18 +740,23 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 																								jointedCount, dOutA, (unsigned int)outCap, dCount, (int*)dRun, dCount + 1, gone);
 		pairLongKernel<<<dim3(256), dim3(S2_BLOCK), 0, st>>>(dS, dMoved, dIdxOut, dBox, dMovedSorted, n, sortedPairKeys, nc, dJointed, jointedCount, dOutA,
 															  (unsigned int)outCap, dCount, (const int*)dRun, dCount + 1, gone);
+		if (ordered)
+		{
+			// the reference's creation order (tree_mirror.hip): (move-buffer position of the asking proxy, tree, reversed traversal rank)
+			launchOrderPairs(st, trees, dS, dMoved, dOutA, dCount, (unsigned int)outCap, dCreationKeys, dOutB);
+		}
 		BP_TRY(hipGetLastError());
 		if (hostFoundDev != nullptr)
 		{
 			// the count and the first keys straight into the pinned page, the counters zeroed for the next query: one small kernel where
 			// a memset and two copies were three blit kernels (~4.5 us each, serial on the stream)
-			publishPairsKernel<<<dim3(1), dim3(S2_BLOCK), 0, st>>>(dCount, dOutA, (unsigned int)std::min<size_t>(kFirst, outCap), hostFoundDev, hostKeysDev);
+			publishPairsKernel<<<dim3(1), dim3(S2_BLOCK), 0, st>>>(dCount, dResult, (unsigned int)std::min<size_t>(kFirst, outCap), hostFoundDev, hostKeysDev);
 			BP_TRY(hipGetLastError());
 		}
 		else
 		{
 			BP_TRY(hipMemcpyAsync(hostFound, dCount, 4, hipMemcpyDeviceToHost, st));
-			BP_TRY(hipMemcpyAsync(hostKeys, dOutA, (size_t)std::min<size_t>(kFirst, outCap) * 8, hipMemcpyDeviceToHost, st));
+			BP_TRY(hipMemcpyAsync(hostKeys, dResult, (size_t)std::min<size_t>(kFirst, outCap) * 8, hipMemcpyDeviceToHost, st));
 		}
 		return S2AMD_OK;
 	};
@@ -758,7 +765,8 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 		const unsigned long long words[] = {(unsigned long long)(uintptr_t)dS, (unsigned long long)ns, (unsigned long long)n, (unsigned long long)nc,
 											(unsigned long long)(uintptr_t)dJointed, (unsigned long long)jointedCount, (unsigned long long)(uintptr_t)*scratch,
 											(unsigned long long)(uintptr_t)sortedPairKeys, (unsigned long long)outCap, (unsigned long long)tmpBytes,
-											(unsigned long long)shapeBits, (unsigned long long)(uintptr_t)pairLog, (unsigned long long)(uintptr_t)pairLogSlots, (unsigned long long)(uintptr_t)dPairs};
+											(unsigned long long)shapeBits, (unsigned long long)(uintptr_t)pairLog, (unsigned long long)(uintptr_t)pairLogSlots, (unsigned long long)(uintptr_t)dPairs,
+											(unsigned long long)(uintptr_t)trees};
 		for (unsigned long long w : words)
 		{
 			key = (key ^ w) * 1099511628211ull;
@@ -860,9 +868,18 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 		BP_TRY(hipStreamSynchronize(st));
 	}
 	const unsigned int found = *hostFound;
-	std::vector<unsigned long long> out(hostKeys, hostKeys + std::min<size_t>(std::min<size_t>(kFirst, outCap), found));
 	*pairCount = (int32_t)found;
-	if ((int64_t)found > (int64_t)pairCapacity || (size_t)found > outCap)
+	if ((size_t)found > outCap)
+	{
+		// more new pairs than the device-side buffer holds (a world with few contact slots and many bodies landing at once): the
+		// buffer grows to fit and the query runs again, whole -- its inputs (move flags, pair slots) are what they were.  Only a
+		// caller's buffer that is too small is the caller's to fix.
+		cache->outCapWanted = (size_t)found + (size_t)found / 4;
+		cache->key = 0, cache->keySeen = 0;
+		return findPairsResident(st, dS, ns, liveShapes, dPairs, nc, dJointed, jointedCount, outPairs, pairCapacity, pairCount, scratch, scratchBytes, sortedPairKeys,
+								 sortedPairKeysValid, cache, S2_PAIRS_FULL, pairLog, pairLogSlots, trees);
+	}
+	if ((int64_t)found > (int64_t)pairCapacity)
 	{
 		return s2amdFail(S2AMD_E_CAPACITY, "pair buffer too small: " + std::to_string(found) + " pairs found");
 	}
@@ -870,13 +887,17 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 	{
 		return S2AMD_OK;
 	}
+	std::vector<unsigned long long> out(hostKeys, hostKeys + std::min<size_t>(std::min<size_t>(kFirst, outCap), found));
 	out.resize(found);
 	if (found > kFirst)
 	{
-		BP_TRY(hipMemcpyAsync(out.data() + kFirst, dOutA + kFirst, (size_t)(found - kFirst) * 8, hipMemcpyDeviceToHost, st));
+		BP_TRY(hipMemcpyAsync(out.data() + kFirst, dResult + kFirst, (size_t)(found - kFirst) * 8, hipMemcpyDeviceToHost, st));
 		BP_TRY(hipStreamSynchronize(st));
 	}
-	std::sort(out.begin(), out.end()); // deterministic output order: by (A, B)
+	if (!ordered)
+	{
+		std::sort(out.begin(), out.end()); // deterministic output order: by (A, B)
+	}
 	for (unsigned int i = 0; i < found; ++i)
 	{
 		outPairs[2 * i] = (int32_t)(out[i] >> 32);

@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "solver2d_amd.h"
+
 struct BodyView;
 struct ContactView;
 struct JointView;
@@ -205,6 +207,35 @@ void launchUpdateContacts(hipStream_t st, const s2amdBody* bodies, const float* 
 void launchStage4(hipStream_t st, s2amdBody* bodies, int bodyCapacity, s2amdShape* shapes, int shapeCapacity, float* origins, int* summary,
 				  const unsigned int* stepFailed = nullptr);
 // stage 1 on resident arrays: new pairs sorted by (A, B) into the host array outPairs; dJointed: sorted (min body << 32 | max body) keys
+// the reference's broad-phase trees on the device (tree_mirror.hip): one s2DynamicTree's node array, the flags and leaf counts beside it,
+// and the rebuild's scratch
+struct TreeView
+{
+	s2amdTreeNode* nodes;
+	int* flag;	 // s2TreeNode.enlarged of the internal nodes, as a word the enlarge pass can exchange
+	int* leaves; // real leaves below every node: the traversal rank of a leaf is a sum of these
+	int* state;	 // [0] root, [1] nodes flagged since the last rebuild, [2] error
+	int capacity;
+	int *marked, *acc, *pending, *oldPre, *leafIdx, *seg, *segStart, *segEnd, *segSplit, *scan, *partner, *arrive;
+	float *cx, *cy;
+	unsigned int* bounds;
+};
+struct TreeViews
+{
+	TreeView t[3];		 // by s2BodyType: static, kinematic, dynamic (include/solver2d/types.h:99-105)
+	const int* refitPos; // shape -> position in the refit order (the move buffer's order), or null: the shape index
+};
+struct DeviceTrees;
+void treesFree(s2amdSolver* s);
+void treesForget(s2amdSolver* s);
+bool treesActive(const s2amdSolver* s);
+const TreeViews* treesViews(const s2amdSolver* s);
+int treesSyncRefitOrder(s2amdSolver* s);
+int worldWarmPairQuery(s2amdSolver* s); // world.hip
+void launchTreeEnlarge(s2amdSolver* s, hipStream_t st, const unsigned int* stepFailed);
+void launchTreeRebuild(s2amdSolver* s, hipStream_t st);
+void launchOrderPairs(hipStream_t st, const TreeViews* views, const s2amdShape* shapes, const unsigned char* moved, const unsigned long long* keys,
+					  const unsigned int* count, unsigned int cap, unsigned long long* ckeys, unsigned long long* out);
 // the captured launch sequence of the resident pair query and its pinned read-back buffer (owned by the solver)
 struct PairQueryGraph
 {
@@ -213,11 +244,12 @@ struct PairQueryGraph
 	bool disabled = false;
 	char* host = nullptr;
 	void* countAt = nullptr; // where the query's counters live in the scratch block (zeroed when that changes)
+	size_t outCapWanted = 0; // a query found more pairs than the device-side buffer held: the next one makes it this large
 };
 int findPairsResident(hipStream_t st, const s2amdShape* shapes, int shapeCapacity, int liveShapes, const s2amdPairState* pairs, int contactCapacity,
 					  const unsigned long long* jointed, int jointedCount, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount, void** scratch,
 					  size_t* scratchBytes, unsigned long long* sortedPairKeys, bool* sortedPairKeysValid, PairQueryGraph* cache, int mode = 0,
-					  const unsigned long long* pairLog = nullptr, const int* pairLogSlots = nullptr);
+					  const unsigned long long* pairLog = nullptr, const int* pairLogSlots = nullptr, const TreeViews* trees = nullptr);
 #define S2_PAIR_LOG_ENTRIES 255 // broadphase.hip: S2_PAIR_LOG_CAPACITY
 #define S2_PAIRS_FULL 0
 #define S2_PAIRS_WARM 1
@@ -240,6 +272,7 @@ void s2Warm_wide_kernel(hipStream_t st);
 void s2Warm_generic_kernel(hipStream_t st);
 void s2Warm_broadphase(hipStream_t st);
 void s2Warm_narrowphase(hipStream_t st);
+void s2Warm_tree_mirror(hipStream_t st);
 void s2Warm_structure(hipStream_t st);
 void s2Warm_world(hipStream_t st);
 void s2Warm_sharded(hipStream_t st);

@@ -193,6 +193,7 @@ int s2amd_create(int device, s2amdSolver** out)
 			s2Warm_generic_kernel(s->stream);
 			s2Warm_broadphase(s->stream);
 			s2Warm_narrowphase(s->stream);
+			s2Warm_tree_mirror(s->stream);
 			s2Warm_structure(s->stream);
 			s2Warm_world(s->stream);
 			s2Warm_sharded(s->stream);
@@ -235,6 +236,7 @@ void s2amd_destroy(s2amdSolver* s)
 	{
 		b->release();
 	}
+	treesFree(s);
 	if (s->hostError)
 	{
 		(void)hipHostFree(s->hostError);

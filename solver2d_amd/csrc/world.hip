@@ -411,6 +411,26 @@ int fetchPointCounts(s2amdSolver* s)
 	return S2AMD_OK;
 }
 
+// the stage-1 pair query's scratch, sorted pair keys and captured graph, made ahead of the first query (s2amd_world_upload with
+// "prebuild_solver"; again when the device gets the trees that order the query's pairs: s2amd_world_set_tree)
+int worldWarmPairQuery(s2amdSolver* s)
+{
+	if (s->liveShapes < 2)
+	{
+		return S2AMD_OK;
+	}
+	int32_t none = 0;
+	int rc = s->dPairKeys.ensure(std::max<size_t>((size_t)s->contactCapacity * 12, 256));
+	if (rc)
+	{
+		return rc;
+	}
+	return findPairsResident(s->stream, (const s2amdShape*)s->dShapes.p, s->shapeCapacity, s->liveShapes, (const s2amdPairState*)s->dPairs.p, s->contactCapacity,
+							 (const unsigned long long*)s->dJointedKeys.p, s->jointedCount, nullptr, 0, &none, &s->dPairScratch.p, &s->dPairScratch.bytes,
+							 (unsigned long long*)s->dPairKeys.p, &s->pairKeysValid, &s->pairQuery, S2_PAIRS_WARM, (const unsigned long long*)s->dPairLog.p,
+							 (const int*)((const unsigned long long*)s->dPairLog.p + S2_PAIR_LOG_ENTRIES + 1), treesViews(s));
+}
+
 #pragma GCC visibility push(default)
 extern "C"
 {
@@ -486,6 +506,7 @@ int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapa
 	}
 	s->stepBackValid = false;
 	s->refitOrderCount = 0; // (the caller's order belongs to the world it was sent for)
+	treesForget(s);			// (... and so do its trees)
 	for (int i = 0; i < contactCapacity; ++i)
 	{
 		if (pairs[i].shapeA >= shapeCapacity || pairs[i].shapeB >= shapeCapacity)
@@ -657,17 +678,9 @@ int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapa
 			return rcBuild;
 		}
 		// ... and the stage-1 pair query (s2amd_world_find_pairs): its scratch, its sorted pair keys and its captured graph
-		if (s->liveShapes >= 2)
+		if ((rcBuild = worldWarmPairQuery(s)) != 0)
 		{
-			int32_t none = 0;
-			if ((rcBuild = s->dPairKeys.ensure(std::max<size_t>((size_t)s->contactCapacity * 12, 256))) != 0 ||
-				(rcBuild = findPairsResident(s->stream, (const s2amdShape*)s->dShapes.p, s->shapeCapacity, s->liveShapes, (const s2amdPairState*)s->dPairs.p, s->contactCapacity,
-											 (const unsigned long long*)s->dJointedKeys.p, s->jointedCount, nullptr, 0, &none, &s->dPairScratch.p, &s->dPairScratch.bytes,
-											 (unsigned long long*)s->dPairKeys.p, &s->pairKeysValid, &s->pairQuery, S2_PAIRS_WARM,
-											 (const unsigned long long*)s->dPairLog.p, (const int*)((const unsigned long long*)s->dPairLog.p + S2_PAIR_LOG_ENTRIES + 1))) != 0)
-			{
-				return rcBuild;
-			}
+			return rcBuild;
 		}
 	}
 	return S2AMD_OK;
@@ -701,6 +714,9 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 	// behind it saw the bodies of the previous step (same AABBs, nothing enlarged): the solve is repeated on the
 	// multi-launch path, and so is the refit.
 	s->slotBytesFresh = false;
+	// stage 2 (src/world.c:130): the trees the last refit flagged are rebuilt -- after the pair query of this step's stage 1, which the
+	// caller has run (or the last step enqueued behind its stage 4), before this step's refit flags them again
+	launchTreeRebuild(s, st);
 	{
 		int rcWatched = uploadWatched(s);
 		if (rcWatched)
@@ -817,6 +833,8 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 			launchStage4(st, (s2amdBody*)s->dBodies.p, nb, (s2amdShape*)s->dShapes.p, ns, (float*)s->dOrigins.p, (int*)dSum,
 						 s->persistValid ? s->persist.deviceError : nullptr);
 		}
+		// (... and the proxies of the shapes it re-inflated enlarge the device's trees: src/world.c:283-290)
+		launchTreeEnlarge(s, st, s->persistValid ? s->persist.deviceError : nullptr);
 		const bool stepBack = s->optStepReadback != 0 && s->refitOrderCount > 0 && nb > 0 && ns > 0;
 		if (stepBack && (rc = enqueueStepBack(s)) != 0)
 		{
@@ -834,7 +852,7 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 				(rc = findPairsResident(st, (const s2amdShape*)s->dShapes.p, s->shapeCapacity, s->liveShapes, (const s2amdPairState*)s->dPairs.p, s->contactCapacity,
 										(const unsigned long long*)s->dJointedKeys.p, s->jointedCount, nullptr, 0, &none, &s->dPairScratch.p, &s->dPairScratch.bytes,
 										(unsigned long long*)s->dPairKeys.p, &s->pairKeysValid, &s->pairQuery, S2_PAIRS_ENQUEUE,
-										(const unsigned long long*)s->dPairLog.p, (const int*)((const unsigned long long*)s->dPairLog.p + S2_PAIR_LOG_ENTRIES + 1))) != 0)
+										(const unsigned long long*)s->dPairLog.p, (const int*)((const unsigned long long*)s->dPairLog.p + S2_PAIR_LOG_ENTRIES + 1), treesViews(s))) != 0)
 			{
 				return rc;
 			}
@@ -979,7 +997,7 @@ int s2amd_world_find_pairs(s2amdSolver* s, int32_t* outPairs, int32_t pairCapaci
 	rc = findPairsResident(s->stream, (const s2amdShape*)s->dShapes.p, s->shapeCapacity, s->liveShapes, (const s2amdPairState*)s->dPairs.p, s->contactCapacity,
 							   (const unsigned long long*)s->dJointedKeys.p, s->jointedCount, outPairs, pairCapacity, pairCount, &s->dPairScratch.p,
 							   &s->dPairScratch.bytes, (unsigned long long*)s->dPairKeys.p, &s->pairKeysValid, &s->pairQuery, collect ? S2_PAIRS_COLLECT : S2_PAIRS_FULL,
-							   (const unsigned long long*)s->dPairLog.p, (const int*)((const unsigned long long*)s->dPairLog.p + S2_PAIR_LOG_ENTRIES + 1));
+							   (const unsigned long long*)s->dPairLog.p, (const int*)((const unsigned long long*)s->dPairLog.p + S2_PAIR_LOG_ENTRIES + 1), treesViews(s));
 	if (rc == S2AMD_OK)
 	{
 		s->pairCacheValid = false; // (collected once: the move flags go below, as after a query of this call's own)
@@ -1035,7 +1053,7 @@ int s2amd_world_set_refit_order(s2amdSolver* s, const int32_t* shapeOrder, int32
 	s->stepBackValid = false;
 	if (count == 0)
 	{
-		return S2AMD_OK;
+		return treesSyncRefitOrder(s);
 	}
 	// The order must name every shape stage 4 can re-inflate exactly once: s2amd_world_download_step trusts it (a stale order would
 	// hand the caller a step's moved boxes with some of them missing).  Shapes only change with s2amd_world_upload, which drops the order.
@@ -1067,7 +1085,7 @@ int s2amd_world_set_refit_order(s2amdSolver* s, const int32_t* shapeOrder, int32
 	HIP_TRY(hipMemcpyAsync(s->dRefitOrder.p, shapeOrder, (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	s->refitOrderCount = count;
-	return S2AMD_OK;
+	return treesSyncRefitOrder(s);
 }
 
 int s2amd_world_download_step(s2amdSolver* s, float* poses, int32_t bodyCapacity, s2amdMovedBox* moved, int32_t movedCapacity, int32_t* movedCount)

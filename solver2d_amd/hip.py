@@ -24,7 +24,7 @@ EXPORTS = [
     "s2amd_restore_bodies", "s2amd_get_contact_order", "s2amd_get_joint_order", "s2amd_get_stats",
     "s2amd_set_option", "s2amd_export_poses", "s2amd_export_poses_async", "s2amd_export_bodies_async", "s2amd_export_wait", "s2amd_measure_dominant", "s2amd_refit_shapes", "s2amd_find_pairs", "s2amd_synchronize", "s2amd_update_contacts", "s2amd_find_islands", "s2amd_color_constraints",
     "s2amd_world_upload", "s2amd_world_step", "s2amd_world_download", "s2amd_world_find_pairs", "s2amd_world_set_contacts",
-    "s2amd_device_alloc", "s2amd_device_free", "s2amd_device_read", "s2amd_world_separated", "s2amd_world_download_boxes", "s2amd_world_set_refit_order", "s2amd_world_download_step",
+    "s2amd_device_alloc", "s2amd_device_free", "s2amd_device_read", "s2amd_world_separated", "s2amd_world_download_boxes", "s2amd_world_set_refit_order", "s2amd_world_download_step", "s2amd_world_set_tree", "s2amd_world_get_tree",
     "s2amd_get_strip_owners",
     "s2amd_sharded_create", "s2amd_sharded_destroy", "s2amd_sharded_shard_count", "s2amd_sharded_solver", "s2amd_sharded_upload", "s2amd_sharded_step",
     "s2amd_sharded_download", "s2amd_sharded_read_bodies", "s2amd_sharded_reshard", "s2amd_sharded_get_partition",
@@ -82,6 +82,9 @@ def load(fast=False):
     L.s2amd_world_set_contacts.argtypes = [vp, vp, i32, vp, vp]
     L.s2amd_world_separated.argtypes = [vp, vp, i32, ctypes.POINTER(i32)]
     L.s2amd_world_download_boxes.argtypes = [vp, vp, i32]
+    L.s2amd_world_set_refit_order.argtypes = [vp, vp, i32]
+    L.s2amd_world_set_tree.argtypes = [vp, i32, vp, i32, i32]
+    L.s2amd_world_get_tree.argtypes = [vp, i32, vp, i32, ctypes.POINTER(i32)]
     L.s2amd_world_download.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, vp]
     L.s2amd_device_alloc.argtypes = [vp, ctypes.c_uint64, ctypes.POINTER(vp)]
     L.s2amd_device_free.argtypes = [vp, vp]
@@ -300,6 +303,24 @@ class Solver:
                 continue
             self._ck(rc)
             return out[: n.value].copy()
+
+    def world_set_refit_order(self, order):
+        """The order the caller's refit visits the movable shapes in (= the move buffer's order)."""
+        order = np.ascontiguousarray(order, dtype=np.int32)
+        self._ck(self._L.s2amd_world_set_refit_order(self._h, wire.as_ptr(order), len(order)))
+
+    def world_set_tree(self, body_type, nodes, root):
+        """One of the reference's three broad-phase trees (s2TreeNode records, wire.tree_node_dtype) onto the device."""
+        nodes = np.ascontiguousarray(nodes)
+        assert nodes.dtype == wire.tree_node_dtype
+        self._ck(self._L.s2amd_world_set_tree(self._h, int(body_type), wire.as_ptr(nodes), len(nodes), int(root)))
+
+    def world_get_tree(self, body_type, node_capacity):
+        """(nodes, root) of a device tree as the reference would hold it now."""
+        nodes = np.zeros(int(node_capacity), dtype=wire.tree_node_dtype)
+        root = ctypes.c_int32()
+        self._ck(self._L.s2amd_world_get_tree(self._h, int(body_type), wire.as_ptr(nodes), len(nodes), ctypes.byref(root)))
+        return nodes, root.value
 
     def world_download_boxes(self, shape_capacity):
         """s2amdShapeBox of every resident shape slot after the last world_step."""

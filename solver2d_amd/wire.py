@@ -7,7 +7,7 @@ library.  Arrays of these dtypes are what the Python host side hands to the C en
 import ctypes
 import numpy as np
 
-API_VERSION = 4
+API_VERSION = 5
 
 SOLVER_NAMES = [
     "Jacobi", "PGS", "PGS_NGS", "PGS_NGS_Block", "PGS_Soft",
@@ -145,5 +145,9 @@ def as_ptr(arr, ctype=ctypes.c_void_p):
 
 
 # s2amdShapeBox (include/solver2d_amd.h): what stage 4 changed in a shape
+# s2TreeNode byte for byte (include/solver2d/dynamic_tree.h:14-41; s2amdTreeNode)
+tree_node_dtype = np.dtype([("aabb", np.float32, 4), ("categoryBits", np.uint32), ("parent", np.int32), ("child1", np.int32), ("child2", np.int32),
+                            ("userData", np.int32), ("height", np.int16), ("enlarged", np.uint8), ("pad", np.uint8, 9)])
+assert tree_node_dtype.itemsize == 48
 shape_box_dtype = np.dtype([("aabb", np.float32, 4), ("fatAABB", np.float32, 4), ("enlarged", np.int32)])
 assert shape_box_dtype.itemsize == 36

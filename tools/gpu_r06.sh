@@ -1,0 +1,16 @@
+#!/bin/sh
+# Round 6 GPU sessions: tools/gpu_r06.sh <stage>   (run through gpurun from the repository root; output under gpurun_out/)
+set -x
+mkdir -p gpurun_out
+case "$1" in
+trees)
+	python -m pytest tests/test_gpu_trees.py -x -q 2>&1 | tail -25 > gpurun_out/r06_trees.txt
+	python -m pytest tests/test_gpu_dropin.py -x -q -k "device_pairs" 2>&1 | tail -8 >> gpurun_out/r06_trees.txt
+	python -m pytest tests/test_gpu_world.py tests/test_gpu_broadphase.py -x -q 2>&1 | tail -8 >> gpurun_out/r06_trees.txt
+	(tools/dropin_product_demo.sh 200 40 pyramid 3 4 2 45; S2AMD_DEVICE_TREES=0 S2AMD_DROPIN=step S2AMD_DEVICE_PAIRS=1 S2AMD_LIBRARY="$PWD/solver2d_amd/libs2amd.so" tools/dropin_product_demo.bin 200 40 pyramid 3 4 2 45) > gpurun_out/r06_dropin_default_solver.txt 2>&1
+	tools/dropin_product_demo.sh 200 40 pyramid 7 8 4 45 > gpurun_out/r06_dropin_demo.txt 2>&1
+	cat gpurun_out/r06_trees.txt; tail -30 gpurun_out/r06_dropin_default_solver.txt
+	;;
+*)
+	echo "unknown stage $1"; exit 2;;
+esac

@@ -611,7 +611,7 @@ __global__ __launch_bounds__(S2_BLOCK) void residentPairKeysKernel(const s2amdPa
 int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShapes, const s2amdPairState* dPairs, int nc,
 					  const unsigned long long* dJointed, int jointedCount, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount, void** scratch,
 					  size_t* scratchBytes, unsigned long long* sortedPairKeys, bool* sortedPairKeysValid, PairQueryGraph* cache, int mode,
-					  const unsigned long long* pairLog, const int* pairLogSlots, const TreeViews* trees)
+					  const unsigned long long* pairLog, const int* pairLogSlots, const TreeViews* trees, const PairQueryHook* hook)
 {
 	// mode: S2_PAIRS_FULL the whole query; S2_PAIRS_WARM buffers + captured graph, nothing runs (s2amd_world_upload); S2_PAIRS_ENQUEUE
 	// the query enqueued behind the caller's work, no wait (s2amd_world_step); S2_PAIRS_COLLECT the results of such a query, after the
@@ -726,7 +726,9 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 	}
 	// The query proper -- key generation, the sort of the proxies, the sweep kernels, the read-back -- is the same dozen launches
 	// every step: the second time a sequence (arrays, sizes) comes along it is captured into a hipGraph and replayed from then on
-	auto enqueue = [&]() -> int {
+	// (with the reference's trees on the device the query has a tail that is not part of the graph: the refit's enlarge pass -- which
+	// waits for the tree rebuild running beside the step, an event of another stream -- the ranking of the pairs, the read-back)
+	auto enqueueSet = [&]() -> int {
 		if (hostFoundDev == nullptr)
 		{
 			BP_TRY(hipMemsetAsync(dCount, 0, 256, st)); // (else publishPairsKernel left them at zero, and the scratch was zeroed when it was made)
@@ -740,12 +742,20 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 																								jointedCount, dOutA, (unsigned int)outCap, dCount, (int*)dRun, dCount + 1, gone);
 		pairLongKernel<<<dim3(256), dim3(S2_BLOCK), 0, st>>>(dS, dMoved, dIdxOut, dBox, dMovedSorted, n, sortedPairKeys, nc, dJointed, jointedCount, dOutA,
 															  (unsigned int)outCap, dCount, (const int*)dRun, dCount + 1, gone);
+		BP_TRY(hipGetLastError());
+		return S2AMD_OK;
+	};
+	auto enqueueTail = [&]() -> int {
 		if (ordered)
 		{
+			if (hook != nullptr && hook->fn != nullptr)
+			{
+				hook->fn(hook->arg, st);
+			}
 			// the reference's creation order (tree_mirror.hip): (move-buffer position of the asking proxy, tree, reversed traversal rank)
 			launchOrderPairs(st, trees, dS, dMoved, dOutA, dCount, (unsigned int)outCap, dCreationKeys, dOutB);
+			BP_TRY(hipGetLastError());
 		}
-		BP_TRY(hipGetLastError());
 		if (hostFoundDev != nullptr)
 		{
 			// the count and the first keys straight into the pinned page, the counters zeroed for the next query: one small kernel where
@@ -760,6 +770,11 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 		}
 		return S2AMD_OK;
 	};
+	auto enqueue = [&]() -> int { // what a captured graph holds
+		const int rcSet = enqueueSet();
+		return rcSet != S2AMD_OK || ordered ? rcSet : enqueueTail();
+	};
+	bool ran = false;
 	unsigned long long key = 1469598103934665603ull;
 	{
 		const unsigned long long words[] = {(unsigned long long)(uintptr_t)dS, (unsigned long long)ns, (unsigned long long)n, (unsigned long long)nc,
@@ -819,6 +834,7 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 		{
 			return rcE;
 		}
+		ran = true;
 	}
 	else
 	{
@@ -848,6 +864,7 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 				{
 					return rcE;
 				}
+				ran = true;
 			}
 			if (g)
 			{
@@ -857,6 +874,15 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 		if (cache->exec != nullptr && key == cache->key)
 		{
 			BP_TRY(hipGraphLaunch(cache->exec, st));
+			ran = true;
+		}
+	}
+	if (ran && ordered)
+	{
+		const int rcTail = enqueueTail();
+		if (rcTail)
+		{
+			return rcTail;
 		}
 	}
 	if (mode == S2_PAIRS_ENQUEUE)
@@ -877,7 +903,7 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 		cache->outCapWanted = (size_t)found + (size_t)found / 4;
 		cache->key = 0, cache->keySeen = 0;
 		return findPairsResident(st, dS, ns, liveShapes, dPairs, nc, dJointed, jointedCount, outPairs, pairCapacity, pairCount, scratch, scratchBytes, sortedPairKeys,
-								 sortedPairKeysValid, cache, S2_PAIRS_FULL, pairLog, pairLogSlots, trees);
+								 sortedPairKeysValid, cache, S2_PAIRS_FULL, pairLog, pairLogSlots, trees, nullptr);
 	}
 	if ((int64_t)found > (int64_t)pairCapacity)
 	{

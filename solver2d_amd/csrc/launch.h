@@ -214,11 +214,13 @@ struct TreeView
 	s2amdTreeNode* nodes;
 	int* flag;	 // s2TreeNode.enlarged of the internal nodes, as a word the enlarge pass can exchange
 	int* leaves; // real leaves below every node: the traversal rank of a leaf is a sum of these
-	int* state;	 // [0] root, [1] nodes flagged since the last rebuild, [2] error
+	int* state;	 // [0] root, [1] flagged nodes of the rebuild in flight (0 between rebuilds), [2] error
 	int capacity;
-	int *marked, *acc, *pending, *oldPre, *leafIdx, *seg, *segStart, *segEnd, *segSplit, *scan, *partner, *arrive;
+	// the rebuild's scratch: flagged nodes below a flagged node and its flagged children still to report; the flagged nodes in pre-order;
+	// the gathered leaves in depth-first order with their centres; the exchange partners of a split; reports at a new node
+	int *acc, *pending, *oldPre, *leafIdx, *partner, *arrive;
 	float *cx, *cy;
-	unsigned int* bounds;
+	int *tasks, *ready, *qstate; // the build's queue: {start, end, pre, parent, side} per task; published flags; {next, queued, leaves left, done}
 };
 struct TreeViews
 {
@@ -234,6 +236,7 @@ int treesSyncRefitOrder(s2amdSolver* s);
 int worldWarmPairQuery(s2amdSolver* s); // world.hip
 void launchTreeEnlarge(s2amdSolver* s, hipStream_t st, const unsigned int* stepFailed);
 void launchTreeRebuild(s2amdSolver* s, hipStream_t st);
+void treesJoin(s2amdSolver* s, hipStream_t st);
 void launchOrderPairs(hipStream_t st, const TreeViews* views, const s2amdShape* shapes, const unsigned char* moved, const unsigned long long* keys,
 					  const unsigned int* count, unsigned int cap, unsigned long long* ckeys, unsigned long long* out);
 // the captured launch sequence of the resident pair query and its pinned read-back buffer (owned by the solver)
@@ -246,10 +249,17 @@ struct PairQueryGraph
 	void* countAt = nullptr; // where the query's counters live in the scratch block (zeroed when that changes)
 	size_t outCapWanted = 0; // a query found more pairs than the device-side buffer held: the next one makes it this large
 };
+// something the ordered query runs between finding its pairs and ranking them (world.hip: the refit's tree enlarge pass)
+struct PairQueryHook
+{
+	void (*fn)(void* arg, hipStream_t st);
+	void* arg;
+};
 int findPairsResident(hipStream_t st, const s2amdShape* shapes, int shapeCapacity, int liveShapes, const s2amdPairState* pairs, int contactCapacity,
 					  const unsigned long long* jointed, int jointedCount, int32_t* outPairs, int32_t pairCapacity, int32_t* pairCount, void** scratch,
 					  size_t* scratchBytes, unsigned long long* sortedPairKeys, bool* sortedPairKeysValid, PairQueryGraph* cache, int mode = 0,
-					  const unsigned long long* pairLog = nullptr, const int* pairLogSlots = nullptr, const TreeViews* trees = nullptr);
+					  const unsigned long long* pairLog = nullptr, const int* pairLogSlots = nullptr, const TreeViews* trees = nullptr,
+					  const PairQueryHook* hook = nullptr);
 #define S2_PAIR_LOG_ENTRIES 255 // broadphase.hip: S2_PAIR_LOG_CAPACITY
 #define S2_PAIRS_FULL 0
 #define S2_PAIRS_WARM 1

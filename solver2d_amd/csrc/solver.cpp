@@ -1011,6 +1011,10 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 		f = 1e-3f * (float)std::max(value, 1);
 		s->structureDirty = true;
 	}
+	else if (strcmp(key, "tree_stream") == 0)
+	{
+		s->optTreeStream = value != 0 ? 1 : 0;
+	}
 	else if (strcmp(key, "pairs_in_step") == 0)
 	{
 		s->optPairsInStep = value != 0; // the stage-1 pair query enqueued behind every world step (world.hip)

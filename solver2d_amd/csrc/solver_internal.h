@@ -501,6 +501,7 @@ struct SolverRest
 	DevBuf dShapeBoxes;		// world chain: s2amd_world_download_boxes' staging
 	DevBuf dRefitOrder, dStepBack; // s2amd_world_set_refit_order; staging of s2amd_world_download_step {count, moved boxes} and the poses
 	int refitOrderCount = 0;
+	int optTreeStream = 1;		  // "tree_stream": the device trees' rebuild on a stream of its own beside stage 3 and the solve (0: on the step's stream; tree_mirror.hip)
 	DeviceTrees* trees = nullptr; // the reference's broad-phase trees on the device (tree_mirror.hip; s2amd_world_set_tree)
 	int lastMovedCount = 0; // enlarged shapes of the last s2amd_world_step
 	DevBuf dSlotBytes;		// world chain: one byte per pair slot for a structure build (world.hip: slotBytesKernel)

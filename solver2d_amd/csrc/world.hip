@@ -833,8 +833,13 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 			launchStage4(st, (s2amdBody*)s->dBodies.p, nb, (s2amdShape*)s->dShapes.p, ns, (float*)s->dOrigins.p, (int*)dSum,
 						 s->persistValid ? s->persist.deviceError : nullptr);
 		}
-		// (... and the proxies of the shapes it re-inflated enlarge the device's trees: src/world.c:283-290)
-		launchTreeEnlarge(s, st, s->persistValid ? s->persist.deviceError : nullptr);
+		// (... and the proxies of the shapes it re-inflated enlarge the device's trees, src/world.c:283-290 -- once the rebuild running
+		// beside this step is through: behind the pair query's own kernels when one rides along, which do not read the trees)
+		const bool pairsRide = s->optPairsInStep != 0 && s->pairQueryUsed && fallbacks == 0 && nearRetries == 0 && s->liveShapes >= 2;
+		if (!(pairsRide && treesActive(s)))
+		{
+			launchTreeEnlarge(s, st, s->persistValid ? s->persist.deviceError : nullptr);
+		}
 		const bool stepBack = s->optStepReadback != 0 && s->refitOrderCount > 0 && nb > 0 && ns > 0;
 		if (stepBack && (rc = enqueueStepBack(s)) != 0)
 		{
@@ -845,14 +850,20 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 		// Pairs this step's stage 3 destroyed are still in the sorted directory of the pair set: the kernels check what a directory entry's
 		// slot holds now (broadphase.hip: PairSetView).  Not in a step that is being repeated.
 		s->pairCacheValid = false;
-		if (s->optPairsInStep != 0 && s->pairQueryUsed && fallbacks == 0 && nearRetries == 0 && s->liveShapes >= 2)
+		if (pairsRide)
 		{
 			int32_t none = 0;
+			const PairQueryHook enlarge{[](void* arg, hipStream_t hst) {
+											s2amdSolver* hs = (s2amdSolver*)arg;
+											launchTreeEnlarge(hs, hst, hs->persistValid ? hs->persist.deviceError : nullptr);
+										},
+										s};
 			if ((rc = s->dPairKeys.ensure(std::max<size_t>((size_t)s->contactCapacity * 12, 256))) != 0 || (rc = pairLogFlush(s)) != 0 ||
 				(rc = findPairsResident(st, (const s2amdShape*)s->dShapes.p, s->shapeCapacity, s->liveShapes, (const s2amdPairState*)s->dPairs.p, s->contactCapacity,
 										(const unsigned long long*)s->dJointedKeys.p, s->jointedCount, nullptr, 0, &none, &s->dPairScratch.p, &s->dPairScratch.bytes,
 										(unsigned long long*)s->dPairKeys.p, &s->pairKeysValid, &s->pairQuery, S2_PAIRS_ENQUEUE,
-										(const unsigned long long*)s->dPairLog.p, (const int*)((const unsigned long long*)s->dPairLog.p + S2_PAIR_LOG_ENTRIES + 1), treesViews(s))) != 0)
+										(const unsigned long long*)s->dPairLog.p, (const int*)((const unsigned long long*)s->dPairLog.p + S2_PAIR_LOG_ENTRIES + 1), treesViews(s),
+										&enlarge)) != 0)
 			{
 				return rc;
 			}

@@ -150,6 +150,42 @@ def rebuild(nodes, root):
                     k += ms(int(c1[p])) + 1
                 x = p
             leaf_idx[k] = c
+    # The same two orders without counting anything bottom-up (what the device does: no atomics on the way): with
+    # first(n) = real leaves left of n's subtree (a walk up over the leaf counts the tree keeps), gathered leaves in depth-first
+    # order are gathered leaves by `first`; flagged nodes in pre-order are flagged nodes by `first`, ancestors before descendants
+    # (those sharing a `first` lie on one leftmost path: a node's place among them = its consecutive child1 steps going up).
+    counts = leaf_counts(nodes, root)
+
+    def first_and_chain(n):
+        first, chain, x, counting = 0, 0, n, True
+        while x != root:
+            p = int(par[x])
+            if c2[p] == x:
+                first += int(counts[c1[p]])
+                counting = False
+            elif counting:
+                chain += 1
+            x = p
+        return first, chain
+    N = int(counts[root])
+    cnt_f, cnt_g = np.zeros(N + 1, dtype=np.int64), np.zeros(N + 1, dtype=np.int64)
+    info = {}
+    for n in marked:
+        f, ch = first_and_chain(n)
+        info[n] = (f, ch)
+        cnt_f[f] += 1
+        for c in (int(c1[n]), int(c2[n])):
+            if not flagged(c):
+                cnt_g[f + (int(counts[c1[n]]) if c == c2[n] else 0)] = 1
+    pre_f = np.cumsum(cnt_f) - cnt_f
+    pre_g = np.cumsum(cnt_g) - cnt_g
+    for n in marked:
+        f, ch = info[n]
+        assert old_pre[pre_f[f] + ch] == n
+        for c in (int(c1[n]), int(c2[n])):
+            if not flagged(c):
+                assert leaf_idx[pre_g[f + (int(counts[c1[n]]) if c == c2[n] else 0)]] == c
+    assert int(cnt_f.sum()) == M and int(cnt_g.sum()) == L
     aabb = nodes["aabb"]
     cx = (np.float32(0.5) * (aabb[leaf_idx, 0] + aabb[leaf_idx, 2])).astype(np.float32)  # s2AABB_Center, aabb.h:28-32
     cy = (np.float32(0.5) * (aabb[leaf_idx, 1] + aabb[leaf_idx, 3])).astype(np.float32)

@@ -11,6 +11,14 @@ trees)
 	tools/dropin_product_demo.sh 200 40 pyramid 7 8 4 45 > gpurun_out/r06_dropin_demo.txt 2>&1
 	cat gpurun_out/r06_trees.txt; tail -30 gpurun_out/r06_dropin_default_solver.txt
 	;;
+trees2)
+	python -m pytest tests/test_gpu_trees.py -x -q 2>&1 | tail -25 > gpurun_out/r06_trees.txt
+	python -m pytest tests/test_gpu_dropin.py -x -q -k "device_pairs" 2>&1 | tail -8 >> gpurun_out/r06_trees.txt
+	(tools/dropin_product_demo.sh 200 40 pyramid 3 4 2 45; S2AMD_DEVICE_TREES=0 S2AMD_DROPIN=step S2AMD_DEVICE_PAIRS=1 S2AMD_LIBRARY="$PWD/solver2d_amd/libs2amd.so" tools/dropin_product_demo.bin 200 40 pyramid 3 4 2 45) > gpurun_out/r06_dropin_default_solver.txt 2>&1
+	cd /tmp && export TMPDIR=/tmp && S2AMD_DROPIN=step S2AMD_DEVICE_PAIRS=1 S2AMD_LIBRARY="$GRAFT_REPO_ROOT/solver2d_amd/libs2amd.so" rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_trees -o trace -- $GRAFT_REPO_ROOT/tools/dropin_product_demo.bin 200 40 pyramid 3 4 2 45 > /dev/null 2>&1; cd $GRAFT_REPO_ROOT
+	python tools/rocpd_summary.py $(find gpurun_out/prof_trees -name '*_results.db' | head -1) > gpurun_out/r06_trees_kernel_trace.txt 2>&1; rm -rf gpurun_out/prof_trees
+	cat gpurun_out/r06_trees.txt; tail -12 gpurun_out/r06_dropin_default_solver.txt; head -40 gpurun_out/r06_trees_kernel_trace.txt
+	;;
 *)
 	echo "unknown stage $1"; exit 2;;
 esac

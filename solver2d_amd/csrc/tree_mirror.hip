@@ -36,6 +36,7 @@
 #define TREE_THREADS 1024
 #define TREE_NULL (-1)
 #define TREE_SMALL TREE_THREADS // a segment this short is finished by one task
+#define TREE_BATCH 4				 // loads a lane has in flight in the passes over a long segment
 #define TREE_TASK_INTS 5		 // start, end, pre-order index of its node, the parent's node id, which child of it
 
 static_assert(sizeof(s2amdTreeNode) == 48, "s2TreeNode is 48 bytes (include/solver2d/dynamic_tree.h:14-41)");
@@ -292,34 +293,89 @@ __global__ __launch_bounds__(S2_BLOCK) void treeGatherWalkKernel(TreeViews* view
 	}
 }
 
-// exclusive prefix sums of the two histograms, in place; the counts (M flagged nodes, M + 1 gathered leaves) start the build's queue
+// exclusive prefix sums of the two histograms, in place; the counts (M flagged nodes, M + 1 gathered leaves) start the build's queue.
+// Every wave owns a run of 64-entry tiles and loads them all before it adds anything (a load per tile in turn is a memory round trip
+// per tile: 51 us for 2 x 20,000 entries).
+#define TREE_SCAN_TILES 24 // tiles a wave holds in registers per batch
 __global__ __launch_bounds__(TREE_THREADS) void treeGatherScanKernel(TreeViews* views, int which)
 {
-	__shared__ int lds[TREE_THREADS / 64 + 2];
+	__shared__ int sWave[2][TREE_THREADS / 64];
 	TreeView& t = views->t[which];
 	if (t.capacity <= 0 || t.qstate[3] != 0)
 	{
 		return;
 	}
 	const int N = t.leaves[t.state[0]] + 1; // `first` runs over [0, proxies)
-	const int tid = threadIdx.x;
-	const int chunk = (N + TREE_THREADS - 1) / TREE_THREADS;
-	const int lo = min(tid * chunk, N), hi = min(lo + chunk, N);
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int tiles = (N + 63) / 64, perWave = (tiles + TREE_THREADS / 64 - 1) / (TREE_THREADS / 64);
+	const int tile0 = min(wave * perWave, tiles), tile1 = min(tile0 + perWave, tiles);
 	int totals[2] = {0, 0};
 	for (int which2 = 0; which2 < 2; ++which2)
 	{
 		int* a = which2 == 0 ? t.arrive : t.partner;
-		int mine = 0;
-		for (int i = lo; i < hi; ++i)
+		// pass 1: the wave's sum
+		int sum = 0;
+		for (int b0 = tile0; b0 < tile1; b0 += TREE_SCAN_TILES)
 		{
-			mine += a[i];
+			int v[TREE_SCAN_TILES];
+#pragma unroll
+			for (int k = 0; k < TREE_SCAN_TILES; ++k)
+			{
+				const int i = (b0 + k) * 64 + lane;
+				v[k] = (b0 + k < tile1 && i < N) ? a[i] : 0;
+			}
+#pragma unroll
+			for (int k = 0; k < TREE_SCAN_TILES; ++k)
+			{
+				sum += v[k];
+			}
 		}
-		int run = blockExclusive(mine, lds, &totals[which2]);
-		for (int i = lo; i < hi; ++i)
+#pragma unroll
+		for (int d = 32; d >= 1; d >>= 1)
 		{
-			const int v = a[i];
-			a[i] = run;
-			run += v;
+			sum += __shfl_xor(sum, d, 64);
+		}
+		if (lane == 0)
+		{
+			sWave[which2][wave] = sum;
+		}
+		__syncthreads();
+		int run = 0;
+		for (int w = 0; w < TREE_THREADS / 64; ++w)
+		{
+			run += w < wave ? sWave[which2][w] : 0;
+			totals[which2] += sWave[which2][w];
+		}
+		// pass 2: prefixes
+		for (int b0 = tile0; b0 < tile1; b0 += TREE_SCAN_TILES)
+		{
+			int v[TREE_SCAN_TILES];
+#pragma unroll
+			for (int k = 0; k < TREE_SCAN_TILES; ++k)
+			{
+				const int i = (b0 + k) * 64 + lane;
+				v[k] = (b0 + k < tile1 && i < N) ? a[i] : 0;
+			}
+#pragma unroll
+			for (int k = 0; k < TREE_SCAN_TILES; ++k)
+			{
+				int x = v[k];
+#pragma unroll
+				for (int d = 1; d < 64; d <<= 1)
+				{
+					const int y = __shfl_up(x, d, 64);
+					if (lane >= d)
+					{
+						x += y;
+					}
+				}
+				const int i = (b0 + k) * 64 + lane;
+				if (b0 + k < tile1 && i < N)
+				{
+					a[i] = run + x - v[k];
+				}
+				run += __shfl(x, 63, 64);
+			}
 		}
 	}
 	if (tid == 0)
@@ -512,11 +568,27 @@ __global__ __launch_bounds__(TREE_THREADS) void treeBuildTasksKernel(TreeViews* 
 		if (n > TREE_SMALL)
 		{
 			// ---- one split of a long segment, in global memory (s2PartitionMid, src/dynamic_tree.c:1317-1427) ----
+			// Loads are issued TREE_BATCH at a time (a tile loaded when it is needed is a memory round trip per tile and pass: 100 us
+			// for the top segment of the base-200 pyramid).
 			unsigned int lx = 0xffffffffu, ly = 0xffffffffu, ux = 0u, uy = 0u;
-			for (int i = start + tid; i < end; i += TREE_THREADS)
+			for (int i0 = start + tid; i0 < end; i0 += TREE_BATCH * TREE_THREADS)
 			{
-				const unsigned int x = sortable(t.cx[i]), y = sortable(t.cy[i]);
-				lx = min(lx, x), ly = min(ly, y), ux = max(ux, x), uy = max(uy, y);
+				float vx[TREE_BATCH], vy[TREE_BATCH];
+#pragma unroll
+				for (int k = 0; k < TREE_BATCH; ++k)
+				{
+					const int i = i0 + k * TREE_THREADS;
+					vx[k] = i < end ? t.cx[i] : 0.0f, vy[k] = i < end ? t.cy[i] : 0.0f;
+				}
+#pragma unroll
+				for (int k = 0; k < TREE_BATCH; ++k)
+				{
+					if (i0 + k * TREE_THREADS < end)
+					{
+						const unsigned int x = sortable(vx[k]), y = sortable(vy[k]);
+						lx = min(lx, x), ly = min(ly, y), ux = max(ux, x), uy = max(uy, y);
+					}
+				}
 			}
 #pragma unroll
 			for (int d = 32; d >= 1; d >>= 1)
@@ -543,10 +615,21 @@ __global__ __launch_bounds__(TREE_THREADS) void treeBuildTasksKernel(TreeViews* 
 			const int tiles = (n + 63) / 64, perWave = (tiles + TREE_THREADS / 64 - 1) / (TREE_THREADS / 64);
 			const int tile0 = min(wave * perWave, tiles), tile1 = min(tile0 + perWave, tiles);
 			int mine = 0;
-			for (int tile = tile0; tile < tile1; ++tile)
+#pragma unroll 1
+			for (int b0 = tile0; b0 < tile1; b0 += TREE_BATCH)
 			{
-				const int i = start + tile * 64 + lane;
-				mine += __popcll(__ballot(i < end && centre[i] < pivot));
+				float v[TREE_BATCH];
+#pragma unroll
+				for (int k = 0; k < TREE_BATCH; ++k)
+				{
+					const int i = start + (b0 + k) * 64 + lane;
+					v[k] = (b0 + k < tile1 && i < end) ? centre[i] : pivot;
+				}
+#pragma unroll
+				for (int k = 0; k < TREE_BATCH; ++k)
+				{
+					mine += __popcll(__ballot(v[k] < pivot));
+				}
 			}
 			__syncthreads();
 			if (lane == 0)
@@ -563,40 +646,73 @@ __global__ __launch_bounds__(TREE_THREADS) void treeBuildTasksKernel(TreeViews* 
 			int split = n / 2; // (:1422-1429: nothing on one side of the pivot)
 			if (m > 0 && m < n)
 			{
-				// the Hoare loop's exchanges (:1357-1420): the j-th misplaced element from the left with the j-th from the right
+				// the Hoare loop's exchanges (:1357-1420): the j-th misplaced element from the left (position into `acc`) with the j-th
+				// from the right (into `partner`); there are as many of the one as of the other
 				split = m;
-				int running = base;
-				for (int tile = tile0; tile < tile1; ++tile)
+				int running = base, misplaced = 0;
+#pragma unroll 1
+				for (int b0 = tile0; b0 < tile1; b0 += TREE_BATCH)
 				{
-					const int i = start + tile * 64 + lane;
-					const bool left = i < end && centre[i] < pivot;
-					const unsigned long long mask = __ballot(left);
-					const int before = running + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
-					if (left && i - start >= m)
+					float v[TREE_BATCH];
+#pragma unroll
+					for (int k = 0; k < TREE_BATCH; ++k)
 					{
-						t.partner[start + (m - before - 1)] = i;
+						const int i = start + (b0 + k) * 64 + lane;
+						v[k] = (b0 + k < tile1 && i < end) ? centre[i] : pivot;
 					}
-					running += __popcll(mask);
+#pragma unroll
+					for (int k = 0; k < TREE_BATCH; ++k)
+					{
+						const int i = start + (b0 + k) * 64 + lane;
+						const bool in = b0 + k < tile1 && i < end;
+						const bool left = v[k] < pivot;
+						const unsigned long long mask = __ballot(left);
+						const int before = running + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
+						if (in && left && i - start >= m)
+						{
+							t.partner[start + (m - before - 1)] = i;
+						}
+						else if (in && !left && i - start < m)
+						{
+							t.acc[start + (i - start - before)] = i;
+						}
+						misplaced += __popcll(__ballot(in && !left && i - start < m));
+						running += __popcll(mask);
+					}
 				}
 				__syncthreads();
-				running = base;
-				for (int tile = tile0; tile < tile1; ++tile)
+				if (lane == 0)
 				{
-					const int i = start + tile * 64 + lane;
-					const bool left = i < end && centre[i] < pivot;
-					const unsigned long long mask = __ballot(left);
-					const int before = running + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mask, 0u));
-					if (i < end && !left && i - start < m)
+					lds[wave] = misplaced;
+				}
+				__threadfence_block();
+				__syncthreads();
+				int pairs = 0;
+				for (int w = 0; w < TREE_THREADS / 64; ++w)
+				{
+					pairs += lds[w];
+				}
+				for (int j0 = tid; j0 < pairs; j0 += TREE_BATCH * TREE_THREADS)
+				{
+					int pi[TREE_BATCH], pp[TREE_BATCH];
+#pragma unroll
+					for (int k = 0; k < TREE_BATCH; ++k)
 					{
-						// (only the bits of lower lanes and earlier tiles are used, all left of the split: what the lanes right of it
-						// read while their elements are being exchanged does not matter)
-						const int p = t.partner[start + (i - start - before)];
-						const int li = t.leafIdx[i];
-						const float x = t.cx[i], y = t.cy[i];
-						t.leafIdx[i] = t.leafIdx[p], t.cx[i] = t.cx[p], t.cy[i] = t.cy[p];
-						t.leafIdx[p] = li, t.cx[p] = x, t.cy[p] = y;
+						const int j = j0 + k * TREE_THREADS;
+						pi[k] = j < pairs ? t.acc[start + j] : -1, pp[k] = j < pairs ? t.partner[start + j] : -1;
 					}
-					running += __popcll(mask);
+#pragma unroll
+					for (int k = 0; k < TREE_BATCH; ++k)
+					{
+						if (pi[k] >= 0)
+						{
+							const int i = pi[k], p = pp[k];
+							const int li = t.leafIdx[i], lp = t.leafIdx[p];
+							const float ox = t.cx[i], oy = t.cy[i], px = t.cx[p], py = t.cy[p];
+							t.leafIdx[i] = lp, t.cx[i] = px, t.cy[i] = py;
+							t.leafIdx[p] = li, t.cx[p] = ox, t.cy[p] = oy;
+						}
+					}
 				}
 			}
 			__threadfence();

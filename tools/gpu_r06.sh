@@ -19,6 +19,13 @@ trees2)
 	python tools/rocpd_summary.py $(find gpurun_out/prof_trees -name '*_results.db' | head -1) > gpurun_out/r06_trees_kernel_trace.txt 2>&1; rm -rf gpurun_out/prof_trees
 	cat gpurun_out/r06_trees.txt; tail -12 gpurun_out/r06_dropin_default_solver.txt; head -40 gpurun_out/r06_trees_kernel_trace.txt
 	;;
+full)
+	python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > gpurun_out/r06_gpu_suite.txt
+	tools/dropin_product_demo.sh 200 40 pyramid 7 8 4 45 > gpurun_out/r06_dropin_demo.txt 2>&1
+	S2AMD_DROPIN=step S2AMD_DEVICE_PAIRS=1 S2AMD_LIBRARY="$PWD/solver2d_amd/libs2amd.so" tools/dropin_product_demo.bin 200 40 pyramid 3 4 2 45 >> gpurun_out/r06_dropin_demo.txt 2>&1
+	python bench.py > gpurun_out/r06_bench.json 2> gpurun_out/r06_bench.err
+	cat gpurun_out/r06_gpu_suite.txt; tail -4 gpurun_out/r06_dropin_demo.txt; cat gpurun_out/r06_bench.json | cut -c1-1500
+	;;
 *)
 	echo "unknown stage $1"; exit 2;;
 esac

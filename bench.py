@@ -256,7 +256,12 @@ def island_sharded_leg(ranks, islands, base, vel, pos, steps, warmup, graph=True
     mine = int((sw.mine.contacts["pointCount"] > 0).sum())
     # the group kernel runs the WHOLE step of its islands in one launch: constraint-sweeps per launch = mine * sweeps
     algo = ALGO_BYTES_LDS_PATH * mine * sweeps
-    achieved = algo / max(us * 1e-6, 1e-12) / 1e9
+    model_gbs = algo / max(us * 1e-6, 1e-12) / 1e9
+    # what the launch has to move at the very least: every wire contact in once per STEP (152 B) and its impulses out (16 B per point),
+    # every body of the rank in (88 B) and its solver fields out (36 B) -- the records live in registers / LDS in between
+    bodies_mine = int((sw.mine.bodies["type"] >= 0).sum())
+    min_bytes = mine * (152.0 + 32.0) + bodies_mine * (88.0 + 36.0)
+    achieved = min_bytes / max(us * 1e-6, 1e-12) / 1e9
     out_line = {
         "metric": "contact-constraints x iters/sec, %d independent base-%d pyramids TGS_Soft, islands sharded over the GPUs" % (islands * (ranks.world if weak else 1), base),
         "value": C_total * sweeps * steps / elapsed, "unit": "constraint-iters/s", "n_gpus": ranks.world, "steps": steps, "warmup": warmup,
@@ -275,24 +280,28 @@ def island_sharded_leg(ranks, islands, base, vel, pos, steps, warmup, graph=True
                      "traffic_source": pmc_traffic_bytes(ISLAND_KERNELS, "config5", live_us=us)[1] if ranks.world == 1 and islands == 512 and base == 40 else None,
                      "kernel": "wideIslandKernel / islandStepKernel (whole step of this rank's islands in one launch: constraints resident in registers, bodies in "
                                "LDS, records prepared from and impulses stored to the wire contacts by the kernel itself)", "avg_launch_us": us,
-                     "algorithmic_bytes_per_launch": algo,
-                     "byte_model": "136 B per constraint-sweep (SURVEY.md 8d, body state served from LDS) x %d constraints x %d sweeps" % (mine, sweeps),
-                     "note": "`frac` is the contract's byte MODEL over the kernel's time, not a bandwidth (it passes 1 once the kernel is faster than the model's bytes at 8 TB/s): the kernel reads one wire record per "
-                             "constraint and STEP (152 B in, 16 B per point out = %.2f GB) and keeps it in registers, so `traffic` (PMC) is a "
-                             "fraction of the model and the kernel is VALU-issue bound -- see `issue`" % (mine * (152.0 + 32.0) / 1e9)},
+                     "algorithmic_bytes_per_launch": min_bytes,
+                     "byte_model": "the launch's MINIMUM traffic: %d constraints x (152 B wire record in + 2 x 16 B impulses out) + %d bodies x (88 B in + 36 B "
+                                   "out), once per step -- the kernel keeps the records in registers and the bodies in LDS for all %d sweeps" % (mine, bodies_mine, sweeps),
+                     # SURVEY.md 8(d)'s per-sweep model, kept as a labelled extra: it counts a record per SWEEP while the kernel reads it per
+                     # STEP, so it is not a bandwidth and passes the peak once the kernel is fast (r5 reported it as `frac`: 1.003)
+                     "contract_model_8d": {"bytes_per_launch": algo, "bytes_per_constraint_sweep": ALGO_BYTES_LDS_PATH, "gbs_if_it_were_traffic": model_gbs,
+                                           "over_peak": model_gbs / HBM_PEAK_GBS},
+                     "note": "`frac` = minimum bytes / kernel time / 8 TB/s (<= 1 by construction); `traffic` (PMC) over `algorithmic_bytes_per_launch` says how "
+                             "much more than the minimum the kernel moves; the kernel is VALU-issue bound -- see `issue`"},
     }
     line = out_line
     traffic = line["roofline"]["traffic"]
     if traffic:
         line["roofline"]["traffic_gbs"] = traffic / max(us * 1e-6, 1e-12) / 1e9
         line["roofline"]["traffic_frac_of_peak"] = line["roofline"]["traffic_gbs"] / HBM_PEAK_GBS
-        line["roofline"]["traffic_over_model"] = traffic / algo
+        line["roofline"]["traffic_over_minimum"] = traffic / min_bytes
     line["issue"] = finish_issue(pmc_issue(ISLAND_KERNELS, "config5", live_us=us), st["groupCount"]) if ranks.world == 1 and islands == 512 and base == 40 else None
     if line["issue"] is not None and "refused" not in line["issue"]:
         line["issue"]["note"] = "512 workgroups of 512 threads on 256 CUs (two passes): the kernel is VALU-issue bound, not bandwidth bound"
         # what bounds this kernel, as a fraction: the share of a SIMD's cycles in which it issues a VALU instruction
         line["roofline"]["issue_frac"] = line["issue"]["valu_issue_frac_per_simd"]
-        line["roofline"]["bound_in_fact"] = "VALU issue (see `issue`); `frac` above is the contract's byte model over the kernel's time"
+        line["roofline"]["bound_in_fact"] = "VALU issue (see `issue`)"
     return line
 
 
@@ -513,7 +522,8 @@ def fast_leg(device_index, base, vel, pos, steps, warmup, graph, opts):
 def sharded_abi_leg(device_index, islands, base, vel, pos, steps, warmup, shard_counts=(1, 2, 4)):
     """BASELINE.json configs[4] through the C-ABI's own sharding (include/solver2d_amd.h: s2amd_sharded_*; csrc/sharded.hip): ONE
     process, the world's islands found on the device and bin-packed onto k shards -- here k LOGICAL shards on this one GPU, so the
-    numbers say what the partition and the per-step exchange (compact, peer copy, scatter: k x (k - 1) copies) cost, not how k GPUs
+    numbers say what the partition and the per-step exchange (one kernel per shard storing its rows into every shard's copy of the
+    world's body records, on a stream of its own; between distinct GPUs one ncclAllGather per device instead) cost, not how k GPUs
     scale; the multi-process form over RCCL is `island_sharded`.  The k-shard results equal the unsharded world's bit for bit
     (tests/test_gpu_sharded.py)."""
     world = synthetic.pyramid(base, count=islands)
@@ -528,14 +538,23 @@ def sharded_abi_leg(device_index, islands, base, vel, pos, steps, warmup, shard_
             upload_ms = 1e3 * (time.perf_counter() - t0)
             for _ in range(warmup):
                 sh.step(params)
+            # consecutive steps enqueued back to back, one host wait at the end -- as the unsharded line and `island_sharded` are timed
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                sh.step_async(params)
+            sh.wait()
+            ms = 1e3 * (time.perf_counter() - t0) / steps
+            ops, _waits, form = sh.step_ops()
             t0 = time.perf_counter()
             for _ in range(steps):
                 sh.step(params)
-            ms = 1e3 * (time.perf_counter() - t0) / steps
+            ms_waited = 1e3 * (time.perf_counter() - t0) / steps
             owner, n_islands, _ = sh.partition()
             per_shard = np.bincount(owner[owner >= 0], minlength=k).tolist()
-        rows.append({"shards": k, "ms_per_step": ms, "value": C * sweeps / (ms * 1e-3), "upload_and_partition_ms": upload_ms, "islands": n_islands,
-                     "bodies_per_shard": per_shard, "exchange_bytes_per_step": int(sum(per_shard) * 32 * max(k - 1, 0))})
+        rows.append({"shards": k, "ms_per_step": ms, "ms_per_step_waiting_after_each": ms_waited, "value": C * sweeps / (ms * 1e-3),
+                     "upload_and_partition_ms": upload_ms, "islands": n_islands, "bodies_per_shard": per_shard,
+                     "exchange": ("stores", "rccl", "peer copies")[form], "stream_ops_per_step": ops,
+                     "exchange_bytes_per_step": int(sum(per_shard) * 32 * max(k - 1, 0))})
     return {"workload": "%d independent base-%d pyramids (%d constraints), s2_solverTGS_Soft %d/%d; islands found on the device (s2amd_find_islands), "
                         "bin-packed onto k logical shards of ONE GPU by s2amd_sharded_upload; one exchange of the owned body records per step" % (
                             islands, base, C, vel, pos),

@@ -490,13 +490,22 @@ int s2amd_set_option(s2amdSolver* solver, const char* key, int32_t value);
  * is partitioned over `deviceCount` shards, one s2amdSolver each on the HIP device named for it (the same ordinal may be named more
  * than once: logical shards on one GPU).  Islands share no movable body, so a step needs no collective: every shard runs the whole
  * s2Solve_* of its islands; the step's ONE exchange carries each shard's owned body records -- {position, rot}, {linearVelocity,
- * angularVelocity, 0}: 28 bytes per body in two 16-byte records -- to every other shard's device (peer copies: xGMI between the GPUs of
- * a node), where they are scattered into that device's copy of the WHOLE world's body records.  The multi-PROCESS form of the same
- * partition (one rank per GPU over RCCL) is solver2d_amd/distributed.py.
+ * angularVelocity, 0}: 28 bytes per body in two 16-byte records -- into every device's copy of the WHOLE world's body records, on a
+ * stream of its own per shard (the next step's solve does not wait for it).  How it travels is chosen at s2amd_sharded_create: ONE
+ * kernel per shard storing into every copy when the shards share a device; ONE ncclAllGather per device plus a scatter kernel between
+ * distinct devices (RCCL over xGMI, single process: librccl.so is looked up at run time and the library loads without it); peer
+ * copies otherwise (S2AMD_SHARDED_EXCHANGE=stores|rccl|copies overrides).  The multi-PROCESS form of the same partition (one rank per
+ * GPU, torch.distributed over RCCL) is solver2d_amd/distributed.py.
  *   s2amd_sharded_upload    islands found on the device, bin-packed by constraint count (2 per contact constraint + 1 per joint; longest
  *                           processing time first, ties by index: deterministic), every shard's sub-world uploaded -- its islands'
  *                           bodies and constraints in pool order, immovable bodies they touch as read-only replicas;
- *   s2amd_sharded_step      == s2Solve_<solverType> of the whole world, results resident on the shards' devices, + the exchange;
+ *   s2amd_sharded_step      == s2Solve_<solverType> of the whole world, results resident on the shards' devices, + the exchange
+ *                           (== s2amd_sharded_step_async + s2amd_sharded_wait);
+ *   s2amd_sharded_step_async  (API 5) the same, enqueued only: O(shards) stream operations, no host wait;
+ *   s2amd_sharded_wait      (API 5) the one host wait (one stream, which takes every shard's last event).  A shard whose persistent
+ *                           launch lost a hand-off is noticed here: with ONE step outstanding its step is repeated and its rows exchanged
+ *                           again; with more, the steps behind the failing one were dropped on that shard only, the call fails and the
+ *                           world must be uploaded again.  Download, read_bodies, reshard and upload wait by themselves;
  *   s2amd_sharded_download  the world's arrays on the host, every body and constraint from the shard that owns it; constraintIndex as
  *                           the reference's gather loop over the whole pool writes it;
  *   s2amd_sharded_read_bodies  float[bodyCapacity][8] of the world's body records as of the last exchange, read from `shard`'s device;
@@ -514,6 +523,13 @@ s2amdSolver* s2amd_sharded_solver(s2amdShardedSolver* sharded, int32_t shard);
 int s2amd_sharded_upload(s2amdShardedSolver* sharded, const s2amdBody* bodies, int32_t bodyCapacity, const s2amdContact* contacts, int32_t contactCapacity,
 						 const s2amdJoint* joints, int32_t jointCapacity);
 int s2amd_sharded_step(s2amdShardedSolver* sharded, const s2amdStepParams* params);
+int s2amd_sharded_step_async(s2amdShardedSolver* sharded, const s2amdStepParams* params);
+int s2amd_sharded_wait(s2amdShardedSolver* sharded);
+/* what the last s2amd_sharded_step_async enqueued, counted where it is enqueued: stream operations (launches, copies, collectives,
+ * event records and waits), host waits since (s2amd_sharded_wait: 1), and the form of the exchange (0 stores, 1 rccl, 2 peer copies) */
+int s2amd_sharded_get_step_ops(s2amdShardedSolver* sharded, int32_t* streamOps, int32_t* hostWaits, int32_t* exchange);
+/* the same count for `shards` shards in the given form, by the code that enqueues a step, enqueueing nothing (no device needed) */
+int s2amd_sharded_count_ops(int32_t shards, int32_t exchange, int32_t* streamOps);
 int s2amd_sharded_download(s2amdShardedSolver* sharded, s2amdBody* bodies, int32_t bodyCapacity, s2amdContact* contacts, int32_t contactCapacity,
 						   s2amdJoint* joints, int32_t jointCapacity);
 int s2amd_sharded_read_bodies(s2amdShardedSolver* sharded, int32_t shard, float* records, int32_t bodyCapacity);

@@ -9,11 +9,19 @@
 //   upload   islands found on the device, bin-packed onto the shards by constraint count (longest processing time first), every
 //            shard's sub-world (its islands' bodies, the immovable bodies they touch as read-only replicas, its constraints)
 //            uploaded to its device's solver;
-//   step     every shard's s2Solve_* enqueued on its own device -- no collective inside a step --, then the step's ONE exchange:
-//            each shard's owned body records ({position, rot}, {linearVelocity, angularVelocity}: the 28 bytes per body of SURVEY.md
-//            8e in two 16-byte records) compacted on its device, copied to every other device (hipMemcpyPeerAsync: xGMI between the
-//            GPUs of one node; a plain device copy between logical shards of one GPU) and scattered into that device's copy of the
-//            WHOLE world's body records -- every device ends the step with every body, what a device-side collision phase needs;
+//   step     every shard's s2Solve_* enqueued on its own device -- no collective inside a step --, then the step's ONE exchange of the
+//            owned body records ({position, rot}, {linearVelocity, angularVelocity}: the 28 bytes per body of SURVEY.md 8e in two
+//            16-byte records) into every device's copy of the WHOLE world's body records -- every device ends the step with every
+//            body, what a device-side collision phase needs.  The exchange runs on a stream of its own per shard, behind an event of
+//            the solve stream; the next step's solve does not wait for it (it reads only its own shard), only the next export does.
+//            Three forms, O(n) stream operations per step in the first two (round 6; r5 enqueued n (n - 1) wait / copy / scatter
+//            triples on the destinations' SOLVE streams and synchronised every shard in turn):
+//              stores  shards that share one device: ONE kernel per shard writes its rows into every shard's world copy;
+//              rccl    n distinct devices: one ncclAllGather per device (single process, ncclCommInitAll; librccl.so is dlopen'ed, the
+//                      library loads without it) of the padded compact runs, one scatter kernel per device;
+//              copies  whatever is left (some devices shared, some not, or no RCCL): r5's peer copies, on the exchange streams.
+//            s2amd_sharded_step_async enqueues and returns; s2amd_sharded_wait is the one place the host waits (one stream) and
+//            where a shard's lost hand-off is noticed and its step repeated;
 //   reshard  the constraint graph changed: every shard's solver state comes down, islands are found again (device), an island
 //            stays on the shard that owned most of its bodies (a created contact that joins two islands moves the smaller one),
 //            the partition is rebalanced past REBALANCE_THRESHOLD, the new sub-worlds go up.
@@ -25,7 +33,10 @@
 
 #include "solver2d_amd.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -34,6 +45,8 @@
 int s2amdFail(int code, const std::string& msg);
 hipStream_t s2amdStream(s2amdSolver* s);
 int s2amdDevice(s2amdSolver* s);
+bool s2amdStepFailed(s2amdSolver* s); // solver.cpp: the host-visible error word of an enqueued step (no device call)
+extern "C" int s2amd_sharded_wait(s2amdShardedSolver* w);
 
 namespace
 {
@@ -73,6 +86,88 @@ __global__ void scatterOwnedKernel(const float4* compact, const int* ownedWorld,
 		world[2 * b + 1] = compact[2 * i + 1];
 	}
 }
+
+// the owned rows of a shard's exported records straight into every world copy this device can store to (shards of one device)
+__global__ void pushOwnedKernel(const float4* records, const int* ownedLocal, const int* ownedWorld, int n, float4* const* worlds, int nWorlds)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n)
+	{
+		const int b = ownedLocal[i], wi = ownedWorld[i];
+		const float4 r0 = records[2 * b], r1 = records[2 * b + 1];
+		for (int d = 0; d < nWorlds; ++d)
+		{
+			worlds[d][2 * wi] = r0;
+			worlds[d][2 * wi + 1] = r1;
+		}
+	}
+}
+
+// every rank's padded compact run as ncclAllGather delivered it -> the world's rows (ids[k] < 0: padding)
+__global__ void scatterGatheredKernel(const float4* gathered, const int* ids, int total, float4* world)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < total && ids[i] >= 0)
+	{
+		const int b = ids[i];
+		world[2 * b] = gathered[2 * i];
+		world[2 * b + 1] = gathered[2 * i + 1];
+	}
+}
+
+// RCCL, looked up at run time: the library loads and runs without it (one GPU, or shards that share one)
+struct RcclApi
+{
+	void* lib = nullptr;
+	int (*commInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+	int (*commDestroy)(void* comm) = nullptr;
+	int (*groupStart)() = nullptr;
+	int (*groupEnd)() = nullptr;
+	int (*allGather)(const void* send, void* recv, size_t sendcount, int datatype, void* comm, hipStream_t stream) = nullptr;
+	const char* (*errorString)(int) = nullptr;
+	bool tried = false;
+	bool load()
+	{
+		if (tried)
+		{
+			return lib != nullptr;
+		}
+		tried = true;
+		const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+		for (const char* name : names)
+		{
+			if ((lib = dlopen(name, RTLD_NOW | RTLD_LOCAL)) != nullptr)
+			{
+				break;
+			}
+		}
+		if (lib == nullptr)
+		{
+			return false;
+		}
+		*(void**)(&commInitAll) = dlsym(lib, "ncclCommInitAll");
+		*(void**)(&commDestroy) = dlsym(lib, "ncclCommDestroy");
+		*(void**)(&groupStart) = dlsym(lib, "ncclGroupStart");
+		*(void**)(&groupEnd) = dlsym(lib, "ncclGroupEnd");
+		*(void**)(&allGather) = dlsym(lib, "ncclAllGather");
+		*(void**)(&errorString) = dlsym(lib, "ncclGetErrorString");
+		if (!commInitAll || !commDestroy || !groupStart || !groupEnd || !allGather)
+		{
+			dlclose(lib);
+			lib = nullptr;
+		}
+		return lib != nullptr;
+	}
+};
+RcclApi g_rccl;
+constexpr int kNcclFloat = 7; // ncclFloat32 (nccl.h: ncclDataType_t)
+
+enum Exchange
+{
+	EX_STORES = 0,
+	EX_RCCL = 1,
+	EX_COPIES = 2
+};
 
 struct DeviceBlock
 {
@@ -122,6 +217,13 @@ struct Shard
 	DeviceBlock dRecords, dOwnedLocal, dOwnedWorld, dCompact, dWorld;
 	std::vector<DeviceBlock> inbox, inboxIds; // per source shard: its compact run and the pool indices of its rows
 	hipEvent_t evCompact = nullptr;			  // this shard's compact run is complete
+	// (round 6) the exchange's own stream: it starts behind `evStep` of the solve stream and ends in `evXchg`, which only the next
+	// step's export (it rewrites dRecords) and the host's one wait look at
+	hipStream_t xs = nullptr;
+	hipEvent_t evStep = nullptr, evXchg = nullptr;
+	DeviceBlock dPeers;				 // stores: every shard's dWorld, as this device addresses it
+	DeviceBlock dGather, dGatherIds; // rccl: n padded compact runs as the all-gather delivers them; the pool index of every row (-1: padding)
+	void* comm = nullptr;			 // rccl: this device's communicator
 	bool uploaded = false;
 };
 
@@ -142,6 +244,13 @@ struct s2amdShardedSolver
 	long steps = 0;
 	int repeatedSteps = 0; // shard steps repeated after a persistent launch lost a hand-off
 	int lastSolverType = -1; // of the last step (-1: none yet): whether its driver writes manifold.constraintIndex
+	int exchange = EX_COPIES; // how the step's exchange travels (Exchange; chosen at s2amd_sharded_create)
+	size_t maxOwned = 0;	  // rccl: rows per rank of the padded all-gather
+	std::vector<s2amdStepParams> outstanding; // steps enqueued since the host last waited (s2amd_sharded_wait)
+	// what the last s2amd_sharded_step_async enqueued, counted where it is enqueued: {stream operations (launches, copies, event
+	// records and waits, collectives), host waits}
+	int32_t opsLastStep = 0, hostWaitsLastStep = 0;
+	bool dry = false; // s2amd_sharded_count_ops: count, enqueue nothing
 };
 
 namespace
@@ -364,6 +473,80 @@ int findIslands(s2amdShardedSolver* w)
 	return rc;
 }
 
+// body indices of the live constraints, before anything indexes w.bodies / w.island with them (s2amd_find_islands checks them too, but
+// returns early on an empty body pool)
+int checkConstraintBodies(int nb, const s2amdContact* contacts, int nc, const s2amdJoint* joints, int nj)
+{
+	for (int k = 0; k < nc; ++k)
+	{
+		const s2amdContact& c = contacts[k];
+		if (c.pointCount > 0 && (c.bodyA < 0 || c.bodyA >= nb || c.bodyB < 0 || c.bodyB >= nb))
+		{
+			return s2amdFail(S2AMD_E_INVALID, "contact " + std::to_string(k) + " names a body outside the pool");
+		}
+	}
+	for (int k = 0; k < nj; ++k)
+	{
+		const s2amdJoint& j = joints[k];
+		if (j.type >= 0 && (j.bodyA < 0 || j.bodyA >= nb || j.bodyB < 0 || j.bodyB >= nb))
+		{
+			return s2amdFail(S2AMD_E_INVALID, "joint " + std::to_string(k) + " names a body outside the pool");
+		}
+	}
+	return S2AMD_OK;
+}
+
+// what the chosen form of the exchange reads: every shard's table of world copies (stores), or the pool index of every row of the
+// padded all-gather (rccl)
+int buildExchangeTables(s2amdShardedSolver* w)
+{
+	const int nShards = (int)w->shards.size();
+	int rc = S2AMD_OK;
+	if (w->exchange == EX_STORES)
+	{
+		std::vector<float4*> worlds((size_t)nShards);
+		for (int s = 0; s < nShards; ++s)
+		{
+			worlds[(size_t)s] = (float4*)w->shards[(size_t)s].dWorld.p;
+		}
+		for (Shard& sh : w->shards)
+		{
+			if ((rc = sh.dPeers.ensure(sh.device, (size_t)nShards * sizeof(float4*))) != 0)
+			{
+				return rc;
+			}
+			SH_TRY(hipSetDevice(sh.device));
+			SH_TRY(hipMemcpy(sh.dPeers.p, worlds.data(), (size_t)nShards * sizeof(float4*), hipMemcpyHostToDevice));
+		}
+	}
+	else if (w->exchange == EX_RCCL)
+	{
+		w->maxOwned = 1;
+		for (const Shard& sh : w->shards)
+		{
+			w->maxOwned = std::max(w->maxOwned, sh.ownedWorld.size());
+		}
+		std::vector<int> ids((size_t)nShards * w->maxOwned, -1);
+		for (int s = 0; s < nShards; ++s)
+		{
+			const Shard& src = w->shards[(size_t)s];
+			std::copy(src.ownedWorld.begin(), src.ownedWorld.end(), ids.begin() + (size_t)s * w->maxOwned);
+		}
+		for (Shard& sh : w->shards)
+		{
+			if ((rc = sh.dGather.ensure(sh.device, ids.size() * 32)) != 0 || (rc = sh.dGatherIds.ensure(sh.device, ids.size() * sizeof(int))) != 0 ||
+				(rc = sh.dCompact.ensure(sh.device, w->maxOwned * 32)) != 0)
+			{
+				return rc;
+			}
+			SH_TRY(hipSetDevice(sh.device));
+			SH_TRY(hipMemcpy(sh.dGatherIds.p, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice));
+			SH_TRY(hipMemset(sh.dCompact.p, 0, w->maxOwned * 32)); // (the padding rows travel: they are never scattered)
+		}
+	}
+	return S2AMD_OK;
+}
+
 // partition (fresh, or sticky when previousOwner is given), extract, upload, exchange buffers
 int partitionAndUpload(s2amdShardedSolver* w, const std::vector<int32_t>& previousOwner)
 {
@@ -455,6 +638,11 @@ int partitionAndUpload(s2amdShardedSolver* w, const std::vector<int32_t>& previo
 			}
 		}
 	}
+	if ((rc = buildExchangeTables(w)) != 0)
+	{
+		return rc;
+	}
+	w->outstanding.clear();
 	w->resident = true;
 	return S2AMD_OK;
 }
@@ -531,9 +719,11 @@ int s2amd_sharded_create(const int32_t* devices, int32_t deviceCount, s2amdShard
 			// the steps of all shards are enqueued before any is waited for
 			rc = s2amd_set_option(sh.solver, "async", 1);
 		}
-		if (rc == S2AMD_OK && (hipSetDevice(sh.device) != hipSuccess || hipEventCreateWithFlags(&sh.evCompact, hipEventDisableTiming) != hipSuccess))
+		if (rc == S2AMD_OK && (hipSetDevice(sh.device) != hipSuccess || hipEventCreateWithFlags(&sh.evCompact, hipEventDisableTiming) != hipSuccess ||
+								hipEventCreateWithFlags(&sh.evStep, hipEventDisableTiming) != hipSuccess ||
+								hipEventCreateWithFlags(&sh.evXchg, hipEventDisableTiming) != hipSuccess))
 		{
-			rc = s2amdFail(S2AMD_E_DEVICE, "could not create the shard's event");
+			rc = s2amdFail(S2AMD_E_DEVICE, "could not create the shard's exchange stream and events");
 		}
 		if (rc)
 		{
@@ -556,6 +746,59 @@ int s2amd_sharded_create(const int32_t* devices, int32_t deviceCount, s2amdShard
 			(void)hipGetLastError(); // (already enabled: not an error)
 		}
 	}
+	// how the step's exchange travels: stores between shards of one device, RCCL between distinct devices, peer copies for the rest
+	// (S2AMD_SHARDED_EXCHANGE=stores|rccl|copies overrides: tests, and a node whose RCCL misbehaves)
+	{
+		bool allSame = true, allDistinct = true;
+		for (int i = 0; i < deviceCount; ++i)
+		{
+			for (int j = i + 1; j < deviceCount; ++j)
+			{
+				allSame = allSame && devices[i] == devices[j];
+				allDistinct = allDistinct && devices[i] != devices[j];
+			}
+		}
+		const char* forced = getenv("S2AMD_SHARDED_EXCHANGE");
+		w->exchange = allSame ? EX_STORES : (allDistinct ? EX_RCCL : EX_COPIES);
+		if (forced != nullptr && strcmp(forced, "copies") == 0)
+		{
+			w->exchange = EX_COPIES;
+		}
+		else if (forced != nullptr && strcmp(forced, "rccl") == 0 && allDistinct)
+		{
+			w->exchange = EX_RCCL; // (one rank per device: shards that share a device cannot be RCCL ranks)
+		}
+		else if (forced != nullptr && strcmp(forced, "stores") == 0 && allSame)
+		{
+			w->exchange = EX_STORES;
+		}
+		if (w->exchange == EX_RCCL)
+		{
+			std::vector<void*> comms((size_t)deviceCount, nullptr);
+			std::vector<int> devs(devices, devices + deviceCount);
+			if (!g_rccl.load() || g_rccl.commInitAll(comms.data(), deviceCount, devs.data()) != 0)
+			{
+				w->exchange = EX_COPIES; // (no librccl.so, or it would not initialise: the peer copies)
+			}
+			else
+			{
+				for (int i = 0; i < deviceCount; ++i)
+				{
+					w->shards[(size_t)i].comm = comms[(size_t)i];
+				}
+			}
+		}
+	}
+	// the exchange's own streams, where it has them (shards of one device send their rows on the solve stream -- and a stream more per
+	// shard moved their solve streams onto ONE hardware queue of the four: 4 logical shards took 0.76 ms a step instead of 0.50)
+	for (Shard& sh : w->shards)
+	{
+		if (w->exchange != EX_STORES && (hipSetDevice(sh.device) != hipSuccess || hipStreamCreateWithFlags(&sh.xs, hipStreamNonBlocking) != hipSuccess))
+		{
+			s2amd_sharded_destroy(w);
+			return s2amdFail(S2AMD_E_DEVICE, "could not create the shard's exchange stream");
+		}
+	}
 	*out = w;
 	return S2AMD_OK;
 }
@@ -572,7 +815,17 @@ void s2amd_sharded_destroy(s2amdShardedSolver* w)
 		{
 			(void)s2amd_synchronize(sh.solver);
 		}
-		DeviceBlock* blocks[] = {&sh.dRecords, &sh.dOwnedLocal, &sh.dOwnedWorld, &sh.dCompact, &sh.dWorld};
+		if (sh.xs)
+		{
+			(void)hipSetDevice(sh.device);
+			(void)hipStreamSynchronize(sh.xs);
+		}
+		if (sh.comm && g_rccl.commDestroy)
+		{
+			(void)g_rccl.commDestroy(sh.comm);
+			sh.comm = nullptr;
+		}
+		DeviceBlock* blocks[] = {&sh.dRecords, &sh.dOwnedLocal, &sh.dOwnedWorld, &sh.dCompact, &sh.dWorld, &sh.dPeers, &sh.dGather, &sh.dGatherIds};
 		for (DeviceBlock* b : blocks)
 		{
 			b->release();
@@ -589,6 +842,18 @@ void s2amd_sharded_destroy(s2amdShardedSolver* w)
 		{
 			(void)hipSetDevice(sh.device);
 			(void)hipEventDestroy(sh.evCompact);
+		}
+		if (sh.evStep)
+		{
+			(void)hipEventDestroy(sh.evStep);
+		}
+		if (sh.evXchg)
+		{
+			(void)hipEventDestroy(sh.evXchg);
+		}
+		if (sh.xs)
+		{
+			(void)hipStreamDestroy(sh.xs);
 		}
 		if (sh.solver)
 		{
@@ -613,6 +878,15 @@ int s2amd_sharded_upload(s2amdShardedSolver* w, const s2amdBody* bodies, int32_t
 	{
 		return s2amdFail(S2AMD_E_INVALID, "bad argument");
 	}
+	int rc = checkConstraintBodies(bodyCapacity, contacts, contactCapacity, joints, jointCapacity);
+	if (rc)
+	{
+		return rc;
+	}
+	if (w->resident && (rc = s2amd_sharded_wait(w)) != 0)
+	{
+		return rc;
+	}
 	w->bodies.assign(bodies, bodies + bodyCapacity);
 	w->contacts.assign(contacts, contacts + contactCapacity);
 	w->joints.assign(joints, joints + jointCapacity);
@@ -621,22 +895,27 @@ int s2amd_sharded_upload(s2amdShardedSolver* w, const s2amdBody* bodies, int32_t
 	return partitionAndUpload(w, none);
 }
 
-int s2amd_sharded_step(s2amdShardedSolver* w, const s2amdStepParams* params)
+// one shard's step and its part of the exchange, enqueued: the solve on the solver's stream, the rows on the exchange stream behind it
+static int enqueueShard(s2amdShardedSolver* w, int index, const s2amdStepParams* params, int32_t* ops)
 {
-	if (!w || !params)
-	{
-		return s2amdFail(S2AMD_E_INVALID, "null argument");
-	}
-	if (!w->resident)
-	{
-		return s2amdFail(S2AMD_E_STATE, "s2amd_sharded_step called before s2amd_sharded_upload");
-	}
+	Shard& sh = w->shards[(size_t)index];
+	const bool dry = w->dry;
 	const int nShards = (int)w->shards.size();
-	// every shard's s2Solve_*, its records exported and its owned rows compacted and scattered into its own world copy: enqueued
-	// on the shard's own stream, nothing waited for
-	for (Shard& sh : w->shards)
+	const size_t n = sh.ownedLocal.size();
+	hipStream_t st = dry ? nullptr : s2amdStream(sh.solver);
+	// Shards of one device gain nothing from a second stream each (the device is the same one, and more streams than hardware queues
+	// serialise in ways nobody asked for: 4 shards took 0.78 ms that way against 0.50): their rows go out on the solve stream itself.
+	const bool beside = w->exchange != EX_STORES;
+	hipStream_t xs = dry ? nullptr : (beside ? sh.xs : st);
+	if (!dry)
 	{
+		SH_TRY(hipSetDevice(sh.device));
 		int rc = s2amd_step_resident(sh.solver, params);
+		if (rc == S2AMD_OK && beside)
+		{
+			// (the last exchange has read the records this step's export rewrites; the solve itself did not have to wait for it)
+			SH_TRY(hipStreamWaitEvent(st, sh.evXchg, 0));
+		}
 		if (rc == S2AMD_OK)
 		{
 			rc = s2amd_export_bodies_async(sh.solver, sh.dRecords.p, (int32_t)sh.bodies.size(), 0);
@@ -645,88 +924,293 @@ int s2amd_sharded_step(s2amdShardedSolver* w, const s2amdStepParams* params)
 		{
 			return rc;
 		}
-		const size_t n = sh.ownedLocal.size();
-		hipStream_t st = s2amdStream(sh.solver);
-		SH_TRY(hipSetDevice(sh.device));
-		if (n > 0)
+		if (beside)
 		{
-			compactOwnedKernel<<<blocksFor(n), dim3(256), 0, st>>>((const float4*)sh.dRecords.p, (const int*)sh.dOwnedLocal.p, (int)n, (float4*)sh.dCompact.p);
-			scatterOwnedKernel<<<blocksFor(n), dim3(256), 0, st>>>((const float4*)sh.dCompact.p, (const int*)sh.dOwnedWorld.p, (int)n, (float4*)sh.dWorld.p);
+			SH_TRY(hipEventRecord(sh.evStep, st));
+			SH_TRY(hipStreamWaitEvent(sh.xs, sh.evStep, 0));
 		}
-		SH_TRY(hipGetLastError());
-		SH_TRY(hipEventRecord(sh.evCompact, st));
 	}
-	// the step's one exchange: every compact run to every other shard's device, scattered there into its world copy
-	for (int t = 0; t < nShards; ++t)
+	*ops += beside ? 5 : 2; // step, export (+ wait, record, wait)
+	if (w->exchange == EX_STORES)
 	{
-		Shard& dst = w->shards[(size_t)t];
-		hipStream_t st = s2amdStream(dst.solver);
-		SH_TRY(hipSetDevice(dst.device));
-		for (int s = 0; s < nShards; ++s)
+		if (!dry && n > 0)
 		{
-			const Shard& src = w->shards[(size_t)s];
-			const size_t n = src.ownedLocal.size();
-			if (s == t || n == 0)
-			{
-				continue;
-			}
-			SH_TRY(hipStreamWaitEvent(st, src.evCompact, 0));
-			SH_TRY(hipMemcpyPeerAsync(dst.inbox[(size_t)s].p, dst.device, src.dCompact.p, src.device, n * 32, st));
-			scatterOwnedKernel<<<blocksFor(n), dim3(256), 0, st>>>((const float4*)dst.inbox[(size_t)s].p, (const int*)dst.inboxIds[(size_t)s].p, (int)n,
-																   (float4*)dst.dWorld.p);
+			pushOwnedKernel<<<blocksFor(n), dim3(256), 0, xs>>>((const float4*)sh.dRecords.p, (const int*)sh.dOwnedLocal.p, (const int*)sh.dOwnedWorld.p, (int)n,
+																(float4* const*)sh.dPeers.p, nShards);
+			SH_TRY(hipGetLastError());
 		}
-		SH_TRY(hipGetLastError());
+		*ops += 1;
 	}
-	// ... and waited for.  A shard whose persistent launch lost a hand-off (another process on its GPU) has left its arrays untouched
-	// and keeps to the multi-launch path from now on: its step is repeated, its rows exchanged again
-	for (int t = 0; t < nShards; ++t)
+	else
 	{
-		Shard& sh = w->shards[(size_t)t];
-		int rc = s2amd_synchronize(sh.solver);
-		for (int attempt = 0; rc == S2AMD_E_DEVICE && attempt < 2; ++attempt)
+		if (!dry && n > 0)
 		{
-			w->repeatedSteps += 1;
-			rc = s2amd_step_resident(sh.solver, params);
-			if (rc == S2AMD_OK)
+			compactOwnedKernel<<<blocksFor(n), dim3(256), 0, sh.xs>>>((const float4*)sh.dRecords.p, (const int*)sh.dOwnedLocal.p, (int)n, (float4*)sh.dCompact.p);
+			SH_TRY(hipGetLastError());
+		}
+		*ops += 1;
+		if (w->exchange == EX_COPIES)
+		{
+			if (!dry && n > 0)
 			{
-				rc = s2amd_export_bodies_async(sh.solver, sh.dRecords.p, (int32_t)sh.bodies.size(), 0);
+				scatterOwnedKernel<<<blocksFor(n), dim3(256), 0, sh.xs>>>((const float4*)sh.dCompact.p, (const int*)sh.dOwnedWorld.p, (int)n, (float4*)sh.dWorld.p);
+				SH_TRY(hipGetLastError());
 			}
-			const size_t n = sh.ownedLocal.size();
-			if (rc == S2AMD_OK && n > 0)
+			if (!dry)
 			{
-				hipStream_t st = s2amdStream(sh.solver);
-				SH_TRY(hipSetDevice(sh.device));
-				compactOwnedKernel<<<blocksFor(n), dim3(256), 0, st>>>((const float4*)sh.dRecords.p, (const int*)sh.dOwnedLocal.p, (int)n, (float4*)sh.dCompact.p);
-				scatterOwnedKernel<<<blocksFor(n), dim3(256), 0, st>>>((const float4*)sh.dCompact.p, (const int*)sh.dOwnedWorld.p, (int)n, (float4*)sh.dWorld.p);
-				SH_TRY(hipStreamSynchronize(st));
-				for (int d = 0; d < nShards; ++d)
+				SH_TRY(hipEventRecord(sh.evCompact, sh.xs));
+			}
+			*ops += 2;
+		}
+	}
+	return S2AMD_OK;
+}
+
+// the rest of the exchange, which involves more than one shard: the collective, or the peer copies; every exchange stream ends in its event
+static int enqueueExchange(s2amdShardedSolver* w, int only, int32_t* ops)
+{
+	const bool dry = w->dry;
+	const int nShards = (int)w->shards.size();
+	if (w->exchange == EX_RCCL)
+	{
+		// one all-gather per device in one group: every device receives every rank's padded run (only == -1: a repeated shard's rows
+		// travel with everybody's, the others' being what they were)
+		if (!dry)
+		{
+			if (g_rccl.groupStart() != 0)
+			{
+				return s2amdFail(S2AMD_E_DEVICE, "ncclGroupStart failed");
+			}
+			for (Shard& sh : w->shards)
+			{
+				const int rcN = g_rccl.allGather(sh.dCompact.p, sh.dGather.p, w->maxOwned * 8, kNcclFloat, sh.comm, sh.xs);
+				if (rcN != 0)
 				{
-					if (d == t)
-					{
-						continue;
-					}
-					Shard& dst = w->shards[(size_t)d];
-					hipStream_t dstStream = s2amdStream(dst.solver);
-					SH_TRY(hipSetDevice(dst.device));
-					SH_TRY(hipMemcpyPeerAsync(dst.inbox[(size_t)t].p, dst.device, sh.dCompact.p, sh.device, n * 32, dstStream));
-					scatterOwnedKernel<<<blocksFor(n), dim3(256), 0, dstStream>>>((const float4*)dst.inbox[(size_t)t].p, (const int*)dst.inboxIds[(size_t)t].p,
-																					  (int)n, (float4*)dst.dWorld.p);
-					SH_TRY(hipStreamSynchronize(dstStream));
+					(void)g_rccl.groupEnd();
+					return s2amdFail(S2AMD_E_DEVICE, std::string("ncclAllGather failed: ") + (g_rccl.errorString ? g_rccl.errorString(rcN) : "?"));
 				}
 			}
+			if (g_rccl.groupEnd() != 0)
+			{
+				return s2amdFail(S2AMD_E_DEVICE, "ncclGroupEnd failed");
+			}
+			for (Shard& sh : w->shards)
+			{
+				const size_t total = (size_t)nShards * w->maxOwned;
+				SH_TRY(hipSetDevice(sh.device));
+				scatterGatheredKernel<<<blocksFor(total), dim3(256), 0, sh.xs>>>((const float4*)sh.dGather.p, (const int*)sh.dGatherIds.p, (int)total, (float4*)sh.dWorld.p);
+				SH_TRY(hipGetLastError());
+			}
+		}
+		*ops += 2 * nShards;
+	}
+	else if (w->exchange == EX_COPIES)
+	{
+		for (int t = 0; t < nShards; ++t)
+		{
+			Shard& dst = w->shards[(size_t)t];
+			if (!dry)
+			{
+				SH_TRY(hipSetDevice(dst.device));
+			}
+			for (int s = 0; s < nShards; ++s)
+			{
+				const Shard& src = w->shards[(size_t)s];
+				const size_t n = src.ownedLocal.size();
+				if (s == t || n == 0 || (only >= 0 && s != only))
+				{
+					continue;
+				}
+				if (!dry)
+				{
+					SH_TRY(hipStreamWaitEvent(dst.xs, src.evCompact, 0));
+					SH_TRY(hipMemcpyPeerAsync(dst.inbox[(size_t)s].p, dst.device, src.dCompact.p, src.device, n * 32, dst.xs));
+					scatterOwnedKernel<<<blocksFor(n), dim3(256), 0, dst.xs>>>((const float4*)dst.inbox[(size_t)s].p, (const int*)dst.inboxIds[(size_t)s].p, (int)n,
+																			   (float4*)dst.dWorld.p);
+					SH_TRY(hipGetLastError());
+				}
+				*ops += 3;
+			}
+		}
+	}
+	for (Shard& sh : w->shards)
+	{
+		if (!dry)
+		{
+			SH_TRY(hipSetDevice(sh.device));
+			SH_TRY(hipEventRecord(sh.evXchg, w->exchange == EX_STORES ? s2amdStream(sh.solver) : sh.xs));
+		}
+		*ops += 1;
+	}
+	return S2AMD_OK;
+}
+
+int s2amd_sharded_step_async(s2amdShardedSolver* w, const s2amdStepParams* params)
+{
+	if (!w || !params)
+	{
+		return s2amdFail(S2AMD_E_INVALID, "null argument");
+	}
+	if (!w->resident && !w->dry)
+	{
+		return s2amdFail(S2AMD_E_STATE, "s2amd_sharded_step called before s2amd_sharded_upload");
+	}
+	const int nShards = (int)w->shards.size();
+	int32_t ops = 0;
+	for (int i = 0; i < nShards; ++i)
+	{
+		const int rc = enqueueShard(w, i, params, &ops);
+		if (rc)
+		{
+			// (earlier shards have this step enqueued and this one has not: the world's shards disagree from here on)
+			w->resident = false;
+			return rc;
+		}
+	}
+	const int rc = enqueueExchange(w, -1, &ops);
+	if (rc)
+	{
+		w->resident = false;
+		return rc;
+	}
+	w->opsLastStep = ops;
+	w->hostWaitsLastStep = 0;
+	w->outstanding.push_back(*params);
+	w->steps += 1;
+	w->lastSolverType = params->solverType;
+	return S2AMD_OK;
+}
+
+// The one place the host waits: shard 0's exchange stream takes every other shard's last event, and the host takes that stream.  A shard
+// whose persistent launch lost a hand-off (another process on its GPU) has left its arrays untouched and keeps to the multi-launch path
+// from now on: its step is repeated and its rows exchanged again -- possible when one step is outstanding; with more, the steps
+// behind the failing one were dropped too and the world is marked torn (upload it again).
+int s2amd_sharded_wait(s2amdShardedSolver* w)
+{
+	if (!w)
+	{
+		return s2amdFail(S2AMD_E_INVALID, "null solver");
+	}
+	if (w->outstanding.empty() || w->shards.empty())
+	{
+		return S2AMD_OK;
+	}
+	const int nShards = (int)w->shards.size();
+	Shard& first = w->shards[0];
+	hipStream_t join = first.xs != nullptr ? first.xs : s2amdStream(first.solver);
+	SH_TRY(hipSetDevice(first.device));
+	for (int t = 0; t < nShards; ++t)
+	{
+		if (t > 0 || first.xs != nullptr)
+		{
+			SH_TRY(hipStreamWaitEvent(join, w->shards[(size_t)t].evXchg, 0));
+		}
+	}
+	SH_TRY(hipStreamSynchronize(join));
+	w->hostWaitsLastStep += 1;
+	int result = S2AMD_OK;
+	for (int t = 0; t < nShards && result == S2AMD_OK; ++t)
+	{
+		Shard& sh = w->shards[(size_t)t];
+		if (!s2amdStepFailed(sh.solver))
+		{
+			continue; // (the error word is host-visible: nothing to ask the device)
+		}
+		int rc = s2amd_synchronize(sh.solver); // (clears the error words, drops the solver to its fall-back path)
+		if (rc != S2AMD_E_DEVICE)
+		{
+			result = rc != S2AMD_OK ? rc : s2amdFail(S2AMD_E_DEVICE, "a shard reported a failed step and none on inspection");
+			break;
+		}
+		if (w->outstanding.size() > 1)
+		{
+			w->resident = false;
+			result = s2amdFail(S2AMD_E_DEVICE, "shard " + std::to_string(t) + " lost a hand-off with " + std::to_string(w->outstanding.size()) +
+													" steps outstanding: the steps behind the failing one were dropped on that shard only; upload the world again "
+													"(or wait after every step: s2amd_sharded_step)");
+			break;
+		}
+		const s2amdStepParams params = w->outstanding.back();
+		// (near hand-offs off, then the overflow workgroup off, then the persistent kernels off: three repeats can be legitimate)
+		for (int attempt = 0; rc == S2AMD_E_DEVICE && attempt < 4; ++attempt)
+		{
+			w->repeatedSteps += 1;
+			int32_t ops = 0;
+			rc = enqueueShard(w, t, &params, &ops);
 			if (rc == S2AMD_OK)
 			{
-				rc = s2amd_synchronize(sh.solver);
+				rc = enqueueExchange(w, t, &ops);
+			}
+			if (rc == S2AMD_OK)
+			{
+				for (Shard& other : w->shards)
+				{
+					SH_TRY(hipSetDevice(other.device));
+					SH_TRY(hipStreamSynchronize(other.xs != nullptr ? other.xs : s2amdStream(other.solver)));
+					w->hostWaitsLastStep += 1;
+				}
+				rc = s2amdStepFailed(sh.solver) ? s2amd_synchronize(sh.solver) : S2AMD_OK;
 			}
 		}
 		if (rc)
 		{
-			return rc;
+			w->resident = false; // (the shard could not complete the step the others have: torn)
+			result = rc;
 		}
 	}
-	w->steps += 1;
-	w->lastSolverType = params->solverType;
+	w->outstanding.clear();
+	return result;
+}
+
+int s2amd_sharded_step(s2amdShardedSolver* w, const s2amdStepParams* params)
+{
+	const int rc = s2amd_sharded_step_async(w, params);
+	return rc != S2AMD_OK ? rc : s2amd_sharded_wait(w);
+}
+
+// {stream operations, host waits} of the last s2amd_sharded_step_async (+ the waits of the s2amd_sharded_wait behind it), and how the
+// exchange travels (0 stores, 1 rccl, 2 peer copies)
+int s2amd_sharded_get_step_ops(s2amdShardedSolver* w, int32_t* streamOps, int32_t* hostWaits, int32_t* exchange)
+{
+	if (!w)
+	{
+		return s2amdFail(S2AMD_E_INVALID, "null solver");
+	}
+	if (streamOps)
+	{
+		*streamOps = w->opsLastStep;
+	}
+	if (hostWaits)
+	{
+		*hostWaits = w->hostWaitsLastStep;
+	}
+	if (exchange)
+	{
+		*exchange = w->exchange;
+	}
 	return S2AMD_OK;
+}
+
+// what one step of `shards` shards enqueues in the given form of the exchange, counted by the code that enqueues it (nothing is
+// enqueued: callable without a device)
+int s2amd_sharded_count_ops(int32_t shards, int32_t exchange, int32_t* streamOps)
+{
+	if (shards <= 0 || shards > 64 || exchange < 0 || exchange > 2 || !streamOps)
+	{
+		return s2amdFail(S2AMD_E_INVALID, "bad argument");
+	}
+	s2amdShardedSolver w;
+	w.shards.resize((size_t)shards);
+	for (Shard& sh : w.shards)
+	{
+		sh.ownedLocal.assign(1, 0); // (every shard owns something)
+	}
+	w.exchange = exchange;
+	w.dry = true;
+	s2amdStepParams params{};
+	const int rc = s2amd_sharded_step_async(&w, &params);
+	*streamOps = w.opsLastStep;
+	return rc;
 }
 
 int s2amd_sharded_read_bodies(s2amdShardedSolver* w, int32_t shard, float* out, int32_t bodyCapacity)
@@ -743,9 +1227,16 @@ int s2amd_sharded_read_bodies(s2amdShardedSolver* w, int32_t shard, float* out, 
 	{
 		return s2amdFail(S2AMD_E_CAPACITY, "body record buffer too small");
 	}
+	{
+		const int rcWait = s2amd_sharded_wait(w);
+		if (rcWait)
+		{
+			return rcWait;
+		}
+	}
 	Shard& sh = w->shards[(size_t)shard];
 	SH_TRY(hipSetDevice(sh.device));
-	SH_TRY(hipStreamSynchronize(s2amdStream(sh.solver)));
+	SH_TRY(hipStreamSynchronize(sh.xs != nullptr ? sh.xs : s2amdStream(sh.solver)));
 	if (!w->bodies.empty())
 	{
 		SH_TRY(hipMemcpy(out, sh.dWorld.p, w->bodies.size() * 32, hipMemcpyDeviceToHost));
@@ -769,7 +1260,11 @@ int s2amd_sharded_download(s2amdShardedSolver* w, s2amdBody* bodies, int32_t bod
 	{
 		return s2amdFail(S2AMD_E_CAPACITY, "output arrays smaller than the resident world");
 	}
-	int rc = pullShards(w);
+	int rc = s2amd_sharded_wait(w);
+	if (rc == S2AMD_OK)
+	{
+		rc = pullShards(w);
+	}
 	if (rc)
 	{
 		return rc;
@@ -814,7 +1309,17 @@ int s2amd_sharded_reshard(s2amdShardedSolver* w, const s2amdContact* contacts, i
 	{
 		return s2amdFail(S2AMD_E_INVALID, "the new constraint arrays must have the pool capacities of the uploaded world");
 	}
-	int rc = pullShards(w); // bodies, impulses, TGS_Sticky's friction cache: the solver state lives with the owner
+	// (validated before anything is touched: a failed reshard leaves the solver as it was)
+	int rc = checkConstraintBodies((int)w->bodies.size(), contacts ? contacts : w->contacts.data(), (int)w->contacts.size(), joints ? joints : w->joints.data(),
+								   (int)w->joints.size());
+	if (rc == S2AMD_OK)
+	{
+		rc = s2amd_sharded_wait(w);
+	}
+	if (rc == S2AMD_OK)
+	{
+		rc = pullShards(w); // bodies, impulses, TGS_Sticky's friction cache: the solver state lives with the owner
+	}
 	if (rc)
 	{
 		return rc;

@@ -6,6 +6,7 @@
 // or joints is one launch per colour batch.  There is NO CPU fallback: without a gfx950 device
 // s2amd_create fails with S2AMD_E_NODEVICE.
 
+#include <atomic>
 #include "solver_executor.h"
 
 namespace
@@ -31,6 +32,7 @@ void s2amdRecordDeviceMs(s2amdSolver* s, float ms)
 {
 	s->stats.deviceMs = ms;
 }
+bool s2amdStepFailed(s2amdSolver* s) { return s != nullptr && s->hostError != nullptr && *s->hostError != 0u; }
 int s2amdDevice(s2amdSolver* s)
 {
 	return s->device;
@@ -178,10 +180,10 @@ int s2amd_create(int device, s2amdSolver** out)
 	}
 	{
 		// every code object of the library loaded now, not by whichever step first launches a kernel of it (launch.h: S2_DEFINE_WARM)
-		static bool warmed[64] = {};
-		if (device < 64 && !warmed[device])
+		// (two threads creating solvers at once -- one per device of a sharded solver -- must not both find the flag clear, nor race on it)
+		static std::atomic<bool> warmed[64];
+		if (device < 64 && !warmed[device].exchange(true))
 		{
-			warmed[device] = true;
 			s2Warm_contact_kernels(s->stream);
 			s2Warm_body_kernels(s->stream);
 			s2Warm_joint_kernels(s->stream);
@@ -218,6 +220,10 @@ void s2amd_destroy(s2amdSolver* s)
 	if (devPoolSolverDestroyed(s->device))
 	{
 		devPoolDrain(); // (what the copies gave back on this device, once its last solver goes: solver_internal.h: DevBuf)
+		if (devPoolNoSolverLeft())
+		{
+			spareClonesRelease(); // (... and the retired copies themselves -- megabytes of host vectors -- with the process's last solver)
+		}
 	}
 	(void)hipStreamSynchronize(s->stream);
 	destroyGraph(s);

@@ -70,6 +70,18 @@ bool devPoolSolverDestroyed(int device)
 	g_alive[device] = std::max(g_alive[device] - 1, 0);
 	return g_alive[device] == 0;
 }
+bool devPoolNoSolverLeft()
+{
+	std::lock_guard<std::mutex> lock(g_aliveMutex);
+	for (int n : g_alive)
+	{
+		if (n != 0)
+		{
+			return false;
+		}
+	}
+	return true;
+}
 
 void devPoolThread(bool on) { tlsDevPool = on; }
 bool devPoolOn() { return tlsDevPool; }
@@ -404,6 +416,21 @@ void reap(AsyncBuild*& list, bool wait)
 }
 
 } // namespace
+
+// the process's last solver is gone (s2amd_destroy): the retired copies go too, like the device pools
+void spareClonesRelease()
+{
+	std::vector<s2amdSolver*> spare;
+	{
+		std::lock_guard<std::mutex> lock(gSpareMutex);
+		spare.swap(gSpareClones);
+	}
+	for (s2amdSolver* c : spare)
+	{
+		delete c;
+	}
+}
+
 
 bool asyncBuildsOn(const s2amdSolver* s)
 {

@@ -75,6 +75,8 @@ bool devPoolGive(void* p, size_t bytes);
 void devPoolDrain(); // (the calling thread's current device's pool)
 void devPoolSolverCreated(int device);
 bool devPoolSolverDestroyed(int device);
+bool devPoolNoSolverLeft();
+void spareClonesRelease(); // solver_async.cpp: the retired copies of solvers kept for the next structure request
 
 // growable raw device allocation
 struct DevBuf

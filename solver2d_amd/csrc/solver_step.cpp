@@ -636,6 +636,11 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 		key = fnv(key, gens, sizeof(gens));
 		int sizes[3] = {s->bodyCapacity, s->contactCapacity, s->jointCapacity};
 		key = fnv(key, sizes, sizeof(sizes));
+		// (the world step's stage 4 rides in the captured epilogue launch with its arguments baked in: a shape array that moved or grew
+		// under the same body / contact / joint capacities -- a shape added to an existing body -- is another graph)
+		const uint64_t stage4Words[4] = {(uint64_t)(uintptr_t)s->stage4.shapes, (uint64_t)s->stage4.shapeCapacity, (uint64_t)(uintptr_t)s->stage4.origins,
+										 (uint64_t)(uintptr_t)s->stage4.summary};
+		key = fnv(key, stage4Words, sizeof(stage4Words));
 		if (key == 0)
 		{
 			key = 1;

@@ -28,6 +28,7 @@ EXPORTS = [
     "s2amd_get_strip_owners",
     "s2amd_sharded_create", "s2amd_sharded_destroy", "s2amd_sharded_shard_count", "s2amd_sharded_solver", "s2amd_sharded_upload", "s2amd_sharded_step",
     "s2amd_sharded_download", "s2amd_sharded_read_bodies", "s2amd_sharded_reshard", "s2amd_sharded_get_partition",
+    "s2amd_sharded_step_async", "s2amd_sharded_wait", "s2amd_sharded_get_step_ops", "s2amd_sharded_count_ops",
 ]
 
 _libs = {}
@@ -99,6 +100,10 @@ def load(fast=False):
     L.s2amd_sharded_solver.restype = vp
     L.s2amd_sharded_upload.argtypes = [vp, vp, i32, vp, i32, vp, i32]
     L.s2amd_sharded_step.argtypes = [vp, ctypes.POINTER(wire.StepParams)]
+    L.s2amd_sharded_step_async.argtypes = [vp, ctypes.POINTER(wire.StepParams)]
+    L.s2amd_sharded_wait.argtypes = [vp]
+    L.s2amd_sharded_get_step_ops.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.s2amd_sharded_count_ops.argtypes = [i32, i32, ctypes.POINTER(i32)]
     L.s2amd_sharded_download.argtypes = [vp, vp, i32, vp, i32, vp, i32]
     L.s2amd_sharded_read_bodies.argtypes = [vp, i32, vp, i32]
     L.s2amd_sharded_reshard.argtypes = [vp, vp, i32, vp, i32]
@@ -477,6 +482,19 @@ class ShardedSolver:
 
     def step(self, params):
         self._ck(self._L.s2amd_sharded_step(self._h, ctypes.byref(params)))
+
+    def step_async(self, params):
+        """The step enqueued on the shards' streams, nothing waited for (wait() collects)."""
+        self._ck(self._L.s2amd_sharded_step_async(self._h, ctypes.byref(params)))
+
+    def wait(self):
+        self._ck(self._L.s2amd_sharded_wait(self._h))
+
+    def step_ops(self):
+        """(stream operations the last step enqueued, host waits since, exchange form: 0 stores / 1 rccl / 2 peer copies)"""
+        ops, waits, ex = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        self._ck(self._L.s2amd_sharded_get_step_ops(self._h, ctypes.byref(ops), ctypes.byref(waits), ctypes.byref(ex)))
+        return ops.value, waits.value, ex.value
 
     def download(self, bodies, contacts, joints):
         self._ck(self._L.s2amd_sharded_download(self._h, *Solver._args(bodies, contacts, joints)))

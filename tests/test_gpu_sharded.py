@@ -155,3 +155,57 @@ def test_sharded_api_state_errors():
             sh.shard(2)
     with pytest.raises(hip.S2AmdError):
         hip.ShardedSolver([])
+
+
+@pytest.mark.parametrize("mode,shards", [("stores", 3), ("copies", 3), ("copies", 2), ("rccl", 1)])
+def test_pipelined_steps_in_every_form_of_the_exchange(mode, shards, monkeypatch):
+    """s2amd_sharded_step_async x 5, one s2amd_sharded_wait: the exchange as stores into every world copy (shards of one device), as
+    round 5's peer copies (forced), and -- one rank, all this box has -- through RCCL's all-gather; every form ends with the unsharded
+    world's bits on the host and in every shard's copy of the body records, and enqueues what s2amd_sharded_count_ops says it does."""
+    import ctypes
+    monkeypatch.setenv("S2AMD_SHARDED_EXCHANGE", mode)
+    params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+    world = _mixed_world()
+    want = _unsharded(world, params, 5)
+    got = common.copy3(world)
+    with hip.ShardedSolver([0] * shards) as sh:
+        sh.upload(*world)
+        for _ in range(5):
+            sh.step_async(params)
+        ops, waits, form = sh.step_ops()
+        assert waits == 0
+        sh.wait()
+        assert sh.step_ops()[1] == 1
+        records = [sh.read_bodies(k) for k in range(shards)]
+        sh.download(*got)
+    if mode == "rccl" and form != 1:
+        pytest.skip("librccl.so could not be loaded or initialised here: the exchange fell back to peer copies")
+    assert form == {"stores": 0, "copies": 2, "rccl": 1}[mode]
+    counted = ctypes.c_int32()
+    assert hip.load().s2amd_sharded_count_ops(shards, form, ctypes.byref(counted)) == 0
+    assert ops == counted.value
+    common.compare_exact(got, want, "%s, %d shards, pipelined" % (mode, shards))
+    live = want[0]["type"] >= 0
+    for r in records:
+        assert np.array_equal(r[live, 0:2], want[0]["position"][live]) and np.array_equal(r[live, 4:6], want[0]["linearVelocity"][live])
+
+
+def test_sharded_upload_refuses_constraints_that_name_no_body():
+    world = _mixed_world()
+    bad = common.copy3(world)
+    k = int(np.flatnonzero(bad[1]["pointCount"] > 0)[0])
+    bad[1]["bodyB"][k] = len(bad[0]) + 5
+    with hip.ShardedSolver([0, 0]) as sh:
+        with pytest.raises(hip.S2AmdError):
+            sh.upload(*bad)
+        with pytest.raises(hip.S2AmdError):
+            sh.upload(np.zeros(0, dtype=wire.body_dtype), world[1], world[2])  # constraints with points and no bodies at all
+        sh.upload(*world)
+        with pytest.raises(hip.S2AmdError):
+            sh.reshard(contacts=bad[1])
+        # ... and the refused reshard left the solver as it was
+        params = wire.StepParams.make("TGS_Soft", 1.0 / 60.0, 8, 4, True)
+        sh.step(params)
+        got = common.copy3(world)
+        sh.download(*got)
+    common.compare_exact(got, _unsharded(world, params, 1), "after a refused reshard")

@@ -26,6 +26,11 @@ full)
 	python bench.py > gpurun_out/r06_bench.json 2> gpurun_out/r06_bench.err
 	cat gpurun_out/r06_gpu_suite.txt; tail -4 gpurun_out/r06_dropin_demo.txt; cat gpurun_out/r06_bench.json | cut -c1-1500
 	;;
+sharded)
+	python -m pytest tests/test_gpu_sharded.py tests/test_gpu_reshard.py -x -q 2>&1 | tail -15 > gpurun_out/r06_sharded.txt
+	python bench.py --steps 100 --warmup 20 --no-cpu > gpurun_out/r06_bench_sharded.json 2>gpurun_out/r06_bench_sharded.err
+	cat gpurun_out/r06_sharded.txt; python -c "import json;d=json.load(open('gpurun_out/r06_bench_sharded.json'));print(json.dumps(d['sharded_abi'],indent=1)[:3000]);print(d['island_sharded']['ms_per_step'])"
+	;;
 *)
 	echo "unknown stage $1"; exit 2;;
 esac

@@ -448,6 +448,11 @@ int s2amd_get_contact_order(s2amdSolver* solver, int32_t* order, int32_t orderCa
 							int32_t colorCapacity, int32_t* constraintCount, int32_t* colorCount);
 int s2amd_get_joint_order(s2amdSolver* solver, int32_t* order, int32_t orderCapacity, int32_t* colorOffsets,
 						  int32_t colorCapacity, int32_t* jointCount, int32_t* colorCount);
+/* (API 5) writable[b] = 1: the sweeps the contact order above was coloured for write body b -- no two constraints of one colour share
+ * such a body (the check a caller can make of an order it is handed).  *solverClass: 0 the velocity sweeps (bodies with mass), 1 the
+ * position sweeps of PGS_NGS / PGS_NGS_Block / TGS_NGS, which also rewrite the rotation of immovable bodies (src/solve_common.c:383-392:
+ * only a static body whose rotation that normalisation leaves alone is read-only there). */
+int s2amd_get_writable_bodies(s2amdSolver* solver, uint8_t* writable, int32_t bodyCapacity, int32_t* solverClass);
 int s2amd_get_stats(s2amdSolver* solver, s2amdStepStats* stats);
 /* (API 3) Which strip -- which workgroup of the persistent step kernel -- owns each body in the structure in use, and which bodies the
  * seam between strips i and i + 1 carries: ownerStrip[body] = strip or -1 (a static body, a body of an LDS group or of the global part;

@@ -572,6 +572,33 @@ int s2amd_get_contact_order(s2amdSolver* s, int32_t* order, int32_t orderCapacit
 	return copyOrder(active, offsets, order, orderCapacity, colorOffsets, colorCapacity, constraintCount, colorCount);
 }
 
+// The bodies the sweeps of the last structure write -- the nodes two constraints of one colour must not share.  Velocity-class sweeps
+// (every solver's contact passes but the position passes below) write the bodies with mass; the position-class sweeps of PGS_NGS /
+// PGS_NGS_Block / TGS_NGS also store rot = normalize(rot) of immovable bodies (src/solve_common.c:383-392), so there only a static body
+// whose rotation is a fixed point of that normalisation is read-only (solver_step.cpp: the flags of the upload).
+int s2amd_get_writable_bodies(s2amdSolver* s, uint8_t* writable, int32_t bodyCapacity, int32_t* solverClass)
+{
+	if (!s || bodyCapacity < 0 || (bodyCapacity > 0 && !writable))
+	{
+		return fail(S2AMD_E_INVALID, "bad argument");
+	}
+	if ((int)s->hBodyFlags.size() > bodyCapacity)
+	{
+		return fail(S2AMD_E_CAPACITY, "the solver holds " + std::to_string(s->hBodyFlags.size()) + " bodies");
+	}
+	const int cls = s->orderSolverClass == 1 ? 1 : 0;
+	const uint32_t bit = cls == 1 ? S2F_WRITE_POS : S2F_WRITE_VEL;
+	for (size_t i = 0; i < s->hBodyFlags.size(); ++i)
+	{
+		writable[i] = (s->hBodyFlags[i] & bit) != 0 ? 1 : 0;
+	}
+	if (solverClass)
+	{
+		*solverClass = cls;
+	}
+	return S2AMD_OK;
+}
+
 int s2amd_get_joint_order(s2amdSolver* s, int32_t* order, int32_t orderCapacity, int32_t* colorOffsets, int32_t colorCapacity, int32_t* jointCount,
 						  int32_t* colorCount)
 {

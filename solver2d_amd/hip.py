@@ -21,7 +21,7 @@ FAST_LIB_PATH = os.environ.get("S2AMD_FAST_LIB") or os.path.join(_HERE, "libs2am
 EXPORTS = [
     "s2amd_api_version", "s2amd_build_flags", "s2amd_device_count", "s2amd_device_bus_id", "s2amd_last_error", "s2amd_create", "s2amd_destroy",
     "s2amd_solve", "s2amd_upload", "s2amd_step_resident", "s2amd_download", "s2amd_save_bodies",
-    "s2amd_restore_bodies", "s2amd_get_contact_order", "s2amd_get_joint_order", "s2amd_get_stats",
+    "s2amd_restore_bodies", "s2amd_get_contact_order", "s2amd_get_joint_order", "s2amd_get_writable_bodies", "s2amd_get_stats",
     "s2amd_set_option", "s2amd_export_poses", "s2amd_export_poses_async", "s2amd_export_bodies_async", "s2amd_export_wait", "s2amd_measure_dominant", "s2amd_refit_shapes", "s2amd_find_pairs", "s2amd_synchronize", "s2amd_update_contacts", "s2amd_find_islands", "s2amd_color_constraints",
     "s2amd_world_upload", "s2amd_world_step", "s2amd_world_download", "s2amd_world_find_pairs", "s2amd_world_set_contacts",
     "s2amd_device_alloc", "s2amd_device_free", "s2amd_device_read", "s2amd_world_separated", "s2amd_world_download_boxes", "s2amd_world_set_refit_order", "s2amd_world_download_step", "s2amd_world_set_tree", "s2amd_world_get_tree",
@@ -65,6 +65,7 @@ def load(fast=False):
     L.s2amd_synchronize.argtypes = [vp]
     L.s2amd_get_contact_order.argtypes = [vp, vp, i32, vp, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.s2amd_get_joint_order.argtypes = [vp, vp, i32, vp, i32, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.s2amd_get_writable_bodies.argtypes = [vp, vp, i32, ctypes.POINTER(i32)]
     L.s2amd_get_strip_owners.argtypes = [vp, vp, vp, i32, ctypes.POINTER(i32)]
     L.s2amd_get_stats.argtypes = [vp, ctypes.POINTER(wire.StepStats)]
     L.s2amd_set_option.argtypes = [vp, ctypes.c_char_p, i32]
@@ -197,6 +198,13 @@ class Solver:
 
     def __exit__(self, *a):
         self.close()
+
+    def writable_bodies(self, body_capacity):
+        """(writable uint8[nb], solver class): the bodies the coloured sweeps write -- what one colour must not share."""
+        out = np.zeros(int(body_capacity), dtype=np.uint8)
+        cls = ctypes.c_int32()
+        self._ck(self._L.s2amd_get_writable_bodies(self._h, wire.as_ptr(out), len(out), ctypes.byref(cls)))
+        return out, cls.value
 
     def set_option(self, key, value):
         self._ck(self._L.s2amd_set_option(self._h, key.encode(), int(value)))

@@ -46,8 +46,23 @@ CASES = [
 ONLY_MISSING = bool(os.environ.get("S2_GOLDEN_ONLY_MISSING"))
 
 
+def big_inputs():
+    """Full-size solver INPUTS (no post state: the GPU tests check them against the oracle): BASELINE.json configs[2], the Tumbler with
+    10,000 boxes stepped by the reference until the boxes have settled in the turning drum, captured at s2Solve_* entry.  Settled
+    under TGS_Soft: the reference's own Jacobi solver diverges on piles."""
+    path = os.path.join(OUT, "big_tumbler10000_input.npz")
+    if ONLY_MISSING and os.path.exists(path):
+        return 0
+    with refbind.RefWorld("tumbler", "TGS_Soft", 10000, 0) as w:
+        for _ in range(150):
+            w.step(1.0 / 60.0, 8, 4, True)
+        _params, pre, _post = w.step_captured(1.0 / 60.0, 8, 4, True)
+    np.savez_compressed(path, pre_bodies=pre[0], pre_contacts=pre[1], pre_joints=pre[2])
+    return os.path.getsize(path)
+
+
 def main():
-    total = 0
+    total = big_inputs()
     for scene, p0, p1, at in CASES:
         for solver in wire.SOLVER_NAMES:
             vel, pos = common.DEFAULT_ITERS[solver]

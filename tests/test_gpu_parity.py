@@ -63,6 +63,16 @@ def gpu_vs_oracle_loose(solver, params, pre, what):
     jorder, _ = solver.joint_order()
     active = np.flatnonzero(pre[1]["pointCount"] > 0)
     assert sorted(order.tolist()) == active.tolist()
+    assert offsets[0] == 0 and offsets[-1] == len(order)
+    if params.solverType != wire.SOLVER_ID["Jacobi"]:
+        # no colour holds two constraints on one body its sweeps write (s2amd_get_writable_bodies: the library's own rule, which for
+        # the position passes counts a rotated static body as written -- solve_common.c:383-392)
+        writable, _cls = solver.writable_bodies(len(pre[0]))
+        a, b = pre[1]["bodyA"][order], pre[1]["bodyB"][order]
+        colour = np.repeat(np.arange(len(offsets) - 1), np.diff(offsets))
+        touched = np.concatenate([a, b]).astype(np.int64)
+        keys = np.concatenate([colour, colour]).astype(np.int64)[writable[touched] != 0] * (len(pre[0]) + 1) + touched[writable[touched] != 0]
+        assert len(np.unique(keys)) == len(keys), "%s: a colour holds two constraints on one writable body" % what
     want = common.copy3(pre)
     oraclebind.solve(params, *want, contact_order=order, joint_order=jorder)
     common.compare_exact(got, want, what)

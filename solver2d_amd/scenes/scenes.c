@@ -390,7 +390,10 @@ typedef struct SceneEntry
 static const SceneEntry s_scenes[] = {{"pyramid"},		{"multi_pyramid"},	{"joint_grid"},		  {"tumbler"},	  {"mixed"},
 									  {"vertical_stack"}, {"circle_pile"},	{"shapes_zoo"},		  {"arch"},		  {"high_mass_ratio"},
 									  {"overlap_recovery"}, {"card_house"}, {"far_pyramid"},	  {"far_stack"},  {"far_recovery"},
-									  {"far_ragdoll_pile"}, {"far_chain"},	{"ragdoll"},		  {"ball_and_chain"}, {"bridge"}};
+									  {"far_ragdoll_pile"}, {"far_chain"},	{"ragdoll"},		  {"ball_and_chain"}, {"bridge"},
+									  // (round 6) the rest of the reference's 26 samples
+									  {"single_box"},	  {"warm_start_energy"}, {"friction_ramp"},  {"rush"},		  {"double_domino"},
+									  {"confined"},		  {"circle_stack"},	{"ragdoll_stress"}, {"stretched_chain"}};
 
 S2SCENE_API int s2scene_count(void)
 {
@@ -889,6 +892,417 @@ static void sceneBridge(s2WorldId w, int count)
 	}
 }
 
+// ---- the reference's remaining samples (round 6): every "Contact" and "Joints" sample has a constructor here ----
+// Three of them do something in their Step override besides stepping the world: s2scene_pre_step / s2scene_post_step below are
+// those overrides, so a headless loop  pre_step -> s2World_Step -> post_step  is the sample as the GUI runs it.
+
+// what a sample keeps between steps, per world slot (the reference has s2_maxWorlds = 32 of them, constants.h:12)
+#define SCENE_MAX_WORLDS 32
+#define RUSH_COUNT 400		// sample_contact.cpp:572
+#define STRESS_HUMANS 32	// sample_joints.cpp:212
+#define HUMAN_BONES 11
+typedef struct HumanIds
+{
+	s2BodyId bones[HUMAN_BONES];
+	s2JointId joints[HUMAN_BONES];
+	int spawned;
+} HumanIds;
+typedef struct SceneState
+{
+	int kind; // 0 nothing to do between steps, 1 warm_start_energy, 2 rush, 3 ragdoll_stress
+	uint16_t revision;
+	s2BodyId top;
+	s2BodyId rush[RUSH_COUNT];
+	HumanIds humans[STRESS_HUMANS];
+	float wait, side;
+} SceneState;
+static SceneState s_state[SCENE_MAX_WORLDS];
+
+static SceneState* stateOf(s2WorldId w, int create)
+{
+	if (w.index < 0 || w.index >= SCENE_MAX_WORLDS)
+	{
+		return NULL;
+	}
+	SceneState* st = s_state + w.index;
+	if (create)
+	{
+		memset(st, 0, sizeof(*st));
+		st->revision = w.revision;
+	}
+	return st->revision == w.revision ? st : NULL;
+}
+
+// "Single Box" (sample_contact.cpp:13-51): one 2 m box dropped from 4 m onto a segment
+static void sceneSingleBox(s2WorldId w)
+{
+	const float extent = 1.0f;
+	s2ShapeDef sd = s2_defaultShapeDef;
+	sd.friction = 0.5f;
+	makeGroundSegment(w, 0.0f, 0.0f, 0.5f * 2.0f * 66.0f * extent, &sd);
+	s2Polygon box = s2MakeBox(extent, extent);
+	s2CreatePolygonShape(makeDynamic(w, 0.0f, 4.0f, 0.0f), &sd, &box);
+}
+
+// "Warm Start Energy" (sample_contact.cpp:53-118): three touching circles in a column, the top one a hundred times denser; after
+// 120 steps the top one is destroyed (s2scene_pre_step) and what the warm start has stored pushes the other two apart
+static void sceneWarmStartEnergy(s2WorldId w)
+{
+	SceneState* st = stateOf(w, 1);
+	s2ShapeDef sd = s2_defaultShapeDef;
+	makeGroundSegment(w, 0.0f, 0.0f, 10.0f, &sd);
+	s2Circle circle = {{0.0f, 0.0f}, 0.5f};
+	const float separation = 0.0f;
+	for (int i = 0; i < 3; ++i)
+	{
+		s2BodyId id = makeDynamic(w, 0.0f, 0.5f + (float)i + separation, 0.0f);
+		sd.density = i == 2 ? 100.0f : 1.0f;
+		s2CreateCircleShape(id, &sd, &circle);
+		if (i == 2 && st != NULL)
+		{
+			st->kind = 1;
+			st->top = id;
+		}
+	}
+}
+
+// "Friction Ramp" (sample_contact.cpp:300-366): five boxes of friction 0.75 ... 0 sliding down three ramps of friction 0.2 --
+// the one sample whose contacts mix two different shape frictions (src/contact.c:179)
+static void sceneFrictionRamp(s2WorldId w)
+{
+	s2BodyId ground = s2CreateBody(w, &s2_defaultBodyDef);
+	s2ShapeDef sd = s2_defaultShapeDef;
+	sd.friction = 0.2f;
+	s2Segment segment = {{-40.0f, 0.0f}, {40.0f, 0.0f}};
+	s2CreateSegmentShape(ground, &sd, &segment);
+	const float ramps[5][5] = {{13.0f, 0.25f, -4.0f, 22.0f, -0.25f}, {0.25f, 1.0f, 10.5f, 19.0f, 0.0f}, {13.0f, 0.25f, 4.0f, 14.0f, 0.25f},
+							   {0.25f, 1.0f, -10.5f, 11.0f, 0.0f},	 {13.0f, 0.25f, -4.0f, 6.0f, -0.25f}};
+	for (int i = 0; i < 5; ++i)
+	{
+		s2Polygon box = s2MakeOffsetBox(ramps[i][0], ramps[i][1], (s2Vec2){ramps[i][2], ramps[i][3]}, ramps[i][4]);
+		s2CreatePolygonShape(ground, &sd, &box);
+	}
+	s2Polygon box = s2MakeBox(0.5f, 0.5f);
+	s2ShapeDef bd = s2_defaultShapeDef;
+	bd.density = 25.0f;
+	const float friction[5] = {0.75f, 0.5f, 0.35f, 0.1f, 0.0f};
+	for (int i = 0; i < 5; ++i)
+	{
+		bd.friction = friction[i];
+		s2CreatePolygonShape(makeDynamic(w, -15.0f + 4.0f * (float)i, 28.0f, 0.0f), &bd, &box);
+	}
+}
+
+// "Rush" (sample_contact.cpp:562-661): 400 weightless circles on a spiral around a static one, pulled to the centre by a force of
+// 1000 N applied before every step (s2scene_pre_step: s2Body_ApplyForceToCenter, the one sample that uses applied forces)
+static void sceneRush(s2WorldId w, int count)
+{
+	SceneState* st = stateOf(w, 1);
+	s2BodyDef bd = s2_defaultBodyDef;
+	s2BodyId ground = s2CreateBody(w, &bd);
+	s2Circle circle = {{0.0f, 0.0f}, 0.5f};
+	s2ShapeDef sd = s2_defaultShapeDef;
+	sd.friction = 0.2f;
+	sd.density = 100.0f;
+	s2CreateCircleShape(ground, &sd, &circle);
+	float distance = 5.0f, angle = 0.0f;
+	const float deltaAngle = 1.0f / distance, deltaDistance = 0.05f;
+	bd.type = s2_dynamicBody;
+	bd.gravityScale = 0.0f;
+	if (count > RUSH_COUNT)
+	{
+		count = RUSH_COUNT;
+	}
+	for (int i = 0; i < count; ++i)
+	{
+		bd.position = (s2Vec2){distance * cosf(angle), distance * sinf(angle)};
+		s2BodyId id = s2CreateBody(w, &bd);
+		s2CreateCircleShape(id, &sd, &circle);
+		if (st != NULL)
+		{
+			st->rush[i] = id;
+		}
+		angle += deltaAngle;
+		distance += deltaDistance;
+	}
+	if (st != NULL)
+	{
+		st->kind = 2;
+		st->wait = (float)count; // (how many there are)
+	}
+}
+
+// "Double Domino" (sample_contact.cpp:761-812): fifteen dominoes, the first one tipped by an impulse at creation
+static void sceneDoubleDomino(s2WorldId w)
+{
+	makeStaticBox(w, 0.0f, -1.0f, 100.0f, 1.0f, 0.0f);
+	s2Polygon box = s2MakeBox(0.125f, 0.5f);
+	s2ShapeDef sd = s2_defaultShapeDef;
+	sd.friction = 0.6f;
+	const int count = 15;
+	float x = -0.5f * (float)count;
+	for (int i = 0; i < count; ++i)
+	{
+		s2BodyId id = makeDynamic(w, x, 0.5f, 0.0f);
+		s2CreatePolygonShape(id, &sd, &box);
+		if (i == 0)
+		{
+			s2Body_ApplyLinearImpulse(id, (s2Vec2){0.2f, 0.0f}, (s2Vec2){x, 1.0f});
+		}
+		x += 1.0f;
+	}
+}
+
+// "Confined" (sample_contact.cpp:814-886): 625 weightless circles of radius 0.5 on a lattice of pitch 0.72 inside a box of four
+// static capsules -- every circle overlaps its neighbours at the start, nothing can get out
+static void sceneConfined(s2WorldId w, int gridCount)
+{
+	s2BodyId ground = s2CreateBody(w, &s2_defaultBodyDef);
+	const float walls[4][4] = {{-10.5f, 0.0f, 10.5f, 0.0f}, {-10.5f, 0.0f, -10.5f, 20.5f}, {10.5f, 0.0f, 10.5f, 20.5f}, {-10.5f, 20.5f, 10.5f, 20.5f}};
+	for (int i = 0; i < 4; ++i)
+	{
+		s2Capsule capsule = {{walls[i][0], walls[i][1]}, {walls[i][2], walls[i][3]}, 0.5f};
+		s2CreateCapsuleShape(ground, &s2_defaultShapeDef, &capsule);
+	}
+	s2BodyDef bd = s2_defaultBodyDef;
+	bd.type = s2_dynamicBody;
+	bd.gravityScale = 0.0f;
+	s2Circle circle = {{0.0f, 0.0f}, 0.5f};
+	for (int column = 0; column < gridCount; ++column)
+	{
+		for (int row = 0; row < gridCount; ++row)
+		{
+			bd.position = (s2Vec2){-8.75f + (float)column * 18.0f / (float)gridCount, 1.5f + (float)row * 18.0f / (float)gridCount};
+			s2CreateCircleShape(s2CreateBody(w, &bd), &s2_defaultShapeDef, &circle);
+		}
+	}
+}
+
+// "Circle Stack" (sample_contact.cpp:971-1010): ten circles of radius 1 dropped in a column, 3 m apart
+static void sceneCircleStack(s2WorldId w, int count)
+{
+	s2ShapeDef sd = s2_defaultShapeDef;
+	makeGroundSegment(w, 0.0f, 0.0f, 40.0f, &sd);
+	s2Circle circle = {{0.0f, 0.0f}, 1.0f};
+	for (int i = 0; i < count; ++i)
+	{
+		s2CreateCircleShape(makeDynamic(w, 0.0f, 4.0f + 3.0f * (float)i, 0.0f), &sd, &circle);
+	}
+}
+
+// the ragdoll of spawnHuman with its ids kept (samples/collection/human.cpp:24-347), so that it can be taken out of the world again
+static void spawnHumanKept(s2WorldId w, float px, float py, float scale, int groupIndex, HumanIds* out)
+{
+	s2ShapeDef sd = s2_defaultShapeDef;
+	sd.friction = 0.4f;
+	sd.filter.groupIndex = -groupIndex;
+	s2ShapeDef foot = sd;
+	foot.friction = 0.1f;
+	const float s = scale, maxTorque = 0.025f * s;
+	for (int i = 0; i < HUMAN_BONES; ++i)
+	{
+		const BoneRow* r = s_human + i;
+		out->bones[i] = makeDynamic(w, px + 0.0f, py + r->bodyY * s, 0.0f);
+		out->joints[i] = s2_nullJointId;
+		for (int c = 0; c < 2; ++c)
+		{
+			if (r->cap[c][4] > 0.0f)
+			{
+				s2Capsule cap = {{r->cap[c][0] * s, r->cap[c][1] * s}, {r->cap[c][2] * s, r->cap[c][3] * s}, r->cap[c][4] * s};
+				s2CreateCapsuleShape(out->bones[i], (c == 1 && r->footSecond) ? &foot : &sd, &cap);
+			}
+		}
+		if (r->parent >= 0)
+		{
+			s2Vec2 pivot = {px + 0.0f, py + r->pivotY * s};
+			s2RevoluteJointDef jd = s2DefaultRevoluteJointDef();
+			jd.bodyIdA = out->bones[r->parent];
+			jd.bodyIdB = out->bones[i];
+			jd.localAnchorA = s2Body_GetLocalPoint(jd.bodyIdA, pivot);
+			jd.localAnchorB = s2Body_GetLocalPoint(jd.bodyIdB, pivot);
+			jd.enableLimit = true;
+			jd.lowerAngle = r->lower * s2_pi;
+			jd.upperAngle = r->upper * s2_pi;
+			jd.enableMotor = true;
+			jd.maxMotorTorque = r->torque * maxTorque;
+			jd.drawSize = 0.025f;
+			out->joints[i] = s2CreateRevoluteJoint(w, &jd);
+		}
+	}
+	out->spawned = 1;
+}
+
+// Ragdoll Stress's CreateElement (sample_joints.cpp:293-318): the first free slot gets a ragdoll of scale 2, left and right in turn
+static void stressCreateElement(s2WorldId w, SceneState* st)
+{
+	for (int i = 0; i < STRESS_HUMANS; ++i)
+	{
+		if (!st->humans[i].spawned)
+		{
+			spawnHumanKept(w, st->side, 28.0f, 2.0f, i + 1, st->humans + i);
+			st->side = -st->side;
+			return;
+		}
+	}
+}
+
+// "Ragdoll Stress" (sample_joints.cpp:207-362): a funnel of twenty static capsules with three motorised paddles in it; a ragdoll is
+// dropped in every half second and taken out of the world when it has fallen through (s2scene_post_step): bodies, shapes and
+// joints created and destroyed while the world runs
+static void sceneRagdollStress(s2WorldId w)
+{
+	SceneState* st = stateOf(w, 1);
+	s2BodyId ground = s2CreateBody(w, &s2_defaultBodyDef);
+	const s2Vec2 points[20] = {
+		{-16.8672504f, 31.088623f},	   {16.8672485f, 31.088623f},	 {16.8672485f, 17.1978741f}, {8.26824951f, 11.906374f},
+		{16.8672485f, 11.906374f},	   {16.8672485f, -0.661376953f}, {8.26824951f, -5.953125f},	 {16.8672485f, -5.953125f},
+		{16.8672485f, -13.229126f},	   {3.63799858f, -23.151123f},	 {3.63799858f, -31.088623f}, {-3.63800049f, -31.088623f},
+		{-3.63800049f, -23.151123f},   {-16.8672504f, -13.229126f},	 {-16.8672504f, -5.953125f}, {-8.26825142f, -5.953125f},
+		{-16.8672504f, -0.661376953f}, {-16.8672504f, 11.906374f},	 {-8.26825142f, 11.906374f}, {-16.8672504f, 17.1978741f},
+	};
+	s2ShapeDef sd = s2_defaultShapeDef;
+	sd.friction = 0.2f;
+	for (int i = 0; i < 20; ++i)
+	{
+		s2Capsule capsule = {points[i], points[(i + 1) % 20], 0.5f};
+		s2CreateCapsuleShape(ground, &sd, &capsule);
+	}
+	float sign = 1.0f, y = 14.0f;
+	for (int i = 0; i < 3; ++i)
+	{
+		s2BodyId id = makeDynamic(w, 0.0f, y, 0.0f);
+		s2Polygon box = s2MakeBox(6.0f, 0.5f);
+		s2ShapeDef pd = s2_defaultShapeDef;
+		pd.friction = 0.1f;
+		pd.restitution = 1.0f;
+		pd.density = 1.0f;
+		s2CreatePolygonShape(id, &pd, &box);
+		s2RevoluteJointDef jd = s2DefaultRevoluteJointDef();
+		jd.bodyIdA = ground;
+		jd.bodyIdB = id;
+		jd.localAnchorA = (s2Vec2){0.0f, y};
+		jd.localAnchorB = s2Vec2_zero;
+		jd.maxMotorTorque = 200.0f;
+		jd.motorSpeed = 5.0f * sign;
+		jd.enableMotor = true;
+		jd.drawSize = 0.2f;
+		s2CreateRevoluteJoint(w, &jd);
+		y -= 14.0f;
+		sign = -sign;
+	}
+	if (st != NULL)
+	{
+		st->kind = 3;
+		st->wait = 0.5f;
+		st->side = -15.0f;
+		stressCreateElement(w, st);
+	}
+}
+
+// "Stretched Chain" (sample_joints.cpp:529-600): forty bodies created 2 m apart and jointed with anchors 1 m apart -- every joint
+// starts a metre open, the whole error is the solver's to remove
+static void sceneStretchedChain(s2WorldId w, int count)
+{
+	s2BodyId ground = s2CreateBody(w, &s2_defaultBodyDef);
+	const float length = 1.0f, base = length * (float)count;
+	s2ShapeDef sd = s2_defaultShapeDef;
+	sd.filter.maskBits = 0;
+	s2Circle circle = {{0.0f, 0.0f}, 0.2f};
+	s2RevoluteJointDef jd = s2DefaultRevoluteJointDef();
+	jd.drawSize = 0.2f;
+	jd.bodyIdA = ground;
+	jd.localAnchorA.y = base - 0.5f * length;
+	jd.localAnchorB.y = 0.5f * length;
+	float y = base - 2.0f * length;
+	for (int i = 0; i < count; ++i)
+	{
+		s2BodyId id = makeDynamic(w, 0.0f, y, 0.0f);
+		s2CreateCircleShape(id, &sd, &circle);
+		jd.bodyIdB = id;
+		s2CreateRevoluteJoint(w, &jd);
+		jd.bodyIdA = id;
+		jd.localAnchorA.y = -0.5f * length;
+		y -= 2.0f * length;
+	}
+}
+
+// The part of a sample's Step override that runs BEFORE Sample::Step (samples/sample.cpp:126-137).  stepIndex: steps taken so far.
+S2SCENE_API void s2scene_pre_step(s2WorldId w, int stepIndex, float timeStep)
+{
+	SceneState* st = stateOf(w, 0);
+	if (st == NULL)
+	{
+		return;
+	}
+	if (st->kind == 1 && stepIndex == 120 && st->top.index != s2_nullBodyId.index)
+	{
+		s2DestroyBody(st->top); // sample_contact.cpp:101-110
+		st->top = s2_nullBodyId;
+	}
+	else if (st->kind == 2 && timeStep > 0.0f)
+	{
+		const float force = 1000.0f; // sample_contact.cpp:632-650
+		const int count = (int)st->wait;
+		for (int i = 0; i < count; ++i)
+		{
+			s2Vec2 p = s2Body_GetPosition(st->rush[i]);
+			float distance = s2Length(p);
+			if (distance < 0.1f)
+			{
+				continue;
+			}
+			float scale = force / distance;
+			s2Body_ApplyForceToCenter(st->rush[i], (s2Vec2){-scale * p.x, -scale * p.y});
+		}
+	}
+}
+
+// ... and the part that runs AFTER it: Ragdoll Stress takes out the ragdolls that fell through and drops the next one
+// (sample_joints.cpp:320-349)
+S2SCENE_API void s2scene_post_step(s2WorldId w, float hertz)
+{
+	SceneState* st = stateOf(w, 0);
+	if (st == NULL || st->kind != 3)
+	{
+		return;
+	}
+	for (int i = 0; i < STRESS_HUMANS; ++i)
+	{
+		HumanIds* h = st->humans + i;
+		if (!h->spawned)
+		{
+			continue;
+		}
+		s2Vec2 p = s2Body_GetPosition(h->bones[1]); // Bone::e_torso
+		if (p.y < -25.0f)
+		{
+			for (int b = 0; b < HUMAN_BONES; ++b) // Human::Despawn, samples/collection/human.cpp:350-377
+			{
+				if (h->joints[b].index != s2_nullJointId.index)
+				{
+					s2DestroyJoint(h->joints[b]);
+					h->joints[b] = s2_nullJointId;
+				}
+			}
+			for (int b = 0; b < HUMAN_BONES; ++b)
+			{
+				s2DestroyBody(h->bones[b]);
+				h->bones[b] = s2_nullBodyId;
+			}
+			h->spawned = 0;
+		}
+	}
+	if (hertz > 0.0f)
+	{
+		st->wait -= 1.0f / hertz;
+		if (st->wait < 0.0f)
+		{
+			stressCreateElement(w, st);
+			st->wait += 0.5f;
+		}
+	}
+}
+
 // Returns the new world (null id on unknown scene / no free world slot).
 S2SCENE_API s2WorldId s2scene_create(const char* name, int solverType, int p0, int p1)
 {
@@ -899,6 +1313,7 @@ S2SCENE_API s2WorldId s2scene_create(const char* name, int solverType, int p0, i
 	{
 		return w;
 	}
+	(void)stateOf(w, 1); // (whatever sample lived in this world slot before has left)
 
 	if (strcmp(name, "pyramid") == 0)
 	{
@@ -980,6 +1395,42 @@ S2SCENE_API s2WorldId s2scene_create(const char* name, int solverType, int p0, i
 	else if (strcmp(name, "bridge") == 0)
 	{
 		sceneBridge(w, p0 > 0 ? p0 : 160);
+	}
+	else if (strcmp(name, "single_box") == 0)
+	{
+		sceneSingleBox(w);
+	}
+	else if (strcmp(name, "warm_start_energy") == 0)
+	{
+		sceneWarmStartEnergy(w);
+	}
+	else if (strcmp(name, "friction_ramp") == 0)
+	{
+		sceneFrictionRamp(w);
+	}
+	else if (strcmp(name, "rush") == 0)
+	{
+		sceneRush(w, p0 > 0 ? p0 : RUSH_COUNT);
+	}
+	else if (strcmp(name, "double_domino") == 0)
+	{
+		sceneDoubleDomino(w);
+	}
+	else if (strcmp(name, "confined") == 0)
+	{
+		sceneConfined(w, p0 > 0 ? p0 : 25);
+	}
+	else if (strcmp(name, "circle_stack") == 0)
+	{
+		sceneCircleStack(w, p0 > 0 ? p0 : 10);
+	}
+	else if (strcmp(name, "ragdoll_stress") == 0)
+	{
+		sceneRagdollStress(w);
+	}
+	else if (strcmp(name, "stretched_chain") == 0)
+	{
+		sceneStretchedChain(w, p0 > 0 ? p0 : 40);
 	}
 	else
 	{

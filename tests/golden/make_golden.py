@@ -42,6 +42,17 @@ CASES = [
     ("ragdoll", 0, 0, (75,)),
     ("ball_and_chain", 40, 0, (50,)),
     ("bridge", 40, 0, (30,)),
+    # (round 6) the rest of the reference's samples: at rest, right after the top circle is destroyed, sliding on mixed frictions, under
+    # applied forces, mid-topple, packed and overlapping, stacking up, with three ragdolls in the funnel, with joints still open
+    ("single_box", 0, 0, (30,)),
+    ("warm_start_energy", 0, 0, (121,)),
+    ("friction_ramp", 0, 0, (90,)),
+    ("rush", 0, 0, (40,)),
+    ("double_domino", 0, 0, (60,)),
+    ("confined", 0, 0, (10,)),
+    ("circle_stack", 0, 0, (100,)),
+    ("ragdoll_stress", 0, 0, (95,)),
+    ("stretched_chain", 0, 0, (20,)),
 ]
 ONLY_MISSING = bool(os.environ.get("S2_GOLDEN_ONLY_MISSING"))
 

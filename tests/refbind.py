@@ -40,6 +40,10 @@ def lib():
         L.s2scene_name.argtypes = [ctypes.c_int]
         L.s2ref_step.argtypes = [WorldId, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.s2ref_step.restype = None
+        L.s2scene_pre_step.argtypes = [WorldId, ctypes.c_int, ctypes.c_float]
+        L.s2scene_pre_step.restype = None
+        L.s2scene_post_step.argtypes = [WorldId, ctypes.c_float]
+        L.s2scene_post_step.restype = None
         L.s2ref_destroy_world.argtypes = [WorldId]
         L.s2ref_destroy_world.restype = None
         L.s2ref_set_mode.argtypes = [ctypes.c_int]
@@ -82,6 +86,7 @@ class RefWorld:
         self.id = L.s2scene_create(scene.encode(), sid, int(p0), int(p1))
         if self.id.index < 0:
             raise RuntimeError("s2scene_create(%s) failed" % scene)
+        self.steps = 0
 
     def close(self):
         if self.id is not None:
@@ -95,7 +100,13 @@ class RefWorld:
         self.close()
 
     def step(self, dt=1.0 / 60.0, vel_iters=4, pos_iters=2, warm_start=True):
-        lib().s2ref_step(self.id, ctypes.c_float(dt), vel_iters, pos_iters, 1 if warm_start else 0)
+        """One frame of the sample as the reference's GUI runs it: what the sample's Step override does before stepping the world
+        (Warm Start Energy destroys its top body, Rush applies its forces), s2World_Step, what it does after (Ragdoll Stress)."""
+        L = lib()
+        L.s2scene_pre_step(self.id, self.steps, ctypes.c_float(dt))
+        L.s2ref_step(self.id, ctypes.c_float(dt), vel_iters, pos_iters, 1 if warm_start else 0)
+        self.steps += 1
+        L.s2scene_post_step(self.id, ctypes.c_float(1.0 / dt if dt > 0 else 0.0))
 
     def sizes(self):
         nb, nc, nj = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()

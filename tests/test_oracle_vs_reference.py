@@ -39,8 +39,20 @@ SCENES = [
     ("ragdoll", 0, 0, 100),
     ("ball_and_chain", 40, 0, 60),
     ("bridge", 40, 0, 50),
+    # (round 6) the rest of the reference's 26 samples: a lone box, warm-start energy released when the heavy top circle is destroyed at
+    # step 120, contacts that mix two shape frictions, 400 circles under applied forces, a toppling domino row, 625 overlapping circles
+    # in a closed box, a falling column of circles, ragdolls created and destroyed while the world runs, joints that start a metre open
+    ("single_box", 0, 0, 60),
+    ("warm_start_energy", 0, 0, 140),
+    ("friction_ramp", 0, 0, 120),
+    ("rush", 0, 0, 60),
+    ("double_domino", 0, 0, 90),
+    ("confined", 0, 0, 30),
+    ("circle_stack", 0, 0, 120),
+    ("ragdoll_stress", 0, 0, 100),
+    ("stretched_chain", 0, 0, 60),
 ]
-JOINT_ONLY = ("joint_grid", "far_chain", "ball_and_chain", "bridge")
+JOINT_ONLY = ("joint_grid", "far_chain", "ball_and_chain", "bridge", "stretched_chain")
 
 
 @pytest.mark.parametrize("solver", wire.SOLVER_NAMES)
@@ -57,6 +69,23 @@ def test_bit_exact(solver, scene, p0, p1, steps):
             active = max(active, int((pre[1]["pointCount"] > 0).sum()))
         if scene not in JOINT_ONLY:
             assert active > 0, "scene produced no contact constraints"
+
+
+@pytest.mark.parametrize("solver", ["TGS_Soft", "PGS_NGS_Block", "PGS_Soft"])
+def test_ragdolls_created_and_destroyed_while_the_world_runs(solver):
+    """Ragdoll Stress long enough for the first ragdolls to fall through the funnel and be taken out of the world (steps 456, 396, 367
+    under these three solvers): body, shape, joint and contact slots freed and reused mid-run."""
+    vel, pos = common.DEFAULT_ITERS[solver]
+    with refbind.RefWorld("ragdoll_stress", solver, 0, 0) as world:
+        live = []
+        for step in range(520):
+            params, pre, post = world.step_captured(1.0 / 60.0, vel, pos, True)
+            live.append(int((pre[0]["type"] >= 0).sum()))
+            if step % 4 == 0 or step > 400:
+                got = common.copy3(pre)
+                oraclebind.solve(params, *got)
+                common.compare_exact(got, post, "ragdoll_stress/%s step %d" % (solver, step))
+        assert max(live) > live[0] and any(b < a for a, b in zip(live, live[1:])), "no ragdoll was created, or none destroyed"
 
 
 @pytest.mark.parametrize("solver", wire.SOLVER_NAMES)

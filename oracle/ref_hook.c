@@ -100,9 +100,18 @@ static void fillParams(const s2World* world, const s2StepContext* context, int s
 
 static void narrowPhaseDone(const s2World* world);
 
+// a world the tests keep on the reference's own code while the binding drives the others (s2ref_plain_world): the checker next to
+// the thing checked, stepped in turn
+static int g_plainWorld = -1;
+
 static void hookSolve(s2World* world, s2StepContext* context, int solverType, s2SolveFcn* real)
 {
 	narrowPhaseDone(world);
+	if (world->index == g_plainWorld && g_mode == 2)
+	{
+		real(world, context);
+		return;
+	}
 	if (g_mode == 1)
 	{
 		fillParams(world, context, solverType);
@@ -513,6 +522,12 @@ S2REF_API int s2ref_use_amd(const char* path, int device)
 	return 0;
 }
 
+// index of the world that stays on the reference's own s2World_Step and solvers whatever the switches above say (-1: none)
+S2REF_API void s2ref_plain_world(int index)
+{
+	g_plainWorld = index;
+}
+
 // As s2ref_use_amd, plus stage 3 and stage 4: the whole of s2World_Step but its tree and pool bookkeeping on the GPU.
 S2REF_API int s2ref_use_amd_world(const char* path, int device)
 {
@@ -533,7 +548,7 @@ void __real_s2UpdateBroadPhasePairs(s2World* world);
 void s2ref_World_Step_reference(s2WorldId worldId, float timeStep, int velIters, int posIters, bool warmStart);
 S2REF_API void s2World_Step(s2WorldId worldId, float timeStep, int velIters, int posIters, bool warmStart)
 {
-	if (!g_wholeStep)
+	if (!g_wholeStep || worldId.index == g_plainWorld)
 	{
 		s2ref_World_Step_reference(worldId, timeStep, velIters, posIters, warmStart);
 		return;
@@ -558,6 +573,14 @@ void __wrap_s2DestroyBody(s2BodyId bodyId)
 {
 	(void)s2amdBinding_Sync(s2GetWorldFromIndex(bodyId.world));
 	__real_s2DestroyBody(bodyId);
+}
+// (an applied force is an edit of the host's body the resident copy has to follow: the product drop-in wraps every setter,
+// shim/s2_amd_dropin.c: S2_DROPIN_EDIT; here the one the Rush sample uses)
+void __real_s2Body_ApplyForceToCenter(s2BodyId bodyId, s2Vec2 force);
+void __wrap_s2Body_ApplyForceToCenter(s2BodyId bodyId, s2Vec2 force)
+{
+	s2amdBinding_Invalidate(s2GetWorldFromIndex(bodyId.world));
+	__real_s2Body_ApplyForceToCenter(bodyId, force);
 }
 #define S2REF_SHAPE_WRAP(NAME, GEOM)                                                                                             \
 	s2ShapeId __real_##NAME(s2BodyId bodyId, const s2ShapeDef* def, const GEOM* geometry);                                       \

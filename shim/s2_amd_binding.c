@@ -594,10 +594,33 @@ static WorldBinding* bindingOf(const s2World* world)
 		return NULL;
 	}
 	WorldBinding* b = s_bindings + world->index;
-	if (b->solver == NULL && (s_api.create(s_api.device, &b->solver) != 0 || b->solver == NULL))
+	if (b->solver == NULL)
 	{
-		b->solver = NULL;
-		return NULL;
+		if (s_api.create(s_api.device, &b->solver) != 0 || b->solver == NULL)
+		{
+			b->solver = NULL;
+			return NULL;
+		}
+		// S2AMD_OPTIONS="key=value,key=value": s2amd_set_option for every solver the binding makes (include/solver2d_amd.h lists the keys)
+		const char* options = getenv("S2AMD_OPTIONS");
+		if (options != NULL)
+		{
+			char buffer[512];
+			strncpy(buffer, options, sizeof(buffer) - 1);
+			buffer[sizeof(buffer) - 1] = 0;
+			for (char* item = strtok(buffer, ","); item != NULL; item = strtok(NULL, ","))
+			{
+				char* eq = strchr(item, '=');
+				if (eq != NULL)
+				{
+					*eq = 0;
+					if (s_api.setOption(b->solver, item, (int32_t)atoi(eq + 1)) != 0)
+					{
+						fprintf(stderr, "s2amd binding: S2AMD_OPTIONS: option \"%s\" refused: %s\n", item, s_api.lastError());
+					}
+				}
+			}
+		}
 	}
 	return b;
 }

@@ -113,6 +113,22 @@ def test_a_program_on_the_public_api_runs_on_the_gpu_through_the_product_library
     assert solver_only == step_host_pairs == step_dev_pairs, out
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,steps,settle", [("rush", 40, 20), ("ragdoll_stress", 160, 0), ("warm_start_energy", 30, 100)])
+def test_samples_that_edit_the_world_every_frame_through_the_product_library(built, scene, steps, settle):
+    """The three reference samples whose Step override touches the world (solver2d_amd/scenes/scenes.c: s2scene_pre_step / _post_step):
+    Rush applies a force to each of its 400 bodies before every step, Ragdoll Stress creates a ragdoll (11 bodies, 14 shapes, 10 joints)
+    every 30 steps, Warm Start Energy destroys a body at step 120.  Under s2Solve_Jacobi, whose result does not depend on the sweep order,
+    every route -- the reference's own CPU solver included -- must end in the same bits."""
+    if not os.path.exists(DEMO):
+        pytest.skip("demo binary not built")
+    args = [0, steps, scene, 0, 4, 2, settle]
+    reference, _ = _digest({"S2AMD_DROPIN": "off"}, args)
+    for env in ({"S2AMD_DROPIN": "solver"}, {"S2AMD_DROPIN": "step", "S2AMD_DEVICE_PAIRS": "0"}, {"S2AMD_DROPIN": "step", "S2AMD_DEVICE_PAIRS": "1"}):
+        digest, out = _digest(env, args)
+        assert digest == reference, (env, out)
+
+
 def _edited(env_extra, args):
     digest, out = _digest(dict(env_extra, S2DEMO_EDITS="1"), args)
     m = re.search(r"edited body at \(([-\d.]+), ([-\d.]+)\) angle ([-\d.]+)", out)

@@ -205,3 +205,44 @@ def test_binding_host_replay_agrees_with_the_device_trees(scene, p0, solver_name
     queries, order_differs, tree_checks, tree_differs = list(out)
     assert tree_checks > 0 or scene == "pyramid", "no query of this loop found a pair: nothing was compared"
     assert order_differs == 0 and tree_differs == 0, "%d of %d queries ordered differently, %d of %d trees differ" % (order_differs, queries, tree_differs, tree_checks)
+
+
+@pytest.mark.parametrize("scene,p0,steps", [("tumbler", 150, 150), ("shapes_zoo", 40, 200), ("circle_pile", 20, 120), ("confined", 12, 60), ("rush", 150, 80),
+                                            ("pyramid", 20, 60), ("card_house", 0, 60), ("warm_start_energy", 0, 140), ("friction_ramp", 0, 150)])
+def test_device_ranked_pool_slots_equal_the_references_own_creation_sequence(scene, p0, steps, monkeypatch):
+    """The reference ALONE (its trees, its s2UpdateBroadPhasePairs, its s2CreateContact sequence, its CPU solver) beside the product
+    binding with everything on the device (pairs found, ranked by the device's trees, created in that order).  Under s2Solve_Jacobi the
+    contact pass does not depend on the sweep order (every body adds its constraints' deltas in pool order), so on worlds whose joints
+    do not share bodies the two are the same computation: after EVERY step the contact pools hold the same pairs in the same slots,
+    and the bodies the same bits.  (Option `incremental` 0: a created contact placed into the existing structure goes to the END of
+    its bodies' lists -- the sum order the device reports and the oracle follows, not the pool's.)"""
+    monkeypatch.setenv("S2AMD_OPTIONS", "incremental=0")
+    L = refbind.lib()
+    L.s2ref_use_amd_world.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    L.s2ref_use_amd_world.restype = ctypes.c_int
+    with refbind.RefWorld(scene, "Jacobi", p0, 0) as ref, refbind.RefWorld(scene, "Jacobi", p0, 0) as dev:
+        created = 0
+        assert L.s2ref_use_amd_world(hip.LIB_PATH.encode(), 0) == 0
+        L.s2ref_world_device_pairs(1)
+        L.s2amdBinding_DeviceTrees(1, 0)
+        L.s2ref_plain_world(ref.id.index)  # (this one stays on the reference's own code)
+        try:
+            for step in range(steps):
+                ref.step(1.0 / 60.0, 4, 2, True)
+                dev.step(1.0 / 60.0, 4, 2, True)
+                assert L.s2ref_replace_error() == 0
+                if step % 5 == 4 or step < 3:
+                    pa_r, pb_r = ref.contact_pairs()
+                    pa_d, pb_d = dev.contact_pairs()
+                    assert np.array_equal(pa_r, pa_d) and np.array_equal(pb_r, pb_d), "step %d: %d slots differ" % (step, int((pa_r != pa_d).sum() + (pb_r != pb_d).sum()))
+                    created = max(created, int((pa_r >= 0).sum()))
+            br, cr, jr = ref.pack()
+            bd, cd, jd = dev.pack()
+        finally:
+            L.s2ref_plain_world(-1)
+            L.s2ref_world_device_pairs(0)
+            assert L.s2ref_use_amd_world(None, 0) == 0
+    assert created > 0
+    live = br["type"] >= 0
+    assert np.array_equal(br["position"][live].view(np.uint32), bd["position"][live].view(np.uint32)), "%s: the two worlds drifted apart" % scene
+    assert np.array_equal(br["rot"][live].view(np.uint32), bd["rot"][live].view(np.uint32))

@@ -13,6 +13,8 @@
 #include <time.h>
 
 s2WorldId s2scene_create(const char* name, int solverType, int p0, int p1);
+void s2scene_pre_step(s2WorldId w, int stepIndex, float timeStep);
+void s2scene_post_step(s2WorldId w, float hertz);
 void s2amdDropin_Timing(double out[6]);
 unsigned long long s2amdDropin_StateDigest(s2WorldId worldId);
 
@@ -33,9 +35,14 @@ int main(int argc, char** argv)
 	const int settle = argc > 7 ? atoi(argv[7]) : 45;
 	const char* route = getenv("S2AMD_DROPIN") ? getenv("S2AMD_DROPIN") : "step";
 	s2WorldId w = s2scene_create(scene, solver, base, 0);
-	for (int i = 0; i < settle; ++i)
+	/* (a frame of a sample = what its Step override does before the step -- Warm Start Energy destroys a body, Rush applies forces --,
+	 * the step, what it does after -- Ragdoll Stress creates and destroys ragdolls: solver2d_amd/scenes/scenes.c) */
+	int frame = 0;
+	for (int i = 0; i < settle; ++i, ++frame)
 	{
+		s2scene_pre_step(w, frame, 1.0f / 60.0f);
 		s2World_Step(w, 1.0f / 60.0f, vel, pos, true);
+		s2scene_post_step(w, 60.0f);
 	}
 	double phases[6];
 	s2amdDropin_Timing(phases);
@@ -64,7 +71,10 @@ int main(int argc, char** argv)
 			s2Polygon box = s2MakeSquare(0.4f);
 			s2CreatePolygonShape(extra, &sd, &box);
 		}
+		s2scene_pre_step(w, frame, 1.0f / 60.0f);
 		s2World_Step(w, 1.0f / 60.0f, vel, pos, true);
+		s2scene_post_step(w, 60.0f);
+		frame += 1;
 	}
 	const double ms = 1e3 * (now() - t0) / steps;
 	s2amdDropin_Timing(phases);

@@ -554,6 +554,23 @@ int s2amd_get_contact_order(s2amdSolver* s, int32_t* order, int32_t orderCapacit
 	const SweepSet& cs = s->contacts;
 	std::vector<int> active, offsets(1, 0);
 	active.reserve(cs.order.size());
+	// (some launch batches are sequential tails -- a hub body's constraints, or a group's tiny colours, swept one after the other by one
+	// wave: each of their constraints is a colour of its own in what is reported, so that a reported colour never holds two
+	// constraints on one writable body)
+	std::vector<uint8_t> sequential(cs.order.size(), 0);
+	for (const HostGroupTable* t : {&s->hGroups, &s->hResident, &s->hStripA, &s->hStripB, &s->hContactTail})
+	{
+		for (const int4& batch : t->cBatches)
+		{
+			if (batch.z == 1)
+			{
+				for (int k2 = std::max(batch.x, 0); k2 < batch.y && k2 < (int)sequential.size(); ++k2)
+				{
+					sequential[(size_t)k2] = 1;
+				}
+			}
+		}
+	}
 	size_t k = 0;
 	for (size_t c = 0; c + 1 < cs.colorOffsets.size(); ++c)
 	{
@@ -562,6 +579,10 @@ int s2amd_get_contact_order(s2amdSolver* s, int32_t* order, int32_t orderCapacit
 			if (cs.order[k] >= 0 && s->hContactPoints[(size_t)cs.order[k]] > 0) // (-1: a free position of the slack layout)
 			{
 				active.push_back(cs.order[k]);
+				if (sequential[k])
+				{
+					offsets.push_back((int)active.size());
+				}
 			}
 		}
 		if ((int)active.size() > offsets.back())

@@ -519,7 +519,7 @@ def fast_leg(device_index, base, vel, pos, steps, warmup, graph, opts):
                                             "velocity_error_over_scale_per_sweep": dvel / vscale / (sweeps + vel)}}
 
 
-def sharded_abi_leg(device_index, islands, base, vel, pos, steps, warmup, shard_counts=(1, 2, 4)):
+def sharded_abi_leg(device_index, islands, base, vel, pos, steps, warmup, shard_counts=(1, 2, 4), device_lists=None):
     """BASELINE.json configs[4] through the C-ABI's own sharding (include/solver2d_amd.h: s2amd_sharded_*; csrc/sharded.hip): ONE
     process, the world's islands found on the device and bin-packed onto k shards -- here k LOGICAL shards on this one GPU, so the
     numbers say what the partition and the per-step exchange (one kernel per shard storing its rows into every shard's copy of the
@@ -531,8 +531,9 @@ def sharded_abi_leg(device_index, islands, base, vel, pos, steps, warmup, shard_
     sweeps = wire.solve_sweeps_per_step("TGS_Soft", vel, pos)
     C = int((world[1]["pointCount"] > 0).sum())
     rows = []
-    for k in shard_counts:
-        with hip.ShardedSolver([device_index] * k) as sh:
+    for devices_k in (device_lists if device_lists is not None else [[device_index] * k for k in shard_counts]):
+        k = len(devices_k)
+        with hip.ShardedSolver(devices_k) as sh:
             t0 = time.perf_counter()
             sh.upload(*world)
             upload_ms = 1e3 * (time.perf_counter() - t0)
@@ -551,15 +552,50 @@ def sharded_abi_leg(device_index, islands, base, vel, pos, steps, warmup, shard_
             ms_waited = 1e3 * (time.perf_counter() - t0) / steps
             owner, n_islands, _ = sh.partition()
             per_shard = np.bincount(owner[owner >= 0], minlength=k).tolist()
-        rows.append({"shards": k, "ms_per_step": ms, "ms_per_step_waiting_after_each": ms_waited, "value": C * sweeps / (ms * 1e-3),
+        rows.append({"shards": k, "devices": list(devices_k), "ms_per_step": ms, "ms_per_step_waiting_after_each": ms_waited, "value": C * sweeps / (ms * 1e-3),
                      "upload_and_partition_ms": upload_ms, "islands": n_islands, "bodies_per_shard": per_shard,
                      "exchange": ("stores", "rccl", "peer copies")[form], "stream_ops_per_step": ops,
                      "exchange_bytes_per_step": int(sum(per_shard) * 32 * max(k - 1, 0))})
+    if device_lists is not None:
+        return {"workload": "%d independent base-%d pyramids (%d constraints), s2_solverTGS_Soft %d/%d; ONE process, one shard per GPU behind the C-ABI "
+                            "(s2amd_sharded_*): islands found on device 0, bin-packed, the per-step exchange of the owned body records over RCCL "
+                            "(ncclAllGather, single process) where it loads, peer copies otherwise" % (islands, base, C, vel, pos),
+                "unit": "constraint-iters/s", "steps": steps, "scaling": "strong", "by_device_count": rows}
     return {"workload": "%d independent base-%d pyramids (%d constraints), s2_solverTGS_Soft %d/%d; islands found on the device (s2amd_find_islands), "
                         "bin-packed onto k logical shards of ONE GPU by s2amd_sharded_upload; one exchange of the owned body records per step" % (
                             islands, base, C, vel, pos),
             "unit": "constraint-iters/s", "steps": steps, "by_shard_count": rows,
             "note": "logical shards of one GPU: what the partition and the exchange cost; not a scaling measurement"}
+
+
+def sharded_abi_multi_gpu(world, islands, base, vel, pos):
+    """configs[4] through the C-ABI's own sharding on 1, 2, ... `world` GPUs of this node, in a process of its own with a hard time limit
+    (rank 0 of an N-rank job runs it after everything else: a single process that drives N devices, RCCL's single-process communicators
+    included -- if it cannot run here, the line says why and the job's numbers stand)."""
+    import subprocess
+    lists = []
+    k = 1
+    while k <= world:
+        lists.append(",".join(str(d) for d in range(k)))
+        k *= 2
+    cmd = [sys.executable, os.path.abspath(__file__), "--sharded-abi-devices", ";".join(lists), "--islands", str(islands), "--island-base", str(base),
+           "--vel-iters", str(vel), "--pos-iters", str(pos)]
+    env = dict(os.environ)
+    for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE"):
+        env.pop(key, None)
+    try:
+        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    except subprocess.TimeoutExpired:
+        return {"skipped": "no result within 240 s"}
+    except Exception as e:  # pragma: no cover
+        return {"skipped": repr(e)}
+    for line in reversed(out.stdout.decode(errors="replace").splitlines()):
+        if line.startswith("{"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                break
+    return {"skipped": "exit code %d: %s" % (out.returncode, out.stderr.decode(errors="replace")[-400:])}
 
 
 def churn_leg(device_index, base):
@@ -597,6 +633,8 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=(2, 5),
                     help="2 = BASELINE's headline (LargePyramid base-200, one island per GPU); 5 = configs[4]: 512 x base-40, islands sharded over "
                          "the GPUs, as the line itself")
+    ap.add_argument("--sharded-abi-devices", default=None, metavar="0;0,1;0,1,2,3",
+                    help="only this: configs[4] through s2amd_sharded_* on each of the given device lists, one process (see sharded_abi_multi_gpu)")
     ap.add_argument("--islands", type=int, default=512)
     ap.add_argument("--weak", action="store_true", help="--config 5: --islands pyramids PER GPU (weak scaling) instead of in all (strong scaling)")
     ap.add_argument("--island-base", type=int, default=40)
@@ -604,6 +642,15 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="only the headline line (no whole_step / configs / island_sharded objects)")
     ap.add_argument("--restore", action="store_true", help="copy the step-0 bodies back before every step (round 3's headline loop) instead of consecutive steps")
     args = ap.parse_args()
+
+    if args.sharded_abi_devices:
+        lists = [[int(d) for d in part.split(",")] for part in args.sharded_abi_devices.split(";") if part]
+        have = hip.load().s2amd_device_count()
+        if any(d >= have for part in lists for d in part):
+            print(json.dumps({"skipped": "this process sees %d device(s)" % have}))
+            return
+        print(json.dumps(sharded_abi_leg(0, args.islands, args.island_base, args.vel_iters, args.pos_iters, 30, 5, device_lists=lists)))
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, RCCL) rather than
@@ -833,6 +880,9 @@ def main():
             out["island_sharded"] = sharded
             if weak is not None:
                 out["island_sharded_weak"] = weak
+            if world > 1:
+                # the same partition in ONE process behind the C-ABI, RCCL from the library (no PyTorch): measured on the node's GPUs
+                out["sharded_abi_multi_gpu"] = sharded_abi_multi_gpu(world, args.islands, args.island_base, args.vel_iters, args.pos_iters)
             if world == 1:
                 out["whole_step"] = whole_step_leg(ranks.device_index, args.base, args.vel_iters, args.pos_iters, 200, 240)
                 # SURVEY.md 8d's trajectory figure (settled world, stage 3 -> solve -> stage 4 every step): the honest whole-step number

@@ -586,177 +586,7 @@ __global__ __launch_bounds__(S2_BLOCK) void publishPairsKernel(unsigned int* cou
 	if (threadIdx.x == 0)
 	{
 		hostFound[0] = found;
-		hostFound[1] = count[2]; // (the order repair met more moved proxies than it holds: the caller runs the query again, sorted)
-		count[0] = 0u, count[1] = 0u, count[2] = 0u;
-	}
-}
-
-// The sweep order of the proxies from the last query's, in ONE launch: a fat box only changes when the refit re-inflates it, so the order
-// of everything that did not move stands, and the few that did (460 of 20,100 per step in the settled base-200 pyramid) are sorted among
-// themselves and merged in -- where the library sort took five launches and 42 us for 20k keys every step (r5).  Also what
-// residentShapeKeysKernel and gatherBoxesKernel made: the move flags per shape, the boxes and flags in sweep order.
-//   idx / keys   in: the last query's order (shape per position, its key then) -- sorted by (key, shape), every live shape once;
-//                out: this query's
-// One workgroup; more than S2_REPAIR_MAX moved proxies: nothing is written, flags[2] = 1 (the caller sorts instead).
-#define S2_REPAIR_THREADS 1024
-#define S2_REPAIR_MAX 1024
-__global__ __launch_bounds__(S2_REPAIR_THREADS) void repairOrderKernel(const s2amdShape* shapes, int ns, int n, int* idx, uint32_t* keys, int* tmpIdx, uint32_t* tmpKeys,
-																   int* before, float4* box, unsigned char* movedSorted, unsigned char* moved, unsigned int* flags)
-{
-	__shared__ unsigned long long sMoved[S2_REPAIR_MAX];
-	__shared__ int sScan[S2_REPAIR_THREADS / 64 + 1];
-	__shared__ int sCount;
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	if (tid == 0)
-	{
-		sCount = 0;
-	}
-	for (int i = tid; i < ns; i += S2_REPAIR_THREADS)
-	{
-		moved[i] = (shapes[i].type != S2AMD_SHAPE_FREE && shapes[i].enlarged != 0) ? 1 : 0;
-	}
-	for (int i = tid; i < S2_REPAIR_MAX; i += S2_REPAIR_THREADS)
-	{
-		sMoved[i] = ~0ull;
-	}
-	__syncthreads();
-	// the ones that stay, counted up to every position of the old order; the ones that moved, with their new keys
-	const int chunk = (n + S2_REPAIR_THREADS - 1) / S2_REPAIR_THREADS;
-	const int lo = min(tid * chunk, n), hi = min(lo + chunk, n);
-	int stay = 0;
-	for (int j = lo; j < hi; ++j)
-	{
-		const int sh = idx[j];
-		if (shapes[sh].enlarged != 0)
-		{
-			const int at = atomicAdd(&sCount, 1);
-			if (at < S2_REPAIR_MAX)
-			{
-				const uint32_t u = __float_as_uint(shapes[sh].fatAABB[0]);
-				const uint32_t key = (u & 0x80000000u) ? ~u : (u | 0x80000000u); // sortableFloat
-				sMoved[at] = ((unsigned long long)key << 32) | (unsigned long long)(unsigned int)sh;
-			}
-		}
-		else
-		{
-			stay += 1;
-		}
-	}
-	int x = stay;
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1)
-	{
-		const int y = __shfl_up(x, d, 64);
-		if (lane >= d)
-		{
-			x += y;
-		}
-	}
-	if (lane == 63)
-	{
-		sScan[wave] = x;
-	}
-	__syncthreads();
-	const int m = sCount;
-	if (m > S2_REPAIR_MAX)
-	{
-		if (tid == 0)
-		{
-			flags[2] = 1u;
-		}
-		return;
-	}
-	int base = 0;
-	for (int w = 0; w < wave; ++w)
-	{
-		base += sScan[w];
-	}
-	int run = base + x - stay;
-	for (int j = lo; j < hi; ++j)
-	{
-		before[j] = run;
-		run += shapes[idx[j]].enlarged != 0 ? 0 : 1;
-	}
-	if (tid == S2_REPAIR_THREADS - 1)
-	{
-		before[n] = run; // (every chunk is full or empty but the last: the last thread ends at n)
-	}
-	// the moved ones sorted by (key, shape): bitonic over the padded list
-	for (int k = 2; k <= S2_REPAIR_MAX; k <<= 1)
-	{
-		for (int j = k >> 1; j > 0; j >>= 1)
-		{
-			__syncthreads();
-			const int i = tid, partner = i ^ j;
-			if (partner > i)
-			{
-				const unsigned long long a = sMoved[i], b = sMoved[partner];
-				const bool up = (i & k) == 0;
-				if ((a > b) == up)
-				{
-					sMoved[i] = b, sMoved[partner] = a;
-				}
-			}
-		}
-	}
-	__syncthreads();
-	// merge: a place = the rank in one's own list + the number of the other list's entries below
-	for (int j = lo; j < hi; ++j)
-	{
-		const int sh = idx[j];
-		if (shapes[sh].enlarged != 0)
-		{
-			continue;
-		}
-		const unsigned long long mine = ((unsigned long long)keys[j] << 32) | (unsigned long long)(unsigned int)sh;
-		int a = 0, b = m;
-		while (a < b)
-		{
-			const int mid = (a + b) >> 1;
-			if (sMoved[mid] < mine)
-			{
-				a = mid + 1;
-			}
-			else
-			{
-				b = mid;
-			}
-		}
-		const int pos = before[j] + a;
-		tmpIdx[pos] = sh;
-		tmpKeys[pos] = keys[j];
-	}
-	for (int r = tid; r < m; r += S2_REPAIR_THREADS)
-	{
-		const unsigned long long mine = sMoved[r];
-		int a = 0, b = n;
-		while (a < b)
-		{
-			const int mid = (a + b) >> 1;
-			const unsigned long long there = ((unsigned long long)keys[mid] << 32) | (unsigned long long)(unsigned int)idx[mid];
-			if (there < mine)
-			{
-				a = mid + 1;
-			}
-			else
-			{
-				b = mid;
-			}
-		}
-		const int pos = r + before[a];
-		tmpIdx[pos] = (int)(mine & 0xffffffffull);
-		tmpKeys[pos] = (uint32_t)(mine >> 32);
-	}
-	__threadfence_block();
-	__syncthreads();
-	for (int j = tid; j < n; j += S2_REPAIR_THREADS)
-	{
-		const int sh = tmpIdx[j];
-		idx[j] = sh;
-		keys[j] = tmpKeys[j];
-		const float* f = shapes[sh].fatAABB;
-		box[j] = make_float4(f[0], f[1], f[2], f[3]);
-		movedSorted[j] = shapes[sh].enlarged != 0 ? 1 : 0;
+		count[0] = 0u, count[1] = 0u;
 	}
 }
 
@@ -829,7 +659,6 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 		BP_TRY(hipMalloc(scratch, total + total / 4));
 		*scratchBytes = total + total / 4;
 		cache->countAt = nullptr;
-		cache->orderValid = false; // (the last query's sweep order went with the old block)
 	}
 	char* p = (char*)*scratch;
 	size_t li = 0;
@@ -938,7 +767,6 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 		else
 		{
 			BP_TRY(hipMemcpyAsync(hostFound, dCount, 4, hipMemcpyDeviceToHost, st));
-			BP_TRY(hipMemcpyAsync(hostFound + 1, dCount + 2, 4, hipMemcpyDeviceToHost, st));
 			BP_TRY(hipMemcpyAsync(hostKeys, dResult, (size_t)std::min<size_t>(kFirst, outCap) * 8, hipMemcpyDeviceToHost, st));
 		}
 		return S2AMD_OK;
@@ -946,23 +774,6 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 	auto enqueue = [&]() -> int { // what a captured graph holds
 		const int rcSet = enqueueSet();
 		return rcSet != S2AMD_OK || ordered ? rcSet : enqueueTail();
-	};
-	// the sweep order repaired from the last query's (repairOrderKernel) instead of sorted afresh: when there is a last query's order
-	// in this scratch block and the caller expects few moved proxies (the count of the step before; the kernel itself refuses more than
-	// it holds, and the query is then run again, sorted).  Three launches: not worth a graph.
-	const bool repair = cache->orderValid && cache->movedHint >= 0 && cache->movedHint <= S2_REPAIR_MAX / 2 && n >= 2 && !warmOnly && mode != S2_PAIRS_COLLECT;
-	auto enqueueRepaired = [&]() -> int {
-		if (hostFoundDev == nullptr)
-		{
-			BP_TRY(hipMemsetAsync(dCount, 0, 256, st));
-		}
-		repairOrderKernel<<<dim3(1), dim3(S2_REPAIR_THREADS), 0, st>>>(dS, ns, n, dIdxOut, dKeysOut, dIdxIn, dKeysIn, (int*)dRun, dBox, dMovedSorted, dMoved, dCount);
-		pairWaveKernel<<<dim3((unsigned)std::min((n + 3) / 4, 16384)), dim3(S2_BLOCK), 0, st>>>(dS, dMoved, dIdxOut, dBox, dMovedSorted, n, sortedPairKeys, nc, dJointed,
-																								jointedCount, dOutA, (unsigned int)outCap, dCount, (int*)dRun, dCount + 1, gone);
-		pairLongKernel<<<dim3(256), dim3(S2_BLOCK), 0, st>>>(dS, dMoved, dIdxOut, dBox, dMovedSorted, n, sortedPairKeys, nc, dJointed, jointedCount, dOutA,
-															  (unsigned int)outCap, dCount, (const int*)dRun, dCount + 1, gone);
-		BP_TRY(hipGetLastError());
-		return enqueueTail();
 	};
 	bool ran = false;
 	unsigned long long key = 1469598103934665603ull;
@@ -1012,19 +823,9 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 		BP_TRY(hipStreamSynchronize(st));
 		return S2AMD_OK;
 	}
-	bool repaired = false;
 	if (mode == S2_PAIRS_COLLECT)
 	{
 		// (enqueued by an earlier call in S2_PAIRS_ENQUEUE mode; the caller has waited for the stream since)
-	}
-	else if (repair)
-	{
-		const int rcR = enqueueRepaired();
-		if (rcR)
-		{
-			return rcR;
-		}
-		repaired = true;
 	}
 	else if (cache->disabled || (key != cache->key && key != cache->keySeen))
 	{
@@ -1085,10 +886,6 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 			return rcTail;
 		}
 	}
-	if (ran || repaired)
-	{
-		cache->orderValid = true; // (both routes leave this query's sweep order in the scratch block)
-	}
 	if (mode == S2_PAIRS_ENQUEUE)
 	{
 		return S2AMD_OK;
@@ -1099,14 +896,6 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 	}
 	const unsigned int found = *hostFound;
 	*pairCount = (int32_t)found;
-	if (hostFound[1] != 0u)
-	{
-		// the order repair met more moved proxies than it holds and wrote nothing: the query again, sorted (its inputs are what they were)
-		hostFound[1] = 0u;
-		cache->movedHint = -1;
-		return findPairsResident(st, dS, ns, liveShapes, dPairs, nc, dJointed, jointedCount, outPairs, pairCapacity, pairCount, scratch, scratchBytes, sortedPairKeys,
-								 sortedPairKeysValid, cache, S2_PAIRS_FULL, pairLog, pairLogSlots, trees, nullptr);
-	}
 	if ((size_t)found > outCap)
 	{
 		// more new pairs than the device-side buffer holds (a world with few contact slots and many bodies landing at once): the

@@ -248,8 +248,6 @@ struct PairQueryGraph
 	char* host = nullptr;
 	void* countAt = nullptr; // where the query's counters live in the scratch block (zeroed when that changes)
 	size_t outCapWanted = 0; // a query found more pairs than the device-side buffer held: the next one makes it this large
-	bool orderValid = false; // the scratch block holds the last query's sweep order of this world's shapes (repairOrderKernel starts from it)
-	int movedHint = -1;		 // how many proxies the caller expects to have moved (-1: no idea: sort)
 };
 // something the ordered query runs between finding its pairs and ranking them (world.hip: the refit's tree enlarge pass)
 struct PairQueryHook

@@ -507,8 +507,6 @@ int s2amd_world_upload(s2amdSolver* s, const s2amdBody* bodies, int32_t bodyCapa
 	s->stepBackValid = false;
 	s->refitOrderCount = 0; // (the caller's order belongs to the world it was sent for)
 	treesForget(s);			// (... and so do its trees)
-	s->pairQuery.orderValid = false; // (... and the pair query's sweep order: other shapes)
-	s->pairQuery.movedHint = -1;
 	for (int i = 0; i < contactCapacity; ++i)
 	{
 		if (pairs[i].shapeA >= shapeCapacity || pairs[i].shapeB >= shapeCapacity)
@@ -855,7 +853,6 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 		if (pairsRide)
 		{
 			int32_t none = 0;
-			s->pairQuery.movedHint = s->lastMovedCount; // (the step before moved this many: few, and the sweep order is repaired, not sorted)
 			const PairQueryHook enlarge{[](void* arg, hipStream_t hst) {
 											s2amdSolver* hs = (s2amdSolver*)arg;
 											launchTreeEnlarge(hs, hst, hs->persistValid ? hs->persist.deviceError : nullptr);
@@ -1003,7 +1000,6 @@ int s2amd_world_find_pairs(s2amdSolver* s, int32_t* outPairs, int32_t pairCapaci
 	// or the step was repeated: then it runs now)
 	const bool collect = s->pairCacheValid;
 	s->pairQueryUsed = true;
-	s->pairQuery.movedHint = s->lastMovedCount;
 	int rc = collect ? S2AMD_OK : pairLogFlush(s);
 	if (rc)
 	{

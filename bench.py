@@ -62,7 +62,7 @@ from solver2d_amd import hip, synthetic, wire  # noqa: E402
 
 ALGO_BYTES_PER_CONSTRAINT_SWEEP = 232.0
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: 8.0 TB/s spec
-PROFILE_ROUNDS = ("r05", "r04", "r03", "r02", "r01")  # committed rocprofv3 summaries, newest first
+PROFILE_ROUNDS = ("r06", "r05", "r04", "r03", "r02", "r01")  # committed rocprofv3 summaries, newest first
 # A committed counter pass describes the build it profiled.  It is quoted on the line only when the kernel it names is the kernel this
 # run launched AND its average duration there agrees with the live one within this fraction (counter passes run a few per cent slower
 # than plain ones); otherwise `traffic` / `issue` are null with the reason beside them.

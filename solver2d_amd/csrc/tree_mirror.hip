@@ -36,7 +36,7 @@
 #define TREE_THREADS 1024
 #define TREE_NULL (-1)
 #define TREE_SMALL TREE_THREADS // a segment this short is finished by one task
-#define TREE_BATCH 4				 // loads a lane has in flight in the passes over a long segment
+#define TREE_BATCH 8				 // loads a lane has in flight in the passes over a long segment
 #define TREE_TASK_INTS 5		 // start, end, pre-order index of its node, the parent's node id, which child of it
 
 static_assert(sizeof(s2amdTreeNode) == 48, "s2TreeNode is 48 bytes (include/solver2d/dynamic_tree.h:14-41)");
@@ -115,53 +115,6 @@ S2_DEV void treeReport(TreeView& t, int n, int newRoot)
 	}
 }
 
-// exclusive prefix sum of one int per thread over the workgroup; *total = the sum
-S2_DEV int blockExclusive(int v, int* lds, int* total)
-{
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	int x = v;
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1)
-	{
-		const int y = __shfl_up(x, d, 64);
-		if (lane >= d)
-		{
-			x += y;
-		}
-	}
-	if (lane == 63)
-	{
-		lds[wave] = x;
-	}
-	__syncthreads();
-	if (wave == 0)
-	{
-		const int w = lane < TREE_THREADS / 64 ? lds[lane] : 0;
-		int xs = w;
-#pragma unroll
-		for (int d = 1; d < TREE_THREADS / 64; d <<= 1)
-		{
-			const int y = __shfl_up(xs, d, 64);
-			if (lane >= d)
-			{
-				xs += y;
-			}
-		}
-		if (lane < TREE_THREADS / 64)
-		{
-			lds[lane] = xs - w;
-		}
-		if (lane == TREE_THREADS / 64 - 1)
-		{
-			lds[TREE_THREADS / 64] = xs;
-		}
-	}
-	__syncthreads();
-	*total = lds[TREE_THREADS / 64];
-	const int r = lds[wave] + x - v;
-	__syncthreads();
-	return r;
-}
 } // namespace
 
 // ---- stage 4: the shapes the refit re-inflated enlarge their proxies ----
@@ -299,7 +252,7 @@ __global__ __launch_bounds__(S2_BLOCK) void treeGatherWalkKernel(TreeViews* view
 #define TREE_SCAN_TILES 24 // tiles a wave holds in registers per batch
 __global__ __launch_bounds__(TREE_THREADS) void treeGatherScanKernel(TreeViews* views, int which)
 {
-	__shared__ int sWave[2][TREE_THREADS / 64];
+	__shared__ unsigned long long sWave[TREE_THREADS / 64];
 	TreeView& t = views->t[which];
 	if (t.capacity <= 0 || t.qstate[3] != 0)
 	{
@@ -309,79 +262,81 @@ __global__ __launch_bounds__(TREE_THREADS) void treeGatherScanKernel(TreeViews* 
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int tiles = (N + 63) / 64, perWave = (tiles + TREE_THREADS / 64 - 1) / (TREE_THREADS / 64);
 	const int tile0 = min(wave * perWave, tiles), tile1 = min(tile0 + perWave, tiles);
-	int totals[2] = {0, 0};
-	for (int which2 = 0; which2 < 2; ++which2)
+	// both histograms at once: leaves in the high word, flagged nodes in the low one (neither sum reaches 2^31)
+	unsigned long long v[TREE_SCAN_TILES];
+	unsigned long long sum = 0ull;
+	for (int b0 = tile0; b0 < tile1; b0 += TREE_SCAN_TILES)
 	{
-		int* a = which2 == 0 ? t.arrive : t.partner;
-		// pass 1: the wave's sum
-		int sum = 0;
-		for (int b0 = tile0; b0 < tile1; b0 += TREE_SCAN_TILES)
+#pragma unroll
+		for (int k = 0; k < TREE_SCAN_TILES; ++k)
 		{
-			int v[TREE_SCAN_TILES];
+			const int i = (b0 + k) * 64 + lane;
+			const bool in = b0 + k < tile1 && i < N;
+			v[k] = in ? (((unsigned long long)(unsigned int)t.partner[i] << 32) | (unsigned long long)(unsigned int)t.arrive[i]) : 0ull;
+		}
+#pragma unroll
+		for (int k = 0; k < TREE_SCAN_TILES; ++k)
+		{
+			sum += v[k];
+		}
+	}
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1)
+	{
+		sum += ((unsigned long long)(unsigned int)__shfl_xor((int)(sum >> 32), d, 64) << 32) | (unsigned long long)(unsigned int)__shfl_xor((int)(sum & 0xffffffffull), d, 64);
+	}
+	if (lane == 0)
+	{
+		sWave[wave] = sum;
+	}
+	__syncthreads();
+	unsigned long long run = 0ull, total = 0ull;
+	for (int w = 0; w < TREE_THREADS / 64; ++w)
+	{
+		run += w < wave ? sWave[w] : 0ull;
+		total += sWave[w];
+	}
+	const bool kept = tile1 - tile0 <= TREE_SCAN_TILES; // (the wave's whole run is still in its registers)
+	for (int b0 = tile0; b0 < tile1; b0 += TREE_SCAN_TILES)
+	{
+		if (!kept)
+		{
 #pragma unroll
 			for (int k = 0; k < TREE_SCAN_TILES; ++k)
 			{
 				const int i = (b0 + k) * 64 + lane;
-				v[k] = (b0 + k < tile1 && i < N) ? a[i] : 0;
-			}
-#pragma unroll
-			for (int k = 0; k < TREE_SCAN_TILES; ++k)
-			{
-				sum += v[k];
+				const bool in = b0 + k < tile1 && i < N;
+				v[k] = in ? (((unsigned long long)(unsigned int)t.partner[i] << 32) | (unsigned long long)(unsigned int)t.arrive[i]) : 0ull;
 			}
 		}
 #pragma unroll
-		for (int d = 32; d >= 1; d >>= 1)
+		for (int k = 0; k < TREE_SCAN_TILES; ++k)
 		{
-			sum += __shfl_xor(sum, d, 64);
-		}
-		if (lane == 0)
-		{
-			sWave[which2][wave] = sum;
-		}
-		__syncthreads();
-		int run = 0;
-		for (int w = 0; w < TREE_THREADS / 64; ++w)
-		{
-			run += w < wave ? sWave[which2][w] : 0;
-			totals[which2] += sWave[which2][w];
-		}
-		// pass 2: prefixes
-		for (int b0 = tile0; b0 < tile1; b0 += TREE_SCAN_TILES)
-		{
-			int v[TREE_SCAN_TILES];
+			unsigned long long x = v[k];
 #pragma unroll
-			for (int k = 0; k < TREE_SCAN_TILES; ++k)
+			for (int d = 1; d < 64; d <<= 1)
 			{
-				const int i = (b0 + k) * 64 + lane;
-				v[k] = (b0 + k < tile1 && i < N) ? a[i] : 0;
-			}
-#pragma unroll
-			for (int k = 0; k < TREE_SCAN_TILES; ++k)
-			{
-				int x = v[k];
-#pragma unroll
-				for (int d = 1; d < 64; d <<= 1)
+				const unsigned long long y = ((unsigned long long)(unsigned int)__shfl_up((int)(x >> 32), d, 64) << 32) |
+											 (unsigned long long)(unsigned int)__shfl_up((int)(x & 0xffffffffull), d, 64);
+				if (lane >= d)
 				{
-					const int y = __shfl_up(x, d, 64);
-					if (lane >= d)
-					{
-						x += y;
-					}
+					x += y;
 				}
-				const int i = (b0 + k) * 64 + lane;
-				if (b0 + k < tile1 && i < N)
-				{
-					a[i] = run + x - v[k];
-				}
-				run += __shfl(x, 63, 64);
 			}
+			const int i = (b0 + k) * 64 + lane;
+			if (b0 + k < tile1 && i < N)
+			{
+				const unsigned long long before = run + x - v[k];
+				t.arrive[i] = (int)(before & 0xffffffffull);
+				t.partner[i] = (int)(before >> 32);
+			}
+			run += ((unsigned long long)(unsigned int)__shfl((int)(x >> 32), 63, 64) << 32) | (unsigned long long)(unsigned int)__shfl((int)(x & 0xffffffffull), 63, 64);
 		}
 	}
 	if (tid == 0)
 	{
-		const int M = totals[0];
-		if (totals[1] != M + 1)
+		const int M = (int)(total & 0xffffffffull), leavesFound = (int)(total >> 32);
+		if (leavesFound != M + 1)
 		{
 			atomicExch(t.state + 2, 3); // a flagged node whose parent is not flagged
 			t.qstate[3] = 1;
@@ -489,7 +444,7 @@ __global__ __launch_bounds__(S2_BLOCK) void treeBoxesClimbKernel(TreeViews* view
 __global__ __launch_bounds__(TREE_THREADS) void treeBuildTasksKernel(TreeViews* views, int which)
 {
 	__shared__ int sTask[TREE_TASK_INTS + 1];
-	__shared__ int lds[TREE_THREADS / 64 + 2];
+	__shared__ int lds[2 * (TREE_THREADS / 64) + 2];
 	__shared__ unsigned int sRed[4 * (TREE_THREADS / 64)];
 	__shared__ int sLeaf[TREE_SMALL];
 	__shared__ float sCx[TREE_SMALL], sCy[TREE_SMALL];
@@ -746,6 +701,11 @@ __global__ __launch_bounds__(TREE_THREADS) void treeBuildTasksKernel(TreeViews* 
 			// ---- a short segment down to its leaves, in LDS, with the segment's own numbering (element i - start, node pre + local
 			// index): every level of all its open sub-segments at once ----
 			const bool has = tid < n;
+			// (every local segment's bounds start empty: a segment is named by its local pre-order index, used once)
+			for (int i = tid; i < 4 * TREE_SMALL; i += TREE_THREADS)
+			{
+				gBounds[i] = (i & 2) ? 0u : 0xffffffffu;
+			}
 			if (has)
 			{
 				sLeaf[tid] = t.leafIdx[start + tid], sCx[tid] = t.cx[start + tid], sCy[tid] = t.cy[start + tid];
@@ -754,7 +714,12 @@ __global__ __launch_bounds__(TREE_THREADS) void treeBuildTasksKernel(TreeViews* 
 			if (tid == 0)
 			{
 				gStart[0] = 0, gEnd[0] = n;
-				gBounds[0] = 0xffffffffu, gBounds[1] = 0xffffffffu, gBounds[2] = 0u, gBounds[3] = 0u;
+			}
+			__syncthreads();
+			if (has && n > 2)
+			{
+				atomicMin(gBounds + 0, sortable(sCx[tid])), atomicMin(gBounds + 1, sortable(sCy[tid]));
+				atomicMax(gBounds + 2, sortable(sCx[tid])), atomicMax(gBounds + 3, sortable(sCy[tid]));
 			}
 			__syncthreads();
 			for (int level = 0; level <= n; ++level)
@@ -762,12 +727,6 @@ __global__ __launch_bounds__(TREE_THREADS) void treeBuildTasksKernel(TreeViews* 
 				const int s = has ? sSeg[tid] : -1;
 				const int s0 = s >= 0 ? gStart[s] : 0, s1 = s >= 0 ? gEnd[s] : 0;
 				const bool wide = s >= 0 && s1 - s0 > 2; // (:1320-1323: two elements or fewer are split in the middle, untouched)
-				if (wide)
-				{
-					atomicMin(gBounds + 4 * s + 0, sortable(sCx[tid])), atomicMin(gBounds + 4 * s + 1, sortable(sCy[tid]));
-					atomicMax(gBounds + 4 * s + 2, sortable(sCx[tid])), atomicMax(gBounds + 4 * s + 3, sortable(sCy[tid]));
-				}
-				__syncthreads();
 				bool left = false;
 				if (wide)
 				{
@@ -775,8 +734,29 @@ __global__ __launch_bounds__(TREE_THREADS) void treeBuildTasksKernel(TreeViews* 
 					const float fux = unsortable(gBounds[4 * s + 2]), fuy = unsortable(gBounds[4 * s + 3]);
 					left = (fux - flx) > (fuy - fly) ? sCx[tid] < 0.5f * (flx + fux) : sCy[tid] < 0.5f * (fly + fuy);
 				}
-				int total = 0;
-				const int before0 = blockExclusive(left ? 1 : 0, lds, &total);
+				// prefix sum of the predicate over the task's elements: one barrier (every thread adds the waves before its own)
+				int x = left ? 1 : 0;
+#pragma unroll
+				for (int d = 1; d < 64; d <<= 1)
+				{
+					const int y = __shfl_up(x, d, 64);
+					if (lane >= d)
+					{
+						x += y;
+					}
+				}
+				int* waveSums = lds + (level & 1) * (TREE_THREADS / 64); // (two sets: the next level writes while a slow wave still adds)
+				if (lane == 63)
+				{
+					waveSums[wave] = x;
+				}
+				__syncthreads();
+				int before0 = x - (left ? 1 : 0), total = 0;
+				for (int w = 0; w < TREE_THREADS / 64; ++w)
+				{
+					before0 += w < wave ? waveSums[w] : 0;
+					total += waveSums[w];
+				}
 				sScan[tid] = before0;
 				if (tid == 0)
 				{
@@ -805,9 +785,9 @@ __global__ __launch_bounds__(TREE_THREADS) void treeBuildTasksKernel(TreeViews* 
 				{
 					const int p = sPartner[s0 + (tid - s0 - (before0 - sScan[s0]))];
 					const int li = sLeaf[tid];
-					const float x = sCx[tid], y = sCy[tid];
+					const float x2 = sCx[tid], y2 = sCy[tid];
 					sLeaf[tid] = sLeaf[p], sCx[tid] = sCx[p], sCy[tid] = sCy[p];
-					sLeaf[p] = li, sCx[p] = x, sCy[p] = y;
+					sLeaf[p] = li, sCx[p] = x2, sCy[p] = y2;
 				}
 				__syncthreads();
 				int open = 0;
@@ -828,7 +808,12 @@ __global__ __launch_bounds__(TREE_THREADS) void treeBuildTasksKernel(TreeViews* 
 						{
 							(inLeft ? cLeft : cRight)[s] = cs;
 							gStart[cs] = ps, gEnd[cs] = pe;
-							gBounds[4 * cs + 0] = 0xffffffffu, gBounds[4 * cs + 1] = 0xffffffffu, gBounds[4 * cs + 2] = 0u, gBounds[4 * cs + 3] = 0u;
+						}
+						if (pe - ps > 2)
+						{
+							// (the part's centres into its bounds now: the next level starts with them)
+							atomicMin(gBounds + 4 * cs + 0, sortable(sCx[tid])), atomicMin(gBounds + 4 * cs + 1, sortable(sCy[tid]));
+							atomicMax(gBounds + 4 * cs + 2, sortable(sCx[tid])), atomicMax(gBounds + 4 * cs + 3, sortable(sCy[tid]));
 						}
 						sSeg[tid] = cs;
 						open = 1;
@@ -889,12 +874,8 @@ __global__ __launch_bounds__(TREE_THREADS) void treeBuildTasksKernel(TreeViews* 
 					hL = 1 + (hL > hR ? hL : hR), catL |= catR, lvL += lvR;
 					fBox[4 * tid + 0] = b0, fBox[4 * tid + 1] = b1, fBox[4 * tid + 2] = b2, fBox[4 * tid + 3] = b3;
 					fCat[tid] = catL, fLeaves[tid] = lvL;
+					fHeight[tid] = hL; // (a parent looks at this in the NEXT round's first half, behind the barrier below)
 					finished = true;
-				}
-				__syncthreads();
-				if (now)
-				{
-					fHeight[tid] = hL;
 				}
 				if (__syncthreads_and(finished ? 1 : 0) != 0)
 				{

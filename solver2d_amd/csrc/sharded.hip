@@ -36,6 +36,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -133,10 +134,19 @@ struct RcclApi
 			return lib != nullptr;
 		}
 		tried = true;
+		// (an RCCL the process has loaded already -- PyTorch brings its own -- is the one to use: two copies in one process do not
+		// initialise side by side)
 		const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
 		for (const char* name : names)
 		{
-			if ((lib = dlopen(name, RTLD_NOW | RTLD_LOCAL)) != nullptr)
+			if ((lib = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD)) != nullptr)
+			{
+				break;
+			}
+		}
+		for (const char* name : names)
+		{
+			if (lib != nullptr || (lib = dlopen(name, RTLD_NOW | RTLD_LOCAL)) != nullptr)
 			{
 				break;
 			}
@@ -776,9 +786,16 @@ int s2amd_sharded_create(const int32_t* devices, int32_t deviceCount, s2amdShard
 		{
 			std::vector<void*> comms((size_t)deviceCount, nullptr);
 			std::vector<int> devs(devices, devices + deviceCount);
-			if (!g_rccl.load() || g_rccl.commInitAll(comms.data(), deviceCount, devs.data()) != 0)
+			const bool loaded = g_rccl.load();
+			const int rcInit = loaded ? g_rccl.commInitAll(comms.data(), deviceCount, devs.data()) : -1;
+			if (!loaded || rcInit != 0)
 			{
 				w->exchange = EX_COPIES; // (no librccl.so, or it would not initialise: the peer copies)
+				if (getenv("S2AMD_DEBUG") != nullptr)
+				{
+					fprintf(stderr, "[s2amd] sharded exchange: RCCL %s (%s): peer copies instead\n", loaded ? "would not initialise" : "could not be loaded",
+							loaded ? (g_rccl.errorString ? g_rccl.errorString(rcInit) : "?") : (dlerror() ? dlerror() : "dlopen"));
+				}
 			}
 			else
 			{

@@ -574,7 +574,7 @@ __global__ __launch_bounds__(S2_BLOCK) void residentShapeKeysKernel(const s2amdS
 // the resident query's results to the host: count[0] pairs found (count[1]: the long runs' counter), the first `first` keys; both counters
 // zero again for the next query
 __global__ __launch_bounds__(S2_BLOCK) void publishPairsKernel(unsigned int* count, const unsigned long long* keys, unsigned int first, unsigned int* hostFound,
-															   unsigned long long* hostKeys)
+															   unsigned long long* hostKeys, const TreeViews* trees)
 {
 	const unsigned int found = count[0];
 	const unsigned int n = found < first ? found : first;
@@ -586,6 +586,8 @@ __global__ __launch_bounds__(S2_BLOCK) void publishPairsKernel(unsigned int* cou
 	if (threadIdx.x == 0)
 	{
 		hostFound[0] = found;
+		// (the device trees' error words travel with the pairs they ordered: a tree that lost its shape must not order anything quietly)
+		hostFound[1] = trees != nullptr ? (unsigned int)(trees->t[0].state[2] | trees->t[1].state[2] | trees->t[2].state[2]) : 0u;
 		count[0] = 0u, count[1] = 0u;
 	}
 }
@@ -761,7 +763,7 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 		{
 			// the count and the first keys straight into the pinned page, the counters zeroed for the next query: one small kernel where
 			// a memset and two copies were three blit kernels (~4.5 us each, serial on the stream)
-			publishPairsKernel<<<dim3(1), dim3(S2_BLOCK), 0, st>>>(dCount, dResult, (unsigned int)std::min<size_t>(kFirst, outCap), hostFoundDev, hostKeysDev);
+			publishPairsKernel<<<dim3(1), dim3(S2_BLOCK), 0, st>>>(dCount, dResult, (unsigned int)std::min<size_t>(kFirst, outCap), hostFoundDev, hostKeysDev, trees);
 			BP_TRY(hipGetLastError());
 		}
 		else
@@ -896,6 +898,11 @@ int findPairsResident(hipStream_t st, const s2amdShape* dS, int ns, int liveShap
 	}
 	const unsigned int found = *hostFound;
 	*pairCount = (int32_t)found;
+	if (ordered && hostFound[1] != 0u)
+	{
+		return s2amdFail(S2AMD_E_DEVICE, "the device's broad-phase trees reported error " + std::to_string(hostFound[1]) +
+											 " (tree_mirror.hip): the order of the new pairs cannot be trusted -- upload the world and its trees again");
+	}
 	if ((size_t)found > outCap)
 	{
 		// more new pairs than the device-side buffer holds (a world with few contact slots and many bodies landing at once): the

@@ -46,6 +46,7 @@
 int s2amdFail(int code, const std::string& msg);
 hipStream_t s2amdStream(s2amdSolver* s);
 int s2amdDevice(s2amdSolver* s);
+const s2amdBody* s2amdResidentBodies(s2amdSolver* s); // solver.cpp: the resident wire bodies (device pointer)
 bool s2amdStepFailed(s2amdSolver* s); // solver.cpp: the host-visible error word of an enqueued step (no device call)
 extern "C" int s2amd_sharded_wait(s2amdShardedSolver* w);
 
@@ -88,14 +89,18 @@ __global__ void scatterOwnedKernel(const float4* compact, const int* ownedWorld,
 	}
 }
 
-// the owned rows of a shard's exported records straight into every world copy this device can store to (shards of one device)
-__global__ void pushOwnedKernel(const float4* records, const int* ownedLocal, const int* ownedWorld, int n, float4* const* worlds, int nWorlds)
+// the owned rows of a shard into every world copy this device can store to (shards of one device),
+// ... straight from the solver's resident wire bodies (the records exportBodiesKernel would make, body_kernels.hip: {position, rot},
+// {linearVelocity, angularVelocity, 0}): shards of one device need no staging copy in between
+__global__ void pushOwnedBodiesKernel(const s2amdBody* wire, const int* ownedLocal, const int* ownedWorld, int n, float4* const* worlds, int nWorlds)
 {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n)
 	{
-		const int b = ownedLocal[i], wi = ownedWorld[i];
-		const float4 r0 = records[2 * b], r1 = records[2 * b + 1];
+		const s2amdBody* b = wire + ownedLocal[i];
+		const int wi = ownedWorld[i];
+		const float4 r0 = make_float4(b->position[0], b->position[1], b->rot[0], b->rot[1]);
+		const float4 r1 = make_float4(b->linearVelocity[0], b->linearVelocity[1], b->angularVelocity, 0.0f);
 		for (int d = 0; d < nWorlds; ++d)
 		{
 			worlds[d][2 * wi] = r0;
@@ -933,7 +938,7 @@ static int enqueueShard(s2amdShardedSolver* w, int index, const s2amdStepParams*
 			// (the last exchange has read the records this step's export rewrites; the solve itself did not have to wait for it)
 			SH_TRY(hipStreamWaitEvent(st, sh.evXchg, 0));
 		}
-		if (rc == S2AMD_OK)
+		if (rc == S2AMD_OK && beside)
 		{
 			rc = s2amd_export_bodies_async(sh.solver, sh.dRecords.p, (int32_t)sh.bodies.size(), 0);
 		}
@@ -947,13 +952,13 @@ static int enqueueShard(s2amdShardedSolver* w, int index, const s2amdStepParams*
 			SH_TRY(hipStreamWaitEvent(sh.xs, sh.evStep, 0));
 		}
 	}
-	*ops += beside ? 5 : 2; // step, export (+ wait, record, wait)
+	*ops += beside ? 5 : 1; // step (+ wait, export, record, wait)
 	if (w->exchange == EX_STORES)
 	{
 		if (!dry && n > 0)
 		{
-			pushOwnedKernel<<<blocksFor(n), dim3(256), 0, xs>>>((const float4*)sh.dRecords.p, (const int*)sh.dOwnedLocal.p, (const int*)sh.dOwnedWorld.p, (int)n,
-																(float4* const*)sh.dPeers.p, nShards);
+			pushOwnedBodiesKernel<<<blocksFor(n), dim3(256), 0, xs>>>(s2amdResidentBodies(sh.solver), (const int*)sh.dOwnedLocal.p, (const int*)sh.dOwnedWorld.p, (int)n,
+																	  (float4* const*)sh.dPeers.p, nShards);
 			SH_TRY(hipGetLastError());
 		}
 		*ops += 1;

@@ -32,6 +32,7 @@ void s2amdRecordDeviceMs(s2amdSolver* s, float ms)
 {
 	s->stats.deviceMs = ms;
 }
+const s2amdBody* s2amdResidentBodies(s2amdSolver* s) { return s != nullptr ? (const s2amdBody*)s->dBodies.p : nullptr; }
 bool s2amdStepFailed(s2amdSolver* s) { return s != nullptr && s->hostError != nullptr && *s->hostError != 0u; }
 int s2amdDevice(s2amdSolver* s)
 {

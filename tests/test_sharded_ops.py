@@ -17,7 +17,7 @@ def test_stream_operations_per_step_grow_linearly_with_the_shards():
         per_shard = [_ops(n, form) / n for n in (1, 2, 4, 8, 16)]
         assert max(per_shard) == min(per_shard), (form, per_shard)
         assert per_shard[0] <= 9
-    assert _ops(8, 0) == 8 * 4 and _ops(8, 1) == 8 * 9
+    assert _ops(8, 0) == 8 * 3 and _ops(8, 1) == 8 * 9
     # the peer copies: a wait, a copy and a scatter per ordered pair of shards
     assert _ops(8, 2) == 8 * 9 + 3 * 8 * 7
 

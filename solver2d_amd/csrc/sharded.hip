@@ -139,16 +139,27 @@ struct RcclApi
 			return lib != nullptr;
 		}
 		tried = true;
-		// (an RCCL the process has loaded already -- PyTorch brings its own -- is the one to use: two copies in one process do not
-		// initialise side by side)
-		const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-		for (const char* name : names)
+		// (the RCCL that sits BESIDE the HIP runtime this process runs on comes first: RCCL opens "libhsa-runtime64.so" by its bare name,
+		// which resolves through its own RUNPATH -- PyTorch ships private copies of all three libraries, and an RCCL of one set beside a
+		// HIP runtime of the other finds an HSA runtime nobody initialised: "no ROCm-capable device is detected")
+		Dl_info hipAt;
+		if (dladdr((const void*)&hipGetDeviceCount, &hipAt) != 0 && hipAt.dli_fname != nullptr)
 		{
-			if ((lib = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD)) != nullptr)
+			std::string dir(hipAt.dli_fname);
+			const size_t slash = dir.rfind('/');
+			if (slash != std::string::npos)
 			{
-				break;
+				dir.resize(slash + 1);
+				for (const char* leaf : {"librccl.so", "librccl.so.1"})
+				{
+					if (lib == nullptr)
+					{
+						lib = dlopen((dir + leaf).c_str(), RTLD_NOW | RTLD_LOCAL);
+					}
+				}
 			}
 		}
+		const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
 		for (const char* name : names)
 		{
 			if (lib != nullptr || (lib = dlopen(name, RTLD_NOW | RTLD_LOCAL)) != nullptr)

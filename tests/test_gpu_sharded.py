@@ -9,6 +9,8 @@ shards on this box's one GPU (the peer copies of the exchange become device copi
   * re-sharding when a created contact joins islands of two shards and is destroyed again == one solver through the same script, and
     only the smaller island moves.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -178,8 +180,8 @@ def test_pipelined_steps_in_every_form_of_the_exchange(mode, shards, monkeypatch
         assert sh.step_ops()[1] == 1
         records = [sh.read_bodies(k) for k in range(shards)]
         sh.download(*got)
-    if mode == "rccl" and form != 1:
-        pytest.skip("librccl.so could not be loaded or initialised here: the exchange fell back to peer copies")
+    if mode == "rccl" and form != 1 and not os.path.exists("/opt/rocm/lib/librccl.so"):
+        pytest.skip("no librccl.so on this box: the exchange fell back to peer copies")
     assert form == {"stores": 0, "copies": 2, "rccl": 1}[mode]
     counted = ctypes.c_int32()
     assert hip.load().s2amd_sharded_count_ops(shards, form, ctypes.byref(counted)) == 0

@@ -29,6 +29,11 @@
 #include "persist_handoff.h"
 
 #define S2_GENERIC_THREADS 512
+// 1: in-kernel time stamps (S2AMD_DEBUG_TIMES; wall_clock64 ticks of 10 ns, one workgroup in the middle) are compiled in: after the loads,
+// and per constraint op after the interiors, the forward hand-off, the seam and the return hand-off (tools/generic_stamps.sh)
+#ifndef S2_GENERIC_INSTRUMENTED
+#define S2_GENERIC_INSTRUMENTED 0
+#endif
 #define S2_GENERIC_BATCH_RECORDS 64 // colour batches of a strip and its seam (contacts and joints) whose descriptors are kept in LDS
 
 // seam-group-local body slots -> this workgroup's LDS slots (PersistView::remap, staged in LDS)
@@ -167,6 +172,15 @@ __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactV
 {
 	extern __shared__ __attribute__((aligned(16))) float4 lds[];
 	const int tid = (int)threadIdx.x;
+	const bool stamp = S2_GENERIC_INSTRUMENTED && pv.debugTimes != nullptr && blockIdx.x == gridDim.x / 2 && tid == 0;
+	int stamps = 0;
+	auto stampAt = [&]() {
+		if (stamp && stamps < 250)
+		{
+			pv.debugTimes[stamps++] = wall_clock64();
+		}
+	};
+	stampAt(); // (kernel start)
 	// Strip <-> workgroup: consecutive strips on ONE XCD, so that a seam's two workgroups share an L2 (the dispatcher is observed
 	// to place block b on XCD b % 8: a speed assumption only).  The census (wide_kernel.hip): every workgroup publishes the XCD it
 	// REALLY runs on, and a hand-off takes the L2 path (workgroup-scope stores, no write-through) only towards a neighbour that
@@ -323,6 +337,7 @@ __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactV
 		__syncthreads();
 	}
 
+	stampAt(); // (loads done)
 	unsigned epoch = 0; // the buffers are zero at launch (cleared by the previous step's epilogue)
 	int bad = 0;
 	for (int oi = 0; oi < opCount && !bad; ++oi)
@@ -336,6 +351,7 @@ __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactV
 					integrateVelocitiesOne(lb, i, g, (int)((uint32_t)ids[i] & ~S2G_OWNED));
 				}
 				__syncthreads();
+				stampAt();
 				continue;
 			case OP_INTEGRATE_POS:
 				for (int i = tid; i < nb; i += S2_GENERIC_THREADS)
@@ -343,6 +359,7 @@ __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactV
 					integratePositionsOne(lb, i, g, (int)((uint32_t)ids[i] & ~S2G_OWNED), op.h);
 				}
 				__syncthreads();
+				stampAt();
 				continue;
 			case OP_FINALIZE:
 				for (int i = tid; i < nb; i += S2_GENERIC_THREADS)
@@ -351,6 +368,7 @@ __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactV
 					finalizePositionsOne(lb, i, g, (int)(id & ~S2G_OWNED), op.flag, (id & S2G_OWNED) != 0);
 				}
 				__syncthreads();
+				stampAt();
 				continue;
 			case OP_XPBD_INTEGRATE:
 				for (int i = tid; i < nb; i += S2_GENERIC_THREADS)
@@ -358,6 +376,7 @@ __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactV
 					xpbdIntegrateOne(lb, ldq0, i, g, (int)((uint32_t)ids[i] & ~S2G_OWNED), op.h);
 				}
 				__syncthreads();
+				stampAt();
 				continue;
 			case OP_XPBD_PROJECT:
 				for (int i = tid; i < nb; i += S2_GENERIC_THREADS)
@@ -365,6 +384,7 @@ __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactV
 					xpbdProjectOne(lb, ldq0, i, g, (int)((uint32_t)ids[i] & ~S2G_OWNED), op.inv_h);
 				}
 				__syncthreads();
+				stampAt();
 				continue;
 			default:
 				break;
@@ -378,6 +398,7 @@ __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactV
 		{
 			sweepOp(op, c, jv, lb, sc, wire, batchC, 0, nC, batchJ, 0, nJ, 0);
 		}
+		stampAt();
 		if ((op.code == OP_JOINT_SWEEP ? seamJoints : seamContacts) == 0)
 		{
 			continue; // nothing of this kind in any seam: every workgroup skips the hand-offs
@@ -410,6 +431,7 @@ __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactV
 		{
 			break;
 		}
+		stampAt();
 		// ---- the seam to my right ----
 		if (seam >= 0)
 		{
@@ -422,6 +444,7 @@ __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactV
 				sweepOp(op, c, jv, sb, sc, wire, batchSC, 0, nSC, batchSJ, 0, nSJ, 0);
 			}
 		}
+		stampAt();
 		// ---- return: the right neighbour's bodies back to their owner, mine back from the left neighbour ----
 		epoch += 1;
 		for (int t = tid; t < nImp1; t += S2_GENERIC_THREADS)
@@ -444,6 +467,7 @@ __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactV
 			}
 		}
 		bad = __syncthreads_or(fail);
+		stampAt();
 	}
 
 	if (jointsInLds && !bad)
@@ -468,6 +492,12 @@ __global__ __launch_bounds__(S2_GENERIC_THREADS) void genericStepKernel(ContactV
 				g.dq0[gi] = ldq0[i];
 			}
 		}
+	}
+	stampAt();
+	if (stamp)
+	{
+		pv.debugTimes[254] = 0ull; // plain ticks (solver.cpp prints them at destroy)
+		pv.debugTimes[255] = (unsigned long long)stamps;
 	}
 }
 

@@ -957,6 +957,12 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	{
 		s->optBodyWarm = value;
 	}
+	else if (strcmp(key, "group_patience") == 0)
+	{
+		s->optGroupPatience = value;
+		s->groupPatienceNow = 0;
+		s->structureDirty = true;
+	}
 	else if (strcmp(key, "groups") == 0)
 	{
 		s->optGroups = value;

@@ -864,6 +864,8 @@ bool incrementalApply(s2amdSolver* s, const std::vector<ContactChange>& changes)
 		// ---- the slot's previous entry (a destroyed contact whose entry lingered) gives its place back ----
 		if (!removeEntry(s, p, ch.slot))
 		{
+			// (an entry in an LDS group's tables, unless strips hold it: SolverRest::groupPatienceNow)
+			s->dirtyByGroups = inc.positionOfSlot[(size_t)ch.slot] == -2 && !(s->stripInc.valid && ch.slot < (int)s->stripInc.positionOfSlot.size() && s->stripInc.positionOfSlot[(size_t)ch.slot] >= 0);
 			return giveUp("old entry of the slot not removable");
 		}
 		if (ch.a < 0)
@@ -891,6 +893,7 @@ bool incrementalApply(s2amdSolver* s, const std::vector<ContactChange>& changes)
 				unwatchSlot(s, ch.slot);
 				continue;
 			}
+			s->dirtyByGroups = ownedByLdsGroup(s, ch.a) || ownedByLdsGroup(s, ch.b);
 			return giveUp("body owned by a group or strip");
 		}
 		inc.placedInGlobalPart = true;
@@ -989,7 +992,9 @@ bool incrementalApply(s2amdSolver* s, const std::vector<ContactChange>& changes)
 			// every colour batch is taken on these bodies: the rebuild adds empty ones for the next such contact.  (Twice as many
 			// every time -- up to 16 -- was measured on the Tumbler filled from scratch, r4: fewer rebuilds, 57 instead of 67 of 120
 			// steps, but every spare colour in use is a launch per sweep: 287 instead of 257 launches per step, no faster.)
-			s->spareColours = 2;
+			// (r6: ... but where the structures die of it one after the other -- a pile coming down under the reference's default solver:
+			// 98 of 105 builds, one per step -- twice as many each time: an empty colour costs nothing until it is used)
+			s->spareColours = s->graphAge < 8 ? std::min(std::max(2 * s->spareColours, 2), 16) : std::max(s->spareColours, 2);
 			return giveUp("no free colour");
 		}
 		if ((int)inc.freePositions[(size_t)chosen].size() == inc.batchEnd[(size_t)chosen] - inc.batchBegin[(size_t)chosen])
@@ -1117,6 +1122,16 @@ bool canDeferCreated(const s2amdSolver* s, int slot, int a, int b)
 }
 
 // a watched manifold between these bodies got its first points: can it take a place in the strips (instead of a rebuild)?
+bool ownedByLdsGroup(const s2amdSolver* s, int body)
+{
+	if (body < 0 || body >= (int)s->hBodyFlagsFinal.size() || (s->hBodyFlagsFinal[(size_t)body] & S2F_IN_GROUP) == 0)
+	{
+		return false;
+	}
+	const IncrementalStrips& m = s->stripInc;
+	return !(m.valid && body < (int)m.ownerStrip.size() && m.ownerStrip[(size_t)body] >= 0);
+}
+
 bool stripCanPlace(const s2amdSolver* s, int a, int b)
 {
 	const int nb = (int)s->hBodyFlagsFinal.size();

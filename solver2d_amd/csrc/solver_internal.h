@@ -418,6 +418,7 @@ struct SolverStructure
 	int looseBodies = 0; // live non-static bodies that no LDS group owns
 	int orderSolverClass = -1; // 0 velocity colouring, 1 position colouring
 	bool orderGrouped = false;
+	bool orderLdsGroups = false; // ... with small islands in LDS groups (SolverRest::groupPatienceNow)
 	bool orderResident = false; // the groups were laid out for the resident-island kernel where they fit
 	bool orderColourless = false; // built for s2Solve_Jacobi: the global contact part is one batch in pool order, no colours
 	bool orderStrips = false;
@@ -479,6 +480,7 @@ struct SolverRest
 	size_t hostStepBackBytes = 0, stepBackPoseOffset = 0;
 	int stepBackBoxes = 0;
 	bool stepBackValid = false;
+	bool stepBackListFresh = false; // this step's list of re-inflated shapes is on the device (enqueueStepBack ran; launchTreeEnlarge reads it)
 	int optStepReadback = 1;
 	std::vector<uint8_t> hPointBytes;
 	std::vector<uint8_t> hShapeMovable; // world chain: live shapes of non-static bodies (what s2amd_world_set_refit_order must cover)
@@ -559,6 +561,14 @@ struct SolverRest
 	long slicedSteps = 0;	  // steps that ran sliced, since s2amd_create
 	bool slicedThisStep = false;
 	int stripPatienceNow = 1; // ... as it stands: doubled every time a strip structure died young (noteGraphChanged)
+	// ... and the same patience for the LDS groups and resident islands: their tables take no created contact (a contact of one of their
+	// bodies, a pool slot of theirs that is used again, a watched manifold that gains its points are each a rebuild on the stepping
+	// thread), so a world that keeps doing that to them -- the debris of a pyramid the reference's default solver lets collapse: a 2.4 ms
+	// build in EVERY step, measured r6 -- gets its next structures without them: small islands in the colour batches of the global part,
+	// where every contact has a place.  Steps the graph must have been quiet for before groups are built again; 0: at once.
+	int groupPatienceNow = 0;
+	bool dirtyByGroups = false; // the rebuild that is due was forced by something an LDS group / resident island could not take
+	int optGroupPatience = 1;	// "group_patience" 0: groups whatever they cost (tests; round 5's behaviour)
 	bool stripPatienceSet = false; // "strip_patience" was set by the caller (else a resident world builds its strips at once: stripPatienceBase)
 	int optStripsAnySolver = 0; // tests: strips for every solver and with joints (through the generic group interpreter)
 
@@ -650,7 +660,17 @@ inline void noteGraphChanged(s2amdSolver* s, bool newWorld = false)
 	{
 		s->stripScaleFound = 0.0f;
 		s->stripSearchNotBefore = 0, s->stripSearchPause = 256;
+		s->groupPatienceNow = 0;
 	}
+	else if (s->optGroupPatience != 0 && s->dirtyByGroups && s->graphAge < 8)
+	{
+		s->groupPatienceNow = std::min(std::max(2 * s->groupPatienceNow, 4), 256); // (groups that died young)
+	}
+	else if (s->graphAge >= 256)
+	{
+		s->groupPatienceNow = 0;
+	}
+	s->dirtyByGroups = false;
 	if (newWorld || s->optStripPatience == 0)
 	{
 		s->stripPatienceNow = base; // (strip_patience 0 as an OPTION means "always at once", no backing off: tests)
@@ -730,6 +750,7 @@ void deferCreated(s2amdSolver* s, int slot, int a, int b);
 void unwatchSlot(s2amdSolver* s, int slot);
 int uploadWatched(s2amdSolver* s);
 bool stripCanPlace(const s2amdSolver* s, int a, int b);
+bool ownedByLdsGroup(const s2amdSolver* s, int body); // an LDS group or a resident island (not a strip) holds the body: nothing can be placed on it
 // ... or, failing that, a free position of the overflow region behind the strips (IncrementalStrips::overflowFree): the steps run sliced
 // until a worker thread's structure that holds the contact is adopted
 bool overflowCanPlace(const s2amdSolver* s, int a, int b);

@@ -197,6 +197,7 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 			{
 				hubTouched = true;
 				s->dirtyReason = "watched manifold flipped";
+				s->dirtyByGroups = s->dirtyByGroups || ownedByLdsGroup(s, c.bodyA) || ownedByLdsGroup(s, c.bodyB);
 			}
 		}
 		if (!edge && s->hContactEdge[i])

@@ -264,7 +264,7 @@ void colourPart(const std::vector<int>& ids, const std::vector<int>& ea, const s
 		for (int bi = 0; bi < batches; ++bi)
 		{
 			const int n = bi < parallel ? partOffsets[(size_t)bi + 1] - partOffsets[bi] : 0;
-			const int cap = bi < parallel ? ((n + std::max(32, (n / 8) << slackShift)) + 31) & ~31 : 64;
+			const int cap = bi < parallel ? ((n + std::max(32, (n / 8) << slackShift)) + 31) & ~31 : std::max(64, ((int)ids.size() / 64 + 31) & ~31);
 			const int begin = (int)laidOut.size();
 			batchOffsetsOut.push_back(base + begin);
 			inc->batchBegin[(size_t)bi] = base + begin, inc->batchEnd[(size_t)bi] = base + begin + cap;
@@ -1545,6 +1545,7 @@ struct StructureBuild
 	const int cls; // 0: the sweeps write velocities, 1: positions too (conflict = what a colour must not share)
 	const bool needAdj; // s2Solve_Jacobi: body-centric apply instead of colours
 	const bool grouped;
+	const bool ldsGroups; // small islands into LDS groups / resident islands (else: with everything else, into strips or the global part)
 	const bool wantStrips;
 	const bool residentWanted;
 	const bool stripSlackWanted; // strip and seam rounds get free positions for created contacts (IncrementalStrips): the soft contact solvers' strips
@@ -1579,6 +1580,7 @@ struct StructureBuild
 	StructureBuild(s2amdSolver* solver, int type, float scale)
 		: s(solver), solverType(type), stripScale(scale), cls(isPositionSolver(type) ? 1 : 0), needAdj(type == s2amd_solverJacobi),
 		  grouped(solver->optGroups != 0 && !needAdj),
+		  ldsGroups(grouped && (solver->optGroupPatience == 0 || solver->graphAge >= solver->groupPatienceNow)),
 		  // strips pay off through the lean / persistent strip kernels, which exist for the soft contact sweeps
 		  wantStrips(grouped && solver->optStrips != 0 && !solver->stripsRejected && solver->graphAge >= solver->stripPatienceNow &&
 					 (solver->optStripsAnySolver != 0 || isSoftFamily(type) || genericWanted(solver))),
@@ -1628,7 +1630,7 @@ struct StructureBuild
 	bool onlyStripsMissing() const
 	{
 		const bool colourFree = s->inc.colourFreePlaced && !needAdj;
-		return !s->structureDirty && cls == s->orderSolverClass && grouped == s->orderGrouped && wantStrips && !s->orderStrips && s->adjValid && !colourFree &&
+		return !s->structureDirty && cls == s->orderSolverClass && grouped == s->orderGrouped && ldsGroups == s->orderLdsGroups && wantStrips && !s->orderStrips && s->adjValid && !colourFree &&
 			   residentWanted == s->orderResident && needAdj == s->orderColourless;
 	}
 
@@ -1637,7 +1639,7 @@ struct StructureBuild
 	{
 		// (contacts placed into a structure built for s2Solve_Jacobi took any free position, whatever its colour: only Jacobi can run on that)
 		const bool colourFree = s->inc.colourFreePlaced && !needAdj;
-		return !s->structureDirty && cls == s->orderSolverClass && grouped == s->orderGrouped && wantStrips == s->orderStrips && (!wantStrips || stripBodiesFor(s, solverType) == s->orderStripBodies) && s->adjValid && !colourFree &&
+		return !s->structureDirty && cls == s->orderSolverClass && grouped == s->orderGrouped && ldsGroups == s->orderLdsGroups && wantStrips == s->orderStrips && (!wantStrips || stripBodiesFor(s, solverType) == s->orderStripBodies) && s->adjValid && !colourFree &&
 			   residentWanted == s->orderResident && needAdj == s->orderColourless;
 	}
 
@@ -1764,7 +1766,7 @@ struct StructureBuild
 		cPart.assign((size_t)C, -1), jPart.assign((size_t)J, -1);
 		groupCount = 0;
 		flags = s->hBodyFlags;
-		if (grouped && (C > 0 || J > 0))
+		if (ldsGroups && (C > 0 || J > 0))
 		{
 			UnionFind uf(nb);
 			auto link = [&](int a, int b) {
@@ -1839,7 +1841,7 @@ struct StructureBuild
 					return groupOfRoot[root];
 				}
 				int n = islandBodies[root];
-				if (n > s->optMaxGroupBodies)
+				if (n > s->optMaxGroupBodies || !ldsGroups)
 				{
 					groupOfRoot[root] = -1;
 					return -1;
@@ -2797,6 +2799,7 @@ struct StructureBuild
 		s->orderResident = residentWanted;
 		s->orderColourless = needAdj;
 		s->orderGrouped = grouped;
+		s->orderLdsGroups = ldsGroups;
 		if (getenv("S2AMD_DEBUG"))
 		{
 			int real = 0;

@@ -38,6 +38,7 @@
 #define TREE_SMALL TREE_THREADS // a segment this short is finished by one task
 #define TREE_BATCH 8				 // loads a lane has in flight in the passes over a long segment
 #define TREE_TASK_INTS 5		 // start, end, pre-order index of its node, the parent's node id, which child of it
+#define TREE_POLL_LIMIT (1u << 22) // polls of a workgroup waiting for its task before the build is declared starved (about a second)
 
 static_assert(sizeof(s2amdTreeNode) == 48, "s2TreeNode is 48 bytes (include/solver2d/dynamic_tree.h:14-41)");
 
@@ -118,22 +119,8 @@ S2_DEV void treeReport(TreeView& t, int n, int newRoot)
 } // namespace
 
 // ---- stage 4: the shapes the refit re-inflated enlarge their proxies ----
-__global__ __launch_bounds__(S2_BLOCK) void treeEnlargeKernel(const s2amdShape* shapes, int ns, TreeViews* views, const unsigned int* stepFailed)
+S2_DEV void treeEnlargeOne(const s2amdShape& sh, TreeViews* views)
 {
-	if (stepFailed != nullptr && *stepFailed != 0u)
-	{
-		return; // (the step will be repeated: stage 4 stood down, the flags are the previous step's)
-	}
-	const int si = blockIdx.x * blockDim.x + threadIdx.x;
-	if (si >= ns)
-	{
-		return;
-	}
-	const s2amdShape& sh = shapes[si];
-	if (sh.type == S2AMD_SHAPE_FREE || sh.enlarged == 0)
-	{
-		return;
-	}
 	const int type = sh.proxyKey & 0xF; // S2_PROXY_TYPE, src/broad_phase.h:18
 	if (type != 1 && type != 2)
 	{
@@ -162,6 +149,45 @@ __global__ __launch_bounds__(S2_BLOCK) void treeEnlargeKernel(const s2amdShape* 
 		}
 		t.nodes[p].enlarged = 1;
 		p = t.nodes[p].parent;
+	}
+}
+
+__global__ __launch_bounds__(S2_BLOCK) void treeEnlargeKernel(const s2amdShape* shapes, int ns, TreeViews* views, const unsigned int* stepFailed)
+{
+	if (stepFailed != nullptr && *stepFailed != 0u)
+	{
+		return; // (the step will be repeated: stage 4 stood down, the flags are the previous step's)
+	}
+	const int si = blockIdx.x * blockDim.x + threadIdx.x;
+	if (si >= ns)
+	{
+		return;
+	}
+	const s2amdShape& sh = shapes[si];
+	if (sh.type == S2AMD_SHAPE_FREE || sh.enlarged == 0)
+	{
+		return;
+	}
+	treeEnlargeOne(sh, views);
+}
+
+// ... from the list of re-inflated shapes the step's own read-back has just made (world.hip: stepBackKernel; {count, -, -, -, entries}):
+// a few hundred entries on a settled world instead of a look at every shape record (17 us at 27,000 shapes)
+__global__ __launch_bounds__(S2_BLOCK) void treeEnlargeListKernel(const s2amdShape* shapes, int ns, const int32_t* list, TreeViews* views, const unsigned int* stepFailed)
+{
+	if (stepFailed != nullptr && *stepFailed != 0u)
+	{
+		return;
+	}
+	const int count = list[0] < ns ? list[0] : ns;
+	const s2amdMovedBox* moved = (const s2amdMovedBox*)(list + 4);
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
+	{
+		const int si = moved[i].shape;
+		if (si >= 0 && si < ns)
+		{
+			treeEnlargeOne(shapes[si], views);
+		}
 	}
 }
 
@@ -477,7 +503,9 @@ __global__ __launch_bounds__(TREE_THREADS) void treeBuildTasksKernel(TreeViews* 
 				const int slot = atomicAdd(t.qstate + 0, 1);
 				if (slot < M)
 				{
-					for (;;)
+					// (bounded: a queue that starves -- a count that does not add up -- ends the build with error 5 instead of holding
+					// the device; a second or so of polls, five thousand times the longest rebuild measured)
+					for (unsigned int polls = 0;; ++polls)
 					{
 						if (__atomic_load_n(t.ready + slot, __ATOMIC_RELAXED) != 0)
 						{
@@ -486,6 +514,12 @@ __global__ __launch_bounds__(TREE_THREADS) void treeBuildTasksKernel(TreeViews* 
 						}
 						if (__atomic_load_n(t.qstate + 3, __ATOMIC_RELAXED) != 0)
 						{
+							break;
+						}
+						if (polls >= TREE_POLL_LIMIT)
+						{
+							atomicExch(t.state + 2, 5);
+							atomicExch(t.qstate + 3, 1);
 							break;
 						}
 						__builtin_amdgcn_s_sleep(8);
@@ -1117,6 +1151,13 @@ void launchTreeEnlarge(s2amdSolver* s, hipStream_t st, const unsigned int* stepF
 		return;
 	}
 	treesJoin(s, st);
+	if (s->stepBackListFresh && s->dStepBack.p != nullptr)
+	{
+		const int blocks = (s->shapeCapacity + S2_BLOCK - 1) / S2_BLOCK; // (everything may have moved; a block without an entry is gone at once)
+		treeEnlargeListKernel<<<dim3((unsigned)blocks), dim3(S2_BLOCK), 0, st>>>((const s2amdShape*)s->dShapes.p, s->shapeCapacity, (const int32_t*)s->dStepBack.p,
+																				 (TreeViews*)s->trees->dViews.p, stepFailed);
+		return;
+	}
 	treeEnlargeKernel<<<dim3((unsigned)((s->shapeCapacity + S2_BLOCK - 1) / S2_BLOCK)), dim3(S2_BLOCK), 0, st>>>((const s2amdShape*)s->dShapes.p, s->shapeCapacity,
 																											  (TreeViews*)s->trees->dViews.p, stepFailed);
 }

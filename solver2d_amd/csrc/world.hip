@@ -139,9 +139,19 @@ __global__ __launch_bounds__(S2_BLOCK) void movedCountKernel(const s2amdShape* s
 	}
 }
 
+// (blocks behind the list's tiles, if any, write the step's poses: stepPosesKernel's work without its launch)
 __global__ __launch_bounds__(S2_BLOCK) void movedWriteKernel(const s2amdShape* shapes, int shapeCapacity, const int* order, int n, const int* counts, int32_t* out,
-															int capacity)
+															int capacity, int tiles, const s2amdBody* bodies, const float* origins, int nb, float4* poses)
 {
+	if ((int)blockIdx.x >= tiles)
+	{
+		const int i = ((int)blockIdx.x - tiles) * S2_BLOCK + (int)threadIdx.x;
+		if (i < nb)
+		{
+			poses[i] = make_float4(origins[2 * i], origins[2 * i + 1], bodies[i].rot[0], bodies[i].rot[1]);
+		}
+		return;
+	}
 	__shared__ int waves[S2_BLOCK / 64];
 	__shared__ int base;
 	int sh = 0;
@@ -176,7 +186,7 @@ __global__ __launch_bounds__(S2_BLOCK) void movedWriteKernel(const s2amdShape* s
 		at += waves[w];
 	}
 	at += __popcll(mask & ((1ull << lane) - 1ull));
-	if (blockIdx.x == gridDim.x - 1 && threadIdx.x == blockDim.x - 1)
+	if ((int)blockIdx.x == tiles - 1 && threadIdx.x == blockDim.x - 1)
 	{
 		out[0] = at + (mine ? 1 : 0);
 	}
@@ -245,10 +255,11 @@ int enqueueStepBack(s2amdSolver* s)
 		return rc;
 	}
 	movedCountKernel<<<dim3((unsigned)tiles), dim3(S2_BLOCK), 0, s->stream>>>((const s2amdShape*)s->dShapes.p, ns, (const int*)s->dRefitOrder.p, n, (int*)s->dScanTmp.p);
-	movedWriteKernel<<<dim3((unsigned)tiles), dim3(S2_BLOCK), 0, s->stream>>>((const s2amdShape*)s->dShapes.p, ns, (const int*)s->dRefitOrder.p, n, (const int*)s->dScanTmp.p,
-																			   (int32_t*)base, ns);
-	stepPosesKernel<<<gridFor((size_t)nb), dim3(S2_BLOCK), 0, s->stream>>>((const s2amdBody*)s->dBodies.p, (const float*)s->dOrigins.p, nb, (float4*)(base + poseOffset));
+	movedWriteKernel<<<dim3((unsigned)(tiles + (nb + S2_BLOCK - 1) / S2_BLOCK)), dim3(S2_BLOCK), 0, s->stream>>>(
+		(const s2amdShape*)s->dShapes.p, ns, (const int*)s->dRefitOrder.p, n, (const int*)s->dScanTmp.p, (int32_t*)base, ns, tiles, (const s2amdBody*)s->dBodies.p,
+		(const float*)s->dOrigins.p, nb, (float4*)(base + poseOffset));
 	HIP_TRY(hipGetLastError());
+	s->stepBackListFresh = true; // (launchTreeEnlarge: the re-inflated shapes are a list on the device from here on)
 	HIP_TRY(hipMemcpyAsync(s->hostStepBack, base, 16 + (size_t)guess * sizeof(s2amdMovedBox), hipMemcpyDeviceToHost, s->stream));
 	HIP_TRY(hipMemcpyAsync(s->hostStepBack + hostPose, base + poseOffset, (size_t)nb * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
 	s->stepBackBoxes = guess;
@@ -754,6 +765,7 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 			// ... and under the soft contact solvers a manifold between bodies of the strips takes a free position of a strip or
 			// seam round (solver_internal.h: IncrementalStrips); every other flip rebuilds the structure
 			bool handled = false;
+			bool byGroups = false; // (a flipped manifold on a body an LDS group holds: SolverRest::groupPatienceNow)
 			const bool jacobi = s->inc.valid && s->inc.ignoreColours && s->optIncremental != 0;
 			const bool strips = s->inc.valid && s->stripInc.valid && s->optIncremental != 0;
 			// ... and (r4) a manifold between bodies of the global part takes a free colour position or, a hub's, a free position of
@@ -774,6 +786,7 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 						s->inc.positionOfSlot[(size_t)i] == -1)
 					{
 						flipped.push_back(ContactChange{i, s->hContactA[(size_t)i], s->hContactB[(size_t)i]});
+						byGroups = byGroups || ownedByLdsGroup(s, s->hContactA[(size_t)i]) || ownedByLdsGroup(s, s->hContactB[(size_t)i]);
 						// (r5: ... or, where it fits no strip round, an overflow position behind the strips: the steps run sliced until a
 						// worker thread's structure is adopted -- solver_internal.h: IncrementalStrips)
 						placeable = placeable && (jacobi || inGlobalPart(s->hContactA[(size_t)i], s->hContactB[(size_t)i]) ||
@@ -801,6 +814,7 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 				{
 					s->dirtyReason = "watched manifold flipped";
 				}
+				s->dirtyByGroups = s->dirtyByGroups || byGroups;
 				noteGraphChanged(s);
 			}
 		}
@@ -836,14 +850,15 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 		// (... and the proxies of the shapes it re-inflated enlarge the device's trees, src/world.c:283-290 -- once the rebuild running
 		// beside this step is through: behind the pair query's own kernels when one rides along, which do not read the trees)
 		const bool pairsRide = s->optPairsInStep != 0 && s->pairQueryUsed && fallbacks == 0 && nearRetries == 0 && s->liveShapes >= 2;
-		if (!(pairsRide && treesActive(s)))
-		{
-			launchTreeEnlarge(s, st, s->persistValid ? s->persist.deviceError : nullptr);
-		}
 		const bool stepBack = s->optStepReadback != 0 && s->refitOrderCount > 0 && nb > 0 && ns > 0;
+		s->stepBackListFresh = false;
 		if (stepBack && (rc = enqueueStepBack(s)) != 0)
 		{
 			return rc;
+		}
+		if (!(pairsRide && treesActive(s)))
+		{
+			launchTreeEnlarge(s, st, s->persistValid ? s->persist.deviceError : nullptr);
 		}
 		// Stage 1 of the NEXT step behind stage 4 of this one: the pair query reads what the refit just wrote (the re-inflated fat boxes,
 		// the move flags) and its results come back with this step's counters -- s2amd_world_find_pairs then costs no device round trip.
@@ -1153,7 +1168,7 @@ int s2amd_world_download_step(s2amdSolver* s, float* poses, int32_t bodyCapacity
 		}
 		movedCountKernel<<<dim3((unsigned)tiles), dim3(S2_BLOCK), 0, s->stream>>>((const s2amdShape*)s->dShapes.p, s->shapeCapacity, order, n, (int*)s->dScanTmp.p);
 		movedWriteKernel<<<dim3((unsigned)tiles), dim3(S2_BLOCK), 0, s->stream>>>((const s2amdShape*)s->dShapes.p, s->shapeCapacity, order, n, (const int*)s->dScanTmp.p,
-																				   (int32_t*)base, want);
+																				   (int32_t*)base, want, tiles, nullptr, nullptr, 0, nullptr);
 		HIP_TRY(hipGetLastError());
 	}
 	if (poses && nb > 0)

@@ -115,13 +115,16 @@ WHOLE_STEP_CASES += [("mixed", 24, name, 60) for name in wire.SOLVER_NAMES] + [(
 
 
 @pytest.mark.parametrize("scene,p0,solver_name,steps", WHOLE_STEP_CASES)
-def test_native_shim_whole_step_on_the_gpu(scene, p0, solver_name, steps):
+def test_native_shim_whole_step_on_the_gpu(scene, p0, solver_name, steps, monkeypatch):
     """oracle/ref_hook.c: s2ref_use_amd_world: the library's exported s2World_Step keeps the reference's stage 1 and 2 (dynamic
     trees, contact pool) and runs stage 3, the solve and stage 4 on the resident world chain (s2amd_world_step), bringing
     back bodies, separations and re-inflated boxes every step and the manifolds on demand.  The trajectory must be the one
     the solver-only shim produces -- the device's narrow phase and refit are bit-exact restatements of the host's, the
     constraint graph and hence the sweep order are the same --, bit for bit: bodies, manifolds, impulses, pair table."""
     import ctypes
+    # (the same structure POLICY on both routes: "group_patience" -- LDS groups stand back where created contacts keep hitting them -- is driven
+    # by what the placement of the whole-step route could not take, events the solve-only route, which builds for every new contact, never sees)
+    monkeypatch.setenv("S2AMD_OPTIONS", "group_patience=0")
     vel, pos = common.DEFAULT_ITERS[solver_name]
     L = refbind.lib()
     for f in (L.s2ref_use_amd, L.s2ref_use_amd_world):

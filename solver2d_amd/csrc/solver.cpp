@@ -957,6 +957,10 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	{
 		s->optBodyWarm = value;
 	}
+	else if (strcmp(key, "flip_colours") == 0)
+	{
+		s->optFlipColours = value;
+	}
 	else if (strcmp(key, "group_patience") == 0)
 	{
 		s->optGroupPatience = value;

@@ -67,6 +67,7 @@ bool adjInsert(Patcher& p, int body, int key)
 		const int cap = std::max(8, 2 * inc.adjCapacity[(size_t)body]);
 		if ((size_t)inc.adjUsed + (size_t)cap > inc.adjList.size())
 		{
+			inc.adjFailure = 1;
 			return false;
 		}
 		for (int i = 0; i < r.y; ++i)
@@ -95,6 +96,7 @@ bool adjInsert(Patcher& p, int body, int key)
 		const int n = inc.heavy[0];
 		if (n + 1 >= (int)inc.heavy.size())
 		{
+			inc.adjFailure = 2;
 			return false;
 		}
 		inc.heavy[(size_t)n + 1] = body;
@@ -538,9 +540,9 @@ bool stripPlace(s2amdSolver* s, Patcher& p, const ContactChange& ch)
 		IncrementalStrips::Round& round = m.rounds[(size_t)spare.front()];
 		const int r = round.round;
 		const int begin = round.freePositions.back(), end = round.freePositions.front() + 1;
-		if (r != n || r >= 32)
+		if (r != n || r >= 32 || r + 1 > m.roundLimit[table])
 		{
-			return false;
+			return false; // (... or one round more than this solver's kernel has a layout for: the overflow positions, or a rebuild)
 		}
 		if (table == 0)
 		{
@@ -865,7 +867,7 @@ bool incrementalApply(s2amdSolver* s, const std::vector<ContactChange>& changes)
 		if (!removeEntry(s, p, ch.slot))
 		{
 			// (an entry in an LDS group's tables, unless strips hold it: SolverRest::groupPatienceNow)
-			s->dirtyByGroups = inc.positionOfSlot[(size_t)ch.slot] == -2 && !(s->stripInc.valid && ch.slot < (int)s->stripInc.positionOfSlot.size() && s->stripInc.positionOfSlot[(size_t)ch.slot] >= 0);
+			s->dirtyByGroups = inc.positionOfSlot[(size_t)ch.slot] == -2 && (ownedByLdsGroup(s, s->hContactA[(size_t)ch.slot]) || ownedByLdsGroup(s, s->hContactB[(size_t)ch.slot]));
 			return giveUp("old entry of the slot not removable");
 		}
 		if (ch.a < 0)
@@ -965,7 +967,7 @@ bool incrementalApply(s2amdSolver* s, const std::vector<ContactChange>& changes)
 				{
 					s->slackShift = std::min(s->slackShift + 1, 3);
 					s->slackBumped = true;
-					return giveUp("incidence list full");
+					return giveUp(inc.adjFailure == 2 ? "list of heavy bodies full (tail)" : "incidence list full");
 				}
 				inc.inserted += 1;
 				inc.tailPlaced += 1;
@@ -1022,7 +1024,7 @@ bool incrementalApply(s2amdSolver* s, const std::vector<ContactChange>& changes)
 		{
 			s->slackShift = std::min(s->slackShift + 1, 3);
 			s->slackBumped = true;
-			return giveUp("incidence lists full");
+			return giveUp(inc.adjFailure == 2 ? "list of heavy bodies full" : "incidence lists full");
 		}
 		inc.inserted += 1;
 		s->placedTotal += 1;
@@ -1124,12 +1126,7 @@ bool canDeferCreated(const s2amdSolver* s, int slot, int a, int b)
 // a watched manifold between these bodies got its first points: can it take a place in the strips (instead of a rebuild)?
 bool ownedByLdsGroup(const s2amdSolver* s, int body)
 {
-	if (body < 0 || body >= (int)s->hBodyFlagsFinal.size() || (s->hBodyFlagsFinal[(size_t)body] & S2F_IN_GROUP) == 0)
-	{
-		return false;
-	}
-	const IncrementalStrips& m = s->stripInc;
-	return !(m.valid && body < (int)m.ownerStrip.size() && m.ownerStrip[(size_t)body] >= 0);
+	return body >= 0 && body < (int)s->hBodyLdsOwned.size() && s->hBodyLdsOwned[(size_t)body] != 0;
 }
 
 bool stripCanPlace(const s2amdSolver* s, int a, int b)
@@ -1178,7 +1175,11 @@ bool overflowCanPlace(const s2amdSolver* s, int a, int b)
 bool tailCanPlace(const s2amdSolver* s, int a, int b)
 {
 	const int nb = (int)s->hBodyFlagsFinal.size();
-	if (!s->inc.valid || s->inc.ignoreColours || s->inc.tailFree.empty() || s->optIncremental == 0 || s->structureDirty || a < 0 || b < 0 || a >= nb || b >= nb || a == b)
+	// (r6: with or without a tail -- a pile of boxes pressed together has hundreds of bodies with more than S2_HUB_DEGREE potential
+	// contacts and no colour small enough to make a tail; their manifolds take a free colour position like any created contact, and only
+	// the one that finds none -- incrementalApply -- costs the build that every one of them used to cost: 134 of 200 wreck steps under XPBD)
+	if (!s->inc.valid || s->inc.ignoreColours || (s->optFlipColours == 0 && s->inc.tailFree.empty()) || s->optIncremental == 0 || s->structureDirty || a < 0 || b < 0 ||
+		a >= nb || b >= nb || a == b)
 	{
 		return false;
 	}

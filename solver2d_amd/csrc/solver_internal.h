@@ -227,6 +227,7 @@ struct IncrementalGlobal
 	std::vector<int> adjCapacity;		// per body
 	std::vector<int> adjList;			// device-sized mirror
 	int adjUsed = 0;					// first never-used entry of adjList
+	int adjFailure = 0;					// why adjInsert last said no: 1 no room to move a list to, 2 the list of heavy bodies is full
 	std::vector<int> heavy;				// [0] = count, then body slots; size = capacity + 1
 	// patch list of the current call: {address lo, address hi, value, 0}
 	std::vector<uint4> patches;
@@ -273,6 +274,10 @@ struct IncrementalStrips
 	std::vector<int> bodyOffset[2];		// per group: its first entry in roundMask
 	std::vector<int> positionOfSlot;	// contact slot -> strip position, -1
 	long placed = 0, roundsOpened = 0;
+	// rounds a strip / a seam may have OPEN under the solver these strips were built for: s2Solve_SoftStep's resident kernel exists in
+	// the <3, 2> layout only (wide_kernel.hip: wideExtraRecords) -- a seventh interior or third seam round opened for a created contact
+	// left it without a kernel, and the step rebuilt the strips instead (wreck-200 under SoftStep, r6: 50 such steps of 200, 5-40 ms each)
+	int roundLimit[2] = {S2_STRIP_ROUNDS_MAX, S2_PERSIST_B_ROUNDS};
 	// A body that JOINS an island (a ball thrown into the pile).  A writable body without a single constraint in
 	// the strips is owned by whichever strip the build put it in; when its first contact is with a body of another strip it MOVES there
 	// -- the receiving strip's body list is written again behind the table (one more entry; the descriptor's two words follow it), the
@@ -340,6 +345,7 @@ struct SolverStructure
 	int watchedCount = 0;
 	DevBuf dWatched;
 	std::vector<uint32_t> hBodyFlagsFinal; // ... + S2F_IN_GROUP as the last structure build uploaded them
+	std::vector<uint8_t> hBodyLdsOwned; // per body: an LDS group or a resident island (not a strip) owns it
 	DevBuf dBodyFlags;
 
 	// working SoA
@@ -568,7 +574,12 @@ struct SolverRest
 	// where every contact has a place.  Steps the graph must have been quiet for before groups are built again; 0: at once.
 	int groupPatienceNow = 0;
 	bool dirtyByGroups = false; // the rebuild that is due was forced by something an LDS group / resident island could not take
+	// ... and the sequential tail's room for created contacts (S2_TAIL_SLACK positions, S2_TAIL_BODY_SLACK bodies) times 2^this: raised when
+	// structures die young of a hub's manifold that gained its points and found the tail full
+	int tailSlackShift = 0;
+	bool dirtyByWatched = false;
 	int optGroupPatience = 1;	// "group_patience" 0: groups whatever they cost (tests; round 5's behaviour)
+	int optFlipColours = 1;		// "flip_colours" 0: a hub's manifold that gains its points is placed only where a sequential tail has room (round 5)
 	bool stripPatienceSet = false; // "strip_patience" was set by the caller (else a resident world builds its strips at once: stripPatienceBase)
 	int optStripsAnySolver = 0; // tests: strips for every solver and with joints (through the generic group interpreter)
 
@@ -671,6 +682,15 @@ inline void noteGraphChanged(s2amdSolver* s, bool newWorld = false)
 		s->groupPatienceNow = 0;
 	}
 	s->dirtyByGroups = false;
+	if (!newWorld && s->dirtyByWatched && s->graphAge < 8)
+	{
+		s->tailSlackShift = std::min(s->tailSlackShift + 1, 4);
+	}
+	else if (newWorld || s->graphAge >= 256)
+	{
+		s->tailSlackShift = 0;
+	}
+	s->dirtyByWatched = false;
 	if (newWorld || s->optStripPatience == 0)
 	{
 		s->stripPatienceNow = base; // (strip_patience 0 as an OPTION means "always at once", no backing off: tests)

@@ -197,6 +197,7 @@ int refreshShadows(s2amdSolver* s, const s2amdBody* bodies, int nb, const s2amdC
 			{
 				hubTouched = true;
 				s->dirtyReason = "watched manifold flipped";
+				s->dirtyByWatched = true;
 				s->dirtyByGroups = s->dirtyByGroups || ownedByLdsGroup(s, c.bodyA) || ownedByLdsGroup(s, c.bodyB);
 			}
 		}
@@ -518,6 +519,7 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 		{
 			s->structureDirty = true;
 			s->dirtyReason = "strips with placed contacts off the persistent kernel";
+			s->graphAge = 0; // (the graph HAS just changed: no search over strip widths -- seven more builds, 40 ms at base 200 -- in this step)
 			if ((rc = buildStructure(s, params->solverType)) != 0)
 			{
 				return rc;

@@ -213,7 +213,7 @@ struct EdgeList
 // rebuild (IncrementalGlobal, solver_incremental.cpp).  *positions then has -1 at the free positions.
 void colourPart(const std::vector<int>& ids, const std::vector<int>& ea, const std::vector<int>& eb, const std::vector<uint8_t>& conflict,
 				int bodyCount, SweepSet& set, std::vector<int>& batchOffsetsOut, bool& hasTailOut, std::vector<int>* positions, int balanced = 0,
-				IncrementalGlobal* inc = nullptr, int spareColours = 0, int slackShift = 0, bool colourless = false, int roundSlack = 0)
+				IncrementalGlobal* inc = nullptr, int spareColours = 0, int slackShift = 0, bool colourless = false, int roundSlack = 0, int tailSlack = S2_TAIL_SLACK)
 {
 	std::vector<int> color, partOrder, partOffsets;
 	int cc;
@@ -297,7 +297,7 @@ void colourPart(const std::vector<int>& ids, const std::vector<int>& ea, const s
 		{
 			// ... and behind them free positions for created contacts no parallel colour can take (IncrementalGlobal::tailFree)
 			const int first = (int)laidOut.size();
-			laidOut.resize(laidOut.size() + (size_t)S2_TAIL_SLACK, -1);
+			laidOut.resize(laidOut.size() + (size_t)tailSlack, -1);
 			inc->tailBegin = base + tailStart, inc->tailEnd = base + (int)laidOut.size();
 			for (int k = (int)laidOut.size() - 1; k >= first; --k)
 			{
@@ -791,13 +791,16 @@ static int buildAdjacency(s2amdSolver* s, const std::vector<uint8_t>& conflict, 
 	int total = 0;
 	for (int i = 0; i < nb; ++i)
 	{
-		const int cap = s->hBodyLive[(size_t)i] && conflict[(size_t)i] ? ((count[(size_t)i] + std::max(4 << s->slackShift, count[(size_t)i] / 4) + 3) & ~3) : 0;
+		const int cap = s->hBodyLive[(size_t)i] && conflict[(size_t)i] ? ((count[(size_t)i] + std::max(4 << std::min(s->slackShift, 1), count[(size_t)i] / 4) + 3) & ~3) : 0;
 		inc.adjRange[(size_t)i] = make_int2(total, 0);
 		inc.adjCapacity[(size_t)i] = cap;
 		total += cap;
 	}
 	inc.adjUsed = total;
-	inc.adjList.assign((size_t)total + (size_t)std::max(1024, (total / 4) << s->slackShift), 0); // room for lists that outgrow their slack and move to the end
+	// room for lists that outgrow their slack and move to the end: as much again as the lists themselves, whatever the slack -- entries
+	// nobody uses cost a memset, while lists that found no room cost a build each (r6: 30 of the Tumbler fill's 54, 25 of 90 under XPBD in
+	// the wrecked pyramid) and the slack they then doubled made every later build dearer (8 entries more per body: 2.7 ms of upload)
+	inc.adjList.assign((size_t)total + (size_t)std::max(4096, total), 0);
 	for (int k = 0; k < GC; ++k)
 	{
 		if (cs.order[(size_t)k] < 0)
@@ -824,7 +827,9 @@ static int buildAdjacency(s2amdSolver* s, const std::vector<uint8_t>& conflict, 
 			heavyBodies.push_back(i);
 		}
 	}
-	const int heavyCap = (((int)heavyBodies.size() + 16) + 15) & ~15;
+	// (room for bodies that become heavy under placed contacts: a wave of the body-centric launches per entry, idle while it is free --
+	// 16 were used up in a step or two of a pile that is being pressed together: 29 of the Tumbler fill's 54 builds, and with 64 still 27)
+	const int heavyCap = (((int)heavyBodies.size() + std::max(1024, (int)heavyBodies.size())) + 15) & ~15;
 	inc.heavy.assign((size_t)heavyCap + 1, 0);
 	inc.heavy[0] = (int)heavyBodies.size();
 	std::copy(heavyBodies.begin(), heavyBodies.end(), inc.heavy.begin() + 1);
@@ -2110,7 +2115,8 @@ struct StructureBuild
 		s->inc = IncrementalGlobal();
 		const bool slack = s->optIncremental != 0 && s->optMessage == 0;
 		s->inc.ignoreColours = needAdj;
-		colourPart(ids, a, b, conflict, nb, cs, cs.batchOffsets, cs.hasTail, &pos, 0, slack ? &s->inc : nullptr, needAdj ? 0 : s->spareColours, s->slackShift, needAdj);
+		colourPart(ids, a, b, conflict, nb, cs, cs.batchOffsets, cs.hasTail, &pos, 0, slack ? &s->inc : nullptr, needAdj ? 0 : s->spareColours, s->slackShift, needAdj, 0,
+				   S2_TAIL_SLACK << s->tailSlackShift);
 		cs.globalCount = (int)cs.order.size(); // (with the free positions of the slack layout)
 		cs.local.assign((size_t)cs.globalCount, make_int2(0, 0));
 		if (slack)
@@ -2142,7 +2148,8 @@ struct StructureBuild
 			}
 			s->inc.tailBodySlot.clear();
 			s->inc.tailBodyCount = s->inc.tailBodyCapacity = 0;
-			if ((int)bodies.size() + S2_TAIL_BODY_SLACK > 2800)
+			const int tailBodySlack = S2_TAIL_BODY_SLACK << s->tailSlackShift;
+			if ((int)bodies.size() + tailBodySlack > 2800)
 			{
 				s->inc.tailBegin = s->inc.tailEnd = 0;
 				s->inc.tailFree.clear();
@@ -2168,14 +2175,14 @@ struct StructureBuild
 				t.cBatchOffsets = {0, 1};
 				t.jBatchOffsets = {0, 0};
 				const bool tailSlack = slack && !s->inc.tailFree.empty();
-				t.maxBodies = (int)bodies.size() + (tailSlack ? S2_TAIL_BODY_SLACK : 0); // (the launch's LDS: room for the bodies created contacts bring along)
+				t.maxBodies = (int)bodies.size() + (tailSlack ? tailBodySlack : 0); // (the launch's LDS: room for the bodies created contacts bring along)
 				if (tailSlack)
 				{
 					for (size_t i = 0; i < bodies.size(); ++i)
 					{
 						s->inc.tailBodySlot[(int)((uint32_t)bodies[i] & ~S2G_OWNED)] = (int)i;
 					}
-					s->inc.tailBodyCount = (int)bodies.size(), s->inc.tailBodyCapacity = (int)bodies.size() + S2_TAIL_BODY_SLACK;
+					s->inc.tailBodyCount = (int)bodies.size(), s->inc.tailBodyCapacity = (int)bodies.size() + tailBodySlack;
 				}
 			}
 		}
@@ -2465,6 +2472,19 @@ struct StructureBuild
 			}
 		}
 		s->hBodyFlagsFinal = flags;
+		// (which of the bodies with S2F_IN_GROUP an LDS group or a resident island holds -- their tables take no created contact --, as
+		// against a strip: what SolverRest::groupPatienceNow counts)
+		s->hBodyLdsOwned.assign((size_t)nb, 0);
+		for (const HostGroupTable* t : {&s->hGroups, &s->hResident})
+		{
+			for (int id : t->bodyIds)
+			{
+				if ((uint32_t)id & S2G_OWNED)
+				{
+					s->hBodyLdsOwned[(size_t)((uint32_t)id & ~S2G_OWNED)] = 1;
+				}
+			}
+		}
 		s->looseBodies = 0;
 		for (int i = 0; i < nb; ++i)
 		{
@@ -2561,7 +2581,7 @@ struct StructureBuild
 			rebuild = true;
 			return S2AMD_OK;
 		}
-		if ((rc = uploadGroupTable(s, s->hGroups, s->dGroups)) != 0 || (rc = uploadGroupTable(s, s->hContactTail, s->dContactTail, s->hContactTail.count() > 0 ? (size_t)S2_TAIL_BODY_SLACK : 0)) != 0 ||
+		if ((rc = uploadGroupTable(s, s->hGroups, s->dGroups)) != 0 || (rc = uploadGroupTable(s, s->hContactTail, s->dContactTail, s->hContactTail.count() > 0 ? (size_t)(S2_TAIL_BODY_SLACK << s->tailSlackShift) : 0)) != 0 ||
 			(rc = uploadGroupTable(s, s->hJointTail, s->dJointTail)) != 0 ||
 			(rc = uploadGroupTable(s, s->hStripA, s->dStripA, s->hStripA.count() > 0 ? (size_t)32 * (size_t)(s->hStripA.maxBodies + S2_STRIP_ADOPT_SLACK) : 0)) != 0 ||
 			(rc = uploadGroupTable(s, s->hStripB, s->dStripB)) != 0)
@@ -2623,6 +2643,10 @@ struct StructureBuild
 			return;
 		}
 		m.base = stripBaseC, m.end = stripBaseC + cs.stripCount;
+		if (solverType == s2amd_solverSoftStep)
+		{
+			m.roundLimit[0] = S2_STRIP_ROUNDS, m.roundLimit[1] = 2;
+		}
 		m.roundOfPosition.assign((size_t)cs.stripCount, -1);
 		m.ownerStrip.assign((size_t)nb, -1), m.ownerSlot.assign((size_t)nb, -1);
 		m.positionOfSlot.assign((size_t)s->contactCapacity, -1);

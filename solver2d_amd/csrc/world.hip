@@ -770,7 +770,7 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 			const bool strips = s->inc.valid && s->stripInc.valid && s->optIncremental != 0;
 			// ... and (r4) a manifold between bodies of the global part takes a free colour position or, a hub's, a free position of
 			// the sequential tail (solver_internal.h: IncrementalGlobal::tailFree)
-			const bool tail = s->inc.valid && !s->inc.ignoreColours && !s->inc.tailFree.empty() && s->optIncremental != 0;
+			const bool tail = s->inc.valid && !s->inc.ignoreColours && s->optIncremental != 0 && (s->optFlipColours != 0 || !s->inc.tailFree.empty()); // (r6: a free colour position will do: tailCanPlace)
 			auto inGlobalPart = [&](int a, int b) { return tailCanPlace(s, a, b); };
 			if (jacobi || strips || tail)
 			{
@@ -813,8 +813,16 @@ int s2amd_world_step(s2amdSolver* s, const s2amdStepParams* params, s2amdWorldSt
 				if (!(s->inc.ignoreColours && s->optIncremental != 0))
 				{
 					s->dirtyReason = "watched manifold flipped";
+					s->dirtyByWatched = true;
 				}
 				s->dirtyByGroups = s->dirtyByGroups || byGroups;
+				static const bool debugPrep = getenv("S2AMD_DEBUG_PREP") != nullptr;
+				if (debugPrep)
+				{
+					fprintf(stderr, "[s2amd] watched flips %d not placed: jacobi %d strips %d tail %d (free %zu, bodies %d of %d, tail groups %d), watched %d, global %d of %d positions\n",
+							hSum->watchedFlips, jacobi ? 1 : 0, strips ? 1 : 0, tail ? 1 : 0, s->inc.tailFree.size(), s->inc.tailBodyCount, s->inc.tailBodyCapacity,
+							s->dContactTail.view.groupCount, s->watchedCount, s->contacts.globalCount, (int)s->contacts.order.size());
+				}
 				noteGraphChanged(s);
 			}
 		}

@@ -123,8 +123,9 @@ def test_native_shim_whole_step_on_the_gpu(scene, p0, solver_name, steps, monkey
     constraint graph and hence the sweep order are the same --, bit for bit: bodies, manifolds, impulses, pair table."""
     import ctypes
     # (the same structure POLICY on both routes: "group_patience" -- LDS groups stand back where created contacts keep hitting them -- is driven
-    # by what the placement of the whole-step route could not take, events the solve-only route, which builds for every new contact, never sees)
-    monkeypatch.setenv("S2AMD_OPTIONS", "group_patience=0")
+    # by what the placement of the whole-step route could not take, events the solve-only route, which builds for every new contact, never
+    # sees; "flip_colours" -- a hub's manifold that gains its points takes a colour position -- places where that route builds)
+    monkeypatch.setenv("S2AMD_OPTIONS", "group_patience=0,flip_colours=0")
     vel, pos = common.DEFAULT_ITERS[solver_name]
     L = refbind.lib()
     for f in (L.s2ref_use_amd, L.s2ref_use_amd_world):

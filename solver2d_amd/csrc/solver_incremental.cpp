@@ -167,7 +167,7 @@ static bool stripBodyIsFree(const s2amdSolver* s, int body)
 static bool stripCanAdopt(const s2amdSolver* s, int g)
 {
 	const IncrementalStrips& m = s->stripInc;
-	if (s->optStripAdopt == 0 || g < 0 || g >= (int)m.stripBodyCount.size() || m.adoptedBy[(size_t)g] >= S2_STRIP_ADOPT_SLACK || (int)s->hPersistDescs.size() != (int)m.stripBodyCount.size())
+	if (s->optStripAdopt == 0 || m.takeOnly || g < 0 || g >= (int)m.stripBodyCount.size() || m.adoptedBy[(size_t)g] >= S2_STRIP_ADOPT_SLACK || (int)s->hPersistDescs.size() != (int)m.stripBodyCount.size())
 	{
 		return false;
 	}
@@ -260,7 +260,7 @@ static bool stripHomeWhy(const s2amdSolver* s, int a, int b, int& table, int& gr
 					return false;
 				}
 			}
-			const bool room = mover && s->optStripAdopt != 0 && (int)s->hPersistDescs.size() == (int)m.stripBodyCount.size() && !m.seamBodyCount.empty() &&
+			const bool room = mover && s->optStripAdopt != 0 && !m.takeOnly && (int)s->hPersistDescs.size() == (int)m.stripBodyCount.size() && !m.seamBodyCount.empty() &&
 							  m.seamExtra[0][(size_t)group] + extraLeft <= S2_STRIP_ADOPT_SLACK && m.seamExtra[1][(size_t)group] + extraRight <= S2_STRIP_ADOPT_SLACK &&
 							  m.adoptedBy[(size_t)sm] + importsOf[0] <= S2_STRIP_ADOPT_SLACK && m.adoptedBy[(size_t)sm + 1] + importsOf[1] <= S2_STRIP_ADOPT_SLACK &&
 							  s->hPersistDescs[(size_t)sm].exportCount[1] + extraLeft <= 256 && s->hPersistDescs[(size_t)sm + 1].exportCount[0] + extraRight <= 256;

@@ -278,6 +278,10 @@ struct IncrementalStrips
 	// the <3, 2> layout only (wide_kernel.hip: wideExtraRecords) -- a seventh interior or third seam round opened for a created contact
 	// left it without a kernel, and the step rebuilt the strips instead (wreck-200 under SoftStep, r6: 50 such steps of 200, 5-40 ms each)
 	int roundLimit[2] = {S2_STRIP_ROUNDS_MAX, S2_PERSIST_B_ROUNDS};
+	// strips the OP INTERPRETER sweeps (generic_kernel.hip: every solver family but the soft ones): it finds its rounds and body lists in the
+	// group tables, which placement does not patch -- so a created contact takes a free position of a round the build laid out, between two
+	// bodies the strip or seam already lists, or nothing: no adopted body, no extended seam, no opened round, no overflow position
+	bool takeOnly = false;
 	// A body that JOINS an island (a ball thrown into the pile).  A writable body without a single constraint in
 	// the strips is owned by whichever strip the build put it in; when its first contact is with a body of another strip it MOVES there
 	// -- the receiving strip's body list is written again behind the table (one more entry; the descriptor's two words follow it), the
@@ -579,6 +583,7 @@ struct SolverRest
 	int tailSlackShift = 0;
 	bool dirtyByWatched = false;
 	int optGroupPatience = 1;	// "group_patience" 0: groups whatever they cost (tests; round 5's behaviour)
+	int optGenericPlace = 1;	// "generic_place" 0: the op interpreter's strips take no created contact (round 5)
 	int optFlipColours = 1;		// "flip_colours" 0: a hub's manifold that gains its points is placed only where a sequential tail has room (round 5)
 	bool stripPatienceSet = false; // "strip_patience" was set by the caller (else a resident world builds its strips at once: stripPatienceBase)
 	int optStripsAnySolver = 0; // tests: strips for every solver and with joints (through the generic group interpreter)
@@ -695,7 +700,7 @@ inline void noteGraphChanged(s2amdSolver* s, bool newWorld = false)
 	{
 		s->stripPatienceNow = base; // (strip_patience 0 as an OPTION means "always at once", no backing off: tests)
 	}
-	else if (stripsInUse && s->stripInc.valid)
+	else if (stripsInUse && s->stripInc.valid && !s->stripInc.takeOnly)
 	{
 		// strips that take created contacts in place (IncrementalStrips) die only of a contact that fits nowhere: they are worth
 		// building again AT ONCE -- in the step that found the contact, no colour-batch structure in between -- unless this one lived for

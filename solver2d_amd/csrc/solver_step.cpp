@@ -515,7 +515,9 @@ int doStep(s2amdSolver* s, const s2amdStepParams* params)
 		// multi-launch strip path (warm-start slot tables) needs the structure built again
 		Executor probe{s, s->stream, plan, isPositionSolver(params->solverType) ? 1 : 0, false};
 		int kind, warm;
-		if (s->stripInc.touched && s->dStripA.view.groupCount > 0 && !probe.persistPlan(kind, warm)) // (the op interpreter reads the group tables, which placement does not patch)
+		// (the op interpreter reads the group tables, which placement does not patch: it takes strips whose placed contacts sit in rounds the
+		// build laid out and nothing else -- IncrementalStrips::takeOnly)
+		if (s->stripInc.touched && s->dStripA.view.groupCount > 0 && !probe.persistPlan(kind, warm) && !(s->stripInc.takeOnly && probe.genericPlan()))
 		{
 			s->structureDirty = true;
 			s->dirtyReason = "strips with placed contacts off the persistent kernel";

@@ -1594,7 +1594,8 @@ struct StructureBuild
 		  // PGS_Soft (`wide` off) a seam round that outgrows 256 positions is dealt in two passes, which cost them 0.26 -> 0.40 ms per
 		  // SoftStep step at base 200)
 		  stripSlackWanted(solver->optStripSlack != 0 && solver->optIncremental != 0 && solver->optPersist != 0 &&
-						   (type == s2amd_solverTGS_Soft || (solver->optWide != 0 && (type == s2amd_solverSoftStep || type == s2amd_solverPGS_Soft)))),
+						   (type == s2amd_solverTGS_Soft || (solver->optWide != 0 && (type == s2amd_solverSoftStep || type == s2amd_solverPGS_Soft)) ||
+							(!isSoftFamily(type) && solver->optGenericPlace != 0 && genericWanted(solver)))), // (r6: IncrementalStrips::takeOnly)
 		  nb(solver->bodyCapacity),
 		  cs(solver->contacts), js(solver->joints), slots(solver->bodyCapacity)
 	{
@@ -2638,11 +2639,17 @@ struct StructureBuild
 	{
 		IncrementalStrips& m = s->stripInc;
 		m = IncrementalStrips{};
-		if (!strips.active || !stripSlackWanted || !s->persistValid || js.stripCount != 0)
+		const bool interpreter = !isSoftFamily(solverType);
+		if (!strips.active || !stripSlackWanted || !(interpreter ? s->genericValid : s->persistValid) || js.stripCount != 0)
 		{
 			return;
 		}
 		m.base = stripBaseC, m.end = stripBaseC + cs.stripCount;
+		if (interpreter)
+		{
+			m.takeOnly = true;
+			m.roundLimit[0] = m.roundLimit[1] = 0;
+		}
 		if (solverType == s2amd_solverSoftStep)
 		{
 			m.roundLimit[0] = S2_STRIP_ROUNDS, m.roundLimit[1] = 2;

@@ -593,6 +593,53 @@ def test_rain_world_loop_through_the_strip_paths(seed, solver_name):
     assert persistent > 20, persistent  # (of 120 steps: the pile has to form first, and every created contact rebuilds the structure)
 
 
+@pytest.mark.parametrize("seed,solver_name", [(3, "PGS_NGS_Block"), (5, "XPBD"), (7, "TGS_Sticky"), (13, "TGS_NGS")])
+def test_rain_world_loop_on_the_op_interpreters_strips(seed, solver_name):
+    """... and under the solvers the op interpreter sweeps (generic_kernel.hip): their strips take a created contact only where a round the
+    build laid out has a free position between two bodies the strip or seam already lists (IncrementalStrips::takeOnly, r6) -- every
+    other contact still builds.  120 steps of the whole loop, bit-exact against the oracle chain swept in the reported order; some
+    steps must have run the persistent launch with contacts placed since the last build."""
+    from tests import common, oraclebind
+    rng = np.random.default_rng(7000 + seed)
+    vel, pos = common.DEFAULT_ITERS[solver_name]
+    params = wire.StepParams.make(solver_name, 1.0 / 60.0, vel, pos, True)
+    world = world_chain.rain_world(seed, int(rng.integers(300, 900)), spin=bool(seed % 2))
+    ref = world_chain.copy_world(world)
+    persistent = placed_while_persistent = 0
+    last = None
+    with hip.Solver(0) as s:
+        s.set_option("strip_patience", 0)
+        s.set_option("strip_min_bodies", 0)
+        s.set_option("strip_bodies", int(rng.integers(30, 160)))
+        s.set_option("max_group_bodies", int(rng.choice([32, 64, 128])))
+        s.world_upload(*[world[k] for k in world_chain.WORLD_KEYS])
+        for step in range(120):
+            if world_chain.moved_any(ref):
+                got = s.world_find_pairs()
+                want = world_chain.oracle_find_pairs(ref)
+                assert np.array_equal(got, want), "step %d: new pairs" % step
+                if len(got):
+                    slots, contacts, pairs = _create_contacts(ref, got)
+                    s.world_set_contacts(slots, contacts, pairs)
+            info = s.world_step(params)
+            order, _ = s.contact_order()
+            jorder, _ = s.joint_order()
+            status = world_chain.oracle_world_step(params, ref, contact_order=order, joint_order=jorder)
+            assert info["separatedCount"] == int((status == wire.PAIR_SEPARATED).sum()), "step %d" % step
+            st = s.stats()
+            persistent += st["persistent"]
+            if last is not None and st["persistent"] and st["structureBuilds"] == last["structureBuilds"] and st["placedContacts"] > last["placedContacts"]:
+                placed_while_persistent += 1
+            last = st
+            if step % 5 == 4:
+                out = world_chain.copy_world(world)
+                res = s.world_download(*[out[k] for k in world_chain.WORLD_KEYS])
+                world_chain.assert_device_equals_oracle(dict(zip(world_chain.WORLD_KEYS, res[:6])), ref,
+                                                        "rain-interpreter %d %s step %d" % (seed, solver_name, step))
+    print("persistent %d of 120, steps that placed into a running strip structure %d" % (persistent, placed_while_persistent))
+    assert persistent > 5 and placed_while_persistent > 0, (persistent, placed_while_persistent)
+
+
 def test_world_download_boxes_equals_the_shape_records():
     """s2amd_world_download_boxes: the 36-byte {aabb, fatAABB, enlarged} of every shape slot == the same fields of the full
     shape records s2amd_world_download returns (what the reference-side binding reads after every step)."""

@@ -218,7 +218,7 @@ void sortByColor(const std::vector<int>& ids, const std::vector<int>& color, int
 // Launch batches from colour offsets.  Colours are launched one kernel each; when the colouring
 // has a long run of tiny high colours (a body with dozens of constraints forces one colour per
 // constraint) that run becomes ONE sequential tail batch instead of dozens of launches.
-bool makeBatches(const std::vector<int>& colorOffsets, std::vector<int>& batchOffsets, bool allowTail)
+bool makeBatches(const std::vector<int>& colorOffsets, std::vector<int>& batchOffsets, bool allowTail, int tinyColor)
 {
 	int n = (int)colorOffsets.size() - 1;
 	batchOffsets.clear();
@@ -230,7 +230,10 @@ bool makeBatches(const std::vector<int>& colorOffsets, std::vector<int>& batchOf
 	int total = colorOffsets[n];
 	// the tail starts at the first colour from which on EVERY colour is tiny (a launch would cost more
 	// than sweeping its few constraints serially); it must replace at least kMinTailColors launches
-	const int kTinyColor = 32, kMinTailColors = 4;
+	// (tinyColor: 32 where a colour is a LAUNCH; inside an LDS group a colour is a barrier -- about the time of three turns of the tail's
+	// walk --, and a tail that began at the first colour of 32 constraints swept 130 of a card house's 161 constraints one after the other:
+	// 1.35 ms per TGS_Soft step, r6)
+	const int kTinyColor = tinyColor, kMinTailColors = 4;
 	int tailColor = n;
 	for (int c = n - 1; c >= 1; --c)
 	{

@@ -16,6 +16,8 @@
 #include "group_ops.h"
 
 #define S2_GROUP_THREADS 512
+#define S2_GROUP_STAGED_BATCHES 192 // colour batches (contacts + joints) of a group and ...
+#define S2_GROUP_STAGED_OPS 128		// ... ops of a step whose records the kernel keeps in LDS, where they fit beside the bodies
 
 // The sequential tail, one WAVE instead of one lane: every lane pulls its own constraint into registers (the misses of 64
 // constraints in flight at once, no dependent L2 round trip left in the walk), then the lanes take turns in sweep order.
@@ -152,8 +154,8 @@ S2_DEV void sweepSoftPreloaded(const ContactView& c, const LB& lb, const int4* b
 }
 
 template <int THREADS, int PRELOAD>
-__global__ __launch_bounds__(THREADS) void groupKernel(ContactView c, JointView jv, BodyView g, GroupTable gt, const Op* ops, int opCount, StepConsts sc,
-													   s2amdContact* wire, int useDq0)
+__global__ __launch_bounds__(THREADS) void groupKernel(ContactView c, JointView jv, BodyView g, GroupTable gt, const Op* opsGlobal, int opCount, StepConsts sc,
+													   s2amdContact* wire, int useDq0, int stageTables)
 {
 	extern __shared__ __attribute__((aligned(16))) float4 lds[];
 	const int grp = blockIdx.x;
@@ -185,8 +187,30 @@ __global__ __launch_bounds__(THREADS) void groupKernel(ContactView c, JointView 
 	lb.softDiet = sc.softDiet;
 	auto pfC = [&](int k) { prefetchContact(c, k); };
 	auto pfJ = [&](int k) { prefetchJoint(jv, k); };
-	const int cb0 = gt.cBatchOffsets[grp], cb1 = gt.cBatchOffsets[grp + 1];
-	const int jb0 = gt.jBatchOffsets[grp], jb1 = gt.jBatchOffsets[grp + 1];
+	// The colour batches' descriptors and the op list in LDS (r6): a round starts by reading its {begin, end, tail} and an op by reading
+	// its record -- from global memory each is a dependent L2 round trip on the critical path, ~900 of them in a TGS_Soft step of a card
+	// house whose 161 constraints take 1.35 ms (the op interpreter of the strips has done this since r4).  Where the host found room.
+	const int cbG = gt.cBatchOffsets[grp], jbG = gt.jBatchOffsets[grp];
+	const int nCB = gt.cBatchOffsets[grp + 1] - cbG, nJB = gt.jBatchOffsets[grp + 1] - jbG;
+	const int4* batchC = gt.cBatches + cbG;
+	const int4* batchJ = gt.jBatches + jbG;
+	const Op* ops = opsGlobal;
+	if (stageTables != 0 && nCB + nJB <= S2_GROUP_STAGED_BATCHES && opCount <= S2_GROUP_STAGED_OPS)
+	{
+		int4* lbatch = (int4*)(lds + (useDq0 ? 3 : 2) * nb + (nb + 1) / 2);
+		Op* lops = (Op*)(lbatch + S2_GROUP_STAGED_BATCHES);
+		for (int i = threadIdx.x; i < nCB + nJB; i += blockDim.x)
+		{
+			lbatch[i] = i < nCB ? batchC[i] : batchJ[i - nCB];
+		}
+		for (int i = threadIdx.x; i < opCount * 8; i += blockDim.x)
+		{
+			((int*)lops)[i] = ((const int*)opsGlobal)[i];
+		}
+		batchC = lbatch, batchJ = lbatch + nCB, ops = lops;
+		__syncthreads();
+	}
+	const int cb0 = 0, cb1 = nCB, jb0 = 0, jb1 = nJB;
 
 	for (int oi = 0; oi < opCount; ++oi)
 	{
@@ -233,22 +257,22 @@ __global__ __launch_bounds__(THREADS) void groupKernel(ContactView c, JointView 
 				switch (op.kind)
 				{
 					case JSOLVE_PLAIN:
-						forBatches(gt.jBatches, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_PLAIN>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
+						forBatches(batchJ, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_PLAIN>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
 						break;
 					case JSOLVE_SOFT:
-						forBatches(gt.jBatches, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_SOFT>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
+						forBatches(batchJ, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_SOFT>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
 						break;
 					case JSOLVE_BAUMGARTE:
-						forBatches(gt.jBatches, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_BAUMGARTE>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
+						forBatches(batchJ, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_BAUMGARTE>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
 						break;
 					case JSOLVE_POSITION:
-						forBatches(gt.jBatches, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_POSITION>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
+						forBatches(batchJ, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_POSITION>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
 						break;
 					case JSOLVE_XPBD:
-						forBatches(gt.jBatches, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_XPBD>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
+						forBatches(batchJ, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_XPBD>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
 						break;
 					case JSOLVE_WARM:
-						forBatches(gt.jBatches, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_WARM>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
+						forBatches(batchJ, jb0, jb1, pfJ, [&](int k) { solveJointsOne<JSOLVE_WARM>(jv, lb, sc, op.h, op.inv_h, op.useBias, k); });
 						break;
 				}
 				break;
@@ -257,17 +281,17 @@ __global__ __launch_bounds__(THREADS) void groupKernel(ContactView c, JointView 
 				{
 					case WARM_CURRENT:
 						forBatchesSplit<WarmRegs>(
-							gt.cBatches, cb0, cb1, [&](int k) { return loadWarm<WARM_CURRENT>(c, lb, k); }, [&](WarmRegs& r, int) { applyWarm<WARM_CURRENT>(r, lb); },
+							batchC, cb0, cb1, [&](int k) { return loadWarm<WARM_CURRENT>(c, lb, k); }, [&](WarmRegs& r, int) { applyWarm<WARM_CURRENT>(r, lb); },
 							[](const WarmRegs&, int) {}, [&](int k) { warmStartContactsOne<WARM_CURRENT>(c, lb, k); });
 						break;
 					case WARM_FIXED:
 						forBatchesSplit<WarmRegs>(
-							gt.cBatches, cb0, cb1, [&](int k) { return loadWarm<WARM_FIXED>(c, lb, k); }, [&](WarmRegs& r, int) { applyWarm<WARM_FIXED>(r, lb); },
+							batchC, cb0, cb1, [&](int k) { return loadWarm<WARM_FIXED>(c, lb, k); }, [&](WarmRegs& r, int) { applyWarm<WARM_FIXED>(r, lb); },
 							[](const WarmRegs&, int) {}, [&](int k) { warmStartContactsOne<WARM_FIXED>(c, lb, k); });
 						break;
 					case WARM_BLOCK:
 						forBatchesSplit<WarmRegs>(
-							gt.cBatches, cb0, cb1, [&](int k) { return loadWarm<WARM_BLOCK>(c, lb, k); }, [&](WarmRegs& r, int) { applyWarm<WARM_BLOCK>(r, lb); },
+							batchC, cb0, cb1, [&](int k) { return loadWarm<WARM_BLOCK>(c, lb, k); }, [&](WarmRegs& r, int) { applyWarm<WARM_BLOCK>(r, lb); },
 							[](const WarmRegs&, int) {}, [&](int k) { warmStartContactsOne<WARM_BLOCK>(c, lb, k); });
 						break;
 				}
@@ -278,12 +302,12 @@ __global__ __launch_bounds__(THREADS) void groupKernel(ContactView c, JointView 
 					case SOFT_TGS:
 						if constexpr (PRELOAD > 0)
 						{
-							sweepSoftPreloaded<SOFT_TGS, PRELOAD>(c, lb, gt.cBatches, cb0, cb1, op.inv_h, op.useBias);
+							sweepSoftPreloaded<SOFT_TGS, PRELOAD>(c, lb, batchC, cb0, cb1, op.inv_h, op.useBias);
 						}
 						else
 						{
 							forBatchesSplit<TailSoft<SOFT_TGS>>(
-								gt.cBatches, cb0, cb1,
+								batchC, cb0, cb1,
 								[&](int k) {
 									TailSoft<SOFT_TGS> t;
 									t.r = loadSoftB<SOFT_TGS>(c, lb, k);
@@ -299,12 +323,12 @@ __global__ __launch_bounds__(THREADS) void groupKernel(ContactView c, JointView 
 					case SOFT_PGS:
 						if constexpr (PRELOAD > 0)
 						{
-							sweepSoftPreloaded<SOFT_PGS, PRELOAD>(c, lb, gt.cBatches, cb0, cb1, op.inv_h, op.useBias);
+							sweepSoftPreloaded<SOFT_PGS, PRELOAD>(c, lb, batchC, cb0, cb1, op.inv_h, op.useBias);
 						}
 						else
 						{
 							forBatchesSplit<TailSoft<SOFT_PGS>>(
-								gt.cBatches, cb0, cb1,
+								batchC, cb0, cb1,
 								[&](int k) {
 									TailSoft<SOFT_PGS> t;
 									t.r = loadSoftB<SOFT_PGS>(c, lb, k);
@@ -320,12 +344,12 @@ __global__ __launch_bounds__(THREADS) void groupKernel(ContactView c, JointView 
 					case SOFT_FIXED:
 						if constexpr (PRELOAD > 0)
 						{
-							sweepSoftPreloaded<SOFT_FIXED, PRELOAD>(c, lb, gt.cBatches, cb0, cb1, op.inv_h, op.useBias);
+							sweepSoftPreloaded<SOFT_FIXED, PRELOAD>(c, lb, batchC, cb0, cb1, op.inv_h, op.useBias);
 						}
 						else
 						{
 							forBatchesSplit<TailSoft<SOFT_FIXED>>(
-								gt.cBatches, cb0, cb1,
+								batchC, cb0, cb1,
 								[&](int k) {
 									TailSoft<SOFT_FIXED> t;
 									t.r = loadSoftB<SOFT_FIXED>(c, lb, k);
@@ -346,33 +370,33 @@ __global__ __launch_bounds__(THREADS) void groupKernel(ContactView c, JointView 
 				switch (op.kind)
 				{
 					case RIGID_BAUMGARTE:
-						forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { solveContactsRigidOne<RIGID_BAUMGARTE>(c, lb, op.inv_h, k); });
+						forBatches(batchC, cb0, cb1, pfC, [&](int k) { solveContactsRigidOne<RIGID_BAUMGARTE>(c, lb, op.inv_h, k); });
 						break;
 					case RIGID_PGS:
-						forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { solveContactsRigidOne<RIGID_PGS>(c, lb, op.inv_h, k); });
+						forBatches(batchC, cb0, cb1, pfC, [&](int k) { solveContactsRigidOne<RIGID_PGS>(c, lb, op.inv_h, k); });
 						break;
 					case RIGID_TGS:
-						forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { solveContactsRigidOne<RIGID_TGS>(c, lb, op.inv_h, k); });
+						forBatches(batchC, cb0, cb1, pfC, [&](int k) { solveContactsRigidOne<RIGID_TGS>(c, lb, op.inv_h, k); });
 						break;
 				}
 				break;
 			case OP_SOLVE_STICKY:
-				forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { solveContactsStickyOne(c, lb, wire, op.inv_h, op.useBias, k); });
+				forBatches(batchC, cb0, cb1, pfC, [&](int k) { solveContactsStickyOne(c, lb, wire, op.inv_h, op.useBias, k); });
 				break;
 			case OP_SOLVE_NGS:
-				forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { solveContactsNGSOne(c, lb, k); });
+				forBatches(batchC, cb0, cb1, pfC, [&](int k) { solveContactsNGSOne(c, lb, k); });
 				break;
 			case OP_XPBD_POS:
-				forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { xpbdContactPositionsOne(c, lb, op.h, k); });
+				forBatches(batchC, cb0, cb1, pfC, [&](int k) { xpbdContactPositionsOne(c, lb, op.h, k); });
 				break;
 			case OP_XPBD_VEL:
-				forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { xpbdContactVelocitiesOne(c, lb, op.h, k); });
+				forBatches(batchC, cb0, cb1, pfC, [&](int k) { xpbdContactVelocitiesOne(c, lb, op.h, k); });
 				break;
 			case OP_BLOCK_VEL:
-				forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { blockSolveVelocityOne(c, lb, k); });
+				forBatches(batchC, cb0, cb1, pfC, [&](int k) { blockSolveVelocityOne(c, lb, k); });
 				break;
 			case OP_BLOCK_POS:
-				forBatches(gt.cBatches, cb0, cb1, pfC, [&](int k) { blockSolvePositionOne(c, lb, k); });
+				forBatches(batchC, cb0, cb1, pfC, [&](int k) { blockSolvePositionOne(c, lb, k); });
 				break;
 			default:
 				break;
@@ -419,7 +443,7 @@ void launchStripKernel(hipStream_t s, const ContactView& c, const JointView& j, 
 	}
 	size_t lds = (size_t)maxBodies * (useDq0 ? 56 : 40);
 	groupKernel<S2_STRIP_THREADS, S2_STRIP_PRELOAD>
-		<<<dim3((unsigned)gt.groupCount), dim3(S2_STRIP_THREADS), lds, s>>>(c, j, g, gt, ops, opCount, sc, wire, useDq0);
+		<<<dim3((unsigned)gt.groupCount), dim3(S2_STRIP_THREADS), lds, s>>>(c, j, g, gt, ops, opCount, sc, wire, useDq0, 0);
 }
 
 void launchGroupKernel(hipStream_t s, const ContactView& c, const JointView& j, const BodyView& g, const GroupTable& gt, const Op* ops, int opCount,
@@ -430,7 +454,12 @@ void launchGroupKernel(hipStream_t s, const ContactView& c, const JointView& j, 
 		return;
 	}
 	size_t lds = (size_t)maxBodies * (useDq0 ? 56 : 40);
-	groupKernel<S2_GROUP_THREADS, 0><<<dim3((unsigned)gt.groupCount), dim3(S2_GROUP_THREADS), lds, s>>>(c, j, g, gt, ops, opCount, sc, wire, useDq0);
+	// (the staged tables behind the bodies of the largest group: 16-byte aligned, and only where 160 KiB hold them too -- a whole-step
+	// launch; the one-op launches of a sequential tail have one batch and one op to read)
+	const size_t staged = (((size_t)maxBodies + 1) / 2 * 16 + (size_t)(useDq0 ? 3 : 2) * maxBodies * 16) + (size_t)S2_GROUP_STAGED_BATCHES * 16 + (size_t)S2_GROUP_STAGED_OPS * sizeof(Op);
+	const int stage = opCount > 1 && staged <= 160 * 1024 ? 1 : 0;
+	lds = stage ? std::max(lds, staged) : lds;
+	groupKernel<S2_GROUP_THREADS, 0><<<dim3((unsigned)gt.groupCount), dim3(S2_GROUP_THREADS), lds, s>>>(c, j, g, gt, ops, opCount, sc, wire, useDq0, stage);
 }
 
 S2_DEFINE_WARM(group_kernel)

@@ -957,6 +957,11 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	{
 		s->optBodyWarm = value;
 	}
+	else if (strcmp(key, "group_tiny_colour") == 0)
+	{
+		s->optGroupTinyColour = std::max(0, value);
+		s->structureDirty = true;
+	}
 	else if (strcmp(key, "generic_place") == 0)
 	{
 		s->optGenericPlace = value;

@@ -135,7 +135,7 @@ bool rotIsFixedPoint(float s, float c);
 int colorGraph(const std::vector<int>& ea, const std::vector<int>& eb, const std::vector<uint8_t>& conflict, int bodyCount,
 			   std::vector<int>& color, int balanced = 0, std::vector<uint64_t>* bitsOut = nullptr);
 void sortByColor(const std::vector<int>& ids, const std::vector<int>& color, int colorCount, std::vector<int>& order, std::vector<int>& offsets);
-bool makeBatches(const std::vector<int>& colorOffsets, std::vector<int>& batchOffsets, bool allowTail = true);
+bool makeBatches(const std::vector<int>& colorOffsets, std::vector<int>& batchOffsets, bool allowTail = true, int tinyColor = 32);
 uint64_t fnv(uint64_t h, const void* data, size_t n);
 
 // One sweepable family (contacts or joints): order, colour batches, LDS groups
@@ -583,6 +583,7 @@ struct SolverRest
 	int tailSlackShift = 0;
 	bool dirtyByWatched = false;
 	int optGroupPatience = 1;	// "group_patience" 0: groups whatever they cost (tests; round 5's behaviour)
+	int optGroupTinyColour = 3; // "group_tiny_colour": colours of an LDS group with at most this many constraints may form its sequential tail (32: round 5)
 	int optGenericPlace = 1;	// "generic_place" 0: the op interpreter's strips take no created contact (round 5)
 	int optFlipColours = 1;		// "flip_colours" 0: a hub's manifold that gains its points is placed only where a sequential tail has room (round 5)
 	bool stripPatienceSet = false; // "strip_patience" was set by the caller (else a resident world builds its strips at once: stripPatienceBase)

@@ -213,7 +213,8 @@ struct EdgeList
 // rebuild (IncrementalGlobal, solver_incremental.cpp).  *positions then has -1 at the free positions.
 void colourPart(const std::vector<int>& ids, const std::vector<int>& ea, const std::vector<int>& eb, const std::vector<uint8_t>& conflict,
 				int bodyCount, SweepSet& set, std::vector<int>& batchOffsetsOut, bool& hasTailOut, std::vector<int>* positions, int balanced = 0,
-				IncrementalGlobal* inc = nullptr, int spareColours = 0, int slackShift = 0, bool colourless = false, int roundSlack = 0, int tailSlack = S2_TAIL_SLACK)
+				IncrementalGlobal* inc = nullptr, int spareColours = 0, int slackShift = 0, bool colourless = false, int roundSlack = 0, int tailSlack = S2_TAIL_SLACK,
+				int tinyColour = 32)
 {
 	std::vector<int> color, partOrder, partOffsets;
 	int cc;
@@ -240,7 +241,7 @@ void colourPart(const std::vector<int>& ids, const std::vector<int>& ea, const s
 	}
 	sortByColor(pos, color, cc, partOrder, partOffsets);
 	std::vector<int> rel;
-	hasTailOut = makeBatches(partOffsets, rel, balanced == 0);
+	hasTailOut = makeBatches(partOffsets, rel, balanced == 0, tinyColour);
 	int base = (int)set.order.size();
 	if (set.colorOffsets.empty())
 	{
@@ -2280,8 +2281,10 @@ struct StructureBuild
 		const bool stripTable = &t == &s->hStripA || &t == &s->hStripB;
 		const int roundSlack = (stripTable && stripSlackWanted && jKs.empty()) ? 16 : 0;
 		const double tg1 = prepTimes ? nowMs() : 0.0;
-		colourPart(ids, la, lb, lconf, (int)bodies.size(), cs, batchOffsets, tail, &pos, (&t == &s->hGroups || &t == &s->hResident) ? 0 : 256, nullptr, 0, 0,
-				   false, roundSlack);
+		// (a colour of an LDS group is a barrier, not a launch: only colours of three constraints or fewer are worth a sequential tail)
+		const bool ldsTable = &t == &s->hGroups || &t == &s->hResident;
+		colourPart(ids, la, lb, lconf, (int)bodies.size(), cs, batchOffsets, tail, &pos, ldsTable ? 0 : 256, nullptr, 0, 0, false, roundSlack, S2_TAIL_SLACK,
+				   ldsTable ? s->optGroupTinyColour : 32);
 		const double tg2 = prepTimes ? nowMs() : 0.0;
 		tSlots += tg1 - tg0, tColour += tg2 - tg1;
 		for (size_t i = 0; i < pos.size(); ++i)

@@ -957,6 +957,10 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	{
 		s->optBodyWarm = value;
 	}
+	else if (strcmp(key, "pair_query_graph") == 0)
+	{
+		s->pairQuery.disabled = value == 0; // (0: the pair query's kernels are enqueued one by one instead of replayed from a captured graph: diagnostics)
+	}
 	else if (strcmp(key, "group_tiny_colour") == 0)
 	{
 		s->optGroupTinyColour = std::max(0, value);

@@ -322,6 +322,7 @@ struct IncrementalStrips
 #define S2_OVERFLOW_SLACK 32
 #define S2_STRIP_ADOPT_SLACK 8
 #define S2_TAIL_SLACK 64
+#define S2_GROUP_PATIENCE_MIN_POSITIONS 16384 // sweep positions (contacts + joints) from which on SolverRest::groupPatienceNow applies
 #define S2_TAIL_BODY_SLACK 32
 
 // What a STRUCTURE BUILD produces and the incremental placement keeps up to date: the host's picture of the constraint graph as the
@@ -679,9 +680,12 @@ inline void noteGraphChanged(s2amdSolver* s, bool newWorld = false)
 		s->stripSearchNotBefore = 0, s->stripSearchPause = 256;
 		s->groupPatienceNow = 0;
 	}
-	else if (s->optGroupPatience != 0 && s->dirtyByGroups && s->graphAge < 8)
+	else if (s->optGroupPatience != 0 && s->dirtyByGroups && s->graphAge < 8 && s->contacts.order.size() + s->joints.order.size() >= S2_GROUP_PATIENCE_MIN_POSITIONS)
 	{
-		s->groupPatienceNow = std::min(std::max(2 * s->groupPatienceNow, 4), 256); // (groups that died young)
+		// (groups that died young -- in a world whose build costs more than the launches the colour batches cost per step: a build is
+		// ~40 ns per constraint, the multi-launch path 0.5-1 ms per step whatever the size; for a world of a few hundred constraints
+		// building again is the cheap way -- mixed-60: 0.28 ms per step with its groups, 0.72 without them)
+		s->groupPatienceNow = std::min(std::max(2 * s->groupPatienceNow, 4), 256);
 	}
 	else if (s->graphAge >= 256)
 	{

@@ -2281,10 +2281,10 @@ struct StructureBuild
 		const bool stripTable = &t == &s->hStripA || &t == &s->hStripB;
 		const int roundSlack = (stripTable && stripSlackWanted && jKs.empty()) ? 16 : 0;
 		const double tg1 = prepTimes ? nowMs() : 0.0;
-		// (a colour of an LDS group is a barrier, not a launch: only colours of three constraints or fewer are worth a sequential tail)
+		// (a colour of an LDS group or a strip is a barrier, not a launch: only colours of three constraints or fewer are worth a sequential tail)
 		const bool ldsTable = &t == &s->hGroups || &t == &s->hResident;
 		colourPart(ids, la, lb, lconf, (int)bodies.size(), cs, batchOffsets, tail, &pos, ldsTable ? 0 : 256, nullptr, 0, 0, false, roundSlack, S2_TAIL_SLACK,
-				   ldsTable ? s->optGroupTinyColour : 32);
+				   s->optGroupTinyColour);
 		const double tg2 = prepTimes ? nowMs() : 0.0;
 		tSlots += tg1 - tg0, tColour += tg2 - tg1;
 		for (size_t i = 0; i < pos.size(); ++i)
@@ -2317,7 +2317,7 @@ struct StructureBuild
 			}
 		}
 		t.cBatchOffsets.push_back((int)t.cBatches.size());
-		colourPart(jids, jla, jlb, lconf, (int)bodies.size(), js, batchOffsets, tail, &pos);
+		colourPart(jids, jla, jlb, lconf, (int)bodies.size(), js, batchOffsets, tail, &pos, 0, nullptr, 0, 0, false, 0, S2_TAIL_SLACK, s->optGroupTinyColour);
 		for (size_t i = 0; i < pos.size(); ++i)
 		{
 			js.local.push_back(make_int2(std::max(jla[(size_t)pos[i]], 0), jlb[(size_t)pos[i]]));

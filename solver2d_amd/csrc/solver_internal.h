@@ -598,14 +598,17 @@ struct SolverRest
 	int optGraphMinLaunches = 6; // "graph_min_launches": steps of fewer launches are enqueued directly, never captured
 	int optProfile = 0;
 	int optGroups = 1;
-	int optMaxGroupBodies = 2048;
+	// (r6: 1,024, was 2,048 -- one workgroup sweeping an island of 1,275 bodies takes 0.34 ms per TGS_Soft step and 0.43 at 1,830, the
+	// strips 0.136 whatever the size; below ~900 bodies the group is the faster one: profiles/r06_island_size_sweep.txt)
+	int optMaxGroupBodies = 1024;
 	int optPackGroupBodies = 1024;
 	int optStrips = 1;		   // cut islands that do not fit one LDS group into strips of BFS levels (2 launches per sweep)
 	int optStripBodies = 8;  // target bodies per strip: small = strips of exactly two BFS levels, five interior colour rounds (r3: 133 us per step at base 200
 	bool stripBodiesSet = false; // "strip_bodies" was set by the caller: every solver gets that width
 	int optStripBodiesLds = 320; // ... of SoftStep / PGS_Soft, whose seam constraints live in LDS and are swept by both neighbours (strip_kernel.hip): few, wide strips
 							 // against 154 us with the six rounds of three-level strips); strip_retry tries wider ones when there are more level pairs than CUs
-	int optStripMinBodies = 4096; // loose bodies below which the colour-batch path is kept
+	int optStripMinBodies = 768; // loose bodies below which the colour-batch path is kept (r6: was 4,096 -- base-60 to base-80 pyramids ran 114 launches, 0.37 ms, where strips take 0.136;
+								 // below the smallest island that is too big for an LDS group)
 
 	// profiling events for the contact solve sweeps
 	std::vector<hipEvent_t> sweepEvents;

@@ -1848,7 +1848,10 @@ struct StructureBuild
 					return groupOfRoot[root];
 				}
 				int n = islandBodies[root];
-				if (n > s->optMaxGroupBodies || !ldsGroups)
+				// (the soft solvers' resident-island kernel takes 8 rounds of 512 constraints: a pyramid of 990 bodies falls to the
+				// group interpreter, 0.28 ms per TGS_Soft step, where strips take 0.136 -- island_size_sweep, r6)
+				const int groupLimit = isSoftFamily(solverType) ? std::min(s->optMaxGroupBodies, 896) : s->optMaxGroupBodies;
+				if (n > groupLimit || !ldsGroups)
 				{
 					groupOfRoot[root] = -1;
 					return -1;

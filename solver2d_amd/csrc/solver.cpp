@@ -1189,6 +1189,7 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	else if (strcmp(key, "pack_group_bodies") == 0)
 	{
 		s->optPackGroupBodies = std::max(1, value);
+		s->packGroupBodiesSet = true;
 		s->structureDirty = true;
 	}
 	else

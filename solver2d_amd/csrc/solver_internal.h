@@ -602,6 +602,7 @@ struct SolverRest
 	// strips 0.136 whatever the size; below ~900 bodies the group is the faster one: profiles/r06_island_size_sweep.txt)
 	int optMaxGroupBodies = 1024;
 	int optPackGroupBodies = 1024;
+	bool packGroupBodiesSet = false; // "pack_group_bodies" was set by the caller (else: spread over the CUs, StructureBuild::findIslands)
 	int optStrips = 1;		   // cut islands that do not fit one LDS group into strips of BFS levels (2 launches per sweep)
 	int optStripBodies = 8;  // target bodies per strip: small = strips of exactly two BFS levels, five interior colour rounds (r3: 133 us per step at base 200
 	bool stripBodiesSet = false; // "strip_bodies" was set by the caller: every solver gets that width

@@ -1838,6 +1838,24 @@ struct StructureBuild
 			// pack eligible islands into groups in order of first appearance
 			std::vector<int> groupOfRoot((size_t)nb, -2); // -2 unassigned, -1 global
 			int curBodies = 0;
+			const int groupLimitAll = isSoftFamily(solverType) ? std::min(s->optMaxGroupBodies, 896) : s->optMaxGroupBodies;
+			// How full a group is packed: a group is ONE workgroup, so the small islands of a world are spread over as many groups
+			// as the GPU has CUs before any group gets a second helping (r6: 40 small pyramids packed 1,024 bodies to the group ran
+			// on a dozen workgroups, and the fuller groups overflowed the resident kernel's 512 constraints per round: 0.54 ms per
+			// TGS_Soft step, 0.27 at 640 bodies per group).  An island's sweep order does not depend on its group's company.
+			int packBodies = s->optPackGroupBodies;
+			if (!s->packGroupBodiesSet && s->cuCount > 0)
+			{
+				long long eligible = 0;
+				for (int i = 0; i < nb; ++i)
+				{
+					if (islandBodies[(size_t)i] > 0 && islandBodies[(size_t)i] <= groupLimitAll)
+					{
+						eligible += islandBodies[(size_t)i];
+					}
+				}
+				packBodies = (int)std::min<long long>(std::max<long long>(eligible / s->cuCount, 128), s->optPackGroupBodies);
+			}
 			auto assign = [&](int root) {
 				if (root < 0)
 				{
@@ -1850,13 +1868,13 @@ struct StructureBuild
 				int n = islandBodies[root];
 				// (the soft solvers' resident-island kernel takes 8 rounds of 512 constraints: a pyramid of 990 bodies falls to the
 				// group interpreter, 0.28 ms per TGS_Soft step, where strips take 0.136 -- island_size_sweep, r6)
-				const int groupLimit = isSoftFamily(solverType) ? std::min(s->optMaxGroupBodies, 896) : s->optMaxGroupBodies;
+				const int groupLimit = groupLimitAll;
 				if (n > groupLimit || !ldsGroups)
 				{
 					groupOfRoot[root] = -1;
 					return -1;
 				}
-				if (groupCount == 0 || curBodies + n > s->optPackGroupBodies)
+				if (groupCount == 0 || curBodies + n > packBodies)
 				{
 					groupCount += 1;
 					curBodies = 0;

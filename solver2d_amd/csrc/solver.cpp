@@ -961,6 +961,11 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	{
 		s->pairQuery.disabled = value == 0; // (0: the pair query's kernels are enqueued one by one instead of replayed from a captured graph: diagnostics)
 	}
+	else if (strcmp(key, "tail_tiny_colour") == 0)
+	{
+		s->optTailTinyColour = std::max(0, value);
+		s->structureDirty = true;
+	}
 	else if (strcmp(key, "group_tiny_colour") == 0)
 	{
 		s->optGroupTinyColour = std::max(0, value);

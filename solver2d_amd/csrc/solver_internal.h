@@ -584,6 +584,7 @@ struct SolverRest
 	int tailSlackShift = 0;
 	bool dirtyByWatched = false;
 	int optGroupPatience = 1;	// "group_patience" 0: groups whatever they cost (tests; round 5's behaviour)
+	int optTailTinyColour = 32; // "tail_tiny_colour": ... of the global part (a colour there is a launch per sweep)
 	int optGroupTinyColour = 3; // "group_tiny_colour": colours of an LDS group with at most this many constraints may form its sequential tail (32: round 5)
 	int optGenericPlace = 1;	// "generic_place" 0: the op interpreter's strips take no created contact (round 5)
 	int optFlipColours = 1;		// "flip_colours" 0: a hub's manifold that gains its points is placed only where a sequential tail has room (round 5)

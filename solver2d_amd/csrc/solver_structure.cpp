@@ -2139,7 +2139,7 @@ struct StructureBuild
 		const bool slack = s->optIncremental != 0 && s->optMessage == 0;
 		s->inc.ignoreColours = needAdj;
 		colourPart(ids, a, b, conflict, nb, cs, cs.batchOffsets, cs.hasTail, &pos, 0, slack ? &s->inc : nullptr, needAdj ? 0 : s->spareColours, s->slackShift, needAdj, 0,
-				   S2_TAIL_SLACK << s->tailSlackShift);
+				   S2_TAIL_SLACK << s->tailSlackShift, s->optTailTinyColour);
 		cs.globalCount = (int)cs.order.size(); // (with the free positions of the slack layout)
 		cs.local.assign((size_t)cs.globalCount, make_int2(0, 0));
 		if (slack)

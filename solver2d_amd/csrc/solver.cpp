@@ -995,6 +995,7 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	{
 		s->stripsRejected = false;
 		s->optMaxGroupBodies = std::max(1, std::min(value, 2816)) /* 56 B of LDS per body with XPBD's dq0 */;
+		s->maxGroupBodiesSet = true;
 		s->structureDirty = true;
 	}
 	else if (strcmp(key, "strips") == 0)

@@ -602,6 +602,7 @@ struct SolverRest
 	// (r6: 1,024, was 2,048 -- one workgroup sweeping an island of 1,275 bodies takes 0.34 ms per TGS_Soft step and 0.43 at 1,830, the
 	// strips 0.136 whatever the size; below ~900 bodies the group is the faster one: profiles/r06_island_size_sweep.txt)
 	int optMaxGroupBodies = 1024;
+	bool maxGroupBodiesSet = false; // "max_group_bodies" was set by the caller: that limit and nothing else (StructureBuild::findIslands)
 	int optPackGroupBodies = 1024;
 	bool packGroupBodiesSet = false; // "pack_group_bodies" was set by the caller (else: spread over the CUs, StructureBuild::findIslands)
 	int optStrips = 1;		   // cut islands that do not fit one LDS group into strips of BFS levels (2 launches per sweep)

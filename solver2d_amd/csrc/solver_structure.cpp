@@ -1838,7 +1838,24 @@ struct StructureBuild
 			// pack eligible islands into groups in order of first appearance
 			std::vector<int> groupOfRoot((size_t)nb, -2); // -2 unassigned, -1 global
 			int curBodies = 0;
-			const int groupLimitAll = isSoftFamily(solverType) ? std::min(s->optMaxGroupBodies, 896) : s->optMaxGroupBodies;
+			// Islands of ~900 - 2,048 bodies fit one workgroup but are swept faster by strips (island_size_sweep, r6) -- as long as
+			// there are few of them: strips need ALL their workgroups co-resident, and 64 pyramids of 1,830 bodies cut into 1,856 strips
+			// fell off the persistent kernel (1.77 ms per TGS_Soft step; 0.43 as 64 groups side by side, which keep 64 CUs busy anyway).
+			// So: the lower limit while the islands above it hold no more bodies than a few hundred strips' worth.
+			int groupLimitAll = s->optMaxGroupBodies;
+			if (!s->maxGroupBodiesSet)
+			{
+				const int lower = isSoftFamily(solverType) ? 896 : 1024, upper = 2048;
+				long long midBodies = 0;
+				for (int i = 0; i < nb; ++i)
+				{
+					if (islandBodies[(size_t)i] > lower && islandBodies[(size_t)i] <= upper)
+					{
+						midBodies += islandBodies[(size_t)i];
+					}
+				}
+				groupLimitAll = midBodies <= 16384 ? lower : upper;
+			}
 			// How full a group is packed: a group is ONE workgroup, so the small islands of a world are spread over as many groups
 			// as the GPU has CUs before any group gets a second helping (r6: 40 small pyramids packed 1,024 bodies to the group ran
 			// on a dozen workgroups, and the fuller groups overflowed the resident kernel's 512 constraints per round: 0.54 ms per

@@ -1841,20 +1841,24 @@ struct StructureBuild
 			// Islands of ~900 - 2,048 bodies fit one workgroup but are swept faster by strips (island_size_sweep, r6) -- as long as
 			// there are few of them: strips need ALL their workgroups co-resident, and 64 pyramids of 1,830 bodies cut into 1,856 strips
 			// fell off the persistent kernel (1.77 ms per TGS_Soft step; 0.43 as 64 groups side by side, which keep 64 CUs busy anyway).
-			// So: the lower limit while the islands above it hold no more bodies than a few hundred strips' worth.
+			// So: the lower limit while the islands above it hold no more bodies than the strips can take.
 			int groupLimitAll = s->optMaxGroupBodies;
 			if (!s->maxGroupBodiesSet)
 			{
-				const int lower = isSoftFamily(solverType) ? 896 : 1024, upper = 2048;
-				long long midBodies = 0;
+				// (measured, tools/many_islands_table.py: strips hold up to 64 pyramids of 1,275 bodies -- 82k bodies in 240 strips,
+				// 0.19 ms per TGS_Soft step against 0.36 as groups -- and 40 of 1,830; at 117k the partition no longer fits the kernel.
+				// Under the op interpreter the groups catch up from ~32 such islands on: 0.17 against 0.22 ms.)
+				const bool soft = isSoftFamily(solverType);
+				const int lower = soft ? 896 : 1024, upper = 2048;
+				long long above = 0; // bodies of every island the lower limit sends to the strips
 				for (int i = 0; i < nb; ++i)
 				{
-					if (islandBodies[(size_t)i] > lower && islandBodies[(size_t)i] <= upper)
+					if (islandBodies[(size_t)i] > lower)
 					{
-						midBodies += islandBodies[(size_t)i];
+						above += islandBodies[(size_t)i];
 					}
 				}
-				groupLimitAll = midBodies <= 16384 ? lower : upper;
+				groupLimitAll = above <= (soft ? 81920 : 32768) ? lower : upper;
 			}
 			// How full a group is packed: a group is ONE workgroup, so the small islands of a world are spread over as many groups
 			// as the GPU has CUs before any group gets a second helping (r6: 40 small pyramids packed 1,024 bodies to the group ran

@@ -12,6 +12,9 @@ for name in wire.SOLVER_NAMES:
     params = wire.StepParams.make(name, 1.0 / 60.0, vel, pos, True)
     with hip.Solver(0) as gpu:
         gpu.set_option("strip_patience", 0)
+        for kv in sys.argv[3:]:
+            k, v = kv.split("=")
+            gpu.set_option(k, int(v))
         gpu.upload(bodies, contacts, joints)
         gpu.save_bodies()
         gpu.set_option("async", 1)

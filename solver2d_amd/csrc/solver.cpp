@@ -1190,6 +1190,7 @@ int s2amd_set_option(s2amdSolver* s, const char* key, int32_t value)
 	{
 		s->stripsRejected = false;
 		s->optStripMinBodies = std::max(0, value);
+		s->stripMinBodiesSet = true;
 		s->structureDirty = true;
 	}
 	else if (strcmp(key, "pack_group_bodies") == 0)

@@ -610,6 +610,7 @@ struct SolverRest
 	bool stripBodiesSet = false; // "strip_bodies" was set by the caller: every solver gets that width
 	int optStripBodiesLds = 320; // ... of SoftStep / PGS_Soft, whose seam constraints live in LDS and are swept by both neighbours (strip_kernel.hip): few, wide strips
 							 // against 154 us with the six rounds of three-level strips); strip_retry tries wider ones when there are more level pairs than CUs
+	bool stripMinBodiesSet = false; // "strip_min_bodies" was set by the caller
 	int optStripMinBodies = 768; // loose bodies below which the colour-batch path is kept (r6: was 4,096 -- base-60 to base-80 pyramids ran 114 launches, 0.37 ms, where strips take 0.136;
 								 // below the smallest island that is too big for an LDS group)
 

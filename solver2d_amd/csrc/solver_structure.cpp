@@ -1627,6 +1627,16 @@ struct StructureBuild
 		return solver->optStripBodiesLds;
 	}
 
+	// bodies from which on an island is swept faster by strips than by one workgroup, where it has the strips to itself (findIslands)
+	static int groupLowerLimit(int type)
+	{
+		// (measured and NOT adopted, r6: s2Solve_SoftStep / s2Solve_PGS_Soft have no register-resident island kernel and their strips beat
+		// one workgroup from 80 / 200 bodies on -- 0.136 against 0.17-0.25 ms, 0.060 against 0.07-0.09 --, but a lower limit for them
+		// makes the two routes of the drop-in build different structures and moves PGS_Soft's unconverged pile outside the physical
+		// tolerances the tests hold the group order to)
+		return isSoftFamily(type) ? 896 : 1024;
+	}
+
 	static bool isSoftFamily(int type)
 	{
 		return type == s2amd_solverTGS_Soft || type == s2amd_solverSoftStep || type == s2amd_solverPGS_Soft;
@@ -1849,7 +1859,7 @@ struct StructureBuild
 				// 0.19 ms per TGS_Soft step against 0.36 as groups -- and 40 of 1,830; at 117k the partition no longer fits the kernel.
 				// Under the op interpreter the groups catch up from ~32 such islands on: 0.17 against 0.22 ms.)
 				const bool soft = isSoftFamily(solverType);
-				const int lower = soft ? 896 : 1024, upper = 2048;
+				const int lower = groupLowerLimit(solverType), upper = 2048;
 				long long above = 0; // bodies of every island the lower limit sends to the strips
 				for (int i = 0; i < nb; ++i)
 				{
@@ -1977,7 +1987,8 @@ struct StructureBuild
 				loose[i] = s->hBodyLive[i] && !s->hBodyStatic[i] && !ownedByIsland[i];
 				looseCount += loose[i];
 			}
-			if (looseCount >= s->optStripMinBodies)
+			// (an island the lower group limit sent here is worth its strips whatever its size: else it would fall to the colour batches)
+			if (looseCount >= (s->stripMinBodiesSet || s->maxGroupBodiesSet ? s->optStripMinBodies : std::min(s->optStripMinBodies, groupLowerLimit(solverType))))
 			{
 				partitionStrips(ce, je, cOf[0], jOf[0], conflict, loose, nb, std::max(8, (int)((float)stripBodiesFor(s, solverType) * stripScale)), s->optMaxGroupBodies, strips);
 			}
